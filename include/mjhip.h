@@ -1,0 +1,113 @@
+/* mjhip -- MI355X-native batched mj_step: C ABI of libmjhip.so
+ *
+ * Drop-in boundary for ONE path of MuJoCo: stepping many independent environments of one model.
+ * The caller keeps owning its mjModel / mjData (created by MuJoCo itself); this library mirrors
+ * the model constants and a batch of mjData states in GPU memory (SoA across environments) and
+ * advances them with hand-written HIP kernels (one wavefront per environment).
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the MuJoCo
+ * source tree).  Signatures use only plain pointers and sizes; `mjModel`/`mjData` are the
+ * reference's own structs (include/mujoco/mjmodel.h, mjdata.h), passed by address and only read
+ * through their public fields.
+ *
+ * Error handling: functions returning int return 0 on success and a negative code on failure;
+ * functions returning a handle return NULL on failure.  mjhip_last_error() gives the message of
+ * the last failure on the calling thread.  Numerical trouble inside a step is NOT an error: it is
+ * reported exactly like the reference does, through per-environment warning counters
+ * (mjData.warning[], include/mujoco/mjdata.h:74) readable as the batch field "warning".
+ */
+#ifndef MJHIP_H_
+#define MJHIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct mjModel_;
+struct mjData_;
+typedef struct mjhipModel_ mjhipModel;   /* device copy of the model constants            */
+typedef struct mjhipBatch_ mjhipBatch;   /* nenv device-resident mjData mirrors of a model */
+
+#define MJHIP_API __attribute__((visibility("default")))
+
+/* library / backend identification: "hip-gfx950" for the product, "hostsim" for the test-only
+ * wavefront emulation built under tests/hostsim (never shipped). */
+MJHIP_API const char* mjhip_backend(void);
+MJHIP_API const char* mjhip_last_error(void);
+
+/* number of visible GPUs (0 when the HIP runtime finds none: every compute entry point then fails
+ * loudly -- there is no CPU fallback in the product). */
+MJHIP_API int mjhip_device_count(void);
+
+/* ---- model ------------------------------------------------------------------------------------
+ * Replaces: nothing in the reference has a device model; this is the upload step that precedes the
+ * calls below.  Reads the arrays of `m` listed in mujoco_amd/csrc/mjh_types.h.  Fails (NULL) with a
+ * message naming the feature if the model uses something the GPU path does not implement.
+ * nconmax / nefcmax: per-environment contact / constraint-row capacity (0 = choose from the
+ * model); overflow raises mjWARN_CONTACTFULL / mjWARN_CNSTRFULL like a full arena does in the
+ * reference (engine_collision_driver.c:2028, engine_core_constraint.c:145). */
+MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, int nefcmax);
+MJHIP_API void mjhip_model_destroy(mjhipModel* model);
+/* sizes: name is one of nq nv nu na nbody njnt ngeom nsite ntendon npair nconmax nefcmax nstate */
+MJHIP_API int mjhip_model_size(const mjhipModel* model, const char* name);
+
+/* Product-side reader of the reference's binary model format (mj_loadModel / mj_saveModel,
+ * src/engine/engine_io.c:514-700) so that bench/smoke can obtain an mjModel without MuJoCo being
+ * installed.  The returned struct is laid out exactly as MuJoCo's; free with mjhip_free_mjb. */
+MJHIP_API struct mjModel_* mjhip_load_mjb(const char* path);
+MJHIP_API void mjhip_free_mjb(struct mjModel_* m);
+
+/* ---- batch ------------------------------------------------------------------------------------
+ * Replaces: mj_makeData x nenv (src/engine/engine_io.c) + one mjData per worker thread of
+ * python/mujoco/rollout.cc.  All environments start at mj_resetData state (qpos0, zero velocity). */
+MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* model, int nenv, int device);
+MJHIP_API void mjhip_batch_destroy(mjhipBatch* batch);
+MJHIP_API int mjhip_batch_nenv(const mjhipBatch* batch);
+MJHIP_API int mjhip_batch_reset(mjhipBatch* batch);   /* mj_resetData for every env */
+
+/* Field access.  A field is one array [nenv][count] (see mjh_types.h, MJH_BATCH_*_FIELDS); names
+ * follow mjData (qpos, qvel, ctrl, xpos, qLD, efc_J, ...) plus "counts" = {ncon,nefc,ne,nf,nl,
+ * solver_niter,nisland,0} and "warning".  mjhip_batch_field returns the DEVICE pointer (zero-copy
+ * interop with e.g. torch tensors); get/set copy a whole field from/to HOST memory. */
+MJHIP_API int mjhip_batch_field(mjhipBatch* batch, const char* name, void** device_ptr,
+                                int* count_per_env, int* is_int);
+MJHIP_API int mjhip_batch_get(mjhipBatch* batch, const char* name, void* host_dst);
+MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* host_src);
+
+/* mj_forward restricted to a stage mask (bits MJH_STAGE_* of mjh_step.h; -1 = all).
+ * Replaces mj_forward / mj_forwardSkip (src/engine/engine_forward.c:1783-1842) for every env. */
+MJHIP_API int mjhip_batch_forward(mjhipBatch* batch, int stages, void* hip_stream);
+
+/* nstep x mj_step for every env with the device-resident ctrl / qfrc_applied
+ * (closed-loop RL stepping).  Replaces mj_step (src/engine/engine_forward.c:1846). */
+MJHIP_API int mjhip_batch_step(mjhipBatch* batch, int nstep, void* hip_stream);
+
+/* Open-loop rollout of every env in the batch: the contract of _unsafe_rollout
+ * (python/mujoco/rollout.cc:71-178) with one environment per rollout.
+ *   state0      [nenv][nstate]            FULLPHYSICS initial states, or NULL (keep current)
+ *   warmstart0  [nenv][nv]                or NULL (zeros)
+ *   control     [nenv][nstep][ncontrol]   or NULL; ncontrol = mj_stateSize(control_spec)
+ *   state       [nenv][nstep][nstate]     output, or NULL
+ * control_spec: mjtState bits; supported: mjSTATE_CTRL | mjSTATE_QFRC_APPLIED.
+ * on_device != 0: the four pointers are DEVICE pointers (no PCIe traffic in the call). */
+MJHIP_API int mjhip_batch_rollout(mjhipBatch* batch, int nstep, unsigned control_spec,
+                                  const double* state0, const double* warmstart0,
+                                  const double* control, double* state, int on_device,
+                                  void* hip_stream);
+MJHIP_API int mjhip_batch_sync(mjhipBatch* batch, void* hip_stream);
+
+/* ---- the drop-in ------------------------------------------------------------------------------
+ * Same arguments and semantics as the reference's _unsafe_rollout / Rollout::rollout
+ * (python/mujoco/rollout.cc:74, :250): nbatch rollouts of nstep steps, HOST pointers, models in
+ * m[0..nbatch) must be the same model (checked by size+content signature), d[0] receives the final
+ * state of the last rollout (time, qpos, qvel, act, ctrl, qacc_warmstart, warning counters).
+ * Device model + batch are cached inside the library keyed by the model. */
+MJHIP_API int mjhip_rollout(const struct mjModel_* const* m, struct mjData_* const* d, int nbatch,
+                            int nstep, unsigned control_spec, const double* state0,
+                            const double* warmstart0, const double* control, double* state,
+                            double* sensordata);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* MJHIP_H_ */

@@ -1,0 +1,281 @@
+// Collision stage of the batched step: candidate geom pairs -> contacts, one wavefront per env.
+//
+// The reference runs sweep-and-prune over bodies, then a BVH midphase, then the narrowphase
+// (engine_collision_driver.c:595-886).  Broad- and midphase only CULL pairs conservatively, so the
+// contact list equals "narrowphase over every geom pair that survives the model-constant filters"
+// in the reference's order: ascending body-pair signature, then (g1,g2) within a body pair, then
+// the collider's own emission order.  The host precomputes that ordered static
+// pair list with its mixed contact parameters (mjh_host.cpp: build_pairs); here each lane takes
+// pairs, applies the reference's bounding-sphere filter and the analytic collider, and the wave
+// compacts the survivors in order with a prefix sum.
+#pragma once
+
+#include "mjh_types.h"
+
+struct PreContact {        // mjPreContact, include/mujoco/mjdata.h:29
+  real dist, pos[3], normal[3], tangent[3];
+};
+
+// mjraw_PlaneSphere, engine_collision_primitive.c:28
+MJH_DEV int col_plane_sphere(PreContact* c, real margin, const real* pos1, const real* mat1,
+                             const real* pos2, real radius) {
+  c->normal[0] = mat1[2]; c->normal[1] = mat1[5]; c->normal[2] = mat1[8];
+  real tmp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
+  real cdist = v3_dot(tmp, c->normal);
+  if (cdist > margin + radius) return 0;
+  c->dist = cdist - radius;
+  v3_scl(tmp, c->normal, -c->dist / 2 - radius);
+  v3_add(c->pos, pos2, tmp);
+  v3_zero(c->tangent);
+  return 1;
+}
+
+// mjc_PlaneCapsule, engine_collision_primitive.c:66
+MJH_DEV int col_plane_capsule(PreContact* c, real margin, const real* pos1, const real* mat1,
+                              const real* pos2, const real* mat2, const real* size2) {
+  real axis[3] = {mat2[2], mat2[5], mat2[8]};
+  real seg[3] = {size2[1]*axis[0], size2[1]*axis[1], size2[1]*axis[2]};
+  real end[3];
+  v3_add(end, pos2, seg);
+  int n1 = col_plane_sphere(c, margin, pos1, mat1, end, size2[0]);
+  v3_sub(end, pos2, seg);
+  int n2 = col_plane_sphere(c + n1, margin, pos1, mat1, end, size2[0]);
+  if (n1) v3_copy(c[0].tangent, axis);
+  if (n2) v3_copy(c[n1].tangent, axis);
+  return n1 + n2;
+}
+
+// mjraw_SphereSphere, engine_collision_primitive.c:262
+MJH_DEV int col_sphere_sphere(PreContact* c, real margin, const real* pos1, const real* mat1, real r1,
+                              const real* pos2, const real* mat2, real r2) {
+  real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  real cdist_sqr = v3_dot(dif, dif);
+  real min_dist = margin + r1 + r2;
+  if (cdist_sqr > min_dist*min_dist) return 0;
+  c->dist = sqrt(cdist_sqr) - r1 - r2;
+  v3_sub(c->normal, pos2, pos1);
+  real len = v3_normalize(c->normal);
+  if (len < MJH_MINVAL) {
+    real a1[3] = {mat1[2], mat1[5], mat1[8]};
+    real a2[3] = {mat2[2], mat2[5], mat2[8]};
+    v3_cross(c->normal, a1, a2);
+    v3_normalize(c->normal);
+  }
+  v3_scl(c->pos, c->normal, r1 + c->dist / 2);
+  v3_addto(c->pos, pos1);
+  v3_zero(c->tangent);
+  return 1;
+}
+
+// mjraw_SphereCapsule, engine_collision_primitive.c:313
+MJH_DEV int col_sphere_capsule(PreContact* c, real margin, const real* pos1, const real* mat1, real r1,
+                               const real* pos2, const real* mat2, const real* size2) {
+  real len = size2[1];
+  real axis[3] = {mat2[2], mat2[5], mat2[8]};
+  real vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  real x = r_clip(v3_dot(axis, vec), -len, len);
+  v3_scl(vec, axis, x);
+  v3_addto(vec, pos2);
+  return col_sphere_sphere(c, margin, pos1, mat1, r1, vec, mat2, size2[0]);
+}
+
+// mjraw_CapsuleCapsule, engine_collision_primitive.c:425
+MJH_DEV int col_capsule_capsule(PreContact* c, real margin, const real* pos1, const real* mat1,
+                                const real* size1, const real* pos2, const real* mat2,
+                                const real* size2) {
+  real axis1[3] = {mat1[2]*size1[1], mat1[5]*size1[1], mat1[8]*size1[1]};
+  real axis2[3] = {mat2[2]*size2[1], mat2[5]*size2[1], mat2[8]*size2[1]};
+  real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  real ma =  v3_dot(axis1, axis1);
+  real mb = -v3_dot(axis1, axis2);
+  real mc =  v3_dot(axis2, axis2);
+  real u  = -v3_dot(axis1, dif);
+  real v  =  v3_dot(axis2, dif);
+  real det = ma*mc - mb*mb;
+  real r1 = size1[0], r2 = size2[0];
+  real vec1[3], vec2[3];
+
+  if (fabs(det) >= MJH_MINVAL) {
+    real x1 = (mc*u - mb*v) / det;
+    real x2 = (ma*v - mb*u) / det;
+    if (x1 > 1) {
+      x1 = 1;
+      x2 = (v - mb) / mc;
+    } else if (x1 < -1) {
+      x1 = -1;
+      x2 = (v + mb) / mc;
+    }
+    if (x2 > 1) {
+      x2 = 1;
+      x1 = r_clip((u - mb) / ma, -1, 1);
+    } else if (x2 < -1) {
+      x2 = -1;
+      x1 = r_clip((u + mb) / ma, -1, 1);
+    }
+    v3_scl(vec1, axis1, x1);
+    v3_addto(vec1, pos1);
+    v3_scl(vec2, axis2, x2);
+    v3_addto(vec2, pos2);
+    return col_sphere_sphere(c, margin, vec1, mat1, r1, vec2, mat2, r2);
+  }
+
+  // parallel axes: up to two contacts from the four end-point tests
+  v3_add(vec1, pos1, axis1);
+  real x2 = r_clip((v - mb) / mc, -1, 1);
+  v3_scl(vec2, axis2, x2);
+  v3_addto(vec2, pos2);
+  int n1 = col_sphere_sphere(c, margin, vec1, mat1, r1, vec2, mat2, r2);
+
+  v3_sub(vec1, pos1, axis1);
+  x2 = r_clip((v + mb) / mc, -1, 1);
+  v3_scl(vec2, axis2, x2);
+  v3_addto(vec2, pos2);
+  int n2 = col_sphere_sphere(c + n1, margin, vec1, mat1, r1, vec2, mat2, r2);
+  if (n1 + n2 >= 2) return n1 + n2;
+
+  v3_add(vec2, pos2, axis2);
+  real x1 = r_clip((u - mb) / ma, -1, 1);
+  v3_scl(vec1, axis1, x1);
+  v3_addto(vec1, pos1);
+  int n3 = col_sphere_sphere(c + n1 + n2, margin, vec1, mat1, r1, vec2, mat2, r2);
+  if (n1 + n2 + n3 >= 2) return n1 + n2 + n3;
+
+  v3_sub(vec2, pos2, axis2);
+  x1 = r_clip((u + mb) / ma, -1, 1);
+  v3_scl(vec1, axis1, x1);
+  v3_addto(vec1, pos1);
+  int n4 = col_sphere_sphere(c + n1 + n2 + n3, margin, vec1, mat1, r1, vec2, mat2, r2);
+  return n1 + n2 + n3 + n4;
+}
+
+// complete a contact frame from its normal (+ optional tangent)   (mju_makeFrame, engine_util_spatial.c:512)
+MJH_DEV void make_frame(real* frame) {
+  v3_normalize(frame);
+  if (v3_dot(frame + 3, frame + 3) < 0.25) {
+    v3_zero(frame + 3);
+    if (frame[1] < 0.5 && frame[1] > -0.5) frame[4] = 1;
+    else frame[5] = 1;
+  }
+  real tmp[3];
+  v3_scl(tmp, frame, v3_dot(frame, frame + 3));
+  v3_subfrom(frame + 3, tmp);
+  v3_normalize(frame + 3);
+  v3_cross(frame + 6, frame, frame + 3);
+}
+
+// mj_filterSphere, engine_collision_driver.c:267: 1 = cull
+MJH_DEV int filter_sphere(const DModel& M, const real* gx, const real* gm, int g1, int g2, real margin) {
+  real rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
+  if (rb1 > 0 && rb2 > 0) {
+    const real* p1 = gx + 3*g1; const real* p2 = gx + 3*g2;
+    real bound = rb1 + rb2 + margin;
+    real dif[3] = {p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2]};
+    real d2 = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2];
+    return d2 > bound*bound;
+  }
+  if (M.geom_type[g1] == MJH_GEOM_PLANE && rb2 > 0) {
+    const real* m1 = gm + 9*g1;
+    real nrm[3] = {m1[2], m1[5], m1[8]};
+    real dif[3];
+    v3_sub(dif, gx + 3*g2, gx + 3*g1);
+    if (v3_dot(dif, nrm) > margin + rb2) return 1;
+  }
+  if (M.geom_type[g2] == MJH_GEOM_PLANE && rb1 > 0) {
+    const real* m2 = gm + 9*g2;
+    real nrm[3] = {m2[2], m2[5], m2[8]};
+    real dif[3];
+    v3_sub(dif, gx + 3*g1, gx + 3*g2);
+    if (v3_dot(dif, nrm) > margin + rb1) return 1;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_collision over the static pair list
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_collision(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  int* counts = MJH_F(B, counts, e);
+  const int dsbl = M.o.disableflags;
+  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || s.npair == 0) {
+    if (wv_lane() == 0) counts[MJH_C_NCON] = 0;
+    wv_sync();
+    return;
+  }
+  const real* gx = MJH_F(B, geom_xpos, e);
+  const real* gm = MJH_F(B, geom_xmat, e);
+  real* cdist = MJH_F(B, con_dist, e);
+  real* cpos = MJH_F(B, con_pos, e);
+  real* cframe = MJH_F(B, con_frame, e);
+  real* cmu = MJH_F(B, con_mu, e);
+  int* cpair = MJH_F(B, con_pair, e);
+  int* cgeom = MJH_F(B, con_geom, e);
+  int* cdim = MJH_F(B, con_dim, e);
+  int* cexcl = MJH_F(B, con_exclude, e);
+  int* cefc = MJH_F(B, con_efcadr, e);
+  int* warn = MJH_F(B, warning, e);
+
+  int base = 0;        // contacts emitted by earlier chunks (wave-uniform)
+  int overflow = 0;
+  for (int p0 = 0; p0 < s.npair; p0 += MJH_WAVE) {
+    int p = p0 + wv_lane();
+    PreContact pc[2];
+    int n = 0;
+    if (p < s.npair) {
+      int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+      real margin = M.pair_margin[p];       // margin + gap: collider threshold
+      if (!filter_sphere(M, gx, gm, g1, g2, margin)) {
+        const real* pos1 = gx + 3*g1; const real* mat1 = gm + 9*g1; const real* size1 = M.geom_size + 3*g1;
+        const real* pos2 = gx + 3*g2; const real* mat2 = gm + 9*g2; const real* size2 = M.geom_size + 3*g2;
+        switch (M.pair_func[p]) {
+          case MJH_COL_PLANE_SPHERE:
+            n = col_plane_sphere(pc, margin, pos1, mat1, pos2, size2[0]); break;
+          case MJH_COL_PLANE_CAPSULE:
+            n = col_plane_capsule(pc, margin, pos1, mat1, pos2, mat2, size2); break;
+          case MJH_COL_SPHERE_SPHERE:
+            n = col_sphere_sphere(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2[0]); break;
+          case MJH_COL_SPHERE_CAPSULE:
+            n = col_sphere_capsule(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
+          case MJH_COL_CAPSULE_CAPSULE:
+            n = col_capsule_capsule(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
+          default: break;
+        }
+      }
+    }
+    int off = base + wv_exscan_i(n);
+    int total = wv_sum_i(n);
+    for (int k = 0; k < n; k++) {
+      int c = off + k;
+      if (c >= s.nconmax) { overflow = 1; continue; }
+      // mj_narrowphase fill + mj_setContact, engine_collision_driver.c:2050-2075, :1839-1875
+      cdist[c] = pc[k].dist;
+      v3_copy(cpos + 3*c, pc[k].pos);
+      real fr[9];
+      v3_copy(fr, pc[k].normal);
+      v3_copy(fr + 3, pc[k].tangent);
+      v3_zero(fr + 6);
+      make_frame(fr);
+      for (int q = 0; q < 9; q++) cframe[9*c + q] = fr[q];
+      cpair[c] = p;
+      cgeom[2*c] = M.pair_geom1[p];
+      cgeom[2*c + 1] = M.pair_geom2[p];
+      cdim[c] = M.pair_dim[p];
+      cexcl[c] = (pc[k].dist >= M.pair_includemargin[p]) ? 1 : 0;
+      cefc[c] = -1;
+      cmu[c] = 0;
+    }
+    base += total;
+  }
+  overflow = wv_any(overflow);
+  if (wv_lane() == 0) {
+    if (overflow) {
+      // the reference drops the whole narrowphase batch when the arena is full
+      // (engine_collision_driver.c:2028-2031); we keep the first nconmax and raise the same warning
+      warn[MJH_WARN_CONTACTFULL]++;
+      counts[MJH_C_NCON] = s.nconmax;
+    } else {
+      counts[MJH_C_NCON] = base;
+    }
+  }
+  wv_sync();
+}

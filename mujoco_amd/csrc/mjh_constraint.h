@@ -1,0 +1,515 @@
+// Constraint assembly stages: mj_makeConstraint, mj_projectConstraint (Y, AR), mj_referenceConstraint,
+// mj_constraintUpdate -- dense Jacobian, pyramidal/frictionless contacts, joint/tendon limits,
+// dof/tendon friction loss.  One wavefront per environment.  (reference: engine_core_constraint.c)
+#pragma once
+
+#include "mjh_types.h"
+
+// impedance curve                                  (getimpedance, engine_core_constraint.c:2099)
+MJH_DEV real imp_power(real a, real b) {
+  if (b == 1) return a;
+  if (b == 2) return a*a;
+  return pow(a, b);
+}
+MJH_DEV void get_impedance(const real* solimp, real pos, real margin, real* imp, real* impP) {
+  if (solimp[0] == solimp[1] || solimp[2] <= MJH_MINVAL) {
+    *imp = 0.5*(solimp[0] + solimp[1]);
+    *impP = 0;
+    return;
+  }
+  real x = (pos - margin) / solimp[2];
+  real sgn = 1;
+  if (x < 0) { x = -x; sgn = -1; }
+  if (x >= 1 || x <= 0) {
+    *imp = (x >= 1 ? solimp[1] : solimp[0]);
+    *impP = 0;
+    return;
+  }
+  real y, yP;
+  if (solimp[4] == 1) {
+    y = x; yP = 1;
+  } else if (x <= solimp[3]) {
+    real a = 1/imp_power(solimp[3], solimp[4]-1);
+    y = a*imp_power(x, solimp[4]);
+    yP = solimp[4] * a*imp_power(x, solimp[4]-1);
+  } else {
+    real b = 1/imp_power(1-solimp[3], solimp[4]-1);
+    y = 1-b*imp_power(1-x, solimp[4]);
+    yP = solimp[4] * b*imp_power(1-x, solimp[4]-1);
+  }
+  *imp = solimp[0] + y*(solimp[1]-solimp[0]);
+  *impP = yP * sgn * (solimp[1]-solimp[0]) / solimp[2];
+}
+
+// sanitise solref/solimp                           (getsolparam tail, engine_core_constraint.c:2019-2047)
+// (mixed-sign solref is rejected at model upload, so only the clamps remain)
+MJH_DEV void fix_solparam(const DModel& M, real* solref, real* solimp) {
+  if (!(M.o.disableflags & (1<<12)) && solref[0] > 0) solref[0] = r_max(solref[0], 2*M.o.timestep);
+  solimp[0] = r_min(0.9999, r_max(0.0001, solimp[0]));
+  solimp[1] = r_min(0.9999, r_max(0.0001, solimp[1]));
+  solimp[2] = r_max(0, solimp[2]);
+  solimp[3] = r_min(0.9999, r_max(0.0001, solimp[3]));
+  solimp[4] = r_max(1, solimp[4]);
+}
+
+// K, B, I, P of one row                            (mj_makeImpedance body, engine_core_constraint.c:2170-2207)
+MJH_DEV void set_kbip(real* KBIP, const real* ref, const real* solimp, real imp, real impP, int friction_row) {
+  if (friction_row) {
+    KBIP[0] = 0;
+  } else if (ref[0] > 0) {
+    KBIP[0] = 1 / r_max(MJH_MINVAL, solimp[1]*solimp[1] * ref[0]*ref[0] * ref[1]*ref[1]);
+  } else {
+    KBIP[0] = -ref[0] / r_max(MJH_MINVAL, solimp[1]*solimp[1]);
+  }
+  if (ref[1] > 0) {
+    KBIP[1] = 2 / r_max(MJH_MINVAL, solimp[1]*ref[0]);
+  } else {
+    KBIP[1] = -ref[1] / r_max(MJH_MINVAL, solimp[1]);
+  }
+  KBIP[2] = imp;
+  KBIP[3] = impP;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_makeConstraint                                (engine_core_constraint.c:2824-2914)
+// row order: friction(dof, tendon) | limits(joint lower/upper, tendon lower/upper) | contacts
+// Phase 1: every candidate (one per lane) decides how many rows it emits; an ordered prefix sum
+//          gives each its first row.  Phase 2: owners write the scalar row data and the sparse
+//          non-contact Jacobian rows.  Phase 3: contact Jacobians, lanes over dof columns.
+// Phase 4: diagApprox + impedance (R, D, KBIP), lanes over constraint blocks.
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const int nv = s.nv;
+  int* counts = MJH_F(B, counts, e);
+  int* warn = MJH_F(B, warning, e);
+  const int dsbl = M.o.disableflags;
+  const real* qpos = MJH_F(B, qpos, e);
+  const real* ten_length = MJH_F(B, ten_length, e);
+  const real* ten_J = MJH_F(B, ten_J, e);
+  real* J = MJH_F(B, efc_J, e);
+  real* epos = MJH_F(B, efc_pos, e);
+  real* emargin = MJH_F(B, efc_margin, e);
+  real* efloss = MJH_F(B, efc_frictionloss, e);
+  real* ediagA = MJH_F(B, efc_diagA, e);
+  real* eKBIP = MJH_F(B, efc_KBIP, e);
+  real* eD = MJH_F(B, efc_D, e);
+  real* eR = MJH_F(B, efc_R, e);
+  int* etype = MJH_F(B, efc_type, e);
+  int* eid = MJH_F(B, efc_id, e);
+  const real* cdist = MJH_F(B, con_dist, e);
+  const real* cposv = MJH_F(B, con_pos, e);
+  const real* cframe = MJH_F(B, con_frame, e);
+  real* cmu = MJH_F(B, con_mu, e);
+  const int* cpair = MJH_F(B, con_pair, e);
+  const int* cgeom = MJH_F(B, con_geom, e);
+  const int* cdim = MJH_F(B, con_dim, e);
+  const int* cexcl = MJH_F(B, con_exclude, e);
+  int* cefc = MJH_F(B, con_efcadr, e);
+  const int ncon = counts[MJH_C_NCON];
+
+  if (dsbl & (1<<0)) {
+    if (wv_lane() == 0) { counts[MJH_C_NEFC] = 0; counts[MJH_C_NE] = 0; counts[MJH_C_NF] = 0; counts[MJH_C_NL] = 0; }
+    wv_sync();
+    return;
+  }
+
+  // candidate index space: [dof friction | tendon friction | joints (2 sides) | tendons (2 sides) | contacts]
+  const int c_tf = nv;
+  const int c_jl = c_tf + s.ntendon;
+  const int c_tl = c_jl + 2*s.njnt;
+  const int c_con = c_tl + 2*s.ntendon;
+  const int ncand = c_con + ncon;
+  const int ispyramid = (M.o.cone == 0);
+
+  int row_base = 0;     // rows emitted by earlier chunks (wave-uniform)
+  int nf_total = 0, nl_total = 0;
+  int overflow = 0;
+  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
+    int c = c0 + wv_lane();
+    int nrow = 0, type = 0, id = 0, side = 0;
+    real dist = 0, margin = 0, floss = 0;
+    if (c < ncand) {
+      if (c < c_tf) {                       // dof friction loss (mj_instantiateFriction :1270)
+        if (!(dsbl & (1<<2)) && M.dof_frictionloss[c] != 0) {
+          nrow = 1; type = MJH_CNSTR_FRICTION_DOF; id = c; floss = M.dof_frictionloss[c];
+        }
+      } else if (c < c_jl) {                // tendon friction loss
+        int t = c - c_tf;
+        if (!(dsbl & (1<<2)) && M.tendon_frictionloss[t] > 0) {
+          // empty-row guard of mj_addConstraint (:431-447): skip all-zero Jacobian rows
+          int nz = 0;
+          for (int k = 0; k < M.ten_J_rownnz[t]; k++) if (ten_J[M.ten_J_rowadr[t] + k] != 0) nz = 1;
+          if (nz) { nrow = 1; type = MJH_CNSTR_FRICTION_TENDON; id = t; floss = M.tendon_frictionloss[t]; }
+        }
+      } else if (c < c_tl) {                // joint limits (mj_instantiateLimit :1360)
+        int j = (c - c_jl) >> 1;
+        side = ((c - c_jl) & 1) ? 1 : -1;
+        if (!(dsbl & (1<<3)) && M.jnt_limited[j]) {
+          int jt = M.jnt_type[j];
+          margin = M.jnt_margin[j];
+          if (jt == MJH_JNT_SLIDE || jt == MJH_JNT_HINGE) {
+            real value = qpos[M.jnt_qposadr[j]];
+            dist = side * (M.jnt_range[2*j + (side+1)/2] - value);
+            if (dist < margin) { nrow = 1; type = MJH_CNSTR_LIMIT_JOINT; id = j; }
+          } else if (jt == MJH_JNT_BALL && side == -1) {
+            int adr = M.jnt_qposadr[j];
+            real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
+            real aa[3];
+            q_normalize(quat);
+            q_tovel(aa, quat, 1);
+            real value = v3_normalize(aa);
+            dist = r_max(M.jnt_range[2*j], M.jnt_range[2*j+1]) - value;
+            if (dist < margin) { nrow = 1; type = MJH_CNSTR_LIMIT_JOINT; id = j; side = 0; }
+          }
+        }
+      } else if (c < c_con) {               // tendon limits
+        int t = (c - c_tl) >> 1;
+        side = ((c - c_tl) & 1) ? 1 : -1;
+        if (!(dsbl & (1<<3)) && M.tendon_limited[t]) {
+          margin = M.tendon_margin[t];
+          dist = side * (M.tendon_range[2*t + (side+1)/2] - ten_length[t]);
+          if (dist < margin) {
+            int nz = 0;
+            for (int k = 0; k < M.ten_J_rownnz[t]; k++) if (ten_J[M.ten_J_rowadr[t] + k] != 0) nz = 1;
+            if (nz) { nrow = 1; type = MJH_CNSTR_LIMIT_TENDON; id = t; }
+          }
+        }
+      } else {                              // contacts (mj_instantiateContact :1617)
+        int k = c - c_con;
+        if (!(dsbl & (1<<4)) && !cexcl[k]) {
+          int dim = cdim[k];
+          id = k;
+          dist = cdist[k];
+          margin = M.pair_includemargin[cpair[k]];
+          if (dim == 1) { nrow = 1; type = MJH_CNSTR_CONTACT_FRICTIONLESS; }
+          else if (ispyramid) { nrow = 2*(dim - 1); type = MJH_CNSTR_CONTACT_PYRAMIDAL; }
+          else { nrow = dim; type = MJH_CNSTR_CONTACT_ELLIPTIC; }
+        }
+      }
+    }
+    int r0 = row_base + wv_exscan_i(nrow);
+    int total = wv_sum_i(nrow);
+    nf_total += wv_sum_i((type == MJH_CNSTR_FRICTION_DOF || type == MJH_CNSTR_FRICTION_TENDON) ? nrow : 0);
+    nl_total += wv_sum_i((type == MJH_CNSTR_LIMIT_JOINT || type == MJH_CNSTR_LIMIT_TENDON) ? nrow : 0);
+    if (nrow && r0 + nrow > s.nefcmax) { overflow = 1; nrow = 0; }
+    // scalar row data + sparse (non-contact) Jacobian rows
+    for (int k = 0; k < nrow; k++) {
+      int r = r0 + k;
+      etype[r] = type;
+      eid[r] = id;
+      epos[r] = dist;
+      emargin[r] = margin;
+      efloss[r] = floss;
+      if (type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
+        real* Jr = J + (size_t)r*nv;
+        for (int q = 0; q < nv; q++) Jr[q] = 0;
+        if (type == MJH_CNSTR_FRICTION_DOF) {
+          Jr[id] = 1;
+        } else if (type == MJH_CNSTR_LIMIT_JOINT) {
+          if (side == 0) {
+            // ball joint: J = -axis
+            int adr = M.jnt_qposadr[id];
+            real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
+            real aa[3];
+            q_normalize(quat);
+            q_tovel(aa, quat, 1);
+            v3_normalize(aa);
+            int d = M.jnt_dofadr[id];
+            Jr[d] = aa[0]*-1; Jr[d+1] = aa[1]*-1; Jr[d+2] = aa[2]*-1;
+          } else {
+            Jr[M.jnt_dofadr[id]] = -(real)side;
+          }
+        } else {
+          // tendon friction / limit: +-ten_J scattered to dense
+          int a0 = M.ten_J_rowadr[id];
+          for (int q = 0; q < M.ten_J_rownnz[id]; q++) {
+            real v = ten_J[a0 + q];
+            if (type == MJH_CNSTR_LIMIT_TENDON) v = v * (real)(-side);
+            Jr[M.ten_J_colind[a0 + q]] = v;
+          }
+        }
+      }
+    }
+    if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS && c < ncand && c >= c_con) {
+      cefc[id] = nrow ? r0 : -1;
+    }
+    row_base += total;
+  }
+  overflow = wv_any(overflow);
+  int nefc = row_base;
+  if (overflow) {
+    // arena-full semantics of the reference (arenaAllocEfc :145-152): no constraints this step
+    nefc = 0; nf_total = 0; nl_total = 0;
+    MJH_FOR_LANES(k, ncon) cefc[k] = -1;
+  }
+  if (wv_lane() == 0) {
+    if (overflow) warn[MJH_WARN_CNSTRFULL]++;
+    counts[MJH_C_NEFC] = nefc;
+    counts[MJH_C_NE] = 0;
+    counts[MJH_C_NF] = nf_total;
+    counts[MJH_C_NL] = nl_total;
+  }
+  wv_sync();
+  if (nefc == 0) return;
+
+  // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
+  const real* cdof = MJH_F(B, cdof, e);
+  const real* subtree_com = MJH_F(B, subtree_com, e);
+  for (int k = 0; k < ncon; k++) {
+    int r0 = cefc[k];
+    if (r0 < 0) continue;
+    int dim = cdim[k];
+    int b1 = M.geom_bodyid[cgeom[2*k]], b2 = M.geom_bodyid[cgeom[2*k+1]];
+    int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    const real* point = cposv + 3*k;
+    const real* fr = cframe + 9*k;
+    const real* fri = M.pair_friction + 5*cpair[k];
+    real off1[3], off2[3];
+    v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
+    v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
+    MJH_FOR_LANES(j, nv) {
+      // translational point Jacobians of both bodies (mj_jac, engine_core_util.c:176)
+      int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+      const real* cd = cdof + 6*j;
+      if (in1) {
+        real t[3];
+        v3_cross(t, cd, off1);
+        j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2];
+      }
+      if (in2) {
+        real t[3];
+        v3_cross(t, cd, off2);
+        j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
+      }
+      real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+      // rotate into the contact frame (mju_mulMatMat with zero-skip, engine_util_blas.c:619)
+      int nr = dim > 1 ? 3 : 1;
+      real jr[3] = {0, 0, 0};
+      for (int a = 0; a < nr; a++) {
+        real acc = 0;
+        for (int q = 0; q < 3; q++) {
+          real t = fr[3*a + q];
+          if (t != 0) acc += jd[q]*t;
+        }
+        jr[a] = acc;
+      }
+      if (dim == 1) {
+        J[(size_t)r0*nv + j] = jr[0];
+      } else if (ispyramid) {
+        for (int a = 1; a < dim; a++) {
+          // only translational friction dims (condim<=3) are supported; others rejected at upload
+          J[(size_t)(r0 + 2*(a-1))*nv + j] = jr[0] + jr[a]*fri[a-1];
+          J[(size_t)(r0 + 2*(a-1) + 1)*nv + j] = jr[0] + jr[a]*(-fri[a-1]);
+        }
+      } else {
+        for (int a = 0; a < dim; a++) J[(size_t)(r0 + a)*nv + j] = jr[a];
+      }
+    }
+  }
+  wv_sync();
+
+  // ---- diagApprox + impedance: lanes over blocks -------------------------------------------------
+  // non-contact rows: one block per row
+  const int nnc = nf_total + nl_total;
+  MJH_FOR_LANES(r, nnc) {
+    int type = etype[r], id = eid[r];
+    real solref[2], solimp[5], dA;
+    if (type == MJH_CNSTR_FRICTION_DOF) {
+      dA = M.dof_invweight0[id];
+      solref[0] = M.dof_solref[2*id]; solref[1] = M.dof_solref[2*id+1];
+      for (int q = 0; q < 5; q++) solimp[q] = M.dof_solimp[5*id + q];
+    } else if (type == MJH_CNSTR_LIMIT_JOINT) {
+      dA = M.dof_invweight0[M.jnt_dofadr[id]];
+      solref[0] = M.jnt_solref[2*id]; solref[1] = M.jnt_solref[2*id+1];
+      for (int q = 0; q < 5; q++) solimp[q] = M.jnt_solimp[5*id + q];
+    } else {
+      // tendon friction uses the limit parameters' layout with its own arrays; only limits are
+      // uploaded (tendon frictionloss is rejected at upload)
+      dA = M.tendon_invweight0[id];
+      solref[0] = M.tendon_solref_lim[2*id]; solref[1] = M.tendon_solref_lim[2*id+1];
+      for (int q = 0; q < 5; q++) solimp[q] = M.tendon_solimp_lim[5*id + q];
+    }
+    fix_solparam(M, solref, solimp);
+    real imp, impP;
+    get_impedance(solimp, epos[r], emargin[r], &imp, &impP);
+    real R = r_max(MJH_MINVAL, (1-imp)*dA/imp);
+    int fr_row = (type == MJH_CNSTR_FRICTION_DOF || type == MJH_CNSTR_FRICTION_TENDON);
+    set_kbip(eKBIP + 4*r, solref, solimp, imp, impP, fr_row);
+    eR[r] = R;
+    eD[r] = 1 / R;
+    ediagA[r] = R * imp / (1 - imp);
+  }
+  // contact blocks
+  MJH_FOR_LANES(k, ncon) {
+    int r0 = cefc[k];
+    if (r0 < 0) continue;
+    int p = cpair[k];
+    int dim = cdim[k];
+    int type = etype[r0];
+    int b1 = M.geom_bodyid[cgeom[2*k]], b2 = M.geom_bodyid[cgeom[2*k+1]];
+    // mj_diagApprox, contact case (:1895-1970)
+    real tran = 0, rot = 0;
+    tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
+    tran += M.body_invweight0[2*b2] * 1;  rot += M.body_invweight0[2*b2+1] * 1;
+    const real* fri = M.pair_friction + 5*p;
+    real solref[2] = {M.pair_solref[2*p], M.pair_solref[2*p+1]};
+    real solimp[5];
+    for (int q = 0; q < 5; q++) solimp[q] = M.pair_solimp[5*p + q];
+    fix_solparam(M, solref, solimp);
+    real imp, impP;
+    get_impedance(solimp, epos[r0], emargin[r0], &imp, &impP);
+    int nrow = (type == MJH_CNSTR_CONTACT_FRICTIONLESS) ? 1 : (type == MJH_CNSTR_CONTACT_PYRAMIDAL ? 2*(dim-1) : dim);
+    for (int a = 0; a < nrow; a++) {
+      real dA;
+      if (type == MJH_CNSTR_CONTACT_FRICTIONLESS) dA = tran;
+      else if (type == MJH_CNSTR_CONTACT_PYRAMIDAL) {
+        int jj = a >> 1;
+        dA = tran + fri[jj]*fri[jj]*(jj < 2 ? tran : rot);
+      } else dA = (a < 3 ? tran : rot);
+      eR[r0 + a] = r_max(MJH_MINVAL, (1-imp)*dA/imp);
+      set_kbip(eKBIP + 4*(r0 + a), solref, solimp, imp, impP, 0);
+    }
+    if (type == MJH_CNSTR_CONTACT_PYRAMIDAL) {
+      // (:2213-2253) R[1] = R[0]/impratio; mu = friction[0]*sqrt(R[1]/R[0]); all rows Rpy = 2 mu^2 R[0]
+      real R0 = eR[r0];
+      real R1 = R0 / r_max(MJH_MINVAL, M.o.impratio);
+      real mu = fri[0] * sqrt(R1/R0);
+      cmu[k] = mu;
+      real Rpy = 2*mu*mu*R0;
+      for (int a = 0; a < nrow; a++) eR[r0 + a] = Rpy;
+    }
+    for (int a = 0; a < nrow; a++) {
+      real R = eR[r0 + a];
+      eD[r0 + a] = 1 / R;
+      ediagA[r0 + a] = R * imp / (1 - imp);
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_projectConstraint for dual solvers: Y = J L^-T D^-1/2, AR = Y Y' + diag(R)
+//                                                  (engine_core_constraint.c:2918-3137)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_project(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const int nv = s.nv;
+  const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
+  if (!nefc) return;
+  const real* qLD = MJH_F(B, qLD, e);
+  const real* J = MJH_F(B, efc_J, e);
+  real* Y = MJH_F(B, efc_Y, e);
+  real* AR = MJH_F(B, efc_AR, e);
+  const real* R = MJH_F(B, efc_R, e);
+  real* sqrtInvD = MJH_F(B, scratch, e);
+
+  MJH_FOR_LANES(i, nv) sqrtInvD[i] = 1 / sqrt(qLD[M.M_rowadr[i] + M.M_rownnz[i] - 1]);
+  wv_sync();
+  // one lane per row: half back-substitution (mj_solveM2, engine_core_smooth.c:2130)
+  MJH_FOR_LANES(r, nefc) {
+    real* x = Y + (size_t)r*nv;
+    const real* y = J + (size_t)r*nv;
+    for (int i = 0; i < nv; i++) x[i] = y[i];
+    for (int i = nv - 1; i > 0; i--) {
+      if (M.dof_simplenum[i]) continue;
+      real xi = x[i];
+      if (xi != 0) {
+        int start = M.M_rowadr[i], end = start + M.M_rownnz[i] - 1;
+        for (int adr = start; adr < end; adr++) x[M.M_colind[adr]] -= qLD[adr] * xi;
+      }
+    }
+    for (int i = 0; i < nv; i++) x[i] *= sqrtInvD[i];
+  }
+  wv_sync();
+  // AR lower triangle: AR[i][k] = sum_j Y[k][j]*Y[i][j] in j order (mju_sqrMatTD on Y', engine_util_blas.c:664)
+  const int npairs = nefc*(nefc + 1)/2;
+  MJH_FOR_LANES(w, npairs) {
+    int i = (int)((sqrt(8.0*w + 1.0) - 1.0)*0.5);
+    while (i*(i+1)/2 > w) i--;
+    while ((i+1)*(i+2)/2 <= w) i++;
+    int k = w - i*(i+1)/2;
+    const real* Yi = Y + (size_t)i*nv;
+    const real* Yk = Y + (size_t)k*nv;
+    real acc = 0;
+    for (int j = 0; j < nv; j++) {
+      real t = Yi[j];
+      if (t != 0) acc += Yk[j]*t;
+    }
+    if (i == k) acc += R[i];
+    AR[(size_t)i*nefc + k] = acc;
+    AR[(size_t)k*nefc + i] = acc;
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_referenceConstraint: efc_vel = J qvel, aref   (engine_core_constraint.c:3245-3270)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_reference(const DModel& M, const DBatch& B, int e) {
+  const int nv = M.s.nv;
+  const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
+  if (!nefc) return;
+  const real* J = MJH_F(B, efc_J, e);
+  const real* qvel = MJH_F(B, qvel, e);
+  const real* KBIP = MJH_F(B, efc_KBIP, e);
+  const real* pos = MJH_F(B, efc_pos, e);
+  const real* margin = MJH_F(B, efc_margin, e);
+  real* vel = MJH_F(B, efc_vel, e);
+  real* aref = MJH_F(B, efc_aref, e);
+  MJH_FOR_LANES(r, nefc) {
+    real v = dot_ref(J + (size_t)r*nv, qvel, nv);
+    vel[r] = v;
+    aref[r] = -KBIP[4*r+1]*v - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_constraintUpdate_impl without cone Hessians, pyramidal/scalar rows
+//                                                  (engine_core_constraint.c:3275-3468)
+// writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV real constraint_update(const DBatch& B, int e, const real* jar, int want_cost) {
+  const int* counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
+  const real* D = MJH_F(B, efc_D, e);
+  const real* R = MJH_F(B, efc_R, e);
+  const real* floss = MJH_F(B, efc_frictionloss, e);
+  real* force = MJH_F(B, efc_force, e);
+  int* state = MJH_F(B, efc_state, e);
+  MJH_FOR_LANES(i, nefc) {
+    real f = -D[i]*jar[i];
+    int st;
+    if (i < ne) {
+      st = MJH_STATE_QUADRATIC;
+    } else if (i < ne + nf) {
+      if (jar[i] <= -R[i]*floss[i]) { f = floss[i]; st = MJH_STATE_LINEARNEG; }
+      else if (jar[i] >= R[i]*floss[i]) { f = -floss[i]; st = MJH_STATE_LINEARPOS; }
+      else st = MJH_STATE_QUADRATIC;
+    } else {
+      if (jar[i] >= 0) { f = 0; st = MJH_STATE_SATISFIED; }
+      else st = MJH_STATE_QUADRATIC;
+    }
+    force[i] = f;
+    state[i] = st;
+  }
+  wv_sync();
+  real cost = 0;
+  if (want_cost) {
+    for (int i = 0; i < nefc; i++) {
+      if (i < ne) {
+        cost += 0.5*D[i]*jar[i]*jar[i];
+      } else if (i < ne + nf) {
+        if (jar[i] <= -R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] - floss[i]*jar[i];
+        else if (jar[i] >= R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] + floss[i]*jar[i];
+        else cost += 0.5*D[i]*jar[i]*jar[i];
+      } else if (jar[i] < 0) {
+        cost += 0.5*D[i]*jar[i]*jar[i];
+      }
+    }
+  }
+  return cost;
+}

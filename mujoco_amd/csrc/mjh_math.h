@@ -1,0 +1,259 @@
+// Small fixed-size fp64 math used by the mjhip kernels.
+//
+// Operation ORDER matters here: the parity target is the reference engine compiled without FMA
+// contraction, so every expression below is written with the same association as the reference
+// helper it stands in for (cited per function; files relative to /root/reference/src/engine).
+// The kernels are compiled with -ffp-contract=off.
+#pragma once
+
+#include "mjh_spmd.h"
+
+#define MJH_MINVAL 1E-15   // mjMINVAL, include/mujoco/mjmodel.h:24
+#define MJH_MAXVAL 1E+10   // mjMAXVAL, mjmodel.h:25
+#define MJH_PI 3.14159265358979323846
+
+typedef double real;
+
+MJH_DEV void v3_zero(real* r) { r[0] = 0; r[1] = 0; r[2] = 0; }
+MJH_DEV void v3_copy(real* r, const real* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+MJH_DEV void v3_scl(real* r, const real* a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
+MJH_DEV void v3_add(real* r, const real* a, const real* b) { r[0] = a[0]+b[0]; r[1] = a[1]+b[1]; r[2] = a[2]+b[2]; }
+MJH_DEV void v3_sub(real* r, const real* a, const real* b) { r[0] = a[0]-b[0]; r[1] = a[1]-b[1]; r[2] = a[2]-b[2]; }
+MJH_DEV void v3_addto(real* r, const real* a) { r[0] += a[0]; r[1] += a[1]; r[2] += a[2]; }
+MJH_DEV void v3_subfrom(real* r, const real* a) { r[0] -= a[0]; r[1] -= a[1]; r[2] -= a[2]; }
+// r += a*s                                     (mji_addToScl3, engine_inline.h:108)
+MJH_DEV void v3_addtoscl(real* r, const real* a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
+// a.b, left-to-right                           (mju_dot3, engine_util_blas.c:140)
+MJH_DEV real v3_dot(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+MJH_DEV real v3_norm(const real* a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
+// normalize, return previous length            (mju_normalize3, engine_util_blas.c:115)
+MJH_DEV real v3_normalize(real* v) {
+  real n = sqrt(v[0]*v[0] + v[1]*v[1] + v[2]*v[2]);
+  if (n < MJH_MINVAL) {
+    v[0] = 1; v[1] = 0; v[2] = 0;
+  } else {
+    real inv = 1/n;
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+  }
+  return n;
+}
+// cross product                                (mji_cross, engine_inline.h:418)
+MJH_DEV void v3_cross(real* r, const real* a, const real* b) {
+  r[0] = a[1]*b[2] - a[2]*b[1];
+  r[1] = a[2]*b[0] - a[0]*b[2];
+  r[2] = a[0]*b[1] - a[1]*b[0];
+}
+// r = M v, row-major 3x3                       (mji_mulMatVec3, engine_inline.h:147)
+MJH_DEV void m3_mulvec(real* r, const real* m, const real* v) {
+  r[0] = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  r[1] = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  r[2] = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+}
+// r = M' v                                     (mji_mulMatTVec3, engine_inline.h:157)
+MJH_DEV void m3_multvec(real* r, const real* m, const real* v) {
+  r[0] = m[0]*v[0] + m[3]*v[1] + m[6]*v[2];
+  r[1] = m[1]*v[0] + m[4]*v[1] + m[7]*v[2];
+  r[2] = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
+}
+
+MJH_DEV void q_copy(real* r, const real* q) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3]; }
+// normalize quaternion in place                (mju_normalize4 / mji__normalize4, engine_inline.h:228)
+MJH_DEV real q_normalize(real* q) {
+  real n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  if (n < MJH_MINVAL) {
+    q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0;
+  } else if (fabs(n - 1) > MJH_MINVAL) {
+    real inv = 1/n;
+    q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+  }
+  return n;
+}
+// r = qa * qb (r may alias)                    (mju_mulQuat, engine_util_spatial.c:66)
+MJH_DEV void q_mul(real* r, const real* a, const real* b) {
+  real t0 = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
+  real t1 = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+  real t2 = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1];
+  real t3 = a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+// rotate vector by quaternion, r must not alias q   (mji_rotVecQuat, engine_inline.h:252)
+MJH_DEV void q_rotvec(real* r, const real* v, const real* q) {
+  if (q[0] == 1 && q[1] == 0 && q[2] == 0 && q[3] == 0) {
+    real v0 = v[0], v1 = v[1], v2 = v[2];
+    r[0] = v0; r[1] = v1; r[2] = v2;
+  } else {
+    real v0 = v[0], v1 = v[1], v2 = v[2];
+    real t0 = q[0]*v0 + q[2]*v2 - q[3]*v1;
+    real t1 = q[0]*v1 + q[3]*v0 - q[1]*v2;
+    real t2 = q[0]*v2 + q[1]*v1 - q[2]*v0;
+    r[0] = v0 + 2 * (q[2]*t2 - q[3]*t1);
+    r[1] = v1 + 2 * (q[3]*t0 - q[1]*t2);
+    r[2] = v2 + 2 * (q[1]*t1 - q[2]*t0);
+  }
+}
+// axis-angle to quaternion                     (mji_axisAngle2Quat, engine_inline.h:308)
+MJH_DEV void q_axisangle(real* r, const real* axis, real angle) {
+  if (angle == 0) {
+    r[0] = 1; r[1] = 0; r[2] = 0; r[3] = 0;
+  } else {
+    real s = sin(angle*0.5);
+    r[0] = cos(angle*0.5);
+    r[1] = axis[0]*s;
+    r[2] = axis[1]*s;
+    r[3] = axis[2]*s;
+  }
+}
+// quaternion to rotation matrix                (mju_quat2Mat, engine_util_spatial.c:145)
+MJH_DEV void q_tomat(real* r, const real* q) {
+  if (q[0] == 1 && q[1] == 0 && q[2] == 0 && q[3] == 0) {
+    r[0] = 1; r[1] = 0; r[2] = 0;
+    r[3] = 0; r[4] = 1; r[5] = 0;
+    r[6] = 0; r[7] = 0; r[8] = 1;
+  } else {
+    real q00 = q[0]*q[0], q01 = q[0]*q[1], q02 = q[0]*q[2], q03 = q[0]*q[3];
+    real q11 = q[1]*q[1], q12 = q[1]*q[2], q13 = q[1]*q[3];
+    real q22 = q[2]*q[2], q23 = q[2]*q[3], q33 = q[3]*q[3];
+    r[0] = q00 + q11 - q22 - q33;
+    r[4] = q00 - q11 + q22 - q33;
+    r[8] = q00 - q11 - q22 + q33;
+    r[1] = 2*(q12 - q03);
+    r[2] = 2*(q13 + q02);
+    r[3] = 2*(q12 + q03);
+    r[5] = 2*(q23 - q01);
+    r[6] = 2*(q13 - q02);
+    r[7] = 2*(q23 + q01);
+  }
+}
+// orientation-difference quaternion -> 3D velocity   (mji_quat2Vel, engine_inline.h:330)
+MJH_DEV void q_tovel(real* r, const real* q, real dt) {
+  real axis[3] = {q[1], q[2], q[3]};
+  real sin_a_2 = v3_normalize(axis);
+  real speed = 2 * atan2(sin_a_2, q[0]);
+  if (speed > MJH_PI) speed -= 2*MJH_PI;
+  speed /= dt;
+  v3_scl(r, axis, speed);
+}
+// r = vel such that qb*quat(r) = qa             (mji_subQuat, engine_inline.h:347)
+MJH_DEV void q_sub(real* r, const real* qa, const real* qb) {
+  real qneg[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
+  real qdif[4];
+  q_mul(qdif, qneg, qa);
+  q_tovel(r, qdif, 1);
+}
+// integrate quaternion by angular velocity      (mju_quatIntegrate, engine_util_spatial.c:234)
+MJH_DEV void q_integrate(real* q, const real* vel, real scale) {
+  real tmp[3] = {vel[0], vel[1], vel[2]};
+  real angle = scale * v3_normalize(tmp);
+  real qrot[4];
+  q_axisangle(qrot, tmp, angle);
+  q_normalize(q);
+  q_mul(q, q, qrot);
+}
+
+// ---- spatial (6D, rotation:translation) -------------------------------------------------------
+
+// motion cross product                          (mji_crossMotion, engine_inline.h:428)
+MJH_DEV void sp_cross_motion(real* r, const real* vel, const real* v) {
+  r[0] = -vel[2]*v[1] + vel[1]*v[2];
+  r[1] =  vel[2]*v[0] - vel[0]*v[2];
+  r[2] = -vel[1]*v[0] + vel[0]*v[1];
+  r[3] = -vel[2]*v[4] + vel[1]*v[5];
+  r[4] =  vel[2]*v[3] - vel[0]*v[5];
+  r[5] = -vel[1]*v[3] + vel[0]*v[4];
+  r[3] += -vel[5]*v[1] + vel[4]*v[2];
+  r[4] +=  vel[5]*v[0] - vel[3]*v[2];
+  r[5] += -vel[4]*v[0] + vel[3]*v[1];
+}
+// force cross product                           (mji_crossForce, engine_inline.h:445)
+MJH_DEV void sp_cross_force(real* r, const real* vel, const real* f) {
+  r[0] = -vel[2]*f[1] + vel[1]*f[2];
+  r[1] =  vel[2]*f[0] - vel[0]*f[2];
+  r[2] = -vel[1]*f[0] + vel[0]*f[1];
+  r[3] = -vel[2]*f[4] + vel[1]*f[5];
+  r[4] =  vel[2]*f[3] - vel[0]*f[5];
+  r[5] = -vel[1]*f[3] + vel[0]*f[4];
+  r[0] += -vel[5]*f[4] + vel[4]*f[5];
+  r[1] +=  vel[5]*f[3] - vel[3]*f[5];
+  r[2] += -vel[4]*f[3] + vel[3]*f[4];
+}
+// 6D dot in mju_dot's association               (mji_dot6, engine_inline.h:462)
+MJH_DEV real sp_dot6(const real* a, const real* b) {
+  return ((a[0]*b[0] + a[2]*b[2]) + (a[1]*b[1] + a[3]*b[3])) + (a[4]*b[4] + a[5]*b[5]);
+}
+// r = I(10) * v(6)                              (mju_mulInertVec, engine_util_spatial.c:439)
+MJH_DEV void sp_mul_inert(real* r, const real* i, const real* v) {
+  r[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
+  r[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
+  r[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
+  r[3] = i[8]*v[1] - i[7]*v[2] + i[9]*v[3];
+  r[4] = i[6]*v[2] - i[8]*v[0] + i[9]*v[4];
+  r[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
+}
+// body inertia in the com-based frame           (mju_inertCom, engine_util_spatial.c:405)
+MJH_DEV void sp_inert_com(real* r, const real* inert, const real* mat, const real* dif, real mass) {
+  real t[9] = {mat[0]*inert[0], mat[3]*inert[0], mat[6]*inert[0],
+               mat[1]*inert[1], mat[4]*inert[1], mat[7]*inert[1],
+               mat[2]*inert[2], mat[5]*inert[2], mat[8]*inert[2]};
+  r[0] = mat[0]*t[0] + mat[1]*t[3] + mat[2]*t[6];
+  r[1] = mat[3]*t[1] + mat[4]*t[4] + mat[5]*t[7];
+  r[2] = mat[6]*t[2] + mat[7]*t[5] + mat[8]*t[8];
+  r[3] = mat[0]*t[1] + mat[1]*t[4] + mat[2]*t[7];
+  r[4] = mat[0]*t[2] + mat[1]*t[5] + mat[2]*t[8];
+  r[5] = mat[3]*t[2] + mat[4]*t[5] + mat[5]*t[8];
+  r[0] += mass*(dif[1]*dif[1] + dif[2]*dif[2]);
+  r[1] += mass*(dif[0]*dif[0] + dif[2]*dif[2]);
+  r[2] += mass*(dif[0]*dif[0] + dif[1]*dif[1]);
+  r[3] -= mass*dif[0]*dif[1];
+  r[4] -= mass*dif[0]*dif[2];
+  r[5] -= mass*dif[1]*dif[2];
+  r[6] = mass*dif[0];
+  r[7] = mass*dif[1];
+  r[8] = mass*dif[2];
+  r[9] = mass;
+}
+
+// ---- misc -------------------------------------------------------------------------------------
+
+MJH_DEV real r_clip(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+MJH_DEV real r_max(real a, real b) { return a > b ? a : b; }
+MJH_DEV real r_min(real a, real b) { return a < b ? a : b; }
+// mju_isBad, engine_util_misc.c:2022
+MJH_DEV int r_isbad(real x) { return (x != x) || (x > MJH_MAXVAL) || (x < -MJH_MAXVAL); }
+
+// dense dot product in mju_dot's association (4 interleaved partial sums, then (r0+r2)+(r1+r3),
+// then the 1..3 element tail as ONE expression) -- engine_util_blas.c:493-527.
+// stride-aware so rows/columns of env-local matrices can be passed directly.
+MJH_DEV real dot_ref(const real* a, const real* b, int n) {
+  real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int i = 0;
+  for (; i <= n - 4; i += 4) {
+    r0 += a[i]*b[i];
+    r1 += a[i+1]*b[i+1];
+    r2 += a[i+2]*b[i+2];
+    r3 += a[i+3]*b[i+3];
+  }
+  real res = (r0 + r2) + (r1 + r3);
+  int rem = n - i;
+  if (rem == 3) {
+    res += a[i]*b[i] + a[i+1]*b[i+1] + a[i+2]*b[i+2];
+  } else if (rem == 2) {
+    res += a[i]*b[i] + a[i+1]*b[i+1];
+  } else if (rem == 1) {
+    res += a[i]*b[i];
+  }
+  return res;
+}
+// sparse . dense in mju_dotSparse's association (tail added one by one) -- engine_util_sparse.h:197
+MJH_DEV real dot_sparse_ref(const real* a, const real* x, int nnz, const int* ind) {
+  real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int i = 0;
+  for (; i <= nnz - 4; i += 4) {
+    r0 += a[i]*x[ind[i]];
+    r1 += a[i+1]*x[ind[i+1]];
+    r2 += a[i+2]*x[ind[i+2]];
+    r3 += a[i+3]*x[ind[i+3]];
+  }
+  real res = (r0 + r2) + (r1 + r3);
+  for (; i < nnz; i++) res += a[i]*x[ind[i]];
+  return res;
+}

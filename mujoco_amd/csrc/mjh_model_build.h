@@ -1,0 +1,500 @@
+// Host-side construction of the device model tables from an mjModel (pure C++, no HIP).
+//
+// Direct copies of mjModel arrays + everything that depends only on the model and that the
+// reference recomputes every step: tree levels / child lists for level-synchronous traversal,
+// per-body dof-ancestor masks (mj_jac chains, engine_core_util.c:176), effective armature and
+// damping incl. actuator contributions (mj_actuatorArmature/Damping, engine_core_util.c:1119-1220),
+// and the static candidate geom-pair list in the reference's contact order with mixed contact
+// parameters (mj_collision / mj_contactParam, engine_collision_driver.c:595-886,1740-1835).
+//
+// Anything the GPU path does not implement is rejected HERE, loudly, with the feature named.
+#pragma once
+
+#include <mujoco/mujoco.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mjh_types.h"
+
+struct HostModel {
+  DSizes s;
+  DOptions o;
+#define X(name, cnt) std::vector<int> name;
+  MJH_MODEL_INT_FIELDS(X)
+#undef X
+#define X(name, cnt) std::vector<real> name;
+  MJH_MODEL_REAL_FIELDS(X)
+#undef X
+};
+
+static_assert(sizeof(mjtNum) == sizeof(real), "mjhip is fp64 only");
+static_assert(mjJNT_FREE == MJH_JNT_FREE && mjJNT_BALL == MJH_JNT_BALL &&
+              mjJNT_SLIDE == MJH_JNT_SLIDE && mjJNT_HINGE == MJH_JNT_HINGE, "joint enum");
+static_assert(mjGEOM_PLANE == MJH_GEOM_PLANE && mjGEOM_SPHERE == MJH_GEOM_SPHERE &&
+              mjGEOM_CAPSULE == MJH_GEOM_CAPSULE && mjGEOM_BOX == MJH_GEOM_BOX, "geom enum");
+static_assert(mjCNSTR_FRICTION_DOF == MJH_CNSTR_FRICTION_DOF &&
+              mjCNSTR_LIMIT_JOINT == MJH_CNSTR_LIMIT_JOINT &&
+              mjCNSTR_LIMIT_TENDON == MJH_CNSTR_LIMIT_TENDON &&
+              mjCNSTR_CONTACT_FRICTIONLESS == MJH_CNSTR_CONTACT_FRICTIONLESS &&
+              mjCNSTR_CONTACT_PYRAMIDAL == MJH_CNSTR_CONTACT_PYRAMIDAL &&
+              mjCNSTR_CONTACT_ELLIPTIC == MJH_CNSTR_CONTACT_ELLIPTIC, "constraint enum");
+static_assert(mjCNSTRSTATE_SATISFIED == MJH_STATE_SATISFIED && mjCNSTRSTATE_QUADRATIC == MJH_STATE_QUADRATIC &&
+              mjCNSTRSTATE_LINEARNEG == MJH_STATE_LINEARNEG && mjCNSTRSTATE_LINEARPOS == MJH_STATE_LINEARPOS,
+              "constraint state enum");
+static_assert(mjWARN_CONTACTFULL == MJH_WARN_CONTACTFULL && mjWARN_CNSTRFULL == MJH_WARN_CNSTRFULL &&
+              mjWARN_BADQPOS == MJH_WARN_BADQPOS && mjWARN_BADQVEL == MJH_WARN_BADQVEL &&
+              mjWARN_BADQACC == MJH_WARN_BADQACC && mjWARN_BADCTRL == MJH_WARN_BADCTRL &&
+              mjNWARNING <= 7, "warning enum");
+static_assert(mjSAMEFRAME_BODY == MJH_SAMEFRAME_BODY && mjSAMEFRAME_INERTIA == MJH_SAMEFRAME_INERTIA &&
+              mjSAMEFRAME_BODYROT == MJH_SAMEFRAME_BODYROT && mjSAMEFRAME_INERTIAROT == MJH_SAMEFRAME_INERTIAROT,
+              "sameframe enum");
+static_assert(mjDSBL_CONSTRAINT == 1<<0 && mjDSBL_FRICTIONLOSS == 1<<2 && mjDSBL_LIMIT == 1<<3 &&
+              mjDSBL_CONTACT == 1<<4 && mjDSBL_SPRING == 1<<5 && mjDSBL_DAMPER == 1<<6 &&
+              mjDSBL_GRAVITY == 1<<7 && mjDSBL_CLAMPCTRL == 1<<8 && mjDSBL_WARMSTART == 1<<9 &&
+              mjDSBL_ACTUATION == 1<<11 && mjDSBL_REFSAFE == 1<<12 && mjDSBL_AUTORESET == 1<<16,
+              "disable bits");
+static_assert(mjNPOLY == 2 && mjNREF == 2 && mjNIMP == 5 && mjNGAIN == 10 && mjNBIAS == 10, "sizes");
+
+namespace mjhb {
+
+template <class T, class U>
+static void copy_arr(std::vector<T>& dst, const U* src, size_t n) {
+  dst.resize(n);
+  for (size_t i = 0; i < n; i++) dst[i] = (T)src[i];
+}
+
+static inline bool filter_bitmask(int ct1, int ca1, int ct2, int ca2) {
+  return !(ct1 & ca2) && !(ct2 & ca1);
+}
+
+// mj_actuatorDamping / mj_actuatorArmature for joints and tendons
+static real actuator_contrib(const mjModel* m, int is_tendon, int id, int want_armature, real* poly) {
+  int actuatorid = is_tendon ? m->tendon_actuatorid[id] : m->jnt_actuatorid[id];
+  if (actuatorid == -1) return 0;
+  real out = 0;
+  auto add = [&](int k) {
+    real g = m->actuator_gear[6*m->actuator_outadr[k]];
+    real gear2 = g*g;
+    if (want_armature) {
+      out += m->actuator_armature[k] * gear2;
+    } else {
+      out += m->actuator_damping[k] * gear2;
+      for (int j = 0; j < mjNPOLY; j++) poly[j] += m->actuator_dampingpoly[mjNPOLY*k + j] * gear2;
+    }
+  };
+  if (actuatorid >= 0) {
+    // single contributor: the reference assigns (not accumulates) damping/armature here
+    real g = m->actuator_gear[6*m->actuator_outadr[actuatorid]];
+    real gear2 = g*g;
+    if (want_armature) return m->actuator_armature[actuatorid] * gear2;
+    out = m->actuator_damping[actuatorid] * gear2;
+    for (int j = 0; j < mjNPOLY; j++) poly[j] += m->actuator_dampingpoly[mjNPOLY*actuatorid + j] * gear2;
+    return out;
+  }
+  for (int k = 0; k < m->nactuator; k++) {
+    if (m->actuator_trnid[2*k] != id) continue;
+    if (!is_tendon && m->actuator_trntype[k] != mjTRN_JOINT && m->actuator_trntype[k] != mjTRN_JOINTINPARENT) continue;
+    if (is_tendon && m->actuator_trntype[k] != mjTRN_TENDON) continue;
+    add(k);
+  }
+  return out;
+}
+
+// pair collider available on the GPU path; -1 if the reference collides the types but we do not
+static int pair_func(int t1, int t2, int* maxcon) {
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_SPHERE) { *maxcon = 1; return MJH_COL_PLANE_SPHERE; }
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_CAPSULE) { *maxcon = 2; return MJH_COL_PLANE_CAPSULE; }
+  if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_SPHERE) { *maxcon = 1; return MJH_COL_SPHERE_SPHERE; }
+  if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CAPSULE) { *maxcon = 1; return MJH_COL_SPHERE_CAPSULE; }
+  if (t1 == mjGEOM_CAPSULE && t2 == mjGEOM_CAPSULE) { *maxcon = 2; return MJH_COL_CAPSULE_CAPSULE; }
+  *maxcon = 0;
+  return -1;
+}
+
+// does the reference have a collision function for (t1<=t2)?  (mjCOLLISIONFUNC, engine_collision_driver.c:45-56)
+static bool ref_collides(int t1, int t2) {
+  if (t1 == mjGEOM_PLANE) return t2 >= mjGEOM_SPHERE;   // plane-plane, plane-hfield: none
+  if (t1 == mjGEOM_HFIELD) return t2 >= mjGEOM_SPHERE;
+  return true;
+}
+
+struct BuildCaps { int nconmax = 0; int nefcmax = 0; };
+
+#define MJH_REJECT(cond, msg) do { if (cond) { *err = std::string("mjhip: unsupported model feature: ") + (msg); return false; } } while (0)
+
+static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::string* err) {
+  DSizes& s = H->s;
+  DOptions& o = H->o;
+  memset(&s, 0, sizeof(s));
+  memset(&o, 0, sizeof(o));
+
+  // ---------------- feature gate ------------------------------------------------------------------
+  MJH_REJECT(m->nv == 0, "model without degrees of freedom");
+  MJH_REJECT(m->nmocap > 0, "mocap bodies");
+  MJH_REJECT(m->neq > 0, "equality constraints");
+  MJH_REJECT(m->nflex > 0, "flex objects");
+  MJH_REJECT(m->nplugin > 0, "plugins");
+  MJH_REJECT(m->nsensor > 0, "sensors (sensordata output)");
+  MJH_REJECT(m->na > 0, "stateful actuators (na > 0)");
+  MJH_REJECT(m->nhistory > 0, "history buffers / delays");
+  MJH_REJECT(m->npair > 0, "explicit contact <pair>s");
+  MJH_REJECT(m->ngravcomp > 0 || m->flg_gravcomp, "gravity compensation");
+  MJH_REJECT(m->flg_adhesion, "contact adhesion");
+  MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
+  MJH_REJECT(m->opt.integrator != mjINT_EULER, "integrators other than Euler (RK4/implicit are next)");
+  MJH_REJECT(m->opt.solver != mjSOL_PGS, "solvers other than PGS (set opt.solver = mjSOL_PGS; Newton/CG are next)");
+  MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
+  MJH_REJECT(m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60),
+             "sparse constraint Jacobian (nv >= 60 or jacobian=sparse)");   // mj_isSparse, engine_core_util.c:29
+  MJH_REJECT(m->opt.enableflags & (mjENBL_SLEEP | mjENBL_DIAGEXACT | mjENBL_FWDINV | mjENBL_ENERGY),
+             "enable flags sleep/diagexact/fwdinv/energy");
+  MJH_REJECT(m->opt.density != 0 || m->opt.viscosity != 0, "fluid forces (density/viscosity)");
+  MJH_REJECT(m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0, "wind");
+  MJH_REJECT(m->nactuator != m->nu, "multi-input actuators (nactuator != nu)");
+  MJH_REJECT(m->nout != m->nu, "multi-output actuators (nout != nu)");
+  for (int i = 0; i < m->nactuator; i++) {
+    MJH_REJECT(m->actuator_ctrlnum[i] != 1 || m->actuator_ctrladr[i] != i, "actuator control blocks other than one scalar");
+    MJH_REJECT(m->actuator_outnum[i] != 1 || m->actuator_outadr[i] != i, "actuator output blocks other than one scalar");
+    MJH_REJECT(m->actuator_dyntype[i] != mjDYN_NONE, "actuator dynamics (dyntype != none)");
+    MJH_REJECT(m->actuator_gaintype[i] != mjGAIN_FIXED && m->actuator_gaintype[i] != mjGAIN_AFFINE, "actuator gain types other than fixed/affine");
+    MJH_REJECT(m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE, "actuator bias types other than none/affine");
+    MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
+    MJH_REJECT(m->actuator_delay[i] != 0, "actuator delays");
+    int tt = m->actuator_trntype[i];
+    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT, "actuator transmissions other than joint");
+    int jt = m->jnt_type[m->actuator_trnid[2*i]];
+    MJH_REJECT(jt != mjJNT_HINGE && jt != mjJNT_SLIDE, "actuators on ball/free joints");
+    // servo wrap period (wrapPeriod, engine_forward.c:305-342) is zero for hinge/slide joint transmissions
+  }
+  for (int i = 0; i < m->ntendon; i++) {
+    MJH_REJECT(m->wrap_type[m->tendon_adr[i]] != mjWRAP_JOINT, "spatial tendons");
+    MJH_REJECT(m->tendon_frictionloss[i] > 0, "tendon friction loss");
+    MJH_REJECT(m->tendon_armature[i] != 0 || actuator_contrib(m, 1, i, 1, nullptr) != 0, "tendon armature");
+    MJH_REJECT(m->tendon_actfrclimited[i], "tendon actuator force limits");
+  }
+  for (int i = 0; i < m->njnt; i++) {
+    MJH_REJECT(m->jnt_actgravcomp[i], "actuator-level gravity compensation");
+    if (m->jnt_limited[i]) {
+      const mjtNum* r = m->jnt_solref + mjNREF*i;
+      MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on a joint limit");
+    }
+  }
+  for (int i = 0; i < m->nv; i++) {
+    if (m->dof_frictionloss[i] != 0) {
+      const mjtNum* r = m->dof_solref + mjNREF*i;
+      MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on dof friction");
+    }
+  }
+
+  // ---------------- sizes & options -----------------------------------------------------------------
+  s.nq = m->nq; s.nv = m->nv; s.nu = m->nu; s.na = m->na; s.nbody = m->nbody; s.njnt = m->njnt;
+  s.ngeom = m->ngeom; s.nsite = m->nsite; s.ntendon = m->ntendon; s.nwrap = m->nwrap;
+  s.nC = m->nC; s.nJten = m->nJten; s.ntree = m->ntree;
+  s.nvw = (m->nv + 31)/32;
+  s.nstate = 1 + m->nq + m->nv + m->na;
+  s.nmoment = m->nu;
+
+  o.timestep = m->opt.timestep; o.impratio = m->opt.impratio; o.tolerance = m->opt.tolerance;
+  for (int k = 0; k < 3; k++) o.gravity[k] = m->opt.gravity[k];
+  o.meaninertia = m->stat.meaninertia;
+  o.integrator = m->opt.integrator; o.cone = m->opt.cone; o.solver = m->opt.solver;
+  o.iterations = m->opt.iterations;
+  o.disableflags = m->opt.disableflags; o.enableflags = m->opt.enableflags;
+
+  // ---------------- direct copies ----------------------------------------------------------------------
+  copy_arr(H->body_parentid, m->body_parentid, m->nbody);
+  copy_arr(H->body_rootid, m->body_rootid, m->nbody);
+  copy_arr(H->body_weldid, m->body_weldid, m->nbody);
+  copy_arr(H->body_mocapid, m->body_mocapid, m->nbody);
+  copy_arr(H->body_jntnum, m->body_jntnum, m->nbody);
+  copy_arr(H->body_jntadr, m->body_jntadr, m->nbody);
+  copy_arr(H->body_dofnum, m->body_dofnum, m->nbody);
+  copy_arr(H->body_dofadr, m->body_dofadr, m->nbody);
+  copy_arr(H->body_geomnum, m->body_geomnum, m->nbody);
+  copy_arr(H->body_geomadr, m->body_geomadr, m->nbody);
+  copy_arr(H->body_sameframe, m->body_sameframe, m->nbody);
+  copy_arr(H->jnt_type, m->jnt_type, m->njnt);
+  copy_arr(H->jnt_qposadr, m->jnt_qposadr, m->njnt);
+  copy_arr(H->jnt_dofadr, m->jnt_dofadr, m->njnt);
+  copy_arr(H->jnt_bodyid, m->jnt_bodyid, m->njnt);
+  copy_arr(H->jnt_limited, m->jnt_limited, m->njnt);
+  copy_arr(H->jnt_actfrclimited, m->jnt_actfrclimited, m->njnt);
+  copy_arr(H->dof_bodyid, m->dof_bodyid, m->nv);
+  copy_arr(H->dof_jntid, m->dof_jntid, m->nv);
+  copy_arr(H->dof_parentid, m->dof_parentid, m->nv);
+  copy_arr(H->dof_simplenum, m->dof_simplenum, m->nv);
+  copy_arr(H->M_rownnz, m->M_rownnz, m->nv);
+  copy_arr(H->M_rowadr, m->M_rowadr, m->nv);
+  copy_arr(H->M_colind, m->M_colind, m->nC);
+  copy_arr(H->geom_type, m->geom_type, m->ngeom);
+  copy_arr(H->geom_bodyid, m->geom_bodyid, m->ngeom);
+  copy_arr(H->geom_sameframe, m->geom_sameframe, m->ngeom);
+  copy_arr(H->site_bodyid, m->site_bodyid, m->nsite);
+  copy_arr(H->site_sameframe, m->site_sameframe, m->nsite);
+  copy_arr(H->tendon_adr, m->tendon_adr, m->ntendon);
+  copy_arr(H->tendon_num, m->tendon_num, m->ntendon);
+  copy_arr(H->tendon_limited, m->tendon_limited, m->ntendon);
+  copy_arr(H->ten_J_rownnz, m->ten_J_rownnz, m->ntendon);
+  copy_arr(H->ten_J_rowadr, m->ten_J_rowadr, m->ntendon);
+  copy_arr(H->ten_J_colind, m->ten_J_colind, m->nJten);
+  copy_arr(H->wrap_type, m->wrap_type, m->nwrap);
+  copy_arr(H->wrap_objid, m->wrap_objid, m->nwrap);
+  copy_arr(H->actuator_trntype, m->actuator_trntype, m->nu);
+  copy_arr(H->actuator_trnid, m->actuator_trnid, 2*m->nu);
+  copy_arr(H->actuator_gaintype, m->actuator_gaintype, m->nu);
+  copy_arr(H->actuator_biastype, m->actuator_biastype, m->nu);
+  copy_arr(H->actuator_ctrllimited, m->actuator_ctrllimited, m->nu);
+  copy_arr(H->actuator_forcelimited, m->actuator_forcelimited, m->nu);
+
+  copy_arr(H->qpos0, m->qpos0, m->nq);
+  copy_arr(H->qpos_spring, m->qpos_spring, m->nq);
+  copy_arr(H->body_pos, m->body_pos, 3*m->nbody);
+  copy_arr(H->body_quat, m->body_quat, 4*m->nbody);
+  copy_arr(H->body_ipos, m->body_ipos, 3*m->nbody);
+  copy_arr(H->body_iquat, m->body_iquat, 4*m->nbody);
+  copy_arr(H->body_mass, m->body_mass, m->nbody);
+  copy_arr(H->body_subtreemass, m->body_subtreemass, m->nbody);
+  copy_arr(H->body_inertia, m->body_inertia, 3*m->nbody);
+  copy_arr(H->body_invweight0, m->body_invweight0, 2*m->nbody);
+  copy_arr(H->jnt_pos, m->jnt_pos, 3*m->njnt);
+  copy_arr(H->jnt_axis, m->jnt_axis, 3*m->njnt);
+  copy_arr(H->jnt_stiffness, m->jnt_stiffness, m->njnt);
+  copy_arr(H->jnt_stiffnesspoly, m->jnt_stiffnesspoly, 2*m->njnt);
+  copy_arr(H->jnt_range, m->jnt_range, 2*m->njnt);
+  copy_arr(H->jnt_margin, m->jnt_margin, m->njnt);
+  copy_arr(H->jnt_solref, m->jnt_solref, 2*m->njnt);
+  copy_arr(H->jnt_solimp, m->jnt_solimp, 5*m->njnt);
+  copy_arr(H->jnt_actfrcrange, m->jnt_actfrcrange, 2*m->njnt);
+  copy_arr(H->dof_invweight0, m->dof_invweight0, m->nv);
+  copy_arr(H->dof_M0, m->dof_M0, m->nv);
+  copy_arr(H->dof_frictionloss, m->dof_frictionloss, m->nv);
+  copy_arr(H->dof_solref, m->dof_solref, 2*m->nv);
+  copy_arr(H->dof_solimp, m->dof_solimp, 5*m->nv);
+  copy_arr(H->geom_pos, m->geom_pos, 3*m->ngeom);
+  copy_arr(H->geom_quat, m->geom_quat, 4*m->ngeom);
+  copy_arr(H->geom_size, m->geom_size, 3*m->ngeom);
+  copy_arr(H->geom_rbound, m->geom_rbound, m->ngeom);
+  copy_arr(H->site_pos, m->site_pos, 3*m->nsite);
+  copy_arr(H->site_quat, m->site_quat, 4*m->nsite);
+  copy_arr(H->tendon_range, m->tendon_range, 2*m->ntendon);
+  copy_arr(H->tendon_margin, m->tendon_margin, m->ntendon);
+  copy_arr(H->tendon_solref_lim, m->tendon_solref_lim, 2*m->ntendon);
+  copy_arr(H->tendon_solimp_lim, m->tendon_solimp_lim, 5*m->ntendon);
+  copy_arr(H->tendon_invweight0, m->tendon_invweight0, m->ntendon);
+  copy_arr(H->tendon_stiffness, m->tendon_stiffness, m->ntendon);
+  copy_arr(H->tendon_stiffnesspoly, m->tendon_stiffnesspoly, 2*m->ntendon);
+  copy_arr(H->tendon_lengthspring, m->tendon_lengthspring, 2*m->ntendon);
+  copy_arr(H->tendon_frictionloss, m->tendon_frictionloss, m->ntendon);
+  copy_arr(H->wrap_prm, m->wrap_prm, m->nwrap);
+  copy_arr(H->actuator_gear, m->actuator_gear, 6*m->nu);
+  copy_arr(H->actuator_ctrlrange, m->actuator_ctrlrange, 2*m->nu);
+  copy_arr(H->actuator_forcerange, m->actuator_forcerange, 2*m->nu);
+  copy_arr(H->actuator_gainprm, m->actuator_gainprm, 10*m->nu);
+  copy_arr(H->actuator_biasprm, m->actuator_biasprm, 10*m->nu);
+  copy_arr(H->actuator_cranklength, m->actuator_cranklength, m->nu);
+
+  // ---------------- derived: dofs ------------------------------------------------------------------------
+  H->dof_jnttype.resize(m->nv);
+  for (int i = 0; i < m->nv; i++) H->dof_jnttype[i] = m->jnt_type[m->dof_jntid[i]];
+  H->dof_armature_eff.resize(m->nv);
+  H->dof_damping_eff.resize(m->nv);
+  H->dof_dampingpoly_eff.assign(2*m->nv, 0);
+  int euler_damp = 0;
+  for (int i = 0; i < m->nv; i++) {
+    int j = m->dof_jntid[i];
+    H->dof_armature_eff[i] = m->dof_armature[i] + actuator_contrib(m, 0, j, 1, nullptr);
+    real poly[2] = {m->dof_dampingpoly[2*i], m->dof_dampingpoly[2*i+1]};
+    H->dof_damping_eff[i] = m->dof_damping[i] + actuator_contrib(m, 0, j, 0, poly);
+    H->dof_dampingpoly_eff[2*i] = poly[0];
+    H->dof_dampingpoly_eff[2*i+1] = poly[1];
+    // gate of the implicit-damping branch (engine_forward.c:1409-1420)
+    if (m->dof_damping[i] > 0 || m->dof_dampingpoly[2*i] != 0 || m->dof_dampingpoly[2*i+1] != 0 ||
+        m->jnt_actuatorid[j] != -1) euler_damp = 1;
+  }
+  if ((m->opt.disableflags & mjDSBL_EULERDAMP) || (m->opt.disableflags & mjDSBL_DAMPER)) euler_damp = 0;
+  o.euler_damp = euler_damp;
+  H->tendon_damping_eff.resize(m->ntendon);
+  H->tendon_dampingpoly_eff.assign(2*m->ntendon, 0);
+  H->tendon_armature_eff.assign(m->ntendon, 0);
+  for (int i = 0; i < m->ntendon; i++) {
+    real poly[2] = {m->tendon_dampingpoly[2*i], m->tendon_dampingpoly[2*i+1]};
+    H->tendon_damping_eff[i] = m->tendon_damping[i] + actuator_contrib(m, 1, i, 0, poly);
+    H->tendon_dampingpoly_eff[2*i] = poly[0];
+    H->tendon_dampingpoly_eff[2*i+1] = poly[1];
+  }
+  H->actuator_momentadr.resize(m->nu + 1);
+  for (int i = 0; i <= m->nu; i++) H->actuator_momentadr[i] = i;
+
+  // ---------------- derived: tree levels, children, dof ancestors --------------------------------------
+  std::vector<int> depth(m->nbody, 0);
+  int nlevel = 1;
+  for (int i = 1; i < m->nbody; i++) {
+    depth[i] = depth[m->body_parentid[i]] + 1;
+    nlevel = std::max(nlevel, depth[i] + 1);
+  }
+  s.nlevel = nlevel;
+  H->body_level_adr.assign(nlevel + 1, 0);
+  for (int i = 0; i < m->nbody; i++) H->body_level_adr[depth[i] + 1]++;
+  for (int L = 0; L < nlevel; L++) H->body_level_adr[L+1] += H->body_level_adr[L];
+  H->body_level_ids.assign(m->nbody, 0);
+  {
+    std::vector<int> fill(H->body_level_adr.begin(), H->body_level_adr.end() - 1);
+    for (int i = 0; i < m->nbody; i++) H->body_level_ids[fill[depth[i]]++] = i;
+  }
+  H->body_child_adr.assign(m->nbody + 1, 0);
+  for (int i = 1; i < m->nbody; i++) H->body_child_adr[m->body_parentid[i] + 1]++;
+  for (int i = 0; i < m->nbody; i++) H->body_child_adr[i+1] += H->body_child_adr[i];
+  H->body_child_ids.assign(m->nbody, 0);
+  {
+    // children in DECREASING body id: the order in which `for b = nbody-1..1` visits them
+    std::vector<int> fill(H->body_child_adr.begin(), H->body_child_adr.end() - 1);
+    for (int i = m->nbody - 1; i >= 1; i--) H->body_child_ids[fill[m->body_parentid[i]]++] = i;
+  }
+  H->body_dofanc.assign((size_t)m->nbody * s.nvw, 0);
+  for (int b = 0; b < m->nbody; b++) {
+    int w = m->body_weldid[b];
+    if (m->body_dofnum[w] == 0) continue;
+    int i = m->body_dofadr[w] + m->body_dofnum[w] - 1;
+    while (i >= 0) {
+      H->body_dofanc[(size_t)b*s.nvw + (i >> 5)] |= (1u << (i & 31));
+      i = m->dof_parentid[i];
+    }
+  }
+
+  // ---------------- static candidate pairs in reference contact order --------------------------------
+  const int dsbl_filterparent = m->opt.disableflags & mjDSBL_FILTERPARENT;
+  const int midphase = !(m->opt.disableflags & mjDSBL_MIDPHASE);
+  const int override_ = m->opt.enableflags & mjENBL_OVERRIDE;
+  struct GP { int g1, g2; };
+  int maxcon_total = 0;
+  for (int b1 = 0; b1 < m->nbody; b1++) {
+    if (!(m->body_contype[b1] || m->body_conaffinity[b1])) continue;
+    for (int b2 = b1 + 1; b2 < m->nbody; b2++) {
+      if (!(m->body_contype[b2] || m->body_conaffinity[b2])) continue;
+      int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+      int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+      // filterBodyPair (engine_collision_driver.c:288-319), nothing asleep
+      if (w1 == w2) continue;
+      if (m->body_dofnum[w1] == 0 && m->body_dofnum[w2] == 0) continue;
+      if (!dsbl_filterparent && w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+      if (filter_bitmask(m->body_contype[b1], m->body_conaffinity[b1],
+                         m->body_contype[b2], m->body_conaffinity[b2])) continue;
+      unsigned sig = ((unsigned)b1 << 16) + (unsigned)b2;
+      bool excluded = false;
+      for (int x = 0; x < m->nexclude; x++) if ((unsigned)m->exclude_signature[x] == sig) excluded = true;
+      if (excluded) continue;
+
+      std::vector<GP> gps;
+      for (int g1 = m->body_geomadr[b1]; g1 < m->body_geomadr[b1] + m->body_geomnum[b1]; g1++) {
+        for (int g2 = m->body_geomadr[b2]; g2 < m->body_geomadr[b2] + m->body_geomnum[b2]; g2++) {
+          if (filter_bitmask(m->geom_contype[g1], m->geom_conaffinity[g1],
+                             m->geom_contype[g2], m->geom_conaffinity[g2])) continue;
+          int a = g1, b = g2;
+          if (m->geom_type[a] > m->geom_type[b]) std::swap(a, b);   // pushGeomGeom
+          if (!ref_collides(m->geom_type[a], m->geom_type[b])) continue;
+          gps.push_back({a, b});
+        }
+      }
+      // midphase route: contacts are sorted by the STORED (type-ordered) geom ids (contactcompare :410-440)
+      bool single = m->body_geomnum[b1] == 1 && m->body_geomnum[b2] == 1;
+      if (!single && midphase && m->body_bvhadr[b1] >= 0 && m->body_bvhadr[b2] >= 0) {
+        std::stable_sort(gps.begin(), gps.end(), [](const GP& x, const GP& y) {
+          return x.g1 != y.g1 ? x.g1 < y.g1 : x.g2 < y.g2; });
+      }
+      for (const GP& gp : gps) {
+        int g1 = gp.g1, g2 = gp.g2;
+        int maxcon = 0;
+        int func = pair_func(m->geom_type[g1], m->geom_type[g2], &maxcon);
+        MJH_REJECT(func < 0, "collision between geom types other than plane/sphere/capsule");
+        // mj_contactParam (engine_collision_driver.c:1740-1835)
+        int condim;
+        real solref[2], solimp[5], fri[3];
+        int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+        const mjtNum *sr1 = m->geom_solref + 2*g1, *sr2 = m->geom_solref + 2*g2;
+        const mjtNum *si1 = m->geom_solimp + 5*g1, *si2 = m->geom_solimp + 5*g2;
+        const mjtNum *f1 = m->geom_friction + 3*g1, *f2 = m->geom_friction + 3*g2;
+        if (p1 > p2) {
+          condim = m->geom_condim[g1];
+          for (int k = 0; k < 2; k++) solref[k] = sr1[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si1[k];
+          for (int k = 0; k < 3; k++) fri[k] = f1[k];
+        } else if (p1 < p2) {
+          condim = m->geom_condim[g2];
+          for (int k = 0; k < 2; k++) solref[k] = sr2[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = f2[k];
+        } else {
+          condim = std::max(m->geom_condim[g1], m->geom_condim[g2]);
+          real m1 = m->geom_solmix[g1], m2 = m->geom_solmix[g2], mix;
+          if (m1 >= mjMINVAL && m2 >= mjMINVAL) mix = m1 / (m1 + m2);
+          else if (m1 < mjMINVAL && m2 < mjMINVAL) mix = 0.5;
+          else if (m1 < mjMINVAL) mix = 0.0;
+          else mix = 1.0;
+          if (sr1[0] > 0 && sr2[0] > 0) {
+            for (int k = 0; k < 2; k++) solref[k] = mix*sr1[k] + (1-mix)*sr2[k];
+          } else {
+            for (int k = 0; k < 2; k++) solref[k] = std::min(sr1[k], sr2[k]);
+          }
+          for (int k = 0; k < 5; k++) solimp[k] = mix*si1[k] + (1-mix)*si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = std::max(f1[k], f2[k]);
+        }
+        real friction[5] = {fri[0], fri[0], fri[1], fri[2], fri[2]};
+        real margin = m->geom_margin[g1] + m->geom_margin[g2];
+        real gap = m->geom_gap[g1] + m->geom_gap[g2];
+        if (override_) {
+          // mj_assignMargin/Ref/Imp/Friction (engine_core_constraint.c:177-218)
+          margin = m->opt.o_margin;
+          for (int k = 0; k < 2; k++) solref[k] = m->opt.o_solref[k];
+          for (int k = 0; k < 5; k++) solimp[k] = m->opt.o_solimp[k];
+          for (int k = 0; k < 5; k++) friction[k] = m->opt.o_friction[k];
+        }
+        for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
+        MJH_REJECT(condim > 3, "contact condim > 3 (torsional/rolling friction)");
+        MJH_REJECT(condim > 1 && m->opt.cone != mjCONE_PYRAMIDAL, "elliptic friction cones");
+        MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
+        H->pair_geom1.push_back(g1);
+        H->pair_geom2.push_back(g2);
+        H->pair_dim.push_back(condim);
+        H->pair_maxcon.push_back(maxcon);
+        H->pair_func.push_back(func);
+        H->pair_margin.push_back(margin + gap);
+        H->pair_includemargin.push_back(margin);
+        for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
+        for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
+        for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
+        for (int k = 0; k < 5; k++) H->pair_solimp.push_back(solimp[k]);
+        maxcon_total += maxcon;
+      }
+    }
+  }
+  s.npair = (int)H->pair_geom1.size();
+
+  // ---------------- capacities ---------------------------------------------------------------------------
+  int nlimit = 0;
+  for (int i = 0; i < m->njnt; i++) if (m->jnt_limited[i]) nlimit += (m->jnt_type[i] == mjJNT_BALL) ? 1 : 2;
+  for (int i = 0; i < m->ntendon; i++) if (m->tendon_limited[i]) nlimit += 2;
+  int nfric = 0;
+  for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
+  s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
+  int rows_per_con = 1;
+  for (int c : H->pair_dim) rows_per_con = std::max(rows_per_con, c == 1 ? 1 : 2*(c-1));
+  int nefc_bound = nfric + nlimit + rows_per_con*s.nconmax;
+  s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));
+  return true;
+}
+
+// verify that every vector has exactly the size its X-macro declares
+static bool check_sizes(const HostModel& H, std::string* err) {
+  const DSizes& s = H.s;
+#define X(name, cnt) if ((long long)H.name.size() != (long long)(cnt)) { *err = std::string("mjhip internal: size of ") + #name; return false; }
+  MJH_MODEL_INT_FIELDS(X)
+  MJH_MODEL_REAL_FIELDS(X)
+#undef X
+  return true;
+}
+
+}  // namespace mjhb

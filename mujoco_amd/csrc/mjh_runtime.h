@@ -1,0 +1,404 @@
+// Host runtime shared by the two builds of the C ABI (include/mjhip.h):
+//   product   : mjh_hip.hip     -> Backend = HIP runtime + __global__ kernels (libmjhip.so)
+//   test-only : tests/hostsim   -> Backend = malloc + the wavefront emulation of mjh_spmd.h
+// Everything here is plain C++: model upload, batch allocation (one SoA-across-envs arena per
+// batch), field registry, rollout argument marshalling, the mjhip_rollout drop-in.
+//
+// The including translation unit must define, before including this file, a struct `Backend` with:
+//   static const char* name();
+//   static int  device_count();
+//   static bool set_device(int dev, std::string* err);
+//   static void* alloc(size_t bytes);            // device memory, nullptr on failure
+//   static void free(void* p);
+//   static bool h2d(void* dst, const void* src, size_t bytes, void* stream);
+//   static bool d2h(void* dst, const void* src, size_t bytes, void* stream);
+//   static bool zero(void* dst, size_t bytes, void* stream);
+//   static bool sync(void* stream);
+//   static bool launch_forward(const DModel&, const DBatch&, int nenv, int stages, void* stream);
+//   static bool launch_rollout(const DModel&, const DBatch&, int nenv, const RolloutArgs&, void* stream);
+//   static bool launch_reset(const DModel&, const DBatch&, int nenv, void* stream);
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mjhip.h"
+#include "mjh_model_build.h"
+#include "mjh_mjb.h"
+#include "mjh_step.h"
+
+static thread_local std::string g_mjhip_err;
+static void set_err(const std::string& e) { g_mjhip_err = e; }
+
+struct mjhipModel_ {
+  HostModel H;
+  DModel D;                 // device pointers
+  std::vector<void*> allocs;
+  int device = 0;
+  std::vector<char> signature;   // bytes identifying the source mjModel (for the rollout cache)
+};
+
+struct FieldInfo { void* ptr; int count; int is_int; };
+
+struct mjhipBatch_ {
+  mjhipModel_* model = nullptr;
+  DBatch D;
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  std::map<std::string, FieldInfo> fields;
+  int nenv = 0;
+};
+
+template <class T>
+static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, const T** out, std::string* err) {
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  void* p = Backend::alloc(bytes);
+  if (!p) { *err = "mjhip: device allocation failed (model)"; return false; }
+  M->allocs.push_back(p);
+  if (!v.empty() && !Backend::h2d(p, v.data(), v.size()*sizeof(T), nullptr)) {
+    *err = "mjhip: host->device copy failed (model)";
+    return false;
+  }
+  *out = (const T*)p;
+  return true;
+}
+
+extern "C" {
+
+MJHIP_API const char* mjhip_backend(void) { return Backend::name(); }
+MJHIP_API const char* mjhip_last_error(void) { return g_mjhip_err.c_str(); }
+MJHIP_API int mjhip_device_count(void) { return Backend::device_count(); }
+
+MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, int nefcmax) {
+  if (!m) { set_err("mjhip_model_create: null mjModel"); return nullptr; }
+  if (Backend::device_count() <= 0) {
+    set_err("mjhip: no HIP device visible -- libmjhip has no CPU fallback");
+    return nullptr;
+  }
+  mjhipModel_* M = new mjhipModel_();
+  std::string err;
+  mjhb::BuildCaps caps;
+  caps.nconmax = nconmax; caps.nefcmax = nefcmax;
+  if (!mjhb::build((const mjModel*)m, caps, &M->H, &err) || !mjhb::check_sizes(M->H, &err)) {
+    set_err(err);
+    delete M;
+    return nullptr;
+  }
+  M->D.s = M->H.s;
+  M->D.o = M->H.o;
+  bool ok = true;
+#define X(name, cnt) ok = ok && upload_vec<int>(M, M->H.name, &M->D.name, &err);
+  MJH_MODEL_INT_FIELDS(X)
+#undef X
+#define X(name, cnt) ok = ok && upload_vec<real>(M, M->H.name, &M->D.name, &err);
+  MJH_MODEL_REAL_FIELDS(X)
+#undef X
+  if (!ok || !Backend::sync(nullptr)) {
+    set_err(err.empty() ? "mjhip: model upload failed" : err);
+    mjhip_model_destroy(M);
+    return nullptr;
+  }
+  // signature for the rollout cache: sizes + option block + the constant buffer contents
+  const mjModel* mm = (const mjModel*)m;
+  M->signature.assign((const char*)mm->buffer, (const char*)mm->buffer + mm->nbuffer);
+  M->signature.insert(M->signature.end(), (const char*)&mm->opt, (const char*)&mm->opt + sizeof(mm->opt));
+  return M;
+}
+
+MJHIP_API void mjhip_model_destroy(mjhipModel* M) {
+  if (!M) return;
+  for (void* p : M->allocs) Backend::free(p);
+  delete M;
+}
+
+MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
+  if (!M || !name) return -1;
+  const DSizes& s = M->H.s;
+#define SZ(n) if (!strcmp(name, #n)) return s.n;
+  SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
+  SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
+#undef SZ
+  set_err(std::string("mjhip_model_size: unknown size ") + name);
+  return -1;
+}
+
+MJHIP_API struct mjModel_* mjhip_load_mjb(const char* path) {
+  std::string err;
+  mjModel* m = mjhmjb::load(path, &err);
+  if (!m) set_err(err);
+  return (struct mjModel_*)m;
+}
+MJHIP_API void mjhip_free_mjb(struct mjModel_* m) { mjhmjb::release((mjModel*)m); }
+
+MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
+  if (!M || nenv <= 0) { set_err("mjhip_batch_create: bad arguments"); return nullptr; }
+  std::string err;
+  if (!Backend::set_device(device, &err)) { set_err(err); return nullptr; }
+  mjhipBatch_* Bt = new mjhipBatch_();
+  Bt->model = M;
+  Bt->nenv = nenv;
+  const DSizes& s = M->H.s;
+  // one arena; every field aligned to 256 bytes
+  size_t off = 0;
+  auto place = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  std::vector<std::pair<size_t, size_t>> spans;
+#define X(name, cnt) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(real)*nenv), n}); }
+  MJH_BATCH_REAL_FIELDS(X)
+#undef X
+#define X(name, cnt) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(int)*nenv), n}); }
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  Bt->arena_bytes = off;
+  Bt->arena = Backend::alloc(off);
+  if (!Bt->arena) {
+    set_err("mjhip: device allocation failed (batch arena of " + std::to_string(off) + " bytes)");
+    delete Bt;
+    return nullptr;
+  }
+  Backend::zero(Bt->arena, off, nullptr);
+  char* base = (char*)Bt->arena;
+  size_t k = 0;
+  Bt->D.nenv = nenv;
+#define X(name, cnt) Bt->D.name = (real*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
+  Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 0}; k++;
+  MJH_BATCH_REAL_FIELDS(X)
+#undef X
+#define X(name, cnt) Bt->D.name = (int*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
+  Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 1}; k++;
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  if (mjhip_batch_reset(Bt) != 0) { mjhip_batch_destroy(Bt); return nullptr; }
+  return Bt;
+}
+
+MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
+  if (!Bt) return;
+  if (Bt->arena) Backend::free(Bt->arena);
+  delete Bt;
+}
+
+MJHIP_API int mjhip_batch_nenv(const mjhipBatch* Bt) { return Bt ? Bt->nenv : -1; }
+
+MJHIP_API int mjhip_batch_reset(mjhipBatch* Bt) {
+  if (!Bt) return -1;
+  if (!Backend::launch_reset(Bt->model->D, Bt->D, Bt->nenv, nullptr) || !Backend::sync(nullptr)) {
+    set_err("mjhip_batch_reset: kernel launch failed");
+    return -2;
+  }
+  return 0;
+}
+
+MJHIP_API int mjhip_batch_field(mjhipBatch* Bt, const char* name, void** device_ptr,
+                                int* count_per_env, int* is_int) {
+  if (!Bt || !name) return -1;
+  auto it = Bt->fields.find(name);
+  if (it == Bt->fields.end()) { set_err(std::string("mjhip: unknown batch field ") + name); return -2; }
+  if (device_ptr) *device_ptr = it->second.ptr;
+  if (count_per_env) *count_per_env = it->second.count;
+  if (is_int) *is_int = it->second.is_int;
+  return 0;
+}
+
+static size_t field_stride(const mjhipBatch_* Bt, const FieldInfo& f) {
+  return (size_t)std::max(1, f.count) * (f.is_int ? sizeof(int) : sizeof(real));
+}
+
+MJHIP_API int mjhip_batch_get(mjhipBatch* Bt, const char* name, void* host_dst) {
+  void* p; int cnt, isint;
+  if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
+  if (cnt == 0) return 0;
+  size_t bytes = (size_t)cnt * (isint ? sizeof(int) : sizeof(real)) * Bt->nenv;
+  if (!Backend::d2h(host_dst, p, bytes, nullptr) || !Backend::sync(nullptr)) {
+    set_err("mjhip_batch_get: copy failed"); return -3;
+  }
+  return 0;
+}
+
+MJHIP_API int mjhip_batch_set(mjhipBatch* Bt, const char* name, const void* host_src) {
+  void* p; int cnt, isint;
+  if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
+  if (cnt == 0) return 0;
+  size_t bytes = (size_t)cnt * (isint ? sizeof(int) : sizeof(real)) * Bt->nenv;
+  if (!Backend::h2d(p, host_src, bytes, nullptr) || !Backend::sync(nullptr)) {
+    set_err("mjhip_batch_set: copy failed"); return -3;
+  }
+  return 0;
+}
+
+MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
+  if (!Bt) return -1;
+  if (stages < 0) stages = MJH_STAGE_ALL;
+  if (!Backend::launch_forward(Bt->model->D, Bt->D, Bt->nenv, stages, stream)) {
+    set_err("mjhip_batch_forward: kernel launch failed"); return -2;
+  }
+  return 0;
+}
+
+MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
+  if (!Bt || nstep < 0) return -1;
+  RolloutArgs A;
+  memset(&A, 0, sizeof(A));
+  A.nstep = nstep;
+  A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied
+  A.init = 0;
+  if (!Backend::launch_rollout(Bt->model->D, Bt->D, Bt->nenv, A, stream)) {
+    set_err("mjhip_batch_step: kernel launch failed"); return -2;
+  }
+  return 0;
+}
+
+// mjtState bits (include/mujoco/mjtype.h:504-527)
+static int control_size(const DSizes& s, unsigned spec, int* qfrc_off, std::string* err) {
+  const unsigned supported = mjSTATE_CTRL | mjSTATE_QFRC_APPLIED;
+  if (spec & ~supported) {
+    *err = "mjhip: control_spec bits other than mjSTATE_CTRL | mjSTATE_QFRC_APPLIED are not supported";
+    return -1;
+  }
+  int n = 0;
+  if (spec & mjSTATE_CTRL) n += s.nu;
+  *qfrc_off = n;
+  if (spec & mjSTATE_QFRC_APPLIED) n += s.nv;
+  return n;
+}
+
+MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_spec,
+                                  const double* state0, const double* warmstart0,
+                                  const double* control, double* state, int on_device,
+                                  void* stream) {
+  if (!Bt || nstep < 0) { set_err("mjhip_batch_rollout: bad arguments"); return -1; }
+  const DSizes& s = Bt->model->H.s;
+  std::string err;
+  int qfrc_off = 0;
+  int ncontrol = control_size(s, control_spec, &qfrc_off, &err);
+  if (ncontrol < 0) { set_err(err); return -2; }
+  const size_t nenv = Bt->nenv;
+  RolloutArgs A;
+  memset(&A, 0, sizeof(A));
+  A.nstep = nstep;
+  A.has_ctrl = (control_spec & mjSTATE_CTRL) ? 1 : 0;
+  A.has_qfrc = (control_spec & mjSTATE_QFRC_APPLIED) ? 1 : 0;
+  A.ncontrol = ncontrol;
+  A.qfrc_off = qfrc_off;
+  A.init = 1;
+  std::vector<void*> tmp;
+  auto cleanup = [&]() { for (void* p : tmp) Backend::free(p); };
+  if (on_device) {
+    A.state0 = state0; A.warmstart0 = warmstart0; A.control = control; A.state = state;
+  } else {
+    auto up = [&](const double* src, size_t n, const real** dst) -> bool {
+      if (!src || n == 0) { *dst = nullptr; return true; }
+      void* p = Backend::alloc(n*sizeof(real));
+      if (!p) return false;
+      tmp.push_back(p);
+      *dst = (const real*)p;
+      return Backend::h2d(p, src, n*sizeof(real), stream);
+    };
+    bool ok = up(state0, nenv*s.nstate, &A.state0) && up(warmstart0, nenv*s.nv, &A.warmstart0) &&
+              up(control, ncontrol ? nenv*(size_t)nstep*ncontrol : 0, &A.control);
+    if (ok && state && nstep > 0) {
+      void* p = Backend::alloc(nenv*(size_t)nstep*s.nstate*sizeof(real));
+      if (!p) ok = false; else { tmp.push_back(p); A.state = (real*)p; }
+    }
+    if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
+  }
+  if (!A.control) { /* no control array: inputs not in the spec stay zero, those in it keep current */ }
+  if (!Backend::launch_rollout(Bt->model->D, Bt->D, Bt->nenv, A, stream)) {
+    cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4;
+  }
+  if (!on_device) {
+    bool ok = true;
+    if (state && nstep > 0) ok = Backend::d2h(state, A.state, nenv*(size_t)nstep*s.nstate*sizeof(real), stream);
+    ok = Backend::sync(stream) && ok;
+    cleanup();
+    if (!ok) { set_err("mjhip_batch_rollout: device->host copy failed"); return -5; }
+  }
+  return 0;
+}
+
+MJHIP_API int mjhip_batch_sync(mjhipBatch* Bt, void* stream) {
+  (void)Bt;
+  if (!Backend::sync(stream)) { set_err("mjhip_batch_sync: failed"); return -1; }
+  return 0;
+}
+
+// ---- the drop-in: _unsafe_rollout contract ------------------------------------------------------------
+struct RolloutCache {
+  std::mutex mu;
+  mjhipModel_* model = nullptr;
+  mjhipBatch_* batch = nullptr;
+};
+static RolloutCache g_cache;
+
+MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* const* dp, int nbatch,
+                            int nstep, unsigned control_spec, const double* state0,
+                            const double* warmstart0, const double* control, double* state,
+                            double* sensordata) {
+  if (!mp || !dp || nbatch <= 0 || nstep < 0 || !state0) { set_err("mjhip_rollout: bad arguments"); return -1; }
+  const mjModel* m0 = (const mjModel*)mp[0];
+  for (int r = 1; r < nbatch; r++) {
+    const mjModel* mr = (const mjModel*)mp[r];
+    if (mr == m0) continue;
+    if (mr->nbuffer != m0->nbuffer || memcmp(mr->buffer, m0->buffer, m0->nbuffer) ||
+        memcmp(&mr->opt, &m0->opt, sizeof(m0->opt))) {
+      set_err("mjhip_rollout: per-rollout model variation is not supported (all m[r] must be identical)");
+      return -2;
+    }
+  }
+  if (sensordata && m0->nsensordata > 0) { set_err("mjhip_rollout: sensordata output is not supported"); return -2; }
+  std::lock_guard<std::mutex> lock(g_cache.mu);
+  // (re)build the cached device model / batch
+  bool same = g_cache.model &&
+      g_cache.model->signature.size() == (size_t)m0->nbuffer + sizeof(m0->opt) &&
+      !memcmp(g_cache.model->signature.data(), m0->buffer, m0->nbuffer) &&
+      !memcmp(g_cache.model->signature.data() + m0->nbuffer, &m0->opt, sizeof(m0->opt));
+  if (!same) {
+    if (g_cache.batch) { mjhip_batch_destroy(g_cache.batch); g_cache.batch = nullptr; }
+    if (g_cache.model) { mjhip_model_destroy(g_cache.model); g_cache.model = nullptr; }
+    g_cache.model = mjhip_model_create(mp[0], 0, 0);
+    if (!g_cache.model) return -3;
+  }
+  if (!g_cache.batch || g_cache.batch->nenv != nbatch) {
+    if (g_cache.batch) mjhip_batch_destroy(g_cache.batch);
+    g_cache.batch = mjhip_batch_create(g_cache.model, nbatch, 0);
+    if (!g_cache.batch) return -4;
+  }
+  mjhipBatch_* Bt = g_cache.batch;
+  // "computationally stateless": user inputs not in control_spec are cleared (rollout.cc:85-115)
+  if (mjhip_batch_reset(Bt)) return -5;
+  int rc = mjhip_batch_rollout(Bt, nstep, control_spec, state0, warmstart0, control, state, 0, nullptr);
+  if (rc) return rc;
+  // d[0] <- final state of the LAST rollout (rollout.cc:73)
+  mjData* d = (mjData*)dp[0];
+  if (d) {
+    const DSizes& s = g_cache.model->H.s;
+    const int last = nbatch - 1;
+    auto pull = [&](const char* name, double* dst, int n) {
+      if (n <= 0) return;
+      void* p; int cnt, isint;
+      mjhip_batch_field(Bt, name, &p, &cnt, &isint);
+      Backend::d2h(dst, (const char*)p + (size_t)last*cnt*sizeof(real), (size_t)n*sizeof(real), nullptr);
+    };
+    pull("time", &d->time, 1);
+    pull("qpos", d->qpos, s.nq);
+    pull("qvel", d->qvel, s.nv);
+    pull("act", d->act, s.na);
+    pull("ctrl", d->ctrl, s.nu);
+    pull("qfrc_applied", d->qfrc_applied, s.nv);
+    pull("qacc_warmstart", d->qacc_warmstart, s.nv);
+    pull("qacc", d->qacc, s.nv);
+    int w[8];
+    void* p; int cnt, isint;
+    mjhip_batch_field(Bt, "warning", &p, &cnt, &isint);
+    Backend::d2h(w, (const char*)p + (size_t)last*cnt*sizeof(int), 8*sizeof(int), nullptr);
+    Backend::sync(nullptr);
+    for (int k = 0; k < mjNWARNING; k++) d->warning[k].number = w[k];
+  }
+  return 0;
+}
+
+}  // extern "C"

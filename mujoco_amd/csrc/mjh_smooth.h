@@ -1,0 +1,738 @@
+// Smooth (constraint-free) dynamics stages of the batched step, one wavefront per environment.
+//
+// Every function here is called by all 64 lanes of the wavefront that owns environment `e`.
+// Lanes split the independent work items of a phase (bodies of one tree level, joints, dofs,
+// matrix rows); phases are separated by wv_sync().  Per-item arithmetic follows the reference
+// engine's operation order (files below are relative to /root/reference/src/engine) so results
+// agree with the no-FMA CPU build to the last bit wherever the item decomposition allows it.
+#pragma once
+
+#include "mjh_types.h"
+
+// ------------------------------------------------------------------------------------------------
+// frame of a geom/site/inertial frame attached to a body      (mj_local2Global, engine_core_util.c:975)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void local2global(real* opos, real* omat, const real* pos, const real* quat,
+                          const real* xpos, const real* xquat, const real* xmat,
+                          const real* xipos, const real* ximat, int sameframe) {
+  // position
+  if (sameframe == MJH_SAMEFRAME_BODY) {
+    v3_copy(opos, xpos);
+  } else if (sameframe == MJH_SAMEFRAME_INERTIA) {
+    v3_copy(opos, xipos);
+  } else {
+    real t[3];
+    m3_mulvec(t, xmat, pos);
+    v3_addto(t, xpos);
+    v3_copy(opos, t);
+  }
+  // orientation
+  if (sameframe == MJH_SAMEFRAME_NONE) {
+    real q[4];
+    q_mul(q, xquat, quat);
+    q_tomat(omat, q);
+  } else if (sameframe == MJH_SAMEFRAME_BODY || sameframe == MJH_SAMEFRAME_BODYROT) {
+    for (int k = 0; k < 9; k++) omat[k] = xmat[k];
+  } else {
+    for (int k = 0; k < 9; k++) omat[k] = ximat[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_kinematics                                  (engine_core_smooth.c:40-242)
+// level-synchronous: all bodies of one depth level are independent given their parents
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_kinematics(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* qpos = MJH_F(B, qpos, e);
+  real* xpos = MJH_F(B, xpos, e);
+  real* xquat = MJH_F(B, xquat, e);
+  real* xmat = MJH_F(B, xmat, e);
+  real* xipos = MJH_F(B, xipos, e);
+  real* ximat = MJH_F(B, ximat, e);
+  real* xanchor = MJH_F(B, xanchor, e);
+  real* xaxis = MJH_F(B, xaxis, e);
+
+  // world body
+  if (wv_lane() == 0) {
+    v3_zero(xpos); v3_zero(xipos);
+    xquat[0] = 1; xquat[1] = 0; xquat[2] = 0; xquat[3] = 0;
+    for (int k = 0; k < 9; k++) { xmat[k] = (k % 4 == 0) ? 1 : 0; ximat[k] = (k % 4 == 0) ? 1 : 0; }
+  }
+  wv_sync();
+
+  for (int L = 1; L < s.nlevel; L++) {
+    int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
+    MJH_FOR_LANES(k, a1 - a0) {
+      int i = M.body_level_ids[a0 + k];
+      real pos[3], quat[4];
+      int jntadr = M.body_jntadr[i], jntnum = M.body_jntnum[i];
+
+      if (jntnum == 1 && M.jnt_type[jntadr] == MJH_JNT_FREE) {
+        int qadr = M.jnt_qposadr[jntadr];
+        v3_copy(pos, qpos + qadr);
+        q_copy(quat, qpos + qadr + 3);
+        q_normalize(quat);
+        v3_copy(xanchor + 3*jntadr, pos);
+        v3_copy(xaxis + 3*jntadr, M.jnt_axis + 3*jntadr);
+      } else {
+        int pid = M.body_parentid[i];
+        const real* bpos = M.body_pos + 3*i;
+        const real* bquat = M.body_quat + 4*i;
+        if (pid) {
+          m3_mulvec(pos, xmat + 9*pid, bpos);
+          v3_addto(pos, xpos + 3*pid);
+          q_mul(quat, xquat + 4*pid, bquat);
+        } else {
+          v3_copy(pos, bpos);
+          q_copy(quat, bquat);
+        }
+        for (int j = 0; j < jntnum; j++) {
+          int jid = jntadr + j;
+          int qadr = M.jnt_qposadr[jid];
+          int jt = M.jnt_type[jid];
+          real anchor[3], axis[3];
+          q_rotvec(axis, M.jnt_axis + 3*jid, quat);
+          q_rotvec(anchor, M.jnt_pos + 3*jid, quat);
+          v3_addto(anchor, pos);
+          if (jt == MJH_JNT_SLIDE) {
+            v3_addtoscl(pos, axis, qpos[qadr] - M.qpos0[qadr]);
+          } else {
+            real qloc[4];
+            if (jt == MJH_JNT_BALL) {
+              q_copy(qloc, qpos + qadr);
+              q_normalize(qloc);
+            } else {
+              q_axisangle(qloc, M.jnt_axis + 3*jid, qpos[qadr] - M.qpos0[qadr]);
+            }
+            q_mul(quat, quat, qloc);
+            real vec[3];
+            q_rotvec(vec, M.jnt_pos + 3*jid, quat);
+            v3_sub(pos, anchor, vec);
+          }
+          v3_copy(xanchor + 3*jid, anchor);
+          v3_copy(xaxis + 3*jid, axis);
+        }
+      }
+      q_normalize(quat);
+      q_copy(xquat + 4*i, quat);
+      v3_copy(xpos + 3*i, pos);
+      q_tomat(xmat + 9*i, quat);
+    }
+    wv_sync();
+  }
+
+  // inertial frames
+  MJH_FOR_LANES(k, s.nbody - 1) {
+    int i = k + 1;
+    local2global(xipos + 3*i, ximat + 9*i, M.body_ipos + 3*i, M.body_iquat + 4*i,
+                 xpos + 3*i, xquat + 4*i, xmat + 9*i, xipos + 3*i, ximat + 9*i,
+                 M.body_sameframe[i]);
+  }
+  wv_sync();
+
+  // geoms and sites
+  real* geom_xpos = MJH_F(B, geom_xpos, e);
+  real* geom_xmat = MJH_F(B, geom_xmat, e);
+  MJH_FOR_LANES(g, s.ngeom) {
+    int b = M.geom_bodyid[g];
+    local2global(geom_xpos + 3*g, geom_xmat + 9*g, M.geom_pos + 3*g, M.geom_quat + 4*g,
+                 xpos + 3*b, xquat + 4*b, xmat + 9*b, xipos + 3*b, ximat + 9*b,
+                 M.geom_sameframe[g]);
+  }
+  real* site_xpos = MJH_F(B, site_xpos, e);
+  real* site_xmat = MJH_F(B, site_xmat, e);
+  MJH_FOR_LANES(g, s.nsite) {
+    int b = M.site_bodyid[g];
+    local2global(site_xpos + 3*g, site_xmat + 9*g, M.site_pos + 3*g, M.site_quat + 4*g,
+                 xpos + 3*b, xquat + 4*b, xmat + 9*b, xipos + 3*b, ximat + 9*b,
+                 M.site_sameframe[g]);
+  }
+  wv_sync();
+}
+
+// accumulate per-body n-vectors into parents, deepest level first; children of one parent are
+// added in decreasing body id, which reproduces the reference's `for b = nbody-1 .. 1` order.
+MJH_DEV void tree_accumulate_to_parent(const DModel& M, real* x, int n, int include_world) {
+  const DSizes& s = M.s;
+  for (int L = s.nlevel - 2; L >= (include_world ? 0 : 1); L--) {
+    int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
+    MJH_FOR_LANES(k, a1 - a0) {
+      int p = M.body_level_ids[a0 + k];
+      int c0 = M.body_child_adr[p], c1 = M.body_child_adr[p+1];
+      for (int c = c0; c < c1; c++) {
+        int ch = M.body_child_ids[c];
+        for (int q = 0; q < n; q++) x[n*p + q] += x[n*ch + q];
+      }
+    }
+    wv_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_comPos                                      (engine_core_smooth.c:246-350)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_compos(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* xipos = MJH_F(B, xipos, e);
+  const real* ximat = MJH_F(B, ximat, e);
+  const real* xmat = MJH_F(B, xmat, e);
+  const real* xanchor = MJH_F(B, xanchor, e);
+  const real* xaxis = MJH_F(B, xaxis, e);
+  real* subtree_com = MJH_F(B, subtree_com, e);
+  real* cinert = MJH_F(B, cinert, e);
+  real* cdof = MJH_F(B, cdof, e);
+
+  MJH_FOR_LANES(i, s.nbody) v3_scl(subtree_com + 3*i, xipos + 3*i, M.body_mass[i]);
+  wv_sync();
+  tree_accumulate_to_parent(M, subtree_com, 3, 1);
+  MJH_FOR_LANES(i, s.nbody) {
+    if (M.body_subtreemass[i] < MJH_MINVAL) {
+      v3_copy(subtree_com + 3*i, xipos + 3*i);
+    } else {
+      real inv = 1.0 / M.body_subtreemass[i];
+      v3_scl(subtree_com + 3*i, subtree_com + 3*i, inv);
+    }
+  }
+  wv_sync();
+
+  MJH_FOR_LANES(i, s.nbody) {
+    if (i == 0) {
+      for (int k = 0; k < 10; k++) cinert[k] = 0;
+    } else {
+      real off[3];
+      v3_sub(off, xipos + 3*i, subtree_com + 3*M.body_rootid[i]);
+      sp_inert_com(cinert + 10*i, M.body_inertia + 3*i, ximat + 9*i, off, M.body_mass[i]);
+    }
+  }
+  MJH_FOR_LANES(j, s.njnt) {
+    int i = M.jnt_bodyid[j];
+    int da = 6*M.jnt_dofadr[j];
+    real off[3];
+    v3_sub(off, subtree_com + 3*M.body_rootid[i], xanchor + 3*j);
+    int jt = M.jnt_type[j];
+    int skip = 0;
+    if (jt == MJH_JNT_FREE) {
+      for (int k = 0; k < 18; k++) cdof[da + k] = 0;
+      cdof[da + 3 + 0] = 1;
+      cdof[da + 3 + 7] = 1;
+      cdof[da + 3 + 14] = 1;
+      skip = 18;
+    }
+    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+      for (int k = 0; k < 3; k++) {
+        real axis[3] = {xmat[9*i + k], xmat[9*i + k + 3], xmat[9*i + k + 6]};
+        real* r = cdof + da + skip + 6*k;
+        v3_copy(r, axis);
+        v3_cross(r + 3, axis, off);
+      }
+    } else if (jt == MJH_JNT_SLIDE) {
+      v3_zero(cdof + da);
+      v3_copy(cdof + da + 3, xaxis + 3*j);
+    } else {
+      v3_copy(cdof + da, xaxis + 3*j);
+      v3_cross(cdof + da + 3, xaxis + 3*j, off);
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_tendon, fixed tendons only                  (engine_core_smooth.c:927-986)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_tendon(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  if (!s.ntendon) return;
+  const real* qpos = MJH_F(B, qpos, e);
+  real* L = MJH_F(B, ten_length, e);
+  real* J = MJH_F(B, ten_J, e);
+  MJH_FOR_LANES(i, s.ntendon) {
+    int adr = M.tendon_adr[i], num = M.tendon_num[i];
+    int radr = M.ten_J_rowadr[i], rnnz = M.ten_J_rownnz[i];
+    real len = 0;
+    for (int k = 0; k < rnnz; k++) J[radr + k] = 0;
+    for (int j = 0; j < num; j++) {
+      int jid = M.wrap_objid[adr + j];
+      real coef = M.wrap_prm[adr + j];
+      len += coef * qpos[M.jnt_qposadr[jid]];
+      int dof = M.jnt_dofadr[jid];
+      // dst = 1*dst + coef*1 at the matching column (mju_combineSparseInc)
+      for (int k = 0; k < rnnz; k++) {
+        if (M.ten_J_colind[radr + k] == dof) J[radr + k] = 1*J[radr + k] + coef*1;
+      }
+    }
+    L[i] = len;
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_transmission: joint (slide/hinge) transmissions   (engine_core_smooth.c:1265-1329)
+// moment is kept sparse with a static per-actuator row capacity (actuator_momentadr)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_transmission(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  if (!s.nu) return;
+  const real* qpos = MJH_F(B, qpos, e);
+  real* length = MJH_F(B, actuator_length, e);
+  real* moment = MJH_F(B, actuator_moment, e);
+  int* rownnz = MJH_F(B, moment_rownnz, e);
+  int* colind = MJH_F(B, moment_colind, e);
+  MJH_FOR_LANES(i, s.nu) {
+    int id = M.actuator_trnid[2*i];
+    const real* gear = M.actuator_gear + 6*i;
+    int adr = M.actuator_momentadr[i];
+    // slide / hinge joint: scalar gear (other transmissions are rejected at model upload)
+    rownnz[i] = 1;
+    colind[adr] = M.jnt_dofadr[id];
+    length[i] = qpos[M.jnt_qposadr[id]]*gear[0];
+    moment[adr] = gear[0];
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_crb (+ mj_makeM)                            (engine_core_smooth.c:1890-1971)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_crb(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* cinert = MJH_F(B, cinert, e);
+  const real* cdof = MJH_F(B, cdof, e);
+  real* crb = MJH_F(B, crb, e);
+  real* Mq = MJH_F(B, M, e);
+
+  MJH_FOR_LANES(k, 10*s.nbody) crb[k] = cinert[k];
+  wv_sync();
+  tree_accumulate_to_parent(M, crb, 10, 0);
+
+  MJH_FOR_LANES(i, s.nv) {
+    int adr = M.M_rowadr[i];
+    if (M.dof_simplenum[i]) {
+      Mq[adr] = M.dof_M0[i];
+    } else {
+      int a = adr + M.M_rownnz[i] - 1;
+      real buf[6];
+      sp_mul_inert(buf, crb + 10*M.dof_bodyid[i], cdof + 6*i);
+      // diagonal starts from the (effective) armature, off-diagonals from zero
+      real init = M.dof_armature_eff[i];
+      for (int j = i; j >= 0; j = M.dof_parentid[j]) {
+        Mq[a--] = init + sp_dot6(cdof + 6*j, buf);
+        init = 0;
+      }
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse L'DL factorisation in place              (mj_factorI, engine_core_smooth.c:2005-2029)
+// rows nv-1 .. 0 in order; for one row k the updates of its ancestor rows are independent
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void factor_ld(const DModel& M, real* mat, real* diaginv) {
+  const int nv = M.s.nv;
+  for (int k = nv - 1; k >= 0; k--) {
+    int start = M.M_rowadr[k];
+    int diag = M.M_rownnz[k] - 1;
+    int end = start + diag;
+    real invD = 1 / mat[end];
+    // flattened (ancestor entry, element) work list: entry a (0..diag-1) updates row i=colind[start+a],
+    // elements 0..a  (row i of the CSR has exactly a+1 entries: ancestors of i, then i)
+    int total = diag*(diag + 1)/2;
+    MJH_FOR_LANES(w, total) {
+      // invert w = a*(a+1)/2 + el, 0 <= el <= a
+      int a = (int)((sqrt(8.0*w + 1.0) - 1.0)*0.5);
+      while (a*(a+1)/2 > w) a--;
+      while ((a+1)*(a+2)/2 <= w) a++;
+      int el = w - a*(a+1)/2;
+      int i = M.M_colind[start + a];
+      real scl = -mat[start + a] * invD;
+      mat[M.M_rowadr[i] + el] += mat[start + el] * scl;
+    }
+    wv_sync();
+    MJH_FOR_LANES(a, diag) mat[start + a] = mat[start + a] * invD;
+    if (wv_lane() == 0 && diaginv) diaginv[k] = invD;
+    wv_sync();
+  }
+}
+
+MJH_DEV void stage_factor_m(const DModel& M, const DBatch& B, int e) {
+  const real* Mq = MJH_F(B, M, e);
+  real* qLD = MJH_F(B, qLD, e);
+  MJH_FOR_LANES(k, M.s.nC) qLD[k] = Mq[k];
+  wv_sync();
+  factor_ld(M, qLD, MJH_F(B, qLDiagInv, e));
+}
+
+// ------------------------------------------------------------------------------------------------
+// x <- inv(L'DL) x, one vector                    (mj_solveLD, engine_core_smooth.c:2033-2109)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void solve_ld(const DModel& M, real* x, const real* qLD, const real* diaginv) {
+  const int nv = M.s.nv;
+  // x <- L^-T x : row i scatters into its ancestors (independent targets)
+  for (int i = nv - 1; i >= 0; i--) {
+    int nnz = M.M_rownnz[i];
+    if (nnz == 1) continue;
+    real xi = x[i];
+    if (xi != 0) {
+      int start = M.M_rowadr[i];
+      MJH_FOR_LANES(a, nnz - 1) x[M.M_colind[start + a]] -= qLD[start + a] * xi;
+    }
+    wv_sync();
+  }
+  // x <- D^-1 x
+  MJH_FOR_LANES(i, nv) x[i] *= diaginv[i];
+  wv_sync();
+  // x <- L^-1 x : row i gathers from its ancestors (mju_dotSparse association)
+  for (int i = 0; i < nv; i++) {
+    int nnz = M.M_rownnz[i];
+    if (nnz == 1) continue;
+    if (wv_lane() == 0) {
+      int adr = M.M_rowadr[i];
+      x[i] -= dot_sparse_ref(qLD + adr, x, nnz - 1, M.M_colind + adr);
+    }
+    wv_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_comVel                                      (engine_core_smooth.c:2179-2239)
+// ------------------------------------------------------------------------------------------------
+// res(6) = sum_r dof[r](6) * vec[r], r < n          (mju_mulDofVec, engine_util_spatial.c:466)
+MJH_DEV void mul_dof_vec(real* res, const real* dof, const real* vec, int n) {
+  if (n == 1) {
+    for (int k = 0; k < 6; k++) res[k] = dof[k]*vec[0];
+  } else {
+    for (int k = 0; k < 6; k++) res[k] = 0;
+    for (int r = 0; r < n; r++) {
+      real t = vec[r];
+      if (t != 0) for (int k = 0; k < 6; k++) res[k] += dof[6*r + k]*t;
+    }
+  }
+}
+
+MJH_DEV void stage_comvel(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* qvel = MJH_F(B, qvel, e);
+  const real* cdof = MJH_F(B, cdof, e);
+  real* cvel = MJH_F(B, cvel, e);
+  real* cdof_dot = MJH_F(B, cdof_dot, e);
+  if (wv_lane() == 0) for (int k = 0; k < 6; k++) cvel[k] = 0;
+  wv_sync();
+  for (int L = 1; L < s.nlevel; L++) {
+    int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
+    MJH_FOR_LANES(k, a1 - a0) {
+      int i = M.body_level_ids[a0 + k];
+      real v[6], tmp[6];
+      for (int q = 0; q < 6; q++) v[q] = cvel[6*M.body_parentid[i] + q];
+      int dofnum = M.body_dofnum[i], bda = M.body_dofadr[i];
+      for (int j = 0; j < dofnum; j++) {
+        int jt = M.dof_jnttype[bda + j];
+        if (jt == MJH_JNT_FREE) {
+          for (int q = 0; q < 18; q++) cdof_dot[6*bda + q] = 0;
+          mul_dof_vec(tmp, cdof + 6*bda, qvel + bda, 3);
+          for (int q = 0; q < 6; q++) v[q] += tmp[q];
+          j += 3;
+        }
+        if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+          for (int r = 0; r < 3; r++)
+            sp_cross_motion(cdof_dot + 6*(bda + j + r), v, cdof + 6*(bda + j + r));
+          mul_dof_vec(tmp, cdof + 6*(bda + j), qvel + bda + j, 3);
+          for (int q = 0; q < 6; q++) v[q] += tmp[q];
+          j += 2;
+        } else {
+          sp_cross_motion(cdof_dot + 6*(bda + j), v, cdof + 6*(bda + j));
+          mul_dof_vec(tmp, cdof + 6*(bda + j), qvel + bda + j, 1);
+          for (int q = 0; q < 6; q++) v[q] += tmp[q];
+        }
+      }
+      for (int q = 0; q < 6; q++) cvel[6*i + q] = v[q];
+    }
+    wv_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_passive: joint springs, dof dampers, tendon spring-dampers   (engine_passive.c:655-842,1047)
+// ------------------------------------------------------------------------------------------------
+// mju_polyForce, engine_util_misc.c:2314 (mjNPOLY = 2)
+MJH_DEV real poly_force(real linear, const real* poly, real x, int odd) {
+  x = odd ? fabs(x) : x;
+  real res = linear;
+  real xpow = 1;
+  for (int i = 0; i < 2; i++) {
+    xpow *= x;
+    res += poly[i] * xpow;
+  }
+  return res;
+}
+// mjd_xPolyForce, engine_util_misc.c:2329
+MJH_DEV real poly_force_deriv(real linear, const real* poly, real x, int odd) {
+  x = odd ? fabs(x) : x;
+  real res = linear;
+  real xpow = 1;
+  for (int i = 0; i < 2; i++) {
+    xpow *= x;
+    res += (i+2) * poly[i] * xpow;
+  }
+  return res;
+}
+
+MJH_DEV void stage_passive(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* qpos = MJH_F(B, qpos, e);
+  const real* qvel = MJH_F(B, qvel, e);
+  real* fs = MJH_F(B, qfrc_spring, e);
+  real* fd = MJH_F(B, qfrc_damper, e);
+  real* fp = MJH_F(B, qfrc_passive, e);
+  const int dsbl = M.o.disableflags;
+  const int enbl_spring = !(dsbl & (1<<5)), enbl_damper = !(dsbl & (1<<6));
+
+  MJH_FOR_LANES(i, s.nv) { fs[i] = 0; fd[i] = 0; fp[i] = 0; }
+  wv_sync();
+  if (!enbl_spring && !enbl_damper) return;
+
+  if (enbl_spring) {
+    MJH_FOR_LANES(j, s.njnt) {
+      real k0 = M.jnt_stiffness[j];
+      const real* sp = M.jnt_stiffnesspoly + 2*j;
+      if (k0 == 0 && sp[0] == 0 && sp[1] == 0) continue;
+      int padr = M.jnt_qposadr[j], dadr = M.jnt_dofadr[j];
+      int jt = M.jnt_type[j];
+      if (jt == MJH_JNT_FREE) {
+        real dif[3];
+        v3_sub(dif, qpos + padr, M.qpos_spring + padr);
+        real r = v3_norm(dif);
+        real k = poly_force(k0, sp, r, 0);
+        v3_addtoscl(fs + dadr, dif, -k);
+        dadr += 3; padr += 3;
+      }
+      if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+        real dif[3], quat[4];
+        q_copy(quat, qpos + padr);
+        q_normalize(quat);
+        q_sub(dif, quat, M.qpos_spring + padr);
+        real r = v3_norm(dif);
+        real k = poly_force(k0, sp, r, 0);
+        v3_addtoscl(fs + dadr, dif, -k);
+      } else {
+        real x = qpos[padr] - M.qpos_spring[padr];
+        fs[dadr] = -x * poly_force(k0, sp, x, 0);
+      }
+    }
+  }
+  if (enbl_damper) {
+    MJH_FOR_LANES(i, s.nv) {
+      real damping = M.dof_damping_eff[i];
+      const real* dp = M.dof_dampingpoly_eff + 2*i;
+      if (damping != 0 || dp[0] != 0 || dp[1] != 0) {
+        real v = qvel[i];
+        fd[i] = -v * poly_force(damping, dp, v, 1);
+      }
+    }
+  }
+  wv_sync();
+
+  // tendon spring-dampers accumulate into shared dofs: keep the reference's tendon order
+  if (s.ntendon && wv_lane() == 0) {
+    const real* tl = MJH_F(B, ten_length, e);
+    const real* tv = MJH_F(B, ten_velocity, e);
+    const real* tJ = MJH_F(B, ten_J, e);
+    for (int i = 0; i < s.ntendon; i++) {
+      real stiffness = enbl_spring ? M.tendon_stiffness[i] : 0;
+      const real* sp = M.tendon_stiffnesspoly + 2*i;
+      real damping = enbl_damper ? M.tendon_damping_eff[i] : 0;
+      real dp[2] = {0, 0};
+      if (enbl_damper) { dp[0] = M.tendon_dampingpoly_eff[2*i]; dp[1] = M.tendon_dampingpoly_eff[2*i+1]; }
+      if (stiffness == 0 && (!enbl_spring || (sp[0] == 0 && sp[1] == 0)) &&
+          damping == 0 && dp[0] == 0 && dp[1] == 0) continue;
+      real length = tl[i];
+      real lower = M.tendon_lengthspring[2*i], upper = M.tendon_lengthspring[2*i+1];
+      real x = (length > upper) ? length - upper : (length < lower) ? length - lower : 0;
+      real frc_spring = enbl_spring ? -x * poly_force(stiffness, sp, x, 0) : 0;
+      real v = tv[i];
+      real frc_damper = enbl_damper ? -v * poly_force(damping, dp, v, 1) : 0;
+      if (frc_spring != 0 || frc_damper != 0) {
+        int a0 = M.ten_J_rowadr[i], a1 = a0 + M.ten_J_rownnz[i];
+        for (int j = a0; j < a1; j++) {
+          int k = M.ten_J_colind[j];
+          fs[k] += tJ[j] * frc_spring;
+          fd[k] += tJ[j] * frc_damper;
+        }
+      }
+    }
+  }
+  wv_sync();
+  MJH_FOR_LANES(i, s.nv) fp[i] = fs[i] + fd[i];
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_rne(flg_acc=0) -> qfrc_bias                  (engine_core_smooth.c:2328-2389)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_rne(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* qvel = MJH_F(B, qvel, e);
+  const real* cdof = MJH_F(B, cdof, e);
+  const real* cdof_dot = MJH_F(B, cdof_dot, e);
+  const real* cvel = MJH_F(B, cvel, e);
+  const real* cinert = MJH_F(B, cinert, e);
+  real* cacc = MJH_F(B, cacc, e);
+  real* cfrc = MJH_F(B, cfrc, e);
+  real* bias = MJH_F(B, qfrc_bias, e);
+
+  if (wv_lane() == 0) {
+    for (int k = 0; k < 6; k++) cacc[k] = 0;
+    if (!(M.o.disableflags & (1<<7))) {
+      cacc[3] = M.o.gravity[0]*-1; cacc[4] = M.o.gravity[1]*-1; cacc[5] = M.o.gravity[2]*-1;
+    }
+  }
+  wv_sync();
+  for (int L = 1; L < s.nlevel; L++) {
+    int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
+    MJH_FOR_LANES(k, a1 - a0) {
+      int i = M.body_level_ids[a0 + k];
+      int bda = M.body_dofadr[i];
+      real tmp[6], tmp1[6];
+      mul_dof_vec(tmp, cdof_dot + 6*bda, qvel + bda, M.body_dofnum[i]);
+      for (int q = 0; q < 6; q++) cacc[6*i + q] = cacc[6*M.body_parentid[i] + q] + tmp[q];
+      real f[6];
+      sp_mul_inert(f, cinert + 10*i, cacc + 6*i);
+      sp_mul_inert(tmp, cinert + 10*i, cvel + 6*i);
+      sp_cross_force(tmp1, cvel + 6*i, tmp);
+      for (int q = 0; q < 6; q++) cfrc[6*i + q] = f[q] + tmp1[q];
+    }
+    wv_sync();
+  }
+  if (wv_lane() == 0) for (int k = 0; k < 6; k++) cfrc[k] = 0;
+  wv_sync();
+  tree_accumulate_to_parent(M, cfrc, 6, 0);
+  MJH_FOR_LANES(i, s.nv) bias[i] = sp_dot6(cdof + 6*i, cfrc + 6*M.dof_bodyid[i]);
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// tendon / actuator velocities                    (mj_fwdVelocity head, engine_forward.c:197-208)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* qvel = MJH_F(B, qvel, e);
+  if (s.ntendon) {
+    const real* tJ = MJH_F(B, ten_J, e);
+    real* tv = MJH_F(B, ten_velocity, e);
+    MJH_FOR_LANES(i, s.ntendon) {
+      int adr = M.ten_J_rowadr[i];
+      tv[i] = dot_sparse_ref(tJ + adr, qvel, M.ten_J_rownnz[i], M.ten_J_colind + adr);
+    }
+  }
+  if (s.nu) {
+    const real* mom = MJH_F(B, actuator_moment, e);
+    const int* rownnz = MJH_F(B, moment_rownnz, e);
+    const int* colind = MJH_F(B, moment_colind, e);
+    real* av = MJH_F(B, actuator_velocity, e);
+    const int dsbl_act = M.o.disableflags & (1<<11);
+    MJH_FOR_LANES(i, s.nu) {
+      int adr = M.actuator_momentadr[i];
+      av[i] = dsbl_act ? 0 : dot_sparse_ref(mom + adr, qvel, rownnz[i], colind + adr);
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_fwdActuation: stateless actuators (dyntype none), fixed/affine gain, none/affine bias
+//                                                 (engine_forward.c:353-1003)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_actuation(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  real* force = MJH_F(B, actuator_force, e);
+  real* qfa = MJH_F(B, qfrc_actuator, e);
+  const int dsbl = M.o.disableflags;
+  if (s.nu == 0 || (dsbl & (1<<11))) {
+    MJH_FOR_LANES(i, s.nu) force[i] = 0;
+    MJH_FOR_LANES(i, s.nv) qfa[i] = 0;
+    wv_sync();
+    return;
+  }
+  const real* ctrl_in = MJH_F(B, ctrl, e);
+  const real* len = MJH_F(B, actuator_length, e);
+  const real* vel = MJH_F(B, actuator_velocity, e);
+  int* warn = MJH_F(B, warning, e);
+
+  // any bad control (after clamping) zeroes ALL controls
+  int bad = 0;
+  MJH_FOR_LANES(i, s.nu) {
+    real c = ctrl_in[i];
+    if (!(dsbl & (1<<8)) && M.actuator_ctrllimited[i])
+      c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
+    if (r_isbad(c)) bad = 1;
+  }
+  bad = wv_any(bad);
+  if (bad && wv_lane() == 0) warn[MJH_WARN_BADCTRL]++;
+
+  MJH_FOR_LANES(i, s.nu) {
+    real c = ctrl_in[i];
+    if (!(dsbl & (1<<8)) && M.actuator_ctrllimited[i])
+      c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
+    if (bad) c = 0;
+    const real* gp = M.actuator_gainprm + 10*i;
+    const real* bp = M.actuator_biasprm + 10*i;
+    real gain;
+    if (M.actuator_gaintype[i] == MJH_GAIN_FIXED) gain = gp[0];
+    else gain = gp[0] + gp[1]*len[i] + gp[2]*vel[i];
+    real f = gain * c;
+    real bias = 0.0;
+    if (M.actuator_biastype[i] == MJH_BIAS_AFFINE) bias = bp[0] + bp[1]*len[i] + bp[2]*vel[i];
+    f += bias;
+    if (M.actuator_forcelimited[i])
+      f = r_clip(f, M.actuator_forcerange[2*i], M.actuator_forcerange[2*i+1]);
+    force[i] = f;
+  }
+  wv_sync();
+
+  // qfrc_actuator = moment' * force, rows added in actuator order (mju_mulMatTVecSparse)
+  const real* mom = MJH_F(B, actuator_moment, e);
+  const int* rownnz = MJH_F(B, moment_rownnz, e);
+  const int* colind = MJH_F(B, moment_colind, e);
+  MJH_FOR_LANES(j, s.nv) {
+    real r = 0;
+    for (int i = 0; i < s.nu; i++) {
+      real scl = force[i];
+      if (scl == 0) continue;
+      int adr = M.actuator_momentadr[i];
+      for (int k = 0; k < rownnz[i]; k++) if (colind[adr + k] == j) r += mom[adr + k]*scl;
+    }
+    qfa[j] = r;
+  }
+  wv_sync();
+  // joint-level actuator force limits (clampVec with jnt_dofadr index)
+  MJH_FOR_LANES(j, s.njnt) {
+    if (M.jnt_actfrclimited[j]) {
+      int d = M.jnt_dofadr[j];
+      qfa[d] = r_clip(qfa[d], M.jnt_actfrcrange[2*j], M.jnt_actfrcrange[2*j+1]);
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_fwdAcceleration                              (engine_forward.c:1007-1052)
+// (xfrc_applied is handled by the host API: non-zero Cartesian forces are rejected for now)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_acceleration(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const real* fp = MJH_F(B, qfrc_passive, e);
+  const real* fb = MJH_F(B, qfrc_bias, e);
+  const real* fa = MJH_F(B, qfrc_applied, e);
+  const real* fu = MJH_F(B, qfrc_actuator, e);
+  real* fsm = MJH_F(B, qfrc_smooth, e);
+  real* qas = MJH_F(B, qacc_smooth, e);
+  MJH_FOR_LANES(i, s.nv) {
+    real f = fp[i] - fb[i];
+    f += fa[i];
+    f += fu[i];
+    fsm[i] = f;
+    qas[i] = f;
+  }
+  wv_sync();
+  solve_ld(M, qas, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
+}

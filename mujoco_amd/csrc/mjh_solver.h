@@ -1,0 +1,235 @@
+// Constraint solve stage: mj_fwdConstraint with the PGS (dual) solver, one wavefront per env.
+//
+// The PGS sweep is inherently sequential over constraint rows (Gauss-Seidel); what the wavefront
+// parallelises is each row's residual b_i + AR_i . f.  The reference sums that dot product with
+// four interleaved partial sums (mju_dot, engine_util_blas.c:493-527); lanes 0..3 each carry one of
+// them and the wave combines them with three adds, so the sweep reproduces the CPU result bit for
+// bit -- including the iteration at which `improvement < tolerance` fires -- while the residual
+// costs ceil(nefc/4) dependent multiply-adds instead of nefc.
+#pragma once
+
+#include "mjh_types.h"
+#include "mjh_smooth.h"
+#include "mjh_constraint.h"
+
+// wave-cooperative dot product in mju_dot's association; result is wave-uniform.
+// a and b may be written by other lanes before the call (caller syncs).
+MJH_DEV real wave_dot_ref(const real* a, const real* b, int n) {
+  const int lane = wv_lane();
+  const int n4 = n & ~3;
+  real r = 0;
+  if (lane < 4) {
+    for (int i = lane; i < n4; i += 4) r += a[i]*b[i];
+  }
+  real r0 = wv_bcast(r, 0), r1 = wv_bcast(r, 1), r2 = wv_bcast(r, 2), r3 = wv_bcast(r, 3);
+  real res = (r0 + r2) + (r1 + r3);
+  int rem = n - n4;
+  if (rem == 3) res += a[n4]*b[n4] + a[n4+1]*b[n4+1] + a[n4+2]*b[n4+2];
+  else if (rem == 2) res += a[n4]*b[n4] + a[n4+1]*b[n4+1];
+  else if (rem == 1) res += a[n4]*b[n4];
+  return res;
+}
+
+// PCG32, engine_solver.c:241-254
+struct Pcg32 { uint64_t state, inc; };
+MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
+  uint64_t old = rng->state;
+  rng->state = old * 6364136223846793005ULL + (rng->inc | 1);
+  uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+  uint32_t rot = (uint32_t)(old >> 59u);
+  return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
+}
+
+// ------------------------------------------------------------------------------------------------
+// solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void solve_pgs(const DModel& M, const DBatch& B, int e) {
+  int* counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
+  const real* AR = MJH_F(B, efc_AR, e);
+  const real* b = MJH_F(B, efc_b, e);
+  const real* floss = MJH_F(B, efc_frictionloss, e);
+  real* force = MJH_F(B, efc_force, e);
+  real* scratch = MJH_F(B, scratch, e);
+  const int nmax = M.s.nefcmax;
+  real* ARinv = scratch;                 // [nefc]
+  real* force_prev = scratch + nmax;     // [nefc]
+  real* force_mom = scratch + 2*nmax;    // [nefc]
+  int* order = MJH_F(B, iscratch, e);    // [nefc] block visitation order (persists across iterations)
+  const int lane = wv_lane();
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+
+  MJH_FOR_LANES(i, nefc) {
+    ARinv[i] = 1 / AR[(size_t)i*nefc + i];
+    force_prev[i] = force[i];
+    order[i] = i;
+  }
+  wv_sync();
+
+  Pcg32 rng;
+  rng.state = 0; rng.inc = 1;
+  pcg32_next(&rng);
+
+  int iter = 0, nesterov_k = 0;
+  while (iter < maxiter) {
+    // ---- Nesterov extrapolation (:508-554)
+    real beta = 0;
+    if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+    if (beta > 0) {
+      MJH_FOR_LANES(i, nefc) {
+        real f_save = force[i];
+        real f = f_save + beta*(f_save - force_prev[i]);
+        force_prev[i] = f_save;
+        if (i >= ne && i < ne + nf) f = r_clip(f, -floss[i], floss[i]);
+        else if (i >= ne + nf && f < 0) f = 0;
+        force[i] = f;
+        force_mom[i] = f;
+      }
+    } else {
+      MJH_FOR_LANES(i, nefc) {
+        real f = force[i];
+        force_prev[i] = f;
+        force_mom[i] = f;
+      }
+    }
+    // ---- shuffle block order (Fisher-Yates with the shared PCG32 stream, :256-265)
+    // every lane advances its own copy of the generator identically; lane 0 owns the array
+    for (int i = nefc - 1; i > 0; i--) {
+      uint32_t j = pcg32_next(&rng) % (uint32_t)(i + 1);
+      if (lane == 0) {
+        int t = order[i]; order[i] = order[j]; order[j] = t;
+      }
+    }
+    wv_sync();
+
+    // ---- one sweep
+    real improvement = 0;
+    for (int bi = 0; bi < nefc; bi++) {
+      const int i = order[bi];
+      real res = b[i] + wave_dot_ref(AR + (size_t)i*nefc, force, nefc);
+      real oldf = force[i];
+      real f = oldf - res*ARinv[i];
+      if (i >= ne && i < ne + nf) {
+        if (f < -floss[i]) f = -floss[i];
+        else if (f > floss[i]) f = floss[i];
+      } else if (i >= ne + nf) {
+        if (f < 0) f = 0;
+      }
+      // costChange (:216-237) with A = 1/ARinv
+      real A = 1/ARinv[i];
+      real delta = f - oldf;
+      real change = 0.5*delta*delta*A + delta*res;
+      if (change > 1e-10) { f = oldf; change = 0; }
+      improvement -= change;
+      wv_sync();                  // all lanes have consumed force[] for this row
+      if (lane == 0) force[i] = f;
+      wv_sync();
+    }
+    improvement *= scale;
+
+    // ---- gradient restart (:694-713)
+    int restart = 0;
+    if (iter > 0) {
+      real dotce = 0;
+      for (int i = 0; i < nefc; i++) {
+        real correction = force[i] - force_mom[i];
+        real extrapolation = force_mom[i] - force_prev[i];
+        dotce += correction * extrapolation;
+      }
+      restart = (dotce < 0);
+    }
+    if (restart) nesterov_k = 0; else nesterov_k++;
+    iter++;
+    if (improvement < M.o.tolerance) break;
+    wv_sync();
+  }
+  wv_sync();
+
+  // final dual state (dualState, :270-345) and iteration count
+  int* state = MJH_F(B, efc_state, e);
+  MJH_FOR_LANES(i, nefc) {
+    int st;
+    if (i < ne) st = MJH_STATE_QUADRATIC;
+    else if (i < ne + nf) {
+      if (force[i] <= -floss[i]) st = MJH_STATE_LINEARPOS;
+      else if (force[i] >= floss[i]) st = MJH_STATE_LINEARNEG;
+      else st = MJH_STATE_QUADRATIC;
+    } else st = (force[i] <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+    state[i] = st;
+  }
+  if (lane == 0) counts[MJH_C_NITER] = iter;
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
+  const DSizes& s = M.s;
+  const int nv = s.nv;
+  int* counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC];
+  real* qfc = MJH_F(B, qfrc_constraint, e);
+  real* qacc = MJH_F(B, qacc, e);
+  const real* qas = MJH_F(B, qacc_smooth, e);
+
+  if (!nefc) {
+    MJH_FOR_LANES(i, nv) { qfc[i] = 0; qacc[i] = qas[i]; }
+    if (wv_lane() == 0) counts[MJH_C_NITER] = 0;
+    wv_sync();
+    return;
+  }
+  const real* J = MJH_F(B, efc_J, e);
+  const real* aref = MJH_F(B, efc_aref, e);
+  const real* AR = MJH_F(B, efc_AR, e);
+  real* eb = MJH_F(B, efc_b, e);
+  real* force = MJH_F(B, efc_force, e);
+  real* scratch = MJH_F(B, scratch, e);
+  real* jar = scratch + 3*s.nefcmax;     // [nefc]
+  real* ARf = scratch + 4*s.nefcmax;     // [nefc]
+  const real* qws = MJH_F(B, qacc_warmstart, e);
+
+  // efc_b = J*qacc_smooth - aref ; jar = J*qacc_warmstart - aref
+  MJH_FOR_LANES(r, nefc) {
+    const real* Jr = J + (size_t)r*nv;
+    real t = dot_ref(Jr, qas, nv);
+    eb[r] = t - aref[r];
+    real u = dot_ref(Jr, qws, nv);
+    jar[r] = u - aref[r];
+  }
+  wv_sync();
+
+  if (!(M.o.disableflags & (1<<9))) {
+    constraint_update(B, e, jar, 0);        // efc_force(qacc_warmstart), syncs internally
+    // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
+    MJH_FOR_LANES(r, nefc) ARf[r] = dot_ref(AR + (size_t)r*nefc, force, nefc);
+    wv_sync();
+    real pgs_ws = wave_dot_ref(force, eb, nefc);
+    pgs_ws += 0.5*wave_dot_ref(force, ARf, nefc);
+    wv_sync();
+    if (pgs_ws > 0) {
+      MJH_FOR_LANES(r, nefc) force[r] = 0;
+    }
+  } else {
+    MJH_FOR_LANES(r, nefc) force[r] = 0;
+  }
+  wv_sync();
+
+  solve_pgs(M, B, e);
+
+  // mj_dualFinish (engine_solver.c:72-85): qfrc_constraint = J' f ; qacc = M \ qfrc_constraint + qacc_smooth
+  MJH_FOR_LANES(j, nv) {
+    real acc = 0;
+    for (int r = 0; r < nefc; r++) {
+      real f = force[r];
+      if (f != 0) acc += J[(size_t)r*nv + j]*f;
+    }
+    qfc[j] = acc;
+    qacc[j] = acc;
+  }
+  wv_sync();
+  solve_ld(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
+  MJH_FOR_LANES(j, nv) qacc[j] += qas[j];
+  wv_sync();
+}

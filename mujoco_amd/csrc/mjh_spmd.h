@@ -1,0 +1,165 @@
+// SPMD layer for the mjhip kernels: one 64-lane wavefront per environment.
+//
+// All physics kernels are written once, in HIP device style (lane = threadIdx.x, block = one
+// wavefront = one environment, __syncthreads() between phases, wave-level reductions through
+// the helpers below).  Two builds exist:
+//
+//   * hipcc --offload-arch=gfx950   : the product.  Lanes are the 64 lanes of a CDNA4 wavefront,
+//                                     wv_sync() is s_barrier + waitcnt, reductions use DPP/shuffles.
+//   * g++ -DMJH_HOSTSIM (tests only): a deterministic fiber emulation of one wavefront (64 ucontext
+//                                     fibers, switched at every wv_sync()).  It exists so kernel
+//                                     logic can be parity-checked against the oracle in a container
+//                                     with no GPU; it is compiled only by tests/hostsim and is
+//                                     never loaded by the product library.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#define MJH_WAVE 64
+
+#ifdef MJH_HOSTSIM
+// ------------------------------------------------------------------------------------------------
+// host emulation of a wavefront (tests only)
+// ------------------------------------------------------------------------------------------------
+#include <ucontext.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MJH_DEV static inline
+#define MJH_GLOBAL static void
+#define MJH_SHARED static
+
+namespace mjhsim {
+struct WaveSim {
+  ucontext_t sched;
+  ucontext_t ctx[MJH_WAVE];
+  char* stacks;
+  int cur;            // lane currently running
+  int done[MJH_WAVE];
+  int env;            // blockIdx.x
+  int reverse;        // run lanes 63..0 instead of 0..63 (race detector)
+  // scratch for cross-lane primitives
+  double dscratch[MJH_WAVE];
+  long long iscratch[MJH_WAVE];
+};
+extern thread_local WaveSim* g_wave;
+static inline int lane() { return g_wave->cur; }
+static inline int env() { return g_wave->env; }
+static inline void yield() { swapcontext(&g_wave->ctx[g_wave->cur], &g_wave->sched); }
+}  // namespace mjhsim
+
+MJH_DEV int wv_lane() { return mjhsim::lane(); }
+MJH_DEV int wv_env() { return mjhsim::env(); }
+MJH_DEV void wv_sync() { mjhsim::yield(); }
+
+// broadcast v from lane src to all lanes (src must be wave-uniform)
+MJH_DEV double wv_bcast(double v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[src];
+  mjhsim::yield();
+  return r;
+}
+MJH_DEV int wv_bcast_i(int v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  int r = (int)w->iscratch[src];
+  mjhsim::yield();
+  return r;
+}
+// 64-bit mask of lanes with pred != 0
+MJH_DEV uint64_t wv_ballot(int pred) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = pred ? 1 : 0;
+  mjhsim::yield();
+  uint64_t m = 0;
+  for (int l = 0; l < MJH_WAVE; l++) if (w->iscratch[l]) m |= (1ull << l);
+  mjhsim::yield();
+  return m;
+}
+// integer sum over all lanes
+MJH_DEV int wv_sum_i(int v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  long long s = 0;
+  for (int l = 0; l < MJH_WAVE; l++) s += w->iscratch[l];
+  mjhsim::yield();
+  return (int)s;
+}
+// exclusive prefix sum over lanes
+MJH_DEV int wv_exscan_i(int v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  long long s = 0;
+  for (int l = 0; l < w->cur; l++) s += w->iscratch[l];
+  mjhsim::yield();
+  return (int)s;
+}
+// value held by lane (lane ^ mask)
+MJH_DEV double wv_shfl_xor(double v, int mask) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[w->cur ^ mask];
+  mjhsim::yield();
+  return r;
+}
+// value held by lane src (src may differ per lane)
+MJH_DEV double wv_shfl(double v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[src & (MJH_WAVE - 1)];
+  mjhsim::yield();
+  return r;
+}
+MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
+
+#else
+// ------------------------------------------------------------------------------------------------
+// CDNA4 device build
+// ------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+
+#define MJH_DEV __device__ __forceinline__
+#define MJH_GLOBAL __global__ void
+#define MJH_SHARED __shared__
+
+MJH_DEV int wv_lane() { return (int)threadIdx.x; }
+MJH_DEV int wv_env() { return (int)blockIdx.x; }
+// block == one wavefront: s_barrier is (nearly) free, the waitcnt/fence part is what we need
+MJH_DEV void wv_sync() { __syncthreads(); }
+
+MJH_DEV double wv_bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+MJH_DEV int wv_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+MJH_DEV uint64_t wv_ballot(int pred) { return __ballot(pred); }
+MJH_DEV int wv_sum_i(int v) {
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+MJH_DEV int wv_exscan_i(int v) {
+  int x = v;
+  int lane = (int)threadIdx.x;
+  for (int d = 1; d < 64; d <<= 1) {
+    int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  return x - v;
+}
+MJH_DEV double wv_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+MJH_DEV double wv_shfl(double v, int src) { return __shfl(v, src, 64); }
+MJH_DEV int wv_any(int pred) { return __any(pred); }
+
+#endif  // MJH_HOSTSIM
+
+// lane loop: for (i = lane; i < n; i += 64)
+#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_WAVE)

@@ -1,0 +1,302 @@
+// Device-side data model of the mjhip batched stepper.
+//
+//   DModel : read-only model constants, replicated per GPU, shared by every environment.  Built
+//            once from an mjModel by mjh_host.cpp (direct copies of mjModel arrays + tables that
+//            are precomputed from it: tree levels, dof-ancestor masks, the static candidate
+//            geom-pair list in reference contact order with mixed contact parameters, effective
+//            damping/armature).
+//   DBatch : per-environment mjData mirror, laid out SoA-across-envs: every mjData field f is ONE
+//            device array [nenv][n_f] (environment-major, element innermost) so that the 64
+//            lanes of the wavefront that owns environment e read contiguous memory, and so a
+//            whole field (e.g. qpos of all envs) is one dense matrix for the caller.
+//
+// Field lists are X-macros: the host uploader, the device structs and the test accessors are all
+// generated from them.
+#pragma once
+
+#include "mjh_math.h"
+
+// ---- model: int arrays ------------------------------------------------------------------------
+// X(name, count-expression in terms of the size fields of DModel (s.))
+#define MJH_MODEL_INT_FIELDS(X)                \
+  X(body_parentid, s.nbody)                    \
+  X(body_rootid, s.nbody)                      \
+  X(body_weldid, s.nbody)                      \
+  X(body_mocapid, s.nbody)                     \
+  X(body_jntnum, s.nbody)                      \
+  X(body_jntadr, s.nbody)                      \
+  X(body_dofnum, s.nbody)                      \
+  X(body_dofadr, s.nbody)                      \
+  X(body_sameframe, s.nbody)                   \
+  X(body_level_adr, s.nlevel + 1)              \
+  X(body_level_ids, s.nbody)                   \
+  X(body_child_adr, s.nbody + 1)               \
+  X(body_child_ids, s.nbody)                   \
+  X(body_geomnum, s.nbody)                     \
+  X(body_geomadr, s.nbody)                     \
+  X(body_dofanc, s.nbody * s.nvw)              \
+  X(jnt_type, s.njnt)                          \
+  X(jnt_qposadr, s.njnt)                       \
+  X(jnt_dofadr, s.njnt)                        \
+  X(jnt_bodyid, s.njnt)                        \
+  X(jnt_limited, s.njnt)                       \
+  X(dof_bodyid, s.nv)                          \
+  X(dof_jntid, s.nv)                           \
+  X(dof_parentid, s.nv)                        \
+  X(dof_simplenum, s.nv)                       \
+  X(dof_jnttype, s.nv)                         \
+  X(M_rownnz, s.nv)                            \
+  X(M_rowadr, s.nv)                            \
+  X(M_colind, s.nC)                            \
+  X(geom_type, s.ngeom)                        \
+  X(geom_bodyid, s.ngeom)                      \
+  X(geom_sameframe, s.ngeom)                   \
+  X(site_bodyid, s.nsite)                      \
+  X(site_sameframe, s.nsite)                   \
+  X(tendon_adr, s.ntendon)                     \
+  X(tendon_num, s.ntendon)                     \
+  X(tendon_limited, s.ntendon)                 \
+  X(ten_J_rownnz, s.ntendon)                   \
+  X(ten_J_rowadr, s.ntendon)                   \
+  X(ten_J_colind, s.nJten)                     \
+  X(wrap_type, s.nwrap)                        \
+  X(wrap_objid, s.nwrap)                       \
+  X(actuator_trntype, s.nu)                    \
+  X(actuator_trnid, 2 * s.nu)                  \
+  X(actuator_gaintype, s.nu)                   \
+  X(actuator_biastype, s.nu)                   \
+  X(actuator_ctrllimited, s.nu)                \
+  X(actuator_forcelimited, s.nu)               \
+  X(actuator_momentadr, s.nu + 1)              \
+  X(jnt_actfrclimited, s.njnt)                 \
+  X(pair_geom1, s.npair)                       \
+  X(pair_geom2, s.npair)                       \
+  X(pair_dim, s.npair)                         \
+  X(pair_maxcon, s.npair)                      \
+  X(pair_func, s.npair)
+
+// ---- model: real arrays -----------------------------------------------------------------------
+#define MJH_MODEL_REAL_FIELDS(X)               \
+  X(qpos0, s.nq)                               \
+  X(qpos_spring, s.nq)                         \
+  X(body_pos, 3 * s.nbody)                     \
+  X(body_quat, 4 * s.nbody)                    \
+  X(body_ipos, 3 * s.nbody)                    \
+  X(body_iquat, 4 * s.nbody)                   \
+  X(body_mass, s.nbody)                        \
+  X(body_subtreemass, s.nbody)                 \
+  X(body_inertia, 3 * s.nbody)                 \
+  X(body_invweight0, 2 * s.nbody)              \
+  X(jnt_pos, 3 * s.njnt)                       \
+  X(jnt_axis, 3 * s.njnt)                      \
+  X(jnt_stiffness, s.njnt)                     \
+  X(jnt_stiffnesspoly, 2 * s.njnt)             \
+  X(jnt_range, 2 * s.njnt)                     \
+  X(jnt_margin, s.njnt)                        \
+  X(jnt_solref, 2 * s.njnt)                    \
+  X(jnt_solimp, 5 * s.njnt)                    \
+  X(jnt_actfrcrange, 2 * s.njnt)               \
+  X(dof_armature_eff, s.nv)                    \
+  X(dof_damping_eff, s.nv)                     \
+  X(dof_dampingpoly_eff, 2 * s.nv)             \
+  X(dof_invweight0, s.nv)                      \
+  X(dof_M0, s.nv)                              \
+  X(dof_frictionloss, s.nv)                    \
+  X(dof_solref, 2 * s.nv)                      \
+  X(dof_solimp, 5 * s.nv)                      \
+  X(geom_pos, 3 * s.ngeom)                     \
+  X(geom_quat, 4 * s.ngeom)                    \
+  X(geom_size, 3 * s.ngeom)                    \
+  X(geom_rbound, s.ngeom)                      \
+  X(site_pos, 3 * s.nsite)                     \
+  X(site_quat, 4 * s.nsite)                    \
+  X(tendon_range, 2 * s.ntendon)               \
+  X(tendon_margin, s.ntendon)                  \
+  X(tendon_solref_lim, 2 * s.ntendon)          \
+  X(tendon_solimp_lim, 5 * s.ntendon)          \
+  X(tendon_invweight0, s.ntendon)              \
+  X(tendon_stiffness, s.ntendon)               \
+  X(tendon_stiffnesspoly, 2 * s.ntendon)       \
+  X(tendon_damping_eff, s.ntendon)             \
+  X(tendon_dampingpoly_eff, 2 * s.ntendon)     \
+  X(tendon_armature_eff, s.ntendon)            \
+  X(tendon_lengthspring, 2 * s.ntendon)        \
+  X(tendon_frictionloss, s.ntendon)            \
+  X(wrap_prm, s.nwrap)                         \
+  X(actuator_gear, 6 * s.nu)                   \
+  X(actuator_ctrlrange, 2 * s.nu)              \
+  X(actuator_forcerange, 2 * s.nu)             \
+  X(actuator_gainprm, 10 * s.nu)               \
+  X(actuator_biasprm, 10 * s.nu)               \
+  X(actuator_cranklength, s.nu)                \
+  X(pair_margin, s.npair)                      \
+  X(pair_includemargin, s.npair)               \
+  X(pair_friction, 5 * s.npair)                \
+  X(pair_solref, 2 * s.npair)                  \
+  X(pair_solreffriction, 2 * s.npair)          \
+  X(pair_solimp, 5 * s.npair)
+
+struct DSizes {
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int nlevel;      // depth levels of the kinematic tree (world = level 0)
+  int nvw;         // 32-bit words per dof-ancestor mask = (nv+31)/32
+  int npair;       // static candidate geom pairs (reference contact order)
+  int nmoment;     // capacity of the sparse actuator_moment (sum of per-actuator row capacity)
+  int nconmax;     // per-env contact capacity
+  int nefcmax;     // per-env constraint-row capacity
+  int nstate;      // mj_stateSize(FULLPHYSICS)
+};
+
+struct DOptions {
+  real timestep, impratio, tolerance;
+  real gravity[3];
+  real meaninertia;
+  int integrator, cone, solver, iterations;
+  int disableflags, enableflags;
+  int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
+  int has_ten_armature;
+};
+
+struct DModel {
+  DSizes s;
+  DOptions o;
+#define X(name, cnt) const int* name;
+  MJH_MODEL_INT_FIELDS(X)
+#undef X
+#define X(name, cnt) const real* name;
+  MJH_MODEL_REAL_FIELDS(X)
+#undef X
+};
+
+// ---- batch: per-environment arrays -------------------------------------------------------------
+// X(name, per-env count)
+#define MJH_BATCH_REAL_FIELDS(X)               \
+  X(time, 1)                                   \
+  X(qpos, s.nq)                                \
+  X(qvel, s.nv)                                \
+  X(act, s.na)                                 \
+  X(ctrl, s.nu)                                \
+  X(qfrc_applied, s.nv)                        \
+  X(xfrc_applied, 6 * s.nbody)                 \
+  X(qacc_warmstart, s.nv)                      \
+  X(xpos, 3 * s.nbody)                         \
+  X(xquat, 4 * s.nbody)                        \
+  X(xmat, 9 * s.nbody)                         \
+  X(xipos, 3 * s.nbody)                        \
+  X(ximat, 9 * s.nbody)                        \
+  X(xanchor, 3 * s.njnt)                       \
+  X(xaxis, 3 * s.njnt)                         \
+  X(geom_xpos, 3 * s.ngeom)                    \
+  X(geom_xmat, 9 * s.ngeom)                    \
+  X(site_xpos, 3 * s.nsite)                    \
+  X(site_xmat, 9 * s.nsite)                    \
+  X(subtree_com, 3 * s.nbody)                  \
+  X(cinert, 10 * s.nbody)                      \
+  X(cdof, 6 * s.nv)                            \
+  X(ten_length, s.ntendon)                     \
+  X(ten_J, s.nJten)                            \
+  X(ten_velocity, s.ntendon)                   \
+  X(actuator_length, s.nu)                     \
+  X(actuator_moment, s.nmoment)                \
+  X(actuator_velocity, s.nu)                   \
+  X(actuator_force, s.nu)                      \
+  X(crb, 10 * s.nbody)                         \
+  X(M, s.nC)                                   \
+  X(qLD, s.nC)                                 \
+  X(qLDiagInv, s.nv)                           \
+  X(qH, s.nC)                                  \
+  X(qHDiagInv, s.nv)                           \
+  X(cvel, 6 * s.nbody)                         \
+  X(cdof_dot, 6 * s.nv)                        \
+  X(cacc, 6 * s.nbody)                         \
+  X(cfrc, 6 * s.nbody)                         \
+  X(qfrc_spring, s.nv)                         \
+  X(qfrc_damper, s.nv)                         \
+  X(qfrc_passive, s.nv)                        \
+  X(qfrc_bias, s.nv)                           \
+  X(qfrc_actuator, s.nv)                       \
+  X(qfrc_smooth, s.nv)                         \
+  X(qacc_smooth, s.nv)                         \
+  X(qfrc_constraint, s.nv)                     \
+  X(qacc, s.nv)                                \
+  X(con_dist, s.nconmax)                       \
+  X(con_pos, 3 * s.nconmax)                    \
+  X(con_frame, 9 * s.nconmax)                  \
+  X(con_mu, s.nconmax)                         \
+  X(efc_J, s.nefcmax * s.nv)                   \
+  X(efc_Y, s.nefcmax * s.nv)                   \
+  X(efc_AR, s.nefcmax * s.nefcmax)             \
+  X(efc_pos, s.nefcmax)                        \
+  X(efc_margin, s.nefcmax)                     \
+  X(efc_frictionloss, s.nefcmax)               \
+  X(efc_diagA, s.nefcmax)                      \
+  X(efc_KBIP, 4 * s.nefcmax)                   \
+  X(efc_D, s.nefcmax)                          \
+  X(efc_R, s.nefcmax)                          \
+  X(efc_vel, s.nefcmax)                        \
+  X(efc_aref, s.nefcmax)                       \
+  X(efc_b, s.nefcmax)                          \
+  X(efc_force, s.nefcmax)                      \
+  X(scratch, 8 * s.nefcmax + 8 * s.nv + 64)
+
+#define MJH_BATCH_INT_FIELDS(X)                \
+  X(counts, 8)        /* ncon, nefc, ne, nf, nl, solver_niter, nisland, - */ \
+  X(warning, 8)       /* per mjtWarning counter (include/mujoco/mjdata.h:74) */ \
+  X(con_pair, s.nconmax)      /* index into the static pair list */ \
+  X(con_geom, 2 * s.nconmax)  \
+  X(con_dim, s.nconmax)       \
+  X(con_exclude, s.nconmax)   \
+  X(con_efcadr, s.nconmax)    \
+  X(moment_rownnz, s.nu)      \
+  X(moment_colind, s.nmoment) \
+  X(efc_type, s.nefcmax)      \
+  X(efc_id, s.nefcmax)        \
+  X(efc_state, s.nefcmax)     \
+  X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64)
+
+// indices into DBatch::counts
+#define MJH_C_NCON 0
+#define MJH_C_NEFC 1
+#define MJH_C_NE 2
+#define MJH_C_NF 3
+#define MJH_C_NL 4
+#define MJH_C_NITER 5
+#define MJH_C_NISLAND 6
+
+struct DBatch {
+  int nenv;
+#define X(name, cnt) real* name; int n_##name;
+  MJH_BATCH_REAL_FIELDS(X)
+#undef X
+#define X(name, cnt) int* name; int n_##name;
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+};
+
+// pointer to env e's slice of field f
+#define MJH_F(B, f, e) ((B).f + (size_t)(e) * (size_t)(B).n_##f)
+
+// constraint / contact enums used on device (include/mujoco/mjtype.h)
+enum {
+  MJH_JNT_FREE = 0, MJH_JNT_BALL = 1, MJH_JNT_SLIDE = 2, MJH_JNT_HINGE = 3,
+  MJH_GEOM_PLANE = 0, MJH_GEOM_HFIELD = 1, MJH_GEOM_SPHERE = 2, MJH_GEOM_CAPSULE = 3,
+  MJH_GEOM_ELLIPSOID = 4, MJH_GEOM_CYLINDER = 5, MJH_GEOM_BOX = 6, MJH_GEOM_MESH = 7,
+  MJH_CNSTR_EQUALITY = 0, MJH_CNSTR_FRICTION_DOF = 1, MJH_CNSTR_FRICTION_TENDON = 2,
+  MJH_CNSTR_LIMIT_JOINT = 3, MJH_CNSTR_LIMIT_TENDON = 4, MJH_CNSTR_CONTACT_FRICTIONLESS = 5,
+  MJH_CNSTR_CONTACT_PYRAMIDAL = 6, MJH_CNSTR_CONTACT_ELLIPTIC = 7,
+  MJH_STATE_SATISFIED = 0, MJH_STATE_QUADRATIC = 1, MJH_STATE_LINEARNEG = 2,
+  MJH_STATE_LINEARPOS = 3, MJH_STATE_CONE = 4,
+  MJH_SAMEFRAME_NONE = 0, MJH_SAMEFRAME_BODY = 1, MJH_SAMEFRAME_INERTIA = 2,
+  MJH_SAMEFRAME_BODYROT = 3, MJH_SAMEFRAME_INERTIAROT = 4,
+  MJH_WARN_INERTIA = 0, MJH_WARN_CONTACTFULL = 1, MJH_WARN_CNSTRFULL = 2,
+  MJH_WARN_BADQPOS = 3, MJH_WARN_BADQVEL = 4, MJH_WARN_BADQACC = 5, MJH_WARN_BADCTRL = 6,
+  MJH_WARN_UNSUPPORTED = 7,   // mjhip-only: an env reached a feature the GPU path does not implement
+  MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2,
+  MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1,
+  MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1,
+  MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
+  MJH_INT_EULER = 0, MJH_INT_RK4 = 1,
+  // pair_func: which narrowphase routine a static pair uses
+  MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
+  MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4,
+};
