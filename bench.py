@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched mj_step hot path (BASELINE.json: humanoid.xml, 4096
+envs/GPU, PGS solver, Euler, fp64) on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one mj_step of every environment of the rank's batch.  Controls are synthetic
+random actions U(ctrlrange) drawn once per (env, step) and resident in HBM before the timed region
+(SURVEY.md 8d mode B); the state after every step is written to a device array
+[nenv][K][nstate] (the rollout API's `state` output, worst-case I/O).  The K timed steps run as
+ONE launch of the rollout kernel (one wavefront per environment loops over the steps), bracketed
+by barrier + device synchronisation; the time is the max over ranks.  Environments shard across
+ranks with no per-step exchange (weak scaling: 4096 envs on every GPU); the only collective is the
+end-of-chunk gather of the final states to rank 0 over RCCL, inside the timed region.
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline object for the dominant (only)
+kernel and, at N=1, the CPU baseline: the reference engine's own `testspeed` (oracle/_ref, built
+from the reference sources) on all host cores for a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NENV_PER_GPU = 4096
+# algorithmic HBM bytes per env-step: state read + state written
+# (2*nstate), control read (ncontrol), warmstart read + written (2*nv), 8 bytes each
+HBM_PEAK_GBS = 8000.0
+
+
+def initial_states(qpos0: np.ndarray, nv: int, nenv: int, seed: int) -> np.ndarray:
+    """reset state + hinge perturbation N(0,0.05^2), qvel ~ N(0,0.1^2), env-major draws.
+    humanoid: qpos[0:7] is the free joint (left untouched), the rest are hinges."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nq = qpos0.size
+    s0 = np.zeros((nenv, 1 + nq + nv))
+    for e in range(nenv):
+        s0[e, 1:1 + nq] = qpos0
+        s0[e, 8:1 + nq] += rng.normal(0, 0.05, size=nq - 7)
+        s0[e, 1 + nq:] = rng.normal(0, 0.1, size=nv)
+    return s0
+
+
+def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
+    """reference CPU engine timed by the reference's own sample/testspeed.cc (compiled from the
+    reference sources into oracle/_ref by oracle/Makefile) on the host cores of this box."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "testspeed")
+    mjb = os.path.join(ROOT, "tests", "golden", "humanoid.mjb")
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"))
+
+    def run(nstep):
+        out = subprocess.run([exe, mjb, f"--nstep={nstep}", f"--nthread={nthread}", "--solver=PGS"],
+                             capture_output=True, text=True, env=env, timeout=600).stdout
+        m = re.search(r"Total steps per second\s*:\s*([0-9.]+)", out)
+        it = re.search(r"PGS iters / step\s*:\s*([0-9.]+)", out)
+        return (float(m.group(1)) if m else None), (float(it.group(1)) if it else None)
+
+    sps, _ = run(2000)                          # calibration
+    if not sps:
+        return None
+    nstep = int(max(2000, min(400000, budget_s * sps / nthread)))
+    sps, iters = run(nstep)
+    return {"value": sps, "unit": "env-steps/s", "cores": nthread, "kind": "reference",
+            "sample": f"reference sample/testspeed.cc on liboracle_fast (-O3 -mavx), humanoid.mjb --solver=PGS "
+                      f"--nthread={nthread} --nstep={nstep} (OU-Halton ctrl noise, its default regime; "
+                      f"{iters} PGS iters/step)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")
+    args = ap.parse_args()
+
+    import torch
+    import mujoco_amd as ma
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the mjhip path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lib = ma.lib()
+    model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
+    model.set_option("solver", 0)          # PGS (BASELINE config 2); integrator stays Euler
+    dm = ma.DeviceModel(lib, model)
+    nenv, K, W = args.envs_per_gpu, args.steps, args.warmup
+    nq, nv, nu, nstate = dm.nq, dm.nv, dm.nu, dm.nstate
+    batch = ma.Batch(dm, nenv, device=local_rank)
+    qpos0 = batch.get("qpos")[0]
+
+    # synthetic inputs, resident in HBM before timing
+    s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank)
+    crng = np.random.Generator(np.random.PCG64(4321 + rank))
+    dev = torch.device("cuda", local_rank)
+    state0 = torch.from_numpy(s0).to(dev)
+    ctrl_w = torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, max(W, 1), nu))).to(dev)
+    ctrl_k = torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, K, nu))).to(dev)
+    state_out = None if args.no_state_output else torch.empty((nenv, K, nstate), dtype=torch.float64, device=dev)
+    ws_ptr, _, _ = batch.field_info("qacc_warmstart")
+    qpos_ptr, _, _ = batch.field_info("qpos")
+    final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
+    gathered = [torch.empty_like(final) for _ in range(world)] if (dist and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup: W untimed steps from the initial states
+    if W > 0:
+        batch.rollout_device(W, ma.mjSTATE_CTRL, state0.data_ptr(), 0, ctrl_w.data_ptr(), 0, stream)
+    barrier()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    # the timed region: K steps, continuing from the warmed-up state (state0 = NULL keeps it,
+    # warmstart0 = the batch's own qacc_warmstart keeps the solver warm start)
+    batch.rollout_device(K, ma.mjSTATE_CTRL, 0, ws_ptr, ctrl_k.data_ptr(),
+                         0 if state_out is None else state_out.data_ptr(), stream)
+    ev1.record()
+    if state_out is not None:
+        final.copy_(state_out[:, -1])
+    if dist:
+        dist.gather(final, gathered, dst=0)       # end-of-chunk observation gather (RCCL over xGMI)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)
+
+    if dist:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+    warn = int(batch.get("warning").sum())
+    counts = batch.get("counts")
+
+    if rank == 0:
+        total_env_steps = nenv * world * K
+        value = total_env_steps / elapsed
+        bytes_per_env_step = 8 * (2 * nstate + nu + 2 * nv)
+        achieved = bytes_per_env_step * nenv * K / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "env-steps/sec on humanoid.xml, 4096 envs/GPU",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "model/humanoid/humanoid.xml, 4096 envs/GPU, PGS solver, Euler, fp64, "
+                                   "random actions U(ctrlrange), per-step state output" +
+                                   ("" if state_out is not None else " disabled"),
+                       "envs_per_gpu": nenv, "nstep": K, "solver": "PGS", "integrator": "Euler",
+                       "parallelism": f"env-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mjh_k_rollout", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_env_step": bytes_per_env_step},
+            "end_state": {"warnings": warn, "mean_ncon": float(counts[:, 0].mean()),
+                          "mean_nefc": float(counts[:, 1].mean()), "mean_pgs_iter": float(counts[:, 5].mean())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(os.cpu_count() or 1)
+            if cb:
+                res["cpu_baseline"] = cb
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,10 @@ MJHIP_API int mjhip_model_size(const mjhipModel* model, const char* name);
  * installed.  The returned struct is laid out exactly as MuJoCo's; free with mjhip_free_mjb. */
 MJHIP_API struct mjModel_* mjhip_load_mjb(const char* path);
 MJHIP_API void mjhip_free_mjb(struct mjModel_* m);
+/* set one scalar of m->opt (mjOption, include/mujoco/mjmodel.h:83-126) by name, e.g. "solver",
+ * "iterations", "tolerance", "timestep", "integrator", "cone", "disableflags"; what the reference's
+ * bindings do with `model.opt.solver = ...`.  Must precede mjhip_model_create. */
+MJHIP_API int mjhip_set_option(struct mjModel_* m, const char* name, double value);
 
 /* ---- batch ------------------------------------------------------------------------------------
  * Replaces: mj_makeData x nenv (src/engine/engine_io.c) + one mjData per worker thread of

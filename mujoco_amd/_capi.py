@@ -69,6 +69,8 @@ class Lib:
         lib.mjhip_load_mjb.restype = vp
         lib.mjhip_load_mjb.argtypes = [C.c_char_p]
         lib.mjhip_free_mjb.argtypes = [vp]
+        lib.mjhip_set_option.restype = ci
+        lib.mjhip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
         lib.mjhip_batch_create.restype = vp
         lib.mjhip_batch_create.argtypes = [vp, ci, ci]
         lib.mjhip_batch_destroy.argtypes = [vp]
@@ -97,7 +99,7 @@ class Lib:
     # every symbol include/mjhip.h declares (checked by the CPU test-suite)
     SYMBOLS = (
         "mjhip_backend", "mjhip_last_error", "mjhip_device_count", "mjhip_model_create",
-        "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb",
+        "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb", "mjhip_set_option",
         "mjhip_batch_create", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_sync", "mjhip_rollout",
@@ -137,6 +139,9 @@ class MjbModel:
         if not p:
             raise MjhipError(lib.error())
         self._address = int(p)
+
+    def set_option(self, name: str, value: float) -> None:
+        self._lib.check(self._lib.c.mjhip_set_option(self._address, name.encode(), float(value)), "set_option")
 
     def __del__(self):
         try:

@@ -1,0 +1,74 @@
+// libmjhip.so -- the product build of the mjhip C ABI (include/mjhip.h) for MI355X (gfx950).
+//
+// One HIP block == one 64-lane wavefront == one environment.  Kernels are thin __global__
+// wrappers around the stage functions of mjh_smooth/collision/constraint/solver/step.h; the host
+// runtime (model upload, batch arena, rollout marshalling) is mjh_runtime.h.
+//
+// Build (see __graft_entry__.build):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -shared \
+//         -I<mujoco include dir> mjh_hip.hip -o libmjhip.so
+// -ffp-contract=off is part of the numerical contract: the parity oracle is the reference engine
+// built without FMA contraction, and the kernels reproduce its operation order.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "mjh_spmd.h"
+#include "mjh_types.h"
+#include "mjh_step.h"
+
+__global__ __launch_bounds__(MJH_WAVE) void mjh_k_forward(DModel M, DBatch B, int stages) {
+  forward(M, B, (int)blockIdx.x, stages);
+}
+
+__global__ __launch_bounds__(MJH_WAVE) void mjh_k_rollout(DModel M, DBatch B, RolloutArgs A) {
+  rollout_env(M, B, (int)blockIdx.x, A);
+}
+
+__global__ __launch_bounds__(MJH_WAVE) void mjh_k_reset(DModel M, DBatch B) {
+  reset_env(M, B, (int)blockIdx.x);
+}
+
+struct Backend {
+  static const char* name() { return "hip-gfx950"; }
+  static int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+  }
+  static bool set_device(int dev, std::string* err) {
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) { *err = std::string("mjhip: hipSetDevice failed: ") + hipGetErrorString(e); return false; }
+    return true;
+  }
+  static void* alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    return p;
+  }
+  static void free(void* p) { (void)hipFree(p); }
+  static bool h2d(void* dst, const void* src, size_t n, void* stream) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess;
+  }
+  static bool d2h(void* dst, const void* src, size_t n, void* stream) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess;
+  }
+  static bool zero(void* dst, size_t n, void* stream) {
+    return hipMemsetAsync(dst, 0, n, (hipStream_t)stream) == hipSuccess;
+  }
+  static bool sync(void* stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess; }
+  static bool launch_forward(const DModel& M, const DBatch& B, int nenv, int stages, void* stream) {
+    hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, stages);
+    return hipGetLastError() == hipSuccess;
+  }
+  static bool launch_rollout(const DModel& M, const DBatch& B, int nenv, const RolloutArgs& A, void* stream) {
+    hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, A);
+    return hipGetLastError() == hipSuccess;
+  }
+  static bool launch_reset(const DModel& M, const DBatch& B, int nenv, void* stream) {
+    hipLaunchKernelGGL(mjh_k_reset, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B);
+    return hipGetLastError() == hipSuccess;
+  }
+};
+
+#include "mjh_runtime.h"

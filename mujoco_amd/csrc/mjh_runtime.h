@@ -135,6 +135,20 @@ MJHIP_API struct mjModel_* mjhip_load_mjb(const char* path) {
 }
 MJHIP_API void mjhip_free_mjb(struct mjModel_* m) { mjhmjb::release((mjModel*)m); }
 
+MJHIP_API int mjhip_set_option(struct mjModel_* mm, const char* name, double value) {
+  mjModel* m = (mjModel*)mm;
+  if (!m || !name) return -1;
+#define OPTD(n) if (!strcmp(name, #n)) { m->opt.n = value; return 0; }
+#define OPTI(n) if (!strcmp(name, #n)) { m->opt.n = (int)value; return 0; }
+  OPTD(timestep) OPTD(impratio) OPTD(tolerance) OPTD(ls_tolerance) OPTD(noslip_tolerance)
+  OPTI(integrator) OPTI(cone) OPTI(jacobian) OPTI(solver) OPTI(iterations) OPTI(ls_iterations)
+  OPTI(noslip_iterations) OPTI(disableflags) OPTI(enableflags)
+#undef OPTD
+#undef OPTI
+  set_err(std::string("mjhip_set_option: unknown option ") + name);
+  return -2;
+}
+
 MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   if (!M || nenv <= 0) { set_err("mjhip_batch_create: bad arguments"); return nullptr; }
   std::string err;

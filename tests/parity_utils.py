@@ -1,0 +1,96 @@
+"""Comparison helpers shared by the hostsim (CPU) and HIP (GPU) parity tests."""
+import numpy as np
+
+from mujoco_amd import _capi as K
+
+# every per-env array the forward pass produces, with the oracle attribute it mirrors
+FORWARD_FIELDS = [
+    "xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat",
+    "subtree_com", "cinert", "cdof", "ten_length", "ten_J", "crb", "M", "qLD", "qLDiagInv",
+    "actuator_length", "actuator_velocity", "actuator_force", "ten_velocity", "cvel", "cdof_dot",
+    "qfrc_spring", "qfrc_damper", "qfrc_passive", "qfrc_bias", "qfrc_actuator", "qfrc_smooth",
+    "qacc_smooth", "qfrc_constraint", "qacc",
+]
+EFC_FIELDS = ["efc_J", "efc_pos", "efc_margin", "efc_diagA", "efc_R", "efc_D", "efc_KBIP", "efc_Y",
+              "efc_AR", "efc_vel", "efc_aref", "efc_b", "efc_force"]
+
+
+def relerr(got, ref):
+    got = np.asarray(got, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    if ref.size == 0:
+        return 0.0
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+
+
+def load_states(batch, states):
+    batch.set("qpos", np.stack([s["qpos"] for s in states]))
+    batch.set("qvel", np.stack([s["qvel"] for s in states]))
+    batch.set("qacc_warmstart", np.stack([s["qacc_warmstart"] for s in states]))
+    batch.set("ctrl", np.stack([s["ctrl"] for s in states]))
+
+
+def check_forward(rb, m, batch, states, tol, exact_ints=True):
+    """run forward on the batch, mj_forward on the oracle for every env, compare everything.
+    Integer observables (counts, types, ids, contact geoms, efc addresses, solver iterations) must
+    match exactly; floats to `tol` relative (tol=0 -> bit-exact)."""
+    load_states(batch, states)
+    batch.forward()
+    got = {f: batch.get(f) for f in FORWARD_FIELDS + EFC_FIELDS}
+    counts = batch.get("counts")
+    ints = {f: batch.get(f) for f in ["con_geom", "con_dim", "con_exclude", "con_efcadr", "efc_type", "efc_id", "efc_state"]}
+    cons = {f: batch.get(f) for f in ["con_dist", "con_pos", "con_frame", "con_mu"]}
+    d = rb.MjData(m)
+    worst = 0.0
+    nv = m.nv
+    for e, s in enumerate(states):
+        d.qpos[:] = s["qpos"]; d.qvel[:] = s["qvel"]; d.qacc_warmstart[:] = s["qacc_warmstart"]; d.ctrl[:] = s["ctrl"]
+        rb.mj_forward(m, d)
+        ncon, nefc = d.ncon, d.nefc
+        assert counts[e][0] == ncon, f"env {e}: ncon {counts[e][0]} != {ncon}"
+        assert counts[e][1] == nefc, f"env {e}: nefc {counts[e][1]} != {nefc}"
+        assert counts[e][3] == d.nf and counts[e][4] == d.nl
+        assert counts[e][5] == d.solver_niter[0], f"env {e}: PGS iterations {counts[e][5]} != {d.solver_niter[0]}"
+        c = d.contact
+        if ncon:
+            assert np.array_equal(ints["con_geom"][e].reshape(-1, 2)[:ncon], c["geom"])
+            assert np.array_equal(ints["con_dim"][e][:ncon], c["dim"])
+            assert np.array_equal(ints["con_exclude"][e][:ncon], c["exclude"])
+            assert np.array_equal(ints["con_efcadr"][e][:ncon], c["efc_address"])
+            for f, ref in [("con_dist", c["dist"]), ("con_pos", c["pos"]), ("con_frame", c["frame"]), ("con_mu", c["mu"])]:
+                err = relerr(cons[f][e][:np.asarray(ref).size], ref)
+                worst = max(worst, err)
+                assert err <= tol, f"env {e} {f}: {err}"
+        if nefc:
+            assert np.array_equal(ints["efc_type"][e][:nefc], d.efc_type)
+            assert np.array_equal(ints["efc_id"][e][:nefc], d.efc_id)
+            assert np.array_equal(ints["efc_state"][e][:nefc], d.efc_state)
+            for f in EFC_FIELDS:
+                ref = np.asarray(getattr(d, f)).ravel()
+                err = relerr(got[f][e][:ref.size], ref)
+                worst = max(worst, err)
+                assert err <= tol, f"env {e} {f}: {err}"
+        for f in FORWARD_FIELDS:
+            ref = np.asarray(getattr(d, f)).ravel()
+            err = relerr(got[f][e][:ref.size], ref)
+            worst = max(worst, err)
+            assert err <= tol, f"env {e} {f}: {err}"
+    return worst
+
+
+def oracle_rollout(rb, m, state0, ctrl, warmstart0=None):
+    """serial mj_step loop: the py_rollout of the reference's rollout_test.py:976-1001"""
+    nenv, nstep = ctrl.shape[:2]
+    d = rb.MjData(m)
+    out = np.zeros((nenv, nstep, state0.shape[1]))
+    ints = np.zeros((nenv, nstep, 3), np.int32)
+    for e in range(nenv):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, state0[e], rb.mjSTATE_FULLPHYSICS)
+        d.qacc_warmstart[:] = 0 if warmstart0 is None else warmstart0[e]
+        for t in range(nstep):
+            d.ctrl[:] = ctrl[e, t]
+            rb.mj_step(m, d)
+            out[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+            ints[e, t] = (d.ncon, d.nefc, d.solver_niter[0])
+    return out, ints

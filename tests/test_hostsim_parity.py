@@ -1,0 +1,98 @@
+"""CPU: the kernel sources, compiled for the host wavefront emulation (tests/hostsim), against the
+oracle.  Same C ABI, same kernels as the GPU build; only the lane scheduler differs.  Bit-exact
+agreement is asserted (tol=0): the kernels follow the reference's operation order."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mujoco_amd import _capi as K
+from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
+from parity_utils import check_forward, oracle_rollout
+
+
+@pytest.fixture(scope="module")
+def setup(rb, hostsim_lib):
+    m = humanoid_pgs_oracle(rb)
+    dm = K.DeviceModel(hostsim_lib, m)
+    return m, dm
+
+
+def test_static_tables(setup):
+    m, dm = setup
+    assert dm.nq == 28 and dm.nv == 27 and dm.nstate == 56
+    assert dm.npair > 100          # static candidate pairs
+    assert dm.nlevel == 7
+
+
+def test_forward_bit_exact(rb, setup):
+    m, dm = setup
+    states = contact_rich_states(rb, m, 6, seed=3)
+    b = K.Batch(dm, len(states))
+    worst = check_forward(rb, m, b, states, tol=0.0)
+    assert worst == 0.0
+
+
+def test_rollout_bit_exact_vs_golden(setup, golden):
+    m, dm = setup
+    fx = golden("humanoid")
+    n, T = 4, 25
+    b = K.Batch(dm, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T])
+    assert np.array_equal(out, fx["state"][:n, :T])
+
+
+def test_lane_order_independence(golden):
+    """race detector: the emulation run with lanes scheduled 63..0 gives identical bits"""
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from mujoco_amd import _capi as K\n"
+        "lib = K.Lib(%r)\n"
+        "m = K.MjbModel(lib, %r); m.set_option('solver', 0)\n"
+        "dm = K.DeviceModel(lib, m)\n"
+        "fx = np.load(%r)\n"
+        "b = K.Batch(dm, 2)\n"
+        "out = b.rollout_host(12, K.mjSTATE_CTRL, fx['state0'][1:3], None, fx['ctrl'][1:3, :12])\n"
+        "assert np.array_equal(out, fx['state'][1:3, :12]), 'reverse lane order changed the result'\n"
+    ) % (ROOT, HOSTSIM_LIB, os.path.join(GOLDEN, "humanoid.mjb"), os.path.join(GOLDEN, "humanoid_traj.npz"))
+    env = dict(os.environ, MJH_HOSTSIM_REVERSE="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env)
+
+
+def test_warning_freezes_trajectory(rb, setup):
+    """rollout.cc:135-155: after a warning the rest of the trajectory is back-filled"""
+    m, dm = setup
+    d = rb.MjData(m)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    s0[0, 1 + 28 + 3] = 1e12     # bad qvel -> mjWARN_BADQVEL, auto reset
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(5, K.mjSTATE_CTRL, s0, None, np.zeros((1, 5, 21)))
+    ref, _ = oracle_rollout(rb, m, s0, np.zeros((1, 1, 21)))
+    assert np.array_equal(out[0, 0], ref[0, 0])
+    for t in range(1, 5):
+        assert np.array_equal(out[0, t], out[0, 0])
+    assert b.get("warning")[0, 4] == 1
+
+
+def test_capacity_overflow_raises_warning(rb, hostsim_lib, golden):
+    m = humanoid_pgs_oracle(rb)
+    dm = K.DeviceModel(hostsim_lib, m, 2, 8)     # absurdly small capacities
+    d = rb.MjData(m)
+    rb.mj_resetDataKeyframe(m, d, 2)
+    b = K.Batch(dm, 1)
+    b.set("qpos", np.array(d.qpos)[None])
+    b.forward()
+    w = b.get("warning")[0]
+    assert w[1] >= 1 or w[2] >= 1    # CONTACTFULL or CNSTRFULL
+
+
+def test_unsupported_models_are_rejected(rb, hostsim_lib):
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))   # Newton by default
+    with pytest.raises(K.MjhipError, match="PGS"):
+        K.DeviceModel(hostsim_lib, m)
+    sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
+    sc.opt.solver = 0
+    with pytest.raises(K.MjhipError, match="unsupported"):
+        K.DeviceModel(hostsim_lib, sc)
