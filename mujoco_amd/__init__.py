@@ -14,7 +14,7 @@ from ._capi import (Batch, DeviceModel, Lib, MjbModel, MjhipError, STAGE_ALL, mj
                     mjSTATE_FULLPHYSICS, mjSTATE_QFRC_APPLIED)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmjhip.so")
+LIB_PATH = os.environ.get("MJHIP_LIB", os.path.join(_HERE, "csrc", "libmjhip.so"))
 _lib = None
 
 

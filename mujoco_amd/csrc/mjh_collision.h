@@ -193,7 +193,7 @@ MJH_DEV int filter_sphere(const DModel& M, const real* gx, const real* gm, int g
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_collision(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   int* counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;

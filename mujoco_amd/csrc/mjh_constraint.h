@@ -78,7 +78,7 @@ MJH_DEV void set_kbip(real* KBIP, const real* ref, const real* solimp, real imp,
 //          non-contact Jacobian rows.  Phase 3: contact Jacobians, lanes over dof columns.
 // Phase 4: diagApprox + impedance (R, D, KBIP), lanes over constraint blocks.
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
   int* counts = MJH_F(B, counts, e);
@@ -394,7 +394,7 @@ MJH_DEV void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
 // mj_projectConstraint for dual solvers: Y = J L^-T D^-1/2, AR = Y Y' + diag(R)
 //                                                  (engine_core_constraint.c:2918-3137)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_project(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
@@ -448,7 +448,7 @@ MJH_DEV void stage_project(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_referenceConstraint: efc_vel = J qvel, aref   (engine_core_constraint.c:3245-3270)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_reference(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
   const int nv = M.s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;

@@ -17,16 +17,22 @@
 #include "mjh_types.h"
 #include "mjh_step.h"
 
-__global__ __launch_bounds__(MJH_WAVE) void mjh_k_forward(DModel M, DBatch B, int stages) {
-  forward(M, B, (int)blockIdx.x, stages);
+// The model / batch descriptors (tables of device pointers, ~1 KB each) live in device memory and
+// are read through the scalar cache on demand; passing them by value made the compiler hoist
+// every pointer into SGPRs for the whole kernel (hundreds of spills).
+__global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_forward(const DModel* __restrict__ M,
+                                                          const DBatch* __restrict__ B, int stages) {
+  forward_or_euler(*M, *B, (int)blockIdx.x, stages);
 }
 
-__global__ __launch_bounds__(MJH_WAVE) void mjh_k_rollout(DModel M, DBatch B, RolloutArgs A) {
-  rollout_env(M, B, (int)blockIdx.x, A);
+__global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_rollout(const DModel* __restrict__ M,
+                                                          const DBatch* __restrict__ B, RolloutArgs A) {
+  rollout_env(*M, *B, (int)blockIdx.x, A);
 }
 
-__global__ __launch_bounds__(MJH_WAVE) void mjh_k_reset(DModel M, DBatch B) {
-  reset_env(M, B, (int)blockIdx.x);
+__global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_reset(const DModel* __restrict__ M,
+                                                        const DBatch* __restrict__ B) {
+  reset_env(*M, *B, (int)blockIdx.x);
 }
 
 struct Backend {
@@ -57,15 +63,15 @@ struct Backend {
     return hipMemsetAsync(dst, 0, n, (hipStream_t)stream) == hipSuccess;
   }
   static bool sync(void* stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess; }
-  static bool launch_forward(const DModel& M, const DBatch& B, int nenv, int stages, void* stream) {
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void* stream) {
     hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, stages);
     return hipGetLastError() == hipSuccess;
   }
-  static bool launch_rollout(const DModel& M, const DBatch& B, int nenv, const RolloutArgs& A, void* stream) {
+  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, void* stream) {
     hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, A);
     return hipGetLastError() == hipSuccess;
   }
-  static bool launch_reset(const DModel& M, const DBatch& B, int nenv, void* stream) {
+  static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream) {
     hipLaunchKernelGGL(mjh_k_reset, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B);
     return hipGetLastError() == hipSuccess;
   }

@@ -14,9 +14,10 @@
 //   static bool d2h(void* dst, const void* src, size_t bytes, void* stream);
 //   static bool zero(void* dst, size_t bytes, void* stream);
 //   static bool sync(void* stream);
-//   static bool launch_forward(const DModel&, const DBatch&, int nenv, int stages, void* stream);
-//   static bool launch_rollout(const DModel&, const DBatch&, int nenv, const RolloutArgs&, void* stream);
-//   static bool launch_reset(const DModel&, const DBatch&, int nenv, void* stream);
+//   (M, B below are DEVICE pointers to the descriptor structs)
+//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void* stream);
+//   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, void* stream);
+//   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
 #pragma once
 
 #include <cstdio>
@@ -37,7 +38,8 @@ static void set_err(const std::string& e) { g_mjhip_err = e; }
 
 struct mjhipModel_ {
   HostModel H;
-  DModel D;                 // device pointers
+  DModel D;                 // device pointers (host copy of the struct)
+  DModel* D_dev = nullptr;  // the same struct in device memory: what the kernels receive
   std::vector<void*> allocs;
   int device = 0;
   std::vector<char> signature;   // bytes identifying the source mjModel (for the rollout cache)
@@ -48,6 +50,7 @@ struct FieldInfo { void* ptr; int count; int is_int; };
 struct mjhipBatch_ {
   mjhipModel_* model = nullptr;
   DBatch D;
+  DBatch* D_dev = nullptr;
   void* arena = nullptr;
   size_t arena_bytes = 0;
   std::map<std::string, FieldInfo> fields;
@@ -98,6 +101,11 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
 #define X(name, cnt) ok = ok && upload_vec<real>(M, M->H.name, &M->D.name, &err);
   MJH_MODEL_REAL_FIELDS(X)
 #undef X
+  if (ok) {
+    M->D_dev = (DModel*)Backend::alloc(sizeof(DModel));
+    ok = M->D_dev && Backend::h2d(M->D_dev, &M->D, sizeof(DModel), nullptr);
+    if (M->D_dev) M->allocs.push_back(M->D_dev);
+  }
   if (!ok || !Backend::sync(nullptr)) {
     set_err(err.empty() ? "mjhip: model upload failed" : err);
     mjhip_model_destroy(M);
@@ -186,6 +194,12 @@ MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 1}; k++;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
+  Bt->D_dev = (DBatch*)Backend::alloc(sizeof(DBatch));
+  if (!Bt->D_dev || !Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr)) {
+    set_err("mjhip: device allocation failed (batch descriptor)");
+    mjhip_batch_destroy(Bt);
+    return nullptr;
+  }
   if (mjhip_batch_reset(Bt) != 0) { mjhip_batch_destroy(Bt); return nullptr; }
   return Bt;
 }
@@ -193,6 +207,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
 MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
   if (!Bt) return;
   if (Bt->arena) Backend::free(Bt->arena);
+  if (Bt->D_dev) Backend::free(Bt->D_dev);
   delete Bt;
 }
 
@@ -200,7 +215,7 @@ MJHIP_API int mjhip_batch_nenv(const mjhipBatch* Bt) { return Bt ? Bt->nenv : -1
 
 MJHIP_API int mjhip_batch_reset(mjhipBatch* Bt) {
   if (!Bt) return -1;
-  if (!Backend::launch_reset(Bt->model->D, Bt->D, Bt->nenv, nullptr) || !Backend::sync(nullptr)) {
+  if (!Backend::launch_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_reset: kernel launch failed");
     return -2;
   }
@@ -246,8 +261,8 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* Bt, const char* name, const void* host
 
 MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt) return -1;
-  if (stages < 0) stages = MJH_STAGE_ALL;
-  if (!Backend::launch_forward(Bt->model->D, Bt->D, Bt->nenv, stages, stream)) {
+  if (stages < 0) stages = MJH_STAGE_ALL;   // -1: mj_forward
+  if (!Backend::launch_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, stages, stream)) {
     set_err("mjhip_batch_forward: kernel launch failed"); return -2;
   }
   return 0;
@@ -260,7 +275,7 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   A.nstep = nstep;
   A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied
   A.init = 0;
-  if (!Backend::launch_rollout(Bt->model->D, Bt->D, Bt->nenv, A, stream)) {
+  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->D_dev, Bt->nenv, A, stream)) {
     set_err("mjhip_batch_step: kernel launch failed"); return -2;
   }
   return 0;
@@ -321,7 +336,7 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
     if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
   }
   if (!A.control) { /* no control array: inputs not in the spec stay zero, those in it keep current */ }
-  if (!Backend::launch_rollout(Bt->model->D, Bt->D, Bt->nenv, A, stream)) {
+  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->D_dev, Bt->nenv, A, stream)) {
     cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4;
   }
   if (!on_device) {

@@ -42,7 +42,7 @@ MJH_DEV void local2global(real* opos, real* omat, const real* pos, const real* q
 // mj_kinematics                                  (engine_core_smooth.c:40-242)
 // level-synchronous: all bodies of one depth level are independent given their parents
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_kinematics(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* qpos = MJH_F(B, qpos, e);
   real* xpos = MJH_F(B, xpos, e);
@@ -172,7 +172,7 @@ MJH_DEV void tree_accumulate_to_parent(const DModel& M, real* x, int n, int incl
 // ------------------------------------------------------------------------------------------------
 // mj_comPos                                      (engine_core_smooth.c:246-350)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_compos(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* xipos = MJH_F(B, xipos, e);
   const real* ximat = MJH_F(B, ximat, e);
@@ -240,7 +240,7 @@ MJH_DEV void stage_compos(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_tendon, fixed tendons only                  (engine_core_smooth.c:927-986)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_tendon(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_tendon(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   if (!s.ntendon) return;
   const real* qpos = MJH_F(B, qpos, e);
@@ -270,7 +270,7 @@ MJH_DEV void stage_tendon(const DModel& M, const DBatch& B, int e) {
 // mj_transmission: joint (slide/hinge) transmissions   (engine_core_smooth.c:1265-1329)
 // moment is kept sparse with a static per-actuator row capacity (actuator_momentadr)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_transmission(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   if (!s.nu) return;
   const real* qpos = MJH_F(B, qpos, e);
@@ -294,7 +294,7 @@ MJH_DEV void stage_transmission(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_crb (+ mj_makeM)                            (engine_core_smooth.c:1890-1971)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_crb(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* cinert = MJH_F(B, cinert, e);
   const real* cdof = MJH_F(B, cdof, e);
@@ -328,7 +328,7 @@ MJH_DEV void stage_crb(const DModel& M, const DBatch& B, int e) {
 // sparse L'DL factorisation in place              (mj_factorI, engine_core_smooth.c:2005-2029)
 // rows nv-1 .. 0 in order; for one row k the updates of its ancestor rows are independent
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void factor_ld(const DModel& M, real* mat, real* diaginv) {
+MJH_DEVN void factor_ld(const DModel& M, real* mat, real* diaginv) {
   const int nv = M.s.nv;
   for (int k = nv - 1; k >= 0; k--) {
     int start = M.M_rowadr[k];
@@ -355,7 +355,7 @@ MJH_DEV void factor_ld(const DModel& M, real* mat, real* diaginv) {
   }
 }
 
-MJH_DEV void stage_factor_m(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
   const real* Mq = MJH_F(B, M, e);
   real* qLD = MJH_F(B, qLD, e);
   MJH_FOR_LANES(k, M.s.nC) qLD[k] = Mq[k];
@@ -366,7 +366,7 @@ MJH_DEV void stage_factor_m(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // x <- inv(L'DL) x, one vector                    (mj_solveLD, engine_core_smooth.c:2033-2109)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void solve_ld(const DModel& M, real* x, const real* qLD, const real* diaginv) {
+MJH_DEVN void solve_ld(const DModel& M, real* x, const real* qLD, const real* diaginv) {
   const int nv = M.s.nv;
   // x <- L^-T x : row i scatters into its ancestors (independent targets)
   for (int i = nv - 1; i >= 0; i--) {
@@ -410,7 +410,7 @@ MJH_DEV void mul_dof_vec(real* res, const real* dof, const real* vec, int n) {
   }
 }
 
-MJH_DEV void stage_comvel(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_comvel(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* qvel = MJH_F(B, qvel, e);
   const real* cdof = MJH_F(B, cdof, e);
@@ -477,7 +477,7 @@ MJH_DEV real poly_force_deriv(real linear, const real* poly, real x, int odd) {
   return res;
 }
 
-MJH_DEV void stage_passive(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* qpos = MJH_F(B, qpos, e);
   const real* qvel = MJH_F(B, qvel, e);
@@ -569,7 +569,7 @@ MJH_DEV void stage_passive(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_rne(flg_acc=0) -> qfrc_bias                  (engine_core_smooth.c:2328-2389)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_rne(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_rne(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* qvel = MJH_F(B, qvel, e);
   const real* cdof = MJH_F(B, cdof, e);
@@ -613,7 +613,7 @@ MJH_DEV void stage_rne(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // tendon / actuator velocities                    (mj_fwdVelocity head, engine_forward.c:197-208)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* qvel = MJH_F(B, qvel, e);
   if (s.ntendon) {
@@ -642,7 +642,7 @@ MJH_DEV void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
 // mj_fwdActuation: stateless actuators (dyntype none), fixed/affine gain, none/affine bias
 //                                                 (engine_forward.c:353-1003)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_actuation(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   real* force = MJH_F(B, actuator_force, e);
   real* qfa = MJH_F(B, qfrc_actuator, e);
@@ -718,7 +718,7 @@ MJH_DEV void stage_actuation(const DModel& M, const DBatch& B, int e) {
 // mj_fwdAcceleration                              (engine_forward.c:1007-1052)
 // (xfrc_applied is handled by the host API: non-zero Cartesian forces are rejected for now)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_acceleration(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_acceleration(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const real* fp = MJH_F(B, qfrc_passive, e);
   const real* fb = MJH_F(B, qfrc_bias, e);

@@ -43,7 +43,7 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // ------------------------------------------------------------------------------------------------
 // solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void solve_pgs(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
   int* counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
   const real* AR = MJH_F(B, efc_AR, e);
@@ -165,7 +165,7 @@ MJH_DEV void solve_pgs(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
   int* counts = MJH_F(B, counts, e);

@@ -27,6 +27,7 @@
 #include <string.h>
 
 #define MJH_DEV static inline
+#define MJH_DEVN static __attribute__((noinline))
 #define MJH_GLOBAL static void
 #define MJH_SHARED static
 
@@ -127,6 +128,10 @@ MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
 #include <hip/hip_runtime.h>
 
 #define MJH_DEV __device__ __forceinline__
+// out-of-line device function: gives the big stages their own register allocation scope
+// register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident
+#define MJH_WAVES_PER_EU 4
+#define MJH_DEVN __device__ __noinline__ static
 #define MJH_GLOBAL __global__ void
 #define MJH_SHARED __shared__
 

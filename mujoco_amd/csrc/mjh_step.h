@@ -20,6 +20,7 @@ enum {
   MJH_STAGE_ACTUATION  = 1<<7,   // actuation + acceleration
   MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint
   MJH_STAGE_ALL        = (1<<9) - 1,
+  MJH_STAGE_EULER      = 1<<9,   // mj_Euler + mj_advance (not part of mj_forward; for per-stage runs)
 };
 
 // mj_resetData as far as the state vector is concerned (engine_io.c:1289-1420)
@@ -61,7 +62,7 @@ MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, const real* x, in
 }
 
 // mj_forwardSkip(mjSTAGE_NONE, skipsensor) restricted by a stage mask   (engine_forward.c:1783-1836)
-MJH_DEV void forward(const DModel& M, const DBatch& B, int e, int stages) {
+MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
   if (stages & MJH_STAGE_KINEMATICS) {
     stage_kinematics(M, B, e);
     stage_compos(M, B, e);
@@ -89,8 +90,14 @@ MJH_DEV void forward(const DModel& M, const DBatch& B, int e, int stages) {
   if (stages & MJH_STAGE_CONSTRAINT) stage_fwd_constraint(M, B, e);
 }
 
+MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e);
+MJH_DEV void forward_or_euler(const DModel& M, const DBatch& B, int e, int stages) {
+  forward(M, B, e, stages);
+  if (stages & MJH_STAGE_EULER) euler_advance(M, B, e);
+}
+
 // mj_EulerSkip + mj_advance                        (engine_forward.c:1398-1476, :1261-1395)
-MJH_DEV void euler_advance(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
   const real h = M.o.timestep;

@@ -86,16 +86,16 @@ struct Backend {
   static bool d2h(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
   static bool zero(void* dst, size_t n, void*) { memset(dst, 0, n); return true; }
   static bool sync(void*) { return true; }
-  static bool launch_forward(const DModel& M, const DBatch& B, int nenv, int stages, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { forward(M, B, wv_env(), stages); });
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void*) {
+    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { forward_or_euler(*M, *B, wv_env(), stages); });
     return true;
   }
-  static bool launch_rollout(const DModel& M, const DBatch& B, int nenv, const RolloutArgs& A, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { rollout_env(M, B, wv_env(), A); });
+  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, void*) {
+    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { rollout_env(*M, *B, wv_env(), A); });
     return true;
   }
-  static bool launch_reset(const DModel& M, const DBatch& B, int nenv, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { reset_env(M, B, wv_env()); });
+  static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void*) {
+    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { reset_env(*M, *B, wv_env()); });
     return true;
   }
 };
