@@ -9,8 +9,9 @@ A "step" is one mj_step of every environment of the rank's batch.  Controls are 
 random actions U(ctrlrange) drawn once per (env, step) and resident in HBM before the timed region
 (SURVEY.md 8d mode B); the state after every step is written to a device array
 [nenv][K][nstate] (the rollout API's `state` output, worst-case I/O).  The K timed steps run as
-ONE launch of the rollout kernel (one wavefront per environment loops over the steps), bracketed
-by barrier + device synchronisation; the time is the max over ranks.  Environments shard across
+launches of the rollout kernel of --chunk steps each (one wavefront per environment loops over
+the steps of a launch), bracketed by barrier + device synchronisation; the time is the max over
+ranks.  Environments shard across
 ranks with no per-step exchange (weak scaling: 4096 envs on every GPU); the only collective is the
 end-of-chunk gather of the final states to rank 0 over RCCL, inside the timed region.
 
@@ -82,8 +83,9 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--chunk", type=int, default=10, help="steps per rollout-kernel launch")
     ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")
@@ -115,16 +117,22 @@ def main() -> None:
     batch = ma.Batch(dm, nenv, device=local_rank)
     qpos0 = batch.get("qpos")[0]
 
-    # synthetic inputs, resident in HBM before timing
+    # synthetic inputs, resident in HBM before timing.  Steps are issued in launches of C steps
+    # (one rollout-kernel launch = C x nenv env-steps) so that every launch is the same unit of
+    # work for the profiler; controls / state outputs are laid out per launch.
+    C = max(1, min(args.chunk, K))
+    def chunks(n):
+        return [C] * (n // C) + ([n % C] if n % C else [])
     s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank)
     crng = np.random.Generator(np.random.PCG64(4321 + rank))
     dev = torch.device("cuda", local_rank)
     state0 = torch.from_numpy(s0).to(dev)
-    ctrl_w = torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, max(W, 1), nu))).to(dev)
-    ctrl_k = torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, K, nu))).to(dev)
-    state_out = None if args.no_state_output else torch.empty((nenv, K, nstate), dtype=torch.float64, device=dev)
+    lo, hi = -1.0, 1.0       # humanoid ctrlrange
+    ctrl_w = [torch.from_numpy(crng.uniform(lo, hi, size=(nenv, c, nu))).to(dev) for c in chunks(W)]
+    ctrl_k = [torch.from_numpy(crng.uniform(lo, hi, size=(nenv, c, nu))).to(dev) for c in chunks(K)]
+    state_k = [None if args.no_state_output else torch.empty((nenv, c, nstate), dtype=torch.float64, device=dev)
+               for c in chunks(K)]
     ws_ptr, _, _ = batch.field_info("qacc_warmstart")
-    qpos_ptr, _, _ = batch.field_info("qpos")
     final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
     gathered = [torch.empty_like(final) for _ in range(world)] if (dist and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
@@ -134,26 +142,42 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup: W untimed steps from the initial states
-    if W > 0:
-        batch.rollout_device(W, ma.mjSTATE_CTRL, state0.data_ptr(), 0, ctrl_w.data_ptr(), 0, stream)
-    barrier()
+    events = []
 
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    def launch(ctrl, out, first):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        # first launch loads the initial states; later ones continue (state0 = NULL keeps the
+        # state, warmstart0 = the batch's own qacc_warmstart keeps the solver warm start)
+        batch.rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, state0.data_ptr() if first else 0,
+                             0 if first else ws_ptr, ctrl.data_ptr(),
+                             0 if out is None else out.data_ptr(), stream)
+        e1.record()
+        events.append((e0, e1, ctrl.shape[1]))
+
+    # warmup: W untimed steps from the initial states
+    first = True
+    for c in ctrl_w:
+        launch(c, None, first)
+        first = False
+    barrier()
+    n_warm_launch = len(events)
+
     t0 = time.perf_counter()
-    ev0.record()
-    # the timed region: K steps, continuing from the warmed-up state (state0 = NULL keeps it,
-    # warmstart0 = the batch's own qacc_warmstart keeps the solver warm start)
-    batch.rollout_device(K, ma.mjSTATE_CTRL, 0, ws_ptr, ctrl_k.data_ptr(),
-                         0 if state_out is None else state_out.data_ptr(), stream)
-    ev1.record()
-    if state_out is not None:
-        final.copy_(state_out[:, -1])
+    for c, o in zip(ctrl_k, state_k):
+        launch(c, o, first)
+        first = False
+    if state_k[-1] is not None:
+        final.copy_(state_k[-1][:, -1])
     if dist:
         dist.gather(final, gathered, dst=0)       # end-of-chunk observation gather (RCCL over xGMI)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)
+    timed = [(a.elapsed_time(b), n) for a, b, n in events[n_warm_launch:]]
+    allev = [(a.elapsed_time(b), n) for a, b, n in events]
+    kernel_ms = sum(t for t, _ in timed)
+    launch_ms_timed = float(np.mean([t for t, n in timed if n == C])) if any(n == C for _, n in timed) else kernel_ms
+    launch_ms_all = float(np.mean([t for t, n in allev if n == C])) if any(n == C for _, n in allev) else launch_ms_timed
 
     if dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
@@ -166,7 +190,8 @@ def main() -> None:
         total_env_steps = nenv * world * K
         value = total_env_steps / elapsed
         bytes_per_env_step = 8 * (2 * nstate + nu + 2 * nv)
-        achieved = bytes_per_env_step * nenv * K / (kernel_ms * 1e-3) / 1e9
+        # one launch = C steps of nenv envs; achieved = algorithmic bytes per launch / avg launch time
+        achieved = bytes_per_env_step * nenv * C / (launch_ms_timed * 1e-3) / 1e9
         res = {
             "metric": "env-steps/sec on humanoid.xml, 4096 envs/GPU",
             "value": value,
@@ -182,13 +207,16 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": "model/humanoid/humanoid.xml, 4096 envs/GPU, PGS solver, Euler, fp64, "
                                    "random actions U(ctrlrange), per-step state output" +
-                                   ("" if state_out is not None else " disabled"),
+                                   ("" if not args.no_state_output else " disabled"),
                        "envs_per_gpu": nenv, "nstep": K, "solver": "PGS", "integrator": "Euler",
                        "parallelism": f"env-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mjh_k_rollout", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_env_step": bytes_per_env_step},
+                         "kernel": "mjh_k_rollout", "steps_per_launch": C,
+                         "launch_ms": launch_ms_timed, "launch_ms_incl_warmup": launch_ms_all,
+                         "kernel_ms_total": kernel_ms,
+                         "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "algorithmic_bytes_per_launch": bytes_per_env_step * nenv * C},
             "end_state": {"warnings": warn, "mean_ncon": float(counts[:, 0].mean()),
                           "mean_nefc": float(counts[:, 1].mean()), "mean_pgs_iter": float(counts[:, 5].mean())},
         }

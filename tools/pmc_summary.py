@@ -1,0 +1,35 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes for the rollout kernel.
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  Correction for gfx950 per
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE under-reports a wide coalesced read
+stream by exactly 2x (128-B requests tallied at 64 B); other access widths and WRITE_SIZE are
+uncalibrated.  Both the raw and the x2-corrected read figure are printed.
+"""
+import csv
+import glob
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def load(sub, counter):
+    vals = []
+    for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "rollout" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+fetch = load("pmc_fetch", "FETCH_SIZE")
+write = load("pmc_write", "WRITE_SIZE")
+for name, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+    if v:
+        print(f"{name}: {len(v)} dispatches, mean {sum(v)/len(v):.1f} KiB/dispatch, min {min(v):.1f}, max {max(v):.1f}")
+    else:
+        print(f"{name}: no samples")
+if fetch and write:
+    f, w = sum(fetch) / len(fetch) * 1024, sum(write) / len(write) * 1024
+    print(f"per launch (10 steps x 4096 envs): read {f/1e6:.2f} MB raw / {2*f/1e6:.2f} MB with the gfx950 x2 correction, "
+          f"written {w/1e6:.2f} MB; per env-step: {(2*f+w)/40960:.0f} B (corrected)")
