@@ -78,8 +78,23 @@ MJHIP_API int mjhip_batch_field(mjhipBatch* batch, const char* name, void** devi
 MJHIP_API int mjhip_batch_get(mjhipBatch* batch, const char* name, void* host_dst);
 MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* host_src);
 
+/* LDS residency plan of the batch kernels (no reference counterpart: the reference keeps mjData in
+ * host DRAM).  Each environment is stepped by one 64-lane wavefront that owns `lds_bytes` of LDS;
+ * the plan decides which mjData fields live there while they are in use (see mjh_types.h).
+ * mjhip_batch_create plans with $MJHIP_LDS_BYTES or a default; 0 disables residency (all fields
+ * in HBM).  Returns the bytes left for the per-step constraint arrays, or <0 on error.
+ * mjhip_batch_lds_report: printable description of the current plan. */
+MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* batch, int lds_bytes);
+MJHIP_API const char* mjhip_batch_lds_report(const mjhipBatch* batch);
+
 /* mj_forward restricted to a stage mask (bits MJH_STAGE_* of mjh_step.h; -1 = all).
- * Replaces mj_forward / mj_forwardSkip (src/engine/engine_forward.c:1783-1842) for every env. */
+ * Replaces mj_forward / mj_forwardSkip (src/engine/engine_forward.c:1783-1842) for every env.
+ * By default every intermediate is materialised in its global field (inspection); OR-ing
+ * MJHIP_STAGE_LDS into `stages` runs the stages on the LDS residency plan, exactly as the
+ * step/rollout kernels do, and copies each field back to its global home after every stage. */
+#define MJHIP_STAGE_ALL 0x1ff
+#define MJHIP_STAGE_EULER 0x200
+#define MJHIP_STAGE_LDS (1 << 21)
 MJHIP_API int mjhip_batch_forward(mjhipBatch* batch, int stages, void* hip_stream);
 
 /* nstep x mj_step for every env with the device-resident ctrl / qfrc_applied

@@ -24,6 +24,8 @@ STAGE_VELOCITY = 1 << 6
 STAGE_ACTUATION = 1 << 7
 STAGE_CONSTRAINT = 1 << 8
 STAGE_ALL = (1 << 9) - 1
+STAGE_EULER = 1 << 9
+STAGE_LDS = 1 << 21      # run forward() on the LDS residency plan with per-stage write-back (debug)
 
 # mjtState bits (include/mujoco/mjtype.h:504-527)
 mjSTATE_TIME = 1 << 0
@@ -84,6 +86,10 @@ class Lib:
         lib.mjhip_batch_get.argtypes = [vp, C.c_char_p, vp]
         lib.mjhip_batch_set.restype = ci
         lib.mjhip_batch_set.argtypes = [vp, C.c_char_p, vp]
+        lib.mjhip_batch_plan_lds.restype = ci
+        lib.mjhip_batch_plan_lds.argtypes = [vp, ci]
+        lib.mjhip_batch_lds_report.restype = C.c_char_p
+        lib.mjhip_batch_lds_report.argtypes = [vp]
         lib.mjhip_batch_forward.restype = ci
         lib.mjhip_batch_forward.argtypes = [vp, ci, vp]
         lib.mjhip_batch_step.restype = ci
@@ -223,9 +229,23 @@ class Batch:
     def reset(self) -> None:
         self._lib.check(self._lib.c.mjhip_batch_reset(self._h), "reset")
 
-    def forward(self, stages: int = -1, stream: int = 0) -> None:
+    def forward(self, stages: int = -1, stream: int = 0, lds: bool = False) -> None:
+        if stages < 0:
+            stages = STAGE_ALL
+        if lds:
+            stages |= STAGE_LDS
         self._lib.check(self._lib.c.mjhip_batch_forward(self._h, int(stages), stream or None), "forward")
         self.sync(stream)
+
+    def plan_lds(self, lds_bytes: int) -> int:
+        """(re)plan LDS residency with `lds_bytes` per one-wavefront workgroup; 0 = all global.
+        Returns the bytes left for the per-step constraint arrays."""
+        rc = self._lib.c.mjhip_batch_plan_lds(self._h, int(lds_bytes))
+        self._lib.check(min(rc, 0), "plan_lds")
+        return rc
+
+    def lds_report(self) -> str:
+        return self._lib.c.mjhip_batch_lds_report(self._h).decode()
 
     def step(self, nstep: int = 1, stream: int = 0, sync: bool = True) -> None:
         self._lib.check(self._lib.c.mjhip_batch_step(self._h, int(nstep), stream or None), "step")

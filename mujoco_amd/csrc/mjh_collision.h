@@ -204,15 +204,6 @@ MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
   }
   const real* gx = MJH_F(B, geom_xpos, e);
   const real* gm = MJH_F(B, geom_xmat, e);
-  real* cdist = MJH_F(B, con_dist, e);
-  real* cpos = MJH_F(B, con_pos, e);
-  real* cframe = MJH_F(B, con_frame, e);
-  real* cmu = MJH_F(B, con_mu, e);
-  int* cpair = MJH_F(B, con_pair, e);
-  int* cgeom = MJH_F(B, con_geom, e);
-  int* cdim = MJH_F(B, con_dim, e);
-  int* cexcl = MJH_F(B, con_exclude, e);
-  int* cefc = MJH_F(B, con_efcadr, e);
   int* warn = MJH_F(B, warning, e);
 
   int base = 0;        // contacts emitted by earlier chunks (wave-uniform)
@@ -248,21 +239,23 @@ MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
       int c = off + k;
       if (c >= s.nconmax) { overflow = 1; continue; }
       // mj_narrowphase fill + mj_setContact, engine_collision_driver.c:2050-2075, :1839-1875
-      cdist[c] = pc[k].dist;
-      v3_copy(cpos + 3*c, pc[k].pos);
+      MJH_CON(B, con_dist, e, 1, c)[0] = pc[k].dist;
+      v3_copy(MJH_CON(B, con_pos, e, 3, c), pc[k].pos);
       real fr[9];
       v3_copy(fr, pc[k].normal);
       v3_copy(fr + 3, pc[k].tangent);
       v3_zero(fr + 6);
       make_frame(fr);
-      for (int q = 0; q < 9; q++) cframe[9*c + q] = fr[q];
-      cpair[c] = p;
-      cgeom[2*c] = M.pair_geom1[p];
-      cgeom[2*c + 1] = M.pair_geom2[p];
-      cdim[c] = M.pair_dim[p];
-      cexcl[c] = (pc[k].dist >= M.pair_includemargin[p]) ? 1 : 0;
-      cefc[c] = -1;
-      cmu[c] = 0;
+      real* cframe = MJH_CON(B, con_frame, e, 9, c);
+      for (int q = 0; q < 9; q++) cframe[q] = fr[q];
+      MJH_CON(B, con_pair, e, 1, c)[0] = p;
+      int* cgeom = MJH_CON(B, con_geom, e, 2, c);
+      cgeom[0] = M.pair_geom1[p];
+      cgeom[1] = M.pair_geom2[p];
+      MJH_CON(B, con_dim, e, 1, c)[0] = M.pair_dim[p];
+      MJH_CON(B, con_exclude, e, 1, c)[0] = (pc[k].dist >= M.pair_includemargin[p]) ? 1 : 0;
+      MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
+      MJH_CON(B, con_mu, e, 1, c)[0] = 0;
     }
     base += total;
   }

@@ -5,6 +5,83 @@
 
 #include "mjh_types.h"
 
+// ------------------------------------------------------------------------------------------------
+// constraint arrays of one environment
+// Their sizes are known only once nefc is: with an LDS plan they are packed, smallest and most
+// latency-critical first, into the dynamic LDS region [dyn_off, lds_bytes) that the plan keeps
+// free from MJH_T_MAKE to MJH_T_CONSTRAINT; whatever does not fit stays in its global home.  The
+// packing is a pure function of (nefc, plan), so every stage recomputes the same pointers.
+// ------------------------------------------------------------------------------------------------
+struct Efc {
+  real *force, *b, *ARinv, *fprev, *fmom, *R, *D, *floss, *aref, *jar, *ARf, *pos, *margin, *KBIP,
+       *diagA, *vel, *sqrtInvD, *AR, *J, *Y;
+  int *order, *state, *type, *id;
+};
+
+// list of (member, global home expression, element count) in packing order
+#define MJH_EFC_REAL_ARRAYS(X)                                       \
+  X(force, MJH_G(B, efc_force, e), nefc)                             \
+  X(b, MJH_G(B, efc_b, e), nefc)                                     \
+  X(ARinv, MJH_G(B, scratch, e), nefc)                               \
+  X(fprev, MJH_G(B, scratch, e) + nmax, nefc)                        \
+  X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc)                       \
+  X(R, MJH_G(B, efc_R, e), nefc)                                     \
+  X(D, MJH_G(B, efc_D, e), nefc)                                     \
+  X(floss, MJH_G(B, efc_frictionloss, e), nefc)                      \
+  X(aref, MJH_G(B, efc_aref, e), nefc)                               \
+  X(jar, MJH_G(B, scratch, e) + 3*nmax, nefc)                        \
+  X(ARf, MJH_G(B, scratch, e) + 4*nmax, nefc)                        \
+  X(pos, MJH_G(B, efc_pos, e), nefc)                                 \
+  X(margin, MJH_G(B, efc_margin, e), nefc)                           \
+  X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc)                             \
+  X(diagA, MJH_G(B, efc_diagA, e), nefc)                             \
+  X(vel, MJH_G(B, efc_vel, e), nefc)                                 \
+  X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, nv)                     \
+  X(AR, MJH_G(B, efc_AR, e), nefc*nefc)                              \
+  X(J, MJH_G(B, efc_J, e), nefc*nv)                                  \
+  X(Y, MJH_G(B, efc_Y, e), nefc*nv)
+#define MJH_EFC_INT_ARRAYS(X)                                        \
+  X(order, MJH_G(B, iscratch, e), nefc)                              \
+  X(state, MJH_G(B, efc_state, e), nefc)                             \
+  X(type, MJH_G(B, efc_type, e), nefc)                               \
+  X(id, MJH_G(B, efc_id, e), nefc)
+
+// returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
+// ints first)
+MJH_DEV unsigned efc_layout(const DModel& M, const DBatch& B, int e, int nefc, Efc& P) {
+  const int nv = M.s.nv, nmax = M.s.nefcmax;
+  int off = B.dyn_off;
+  const int end = B.lds_bytes;
+  unsigned mask = 0, bit = 1;
+  // ints first (tiny), then reals in priority order; an array either fits entirely or stays global
+#define X(m, home, cnt) { int bytes = (int)sizeof(int)*(cnt); \
+    if (off + bytes <= end) { P.m = (int*)(mjh_lds() + off); off += (bytes + 7) & ~7; mask |= bit; } else P.m = (home); bit <<= 1; }
+  MJH_EFC_INT_ARRAYS(X)
+#undef X
+#define X(m, home, cnt) { int bytes = (int)sizeof(real)*(cnt); \
+    if (off + bytes <= end) { P.m = (real*)(mjh_lds() + off); off += bytes; mask |= bit; } else P.m = (home); bit <<= 1; }
+  MJH_EFC_REAL_ARRAYS(X)
+#undef X
+  return mask;
+}
+
+// debug write-back of the LDS-resident constraint arrays to their global homes
+MJH_DEVN void efc_writeback(const DModel& M, const DBatch& B, int e) {
+  const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
+  const int nv = M.s.nv, nmax = M.s.nefcmax;
+  (void)nv; (void)nmax;
+  if (!nefc) return;
+  Efc P;
+  const unsigned mask = efc_layout(M, B, e, nefc, P);
+  unsigned bit = 1;
+#define X(m, home, cnt) { int* g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+  MJH_EFC_INT_ARRAYS(X)
+#undef X
+#define X(m, home, cnt) { real* g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+  MJH_EFC_REAL_ARRAYS(X)
+#undef X
+}
+
 // impedance curve                                  (getimpedance, engine_core_constraint.c:2099)
 MJH_DEV real imp_power(real a, real b) {
   if (b == 1) return a;
@@ -78,6 +155,9 @@ MJH_DEV void set_kbip(real* KBIP, const real* ref, const real* solimp, real imp,
 //          non-contact Jacobian rows.  Phase 3: contact Jacobians, lanes over dof columns.
 // Phase 4: diagApprox + impedance (R, D, KBIP), lanes over constraint blocks.
 // ------------------------------------------------------------------------------------------------
+// one candidate's classification: how many rows it emits and their scalar data
+struct Cand { int nrow, type, id, side; real dist, margin, floss; };
+
 MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
@@ -87,25 +167,6 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   const real* qpos = MJH_F(B, qpos, e);
   const real* ten_length = MJH_F(B, ten_length, e);
   const real* ten_J = MJH_F(B, ten_J, e);
-  real* J = MJH_F(B, efc_J, e);
-  real* epos = MJH_F(B, efc_pos, e);
-  real* emargin = MJH_F(B, efc_margin, e);
-  real* efloss = MJH_F(B, efc_frictionloss, e);
-  real* ediagA = MJH_F(B, efc_diagA, e);
-  real* eKBIP = MJH_F(B, efc_KBIP, e);
-  real* eD = MJH_F(B, efc_D, e);
-  real* eR = MJH_F(B, efc_R, e);
-  int* etype = MJH_F(B, efc_type, e);
-  int* eid = MJH_F(B, efc_id, e);
-  const real* cdist = MJH_F(B, con_dist, e);
-  const real* cposv = MJH_F(B, con_pos, e);
-  const real* cframe = MJH_F(B, con_frame, e);
-  real* cmu = MJH_F(B, con_mu, e);
-  const int* cpair = MJH_F(B, con_pair, e);
-  const int* cgeom = MJH_F(B, con_geom, e);
-  const int* cdim = MJH_F(B, con_dim, e);
-  const int* cexcl = MJH_F(B, con_exclude, e);
-  int* cefc = MJH_F(B, con_efcadr, e);
   const int ncon = counts[MJH_C_NCON];
 
   if (dsbl & (1<<0)) {
@@ -122,126 +183,82 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   const int ncand = c_con + ncon;
   const int ispyramid = (M.o.cone == 0);
 
-  int row_base = 0;     // rows emitted by earlier chunks (wave-uniform)
-  int nf_total = 0, nl_total = 0;
-  int overflow = 0;
-  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
-    int c = c0 + wv_lane();
-    int nrow = 0, type = 0, id = 0, side = 0;
-    real dist = 0, margin = 0, floss = 0;
-    if (c < ncand) {
-      if (c < c_tf) {                       // dof friction loss (mj_instantiateFriction :1270)
-        if (!(dsbl & (1<<2)) && M.dof_frictionloss[c] != 0) {
-          nrow = 1; type = MJH_CNSTR_FRICTION_DOF; id = c; floss = M.dof_frictionloss[c];
+  auto classify = [&](int c, Cand& k) {
+    k.nrow = 0; k.type = 0; k.id = 0; k.side = 0; k.dist = 0; k.margin = 0; k.floss = 0;
+    if (c >= ncand) return;
+    if (c < c_tf) {                       // dof friction loss (mj_instantiateFriction :1270)
+      if (!(dsbl & (1<<2)) && M.dof_frictionloss[c] != 0) {
+        k.nrow = 1; k.type = MJH_CNSTR_FRICTION_DOF; k.id = c; k.floss = M.dof_frictionloss[c];
+      }
+    } else if (c < c_jl) {                // tendon friction loss
+      int t = c - c_tf;
+      if (!(dsbl & (1<<2)) && M.tendon_frictionloss[t] > 0) {
+        // empty-row guard of mj_addConstraint (:431-447): skip all-zero Jacobian rows
+        int nz = 0;
+        for (int q = 0; q < M.ten_J_rownnz[t]; q++) if (ten_J[M.ten_J_rowadr[t] + q] != 0) nz = 1;
+        if (nz) { k.nrow = 1; k.type = MJH_CNSTR_FRICTION_TENDON; k.id = t; k.floss = M.tendon_frictionloss[t]; }
+      }
+    } else if (c < c_tl) {                // joint limits (mj_instantiateLimit :1360)
+      int j = (c - c_jl) >> 1;
+      k.side = ((c - c_jl) & 1) ? 1 : -1;
+      if (!(dsbl & (1<<3)) && M.jnt_limited[j]) {
+        int jt = M.jnt_type[j];
+        k.margin = M.jnt_margin[j];
+        if (jt == MJH_JNT_SLIDE || jt == MJH_JNT_HINGE) {
+          real value = qpos[M.jnt_qposadr[j]];
+          k.dist = k.side * (M.jnt_range[2*j + (k.side+1)/2] - value);
+          if (k.dist < k.margin) { k.nrow = 1; k.type = MJH_CNSTR_LIMIT_JOINT; k.id = j; }
+        } else if (jt == MJH_JNT_BALL && k.side == -1) {
+          int adr = M.jnt_qposadr[j];
+          real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
+          real aa[3];
+          q_normalize(quat);
+          q_tovel(aa, quat, 1);
+          real value = v3_normalize(aa);
+          k.dist = r_max(M.jnt_range[2*j], M.jnt_range[2*j+1]) - value;
+          if (k.dist < k.margin) { k.nrow = 1; k.type = MJH_CNSTR_LIMIT_JOINT; k.id = j; k.side = 0; }
         }
-      } else if (c < c_jl) {                // tendon friction loss
-        int t = c - c_tf;
-        if (!(dsbl & (1<<2)) && M.tendon_frictionloss[t] > 0) {
-          // empty-row guard of mj_addConstraint (:431-447): skip all-zero Jacobian rows
+      }
+    } else if (c < c_con) {               // tendon limits
+      int t = (c - c_tl) >> 1;
+      k.side = ((c - c_tl) & 1) ? 1 : -1;
+      if (!(dsbl & (1<<3)) && M.tendon_limited[t]) {
+        k.margin = M.tendon_margin[t];
+        k.dist = k.side * (M.tendon_range[2*t + (k.side+1)/2] - ten_length[t]);
+        if (k.dist < k.margin) {
           int nz = 0;
-          for (int k = 0; k < M.ten_J_rownnz[t]; k++) if (ten_J[M.ten_J_rowadr[t] + k] != 0) nz = 1;
-          if (nz) { nrow = 1; type = MJH_CNSTR_FRICTION_TENDON; id = t; floss = M.tendon_frictionloss[t]; }
-        }
-      } else if (c < c_tl) {                // joint limits (mj_instantiateLimit :1360)
-        int j = (c - c_jl) >> 1;
-        side = ((c - c_jl) & 1) ? 1 : -1;
-        if (!(dsbl & (1<<3)) && M.jnt_limited[j]) {
-          int jt = M.jnt_type[j];
-          margin = M.jnt_margin[j];
-          if (jt == MJH_JNT_SLIDE || jt == MJH_JNT_HINGE) {
-            real value = qpos[M.jnt_qposadr[j]];
-            dist = side * (M.jnt_range[2*j + (side+1)/2] - value);
-            if (dist < margin) { nrow = 1; type = MJH_CNSTR_LIMIT_JOINT; id = j; }
-          } else if (jt == MJH_JNT_BALL && side == -1) {
-            int adr = M.jnt_qposadr[j];
-            real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
-            real aa[3];
-            q_normalize(quat);
-            q_tovel(aa, quat, 1);
-            real value = v3_normalize(aa);
-            dist = r_max(M.jnt_range[2*j], M.jnt_range[2*j+1]) - value;
-            if (dist < margin) { nrow = 1; type = MJH_CNSTR_LIMIT_JOINT; id = j; side = 0; }
-          }
-        }
-      } else if (c < c_con) {               // tendon limits
-        int t = (c - c_tl) >> 1;
-        side = ((c - c_tl) & 1) ? 1 : -1;
-        if (!(dsbl & (1<<3)) && M.tendon_limited[t]) {
-          margin = M.tendon_margin[t];
-          dist = side * (M.tendon_range[2*t + (side+1)/2] - ten_length[t]);
-          if (dist < margin) {
-            int nz = 0;
-            for (int k = 0; k < M.ten_J_rownnz[t]; k++) if (ten_J[M.ten_J_rowadr[t] + k] != 0) nz = 1;
-            if (nz) { nrow = 1; type = MJH_CNSTR_LIMIT_TENDON; id = t; }
-          }
-        }
-      } else {                              // contacts (mj_instantiateContact :1617)
-        int k = c - c_con;
-        if (!(dsbl & (1<<4)) && !cexcl[k]) {
-          int dim = cdim[k];
-          id = k;
-          dist = cdist[k];
-          margin = M.pair_includemargin[cpair[k]];
-          if (dim == 1) { nrow = 1; type = MJH_CNSTR_CONTACT_FRICTIONLESS; }
-          else if (ispyramid) { nrow = 2*(dim - 1); type = MJH_CNSTR_CONTACT_PYRAMIDAL; }
-          else { nrow = dim; type = MJH_CNSTR_CONTACT_ELLIPTIC; }
+          for (int q = 0; q < M.ten_J_rownnz[t]; q++) if (ten_J[M.ten_J_rowadr[t] + q] != 0) nz = 1;
+          if (nz) { k.nrow = 1; k.type = MJH_CNSTR_LIMIT_TENDON; k.id = t; }
         }
       }
-    }
-    int r0 = row_base + wv_exscan_i(nrow);
-    int total = wv_sum_i(nrow);
-    nf_total += wv_sum_i((type == MJH_CNSTR_FRICTION_DOF || type == MJH_CNSTR_FRICTION_TENDON) ? nrow : 0);
-    nl_total += wv_sum_i((type == MJH_CNSTR_LIMIT_JOINT || type == MJH_CNSTR_LIMIT_TENDON) ? nrow : 0);
-    if (nrow && r0 + nrow > s.nefcmax) { overflow = 1; nrow = 0; }
-    // scalar row data + sparse (non-contact) Jacobian rows
-    for (int k = 0; k < nrow; k++) {
-      int r = r0 + k;
-      etype[r] = type;
-      eid[r] = id;
-      epos[r] = dist;
-      emargin[r] = margin;
-      efloss[r] = floss;
-      if (type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
-        real* Jr = J + (size_t)r*nv;
-        for (int q = 0; q < nv; q++) Jr[q] = 0;
-        if (type == MJH_CNSTR_FRICTION_DOF) {
-          Jr[id] = 1;
-        } else if (type == MJH_CNSTR_LIMIT_JOINT) {
-          if (side == 0) {
-            // ball joint: J = -axis
-            int adr = M.jnt_qposadr[id];
-            real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
-            real aa[3];
-            q_normalize(quat);
-            q_tovel(aa, quat, 1);
-            v3_normalize(aa);
-            int d = M.jnt_dofadr[id];
-            Jr[d] = aa[0]*-1; Jr[d+1] = aa[1]*-1; Jr[d+2] = aa[2]*-1;
-          } else {
-            Jr[M.jnt_dofadr[id]] = -(real)side;
-          }
-        } else {
-          // tendon friction / limit: +-ten_J scattered to dense
-          int a0 = M.ten_J_rowadr[id];
-          for (int q = 0; q < M.ten_J_rownnz[id]; q++) {
-            real v = ten_J[a0 + q];
-            if (type == MJH_CNSTR_LIMIT_TENDON) v = v * (real)(-side);
-            Jr[M.ten_J_colind[a0 + q]] = v;
-          }
-        }
+    } else {                              // contacts (mj_instantiateContact :1617)
+      int kc = c - c_con;
+      if (!(dsbl & (1<<4)) && !MJH_CON(B, con_exclude, e, 1, kc)[0]) {
+        int dim = MJH_CON(B, con_dim, e, 1, kc)[0];
+        k.id = kc;
+        k.dist = MJH_CON(B, con_dist, e, 1, kc)[0];
+        k.margin = M.pair_includemargin[MJH_CON(B, con_pair, e, 1, kc)[0]];
+        if (dim == 1) { k.nrow = 1; k.type = MJH_CNSTR_CONTACT_FRICTIONLESS; }
+        else if (ispyramid) { k.nrow = 2*(dim - 1); k.type = MJH_CNSTR_CONTACT_PYRAMIDAL; }
+        else { k.nrow = dim; k.type = MJH_CNSTR_CONTACT_ELLIPTIC; }
       }
     }
-    if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS && c < ncand && c >= c_con) {
-      cefc[id] = nrow ? r0 : -1;
-    }
-    row_base += total;
+  };
+
+  // ---- pass 1: count rows (the reference's count_only pass, :2833-2860) ---------------------------
+  int nefc = 0, nf_total = 0, nl_total = 0;
+  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
+    Cand k;
+    classify(c0 + wv_lane(), k);
+    nefc += wv_sum_i(k.nrow);
+    nf_total += wv_sum_i((k.type == MJH_CNSTR_FRICTION_DOF || k.type == MJH_CNSTR_FRICTION_TENDON) ? k.nrow : 0);
+    nl_total += wv_sum_i((k.type == MJH_CNSTR_LIMIT_JOINT || k.type == MJH_CNSTR_LIMIT_TENDON) ? k.nrow : 0);
   }
-  overflow = wv_any(overflow);
-  int nefc = row_base;
+  const int overflow = nefc > s.nefcmax;
   if (overflow) {
     // arena-full semantics of the reference (arenaAllocEfc :145-152): no constraints this step
     nefc = 0; nf_total = 0; nl_total = 0;
-    MJH_FOR_LANES(k, ncon) cefc[k] = -1;
+    for (int k = wv_lane(); k < ncon; k += MJH_WAVE) MJH_CON(B, con_efcadr, e, 1, k)[0] = -1;
   }
   if (wv_lane() == 0) {
     if (overflow) warn[MJH_WARN_CNSTRFULL]++;
@@ -253,18 +270,72 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   wv_sync();
   if (nefc == 0) return;
 
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  real* J = P.J;
+
+  // ---- pass 2: scalar row data + sparse (non-contact) Jacobian rows -------------------------------
+  int row_base = 0;     // rows emitted by earlier chunks (wave-uniform)
+  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
+    const int c = c0 + wv_lane();
+    Cand k;
+    classify(c, k);
+    const int r0 = row_base + wv_exscan_i(k.nrow);
+    row_base += wv_sum_i(k.nrow);
+    for (int a = 0; a < k.nrow; a++) {
+      int r = r0 + a;
+      P.type[r] = k.type;
+      P.id[r] = k.id;
+      P.pos[r] = k.dist;
+      P.margin[r] = k.margin;
+      P.floss[r] = k.floss;
+      if (k.type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
+        real* Jr = J + (size_t)r*nv;
+        for (int q = 0; q < nv; q++) Jr[q] = 0;
+        if (k.type == MJH_CNSTR_FRICTION_DOF) {
+          Jr[k.id] = 1;
+        } else if (k.type == MJH_CNSTR_LIMIT_JOINT) {
+          if (k.side == 0) {
+            // ball joint: J = -axis
+            int adr = M.jnt_qposadr[k.id];
+            real quat[4] = {qpos[adr], qpos[adr+1], qpos[adr+2], qpos[adr+3]};
+            real aa[3];
+            q_normalize(quat);
+            q_tovel(aa, quat, 1);
+            v3_normalize(aa);
+            int d = M.jnt_dofadr[k.id];
+            Jr[d] = aa[0]*-1; Jr[d+1] = aa[1]*-1; Jr[d+2] = aa[2]*-1;
+          } else {
+            Jr[M.jnt_dofadr[k.id]] = -(real)k.side;
+          }
+        } else {
+          // tendon friction / limit: +-ten_J scattered to dense
+          int a0 = M.ten_J_rowadr[k.id];
+          for (int q = 0; q < M.ten_J_rownnz[k.id]; q++) {
+            real v = ten_J[a0 + q];
+            if (k.type == MJH_CNSTR_LIMIT_TENDON) v = v * (real)(-k.side);
+            Jr[M.ten_J_colind[a0 + q]] = v;
+          }
+        }
+      }
+    }
+    if (k.type >= MJH_CNSTR_CONTACT_FRICTIONLESS) MJH_CON(B, con_efcadr, e, 1, k.id)[0] = k.nrow ? r0 : -1;
+  }
+  wv_sync();
+
   // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
   const real* cdof = MJH_F(B, cdof, e);
   const real* subtree_com = MJH_F(B, subtree_com, e);
   for (int k = 0; k < ncon; k++) {
-    int r0 = cefc[k];
+    int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     if (r0 < 0) continue;
-    int dim = cdim[k];
-    int b1 = M.geom_bodyid[cgeom[2*k]], b2 = M.geom_bodyid[cgeom[2*k+1]];
+    int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+    const int* cg = MJH_CON(B, con_geom, e, 2, k);
+    int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
     int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
-    const real* point = cposv + 3*k;
-    const real* fr = cframe + 9*k;
-    const real* fri = M.pair_friction + 5*cpair[k];
+    const real* point = MJH_CON(B, con_pos, e, 3, k);
+    const real* fr = MJH_CON(B, con_frame, e, 9, k);
+    const real* fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
     real off1[3], off2[3];
     v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
     v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
@@ -315,7 +386,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   // non-contact rows: one block per row
   const int nnc = nf_total + nl_total;
   MJH_FOR_LANES(r, nnc) {
-    int type = etype[r], id = eid[r];
+    int type = P.type[r], id = P.id[r];
     real solref[2], solimp[5], dA;
     if (type == MJH_CNSTR_FRICTION_DOF) {
       dA = M.dof_invweight0[id];
@@ -334,22 +405,23 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
     }
     fix_solparam(M, solref, solimp);
     real imp, impP;
-    get_impedance(solimp, epos[r], emargin[r], &imp, &impP);
+    get_impedance(solimp, P.pos[r], P.margin[r], &imp, &impP);
     real R = r_max(MJH_MINVAL, (1-imp)*dA/imp);
     int fr_row = (type == MJH_CNSTR_FRICTION_DOF || type == MJH_CNSTR_FRICTION_TENDON);
-    set_kbip(eKBIP + 4*r, solref, solimp, imp, impP, fr_row);
-    eR[r] = R;
-    eD[r] = 1 / R;
-    ediagA[r] = R * imp / (1 - imp);
+    set_kbip(P.KBIP + 4*r, solref, solimp, imp, impP, fr_row);
+    P.R[r] = R;
+    P.D[r] = 1 / R;
+    P.diagA[r] = R * imp / (1 - imp);
   }
   // contact blocks
   MJH_FOR_LANES(k, ncon) {
-    int r0 = cefc[k];
+    int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     if (r0 < 0) continue;
-    int p = cpair[k];
-    int dim = cdim[k];
-    int type = etype[r0];
-    int b1 = M.geom_bodyid[cgeom[2*k]], b2 = M.geom_bodyid[cgeom[2*k+1]];
+    int p = MJH_CON(B, con_pair, e, 1, k)[0];
+    int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+    int type = P.type[r0];
+    const int* cg = MJH_CON(B, con_geom, e, 2, k);
+    int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
     // mj_diagApprox, contact case (:1895-1970)
     real tran = 0, rot = 0;
     tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
@@ -360,7 +432,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
     for (int q = 0; q < 5; q++) solimp[q] = M.pair_solimp[5*p + q];
     fix_solparam(M, solref, solimp);
     real imp, impP;
-    get_impedance(solimp, epos[r0], emargin[r0], &imp, &impP);
+    get_impedance(solimp, P.pos[r0], P.margin[r0], &imp, &impP);
     int nrow = (type == MJH_CNSTR_CONTACT_FRICTIONLESS) ? 1 : (type == MJH_CNSTR_CONTACT_PYRAMIDAL ? 2*(dim-1) : dim);
     for (int a = 0; a < nrow; a++) {
       real dA;
@@ -369,22 +441,22 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
         int jj = a >> 1;
         dA = tran + fri[jj]*fri[jj]*(jj < 2 ? tran : rot);
       } else dA = (a < 3 ? tran : rot);
-      eR[r0 + a] = r_max(MJH_MINVAL, (1-imp)*dA/imp);
-      set_kbip(eKBIP + 4*(r0 + a), solref, solimp, imp, impP, 0);
+      P.R[r0 + a] = r_max(MJH_MINVAL, (1-imp)*dA/imp);
+      set_kbip(P.KBIP + 4*(r0 + a), solref, solimp, imp, impP, 0);
     }
     if (type == MJH_CNSTR_CONTACT_PYRAMIDAL) {
       // (:2213-2253) R[1] = R[0]/impratio; mu = friction[0]*sqrt(R[1]/R[0]); all rows Rpy = 2 mu^2 R[0]
-      real R0 = eR[r0];
+      real R0 = P.R[r0];
       real R1 = R0 / r_max(MJH_MINVAL, M.o.impratio);
       real mu = fri[0] * sqrt(R1/R0);
-      cmu[k] = mu;
+      MJH_CON(B, con_mu, e, 1, k)[0] = mu;
       real Rpy = 2*mu*mu*R0;
-      for (int a = 0; a < nrow; a++) eR[r0 + a] = Rpy;
+      for (int a = 0; a < nrow; a++) P.R[r0 + a] = Rpy;
     }
     for (int a = 0; a < nrow; a++) {
-      real R = eR[r0 + a];
-      eD[r0 + a] = 1 / R;
-      ediagA[r0 + a] = R * imp / (1 - imp);
+      real R = P.R[r0 + a];
+      P.D[r0 + a] = 1 / R;
+      P.diagA[r0 + a] = R * imp / (1 - imp);
     }
   }
   wv_sync();
@@ -400,11 +472,13 @@ MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;
   const real* qLD = MJH_F(B, qLD, e);
-  const real* J = MJH_F(B, efc_J, e);
-  real* Y = MJH_F(B, efc_Y, e);
-  real* AR = MJH_F(B, efc_AR, e);
-  const real* R = MJH_F(B, efc_R, e);
-  real* sqrtInvD = MJH_F(B, scratch, e);
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  const real* J = P.J;
+  real* Y = P.Y;
+  real* AR = P.AR;
+  const real* R = P.R;
+  real* sqrtInvD = P.sqrtInvD;
 
   MJH_FOR_LANES(i, nv) sqrtInvD[i] = 1 / sqrt(qLD[M.M_rowadr[i] + M.M_rownnz[i] - 1]);
   wv_sync();
@@ -452,13 +526,15 @@ MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
   const int nv = M.s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;
-  const real* J = MJH_F(B, efc_J, e);
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  const real* J = P.J;
   const real* qvel = MJH_F(B, qvel, e);
-  const real* KBIP = MJH_F(B, efc_KBIP, e);
-  const real* pos = MJH_F(B, efc_pos, e);
-  const real* margin = MJH_F(B, efc_margin, e);
-  real* vel = MJH_F(B, efc_vel, e);
-  real* aref = MJH_F(B, efc_aref, e);
+  const real* KBIP = P.KBIP;
+  const real* pos = P.pos;
+  const real* margin = P.margin;
+  real* vel = P.vel;
+  real* aref = P.aref;
   MJH_FOR_LANES(r, nefc) {
     real v = dot_ref(J + (size_t)r*nv, qvel, nv);
     vel[r] = v;
@@ -472,14 +548,14 @@ MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
 //                                                  (engine_core_constraint.c:3275-3468)
 // writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV real constraint_update(const DBatch& B, int e, const real* jar, int want_cost) {
+MJH_DEV real constraint_update(const DBatch& B, int e, const Efc& P, const real* jar, int want_cost) {
   const int* counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
-  const real* D = MJH_F(B, efc_D, e);
-  const real* R = MJH_F(B, efc_R, e);
-  const real* floss = MJH_F(B, efc_frictionloss, e);
-  real* force = MJH_F(B, efc_force, e);
-  int* state = MJH_F(B, efc_state, e);
+  const real* D = P.D;
+  const real* R = P.R;
+  const real* floss = P.floss;
+  real* force = P.force;
+  int* state = P.state;
   MJH_FOR_LANES(i, nefc) {
     real f = -D[i]*jar[i];
     int st;

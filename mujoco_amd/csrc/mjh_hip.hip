@@ -63,12 +63,15 @@ struct Backend {
     return hipMemsetAsync(dst, 0, n, (hipStream_t)stream) == hipSuccess;
   }
   static bool sync(void* stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess; }
-  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void* stream) {
-    hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, stages);
+  // largest dynamic LDS block a workgroup may request (gfx950: 160 KB per CU; one workgroup is
+  // allowed 64 KB without opting in, which is already far beyond the useful range here)
+  static int max_lds() { return 64 * 1024; }
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream) {
+    hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, stages);
     return hipGetLastError() == hipSuccess;
   }
-  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, void* stream) {
-    hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, A);
+  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void* stream) {
+    hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, A);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream) {

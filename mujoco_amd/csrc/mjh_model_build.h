@@ -480,6 +480,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int nfric = 0;
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
+  s.nconlds = std::min(s.nconmax, 8);
   int rows_per_con = 1;
   for (int c : H->pair_dim) rows_per_con = std::max(rows_per_con, c == 1 ? 1 : 2*(c-1));
   int nefc_bound = nfric + nlimit + rows_per_con*s.nconmax;

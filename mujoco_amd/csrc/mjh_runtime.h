@@ -15,9 +15,11 @@
 //   static bool zero(void* dst, size_t bytes, void* stream);
 //   static bool sync(void* stream);
 //   (M, B below are DEVICE pointers to the descriptor structs)
-//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void* stream);
-//   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, void* stream);
+//   (lds = bytes of LDS per one-wavefront workgroup demanded by the batch descriptor's plan, 0 = none)
+//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
+//   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, void* stream);
 //   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
+//   static int  max_lds();                       // largest LDS block one workgroup may ask for
 #pragma once
 
 #include <cstdio>
@@ -32,6 +34,12 @@
 #include "mjh_model_build.h"
 #include "mjh_mjb.h"
 #include "mjh_step.h"
+
+#include <algorithm>
+
+#ifndef MJHIP_DEFAULT_LDS_BYTES
+#define MJHIP_DEFAULT_LDS_BYTES 20480   // 8 one-wavefront workgroups per CU (160 KB LDS)
+#endif
 
 static thread_local std::string g_mjhip_err;
 static void set_err(const std::string& e) { g_mjhip_err = e; }
@@ -49,8 +57,11 @@ struct FieldInfo { void* ptr; int count; int is_int; };
 
 struct mjhipBatch_ {
   mjhipModel_* model = nullptr;
-  DBatch D;
+  DBatch D;                    // all-global descriptor (l_* = -1): inspection / debug kernels
   DBatch* D_dev = nullptr;
+  DBatch L;                    // descriptor with the LDS residency plan (rollout / step kernels)
+  DBatch* L_dev = nullptr;
+  std::string plan_report;     // human-readable plan (mjhip_batch_lds_report)
   void* arena = nullptr;
   size_t arena_bytes = 0;
   std::map<std::string, FieldInfo> fields;
@@ -68,6 +79,90 @@ static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, const T** out, s
     return false;
   }
   *out = (const T*)p;
+  return true;
+}
+
+
+// ---- LDS residency plan ---------------------------------------------------------------------------
+// Interval overlay of the per-field lifetimes of mjh_types.h inside a block of `budget` bytes.
+// Fields alive during constraint assembly/solve are packed first from offset 0; the bytes above
+// them form the dynamic region handed to efc_layout().  Fields that die before MJH_T_MAKE may sit
+// anywhere, including on top of that region.  A field that does not fit stays global.
+struct PlanField { const char* name; int* l; int bytes; int t0, t1; int off; };
+
+static bool plan_lds(mjhipBatch_* Bt, int budget, std::string* report) {
+  DBatch& L = Bt->L;
+  L = Bt->D;
+  const DSizes& s = Bt->model->H.s;
+  std::vector<PlanField> f;
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0) \
+    f.push_back(PlanField{#name, &L.l_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
+  MJH_BATCH_REAL_FIELDS(X)
+#undef X
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0) \
+    f.push_back(PlanField{#name, &L.l_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  budget &= ~7;
+  auto live_in = [](const PlanField& a, int t0, int t1) { return a.t0 <= t1 && t0 <= a.t1; };
+  auto place = [&](PlanField& x, int limit) -> bool {
+    // candidate offsets: 0 and the end of every placed field x conflicts with
+    std::vector<int> cand{0};
+    for (auto& y : f) if (y.off >= 0 && live_in(y, x.t0, x.t1)) cand.push_back(y.off + y.bytes);
+    std::sort(cand.begin(), cand.end());
+    for (int c : cand) {
+      if (c + x.bytes > limit) break;
+      bool ok = true;
+      for (auto& y : f) if (y.off >= 0 && live_in(y, x.t0, x.t1) && c < y.off + y.bytes && y.off < c + x.bytes) { ok = false; break; }
+      if (ok) { x.off = c; return true; }
+    }
+    return false;
+  };
+  std::vector<int> order(f.size());
+  for (size_t i = 0; i < f.size(); i++) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    int la = f[a].t1 - f[a].t0, lb = f[b].t1 - f[b].t0;
+    if (la != lb) return la > lb;            // long-lived first
+    return f[a].bytes > f[b].bytes;
+  });
+  bool ok = budget > 0;
+  int dyn_off = 0;
+  // phase A: alive while the constraint arrays are
+  for (int i : order) {
+    PlanField& x = f[i];
+    if (!live_in(x, MJH_T_MAKE, MJH_T_CONSTRAINT)) continue;
+    bool persistent = (x.t0 == MJH_T_BEGIN && x.t1 == MJH_T_END);
+    if (ok && place(x, budget)) dyn_off = std::max(dyn_off, x.off + x.bytes);
+    else if (persistent) ok = false;         // the state itself must fit, else no plan at all
+  }
+  // phase B: everything else, free to overlay the dynamic region (it is dead by MJH_T_MAKE or
+  // born after MJH_T_CONSTRAINT)
+  for (int i : order) {
+    PlanField& x = f[i];
+    if (live_in(x, MJH_T_MAKE, MJH_T_CONSTRAINT)) continue;
+    if (ok) place(x, budget);
+  }
+  char line[256];
+  if (!ok) {
+    L = Bt->D;
+    if (report) *report = "no LDS plan (budget " + std::to_string(budget) + " B): all fields global\n";
+    return false;
+  }
+  for (auto& x : f) *x.l = x.off;
+  L.lds_bytes = budget;
+  L.dyn_off = dyn_off;
+  L.nconlds = s.nconlds;
+  if (report) {
+    report->clear();
+    snprintf(line, sizeof line, "LDS plan: %d B per workgroup, static [0,%d), dynamic constraint region [%d,%d)\n",
+             budget, dyn_off, dyn_off, budget);
+    *report += line;
+    for (auto& x : f) {
+      snprintf(line, sizeof line, "  %-18s %6d B  t[%2d,%2d]  %s%d\n", x.name, x.bytes, x.t0, x.t1,
+               x.off >= 0 ? "lds@" : "global ", x.off);
+      *report += line;
+    }
+  }
   return true;
 }
 
@@ -169,10 +264,10 @@ MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   size_t off = 0;
   auto place = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   std::vector<std::pair<size_t, size_t>> spans;
-#define X(name, cnt) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(real)*nenv), n}); }
+#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(real)*nenv), n}); }
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(int)*nenv), n}); }
+#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(int)*nenv), n}); }
   MJH_BATCH_INT_FIELDS(X)
 #undef X
   Bt->arena_bytes = off;
@@ -185,20 +280,28 @@ MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   Backend::zero(Bt->arena, off, nullptr);
   char* base = (char*)Bt->arena;
   size_t k = 0;
+  memset(&Bt->D, 0, sizeof(DBatch));
   Bt->D.nenv = nenv;
-#define X(name, cnt) Bt->D.name = (real*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
-  Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 0}; k++;
+#define X(name, cnt, lcnt, t0, t1) Bt->D.name = (real*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
+  Bt->D.l_##name = -1; Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 0}; k++;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt) Bt->D.name = (int*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
-  Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 1}; k++;
+#define X(name, cnt, lcnt, t0, t1) Bt->D.name = (int*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
+  Bt->D.l_##name = -1; Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 1}; k++;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
   Bt->D_dev = (DBatch*)Backend::alloc(sizeof(DBatch));
-  if (!Bt->D_dev || !Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr)) {
+  Bt->L_dev = (DBatch*)Backend::alloc(sizeof(DBatch));
+  if (!Bt->D_dev || !Bt->L_dev || !Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr)) {
     set_err("mjhip: device allocation failed (batch descriptor)");
     mjhip_batch_destroy(Bt);
     return nullptr;
+  }
+  // residency plan: MJHIP_LDS_BYTES overrides the default per-workgroup LDS budget (0 disables)
+  {
+    int budget = MJHIP_DEFAULT_LDS_BYTES;
+    if (const char* ev = getenv("MJHIP_LDS_BYTES")) budget = atoi(ev);
+    if (mjhip_batch_plan_lds(Bt, budget) < 0) { mjhip_batch_destroy(Bt); return nullptr; }
   }
   if (mjhip_batch_reset(Bt) != 0) { mjhip_batch_destroy(Bt); return nullptr; }
   return Bt;
@@ -208,10 +311,25 @@ MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
   if (!Bt) return;
   if (Bt->arena) Backend::free(Bt->arena);
   if (Bt->D_dev) Backend::free(Bt->D_dev);
+  if (Bt->L_dev) Backend::free(Bt->L_dev);
   delete Bt;
 }
 
 MJHIP_API int mjhip_batch_nenv(const mjhipBatch* Bt) { return Bt ? Bt->nenv : -1; }
+
+MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
+  if (!Bt) return -1;
+  if (lds_bytes < 0) lds_bytes = 0;
+  if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
+  plan_lds(Bt, lds_bytes, &Bt->plan_report);
+  if (!Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) || !Backend::sync(nullptr)) {
+    set_err("mjhip_batch_plan_lds: descriptor upload failed");
+    return -2;
+  }
+  return Bt->L.lds_bytes ? Bt->L.lds_bytes - Bt->L.dyn_off : 0;
+}
+
+MJHIP_API const char* mjhip_batch_lds_report(const mjhipBatch* Bt) { return Bt ? Bt->plan_report.c_str() : ""; }
 
 MJHIP_API int mjhip_batch_reset(mjhipBatch* Bt) {
   if (!Bt) return -1;
@@ -262,7 +380,13 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* Bt, const char* name, const void* host
 MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt) return -1;
   if (stages < 0) stages = MJH_STAGE_ALL;   // -1: mj_forward
-  if (!Backend::launch_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, stages, stream)) {
+  // MJHIP_STAGE_LDS: run on the LDS residency plan and write every stage's fields back to their
+  // global homes (debug / parity tests of the resident path); default: everything global
+  const bool lds = (stages & MJH_STAGE_LDS) && Bt->L.lds_bytes;
+  stages &= ~(MJH_STAGE_LDS | MJH_STAGE_WRITEBACK);
+  if (lds) stages |= MJH_STAGE_WRITEBACK;
+  if (!Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, stages,
+                               lds ? Bt->L.lds_bytes : 0, stream)) {
     set_err("mjhip_batch_forward: kernel launch failed"); return -2;
   }
   return 0;
@@ -275,7 +399,7 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   A.nstep = nstep;
   A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied
   A.init = 0;
-  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->D_dev, Bt->nenv, A, stream)) {
+  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream)) {
     set_err("mjhip_batch_step: kernel launch failed"); return -2;
   }
   return 0;
@@ -336,7 +460,7 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
     if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
   }
   if (!A.control) { /* no control array: inputs not in the spec stay zero, those in it keep current */ }
-  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->D_dev, Bt->nenv, A, stream)) {
+  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream)) {
     cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4;
   }
   if (!on_device) {

@@ -358,7 +358,8 @@ MJH_DEVN void factor_ld(const DModel& M, real* mat, real* diaginv) {
 MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
   const real* Mq = MJH_F(B, M, e);
   real* qLD = MJH_F(B, qLD, e);
-  MJH_FOR_LANES(k, M.s.nC) qLD[k] = Mq[k];
+  real* Mkeep = MJH_G(B, qH, e);     // M parked in global memory for mj_Euler's qH = M + h*diag(B)
+  MJH_FOR_LANES(k, M.s.nC) { real v = Mq[k]; qLD[k] = v; Mkeep[k] = v; }
   wv_sync();
   factor_ld(M, qLD, MJH_F(B, qLDiagInv, e));
 }

@@ -46,16 +46,16 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
   int* counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
-  const real* AR = MJH_F(B, efc_AR, e);
-  const real* b = MJH_F(B, efc_b, e);
-  const real* floss = MJH_F(B, efc_frictionloss, e);
-  real* force = MJH_F(B, efc_force, e);
-  real* scratch = MJH_F(B, scratch, e);
-  const int nmax = M.s.nefcmax;
-  real* ARinv = scratch;                 // [nefc]
-  real* force_prev = scratch + nmax;     // [nefc]
-  real* force_mom = scratch + 2*nmax;    // [nefc]
-  int* order = MJH_F(B, iscratch, e);    // [nefc] block visitation order (persists across iterations)
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  const real* AR = P.AR;
+  const real* b = P.b;
+  const real* floss = P.floss;
+  real* force = P.force;
+  real* ARinv = P.ARinv;                 // [nefc]
+  real* force_prev = P.fprev;            // [nefc]
+  real* force_mom = P.fmom;              // [nefc]
+  int* order = P.order;                  // [nefc] block visitation order (persists across iterations)
   const int lane = wv_lane();
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
@@ -147,7 +147,7 @@ MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   // final dual state (dualState, :270-345) and iteration count
-  int* state = MJH_F(B, efc_state, e);
+  int* state = P.state;
   MJH_FOR_LANES(i, nefc) {
     int st;
     if (i < ne) st = MJH_STATE_QUADRATIC;
@@ -180,14 +180,15 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
     wv_sync();
     return;
   }
-  const real* J = MJH_F(B, efc_J, e);
-  const real* aref = MJH_F(B, efc_aref, e);
-  const real* AR = MJH_F(B, efc_AR, e);
-  real* eb = MJH_F(B, efc_b, e);
-  real* force = MJH_F(B, efc_force, e);
-  real* scratch = MJH_F(B, scratch, e);
-  real* jar = scratch + 3*s.nefcmax;     // [nefc]
-  real* ARf = scratch + 4*s.nefcmax;     // [nefc]
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  const real* J = P.J;
+  const real* aref = P.aref;
+  const real* AR = P.AR;
+  real* eb = P.b;
+  real* force = P.force;
+  real* jar = P.jar;                     // [nefc]
+  real* ARf = P.ARf;                     // [nefc]
   const real* qws = MJH_F(B, qacc_warmstart, e);
 
   // efc_b = J*qacc_smooth - aref ; jar = J*qacc_warmstart - aref
@@ -201,7 +202,7 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   if (!(M.o.disableflags & (1<<9))) {
-    constraint_update(B, e, jar, 0);        // efc_force(qacc_warmstart), syncs internally
+    constraint_update(B, e, P, jar, 0);        // efc_force(qacc_warmstart), syncs internally
     // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
     MJH_FOR_LANES(r, nefc) ARf[r] = dot_ref(AR + (size_t)r*nefc, force, nefc);
     wv_sync();

@@ -120,6 +120,7 @@ MJH_DEV double wv_shfl(double v, int src) {
   return r;
 }
 MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
+MJH_DEV long long wv_clock() { return 0; }
 
 #else
 // ------------------------------------------------------------------------------------------------
@@ -130,7 +131,7 @@ MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
 #define MJH_DEV __device__ __forceinline__
 // out-of-line device function: gives the big stages their own register allocation scope
 // register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident
-#define MJH_WAVES_PER_EU 4
+#define MJH_WAVES_PER_EU 2
 #define MJH_DEVN __device__ __noinline__ static
 #define MJH_GLOBAL __global__ void
 #define MJH_SHARED __shared__
@@ -163,6 +164,8 @@ MJH_DEV int wv_exscan_i(int v) {
 MJH_DEV double wv_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 MJH_DEV double wv_shfl(double v, int src) { return __shfl(v, src, 64); }
 MJH_DEV int wv_any(int pred) { return __any(pred); }
+// constant-rate (100 MHz) timestamp, for -DMJH_PROFILE builds
+MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 
 #endif  // MJH_HOSTSIM
 

@@ -21,6 +21,8 @@ enum {
   MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint
   MJH_STAGE_ALL        = (1<<9) - 1,
   MJH_STAGE_EULER      = 1<<9,   // mj_Euler + mj_advance (not part of mj_forward; for per-stage runs)
+  MJH_STAGE_LDS        = 1<<21,  // host flag of mjhip_batch_forward: use the LDS residency plan (+ write-back)
+  MJH_STAGE_WRITEBACK  = 1<<20,  // debug: copy LDS-resident fields to their global homes after every stage
 };
 
 // mj_resetData as far as the state vector is concerned (engine_io.c:1289-1420)
@@ -36,7 +38,7 @@ MJH_DEV void reset_env(const DModel& M, const DBatch& B, int e) {
   MJH_FOR_LANES(i, s.na) act[i] = 0;
   real* ctrl = MJH_F(B, ctrl, e);
   MJH_FOR_LANES(i, s.nu) ctrl[i] = 0;
-  real* xf = MJH_F(B, xfrc_applied, e);
+  real* xf = MJH_G(B, xfrc_applied, e);
   MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
   int* warn = MJH_F(B, warning, e);
   if (wv_lane() == 0) {
@@ -61,42 +63,118 @@ MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, const real* x, in
   return bad;
 }
 
+// ---- LDS residency helpers -----------------------------------------------------------------------
+// copy a field between its global home and its LDS slot (no-op for fields the plan left global)
+template <class T>
+MJH_DEV void lds_copy_in(T* g, int n, int l, int e) {
+  if (l < 0) return;
+  T* dst = (T*)(mjh_lds() + l);
+  const T* src = g + (size_t)e*(size_t)n;
+  MJH_FOR_LANES(i, n) dst[i] = src[i];
+}
+template <class T>
+MJH_DEV void lds_copy_out(T* g, int n, int l, int e, int cnt) {
+  if (l < 0) return;
+  const T* src = (const T*)(mjh_lds() + l);
+  T* dst = g + (size_t)e*(size_t)n;
+  MJH_FOR_LANES(i, cnt) dst[i] = src[i];
+}
+
+// kernel entry: persistent state, global home -> LDS
+MJH_DEV void lds_enter(const DModel& M, const DBatch& B, int e) {
+  if (!B.lds_bytes) return;
+  const DSizes& s = M.s;
+  (void)s;
+#define X(name, cnt, lcnt, t0, t1) if ((t0) == MJH_T_BEGIN && (t1) == MJH_T_END) lds_copy_in(B.name, B.n_##name, B.l_##name, e);
+  MJH_BATCH_REAL_FIELDS(X)
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  wv_sync();
+}
+// kernel exit: persistent + exported fields, LDS -> global home
+MJH_DEV void lds_exit(const DModel& M, const DBatch& B, int e) {
+  if (!B.lds_bytes) return;
+  const DSizes& s = M.s;
+  (void)s;
+  wv_sync();
+#define X(name, cnt, lcnt, t0, t1) if ((t1) == MJH_T_END) lds_copy_out(B.name, B.n_##name, B.l_##name, e, (int)(lcnt));
+  MJH_BATCH_REAL_FIELDS(X)
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  wv_sync();
+}
+// debug write-back (tests): after timeline point t, every LDS-resident field live at t is copied to
+// its global home, so the host can inspect intermediates of the LDS path field by field
+MJH_DEVN void lds_writeback(const DModel& M, const DBatch& B, int e, int t) {
+  if (!B.lds_bytes) return;
+  const DSizes& s = M.s;
+  (void)s;
+  wv_sync();
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, e, (int)(lcnt));
+  MJH_BATCH_REAL_FIELDS(X)
+  MJH_BATCH_INT_FIELDS(X)
+#undef X
+  if (t >= MJH_T_MAKE && t <= MJH_T_CONSTRAINT) efc_writeback(M, B, e);
+  wv_sync();
+}
+
 // mj_forwardSkip(mjSTAGE_NONE, skipsensor) restricted by a stage mask   (engine_forward.c:1783-1836)
+// Stages run in the order of the MJH_T_* timeline: the velocity-dependent smooth terms are taken
+// before constraint assembly (none of them reads a constraint quantity), which shortens the LDS
+// lifetimes of the per-body spatial arrays; every stage computes exactly what the reference does.
+#ifdef MJH_PROFILE
+// per-stage wall time of lane 0, accumulated per environment into the global field `prof` (us)
+#define MJH_TIMED(t, call) do { long long c0_ = wv_clock(); call; \
+    if (wv_lane() == 0) MJH_G(B, prof, e)[t] += (real)(wv_clock() - c0_) * 0.01; } while (0)
+#else
+#define MJH_TIMED(t, call) do { call; } while (0)
+#endif
+#define MJH_RUN(t, call) do { MJH_TIMED(t, call); if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, t); } while (0)
 MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
+  const int pgs = (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
-    stage_kinematics(M, B, e);
-    stage_compos(M, B, e);
-    stage_tendon(M, B, e);
+    MJH_RUN(MJH_T_KIN, stage_kinematics(M, B, e));
+    MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
+    MJH_RUN(MJH_T_TENDON, stage_tendon(M, B, e));
   }
   if (stages & MJH_STAGE_INERTIA) {
-    stage_crb(M, B, e);
-    stage_factor_m(M, B, e);
+    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e));
+    MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
   }
-  if (stages & MJH_STAGE_COLLISION) stage_collision(M, B, e);
-  if (stages & MJH_STAGE_MAKE) stage_make_constraint(M, B, e);
-  if ((stages & MJH_STAGE_PROJECT) && M.o.solver == MJH_SOL_PGS) stage_project(M, B, e);
-  if (stages & MJH_STAGE_TRANSMISSION) stage_transmission(M, B, e);
+  if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
+  if (stages & MJH_STAGE_TRANSMISSION) MJH_RUN(MJH_T_TRANSMISSION, stage_transmission(M, B, e));
   if (stages & MJH_STAGE_VELOCITY) {
-    stage_ten_act_velocity(M, B, e);
-    stage_comvel(M, B, e);
-    stage_passive(M, B, e);
-    stage_reference(M, B, e);
-    stage_rne(M, B, e);
+    MJH_RUN(MJH_T_TAVEL, stage_ten_act_velocity(M, B, e));
+    MJH_RUN(MJH_T_COMVEL, stage_comvel(M, B, e));
+    MJH_RUN(MJH_T_PASSIVE, stage_passive(M, B, e));
+    MJH_RUN(MJH_T_RNE, stage_rne(M, B, e));
   }
   if (stages & MJH_STAGE_ACTUATION) {
-    stage_actuation(M, B, e);
-    stage_acceleration(M, B, e);
+    MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));
+    MJH_RUN(MJH_T_ACCEL, stage_acceleration(M, B, e));
   }
-  if (stages & MJH_STAGE_CONSTRAINT) stage_fwd_constraint(M, B, e);
+  if (stages & MJH_STAGE_MAKE) MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
+  if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
+  if (stages & MJH_STAGE_VELOCITY) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
+  if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
 }
 
 MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e);
+// body of the forward kernel (mjhip_batch_forward): stage-masked mj_forward (+ optional Euler step)
 MJH_DEV void forward_or_euler(const DModel& M, const DBatch& B, int e, int stages) {
+  lds_enter(M, B, e);
   forward(M, B, e, stages);
-  if (stages & MJH_STAGE_EULER) euler_advance(M, B, e);
+  if (stages & MJH_STAGE_EULER) {
+    euler_advance(M, B, e);
+    if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, MJH_T_EULER);
+  }
+  lds_exit(M, B, e);
 }
 
 // mj_EulerSkip + mj_advance                        (engine_forward.c:1398-1476, :1261-1395)
+// The implicit-damping matrix qH = M + h*diag(B) is factorised in the slots of qLD/qLDiagInv,
+// which are dead once the constraint solve has produced qacc; M itself was parked in the global
+// field qH by stage_factor_m.
 MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
@@ -104,11 +182,12 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
   real* qvel = MJH_F(B, qvel, e);
   real* qpos = MJH_F(B, qpos, e);
   const real* qacc = MJH_F(B, qacc, e);
-  real* qe = MJH_F(B, scratch, e);          // integrated acceleration [nv]
+  real* qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
 
   if (M.o.euler_damp) {
-    const real* Mq = MJH_F(B, M, e);
-    real* qH = MJH_F(B, qH, e);
+    const real* Mq = MJH_G(B, qH, e);
+    real* qH = MJH_F(B, qLD, e);
+    real* qHDiagInv = MJH_F(B, qLDiagInv, e);
     MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
     wv_sync();
     MJH_FOR_LANES(i, nv) {
@@ -116,12 +195,12 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
       qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
     }
     wv_sync();
-    factor_ld(M, qH, MJH_F(B, qHDiagInv, e));
+    factor_ld(M, qH, qHDiagInv);
     const real* fs = MJH_F(B, qfrc_smooth, e);
     const real* fc = MJH_F(B, qfrc_constraint, e);
     MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
     wv_sync();
-    solve_ld(M, qe, qH, MJH_F(B, qHDiagInv, e));
+    solve_ld(M, qe, qH, qHDiagInv);
   } else {
     MJH_FOR_LANES(i, nv) qe[i] = qacc[i];
     wv_sync();
@@ -159,7 +238,7 @@ MJH_DEV void step_env(const DModel& M, const DBatch& B, int e) {
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
-  euler_advance(M, B, e);
+  MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
 }
 
 // pack FULLPHYSICS state [time, qpos, qvel, act]    (mj_getState, engine_support.c:214)
@@ -204,6 +283,7 @@ struct RolloutArgs {
 MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
   const DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
+  lds_enter(M, B, e);
   if (A.init) {
     if (A.state0) set_state(M, B, e, A.state0 + r*s.nstate);
     real* ws = MJH_F(B, qacc_warmstart, e);
@@ -212,11 +292,12 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
     if (!A.has_ctrl) { real* c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
     if (!A.has_qfrc) { real* f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
-    real* xf = MJH_F(B, xfrc_applied, e);
-    MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
     wv_sync();
   }
   const int* warn = MJH_F(B, warning, e);
+#ifdef MJH_PROFILE
+  const long long c_start = wv_clock();
+#endif
   for (int t = 0; t < A.nstep; t++) {
     // any warning freezes the trajectory: back-fill the rest with the current state (:135-155)
     int nw = 0;
@@ -234,4 +315,17 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
     if (A.state) get_state(M, B, e, A.state + step*s.nstate);
     wv_sync();
   }
+  lds_exit(M, B, e);
+#ifdef MJH_PROFILE
+  if (wv_lane() == 0) {
+    real* pr = MJH_G(B, prof, e);
+    const long long c_end = wv_clock();
+    pr[31] += (real)(c_end - c_start) * 0.01; pr[30] += A.nstep;
+    pr[28] = (real)c_start * 0.01; pr[29] = (real)c_end * 0.01;      // residency census (last launch)
+#ifndef MJH_HOSTSIM
+    pr[27] = (real)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_ID
+    pr[26] = (real)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // XCC_ID
+#endif
+  }
+#endif
 }

@@ -143,6 +143,7 @@ struct DSizes {
   int npair;       // static candidate geom pairs (reference contact order)
   int nmoment;     // capacity of the sparse actuator_moment (sum of per-actuator row capacity)
   int nconmax;     // per-env contact capacity
+  int nconlds;     // contact slots kept in LDS by the residency plan
   int nefcmax;     // per-env constraint-row capacity
   int nstate;      // mj_stateSize(FULLPHYSICS)
 };
@@ -169,90 +170,114 @@ struct DModel {
 };
 
 // ---- batch: per-environment arrays -------------------------------------------------------------
-// X(name, per-env count)
-#define MJH_BATCH_REAL_FIELDS(X)               \
-  X(time, 1)                                   \
-  X(qpos, s.nq)                                \
-  X(qvel, s.nv)                                \
-  X(act, s.na)                                 \
-  X(ctrl, s.nu)                                \
-  X(qfrc_applied, s.nv)                        \
-  X(xfrc_applied, 6 * s.nbody)                 \
-  X(qacc_warmstart, s.nv)                      \
-  X(xpos, 3 * s.nbody)                         \
-  X(xquat, 4 * s.nbody)                        \
-  X(xmat, 9 * s.nbody)                         \
-  X(xipos, 3 * s.nbody)                        \
-  X(ximat, 9 * s.nbody)                        \
-  X(xanchor, 3 * s.njnt)                       \
-  X(xaxis, 3 * s.njnt)                         \
-  X(geom_xpos, 3 * s.ngeom)                    \
-  X(geom_xmat, 9 * s.ngeom)                    \
-  X(site_xpos, 3 * s.nsite)                    \
-  X(site_xmat, 9 * s.nsite)                    \
-  X(subtree_com, 3 * s.nbody)                  \
-  X(cinert, 10 * s.nbody)                      \
-  X(cdof, 6 * s.nv)                            \
-  X(ten_length, s.ntendon)                     \
-  X(ten_J, s.nJten)                            \
-  X(ten_velocity, s.ntendon)                   \
-  X(actuator_length, s.nu)                     \
-  X(actuator_moment, s.nmoment)                \
-  X(actuator_velocity, s.nu)                   \
-  X(actuator_force, s.nu)                      \
-  X(crb, 10 * s.nbody)                         \
-  X(M, s.nC)                                   \
-  X(qLD, s.nC)                                 \
-  X(qLDiagInv, s.nv)                           \
-  X(qH, s.nC)                                  \
-  X(qHDiagInv, s.nv)                           \
-  X(cvel, 6 * s.nbody)                         \
-  X(cdof_dot, 6 * s.nv)                        \
-  X(cacc, 6 * s.nbody)                         \
-  X(cfrc, 6 * s.nbody)                         \
-  X(qfrc_spring, s.nv)                         \
-  X(qfrc_damper, s.nv)                         \
-  X(qfrc_passive, s.nv)                        \
-  X(qfrc_bias, s.nv)                           \
-  X(qfrc_actuator, s.nv)                       \
-  X(qfrc_smooth, s.nv)                         \
-  X(qacc_smooth, s.nv)                         \
-  X(qfrc_constraint, s.nv)                     \
-  X(qacc, s.nv)                                \
-  X(con_dist, s.nconmax)                       \
-  X(con_pos, 3 * s.nconmax)                    \
-  X(con_frame, 9 * s.nconmax)                  \
-  X(con_mu, s.nconmax)                         \
-  X(efc_J, s.nefcmax * s.nv)                   \
-  X(efc_Y, s.nefcmax * s.nv)                   \
-  X(efc_AR, s.nefcmax * s.nefcmax)             \
-  X(efc_pos, s.nefcmax)                        \
-  X(efc_margin, s.nefcmax)                     \
-  X(efc_frictionloss, s.nefcmax)               \
-  X(efc_diagA, s.nefcmax)                      \
-  X(efc_KBIP, 4 * s.nefcmax)                   \
-  X(efc_D, s.nefcmax)                          \
-  X(efc_R, s.nefcmax)                          \
-  X(efc_vel, s.nefcmax)                        \
-  X(efc_aref, s.nefcmax)                       \
-  X(efc_b, s.nefcmax)                          \
-  X(efc_force, s.nefcmax)                      \
-  X(scratch, 8 * s.nefcmax + 8 * s.nv + 64)
+// Residency.  Every field has a global-memory home [nenv][gcnt] (what the C ABI exposes).  A batch
+// can additionally carry an LDS plan: each one-wavefront workgroup owns `lds_bytes` of LDS, and a
+// field with an LDS offset is read and written THERE while it is live; its global home is touched
+// only at kernel boundaries (persistent state) or by the debug write-back.  The plan is computed
+// on the host (mjh_runtime.h: plan_lds) from the lifetimes below by interval overlay: two fields
+// whose lifetimes do not intersect may share LDS bytes.
+//
+// step timeline (the order stages run in; lifetimes are [first write, last read] on this axis)
+enum {
+  MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COMPOS = 2, MJH_T_TENDON = 3, MJH_T_CRB = 4, MJH_T_FACTOR = 5,
+  MJH_T_COLLISION = 6, MJH_T_TRANSMISSION = 7, MJH_T_TAVEL = 8, MJH_T_COMVEL = 9, MJH_T_PASSIVE = 10,
+  MJH_T_RNE = 11, MJH_T_ACTUATION = 12, MJH_T_ACCEL = 13, MJH_T_MAKE = 14, MJH_T_PROJECT = 15,
+  MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17, MJH_T_EULER = 18, MJH_T_END = 19,
+};
+#define MJH_T_GLB (-1)         // global only
+#define MJH_LDS_CON (s.nconlds)  // contact slots kept in LDS (the rest of a contact list is global)
 
-#define MJH_BATCH_INT_FIELDS(X)                \
-  X(counts, 8)        /* ncon, nefc, ne, nf, nl, solver_niter, nisland, - */ \
-  X(warning, 8)       /* per mjtWarning counter (include/mujoco/mjdata.h:74) */ \
-  X(con_pair, s.nconmax)      /* index into the static pair list */ \
-  X(con_geom, 2 * s.nconmax)  \
-  X(con_dim, s.nconmax)       \
-  X(con_exclude, s.nconmax)   \
-  X(con_efcadr, s.nconmax)    \
-  X(moment_rownnz, s.nu)      \
-  X(moment_colind, s.nmoment) \
-  X(efc_type, s.nefcmax)      \
-  X(efc_id, s.nefcmax)        \
-  X(efc_state, s.nefcmax)     \
-  X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64)
+// X(name, global per-env count, LDS count, first, last)
+//   first == MJH_T_BEGIN && last == MJH_T_END : persistent state, loaded from / stored to its
+//   global home at kernel entry / exit; last == MJH_T_END alone: stored at kernel exit (exported)
+#define MJH_BATCH_REAL_FIELDS(X)                                                  \
+  X(time, 1, 1, MJH_T_BEGIN, MJH_T_END)                                           \
+  X(qpos, s.nq, s.nq, MJH_T_BEGIN, MJH_T_END)                                     \
+  X(qvel, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                                     \
+  X(act, s.na, s.na, MJH_T_BEGIN, MJH_T_END)                                      \
+  X(ctrl, s.nu, s.nu, MJH_T_BEGIN, MJH_T_END)                                     \
+  X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \
+  X(qacc_warmstart, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                           \
+  X(xfrc_applied, 6 * s.nbody, 0, MJH_T_GLB, MJH_T_GLB)                           \
+  X(xpos, 3 * s.nbody, 3 * s.nbody, MJH_T_KIN, MJH_T_KIN)                         \
+  X(xquat, 4 * s.nbody, 4 * s.nbody, MJH_T_KIN, MJH_T_KIN)                        \
+  X(xmat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                      \
+  X(xipos, 3 * s.nbody, 3 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                     \
+  X(ximat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                     \
+  X(xanchor, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                     \
+  X(xaxis, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                       \
+  X(geom_xpos, 3 * s.ngeom, 3 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
+  X(geom_xmat, 9 * s.ngeom, 9 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
+  X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_KIN)                    \
+  X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_KIN)                    \
+  X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \
+  X(cinert, 10 * s.nbody, 10 * s.nbody, MJH_T_COMPOS, MJH_T_RNE)                  \
+  X(cdof, 6 * s.nv, 6 * s.nv, MJH_T_COMPOS, MJH_T_MAKE)                           \
+  X(ten_length, s.ntendon, s.ntendon, MJH_T_TENDON, MJH_T_MAKE)                   \
+  X(ten_J, s.nJten, s.nJten, MJH_T_TENDON, MJH_T_MAKE)                            \
+  X(ten_velocity, s.ntendon, s.ntendon, MJH_T_TAVEL, MJH_T_PASSIVE)               \
+  X(actuator_length, s.nu, s.nu, MJH_T_TRANSMISSION, MJH_T_ACTUATION)             \
+  X(actuator_moment, s.nmoment, s.nmoment, MJH_T_TRANSMISSION, MJH_T_ACTUATION)   \
+  X(actuator_velocity, s.nu, s.nu, MJH_T_TAVEL, MJH_T_ACTUATION)                  \
+  X(actuator_force, s.nu, s.nu, MJH_T_ACTUATION, MJH_T_ACTUATION)                 \
+  X(crb, 10 * s.nbody, 10 * s.nbody, MJH_T_CRB, MJH_T_CRB)                        \
+  X(M, s.nC, s.nC, MJH_T_CRB, MJH_T_FACTOR)                                       \
+  X(qLD, s.nC, s.nC, MJH_T_FACTOR, MJH_T_EULER)                                   \
+  X(qLDiagInv, s.nv, s.nv, MJH_T_FACTOR, MJH_T_EULER)                             \
+  X(qH, s.nC, 0, MJH_T_GLB, MJH_T_GLB)                                            \
+  X(cvel, 6 * s.nbody, 6 * s.nbody, MJH_T_COMVEL, MJH_T_RNE)                      \
+  X(cdof_dot, 6 * s.nv, 6 * s.nv, MJH_T_COMVEL, MJH_T_RNE)                        \
+  X(cacc, 6 * s.nbody, 6 * s.nbody, MJH_T_RNE, MJH_T_RNE)                         \
+  X(cfrc, 6 * s.nbody, 6 * s.nbody, MJH_T_RNE, MJH_T_RNE)                         \
+  X(qfrc_spring, s.nv, s.nv, MJH_T_PASSIVE, MJH_T_PASSIVE)                        \
+  X(qfrc_damper, s.nv, s.nv, MJH_T_PASSIVE, MJH_T_PASSIVE)                        \
+  X(qfrc_passive, s.nv, s.nv, MJH_T_PASSIVE, MJH_T_ACCEL)                         \
+  X(qfrc_bias, s.nv, s.nv, MJH_T_RNE, MJH_T_ACCEL)                                \
+  X(qfrc_actuator, s.nv, s.nv, MJH_T_ACTUATION, MJH_T_ACCEL)                      \
+  X(qfrc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_EULER)                            \
+  X(qacc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_CONSTRAINT)                       \
+  X(qfrc_constraint, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_EULER)                   \
+  X(qacc, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_END)                                \
+  X(qe, s.nv, s.nv, MJH_T_EULER, MJH_T_EULER)                                     \
+  X(con_dist, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                \
+  X(con_pos, 3 * s.nconmax, 3 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)         \
+  X(con_frame, 9 * s.nconmax, 9 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)       \
+  X(con_mu, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                  \
+  X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(efc_AR, s.nefcmax * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                       \
+  X(efc_pos, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                  \
+  X(efc_margin, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                               \
+  X(efc_frictionloss, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                         \
+  X(efc_diagA, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  X(efc_KBIP, 4 * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(efc_D, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(efc_R, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(efc_vel, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                  \
+  X(efc_aref, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
+  X(efc_b, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(efc_force, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
+  /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
+  X(prof, 32, 0, MJH_T_GLB, MJH_T_GLB)
+
+#define MJH_BATCH_INT_FIELDS(X)                                                   \
+  /* counts: ncon, nefc, ne, nf, nl, solver_niter, nisland, - */                  \
+  X(counts, 8, 8, MJH_T_COLLISION, MJH_T_END)                                     \
+  /* per mjtWarning counter (include/mujoco/mjdata.h:74) */                       \
+  X(warning, 8, 8, MJH_T_BEGIN, MJH_T_END)                                        \
+  /* con_pair: index into the static pair list */                                 \
+  X(con_pair, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                \
+  X(con_geom, 2 * s.nconmax, 2 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)        \
+  X(con_dim, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                 \
+  X(con_exclude, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)             \
+  X(con_efcadr, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)              \
+  X(moment_rownnz, s.nu, s.nu, MJH_T_TRANSMISSION, MJH_T_ACTUATION)               \
+  X(moment_colind, s.nmoment, s.nmoment, MJH_T_TRANSMISSION, MJH_T_ACTUATION)     \
+  X(efc_type, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
+  X(efc_id, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  X(efc_state, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0
@@ -263,18 +288,53 @@ struct DModel {
 #define MJH_C_NITER 5
 #define MJH_C_NISLAND 6
 
+// name : global home, n_name : per-env element count of the home, l_name : byte offset inside the
+// workgroup's LDS block or -1
 struct DBatch {
   int nenv;
-#define X(name, cnt) real* name; int n_##name;
+  int lds_bytes;     // LDS bytes per one-wavefront workgroup (0: no LDS plan, everything global)
+  int dyn_off;       // [dyn_off, lds_bytes): free during MJH_T_MAKE..MJH_T_CONSTRAINT -> constraint arrays
+  int nconlds;       // contact slots resident in LDS
+#define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt) int* name; int n_##name;
+#define X(name, cnt, lcnt, t0, t1) int* name; int n_##name; int l_##name;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
 };
 
-// pointer to env e's slice of field f
-#define MJH_F(B, f, e) ((B).f + (size_t)(e) * (size_t)(B).n_##f)
+// the workgroup's LDS block
+#ifdef MJH_HOSTSIM
+#define MJH_LDS_MAX (160 * 1024)
+namespace mjhsim { extern thread_local char g_lds[MJH_LDS_MAX]; }
+MJH_DEV char* mjh_lds() { return mjhsim::g_lds; }
+#else
+// The block is the launch's dynamic LDS allocation; the kernels declare no static __shared__
+// data, so it starts at LDS offset 0 and its generic (flat) address is the shared aperture base
+// itself.  Fields are reached through pointers that are LDS or global by plan, hence flat
+// loads/stores throughout; reading the aperture register directly also sidesteps ROCm 7.2's
+// mis-selection of the local->flat cast in divergent code ("V_CMP_NE_U32 0, src_shared_base").
+MJH_DEV char* mjh_lds() {
+  unsigned long long base;
+  asm("s_mov_b64 %0, src_shared_base" : "=s"(base));
+  return (char*)base;
+}
+#endif
+
+template <class T>
+MJH_DEV T* mjh_fp(T* g, int n, int l, int e) {
+  return l >= 0 ? (T*)(mjh_lds() + l) : g + (size_t)e * (size_t)n;
+}
+// pointer to env e's slice of field f (LDS if the plan placed it there, else its global home)
+#define MJH_F(B, f, e) mjh_fp((B).f, (B).n_##f, (B).l_##f, (e))
+// global home of env e's slice, whatever the plan says
+#define MJH_G(B, f, e) ((B).f + (size_t)(e) * (size_t)(B).n_##f)
+// record k (of `stride` elements) of a per-contact field: the first nconlds slots may live in LDS
+template <class T>
+MJH_DEV T* mjh_cp(T* g, int n, int l, int e, int stride, int k, int nconlds) {
+  return (l >= 0 && k < nconlds) ? (T*)(mjh_lds() + l) + stride*k : g + (size_t)e * (size_t)n + stride*k;
+}
+#define MJH_CON(B, f, e, stride, k) mjh_cp((B).f, (B).n_##f, (B).l_##f, (e), (stride), (k), (B).nconlds)
 
 // constraint / contact enums used on device (include/mujoco/mjtype.h)
 enum {

@@ -16,11 +16,13 @@
 
 #include "../../mujoco_amd/csrc/mjh_spmd.h"
 
+#include "../../mujoco_amd/csrc/mjh_types.h"
+
 namespace mjhsim {
 thread_local WaveSim* g_wave = nullptr;
+thread_local char g_lds[MJH_LDS_MAX];     // the emulated workgroup's LDS block
 }
 
-#include "../../mujoco_amd/csrc/mjh_types.h"
 #include "../../mujoco_amd/csrc/mjh_step.h"
 
 namespace {
@@ -86,12 +88,15 @@ struct Backend {
   static bool d2h(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
   static bool zero(void* dst, size_t n, void*) { memset(dst, 0, n); return true; }
   static bool sync(void*) { return true; }
-  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { forward_or_euler(*M, *B, wv_env(), stages); });
+  static int max_lds() { return 64 * 1024; }
+  // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
+  static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void*) {
+    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { forward_or_euler(*M, *B, wv_env(), stages); }); }
     return true;
   }
-  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { rollout_env(*M, *B, wv_env(), A); });
+  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void*) {
+    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { rollout_env(*M, *B, wv_env(), A); }); }
     return true;
   }
   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void*) {

@@ -30,12 +30,12 @@ def load_states(batch, states):
     batch.set("ctrl", np.stack([s["ctrl"] for s in states]))
 
 
-def check_forward(rb, m, batch, states, tol, exact_ints=True):
+def check_forward(rb, m, batch, states, tol, exact_ints=True, lds=False):
     """run forward on the batch, mj_forward on the oracle for every env, compare everything.
     Integer observables (counts, types, ids, contact geoms, efc addresses, solver iterations) must
     match exactly; floats to `tol` relative (tol=0 -> bit-exact)."""
     load_states(batch, states)
-    batch.forward()
+    batch.forward(lds=lds)
     got = {f: batch.get(f) for f in FORWARD_FIELDS + EFC_FIELDS}
     counts = batch.get("counts")
     ints = {f: batch.get(f) for f in ["con_geom", "con_dim", "con_exclude", "con_efcadr", "efc_type", "efc_id", "efc_state"]}

@@ -35,6 +35,38 @@ def test_forward_bit_exact(rb, setup):
     assert worst == 0.0
 
 
+@pytest.mark.parametrize("budget", [4096, 10240, 20480, 65536])
+def test_forward_bit_exact_lds_resident(rb, setup, budget):
+    """the same stages run on the LDS residency plan (what step/rollout use), every field written
+    back after each stage: bit-exact again, for plans from 'almost nothing fits' to 'everything fits'"""
+    m, dm = setup
+    states = contact_rich_states(rb, m, 4, seed=7)
+    b = K.Batch(dm, len(states))
+    left = b.plan_lds(budget)
+    assert left >= 0 and "LDS plan" in b.lds_report()
+    worst = check_forward(rb, m, b, states, tol=0.0, lds=True)
+    assert worst == 0.0
+
+
+@pytest.mark.parametrize("budget", [0, 6144, 12288, 20480])
+def test_rollout_bit_exact_any_lds_budget(setup, golden, budget):
+    m, dm = setup
+    fx = golden("humanoid")
+    b = K.Batch(dm, 3)
+    b.plan_lds(budget)
+    out = b.rollout_host(12, K.mjSTATE_CTRL, fx["state0"][3:6], None, fx["ctrl"][3:6, :12])
+    assert np.array_equal(out, fx["state"][3:6, :12])
+    # closed-loop stepping continues from the state the rollout kernel exported
+    b2 = K.Batch(dm, 3)
+    b2.plan_lds(budget)
+    b2.set("time", fx["state0"][3:6, :1]); b2.set("qpos", fx["state0"][3:6, 1:29]); b2.set("qvel", fx["state0"][3:6, 29:])
+    for t in range(4):
+        b2.set("ctrl", fx["ctrl"][3:6, t])
+        b2.step(1)
+    assert np.array_equal(b2.get("qpos"), fx["state"][3:6, 3, 1:29])
+    assert np.array_equal(b2.get("qvel"), fx["state"][3:6, 3, 29:])
+
+
 def test_rollout_bit_exact_vs_golden(setup, golden):
     m, dm = setup
     fx = golden("humanoid")

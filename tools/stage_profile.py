@@ -1,0 +1,59 @@
+"""Per-stage time of the rollout kernel (needs a library built with -DMJH_PROFILE; see
+tools/gpu_stageprof.sh).  Prints mean microseconds per env-step spent in each timeline stage."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import mujoco_amd as ma
+from bench import initial_states
+
+NAMES = ["begin", "kin", "compos", "tendon", "crb", "factor", "collision", "transmission", "tavel", "comvel",
+         "passive", "rne", "actuation", "accel", "make", "project", "reference", "constraint", "euler", "end"]
+lib = ma.lib()
+model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
+model.set_option("solver", 0)
+dm = ma.DeviceModel(lib, model)
+nenv = int(os.environ.get("NENV", 4096)); K = 100; W = 50
+b = ma.Batch(dm, nenv)
+print(b.lds_report().splitlines()[0])
+s0 = initial_states(b.get("qpos")[0], dm.nv, nenv, 1234)
+rng = np.random.Generator(np.random.PCG64(4321))
+dev = torch.device("cuda", 0)
+st0 = torch.from_numpy(s0).to(dev)
+cw = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, W, dm.nu))).to(dev)
+ck = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, K, dm.nu))).to(dev)
+ws_ptr = b.field_info("qacc_warmstart")[0]
+b.rollout_device(W, ma.mjSTATE_CTRL, st0.data_ptr(), 0, cw.data_ptr(), 0, 0)
+b.sync()
+b.set("prof", np.zeros((nenv, 32)))
+import time
+t0 = time.perf_counter()
+for c in range(0, K, 10):
+    b.rollout_device(10, ma.mjSTATE_CTRL, 0, ws_ptr, ck[:, c:c+10].contiguous().data_ptr(), 0, 0)
+b.sync()
+el = time.perf_counter() - t0
+p = b.get("prof")
+nst = p[:, 30].mean()
+print(f"wall {el*1e3/K:.3f} ms/step -> {nenv*K/el/1e6:.3f} M env-steps/s; in-kernel us per env-step: {p[:,31].mean()/nst:.1f}")
+tot = 0
+for i, n in enumerate(NAMES):
+    v = p[:, i].mean() / nst
+    tot += v
+    if v > 0: print(f"  {n:14s} {v:9.2f} us")
+print(f"  {'sum':14s} {tot:9.2f} us")
+c = b.get("counts")
+print("mean ncon", c[:, 0].mean(), "nefc", c[:, 1].mean(), "pgs iter", c[:, 5].mean())
+
+# residency census of the last launch: how many waves were running at the median time
+st, en = p[:, 28], p[:, 29]
+tm = np.median(np.concatenate([st, en]))
+print("last launch: span %.1f us, mean wave duration %.1f us, waves resident at median time: %d of %d" % (
+    en.max() - st.min(), (en - st).mean(), int(((st <= tm) & (en >= tm)).sum()), nenv))
+hw = p[:, 27].astype(np.int64); xcc = p[:, 26].astype(np.int64) & 0xf
+cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1; simd = (hw >> 4) & 3
+key = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + simd
+u, cnt = np.unique(key, return_counts=True)
+print("distinct (xcc,se,sh,cu,simd):", len(u), " distinct xcc:", len(np.unique(xcc)), " waves per simd: min %d max %d" % (cnt.min(), cnt.max()))
+order = np.argsort(st)
+print("start-time quantiles (us from first):", np.round(np.quantile(st - st.min(), [0, .1, .25, .5, .75, .9, 1]), 1))
