@@ -108,6 +108,7 @@ class Lib:
         "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb", "mjhip_set_option",
         "mjhip_batch_create", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
+        "mjhip_batch_plan_lds", "mjhip_batch_lds_report",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_sync", "mjhip_rollout",
     )
 
