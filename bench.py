@@ -132,7 +132,6 @@ def main() -> None:
     ctrl_k = [torch.from_numpy(crng.uniform(lo, hi, size=(nenv, c, nu))).to(dev) for c in chunks(K)]
     state_k = [None if args.no_state_output else torch.empty((nenv, c, nstate), dtype=torch.float64, device=dev)
                for c in chunks(K)]
-    ws_ptr, _, _ = batch.field_info("qacc_warmstart")
     final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
     gathered = [torch.empty_like(final) for _ in range(world)] if (dist and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
@@ -147,11 +146,11 @@ def main() -> None:
     def launch(ctrl, out, first):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        # first launch loads the initial states; later ones continue (state0 = NULL keeps the
-        # state, warmstart0 = the batch's own qacc_warmstart keeps the solver warm start)
+        # first launch loads the initial states; later ones continue from the batch's own state,
+        # warm start and warning counters (MJHIP_ROLLOUT_CONTINUE)
         batch.rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, state0.data_ptr() if first else 0,
-                             0 if first else ws_ptr, ctrl.data_ptr(),
-                             0 if out is None else out.data_ptr(), stream)
+                             0, ctrl.data_ptr(), 0 if out is None else out.data_ptr(), stream,
+                             cont=not first)
         e1.record()
         events.append((e0, e1, ctrl.shape[1]))
 

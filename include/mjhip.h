@@ -65,6 +65,17 @@ MJHIP_API int mjhip_set_option(struct mjModel_* m, const char* name, double valu
  * Replaces: mj_makeData x nenv (src/engine/engine_io.c) + one mjData per worker thread of
  * python/mujoco/rollout.cc.  All environments start at mj_resetData state (qpos0, zero velocity). */
 MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* model, int nenv, int device);
+/* Explicit device layout of the batch (mjhip_batch_create uses $MJHIP_LAYOUT or the default):
+ *   MJHIP_LAYOUT_AOS  every field [nenv][count]; one wavefront steps one environment through the
+ *                     whole mj_step in a single kernel (LDS-resident working set);
+ *   MJHIP_LAYOUT_SOA  every field [count][nenvpad] (SoA across environments, nenvpad = nenv rounded
+ *                     up to 64); a step is three kernels: the constraint-free stages with one LANE
+ *                     per environment (coalesced, scalar model constants), collision..PGS with one
+ *                     wavefront per environment, then integration with one lane per environment.
+ * Host-side get/set and the rollout arrays are [nenv][...] in both layouts. */
+#define MJHIP_LAYOUT_AOS 0
+#define MJHIP_LAYOUT_SOA 1
+MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* model, int nenv, int device, int layout);
 MJHIP_API void mjhip_batch_destroy(mjhipBatch* batch);
 MJHIP_API int mjhip_batch_nenv(const mjhipBatch* batch);
 MJHIP_API int mjhip_batch_reset(mjhipBatch* batch);   /* mj_resetData for every env */
@@ -92,7 +103,7 @@ MJHIP_API const char* mjhip_batch_lds_report(const mjhipBatch* batch);
  * By default every intermediate is materialised in its global field (inspection); OR-ing
  * MJHIP_STAGE_LDS into `stages` runs the stages on the LDS residency plan, exactly as the
  * step/rollout kernels do, and copies each field back to its global home after every stage. */
-#define MJHIP_STAGE_ALL 0x1ff
+#define MJHIP_STAGE_ALL 0xdff
 #define MJHIP_STAGE_EULER 0x200
 #define MJHIP_STAGE_LDS (1 << 21)
 MJHIP_API int mjhip_batch_forward(mjhipBatch* batch, int stages, void* hip_stream);
@@ -108,7 +119,11 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* batch, int nstep, void* hip_stream);
  *   control     [nenv][nstep][ncontrol]   or NULL; ncontrol = mj_stateSize(control_spec)
  *   state       [nenv][nstep][nstate]     output, or NULL
  * control_spec: mjtState bits; supported: mjSTATE_CTRL | mjSTATE_QFRC_APPLIED.
- * on_device != 0: the four pointers are DEVICE pointers (no PCIe traffic in the call). */
+ * on_device: bit flags.  MJHIP_ROLLOUT_ON_DEVICE: the four pointers are DEVICE pointers (no PCIe
+ * traffic in the call).  MJHIP_ROLLOUT_CONTINUE: keep the batch's current state, warm start and
+ * warning counters instead of loading state0 / warmstart0 (chunked rollouts). */
+#define MJHIP_ROLLOUT_ON_DEVICE 1
+#define MJHIP_ROLLOUT_CONTINUE 2
 MJHIP_API int mjhip_batch_rollout(mjhipBatch* batch, int nstep, unsigned control_spec,
                                   const double* state0, const double* warmstart0,
                                   const double* control, double* state, int on_device,

@@ -23,7 +23,9 @@ STAGE_TRANSMISSION = 1 << 5
 STAGE_VELOCITY = 1 << 6
 STAGE_ACTUATION = 1 << 7
 STAGE_CONSTRAINT = 1 << 8
-STAGE_ALL = (1 << 9) - 1
+STAGE_FINISH = 1 << 10
+STAGE_REFERENCE = 1 << 11
+STAGE_ALL = ((1 << 9) - 1) | STAGE_FINISH | STAGE_REFERENCE
 STAGE_EULER = 1 << 9
 STAGE_LDS = 1 << 21      # run forward() on the LDS residency plan with per-stage write-back (debug)
 
@@ -75,6 +77,8 @@ class Lib:
         lib.mjhip_set_option.argtypes = [vp, C.c_char_p, C.c_double]
         lib.mjhip_batch_create.restype = vp
         lib.mjhip_batch_create.argtypes = [vp, ci, ci]
+        lib.mjhip_batch_create_layout.restype = vp
+        lib.mjhip_batch_create_layout.argtypes = [vp, ci, ci, ci]
         lib.mjhip_batch_destroy.argtypes = [vp]
         lib.mjhip_batch_nenv.restype = ci
         lib.mjhip_batch_nenv.argtypes = [vp]
@@ -106,7 +110,7 @@ class Lib:
     SYMBOLS = (
         "mjhip_backend", "mjhip_last_error", "mjhip_device_count", "mjhip_model_create",
         "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb", "mjhip_set_option",
-        "mjhip_batch_create", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
+        "mjhip_batch_create", "mjhip_batch_create_layout", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_plan_lds", "mjhip_batch_lds_report",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_sync", "mjhip_rollout",
@@ -196,10 +200,16 @@ class DeviceModel:
 class Batch:
     """nenv device-resident environments of one model (mjhip_batch_create)."""
 
-    def __init__(self, model: DeviceModel, nenv: int, device: int = 0):
+    def __init__(self, model: DeviceModel, nenv: int, device: int = 0, layout: Optional[str] = None):
+        """layout: "aos" (one wavefront per env, single kernel), "soa" (lane-per-env pipeline) or
+        None (library default / $MJHIP_LAYOUT)"""
         self._lib = model._lib
         self.model = model
-        h = self._lib.c.mjhip_batch_create(model._h, int(nenv), int(device))
+        if layout is None:
+            h = self._lib.c.mjhip_batch_create(model._h, int(nenv), int(device))
+        else:
+            h = self._lib.c.mjhip_batch_create_layout(model._h, int(nenv), int(device),
+                                                     {"aos": 0, "soa": 1}[layout])
         if not h:
             raise MjhipError(self._lib.error())
         self._h = h
@@ -273,11 +283,12 @@ class Batch:
         return out
 
     def rollout_device(self, nstep: int, control_spec: int, state0_ptr: int, warmstart0_ptr: int,
-                       control_ptr: int, state_ptr: int, stream: int = 0) -> None:
-        """device-pointer rollout (asynchronous on `stream`)."""
+                       control_ptr: int, state_ptr: int, stream: int = 0, cont: bool = False) -> None:
+        """device-pointer rollout (asynchronous on `stream`).  cont=True continues from the batch's
+        current state / warm start / warnings (MJHIP_ROLLOUT_CONTINUE) instead of loading state0."""
         rc = self._lib.c.mjhip_batch_rollout(
             self._h, int(nstep), int(control_spec), state0_ptr or None, warmstart0_ptr or None,
-            control_ptr or None, state_ptr or None, 1, stream or None)
+            control_ptr or None, state_ptr or None, 1 | (2 if cont else 0), stream or None)
         self._lib.check(rc, "rollout")
 
     def close(self):

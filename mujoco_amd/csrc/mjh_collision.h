@@ -8,17 +8,17 @@
 // pair list with its mixed contact parameters (mjh_host.cpp: build_pairs); here each lane takes
 // pairs, applies the reference's bounding-sphere filter and the analytic collider, and the wave
 // compacts the survivors in order with a prefix sum.
-#pragma once
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
-#include "mjh_types.h"
 
 struct PreContact {        // mjPreContact, include/mujoco/mjdata.h:29
   real dist, pos[3], normal[3], tangent[3];
 };
 
 // mjraw_PlaneSphere, engine_collision_primitive.c:28
-MJH_DEV int col_plane_sphere(PreContact* c, real margin, const real* pos1, const real* mat1,
-                             const real* pos2, real radius) {
+template <class P0, class P1, class P2>
+MJH_DEV int col_plane_sphere(PreContact* c, real margin, P0 pos1, P1 mat1,
+                             P2 pos2, real radius) {
   c->normal[0] = mat1[2]; c->normal[1] = mat1[5]; c->normal[2] = mat1[8];
   real tmp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
   real cdist = v3_dot(tmp, c->normal);
@@ -31,8 +31,9 @@ MJH_DEV int col_plane_sphere(PreContact* c, real margin, const real* pos1, const
 }
 
 // mjc_PlaneCapsule, engine_collision_primitive.c:66
-MJH_DEV int col_plane_capsule(PreContact* c, real margin, const real* pos1, const real* mat1,
-                              const real* pos2, const real* mat2, const real* size2) {
+template <class P0, class P1, class P2, class P3, class P4>
+MJH_DEV int col_plane_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
+                              P2 pos2, P3 mat2, P4 size2) {
   real axis[3] = {mat2[2], mat2[5], mat2[8]};
   real seg[3] = {size2[1]*axis[0], size2[1]*axis[1], size2[1]*axis[2]};
   real end[3];
@@ -46,8 +47,9 @@ MJH_DEV int col_plane_capsule(PreContact* c, real margin, const real* pos1, cons
 }
 
 // mjraw_SphereSphere, engine_collision_primitive.c:262
-MJH_DEV int col_sphere_sphere(PreContact* c, real margin, const real* pos1, const real* mat1, real r1,
-                              const real* pos2, const real* mat2, real r2) {
+template <class P0, class P1, class P2, class P3>
+MJH_DEV int col_sphere_sphere(PreContact* c, real margin, P0 pos1, P1 mat1, real r1,
+                              P2 pos2, P3 mat2, real r2) {
   real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
   real cdist_sqr = v3_dot(dif, dif);
   real min_dist = margin + r1 + r2;
@@ -68,8 +70,9 @@ MJH_DEV int col_sphere_sphere(PreContact* c, real margin, const real* pos1, cons
 }
 
 // mjraw_SphereCapsule, engine_collision_primitive.c:313
-MJH_DEV int col_sphere_capsule(PreContact* c, real margin, const real* pos1, const real* mat1, real r1,
-                               const real* pos2, const real* mat2, const real* size2) {
+template <class P0, class P1, class P2, class P3, class P4>
+MJH_DEV int col_sphere_capsule(PreContact* c, real margin, P0 pos1, P1 mat1, real r1,
+                               P2 pos2, P3 mat2, P4 size2) {
   real len = size2[1];
   real axis[3] = {mat2[2], mat2[5], mat2[8]};
   real vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
@@ -80,9 +83,10 @@ MJH_DEV int col_sphere_capsule(PreContact* c, real margin, const real* pos1, con
 }
 
 // mjraw_CapsuleCapsule, engine_collision_primitive.c:425
-MJH_DEV int col_capsule_capsule(PreContact* c, real margin, const real* pos1, const real* mat1,
-                                const real* size1, const real* pos2, const real* mat2,
-                                const real* size2) {
+template <class P0, class P1, class P2, class P3, class P4, class P5>
+MJH_DEV int col_capsule_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
+                                P2 size1, P3 pos2, P4 mat2,
+                                P5 size2) {
   real axis1[3] = {mat1[2]*size1[1], mat1[5]*size1[1], mat1[8]*size1[1]};
   real axis2[3] = {mat2[2]*size2[1], mat2[5]*size2[1], mat2[8]*size2[1]};
   real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
@@ -149,7 +153,8 @@ MJH_DEV int col_capsule_capsule(PreContact* c, real margin, const real* pos1, co
 }
 
 // complete a contact frame from its normal (+ optional tangent)   (mju_makeFrame, engine_util_spatial.c:512)
-MJH_DEV void make_frame(real* frame) {
+template <class P0>
+MJH_DEV void make_frame(P0 frame) {
   v3_normalize(frame);
   if (v3_dot(frame + 3, frame + 3) < 0.25) {
     v3_zero(frame + 3);
@@ -164,24 +169,25 @@ MJH_DEV void make_frame(real* frame) {
 }
 
 // mj_filterSphere, engine_collision_driver.c:267: 1 = cull
-MJH_DEV int filter_sphere(const DModel& M, const real* gx, const real* gm, int g1, int g2, real margin) {
+template <class P0, class P1>
+MJH_DEV int filter_sphere(const DModel& M, P0 gx, P1 gm, int g1, int g2, real margin) {
   real rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
   if (rb1 > 0 && rb2 > 0) {
-    const real* p1 = gx + 3*g1; const real* p2 = gx + 3*g2;
+    crptr p1 = gx + 3*g1; crptr p2 = gx + 3*g2;
     real bound = rb1 + rb2 + margin;
     real dif[3] = {p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2]};
     real d2 = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2];
     return d2 > bound*bound;
   }
   if (M.geom_type[g1] == MJH_GEOM_PLANE && rb2 > 0) {
-    const real* m1 = gm + 9*g1;
+    crptr m1 = gm + 9*g1;
     real nrm[3] = {m1[2], m1[5], m1[8]};
     real dif[3];
     v3_sub(dif, gx + 3*g2, gx + 3*g1);
     if (v3_dot(dif, nrm) > margin + rb2) return 1;
   }
   if (M.geom_type[g2] == MJH_GEOM_PLANE && rb1 > 0) {
-    const real* m2 = gm + 9*g2;
+    crptr m2 = gm + 9*g2;
     real nrm[3] = {m2[2], m2[5], m2[8]};
     real dif[3];
     v3_sub(dif, gx + 3*g1, gx + 3*g2);
@@ -195,20 +201,20 @@ MJH_DEV int filter_sphere(const DModel& M, const real* gx, const real* gm, int g
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  int* counts = MJH_F(B, counts, e);
+  iptr counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;
   if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || s.npair == 0) {
     if (wv_lane() == 0) counts[MJH_C_NCON] = 0;
     wv_sync();
     return;
   }
-  const real* gx = MJH_F(B, geom_xpos, e);
-  const real* gm = MJH_F(B, geom_xmat, e);
-  int* warn = MJH_F(B, warning, e);
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  iptr warn = MJH_F(B, warning, e);
 
   int base = 0;        // contacts emitted by earlier chunks (wave-uniform)
   int overflow = 0;
-  for (int p0 = 0; p0 < s.npair; p0 += MJH_WAVE) {
+  for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
     int p = p0 + wv_lane();
     PreContact pc[2];
     int n = 0;
@@ -216,8 +222,8 @@ MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
       int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
       real margin = M.pair_margin[p];       // margin + gap: collider threshold
       if (!filter_sphere(M, gx, gm, g1, g2, margin)) {
-        const real* pos1 = gx + 3*g1; const real* mat1 = gm + 9*g1; const real* size1 = M.geom_size + 3*g1;
-        const real* pos2 = gx + 3*g2; const real* mat2 = gm + 9*g2; const real* size2 = M.geom_size + 3*g2;
+        crptr pos1 = gx + 3*g1; crptr mat1 = gm + 9*g1; const real* size1 = M.geom_size + 3*g1;
+        crptr pos2 = gx + 3*g2; crptr mat2 = gm + 9*g2; const real* size2 = M.geom_size + 3*g2;
         switch (M.pair_func[p]) {
           case MJH_COL_PLANE_SPHERE:
             n = col_plane_sphere(pc, margin, pos1, mat1, pos2, size2[0]); break;
@@ -246,10 +252,10 @@ MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
       v3_copy(fr + 3, pc[k].tangent);
       v3_zero(fr + 6);
       make_frame(fr);
-      real* cframe = MJH_CON(B, con_frame, e, 9, c);
+      rptr cframe = MJH_CON(B, con_frame, e, 9, c);
       for (int q = 0; q < 9; q++) cframe[q] = fr[q];
       MJH_CON(B, con_pair, e, 1, c)[0] = p;
-      int* cgeom = MJH_CON(B, con_geom, e, 2, c);
+      iptr cgeom = MJH_CON(B, con_geom, e, 2, c);
       cgeom[0] = M.pair_geom1[p];
       cgeom[1] = M.pair_geom2[p];
       MJH_CON(B, con_dim, e, 1, c)[0] = M.pair_dim[p];

@@ -1,9 +1,8 @@
 // Constraint assembly stages: mj_makeConstraint, mj_projectConstraint (Y, AR), mj_referenceConstraint,
 // mj_constraintUpdate -- dense Jacobian, pyramidal/frictionless contacts, joint/tendon limits,
 // dof/tendon friction loss.  One wavefront per environment.  (reference: engine_core_constraint.c)
-#pragma once
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
-#include "mjh_types.h"
 
 // ------------------------------------------------------------------------------------------------
 // constraint arrays of one environment
@@ -13,9 +12,9 @@
 // packing is a pure function of (nefc, plan), so every stage recomputes the same pointers.
 // ------------------------------------------------------------------------------------------------
 struct Efc {
-  real *force, *b, *ARinv, *fprev, *fmom, *R, *D, *floss, *aref, *jar, *ARf, *pos, *margin, *KBIP,
-       *diagA, *vel, *sqrtInvD, *AR, *J, *Y;
-  int *order, *state, *type, *id;
+  rptr force, b, ARinv, fprev, fmom, R, D, floss, aref, jar, ARf, pos, margin, KBIP,
+       diagA, vel, sqrtInvD, AR, J, Y;
+  iptr order, state, type, id;
 };
 
 // list of (member, global home expression, element count) in packing order
@@ -55,11 +54,11 @@ MJH_DEV unsigned efc_layout(const DModel& M, const DBatch& B, int e, int nefc, E
   unsigned mask = 0, bit = 1;
   // ints first (tiny), then reals in priority order; an array either fits entirely or stays global
 #define X(m, home, cnt) { int bytes = (int)sizeof(int)*(cnt); \
-    if (off + bytes <= end) { P.m = (int*)(mjh_lds() + off); off += (bytes + 7) & ~7; mask |= bit; } else P.m = (home); bit <<= 1; }
+    if (off + bytes <= end) { P.m = iptr{(int*)(mjh_lds() + off), 1}; off += (bytes + 7) & ~7; mask |= bit; } else P.m = (home); bit <<= 1; }
   MJH_EFC_INT_ARRAYS(X)
 #undef X
 #define X(m, home, cnt) { int bytes = (int)sizeof(real)*(cnt); \
-    if (off + bytes <= end) { P.m = (real*)(mjh_lds() + off); off += bytes; mask |= bit; } else P.m = (home); bit <<= 1; }
+    if (off + bytes <= end) { P.m = rptr{(real*)(mjh_lds() + off), 1}; off += bytes; mask |= bit; } else P.m = (home); bit <<= 1; }
   MJH_EFC_REAL_ARRAYS(X)
 #undef X
   return mask;
@@ -74,10 +73,10 @@ MJH_DEVN void efc_writeback(const DModel& M, const DBatch& B, int e) {
   Efc P;
   const unsigned mask = efc_layout(M, B, e, nefc, P);
   unsigned bit = 1;
-#define X(m, home, cnt) { int* g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+#define X(m, home, cnt) { iptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_INT_ARRAYS(X)
 #undef X
-#define X(m, home, cnt) { real* g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+#define X(m, home, cnt) { rptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_REAL_ARRAYS(X)
 #undef X
 }
@@ -88,7 +87,8 @@ MJH_DEV real imp_power(real a, real b) {
   if (b == 2) return a*a;
   return pow(a, b);
 }
-MJH_DEV void get_impedance(const real* solimp, real pos, real margin, real* imp, real* impP) {
+template <class P0, class P1, class P2>
+MJH_DEV void get_impedance(P0 solimp, real pos, real margin, P1 imp, P2 impP) {
   if (solimp[0] == solimp[1] || solimp[2] <= MJH_MINVAL) {
     *imp = 0.5*(solimp[0] + solimp[1]);
     *impP = 0;
@@ -120,7 +120,8 @@ MJH_DEV void get_impedance(const real* solimp, real pos, real margin, real* imp,
 
 // sanitise solref/solimp                           (getsolparam tail, engine_core_constraint.c:2019-2047)
 // (mixed-sign solref is rejected at model upload, so only the clamps remain)
-MJH_DEV void fix_solparam(const DModel& M, real* solref, real* solimp) {
+template <class P0, class P1>
+MJH_DEV void fix_solparam(const DModel& M, P0 solref, P1 solimp) {
   if (!(M.o.disableflags & (1<<12)) && solref[0] > 0) solref[0] = r_max(solref[0], 2*M.o.timestep);
   solimp[0] = r_min(0.9999, r_max(0.0001, solimp[0]));
   solimp[1] = r_min(0.9999, r_max(0.0001, solimp[1]));
@@ -130,7 +131,8 @@ MJH_DEV void fix_solparam(const DModel& M, real* solref, real* solimp) {
 }
 
 // K, B, I, P of one row                            (mj_makeImpedance body, engine_core_constraint.c:2170-2207)
-MJH_DEV void set_kbip(real* KBIP, const real* ref, const real* solimp, real imp, real impP, int friction_row) {
+template <class P0, class P1, class P2>
+MJH_DEV void set_kbip(P0 KBIP, P1 ref, P2 solimp, real imp, real impP, int friction_row) {
   if (friction_row) {
     KBIP[0] = 0;
   } else if (ref[0] > 0) {
@@ -161,12 +163,12 @@ struct Cand { int nrow, type, id, side; real dist, margin, floss; };
 MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
-  int* counts = MJH_F(B, counts, e);
-  int* warn = MJH_F(B, warning, e);
+  iptr counts = MJH_F(B, counts, e);
+  iptr warn = MJH_F(B, warning, e);
   const int dsbl = M.o.disableflags;
-  const real* qpos = MJH_F(B, qpos, e);
-  const real* ten_length = MJH_F(B, ten_length, e);
-  const real* ten_J = MJH_F(B, ten_J, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  crptr ten_length = MJH_F(B, ten_length, e);
+  crptr ten_J = MJH_F(B, ten_J, e);
   const int ncon = counts[MJH_C_NCON];
 
   if (dsbl & (1<<0)) {
@@ -247,7 +249,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
 
   // ---- pass 1: count rows (the reference's count_only pass, :2833-2860) ---------------------------
   int nefc = 0, nf_total = 0, nl_total = 0;
-  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
+  for (int c0 = 0; c0 < ncand; c0 += MJH_W) {
     Cand k;
     classify(c0 + wv_lane(), k);
     nefc += wv_sum_i(k.nrow);
@@ -258,7 +260,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   if (overflow) {
     // arena-full semantics of the reference (arenaAllocEfc :145-152): no constraints this step
     nefc = 0; nf_total = 0; nl_total = 0;
-    for (int k = wv_lane(); k < ncon; k += MJH_WAVE) MJH_CON(B, con_efcadr, e, 1, k)[0] = -1;
+    for (int k = wv_lane(); k < ncon; k += MJH_W) MJH_CON(B, con_efcadr, e, 1, k)[0] = -1;
   }
   if (wv_lane() == 0) {
     if (overflow) warn[MJH_WARN_CNSTRFULL]++;
@@ -272,11 +274,11 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
 
   Efc P;
   efc_layout(M, B, e, nefc, P);
-  real* J = P.J;
+  rptr J = P.J;
 
   // ---- pass 2: scalar row data + sparse (non-contact) Jacobian rows -------------------------------
   int row_base = 0;     // rows emitted by earlier chunks (wave-uniform)
-  for (int c0 = 0; c0 < ncand; c0 += MJH_WAVE) {
+  for (int c0 = 0; c0 < ncand; c0 += MJH_W) {
     const int c = c0 + wv_lane();
     Cand k;
     classify(c, k);
@@ -290,7 +292,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
       P.margin[r] = k.margin;
       P.floss[r] = k.floss;
       if (k.type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
-        real* Jr = J + (size_t)r*nv;
+        rptr Jr = J + (size_t)r*nv;
         for (int q = 0; q < nv; q++) Jr[q] = 0;
         if (k.type == MJH_CNSTR_FRICTION_DOF) {
           Jr[k.id] = 1;
@@ -324,17 +326,17 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
-  const real* cdof = MJH_F(B, cdof, e);
-  const real* subtree_com = MJH_F(B, subtree_com, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr subtree_com = MJH_F(B, subtree_com, e);
   for (int k = 0; k < ncon; k++) {
     int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     if (r0 < 0) continue;
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
-    const int* cg = MJH_CON(B, con_geom, e, 2, k);
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
     int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
     int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
-    const real* point = MJH_CON(B, con_pos, e, 3, k);
-    const real* fr = MJH_CON(B, con_frame, e, 9, k);
+    crptr point = MJH_CON(B, con_pos, e, 3, k);
+    crptr fr = MJH_CON(B, con_frame, e, 9, k);
     const real* fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
     real off1[3], off2[3];
     v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
@@ -344,7 +346,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
       int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
       int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
       real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
-      const real* cd = cdof + 6*j;
+      crptr cd = cdof + 6*j;
       if (in1) {
         real t[3];
         v3_cross(t, cd, off1);
@@ -420,7 +422,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
     int p = MJH_CON(B, con_pair, e, 1, k)[0];
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     int type = P.type[r0];
-    const int* cg = MJH_CON(B, con_geom, e, 2, k);
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
     int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
     // mj_diagApprox, contact case (:1895-1970)
     real tran = 0, rot = 0;
@@ -471,21 +473,21 @@ MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
   const int nv = s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;
-  const real* qLD = MJH_F(B, qLD, e);
+  crptr qLD = MJH_F(B, qLD, e);
   Efc P;
   efc_layout(M, B, e, nefc, P);
-  const real* J = P.J;
-  real* Y = P.Y;
-  real* AR = P.AR;
-  const real* R = P.R;
-  real* sqrtInvD = P.sqrtInvD;
+  crptr J = P.J;
+  rptr Y = P.Y;
+  rptr AR = P.AR;
+  crptr R = P.R;
+  rptr sqrtInvD = P.sqrtInvD;
 
   MJH_FOR_LANES(i, nv) sqrtInvD[i] = 1 / sqrt(qLD[M.M_rowadr[i] + M.M_rownnz[i] - 1]);
   wv_sync();
   // one lane per row: half back-substitution (mj_solveM2, engine_core_smooth.c:2130)
   MJH_FOR_LANES(r, nefc) {
-    real* x = Y + (size_t)r*nv;
-    const real* y = J + (size_t)r*nv;
+    rptr x = Y + (size_t)r*nv;
+    crptr y = J + (size_t)r*nv;
     for (int i = 0; i < nv; i++) x[i] = y[i];
     for (int i = nv - 1; i > 0; i--) {
       if (M.dof_simplenum[i]) continue;
@@ -505,8 +507,9 @@ MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
     while (i*(i+1)/2 > w) i--;
     while ((i+1)*(i+2)/2 <= w) i++;
     int k = w - i*(i+1)/2;
-    const real* Yi = Y + (size_t)i*nv;
-    const real* Yk = Y + (size_t)k*nv;
+    // (lane mode runs this loop serially; it is only reached there on the rare reset-and-redo path)
+    crptr Yi = Y + (size_t)i*nv;
+    crptr Yk = Y + (size_t)k*nv;
     real acc = 0;
     for (int j = 0; j < nv; j++) {
       real t = Yi[j];
@@ -528,13 +531,13 @@ MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
   if (!nefc) return;
   Efc P;
   efc_layout(M, B, e, nefc, P);
-  const real* J = P.J;
-  const real* qvel = MJH_F(B, qvel, e);
-  const real* KBIP = P.KBIP;
-  const real* pos = P.pos;
-  const real* margin = P.margin;
-  real* vel = P.vel;
-  real* aref = P.aref;
+  crptr J = P.J;
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr KBIP = P.KBIP;
+  crptr pos = P.pos;
+  crptr margin = P.margin;
+  rptr vel = P.vel;
+  rptr aref = P.aref;
   MJH_FOR_LANES(r, nefc) {
     real v = dot_ref(J + (size_t)r*nv, qvel, nv);
     vel[r] = v;
@@ -548,14 +551,15 @@ MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
 //                                                  (engine_core_constraint.c:3275-3468)
 // writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV real constraint_update(const DBatch& B, int e, const Efc& P, const real* jar, int want_cost) {
-  const int* counts = MJH_F(B, counts, e);
+template <class P0>
+MJH_DEV real constraint_update(const DBatch& B, int e, const Efc& P, P0 jar, int want_cost) {
+  ciptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
-  const real* D = P.D;
-  const real* R = P.R;
-  const real* floss = P.floss;
-  real* force = P.force;
-  int* state = P.state;
+  crptr D = P.D;
+  crptr R = P.R;
+  crptr floss = P.floss;
+  rptr force = P.force;
+  iptr state = P.state;
   MJH_FOR_LANES(i, nefc) {
     real f = -D[i]*jar[i];
     int st;

@@ -13,26 +13,46 @@
 
 #include <string>
 
-#include "mjh_spmd.h"
-#include "mjh_types.h"
-#include "mjh_step.h"
+#include "mjh_modes.h"
 
 // The model / batch descriptors (tables of device pointers, ~1 KB each) live in device memory and
 // are read through the scalar cache on demand; passing them by value made the compiler hoist
 // every pointer into SGPRs for the whole kernel (hundreds of spills).
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_forward(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, int stages) {
-  forward_or_euler(*M, *B, (int)blockIdx.x, stages);
+  wv::forward_or_euler(*M, *B, (int)blockIdx.x, stages);
 }
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_rollout(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, RolloutArgs A) {
-  rollout_env(*M, *B, (int)blockIdx.x, A);
+  wv::rollout_env(*M, *B, (int)blockIdx.x, A);
 }
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_reset(const DModel* __restrict__ M,
                                                         const DBatch* __restrict__ B) {
-  reset_env(*M, *B, (int)blockIdx.x);
+  wv::reset_env(*M, *B, (int)blockIdx.x);
+}
+
+// ---- lane-mode kernels of the SoA pipeline: one lane per environment, epw environments per wavefront
+#define MJH_LANE_KERNEL __global__ __launch_bounds__(MJH_WAVE)
+#define MJH_LANE_ENV() const int lane_ = (int)threadIdx.x; if (lane_ >= epw) return; \
+                       const int e = (int)blockIdx.x * epw + lane_; if (e >= B->nenv) return;
+
+MJH_LANE_KERNEL void mjh_k_smooth(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A, int epw) {
+  MJH_LANE_ENV();
+  ln::smooth_env(*M, *B, e, A);
+}
+MJH_LANE_KERNEL void mjh_k_integrate(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A, int epw) {
+  MJH_LANE_ENV();
+  ln::integrate_env(*M, *B, e, A);
+}
+MJH_LANE_KERNEL void mjh_k_lane_forward(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages, int epw) {
+  MJH_LANE_ENV();
+  ln::forward_or_euler(*M, *B, e, stages);
+}
+MJH_LANE_KERNEL void mjh_k_lane_reset(const DModel* __restrict__ M, const DBatch* __restrict__ B, int epw) {
+  MJH_LANE_ENV();
+  ln::reset_env(*M, *B, e);
 }
 
 struct Backend {
@@ -72,6 +92,23 @@ struct Backend {
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void* stream) {
     hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, A);
+    return hipGetLastError() == hipSuccess;
+  }
+  static dim3 lane_grid(int nenv, int epw) { return dim3((nenv + epw - 1) / epw); }
+  static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {
+    hipLaunchKernelGGL(mjh_k_smooth, lane_grid(nenv, epw), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, A, epw);
+    return hipGetLastError() == hipSuccess;
+  }
+  static bool launch_integrate(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {
+    hipLaunchKernelGGL(mjh_k_integrate, lane_grid(nenv, epw), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, A, epw);
+    return hipGetLastError() == hipSuccess;
+  }
+  static bool launch_lane_forward(const DModel* M, const DBatch* B, int nenv, int epw, int stages, void* stream) {
+    hipLaunchKernelGGL(mjh_k_lane_forward, lane_grid(nenv, epw), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, stages, epw);
+    return hipGetLastError() == hipSuccess;
+  }
+  static bool launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int epw, void* stream) {
+    hipLaunchKernelGGL(mjh_k_lane_reset, lane_grid(nenv, epw), dim3(MJH_WAVE), 0, (hipStream_t)stream, M, B, epw);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream) {

@@ -14,20 +14,47 @@
 
 typedef double real;
 
-MJH_DEV void v3_zero(real* r) { r[0] = 0; r[1] = 0; r[2] = 0; }
-MJH_DEV void v3_copy(real* r, const real* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
-MJH_DEV void v3_scl(real* r, const real* a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
-MJH_DEV void v3_add(real* r, const real* a, const real* b) { r[0] = a[0]+b[0]; r[1] = a[1]+b[1]; r[2] = a[2]+b[2]; }
-MJH_DEV void v3_sub(real* r, const real* a, const real* b) { r[0] = a[0]-b[0]; r[1] = a[1]-b[1]; r[2] = a[2]-b[2]; }
-MJH_DEV void v3_addto(real* r, const real* a) { r[0] += a[0]; r[1] += a[1]; r[2] += a[2]; }
-MJH_DEV void v3_subfrom(real* r, const real* a) { r[0] -= a[0]; r[1] -= a[1]; r[2] -= a[2]; }
+// strided view of a vector: element i lives at p[i*s].  Every per-environment array of the batch is
+// handed to the stage code as one of these, so the same stage source runs on environment-major
+// data (s = 1; also LDS-resident slices) and on SoA-across-environments data (s = nenvpad).
+template <class T>
+struct SP {
+  T* p;
+  int s;
+  template <class I> MJH_MEM T& operator[](I i) const { return p[(long long)i * s]; }
+  template <class I> MJH_MEM SP operator+(I k) const { return SP{p + (long long)k * s, s}; }
+  MJH_MEM operator SP<const T>() const { return SP<const T>{p, s}; }
+};
+typedef SP<real> rptr;
+typedef SP<const real> crptr;
+typedef SP<int> iptr;
+typedef SP<const int> ciptr;
+
+template <class P0>
+MJH_DEV void v3_zero(P0 r) { r[0] = 0; r[1] = 0; r[2] = 0; }
+template <class P0, class P1>
+MJH_DEV void v3_copy(P0 r, P1 a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+template <class P0, class P1>
+MJH_DEV void v3_scl(P0 r, P1 a, real s) { r[0] = a[0]*s; r[1] = a[1]*s; r[2] = a[2]*s; }
+template <class P0, class P1, class P2>
+MJH_DEV void v3_add(P0 r, P1 a, P2 b) { r[0] = a[0]+b[0]; r[1] = a[1]+b[1]; r[2] = a[2]+b[2]; }
+template <class P0, class P1, class P2>
+MJH_DEV void v3_sub(P0 r, P1 a, P2 b) { r[0] = a[0]-b[0]; r[1] = a[1]-b[1]; r[2] = a[2]-b[2]; }
+template <class P0, class P1>
+MJH_DEV void v3_addto(P0 r, P1 a) { r[0] += a[0]; r[1] += a[1]; r[2] += a[2]; }
+template <class P0, class P1>
+MJH_DEV void v3_subfrom(P0 r, P1 a) { r[0] -= a[0]; r[1] -= a[1]; r[2] -= a[2]; }
 // r += a*s                                     (mji_addToScl3, engine_inline.h:108)
-MJH_DEV void v3_addtoscl(real* r, const real* a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
+template <class P0, class P1>
+MJH_DEV void v3_addtoscl(P0 r, P1 a, real s) { r[0] += a[0]*s; r[1] += a[1]*s; r[2] += a[2]*s; }
 // a.b, left-to-right                           (mju_dot3, engine_util_blas.c:140)
-MJH_DEV real v3_dot(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
-MJH_DEV real v3_norm(const real* a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
+template <class P0, class P1>
+MJH_DEV real v3_dot(P0 a, P1 b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+template <class P0>
+MJH_DEV real v3_norm(P0 a) { return sqrt(a[0]*a[0] + a[1]*a[1] + a[2]*a[2]); }
 // normalize, return previous length            (mju_normalize3, engine_util_blas.c:115)
-MJH_DEV real v3_normalize(real* v) {
+template <class P0>
+MJH_DEV real v3_normalize(P0 v) {
   real n = sqrt(v[0]*v[0] + v[1]*v[1] + v[2]*v[2]);
   if (n < MJH_MINVAL) {
     v[0] = 1; v[1] = 0; v[2] = 0;
@@ -38,27 +65,32 @@ MJH_DEV real v3_normalize(real* v) {
   return n;
 }
 // cross product                                (mji_cross, engine_inline.h:418)
-MJH_DEV void v3_cross(real* r, const real* a, const real* b) {
+template <class P0, class P1, class P2>
+MJH_DEV void v3_cross(P0 r, P1 a, P2 b) {
   r[0] = a[1]*b[2] - a[2]*b[1];
   r[1] = a[2]*b[0] - a[0]*b[2];
   r[2] = a[0]*b[1] - a[1]*b[0];
 }
 // r = M v, row-major 3x3                       (mji_mulMatVec3, engine_inline.h:147)
-MJH_DEV void m3_mulvec(real* r, const real* m, const real* v) {
+template <class P0, class P1, class P2>
+MJH_DEV void m3_mulvec(P0 r, P1 m, P2 v) {
   r[0] = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
   r[1] = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
   r[2] = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
 }
 // r = M' v                                     (mji_mulMatTVec3, engine_inline.h:157)
-MJH_DEV void m3_multvec(real* r, const real* m, const real* v) {
+template <class P0, class P1, class P2>
+MJH_DEV void m3_multvec(P0 r, P1 m, P2 v) {
   r[0] = m[0]*v[0] + m[3]*v[1] + m[6]*v[2];
   r[1] = m[1]*v[0] + m[4]*v[1] + m[7]*v[2];
   r[2] = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
 }
 
-MJH_DEV void q_copy(real* r, const real* q) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3]; }
+template <class P0, class P1>
+MJH_DEV void q_copy(P0 r, P1 q) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3]; }
 // normalize quaternion in place                (mju_normalize4 / mji__normalize4, engine_inline.h:228)
-MJH_DEV real q_normalize(real* q) {
+template <class P0>
+MJH_DEV real q_normalize(P0 q) {
   real n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
   if (n < MJH_MINVAL) {
     q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0;
@@ -69,7 +101,8 @@ MJH_DEV real q_normalize(real* q) {
   return n;
 }
 // r = qa * qb (r may alias)                    (mju_mulQuat, engine_util_spatial.c:66)
-MJH_DEV void q_mul(real* r, const real* a, const real* b) {
+template <class P0, class P1, class P2>
+MJH_DEV void q_mul(P0 r, P1 a, P2 b) {
   real t0 = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
   real t1 = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
   real t2 = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1];
@@ -77,7 +110,8 @@ MJH_DEV void q_mul(real* r, const real* a, const real* b) {
   r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
 }
 // rotate vector by quaternion, r must not alias q   (mji_rotVecQuat, engine_inline.h:252)
-MJH_DEV void q_rotvec(real* r, const real* v, const real* q) {
+template <class P0, class P1, class P2>
+MJH_DEV void q_rotvec(P0 r, P1 v, P2 q) {
   if (q[0] == 1 && q[1] == 0 && q[2] == 0 && q[3] == 0) {
     real v0 = v[0], v1 = v[1], v2 = v[2];
     r[0] = v0; r[1] = v1; r[2] = v2;
@@ -92,7 +126,8 @@ MJH_DEV void q_rotvec(real* r, const real* v, const real* q) {
   }
 }
 // axis-angle to quaternion                     (mji_axisAngle2Quat, engine_inline.h:308)
-MJH_DEV void q_axisangle(real* r, const real* axis, real angle) {
+template <class P0, class P1>
+MJH_DEV void q_axisangle(P0 r, P1 axis, real angle) {
   if (angle == 0) {
     r[0] = 1; r[1] = 0; r[2] = 0; r[3] = 0;
   } else {
@@ -104,7 +139,8 @@ MJH_DEV void q_axisangle(real* r, const real* axis, real angle) {
   }
 }
 // quaternion to rotation matrix                (mju_quat2Mat, engine_util_spatial.c:145)
-MJH_DEV void q_tomat(real* r, const real* q) {
+template <class P0, class P1>
+MJH_DEV void q_tomat(P0 r, P1 q) {
   if (q[0] == 1 && q[1] == 0 && q[2] == 0 && q[3] == 0) {
     r[0] = 1; r[1] = 0; r[2] = 0;
     r[3] = 0; r[4] = 1; r[5] = 0;
@@ -125,7 +161,8 @@ MJH_DEV void q_tomat(real* r, const real* q) {
   }
 }
 // orientation-difference quaternion -> 3D velocity   (mji_quat2Vel, engine_inline.h:330)
-MJH_DEV void q_tovel(real* r, const real* q, real dt) {
+template <class P0, class P1>
+MJH_DEV void q_tovel(P0 r, P1 q, real dt) {
   real axis[3] = {q[1], q[2], q[3]};
   real sin_a_2 = v3_normalize(axis);
   real speed = 2 * atan2(sin_a_2, q[0]);
@@ -134,14 +171,16 @@ MJH_DEV void q_tovel(real* r, const real* q, real dt) {
   v3_scl(r, axis, speed);
 }
 // r = vel such that qb*quat(r) = qa             (mji_subQuat, engine_inline.h:347)
-MJH_DEV void q_sub(real* r, const real* qa, const real* qb) {
+template <class P0, class P1, class P2>
+MJH_DEV void q_sub(P0 r, P1 qa, P2 qb) {
   real qneg[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
   real qdif[4];
   q_mul(qdif, qneg, qa);
   q_tovel(r, qdif, 1);
 }
 // integrate quaternion by angular velocity      (mju_quatIntegrate, engine_util_spatial.c:234)
-MJH_DEV void q_integrate(real* q, const real* vel, real scale) {
+template <class P0, class P1>
+MJH_DEV void q_integrate(P0 q, P1 vel, real scale) {
   real tmp[3] = {vel[0], vel[1], vel[2]};
   real angle = scale * v3_normalize(tmp);
   real qrot[4];
@@ -153,7 +192,8 @@ MJH_DEV void q_integrate(real* q, const real* vel, real scale) {
 // ---- spatial (6D, rotation:translation) -------------------------------------------------------
 
 // motion cross product                          (mji_crossMotion, engine_inline.h:428)
-MJH_DEV void sp_cross_motion(real* r, const real* vel, const real* v) {
+template <class P0, class P1, class P2>
+MJH_DEV void sp_cross_motion(P0 r, P1 vel, P2 v) {
   r[0] = -vel[2]*v[1] + vel[1]*v[2];
   r[1] =  vel[2]*v[0] - vel[0]*v[2];
   r[2] = -vel[1]*v[0] + vel[0]*v[1];
@@ -165,7 +205,8 @@ MJH_DEV void sp_cross_motion(real* r, const real* vel, const real* v) {
   r[5] += -vel[4]*v[0] + vel[3]*v[1];
 }
 // force cross product                           (mji_crossForce, engine_inline.h:445)
-MJH_DEV void sp_cross_force(real* r, const real* vel, const real* f) {
+template <class P0, class P1, class P2>
+MJH_DEV void sp_cross_force(P0 r, P1 vel, P2 f) {
   r[0] = -vel[2]*f[1] + vel[1]*f[2];
   r[1] =  vel[2]*f[0] - vel[0]*f[2];
   r[2] = -vel[1]*f[0] + vel[0]*f[1];
@@ -177,11 +218,13 @@ MJH_DEV void sp_cross_force(real* r, const real* vel, const real* f) {
   r[2] += -vel[4]*f[3] + vel[3]*f[4];
 }
 // 6D dot in mju_dot's association               (mji_dot6, engine_inline.h:462)
-MJH_DEV real sp_dot6(const real* a, const real* b) {
+template <class P0, class P1>
+MJH_DEV real sp_dot6(P0 a, P1 b) {
   return ((a[0]*b[0] + a[2]*b[2]) + (a[1]*b[1] + a[3]*b[3])) + (a[4]*b[4] + a[5]*b[5]);
 }
 // r = I(10) * v(6)                              (mju_mulInertVec, engine_util_spatial.c:439)
-MJH_DEV void sp_mul_inert(real* r, const real* i, const real* v) {
+template <class P0, class P1, class P2>
+MJH_DEV void sp_mul_inert(P0 r, P1 i, P2 v) {
   r[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
   r[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
   r[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
@@ -190,7 +233,8 @@ MJH_DEV void sp_mul_inert(real* r, const real* i, const real* v) {
   r[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
 }
 // body inertia in the com-based frame           (mju_inertCom, engine_util_spatial.c:405)
-MJH_DEV void sp_inert_com(real* r, const real* inert, const real* mat, const real* dif, real mass) {
+template <class P0, class P1, class P2, class P3>
+MJH_DEV void sp_inert_com(P0 r, P1 inert, P2 mat, P3 dif, real mass) {
   real t[9] = {mat[0]*inert[0], mat[3]*inert[0], mat[6]*inert[0],
                mat[1]*inert[1], mat[4]*inert[1], mat[7]*inert[1],
                mat[2]*inert[2], mat[5]*inert[2], mat[8]*inert[2]};
@@ -223,7 +267,8 @@ MJH_DEV int r_isbad(real x) { return (x != x) || (x > MJH_MAXVAL) || (x < -MJH_M
 // dense dot product in mju_dot's association (4 interleaved partial sums, then (r0+r2)+(r1+r3),
 // then the 1..3 element tail as ONE expression) -- engine_util_blas.c:493-527.
 // stride-aware so rows/columns of env-local matrices can be passed directly.
-MJH_DEV real dot_ref(const real* a, const real* b, int n) {
+template <class P0, class P1>
+MJH_DEV real dot_ref(P0 a, P1 b, int n) {
   real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   int i = 0;
   for (; i <= n - 4; i += 4) {
@@ -244,7 +289,8 @@ MJH_DEV real dot_ref(const real* a, const real* b, int n) {
   return res;
 }
 // sparse . dense in mju_dotSparse's association (tail added one by one) -- engine_util_sparse.h:197
-MJH_DEV real dot_sparse_ref(const real* a, const real* x, int nnz, const int* ind) {
+template <class P0, class P1, class P2>
+MJH_DEV real dot_sparse_ref(P0 a, P1 x, int nnz, P2 ind) {
   real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   int i = 0;
   for (; i <= nnz - 4; i += 4) {

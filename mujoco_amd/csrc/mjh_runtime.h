@@ -19,6 +19,11 @@
 //   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
 //   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, void* stream);
 //   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
+//   lane-mode kernels of the SoA pipeline (epw = environments per wavefront):
+//   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs&, void* stream);
+//   static bool launch_integrate(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs&, void* stream);
+//   static bool launch_lane_forward(const DModel* M, const DBatch* B, int nenv, int epw, int stages, void* stream);
+//   static bool launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int epw, void* stream);
 //   static int  max_lds();                       // largest LDS block one workgroup may ask for
 #pragma once
 
@@ -33,10 +38,13 @@
 #include "../../include/mjhip.h"
 #include "mjh_model_build.h"
 #include "mjh_mjb.h"
-#include "mjh_step.h"
+#include "mjh_modes.h"
 
 #include <algorithm>
 
+#ifndef MJHIP_DEFAULT_LAYOUT
+#define MJHIP_DEFAULT_LAYOUT MJHIP_LAYOUT_AOS
+#endif
 #ifndef MJHIP_DEFAULT_LDS_BYTES
 #define MJHIP_DEFAULT_LDS_BYTES 20480   // 8 one-wavefront workgroups per CU (160 KB LDS)
 #endif
@@ -62,6 +70,9 @@ struct mjhipBatch_ {
   DBatch L;                    // descriptor with the LDS residency plan (rollout / step kernels)
   DBatch* L_dev = nullptr;
   std::string plan_report;     // human-readable plan (mjhip_batch_lds_report)
+  int soa = 0;                 // 0: fields [nenv][count]; else nenvpad: fields [count][nenvpad]
+  int nenvpad = 0;
+  int epw = 64;                // environments per wavefront of the lane-mode kernels (<= 64)
   void* arena = nullptr;
   size_t arena_bytes = 0;
   std::map<std::string, FieldInfo> fields;
@@ -88,19 +99,28 @@ static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, const T** out, s
 // Fields alive during constraint assembly/solve are packed first from offset 0; the bytes above
 // them form the dynamic region handed to efc_layout().  Fields that die before MJH_T_MAKE may sit
 // anywhere, including on top of that region.  A field that does not fit stays global.
-struct PlanField { const char* name; int* l; int bytes; int t0, t1; int off; };
+struct PlanField { const char* name; int* l; int* io; int bytes; int t0, t1; int off; };
 
-static bool plan_lds(mjhipBatch_* Bt, int budget, std::string* report) {
+// span_first..span_last: the timeline points the kernel using this plan executes.  Only fields
+// whose lifetime intersects the span are placed.  `skip`: fields alive across the span that the
+// kernel never touches (left in HBM); `readonly`: persistent fields the kernel reads but does not
+// modify (loaded at entry, not stored at exit).
+static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
+                     const std::vector<std::string>& skip, const std::vector<std::string>& readonly,
+                     std::string* report) {
   DBatch& L = Bt->L;
   L = Bt->D;
   const DSizes& s = Bt->model->H.s;
   std::vector<PlanField> f;
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0) \
-    f.push_back(PlanField{#name, &L.l_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
+  auto listed = [](const std::vector<std::string>& v, const char* n) {
+    return std::find(v.begin(), v.end(), std::string(n)) != v.end();
+  };
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (t0) <= span_last && span_first <= (t1) && !listed(skip, #name)) \
+    f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0) \
-    f.push_back(PlanField{#name, &L.l_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (t0) <= span_last && span_first <= (t1) && !listed(skip, #name)) \
+    f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_INT_FIELDS(X)
 #undef X
   budget &= ~7;
@@ -148,7 +168,18 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, std::string* report) {
     if (report) *report = "no LDS plan (budget " + std::to_string(budget) + " B): all fields global\n";
     return false;
   }
-  for (auto& x : f) *x.l = x.off;
+  for (auto& x : f) {
+    *x.l = x.off;
+    if (x.off < 0) continue;
+    const bool persistent = (x.t0 == MJH_T_BEGIN);
+    const bool live_in = x.t0 < span_first;                       // produced before this kernel
+    const bool live_out = x.t1 > span_last;                       // consumed after it
+    const bool born_here = x.t0 >= span_first;
+    int io = 0;
+    if (live_in) io |= 1;
+    if (live_out && (born_here || (persistent && !listed(readonly, x.name)))) io |= 2;
+    *x.io = io;
+  }
   L.lds_bytes = budget;
   L.dyn_off = dyn_off;
   L.nconlds = s.nconlds;
@@ -158,8 +189,9 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, std::string* report) {
              budget, dyn_off, dyn_off, budget);
     *report += line;
     for (auto& x : f) {
-      snprintf(line, sizeof line, "  %-18s %6d B  t[%2d,%2d]  %s%d\n", x.name, x.bytes, x.t0, x.t1,
-               x.off >= 0 ? "lds@" : "global ", x.off);
+      snprintf(line, sizeof line, "  %-18s %6d B  t[%2d,%2d]  %s%d%s%s\n", x.name, x.bytes, x.t0, x.t1,
+               x.off >= 0 ? "lds@" : "global ", x.off, (x.off >= 0 && (*x.io & 1)) ? " in" : "",
+               (x.off >= 0 && (*x.io & 2)) ? " out" : "");
       *report += line;
     }
   }
@@ -253,21 +285,32 @@ MJHIP_API int mjhip_set_option(struct mjModel_* mm, const char* name, double val
 }
 
 MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
+  // $MJHIP_LAYOUT = aos | soa overrides the default layout
+  int layout = MJHIP_DEFAULT_LAYOUT;
+  if (const char* ev = getenv("MJHIP_LAYOUT")) layout = (!strcmp(ev, "aos") || !strcmp(ev, "0")) ? MJHIP_LAYOUT_AOS : MJHIP_LAYOUT_SOA;
+  return mjhip_batch_create_layout(M, nenv, device, layout);
+}
+
+MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int device, int layout) {
   if (!M || nenv <= 0) { set_err("mjhip_batch_create: bad arguments"); return nullptr; }
   std::string err;
   if (!Backend::set_device(device, &err)) { set_err(err); return nullptr; }
   mjhipBatch_* Bt = new mjhipBatch_();
   Bt->model = M;
   Bt->nenv = nenv;
+  Bt->nenvpad = (nenv + 63) & ~63;
+  Bt->soa = (layout == MJHIP_LAYOUT_SOA) ? Bt->nenvpad : 0;
+  if (const char* ev = getenv("MJHIP_EPW")) { int v = atoi(ev); if (v >= 1 && v <= 64) Bt->epw = v; }
+  const size_t nalloc = (size_t)Bt->nenvpad;
   const DSizes& s = M->H.s;
   // one arena; every field aligned to 256 bytes
   size_t off = 0;
   auto place = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   std::vector<std::pair<size_t, size_t>> spans;
-#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(real)*nenv), n}); }
+#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(real)*nalloc), n}); }
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(int)*nenv), n}); }
+#define X(name, cnt, lcnt, t0, t1) { size_t n = (size_t)std::max(1, (int)(cnt)); spans.push_back({place(n*sizeof(int)*nalloc), n}); }
   MJH_BATCH_INT_FIELDS(X)
 #undef X
   Bt->arena_bytes = off;
@@ -282,6 +325,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   size_t k = 0;
   memset(&Bt->D, 0, sizeof(DBatch));
   Bt->D.nenv = nenv;
+  Bt->D.soa = Bt->soa;
 #define X(name, cnt, lcnt, t0, t1) Bt->D.name = (real*)(base + spans[k].first); Bt->D.n_##name = (int)spans[k].second; \
   Bt->D.l_##name = -1; Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 0}; k++;
   MJH_BATCH_REAL_FIELDS(X)
@@ -321,7 +365,15 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
   if (lds_bytes < 0) lds_bytes = 0;
   if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
-  plan_lds(Bt, lds_bytes, &Bt->plan_report);
+  if (Bt->soa) {
+    // the constraint kernel of the per-step pipeline: collision .. PGS
+    plan_lds(Bt, lds_bytes, MJH_T_COLLISION, MJH_T_CONSTRAINT,
+             {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"},
+             {"qpos", "qvel", "qacc_warmstart"}, &Bt->plan_report);
+  } else {
+    // the single wave-per-environment kernel: the whole step
+    plan_lds(Bt, lds_bytes, MJH_T_KIN, MJH_T_EULER, {}, {}, &Bt->plan_report);
+  }
   if (!Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_plan_lds: descriptor upload failed");
     return -2;
@@ -333,7 +385,9 @@ MJHIP_API const char* mjhip_batch_lds_report(const mjhipBatch* Bt) { return Bt ?
 
 MJHIP_API int mjhip_batch_reset(mjhipBatch* Bt) {
   if (!Bt) return -1;
-  if (!Backend::launch_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, nullptr) || !Backend::sync(nullptr)) {
+  bool ok = Bt->soa ? Backend::launch_lane_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, nullptr)
+                    : Backend::launch_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, nullptr);
+  if (!ok || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_reset: kernel launch failed");
     return -2;
   }
@@ -355,14 +409,27 @@ static size_t field_stride(const mjhipBatch_* Bt, const FieldInfo& f) {
   return (size_t)std::max(1, f.count) * (f.is_int ? sizeof(int) : sizeof(real));
 }
 
+// host <-> device copies of one field; the host side is always [nenv][count]
 MJHIP_API int mjhip_batch_get(mjhipBatch* Bt, const char* name, void* host_dst) {
   void* p; int cnt, isint;
   if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
   if (cnt == 0) return 0;
-  size_t bytes = (size_t)cnt * (isint ? sizeof(int) : sizeof(real)) * Bt->nenv;
-  if (!Backend::d2h(host_dst, p, bytes, nullptr) || !Backend::sync(nullptr)) {
+  const size_t esz = isint ? sizeof(int) : sizeof(real);
+  if (!Bt->soa) {
+    size_t bytes = (size_t)cnt * esz * Bt->nenv;
+    if (!Backend::d2h(host_dst, p, bytes, nullptr) || !Backend::sync(nullptr)) {
+      set_err("mjhip_batch_get: copy failed"); return -3;
+    }
+    return 0;
+  }
+  const size_t np = (size_t)Bt->nenvpad;
+  std::vector<char> tmp((size_t)cnt * np * esz);
+  if (!Backend::d2h(tmp.data(), p, tmp.size(), nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_get: copy failed"); return -3;
   }
+  for (int e = 0; e < Bt->nenv; e++)
+    for (int i = 0; i < cnt; i++)
+      memcpy((char*)host_dst + ((size_t)e*cnt + i)*esz, tmp.data() + ((size_t)i*np + e)*esz, esz);
   return 0;
 }
 
@@ -370,11 +437,33 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* Bt, const char* name, const void* host
   void* p; int cnt, isint;
   if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
   if (cnt == 0) return 0;
-  size_t bytes = (size_t)cnt * (isint ? sizeof(int) : sizeof(real)) * Bt->nenv;
-  if (!Backend::h2d(p, host_src, bytes, nullptr) || !Backend::sync(nullptr)) {
+  const size_t esz = isint ? sizeof(int) : sizeof(real);
+  if (!Bt->soa) {
+    size_t bytes = (size_t)cnt * esz * Bt->nenv;
+    if (!Backend::h2d(p, host_src, bytes, nullptr) || !Backend::sync(nullptr)) {
+      set_err("mjhip_batch_set: copy failed"); return -3;
+    }
+    return 0;
+  }
+  const size_t np = (size_t)Bt->nenvpad;
+  std::vector<char> tmp((size_t)cnt * np * esz, 0);
+  for (int e = 0; e < Bt->nenv; e++)
+    for (int i = 0; i < cnt; i++)
+      memcpy(tmp.data() + ((size_t)i*np + e)*esz, (const char*)host_src + ((size_t)e*cnt + i)*esz, esz);
+  if (!Backend::h2d(p, tmp.data(), tmp.size(), nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_set: copy failed"); return -3;
   }
   return 0;
+}
+
+// one mj_step of every environment on an SoA batch: smooth (lane) -> constraint (wave) -> integrate (lane)
+static bool pipeline_step(mjhipBatch_* Bt, const RolloutArgs& A, void* stream) {
+  const DModel* M = Bt->model->D_dev;
+  if (!Backend::launch_smooth(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream)) return false;
+  const bool lds = Bt->L.lds_bytes > 0;
+  if (!Backend::launch_forward(M, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, MJH_STAGES_CONSTRAINT_MASK | MJH_STAGE_IFACTIVE,
+                               lds ? Bt->L.lds_bytes : 0, stream)) return false;
+  return Backend::launch_integrate(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream);
 }
 
 MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
@@ -383,12 +472,23 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   // MJHIP_STAGE_LDS: run on the LDS residency plan and write every stage's fields back to their
   // global homes (debug / parity tests of the resident path); default: everything global
   const bool lds = (stages & MJH_STAGE_LDS) && Bt->L.lds_bytes;
-  stages &= ~(MJH_STAGE_LDS | MJH_STAGE_WRITEBACK);
-  if (lds) stages |= MJH_STAGE_WRITEBACK;
-  if (!Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, stages,
-                               lds ? Bt->L.lds_bytes : 0, stream)) {
-    set_err("mjhip_batch_forward: kernel launch failed"); return -2;
+  stages &= ~(MJH_STAGE_LDS | MJH_STAGE_WRITEBACK | MJH_STAGE_IFACTIVE);
+  bool ok = true;
+  if (!Bt->soa) {
+    if (lds) stages |= MJH_STAGE_WRITEBACK;
+    ok = Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, stages,
+                                 lds ? Bt->L.lds_bytes : 0, stream);
+  } else {
+    // the pipeline's split: lane-mode kernel for the smooth stages, wave-mode kernel for the
+    // constraint stages (on its LDS plan + write-back if asked), lane-mode kernel for the tail
+    const int s1 = stages & MJH_STAGES_SMOOTH_MASK, s2 = stages & MJH_STAGES_CONSTRAINT_MASK;
+    const int s3 = stages & (MJH_STAGE_FINISH | MJH_STAGE_EULER);
+    if (s1) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s1, stream);
+    if (s2) ok = ok && Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv,
+                                               s2 | (lds ? MJH_STAGE_WRITEBACK : 0), lds ? Bt->L.lds_bytes : 0, stream);
+    if (s3) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s3, stream);
   }
+  if (!ok) { set_err("mjhip_batch_forward: kernel launch failed"); return -2; }
   return 0;
 }
 
@@ -399,9 +499,13 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   A.nstep = nstep;
   A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied
   A.init = 0;
-  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream)) {
-    set_err("mjhip_batch_step: kernel launch failed"); return -2;
+  bool ok = true;
+  if (Bt->soa) {
+    for (int t = 0; t < nstep && ok; t++) { A.t0 = t; ok = pipeline_step(Bt, A, stream); }
+  } else {
+    ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream);
   }
+  if (!ok) { set_err("mjhip_batch_step: kernel launch failed"); return -2; }
   return 0;
 }
 
@@ -437,7 +541,8 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
   A.has_qfrc = (control_spec & mjSTATE_QFRC_APPLIED) ? 1 : 0;
   A.ncontrol = ncontrol;
   A.qfrc_off = qfrc_off;
-  A.init = 1;
+  A.init = (on_device & MJHIP_ROLLOUT_CONTINUE) ? 0 : 1;
+  on_device &= MJHIP_ROLLOUT_ON_DEVICE;
   std::vector<void*> tmp;
   auto cleanup = [&]() { for (void* p : tmp) Backend::free(p); };
   if (on_device) {
@@ -460,9 +565,17 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
     if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
   }
   if (!A.control) { /* no control array: inputs not in the spec stay zero, those in it keep current */ }
-  if (!Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream)) {
-    cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4;
+  bool launched = true;
+  if (Bt->soa) {
+    for (int t = 0; t < nstep && launched; t++) {
+      A.t0 = t;
+      launched = pipeline_step(Bt, A, stream);
+      A.init = 0;
+    }
+  } else {
+    launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream);
   }
+  if (!launched) { cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
   if (!on_device) {
     bool ok = true;
     if (state && nstep > 0) ok = Backend::d2h(state, A.state, nenv*(size_t)nstep*s.nstate*sizeof(real), stream);
@@ -534,7 +647,12 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
       if (n <= 0) return;
       void* p; int cnt, isint;
       mjhip_batch_field(Bt, name, &p, &cnt, &isint);
-      Backend::d2h(dst, (const char*)p + (size_t)last*cnt*sizeof(real), (size_t)n*sizeof(real), nullptr);
+      if (!Bt->soa) {
+        Backend::d2h(dst, (const char*)p + (size_t)last*cnt*sizeof(real), (size_t)n*sizeof(real), nullptr);
+      } else {
+        for (int i = 0; i < n; i++)
+          Backend::d2h(dst + i, (const char*)p + ((size_t)i*Bt->nenvpad + last)*sizeof(real), sizeof(real), nullptr);
+      }
     };
     pull("time", &d->time, 1);
     pull("qpos", d->qpos, s.nq);
@@ -547,7 +665,12 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
     int w[8];
     void* p; int cnt, isint;
     mjhip_batch_field(Bt, "warning", &p, &cnt, &isint);
-    Backend::d2h(w, (const char*)p + (size_t)last*cnt*sizeof(int), 8*sizeof(int), nullptr);
+    if (!Bt->soa) {
+      Backend::d2h(w, (const char*)p + (size_t)last*cnt*sizeof(int), 8*sizeof(int), nullptr);
+    } else {
+      for (int i = 0; i < 8; i++)
+        Backend::d2h(w + i, (const char*)p + ((size_t)i*Bt->nenvpad + last)*sizeof(int), sizeof(int), nullptr);
+    }
     Backend::sync(nullptr);
     for (int k = 0; k < mjNWARNING; k++) d->warning[k].number = w[k];
   }

@@ -5,16 +5,16 @@
 // matrix rows); phases are separated by wv_sync().  Per-item arithmetic follows the reference
 // engine's operation order (files below are relative to /root/reference/src/engine) so results
 // agree with the no-FMA CPU build to the last bit wherever the item decomposition allows it.
-#pragma once
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
-#include "mjh_types.h"
 
 // ------------------------------------------------------------------------------------------------
 // frame of a geom/site/inertial frame attached to a body      (mj_local2Global, engine_core_util.c:975)
 // ------------------------------------------------------------------------------------------------
-MJH_DEV void local2global(real* opos, real* omat, const real* pos, const real* quat,
-                          const real* xpos, const real* xquat, const real* xmat,
-                          const real* xipos, const real* ximat, int sameframe) {
+template <class P0, class P1, class P2, class P3, class P4, class P5, class P6, class P7, class P8>
+MJH_DEV void local2global(P0 opos, P1 omat, P2 pos, P3 quat,
+                          P4 xpos, P5 xquat, P6 xmat,
+                          P7 xipos, P8 ximat, int sameframe) {
   // position
   if (sameframe == MJH_SAMEFRAME_BODY) {
     v3_copy(opos, xpos);
@@ -44,14 +44,14 @@ MJH_DEV void local2global(real* opos, real* omat, const real* pos, const real* q
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* qpos = MJH_F(B, qpos, e);
-  real* xpos = MJH_F(B, xpos, e);
-  real* xquat = MJH_F(B, xquat, e);
-  real* xmat = MJH_F(B, xmat, e);
-  real* xipos = MJH_F(B, xipos, e);
-  real* ximat = MJH_F(B, ximat, e);
-  real* xanchor = MJH_F(B, xanchor, e);
-  real* xaxis = MJH_F(B, xaxis, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  rptr xpos = MJH_F(B, xpos, e);
+  rptr xquat = MJH_F(B, xquat, e);
+  rptr xmat = MJH_F(B, xmat, e);
+  rptr xipos = MJH_F(B, xipos, e);
+  rptr ximat = MJH_F(B, ximat, e);
+  rptr xanchor = MJH_F(B, xanchor, e);
+  rptr xaxis = MJH_F(B, xaxis, e);
 
   // world body
   if (wv_lane() == 0) {
@@ -132,16 +132,16 @@ MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   // geoms and sites
-  real* geom_xpos = MJH_F(B, geom_xpos, e);
-  real* geom_xmat = MJH_F(B, geom_xmat, e);
+  rptr geom_xpos = MJH_F(B, geom_xpos, e);
+  rptr geom_xmat = MJH_F(B, geom_xmat, e);
   MJH_FOR_LANES(g, s.ngeom) {
     int b = M.geom_bodyid[g];
     local2global(geom_xpos + 3*g, geom_xmat + 9*g, M.geom_pos + 3*g, M.geom_quat + 4*g,
                  xpos + 3*b, xquat + 4*b, xmat + 9*b, xipos + 3*b, ximat + 9*b,
                  M.geom_sameframe[g]);
   }
-  real* site_xpos = MJH_F(B, site_xpos, e);
-  real* site_xmat = MJH_F(B, site_xmat, e);
+  rptr site_xpos = MJH_F(B, site_xpos, e);
+  rptr site_xmat = MJH_F(B, site_xmat, e);
   MJH_FOR_LANES(g, s.nsite) {
     int b = M.site_bodyid[g];
     local2global(site_xpos + 3*g, site_xmat + 9*g, M.site_pos + 3*g, M.site_quat + 4*g,
@@ -153,7 +153,8 @@ MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
 
 // accumulate per-body n-vectors into parents, deepest level first; children of one parent are
 // added in decreasing body id, which reproduces the reference's `for b = nbody-1 .. 1` order.
-MJH_DEV void tree_accumulate_to_parent(const DModel& M, real* x, int n, int include_world) {
+template <class P0>
+MJH_DEV void tree_accumulate_to_parent(const DModel& M, P0 x, int n, int include_world) {
   const DSizes& s = M.s;
   for (int L = s.nlevel - 2; L >= (include_world ? 0 : 1); L--) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
@@ -174,14 +175,14 @@ MJH_DEV void tree_accumulate_to_parent(const DModel& M, real* x, int n, int incl
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* xipos = MJH_F(B, xipos, e);
-  const real* ximat = MJH_F(B, ximat, e);
-  const real* xmat = MJH_F(B, xmat, e);
-  const real* xanchor = MJH_F(B, xanchor, e);
-  const real* xaxis = MJH_F(B, xaxis, e);
-  real* subtree_com = MJH_F(B, subtree_com, e);
-  real* cinert = MJH_F(B, cinert, e);
-  real* cdof = MJH_F(B, cdof, e);
+  crptr xipos = MJH_F(B, xipos, e);
+  crptr ximat = MJH_F(B, ximat, e);
+  crptr xmat = MJH_F(B, xmat, e);
+  crptr xanchor = MJH_F(B, xanchor, e);
+  crptr xaxis = MJH_F(B, xaxis, e);
+  rptr subtree_com = MJH_F(B, subtree_com, e);
+  rptr cinert = MJH_F(B, cinert, e);
+  rptr cdof = MJH_F(B, cdof, e);
 
   MJH_FOR_LANES(i, s.nbody) v3_scl(subtree_com + 3*i, xipos + 3*i, M.body_mass[i]);
   wv_sync();
@@ -222,7 +223,7 @@ MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
     if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
       for (int k = 0; k < 3; k++) {
         real axis[3] = {xmat[9*i + k], xmat[9*i + k + 3], xmat[9*i + k + 6]};
-        real* r = cdof + da + skip + 6*k;
+        rptr r = cdof + da + skip + 6*k;
         v3_copy(r, axis);
         v3_cross(r + 3, axis, off);
       }
@@ -243,9 +244,9 @@ MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
 MJH_DEVN void stage_tendon(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   if (!s.ntendon) return;
-  const real* qpos = MJH_F(B, qpos, e);
-  real* L = MJH_F(B, ten_length, e);
-  real* J = MJH_F(B, ten_J, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  rptr L = MJH_F(B, ten_length, e);
+  rptr J = MJH_F(B, ten_J, e);
   MJH_FOR_LANES(i, s.ntendon) {
     int adr = M.tendon_adr[i], num = M.tendon_num[i];
     int radr = M.ten_J_rowadr[i], rnnz = M.ten_J_rownnz[i];
@@ -273,11 +274,11 @@ MJH_DEVN void stage_tendon(const DModel& M, const DBatch& B, int e) {
 MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   if (!s.nu) return;
-  const real* qpos = MJH_F(B, qpos, e);
-  real* length = MJH_F(B, actuator_length, e);
-  real* moment = MJH_F(B, actuator_moment, e);
-  int* rownnz = MJH_F(B, moment_rownnz, e);
-  int* colind = MJH_F(B, moment_colind, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  rptr length = MJH_F(B, actuator_length, e);
+  rptr moment = MJH_F(B, actuator_moment, e);
+  iptr rownnz = MJH_F(B, moment_rownnz, e);
+  iptr colind = MJH_F(B, moment_colind, e);
   MJH_FOR_LANES(i, s.nu) {
     int id = M.actuator_trnid[2*i];
     const real* gear = M.actuator_gear + 6*i;
@@ -296,10 +297,10 @@ MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* cinert = MJH_F(B, cinert, e);
-  const real* cdof = MJH_F(B, cdof, e);
-  real* crb = MJH_F(B, crb, e);
-  real* Mq = MJH_F(B, M, e);
+  crptr cinert = MJH_F(B, cinert, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  rptr crb = MJH_F(B, crb, e);
+  rptr Mq = MJH_F(B, M, e);
 
   MJH_FOR_LANES(k, 10*s.nbody) crb[k] = cinert[k];
   wv_sync();
@@ -328,7 +329,8 @@ MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
 // sparse L'DL factorisation in place              (mj_factorI, engine_core_smooth.c:2005-2029)
 // rows nv-1 .. 0 in order; for one row k the updates of its ancestor rows are independent
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void factor_ld(const DModel& M, real* mat, real* diaginv) {
+template <class P0, class P1>
+MJH_DEVN void factor_ld(const DModel& M, P0 mat, P1 diaginv) {
   const int nv = M.s.nv;
   for (int k = nv - 1; k >= 0; k--) {
     int start = M.M_rowadr[k];
@@ -337,6 +339,13 @@ MJH_DEVN void factor_ld(const DModel& M, real* mat, real* diaginv) {
     real invD = 1 / mat[end];
     // flattened (ancestor entry, element) work list: entry a (0..diag-1) updates row i=colind[start+a],
     // elements 0..a  (row i of the CSR has exactly a+1 entries: ancestors of i, then i)
+#if MJH_LANE_MODE
+    for (int a = 0; a < diag; a++) {
+      int adr_i = M.M_rowadr[M.M_colind[start + a]];
+      real scl = -mat[start + a] * invD;
+      for (int el = 0; el <= a; el++) mat[adr_i + el] += mat[start + el] * scl;
+    }
+#else
     int total = diag*(diag + 1)/2;
     MJH_FOR_LANES(w, total) {
       // invert w = a*(a+1)/2 + el, 0 <= el <= a
@@ -348,17 +357,18 @@ MJH_DEVN void factor_ld(const DModel& M, real* mat, real* diaginv) {
       real scl = -mat[start + a] * invD;
       mat[M.M_rowadr[i] + el] += mat[start + el] * scl;
     }
+#endif
     wv_sync();
     MJH_FOR_LANES(a, diag) mat[start + a] = mat[start + a] * invD;
-    if (wv_lane() == 0 && diaginv) diaginv[k] = invD;
+    if (wv_lane() == 0) diaginv[k] = invD;
     wv_sync();
   }
 }
 
 MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
-  const real* Mq = MJH_F(B, M, e);
-  real* qLD = MJH_F(B, qLD, e);
-  real* Mkeep = MJH_G(B, qH, e);     // M parked in global memory for mj_Euler's qH = M + h*diag(B)
+  crptr Mq = MJH_F(B, M, e);
+  rptr qLD = MJH_F(B, qLD, e);
+  rptr Mkeep = MJH_G(B, qH, e);     // M parked in global memory for mj_Euler's qH = M + h*diag(B)
   MJH_FOR_LANES(k, M.s.nC) { real v = Mq[k]; qLD[k] = v; Mkeep[k] = v; }
   wv_sync();
   factor_ld(M, qLD, MJH_F(B, qLDiagInv, e));
@@ -367,7 +377,8 @@ MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // x <- inv(L'DL) x, one vector                    (mj_solveLD, engine_core_smooth.c:2033-2109)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void solve_ld(const DModel& M, real* x, const real* qLD, const real* diaginv) {
+template <class P0, class P1, class P2>
+MJH_DEVN void solve_ld(const DModel& M, P0 x, P1 qLD, P2 diaginv) {
   const int nv = M.s.nv;
   // x <- L^-T x : row i scatters into its ancestors (independent targets)
   for (int i = nv - 1; i >= 0; i--) {
@@ -399,7 +410,8 @@ MJH_DEVN void solve_ld(const DModel& M, real* x, const real* qLD, const real* di
 // mj_comVel                                      (engine_core_smooth.c:2179-2239)
 // ------------------------------------------------------------------------------------------------
 // res(6) = sum_r dof[r](6) * vec[r], r < n          (mju_mulDofVec, engine_util_spatial.c:466)
-MJH_DEV void mul_dof_vec(real* res, const real* dof, const real* vec, int n) {
+template <class P0, class P1, class P2>
+MJH_DEV void mul_dof_vec(P0 res, P1 dof, P2 vec, int n) {
   if (n == 1) {
     for (int k = 0; k < 6; k++) res[k] = dof[k]*vec[0];
   } else {
@@ -413,10 +425,10 @@ MJH_DEV void mul_dof_vec(real* res, const real* dof, const real* vec, int n) {
 
 MJH_DEVN void stage_comvel(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* qvel = MJH_F(B, qvel, e);
-  const real* cdof = MJH_F(B, cdof, e);
-  real* cvel = MJH_F(B, cvel, e);
-  real* cdof_dot = MJH_F(B, cdof_dot, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  rptr cvel = MJH_F(B, cvel, e);
+  rptr cdof_dot = MJH_F(B, cdof_dot, e);
   if (wv_lane() == 0) for (int k = 0; k < 6; k++) cvel[k] = 0;
   wv_sync();
   for (int L = 1; L < s.nlevel; L++) {
@@ -456,7 +468,8 @@ MJH_DEVN void stage_comvel(const DModel& M, const DBatch& B, int e) {
 // mj_passive: joint springs, dof dampers, tendon spring-dampers   (engine_passive.c:655-842,1047)
 // ------------------------------------------------------------------------------------------------
 // mju_polyForce, engine_util_misc.c:2314 (mjNPOLY = 2)
-MJH_DEV real poly_force(real linear, const real* poly, real x, int odd) {
+template <class P0>
+MJH_DEV real poly_force(real linear, P0 poly, real x, int odd) {
   x = odd ? fabs(x) : x;
   real res = linear;
   real xpow = 1;
@@ -467,7 +480,8 @@ MJH_DEV real poly_force(real linear, const real* poly, real x, int odd) {
   return res;
 }
 // mjd_xPolyForce, engine_util_misc.c:2329
-MJH_DEV real poly_force_deriv(real linear, const real* poly, real x, int odd) {
+template <class P0>
+MJH_DEV real poly_force_deriv(real linear, P0 poly, real x, int odd) {
   x = odd ? fabs(x) : x;
   real res = linear;
   real xpow = 1;
@@ -480,11 +494,11 @@ MJH_DEV real poly_force_deriv(real linear, const real* poly, real x, int odd) {
 
 MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* qpos = MJH_F(B, qpos, e);
-  const real* qvel = MJH_F(B, qvel, e);
-  real* fs = MJH_F(B, qfrc_spring, e);
-  real* fd = MJH_F(B, qfrc_damper, e);
-  real* fp = MJH_F(B, qfrc_passive, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  rptr fs = MJH_F(B, qfrc_spring, e);
+  rptr fd = MJH_F(B, qfrc_damper, e);
+  rptr fp = MJH_F(B, qfrc_passive, e);
   const int dsbl = M.o.disableflags;
   const int enbl_spring = !(dsbl & (1<<5)), enbl_damper = !(dsbl & (1<<6));
 
@@ -535,9 +549,9 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
 
   // tendon spring-dampers accumulate into shared dofs: keep the reference's tendon order
   if (s.ntendon && wv_lane() == 0) {
-    const real* tl = MJH_F(B, ten_length, e);
-    const real* tv = MJH_F(B, ten_velocity, e);
-    const real* tJ = MJH_F(B, ten_J, e);
+    crptr tl = MJH_F(B, ten_length, e);
+    crptr tv = MJH_F(B, ten_velocity, e);
+    crptr tJ = MJH_F(B, ten_J, e);
     for (int i = 0; i < s.ntendon; i++) {
       real stiffness = enbl_spring ? M.tendon_stiffness[i] : 0;
       const real* sp = M.tendon_stiffnesspoly + 2*i;
@@ -572,14 +586,14 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_rne(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* qvel = MJH_F(B, qvel, e);
-  const real* cdof = MJH_F(B, cdof, e);
-  const real* cdof_dot = MJH_F(B, cdof_dot, e);
-  const real* cvel = MJH_F(B, cvel, e);
-  const real* cinert = MJH_F(B, cinert, e);
-  real* cacc = MJH_F(B, cacc, e);
-  real* cfrc = MJH_F(B, cfrc, e);
-  real* bias = MJH_F(B, qfrc_bias, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr cdof_dot = MJH_F(B, cdof_dot, e);
+  crptr cvel = MJH_F(B, cvel, e);
+  crptr cinert = MJH_F(B, cinert, e);
+  rptr cacc = MJH_F(B, cacc, e);
+  rptr cfrc = MJH_F(B, cfrc, e);
+  rptr bias = MJH_F(B, qfrc_bias, e);
 
   if (wv_lane() == 0) {
     for (int k = 0; k < 6; k++) cacc[k] = 0;
@@ -616,20 +630,20 @@ MJH_DEVN void stage_rne(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* qvel = MJH_F(B, qvel, e);
+  crptr qvel = MJH_F(B, qvel, e);
   if (s.ntendon) {
-    const real* tJ = MJH_F(B, ten_J, e);
-    real* tv = MJH_F(B, ten_velocity, e);
+    crptr tJ = MJH_F(B, ten_J, e);
+    rptr tv = MJH_F(B, ten_velocity, e);
     MJH_FOR_LANES(i, s.ntendon) {
       int adr = M.ten_J_rowadr[i];
       tv[i] = dot_sparse_ref(tJ + adr, qvel, M.ten_J_rownnz[i], M.ten_J_colind + adr);
     }
   }
   if (s.nu) {
-    const real* mom = MJH_F(B, actuator_moment, e);
-    const int* rownnz = MJH_F(B, moment_rownnz, e);
-    const int* colind = MJH_F(B, moment_colind, e);
-    real* av = MJH_F(B, actuator_velocity, e);
+    crptr mom = MJH_F(B, actuator_moment, e);
+    ciptr rownnz = MJH_F(B, moment_rownnz, e);
+    ciptr colind = MJH_F(B, moment_colind, e);
+    rptr av = MJH_F(B, actuator_velocity, e);
     const int dsbl_act = M.o.disableflags & (1<<11);
     MJH_FOR_LANES(i, s.nu) {
       int adr = M.actuator_momentadr[i];
@@ -645,8 +659,8 @@ MJH_DEVN void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  real* force = MJH_F(B, actuator_force, e);
-  real* qfa = MJH_F(B, qfrc_actuator, e);
+  rptr force = MJH_F(B, actuator_force, e);
+  rptr qfa = MJH_F(B, qfrc_actuator, e);
   const int dsbl = M.o.disableflags;
   if (s.nu == 0 || (dsbl & (1<<11))) {
     MJH_FOR_LANES(i, s.nu) force[i] = 0;
@@ -654,10 +668,10 @@ MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
     wv_sync();
     return;
   }
-  const real* ctrl_in = MJH_F(B, ctrl, e);
-  const real* len = MJH_F(B, actuator_length, e);
-  const real* vel = MJH_F(B, actuator_velocity, e);
-  int* warn = MJH_F(B, warning, e);
+  crptr ctrl_in = MJH_F(B, ctrl, e);
+  crptr len = MJH_F(B, actuator_length, e);
+  crptr vel = MJH_F(B, actuator_velocity, e);
+  iptr warn = MJH_F(B, warning, e);
 
   // any bad control (after clamping) zeroes ALL controls
   int bad = 0;
@@ -691,9 +705,9 @@ MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   // qfrc_actuator = moment' * force, rows added in actuator order (mju_mulMatTVecSparse)
-  const real* mom = MJH_F(B, actuator_moment, e);
-  const int* rownnz = MJH_F(B, moment_rownnz, e);
-  const int* colind = MJH_F(B, moment_colind, e);
+  crptr mom = MJH_F(B, actuator_moment, e);
+  ciptr rownnz = MJH_F(B, moment_rownnz, e);
+  ciptr colind = MJH_F(B, moment_colind, e);
   MJH_FOR_LANES(j, s.nv) {
     real r = 0;
     for (int i = 0; i < s.nu; i++) {
@@ -721,12 +735,12 @@ MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_acceleration(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  const real* fp = MJH_F(B, qfrc_passive, e);
-  const real* fb = MJH_F(B, qfrc_bias, e);
-  const real* fa = MJH_F(B, qfrc_applied, e);
-  const real* fu = MJH_F(B, qfrc_actuator, e);
-  real* fsm = MJH_F(B, qfrc_smooth, e);
-  real* qas = MJH_F(B, qacc_smooth, e);
+  crptr fp = MJH_F(B, qfrc_passive, e);
+  crptr fb = MJH_F(B, qfrc_bias, e);
+  crptr fa = MJH_F(B, qfrc_applied, e);
+  crptr fu = MJH_F(B, qfrc_actuator, e);
+  rptr fsm = MJH_F(B, qfrc_smooth, e);
+  rptr qas = MJH_F(B, qacc_smooth, e);
   MJH_FOR_LANES(i, s.nv) {
     real f = fp[i] - fb[i];
     f += fa[i];

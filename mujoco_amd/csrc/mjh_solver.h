@@ -6,15 +6,16 @@
 // them and the wave combines them with three adds, so the sweep reproduces the CPU result bit for
 // bit -- including the iteration at which `improvement < tolerance` fires -- while the residual
 // costs ceil(nefc/4) dependent multiply-adds instead of nefc.
-#pragma once
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
-#include "mjh_types.h"
-#include "mjh_smooth.h"
-#include "mjh_constraint.h"
 
 // wave-cooperative dot product in mju_dot's association; result is wave-uniform.
 // a and b may be written by other lanes before the call (caller syncs).
-MJH_DEV real wave_dot_ref(const real* a, const real* b, int n) {
+template <class P0, class P1>
+MJH_DEV real wave_dot_ref(P0 a, P1 b, int n) {
+#if MJH_LANE_MODE
+  return dot_ref(a, b, n);
+#else
   const int lane = wv_lane();
   const int n4 = n & ~3;
   real r = 0;
@@ -28,6 +29,7 @@ MJH_DEV real wave_dot_ref(const real* a, const real* b, int n) {
   else if (rem == 2) res += a[n4]*b[n4] + a[n4+1]*b[n4+1];
   else if (rem == 1) res += a[n4]*b[n4];
   return res;
+#endif
 }
 
 // PCG32, engine_solver.c:241-254
@@ -44,18 +46,18 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
-  int* counts = MJH_F(B, counts, e);
+  iptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
   Efc P;
   efc_layout(M, B, e, nefc, P);
-  const real* AR = P.AR;
-  const real* b = P.b;
-  const real* floss = P.floss;
-  real* force = P.force;
-  real* ARinv = P.ARinv;                 // [nefc]
-  real* force_prev = P.fprev;            // [nefc]
-  real* force_mom = P.fmom;              // [nefc]
-  int* order = P.order;                  // [nefc] block visitation order (persists across iterations)
+  crptr AR = P.AR;
+  crptr b = P.b;
+  crptr floss = P.floss;
+  rptr force = P.force;
+  rptr ARinv = P.ARinv;                 // [nefc]
+  rptr force_prev = P.fprev;            // [nefc]
+  rptr force_mom = P.fmom;              // [nefc]
+  iptr order = P.order;                  // [nefc] block visitation order (persists across iterations)
   const int lane = wv_lane();
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
@@ -147,7 +149,7 @@ MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
   // final dual state (dualState, :270-345) and iteration count
-  int* state = P.state;
+  iptr state = P.state;
   MJH_FOR_LANES(i, nefc) {
     int st;
     if (i < ne) st = MJH_STATE_QUADRATIC;
@@ -168,32 +170,31 @@ MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
 MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
-  int* counts = MJH_F(B, counts, e);
+  iptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC];
-  real* qfc = MJH_F(B, qfrc_constraint, e);
-  real* qacc = MJH_F(B, qacc, e);
-  const real* qas = MJH_F(B, qacc_smooth, e);
+  rptr qfc = MJH_F(B, qfrc_constraint, e);
+  crptr qas = MJH_F(B, qacc_smooth, e);
 
   if (!nefc) {
-    MJH_FOR_LANES(i, nv) { qfc[i] = 0; qacc[i] = qas[i]; }
+    MJH_FOR_LANES(i, nv) qfc[i] = 0;
     if (wv_lane() == 0) counts[MJH_C_NITER] = 0;
     wv_sync();
     return;
   }
   Efc P;
   efc_layout(M, B, e, nefc, P);
-  const real* J = P.J;
-  const real* aref = P.aref;
-  const real* AR = P.AR;
-  real* eb = P.b;
-  real* force = P.force;
-  real* jar = P.jar;                     // [nefc]
-  real* ARf = P.ARf;                     // [nefc]
-  const real* qws = MJH_F(B, qacc_warmstart, e);
+  crptr J = P.J;
+  crptr aref = P.aref;
+  crptr AR = P.AR;
+  rptr eb = P.b;
+  rptr force = P.force;
+  rptr jar = P.jar;                     // [nefc]
+  rptr ARf = P.ARf;                     // [nefc]
+  crptr qws = MJH_F(B, qacc_warmstart, e);
 
   // efc_b = J*qacc_smooth - aref ; jar = J*qacc_warmstart - aref
   MJH_FOR_LANES(r, nefc) {
-    const real* Jr = J + (size_t)r*nv;
+    crptr Jr = J + (size_t)r*nv;
     real t = dot_ref(Jr, qas, nv);
     eb[r] = t - aref[r];
     real u = dot_ref(Jr, qws, nv);
@@ -219,7 +220,7 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
 
   solve_pgs(M, B, e);
 
-  // mj_dualFinish (engine_solver.c:72-85): qfrc_constraint = J' f ; qacc = M \ qfrc_constraint + qacc_smooth
+  // mj_dualFinish, first half (engine_solver.c:72-85): qfrc_constraint = J' f
   MJH_FOR_LANES(j, nv) {
     real acc = 0;
     for (int r = 0; r < nefc; r++) {
@@ -227,8 +228,23 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
       if (f != 0) acc += J[(size_t)r*nv + j]*f;
     }
     qfc[j] = acc;
-    qacc[j] = acc;
   }
+  wv_sync();
+}
+
+// mj_dualFinish, second half: qacc = M \ qfrc_constraint + qacc_smooth   (engine_solver.c:80-84)
+MJH_DEVN void stage_finish(const DModel& M, const DBatch& B, int e) {
+  const int nv = M.s.nv;
+  const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
+  crptr qfc = MJH_F(B, qfrc_constraint, e);
+  crptr qas = MJH_F(B, qacc_smooth, e);
+  rptr qacc = MJH_F(B, qacc, e);
+  if (!nefc) {
+    MJH_FOR_LANES(i, nv) qacc[i] = qas[i];
+    wv_sync();
+    return;
+  }
+  MJH_FOR_LANES(j, nv) qacc[j] = qfc[j];
   wv_sync();
   solve_ld(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
   MJH_FOR_LANES(j, nv) qacc[j] += qas[j];

@@ -27,7 +27,9 @@
 #include <string.h>
 
 #define MJH_DEV static inline
-#define MJH_DEVN static __attribute__((noinline))
+#define MJH_MEM inline
+#define MJH_DEVN_WAVE static __attribute__((noinline))
+#define MJH_DEVN_LANE static inline
 #define MJH_GLOBAL static void
 #define MJH_SHARED static
 
@@ -129,10 +131,12 @@ MJH_DEV long long wv_clock() { return 0; }
 #include <hip/hip_runtime.h>
 
 #define MJH_DEV __device__ __forceinline__
+#define MJH_MEM __device__ __forceinline__
 // out-of-line device function: gives the big stages their own register allocation scope
 // register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident
 #define MJH_WAVES_PER_EU 2
-#define MJH_DEVN __device__ __noinline__ static
+#define MJH_DEVN_WAVE __device__ __noinline__ static
+#define MJH_DEVN_LANE __device__ __forceinline__ static
 #define MJH_GLOBAL __global__ void
 #define MJH_SHARED __shared__
 
@@ -169,5 +173,3 @@ MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 
 #endif  // MJH_HOSTSIM
 
-// lane loop: for (i = lane; i < n; i += 64)
-#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_WAVE)

@@ -1,46 +1,24 @@
 // mj_step for one environment per wavefront: checks -> forward -> Euler/advance, and the rollout
 // loop around it (python/mujoco/rollout.cc:74-178 restated per environment).
-#pragma once
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
-#include "mjh_types.h"
-#include "mjh_smooth.h"
-#include "mjh_collision.h"
-#include "mjh_constraint.h"
-#include "mjh_solver.h"
-
-// stage bits for partial forward evaluation (tests and per-stage profiling)
-enum {
-  MJH_STAGE_KINEMATICS = 1<<0,   // kinematics, comPos, tendon
-  MJH_STAGE_INERTIA    = 1<<1,   // crb, factorM
-  MJH_STAGE_COLLISION  = 1<<2,
-  MJH_STAGE_MAKE       = 1<<3,   // makeConstraint
-  MJH_STAGE_PROJECT    = 1<<4,   // Y, AR
-  MJH_STAGE_TRANSMISSION = 1<<5,
-  MJH_STAGE_VELOCITY   = 1<<6,   // ten/act velocity, comVel, passive, reference, rne
-  MJH_STAGE_ACTUATION  = 1<<7,   // actuation + acceleration
-  MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint
-  MJH_STAGE_ALL        = (1<<9) - 1,
-  MJH_STAGE_EULER      = 1<<9,   // mj_Euler + mj_advance (not part of mj_forward; for per-stage runs)
-  MJH_STAGE_LDS        = 1<<21,  // host flag of mjhip_batch_forward: use the LDS residency plan (+ write-back)
-  MJH_STAGE_WRITEBACK  = 1<<20,  // debug: copy LDS-resident fields to their global homes after every stage
-};
 
 // mj_resetData as far as the state vector is concerned (engine_io.c:1289-1420)
 MJH_DEV void reset_env(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
-  real* qpos = MJH_F(B, qpos, e);
+  rptr qpos = MJH_F(B, qpos, e);
   MJH_FOR_LANES(i, s.nq) qpos[i] = M.qpos0[i];
-  real* qvel = MJH_F(B, qvel, e);
-  real* ws = MJH_F(B, qacc_warmstart, e);
-  real* fa = MJH_F(B, qfrc_applied, e);
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
+  rptr fa = MJH_F(B, qfrc_applied, e);
   MJH_FOR_LANES(i, s.nv) { qvel[i] = 0; ws[i] = 0; fa[i] = 0; }
-  real* act = MJH_F(B, act, e);
+  rptr act = MJH_F(B, act, e);
   MJH_FOR_LANES(i, s.na) act[i] = 0;
-  real* ctrl = MJH_F(B, ctrl, e);
+  rptr ctrl = MJH_F(B, ctrl, e);
   MJH_FOR_LANES(i, s.nu) ctrl[i] = 0;
-  real* xf = MJH_G(B, xfrc_applied, e);
+  rptr xf = MJH_G(B, xfrc_applied, e);
   MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
-  int* warn = MJH_F(B, warning, e);
+  iptr warn = MJH_F(B, warning, e);
   if (wv_lane() == 0) {
     MJH_F(B, time, e)[0] = 0;
     for (int k = 0; k < 8; k++) warn[k] = 0;
@@ -49,14 +27,15 @@ MJH_DEV void reset_env(const DModel& M, const DBatch& B, int e) {
 }
 
 // mj_checkPos / mj_checkVel / mj_checkAcc (engine_forward.c:54-113): returns 1 if x had a bad value
-MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, const real* x, int n, int which) {
+template <class P0>
+MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, P0 x, int n, int which) {
   int bad = 0;
   MJH_FOR_LANES(i, n) if (r_isbad(x[i])) bad = 1;
   bad = wv_any(bad);
   if (bad) {
     wv_sync();
     if (!(M.o.disableflags & (1<<16))) reset_env(M, B, e);
-    int* warn = MJH_F(B, warning, e);
+    iptr warn = MJH_F(B, warning, e);
     if (wv_lane() == 0) warn[which] += 1;
     wv_sync();
   }
@@ -66,17 +45,17 @@ MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, const real* x, in
 // ---- LDS residency helpers -----------------------------------------------------------------------
 // copy a field between its global home and its LDS slot (no-op for fields the plan left global)
 template <class T>
-MJH_DEV void lds_copy_in(T* g, int n, int l, int e) {
+MJH_DEV void lds_copy_in(T* g, int n, int l, int soa, int e, int cnt) {
   if (l < 0) return;
   T* dst = (T*)(mjh_lds() + l);
-  const T* src = g + (size_t)e*(size_t)n;
-  MJH_FOR_LANES(i, n) dst[i] = src[i];
+  SP<T> src = mjh_gp(g, n, soa, e);
+  MJH_FOR_LANES(i, cnt) dst[i] = src[i];
 }
 template <class T>
-MJH_DEV void lds_copy_out(T* g, int n, int l, int e, int cnt) {
+MJH_DEV void lds_copy_out(T* g, int n, int l, int soa, int e, int cnt) {
   if (l < 0) return;
   const T* src = (const T*)(mjh_lds() + l);
-  T* dst = g + (size_t)e*(size_t)n;
+  SP<T> dst = mjh_gp(g, n, soa, e);
   MJH_FOR_LANES(i, cnt) dst[i] = src[i];
 }
 
@@ -85,7 +64,7 @@ MJH_DEV void lds_enter(const DModel& M, const DBatch& B, int e) {
   if (!B.lds_bytes) return;
   const DSizes& s = M.s;
   (void)s;
-#define X(name, cnt, lcnt, t0, t1) if ((t0) == MJH_T_BEGIN && (t1) == MJH_T_END) lds_copy_in(B.name, B.n_##name, B.l_##name, e);
+#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 1) lds_copy_in(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -97,7 +76,7 @@ MJH_DEV void lds_exit(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   (void)s;
   wv_sync();
-#define X(name, cnt, lcnt, t0, t1) if ((t1) == MJH_T_END) lds_copy_out(B.name, B.n_##name, B.l_##name, e, (int)(lcnt));
+#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 2) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -110,7 +89,7 @@ MJH_DEVN void lds_writeback(const DModel& M, const DBatch& B, int e, int t) {
   const DSizes& s = M.s;
   (void)s;
   wv_sync();
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, e, (int)(lcnt));
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -141,7 +120,6 @@ MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
     MJH_RUN(MJH_T_CRB, stage_crb(M, B, e));
     MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
   }
-  if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
   if (stages & MJH_STAGE_TRANSMISSION) MJH_RUN(MJH_T_TRANSMISSION, stage_transmission(M, B, e));
   if (stages & MJH_STAGE_VELOCITY) {
     MJH_RUN(MJH_T_TAVEL, stage_ten_act_velocity(M, B, e));
@@ -153,15 +131,19 @@ MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
     MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));
     MJH_RUN(MJH_T_ACCEL, stage_acceleration(M, B, e));
   }
+  if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
   if (stages & MJH_STAGE_MAKE) MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
   if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
-  if (stages & MJH_STAGE_VELOCITY) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
+  if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
+  if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
 }
 
 MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e);
 // body of the forward kernel (mjhip_batch_forward): stage-masked mj_forward (+ optional Euler step)
 MJH_DEV void forward_or_euler(const DModel& M, const DBatch& B, int e, int stages) {
+  // pipeline use: the constraint kernel skips environments frozen by a warning
+  if ((stages & MJH_STAGE_IFACTIVE) && !MJH_G(B, active, e)[0]) return;
   lds_enter(M, B, e);
   forward(M, B, e, stages);
   if (stages & MJH_STAGE_EULER) {
@@ -179,15 +161,15 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
   const DSizes& s = M.s;
   const int nv = s.nv;
   const real h = M.o.timestep;
-  real* qvel = MJH_F(B, qvel, e);
-  real* qpos = MJH_F(B, qpos, e);
-  const real* qacc = MJH_F(B, qacc, e);
-  real* qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr qpos = MJH_F(B, qpos, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  rptr qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
 
   if (M.o.euler_damp) {
-    const real* Mq = MJH_G(B, qH, e);
-    real* qH = MJH_F(B, qLD, e);
-    real* qHDiagInv = MJH_F(B, qLDiagInv, e);
+    crptr Mq = MJH_G(B, qH, e);
+    rptr qH = MJH_F(B, qLD, e);
+    rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
     MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
     wv_sync();
     MJH_FOR_LANES(i, nv) {
@@ -196,8 +178,8 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
     }
     wv_sync();
     factor_ld(M, qH, qHDiagInv);
-    const real* fs = MJH_F(B, qfrc_smooth, e);
-    const real* fc = MJH_F(B, qfrc_constraint, e);
+    crptr fs = MJH_F(B, qfrc_smooth, e);
+    crptr fc = MJH_F(B, qfrc_constraint, e);
     MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
     wv_sync();
     solve_ld(M, qe, qH, qHDiagInv);
@@ -222,7 +204,7 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
       qpos[padr] += h * qvel[vadr];
     }
   }
-  real* ws = MJH_F(B, qacc_warmstart, e);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
   MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
   if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
   wv_sync();
@@ -242,42 +224,29 @@ MJH_DEV void step_env(const DModel& M, const DBatch& B, int e) {
 }
 
 // pack FULLPHYSICS state [time, qpos, qvel, act]    (mj_getState, engine_support.c:214)
-MJH_DEV void get_state(const DModel& M, const DBatch& B, int e, real* out) {
+template <class P0>
+MJH_DEV void get_state(const DModel& M, const DBatch& B, int e, P0 out) {
   const DSizes& s = M.s;
   if (wv_lane() == 0) out[0] = MJH_F(B, time, e)[0];
-  const real* qpos = MJH_F(B, qpos, e);
-  const real* qvel = MJH_F(B, qvel, e);
-  const real* act = MJH_F(B, act, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr act = MJH_F(B, act, e);
   MJH_FOR_LANES(i, s.nq) out[1 + i] = qpos[i];
   MJH_FOR_LANES(i, s.nv) out[1 + s.nq + i] = qvel[i];
   MJH_FOR_LANES(i, s.na) out[1 + s.nq + s.nv + i] = act[i];
 }
 
-MJH_DEV void set_state(const DModel& M, const DBatch& B, int e, const real* in) {
+template <class P0>
+MJH_DEV void set_state(const DModel& M, const DBatch& B, int e, P0 in) {
   const DSizes& s = M.s;
   if (wv_lane() == 0) MJH_F(B, time, e)[0] = in[0];
-  real* qpos = MJH_F(B, qpos, e);
-  real* qvel = MJH_F(B, qvel, e);
-  real* act = MJH_F(B, act, e);
+  rptr qpos = MJH_F(B, qpos, e);
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr act = MJH_F(B, act, e);
   MJH_FOR_LANES(i, s.nq) qpos[i] = in[1 + i];
   MJH_FOR_LANES(i, s.nv) qvel[i] = in[1 + s.nq + i];
   MJH_FOR_LANES(i, s.na) act[i] = in[1 + s.nq + s.nv + i];
 }
-
-// arguments of the rollout kernel (device pointers; layouts of python/mujoco/rollout.cc:51-69)
-struct RolloutArgs {
-  int nstep;
-  int has_ctrl;            // control_spec contains mjSTATE_CTRL
-  int has_qfrc;            // control_spec contains mjSTATE_QFRC_APPLIED
-  int ncontrol;            // mj_stateSize(control_spec)
-  int qfrc_off;            // offset of qfrc_applied inside one control vector
-  int init;                // 1: load state0/warmstart0, clear warnings (start of a rollout)
-  const real* state0;      // [nenv][nstate]        or null
-  const real* warmstart0;  // [nenv][nv]            or null -> zeros
-  const real* control;     // [nenv][nstep][ncontrol] or null
-  real* state;             // [nenv][nstep][nstate] or null
-  int env_offset;          // first env of this launch inside state0/control/state
-};
 
 // _unsafe_rollout for one environment                (python/mujoco/rollout.cc:74-178)
 MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
@@ -286,15 +255,15 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
   lds_enter(M, B, e);
   if (A.init) {
     if (A.state0) set_state(M, B, e, A.state0 + r*s.nstate);
-    real* ws = MJH_F(B, qacc_warmstart, e);
+    rptr ws = MJH_F(B, qacc_warmstart, e);
     MJH_FOR_LANES(i, s.nv) ws[i] = A.warmstart0 ? A.warmstart0[r*s.nv + i] : 0;
-    int* warn = MJH_F(B, warning, e);
+    iptr warn = MJH_F(B, warning, e);
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
-    if (!A.has_ctrl) { real* c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
-    if (!A.has_qfrc) { real* f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
+    if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
+    if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
     wv_sync();
   }
-  const int* warn = MJH_F(B, warning, e);
+  ciptr warn = MJH_F(B, warning, e);
 #ifdef MJH_PROFILE
   const long long c_start = wv_clock();
 #endif
@@ -306,8 +275,8 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
     if (!nw) {
       if (A.control) {
         const real* u = A.control + step*A.ncontrol;
-        if (A.has_ctrl) { real* c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
-        if (A.has_qfrc) { real* f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
+        if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
+        if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
         wv_sync();
       }
       step_env(M, B, e);
@@ -318,7 +287,7 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
   lds_exit(M, B, e);
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {
-    real* pr = MJH_G(B, prof, e);
+    rptr pr = MJH_G(B, prof, e);
     const long long c_end = wv_clock();
     pr[31] += (real)(c_end - c_start) * 0.01; pr[30] += A.nstep;
     pr[28] = (real)c_start * 0.01; pr[29] = (real)c_end * 0.01;      // residency census (last launch)
@@ -328,4 +297,57 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
 #endif
   }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The per-step pipeline (SoA batches): one mj_step of every environment is three kernels
+//   smooth_env     (lane mode)  rollout prologue, checks, every constraint-free stage
+//   forward_or_euler(wave mode) collision .. PGS with MJH_STAGE_IFACTIVE   (kernel mjh_k_forward)
+//   integrate_env  (lane mode)  qacc, checkAcc, Euler, advance, state output
+// Together they are rollout_env's loop body; A.t0 is the step's index in control/state.
+// ------------------------------------------------------------------------------------------------
+
+MJH_DEV void smooth_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
+  const DSizes& s = M.s;
+  const size_t r = (size_t)(A.env_offset + e);
+  if (A.init) {
+    if (A.state0) set_state(M, B, e, A.state0 + r*s.nstate);
+    rptr ws = MJH_F(B, qacc_warmstart, e);
+    MJH_FOR_LANES(i, s.nv) ws[i] = A.warmstart0 ? A.warmstart0[r*s.nv + i] : 0;
+    iptr warn = MJH_F(B, warning, e);
+    if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
+    if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
+    if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
+    wv_sync();
+  }
+  // any warning freezes the trajectory (python/mujoco/rollout.cc:135-155)
+  ciptr warn = MJH_F(B, warning, e);
+  int nw = 0;
+  for (int k = 0; k < 8; k++) nw |= warn[k];
+  if (wv_lane() == 0) MJH_G(B, active, e)[0] = nw ? 0 : 1;
+  if (nw) return;
+  if (A.control) {
+    const real* u = A.control + (r*(size_t)A.nstep + A.t0)*A.ncontrol;
+    if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
+    if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
+    wv_sync();
+  }
+  check_bad(M, B, e, MJH_F(B, qpos, e), s.nq, MJH_WARN_BADQPOS);
+  check_bad(M, B, e, MJH_F(B, qvel, e), s.nv, MJH_WARN_BADQVEL);
+  forward(M, B, e, MJH_STAGES_SMOOTH_MASK);
+}
+
+MJH_DEV void integrate_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
+  const DSizes& s = M.s;
+  const size_t r = (size_t)(A.env_offset + e);
+  if (MJH_G(B, active, e)[0]) {
+    stage_finish(M, B, e);
+    int bad = check_bad(M, B, e, MJH_F(B, qacc, e), s.nv, MJH_WARN_BADQACC);
+    // bad qacc: the state was reset; the reference re-runs mj_forward before integrating
+    // (engine_forward.c:1863-1870).  Rare, so the whole forward pass is redone right here.
+    if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
+    MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
+  }
+  if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);
 }

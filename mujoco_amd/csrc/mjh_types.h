@@ -180,9 +180,10 @@ struct DModel {
 // step timeline (the order stages run in; lifetimes are [first write, last read] on this axis)
 enum {
   MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COMPOS = 2, MJH_T_TENDON = 3, MJH_T_CRB = 4, MJH_T_FACTOR = 5,
-  MJH_T_COLLISION = 6, MJH_T_TRANSMISSION = 7, MJH_T_TAVEL = 8, MJH_T_COMVEL = 9, MJH_T_PASSIVE = 10,
-  MJH_T_RNE = 11, MJH_T_ACTUATION = 12, MJH_T_ACCEL = 13, MJH_T_MAKE = 14, MJH_T_PROJECT = 15,
-  MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17, MJH_T_EULER = 18, MJH_T_END = 19,
+  MJH_T_TRANSMISSION = 6, MJH_T_TAVEL = 7, MJH_T_COMVEL = 8, MJH_T_PASSIVE = 9, MJH_T_RNE = 10,
+  MJH_T_ACTUATION = 11, MJH_T_ACCEL = 12,
+  MJH_T_COLLISION = 13, MJH_T_MAKE = 14, MJH_T_PROJECT = 15, MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17,
+  MJH_T_FINISH = 18, MJH_T_EULER = 19, MJH_T_END = 20,
 };
 #define MJH_T_GLB (-1)         // global only
 #define MJH_LDS_CON (s.nconlds)  // contact slots kept in LDS (the rest of a contact list is global)
@@ -235,9 +236,9 @@ enum {
   X(qfrc_bias, s.nv, s.nv, MJH_T_RNE, MJH_T_ACCEL)                                \
   X(qfrc_actuator, s.nv, s.nv, MJH_T_ACTUATION, MJH_T_ACCEL)                      \
   X(qfrc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_EULER)                            \
-  X(qacc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_CONSTRAINT)                       \
+  X(qacc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_FINISH)                           \
   X(qfrc_constraint, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_EULER)                   \
-  X(qacc, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_END)                                \
+  X(qacc, s.nv, s.nv, MJH_T_FINISH, MJH_T_END)                                    \
   X(qe, s.nv, s.nv, MJH_T_EULER, MJH_T_EULER)                                     \
   X(con_dist, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                \
   X(con_pos, 3 * s.nconmax, 3 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)         \
@@ -277,7 +278,9 @@ enum {
   X(efc_type, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(efc_id, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(efc_state, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
-  X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)
+  X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)         \
+  /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
+  X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0
@@ -289,16 +292,18 @@ enum {
 #define MJH_C_NISLAND 6
 
 // name : global home, n_name : per-env element count of the home, l_name : byte offset inside the
-// workgroup's LDS block or -1
+// workgroup's LDS block or -1, io_name : bit 0 = copy home -> LDS at kernel entry (live-in),
+// bit 1 = copy LDS -> home at kernel exit (live-out)
 struct DBatch {
   int nenv;
   int lds_bytes;     // LDS bytes per one-wavefront workgroup (0: no LDS plan, everything global)
   int dyn_off;       // [dyn_off, lds_bytes): free during MJH_T_MAKE..MJH_T_CONSTRAINT -> constraint arrays
   int nconlds;       // contact slots resident in LDS
-#define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name;
+  int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
+#define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) int* name; int n_##name; int l_##name;
+#define X(name, cnt, lcnt, t0, t1) int* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
 };
@@ -321,20 +326,29 @@ MJH_DEV char* mjh_lds() {
 }
 #endif
 
+// A field slice is handed out as a strided view (mjh_math.h: SP): stride 1 when the slice is LDS
+// resident or the batch is laid out environment-major ([nenv][count]), stride nenvpad when the
+// batch is laid out SoA across environments ([count][nenvpad], element i of env e at i*nenvpad+e).
 template <class T>
-MJH_DEV T* mjh_fp(T* g, int n, int l, int e) {
-  return l >= 0 ? (T*)(mjh_lds() + l) : g + (size_t)e * (size_t)n;
+MJH_DEV SP<T> mjh_gp(T* g, int n, int soa, int e) {
+  return soa ? SP<T>{g + e, soa} : SP<T>{g + (size_t)e * (size_t)n, 1};
 }
-// pointer to env e's slice of field f (LDS if the plan placed it there, else its global home)
-#define MJH_F(B, f, e) mjh_fp((B).f, (B).n_##f, (B).l_##f, (e))
+template <class T>
+MJH_DEV SP<T> mjh_fp(T* g, int n, int l, int soa, int e) {
+  if (l >= 0) return SP<T>{(T*)(mjh_lds() + l), 1};
+  return mjh_gp(g, n, soa, e);
+}
+// env e's slice of field f (LDS if the plan placed it there, else its global home)
+#define MJH_F(B, f, e) mjh_fp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e))
 // global home of env e's slice, whatever the plan says
-#define MJH_G(B, f, e) ((B).f + (size_t)(e) * (size_t)(B).n_##f)
+#define MJH_G(B, f, e) mjh_gp((B).f, (B).n_##f, (B).soa, (e))
 // record k (of `stride` elements) of a per-contact field: the first nconlds slots may live in LDS
 template <class T>
-MJH_DEV T* mjh_cp(T* g, int n, int l, int e, int stride, int k, int nconlds) {
-  return (l >= 0 && k < nconlds) ? (T*)(mjh_lds() + l) + stride*k : g + (size_t)e * (size_t)n + stride*k;
+MJH_DEV SP<T> mjh_cp(T* g, int n, int l, int soa, int e, int stride, int k, int nconlds) {
+  if (l >= 0 && k < nconlds) return SP<T>{(T*)(mjh_lds() + l) + stride*k, 1};
+  return mjh_gp(g, n, soa, e) + stride*k;
 }
-#define MJH_CON(B, f, e, stride, k) mjh_cp((B).f, (B).n_##f, (B).l_##f, (e), (stride), (k), (B).nconlds)
+#define MJH_CON(B, f, e, stride, k) mjh_cp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e), (stride), (k), (B).nconlds)
 
 // constraint / contact enums used on device (include/mujoco/mjtype.h)
 enum {
@@ -360,3 +374,45 @@ enum {
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4,
 };
+
+// stage bits for partial forward evaluation (tests and per-stage profiling)
+enum {
+  MJH_STAGE_KINEMATICS = 1<<0,   // kinematics, comPos, tendon
+  MJH_STAGE_INERTIA    = 1<<1,   // crb, factorM
+  MJH_STAGE_COLLISION  = 1<<2,
+  MJH_STAGE_MAKE       = 1<<3,   // makeConstraint
+  MJH_STAGE_PROJECT    = 1<<4,   // Y, AR
+  MJH_STAGE_TRANSMISSION = 1<<5,
+  MJH_STAGE_VELOCITY   = 1<<6,   // ten/act velocity, comVel, passive, reference, rne
+  MJH_STAGE_ACTUATION  = 1<<7,   // actuation + acceleration
+  MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint (solve)
+  MJH_STAGE_REFERENCE  = 1<<11,  // mj_referenceConstraint (efc_vel, efc_aref)
+  MJH_STAGE_IFACTIVE   = 1<<22,  // pipeline flag: skip environments whose `active` flag is 0
+  MJH_STAGE_FINISH     = 1<<10,  // qacc = M^-1 qfrc_constraint + qacc_smooth (tail of fwdConstraint)
+  MJH_STAGE_ALL        = ((1<<9) - 1) | (1<<10) | (1<<11),
+  MJH_STAGE_EULER      = 1<<9,   // mj_Euler + mj_advance (not part of mj_forward; for per-stage runs)
+  MJH_STAGE_LDS        = 1<<21,  // host flag of mjhip_batch_forward: use the LDS residency plan (+ write-back)
+  MJH_STAGE_WRITEBACK  = 1<<20,  // debug: copy LDS-resident fields to their global homes after every stage
+};
+
+
+// stage sets of the three kernels of the per-step pipeline
+#define MJH_STAGES_SMOOTH_MASK (MJH_STAGE_KINEMATICS | MJH_STAGE_INERTIA | MJH_STAGE_TRANSMISSION | MJH_STAGE_VELOCITY | MJH_STAGE_ACTUATION)
+#define MJH_STAGES_CONSTRAINT_MASK (MJH_STAGE_COLLISION | MJH_STAGE_MAKE | MJH_STAGE_PROJECT | MJH_STAGE_REFERENCE | MJH_STAGE_CONSTRAINT)
+
+// arguments of the rollout kernel (device pointers; layouts of python/mujoco/rollout.cc:51-69)
+struct RolloutArgs {
+  int nstep;
+  int has_ctrl;            // control_spec contains mjSTATE_CTRL
+  int has_qfrc;            // control_spec contains mjSTATE_QFRC_APPLIED
+  int ncontrol;            // mj_stateSize(control_spec)
+  int qfrc_off;            // offset of qfrc_applied inside one control vector
+  int init;                // 1: load state0/warmstart0, clear warnings (start of a rollout)
+  int t0;                  // (per-step kernels) index of this step inside control/state
+  const real* state0;      // [nenv][nstate]        or null
+  const real* warmstart0;  // [nenv][nv]            or null -> zeros
+  const real* control;     // [nenv][nstep][ncontrol] or null
+  real* state;             // [nenv][nstep][nstate] or null
+  int env_offset;          // first env of this launch inside state0/control/state
+};
+

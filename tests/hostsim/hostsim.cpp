@@ -16,6 +16,7 @@
 
 #include "../../mujoco_amd/csrc/mjh_spmd.h"
 
+#include "../../mujoco_amd/csrc/mjh_math.h"
 #include "../../mujoco_amd/csrc/mjh_types.h"
 
 namespace mjhsim {
@@ -23,7 +24,7 @@ thread_local WaveSim* g_wave = nullptr;
 thread_local char g_lds[MJH_LDS_MAX];     // the emulated workgroup's LDS block
 }
 
-#include "../../mujoco_amd/csrc/mjh_step.h"
+#include "../../mujoco_amd/csrc/mjh_modes.h"
 
 namespace {
 
@@ -92,15 +93,32 @@ struct Backend {
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void*) {
-    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { forward_or_euler(*M, *B, wv_env(), stages); }); }
+    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { wv::forward_or_euler(*M, *B, wv_env(), stages); }); }
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void*) {
-    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { rollout_env(*M, *B, wv_env(), A); }); }
+    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { wv::rollout_env(*M, *B, wv_env(), A); }); }
+    return true;
+  }
+  // lane mode needs no wavefront emulation: every environment is an ordinary serial call
+  static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int, const RolloutArgs& A, void*) {
+    for (int e = 0; e < nenv; e++) ln::smooth_env(*M, *B, e, A);
+    return true;
+  }
+  static bool launch_integrate(const DModel* M, const DBatch* B, int nenv, int, const RolloutArgs& A, void*) {
+    for (int e = 0; e < nenv; e++) ln::integrate_env(*M, *B, e, A);
+    return true;
+  }
+  static bool launch_lane_forward(const DModel* M, const DBatch* B, int nenv, int, int stages, void*) {
+    for (int e = 0; e < nenv; e++) ln::forward_or_euler(*M, *B, e, stages);
+    return true;
+  }
+  static bool launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int, void*) {
+    for (int e = 0; e < nenv; e++) ln::reset_env(*M, *B, e);
     return true;
   }
   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void*) {
-    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { reset_env(*M, *B, wv_env()); });
+    for (int e = 0; e < nenv; e++) runner()->run(e, [&]() { wv::reset_env(*M, *B, wv_env()); });
     return true;
   }
 };
