@@ -481,6 +481,73 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
   s.nconlds = std::min(s.nconmax, 8);
+  // L'DL fast path tables (mjh_smooth.h: factor_ld / solve_ld)
+  {
+    const int nv = m->nv;
+    int maxdepth = 0;
+    for (int i = 0; i < nv; i++) maxdepth = std::max(maxdepth, m->M_rownnz[i] - 1);
+    s.ld_fast = (nv <= 64 && m->nC <= 1024 && maxdepth <= 16) ? 1 : 0;
+    H->dof_ancmask.assign(2*(size_t)nv, 0);
+    H->ld_prog_adr.assign((size_t)nv + 1, 0);
+    H->ld_prog.clear();
+    if (s.ld_fast) {
+      for (int i = 0; i < nv; i++) {
+        unsigned long long mask = 0;
+        for (int a = 0; a < m->M_rownnz[i] - 1; a++) mask |= 1ull << m->M_colind[m->M_rowadr[i] + a];
+        H->dof_ancmask[2*i] = (int)(unsigned)(mask & 0xffffffffu);
+        H->dof_ancmask[2*i + 1] = (int)(unsigned)(mask >> 32);
+      }
+      // items are stored pivot by pivot in the order the factorisation visits them (k = nv-1 .. 0)
+      std::vector<std::vector<int>> per(nv);
+      for (int k = 0; k < nv; k++) {
+        int start = m->M_rowadr[k], diag = m->M_rownnz[k] - 1;
+        for (int a = 0; a < diag; a++) {
+          int i = m->M_colind[start + a];
+          for (int el = 0; el <= a; el++)
+            per[k].push_back((m->M_rowadr[i] + el) | ((start + el) << 10) | ((start + a) << 20));
+        }
+      }
+      for (int k = 0; k < nv; k++) {
+        H->ld_prog_adr[k] = (int)H->ld_prog.size();
+        H->ld_prog.insert(H->ld_prog.end(), per[k].begin(), per[k].end());
+      }
+      H->ld_prog_adr[nv] = (int)H->ld_prog.size();
+    }
+    if (H->ld_prog.empty()) H->ld_prog.push_back(0);
+    s.nldprog = (int)H->ld_prog.size();
+  }
+  // PGS visitation orders for nefc = 1..64 (engine_solver.c:241-265, :498-502): PCG32 with
+  // state = 0, inc = 1 and one warm-up draw per solver call; every iteration Fisher-Yates-shuffles
+  // the order array left by the previous iteration with j = next % (i+1), i = n-1 .. 1
+  {
+    s.pgs_iters = std::max(0, std::min((int)m->opt.iterations, 128));
+    H->pgs_order_adr.assign(66, 0);
+    H->pgs_order.clear();
+    for (int n = 0; n <= 64; n++) {
+      H->pgs_order_adr[n] = (int)H->pgs_order.size();
+      uint64_t state = 0, inc = 1;
+      auto next = [&]() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + (inc | 1);
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (uint32_t)((xorshifted >> rot) | (xorshifted << ((-rot) & 31)));
+      };
+      next();
+      std::vector<int> order(n);
+      for (int i = 0; i < n; i++) order[i] = i;
+      for (int it = 0; it < s.pgs_iters; it++) {
+        for (int i = n - 1; i > 0; i--) {
+          uint32_t j = next() % (uint32_t)(i + 1);
+          std::swap(order[i], order[j]);
+        }
+        H->pgs_order.insert(H->pgs_order.end(), order.begin(), order.end());
+      }
+    }
+    H->pgs_order_adr[65] = (int)H->pgs_order.size();
+    if (H->pgs_order.empty()) H->pgs_order.push_back(0);
+    s.npgsorder = (int)H->pgs_order.size();
+  }
   int rows_per_con = 1;
   for (int c : H->pair_dim) rows_per_con = std::max(rows_per_con, c == 1 ? 1 : 2*(c-1));
   int nefc_bound = nfric + nlimit + rows_per_con*s.nconmax;

@@ -325,6 +325,130 @@ MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 }
 
+#if !MJH_LANE_MODE
+// ------------------------------------------------------------------------------------------------
+// Wavefront L'DL routines for nv <= 64 (M.s.ld_fast): lane i owns dof i.
+// Row addresses, row lengths and the strict-ancestor masks sit in registers and are handed around
+// with v_readlane, so the serial sweeps contain no dependent model-memory loads; qLD itself is
+// read where it lives (LDS by plan).  Same arithmetic, same order as the generic versions below.
+// ------------------------------------------------------------------------------------------------
+template <class P0, class P1>
+MJH_DEVN void factor_ld_fast(const DModel& M_, P0 mat, P1 diaginv) {
+  const auto& M = wv_uniform_ref(M_);
+  const auto* ld_prog = wv_uniform_ptr(M.ld_prog);
+  const int nv = M.s.nv;
+  const int lane = wv_lane();
+  const int li = lane < nv ? lane : 0;
+  const int myadr = wv_uniform_ptr(M.M_rowadr)[li];
+  const int mynnz = wv_uniform_ptr(M.M_rownnz)[li];
+  const int myprog = wv_uniform_ptr(M.ld_prog_adr)[li];
+  // first 64 update items of the pivot about to be processed (prefetched one pivot ahead)
+  const int first = wv_bcast_i(myprog, nv - 1) + lane;
+  int item = ld_prog[first < M.s.nldprog ? first : 0];
+  for (int k = nv - 1; k >= 0; k--) {
+    const int start = wv_bcast_i(myadr, k);
+    const int diag = wv_bcast_i(mynnz, k) - 1;
+    const int pbase = wv_bcast_i(myprog, k);
+    const int total = diag*(diag + 1)/2;
+    int item_next = 0;
+    if (k > 0) {
+      int nb = wv_bcast_i(myprog, k - 1) + lane;
+      item_next = ld_prog[nb < M.s.nldprog ? nb : 0];
+    }
+    const real invD = 1 / mat[start + diag];
+    for (int w = lane; w < total; w += MJH_W) {
+      const int it = (w < MJH_W) ? item : ld_prog[pbase + w];
+      const int dst = it & 1023, src = (it >> 10) & 1023, sc = (it >> 20) & 1023;
+      const real scl = -mat[sc] * invD;
+      mat[dst] += mat[src] * scl;
+    }
+    wv_sync();
+    if (lane < diag) mat[start + lane] = mat[start + lane] * invD;     // diag <= 16
+    if (lane == 0) diaginv[k] = invD;
+    wv_sync();
+    item = item_next;
+  }
+}
+
+template <class P0, class P1, class P2>
+MJH_DEVN void solve_ld_fast(const DModel& M_, P0 xmem, P1 qLD, P2 diaginv) {
+  const auto& M = wv_uniform_ref(M_);
+  const auto* colind = wv_uniform_ptr(M.M_colind);
+  const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);
+  const int nv = M.s.nv;
+  const int lane = wv_lane();
+  const int li = lane < nv ? lane : 0;
+  const int myadr = wv_uniform_ptr(M.M_rowadr)[li];
+  const int mynnz = wv_uniform_ptr(M.M_rownnz)[li];
+  const int mydepth = mynnz - 1;                       // my position in every descendant's row
+  const int anc_lo = ancmask[2*li], anc_hi = ancmask[2*li + 1];
+  real x = lane < nv ? xmem[li] : 0;
+  const real dinv = lane < nv ? diaginv[li] : 0;
+
+  // x <- L^-T x : row i scatters into its ancestors; lane a is an ancestor of i iff bit a of i's mask
+  int ilast = nv - 1;
+  while (ilast > 0 && wv_bcast_i(mynnz, ilast) == 1) ilast--;
+  real q = 0;
+  {
+    const int lo = wv_bcast_i(anc_lo, ilast), hi = wv_bcast_i(anc_hi, ilast);
+    const int isanc = lane < 32 ? (lo >> lane) & 1 : (hi >> (lane - 32)) & 1;
+    const int adr = wv_bcast_i(myadr, ilast);
+    if (isanc) q = qLD[adr + mydepth];
+  }
+  for (int i = ilast; i > 0; ) {
+    // next row with off-diagonals, and its coefficient for this lane (prefetch)
+    int inext = i - 1;
+    while (inext > 0 && wv_bcast_i(mynnz, inext) == 1) inext--;
+    real qnext = 0;
+    if (inext > 0) {
+      const int lo = wv_bcast_i(anc_lo, inext), hi = wv_bcast_i(anc_hi, inext);
+      const int isanc = lane < 32 ? (lo >> lane) & 1 : (hi >> (lane - 32)) & 1;
+      const int adr = wv_bcast_i(myadr, inext);
+      if (isanc) qnext = qLD[adr + mydepth];
+    }
+    const real xi = wv_bcast(x, i);
+    if (xi != 0) {
+      const int lo = wv_bcast_i(anc_lo, i), hi = wv_bcast_i(anc_hi, i);
+      const int isanc = lane < 32 ? (lo >> lane) & 1 : (hi >> (lane - 32)) & 1;
+      if (isanc) x -= q * xi;
+    }
+    q = qnext;
+    i = inext;
+  }
+  // x <- D^-1 x
+  x *= dinv;
+  // x <- L^-1 x : for row i, lane k < nnz-1 takes position k of the row (ancestor colind[adr+k]);
+  // mju_dotSparse sums positions in four interleaved chains, (r0+r2)+(r1+r3), then the tail one by one
+  for (int i = 1; i < nv; i++) {
+    const int nnz1 = wv_bcast_i(mynnz, i) - 1;
+    if (nnz1 == 0) continue;
+    const int adr = wv_bcast_i(myadr, i);
+    const int act = lane < nnz1;
+    const int anc = act ? colind[adr + lane] : 0;
+    const real qk = act ? qLD[adr + lane] : 0;
+    const real xa = wv_shfl(x, anc);
+    const real p = qk * xa;
+    const int n4 = nnz1 & ~3, L = n4 >> 2;
+    real acc = 0;
+    if (L > 0) {
+      acc = acc + p;
+      if (L > 1) {
+        acc = acc + wv_row_shl<4>(p);
+        if (L > 2) {
+          acc = acc + wv_row_shl<8>(p);
+          if (L > 3) acc = acc + wv_row_shl<12>(p);
+        }
+      }
+    }
+    real res = (wv_bcast(acc, 0) + wv_bcast(acc, 2)) + (wv_bcast(acc, 1) + wv_bcast(acc, 3));
+    for (int t = n4; t < nnz1; t++) res += wv_bcast(p, t);
+    if (lane == i) x -= res;
+  }
+  if (lane < nv) xmem[li] = x;
+  wv_sync();
+}
+#endif  // !MJH_LANE_MODE
+
 // ------------------------------------------------------------------------------------------------
 // sparse L'DL factorisation in place              (mj_factorI, engine_core_smooth.c:2005-2029)
 // rows nv-1 .. 0 in order; for one row k the updates of its ancestor rows are independent
@@ -332,6 +456,9 @@ MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
 template <class P0, class P1>
 MJH_DEVN void factor_ld(const DModel& M, P0 mat, P1 diaginv) {
   const int nv = M.s.nv;
+#if !MJH_LANE_MODE
+  if (M.s.ld_fast) { factor_ld_fast(M, mat, diaginv); return; }
+#endif
   for (int k = nv - 1; k >= 0; k--) {
     int start = M.M_rowadr[k];
     int diag = M.M_rownnz[k] - 1;
@@ -380,6 +507,9 @@ MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
 template <class P0, class P1, class P2>
 MJH_DEVN void solve_ld(const DModel& M, P0 x, P1 qLD, P2 diaginv) {
   const int nv = M.s.nv;
+#if !MJH_LANE_MODE
+  if (M.s.ld_fast) { solve_ld_fast(M, x, qLD, diaginv); return; }
+#endif
   // x <- L^-T x : row i scatters into its ancestors (independent targets)
   for (int i = nv - 1; i >= 0; i--) {
     int nnz = M.M_rownnz[i];

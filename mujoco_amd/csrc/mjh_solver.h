@@ -42,6 +42,149 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
   return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
 }
 
+#if !MJH_LANE_MODE
+// ------------------------------------------------------------------------------------------------
+// solPGS for nefc <= 64 with the iterate in registers           (engine_solver.c:457-741)
+//
+// Lane layout.  mju_dot sums a row product in four interleaved chains (j = c, c+4, c+8, ...), each
+// strictly left to right, then (r0+r2)+(r1+r3), then the 1..3 tail products as one expression.
+// Chain c is given DPP row c: constraint j < n4 lives in lane 16*(j&3) + (j>>2), tail constraint
+// n4+t in lane 16*t + 15 (free because n4 <= 60 whenever a tail exists).  A chain sum is then
+// L = n4/4 dependent adds, each fed by a row broadcast (v_mov_dpp row_newbcast:k) -- no LDS, no
+// barrier -- and reproduces the reference's rounding exactly.
+// Every lane keeps force, b, 1/AR_jj, frictionloss and the Nesterov history of its own constraint;
+// the owner lane of the row being visited updates itself.  The visitation order of iteration k
+// comes from the precomputed table M.pgs_order (it depends on (nefc, k) only).
+// ------------------------------------------------------------------------------------------------
+#define MJH_PGS_CHAIN_STEP(k) if (L > k) { acc = acc + wv_row_bcast<k>(p);
+#define MJH_PGS_CHAIN_END }}}}}}}}}}}}}}}
+
+MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
+  const auto& M = wv_uniform_ref(M_);
+  const DBatch& B = B_;
+  const int e = wv_uniform_i(e_);
+  iptr counts = MJH_F(B, counts, e);
+  const int n = wv_uniform_i(counts[MJH_C_NEFC]), ne = wv_uniform_i(counts[MJH_C_NE]), nf = wv_uniform_i(counts[MJH_C_NF]);
+  Efc P;
+  efc_layout(M_, B, e, n, P);
+  const int lane = wv_lane();
+  const int n4 = n & ~3, L = n4 >> 2, ntail = n - n4;
+  const int row = lane >> 4, col = lane & 15;
+  // constraint owned by this lane (-1: none)
+  int j = -1;
+  if (col < L) j = 4*col + row;
+  else if (col == 15 && row < ntail) j = n4 + row;
+  const int own = (j >= 0);
+  const int jj = own ? j : 0;
+  const int kind = (jj < ne) ? 0 : (jj < ne + nf ? 1 : 2);   // equality / friction / inequality
+  real f = own ? P.force[jj] : 0;
+  const real bj = own ? P.b[jj] : 0;
+  const real fl = own ? P.floss[jj] : 0;
+  const real arjj = own ? P.AR[(size_t)jj*n + jj] : 1;
+  const real ainv = 1 / arjj;
+  real fprev = f, fmom = f;
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const auto* otab = wv_uniform_ptr(M.pgs_order) + wv_uniform_ptr(M.pgs_order_adr)[n];
+
+  int iter = 0, nesterov_k = 0;
+  while (iter < maxiter) {
+    // ---- Nesterov extrapolation (:508-554)
+    real beta = 0;
+    if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+    if (beta > 0) {
+      real f_save = f;
+      real fx = f_save + beta*(f_save - fprev);
+      fprev = f_save;
+      if (kind == 1) fx = r_clip(fx, -fl, fl);
+      else if (kind == 2 && fx < 0) fx = 0;
+      f = fx;
+      fmom = fx;
+    } else {
+      fprev = f;
+      fmom = f;
+    }
+    // ---- this iteration's visitation order: lane b holds order[b]
+    const int ord = (lane < n) ? otab[iter*n + lane] : 0;
+
+    // ---- one sweep
+    real improvement = 0;
+    int i = wv_bcast_i(ord, 0);
+    real a = own ? P.AR[(size_t)i*n + jj] : 0;       // row of the first visited constraint
+    for (int bi = 0; bi < n; bi++) {
+      // prefetch the next row while this one is reduced
+      const int inext = wv_bcast_i(ord, bi + 1 < n ? bi + 1 : bi);
+      const real anext = own ? P.AR[(size_t)inext*n + jj] : 0;
+      const real p = a*f;
+      // chain sums: acc of DPP row c = r_c (mju_dot's res_c), valid in every lane of the row
+      real acc = 0;
+      if (L > 0) { acc = acc + wv_row_bcast<0>(p);
+      MJH_PGS_CHAIN_STEP(1) MJH_PGS_CHAIN_STEP(2) MJH_PGS_CHAIN_STEP(3) MJH_PGS_CHAIN_STEP(4)
+      MJH_PGS_CHAIN_STEP(5) MJH_PGS_CHAIN_STEP(6) MJH_PGS_CHAIN_STEP(7) MJH_PGS_CHAIN_STEP(8)
+      MJH_PGS_CHAIN_STEP(9) MJH_PGS_CHAIN_STEP(10) MJH_PGS_CHAIN_STEP(11) MJH_PGS_CHAIN_STEP(12)
+      MJH_PGS_CHAIN_STEP(13) MJH_PGS_CHAIN_STEP(14) MJH_PGS_CHAIN_STEP(15)
+      MJH_PGS_CHAIN_END }
+      real dot = (wv_bcast(acc, 0) + wv_bcast(acc, 32)) + (wv_bcast(acc, 16) + wv_bcast(acc, 48));
+      if (ntail == 3) dot += wv_bcast(p, 15) + wv_bcast(p, 31) + wv_bcast(p, 47);
+      else if (ntail == 2) dot += wv_bcast(p, 15) + wv_bcast(p, 31);
+      else if (ntail == 1) dot += wv_bcast(p, 15);
+      // every lane evaluates the update for its own constraint; only the owner of row i keeps it
+      const real res = bj + dot;
+      const real oldf = f;
+      real fn = oldf - res*ainv;
+      if (kind == 1) {
+        if (fn < -fl) fn = -fl;
+        else if (fn > fl) fn = fl;
+      } else if (kind == 2) {
+        if (fn < 0) fn = 0;
+      }
+      // costChange (:216-237) with A = 1/ARinv
+      const real A = 1/ainv;
+      const real delta = fn - oldf;
+      real change = 0.5*delta*delta*A + delta*res;
+      if (change > 1e-10) { fn = oldf; change = 0; }
+      // owner lane of constraint i
+      const int li = (i < n4) ? 16*(i & 3) + (i >> 2) : 16*(i - n4) + 15;
+      if (lane == li) f = fn;
+      improvement -= wv_bcast(change, li);
+      i = inext;
+      a = anext;
+    }
+    improvement *= scale;
+
+    // ---- gradient restart (:694-713): sum over constraints in index order
+    int restart = 0;
+    if (iter > 0) {
+      const real ce = (f - fmom) * (fmom - fprev);
+      real dotce = 0;
+      for (int q = 0; q < n; q++) {
+        const int lq = (q < n4) ? 16*(q & 3) + (q >> 2) : 16*(q - n4) + 15;
+        dotce += wv_bcast(ce, lq);
+      }
+      restart = (dotce < 0);
+    }
+    if (restart) nesterov_k = 0; else nesterov_k++;
+    iter++;
+    if (improvement < M.o.tolerance) break;
+  }
+
+  // final dual state (dualState, :270-345), forces back to memory, iteration count
+  if (own) {
+    int st;
+    if (kind == 0) st = MJH_STATE_QUADRATIC;
+    else if (kind == 1) {
+      if (f <= -fl) st = MJH_STATE_LINEARPOS;
+      else if (f >= fl) st = MJH_STATE_LINEARNEG;
+      else st = MJH_STATE_QUADRATIC;
+    } else st = (f <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+    P.state[jj] = st;
+    P.force[jj] = f;
+  }
+  if (lane == 0) counts[MJH_C_NITER] = iter;
+  wv_sync();
+}
+#endif  // !MJH_LANE_MODE
+
 // ------------------------------------------------------------------------------------------------
 // solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
 // ------------------------------------------------------------------------------------------------
@@ -218,6 +361,10 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
   }
   wv_sync();
 
+#if !MJH_LANE_MODE
+  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters) solve_pgs_fast(M, B, e);
+  else
+#endif
   solve_pgs(M, B, e);
 
   // mj_dualFinish, first half (engine_solver.c:72-85): qfrc_constraint = J' f

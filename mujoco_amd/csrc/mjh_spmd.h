@@ -28,6 +28,11 @@
 
 #define MJH_DEV static inline
 #define MJH_MEM inline
+// wave-uniform, read-only views of model data (identity on the host)
+#define MJH_CONST_AS
+template <class T> static inline const T* wv_uniform_ptr(const T* p) { return p; }
+template <class T> static inline const T& wv_uniform_ref(const T& r) { return r; }
+static inline int wv_uniform_i(int v) { return v; }
 #define MJH_DEVN_WAVE static __attribute__((noinline))
 #define MJH_DEVN_LANE static inline
 #define MJH_GLOBAL static void
@@ -122,6 +127,26 @@ MJH_DEV double wv_shfl(double v, int src) {
   return r;
 }
 MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
+// value held by lane (lane + K) of the caller's 16-lane row; 0 beyond the row's end
+template <int K>
+MJH_DEV double wv_row_shl(double v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = ((w->cur & 15) + K < 16) ? w->dscratch[w->cur + K] : 0.0;
+  mjhsim::yield();
+  return r;
+}
+// value held by lane K of the caller's 16-lane row
+template <int K>
+MJH_DEV double wv_row_bcast(double v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[(w->cur & ~15) + K];
+  mjhsim::yield();
+  return r;
+}
 MJH_DEV long long wv_clock() { return 0; }
 
 #else
@@ -132,6 +157,22 @@ MJH_DEV long long wv_clock() { return 0; }
 
 #define MJH_DEV __device__ __forceinline__
 #define MJH_MEM __device__ __forceinline__
+// Wave-uniform, read-only views of model data.  A stage function that was not inlined receives
+// its pointers in VGPRs, so the compiler must assume they differ per lane: every model constant
+// becomes a vector load and every loop a divergent loop.  These helpers move the pointer to
+// SGPRs (v_readfirstlane) and retype it to the constant address space, which makes the loads
+// scalar (s_load) and their results provably uniform.
+#define MJH_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const MJH_CONST_AS T* wv_uniform_ptr(const T* p) {
+  unsigned long long a = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const MJH_CONST_AS T*)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ const MJH_CONST_AS T& wv_uniform_ref(const T& r) { return *wv_uniform_ptr(&r); }
+__device__ __forceinline__ int wv_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // out-of-line device function: gives the big stages their own register allocation scope
 // register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident
 #define MJH_WAVES_PER_EU 2
@@ -168,6 +209,20 @@ MJH_DEV int wv_exscan_i(int v) {
 MJH_DEV double wv_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 MJH_DEV double wv_shfl(double v, int src) { return __shfl(v, src, 64); }
 MJH_DEV int wv_any(int pred) { return __any(pred); }
+// value held by lane (lane + K) of the caller's 16-lane DPP row, 0 beyond its end (row_shl:K)
+template <int K>
+MJH_DEV double wv_row_shl(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + K, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// value held by lane K of the caller's 16-lane DPP row (v_mov_b32_dpp row_newbcast:K, no LDS)
+template <int K>
+MJH_DEV double wv_row_bcast(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 // constant-rate (100 MHz) timestamp, for -DMJH_PROFILE builds
 MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 

@@ -73,7 +73,16 @@
   X(pair_geom2, s.npair)                       \
   X(pair_dim, s.npair)                         \
   X(pair_maxcon, s.npair)                      \
-  X(pair_func, s.npair)
+  X(pair_func, s.npair)                        \
+  /* PGS block visitation orders: engine_solver.c shuffles with a PCG32 that is re-seeded at every \
+     solver call, so the order array after iteration k depends only on (nefc, k): precomputed */ \
+  X(pgs_order_adr, 66)                         \
+  /* L'DL fast path: strict-ancestor bit mask of every dof (2 words), and the flattened update \
+     list of mj_factorI: for pivot row k, items dst | src<<10 | scl<<20 (indices into qLD) */ \
+  X(dof_ancmask, 2 * s.nv)                     \
+  X(ld_prog_adr, s.nv + 1)                     \
+  X(ld_prog, s.nldprog)                        \
+  X(pgs_order, s.npgsorder)
 
 // ---- model: real arrays -----------------------------------------------------------------------
 #define MJH_MODEL_REAL_FIELDS(X)               \
@@ -146,6 +155,10 @@ struct DSizes {
   int nconlds;     // contact slots kept in LDS by the residency plan
   int nefcmax;     // per-env constraint-row capacity
   int nstate;      // mj_stateSize(FULLPHYSICS)
+  int npgsorder;   // entries of the precomputed PGS visitation-order table
+  int nldprog;     // entries of the flattened L'DL update list
+  int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
+  int pgs_iters;   // iterations covered by that table (min(opt.iterations, 128))
 };
 
 struct DOptions {

@@ -8,8 +8,9 @@ import torch
 import mujoco_amd as ma
 from bench import initial_states
 
-NAMES = ["begin", "kin", "compos", "tendon", "crb", "factor", "collision", "transmission", "tavel", "comvel",
-         "passive", "rne", "actuation", "accel", "make", "project", "reference", "constraint", "euler", "end"]
+NAMES = ["begin", "kin", "compos", "tendon", "crb", "factor", "transmission", "tavel", "comvel",
+         "passive", "rne", "actuation", "accel", "collision", "make", "project", "reference", "constraint",
+         "finish", "euler", "end"]
 lib = ma.lib()
 model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
 model.set_option("solver", 0)
@@ -23,14 +24,14 @@ dev = torch.device("cuda", 0)
 st0 = torch.from_numpy(s0).to(dev)
 cw = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, W, dm.nu))).to(dev)
 ck = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, K, dm.nu))).to(dev)
-ws_ptr = b.field_info("qacc_warmstart")[0]
+
 b.rollout_device(W, ma.mjSTATE_CTRL, st0.data_ptr(), 0, cw.data_ptr(), 0, 0)
 b.sync()
 b.set("prof", np.zeros((nenv, 32)))
 import time
 t0 = time.perf_counter()
 for c in range(0, K, 10):
-    b.rollout_device(10, ma.mjSTATE_CTRL, 0, ws_ptr, ck[:, c:c+10].contiguous().data_ptr(), 0, 0)
+    b.rollout_device(10, ma.mjSTATE_CTRL, 0, 0, ck[:, c:c+10].contiguous().data_ptr(), 0, 0, cont=True)
 b.sync()
 el = time.perf_counter() - t0
 p = b.get("prof")
@@ -57,3 +58,13 @@ u, cnt = np.unique(key, return_counts=True)
 print("distinct (xcc,se,sh,cu,simd):", len(u), " distinct xcc:", len(np.unique(xcc)), " waves per simd: min %d max %d" % (cnt.min(), cnt.max()))
 order = np.argsort(st)
 print("start-time quantiles (us from first):", np.round(np.quantile(st - st.min(), [0, .1, .25, .5, .75, .9, 1]), 1))
+
+# the heaviest environments of the measured window
+tot = p[:, 31]
+idx = np.argsort(-tot)[:5]
+print("heaviest envs (us per step by stage):")
+for e in idx:
+    print("  env %d: total %.0f us/step, nefc(last) %d niter(last) %d :" % (e, tot[e]/nst, c[e,1], c[e,5]),
+          " ".join("%s=%.0f" % (NAMES[i], p[e,i]/nst) for i in range(len(NAMES)) if p[e,i]/nst >= 5))
+print("duration quantiles us/step:", np.round(np.quantile(tot/nst, [0, .25, .5, .75, .9, .99, 1]), 0))
+print("nefc quantiles:", np.quantile(c[:,1], [0, .25, .5, .75, .9, .99, 1]), " niter quantiles:", np.quantile(c[:,5], [0,.25,.5,.75,.9,.99,1]))
