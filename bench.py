@@ -80,6 +80,20 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
                       f"{iters} PGS iters/step)"}
 
 
+def measured_traffic(steps_per_launch: int, nenv: int):
+    """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command (tools/gpu_profile.sh -> profiles/<round>/pmc_summary.txt; FETCH_SIZE x2 per the
+    gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the launch."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt"))):
+        m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB",
+                      open(f).read())
+        if m and int(m.group(1)) == steps_per_launch and int(m.group(2)) == nenv:
+            best = (float(m.group(4)) + float(m.group(5))) * 1e6
+    return best
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +107,7 @@ def main() -> None:
 
     import torch
     import mujoco_amd as ma
+    from mujoco_amd.sharding import gather_to_rank0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +148,6 @@ def main() -> None:
     state_k = [None if args.no_state_output else torch.empty((nenv, c, nstate), dtype=torch.float64, device=dev)
                for c in chunks(K)]
     final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
-    gathered = [torch.empty_like(final) for _ in range(world)] if (dist and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -169,7 +183,7 @@ def main() -> None:
     if state_k[-1] is not None:
         final.copy_(state_k[-1][:, -1])
     if dist:
-        dist.gather(final, gathered, dst=0)       # end-of-chunk observation gather (RCCL over xGMI)
+        gather_to_rank0(final, rank, world, dist)  # end-of-run state gather (RCCL over xGMI)
     barrier()
     elapsed = time.perf_counter() - t0
     timed = [(a.elapsed_time(b), n) for a, b, n in events[n_warm_launch:]]
@@ -208,9 +222,11 @@ def main() -> None:
                                    "random actions U(ctrlrange), per-step state output" +
                                    ("" if not args.no_state_output else " disabled"),
                        "envs_per_gpu": nenv, "nstep": K, "solver": "PGS", "integrator": "Euler",
-                       "parallelism": f"env-sharded x{world}"},
+                       "parallelism": f"env-sharded x{world}",
+                       "mapping": batch.lds_report().splitlines()[0] if batch.lds_report() else "no LDS plan",
+                       "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv),
                          "kernel": "mjh_k_rollout", "steps_per_launch": C,
                          "launch_ms": launch_ms_timed, "launch_ms_incl_warmup": launch_ms_all,
                          "kernel_ms_total": kernel_ms,

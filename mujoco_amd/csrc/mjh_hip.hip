@@ -25,7 +25,31 @@ __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WA
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_rollout(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, RolloutArgs A) {
-  wv::rollout_env(*M, *B, (int)blockIdx.x, A);
+  // workgroups are dispatched in blockIdx order: perm lists the environments by decreasing cost
+  wv::rollout_env(*M, *B, B->perm[blockIdx.x], A);
+}
+
+// Longest-processing-time-first launch order for the next rollout launch: counting sort of the
+// environments by the cost measured in the last one (256 buckets, one workgroup).
+__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B) {
+  __shared__ int hist[256];
+  __shared__ int maxc;
+  const int n = B->nenv, tid = (int)threadIdx.x;
+  const int* cost = B->cost;
+  int* perm = B->perm;
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) maxc = 1;
+  __syncthreads();
+  int m = 1;
+  for (int e = tid; e < n; e += 1024) m = max(m, cost[e]);
+  atomicMax(&maxc, m);
+  __syncthreads();
+  const float scale = 255.0f / (float)maxc;
+  for (int e = tid; e < n; e += 1024) atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int b = 0; b < 256; b++) { int c = hist[b]; hist[b] = acc; acc += c; } }
+  __syncthreads();
+  for (int e = tid; e < n; e += 1024) perm[atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1)] = e;
 }
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_reset(const DModel* __restrict__ M,
@@ -92,6 +116,8 @@ struct Backend {
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void* stream) {
     hipLaunchKernelGGL(mjh_k_rollout, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, A);
+    if (hipGetLastError() != hipSuccess) return false;
+    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B);
     return hipGetLastError() == hipSuccess;
   }
   static dim3 lane_grid(int nenv, int epw) { return dim3((nenv + epw - 1) / epw); }

@@ -341,6 +341,13 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
     mjhip_batch_destroy(Bt);
     return nullptr;
   }
+  {
+    std::vector<int> ident((size_t)Bt->nenvpad);
+    for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
+    if (!Backend::h2d(Bt->D.perm, ident.data(), ident.size()*sizeof(int), nullptr) || !Backend::sync(nullptr)) {
+      set_err("mjhip: batch initialisation failed"); mjhip_batch_destroy(Bt); return nullptr;
+    }
+  }
   // residency plan: MJHIP_LDS_BYTES overrides the default per-workgroup LDS budget (0 disables)
   {
     int budget = MJHIP_DEFAULT_LDS_BYTES;

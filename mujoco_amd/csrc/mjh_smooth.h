@@ -419,13 +419,23 @@ MJH_DEVN void solve_ld_fast(const DModel& M_, P0 xmem, P1 qLD, P2 diaginv) {
   x *= dinv;
   // x <- L^-1 x : for row i, lane k < nnz-1 takes position k of the row (ancestor colind[adr+k]);
   // mju_dotSparse sums positions in four interleaved chains, (r0+r2)+(r1+r3), then the tail one by one
+  // (lane k's ancestor index and coefficient of the next row are fetched while this row is reduced)
+  int anc_n = 0;
+  real qk_n = 0;
+  if (nv > 1) {
+    const int nnz1 = wv_bcast_i(mynnz, 1) - 1, adr = wv_bcast_i(myadr, 1);
+    if (lane < nnz1) { anc_n = colind[adr + lane]; qk_n = qLD[adr + lane]; }
+  }
   for (int i = 1; i < nv; i++) {
     const int nnz1 = wv_bcast_i(mynnz, i) - 1;
+    const int anc = anc_n;
+    const real qk = qk_n;
+    anc_n = 0; qk_n = 0;
+    if (i + 1 < nv) {
+      const int nnz1n = wv_bcast_i(mynnz, i + 1) - 1, adrn = wv_bcast_i(myadr, i + 1);
+      if (lane < nnz1n) { anc_n = colind[adrn + lane]; qk_n = qLD[adrn + lane]; }
+    }
     if (nnz1 == 0) continue;
-    const int adr = wv_bcast_i(myadr, i);
-    const int act = lane < nnz1;
-    const int anc = act ? colind[adr + lane] : 0;
-    const real qk = act ? qLD[adr + lane] : 0;
     const real xa = wv_shfl(x, anc);
     const real p = qk * xa;
     const int n4 = nnz1 & ~3, L = n4 >> 2;

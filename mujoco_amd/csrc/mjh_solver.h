@@ -82,13 +82,18 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
   const real fl = own ? P.floss[jj] : 0;
   const real arjj = own ? P.AR[(size_t)jj*n + jj] : 1;
   const real ainv = 1 / arjj;
+  const real A = 1/ainv;                  // costChange's A (:216-237), the same bits every visit
   real fprev = f, fmom = f;
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
   const auto* otab = wv_uniform_ptr(M.pgs_order) + wv_uniform_ptr(M.pgs_order_adr)[n];
 
   int iter = 0, nesterov_k = 0;
+  // visitation order of the coming iteration (lane b holds order[b]); fetched one iteration ahead
+  int ord_next = (lane < n) ? otab[lane] : 0;
   while (iter < maxiter) {
+    const int ord = ord_next;
+    if (iter + 1 < maxiter) ord_next = (lane < n) ? otab[(iter + 1)*n + lane] : 0;
     // ---- Nesterov extrapolation (:508-554)
     real beta = 0;
     if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
@@ -104,9 +109,6 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
       fprev = f;
       fmom = f;
     }
-    // ---- this iteration's visitation order: lane b holds order[b]
-    const int ord = (lane < n) ? otab[iter*n + lane] : 0;
-
     // ---- one sweep
     real improvement = 0;
     int i = wv_bcast_i(ord, 0);
@@ -139,7 +141,6 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
         if (fn < 0) fn = 0;
       }
       // costChange (:216-237) with A = 1/ARinv
-      const real A = 1/ainv;
       const real delta = fn - oldf;
       real change = 0.5*delta*delta*A + delta*res;
       if (change > 1e-10) { fn = oldf; change = 0; }

@@ -252,6 +252,7 @@ MJH_DEV void set_state(const DModel& M, const DBatch& B, int e, P0 in) {
 MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
   const DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
+  const long long c_begin = wv_clock();
   lds_enter(M, B, e);
   if (A.init) {
     if (A.state0) set_state(M, B, e, A.state0 + r*s.nstate);
@@ -285,6 +286,8 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
     wv_sync();
   }
   lds_exit(M, B, e);
+  // what this environment cost: the next launch starts the expensive ones first (mjh_k_balance)
+  if (wv_lane() == 0) MJH_G(B, cost, e)[0] = (int)((wv_clock() - c_begin) >> 4);
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {
     rptr pr = MJH_G(B, prof, e);

@@ -293,7 +293,11 @@ enum {
   X(efc_state, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
   X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)         \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
-  X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)
+  X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)                                           \
+  /* load balancing of the wave-per-environment kernels: cost = wall-clock ticks env e took in   \
+     its last launch; perm = launch order (workgroup w steps env perm[w]), most expensive first */ \
+  X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
+  X(perm, 1, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0

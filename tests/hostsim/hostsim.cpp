@@ -97,7 +97,8 @@ struct Backend {
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void*) {
-    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { wv::rollout_env(*M, *B, wv_env(), A); }); }
+    // (launch order: the emulation runs the permutation back to front to show results do not depend on it)
+    for (int w = nenv - 1; w >= 0; w--) { poison_lds(lds); runner()->run(B->perm[w], [&]() { wv::rollout_env(*M, *B, wv_env(), A); }); }
     return true;
   }
   // lane mode needs no wavefront emulation: every environment is an ordinary serial call

@@ -68,3 +68,12 @@ for e in idx:
           " ".join("%s=%.0f" % (NAMES[i], p[e,i]/nst) for i in range(len(NAMES)) if p[e,i]/nst >= 5))
 print("duration quantiles us/step:", np.round(np.quantile(tot/nst, [0, .25, .5, .75, .9, .99, 1]), 0))
 print("nefc quantiles:", np.quantile(c[:,1], [0, .25, .5, .75, .9, .99, 1]), " niter quantiles:", np.quantile(c[:,5], [0,.25,.5,.75,.9,.99,1]))
+
+t0_ = st.min()
+ts = np.linspace(0, en.max() - t0_, 21)
+print("running waves over time (us: count):", " ".join("%d:%d" % (t, int(((st - t0_ <= t) & (en - t0_ >= t)).sum())) for t in ts))
+dur = en - st
+late = np.argsort(-en)[:6]
+print("last finishers: (start us, dur us, cost-rank)", [(int(st[e]-t0_), int(dur[e]), int((dur > dur[e]).sum())) for e in late])
+first = np.argsort(st)[:2048]
+print("mean duration of the first 2048 starters %.0f us, of the rest %.0f us" % (dur[first].mean(), np.delete(dur, first).mean()))
