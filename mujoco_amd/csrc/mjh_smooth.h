@@ -467,7 +467,11 @@ template <class P0, class P1>
 MJH_DEVN void factor_ld(const DModel& M, P0 mat, P1 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
-  if (M.s.ld_fast) { factor_ld_fast(M, mat, diaginv); return; }
+  if (M.s.ld_fast) {
+    if (mjh_in_lds(mat)) factor_ld_fast(M, mjh_local(mat.p), diaginv);
+    else factor_ld_fast(M, mat, diaginv);
+    return;
+  }
 #endif
   for (int k = nv - 1; k >= 0; k--) {
     int start = M.M_rowadr[k];
@@ -518,7 +522,11 @@ template <class P0, class P1, class P2>
 MJH_DEVN void solve_ld(const DModel& M, P0 x, P1 qLD, P2 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
-  if (M.s.ld_fast) { solve_ld_fast(M, x, qLD, diaginv); return; }
+  if (M.s.ld_fast) {
+    if (mjh_in_lds(qLD)) solve_ld_fast(M, x, mjh_local(qLD.p), diaginv);
+    else solve_ld_fast(M, x, qLD, diaginv);
+    return;
+  }
 #endif
   // x <- L^-T x : row i scatters into its ancestors (independent targets)
   for (int i = nv - 1; i >= 0; i--) {

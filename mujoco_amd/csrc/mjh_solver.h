@@ -59,6 +59,9 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 #define MJH_PGS_CHAIN_STEP(k) if (L > k) { acc = acc + wv_row_bcast<k>(p);
 #define MJH_PGS_CHAIN_END }}}}}}}}}}}}}}}
 
+// ARL = 1: AR is resident in LDS and is read with ds_read through a local-address-space pointer
+// (in-order returns let the next row's prefetch stay in flight; a flat load would have to drain)
+template <int ARL>
 MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
   const DBatch& B = B_;
@@ -77,10 +80,23 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
   const int own = (j >= 0);
   const int jj = own ? j : 0;
   const int kind = (jj < ne) ? 0 : (jj < ne + nf ? 1 : 2);   // equality / friction / inequality
+  const bool isfric = (kind == 1), isineq = (kind == 2);
   real f = own ? P.force[jj] : 0;
   const real bj = own ? P.b[jj] : 0;
   const real fl = own ? P.floss[jj] : 0;
-  const real arjj = own ? P.AR[(size_t)jj*n + jj] : 1;
+#if defined(MJH_HOSTSIM)
+  const real* ARl = nullptr;
+#else
+  // byte offset of AR inside the workgroup's LDS block (the block starts at LDS address 0)
+  const __attribute__((address_space(3))) real* ARl =
+      (const __attribute__((address_space(3))) real*)(unsigned)(size_t)((const char*)P.AR.p - mjh_lds());
+#endif
+  (void)ARl;
+  auto ar_load = [&](int r) -> real {       // AR[r][jj]
+    if (ARL) return ARl[r*n + jj];
+    return P.AR[(size_t)r*n + jj];
+  };
+  const real arjj = own ? ar_load(jj) : 1;
   const real ainv = 1 / arjj;
   const real A = 1/ainv;                  // costChange's A (:216-237), the same bits every visit
   real fprev = f, fmom = f;
@@ -112,12 +128,16 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
     // ---- one sweep
     real improvement = 0;
     int i = wv_bcast_i(ord, 0);
-    real a = own ? P.AR[(size_t)i*n + jj] : 0;       // row of the first visited constraint
+    real a = own ? ar_load(i) : 0;                   // row of the first visited constraint
     for (int bi = 0; bi < n; bi++) {
-      // prefetch the next row while this one is reduced
-      const int inext = wv_bcast_i(ord, bi + 1 < n ? bi + 1 : bi);
-      const real anext = own ? P.AR[(size_t)inext*n + jj] : 0;
       const real p = a*f;
+      // prefetch the next row while this one is reduced (issued after the product so that the
+      // wait for the current row does not also drain this load)
+      int inext = wv_bcast_i(ord, bi + 1 < n ? bi + 1 : bi);
+#if !defined(MJH_HOSTSIM)
+      asm volatile("" : "+s"(inext) : "v"(p));      // orders the prefetch after the product
+#endif
+      const real anext = own ? ar_load(inext) : 0;
       // chain sums: acc of DPP row c = r_c (mju_dot's res_c), valid in every lane of the row
       real acc = 0;
       if (L > 0) { acc = acc + wv_row_bcast<0>(p);
@@ -134,12 +154,10 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
       const real res = bj + dot;
       const real oldf = f;
       real fn = oldf - res*ainv;
-      if (kind == 1) {
-        if (fn < -fl) fn = -fl;
-        else if (fn > fl) fn = fl;
-      } else if (kind == 2) {
-        if (fn < 0) fn = 0;
-      }
+      // projection, branch-free: friction rows clamp to [-fl, fl], inequality rows to [0, inf)
+      const real fclamp = (fn < -fl) ? -fl : ((fn > fl) ? fl : fn);
+      const real fpos = (fn < 0) ? 0 : fn;
+      fn = isfric ? fclamp : (isineq ? fpos : fn);
       // costChange (:216-237) with A = 1/ARinv
       const real delta = fn - oldf;
       real change = 0.5*delta*delta*A + delta*res;
@@ -363,8 +381,14 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 
 #if !MJH_LANE_MODE
-  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters) solve_pgs_fast(M, B, e);
-  else
+  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters) {
+#if defined(MJH_HOSTSIM)
+    solve_pgs_fast<0>(M, B, e);
+#else
+    if (mjh_in_lds(P.AR)) solve_pgs_fast<1>(M, B, e);
+    else solve_pgs_fast<0>(M, B, e);
+#endif
+  } else
 #endif
   solve_pgs(M, B, e);
 

@@ -219,8 +219,9 @@ MJH_DEV double wv_row_shl(double v) {
 // value held by lane K of the caller's 16-lane DPP row (v_mov_b32_dpp row_newbcast:K, no LDS)
 template <int K>
 MJH_DEV double wv_row_bcast(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + K, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + K, 0xf, 0xf, false);
+  // (mov_dpp: no "old" operand to preserve -- every lane of a row broadcast is written)
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 // constant-rate (100 MHz) timestamp, for -DMJH_PROFILE builds

@@ -346,6 +346,37 @@ MJH_DEV char* mjh_lds() {
 // A field slice is handed out as a strided view (mjh_math.h: SP): stride 1 when the slice is LDS
 // resident or the batch is laid out environment-major ([nenv][count]), stride nenvpad when the
 // batch is laid out SoA across environments ([count][nenvpad], element i of env e at i*nenvpad+e).
+// Local-address-space (ds_read/ds_write) access to a slice that the plan placed in LDS.  LDS
+// returns are in order, so ds accesses pipeline (lgkmcnt(k)) where flat accesses must drain.
+#ifdef MJH_HOSTSIM
+template <class T> struct LP {
+  T* p;
+  template <class I> MJH_MEM T& operator[](I i) const { return p[i]; }
+};
+template <class T> MJH_DEV LP<T> mjh_local(T* flat) { return LP<T>{flat}; }
+MJH_DEV long long mjh_lds_offset(const void* flat) { return (const char*)flat - mjh_lds(); }
+#else
+template <class T> struct LP {
+  __attribute__((address_space(3))) T* p;
+  template <class I> MJH_MEM __attribute__((address_space(3))) T& operator[](I i) const { return p[i]; }
+};
+// the workgroup's block starts at LDS address 0, so the local address is the offset from its base
+template <class T> MJH_DEV LP<T> mjh_local(T* flat) {
+  return LP<T>{(__attribute__((address_space(3))) T*)(unsigned)(size_t)((const char*)flat - mjh_lds())};
+}
+MJH_DEV long long mjh_lds_offset(const void* flat) { return (const char*)flat - mjh_lds(); }
+#endif
+// 1 if the contiguous slice lives in this workgroup's LDS block (flat LDS addresses are the shared
+// aperture base + offset; 160 KB is the whole LDS of a CU)
+template <class T> MJH_DEV int mjh_in_lds(const SP<T>& v) {
+#ifdef MJH_HOSTSIM
+  return 0;      // the emulation exercises the generic-pointer instantiation
+#else
+  const long long off = mjh_lds_offset((const void*)v.p);
+  return v.s == 1 && off >= 0 && off < 160*1024;
+#endif
+}
+
 template <class T>
 MJH_DEV SP<T> mjh_gp(T* g, int n, int soa, int e) {
   return soa ? SP<T>{g + e, soa} : SP<T>{g + (size_t)e * (size_t)n, 1};

@@ -31,6 +31,8 @@ b.set("prof", np.zeros((nenv, 32)))
 import time
 t0 = time.perf_counter()
 for c in range(0, K, 10):
+    if c == K - 10:
+        b.sync(); cost_pred = b.get("cost")[:, 0].copy(); perm_used = b.get("perm")[:, 0].copy()
     b.rollout_device(10, ma.mjSTATE_CTRL, 0, 0, ck[:, c:c+10].contiguous().data_ptr(), 0, 0, cont=True)
 b.sync()
 el = time.perf_counter() - t0
@@ -77,3 +79,11 @@ late = np.argsort(-en)[:6]
 print("last finishers: (start us, dur us, cost-rank)", [(int(st[e]-t0_), int(dur[e]), int((dur > dur[e]).sum())) for e in late])
 first = np.argsort(st)[:2048]
 print("mean duration of the first 2048 starters %.0f us, of the rest %.0f us" % (dur[first].mean(), np.delete(dur, first).mean()))
+
+cost_now = b.get("cost")[:, 0]
+print("cost prediction: corr(prev launch cost, this launch cost) = %.3f" % np.corrcoef(cost_pred, cost_now)[0,1])
+pos = np.empty(nenv, int); pos[perm_used] = np.arange(nenv)
+heavy = np.argsort(-cost_now)[:10]
+print("launch position (0 = first) of this launch's 10 heaviest envs:", pos[heavy].tolist())
+print("start time (us) of those:", [int(st[e]-t0_) for e in heavy])
+print("start time quantiles by launch position decile:", [int(np.median(st[perm_used[i*410:(i+1)*410]]-t0_)) for i in range(10)])
