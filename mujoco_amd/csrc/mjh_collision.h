@@ -170,7 +170,7 @@ MJH_DEV void make_frame(P0 frame) {
 
 // mj_filterSphere, engine_collision_driver.c:267: 1 = cull
 template <class P0, class P1>
-MJH_DEV int filter_sphere(const DModel& M, P0 gx, P1 gm, int g1, int g2, real margin) {
+MJH_DEV int filter_sphere(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
   real rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
   if (rb1 > 0 && rb2 > 0) {
     crptr p1 = gx + 3*g1; crptr p2 = gx + 3*g2;
@@ -199,8 +199,9 @@ MJH_DEV int filter_sphere(const DModel& M, P0 gx, P1 gm, int g1, int g2, real ma
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   iptr counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;
   if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || s.npair == 0) {
@@ -222,8 +223,8 @@ MJH_DEVN void stage_collision(const DModel& M, const DBatch& B, int e) {
       int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
       real margin = M.pair_margin[p];       // margin + gap: collider threshold
       if (!filter_sphere(M, gx, gm, g1, g2, margin)) {
-        crptr pos1 = gx + 3*g1; crptr mat1 = gm + 9*g1; const real* size1 = M.geom_size + 3*g1;
-        crptr pos2 = gx + 3*g2; crptr mat2 = gm + 9*g2; const real* size2 = M.geom_size + 3*g2;
+        crptr pos1 = gx + 3*g1; crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+        crptr pos2 = gx + 3*g2; crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
         switch (M.pair_func[p]) {
           case MJH_COL_PLANE_SPHERE:
             n = col_plane_sphere(pc, margin, pos1, mat1, pos2, size2[0]); break;

@@ -47,7 +47,7 @@ struct Efc {
 
 // returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
 // ints first)
-MJH_DEV unsigned efc_layout(const DModel& M, const DBatch& B, int e, int nefc, Efc& P) {
+MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   int off = B.dyn_off;
   const int end = B.lds_bytes;
@@ -65,7 +65,8 @@ MJH_DEV unsigned efc_layout(const DModel& M, const DBatch& B, int e, int nefc, E
 }
 
 // debug write-back of the LDS-resident constraint arrays to their global homes
-MJH_DEVN void efc_writeback(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   (void)nv; (void)nmax;
@@ -121,7 +122,7 @@ MJH_DEV void get_impedance(P0 solimp, real pos, real margin, P1 imp, P2 impP) {
 // sanitise solref/solimp                           (getsolparam tail, engine_core_constraint.c:2019-2047)
 // (mixed-sign solref is rejected at model upload, so only the clamps remain)
 template <class P0, class P1>
-MJH_DEV void fix_solparam(const DModel& M, P0 solref, P1 solimp) {
+MJH_DEV void fix_solparam(MREF M, P0 solref, P1 solimp) {
   if (!(M.o.disableflags & (1<<12)) && solref[0] > 0) solref[0] = r_max(solref[0], 2*M.o.timestep);
   solimp[0] = r_min(0.9999, r_max(0.0001, solimp[0]));
   solimp[1] = r_min(0.9999, r_max(0.0001, solimp[1]));
@@ -160,8 +161,9 @@ MJH_DEV void set_kbip(P0 KBIP, P1 ref, P2 solimp, real imp, real impP, int frict
 // one candidate's classification: how many rows it emits and their scalar data
 struct Cand { int nrow, type, id, side; real dist, margin, floss; };
 
-MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   const int nv = s.nv;
   iptr counts = MJH_F(B, counts, e);
   iptr warn = MJH_F(B, warning, e);
@@ -337,7 +339,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
     int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
-    const real* fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
+    auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
     real off1[3], off2[3];
     v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
     v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
@@ -428,7 +430,7 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
     real tran = 0, rot = 0;
     tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
     tran += M.body_invweight0[2*b2] * 1;  rot += M.body_invweight0[2*b2+1] * 1;
-    const real* fri = M.pair_friction + 5*p;
+    auto fri = M.pair_friction + 5*p;
     real solref[2] = {M.pair_solref[2*p], M.pair_solref[2*p+1]};
     real solimp[5];
     for (int q = 0; q < 5; q++) solimp[q] = M.pair_solimp[5*p + q];
@@ -468,8 +470,9 @@ MJH_DEVN void stage_make_constraint(const DModel& M, const DBatch& B, int e) {
 // mj_projectConstraint for dual solvers: Y = J L^-T D^-1/2, AR = Y Y' + diag(R)
 //                                                  (engine_core_constraint.c:2918-3137)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   const int nv = s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;
@@ -525,7 +528,8 @@ MJH_DEVN void stage_project(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_referenceConstraint: efc_vel = J qvel, aref   (engine_core_constraint.c:3245-3270)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   const int nv = M.s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   if (!nefc) return;
@@ -552,7 +556,7 @@ MJH_DEVN void stage_reference(const DModel& M, const DBatch& B, int e) {
 // writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
 // ------------------------------------------------------------------------------------------------
 template <class P0>
-MJH_DEV real constraint_update(const DBatch& B, int e, const Efc& P, P0 jar, int want_cost) {
+MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cost) {
   ciptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
   crptr D = P.D;

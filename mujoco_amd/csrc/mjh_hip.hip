@@ -20,13 +20,13 @@
 // every pointer into SGPRs for the whole kernel (hundreds of spills).
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_forward(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, int stages) {
-  wv::forward_or_euler(*M, *B, (int)blockIdx.x, stages);
+  wv::forward_or_euler(wv_const_ref(M), wv_const_ref(B), (int)blockIdx.x, stages);
 }
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_rollout(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, RolloutArgs A) {
   // workgroups are dispatched in blockIdx order: perm lists the environments by decreasing cost
-  wv::rollout_env(*M, *B, B->perm[blockIdx.x], A);
+  wv::rollout_env(wv_const_ref(M), wv_const_ref(B), B->perm[blockIdx.x], A);
 }
 
 // Longest-processing-time-first launch order for the next rollout launch: counting sort of the
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
 
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_reset(const DModel* __restrict__ M,
                                                         const DBatch* __restrict__ B) {
-  wv::reset_env(*M, *B, (int)blockIdx.x);
+  wv::reset_env(wv_const_ref(M), wv_const_ref(B), (int)blockIdx.x);
 }
 
 // ---- lane-mode kernels of the SoA pipeline: one lane per environment, epw environments per wavefront
@@ -64,19 +64,19 @@ __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WA
 
 MJH_LANE_KERNEL void mjh_k_smooth(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A, int epw) {
   MJH_LANE_ENV();
-  ln::smooth_env(*M, *B, e, A);
+  ln::smooth_env(wv_const_ref(M), wv_const_ref(B), e, A);
 }
 MJH_LANE_KERNEL void mjh_k_integrate(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A, int epw) {
   MJH_LANE_ENV();
-  ln::integrate_env(*M, *B, e, A);
+  ln::integrate_env(wv_const_ref(M), wv_const_ref(B), e, A);
 }
 MJH_LANE_KERNEL void mjh_k_lane_forward(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages, int epw) {
   MJH_LANE_ENV();
-  ln::forward_or_euler(*M, *B, e, stages);
+  ln::forward_or_euler(wv_const_ref(M), wv_const_ref(B), e, stages);
 }
 MJH_LANE_KERNEL void mjh_k_lane_reset(const DModel* __restrict__ M, const DBatch* __restrict__ B, int epw) {
   MJH_LANE_ENV();
-  ln::reset_env(*M, *B, e);
+  ln::reset_env(wv_const_ref(M), wv_const_ref(B), e);
 }
 
 struct Backend {

@@ -26,6 +26,8 @@
 #define MJH_LANE_MODE 0
 #define MJH_DEVN MJH_DEVN_WAVE
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
+// entry of an out-of-line stage function: its arguments arrive in VGPRs; all three are wave-uniform
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_)
 namespace wv {
 #include "mjh_stages.inc"
 }
@@ -33,6 +35,7 @@ namespace wv {
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
 #undef MJH_FOR_LANES
+#undef MJH_ENTER
 
 // ------------------------------------------------------------------------------------------------
 // lane mode
@@ -41,6 +44,8 @@ namespace wv {
 #define MJH_LANE_MODE 1
 #define MJH_DEVN MJH_DEVN_LANE
 #define MJH_FOR_LANES(i, n) for (int i = 0; i < (n); i++)
+// (stage functions are inlined into the kernel here: descriptors are already uniform, e is per lane)
+#define MJH_ENTER(M_, B_, e_) MREF M = M_; BREF B = B_; const int e = e_
 namespace ln {
 // the SPMD vocabulary for a width-1 "wave": these hide the wavefront primitives of mjh_spmd.h
 MJH_DEV int wv_lane() { return 0; }
@@ -57,3 +62,4 @@ MJH_DEV int wv_any(int pred) { return pred != 0; }
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
 #undef MJH_FOR_LANES
+#undef MJH_ENTER

@@ -79,8 +79,10 @@ struct mjhipBatch_ {
   int nenv = 0;
 };
 
+// `slot` is the address of a DModel table pointer (a constant-address-space pointer in the device
+// build); the device address is stored into it bytewise
 template <class T>
-static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, const T** out, std::string* err) {
+static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, void* slot, std::string* err) {
   size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
   void* p = Backend::alloc(bytes);
   if (!p) { *err = "mjhip: device allocation failed (model)"; return false; }
@@ -89,7 +91,7 @@ static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, const T** out, s
     *err = "mjhip: host->device copy failed (model)";
     return false;
   }
-  *out = (const T*)p;
+  memcpy(slot, &p, sizeof p);
   return true;
 }
 
@@ -222,10 +224,10 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
   M->D.s = M->H.s;
   M->D.o = M->H.o;
   bool ok = true;
-#define X(name, cnt) ok = ok && upload_vec<int>(M, M->H.name, &M->D.name, &err);
+#define X(name, cnt) ok = ok && upload_vec<int>(M, M->H.name, (void*)&M->D.name, &err);
   MJH_MODEL_INT_FIELDS(X)
 #undef X
-#define X(name, cnt) ok = ok && upload_vec<real>(M, M->H.name, &M->D.name, &err);
+#define X(name, cnt) ok = ok && upload_vec<real>(M, M->H.name, (void*)&M->D.name, &err);
   MJH_MODEL_REAL_FIELDS(X)
 #undef X
   if (ok) {

@@ -42,8 +42,9 @@ MJH_DEV void local2global(P0 opos, P1 omat, P2 pos, P3 quat,
 // mj_kinematics                                  (engine_core_smooth.c:40-242)
 // level-synchronous: all bodies of one depth level are independent given their parents
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr qpos = MJH_F(B, qpos, e);
   rptr xpos = MJH_F(B, xpos, e);
   rptr xquat = MJH_F(B, xquat, e);
@@ -77,8 +78,8 @@ MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
         v3_copy(xaxis + 3*jntadr, M.jnt_axis + 3*jntadr);
       } else {
         int pid = M.body_parentid[i];
-        const real* bpos = M.body_pos + 3*i;
-        const real* bquat = M.body_quat + 4*i;
+        auto bpos = M.body_pos + 3*i;
+        auto bquat = M.body_quat + 4*i;
         if (pid) {
           m3_mulvec(pos, xmat + 9*pid, bpos);
           v3_addto(pos, xpos + 3*pid);
@@ -154,8 +155,8 @@ MJH_DEVN void stage_kinematics(const DModel& M, const DBatch& B, int e) {
 // accumulate per-body n-vectors into parents, deepest level first; children of one parent are
 // added in decreasing body id, which reproduces the reference's `for b = nbody-1 .. 1` order.
 template <class P0>
-MJH_DEV void tree_accumulate_to_parent(const DModel& M, P0 x, int n, int include_world) {
-  const DSizes& s = M.s;
+MJH_DEV void tree_accumulate_to_parent(MREF M, P0 x, int n, int include_world) {
+  const MJH_CONST_AS DSizes& s = M.s;
   for (int L = s.nlevel - 2; L >= (include_world ? 0 : 1); L--) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
     MJH_FOR_LANES(k, a1 - a0) {
@@ -173,8 +174,9 @@ MJH_DEV void tree_accumulate_to_parent(const DModel& M, P0 x, int n, int include
 // ------------------------------------------------------------------------------------------------
 // mj_comPos                                      (engine_core_smooth.c:246-350)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_compos(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr xipos = MJH_F(B, xipos, e);
   crptr ximat = MJH_F(B, ximat, e);
   crptr xmat = MJH_F(B, xmat, e);
@@ -241,8 +243,9 @@ MJH_DEVN void stage_compos(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_tendon, fixed tendons only                  (engine_core_smooth.c:927-986)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_tendon(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_tendon(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   if (!s.ntendon) return;
   crptr qpos = MJH_F(B, qpos, e);
   rptr L = MJH_F(B, ten_length, e);
@@ -271,8 +274,9 @@ MJH_DEVN void stage_tendon(const DModel& M, const DBatch& B, int e) {
 // mj_transmission: joint (slide/hinge) transmissions   (engine_core_smooth.c:1265-1329)
 // moment is kept sparse with a static per-actuator row capacity (actuator_momentadr)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   if (!s.nu) return;
   crptr qpos = MJH_F(B, qpos, e);
   rptr length = MJH_F(B, actuator_length, e);
@@ -281,7 +285,7 @@ MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
   iptr colind = MJH_F(B, moment_colind, e);
   MJH_FOR_LANES(i, s.nu) {
     int id = M.actuator_trnid[2*i];
-    const real* gear = M.actuator_gear + 6*i;
+    auto gear = M.actuator_gear + 6*i;
     int adr = M.actuator_momentadr[i];
     // slide / hinge joint: scalar gear (other transmissions are rejected at model upload)
     rownnz[i] = 1;
@@ -295,8 +299,9 @@ MJH_DEVN void stage_transmission(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_crb (+ mj_makeM)                            (engine_core_smooth.c:1890-1971)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr cinert = MJH_F(B, cinert, e);
   crptr cdof = MJH_F(B, cdof, e);
   rptr crb = MJH_F(B, crb, e);
@@ -333,8 +338,8 @@ MJH_DEVN void stage_crb(const DModel& M, const DBatch& B, int e) {
 // read where it lives (LDS by plan).  Same arithmetic, same order as the generic versions below.
 // ------------------------------------------------------------------------------------------------
 template <class P0, class P1>
-MJH_DEVN void factor_ld_fast(const DModel& M_, P0 mat, P1 diaginv) {
-  const auto& M = wv_uniform_ref(M_);
+MJH_DEVN void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
+  MREF M = wv_uniform_ref(M_);
   const auto* ld_prog = wv_uniform_ptr(M.ld_prog);
   const int nv = M.s.nv;
   const int lane = wv_lane();
@@ -371,8 +376,8 @@ MJH_DEVN void factor_ld_fast(const DModel& M_, P0 mat, P1 diaginv) {
 }
 
 template <class P0, class P1, class P2>
-MJH_DEVN void solve_ld_fast(const DModel& M_, P0 xmem, P1 qLD, P2 diaginv) {
-  const auto& M = wv_uniform_ref(M_);
+MJH_DEVN void solve_ld_fast(MREF M_, P0 xmem, P1 qLD, P2 diaginv) {
+  MREF M = wv_uniform_ref(M_);
   const auto* colind = wv_uniform_ptr(M.M_colind);
   const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);
   const int nv = M.s.nv;
@@ -464,7 +469,7 @@ MJH_DEVN void solve_ld_fast(const DModel& M_, P0 xmem, P1 qLD, P2 diaginv) {
 // rows nv-1 .. 0 in order; for one row k the updates of its ancestor rows are independent
 // ------------------------------------------------------------------------------------------------
 template <class P0, class P1>
-MJH_DEVN void factor_ld(const DModel& M, P0 mat, P1 diaginv) {
+MJH_DEVN void factor_ld(MREF M, P0 mat, P1 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
   if (M.s.ld_fast) {
@@ -506,7 +511,8 @@ MJH_DEVN void factor_ld(const DModel& M, P0 mat, P1 diaginv) {
   }
 }
 
-MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_factor_m(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   crptr Mq = MJH_F(B, M, e);
   rptr qLD = MJH_F(B, qLD, e);
   rptr Mkeep = MJH_G(B, qH, e);     // M parked in global memory for mj_Euler's qH = M + h*diag(B)
@@ -519,7 +525,7 @@ MJH_DEVN void stage_factor_m(const DModel& M, const DBatch& B, int e) {
 // x <- inv(L'DL) x, one vector                    (mj_solveLD, engine_core_smooth.c:2033-2109)
 // ------------------------------------------------------------------------------------------------
 template <class P0, class P1, class P2>
-MJH_DEVN void solve_ld(const DModel& M, P0 x, P1 qLD, P2 diaginv) {
+MJH_DEVN void solve_ld(MREF M, P0 x, P1 qLD, P2 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
   if (M.s.ld_fast) {
@@ -571,8 +577,9 @@ MJH_DEV void mul_dof_vec(P0 res, P1 dof, P2 vec, int n) {
   }
 }
 
-MJH_DEVN void stage_comvel(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_comvel(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr qvel = MJH_F(B, qvel, e);
   crptr cdof = MJH_F(B, cdof, e);
   rptr cvel = MJH_F(B, cvel, e);
@@ -640,8 +647,9 @@ MJH_DEV real poly_force_deriv(real linear, P0 poly, real x, int odd) {
   return res;
 }
 
-MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr qpos = MJH_F(B, qpos, e);
   crptr qvel = MJH_F(B, qvel, e);
   rptr fs = MJH_F(B, qfrc_spring, e);
@@ -657,7 +665,7 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
   if (enbl_spring) {
     MJH_FOR_LANES(j, s.njnt) {
       real k0 = M.jnt_stiffness[j];
-      const real* sp = M.jnt_stiffnesspoly + 2*j;
+      auto sp = M.jnt_stiffnesspoly + 2*j;
       if (k0 == 0 && sp[0] == 0 && sp[1] == 0) continue;
       int padr = M.jnt_qposadr[j], dadr = M.jnt_dofadr[j];
       int jt = M.jnt_type[j];
@@ -686,7 +694,7 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
   if (enbl_damper) {
     MJH_FOR_LANES(i, s.nv) {
       real damping = M.dof_damping_eff[i];
-      const real* dp = M.dof_dampingpoly_eff + 2*i;
+      auto dp = M.dof_dampingpoly_eff + 2*i;
       if (damping != 0 || dp[0] != 0 || dp[1] != 0) {
         real v = qvel[i];
         fd[i] = -v * poly_force(damping, dp, v, 1);
@@ -702,7 +710,7 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
     crptr tJ = MJH_F(B, ten_J, e);
     for (int i = 0; i < s.ntendon; i++) {
       real stiffness = enbl_spring ? M.tendon_stiffness[i] : 0;
-      const real* sp = M.tendon_stiffnesspoly + 2*i;
+      auto sp = M.tendon_stiffnesspoly + 2*i;
       real damping = enbl_damper ? M.tendon_damping_eff[i] : 0;
       real dp[2] = {0, 0};
       if (enbl_damper) { dp[0] = M.tendon_dampingpoly_eff[2*i]; dp[1] = M.tendon_dampingpoly_eff[2*i+1]; }
@@ -732,8 +740,9 @@ MJH_DEVN void stage_passive(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_rne(flg_acc=0) -> qfrc_bias                  (engine_core_smooth.c:2328-2389)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_rne(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_rne(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr qvel = MJH_F(B, qvel, e);
   crptr cdof = MJH_F(B, cdof, e);
   crptr cdof_dot = MJH_F(B, cdof_dot, e);
@@ -776,8 +785,9 @@ MJH_DEVN void stage_rne(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // tendon / actuator velocities                    (mj_fwdVelocity head, engine_forward.c:197-208)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_ten_act_velocity(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr qvel = MJH_F(B, qvel, e);
   if (s.ntendon) {
     crptr tJ = MJH_F(B, ten_J, e);
@@ -805,8 +815,9 @@ MJH_DEVN void stage_ten_act_velocity(const DModel& M, const DBatch& B, int e) {
 // mj_fwdActuation: stateless actuators (dyntype none), fixed/affine gain, none/affine bias
 //                                                 (engine_forward.c:353-1003)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   rptr force = MJH_F(B, actuator_force, e);
   rptr qfa = MJH_F(B, qfrc_actuator, e);
   const int dsbl = M.o.disableflags;
@@ -837,8 +848,8 @@ MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
     if (!(dsbl & (1<<8)) && M.actuator_ctrllimited[i])
       c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
     if (bad) c = 0;
-    const real* gp = M.actuator_gainprm + 10*i;
-    const real* bp = M.actuator_biasprm + 10*i;
+    auto gp = M.actuator_gainprm + 10*i;
+    auto bp = M.actuator_biasprm + 10*i;
     real gain;
     if (M.actuator_gaintype[i] == MJH_GAIN_FIXED) gain = gp[0];
     else gain = gp[0] + gp[1]*len[i] + gp[2]*vel[i];
@@ -881,8 +892,9 @@ MJH_DEVN void stage_actuation(const DModel& M, const DBatch& B, int e) {
 // mj_fwdAcceleration                              (engine_forward.c:1007-1052)
 // (xfrc_applied is handled by the host API: non-zero Cartesian forces are rejected for now)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_acceleration(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_acceleration(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   crptr fp = MJH_F(B, qfrc_passive, e);
   crptr fb = MJH_F(B, qfrc_bias, e);
   crptr fa = MJH_F(B, qfrc_applied, e);

@@ -62,14 +62,14 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // ARL = 1: AR is resident in LDS and is read with ds_read through a local-address-space pointer
 // (in-order returns let the next row's prefetch stay in flight; a flat load would have to drain)
 template <int ARL>
-MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
+MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
-  const DBatch& B = B_;
+  BREF B = B_;
   const int e = wv_uniform_i(e_);
   iptr counts = MJH_F(B, counts, e);
   const int n = wv_uniform_i(counts[MJH_C_NEFC]), ne = wv_uniform_i(counts[MJH_C_NE]), nf = wv_uniform_i(counts[MJH_C_NF]);
   Efc P;
-  efc_layout(M_, B, e, n, P);
+  efc_layout(M, B, e, n, P);
   const int lane = wv_lane();
   const int n4 = n & ~3, L = n4 >> 2, ntail = n - n4;
   const int row = lane >> 4, col = lane & 15;
@@ -207,7 +207,8 @@ MJH_DEVN void solve_pgs_fast(const DModel& M_, const DBatch& B_, int e_) {
 // ------------------------------------------------------------------------------------------------
 // solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   iptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
   Efc P;
@@ -329,8 +330,9 @@ MJH_DEVN void solve_pgs(const DModel& M, const DBatch& B, int e) {
 // ------------------------------------------------------------------------------------------------
 // mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   const int nv = s.nv;
   iptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC];
@@ -405,7 +407,8 @@ MJH_DEVN void stage_fwd_constraint(const DModel& M, const DBatch& B, int e) {
 }
 
 // mj_dualFinish, second half: qacc = M \ qfrc_constraint + qacc_smooth   (engine_solver.c:80-84)
-MJH_DEVN void stage_finish(const DModel& M, const DBatch& B, int e) {
+MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   const int nv = M.s.nv;
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   crptr qfc = MJH_F(B, qfrc_constraint, e);

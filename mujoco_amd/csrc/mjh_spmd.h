@@ -32,6 +32,7 @@
 #define MJH_CONST_AS
 template <class T> static inline const T* wv_uniform_ptr(const T* p) { return p; }
 template <class T> static inline const T& wv_uniform_ref(const T& r) { return r; }
+template <class T> static inline const T& wv_const_ref(const T* p) { return *p; }
 static inline int wv_uniform_i(int v) { return v; }
 #define MJH_DEVN_WAVE static __attribute__((noinline))
 #define MJH_DEVN_LANE static inline
@@ -171,7 +172,19 @@ __device__ __forceinline__ const MJH_CONST_AS T* wv_uniform_ptr(const T* p) {
   return (const MJH_CONST_AS T*)(((unsigned long long)hi << 32) | lo);
 }
 template <class T>
-__device__ __forceinline__ const MJH_CONST_AS T& wv_uniform_ref(const T& r) { return *wv_uniform_ptr(&r); }
+__device__ __forceinline__ const MJH_CONST_AS T* wv_uniform_ptr(const MJH_CONST_AS T* p) {
+  unsigned long long a = (unsigned long long)p;
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const MJH_CONST_AS T*)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ const MJH_CONST_AS T& wv_uniform_ref(const MJH_CONST_AS T& r) { return *wv_uniform_ptr(&r); }
+// kernel argument (global pointer, already uniform) -> constant-address-space reference
+template <class T>
+__device__ __forceinline__ const MJH_CONST_AS T& wv_const_ref(const T* p) {
+  return *(const MJH_CONST_AS T*)(unsigned long long)p;
+}
 __device__ __forceinline__ int wv_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // out-of-line device function: gives the big stages their own register allocation scope
 // register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident

@@ -4,8 +4,8 @@
 
 
 // mj_resetData as far as the state vector is concerned (engine_io.c:1289-1420)
-MJH_DEV void reset_env(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEV void reset_env(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
   rptr qpos = MJH_F(B, qpos, e);
   MJH_FOR_LANES(i, s.nq) qpos[i] = M.qpos0[i];
   rptr qvel = MJH_F(B, qvel, e);
@@ -28,7 +28,7 @@ MJH_DEV void reset_env(const DModel& M, const DBatch& B, int e) {
 
 // mj_checkPos / mj_checkVel / mj_checkAcc (engine_forward.c:54-113): returns 1 if x had a bad value
 template <class P0>
-MJH_DEV int check_bad(const DModel& M, const DBatch& B, int e, P0 x, int n, int which) {
+MJH_DEV int check_bad(MREF M, BREF B, int e, P0 x, int n, int which) {
   int bad = 0;
   MJH_FOR_LANES(i, n) if (r_isbad(x[i])) bad = 1;
   bad = wv_any(bad);
@@ -60,9 +60,9 @@ MJH_DEV void lds_copy_out(T* g, int n, int l, int soa, int e, int cnt) {
 }
 
 // kernel entry: persistent state, global home -> LDS
-MJH_DEV void lds_enter(const DModel& M, const DBatch& B, int e) {
+MJH_DEV void lds_enter(MREF M, BREF B, int e) {
   if (!B.lds_bytes) return;
-  const DSizes& s = M.s;
+  const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
 #define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 1) lds_copy_in(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
   MJH_BATCH_REAL_FIELDS(X)
@@ -71,9 +71,9 @@ MJH_DEV void lds_enter(const DModel& M, const DBatch& B, int e) {
   wv_sync();
 }
 // kernel exit: persistent + exported fields, LDS -> global home
-MJH_DEV void lds_exit(const DModel& M, const DBatch& B, int e) {
+MJH_DEV void lds_exit(MREF M, BREF B, int e) {
   if (!B.lds_bytes) return;
-  const DSizes& s = M.s;
+  const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
   wv_sync();
 #define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 2) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
@@ -84,9 +84,10 @@ MJH_DEV void lds_exit(const DModel& M, const DBatch& B, int e) {
 }
 // debug write-back (tests): after timeline point t, every LDS-resident field live at t is copied to
 // its global home, so the host can inspect intermediates of the LDS path field by field
-MJH_DEVN void lds_writeback(const DModel& M, const DBatch& B, int e, int t) {
+MJH_DEVN void lds_writeback(MREF M_, BREF B_, int e_, int t) {
+  MJH_ENTER(M_, B_, e_);
   if (!B.lds_bytes) return;
-  const DSizes& s = M.s;
+  const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
   wv_sync();
 #define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
@@ -109,7 +110,8 @@ MJH_DEVN void lds_writeback(const DModel& M, const DBatch& B, int e, int t) {
 #define MJH_TIMED(t, call) do { call; } while (0)
 #endif
 #define MJH_RUN(t, call) do { MJH_TIMED(t, call); if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, t); } while (0)
-MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
+MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
+  MJH_ENTER(M_, B_, e_);
   const int pgs = (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
     MJH_RUN(MJH_T_KIN, stage_kinematics(M, B, e));
@@ -139,9 +141,9 @@ MJH_DEVN void forward(const DModel& M, const DBatch& B, int e, int stages) {
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
 }
 
-MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e);
+MJH_DEVN void euler_advance(MREF M, BREF B, int e);
 // body of the forward kernel (mjhip_batch_forward): stage-masked mj_forward (+ optional Euler step)
-MJH_DEV void forward_or_euler(const DModel& M, const DBatch& B, int e, int stages) {
+MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
   // pipeline use: the constraint kernel skips environments frozen by a warning
   if ((stages & MJH_STAGE_IFACTIVE) && !MJH_G(B, active, e)[0]) return;
   lds_enter(M, B, e);
@@ -157,8 +159,9 @@ MJH_DEV void forward_or_euler(const DModel& M, const DBatch& B, int e, int stage
 // The implicit-damping matrix qH = M + h*diag(B) is factorised in the slots of qLD/qLDiagInv,
 // which are dead once the constraint solve has produced qacc; M itself was parked in the global
 // field qH by stage_factor_m.
-MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
-  const DSizes& s = M.s;
+MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
   const int nv = s.nv;
   const real h = M.o.timestep;
   rptr qvel = MJH_F(B, qvel, e);
@@ -211,7 +214,7 @@ MJH_DEVN void euler_advance(const DModel& M, const DBatch& B, int e) {
 }
 
 // mj_step                                          (engine_forward.c:1846-1880)
-MJH_DEV void step_env(const DModel& M, const DBatch& B, int e) {
+MJH_DEV void step_env(MREF M, BREF B, int e) {
   check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
   check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL);
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -225,8 +228,8 @@ MJH_DEV void step_env(const DModel& M, const DBatch& B, int e) {
 
 // pack FULLPHYSICS state [time, qpos, qvel, act]    (mj_getState, engine_support.c:214)
 template <class P0>
-MJH_DEV void get_state(const DModel& M, const DBatch& B, int e, P0 out) {
-  const DSizes& s = M.s;
+MJH_DEV void get_state(MREF M, BREF B, int e, P0 out) {
+  const MJH_CONST_AS DSizes& s = M.s;
   if (wv_lane() == 0) out[0] = MJH_F(B, time, e)[0];
   crptr qpos = MJH_F(B, qpos, e);
   crptr qvel = MJH_F(B, qvel, e);
@@ -237,8 +240,8 @@ MJH_DEV void get_state(const DModel& M, const DBatch& B, int e, P0 out) {
 }
 
 template <class P0>
-MJH_DEV void set_state(const DModel& M, const DBatch& B, int e, P0 in) {
-  const DSizes& s = M.s;
+MJH_DEV void set_state(MREF M, BREF B, int e, P0 in) {
+  const MJH_CONST_AS DSizes& s = M.s;
   if (wv_lane() == 0) MJH_F(B, time, e)[0] = in[0];
   rptr qpos = MJH_F(B, qpos, e);
   rptr qvel = MJH_F(B, qvel, e);
@@ -249,8 +252,8 @@ MJH_DEV void set_state(const DModel& M, const DBatch& B, int e, P0 in) {
 }
 
 // _unsafe_rollout for one environment                (python/mujoco/rollout.cc:74-178)
-MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
-  const DSizes& s = M.s;
+MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
+  const MJH_CONST_AS DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
   const long long c_begin = wv_clock();
   lds_enter(M, B, e);
@@ -311,8 +314,8 @@ MJH_DEV void rollout_env(const DModel& M, const DBatch& B, int e, const RolloutA
 // Together they are rollout_env's loop body; A.t0 is the step's index in control/state.
 // ------------------------------------------------------------------------------------------------
 
-MJH_DEV void smooth_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
-  const DSizes& s = M.s;
+MJH_DEV void smooth_env(MREF M, BREF B, int e, const RolloutArgs& A) {
+  const MJH_CONST_AS DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
   if (A.init) {
     if (A.state0) set_state(M, B, e, A.state0 + r*s.nstate);
@@ -341,8 +344,8 @@ MJH_DEV void smooth_env(const DModel& M, const DBatch& B, int e, const RolloutAr
   forward(M, B, e, MJH_STAGES_SMOOTH_MASK);
 }
 
-MJH_DEV void integrate_env(const DModel& M, const DBatch& B, int e, const RolloutArgs& A) {
-  const DSizes& s = M.s;
+MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
+  const MJH_CONST_AS DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
   if (MJH_G(B, active, e)[0]) {
     stage_finish(M, B, e);

@@ -171,13 +171,15 @@ struct DOptions {
   int has_ten_armature;
 };
 
+// (device build: the table pointers are constant-address-space pointers, so a wave-uniform index
+// turns into a scalar load and a per-lane index into a global load with a scalar base)
 struct DModel {
   DSizes s;
   DOptions o;
-#define X(name, cnt) const int* name;
+#define X(name, cnt) const MJH_CONST_AS int* name;
   MJH_MODEL_INT_FIELDS(X)
 #undef X
-#define X(name, cnt) const real* name;
+#define X(name, cnt) const MJH_CONST_AS real* name;
   MJH_MODEL_REAL_FIELDS(X)
 #undef X
 };
@@ -324,6 +326,10 @@ struct DBatch {
   MJH_BATCH_INT_FIELDS(X)
 #undef X
 };
+
+// how the stage functions receive the two descriptors: read-only, constant address space
+typedef const MJH_CONST_AS DModel& MREF;
+typedef const MJH_CONST_AS DBatch& BREF;
 
 // the workgroup's LDS block
 #ifdef MJH_HOSTSIM
