@@ -23,6 +23,12 @@ __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WA
   wv::forward_or_euler(wv_const_ref(M), wv_const_ref(B), (int)blockIdx.x, stages);
 }
 
+// the same stage-masked kernel for SoA batches (strided views): constraint kernel of the pipeline
+__global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_forward_soa(const DModel* __restrict__ M,
+                                                          const DBatch* __restrict__ B, int stages) {
+  ws::forward_or_euler(wv_const_ref(M), wv_const_ref(B), (int)blockIdx.x, stages);
+}
+
 __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(MJH_WAVES_PER_EU, MJH_WAVES_PER_EU))) void mjh_k_rollout(const DModel* __restrict__ M,
                                                           const DBatch* __restrict__ B, RolloutArgs A) {
   // workgroups are dispatched in blockIdx order: perm lists the environments by decreasing cost
@@ -110,8 +116,9 @@ struct Backend {
   // largest dynamic LDS block a workgroup may request (gfx950: 160 KB per CU; one workgroup is
   // allowed 64 KB without opting in, which is already far beyond the useful range here)
   static int max_lds() { return 64 * 1024; }
-  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream) {
-    hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, stages);
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, void* stream) {
+    if (soa) hipLaunchKernelGGL(mjh_k_forward_soa, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, stages);
+    else hipLaunchKernelGGL(mjh_k_forward, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, stages);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void* stream) {

@@ -27,8 +27,17 @@
 #define MJH_DEVN MJH_DEVN_WAVE
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 // entry of an out-of-line stage function: its arguments arrive in VGPRs; all three are wave-uniform
-#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_)
+// namespace wv serves environment-major batches only (B.soa == 0): telling the compiler makes every
+// strided view a unit-stride view (no index multiply per access)
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
+                              if (B.soa != 0) __builtin_unreachable()
 namespace wv {
+#include "mjh_stages.inc"
+}
+#undef MJH_ENTER
+// namespace ws: the same wave mapping on SoA batches (constraint kernel of the per-step pipeline)
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_)
+namespace ws {
 #include "mjh_stages.inc"
 }
 #undef MJH_W

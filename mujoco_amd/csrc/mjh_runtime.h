@@ -16,7 +16,7 @@
 //   static bool sync(void* stream);
 //   (M, B below are DEVICE pointers to the descriptor structs)
 //   (lds = bytes of LDS per one-wavefront workgroup demanded by the batch descriptor's plan, 0 = none)
-//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
+//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, void* stream);
 //   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, void* stream);
 //   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
 //   lane-mode kernels of the SoA pipeline (epw = environments per wavefront):
@@ -471,7 +471,7 @@ static bool pipeline_step(mjhipBatch_* Bt, const RolloutArgs& A, void* stream) {
   if (!Backend::launch_smooth(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream)) return false;
   const bool lds = Bt->L.lds_bytes > 0;
   if (!Backend::launch_forward(M, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, MJH_STAGES_CONSTRAINT_MASK | MJH_STAGE_IFACTIVE,
-                               lds ? Bt->L.lds_bytes : 0, stream)) return false;
+                               lds ? Bt->L.lds_bytes : 0, 1, stream)) return false;
   return Backend::launch_integrate(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream);
 }
 
@@ -486,7 +486,7 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt->soa) {
     if (lds) stages |= MJH_STAGE_WRITEBACK;
     ok = Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, stages,
-                                 lds ? Bt->L.lds_bytes : 0, stream);
+                                 lds ? Bt->L.lds_bytes : 0, 0, stream);
   } else {
     // the pipeline's split: lane-mode kernel for the smooth stages, wave-mode kernel for the
     // constraint stages (on its LDS plan + write-back if asked), lane-mode kernel for the tail
@@ -494,7 +494,7 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
     const int s3 = stages & (MJH_STAGE_FINISH | MJH_STAGE_EULER);
     if (s1) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s1, stream);
     if (s2) ok = ok && Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv,
-                                               s2 | (lds ? MJH_STAGE_WRITEBACK : 0), lds ? Bt->L.lds_bytes : 0, stream);
+                                               s2 | (lds ? MJH_STAGE_WRITEBACK : 0), lds ? Bt->L.lds_bytes : 0, 1, stream);
     if (s3) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s3, stream);
   }
   if (!ok) { set_err("mjhip_batch_forward: kernel launch failed"); return -2; }

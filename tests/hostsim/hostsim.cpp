@@ -92,8 +92,12 @@ struct Backend {
   static int max_lds() { return 64 * 1024; }
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
-  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void*) {
-    for (int e = 0; e < nenv; e++) { poison_lds(lds); runner()->run(e, [&]() { wv::forward_or_euler(*M, *B, wv_env(), stages); }); }
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, void*) {
+    for (int e = 0; e < nenv; e++) {
+      poison_lds(lds);
+      if (soa) runner()->run(e, [&]() { ws::forward_or_euler(*M, *B, wv_env(), stages); });
+      else runner()->run(e, [&]() { wv::forward_or_euler(*M, *B, wv_env(), stages); });
+    }
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void*) {

@@ -67,6 +67,28 @@ def test_rollout_bit_exact_any_lds_budget(setup, golden, budget):
     assert np.array_equal(b2.get("qvel"), fx["state"][3:6, 3, 29:])
 
 
+@pytest.mark.parametrize("lds", [False, True])
+def test_soa_pipeline_forward_bit_exact(rb, setup, lds):
+    """SoA-across-environments batch: lane-per-env smooth kernels + wave-per-env constraint kernel
+    (on its own LDS plan when lds=True) + lane-per-env tail, every field against the oracle"""
+    m, dm = setup
+    states = contact_rich_states(rb, m, 3, seed=9)
+    b = K.Batch(dm, len(states), layout="soa")
+    worst = check_forward(rb, m, b, states, tol=0.0, lds=lds)
+    assert worst == 0.0
+
+
+def test_soa_pipeline_rollout_bit_exact(setup, golden):
+    m, dm = setup
+    fx = golden("humanoid")
+    b = K.Batch(dm, 3, layout="soa")
+    out = b.rollout_host(15, K.mjSTATE_CTRL, fx["state0"][2:5], None, fx["ctrl"][2:5, :15])
+    assert np.array_equal(out, fx["state"][2:5, :15])
+    b.plan_lds(0)
+    out = b.rollout_host(6, K.mjSTATE_CTRL, fx["state0"][2:5], None, fx["ctrl"][2:5, :6])
+    assert np.array_equal(out, fx["state"][2:5, :6])
+
+
 def test_rollout_bit_exact_vs_golden(setup, golden):
     m, dm = setup
     fx = golden("humanoid")
