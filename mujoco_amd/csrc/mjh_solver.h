@@ -99,6 +99,10 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const real arjj = own ? ar_load(jj) : 1;
   const real ainv = 1 / arjj;
   const real A = 1/ainv;                  // costChange's A (:216-237), the same bits every visit
+  // projection bounds of my constraint: equality (-inf, inf), friction [-fl, fl], inequality [0, inf)
+  const real pinf = __builtin_huge_val();
+  const real blo = isfric ? -fl : (isineq ? 0.0 : -pinf);
+  const real bhi = isfric ? fl : pinf;
   real fprev = f, fmom = f;
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
@@ -125,6 +129,8 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
       fprev = f;
       fmom = f;
     }
+    // owner lane of the constraint visited at position b, computed by lane b for its own entry
+    const int ordlane = (ord < n4) ? 16*(ord & 3) + (ord >> 2) : 16*(ord - n4) + 15;
     // ---- one sweep
     real improvement = 0;
     int i = wv_bcast_i(ord, 0);
@@ -154,16 +160,14 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
       const real res = bj + dot;
       const real oldf = f;
       real fn = oldf - res*ainv;
-      // projection, branch-free: friction rows clamp to [-fl, fl], inequality rows to [0, inf)
-      const real fclamp = (fn < -fl) ? -fl : ((fn > fl) ? fl : fn);
-      const real fpos = (fn < 0) ? 0 : fn;
-      fn = isfric ? fclamp : (isineq ? fpos : fn);
+      // projection onto [blo, bhi] (compare-and-select keeps the reference's `if (f < lo) f = lo`
+      // semantics for -0.0 and NaN)
+      fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
       // costChange (:216-237) with A = 1/ARinv
       const real delta = fn - oldf;
       real change = 0.5*delta*delta*A + delta*res;
       if (change > 1e-10) { fn = oldf; change = 0; }
-      // owner lane of constraint i
-      const int li = (i < n4) ? 16*(i & 3) + (i >> 2) : 16*(i - n4) + 15;
+      const int li = wv_bcast_i(ordlane, bi);          // owner lane of constraint i
       if (lane == li) f = fn;
       improvement -= wv_bcast(change, li);
       i = inext;
@@ -356,6 +360,12 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   rptr ARf = P.ARf;                     // [nefc]
   crptr qws = MJH_F(B, qacc_warmstart, e);
 
+#ifdef MJH_PROFILE
+  long long pc0 = wv_clock();
+#define MJH_SUBPROF(slot) do { long long c_ = wv_clock(); if (wv_lane() == 0) MJH_G(B, prof, e)[slot] += (real)(c_ - pc0)*0.01; pc0 = c_; } while (0)
+#else
+#define MJH_SUBPROF(slot) do {} while (0)
+#endif
   // efc_b = J*qacc_smooth - aref ; jar = J*qacc_warmstart - aref
   MJH_FOR_LANES(r, nefc) {
     crptr Jr = J + (size_t)r*nv;
@@ -381,6 +391,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
     MJH_FOR_LANES(r, nefc) force[r] = 0;
   }
   wv_sync();
+  MJH_SUBPROF(22);     // efc_b, jar, warm start
 
 #if !MJH_LANE_MODE
   if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters) {
@@ -393,6 +404,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   } else
 #endif
   solve_pgs(M, B, e);
+  MJH_SUBPROF(23);     // PGS
 
   // mj_dualFinish, first half (engine_solver.c:72-85): qfrc_constraint = J' f
   MJH_FOR_LANES(j, nv) {
@@ -404,6 +416,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
     qfc[j] = acc;
   }
   wv_sync();
+  MJH_SUBPROF(24);     // J' f
 }
 
 // mj_dualFinish, second half: qacc = M \ qfrc_constraint + qacc_smooth   (engine_solver.c:80-84)

@@ -45,6 +45,7 @@ for i, n in enumerate(NAMES):
     tot += v
     if v > 0: print(f"  {n:14s} {v:9.2f} us")
 print(f"  {'sum':14s} {tot:9.2f} us")
+print("  inside constraint: b/jar/warmstart %.2f  PGS %.2f  J'f %.2f us" % tuple(p[:, k].mean()/nst for k in (22, 23, 24)))
 c = b.get("counts")
 print("mean ncon", c[:, 0].mean(), "nefc", c[:, 1].mean(), "pgs iter", c[:, 5].mean())
 
