@@ -145,7 +145,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->ngravcomp > 0 || m->flg_gravcomp, "gravity compensation");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
-  MJH_REJECT(m->opt.integrator != mjINT_EULER, "integrators other than Euler (RK4/implicit are next)");
+  MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4, "integrators other than Euler and RK4 (implicit/implicitfast are next)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS, "solvers other than PGS (set opt.solver = mjSOL_PGS; Newton/CG are next)");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
   MJH_REJECT(m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60),

@@ -141,6 +141,104 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
 }
 
+// mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
+template <class P0, class P1>
+MJH_DEV void integrate_pos(MREF M, P0 qpos, P1 qvel, real h) {
+  MJH_FOR_LANES(j, M.s.njnt) {
+    int padr = M.jnt_qposadr[j], vadr = M.jnt_dofadr[j];
+    int jt = M.jnt_type[j];
+    if (jt == MJH_JNT_FREE) {
+      for (int i = 0; i < 3; i++) qpos[padr + i] += h * qvel[vadr + i];
+      padr += 3; vadr += 3;
+    }
+    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+      q_integrate(qpos + padr, qvel + vadr, h);
+    } else {
+      qpos[padr] += h * qvel[vadr];
+    }
+  }
+}
+
+MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages);
+
+// mj_RungeKutta(m, d, 4) + mj_advance                 (engine_forward.c:1486-1587, :1261-1395)
+// mj_forward for stage 0 has already run (mj_step); the three further evaluations warm-start from
+// the same qacc_warmstart, which only mj_advance overwrites.
+MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nq = s.nq, nv = s.nv, nx = nq + nv;
+  const real h = M.o.timestep;
+  const real A[9] = {0.5, 0, 0,  0, 0.5, 0,  0, 0, 1};
+  const real Bw[4] = {1.0/6.0, 1.0/3.0, 1.0/3.0, 1.0/6.0};
+  rptr qpos = MJH_F(B, qpos, e);
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr tm = MJH_F(B, time, e);
+  rptr X = MJH_G(B, rk_X, e);
+  rptr F = MJH_G(B, rk_F, e);
+  rptr dX = MJH_G(B, rk_dX, e);
+  const real time0 = tm[0];
+  real T[3];
+  for (int i = 1; i < 4; i++) {
+    real C = 0;
+    for (int j = 0; j < i; j++) C += A[(i-1)*3 + j];
+    T[i-1] = time0 + C*h;
+  }
+  {
+    crptr qacc = MJH_F(B, qacc, e);
+    MJH_FOR_LANES(k, nq) X[k] = qpos[k];
+    MJH_FOR_LANES(k, nv) { X[nq + k] = qvel[k]; F[k] = qacc[k]; }
+    wv_sync();
+  }
+  for (int i = 1; i < 4; i++) {
+    // dX = sum_j A(i,j) * (X[j].qvel, F[j])   (every j < i is added, zero weights included)
+    MJH_FOR_LANES(k, nv) {
+      real dv = 0, da = 0;
+      for (int j = 0; j < i; j++) {
+        dv += X[j*nx + nq + k] * A[(i-1)*3 + j];
+        da += F[j*nv + k] * A[(i-1)*3 + j];
+      }
+      dX[k] = dv;
+      dX[nv + k] = da;
+    }
+    // X[i] = X[0] (+) dX
+    MJH_FOR_LANES(k, nx) X[i*nx + k] = X[k];
+    wv_sync();
+    integrate_pos(M, X + i*nx, dX, h);
+    MJH_FOR_LANES(k, nv) X[i*nx + nq + k] += dX[nv + k] * h;
+    wv_sync();
+    MJH_FOR_LANES(k, nq) qpos[k] = X[i*nx + k];
+    MJH_FOR_LANES(k, nv) qvel[k] = X[i*nx + nq + k];
+    if (wv_lane() == 0) tm[0] = T[i-1];
+    wv_sync();
+    forward(M, B, e, MJH_STAGE_ALL);
+    crptr qacc = MJH_F(B, qacc, e);
+    MJH_FOR_LANES(k, nv) F[i*nv + k] = qacc[k];
+    wv_sync();
+  }
+  // final combination with B, state reset, mj_advance
+  MJH_FOR_LANES(k, nv) {
+    real dv = 0, da = 0;
+    for (int j = 0; j < 4; j++) {
+      dv += X[j*nx + nq + k] * Bw[j];
+      da += F[j*nv + k] * Bw[j];
+    }
+    dX[k] = dv;
+    dX[nv + k] = da;
+  }
+  MJH_FOR_LANES(k, nq) qpos[k] = X[k];
+  MJH_FOR_LANES(k, nv) qvel[k] = X[nq + k];
+  wv_sync();
+  MJH_FOR_LANES(k, nv) qvel[k] += dX[nv + k] * h;
+  wv_sync();
+  integrate_pos(M, qpos, dX, h);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  MJH_FOR_LANES(k, nv) ws[k] = qacc[k];
+  if (wv_lane() == 0) tm[0] = time0 + h;
+  wv_sync();
+}
+
 MJH_DEVN void euler_advance(MREF M, BREF B, int e);
 // body of the forward kernel (mjhip_batch_forward): stage-masked mj_forward (+ optional Euler step)
 MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
@@ -194,19 +292,7 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
   // mj_advance: qvel += h*qacc ; qpos integrates the NEW qvel ; time ; warmstart
   MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
   wv_sync();
-  MJH_FOR_LANES(j, s.njnt) {
-    int padr = M.jnt_qposadr[j], vadr = M.jnt_dofadr[j];
-    int jt = M.jnt_type[j];
-    if (jt == MJH_JNT_FREE) {
-      for (int i = 0; i < 3; i++) qpos[padr + i] += h * qvel[vadr + i];
-      padr += 3; vadr += 3;
-    }
-    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
-      q_integrate(qpos + padr, qvel + vadr, h);
-    } else {
-      qpos[padr] += h * qvel[vadr];
-    }
-  }
+  integrate_pos(M, qpos, qvel, h);
   rptr ws = MJH_F(B, qacc_warmstart, e);
   MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
   if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
@@ -223,7 +309,8 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
-  MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
+  if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+  else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
 }
 
 // pack FULLPHYSICS state [time, qpos, qvel, act]    (mj_getState, engine_support.c:214)
@@ -353,7 +440,8 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     // bad qacc: the state was reset; the reference re-runs mj_forward before integrating
     // (engine_forward.c:1863-1870).  Rare, so the whole forward pass is redone right here.
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
-    MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
+    if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+    else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);
 }

@@ -273,6 +273,10 @@ enum {
   X(efc_aref, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(efc_b, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(efc_force, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  /* mj_RungeKutta intermediates: X[4] = (qpos, qvel), F[4] = qacc, dX */           \
+  X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
+  X(rk_dX, 2 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                     \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
   /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
   X(prof, 32, 0, MJH_T_GLB, MJH_T_GLB)

@@ -108,6 +108,24 @@ def test_rollout_api_matches_serial_oracle(rb, hip_lib):
         rollout.rollout(m, d, s0[:, :-1], ctrl)
 
 
+def test_rk4_rollout_vs_live_oracle(rb, hip_lib, golden):
+    """RK4 integrator (mj_RungeKutta, engine_forward.c:1486-1587) on the GPU against the oracle"""
+    m = humanoid_pgs_oracle(rb)
+    m.opt.integrator = 1
+    mm = mujoco_amd.MjbModel(hip_lib, os.path.join(GOLDEN, "humanoid.mjb"))
+    mm.set_option("solver", 0)
+    mm.set_option("integrator", 1)
+    dmr = K.DeviceModel(hip_lib, mm)
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 10
+    ref, ints = oracle_rollout(rb, m, fx["state0"], fx["ctrl"][:, :T])
+    b = K.Batch(dmr, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    print("rk4 rollout rel err", relerr(out, ref))
+    assert relerr(out, ref) <= TOL
+    assert np.array_equal(b.get("counts")[:, 1], ints[:, -1, 1])
+
+
 def test_full_size_batch_properties(hip_lib, dm, golden):
     """BASELINE size (4096 envs): size-independent properties -- replicated envs give identical
     bits, an env's trajectory does not depend on its position in the batch, no warnings."""

@@ -89,6 +89,23 @@ def test_soa_pipeline_rollout_bit_exact(setup, golden):
     assert np.array_equal(out, fx["state"][2:5, :6])
 
 
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_rk4_rollout_bit_exact(rb, hostsim_lib, golden, layout):
+    """mj_RungeKutta(N=4) (engine_forward.c:1486-1587): four forward evaluations per step, positions
+    combined on the manifold -- against the oracle stepping with opt.integrator = mjINT_RK4"""
+    m = humanoid_pgs_oracle(rb)
+    m.opt.integrator = 1
+    dm = K.DeviceModel(hostsim_lib, m)
+    fx = golden("humanoid")
+    n, T = 2, 6
+    s0, ctrl = fx["state0"][4:4 + n], fx["ctrl"][4:4 + n, :T]
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, n, layout=layout)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(b.get("counts")[:, 1], ints[:, -1, 1])      # nefc of the last evaluation
+
+
 def test_rollout_bit_exact_vs_golden(setup, golden):
     m, dm = setup
     fx = golden("humanoid")
