@@ -46,7 +46,7 @@
 #define MJHIP_DEFAULT_LAYOUT MJHIP_LAYOUT_AOS
 #endif
 #ifndef MJHIP_DEFAULT_LDS_BYTES
-#define MJHIP_DEFAULT_LDS_BYTES 20480   // 8 one-wavefront workgroups per CU (160 KB LDS)
+#define MJHIP_DEFAULT_LDS_BYTES 10240   // 16 one-wavefront workgroups per CU (160 KB LDS): 4096 environments resident at once
 #endif
 
 static thread_local std::string g_mjhip_err;

@@ -11,8 +11,8 @@ cd $OLDPWD
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 cat $OUT/kernel_stats.csv
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 50 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 50 --warmup 0 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 200 --warmup 0 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 200 --warmup 0 > /dev/null 2> $OUT/pmc_write.err
 cd $OLDPWD
 python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
 # keep the merged payload small

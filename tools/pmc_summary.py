@@ -11,6 +11,12 @@ import os
 import sys
 
 out = sys.argv[1]
+import json
+try:
+    _b = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
+    STEPS_PER_LAUNCH = int(_b["roofline"]["steps_per_launch"]); NENV = int(_b["config"]["envs_per_gpu"])
+except Exception:
+    STEPS_PER_LAUNCH, NENV = 10, 4096
 
 
 def load(sub, counter):
@@ -31,5 +37,5 @@ for name, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         print(f"{name}: no samples")
 if fetch and write:
     f, w = sum(fetch) / len(fetch) * 1024, sum(write) / len(write) * 1024
-    print(f"per launch (10 steps x 4096 envs): read {f/1e6:.2f} MB raw / {2*f/1e6:.2f} MB with the gfx950 x2 correction, "
-          f"written {w/1e6:.2f} MB; per env-step: {(2*f+w)/40960:.0f} B (corrected)")
+    print(f"per launch ({STEPS_PER_LAUNCH} steps x {NENV} envs): read {f/1e6:.2f} MB raw / {2*f/1e6:.2f} MB with the gfx950 x2 correction, "
+          f"written {w/1e6:.2f} MB; per env-step: {(2*f+w)/(STEPS_PER_LAUNCH*NENV):.0f} B (corrected)")
