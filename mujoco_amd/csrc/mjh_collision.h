@@ -152,6 +152,79 @@ MJH_DEV int col_capsule_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
   return n1 + n2 + n3 + n4;
 }
 
+// mjc_PlaneCylinder, engine_collision_primitive.c:101-208 (up to 4 contacts)
+template <class P0, class P1, class P2, class P3, class P4>
+MJH_DEV int col_plane_cylinder(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
+  real normal[3] = {mat1[2], mat1[5], mat1[8]};
+  real axis[3] = {mat2[2], mat2[5], mat2[8]};
+  real prjaxis = v3_dot(normal, axis);
+  if (prjaxis > 0) {
+    v3_scl(axis, axis, -1);
+    prjaxis = -prjaxis;
+  }
+  real vec[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
+  real dist0 = v3_dot(vec, normal);
+  v3_scl(vec, axis, prjaxis);
+  v3_subfrom(vec, normal);
+  real len_sqr = v3_dot(vec, vec);
+  if (len_sqr >= MJH_MINVAL*MJH_MINVAL) {
+    real scl = size2[0]/sqrt(len_sqr);
+    vec[0] *= scl; vec[1] *= scl; vec[2] *= scl;
+  } else {
+    vec[0] = mat2[0]*size2[0];
+    vec[1] = mat2[3]*size2[0];
+    vec[2] = mat2[6]*size2[0];
+  }
+  real prjvec = v3_dot(vec, normal);
+  v3_scl(axis, axis, size2[1]);
+  prjaxis *= size2[1];
+  int cnt = 0;
+  if (dist0 + prjaxis + prjvec <= margin) {
+    con[cnt].dist = dist0 + prjaxis + prjvec;
+    v3_add(con[cnt].pos, pos2, vec);
+    v3_addto(con[cnt].pos, axis);
+    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
+    v3_copy(con[cnt].normal, normal);
+    v3_zero(con[cnt].tangent);
+    cnt++;
+  } else {
+    return 0;
+  }
+  if (dist0 - prjaxis + prjvec <= margin) {
+    con[cnt].dist = dist0 - prjaxis + prjvec;
+    v3_add(con[cnt].pos, pos2, vec);
+    v3_subfrom(con[cnt].pos, axis);
+    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
+    v3_copy(con[cnt].normal, normal);
+    v3_zero(con[cnt].tangent);
+    cnt++;
+  }
+  real prjvec1 = -prjvec*0.5;
+  if (dist0 + prjaxis + prjvec1 <= margin) {
+    real vec1[3];
+    v3_cross(vec1, vec, axis);
+    v3_normalize(vec1);
+    v3_scl(vec1, vec1, size2[0] * sqrt(3.0) / 2);
+    con[cnt].dist = dist0 + prjaxis + prjvec1;
+    v3_add(con[cnt].pos, pos2, vec1);
+    v3_addto(con[cnt].pos, axis);
+    v3_addtoscl(con[cnt].pos, vec, -0.5);
+    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
+    v3_copy(con[cnt].normal, normal);
+    v3_zero(con[cnt].tangent);
+    cnt++;
+    con[cnt].dist = dist0 + prjaxis + prjvec1;
+    v3_sub(con[cnt].pos, pos2, vec1);
+    v3_addto(con[cnt].pos, axis);
+    v3_addtoscl(con[cnt].pos, vec, -0.5);
+    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
+    v3_copy(con[cnt].normal, normal);
+    v3_zero(con[cnt].tangent);
+    cnt++;
+  }
+  return cnt;
+}
+
 // complete a contact frame from its normal (+ optional tangent)   (mju_makeFrame, engine_util_spatial.c:512)
 template <class P0>
 MJH_DEV void make_frame(P0 frame) {
@@ -217,8 +290,9 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   int overflow = 0;
   for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
     int p = p0 + wv_lane();
-    PreContact pc[2];
+    PreContact pc[4];
     int n = 0;
+    int unsupported = 0;
     if (p < s.npair) {
       int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
       real margin = M.pair_margin[p];       // margin + gap: collider threshold
@@ -236,10 +310,17 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             n = col_sphere_capsule(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
           case MJH_COL_CAPSULE_CAPSULE:
             n = col_capsule_capsule(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
+          case MJH_COL_PLANE_CYLINDER:
+            n = col_plane_cylinder(pc, margin, pos1, mat1, pos2, mat2, size2); break;
+          case MJH_COL_UNSUPPORTED:
+            unsupported = 1; break;
           default: break;
         }
       }
     }
+    // a pair whose collider mjhip does not have reached the narrowphase: the result could differ
+    // from the reference's, so the environment is flagged (and frozen by the rollout loop)
+    if (wv_any(unsupported) && wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++;
     int off = base + wv_exscan_i(n);
     int total = wv_sum_i(n);
     for (int k = 0; k < n; k++) {

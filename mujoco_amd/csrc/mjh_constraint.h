@@ -14,7 +14,7 @@
 struct Efc {
   rptr force, b, ARinv, fprev, fmom, R, D, floss, aref, jar, ARf, pos, margin, KBIP,
        diagA, vel, sqrtInvD, AR, J, Y;
-  iptr order, state, type, id;
+  iptr order, state, type, id, island;
 };
 
 // list of (member, global home expression, element count) in packing order
@@ -43,7 +43,8 @@ struct Efc {
   X(order, MJH_G(B, iscratch, e), nefc)                              \
   X(state, MJH_G(B, efc_state, e), nefc)                             \
   X(type, MJH_G(B, efc_type, e), nefc)                               \
-  X(id, MJH_G(B, efc_id, e), nefc)
+  X(id, MJH_G(B, efc_id, e), nefc)                                   \
+  X(island, MJH_G(B, efc_island, e), nefc)
 
 // returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
 // ints first)
@@ -462,6 +463,104 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       P.D[r0 + a] = 1 / R;
       P.diagA[r0 + a] = R * imp / (1 - imp);
     }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_island, the part the PGS solver needs          (engine_island.c:363-483, :129-150)
+// island of every constraint row = connected component (union-find over the kinematic trees a
+// constraint touches), numbered in ascending order of the component's smallest tree.  One tree
+// (or islands disabled): every row is in island 0.  The union-find itself is a short serial scan.
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  iptr counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC];
+  if (!nefc) {
+    if (wv_lane() == 0) counts[MJH_C_NISLAND] = 0;
+    wv_sync();
+    return;
+  }
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  const int nv = s.nv, ntree = s.ntree;
+  if (ntree <= 1 || (M.o.disableflags & (1<<18))) {
+    MJH_FOR_LANES(i, nefc) P.island[i] = 0;
+    if (wv_lane() == 0) counts[MJH_C_NISLAND] = (M.o.disableflags & (1<<18)) ? 0 : 1;
+    wv_sync();
+    return;
+  }
+  if (wv_lane() == 0) {
+    iptr work = MJH_G(B, island_work, e);
+    iptr efc_tree = work;                       // [nefc]
+    iptr parent = work + s.nefcmax;             // [ntree]
+    iptr tree_island = parent + ntree;          // [ntree]
+    for (int t = 0; t < ntree; t++) parent[t] = -1;
+    auto root_of = [&](int tree) {
+      int root = tree;
+      while (parent[root] != root) root = parent[root];
+      while (parent[tree] != tree) { int next = parent[tree]; parent[tree] = root; tree = next; }
+      return root;
+    };
+    auto merge = [&](int t1, int t2) {          // mj_dsuMerge; -1 = static endpoint
+      if (t1 == -1) t1 = t2;
+      if (t2 == -1) t2 = t1;
+      if (parent[t1] == -1) parent[t1] = t1;
+      if (parent[t2] == -1) parent[t2] = t2;
+      if (parent[t1] == parent[t2]) return;
+      int r1 = root_of(t1), r2 = root_of(t2);
+      if (r1 < r2) parent[r2] = r1;
+      else if (r2 < r1) parent[r1] = r2;
+    };
+    int ptype = -1, pid = -1;
+    for (int i = 0; i < nefc; i++) {
+      const int type = P.type[i], id = P.id[i];
+      if (i > 0 && type == ptype && id == pid) { efc_tree[i] = efc_tree[i-1]; continue; }
+      ptype = type; pid = id;
+      int trees[2] = {-2, -2};
+      if (type == MJH_CNSTR_FRICTION_DOF) {
+        trees[0] = M.dof_treeid[id];
+      } else if (type == MJH_CNSTR_LIMIT_JOINT) {
+        trees[0] = M.dof_treeid[M.jnt_dofadr[id]];
+      } else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) {
+        ciptr cg = MJH_CON(B, con_geom, e, 2, id);
+        trees[0] = M.body_treeid[M.geom_bodyid[cg[0]]];
+        trees[1] = M.body_treeid[M.geom_bodyid[cg[1]]];
+      }
+      if (trees[0] != -2) {
+        int t1 = trees[0], t2 = trees[1];
+        efc_tree[i] = t1 >= 0 ? t1 : t2;
+        if (t2 == -2) merge(t1, -1); else merge(t1, t2);
+      } else {
+        // generic scan of the dense Jacobian row (tendon rows): trees in order of first non-zero dof
+        crptr Jr = P.J + (size_t)i*nv;
+        int t1 = -2, tprev = -1, first = -2;
+        for (int j = 0; j < nv; j++) {
+          if (Jr[j] != 0) {
+            int tj = M.dof_treeid[j];
+            if (tj != tprev) {
+              if (t1 == -2) { t1 = tj; first = tj; }
+              else { merge(t1, tj); t1 = tj; }
+              tprev = tj;
+            }
+            j = M.tree_dofadr[tj] + M.tree_dofnum[tj] - 1;
+          }
+        }
+        if (t1 != -2 && t1 == first && tprev == first) merge(first, -1);
+        efc_tree[i] = first >= 0 ? first : 0;
+      }
+    }
+    // mj_dsuAssign: ids in ascending order of canonical roots
+    int nisland = 0;
+    for (int t = 0; t < ntree; t++) {
+      if (parent[t] == -1) { tree_island[t] = -1; continue; }
+      if (parent[t] == t) tree_island[t] = nisland++;
+      else { parent[t] = parent[parent[t]]; tree_island[t] = tree_island[parent[t]]; }
+    }
+    for (int i = 0; i < nefc; i++) P.island[i] = tree_island[efc_tree[i]];
+    counts[MJH_C_NISLAND] = nisland;
   }
   wv_sync();
 }

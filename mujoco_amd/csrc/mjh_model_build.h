@@ -111,6 +111,12 @@ static int pair_func(int t1, int t2, int* maxcon) {
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_SPHERE) { *maxcon = 1; return MJH_COL_SPHERE_SPHERE; }
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CAPSULE) { *maxcon = 1; return MJH_COL_SPHERE_CAPSULE; }
   if (t1 == mjGEOM_CAPSULE && t2 == mjGEOM_CAPSULE) { *maxcon = 2; return MJH_COL_CAPSULE_CAPSULE; }
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_CYLINDER) { *maxcon = 4; return MJH_COL_PLANE_CYLINDER; }
+  // convex primitives the reference sends to its GJK/EPA or box routines: the pair stays in the list
+  // (so ordering and filtering match) but reaching its narrowphase raises mjhip's UNSUPPORTED warning
+  auto prim = [](int t) { return t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER ||
+                                 t == mjGEOM_ELLIPSOID || t == mjGEOM_BOX; };
+  if ((t1 == mjGEOM_PLANE || prim(t1)) && prim(t2)) { *maxcon = 0; return MJH_COL_UNSUPPORTED; }
   *maxcon = 0;
   return -1;
 }
@@ -165,7 +171,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
     MJH_REJECT(m->actuator_delay[i] != 0, "actuator delays");
     int tt = m->actuator_trntype[i];
-    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT, "actuator transmissions other than joint");
+    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT && tt != mjTRN_SLIDERCRANK,
+               "actuator transmissions other than joint / slider-crank");
+    if (tt == mjTRN_SLIDERCRANK) {
+      MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
+                 m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
+                 "actuator-level armature/damping on a slider-crank transmission");
+      continue;
+    }
     int jt = m->jnt_type[m->actuator_trnid[2*i]];
     MJH_REJECT(jt != mjJNT_HINGE && jt != mjJNT_SLIDE, "actuators on ball/free joints");
     // servo wrap period (wrapPeriod, engine_forward.c:305-342) is zero for hinge/slide joint transmissions
@@ -196,7 +209,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   s.nC = m->nC; s.nJten = m->nJten; s.ntree = m->ntree;
   s.nvw = (m->nv + 31)/32;
   s.nstate = 1 + m->nq + m->nv + m->na;
-  s.nmoment = m->nu;
+  s.nmoment = m->nu;   // (recomputed below once the transmission types are known)
 
   o.timestep = m->opt.timestep; o.impratio = m->opt.impratio; o.tolerance = m->opt.tolerance;
   for (int k = 0; k < 3; k++) o.gravity[k] = m->opt.gravity[k];
@@ -326,8 +339,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     H->tendon_dampingpoly_eff[2*i] = poly[0];
     H->tendon_dampingpoly_eff[2*i+1] = poly[1];
   }
+  // sparse actuator_moment: static row capacity 1 for joint transmissions, nv for slider-cranks
   H->actuator_momentadr.resize(m->nu + 1);
-  for (int i = 0; i <= m->nu; i++) H->actuator_momentadr[i] = i;
+  H->actuator_momentadr[0] = 0;
+  for (int i = 0; i < m->nu; i++)
+    H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + (m->actuator_trntype[i] == mjTRN_SLIDERCRANK ? m->nv : 1);
+  s.nmoment = H->actuator_momentadr[m->nu];
 
   // ---------------- derived: tree levels, children, dof ancestors --------------------------------------
   std::vector<int> depth(m->nbody, 0);
@@ -409,7 +426,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         int g1 = gp.g1, g2 = gp.g2;
         int maxcon = 0;
         int func = pair_func(m->geom_type[g1], m->geom_type[g2], &maxcon);
-        MJH_REJECT(func < 0, "collision between geom types other than plane/sphere/capsule");
+        MJH_REJECT(func < 0, "collision with mesh/hfield/sdf geoms");
         // mj_contactParam (engine_collision_driver.c:1740-1835)
         int condim;
         real solref[2], solimp[5], fri[3];
@@ -481,6 +498,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
   s.nconlds = std::min(s.nconmax, 8);
+  // tree ids (constraint islands, engine_island.c)
+  H->body_treeid.assign(m->body_treeid, m->body_treeid + m->nbody);
+  H->dof_treeid.assign(m->dof_treeid, m->dof_treeid + m->nv);
+  H->tree_dofadr.assign(m->tree_dofadr, m->tree_dofadr + m->ntree);
+  H->tree_dofnum.assign(m->tree_dofnum, m->tree_dofnum + m->ntree);
   // L'DL fast path tables (mjh_smooth.h: factor_ld / solve_ld)
   {
     const int nv = m->nv;

@@ -287,11 +287,76 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
     int id = M.actuator_trnid[2*i];
     auto gear = M.actuator_gear + 6*i;
     int adr = M.actuator_momentadr[i];
-    // slide / hinge joint: scalar gear (other transmissions are rejected at model upload)
-    rownnz[i] = 1;
-    colind[adr] = M.jnt_dofadr[id];
-    length[i] = qpos[M.jnt_qposadr[id]]*gear[0];
-    moment[adr] = gear[0];
+    if (M.actuator_trntype[i] == MJH_TRN_SLIDERCRANK) {
+      // slider-crank (engine_core_smooth.c:1396-1465): length = a.v - sqrt((a.v)^2 + r^2 - v.v)
+      crptr site_xpos = MJH_F(B, site_xpos, e);
+      crptr site_xmat = MJH_F(B, site_xmat, e);
+      crptr cdof = MJH_F(B, cdof, e);
+      crptr subtree_com = MJH_F(B, subtree_com, e);
+      const int idslider = M.actuator_trnid[2*i + 1];
+      const real rod = M.actuator_cranklength[i];
+      real axis[3] = {site_xmat[9*idslider + 2], site_xmat[9*idslider + 5], site_xmat[9*idslider + 8]};
+      real vec[3];
+      v3_sub(vec, site_xpos + 3*id, site_xpos + 3*idslider);
+      real av = v3_dot(vec, axis);
+      real sdet, det = av*av + rod*rod - v3_dot(vec, vec);
+      int ok = 1;
+      real len;
+      if (det <= 0) { ok = 0; sdet = 0; len = av; }
+      else { sdet = sqrt(det); len = av - sdet; }
+      real dlda[3], dldv[3];
+      if (ok) {
+        v3_scl(dldv, axis, 1 - av/sdet);
+        v3_scl(dlda, vec, 1/sdet);
+        v3_addto(dldv, dlda);
+        v3_scl(dlda, vec, 1 - av/sdet);
+      } else {
+        v3_copy(dlda, vec);
+        v3_copy(dldv, axis);
+      }
+      // Jacobians of the slider point / axis and of the crank site (mj_jacPointAxis, mj_jacSite),
+      // chain rule, compression of the non-zero entries
+      const int bs = M.site_bodyid[idslider], bc = M.site_bodyid[id];
+      const int ws = M.body_weldid[bs], wc = M.body_weldid[bc];
+      real offs[3], offc[3];
+      v3_sub(offs, site_xpos + 3*idslider, subtree_com + 3*M.body_rootid[bs]);
+      v3_sub(offc, site_xpos + 3*id, subtree_com + 3*M.body_rootid[bc]);
+      int nnz = 0;
+      for (int j = 0; j < s.nv; j++) {
+        int ins = (M.body_dofanc[ws*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        int inc = (M.body_dofanc[wc*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        crptr cd = cdof + 6*j;
+        real jS[3] = {0, 0, 0}, jr[3] = {0, 0, 0}, jC[3] = {0, 0, 0};
+        if (ins) {
+          real t[3];
+          v3_cross(t, cd, offs);
+          jS[0] = cd[3] + t[0]; jS[1] = cd[4] + t[1]; jS[2] = cd[5] + t[2];
+          jr[0] = cd[0]; jr[1] = cd[1]; jr[2] = cd[2];
+        }
+        if (inc) {
+          real t[3];
+          v3_cross(t, cd, offc);
+          jC[0] = cd[3] + t[0]; jC[1] = cd[4] + t[1]; jC[2] = cd[5] + t[2];
+        }
+        real jA[3] = {jr[1]*axis[2] - jr[2]*axis[1], jr[2]*axis[0] - jr[0]*axis[2], jr[0]*axis[1] - jr[1]*axis[0]};
+        real jac[3] = {jC[0] - jS[0], jC[1] - jS[1], jC[2] - jS[2]};
+        real mrow = 0;
+        for (int k = 0; k < 3; k++) mrow += dlda[k]*jA[k] + dldv[k]*jac[k];
+        if (mrow != 0) {
+          moment[adr + nnz] = mrow * gear[0];
+          colind[adr + nnz] = j;
+          nnz++;
+        }
+      }
+      length[i] = len * gear[0];
+      rownnz[i] = nnz;
+    } else {
+      // slide / hinge joint: scalar gear
+      rownnz[i] = 1;
+      colind[adr] = M.jnt_dofadr[id];
+      length[i] = qpos[M.jnt_qposadr[id]]*gear[0];
+      moment[adr] = gear[0];
+    }
   }
   wv_sync();
 }

@@ -103,43 +103,85 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const real pinf = __builtin_huge_val();
   const real blo = isfric ? -fl : (isineq ? 0.0 : -pinf);
   const real bhi = isfric ? fl : pinf;
-  real fprev = f, fmom = f;
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
-  const auto* otab = wv_uniform_ptr(M.pgs_order) + wv_uniform_ptr(M.pgs_order_adr)[n];
+  const auto* otab_all = wv_uniform_ptr(M.pgs_order);
+  const auto* otab_adr = wv_uniform_ptr(M.pgs_order_adr);
+
+  // Constraint islands (engine_forward.c:1187-1222): with islands on, the reference runs this same
+  // loop once per island over that island's rows (their original relative order, its own PCG
+  // stream, momentum and termination), residuals still taken over the full row.  nisland == 0
+  // (islands disabled) is one pass over everything.
+  const int nisl_raw = wv_uniform_i(counts[MJH_C_NISLAND]);
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  const int myisl = (own && nisl > 1) ? P.island[jj] : 0;
+  int niter0 = 0;
+
+  for (int isl = 0; isl < nisl; isl++) {
+    const int member = own && myisl == isl;
+    int nk = n;                 // rows of this island
+    int crank = jj;             // island-local index of my constraint
+    if (nisl > 1) {
+      nk = wv_sum_i(member);
+      crank = 0;
+      for (int q = 0; q < n; q++) {
+        const int inq = (P.island[q] == isl);
+        if (inq && q < jj) crank++;
+      }
+      // efclist: island-local index -> global row (kept in the order scratch array)
+      if (member) P.order[crank] = jj;
+      wv_sync();
+    }
+    if (nk == 0) continue;
+    // global row / owner lane of island-local index `lane`
+    int grow = lane;
+    if (nisl > 1) grow = (lane < nk) ? P.order[lane] : 0;
+    const int growlane = (grow < n4) ? 16*(grow & 3) + (grow >> 2) : 16*(grow - n4) + 15;
+    wv_sync();
+    const auto* otab = otab_all + otab_adr[nk];
+    real fprev = f, fmom = f;
 
   int iter = 0, nesterov_k = 0;
   // visitation order of the coming iteration (lane b holds order[b]); fetched one iteration ahead
-  int ord_next = (lane < n) ? otab[lane] : 0;
+  int ord_next = (lane < nk) ? otab[lane] : 0;
   while (iter < maxiter) {
-    const int ord = ord_next;
-    if (iter + 1 < maxiter) ord_next = (lane < n) ? otab[(iter + 1)*n + lane] : 0;
+    // island-local index visited at position b -> its global row and owner lane (per lane b)
+    const int ordc = ord_next;
+    if (iter + 1 < maxiter) ord_next = (lane < nk) ? otab[(iter + 1)*nk + lane] : 0;
+    int ord = ordc, ordlane;
+    if (nisl > 1) {
+      ord = wv_shfl_i(grow, ordc);
+      ordlane = wv_shfl_i(growlane, ordc);
+    } else {
+      ordlane = (ord < n4) ? 16*(ord & 3) + (ord >> 2) : 16*(ord - n4) + 15;
+    }
     // ---- Nesterov extrapolation (:508-554)
     real beta = 0;
     if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
-    if (beta > 0) {
-      real f_save = f;
-      real fx = f_save + beta*(f_save - fprev);
-      fprev = f_save;
-      if (kind == 1) fx = r_clip(fx, -fl, fl);
-      else if (kind == 2 && fx < 0) fx = 0;
-      f = fx;
-      fmom = fx;
-    } else {
-      fprev = f;
-      fmom = f;
+    if (member) {
+      if (beta > 0) {
+        real f_save = f;
+        real fx = f_save + beta*(f_save - fprev);
+        fprev = f_save;
+        if (kind == 1) fx = r_clip(fx, -fl, fl);
+        else if (kind == 2 && fx < 0) fx = 0;
+        f = fx;
+        fmom = fx;
+      } else {
+        fprev = f;
+        fmom = f;
+      }
     }
-    // owner lane of the constraint visited at position b, computed by lane b for its own entry
-    const int ordlane = (ord < n4) ? 16*(ord & 3) + (ord >> 2) : 16*(ord - n4) + 15;
+
     // ---- one sweep
     real improvement = 0;
     int i = wv_bcast_i(ord, 0);
     real a = own ? ar_load(i) : 0;                   // row of the first visited constraint
-    for (int bi = 0; bi < n; bi++) {
+    for (int bi = 0; bi < nk; bi++) {
       const real p = a*f;
       // prefetch the next row while this one is reduced (issued after the product so that the
       // wait for the current row does not also drain this load)
-      int inext = wv_bcast_i(ord, bi + 1 < n ? bi + 1 : bi);
+      int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
 #if !defined(MJH_HOSTSIM)
       asm volatile("" : "+s"(inext) : "v"(p));      // orders the prefetch after the product
 #endif
@@ -175,20 +217,19 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
     }
     improvement *= scale;
 
-    // ---- gradient restart (:694-713): sum over constraints in index order
+    // ---- gradient restart (:694-713): sum over the island's constraints in index order
     int restart = 0;
     if (iter > 0) {
       const real ce = (f - fmom) * (fmom - fprev);
       real dotce = 0;
-      for (int q = 0; q < n; q++) {
-        const int lq = (q < n4) ? 16*(q & 3) + (q >> 2) : 16*(q - n4) + 15;
-        dotce += wv_bcast(ce, lq);
-      }
+      for (int q = 0; q < nk; q++) dotce += wv_bcast(ce, wv_bcast_i(growlane, q));
       restart = (dotce < 0);
     }
     if (restart) nesterov_k = 0; else nesterov_k++;
     iter++;
     if (improvement < M.o.tolerance) break;
+  }
+    if (isl == 0) niter0 = iter;
   }
 
   // final dual state (dualState, :270-345), forces back to memory, iteration count
@@ -203,7 +244,7 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
     P.state[jj] = st;
     P.force[jj] = f;
   }
-  if (lane == 0) counts[MJH_C_NITER] = iter;
+  if (lane == 0) counts[MJH_C_NITER] = niter0;
   wv_sync();
 }
 #endif  // !MJH_LANE_MODE
@@ -403,7 +444,11 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 #endif
   } else
 #endif
-  solve_pgs(M, B, e);
+  {
+    // the generic sweep is monolithic: several islands need the per-island loop of the fast path
+    if (counts[MJH_C_NISLAND] > 1 && wv_lane() == 0) MJH_F(B, warning, e)[MJH_WARN_UNSUPPORTED]++;
+    solve_pgs(M, B, e);
+  }
   MJH_SUBPROF(23);     // PGS
 
   // mj_dualFinish, first half (engine_solver.c:72-85): qfrc_constraint = J' f

@@ -128,6 +128,15 @@ MJH_DEV double wv_shfl(double v, int src) {
   return r;
 }
 MJH_DEV int wv_any(int pred) { return wv_ballot(pred) != 0; }
+// int held by lane src (src may differ per lane)
+MJH_DEV int wv_shfl_i(int v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  int r = (int)w->iscratch[src & (MJH_WAVE - 1)];
+  mjhsim::yield();
+  return r;
+}
 // value held by lane (lane + K) of the caller's 16-lane row; 0 beyond the row's end
 template <int K>
 MJH_DEV double wv_row_shl(double v) {
@@ -222,6 +231,7 @@ MJH_DEV int wv_exscan_i(int v) {
 MJH_DEV double wv_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
 MJH_DEV double wv_shfl(double v, int src) { return __shfl(v, src, 64); }
 MJH_DEV int wv_any(int pred) { return __any(pred); }
+MJH_DEV int wv_shfl_i(int v, int src) { return __shfl(v, src, 64); }
 // value held by lane (lane + K) of the caller's 16-lane DPP row, 0 beyond its end (row_shl:K)
 template <int K>
 MJH_DEV double wv_row_shl(double v) {

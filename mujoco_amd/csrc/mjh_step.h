@@ -134,7 +134,10 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_ACCEL, stage_acceleration(M, B, e));
   }
   if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
-  if (stages & MJH_STAGE_MAKE) MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
+  if (stages & MJH_STAGE_MAKE) {
+    MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
+    stage_island(M, B, e);
+  }
   if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));

@@ -35,6 +35,10 @@
   X(body_geomnum, s.nbody)                     \
   X(body_geomadr, s.nbody)                     \
   X(body_dofanc, s.nbody * s.nvw)              \
+  X(body_treeid, s.nbody)                      \
+  X(dof_treeid, s.nv)                          \
+  X(tree_dofadr, s.ntree)                      \
+  X(tree_dofnum, s.ntree)                      \
   X(jnt_type, s.njnt)                          \
   X(jnt_qposadr, s.njnt)                       \
   X(jnt_dofadr, s.njnt)                        \
@@ -224,8 +228,8 @@ enum {
   X(xaxis, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                       \
   X(geom_xpos, 3 * s.ngeom, 3 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
   X(geom_xmat, 9 * s.ngeom, 9 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
-  X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_KIN)                    \
-  X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_KIN)                    \
+  X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
+  X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \
   X(cinert, 10 * s.nbody, 10 * s.nbody, MJH_T_COMPOS, MJH_T_RNE)                  \
   X(cdof, 6 * s.nv, 6 * s.nv, MJH_T_COMPOS, MJH_T_MAKE)                           \
@@ -297,6 +301,9 @@ enum {
   X(efc_type, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(efc_id, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(efc_state, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  /* constraint islands (engine_island.c): island of every row; union-find work space */ \
+  X(efc_island, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                               \
+  X(island_work, s.nefcmax + 2 * s.ntree + 8, 0, MJH_T_GLB, MJH_T_GLB)            \
   X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)         \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
   X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)                                           \
@@ -430,7 +437,8 @@ enum {
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1,
   // pair_func: which narrowphase routine a static pair uses
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
-  MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4,
+  MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
+  MJH_COL_UNSUPPORTED = 6,   // convex pair without a GPU collider: raises MJH_WARN_UNSUPPORTED if it survives the filter
 };
 
 // stage bits for partial forward evaluation (tests and per-stage profiling)

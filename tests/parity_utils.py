@@ -94,3 +94,19 @@ def oracle_rollout(rb, m, state0, ctrl, warmstart0=None):
             out[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
             ints[e, t] = (d.ncon, d.nefc, d.solver_niter[0])
     return out, ints
+
+
+# free cylinders (tilted, lying, upright) and a capsule dropping on a plane: multi-point
+# plane-cylinder contacts, pyramidal + frictionless, one constraint island per body
+CYL_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="60"/>
+  <worldbody>
+    <geom type="plane" size="2 2 .01"/>
+    <body pos="0 0 .12" euler="25 40 0"><freejoint/><geom type="cylinder" size=".05 .08" condim="3"/></body>
+    <body pos="1 0 .09" euler="90 0 10"><freejoint/><geom type="cylinder" size=".07 .03" condim="1"/></body>
+    <body pos="0 1 .2" euler="0 0 0"><freejoint/><geom type="cylinder" size=".04 .1" condim="3"/></body>
+    <body pos="1 1 .1"><freejoint/><geom type="capsule" size=".03 .06" condim="3"/></body>
+  </worldbody>
+</mujoco>
+"""

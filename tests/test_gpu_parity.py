@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -124,6 +124,41 @@ def test_rk4_rollout_vs_live_oracle(rb, hip_lib, golden):
     print("rk4 rollout rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL
     assert np.array_equal(b.get("counts")[:, 1], ints[:, -1, 1])
+
+
+def test_slider_crank_vs_golden(hip_lib, golden):
+    """BASELINE config 1: slider-crank transmissions + position actuators (no contacts in this regime)"""
+    mm = mujoco_amd.MjbModel(hip_lib, os.path.join(GOLDEN, "slider_crank.mjb"))
+    mm.set_option("solver", 0)
+    dmc = K.DeviceModel(hip_lib, mm)
+    fx = golden("slider_crank")
+    n, T = fx["state0"].shape[0], fx["ctrl"].shape[1]
+    b = K.Batch(dmc, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"])
+    print("slider_crank rollout rel err", relerr(out, fx["state"]))
+    assert relerr(out, fx["state"]) <= TOL
+    assert b.get("warning").sum() == 0
+
+
+def test_cylinder_scene_islands_vs_live_oracle(rb, hip_lib, tmp_path):
+    """plane-cylinder collider (up to 4 contacts) and per-island PGS on a 4-tree scene"""
+    xml = tmp_path / "cyl.xml"
+    xml.write_text(CYL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = 0
+    dmc = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 60
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmc, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("cylinder scene rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
+    assert relerr(out, ref) <= TOL
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1] and c[5] == ints[0, -1, 2]
 
 
 def test_full_size_batch_properties(hip_lib, dm, golden):

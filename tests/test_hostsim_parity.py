@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import check_forward, oracle_rollout
+from parity_utils import CYL_XML, check_forward, oracle_rollout
 
 
 @pytest.fixture(scope="module")
@@ -165,5 +165,63 @@ def test_unsupported_models_are_rejected(rb, hostsim_lib):
         K.DeviceModel(hostsim_lib, m)
     sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
     sc.opt.solver = 0
+    sc.opt.integrator = 2      # mjINT_IMPLICIT
     with pytest.raises(K.MjhipError, match="unsupported"):
         K.DeviceModel(hostsim_lib, sc)
+
+
+FORWARD_FIELDS_SC = ["site_xpos", "site_xmat", "actuator_length", "actuator_velocity", "actuator_force",
+                     "qfrc_actuator", "qacc_smooth", "qacc"]
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_slider_crank_bit_exact(rb, hostsim_lib, golden, layout):
+    """BASELINE config 1 (model/slider_crank): slider-crank transmissions (engine_core_smooth.c:1396),
+    position actuators, cylinder geoms -- forward fields and the golden trajectory, bit for bit"""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
+    m.opt.solver = 0
+    dm = K.DeviceModel(hostsim_lib, m)
+    fx = golden("slider_crank")
+    n, T = 4, 40
+    b = K.Batch(dm, n, layout=layout)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T])
+    assert np.array_equal(out, fx["state"][:n, :T])
+    assert b.get("warning").sum() == 0
+    # forward-pass fields of the transmission against the live oracle
+    d = rb.MjData(m)
+    b.set("qpos", fx["state"][:n, T - 1, 1:1 + m.nq]); b.set("qvel", fx["state"][:n, T - 1, 1 + m.nq:])
+    b.set("ctrl", fx["ctrl"][:n, T - 1])
+    b.forward()
+    for e in range(n):
+        d.qpos[:] = fx["state"][e, T - 1, 1:1 + m.nq]; d.qvel[:] = fx["state"][e, T - 1, 1 + m.nq:]
+        d.ctrl[:] = fx["ctrl"][e, T - 1]
+        d.qacc_warmstart[:] = b.get("qacc_warmstart")[e]
+        rb.mj_forward(m, d)
+        for f in FORWARD_FIELDS_SC:
+            ref = np.asarray(getattr(d, f)).ravel()
+            assert np.array_equal(b.get(f)[e][:ref.size], ref), (e, f)
+
+
+
+
+
+def test_plane_cylinder_collider_bit_exact(rb, hostsim_lib, tmp_path):
+    """mjc_PlaneCylinder (engine_collision_primitive.c:101-208): tilted, lying and upright cylinders
+    dropping on a plane -- up to 4 contacts per pair, pyramidal and frictionless"""
+    xml = tmp_path / "cyl.xml"
+    xml.write_text(CYL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = 0
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 90
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 0].max() >= 6, "the scene is supposed to produce multi-point cylinder contacts"
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
+    assert b.get("counts")[0, 0] == ints[0, -1, 0]

@@ -12,7 +12,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" \
            "SQ_INSTS_FLAT_LDS_ONLY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 30 --warmup 10 > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o pmc -- python $OLDPWD/bench.py --no-cpu-baseline --steps 100 --warmup 100 > $OUT/p$i.log 2>&1
   tail -2 $OUT/p$i.log
 done
 cd $OLDPWD
