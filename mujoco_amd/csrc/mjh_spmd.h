@@ -197,7 +197,9 @@ __device__ __forceinline__ const MJH_CONST_AS T& wv_const_ref(const T* p) {
 __device__ __forceinline__ int wv_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // out-of-line device function: gives the big stages their own register allocation scope
 // register budget: 4 waves/SIMD (<=128 VGPRs) so that 4096 one-wave environments are co-resident
+#ifndef MJH_WAVES_PER_EU
 #define MJH_WAVES_PER_EU 4
+#endif
 #define MJH_DEVN_WAVE __device__ __noinline__ static
 #define MJH_DEVN_LANE __device__ __forceinline__ static
 #define MJH_GLOBAL __global__ void

@@ -1,21 +1,13 @@
-# usage: bash tools/gpu_sweep.sh   (on the GPU box): correctness first, then waves/SIMD x LDS budget sweep
-set -x
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
-tail -4 gpurun_out/smoke.log
-timeout 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-tail -15 gpurun_out/pytest_gpu.log
-: > gpurun_out/sweep.txt
-for w in 2 3 4; do
-  for lds in 0 10240 13312 16384 20480 26624 32768; do
-    echo "== waves_per_eu=$w lds=$lds" >> gpurun_out/sweep.txt
-    MJHIP_LIB=$PWD/tools/variants/gpurun_out_libs_w$w.so MJHIP_LDS_BYTES=$lds timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+: > gpurun_out/sweep4.txt
+for cfg in "4 7168 50" "4 8192 50" "4 9216 50" "4 9728 50" "4 10240 50" "4 9216 25" "4 9216 100" "4 9216 10"; do
+  set -- $cfg
+  echo "== waves_per_eu=$1 lds=$2 chunk=$3" >> gpurun_out/sweep4.txt
+  MJHIP_LIB=$PWD/tools/variants/libmjhip_w$1.so MJHIP_LDS_BYTES=$2 timeout 300 python bench.py --steps 400 --warmup 100 --chunk $3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 try:
-    r = json.loads(sys.stdin.readline()); print(r['value'], r['ms_per_step'], r['end_state'])
+    r = json.loads(sys.stdin.readline()); print(r['value'], r['ms_per_step'])
 except Exception as ex: print('FAILED', ex)
-" >> gpurun_out/sweep.txt
-  done
+" >> gpurun_out/sweep4.txt
 done
-cat gpurun_out/sweep.txt
+cat gpurun_out/sweep4.txt
