@@ -17,51 +17,61 @@ struct Efc {
   iptr order, state, type, id, island;
 };
 
-// list of (member, global home expression, element count) in packing order
+// Two regions of the workgroup's LDS block take these arrays:
+//   region 1 [dyn_off, lds_bytes)  free from MJH_T_MAKE on: arrays written by constraint assembly
+//   region 2 [dyn2_off, dyn_off)   holds the fields that die with MJH_T_MAKE (cdof, subtree_com, the
+//                                  contact slots, tendon rows); free from MJH_T_PROJECT on, it takes the
+//                                  arrays born there (AR first -- the PGS sweep reads it every row)
+// Packing order = priority; an array either fits entirely or stays in its global home.
+// lists: (member, global home expression, element count, region it is born in)
 #define MJH_EFC_REAL_ARRAYS(X)                                       \
-  X(force, MJH_G(B, efc_force, e), nefc)                             \
-  X(b, MJH_G(B, efc_b, e), nefc)                                     \
-  X(ARinv, MJH_G(B, scratch, e), nefc)                               \
-  X(fprev, MJH_G(B, scratch, e) + nmax, nefc)                        \
-  X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc)                       \
-  X(R, MJH_G(B, efc_R, e), nefc)                                     \
-  X(D, MJH_G(B, efc_D, e), nefc)                                     \
-  X(floss, MJH_G(B, efc_frictionloss, e), nefc)                      \
-  X(aref, MJH_G(B, efc_aref, e), nefc)                               \
-  X(jar, MJH_G(B, scratch, e) + 3*nmax, nefc)                        \
-  X(ARf, MJH_G(B, scratch, e) + 4*nmax, nefc)                        \
-  X(pos, MJH_G(B, efc_pos, e), nefc)                                 \
-  X(margin, MJH_G(B, efc_margin, e), nefc)                           \
-  X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc)                             \
-  X(diagA, MJH_G(B, efc_diagA, e), nefc)                             \
-  X(vel, MJH_G(B, efc_vel, e), nefc)                                 \
-  X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, nv)                     \
-  X(AR, MJH_G(B, efc_AR, e), nefc*nefc)                              \
-  X(J, MJH_G(B, efc_J, e), nefc*nv)                                  \
-  X(Y, MJH_G(B, efc_Y, e), nefc*nv)
+  X(force, MJH_G(B, efc_force, e), nefc, 1)                          \
+  X(b, MJH_G(B, efc_b, e), nefc, 1)                                  \
+  X(floss, MJH_G(B, efc_frictionloss, e), nefc, 1)                   \
+  X(AR, MJH_G(B, efc_AR, e), nefc*nefc, 2)                           \
+  X(R, MJH_G(B, efc_R, e), nefc, 1)                                  \
+  X(D, MJH_G(B, efc_D, e), nefc, 1)                                  \
+  X(aref, MJH_G(B, efc_aref, e), nefc, 1)                            \
+  X(jar, MJH_G(B, scratch, e) + 3*nmax, nefc, 1)                     \
+  X(ARf, MJH_G(B, scratch, e) + 4*nmax, nefc, 1)                     \
+  X(pos, MJH_G(B, efc_pos, e), nefc, 1)                              \
+  X(margin, MJH_G(B, efc_margin, e), nefc, 1)                        \
+  X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc, 1)                          \
+  X(diagA, MJH_G(B, efc_diagA, e), nefc, 1)                          \
+  X(vel, MJH_G(B, efc_vel, e), nefc, 1)                              \
+  X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, nv, 2)                  \
+  X(J, MJH_G(B, efc_J, e), nefc*nv, 1)                               \
+  X(Y, MJH_G(B, efc_Y, e), nefc*nv, 2)                               \
+  X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
+  X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
+  X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
-  X(order, MJH_G(B, iscratch, e), nefc)                              \
-  X(state, MJH_G(B, efc_state, e), nefc)                             \
-  X(type, MJH_G(B, efc_type, e), nefc)                               \
-  X(id, MJH_G(B, efc_id, e), nefc)                                   \
-  X(island, MJH_G(B, efc_island, e), nefc)
+  X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
+  X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
+  X(type, MJH_G(B, efc_type, e), nefc, 1)                            \
+  X(id, MJH_G(B, efc_id, e), nefc, 1)                                \
+  X(island, MJH_G(B, efc_island, e), nefc, 1)
 
 // returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
 // ints first)
 MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int nv = M.s.nv, nmax = M.s.nefcmax;
-  int off = B.dyn_off;
-  const int end = B.lds_bytes;
+  int off1 = B.dyn_off, off2 = B.dyn2_off;
+  const int end1 = B.lds_bytes, end2 = B.dyn_off;
   unsigned mask = 0, bit = 1;
-  // ints first (tiny), then reals in priority order; an array either fits entirely or stays global
-#define X(m, home, cnt) { int bytes = (int)sizeof(int)*(cnt); \
-    if (off + bytes <= end) { P.m = iptr{(int*)(mjh_lds() + off), 1}; off += (bytes + 7) & ~7; mask |= bit; } else P.m = (home); bit <<= 1; }
+  // a region-2 array that does not fit its region falls through to what is left of region 1
+#define MJH_EFC_PLACE(T, m, home, bytes, region)                                              \
+    if ((region) == 2 && off2 + (bytes) <= end2) { P.m = SP<T>{(T*)(mjh_lds() + off2), 1}; off2 += ((bytes) + 7) & ~7; mask |= bit; } \
+    else if (off1 + (bytes) <= end1) { P.m = SP<T>{(T*)(mjh_lds() + off1), 1}; off1 += ((bytes) + 7) & ~7; mask |= bit; }            \
+    else P.m = (home);                                                                        \
+    bit <<= 1;
+#define X(m, home, cnt, region) { const int bytes_ = (int)sizeof(int)*(cnt); MJH_EFC_PLACE(int, m, home, bytes_, region) }
   MJH_EFC_INT_ARRAYS(X)
 #undef X
-#define X(m, home, cnt) { int bytes = (int)sizeof(real)*(cnt); \
-    if (off + bytes <= end) { P.m = rptr{(real*)(mjh_lds() + off), 1}; off += bytes; mask |= bit; } else P.m = (home); bit <<= 1; }
+#define X(m, home, cnt, region) { const int bytes_ = (int)sizeof(real)*(cnt); MJH_EFC_PLACE(real, m, home, bytes_, region) }
   MJH_EFC_REAL_ARRAYS(X)
 #undef X
+#undef MJH_EFC_PLACE
   return mask;
 }
 
@@ -75,10 +85,10 @@ MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   Efc P;
   const unsigned mask = efc_layout(M, B, e, nefc, P);
   unsigned bit = 1;
-#define X(m, home, cnt) { iptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+#define X(m, home, cnt, region) { iptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_INT_ARRAYS(X)
 #undef X
-#define X(m, home, cnt) { rptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+#define X(m, home, cnt, region) { rptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_REAL_ARRAYS(X)
 #undef X
 }

@@ -148,14 +148,22 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
     return f[a].bytes > f[b].bytes;
   });
   bool ok = budget > 0;
-  int dyn_off = 0;
-  // phase A: alive while the constraint arrays are
+  int dyn_off = 0, dyn2_off = 0;
+  // phase A1: alive from MJH_T_PROJECT to MJH_T_CONSTRAINT (packed lowest)
   for (int i : order) {
     PlanField& x = f[i];
-    if (!live_in(x, MJH_T_MAKE, MJH_T_CONSTRAINT)) continue;
+    if (!live_in(x, MJH_T_PROJECT, MJH_T_CONSTRAINT)) continue;
     bool persistent = (x.t0 == MJH_T_BEGIN && x.t1 == MJH_T_END);
-    if (ok && place(x, budget)) dyn_off = std::max(dyn_off, x.off + x.bytes);
+    if (ok && place(x, budget)) dyn2_off = std::max(dyn2_off, x.off + x.bytes);
     else if (persistent) ok = false;         // the state itself must fit, else no plan at all
+  }
+  dyn_off = dyn2_off;
+  // phase A2: alive at MJH_T_MAKE but dead afterwards (cdof, subtree_com, contact slots, tendon
+  // rows): they sit between the two dynamic regions, the lower of which reuses their bytes
+  for (int i : order) {
+    PlanField& x = f[i];
+    if (live_in(x, MJH_T_PROJECT, MJH_T_CONSTRAINT) || !live_in(x, MJH_T_MAKE, MJH_T_MAKE)) continue;
+    if (ok && place(x, budget)) dyn_off = std::max(dyn_off, x.off + x.bytes);
   }
   // phase B: everything else, free to overlay the dynamic region (it is dead by MJH_T_MAKE or
   // born after MJH_T_CONSTRAINT)
@@ -184,11 +192,12 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
   }
   L.lds_bytes = budget;
   L.dyn_off = dyn_off;
+  L.dyn2_off = dyn2_off;
   L.nconlds = s.nconlds;
   if (report) {
     report->clear();
-    snprintf(line, sizeof line, "LDS plan: %d B per workgroup, static [0,%d), dynamic constraint region [%d,%d)\n",
-             budget, dyn_off, dyn_off, budget);
+    snprintf(line, sizeof line, "LDS plan: %d B per workgroup, static [0,%d), dynamic constraint regions [%d,%d) from make + [%d,%d) from project\n",
+             budget, dyn_off, dyn_off, budget, dyn2_off, dyn_off);
     *report += line;
     for (auto& x : f) {
       snprintf(line, sizeof line, "  %-18s %6d B  t[%2d,%2d]  %s%d%s%s\n", x.name, x.bytes, x.t0, x.t1,

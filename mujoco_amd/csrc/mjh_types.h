@@ -328,6 +328,7 @@ struct DBatch {
   int nenv;
   int lds_bytes;     // LDS bytes per one-wavefront workgroup (0: no LDS plan, everything global)
   int dyn_off;       // [dyn_off, lds_bytes): free during MJH_T_MAKE..MJH_T_CONSTRAINT -> constraint arrays
+  int dyn2_off;      // [dyn2_off, dyn_off): holds fields that die with MJH_T_MAKE; free from MJH_T_PROJECT on
   int nconlds;       // contact slots resident in LDS
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;

@@ -106,6 +106,22 @@ def test_rk4_rollout_bit_exact(rb, hostsim_lib, golden, layout):
     assert np.array_equal(b.get("counts")[:, 1], ints[:, -1, 1])      # nefc of the last evaluation
 
 
+def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
+    """opt.iterations above the precomputed visitation-order table (128) takes the generic PGS sweep
+    (LDS/HBM-resident iterate, in-kernel PCG32 shuffle) instead of the register-resident one"""
+    m = humanoid_pgs_oracle(rb)
+    m.opt.iterations = 150
+    dm = K.DeviceModel(hostsim_lib, m)
+    fx = golden("humanoid")
+    n, T = 3, 8
+    s0, ctrl = fx["state0"][1:1 + n], fx["ctrl"][1:1 + n, :T]
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(b.get("counts")[:, 5], ints[:, -1, 2])
+
+
 def test_rollout_bit_exact_vs_golden(setup, golden):
     m, dm = setup
     fx = golden("humanoid")
