@@ -122,7 +122,7 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
     int nk = n;                 // rows of this island
     int crank = jj;             // island-local index of my constraint
     if (nisl > 1) {
-      nk = wv_sum_i(member);
+      nk = wv_uniform_i(wv_sum_i(member));
       crank = 0;
       for (int q = 0; q < n; q++) {
         const int inq = (P.island[q] == isl);
@@ -375,6 +375,7 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
 // ------------------------------------------------------------------------------------------------
 // mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
 // ------------------------------------------------------------------------------------------------
+MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_);
 MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -417,6 +418,11 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   }
   wv_sync();
 
+  if (M.o.solver == MJH_SOL_NEWTON) {
+    wv_sync();
+    solve_newton(M, B, e);            // (defined in mjh_newton.h; leaves qacc, qfrc_constraint, efc_force/state)
+    return;
+  }
   if (!(M.o.disableflags & (1<<9))) {
     constraint_update(B, e, P, jar, 0);        // efc_force(qacc_warmstart), syncs internally
     // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
@@ -477,6 +483,7 @@ MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
     wv_sync();
     return;
   }
+  if (M.o.solver == MJH_SOL_NEWTON) return;      // the primal solver works on qacc itself
   MJH_FOR_LANES(j, nv) qacc[j] = qfc[j];
   wv_sync();
   solve_ld(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));

@@ -166,10 +166,10 @@ struct DSizes {
 };
 
 struct DOptions {
-  real timestep, impratio, tolerance;
+  real timestep, impratio, tolerance, ls_tolerance;
   real gravity[3];
   real meaninertia;
-  int integrator, cone, solver, iterations;
+  int integrator, cone, solver, iterations, ls_iterations;
   int disableflags, enableflags;
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_ten_armature;
@@ -257,7 +257,7 @@ enum {
   X(qfrc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_EULER)                            \
   X(qacc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_FINISH)                           \
   X(qfrc_constraint, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_EULER)                   \
-  X(qacc, s.nv, s.nv, MJH_T_FINISH, MJH_T_END)                                    \
+  X(qacc, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_END)                                \
   X(qe, s.nv, s.nv, MJH_T_EULER, MJH_T_EULER)                                     \
   X(con_dist, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                \
   X(con_pos, 3 * s.nconmax, 3 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)         \
@@ -277,6 +277,10 @@ enum {
   X(efc_aref, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(efc_b, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(efc_force, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
+  X(nt_M, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  X(nt_H, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  X(nt_vec, 6 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   /* mj_RungeKutta intermediates: X[4] = (qpos, qvel), F[4] = qacc, dX */           \
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \

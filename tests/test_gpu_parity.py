@@ -161,6 +161,22 @@ def test_cylinder_scene_islands_vs_live_oracle(rb, hip_lib, tmp_path):
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1] and c[5] == ints[0, -1, 2]
 
 
+def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):
+    """humanoid with the reference's default options (Newton solver) on the GPU"""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+    mm = mujoco_amd.MjbModel(hip_lib, os.path.join(GOLDEN, "humanoid.mjb"))
+    dmn = K.DeviceModel(hip_lib, mm)
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 40
+    ref, ints = oracle_rollout(rb, m, fx["state0"], fx["ctrl"][:, :T])
+    b = K.Batch(dmn, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    print("newton rollout rel err", relerr(out, ref))
+    assert relerr(out, ref) <= TOL
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1])
+
+
 def test_full_size_batch_properties(hip_lib, dm, golden):
     """BASELINE size (4096 envs): size-independent properties -- replicated envs give identical
     bits, an env's trajectory does not depend on its position in the batch, no warnings."""

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, check_forward, oracle_rollout
+from parity_utils import CYL_XML, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -106,6 +106,43 @@ def test_rk4_rollout_bit_exact(rb, hostsim_lib, golden, layout):
     assert np.array_equal(b.get("counts")[:, 1], ints[:, -1, 1])      # nefc of the last evaluation
 
 
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_newton_solver_matches_reference(rb, hostsim_lib, golden, layout):
+    """the reference's DEFAULT solver (mjSOL_NEWTON, engine_solver.c:2344-2587) on humanoid as shipped:
+    not an operation-for-operation restatement (see mjh_newton.h), so the bar is the north star's
+    1e-6 relative on qpos/qvel -- observed ~1e-12 -- with contact/constraint counts exact"""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+    assert m.opt.solver == 2
+    dm = K.DeviceModel(hostsim_lib, m)
+    fx = golden("humanoid")
+    n, T = 4, 30
+    s0, ctrl = fx["state0"][:n], fx["ctrl"][:n, :T]
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, n, layout=layout)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    err = relerr(out, ref)
+    assert err <= 1e-9, err
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1])
+    assert np.all(np.abs(c[:, 5] - ints[:, -1, 2]) <= 1)          # Newton iterations, last step
+    # one forward pass from contact-rich keyframes: constraint forces and accelerations
+    states = contact_rich_states(rb, m, 4, seed=2)
+    b2 = K.Batch(dm, len(states), layout=layout)
+    from parity_utils import load_states
+    load_states(b2, states)
+    b2.forward()
+    d = rb.MjData(m)
+    for e, st in enumerate(states):
+        d.qpos[:] = st["qpos"]; d.qvel[:] = st["qvel"]; d.qacc_warmstart[:] = st["qacc_warmstart"]; d.ctrl[:] = st["ctrl"]
+        rb.mj_forward(m, d)
+        assert b2.get("counts")[e, 1] == d.nefc
+        for f in ["qacc", "qfrc_constraint"]:
+            assert relerr(b2.get(f)[e], np.asarray(getattr(d, f))) <= 1e-7, (e, f)
+        if d.nefc:
+            scale = max(1.0, np.abs(d.efc_force).max())
+            assert np.max(np.abs(b2.get("efc_force")[e][:d.nefc] - d.efc_force)) / scale <= 1e-7
+
+
 def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
     """opt.iterations above the precomputed visitation-order table (128) takes the generic PGS sweep
     (LDS/HBM-resident iterate, in-kernel PCG32 shuffle) instead of the register-resident one"""
@@ -176,8 +213,9 @@ def test_capacity_overflow_raises_warning(rb, hostsim_lib, golden):
 
 
 def test_unsupported_models_are_rejected(rb, hostsim_lib):
-    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))   # Newton by default
-    with pytest.raises(K.MjhipError, match="PGS"):
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+    m.opt.solver = 1                                                          # mjSOL_CG
+    with pytest.raises(K.MjhipError, match="CG"):
         K.DeviceModel(hostsim_lib, m)
     sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
     sc.opt.solver = 0
