@@ -103,6 +103,9 @@ def main() -> None:
     ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")
+    ap.add_argument("--solver", choices=["pgs", "newton"], default="pgs",
+                    help="pgs = BASELINE config 2 (the metric); newton = the reference's default solver")
+    ap.add_argument("--integrator", choices=["euler", "rk4"], default="euler")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +128,8 @@ def main() -> None:
 
     lib = ma.lib()
     model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
-    model.set_option("solver", 0)          # PGS (BASELINE config 2); integrator stays Euler
+    model.set_option("solver", 0 if args.solver == "pgs" else 2)     # PGS = BASELINE config 2
+    model.set_option("integrator", 0 if args.integrator == "euler" else 1)
     dm = ma.DeviceModel(lib, model)
     nenv, K, W = args.envs_per_gpu, args.steps, args.warmup
     nq, nv, nu, nstate = dm.nq, dm.nv, dm.nu, dm.nstate
@@ -218,10 +222,10 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "model/humanoid/humanoid.xml, 4096 envs/GPU, PGS solver, Euler, fp64, "
+            "config": {"workload": f"model/humanoid/humanoid.xml, {nenv} envs/GPU, {args.solver.upper()} solver, {args.integrator}, fp64, "
                                    "random actions U(ctrlrange), per-step state output" +
                                    ("" if not args.no_state_output else " disabled"),
-                       "envs_per_gpu": nenv, "nstep": K, "solver": "PGS", "integrator": "Euler",
+                       "envs_per_gpu": nenv, "nstep": K, "solver": args.solver.upper(), "integrator": args.integrator,
                        "parallelism": f"env-sharded x{world}",
                        "mapping": batch.lds_report().splitlines()[0] if batch.lds_report() else "no LDS plan",
                        "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
