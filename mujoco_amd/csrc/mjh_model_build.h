@@ -152,7 +152,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4, "integrators other than Euler and RK4 (implicit/implicitfast are next)");
-  MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON, "the CG solver (PGS and Newton are implemented)");
+  MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
   MJH_REJECT(m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60),
              "sparse constraint Jacobian (nv >= 60 or jacobian=sparse)");   // mj_isSparse, engine_core_util.c:29

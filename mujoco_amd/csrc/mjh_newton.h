@@ -46,7 +46,10 @@ MJH_DEV real nt_row_costdif(int kind, real x0, real x1, real D, real R, real f) 
 
 struct NtPoint { real alpha, cost, d1, d2; };
 
-MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
+// flg_newton = 0: the conjugate-gradient variant (mj_solCG): same cost, line search and warm start;
+// the search direction is the M^-1-preconditioned gradient with Hager-Zhang conjugation
+// (engine_solver.c:2506-2536) and no Hessian is built.
+MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   const int nv = s.nv;
@@ -65,6 +68,7 @@ MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
   rptr H = MJH_G(B, nt_H, e);           // Hessian, then its Cholesky factor (lower)
   rptr vec = MJH_G(B, nt_vec, e);
   rptr Ma = vec, grad = vec + nv, Mgrad = vec + 2*nv, search = vec + 3*nv, Mv = vec + 4*nv;
+  rptr gradold = vec + 6*nv, Mgradold = vec + 7*nv;
   rptr jar = P.jar, Jv = P.ARf;
   const int lane = wv_lane();
   const real tol = M.o.tolerance;
@@ -208,18 +212,20 @@ MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
     }
   };
 
+  auto precondition = [&]() {                      // Mgrad = M \ grad (CG preconditioner, certificate)
+    MJH_FOR_LANES(i, nv) Mgrad[i] = grad[i];
+    wv_sync();
+    solve_ld(M, Mgrad, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
+  };
   int iter = 0;
   int done;
   {
     // convergence certificate with M^-1 (engine_solver.c:2393-2409)
-    rptr tmp = vec + 5*nv;
-    MJH_FOR_LANES(i, nv) tmp[i] = grad[i];
-    wv_sync();
-    solve_ld(M, tmp, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
-    const real gap = r_max(0, 0.5*scale*dot_nv(grad, tmp));
+    precondition();
+    const real gap = r_max(0, 0.5*scale*dot_nv(grad, Mgrad));
     const real gnorm = scale*sqrt(dot_nv(grad, grad));
-    done = (gap < tol) && (gnorm < tol);
-    if (!done) {
+    done = (gap < tol) && (!flg_newton || gnorm < tol);
+    if (!done && flg_newton) {
       factor_and_solve();
       done = (gnorm < tol) && (r_max(0, 0.5*scale*dot_nv(grad, Mgrad)) < tol);
     }
@@ -308,17 +314,41 @@ MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
     // ---- move, update constraints / gradient / Hessian
     MJH_FOR_LANES(i, nv) { qacc[i] += search[i]*alpha; Ma[i] += Mv[i]*alpha; }
     MJH_FOR_LANES(r, nefc) jar[r] += Jv[r]*alpha;
+    if (!flg_newton) MJH_FOR_LANES(i, nv) { gradold[i] = grad[i]; Mgradold[i] = Mgrad[i]; }
     wv_sync();
     update_constraint();
-    factor_and_solve();
+    if (flg_newton) factor_and_solve(); else precondition();
     const real imp = scale*improvement;
     const real gradient = scale*sqrt(dot_nv(grad, grad));
-    const real decrement = r_max(0, 0.5*scale*dot_nv(grad, Mgrad));
+    const real decrement = flg_newton ? r_max(0, 0.5*scale*dot_nv(grad, Mgrad)) : 0;
     iter++;
-    if ((imp > 0 && imp < tol) || gradient < tol || decrement < tol) break;
-    MJH_FOR_LANES(i, nv) search[i] = -Mgrad[i];
+    if ((imp > 0 && imp < tol) || gradient < tol || (flg_newton && decrement < tol)) break;
+    if (flg_newton) {
+      MJH_FOR_LANES(i, nv) search[i] = -Mgrad[i];
+    } else {
+      // Hager-Zhang conjugate direction (engine_solver.c:2506-2536)
+      real dy = 0, yMy = 0, yMg = 0, dg = 0, dd = 0, gg = 0;
+      MJH_FOR_LANES(i, nv) {
+        const real y = grad[i] - gradold[i], My = Mgrad[i] - Mgradold[i];
+        dy += search[i]*y; yMy += y*My; yMg += y*Mgrad[i]; dg += search[i]*grad[i];
+        dd += search[i]*search[i]; gg += grad[i]*grad[i];
+      }
+      dy = wv_sum_d(dy); yMy = wv_sum_d(yMy); yMg = wv_sum_d(yMg); dg = wv_sum_d(dg);
+      dd = wv_sum_d(dd); gg = wv_sum_d(gg);
+      real beta = 0;
+      if (!(dy < MJH_MINVAL)) {
+        const real beta_hz = (yMg - 2*(yMy/dy)*dg) / dy;
+        const real eta_k = -1.0 / r_max(MJH_MINVAL, sqrt(dd) * r_min(0.01, sqrt(gg)));
+        beta = r_max(eta_k, beta_hz);
+      }
+      wv_sync();
+      MJH_FOR_LANES(i, nv) search[i] = -Mgrad[i] + beta*search[i];
+    }
     wv_sync();
   }
   if (lane == 0) counts[MJH_C_NITER] = iter;
   wv_sync();
 }
+
+MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) { solve_primal(M_, B_, e_, 1); }
+MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) { solve_primal(M_, B_, e_, 0); }

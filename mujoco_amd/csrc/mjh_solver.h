@@ -376,6 +376,7 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
 // mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_);
+MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_);
 MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -418,9 +419,10 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   }
   wv_sync();
 
-  if (M.o.solver == MJH_SOL_NEWTON) {
+  if (M.o.solver != MJH_SOL_PGS) {
+    // primal solvers (mjh_newton.h) leave qacc, qfrc_constraint, efc_force/state
     wv_sync();
-    solve_newton(M, B, e);            // (defined in mjh_newton.h; leaves qacc, qfrc_constraint, efc_force/state)
+    if (M.o.solver == MJH_SOL_NEWTON) solve_newton(M, B, e); else solve_cg(M, B, e);
     return;
   }
   if (!(M.o.disableflags & (1<<9))) {
@@ -483,7 +485,7 @@ MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
     wv_sync();
     return;
   }
-  if (M.o.solver == MJH_SOL_NEWTON) return;      // the primal solver works on qacc itself
+  if (M.o.solver != MJH_SOL_PGS) return;         // the primal solvers work on qacc itself
   MJH_FOR_LANES(j, nv) qacc[j] = qfc[j];
   wv_sync();
   solve_ld(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));

@@ -280,7 +280,7 @@ enum {
   /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
   X(nt_M, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(nt_H, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
-  X(nt_vec, 6 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(nt_vec, 8 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   /* mj_RungeKutta intermediates: X[4] = (qpos, qvel), F[4] = qacc, dX */           \
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \

@@ -143,6 +143,35 @@ def test_newton_solver_matches_reference(rb, hostsim_lib, golden, layout):
             assert np.max(np.abs(b2.get("efc_force")[e][:d.nefc] - d.efc_force)) / scale <= 1e-7
 
 
+def test_cg_solver_single_step_parity(rb, hostsim_lib, golden):
+    """mjSOL_CG (mj_solPrimal without the Hessian): one mj_step from identical (state, warm start,
+    ctrl) within the north star's 1e-6.  CG stops at a cost tolerance, not a force tolerance, so two
+    implementations whose iterations differ in the last bits drift apart over long rollouts at the
+    solver's own accuracy -- the per-step statement is the meaningful one."""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+    m.opt.solver = 1
+    dm = K.DeviceModel(hostsim_lib, m)
+    states = contact_rich_states(rb, m, 8, seed=13)
+    n = len(states)
+    s0 = np.zeros((n, 56))
+    for e, st in enumerate(states):
+        s0[e, 0] = st["time"]; s0[e, 1:29] = st["qpos"]; s0[e, 29:] = st["qvel"]
+    ws = np.stack([st["qacc_warmstart"] for st in states])
+    ctrl = np.stack([st["ctrl"] for st in states])[:, None]
+    b = K.Batch(dm, n)
+    out = b.rollout_host(1, K.mjSTATE_CTRL, s0, ws, ctrl)[:, 0]
+    d = rb.MjData(m)
+    for e in range(n):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
+        d.qacc_warmstart[:] = ws[e]
+        d.ctrl[:] = ctrl[e, 0]
+        rb.mj_step(m, d)
+        ref = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        assert relerr(out[e], ref) <= 1e-6, (e, relerr(out[e], ref))
+        assert b.get("counts")[e, 1] == d.nefc
+
+
 def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
     """opt.iterations above the precomputed visitation-order table (128) takes the generic PGS sweep
     (LDS/HBM-resident iterate, in-kernel PCG32 shuffle) instead of the register-resident one"""
@@ -214,8 +243,8 @@ def test_capacity_overflow_raises_warning(rb, hostsim_lib, golden):
 
 def test_unsupported_models_are_rejected(rb, hostsim_lib):
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
-    m.opt.solver = 1                                                          # mjSOL_CG
-    with pytest.raises(K.MjhipError, match="CG"):
+    m.opt.cone = 1                                                            # mjCONE_ELLIPTIC
+    with pytest.raises(K.MjhipError, match="elliptic"):
         K.DeviceModel(hostsim_lib, m)
     sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
     sc.opt.solver = 0
