@@ -308,3 +308,47 @@ def test_plane_cylinder_collider_bit_exact(rb, hostsim_lib, tmp_path):
     assert np.array_equal(out, ref)
     assert b.get("warning").sum() == 0
     assert b.get("counts")[0, 0] == ints[0, -1, 0]
+
+
+def _chain_xml(nlinks=20):
+    """serial chain deeper than the register-resident L'DL routines handle (depth > 16), with a
+    ball joint (limited), a slide joint, hinges, motors and a position actuator"""
+    xml = ['<mujoco>', '  <option timestep="0.003" solver="PGS" iterations="50" jacobian="dense"/>',
+           '  <default><geom type="capsule" size=".02" condim="3"/><joint damping=".05" armature=".001"/></default>',
+           '  <worldbody>', '    <geom type="plane" size="5 5 .01" pos="0 0 -.6"/>',
+           '    <body pos="0 0 0">', '      <joint name="j0" type="ball" limited="true" range="0 1.2"/>',
+           '      <geom fromto="0 0 0 .1 0 0"/>']
+    for i in range(1, nlinks + 1):
+        if i == 7:
+            jt = 'type="slide" axis="1 0 0" range="-.02 .02" limited="true"'
+        elif i == 12:
+            jt = 'type="ball"'
+        else:
+            jt = 'type="hinge" axis="0 %d %d" range="-60 60" limited="true"' % (i % 2, (i + 1) % 2)
+        xml += ['<body pos=".1 0 0">', '<joint name="j%d" %s/>' % (i, jt), '<geom fromto="0 0 0 .1 0 0"/>']
+    xml += ['</body>'] * nlinks
+    xml += ['    </body>', '  </worldbody>',
+            '  <actuator><motor joint="j3" gear="2"/><motor joint="j9" gear="1"/><position joint="j15" kp="5"/></actuator>',
+            '</mujoco>']
+    return '\n'.join(xml)
+
+
+def test_deep_chain_generic_paths_bit_exact(rb, hostsim_lib, tmp_path):
+    """21-link chain: tree depth 24 (> 16: generic L'DL factor/solve), nefc up to ~80 (> 64: generic PGS
+    sweep), ball-joint limit, slide joint, position actuator -- 150 steps, bit for bit"""
+    xml = tmp_path / "chain.xml"
+    xml.write_text(_chain_xml())
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert max(m.M_rownnz) - 1 > 16
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 150
+    ctrl = np.random.default_rng(1).uniform(-1, 1, size=(1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 1].max() > 64
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
