@@ -169,6 +169,162 @@ MJH_DEV void set_kbip(P0 KBIP, P1 ref, P2 solimp, real imp, real impP, int frict
 //          non-contact Jacobian rows.  Phase 3: contact Jacobians, lanes over dof columns.
 // Phase 4: diagApprox + impedance (R, D, KBIP), lanes over constraint blocks.
 // ------------------------------------------------------------------------------------------------
+// quaternion helpers of the weld constraint (engine_util_spatial.c:81-92, :96-101, :225-230)
+template <class P0, class P1, class P2>
+MJH_DEV void q_mulaxis(P0 res, P1 quat, P2 axis) {
+  real t0 = -quat[1]*axis[0] - quat[2]*axis[1] - quat[3]*axis[2];
+  real t1 = quat[0]*axis[0] + quat[2]*axis[2] - quat[3]*axis[1];
+  real t2 = quat[0]*axis[1] + quat[3]*axis[0] - quat[1]*axis[2];
+  real t3 = quat[0]*axis[2] + quat[1]*axis[1] - quat[2]*axis[0];
+  res[0] = t0; res[1] = t1; res[2] = t2; res[3] = t3;
+}
+template <class P0, class P1>
+MJH_DEV void q_neg(P0 res, P1 q) { res[0] = q[0]; res[1] = -q[1]; res[2] = -q[2]; res[3] = -q[3]; }
+template <class P0, class P1, class P2>
+MJH_DEV void q_deriv(P0 res, P1 quat, P2 vel) {
+  res[0] = 0.5*(-vel[0]*quat[1] - vel[1]*quat[2] - vel[2]*quat[3]);
+  res[1] = 0.5*( vel[0]*quat[0] + vel[1]*quat[3] - vel[2]*quat[2]);
+  res[2] = 0.5*(-vel[0]*quat[3] + vel[1]*quat[0] + vel[2]*quat[1]);
+  res[3] = 0.5*( vel[0]*quat[2] - vel[1]*quat[1] + vel[2]*quat[0]);
+}
+
+// anchors of a connect/weld equality in global coordinates   (mj_equalityAnchors, :561-590)
+MJH_DEV void equality_anchors(MREF M, BREF B, int e, int q, real* pos0, real* pos1, int* body0, int* body1) {
+  const int o1 = M.eq_obj1id[q], o2 = M.eq_obj2id[q];
+  if (!M.eq_objsite[q]) {
+    crptr xpos = MJH_F(B, xpos, e);
+    crptr xmat = MJH_F(B, xmat, e);
+    auto data = M.eq_data + 11*q;
+    // connect: anchors data[0:3], data[3:6]; weld: data[3:6] on body 1, data[0:3] on body 2
+    const int a0 = (M.eq_type[q] == MJH_EQ_CONNECT) ? 0 : 3, a1 = 3 - a0;
+    m3_mulvec(pos0, xmat + 9*o1, data + a0);
+    v3_addto(pos0, xpos + 3*o1);
+    m3_mulvec(pos1, xmat + 9*o2, data + a1);
+    v3_addto(pos1, xpos + 3*o2);
+    *body0 = o1; *body1 = o2;
+  } else {
+    crptr site_xpos = MJH_F(B, site_xpos, e);
+    v3_copy(pos0, site_xpos + 3*o1);
+    v3_copy(pos1, site_xpos + 3*o2);
+    *body0 = M.site_bodyid[o1]; *body1 = M.site_bodyid[o2];
+  }
+}
+
+// the two orientation quaternions of a weld: quat = q0*relpose, quat1 = neg(q1)   (:668-686)
+MJH_DEV void weld_quats(MREF M, BREF B, int e, int q, int body0, int body1, real* quat, real* quat1) {
+  crptr xquat = MJH_F(B, xquat, e);
+  if (!M.eq_objsite[q]) {
+    q_mul(quat, xquat + 4*M.eq_obj1id[q], M.eq_data + 11*q + 6);
+    q_neg(quat1, xquat + 4*M.eq_obj2id[q]);
+  } else {
+    real qs1[4];
+    q_mul(quat, xquat + 4*body0, M.site_quat + 4*M.eq_obj1id[q]);
+    q_mul(qs1, xquat + 4*body1, M.site_quat + 4*M.eq_obj2id[q]);
+    q_neg(quat1, qs1);
+  }
+}
+
+// rows of the active equality constraints: efc_pos and the dense Jacobian   (mj_instantiateEquality)
+MJH_DEV void stage_equality_rows(MREF M, BREF B, int e, const Efc& P) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nv = s.nv;
+  crptr qpos = MJH_F(B, qpos, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr subtree_com = MJH_F(B, subtree_com, e);
+  ciptr efcadr = MJH_G(B, eq_efcadr, e);
+  rptr J = P.J;
+  for (int q = 0; q < s.neq; q++) {
+    const int r0 = efcadr[q];
+    if (r0 < 0) continue;
+    const int et = M.eq_type[q];
+    auto data = M.eq_data + 11*q;
+    if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
+      real pos0[3], pos1[3], cpos[6] = {0, 0, 0, 0, 0, 0};
+      int b0, b1;
+      equality_anchors(M, B, e, q, pos0, pos1, &b0, &b1);
+      v3_sub(cpos, pos0, pos1);
+      real quat[4] = {1, 0, 0, 0}, quat1[4] = {1, 0, 0, 0};
+      const real torquescale = data[10];
+      if (et == MJH_EQ_WELD) {
+        real quat2[4];
+        weld_quats(M, B, e, q, b0, b1, quat, quat1);
+        q_mul(quat2, quat1, quat);
+        v3_scl(cpos + 3, quat2 + 1, torquescale);
+      }
+      const int w0 = M.body_weldid[b0], w1 = M.body_weldid[b1];
+      real off0[3], off1[3];
+      v3_sub(off0, pos0, subtree_com + 3*M.body_rootid[b0]);
+      v3_sub(off1, pos1, subtree_com + 3*M.body_rootid[b1]);
+      MJH_FOR_LANES(j, nv) {
+        const int in0 = (M.body_dofanc[w0*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        crptr cd = cdof + 6*j;
+        real p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0}, r0v[3] = {0, 0, 0}, r1v[3] = {0, 0, 0};
+        if (in0) {
+          real t[3];
+          v3_cross(t, cd, off0);
+          p0[0] = cd[3] + t[0]; p0[1] = cd[4] + t[1]; p0[2] = cd[5] + t[2];
+          r0v[0] = cd[0]; r0v[1] = cd[1]; r0v[2] = cd[2];
+        }
+        if (in1) {
+          real t[3];
+          v3_cross(t, cd, off1);
+          p1[0] = cd[3] + t[0]; p1[1] = cd[4] + t[1]; p1[2] = cd[5] + t[2];
+          r1v[0] = cd[0]; r1v[1] = cd[1]; r1v[2] = cd[2];
+        }
+        // difference (opposite of contact: 0 - 1)
+        for (int k = 0; k < 3; k++) J[(size_t)(r0 + k)*nv + j] = p0[k] - p1[k];
+        if (et == MJH_EQ_WELD) {
+          // 0.5 * neg(q1) * (jac0-jac1) * q0 * relpose, then torquescale
+          real axis[3] = {r0v[0] - r1v[0], r0v[1] - r1v[1], r0v[2] - r1v[2]};
+          real quat2[4], quat3[4];
+          q_mulaxis(quat2, quat1, axis);
+          q_mul(quat3, quat2, quat);
+          for (int k = 0; k < 3; k++) J[(size_t)(r0 + 3 + k)*nv + j] = (0.5*quat3[1 + k]) * torquescale;
+        }
+      }
+      const int size = (et == MJH_EQ_WELD) ? 6 : 3;
+      if (wv_lane() == 0) for (int k = 0; k < size; k++) P.pos[r0 + k] = cpos[k];
+    } else {
+      // joint / tendon coupling: pos0 - ref0 - data0 - poly(pos1 - ref1)        (:726-806)
+      const int o1 = M.eq_obj1id[q], o2 = M.eq_obj2id[q];
+      real p[2] = {0, 0}, ref[2] = {0, 0};
+      crptr ten_length = MJH_F(B, ten_length, e);
+      crptr ten_J = MJH_F(B, ten_J, e);
+      for (int k = 0; k < 1 + (o2 >= 0); k++) {
+        const int id = k ? o2 : o1;
+        if (et == MJH_EQ_JOINT) { p[k] = qpos[M.jnt_qposadr[id]]; ref[k] = M.qpos0[M.jnt_qposadr[id]]; }
+        else { p[k] = ten_length[id]; ref[k] = M.tendon_length0[id]; }
+      }
+      real cp, deriv = 0;
+      if (o2 >= 0) {
+        const real dif = p[1] - ref[1];
+        cp = p[0] - ref[0] - data[0] - (data[1]*dif + data[2]*dif*dif + data[3]*dif*dif*dif + data[4]*dif*dif*dif*dif);
+        deriv = data[1] + 2*data[2]*dif + 3*data[3]*dif*dif + 4*data[4]*dif*dif*dif;
+      } else {
+        cp = p[0] - ref[0] - data[0];
+      }
+      MJH_FOR_LANES(j, nv) {
+        real j0 = 0, j1 = 0;
+        if (et == MJH_EQ_JOINT) {
+          j0 = (j == M.jnt_dofadr[o1]) ? 1 : 0;
+          if (o2 >= 0) j1 = (j == M.jnt_dofadr[o2]) ? 1 : 0;
+        } else {
+          for (int a = 0; a < M.ten_J_rownnz[o1]; a++)
+            if (M.ten_J_colind[M.ten_J_rowadr[o1] + a] == j) j0 = ten_J[M.ten_J_rowadr[o1] + a];
+          if (o2 >= 0)
+            for (int a = 0; a < M.ten_J_rownnz[o2]; a++)
+              if (M.ten_J_colind[M.ten_J_rowadr[o2] + a] == j) j1 = ten_J[M.ten_J_rowadr[o2] + a];
+        }
+        // dense: jac0 += jac1 * (-deriv)
+        J[(size_t)r0*nv + j] = (o2 >= 0) ? j0 + j1*(-deriv) : j0;
+      }
+      if (wv_lane() == 0) P.pos[r0] = cp;
+    }
+  }
+  wv_sync();
+}
+
 // one candidate's classification: how many rows it emits and their scalar data
 struct Cand { int nrow, type, id, side; real dist, margin, floss; };
 
@@ -190,8 +346,9 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     return;
   }
 
-  // candidate index space: [dof friction | tendon friction | joints (2 sides) | tendons (2 sides) | contacts]
-  const int c_tf = nv;
+  // candidate index space: [equalities | dof friction | tendon friction | joints (2 sides) | tendons (2 sides) | contacts]
+  const int c_df = (dsbl & (1<<1)) ? 0 : s.neq;          // mjDSBL_EQUALITY
+  const int c_tf = c_df + nv;
   const int c_jl = c_tf + s.ntendon;
   const int c_tl = c_jl + 2*s.njnt;
   const int c_con = c_tl + 2*s.ntendon;
@@ -201,9 +358,14 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   auto classify = [&](int c, Cand& k) {
     k.nrow = 0; k.type = 0; k.id = 0; k.side = 0; k.dist = 0; k.margin = 0; k.floss = 0;
     if (c >= ncand) return;
-    if (c < c_tf) {                       // dof friction loss (mj_instantiateFriction :1270)
-      if (!(dsbl & (1<<2)) && M.dof_frictionloss[c] != 0) {
-        k.nrow = 1; k.type = MJH_CNSTR_FRICTION_DOF; k.id = c; k.floss = M.dof_frictionloss[c];
+    if (c < c_df) {                       // equality (mj_instantiateEquality :596)
+      if (MJH_G(B, eq_active, e)[c]) {
+        k.nrow = M.eq_rowadr[c + 1] - M.eq_rowadr[c]; k.type = MJH_CNSTR_EQUALITY; k.id = c;
+      }
+    } else if (c < c_tf) {                // dof friction loss (mj_instantiateFriction :1270)
+      const int dof = c - c_df;
+      if (!(dsbl & (1<<2)) && M.dof_frictionloss[dof] != 0) {
+        k.nrow = 1; k.type = MJH_CNSTR_FRICTION_DOF; k.id = dof; k.floss = M.dof_frictionloss[dof];
       }
     } else if (c < c_jl) {                // tendon friction loss
       int t = c - c_tf;
@@ -261,24 +423,25 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   };
 
   // ---- pass 1: count rows (the reference's count_only pass, :2833-2860) ---------------------------
-  int nefc = 0, nf_total = 0, nl_total = 0;
+  int nefc = 0, ne_total = 0, nf_total = 0, nl_total = 0;
   for (int c0 = 0; c0 < ncand; c0 += MJH_W) {
     Cand k;
     classify(c0 + wv_lane(), k);
     nefc += wv_sum_i(k.nrow);
+    ne_total += wv_sum_i(k.type == MJH_CNSTR_EQUALITY ? k.nrow : 0);
     nf_total += wv_sum_i((k.type == MJH_CNSTR_FRICTION_DOF || k.type == MJH_CNSTR_FRICTION_TENDON) ? k.nrow : 0);
     nl_total += wv_sum_i((k.type == MJH_CNSTR_LIMIT_JOINT || k.type == MJH_CNSTR_LIMIT_TENDON) ? k.nrow : 0);
   }
   const int overflow = nefc > s.nefcmax;
   if (overflow) {
     // arena-full semantics of the reference (arenaAllocEfc :145-152): no constraints this step
-    nefc = 0; nf_total = 0; nl_total = 0;
+    nefc = 0; ne_total = 0; nf_total = 0; nl_total = 0;
     for (int k = wv_lane(); k < ncon; k += MJH_W) MJH_CON(B, con_efcadr, e, 1, k)[0] = -1;
   }
   if (wv_lane() == 0) {
     if (overflow) warn[MJH_WARN_CNSTRFULL]++;
     counts[MJH_C_NEFC] = nefc;
-    counts[MJH_C_NE] = 0;
+    counts[MJH_C_NE] = ne_total;
     counts[MJH_C_NF] = nf_total;
     counts[MJH_C_NL] = nl_total;
   }
@@ -304,7 +467,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       P.pos[r] = k.dist;
       P.margin[r] = k.margin;
       P.floss[r] = k.floss;
-      if (k.type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
+      if (k.type != MJH_CNSTR_EQUALITY && k.type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
         rptr Jr = J + (size_t)r*nv;
         for (int q = 0; q < nv; q++) Jr[q] = 0;
         if (k.type == MJH_CNSTR_FRICTION_DOF) {
@@ -335,8 +498,12 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       }
     }
     if (k.type >= MJH_CNSTR_CONTACT_FRICTIONLESS) MJH_CON(B, con_efcadr, e, 1, k.id)[0] = k.nrow ? r0 : -1;
+    if (c < c_df) MJH_G(B, eq_efcadr, e)[c] = k.nrow ? r0 : -1;
   }
   wv_sync();
+
+  // ---- equality rows: residual and Jacobian per active equality, lanes over dof columns ------------
+  if (ne_total) stage_equality_rows(M, B, e, P);
 
   // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
   crptr cdof = MJH_F(B, cdof, e);
@@ -399,11 +566,29 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
 
   // ---- diagApprox + impedance: lanes over blocks -------------------------------------------------
   // non-contact rows: one block per row
-  const int nnc = nf_total + nl_total;
+  const int nnc = ne_total + nf_total + nl_total;
   MJH_FOR_LANES(r, nnc) {
     int type = P.type[r], id = P.id[r];
     real solref[2], solimp[5], dA;
-    if (type == MJH_CNSTR_FRICTION_DOF) {
+    real imp_pos = P.pos[r];
+    if (type == MJH_CNSTR_EQUALITY) {
+      // mj_diagApprox :1733-1780, getsolparam :1988, getposdim :2070-2078
+      const int et = M.eq_type[id];
+      const int r0 = MJH_G(B, eq_efcadr, e)[id];
+      if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
+        int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
+        if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }
+        const int rot = (et == MJH_EQ_WELD && r - r0 > 2) ? 1 : 0;
+        dA = M.body_invweight0[2*b1 + rot] + M.body_invweight0[2*b2 + rot];
+        imp_pos = sqrt(dot_ref(P.pos + r0, P.pos + r0, et == MJH_EQ_WELD ? 6 : 3));
+      } else {
+        const int o1 = M.eq_obj1id[id], o2 = M.eq_obj2id[id];
+        dA = (et == MJH_EQ_JOINT) ? M.dof_invweight0[M.jnt_dofadr[o1]] : M.tendon_invweight0[o1];
+        if (o2 >= 0) dA += (et == MJH_EQ_JOINT) ? M.dof_invweight0[M.jnt_dofadr[o2]] : M.tendon_invweight0[o2];
+      }
+      solref[0] = M.eq_solref[2*id]; solref[1] = M.eq_solref[2*id+1];
+      for (int q = 0; q < 5; q++) solimp[q] = M.eq_solimp[5*id + q];
+    } else if (type == MJH_CNSTR_FRICTION_DOF) {
       dA = M.dof_invweight0[id];
       solref[0] = M.dof_solref[2*id]; solref[1] = M.dof_solref[2*id+1];
       for (int q = 0; q < 5; q++) solimp[q] = M.dof_solimp[5*id + q];
@@ -420,7 +605,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     }
     fix_solparam(M, solref, solimp);
     real imp, impP;
-    get_impedance(solimp, P.pos[r], P.margin[r], &imp, &impP);
+    get_impedance(solimp, imp_pos, P.margin[r], &imp, &impP);
     real R = r_max(MJH_MINVAL, (1-imp)*dA/imp);
     int fr_row = (type == MJH_CNSTR_FRICTION_DOF || type == MJH_CNSTR_FRICTION_TENDON);
     set_kbip(P.KBIP + 4*r, solref, solimp, imp, impP, fr_row);
@@ -538,6 +723,11 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
         ciptr cg = MJH_CON(B, con_geom, e, 2, id);
         trees[0] = M.body_treeid[M.geom_bodyid[cg[0]]];
         trees[1] = M.body_treeid[M.geom_bodyid[cg[1]]];
+      } else if (type == MJH_CNSTR_EQUALITY && (M.eq_type[id] == MJH_EQ_CONNECT || M.eq_type[id] == MJH_EQ_WELD)) {
+        int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
+        if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }
+        trees[0] = M.body_treeid[b1];
+        trees[1] = M.body_treeid[b2];
       }
       if (trees[0] != -2) {
         int t1 = trees[0], t2 = trees[1];
@@ -657,6 +847,108 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
     aref[r] = -KBIP[4*r+1]*v - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
   }
   wv_sync();
+  // subtract Jdot*v for connect / weld equalities               (mj_Jdotv, :1056-1250)
+  const int ne = MJH_F(B, counts, e)[MJH_C_NE];
+  if (ne) {
+    const MJH_CONST_AS DSizes& s = M.s;
+    crptr cdof = MJH_F(B, cdof, e);
+    crptr cdof_dot = MJH_F(B, cdof_dot, e);
+    crptr cvel = MJH_F(B, cvel, e);
+    crptr subtree_com = MJH_F(B, subtree_com, e);
+    ciptr efcadr = MJH_G(B, eq_efcadr, e);
+    rptr tmp = MJH_G(B, scratch, e) + 6*M.s.nefcmax;      // 4 x 3 partial sums per lane pass
+    for (int q = 0; q < s.neq; q++) {
+      const int r0 = efcadr[q];
+      const int et = M.eq_type[q];
+      if (r0 < 0 || (et != MJH_EQ_CONNECT && et != MJH_EQ_WELD)) continue;
+      real pos0[3], pos1[3];
+      int b0, b1;
+      equality_anchors(M, B, e, q, pos0, pos1, &b0, &b1);
+      // mj_jacDot(point, body) * qvel, dense: every lane accumulates the columns it owns in dof order
+      // (mju_mulMatVec = row-wise mju_dot: the four-accumulator order is reproduced below)
+      real jdv[2][3], jrdv[2][3];
+      for (int side = 0; side < 2; side++) {
+        const int body = side ? b1 : b0;
+        auto point = side ? pos1 : pos0;
+        const int wb = M.body_weldid[body];
+        real offset[3], pvel3[3];
+        auto com = subtree_com + 3*M.body_rootid[body];
+        v3_sub(offset, point, com);
+        {
+          // mju_transformSpatial(pvel, cvel[body], 0, point, com, 0): linear part
+          real dif[3], cros[3];
+          v3_sub(dif, point, com);
+          v3_cross(cros, dif, cvel + 6*body);
+          v3_sub(pvel3, cvel + 6*body + 3, cros);
+        }
+        // columns
+        rptr colp = MJH_G(B, nt_vec, e);         // [3*nv] translational, then [3*nv] rotational (needs 6*nv <= 8*nv)
+        MJH_FOR_LANES(j, nv) {
+          const int in = (M.body_dofanc[wb*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          real jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
+          if (in) {
+            real cd_dot[6];
+            for (int k = 0; k < 6; k++) cd_dot[k] = cdof_dot[6*j + k];
+            const int jt = M.dof_jnttype[j];
+            const int dadr = M.jnt_dofadr[M.dof_jntid[j]];
+            const int is_quat = jt == MJH_JNT_BALL || (jt == MJH_JNT_FREE && j >= dadr + 3);
+            if (is_quat) sp_cross_motion(cd_dot, cvel + 6*M.dof_bodyid[j], cdof + 6*j);
+            real t1[3], t2[3];
+            v3_cross(t1, cd_dot, offset);
+            v3_cross(t2, cdof + 6*j, pvel3);
+            // zero-initialised, then +=
+            jr[0] += cd_dot[0]; jr[1] += cd_dot[1]; jr[2] += cd_dot[2];
+            jp[0] += cd_dot[3] + t1[0] + t2[0]; jp[1] += cd_dot[4] + t1[1] + t2[1]; jp[2] += cd_dot[5] + t1[2] + t2[2];
+          }
+          for (int k = 0; k < 3; k++) { colp[k*nv + j] = jp[k]; colp[(3 + k)*nv + j] = jr[k]; }
+        }
+        wv_sync();
+        for (int k = 0; k < 3; k++) {
+          jdv[side][k] = dot_ref(colp + k*nv, qvel, nv);
+          jrdv[side][k] = dot_ref(colp + (3 + k)*nv, qvel, nv);
+        }
+        wv_sync();
+      }
+      if (wv_lane() == 0) {
+        for (int k = 0; k < 3; k++) aref[r0 + k] -= jdv[0][k] - jdv[1][k];
+        if (et == MJH_EQ_WELD) {
+          auto data = M.eq_data + 11*q;
+          const real torquescale = data[10];
+          crptr xquat = MJH_F(B, xquat, e);
+          real q0r[4], negq1[4];
+          weld_quats(M, B, e, q, b0, b1, q0r, negq1);
+          auto omega1 = cvel + 6*b0;
+          auto omega2 = cvel + 6*b1;
+          real domega[3];
+          v3_sub(domega, omega1, omega2);
+          real qdot0[4], qdot0r[4], negqdot1[4];
+          if (!M.eq_objsite[q]) {
+            q_deriv(qdot0, xquat + 4*b0, omega1);
+            q_mul(qdot0r, qdot0, data + 6);
+            real qdot1[4];
+            q_deriv(qdot1, xquat + 4*b1, omega2);
+            q_neg(negqdot1, qdot1);
+          } else {
+            real qfull0[4], qfull1[4], qdot1[4];
+            q_mul(qfull0, xquat + 4*b0, M.site_quat + 4*M.eq_obj1id[q]);
+            q_deriv(qdot0, qfull0, omega1);
+            q_copy(qdot0r, qdot0);
+            q_mul(qfull1, xquat + 4*b1, M.site_quat + 4*M.eq_obj2id[q]);
+            q_deriv(qdot1, qfull1, omega2);
+            q_neg(negqdot1, qdot1);
+          }
+          real djrdv[3] = {jrdv[0][0] - jrdv[1][0], jrdv[0][1] - jrdv[1][1], jrdv[0][2] - jrdv[1][2]};
+          real t1a[4], t1[4], t2a[4], t2[4], t3a[4], t3[4];
+          q_mulaxis(t1a, negqdot1, domega); q_mul(t1, t1a, q0r);
+          q_mulaxis(t2a, negq1, djrdv);     q_mul(t2, t2a, q0r);
+          q_mulaxis(t3a, negq1, domega);    q_mul(t3, t3a, qdot0r);
+          for (int k = 0; k < 3; k++) aref[r0 + 3 + k] -= 0.5 * (t1[1 + k] + t2[1 + k] + t3[1 + k]) * torquescale;
+        }
+      }
+      wv_sync();
+    }
+    (void)tmp;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -141,7 +141,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // ---------------- feature gate ------------------------------------------------------------------
   MJH_REJECT(m->nv == 0, "model without degrees of freedom");
   MJH_REJECT(m->nmocap > 0, "mocap bodies");
-  MJH_REJECT(m->neq > 0, "equality constraints");
+  for (int i = 0; i < m->neq; i++) {
+    MJH_REJECT(m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT &&
+               m->eq_type[i] != mjEQ_TENDON, "flex equality constraints");
+    if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD)
+      MJH_REJECT(m->eq_objtype[i] != mjOBJ_BODY && m->eq_objtype[i] != mjOBJ_SITE, "connect/weld between objects other than bodies or sites");
+    const mjtNum* r = m->eq_solref + 2*i;
+    MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on an equality constraint");
+  }
   MJH_REJECT(m->nflex > 0, "flex objects");
   MJH_REJECT(m->nplugin > 0, "plugins");
   MJH_REJECT(m->nsensor > 0, "sensors (sensordata output)");
@@ -205,6 +212,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
 
   // ---------------- sizes & options -----------------------------------------------------------------
   s.nq = m->nq; s.nv = m->nv; s.nu = m->nu; s.na = m->na; s.nbody = m->nbody; s.njnt = m->njnt;
+  s.neq = m->neq;
   s.ngeom = m->ngeom; s.nsite = m->nsite; s.ntendon = m->ntendon; s.nwrap = m->nwrap;
   s.nC = m->nC; s.nJten = m->nJten; s.ntree = m->ntree;
   s.nvw = (m->nv + 31)/32;
@@ -247,6 +255,30 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->geom_bodyid, m->geom_bodyid, m->ngeom);
   copy_arr(H->geom_sameframe, m->geom_sameframe, m->ngeom);
   copy_arr(H->site_bodyid, m->site_bodyid, m->nsite);
+  // equality constraints: rows per equality (connect 3, weld 6, joint/tendon 1)
+  copy_arr(H->eq_type, m->eq_type, m->neq);
+  copy_arr(H->eq_obj1id, m->eq_obj1id, m->neq);
+  copy_arr(H->eq_obj2id, m->eq_obj2id, m->neq);
+  H->eq_objsite.resize(m->neq);
+  H->eq_active0.resize(m->neq);
+  H->eq_rowadr.assign((size_t)m->neq + 1, 0);
+  for (int i = 0; i < m->neq; i++) {
+    H->eq_objsite[i] = (m->eq_objtype[i] == mjOBJ_SITE) ? 1 : 0;
+    H->eq_active0[i] = m->eq_active0[i] ? 1 : 0;
+    int size = m->eq_type[i] == mjEQ_CONNECT ? 3 : (m->eq_type[i] == mjEQ_WELD ? 6 : 1);
+    if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD) {
+      // both bodies static: the Jacobian block is identically zero and mj_addConstraint drops the
+      // whole constraint (empty-block guard, engine_core_constraint.c:424-447)
+      int b1 = m->eq_obj1id[i], b2 = m->eq_obj2id[i];
+      if (m->eq_objtype[i] == mjOBJ_SITE) { b1 = m->site_bodyid[b1]; b2 = m->site_bodyid[b2]; }
+      if (m->body_treeid[b1] < 0 && m->body_treeid[b2] < 0) size = 0;
+    }
+    H->eq_rowadr[i + 1] = H->eq_rowadr[i] + size;
+  }
+  copy_arr(H->eq_solref, m->eq_solref, 2*m->neq);
+  copy_arr(H->eq_solimp, m->eq_solimp, 5*m->neq);
+  copy_arr(H->eq_data, m->eq_data, mjNEQDATA*m->neq);
+  copy_arr(H->tendon_length0, m->tendon_length0, m->ntendon);
   copy_arr(H->site_sameframe, m->site_sameframe, m->nsite);
   copy_arr(H->tendon_adr, m->tendon_adr, m->ntendon);
   copy_arr(H->tendon_num, m->tendon_num, m->ntendon);
@@ -572,7 +604,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   int rows_per_con = 1;
   for (int c : H->pair_dim) rows_per_con = std::max(rows_per_con, c == 1 ? 1 : 2*(c-1));
-  int nefc_bound = nfric + nlimit + rows_per_con*s.nconmax;
+  int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));
   return true;
 }

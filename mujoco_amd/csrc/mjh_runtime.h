@@ -383,14 +383,20 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
   if (lds_bytes < 0) lds_bytes = 0;
   if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
+  // equality constraints read kinematics / velocity quantities long after their usual lifetimes
+  // (rows at make, Jdot*v at reference): such models keep those fields in their global homes
+  std::vector<std::string> eqskip;
+  if (Bt->model->H.s.neq > 0)
+    eqskip = {"xpos", "xquat", "xmat", "site_xpos", "cdof", "subtree_com", "cvel", "cdof_dot"};
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS
-    plan_lds(Bt, lds_bytes, MJH_T_COLLISION, MJH_T_CONSTRAINT,
-             {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"},
+    std::vector<std::string> skip = {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"};
+    skip.insert(skip.end(), eqskip.begin(), eqskip.end());
+    plan_lds(Bt, lds_bytes, MJH_T_COLLISION, MJH_T_CONSTRAINT, skip,
              {"qpos", "qvel", "qacc_warmstart"}, &Bt->plan_report);
   } else {
     // the single wave-per-environment kernel: the whole step
-    plan_lds(Bt, lds_bytes, MJH_T_KIN, MJH_T_EULER, {}, {}, &Bt->plan_report);
+    plan_lds(Bt, lds_bytes, MJH_T_KIN, MJH_T_EULER, eqskip, {}, &Bt->plan_report);
   }
   if (!Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_plan_lds: descriptor upload failed");

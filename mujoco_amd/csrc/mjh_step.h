@@ -18,6 +18,8 @@ MJH_DEV void reset_env(MREF M, BREF B, int e) {
   MJH_FOR_LANES(i, s.nu) ctrl[i] = 0;
   rptr xf = MJH_G(B, xfrc_applied, e);
   MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
+  iptr eqa = MJH_G(B, eq_active, e);
+  MJH_FOR_LANES(i, s.neq) eqa[i] = M.eq_active0[i];
   iptr warn = MJH_F(B, warning, e);
   if (wv_lane() == 0) {
     MJH_F(B, time, e)[0] = 0;

@@ -78,6 +78,13 @@
   X(pair_dim, s.npair)                         \
   X(pair_maxcon, s.npair)                      \
   X(pair_func, s.npair)                        \
+  /* equality constraints (connect / weld / joint / tendon) */ \
+  X(eq_type, s.neq)                            \
+  X(eq_obj1id, s.neq)                          \
+  X(eq_obj2id, s.neq)                          \
+  X(eq_objsite, s.neq)                         \
+  X(eq_active0, s.neq)                         \
+  X(eq_rowadr, s.neq + 1)                      \
   /* PGS block visitation orders: engine_solver.c shuffles with a PCG32 that is re-seeded at every \
      solver call, so the order array after iteration k depends only on (nefc, k): precomputed */ \
   X(pgs_order_adr, 66)                         \
@@ -147,10 +154,15 @@
   X(pair_friction, 5 * s.npair)                \
   X(pair_solref, 2 * s.npair)                  \
   X(pair_solreffriction, 2 * s.npair)          \
-  X(pair_solimp, 5 * s.npair)
+  X(pair_solimp, 5 * s.npair)                  \
+  X(eq_solref, 2 * s.neq)                      \
+  X(eq_solimp, 5 * s.neq)                      \
+  X(eq_data, 11 * s.neq)                       \
+  X(tendon_length0, s.ntendon)
 
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int neq;         // equality constraints
   int nlevel;      // depth levels of the kinematic tree (world = level 0)
   int nvw;         // 32-bit words per dof-ancestor mask = (nv+31)/32
   int npair;       // static candidate geom pairs (reference contact order)
@@ -310,6 +322,9 @@ enum {
   X(island_work, s.nefcmax + 2 * s.ntree + 8, 0, MJH_T_GLB, MJH_T_GLB)            \
   X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)         \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
+  /* mjData.eq_active (user-switchable), first efc row of every equality this step */ \
+  X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(eq_efcadr, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)                                           \
   /* load balancing of the wave-per-environment kernels: cost = wall-clock ticks env e took in   \
      its last launch; perm = launch order (workgroup w steps env perm[w]), most expensive first */ \
@@ -442,6 +457,7 @@ enum {
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1,
   // pair_func: which narrowphase routine a static pair uses
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
+  MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
   MJH_COL_UNSUPPORTED = 6,   // convex pair without a GPU collider: raises MJH_WARN_UNSUPPORTED if it survives the filter
 };

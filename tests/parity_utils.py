@@ -110,3 +110,57 @@ CYL_XML = """
   </worldbody>
 </mujoco>
 """
+
+
+# every equality type the GPU path implements, mixed with limits, friction loss and contacts:
+# a 4-link chain closed on the world by a body connect, a site-based connect between two free
+# spheres, a soft weld between free capsules, a site weld with torquescale to a static post, a
+# static-static weld (dropped by the empty-Jacobian guard), a quadratic joint coupling, a tendon
+# coupling, and one equality that starts inactive
+EQ_XML = """
+<mujoco>
+  <option timestep="0.002" solver="PGS" iterations="80" tolerance="0"/>
+  <default><geom type="capsule" size=".02" condim="3"/><joint damping=".02"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="post" pos="1 0 0"><geom type="sphere" size=".03"/><site name="post_s" pos="0 0 .1"/></body>
+    <body name="post2" pos="1 .5 0"><geom type="sphere" size=".03"/></body>
+    <body name="l1" pos="0 0 .4">
+      <joint name="h1" axis="0 1 0"/><geom fromto="0 0 0 .15 0 0"/>
+      <body name="l2" pos=".15 0 0">
+        <joint name="h2" axis="0 1 0" range="-100 100" limited="true"/><geom fromto="0 0 0 .15 0 0"/>
+        <body name="l3" pos=".15 0 0">
+          <joint name="h3" axis="0 1 0"/><geom fromto="0 0 0 .15 0 0"/>
+          <body name="l4" pos=".15 0 0">
+            <joint name="h4" type="ball"/><geom fromto="0 0 0 .15 0 0"/>
+          </body>
+        </body>
+      </body>
+    </body>
+    <body name="s1" pos="0 .6 .1"><freejoint/><geom type="sphere" size=".05"/><site name="s1_s" pos=".05 0 0"/></body>
+    <body name="s2" pos=".14 .6 .1"><freejoint/><geom type="sphere" size=".04"/><site name="s2_s" pos="-.04 0 0"/></body>
+    <body name="c1" pos="-.6 0 .07" euler="0 30 0"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
+    <body name="c2" pos="-.6 .1 .12" euler="10 0 40"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
+    <body name="w1" pos="1 0 .25"><freejoint/><geom type="sphere" size=".04"/><site name="w1_s" pos="0 0 -.1" euler="0 0 20"/></body>
+    <body name="p1" pos="-.3 -.6 .3"><joint name="q1" axis="1 0 0" frictionloss=".02"/><geom fromto="0 0 0 0 0 -.2"/></body>
+    <body name="p2" pos="0 -.6 .3"><joint name="q2" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/></body>
+    <body name="p3" pos=".3 -.6 .3"><joint name="q3" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.25"/></body>
+    <body name="p4" pos=".6 -.6 .3"><joint name="q4" type="slide" axis="0 0 1" range="-.3 .3" limited="true"/><geom type="sphere" size=".04"/></body>
+  </worldbody>
+  <tendon>
+    <fixed name="t1"><joint joint="q3" coef="1"/></fixed>
+    <fixed name="t2"><joint joint="q4" coef="2"/><joint joint="q2" coef=".3"/></fixed>
+  </tendon>
+  <equality>
+    <connect body1="l4" body2="world" anchor=".15 0 0"/>
+    <connect site1="s1_s" site2="s2_s" solref=".01 1"/>
+    <weld body1="c1" body2="c2" solref=".03 .7" solimp=".8 .95 .01"/>
+    <weld site1="w1_s" site2="post_s" torquescale=".5"/>
+    <weld body1="post" body2="post2"/>
+    <joint joint1="q1" joint2="q2" polycoef=".1 .8 .3 0 0"/>
+    <tendon tendon1="t1" tendon2="t2" polycoef="0 1.2 0 0 0"/>
+    <joint joint1="q3" active="false"/>
+  </equality>
+  <actuator><motor joint="h1" gear="1"/><motor joint="q1" gear=".5"/></actuator>
+</mujoco>
+"""

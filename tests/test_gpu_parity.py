@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -159,6 +159,29 @@ def test_cylinder_scene_islands_vs_live_oracle(rb, hip_lib, tmp_path):
     assert relerr(out, ref) <= TOL
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1] and c[5] == ints[0, -1, 2]
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+def test_equality_constraints_vs_live_oracle(rb, hip_lib, tmp_path, solver):
+    """connect / weld / joint / tendon equalities mixed with contacts, limits and friction loss"""
+    xml = tmp_path / "eq.xml"
+    xml.write_text(EQ_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dme = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80
+    ctrl = np.random.default_rng(5).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dme, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("equality scene solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):

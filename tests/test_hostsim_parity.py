@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -308,6 +308,35 @@ def test_plane_cylinder_collider_bit_exact(rb, hostsim_lib, tmp_path):
     assert np.array_equal(out, ref)
     assert b.get("warning").sum() == 0
     assert b.get("counts")[0, 0] == ints[0, -1, 0]
+
+
+@pytest.mark.parametrize("solver,tol", [(0, 0.0), (2, 1e-9)])
+def test_equality_constraints(rb, hostsim_lib, tmp_path, solver, tol):
+    """connect / weld / joint / tendon equalities (mj_instantiateEquality,
+    engine_core_constraint.c:800-1110) incl. site-based anchors, torquescale, polynomial couplings, the
+    Jdot*v reference term, an inactive equality and a static-static weld that the empty-Jacobian
+    guard of mj_addConstraint drops -- PGS bit-exact, Newton to solver round-off"""
+    xml = tmp_path / "eq.xml"
+    xml.write_text(EQ_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80
+    ctrl = np.random.default_rng(5).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 0].max() >= 4 and ints[0, :, 1].max() >= 40
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
 def _chain_xml(nlinks=20):
