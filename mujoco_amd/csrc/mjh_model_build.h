@@ -158,7 +158,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->ngravcomp > 0 || m->flg_gravcomp, "gravity compensation");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
-  MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4, "integrators other than Euler and RK4 (implicit/implicitfast are next)");
+  MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
+             "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
   MJH_REJECT(m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60),
@@ -243,6 +244,19 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->jnt_dofadr, m->jnt_dofadr, m->njnt);
   copy_arr(H->jnt_bodyid, m->jnt_bodyid, m->njnt);
   copy_arr(H->jnt_limited, m->jnt_limited, m->njnt);
+  // standalone free bodies (mj_isFreeBody, engine_derivative.c:822-838): implicitfast solves their
+  // 6x6 block separately
+  H->jnt_freebody.assign(m->njnt, 0);
+  for (int j = 0; j < m->njnt; j++) {
+    int b = m->jnt_bodyid[j];
+    if (m->jnt_type[j] != mjJNT_FREE || m->body_jntnum[b] != 1) continue;
+    int adr = m->jnt_dofadr[j];
+    if (m->tree_dofnum[m->dof_treeid[adr]] != 6 || m->body_subtreemass[b] != m->body_mass[b]) continue;
+    H->jnt_freebody[j] = 1;
+  }
+  H->M_rowid.assign(m->nC, 0);
+  for (int i = 0; i < m->nv; i++)
+    for (int k = 0; k < m->M_rownnz[i]; k++) H->M_rowid[m->M_rowadr[i] + k] = i;
   copy_arr(H->jnt_actfrclimited, m->jnt_actfrclimited, m->njnt);
   copy_arr(H->dof_bodyid, m->dof_bodyid, m->nv);
   copy_arr(H->dof_jntid, m->dof_jntid, m->nv);

@@ -388,6 +388,13 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   std::vector<std::string> eqskip;
   if (Bt->model->H.s.neq > 0)
     eqskip = {"xpos", "xquat", "xmat", "site_xpos", "cdof", "subtree_com", "cvel", "cdof_dot"};
+  // implicitfast differentiates the actuator / damper forces at integration time, and standalone
+  // free bodies need their frames for the gyroscopic derivative
+  if (Bt->model->H.o.integrator == MJH_INT_IMPLICITFAST) {
+    for (const char* f : {"xpos", "xmat", "xipos", "ximat", "ten_J", "ten_velocity", "actuator_moment",
+                          "moment_rownnz", "moment_colind", "actuator_force"})
+      eqskip.push_back(f);
+  }
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS
     std::vector<std::string> skip = {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"};

@@ -304,6 +304,219 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 
+// 3x3 blocks of d(qfrc_bias)/d(qvel) of a standalone free body: the rotational columns of the 6x6
+// Jacobian are [-mass*lin ; rot]            (freeBias_vel_blocks, engine_derivative.c:711-786)
+MJH_DEV void free_bias_blocks(real mass, const real* R, const real* Xi, const real* inertia,
+                              const real* sv, const real* qvel_rot, real* lin, real* rot) {
+  real w[3];
+  m3_mulvec(w, R, qvel_rot);
+  // world inertia about the COM: Xi * diag(inertia) * Xi'
+  real XI[9], Iw[9];
+  for (int i = 0; i < 3; i++) for (int c = 0; c < 3; c++) XI[3*i+c] = Xi[3*i+c]*inertia[c];
+  Iw[0] = XI[0]*Xi[0] + XI[1]*Xi[1] + XI[2]*Xi[2];
+  Iw[4] = XI[3]*Xi[3] + XI[4]*Xi[4] + XI[5]*Xi[5];
+  Iw[8] = XI[6]*Xi[6] + XI[7]*Xi[7] + XI[8]*Xi[8];
+  Iw[1] = Iw[3] = XI[0]*Xi[3] + XI[1]*Xi[4] + XI[2]*Xi[5];
+  Iw[2] = Iw[6] = XI[0]*Xi[6] + XI[1]*Xi[7] + XI[2]*Xi[8];
+  Iw[5] = Iw[7] = XI[3]*Xi[6] + XI[4]*Xi[7] + XI[5]*Xi[8];
+  real ws[3], Iww[3];
+  v3_cross(ws, w, sv);
+  m3_mulvec(Iww, Iw, w);
+  // K = s w' - (w.s) I + [w x s]_x
+  const real wds = w[0]*sv[0] + w[1]*sv[1] + w[2]*sv[2];
+  real K[9];
+  K[0] = sv[0]*w[0] - wds;   K[1] = sv[0]*w[1] - ws[2];  K[2] = sv[0]*w[2] + ws[1];
+  K[3] = sv[1]*w[0] + ws[2]; K[4] = sv[1]*w[1] - wds;    K[5] = sv[1]*w[2] - ws[0];
+  K[6] = sv[2]*w[0] - ws[1]; K[7] = sv[2]*w[1] + ws[0];  K[8] = sv[2]*w[2] - wds;
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+    lin[3*r+c] = K[3*r]*R[c] + K[3*r+1]*R[3+c] + K[3*r+2]*R[6+c];
+  // C = -mass [s]_x K + [w]_x Iw - [Iw w]_x
+  real C[9];
+  for (int c = 0; c < 3; c++) {
+    real sk0 = sv[1]*K[6+c] - sv[2]*K[3+c];
+    real sk1 = sv[2]*K[c] - sv[0]*K[6+c];
+    real sk2 = sv[0]*K[3+c] - sv[1]*K[c];
+    real wi0 = w[1]*Iw[6+c] - w[2]*Iw[3+c];
+    real wi1 = w[2]*Iw[c] - w[0]*Iw[6+c];
+    real wi2 = w[0]*Iw[3+c] - w[1]*Iw[c];
+    C[c]     = -mass*sk0 + wi0 + (c == 1 ? Iww[2] : (c == 2 ? -Iww[1] : 0));
+    C[3 + c] = -mass*sk1 + wi1 + (c == 0 ? -Iww[2] : (c == 2 ? Iww[0] : 0));
+    C[6 + c] = -mass*sk2 + wi2 + (c == 0 ? Iww[1] : (c == 1 ? -Iww[0] : 0));
+  }
+  real T[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+    T[3*r+c] = R[r]*C[c] + R[3+r]*C[3+c] + R[6+r]*C[6+c];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+    rot[3*r+c] = T[3*r]*R[c] + T[3*r+1]*R[3+c] + T[3*r+2]*R[6+c];
+}
+
+// velocity derivative of one actuator's force, 0 when it does not contribute
+// (mjd_actuator_vel, engine_derivative.c:2350-2490: affine gain/bias, stateless actuators)
+MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl) {
+  if (M.actuator_forcelimited[a]) {
+    if (force <= M.actuator_forcerange[2*a] || force >= M.actuator_forcerange[2*a+1]) return 0;
+  }
+  real bias_vel = 0, gain_vel = 0;
+  if (M.actuator_biastype[a] == MJH_BIAS_AFFINE) bias_vel = M.actuator_biasprm[10*a + 2];
+  if (M.actuator_gaintype[a] != MJH_GAIN_FIXED) gain_vel = M.actuator_gainprm[10*a + 2];
+  if (gain_vel != 0) bias_vel += gain_vel * ctrl;
+  return bias_vel;
+}
+
+// mj_implicitSkip (implicitfast branch) + mj_advance        (engine_forward.c:1649-1770)
+// qH = M - h * lower(qDeriv), qDeriv = d(qfrc_actuator + qfrc_passive)/d(qvel) accumulated per
+// M entry in the reference's order (actuators, dof damping, tendon damping); standalone free
+// bodies keep their rows of M and get the unsymmetric 6x6 solve with the gyroscopic derivative.
+MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nv = s.nv;
+  const real h = M.o.timestep;
+  const int dsbl = M.o.disableflags;
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr qpos = MJH_F(B, qpos, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  rptr qe = MJH_F(B, qe, e);
+  crptr Mq = MJH_G(B, qH, e);
+  rptr qH = MJH_F(B, qLD, e);
+  rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
+  crptr mom = MJH_F(B, actuator_moment, e);
+  ciptr mnnz = MJH_F(B, moment_rownnz, e);
+  ciptr mcol = MJH_F(B, moment_colind, e);
+  crptr force = MJH_F(B, actuator_force, e);
+  crptr ctrl = MJH_F(B, ctrl, e);
+  crptr tJ = MJH_F(B, ten_J, e);
+  crptr tvel = MJH_F(B, ten_velocity, e);
+  const int act_on = !(dsbl & (1<<11)) && s.nu > 0;
+  const int passive_on = !((dsbl & (1<<5)) && (dsbl & (1<<6)));
+  const int damper_on = passive_on && !(dsbl & (1<<6));
+
+  MJH_FOR_LANES(k, s.nC) {
+    const int i = M.M_rowid[k], j = M.M_colind[k];
+    real q = 0;
+    if (act_on) {
+      for (int a = 0; a < s.nu; a++) {
+        real bv = actuator_vel_deriv(M, a, force[a], ctrl[a]);
+        if (bv == 0) continue;
+        const int adr = M.actuator_momentadr[a];
+        real mi = 0, mj = 0;
+        int hi = 0, hj = 0;
+        for (int c = 0; c < mnnz[a]; c++) {
+          if (mcol[adr + c] == i) { mi = mom[adr + c]; hi = 1; }
+          if (mcol[adr + c] == j) { mj = mom[adr + c]; hj = 1; }
+        }
+        if (hi && hj) q += mj * (mi*bv);
+      }
+    }
+    if (damper_on) {
+      if (i == j) q -= poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+      for (int t = 0; t < s.ntendon; t++) {
+        real dp[2] = {M.tendon_dampingpoly_eff[2*t], M.tendon_dampingpoly_eff[2*t+1]};
+        real bt = -poly_force_deriv(M.tendon_damping_eff[t], dp, tvel[t], 1);
+        if (bt == 0) continue;
+        const int adr = M.ten_J_rowadr[t];
+        real ji = 0, jj = 0;
+        int hi = 0, hj = 0;
+        for (int c = 0; c < M.ten_J_rownnz[t]; c++) {
+          if (M.ten_J_colind[adr + c] == i) { ji = tJ[adr + c]; hi = 1; }
+          if (M.ten_J_colind[adr + c] == j) { jj = tJ[adr + c]; hj = 1; }
+        }
+        if (hi && hj) q += jj * (ji*bt);
+      }
+    }
+    // rows of standalone free bodies stay M
+    const int jn = M.dof_jntid[i];
+    if (M.jnt_freebody[jn]) qH[k] = Mq[k];
+    else qH[k] = Mq[k] + q*(-h);
+  }
+  wv_sync();
+  factor_ld(M, qH, qHDiagInv);
+  crptr fs = MJH_F(B, qfrc_smooth, e);
+  crptr fc = MJH_F(B, qfrc_constraint, e);
+  rptr qf = MJH_F(B, rk_F, e);             // qfrc = qfrc_smooth + qfrc_constraint (kept for the 6x6 solves)
+  MJH_FOR_LANES(i, nv) { real f = fs[i] + fc[i]; qf[i] = f; qe[i] = f; }
+  wv_sync();
+  solve_ld(M, qe, qH, qHDiagInv);
+
+  // standalone free bodies: A = M_block - h*qDeriv_block + h*d(bias)/dv, LU with partial pivoting
+  // (mjd_freeMhat engine_derivative.c:844-893, mju_factorLU6/solveLU6 engine_util_solve.c:857-931)
+  crptr xpos = MJH_F(B, xpos, e);
+  crptr xipos = MJH_F(B, xipos, e);
+  crptr xmat = MJH_F(B, xmat, e);
+  crptr ximat = MJH_F(B, ximat, e);
+  MJH_FOR_LANES(jn, s.njnt) {
+    if (!M.jnt_freebody[jn]) continue;
+    const int b = M.jnt_bodyid[jn], adr = M.jnt_dofadr[jn];
+    real A[36];
+    for (int k = 0; k < 36; k++) A[k] = 0;
+    for (int r = 0; r < 6; r++) {
+      const int ra = M.M_rowadr[adr + r];
+      for (int k = 0; k < M.M_rownnz[adr + r]; k++) {
+        int c = M.M_colind[ra + k] - adr;
+        A[6*r + c] = Mq[ra + k];
+        A[6*c + r] = Mq[ra + k];
+      }
+    }
+    for (int r = 0; r < 6; r++) {
+      real qd = 0;
+      if (damper_on) qd -= poly_force_deriv(M.dof_damping_eff[adr + r], M.dof_dampingpoly_eff + 2*(adr + r), qvel[adr + r], 1);
+      for (int c = 0; c < 6; c++) A[6*r + c] -= h * (r == c ? qd : (real)0);
+    }
+    real sv[3], R[9], Xi[9], inr[3], wq[3], lin[9], rot[9];
+    for (int k = 0; k < 3; k++) { sv[k] = xipos[3*b + k] - xpos[3*b + k]; inr[k] = M.body_inertia[3*b + k]; wq[k] = qvel[adr + 3 + k]; }
+    for (int k = 0; k < 9; k++) { R[k] = xmat[9*b + k]; Xi[k] = ximat[9*b + k]; }
+    const real mass = M.body_mass[b];
+    free_bias_blocks(mass, R, Xi, inr, sv, wq, lin, rot);
+    const real hm = -h * mass;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+      A[6*r + 3 + c] += hm * lin[3*r + c];
+      A[6*(3 + r) + 3 + c] += h * rot[3*r + c];
+    }
+    // LU with row pivoting
+    int piv[6];
+    int ok = 1;
+    for (int k = 0; k < 6 && ok; k++) {
+      piv[k] = k;
+      real mx = fabs(A[6*k + k]);
+      int mr = k;
+      for (int i = k + 1; i < 6; i++) { real v = fabs(A[6*i + k]); if (v > mx) { mx = v; mr = i; } }
+      if (mx < MJH_MINVAL) { ok = 0; break; }
+      if (mr != k) {
+        piv[k] = mr;
+        for (int c = 0; c < 6; c++) { real t = A[6*k + c]; A[6*k + c] = A[6*mr + c]; A[6*mr + c] = t; }
+      }
+      const real di = 1.0 / A[6*k + k];
+      for (int i = k + 1; i < 6; i++) {
+        A[6*i + k] *= di;
+        const real aik = A[6*i + k];
+        for (int c = k + 1; c < 6; c++) A[6*i + c] -= aik * A[6*k + c];
+      }
+    }
+    if (ok) {
+      real x[6];
+      for (int i = 0; i < 6; i++) x[i] = qf[adr + i];
+      for (int i = 0; i < 6; i++) {
+        if (piv[i] != i) { real t = x[i]; x[i] = x[piv[i]]; x[piv[i]] = t; }
+        for (int c = 0; c < i; c++) x[i] -= A[6*i + c] * x[c];
+      }
+      for (int i = 5; i >= 0; i--) {
+        for (int c = i + 1; c < 6; c++) x[i] -= A[6*i + c] * x[c];
+        x[i] /= A[6*i + i];
+      }
+      for (int i = 0; i < 6; i++) qe[adr + i] = x[i];
+    }
+  }
+  wv_sync();
+
+  MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
+  wv_sync();
+  integrate_pos(M, qpos, qvel, h);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
+  MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
+  if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
+  wv_sync();
+}
+
 // mj_step                                          (engine_forward.c:1846-1880)
 MJH_DEV void step_env(MREF M, BREF B, int e) {
   check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
@@ -315,6 +528,7 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
   if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+  else if (M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
   else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
 }
 

@@ -44,6 +44,8 @@
   X(jnt_dofadr, s.njnt)                        \
   X(jnt_bodyid, s.njnt)                        \
   X(jnt_limited, s.njnt)                       \
+  X(jnt_freebody, s.njnt)                      \
+  X(M_rowid, s.nC)                             \
   X(dof_bodyid, s.nv)                          \
   X(dof_jntid, s.nv)                           \
   X(dof_parentid, s.nv)                        \
@@ -454,7 +456,7 @@ enum {
   MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1,
   MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
-  MJH_INT_EULER = 0, MJH_INT_RK4 = 1,
+  MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
   // pair_func: which narrowphase routine a static pair uses
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
   MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3,

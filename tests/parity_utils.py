@@ -119,7 +119,7 @@ CYL_XML = """
 # coupling, and one equality that starts inactive
 EQ_XML = """
 <mujoco>
-  <option timestep="0.002" solver="PGS" iterations="80" tolerance="0"/>
+  <option timestep="0.002" solver="PGS" iterations="40" tolerance="0"/>
   <default><geom type="capsule" size=".02" condim="3"/><joint damping=".02"/></default>
   <worldbody>
     <geom type="plane" size="3 3 .01"/>
@@ -137,10 +137,10 @@ EQ_XML = """
         </body>
       </body>
     </body>
-    <body name="s1" pos="0 .6 .1"><freejoint/><geom type="sphere" size=".05"/><site name="s1_s" pos=".05 0 0"/></body>
-    <body name="s2" pos=".14 .6 .1"><freejoint/><geom type="sphere" size=".04"/><site name="s2_s" pos="-.04 0 0"/></body>
-    <body name="c1" pos="-.6 0 .07" euler="0 30 0"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
-    <body name="c2" pos="-.6 .1 .12" euler="10 0 40"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
+    <body name="s1" pos="0 .6 .0505"><freejoint/><geom type="sphere" size=".05"/><site name="s1_s" pos=".05 0 0"/></body>
+    <body name="s2" pos=".14 .6 .0405"><freejoint/><geom type="sphere" size=".04"/><site name="s2_s" pos="-.04 0 0"/></body>
+    <body name="c1" pos="-.6 0 .061" euler="0 30 0"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
+    <body name="c2" pos="-.6 .1 .07" euler="0 35 40"><freejoint/><geom fromto="-.08 0 0 .08 0 0"/></body>
     <body name="w1" pos="1 0 .25"><freejoint/><geom type="sphere" size=".04"/><site name="w1_s" pos="0 0 -.1" euler="0 0 20"/></body>
     <body name="p1" pos="-.3 -.6 .3"><joint name="q1" axis="1 0 0" frictionloss=".02"/><geom fromto="0 0 0 0 0 -.2"/></body>
     <body name="p2" pos="0 -.6 .3"><joint name="q2" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/></body>
@@ -162,5 +162,43 @@ EQ_XML = """
     <joint joint1="q3" active="false"/>
   </equality>
   <actuator><motor joint="h1" gear="1"/><motor joint="q1" gear=".5"/></actuator>
+</mujoco>
+"""
+
+
+# implicitfast coverage: velocity-dependent actuators (velocity servo, position servo with kv, affine
+# gain with a velocity term, force-limited), tendon damping, joint damping, and standalone free
+# bodies whose COM is off the joint origin (gyroscopic 6x6 solve) next to a free body with a child
+IMPL_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40" integrator="implicitfast"/>
+  <default><geom type="capsule" size=".03" condim="3"/><joint damping=".3"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="a1" pos="0 0 .8">
+      <joint name="j1" axis="0 1 0"/><geom fromto="0 0 0 .25 0 0"/>
+      <body name="a2" pos=".25 0 0">
+        <joint name="j2" axis="0 1 0" range="-120 120" limited="true"/><geom fromto="0 0 0 .2 0 0"/>
+        <body name="a3" pos=".2 0 0">
+          <joint name="j3" axis="0 0 1"/><geom fromto="0 0 0 .15 0 0"/>
+          <body name="a4" pos=".15 0 0"><joint name="j4" type="slide" axis="1 0 0" damping="2"/><geom type="sphere" size=".04"/></body>
+        </body>
+      </body>
+    </body>
+    <body name="f1" pos="-.5 0 .3" euler="20 30 0"><freejoint/><geom type="capsule" fromto="0 0 0 .2 .05 0" size=".04"/><geom type="sphere" size=".06" pos=".1 .1 .05"/></body>
+    <body name="f2" pos="-.5 .6 .09" euler="0 0 0"><joint type="free" damping=".05"/><geom type="cylinder" size=".08 .03" pos=".02 0 0"/></body>
+    <body name="f3" pos=".6 .6 .3"><freejoint/><geom type="sphere" size=".05"/>
+      <body pos=".12 0 0"><joint name="k1" axis="0 1 0"/><geom fromto="0 0 0 .1 0 0"/></body></body>
+  </worldbody>
+  <tendon>
+    <fixed name="t1" damping=".8"><joint joint="j2" coef="1"/><joint joint="j3" coef="-.7"/></fixed>
+  </tendon>
+  <actuator>
+    <velocity joint="j1" kv="2" ctrlrange="-3 3"/>
+    <position joint="j2" kp="8" kv=".6"/>
+    <general joint="j3" gaintype="affine" gainprm="1.5 0 -.4" biastype="affine" biasprm="0 -1 -.2"/>
+    <velocity joint="j4" kv="5" forcerange="-.4 .4"/>
+    <motor joint="k1" gear=".3"/>
+  </actuator>
 </mujoco>
 """

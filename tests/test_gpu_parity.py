@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -182,6 +182,28 @@ def test_equality_constraints_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+def test_implicitfast_vs_live_oracle(rb, hip_lib, tmp_path, solver):
+    """implicitfast: velocity-dependent actuators, tendon damping, standalone free bodies"""
+    xml = tmp_path / "impl.xml"
+    xml.write_text(IMPL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dmi = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 100
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmi, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("implicitfast scene solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):

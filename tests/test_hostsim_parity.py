@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -324,10 +324,10 @@ def test_equality_constraints(rb, hostsim_lib, tmp_path, solver, tol):
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
-    T = 80
+    T = 24 if solver == 0 else 10
     ctrl = np.random.default_rng(5).uniform(-1, 1, (1, T, m.nu))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
-    assert ints[0, :, 0].max() >= 4 and ints[0, :, 1].max() >= 40
+    assert ints[0, :, 0].max() >= 3 and ints[0, :, 1].max() >= 30
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     if tol == 0.0:
@@ -337,6 +337,47 @@ def test_equality_constraints(rb, hostsim_lib, tmp_path, solver, tol):
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+@pytest.mark.parametrize("solver,tol", [(0, 0.0), (2, 1e-9)])
+def test_implicitfast_integrator(rb, hostsim_lib, tmp_path, solver, tol):
+    """mj_implicitSkip, implicitfast branch (engine_forward.c:1649-1770): qH = M - h*qDeriv with the
+    actuator / joint-damper / tendon-damper velocity derivatives (mjd_actuator_vel, mjd_passive_vel)
+    and the unsymmetric 6x6 solve of standalone free bodies (mjd_freeMhat)"""
+    xml = tmp_path / "impl.xml"
+    xml.write_text(IMPL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 30 if solver == 0 else 12
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
+    assert b.get("warning").sum() == 0
+
+
+def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
+    """the BASELINE humanoid with integrator=implicitfast: damping-only qDeriv, one tree"""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+    m.opt.solver = 0
+    m.opt.integrator = 3
+    dm = K.DeviceModel(hostsim_lib, m)
+    fx = golden("humanoid")
+    T = 12
+    s0, ctrl = fx["state0"][:2], fx["ctrl"][:2, :T]
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 2)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
 
 
 def _chain_xml(nlinks=20):
