@@ -13,7 +13,7 @@
 // ------------------------------------------------------------------------------------------------
 struct Efc {
   rptr force, b, ARinv, fprev, fmom, R, D, floss, aref, jar, ARf, pos, margin, KBIP,
-       diagA, vel, sqrtInvD, AR, J, Y;
+       diagA, vel, sqrtInvD, AR, J, Y, cone;
   iptr order, state, type, id, island;
 };
 
@@ -44,7 +44,8 @@ struct Efc {
   X(Y, MJH_G(B, efc_Y, e), nefc*nv, 2)                               \
   X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
-  X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)
+  X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
+  X(cone, MJH_G(B, efc_cone, e), nefc, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
   X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
   X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
@@ -464,9 +465,12 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       int r = r0 + a;
       P.type[r] = k.type;
       P.id[r] = k.id;
-      P.pos[r] = k.dist;
-      P.margin[r] = k.margin;
+      // elliptic cone: only the normal row carries the distance (:1696-1700)
+      const int tangent = (k.type == MJH_CNSTR_CONTACT_ELLIPTIC && a > 0);
+      P.pos[r] = tangent ? (real)0 : k.dist;
+      P.margin[r] = tangent ? (real)0 : k.margin;
       P.floss[r] = k.floss;
+      if (!ispyramid) P.cone[r] = 0;      // set for elliptic blocks with the impedance below
       if (k.type != MJH_CNSTR_EQUALITY && k.type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
         rptr Jr = J + (size_t)r*nv;
         for (int q = 0; q < nv; q++) Jr[q] = 0;
@@ -540,7 +544,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
       // rotate into the contact frame (mju_mulMatMat with zero-skip, engine_util_blas.c:619)
       int nr = dim > 1 ? 3 : 1;
-      real jr[3] = {0, 0, 0};
+      real jr[6] = {0, 0, 0, 0, 0, 0};
       for (int a = 0; a < nr; a++) {
         real acc = 0;
         for (int q = 0; q < 3; q++) {
@@ -549,11 +553,24 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         }
         jr[a] = acc;
       }
+      if (dim > 3) {
+        // torsional / rolling rows: rotational Jacobian difference in the contact frame (:1663-1665)
+        real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0),
+                      (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
+                      (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+        for (int a = 0; a < dim - 3; a++) {
+          real acc = 0;
+          for (int q = 0; q < 3; q++) {
+            real t = fr[3*a + q];
+            if (t != 0) acc += rd[q]*t;
+          }
+          jr[3 + a] = acc;
+        }
+      }
       if (dim == 1) {
         J[(size_t)r0*nv + j] = jr[0];
       } else if (ispyramid) {
         for (int a = 1; a < dim; a++) {
-          // only translational friction dims (condim<=3) are supported; others rejected at upload
           J[(size_t)(r0 + 2*(a-1))*nv + j] = jr[0] + jr[a]*fri[a-1];
           J[(size_t)(r0 + 2*(a-1) + 1)*nv + j] = jr[0] + jr[a]*(-fri[a-1]);
         }
@@ -642,7 +659,17 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         dA = tran + fri[jj]*fri[jj]*(jj < 2 ? tran : rot);
       } else dA = (a < 3 ? tran : rot);
       P.R[r0 + a] = r_max(MJH_MINVAL, (1-imp)*dA/imp);
-      set_kbip(P.KBIP + 4*(r0 + a), solref, solimp, imp, impP, 0);
+      // elliptic friction rows: K = 0 (solreffriction is zero for geom-geom contacts, :2181-2189)
+      set_kbip(P.KBIP + 4*(r0 + a), solref, solimp, imp, impP, type == MJH_CNSTR_CONTACT_ELLIPTIC && a > 0);
+    }
+    if (type == MJH_CNSTR_CONTACT_ELLIPTIC) {
+      // (:2213-2237) R[1] = R[0]/impratio, mu = friction[0]*sqrt(R[1]/R[0]), R[j]*mu[j]^2 = R[1]*mu[1]^2
+      P.R[r0 + 1] = P.R[r0] / r_max(MJH_MINVAL, M.o.impratio);
+      real mu = fri[0] * sqrt(P.R[r0 + 1]/P.R[r0]);
+      MJH_CON(B, con_mu, e, 1, k)[0] = mu;
+      for (int a = 1; a < dim - 1; a++) P.R[r0 + a + 1] = P.R[r0 + 1]*fri[0]*fri[0]/(fri[a]*fri[a]);
+      P.cone[r0] = mu;
+      for (int a = 1; a < dim; a++) P.cone[r0 + a] = fri[a - 1];
     }
     if (type == MJH_CNSTR_CONTACT_PYRAMIDAL) {
       // (:2213-2253) R[1] = R[0]/impratio; mu = friction[0]*sqrt(R[1]/R[0]); all rows Rpy = 2 mu^2 R[0]
@@ -952,8 +979,94 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// mj_constraintUpdate_impl without cone Hessians, pyramidal/scalar rows
-//                                                  (engine_core_constraint.c:3275-3468)
+// elliptic cone blocks: rows [i, i+dim) of one contact; P.cone holds mu on the normal row and
+// friction[j-1] on the others
+// ------------------------------------------------------------------------------------------------
+MJH_DEV int cone_leader(const Efc& P, int i) {
+  return P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC &&
+         (i == 0 || P.type[i-1] != MJH_CNSTR_CONTACT_ELLIPTIC || P.id[i-1] != P.id[i]);
+}
+MJH_DEV int cone_dim(const Efc& P, int i, int nefc) {
+  int dim = 1;
+  while (i + dim < nefc && P.type[i + dim] == MJH_CNSTR_CONTACT_ELLIPTIC && P.id[i + dim] == P.id[i]) dim++;
+  return dim;
+}
+
+// zone of the block at residual jar: 0 top (satisfied), 1 bottom (quadratic), 2 middle (cone);
+// fills U (regular-cone coordinates), N, T                 (engine_core_constraint.c:3357-3372)
+template <class P0>
+MJH_DEV int cone_zone(const Efc& P, int i, int dim, P0 jar, real* U, real* N_, real* T_) {
+  const real mu = P.cone[i];
+  U[0] = jar[i]*mu;
+  for (int j = 1; j < dim; j++) U[j] = jar[i+j]*P.cone[i+j];
+  const real N = U[0];
+  const real T = sqrt(dot_ref(U + 1, U + 1, dim - 1));
+  *N_ = N; *T_ = T;
+  if (N >= mu*T || (T <= 0 && N >= 0)) return 0;
+  if (mu*N + T <= 0 || (T <= 0 && N < 0)) return 1;
+  return 2;
+}
+
+// force/state of one block; optional cone Hessian (dim x dim, row-major) for the middle zone
+//                                                           (engine_core_constraint.c:3352-3452)
+template <class P0, class P1>
+MJH_DEV void cone_update(const Efc& P, int i, int dim, P0 jar, P1 Hc, int want_hessian) {
+  real U[6], N, T;
+  const int zone = cone_zone(P, i, dim, jar, U, &N, &T);
+  const real mu = P.cone[i];
+  int st;
+  if (zone == 0) {
+    for (int j = 0; j < dim; j++) P.force[i+j] = 0;
+    st = MJH_STATE_SATISFIED;
+  } else if (zone == 1) {
+    for (int j = 0; j < dim; j++) P.force[i+j] = -P.D[i+j]*jar[i+j];
+    st = MJH_STATE_QUADRATIC;
+  } else {
+    const real Dm = P.D[i]/(mu*mu*(1+mu*mu));
+    const real NmT = N - mu*T;
+    const real f0 = -Dm*NmT*mu;
+    P.force[i] = f0;
+    for (int j = 1; j < dim; j++) P.force[i+j] = -f0/T*U[j]*P.cone[i+j];
+    st = MJH_STATE_CONE;
+    if (want_hessian) {
+      real scl = -mu/T;
+      Hc[0] = 1;
+      for (int j = 1; j < dim; j++) Hc[j] = scl*U[j];
+      scl = mu*N/(T*T*T);
+      for (int k = 1; k < dim; k++)
+        for (int j = k; j < dim; j++) Hc[k*dim+j] = scl*U[j]*U[k];
+      scl = mu*mu - mu*N/T;
+      for (int j = 1; j < dim; j++) Hc[j*(dim+1)] += scl;
+      for (int k = 0; k < dim; k++) {
+        scl = Dm * (k == 0 ? mu : (real)P.cone[i+k]);
+        for (int j = k; j < dim; j++) Hc[k*dim+j] *= scl * (j == 0 ? mu : (real)P.cone[i+j]);
+      }
+      for (int k = 0; k < dim; k++)
+        for (int j = k + 1; j < dim; j++) Hc[j*dim+k] = Hc[k*dim+j];
+    }
+  }
+  for (int j = 0; j < dim; j++) P.state[i+j] = st;
+}
+
+// cost of one block at residual jar                        (engine_core_constraint.c:3374-3392)
+template <class P0>
+MJH_DEV real cone_cost(const Efc& P, int i, int dim, P0 jar) {
+  real U[6], N, T;
+  const int zone = cone_zone(P, i, dim, jar, U, &N, &T);
+  real c = 0;
+  if (zone == 1) {
+    for (int j = 0; j < dim; j++) c += 0.5*P.D[i+j]*jar[i+j]*jar[i+j];
+  } else if (zone == 2) {
+    const real mu = P.cone[i];
+    const real Dm = P.D[i]/(mu*mu*(1+mu*mu));
+    const real NmT = N - mu*T;
+    c = 0.5*Dm*NmT*NmT;
+  }
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mj_constraintUpdate_impl without cone Hessians    (engine_core_constraint.c:3275-3468)
 // writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
 // ------------------------------------------------------------------------------------------------
 template <class P0>
@@ -966,6 +1079,10 @@ MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cos
   rptr force = P.force;
   iptr state = P.state;
   MJH_FOR_LANES(i, nefc) {
+    if (i >= ne + nf && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+      if (cone_leader(P, i)) cone_update(P, i, cone_dim(P, i, nefc), jar, (real*)nullptr, 0);
+      continue;
+    }
     real f = -D[i]*jar[i];
     int st;
     if (i < ne) {
@@ -991,6 +1108,10 @@ MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cos
         if (jar[i] <= -R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] - floss[i]*jar[i];
         else if (jar[i] >= R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] + floss[i]*jar[i];
         else cost += 0.5*D[i]*jar[i]*jar[i];
+      } else if (P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+        const int dim = cone_dim(P, i, nefc);
+        cost += cone_cost(P, i, dim, jar);
+        i += dim - 1;
       } else if (jar[i] < 0) {
         cost += 0.5*D[i]*jar[i]*jar[i];
       }

@@ -516,8 +516,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           for (int k = 0; k < 5; k++) friction[k] = m->opt.o_friction[k];
         }
         for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
-        MJH_REJECT(condim > 3, "contact condim > 3 (torsional/rolling friction)");
-        MJH_REJECT(condim > 1 && m->opt.cone != mjCONE_PYRAMIDAL, "elliptic friction cones");
         MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
         H->pair_geom1.push_back(g1);
         H->pair_geom2.push_back(g2);
@@ -617,7 +615,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     s.npgsorder = (int)H->pgs_order.size();
   }
   int rows_per_con = 1;
-  for (int c : H->pair_dim) rows_per_con = std::max(rows_per_con, c == 1 ? 1 : 2*(c-1));
+  for (int c : H->pair_dim)
+    rows_per_con = std::max(rows_per_con, c == 1 ? 1 : (m->opt.cone == mjCONE_PYRAMIDAL ? 2*(c-1) : c));
+  s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));
   return true;

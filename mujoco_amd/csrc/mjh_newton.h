@@ -46,6 +46,74 @@ MJH_DEV real nt_row_costdif(int kind, real x0, real x1, real D, real R, real f) 
 
 struct NtPoint { real alpha, cost, d1, d2; };
 
+// line-search data of one elliptic block (PrimalPrepare, engine_solver.c:1476-1516): the bottom-zone
+// quadratic q[0..2], and the regular-cone quantities U0, V0, UU, UV, VV, Dm
+struct NtCone { real q0, q1, q2, U0, V0, UU, UV, VV, Dm, mu; };
+template <class P0, class P1>
+MJH_DEV void nt_cone_prepare(const Efc& P, int i, int dim, P0 jar, P1 Jv, NtCone& c) {
+  const real mu = P.cone[i];
+  real q0 = 0, q1 = 0, q2 = 0, UU = 0, UV = 0, VV = 0;
+  for (int j = 0; j < dim; j++) {
+    const real DJ = P.D[i+j]*jar[i+j];
+    q0 += jar[i+j]*DJ;
+    q1 += Jv[i+j]*DJ;
+    q2 += Jv[i+j]*P.D[i+j]*Jv[i+j];
+    if (j) {
+      const real U = jar[i+j]*P.cone[i+j], V = Jv[i+j]*P.cone[i+j];
+      UU += U*U; UV += U*V; VV += V*V;
+    }
+  }
+  c.q0 = 0.5*q0; c.q1 = q1; c.q2 = 0.5*q2;
+  c.U0 = jar[i]*mu; c.V0 = Jv[i]*mu; c.UU = UU; c.UV = UV; c.VV = VV;
+  c.Dm = P.D[i] / ((mu*mu) * (1 + (mu*mu)));
+  c.mu = mu;
+}
+// zone of a (N, T^2) pair: 1 top, 2 bottom, 3 middle; T returned
+MJH_DEV int nt_cone_zone(real N, real Tsqr, real mu, real* T) {
+  *T = 0;
+  if (Tsqr <= 0) return (N < 0) ? 2 : 1;
+  *T = sqrt(Tsqr);
+  if (N >= mu*(*T)) return 1;
+  if (mu*N + (*T) <= 0) return 2;
+  return 3;
+}
+// cost(alpha) - cost(0) of the block, cancellation-free per zone pair, plus the first and second
+// derivative along the line                   (ellipticCostDif / PrimalEval, engine_solver.c:1573-1790)
+MJH_DEV real nt_cone_eval(const NtCone& c, real alpha, real* d1, real* d2) {
+  const real mu = c.mu, Dm = c.Dm;
+  real T0, T;
+  const int z0 = nt_cone_zone(c.U0, c.UU, mu, &T0);
+  const real N = c.U0 + alpha*c.V0;
+  const real Tsqr = c.UU + alpha*(2*c.UV + alpha*c.VV);
+  const int za = nt_cone_zone(N, Tsqr, mu, &T);
+  *d1 = 0; *d2 = 0;
+  if (za == 2) { *d1 = 2*alpha*c.q2 + c.q1; *d2 = 2*c.q2; }
+  else if (za == 3) {
+    const real N1 = c.V0;
+    const real T1 = (c.UV + alpha*c.VV)/T;
+    const real T2 = c.VV/T - (c.UV + alpha*c.VV)*T1/(T*T);
+    *d1 = Dm*(N - mu*T)*(N1 - mu*T1);
+    *d2 = Dm*((N1 - mu*T1)*(N1 - mu*T1) + (N - mu*T)*(-mu*T2));
+  }
+  const real quad = alpha*alpha*c.q2 + alpha*c.q1;
+  if (z0 == 1 && za == 1) return 0;
+  if (z0 == 2 && za == 2) return quad;
+  if (z0 == 3 && za == 3) {
+    const real Tsqr_delta = alpha*(2*c.UV + alpha*c.VV);
+    const real T_delta = Tsqr_delta / (T + T0);
+    const real r_delta = alpha*c.V0 - mu*T_delta;
+    const real r0 = c.U0 - mu*T0;
+    return 0.5*Dm*r_delta*(2*r0 + r_delta);
+  }
+  if (z0 == 3 && za == 2) { const real b0 = mu*c.U0 + T0; return alpha*(alpha*c.q2 + c.q1) + 0.5*Dm*b0*b0; }
+  if (z0 == 2 && za == 3) { const real bb = mu*N + T; return alpha*(alpha*c.q2 + c.q1) - 0.5*Dm*bb*bb; }
+  if (z0 == 1 && za == 2) return quad + c.q0;
+  if (z0 == 1 && za == 3) { const real r = N - mu*T; return 0.5*Dm*r*r; }
+  if (z0 == 3 && za == 1) { const real r0 = c.U0 - mu*T0; return -0.5*Dm*r0*r0; }
+  if (z0 == 2 && za == 1) return -c.q0;
+  return 0;
+}
+
 // flg_newton = 0: the conjugate-gradient variant (mj_solCG): same cost, line search and warm start;
 // the search direction is the M^-1-preconditioned gradient with Hager-Zhang conjugation
 // (engine_solver.c:2506-2536) and no Hessian is built.
@@ -103,10 +171,22 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
     wv_sync();
   };
-  auto row_kind = [&](int r) { return r < ne ? 0 : (r < ne + nf ? 1 : 2); };
+  // 0 equality, 1 friction loss, 2 inequality, 3 first row of an elliptic block, 4 its other rows
+  const int elliptic = (M.o.cone != 0);
+  auto row_kind = [&](int r) {
+    if (r < ne) return 0;
+    if (r < ne + nf) return 1;
+    if (elliptic && P.type[r] == MJH_CNSTR_CONTACT_ELLIPTIC) return cone_leader(P, r) ? 3 : 4;
+    return 2;
+  };
+  rptr conH = MJH_G(B, con_H, e);
   auto constraint_cost = [&](crptr x) {             // sum of row costs at residual x
     real c = 0;
-    MJH_FOR_LANES(r, nefc) { real a, b; c += nt_row_cost(row_kind(r), x[r], P.D[r], P.R[r], P.floss[r], &a, &b); }
+    MJH_FOR_LANES(r, nefc) {
+      const int kind = row_kind(r);
+      if (kind == 3) c += cone_cost(P, r, cone_dim(P, r, nefc), x);
+      else if (kind < 3) { real a, b; c += nt_row_cost(kind, x[r], P.D[r], P.R[r], P.floss[r], &a, &b); }
+    }
     return wv_sum_d(c);
   };
   auto dot_nv = [&](crptr a, crptr b) {
@@ -124,33 +204,62 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     const real cost_ws = constraint_cost(jar) + wv_sum_d(g);
     const real cost_smooth = constraint_cost(P.b);
     const int use_smooth = cost_ws > cost_smooth;
+#ifdef MJH_DEBUG_NT
+    if (lane == 0) printf("warmstart: cost_ws %.15g cost_smooth %.15g use_smooth %d\n", cost_ws, cost_smooth, use_smooth);
+#endif
     MJH_FOR_LANES(i, nv) qacc[i] = use_smooth ? qas[i] : qws[i];
   } else {
     MJH_FOR_LANES(i, nv) qacc[i] = qas[i];
   }
   wv_sync();
 
-  // ---- initial Ma, jar, forces, gradient
+  // ---- constraint islands (engine_forward.c:1187-1212): one solve per island, each with its own
+  // scale, line searches and termination.  M and the Hessian are block diagonal across islands, so
+  // masking the gradient to the island's dofs confines the whole iteration to it.
+  const int nisl_raw = counts[MJH_C_NISLAND];
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  const int multi_tree = (s.ntree > 1) && (nisl_raw > 0);
+  ciptr tree_island = MJH_G(B, island_work, e) + s.nefcmax + s.ntree;   // left by stage_island
+  int isl = 0;
+  auto in_dof = [&](int i) { return !multi_tree || tree_island[M.dof_treeid[i]] == isl; };
+  auto in_row = [&](int r) { return nisl_raw <= 1 || P.island[r] == isl; };
+  if (multi_tree && !(M.o.disableflags & (1<<9))) {
+    // dofs of unconstrained trees start (and stay) at qacc_smooth   (warmstart, :1117-1124)
+    MJH_FOR_LANES(i, nv) if (tree_island[M.dof_treeid[i]] < 0) qacc[i] = qas[i];
+    wv_sync();
+  }
+
+  // ---- initial Ma, jar
   mul_M(Ma, qacc);
   mul_J(jar, qacc, 1);
+  int niter0 = 0;
   auto update_constraint = [&]() {                  // efc_force, efc_state, qfrc_constraint, grad
     MJH_FOR_LANES(r, nefc) {
+      if (!in_row(r)) continue;
+      const int kind = row_kind(r);
+      if (kind >= 3) {
+        // elliptic block: forces, state and (Newton) the cone Hessian of the middle zone
+        if (kind == 3) cone_update(P, r, cone_dim(P, r, nefc), jar, conH + 36*P.id[r], flg_newton);
+        continue;
+      }
       real d1, d2;
-      nt_row_cost(row_kind(r), jar[r], P.D[r], P.R[r], P.floss[r], &d1, &d2);
+      nt_row_cost(kind, jar[r], P.D[r], P.R[r], P.floss[r], &d1, &d2);
       P.force[r] = -d1;
       int st = MJH_STATE_QUADRATIC;
-      if (d2 == 0) st = (row_kind(r) == 2) ? MJH_STATE_SATISFIED : (d1 < 0 ? MJH_STATE_LINEARNEG : MJH_STATE_LINEARPOS);
+      if (d2 == 0) st = (kind == 2) ? MJH_STATE_SATISFIED : (d1 < 0 ? MJH_STATE_LINEARNEG : MJH_STATE_LINEARPOS);
       P.state[r] = st;
     }
     wv_sync();
     MJH_FOR_LANES(j, nv) {
       real acc = 0;
       for (int r = 0; r < nefc; r++) acc += J[(size_t)r*nv + j]*P.force[r];
-      qfc[j] = acc;
-      grad[j] = Ma[j] - qfs[j] - acc;
+      if (in_dof(j)) { qfc[j] = acc; grad[j] = Ma[j] - qfs[j] - acc; }
+      else grad[j] = 0;
     }
     wv_sync();
   };
+  if (multi_tree) { MJH_FOR_LANES(j, nv) qfc[j] = 0; wv_sync(); }
+  for (isl = 0; isl < nisl; isl++) {
   update_constraint();
 
   // termination scale: 1/trace(M) over the dofs of constrained trees when islands are on
@@ -159,10 +268,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   if (!(M.o.disableflags & (1<<18))) {
     real tr = 0;
     MJH_FOR_LANES(i, nv) {
-      int touched = 0;
-      for (int r = 0; r < nefc && !touched; r++) if (J[(size_t)r*nv + i] != 0) touched = 1;
-      // a tree is in an island as soon as one of its dofs carries a constraint
-      tr += Md[i*nv + i] * (real)touched;
+      // inertia of this island's dofs (engine_solver.c:2383-2390)
+      tr += Md[i*nv + i] * (real)(in_dof(i) ? 1 : 0);
     }
     tr = wv_sum_d(tr);
     scale = 1 / (tr > 0 ? tr : 1);
@@ -175,8 +282,24 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     MJH_FOR_LANES(k, nv*nv) {
       const int i = k / nv, j = k - i*nv;
       real acc = Md[k];
-      for (int r = 0; r < nefc; r++)
-        if (P.state[r] == MJH_STATE_QUADRATIC) acc += P.D[r]*J[(size_t)r*nv + i]*J[(size_t)r*nv + j];
+      for (int r = 0; r < nefc; r++) {
+        if (!in_row(r)) continue;       // the blocks of other islands stay M (never used: grad is 0 there)
+        const int st = P.state[r];
+        if (st == MJH_STATE_QUADRATIC) acc += P.D[r]*J[(size_t)r*nv + i]*J[(size_t)r*nv + j];
+        else if (st == MJH_STATE_CONE) {
+          // J_blk' Hc J_blk of a middle-zone cone block (HessianCone, engine_solver.c:2219-2281)
+          const int dim = cone_dim(P, r, nefc);
+          crptr Hc = conH + 36*P.id[r];
+          for (int a = 0; a < dim; a++) {
+            const real Ja = J[(size_t)(r + a)*nv + i];
+            if (Ja == 0) continue;
+            real t = 0;
+            for (int b2 = 0; b2 < dim; b2++) t += Hc[a*dim + b2]*J[(size_t)(r + b2)*nv + j];
+            acc += Ja*t;
+          }
+          r += dim - 1;
+        }
+      }
       H[k] = acc;
     }
     wv_sync();
@@ -248,7 +371,18 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const real al = p.alpha;
       real c = 0, d1 = 0, d2 = 0;
       MJH_FOR_LANES(r, nefc) {
+        if (!in_row(r)) continue;
         const int kind = row_kind(r);
+        if (kind >= 3) {
+          if (kind == 3) {
+            NtCone cb;
+            nt_cone_prepare(P, r, cone_dim(P, r, nefc), jar, Jv, cb);
+            real a1, a2;
+            c += nt_cone_eval(cb, al, &a1, &a2);
+            d1 += a1; d2 += a2;
+          }
+          continue;
+        }
         const real x0 = jar[r], dx = Jv[r], x1 = x0 + al*dx;
         real a1, a2;
         nt_row_cost(kind, x1, P.D[r], P.R[r], P.floss[r], &a1, &a2);
@@ -265,6 +399,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     NtPoint p0, p1, p2, pmid, p1next, p2next;
     real alpha = 0, improvement = 0;
     p0.alpha = 0; eval(p0);
+#ifdef MJH_DEBUG_NT
+    if (lane == 0) printf("iter %d  p0: cost %g d1 %.12g d2 %.12g  -d1/d2 %.12g\n", iter, p0.cost, p0.d1, p0.d2, -p0.d1/p0.d2);
+#endif
     p1.alpha = p0.alpha - p0.d1/p0.d2; eval(p1);
     int found = 0;
     if (fabs(p1.d1) < gtol && (p1.alpha == 0 || p1.cost < 0)) {
@@ -309,6 +446,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         else alpha = 0;
       }
     }
+#ifdef MJH_DEBUG_NT
+    if (lane == 0) printf("iter %d alpha %.15g improvement %g lsiter %d gtol %g p1.d1 %g p1.cost %g\n", iter, alpha, improvement, lsiter, gtol, p1.d1, p1.cost);
+#endif
     if (alpha == 0) break;
 
     // ---- move, update constraints / gradient / Hessian
@@ -346,7 +486,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
     wv_sync();
   }
-  if (lane == 0) counts[MJH_C_NITER] = iter;
+  if (isl == 0) niter0 = iter;
+  }   // islands
+  if (lane == 0) counts[MJH_C_NITER] = niter0;
   wv_sync();
 }
 

@@ -250,125 +250,367 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
 #endif  // !MJH_LANE_MODE
 
 // ------------------------------------------------------------------------------------------------
-// solPGS, scalar blocks (pyramidal / frictionless / limits / friction loss)   (engine_solver.c:457-741)
+// solPGS, generic form                                            (engine_solver.c:457-741)
+// Any nefc, constraint islands (one pass of the reference's loop per island, residuals over the
+// full row) and elliptic cone blocks: normal or ray update followed by the friction QCQP
+// (:598-672, mju_QCQP2/3/N engine_util_solve.c:1197-1443).  The residual dot products are wave
+// cooperative in mju_dot's association; the small block algebra is evaluated redundantly by every
+// lane and lane 0 stores the result, so the sweep stays bit-compatible with the CPU.
 // ------------------------------------------------------------------------------------------------
+// Cholesky of a small dense matrix with rank threshold / solve     (engine_util_solve.c:33-101)
+MJH_DEV int small_chol_factor(real* mat, int n, real mindiag) {
+  int rank = n;
+  for (int j = 0; j < n; j++) {
+    real tmp = mat[j*(n+1)];
+    if (j) tmp -= dot_ref(mat + j*n, mat + j*n, j);
+    const int deficient = tmp < mindiag;
+    if (deficient) { tmp = mindiag; rank--; }
+    mat[j*(n+1)] = sqrt(tmp);
+    if (deficient) {
+      for (int i = j + 1; i < n; i++) mat[i*n+j] = 0;
+    } else {
+      tmp = 1/mat[j*(n+1)];
+      for (int i = j + 1; i < n; i++) mat[i*n+j] = (mat[i*n+j] - dot_ref(mat + i*n, mat + j*n, j)) * tmp;
+    }
+  }
+  return rank;
+}
+MJH_DEV void small_chol_solve(real* res, const real* mat, const real* vec, int n) {
+  for (int i = 0; i < n; i++) res[i] = vec[i];
+  for (int i = 0; i < n; i++) {
+    if (i) res[i] -= dot_ref(mat + i*n, res, i);
+    res[i] /= mat[i*(n+1)];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    for (int j = i + 1; j < n; j++) res[i] -= mat[j*n+i] * res[j];
+    res[i] /= mat[i*(n+1)];
+  }
+}
+
+// min 0.5 x'Ax + x'b  s.t.  sum (x_i/d_i)^2 <= r^2, Newton iteration on the multiplier; returns 1
+// when the constraint is active                           (engine_util_solve.c:1197-1443)
+MJH_DEV int qcqp_solve(real* res, const real* Ain, const real* bin, const real* d, real r, int n) {
+  real la = 0;
+  if (n == 2) {
+    const real b1 = bin[0]*d[0], b2 = bin[1]*d[1];
+    const real A11 = Ain[0]*d[0]*d[0], A22 = Ain[3]*d[1]*d[1], A12 = Ain[1]*d[0]*d[1];
+    real v1 = 0, v2 = 0;
+    for (int iter = 0; iter < 20; iter++) {
+      const real det = (A11+la)*(A22+la) - A12*A12;
+      if (det < 1e-10) { res[0] = 0; res[1] = 0; return 0; }
+      const real detinv = 1/det;
+      const real P11 = (A22+la)*detinv, P22 = (A11+la)*detinv, P12 = -A12*detinv;
+      v1 = -P11*b1 - P12*b2;
+      v2 = -P12*b1 - P22*b2;
+      const real val = v1*v1 + v2*v2 - r*r;
+      if (val < 1e-10) break;
+      const real deriv = -2.0*(P11*v1*v1 + 2.0*P12*v1*v2 + P22*v2*v2);
+      const real delta = -val/deriv;
+      if (delta < 1e-10) break;
+      la += delta;
+    }
+    res[0] = v1*d[0]; res[1] = v2*d[1];
+    return la != 0;
+  }
+  if (n == 3) {
+    const real b1 = bin[0]*d[0], b2 = bin[1]*d[1], b3 = bin[2]*d[2];
+    const real A11 = Ain[0]*d[0]*d[0], A22 = Ain[4]*d[1]*d[1], A33 = Ain[8]*d[2]*d[2];
+    const real A12 = Ain[1]*d[0]*d[1], A13 = Ain[2]*d[0]*d[2], A23 = Ain[5]*d[1]*d[2];
+    real v1 = 0, v2 = 0, v3 = 0;
+    for (int iter = 0; iter < 20; iter++) {
+      real P11 = (A22+la)*(A33+la) - A23*A23;
+      real P22 = (A11+la)*(A33+la) - A13*A13;
+      real P33 = (A11+la)*(A22+la) - A12*A12;
+      real P12 = A13*A23 - A12*(A33+la);
+      real P13 = A12*A23 - A13*(A22+la);
+      real P23 = A12*A13 - A23*(A11+la);
+      const real det = (A11+la)*P11 + A12*P12 + A13*P13;
+      if (det < 1e-10) { res[0] = 0; res[1] = 0; res[2] = 0; return 0; }
+      const real detinv = 1/det;
+      P11 *= detinv; P22 *= detinv; P33 *= detinv; P12 *= detinv; P13 *= detinv; P23 *= detinv;
+      v1 = -P11*b1 - P12*b2 - P13*b3;
+      v2 = -P12*b1 - P22*b2 - P23*b3;
+      v3 = -P13*b1 - P23*b2 - P33*b3;
+      const real val = v1*v1 + v2*v2 + v3*v3 - r*r;
+      if (val < 1e-10) break;
+      const real deriv = -2.0*(P11*v1*v1 + P22*v2*v2 + P33*v3*v3) - 4.0*(P12*v1*v2 + P13*v1*v3 + P23*v2*v3);
+      const real delta = -val/deriv;
+      if (delta < 1e-10) break;
+      la += delta;
+    }
+    res[0] = v1*d[0]; res[1] = v2*d[1]; res[2] = v3*d[2];
+    return la != 0;
+  }
+  real A[25], Ala[25], b[5], tmp[5];
+  for (int i = 0; i < n; i++) {
+    b[i] = bin[i] * d[i];
+    for (int j = 0; j < n; j++) A[j+i*n] = Ain[j+i*n] * d[i] * d[j];
+  }
+  for (int iter = 0; iter < 20; iter++) {
+    for (int i = 0; i < n*n; i++) Ala[i] = A[i];
+    for (int i = 0; i < n; i++) Ala[i*(n+1)] += la;
+    if (small_chol_factor(Ala, n, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return 0; }
+    small_chol_solve(res, Ala, b, n);
+    for (int i = 0; i < n; i++) res[i] = res[i]*-1;
+    const real val = dot_ref(res, res, n) - r*r;
+    if (val < 1e-10) break;
+    small_chol_solve(tmp, Ala, res, n);
+    const real deriv = -2.0 * dot_ref(res, tmp, n);
+    const real delta = -val/deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] = res[i] * d[i];
+  return la != 0;
+}
+
+// scale the friction part of a contact force onto / into the friction ellipsoid  (:366-381)
+MJH_DEV void project_ellipsoid(real* fr, real normal, const real* mu, int dim, int feasible) {
+  real ss = 0;
+  for (int j = 0; j < dim - 1; j++) ss += fr[j]*fr[j] / (mu[j]*mu[j]);
+  const real normal2 = normal*normal;
+  if (!feasible || ss > normal2) {
+    const real scl = sqrt(normal2 / r_max(MJH_MINVAL, ss));
+    for (int j = 0; j < dim - 1; j++) fr[j] *= scl;
+  }
+}
+
 MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   iptr counts = MJH_F(B, counts, e);
-  const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
+  const int nefc = counts[MJH_C_NEFC], ne_all = counts[MJH_C_NE], nf_all = counts[MJH_C_NF];
   Efc P;
   efc_layout(M, B, e, nefc, P);
   crptr AR = P.AR;
   crptr b = P.b;
   crptr floss = P.floss;
   rptr force = P.force;
-  rptr ARinv = P.ARinv;                 // [nefc]
-  rptr force_prev = P.fprev;            // [nefc]
-  rptr force_mom = P.fmom;              // [nefc]
-  iptr order = P.order;                  // [nefc] block visitation order (persists across iterations)
+  rptr ARinv = P.ARinv;                 // [nefc] by row
+  rptr force_prev = P.fprev;            // [nk] by island position
+  rptr force_mom = P.fmom;              // [nk]
+  iptr blockstart = P.order;            // [nblocks] island positions, shuffled in place
+  iptr efclist = MJH_G(B, iscratch, e) + M.s.nefcmax;     // [nk] island position -> row
+  iptr state = P.state;
   const int lane = wv_lane();
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const int elliptic = (M.o.cone != 0);
 
-  MJH_FOR_LANES(i, nefc) {
-    ARinv[i] = 1 / AR[(size_t)i*nefc + i];
-    force_prev[i] = force[i];
-    order[i] = i;
-  }
+  MJH_FOR_LANES(i, nefc) ARinv[i] = 1 / AR[(size_t)i*nefc + i];
   wv_sync();
 
-  Pcg32 rng;
-  rng.state = 0; rng.inc = 1;
-  pcg32_next(&rng);
-
-  int iter = 0, nesterov_k = 0;
-  while (iter < maxiter) {
-    // ---- Nesterov extrapolation (:508-554)
-    real beta = 0;
-    if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
-    if (beta > 0) {
-      MJH_FOR_LANES(i, nefc) {
-        real f_save = force[i];
-        real f = f_save + beta*(f_save - force_prev[i]);
-        force_prev[i] = f_save;
-        if (i >= ne && i < ne + nf) f = r_clip(f, -floss[i], floss[i]);
-        else if (i >= ne + nf && f < 0) f = 0;
-        force[i] = f;
-        force_mom[i] = f;
+  const int nisl_raw = counts[MJH_C_NISLAND];
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  int niter0 = 0;
+  for (int isl = 0; isl < nisl; isl++) {
+    // ---- efclist, per-island ne/nf, blocks (lane 0; short serial scans)
+    int nk = 0, ne = 0, nf = 0, nblocks = 0;
+    if (lane == 0) {
+      for (int i = 0; i < nefc; i++) {
+        if (nisl > 1 && P.island[i] != isl) continue;
+        efclist[nk++] = i;
+        if (i < ne_all) ne++; else if (i < ne_all + nf_all) nf++;
       }
-    } else {
-      MJH_FOR_LANES(i, nefc) {
-        real f = force[i];
-        force_prev[i] = f;
-        force_mom[i] = f;
+      for (int c = 0; c < nk; ) {
+        blockstart[nblocks++] = c;
+        const int i = efclist[c];
+        c += (elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) ? cone_dim(P, i, nefc) : 1;
       }
     }
-    // ---- shuffle block order (Fisher-Yates with the shared PCG32 stream, :256-265)
-    // every lane advances its own copy of the generator identically; lane 0 owns the array
-    for (int i = nefc - 1; i > 0; i--) {
-      uint32_t j = pcg32_next(&rng) % (uint32_t)(i + 1);
-      if (lane == 0) {
-        int t = order[i]; order[i] = order[j]; order[j] = t;
-      }
-    }
+    nk = wv_bcast_i(nk, 0); ne = wv_bcast_i(ne, 0); nf = wv_bcast_i(nf, 0); nblocks = wv_bcast_i(nblocks, 0);
+    wv_sync();
+    if (nk == 0) continue;
+    MJH_FOR_LANES(c, nk) force_prev[c] = force[efclist[c]];
     wv_sync();
 
-    // ---- one sweep
-    real improvement = 0;
-    for (int bi = 0; bi < nefc; bi++) {
-      const int i = order[bi];
-      real res = b[i] + wave_dot_ref(AR + (size_t)i*nefc, force, nefc);
-      real oldf = force[i];
-      real f = oldf - res*ARinv[i];
-      if (i >= ne && i < ne + nf) {
-        if (f < -floss[i]) f = -floss[i];
-        else if (f > floss[i]) f = floss[i];
-      } else if (i >= ne + nf) {
-        if (f < 0) f = 0;
+    Pcg32 rng;
+    rng.state = 0; rng.inc = 1;
+    pcg32_next(&rng);
+
+    int iter = 0, nesterov_k = 0;
+    while (iter < maxiter) {
+      // ---- Nesterov extrapolation (:508-554)
+      real beta = 0;
+      if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+      if (beta > 0) {
+        MJH_FOR_LANES(c, nk) {
+          const int i = efclist[c];
+          real f_save = force[i];
+          real f = f_save + beta*(f_save - force_prev[c]);
+          force_prev[c] = f_save;
+          if (c >= ne && c < ne + nf) f = r_clip(f, -floss[i], floss[i]);
+          else if (c >= ne + nf && !(elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) && f < 0) f = 0;
+          force[i] = f;
+        }
+        wv_sync();
+        if (elliptic) {
+          // projectCone (:421-437) on every elliptic block
+          MJH_FOR_LANES(c, nk) {
+            const int i = efclist[c];
+            if (c < ne + nf || !cone_leader(P, i)) continue;
+            const int dim = cone_dim(P, i, nefc);
+            if (force[i] < 0) {
+              for (int j = 0; j < dim; j++) force[i+j] = 0;
+            } else {
+              real fr[5], mu[5];
+              for (int j = 0; j < dim - 1; j++) { fr[j] = force[i+1+j]; mu[j] = P.cone[i+1+j]; }
+              project_ellipsoid(fr, force[i], mu, dim, 1);
+              for (int j = 0; j < dim - 1; j++) force[i+1+j] = fr[j];
+            }
+          }
+          wv_sync();
+        }
+        MJH_FOR_LANES(c, nk) force_mom[c] = force[efclist[c]];
+      } else {
+        MJH_FOR_LANES(c, nk) {
+          real f = force[efclist[c]];
+          force_prev[c] = f;
+          force_mom[c] = f;
+        }
       }
-      // costChange (:216-237) with A = 1/ARinv
-      real A = 1/ARinv[i];
-      real delta = f - oldf;
-      real change = 0.5*delta*delta*A + delta*res;
-      if (change > 1e-10) { f = oldf; change = 0; }
-      improvement -= change;
-      wv_sync();                  // all lanes have consumed force[] for this row
-      if (lane == 0) force[i] = f;
+      // ---- shuffle block order (Fisher-Yates with the shared PCG32 stream, :256-265)
+      for (int i = nblocks - 1; i > 0; i--) {
+        uint32_t j = pcg32_next(&rng) % (uint32_t)(i + 1);
+        if (lane == 0) {
+          int t = blockstart[i]; blockstart[i] = blockstart[j]; blockstart[j] = t;
+        }
+      }
+      wv_sync();
+
+      // ---- one sweep
+      real improvement = 0;
+      for (int bi = 0; bi < nblocks; bi++) {
+        const int c = blockstart[bi];
+        const int i = efclist[c];
+        if (!(elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC)) {
+          real res = b[i] + wave_dot_ref(AR + (size_t)i*nefc, force, nefc);
+          real oldf = force[i];
+          real f = oldf - res*ARinv[i];
+          if (c >= ne && c < ne + nf) {
+            if (f < -floss[i]) f = -floss[i];
+            else if (f > floss[i]) f = floss[i];
+          } else if (c >= ne + nf) {
+            if (f < 0) f = 0;
+          }
+          // costChange (:216-237) with A = 1/ARinv
+          real A = 1/ARinv[i];
+          real delta = f - oldf;
+          real change = 0.5*delta*delta*A + delta*res;
+          if (change > 1e-10) { f = oldf; change = 0; }
+          improvement -= change;
+          wv_sync();                  // all lanes have consumed force[] for this row
+          if (lane == 0) force[i] = f;
+          wv_sync();
+          continue;
+        }
+        // ---- elliptic block (:598-672)
+        const int dim = cone_dim(P, i, nefc);
+        real res[6], oldforce[6], fl[6], Athis[36], mu[5];
+        for (int j = 0; j < dim; j++) {
+          res[j] = b[i+j] + wave_dot_ref(AR + (size_t)(i+j)*nefc, force, nefc);
+          oldforce[j] = force[i+j];
+          fl[j] = oldforce[j];
+          for (int k = 0; k < dim; k++) Athis[j*dim + k] = AR[(size_t)(i+j)*nefc + i + k];
+        }
+        for (int j = 0; j < dim - 1; j++) mu[j] = P.cone[i+1+j];
+        if (fl[0] < MJH_MINVAL) {
+          // normal update
+          fl[0] -= res[0]*ARinv[i];
+          if (fl[0] < 0) fl[0] = 0;
+          for (int j = 1; j < dim; j++) fl[j] = 0;
+        } else {
+          // ray update
+          real v[6], v1[6];
+          for (int j = 0; j < dim; j++) v[j] = fl[j];
+          for (int j = 0; j < dim; j++) v1[j] = dot_ref(Athis + j*dim, v, dim);
+          const real denom = dot_ref(v, v1, dim);
+          if (denom >= MJH_MINVAL) {
+            real x = -dot_ref(v, res, dim) / denom;
+            if (fl[0] + x*v[0] < 0) x = -v[0]/fl[0];
+            for (int j = 0; j < dim; j++) fl[j] += x*v[j];
+          }
+        }
+        // friction update with the normal force fixed
+        real bc[5], Ac[25];
+        for (int j = 0; j < dim - 1; j++) bc[j] = res[j+1];
+        for (int j = 0; j < dim - 1; j++) {
+          for (int k = 0; k < dim - 1; k++) Ac[j*(dim-1) + k] = Athis[(j+1)*dim + 1 + k];
+          bc[j] -= dot_ref(Ac + j*(dim-1), oldforce + 1, dim - 1);
+          bc[j] += Athis[(j+1)*dim]*(fl[0] - oldforce[0]);
+        }
+        if (fl[0] < MJH_MINVAL) {
+          for (int j = 1; j < dim; j++) fl[j] = 0;
+        } else {
+          real v[5];
+          const int active = qcqp_solve(v, Ac, bc, mu, fl[0], dim - 1);
+          if (active) project_ellipsoid(v, fl[0], mu, dim, 0);
+          for (int j = 0; j < dim - 1; j++) fl[1+j] = v[j];
+        }
+        // costChange, block form
+        real delta[6];
+        for (int j = 0; j < dim; j++) delta[j] = fl[j] - oldforce[j];
+        real quadf = 0;
+        for (int j = 0; j < dim; j++) quadf += delta[j] * dot_ref(Athis + j*dim, delta, dim);
+        real change = 0.5*quadf + dot_ref(delta, res, dim);
+        if (change > 1e-10) {
+          for (int j = 0; j < dim; j++) fl[j] = oldforce[j];
+          change = 0;
+        }
+        improvement -= change;
+        wv_sync();
+        if (lane == 0) for (int j = 0; j < dim; j++) force[i+j] = fl[j];
+        wv_sync();
+      }
+      improvement *= scale;
+
+      // ---- gradient restart (:694-713)
+      int restart = 0;
+      if (iter > 0) {
+        real dotce = 0;
+        for (int c = 0; c < nk; c++) {
+          const int i = efclist[c];
+          real correction = force[i] - force_mom[c];
+          real extrapolation = force_mom[c] - force_prev[c];
+          dotce += correction * extrapolation;
+        }
+        restart = (dotce < 0);
+      }
+      if (restart) nesterov_k = 0; else nesterov_k++;
+      iter++;
+      if (improvement < M.o.tolerance) break;
       wv_sync();
     }
-    improvement *= scale;
+    wv_sync();
+    if (isl == 0) niter0 = iter;
 
-    // ---- gradient restart (:694-713)
-    int restart = 0;
-    if (iter > 0) {
-      real dotce = 0;
-      for (int i = 0; i < nefc; i++) {
-        real correction = force[i] - force_mom[i];
-        real extrapolation = force_mom[i] - force_prev[i];
-        dotce += correction * extrapolation;
-      }
-      restart = (dotce < 0);
+    // final dual state of this island (dualState, :270-345)
+    MJH_FOR_LANES(c, nk) {
+      const int i = efclist[c];
+      int st;
+      if (c < ne) st = MJH_STATE_QUADRATIC;
+      else if (c < ne + nf) {
+        if (force[i] <= -floss[i]) st = MJH_STATE_LINEARPOS;
+        else if (force[i] >= floss[i]) st = MJH_STATE_LINEARNEG;
+        else st = MJH_STATE_QUADRATIC;
+      } else if (elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+        if (!cone_leader(P, i)) continue;
+        const int dim = cone_dim(P, i, nefc);
+        const real mu = P.cone[i];
+        real f[6];
+        f[0] = force[i]/mu;
+        for (int j = 1; j < dim; j++) f[j] = force[i+j]/P.cone[i+j];
+        const real N = f[0];
+        const real T = sqrt(dot_ref(f + 1, f + 1, dim - 1));
+        if (mu*N >= T) st = MJH_STATE_SATISFIED;
+        else if (N + mu*T <= 0) st = MJH_STATE_QUADRATIC;
+        else st = MJH_STATE_CONE;
+        for (int j = 1; j < dim; j++) state[i+j] = st;
+      } else st = (force[i] <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+      state[i] = st;
     }
-    if (restart) nesterov_k = 0; else nesterov_k++;
-    iter++;
-    if (improvement < M.o.tolerance) break;
     wv_sync();
   }
-  wv_sync();
-
-  // final dual state (dualState, :270-345) and iteration count
-  iptr state = P.state;
-  MJH_FOR_LANES(i, nefc) {
-    int st;
-    if (i < ne) st = MJH_STATE_QUADRATIC;
-    else if (i < ne + nf) {
-      if (force[i] <= -floss[i]) st = MJH_STATE_LINEARPOS;
-      else if (force[i] >= floss[i]) st = MJH_STATE_LINEARNEG;
-      else st = MJH_STATE_QUADRATIC;
-    } else st = (force[i] <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
-    state[i] = st;
-  }
-  if (lane == 0) counts[MJH_C_NITER] = iter;
+  if (lane == 0) counts[MJH_C_NITER] = niter0;
   wv_sync();
 }
 
@@ -443,7 +685,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   MJH_SUBPROF(22);     // efc_b, jar, warm start
 
 #if !MJH_LANE_MODE
-  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters) {
+  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters && M.o.cone == 0) {
 #if defined(MJH_HOSTSIM)
     solve_pgs_fast<0>(M, B, e);
 #else
@@ -453,8 +695,6 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   } else
 #endif
   {
-    // the generic sweep is monolithic: several islands need the per-island loop of the fast path
-    if (counts[MJH_C_NISLAND] > 1 && wv_lane() == 0) MJH_F(B, warning, e)[MJH_WARN_UNSUPPORTED]++;
     solve_pgs(M, B, e);
   }
   MJH_SUBPROF(23);     // PGS

@@ -171,6 +171,7 @@ struct DSizes {
   int nmoment;     // capacity of the sparse actuator_moment (sum of per-actuator row capacity)
   int nconmax;     // per-env contact capacity
   int nconlds;     // contact slots kept in LDS by the residency plan
+  int nconH;       // contacts with a cone-Hessian slot (elliptic cones + primal solver), else 0
   int nefcmax;     // per-env constraint-row capacity
   int nstate;      // mj_stateSize(FULLPHYSICS)
   int npgsorder;   // entries of the precomputed PGS visitation-order table
@@ -291,6 +292,8 @@ enum {
   X(efc_aref, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(efc_b, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(efc_force, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  X(efc_cone, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
+  X(con_H, 36 * s.nconH, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
   X(nt_M, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(nt_H, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \

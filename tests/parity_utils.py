@@ -202,3 +202,39 @@ IMPL_XML = """
   </actuator>
 </mujoco>
 """
+
+
+# torsional (condim 4) and rolling (condim 6) friction: spinning / rolling spheres, a capsule and a
+# cylinder on a plane, plus a sphere-sphere stack; used with both pyramidal and elliptic cones
+CONDIM_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50" impratio="3"/>
+  <worldbody>
+    <geom type="plane" size="3 3 .01" condim="3" friction="1 .02 .002"/>
+    <body pos="0 0 .0502"><freejoint/><geom type="sphere" size=".05" condim="4" friction=".8 .03 .001"/></body>
+    <body pos=".4 0 .0604"><freejoint/><geom type="sphere" size=".06" condim="6" friction=".6 .02 .004"/></body>
+    <body pos=".4 0 .161"><freejoint/><geom type="sphere" size=".04" condim="6" friction=".9 .01 .003"/></body>
+    <body pos="-.4 0 .041" euler="0 88 0"><freejoint/><geom type="capsule" size=".04 .1" condim="6" friction=".7 .05 .002"/></body>
+    <body pos="0 .5 .0505"><freejoint/><geom type="cylinder" size=".07 .05" condim="4" friction="1.2 .04 .001"/></body>
+    <body pos=".5 .5 .2"><joint type="slide" axis="0 0 1" damping="1"/><joint type="hinge" axis="0 0 1" damping=".01"/>
+      <geom type="sphere" size=".05" condim="4" friction=".5 .05 .001"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def condim_scene_state(rb, m):
+    """initial state of CONDIM_XML: bodies resting on the plane, sliding slowly and spinning fast"""
+    import numpy as np
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    rng = np.random.default_rng(3)
+    v = rng.normal(0, 1.0, m.nv)
+    for k in range(5):            # the five free bodies
+        v[6*k:6*k+3] *= 0.3
+        v[6*k+2] = -0.05
+        v[6*k+3:6*k+6] *= 4.0
+    v[30] = -0.5
+    v[31] = 6.0
+    d.qvel[:] = v
+    return rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()

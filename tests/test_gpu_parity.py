@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -204,6 +204,43 @@ def test_implicitfast_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     print("implicitfast scene solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
     assert relerr(out, ref) <= TOL
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("cone,solver", [(0, 0), (1, 0), (1, 2), (1, 1)])
+def test_condim_and_elliptic_cones_vs_live_oracle(rb, hip_lib, tmp_path, cone, solver):
+    """condim 4/6 contacts, pyramidal and elliptic cones, PGS / Newton / CG"""
+    xml = tmp_path / "condim.xml"
+    xml.write_text(CONDIM_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    m.opt.solver = solver
+    dmc = K.DeviceModel(hip_lib, m)
+    s0 = condim_scene_state(rb, m)
+    T = 60
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmc, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("condim scene cone", cone, "solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+
+
+def test_elliptic_humanoid_vs_live_oracle(rb, hip_lib, golden):
+    """humanoid, cone=elliptic, PGS and Newton, the contact-rich golden environments"""
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 40
+    for solver in (0, 2):
+        m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
+        m.opt.solver = solver
+        m.opt.cone = 1
+        dme = K.DeviceModel(hip_lib, m)
+        ref, ints = oracle_rollout(rb, m, fx["state0"][:n], fx["ctrl"][:n, :T])
+        b = K.Batch(dme, n)
+        out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T])
+        print("elliptic humanoid solver", solver, "rel err", relerr(out, ref), "max nefc", ints[:, :, 1].max())
+        assert relerr(out, ref) <= TOL
+        assert b.get("warning").sum() == 0
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):
