@@ -22,7 +22,6 @@
 // ------------------------------------------------------------------------------------------------
 // host emulation of a wavefront (tests only)
 // ------------------------------------------------------------------------------------------------
-#include <ucontext.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -41,8 +40,8 @@ static inline int wv_uniform_i(int v) { return v; }
 
 namespace mjhsim {
 struct WaveSim {
-  ucontext_t sched;
-  ucontext_t ctx[MJH_WAVE];
+  void* sched_sp;            // saved stack pointers of the scheduler and of the 64 lane fibers
+  void* ctx_sp[MJH_WAVE];    // (mjh_ctx_switch, hostsim.cpp: a register-only switch, no syscalls)
   char* stacks;
   int cur;            // lane currently running
   int done[MJH_WAVE];
@@ -55,7 +54,8 @@ struct WaveSim {
 extern thread_local WaveSim* g_wave;
 static inline int lane() { return g_wave->cur; }
 static inline int env() { return g_wave->env; }
-static inline void yield() { swapcontext(&g_wave->ctx[g_wave->cur], &g_wave->sched); }
+extern "C" void mjh_ctx_switch(void** from_sp, void* to_sp);
+static inline void yield() { mjh_ctx_switch(&g_wave->ctx_sp[g_wave->cur], g_wave->sched_sp); }
 }  // namespace mjhsim
 
 MJH_DEV int wv_lane() { return mjhsim::lane(); }

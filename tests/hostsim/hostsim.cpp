@@ -6,7 +6,6 @@
 // include/mjhip.h from libmjhip_hostsim.so so the parity tests can drive the kernel logic against
 // the oracle in a container without a GPU.  Running the lanes in reverse order (env var
 // MJH_HOSTSIM_REVERSE=1) must give bit-identical results: that is the race detector.
-#include <ucontext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -38,24 +37,25 @@ struct Runner {
     w.reverse = getenv("MJH_HOSTSIM_REVERSE") && atoi(getenv("MJH_HOSTSIM_REVERSE"));
   }
   ~Runner() { free(w.stacks); }
-  static void trampoline(unsigned lo, unsigned hi) {
-    Runner* r = (Runner*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
-    r->body();
-    r->w.done[r->w.cur] = 1;
-    // returning switches to uc_link (the scheduler)
-  }
+  // first frame of every lane fiber: runs the kernel body, marks the lane done and hands control
+  // back to the scheduler for good
+  static void fiber_entry();
   void run(int env, const std::function<void()>& fn) {
     body = fn;
     w.env = env;
     mjhsim::g_wave = &w;
+    unsigned csr[2] = {0, 0};
+    asm volatile("stmxcsr %0\n\tfnstcw %1" : "=m"(csr[0]), "=m"(csr[1]));
     for (int l = 0; l < MJH_WAVE; l++) {
       w.done[l] = 0;
-      getcontext(&w.ctx[l]);
-      w.ctx[l].uc_stack.ss_sp = w.stacks + kStack * l;
-      w.ctx[l].uc_stack.ss_size = kStack;
-      w.ctx[l].uc_link = &w.sched;
-      uintptr_t p = (uintptr_t)this;
-      makecontext(&w.ctx[l], (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+      // initial frame popped by mjh_ctx_switch: [mxcsr|x87cw] r15 r14 r13 r12 rbx rbp, return address
+      uintptr_t top = ((uintptr_t)(w.stacks + kStack * (l + 1))) & ~(uintptr_t)15;
+      uintptr_t* sp = (uintptr_t*)top;
+      *--sp = 0;                                  // the entry function's (never used) return address
+      *--sp = (uintptr_t)&Runner::fiber_entry;
+      for (int k = 0; k < 6; k++) *--sp = 0;
+      *--sp = (uintptr_t)csr[0] | ((uintptr_t)csr[1] << 32);
+      w.ctx_sp[l] = sp;
     }
     int remaining = MJH_WAVE;
     while (remaining) {
@@ -64,7 +64,7 @@ struct Runner {
         int l = w.reverse ? MJH_WAVE - 1 - k : k;
         if (w.done[l]) continue;
         w.cur = l;
-        swapcontext(&w.sched, &w.ctx[l]);
+        mjhsim::mjh_ctx_switch(&w.sched_sp, w.ctx_sp[l]);
         if (!w.done[l]) remaining++;
       }
     }
@@ -75,6 +75,14 @@ thread_local Runner* g_runner = nullptr;
 Runner* runner() {
   if (!g_runner) g_runner = new Runner();
   return g_runner;
+}
+
+void Runner::fiber_entry() {
+  Runner* r = g_runner;
+  r->body();
+  r->w.done[r->w.cur] = 1;
+  mjhsim::mjh_ctx_switch(&r->w.ctx_sp[r->w.cur], r->w.sched_sp);
+  abort();     // a finished lane is never resumed
 }
 
 }  // namespace
@@ -129,3 +137,35 @@ struct Backend {
 };
 
 #include "../../mujoco_amd/csrc/mjh_runtime.h"
+
+// register-only context switch (x86-64 SysV): callee-saved integer registers, MXCSR and the x87
+// control word live on the outgoing stack; glibc's swapcontext would add two sigprocmask system
+// calls per switch, which dominated the emulation's run time
+asm(R"(
+.text
+.globl mjh_ctx_switch
+.type mjh_ctx_switch,@function
+mjh_ctx_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size mjh_ctx_switch, .-mjh_ctx_switch
+)");

@@ -324,7 +324,7 @@ def test_equality_constraints(rb, hostsim_lib, tmp_path, solver, tol):
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
-    T = 24 if solver == 0 else 10
+    T = 80 if solver == 0 else 30
     ctrl = np.random.default_rng(5).uniform(-1, 1, (1, T, m.nu))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
     assert ints[0, :, 0].max() >= 3 and ints[0, :, 1].max() >= 30
@@ -353,7 +353,7 @@ def test_implicitfast_integrator(rb, hostsim_lib, tmp_path, solver, tol):
     rb.mj_resetData(m, d)
     d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
-    T = 30 if solver == 0 else 12
+    T = 80 if solver == 0 else 40
     ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dm, 1)
@@ -393,7 +393,7 @@ def test_condim_and_elliptic_cones(rb, hostsim_lib, tmp_path, cone, solver, tol)
     m.opt.solver = solver
     dm = K.DeviceModel(hostsim_lib, m)
     s0 = condim_scene_state(rb, m)
-    T = 16 if solver == 0 else 8
+    T = 50 if solver == 0 else 25
     ctrl = np.zeros((1, T, 0))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
     assert ints[0, :, 0].max() >= 5, "the scene is supposed to keep its bodies in contact"
