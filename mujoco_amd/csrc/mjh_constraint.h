@@ -1070,7 +1070,7 @@ MJH_DEV real cone_cost(const Efc& P, int i, int dim, P0 jar) {
 // writes force/state; returns the cost in lane-uniform form (summed in row order by every lane)
 // ------------------------------------------------------------------------------------------------
 template <class P0>
-MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cost) {
+MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cost, int elliptic) {
   ciptr counts = MJH_F(B, counts, e);
   const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
   crptr D = P.D;
@@ -1079,7 +1079,7 @@ MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cos
   rptr force = P.force;
   iptr state = P.state;
   MJH_FOR_LANES(i, nefc) {
-    if (i >= ne + nf && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+    if (elliptic && i >= ne + nf && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
       if (cone_leader(P, i)) cone_update(P, i, cone_dim(P, i, nefc), jar, (real*)nullptr, 0);
       continue;
     }
@@ -1108,7 +1108,7 @@ MJH_DEV real constraint_update(BREF B, int e, const Efc& P, P0 jar, int want_cos
         if (jar[i] <= -R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] - floss[i]*jar[i];
         else if (jar[i] >= R[i]*floss[i]) cost += -0.5*R[i]*floss[i]*floss[i] + floss[i]*jar[i];
         else cost += 0.5*D[i]*jar[i]*jar[i];
-      } else if (P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+      } else if (elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
         const int dim = cone_dim(P, i, nefc);
         cost += cone_cost(P, i, dim, jar);
         i += dim - 1;

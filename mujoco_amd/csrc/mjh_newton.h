@@ -114,9 +114,38 @@ MJH_DEV real nt_cone_eval(const NtCone& c, real alpha, real* d1, real* d2) {
   return 0;
 }
 
+// cone-block helpers of solve_primal<1>
+MJH_DEV real nt_cone_line(const Efc& P, int r, int nefc, real alpha, real* d1, real* d2) {
+  NtCone cb;
+  nt_cone_prepare(P, r, cone_dim(P, r, nefc), P.jar, P.ARf, cb);
+  return nt_cone_eval(cb, alpha, d1, d2);
+}
+MJH_DEV real nt_cone_cost(const Efc& P, int r, int nefc, crptr x) { return cone_cost(P, r, cone_dim(P, r, nefc), x); }
+MJH_DEV void nt_cone_update(const Efc& P, int r, int nefc, rptr Hc, int want_hessian) {
+  cone_update(P, r, cone_dim(P, r, nefc), P.jar, Hc, want_hessian);
+}
+// (J_blk' Hc J_blk)(i, j) of the middle-zone cone block starting at row r; returns the block's dim
+MJH_DEV int nt_cone_hessian_term(const Efc& P, int r, int nefc, int nv, crptr Hc, int i, int j, real* acc) {
+  const int dim = cone_dim(P, r, nefc);
+  crptr J = P.J;
+  real sum = 0;
+  for (int a = 0; a < dim; a++) {
+    const real Ja = J[(size_t)(r + a)*nv + i];
+    if (Ja == 0) continue;
+    real t = 0;
+    for (int b2 = 0; b2 < dim; b2++) t += Hc[a*dim + b2]*J[(size_t)(r + b2)*nv + j];
+    sum += Ja*t;
+  }
+  *acc += sum;
+  return dim;
+}
+
 // flg_newton = 0: the conjugate-gradient variant (mj_solCG): same cost, line search and warm start;
 // the search direction is the M^-1-preconditioned gradient with Hager-Zhang conjugation
 // (engine_solver.c:2506-2536) and no Hessian is built.
+// ELL = 0: instantiation without any elliptic-cone code (the common pyramidal case keeps its
+// register budget); ELL = 1: cone blocks enabled
+template <int ELL>
 MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -172,7 +201,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     wv_sync();
   };
   // 0 equality, 1 friction loss, 2 inequality, 3 first row of an elliptic block, 4 its other rows
-  const int elliptic = (M.o.cone != 0);
+  const int elliptic = ELL ? (M.o.cone != 0) : 0;
   auto row_kind = [&](int r) {
     if (r < ne) return 0;
     if (r < ne + nf) return 1;
@@ -184,7 +213,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     real c = 0;
     MJH_FOR_LANES(r, nefc) {
       const int kind = row_kind(r);
-      if (kind == 3) c += cone_cost(P, r, cone_dim(P, r, nefc), x);
+      if (kind == 3) c += nt_cone_cost(P, r, nefc, x);
       else if (kind < 3) { real a, b; c += nt_row_cost(kind, x[r], P.D[r], P.R[r], P.floss[r], &a, &b); }
     }
     return wv_sum_d(c);
@@ -239,7 +268,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const int kind = row_kind(r);
       if (kind >= 3) {
         // elliptic block: forces, state and (Newton) the cone Hessian of the middle zone
-        if (kind == 3) cone_update(P, r, cone_dim(P, r, nefc), jar, conH + 36*P.id[r], flg_newton);
+        if (kind == 3) nt_cone_update(P, r, nefc, conH + 36*P.id[r], flg_newton);
         continue;
       }
       real d1, d2;
@@ -286,18 +315,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         if (!in_row(r)) continue;       // the blocks of other islands stay M (never used: grad is 0 there)
         const int st = P.state[r];
         if (st == MJH_STATE_QUADRATIC) acc += P.D[r]*J[(size_t)r*nv + i]*J[(size_t)r*nv + j];
-        else if (st == MJH_STATE_CONE) {
+        else if (ELL && st == MJH_STATE_CONE) {
           // J_blk' Hc J_blk of a middle-zone cone block (HessianCone, engine_solver.c:2219-2281)
-          const int dim = cone_dim(P, r, nefc);
-          crptr Hc = conH + 36*P.id[r];
-          for (int a = 0; a < dim; a++) {
-            const real Ja = J[(size_t)(r + a)*nv + i];
-            if (Ja == 0) continue;
-            real t = 0;
-            for (int b2 = 0; b2 < dim; b2++) t += Hc[a*dim + b2]*J[(size_t)(r + b2)*nv + j];
-            acc += Ja*t;
-          }
-          r += dim - 1;
+          r += nt_cone_hessian_term(P, r, nefc, nv, conH + 36*P.id[r], i, j, &acc) - 1;
         }
       }
       H[k] = acc;
@@ -375,10 +395,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         const int kind = row_kind(r);
         if (kind >= 3) {
           if (kind == 3) {
-            NtCone cb;
-            nt_cone_prepare(P, r, cone_dim(P, r, nefc), jar, Jv, cb);
             real a1, a2;
-            c += nt_cone_eval(cb, al, &a1, &a2);
+            c += nt_cone_line(P, r, nefc, al, &a1, &a2);      // reads P.jar / P.ARf (= jar, Jv)
             d1 += a1; d2 += a2;
           }
           continue;
@@ -492,5 +510,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   wv_sync();
 }
 
-MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) { solve_primal(M_, B_, e_, 1); }
-MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) { solve_primal(M_, B_, e_, 0); }
+MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
+  if (M_.o.cone != 0) solve_primal<1>(M_, B_, e_, 1); else solve_primal<0>(M_, B_, e_, 1);
+}
+MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) {
+  if (M_.o.cone != 0) solve_primal<1>(M_, B_, e_, 0); else solve_primal<0>(M_, B_, e_, 0);
+}

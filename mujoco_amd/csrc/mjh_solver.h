@@ -668,7 +668,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
     return;
   }
   if (!(M.o.disableflags & (1<<9))) {
-    constraint_update(B, e, P, jar, 0);        // efc_force(qacc_warmstart), syncs internally
+    constraint_update(B, e, P, jar, 0, M.o.cone != 0);        // efc_force(qacc_warmstart), syncs internally
     // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
     MJH_FOR_LANES(r, nefc) ARf[r] = dot_ref(AR + (size_t)r*nefc, force, nefc);
     wv_sync();
