@@ -614,11 +614,15 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       solref[0] = M.jnt_solref[2*id]; solref[1] = M.jnt_solref[2*id+1];
       for (int q = 0; q < 5; q++) solimp[q] = M.jnt_solimp[5*id + q];
     } else {
-      // tendon friction uses the limit parameters' layout with its own arrays; only limits are
-      // uploaded (tendon frictionloss is rejected at upload)
+      // tendon limit / tendon friction loss (getsolparam :2002-2010)
       dA = M.tendon_invweight0[id];
-      solref[0] = M.tendon_solref_lim[2*id]; solref[1] = M.tendon_solref_lim[2*id+1];
-      for (int q = 0; q < 5; q++) solimp[q] = M.tendon_solimp_lim[5*id + q];
+      if (type == MJH_CNSTR_FRICTION_TENDON) {
+        solref[0] = M.tendon_solref_fri[2*id]; solref[1] = M.tendon_solref_fri[2*id+1];
+        for (int q = 0; q < 5; q++) solimp[q] = M.tendon_solimp_fri[5*id + q];
+      } else {
+        solref[0] = M.tendon_solref_lim[2*id]; solref[1] = M.tendon_solref_lim[2*id+1];
+        for (int q = 0; q < 5; q++) solimp[q] = M.tendon_solimp_lim[5*id + q];
+      }
     }
     fix_solparam(M, solref, solimp);
     real imp, impP;

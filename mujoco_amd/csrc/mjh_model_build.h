@@ -162,8 +162,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
              "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
-  MJH_REJECT(m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60),
-             "sparse constraint Jacobian (nv >= 60 or jacobian=sparse)");   // mj_isSparse, engine_core_util.c:29
+  // mj_isSparse (engine_core_util.c:29): with jacobian=sparse, or auto and nv >= 60, the reference
+  // runs its sparse code paths.  They compute the same quantities with sums taken over the non-zeros
+  // only; this path always evaluates the dense form, so such models agree with the reference to
+  // rounding (not bit for bit) -- the parity tests hold them to the 1e-6 bar.
   MJH_REJECT(m->opt.enableflags & (mjENBL_SLEEP | mjENBL_DIAGEXACT | mjENBL_FWDINV | mjENBL_ENERGY),
              "enable flags sleep/diagexact/fwdinv/energy");
   MJH_REJECT(m->opt.density != 0 || m->opt.viscosity != 0, "fluid forces (density/viscosity)");
@@ -193,7 +195,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   for (int i = 0; i < m->ntendon; i++) {
     MJH_REJECT(m->wrap_type[m->tendon_adr[i]] != mjWRAP_JOINT, "spatial tendons");
-    MJH_REJECT(m->tendon_frictionloss[i] > 0, "tendon friction loss");
+    if (m->tendon_frictionloss[i] > 0) {
+      const mjtNum* r = m->tendon_solref_fri + 2*i;
+      MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on tendon friction");
+    }
     MJH_REJECT(m->tendon_armature[i] != 0 || actuator_contrib(m, 1, i, 1, nullptr) != 0, "tendon armature");
     MJH_REJECT(m->tendon_actfrclimited[i], "tendon actuator force limits");
   }
@@ -343,6 +348,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->tendon_margin, m->tendon_margin, m->ntendon);
   copy_arr(H->tendon_solref_lim, m->tendon_solref_lim, 2*m->ntendon);
   copy_arr(H->tendon_solimp_lim, m->tendon_solimp_lim, 5*m->ntendon);
+  copy_arr(H->tendon_solref_fri, m->tendon_solref_fri, 2*m->ntendon);
+  copy_arr(H->tendon_solimp_fri, m->tendon_solimp_fri, 5*m->ntendon);
   copy_arr(H->tendon_invweight0, m->tendon_invweight0, m->ntendon);
   copy_arr(H->tendon_stiffness, m->tendon_stiffness, m->ntendon);
   copy_arr(H->tendon_stiffnesspoly, m->tendon_stiffnesspoly, 2*m->ntendon);
@@ -540,6 +547,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_limited[i]) nlimit += 2;
   int nfric = 0;
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
+  for (int i = 0; i < m->ntendon; i++) if (m->tendon_frictionloss[i] > 0) nfric++;
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
   s.nconlds = std::min(s.nconmax, 8);
   // tree ids (constraint islands, engine_island.c)

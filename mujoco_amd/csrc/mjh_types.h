@@ -136,6 +136,8 @@
   X(tendon_margin, s.ntendon)                  \
   X(tendon_solref_lim, 2 * s.ntendon)          \
   X(tendon_solimp_lim, 5 * s.ntendon)          \
+  X(tendon_solref_fri, 2 * s.ntendon)          \
+  X(tendon_solimp_fri, 5 * s.ntendon)          \
   X(tendon_invweight0, s.ntendon)              \
   X(tendon_stiffness, s.ntendon)               \
   X(tendon_stiffnesspoly, 2 * s.ntendon)       \

@@ -149,7 +149,7 @@ EQ_XML = """
   </worldbody>
   <tendon>
     <fixed name="t1"><joint joint="q3" coef="1"/></fixed>
-    <fixed name="t2"><joint joint="q4" coef="2"/><joint joint="q2" coef=".3"/></fixed>
+    <fixed name="t2" frictionloss=".08" solreffriction=".03 1"><joint joint="q4" coef="2"/><joint joint="q2" coef=".3"/></fixed>
   </tendon>
   <equality>
     <connect body1="l4" body2="world" anchor=".15 0 0"/>
@@ -238,3 +238,26 @@ def condim_scene_state(rb, m):
     v[31] = 6.0
     d.qvel[:] = v
     return rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+
+
+def chain_xml(nlinks=20):
+    """serial chain deeper than the register-resident L'DL routines handle (depth > 16), with a
+    ball joint (limited), a slide joint, hinges, motors and a position actuator"""
+    xml = ['<mujoco>', '  <option timestep="0.003" solver="PGS" iterations="50" jacobian="dense"/>',
+           '  <default><geom type="capsule" size=".02" condim="3"/><joint damping=".05" armature=".001"/></default>',
+           '  <worldbody>', '    <geom type="plane" size="5 5 .01" pos="0 0 -.6"/>',
+           '    <body pos="0 0 0">', '      <joint name="j0" type="ball" limited="true" range="0 1.2"/>',
+           '      <geom fromto="0 0 0 .1 0 0"/>']
+    for i in range(1, nlinks + 1):
+        if i == 7:
+            jt = 'type="slide" axis="1 0 0" range="-.02 .02" limited="true"'
+        elif i == 12:
+            jt = 'type="ball"'
+        else:
+            jt = 'type="hinge" axis="0 %d %d" range="-60 60" limited="true"' % (i % 2, (i + 1) % 2)
+        xml += ['<body pos=".1 0 0">', '<joint name="j%d" %s/>' % (i, jt), '<geom fromto="0 0 0 .1 0 0"/>']
+    xml += ['</body>'] * nlinks
+    xml += ['    </body>', '  </worldbody>',
+            '  <actuator><motor joint="j3" gear="2"/><motor joint="j9" gear="1"/><position joint="j15" kp="5"/></actuator>',
+            '</mujoco>']
+    return '\n'.join(xml)

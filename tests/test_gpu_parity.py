@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -241,6 +241,28 @@ def test_elliptic_humanoid_vs_live_oracle(rb, hip_lib, golden):
         print("elliptic humanoid solver", solver, "rel err", relerr(out, ref), "max nefc", ints[:, :, 1].max())
         assert relerr(out, ref) <= TOL
         assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("solver", [0, 2])
+def test_sparse_jacobian_model_vs_live_oracle(rb, hip_lib, tmp_path, solver):
+    """67-dof chain, jacobian=auto (sparse paths in the reference), up to ~230 constraint rows"""
+    xml = tmp_path / "chain.xml"
+    xml.write_text(chain_xml(62).replace('jacobian="dense"', 'jacobian="auto"'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dms = K.DeviceModel(hip_lib, m, 80, 300)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 170
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dms, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("sparse-jacobian chain solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):

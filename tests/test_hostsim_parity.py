@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -380,6 +380,33 @@ def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
     assert np.array_equal(out, ref)
 
 
+@pytest.mark.parametrize("solver", [0, 2])
+def test_sparse_jacobian_model_within_tolerance(rb, hostsim_lib, tmp_path, solver):
+    """nv >= 60 with jacobian=auto: the reference switches to its sparse code paths (mj_isSparse,
+    engine_core_util.c:29); this path evaluates the same quantities densely, so parity is to
+    rounding instead of bit for bit.  67 dofs, up to ~230 constraint rows (generic PGS and L'DL)."""
+    xml = tmp_path / "chain.xml"
+    xml.write_text(chain_xml(62).replace('jacobian="dense"', 'jacobian="auto"'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.nv >= 60
+    m.opt.solver = solver
+    dm = K.DeviceModel(hostsim_lib, m, 80, 300)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 120
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 1].max() > 64
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert relerr(out, ref) <= 1e-7
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
 @pytest.mark.parametrize("cone,solver,tol", [(0, 0, 0.0), (1, 0, 0.0), (1, 2, 1e-9), (1, 1, 1e-7)])
 def test_condim_and_elliptic_cones(rb, hostsim_lib, tmp_path, cone, solver, tol):
     """torsional / rolling friction rows (condim 4 and 6) with pyramidal and elliptic cones
@@ -424,34 +451,11 @@ def test_elliptic_humanoid_pgs_bit_exact(rb, hostsim_lib, golden):
     assert np.array_equal(out, ref)
 
 
-def _chain_xml(nlinks=20):
-    """serial chain deeper than the register-resident L'DL routines handle (depth > 16), with a
-    ball joint (limited), a slide joint, hinges, motors and a position actuator"""
-    xml = ['<mujoco>', '  <option timestep="0.003" solver="PGS" iterations="50" jacobian="dense"/>',
-           '  <default><geom type="capsule" size=".02" condim="3"/><joint damping=".05" armature=".001"/></default>',
-           '  <worldbody>', '    <geom type="plane" size="5 5 .01" pos="0 0 -.6"/>',
-           '    <body pos="0 0 0">', '      <joint name="j0" type="ball" limited="true" range="0 1.2"/>',
-           '      <geom fromto="0 0 0 .1 0 0"/>']
-    for i in range(1, nlinks + 1):
-        if i == 7:
-            jt = 'type="slide" axis="1 0 0" range="-.02 .02" limited="true"'
-        elif i == 12:
-            jt = 'type="ball"'
-        else:
-            jt = 'type="hinge" axis="0 %d %d" range="-60 60" limited="true"' % (i % 2, (i + 1) % 2)
-        xml += ['<body pos=".1 0 0">', '<joint name="j%d" %s/>' % (i, jt), '<geom fromto="0 0 0 .1 0 0"/>']
-    xml += ['</body>'] * nlinks
-    xml += ['    </body>', '  </worldbody>',
-            '  <actuator><motor joint="j3" gear="2"/><motor joint="j9" gear="1"/><position joint="j15" kp="5"/></actuator>',
-            '</mujoco>']
-    return '\n'.join(xml)
-
-
 def test_deep_chain_generic_paths_bit_exact(rb, hostsim_lib, tmp_path):
     """21-link chain: tree depth 24 (> 16: generic L'DL factor/solve), nefc up to ~80 (> 64: generic PGS
     sweep), ball-joint limit, slide joint, position actuator -- 150 steps, bit for bit"""
     xml = tmp_path / "chain.xml"
-    xml.write_text(_chain_xml())
+    xml.write_text(chain_xml())
     m = rb.MjModel.from_xml_path(str(xml))
     assert max(m.M_rownnz) - 1 > 16
     dm = K.DeviceModel(hostsim_lib, m)
