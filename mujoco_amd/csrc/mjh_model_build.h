@@ -152,7 +152,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->nflex > 0, "flex objects");
   MJH_REJECT(m->nplugin > 0, "plugins");
   MJH_REJECT(m->nsensor > 0, "sensors (sensordata output)");
-  MJH_REJECT(m->na > 0, "stateful actuators (na > 0)");
+  MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->npair > 0, "explicit contact <pair>s");
   MJH_REJECT(m->ngravcomp > 0 || m->flg_gravcomp, "gravity compensation");
@@ -175,7 +175,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->nactuator; i++) {
     MJH_REJECT(m->actuator_ctrlnum[i] != 1 || m->actuator_ctrladr[i] != i, "actuator control blocks other than one scalar");
     MJH_REJECT(m->actuator_outnum[i] != 1 || m->actuator_outadr[i] != i, "actuator output blocks other than one scalar");
-    MJH_REJECT(m->actuator_dyntype[i] != mjDYN_NONE, "actuator dynamics (dyntype != none)");
+    {
+      const int dt = m->actuator_dyntype[i];
+      MJH_REJECT(dt != mjDYN_NONE && dt != mjDYN_INTEGRATOR && dt != mjDYN_FILTER && dt != mjDYN_FILTEREXACT,
+                 "actuator dynamics other than none/integrator/filter/filterexact (muscle, dcmotor, pid, user)");
+      MJH_REJECT(dt == mjDYN_NONE ? m->actuator_actnum[i] != 0 : m->actuator_actnum[i] != 1,
+                 "actuators with more than one activation variable");
+    }
     MJH_REJECT(m->actuator_gaintype[i] != mjGAIN_FIXED && m->actuator_gaintype[i] != mjGAIN_AFFINE, "actuator gain types other than fixed/affine");
     MJH_REJECT(m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE, "actuator bias types other than none/affine");
     MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
@@ -313,6 +319,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->actuator_biastype, m->actuator_biastype, m->nu);
   copy_arr(H->actuator_ctrllimited, m->actuator_ctrllimited, m->nu);
   copy_arr(H->actuator_forcelimited, m->actuator_forcelimited, m->nu);
+  copy_arr(H->actuator_dyntype, m->actuator_dyntype, m->nu);
+  copy_arr(H->actuator_actadr, m->actuator_actadr, m->nu);
+  copy_arr(H->actuator_actlimited, m->actuator_actlimited, m->nu);
+  copy_arr(H->actuator_actearly, m->actuator_actearly, m->nu);
+  copy_arr(H->actuator_actrange, m->actuator_actrange, 2*m->nu);
+  H->actuator_dyntau.resize(m->nu);
+  for (int i = 0; i < m->nu; i++) H->actuator_dyntau[i] = m->actuator_dynprm[mjNDYN*i];
 
   copy_arr(H->qpos0, m->qpos0, m->nq);
   copy_arr(H->qpos_spring, m->qpos_spring, m->nq);

@@ -880,6 +880,19 @@ MJH_DEVN void stage_ten_act_velocity(MREF M_, BREF B_, int e_) {
 // mj_fwdActuation: stateless actuators (dyntype none), fixed/affine gain, none/affine bias
 //                                                 (engine_forward.c:353-1003)
 // ------------------------------------------------------------------------------------------------
+// mj_nextActivation                               (engine_support.c:706-775)
+// integrator / filter: Euler; filterexact: closed form; then the actrange clamp
+MJH_DEV real next_activation(MREF M, int a, real act, real act_dot) {
+  if (M.actuator_dyntype[a] == MJH_DYN_FILTEREXACT) {
+    const real tau = r_max(MJH_MINVAL, M.actuator_dyntau[a]);
+    act = act + act_dot * tau * (1 - exp(-M.o.timestep / tau));
+  } else {
+    act = act + act_dot * M.o.timestep;
+  }
+  if (M.actuator_actlimited[a]) act = r_clip(act, M.actuator_actrange[2*a], M.actuator_actrange[2*a+1]);
+  return act;
+}
+
 MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -908,11 +921,23 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
   bad = wv_any(bad);
   if (bad && wv_lane() == 0) warn[MJH_WARN_BADCTRL]++;
 
+  rptr act = MJH_F(B, act, e);
+  rptr act_dot = MJH_F(B, act_dot, e);
   MJH_FOR_LANES(i, s.nu) {
     real c = ctrl_in[i];
     if (!(dsbl & (1<<8)) && M.actuator_ctrllimited[i])
       c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
     if (bad) c = 0;
+    // stateful actuators: act_dot from the control, the force sees the activation (:403-447, :800-817)
+    const int dyn = M.actuator_dyntype[i];
+    if (dyn != MJH_DYN_NONE) {
+      const int aa = M.actuator_actadr[i];
+      real ad;
+      if (dyn == MJH_DYN_INTEGRATOR) ad = c;
+      else ad = (c - act[aa]) / r_max(MJH_MINVAL, M.actuator_dyntau[i]);
+      act_dot[aa] = ad;
+      c = M.actuator_actearly[i] ? next_activation(M, i, act[aa], ad) : (real)act[aa];
+    }
     auto gp = M.actuator_gainprm + 10*i;
     auto bp = M.actuator_biasprm + 10*i;
     real gain;

@@ -166,6 +166,19 @@ MJH_DEV void integrate_pos(MREF M, P0 qpos, P1 qvel, real h) {
 
 MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages);
 
+// mj_advance, activation part                      (engine_forward.c:1314-1323)
+template <class P0>
+MJH_DEV void advance_act(MREF M, BREF B, int e, P0 act_dot) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!s.na || (M.o.disableflags & (1<<11))) return;
+  rptr act = MJH_F(B, act, e);
+  MJH_FOR_LANES(i, s.nu) {
+    if (M.actuator_dyntype[i] == MJH_DYN_NONE) continue;
+    const int aa = M.actuator_actadr[i];
+    act[aa] = next_activation(M, i, act[aa], act_dot[aa]);
+  }
+}
+
 // mj_RungeKutta(m, d, 4) + mj_advance                 (engine_forward.c:1486-1587, :1261-1395)
 // mj_forward for stage 0 has already run (mj_step); the three further evaluations warm-start from
 // the same qacc_warmstart, which only mj_advance overwrites.
@@ -182,6 +195,13 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
   rptr X = MJH_G(B, rk_X, e);
   rptr F = MJH_G(B, rk_F, e);
   rptr dX = MJH_G(B, rk_dX, e);
+  // activations: X part [4][na], F part [4][na], combined act_dot [na]
+  const int na = s.na;
+  rptr act = MJH_F(B, act, e);
+  crptr act_dot = MJH_F(B, act_dot, e);
+  rptr XA = MJH_G(B, rk_act, e);
+  rptr FA = XA + 4*na;
+  rptr dA = XA + 8*na;
   const real time0 = tm[0];
   real T[3];
   for (int i = 1; i < 4; i++) {
@@ -193,6 +213,7 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
     crptr qacc = MJH_F(B, qacc, e);
     MJH_FOR_LANES(k, nq) X[k] = qpos[k];
     MJH_FOR_LANES(k, nv) { X[nq + k] = qvel[k]; F[k] = qacc[k]; }
+    MJH_FOR_LANES(k, na) { XA[k] = act[k]; FA[k] = act_dot[k]; }
     wv_sync();
   }
   for (int i = 1; i < 4; i++) {
@@ -205,6 +226,12 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
       }
       dX[k] = dv;
       dX[nv + k] = da;
+    }
+    MJH_FOR_LANES(k, na) {
+      real da = 0;
+      for (int j = 0; j < i; j++) da += FA[j*na + k] * A[(i-1)*3 + j];
+      XA[i*na + k] = XA[k] + da*h;
+      act[k] = XA[i*na + k];
     }
     // X[i] = X[0] (+) dX
     MJH_FOR_LANES(k, nx) X[i*nx + k] = X[k];
@@ -219,6 +246,7 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
     forward(M, B, e, MJH_STAGE_ALL);
     crptr qacc = MJH_F(B, qacc, e);
     MJH_FOR_LANES(k, nv) F[i*nv + k] = qacc[k];
+    MJH_FOR_LANES(k, na) FA[i*na + k] = act_dot[k];
     wv_sync();
   }
   // final combination with B, state reset, mj_advance
@@ -231,9 +259,16 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
     dX[k] = dv;
     dX[nv + k] = da;
   }
+  MJH_FOR_LANES(k, na) {
+    real da = 0;
+    for (int j = 0; j < 4; j++) da += FA[j*na + k] * Bw[j];
+    dA[k] = da;
+    act[k] = XA[k];
+  }
   MJH_FOR_LANES(k, nq) qpos[k] = X[k];
   MJH_FOR_LANES(k, nv) qvel[k] = X[nq + k];
   wv_sync();
+  advance_act(M, B, e, dA);
   MJH_FOR_LANES(k, nv) qvel[k] += dX[nv + k] * h;
   wv_sync();
   integrate_pos(M, qpos, dX, h);
@@ -294,7 +329,8 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
     wv_sync();
   }
 
-  // mj_advance: qvel += h*qacc ; qpos integrates the NEW qvel ; time ; warmstart
+  // mj_advance: activations ; qvel += h*qacc ; qpos integrates the NEW qvel ; time ; warmstart
+  advance_act(M, B, e, MJH_F(B, act_dot, e));
   MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
   wv_sync();
   integrate_pos(M, qpos, qvel, h);
@@ -352,14 +388,14 @@ MJH_DEV void free_bias_blocks(real mass, const real* R, const real* Xi, const re
 
 // velocity derivative of one actuator's force, 0 when it does not contribute
 // (mjd_actuator_vel, engine_derivative.c:2350-2490: affine gain/bias, stateless actuators)
-MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl) {
+MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl_or_act) {
   if (M.actuator_forcelimited[a]) {
     if (force <= M.actuator_forcerange[2*a] || force >= M.actuator_forcerange[2*a+1]) return 0;
   }
   real bias_vel = 0, gain_vel = 0;
   if (M.actuator_biastype[a] == MJH_BIAS_AFFINE) bias_vel = M.actuator_biasprm[10*a + 2];
   if (M.actuator_gaintype[a] != MJH_GAIN_FIXED) gain_vel = M.actuator_gainprm[10*a + 2];
-  if (gain_vel != 0) bias_vel += gain_vel * ctrl;
+  if (gain_vel != 0) bias_vel += gain_vel * ctrl_or_act;
   return bias_vel;
 }
 
@@ -385,6 +421,8 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   ciptr mcol = MJH_F(B, moment_colind, e);
   crptr force = MJH_F(B, actuator_force, e);
   crptr ctrl = MJH_F(B, ctrl, e);
+  crptr actv = MJH_F(B, act, e);
+  crptr actd = MJH_F(B, act_dot, e);
   crptr tJ = MJH_F(B, ten_J, e);
   crptr tvel = MJH_F(B, ten_velocity, e);
   const int act_on = !(dsbl & (1<<11)) && s.nu > 0;
@@ -396,7 +434,13 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
     real q = 0;
     if (act_on) {
       for (int a = 0; a < s.nu; a++) {
-        real bv = actuator_vel_deriv(M, a, force[a], ctrl[a]);
+        // the gain multiplies ctrl, or the (next, if actearly) activation (:2475-2490)
+        real u = ctrl[a];
+        if (M.actuator_dyntype[a] != MJH_DYN_NONE) {
+          const int aa = M.actuator_actadr[a];
+          u = M.actuator_actearly[a] ? next_activation(M, a, actv[aa], actd[aa]) : (real)actv[aa];
+        }
+        real bv = actuator_vel_deriv(M, a, force[a], u);
         if (bv == 0) continue;
         const int adr = M.actuator_momentadr[a];
         real mi = 0, mj = 0;
@@ -508,6 +552,7 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   }
   wv_sync();
 
+  advance_act(M, B, e, MJH_F(B, act_dot, e));
   MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
   wv_sync();
   integrate_pos(M, qpos, qvel, h);

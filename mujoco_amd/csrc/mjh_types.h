@@ -73,6 +73,10 @@
   X(actuator_biastype, s.nu)                   \
   X(actuator_ctrllimited, s.nu)                \
   X(actuator_forcelimited, s.nu)               \
+  X(actuator_dyntype, s.nu)                    \
+  X(actuator_actadr, s.nu)                     \
+  X(actuator_actlimited, s.nu)                 \
+  X(actuator_actearly, s.nu)                   \
   X(actuator_momentadr, s.nu + 1)              \
   X(jnt_actfrclimited, s.njnt)                 \
   X(pair_geom1, s.npair)                       \
@@ -150,6 +154,8 @@
   X(actuator_gear, 6 * s.nu)                   \
   X(actuator_ctrlrange, 2 * s.nu)              \
   X(actuator_forcerange, 2 * s.nu)             \
+  X(actuator_actrange, 2 * s.nu)               \
+  X(actuator_dyntau, s.nu)                     \
   X(actuator_gainprm, 10 * s.nu)               \
   X(actuator_biasprm, 10 * s.nu)               \
   X(actuator_cranklength, s.nu)                \
@@ -232,6 +238,7 @@ enum {
   X(qpos, s.nq, s.nq, MJH_T_BEGIN, MJH_T_END)                                     \
   X(qvel, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                                     \
   X(act, s.na, s.na, MJH_T_BEGIN, MJH_T_END)                                      \
+  X(act_dot, s.na, s.na, MJH_T_ACTUATION, MJH_T_END)                              \
   X(ctrl, s.nu, s.nu, MJH_T_BEGIN, MJH_T_END)                                     \
   X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \
   X(qacc_warmstart, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                           \
@@ -304,6 +311,7 @@ enum {
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
   X(rk_dX, 2 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                     \
+  X(rk_act, 9 * s.na, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
   /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
   X(prof, 32, 0, MJH_T_GLB, MJH_T_GLB)
@@ -460,6 +468,7 @@ enum {
   MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2,
   MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1,
   MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1,
+  MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
   // pair_func: which narrowphase routine a static pair uses

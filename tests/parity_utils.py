@@ -261,3 +261,36 @@ def chain_xml(nlinks=20):
             '  <actuator><motor joint="j3" gear="2"/><motor joint="j9" gear="1"/><position joint="j15" kp="5"/></actuator>',
             '</mujoco>']
     return '\n'.join(xml)
+
+
+# stateful actuators: first-order filters (Euler and exact), an integrated-velocity servo with an
+# activation range, one with actearly; joint damping so that every integrator has work to do
+ACT_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40"/>
+  <default><geom type="capsule" size=".03" condim="3"/><joint damping=".2" armature=".01"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="a1" pos="0 0 .7">
+      <joint name="j1" axis="0 1 0"/><geom fromto="0 0 0 .25 0 0"/>
+      <body name="a2" pos=".25 0 0">
+        <joint name="j2" axis="0 1 0" range="-120 120" limited="true"/><geom fromto="0 0 0 .2 0 0"/>
+        <body name="a3" pos=".2 0 0">
+          <joint name="j3" axis="0 0 1"/><geom fromto="0 0 0 .15 0 0"/>
+          <body name="a4" pos=".15 0 0"><joint name="j4" type="slide" axis="1 0 0" range="-.1 .1" limited="true"/><geom type="sphere" size=".04"/></body>
+        </body>
+      </body>
+    </body>
+    <body name="b1" pos="0 .5 .4"><joint name="k1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.3"/>
+      <body pos="0 0 -.3"><joint name="k2" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.25"/></body></body>
+  </worldbody>
+  <actuator>
+    <position joint="j1" kp="20" kv="1" timeconst=".05" ctrlrange="-1 1"/>
+    <general joint="j2" dyntype="filter" dynprm=".03" gainprm="4" biastype="affine" biasprm="0 0 -.3"/>
+    <intvelocity joint="j3" kp="15" kv=".5" actrange="-1.2 1.2"/>
+    <general joint="j4" dyntype="integrator" gainprm="3" actlimited="true" actrange="-.5 .5" actearly="true"/>
+    <general joint="k1" dyntype="filterexact" dynprm=".02" gainprm="2" actearly="true"/>
+    <motor joint="k2" gear=".5"/>
+  </actuator>
+</mujoco>
+"""

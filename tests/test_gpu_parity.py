@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -261,6 +261,29 @@ def test_sparse_jacobian_model_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     b = K.Batch(dms, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("sparse-jacobian chain solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_stateful_actuators_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """filter / filterexact / integrator actuator dynamics under Euler, RK4 and implicitfast"""
+    xml = tmp_path / "act.xml"
+    xml.write_text(ACT_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dma = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    d.act[:] = np.random.default_rng(2).normal(0, .2, m.na)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 150
+    ctrl = np.random.default_rng(0).uniform(-1.5, 1.5, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dma, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("stateful actuators integrator", integrator, "rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL
     assert b.get("warning").sum() == 0
 

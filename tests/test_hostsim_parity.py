@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -378,6 +378,31 @@ def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
     b = K.Batch(dm, 2)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_stateful_actuators_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """act_dot / mj_nextActivation (engine_forward.c:403-447, engine_support.c:706-775): filter,
+    filterexact and integrator dynamics, actrange clamp, actearly, activations in the RK4 tableau
+    and in the implicitfast actuator derivative -- Euler, RK4 and implicitfast, PGS bit-exact"""
+    xml = tmp_path / "act.xml"
+    xml.write_text(ACT_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    d.act[:] = np.random.default_rng(2).normal(0, .2, m.na)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    assert s0.shape[1] == 1 + m.nq + m.nv + m.na
+    T = 80
+    ctrl = np.random.default_rng(0).uniform(-1.5, 1.5, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
 
 
 @pytest.mark.parametrize("solver", [0, 2])
