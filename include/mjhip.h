@@ -128,6 +128,12 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* batch, int nstep, unsigned control
                                   const double* state0, const double* warmstart0,
                                   const double* control, double* state, int on_device,
                                   void* hip_stream);
+/* Same, plus the sensor readings of every step (the `sensordata` output of _unsafe_rollout,
+ * python/mujoco/rollout.cc:77,:130-133):  sensordata [nenv][nstep][nsensordata] or NULL. */
+MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* batch, int nstep, unsigned control_spec,
+                                          const double* state0, const double* warmstart0,
+                                          const double* control, double* state, double* sensordata,
+                                          int on_device, void* hip_stream);
 MJHIP_API int mjhip_batch_sync(mjhipBatch* batch, void* hip_stream);
 
 /* ---- the drop-in ------------------------------------------------------------------------------

@@ -100,6 +100,8 @@ class Lib:
         lib.mjhip_batch_step.argtypes = [vp, ci, vp]
         lib.mjhip_batch_rollout.restype = ci
         lib.mjhip_batch_rollout.argtypes = [vp, ci, cu, dp, dp, dp, dp, ci, vp]
+        lib.mjhip_batch_rollout_sensors.restype = ci
+        lib.mjhip_batch_rollout_sensors.argtypes = [vp, ci, cu, dp, dp, dp, dp, dp, ci, vp]
         lib.mjhip_batch_sync.restype = ci
         lib.mjhip_batch_sync.argtypes = [vp, vp]
         lib.mjhip_rollout.restype = ci
@@ -113,7 +115,7 @@ class Lib:
         "mjhip_batch_create", "mjhip_batch_create_layout", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_plan_lds", "mjhip_batch_lds_report",
-        "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_sync", "mjhip_rollout",
+        "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
     )
 
     def backend(self) -> str:
@@ -267,20 +269,23 @@ class Batch:
         self._lib.check(self._lib.c.mjhip_batch_sync(self._h, stream or None), "sync")
 
     def rollout_host(self, nstep: int, control_spec: int, state0, warmstart0=None, control=None,
-                     want_state: bool = True) -> Optional[np.ndarray]:
-        """host-array rollout of every env (numpy in / numpy out)."""
+                     want_state: bool = True, want_sensordata: bool = False):
+        """host-array rollout of every env (numpy in / numpy out).  With want_sensordata the
+        result is the pair (state, sensordata[nenv, nstep, nsensordata])."""
         nstate = self.model.size("nstate")
         s0 = np.ascontiguousarray(state0, dtype=np.float64)
         assert s0.shape == (self.nenv, nstate), s0.shape
         ws = None if warmstart0 is None else np.ascontiguousarray(warmstart0, dtype=np.float64)
         ct = None if control is None else np.ascontiguousarray(control, dtype=np.float64)
         out = np.zeros((self.nenv, nstep, nstate)) if want_state else None
-        rc = self._lib.c.mjhip_batch_rollout(
+        sd = np.zeros((self.nenv, nstep, self.model.size("nsensordata"))) if want_sensordata else None
+        rc = self._lib.c.mjhip_batch_rollout_sensors(
             self._h, int(nstep), int(control_spec), s0.ctypes.data,
             None if ws is None else ws.ctypes.data, None if ct is None else ct.ctypes.data,
-            None if out is None else out.ctypes.data, 0, None)
+            None if out is None else out.ctypes.data, None if sd is None or sd.size == 0 else sd.ctypes.data,
+            0, None)
         self._lib.check(rc, "rollout")
-        return out
+        return (out, sd) if want_sensordata else out
 
     def rollout_device(self, nstep: int, control_spec: int, state0_ptr: int, warmstart0_ptr: int,
                        control_ptr: int, state_ptr: int, stream: int = 0, cont: bool = False) -> None:

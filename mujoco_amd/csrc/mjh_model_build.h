@@ -151,7 +151,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   MJH_REJECT(m->nflex > 0, "flex objects");
   MJH_REJECT(m->nplugin > 0, "plugins");
-  MJH_REJECT(m->nsensor > 0, "sensors (sensordata output)");
+  for (int i = 0; i < m->nsensor; i++) {
+    MJH_REJECT(m->sensor_history[2*i] != 0 || m->sensor_delay[i] != 0, "sensor history / delay");
+  }
   MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->npair > 0, "explicit contact <pair>s");
@@ -638,6 +640,78 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int rows_per_con = 1;
   for (int c : H->pair_dim)
     rows_per_con = std::max(rows_per_con, c == 1 ? 1 : (m->opt.cone == mjCONE_PYRAMIDAL ? 2*(c-1) : c));
+  // ---- sensors (engine_sensor.c): kinds translated to the device enum, frame objects to MJH_OBJ_*
+  s.nsensor = m->nsensor;
+  s.nsensordata = m->nsensordata;
+  s.nbody_sens = m->nsensor ? m->nbody : 0;
+  s.sens_rnepost = 0; s.sens_subtreevel = 0;
+  H->sensor_type.assign(m->nsensor, 0);
+  H->sensor_objtype.assign(m->nsensor, MJH_OBJ_NONE);
+  H->sensor_reftype.assign(m->nsensor, MJH_OBJ_NONE);
+  copy_arr(H->sensor_datatype, m->sensor_datatype, m->nsensor);
+  copy_arr(H->sensor_objid, m->sensor_objid, m->nsensor);
+  copy_arr(H->sensor_refid, m->sensor_refid, m->nsensor);
+  copy_arr(H->sensor_dim, m->sensor_dim, m->nsensor);
+  copy_arr(H->sensor_adr, m->sensor_adr, m->nsensor);
+  copy_arr(H->sensor_cutoff, m->sensor_cutoff, m->nsensor);
+  for (int i = 0; i < m->nsensor; i++) {
+    int t = -1;
+    switch (m->sensor_type[i]) {
+      case mjSENS_JOINTPOS: t = MJH_SENS_JOINTPOS; break;
+      case mjSENS_JOINTVEL: t = MJH_SENS_JOINTVEL; break;
+      case mjSENS_TENDONPOS: t = MJH_SENS_TENDONPOS; break;
+      case mjSENS_TENDONVEL: t = MJH_SENS_TENDONVEL; break;
+      case mjSENS_ACTUATORPOS: t = MJH_SENS_ACTUATORPOS; break;
+      case mjSENS_ACTUATORVEL: t = MJH_SENS_ACTUATORVEL; break;
+      case mjSENS_ACTUATORFRC: t = MJH_SENS_ACTUATORFRC; break;
+      case mjSENS_JOINTACTFRC: t = MJH_SENS_JOINTACTFRC; break;
+      case mjSENS_BALLQUAT: t = MJH_SENS_BALLQUAT; break;
+      case mjSENS_BALLANGVEL: t = MJH_SENS_BALLANGVEL; break;
+      case mjSENS_JOINTLIMITPOS: t = MJH_SENS_JOINTLIMITPOS; break;
+      case mjSENS_JOINTLIMITVEL: t = MJH_SENS_JOINTLIMITVEL; break;
+      case mjSENS_JOINTLIMITFRC: t = MJH_SENS_JOINTLIMITFRC; break;
+      case mjSENS_TENDONLIMITPOS: t = MJH_SENS_TENDONLIMITPOS; break;
+      case mjSENS_TENDONLIMITVEL: t = MJH_SENS_TENDONLIMITVEL; break;
+      case mjSENS_TENDONLIMITFRC: t = MJH_SENS_TENDONLIMITFRC; break;
+      case mjSENS_FRAMEPOS: t = MJH_SENS_FRAMEPOS; break;
+      case mjSENS_FRAMEQUAT: t = MJH_SENS_FRAMEQUAT; break;
+      case mjSENS_FRAMEXAXIS: t = MJH_SENS_FRAMEXAXIS; break;
+      case mjSENS_FRAMEYAXIS: t = MJH_SENS_FRAMEYAXIS; break;
+      case mjSENS_FRAMEZAXIS: t = MJH_SENS_FRAMEZAXIS; break;
+      case mjSENS_FRAMELINVEL: t = MJH_SENS_FRAMELINVEL; break;
+      case mjSENS_FRAMEANGVEL: t = MJH_SENS_FRAMEANGVEL; break;
+      case mjSENS_FRAMELINACC: t = MJH_SENS_FRAMELINACC; s.sens_rnepost = 1; break;
+      case mjSENS_FRAMEANGACC: t = MJH_SENS_FRAMEANGACC; s.sens_rnepost = 1; break;
+      case mjSENS_SUBTREECOM: t = MJH_SENS_SUBTREECOM; break;
+      case mjSENS_SUBTREELINVEL: t = MJH_SENS_SUBTREELINVEL; s.sens_subtreevel = 1; break;
+      case mjSENS_SUBTREEANGMOM: t = MJH_SENS_SUBTREEANGMOM; s.sens_subtreevel = 1; break;
+      case mjSENS_CLOCK: t = MJH_SENS_CLOCK; break;
+      case mjSENS_VELOCIMETER: t = MJH_SENS_VELOCIMETER; break;
+      case mjSENS_GYRO: t = MJH_SENS_GYRO; break;
+      case mjSENS_ACCELEROMETER: t = MJH_SENS_ACCELEROMETER; s.sens_rnepost = 1; break;
+      case mjSENS_FORCE: t = MJH_SENS_FORCE; s.sens_rnepost = 1; break;
+      case mjSENS_TORQUE: t = MJH_SENS_TORQUE; s.sens_rnepost = 1; break;
+      case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
+      default: break;
+    }
+    MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer "
+                      "(touch, rangefinder, camprojection, contact, geom distance, energy, tactile, user, plugin)");
+    H->sensor_type[i] = t;
+    auto frame_obj = [&](int ot, int* out) -> bool {
+      if (ot == mjOBJ_BODY) *out = MJH_OBJ_BODY;
+      else if (ot == mjOBJ_XBODY) *out = MJH_OBJ_XBODY;
+      else if (ot == mjOBJ_GEOM) *out = MJH_OBJ_GEOM;
+      else if (ot == mjOBJ_SITE) *out = MJH_OBJ_SITE;
+      else return false;
+      return true;
+    };
+    if (t >= MJH_SENS_FRAMEPOS && t <= MJH_SENS_FRAMEANGACC) {
+      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "frame sensors attached to cameras");
+      if (m->sensor_refid[i] >= 0)
+        MJH_REJECT(!frame_obj(m->sensor_reftype[i], &H->sensor_reftype[i]), "frame sensors with a camera reference frame");
+    }
+  }
+  for (int k = 0; k < 3; k++) o.magnetic[k] = m->opt.magnetic[k];
   s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));

@@ -267,7 +267,7 @@ MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
   const DSizes& s = M->H.s;
 #define SZ(n) if (!strcmp(name, #n)) return s.n;
   SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
-  SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
+  SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
 #undef SZ
   set_err(std::string("mjhip_model_size: unknown size ") + name);
   return -1;
@@ -383,6 +383,9 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
   if (lds_bytes < 0) lds_bytes = 0;
   if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
+  // sensors read kinematic / velocity / constraint quantities after the solve: such models keep
+  // every field in its global home (no residency plan)
+  if (Bt->model->H.s.nsensor > 0) lds_bytes = 0;
   // equality constraints read kinematics / velocity quantities long after their usual lifetimes
   // (rows at make, Jdot*v at reference): such models keep those fields in their global homes
   std::vector<std::string> eqskip;
@@ -500,6 +503,7 @@ static bool pipeline_step(mjhipBatch_* Bt, const RolloutArgs& A, void* stream) {
 MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt) return -1;
   if (stages < 0) stages = MJH_STAGE_ALL;   // -1: mj_forward
+  if ((stages & MJH_STAGE_ALL) == MJH_STAGE_ALL) stages |= MJH_STAGE_SENSOR;   // mj_forward evaluates the sensors
   // MJHIP_STAGE_LDS: run on the LDS residency plan and write every stage's fields back to their
   // global homes (debug / parity tests of the resident path); default: everything global
   const bool lds = (stages & MJH_STAGE_LDS) && Bt->L.lds_bytes;
@@ -554,11 +558,25 @@ static int control_size(const DSizes& s, unsigned spec, int* qfrc_off, std::stri
   return n;
 }
 
+MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned control_spec,
+                                          const double* state0, const double* warmstart0,
+                                          const double* control, double* state, double* sensordata,
+                                          int on_device, void* stream);
 MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_spec,
                                   const double* state0, const double* warmstart0,
                                   const double* control, double* state, int on_device,
                                   void* stream) {
+  return mjhip_batch_rollout_sensors(Bt, nstep, control_spec, state0, warmstart0, control, state, nullptr,
+                                     on_device, stream);
+}
+
+MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned control_spec,
+                                          const double* state0, const double* warmstart0,
+                                          const double* control, double* state, double* sensordata,
+                                          int on_device, void* stream) {
   if (!Bt || nstep < 0) { set_err("mjhip_batch_rollout: bad arguments"); return -1; }
+  if (sensordata && Bt->model->H.s.nsensordata == 0) sensordata = nullptr;
+  if (sensordata && Bt->soa) { set_err("mjhip_batch_rollout: sensordata needs the AoS (wave-per-environment) layout"); return -2; }
   const DSizes& s = Bt->model->H.s;
   std::string err;
   int qfrc_off = 0;
@@ -578,6 +596,7 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
   auto cleanup = [&]() { for (void* p : tmp) Backend::free(p); };
   if (on_device) {
     A.state0 = state0; A.warmstart0 = warmstart0; A.control = control; A.state = state;
+    A.sensordata = sensordata;
   } else {
     auto up = [&](const double* src, size_t n, const real** dst) -> bool {
       if (!src || n == 0) { *dst = nullptr; return true; }
@@ -592,6 +611,10 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
     if (ok && state && nstep > 0) {
       void* p = Backend::alloc(nenv*(size_t)nstep*s.nstate*sizeof(real));
       if (!p) ok = false; else { tmp.push_back(p); A.state = (real*)p; }
+    }
+    if (ok && sensordata && nstep > 0) {
+      void* p = Backend::alloc(nenv*(size_t)nstep*s.nsensordata*sizeof(real));
+      if (!p) ok = false; else { tmp.push_back(p); A.sensordata = (real*)p; }
     }
     if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
   }
@@ -610,6 +633,8 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
   if (!on_device) {
     bool ok = true;
     if (state && nstep > 0) ok = Backend::d2h(state, A.state, nenv*(size_t)nstep*s.nstate*sizeof(real), stream);
+    if (sensordata && nstep > 0)
+      ok = Backend::d2h(sensordata, A.sensordata, nenv*(size_t)nstep*s.nsensordata*sizeof(real), stream) && ok;
     ok = Backend::sync(stream) && ok;
     cleanup();
     if (!ok) { set_err("mjhip_batch_rollout: device->host copy failed"); return -5; }
@@ -646,7 +671,6 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
       return -2;
     }
   }
-  if (sensordata && m0->nsensordata > 0) { set_err("mjhip_rollout: sensordata output is not supported"); return -2; }
   std::lock_guard<std::mutex> lock(g_cache.mu);
   // (re)build the cached device model / batch
   bool same = g_cache.model &&
@@ -667,7 +691,8 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
   mjhipBatch_* Bt = g_cache.batch;
   // "computationally stateless": user inputs not in control_spec are cleared (rollout.cc:85-115)
   if (mjhip_batch_reset(Bt)) return -5;
-  int rc = mjhip_batch_rollout(Bt, nstep, control_spec, state0, warmstart0, control, state, 0, nullptr);
+  int rc = mjhip_batch_rollout_sensors(Bt, nstep, control_spec, state0, warmstart0, control, state, sensordata,
+                                       0, nullptr);
   if (rc) return rc;
   // d[0] <- final state of the LAST rollout (rollout.cc:73)
   mjData* d = (mjData*)dp[0];
@@ -693,6 +718,7 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
     pull("qfrc_applied", d->qfrc_applied, s.nv);
     pull("qacc_warmstart", d->qacc_warmstart, s.nv);
     pull("qacc", d->qacc, s.nv);
+    pull("sensordata", d->sensordata, s.nsensordata);
     int w[8];
     void* p; int cnt, isint;
     mjhip_batch_field(Bt, "warning", &p, &cnt, &isint);

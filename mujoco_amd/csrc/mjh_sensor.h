@@ -1,0 +1,345 @@
+// Sensors: mj_sensorPos / mj_sensorVel / mj_sensorAcc (engine_sensor.c:1498-1660) evaluated once
+// per mj_forward after the constraint solve, with the support computations they pull in:
+// mj_subtreeVel (engine_core_smooth.c:2249), mj_rnePostConstraint (:2394), mj_objectVelocity /
+// mj_objectAcceleration (engine_core_util.c:835, :909), mj_contactForce (:1075).
+// Models with sensors run without an LDS residency plan (every field in its global home), so all
+// the kinematic / velocity / constraint quantities read here are still valid.
+// (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
+
+
+// mju_transformSpatial (engine_util_spatial.c:482): motion (flg_force 0) or force vector moved
+// from oldpos to newpos, optionally rotated into the frame rot (new -> old)
+template <class P0, class P1, class P2, class P3>
+MJH_DEV void sp_transform(real* res, P0 vec, int flg_force, P1 newpos, P2 oldpos, P3 rot, int has_rot) {
+  real dif[3], cros[3], tran[6];
+  for (int k = 0; k < 6; k++) tran[k] = vec[k];
+  v3_sub(dif, newpos, oldpos);
+  if (flg_force) {
+    real f[3] = {vec[3], vec[4], vec[5]};
+    v3_cross(cros, dif, f);
+    tran[0] = vec[0] - cros[0]; tran[1] = vec[1] - cros[1]; tran[2] = vec[2] - cros[2];
+  } else {
+    real w[3] = {vec[0], vec[1], vec[2]};
+    v3_cross(cros, dif, w);
+    tran[3] = vec[3] - cros[0]; tran[4] = vec[4] - cros[1]; tran[5] = vec[5] - cros[2];
+  }
+  if (has_rot) {
+    m3_multvec(res, rot, tran);
+    m3_multvec(res + 3, rot, tran + 3);
+  } else {
+    for (int k = 0; k < 6; k++) res[k] = tran[k];
+  }
+}
+
+// frame of a sensor object: position, orientation matrix, carrying body
+struct SensFrame { crptr pos, mat; int body; };
+MJH_DEV SensFrame sens_frame(MREF M, BREF B, int e, int objtype, int id) {
+  SensFrame f;
+  if (objtype == MJH_OBJ_BODY) { f.pos = MJH_F(B, xipos, e) + 3*id; f.mat = MJH_F(B, ximat, e) + 9*id; f.body = id; }
+  else if (objtype == MJH_OBJ_XBODY) { f.pos = MJH_F(B, xpos, e) + 3*id; f.mat = MJH_F(B, xmat, e) + 9*id; f.body = id; }
+  else if (objtype == MJH_OBJ_GEOM) { f.pos = MJH_F(B, geom_xpos, e) + 3*id; f.mat = MJH_F(B, geom_xmat, e) + 9*id; f.body = M.geom_bodyid[id]; }
+  else { f.pos = MJH_F(B, site_xpos, e) + 3*id; f.mat = MJH_F(B, site_xmat, e) + 9*id; f.body = M.site_bodyid[id]; }
+  return f;
+}
+MJH_DEV void sens_quat(MREF M, BREF B, int e, int objtype, int id, real* quat) {
+  crptr xquat = MJH_F(B, xquat, e);
+  if (objtype == MJH_OBJ_XBODY) q_copy(quat, xquat + 4*id);
+  else if (objtype == MJH_OBJ_BODY) q_mul(quat, xquat + 4*id, M.body_iquat + 4*id);
+  else if (objtype == MJH_OBJ_GEOM) q_mul(quat, xquat + 4*M.geom_bodyid[id], M.geom_quat + 4*id);
+  else q_mul(quat, xquat + 4*M.site_bodyid[id], M.site_quat + 4*id);
+}
+
+// mj_objectVelocity: 6D velocity [rot; lin] of a frame object, world or local orientation
+MJH_DEV void object_velocity(MREF M, BREF B, int e, int objtype, int id, real* res, int flg_local) {
+  const SensFrame f = sens_frame(M, B, e, objtype, id);
+  if (M.body_dofnum[M.body_weldid[f.body]] == 0) { for (int k = 0; k < 6; k++) res[k] = 0; return; }
+  sp_transform(res, MJH_F(B, cvel, e) + 6*f.body, 0, f.pos,
+               MJH_F(B, subtree_com, e) + 3*M.body_rootid[f.body], f.mat, flg_local);
+}
+// mj_objectAcceleration: needs cacc of mj_rnePostConstraint; adds the rotating-frame correction
+MJH_DEV void object_acceleration(MREF M, BREF B, int e, int objtype, int id, real* res, int flg_local) {
+  const SensFrame f = sens_frame(M, B, e, objtype, id);
+  if (M.body_dofnum[M.body_weldid[f.body]] == 0) { for (int k = 0; k < 6; k++) res[k] = 0; return; }
+  crptr com = MJH_F(B, subtree_com, e) + 3*M.body_rootid[f.body];
+  sp_transform(res, MJH_G(B, cacc_post, e) + 6*f.body, 0, f.pos, com, f.mat, flg_local);
+  real vel[6], corr[3];
+  sp_transform(vel, MJH_F(B, cvel, e) + 6*f.body, 0, f.pos, com, f.mat, flg_local);
+  v3_cross(corr, vel, vel + 3);
+  res[3] += corr[0]; res[4] += corr[1]; res[5] += corr[2];
+}
+
+// mj_contactForce: contact-frame [force; torque] from the constraint forces
+MJH_DEV void contact_force(MREF M, BREF B, int e, const Efc& P, int k, real* result) {
+  for (int q = 0; q < 6; q++) result[q] = 0;
+  const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
+  if (r0 < 0) return;
+  const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+  if (M.o.cone == 0) {
+    // mju_decodePyramid (engine_util_misc.c:1584)
+    if (dim == 1) { result[0] = P.force[r0]; return; }
+    auto mu = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
+    real fn = 0;
+    for (int i = 0; i < 2*(dim - 1); i++) fn += P.force[r0 + i];
+    result[0] = fn;
+    for (int i = 0; i < dim - 1; i++) result[i + 1] = (P.force[r0 + 2*i] - P.force[r0 + 2*i + 1]) * mu[i];
+  } else {
+    for (int i = 0; i < dim; i++) result[i] = P.force[r0 + i];
+  }
+}
+
+// mj_subtreeVel (lane 0)
+MJH_DEV void sens_subtree_vel(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  rptr bvel = MJH_G(B, sens_bvel, e);
+  rptr linvel = MJH_G(B, subtree_linvel, e);
+  rptr angmom = MJH_G(B, subtree_angmom, e);
+  crptr ximat = MJH_F(B, ximat, e);
+  crptr xipos = MJH_F(B, xipos, e);
+  crptr com = MJH_F(B, subtree_com, e);
+  for (int i = 0; i < s.nbody; i++) {
+    real v[6];
+    object_velocity(M, B, e, MJH_OBJ_BODY, i, v, 0);
+    for (int k = 0; k < 6; k++) bvel[6*i + k] = v[k];
+    for (int k = 0; k < 3; k++) linvel[3*i + k] = v[3 + k]*M.body_mass[i];
+    real dv[3], out[3];
+    m3_multvec(dv, ximat + 9*i, v);
+    dv[0] *= M.body_inertia[3*i]; dv[1] *= M.body_inertia[3*i+1]; dv[2] *= M.body_inertia[3*i+2];
+    m3_mulvec(out, ximat + 9*i, dv);
+    for (int k = 0; k < 3; k++) angmom[3*i + k] = out[k];
+  }
+  for (int i = s.nbody - 1; i >= 0; i--) {
+    if (i) for (int k = 0; k < 3; k++) linvel[3*M.body_parentid[i] + k] += linvel[3*i + k];
+    const real inv = 1/r_max(MJH_MINVAL, M.body_subtreemass[i]);
+    for (int k = 0; k < 3; k++) linvel[3*i + k] = linvel[3*i + k]*inv;
+  }
+  for (int i = s.nbody - 1; i > 0; i--) {
+    const int parent = M.body_parentid[i];
+    real dx[3], dv[3], dp[3], dL[3];
+    v3_sub(dx, xipos + 3*i, com + 3*i);
+    for (int k = 0; k < 3; k++) dv[k] = bvel[6*i + 3 + k] - linvel[3*i + k];
+    v3_scl(dp, dv, M.body_mass[i]);
+    v3_cross(dL, dx, dp);
+    for (int k = 0; k < 3; k++) angmom[3*i + k] += dL[k];
+    for (int k = 0; k < 3; k++) angmom[3*parent + k] += angmom[3*i + k];
+    v3_sub(dx, com + 3*i, com + 3*parent);
+    for (int k = 0; k < 3; k++) dv[k] = linvel[3*i + k] - linvel[3*parent + k];
+    v3_scl(dv, dv, M.body_subtreemass[i]);
+    v3_cross(dL, dx, dv);
+    for (int k = 0; k < 3; k++) angmom[3*parent + k] += dL[k];
+  }
+}
+
+// mj_rnePostConstraint (lane 0): cacc, cfrc_ext (contacts, connect/weld), cfrc_int
+MJH_DEV void sens_rne_post(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  rptr cacc = MJH_G(B, cacc_post, e);
+  rptr cint = MJH_G(B, cfrc_int, e);
+  rptr cext = MJH_G(B, cfrc_ext, e);
+  crptr com = MJH_F(B, subtree_com, e);
+  ciptr counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ncon = counts[MJH_C_NCON], ne = counts[MJH_C_NE];
+  for (int k = 0; k < 6; k++) cacc[k] = 0;
+  if (!(M.o.disableflags & (1<<7))) for (int k = 0; k < 3; k++) cacc[3 + k] = M.o.gravity[k]*-1;
+  for (int k = 0; k < 6*s.nbody; k++) cext[k] = 0;
+  Efc P;
+  if (nefc) efc_layout(M, B, e, nefc, P);
+  // contacts
+  for (int c = 0; nefc && c < ncon; c++) {
+    if (MJH_CON(B, con_efcadr, e, 1, c)[0] < 0) continue;
+    real lfrc[6], cfrc[6], cc[6];
+    contact_force(M, B, e, P, c, lfrc);
+    crptr fr = MJH_CON(B, con_frame, e, 9, c);
+    crptr cpos = MJH_CON(B, con_pos, e, 3, c);
+    m3_multvec(cfrc, fr, lfrc + 3);
+    m3_multvec(cfrc + 3, fr, lfrc);
+    ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+    int k = M.geom_bodyid[cg[0]];
+    if (k) {
+      sp_transform(cc, cfrc, 1, com + 3*M.body_rootid[k], cpos, cpos, 0);
+      for (int q = 0; q < 6; q++) cext[6*k + q] -= cc[q];
+    }
+    k = M.geom_bodyid[cg[1]];
+    if (k) {
+      sp_transform(cc, cfrc, 1, com + 3*M.body_rootid[k], cpos, cpos, 0);
+      for (int q = 0; q < 6; q++) cext[6*k + q] += cc[q];
+    }
+  }
+  // connect / weld equalities
+  for (int i = 0; i < ne; ) {
+    const int id = P.id[i];
+    const int et = M.eq_type[id];
+    if (et != MJH_EQ_CONNECT && et != MJH_EQ_WELD) { i++; continue; }
+    real cfrc[6], cc[6], pos0[3], pos1[3];
+    for (int q = 0; q < 3; q++) { cfrc[3 + q] = P.force[i + q]; cfrc[q] = (et == MJH_EQ_WELD) ? (real)P.force[i + 3 + q] : (real)0; }
+    int b0, b1;
+    equality_anchors(M, B, e, id, pos0, pos1, &b0, &b1);
+    if (b0) {
+      sp_transform(cc, cfrc, 1, com + 3*M.body_rootid[b0], pos0, pos0, 0);
+      for (int q = 0; q < 6; q++) cext[6*b0 + q] += cc[q];
+    }
+    if (b1) {
+      sp_transform(cc, cfrc, 1, com + 3*M.body_rootid[b1], pos1, pos1, 0);
+      for (int q = 0; q < 6; q++) cext[6*b1 + q] -= cc[q];
+    }
+    i += (et == MJH_EQ_WELD) ? 6 : 3;
+  }
+  // forward pass: cacc, cfrc_int = cfrc_body - cfrc_ext ; backward pass: accumulate to parents
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr cdof_dot = MJH_F(B, cdof_dot, e);
+  crptr cvel = MJH_F(B, cvel, e);
+  crptr cinert = MJH_F(B, cinert, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  for (int k = 0; k < 6; k++) cint[k] = 0;
+  for (int j = 1; j < s.nbody; j++) {
+    const int bda = M.body_dofadr[j];
+    real tmp[6], fb[6], fc[6], fx[6];
+    mul_dof_vec(tmp, cdof_dot + 6*bda, qvel + bda, M.body_dofnum[j]);
+    for (int q = 0; q < 6; q++) cacc[6*j + q] = cacc[6*M.body_parentid[j] + q] + tmp[q];
+    mul_dof_vec(tmp, cdof + 6*bda, qacc + bda, M.body_dofnum[j]);
+    for (int q = 0; q < 6; q++) cacc[6*j + q] += tmp[q];
+    sp_mul_inert(fb, cinert + 10*j, cacc + 6*j);
+    sp_mul_inert(fc, cinert + 10*j, cvel + 6*j);
+    sp_cross_force(fx, cvel + 6*j, fc);
+    for (int q = 0; q < 6; q++) fb[q] += fx[q];
+    for (int q = 0; q < 6; q++) cint[6*j + q] = fb[q] - cext[6*j + q];
+  }
+  for (int j = s.nbody - 1; j > 0; j--)
+    for (int q = 0; q < 6; q++) cint[6*M.body_parentid[j] + q] += cint[6*j + q];
+}
+
+MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!s.nsensor || (M.o.disableflags & (1<<13))) return;
+  if (wv_lane() == 0) {
+    if (s.sens_subtreevel) sens_subtree_vel(M, B, e);
+    if (s.sens_rnepost) sens_rne_post(M, B, e);
+  }
+  wv_sync();
+  ciptr counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
+  Efc P;
+  if (nefc) efc_layout(M, B, e, nefc, P);
+  rptr out = MJH_G(B, sensordata, e);
+  MJH_FOR_LANES(i, s.nsensor) {
+    const int type = M.sensor_type[i], objtype = M.sensor_objtype[i], objid = M.sensor_objid[i];
+    const int reftype = M.sensor_reftype[i], refid = M.sensor_refid[i];
+    const int dim = M.sensor_dim[i];
+    real v[6] = {0, 0, 0, 0, 0, 0};
+    // limit sensors: the first matching constraint row
+    int lrow = -1;
+    if (type >= MJH_SENS_JOINTLIMITPOS && type <= MJH_SENS_TENDONLIMITFRC) {
+      const int want = (type <= MJH_SENS_JOINTLIMITFRC) ? MJH_CNSTR_LIMIT_JOINT : MJH_CNSTR_LIMIT_TENDON;
+      for (int j = ne + nf; j < nefc; j++) if (P.type[j] == want && P.id[j] == objid) { lrow = j; break; }
+    }
+    switch (type) {
+    case MJH_SENS_JOINTPOS: v[0] = MJH_F(B, qpos, e)[M.jnt_qposadr[objid]]; break;
+    case MJH_SENS_JOINTVEL: v[0] = MJH_F(B, qvel, e)[M.jnt_dofadr[objid]]; break;
+    case MJH_SENS_TENDONPOS: v[0] = MJH_F(B, ten_length, e)[objid]; break;
+    case MJH_SENS_TENDONVEL: v[0] = MJH_F(B, ten_velocity, e)[objid]; break;
+    case MJH_SENS_ACTUATORPOS: v[0] = MJH_F(B, actuator_length, e)[objid]; break;
+    case MJH_SENS_ACTUATORVEL: v[0] = MJH_F(B, actuator_velocity, e)[objid]; break;
+    case MJH_SENS_ACTUATORFRC: v[0] = MJH_F(B, actuator_force, e)[objid]; break;
+    case MJH_SENS_JOINTACTFRC: v[0] = MJH_F(B, qfrc_actuator, e)[M.jnt_dofadr[objid]]; break;
+    case MJH_SENS_BALLQUAT: {
+      crptr q = MJH_F(B, qpos, e) + M.jnt_qposadr[objid];
+      real qq[4] = {q[0], q[1], q[2], q[3]};
+      q_normalize(qq);
+      for (int k = 0; k < 4; k++) v[k] = qq[k];
+    } break;
+    case MJH_SENS_BALLANGVEL: { crptr w = MJH_F(B, qvel, e) + M.jnt_dofadr[objid]; v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; } break;
+    case MJH_SENS_JOINTLIMITPOS: case MJH_SENS_TENDONLIMITPOS: if (lrow >= 0) v[0] = P.pos[lrow] - P.margin[lrow]; break;
+    case MJH_SENS_JOINTLIMITVEL: case MJH_SENS_TENDONLIMITVEL: if (lrow >= 0) v[0] = P.vel[lrow]; break;
+    case MJH_SENS_JOINTLIMITFRC: case MJH_SENS_TENDONLIMITFRC: if (lrow >= 0) v[0] = P.force[lrow]; break;
+    case MJH_SENS_FRAMEPOS: case MJH_SENS_FRAMEXAXIS: case MJH_SENS_FRAMEYAXIS: case MJH_SENS_FRAMEZAXIS: {
+      const SensFrame f = sens_frame(M, B, e, objtype, objid);
+      real a[3];
+      if (type == MJH_SENS_FRAMEPOS) { a[0] = f.pos[0]; a[1] = f.pos[1]; a[2] = f.pos[2]; }
+      else { const int off = type - MJH_SENS_FRAMEXAXIS; a[0] = f.mat[off]; a[1] = f.mat[off + 3]; a[2] = f.mat[off + 6]; }
+      if (refid == -1) { v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; }
+      else {
+        const SensFrame r = sens_frame(M, B, e, reftype, refid);
+        if (type == MJH_SENS_FRAMEPOS) { real rv[3]; v3_sub(rv, a, r.pos); m3_multvec(v, r.mat, rv); }
+        else m3_multvec(v, r.mat, a);
+      }
+    } break;
+    case MJH_SENS_FRAMEQUAT: {
+      real oq[4];
+      sens_quat(M, B, e, objtype, objid, oq);
+      if (refid == -1) { for (int k = 0; k < 4; k++) v[k] = oq[k]; }
+      else {
+        real rq[4], nq[4], res[4];
+        sens_quat(M, B, e, reftype, refid, rq);
+        q_neg(nq, rq);
+        q_mul(res, nq, oq);
+        for (int k = 0; k < 4; k++) v[k] = res[k];
+      }
+    } break;
+    case MJH_SENS_FRAMELINVEL: case MJH_SENS_FRAMEANGVEL: {
+      real xvel[6];
+      object_velocity(M, B, e, objtype, objid, xvel, 0);
+      if (refid > -1) {
+        const SensFrame f = sens_frame(M, B, e, objtype, objid);
+        const SensFrame r = sens_frame(M, B, e, reftype, refid);
+        real xref[6], rel[6], rv[3], cr[3];
+        object_velocity(M, B, e, reftype, refid, xref, 0);
+        for (int k = 0; k < 6; k++) rel[k] = xvel[k] - xref[k];
+        v3_sub(rv, f.pos, r.pos);
+        v3_cross(cr, rv, xref);
+        rel[3] += cr[0]; rel[4] += cr[1]; rel[5] += cr[2];
+        m3_multvec(xvel, r.mat, rel);
+        m3_multvec(xvel + 3, r.mat, rel + 3);
+      }
+      const int o = (type == MJH_SENS_FRAMELINVEL) ? 3 : 0;
+      v[0] = xvel[o]; v[1] = xvel[o + 1]; v[2] = xvel[o + 2];
+    } break;
+    case MJH_SENS_FRAMELINACC: case MJH_SENS_FRAMEANGACC: {
+      real acc[6];
+      object_acceleration(M, B, e, objtype, objid, acc, 0);
+      const int o = (type == MJH_SENS_FRAMELINACC) ? 3 : 0;
+      v[0] = acc[o]; v[1] = acc[o + 1]; v[2] = acc[o + 2];
+    } break;
+    case MJH_SENS_SUBTREECOM: { crptr c = MJH_F(B, subtree_com, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
+    case MJH_SENS_SUBTREELINVEL: { crptr c = MJH_G(B, subtree_linvel, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
+    case MJH_SENS_SUBTREEANGMOM: { crptr c = MJH_G(B, subtree_angmom, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
+    case MJH_SENS_CLOCK: v[0] = MJH_F(B, time, e)[0]; break;
+    case MJH_SENS_VELOCIMETER: case MJH_SENS_GYRO: {
+      real xvel[6];
+      object_velocity(M, B, e, MJH_OBJ_SITE, objid, xvel, 1);
+      const int o = (type == MJH_SENS_VELOCIMETER) ? 3 : 0;
+      v[0] = xvel[o]; v[1] = xvel[o + 1]; v[2] = xvel[o + 2];
+    } break;
+    case MJH_SENS_ACCELEROMETER: {
+      real acc[6];
+      object_acceleration(M, B, e, MJH_OBJ_SITE, objid, acc, 1);
+      v[0] = acc[3]; v[1] = acc[4]; v[2] = acc[5];
+    } break;
+    case MJH_SENS_FORCE: case MJH_SENS_TORQUE: {
+      const int body = M.site_bodyid[objid];
+      real t[6];
+      sp_transform(t, MJH_G(B, cfrc_int, e) + 6*body, 1, MJH_F(B, site_xpos, e) + 3*objid,
+                   MJH_F(B, subtree_com, e) + 3*M.body_rootid[body], MJH_F(B, site_xmat, e) + 9*objid, 1);
+      const int o = (type == MJH_SENS_FORCE) ? 3 : 0;
+      v[0] = t[o]; v[1] = t[o + 1]; v[2] = t[o + 2];
+    } break;
+    case MJH_SENS_MAGNETOMETER: {
+      real mg[3] = {M.o.magnetic[0], M.o.magnetic[1], M.o.magnetic[2]};
+      m3_multvec(v, MJH_F(B, site_xmat, e) + 9*objid, mg);
+    } break;
+    default: break;
+    }
+    // apply_cutoff (engine_sensor.c:198-223): datatype 0 real -> both sides, 1 positive -> upper only
+    const real cutoff = M.sensor_cutoff[i];
+    const int adr = M.sensor_adr[i];
+    for (int k = 0; k < dim; k++) {
+      real x = v[k];
+      if (cutoff > 0) {
+        if (M.sensor_datatype[i] == 0) x = r_clip(x, -cutoff, cutoff);
+        else if (M.sensor_datatype[i] == 1) x = r_min(cutoff, x);
+      }
+      out[adr + k] = x;
+    }
+  }
+  wv_sync();
+}

@@ -144,6 +144,7 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
+  if ((stages & MJH_STAGE_SENSOR) && M.s.nsensor) stage_sensors(M, B, e);
 }
 
 // mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
@@ -567,7 +568,7 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
   check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
   check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL);
   for (int attempt = 0; attempt < 2; attempt++) {
-    forward(M, B, e, MJH_STAGE_ALL);
+    forward(M, B, e, MJH_STAGE_ALL | MJH_STAGE_SENSOR);
     int bad = check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC);
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;
@@ -637,6 +638,10 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
       step_env(M, B, e);
     }
     if (A.state) get_state(M, B, e, A.state + step*s.nstate);
+    if (A.sensordata) {
+      crptr sd = MJH_G(B, sensordata, e);
+      MJH_FOR_LANES(i, s.nsensordata) A.sensordata[step*s.nsensordata + i] = sd[i];
+    }
     wv_sync();
   }
   lds_exit(M, B, e);

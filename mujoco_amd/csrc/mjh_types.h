@@ -60,6 +60,14 @@
   X(site_bodyid, s.nsite)                      \
   X(site_sameframe, s.nsite)                   \
   X(tendon_adr, s.ntendon)                     \
+  X(sensor_type, s.nsensor)                    \
+  X(sensor_datatype, s.nsensor)                \
+  X(sensor_objtype, s.nsensor)                 \
+  X(sensor_objid, s.nsensor)                   \
+  X(sensor_reftype, s.nsensor)                 \
+  X(sensor_refid, s.nsensor)                   \
+  X(sensor_dim, s.nsensor)                     \
+  X(sensor_adr, s.nsensor)                     \
   X(tendon_num, s.ntendon)                     \
   X(tendon_limited, s.ntendon)                 \
   X(ten_J_rownnz, s.ntendon)                   \
@@ -111,6 +119,7 @@
   X(body_iquat, 4 * s.nbody)                   \
   X(body_mass, s.nbody)                        \
   X(body_subtreemass, s.nbody)                 \
+  X(sensor_cutoff, s.nsensor)                  \
   X(body_inertia, 3 * s.nbody)                 \
   X(body_invweight0, 2 * s.nbody)              \
   X(jnt_pos, 3 * s.njnt)                       \
@@ -182,6 +191,9 @@ struct DSizes {
   int nconH;       // contacts with a cone-Hessian slot (elliptic cones + primal solver), else 0
   int nefcmax;     // per-env constraint-row capacity
   int nstate;      // mj_stateSize(FULLPHYSICS)
+  int nsensor, nsensordata;
+  int nbody_sens;  // nbody when the model has sensors (cacc / cfrc / subtree velocity arrays), else 0
+  int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
   int npgsorder;   // entries of the precomputed PGS visitation-order table
   int nldprog;     // entries of the flattened L'DL update list
   int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
@@ -191,6 +203,7 @@ struct DSizes {
 struct DOptions {
   real timestep, impratio, tolerance, ls_tolerance;
   real gravity[3];
+  real magnetic[3];
   real meaninertia;
   int integrator, cone, solver, iterations, ls_iterations;
   int disableflags, enableflags;
@@ -302,6 +315,13 @@ enum {
   X(efc_b, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(efc_force, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                \
   X(efc_cone, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
+  X(sensordata, s.nsensordata, 0, MJH_T_GLB, MJH_T_GLB)                           \
+  X(cacc_post, 6 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                         \
+  X(cfrc_int, 6 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                          \
+  X(cfrc_ext, 6 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                          \
+  X(sens_bvel, 6 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                         \
+  X(subtree_linvel, 3 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                    \
+  X(subtree_angmom, 3 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                    \
   X(con_H, 36 * s.nconH, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
   X(nt_M, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
@@ -468,6 +488,16 @@ enum {
   MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2,
   MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1,
   MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1,
+  // sensor kinds (host translation of mjtSensor) and frame-object kinds (mjtObj)
+  MJH_SENS_JOINTPOS = 0, MJH_SENS_JOINTVEL, MJH_SENS_TENDONPOS, MJH_SENS_TENDONVEL, MJH_SENS_ACTUATORPOS,
+  MJH_SENS_ACTUATORVEL, MJH_SENS_ACTUATORFRC, MJH_SENS_JOINTACTFRC, MJH_SENS_BALLQUAT, MJH_SENS_BALLANGVEL,
+  MJH_SENS_JOINTLIMITPOS, MJH_SENS_JOINTLIMITVEL, MJH_SENS_JOINTLIMITFRC, MJH_SENS_TENDONLIMITPOS,
+  MJH_SENS_TENDONLIMITVEL, MJH_SENS_TENDONLIMITFRC, MJH_SENS_FRAMEPOS, MJH_SENS_FRAMEQUAT, MJH_SENS_FRAMEXAXIS,
+  MJH_SENS_FRAMEYAXIS, MJH_SENS_FRAMEZAXIS, MJH_SENS_FRAMELINVEL, MJH_SENS_FRAMEANGVEL, MJH_SENS_FRAMELINACC,
+  MJH_SENS_FRAMEANGACC, MJH_SENS_SUBTREECOM, MJH_SENS_SUBTREELINVEL, MJH_SENS_SUBTREEANGMOM, MJH_SENS_CLOCK,
+  MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
+  MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH,
+  MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
@@ -490,6 +520,7 @@ enum {
   MJH_STAGE_ACTUATION  = 1<<7,   // actuation + acceleration
   MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint (solve)
   MJH_STAGE_REFERENCE  = 1<<11,  // mj_referenceConstraint (efc_vel, efc_aref)
+  MJH_STAGE_SENSOR     = 1<<12,  // mj_sensorPos/Vel/Acc (not part of MJH_STAGE_ALL: RK4 sub-steps skip it)
   MJH_STAGE_IFACTIVE   = 1<<22,  // pipeline flag: skip environments whose `active` flag is 0
   MJH_STAGE_FINISH     = 1<<10,  // qacc = M^-1 qfrc_constraint + qacc_smooth (tail of fwdConstraint)
   MJH_STAGE_ALL        = ((1<<9) - 1) | (1<<10) | (1<<11),
@@ -516,6 +547,7 @@ struct RolloutArgs {
   const real* warmstart0;  // [nenv][nv]            or null -> zeros
   const real* control;     // [nenv][nstep][ncontrol] or null
   real* state;             // [nenv][nstep][nstate] or null
+  real* sensordata;        // [nenv][nstep][nsensordata] or null
   int env_offset;          // first env of this launch inside state0/control/state
 };
 

@@ -294,3 +294,59 @@ ACT_XML = """
   </actuator>
 </mujoco>
 """
+
+
+# sensors: every kind the GPU path evaluates, on a model with contacts, a weld, limits, a tendon,
+# a ball joint and a free body (IMU sites on moving bodies, frame sensors with reference frames)
+SENSOR_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50" magnetic="0 -.3 .4"/>
+  <default><geom type="capsule" size=".03" condim="3"/><joint damping=".1"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 .01"/>
+    <site name="world_s" pos=".2 .1 .3" euler="10 20 30"/>
+    <body name="a1" pos="0 0 .6">
+      <joint name="j1" axis="0 1 0" range="-40 40" limited="true"/><geom name="g1" fromto="0 0 0 .25 0 0"/>
+      <site name="imu1" pos=".1 0 .02" euler="0 15 40"/>
+      <body name="a2" pos=".25 0 0">
+        <joint name="j2" type="ball"/><geom fromto="0 0 0 .2 0 0"/>
+        <site name="imu2" pos=".15 .01 0" euler="30 0 0"/>
+        <body name="a3" pos=".2 0 0"><joint name="j3" type="slide" axis="1 0 0" range="-.05 .05" limited="true"/>
+          <geom name="g3" type="sphere" size=".05"/><site name="tip" pos=".05 0 0"/></body>
+      </body>
+    </body>
+    <body name="f1" pos="-.5 0 .08" euler="0 70 20"><freejoint/><geom name="gf" fromto="-.1 0 0 .1 0 0" size=".04"/>
+      <site name="imuf" pos=".05 0 .01" euler="5 10 15"/></body>
+    <body name="f2" pos="-.5 .4 .3"><freejoint/><geom type="sphere" size=".05"/><site name="f2s"/></body>
+    <body name="p1" pos=".3 -.5 .5"><joint name="q1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/>
+      <body pos="0 0 -.2"><joint name="q2" axis="1 0 0" range="-30 30" limited="true"/><geom fromto="0 0 0 0 0 -.2"/><site name="p_end" pos="0 0 -.2"/></body></body>
+  </worldbody>
+  <tendon><fixed name="t1" range="-.2 .2" limited="true"><joint joint="q1" coef="1"/><joint joint="q2" coef=".5"/></fixed></tendon>
+  <equality><weld body1="f2" body2="a1" solref=".02 1"/></equality>
+  <actuator>
+    <motor name="m1" joint="j1" gear="2"/><position name="m2" joint="j3" kp="30"/><motor name="m3" joint="q1" gear=".8"/>
+  </actuator>
+  <sensor>
+    <jointpos joint="j1"/><jointvel joint="j1"/><jointpos joint="j3"/><jointvel joint="q2"/>
+    <tendonpos tendon="t1"/><tendonvel tendon="t1"/>
+    <actuatorpos actuator="m2"/><actuatorvel actuator="m2"/><actuatorfrc actuator="m2"/><actuatorfrc actuator="m1" cutoff=".5"/>
+    <jointactuatorfrc joint="j1"/>
+    <ballquat joint="j2"/><ballangvel joint="j2"/>
+    <jointlimitpos joint="j1"/><jointlimitvel joint="j1"/><jointlimitfrc joint="j1"/>
+    <jointlimitpos joint="j3"/><jointlimitfrc joint="j3"/>
+    <tendonlimitpos tendon="t1"/><tendonlimitvel tendon="t1"/><tendonlimitfrc tendon="t1"/>
+    <framepos objtype="site" objname="tip"/><framepos objtype="body" objname="a3" reftype="site" refname="world_s"/>
+    <framequat objtype="xbody" objname="a2"/><framequat objtype="geom" objname="g1" reftype="body" refname="f1"/>
+    <framexaxis objtype="site" objname="imu1"/><frameyaxis objtype="body" objname="a2" reftype="xbody" refname="a1"/><framezaxis objtype="geom" objname="gf"/>
+    <framelinvel objtype="site" objname="tip"/><frameangvel objtype="body" objname="a3"/>
+    <framelinvel objtype="site" objname="tip" reftype="site" refname="imuf"/><frameangvel objtype="xbody" objname="f1" reftype="body" refname="a2"/>
+    <framelinacc objtype="site" objname="tip"/><frameangacc objtype="body" objname="f1"/>
+    <subtreecom body="a1"/><subtreelinvel body="a1"/><subtreeangmom body="a1"/><subtreeangmom body="p1"/>
+    <clock/>
+    <velocimeter site="imu1"/><gyro site="imu2"/><accelerometer site="imu1"/><accelerometer site="imuf"/>
+    <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
+    <magnetometer site="imu1"/>
+    <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
+  </sensor>
+</mujoco>
+"""

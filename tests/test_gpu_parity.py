@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -286,6 +286,32 @@ def test_stateful_actuators_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
     print("stateful actuators integrator", integrator, "rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL
     assert b.get("warning").sum() == 0
+
+
+def test_sensors_vs_live_oracle(rb, hip_lib, tmp_path):
+    """sensordata of every rollout step: 113 readings of 45 sensors incl. IMU / force / torque"""
+    xml = tmp_path / "sens.xml"
+    xml.write_text(SENSOR_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dmx = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 300
+    ctrl = np.random.default_rng(0).uniform(-3, 3, (1, T, m.nu))
+    sref = np.zeros((1, T, m.nsensordata))
+    ref = np.zeros((1, T, s0.shape[1]))
+    for t in range(T):
+        d.ctrl[:] = ctrl[0, t]
+        rb.mj_step(m, d)
+        ref[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        sref[0, t] = d.sensordata
+    b = K.Batch(dmx, 1)
+    out, sd = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl, want_sensordata=True)
+    print("sensor scene: state rel err", relerr(out, ref), "sensordata rel err", relerr(sd, sref))
+    assert relerr(out, ref) <= TOL
+    assert relerr(sd, sref) <= TOL
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):

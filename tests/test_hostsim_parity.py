@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -378,6 +378,51 @@ def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
     b = K.Batch(dm, 2)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+def _sensor_reference(rb, m, s0, ctrl):
+    d = rb.MjData(m)
+    T = ctrl.shape[1]
+    ref = np.zeros((1, T, s0.shape[1]))
+    sref = np.zeros((1, T, m.nsensordata))
+    rb.mj_resetData(m, d)
+    rb.mj_setState(m, d, s0[0], rb.mjSTATE_FULLPHYSICS)
+    for t in range(T):
+        d.ctrl[:] = ctrl[0, t]
+        rb.mj_step(m, d)
+        ref[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        sref[0, t] = d.sensordata
+    return ref, sref
+
+
+@pytest.mark.parametrize("integrator", [0, 1])
+def test_sensors_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """mj_sensorPos/Vel/Acc (engine_sensor.c:1498-1660) with mj_subtreeVel and mj_rnePostConstraint:
+    joint/tendon/actuator/ball/limit sensors, frame sensors with and without reference frames,
+    subtree COM / velocity / angular momentum, clock, velocimeter, gyro, accelerometer, force,
+    torque, magnetometer, cutoff -- the `sensordata` output of the rollout, every step"""
+    xml = tmp_path / "sens.xml"
+    xml.write_text(SENSOR_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 200
+    ctrl = np.random.default_rng(0).uniform(-3, 3, (1, T, m.nu))
+    ref, sref = _sensor_reference(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out, sd = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl, want_sensordata=True)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(sd, sref)
+    # mj_forward leaves the same readings in the batch's sensordata field
+    rb.mj_setState(m, d, ref[0, -1], rb.mjSTATE_FULLPHYSICS)
+    d.ctrl[:] = ctrl[0, -1]
+    rb.mj_forward(m, d)
+    b.forward()
+    assert relerr(b.get("sensordata")[0], np.array(d.sensordata)) <= 1e-12
 
 
 @pytest.mark.parametrize("integrator", [0, 1, 3])

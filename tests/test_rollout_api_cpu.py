@@ -149,3 +149,33 @@ def test_model_list_and_closed_object(rb, api):                 # rollout_test.p
         np.testing.assert_array_equal(st, ref)
     with pytest.raises(RuntimeError, match="after thread pool shutdown"):
         r.rollout(m, d, s0, ctrl)
+
+
+def test_sensordata_output(rb, hostsim_lib, monkeypatch, tmp_path):   # rollout_test.py: sensordata of every step
+    """a model with sensors: `rollout` returns the per-step sensordata next to the state, and the
+    caller's mjData ends with the last rollout's final readings (rollout.cc:73,:130-133)"""
+    from parity_utils import SENSOR_XML
+    monkeypatch.setattr(mujoco_amd, "lib", lambda: hostsim_lib)
+    xml = tmp_path / "sens.xml"
+    xml.write_text(SENSOR_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    rng = np.random.default_rng(11)
+    nbatch, nstep = 2, 12
+    init = np.tile(s0, (nbatch, 1))
+    init[:, 1 + m.nq:] = rng.normal(0, .3, size=(nbatch, m.nv))
+    ctrl = rng.uniform(-2, 2, size=(nbatch, nstep, m.nu))
+    state, sensordata = rollout.rollout(m, d, init, ctrl)
+    assert sensordata.shape == (nbatch, nstep, m.nsensordata)
+    dd = rb.MjData(m)
+    for r in range(nbatch):
+        rb.mj_resetData(m, dd)
+        rb.mj_setState(m, dd, init[r], rb.mjSTATE_FULLPHYSICS)
+        for t in range(nstep):
+            dd.ctrl[:] = ctrl[r, t]
+            rb.mj_step(m, dd)
+            np.testing.assert_array_equal(state[r, t], rb.mj_getState(m, dd, rb.mjSTATE_FULLPHYSICS))
+            np.testing.assert_array_equal(sensordata[r, t], np.array(dd.sensordata))
+    np.testing.assert_array_equal(np.array(d.sensordata), sensordata[-1, -1])
