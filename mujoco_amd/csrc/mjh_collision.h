@@ -152,6 +152,115 @@ MJH_DEV int col_capsule_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
   return n1 + n2 + n3 + n4;
 }
 
+// mjc_PlaneBox (engine_collision_primitive.c:210-256): corners below the plane, at most 4
+template <class P0, class P1, class P2, class P3, class P4>
+MJH_DEV int col_plane_box(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
+  real norm[3] = {mat1[2], mat1[5], mat1[8]};
+  real dif[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
+  const real dist = v3_dot(dif, norm);
+  int cnt = 0;
+  for (int i = 0; i < 8; i++) {
+    real vec[3], corner[3];
+    vec[0] = (i & 1) ? (real)size2[0] : -(real)size2[0];
+    vec[1] = (i & 2) ? (real)size2[1] : -(real)size2[1];
+    vec[2] = (i & 4) ? (real)size2[2] : -(real)size2[2];
+    m3_mulvec(corner, mat2, vec);
+    const real ldist = v3_dot(norm, corner);
+    if (dist + ldist > margin || ldist > 0) continue;
+    con[cnt].dist = dist + ldist;
+    v3_copy(con[cnt].normal, norm);
+    v3_addto(corner, pos2);
+    v3_scl(vec, norm, -con[cnt].dist / 2);
+    v3_add(con[cnt].pos, corner, vec);
+    v3_zero(con[cnt].tangent);
+    if (++cnt >= 4) return 4;
+  }
+  return cnt;
+}
+
+// mjraw_SphereBox (engine_collision_box.c:35-88)
+template <class P0, class P1, class P2, class P3>
+MJH_DEV int col_sphere_box(PreContact* c, real margin, P0 pos1, real r1, P1 pos2, P2 mat2, P3 size2) {
+  real tmp[3], center[3], clamped[3], deepest[3], pos[3];
+  v3_sub(tmp, pos1, pos2);
+  m3_multvec(center, mat2, tmp);
+  for (int i = 0; i < 3; i++) {
+    clamped[i] = center[i];
+    if (clamped[i] < -size2[i]) clamped[i] = -size2[i];
+    else if (clamped[i] > size2[i]) clamped[i] = size2[i];
+    deepest[i] = center[i];
+  }
+  v3_sub(tmp, clamped, center);
+  real dist = v3_normalize(tmp);
+  if (dist - r1 > margin) return 0;
+  if (dist <= MJH_MINVAL) {
+    // sphere centre inside the box: push out through the nearest face
+    real closest = (size2[0] + size2[1] + size2[2]) * 2;
+    int k = 0;
+    for (int i = 0; i < 6; i++) {
+      const real d = fabs(((i % 2) ? 1 : -1)*size2[i / 2] - center[i / 2]);
+      if (closest > d) { closest = d; k = i; }
+    }
+    real nearest[3] = {0, 0, 0};
+    nearest[k / 2] = (k % 2) ? -1 : 1;
+    v3_copy(pos, center);
+    v3_addtoscl(pos, nearest, (r1 - closest) / 2);
+    m3_mulvec(c->normal, mat2, nearest);
+    dist = -closest;
+  } else {
+    v3_addtoscl(deepest, tmp, r1);
+    v3_zero(pos);
+    v3_addtoscl(pos, clamped, 0.5);
+    v3_addtoscl(pos, deepest, 0.5);
+    m3_mulvec(c->normal, mat2, tmp);
+  }
+  m3_mulvec(tmp, mat2, pos);
+  v3_add(c->pos, tmp, pos2);
+  c->dist = dist - r1;
+  v3_zero(c->tangent);
+  return 1;
+}
+
+// mjc_SphereCylinder (engine_collision_primitive.c:345-421): side / cap / rim cases
+template <class P0, class P1, class P2, class P3, class P4>
+MJH_DEV int col_sphere_cylinder(PreContact* c, real margin, P0 pos1, P1 mat1, real r1, P2 pos2, P3 mat2, P4 size2) {
+  const real radius = size2[0], height = size2[1];
+  real axis[3] = {mat2[2], mat2[5], mat2[8]};
+  real vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  const real x = v3_dot(axis, vec);
+  real a_proj[3], p_proj[3];
+  v3_scl(a_proj, axis, x);
+  v3_sub(p_proj, vec, a_proj);
+  const real p_proj_sqr = v3_dot(p_proj, p_proj);
+  int collide_side = fabs(x) < height;
+  int collide_cap = p_proj_sqr < radius*radius;
+  if (collide_side && collide_cap) {
+    const real dist_cap = height - fabs(x);
+    const real dist_radius = radius - sqrt(p_proj_sqr);
+    if (dist_cap < dist_radius) collide_side = 0; else collide_cap = 0;
+  }
+  if (collide_side) {
+    v3_addto(a_proj, pos2);
+    return col_sphere_sphere(c, margin, pos1, mat1, r1, a_proj, mat2, radius);
+  }
+  if (collide_cap) {
+    real flipmat[9] = {-mat2[0], mat2[1], -mat2[2], -mat2[3], mat2[4], -mat2[5], -mat2[6], mat2[7], -mat2[8]};
+    real capmat[9], pos_cap[3];
+    const real hs = (x > 0) ? height : -height;
+    for (int k = 0; k < 3; k++) pos_cap[k] = pos2[k] + axis[k]*hs;
+    for (int k = 0; k < 9; k++) capmat[k] = (x > 0) ? (real)mat2[k] : flipmat[k];
+    int n = col_plane_sphere(c, margin, pos_cap, capmat, pos1, r1);
+    if (n) { c->normal[0] *= -1; c->normal[1] *= -1; c->normal[2] *= -1; }
+    return n;
+  }
+  // rim: point sphere at the nearest point of the cap's edge
+  v3_scl(p_proj, p_proj, radius / sqrt(p_proj_sqr));
+  v3_scl(vec, axis, x > 0 ? height : -height);
+  v3_addto(vec, p_proj);
+  v3_addto(vec, pos2);
+  return col_sphere_sphere(c, margin, pos1, mat1, r1, vec, mat2, (real)0);
+}
+
 // mjc_PlaneCylinder, engine_collision_primitive.c:101-208 (up to 4 contacts)
 template <class P0, class P1, class P2, class P3, class P4>
 MJH_DEV int col_plane_cylinder(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
@@ -312,6 +421,12 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             n = col_capsule_capsule(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
           case MJH_COL_PLANE_CYLINDER:
             n = col_plane_cylinder(pc, margin, pos1, mat1, pos2, mat2, size2); break;
+          case MJH_COL_PLANE_BOX:
+            n = col_plane_box(pc, margin, pos1, mat1, pos2, mat2, size2); break;
+          case MJH_COL_SPHERE_BOX:
+            n = col_sphere_box(pc, margin, pos1, size1[0], pos2, mat2, size2); break;
+          case MJH_COL_SPHERE_CYLINDER:
+            n = col_sphere_cylinder(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
           case MJH_COL_UNSUPPORTED:
             unsupported = 1; break;
           default: break;

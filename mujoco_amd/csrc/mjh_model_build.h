@@ -112,6 +112,9 @@ static int pair_func(int t1, int t2, int* maxcon) {
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CAPSULE) { *maxcon = 1; return MJH_COL_SPHERE_CAPSULE; }
   if (t1 == mjGEOM_CAPSULE && t2 == mjGEOM_CAPSULE) { *maxcon = 2; return MJH_COL_CAPSULE_CAPSULE; }
   if (t1 == mjGEOM_PLANE && t2 == mjGEOM_CYLINDER) { *maxcon = 4; return MJH_COL_PLANE_CYLINDER; }
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_BOX) { *maxcon = 4; return MJH_COL_PLANE_BOX; }
+  if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_BOX) { *maxcon = 1; return MJH_COL_SPHERE_BOX; }
+  if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CYLINDER) { *maxcon = 1; return MJH_COL_SPHERE_CYLINDER; }
   // convex primitives the reference sends to its GJK/EPA or box routines: the pair stays in the list
   // (so ordering and filtering match) but reaching its narrowphase raises mjhip's UNSUPPORTED warning
   auto prim = [](int t) { return t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER ||

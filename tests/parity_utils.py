@@ -350,3 +350,27 @@ SENSOR_XML = """
   </sensor>
 </mujoco>
 """
+
+
+# plane-box (1..4 corner contacts), sphere-box (outside, and centre inside the box), sphere-cylinder
+# (side, cap and rim cases); the boxes never meet each other or a capsule (those colliders are not
+# on the GPU path yet)
+BOX_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="60"/>
+  <worldbody>
+    <geom type="plane" size="4 4 .01"/>
+    <geom name="table" type="box" size=".3 .3 .05" pos="1.5 0 .05"/>
+    <geom name="pillar" type="cylinder" size=".15 .2" pos="-1.5 0 .2"/>
+    <body pos="0 0 .12" euler="20 35 0"><freejoint/><geom type="box" size=".06 .09 .05" condim="3"/></body>
+    <body pos=".6 0 .051"><freejoint/><geom type="box" size=".1 .1 .05" condim="4"/></body>
+    <body pos="0 .7 .2" euler="44 44 10"><freejoint/><geom type="box" size=".07 .07 .07" condim="1"/></body>
+    <body pos="1.5 .05 .16"><freejoint/><geom type="sphere" size=".06" condim="3"/></body>
+    <body pos="1.78 .1 .1"><freejoint/><geom type="sphere" size=".05" condim="3"/></body>
+    <body pos="1.45 -.1 .08"><freejoint/><geom type="sphere" size=".02" condim="1"/></body>
+    <body pos="-1.5 .02 .465"><freejoint/><geom type="sphere" size=".07" condim="3"/></body>
+    <body pos="-1.29 0 .2"><freejoint/><geom type="sphere" size=".06" condim="3"/></body>
+    <body pos="-1.38 .13 .44"><freejoint/><geom type="sphere" size=".05" condim="1"/></body>
+  </worldbody>
+</mujoco>
+"""

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -378,6 +378,32 @@ def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
     b = K.Batch(dm, 2)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("cone", [0, 1])
+def test_box_and_cylinder_colliders_bit_exact(rb, hostsim_lib, tmp_path, cone):
+    """mjc_PlaneBox (engine_collision_primitive.c:210), mjraw_SphereBox (engine_collision_box.c:35)
+    and mjc_SphereCylinder (engine_collision_primitive.c:345): boxes settling on a plane with 1..4
+    corner contacts, spheres on a box and on / beside / at the rim of a cylinder"""
+    xml = tmp_path / "box.xml"
+    xml.write_text(BOX_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(4).normal(0, .3, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 100
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 0].max() >= 15
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
 def _sensor_reference(rb, m, s0, ctrl):
