@@ -152,6 +152,243 @@ MJH_DEV int col_capsule_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
   return n1 + n2 + n3 + n4;
 }
 
+// ---- box : box (mjc_BoxBox, engine_collision_box.c:697-1066) -------------------------------------
+// separating-axis search over 6 face and 9 edge-cross axes (with the reference's rounding slack,
+// edge bias and face substitution), then either one edge-edge contact at the midpoint of the
+// closest segment points, or the incident face clipped against the reference face (<= 8 contacts)
+#define MJH_BB_SEPEPS 1e-13
+#define MJH_BB_PAREPS 1e-16
+#define MJH_BB_SGNEPS 1e-9
+#define MJH_BB_DUPEPS 1e-14
+#define MJH_BB_EDGEBIAS 1e-6
+#define MJH_BB_MAXVERT 12
+
+// clip the polygon in buffer `cur` of P against sign*v[coord] <= limit; returns the new count and
+// flips *cur when something was clipped (clipHalfPlane, :651-692)
+MJH_DEV int bb_clip(real (*P)[MJH_BB_MAXVERT][3], int* cur, int nin, int coord, real sign, real limit) {
+  real (*in)[3] = P[*cur];
+  real d[MJH_BB_MAXVERT];
+  int all_inside = 1;
+  for (int k = 0; k < nin; k++) {
+    d[k] = sign*in[k][coord] - limit;
+    all_inside &= d[k] <= 0;
+  }
+  if (all_inside) return nin;
+  real (*out)[3] = P[1 - *cur];
+  int nout = 0;
+  for (int k = 0; k < nin; k++) {
+    const int k1 = (k + 1 == nin) ? 0 : k + 1;
+    const real dp = d[k], dq = d[k1];
+    if (dp <= 0 && nout < MJH_BB_MAXVERT) {
+      out[nout][0] = in[k][0]; out[nout][1] = in[k][1]; out[nout][2] = in[k][2];
+      nout++;
+    }
+    if (((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) && nout < MJH_BB_MAXVERT) {
+      const real t = dp / (dp - dq);
+      out[nout][0] = in[k][0] + t*(in[k1][0] - in[k][0]);
+      out[nout][1] = in[k][1] + t*(in[k1][1] - in[k][1]);
+      out[nout][2] = in[k][2] + t*(in[k1][2] - in[k][2]);
+      nout++;
+    }
+  }
+  *cur = 1 - *cur;
+  return nout;
+}
+
+template <class P0, class P1, class P2, class P3, class P4, class P5>
+MJH_DEV int col_box_box(PreContact* con, real margin, P0 pos1_, P1 mat1_, P2 size1_, P3 pos2_, P4 mat2_, P5 size2_) {
+  real pos1[3], pos2[3], mat1[9], mat2[9], size1[3], size2[3];
+  for (int k = 0; k < 3; k++) { pos1[k] = pos1_[k]; pos2[k] = pos2_[k]; size1[k] = size1_[k]; size2[k] = size2_[k]; }
+  for (int k = 0; k < 9; k++) { mat1[k] = mat1_[k]; mat2[k] = mat2_[k]; }
+  real rot[9], rotabs[9], pos21[3], pos12[3], tmp[3];
+  v3_sub(tmp, pos2, pos1);
+  m3_multvec(pos21, mat1, tmp);
+  v3_sub(tmp, pos1, pos2);
+  m3_multvec(pos12, mat2, tmp);
+  // rot = mat1' * mat2 (mju_mulMatTMat3 = mji_mulMatTMat3 order)
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+    rot[3*r + c] = mat1[r]*mat2[c] + mat1[3 + r]*mat2[3 + c] + mat1[6 + r]*mat2[6 + c];
+  for (int k = 0; k < 9; k++) rotabs[k] = fabs(rot[k]);
+
+  const real septol = margin + MJH_BB_SEPEPS*(size1[0] + size1[1] + size1[2] + size2[0] + size2[1] + size2[2]);
+  real sep_best = -MJH_MAXVAL, sep_face = -MJH_MAXVAL;
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const real radius2 = rotabs[3*i+0]*size2[0] + rotabs[3*i+1]*size2[1] + rotabs[3*i+2]*size2[2];
+    const real sep = fabs(pos21[i]) - size1[i] - radius2;
+    if (sep > septol) return 0;
+    if (sep > sep_best) { sep_best = sep; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const real radius1 = rotabs[0+j]*size1[0] + rotabs[3+j]*size1[1] + rotabs[6+j]*size1[2];
+    const real sep = fabs(pos12[j]) - size2[j] - radius1;
+    if (sep > septol) return 0;
+    if (sep > sep_best) { sep_best = sep; code = 3 + j; }
+  }
+  sep_face = sep_best;
+  const int code_face = code;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+      real ax1 = -rot[3*i2+j];
+      real ax2 = rot[3*i1+j];
+      const real norm2 = ax1*ax1 + ax2*ax2;
+      if (norm2 < MJH_BB_PAREPS) continue;
+      const real inv = 1/sqrt(norm2);
+      ax1 *= inv;
+      ax2 *= inv;
+      const real radius1 = size1[i1]*fabs(ax1) + size1[i2]*fabs(ax2);
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const real a2_1 = ax1*rot[3*i1+j1] + ax2*rot[3*i2+j1];
+      const real a2_2 = ax1*rot[3*i1+j2] + ax2*rot[3*i2+j2];
+      const real radius2 = size2[j1]*fabs(a2_1) + size2[j2]*fabs(a2_2);
+      const real sep = fabs(ax1*pos21[i1] + ax2*pos21[i2]) - radius1 - radius2;
+      if (sep > septol) return 0;
+      if (sep - MJH_BB_EDGEBIAS*fabs(sep) > sep_best && sep > sep_face) { sep_best = sep; code = 6 + 3*i + j; }
+    }
+  }
+  if (code < 0) return 0;
+
+  // an edge axis nearly parallel to the best face axis gives way to the face (:806-826)
+  if (code >= 6) {
+    const int i = (code - 6) / 3, j = (code - 6) % 3;
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    real axis[3];
+    axis[i] = 0; axis[i1] = -rot[3*i2+j]; axis[i2] = rot[3*i1+j];
+    v3_normalize(axis);
+    real face_dot;
+    if (code_face < 3) face_dot = fabs(axis[code_face]);
+    else { const int f = code_face - 3; face_dot = fabs(axis[0]*rot[0+f] + axis[1]*rot[3+f] + axis[2]*rot[6+f]); }
+    if (face_dot > 0.99 && sep_best < sep_face + 0.05*fabs(sep_face) + MJH_MINVAL) { code = code_face; sep_best = sep_face; }
+  }
+
+  // ---- edge-edge contact (:830-945)
+  if (code >= 6) {
+    const int i = (code - 6) / 3, j = (code - 6) % 3;
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    real axis[3];
+    axis[i] = 0; axis[i1] = -rot[3*i2+j]; axis[i2] = rot[3*i1+j];
+    v3_normalize(axis);
+    if (v3_dot(axis, pos21) < 0) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; }
+    real a2[3] = {axis[0]*rot[0+0] + axis[1]*rot[3+0] + axis[2]*rot[6+0],
+                  axis[0]*rot[0+1] + axis[1]*rot[3+1] + axis[2]*rot[6+1],
+                  axis[0]*rot[0+2] + axis[1]*rot[3+2] + axis[2]*rot[6+2]};
+    int amb1 = -1, amb2 = -1;
+    if (fabs(axis[i1]) < MJH_BB_SGNEPS) amb1 = i1; else if (fabs(axis[i2]) < MJH_BB_SGNEPS) amb1 = i2;
+    if (fabs(a2[j1]) < MJH_BB_SGNEPS) amb2 = j1; else if (fabs(a2[j2]) < MJH_BB_SGNEPS) amb2 = j2;
+    real d2[3] = {rot[0+j], rot[3+j], rot[6+j]};
+    const real b = d2[i];
+    const real denom = 1 - b*b;
+    real w1[3] = {0, 0, 0}, w2[3] = {0, 0, 0};
+    real best_d2 = MJH_MAXVAL;
+    for (int v1 = 0; v1 < (amb1 >= 0 ? 2 : 1); v1++) {
+      for (int v2 = 0; v2 < (amb2 >= 0 ? 2 : 1); v2++) {
+        real c1[3], cc[3], c2[3], ev[3];
+        c1[i] = 0;
+        c1[i1] = axis[i1] >= 0 ? size1[i1] : -size1[i1];
+        c1[i2] = axis[i2] >= 0 ? size1[i2] : -size1[i2];
+        if (amb1 >= 0 && v1) c1[amb1] = -c1[amb1];
+        cc[j] = 0;
+        cc[j1] = a2[j1] >= 0 ? -size2[j1] : size2[j1];
+        cc[j2] = a2[j2] >= 0 ? -size2[j2] : size2[j2];
+        if (amb2 >= 0 && v2) cc[amb2] = -cc[amb2];
+        m3_mulvec(c2, rot, cc);
+        v3_addto(c2, pos21);
+        v3_sub(ev, c2, c1);
+        const real d1e = ev[i];
+        const real d2e = v3_dot(d2, ev);
+        real sp = denom < MJH_MINVAL ? 0 : (d1e - b*d2e) / denom;
+        sp = r_clip(sp, -size1[i], size1[i]);
+        const real tp = r_clip(b*sp - d2e, -size2[j], size2[j]);
+        sp = r_clip(d1e + b*tp, -size1[i], size1[i]);
+        real p1[3] = {c1[0], c1[1], c1[2]}, p2[3] = {c2[0], c2[1], c2[2]}, gap[3];
+        p1[i] += sp;
+        v3_addtoscl(p2, d2, tp);
+        v3_sub(gap, p2, p1);
+        const real gap2 = v3_dot(gap, gap);
+        if (gap2 < best_d2) { best_d2 = gap2; v3_copy(w1, p1); v3_copy(w2, p2); }
+      }
+    }
+    real gap[3];
+    v3_sub(gap, w2, w1);
+    const real dist = v3_dot(gap, axis);
+    if (dist > septol) return 0;
+    real mid[3] = {0.5*(w1[0] + w2[0]), 0.5*(w1[1] + w2[1]), 0.5*(w1[2] + w2[2])};
+    con[0].dist = dist;
+    m3_mulvec(tmp, mat1, mid);
+    v3_add(con[0].pos, tmp, pos1);
+    m3_mulvec(con[0].normal, mat1, axis);
+    v3_zero(con[0].tangent);
+    return 1;
+  }
+
+  // ---- face contact: clip the incident face against the reference face (:949-1066)
+  const int ref1 = code < 3;
+  const int a = ref1 ? code : code - 3;
+  const real* sizeref = ref1 ? size1 : size2;
+  const real* sizeinc = ref1 ? size2 : size1;
+  const real* posref = ref1 ? pos1 : pos2;
+  const real* matref = ref1 ? mat1 : mat2;
+  const real* posoi = ref1 ? pos21 : pos12;
+  real rinc[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rinc[3*r + c] = ref1 ? rot[3*r + c] : rot[3*c + r];
+  const real sgn = posoi[a] >= 0 ? 1 : -1;
+  int binc = 0;
+  for (int k = 1; k < 3; k++) if (fabs(rinc[3*a+k]) > fabs(rinc[3*a+binc])) binc = k;
+  const real tinc = sgn*rinc[3*a+binc] > 0 ? -1 : 1;
+  const int ax = (a + 1) % 3, ay = (a + 2) % 3, bu = (binc + 1) % 3, bv = (binc + 2) % 3;
+  real poly[2][MJH_BB_MAXVERT][3];
+  real cx[3], du[3], dv[3];
+  for (int r = 0; r < 3; r++) {
+    const int c = r == 0 ? ax : (r == 1 ? ay : a);
+    cx[r] = posoi[c] + tinc*sizeinc[binc]*rinc[3*c+binc];
+    du[r] = sizeinc[bu]*rinc[3*c+bu];
+    dv[r] = sizeinc[bv]*rinc[3*c+bv];
+  }
+  cx[2] = sgn*cx[2] - sizeref[a];
+  du[2] *= sgn;
+  dv[2] *= sgn;
+  for (int k = 0; k < 4; k++) {
+    const real su = (k == 0 || k == 3) ? 1 : -1, sv = (k < 2) ? 1 : -1;
+    poly[0][k][0] = cx[0] + su*du[0] + sv*dv[0];
+    poly[0][k][1] = cx[1] + su*du[1] + sv*dv[1];
+    poly[0][k][2] = cx[2] + su*du[2] + sv*dv[2];
+  }
+  int nvert = 4, cur = 0;
+  nvert = bb_clip(poly, &cur, nvert, 0, 1, sizeref[ax]);
+  nvert = bb_clip(poly, &cur, nvert, 0, -1, sizeref[ax]);
+  nvert = bb_clip(poly, &cur, nvert, 1, 1, sizeref[ay]);
+  nvert = bb_clip(poly, &cur, nvert, 1, -1, sizeref[ay]);
+  real accepted[MJH_BB_MAXVERT][3];
+  int naccept = 0;
+  const real dupe2 = MJH_BB_DUPEPS*(sizeref[ax]*sizeref[ax] + sizeref[ay]*sizeref[ay]);
+  for (int k = 0; k < nvert; k++) {
+    if (poly[cur][k][2] > margin) continue;
+    int dupe = 0;
+    for (int q = 0; q < naccept; q++) {
+      const real dx = accepted[q][0] - poly[cur][k][0];
+      const real dy = accepted[q][1] - poly[cur][k][1];
+      if (dx*dx + dy*dy < dupe2) { dupe = 1; break; }
+    }
+    if (!dupe) { accepted[naccept][0] = poly[cur][k][0]; accepted[naccept][1] = poly[cur][k][1]; accepted[naccept][2] = poly[cur][k][2]; naccept++; }
+  }
+  if (naccept == 0) return 0;
+  const real nsign = ref1 ? sgn : -sgn;
+  real normal[3] = {nsign*matref[3*0+a], nsign*matref[3*1+a], nsign*matref[3*2+a]};
+  for (int k = 0; k < naccept; k++) {
+    real posc[3];
+    posc[ax] = accepted[k][0];
+    posc[ay] = accepted[k][1];
+    posc[a] = sgn*(sizeref[a] + 0.5*accepted[k][2]);
+    con[k].dist = accepted[k][2];
+    m3_mulvec(tmp, matref, posc);
+    v3_add(con[k].pos, tmp, posref);
+    v3_copy(con[k].normal, normal);
+    v3_zero(con[k].tangent);
+  }
+  return naccept;
+}
+
 // mjc_PlaneBox (engine_collision_primitive.c:210-256): corners below the plane, at most 4
 template <class P0, class P1, class P2, class P3, class P4>
 MJH_DEV int col_plane_box(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
@@ -399,7 +636,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   int overflow = 0;
   for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
     int p = p0 + wv_lane();
-    PreContact pc[4];
+    PreContact pc[8];
     int n = 0;
     int unsupported = 0;
     if (p < s.npair) {
@@ -425,6 +662,8 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             n = col_plane_box(pc, margin, pos1, mat1, pos2, mat2, size2); break;
           case MJH_COL_SPHERE_BOX:
             n = col_sphere_box(pc, margin, pos1, size1[0], pos2, mat2, size2); break;
+          case MJH_COL_BOX_BOX:
+            n = col_box_box(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
           case MJH_COL_SPHERE_CYLINDER:
             n = col_sphere_cylinder(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
           case MJH_COL_UNSUPPORTED:

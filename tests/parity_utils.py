@@ -374,3 +374,25 @@ BOX_XML = """
   </worldbody>
 </mujoco>
 """
+
+
+# box-box: a box resting on a static table (face manifold, 4 points), a rotated box on it (clipped
+# polygon), a stack of two free boxes, an edge-on-edge crossing and a corner-into-face landing
+BOXBOX_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="60"/>
+  <worldbody>
+    <geom type="plane" size="4 4 .01"/>
+    <geom name="table" type="box" size=".4 .4 .05" pos="0 0 .3"/>
+    <geom name="bar" type="box" size=".5 .03 .03" pos="1.5 0 .3" euler="0 0 20"/>
+    <body pos="-.15 -.1 .401"><freejoint/><geom type="box" size=".08 .06 .05" condim="3"/></body>
+    <body pos=".2 .15 .405" euler="0 0 33"><freejoint/><geom type="box" size=".07 .1 .05" condim="3"/>
+      </body>
+    <body pos=".2 .15 .505" euler="0 0 10"><freejoint/><geom type="box" size=".05 .05 .05" condim="4"/></body>
+    <body pos="1.5 0 .37" euler="90 0 80"><freejoint/><geom type="box" size=".03 .03 .3" condim="3"/></body>
+    <body pos="-.2 .2 .49" euler="40 35 10"><freejoint/><geom type="box" size=".06 .06 .06" condim="1"/></body>
+    <body pos="-1 0 .051"><freejoint/><geom type="box" size=".2 .2 .05" condim="3"/></body>
+    <body pos="-1.05 .02 .152" euler="0 0 45"><freejoint/><geom type="box" size=".1 .1 .05" condim="3"/></body>
+  </worldbody>
+</mujoco>
+"""

@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -306,6 +306,28 @@ def test_box_and_cylinder_colliders_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     b = K.Batch(dmb, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("box scene cone", cone, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("cone", [0, 1])
+def test_box_box_collider_vs_live_oracle(rb, hip_lib, tmp_path, cone):
+    """box-box stacks and crossings, up to 29 simultaneous contacts"""
+    xml = tmp_path / "boxbox.xml"
+    xml.write_text(BOXBOX_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    dmb = K.DeviceModel(hip_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(4).normal(0, .3, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 250
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmb, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("box-box scene cone", cone, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
     assert relerr(out, ref) <= TOL
     assert b.get("warning").sum() == 0
 
