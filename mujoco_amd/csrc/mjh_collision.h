@@ -195,11 +195,10 @@ MJH_DEV int bb_clip(real (*P)[MJH_BB_MAXVERT][3], int* cur, int nin, int coord, 
   return nout;
 }
 
-template <class P0, class P1, class P2, class P3, class P4, class P5>
-MJH_DEV int col_box_box(PreContact* con, real margin, P0 pos1_, P1 mat1_, P2 size1_, P3 pos2_, P4 mat2_, P5 size2_) {
-  real pos1[3], pos2[3], mat1[9], mat2[9], size1[3], size2[3];
-  for (int k = 0; k < 3; k++) { pos1[k] = pos1_[k]; pos2[k] = pos2_[k]; size1[k] = size1_[k]; size2[k] = size2_[k]; }
-  for (int k = 0; k < 9; k++) { mat1[k] = mat1_[k]; mat2[k] = mat2_[k]; }
+// out of line: its polygon buffers stay out of stage_collision's frame; g = {pos1[3], mat1[9],
+// size1[3], pos2[3], mat2[9], size2[3]} copied by the caller
+MJH_DEVN int col_box_box_impl(PreContact* con, real margin, const real* g) {
+  const real *pos1 = g, *mat1 = g + 3, *size1 = g + 12, *pos2 = g + 15, *mat2 = g + 18, *size2 = g + 27;
   real rot[9], rotabs[9], pos21[3], pos12[3], tmp[3];
   v3_sub(tmp, pos2, pos1);
   m3_multvec(pos21, mat1, tmp);
@@ -387,6 +386,14 @@ MJH_DEV int col_box_box(PreContact* con, real margin, P0 pos1_, P1 mat1_, P2 siz
     v3_zero(con[k].tangent);
   }
   return naccept;
+}
+
+template <class P0, class P1, class P2, class P3, class P4, class P5>
+MJH_DEV int col_box_box(PreContact* con, real margin, P0 pos1, P1 mat1, P2 size1, P3 pos2, P4 mat2, P5 size2) {
+  real g[30];
+  for (int k = 0; k < 3; k++) { g[k] = pos1[k]; g[12 + k] = size1[k]; g[15 + k] = pos2[k]; g[27 + k] = size2[k]; }
+  for (int k = 0; k < 9; k++) { g[3 + k] = mat1[k]; g[18 + k] = mat2[k]; }
+  return col_box_box_impl(con, margin, g);
 }
 
 // mjc_PlaneBox (engine_collision_primitive.c:210-256): corners below the plane, at most 4
