@@ -144,7 +144,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
 
   // ---------------- feature gate ------------------------------------------------------------------
   MJH_REJECT(m->nv == 0, "model without degrees of freedom");
-  MJH_REJECT(m->nmocap > 0, "mocap bodies");
   for (int i = 0; i < m->neq; i++) {
     MJH_REJECT(m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT &&
                m->eq_type[i] != mjEQ_TENDON, "flex equality constraints");
@@ -645,6 +644,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int c : H->pair_dim)
     rows_per_con = std::max(rows_per_con, c == 1 ? 1 : (m->opt.cone == mjCONE_PYRAMIDAL ? 2*(c-1) : c));
   // ---- sensors (engine_sensor.c): kinds translated to the device enum, frame objects to MJH_OBJ_*
+  s.nmocap = m->nmocap;
   s.nsensor = m->nsensor;
   s.nsensordata = m->nsensordata;
   s.nbody_sens = m->nsensor ? m->nbody : 0;

@@ -532,7 +532,8 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   RolloutArgs A;
   memset(&A, 0, sizeof(A));
   A.nstep = nstep;
-  A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied
+  A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied / mocap poses
+  A.mpos_off = 0; A.mquat_off = 0;
   A.init = 0;
   bool ok = true;
   if (Bt->soa) {
@@ -545,16 +546,23 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
 }
 
 // mjtState bits (include/mujoco/mjtype.h:504-527)
-static int control_size(const DSizes& s, unsigned spec, int* qfrc_off, std::string* err) {
-  const unsigned supported = mjSTATE_CTRL | mjSTATE_QFRC_APPLIED;
+// layout of one control vector = the mjtState bit order of mj_getState (engine_support.c:214)
+static int control_size(const DSizes& s, unsigned spec, int* qfrc_off, int* mpos_off, int* mquat_off,
+                        std::string* err) {
+  const unsigned supported = mjSTATE_CTRL | mjSTATE_QFRC_APPLIED | mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT;
   if (spec & ~supported) {
-    *err = "mjhip: control_spec bits other than mjSTATE_CTRL | mjSTATE_QFRC_APPLIED are not supported";
+    *err = "mjhip: control_spec bits other than mjSTATE_CTRL | mjSTATE_QFRC_APPLIED | mjSTATE_MOCAP_POS | "
+           "mjSTATE_MOCAP_QUAT are not supported";
     return -1;
   }
   int n = 0;
   if (spec & mjSTATE_CTRL) n += s.nu;
   *qfrc_off = n;
   if (spec & mjSTATE_QFRC_APPLIED) n += s.nv;
+  *mpos_off = (spec & mjSTATE_MOCAP_POS) ? n : -1;
+  if (spec & mjSTATE_MOCAP_POS) n += 3*s.nmocap;
+  *mquat_off = (spec & mjSTATE_MOCAP_QUAT) ? n : -1;
+  if (spec & mjSTATE_MOCAP_QUAT) n += 4*s.nmocap;
   return n;
 }
 
@@ -579,8 +587,8 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned co
   if (sensordata && Bt->soa) { set_err("mjhip_batch_rollout: sensordata needs the AoS (wave-per-environment) layout"); return -2; }
   const DSizes& s = Bt->model->H.s;
   std::string err;
-  int qfrc_off = 0;
-  int ncontrol = control_size(s, control_spec, &qfrc_off, &err);
+  int qfrc_off = 0, mpos_off = -1, mquat_off = -1;
+  int ncontrol = control_size(s, control_spec, &qfrc_off, &mpos_off, &mquat_off, &err);
   if (ncontrol < 0) { set_err(err); return -2; }
   const size_t nenv = Bt->nenv;
   RolloutArgs A;
@@ -590,6 +598,7 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned co
   A.has_qfrc = (control_spec & mjSTATE_QFRC_APPLIED) ? 1 : 0;
   A.ncontrol = ncontrol;
   A.qfrc_off = qfrc_off;
+  A.mpos_off = mpos_off; A.mquat_off = mquat_off;
   A.init = (on_device & MJHIP_ROLLOUT_CONTINUE) ? 0 : 1;
   on_device &= MJHIP_ROLLOUT_ON_DEVICE;
   std::vector<void*> tmp;

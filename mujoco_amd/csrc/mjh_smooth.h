@@ -78,8 +78,17 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
         v3_copy(xaxis + 3*jntadr, M.jnt_axis + 3*jntadr);
       } else {
         int pid = M.body_parentid[i];
-        auto bpos = M.body_pos + 3*i;
-        auto bquat = M.body_quat + 4*i;
+        // body pose in the parent: from the model, or the user-driven mocap arrays (:84-93)
+        real bpos[3], bquat[4];
+        const int mid = M.body_mocapid[i];
+        if (mid >= 0) {
+          v3_copy(bpos, MJH_G(B, mocap_pos, e) + 3*mid);
+          q_copy(bquat, MJH_G(B, mocap_quat, e) + 4*mid);
+          q_normalize(bquat);
+        } else {
+          v3_copy(bpos, M.body_pos + 3*i);
+          q_copy(bquat, M.body_quat + 4*i);
+        }
         if (pid) {
           m3_mulvec(pos, xmat + 9*pid, bpos);
           v3_addto(pos, xpos + 3*pid);

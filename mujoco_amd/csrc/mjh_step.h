@@ -3,6 +3,20 @@
 // (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
 
+// mocap poses back to the model's body_pos / body_quat (mj_resetData, engine_io.c)
+MJH_DEV void reset_mocap(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!s.nmocap) return;
+  rptr mp = MJH_G(B, mocap_pos, e);
+  rptr mq = MJH_G(B, mocap_quat, e);
+  MJH_FOR_LANES(i, s.nbody) {
+    const int mid = M.body_mocapid[i];
+    if (mid < 0) continue;
+    for (int k = 0; k < 3; k++) mp[3*mid + k] = M.body_pos[3*i + k];
+    for (int k = 0; k < 4; k++) mq[4*mid + k] = M.body_quat[4*i + k];
+  }
+}
+
 // mj_resetData as far as the state vector is concerned (engine_io.c:1289-1420)
 MJH_DEV void reset_env(MREF M, BREF B, int e) {
   const MJH_CONST_AS DSizes& s = M.s;
@@ -20,6 +34,7 @@ MJH_DEV void reset_env(MREF M, BREF B, int e) {
   MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
   iptr eqa = MJH_G(B, eq_active, e);
   MJH_FOR_LANES(i, s.neq) eqa[i] = M.eq_active0[i];
+  reset_mocap(M, B, e);
   iptr warn = MJH_F(B, warning, e);
   if (wv_lane() == 0) {
     MJH_F(B, time, e)[0] = 0;
@@ -617,6 +632,10 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
     if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
     if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
+    if (A.mpos_off < 0 || A.mquat_off < 0) {
+      // mocap inputs that are not part of the control spec are reset (rollout.cc:85-115)
+      reset_mocap(M, B, e);
+    }
     wv_sync();
   }
   ciptr warn = MJH_F(B, warning, e);
@@ -633,6 +652,8 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
         const real* u = A.control + step*A.ncontrol;
         if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
         if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
+        if (A.mpos_off >= 0) { rptr p = MJH_G(B, mocap_pos, e); MJH_FOR_LANES(i, 3*s.nmocap) p[i] = u[A.mpos_off + i]; }
+        if (A.mquat_off >= 0) { rptr q = MJH_G(B, mocap_quat, e); MJH_FOR_LANES(i, 4*s.nmocap) q[i] = u[A.mquat_off + i]; }
         wv_sync();
       }
       step_env(M, B, e);

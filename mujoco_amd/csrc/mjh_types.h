@@ -192,6 +192,7 @@ struct DSizes {
   int nefcmax;     // per-env constraint-row capacity
   int nstate;      // mj_stateSize(FULLPHYSICS)
   int nsensor, nsensordata;
+  int nmocap;
   int nbody_sens;  // nbody when the model has sensors (cacc / cfrc / subtree velocity arrays), else 0
   int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
   int npgsorder;   // entries of the precomputed PGS visitation-order table
@@ -252,6 +253,8 @@ enum {
   X(qvel, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                                     \
   X(act, s.na, s.na, MJH_T_BEGIN, MJH_T_END)                                      \
   X(act_dot, s.na, s.na, MJH_T_ACTUATION, MJH_T_END)                              \
+  X(mocap_pos, 3 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(mocap_quat, 4 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(ctrl, s.nu, s.nu, MJH_T_BEGIN, MJH_T_END)                                     \
   X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \
   X(qacc_warmstart, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                           \
@@ -542,6 +545,7 @@ struct RolloutArgs {
   int has_qfrc;            // control_spec contains mjSTATE_QFRC_APPLIED
   int ncontrol;            // mj_stateSize(control_spec)
   int qfrc_off;            // offset of qfrc_applied inside one control vector
+  int mpos_off, mquat_off; // offsets of mocap_pos / mocap_quat inside one control vector, -1: absent
   int init;                // 1: load state0/warmstart0, clear warnings (start of a rollout)
   int t0;                  // (per-step kernels) index of this step inside control/state
   const real* state0;      // [nenv][nstate]        or null

@@ -396,3 +396,23 @@ BOXBOX_XML = """
   </worldbody>
 </mujoco>
 """
+
+
+# mocap bodies: a gripper-like box welded to a mocap target that the control array moves
+# (mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT in the control spec), a second mocap body carrying a
+# collision geom that pushes a free sphere around
+MOCAP_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="target" mocap="true" pos="0 0 .4" quat="1 0 0 0"><geom type="sphere" size=".02" contype="0" conaffinity="0"/></body>
+    <body name="paddle" mocap="true" pos=".6 0 .06" euler="0 0 20"><geom type="box" size=".02 .2 .05"/></body>
+    <body name="hand" pos="0 0 .35"><freejoint/><geom type="box" size=".05 .04 .03"/>
+      <body pos="0 0 -.06"><joint name="finger" type="slide" axis="0 1 0" range="-.03 .03" limited="true" damping="1"/><geom type="capsule" size=".01 .02"/></body></body>
+    <body pos=".75 .05 .05"><freejoint/><geom type="sphere" size=".05" condim="3"/></body>
+  </worldbody>
+  <equality><weld body1="hand" body2="target" solref=".02 1"/></equality>
+  <actuator><position joint="finger" kp="20"/></actuator>
+</mujoco>
+"""

@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -332,6 +332,31 @@ def test_box_box_collider_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     assert b.get("warning").sum() == 0
 
 
+def test_mocap_bodies_vs_live_oracle(rb, hip_lib, tmp_path):
+    """mocap poses supplied through the control array (mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT)"""
+    from test_hostsim_parity import _mocap_controls
+    xml = tmp_path / "mocap.xml"
+    xml.write_text(MOCAP_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dmm = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 200
+    spec = K.mjSTATE_CTRL | K.mjSTATE_MOCAP_POS | K.mjSTATE_MOCAP_QUAT
+    ctrl = _mocap_controls(m, T)
+    ref = np.zeros((1, T, s0.shape[1]))
+    for t in range(T):
+        rb.mj_setState(m, d, ctrl[0, t], spec)
+        rb.mj_step(m, d)
+        ref[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b = K.Batch(dmm, 1)
+    out = b.rollout_host(T, spec, s0, None, ctrl)
+    print("mocap scene rel err", relerr(out, ref))
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+
+
 def test_sensors_vs_live_oracle(rb, hip_lib, tmp_path):
     """sensordata of every rollout step: 113 readings of 45 sensors incl. IMU / force / torque"""
     xml = tmp_path / "sens.xml"
@@ -356,6 +381,40 @@ def test_sensors_vs_live_oracle(rb, hip_lib, tmp_path):
     print("sensor scene: state rel err", relerr(out, ref), "sensordata rel err", relerr(sd, sref))
     assert relerr(out, ref) <= TOL
     assert relerr(sd, sref) <= TOL
+
+
+@pytest.mark.parametrize("scene", ["sensor", "boxbox", "equality"])
+def test_batched_feature_scenes_vs_live_oracle(rb, hip_lib, tmp_path, scene):
+    """many environments of the feature scenes at once (different initial velocities and controls
+    per environment): per-environment indexing of every new field, sensordata included"""
+    xml = tmp_path / "scene.xml"
+    xml.write_text({"sensor": SENSOR_XML, "boxbox": BOXBOX_XML, "equality": EQ_XML}[scene])
+    m = rb.MjModel.from_xml_path(str(xml))
+    dmx = K.DeviceModel(hip_lib, m, 64, 200)
+    nenv, T = 48, 40
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = np.tile(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS), (nenv, 1))
+    rng = np.random.default_rng(21)
+    s0[:, 1 + m.nq:1 + m.nq + m.nv] = rng.normal(0, .4, (nenv, m.nv))
+    ctrl = rng.uniform(-2, 2, (nenv, T, m.nu))
+    ref = np.zeros((nenv, T, s0.shape[1]))
+    sref = np.zeros((nenv, T, m.nsensordata))
+    for e in range(nenv):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
+        for t in range(T):
+            d.ctrl[:] = ctrl[e, t]
+            rb.mj_step(m, d)
+            ref[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+            sref[e, t] = d.sensordata
+    b = K.Batch(dmx, nenv)
+    out, sd = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl, want_sensordata=True)
+    print("batched", scene, "state rel err", relerr(out, ref), "sensordata rel err", relerr(sd, sref) if sref.size else 0.0)
+    assert relerr(out, ref) <= TOL
+    if sref.size:
+        assert relerr(sd, sref) <= TOL
+    assert b.get("warning").sum() == 0
 
 
 def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):

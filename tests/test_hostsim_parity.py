@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -430,6 +430,51 @@ def test_box_box_collider_bit_exact(rb, hostsim_lib, tmp_path, cone):
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+def _mocap_controls(m, T):
+    ctrl = np.zeros((1, T, m.nu + 7*m.nmocap))
+    for t in range(T):
+        ctrl[0, t, 0] = 0.02*np.sin(t/7)
+        ctrl[0, t, 1:4] = [.1*np.sin(t/20), .05*t/T, .4 + .05*np.cos(t/15)]
+        ctrl[0, t, 4:7] = [.6 + .3*t/T, .02*np.sin(t/9), .06]
+        ctrl[0, t, 7:11] = [1, .1*np.sin(t/11), 0, .2*t/T]        # not normalised on purpose
+        ctrl[0, t, 11:15] = [np.cos(.2 + t/60), 0, 0, np.sin(.2 + t/60)]
+    return ctrl
+
+
+def test_mocap_bodies_bit_exact(rb, hostsim_lib, tmp_path):
+    """mocap bodies (mj_kinematics, engine_core_smooth.c:84-93) driven through mjSTATE_MOCAP_POS |
+    mjSTATE_MOCAP_QUAT in the control spec of the rollout; a weld to a mocap target and a mocap
+    paddle pushing a sphere.  A second rollout without the mocap bits sees the model's poses again
+    (inputs outside the control spec are reset, rollout.cc:85-115)."""
+    xml = tmp_path / "mocap.xml"
+    xml.write_text(MOCAP_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80
+    spec = K.mjSTATE_CTRL | K.mjSTATE_MOCAP_POS | K.mjSTATE_MOCAP_QUAT
+    ctrl = _mocap_controls(m, T)
+    ref = np.zeros((1, T, s0.shape[1]))
+    for t in range(T):
+        rb.mj_setState(m, d, ctrl[0, t], spec)
+        rb.mj_step(m, d)
+        ref[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, spec, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    rb.mj_resetData(m, d)
+    ref2 = np.zeros((1, T, s0.shape[1]))
+    for t in range(T):
+        d.ctrl[:] = ctrl[0, t, :m.nu]
+        rb.mj_step(m, d)
+        ref2[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    out2 = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl[:, :, :m.nu].copy())
+    assert np.array_equal(out2, ref2)
+    assert b.get("warning").sum() == 0
 
 
 def _sensor_reference(rb, m, s0, ctrl):
