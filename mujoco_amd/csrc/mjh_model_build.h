@@ -160,7 +160,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->npair > 0, "explicit contact <pair>s");
-  MJH_REJECT(m->ngravcomp > 0 || m->flg_gravcomp, "gravity compensation");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
@@ -171,8 +170,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // runs its sparse code paths.  They compute the same quantities with sums taken over the non-zeros
   // only; this path always evaluates the dense form, so such models agree with the reference to
   // rounding (not bit for bit) -- the parity tests hold them to the 1e-6 bar.
-  MJH_REJECT(m->opt.enableflags & (mjENBL_SLEEP | mjENBL_DIAGEXACT | mjENBL_FWDINV | mjENBL_ENERGY),
-             "enable flags sleep/diagexact/fwdinv/energy");
+  // mjENBL_ENERGY and mjENBL_FWDINV only fill diagnostics (d->energy, d->solver_fwdinv) that are not
+  // part of the rollout's outputs (energy sensors are rejected with the sensor list): accepted
+  MJH_REJECT(m->opt.enableflags & (mjENBL_SLEEP | mjENBL_DIAGEXACT), "enable flags sleep / diagexact");
   MJH_REJECT(m->opt.density != 0 || m->opt.viscosity != 0, "fluid forces (density/viscosity)");
   MJH_REJECT(m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0, "wind");
   MJH_REJECT(m->nactuator != m->nu, "multi-input actuators (nactuator != nu)");
@@ -339,6 +339,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_ipos, m->body_ipos, 3*m->nbody);
   copy_arr(H->body_iquat, m->body_iquat, 4*m->nbody);
   copy_arr(H->body_mass, m->body_mass, m->nbody);
+  copy_arr(H->body_gravcomp, m->body_gravcomp, m->nbody);
+  o.has_gravcomp = m->flg_gravcomp ? 1 : 0;
   copy_arr(H->body_subtreemass, m->body_subtreemass, m->nbody);
   copy_arr(H->body_inertia, m->body_inertia, 3*m->nbody);
   copy_arr(H->body_invweight0, m->body_invweight0, 2*m->nbody);

@@ -809,6 +809,36 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
   wv_sync();
   MJH_FOR_LANES(i, s.nv) fp[i] = fs[i] + fd[i];
   wv_sync();
+  // gravity compensation (mj_gravcomp, engine_passive.c:846-867 + :1112-1122): per compensated
+  // body a force -gravity*mass*gravcomp at its COM, mapped through the point Jacobian (mj_applyFT)
+  if (M.o.has_gravcomp && !(dsbl & (1<<7)) &&
+      sqrt(M.o.gravity[0]*M.o.gravity[0] + M.o.gravity[1]*M.o.gravity[1] + M.o.gravity[2]*M.o.gravity[2]) != 0) {
+    crptr xipos = MJH_F(B, xipos, e);
+    crptr cdof = MJH_F(B, cdof, e);
+    crptr com = MJH_F(B, subtree_com, e);
+    MJH_FOR_LANES(j, s.nv) {
+      real acc = 0;
+      crptr cd = cdof + 6*j;
+      for (int b = 1; b < s.nbody; b++) {
+        const real gc = M.body_gravcomp[b];
+        if (gc == 0) continue;
+        real t = 0;
+        if ((M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1) {
+          const real scl = -(M.body_mass[b]*gc);
+          real off[3], cr[3];
+          v3_sub(off, xipos + 3*b, com + 3*M.body_rootid[b]);
+          v3_cross(cr, cd, off);
+          for (int r = 0; r < 3; r++) {
+            const real f = M.o.gravity[r]*scl;
+            if (f != 0) t += (cd[3 + r] + cr[r])*f;
+          }
+        }
+        acc += t;
+      }
+      fp[j] += acc;
+    }
+    wv_sync();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -119,6 +119,7 @@
   X(body_iquat, 4 * s.nbody)                   \
   X(body_mass, s.nbody)                        \
   X(body_subtreemass, s.nbody)                 \
+  X(body_gravcomp, s.nbody)                    \
   X(sensor_cutoff, s.nsensor)                  \
   X(body_inertia, 3 * s.nbody)                 \
   X(body_invweight0, 2 * s.nbody)              \
@@ -210,6 +211,7 @@ struct DOptions {
   int disableflags, enableflags;
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_ten_armature;
+  int has_gravcomp;
 };
 
 // (device build: the table pointers are constant-address-space pointers, so a wave-uniform index

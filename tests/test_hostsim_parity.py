@@ -477,6 +477,28 @@ def test_mocap_bodies_bit_exact(rb, hostsim_lib, tmp_path):
     assert b.get("warning").sum() == 0
 
 
+def test_gravity_compensation_and_diagnostic_flags(rb, hostsim_lib, tmp_path):
+    """body gravcomp (mj_gravcomp, engine_passive.c:846-867) with a tilted gravity vector; the model
+    also sets mjENBL_ENERGY | mjENBL_FWDINV, which only fill diagnostics outside the rollout outputs"""
+    xml = tmp_path / "gc.xml"
+    xml.write_text(ACT_XML.replace('<body name="a2" pos=".25 0 0">', '<body name="a2" pos=".25 0 0" gravcomp=".7">')
+                   .replace('<body name="b1" pos="0 .5 .4">', '<body name="b1" pos="0 .5 .4" gravcomp="1">')
+                   .replace('<option timestep="0.004"', '<option gravity=".5 -.3 -9.81" timestep="0.004"'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.enableflags |= (1 << 1) | (1 << 2)
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 60
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+
+
 def _sensor_reference(rb, m, s0, ctrl):
     d = rb.MjData(m)
     T = ctrl.shape[1]
