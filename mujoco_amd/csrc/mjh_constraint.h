@@ -652,6 +652,9 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     real solimp[5];
     for (int q = 0; q < 5; q++) solimp[q] = M.pair_solimp[5*p + q];
     fix_solparam(M, solref, solimp);
+    // solreffriction of a predefined pair (getsolparam :2031-2040: REFSAFE clamp on the time constant)
+    real srf[2] = {M.pair_solreffriction[2*p], M.pair_solreffriction[2*p+1]};
+    if (!(M.o.disableflags & (1<<12)) && srf[0] > 0) srf[0] = r_max(srf[0], 2*M.o.timestep);
     real imp, impP;
     get_impedance(solimp, P.pos[r0], P.margin[r0], &imp, &impP);
     int nrow = (type == MJH_CNSTR_CONTACT_FRICTIONLESS) ? 1 : (type == MJH_CNSTR_CONTACT_PYRAMIDAL ? 2*(dim-1) : dim);
@@ -663,8 +666,10 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         dA = tran + fri[jj]*fri[jj]*(jj < 2 ? tran : rot);
       } else dA = (a < 3 ? tran : rot);
       P.R[r0 + a] = r_max(MJH_MINVAL, (1-imp)*dA/imp);
-      // elliptic friction rows: K = 0 (solreffriction is zero for geom-geom contacts, :2181-2189)
-      set_kbip(P.KBIP + 4*(r0 + a), solref, solimp, imp, impP, type == MJH_CNSTR_CONTACT_ELLIPTIC && a > 0);
+      // elliptic friction rows: K = 0, B from solreffriction when a predefined pair sets it (:2181-2189)
+      const int fric_row = (type == MJH_CNSTR_CONTACT_ELLIPTIC && a > 0);
+      if (fric_row && (srf[0] != 0 || srf[1] != 0)) set_kbip(P.KBIP + 4*(r0 + a), srf, solimp, imp, impP, 1);
+      else set_kbip(P.KBIP + 4*(r0 + a), solref, solimp, imp, impP, fric_row);
     }
     if (type == MJH_CNSTR_CONTACT_ELLIPTIC) {
       // (:2213-2237) R[1] = R[0]/impratio, mu = friction[0]*sqrt(R[1]/R[0]), R[j]*mu[j]^2 = R[1]*mu[1]^2

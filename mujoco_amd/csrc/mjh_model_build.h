@@ -159,7 +159,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
-  MJH_REJECT(m->npair > 0, "explicit contact <pair>s");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
@@ -459,42 +458,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   const int dsbl_filterparent = m->opt.disableflags & mjDSBL_FILTERPARENT;
   const int midphase = !(m->opt.disableflags & mjDSBL_MIDPHASE);
   const int override_ = m->opt.enableflags & mjENBL_OVERRIDE;
-  struct GP { int g1, g2; };
+  struct GP { int g1, g2, ipair; };
   int maxcon_total = 0;
-  for (int b1 = 0; b1 < m->nbody; b1++) {
-    if (!(m->body_contype[b1] || m->body_conaffinity[b1])) continue;
-    for (int b2 = b1 + 1; b2 < m->nbody; b2++) {
-      if (!(m->body_contype[b2] || m->body_conaffinity[b2])) continue;
-      int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
-      int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
-      // filterBodyPair (engine_collision_driver.c:288-319), nothing asleep
-      if (w1 == w2) continue;
-      if (m->body_dofnum[w1] == 0 && m->body_dofnum[w2] == 0) continue;
-      if (!dsbl_filterparent && w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
-      if (filter_bitmask(m->body_contype[b1], m->body_conaffinity[b1],
-                         m->body_contype[b2], m->body_conaffinity[b2])) continue;
-      unsigned sig = ((unsigned)b1 << 16) + (unsigned)b2;
-      bool excluded = false;
-      for (int x = 0; x < m->nexclude; x++) if ((unsigned)m->exclude_signature[x] == sig) excluded = true;
-      if (excluded) continue;
-
-      std::vector<GP> gps;
-      for (int g1 = m->body_geomadr[b1]; g1 < m->body_geomadr[b1] + m->body_geomnum[b1]; g1++) {
-        for (int g2 = m->body_geomadr[b2]; g2 < m->body_geomadr[b2] + m->body_geomnum[b2]; g2++) {
-          if (filter_bitmask(m->geom_contype[g1], m->geom_conaffinity[g1],
-                             m->geom_contype[g2], m->geom_conaffinity[g2])) continue;
-          int a = g1, b = g2;
-          if (m->geom_type[a] > m->geom_type[b]) std::swap(a, b);   // pushGeomGeom
-          if (!ref_collides(m->geom_type[a], m->geom_type[b])) continue;
-          gps.push_back({a, b});
-        }
-      }
-      // midphase route: contacts are sorted by the STORED (type-ordered) geom ids (contactcompare :410-440)
-      bool single = m->body_geomnum[b1] == 1 && m->body_geomnum[b2] == 1;
-      if (!single && midphase && m->body_bvhadr[b1] >= 0 && m->body_bvhadr[b2] >= 0) {
-        std::stable_sort(gps.begin(), gps.end(), [](const GP& x, const GP& y) {
-          return x.g1 != y.g1 ? x.g1 < y.g1 : x.g2 < y.g2; });
-      }
+  // predefined <pair>s are merged into the list in signature order, ahead of their body pair's own
+  // geom pairs (mj_collision, engine_collision_driver.c:651-664); a geom pair that duplicates a
+  // predefined pair of the same body pair is dropped (filterCollisionPair :550-557)
+  int pairadr = 0;
+  auto emit_pairs = [&](const std::vector<GP>& gps) -> bool {
       for (const GP& gp : gps) {
         int g1 = gp.g1, g2 = gp.g2;
         int maxcon = 0;
@@ -535,6 +505,19 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         real friction[5] = {fri[0], fri[0], fri[1], fri[2], fri[2]};
         real margin = m->geom_margin[g1] + m->geom_margin[g2];
         real gap = m->geom_gap[g1] + m->geom_gap[g2];
+        real solreffriction[2] = {0, 0};
+        if (gp.ipair >= 0) {
+          // predefined pair: its own parameters (engine_collision_driver.c:2048-2057, getMargin/getGap :161-175)
+          const int ip = gp.ipair;
+          condim = m->pair_dim[ip];
+          for (int k = 0; k < 2; k++) solref[k] = m->pair_solref[2*ip + k];
+          for (int k = 0; k < 5; k++) solimp[k] = m->pair_solimp[5*ip + k];
+          for (int k = 0; k < 5; k++) friction[k] = m->pair_friction[5*ip + k];
+          for (int k = 0; k < 2; k++) solreffriction[k] = m->pair_solreffriction[2*ip + k];
+          margin = m->pair_margin[ip];
+          gap = m->pair_gap[ip];
+          MJH_REJECT((solreffriction[0] > 0) != (solreffriction[1] > 0), "mixed-sign pair solreffriction");
+        }
         if (override_) {
           // mj_assignMargin/Ref/Imp/Friction (engine_core_constraint.c:177-218)
           margin = m->opt.o_margin;
@@ -553,11 +536,74 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         H->pair_includemargin.push_back(margin);
         for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
         for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
-        for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
+        for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(solreffriction[k]);
         for (int k = 0; k < 5; k++) H->pair_solimp.push_back(solimp[k]);
         maxcon_total += maxcon;
       }
+      return true;
+  };
+  for (int b1 = 0; b1 < m->nbody; b1++) {
+    const bool b1_on = m->body_contype[b1] || m->body_conaffinity[b1];
+    for (int b2 = b1 + 1; b2 < m->nbody; b2++) {
+      const unsigned sig_here = ((unsigned)b1 << 16) + (unsigned)b2;
+      const int startadr = pairadr;
+      {
+        std::vector<GP> ex;
+        for (; pairadr < m->npair && (unsigned)m->pair_signature[pairadr] <= sig_here; pairadr++) {
+          int a = m->pair_geom1[pairadr], b = m->pair_geom2[pairadr];
+          if (m->geom_type[a] > m->geom_type[b]) std::swap(a, b);
+          ex.push_back({a, b, pairadr});
+        }
+        if (!emit_pairs(ex)) return false;
+      }
+      if (!b1_on || !(m->body_contype[b2] || m->body_conaffinity[b2])) continue;
+      int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+      int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+      // filterBodyPair (engine_collision_driver.c:288-319), nothing asleep
+      if (w1 == w2) continue;
+      if (m->body_dofnum[w1] == 0 && m->body_dofnum[w2] == 0) continue;
+      if (!dsbl_filterparent && w1 != 0 && w2 != 0 && (w1 == pw2 || w2 == pw1)) continue;
+      if (filter_bitmask(m->body_contype[b1], m->body_conaffinity[b1],
+                         m->body_contype[b2], m->body_conaffinity[b2])) continue;
+      unsigned sig = ((unsigned)b1 << 16) + (unsigned)b2;
+      bool excluded = false;
+      for (int x = 0; x < m->nexclude; x++) if ((unsigned)m->exclude_signature[x] == sig) excluded = true;
+      if (excluded) continue;
+
+      std::vector<GP> gps;
+      for (int g1 = m->body_geomadr[b1]; g1 < m->body_geomadr[b1] + m->body_geomnum[b1]; g1++) {
+        for (int g2 = m->body_geomadr[b2]; g2 < m->body_geomadr[b2] + m->body_geomnum[b2]; g2++) {
+          if (filter_bitmask(m->geom_contype[g1], m->geom_conaffinity[g1],
+                             m->geom_contype[g2], m->geom_conaffinity[g2])) continue;
+          int a = g1, b = g2;
+          if (m->geom_type[a] > m->geom_type[b]) std::swap(a, b);   // pushGeomGeom
+          if (!ref_collides(m->geom_type[a], m->geom_type[b])) continue;
+          bool dup = false;
+          for (int k = startadr; k < pairadr; k++)
+            if ((unsigned)m->pair_signature[k] == sig_here &&
+                ((m->pair_geom1[k] == g1 && m->pair_geom2[k] == g2) || (m->pair_geom1[k] == g2 && m->pair_geom2[k] == g1))) dup = true;
+          if (dup) continue;
+          gps.push_back({a, b, -1});
+        }
+      }
+      // midphase route: contacts are sorted by the STORED (type-ordered) geom ids (contactcompare :410-440)
+      bool single = m->body_geomnum[b1] == 1 && m->body_geomnum[b2] == 1;
+      if (!single && midphase && m->body_bvhadr[b1] >= 0 && m->body_bvhadr[b2] >= 0) {
+        std::stable_sort(gps.begin(), gps.end(), [](const GP& x, const GP& y) {
+          return x.g1 != y.g1 ? x.g1 < y.g1 : x.g2 < y.g2; });
+      }
+      if (!emit_pairs(gps)) return false;
     }
+  }
+  {
+    // predefined pairs beyond the last body pair
+    std::vector<GP> ex;
+    for (; pairadr < m->npair; pairadr++) {
+      int a = m->pair_geom1[pairadr], b = m->pair_geom2[pairadr];
+      if (m->geom_type[a] > m->geom_type[b]) std::swap(a, b);
+      ex.push_back({a, b, pairadr});
+    }
+    if (!emit_pairs(ex)) return false;
   }
   s.npair = (int)H->pair_geom1.size();
 

@@ -416,3 +416,32 @@ MOCAP_XML = """
   <actuator><position joint="finger" kp="20"/></actuator>
 </mujoco>
 """
+
+
+# predefined contact <pair>s: one that replaces the automatic sphere-plane pair with its own
+# condim / friction / solref / margin, one between parent and child (filtered automatically, active
+# as a pair), one with solreffriction (used by elliptic friction rows) and an <exclude>
+PAIR_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 .01"/>
+    <body name="s1" pos="0 0 .06"><freejoint/><geom name="gs1" type="sphere" size=".05"/></body>
+    <body name="s2" pos=".3 0 .06"><freejoint/><geom name="gs2" type="sphere" size=".05" condim="3"/></body>
+    <body name="c1" pos="-.4 0 .3">
+      <joint name="h1" axis="0 1 0" damping=".05"/><geom name="gc1" type="capsule" fromto="0 0 0 .2 0 0" size=".03"/>
+      <body name="c2" pos=".2 0 0"><joint name="h2" axis="0 1 0" range="-150 150" limited="true" damping=".05"/>
+        <geom name="gc2" type="capsule" fromto="0 0 0 -.15 0 .05" size=".03"/></body>
+    </body>
+    <body name="b1" pos=".8 0 .051"><freejoint/><geom name="gb1" type="box" size=".06 .06 .05"/></body>
+    <body name="s3" pos=".8 0 .16"><freejoint/><geom name="gs3" type="sphere" size=".05"/></body>
+    <body name="s4" pos="1.2 0 .05"><freejoint/><geom name="gs4" type="sphere" size=".05"/></body>
+  </worldbody>
+  <contact>
+    <pair geom1="floor" geom2="gs1" condim="4" friction=".7 .6 .02 .001 .001" solref=".015 1.2" margin=".01" gap=".002"/>
+    <pair geom1="gc2" geom2="gc1" condim="1" solref=".01 1"/>
+    <pair geom1="gs3" geom2="gb1" condim="3" friction="1.1 .9 .01 .001 .001" solreffriction=".03 .8"/>
+    <exclude body1="s4" body2="b1"/>
+  </contact>
+</mujoco>
+"""

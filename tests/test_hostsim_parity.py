@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -497,6 +497,33 @@ def test_gravity_compensation_and_diagnostic_flags(rb, hostsim_lib, tmp_path):
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("cone", [0, 1])
+def test_predefined_contact_pairs_bit_exact(rb, hostsim_lib, tmp_path, cone):
+    """<contact><pair> entries merged into the candidate list in signature order
+    (mj_collision, engine_collision_driver.c:651-664), with their own condim / friction / solref /
+    solreffriction / margin / gap, replacing the automatic pair of the same geoms and reaching
+    parent-child geoms the automatic filter drops; an <exclude> next to them"""
+    xml = tmp_path / "pair.xml"
+    xml.write_text(PAIR_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    assert m.npair == 3
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(2).normal(0, .6, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 120
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 0].max() >= 6
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
 def _sensor_reference(rb, m, s0, ctrl):
