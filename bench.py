@@ -86,7 +86,15 @@ def measured_traffic(steps_per_launch: int, nenv: int):
     gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the launch."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt")))
+    # profiles/CURRENT names the directory measured on the committed build; it is read last (wins)
+    cur = os.path.join(ROOT, "profiles", "CURRENT")
+    if os.path.exists(cur):
+        f0 = os.path.join(ROOT, "profiles", open(cur).read().strip(), "pmc_summary.txt")
+        if f0 in files:
+            files.remove(f0)
+            files.append(f0)
+    for f in files:
         m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB",
                       open(f).read())
         if m and int(m.group(1)) == steps_per_launch and int(m.group(2)) == nenv:
