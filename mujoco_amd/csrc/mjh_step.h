@@ -702,6 +702,7 @@ MJH_DEV void smooth_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
     if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
     if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
+    if (A.mpos_off < 0 || A.mquat_off < 0) reset_mocap(M, B, e);
     wv_sync();
   }
   // any warning freezes the trajectory (python/mujoco/rollout.cc:135-155)
@@ -714,6 +715,8 @@ MJH_DEV void smooth_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     const real* u = A.control + (r*(size_t)A.nstep + A.t0)*A.ncontrol;
     if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
     if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
+    if (A.mpos_off >= 0) { rptr q = MJH_G(B, mocap_pos, e); MJH_FOR_LANES(i, 3*s.nmocap) q[i] = u[A.mpos_off + i]; }
+    if (A.mquat_off >= 0) { rptr q = MJH_G(B, mocap_quat, e); MJH_FOR_LANES(i, 4*s.nmocap) q[i] = u[A.mquat_off + i]; }
     wv_sync();
   }
   check_bad(M, B, e, MJH_F(B, qpos, e), s.nq, MJH_WARN_BADQPOS);
@@ -731,6 +734,7 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     // (engine_forward.c:1863-1870).  Rare, so the whole forward pass is redone right here.
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
     if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+    else if (M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
     else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);

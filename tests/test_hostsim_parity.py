@@ -526,6 +526,37 @@ def test_predefined_contact_pairs_bit_exact(rb, hostsim_lib, tmp_path, cone):
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
+@pytest.mark.parametrize("scene,opts,exact", [
+    ("IMPL_XML", {}, True), ("ACT_XML", {"integrator": 1}, True), ("EQ_XML", {}, True),
+    ("BOXBOX_XML", {}, True), ("CONDIM_XML", {"cone": 1}, True), ("PAIR_XML", {"cone": 1}, True),
+    ("CONDIM_XML", {"cone": 1, "solver": 2}, False)])
+def test_soa_pipeline_feature_scenes(rb, hostsim_lib, tmp_path, scene, opts, exact):
+    """the per-step SoA pipeline (lane-per-environment smooth / integrate kernels + the wave-mode
+    constraint kernel) on the feature scenes: implicitfast, stateful actuators under RK4,
+    equalities, box-box, elliptic condim 4/6, predefined pairs, multi-island Newton"""
+    import parity_utils
+    xml = tmp_path / "scene.xml"
+    xml.write_text(getattr(parity_utils, scene))
+    m = rb.MjModel.from_xml_path(str(xml))
+    for k, v in opts.items():
+        setattr(m.opt, k, v)
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .4, m.nv)
+    s0 = np.tile(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS), (3, 1))
+    T = 25
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (3, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 3, layout="soa")
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    if exact:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= 1e-9
+    assert b.get("warning").sum() == 0
+
+
 def _sensor_reference(rb, m, s0, ctrl):
     d = rb.MjData(m)
     T = ctrl.shape[1]
