@@ -363,6 +363,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->geom_rbound, m->geom_rbound, m->ngeom);
   copy_arr(H->site_pos, m->site_pos, 3*m->nsite);
   copy_arr(H->site_quat, m->site_quat, 4*m->nsite);
+  copy_arr(H->site_size, m->site_size, 3*m->nsite);
+  copy_arr(H->site_type, m->site_type, m->nsite);
   copy_arr(H->tendon_range, m->tendon_range, 2*m->ntendon);
   copy_arr(H->tendon_margin, m->tendon_margin, m->ntendon);
   copy_arr(H->tendon_solref_lim, m->tendon_solref_lim, 2*m->ntendon);
@@ -744,10 +746,16 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_FORCE: t = MJH_SENS_FORCE; s.sens_rnepost = 1; break;
       case mjSENS_TORQUE: t = MJH_SENS_TORQUE; s.sens_rnepost = 1; break;
       case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
+      case mjSENS_TOUCH: {
+        const int st = m->site_type[m->sensor_objid[i]];
+        if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX) t = MJH_SENS_TOUCH;
+        break;     // capsule / cylinder touch zones: not evaluated yet -> rejected below
+      }
       default: break;
     }
-    MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer "
-                      "(touch, rangefinder, camprojection, contact, geom distance, energy, tactile, user, plugin)");
+    MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/"
+                      "touch with sphere, ellipsoid or box zones (rangefinder, camprojection, contact, geom distance, energy, "
+                      "tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {
       if (ot == mjOBJ_BODY) *out = MJH_OBJ_BODY;

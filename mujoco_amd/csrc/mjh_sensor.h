@@ -87,6 +87,62 @@ MJH_DEV void contact_force(MREF M, BREF B, int e, const Efc& P, int k, real* res
   }
 }
 
+// does the ray pnt + x*vec (x >= 0) meet the site's zone?  (mju_rayGeom >= 0 for sphere, ellipsoid
+// and box sites: ray_quad / ray_sphere / ray_ellipsoid / ray_box, engine_ray.c:103-560)
+MJH_DEV real ray_quad_min(real a, real b, real c) {
+  real det = b*b - a*c;
+  if (det < 0 || a < MJH_MINVAL) return -1;
+  det = sqrt(det);
+  const real x0 = (-b - det)/a, x1 = (-b + det)/a;
+  if (x0 >= 0) return x0;
+  if (x1 >= 0) return x1;
+  return -1;
+}
+template <class P0, class P1, class P2>
+MJH_DEV int ray_hits_zone(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
+  real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
+  if (type == 2) {           // mjGEOM_SPHERE
+    const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
+    const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
+    const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - size[0]*size[0];
+    return ray_quad_min(a, b, c) >= 0;
+  }
+  real lpnt[3], lvec[3];
+  for (int k = 0; k < 3; k++) {
+    lpnt[k] = mat[k]*dif[0] + mat[3 + k]*dif[1] + mat[6 + k]*dif[2];
+    lvec[k] = mat[k]*vec[0] + mat[3 + k]*vec[1] + mat[6 + k]*vec[2];
+  }
+  if (type == 4) {           // mjGEOM_ELLIPSOID
+    real sz[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
+    const real a = sz[0]*lvec[0]*lvec[0] + sz[1]*lvec[1]*lvec[1] + sz[2]*lvec[2]*lvec[2];
+    const real b = sz[0]*lvec[0]*lpnt[0] + sz[1]*lvec[1]*lpnt[1] + sz[2]*lvec[2]*lpnt[2];
+    const real c = sz[0]*lpnt[0]*lpnt[0] + sz[1]*lpnt[1]*lpnt[1] + sz[2]*lpnt[2]*lpnt[2] - 1;
+    return ray_quad_min(a, b, c) >= 0;
+  }
+  // mjGEOM_BOX: bounding-sphere test, then the six faces
+  {
+    const real ssz = size[0]*size[0] + size[1]*size[1] + size[2]*size[2];
+    const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
+    const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
+    const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - ssz;
+    if (ray_quad_min(a, b, c) < 0) return 0;
+  }
+  for (int i = 0; i < 3; i++) {
+    if (fabs(lvec[i]) > MJH_MINVAL) {
+      const int f0 = (i == 0) ? 1 : 0, f1 = (i == 2) ? 1 : 2;
+      for (int side = -1; side <= 1; side += 2) {
+        const real sol = (side*size[i] - lpnt[i])/lvec[i];
+        if (sol >= 0) {
+          const real p0 = lpnt[f0] + sol*lvec[f0];
+          const real p1 = lpnt[f1] + sol*lvec[f1];
+          if (fabs(p0) <= size[f0] && fabs(p1) <= size[f1]) return 1;
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 // mj_subtreeVel (lane 0)
 MJH_DEV void sens_subtree_vel(MREF M, BREF B, int e) {
   const MJH_CONST_AS DSizes& s = M.s;
@@ -322,6 +378,31 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
                    MJH_F(B, subtree_com, e) + 3*M.body_rootid[body], MJH_F(B, site_xmat, e) + 9*objid, 1);
       const int o = (type == MJH_SENS_FORCE) ? 3 : 0;
       v[0] = t[o]; v[1] = t[o + 1]; v[2] = t[o + 2];
+    } break;
+    case MJH_SENS_TOUCH: {
+      // sum of the normal forces of the contacts of the site's body whose force ray meets the
+      // site's zone (engine_sensor.c:980-1025)
+      const int body = M.site_bodyid[objid];
+      const int ncon = counts[MJH_C_NCON];
+      real total = 0;
+      for (int c = 0; nefc && c < ncon; c++) {
+        if (MJH_CON(B, con_efcadr, e, 1, c)[0] < 0) continue;
+        ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+        const int cb0 = M.geom_bodyid[cg[0]], cb1 = M.geom_bodyid[cg[1]];
+        if (body != cb0 && body != cb1) continue;
+        real cf[6];
+        contact_force(M, B, e, P, c, cf);
+        if (cf[0] <= 0) continue;
+        crptr fr = MJH_CON(B, con_frame, e, 9, c);
+        real ray[3] = {fr[0]*cf[0], fr[1]*cf[0], fr[2]*cf[0]};
+        v3_normalize(ray);
+        if (body == cb1) { ray[0] = ray[0]*-1; ray[1] = ray[1]*-1; ray[2] = ray[2]*-1; }
+        crptr cp = MJH_CON(B, con_pos, e, 3, c);
+        real pnt[3] = {cp[0], cp[1], cp[2]};
+        if (ray_hits_zone(M.site_type[objid], MJH_F(B, site_xpos, e) + 3*objid, MJH_F(B, site_xmat, e) + 9*objid,
+                          M.site_size + 3*objid, pnt, ray)) total += cf[0];
+      }
+      v[0] = total;
     } break;
     case MJH_SENS_MAGNETOMETER: {
       real mg[3] = {M.o.magnetic[0], M.o.magnetic[1], M.o.magnetic[2]};

@@ -59,6 +59,7 @@
   X(geom_sameframe, s.ngeom)                   \
   X(site_bodyid, s.nsite)                      \
   X(site_sameframe, s.nsite)                   \
+  X(site_type, s.nsite)                        \
   X(tendon_adr, s.ntendon)                     \
   X(sensor_type, s.nsensor)                    \
   X(sensor_datatype, s.nsensor)                \
@@ -146,6 +147,7 @@
   X(geom_rbound, s.ngeom)                      \
   X(site_pos, 3 * s.nsite)                     \
   X(site_quat, 4 * s.nsite)                    \
+  X(site_size, 3 * s.nsite)                    \
   X(tendon_range, 2 * s.ntendon)               \
   X(tendon_margin, s.ntendon)                  \
   X(tendon_solref_lim, 2 * s.ntendon)          \

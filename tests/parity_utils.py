@@ -316,7 +316,9 @@ SENSOR_XML = """
       </body>
     </body>
     <body name="f1" pos="-.5 0 .08" euler="0 70 20"><freejoint/><geom name="gf" fromto="-.1 0 0 .1 0 0" size=".04"/>
-      <site name="imuf" pos=".05 0 .01" euler="5 10 15"/></body>
+      <site name="imuf" pos=".05 0 .01" euler="5 10 15"/>
+      <site name="touch_box" type="box" size=".16 .06 .06"/><site name="touch_sph" type="sphere" size=".045" pos=".1 0 0"/>
+      <site name="touch_ell" type="ellipsoid" size=".13 .05 .03" pos="-.04 0 0"/></body>
     <body name="f2" pos="-.5 .4 .3"><freejoint/><geom type="sphere" size=".05"/><site name="f2s"/></body>
     <body name="p1" pos=".3 -.5 .5"><joint name="q1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/>
       <body pos="0 0 -.2"><joint name="q2" axis="1 0 0" range="-30 30" limited="true"/><geom fromto="0 0 0 0 0 -.2"/><site name="p_end" pos="0 0 -.2"/></body></body>
@@ -346,6 +348,7 @@ SENSOR_XML = """
     <velocimeter site="imu1"/><gyro site="imu2"/><accelerometer site="imu1"/><accelerometer site="imuf"/>
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>
+    <touch site="touch_box"/><touch site="touch_sph"/><touch site="touch_ell"/>
     <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
   </sensor>
 </mujoco>
