@@ -172,8 +172,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // mjENBL_ENERGY and mjENBL_FWDINV only fill diagnostics (d->energy, d->solver_fwdinv) that are not
   // part of the rollout's outputs (energy sensors are rejected with the sensor list): accepted
   MJH_REJECT(m->opt.enableflags & (mjENBL_SLEEP | mjENBL_DIAGEXACT), "enable flags sleep / diagexact");
-  MJH_REJECT(m->opt.density != 0 || m->opt.viscosity != 0, "fluid forces (density/viscosity)");
-  MJH_REJECT(m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0, "wind");
+  {
+    const bool fluid = m->opt.density != 0 || m->opt.viscosity != 0;
+    MJH_REJECT(!fluid && (m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0), "wind without a fluid medium");
+    MJH_REJECT(fluid && m->opt.integrator == mjINT_IMPLICITFAST, "fluid forces with the implicitfast integrator (their velocity derivative is not implemented)");
+    if (fluid)
+      for (int g = 0; g < m->ngeom; g++)
+        MJH_REJECT(m->geom_fluid[mjNFLUID*g] > 0, "the ellipsoid fluid model (geom fluidshape)");
+  }
   MJH_REJECT(m->nactuator != m->nu, "multi-input actuators (nactuator != nu)");
   MJH_REJECT(m->nout != m->nu, "multi-output actuators (nout != nu)");
   for (int i = 0; i < m->nactuator; i++) {
@@ -340,6 +346,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_mass, m->body_mass, m->nbody);
   copy_arr(H->body_gravcomp, m->body_gravcomp, m->nbody);
   o.has_gravcomp = m->flg_gravcomp ? 1 : 0;
+  o.has_fluid = (m->opt.density != 0 || m->opt.viscosity != 0) ? 1 : 0;
+  o.density = m->opt.density; o.viscosity = m->opt.viscosity;
+  for (int k = 0; k < 3; k++) o.wind[k] = m->opt.wind[k];
+  s.nbody_fluid = o.has_fluid ? m->nbody : 0;
   copy_arr(H->body_subtreemass, m->body_subtreemass, m->nbody);
   copy_arr(H->body_inertia, m->body_inertia, 3*m->nbody);
   copy_arr(H->body_invweight0, m->body_invweight0, 2*m->nbody);

@@ -403,6 +403,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_gravcomp) eqskip.push_back("xipos");    // read by the passive stage
+  if (Bt->model->H.o.has_fluid) { eqskip.push_back("xipos"); eqskip.push_back("ximat"); }
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS
     std::vector<std::string> skip = {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"};

@@ -809,6 +809,89 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
   wv_sync();
   MJH_FOR_LANES(i, s.nv) fp[i] = fs[i] + fd[i];
   wv_sync();
+  // fluid forces, inertia-box model (mj_fluid / mj_inertiaBoxFluidModel, engine_passive.c:871-903,
+  // :1154-1210): viscous and quadratic drag on the equivalent inertia box of every body, in the
+  // body's inertial frame, applied at its COM through mj_applyFT
+  if (M.o.has_fluid && (M.o.viscosity != 0 || M.o.density != 0)) {
+    crptr xipos = MJH_F(B, xipos, e);
+    crptr ximat = MJH_F(B, ximat, e);
+    crptr cvel = MJH_F(B, cvel, e);
+    crptr cdof = MJH_F(B, cdof, e);
+    crptr com = MJH_F(B, subtree_com, e);
+    rptr bf = MJH_G(B, fluid_frc, e);
+    MJH_FOR_LANES(i, s.nbody) {
+      real out[6] = {0, 0, 0, 0, 0, 0};
+      const real mass = M.body_mass[i];
+      if (!(mass < MJH_MINVAL)) {
+        auto inertia = M.body_inertia + 3*i;
+        real box[3];
+        box[0] = sqrt(r_max(MJH_MINVAL, (inertia[1] + inertia[2] - inertia[0])) / mass * 6.0);
+        box[1] = sqrt(r_max(MJH_MINVAL, (inertia[0] + inertia[2] - inertia[1])) / mass * 6.0);
+        box[2] = sqrt(r_max(MJH_MINVAL, (inertia[0] + inertia[1] - inertia[2])) / mass * 6.0);
+        // local 6D velocity of the inertial frame (mj_objectVelocity, flg_local) minus the wind
+        real lvel[6] = {0, 0, 0, 0, 0, 0}, lwind[6];
+        crptr cref = com + 3*M.body_rootid[i];
+        if (M.body_dofnum[M.body_weldid[i]] != 0) {
+          real dif[3], cr[3], tran[6];
+          v3_sub(dif, xipos + 3*i, cref);
+          for (int k = 0; k < 6; k++) tran[k] = cvel[6*i + k];
+          v3_cross(cr, dif, cvel + 6*i);
+          tran[3] = cvel[6*i + 3] - cr[0]; tran[4] = cvel[6*i + 4] - cr[1]; tran[5] = cvel[6*i + 5] - cr[2];
+          m3_multvec(lvel, ximat + 9*i, tran);
+          m3_multvec(lvel + 3, ximat + 9*i, tran + 3);
+        }
+        {
+          real wind[6] = {0, 0, 0, M.o.wind[0], M.o.wind[1], M.o.wind[2]};
+          real dif[3], cr[3], tran[6];
+          v3_sub(dif, xipos + 3*i, cref);
+          for (int k = 0; k < 6; k++) tran[k] = wind[k];
+          v3_cross(cr, dif, wind);
+          tran[3] = wind[3] - cr[0]; tran[4] = wind[4] - cr[1]; tran[5] = wind[5] - cr[2];
+          m3_multvec(lwind, ximat + 9*i, tran);
+          m3_multvec(lwind + 3, ximat + 9*i, tran + 3);
+        }
+        lvel[3] -= lwind[3]; lvel[4] -= lwind[4]; lvel[5] -= lwind[5];
+        real lfrc[6] = {0, 0, 0, 0, 0, 0};
+        const real visc = M.o.viscosity, dens = M.o.density;
+        if (visc > 0) {
+          const real diam = (box[0] + box[1] + box[2])/3.0;
+          const real ka = -MJH_PI*diam*diam*diam*visc, kl = -3.0*MJH_PI*diam*visc;
+          for (int k = 0; k < 3; k++) { lfrc[k] = lvel[k]*ka; lfrc[3 + k] = lvel[3 + k]*kl; }
+        }
+        if (dens > 0) {
+          lfrc[3] -= 0.5*dens*box[1]*box[2]*fabs(lvel[3])*lvel[3];
+          lfrc[4] -= 0.5*dens*box[0]*box[2]*fabs(lvel[4])*lvel[4];
+          lfrc[5] -= 0.5*dens*box[0]*box[1]*fabs(lvel[5])*lvel[5];
+          lfrc[0] -= dens*box[0]*(box[1]*box[1]*box[1]*box[1]+box[2]*box[2]*box[2]*box[2])*fabs(lvel[0])*lvel[0]/64.0;
+          lfrc[1] -= dens*box[1]*(box[0]*box[0]*box[0]*box[0]+box[2]*box[2]*box[2]*box[2])*fabs(lvel[1])*lvel[1]/64.0;
+          lfrc[2] -= dens*box[2]*(box[0]*box[0]*box[0]*box[0]+box[1]*box[1]*box[1]*box[1])*fabs(lvel[2])*lvel[2]/64.0;
+        }
+        m3_mulvec(out, ximat + 9*i, lfrc);
+        m3_mulvec(out + 3, ximat + 9*i, lfrc + 3);
+      }
+      for (int k = 0; k < 6; k++) bf[6*i + k] = out[k];
+    }
+    wv_sync();
+    MJH_FOR_LANES(j, s.nv) {
+      real acc = 0;
+      crptr cd = cdof + 6*j;
+      for (int b = 0; b < s.nbody; b++) {
+        if (M.body_mass[b] < MJH_MINVAL) continue;
+        real tf = 0, tt = 0;
+        if ((M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1) {
+          real off[3], cr[3];
+          v3_sub(off, xipos + 3*b, com + 3*M.body_rootid[b]);
+          v3_cross(cr, cd, off);
+          for (int r = 0; r < 3; r++) { const real f = bf[6*b + 3 + r]; if (f != 0) tf += (cd[3 + r] + cr[r])*f; }
+          for (int r = 0; r < 3; r++) { const real t = bf[6*b + r]; if (t != 0) tt += cd[r]*t; }
+        }
+        acc += tf;
+        acc += tt;
+      }
+      fp[j] += acc;
+    }
+    wv_sync();
+  }
   // gravity compensation (mj_gravcomp, engine_passive.c:846-867 + :1112-1122): per compensated
   // body a force -gravity*mass*gravcomp at its COM, mapped through the point Jacobian (mj_applyFT)
   if (M.o.has_gravcomp && !(dsbl & (1<<7)) &&

@@ -196,6 +196,7 @@ struct DSizes {
   int nstate;      // mj_stateSize(FULLPHYSICS)
   int nsensor, nsensordata;
   int nmocap;
+  int nbody_fluid;  // nbody when fluid forces are on, else 0
   int nbody_sens;  // nbody when the model has sensors (cacc / cfrc / subtree velocity arrays), else 0
   int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
   int npgsorder;   // entries of the precomputed PGS visitation-order table
@@ -214,6 +215,8 @@ struct DOptions {
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_ten_armature;
   int has_gravcomp;
+  int has_fluid;      // opt.density / opt.viscosity set: inertia-box fluid forces
+  real density, viscosity, wind[3];
 };
 
 // (device build: the table pointers are constant-address-space pointers, so a wave-uniform index
@@ -258,6 +261,7 @@ enum {
   X(act, s.na, s.na, MJH_T_BEGIN, MJH_T_END)                                      \
   X(act_dot, s.na, s.na, MJH_T_ACTUATION, MJH_T_END)                              \
   X(mocap_pos, 3 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(fluid_frc, 6 * s.nbody_fluid, 0, MJH_T_GLB, MJH_T_GLB)                        \
   X(mocap_quat, 4 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(ctrl, s.nu, s.nu, MJH_T_BEGIN, MJH_T_END)                                     \
   X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \

@@ -448,3 +448,24 @@ PAIR_XML = """
   </contact>
 </mujoco>
 """
+
+
+# fluid forces (inertia-box model): a 3-link swimmer-like chain and a tumbling free box in a dense,
+# viscous medium with wind
+FLUID_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40" density="3000" viscosity=".2" wind=".3 -.1 .05" integrator="RK4"/>
+  <default><geom type="capsule" size=".04" condim="1"/><joint damping=".02"/></default>
+  <worldbody>
+    <geom type="plane" size="4 4 .01" pos="0 0 -1"/>
+    <body name="head" pos="0 0 0">
+      <joint type="slide" axis="1 0 0"/><joint type="slide" axis="0 1 0"/><joint type="hinge" axis="0 0 1"/>
+      <geom fromto="0 0 0 -.3 0 0"/>
+      <body pos="-.3 0 0"><joint name="r1" axis="0 0 1" range="-100 100" limited="true"/><geom fromto="0 0 0 -.3 0 0"/>
+        <body pos="-.3 0 0"><joint name="r2" axis="0 0 1" range="-100 100" limited="true"/><geom fromto="0 0 0 -.3 0 0" size=".03"/></body></body>
+    </body>
+    <body pos="1 1 0" euler="20 30 40"><freejoint/><geom type="box" size=".1 .05 .2" density="700"/></body>
+  </worldbody>
+  <actuator><motor joint="r1" gear="3"/><motor joint="r2" gear="3"/></actuator>
+</mujoco>
+"""

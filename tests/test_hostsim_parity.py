@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -555,6 +555,27 @@ def test_soa_pipeline_feature_scenes(rb, hostsim_lib, tmp_path, scene, opts, exa
     else:
         assert relerr(out, ref) <= 1e-9
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("integrator", [0, 1])
+def test_fluid_forces_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """mj_fluid, inertia-box model (engine_passive.c:871-903, :1154-1210): viscous and quadratic drag
+    with wind on a swimmer-like chain and a tumbling box; Euler and RK4"""
+    xml = tmp_path / "fluid.xml"
+    xml.write_text(FLUID_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
 
 
 def _sensor_reference(rb, m, s0, ctrl):
