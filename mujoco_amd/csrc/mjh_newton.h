@@ -281,7 +281,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     wv_sync();
     MJH_FOR_LANES(j, nv) {
       real acc = 0;
-      for (int r = 0; r < nefc; r++) acc += J[(size_t)r*nv + j]*P.force[r];
+      // rows of other islands have zero Jacobian entries on this island's dofs, but their forces may
+      // not have been written yet (uninitialised LDS): they must not enter the sum
+      for (int r = 0; r < nefc; r++) if (in_row(r)) acc += J[(size_t)r*nv + j]*P.force[r];
       if (in_dof(j)) { qfc[j] = acc; grad[j] = Ma[j] - qfs[j] - acc; }
       else grad[j] = 0;
     }

@@ -386,10 +386,6 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   // sensors read kinematic / velocity / constraint quantities after the solve: such models keep
   // every field in its global home (no residency plan)
   if (Bt->model->H.s.nsensor > 0) lds_bytes = 0;
-  // the per-step SoA pipeline with a primal solver: a field of the multi-island Newton/CG path is
-  // not covered by the constraint kernel's residency plan yet (the emulation's poisoned LDS
-  // catches it), so that combination runs from the global homes
-  if (Bt->soa && Bt->model->H.o.solver != MJH_SOL_PGS) lds_bytes = 0;
   // equality constraints read kinematics / velocity quantities long after their usual lifetimes
   // (rows at make, Jdot*v at reference): such models keep those fields in their global homes
   std::vector<std::string> eqskip;

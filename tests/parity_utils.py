@@ -469,3 +469,23 @@ FLUID_XML = """
   <actuator><motor joint="r1" gear="3"/><motor joint="r2" gear="3"/></actuator>
 </mujoco>
 """
+
+
+# three separate trees, each tied to the world by its own equality: three constraint islands made
+# of equality rows only (the primal solvers visit them one after the other)
+ISLANDS_XML = """
+<mujoco>
+  <option timestep="0.002"/>
+  <worldbody>
+    <site name="w1" pos="0 0 1"/><site name="w2" pos="1 0 1"/>
+    <body name="b1" pos="0 0 .8"><freejoint/><geom type="capsule" size=".03 .1"/><site name="s1" pos="0 0 .15"/></body>
+    <body name="b2" pos="1 0 .8"><freejoint/><geom type="sphere" size=".06"/><site name="s2" pos="0 .05 .1" euler="10 20 0"/></body>
+    <body name="b3" pos="2 0 .8"><freejoint/><geom type="capsule" size=".03 .1"/></body>
+  </worldbody>
+  <equality>
+    <connect site1="s1" site2="w1"/>
+    <weld site1="s2" site2="w2" solref=".01 1"/>
+    <connect body1="b3" anchor="0 0 .2"/>
+  </equality>
+</mujoco>
+"""

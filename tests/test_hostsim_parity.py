@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -576,6 +576,29 @@ def test_fluid_forces_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("lds", [0, 3328, 10240, 40000])
+def test_newton_islands_any_lds_budget(rb, hostsim_lib, tmp_path, lds):
+    """regression: with several islands the primal solver must not touch the forces of islands it
+    has not solved yet (they sit in uninitialised LDS once the plan places efc_force there)"""
+    xml = tmp_path / "islands.xml"
+    xml.write_text(ISLANDS_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.opt.solver == 2
+    dm = K.DeviceModel(hostsim_lib, m, 64, 300)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 20
+    ref, _ = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    b = K.Batch(dm, 1)
+    b.plan_lds(lds)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    assert np.isfinite(out).all()
+    assert relerr(out, ref) <= 1e-9
+    assert b.get("warning").sum() == 0
 
 
 def _sensor_reference(rb, m, s0, ctrl):
