@@ -756,6 +756,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_FORCE: t = MJH_SENS_FORCE; s.sens_rnepost = 1; break;
       case mjSENS_TORQUE: t = MJH_SENS_TORQUE; s.sens_rnepost = 1; break;
       case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
+      case mjSENS_INSIDESITE: t = MJH_SENS_INSIDESITE; break;
       case mjSENS_TOUCH: {
         const int st = m->site_type[m->sensor_objid[i]];
         if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX) t = MJH_SENS_TOUCH;
@@ -763,7 +764,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       }
       default: break;
     }
-    MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/"
+    MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
                       "touch with sphere, ellipsoid or box zones (rangefinder, camprojection, contact, geom distance, energy, "
                       "tactile, user, plugin)");
     H->sensor_type[i] = t;
@@ -775,6 +776,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       else return false;
       return true;
     };
+    if (t == MJH_SENS_INSIDESITE)
+      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "insidesite sensors attached to cameras");
     if (t >= MJH_SENS_FRAMEPOS && t <= MJH_SENS_FRAMEANGACC) {
       MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "frame sensors attached to cameras");
       if (m->sensor_refid[i] >= 0)

@@ -404,6 +404,33 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
       }
       v[0] = total;
     } break;
+    case MJH_SENS_INSIDESITE: {
+      // 1 if the object's frame origin lies inside the reference site (mju_insideGeom,
+      // engine_util_misc.c:452-496)
+      const SensFrame f = sens_frame(M, B, e, objtype, objid);
+      crptr pt = f.pos;
+      if (objtype == MJH_OBJ_BODY && objid > 0 && M.body_mass[objid] < MJH_MINVAL && M.body_subtreemass[objid] >= MJH_MINVAL)
+        pt = MJH_F(B, subtree_com, e) + 3*objid;
+      crptr sp = MJH_F(B, site_xpos, e) + 3*refid;
+      crptr sm = MJH_F(B, site_xmat, e) + 9*refid;
+      auto sz = M.site_size + 3*refid;
+      const int st = M.site_type[refid];
+      real vec[3], pl[3];
+      v3_sub(vec, pt, sp);
+      int inside = 0;
+      if (st == 2) inside = v3_dot(vec, vec) < sz[0]*sz[0];
+      else {
+        m3_multvec(pl, sm, vec);
+        if (st == 3) {
+          const real z = pl[2], zc = r_clip(z, -sz[1], sz[1]);
+          const real zd = (z - zc)*(z - zc);
+          inside = (pl[0]*pl[0] + pl[1]*pl[1] + zd < sz[0]*sz[0]);
+        } else if (st == 4) inside = (pl[0]*pl[0]/(sz[0]*sz[0]) + pl[1]*pl[1]/(sz[1]*sz[1]) + pl[2]*pl[2]/(sz[2]*sz[2]) < 1);
+        else if (st == 5) inside = (fabs(pl[2]) < sz[1] && pl[0]*pl[0] + pl[1]*pl[1] < sz[0]*sz[0]);
+        else if (st == 6) inside = (fabs(pl[0]) < sz[0] && fabs(pl[1]) < sz[1] && fabs(pl[2]) < sz[2]);
+      }
+      v[0] = inside ? 1 : 0;
+    } break;
     case MJH_SENS_MAGNETOMETER: {
       real mg[3] = {M.o.magnetic[0], M.o.magnetic[1], M.o.magnetic[2]};
       m3_multvec(v, MJH_F(B, site_xmat, e) + 9*objid, mg);

@@ -305,6 +305,8 @@ SENSOR_XML = """
   <worldbody>
     <geom name="floor" type="plane" size="3 3 .01"/>
     <site name="world_s" pos=".2 .1 .3" euler="10 20 30"/>
+    <site name="zone_box" type="box" size=".3 .3 .06" pos="-.5 0 .05"/><site name="zone_cyl" type="cylinder" size=".3 .2" pos=".5 0 .5" euler="0 20 0"/>
+    <site name="zone_sph" type="sphere" size=".25" pos=".45 0 .45"/><site name="zone_cap" type="capsule" size=".15 .3" pos=".4 0 .6" euler="0 90 0"/>
     <body name="a1" pos="0 0 .6">
       <joint name="j1" axis="0 1 0" range="-40 40" limited="true"/><geom name="g1" fromto="0 0 0 .25 0 0"/>
       <site name="imu1" pos=".1 0 .02" euler="0 15 40"/>
@@ -349,6 +351,7 @@ SENSOR_XML = """
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>
     <touch site="touch_box"/><touch site="touch_sph"/><touch site="touch_ell"/>
+    <insidesite objtype="body" objname="f1" site="zone_box"/><insidesite objtype="site" objname="tip" site="zone_cyl"/><insidesite objtype="xbody" objname="a3" site="zone_sph"/><insidesite objtype="geom" objname="g3" site="zone_cap"/>
     <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
   </sensor>
 </mujoco>
