@@ -210,7 +210,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // servo wrap period (wrapPeriod, engine_forward.c:305-342) is zero for hinge/slide joint transmissions
   }
   for (int i = 0; i < m->ntendon; i++) {
-    MJH_REJECT(m->wrap_type[m->tendon_adr[i]] != mjWRAP_JOINT, "spatial tendons");
+    for (int w = m->tendon_adr[i]; w < m->tendon_adr[i] + m->tendon_num[i]; w++)
+      MJH_REJECT(m->wrap_type[w] == mjWRAP_SPHERE || m->wrap_type[w] == mjWRAP_CYLINDER, "tendons wrapping around spheres / cylinders");
     if (m->tendon_frictionloss[i] > 0) {
       const mjtNum* r = m->tendon_solref_fri + 2*i;
       MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on tendon friction");

@@ -264,6 +264,58 @@ MJH_DEVN void stage_tendon(MREF M_, BREF B_, int e_) {
     int radr = M.ten_J_rowadr[i], rnnz = M.ten_J_rownnz[i];
     real len = 0;
     for (int k = 0; k < rnnz; k++) J[radr + k] = 0;
+    if (M.wrap_type[adr] != 1) {
+      // spatial tendon through sites, with pulleys (mj_tendon, engine_core_smooth.c:988-1105; wrapping
+      // geoms are rejected at upload): straight segments between consecutive sites, moments from the
+      // difference of the end-point Jacobians along the segment direction
+      crptr sx = MJH_F(B, site_xpos, e);
+      crptr cdof = MJH_F(B, cdof, e);
+      crptr com = MJH_F(B, subtree_com, e);
+      real divisor = 1;
+      int j = 0;
+      while (j < num - 1) {
+        const int type0 = M.wrap_type[adr + j], type1 = M.wrap_type[adr + j + 1];
+        if (type0 == 2 || type1 == 2) {            // mjWRAP_PULLEY
+          if (type0 == 2) divisor = M.wrap_prm[adr + j];
+          j++;
+          continue;
+        }
+        const int id0 = M.wrap_objid[adr + j], id1 = M.wrap_objid[adr + j + 1];
+        real p0[3], p1[3];
+        v3_copy(p0, sx + 3*id0);
+        v3_copy(p1, sx + 3*id1);
+        const int b0 = M.site_bodyid[id0], b1 = M.site_bodyid[id1];
+        {
+          real dd[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+          len += sqrt(dd[0]*dd[0] + dd[1]*dd[1] + dd[2]*dd[2]) / divisor;
+        }
+        if (b0 != b1) {
+          real dif[3];
+          v3_sub(dif, p1, p0);
+          v3_normalize(dif);
+          real off0[3], off1[3];
+          v3_sub(off0, p0, com + 3*M.body_rootid[b0]);
+          v3_sub(off1, p1, com + 3*M.body_rootid[b1]);
+          const real binv = 1/divisor;
+          for (int k = 0; k < rnnz; k++) {
+            const int c = M.ten_J_colind[radr + k];
+            const int in0 = (M.body_dofanc[b0*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+            const int in1 = (M.body_dofanc[b1*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+            if (!in0 && !in1) continue;
+            crptr cd = cdof + 6*c;
+            real j0[3] = {0, 0, 0}, j1[3] = {0, 0, 0}, t[3];
+            if (in0) { v3_cross(t, cd, off0); j0[0] = cd[3] + t[0]; j0[1] = cd[4] + t[1]; j0[2] = cd[5] + t[2]; }
+            if (in1) { v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+            real tmp = 0;
+            for (int r = 0; r < 3; r++) if (dif[r] != 0) tmp += (j1[r] - j0[r])*dif[r];
+            J[radr + k] += binv*tmp;
+          }
+        }
+        j++;
+      }
+      L[i] = len;
+      continue;
+    }
     for (int j = 0; j < num; j++) {
       int jid = M.wrap_objid[adr + j];
       real coef = M.wrap_prm[adr + j];

@@ -492,3 +492,30 @@ ISLANDS_XML = """
   </equality>
 </mujoco>
 """
+
+
+# spatial tendons through sites: a two-body spring-damper tendon with a length limit, a pulley
+# tendon (two branches, divisor 2) between three bodies, a tendon that ends on a world site, and a
+# tendon equality coupling a spatial and a fixed tendon
+TENDON_XML = """
+<mujoco>
+  <option timestep="0.003" solver="PGS" iterations="50"/>
+  <default><geom type="capsule" size=".02" condim="1"/><joint damping=".05"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01" pos="0 0 -1"/>
+    <site name="anchor" pos="0 0 1"/><site name="anchor2" pos=".8 0 1"/>
+    <body pos="0 0 .6"><joint name="p1" axis="0 1 0"/><joint name="p1b" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.3"/><site name="a1" pos=".02 0 -.1"/>
+      <body pos="0 0 -.3"><joint name="p2" axis="0 1 0"/><geom fromto="0 0 0 .25 0 0"/><site name="a2" pos=".2 0 .02"/><site name="a2b" pos=".1 .02 0"/></body></body>
+    <body pos=".8 0 .5"><freejoint/><geom type="sphere" size=".06"/><site name="f1" pos="0 0 .06"/><site name="f1b" pos=".05 0 0"/></body>
+    <body pos=".4 .5 .5"><joint name="s1" type="slide" axis="0 0 1"/><geom type="sphere" size=".05"/><site name="m1"/></body>
+  </worldbody>
+  <tendon>
+    <spatial name="sp1" stiffness="20" damping=".5" springlength=".25" range="0 .55" limited="true"><site site="a1"/><site site="a2"/></spatial>
+    <spatial name="sp2" stiffness="40" damping="1"><site site="anchor2"/><site site="f1"/></spatial>
+    <spatial name="pul" stiffness="15"><site site="anchor"/><site site="a2b"/><pulley divisor="2"/><site site="anchor"/><site site="m1"/><pulley divisor="2"/><site site="anchor2"/><site site="f1b"/></spatial>
+    <fixed name="fx"><joint joint="s1" coef="1"/></fixed>
+  </tendon>
+  <equality><tendon tendon1="sp1" tendon2="fx" polycoef=".3 .5 0 0 0" solref=".02 1"/></equality>
+  <actuator><motor joint="p1" gear="1"/><motor joint="p2" gear=".5"/></actuator>
+</mujoco>
+"""

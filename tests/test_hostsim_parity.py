@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -599,6 +599,38 @@ def test_newton_islands_any_lds_budget(rb, hostsim_lib, tmp_path, lds):
     assert np.isfinite(out).all()
     assert relerr(out, ref) <= 1e-9
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("solver,tol", [(0, 0.0), (2, 1e-9)])
+def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, tol):
+    """spatial tendons through sites with pulleys (mj_tendon, engine_core_smooth.c:988-1105): lengths,
+    sparse moments from end-point Jacobian differences; spring-dampers, a limit and a tendon
+    equality on top"""
+    xml = tmp_path / "tendon.xml"
+    xml.write_text(TENDON_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 100
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
+    assert b.get("warning").sum() == 0
+    # the tendon quantities themselves after mj_forward
+    rb.mj_setState(m, d, ref[0, -1], rb.mjSTATE_FULLPHYSICS)
+    rb.mj_forward(m, d)
+    b.forward()
+    assert relerr(b.get("ten_length")[0], np.array(d.ten_length)) <= 1e-12
+    assert relerr(b.get("ten_J")[0][:m.nJten], np.array(d.ten_J)[:m.nJten]) <= 1e-12
 
 
 def _sensor_reference(rb, m, s0, ctrl):
