@@ -411,6 +411,17 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       }
       length[i] = len * gear[0];
       rownnz[i] = nnz;
+    } else if (M.actuator_trntype[i] == MJH_TRN_TENDON) {
+      // tendon (engine_core_smooth.c:1468-1480): the tendon's length and moment row, scaled by the gear
+      crptr tl = MJH_F(B, ten_length, e);
+      crptr tJ = MJH_F(B, ten_J, e);
+      const int ra = M.ten_J_rowadr[id], rn = M.ten_J_rownnz[id];
+      length[i] = tl[id]*gear[0];
+      rownnz[i] = rn;
+      for (int k = 0; k < rn; k++) {
+        colind[adr + k] = M.ten_J_colind[ra + k];
+        moment[adr + k] = tJ[ra + k]*gear[0];
+      }
     } else {
       // slide / hinge joint: scalar gear
       rownnz[i] = 1;

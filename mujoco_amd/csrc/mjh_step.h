@@ -445,8 +445,10 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   const int passive_on = !((dsbl & (1<<5)) && (dsbl & (1<<6)));
   const int damper_on = passive_on && !(dsbl & (1<<6));
 
-  MJH_FOR_LANES(k, s.nC) {
-    const int i = M.M_rowid[k], j = M.M_colind[k];
+  // qDeriv(i, j) = d(qfrc_actuator + qfrc_passive)(i) / d(qvel)(j), accumulated in the reference's
+  // order: actuators, dof damping, tendon damping  (mjd_actuator_vel, mjd_passive_vel; an entry of
+  // J'BJ is J(j) * (J(i) * B), addJTBJSparse engine_derivative.c:934-965)
+  auto qderiv_entry = [&](int i, int j) -> real {
     real q = 0;
     if (act_on) {
       for (int a = 0; a < s.nu; a++) {
@@ -484,6 +486,12 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
         if (hi && hj) q += jj * (ji*bt);
       }
     }
+    return q;
+  };
+
+  MJH_FOR_LANES(k, s.nC) {
+    const int i = M.M_rowid[k], j = M.M_colind[k];
+    const real q = qderiv_entry(i, j);
     // rows of standalone free bodies stay M
     const int jn = M.dof_jntid[i];
     if (M.jnt_freebody[jn]) qH[k] = Mq[k];
@@ -517,11 +525,8 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
         A[6*c + r] = Mq[ra + k];
       }
     }
-    for (int r = 0; r < 6; r++) {
-      real qd = 0;
-      if (damper_on) qd -= poly_force_deriv(M.dof_damping_eff[adr + r], M.dof_dampingpoly_eff + 2*(adr + r), qvel[adr + r], 1);
-      for (int c = 0; c < 6; c++) A[6*r + c] -= h * (r == c ? qd : (real)0);
-    }
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) A[6*r + c] -= h * qderiv_entry(adr + r, adr + c);
     real sv[3], R[9], Xi[9], inr[3], wq[3], lin[9], rot[9];
     for (int k = 0; k < 3; k++) { sv[k] = xipos[3*b + k] - xpos[3*b + k]; inr[k] = M.body_inertia[3*b + k]; wq[k] = qvel[adr + 3 + k]; }
     for (int k = 0; k < 9; k++) { R[k] = xmat[9*b + k]; Xi[k] = ximat[9*b + k]; }

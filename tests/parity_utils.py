@@ -516,6 +516,7 @@ TENDON_XML = """
     <fixed name="fx"><joint joint="s1" coef="1"/></fixed>
   </tendon>
   <equality><tendon tendon1="sp1" tendon2="fx" polycoef=".3 .5 0 0 0" solref=".02 1"/></equality>
-  <actuator><motor joint="p1" gear="1"/><motor joint="p2" gear=".5"/></actuator>
+  <actuator><motor joint="p1" gear="1"/><motor joint="p2" gear=".5"/>
+    <position tendon="sp1" kp="10" kv=".2"/><motor tendon="pul" gear="2"/><general tendon="fx" dyntype="filter" dynprm=".05" gainprm="3"/></actuator>
 </mujoco>
 """

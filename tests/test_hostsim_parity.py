@@ -601,15 +601,16 @@ def test_newton_islands_any_lds_budget(rb, hostsim_lib, tmp_path, lds):
     assert b.get("warning").sum() == 0
 
 
-@pytest.mark.parametrize("solver,tol", [(0, 0.0), (2, 1e-9)])
-def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, tol):
+@pytest.mark.parametrize("solver,integrator,tol", [(0, 0, 0.0), (2, 0, 1e-9), (0, 1, 0.0), (0, 3, 0.0)])
+def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, integrator, tol):
     """spatial tendons through sites with pulleys (mj_tendon, engine_core_smooth.c:988-1105): lengths,
     sparse moments from end-point Jacobian differences; spring-dampers, a limit and a tendon
-    equality on top"""
+    equality on top; tendon transmissions (position / motor / filtered general actuators on tendons)"""
     xml = tmp_path / "tendon.xml"
     xml.write_text(TENDON_XML)
     m = rb.MjModel.from_xml_path(str(xml))
     m.opt.solver = solver
+    m.opt.integrator = integrator    # implicitfast: tendon damping enters a standalone free body's 6x6 block
     dm = K.DeviceModel(hostsim_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
