@@ -760,6 +760,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_TORQUE: t = MJH_SENS_TORQUE; s.sens_rnepost = 1; break;
       case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
       case mjSENS_INSIDESITE: t = MJH_SENS_INSIDESITE; break;
+      case mjSENS_TENDONACTFRC: t = MJH_SENS_TENDONACTFRC; break;
       case mjSENS_TOUCH: {
         const int st = m->site_type[m->sensor_objid[i]];
         if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX) t = MJH_SENS_TOUCH;

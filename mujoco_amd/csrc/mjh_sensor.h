@@ -404,6 +404,14 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
       }
       v[0] = total;
     } break;
+    case MJH_SENS_TENDONACTFRC: {
+      // sum of the forces of the actuators acting on this tendon (engine_sensor.c:1313-1321)
+      crptr af = MJH_F(B, actuator_force, e);
+      real frc = 0.0;
+      for (int a = 0; a < s.nu; a++)
+        if (M.actuator_trntype[a] == MJH_TRN_TENDON && M.actuator_trnid[2*a] == objid) frc += af[a];
+      v[0] = frc;
+    } break;
     case MJH_SENS_INSIDESITE: {
       // 1 if the object's frame origin lies inside the reference site (mju_insideGeom,
       // engine_util_misc.c:452-496)

@@ -518,5 +518,6 @@ TENDON_XML = """
   <equality><tendon tendon1="sp1" tendon2="fx" polycoef=".3 .5 0 0 0" solref=".02 1"/></equality>
   <actuator><motor joint="p1" gear="1"/><motor joint="p2" gear=".5"/>
     <position tendon="sp1" kp="10" kv=".2"/><motor tendon="pul" gear="2"/><general tendon="fx" dyntype="filter" dynprm=".05" gainprm="3"/></actuator>
+  <sensor><tendonpos tendon="sp1"/><tendonvel tendon="pul"/><tendonactuatorfrc tendon="sp1"/><tendonactuatorfrc tendon="pul"/><tendonlimitfrc tendon="sp1"/></sensor>
 </mujoco>
 """

@@ -628,10 +628,12 @@ def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, integrator, tol):
     assert b.get("warning").sum() == 0
     # the tendon quantities themselves after mj_forward
     rb.mj_setState(m, d, ref[0, -1], rb.mjSTATE_FULLPHYSICS)
+    d.ctrl[:] = ctrl[0, -1]
     rb.mj_forward(m, d)
     b.forward()
     assert relerr(b.get("ten_length")[0], np.array(d.ten_length)) <= 1e-12
     assert relerr(b.get("ten_J")[0][:m.nJten], np.array(d.ten_J)[:m.nJten]) <= 1e-12
+    assert relerr(b.get("sensordata")[0], np.array(d.sensordata)) <= 1e-12
 
 
 def _sensor_reference(rb, m, s0, ctrl):
