@@ -197,9 +197,16 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
     MJH_REJECT(m->actuator_delay[i] != 0, "actuator delays");
     int tt = m->actuator_trntype[i];
-    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT && tt != mjTRN_SLIDERCRANK && tt != mjTRN_TENDON,
-               "actuator transmissions other than joint / slider-crank / tendon (site, body, SO3)");
+    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT && tt != mjTRN_SLIDERCRANK && tt != mjTRN_TENDON && tt != mjTRN_SITE,
+               "actuator transmissions other than joint / slider-crank / tendon / site (body, SO3)");
     if (tt == mjTRN_TENDON) continue;      // (tendon-level armature / force limits are checked with the tendons)
+    if (tt == mjTRN_SITE) {
+      MJH_REJECT(m->actuator_trnid[2*i + 1] != -1, "site transmissions with a reference site");
+      MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
+                 m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
+                 "actuator-level armature/damping on a site transmission");
+      continue;
+    }
     if (tt == mjTRN_SLIDERCRANK) {
       MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
                  m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
@@ -429,7 +436,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   H->actuator_momentadr.resize(m->nu + 1);
   H->actuator_momentadr[0] = 0;
   for (int i = 0; i < m->nu; i++)
-    H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + (m->actuator_trntype[i] == mjTRN_SLIDERCRANK ? m->nv :
+    H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + ((m->actuator_trntype[i] == mjTRN_SLIDERCRANK || m->actuator_trntype[i] == mjTRN_SITE) ? m->nv :
         (m->actuator_trntype[i] == mjTRN_TENDON ? std::max(1, m->ten_J_rownnz[m->actuator_trnid[2*i]]) : 1));
   s.nmoment = H->actuator_momentadr[m->nu];
 

@@ -411,6 +411,35 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       }
       length[i] = len * gear[0];
       rownnz[i] = nnz;
+    } else if (M.actuator_trntype[i] == MJH_TRN_SITE) {
+      // site, no reference site (engine_core_smooth.c:1573-1593, :1705-1715): the gear is a wrench in
+      // the site frame; moment = site Jacobians projected on it, length 0
+      crptr site_xpos = MJH_F(B, site_xpos, e);
+      crptr site_xmat = MJH_F(B, site_xmat, e);
+      crptr cdof = MJH_F(B, cdof, e);
+      crptr subtree_com = MJH_F(B, subtree_com, e);
+      real g[6] = {gear[0], gear[1], gear[2], gear[3], gear[4], gear[5]};
+      real wrench[6];
+      m3_mulvec(wrench, site_xmat + 9*id, g);
+      m3_mulvec(wrench + 3, site_xmat + 9*id, g + 3);
+      const int bs = M.site_bodyid[id];
+      real off[3];
+      v3_sub(off, site_xpos + 3*id, subtree_com + 3*M.body_rootid[bs]);
+      int nnz = 0;
+      for (int j = 0; j < s.nv; j++) {
+        real t1 = 0, t2 = 0;
+        if ((M.body_dofanc[bs*s.nvw + (j >> 5)] >> (j & 31)) & 1) {
+          crptr cd = cdof + 6*j;
+          real cr[3];
+          v3_cross(cr, cd, off);
+          for (int r = 0; r < 3; r++) if (wrench[r] != 0) t1 += (cd[3 + r] + cr[r])*wrench[r];
+          for (int r = 0; r < 3; r++) if (wrench[3 + r] != 0) t2 += cd[r]*wrench[3 + r];
+        }
+        const real mrow = t1 + t2;
+        if (mrow != 0) { moment[adr + nnz] = mrow; colind[adr + nnz] = j; nnz++; }
+      }
+      length[i] = 0;
+      rownnz[i] = nnz;
     } else if (M.actuator_trntype[i] == MJH_TRN_TENDON) {
       // tendon (engine_core_smooth.c:1468-1480): the tendon's length and moment row, scaled by the gear
       crptr tl = MJH_F(B, ten_length, e);

@@ -521,3 +521,23 @@ TENDON_XML = """
   <sensor><tendonpos tendon="sp1"/><tendonvel tendon="pul"/><tendonactuatorfrc tendon="sp1"/><tendonactuatorfrc tendon="pul"/><tendonlimitfrc tendon="sp1"/></sensor>
 </mujoco>
 """
+
+
+# site transmissions without a reference site: Cartesian force / torque actuators (a thruster on a
+# free body, forces and torques at an arm's tip), one of them with filter dynamics
+SITE_ACT_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40"/>
+  <default><geom type="capsule" size=".03" condim="3"/><joint damping=".1"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body pos="0 0 .6"><joint name="j1" axis="0 1 0"/><geom fromto="0 0 0 .25 0 0"/>
+      <body pos=".25 0 0"><joint name="j2" axis="0 0 1"/><geom fromto="0 0 0 .2 0 0"/><site name="tip" pos=".2 0 0" euler="0 30 10"/></body></body>
+    <body pos="-.5 0 .3"><freejoint/><geom type="box" size=".1 .05 .03"/><site name="thr" pos=".05 0 0" euler="10 0 40"/></body>
+  </worldbody>
+  <actuator>
+    <motor site="tip" gear="0 0 1 0 0 0"/><motor site="tip" gear="0 0 0 0 .5 0"/>
+    <general site="thr" gear=".6 0 1.5 0 0 .1" dyntype="filter" dynprm=".03"/><position site="thr" gear="0 1 0 0 0 0" kp="2" kv=".5"/>
+  </actuator>
+</mujoco>
+"""

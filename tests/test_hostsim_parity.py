@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -634,6 +634,27 @@ def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, integrator, tol):
     assert relerr(b.get("ten_length")[0], np.array(d.ten_length)) <= 1e-12
     assert relerr(b.get("ten_J")[0][:m.nJten], np.array(d.ten_J)[:m.nJten]) <= 1e-12
     assert relerr(b.get("sensordata")[0], np.array(d.sensordata)) <= 1e-12
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_site_transmissions_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """mjTRN_SITE without refsite (engine_core_smooth.c:1573-1593): the gear is a wrench in the site
+    frame, the moment row its projection on the site's Jacobians"""
+    xml = tmp_path / "site.xml"
+    xml.write_text(SITE_ACT_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 60
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
 
 
 def _sensor_reference(rb, m, s0, ctrl):
