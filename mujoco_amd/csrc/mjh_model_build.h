@@ -728,6 +728,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->sensor_dim, m->sensor_dim, m->nsensor);
   copy_arr(H->sensor_adr, m->sensor_adr, m->nsensor);
   copy_arr(H->sensor_cutoff, m->sensor_cutoff, m->nsensor);
+  H->sensor_intprm0.resize(m->nsensor);
+  for (int i = 0; i < m->nsensor; i++) H->sensor_intprm0[i] = m->sensor_intprm[i*mjNSENS];
+  // geoms a ray never sees: fully transparent colour or material (ray_eliminate, engine_ray.c:74-82)
+  H->geom_rayskip.assign(m->ngeom, 0);
+  for (int g = 0; g < m->ngeom; g++) {
+    const int mat = m->geom_matid[g];
+    if ((mat < 0 && m->geom_rgba[4*g + 3] == 0) || (mat >= 0 && m->mat_rgba[4*mat + 3] == 0)) H->geom_rayskip[g] = 1;
+  }
   for (int i = 0; i < m->nsensor; i++) {
     int t = -1;
     switch (m->sensor_type[i]) {
@@ -768,6 +776,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
       case mjSENS_INSIDESITE: t = MJH_SENS_INSIDESITE; break;
       case mjSENS_TENDONACTFRC: t = MJH_SENS_TENDONACTFRC; break;
+      case mjSENS_RANGEFINDER:
+        // site-attached rangefinders; the surface normal output needs the colliders' normals (not evaluated)
+        if (m->sensor_objtype[i] == mjOBJ_SITE && !(m->sensor_intprm[i*mjNSENS] & (1 << mjRAYDATA_NORMAL))) t = MJH_SENS_RANGEFINDER;
+        break;
       case mjSENS_TOUCH: {
         const int st = m->site_type[m->sensor_objid[i]];
         if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX) t = MJH_SENS_TOUCH;
@@ -776,7 +788,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       default: break;
     }
     MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
-                      "touch with sphere, ellipsoid or box zones (rangefinder, camprojection, contact, geom distance, energy, "
+                      "touch with sphere, ellipsoid or box zones / site rangefinders without normals (camprojection, contact, geom distance, energy, "
                       "tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {

@@ -143,6 +143,115 @@ MJH_DEV int ray_hits_zone(int type, P0 pos, P1 mat, P2 size, const real* pnt, co
   return 0;
 }
 
+// distance along the ray pnt + x*vec to one primitive geom, -1 if missed (mju_rayGeom without the
+// normals: ray_plane / ray_sphere / ray_capsule / ray_ellipsoid / ray_cylinder / ray_box,
+// engine_ray.c:204-560)
+MJH_DEV real ray_quad2(real a, real b, real c, real* xx) {
+  real det = b*b - a*c;
+  if (det < 0 || a < MJH_MINVAL) { xx[0] = -1; xx[1] = -1; return -1; }
+  det = sqrt(det);
+  xx[0] = (-b - det)/a;
+  xx[1] = (-b + det)/a;
+  if (xx[0] >= 0) return xx[0];
+  if (xx[1] >= 0) return xx[1];
+  return -1;
+}
+template <class P0>
+MJH_DEV real ray_sphere_dist(P0 pos, real dist_sqr, const real* pnt, const real* vec) {
+  real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
+  const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
+  const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
+  const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - dist_sqr;
+  real xx[2];
+  return ray_quad2(a, b, c, xx);
+}
+template <class P0, class P1, class P2>
+MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
+  if (type == 2) return ray_sphere_dist(pos, size[0]*size[0], pnt, vec);
+  real lpnt[3], lvec[3], xx[2];
+  {
+    real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
+    for (int k = 0; k < 3; k++) {
+      lpnt[k] = mat[k]*dif[0] + mat[3 + k]*dif[1] + mat[6 + k]*dif[2];
+      lvec[k] = mat[k]*vec[0] + mat[3 + k]*vec[1] + mat[6 + k]*vec[2];
+    }
+  }
+  if (type == 0) {                    // plane
+    if (lvec[2] > -MJH_MINVAL) return -1;
+    const real x = -lpnt[2]/lvec[2];
+    if (x < 0) return -1;
+    const real p0 = lpnt[0] + x*lvec[0], p1 = lpnt[1] + x*lvec[1];
+    if ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) return x;
+    return -1;
+  }
+  if (type == 3) {                    // capsule
+    const real ssz = size[0] + size[1];
+    if (ray_sphere_dist(pos, ssz*ssz, pnt, vec) < 0) return -1;
+    real x = -1;
+    real a = lvec[0]*lvec[0] + lvec[1]*lvec[1];
+    real b = lvec[0]*lpnt[0] + lvec[1]*lpnt[1];
+    real c = lpnt[0]*lpnt[0] + lpnt[1]*lpnt[1] - size[0]*size[0];
+    const real sol = ray_quad2(a, b, c, xx);
+    if (sol >= 0 && fabs(lpnt[2] + sol*lvec[2]) <= size[1]) { if (x < 0 || sol < x) x = sol; }
+    real ldif[3] = {lpnt[0], lpnt[1], lpnt[2] - size[1]};
+    a = lvec[0]*lvec[0] + lvec[1]*lvec[1] + lvec[2]*lvec[2];
+    b = lvec[0]*ldif[0] + lvec[1]*ldif[1] + lvec[2]*ldif[2];
+    c = ldif[0]*ldif[0] + ldif[1]*ldif[1] + ldif[2]*ldif[2] - size[0]*size[0];
+    ray_quad2(a, b, c, xx);
+    for (int i = 0; i < 2; i++)
+      if (xx[i] >= 0 && lpnt[2] + xx[i]*lvec[2] >= size[1]) { if (x < 0 || xx[i] < x) x = xx[i]; }
+    ldif[2] = lpnt[2] + size[1];
+    b = lvec[0]*ldif[0] + lvec[1]*ldif[1] + lvec[2]*ldif[2];
+    c = ldif[0]*ldif[0] + ldif[1]*ldif[1] + ldif[2]*ldif[2] - size[0]*size[0];
+    ray_quad2(a, b, c, xx);
+    for (int i = 0; i < 2; i++)
+      if (xx[i] >= 0 && lpnt[2] + xx[i]*lvec[2] <= -size[1]) { if (x < 0 || xx[i] < x) x = xx[i]; }
+    return x;
+  }
+  if (type == 4) {                    // ellipsoid
+    real sz[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
+    const real a = sz[0]*lvec[0]*lvec[0] + sz[1]*lvec[1]*lvec[1] + sz[2]*lvec[2]*lvec[2];
+    const real b = sz[0]*lvec[0]*lpnt[0] + sz[1]*lvec[1]*lpnt[1] + sz[2]*lvec[2]*lpnt[2];
+    const real c = sz[0]*lpnt[0]*lpnt[0] + sz[1]*lpnt[1]*lpnt[1] + sz[2]*lpnt[2]*lpnt[2] - 1;
+    return ray_quad2(a, b, c, xx);
+  }
+  if (type == 5) {                    // cylinder
+    if (ray_sphere_dist(pos, size[0]*size[0] + size[1]*size[1], pnt, vec) < 0) return -1;
+    real x = -1;
+    if (fabs(lvec[2]) > MJH_MINVAL) {
+      for (int side = -1; side <= 1; side += 2) {
+        const real sol = (side*size[1] - lpnt[2])/lvec[2];
+        if (sol >= 0) {
+          const real p0 = lpnt[0] + sol*lvec[0], p1 = lpnt[1] + sol*lvec[1];
+          if (p0*p0 + p1*p1 <= size[0]*size[0]) { if (x < 0 || sol < x) x = sol; }
+        }
+      }
+    }
+    const real a = lvec[0]*lvec[0] + lvec[1]*lvec[1];
+    const real b = lvec[0]*lpnt[0] + lvec[1]*lpnt[1];
+    const real c = lpnt[0]*lpnt[0] + lpnt[1]*lpnt[1] - size[0]*size[0];
+    const real sol = ray_quad2(a, b, c, xx);
+    if (sol >= 0 && fabs(lpnt[2] + sol*lvec[2]) <= size[1]) { if (x < 0 || sol < x) x = sol; }
+    return x;
+  }
+  // box
+  if (ray_sphere_dist(pos, size[0]*size[0] + size[1]*size[1] + size[2]*size[2], pnt, vec) < 0) return -1;
+  real x = -1;
+  for (int i = 0; i < 3; i++) {
+    if (fabs(lvec[i]) > MJH_MINVAL) {
+      const int f0 = (i == 0) ? 1 : 0, f1 = (i == 2) ? 1 : 2;
+      for (int side = -1; side <= 1; side += 2) {
+        const real sol = (side*size[i] - lpnt[i])/lvec[i];
+        if (sol >= 0) {
+          const real p0 = lpnt[f0] + sol*lvec[f0], p1 = lpnt[f1] + sol*lvec[f1];
+          if (fabs(p0) <= size[f0] && fabs(p1) <= size[f1]) { if (x < 0 || sol < x) x = sol; }
+        }
+      }
+    }
+  }
+  return x;
+}
+
 // mj_subtreeVel (lane 0)
 MJH_DEV void sens_subtree_vel(MREF M, BREF B, int e) {
   const MJH_CONST_AS DSizes& s = M.s;
@@ -282,7 +391,7 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
     const int type = M.sensor_type[i], objtype = M.sensor_objtype[i], objid = M.sensor_objid[i];
     const int reftype = M.sensor_reftype[i], refid = M.sensor_refid[i];
     const int dim = M.sensor_dim[i];
-    real v[6] = {0, 0, 0, 0, 0, 0};
+    real v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // limit sensors: the first matching constraint row
     int lrow = -1;
     if (type >= MJH_SENS_JOINTLIMITPOS && type <= MJH_SENS_TENDONLIMITFRC) {
@@ -403,6 +512,31 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
                           M.site_size + 3*objid, pnt, ray)) total += cf[0];
       }
       v[0] = total;
+    } break;
+    case MJH_SENS_RANGEFINDER: {
+      // site-attached rangefinder: one ray along the site's z axis against every visible geom
+      // outside the site's body (mj_ray engine_ray.c:1308-1351, fill_raydata engine_sensor.c:470-520)
+      crptr sp = MJH_F(B, site_xpos, e) + 3*objid;
+      crptr sm = MJH_F(B, site_xmat, e) + 9*objid;
+      real origin[3] = {sp[0], sp[1], sp[2]};
+      real rvec[3] = {sm[2], sm[5], sm[8]};
+      const int exclude = M.site_bodyid[objid];
+      crptr gx = MJH_F(B, geom_xpos, e);
+      crptr gm = MJH_F(B, geom_xmat, e);
+      real dist = -1;
+      for (int g = 0; g < s.ngeom; g++) {
+        if (M.geom_bodyid[g] == exclude || M.geom_rayskip[g]) continue;
+        const real nd = ray_geom_dist(M.geom_type[g], gx + 3*g, gm + 9*g, M.geom_size + 3*g, origin, rvec);
+        if (nd >= 0 && (nd < dist || dist < 0)) dist = nd;
+      }
+      const int spec = M.sensor_intprm0[i];
+      const int hit = dist >= 0;
+      int o = 0;
+      if (spec & 1) v[o++] = dist;                                             // mjRAYDATA_DIST
+      if (spec & 2) { for (int k = 0; k < 3; k++) v[o + k] = hit ? rvec[k] : (real)0; o += 3; }   // DIR
+      if (spec & 4) { for (int k = 0; k < 3; k++) v[o + k] = origin[k]; o += 3; }          // ORIGIN
+      if (spec & 8) { for (int k = 0; k < 3; k++) v[o + k] = hit ? origin[k] + rvec[k]*dist : (real)0; o += 3; }   // POINT
+      if (spec & 32) v[o++] = hit ? dist : (real)-1;                            // DEPTH
     } break;
     case MJH_SENS_TENDONACTFRC: {
       // sum of the forces of the actuators acting on this tendon (engine_sensor.c:1313-1321)

@@ -69,6 +69,8 @@
   X(sensor_refid, s.nsensor)                   \
   X(sensor_dim, s.nsensor)                     \
   X(sensor_adr, s.nsensor)                     \
+  X(sensor_intprm0, s.nsensor)                 \
+  X(geom_rayskip, s.ngeom)                     \
   X(tendon_num, s.ntendon)                     \
   X(tendon_limited, s.ntendon)                 \
   X(ten_J_rownnz, s.ntendon)                   \
@@ -507,7 +509,7 @@ enum {
   MJH_SENS_FRAMEYAXIS, MJH_SENS_FRAMEZAXIS, MJH_SENS_FRAMELINVEL, MJH_SENS_FRAMEANGVEL, MJH_SENS_FRAMELINACC,
   MJH_SENS_FRAMEANGACC, MJH_SENS_SUBTREECOM, MJH_SENS_SUBTREELINVEL, MJH_SENS_SUBTREEANGMOM, MJH_SENS_CLOCK,
   MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
-  MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC,
+  MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
   MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,

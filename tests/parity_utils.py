@@ -304,24 +304,26 @@ SENSOR_XML = """
   <default><geom type="capsule" size=".03" condim="3"/><joint damping=".1"/></default>
   <worldbody>
     <geom name="floor" type="plane" size="3 3 .01"/>
+    <geom name="tgt_box" type="box" size=".2 .3 .1" pos="1.3 0 .3" euler="10 20 0" contype="0" conaffinity="0"/><geom name="tgt_cyl" type="cylinder" size=".15 .3" pos="-.5 .4 -.05" euler="20 0 0" contype="0" conaffinity="0"/>
+    <geom name="tgt_ell" type="ellipsoid" size=".2 .3 .1" pos=".6 0 .1" contype="0" conaffinity="0"/><geom name="ghost" type="sphere" size=".3" pos="-.5 .4 .1" rgba="1 0 0 0" contype="0" conaffinity="0"/>
     <site name="world_s" pos=".2 .1 .3" euler="10 20 30"/>
     <site name="zone_box" type="box" size=".3 .3 .06" pos="-.5 0 .05"/><site name="zone_cyl" type="cylinder" size=".3 .2" pos=".5 0 .5" euler="0 20 0"/>
     <site name="zone_sph" type="sphere" size=".25" pos=".45 0 .45"/><site name="zone_cap" type="capsule" size=".15 .3" pos=".4 0 .6" euler="0 90 0"/>
     <body name="a1" pos="0 0 .6">
       <joint name="j1" axis="0 1 0" range="-40 40" limited="true"/><geom name="g1" fromto="0 0 0 .25 0 0"/>
-      <site name="imu1" pos=".1 0 .02" euler="0 15 40"/>
+      <site name="imu1" pos=".1 0 .02" euler="0 15 40"/><site name="rf_side" pos="0 0 .05" euler="0 100 0"/>
       <body name="a2" pos=".25 0 0">
         <joint name="j2" type="ball"/><geom fromto="0 0 0 .2 0 0"/>
         <site name="imu2" pos=".15 .01 0" euler="30 0 0"/>
         <body name="a3" pos=".2 0 0"><joint name="j3" type="slide" axis="1 0 0" range="-.05 .05" limited="true"/>
-          <geom name="g3" type="sphere" size=".05"/><site name="tip" pos=".05 0 0"/></body>
+          <geom name="g3" type="sphere" size=".05"/><site name="tip" pos=".05 0 0"/><site name="rf_tip" pos=".06 0 0" euler="0 130 20"/></body>
       </body>
     </body>
     <body name="f1" pos="-.5 0 .08" euler="0 70 20"><freejoint/><geom name="gf" fromto="-.1 0 0 .1 0 0" size=".04"/>
       <site name="imuf" pos=".05 0 .01" euler="5 10 15"/>
       <site name="touch_box" type="box" size=".16 .06 .06"/><site name="touch_sph" type="sphere" size=".045" pos=".1 0 0"/>
       <site name="touch_ell" type="ellipsoid" size=".13 .05 .03" pos="-.04 0 0"/></body>
-    <body name="f2" pos="-.5 .4 .3"><freejoint/><geom type="sphere" size=".05"/><site name="f2s"/></body>
+    <body name="f2" pos="-.5 .4 .3"><freejoint/><geom type="sphere" size=".05"/><site name="f2s"/><site name="rf_down" pos="0 0 -.06" euler="180 0 0"/><site name="rf_up" pos="0 0 .06"/></body>
     <body name="p1" pos=".3 -.5 .5"><joint name="q1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/>
       <body pos="0 0 -.2"><joint name="q2" axis="1 0 0" range="-30 30" limited="true"/><geom fromto="0 0 0 0 0 -.2"/><site name="p_end" pos="0 0 -.2"/></body></body>
   </worldbody>
@@ -351,6 +353,7 @@ SENSOR_XML = """
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>
     <touch site="touch_box"/><touch site="touch_sph"/><touch site="touch_ell"/>
+    <rangefinder site="rf_down"/><rangefinder site="rf_side"/><rangefinder site="rf_tip"/><rangefinder site="rf_up"/>
     <insidesite objtype="body" objname="f1" site="zone_box"/><insidesite objtype="site" objname="tip" site="zone_cyl"/><insidesite objtype="xbody" objname="a3" site="zone_sph"/><insidesite objtype="geom" objname="g3" site="zone_cap"/>
     <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
   </sensor>
