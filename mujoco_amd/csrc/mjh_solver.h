@@ -194,7 +194,7 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
       MJH_PGS_CHAIN_STEP(9) MJH_PGS_CHAIN_STEP(10) MJH_PGS_CHAIN_STEP(11) MJH_PGS_CHAIN_STEP(12)
       MJH_PGS_CHAIN_STEP(13) MJH_PGS_CHAIN_STEP(14) MJH_PGS_CHAIN_STEP(15)
       MJH_PGS_CHAIN_END }
-      real dot = (wv_bcast(acc, 0) + wv_bcast(acc, 32)) + (wv_bcast(acc, 16) + wv_bcast(acc, 48));
+      real dot = wv_rows_sum(acc);
       if (ntail == 3) dot += wv_bcast(p, 15) + wv_bcast(p, 31) + wv_bcast(p, 47);
       else if (ntail == 2) dot += wv_bcast(p, 15) + wv_bcast(p, 31);
       else if (ntail == 1) dot += wv_bcast(p, 15);

@@ -157,6 +157,16 @@ MJH_DEV double wv_row_bcast(double v) {
   mjhsim::yield();
   return r;
 }
+// v is uniform inside each 16-lane row (value r_c in row c): every lane gets (r0 + r2) + (r1 + r3),
+// mju_dot's final association of its four partial sums
+MJH_DEV double wv_rows_sum(double v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = (w->dscratch[0] + w->dscratch[32]) + (w->dscratch[16] + w->dscratch[48]);
+  mjhsim::yield();
+  return r;
+}
 MJH_DEV long long wv_clock() { return 0; }
 
 #else
@@ -248,6 +258,22 @@ MJH_DEV double wv_row_bcast(double v) {
   int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
   int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
+}
+// v is uniform inside each 16-lane row (value r_c in row c): every lane gets (r0 + r2) + (r1 + r3),
+// mju_dot's final association of its four partial sums.  gfx950's v_permlane32_swap exchanges the
+// upper 32 lanes of one register with the lower 32 of another (rows 2,3 <-> rows 0,1), then
+// v_permlane16_swap the odd with the even rows: two VALU exchanges and two adds, no SGPR round
+// trip.  (IEEE addition commutes, so which operand of a swap pair lands where is immaterial.)
+MJH_DEV double wv_rows_sum(double v) {
+  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const u32x2_ l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const u32x2_ h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double t = __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+  const unsigned tlo = (unsigned)__double2loint(t), thi = (unsigned)__double2hiint(t);
+  const u32x2_ l2 = __builtin_amdgcn_permlane16_swap(tlo, tlo, false, false);
+  const u32x2_ h2 = __builtin_amdgcn_permlane16_swap(thi, thi, false, false);
+  return __hiloint2double((int)h2.x, (int)l2.x) + __hiloint2double((int)h2.y, (int)l2.y);
 }
 // constant-rate (100 MHz) timestamp, for -DMJH_PROFILE builds
 MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
