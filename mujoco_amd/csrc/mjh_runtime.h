@@ -383,9 +383,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
   if (lds_bytes < 0) lds_bytes = 0;
   if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
-  // sensors read kinematic / velocity / constraint quantities after the solve: such models keep
-  // every field in its global home (no residency plan)
-  if (Bt->model->H.s.nsensor > 0) lds_bytes = 0;
+
   // equality constraints read kinematics / velocity quantities long after their usual lifetimes
   // (rows at make, Jdot*v at reference): such models keep those fields in their global homes
   std::vector<std::string> eqskip;
@@ -396,6 +394,17 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (Bt->model->H.o.integrator == MJH_INT_IMPLICITFAST) {
     for (const char* f : {"xpos", "xmat", "xipos", "ximat", "ten_J", "ten_velocity", "actuator_moment",
                           "moment_rownnz", "moment_colind", "actuator_force"})
+      eqskip.push_back(f);
+  }
+  // sensors are evaluated after the solve and read kinematic / velocity / actuator / contact
+  // quantities past their usual lifetimes: those fields stay in their global homes; the constraint
+  // arrays (efc_*) are still intact at that point and the rest of the plan is unaffected
+  if (Bt->model->H.s.nsensor > 0) {
+    for (const char* f : {"xpos", "xquat", "xmat", "xipos", "ximat", "geom_xpos", "geom_xmat", "site_xpos", "site_xmat",
+                          "subtree_com", "cinert", "cdof", "cdof_dot", "cvel", "ten_length", "ten_velocity", "ten_J",
+                          "actuator_length", "actuator_velocity", "actuator_force", "qfrc_actuator",
+                          "con_dist", "con_pos", "con_frame", "con_mu", "con_pair", "con_geom", "con_dim",
+                          "con_exclude", "con_efcadr"})
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_gravcomp) eqskip.push_back("xipos");    // read by the passive stage
