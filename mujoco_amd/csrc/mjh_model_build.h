@@ -214,7 +214,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       continue;
     }
     int jt = m->jnt_type[m->actuator_trnid[2*i]];
-    MJH_REJECT(jt != mjJNT_HINGE && jt != mjJNT_SLIDE, "actuators on ball/free joints");
+    if (jt == mjJNT_BALL || jt == mjJNT_FREE) {
+      // 3D / 6D gear (engine_core_smooth.c:1331-1392); position servos on ball joints wrap their
+      // set point (wrapPeriod, engine_forward.c:297-328), which is not implemented
+      MJH_REJECT(jt == mjJNT_BALL && m->actuator_gaintype[i] == mjGAIN_FIXED && m->actuator_biastype[i] == mjBIAS_AFFINE &&
+                 m->actuator_gainprm[mjNGAIN*i] == -m->actuator_biasprm[mjNBIAS*i + 1], "position servos on ball joints");
+      MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
+                 m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
+                 "actuator-level armature/damping on a ball or free joint");
+    }
     // servo wrap period (wrapPeriod, engine_forward.c:305-342) is zero for hinge/slide joint transmissions
   }
   for (int i = 0; i < m->ntendon; i++) {
@@ -437,7 +445,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   H->actuator_momentadr[0] = 0;
   for (int i = 0; i < m->nu; i++)
     H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + ((m->actuator_trntype[i] == mjTRN_SLIDERCRANK || m->actuator_trntype[i] == mjTRN_SITE) ? m->nv :
-        (m->actuator_trntype[i] == mjTRN_TENDON ? std::max(1, m->ten_J_rownnz[m->actuator_trnid[2*i]]) : 1));
+        ((m->actuator_trntype[i] == mjTRN_JOINT || m->actuator_trntype[i] == mjTRN_JOINTINPARENT) ?
+          (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_BALL ? 3 : (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_FREE ? 6 : 1)) :
+        (m->actuator_trntype[i] == mjTRN_TENDON ? std::max(1, m->ten_J_rownnz[m->actuator_trnid[2*i]]) : 1)));
   s.nmoment = H->actuator_momentadr[m->nu];
 
   // ---------------- derived: tree levels, children, dof ancestors --------------------------------------

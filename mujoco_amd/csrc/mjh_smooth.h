@@ -451,6 +451,33 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
         colind[adr + k] = M.ten_J_colind[ra + k];
         moment[adr + k] = tJ[ra + k]*gear[0];
       }
+    } else if (M.jnt_type[id] == MJH_JNT_BALL) {
+      // ball joint: 3D gear; length = expmap(quat) . gear (engine_core_smooth.c:1331-1362)
+      const int qa = M.jnt_qposadr[id], da = M.jnt_dofadr[id];
+      real quat[4] = {qpos[qa], qpos[qa+1], qpos[qa+2], qpos[qa+3]};
+      real axis[3], ga[3], g[3] = {gear[0], gear[1], gear[2]};
+      q_normalize(quat);
+      q_tovel(axis, quat, 1);
+      if (M.actuator_trntype[i] == MJH_TRN_JOINT) { ga[0] = g[0]; ga[1] = g[1]; ga[2] = g[2]; }
+      else { real nq[4] = {quat[0], -quat[1], -quat[2], -quat[3]}; q_rotvec(ga, g, nq); }
+      length[i] = v3_dot(axis, ga);
+      rownnz[i] = 3;
+      for (int k = 0; k < 3; k++) { colind[adr + k] = da + k; moment[adr + k] = ga[k]; }
+    } else if (M.jnt_type[id] == MJH_JNT_FREE) {
+      // free joint: 6D gear, no meaningful length (:1364-1392)
+      const int qa = M.jnt_qposadr[id], da = M.jnt_dofadr[id];
+      real ga[3], g[3] = {gear[3], gear[4], gear[5]};
+      if (M.actuator_trntype[i] == MJH_TRN_JOINT) { ga[0] = g[0]; ga[1] = g[1]; ga[2] = g[2]; }
+      else {
+        real quat[4] = {qpos[qa+3], qpos[qa+4], qpos[qa+5], qpos[qa+6]};
+        q_normalize(quat);
+        real nq[4] = {quat[0], -quat[1], -quat[2], -quat[3]};
+        q_rotvec(ga, g, nq);
+      }
+      length[i] = 0;
+      rownnz[i] = 6;
+      for (int k = 0; k < 3; k++) { colind[adr + k] = da + k; moment[adr + k] = gear[k]; }
+      for (int k = 0; k < 3; k++) { colind[adr + 3 + k] = da + 3 + k; moment[adr + 3 + k] = ga[k]; }
     } else {
       // slide / hinge joint: scalar gear
       rownnz[i] = 1;

@@ -544,3 +544,23 @@ SITE_ACT_XML = """
   </actuator>
 </mujoco>
 """
+
+
+# actuators on ball and free joints (3D / 6D gears, joint and jointinparent transmissions)
+BALL_ACT_XML = """<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40"/>
+  <default><geom type="capsule" size=".03" condim="3"/><joint damping=".1"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body pos="0 0 .8"><joint name="b1" type="ball"/><geom fromto="0 0 0 .25 0 0"/>
+      <body pos=".25 0 0"><joint name="b2" type="ball" range="0 60" limited="true"/><geom fromto="0 0 0 .2 0 .05"/></body></body>
+    <body pos="-.5 0 .3" euler="10 20 30"><joint name="fr" type="free"/><geom type="box" size=".1 .05 .03"/></body>
+  </worldbody>
+  <actuator>
+    <motor joint="b1" gear=".5 .2 -.3"/><motor joint="b2" gear="0 .4 .1"/>
+    <general joint="b2" gear=".3 0 .2" gaintype="affine" gainprm="1 .2 -.1" biastype="affine" biasprm=".1 -1 -.2"/>
+    <motor joint="fr" gear="1 0 2 0 .1 .05"/>
+    <motor jointinparent="b1" gear="0 .2 .4"/><general jointinparent="fr" gear="0 0 .5 .1 0 .2" dyntype="filter" dynprm=".05"/>
+  </actuator>
+</mujoco>
+"""

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -655,6 +655,28 @@ def test_site_transmissions_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_ball_and_free_joint_actuators_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """joint / jointinparent transmissions on ball and free joints: 3D and 6D gears, expmap length
+    (engine_core_smooth.c:1331-1392)"""
+    xml = tmp_path / "ball.xml"
+    xml.write_text(BALL_ACT_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80
+    ctrl = np.random.default_rng(0).uniform(-.5, .5, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
 
 
 def _sensor_reference(rb, m, s0, ctrl):
