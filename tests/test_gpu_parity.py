@@ -418,6 +418,28 @@ def test_spatial_tendons_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     assert relerr(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("scene", ["SITE_ACT_XML", "BALL_ACT_XML"])
+def test_cartesian_and_ball_actuators_vs_live_oracle(rb, hip_lib, tmp_path, scene):
+    """site transmissions and actuators on ball / free joints, implicitfast (their moments enter qDeriv)"""
+    import parity_utils
+    xml = tmp_path / "scene.xml"
+    xml.write_text(getattr(parity_utils, scene))
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = 3
+    dmx = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 150
+    ctrl = np.random.default_rng(0).uniform(-.5, .5, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmx, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print(scene, "rel err", relerr(out, ref))
+    assert relerr(out, ref) <= TOL
+
+
 def test_sensors_vs_live_oracle(rb, hip_lib, tmp_path):
     """sensordata of every rollout step: 113 readings of 45 sensors incl. IMU / force / torque"""
     xml = tmp_path / "sens.xml"
