@@ -883,6 +883,60 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
     aref[r] = -KBIP[4*r+1]*v - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
   }
   wv_sync();
+  // relative surface velocity of the contacting geoms (conveyor belts) enters efc_vel of the
+  // tangential / torsional rows before aref is formed  (mj_addSurfaceVel, :3141-3204;
+  // mj_geomSurfaceVelocity, engine_core_util.c:892-905)
+  if (M.o.has_surfacevel) {
+    const MJH_CONST_AS DSizes& s = M.s;
+    const int ncon = MJH_F(B, counts, e)[MJH_C_NCON];
+    crptr gx = MJH_F(B, geom_xpos, e);
+    crptr gm = MJH_F(B, geom_xmat, e);
+    MJH_FOR_LANES(c, ncon) {
+      const int adr = MJH_CON(B, con_efcadr, e, 1, c)[0];
+      if (adr < 0) continue;
+      ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+      crptr cp = MJH_CON(B, con_pos, e, 3, c);
+      crptr fr = MJH_CON(B, con_frame, e, 9, c);
+      real svel[3] = {0, 0, 0}, sang[3] = {0, 0, 0};
+      int active = 0;
+      for (int side = 0; side < 2; side++) {
+        const int g = cg[side];
+        auto sv = M.geom_surfacevel + 6*g;
+        if (!sv[0] && !sv[1] && !sv[2] && !sv[3] && !sv[4] && !sv[5]) continue;
+        active = 1;
+        const real sgn = side ? 1 : -1;
+        real lin[3], ang[3], arm[3], wxr[3], svl[3] = {sv[0], sv[1], sv[2]}, sva[3] = {sv[3], sv[4], sv[5]};
+        m3_mulvec(lin, gm + 9*g, svl);
+        m3_mulvec(ang, gm + 9*g, sva);
+        v3_sub(arm, cp, gx + 3*g);
+        v3_cross(wxr, ang, arm);
+        v3_addto(lin, wxr);
+        v3_addtoscl(svel, lin, sgn);
+        v3_addtoscl(sang, ang, sgn);
+      }
+      if (!active) continue;
+      real cs[6];
+      m3_mulvec(cs, fr, svel);
+      m3_mulvec(cs + 3, fr, sang);
+      cs[0] = 0; cs[4] = 0; cs[5] = 0;
+      const int dim = MJH_CON(B, con_dim, e, 1, c)[0];
+      auto mu = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, c)[0];
+      const int nrow = (dim == 1) ? 1 : (M.o.cone == 0 ? 2*(dim - 1) : dim);
+      if (dim == 1 || M.o.cone != 0) {
+        for (int j = 0; j < dim; j++) vel[adr + j] += cs[j];
+      } else {
+        for (int k = 1; k < dim; k++) {
+          vel[adr + 2*(k-1)] += cs[0] + mu[k-1]*cs[k];
+          vel[adr + 2*(k-1) + 1] += cs[0] - mu[k-1]*cs[k];
+        }
+      }
+      for (int j = 0; j < nrow; j++) {
+        const int r = adr + j;
+        aref[r] = -KBIP[4*r+1]*vel[r] - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
+      }
+    }
+    wv_sync();
+  }
   // subtract Jdot*v for connect / weld equalities               (mj_Jdotv, :1056-1250)
   const int ne = MJH_F(B, counts, e)[MJH_C_NE];
   if (ne) {

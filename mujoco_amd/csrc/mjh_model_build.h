@@ -160,7 +160,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
-  MJH_REJECT(m->flg_surfacevel, "geom surface velocity");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
              "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
@@ -363,6 +362,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_mass, m->body_mass, m->nbody);
   copy_arr(H->body_gravcomp, m->body_gravcomp, m->nbody);
   o.has_gravcomp = m->flg_gravcomp ? 1 : 0;
+  o.has_surfacevel = m->flg_surfacevel ? 1 : 0;
+  copy_arr(H->geom_surfacevel, m->geom_surfacevel, 6*m->ngeom);
   o.has_fluid = (m->opt.density != 0 || m->opt.viscosity != 0) ? 1 : 0;
   o.density = m->opt.density; o.viscosity = m->opt.viscosity;
   for (int k = 0; k < 3; k++) o.wind[k] = m->opt.wind[k];

@@ -408,6 +408,10 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_gravcomp) eqskip.push_back("xipos");    // read by the passive stage
+  if (Bt->model->H.o.has_surfacevel) {   // contact geometry is read again by the reference stage
+    for (const char* f : {"geom_xpos", "geom_xmat", "con_pos", "con_frame", "con_pair", "con_geom", "con_dim", "con_efcadr"})
+      eqskip.push_back(f);
+  }
   if (Bt->model->H.o.has_fluid) { eqskip.push_back("xipos"); eqskip.push_back("ximat"); }
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS

@@ -150,6 +150,7 @@
   X(site_pos, 3 * s.nsite)                     \
   X(site_quat, 4 * s.nsite)                    \
   X(site_size, 3 * s.nsite)                    \
+  X(geom_surfacevel, 6 * s.ngeom)              \
   X(tendon_range, 2 * s.ntendon)               \
   X(tendon_margin, s.ntendon)                  \
   X(tendon_solref_lim, 2 * s.ntendon)          \
@@ -217,6 +218,7 @@ struct DOptions {
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_ten_armature;
   int has_gravcomp;
+  int has_surfacevel; // some geom has a surface velocity (conveyor belts)
   int has_fluid;      // opt.density / opt.viscosity set: inertia-box fluid forces
   real density, viscosity, wind[3];
 };

@@ -564,3 +564,20 @@ BALL_ACT_XML = """<mujoco>
   </actuator>
 </mujoco>
 """
+
+
+# geom surface velocities: a spinning floor (turntable), a conveyor belt box and a box that drives
+# itself; sliding, torsional and rolling contacts on them
+SURFACEVEL_XML = """<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="4 4 .01" surfacevel="0 0 0 0 0 1.5"/>
+    <geom name="belt" type="box" size="1 .3 .05" pos="0 1.5 .05" surfacevel=".6 0 0 0 0 0" friction="1 .01 .001"/>
+    <body pos="-.5 1.5 .151"><freejoint/><geom type="box" size=".08 .06 .05" condim="3"/></body>
+    <body pos="0 1.45 .16"><freejoint/><geom type="sphere" size=".06" condim="4" friction=".8 .02 .001"/></body>
+    <body pos=".5 .2 .06"><freejoint/><geom type="sphere" size=".06" condim="6"/></body>
+    <body pos="-.6 -.3 .051"><freejoint/><geom type="box" size=".1 .1 .05" condim="4" surfacevel="0 .2 0 0 0 0"/></body>
+    <body pos="0 -.8 .04" euler="90 0 0"><freejoint/><geom type="capsule" size=".04 .1" condim="3"/></body>
+  </worldbody>
+</mujoco>
+"""

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -676,6 +676,31 @@ def test_ball_and_free_joint_actuators_bit_exact(rb, hostsim_lib, tmp_path, inte
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("cone,solver,tol", [(0, 0, 0.0), (1, 0, 0.0), (1, 2, 1e-9)])
+def test_geom_surface_velocity(rb, hostsim_lib, tmp_path, cone, solver, tol):
+    """mj_addSurfaceVel (engine_core_constraint.c:3141-3204): the relative surface velocity of the
+    contacting geoms enters efc_vel of the tangential / torsional rows (conveyor, turntable)"""
+    xml = tmp_path / "sv.xml"
+    xml.write_text(SURFACEVEL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    m.opt.solver = solver
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 100
+    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    assert np.abs(ref[0, -1] - s0[0]).max() > 1.0, "the belts are supposed to move the objects"
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
     assert b.get("warning").sum() == 0
 
 
