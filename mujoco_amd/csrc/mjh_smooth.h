@@ -80,7 +80,7 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
         int pid = M.body_parentid[i];
         // body pose in the parent: from the model, or the user-driven mocap arrays (:84-93)
         real bpos[3], bquat[4];
-        const int mid = M.body_mocapid[i];
+        const int mid = s.nmocap ? (int)M.body_mocapid[i] : -1;
         if (mid >= 0) {
           v3_copy(bpos, MJH_G(B, mocap_pos, e) + 3*mid);
           q_copy(bquat, MJH_G(B, mocap_quat, e) + 4*mid);
@@ -1170,7 +1170,7 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
       c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
     if (bad) c = 0;
     // stateful actuators: act_dot from the control, the force sees the activation (:403-447, :800-817)
-    const int dyn = M.actuator_dyntype[i];
+    const int dyn = s.na ? (int)M.actuator_dyntype[i] : (int)MJH_DYN_NONE;
     if (dyn != MJH_DYN_NONE) {
       const int aa = M.actuator_actadr[i];
       real ad;

@@ -194,7 +194,14 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
       MJH_PGS_CHAIN_STEP(9) MJH_PGS_CHAIN_STEP(10) MJH_PGS_CHAIN_STEP(11) MJH_PGS_CHAIN_STEP(12)
       MJH_PGS_CHAIN_STEP(13) MJH_PGS_CHAIN_STEP(14) MJH_PGS_CHAIN_STEP(15)
       MJH_PGS_CHAIN_END }
+      // (r0 + r2) + (r1 + r3) through v_readlane + scalar operands: measured 3 % faster than the
+      // all-VALU v_permlane32_swap / v_permlane16_swap combine (wv_rows_sum, -DMJH_PERMLANE_COMBINE) --
+      // the kernel is VALU-issue bound and the readlane path runs beside it
+#ifdef MJH_PERMLANE_COMBINE
       real dot = wv_rows_sum(acc);
+#else
+      real dot = (wv_bcast(acc, 0) + wv_bcast(acc, 32)) + (wv_bcast(acc, 16) + wv_bcast(acc, 48));
+#endif
       if (ntail == 3) dot += wv_bcast(p, 15) + wv_bcast(p, 31) + wv_bcast(p, 47);
       else if (ntail == 2) dot += wv_bcast(p, 15) + wv_bcast(p, 31);
       else if (ntail == 1) dot += wv_bcast(p, 15);
