@@ -11,13 +11,21 @@ random actions U(ctrlrange) drawn once per (env, step) and resident in HBM befor
 [nenv][K][nstate] (the rollout API's `state` output, worst-case I/O).  The K timed steps run as
 launches of the rollout kernel of --chunk steps each (one wavefront per environment loops over
 the steps of a launch), bracketed by barrier + device synchronisation; the time is the max over
-ranks.  Environments shard across
-ranks with no per-step exchange (weak scaling: 4096 envs on every GPU); the only collective is the
-end-of-chunk gather of the final states to rank 0 over RCCL, inside the timed region.
+ranks.  The W warm-up steps exercise EVERY code path of the timed region (launch with a state
+output, the strided final-state copy, the gather), so nothing is loaded or compiled inside the
+timer and wall time == kernel time at any --steps.  Environments shard across ranks with no
+per-step exchange (weak scaling: 4096 envs on every GPU); the only collective is the end-of-run
+gather of the final states to rank 0 over RCCL, inside the timed region.
 
-Prints ONE JSON line (rank 0) with the throughput, the roofline object for the dominant (only)
-kernel and, at N=1, the CPU baseline: the reference engine's own `testspeed` (oracle/_ref, built
-from the reference sources) on all host cores for a bounded sample.
+Prints ONE JSON line (rank 0) with the throughput and
+  roofline       the dominant (only) kernel against the HBM bound,
+  parity_sample  64 of the timed environments re-stepped on the compiled reference (oracle/_ref),
+                 every step of warm-up + timed region: max relative state error per step and the
+                 integer counts (ncon, nefc, solver iterations) of the last step,
+  testspeed_regime  the same kernel in the reference testspeed's control regime (OU-filtered
+                 Halton noise, `sample/testspeed.cc:72-112`, after the humanoids have settled on
+                 the floor: nefc ~ 46) so that CPU and GPU legs run the same contact regime,
+  cpu_baseline   (N=1) the reference engine's own `testspeed` on all host cores, bounded sample.
 """
 from __future__ import annotations
 
@@ -35,8 +43,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NENV_PER_GPU = 4096
-# algorithmic HBM bytes per env-step: state read + state written
-# (2*nstate), control read (ncontrol), warmstart read + written (2*nv), 8 bytes each
 HBM_PEAK_GBS = 8000.0
 
 
@@ -53,6 +59,33 @@ def initial_states(qpos0: np.ndarray, nv: int, nenv: int, seed: int) -> np.ndarr
     return s0
 
 
+def halton(index: int, base: int) -> float:
+    """mju_Halton (src/engine/engine_util_misc.c:2283)"""
+    n0, f, hn = index, 1.0 / base, 0.0
+    while n0 > 0:
+        n1 = n0 // base
+        hn += f * (n0 - n1 * base)
+        f /= base
+        n0 = n1
+    return hn
+
+
+def ctrl_noise(nstep: int, nu: int, dt: float, lo: np.ndarray, hi: np.ndarray,
+               noise_std: float = 0.01, noise_rate: float = 0.1) -> np.ndarray:
+    """CtrlNoise of the reference's sample/testspeed.cc:72-112 (all actuators ctrl-limited, no
+    keyframe): an Ornstein-Uhlenbeck filtered Halton sequence around the range midpoint."""
+    rate = np.exp(-dt / noise_rate)
+    scale = noise_std * np.sqrt(1 - rate * rate)
+    mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    out = np.zeros((nstep, nu))
+    for t in range(nstep):
+        for i in range(nu):
+            c = rate * out[t - 1, i] + (1 - rate) * mid[i] if t > 0 else mid[i]
+            c += scale * half[i] * (2 * halton(t, i + 2) - 1)
+            out[t, i] = min(max(c, lo[i]), hi[i])
+    return out
+
+
 def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
     """reference CPU engine timed by the reference's own sample/testspeed.cc (compiled from the
     reference sources into oracle/_ref by oracle/Makefile) on the host cores of this box."""
@@ -67,14 +100,18 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
                              capture_output=True, text=True, env=env, timeout=600).stdout
         m = re.search(r"Total steps per second\s*:\s*([0-9.]+)", out)
         it = re.search(r"PGS iters / step\s*:\s*([0-9.]+)", out)
-        return (float(m.group(1)) if m else None), (float(it.group(1)) if it else None)
+        nc = re.search(r"Contacts / step\s*:\s*([0-9.]+)", out)
+        ne = re.search(r"Constraints / step\s*:\s*([0-9.]+)", out)
+        g = lambda x: float(x.group(1)) if x else None
+        return g(m), g(it), g(nc), g(ne)
 
-    sps, _ = run(2000)                          # calibration
+    sps, *_ = run(2000)                          # calibration
     if not sps:
         return None
     nstep = int(max(2000, min(400000, budget_s * sps / nthread)))
-    sps, iters = run(nstep)
+    sps, iters, ncon, nefc = run(nstep)
     return {"value": sps, "unit": "env-steps/s", "cores": nthread, "kind": "reference",
+            "mean_ncon": ncon, "mean_nefc": nefc, "mean_pgs_iter": iters,
             "sample": f"reference sample/testspeed.cc on liboracle_fast (-O3 -mavx), humanoid.mjb --solver=PGS "
                       f"--nthread={nthread} --nstep={nstep} (OU-Halton ctrl noise, its default regime; "
                       f"{iters} PGS iters/step)"}
@@ -82,24 +119,68 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
 
 def measured_traffic(steps_per_launch: int, nenv: int):
     """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    same command (tools/gpu_profile.sh -> profiles/<round>/pmc_summary.txt; FETCH_SIZE x2 per the
+    same command (tools/gpu_profile.sh -> profiles/<round>/pmc_summary*.txt; FETCH_SIZE x2 per the
     gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the launch."""
     import glob
     best = None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.txt")))
     # profiles/CURRENT names the directory measured on the committed build; it is read last (wins)
     cur = os.path.join(ROOT, "profiles", "CURRENT")
     if os.path.exists(cur):
-        f0 = os.path.join(ROOT, "profiles", open(cur).read().strip(), "pmc_summary.txt")
-        if f0 in files:
-            files.remove(f0)
-            files.append(f0)
+        pref = os.path.join(ROOT, "profiles", open(cur).read().strip()) + os.sep
+        files = [f for f in files if not f.startswith(pref)] + [f for f in files if f.startswith(pref)]
     for f in files:
         m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB",
                       open(f).read())
         if m and int(m.group(1)) == steps_per_launch and int(m.group(2)) == nenv:
             best = (float(m.group(4)) + float(m.group(5))) * 1e6
     return best
+
+
+def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, gpu_counts, envs):
+    """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
+    as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
+    (warm-up + timed).  The oracle is stepped from s0 with its own warm start; after every step its
+    state is compared with the GPU's and then re-synchronised to it, so the figure is the per-step
+    error of every step of the timed workload, not a chaotic accumulation."""
+    try:
+        from oracle import refbind as rb
+        if not rb.available():
+            return None
+    except Exception:
+        return None
+    m = rb.MjModel.from_binary_path(model_path)
+    m.opt.solver = solver
+    m.opt.integrator = integrator
+    spec = rb.mjSTATE_FULLPHYSICS
+    worst, worst_at = 0.0, None
+    counts_ok, nbad = True, 0
+    T = ctrl.shape[1]
+    for k, e in enumerate(envs):
+        d = rb.MjData(m)
+        rb.mj_setState(m, d, s0[k], spec)
+        for t in range(T):
+            d.ctrl[:] = ctrl[k, t]
+            rb.mj_step(m, d)
+            ref = rb.mj_getState(m, d, spec)
+            got = gpu_state[k, t]
+            err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+            if not np.isfinite(err):
+                err = float("inf")
+            if err > worst:
+                worst, worst_at = err, (int(e), t)
+            if t < T - 1:
+                rb.mj_setState(m, d, got, spec)
+        c = gpu_counts[k]
+        if (int(c[0]), int(c[1]), int(c[5])) != (int(d.ncon), int(d.nefc), int(d.solver_niter[0])):
+            counts_ok = False
+            nbad += 1
+    return {"envs": len(envs), "steps_checked": T, "max_rel_err": worst, "worst_env_step": worst_at,
+            "tolerance": 1e-6, "counts_exact_last_step": counts_ok, "count_mismatches": nbad,
+            "ok": bool(worst <= 1e-6 and counts_ok),
+            "protocol": "oracle/_ref mj_step from the same state0/controls, compared after every step of "
+                        "warm-up + timed region and re-synchronised to the GPU state (own warm start kept); "
+                        "ncon/nefc/solver_niter of the last step exact"}
 
 
 def main() -> None:
@@ -111,9 +192,18 @@ def main() -> None:
     ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")
-    ap.add_argument("--solver", choices=["pgs", "newton"], default="pgs",
+    ap.add_argument("--solver", choices=["pgs", "newton", "cg"], default="pgs",
                     help="pgs = BASELINE config 2 (the metric); newton = the reference's default solver")
-    ap.add_argument("--integrator", choices=["euler", "rk4"], default="euler")
+    ap.add_argument("--integrator", choices=["euler", "rk4", "implicitfast"], default="euler")
+    ap.add_argument("--ctrl", choices=["uniform", "ou-halton"], default="uniform",
+                    help="uniform = U(ctrlrange) per (env, step) (SURVEY 8d mode B, the metric); ou-halton = "
+                         "testspeed's CtrlNoise sequence shared by all envs (mode A)")
+    ap.add_argument("--settle", type=int, default=0, help="untimed steps before the warm-up (contact-rich regime)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="only the timed region (profiling runs): no parity sample, no testspeed-regime leg, no CPU baseline")
+    ap.add_argument("--regime-steps", type=int, default=200, help="timed steps of the testspeed-regime leg")
+    ap.add_argument("--regime-settle", type=int, default=1000, help="untimed settling steps of that leg")
+    ap.add_argument("--parity-envs", type=int, default=64)
     args = ap.parse_args()
 
     import torch
@@ -135,32 +225,26 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = ma.lib()
-    model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
-    model.set_option("solver", 0 if args.solver == "pgs" else 2)     # PGS = BASELINE config 2
-    model.set_option("integrator", 0 if args.integrator == "euler" else 1)
+    model_path = os.path.join(ROOT, "tests", "golden", "humanoid.mjb")
+    model = ma.MjbModel(lib, model_path)
+    solver_id = {"pgs": 0, "cg": 1, "newton": 2}[args.solver]
+    integ_id = {"euler": 0, "rk4": 1, "implicitfast": 3}[args.integrator]
+    model.set_option("solver", solver_id)     # PGS = BASELINE config 2
+    model.set_option("integrator", integ_id)
     dm = ma.DeviceModel(lib, model)
     nenv, K, W = args.envs_per_gpu, args.steps, args.warmup
     nq, nv, nu, nstate = dm.nq, dm.nv, dm.nu, dm.nstate
     batch = ma.Batch(dm, nenv, device=local_rank)
     qpos0 = batch.get("qpos")[0]
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    lo, hi = -np.ones(nu), np.ones(nu)       # humanoid ctrlrange
+    dt = 0.005                                # humanoid.xml:17
 
-    # synthetic inputs, resident in HBM before timing.  Steps are issued in launches of C steps
-    # (one rollout-kernel launch = C x nenv env-steps) so that every launch is the same unit of
-    # work for the profiler; controls / state outputs are laid out per launch.
     C = max(1, min(args.chunk, K))
+
     def chunks(n):
         return [C] * (n // C) + ([n % C] if n % C else [])
-    s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank)
-    crng = np.random.Generator(np.random.PCG64(4321 + rank))
-    dev = torch.device("cuda", local_rank)
-    state0 = torch.from_numpy(s0).to(dev)
-    lo, hi = -1.0, 1.0       # humanoid ctrlrange
-    ctrl_w = [torch.from_numpy(crng.uniform(lo, hi, size=(nenv, c, nu))).to(dev) for c in chunks(W)]
-    ctrl_k = [torch.from_numpy(crng.uniform(lo, hi, size=(nenv, c, nu))).to(dev) for c in chunks(K)]
-    state_k = [None if args.no_state_output else torch.empty((nenv, c, nstate), dtype=torch.float64, device=dev)
-               for c in chunks(K)]
-    final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
         if dist:
@@ -169,41 +253,81 @@ def main() -> None:
 
     events = []
 
-    def launch(ctrl, out, first):
+    def launch(ctrl, out, state0=None):
+        """one rollout-kernel launch of ctrl.shape[1] steps; state0 given: load the initial states,
+        else continue from the batch's own state, warm start and warning counters"""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        # first launch loads the initial states; later ones continue from the batch's own state,
-        # warm start and warning counters (MJHIP_ROLLOUT_CONTINUE)
-        batch.rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, state0.data_ptr() if first else 0,
+        batch.rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, 0 if state0 is None else state0.data_ptr(),
                              0, ctrl.data_ptr(), 0 if out is None else out.data_ptr(), stream,
-                             cont=not first)
+                             cont=state0 is None)
         e1.record()
         events.append((e0, e1, ctrl.shape[1]))
 
-    # warmup: W untimed steps from the initial states
-    first = True
-    for c in ctrl_w:
-        launch(c, None, first)
-        first = False
-    barrier()
-    n_warm_launch = len(events)
+    def make_controls(kind, crng, sizes, t_begin):
+        """device control arrays [nenv][c][nu] for consecutive launches of the given sizes"""
+        out, t = [], t_begin
+        if kind == "uniform":
+            for c in sizes:
+                out.append(torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, c, nu))).to(dev))
+        else:
+            seq = ctrl_noise(t_begin + sum(sizes), nu, dt, lo, hi)
+            for c in sizes:
+                out.append(torch.from_numpy(np.ascontiguousarray(seq[t:t + c])).to(dev)[None].expand(nenv, c, nu).contiguous())
+                t += c
+        return out
 
-    t0 = time.perf_counter()
-    for c, o in zip(ctrl_k, state_k):
-        launch(c, o, first)
-        first = False
-    if state_k[-1] is not None:
-        final.copy_(state_k[-1][:, -1])
-    if dist:
-        gather_to_rank0(final, rank, world, dist)  # end-of-run state gather (RCCL over xGMI)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    timed = [(a.elapsed_time(b), n) for a, b, n in events[n_warm_launch:]]
-    allev = [(a.elapsed_time(b), n) for a, b, n in events]
+    def timed_region(state0, ctrl_settle, ctrl_w, ctrl_k, want_state):
+        """settle (untimed, no output) -> W warm-up steps through every code path of the timed
+        region -> barrier -> K timed steps -> final-state copy (+ gather) -> barrier"""
+        del events[:]
+        first = state0
+        for c in ctrl_settle:
+            launch(c, None, first)
+            first = None
+        state_w = [torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if want_state else None
+                   for c in ctrl_w]
+        state_k = [torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if want_state else None
+                   for c in ctrl_k]
+        final = torch.empty((nenv, nstate), dtype=torch.float64, device=dev)
+
+        def finish(last):
+            if last is not None:
+                final.copy_(last[:, -1])
+            if dist:
+                gather_to_rank0(final, rank, world, dist)  # end-of-run state gather (RCCL over xGMI)
+
+        for c, o in zip(ctrl_w, state_w):
+            launch(c, o, first)
+            first = None
+        if not ctrl_w:
+            # no warm-up steps asked for: still load the copy / gather code paths (zero simulation steps)
+            finish(torch.zeros((nenv, 1, nstate), dtype=torch.float64, device=dev) if want_state else None)
+        else:
+            finish(state_w[-1])
+        barrier()
+        n_warm = len(events)
+        t0 = time.perf_counter()
+        for c, o in zip(ctrl_k, state_k):
+            launch(c, o, first)
+            first = None
+        finish(state_k[-1] if state_k else None)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timed = [(a.elapsed_time(b), n) for a, b, n in events[n_warm:]]
+        return elapsed, timed, state_w, state_k
+
+    # ---------------- the metric: random actions U(ctrlrange), BASELINE config 2 -----------------
+    s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank)
+    state0 = torch.from_numpy(s0).to(dev)
+    crng = np.random.Generator(np.random.PCG64(4321 + rank))
+    want_state = not args.no_state_output
+    ctrl_s = make_controls(args.ctrl, crng, chunks(args.settle) if args.settle else [], 0)
+    ctrl_w = make_controls(args.ctrl, crng, chunks(W) if W else [], args.settle)
+    ctrl_k = make_controls(args.ctrl, crng, chunks(K), args.settle + W)
+    elapsed, timed, state_w, state_k = timed_region(state0, ctrl_s, ctrl_w, ctrl_k, want_state)
     kernel_ms = sum(t for t, _ in timed)
     launch_ms_timed = float(np.mean([t for t, n in timed if n == C])) if any(n == C for _, n in timed) else kernel_ms
-    launch_ms_all = float(np.mean([t for t, n in allev if n == C])) if any(n == C for _, n in allev) else launch_ms_timed
-
     if dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,9 +335,12 @@ def main() -> None:
     warn = int(batch.get("warning").sum())
     counts = batch.get("counts")
 
+    res = None
     if rank == 0:
         total_env_steps = nenv * world * K
         value = total_env_steps / elapsed
+        # algorithmic HBM bytes per env-step: state read + state written
+        # (2*nstate), control read (ncontrol), warmstart read + written (2*nv), 8 bytes each
         bytes_per_env_step = 8 * (2 * nstate + nu + 2 * nv)
         # one launch = C steps of nenv envs; achieved = algorithmic bytes per launch / avg launch time
         achieved = bytes_per_env_step * nenv * C / (launch_ms_timed * 1e-3) / 1e9
@@ -231,23 +358,63 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"model/humanoid/humanoid.xml, {nenv} envs/GPU, {args.solver.upper()} solver, {args.integrator}, fp64, "
-                                   "random actions U(ctrlrange), per-step state output" +
-                                   ("" if not args.no_state_output else " disabled"),
+                                   + ("random actions U(ctrlrange)" if args.ctrl == "uniform" else "testspeed OU-Halton ctrl noise")
+                                   + ", per-step state output" + ("" if want_state else " disabled"),
                        "envs_per_gpu": nenv, "nstep": K, "solver": args.solver.upper(), "integrator": args.integrator,
+                       "ctrl": args.ctrl, "settle": args.settle,
                        "parallelism": f"env-sharded x{world}",
                        "mapping": batch.lds_report().splitlines()[0] if batch.lds_report() else "no LDS plan",
+                       "kernel_variant": batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic",
                        "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv),
                          "kernel": "mjh_k_rollout", "steps_per_launch": C,
-                         "launch_ms": launch_ms_timed, "launch_ms_incl_warmup": launch_ms_all,
-                         "kernel_ms_total": kernel_ms,
+                         "launch_ms": launch_ms_timed, "kernel_ms_total": kernel_ms,
+                         "wall_ms_total": elapsed * 1e3,
                          "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "algorithmic_bytes_per_launch": bytes_per_env_step * nenv * C},
             "end_state": {"warnings": warn, "mean_ncon": float(counts[:, 0].mean()),
                           "mean_nefc": float(counts[:, 1].mean()), "mean_pgs_iter": float(counts[:, 5].mean())},
         }
-        if world == 1 and not args.no_cpu_baseline:
+
+    # ---------------- parity of the timed workload against the compiled reference ----------------
+    if rank == 0 and not args.no_extra and want_state and args.settle == 0 and args.parity_envs > 0:
+        envs = np.unique(np.linspace(0, nenv - 1, min(args.parity_envs, nenv)).astype(int))
+        idx = torch.from_numpy(envs).to(dev)
+        gs = torch.cat([x.index_select(0, idx) for x in state_w + state_k], dim=1).cpu().numpy()
+        cs = torch.cat([x.index_select(0, idx) for x in ctrl_w + ctrl_k], dim=1).cpu().numpy()
+        try:
+            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, counts[envs], envs)
+        except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
+            res["parity_sample"] = {"ok": False, "error": repr(exc)}
+    del state_w, state_k, ctrl_w, ctrl_k
+
+    # ---------------- the same kernel in the reference testspeed's control regime ----------------
+    if not args.no_extra and args.ctrl == "uniform" and args.regime_steps > 0:
+        K2, S2, W2 = args.regime_steps, args.regime_settle, 20
+        C2 = max(1, min(args.chunk, K2))
+        sizes = lambda n: [C2] * (n // C2) + ([n % C2] if n % C2 else [])
+        c_s = make_controls("ou-halton", None, sizes(S2), 0)
+        c_w = make_controls("ou-halton", None, sizes(W2), S2)
+        c_k = make_controls("ou-halton", None, sizes(K2), S2 + W2)
+        el2, timed2, _, _ = timed_region(state0, c_s, c_w, c_k, want_state)
+        k2 = sum(t for t, _ in timed2)
+        if dist:
+            t = torch.tensor([el2, k2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2, k2 = float(t[0]), float(t[1])
+        cn = batch.get("counts")
+        if rank == 0:
+            res["testspeed_regime"] = {
+                "value": nenv * world * K2 / el2, "unit": "env-steps/s", "steps": K2, "settle": S2 + W2,
+                "ms_per_step": el2 * 1e3 / K2, "kernel_ms_total": k2, "steps_per_launch": C2,
+                "ctrl": "CtrlNoise of sample/testspeed.cc:72-112 (std 0.01, rate 0.1), one sequence shared by all envs; "
+                        "initial states as in the metric leg",
+                "end_state": {"warnings": int(batch.get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
+                              "mean_nefc": float(cn[:, 1].mean()), "mean_pgs_iter": float(cn[:, 5].mean())}}
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extra:
             cb = cpu_baseline(os.cpu_count() or 1)
             if cb:
                 res["cpu_baseline"] = cb

@@ -48,7 +48,8 @@ MJHIP_API int mjhip_device_count(void);
  * reference (engine_collision_driver.c:2028, engine_core_constraint.c:145). */
 MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, int nefcmax);
 MJHIP_API void mjhip_model_destroy(mjhipModel* model);
-/* sizes: name is one of nq nv nu na nbody njnt ngeom nsite ntendon npair nconmax nefcmax nstate */
+/* sizes: name is one of nq nv nu na nbody njnt ngeom nsite ntendon npair nconmax nefcmax nstate, or
+ * "features" (bit set of optional features the model needs from a kernel variant) */
 MJHIP_API int mjhip_model_size(const mjhipModel* model, const char* name);
 
 /* Product-side reader of the reference's binary model format (mj_loadModel / mj_saveModel,
@@ -88,6 +89,20 @@ MJHIP_API int mjhip_batch_field(mjhipBatch* batch, const char* name, void** devi
                                 int* count_per_env, int* is_int);
 MJHIP_API int mjhip_batch_get(mjhipBatch* batch, const char* name, void* host_dst);
 MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* host_src);
+
+/* Kernel variant that steps the batch (no reference counterpart).  The stage sources are compiled in
+ * several mappings (mujoco_amd/csrc/mjh_modes.h):
+ *   "generic"  one wavefront per environment, every supported model feature;
+ *   "lean"     the same mapping compiled for the lean feature set only (PGS, pyramidal cones, Euler,
+ *              plane/sphere/capsule colliders, no sensors/equalities/...): no stack frames or register
+ *              pressure from features the model does not use;
+ *   "lean2"    lean, TWO environments per wavefront (32 lanes each, 256 VGPRs);
+ *   "lean4"    lean, four environments per wavefront (16 lanes each).
+ * mjhip_batch_create picks the leanest variant that covers the model ("auto"; $MJHIP_VARIANT
+ * overrides).  All variants produce bit-identical results.  set: 0 on success, <0 if the model needs
+ * a feature the variant lacks. */
+MJHIP_API int mjhip_batch_set_variant(mjhipBatch* batch, const char* name);
+MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* batch);
 
 /* LDS residency plan of the batch kernels (no reference counterpart: the reference keeps mjData in
  * host DRAM).  Each environment is stepped by one 64-lane wavefront that owns `lds_bytes` of LDS;

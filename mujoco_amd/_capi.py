@@ -90,6 +90,10 @@ class Lib:
         lib.mjhip_batch_get.argtypes = [vp, C.c_char_p, vp]
         lib.mjhip_batch_set.restype = ci
         lib.mjhip_batch_set.argtypes = [vp, C.c_char_p, vp]
+        lib.mjhip_batch_set_variant.restype = ci
+        lib.mjhip_batch_set_variant.argtypes = [vp, C.c_char_p]
+        lib.mjhip_batch_variant.restype = C.c_char_p
+        lib.mjhip_batch_variant.argtypes = [vp]
         lib.mjhip_batch_plan_lds.restype = ci
         lib.mjhip_batch_plan_lds.argtypes = [vp, ci]
         lib.mjhip_batch_lds_report.restype = C.c_char_p
@@ -114,7 +118,7 @@ class Lib:
         "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb", "mjhip_set_option",
         "mjhip_batch_create", "mjhip_batch_create_layout", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
-        "mjhip_batch_plan_lds", "mjhip_batch_lds_report",
+        "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
     )
 
@@ -256,6 +260,13 @@ class Batch:
         rc = self._lib.c.mjhip_batch_plan_lds(self._h, int(lds_bytes))
         self._lib.check(min(rc, 0), "plan_lds")
         return rc
+
+    def kernel_variant(self) -> str:
+        """name of the kernel mapping that steps this batch: generic | lean | lean2 | lean4"""
+        return self._lib.c.mjhip_batch_variant(self._h).decode()
+
+    def set_variant(self, name: str) -> None:
+        self._lib.check(self._lib.c.mjhip_batch_set_variant(self._h, name.encode()), f"set_variant {name}")
 
     def lds_report(self) -> str:
         return self._lib.c.mjhip_batch_lds_report(self._h).decode()

@@ -1,582 +1,525 @@
-// Collision stage of the batched step: candidate geom pairs -> contacts, one wavefront per env.
+// Collision stage of the batched step: candidate geom pairs -> contacts.
 //
 // The reference runs sweep-and-prune over bodies, then a BVH midphase, then the narrowphase
 // (engine_collision_driver.c:595-886).  Broad- and midphase only CULL pairs conservatively, so the
 // contact list equals "narrowphase over every geom pair that survives the model-constant filters"
 // in the reference's order: ascending body-pair signature, then (g1,g2) within a body pair, then
 // the collider's own emission order.  The host precomputes that ordered static
-// pair list with its mixed contact parameters (mjh_host.cpp: build_pairs); here each lane takes
-// pairs, applies the reference's bounding-sphere filter and the analytic collider, and the wave
-// compacts the survivors in order with a prefix sum.
+// pair list with its mixed contact parameters (mjh_model_build.h).
+//
+// Mapping onto a lane group (the MJH_W lanes that step one environment):
+//   * the pair list is walked in chunks of MJH_W pairs, one pair per lane: bounding-sphere filter,
+//     then the closed-form point colliders (plane/sphere/capsule: at most two contacts, kept in
+//     registers -- no contact array in private memory);
+//   * pairs of the chunk that need a multi-contact collider (box, cylinder) are taken ONE AT A
+//     TIME BY THE WHOLE GROUP: separating axes, box corners, polygon vertices and contact
+//     candidates are spread over lanes, selections are ballots / in-order scans that reproduce
+//     the reference's first-wins tie rules, and every surviving lane holds exactly one contact;
+//   * slots: a contact's index is (contacts of earlier chunks) + (exclusive scan of the per-pair
+//     counts) + its rank inside the pair, so lanes write their contacts straight into the
+//     (LDS-resident) contact slots in reference order.
+// All arithmetic that reaches a contact is evaluated in the reference's association
+// (engine_collision_primitive.c, engine_collision_box.c; cited per routine), which is what makes
+// contact counts and geometry agree bit for bit.
 // (included once per SPMD mode by mjh_modes.h -- no include guard, no includes of its own)
 
+struct V3 { real x, y, z; };
+MJH_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MJH_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MJH_DEV V3 operator*(V3 a, real s) { return V3{a.x*s, a.y*s, a.z*s}; }
+MJH_DEV real dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+MJH_DEV V3 cross(V3 a, V3 b) { return V3{a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x}; }
+template <class P> MJH_DEV V3 ld3(P p) { return V3{p[0], p[1], p[2]}; }
+template <class P> MJH_DEV void st3(P p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+// column c of a row-major 3x3 (c may differ per lane: the matrix lives in memory)
+template <class P> MJH_DEV V3 mcol(P m, int c) { return V3{m[c], m[3 + c], m[6 + c]}; }
+// M v and M' v in the reference's association (mji_mulMatVec3 / mji_mulMatTVec3)
+template <class P> MJH_DEV V3 mmul(P m, V3 v) {
+  return V3{m[0]*v.x + m[1]*v.y + m[2]*v.z, m[3]*v.x + m[4]*v.y + m[5]*v.z, m[6]*v.x + m[7]*v.y + m[8]*v.z};
+}
+template <class P> MJH_DEV real mtrow(P m, int i, V3 v) { return m[i]*v.x + m[3 + i]*v.y + m[6 + i]*v.z; }
+// unit vector + previous length (mju_normalize3: tiny vectors become the x axis)
+MJH_DEV real unitize(V3& v) {
+  const real n = sqrt(v.x*v.x + v.y*v.y + v.z*v.z);
+  if (n < MJH_MINVAL) { v = V3{1, 0, 0}; }
+  else { const real inv = 1/n; v = V3{v.x*inv, v.y*inv, v.z*inv}; }
+  return n;
+}
+// component k of v / v with component k replaced (k may differ per lane; selects, not memory)
+MJH_DEV real comp(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+MJH_DEV V3 with_comp(V3 v, int k, real s) { return V3{k == 0 ? s : v.x, k == 1 ? s : v.y, k == 2 ? s : v.z}; }
+// vector with components (i, i1, i2) = (a, b, c) for a cyclic index triple
+MJH_DEV V3 from_cyclic(int i, real a, real b, real c) {
+  return i == 0 ? V3{a, b, c} : (i == 1 ? V3{c, a, b} : V3{b, c, a});
+}
 
-struct PreContact {        // mjPreContact, include/mujoco/mjdata.h:29
-  real dist, pos[3], normal[3], tangent[3];
-};
+// mask of the lanes below lane k of a group (k < 64; only the low 32 lanes carry collider work)
+MJH_DEV unsigned lanes_below(int k) { return k >= 32 ? ~0u : (1u << k) - 1; }
 
-// mjraw_PlaneSphere, engine_collision_primitive.c:28
-template <class P0, class P1, class P2>
-MJH_DEV int col_plane_sphere(PreContact* c, real margin, P0 pos1, P1 mat1,
-                             P2 pos2, real radius) {
-  c->normal[0] = mat1[2]; c->normal[1] = mat1[5]; c->normal[2] = mat1[8];
-  real tmp[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
-  real cdist = v3_dot(tmp, c->normal);
-  if (cdist > margin + radius) return 0;
-  c->dist = cdist - radius;
-  v3_scl(tmp, c->normal, -c->dist / 2 - radius);
-  v3_add(c->pos, pos2, tmp);
-  v3_zero(c->tangent);
+// one contact candidate held by a lane: distance, position, normal, optional tangent hint
+struct Hit { real dist; V3 pos, nrm, tan; };
+
+// ---- point colliders (one pair per lane) -----------------------------------------------------------
+
+// plane : sphere (mjraw_PlaneSphere, engine_collision_primitive.c:28)
+MJH_DEV int hit_plane_sphere(Hit& h, real margin, V3 ppos, V3 pnrm, V3 centre, real radius) {
+  const real height = dot(centre - ppos, pnrm);
+  if (height > margin + radius) return 0;
+  h.dist = height - radius;
+  h.nrm = pnrm;
+  h.pos = centre + pnrm*(-h.dist/2 - radius);
+  h.tan = V3{0, 0, 0};
   return 1;
 }
 
-// mjc_PlaneCapsule, engine_collision_primitive.c:66
-template <class P0, class P1, class P2, class P3, class P4>
-MJH_DEV int col_plane_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
-                              P2 pos2, P3 mat2, P4 size2) {
-  real axis[3] = {mat2[2], mat2[5], mat2[8]};
-  real seg[3] = {size2[1]*axis[0], size2[1]*axis[1], size2[1]*axis[2]};
-  real end[3];
-  v3_add(end, pos2, seg);
-  int n1 = col_plane_sphere(c, margin, pos1, mat1, end, size2[0]);
-  v3_sub(end, pos2, seg);
-  int n2 = col_plane_sphere(c + n1, margin, pos1, mat1, end, size2[0]);
-  if (n1) v3_copy(c[0].tangent, axis);
-  if (n2) v3_copy(c[n1].tangent, axis);
+// sphere : sphere with the degenerate-centre fallback onto the geoms' z axes
+// (mjraw_SphereSphere, engine_collision_primitive.c:262)
+template <class P1, class P2>
+MJH_DEV int hit_sphere_sphere(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3 c2, P2 mat2, real r2) {
+  const V3 back = c1 - c2;
+  const real d2 = dot(back, back);
+  const real reach = margin + r1 + r2;
+  if (d2 > reach*reach) return 0;
+  h.dist = sqrt(d2) - r1 - r2;
+  V3 n = c2 - c1;
+  if (unitize(n) < MJH_MINVAL) {
+    n = cross(mcol(mat1, 2), mcol(mat2, 2));
+    unitize(n);
+  }
+  h.nrm = n;
+  h.pos = n*(r1 + h.dist/2) + c1;
+  h.tan = V3{0, 0, 0};
+  return 1;
+}
+
+// plane : capsule = the two end spheres, tangent along the capsule (mjc_PlaneCapsule, :66)
+template <class P2, class S2>
+MJH_DEV int hit_plane_capsule(Hit& a, Hit& b, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
+  const V3 axis = mcol(mat2, 2);
+  const V3 half = axis*(real)size2[1];
+  Hit lo;
+  const int n1 = hit_plane_sphere(a, margin, ppos, pnrm, c2 + half, size2[0]);
+  const int n2 = hit_plane_sphere(lo, margin, ppos, pnrm, c2 - half, size2[0]);
+  a.tan = axis;
+  lo.tan = axis;
+  if (n1) b = lo; else a = lo;
   return n1 + n2;
 }
 
-// mjraw_SphereSphere, engine_collision_primitive.c:262
-template <class P0, class P1, class P2, class P3>
-MJH_DEV int col_sphere_sphere(PreContact* c, real margin, P0 pos1, P1 mat1, real r1,
-                              P2 pos2, P3 mat2, real r2) {
-  real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  real cdist_sqr = v3_dot(dif, dif);
-  real min_dist = margin + r1 + r2;
-  if (cdist_sqr > min_dist*min_dist) return 0;
-  c->dist = sqrt(cdist_sqr) - r1 - r2;
-  v3_sub(c->normal, pos2, pos1);
-  real len = v3_normalize(c->normal);
-  if (len < MJH_MINVAL) {
-    real a1[3] = {mat1[2], mat1[5], mat1[8]};
-    real a2[3] = {mat2[2], mat2[5], mat2[8]};
-    v3_cross(c->normal, a1, a2);
-    v3_normalize(c->normal);
-  }
-  v3_scl(c->pos, c->normal, r1 + c->dist / 2);
-  v3_addto(c->pos, pos1);
-  v3_zero(c->tangent);
-  return 1;
+// sphere : capsule = sphere against the nearest point of the segment (mjraw_SphereCapsule, :313)
+template <class P1, class P2, class S2>
+MJH_DEV int hit_sphere_capsule(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3 c2, P2 mat2, S2 size2) {
+  const V3 axis = mcol(mat2, 2);
+  const real half = size2[1];
+  const real t = r_clip(dot(axis, c1 - c2), -half, half);
+  return hit_sphere_sphere(h, margin, c1, mat1, r1, axis*t + c2, mat2, size2[0]);
 }
 
-// mjraw_SphereCapsule, engine_collision_primitive.c:313
-template <class P0, class P1, class P2, class P3, class P4>
-MJH_DEV int col_sphere_capsule(PreContact* c, real margin, P0 pos1, P1 mat1, real r1,
-                               P2 pos2, P3 mat2, P4 size2) {
-  real len = size2[1];
-  real axis[3] = {mat2[2], mat2[5], mat2[8]};
-  real vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  real x = r_clip(v3_dot(axis, vec), -len, len);
-  v3_scl(vec, axis, x);
-  v3_addto(vec, pos2);
-  return col_sphere_sphere(c, margin, pos1, mat1, r1, vec, mat2, size2[0]);
-}
-
-// mjraw_CapsuleCapsule, engine_collision_primitive.c:425
-template <class P0, class P1, class P2, class P3, class P4, class P5>
-MJH_DEV int col_capsule_capsule(PreContact* c, real margin, P0 pos1, P1 mat1,
-                                P2 size1, P3 pos2, P4 mat2,
-                                P5 size2) {
-  real axis1[3] = {mat1[2]*size1[1], mat1[5]*size1[1], mat1[8]*size1[1]};
-  real axis2[3] = {mat2[2]*size2[1], mat2[5]*size2[1], mat2[8]*size2[1]};
-  real dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  real ma =  v3_dot(axis1, axis1);
-  real mb = -v3_dot(axis1, axis2);
-  real mc =  v3_dot(axis2, axis2);
-  real u  = -v3_dot(axis1, dif);
-  real v  =  v3_dot(axis2, dif);
-  real det = ma*mc - mb*mb;
-  real r1 = size1[0], r2 = size2[0];
-  real vec1[3], vec2[3];
-
+// capsule : capsule (mjraw_CapsuleCapsule, :425): closest points of the two segments; parallel
+// axes fall back to four end-point tests that stop at two contacts
+template <class P1, class S1, class P2, class S2>
+MJH_DEV int hit_capsule_capsule(Hit& a, Hit& b, real margin, V3 c1, P1 mat1, S1 size1, V3 c2, P2 mat2, S2 size2) {
+  const V3 u1 = mcol(mat1, 2)*(real)size1[1], u2 = mcol(mat2, 2)*(real)size2[1];
+  const V3 back = c1 - c2;
+  const real ma = dot(u1, u1), mb = -dot(u1, u2), mc = dot(u2, u2);
+  const real u = -dot(u1, back), v = dot(u2, back);
+  const real det = ma*mc - mb*mb;
+  const real r1 = size1[0], r2 = size2[0];
   if (fabs(det) >= MJH_MINVAL) {
     real x1 = (mc*u - mb*v) / det;
     real x2 = (ma*v - mb*u) / det;
-    if (x1 > 1) {
-      x1 = 1;
-      x2 = (v - mb) / mc;
-    } else if (x1 < -1) {
-      x1 = -1;
-      x2 = (v + mb) / mc;
-    }
-    if (x2 > 1) {
-      x2 = 1;
-      x1 = r_clip((u - mb) / ma, -1, 1);
-    } else if (x2 < -1) {
-      x2 = -1;
-      x1 = r_clip((u + mb) / ma, -1, 1);
-    }
-    v3_scl(vec1, axis1, x1);
-    v3_addto(vec1, pos1);
-    v3_scl(vec2, axis2, x2);
-    v3_addto(vec2, pos2);
-    return col_sphere_sphere(c, margin, vec1, mat1, r1, vec2, mat2, r2);
+    if (x1 > 1) { x1 = 1; x2 = (v - mb) / mc; }
+    else if (x1 < -1) { x1 = -1; x2 = (v + mb) / mc; }
+    if (x2 > 1) { x2 = 1; x1 = r_clip((u - mb) / ma, -1, 1); }
+    else if (x2 < -1) { x2 = -1; x1 = r_clip((u + mb) / ma, -1, 1); }
+    return hit_sphere_sphere(a, margin, u1*x1 + c1, mat1, r1, u2*x2 + c2, mat2, r2);
   }
-
-  // parallel axes: up to two contacts from the four end-point tests
-  v3_add(vec1, pos1, axis1);
-  real x2 = r_clip((v - mb) / mc, -1, 1);
-  v3_scl(vec2, axis2, x2);
-  v3_addto(vec2, pos2);
-  int n1 = col_sphere_sphere(c, margin, vec1, mat1, r1, vec2, mat2, r2);
-
-  v3_sub(vec1, pos1, axis1);
-  x2 = r_clip((v + mb) / mc, -1, 1);
-  v3_scl(vec2, axis2, x2);
-  v3_addto(vec2, pos2);
-  int n2 = col_sphere_sphere(c + n1, margin, vec1, mat1, r1, vec2, mat2, r2);
-  if (n1 + n2 >= 2) return n1 + n2;
-
-  v3_add(vec2, pos2, axis2);
-  real x1 = r_clip((u - mb) / ma, -1, 1);
-  v3_scl(vec1, axis1, x1);
-  v3_addto(vec1, pos1);
-  int n3 = col_sphere_sphere(c + n1 + n2, margin, vec1, mat1, r1, vec2, mat2, r2);
-  if (n1 + n2 + n3 >= 2) return n1 + n2 + n3;
-
-  v3_sub(vec2, pos2, axis2);
-  x1 = r_clip((u + mb) / ma, -1, 1);
-  v3_scl(vec1, axis1, x1);
-  v3_addto(vec1, pos1);
-  int n4 = col_sphere_sphere(c + n1 + n2 + n3, margin, vec1, mat1, r1, vec2, mat2, r2);
-  return n1 + n2 + n3 + n4;
+  // parallel: end points of capsule 1 against segment 2, then of capsule 2 against segment 1
+  int n = 0;
+  Hit t;
+  for (int trial = 0; trial < 4 && n < 2; trial++) {
+    V3 q1, q2;
+    if (trial < 2) {
+      const real sgn = trial == 0 ? 1 : -1;
+      q1 = trial == 0 ? c1 + u1 : c1 - u1;
+      q2 = u2*r_clip((v - sgn*mb) / mc, -1, 1) + c2;
+    } else {
+      const real sgn = trial == 2 ? 1 : -1;
+      q2 = trial == 2 ? c2 + u2 : c2 - u2;
+      q1 = u1*r_clip((u - sgn*mb) / ma, -1, 1) + c1;
+    }
+    if (hit_sphere_sphere(t, margin, q1, mat1, r1, q2, mat2, r2)) {
+      if (n == 0) a = t; else b = t;
+      n++;
+    }
+  }
+  return n;
 }
 
-// ---- box : box (mjc_BoxBox, engine_collision_box.c:697-1066) -------------------------------------
-// separating-axis search over 6 face and 9 edge-cross axes (with the reference's rounding slack,
-// edge bias and face substitution), then either one edge-edge contact at the midpoint of the
-// closest segment points, or the incident face clipped against the reference face (<= 8 contacts)
+// sphere : box (mjraw_SphereBox, engine_collision_box.c:35): clamp the centre into the box; a centre
+// inside the box is pushed out through the nearest face
+template <class P2, class S2>
+MJH_DEV int hit_sphere_box(Hit& h, real margin, V3 c1, real r1, V3 c2, P2 mat2, S2 size2) {
+  const V3 off = c1 - c2;
+  const V3 local{mtrow(mat2, 0, off), mtrow(mat2, 1, off), mtrow(mat2, 2, off)};
+  const V3 ext = ld3(size2);
+  const V3 nearest{r_clip(local.x, -ext.x, ext.x), r_clip(local.y, -ext.y, ext.y), r_clip(local.z, -ext.z, ext.z)};
+  V3 dir = nearest - local;
+  real gap = unitize(dir);
+  if (gap - r1 > margin) return 0;
+  V3 lpos;
+  if (gap <= MJH_MINVAL) {
+    // face k = 2*axis + side, the first strictly closer one wins
+    real best = (ext.x + ext.y + ext.z)*2;
+    int face = 0;
+    for (int k = 0; k < 6; k++) {
+      const real d = fabs(((k & 1) ? 1 : -1)*comp(ext, k >> 1) - comp(local, k >> 1));
+      if (best > d) { best = d; face = k; }
+    }
+    const V3 out = with_comp(V3{0, 0, 0}, face >> 1, (face & 1) ? -1 : 1);
+    lpos = local + out*((r1 - best)/2);
+    h.nrm = mmul(mat2, out);
+    gap = -best;
+  } else {
+    const V3 deep = local + dir*r1;
+    lpos = (V3{0, 0, 0} + nearest*0.5) + deep*0.5;
+    h.nrm = mmul(mat2, dir);
+  }
+  h.pos = mmul(mat2, lpos) + c2;
+  h.dist = gap - r1;
+  h.tan = V3{0, 0, 0};
+  return 1;
+}
+
+// sphere : cylinder (mjc_SphereCylinder, engine_collision_primitive.c:345): the sphere meets the
+// barrel (a sphere on the axis), a cap (a plane) or the rim (a point)
+template <class P1, class P2, class S2>
+MJH_DEV int hit_sphere_cylinder(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3 c2, P2 mat2, S2 size2) {
+  const real radius = size2[0], half = size2[1];
+  const V3 axis = mcol(mat2, 2);
+  const V3 off = c1 - c2;
+  const real along = dot(axis, off);
+  const V3 onaxis = axis*along;
+  const V3 radial = off - onaxis;
+  const real rad2 = dot(radial, radial);
+  int barrel = fabs(along) < half, cap = rad2 < radius*radius;
+  if (barrel && cap) {
+    // inside both slabs: the shallower penetration decides
+    if (half - fabs(along) < radius - sqrt(rad2)) barrel = 0; else cap = 0;
+  }
+  if (barrel) return hit_sphere_sphere(h, margin, c1, mat1, r1, onaxis + c2, mat2, radius);
+  const real side = along > 0 ? half : -half;
+  if (cap) {
+    // plane through the cap centre; its normal is the axis turned outwards
+    const V3 capn = along > 0 ? axis : V3{-mat2[2], -mat2[5], -mat2[8]};
+    const int n = hit_plane_sphere(h, margin, V3{c2.x + axis.x*side, c2.y + axis.y*side, c2.z + axis.z*side}, capn, c1, r1);
+    if (n) h.nrm = h.nrm*(real)-1;
+    return n;
+  }
+  const V3 rim = (axis*side + radial*(radius / sqrt(rad2))) + c2;
+  return hit_sphere_sphere(h, margin, c1, mat1, r1, rim, mat2, (real)0);
+}
+
+#if !MJH_LANE_MODE
+// ---- group-cooperative colliders (one pair per lane group) ----------------------------------------
+// Each returns the number of contacts of the pair (uniform over the group); a lane with has != 0
+// holds contact number `rank` of the pair in h.
+
+// plane : box (mjc_PlaneBox, engine_collision_primitive.c:210): lane k < 8 tests corner k; the
+// first four corners below the plane (in corner order) are the contacts
+template <class P2, class S2>
+MJH_DEV int coop_plane_box(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
+  const int k = wv_lane();
+  const real height = dot(c2 - ppos, pnrm);
+  const V3 corner = mmul(mat2, V3{(k & 1) ? (real)size2[0] : -(real)size2[0],
+                                  (k & 2) ? (real)size2[1] : -(real)size2[1],
+                                  (k & 4) ? (real)size2[2] : -(real)size2[2]});
+  const real rel = dot(pnrm, corner);
+  const int below = k < 8 && !(height + rel > margin || rel > 0);
+  const unsigned m = (unsigned)wv_ballot(below);
+  rank = __builtin_popcount(m & lanes_below(k));
+  has = below && rank < 4;
+  h.dist = height + rel;
+  h.nrm = pnrm;
+  h.pos = (corner + c2) + pnrm*(-h.dist/2);
+  h.tan = V3{0, 0, 0};
+  const int total = __builtin_popcount(m);
+  return total < 4 ? total : 4;
+}
+
+// plane : cylinder (mjc_PlaneCylinder, engine_collision_primitive.c:101): the lowest point of the
+// near rim, the matching point of the far rim, and two points of the near rim 120 degrees away;
+// lane k < 4 evaluates candidate k, nothing is reported unless the lowest point is in reach
+template <class P2, class S2>
+MJH_DEV int coop_plane_cylinder(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
+  const int k = wv_lane();
+  V3 axis = mcol(mat2, 2);
+  real tilt = dot(pnrm, axis);
+  if (tilt > 0) { axis = axis*(real)-1; tilt = -tilt; }      // axis points into the plane
+  const real height = dot(c2 - ppos, pnrm);
+  // direction from the axis to the rim point nearest the plane, scaled to the radius
+  V3 down = axis*tilt - pnrm;
+  const real len2 = dot(down, down);
+  if (len2 >= MJH_MINVAL*MJH_MINVAL) down = down*((real)size2[0]/sqrt(len2));
+  else down = V3{mat2[0]*size2[0], mat2[3]*size2[0], mat2[6]*size2[0]};     // upright: any rim point
+  const real drop = dot(down, pnrm);
+  const V3 halfax = axis*(real)size2[1];
+  const real reach = tilt*size2[1];
+  const real d_near = height + reach + drop, d_far = height - reach + drop, d_side = height + reach + (-drop*0.5);
+  const int in0 = d_near <= margin, in1 = in0 && d_far <= margin, in2 = in0 && d_side <= margin;
+  V3 lateral = cross(down, halfax);
+  unitize(lateral);
+  lateral = lateral*(size2[0]*sqrt(3.0)/2);
+  if (k == 0) { h.dist = d_near; h.pos = ((c2 + down) + halfax) + pnrm*(-d_near*0.5); }
+  else if (k == 1) { h.dist = d_far; h.pos = ((c2 + down) - halfax) + pnrm*(-d_far*0.5); }
+  else {
+    const V3 base = k == 2 ? c2 + lateral : c2 - lateral;
+    h.dist = d_side;
+    h.pos = ((base + halfax) + down*(real)-0.5) + pnrm*(-d_side*0.5);
+  }
+  h.nrm = pnrm;
+  h.tan = V3{0, 0, 0};
+  has = (k == 0 && in0) || (k == 1 && in1) || ((k == 2 || k == 3) && in2);
+  rank = k < 2 ? k : (in1 ? k : k - 1);
+  return in0 + in1 + 2*in2;
+}
+
+// box : box (mjc_BoxBox, engine_collision_box.c:697-1066).
+//   1. separating axes: lane a < 15 evaluates axis a (3 + 3 face normals, 9 edge cross products)
+//      straight from the two rotation matrices in memory; any positive separation ends the test;
+//      the winner is picked by an in-order scan of the lanes' values (first-wins ties, the edge
+//      bias and the edge -> face substitution of the reference).
+//   2. edge-edge: the (up to four) sign-ambiguous vertex choices go to lanes 0..3, the closest
+//      pair of points wins, one contact.
+//   3. face: the incident face's 4 corners sit on lanes 0..3 and are clipped against the four
+//      side planes of the reference face, one vertex per lane (Sutherland-Hodgman: a lane emits
+//      its vertex and/or the crossing towards its successor, an exclusive scan gives the new
+//      positions); duplicates are dropped by an in-order ballot loop; every accepted vertex is a
+//      contact (<= 8).
 #define MJH_BB_SEPEPS 1e-13
 #define MJH_BB_PAREPS 1e-16
 #define MJH_BB_SGNEPS 1e-9
 #define MJH_BB_DUPEPS 1e-14
 #define MJH_BB_EDGEBIAS 1e-6
-#define MJH_BB_MAXVERT 12
 
-// clip the polygon in buffer `cur` of P against sign*v[coord] <= limit; returns the new count and
-// flips *cur when something was clipped (clipHalfPlane, :651-692)
-MJH_DEV int bb_clip(real (*P)[MJH_BB_MAXVERT][3], int* cur, int nin, int coord, real sign, real limit) {
-  real (*in)[3] = P[*cur];
-  real d[MJH_BB_MAXVERT];
-  int all_inside = 1;
-  for (int k = 0; k < nin; k++) {
-    d[k] = sign*in[k][coord] - limit;
-    all_inside &= d[k] <= 0;
-  }
-  if (all_inside) return nin;
-  real (*out)[3] = P[1 - *cur];
-  int nout = 0;
-  for (int k = 0; k < nin; k++) {
-    const int k1 = (k + 1 == nin) ? 0 : k + 1;
-    const real dp = d[k], dq = d[k1];
-    if (dp <= 0 && nout < MJH_BB_MAXVERT) {
-      out[nout][0] = in[k][0]; out[nout][1] = in[k][1]; out[nout][2] = in[k][2];
-      nout++;
-    }
-    if (((dp < 0 && dq > 0) || (dp > 0 && dq < 0)) && nout < MJH_BB_MAXVERT) {
-      const real t = dp / (dp - dq);
-      out[nout][0] = in[k][0] + t*(in[k1][0] - in[k][0]);
-      out[nout][1] = in[k][1] + t*(in[k1][1] - in[k][1]);
-      out[nout][2] = in[k][2] + t*(in[k1][2] - in[k][2]);
-      nout++;
-    }
-  }
-  *cur = 1 - *cur;
-  return nout;
-}
-
-// out of line: its polygon buffers stay out of stage_collision's frame; g = {pos1[3], mat1[9],
-// size1[3], pos2[3], mat2[9], size2[3]} copied by the caller
-MJH_DEVN int col_box_box_impl(PreContact* con, real margin, const real* g) {
-  const real *pos1 = g, *mat1 = g + 3, *size1 = g + 12, *pos2 = g + 15, *mat2 = g + 18, *size2 = g + 27;
-  real rot[9], rotabs[9], pos21[3], pos12[3], tmp[3];
-  v3_sub(tmp, pos2, pos1);
-  m3_multvec(pos21, mat1, tmp);
-  v3_sub(tmp, pos1, pos2);
-  m3_multvec(pos12, mat2, tmp);
-  // rot = mat1' * mat2 (mju_mulMatTMat3 = mji_mulMatTMat3 order)
-  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
-    rot[3*r + c] = mat1[r]*mat2[c] + mat1[3 + r]*mat2[3 + c] + mat1[6 + r]*mat2[6 + c];
-  for (int k = 0; k < 9; k++) rotabs[k] = fabs(rot[k]);
-
+template <class P1, class S1, class P2, class S2>
+MJH_DEVN int coop_box_box(Hit& h, int& has, int& rank, real margin, V3 c1, P1 mat1, S1 size1, V3 c2, P2 mat2, S2 size2) {
+  const int lane = wv_lane();
+  has = 0; rank = 0;
+  h.tan = V3{0, 0, 0};
+  // entry (r, c) of mat1' * mat2, evaluated from memory so r, c may differ per lane
+  auto R = [&](int r, int c) -> real { return mat1[r]*mat2[c] + mat1[3 + r]*mat2[3 + c] + mat1[6 + r]*mat2[6 + c]; };
+  const V3 d21 = c2 - c1, d12 = c1 - c2;
+  const V3 p21{mtrow(mat1, 0, d21), mtrow(mat1, 1, d21), mtrow(mat1, 2, d21)};   // box 2 centre in frame 1
+  const V3 p12{mtrow(mat2, 0, d12), mtrow(mat2, 1, d12), mtrow(mat2, 2, d12)};   // box 1 centre in frame 2
   const real septol = margin + MJH_BB_SEPEPS*(size1[0] + size1[1] + size1[2] + size2[0] + size2[1] + size2[2]);
-  real sep_best = -MJH_MAXVAL, sep_face = -MJH_MAXVAL;
-  int code = -1;
-  for (int i = 0; i < 3; i++) {
-    const real radius2 = rotabs[3*i+0]*size2[0] + rotabs[3*i+1]*size2[1] + rotabs[3*i+2]*size2[2];
-    const real sep = fabs(pos21[i]) - size1[i] - radius2;
-    if (sep > septol) return 0;
-    if (sep > sep_best) { sep_best = sep; code = i; }
-  }
-  for (int j = 0; j < 3; j++) {
-    const real radius1 = rotabs[0+j]*size1[0] + rotabs[3+j]*size1[1] + rotabs[6+j]*size1[2];
-    const real sep = fabs(pos12[j]) - size2[j] - radius1;
-    if (sep > septol) return 0;
-    if (sep > sep_best) { sep_best = sep; code = 3 + j; }
-  }
-  sep_face = sep_best;
-  const int code_face = code;
-  for (int i = 0; i < 3; i++) {
-    for (int j = 0; j < 3; j++) {
-      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-      real ax1 = -rot[3*i2+j];
-      real ax2 = rot[3*i1+j];
-      const real norm2 = ax1*ax1 + ax2*ax2;
-      if (norm2 < MJH_BB_PAREPS) continue;
-      const real inv = 1/sqrt(norm2);
-      ax1 *= inv;
-      ax2 *= inv;
-      const real radius1 = size1[i1]*fabs(ax1) + size1[i2]*fabs(ax2);
-      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-      const real a2_1 = ax1*rot[3*i1+j1] + ax2*rot[3*i2+j1];
-      const real a2_2 = ax1*rot[3*i1+j2] + ax2*rot[3*i2+j2];
-      const real radius2 = size2[j1]*fabs(a2_1) + size2[j2]*fabs(a2_2);
-      const real sep = fabs(ax1*pos21[i1] + ax2*pos21[i2]) - radius1 - radius2;
-      if (sep > septol) return 0;
-      if (sep - MJH_BB_EDGEBIAS*fabs(sep) > sep_best && sep > sep_face) { sep_best = sep; code = 6 + 3*i + j; }
+
+  // ---- 1. separation along my axis
+  real sep = 0;
+  int valid = lane < 15;
+  if (lane < 3) {
+    const int i = lane;
+    const real r2 = fabs(R(i, 0))*size2[0] + fabs(R(i, 1))*size2[1] + fabs(R(i, 2))*size2[2];
+    sep = fabs(comp(p21, i)) - size1[i] - r2;
+  } else if (lane < 6) {
+    const int j = lane - 3;
+    const real r1 = fabs(R(0, j))*size1[0] + fabs(R(1, j))*size1[1] + fabs(R(2, j))*size1[2];
+    sep = fabs(comp(p12, j)) - size2[j] - r1;
+  } else if (lane < 15) {
+    const int i = (lane - 6) / 3, j = (lane - 6) % 3;
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    real a1 = -R(i2, j), a2 = R(i1, j);
+    const real n2 = a1*a1 + a2*a2;
+    if (n2 < MJH_BB_PAREPS) valid = 0;          // edges (nearly) parallel: no axis
+    else {
+      const real inv = 1/sqrt(n2);
+      a1 *= inv;
+      a2 *= inv;
+      const real r1 = size1[i1]*fabs(a1) + size1[i2]*fabs(a2);
+      const real b1 = a1*R(i1, j1) + a2*R(i2, j1);
+      const real b2 = a1*R(i1, j2) + a2*R(i2, j2);
+      const real r2 = size2[j1]*fabs(b1) + size2[j2]*fabs(b2);
+      sep = fabs(a1*comp(p21, i1) + a2*comp(p21, i2)) - r1 - r2;
     }
+  }
+  if (wv_any(valid && sep > septol)) return 0;
+  // in-order scan: faces take the first strict maximum, an edge must beat the best so far by the
+  // bias AND the best face
+  real best = -MJH_MAXVAL;
+  int code = -1;
+  for (int a = 0; a < 6; a++) {
+    const real s = wv_bcast(sep, a);
+    if (s > best) { best = s; code = a; }
+  }
+  const real best_face = best;
+  const int code_face = code;
+  const unsigned vmask = (unsigned)wv_ballot(valid);
+  for (int a = 6; a < 15; a++) {
+    const real s = wv_bcast(sep, a);
+    if (((vmask >> a) & 1) && s - MJH_BB_EDGEBIAS*fabs(s) > best && s > best_face) { best = s; code = a; }
   }
   if (code < 0) return 0;
 
-  // an edge axis nearly parallel to the best face axis gives way to the face (:806-826)
+  // edge axis of pair (i, j) in frame 1
+  auto edge_axis = [&](int i, int j) -> V3 {
+    V3 ax = from_cyclic(i, (real)0, -R((i + 2) % 3, j), R((i + 1) % 3, j));
+    unitize(ax);
+    return ax;
+  };
   if (code >= 6) {
-    const int i = (code - 6) / 3, j = (code - 6) % 3;
-    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-    real axis[3];
-    axis[i] = 0; axis[i1] = -rot[3*i2+j]; axis[i2] = rot[3*i1+j];
-    v3_normalize(axis);
-    real face_dot;
-    if (code_face < 3) face_dot = fabs(axis[code_face]);
-    else { const int f = code_face - 3; face_dot = fabs(axis[0]*rot[0+f] + axis[1]*rot[3+f] + axis[2]*rot[6+f]); }
-    if (face_dot > 0.99 && sep_best < sep_face + 0.05*fabs(sep_face) + MJH_MINVAL) { code = code_face; sep_best = sep_face; }
+    // an edge axis nearly parallel to the best face normal gives way to the face (:806-826)
+    const V3 ax = edge_axis((code - 6) / 3, (code - 6) % 3);
+    real along;
+    if (code_face < 3) along = fabs(comp(ax, code_face));
+    else { const int f = code_face - 3; along = fabs(ax.x*R(0, f) + ax.y*R(1, f) + ax.z*R(2, f)); }
+    if (along > 0.99 && best < best_face + 0.05*fabs(best_face) + MJH_MINVAL) { code = code_face; best = best_face; }
   }
 
-  // ---- edge-edge contact (:830-945)
+  // ---- 2. edge-edge contact (:830-945)
   if (code >= 6) {
     const int i = (code - 6) / 3, j = (code - 6) % 3;
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-    real axis[3];
-    axis[i] = 0; axis[i1] = -rot[3*i2+j]; axis[i2] = rot[3*i1+j];
-    v3_normalize(axis);
-    if (v3_dot(axis, pos21) < 0) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; }
-    real a2[3] = {axis[0]*rot[0+0] + axis[1]*rot[3+0] + axis[2]*rot[6+0],
-                  axis[0]*rot[0+1] + axis[1]*rot[3+1] + axis[2]*rot[6+1],
-                  axis[0]*rot[0+2] + axis[1]*rot[3+2] + axis[2]*rot[6+2]};
+    V3 ax = edge_axis(i, j);
+    if (dot(ax, p21) < 0) ax = V3{-ax.x, -ax.y, -ax.z};
+    const V3 ax2{ax.x*R(0, 0) + ax.y*R(1, 0) + ax.z*R(2, 0),
+                 ax.x*R(0, 1) + ax.y*R(1, 1) + ax.z*R(2, 1),
+                 ax.x*R(0, 2) + ax.y*R(1, 2) + ax.z*R(2, 2)};      // the axis in frame 2
+    // a supporting edge is ambiguous when the axis is (nearly) orthogonal to one of its offsets
     int amb1 = -1, amb2 = -1;
-    if (fabs(axis[i1]) < MJH_BB_SGNEPS) amb1 = i1; else if (fabs(axis[i2]) < MJH_BB_SGNEPS) amb1 = i2;
-    if (fabs(a2[j1]) < MJH_BB_SGNEPS) amb2 = j1; else if (fabs(a2[j2]) < MJH_BB_SGNEPS) amb2 = j2;
-    real d2[3] = {rot[0+j], rot[3+j], rot[6+j]};
-    const real b = d2[i];
+    if (fabs(comp(ax, i1)) < MJH_BB_SGNEPS) amb1 = i1; else if (fabs(comp(ax, i2)) < MJH_BB_SGNEPS) amb1 = i2;
+    if (fabs(comp(ax2, j1)) < MJH_BB_SGNEPS) amb2 = j1; else if (fabs(comp(ax2, j2)) < MJH_BB_SGNEPS) amb2 = j2;
+    const V3 e2{R(0, j), R(1, j), R(2, j)};            // direction of box 2's edge in frame 1
+    const real b = comp(e2, i);
     const real denom = 1 - b*b;
-    real w1[3] = {0, 0, 0}, w2[3] = {0, 0, 0};
-    real best_d2 = MJH_MAXVAL;
-    for (int v1 = 0; v1 < (amb1 >= 0 ? 2 : 1); v1++) {
-      for (int v2 = 0; v2 < (amb2 >= 0 ? 2 : 1); v2++) {
-        real c1[3], cc[3], c2[3], ev[3];
-        c1[i] = 0;
-        c1[i1] = axis[i1] >= 0 ? size1[i1] : -size1[i1];
-        c1[i2] = axis[i2] >= 0 ? size1[i2] : -size1[i2];
-        if (amb1 >= 0 && v1) c1[amb1] = -c1[amb1];
-        cc[j] = 0;
-        cc[j1] = a2[j1] >= 0 ? -size2[j1] : size2[j1];
-        cc[j2] = a2[j2] >= 0 ? -size2[j2] : size2[j2];
-        if (amb2 >= 0 && v2) cc[amb2] = -cc[amb2];
-        m3_mulvec(c2, rot, cc);
-        v3_addto(c2, pos21);
-        v3_sub(ev, c2, c1);
-        const real d1e = ev[i];
-        const real d2e = v3_dot(d2, ev);
-        real sp = denom < MJH_MINVAL ? 0 : (d1e - b*d2e) / denom;
-        sp = r_clip(sp, -size1[i], size1[i]);
-        const real tp = r_clip(b*sp - d2e, -size2[j], size2[j]);
-        sp = r_clip(d1e + b*tp, -size1[i], size1[i]);
-        real p1[3] = {c1[0], c1[1], c1[2]}, p2[3] = {c2[0], c2[1], c2[2]}, gap[3];
-        p1[i] += sp;
-        v3_addtoscl(p2, d2, tp);
-        v3_sub(gap, p2, p1);
-        const real gap2 = v3_dot(gap, gap);
-        if (gap2 < best_d2) { best_d2 = gap2; v3_copy(w1, p1); v3_copy(w2, p2); }
-      }
+    // lane q < 4: choice (q >> 1) of edge 1, (q & 1) of edge 2
+    const int f1 = (lane >> 1) & 1, f2 = lane & 1;
+    const int exists = lane < 4 && (!f1 || amb1 >= 0) && (!f2 || amb2 >= 0);
+    real o1 = comp(ax, i1) >= 0 ? (real)size1[i1] : -(real)size1[i1];
+    real o2 = comp(ax, i2) >= 0 ? (real)size1[i2] : -(real)size1[i2];
+    if (f1 && amb1 == i1) o1 = -o1;
+    if (f1 && amb1 == i2) o2 = -o2;
+    const V3 m1 = from_cyclic(i, (real)0, o1, o2);      // middle of edge 1
+    real q1 = comp(ax2, j1) >= 0 ? -(real)size2[j1] : (real)size2[j1];
+    real q2 = comp(ax2, j2) >= 0 ? -(real)size2[j2] : (real)size2[j2];
+    if (f2 && amb2 == j1) q1 = -q1;
+    if (f2 && amb2 == j2) q2 = -q2;
+    const V3 l2 = from_cyclic(j, (real)0, q1, q2);
+    const V3 m2 = V3{R(0, 0)*l2.x + R(0, 1)*l2.y + R(0, 2)*l2.z,
+                     R(1, 0)*l2.x + R(1, 1)*l2.y + R(1, 2)*l2.z,
+                     R(2, 0)*l2.x + R(2, 1)*l2.y + R(2, 2)*l2.z} + p21;      // middle of edge 2, frame 1
+    const V3 mm = m2 - m1;
+    const real g1 = comp(mm, i), g2 = dot(e2, mm);
+    real s = denom < MJH_MINVAL ? 0 : (g1 - b*g2) / denom;
+    s = r_clip(s, -size1[i], size1[i]);
+    const real t = r_clip(b*s - g2, -size2[j], size2[j]);
+    s = r_clip(g1 + b*t, -size1[i], size1[i]);
+    const V3 w1 = with_comp(m1, i, comp(m1, i) + s);
+    const V3 w2 = m2 + e2*t;
+    const V3 gapv = w2 - w1;
+    const real gap2 = dot(gapv, gapv);
+    // first strictly smaller gap in choice order wins
+    int win = -1;
+    real bestgap = MJH_MAXVAL;
+    const unsigned em = (unsigned)wv_ballot(exists);
+    for (int q = 0; q < 4; q++) {
+      const real g = wv_bcast(gap2, q);
+      if (((em >> q) & 1) && g < bestgap) { bestgap = g; win = q; }
     }
-    real gap[3];
-    v3_sub(gap, w2, w1);
-    const real dist = v3_dot(gap, axis);
+    V3 a1{0, 0, 0}, a2{0, 0, 0};
+    if (win >= 0) {
+      a1 = V3{wv_bcast(w1.x, win), wv_bcast(w1.y, win), wv_bcast(w1.z, win)};
+      a2 = V3{wv_bcast(w2.x, win), wv_bcast(w2.y, win), wv_bcast(w2.z, win)};
+    }
+    const real dist = dot(a2 - a1, ax);
     if (dist > septol) return 0;
-    real mid[3] = {0.5*(w1[0] + w2[0]), 0.5*(w1[1] + w2[1]), 0.5*(w1[2] + w2[2])};
-    con[0].dist = dist;
-    m3_mulvec(tmp, mat1, mid);
-    v3_add(con[0].pos, tmp, pos1);
-    m3_mulvec(con[0].normal, mat1, axis);
-    v3_zero(con[0].tangent);
+    const V3 mid{0.5*(a1.x + a2.x), 0.5*(a1.y + a2.y), 0.5*(a1.z + a2.z)};
+    h.dist = dist;
+    h.pos = mmul(mat1, mid) + c1;
+    h.nrm = mmul(mat1, ax);
+    has = lane == 0;
+    rank = 0;
     return 1;
   }
 
-  // ---- face contact: clip the incident face against the reference face (:949-1066)
+  // ---- 3. face contact (:949-1066): reference face `a` of box `ref1 ? 1 : 2`
   const int ref1 = code < 3;
   const int a = ref1 ? code : code - 3;
-  const real* sizeref = ref1 ? size1 : size2;
-  const real* sizeinc = ref1 ? size2 : size1;
-  const real* posref = ref1 ? pos1 : pos2;
-  const real* matref = ref1 ? mat1 : mat2;
-  const real* posoi = ref1 ? pos21 : pos12;
-  real rinc[9];
-  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) rinc[3*r + c] = ref1 ? rot[3*r + c] : rot[3*c + r];
-  const real sgn = posoi[a] >= 0 ? 1 : -1;
+  const int ax = (a + 1) % 3, ay = (a + 2) % 3;
+  auto Rinc = [&](int r, int c) -> real { return ref1 ? R(r, c) : R(c, r); };   // incident box in the reference frame
+  const V3 poi = ref1 ? p21 : p12;
+  const real ref_a = ref1 ? (real)size1[a] : (real)size2[a];
+  const real ref_x = ref1 ? (real)size1[ax] : (real)size2[ax];
+  const real ref_y = ref1 ? (real)size1[ay] : (real)size2[ay];
+  const real sgn = comp(poi, a) >= 0 ? 1 : -1;
+  // incident face: the one most anti-parallel to the reference normal
   int binc = 0;
-  for (int k = 1; k < 3; k++) if (fabs(rinc[3*a+k]) > fabs(rinc[3*a+binc])) binc = k;
-  const real tinc = sgn*rinc[3*a+binc] > 0 ? -1 : 1;
-  const int ax = (a + 1) % 3, ay = (a + 2) % 3, bu = (binc + 1) % 3, bv = (binc + 2) % 3;
-  real poly[2][MJH_BB_MAXVERT][3];
-  real cx[3], du[3], dv[3];
-  for (int r = 0; r < 3; r++) {
-    const int c = r == 0 ? ax : (r == 1 ? ay : a);
-    cx[r] = posoi[c] + tinc*sizeinc[binc]*rinc[3*c+binc];
-    du[r] = sizeinc[bu]*rinc[3*c+bu];
-    dv[r] = sizeinc[bv]*rinc[3*c+bv];
+  for (int k = 1; k < 3; k++) if (fabs(Rinc(a, k)) > fabs(Rinc(a, binc))) binc = k;
+  const real tinc = sgn*Rinc(a, binc) > 0 ? -1 : 1;
+  const int bu = (binc + 1) % 3, bv = (binc + 2) % 3;
+  const real inc_b = ref1 ? (real)size2[binc] : (real)size1[binc];
+  const real inc_u = ref1 ? (real)size2[bu] : (real)size1[bu];
+  const real inc_v = ref1 ? (real)size2[bv] : (real)size1[bv];
+  // face centre and half edges in (x, y, depth) of the reference face
+  V3 fc{comp(poi, ax) + tinc*inc_b*Rinc(ax, binc), comp(poi, ay) + tinc*inc_b*Rinc(ay, binc), comp(poi, a) + tinc*inc_b*Rinc(a, binc)};
+  V3 fu{inc_u*Rinc(ax, bu), inc_u*Rinc(ay, bu), inc_u*Rinc(a, bu)};
+  V3 fv{inc_v*Rinc(ax, bv), inc_v*Rinc(ay, bv), inc_v*Rinc(a, bv)};
+  fc.z = sgn*fc.z - ref_a;
+  fu.z *= sgn;
+  fv.z *= sgn;
+  // my vertex of the polygon (lanes 0..nv-1)
+  const real su = (lane == 0 || lane == 3) ? 1 : -1, sv = (lane < 2) ? 1 : -1;
+  V3 vert{fc.x + su*fu.x + sv*fv.x, fc.y + su*fu.y + sv*fv.y, fc.z + su*fu.z + sv*fv.z};
+  int nvert = 4;
+  for (int side = 0; side < 4; side++) {
+    const real sign = (side & 1) ? -1 : 1, limit = side < 2 ? ref_x : ref_y;
+    const int mine = lane < nvert;
+    const real dp = sign*(side < 2 ? vert.x : vert.y) - limit;
+    if (!wv_any(mine && !(dp <= 0))) continue;              // nothing outside this plane
+    const int nxt = (lane + 1 == nvert) ? 0 : lane + 1;
+    const real dq = wv_shfl(dp, nxt);
+    const V3 vq{wv_shfl(vert.x, nxt), wv_shfl(vert.y, nxt), wv_shfl(vert.z, nxt)};
+    const int keep = mine && dp <= 0;
+    const int cut = mine && ((dp < 0 && dq > 0) || (dp > 0 && dq < 0));
+    const real t = dp / (dp - dq);
+    const V3 crossing{vert.x + t*(vq.x - vert.x), vert.y + t*(vq.y - vert.y), vert.z + t*(vq.z - vert.z)};
+    const V3 out0 = keep ? vert : crossing, out1 = crossing;
+    const int cnt = keep + cut;
+    const int start = wv_exscan_i(cnt);
+    const int total = wv_sum_i(cnt);
+    // gather: output vertex `lane` comes from the input lane whose [start, start+cnt) holds it
+    int src = 0, second = 0;
+    for (int k = 0; k < nvert; k++) {
+      const int sk = wv_bcast_i(start, k), ck = wv_bcast_i(cnt, k);
+      if (lane >= sk && lane < sk + ck) { src = k; second = lane - sk; }
+    }
+    const V3 g0{wv_shfl(out0.x, src), wv_shfl(out0.y, src), wv_shfl(out0.z, src)};
+    const V3 g1{wv_shfl(out1.x, src), wv_shfl(out1.y, src), wv_shfl(out1.z, src)};
+    vert = second ? g1 : g0;
+    nvert = total;
   }
-  cx[2] = sgn*cx[2] - sizeref[a];
-  du[2] *= sgn;
-  dv[2] *= sgn;
-  for (int k = 0; k < 4; k++) {
-    const real su = (k == 0 || k == 3) ? 1 : -1, sv = (k < 2) ? 1 : -1;
-    poly[0][k][0] = cx[0] + su*du[0] + sv*dv[0];
-    poly[0][k][1] = cx[1] + su*du[1] + sv*dv[1];
-    poly[0][k][2] = cx[2] + su*du[2] + sv*dv[2];
-  }
-  int nvert = 4, cur = 0;
-  nvert = bb_clip(poly, &cur, nvert, 0, 1, sizeref[ax]);
-  nvert = bb_clip(poly, &cur, nvert, 0, -1, sizeref[ax]);
-  nvert = bb_clip(poly, &cur, nvert, 1, 1, sizeref[ay]);
-  nvert = bb_clip(poly, &cur, nvert, 1, -1, sizeref[ay]);
-  real accepted[MJH_BB_MAXVERT][3];
-  int naccept = 0;
-  const real dupe2 = MJH_BB_DUPEPS*(sizeref[ax]*sizeref[ax] + sizeref[ay]*sizeref[ay]);
+  // contacts: vertices not above the margin, in polygon order, minus near-duplicates of earlier ones
+  const real dupe2 = MJH_BB_DUPEPS*(ref_x*ref_x + ref_y*ref_y);
+  int accepted = 0;
   for (int k = 0; k < nvert; k++) {
-    if (poly[cur][k][2] > margin) continue;
-    int dupe = 0;
-    for (int q = 0; q < naccept; q++) {
-      const real dx = accepted[q][0] - poly[cur][k][0];
-      const real dy = accepted[q][1] - poly[cur][k][1];
-      if (dx*dx + dy*dy < dupe2) { dupe = 1; break; }
-    }
-    if (!dupe) { accepted[naccept][0] = poly[cur][k][0]; accepted[naccept][1] = poly[cur][k][1]; accepted[naccept][2] = poly[cur][k][2]; naccept++; }
+    const real xk = wv_bcast(vert.x, k), yk = wv_bcast(vert.y, k), zk = wv_bcast(vert.z, k);
+    const real dx = vert.x - xk, dy = vert.y - yk;
+    const int twin = accepted && lane < k && dx*dx + dy*dy < dupe2;
+    const int dup = wv_any(twin);
+    if (lane == k && !(zk > margin) && !dup) accepted = 1;
   }
-  if (naccept == 0) return 0;
+  const unsigned am = (unsigned)wv_ballot(accepted);
+  const int ncontact = __builtin_popcount(am);
+  if (!ncontact) return 0;
+  has = accepted;
+  rank = __builtin_popcount(am & lanes_below(lane));
   const real nsign = ref1 ? sgn : -sgn;
-  real normal[3] = {nsign*matref[3*0+a], nsign*matref[3*1+a], nsign*matref[3*2+a]};
-  for (int k = 0; k < naccept; k++) {
-    real posc[3];
-    posc[ax] = accepted[k][0];
-    posc[ay] = accepted[k][1];
-    posc[a] = sgn*(sizeref[a] + 0.5*accepted[k][2]);
-    con[k].dist = accepted[k][2];
-    m3_mulvec(tmp, matref, posc);
-    v3_add(con[k].pos, tmp, posref);
-    v3_copy(con[k].normal, normal);
-    v3_zero(con[k].tangent);
-  }
-  return naccept;
+  const V3 lp = from_cyclic(a, sgn*(ref_a + 0.5*vert.z), vert.x, vert.y);
+  h.dist = vert.z;
+  if (ref1) { h.pos = mmul(mat1, lp) + c1; h.nrm = mcol(mat1, a)*nsign; }
+  else { h.pos = mmul(mat2, lp) + c2; h.nrm = mcol(mat2, a)*nsign; }
+  return ncontact;
 }
-
-template <class P0, class P1, class P2, class P3, class P4, class P5>
-MJH_DEV int col_box_box(PreContact* con, real margin, P0 pos1, P1 mat1, P2 size1, P3 pos2, P4 mat2, P5 size2) {
-  real g[30];
-  for (int k = 0; k < 3; k++) { g[k] = pos1[k]; g[12 + k] = size1[k]; g[15 + k] = pos2[k]; g[27 + k] = size2[k]; }
-  for (int k = 0; k < 9; k++) { g[3 + k] = mat1[k]; g[18 + k] = mat2[k]; }
-  return col_box_box_impl(con, margin, g);
-}
-
-// mjc_PlaneBox (engine_collision_primitive.c:210-256): corners below the plane, at most 4
-template <class P0, class P1, class P2, class P3, class P4>
-MJH_DEV int col_plane_box(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
-  real norm[3] = {mat1[2], mat1[5], mat1[8]};
-  real dif[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
-  const real dist = v3_dot(dif, norm);
-  int cnt = 0;
-  for (int i = 0; i < 8; i++) {
-    real vec[3], corner[3];
-    vec[0] = (i & 1) ? (real)size2[0] : -(real)size2[0];
-    vec[1] = (i & 2) ? (real)size2[1] : -(real)size2[1];
-    vec[2] = (i & 4) ? (real)size2[2] : -(real)size2[2];
-    m3_mulvec(corner, mat2, vec);
-    const real ldist = v3_dot(norm, corner);
-    if (dist + ldist > margin || ldist > 0) continue;
-    con[cnt].dist = dist + ldist;
-    v3_copy(con[cnt].normal, norm);
-    v3_addto(corner, pos2);
-    v3_scl(vec, norm, -con[cnt].dist / 2);
-    v3_add(con[cnt].pos, corner, vec);
-    v3_zero(con[cnt].tangent);
-    if (++cnt >= 4) return 4;
-  }
-  return cnt;
-}
-
-// mjraw_SphereBox (engine_collision_box.c:35-88)
-template <class P0, class P1, class P2, class P3>
-MJH_DEV int col_sphere_box(PreContact* c, real margin, P0 pos1, real r1, P1 pos2, P2 mat2, P3 size2) {
-  real tmp[3], center[3], clamped[3], deepest[3], pos[3];
-  v3_sub(tmp, pos1, pos2);
-  m3_multvec(center, mat2, tmp);
-  for (int i = 0; i < 3; i++) {
-    clamped[i] = center[i];
-    if (clamped[i] < -size2[i]) clamped[i] = -size2[i];
-    else if (clamped[i] > size2[i]) clamped[i] = size2[i];
-    deepest[i] = center[i];
-  }
-  v3_sub(tmp, clamped, center);
-  real dist = v3_normalize(tmp);
-  if (dist - r1 > margin) return 0;
-  if (dist <= MJH_MINVAL) {
-    // sphere centre inside the box: push out through the nearest face
-    real closest = (size2[0] + size2[1] + size2[2]) * 2;
-    int k = 0;
-    for (int i = 0; i < 6; i++) {
-      const real d = fabs(((i % 2) ? 1 : -1)*size2[i / 2] - center[i / 2]);
-      if (closest > d) { closest = d; k = i; }
-    }
-    real nearest[3] = {0, 0, 0};
-    nearest[k / 2] = (k % 2) ? -1 : 1;
-    v3_copy(pos, center);
-    v3_addtoscl(pos, nearest, (r1 - closest) / 2);
-    m3_mulvec(c->normal, mat2, nearest);
-    dist = -closest;
-  } else {
-    v3_addtoscl(deepest, tmp, r1);
-    v3_zero(pos);
-    v3_addtoscl(pos, clamped, 0.5);
-    v3_addtoscl(pos, deepest, 0.5);
-    m3_mulvec(c->normal, mat2, tmp);
-  }
-  m3_mulvec(tmp, mat2, pos);
-  v3_add(c->pos, tmp, pos2);
-  c->dist = dist - r1;
-  v3_zero(c->tangent);
-  return 1;
-}
-
-// mjc_SphereCylinder (engine_collision_primitive.c:345-421): side / cap / rim cases
-template <class P0, class P1, class P2, class P3, class P4>
-MJH_DEV int col_sphere_cylinder(PreContact* c, real margin, P0 pos1, P1 mat1, real r1, P2 pos2, P3 mat2, P4 size2) {
-  const real radius = size2[0], height = size2[1];
-  real axis[3] = {mat2[2], mat2[5], mat2[8]};
-  real vec[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
-  const real x = v3_dot(axis, vec);
-  real a_proj[3], p_proj[3];
-  v3_scl(a_proj, axis, x);
-  v3_sub(p_proj, vec, a_proj);
-  const real p_proj_sqr = v3_dot(p_proj, p_proj);
-  int collide_side = fabs(x) < height;
-  int collide_cap = p_proj_sqr < radius*radius;
-  if (collide_side && collide_cap) {
-    const real dist_cap = height - fabs(x);
-    const real dist_radius = radius - sqrt(p_proj_sqr);
-    if (dist_cap < dist_radius) collide_side = 0; else collide_cap = 0;
-  }
-  if (collide_side) {
-    v3_addto(a_proj, pos2);
-    return col_sphere_sphere(c, margin, pos1, mat1, r1, a_proj, mat2, radius);
-  }
-  if (collide_cap) {
-    real flipmat[9] = {-mat2[0], mat2[1], -mat2[2], -mat2[3], mat2[4], -mat2[5], -mat2[6], mat2[7], -mat2[8]};
-    real capmat[9], pos_cap[3];
-    const real hs = (x > 0) ? height : -height;
-    for (int k = 0; k < 3; k++) pos_cap[k] = pos2[k] + axis[k]*hs;
-    for (int k = 0; k < 9; k++) capmat[k] = (x > 0) ? (real)mat2[k] : flipmat[k];
-    int n = col_plane_sphere(c, margin, pos_cap, capmat, pos1, r1);
-    if (n) { c->normal[0] *= -1; c->normal[1] *= -1; c->normal[2] *= -1; }
-    return n;
-  }
-  // rim: point sphere at the nearest point of the cap's edge
-  v3_scl(p_proj, p_proj, radius / sqrt(p_proj_sqr));
-  v3_scl(vec, axis, x > 0 ? height : -height);
-  v3_addto(vec, p_proj);
-  v3_addto(vec, pos2);
-  return col_sphere_sphere(c, margin, pos1, mat1, r1, vec, mat2, (real)0);
-}
-
-// mjc_PlaneCylinder, engine_collision_primitive.c:101-208 (up to 4 contacts)
-template <class P0, class P1, class P2, class P3, class P4>
-MJH_DEV int col_plane_cylinder(PreContact* con, real margin, P0 pos1, P1 mat1, P2 pos2, P3 mat2, P4 size2) {
-  real normal[3] = {mat1[2], mat1[5], mat1[8]};
-  real axis[3] = {mat2[2], mat2[5], mat2[8]};
-  real prjaxis = v3_dot(normal, axis);
-  if (prjaxis > 0) {
-    v3_scl(axis, axis, -1);
-    prjaxis = -prjaxis;
-  }
-  real vec[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
-  real dist0 = v3_dot(vec, normal);
-  v3_scl(vec, axis, prjaxis);
-  v3_subfrom(vec, normal);
-  real len_sqr = v3_dot(vec, vec);
-  if (len_sqr >= MJH_MINVAL*MJH_MINVAL) {
-    real scl = size2[0]/sqrt(len_sqr);
-    vec[0] *= scl; vec[1] *= scl; vec[2] *= scl;
-  } else {
-    vec[0] = mat2[0]*size2[0];
-    vec[1] = mat2[3]*size2[0];
-    vec[2] = mat2[6]*size2[0];
-  }
-  real prjvec = v3_dot(vec, normal);
-  v3_scl(axis, axis, size2[1]);
-  prjaxis *= size2[1];
-  int cnt = 0;
-  if (dist0 + prjaxis + prjvec <= margin) {
-    con[cnt].dist = dist0 + prjaxis + prjvec;
-    v3_add(con[cnt].pos, pos2, vec);
-    v3_addto(con[cnt].pos, axis);
-    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
-    v3_copy(con[cnt].normal, normal);
-    v3_zero(con[cnt].tangent);
-    cnt++;
-  } else {
-    return 0;
-  }
-  if (dist0 - prjaxis + prjvec <= margin) {
-    con[cnt].dist = dist0 - prjaxis + prjvec;
-    v3_add(con[cnt].pos, pos2, vec);
-    v3_subfrom(con[cnt].pos, axis);
-    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
-    v3_copy(con[cnt].normal, normal);
-    v3_zero(con[cnt].tangent);
-    cnt++;
-  }
-  real prjvec1 = -prjvec*0.5;
-  if (dist0 + prjaxis + prjvec1 <= margin) {
-    real vec1[3];
-    v3_cross(vec1, vec, axis);
-    v3_normalize(vec1);
-    v3_scl(vec1, vec1, size2[0] * sqrt(3.0) / 2);
-    con[cnt].dist = dist0 + prjaxis + prjvec1;
-    v3_add(con[cnt].pos, pos2, vec1);
-    v3_addto(con[cnt].pos, axis);
-    v3_addtoscl(con[cnt].pos, vec, -0.5);
-    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
-    v3_copy(con[cnt].normal, normal);
-    v3_zero(con[cnt].tangent);
-    cnt++;
-    con[cnt].dist = dist0 + prjaxis + prjvec1;
-    v3_sub(con[cnt].pos, pos2, vec1);
-    v3_addto(con[cnt].pos, axis);
-    v3_addtoscl(con[cnt].pos, vec, -0.5);
-    v3_addtoscl(con[cnt].pos, normal, -con[cnt].dist * 0.5);
-    v3_copy(con[cnt].normal, normal);
-    v3_zero(con[cnt].tangent);
-    cnt++;
-  }
-  return cnt;
-}
+#endif  // !MJH_LANE_MODE
 
 // complete a contact frame from its normal (+ optional tangent)   (mju_makeFrame, engine_util_spatial.c:512)
 template <class P0>
@@ -622,6 +565,25 @@ MJH_DEV int filter_sphere(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
   return 0;
 }
 
+// contact record `c` of the environment <- one hit of static pair p
+// (mj_narrowphase fill + mj_setContact, engine_collision_driver.c:2050-2075, :1839-1875)
+MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
+  MJH_CON(B, con_dist, e, 1, c)[0] = h.dist;
+  st3(MJH_CON(B, con_pos, e, 3, c), h.pos);
+  real fr[9] = {h.nrm.x, h.nrm.y, h.nrm.z, h.tan.x, h.tan.y, h.tan.z, 0, 0, 0};
+  make_frame(fr);
+  rptr cframe = MJH_CON(B, con_frame, e, 9, c);
+  for (int q = 0; q < 9; q++) cframe[q] = fr[q];
+  MJH_CON(B, con_pair, e, 1, c)[0] = p;
+  iptr cgeom = MJH_CON(B, con_geom, e, 2, c);
+  cgeom[0] = M.pair_geom1[p];
+  cgeom[1] = M.pair_geom2[p];
+  MJH_CON(B, con_dim, e, 1, c)[0] = M.pair_dim[p];
+  MJH_CON(B, con_exclude, e, 1, c)[0] = (h.dist >= M.pair_includemargin[p]) ? 1 : 0;
+  MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
+  MJH_CON(B, con_mu, e, 1, c)[0] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
 // ------------------------------------------------------------------------------------------------
@@ -639,72 +601,83 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   crptr gm = MJH_F(B, geom_xmat, e);
   iptr warn = MJH_F(B, warning, e);
 
-  int base = 0;        // contacts emitted by earlier chunks (wave-uniform)
+  int base = 0;        // contacts emitted by earlier chunks (uniform over the group)
   int overflow = 0;
   for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
-    int p = p0 + wv_lane();
-    PreContact pc[8];
+    const int p = p0 + wv_lane();
+    Hit ha, hb;          // the (at most two) contacts of my pair's point collider
     int n = 0;
+    int coop = 0;        // my pair needs a group-cooperative collider
     int unsupported = 0;
     if (p < s.npair) {
-      int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-      real margin = M.pair_margin[p];       // margin + gap: collider threshold
+      const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+      const real margin = M.pair_margin[p];       // margin + gap: collider threshold
       if (!filter_sphere(M, gx, gm, g1, g2, margin)) {
-        crptr pos1 = gx + 3*g1; crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
-        crptr pos2 = gx + 3*g2; crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
-        switch (M.pair_func[p]) {
+        crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+        crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
+        const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
+        const int func = M.pair_func[p];
+        switch (func) {
           case MJH_COL_PLANE_SPHERE:
-            n = col_plane_sphere(pc, margin, pos1, mat1, pos2, size2[0]); break;
+            n = hit_plane_sphere(ha, margin, c1, mcol(mat1, 2), c2, size2[0]); break;
           case MJH_COL_PLANE_CAPSULE:
-            n = col_plane_capsule(pc, margin, pos1, mat1, pos2, mat2, size2); break;
+            n = hit_plane_capsule(ha, hb, margin, c1, mcol(mat1, 2), c2, mat2, size2); break;
           case MJH_COL_SPHERE_SPHERE:
-            n = col_sphere_sphere(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2[0]); break;
+            n = hit_sphere_sphere(ha, margin, c1, mat1, size1[0], c2, mat2, size2[0]); break;
           case MJH_COL_SPHERE_CAPSULE:
-            n = col_sphere_capsule(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
+            n = hit_sphere_capsule(ha, margin, c1, mat1, size1[0], c2, mat2, size2); break;
           case MJH_COL_CAPSULE_CAPSULE:
-            n = col_capsule_capsule(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
-          case MJH_COL_PLANE_CYLINDER:
-            n = col_plane_cylinder(pc, margin, pos1, mat1, pos2, mat2, size2); break;
-          case MJH_COL_PLANE_BOX:
-            n = col_plane_box(pc, margin, pos1, mat1, pos2, mat2, size2); break;
-          case MJH_COL_SPHERE_BOX:
-            n = col_sphere_box(pc, margin, pos1, size1[0], pos2, mat2, size2); break;
-          case MJH_COL_BOX_BOX:
-            n = col_box_box(pc, margin, pos1, mat1, size1, pos2, mat2, size2); break;
-          case MJH_COL_SPHERE_CYLINDER:
-            n = col_sphere_cylinder(pc, margin, pos1, mat1, size1[0], pos2, mat2, size2); break;
-          case MJH_COL_UNSUPPORTED:
-            unsupported = 1; break;
-          default: break;
+            n = hit_capsule_capsule(ha, hb, margin, c1, mat1, size1, c2, mat2, size2); break;
+          default:
+            if (MJH_HAS(MJH_FT_COLCONVEX)) {
+              if (func == MJH_COL_SPHERE_BOX) n = hit_sphere_box(ha, margin, c1, size1[0], c2, mat2, size2);
+              else if (func == MJH_COL_SPHERE_CYLINDER) n = hit_sphere_cylinder(ha, margin, c1, mat1, size1[0], c2, mat2, size2);
+              else if (func == MJH_COL_UNSUPPORTED || MJH_LANE_MODE) unsupported = 1;
+              else coop = 1;
+            }
+            break;
         }
       }
     }
     // a pair whose collider mjhip does not have reached the narrowphase: the result could differ
     // from the reference's, so the environment is flagged (and frozen by the rollout loop)
-    if (wv_any(unsupported) && wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++;
-    int off = base + wv_exscan_i(n);
+    if (MJH_HAS(MJH_FT_COLCONVEX) && wv_any(unsupported) && wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++;
+
+    int before = wv_exscan_i(n);     // contacts of the chunk's earlier pairs (point colliders so far)
     int total = wv_sum_i(n);
-    for (int k = 0; k < n; k++) {
-      int c = off + k;
-      if (c >= s.nconmax) { overflow = 1; continue; }
-      // mj_narrowphase fill + mj_setContact, engine_collision_driver.c:2050-2075, :1839-1875
-      MJH_CON(B, con_dist, e, 1, c)[0] = pc[k].dist;
-      v3_copy(MJH_CON(B, con_pos, e, 3, c), pc[k].pos);
-      real fr[9];
-      v3_copy(fr, pc[k].normal);
-      v3_copy(fr + 3, pc[k].tangent);
-      v3_zero(fr + 6);
-      make_frame(fr);
-      rptr cframe = MJH_CON(B, con_frame, e, 9, c);
-      for (int q = 0; q < 9; q++) cframe[q] = fr[q];
-      MJH_CON(B, con_pair, e, 1, c)[0] = p;
-      iptr cgeom = MJH_CON(B, con_geom, e, 2, c);
-      cgeom[0] = M.pair_geom1[p];
-      cgeom[1] = M.pair_geom2[p];
-      MJH_CON(B, con_dim, e, 1, c)[0] = M.pair_dim[p];
-      MJH_CON(B, con_exclude, e, 1, c)[0] = (pc[k].dist >= M.pair_includemargin[p]) ? 1 : 0;
-      MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
-      MJH_CON(B, con_mu, e, 1, c)[0] = 0;
+#if !MJH_LANE_MODE
+    if (MJH_HAS(MJH_FT_COLCONVEX)) {
+      // cooperative pairs in pair order; `before` of later lanes grows by each pair's count
+      unsigned long long todo = wv_ballot(coop);
+      while (todo) {
+        const int q = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int pq = p0 + q;
+        const int g1 = M.pair_geom1[pq], g2 = M.pair_geom2[pq];
+        const real margin = M.pair_margin[pq];
+        crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+        crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
+        const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
+        Hit hc;
+        int has = 0, rank = 0, cnt = 0;
+        const int func = M.pair_func[pq];
+        if (func == MJH_COL_PLANE_BOX) cnt = coop_plane_box(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
+        else if (func == MJH_COL_PLANE_CYLINDER) cnt = coop_plane_cylinder(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
+        else if (func == MJH_COL_BOX_BOX) cnt = coop_box_box(hc, has, rank, margin, c1, mat1, size1, c2, mat2, size2);
+        const int first = base + wv_bcast_i(before, q);
+        if (has) {
+          const int c = first + rank;
+          if (c >= s.nconmax) overflow = 1; else store_contact(M, B, e, c, pq, hc);
+        }
+        if (wv_lane() > q) before += cnt;
+        total += cnt;
+      }
+    }
+#endif
+    if (n > 0) {
+      const int c = base + before;
+      if (c >= s.nconmax) overflow = 1; else store_contact(M, B, e, c, p, ha);
+      if (n > 1) { if (c + 1 >= s.nconmax) overflow = 1; else store_contact(M, B, e, c + 1, p, hb); }
     }
     base += total;
   }

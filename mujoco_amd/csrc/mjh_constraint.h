@@ -60,10 +60,11 @@ MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   int off1 = B.dyn_off, off2 = B.dyn2_off;
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
   unsigned mask = 0, bit = 1;
+  char* const lds_ = MJH_LDS(B);
   // a region-2 array that does not fit its region falls through to what is left of region 1
 #define MJH_EFC_PLACE(T, m, home, bytes, region)                                              \
-    if ((region) == 2 && off2 + (bytes) <= end2) { P.m = SP<T>{(T*)(mjh_lds() + off2), 1}; off2 += ((bytes) + 7) & ~7; mask |= bit; } \
-    else if (off1 + (bytes) <= end1) { P.m = SP<T>{(T*)(mjh_lds() + off1), 1}; off1 += ((bytes) + 7) & ~7; mask |= bit; }            \
+    if ((region) == 2 && off2 + (bytes) <= end2) { P.m = SP<T>{(T*)(lds_ + off2), 1}; off2 += ((bytes) + 7) & ~7; mask |= bit; } \
+    else if (off1 + (bytes) <= end1) { P.m = SP<T>{(T*)(lds_ + off1), 1}; off1 += ((bytes) + 7) & ~7; mask |= bit; }            \
     else P.m = (home);                                                                        \
     bit <<= 1;
 #define X(m, home, cnt, region) { const int bytes_ = (int)sizeof(int)*(cnt); MJH_EFC_PLACE(int, m, home, bytes_, region) }
@@ -348,13 +349,13 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   }
 
   // candidate index space: [equalities | dof friction | tendon friction | joints (2 sides) | tendons (2 sides) | contacts]
-  const int c_df = (dsbl & (1<<1)) ? 0 : s.neq;          // mjDSBL_EQUALITY
+  const int c_df = (!MJH_HAS(MJH_FT_EQUALITY) || (dsbl & (1<<1))) ? 0 : s.neq;          // mjDSBL_EQUALITY
   const int c_tf = c_df + nv;
   const int c_jl = c_tf + s.ntendon;
   const int c_tl = c_jl + 2*s.njnt;
   const int c_con = c_tl + 2*s.ntendon;
   const int ncand = c_con + ncon;
-  const int ispyramid = (M.o.cone == 0);
+  const int ispyramid = !MJH_HAS(MJH_FT_ELLIPTIC) || (M.o.cone == 0);
 
   auto classify = [&](int c, Cand& k) {
     k.nrow = 0; k.type = 0; k.id = 0; k.side = 0; k.dist = 0; k.margin = 0; k.floss = 0;
@@ -507,7 +508,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   wv_sync();
 
   // ---- equality rows: residual and Jacobian per active equality, lanes over dof columns ------------
-  if (ne_total) stage_equality_rows(M, B, e, P);
+  if (MJH_HAS(MJH_FT_EQUALITY) && ne_total) stage_equality_rows(M, B, e, P);
 
   // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
   crptr cdof = MJH_F(B, cdof, e);
@@ -553,7 +554,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         }
         jr[a] = acc;
       }
-      if (dim > 3) {
+      if (MJH_HAS(MJH_FT_CONDIM46) && dim > 3) {
         // torsional / rolling rows: rotational Jacobian difference in the contact frame (:1663-1665)
         real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0),
                       (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
@@ -588,7 +589,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     int type = P.type[r], id = P.id[r];
     real solref[2], solimp[5], dA;
     real imp_pos = P.pos[r];
-    if (type == MJH_CNSTR_EQUALITY) {
+    if (MJH_HAS(MJH_FT_EQUALITY) && type == MJH_CNSTR_EQUALITY) {
       // mj_diagApprox :1733-1780, getsolparam :1988, getposdim :2070-2078
       const int et = M.eq_type[id];
       const int r0 = MJH_G(B, eq_efcadr, e)[id];
@@ -717,7 +718,7 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
   Efc P;
   efc_layout(M, B, e, nefc, P);
   const int nv = s.nv, ntree = s.ntree;
-  if (ntree <= 1 || (M.o.disableflags & (1<<18))) {
+  if (!MJH_HAS(MJH_FT_ISLANDS) || ntree <= 1 || (M.o.disableflags & (1<<18))) {
     MJH_FOR_LANES(i, nefc) P.island[i] = 0;
     if (wv_lane() == 0) counts[MJH_C_NISLAND] = (M.o.disableflags & (1<<18)) ? 0 : 1;
     wv_sync();
@@ -886,7 +887,7 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
   // relative surface velocity of the contacting geoms (conveyor belts) enters efc_vel of the
   // tangential / torsional rows before aref is formed  (mj_addSurfaceVel, :3141-3204;
   // mj_geomSurfaceVelocity, engine_core_util.c:892-905)
-  if (M.o.has_surfacevel) {
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_surfacevel) {
     const MJH_CONST_AS DSizes& s = M.s;
     const int ncon = MJH_F(B, counts, e)[MJH_C_NCON];
     crptr gx = MJH_F(B, geom_xpos, e);
@@ -939,7 +940,7 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
   }
   // subtract Jdot*v for connect / weld equalities               (mj_Jdotv, :1056-1250)
   const int ne = MJH_F(B, counts, e)[MJH_C_NE];
-  if (ne) {
+  if (MJH_HAS(MJH_FT_EQUALITY) && ne) {
     const MJH_CONST_AS DSizes& s = M.s;
     crptr cdof = MJH_F(B, cdof, e);
     crptr cdof_dot = MJH_F(B, cdof_dot, e);

@@ -1,0 +1,49 @@
+// Kernel + launcher definitions shared by the .hip translation units of libmjhip.so.
+//
+// libmjhip.so compiles each SPMD mapping of the stage sources (mjh_modes.h) in its own translation
+// unit so they build in parallel; a unit instantiates MJH_DEFINE_WAVE_KERNELS for its namespace and
+// exports plain-C launchers that the host runtime (mjh_hip.hip + mjh_runtime.h) calls.
+//
+// One HIP block == one 64-lane wavefront == NSUB environments (NSUB lane groups of 64/NSUB lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mjh_modes.h"
+
+// The model / batch descriptors (tables of device pointers, ~1 KB each) live in device memory and
+// are read through the scalar cache on demand; passing them by value made the compiler hoist
+// every pointer into SGPRs for the whole kernel (hundreds of spills).
+// WPE = waves per SIMD the register budget is sized for: 4 (128 VGPRs) keeps 4096 one-environment
+// wavefronts co-resident; the two-environment mapping needs only half as many wavefronts and gets
+// 256 VGPRs.  SUBEXPR = index of the calling lane's group inside its wavefront.
+#define MJH_DEFINE_WAVE_KERNELS(NS, NSUB, WPE, SUBEXPR)                                                        \
+  __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
+  void mjh_k_forward_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages) {            \
+    const int e = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
+    if (e >= B->nenv) return;                                                                                  \
+    NS::forward_or_euler(wv_const_ref(M), wv_const_ref(B), e, stages);                                         \
+  }                                                                                                            \
+  __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
+  void mjh_k_rollout_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {         \
+    const int e = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
+    if (e >= B->nenv) return;                                                                                  \
+    NS::rollout_env(wv_const_ref(M), wv_const_ref(B), e, A);                                                   \
+  }                                                                                                            \
+  extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
+                                          void* stream) {                                                      \
+    hipLaunchKernelGGL(mjh_k_forward_##NS, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
+                       (size_t)lds*(NSUB), (hipStream_t)stream, M, B, stages);                                 \
+    return hipGetLastError() == hipSuccess;                                                                    \
+  }                                                                                                            \
+  extern "C" bool mjh_launch_rollout_##NS(const DModel* M, const DBatch* B, int nenv, const RolloutArgs* A,    \
+                                          int lds, void* stream) {                                             \
+    hipLaunchKernelGGL(mjh_k_rollout_##NS, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
+                       (size_t)lds*(NSUB), (hipStream_t)stream, M, B, *A);                                     \
+    return hipGetLastError() == hipSuccess;                                                                    \
+  }
+
+#define MJH_DECLARE_WAVE_LAUNCHERS(NS)                                                                         \
+  extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
+                                          void* stream);                                                       \
+  extern "C" bool mjh_launch_rollout_##NS(const DModel* M, const DBatch* B, int nenv, const RolloutArgs* A,    \
+                                          int lds, void* stream);

@@ -822,6 +822,41 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));
+
+  // ---------------- features this model needs from a kernel variant (MJH_FT_*, mjh_types.h) ------------
+  // every `MJH_HAS(x) && condition` of the stage sources has its condition mirrored here
+  {
+    int ft = 0;
+    if (m->opt.solver != mjSOL_PGS) ft |= MJH_FT_PRIMAL;
+    if (m->opt.cone != mjCONE_PYRAMIDAL) ft |= MJH_FT_ELLIPTIC;
+    if (m->neq > 0) ft |= MJH_FT_EQUALITY;
+    if (m->opt.integrator == mjINT_RK4) ft |= MJH_FT_RK4;
+    if (m->opt.integrator == mjINT_IMPLICITFAST) ft |= MJH_FT_IMPLICIT;
+    if (m->nsensor > 0) ft |= MJH_FT_SENSOR;
+    for (int p = 0; p < s.npair; p++) {
+      const int f = H->pair_func[p];
+      if (f != MJH_COL_PLANE_SPHERE && f != MJH_COL_PLANE_CAPSULE && f != MJH_COL_SPHERE_SPHERE &&
+          f != MJH_COL_SPHERE_CAPSULE && f != MJH_COL_CAPSULE_CAPSULE) ft |= MJH_FT_COLCONVEX;
+      if (H->pair_dim[p] > 3) ft |= MJH_FT_CONDIM46;
+    }
+    if (m->na > 0) ft |= MJH_FT_ACT;
+    for (int i = 0; i < m->ntendon; i++) if (m->wrap_type[m->tendon_adr[i]] != mjWRAP_JOINT) ft |= MJH_FT_TENDONSPATIAL;
+    for (int i = 0; i < m->nu; i++) {
+      const int tt = m->actuator_trntype[i];
+      if (tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT) ft |= MJH_FT_TRNMISC;
+      else {
+        const int jt = m->jnt_type[m->actuator_trnid[2*i]];
+        if (jt == mjJNT_BALL || jt == mjJNT_FREE) ft |= MJH_FT_TRNMISC;
+      }
+      if (m->actuator_gaintype[i] != mjGAIN_FIXED || m->actuator_biastype[i] != mjBIAS_NONE ||
+          m->actuator_forcelimited[i]) ft |= MJH_FT_GAINBIAS;
+    }
+    for (int i = 0; i < m->njnt; i++) if (m->jnt_actfrclimited[i]) ft |= MJH_FT_GAINBIAS;
+    if (o.has_gravcomp || o.has_fluid || o.has_surfacevel) ft |= MJH_FT_PASSIVEMISC;
+    if (m->nmocap > 0) ft |= MJH_FT_MOCAP;
+    if (m->ntree > 1) ft |= MJH_FT_ISLANDS;
+    s.features = ft;
+  }
   return true;
 }
 

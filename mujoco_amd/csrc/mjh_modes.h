@@ -1,26 +1,53 @@
-// The stage sources are written once against a small SPMD vocabulary (wv_lane, wv_sync, wv_bcast,
-// wv_ballot, wv_sum_i, wv_exscan_i, wv_any, MJH_FOR_LANES, MJH_W) and compiled in two mappings:
+// The stage sources are written once against a small SPMD vocabulary (wv_lane, wv_sub, wv_sync,
+// wv_bcast, wv_ballot, wv_sum_i, wv_exscan_i, wv_any, MJH_FOR_LANES, MJH_W) and a compile-time
+// feature set (MJH_HAS, mjh_types.h), and compiled in several mappings, one namespace each:
 //
-//   namespace wv : "one wavefront per environment".  MJH_W = 64 work items of a phase run on the 64
-//                  lanes of the wavefront that owns the environment; phases are separated by
-//                  wv_sync(); cross-lane primitives are DPP/readlane/shuffles (mjh_spmd.h).  Used
-//                  where one environment has enough fine-grained parallelism and data-dependent
-//                  length: collision, constraint assembly, AR = Y Y' and the PGS sweep.
-//   namespace ln : "one lane per environment".  MJH_W = 1: every GPU lane walks the serial
-//                  algorithm of its own environment, so a wavefront steps 64 environments in
-//                  lockstep; model constants are wave-uniform (scalar loads), mjData fields are
-//                  read SoA-across-environments (lane stride 8 bytes: fully coalesced), there are
-//                  no barriers and no cross-lane traffic.  Used for the tree recursions and the
-//                  L'DL factor/solves, whose control flow is identical for all environments of
-//                  a model.
+//   wv : "one wavefront per environment", every feature.  MJH_W = 64 work items of a phase run on
+//        the 64 lanes of the wavefront that owns the environment; phases are separated by
+//        wv_sync(); cross-lane primitives are DPP/readlane/shuffles (mjh_spmd.h).
+//   ws : the same mapping on SoA batches (strided views): constraint kernel of the 3-kernel pipeline.
+//   ln : "one lane per environment".  MJH_W = 1: every GPU lane walks the serial algorithm of its
+//        own environment, a wavefront steps 64 environments in lockstep; model constants are
+//        wave-uniform (scalar loads), mjData fields are read SoA-across-environments.
+//   wl : wv restricted to the LEAN feature set (PGS, pyramidal cones, Euler, primitive colliders,
+//        no sensors / equalities / ...): the kernel a model like humanoid.xml actually needs,
+//        without the stack frames and register pressure of everything else.
+//   w2 : LEAN, "two environments per wavefront": MJH_W = 32, lanes 0-31 step environment 2b,
+//        lanes 32-63 environment 2b+1 (b = workgroup).  Most phases of a small model occupy fewer
+//        than 32 lanes, so one instruction now serves two environments; with half as many
+//        wavefronts for the same batch each may use 256 VGPRs (2 waves/SIMD).  The two halves
+//        diverge only where their data does (contact / constraint counts, solver iterations).
+//   w4 : LEAN, four environments per wavefront (MJH_W = 16, one DPP row each).
+//
+// A translation unit selects what it compiles with MJH_BUILD_<NS> (none given: everything, which
+// is what the host emulation does); libmjhip.so compiles the namespaces in separate .hip files so
+// they build in parallel.
 #pragma once
 
 #include "mjh_spmd.h"
 #include "mjh_math.h"
 #include "mjh_types.h"
 
+#if !defined(MJH_BUILD_WV) && !defined(MJH_BUILD_WS) && !defined(MJH_BUILD_LN) && !defined(MJH_BUILD_WL) && \
+    !defined(MJH_BUILD_W2) && !defined(MJH_BUILD_W4)
+#define MJH_BUILD_WV 1
+#define MJH_BUILD_WS 1
+#define MJH_BUILD_LN 1
+#define MJH_BUILD_WL 1
+#define MJH_BUILD_W2 1
+#define MJH_BUILD_W4 1
+#endif
+
+// kernel variants (mjhipBatch_::variant, RolloutArgs consumers): which namespace steps a batch
+enum { MJH_VAR_GENERIC = 0, MJH_VAR_LEAN = 1, MJH_VAR_LEAN2 = 2, MJH_VAR_LEAN4 = 3, MJH_NVARIANT = 4 };
+static inline int mjh_variant_nsub(int v) { return v == MJH_VAR_LEAN2 ? 2 : (v == MJH_VAR_LEAN4 ? 4 : 1); }
+static inline int mjh_variant_features(int v) { return v == MJH_VAR_GENERIC ? MJH_FT_ALL : MJH_FT_LEAN; }
+static inline const char* mjh_variant_name(int v) {
+  return v == MJH_VAR_GENERIC ? "generic" : v == MJH_VAR_LEAN ? "lean" : v == MJH_VAR_LEAN2 ? "lean2" : "lean4";
+}
+
 // ------------------------------------------------------------------------------------------------
-// wave mode
+// wave mode (one environment per wavefront)
 // ------------------------------------------------------------------------------------------------
 #define MJH_W 64
 #define MJH_LANE_MODE 0
@@ -31,16 +58,75 @@
 // strided view a unit-stride view (no index multiply per access)
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
                               if (B.soa != 0) __builtin_unreachable()
+#if MJH_BUILD_WV
+#define MJH_FEATURES MJH_FT_ALL
 namespace wv {
 #include "mjh_stages.inc"
 }
+#undef MJH_FEATURES
+#endif
+#if MJH_BUILD_WL
+#define MJH_FEATURES MJH_FT_LEAN
+namespace wl {
+#include "mjh_stages.inc"
+}
+#undef MJH_FEATURES
+#endif
 #undef MJH_ENTER
 // namespace ws: the same wave mapping on SoA batches (constraint kernel of the per-step pipeline)
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_)
+#if MJH_BUILD_WS
+#define MJH_FEATURES MJH_FT_ALL
 namespace ws {
 #include "mjh_stages.inc"
 }
+#undef MJH_FEATURES
+#endif
 #undef MJH_W
+#undef MJH_FOR_LANES
+#undef MJH_ENTER
+
+// ------------------------------------------------------------------------------------------------
+// sub-wave modes (several environments per wavefront), environment-major batches only
+// ------------------------------------------------------------------------------------------------
+#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
+// (e differs between the groups of a wavefront: it stays in a VGPR; the descriptors are uniform)
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = e_; \
+                              if (B.soa != 0) __builtin_unreachable()
+#define MJH_FEATURES MJH_FT_LEAN
+// the SPMD vocabulary restricted to the caller's group of MJH_W lanes: these hide the wave-wide
+// primitives of mjh_spmd.h (which stay reachable as ::wv_* for values every group shares)
+#define MJH_SUBWAVE_VOCABULARY                                                            \
+  MJH_DEV int wv_lane() { return sw_lane<MJH_W>(); }                                      \
+  MJH_DEV int wv_sub() { return sw_sub<MJH_W>(); }                                        \
+  MJH_DEV void wv_sync() { ::wv_sync(); }                                                 \
+  MJH_DEV double wv_bcast(double v, int src) { return sw_bcast<MJH_W>(v, src); }          \
+  MJH_DEV int wv_bcast_i(int v, int src) { return sw_bcast_i<MJH_W>(v, src); }            \
+  MJH_DEV uint64_t wv_ballot(int pred) { return sw_ballot<MJH_W>(pred); }                 \
+  MJH_DEV int wv_sum_i(int v) { return sw_sum_i<MJH_W>(v); }                              \
+  MJH_DEV int wv_exscan_i(int v) { return sw_exscan_i<MJH_W>(v); }                        \
+  MJH_DEV int wv_any(int pred) { return sw_ballot<MJH_W>(pred) != 0; }                    \
+  MJH_DEV double wv_shfl(double v, int src) { return sw_bcast<MJH_W>(v, src); }           \
+  MJH_DEV int wv_shfl_i(int v, int src) { return sw_bcast_i<MJH_W>(v, src); }             \
+  MJH_DEV double wv_shfl_xor(double v, int mask) { return sw_shfl_xor<MJH_W>(v, mask); }  \
+  MJH_DEV int wv_uniform_i(int v) { return v; }
+#if MJH_BUILD_W2
+#define MJH_W 32
+namespace w2 {
+MJH_SUBWAVE_VOCABULARY
+#include "mjh_stages.inc"
+}
+#undef MJH_W
+#endif
+#if MJH_BUILD_W4
+#define MJH_W 16
+namespace w4 {
+MJH_SUBWAVE_VOCABULARY
+#include "mjh_stages.inc"
+}
+#undef MJH_W
+#endif
+#undef MJH_FEATURES
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
 #undef MJH_FOR_LANES
@@ -55,9 +141,12 @@ namespace ws {
 #define MJH_FOR_LANES(i, n) for (int i = 0; i < (n); i++)
 // (stage functions are inlined into the kernel here: descriptors are already uniform, e is per lane)
 #define MJH_ENTER(M_, B_, e_) MREF M = M_; BREF B = B_; const int e = e_
+#if MJH_BUILD_LN
+#define MJH_FEATURES MJH_FT_ALL
 namespace ln {
 // the SPMD vocabulary for a width-1 "wave": these hide the wavefront primitives of mjh_spmd.h
 MJH_DEV int wv_lane() { return 0; }
+MJH_DEV int wv_sub() { return 0; }
 MJH_DEV void wv_sync() {}
 MJH_DEV double wv_bcast(double v, int) { return v; }
 MJH_DEV int wv_bcast_i(int v, int) { return v; }
@@ -67,6 +156,8 @@ MJH_DEV int wv_exscan_i(int) { return 0; }
 MJH_DEV int wv_any(int pred) { return pred != 0; }
 #include "mjh_stages.inc"
 }
+#undef MJH_FEATURES
+#endif
 #undef MJH_W
 #undef MJH_LANE_MODE
 #undef MJH_DEVN

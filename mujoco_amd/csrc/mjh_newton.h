@@ -15,7 +15,7 @@ MJH_DEV real wv_sum_d(real v) {
 #if MJH_LANE_MODE
   return v;
 #else
-  for (int m = 32; m >= 1; m >>= 1) v += wv_shfl_xor(v, m);
+  for (int m = MJH_W/2; m >= 1; m >>= 1) v += wv_shfl_xor(v, m);
   return v;
 #endif
 }

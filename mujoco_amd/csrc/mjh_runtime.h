@@ -16,8 +16,9 @@
 //   static bool sync(void* stream);
 //   (M, B below are DEVICE pointers to the descriptor structs)
 //   (lds = bytes of LDS per one-wavefront workgroup demanded by the batch descriptor's plan, 0 = none)
-//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, void* stream);
-//   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, void* stream);
+//   (variant = MJH_VAR_* of mjh_modes.h: the kernel mapping that steps the batch; lds is per environment)
+//   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void* stream);
+//   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, int variant, void* stream);
 //   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
 //   lane-mode kernels of the SoA pipeline (epw = environments per wavefront):
 //   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs&, void* stream);
@@ -73,6 +74,8 @@ struct mjhipBatch_ {
   int soa = 0;                 // 0: fields [nenv][count]; else nenvpad: fields [count][nenvpad]
   int nenvpad = 0;
   int epw = 64;                // environments per wavefront of the lane-mode kernels (<= 64)
+  int variant = MJH_VAR_GENERIC;   // kernel mapping (MJH_VAR_*, mjh_modes.h) that steps this batch
+  int lds_request = 0;             // LDS budget per environment last asked for (before clamping)
   void* arena = nullptr;
   size_t arena_bytes = 0;
   std::map<std::string, FieldInfo> fields;
@@ -267,7 +270,7 @@ MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
   const DSizes& s = M->H.s;
 #define SZ(n) if (!strcmp(name, #n)) return s.n;
   SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
-  SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
+  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
 #undef SZ
   set_err(std::string("mjhip_model_size: unknown size ") + name);
   return -1;
@@ -294,6 +297,8 @@ MJHIP_API int mjhip_set_option(struct mjModel_* mm, const char* name, double val
   set_err(std::string("mjhip_set_option: unknown option ") + name);
   return -2;
 }
+
+static int default_variant(const mjhipModel_* M, int soa);
 
 MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   // $MJHIP_LAYOUT = aos | soa overrides the default layout
@@ -352,13 +357,12 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
     mjhip_batch_destroy(Bt);
     return nullptr;
   }
-  {
-    std::vector<int> ident((size_t)Bt->nenvpad);
-    for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
-    if (!Backend::h2d(Bt->D.perm, ident.data(), ident.size()*sizeof(int), nullptr) || !Backend::sync(nullptr)) {
-      set_err("mjhip: batch initialisation failed"); mjhip_batch_destroy(Bt); return nullptr;
-    }
-  }
+  if (!Backend::sync(nullptr)) { set_err("mjhip: batch initialisation failed"); mjhip_batch_destroy(Bt); return nullptr; }
+  // kernel variant: the leanest mapping whose feature set covers the model ($MJHIP_VARIANT overrides)
+  Bt->variant = default_variant(M, Bt->soa);
+  // ($MJHIP_VARIANT is a preference: batches it cannot serve -- SoA layout, models that need
+  // features the lean kernels lack -- keep their default)
+  if (const char* ev = getenv("MJHIP_VARIANT")) (void)mjhip_batch_set_variant(Bt, ev);
   // residency plan: MJHIP_LDS_BYTES overrides the default per-workgroup LDS budget (0 disables)
   {
     int budget = MJHIP_DEFAULT_LDS_BYTES;
@@ -379,10 +383,49 @@ MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
 
 MJHIP_API int mjhip_batch_nenv(const mjhipBatch* Bt) { return Bt ? Bt->nenv : -1; }
 
+// which kernel mappings can step this model at all
+static bool variant_ok(const mjhipModel_* M, int soa, int variant, std::string* why) {
+  if (variant < 0 || variant >= MJH_NVARIANT) { if (why) *why = "unknown variant"; return false; }
+  if (variant == MJH_VAR_GENERIC) return true;
+  if (soa) { if (why) *why = "the lean kernel variants step environment-major (AoS) batches only"; return false; }
+  const int missing = M->H.s.features & ~mjh_variant_features(variant);
+  if (missing) {
+    if (why) { char b[96]; snprintf(b, sizeof b, "the model needs features 0x%x that the lean kernels do not carry", missing); *why = b; }
+    return false;
+  }
+  return true;
+}
+static int default_variant(const mjhipModel_* M, int soa) {
+  // two environments per wavefront when the model's dofs fit a 32-lane group (register-resident
+  // L'DL / PGS layouts), else one
+  if (variant_ok(M, soa, MJH_VAR_LEAN2, nullptr) && M->H.s.nv <= 32 && M->H.s.ld_fast) return MJH_VAR_LEAN2;
+  if (variant_ok(M, soa, MJH_VAR_LEAN, nullptr)) return MJH_VAR_LEAN;
+  return MJH_VAR_GENERIC;
+}
+
+MJHIP_API int mjhip_batch_set_variant(mjhipBatch* Bt, const char* name) {
+  if (!Bt || !name) return -1;
+  int v = -1;
+  for (int k = 0; k < MJH_NVARIANT; k++) if (!strcmp(name, mjh_variant_name(k))) v = k;
+  if (!strcmp(name, "auto")) v = default_variant(Bt->model, Bt->soa);
+  std::string why;
+  if (!variant_ok(Bt->model, Bt->soa, v, &why)) {
+    set_err(std::string("mjhip_batch_set_variant(") + name + "): " + why);
+    return -2;
+  }
+  Bt->variant = v;
+  // the LDS budget of a workgroup is shared by the environments of a wavefront: re-plan
+  if (Bt->L_dev) return mjhip_batch_plan_lds(Bt, Bt->L.lds_bytes ? Bt->L.lds_bytes : Bt->lds_request) < 0 ? -3 : 0;
+  return 0;
+}
+MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* Bt) { return Bt ? mjh_variant_name(Bt->variant) : ""; }
+
 MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
   if (lds_bytes < 0) lds_bytes = 0;
-  if (lds_bytes > Backend::max_lds()) lds_bytes = Backend::max_lds();
+  Bt->lds_request = lds_bytes;
+  const int max_lds = Backend::max_lds() / mjh_variant_nsub(Bt->variant);
+  if (lds_bytes > max_lds) lds_bytes = max_lds;
 
   // equality constraints read kinematics / velocity quantities long after their usual lifetimes
   // (rows at make, Jdot*v at reference): such models keep those fields in their global homes
@@ -511,7 +554,7 @@ static bool pipeline_step(mjhipBatch_* Bt, const RolloutArgs& A, void* stream) {
   if (!Backend::launch_smooth(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream)) return false;
   const bool lds = Bt->L.lds_bytes > 0;
   if (!Backend::launch_forward(M, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, MJH_STAGES_CONSTRAINT_MASK | MJH_STAGE_IFACTIVE,
-                               lds ? Bt->L.lds_bytes : 0, 1, stream)) return false;
+                               lds ? Bt->L.lds_bytes : 0, 1, MJH_VAR_GENERIC, stream)) return false;
   return Backend::launch_integrate(M, Bt->D_dev, Bt->nenv, Bt->epw, A, stream);
 }
 
@@ -527,7 +570,7 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt->soa) {
     if (lds) stages |= MJH_STAGE_WRITEBACK;
     ok = Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv, stages,
-                                 lds ? Bt->L.lds_bytes : 0, 0, stream);
+                                 lds ? Bt->L.lds_bytes : 0, 0, Bt->variant, stream);
   } else {
     // the pipeline's split: lane-mode kernel for the smooth stages, wave-mode kernel for the
     // constraint stages (on its LDS plan + write-back if asked), lane-mode kernel for the tail
@@ -535,7 +578,8 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
     const int s3 = stages & (MJH_STAGE_FINISH | MJH_STAGE_EULER);
     if (s1) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s1, stream);
     if (s2) ok = ok && Backend::launch_forward(Bt->model->D_dev, lds ? Bt->L_dev : Bt->D_dev, Bt->nenv,
-                                               s2 | (lds ? MJH_STAGE_WRITEBACK : 0), lds ? Bt->L.lds_bytes : 0, 1, stream);
+                                               s2 | (lds ? MJH_STAGE_WRITEBACK : 0), lds ? Bt->L.lds_bytes : 0, 1,
+                                               MJH_VAR_GENERIC, stream);
     if (s3) ok = ok && Backend::launch_lane_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, s3, stream);
   }
   if (!ok) { set_err("mjhip_batch_forward: kernel launch failed"); return -2; }
@@ -554,7 +598,7 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   if (Bt->soa) {
     for (int t = 0; t < nstep && ok; t++) { A.t0 = t; ok = pipeline_step(Bt, A, stream); }
   } else {
-    ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream);
+    ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
   }
   if (!ok) { set_err("mjhip_batch_step: kernel launch failed"); return -2; }
   return 0;
@@ -651,7 +695,7 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned co
       A.init = 0;
     }
   } else {
-    launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, stream);
+    launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
   }
   if (!launched) { cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
   if (!on_device) {

@@ -80,7 +80,7 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
         int pid = M.body_parentid[i];
         // body pose in the parent: from the model, or the user-driven mocap arrays (:84-93)
         real bpos[3], bquat[4];
-        const int mid = s.nmocap ? (int)M.body_mocapid[i] : -1;
+        const int mid = (MJH_HAS(MJH_FT_MOCAP) && s.nmocap) ? (int)M.body_mocapid[i] : -1;
         if (mid >= 0) {
           v3_copy(bpos, MJH_G(B, mocap_pos, e) + 3*mid);
           q_copy(bquat, MJH_G(B, mocap_quat, e) + 4*mid);
@@ -264,7 +264,7 @@ MJH_DEVN void stage_tendon(MREF M_, BREF B_, int e_) {
     int radr = M.ten_J_rowadr[i], rnnz = M.ten_J_rownnz[i];
     real len = 0;
     for (int k = 0; k < rnnz; k++) J[radr + k] = 0;
-    if (M.wrap_type[adr] != 1) {
+    if (MJH_HAS(MJH_FT_TENDONSPATIAL) && M.wrap_type[adr] != 1) {
       // spatial tendon through sites, with pulleys (mj_tendon, engine_core_smooth.c:988-1105; wrapping
       // geoms are rejected at upload): straight segments between consecutive sites, moments from the
       // difference of the end-point Jacobians along the segment direction
@@ -348,7 +348,7 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
     int id = M.actuator_trnid[2*i];
     auto gear = M.actuator_gear + 6*i;
     int adr = M.actuator_momentadr[i];
-    if (M.actuator_trntype[i] == MJH_TRN_SLIDERCRANK) {
+    if (MJH_HAS(MJH_FT_TRNMISC) && M.actuator_trntype[i] == MJH_TRN_SLIDERCRANK) {
       // slider-crank (engine_core_smooth.c:1396-1465): length = a.v - sqrt((a.v)^2 + r^2 - v.v)
       crptr site_xpos = MJH_F(B, site_xpos, e);
       crptr site_xmat = MJH_F(B, site_xmat, e);
@@ -411,7 +411,7 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       }
       length[i] = len * gear[0];
       rownnz[i] = nnz;
-    } else if (M.actuator_trntype[i] == MJH_TRN_SITE) {
+    } else if (MJH_HAS(MJH_FT_TRNMISC) && M.actuator_trntype[i] == MJH_TRN_SITE) {
       // site, no reference site (engine_core_smooth.c:1573-1593, :1705-1715): the gear is a wrench in
       // the site frame; moment = site Jacobians projected on it, length 0
       crptr site_xpos = MJH_F(B, site_xpos, e);
@@ -440,7 +440,7 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       }
       length[i] = 0;
       rownnz[i] = nnz;
-    } else if (M.actuator_trntype[i] == MJH_TRN_TENDON) {
+    } else if (MJH_HAS(MJH_FT_TRNMISC) && M.actuator_trntype[i] == MJH_TRN_TENDON) {
       // tendon (engine_core_smooth.c:1468-1480): the tendon's length and moment row, scaled by the gear
       crptr tl = MJH_F(B, ten_length, e);
       crptr tJ = MJH_F(B, ten_J, e);
@@ -451,7 +451,7 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
         colind[adr + k] = M.ten_J_colind[ra + k];
         moment[adr + k] = tJ[ra + k]*gear[0];
       }
-    } else if (M.jnt_type[id] == MJH_JNT_BALL) {
+    } else if (MJH_HAS(MJH_FT_TRNMISC) && M.jnt_type[id] == MJH_JNT_BALL) {
       // ball joint: 3D gear; length = expmap(quat) . gear (engine_core_smooth.c:1331-1362)
       const int qa = M.jnt_qposadr[id], da = M.jnt_dofadr[id];
       real quat[4] = {qpos[qa], qpos[qa+1], qpos[qa+2], qpos[qa+3]};
@@ -463,7 +463,7 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       length[i] = v3_dot(axis, ga);
       rownnz[i] = 3;
       for (int k = 0; k < 3; k++) { colind[adr + k] = da + k; moment[adr + k] = ga[k]; }
-    } else if (M.jnt_type[id] == MJH_JNT_FREE) {
+    } else if (MJH_HAS(MJH_FT_TRNMISC) && M.jnt_type[id] == MJH_JNT_FREE) {
       // free joint: 6D gear, no meaningful length (:1364-1392)
       const int qa = M.jnt_qposadr[id], da = M.jnt_dofadr[id];
       real ga[3], g[3] = {gear[3], gear[4], gear[5]};
@@ -525,7 +525,7 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
 
 #if !MJH_LANE_MODE
 // ------------------------------------------------------------------------------------------------
-// Wavefront L'DL routines for nv <= 64 (M.s.ld_fast): lane i owns dof i.
+// Wavefront L'DL routines for nv <= MJH_W (M.s.ld_fast): lane i of the environment's lane group owns dof i.
 // Row addresses, row lengths and the strict-ancestor masks sit in registers and are handed around
 // with v_readlane, so the serial sweeps contain no dependent model-memory loads; qLD itself is
 // read where it lives (LDS by plan).  Same arithmetic, same order as the generic versions below.
@@ -555,7 +555,7 @@ MJH_DEVN void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
     }
     const real invD = 1 / mat[start + diag];
     for (int w = lane; w < total; w += MJH_W) {
-      const int it = (w < MJH_W) ? item : ld_prog[pbase + w];
+      const int it = (w < MJH_W) ? item : (int)ld_prog[pbase + w];
       const int dst = it & 1023, src = (it >> 10) & 1023, sc = (it >> 20) & 1023;
       const real scl = -mat[sc] * invD;
       mat[dst] += mat[src] * scl;
@@ -665,7 +665,7 @@ template <class P0, class P1>
 MJH_DEVN void factor_ld(MREF M, P0 mat, P1 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
-  if (M.s.ld_fast) {
+  if (M.s.ld_fast && (MJH_W == 64 || M.s.nv <= MJH_W)) {
     if (mjh_in_lds(mat)) factor_ld_fast(M, mjh_local(mat.p), diaginv);
     else factor_ld_fast(M, mat, diaginv);
     return;
@@ -721,7 +721,7 @@ template <class P0, class P1, class P2>
 MJH_DEVN void solve_ld(MREF M, P0 x, P1 qLD, P2 diaginv) {
   const int nv = M.s.nv;
 #if !MJH_LANE_MODE
-  if (M.s.ld_fast) {
+  if (M.s.ld_fast && (MJH_W == 64 || M.s.nv <= MJH_W)) {
     if (mjh_in_lds(qLD)) solve_ld_fast(M, x, mjh_local(qLD.p), diaginv);
     else solve_ld_fast(M, x, qLD, diaginv);
     return;
@@ -931,7 +931,7 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
   // fluid forces, inertia-box model (mj_fluid / mj_inertiaBoxFluidModel, engine_passive.c:871-903,
   // :1154-1210): viscous and quadratic drag on the equivalent inertia box of every body, in the
   // body's inertial frame, applied at its COM through mj_applyFT
-  if (M.o.has_fluid && (M.o.viscosity != 0 || M.o.density != 0)) {
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_fluid && (M.o.viscosity != 0 || M.o.density != 0)) {
     crptr xipos = MJH_F(B, xipos, e);
     crptr ximat = MJH_F(B, ximat, e);
     crptr cvel = MJH_F(B, cvel, e);
@@ -1013,7 +1013,7 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
   }
   // gravity compensation (mj_gravcomp, engine_passive.c:846-867 + :1112-1122): per compensated
   // body a force -gravity*mass*gravcomp at its COM, mapped through the point Jacobian (mj_applyFT)
-  if (M.o.has_gravcomp && !(dsbl & (1<<7)) &&
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_gravcomp && !(dsbl & (1<<7)) &&
       sqrt(M.o.gravity[0]*M.o.gravity[0] + M.o.gravity[1]*M.o.gravity[1] + M.o.gravity[2]*M.o.gravity[2]) != 0) {
     crptr xipos = MJH_F(B, xipos, e);
     crptr cdof = MJH_F(B, cdof, e);
@@ -1170,7 +1170,7 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
       c = r_clip(c, M.actuator_ctrlrange[2*i], M.actuator_ctrlrange[2*i+1]);
     if (bad) c = 0;
     // stateful actuators: act_dot from the control, the force sees the activation (:403-447, :800-817)
-    const int dyn = s.na ? (int)M.actuator_dyntype[i] : (int)MJH_DYN_NONE;
+    const int dyn = (MJH_HAS(MJH_FT_ACT) && s.na) ? (int)M.actuator_dyntype[i] : (int)MJH_DYN_NONE;
     if (dyn != MJH_DYN_NONE) {
       const int aa = M.actuator_actadr[i];
       real ad;
@@ -1182,13 +1182,13 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
     auto gp = M.actuator_gainprm + 10*i;
     auto bp = M.actuator_biasprm + 10*i;
     real gain;
-    if (M.actuator_gaintype[i] == MJH_GAIN_FIXED) gain = gp[0];
+    if (!MJH_HAS(MJH_FT_GAINBIAS) || M.actuator_gaintype[i] == MJH_GAIN_FIXED) gain = gp[0];
     else gain = gp[0] + gp[1]*len[i] + gp[2]*vel[i];
     real f = gain * c;
     real bias = 0.0;
-    if (M.actuator_biastype[i] == MJH_BIAS_AFFINE) bias = bp[0] + bp[1]*len[i] + bp[2]*vel[i];
+    if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_biastype[i] == MJH_BIAS_AFFINE) bias = bp[0] + bp[1]*len[i] + bp[2]*vel[i];
     f += bias;
-    if (M.actuator_forcelimited[i])
+    if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_forcelimited[i])
       f = r_clip(f, M.actuator_forcerange[2*i], M.actuator_forcerange[2*i+1]);
     force[i] = f;
   }
@@ -1211,7 +1211,7 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
   wv_sync();
   // joint-level actuator force limits (clampVec with jnt_dofadr index)
   MJH_FOR_LANES(j, s.njnt) {
-    if (M.jnt_actfrclimited[j]) {
+    if (MJH_HAS(MJH_FT_GAINBIAS) && M.jnt_actfrclimited[j]) {
       int d = M.jnt_dofadr[j];
       qfa[d] = r_clip(qfa[d], M.jnt_actfrcrange[2*j], M.jnt_actfrcrange[2*j+1]);
     }

@@ -42,7 +42,7 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
   return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
 }
 
-#if !MJH_LANE_MODE
+#if !MJH_LANE_MODE && MJH_W == 64
 // ------------------------------------------------------------------------------------------------
 // solPGS for nefc <= 64 with the iterate in registers           (engine_solver.c:457-741)
 //
@@ -254,7 +254,201 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   if (lane == 0) counts[MJH_C_NITER] = niter0;
   wv_sync();
 }
-#endif  // !MJH_LANE_MODE
+#endif  // 64-lane layout
+
+#if !MJH_LANE_MODE && MJH_W == 32
+// ------------------------------------------------------------------------------------------------
+// solPGS for nefc <= 32, iterate in registers, one environment per 32-lane group (two DPP rows)
+//
+// Same idea as the 64-lane layout above with two of mju_dot's four chains per DPP row: chain
+// c = 2*row + slot occupies lanes [8*slot, 8*slot + L) of row `row` (L = n4/4 <= 8), constraint
+// j < n4 lives in lane 16*((j&3)>>1) + 8*(j&1) + (j>>2), tail constraint n4+t in position 7 of
+// chain slot t (free because L <= 7 whenever a tail exists).  Every lane carries two chain sums
+// (its row's slots), fed by v_mov_b64_dpp row_newbcast; the rows are combined with one
+// v_permlane16_swap exchange per sum: (r0 + r2) + (r1 + r3), mju_dot's association.
+// The two groups of a wavefront run this loop independently (their nefc, visitation tables and
+// iteration counts differ): control flow diverges per group, every cross-lane read stays inside
+// the reader's group.
+// ------------------------------------------------------------------------------------------------
+#define MJH_PGS2_STEP(k) if (L > k) { accA = accA + wv_row_bcast<k>(p); accB = accB + wv_row_bcast<8 + k>(p);
+#define MJH_PGS2_END }}}}}}}
+
+template <int ARL>
+MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
+  const auto& M = wv_uniform_ref(M_);
+  BREF B = B_;
+  const int e = e_;
+  iptr counts = MJH_F(B, counts, e);
+  const int n = counts[MJH_C_NEFC], ne = counts[MJH_C_NE], nf = counts[MJH_C_NF];
+  Efc P;
+  efc_layout(M, B, e, n, P);
+  const int lane = wv_lane();
+  const int n4 = n & ~3, L = n4 >> 2, ntail = n - n4;
+  const int chain = 2*(lane >> 4) + ((lane >> 3) & 1), pos = lane & 7;
+  // lane (inside the group) that owns constraint q
+  auto lane_of = [&](int q) -> int {
+    const int c = (q < n4) ? (q & 3) : (q - n4), k = (q < n4) ? (q >> 2) : 7;
+    return 16*(c >> 1) + 8*(c & 1) + k;
+  };
+  // constraint owned by this lane (-1: none)
+  int j = -1;
+  if (pos < L) j = 4*pos + chain;
+  else if (pos == 7 && chain < ntail) j = n4 + chain;
+  const int own = (j >= 0);
+  const int jj = own ? j : 0;
+  const int kind = (jj < ne) ? 0 : (jj < ne + nf ? 1 : 2);   // equality / friction / inequality
+  const bool isfric = (kind == 1), isineq = (kind == 2);
+  real f = own ? P.force[jj] : 0;
+  const real bj = own ? P.b[jj] : 0;
+  const real fl = own ? P.floss[jj] : 0;
+#if defined(MJH_HOSTSIM)
+  const real* ARl = nullptr;
+#else
+  // byte offset of AR inside the workgroup's LDS allocation (which starts at LDS address 0)
+  const __attribute__((address_space(3))) real* ARl =
+      (const __attribute__((address_space(3))) real*)(unsigned)(size_t)((const char*)P.AR.p - mjh_lds());
+#endif
+  (void)ARl;
+  auto ar_load = [&](int r) -> real {       // AR[r][jj]
+    if (ARL) return ARl[r*n + jj];
+    return P.AR[(size_t)r*n + jj];
+  };
+  const real arjj = own ? ar_load(jj) : 1;
+  const real ainv = 1 / arjj;
+  const real A = 1/ainv;                  // costChange's A (:216-237), the same bits every visit
+  const real pinf = __builtin_huge_val();
+  const real blo = isfric ? -fl : (isineq ? 0.0 : -pinf);
+  const real bhi = isfric ? fl : pinf;
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const auto* otab_all = wv_uniform_ptr(M.pgs_order);
+  const auto* otab_adr = wv_uniform_ptr(M.pgs_order_adr);
+
+  // constraint islands as in the 64-lane version (one pass of the loop per island)
+  const int nisl_raw = MJH_HAS(MJH_FT_ISLANDS) ? (int)counts[MJH_C_NISLAND] : 1;
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  const int myisl = (own && nisl > 1) ? (int)P.island[jj] : 0;
+  int niter0 = 0;
+
+  for (int isl = 0; isl < nisl; isl++) {
+    const int member = own && myisl == isl;
+    int nk = n;                 // rows of this island
+    int crank = jj;             // island-local index of my constraint
+    if (nisl > 1) {
+      nk = wv_sum_i(member);
+      crank = 0;
+      for (int q = 0; q < n; q++) {
+        const int inq = (P.island[q] == isl);
+        if (inq && q < jj) crank++;
+      }
+      if (member) P.order[crank] = jj;
+      wv_sync();
+    }
+    if (nk == 0) continue;
+    // global row / owner lane of island-local index `lane`
+    int grow = lane;
+    if (nisl > 1) grow = (lane < nk) ? (int)P.order[lane] : 0;
+    const int growlane = lane_of(grow);
+    wv_sync();
+    const auto* otab = otab_all + otab_adr[nk];
+    real fprev = f, fmom = f;
+
+    int iter = 0, nesterov_k = 0;
+    int ord_next = (lane < nk) ? (int)otab[lane] : 0;
+    while (iter < maxiter) {
+      const int ordc = ord_next;
+      if (iter + 1 < maxiter) ord_next = (lane < nk) ? (int)otab[(iter + 1)*nk + lane] : 0;
+      int ord = ordc, ordlane;
+      if (nisl > 1) {
+        ord = wv_shfl_i(grow, ordc);
+        ordlane = wv_shfl_i(growlane, ordc);
+      } else {
+        ordlane = lane_of(ord);
+      }
+      // ---- Nesterov extrapolation (:508-554)
+      real beta = 0;
+      if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+      if (member) {
+        if (beta > 0) {
+          real f_save = f;
+          real fx = f_save + beta*(f_save - fprev);
+          fprev = f_save;
+          if (kind == 1) fx = r_clip(fx, -fl, fl);
+          else if (kind == 2 && fx < 0) fx = 0;
+          f = fx;
+          fmom = fx;
+        } else {
+          fprev = f;
+          fmom = f;
+        }
+      }
+
+      // ---- one sweep
+      real improvement = 0;
+      int i = wv_bcast_i(ord, 0);
+      real a = own ? ar_load(i) : 0;                   // row of the first visited constraint
+      for (int bi = 0; bi < nk; bi++) {
+        const real p = a*f;
+        const int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
+        const real anext = own ? ar_load(inext) : 0;
+        // chain sums of my DPP row: accA = slot 0 (lanes 0..L-1), accB = slot 1 (lanes 8..8+L-1)
+        real accA = 0, accB = 0;
+        if (L > 0) { accA = accA + wv_row_bcast<0>(p); accB = accB + wv_row_bcast<8>(p);
+        MJH_PGS2_STEP(1) MJH_PGS2_STEP(2) MJH_PGS2_STEP(3) MJH_PGS2_STEP(4)
+        MJH_PGS2_STEP(5) MJH_PGS2_STEP(6) MJH_PGS2_STEP(7)
+        MJH_PGS2_END }
+        // row 0 holds (r0, r1), row 1 holds (r2, r3): (r0 + r2) + (r1 + r3)
+        real dot = (accA + sw_row_swap(accA)) + (accB + sw_row_swap(accB));
+        if (ntail == 3) dot += wv_bcast(p, 7) + wv_bcast(p, 15) + wv_bcast(p, 23);
+        else if (ntail == 2) dot += wv_bcast(p, 7) + wv_bcast(p, 15);
+        else if (ntail == 1) dot += wv_bcast(p, 7);
+        // every lane evaluates the update for its own constraint; only the owner of row i keeps it
+        const real res = bj + dot;
+        const real oldf = f;
+        real fn = oldf - res*ainv;
+        fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
+        const real delta = fn - oldf;
+        real change = 0.5*delta*delta*A + delta*res;
+        if (change > 1e-10) { fn = oldf; change = 0; }
+        const int li = wv_bcast_i(ordlane, bi);          // owner lane of constraint i
+        if (lane == li) f = fn;
+        improvement -= wv_bcast(change, li);
+        i = inext;
+        a = anext;
+      }
+      improvement *= scale;
+
+      // ---- gradient restart (:694-713): sum over the island's constraints in index order
+      int restart = 0;
+      if (iter > 0) {
+        const real ce = (f - fmom) * (fmom - fprev);
+        real dotce = 0;
+        for (int q = 0; q < nk; q++) dotce += wv_bcast(ce, nisl > 1 ? wv_bcast_i(growlane, q) : lane_of(q));
+        restart = (dotce < 0);
+      }
+      if (restart) nesterov_k = 0; else nesterov_k++;
+      iter++;
+      if (improvement < M.o.tolerance) break;
+    }
+    if (isl == 0) niter0 = iter;
+  }
+
+  // final dual state (dualState, :270-345), forces back to memory, iteration count
+  if (own) {
+    int st;
+    if (kind == 0) st = MJH_STATE_QUADRATIC;
+    else if (kind == 1) {
+      if (f <= -fl) st = MJH_STATE_LINEARPOS;
+      else if (f >= fl) st = MJH_STATE_LINEARNEG;
+      else st = MJH_STATE_QUADRATIC;
+    } else st = (f <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+    P.state[jj] = st;
+    P.force[jj] = f;
+  }
+  if (lane == 0) counts[MJH_C_NITER] = niter0;
+  wv_sync();
+}
+#endif  // 32-lane layout
 
 // ------------------------------------------------------------------------------------------------
 // solPGS, generic form                                            (engine_solver.c:457-741)
@@ -401,7 +595,7 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
   const int lane = wv_lane();
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
-  const int elliptic = (M.o.cone != 0);
+  const int elliptic = MJH_HAS(MJH_FT_ELLIPTIC) && (M.o.cone != 0);
 
   MJH_FOR_LANES(i, nefc) ARinv[i] = 1 / AR[(size_t)i*nefc + i];
   wv_sync();
@@ -668,14 +862,14 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   }
   wv_sync();
 
-  if (M.o.solver != MJH_SOL_PGS) {
+  if (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) {
     // primal solvers (mjh_newton.h) leave qacc, qfrc_constraint, efc_force/state
     wv_sync();
     if (M.o.solver == MJH_SOL_NEWTON) solve_newton(M, B, e); else solve_cg(M, B, e);
     return;
   }
   if (!(M.o.disableflags & (1<<9))) {
-    constraint_update(B, e, P, jar, 0, M.o.cone != 0);        // efc_force(qacc_warmstart), syncs internally
+    constraint_update(B, e, P, jar, 0, MJH_HAS(MJH_FT_ELLIPTIC) && M.o.cone != 0);        // efc_force(qacc_warmstart), syncs internally
     // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
     MJH_FOR_LANES(r, nefc) ARf[r] = dot_ref(AR + (size_t)r*nefc, force, nefc);
     wv_sync();
@@ -691,8 +885,8 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   wv_sync();
   MJH_SUBPROF(22);     // efc_b, jar, warm start
 
-#if !MJH_LANE_MODE
-  if (nefc <= 64 && M.o.iterations <= M.s.pgs_iters && M.o.cone == 0) {
+#if !MJH_LANE_MODE && MJH_W >= 32
+  if (nefc <= MJH_W && M.o.iterations <= M.s.pgs_iters && (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
 #if defined(MJH_HOSTSIM)
     solve_pgs_fast<0>(M, B, e);
 #else
@@ -732,7 +926,7 @@ MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
     wv_sync();
     return;
   }
-  if (M.o.solver != MJH_SOL_PGS) return;         // the primal solvers work on qacc itself
+  if (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) return;         // the primal solvers work on qacc itself
   MJH_FOR_LANES(j, nv) qacc[j] = qfc[j];
   wv_sync();
   solve_ld(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));

@@ -6,7 +6,7 @@
 // mocap poses back to the model's body_pos / body_quat (mj_resetData, engine_io.c)
 MJH_DEV void reset_mocap(MREF M, BREF B, int e) {
   const MJH_CONST_AS DSizes& s = M.s;
-  if (!s.nmocap) return;
+  if (!MJH_HAS(MJH_FT_MOCAP) || !s.nmocap) return;
   rptr mp = MJH_G(B, mocap_pos, e);
   rptr mq = MJH_G(B, mocap_quat, e);
   MJH_FOR_LANES(i, s.nbody) {
@@ -62,16 +62,16 @@ MJH_DEV int check_bad(MREF M, BREF B, int e, P0 x, int n, int which) {
 // ---- LDS residency helpers -----------------------------------------------------------------------
 // copy a field between its global home and its LDS slot (no-op for fields the plan left global)
 template <class T>
-MJH_DEV void lds_copy_in(T* g, int n, int l, int soa, int e, int cnt) {
+MJH_DEV void lds_copy_in(T* g, int n, int l, int soa, int e, int cnt, char* lds) {
   if (l < 0) return;
-  T* dst = (T*)(mjh_lds() + l);
+  T* dst = (T*)(lds + l);
   SP<T> src = mjh_gp(g, n, soa, e);
   MJH_FOR_LANES(i, cnt) dst[i] = src[i];
 }
 template <class T>
-MJH_DEV void lds_copy_out(T* g, int n, int l, int soa, int e, int cnt) {
+MJH_DEV void lds_copy_out(T* g, int n, int l, int soa, int e, int cnt, char* lds) {
   if (l < 0) return;
-  const T* src = (const T*)(mjh_lds() + l);
+  const T* src = (const T*)(lds + l);
   SP<T> dst = mjh_gp(g, n, soa, e);
   MJH_FOR_LANES(i, cnt) dst[i] = src[i];
 }
@@ -81,7 +81,7 @@ MJH_DEV void lds_enter(MREF M, BREF B, int e) {
   if (!B.lds_bytes) return;
   const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
-#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 1) lds_copy_in(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
+#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 1) lds_copy_in(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt), MJH_LDS(B));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -93,7 +93,7 @@ MJH_DEV void lds_exit(MREF M, BREF B, int e) {
   const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
   wv_sync();
-#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 2) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
+#define X(name, cnt, lcnt, t0, t1) if (B.io_##name & 2) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt), MJH_LDS(B));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -107,7 +107,7 @@ MJH_DEVN void lds_writeback(MREF M_, BREF B_, int e_, int t) {
   const MJH_CONST_AS DSizes& s = M.s;
   (void)s;
   wv_sync();
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt));
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (t0) <= t && t <= (t1)) lds_copy_out(B.name, B.n_##name, B.l_##name, B.soa, e, (int)(lcnt), MJH_LDS(B));
   MJH_BATCH_REAL_FIELDS(X)
   MJH_BATCH_INT_FIELDS(X)
 #undef X
@@ -129,7 +129,7 @@ MJH_DEVN void lds_writeback(MREF M_, BREF B_, int e_, int t) {
 #define MJH_RUN(t, call) do { MJH_TIMED(t, call); if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, t); } while (0)
 MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   MJH_ENTER(M_, B_, e_);
-  const int pgs = (M.o.solver == MJH_SOL_PGS);
+  const int pgs = !MJH_HAS(MJH_FT_PRIMAL) || (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
     MJH_RUN(MJH_T_KIN, stage_kinematics(M, B, e));
     MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
@@ -159,7 +159,7 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
-  if ((stages & MJH_STAGE_SENSOR) && M.s.nsensor) stage_sensors(M, B, e);
+  if (MJH_HAS(MJH_FT_SENSOR) && (stages & MJH_STAGE_SENSOR) && M.s.nsensor) stage_sensors(M, B, e);
 }
 
 // mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
@@ -186,7 +186,7 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages);
 template <class P0>
 MJH_DEV void advance_act(MREF M, BREF B, int e, P0 act_dot) {
   const MJH_CONST_AS DSizes& s = M.s;
-  if (!s.na || (M.o.disableflags & (1<<11))) return;
+  if (!MJH_HAS(MJH_FT_ACT) || !s.na || (M.o.disableflags & (1<<11))) return;
   rptr act = MJH_F(B, act, e);
   MJH_FOR_LANES(i, s.nu) {
     if (M.actuator_dyntype[i] == MJH_DYN_NONE) continue;
@@ -593,8 +593,8 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
-  if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
-  else if (M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
+  if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
   else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
 }
 
@@ -671,7 +671,7 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     wv_sync();
   }
   lds_exit(M, B, e);
-  // what this environment cost: the next launch starts the expensive ones first (mjh_k_balance)
+  // what this environment cost (tools/tail_stats.py)
   if (wv_lane() == 0) MJH_G(B, cost, e)[0] = (int)((wv_clock() - c_begin) >> 4);
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {
@@ -738,8 +738,8 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     // bad qacc: the state was reset; the reference re-runs mj_forward before integrating
     // (engine_forward.c:1863-1870).  Rare, so the whole forward pass is redone right here.
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
-    if (M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
-    else if (M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
+    if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+    else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
     else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);

@@ -185,8 +185,37 @@
   X(eq_data, 11 * s.neq)                       \
   X(tendon_length0, s.ntendon)
 
+// ---- compile-time feature set of a kernel variant -------------------------------------------------
+// The stage sources are compiled several times (mjh_modes.h); each compilation defines MJH_FEATURES,
+// the set of optional model features its kernels carry.  A heavy branch is written
+// `if (MJH_HAS(MJH_FT_x) && <run-time condition>)`, so a lean variant does not pay -- in code size,
+// stack frame, registers -- for features its models never use.  DSizes::features is the set a model
+// NEEDS (mjh_model_build.h); the runtime only launches variants whose set covers it.
+enum {
+  MJH_FT_PRIMAL        = 1<<0,   // Newton / CG solvers
+  MJH_FT_ELLIPTIC      = 1<<1,   // elliptic friction cones
+  MJH_FT_EQUALITY      = 1<<2,   // equality constraints
+  MJH_FT_RK4           = 1<<3,
+  MJH_FT_IMPLICIT      = 1<<4,   // implicitfast integrator
+  MJH_FT_SENSOR        = 1<<5,
+  MJH_FT_COLCONVEX     = 1<<6,   // colliders beyond plane / sphere / capsule (box, cylinder, ...)
+  MJH_FT_CONDIM46      = 1<<7,   // torsional / rolling friction rows
+  MJH_FT_ACT           = 1<<8,   // stateful actuators (na > 0)
+  MJH_FT_TENDONSPATIAL = 1<<9,   // spatial tendons
+  MJH_FT_TRNMISC       = 1<<10,  // transmissions other than joint / jointinparent on slide or hinge joints
+  MJH_FT_PASSIVEMISC   = 1<<11,  // gravity compensation, fluid forces, surface velocities, polynomial springs / dampers
+  MJH_FT_MOCAP         = 1<<12,
+  MJH_FT_ISLANDS       = 1<<13,  // more than one kinematic tree (union-find; per-island solves)
+  MJH_FT_GAINBIAS      = 1<<14,  // affine gains / biases, force / act limits, joint actuator-force limits
+  MJH_FT_BIGMODEL      = 1<<15,  // nv > 32 or L'DL outside the register-resident fast path
+  MJH_FT_ALL           = 0x7fffffff,
+  MJH_FT_LEAN          = 0,
+};
+#define MJH_HAS(f) (((MJH_FEATURES) & (f)) != 0)
+
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int features;    // MJH_FT_* bits this model needs from a kernel variant
   int neq;         // equality constraints
   int nlevel;      // depth levels of the kinematic tree (world = level 0)
   int nvw;         // 32-bit words per dof-ancestor mask = (nv+31)/32
@@ -376,10 +405,8 @@ enum {
   X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(eq_efcadr, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)                                           \
-  /* load balancing of the wave-per-environment kernels: cost = wall-clock ticks env e took in   \
-     its last launch; perm = launch order (workgroup w steps env perm[w]), most expensive first */ \
-  X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
-  X(perm, 1, 0, MJH_T_GLB, MJH_T_GLB)
+  /* cost = wall-clock ticks (100 MHz >> 4) env e took in its last rollout launch (tail statistics) */ \
+  X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0
@@ -469,21 +496,24 @@ MJH_DEV SP<T> mjh_gp(T* g, int n, int soa, int e) {
   return soa ? SP<T>{g + e, soa} : SP<T>{g + (size_t)e * (size_t)n, 1};
 }
 template <class T>
-MJH_DEV SP<T> mjh_fp(T* g, int n, int l, int soa, int e) {
-  if (l >= 0) return SP<T>{(T*)(mjh_lds() + l), 1};
+MJH_DEV SP<T> mjh_fp(T* g, int n, int l, int soa, int e, char* lds) {
+  if (l >= 0) return SP<T>{(T*)(lds + l), 1};
   return mjh_gp(g, n, soa, e);
 }
+// the LDS block of the environment the calling lane works for: a workgroup (one wavefront) that
+// steps several environments (sub-wave modes of mjh_modes.h) owns wv_sub-many consecutive blocks
+#define MJH_LDS(B) (mjh_lds() + wv_sub()*(B).lds_bytes)
 // env e's slice of field f (LDS if the plan placed it there, else its global home)
-#define MJH_F(B, f, e) mjh_fp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e))
+#define MJH_F(B, f, e) mjh_fp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e), MJH_LDS(B))
 // global home of env e's slice, whatever the plan says
 #define MJH_G(B, f, e) mjh_gp((B).f, (B).n_##f, (B).soa, (e))
 // record k (of `stride` elements) of a per-contact field: the first nconlds slots may live in LDS
 template <class T>
-MJH_DEV SP<T> mjh_cp(T* g, int n, int l, int soa, int e, int stride, int k, int nconlds) {
-  if (l >= 0 && k < nconlds) return SP<T>{(T*)(mjh_lds() + l) + stride*k, 1};
+MJH_DEV SP<T> mjh_cp(T* g, int n, int l, int soa, int e, int stride, int k, int nconlds, char* lds) {
+  if (l >= 0 && k < nconlds) return SP<T>{(T*)(lds + l) + stride*k, 1};
   return mjh_gp(g, n, soa, e) + stride*k;
 }
-#define MJH_CON(B, f, e, stride, k) mjh_cp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e), (stride), (k), (B).nconlds)
+#define MJH_CON(B, f, e, stride, k) mjh_cp((B).f, (B).n_##f, (B).l_##f, (B).soa, (e), (stride), (k), (B).nconlds, MJH_LDS(B))
 
 // constraint / contact enums used on device (include/mujoco/mjtype.h)
 enum {

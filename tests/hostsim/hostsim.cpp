@@ -100,17 +100,31 @@ struct Backend {
   static int max_lds() { return 64 * 1024; }
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
-  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, void*) {
-    for (int e = 0; e < nenv; e++) {
-      poison_lds(lds);
-      if (soa) runner()->run(e, [&]() { ws::forward_or_euler(*M, *B, wv_env(), stages); });
-      else runner()->run(e, [&]() { wv::forward_or_euler(*M, *B, wv_env(), stages); });
+  // run NS's body for the nsub environments of every emulated wavefront (lanes of group g step
+  // environment wave*nsub + g; a group past the end of the batch exits at once, like the kernels)
+  template <class F>
+  static void run_waves(int nenv, int nsub, int lds, F body) {
+    for (int w = (nenv + nsub - 1)/nsub - 1; w >= 0; w--) {     // (back to front: order must not matter)
+      poison_lds(lds*nsub);
+      runner()->run(w, [&]() {
+        const int e = wv_env()*nsub + mjhsim::lane()/(MJH_WAVE/nsub);
+        if (e < nenv) body(e);
+      });
     }
+  }
+  static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void*) {
+    if (soa) run_waves(nenv, 1, lds, [&](int e) { ws::forward_or_euler(*M, *B, e, stages); });
+    else if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int e) { wl::forward_or_euler(*M, *B, e, stages); });
+    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int e) { w2::forward_or_euler(*M, *B, e, stages); });
+    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int e) { w4::forward_or_euler(*M, *B, e, stages); });
+    else run_waves(nenv, 1, lds, [&](int e) { wv::forward_or_euler(*M, *B, e, stages); });
     return true;
   }
-  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, void*) {
-    // (launch order: the emulation runs the permutation back to front to show results do not depend on it)
-    for (int w = nenv - 1; w >= 0; w--) { poison_lds(lds); runner()->run(B->perm[w], [&]() { wv::rollout_env(*M, *B, wv_env(), A); }); }
+  static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void*) {
+    if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int e) { wl::rollout_env(*M, *B, e, A); });
+    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int e) { w2::rollout_env(*M, *B, e, A); });
+    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int e) { w4::rollout_env(*M, *B, e, A); });
+    else run_waves(nenv, 1, lds, [&](int e) { wv::rollout_env(*M, *B, e, A); });
     return true;
   }
   // lane mode needs no wavefront emulation: every environment is an ordinary serial call

@@ -548,3 +548,33 @@ def test_closed_loop_step_matches_rollout(hip_lib, dm, golden):
         b.step(1)
     assert np.array_equal(b.get("qpos"), ref[:, 2, 1:29])
     assert np.array_equal(b.get("qvel"), ref[:, 2, 29:])
+
+
+@pytest.mark.parametrize("variant", ["generic", "lean", "lean2", "lean4"])
+def test_kernel_variants_field_parity(rb, hip_lib, dm, variant):
+    """every mapping of the stage sources (1 / 2 / 4 environments per wavefront, generic or lean
+    feature set: mjh_modes.h) against the live oracle, field by field, on contact-rich states whose
+    constraint counts differ between the environments that share a wavefront"""
+    m = humanoid_pgs_oracle(rb)
+    states = contact_rich_states(rb, m, 35, seed=23)       # odd count: the last wavefront is partly empty
+    b = K.Batch(dm, len(states))
+    b.set_variant(variant)
+    assert b.kernel_variant() == variant
+    worst = check_forward(rb, m, b, states, tol=TOL)
+    worst_lds = check_forward(rb, m, b, states, tol=TOL, lds=True)
+    print(variant, "forward worst rel err", worst, "on the LDS plan", worst_lds)
+
+
+def test_kernel_variants_bit_identical_rollouts(hip_lib, dm, golden):
+    """the variants are the same arithmetic in a different lane mapping: identical bits, 120 steps"""
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], fx["ctrl"].shape[1]
+    outs = {}
+    for variant in ["generic", "lean", "lean2", "lean4"]:
+        b = K.Batch(dm, n)
+        b.set_variant(variant)
+        outs[variant] = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"])
+        assert b.get("warning").sum() == 0
+    for variant in ["lean", "lean2", "lean4"]:
+        assert np.array_equal(outs[variant], outs["generic"]), variant
+    assert relerr(outs["lean2"][:, :10], fx["state"][:, :10]) <= TOL

@@ -864,3 +864,42 @@ def test_deep_chain_generic_paths_bit_exact(rb, hostsim_lib, tmp_path):
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("variant", ["generic", "lean", "lean2", "lean4"])
+def test_kernel_variants_bit_exact(rb, hostsim_lib, golden, variant):
+    """every lane mapping of the stage sources (mjh_modes.h: 1 / 2 / 4 environments per wavefront,
+    generic or lean feature set) reproduces the oracle bit for bit: forward fields on contact-rich
+    states (odd environment count: a partly empty wavefront), then the golden trajectories"""
+    from conftest import contact_rich_states, humanoid_pgs_oracle
+    from parity_utils import check_forward
+    m = humanoid_pgs_oracle(rb)
+    mm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "humanoid.mjb"))
+    mm.set_option("solver", 0)
+    dm = K.DeviceModel(hostsim_lib, mm)
+    assert dm.size("features") == 0          # humanoid needs nothing beyond the lean feature set
+    states = contact_rich_states(rb, m, 7, seed=23)
+    b = K.Batch(dm, len(states))
+    b.set_variant(variant)
+    assert b.kernel_variant() == variant
+    check_forward(rb, m, b, states, tol=0)
+    check_forward(rb, m, b, states, tol=0, lds=True)
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 40
+    b2 = K.Batch(dm, n)
+    b2.set_variant(variant)
+    out = b2.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    assert np.array_equal(out, fx["state"][:, :T])
+
+
+def test_lean_variants_refuse_models_they_cannot_step(rb, hostsim_lib, tmp_path):
+    """a model that needs a feature outside the lean set keeps the generic kernels"""
+    xml = tmp_path / "box.xml"
+    xml.write_text(BOX_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    assert dm.size("features") != 0
+    b = K.Batch(dm, 2)
+    assert b.kernel_variant() == "generic"
+    with pytest.raises(K.MjhipError):
+        b.set_variant("lean2")
