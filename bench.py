@@ -137,12 +137,16 @@ def measured_traffic(steps_per_launch: int, nenv: int):
     return best
 
 
-def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, gpu_counts, envs):
+def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once):
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
-    (warm-up + timed).  The oracle is stepped from s0 with its own warm start; after every step its
-    state is compared with the GPU's and then re-synchronised to it, so the figure is the per-step
-    error of every step of the timed workload, not a chaotic accumulation."""
+    (warm-up + timed).
+      (1) every step of the run: the oracle is stepped from s0 with its own warm start; after every
+          step its state is compared with the GPU's and then re-synchronised to it, so the figure is
+          the per-step error of every step of the timed workload, not a chaotic accumulation;
+      (2) integer observables from IDENTICAL inputs: one more step from the run's final states with
+          the oracle's warm start handed to the GPU (`step_once`), where contact count, constraint
+          count and solver iteration count must agree exactly."""
     try:
         from oracle import refbind as rb
         if not rb.available():
@@ -154,8 +158,8 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, gpu_count
     m.opt.integrator = integrator
     spec = rb.mjSTATE_FULLPHYSICS
     worst, worst_at = 0.0, None
-    counts_ok, nbad = True, 0
     T = ctrl.shape[1]
+    datas = []
     for k, e in enumerate(envs):
         d = rb.MjData(m)
         rb.mj_setState(m, d, s0[k], spec)
@@ -169,18 +173,29 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, gpu_count
                 err = float("inf")
             if err > worst:
                 worst, worst_at = err, (int(e), t)
-            if t < T - 1:
-                rb.mj_setState(m, d, got, spec)
-        c = gpu_counts[k]
+            rb.mj_setState(m, d, got, spec)
+        datas.append(d)
+    # (2) one step from identical (state, warm start, control)
+    rng = np.random.Generator(np.random.PCG64(99))
+    ws = np.stack([np.array(d.qacc_warmstart) for d in datas])
+    u = rng.uniform(-1.0, 1.0, size=(len(envs), 1, ctrl.shape[2]))
+    got, counts = step_once(gpu_state[:, -1], ws, u)
+    nbad, worst1 = 0, 0.0
+    for k, d in enumerate(datas):
+        d.ctrl[:] = u[k, 0]
+        rb.mj_step(m, d)
+        ref = rb.mj_getState(m, d, spec)
+        worst1 = max(worst1, float(np.max(np.abs(got[k] - ref) / np.maximum(1.0, np.abs(ref)))))
+        c = counts[k]
         if (int(c[0]), int(c[1]), int(c[5])) != (int(d.ncon), int(d.nefc), int(d.solver_niter[0])):
-            counts_ok = False
             nbad += 1
     return {"envs": len(envs), "steps_checked": T, "max_rel_err": worst, "worst_env_step": worst_at,
-            "tolerance": 1e-6, "counts_exact_last_step": counts_ok, "count_mismatches": nbad,
-            "ok": bool(worst <= 1e-6 and counts_ok),
+            "tolerance": 1e-6, "identical_input_step": {"max_rel_err": worst1, "count_mismatches": nbad,
+                                                         "checked": "ncon, nefc, solver_niter exact"},
+            "ok": bool(worst <= 1e-6 and worst1 <= 1e-6 and nbad == 0),
             "protocol": "oracle/_ref mj_step from the same state0/controls, compared after every step of "
-                        "warm-up + timed region and re-synchronised to the GPU state (own warm start kept); "
-                        "ncon/nefc/solver_niter of the last step exact"}
+                        "warm-up + timed region and re-synchronised to the GPU state; then one step from "
+                        "identical (state, warm start, control) with exact integer observables"}
 
 
 def main() -> None:
@@ -383,8 +398,13 @@ def main() -> None:
         idx = torch.from_numpy(envs).to(dev)
         gs = torch.cat([x.index_select(0, idx) for x in state_w + state_k], dim=1).cpu().numpy()
         cs = torch.cat([x.index_select(0, idx) for x in ctrl_w + ctrl_k], dim=1).cpu().numpy()
+        def step_once(states, warm, u):
+            small = ma.Batch(dm, len(envs), device=local_rank)
+            out = small.rollout_host(1, ma.mjSTATE_CTRL, states, warm, u)[:, 0]
+            return out, small.get("counts")
+
         try:
-            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, counts[envs], envs)
+            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once)
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
             res["parity_sample"] = {"ok": False, "error": repr(exc)}
     del state_w, state_k, ctrl_w, ctrl_k

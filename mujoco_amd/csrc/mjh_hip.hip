@@ -28,6 +28,29 @@ extern "C" bool mjh_launch_integrate(const DModel* M, const DBatch* B, int nenv,
 extern "C" bool mjh_launch_lane_forward(const DModel* M, const DBatch* B, int nenv, int epw, int stages, void* stream);
 extern "C" bool mjh_launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int epw, void* stream);
 
+// Launch order of the next rollout launch: counting sort of the environments by the work estimate
+// of the last one (256 buckets, one workgroup), most expensive first.
+__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B) {
+  __shared__ int hist[256];
+  __shared__ int maxc;
+  const int n = B->nenv, tid = (int)threadIdx.x;
+  const int* cost = B->cost;
+  int* perm = B->perm;
+  if (tid < 256) hist[tid] = 0;
+  if (tid == 0) maxc = 1;
+  __syncthreads();
+  int m = 1;
+  for (int e = tid; e < n; e += 1024) m = max(m, cost[e]);
+  atomicMax(&maxc, m);
+  __syncthreads();
+  const float scale = 255.0f / (float)maxc;
+  for (int e = tid; e < n; e += 1024) atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
+  __syncthreads();
+  if (tid == 0) { int acc = 0; for (int b = 0; b < 256; b++) { int c = hist[b]; hist[b] = acc; acc += c; } }
+  __syncthreads();
+  for (int e = tid; e < n; e += 1024) perm[atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1)] = e;
+}
+
 __global__ __launch_bounds__(MJH_WAVE) void mjh_k_reset(const DModel* __restrict__ M, const DBatch* __restrict__ B) {
   wv::reset_env(wv_const_ref(M), wv_const_ref(B), (int)blockIdx.x);
 }
@@ -81,6 +104,11 @@ struct Backend {
       case MJH_VAR_LEAN4: return mjh_launch_rollout_w4(M, B, nenv, &A, lds, stream);
       default: return mjh_launch_rollout_wv(M, B, nenv, &A, lds, stream);
     }
+  }
+  static bool launch_balance(const DBatch* B, int nenv, void* stream) {
+    (void)nenv;
+    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B);
+    return hipGetLastError() == hipSuccess;
   }
   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {
     return mjh_launch_smooth(M, B, nenv, epw, &A, stream);

@@ -25,9 +25,12 @@
   }                                                                                                            \
   __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
   void mjh_k_rollout_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {         \
-    const int e = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
-    if (e >= B->nenv) return;                                                                                  \
-    NS::rollout_env(wv_const_ref(M), wv_const_ref(B), e, A);                                                   \
+    const int w = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
+    if (w >= B->nenv) return;                                                                                  \
+    /* perm lists the environments by decreasing cost: workgroups are dispatched in blockIdx order  */        \
+    /* round-robin over the XCDs / CUs, so every SIMD receives a mix of cheap and expensive ones,   */        \
+    /* and the environments that share a wavefront (NSUB > 1) have similar solver work              */        \
+    NS::rollout_env(wv_const_ref(M), wv_const_ref(B), B->perm[w], A);                                          \
   }                                                                                                            \
   extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
                                           void* stream) {                                                      \

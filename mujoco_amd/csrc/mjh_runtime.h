@@ -76,6 +76,7 @@ struct mjhipBatch_ {
   int epw = 64;                // environments per wavefront of the lane-mode kernels (<= 64)
   int variant = MJH_VAR_GENERIC;   // kernel mapping (MJH_VAR_*, mjh_modes.h) that steps this batch
   int lds_request = 0;             // LDS budget per environment last asked for (before clamping)
+  bool balance = true;             // order the next rollout launch by the work estimate of the last
   void* arena = nullptr;
   size_t arena_bytes = 0;
   std::map<std::string, FieldInfo> fields;
@@ -357,7 +358,15 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
     mjhip_batch_destroy(Bt);
     return nullptr;
   }
-  if (!Backend::sync(nullptr)) { set_err("mjhip: batch initialisation failed"); mjhip_batch_destroy(Bt); return nullptr; }
+  {
+    std::vector<int> ident((size_t)Bt->nenvpad);
+    for (size_t i = 0; i < ident.size(); i++) ident[i] = (int)i;
+    if (!Backend::h2d(Bt->D.perm, ident.data(), ident.size()*sizeof(int), nullptr) || !Backend::sync(nullptr)) {
+      set_err("mjhip: batch initialisation failed"); mjhip_batch_destroy(Bt); return nullptr;
+    }
+  }
+  // launch balancing ($MJHIP_BALANCE=0 keeps the identity order; measured in profiles/r02_balance)
+  if (const char* ev = getenv("MJHIP_BALANCE")) Bt->balance = atoi(ev) != 0;
   // kernel variant: the leanest mapping whose feature set covers the model ($MJHIP_VARIANT overrides)
   Bt->variant = default_variant(M, Bt->soa);
   // ($MJHIP_VARIANT is a preference: batches it cannot serve -- SoA layout, models that need
@@ -396,9 +405,10 @@ static bool variant_ok(const mjhipModel_* M, int soa, int variant, std::string* 
   return true;
 }
 static int default_variant(const mjhipModel_* M, int soa) {
-  // two environments per wavefront when the model's dofs fit a 32-lane group (register-resident
-  // L'DL / PGS layouts), else one
-  if (variant_ok(M, soa, MJH_VAR_LEAN2, nullptr) && M->H.s.nv <= 32 && M->H.s.ld_fast) return MJH_VAR_LEAN2;
+  // one environment per wavefront: measured fastest at the batch sizes of interest (4096 envs on
+  // 1024 SIMDs: profiles/r02_variants -- with every environment resident the step is bound by the
+  // dependent chain of one environment, and the two / four environments of a shared wavefront run
+  // their solver loops to the longer of their iteration counts); lean2 / lean4 stay selectable
   if (variant_ok(M, soa, MJH_VAR_LEAN, nullptr)) return MJH_VAR_LEAN;
   return MJH_VAR_GENERIC;
 }
@@ -599,6 +609,7 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
     for (int t = 0; t < nstep && ok; t++) { A.t0 = t; ok = pipeline_step(Bt, A, stream); }
   } else {
     ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
+    if (ok && Bt->balance) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
   }
   if (!ok) { set_err("mjhip_batch_step: kernel launch failed"); return -2; }
   return 0;
@@ -696,6 +707,7 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned co
     }
   } else {
     launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
+    if (launched && Bt->balance) launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
   }
   if (!launched) { cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
   if (!on_device) {

@@ -307,9 +307,15 @@ MJH_DEV double wv_row_shl(double v) {
 // value held by lane K of the caller's 16-lane DPP row (v_mov_b32_dpp row_newbcast:K, no LDS)
 template <int K>
 MJH_DEV double wv_row_bcast(double v) {
+#ifdef MJH_DPP32
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+#else
   // one v_mov_b64_dpp: gfx90a+ has the 64-bit DPP move for exactly this control (row_newbcast);
   // every lane of a row broadcast is written, so the "old" operand is never observed
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);
+#endif
 }
 // v is uniform inside each 16-lane row (value r_c in row c): every lane gets (r0 + r2) + (r1 + r3),
 // mju_dot's final association of its four partial sums.  gfx950's v_permlane32_swap exchanges the

@@ -647,6 +647,7 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
 #ifdef MJH_PROFILE
   const long long c_start = wv_clock();
 #endif
+  int work = 0;
   for (int t = 0; t < A.nstep; t++) {
     // any warning freezes the trajectory: back-fill the rest with the current state (:135-155)
     int nw = 0;
@@ -662,6 +663,8 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
         wv_sync();
       }
       step_env(M, B, e);
+      ciptr cnt = MJH_F(B, counts, e);
+      work += 64 + cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4);
     }
     if (A.state) get_state(M, B, e, A.state + step*s.nstate);
     if (A.sensordata) {
@@ -671,8 +674,12 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     wv_sync();
   }
   lds_exit(M, B, e);
-  // what this environment cost (tools/tail_stats.py)
-  if (wv_lane() == 0) MJH_G(B, cost, e)[0] = (int)((wv_clock() - c_begin) >> 4);
+  // what this environment cost: the next launch deals the environments to the SIMDs by it
+  // (mjh_k_balance); wall time of the wavefront for the tail statistics (tools/tail_stats.py)
+  if (wv_lane() == 0) {
+    MJH_G(B, cost, e)[0] = work;
+    MJH_G(B, wall, e)[0] = (int)((wv_clock() - c_begin) >> 4);
+  }
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {
     rptr pr = MJH_G(B, prof, e);

@@ -405,8 +405,13 @@ enum {
   X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(eq_efcadr, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(active, 1, 0, MJH_T_GLB, MJH_T_GLB)                                           \
-  /* cost = wall-clock ticks (100 MHz >> 4) env e took in its last rollout launch (tail statistics) */ \
-  X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)
+  /* launch balancing of the rollout kernels: cost = work estimate of env e over its last launch   \
+     (sum over steps of 64 + nefc*(solver iterations + 4)); perm = launch order of the next launch, \
+     most expensive first (workgroup w steps envs perm[w*nsub .. w*nsub+nsub)); wall = wall-clock \
+     ticks (100 MHz >> 4) of the env's wavefront in its last launch (tail statistics) */          \
+  X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
+  X(perm, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
+  X(wall, 1, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0

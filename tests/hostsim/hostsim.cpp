@@ -12,6 +12,8 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 #include "../../mujoco_amd/csrc/mjh_spmd.h"
 
@@ -121,10 +123,19 @@ struct Backend {
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void*) {
-    if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int e) { wl::rollout_env(*M, *B, e, A); });
-    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int e) { w2::rollout_env(*M, *B, e, A); });
-    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int e) { w4::rollout_env(*M, *B, e, A); });
-    else run_waves(nenv, 1, lds, [&](int e) { wv::rollout_env(*M, *B, e, A); });
+    // (slot w of the launch steps environment perm[w], like the kernels)
+    if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int w) { wl::rollout_env(*M, *B, B->perm[w], A); });
+    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int w) { w2::rollout_env(*M, *B, B->perm[w], A); });
+    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int w) { w4::rollout_env(*M, *B, B->perm[w], A); });
+    else run_waves(nenv, 1, lds, [&](int w) { wv::rollout_env(*M, *B, B->perm[w], A); });
+    return true;
+  }
+  // the launch order of the next rollout launch: environments by decreasing work estimate
+  static bool launch_balance(const DBatch* B, int nenv, void*) {
+    std::vector<int> idx(nenv);
+    for (int i = 0; i < nenv; i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return B->cost[a] > B->cost[b]; });
+    for (int i = 0; i < nenv; i++) B->perm[i] = idx[i];
     return true;
   }
   // lane mode needs no wavefront emulation: every environment is an ordinary serial call

@@ -17,7 +17,7 @@ model.set_option("solver", 0)
 dm = ma.DeviceModel(lib, model)
 nenv = int(os.environ.get("NENV", 4096)); K = 100; W = 50
 b = ma.Batch(dm, nenv)
-print(b.lds_report().splitlines()[0])
+print("variant", b.kernel_variant(), "|", b.lds_report().splitlines()[0])
 s0 = initial_states(b.get("qpos")[0], dm.nv, nenv, 1234)
 rng = np.random.Generator(np.random.PCG64(4321))
 dev = torch.device("cuda", 0)
@@ -32,7 +32,7 @@ import time
 t0 = time.perf_counter()
 for c in range(0, K, 10):
     if c == K - 10:
-        b.sync(); cost_pred = b.get("cost")[:, 0].copy(); perm_used = b.get("perm")[:, 0].copy()
+        b.sync(); cost_pred = b.get("cost")[:, 0].copy()
     b.rollout_device(10, ma.mjSTATE_CTRL, 0, 0, ck[:, c:c+10].contiguous().data_ptr(), 0, 0, cont=True)
 b.sync()
 el = time.perf_counter() - t0
@@ -83,8 +83,3 @@ print("mean duration of the first 2048 starters %.0f us, of the rest %.0f us" % 
 
 cost_now = b.get("cost")[:, 0]
 print("cost prediction: corr(prev launch cost, this launch cost) = %.3f" % np.corrcoef(cost_pred, cost_now)[0,1])
-pos = np.empty(nenv, int); pos[perm_used] = np.arange(nenv)
-heavy = np.argsort(-cost_now)[:10]
-print("launch position (0 = first) of this launch's 10 heaviest envs:", pos[heavy].tolist())
-print("start time (us) of those:", [int(st[e]-t0_) for e in heavy])
-print("start time quantiles by launch position decile:", [int(np.median(st[perm_used[i*410:(i+1)*410]]-t0_)) for i in range(10)])
