@@ -133,7 +133,10 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* batch, int nstep, void* hip_stream);
  *   warmstart0  [nenv][nv]                or NULL (zeros)
  *   control     [nenv][nstep][ncontrol]   or NULL; ncontrol = mj_stateSize(control_spec)
  *   state       [nenv][nstep][nstate]     output, or NULL
- * control_spec: mjtState bits; supported: mjSTATE_CTRL | mjSTATE_QFRC_APPLIED.
+ * control_spec: any mjSTATE_USER bits (mjtState, include/mujoco/mjtype.h:504-527): ctrl, qfrc_applied,
+ * xfrc_applied, eq_active, mocap_pos, mocap_quat, userdata, laid out in bit order like mj_setState
+ * (engine_support.c:282).  Inputs outside the spec are cleared / reset at the start of a rollout
+ * (rollout.cc:85-115); inputs inside it keep their current values when control is NULL.
  * on_device: bit flags.  MJHIP_ROLLOUT_ON_DEVICE: the four pointers are DEVICE pointers (no PCIe
  * traffic in the call).  MJHIP_ROLLOUT_CONTINUE: keep the batch's current state, warm start and
  * warning counters instead of loading state0 / warmstart0 (chunked rollouts). */
@@ -150,17 +153,34 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* batch, int nstep, unsigned
                                           const double* control, double* state, double* sensordata,
                                           int on_device, void* hip_stream);
 MJHIP_API int mjhip_batch_sync(mjhipBatch* batch, void* hip_stream);
+/* Sum, over environments [0, n) (n <= 0: all), of the warning counters that mean "this trajectory is
+ * not what the reference would have computed": contact / constraint capacity overflow (the
+ * reference's arena grows on demand) and geom pairs without a GPU collider (mjhip's warning slot 7).
+ * Such environments are frozen like after any warning; this makes it visible.  0 on success. */
+MJHIP_API int mjhip_batch_trouble(mjhipBatch* batch, int n, int* ncapacity, int* nunsupported);
 
 /* ---- the drop-in ------------------------------------------------------------------------------
- * Same arguments and semantics as the reference's _unsafe_rollout / Rollout::rollout
- * (python/mujoco/rollout.cc:74, :250): nbatch rollouts of nstep steps, HOST pointers, models in
- * m[0..nbatch) must be the same model (checked by size+content signature), d[0] receives the final
- * state of the last rollout (time, qpos, qvel, act, ctrl, qacc_warmstart, warning counters).
- * Device model + batch are cached inside the library keyed by the model. */
+ * Same arguments and semantics as the reference's _unsafe_rollout / _unsafe_rollout_threaded /
+ * Rollout::rollout (python/mujoco/rollout.cc:74, :181, :250): nbatch rollouts of nstep steps, HOST
+ * pointers.  m[r] may differ per rollout as long as the sizes agree (rollout.cc:100-118;
+ * rollout_test.py:363): rollouts are grouped by model (pointer, then content) and every group is
+ * one device batch.  d[0] receives the last step of the LAST rollout (rollout.cc:73): time, qpos,
+ * qvel, act, the user inputs, qacc_warmstart, qacc, sensordata, warning counters; with control ==
+ * NULL the inputs named by control_spec are TAKEN from d[0] (the reference steps with whatever its
+ * mjData holds).  The work is sharded over all visible GPUs ($MJHIP_DEVICES caps the count), one
+ * host thread per GPU writing disjoint rows of the caller's arrays; device models and batches are
+ * cached per GPU keyed by model content ($MJHIP_CACHE_MODELS entries, default 4), staging buffers
+ * are pooled.  Returns 0 on success, <0 on failure, and -- with complete outputs -- 1 if some
+ * environment overflowed the contact / constraint capacity ($MJHIP_NCONMAX / $MJHIP_NEFCMAX raise
+ * it), 2 if one reached a geom pair that has no GPU collider: such environments were frozen and
+ * back-filled where the reference would have kept simulating (message in mjhip_last_error). */
 MJHIP_API int mjhip_rollout(const struct mjModel_* const* m, struct mjData_* const* d, int nbatch,
                             int nstep, unsigned control_spec, const double* state0,
                             const double* warmstart0, const double* control, double* state,
                             double* sensordata);
+
+/* drop every cached device model / batch of mjhip_rollout (all GPUs) */
+MJHIP_API void mjhip_rollout_clear_cache(void);
 
 #ifdef __cplusplus
 }

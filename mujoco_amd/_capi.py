@@ -108,6 +108,9 @@ class Lib:
         lib.mjhip_batch_rollout_sensors.argtypes = [vp, ci, cu, dp, dp, dp, dp, dp, ci, vp]
         lib.mjhip_batch_sync.restype = ci
         lib.mjhip_batch_sync.argtypes = [vp, vp]
+        lib.mjhip_batch_trouble.restype = ci
+        lib.mjhip_batch_trouble.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+        lib.mjhip_rollout_clear_cache.restype = None
         lib.mjhip_rollout.restype = ci
         lib.mjhip_rollout.argtypes = [vp, vp, ci, ci, cu, dp, dp, dp, dp, dp]
         self.c = lib
@@ -120,6 +123,7 @@ class Lib:
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
+        "mjhip_batch_trouble", "mjhip_rollout_clear_cache",
     )
 
     def backend(self) -> str:
@@ -242,6 +246,13 @@ class Batch:
             a = np.ascontiguousarray(np.broadcast_to(a.reshape((-1, n)), (self.nenv, n)))
         if n:
             self._lib.check(self._lib.c.mjhip_batch_set(self._h, name.encode(), a.ctypes.data), f"set {name}")
+
+    def trouble(self):
+        """(capacity overflows, unsupported-collider hits) summed over the batch's warning counters:
+        non-zero means some environment was frozen where the reference would have kept simulating"""
+        a, b = C.c_int(), C.c_int()
+        self._lib.check(self._lib.c.mjhip_batch_trouble(self._h, 0, C.byref(a), C.byref(b)), "trouble")
+        return int(a.value), int(b.value)
 
     def reset(self) -> None:
         self._lib.check(self._lib.c.mjhip_batch_reset(self._h), "reset")

@@ -62,6 +62,11 @@ struct Backend {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
   }
+  static int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 0;
+    return d;
+  }
   static bool set_device(int dev, std::string* err) {
     hipError_t e = hipSetDevice(dev);
     if (e != hipSuccess) { *err = std::string("mjhip: hipSetDevice failed: ") + hipGetErrorString(e); return false; }

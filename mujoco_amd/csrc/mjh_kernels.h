@@ -26,11 +26,11 @@
   __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
   void mjh_k_rollout_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {         \
     const int w = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
-    if (w >= B->nenv) return;                                                                                  \
+    if (w >= (A.nlaunch ? A.nlaunch : B->nenv)) return;                                                        \
     /* perm lists the environments by decreasing cost: workgroups are dispatched in blockIdx order  */        \
     /* round-robin over the XCDs / CUs, so every SIMD receives a mix of cheap and expensive ones,   */        \
     /* and the environments that share a wavefront (NSUB > 1) have similar solver work              */        \
-    NS::rollout_env(wv_const_ref(M), wv_const_ref(B), B->perm[w], A);                                          \
+    NS::rollout_env(wv_const_ref(M), wv_const_ref(B), A.nlaunch ? w : B->perm[w], A);                          \
   }                                                                                                            \
   extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
                                           void* stream) {                                                      \

@@ -647,7 +647,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int nfric = 0;
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_frictionloss[i] > 0) nfric++;
-  s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 64));
+  s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 128));
   s.nconlds = std::min(s.nconmax, 8);
   // tree ids (constraint islands, engine_island.c)
   H->body_treeid.assign(m->body_treeid, m->body_treeid + m->nbody);
@@ -726,6 +726,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     rows_per_con = std::max(rows_per_con, c == 1 ? 1 : (m->opt.cone == mjCONE_PYRAMIDAL ? 2*(c-1) : c));
   // ---- sensors (engine_sensor.c): kinds translated to the device enum, frame objects to MJH_OBJ_*
   s.nmocap = m->nmocap;
+  s.nuserdata = m->nuserdata;
   s.nsensor = m->nsensor;
   s.nsensordata = m->nsensordata;
   s.nbody_sens = m->nsensor ? m->nbody : 0;
@@ -821,7 +822,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int k = 0; k < 3; k++) o.magnetic[k] = m->opt.magnetic[k];
   s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
-  s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 128));
+  s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 256));
 
   // ---------------- features this model needs from a kernel variant (MJH_FT_*, mjh_types.h) ------------
   // every `MJH_HAS(x) && condition` of the stage sources has its condition mirrored here

@@ -14,6 +14,8 @@
 //   static bool d2h(void* dst, const void* src, size_t bytes, void* stream);
 //   static bool zero(void* dst, size_t bytes, void* stream);
 //   static bool sync(void* stream);
+//   static int  current_device();
+//   static bool launch_balance(const DBatch* B, int nenv, void* stream);   // launch order of the next rollout launch
 //   (M, B below are DEVICE pointers to the descriptor structs)
 //   (lds = bytes of LDS per one-wavefront workgroup demanded by the batch descriptor's plan, 0 = none)
 //   (variant = MJH_VAR_* of mjh_modes.h: the kernel mapping that steps the batch; lds is per environment)
@@ -34,6 +36,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mjhip.h"
@@ -64,8 +67,12 @@ struct mjhipModel_ {
 
 struct FieldInfo { void* ptr; int count; int is_int; };
 
+struct mjhipStage_;
 struct mjhipBatch_ {
   mjhipModel_* model = nullptr;
+  int device = 0;              // the GPU that holds the arena; every entry point selects it
+  bool xfrc_on = false;        // xfrc_applied may be non-zero (mj_xfrcAccumulate runs)
+  mjhipStage_* stage = nullptr;   // pooled device staging of host-pointer rollouts
   DBatch D;                    // all-global descriptor (l_* = -1): inspection / debug kernels
   DBatch* D_dev = nullptr;
   DBatch L;                    // descriptor with the LDS residency plan (rollout / step kernels)
@@ -226,8 +233,12 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
     return nullptr;
   }
   mjhipModel_* M = new mjhipModel_();
+  M->device = Backend::current_device();
   std::string err;
   mjhb::BuildCaps caps;
+  // capacities: explicit arguments, else $MJHIP_NCONMAX / $MJHIP_NEFCMAX, else chosen from the model
+  if (nconmax <= 0) if (const char* ev = getenv("MJHIP_NCONMAX")) nconmax = atoi(ev);
+  if (nefcmax <= 0) if (const char* ev = getenv("MJHIP_NEFCMAX")) nefcmax = atoi(ev);
   caps.nconmax = nconmax; caps.nefcmax = nefcmax;
   if (!mjhb::build((const mjModel*)m, caps, &M->H, &err) || !mjhb::check_sizes(M->H, &err)) {
     set_err(err);
@@ -312,8 +323,14 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   if (!M || nenv <= 0) { set_err("mjhip_batch_create: bad arguments"); return nullptr; }
   std::string err;
   if (!Backend::set_device(device, &err)) { set_err(err); return nullptr; }
+  if (M->device != device) {
+    set_err("mjhip_batch_create: the model was uploaded to device " + std::to_string(M->device) + ", the batch is asked for device " +
+            std::to_string(device) + " (select the device before mjhip_model_create)");
+    return nullptr;
+  }
   mjhipBatch_* Bt = new mjhipBatch_();
   Bt->model = M;
+  Bt->device = device;
   Bt->nenv = nenv;
   Bt->nenvpad = (nenv + 63) & ~63;
   Bt->soa = (layout == MJHIP_LAYOUT_SOA) ? Bt->nenvpad : 0;
@@ -382,8 +399,13 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   return Bt;
 }
 
+struct StageBuf;
+static void stage_release(mjhipStage_* st);
 MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
   if (!Bt) return;
+  std::string err_;
+  Backend::set_device(Bt->device, &err_);
+  if (Bt->stage) stage_release(Bt->stage);
   if (Bt->arena) Backend::free(Bt->arena);
   if (Bt->D_dev) Backend::free(Bt->D_dev);
   if (Bt->L_dev) Backend::free(Bt->L_dev);
@@ -432,6 +454,7 @@ MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* Bt) { return Bt ? mj
 
 MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   if (lds_bytes < 0) lds_bytes = 0;
   Bt->lds_request = lds_bytes;
   const int max_lds = Backend::max_lds() / mjh_variant_nsub(Bt->variant);
@@ -466,6 +489,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_fluid) { eqskip.push_back("xipos"); eqskip.push_back("ximat"); }
+  if (Bt->xfrc_on) eqskip.push_back("xipos");                  // Cartesian forces act at the body COMs (stage_acceleration)
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS
     std::vector<std::string> skip = {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"};
@@ -476,6 +500,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
     // the single wave-per-environment kernel: the whole step
     plan_lds(Bt, lds_bytes, MJH_T_KIN, MJH_T_EULER, eqskip, {}, &Bt->plan_report);
   }
+  Bt->L.xfrc_on = Bt->xfrc_on ? 1 : 0;
   if (!Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) || !Backend::sync(nullptr)) {
     set_err("mjhip_batch_plan_lds: descriptor upload failed");
     return -2;
@@ -487,6 +512,7 @@ MJHIP_API const char* mjhip_batch_lds_report(const mjhipBatch* Bt) { return Bt ?
 
 MJHIP_API int mjhip_batch_reset(mjhipBatch* Bt) {
   if (!Bt) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   bool ok = Bt->soa ? Backend::launch_lane_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, Bt->epw, nullptr)
                     : Backend::launch_reset(Bt->model->D_dev, Bt->D_dev, Bt->nenv, nullptr);
   if (!ok || !Backend::sync(nullptr)) {
@@ -515,6 +541,7 @@ static size_t field_stride(const mjhipBatch_* Bt, const FieldInfo& f) {
 MJHIP_API int mjhip_batch_get(mjhipBatch* Bt, const char* name, void* host_dst) {
   void* p; int cnt, isint;
   if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   if (cnt == 0) return 0;
   const size_t esz = isint ? sizeof(int) : sizeof(real);
   if (!Bt->soa) {
@@ -535,9 +562,12 @@ MJHIP_API int mjhip_batch_get(mjhipBatch* Bt, const char* name, void* host_dst) 
   return 0;
 }
 
+static int enable_xfrc(mjhipBatch_* Bt);
 MJHIP_API int mjhip_batch_set(mjhipBatch* Bt, const char* name, const void* host_src) {
   void* p; int cnt, isint;
   if (mjhip_batch_field(Bt, name, &p, &cnt, &isint)) return -2;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
+  if (!strcmp(name, "xfrc_applied") && enable_xfrc(Bt)) return -3;
   if (cnt == 0) return 0;
   const size_t esz = isint ? sizeof(int) : sizeof(real);
   if (!Bt->soa) {
@@ -570,6 +600,7 @@ static bool pipeline_step(mjhipBatch_* Bt, const RolloutArgs& A, void* stream) {
 
 MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   if (!Bt) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   if (stages < 0) stages = MJH_STAGE_ALL;   // -1: mj_forward
   if ((stages & MJH_STAGE_ALL) == MJH_STAGE_ALL) stages |= MJH_STAGE_SENSOR;   // mj_forward evaluates the sensors
   // MJHIP_STAGE_LDS: run on the LDS residency plan and write every stage's fields back to their
@@ -598,11 +629,13 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
 
 MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   if (!Bt || nstep < 0) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   RolloutArgs A;
   memset(&A, 0, sizeof(A));
   A.nstep = nstep;
   A.has_ctrl = 1; A.has_qfrc = 1;    // keep the resident ctrl / qfrc_applied / mocap poses
   A.mpos_off = 0; A.mquat_off = 0;
+  A.xfrc_off = 0; A.eq_off = 0; A.ud_off = 0;
   A.init = 0;
   bool ok = true;
   if (Bt->soa) {
@@ -616,24 +649,63 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
 }
 
 // mjtState bits (include/mujoco/mjtype.h:504-527)
-// layout of one control vector = the mjtState bit order of mj_getState (engine_support.c:214)
-static int control_size(const DSizes& s, unsigned spec, int* qfrc_off, int* mpos_off, int* mquat_off,
-                        std::string* err) {
-  const unsigned supported = mjSTATE_CTRL | mjSTATE_QFRC_APPLIED | mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT;
-  if (spec & ~supported) {
-    *err = "mjhip: control_spec bits other than mjSTATE_CTRL | mjSTATE_QFRC_APPLIED | mjSTATE_MOCAP_POS | "
-           "mjSTATE_MOCAP_QUAT are not supported";
-    return -1;
+// layout of one control vector = the mjtState bit order of mj_getState (engine_support.c:214):
+// every mjSTATE_USER element can be driven (ctrl, qfrc_applied, xfrc_applied, eq_active, mocap_pos,
+// mocap_quat, userdata), exactly what _unsafe_rollout hands to mj_setState (rollout.cc:160)
+struct ControlLayout { int n, qfrc, xfrc, eq, mpos, mquat, ud; };
+static bool control_layout(const DSizes& s, unsigned spec, ControlLayout* L, std::string* err) {
+  const unsigned user = mjSTATE_CTRL | mjSTATE_QFRC_APPLIED | mjSTATE_XFRC_APPLIED | mjSTATE_EQ_ACTIVE |
+                        mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT | mjSTATE_USERDATA;
+  if (spec & ~user) {
+    *err = "mjhip: control_spec may only contain mjSTATE_USER bits (ctrl, qfrc_applied, xfrc_applied, eq_active, "
+           "mocap_pos, mocap_quat, userdata)";
+    return false;
   }
   int n = 0;
   if (spec & mjSTATE_CTRL) n += s.nu;
-  *qfrc_off = n;
+  L->qfrc = n;
   if (spec & mjSTATE_QFRC_APPLIED) n += s.nv;
-  *mpos_off = (spec & mjSTATE_MOCAP_POS) ? n : -1;
+  L->xfrc = (spec & mjSTATE_XFRC_APPLIED) ? n : -1;
+  if (spec & mjSTATE_XFRC_APPLIED) n += 6*s.nbody;
+  L->eq = (spec & mjSTATE_EQ_ACTIVE) ? n : -1;
+  if (spec & mjSTATE_EQ_ACTIVE) n += s.neq;
+  L->mpos = (spec & mjSTATE_MOCAP_POS) ? n : -1;
   if (spec & mjSTATE_MOCAP_POS) n += 3*s.nmocap;
-  *mquat_off = (spec & mjSTATE_MOCAP_QUAT) ? n : -1;
+  L->mquat = (spec & mjSTATE_MOCAP_QUAT) ? n : -1;
   if (spec & mjSTATE_MOCAP_QUAT) n += 4*s.nmocap;
-  return n;
+  L->ud = (spec & mjSTATE_USERDATA) ? n : -1;
+  if (spec & mjSTATE_USERDATA) n += s.nuserdata;
+  L->n = n;
+  return true;
+}
+
+// Cartesian forces become possible inputs: mj_xfrcAccumulate runs and the plan keeps xipos readable
+static int enable_xfrc(mjhipBatch_* Bt) {
+  if (Bt->xfrc_on) return 0;
+  Bt->xfrc_on = true;
+  Bt->D.xfrc_on = 1;
+  if (!Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr)) { set_err("mjhip: descriptor upload failed"); return -2; }
+  return mjhip_batch_plan_lds(Bt, Bt->lds_request) < 0 ? -2 : 0;
+}
+
+// grow-only device staging buffers of one batch: the rollout arrays of host-pointer calls
+struct StageBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    if (p) Backend::free(p);
+    cap = bytes + bytes/4;
+    p = Backend::alloc(cap);
+    if (!p) { cap = 0; return false; }
+    return true;
+  }
+  void release() { if (p) Backend::free(p); p = nullptr; cap = 0; }
+};
+struct mjhipStage_ { StageBuf state0, warm, control, state, sens; };
+static void stage_release(mjhipStage_* st) {
+  st->state0.release(); st->warm.release(); st->control.release(); st->state.release(); st->sens.release();
+  delete st;
 }
 
 MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned control_spec,
@@ -648,56 +720,58 @@ MJHIP_API int mjhip_batch_rollout(mjhipBatch* Bt, int nstep, unsigned control_sp
                                      on_device, stream);
 }
 
-MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned control_spec,
-                                          const double* state0, const double* warmstart0,
-                                          const double* control, double* state, double* sensordata,
-                                          int on_device, void* stream) {
-  if (!Bt || nstep < 0) { set_err("mjhip_batch_rollout: bad arguments"); return -1; }
+// nlaunch: environments [0, nlaunch) of the batch take part (0 = all of them)
+static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned control_spec,
+                        const double* state0, const double* warmstart0, const double* control,
+                        double* state, double* sensordata, int on_device, void* stream) {
+  if (!Bt || nstep < 0 || nlaunch < 0 || nlaunch > Bt->nenv) { set_err("mjhip_batch_rollout: bad arguments"); return -1; }
+  std::string err;
+  if (!Backend::set_device(Bt->device, &err)) { set_err(err); return -1; }
   if (sensordata && Bt->model->H.s.nsensordata == 0) sensordata = nullptr;
   if (sensordata && Bt->soa) { set_err("mjhip_batch_rollout: sensordata needs the AoS (wave-per-environment) layout"); return -2; }
+  if (nlaunch && nlaunch < Bt->nenv && Bt->soa) { set_err("mjhip_batch_rollout: partial launches need the AoS layout"); return -2; }
   const DSizes& s = Bt->model->H.s;
-  std::string err;
-  int qfrc_off = 0, mpos_off = -1, mquat_off = -1;
-  int ncontrol = control_size(s, control_spec, &qfrc_off, &mpos_off, &mquat_off, &err);
-  if (ncontrol < 0) { set_err(err); return -2; }
-  const size_t nenv = Bt->nenv;
+  ControlLayout CL;
+  if (!control_layout(s, control_spec, &CL, &err)) { set_err(err); return -2; }
+  if ((control_spec & mjSTATE_XFRC_APPLIED) && enable_xfrc(Bt)) return -2;
+  const size_t nenv = nlaunch ? (size_t)nlaunch : (size_t)Bt->nenv;
   RolloutArgs A;
   memset(&A, 0, sizeof(A));
   A.nstep = nstep;
   A.has_ctrl = (control_spec & mjSTATE_CTRL) ? 1 : 0;
   A.has_qfrc = (control_spec & mjSTATE_QFRC_APPLIED) ? 1 : 0;
-  A.ncontrol = ncontrol;
-  A.qfrc_off = qfrc_off;
-  A.mpos_off = mpos_off; A.mquat_off = mquat_off;
+  A.ncontrol = CL.n;
+  A.qfrc_off = CL.qfrc;
+  A.mpos_off = CL.mpos; A.mquat_off = CL.mquat;
+  A.xfrc_off = CL.xfrc; A.eq_off = CL.eq; A.ud_off = CL.ud;
+  A.nlaunch = (nlaunch && nlaunch < Bt->nenv) ? nlaunch : 0;
   A.init = (on_device & MJHIP_ROLLOUT_CONTINUE) ? 0 : 1;
   on_device &= MJHIP_ROLLOUT_ON_DEVICE;
-  std::vector<void*> tmp;
-  auto cleanup = [&]() { for (void* p : tmp) Backend::free(p); };
   if (on_device) {
     A.state0 = state0; A.warmstart0 = warmstart0; A.control = control; A.state = state;
     A.sensordata = sensordata;
   } else {
-    auto up = [&](const double* src, size_t n, const real** dst) -> bool {
+    // host pointers: pooled device staging (grow-only, owned by the batch), asynchronous copies
+    if (!Bt->stage) Bt->stage = new mjhipStage_();
+    auto up = [&](StageBuf& b, const double* src, size_t n, const real** dst) -> bool {
       if (!src || n == 0) { *dst = nullptr; return true; }
-      void* p = Backend::alloc(n*sizeof(real));
-      if (!p) return false;
-      tmp.push_back(p);
-      *dst = (const real*)p;
-      return Backend::h2d(p, src, n*sizeof(real), stream);
+      if (!b.ensure(n*sizeof(real))) return false;
+      *dst = (const real*)b.p;
+      return Backend::h2d(b.p, src, n*sizeof(real), stream);
     };
-    bool ok = up(state0, nenv*s.nstate, &A.state0) && up(warmstart0, nenv*s.nv, &A.warmstart0) &&
-              up(control, ncontrol ? nenv*(size_t)nstep*ncontrol : 0, &A.control);
+    bool ok = up(Bt->stage->state0, state0, nenv*s.nstate, &A.state0) &&
+              up(Bt->stage->warm, warmstart0, nenv*s.nv, &A.warmstart0) &&
+              up(Bt->stage->control, control, CL.n ? nenv*(size_t)nstep*CL.n : 0, &A.control);
     if (ok && state && nstep > 0) {
-      void* p = Backend::alloc(nenv*(size_t)nstep*s.nstate*sizeof(real));
-      if (!p) ok = false; else { tmp.push_back(p); A.state = (real*)p; }
+      ok = Bt->stage->state.ensure(nenv*(size_t)nstep*s.nstate*sizeof(real));
+      A.state = (real*)Bt->stage->state.p;
     }
     if (ok && sensordata && nstep > 0) {
-      void* p = Backend::alloc(nenv*(size_t)nstep*s.nsensordata*sizeof(real));
-      if (!p) ok = false; else { tmp.push_back(p); A.sensordata = (real*)p; }
+      ok = Bt->stage->sens.ensure(nenv*(size_t)nstep*s.nsensordata*sizeof(real));
+      A.sensordata = (real*)Bt->stage->sens.p;
     }
-    if (!ok) { cleanup(); set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
+    if (!ok) { set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
   }
-  if (!A.control) { /* no control array: inputs not in the spec stay zero, those in it keep current */ }
   bool launched = true;
   if (Bt->soa) {
     for (int t = 0; t < nstep && launched; t++) {
@@ -706,110 +780,323 @@ MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned co
       A.init = 0;
     }
   } else {
-    launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
-    if (launched && Bt->balance) launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
+    launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
+    // (a partial launch runs in identity order and leaves the launch order of full launches alone)
+    if (launched && Bt->balance && !A.nlaunch) launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
   }
-  if (!launched) { cleanup(); set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
+  if (!launched) { set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
   if (!on_device) {
     bool ok = true;
     if (state && nstep > 0) ok = Backend::d2h(state, A.state, nenv*(size_t)nstep*s.nstate*sizeof(real), stream);
     if (sensordata && nstep > 0)
       ok = Backend::d2h(sensordata, A.sensordata, nenv*(size_t)nstep*s.nsensordata*sizeof(real), stream) && ok;
     ok = Backend::sync(stream) && ok;
-    cleanup();
     if (!ok) { set_err("mjhip_batch_rollout: device->host copy failed"); return -5; }
   }
   return 0;
 }
 
+MJHIP_API int mjhip_batch_rollout_sensors(mjhipBatch* Bt, int nstep, unsigned control_spec,
+                                          const double* state0, const double* warmstart0,
+                                          const double* control, double* state, double* sensordata,
+                                          int on_device, void* stream) {
+  return rollout_impl(Bt, 0, nstep, control_spec, state0, warmstart0, control, state, sensordata, on_device, stream);
+}
+
 MJHIP_API int mjhip_batch_sync(mjhipBatch* Bt, void* stream) {
-  (void)Bt;
+  std::string err;
+  if (Bt && !Backend::set_device(Bt->device, &err)) { set_err(err); return -1; }
   if (!Backend::sync(stream)) { set_err("mjhip_batch_sync: failed"); return -1; }
   return 0;
 }
 
-// ---- the drop-in: _unsafe_rollout contract ------------------------------------------------------------
-struct RolloutCache {
-  std::mutex mu;
+// sum over environments [0, n) of the warning counters that mean "this trajectory is NOT what the
+// reference would have computed": capacity overflow (the reference's arena grows) and colliders
+// mjhip lacks.  Returns <0 on error.
+MJHIP_API int mjhip_batch_trouble(mjhipBatch* Bt, int n, int* ncapacity, int* nunsupported) {
+  if (!Bt) return -1;
+  if (n <= 0 || n > Bt->nenv) n = Bt->nenv;
+  std::vector<int> w((size_t)Bt->nenv*8);
+  if (mjhip_batch_get(Bt, "warning", w.data())) return -2;
+  int cap = 0, uns = 0;
+  for (int e = 0; e < n; e++) {
+    cap += w[(size_t)e*8 + MJH_WARN_CONTACTFULL] + w[(size_t)e*8 + MJH_WARN_CNSTRFULL];
+    uns += w[(size_t)e*8 + MJH_WARN_UNSUPPORTED];
+  }
+  if (ncapacity) *ncapacity = cap;
+  if (nunsupported) *nunsupported = uns;
+  return 0;
+}
+
+// ---- the drop-in: _unsafe_rollout / _unsafe_rollout_threaded contract ----------------------------------
+// nbatch rollouts, possibly of DIFFERENT models of equal sizes (rollout.cc:100-118 uses m[r]):
+//   * rollouts are grouped by model (pointer, then content); every group is a device batch;
+//   * groups are sharded over the visible GPUs ($MJHIP_DEVICES caps their number): one host thread
+//     and one cached (device model, batch) per GPU, each writing its own rows of the caller's
+//     output arrays -- no exchange between GPUs;
+//   * device models / batches are cached per GPU (a few most recently used models), staging
+//     buffers are pooled per batch.
+static_assert(mjNWARNING <= 8, "the batch keeps 8 warning counters per environment");
+
+struct RollEntry {
+  std::vector<char> sig;
   mjhipModel_* model = nullptr;
   mjhipBatch_* batch = nullptr;
+  unsigned long long stamp = 0;
 };
-static RolloutCache g_cache;
+struct RollDevice { std::vector<RollEntry> cache; };
+struct RollJob {
+  const mjModel* m = nullptr;
+  std::vector<int> rows;       // rollout indices, ascending
+  int device = 0;
+  int rc = 0;
+  int ncap = 0, nuns = 0;
+  std::string err;
+};
+static std::mutex g_roll_mu;
+static std::vector<RollDevice> g_roll_dev;
+static unsigned long long g_roll_stamp = 0;
+
+static bool same_model(const mjModel* a, const mjModel* b) {
+  return a == b || (a->nbuffer == b->nbuffer && !memcmp(&a->opt, &b->opt, sizeof(a->opt)) &&
+                    !memcmp(a->buffer, b->buffer, (size_t)a->nbuffer));
+}
+
+MJHIP_API void mjhip_rollout_clear_cache(void) {
+  std::lock_guard<std::mutex> lock(g_roll_mu);
+  std::string err;
+  for (size_t dv = 0; dv < g_roll_dev.size(); dv++) {
+    Backend::set_device((int)dv, &err);
+    for (auto& c : g_roll_dev[dv].cache) {
+      if (c.batch) mjhip_batch_destroy(c.batch);
+      if (c.model) mjhip_model_destroy(c.model);
+    }
+    g_roll_dev[dv].cache.clear();
+  }
+}
+
+// one job on its device (called from that device's host thread)
+static void roll_run_job(RollJob& J, struct mjData_* const* dp, int nbatch, int nstep, unsigned control_spec,
+                         const double* state0, const double* warmstart0, const double* control,
+                         double* state, double* sensordata) {
+  auto fail = [&](int rc, const std::string& msg) { J.rc = rc; J.err = msg; };
+  std::string err;
+  if (!Backend::set_device(J.device, &err)) return fail(-3, err);
+  RollDevice& RD = g_roll_dev[(size_t)J.device];
+  const mjModel* m = J.m;
+  const int n = (int)J.rows.size();
+  // cached (model, batch) of this GPU
+  RollEntry* E = nullptr;
+  const size_t sigsz = (size_t)m->nbuffer + sizeof(m->opt);
+  for (auto& c : RD.cache)
+    if (c.sig.size() == sigsz && !memcmp(c.sig.data(), m->buffer, (size_t)m->nbuffer) &&
+        !memcmp(c.sig.data() + m->nbuffer, &m->opt, sizeof(m->opt))) { E = &c; break; }
+  if (!E) {
+    size_t maxent = 4;
+    if (const char* ev = getenv("MJHIP_CACHE_MODELS")) maxent = (size_t)std::max(1, atoi(ev));
+    if (RD.cache.size() >= maxent) {
+      size_t old = 0;
+      for (size_t k = 1; k < RD.cache.size(); k++) if (RD.cache[k].stamp < RD.cache[old].stamp) old = k;
+      if (RD.cache[old].batch) mjhip_batch_destroy(RD.cache[old].batch);
+      if (RD.cache[old].model) mjhip_model_destroy(RD.cache[old].model);
+      RD.cache.erase(RD.cache.begin() + (long)old);
+    }
+    RollEntry ne;
+    ne.model = mjhip_model_create((const struct mjModel_*)m, 0, 0);
+    if (!ne.model) return fail(-3, g_mjhip_err);
+    ne.sig = ne.model->signature;
+    RD.cache.push_back(ne);
+    E = &RD.cache.back();
+  }
+  E->stamp = ++g_roll_stamp;
+  if (!E->batch || E->batch->nenv < n) {
+    if (E->batch) mjhip_batch_destroy(E->batch);
+    // the drop-in always uses the environment-major layout (sensordata, partial launches)
+    E->batch = mjhip_batch_create_layout(E->model, n, J.device, MJHIP_LAYOUT_AOS);
+    if (!E->batch) return fail(-4, g_mjhip_err);
+  }
+  mjhipBatch_* Bt = E->batch;
+  const DSizes& s = E->model->H.s;
+  ControlLayout CL;
+  if (!control_layout(s, control_spec, &CL, &err)) return fail(-2, err);
+  const size_t nstate = (size_t)s.nstate, nsens = (size_t)s.nsensordata, ncontrol = (size_t)CL.n;
+
+  // inputs of the control spec with no control array: the rollout steps with the caller's values
+  // (the reference only clears inputs that are NOT in the spec, rollout.cc:85-115)
+  mjData* d0 = (mjData*)dp[0];
+  if (!control && d0) {
+    auto seed = [&](const char* name, const mjtNum* src, int cnt) -> bool {
+      if (cnt <= 0 || !src) return true;
+      std::vector<real> rep((size_t)Bt->nenv*cnt);
+      for (int e = 0; e < Bt->nenv; e++) memcpy(rep.data() + (size_t)e*cnt, src, (size_t)cnt*sizeof(real));
+      return mjhip_batch_set(Bt, name, rep.data()) == 0;
+    };
+    bool ok = true;
+    if (control_spec & mjSTATE_CTRL) ok = ok && seed("ctrl", d0->ctrl, s.nu);
+    if (control_spec & mjSTATE_QFRC_APPLIED) ok = ok && seed("qfrc_applied", d0->qfrc_applied, s.nv);
+    if (control_spec & mjSTATE_XFRC_APPLIED) ok = ok && seed("xfrc_applied", d0->xfrc_applied, 6*s.nbody);
+    if (control_spec & mjSTATE_MOCAP_POS) ok = ok && seed("mocap_pos", d0->mocap_pos, 3*s.nmocap);
+    if (control_spec & mjSTATE_MOCAP_QUAT) ok = ok && seed("mocap_quat", d0->mocap_quat, 4*s.nmocap);
+    if (control_spec & mjSTATE_USERDATA) ok = ok && seed("userdata", d0->userdata, s.nuserdata);
+    if ((control_spec & mjSTATE_EQ_ACTIVE) && s.neq > 0) {
+      std::vector<int> rep((size_t)Bt->nenv*s.neq);
+      for (int e = 0; e < Bt->nenv; e++) for (int k = 0; k < s.neq; k++) rep[(size_t)e*s.neq + k] = d0->eq_active[k];
+      ok = ok && mjhip_batch_set(Bt, "eq_active", rep.data()) == 0;
+    }
+    if (!ok) return fail(-5, g_mjhip_err);
+  }
+
+  // rows of the caller's arrays: a contiguous block is copied in place, anything else is packed
+  bool contiguous = true;
+  for (int k = 1; k < n; k++) if (J.rows[k] != J.rows[0] + k) contiguous = false;
+  const size_t r0 = (size_t)J.rows[0];
+  std::vector<double> p_state0, p_warm, p_control, p_state, p_sens;
+  const double *in_state0 = state0 + r0*nstate, *in_warm = warmstart0 ? warmstart0 + r0*s.nv : nullptr;
+  const double* in_control = control ? control + r0*(size_t)nstep*ncontrol : nullptr;
+  double* out_state = state ? state + r0*(size_t)nstep*nstate : nullptr;
+  double* out_sens = (sensordata && nsens) ? sensordata + r0*(size_t)nstep*nsens : nullptr;
+  if (!contiguous) {
+    auto pack = [&](std::vector<double>& dst, const double* src, size_t width) -> const double* {
+      if (!src || !width) return nullptr;
+      dst.resize((size_t)n*width);
+      for (int k = 0; k < n; k++) memcpy(dst.data() + (size_t)k*width, src + (size_t)J.rows[k]*width, width*sizeof(double));
+      return dst.data();
+    };
+    in_state0 = pack(p_state0, state0, nstate);
+    in_warm = pack(p_warm, warmstart0, (size_t)s.nv);
+    in_control = pack(p_control, control, (size_t)nstep*ncontrol);
+    if (state) { p_state.resize((size_t)n*nstep*nstate); out_state = p_state.data(); }
+    if (sensordata && nsens) { p_sens.resize((size_t)n*nstep*nsens); out_sens = p_sens.data(); }
+  }
+  int rc = rollout_impl(Bt, n, nstep, control_spec, in_state0, in_warm, in_control, out_state, out_sens, 0, nullptr);
+  if (rc) return fail(rc, g_mjhip_err);
+  if (!contiguous) {
+    for (int k = 0; k < n; k++) {
+      if (state) memcpy(state + (size_t)J.rows[k]*nstep*nstate, p_state.data() + (size_t)k*nstep*nstate, (size_t)nstep*nstate*sizeof(double));
+      if (sensordata && nsens) memcpy(sensordata + (size_t)J.rows[k]*nstep*nsens, p_sens.data() + (size_t)k*nstep*nsens, (size_t)nstep*nsens*sizeof(double));
+    }
+  }
+  if (mjhip_batch_trouble(Bt, n, &J.ncap, &J.nuns)) return fail(-6, g_mjhip_err);
+
+  // d[0] <- last step of the LAST rollout (rollout.cc:73)
+  if (J.rows.back() == nbatch - 1 && d0) {
+    const int last = n - 1;
+    bool ok = true;
+    auto pull = [&](const char* name, void* dst, int cnt, size_t esz) {
+      if (cnt <= 0 || !dst) return;
+      void* p; int fc, isint;
+      if (mjhip_batch_field(Bt, name, &p, &fc, &isint) || fc < cnt) { ok = false; return; }
+      ok = Backend::d2h(dst, (const char*)p + (size_t)last*fc*esz, (size_t)cnt*esz, nullptr) && ok;
+    };
+    pull("time", &d0->time, 1, sizeof(real));
+    pull("qpos", d0->qpos, s.nq, sizeof(real));
+    pull("qvel", d0->qvel, s.nv, sizeof(real));
+    pull("act", d0->act, s.na, sizeof(real));
+    pull("ctrl", d0->ctrl, s.nu, sizeof(real));
+    pull("qfrc_applied", d0->qfrc_applied, s.nv, sizeof(real));
+    pull("xfrc_applied", d0->xfrc_applied, 6*s.nbody, sizeof(real));
+    pull("mocap_pos", d0->mocap_pos, 3*s.nmocap, sizeof(real));
+    pull("mocap_quat", d0->mocap_quat, 4*s.nmocap, sizeof(real));
+    pull("userdata", d0->userdata, s.nuserdata, sizeof(real));
+    pull("qacc_warmstart", d0->qacc_warmstart, s.nv, sizeof(real));
+    pull("qacc", d0->qacc, s.nv, sizeof(real));
+    pull("sensordata", d0->sensordata, s.nsensordata, sizeof(real));
+    int w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int> eqa((size_t)std::max(1, s.neq));
+    pull("warning", w, 8, sizeof(int));
+    pull("eq_active", eqa.data(), s.neq, sizeof(int));
+    ok = Backend::sync(nullptr) && ok;
+    if (!ok) return fail(-7, "mjhip_rollout: reading back the final state failed");
+    for (int k = 0; k < mjNWARNING; k++) d0->warning[k].number = w[k];
+    for (int k = 0; k < s.neq; k++) d0->eq_active[k] = (mjtByte)eqa[(size_t)k];
+  }
+}
 
 MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* const* dp, int nbatch,
                             int nstep, unsigned control_spec, const double* state0,
                             const double* warmstart0, const double* control, double* state,
                             double* sensordata) {
   if (!mp || !dp || nbatch <= 0 || nstep < 0 || !state0) { set_err("mjhip_rollout: bad arguments"); return -1; }
+  const int ndev_all = Backend::device_count();
+  if (ndev_all <= 0) { set_err("mjhip: no HIP device visible -- libmjhip has no CPU fallback"); return -3; }
+  int ndev = ndev_all;
+  if (const char* ev = getenv("MJHIP_DEVICES")) ndev = std::max(1, std::min(ndev_all, atoi(ev)));
+  const int home = Backend::current_device();
+
+  // group the rollouts by model; sizes must agree (the caller's arrays have one row width)
   const mjModel* m0 = (const mjModel*)mp[0];
-  for (int r = 1; r < nbatch; r++) {
-    const mjModel* mr = (const mjModel*)mp[r];
-    if (mr == m0) continue;
-    if (mr->nbuffer != m0->nbuffer || memcmp(mr->buffer, m0->buffer, m0->nbuffer) ||
-        memcmp(&mr->opt, &m0->opt, sizeof(m0->opt))) {
-      set_err("mjhip_rollout: per-rollout model variation is not supported (all m[r] must be identical)");
-      return -2;
-    }
-  }
-  std::lock_guard<std::mutex> lock(g_cache.mu);
-  // (re)build the cached device model / batch
-  bool same = g_cache.model &&
-      g_cache.model->signature.size() == (size_t)m0->nbuffer + sizeof(m0->opt) &&
-      !memcmp(g_cache.model->signature.data(), m0->buffer, m0->nbuffer) &&
-      !memcmp(g_cache.model->signature.data() + m0->nbuffer, &m0->opt, sizeof(m0->opt));
-  if (!same) {
-    if (g_cache.batch) { mjhip_batch_destroy(g_cache.batch); g_cache.batch = nullptr; }
-    if (g_cache.model) { mjhip_model_destroy(g_cache.model); g_cache.model = nullptr; }
-    g_cache.model = mjhip_model_create(mp[0], 0, 0);
-    if (!g_cache.model) return -3;
-  }
-  if (!g_cache.batch || g_cache.batch->nenv != nbatch) {
-    if (g_cache.batch) mjhip_batch_destroy(g_cache.batch);
-    g_cache.batch = mjhip_batch_create(g_cache.model, nbatch, 0);
-    if (!g_cache.batch) return -4;
-  }
-  mjhipBatch_* Bt = g_cache.batch;
-  // "computationally stateless": user inputs not in control_spec are cleared (rollout.cc:85-115)
-  if (mjhip_batch_reset(Bt)) return -5;
-  int rc = mjhip_batch_rollout_sensors(Bt, nstep, control_spec, state0, warmstart0, control, state, sensordata,
-                                       0, nullptr);
-  if (rc) return rc;
-  // d[0] <- final state of the LAST rollout (rollout.cc:73)
-  mjData* d = (mjData*)dp[0];
-  if (d) {
-    const DSizes& s = g_cache.model->H.s;
-    const int last = nbatch - 1;
-    auto pull = [&](const char* name, double* dst, int n) {
-      if (n <= 0) return;
-      void* p; int cnt, isint;
-      mjhip_batch_field(Bt, name, &p, &cnt, &isint);
-      if (!Bt->soa) {
-        Backend::d2h(dst, (const char*)p + (size_t)last*cnt*sizeof(real), (size_t)n*sizeof(real), nullptr);
-      } else {
-        for (int i = 0; i < n; i++)
-          Backend::d2h(dst + i, (const char*)p + ((size_t)i*Bt->nenvpad + last)*sizeof(real), sizeof(real), nullptr);
+  std::vector<RollJob> groups;
+  {
+    const mjModel* prev = nullptr;
+    int prev_g = -1;
+    for (int r = 0; r < nbatch; r++) {
+      const mjModel* mr = (const mjModel*)mp[r];
+      if (!mr) { set_err("mjhip_rollout: null model"); return -1; }
+      int g = -1;
+      if (mr == prev) g = prev_g;
+      else {
+        if (mr->nq != m0->nq || mr->nv != m0->nv || mr->nu != m0->nu || mr->na != m0->na || mr->nbody != m0->nbody ||
+            mr->nsensordata != m0->nsensordata || mr->nmocap != m0->nmocap || mr->neq != m0->neq ||
+            mr->nuserdata != m0->nuserdata) {
+          set_err("mjhip_rollout: the models of one call must have identical sizes");
+          return -2;
+        }
+        for (size_t k = 0; k < groups.size() && g < 0; k++) if (same_model(groups[k].m, mr)) g = (int)k;
+        if (g < 0) { groups.emplace_back(); groups.back().m = mr; g = (int)groups.size() - 1; }
       }
-    };
-    pull("time", &d->time, 1);
-    pull("qpos", d->qpos, s.nq);
-    pull("qvel", d->qvel, s.nv);
-    pull("act", d->act, s.na);
-    pull("ctrl", d->ctrl, s.nu);
-    pull("qfrc_applied", d->qfrc_applied, s.nv);
-    pull("qacc_warmstart", d->qacc_warmstart, s.nv);
-    pull("qacc", d->qacc, s.nv);
-    pull("sensordata", d->sensordata, s.nsensordata);
-    int w[8];
-    void* p; int cnt, isint;
-    mjhip_batch_field(Bt, "warning", &p, &cnt, &isint);
-    if (!Bt->soa) {
-      Backend::d2h(w, (const char*)p + (size_t)last*cnt*sizeof(int), 8*sizeof(int), nullptr);
-    } else {
-      for (int i = 0; i < 8; i++)
-        Backend::d2h(w + i, (const char*)p + ((size_t)i*Bt->nenvpad + last)*sizeof(int), sizeof(int), nullptr);
+      groups[(size_t)g].rows.push_back(r);
+      prev = mr; prev_g = g;
     }
-    Backend::sync(nullptr);
-    for (int k = 0; k < mjNWARNING; k++) d->warning[k].number = w[k];
+  }
+  // shard: a group large enough is cut into one contiguous piece per GPU, small groups go round-robin
+  std::vector<RollJob> jobs;
+  int rr = 0;
+  for (auto& G : groups) {
+    const int n = (int)G.rows.size();
+    const int pieces = (ndev > 1 && n >= 2*ndev) ? ndev : 1;
+    for (int k = 0; k < pieces; k++) {
+      const int lo = (int)((long long)n*k/pieces), hi = (int)((long long)n*(k + 1)/pieces);
+      RollJob J;
+      J.m = G.m;
+      J.rows.assign(G.rows.begin() + lo, G.rows.begin() + hi);
+      J.device = pieces > 1 ? k : (rr++ % ndev);
+      jobs.push_back(std::move(J));
+    }
+  }
+
+  std::lock_guard<std::mutex> lock(g_roll_mu);
+  if (g_roll_dev.size() < (size_t)ndev_all) g_roll_dev.resize((size_t)ndev_all);
+  auto run_device = [&](int dev) {
+    for (auto& J : jobs) if (J.device == dev)
+      roll_run_job(J, dp, nbatch, nstep, control_spec, state0, warmstart0, control, state, sensordata);
+  };
+  int used = 0;
+  for (int dv = 0; dv < ndev; dv++) for (auto& J : jobs) if (J.device == dv) { used++; break; }
+  if (used <= 1) {
+    for (int dv = 0; dv < ndev; dv++) run_device(dv);
+  } else {
+    std::vector<std::thread> th;
+    for (int dv = 0; dv < ndev; dv++) th.emplace_back(run_device, dv);
+    for (auto& t : th) t.join();
+  }
+  std::string err;
+  Backend::set_device(home, &err);
+  int ncap = 0, nuns = 0;
+  for (auto& J : jobs) {
+    if (J.rc) { set_err(J.err); return J.rc; }
+    ncap += J.ncap; nuns += J.nuns;
+  }
+  // trajectories that are not what the reference would have computed are reported, not hidden:
+  // positive return codes (the outputs are complete: such environments were frozen and back-filled)
+  if (nuns) {
+    set_err("mjhip_rollout: " + std::to_string(nuns) + " environment(s) reached a geom pair that has no GPU collider "
+            "(mjhip warning slot 7) and were frozen");
+    return 2;
+  }
+  if (ncap) {
+    set_err("mjhip_rollout: " + std::to_string(ncap) + " contact / constraint capacity overflow(s); the affected "
+            "environments were frozen -- raise $MJHIP_NCONMAX / $MJHIP_NEFCMAX");
+    return 1;
   }
   return 0;
 }

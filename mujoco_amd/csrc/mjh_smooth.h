@@ -1232,10 +1232,35 @@ MJH_DEVN void stage_acceleration(MREF M_, BREF B_, int e_) {
   crptr fu = MJH_F(B, qfrc_actuator, e);
   rptr fsm = MJH_F(B, qfrc_smooth, e);
   rptr qas = MJH_F(B, qacc_smooth, e);
+  // Cartesian forces on bodies, projected body by body (mj_xfrcAccumulate -> mj_applyFT at the body's
+  // COM, engine_support.c:438-512): force then torque of each body with a non-zero wrench
+  const int xfrc_on = B.xfrc_on;
+  crptr xf = MJH_G(B, xfrc_applied, e);
+  crptr xipos = MJH_F(B, xipos, e);        // (kept readable by the plan when xfrc_on)
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr com = MJH_F(B, subtree_com, e);
   MJH_FOR_LANES(i, s.nv) {
     real f = fp[i] - fb[i];
     f += fa[i];
     f += fu[i];
+    if (xfrc_on) {
+      crptr cd = cdof + 6*i;
+      for (int b = 1; b < s.nbody; b++) {
+        crptr w = xf + 6*b;
+        if (w[0] == 0 && w[1] == 0 && w[2] == 0 && w[3] == 0 && w[4] == 0 && w[5] == 0) continue;
+        real tf = 0, tt = 0;
+        const int wb = M.body_weldid[b];
+        if ((M.body_dofanc[wb*s.nvw + (i >> 5)] >> (i & 31)) & 1) {
+          real off[3], cr[3];
+          v3_sub(off, xipos + 3*b, com + 3*M.body_rootid[b]);
+          v3_cross(cr, cd, off);
+          for (int r = 0; r < 3; r++) { const real fr = w[r]; if (fr != 0) tf += (cd[3 + r] + cr[r])*fr; }
+          for (int r = 0; r < 3; r++) { const real tr = w[3 + r]; if (tr != 0) tt += cd[r]*tr; }
+        }
+        f += tf;
+        f += tt;
+      }
+    }
     fsm[i] = f;
     qas[i] = f;
   }

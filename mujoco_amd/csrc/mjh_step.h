@@ -34,6 +34,8 @@ MJH_DEV void reset_env(MREF M, BREF B, int e) {
   MJH_FOR_LANES(i, 6*s.nbody) xf[i] = 0;
   iptr eqa = MJH_G(B, eq_active, e);
   MJH_FOR_LANES(i, s.neq) eqa[i] = M.eq_active0[i];
+  rptr ud = MJH_G(B, userdata, e);
+  MJH_FOR_LANES(i, s.nuserdata) ud[i] = 0;
   reset_mocap(M, B, e);
   iptr warn = MJH_F(B, warning, e);
   if (wv_lane() == 0) {
@@ -623,6 +625,31 @@ MJH_DEV void set_state(MREF M, BREF B, int e, P0 in) {
   MJH_FOR_LANES(i, s.na) act[i] = in[1 + s.nq + s.nv + i];
 }
 
+// user inputs that are not part of the control spec are cleared / reset at the start of a rollout
+// (python/mujoco/rollout.cc:85-115); inputs that are part of it keep their current values until
+// the control array (if any) overwrites them
+MJH_DEV void rollout_clear_inputs(MREF M, BREF B, int e, const RolloutArgs& A) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
+  if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
+  if (A.xfrc_off < 0) { rptr x = MJH_G(B, xfrc_applied, e); MJH_FOR_LANES(i, 6*s.nbody) x[i] = 0; }
+  if (A.mpos_off < 0 || A.mquat_off < 0) reset_mocap(M, B, e);
+  if (A.eq_off < 0) { iptr q = MJH_G(B, eq_active, e); MJH_FOR_LANES(i, s.neq) q[i] = M.eq_active0[i]; }
+}
+
+// one control vector -> the user-input fields, in mjtState bit order (mj_setState, engine_support.c:282)
+MJH_DEV void rollout_load_control(MREF M, BREF B, int e, const RolloutArgs& A, const real* u) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
+  if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
+  if (A.xfrc_off >= 0) { rptr x = MJH_G(B, xfrc_applied, e); MJH_FOR_LANES(i, 6*s.nbody) x[i] = u[A.xfrc_off + i]; }
+  // eq_active is a byte array in mjData: the state value is converted like the reference's assignment
+  if (A.eq_off >= 0) { iptr q = MJH_G(B, eq_active, e); MJH_FOR_LANES(i, s.neq) q[i] = (int)(unsigned char)u[A.eq_off + i]; }
+  if (A.mpos_off >= 0) { rptr p = MJH_G(B, mocap_pos, e); MJH_FOR_LANES(i, 3*s.nmocap) p[i] = u[A.mpos_off + i]; }
+  if (A.mquat_off >= 0) { rptr q = MJH_G(B, mocap_quat, e); MJH_FOR_LANES(i, 4*s.nmocap) q[i] = u[A.mquat_off + i]; }
+  if (A.ud_off >= 0) { rptr d = MJH_G(B, userdata, e); MJH_FOR_LANES(i, s.nuserdata) d[i] = u[A.ud_off + i]; }
+}
+
 // _unsafe_rollout for one environment                (python/mujoco/rollout.cc:74-178)
 MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
   const MJH_CONST_AS DSizes& s = M.s;
@@ -635,12 +662,7 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     MJH_FOR_LANES(i, s.nv) ws[i] = A.warmstart0 ? A.warmstart0[r*s.nv + i] : 0;
     iptr warn = MJH_F(B, warning, e);
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
-    if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
-    if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
-    if (A.mpos_off < 0 || A.mquat_off < 0) {
-      // mocap inputs that are not part of the control spec are reset (rollout.cc:85-115)
-      reset_mocap(M, B, e);
-    }
+    rollout_clear_inputs(M, B, e, A);
     wv_sync();
   }
   ciptr warn = MJH_F(B, warning, e);
@@ -655,11 +677,7 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     const size_t step = r*(size_t)A.nstep + t;
     if (!nw) {
       if (A.control) {
-        const real* u = A.control + step*A.ncontrol;
-        if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
-        if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
-        if (A.mpos_off >= 0) { rptr p = MJH_G(B, mocap_pos, e); MJH_FOR_LANES(i, 3*s.nmocap) p[i] = u[A.mpos_off + i]; }
-        if (A.mquat_off >= 0) { rptr q = MJH_G(B, mocap_quat, e); MJH_FOR_LANES(i, 4*s.nmocap) q[i] = u[A.mquat_off + i]; }
+        rollout_load_control(M, B, e, A, A.control + step*A.ncontrol);
         wv_sync();
       }
       step_env(M, B, e);
@@ -712,9 +730,7 @@ MJH_DEV void smooth_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     MJH_FOR_LANES(i, s.nv) ws[i] = A.warmstart0 ? A.warmstart0[r*s.nv + i] : 0;
     iptr warn = MJH_F(B, warning, e);
     if (wv_lane() == 0) for (int k = 0; k < 8; k++) warn[k] = 0;
-    if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
-    if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
-    if (A.mpos_off < 0 || A.mquat_off < 0) reset_mocap(M, B, e);
+    rollout_clear_inputs(M, B, e, A);
     wv_sync();
   }
   // any warning freezes the trajectory (python/mujoco/rollout.cc:135-155)
@@ -724,11 +740,7 @@ MJH_DEV void smooth_env(MREF M, BREF B, int e, const RolloutArgs& A) {
   if (wv_lane() == 0) MJH_G(B, active, e)[0] = nw ? 0 : 1;
   if (nw) return;
   if (A.control) {
-    const real* u = A.control + (r*(size_t)A.nstep + A.t0)*A.ncontrol;
-    if (A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = u[i]; }
-    if (A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = u[A.qfrc_off + i]; }
-    if (A.mpos_off >= 0) { rptr q = MJH_G(B, mocap_pos, e); MJH_FOR_LANES(i, 3*s.nmocap) q[i] = u[A.mpos_off + i]; }
-    if (A.mquat_off >= 0) { rptr q = MJH_G(B, mocap_quat, e); MJH_FOR_LANES(i, 4*s.nmocap) q[i] = u[A.mquat_off + i]; }
+    rollout_load_control(M, B, e, A, A.control + (r*(size_t)A.nstep + A.t0)*A.ncontrol);
     wv_sync();
   }
   check_bad(M, B, e, MJH_F(B, qpos, e), s.nq, MJH_WARN_BADQPOS);

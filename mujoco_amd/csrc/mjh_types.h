@@ -228,6 +228,7 @@ struct DSizes {
   int nstate;      // mj_stateSize(FULLPHYSICS)
   int nsensor, nsensordata;
   int nmocap;
+  int nuserdata;
   int nbody_fluid;  // nbody when fluid forces are on, else 0
   int nbody_sens;  // nbody when the model has sensors (cacc / cfrc / subtree velocity arrays), else 0
   int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
@@ -300,6 +301,7 @@ enum {
   X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \
   X(qacc_warmstart, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                           \
   X(xfrc_applied, 6 * s.nbody, 0, MJH_T_GLB, MJH_T_GLB)                           \
+  X(userdata, s.nuserdata, 0, MJH_T_GLB, MJH_T_GLB)                               \
   X(xpos, 3 * s.nbody, 3 * s.nbody, MJH_T_KIN, MJH_T_KIN)                         \
   X(xquat, 4 * s.nbody, 4 * s.nbody, MJH_T_KIN, MJH_T_KIN)                        \
   X(xmat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                      \
@@ -432,6 +434,7 @@ struct DBatch {
   int dyn2_off;      // [dyn2_off, dyn_off): holds fields that die with MJH_T_MAKE; free from MJH_T_PROJECT on
   int nconlds;       // contact slots resident in LDS
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
+  int xfrc_on;       // 1: xfrc_applied may be non-zero (mj_xfrcAccumulate runs; xipos stays readable at MJH_T_ACCEL)
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
@@ -593,6 +596,7 @@ struct RolloutArgs {
   int ncontrol;            // mj_stateSize(control_spec)
   int qfrc_off;            // offset of qfrc_applied inside one control vector
   int mpos_off, mquat_off; // offsets of mocap_pos / mocap_quat inside one control vector, -1: absent
+  int xfrc_off, eq_off, ud_off;   // offsets of xfrc_applied / eq_active / userdata, -1: absent
   int init;                // 1: load state0/warmstart0, clear warnings (start of a rollout)
   int t0;                  // (per-step kernels) index of this step inside control/state
   const real* state0;      // [nenv][nstate]        or null
@@ -601,5 +605,6 @@ struct RolloutArgs {
   real* state;             // [nenv][nstep][nstate] or null
   real* sensordata;        // [nenv][nstep][nsensordata] or null
   int env_offset;          // first env of this launch inside state0/control/state
+  int nlaunch;             // > 0: only environments [0, nlaunch) take part, in identity order (partial launch)
 };
 

@@ -83,10 +83,17 @@ class Rollout:
             return None if a is None else a.ctypes.data
         rc = lib.c.mjhip_rollout(mp, dp, nbatch, int(nstep), int(control_spec), ptr(initial_state),
                                  ptr(initial_warmstart), ptr(control), ptr(state), ptr(sensordata))
-        if rc != 0:
+        if rc < 0:
             msg = lib.error()
             # size/shape/feature problems are the caller's: same exception type as the reference
             raise ValueError(msg) if rc in (-1, -2) else RuntimeError(msg)
+        if rc == 2:
+            # an environment reached a collider the GPU path lacks: its trajectory is not the reference's
+            raise RuntimeError(lib.error())
+        if rc == 1:
+            # contact / constraint capacity overflow: the affected rollouts were frozen (back-filled)
+            import warnings
+            warnings.warn(lib.error(), RuntimeWarning, stacklevel=3)
 
     def rollout(self, model, data, initial_state, control=None, *, control_spec: int = mjSTATE_CTRL,
                 skip_checks: bool = False, nstep: Optional[int] = None, initial_warmstart=None,

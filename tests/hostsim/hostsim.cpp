@@ -91,8 +91,15 @@ void Runner::fiber_entry() {
 
 struct Backend {
   static const char* name() { return "hostsim"; }
-  static int device_count() { return 1; }
-  static bool set_device(int, std::string*) { return true; }
+  // ($MJH_HOSTSIM_DEVICES > 1 lets the CPU tests drive the multi-GPU sharding of mjhip_rollout)
+  static int device_count() { const char* ev = getenv("MJH_HOSTSIM_DEVICES"); return ev ? std::max(1, atoi(ev)) : 1; }
+  static int& cur_dev() { static thread_local int d = 0; return d; }
+  static int current_device() { return cur_dev(); }
+  static bool set_device(int d, std::string* err) {
+    if (d < 0 || d >= device_count()) { *err = "hostsim: no such device"; return false; }
+    cur_dev() = d;
+    return true;
+  }
   static void* alloc(size_t bytes) { void* p = nullptr; if (posix_memalign(&p, 256, bytes ? bytes : 256)) return nullptr; return p; }
   static void free(void* p) { ::free(p); }
   static bool h2d(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
@@ -124,10 +131,10 @@ struct Backend {
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void*) {
     // (slot w of the launch steps environment perm[w], like the kernels)
-    if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int w) { wl::rollout_env(*M, *B, B->perm[w], A); });
-    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int w) { w2::rollout_env(*M, *B, B->perm[w], A); });
-    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int w) { w4::rollout_env(*M, *B, B->perm[w], A); });
-    else run_waves(nenv, 1, lds, [&](int w) { wv::rollout_env(*M, *B, B->perm[w], A); });
+    if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int w) { wl::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
+    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int w) { w2::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
+    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int w) { w4::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
+    else run_waves(nenv, 1, lds, [&](int w) { wv::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
     return true;
   }
   // the launch order of the next rollout launch: environments by decreasing work estimate

@@ -578,3 +578,115 @@ def test_kernel_variants_bit_identical_rollouts(hip_lib, dm, golden):
     for variant in ["lean", "lean2", "lean4"]:
         assert np.array_equal(outs[variant], outs["generic"]), variant
     assert relerr(outs["lean2"][:, :10], fx["state"][:, :10]) <= TOL
+
+
+# ---- warning semantics on the GPU path (rollout.cc:135-155; engine_forward.c:54-113) -------------------
+
+def test_bad_state_freezes_and_resets_on_gpu(rb, hip_lib, dm):
+    """a bad qvel raises mjWARN_BADQVEL, auto-resets the environment (mj_checkVel) and the rollout
+    loop back-fills the rest of its trajectory; the other environments of the batch (and of the
+    wavefront, for the sub-wave variants) are unaffected"""
+    m = humanoid_pgs_oracle(rb)
+    d = rb.MjData(m)
+    base = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    rng = np.random.default_rng(3)
+    n, T = 6, 6
+    s0 = np.tile(base, (n, 1))
+    s0[:, 29:] = rng.normal(0, .1, size=(n, m.nv))
+    s0[2, 1 + 28 + 3] = 1e12            # bad qvel
+    s0[5, 1 + 4] = np.nan               # bad qpos
+    ctrl = rng.uniform(-1, 1, size=(n, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)        # the oracle loop implements the same freeze rule
+    for variant in ["lean", "lean2", "generic"]:
+        b = K.Batch(dm, n)
+        b.set_variant(variant)
+        out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+        assert relerr(out, ref) <= TOL, variant
+        for e in (2, 5):
+            for t in range(1, T):
+                assert np.array_equal(out[e, t], out[e, 0]), (variant, e, t)
+        w = b.get("warning")
+        assert w[2, 4] == 1 and w[5, 3] == 1 and w[[0, 1, 3, 4]].sum() == 0, variant
+
+
+def test_capacity_overflow_on_gpu(rb, hip_lib):
+    """too small a contact / constraint capacity raises mjWARN_CONTACTFULL / mjWARN_CNSTRFULL (the
+    reference's full-arena warnings, engine_collision_driver.c:2028, engine_core_constraint.c:145),
+    the environment freezes, and mjhip_batch_trouble reports it"""
+    m = humanoid_pgs_oracle(rb)
+    d = rb.MjData(m)
+    rb.mj_resetDataKeyframe(m, d, 2)                # prone: a dozen contacts
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None]
+    for caps, slot in (((2, 0), 1), ((0, 8), 2)):
+        dmc = K.DeviceModel(hip_lib, m, *caps)
+        b = K.Batch(dmc, 1)
+        out = b.rollout_host(4, K.mjSTATE_CTRL, s0, None, np.zeros((1, 4, m.nu)))
+        w = b.get("warning")[0]
+        assert w[slot] >= 1, (caps, w)
+        assert np.array_equal(out[0, 1], out[0, 0]) and np.array_equal(out[0, 3], out[0, 0])
+        assert b.trouble()[0] >= 1
+
+
+def test_rollout_full_horizon_per_step_parity(rb, hip_lib, dm, golden):
+    """all 120 steps of the golden trajectories, asserted: every step restarted from the oracle's
+    previous state and running warm start (so a chaotic trajectory cannot hide or amplify anything)"""
+    fx = golden("humanoid")
+    m = humanoid_pgs_oracle(rb)
+    n, T = fx["state0"].shape[0], fx["ctrl"].shape[1]
+    d = rb.MjData(m)
+    s_in = np.zeros((n, T, 56)); ws_in = np.zeros((n, T, m.nv))
+    for e in range(n):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, fx["state0"][e], rb.mjSTATE_FULLPHYSICS)
+        for t in range(T):
+            s_in[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+            ws_in[e, t] = np.array(d.qacc_warmstart)
+            d.ctrl[:] = fx["ctrl"][e, t]
+            rb.mj_step(m, d)
+            assert np.array_equal(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS), fx["state"][e, t])
+    b = K.Batch(dm, n*T)
+    one = b.rollout_host(1, K.mjSTATE_CTRL, s_in.reshape(n*T, 56), ws_in.reshape(n*T, m.nv),
+                         fx["ctrl"].reshape(n*T, 1, -1))[:, 0].reshape(n, T, 56)
+    err = relerr(one, fx["state"])
+    print("per-step parity over the full 120-step horizon:", err)
+    assert err <= TOL
+
+
+def test_rollout_api_user_inputs_and_multi_model_on_gpu(rb, hip_lib, tmp_path):
+    """the drop-in on the GPU: mjSTATE_USER control spec (xfrc_applied, eq_active, mocap pose,
+    userdata) and one model per rollout (rollout_test.py:363 test_multi_model)"""
+    from mujoco_amd import rollout
+    from test_rollout_api_cpu import USER_XML, _py_rollout
+    models = []
+    for i in range(3):
+        xml = tmp_path / f"m{i}.xml"
+        xml.write_text(USER_XML.replace('name="hand" pos="0 0 .35"', f'name="hand" pos="{.1*i} 0 {.35 + .05*i}"'))
+        models.append(rb.MjModel.from_xml_path(str(xml)))
+    m = models[0]
+    d = rb.MjData(m)
+    rng = np.random.default_rng(5)
+    order = [0, 1, 2, 1, 0, 1]
+    mlist = [models[k] for k in order]
+    nbatch, nstep = len(order), 20
+    s0 = np.zeros((nbatch, 1 + m.nq + m.nv))
+    for e, mm in enumerate(mlist):
+        rb.mj_resetData(mm, d)
+        s0[e] = rb.mj_getState(mm, d, rb.mjSTATE_FULLPHYSICS)
+    s0[:, 1 + m.nq:] = rng.normal(0, .2, size=(nbatch, m.nv))
+    spec = rb.mjSTATE_USER
+    n = rb.mj_stateSize(m, spec)
+    control = np.zeros((nbatch, nstep, n))
+    o = 0
+    control[:, :, o:o + m.nu] = rng.uniform(-.02, .02, size=(nbatch, nstep, m.nu)); o += m.nu
+    control[:, :, o:o + m.nv] = rng.normal(0, .1, size=(nbatch, nstep, m.nv)); o += m.nv
+    xf = rng.normal(0, 2, size=(nbatch, nstep, m.nbody, 6)); xf[:, :, :2] = 0
+    control[:, :, o:o + 6*m.nbody] = xf.reshape(nbatch, nstep, -1); o += 6*m.nbody
+    eqa = np.ones((nbatch, nstep, m.neq)); eqa[0, 8:16, 0] = 0; eqa[1, 5:, 1] = 0
+    control[:, :, o:o + m.neq] = eqa; o += m.neq
+    control[:, :, o:o + 3] = [.05, .02, .42]; o += 3
+    control[:, :, o:o + 4] = [1, .1, 0, .05]; o += 4
+    control[:, :, o:] = rng.normal(size=(nbatch, nstep, m.nuserdata))
+    state, _ = rollout.rollout(mlist, d, s0, control, control_spec=spec)
+    ref = _py_rollout(rb, mlist, s0, control, spec)
+    assert relerr(state, ref) <= TOL
+    print("multi-model + all user inputs: rel err", relerr(state, ref))

@@ -95,10 +95,27 @@ def test_generalized_control(rb, api):                          # rollout_test.p
             rb.mj_step(m, d)
             ref[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     np.testing.assert_array_equal(state, ref)
-    # xfrc_applied is a legal user input for the reference; mjhip reports it as unsupported
-    with pytest.raises(ValueError, match="not supported"):
-        rollout.rollout(m, d, s0, np.zeros((nbatch, nstep, m.nu + 6*m.nbody)),
-                        control_spec=K.mjSTATE_CTRL | K.mjSTATE_XFRC_APPLIED)
+    # every mjSTATE_USER bit at once (humanoid: no equalities / mocap bodies / userdata, so those are
+    # empty); Cartesian forces on bodies go through mj_xfrcAccumulate
+    spec = rb.mjSTATE_USER
+    xfrc = rng.normal(0, 20, size=(nbatch, nstep, 6*m.nbody))
+    xfrc[:, :, :6] = 0                       # the world body's wrench is ignored by the reference
+    xfrc[:, :, 6*3:6*9] = 0                  # and most bodies carry none
+    control = np.concatenate([rng.uniform(-1, 1, size=(nbatch, nstep, m.nu)),
+                              rng.normal(0, 5, size=(nbatch, nstep, m.nv)), xfrc], axis=2)
+    assert control.shape[2] == rb.mj_stateSize(m, spec)
+    state, _ = rollout.rollout(m, d, s0, control, control_spec=spec)
+    ref = np.zeros_like(state)
+    for e in range(nbatch):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
+        for t in range(nstep):
+            rb.mj_setState(m, d, control[e, t], spec)
+            rb.mj_step(m, d)
+            ref[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    np.testing.assert_array_equal(state, ref)
+    ref_noxfrc, _ = oracle_rollout(rb, m, s0, control[:, :, :m.nu])
+    assert not np.array_equal(ref, ref_noxfrc)
 
 
 def test_invalid_and_bad_sizes(api):                            # rollout_test.py:730-787
@@ -179,3 +196,160 @@ def test_sensordata_output(rb, hostsim_lib, monkeypatch, tmp_path):   # rollout_
             np.testing.assert_array_equal(state[r, t], rb.mj_getState(m, dd, rb.mjSTATE_FULLPHYSICS))
             np.testing.assert_array_equal(sensordata[r, t], np.array(dd.sensordata))
     np.testing.assert_array_equal(np.array(d.sensordata), sensordata[-1, -1])
+
+
+USER_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <size nuserdata="3"/>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="target" mocap="true" pos="0 0 .4" quat="1 0 0 0"><geom type="sphere" size=".02" contype="0" conaffinity="0"/></body>
+    <body name="hand" pos="0 0 .35"><freejoint/><geom type="sphere" size=".05"/>
+      <body pos="0 0 -.08"><joint name="finger" type="slide" axis="0 1 0" range="-.03 .03" limited="true" damping="1"/><geom type="capsule" size=".01 .02"/></body></body>
+    <body name="ball" pos=".5 .05 .05"><freejoint/><geom type="sphere" size=".05" condim="3"/></body>
+    <body name="p1" pos="-.5 0 .5"><joint name="q1" axis="0 1 0" damping=".02"/><geom type="capsule" fromto="0 0 0 .2 0 0" size=".02"/></body>
+    <body name="p2" pos="-.5 .3 .5"><joint name="q2" axis="0 1 0" damping=".02"/><geom type="capsule" fromto="0 0 0 .2 0 0" size=".02"/></body>
+  </worldbody>
+  <equality>
+    <weld body1="hand" body2="target" solref=".02 1"/>
+    <joint joint1="q1" joint2="q2" polycoef="0 1 0 0 0"/>
+  </equality>
+  <actuator><position joint="finger" kp="20"/></actuator>
+</mujoco>
+"""
+
+
+def _py_rollout(rb, models, s0, control, spec, warm=None):
+    """the reference's py_rollout with a control spec and one model per rollout (rollout_test.py:976)"""
+    nbatch, nstep = control.shape[:2]
+    out = np.zeros((nbatch, nstep, s0.shape[1]))
+    for e in range(nbatch):
+        m = models[e]
+        d = rb.MjData(m)
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
+        if warm is not None:
+            d.qacc_warmstart[:] = warm[e]
+        for t in range(nstep):
+            rb.mj_setState(m, d, control[e, t], spec)
+            rb.mj_step(m, d)
+            out[e, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    return out
+
+
+def test_every_user_input_drives_the_rollout(rb, hostsim_lib, monkeypatch, tmp_path):
+    """control_spec = mjSTATE_USER on a model that HAS equalities, a mocap body and userdata: ctrl,
+    qfrc_applied, xfrc_applied, eq_active (switching constraints on and off mid-rollout), mocap
+    pose and userdata, in mj_setState's bit order (engine_support.c:282; rollout.cc:160)"""
+    monkeypatch.setattr(mujoco_amd, "lib", lambda: hostsim_lib)
+    xml = tmp_path / "user.xml"
+    xml.write_text(USER_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = np.tile(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS), (3, 1))
+    rng = np.random.default_rng(5)
+    s0[:, 1 + m.nq:] = rng.normal(0, .2, size=(3, m.nv))
+    nbatch, nstep = 3, 25
+    spec = rb.mjSTATE_USER
+    n = rb.mj_stateSize(m, spec)
+    control = np.zeros((nbatch, nstep, n))
+    o = 0
+    control[:, :, o:o + m.nu] = rng.uniform(-.02, .02, size=(nbatch, nstep, m.nu)); o += m.nu
+    control[:, :, o:o + m.nv] = rng.normal(0, .1, size=(nbatch, nstep, m.nv)); o += m.nv
+    xf = rng.normal(0, 2, size=(nbatch, nstep, m.nbody, 6)); xf[:, :, 0] = 0; xf[:, :, 1] = 0; xf[:, ::2, 3] = 0
+    control[:, :, o:o + 6*m.nbody] = xf.reshape(nbatch, nstep, -1); o += 6*m.nbody
+    eqa = np.ones((nbatch, nstep, m.neq)); eqa[0, 8:16, 0] = 0; eqa[1, 5:, 1] = 0; eqa[2, :, :] = 0; eqa[2, 12:, 0] = 1
+    control[:, :, o:o + m.neq] = eqa; o += m.neq
+    for t in range(nstep):
+        control[:, t, o:o + 3] = [.1*np.sin(t/7), .02*t/nstep, .4 + .05*np.cos(t/5)]
+    o += 3*m.nmocap
+    control[:, :, o:o + 4] = [1, .1, 0, .05]; o += 4*m.nmocap          # not normalised on purpose
+    control[:, :, o:o + m.nuserdata] = rng.normal(size=(nbatch, nstep, m.nuserdata)); o += m.nuserdata
+    assert o == n
+    state, _ = rollout.rollout(m, d, s0, control, control_spec=spec)
+    ref = _py_rollout(rb, [m]*nbatch, s0, control, spec)
+    np.testing.assert_array_equal(state, ref)
+    # the caller's mjData holds the last rollout's final inputs as well (rollout.cc:73)
+    np.testing.assert_array_equal(np.array(d.userdata), control[-1, -1, n - m.nuserdata:])
+    np.testing.assert_array_equal(np.array(d.eq_active), eqa[-1, -1])
+    # same physics, inputs outside the spec reset: switching equalities off must have mattered
+    on = control.copy(); on[:, :, 1 + m.nv + 6*m.nbody:1 + m.nv + 6*m.nbody + m.neq] = 1
+    assert not np.array_equal(_py_rollout(rb, [m]*nbatch, s0, on, spec), ref)
+
+
+def test_multi_model(rb, hostsim_lib, monkeypatch, tmp_path):     # rollout_test.py:363-389
+    """one model PER ROLLOUT (the second body of every model is shifted, as in the reference's
+    test): rollouts are grouped by model content, so interleaved duplicates share a batch"""
+    monkeypatch.setattr(mujoco_amd, "lib", lambda: hostsim_lib)
+    models = []
+    for i in range(3):
+        xml = tmp_path / f"m{i}.xml"
+        xml.write_text(USER_XML.replace('name="hand" pos="0 0 .35"', f'name="hand" pos="{.1*i} 0 {.35 + .05*i}"'))
+        models.append(rb.MjModel.from_xml_path(str(xml)))
+    m0 = models[0]
+    d = rb.MjData(m0)
+    rng = np.random.default_rng(3)
+    order = [0, 1, 2, 1, 0, 1]                   # interleaved: groups are not contiguous rows
+    mlist = [models[k] for k in order]
+    nbatch, nstep = len(order), 6
+    s0 = np.zeros((nbatch, 1 + m0.nq + m0.nv))
+    for e, m in enumerate(mlist):
+        rb.mj_resetData(m, d)
+        s0[e] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    s0[:, 1 + m0.nq:] = rng.normal(0, .3, size=(nbatch, m0.nv))
+    control = rng.uniform(-.02, .02, size=(nbatch, nstep, m0.nu))
+    state, _ = rollout.rollout(mlist, d, s0, control)
+    ref = _py_rollout(rb, mlist, s0, control, rb.mjSTATE_CTRL)
+    np.testing.assert_array_equal(state, ref)
+    assert not np.array_equal(state[0], state[1])
+    with pytest.raises(ValueError, match="identical sizes"):
+        rollout.rollout([m0, humanoid_pgs_oracle(rb)], d, s0[:2], control[:2], skip_checks=True, nstep=nstep,
+                        state=np.zeros((2, nstep, s0.shape[1])))
+
+
+def test_control_none_steps_with_the_callers_inputs(rb, api):      # rollout.cc:85-115
+    """control=None with mjSTATE_CTRL in the spec: the reference steps with whatever ctrl its
+    mjData holds (only inputs OUTSIDE the spec are cleared)"""
+    m, d, states, rng = api
+    s0 = states(2)
+    d.ctrl[:] = rng.uniform(-1, 1, size=m.nu)
+    d.qfrc_applied[:] = rng.normal(size=m.nv)               # not in the spec: cleared
+    held = np.array(d.ctrl)
+    state, _ = rollout.rollout(m, d, s0, nstep=4)
+    ref, _ = oracle_rollout(rb, m, s0, np.tile(held, (2, 4, 1)))
+    np.testing.assert_array_equal(state, ref)
+    zero, _ = oracle_rollout(rb, m, s0, np.zeros((2, 4, m.nu)))
+    assert not np.array_equal(ref, zero)
+
+
+def test_rollout_shards_over_devices(rb, api, monkeypatch):
+    """mjhip_rollout cuts a batch into one contiguous piece per visible GPU, one host thread each,
+    every piece writing its own rows of the caller's arrays; here two emulated devices"""
+    m, d, states, rng = api
+    nbatch, nstep = 9, 3
+    s0 = states(nbatch)
+    ctrl = rng.uniform(-1, 1, size=(nbatch, nstep, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    monkeypatch.setenv("MJH_HOSTSIM_DEVICES", "2")
+    state, _ = rollout.rollout(m, d, s0, ctrl)
+    np.testing.assert_array_equal(state, ref)
+    np.testing.assert_array_equal(np.array(d.qpos), ref[-1, -1, 1:29])
+    monkeypatch.setenv("MJHIP_DEVICES", "1")
+    state1, _ = rollout.rollout(m, d, s0, ctrl)
+    np.testing.assert_array_equal(state1, ref)
+
+
+def test_capacity_overflow_is_reported(rb, api, monkeypatch):
+    """an environment that overflows the contact capacity is frozen like after any warning -- the
+    reference's arena would have grown, so the drop-in says so (return code 1 -> RuntimeWarning)"""
+    m, d, states, rng = api
+    rb.mj_resetDataKeyframe(m, d, 2)                 # prone: many contacts
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None]
+    monkeypatch.setenv("MJHIP_NCONMAX", "2")
+    mujoco_amd.lib().c.mjhip_rollout_clear_cache()
+    with pytest.warns(RuntimeWarning, match="capacity"):
+        rollout.rollout(m, d, s0, np.zeros((1, 3, m.nu)))
+    monkeypatch.delenv("MJHIP_NCONMAX")
+    mujoco_amd.lib().c.mjhip_rollout_clear_cache()
