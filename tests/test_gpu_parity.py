@@ -596,12 +596,14 @@ def test_bad_state_freezes_and_resets_on_gpu(rb, hip_lib, dm):
     s0[2, 1 + 28 + 3] = 1e12            # bad qvel
     s0[5, 1 + 4] = np.nan               # bad qpos
     ctrl = rng.uniform(-1, 1, size=(n, T, m.nu))
-    ref, _ = oracle_rollout(rb, m, s0, ctrl)        # the oracle loop implements the same freeze rule
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)        # (a plain mj_step loop: no freeze rule)
+    ok = [0, 1, 3, 4]
     for variant in ["lean", "lean2", "generic"]:
         b = K.Batch(dm, n)
         b.set_variant(variant)
         out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
-        assert relerr(out, ref) <= TOL, variant
+        assert relerr(out[ok], ref[ok]) <= TOL, variant
+        assert relerr(out[[2, 5], 0], ref[[2, 5], 0]) <= TOL, variant      # the step that raised the warning
         for e in (2, 5):
             for t in range(1, T):
                 assert np.array_equal(out[e, t], out[e, 0]), (variant, e, t)
