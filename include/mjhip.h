@@ -127,6 +127,14 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* batch, int stages, void* hip_strea
  * (closed-loop RL stepping).  Replaces mj_step (src/engine/engine_forward.c:1846). */
 MJHIP_API int mjhip_batch_step(mjhipBatch* batch, int nstep, void* hip_stream);
 
+/* mj_step1 / mj_step2 for every env (src/engine/engine_forward.c:1884, :1916): step1 = checkPos/Vel,
+ * fwdPosition, fwdVelocity; the caller may then read any field (mjhip_batch_get / _field) and set
+ * ctrl; step2 = fwdActuation, fwdAcceleration, fwdConstraint, sensors, checkAcc, integration (the
+ * model's implicit integrator, else Euler -- RK4 is not available in the split, like the
+ * reference).  step1 + step2 == mjhip_batch_step(batch, 1) for Euler / implicitfast models. */
+MJHIP_API int mjhip_batch_step1(mjhipBatch* batch, void* hip_stream);
+MJHIP_API int mjhip_batch_step2(mjhipBatch* batch, void* hip_stream);
+
 /* Open-loop rollout of every env in the batch: the contract of _unsafe_rollout
  * (python/mujoco/rollout.cc:71-178) with one environment per rollout.
  *   state0      [nenv][nstate]            FULLPHYSICS initial states, or NULL (keep current)

@@ -102,6 +102,10 @@ class Lib:
         lib.mjhip_batch_forward.argtypes = [vp, ci, vp]
         lib.mjhip_batch_step.restype = ci
         lib.mjhip_batch_step.argtypes = [vp, ci, vp]
+        lib.mjhip_batch_step1.restype = ci
+        lib.mjhip_batch_step1.argtypes = [vp, vp]
+        lib.mjhip_batch_step2.restype = ci
+        lib.mjhip_batch_step2.argtypes = [vp, vp]
         lib.mjhip_batch_rollout.restype = ci
         lib.mjhip_batch_rollout.argtypes = [vp, ci, cu, dp, dp, dp, dp, ci, vp]
         lib.mjhip_batch_rollout_sensors.restype = ci
@@ -123,7 +127,7 @@ class Lib:
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
-        "mjhip_batch_trouble", "mjhip_rollout_clear_cache",
+        "mjhip_batch_trouble", "mjhip_rollout_clear_cache", "mjhip_batch_step1", "mjhip_batch_step2",
     )
 
     def backend(self) -> str:
@@ -286,6 +290,16 @@ class Batch:
         self._lib.check(self._lib.c.mjhip_batch_step(self._h, int(nstep), stream or None), "step")
         if sync:
             self.sync(stream)
+
+    def step1(self, stream: int = 0) -> None:
+        """mj_step1 for every env: everything up to (and including) the velocity stage"""
+        self._lib.check(self._lib.c.mjhip_batch_step1(self._h, stream or None), "step1")
+        self.sync(stream)
+
+    def step2(self, stream: int = 0) -> None:
+        """mj_step2 for every env: actuation, acceleration, constraint solve, integration"""
+        self._lib.check(self._lib.c.mjhip_batch_step2(self._h, stream or None), "step2")
+        self.sync(stream)
 
     def sync(self, stream: int = 0) -> None:
         self._lib.check(self._lib.c.mjhip_batch_sync(self._h, stream or None), "sync")

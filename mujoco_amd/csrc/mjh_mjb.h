@@ -79,15 +79,36 @@ static mjModel* load(const char* path, std::string* err) {
   ok = ok && rd(&m->flg_gravcomp, sizeof(mjtBool)) && rd(&m->flg_surfacevel, sizeof(mjtBool));
   if (!ok) { free(m); *err = "mjhip_load_mjb: truncated size/option block"; return nullptr; }
 
-  // buffer layout
+  // every size field is a count: a negative one is rejected before anything is sized from it (the
+  // arrays are bounded by the file size below; narena / nbuffer are byte counts, not array lengths)
+  {
+    const char* bad = nullptr;
+    // (njmax / nconmax are legacy limits where -1 means "unlimited"; they size nothing here)
+#define X(name) if ((long long)m->name < 0 && !bad && strcmp(#name, "njmax") && strcmp(#name, "nconmax")) bad = #name;
+    MJMODEL_SIZES
+#undef X
+    if (bad) { *err = std::string("mjhip_load_mjb: corrupted file (negative size field ") + bad + ")"; free(m); return nullptr; }
+  }
+
+  // buffer layout; no array can be larger than the file it is read from (this also bounds the
+  // products: every factor is <= fsz < 2^63 / 8 for any real file, checked per term)
   size_t total = 0;
   {
+    bool bad = false;
+    auto term = [&](size_t esz, long long nr, long long nc) -> size_t {
+      if (nr < 0 || nc < 0) { bad = true; return 0; }
+      if (nr == 0 || nc == 0) return 0;
+      if ((unsigned long long)nr > (unsigned long long)fsz / (unsigned long long)nc ||
+          (unsigned long long)(nr*nc) > (unsigned long long)fsz / esz) { bad = true; return 0; }
+      return esz*(size_t)nr*(size_t)nc;
+    };
     MJMODEL_POINTERS_PREAMBLE(m)
-#define X(type, name, nr, nc) total += skip64(total) + sizeof(type)*(size_t)(m->nr)*(size_t)(nc);
+#define X(type, name, nr, nc) total += skip64(total) + term(sizeof(type), (long long)(m->nr), (long long)(nc));
 #define XNV X
     MJMODEL_POINTERS
 #undef X
 #undef XNV
+    if (bad) { free(m); *err = "mjhip_load_mjb: corrupted file (array larger than the file)"; return nullptr; }
   }
   if ((mjtSize)total != m->nbuffer) {
     free(m);

@@ -627,6 +627,29 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
   return 0;
 }
 
+// mj_step1 / mj_step2 (engine_forward.c:1884, :1916): the step split around the point where a
+// controller may read positions / velocities and write ctrl.  Between the two calls every
+// intermediate lives in its global field (inspectable with mjhip_batch_get).
+static int step_half(mjhipBatch_* Bt, int stages, const char* who, void* stream) {
+  if (!Bt) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
+  if (Bt->soa) { set_err(std::string(who) + ": needs the AoS (wave-per-environment) layout"); return -2; }
+  if (!Backend::launch_forward(Bt->model->D_dev, Bt->D_dev, Bt->nenv, stages, 0, 0, Bt->variant, stream)) {
+    set_err(std::string(who) + ": kernel launch failed");
+    return -2;
+  }
+  return 0;
+}
+MJHIP_API int mjhip_batch_step1(mjhipBatch* Bt, void* stream) {
+  return step_half(Bt, MJH_STAGE_CHECKPV | MJH_STAGE_KINEMATICS | MJH_STAGE_INERTIA | MJH_STAGE_COLLISION | MJH_STAGE_MAKE |
+                       MJH_STAGE_PROJECT | MJH_STAGE_TRANSMISSION | MJH_STAGE_VELOCITY | MJH_STAGE_REFERENCE,
+                   "mjhip_batch_step1", stream);
+}
+MJHIP_API int mjhip_batch_step2(mjhipBatch* Bt, void* stream) {
+  return step_half(Bt, MJH_STAGE_ACTUATION | MJH_STAGE_CONSTRAINT | MJH_STAGE_FINISH | MJH_STAGE_SENSOR |
+                       MJH_STAGE_CHECKACC | MJH_STAGE_INTEGRATE, "mjhip_batch_step2", stream);
+}
+
 MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
   if (!Bt || nstep < 0) return -1;
   { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }

@@ -298,13 +298,25 @@ MJH_DEVN void rk4_advance(MREF M_, BREF B_, int e_) {
 }
 
 MJH_DEVN void euler_advance(MREF M, BREF B, int e);
-// body of the forward kernel (mjhip_batch_forward): stage-masked mj_forward (+ optional Euler step)
+MJH_DEVN void implicitfast_advance(MREF M, BREF B, int e);
+template <class P0> MJH_DEV int check_bad(MREF M, BREF B, int e, P0 x, int n, int which);
+// body of the forward kernel (mjhip_batch_forward, mjhip_batch_step1/2): stage-masked mj_forward with
+// the optional checks and integration of mj_step1 / mj_step2 (engine_forward.c:1884-1939)
 MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
   // pipeline use: the constraint kernel skips environments frozen by a warning
   if ((stages & MJH_STAGE_IFACTIVE) && !MJH_G(B, active, e)[0]) return;
   lds_enter(M, B, e);
+  if (stages & MJH_STAGE_CHECKPV) {
+    check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
+    check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL);
+  }
   forward(M, B, e, stages);
-  if (stages & MJH_STAGE_EULER) {
+  if (stages & MJH_STAGE_CHECKACC) check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC);
+  if (stages & MJH_STAGE_INTEGRATE) {
+    // mj_step2: implicit integrators as configured, everything else (RK4 included) is Euler
+    if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) implicitfast_advance(M, B, e);
+    else euler_advance(M, B, e);
+  } else if (stages & MJH_STAGE_EULER) {
     euler_advance(M, B, e);
     if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, MJH_T_EULER);
   }

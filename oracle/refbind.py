@@ -335,6 +335,14 @@ def mj_step(m: MjModel, d: MjData) -> None:
     m._lib.mj_step(m._address, d._address)
 
 
+def mj_step1(m: MjModel, d: MjData) -> None:
+    m._lib.mj_step1(m._address, d._address)
+
+
+def mj_step2(m: MjModel, d: MjData) -> None:
+    m._lib.mj_step2(m._address, d._address)
+
+
 def mj_forward(m: MjModel, d: MjData) -> None:
     m._lib.mj_forward(m._address, d._address)
 

@@ -78,3 +78,23 @@ def test_rollout_module_fails_loudly_without_gpu(rb):
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     with pytest.raises(RuntimeError, match="no HIP device"):
         rollout.rollout(m, d, s0, nstep=2)
+
+
+def test_mjb_reader_rejects_corrupted_sizes(tmp_path):
+    """size fields of a .mjb are validated before anything is sized from them (a negative or huge
+    count must not reach an allocation or a read)"""
+    import struct
+    from conftest import GOLDEN, HOSTSIM_LIB
+    from mujoco_amd import _capi as K
+    if not os.path.exists(HOSTSIM_LIB):
+        pytest.skip("hostsim library not built")
+    lib = K.Lib(HOSTSIM_LIB)
+    raw = bytearray(open(os.path.join(GOLDEN, "humanoid.mjb"), "rb").read())
+    for value in (-5, 2**31 - 1):
+        bad = bytearray(raw)
+        struct.pack_into("<i", bad, 5*4 + 3*4, value)          # an early int size field (after the 5-int header)
+        p = tmp_path / f"bad_{value}.mjb"
+        p.write_bytes(bytes(bad))
+        with pytest.raises(K.MjhipError, match="corrupted|does not match|mismatch"):
+            K.MjbModel(lib, str(p))
+    K.MjbModel(lib, os.path.join(GOLDEN, "humanoid.mjb"))       # the intact file still loads

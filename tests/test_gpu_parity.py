@@ -692,3 +692,37 @@ def test_rollout_api_user_inputs_and_multi_model_on_gpu(rb, hip_lib, tmp_path):
     ref = _py_rollout(rb, mlist, s0, control, spec)
     assert relerr(state, ref) <= TOL
     print("multi-model + all user inputs: rel err", relerr(state, ref))
+
+
+def test_step1_step2_split_on_gpu(rb, hip_lib, dm):
+    """mj_step1 / mj_step2 (engine_forward.c:1884-1939) on the GPU: a controller reads positions and
+    velocities between the halves; against the oracle's own split"""
+    m = humanoid_pgs_oracle(rb)
+    states = contact_rich_states(rb, m, 5, seed=4)
+    b = K.Batch(dm, len(states))
+    b.set("qpos", np.stack([s["qpos"] for s in states]))
+    b.set("qvel", np.stack([s["qvel"] for s in states]))
+    b.set("qacc_warmstart", np.stack([s["qacc_warmstart"] for s in states]))
+    ds = []
+    for s in states:
+        d = rb.MjData(m)
+        d.qpos[:] = s["qpos"]; d.qvel[:] = s["qvel"]; d.qacc_warmstart[:] = s["qacc_warmstart"]
+        ds.append(d)
+    worst = 0.0
+    for t in range(5):
+        b.step1()
+        xpos = b.get("xpos").reshape(len(states), -1, 3)
+        qvel = b.get("qvel")
+        ctrl = np.clip(-0.5*qvel[:, 6:6 + m.nu] + 0.3*(xpos[:, 1, 2:3] - 1.2), -1, 1)
+        b.set("ctrl", ctrl)
+        b.step2()
+        got_q, got_v = b.get("qpos"), b.get("qvel")
+        for e, d in enumerate(ds):
+            rb.mj_step1(m, d)
+            d.ctrl[:] = ctrl[e]
+            rb.mj_step2(m, d)
+            worst = max(worst, relerr(got_q[e], np.array(d.qpos)), relerr(got_v[e], np.array(d.qvel)))
+            # re-synchronise (the controller feeds differences back)
+            d.qpos[:] = got_q[e]; d.qvel[:] = got_v[e]
+    print("step1/step2 closed loop: worst rel err", worst)
+    assert worst <= TOL

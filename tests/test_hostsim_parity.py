@@ -903,3 +903,36 @@ def test_lean_variants_refuse_models_they_cannot_step(rb, hostsim_lib, tmp_path)
     assert b.kernel_variant() == "generic"
     with pytest.raises(K.MjhipError):
         b.set_variant("lean2")
+
+
+def test_step1_step2_split_bit_exact(rb, setup):
+    """mj_step1 / mj_step2 (engine_forward.c:1884-1939): closed-loop stepping with a controller that
+    reads positions and velocities between the two halves; bit-exact against the oracle's split and
+    equal to whole mj_step calls"""
+    m, dm = setup
+    states = contact_rich_states(rb, m, 3, seed=4)
+    b = K.Batch(dm, len(states))
+    b.set("qpos", np.stack([s["qpos"] for s in states]))
+    b.set("qvel", np.stack([s["qvel"] for s in states]))
+    b.set("qacc_warmstart", np.stack([s["qacc_warmstart"] for s in states]))
+    ds = []
+    for s in states:
+        d = rb.MjData(m)
+        d.qpos[:] = s["qpos"]; d.qvel[:] = s["qvel"]; d.qacc_warmstart[:] = s["qacc_warmstart"]
+        ds.append(d)
+    for t in range(6):
+        b.step1()
+        xpos = b.get("xpos").reshape(len(states), -1, 3)
+        qvel = b.get("qvel")
+        ctrl = np.clip(-0.5*qvel[:, 6:6 + m.nu] + 0.3*(xpos[:, 1, 2:3] - 1.2), -1, 1)    # needs step1's results
+        b.set("ctrl", ctrl)
+        b.step2()
+        for e, d in enumerate(ds):
+            rb.mj_step1(m, d)
+            assert np.array_equal(xpos[e], np.array(d.xpos))
+            d.ctrl[:] = ctrl[e]
+            rb.mj_step2(m, d)
+        got_q, got_v = b.get("qpos"), b.get("qvel")
+        for e, d in enumerate(ds):
+            assert np.array_equal(got_q[e], np.array(d.qpos)) and np.array_equal(got_v[e], np.array(d.qvel)), (t, e)
+    assert b.get("warning").sum() == 0
