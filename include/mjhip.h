@@ -103,6 +103,12 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* h
  * a feature the variant lacks. */
 MJHIP_API int mjhip_batch_set_variant(mjhipBatch* batch, const char* name);
 MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* batch);
+/* Opt-in: build AR = Y Y' + diag(R) (mj_makeAR, src/engine/engine_core_constraint.c:3009 -- the one
+ * dense contraction of the step) with v_mfma_f64_16x16x4_f64 instead of the reference-ordered
+ * vector sums.  Results then agree with the reference to rounding (tolerance parity: states within
+ * 1e-6, solver iteration counts within one), not bit for bit.  Default off ($MJHIP_MFMA=1 turns it
+ * on for new batches); measured in profiles/r02_mfma. */
+MJHIP_API int mjhip_batch_set_mfma(mjhipBatch* batch, int on);
 
 /* LDS residency plan of the batch kernels (no reference counterpart: the reference keeps mjData in
  * host DRAM).  Each environment is stepped by one 64-lane wavefront that owns `lds_bytes` of LDS;

@@ -565,6 +565,217 @@ MJH_DEV int filter_sphere(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Broad- and midphase, reproduced as per-pair predicates.
+// The reference decides which geom pairs reach the narrowphase with (a) sweep-and-prune over body
+// bounding intervals in a PCA frame whose sweep-axis end points are rounded to float (mj_broadphase /
+// mj_SAP / makeAAMM, engine_collision_driver.c:1250-1735) and (b), for bodies with several geoms,
+// a descent through two bounding-volume hierarchies with oriented-box tests (mj_collideTree /
+// mj_collideOBB, :898-1240).  Both only cull, but not always conservatively to the last bit (geoms
+// that touch to within rounding), and contact COUNTS must be exact -- so the culls are evaluated
+// here with the reference's own arithmetic instead of being argued away:
+//   * the sweep order is a pure function of the (float value, array position) of the interval end
+//     points, so "pair reported by the sweep" is a closed-form predicate of the two intervals;
+//   * the chain of BVH node pairs a geom pair has to survive is static (mjh_model_build.h).
+// They are asked lazily, by the narrowphase lanes that are about to emit a contact (bp_lazy_cull):
+// most steps of most models never need the PCA frame (a serial eigen-decomposition) or a BVH walk.
+// stage_collision runs right after kinematics, while the inertial frames are still resident.
+// ------------------------------------------------------------------------------------------------
+
+// eigen-frame of a symmetric 3x3 (mju_eig3, engine_util_solve.c:1096-1189): Jacobi rotations
+// accumulated in a quaternion, eigenvalues sorted decreasingly by quarter turns
+MJH_DEV void bp_eig3(real* eigvec, const real* mat) {
+  const real eps = MJH_MINVAL*1000;
+  real quat[4] = {1, 0, 0, 0}, eigval[3] = {0, 0, 0};
+  real D[9], tmp[9];
+  for (int iter = 0; iter < 500; iter++) {
+    q_tomat(eigvec, quat);
+    // tmp = eigvec' * mat ; D = tmp * eigvec
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+      tmp[3*r + c] = eigvec[r]*mat[c] + eigvec[3 + r]*mat[3 + c] + eigvec[6 + r]*mat[6 + c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+      D[3*r + c] = tmp[3*r]*eigvec[c] + tmp[3*r + 1]*eigvec[3 + c] + tmp[3*r + 2]*eigvec[6 + c];
+    eigval[0] = D[0]; eigval[1] = D[4]; eigval[2] = D[8];
+    // largest off-diagonal element: (0,1) about z, (0,2) about y, (1,2) about x
+    int rotk;
+    real off, drr, dcc;
+    if (fabs(D[1]) > fabs(D[2]) && fabs(D[1]) > fabs(D[5])) { rotk = 2; off = D[1]; drr = D[0]; dcc = D[4]; }
+    else if (fabs(D[2]) > fabs(D[5])) { rotk = 1; off = D[2]; drr = D[0]; dcc = D[8]; }
+    else { rotk = 0; off = D[5]; drr = D[4]; dcc = D[8]; }
+    if (fabs(off) < eps) break;
+    const real tau = (dcc - drr)/(2*off);
+    real t;
+    if (tau >= 0) t = 1.0/(tau + sqrt(1 + tau*tau));
+    else t = -1.0/(-tau + sqrt(1 + tau*tau));
+    const real c = 1.0/sqrt(1 + t*t);
+    if (c > 1.0 - eps) break;
+    real sn = (tau >= 0 ? -sqrt(0.5 - 0.5*c) : sqrt(0.5 - 0.5*c));
+    if (rotk == 1) sn = -sn;
+    real rot[4] = {sqrt(1.0 - sn*sn), rotk == 0 ? sn : (real)0, rotk == 1 ? sn : (real)0, rotk == 2 ? sn : (real)0};
+    q_normalize(rot);
+    q_mul(quat, quat, rot);
+    q_normalize(quat);
+  }
+  for (int j = 0; j < 3; j++) {
+    const int j1 = j % 2;
+    const real lo = j1 == 0 ? eigval[0] : eigval[1], hi = j1 == 0 ? eigval[1] : eigval[2];
+    if (lo + eps < hi) {
+      if (j1 == 0) { eigval[0] = hi; eigval[1] = lo; } else { eigval[1] = hi; eigval[2] = lo; }
+      const real h = 0.707106781186548;
+      const int ax = (j1 + 2) % 3;
+      real rot[4] = {h, ax == 0 ? h : (real)0, ax == 1 ? h : (real)0, ax == 2 ? h : (real)0};
+      q_mul(quat, quat, rot);
+      q_normalize(quat);
+    }
+  }
+  q_tomat(eigvec, quat);
+}
+
+// oriented-box overlap of two boxes given as (centre[3], half[3]) in frames (pos, mat), Gottschalk's
+// 6 face axes (mj_collideOBB, :898-991).  CACHED: the BVH-node form, which goes through the products
+// of the frame axes; else the leaf form, which goes through the box centres.  1 = may overlap.
+template <int CACHED, class A1, class A2, class P1, class M1, class P2, class M2>
+MJH_DEV int bp_obb(A1 box1, A2 box2, P1 pos1, M1 mat1, P2 pos2, M2 mat2, real margin) {
+  const int inf1a = box1[3] >= MJH_MAXVAL, inf1b = box1[4] >= MJH_MAXVAL, inf1c = box1[5] >= MJH_MAXVAL;
+  const int inf2a = box2[3] >= MJH_MAXVAL, inf2b = box2[4] >= MJH_MAXVAL, inf2c = box2[5] >= MJH_MAXVAL;
+  if ((inf1a && inf1b && inf1c) || (inf2a && inf2b && inf2c)) return 1;
+  const int infinite1 = inf1a || inf1b || inf1c, infinite2 = inf2a || inf2b || inf2c;
+  // normal[i][j] = column j of mat_i
+  for (int j = 0; j < 2; j++) {          // box whose face normals are tested
+    if (j == 0 ? infinite2 : infinite1) continue;
+    for (int k = 0; k < 3; k++) {
+      const V3 nk = j == 0 ? mcol(mat1, k) : mcol(mat2, k);
+      real proj[2], radius[2];
+      for (int i = 0; i < 2; i++) {
+        const V3 a0 = i == 0 ? mcol(mat1, 0) : mcol(mat2, 0);
+        const V3 a1 = i == 0 ? mcol(mat1, 1) : mcol(mat2, 1);
+        const V3 a2 = i == 0 ? mcol(mat1, 2) : mcol(mat2, 2);
+        const real bc0 = i == 0 ? (real)box1[0] : (real)box2[0], bc1 = i == 0 ? (real)box1[1] : (real)box2[1], bc2 = i == 0 ? (real)box1[2] : (real)box2[2];
+        const real bh0 = i == 0 ? (real)box1[3] : (real)box2[3], bh1 = i == 0 ? (real)box1[4] : (real)box2[4], bh2 = i == 0 ? (real)box1[5] : (real)box2[5];
+        // product[adr + l] = normal[i][l] . normal[j][k]
+        const real pr0 = dot(a0, nk), pr1 = dot(a1, nk), pr2 = dot(a2, nk);
+        if (CACHED) {
+          const V3 xp = i == 0 ? ld3(pos1) : ld3(pos2);
+          proj[i] = bc0*pr0 + bc1*pr1 + bc2*pr2 + dot(xp, nk);
+        } else {
+          const V3 xp = i == 0 ? ld3(pos1) : ld3(pos2);
+          const V3 ctr = (i == 0 ? mmul(mat1, V3{bc0, bc1, bc2}) : mmul(mat2, V3{bc0, bc1, bc2})) + xp;
+          proj[i] = dot(ctr, nk);
+        }
+        radius[i] = fabs(bh0*pr0) + fabs(bh1*pr1) + fabs(bh2*pr2);
+      }
+      if (radius[0] + radius[1] + margin < fabs(proj[1] - proj[0])) return 0;
+    }
+  }
+  return 1;
+}
+
+// PCA frame of the non-world geom positions (mj_broadphase, :1627-1660); 0 if there is none
+template <class GX>
+MJH_DEV int bp_frame(MREF M, GX gx, real* frame) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  real cen[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int g = 0; g < s.ngeom; g++) if (M.geom_bodyid[g]) { cen[0] += gx[3*g]; cen[1] += gx[3*g + 1]; cen[2] += gx[3*g + 2]; cnt++; }
+  if (cnt == 0 || s.nbp < 2) return 0;
+  const real inv = 1.0/cnt;
+  cen[0] *= inv; cen[1] *= inv; cen[2] *= inv;
+  real cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int g = 0; g < s.ngeom; g++) if (M.geom_bodyid[g]) {
+    const real d0 = gx[3*g] - cen[0], d1 = gx[3*g + 1] - cen[1], d2 = gx[3*g + 2] - cen[2];
+    const real D00 = d0*d0, D01 = d0*d1, D02 = d0*d2, D11 = d1*d1, D12 = d1*d2, D22 = d2*d2;
+    cov[0] += D00; cov[1] += D01; cov[2] += D02; cov[3] += D01; cov[4] += D11; cov[5] += D12;
+    cov[6] += D02; cov[7] += D12; cov[8] += D22;
+  }
+  for (int k = 0; k < 9; k++) cov[k] *= inv;
+  bp_eig3(frame, cov);
+  return 1;
+}
+
+// bounding interval of a body along the three frame axes (makeAAMM, :1250-1350)
+template <class GX, class GM>
+MJH_DEV void bp_body_interval(MREF M, GX gx, GM gm, int body, const real* frame, real* lo, real* hi) {
+  const int g0 = M.body_geomadr[body], g1 = g0 + M.body_geomnum[body];
+  for (int g = g0; g < g1; g++) {
+    const real margin = M.geom_bpmargin[g];
+    auto box = M.geom_aabb + 6*g;
+    crptr xp = gx + 3*g; crptr xm = gm + 9*g;
+    const V3 ctr = mmul(xm, V3{box[0], box[1], box[2]}) + ld3(xp);
+    const real rhalf = M.geom_rbound[g];
+    for (int j = 0; j < 3; j++) {
+      const V3 fj{frame[3*j], frame[3*j + 1], frame[3*j + 2]};
+      const real bcen = dot(ctr, fj);
+      const real bhalf = fabs(box[3]*dot(mcol(xm, 0), fj)) + fabs(box[4]*dot(mcol(xm, 1), fj)) + fabs(box[5]*dot(mcol(xm, 2), fj));
+      const real rcen = dot(ld3(xp), fj);
+      const real l = r_max(rcen - rhalf, bcen - bhalf) - margin;
+      const real h = r_min(rcen + rhalf, bcen + bhalf) + margin;
+      if (g == g0) { lo[j] = l; hi[j] = h; }
+      else { lo[j] = r_min(lo[j], l); hi[j] = r_max(hi[j], h); }
+    }
+  }
+}
+
+// would mj_SAP report the body pair at positions (a < b) of the collidable list?  Neither interval
+// ends before the other begins in the order of the stable sort of (float end point, array position:
+// 2*id for a minimum, 2*id + 1 for a maximum), and the other two axes overlap in double precision
+// (:1439-1533)
+template <class GX, class GM>
+MJH_DEV int bp_sap_reports(MREF M, GX gx, GM gm, const real* frame, int sap) {
+  const int a = sap & 0xffff, b = sap >> 16;
+  real alo[3], ahi[3], blo[3], bhi[3];
+  bp_body_interval(M, gx, gm, M.bp_body[a], frame, alo, ahi);
+  bp_body_interval(M, gx, gm, M.bp_body[b], frame, blo, bhi);
+  const float amin = (float)alo[0], amax = (float)ahi[0], bmin = (float)blo[0], bmax = (float)bhi[0];
+  const int a_ends_first = amax < bmin || (amax == bmin && 2*a + 1 < 2*b);
+  const int b_ends_first = bmax < amin || (bmax == amin && 2*b + 1 < 2*a);
+  return !a_ends_first && !b_ends_first &&
+         !(alo[1] > bhi[1] || blo[1] > ahi[1] || alo[2] > bhi[2] || blo[2] > ahi[2]);
+}
+
+// The lazy broad / midphase check of stage_collision, out of line so that the narrowphase loop does
+// not carry its registers: a lane with p >= 0 is about to emit a contact of static pair p and asks
+// whether the reference would have let that pair reach its narrowphase.
+//   * sweep-and-prune (pairs with pair_sap >= 0): needs the PCA frame, computed by the first call of
+//     a step that needs it and parked in the environment's global scratch
+//     (state: -1 not yet, 0 no frame, 1 parked);
+//   * BVH midphase (route 2): the pair's static chain of node-pair tests in the bodies' inertial
+//     frames, then the leaf test on the geoms' own boxes with the summed margins (:1075-1083).
+// Returns (state' + 1) | reached << 2.
+MJH_DEVN int bp_lazy_cull(MREF M_, BREF B_, int e_, int p, int state) {
+  MJH_ENTER(M_, B_, e_);
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  const int sap = p >= 0 ? (int)M.pair_sap[p] : -1;
+  int ok = p >= 0;
+  if (wv_any(sap >= 0)) {
+    rptr park = MJH_G(B, scratch, e);
+    real frame[9];
+    if (state < 0) {
+      state = bp_frame(M, gx, frame);
+      if (state && wv_lane() == 0) for (int k = 0; k < 9; k++) park[k] = frame[k];
+      wv_sync();
+    } else if (state) {
+      for (int k = 0; k < 9; k++) frame[k] = park[k];
+    }
+    if (sap >= 0) ok = state && bp_sap_reports(M, gx, gm, frame, sap);
+  }
+  if (ok && M.pair_route[p] == 2) {
+    crptr xipos = MJH_F(B, xipos, e);
+    crptr ximat = MJH_F(B, ximat, e);
+    const int ga = M.pair_geom1[p], gb = M.pair_geom2[p];
+    // the chain was built with body 1 = the lower body id; the geoms are stored type-ordered
+    int b1 = M.geom_bodyid[ga], b2 = M.geom_bodyid[gb], g1 = ga, g2 = gb;
+    if (b1 > b2) { const int t = b1; b1 = b2; b2 = t; g1 = gb; g2 = ga; }
+    const real bmargin = M.pair_bodymargin[p], lmargin = M.pair_margin[p];
+    for (int q = M.pair_mid_adr[p]; q < M.pair_mid_adr[p + 1] && ok; q++)
+      ok = bp_obb<1>(M.bvh_aabb + 6*M.pair_mid[2*q], M.bvh_aabb + 6*M.pair_mid[2*q + 1],
+                     xipos + 3*b1, ximat + 9*b1, xipos + 3*b2, ximat + 9*b2, bmargin);
+    // (the leaf's bounding-sphere test with the summed margins is the narrowphase's own filter)
+    if (ok) ok = bp_obb<0>(M.geom_aabb + 6*g1, M.geom_aabb + 6*g2, gx + 3*g1, gm + 9*g1, gx + 3*g2, gm + 9*g2, lmargin);
+  }
+  return (state + 1) | (ok << 2);
+}
+
 // contact record `c` of the environment <- one hit of static pair p
 // (mj_narrowphase fill + mj_setContact, engine_collision_driver.c:2050-2075, :1839-1875)
 MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
@@ -603,6 +814,9 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
 
   int base = 0;        // contacts emitted by earlier chunks (uniform over the group)
   int overflow = 0;
+  // sweep-and-prune predicate of the reference, evaluated only for pairs that would emit a contact;
+  // the PCA frame is computed the first time a group needs it (-1: not yet)
+  int frame_state = -1;
   for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
     const int p = p0 + wv_lane();
     Hit ha, hb;          // the (at most two) contacts of my pair's point collider
@@ -637,6 +851,29 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             }
             break;
         }
+      }
+    }
+    if (s.nbp) {
+      // would the reference's broad / midphase have let the pair reach its narrowphase at all?
+      // (asked only by lanes about to emit a contact of a pair that is subject to one of the culls)
+      int ask = (p < s.npair && (n > 0 || coop) && (M.pair_sap[p] >= 0 || M.pair_route[p] == 2)) ? p : -1;
+      if (ask >= 0 && n > 0) {
+        // A contact at distance `dist` below the pair's margin means the two geoms' projections on ANY
+        // axis come within dist of each other, so the (margin-inflated) bounds the culls compare overlap
+        // by at least margin - dist.  If that slack exceeds what rounding the sweep's end points to
+        // float (2^-24 relative, two end points within body reach of the geom centres) can eat, the
+        // pair certainly reached the reference's narrowphase: no need to ask.
+        const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+        const real deepest = n > 1 ? r_min(ha.dist, hb.dist) : ha.dist;
+        const real slack = M.pair_margin[p] - deepest;
+        const real reach = fabs(gx[3*g1]) + fabs(gx[3*g1 + 1]) + fabs(gx[3*g1 + 2]) + fabs(gx[3*g2]) + fabs(gx[3*g2 + 1]) +
+                           fabs(gx[3*g2 + 2]) + M.body_bpext[M.geom_bodyid[g1]] + M.body_bpext[M.geom_bodyid[g2]];
+        if (slack > 1e-6*(1 + reach)) ask = -1;
+      }
+      if (wv_any(ask >= 0)) {
+        const int r = bp_lazy_cull(M, B, e, ask, frame_state);
+        frame_state = (r & 3) - 1;
+        if (ask >= 0 && !(r >> 2)) { n = 0; coop = 0; }
       }
     }
     // a pair whose collider mjhip does not have reached the narrowphase: the result could differ

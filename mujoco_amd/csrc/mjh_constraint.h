@@ -839,6 +839,43 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
     for (int i = 0; i < nv; i++) x[i] *= sqrtInvD[i];
   }
   wv_sync();
+#if !MJH_LANE_MODE && MJH_W == 64 && !defined(MJH_HOSTSIM)
+  // The one dense contraction of the step on the matrix cores (opt-in, mjhip_batch_set_mfma):
+  // AR is tiled 16 x 16, a tile is ceil(nv/4) v_mfma_f64_16x16x4_f64 over the dof dimension with
+  // A = rows of Y of the tile's row block, B = rows of Y of its column block (lane l feeds
+  // element [l & 15][4c + (l >> 4)] of both), accumulators in 4 VGPR pairs per lane:
+  // D[(l >> 4) + 4 r][l & 15].  The hardware's summation order (and its fused multiply-adds)
+  // differ from mju_sqrMatTD's, so this path agrees with the reference to rounding (1e-15 relative
+  // on AR), not bit for bit: solver iteration counts may move by one.
+  if (B.mfma) {
+    typedef double d4_ __attribute__((ext_vector_type(4)));
+    const int lane = wv_lane(), r16 = lane & 15, kq = lane >> 4;
+    const int nt = (nefc + 15) >> 4;
+    for (int I = 0; I < nt; I++) {
+      for (int K = 0; K <= I; K++) {
+        d4_ acc = {0, 0, 0, 0};
+        const int ri = 16*I + r16, rk = 16*K + r16;
+        for (int c = 0; c < nv; c += 4) {
+          const int j = c + kq;
+          const real a = (ri < nefc && j < nv) ? (real)Y[(size_t)ri*nv + j] : (real)0;
+          const real b = (rk < nefc && j < nv) ? (real)Y[(size_t)rk*nv + j] : (real)0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) {
+          const int row = 16*I + kq + 4*r, col = 16*K + r16;
+          if (row < nefc && col <= row) {
+            real v = acc[r];
+            if (row == col) v += R[row];
+            AR[(size_t)row*nefc + col] = v;
+            AR[(size_t)col*nefc + row] = v;
+          }
+        }
+      }
+    }
+    wv_sync();
+    return;
+  }
+#endif
   // AR lower triangle: AR[i][k] = sum_j Y[k][j]*Y[i][j] in j order (mju_sqrMatTD on Y', engine_util_blas.c:664)
   const int npairs = nefc*(nefc + 1)/2;
   MJH_FOR_LANES(w, npairs) {

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "mjh_types.h"
@@ -491,7 +492,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   const int dsbl_filterparent = m->opt.disableflags & mjDSBL_FILTERPARENT;
   const int midphase = !(m->opt.disableflags & mjDSBL_MIDPHASE);
   const int override_ = m->opt.enableflags & mjENBL_OVERRIDE;
-  struct GP { int g1, g2, ipair; };
+  struct GP { int g1, g2, ipair; int b1 = -1, b2 = -1, route = 0; };
+  std::vector<int> pair_b1, pair_b2;     // body pair of every emitted geom pair (-1: predefined)
   int maxcon_total = 0;
   // predefined <pair>s are merged into the list in signature order, ahead of their body pair's own
   // geom pairs (mj_collision, engine_collision_driver.c:651-664); a geom pair that duplicates a
@@ -565,6 +567,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         H->pair_dim.push_back(condim);
         H->pair_maxcon.push_back(maxcon);
         H->pair_func.push_back(func);
+        H->pair_route.push_back(gp.route);
+        pair_b1.push_back(gp.b1);
+        pair_b2.push_back(gp.b2);
         H->pair_margin.push_back(margin + gap);
         H->pair_includemargin.push_back(margin);
         for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
@@ -616,12 +621,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
             if ((unsigned)m->pair_signature[k] == sig_here &&
                 ((m->pair_geom1[k] == g1 && m->pair_geom2[k] == g2) || (m->pair_geom1[k] == g2 && m->pair_geom2[k] == g1))) dup = true;
           if (dup) continue;
-          gps.push_back({a, b, -1});
+          gps.push_back({a, b, -1, b1, b2, 1});
         }
       }
       // midphase route: contacts are sorted by the STORED (type-ordered) geom ids (contactcompare :410-440)
       bool single = m->body_geomnum[b1] == 1 && m->body_geomnum[b2] == 1;
       if (!single && midphase && m->body_bvhadr[b1] >= 0 && m->body_bvhadr[b2] >= 0) {
+        for (GP& x : gps) x.route = 2;
         std::stable_sort(gps.begin(), gps.end(), [](const GP& x, const GP& y) {
           return x.g1 != y.g1 ? x.g1 < y.g1 : x.g2 < y.g2; });
       }
@@ -639,6 +645,113 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     if (!emit_pairs(ex)) return false;
   }
   s.npair = (int)H->pair_geom1.size();
+
+  // ---------------- broad / midphase emulation tables (mjh_collision.h: stage_broadphase) ----------------
+  // The reference culls BODY pairs by sweep-and-prune over float-rounded bounding intervals in a
+  // PCA frame (mj_broadphase / mj_SAP, engine_collision_driver.c:1439-1735) and, for bodies with
+  // several geoms, walks two BVHs testing oriented boxes (mj_collideTree / mj_collideOBB, :898-1240).
+  // Both are functions of the current poses; which tests a given geom pair has to pass is static:
+  //   * sweep-and-prune: the pair of positions of its bodies in the collidable-body list, unless one
+  //     body is always paired (world geoms, static bodies with planes, :1588-1624);
+  //   * midphase: the chain of BVH node pairs from (root, root) down to the pair's two leaves -- the
+  //     descent rule (a leaf never descends, else the box with the larger surface does, :1185-1236)
+  //     only reads model constants.
+  {
+    std::vector<int> pos(m->nbody, -1);
+    for (int b = 1; b < m->nbody; b++)
+      if (m->body_contype[b] || m->body_conaffinity[b]) { pos[b] = (int)H->bp_body.size(); H->bp_body.push_back(b); }
+    auto always = [&](int b) {
+      if (b == 0) return m->body_geomnum[0] > 0;
+      if (m->body_dofnum[m->body_weldid[b]] != 0) return false;
+      for (int g = m->body_geomadr[b]; g < m->body_geomadr[b] + m->body_geomnum[b]; g++)
+        if (m->geom_type[g] == mjGEOM_PLANE) return true;
+      return false;
+    };
+    H->pair_sap.assign(s.npair, -1);
+    H->pair_mid_adr.assign((size_t)s.npair + 1, 0);
+    H->pair_bodymargin.assign(s.npair, 0);
+    bool any_sap = false;
+    for (int p = 0; p < s.npair; p++) {
+      H->pair_mid_adr[p] = (int)H->pair_mid.size()/2;
+      const int b1 = pair_b1[p], b2 = pair_b2[p];
+      if (b1 < 0) continue;                                   // predefined pair: never culled by body
+      if (!always(b1) && !always(b2)) {
+        MJH_REJECT(pos[b1] < 0 || pos[b2] < 0 || H->bp_body.size() >= 0x8000, "internal: broadphase body list");
+        H->pair_sap[p] = std::min(pos[b1], pos[b2]) | (std::max(pos[b1], pos[b2]) << 16);
+        any_sap = true;
+      }
+      if (H->pair_route[p] != 2) continue;
+      const real bm = m->body_margin[b1] + m->body_margin[b2];
+      H->pair_bodymargin[p] = override_ ? (real)m->opt.o_margin : bm;
+      // which geom of the (type-ordered) pair belongs to which body
+      const int ga = m->geom_bodyid[H->pair_geom1[p]] == b1 ? H->pair_geom1[p] : H->pair_geom2[p];
+      const int gb = ga == H->pair_geom1[p] ? H->pair_geom2[p] : H->pair_geom1[p];
+      const int adr1 = m->body_bvhadr[b1], adr2 = m->body_bvhadr[b2];
+      const int* child1 = m->bvh_child + 2*adr1;
+      const int* child2 = m->bvh_child + 2*adr2;
+      // does the subtree of `node` hold the leaf of geom g?
+      std::function<bool(const int*, int, int, int)> holds = [&](const int* child, int adr, int node, int g) -> bool {
+        if (node < 0) return false;
+        if (child[2*node] < 0 && child[2*node + 1] < 0) return m->bvh_nodeid[adr + node] == g;
+        return holds(child, adr, child[2*node], g) || holds(child, adr, child[2*node + 1], g);
+      };
+      int n1 = 0, n2 = 0;
+      for (int guard = 0; guard < 4096; guard++) {
+        const bool leaf1 = child1[2*n1] < 0 && child1[2*n1 + 1] < 0;
+        const bool leaf2 = child2[2*n2] < 0 && child2[2*n2 + 1] < 0;
+        if (leaf1 && leaf2) break;
+        H->pair_mid.push_back(adr1 + n1);
+        H->pair_mid.push_back(adr2 + n2);
+        bool down1;
+        if (!leaf1 && leaf2) down1 = true;
+        else if (leaf1 && !leaf2) down1 = false;
+        else {
+          const mjtNum* a1 = m->bvh_aabb + 6*(adr1 + n1);
+          const mjtNum* a2 = m->bvh_aabb + 6*(adr2 + n2);
+          const mjtNum x1 = a1[3] - a1[0], y1 = a1[4] - a1[1], z1 = a1[5] - a1[2];
+          const mjtNum x2 = a2[3] - a2[0], y2 = a2[4] - a2[1], z2 = a2[5] - a2[2];
+          down1 = (x1*y1 + y1*z1 + z1*x1) > (x2*y2 + y2*z2 + z2*x2);
+        }
+        if (down1) n1 = holds(child1, adr1, child1[2*n1], ga) ? child1[2*n1] : child1[2*n1 + 1];
+        else n2 = holds(child2, adr2, child2[2*n2], gb) ? child2[2*n2] : child2[2*n2 + 1];
+        MJH_REJECT(n1 < 0 || n2 < 0, "internal: BVH chain");
+      }
+      MJH_REJECT(m->bvh_nodeid[adr1 + n1] != ga || m->bvh_nodeid[adr2 + n2] != gb, "internal: BVH leaves");
+    }
+    H->pair_mid_adr[s.npair] = (int)H->pair_mid.size()/2;
+    s.nmid = (int)H->pair_mid.size()/2;
+    s.nbp = (int)H->bp_body.size();
+    bool any_mid = false;
+    for (int p = 0; p < s.npair; p++) if (H->pair_route[p] == 2) any_mid = true;
+    if (!any_sap && !any_mid) { s.nbp = 0; H->bp_body.clear(); }       // nothing to cull: the stage is skipped
+    s.nbvh = (int)m->nbvhstatic;
+    copy_arr(H->bvh_aabb, m->bvh_aabb, 6*(int)m->nbvhstatic);
+    copy_arr(H->geom_aabb, m->geom_aabb, 6*m->ngeom);
+    H->geom_bpmargin.resize(m->ngeom);
+    for (int g = 0; g < m->ngeom; g++)
+      H->geom_bpmargin[g] = override_ ? (real)(0.5*m->opt.o_margin) : (real)(m->geom_margin[g] + m->geom_gap[g]);
+    // reach of a body around any of its geom centres: an upper bound on how far an end point of the
+    // body's bounding interval can lie from the projection of that centre (geoms are rigidly attached,
+    // so centre-to-centre distances are pose independent).  Bounds the float rounding of the sweep.
+    H->body_bpext.assign(m->nbody, 0);
+    for (int b = 0; b < m->nbody; b++) {
+      real far = 0, pad = 0;
+      const int g0 = m->body_geomadr[b], g1 = g0 + m->body_geomnum[b];
+      for (int g = g0; g < g1; g++) {
+        pad = std::max(pad, (real)(m->geom_rbound[g] + std::fabs(H->geom_bpmargin[g])));
+        if (m->geom_rbound[g] <= 0) pad = 1e30;            // planes: no finite interval, always ask
+        for (int h = g0; h < g1; h++) {
+          real d2 = 0;
+          for (int k = 0; k < 3; k++) { real d = m->geom_pos[3*g + k] - m->geom_pos[3*h + k]; d2 += d*d; }
+          far = std::max(far, (real)std::sqrt(d2));
+        }
+      }
+      H->body_bpext[b] = far + pad;
+    }
+    s.npassw = (s.npair + 31)/32;
+    s.bp_any_sap = any_sap ? 1 : 0;
+    s.bp_any_mid = any_mid ? 1 : 0;
+  }
 
   // ---------------- capacities ---------------------------------------------------------------------------
   int nlimit = 0;

@@ -112,15 +112,19 @@ static bool upload_vec(mjhipModel_* M, const std::vector<T>& v, void* slot, std:
 // Fields alive during constraint assembly/solve are packed first from offset 0; the bytes above
 // them form the dynamic region handed to efc_layout().  Fields that die before MJH_T_MAKE may sit
 // anywhere, including on top of that region.  A field that does not fit stays global.
-struct PlanField { const char* name; int* l; int* io; int bytes; int t0, t1; int off; };
+struct PlanField { const char* name; int* l; int* io; int bytes; int t0, t1; int off; int born = 0; };
 
 // span_first..span_last: the timeline points the kernel using this plan executes.  Only fields
 // whose lifetime intersects the span are placed.  `skip`: fields alive across the span that the
 // kernel never touches (left in HBM); `readonly`: persistent fields the kernel reads but does not
 // modify (loaded at entry, not stored at exit).
-static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
+static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
                      const std::vector<std::string>& skip, const std::vector<std::string>& readonly,
                      std::string* report) {
+  // executed: bit t set = the kernel using this plan runs timeline point t
+  auto touches = [&](int t0, int t1) { for (int t = t0; t <= t1; t++) if ((executed >> t) & 1) return true; return false; };
+  int span_first = 0, span_last = 0;
+  for (int t = 0; t < 32; t++) if ((executed >> t) & 1) { if (!span_first) span_first = t; span_last = t; }
   DBatch& L = Bt->L;
   L = Bt->D;
   const DSizes& s = Bt->model->H.s;
@@ -128,15 +132,18 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
   auto listed = [](const std::vector<std::string>& v, const char* n) {
     return std::find(v.begin(), v.end(), std::string(n)) != v.end();
   };
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (t0) <= span_last && span_first <= (t1) && !listed(skip, #name)) \
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (t0) <= span_last && span_first <= (t1) && !listed(skip, #name)) \
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_INT_FIELDS(X)
 #undef X
   budget &= ~7;
+  // a field this kernel does not produce is copied in at kernel entry: it occupies its bytes from the
+  // kernel's first stage on, whatever its nominal first write is
+  for (auto& x : f) { x.born = (executed >> x.t0) & 1; if (!x.born) x.t0 = std::min(x.t0, span_first); }
   auto live_in = [](const PlanField& a, int t0, int t1) { return a.t0 <= t1 && t0 <= a.t1; };
   auto place = [&](PlanField& x, int limit) -> bool {
     // candidate offsets: 0 and the end of every placed field x conflicts with
@@ -193,9 +200,9 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, int span_first, int span_last,
     *x.l = x.off;
     if (x.off < 0) continue;
     const bool persistent = (x.t0 == MJH_T_BEGIN);
-    const bool live_in = x.t0 < span_first;                       // produced before this kernel
+    const bool born_here = x.born != 0;                           // this kernel runs the stage that writes it
+    const bool live_in = !born_here;                              // produced by another kernel / launch
     const bool live_out = x.t1 > span_last;                       // consumed after it
-    const bool born_here = x.t0 >= span_first;
     int io = 0;
     if (live_in) io |= 1;
     if (live_out && (born_here || (persistent && !listed(readonly, x.name)))) io |= 2;
@@ -245,6 +252,10 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
     delete M;
     return nullptr;
   }
+  // ($MJHIP_BROADPHASE=0: skip the reproduction of the reference's broad / midphase culls -- every
+  // static pair goes to the bounding-sphere filter and the narrowphase; conservative, but geoms that
+  // touch to within rounding can then differ from the reference in contact count.  For A/B timing.)
+  if (const char* ev = getenv("MJHIP_BROADPHASE")) if (atoi(ev) == 0) M->H.s.nbp = 0;
   M->D.s = M->H.s;
   M->D.o = M->H.o;
   bool ok = true;
@@ -384,6 +395,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   }
   // launch balancing ($MJHIP_BALANCE=0 keeps the identity order; measured in profiles/r02_balance)
   if (const char* ev = getenv("MJHIP_BALANCE")) Bt->balance = atoi(ev) != 0;
+  if (const char* ev = getenv("MJHIP_MFMA")) { Bt->D.mfma = atoi(ev) != 0; Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr); }
   // kernel variant: the leanest mapping whose feature set covers the model ($MJHIP_VARIANT overrides)
   Bt->variant = default_variant(M, Bt->soa);
   // ($MJHIP_VARIANT is a preference: batches it cannot serve -- SoA layout, models that need
@@ -450,6 +462,15 @@ MJHIP_API int mjhip_batch_set_variant(mjhipBatch* Bt, const char* name) {
   if (Bt->L_dev) return mjhip_batch_plan_lds(Bt, Bt->L.lds_bytes ? Bt->L.lds_bytes : Bt->lds_request) < 0 ? -3 : 0;
   return 0;
 }
+// AR = Y Y' on the matrix cores (tolerance parity); default off, $MJHIP_MFMA=1 turns it on at creation
+MJHIP_API int mjhip_batch_set_mfma(mjhipBatch* Bt, int on) {
+  if (!Bt) return -1;
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
+  Bt->D.mfma = Bt->L.mfma = on ? 1 : 0;
+  if (!Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr) || !Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) ||
+      !Backend::sync(nullptr)) { set_err("mjhip_batch_set_mfma: descriptor upload failed"); return -2; }
+  return 0;
+}
 MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* Bt) { return Bt ? mjh_variant_name(Bt->variant) : ""; }
 
 MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
@@ -494,11 +515,14 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
     // the constraint kernel of the per-step pipeline: collision .. PGS
     std::vector<std::string> skip = {"time", "act", "ctrl", "qfrc_applied", "qfrc_smooth", "qLDiagInv"};
     skip.insert(skip.end(), eqskip.begin(), eqskip.end());
-    plan_lds(Bt, lds_bytes, MJH_T_COLLISION, MJH_T_CONSTRAINT, skip,
-             {"qpos", "qvel", "qacc_warmstart"}, &Bt->plan_report);
+    unsigned ex = 1u << MJH_T_COLLISION;
+    for (int t = MJH_T_MAKE; t <= MJH_T_CONSTRAINT; t++) ex |= 1u << t;
+    plan_lds(Bt, lds_bytes, ex, skip, {"qpos", "qvel", "qacc_warmstart"}, &Bt->plan_report);
   } else {
     // the single wave-per-environment kernel: the whole step
-    plan_lds(Bt, lds_bytes, MJH_T_KIN, MJH_T_EULER, eqskip, {}, &Bt->plan_report);
+    unsigned ex = 0;
+    for (int t = MJH_T_KIN; t <= MJH_T_EULER; t++) ex |= 1u << t;
+    plan_lds(Bt, lds_bytes, ex, eqskip, {}, &Bt->plan_report);
   }
   Bt->L.xfrc_on = Bt->xfrc_on ? 1 : 0;
   if (!Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) || !Backend::sync(nullptr)) {

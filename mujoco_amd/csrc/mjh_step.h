@@ -134,6 +134,10 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   const int pgs = !MJH_HAS(MJH_FT_PRIMAL) || (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
     MJH_RUN(MJH_T_KIN, stage_kinematics(M, B, e));
+  }
+  // (collision needs nothing but the frames kinematics just produced)
+  if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
+  if (stages & MJH_STAGE_KINEMATICS) {
     MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
     MJH_RUN(MJH_T_TENDON, stage_tendon(M, B, e));
   }
@@ -152,7 +156,6 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));
     MJH_RUN(MJH_T_ACCEL, stage_acceleration(M, B, e));
   }
-  if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
   if (stages & MJH_STAGE_MAKE) {
     MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
     stage_island(M, B, e);

@@ -95,6 +95,15 @@
   X(pair_dim, s.npair)                         \
   X(pair_maxcon, s.npair)                      \
   X(pair_func, s.npair)                        \
+  /* broad / midphase emulation (stage_broadphase): index pair into the collidable-body list for  \
+     the sweep-and-prune test (lo | hi<<16, -1: not subject to it), route (0 predefined pair, 1   \
+     direct, 2 BVH midphase), and for route 2 the static chain of BVH node pairs from the roots   \
+     to the pair's leaves (node indices into bvh_aabb) */                                          \
+  X(pair_sap, s.npair)                         \
+  X(pair_route, s.npair)                       \
+  X(pair_mid_adr, s.npair + 1)                 \
+  X(pair_mid, 2 * s.nmid)                      \
+  X(bp_body, s.nbp)                            \
   /* equality constraints (connect / weld / joint / tendon) */ \
   X(eq_type, s.neq)                            \
   X(eq_obj1id, s.neq)                          \
@@ -147,6 +156,11 @@
   X(geom_quat, 4 * s.ngeom)                    \
   X(geom_size, 3 * s.ngeom)                    \
   X(geom_rbound, s.ngeom)                      \
+  X(geom_aabb, 6 * s.ngeom)                    \
+  X(geom_bpmargin, s.ngeom)                    \
+  X(bvh_aabb, 6 * s.nbvh)                      \
+  X(pair_bodymargin, s.npair)                  \
+  X(body_bpext, s.nbody)                       \
   X(site_pos, 3 * s.nsite)                     \
   X(site_quat, 4 * s.nsite)                    \
   X(site_size, 3 * s.nsite)                    \
@@ -220,6 +234,11 @@ struct DSizes {
   int nlevel;      // depth levels of the kinematic tree (world = level 0)
   int nvw;         // 32-bit words per dof-ancestor mask = (nv+31)/32
   int npair;       // static candidate geom pairs (reference contact order)
+  int nbp;         // collidable bodies (sweep-and-prune participants), 0: no pair is subject to the broadphase cull
+  int nbvh, nmid;  // static BVH nodes; entries of the midphase chains
+  int npassw;      // 32-bit words of the per-step pair pass mask
+  int bp_any_mid;  // some pair takes the BVH midphase route
+  int bp_any_sap;  // some pair is subject to the sweep-and-prune cull (else only midphase tests run)
   int nmoment;     // capacity of the sparse actuator_moment (sum of per-actuator row capacity)
   int nconmax;     // per-env contact capacity
   int nconlds;     // contact slots kept in LDS by the residency plan
@@ -276,10 +295,13 @@ struct DModel {
 //
 // step timeline (the order stages run in; lifetimes are [first write, last read] on this axis)
 enum {
-  MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COMPOS = 2, MJH_T_TENDON = 3, MJH_T_CRB = 4, MJH_T_FACTOR = 5,
-  MJH_T_TRANSMISSION = 6, MJH_T_TAVEL = 7, MJH_T_COMVEL = 8, MJH_T_PASSIVE = 9, MJH_T_RNE = 10,
-  MJH_T_ACTUATION = 11, MJH_T_ACCEL = 12,
-  MJH_T_COLLISION = 13, MJH_T_MAKE = 14, MJH_T_PROJECT = 15, MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17,
+  // (collision runs right after kinematics: it only needs the geom and inertial frames, which can
+  // then leave LDS early -- the contact slots that replace them are smaller -- and its broad / midphase
+  // checks find the inertial frames still resident)
+  MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COLLISION = 2, MJH_T_COMPOS = 3, MJH_T_TENDON = 4, MJH_T_CRB = 5, MJH_T_FACTOR = 6,
+  MJH_T_TRANSMISSION = 7, MJH_T_TAVEL = 8, MJH_T_COMVEL = 9, MJH_T_PASSIVE = 10, MJH_T_RNE = 11,
+  MJH_T_ACTUATION = 12, MJH_T_ACCEL = 13,
+  MJH_T_MAKE = 14, MJH_T_PROJECT = 15, MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17,
   MJH_T_FINISH = 18, MJH_T_EULER = 19, MJH_T_END = 20,
 };
 #define MJH_T_GLB (-1)         // global only
@@ -434,6 +456,7 @@ struct DBatch {
   int dyn2_off;      // [dyn2_off, dyn_off): holds fields that die with MJH_T_MAKE; free from MJH_T_PROJECT on
   int nconlds;       // contact slots resident in LDS
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
+  int mfma;          // 1: AR = Y Y' on the matrix cores (v_mfma_f64_16x16x4_f64): tolerance parity, not bit parity
   int xfrc_on;       // 1: xfrc_applied may be non-zero (mj_xfrcAccumulate runs; xipos stays readable at MJH_T_ACCEL)
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_REAL_FIELDS(X)

@@ -581,3 +581,56 @@ SURFACEVEL_XML = """<mujoco>
   </worldbody>
 </mujoco>
 """
+
+
+# geoms that touch EXACTLY (to the last bit): the reference's sweep-and-prune rounds the sweep-axis
+# end points to float and breaks ties by array position (engine_collision_driver.c:1456-1470), so
+# whether such a body pair reaches the narrowphase depends on body order; plus stacked spheres on a
+# plane and a pair that overlaps by one ulp
+TOUCH_XML = """
+<mujoco>
+  <option timestep="0.002" solver="PGS" iterations="30" gravity="0 0 0"/>
+  <worldbody>
+    <body pos="0 0 1"><freejoint/><geom type="sphere" size=".1"/></body>
+    <body pos=".2 0 1"><freejoint/><geom type="sphere" size=".1"/></body>
+    <body pos=".4 0 1"><freejoint/><geom type="sphere" size=".1"/></body>
+    <body pos="1 0 1"><freejoint/><geom type="sphere" size=".125"/></body>
+    <body pos="1 .25 1"><freejoint/><geom type="sphere" size=".125"/></body>
+    <body pos="1 .25 1.25"><freejoint/><geom type="sphere" size=".125"/></body>
+    <body pos="-1 0 1"><freejoint/><geom type="capsule" size=".05 .1"/></body>
+    <body pos="-1 .1 1"><freejoint/><geom type="capsule" size=".05 .1"/></body>
+    <body pos="-1 .2000000000000001 1"><freejoint/><geom type="sphere" size=".05"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+# bodies with several geoms of mixed types whose BVH order differs from their geom order: the
+# midphase (mj_collideTree) visits leaf pairs in its own order, culls with oriented boxes, and the
+# contacts of a body pair are re-sorted afterwards (engine_collision_driver.c:686-716, :996-1240)
+MULTIGEOM_XML = """
+<mujoco>
+  <option timestep="0.003" solver="PGS" iterations="50"/>
+  <default><geom condim="3"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body name="a" pos="0 0 .3" euler="10 20 0"><freejoint/>
+      <geom type="sphere" size=".06" pos=".25 0 0"/>
+      <geom type="capsule" size=".03" fromto="-.25 0 0 .2 0 0"/>
+      <geom type="sphere" size=".05" pos="-.25 .1 0"/>
+      <geom type="capsule" size=".025" fromto="0 -.2 0 0 .2 0"/>
+      <geom type="sphere" size=".04" pos="0 0 .15"/>
+    </body>
+    <body name="b" pos=".05 .05 .55" euler="0 -15 40"><freejoint/>
+      <geom type="capsule" size=".03" fromto="0 0 -.2 0 0 .2"/>
+      <geom type="sphere" size=".07" pos="0 .2 0"/>
+      <geom type="sphere" size=".05" pos="0 -.2 .1"/>
+      <geom type="capsule" size=".02" fromto="-.2 0 0 .2 0 .05"/>
+    </body>
+    <body name="c" pos="-.1 0 .85" euler="30 0 10"><freejoint/>
+      <geom type="sphere" size=".08"/>
+      <geom type="capsule" size=".03" fromto="-.2 0 0 .2 0 0"/>
+      <geom type="capsule" size=".03" fromto="0 -.2 0 0 .2 0"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""

@@ -726,3 +726,92 @@ def test_step1_step2_split_on_gpu(rb, hip_lib, dm):
             d.qpos[:] = got_q[e]; d.qvel[:] = got_v[e]
     print("step1/step2 closed loop: worst rel err", worst)
     assert worst <= TOL
+
+
+def test_mfma_ar_tolerance_parity(rb, hip_lib, dm, golden):
+    """opt-in matrix-core build of AR = Y Y' (v_mfma_f64_16x16x4_f64): AR agrees with the reference
+    to rounding, the step within the 1e-6 bar; contact / constraint counts stay exact, solver
+    iteration counts may move by one (tolerance parity, include/mjhip.h: mjhip_batch_set_mfma)"""
+    m = humanoid_pgs_oracle(rb)
+    states = contact_rich_states(rb, m, 48, seed=31)
+    b = K.Batch(dm, len(states))
+    b.set_mfma(True)
+    from parity_utils import load_states
+    load_states(b, states)
+    b.forward()
+    counts = b.get("counts")
+    AR = b.get("efc_AR")
+    qacc = b.get("qacc")
+    d = rb.MjData(m)
+    worst_ar, worst_q, dn = 0.0, 0.0, 0
+    for e, s in enumerate(states):
+        d.qpos[:] = s["qpos"]; d.qvel[:] = s["qvel"]; d.qacc_warmstart[:] = s["qacc_warmstart"]; d.ctrl[:] = s["ctrl"]
+        rb.mj_forward(m, d)
+        n = d.nefc
+        assert counts[e][0] == d.ncon and counts[e][1] == n
+        if n:
+            ref = np.array(d.efc_AR).reshape(n, n)
+            got = AR[e][:n*n].reshape(n, n)
+            worst_ar = max(worst_ar, float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))))
+        worst_q = max(worst_q, relerr(qacc[e], np.array(d.qacc)))
+        dn = max(dn, abs(int(counts[e][5]) - int(d.solver_niter[0])))
+    print("mfma AR: worst rel err", worst_ar, " qacc", worst_q, " max |delta niter|", dn, " max nefc", counts[:, 1].max())
+    assert counts[:, 1].max() > 16            # more than one 16 x 16 tile is exercised
+    assert worst_ar <= 1e-12 and worst_q <= 1e-6
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 40
+    b2 = K.Batch(dm, n)
+    b2.set_mfma(True)
+    out = b2.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    assert relerr(out[:, :10], fx["state"][:, :10]) <= TOL
+
+
+def test_broadphase_and_midphase_counts_exact_on_gpu(rb, hip_lib, tmp_path):
+    """the reproduced sweep-and-prune / BVH culls on the GPU: exactly touching spheres (contact
+    counts equal to the reference's in every scene) and a pile of multi-geom bodies that takes the
+    midphase route (contact lists equal along a 100-step rollout)"""
+    from parity_utils import MULTIGEOM_XML
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        r1, r2 = [float(np.round(rng.uniform(.03, .2), 3)) for _ in range(2)]
+        dirv = rng.normal(size=3)
+        if trial % 3 == 0:
+            dirv = np.eye(3)[trial % 9 // 3]
+        dirv /= np.linalg.norm(dirv)
+        p1 = np.round(rng.uniform(-1, 1, 3), 2)
+        bodies = [(p1, r1), (p1 + dirv*(r1 + r2), r2)]
+        if trial % 2:
+            bodies = bodies[::-1]
+        bodies += [(rng.uniform(-2, 2, 3), .05) for _ in range(rng.integers(0, 3))]
+        f = tmp_path / "t.xml"
+        f.write_text('<mujoco><option gravity="0 0 0"/><worldbody>' + "".join(
+            '<body pos="%.17g %.17g %.17g"><freejoint/><geom type="sphere" size="%g"/></body>' % (*p, r) for p, r in bodies
+        ) + "</worldbody></mujoco>")
+        m = rb.MjModel.from_xml_path(str(f))
+        d = rb.MjData(m)
+        rb.mj_forward(m, d)
+        b = K.Batch(K.DeviceModel(hip_lib, m), 1)
+        b.forward()
+        assert int(b.get("counts")[0, 0]) == d.ncon, trial
+    xml = tmp_path / "multigeom.xml"
+    xml.write_text(MULTIGEOM_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 100
+    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    dmm = K.DeviceModel(hip_lib, m)
+    b = K.Batch(dmm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    assert relerr(out[:, :30], ref[:, :30]) <= TOL
+    bb = K.Batch(dmm, 1)
+    for t in (0, 20, 40, 60, 80, 99):
+        st = s0[0] if t == 0 else ref[0, t - 1]
+        rb.mj_setState(m, d, st, rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        bb.set("qpos", st[None, 1:1 + m.nq]); bb.set("qvel", st[None, 1 + m.nq:])
+        bb.forward()
+        assert int(bb.get("counts")[0, 0]) == d.ncon, t
+        if d.ncon:
+            assert np.array_equal(bb.get("con_geom")[0].reshape(-1, 2)[:d.ncon], d.contact["geom"]), t

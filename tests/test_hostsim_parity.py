@@ -936,3 +936,108 @@ def test_step1_step2_split_bit_exact(rb, setup):
         for e, d in enumerate(ds):
             assert np.array_equal(got_q[e], np.array(d.qpos)) and np.array_equal(got_v[e], np.array(d.qvel)), (t, e)
     assert b.get("warning").sum() == 0
+
+
+def _contact_lists_equal(rb, m, b, d, e=0):
+    c = b.get("counts")[e]
+    assert c[0] == d.ncon, (c[0], d.ncon)
+    if d.ncon:
+        assert np.array_equal(b.get("con_geom")[e].reshape(-1, 2)[:d.ncon], d.contact["geom"])
+        assert np.array_equal(b.get("con_dist")[e][:d.ncon], d.contact["dist"])
+
+
+def test_broadphase_float_rounding_and_ties_bit_exact(rb, hostsim_lib, tmp_path):
+    """exactly touching geoms: the reference's sweep-and-prune compares float-rounded end points and
+    breaks ties by array position, so identical touching pairs are or are not tested depending on
+    body order; mjhip evaluates the same predicate (stage_broadphase) -- contact lists, not just
+    counts, must agree, statically and while the bodies drift apart / together"""
+    from parity_utils import TOUCH_XML
+    xml = tmp_path / "touch.xml"
+    xml.write_text(TOUCH_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    b = K.Batch(dm, 1)
+    b.forward()
+    rb.mj_forward(m, d)
+    _contact_lists_equal(rb, m, b, d)
+    ncon0 = d.ncon
+    # tiny relative velocities: pairs cross the touching configuration in both directions
+    rng = np.random.default_rng(2)
+    v = np.zeros(m.nv); v[0::6] = rng.normal(0, 1e-3, m.nv // 6); v[1::6] = rng.normal(0, 1e-3, m.nv // 6)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    s0[0, 1 + m.nq:] = v
+    T = 40
+    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    assert np.array_equal(out, ref)
+    assert len(set(ints[0, :, 0].tolist()) | {ncon0}) > 1, "the scene is supposed to change its contact count"
+
+
+def test_multi_geom_bodies_midphase_bit_exact(rb, hostsim_lib, tmp_path):
+    """bodies with several geoms take the BVH midphase route: leaf pairs are culled by oriented-box
+    tests along a static descent chain and the contacts of a body pair are re-sorted; contact lists
+    (geom ids in order, distances) exact at every step of a tumbling pile"""
+    from parity_utils import MULTIGEOM_XML
+    xml = tmp_path / "multigeom.xml"
+    xml.write_text(MULTIGEOM_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 120
+    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    assert ints[0, :, 0].max() >= 6
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    assert np.array_equal(out, ref)
+    # contact lists along the way
+    bb = K.Batch(dm, 1)
+    for t in (0, 30, 60, 90, 119):
+        st = s0[0] if t == 0 else ref[0, t - 1]
+        rb.mj_setState(m, d, st, rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        bb.set("qpos", st[None, 1:1 + m.nq]); bb.set("qvel", st[None, 1 + m.nq:])
+        bb.forward()
+        _contact_lists_equal(rb, m, bb, d)
+
+
+def test_broadphase_emulation_closes_the_touching_gap(rb, hostsim_lib, tmp_path, monkeypatch):
+    """random scenes of spheres that touch exactly: with the reference's sweep-and-prune predicate
+    reproduced (stage_broadphase) the contact count always matches; with the conservative static
+    pair list alone ($MJHIP_BROADPHASE=0) some of these scenes differ -- which is what the stage is for"""
+    rng = np.random.default_rng(0)
+    d_off = d_on = 0
+    for trial in range(150):
+        r1, r2 = [float(np.round(rng.uniform(.03, .2), 3)) for _ in range(2)]
+        dirv = rng.normal(size=3)
+        if trial % 3 == 0:
+            dirv = np.eye(3)[trial % 9 // 3]
+        dirv /= np.linalg.norm(dirv)
+        p1 = np.round(rng.uniform(-1, 1, 3), 2)
+        p2 = p1 + dirv*(r1 + r2)
+        bodies = [(p1, r1), (p2, r2)]
+        if trial % 2:
+            bodies = bodies[::-1]
+        bodies += [(rng.uniform(-2, 2, 3), .05) for _ in range(rng.integers(0, 3))]
+        xml = '<mujoco><option gravity="0 0 0"/><worldbody>' + "".join(
+            '<body pos="%.17g %.17g %.17g"><freejoint/><geom type="sphere" size="%g"/></body>' % (*p, r) for p, r in bodies
+        ) + "</worldbody></mujoco>"
+        f = tmp_path / "t.xml"
+        f.write_text(xml)
+        m = rb.MjModel.from_xml_path(str(f))
+        d = rb.MjData(m)
+        rb.mj_forward(m, d)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MJHIP_BROADPHASE", mode)
+            b = K.Batch(K.DeviceModel(hostsim_lib, m), 1)
+            b.forward()
+            if int(b.get("counts")[0, 0]) != d.ncon:
+                if mode == "1":
+                    d_on += 1
+                else:
+                    d_off += 1
+    assert d_on == 0
+    assert d_off > 0, "these scenes are supposed to expose the conservative pair list"
