@@ -1,4 +1,4 @@
-"""Per-environment cost of one rollout launch (the `cost` field the kernel writes: wall_clock64 >> 4
+"""Per-environment cost of one rollout launch (the `wall` field the kernel writes: wall_clock64 >> 4
 ticks, 100 MHz clock): how much of a launch is the tail of its slowest environments."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +28,13 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1)
-        c = batch.get("cost")[:, 0].astype(np.float64) * 16 / 100.0   # us
+        c = batch.get("wall")[:, 0].astype(np.float64) * 16 / 100.0   # us
+        work = batch.get("cost")[:, 0].astype(np.float64)
         q = np.quantile(c, [0, .5, .9, .99, .999, 1])
+        if L > 0:
+            print("   corr(work estimate of previous launch, of this launch) = %.3f ; corr(work estimate, wall) = %.3f" %
+                  (np.corrcoef(prev_work, work)[0, 1], np.corrcoef(work, c)[0, 1]))
+        prev_work = work
         print("launch %d: kernel %.2f ms (%.2f M env-steps/s); per-env us: mean %.0f  quantiles(0,.5,.9,.99,.999,1) %s  max/mean %.2f" %
               (L, ms, nenv*steps/ms/1e3, c.mean(), np.round(q).tolist(), c.max()/c.mean()))
 
