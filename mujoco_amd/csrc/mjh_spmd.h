@@ -263,7 +263,11 @@ __device__ __forceinline__ int wv_uniform_i(int v) { return __builtin_amdgcn_rea
 #ifndef MJH_WAVES_PER_EU
 #define MJH_WAVES_PER_EU 4
 #endif
+#ifdef MJH_INLINE_STAGES
+#define MJH_DEVN_WAVE __device__ __forceinline__ static
+#else
 #define MJH_DEVN_WAVE __device__ __noinline__ static
+#endif
 #define MJH_DEVN_LANE __device__ __forceinline__ static
 #define MJH_GLOBAL __global__ void
 #define MJH_SHARED __shared__
