@@ -62,6 +62,22 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
   }
   wv_sync();
 
+  // hinge angles -> (sin, cos) of the half angle for ALL joints at once, before the level loop: the
+  // trigonometric evaluations are the most expensive part of a level and do not depend on the tree.
+  // Parked in the joint's xanchor slot (read back by the lane that then overwrites it with the
+  // anchor); cos = 2 marks a zero angle, whose quaternion is exactly the identity (mji_axisAngle2Quat).
+  MJH_FOR_LANES(j, s.njnt) {
+    if (M.jnt_type[j] == MJH_JNT_HINGE) {
+      const int qadr = M.jnt_qposadr[j];
+      const real angle = qpos[qadr] - M.qpos0[qadr];
+      real sn = 0, cs = 2;
+      if (angle != 0) { sn = sin(angle*0.5); cs = cos(angle*0.5); }
+      xanchor[3*j] = sn;
+      xanchor[3*j + 1] = cs;
+    }
+  }
+  wv_sync();
+
   for (int L = 1; L < s.nlevel; L++) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
     MJH_FOR_LANES(k, a1 - a0) {
@@ -102,6 +118,8 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
           int qadr = M.jnt_qposadr[jid];
           int jt = M.jnt_type[jid];
           real anchor[3], axis[3];
+          // (a hinge's half-angle sine / cosine wait in its xanchor slot, see above)
+          const real hsn = xanchor[3*jid], hcs = xanchor[3*jid + 1];
           q_rotvec(axis, M.jnt_axis + 3*jid, quat);
           q_rotvec(anchor, M.jnt_pos + 3*jid, quat);
           v3_addto(anchor, pos);
@@ -112,8 +130,13 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
             if (jt == MJH_JNT_BALL) {
               q_copy(qloc, qpos + qadr);
               q_normalize(qloc);
+            } else if (hcs == 2) {
+              qloc[0] = 1; qloc[1] = 0; qloc[2] = 0; qloc[3] = 0;
             } else {
-              q_axisangle(qloc, M.jnt_axis + 3*jid, qpos[qadr] - M.qpos0[qadr]);
+              qloc[0] = hcs;
+              qloc[1] = M.jnt_axis[3*jid]*hsn;
+              qloc[2] = M.jnt_axis[3*jid + 1]*hsn;
+              qloc[3] = M.jnt_axis[3*jid + 2]*hsn;
             }
             q_mul(quat, quat, qloc);
             real vec[3];
@@ -531,7 +554,7 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
 // read where it lives (LDS by plan).  Same arithmetic, same order as the generic versions below.
 // ------------------------------------------------------------------------------------------------
 template <class P0, class P1>
-MJH_DEVN void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
+MJH_DEVN_HOT void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
   MREF M = wv_uniform_ref(M_);
   const auto* ld_prog = wv_uniform_ptr(M.ld_prog);
   const int nv = M.s.nv;
@@ -569,7 +592,7 @@ MJH_DEVN void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
 }
 
 template <class P0, class P1, class P2>
-MJH_DEVN void solve_ld_fast(MREF M_, P0 xmem, P1 qLD, P2 diaginv) {
+MJH_DEVN_HOT void solve_ld_fast(MREF M_, P0 xmem, P1 qLD, P2 diaginv) {
   MREF M = wv_uniform_ref(M_);
   const auto* colind = wv_uniform_ptr(M.M_colind);
   const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);

@@ -62,7 +62,7 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // ARL = 1: AR is resident in LDS and is read with ds_read through a local-address-space pointer
 // (in-order returns let the next row's prefetch stay in flight; a flat load would have to drain)
 template <int ARL>
-MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
+MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
   BREF B = B_;
   const int e = wv_uniform_i(e_);
@@ -274,7 +274,7 @@ MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
 #define MJH_PGS2_END }}}}}}}
 
 template <int ARL>
-MJH_DEVN void solve_pgs_fast(MREF M_, BREF B_, int e_) {
+MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
   BREF B = B_;
   const int e = e_;

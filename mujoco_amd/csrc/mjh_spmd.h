@@ -34,6 +34,7 @@ template <class T> static inline const T& wv_uniform_ref(const T& r) { return r;
 template <class T> static inline const T& wv_const_ref(const T* p) { return *p; }
 static inline int wv_uniform_i(int v) { return v; }
 #define MJH_DEVN_WAVE static __attribute__((noinline))
+#define MJH_DEVN_HOT static __attribute__((noinline))
 #define MJH_DEVN_LANE static inline
 #define MJH_GLOBAL static void
 #define MJH_SHARED static
@@ -268,6 +269,10 @@ __device__ __forceinline__ int wv_uniform_i(int v) { return __builtin_amdgcn_rea
 #else
 #define MJH_DEVN_WAVE __device__ __noinline__ static
 #endif
+// the register-resident serial sweeps (PGS, L'DL factor / solves): always out of line -- they are
+// leaves that fit the caller-saved registers (nothing to save on entry) and their inner loops must
+// not inherit the register pressure of whatever surrounds the call
+#define MJH_DEVN_HOT __device__ __noinline__ static
 #define MJH_DEVN_LANE __device__ __forceinline__ static
 #define MJH_GLOBAL __global__ void
 #define MJH_SHARED __shared__
