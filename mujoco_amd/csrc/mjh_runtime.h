@@ -185,7 +185,13 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
   }
   // phase B: everything else, free to overlay the dynamic region (it is dead by MJH_T_MAKE or
   // born after MJH_T_CONSTRAINT)
-  for (int i : order) {
+  // (largest byte x lifetime area first: the short-lived per-body arrays of the smooth stages are the
+  // big ones, and first-fit by lifetime alone left holes they did not fit into)
+  std::vector<int> orderB(order);
+  std::stable_sort(orderB.begin(), orderB.end(), [&](int a, int b) {
+    return (long long)f[a].bytes*(f[a].t1 - f[a].t0 + 1) > (long long)f[b].bytes*(f[b].t1 - f[b].t0 + 1);
+  });
+  for (int i : orderB) {
     PlanField& x = f[i];
     if (live_in(x, MJH_T_MAKE, MJH_T_CONSTRAINT)) continue;
     if (ok) place(x, budget);

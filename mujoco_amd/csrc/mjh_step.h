@@ -141,16 +141,16 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
     MJH_RUN(MJH_T_TENDON, stage_tendon(M, B, e));
   }
-  if (stages & MJH_STAGE_INERTIA) {
-    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e));
-    MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
-  }
   if (stages & MJH_STAGE_TRANSMISSION) MJH_RUN(MJH_T_TRANSMISSION, stage_transmission(M, B, e));
   if (stages & MJH_STAGE_VELOCITY) {
     MJH_RUN(MJH_T_TAVEL, stage_ten_act_velocity(M, B, e));
     MJH_RUN(MJH_T_COMVEL, stage_comvel(M, B, e));
     MJH_RUN(MJH_T_PASSIVE, stage_passive(M, B, e));
     MJH_RUN(MJH_T_RNE, stage_rne(M, B, e));
+  }
+  if (stages & MJH_STAGE_INERTIA) {
+    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e));
+    MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
   }
   if (stages & MJH_STAGE_ACTUATION) {
     MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));

@@ -298,9 +298,12 @@ enum {
   // (collision runs right after kinematics: it only needs the geom and inertial frames, which can
   // then leave LDS early -- the contact slots that replace them are smaller -- and its broad / midphase
   // checks find the inertial frames still resident)
-  MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COLLISION = 2, MJH_T_COMPOS = 3, MJH_T_TENDON = 4, MJH_T_CRB = 5, MJH_T_FACTOR = 6,
-  MJH_T_TRANSMISSION = 7, MJH_T_TAVEL = 8, MJH_T_COMVEL = 9, MJH_T_PASSIVE = 10, MJH_T_RNE = 11,
-  MJH_T_ACTUATION = 12, MJH_T_ACCEL = 13,
+  // (the mass matrix is built and factorised only when its first consumer -- the smooth acceleration --
+  // is next: qLD does not sit in LDS through the velocity stages, whose per-body spatial vectors
+  // (cvel, cacc, cfrc) then fit)
+  MJH_T_BEGIN = 0, MJH_T_KIN = 1, MJH_T_COLLISION = 2, MJH_T_COMPOS = 3, MJH_T_TENDON = 4,
+  MJH_T_TRANSMISSION = 5, MJH_T_TAVEL = 6, MJH_T_COMVEL = 7, MJH_T_PASSIVE = 8, MJH_T_RNE = 9,
+  MJH_T_CRB = 10, MJH_T_FACTOR = 11, MJH_T_ACTUATION = 12, MJH_T_ACCEL = 13,
   MJH_T_MAKE = 14, MJH_T_PROJECT = 15, MJH_T_REFERENCE = 16, MJH_T_CONSTRAINT = 17,
   MJH_T_FINISH = 18, MJH_T_EULER = 19, MJH_T_END = 20,
 };
@@ -336,7 +339,7 @@ enum {
   X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \
-  X(cinert, 10 * s.nbody, 10 * s.nbody, MJH_T_COMPOS, MJH_T_RNE)                  \
+  X(cinert, 10 * s.nbody, 10 * s.nbody, MJH_T_COMPOS, MJH_T_CRB)                  \
   X(cdof, 6 * s.nv, 6 * s.nv, MJH_T_COMPOS, MJH_T_MAKE)                           \
   X(ten_length, s.ntendon, s.ntendon, MJH_T_TENDON, MJH_T_MAKE)                   \
   X(ten_J, s.nJten, s.nJten, MJH_T_TENDON, MJH_T_MAKE)                            \

@@ -8,8 +8,8 @@ import torch
 import mujoco_amd as ma
 from bench import initial_states
 
-NAMES = ["begin", "kin", "collision", "compos", "tendon", "crb", "factor", "transmission", "tavel", "comvel",
-         "passive", "rne", "actuation", "accel", "make", "project", "reference", "constraint",
+NAMES = ["begin", "kin", "collision", "compos", "tendon", "transmission", "tavel", "comvel",
+         "passive", "rne", "crb", "factor", "actuation", "accel", "make", "project", "reference", "constraint",
          "finish", "euler", "end"]
 lib = ma.lib()
 model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
