@@ -159,7 +159,7 @@ MJH_DEV int hit_capsule_capsule(Hit& a, Hit& b, real margin, V3 c1, P1 mat1, S1 
 // sphere : box (mjraw_SphereBox, engine_collision_box.c:35): clamp the centre into the box; a centre
 // inside the box is pushed out through the nearest face
 template <class P2, class S2>
-MJH_DEV int hit_sphere_box(Hit& h, real margin, V3 c1, real r1, V3 c2, P2 mat2, S2 size2) {
+MJH_DEVN int hit_sphere_box(Hit& h, real margin, V3 c1, real r1, V3 c2, P2 mat2, S2 size2) {
   const V3 off = c1 - c2;
   const V3 local{mtrow(mat2, 0, off), mtrow(mat2, 1, off), mtrow(mat2, 2, off)};
   const V3 ext = ld3(size2);
@@ -194,7 +194,7 @@ MJH_DEV int hit_sphere_box(Hit& h, real margin, V3 c1, real r1, V3 c2, P2 mat2, 
 // sphere : cylinder (mjc_SphereCylinder, engine_collision_primitive.c:345): the sphere meets the
 // barrel (a sphere on the axis), a cap (a plane) or the rim (a point)
 template <class P1, class P2, class S2>
-MJH_DEV int hit_sphere_cylinder(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3 c2, P2 mat2, S2 size2) {
+MJH_DEVN int hit_sphere_cylinder(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3 c2, P2 mat2, S2 size2) {
   const real radius = size2[0], half = size2[1];
   const V3 axis = mcol(mat2, 2);
   const V3 off = c1 - c2;
@@ -228,7 +228,7 @@ MJH_DEV int hit_sphere_cylinder(Hit& h, real margin, V3 c1, P1 mat1, real r1, V3
 // plane : box (mjc_PlaneBox, engine_collision_primitive.c:210): lane k < 8 tests corner k; the
 // first four corners below the plane (in corner order) are the contacts
 template <class P2, class S2>
-MJH_DEV int coop_plane_box(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
+MJH_DEVN int coop_plane_box(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
   const int k = wv_lane();
   const real height = dot(c2 - ppos, pnrm);
   const V3 corner = mmul(mat2, V3{(k & 1) ? (real)size2[0] : -(real)size2[0],
@@ -251,7 +251,7 @@ MJH_DEV int coop_plane_box(Hit& h, int& has, int& rank, real margin, V3 ppos, V3
 // near rim, the matching point of the far rim, and two points of the near rim 120 degrees away;
 // lane k < 4 evaluates candidate k, nothing is reported unless the lowest point is in reach
 template <class P2, class S2>
-MJH_DEV int coop_plane_cylinder(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
+MJH_DEVN int coop_plane_cylinder(Hit& h, int& has, int& rank, real margin, V3 ppos, V3 pnrm, V3 c2, P2 mat2, S2 size2) {
   const int k = wv_lane();
   V3 axis = mcol(mat2, 2);
   real tilt = dot(pnrm, axis);
@@ -844,8 +844,9 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             n = hit_capsule_capsule(ha, hb, margin, c1, mat1, size1, c2, mat2, size2); break;
           default:
             if (MJH_HAS(MJH_FT_COLCONVEX)) {
-              if (func == MJH_COL_SPHERE_BOX) n = hit_sphere_box(ha, margin, c1, size1[0], c2, mat2, size2);
-              else if (func == MJH_COL_SPHERE_CYLINDER) n = hit_sphere_cylinder(ha, margin, c1, mat1, size1[0], c2, mat2, size2);
+              // (out-of-line colliders write through a reference: a local of their own keeps `ha` in registers)
+              if (func == MJH_COL_SPHERE_BOX) { Hit hx; n = hit_sphere_box(hx, margin, c1, size1[0], c2, mat2, size2); ha = hx; }
+              else if (func == MJH_COL_SPHERE_CYLINDER) { Hit hx; n = hit_sphere_cylinder(hx, margin, c1, mat1, size1[0], c2, mat2, size2); ha = hx; }
               else if (func == MJH_COL_UNSUPPORTED || MJH_LANE_MODE) unsupported = 1;
               else coop = 1;
             }

@@ -308,11 +308,21 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     scale = 1 / (M.o.meaninertia * (real)(nv > 1 ? nv : 1));
   }
 
-  // H = M + J' D_active J, Cholesky, Mgrad = H \ grad
+  // H = M + J' D_active J, Cholesky, Mgrad = H \ grad.
+  // Lanes split the LOWER triangle of H (its upper half is never read).  The factorisation is
+  // right-looking: at step k the finished column k sits in registers (lane i - k holds L[i][k]) and the
+  // trailing update fetches its two factors with cross-lane reads instead of going back to memory
+  // for values other lanes have just written; the two triangular solves keep the right-hand side in
+  // registers (lane = row) and sweep column by column, so each of their nv steps is one broadcast and
+  // one multiply-subtract instead of a serial dot product on one lane.
   auto factor_and_solve = [&]() {
-    MJH_FOR_LANES(k, nv*nv) {
-      const int i = k / nv, j = k - i*nv;
-      real acc = Md[k];
+    const int ntri = nv*(nv + 1)/2;
+    MJH_FOR_LANES(w, ntri) {
+      int i = (int)((sqrt(8.0*w + 1.0) - 1.0)*0.5);
+      while (i*(i+1)/2 > w) i--;
+      while ((i+1)*(i+2)/2 <= w) i++;
+      const int j = w - i*(i+1)/2;
+      real acc = Md[i*nv + j];
       for (int r = 0; r < nefc; r++) {
         if (!in_row(r)) continue;       // the blocks of other islands stay M (never used: grad is 0 there)
         const int st = P.state[r];
@@ -322,39 +332,102 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           r += nt_cone_hessian_term(P, r, nefc, nv, conH + 36*P.id[r], i, j, &acc) - 1;
         }
       }
-      H[k] = acc;
+      H[i*nv + j] = acc;
     }
     wv_sync();
+#if MJH_LANE_MODE
     for (int k = 0; k < nv; k++) {                  // right-looking Cholesky, lower triangle
       const real dkk = sqrt(r_max(H[k*nv + k], MJH_MINVAL));
-      wv_sync();
-      MJH_FOR_LANES(i, nv) if (i >= k) H[i*nv + k] = (i == k) ? dkk : H[i*nv + k] / dkk;
-      wv_sync();
-      const int m = nv - k - 1;
-      MJH_FOR_LANES(w, m*m) {
-        const int i = k + 1 + w / m, j = k + 1 + w % m;
-        if (j <= i) H[i*nv + j] -= H[i*nv + k]*H[j*nv + k];
-      }
-      wv_sync();
+      for (int i = k; i < nv; i++) H[i*nv + k] = (i == k) ? dkk : H[i*nv + k] / dkk;
+      for (int i = k + 1; i < nv; i++) for (int j = k + 1; j <= i; j++) H[i*nv + j] -= H[i*nv + k]*H[j*nv + k];
     }
-    MJH_FOR_LANES(i, nv) Mgrad[i] = grad[i];
-    wv_sync();
-    for (int i = 0; i < nv; i++) {                  // L y = grad
-      if (lane == 0) {
-        real acc = Mgrad[i];
-        for (int j = 0; j < i; j++) acc -= H[i*nv + j]*Mgrad[j];
-        Mgrad[i] = acc / H[i*nv + i];
-      }
-      wv_sync();
+    for (int i = 0; i < nv; i++) Mgrad[i] = grad[i];
+    for (int i = 0; i < nv; i++) {
+      real acc = Mgrad[i];
+      for (int j = 0; j < i; j++) acc -= H[i*nv + j]*Mgrad[j];
+      Mgrad[i] = acc / H[i*nv + i];
     }
-    for (int i = nv - 1; i >= 0; i--) {             // L' x = y
-      if (lane == 0) {
-        real acc = Mgrad[i];
-        for (int j = i + 1; j < nv; j++) acc -= H[j*nv + i]*Mgrad[j];
-        Mgrad[i] = acc / H[i*nv + i];
-      }
-      wv_sync();
+    for (int i = nv - 1; i >= 0; i--) {
+      real acc = Mgrad[i];
+      for (int j = nv - 1; j > i; j--) acc -= H[j*nv + i]*Mgrad[j];
+      Mgrad[i] = acc / H[i*nv + i];
     }
+#else
+    if (nv <= MJH_W) {
+      for (int k = 0; k < nv; k++) {
+        // column k: lane q holds L[k + q][k]
+        const int myrow = k + lane;
+        real col = (myrow < nv) ? (real)H[myrow*nv + k] : (real)0;
+        const real dkk = sqrt(r_max(wv_bcast(col, 0), MJH_MINVAL));
+        col = (lane == 0) ? dkk : col / dkk;
+        if (myrow < nv) H[myrow*nv + k] = col;
+        // trailing update: entry (i, j), k < j <= i, takes L[i][k] and L[j][k] from the column's lanes
+        const int m = nv - k - 1;
+        const int mtri = m*(m + 1)/2;
+        for (int w0 = 0; w0 < mtri; w0 += MJH_W) {
+          const int w = w0 + lane;
+          int a = 0, c = 0;
+          if (w < mtri) {
+            a = (int)((sqrt(8.0*w + 1.0) - 1.0)*0.5);
+            while (a*(a+1)/2 > w) a--;
+            while ((a+1)*(a+2)/2 <= w) a++;
+            c = w - a*(a+1)/2;
+          }
+          const real lik = wv_shfl(col, a + 1), ljk = wv_shfl(col, c + 1);
+          if (w < mtri) H[(k + 1 + a)*nv + (k + 1 + c)] -= lik*ljk;
+        }
+        wv_sync();
+      }
+      // L y = grad, column sweep: y in registers (lane = row)
+      real y = (lane < nv) ? (real)grad[lane] : (real)0;
+      for (int j = 0; j < nv; j++) {
+        const real lij = (lane >= j && lane < nv) ? (real)H[lane*nv + j] : (real)1;
+        if (lane == j) y = y / lij;
+        const real yj = wv_bcast(y, j);
+        if (lane > j && lane < nv) y -= lij*yj;
+      }
+      // L' x = y
+      for (int j = nv - 1; j >= 0; j--) {
+        const real lji = (lane <= j) ? (real)H[j*nv + lane] : (real)1;
+        if (lane == j) y = y / lji;
+        const real xj = wv_bcast(y, j);
+        if (lane < j) y -= lji*xj;
+      }
+      if (lane < nv) Mgrad[lane] = y;
+      wv_sync();
+    } else {
+      for (int k = 0; k < nv; k++) {                  // right-looking Cholesky, lower triangle
+        const real dkk = sqrt(r_max(H[k*nv + k], MJH_MINVAL));
+        wv_sync();
+        MJH_FOR_LANES(i, nv) if (i >= k) H[i*nv + k] = (i == k) ? dkk : H[i*nv + k] / dkk;
+        wv_sync();
+        const int m = nv - k - 1;
+        MJH_FOR_LANES(w, m*m) {
+          const int i = k + 1 + w / m, j = k + 1 + w % m;
+          if (j <= i) H[i*nv + j] -= H[i*nv + k]*H[j*nv + k];
+        }
+        wv_sync();
+      }
+      MJH_FOR_LANES(i, nv) Mgrad[i] = grad[i];
+      wv_sync();
+      for (int i = 0; i < nv; i++) {                  // L y = grad
+        if (lane == 0) {
+          real acc = Mgrad[i];
+          for (int j = 0; j < i; j++) acc -= H[i*nv + j]*Mgrad[j];
+          Mgrad[i] = acc / H[i*nv + i];
+        }
+        wv_sync();
+      }
+      for (int i = nv - 1; i >= 0; i--) {             // L' x = y
+        if (lane == 0) {
+          real acc = Mgrad[i];
+          for (int j = nv - 1; j > i; j--) acc -= H[j*nv + i]*Mgrad[j];
+          Mgrad[i] = acc / H[i*nv + i];
+        }
+        wv_sync();
+      }
+    }
+#endif
   };
 
   auto precondition = [&]() {                      // Mgrad = M \ grad (CG preconditioner, certificate)

@@ -13,7 +13,7 @@ NAMES = ["begin", "kin", "collision", "compos", "tendon", "transmission", "tavel
          "finish", "euler", "end"]
 lib = ma.lib()
 model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
-model.set_option("solver", 0)
+model.set_option("solver", int(os.environ.get("SOLVER", "0")))     # 0 PGS, 1 CG, 2 Newton
 dm = ma.DeviceModel(lib, model)
 nenv = int(os.environ.get("NENV", 4096)); K = 100; W = 50
 b = ma.Batch(dm, nenv)
