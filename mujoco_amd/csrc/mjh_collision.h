@@ -795,6 +795,55 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
   MJH_CON(B, con_mu, e, 1, c)[0] = 0;
 }
 
+#if !MJH_LANE_MODE
+// The group-cooperative colliders of one chunk of MJH_W pairs, in pair order (bit q of `todo`: pair
+// p0 + q).  `slot` is the contact slot my own pair's first contact would take; each cooperative pair
+// before mine pushes it back by that pair's count.  Returns (how far my slot moved) | (contacts
+// emitted) << 12 | overflow << 24.  Out of line: the point colliders around the call site are the hot
+// path of most models, and keeping the clipping code out of their function keeps its register
+// pressure where the lean build's is.
+// (one pair: loads, collider, contact stores.  Returns its contact count | overflow << 8.  A function of
+// its own so that nothing but loop counters is live across the collider calls of the loop below.)
+MJH_DEVN int collide_coop_pair(MREF M_, BREF B_, int e_, int pq, int first) {
+  MJH_ENTER(M_, B_, e_);
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  const int g1 = M.pair_geom1[pq], g2 = M.pair_geom2[pq];
+  const real margin = M.pair_margin[pq];
+  crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+  crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
+  const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
+  Hit hc;
+  int has = 0, rank = 0, cnt = 0;
+  const int func = M.pair_func[pq];
+  if (func == MJH_COL_PLANE_BOX) cnt = coop_plane_box(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
+  else if (func == MJH_COL_PLANE_CYLINDER) cnt = coop_plane_cylinder(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
+  else if (func == MJH_COL_BOX_BOX) cnt = coop_box_box(hc, has, rank, margin, c1, mat1, size1, c2, mat2, size2);
+  int overflow = 0;
+  if (has) {
+    const int c = first + rank;
+    if (c >= M.s.nconmax) overflow = 1; else store_contact(M, B, e, c, pq, hc);
+  }
+  return cnt | (overflow << 8);
+}
+
+MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int p0, unsigned todo_lo, unsigned todo_hi, int slot) {
+  MJH_ENTER(M_, B_, e_);
+  unsigned long long todo = ((unsigned long long)todo_hi << 32) | todo_lo;
+  int moved = 0, emitted = 0, overflow = 0;
+  while (todo) {
+    const int q = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int r = collide_coop_pair(M, B, e, p0 + q, wv_bcast_i(slot + moved, q));
+    const int cnt = r & 0xff;
+    overflow |= r >> 8;
+    if (wv_lane() > q) moved += cnt;
+    emitted += cnt;
+  }
+  return moved | (emitted << 12) | (wv_any(overflow) << 24);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
 // ------------------------------------------------------------------------------------------------
@@ -885,30 +934,12 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     int total = wv_sum_i(n);
 #if !MJH_LANE_MODE
     if (MJH_HAS(MJH_FT_COLCONVEX)) {
-      // cooperative pairs in pair order; `before` of later lanes grows by each pair's count
-      unsigned long long todo = wv_ballot(coop);
-      while (todo) {
-        const int q = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int pq = p0 + q;
-        const int g1 = M.pair_geom1[pq], g2 = M.pair_geom2[pq];
-        const real margin = M.pair_margin[pq];
-        crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
-        crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
-        const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
-        Hit hc;
-        int has = 0, rank = 0, cnt = 0;
-        const int func = M.pair_func[pq];
-        if (func == MJH_COL_PLANE_BOX) cnt = coop_plane_box(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
-        else if (func == MJH_COL_PLANE_CYLINDER) cnt = coop_plane_cylinder(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
-        else if (func == MJH_COL_BOX_BOX) cnt = coop_box_box(hc, has, rank, margin, c1, mat1, size1, c2, mat2, size2);
-        const int first = base + wv_bcast_i(before, q);
-        if (has) {
-          const int c = first + rank;
-          if (c >= s.nconmax) overflow = 1; else store_contact(M, B, e, c, pq, hc);
-        }
-        if (wv_lane() > q) before += cnt;
-        total += cnt;
+      const unsigned long long todo = wv_ballot(coop);
+      if (todo) {
+        const int r = collide_coop_pairs(M, B, e, p0, (unsigned)todo, (unsigned)(todo >> 32), base + before);
+        before += r & 0xfff;
+        total += (r >> 12) & 0xfff;
+        overflow |= r >> 24;
       }
     }
 #endif
