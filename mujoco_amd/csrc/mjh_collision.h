@@ -284,6 +284,173 @@ MJH_DEVN int coop_plane_cylinder(Hit& h, int& has, int& rank, real margin, V3 pp
   return in0 + in1 + 2*in2;
 }
 
+// capsule : box (mjraw_CapsuleBox, engine_collision_box.c:114-590): two sphere-box contacts, one at
+// the point of the capsule's segment closest to the box, one further along the segment where it
+// leaves the box's shadow.
+//   1. closest feature: lanes 0 and 1 drop the segment's two end points onto the box (a face is
+//      closest when at most one coordinate had to be clamped); lanes 2..13 take one box edge each
+//      (axis j = (lane - 2)/4, the four edges parallel to it in corner order) and solve the
+//      clamped segment-segment problem against it.
+//   2. the winner is picked by an in-order scan of the lanes' squared distances: end points by
+//      strict <, edges must win by more than MINVAL (the reference's guard against an axis that is
+//      numerically parallel to the box).
+//   3. where the second sphere goes is a case analysis on the winner (box corner / box edge / box
+//      face) that every lane evaluates on the broadcast winner data.
+//   4. lanes 0 and 1 each collide one sphere with the box.
+template <class P1, class S1, class P2, class S2>
+MJH_DEVN int coop_capsule_box(Hit& h, int& has, int& rank, real margin, V3 c1, P1 mat1, S1 size1, V3 c2, P2 mat2, S2 size2) {
+  const int lane = wv_lane();
+  has = 0; rank = 0;
+  const real radius = size1[0], half = size1[1];
+  const V3 ext = ld3(size2);
+  const V3 off = c1 - c2;
+  const V3 cen{mtrow(mat2, 0, off), mtrow(mat2, 1, off), mtrow(mat2, 2, off)};     // capsule centre, box frame
+  const V3 dirw = mcol(mat1, 2);
+  const V3 dir{mtrow(mat2, 0, dirw), mtrow(mat2, 1, dirw), mtrow(mat2, 2, dirw)};  // capsule axis, box frame
+  const V3 seg = dir*half;
+  const int octant = (seg.x > 0 ? 1 : 0) | (seg.y > 0 ? 2 : 0) | (seg.z > 0 ? 4 : 0);
+  const real far = margin + 2*(radius + half + ext.x + ext.y + ext.z);
+
+  // ---- 1. my candidate: squared distance `cand`, segment parameter tpar in [-1, 1], and for edges the
+  // edge parameter epar, the clamp pattern and the corner the edge starts from
+  real cand = 0, tpar = 0, epar = 0;
+  int ok = 0, face = -1, pattern = 0, corner = 0, eaxis = 0;
+  if (lane < 2) {
+    const real sgn = lane == 0 ? -1 : 1;
+    const V3 tip = cen + seg*sgn;
+    int outside = 0;
+    V3 clamped = tip;
+    for (int j = 0; j < 3; j++) {
+      const real t = comp(tip, j), lim = comp(ext, j);
+      if (t < -lim) { outside++; face = j; clamped = with_comp(clamped, j, -lim); }
+      else if (t > lim) { outside++; face = j; clamped = with_comp(clamped, j, lim); }
+    }
+    const V3 gap = clamped - tip;
+    cand = dot(gap, gap);
+    tpar = sgn;
+    ok = outside <= 1;
+  } else if (lane < 14) {
+    const int q = lane - 2;
+    const int j = q >> 2, r = q & 3;
+    const int i = (r & ((1 << j) - 1)) | ((r >> j) << (j + 1));        // r with a zero inserted at bit j
+    const V3 start = with_comp(V3{(i & 1) ? ext.x : -ext.x, (i & 2) ? ext.y : -ext.y, (i & 4) ? ext.z : -ext.z}, j, (real)0);
+    const V3 rel = start - cen;
+    const real lim = comp(ext, j);
+    const real ma = lim*lim, mb = -lim*comp(seg, j), mc = half*half;
+    const real u = -lim*comp(rel, j), v = dot(seg, rel);
+    const real det = ma*mc - mb*mb;
+    if (!(fabs(det) < MJH_MINVAL)) {
+      const real idet = 1/det;
+      real xe = (mc*u - mb*v)*idet;       // along the edge
+      real xs = (ma*v - mb*u)*idet;       // along the segment
+      int ende = 1, ends = 1;             // 0 / 1 / 2: lower end, interior, upper end
+      if (xe > 1) { xe = 1; ende = 2; xs = (v - mb)*(1/mc); }
+      else if (xe < -1) { xe = -1; ende = 0; xs = (v + mb)*(1/mc); }
+      if (xs > 1 || xs < -1) {
+        const int up = xs > 1;
+        xs = up ? 1 : -1;
+        ends = up ? 2 : 0;
+        xe = (up ? (u - mb) : (u + mb))*(1/ma);
+        if (xe > 1) { xe = 1; ende = 2; } else if (xe < -1) { xe = -1; ende = 0; }
+      }
+      V3 gap = rel + seg*(-xs);
+      gap = with_comp(gap, j, comp(gap, j) + lim*xe);
+      cand = dot(gap, gap);
+      tpar = xs; epar = xe;
+      pattern = ende*3 + ends;
+      corner = i + (1 << j)*(pattern/6);
+      eaxis = j;
+      ok = 1;
+    }
+  }
+
+  // ---- 2. in-order scan
+  const unsigned okmask = (unsigned)wv_ballot(ok);
+  real best = far;
+  int win = -1;
+  for (int a = 0; a < 14; a++) {
+    const real d = wv_bcast(cand, a);
+    if (((okmask >> a) & 1) && d < (a < 2 ? best : best - MJH_MINVAL)) { best = d; win = a; }
+  }
+  if (win < 0) return 0;
+  tpar = wv_bcast(tpar, win);
+  epar = wv_bcast(epar, win);
+  face = wv_bcast_i(face, win);
+  pattern = wv_bcast_i(pattern, win);
+  corner = wv_bcast_i(corner, win);
+  eaxis = wv_bcast_i(eaxis, win);
+
+  // ---- 3. offset of the second sphere along the segment (none: stays below -3)
+  real second = -4;
+  auto shorten = [&](real lim) { if (lim < second) second = lim; };
+  if (win >= 2 && pattern/3 != 1) {
+    // a box corner is closest.  The octants of the capsule axis and of the corner tell whether the
+    // capsule points at / away from the corner (nothing more to find) or runs along an edge or a face
+    int relo = octant ^ corner;
+    if (relo != 0 && relo != 7) {
+      const int single = (relo & (relo - 1)) == 0;
+      const real sense = single ? 1 : -1;
+      if (!single) relo = 7 - relo;
+      const real toend = single ? 1 - tpar : 1 + tpar, tostart = single ? 1 + tpar : 1 - tpar;
+      const int ax = relo == 1 ? 0 : (relo == 2 ? 1 : 2);
+      const int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (comp(dir, ax)*comp(dir, ax) > 0.5) {          // along the box edge
+        second = toend;
+        shorten(2*comp(ext, ax) / fabs(comp(seg, ax)));
+        second *= sense;
+      } else {                                          // across a face
+        second = tostart;
+        shorten(2*comp(ext, ax1) / fabs(comp(seg, ax1)));
+        shorten(2*comp(ext, ax2) / fabs(comp(seg, ax2)));
+        second *= -sense;
+      }
+    }
+  } else if (win >= 2) {
+    // the interior of a box edge is closest: a T configuration has no second point, a crossing does
+    const int relo = (octant ^ corner) & (7 - (1 << eaxis));
+    if (relo == 1 || relo == 2 || relo == 4) {
+      const int ax = eaxis;
+      int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (fabs(comp(dir, ax1)) > fabs(comp(dir, ax2))) ax1 = ax2;     // the face the capsule is flatter to
+      ax2 = 3 - ax - ax1;
+      const int fwd = (relo >> ax2) & 1;
+      const real sense = fwd ? 1 : -1;
+      second = fwd ? 1 - tpar : 1 + tpar;
+      shorten(2*comp(ext, ax2) / fabs(comp(seg, ax2)));
+      const real room = (((octant >> ax) & 1) == fwd) ? 1 - epar : 1 + epar;
+      shorten(comp(ext, ax)*room / fabs(comp(seg, ax)));
+      second *= sense;
+    }
+  } else if (face >= 0) {
+    // an end point is closest to a face: walk to where the segment leaves the face's outline
+    const real sense = win == 0 ? 1 : -1;
+    second = 2;
+    const V3 from = cen + seg*(-sense);
+    for (int i = 0; i < 3; i++) {
+      if (i == face) continue;
+      const real hi = (comp(ext, i) - comp(from, i)) / comp(seg, i) * sense;
+      if (hi > 0) shorten(hi);
+      const real lo = (-comp(ext, i) - comp(from, i)) / comp(seg, i) * sense;
+      if (lo > 0) shorten(lo);
+    }
+    second *= sense;
+  }
+
+  // ---- 4. the spheres
+  const int two = second > -3;
+  int n = 0;
+  Hit hs;
+  if (lane == 0 || (lane == 1 && two)) {
+    const V3 local = cen + seg*(lane == 0 ? tpar : second + tpar);
+    n = hit_sphere_box(hs, margin, mmul(mat2, local) + c2, radius, c2, mat2, size2);
+  }
+  const int n0 = wv_bcast_i(n, 0), n1 = wv_bcast_i(n, 1);
+  h = hs;
+  has = lane < 2 && n > 0;
+  rank = lane == 0 ? 0 : n0;
+  return n0 + n1;
+}
+
 // box : box (mjc_BoxBox, engine_collision_box.c:697-1066).
 //   1. separating axes: lane a < 15 evaluates axis a (3 + 3 face normals, 9 edge cross products)
 //      straight from the two rotation matrices in memory; any positive separation ends the test;
@@ -819,6 +986,7 @@ MJH_DEVN int collide_coop_pair(MREF M_, BREF B_, int e_, int pq, int first) {
   if (func == MJH_COL_PLANE_BOX) cnt = coop_plane_box(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
   else if (func == MJH_COL_PLANE_CYLINDER) cnt = coop_plane_cylinder(hc, has, rank, margin, c1, mcol(mat1, 2), c2, mat2, size2);
   else if (func == MJH_COL_BOX_BOX) cnt = coop_box_box(hc, has, rank, margin, c1, mat1, size1, c2, mat2, size2);
+  else if (func == MJH_COL_CAPSULE_BOX) cnt = coop_capsule_box(hc, has, rank, margin, c1, mat1, size1, c2, mat2, size2);
   int overflow = 0;
   if (has) {
     const int c = first + rank;

@@ -117,6 +117,7 @@ static int pair_func(int t1, int t2, int* maxcon) {
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_BOX) { *maxcon = 1; return MJH_COL_SPHERE_BOX; }
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CYLINDER) { *maxcon = 1; return MJH_COL_SPHERE_CYLINDER; }
   if (t1 == mjGEOM_BOX && t2 == mjGEOM_BOX) { *maxcon = 8; return MJH_COL_BOX_BOX; }
+  if (t1 == mjGEOM_CAPSULE && t2 == mjGEOM_BOX) { *maxcon = 2; return MJH_COL_CAPSULE_BOX; }
   // convex primitives the reference sends to its GJK/EPA or box routines: the pair stays in the list
   // (so ordering and filtering match) but reaching its narrowphase raises mjhip's UNSUPPORTED warning
   auto prim = [](int t) { return t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER ||

@@ -584,7 +584,7 @@ enum {
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
   MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
-  MJH_COL_PLANE_BOX = 7, MJH_COL_SPHERE_BOX = 8, MJH_COL_SPHERE_CYLINDER = 9, MJH_COL_BOX_BOX = 10,
+  MJH_COL_PLANE_BOX = 7, MJH_COL_SPHERE_BOX = 8, MJH_COL_SPHERE_CYLINDER = 9, MJH_COL_BOX_BOX = 10, MJH_COL_CAPSULE_BOX = 11,
   MJH_COL_UNSUPPORTED = 6,   // convex pair without a GPU collider: raises MJH_WARN_UNSUPPORTED if it survives the filter
 };
 

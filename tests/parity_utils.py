@@ -407,6 +407,28 @@ BOXBOX_XML = """
 """
 
 
+# capsules against boxes (mjc_CapsuleBox): lying on a table (two contacts along the capsule), standing
+# on it, hanging over an edge, leaning on a corner, crossing a thin bar, plus one inside a box's margin
+CAPBOX_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="60"/>
+  <worldbody>
+    <geom type="plane" size="4 4 .01"/>
+    <geom name="table" type="box" size=".4 .3 .05" pos="0 0 .3" euler="0 0 15"/>
+    <geom name="bar" type="box" size=".5 .03 .03" pos="1.5 0 .3" euler="0 0 20"/>
+    <geom name="step" type="box" size=".2 .2 .1" pos="-1 0 .1" margin=".01"/>
+    <body pos="-.1 -.05 .395" euler="90 0 30"><freejoint/><geom type="capsule" size=".04 .15" condim="3"/></body>
+    <body pos=".15 .1 .55" euler="3 2 0"><freejoint/><geom type="capsule" size=".04 .15" condim="3"/></body>
+    <body pos=".38 0 .39" euler="0 90 15"><freejoint/><geom type="capsule" size=".03 .2" condim="4"/></body>
+    <body pos="-.3 -.28 .42" euler="50 20 0"><freejoint/><geom type="capsule" size=".05 .1" condim="3"/></body>
+    <body pos="1.5 0 .365" euler="90 0 80"><freejoint/><geom type="capsule" size=".03 .3" condim="1"/></body>
+    <body pos="-1 .1 .26" euler="0 80 45"><freejoint/><geom type="capsule" size=".05 .12" condim="3"/></body>
+    <body pos="-.8 -.1 .3" euler="20 0 0"><freejoint/><geom type="capsule" size=".04 .2" condim="6"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
 # mocap bodies: a gripper-like box welded to a mocap target that the control array moves
 # (mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT in the control spec), a second mocap body carrying a
 # collision geom that pushes a free sphere around

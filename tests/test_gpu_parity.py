@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -330,6 +330,30 @@ def test_box_box_collider_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     print("box-box scene cone", cone, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
     assert relerr(out, ref) <= TOL
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("cone", [0, 1])
+def test_capsule_box_collider_vs_live_oracle(rb, hip_lib, tmp_path, cone):
+    """capsules lying on, standing on, hanging over and crossing boxes (mjc_CapsuleBox)"""
+    xml = tmp_path / "capbox.xml"
+    xml.write_text(CAPBOX_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    dmb = K.DeviceModel(hip_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(4).normal(0, .3, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 250
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmb, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("capsule-box scene cone", cone, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
 def test_mocap_bodies_vs_live_oracle(rb, hip_lib, tmp_path):

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -430,6 +430,79 @@ def test_box_box_collider_bit_exact(rb, hostsim_lib, tmp_path, cone):
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+@pytest.mark.parametrize("cone", [0, 1])
+def test_capsule_box_collider_bit_exact(rb, hostsim_lib, tmp_path, cone):
+    """mjc_CapsuleBox (engine_collision_box.c:114-653): 2 end-point + 12 edge candidates on 14 lanes,
+    in-order winner, second sphere by the corner / edge / face case analysis; a scene of capsules
+    lying on, standing on, hanging over and crossing boxes"""
+    xml = tmp_path / "capbox.xml"
+    xml.write_text(CAPBOX_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(4).normal(0, .3, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 150
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 0].max() >= 8
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+def test_capsule_box_random_poses_bit_exact(rb, hostsim_lib, tmp_path):
+    """one capsule in 300 random / upright / lying / exactly axis-aligned poses around a box: contact
+    count, distance, position and frame equal the reference's bit for bit (every branch of the
+    closest-feature search: faces, edge interiors, corners, parallel-axis skips)"""
+    xml = tmp_path / "capbox1.xml"
+    xml.write_text("""
+<mujoco><worldbody>
+  <geom name="table" type="box" size=".4 .3 .05" pos="0 0 .3" euler="0 0 15"/>
+  <body pos="0 0 .5"><freejoint/><geom type="capsule" size=".04 .15" condim="3"/></body>
+</worldbody></mujoco>""")
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m, 8, 32)
+    d = rb.MjData(m)
+    rng = np.random.default_rng(11)
+    N = 300
+    qpos = np.zeros((N, 7))
+    tz = np.array([np.cos(np.radians(7.5)), 0, 0, np.sin(np.radians(7.5))])     # the table's yaw
+    for k in range(N):
+        q = rng.normal(size=4)
+        if k % 4 == 1: q = np.array([1, 0, 0, 0.]) + rng.normal(size=4)*1e-3
+        if k % 4 == 2: q = np.array([1, 1, 0, 0.]) + rng.normal(size=4)*1e-3
+        if k % 4 == 3: q = tz.copy()
+        if k % 8 == 7:       # lying along the table's x axis: yaw * (90 degrees about y)
+            w1, x1, y1, z1 = tz; w2, x2, y2, z2 = np.cos(np.pi/4), 0, np.sin(np.pi/4), 0
+            q = np.array([w1*w2 - x1*x2 - y1*y2 - z1*z2, w1*x2 + x1*w2 + y1*z2 - z1*y2,
+                          w1*y2 - x1*z2 + y1*w2 + z1*x2, w1*z2 + x1*y2 - y1*x2 + z1*w2])
+        qpos[k, :3] = [rng.uniform(-.55, .55), rng.uniform(-.45, .45), rng.uniform(.2, .55)]
+        qpos[k, 3:] = q / np.linalg.norm(q)
+    b = K.Batch(dm, N)
+    b.reset()
+    b.set("qpos", qpos)
+    b.forward()
+    counts = b.get("counts")[:, 0]
+    cd = b.get("con_dist"); cp = b.get("con_pos").reshape(N, -1, 3); cf = b.get("con_frame").reshape(N, -1, 9)
+    hist = {0: 0, 1: 0, 2: 0}
+    for k in range(N):
+        rb.mj_resetData(m, d)
+        d.qpos[:] = qpos[k]
+        rb.mj_forward(m, d)
+        n = d.ncon
+        hist[n] += 1
+        assert counts[k] == n, k
+        rc = d.contact[:n]
+        assert np.array_equal(cd[k, :n], rc["dist"]) and np.array_equal(cp[k, :n], rc["pos"]) and np.array_equal(cf[k, :n], rc["frame"]), k
+    assert hist[1] > 50 and hist[2] > 20
 
 
 def _mocap_controls(m, T):
