@@ -61,7 +61,10 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 
 // ARL = 1: AR is resident in LDS and is read with ds_read through a local-address-space pointer
 // (in-order returns let the next row's prefetch stay in flight; a flat load would have to drain)
-template <int ARL>
+// LT >= 0: the chain length L = nefc/4 is a compile-time constant (the caller dispatches on it): the
+// chain of a row update is then straight-line code -- no scalar branch per chain step, the DPP moves
+// of a row scheduled ahead of the dependent adds.
+template <int ARL, int LT = -1>
 MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
   BREF B = B_;
@@ -71,7 +74,7 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   Efc P;
   efc_layout(M, B, e, n, P);
   const int lane = wv_lane();
-  const int n4 = n & ~3, L = n4 >> 2, ntail = n - n4;
+  const int n4 = n & ~3, L = LT >= 0 ? LT : (n4 >> 2), ntail = n - n4;
   const int row = lane >> 4, col = lane & 15;
   // constraint owned by this lane (-1: none)
   int j = -1;
@@ -890,7 +893,20 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 #if defined(MJH_HOSTSIM)
     solve_pgs_fast<0>(M, B, e);
 #else
+#if MJH_W == 64 && !defined(MJH_PGS_NO_LSPEC)
+    if (mjh_in_lds(P.AR)) {
+      switch (nefc >> 2) {
+#define MJH_PGS_CASE(k) case k: solve_pgs_fast<1, k>(M, B, e); break;
+        MJH_PGS_CASE(0) MJH_PGS_CASE(1) MJH_PGS_CASE(2) MJH_PGS_CASE(3) MJH_PGS_CASE(4) MJH_PGS_CASE(5)
+        MJH_PGS_CASE(6) MJH_PGS_CASE(7) MJH_PGS_CASE(8) MJH_PGS_CASE(9) MJH_PGS_CASE(10) MJH_PGS_CASE(11)
+        MJH_PGS_CASE(12) MJH_PGS_CASE(13) MJH_PGS_CASE(14) MJH_PGS_CASE(15)
+#undef MJH_PGS_CASE
+        default: solve_pgs_fast<1, 16>(M, B, e); break;
+      }
+    }
+#else
     if (mjh_in_lds(P.AR)) solve_pgs_fast<1>(M, B, e);
+#endif
     else solve_pgs_fast<0>(M, B, e);
 #endif
   } else

@@ -54,6 +54,28 @@ def test_rollout_vs_golden(hip_lib, dm, golden):
     assert np.all(np.isfinite(one))
 
 
+def test_soa_layout_forward_and_rollout_vs_live_oracle(rb, hip_lib, dm, golden):
+    """the SoA-across-environments layout (north_star's coalesced layout: lane-per-environment smooth
+    and integrate kernels + the wave-per-environment constraint kernel): every FORWARD field against
+    the oracle, and a rollout that equals the environment-major default's bit for bit"""
+    m = humanoid_pgs_oracle(rb)
+    states = contact_rich_states(rb, m, 70, seed=13)      # > 64: the lane-mode kernels span two wavefronts
+    b = K.Batch(dm, len(states), layout="soa")
+    worst = check_forward(rb, m, b, states, tol=TOL)
+    print("SoA forward worst rel err", worst)
+    fx = golden("humanoid")
+    n = fx["state0"].shape[0]
+    T = 40
+    bs = K.Batch(dm, n, layout="soa")
+    out_soa = bs.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    ba = K.Batch(dm, n)
+    out_aos = ba.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    assert np.array_equal(out_soa, out_aos)
+    assert relerr(out_soa[:, :10], fx["state"][:, :10]) <= TOL
+    assert np.array_equal(bs.get("counts")[:, :3], ba.get("counts")[:, :3])
+    assert bs.get("warning").sum() == 0
+
+
 def test_single_step_parity_vs_live_oracle(rb, hip_lib, dm):
     """one mj_step from identical (state, warmstart, ctrl): qpos/qvel within 1e-6 relative, integer
     observables exact (the north_star's parity statement)"""
