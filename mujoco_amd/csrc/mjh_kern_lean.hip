@@ -7,4 +7,9 @@
 #define MJH_INLINE_STAGES 1
 #define MJH_BUILD_WL 1
 #include "mjh_kernels.h"
-MJH_DEFINE_WAVE_KERNELS(wl, 1, 4, 0)
+// (MJH_LEAN_WPE: measurement builds only -- tools/gpu_traffic.sh compiles a 2-waves-per-SIMD / 256-VGPR
+// copy to separate spill traffic from the rest)
+#ifndef MJH_LEAN_WPE
+#define MJH_LEAN_WPE 4
+#endif
+MJH_DEFINE_WAVE_KERNELS(wl, 1, MJH_LEAN_WPE, 0)
