@@ -507,7 +507,9 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
                           "subtree_com", "cinert", "cdof", "cdof_dot", "cvel", "ten_length", "ten_velocity", "ten_J",
                           "actuator_length", "actuator_velocity", "actuator_force", "qfrc_actuator",
                           "con_dist", "con_pos", "con_frame", "con_mu", "con_pair", "con_geom", "con_dim",
-                          "con_exclude", "con_efcadr"})
+                          "con_exclude", "con_efcadr",
+                          // born at finish: they would overlay the constraint arrays the sensors still read
+                          "qH2", "qH2DiagInv", "qe"})
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_gravcomp) eqskip.push_back("xipos");    // read by the passive stage

@@ -678,6 +678,96 @@ MJH_DEVN_HOT void solve_ld_fast(MREF M_, P0 xmem, P1 qLD, P2 diaginv) {
   if (lane < nv) xmem[li] = x;
   wv_sync();
 }
+#if MJH_W == 64
+// Two independent solves with the same sparsity in one pass, nv <= 32: lanes 0..31 carry system A
+// (xa, qLDa, dinva), lanes 32..63 system B.  The sweeps of solve_ld_fast are chains of dependent
+// cross-lane steps that keep fewer than half of the wavefront busy; running a second system in the
+// idle half costs no extra steps.  Per system the arithmetic and its order are those of
+// solve_ld_fast (and of mj_solveLD).
+template <class XA, class XB, class Q, class DI>
+MJH_DEVN_HOT void solve_ld_pair(MREF M_, XA xa_mem, Q qLDa, DI dinva, XB xb_mem, Q qLDb, DI dinvb) {
+  MREF M = wv_uniform_ref(M_);
+  const auto* colind = wv_uniform_ptr(M.M_colind);
+  const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);
+  const int nv = M.s.nv;
+  const int lane = wv_lane();
+  const int half = lane >> 5, hl = lane & 31, base = lane & 32;
+  const int li = hl < nv ? hl : 0;
+  const int myadr = wv_uniform_ptr(M.M_rowadr)[li];
+  const int mynnz = wv_uniform_ptr(M.M_rownnz)[li];
+  const int mydepth = mynnz - 1;
+  const int anc_lo = ancmask[2*li];
+  // value of v in lane i of my half
+  auto hb = [&](real v, int i) -> real { const real a = wv_bcast(v, i), b = wv_bcast(v, 32 + i); return half ? b : a; };
+  auto qld = [&](int k) -> real { return half ? (real)qLDb[k] : (real)qLDa[k]; };
+  real x = 0, dinv = 0;
+  if (hl < nv) { x = half ? (real)xb_mem[li] : (real)xa_mem[li]; dinv = half ? (real)dinvb[li] : (real)dinva[li]; }
+
+  // x <- L^-T x
+  int ilast = nv - 1;
+  while (ilast > 0 && wv_bcast_i(mynnz, ilast) == 1) ilast--;
+  real q = 0;
+  {
+    const int lo = wv_bcast_i(anc_lo, ilast);
+    const int adr = wv_bcast_i(myadr, ilast);
+    if ((lo >> hl) & 1) q = qld(adr + mydepth);
+  }
+  for (int i = ilast; i > 0; ) {
+    int inext = i - 1;
+    while (inext > 0 && wv_bcast_i(mynnz, inext) == 1) inext--;
+    real qnext = 0;
+    if (inext > 0) {
+      const int lo = wv_bcast_i(anc_lo, inext);
+      const int adr = wv_bcast_i(myadr, inext);
+      if ((lo >> hl) & 1) qnext = qld(adr + mydepth);
+    }
+    const real xi = hb(x, i);
+    const int lo = wv_bcast_i(anc_lo, i);
+    if (xi != 0 && ((lo >> hl) & 1)) x -= q * xi;
+    q = qnext;
+    i = inext;
+  }
+  // x <- D^-1 x
+  x *= dinv;
+  // x <- L^-1 x
+  int anc_n = 0;
+  real qk_n = 0;
+  if (nv > 1) {
+    const int nnz1 = wv_bcast_i(mynnz, 1) - 1, adr = wv_bcast_i(myadr, 1);
+    if (hl < nnz1) { anc_n = colind[adr + hl]; qk_n = qld(adr + hl); }
+  }
+  for (int i = 1; i < nv; i++) {
+    const int nnz1 = wv_bcast_i(mynnz, i) - 1;
+    const int anc = anc_n;
+    const real qk = qk_n;
+    anc_n = 0; qk_n = 0;
+    if (i + 1 < nv) {
+      const int nnz1n = wv_bcast_i(mynnz, i + 1) - 1, adrn = wv_bcast_i(myadr, i + 1);
+      if (hl < nnz1n) { anc_n = colind[adrn + hl]; qk_n = qld(adrn + hl); }
+    }
+    if (nnz1 == 0) continue;
+    const real xa = wv_shfl(x, base + anc);
+    const real p = qk * xa;
+    const int n4 = nnz1 & ~3, L = n4 >> 2;
+    real acc = 0;
+    if (L > 0) {
+      acc = acc + p;
+      if (L > 1) {
+        acc = acc + wv_row_shl<4>(p);
+        if (L > 2) {
+          acc = acc + wv_row_shl<8>(p);
+          if (L > 3) acc = acc + wv_row_shl<12>(p);
+        }
+      }
+    }
+    real res = (hb(acc, 0) + hb(acc, 2)) + (hb(acc, 1) + hb(acc, 3));
+    for (int t = n4; t < nnz1; t++) res += hb(p, t);
+    if (hl == i) x -= res;
+  }
+  if (hl < nv) { if (half) xb_mem[li] = x; else xa_mem[li] = x; }
+  wv_sync();
+}
+#endif
 #endif  // !MJH_LANE_MODE
 
 // ------------------------------------------------------------------------------------------------
@@ -774,6 +864,21 @@ MJH_DEVN void solve_ld(MREF M, P0 x, P1 qLD, P2 diaginv) {
     }
     wv_sync();
   }
+}
+
+// two solves at once where the paired routine applies (both factors in the same address space),
+// else one after the other
+template <class XA, class XB, class QA, class QB, class DA, class DB>
+MJH_DEV void solve_ld_two(MREF M, XA xa, QA qLDa, DA dinva, XB xb, QB qLDb, DB dinvb) {
+#if !MJH_LANE_MODE && MJH_W == 64
+  if (M.s.ld_fast && M.s.nv <= 32) {
+    const int la = mjh_in_lds(qLDa), lb = mjh_in_lds(qLDb);
+    if (la && lb) { solve_ld_pair(M, xa, mjh_local(qLDa.p), dinva, xb, mjh_local(qLDb.p), dinvb); return; }
+    if (!la && !lb) { solve_ld_pair(M, xa, qLDa, dinva, xb, qLDb, dinvb); return; }
+  }
+#endif
+  solve_ld(M, xa, qLDa, dinva);
+  solve_ld(M, xb, qLDb, dinvb);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -340,7 +340,13 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
   crptr qacc = MJH_F(B, qacc, e);
   rptr qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
 
-  if (M.o.euler_damp) {
+  iptr counts = MJH_F(B, counts, e);
+  const int paired = counts[MJH_C_PAIRED];      // stage_finish already solved the damped system into qe
+  wv_sync();
+  if (wv_lane() == 0) counts[MJH_C_PAIRED] = 0;
+  if (paired) {
+    // nothing to do
+  } else if (M.o.euler_damp) {
     crptr Mq = MJH_G(B, qH, e);
     rptr qH = MJH_F(B, qLD, e);
     rptr qHDiagInv = MJH_F(B, qLDiagInv, e);

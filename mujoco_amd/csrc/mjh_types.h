@@ -353,6 +353,9 @@ enum {
   X(qLD, s.nC, s.nC, MJH_T_FACTOR, MJH_T_EULER)                                   \
   X(qLDiagInv, s.nv, s.nv, MJH_T_FACTOR, MJH_T_EULER)                             \
   X(qH, s.nC, 0, MJH_T_GLB, MJH_T_GLB)                                            \
+  /* factor of qH = M + h*diag(B) when mj_Euler's solve is paired with the finish solve (stage_finish) */ \
+  X(qH2, s.nC, s.nC, MJH_T_FINISH, MJH_T_EULER)                                   \
+  X(qH2DiagInv, s.nv, s.nv, MJH_T_FINISH, MJH_T_EULER)                            \
   X(cvel, 6 * s.nbody, 6 * s.nbody, MJH_T_COMVEL, MJH_T_RNE)                      \
   X(cdof_dot, 6 * s.nv, 6 * s.nv, MJH_T_COMVEL, MJH_T_RNE)                        \
   X(cacc, 6 * s.nbody, 6 * s.nbody, MJH_T_RNE, MJH_T_RNE)                         \
@@ -366,7 +369,7 @@ enum {
   X(qacc_smooth, s.nv, s.nv, MJH_T_ACCEL, MJH_T_FINISH)                           \
   X(qfrc_constraint, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_EULER)                   \
   X(qacc, s.nv, s.nv, MJH_T_CONSTRAINT, MJH_T_END)                                \
-  X(qe, s.nv, s.nv, MJH_T_EULER, MJH_T_EULER)                                     \
+  X(qe, s.nv, s.nv, MJH_T_FINISH, MJH_T_EULER)                                     \
   X(con_dist, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                \
   X(con_pos, 3 * s.nconmax, 3 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)         \
   X(con_frame, 9 * s.nconmax, 9 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)       \
@@ -448,6 +451,7 @@ enum {
 #define MJH_C_NL 4
 #define MJH_C_NITER 5
 #define MJH_C_NISLAND 6
+#define MJH_C_PAIRED 7     // stage_finish already produced mj_Euler's damped acceleration (qe) for this step
 
 // name : global home, n_name : per-env element count of the home, l_name : byte offset inside the
 // workgroup's LDS block or -1, io_name : bit 0 = copy home -> LDS at kernel entry (live-in),
