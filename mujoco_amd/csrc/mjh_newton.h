@@ -171,7 +171,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   const real tol = M.o.tolerance;
 
   // ---- dense M from the parked sparse copy (CSR lower triangle, diagonal last in each row)
-  crptr Ms = MJH_G(B, qH, e);
+  crptr Ms = MJH_G(B, M, e);
   MJH_FOR_LANES(k, nv*nv) Md[k] = 0;
   wv_sync();
   MJH_FOR_LANES(i, nv) {

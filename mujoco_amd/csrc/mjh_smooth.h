@@ -521,7 +521,7 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
   crptr cinert = MJH_F(B, cinert, e);
   crptr cdof = MJH_F(B, cdof, e);
   rptr crb = MJH_F(B, crb, e);
-  rptr Mq = MJH_F(B, M, e);
+  rptr Mq = MJH_F(B, qLD, e);       // M is assembled where it will be factorised
 
   MJH_FOR_LANES(k, 10*s.nbody) crb[k] = cinert[k];
   wv_sync();
@@ -543,6 +543,9 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
       }
     }
   }
+  wv_sync();
+  rptr Mhome = MJH_G(B, M, e);
+  MJH_FOR_LANES(k, s.nC) Mhome[k] = Mq[k];
   wv_sync();
 }
 
@@ -590,6 +593,51 @@ MJH_DEVN_HOT void factor_ld_fast(MREF M_, P0 mat, P1 diaginv) {
     item = item_next;
   }
 }
+
+#if MJH_W == 64
+// Two matrices of M's sparsity factorised in one pass: lanes 0..31 update matrix A, lanes 32..63
+// matrix B, pivot by pivot with the same work list.  The per-pivot chain (pivot read, reciprocal,
+// two barriers) is paid once for both.
+template <class P0, class P1>
+MJH_DEVN_HOT void factor_ld_pair(MREF M_, P0 matA, P1 diaginvA, P0 matB, P1 diaginvB) {
+  MREF M = wv_uniform_ref(M_);
+  const auto* ld_prog = wv_uniform_ptr(M.ld_prog);
+  const int nv = M.s.nv;
+  const int lane = wv_lane();
+  const int half = lane >> 5, hl = lane & 31;
+  const int li = hl < nv ? hl : 0;
+  const int myadr = wv_uniform_ptr(M.M_rowadr)[li];
+  const int mynnz = wv_uniform_ptr(M.M_rownnz)[li];
+  const int myprog = wv_uniform_ptr(M.ld_prog_adr)[li];
+  auto at = [&](int k) -> real { return half ? (real)matB[k] : (real)matA[k]; };
+  auto put = [&](int k, real v) { if (half) matB[k] = v; else matA[k] = v; };
+  const int first = wv_bcast_i(myprog, nv - 1) + hl;
+  int item = ld_prog[first < M.s.nldprog ? first : 0];
+  for (int k = nv - 1; k >= 0; k--) {
+    const int start = wv_bcast_i(myadr, k);
+    const int diag = wv_bcast_i(mynnz, k) - 1;
+    const int pbase = wv_bcast_i(myprog, k);
+    const int total = diag*(diag + 1)/2;
+    int item_next = 0;
+    if (k > 0) {
+      int nb = wv_bcast_i(myprog, k - 1) + hl;
+      item_next = ld_prog[nb < M.s.nldprog ? nb : 0];
+    }
+    const real invD = 1 / at(start + diag);
+    for (int w = hl; w < total; w += 32) {
+      const int it = (w < 32) ? item : (int)ld_prog[pbase + w];
+      const int dst = it & 1023, src = (it >> 10) & 1023, sc = (it >> 20) & 1023;
+      const real scl = -at(sc) * invD;
+      put(dst, at(dst) + at(src) * scl);
+    }
+    wv_sync();
+    if (hl < diag) put(start + hl, at(start + hl) * invD);     // diag <= 16
+    if (hl == 0) { if (half) diaginvB[k] = invD; else diaginvA[k] = invD; }
+    wv_sync();
+    item = item_next;
+  }
+}
+#endif
 
 template <class P0, class P1, class P2>
 MJH_DEVN_HOT void solve_ld_fast(MREF M_, P0 xmem, P1 qLD, P2 diaginv) {
@@ -817,13 +865,55 @@ MJH_DEVN void factor_ld(MREF M, P0 mat, P1 diaginv) {
   }
 }
 
+// does stage_finish also produce mj_Euler's damped acceleration, and stage_factor_m the factor it needs?
+// (Euler integrator with joint damping, register-resident L'DL routines, nv <= 32, environment-major batch)
+MJH_DEV int pairs_euler_solve(MREF M, BREF B) {
+#if !MJH_LANE_MODE && MJH_W == 64
+  return M.o.euler_damp && M.o.integrator == MJH_INT_EULER && M.s.ld_fast && M.s.nv <= 32 && B.soa == 0;
+#else
+  return 0;
+#endif
+}
+
+template <class P0> MJH_DEV real poly_force_deriv(real linear, P0 poly, real x, int odd);
+// did stage_factor_m leave the factor of qH in qH2's global home?  (the condition it evaluates)
+MJH_DEV int pairs_euler_factor(MREF M, BREF B, int e) {
+#if !MJH_LANE_MODE && MJH_W == 64
+  return pairs_euler_solve(M, B) && mjh_in_lds(MJH_F(B, qLD, e)) == mjh_in_lds(MJH_F(B, qHtmp, e));
+#else
+  return 0;
+#endif
+}
+
 MJH_DEVN void stage_factor_m(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
-  crptr Mq = MJH_F(B, M, e);
-  rptr qLD = MJH_F(B, qLD, e);
-  rptr Mkeep = MJH_G(B, qH, e);     // M parked in global memory for mj_Euler's qH = M + h*diag(B)
-  MJH_FOR_LANES(k, M.s.nC) { real v = Mq[k]; qLD[k] = v; Mkeep[k] = v; }
-  wv_sync();
+  rptr qLD = MJH_F(B, qLD, e);      // holds M (stage_crb)
+#if !MJH_LANE_MODE && MJH_W == 64
+  if (pairs_euler_factor(M, B, e)) {
+    // qH = M + h*diag(B) is factorised in the same pass as M (factor_ld_pair) while the LDS that will hold
+    // the constraint arrays is still free, parked in its global home, and picked up again by stage_finish
+    rptr qHt = MJH_F(B, qHtmp, e);
+    rptr qHtD = MJH_F(B, qHtmpDiagInv, e);
+    rptr qLDD = MJH_F(B, qLDiagInv, e);
+    const real h = M.o.timestep;
+    crptr qvel = MJH_F(B, qvel, e);
+    MJH_FOR_LANES(k, M.s.nC) qHt[k] = qLD[k];
+    wv_sync();
+    MJH_FOR_LANES(i, M.s.nv) {
+      real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+      qHt[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+    }
+    wv_sync();
+    if (mjh_in_lds(qLD)) factor_ld_pair(M, mjh_local(qLD.p), qLDD, mjh_local(qHt.p), qHtD);
+    else factor_ld_pair(M, qLD, qLDD, qHt, qHtD);
+    rptr qHg = MJH_G(B, qH2, e);
+    rptr qHgD = MJH_G(B, qH2DiagInv, e);
+    MJH_FOR_LANES(k, M.s.nC) qHg[k] = qHt[k];
+    MJH_FOR_LANES(i, M.s.nv) qHgD[i] = qHtD[i];
+    wv_sync();
+    return;
+  }
+#endif
   factor_ld(M, qLD, MJH_F(B, qLDiagInv, e));
 }
 

@@ -930,16 +930,6 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 }
 
 // mj_dualFinish, second half: qacc = M \ qfrc_constraint + qacc_smooth   (engine_solver.c:80-84)
-// does stage_finish also produce mj_Euler's damped acceleration?  (Euler integrator with joint damping,
-// register-resident L'DL routines, nv <= 32, environment-major batch)
-MJH_DEV int pairs_euler_solve(MREF M, BREF B) {
-#if !MJH_LANE_MODE && MJH_W == 64
-  return M.o.euler_damp && M.o.integrator == MJH_INT_EULER && M.s.ld_fast && M.s.nv <= 32 && B.soa == 0;
-#else
-  return 0;
-#endif
-}
-
 MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const int nv = M.s.nv;
@@ -962,22 +952,31 @@ MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
   // Its factor goes to a slot of its own (the constraint arrays are dead by now).
   if (pairs_euler_solve(M, B)) {
     const MJH_CONST_AS DSizes& s = M.s;
-    const real h = M.o.timestep;
-    crptr Mq = MJH_G(B, qH, e);
     rptr qH = MJH_F(B, qH2, e);
     rptr qHDiagInv = MJH_F(B, qH2DiagInv, e);
-    crptr qvel = MJH_F(B, qvel, e);
     crptr fs = MJH_F(B, qfrc_smooth, e);
     rptr qe = MJH_F(B, qe, e);
-    MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
     MJH_FOR_LANES(i, nv) qe[i] = fs[i] + qfc[i];
-    wv_sync();
-    MJH_FOR_LANES(i, nv) {
-      real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
-      qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+    crptr qHDg = MJH_G(B, qH2DiagInv, e);
+    if (pairs_euler_factor(M, B, e)) {
+      // the factor stage_factor_m parked in the global home (nothing to fetch if that is where qH2 lives)
+      crptr qHg = MJH_G(B, qH2, e);
+      if (qH.p != qHg.p) MJH_FOR_LANES(k, s.nC) qH[k] = qHg[k];
+      if (qHDiagInv.p != qHDg.p) MJH_FOR_LANES(i, nv) qHDiagInv[i] = qHDg[i];
+      wv_sync();
+    } else {
+      const real h = M.o.timestep;
+      crptr Mq = MJH_G(B, M, e);
+      crptr qvel = MJH_F(B, qvel, e);
+      MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
+      wv_sync();
+      MJH_FOR_LANES(i, nv) {
+        real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+        qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+      }
+      wv_sync();
+      factor_ld(M, qH, qHDiagInv);
     }
-    wv_sync();
-    factor_ld(M, qH, qHDiagInv);
     solve_ld_two(M, qacc, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e), qe, qH, qHDiagInv);
     if (wv_lane() == 0) counts[MJH_C_PAIRED] = 1;
     MJH_FOR_LANES(j, nv) qacc[j] += qas[j];

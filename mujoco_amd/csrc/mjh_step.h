@@ -347,7 +347,7 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
   if (paired) {
     // nothing to do
   } else if (M.o.euler_damp) {
-    crptr Mq = MJH_G(B, qH, e);
+    crptr Mq = MJH_G(B, M, e);
     rptr qH = MJH_F(B, qLD, e);
     rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
     MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
@@ -452,7 +452,7 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   rptr qpos = MJH_F(B, qpos, e);
   crptr qacc = MJH_F(B, qacc, e);
   rptr qe = MJH_F(B, qe, e);
-  crptr Mq = MJH_G(B, qH, e);
+  crptr Mq = MJH_G(B, M, e);
   rptr qH = MJH_F(B, qLD, e);
   rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
   crptr mom = MJH_F(B, actuator_moment, e);

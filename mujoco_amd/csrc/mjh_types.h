@@ -349,12 +349,16 @@ enum {
   X(actuator_velocity, s.nu, s.nu, MJH_T_TAVEL, MJH_T_ACTUATION)                  \
   X(actuator_force, s.nu, s.nu, MJH_T_ACTUATION, MJH_T_ACTUATION)                 \
   X(crb, 10 * s.nbody, 10 * s.nbody, MJH_T_CRB, MJH_T_CRB)                        \
-  X(M, s.nC, s.nC, MJH_T_CRB, MJH_T_FACTOR)                                       \
-  X(qLD, s.nC, s.nC, MJH_T_FACTOR, MJH_T_EULER)                                   \
+  /* the mass matrix is assembled in qLD's slot (stage_crb) and copied to this global home: the copy tests \
+     inspect and the one mj_Euler / implicitfast / Newton read after qLD has been factorised in place */ \
+  X(M, s.nC, 0, MJH_T_GLB, MJH_T_GLB)                                             \
+  X(qLD, s.nC, s.nC, MJH_T_CRB, MJH_T_EULER)                                   \
   X(qLDiagInv, s.nv, s.nv, MJH_T_FACTOR, MJH_T_EULER)                             \
-  X(qH, s.nC, 0, MJH_T_GLB, MJH_T_GLB)                                            \
   /* factor of qH = M + h*diag(B) when mj_Euler's solve is paired with the finish solve (stage_finish) */ \
   X(qH2, s.nC, s.nC, MJH_T_FINISH, MJH_T_EULER)                                   \
+  /* qH while it is factorised next to M (stage_factor_m); parked in qH2's global home until finish */ \
+  X(qHtmp, s.nC, s.nC, MJH_T_FACTOR, MJH_T_FACTOR)                                \
+  X(qHtmpDiagInv, s.nv, s.nv, MJH_T_FACTOR, MJH_T_FACTOR)                         \
   X(qH2DiagInv, s.nv, s.nv, MJH_T_FINISH, MJH_T_EULER)                            \
   X(cvel, 6 * s.nbody, 6 * s.nbody, MJH_T_COMVEL, MJH_T_RNE)                      \
   X(cdof_dot, 6 * s.nv, 6 * s.nv, MJH_T_COMVEL, MJH_T_RNE)                        \
