@@ -803,38 +803,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     if (H->ld_prog.empty()) H->ld_prog.push_back(0);
     s.nldprog = (int)H->ld_prog.size();
   }
-  // PGS visitation orders for nefc = 1..64 (engine_solver.c:241-265, :498-502): PCG32 with
-  // state = 0, inc = 1 and one warm-up draw per solver call; every iteration Fisher-Yates-shuffles
-  // the order array left by the previous iteration with j = next % (i+1), i = n-1 .. 1
-  {
-    s.pgs_iters = std::max(0, std::min((int)m->opt.iterations, 128));
-    H->pgs_order_adr.assign(66, 0);
-    H->pgs_order.clear();
-    for (int n = 0; n <= 64; n++) {
-      H->pgs_order_adr[n] = (int)H->pgs_order.size();
-      uint64_t state = 0, inc = 1;
-      auto next = [&]() {
-        uint64_t old = state;
-        state = old * 6364136223846793005ULL + (inc | 1);
-        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
-        uint32_t rot = (uint32_t)(old >> 59u);
-        return (uint32_t)((xorshifted >> rot) | (xorshifted << ((-rot) & 31)));
-      };
-      next();
-      std::vector<int> order(n);
-      for (int i = 0; i < n; i++) order[i] = i;
-      for (int it = 0; it < s.pgs_iters; it++) {
-        for (int i = n - 1; i > 0; i--) {
-          uint32_t j = next() % (uint32_t)(i + 1);
-          std::swap(order[i], order[j]);
-        }
-        H->pgs_order.insert(H->pgs_order.end(), order.begin(), order.end());
-      }
-    }
-    H->pgs_order_adr[65] = (int)H->pgs_order.size();
-    if (H->pgs_order.empty()) H->pgs_order.push_back(0);
-    s.npgsorder = (int)H->pgs_order.size();
-  }
   int rows_per_con = 1;
   for (int c : H->pair_dim)
     rows_per_con = std::max(rows_per_con, c == 1 ? 1 : (m->opt.cone == mjCONE_PYRAMIDAL ? 2*(c-1) : c));
@@ -937,6 +905,39 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 256));
+  // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with
+  // state = 0, inc = 1 and one warm-up draw per solver call; every iteration Fisher-Yates-shuffles
+  // the order array left by the previous iteration with j = next % (i+1), i = n-1 .. 1
+  {
+    s.pgs_iters = std::max(0, std::min((int)m->opt.iterations, 128));
+    H->pgs_order_adr.assign(130, 0);
+    H->pgs_order.clear();
+    s.pgs_nmax = s.nefcmax > 64 ? 128 : 64;
+    for (int n = 0; n <= s.pgs_nmax; n++) {
+      H->pgs_order_adr[n] = (int)H->pgs_order.size();
+      uint64_t state = 0, inc = 1;
+      auto next = [&]() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + (inc | 1);
+        uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t)(old >> 59u);
+        return (uint32_t)((xorshifted >> rot) | (xorshifted << ((-rot) & 31)));
+      };
+      next();
+      std::vector<int> order(n);
+      for (int i = 0; i < n; i++) order[i] = i;
+      for (int it = 0; it < s.pgs_iters; it++) {
+        for (int i = n - 1; i > 0; i--) {
+          uint32_t j = next() % (uint32_t)(i + 1);
+          std::swap(order[i], order[j]);
+        }
+        H->pgs_order.insert(H->pgs_order.end(), order.begin(), order.end());
+      }
+    }
+    for (int n = s.pgs_nmax + 1; n < 130; n++) H->pgs_order_adr[n] = (int)H->pgs_order.size();
+    if (H->pgs_order.empty()) H->pgs_order.push_back(0);
+    s.npgsorder = (int)H->pgs_order.size();
+  }
 
   // ---------------- features this model needs from a kernel variant (MJH_FT_*, mjh_types.h) ------------
   // every `MJH_HAS(x) && condition` of the stage sources has its condition mirrored here

@@ -262,6 +262,7 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
   // static pair goes to the bounding-sphere filter and the narrowphase; conservative, but geoms that
   // touch to within rounding can then differ from the reference in contact count.  For A/B timing.)
   if (const char* ev = getenv("MJHIP_BROADPHASE")) if (atoi(ev) == 0) M->H.s.nbp = 0;
+  if (const char* ev = getenv("MJHIP_PGS_WIDE")) if (atoi(ev) == 0) M->H.s.pgs_nmax = 64;   // A/B: 64 < nefc <= 128 on the memory-based sweep
   M->D.s = M->H.s;
   M->D.o = M->H.o;
   bool ok = true;

@@ -257,6 +257,165 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   if (lane == 0) counts[MJH_C_NITER] = niter0;
   wv_sync();
 }
+// ------------------------------------------------------------------------------------------------
+// solPGS for 64 < nefc <= 128, iterate in registers, TWO constraints per lane.
+//
+// Same layout idea with chains of up to 32 positions: position k of chain c is lane 16*c + (k & 15),
+// slot k >> 4.  Slot 0 holds constraints 4*col + row (all 64 exist because nefc > 64), slot 1 holds
+// 4*(col + 16) + row while col + 16 < L, and the 1..3 tail constraints in column 15 of slot 1 (free
+// because L <= 31 whenever a tail exists).  A chain sum is the 16 row broadcasts of the slot-0
+// products followed by L - 16 of the slot-1 products: mju_dot's order.  AR (> 32 KB here) is read from
+// global memory, the coming row prefetched while the current one is reduced.  A settled humanoid
+// spends a fraction of a percent of its steps with more than 64 rows, but a launch ends with its
+// slowest environment: on the memory-based sweep those few steps set the kernel time of the whole batch.
+// No islands (the caller falls back to the generic sweep when island discovery is on).
+// ------------------------------------------------------------------------------------------------
+#define MJH_PGSW_STEP0(k) acc = acc + wv_row_bcast<k>(p0);
+#define MJH_PGSW_STEP1(k) if (L > 16 + k) { acc = acc + wv_row_bcast<k>(p1);
+#define MJH_PGSW_END }}}}}}}}}}}}}}}}
+
+MJH_DEVN_HOT void solve_pgs_wide(MREF M_, BREF B_, int e_) {
+  const auto& M = wv_uniform_ref(M_);
+  BREF B = B_;
+  const int e = wv_uniform_i(e_);
+  iptr counts = MJH_F(B, counts, e);
+  const int n = wv_uniform_i(counts[MJH_C_NEFC]), ne = wv_uniform_i(counts[MJH_C_NE]), nf = wv_uniform_i(counts[MJH_C_NF]);
+  Efc P;
+  efc_layout(M, B, e, n, P);
+  const int lane = wv_lane();
+  const int n4 = n & ~3, L = n4 >> 2, ntail = n - n4;      // 16 <= L <= 32
+  const int row = lane >> 4, col = lane & 15;
+  // my two constraints (slot 0 always exists)
+  const int j0 = 4*col + row;
+  int j1 = -1;
+  if (col + 16 < L) j1 = 4*(col + 16) + row;
+  else if (col == 15 && row < ntail) j1 = n4 + row;
+  const int own1 = (j1 >= 0);
+  const int jj1 = own1 ? j1 : 0;
+  auto kind_of = [&](int j) -> int { return (j < ne) ? 0 : (j < ne + nf ? 1 : 2); };   // equality / friction / inequality
+  const int kind0 = kind_of(j0), kind1 = kind_of(jj1);
+  real f0 = P.force[j0], f1 = own1 ? (real)P.force[jj1] : 0;
+  const real b0 = P.b[j0], b1 = own1 ? (real)P.b[jj1] : 0;
+  const real fl0 = P.floss[j0], fl1 = own1 ? (real)P.floss[jj1] : 0;
+  auto ar = [&](int r, int j) -> real { return P.AR[(size_t)r*n + j]; };
+  const real ainv0 = 1 / ar(j0, j0), ainv1 = 1 / (own1 ? ar(jj1, jj1) : (real)1);
+  const real A0 = 1/ainv0, A1 = 1/ainv1;
+  const real pinf = __builtin_huge_val();
+  const real blo0 = kind0 == 1 ? -fl0 : (kind0 == 2 ? 0.0 : -pinf), bhi0 = kind0 == 1 ? fl0 : pinf;
+  const real blo1 = kind1 == 1 ? -fl1 : (kind1 == 2 ? 0.0 : -pinf), bhi1 = kind1 == 1 ? fl1 : pinf;
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const auto* otab = wv_uniform_ptr(M.pgs_order) + wv_uniform_ptr(M.pgs_order_adr)[n];
+  // owner (lane, slot) of constraint q
+  auto lane_of = [&](int q) -> int { return (q < n4) ? 16*(q & 3) + ((q >> 2) & 15) : 16*(q - n4) + 15; };
+  auto slot_of = [&](int q) -> int { return (q < n4) ? (q >> 6) : 1; };
+
+  real fprev0 = f0, fmom0 = f0, fprev1 = f1, fmom1 = f1;
+  int iter = 0, nesterov_k = 0;
+  // visitation order of the coming iteration: lane b holds order[b] and order[64 + b]
+  int ordn0 = otab[lane], ordn1 = (64 + lane < n) ? otab[64 + lane] : 0;
+  while (iter < maxiter) {
+    const int ord0 = ordn0, ord1 = ordn1;
+    if (iter + 1 < maxiter) {
+      ordn0 = otab[(iter + 1)*n + lane];
+      ordn1 = (64 + lane < n) ? otab[(iter + 1)*n + 64 + lane] : 0;
+    }
+    // ---- Nesterov extrapolation (:508-554)
+    real beta = 0;
+    if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+    if (beta > 0) {
+      {
+        const real f_save = f0;
+        real fx = f_save + beta*(f_save - fprev0);
+        fprev0 = f_save;
+        if (kind0 == 1) fx = r_clip(fx, -fl0, fl0);
+        else if (kind0 == 2 && fx < 0) fx = 0;
+        f0 = fx; fmom0 = fx;
+      }
+      if (own1) {
+        const real f_save = f1;
+        real fx = f_save + beta*(f_save - fprev1);
+        fprev1 = f_save;
+        if (kind1 == 1) fx = r_clip(fx, -fl1, fl1);
+        else if (kind1 == 2 && fx < 0) fx = 0;
+        f1 = fx; fmom1 = fx;
+      }
+    } else {
+      fprev0 = f0; fmom0 = f0;
+      fprev1 = f1; fmom1 = f1;
+    }
+
+    // ---- one sweep
+    real improvement = 0;
+    int i = wv_bcast_i(ord0, 0);
+    real a0 = ar(i, j0), a1 = own1 ? ar(i, jj1) : 0;
+    for (int bi = 0; bi < n; bi++) {
+      const real p0 = a0*f0, p1 = a1*f1;
+      const int bn = bi + 1 < n ? bi + 1 : bi;
+      int inext = bn < 64 ? wv_bcast_i(ord0, bn) : wv_bcast_i(ord1, bn - 64);
+#if !defined(MJH_HOSTSIM)
+      asm volatile("" : "+s"(inext) : "v"(p0), "v"(p1));      // orders the prefetch after the products
+#endif
+      const real an0 = ar(inext, j0), an1 = own1 ? ar(inext, jj1) : 0;
+      real acc = 0;
+      MJH_PGSW_STEP0(0) MJH_PGSW_STEP0(1) MJH_PGSW_STEP0(2) MJH_PGSW_STEP0(3) MJH_PGSW_STEP0(4) MJH_PGSW_STEP0(5)
+      MJH_PGSW_STEP0(6) MJH_PGSW_STEP0(7) MJH_PGSW_STEP0(8) MJH_PGSW_STEP0(9) MJH_PGSW_STEP0(10) MJH_PGSW_STEP0(11)
+      MJH_PGSW_STEP0(12) MJH_PGSW_STEP0(13) MJH_PGSW_STEP0(14) MJH_PGSW_STEP0(15)
+      MJH_PGSW_STEP1(0) MJH_PGSW_STEP1(1) MJH_PGSW_STEP1(2) MJH_PGSW_STEP1(3) MJH_PGSW_STEP1(4) MJH_PGSW_STEP1(5)
+      MJH_PGSW_STEP1(6) MJH_PGSW_STEP1(7) MJH_PGSW_STEP1(8) MJH_PGSW_STEP1(9) MJH_PGSW_STEP1(10) MJH_PGSW_STEP1(11)
+      MJH_PGSW_STEP1(12) MJH_PGSW_STEP1(13) MJH_PGSW_STEP1(14) MJH_PGSW_STEP1(15)
+      MJH_PGSW_END
+      real dot = (wv_bcast(acc, 0) + wv_bcast(acc, 32)) + (wv_bcast(acc, 16) + wv_bcast(acc, 48));
+      if (ntail == 3) dot += wv_bcast(p1, 15) + wv_bcast(p1, 31) + wv_bcast(p1, 47);
+      else if (ntail == 2) dot += wv_bcast(p1, 15) + wv_bcast(p1, 31);
+      else if (ntail == 1) dot += wv_bcast(p1, 15);
+      // every lane evaluates the update for its constraint in the visited row's slot; the owner keeps it
+      const int si = slot_of(i), li = lane_of(i);
+      const real bj = si ? b1 : b0, oldf = si ? f1 : f0, ainv = si ? ainv1 : ainv0, A = si ? A1 : A0;
+      const real blo = si ? blo1 : blo0, bhi = si ? bhi1 : bhi0;
+      const real res = bj + dot;
+      real fn = oldf - res*ainv;
+      fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
+      const real delta = fn - oldf;
+      real change = 0.5*delta*delta*A + delta*res;
+      if (change > 1e-10) { fn = oldf; change = 0; }
+      if (lane == li) { if (si) f1 = fn; else f0 = fn; }
+      improvement -= wv_bcast(change, li);
+      i = inext;
+      a0 = an0; a1 = an1;
+    }
+    improvement *= scale;
+
+    // ---- gradient restart (:694-713): sum over the constraints in index order
+    int restart = 0;
+    if (iter > 0) {
+      const real ce0 = (f0 - fmom0) * (fmom0 - fprev0), ce1 = (f1 - fmom1) * (fmom1 - fprev1);
+      real dotce = 0;
+      for (int q = 0; q < n; q++) dotce += slot_of(q) ? wv_bcast(ce1, lane_of(q)) : wv_bcast(ce0, lane_of(q));
+      restart = (dotce < 0);
+    }
+    if (restart) nesterov_k = 0; else nesterov_k++;
+    iter++;
+    if (improvement < M.o.tolerance) break;
+  }
+
+  // final dual state (dualState, :270-345), forces back to memory, iteration count
+  auto finish = [&](int j, int kind, real f, real fl) {
+    int st;
+    if (kind == 0) st = MJH_STATE_QUADRATIC;
+    else if (kind == 1) {
+      if (f <= -fl) st = MJH_STATE_LINEARPOS;
+      else if (f >= fl) st = MJH_STATE_LINEARNEG;
+      else st = MJH_STATE_QUADRATIC;
+    } else st = (f <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+    P.state[j] = st;
+    P.force[j] = f;
+  };
+  finish(j0, kind0, f0, fl0);
+  if (own1) finish(jj1, kind1, f1, fl1);
+  if (lane == 0) counts[MJH_C_NITER] = iter;
+  wv_sync();
+}
 #endif  // 64-lane layout
 
 #if !MJH_LANE_MODE && MJH_W == 32
@@ -888,6 +1047,12 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   wv_sync();
   MJH_SUBPROF(22);     // efc_b, jar, warm start
 
+#if !MJH_LANE_MODE && MJH_W == 64
+  if (nefc > 64 && nefc <= 128 && nefc <= M.s.pgs_nmax && M.o.iterations <= M.s.pgs_iters && counts[MJH_C_NISLAND] <= 1 &&
+      (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
+    solve_pgs_wide(M, B, e);
+  } else
+#endif
 #if !MJH_LANE_MODE && MJH_W >= 32
   if (nefc <= MJH_W && M.o.iterations <= M.s.pgs_iters && (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
 #if defined(MJH_HOSTSIM)

@@ -113,7 +113,7 @@
   X(eq_rowadr, s.neq + 1)                      \
   /* PGS block visitation orders: engine_solver.c shuffles with a PCG32 that is re-seeded at every \
      solver call, so the order array after iteration k depends only on (nefc, k): precomputed */ \
-  X(pgs_order_adr, 66)                         \
+  X(pgs_order_adr, 130)                        \
   /* L'DL fast path: strict-ancestor bit mask of every dof (2 words), and the flattened update \
      list of mj_factorI: for pivot row k, items dst | src<<10 | scl<<20 (indices into qLD) */ \
   X(dof_ancmask, 2 * s.nv)                     \
@@ -255,6 +255,7 @@ struct DSizes {
   int nldprog;     // entries of the flattened L'DL update list
   int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
   int pgs_iters;   // iterations covered by that table (min(opt.iterations, 128))
+  int pgs_nmax;    // largest nefc covered by that table (64, or 128 when the constraint capacity allows more than 64 rows)
 };
 
 struct DOptions {

@@ -87,3 +87,29 @@ def contact_rich_states(rb, m, nenv, seed=0, settle=(40, 160)):
                         qacc_warmstart=np.array(d.qacc_warmstart),
                         ctrl=rng.uniform(-1, 1, size=m.nu), time=d.time))
     return out
+
+
+def many_constraint_states(rb, m, want, seed=5, lo=64, hi=128):
+    """humanoid states whose next mj_step has lo < nefc <= hi: dropped lying with bent limbs (the
+    two-constraints-per-lane PGS path)"""
+    d = rb.MjData(m)
+    rng = np.random.default_rng(seed)
+    states, nefcs = [], []
+    for _ in range(400):
+        rb.mj_resetData(m, d)
+        d.qpos[2] = 0.12 + 0.2*rng.uniform()
+        ax = rng.normal(size=3); ax[2] *= 0.2; ax /= np.linalg.norm(ax)
+        ang = np.pi/2 + rng.normal(0, .2)
+        d.qpos[3:7] = [np.cos(ang/2), *(np.sin(ang/2)*ax)]
+        d.qpos[7:] += rng.normal(0, .5, m.nq - 7)
+        took = 0
+        for _t in range(300):
+            d.ctrl[:] = 0.3*rng.uniform(-1, 1, m.nu)
+            pre = dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart),
+                       ctrl=np.array(d.ctrl), time=d.time)
+            rb.mj_step(m, d)
+            if lo < d.nefc <= hi and took < 2 and rng.uniform() < 0.3:
+                states.append(pre); nefcs.append(int(d.nefc)); took += 1
+        if len(states) >= want:
+            break
+    return states[:want], nefcs[:want]

@@ -12,7 +12,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 import mujoco_amd
-from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle
+from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
 from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +74,18 @@ def test_soa_layout_forward_and_rollout_vs_live_oracle(rb, hip_lib, dm, golden):
     assert relerr(out_soa[:, :10], fx["state"][:, :10]) <= TOL
     assert np.array_equal(bs.get("counts")[:, :3], ba.get("counts")[:, :3])
     assert bs.get("warning").sum() == 0
+
+
+def test_pgs_two_constraints_per_lane_vs_live_oracle(rb, hip_lib, dm):
+    """64 < nefc <= 128 (solve_pgs_wide: two constraints per lane, AR read from global memory): every
+    FORWARD field within tolerance, contact / constraint / PGS iteration counts exact"""
+    m = humanoid_pgs_oracle(rb)
+    states, nefcs = many_constraint_states(rb, m, 24)
+    assert min(nefcs) > 64 and max(nefcs) > 96
+    b = K.Batch(dm, len(states))
+    worst = check_forward(rb, m, b, states, tol=TOL)
+    print("wide PGS forward worst rel err", worst, "nefc", sorted(nefcs))
+    assert np.array_equal(b.get("counts")[:, 1], nefcs)
 
 
 def test_single_step_parity_vs_live_oracle(rb, hip_lib, dm):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from mujoco_amd import _capi as K
-from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle
+from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
 from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
 
 
@@ -33,6 +33,26 @@ def test_forward_bit_exact(rb, setup):
     b = K.Batch(dm, len(states))
     worst = check_forward(rb, m, b, states, tol=0.0)
     assert worst == 0.0
+
+
+def test_pgs_two_constraints_per_lane_bit_exact(rb, setup):
+    """64 < nefc <= 128: the register-resident PGS with two constraints per lane (solve_pgs_wide) --
+    every field, force, state and the iteration count against the oracle, bit for bit; and a short
+    rollout through such states"""
+    m, dm = setup
+    states, nefcs = many_constraint_states(rb, m, 12)
+    assert len(states) == 12 and min(nefcs) > 64 and max(nefcs) > 96
+    b = K.Batch(dm, len(states))
+    assert check_forward(rb, m, b, states, tol=0.0) == 0.0
+    assert np.array_equal(b.get("counts")[:, 1], nefcs)
+    s0 = np.stack([np.concatenate([[s["time"]], s["qpos"], s["qvel"]]) for s in states])
+    ws = np.stack([s["qacc_warmstart"] for s in states])
+    ctrl = np.repeat(np.stack([s["ctrl"] for s in states])[:, None], 6, axis=1)
+    ref, ints = oracle_rollout(rb, m, s0, ctrl, ws)
+    out = b.rollout_host(6, K.mjSTATE_CTRL, s0, ws, ctrl)
+    assert np.array_equal(out, ref)
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1]) and np.array_equal(c[:, 5], ints[:, -1, 2])
 
 
 @pytest.mark.parametrize("budget", [4096, 10240, 20480, 65536])
