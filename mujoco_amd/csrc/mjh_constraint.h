@@ -15,6 +15,9 @@ struct Efc {
   rptr force, b, ARinv, fprev, fmom, R, D, floss, aref, jar, ARf, pos, margin, KBIP,
        diagA, vel, sqrtInvD, AR, J, Y, cone;
   iptr order, state, type, id, island;
+  // the larger of the two regions' unused tails (staging space for stage_project)
+  char* free_p;
+  int free_bytes;
 };
 
 // Two regions of the workgroup's LDS block take these arrays:
@@ -53,6 +56,13 @@ struct Efc {
   X(id, MJH_G(B, efc_id, e), nefc, 1)                                \
   X(island, MJH_G(B, efc_island, e), nefc, 1)
 
+// (stage_project) does this array already live in the LDS plan?  (pointer inside the workgroup's block)
+template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* lds, int bytes) {
+  const char* p = (const char*)v.p;
+  return bytes > 0 && p >= lds && p < lds + bytes;
+}
+#define mjh_staged_home(v) mjh_staged_home_impl((v), MJH_LDS(B), B.lds_bytes)
+
 // returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
 // ints first)
 MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
@@ -74,6 +84,11 @@ MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   MJH_EFC_REAL_ARRAYS(X)
 #undef X
 #undef MJH_EFC_PLACE
+  {
+    const int f1 = end1 - off1, f2 = end2 - off2;
+    P.free_p = lds_ + (f2 >= f1 ? off2 : off1);
+    P.free_bytes = B.lds_bytes ? (f2 >= f1 ? f2 : f1) : 0;
+  }
   return mask;
 }
 
@@ -823,7 +838,38 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
 
   MJH_FOR_LANES(i, nv) sqrtInvD[i] = 1 / sqrt(qLD[M.M_rowadr[i] + M.M_rownnz[i] - 1]);
   wv_sync();
-  // one lane per row: half back-substitution (mj_solveM2, engine_core_smooth.c:2130)
+  // one lane per row: half back-substitution (mj_solveM2, engine_core_smooth.c:2130).
+  // The sweep is a chain of ~100 dependent read-modify-writes on the row; when the row's home is global
+  // memory (Y rarely fits the plan) it is staged through the unused tail of the LDS plan, a batch of
+  // rows at a time, element-major ([dof][row of the batch]: the dof index is the same in every lane, so
+  // the lanes of a batch touch consecutive words), and copied out coalesced.
+  const int stage_rows = (int)((unsigned)P.free_bytes / ((unsigned)nv*sizeof(real)));
+  if (!MJH_LANE_MODE && stage_rows >= 4 && !mjh_staged_home(Y)) {
+    const int RB = stage_rows < MJH_W ? stage_rows : MJH_W;
+    const auto xs = mjh_local((real*)P.free_p);        // ds_read / ds_write
+    const int lane = wv_lane();
+    for (int r0 = 0; r0 < nefc; r0 += RB) {
+      const int nb = (nefc - r0) < RB ? (nefc - r0) : RB;
+      // J rows of the batch in, transposed
+      MJH_FOR_LANES(w, nb*nv) { const int r = w / nv, i = w - r*nv; xs[i*RB + r] = J[(size_t)(r0 + r)*nv + i]; }
+      wv_sync();
+      if (lane < nb) {
+        const auto x = mjh_local((real*)P.free_p + lane);
+        for (int i = nv - 1; i > 0; i--) {
+          if (M.dof_simplenum[i]) continue;
+          real xi = x[i*RB];
+          if (xi != 0) {
+            int start = M.M_rowadr[i], end = start + M.M_rownnz[i] - 1;
+            for (int adr = start; adr < end; adr++) x[M.M_colind[adr]*RB] -= qLD[adr] * xi;
+          }
+        }
+        for (int i = 0; i < nv; i++) x[i*RB] *= sqrtInvD[i];
+      }
+      wv_sync();
+      MJH_FOR_LANES(w, nb*nv) { const int r = w / nv, i = w - r*nv; Y[(size_t)(r0 + r)*nv + i] = xs[i*RB + r]; }
+      wv_sync();
+    }
+  } else
   MJH_FOR_LANES(r, nefc) {
     rptr x = Y + (size_t)r*nv;
     crptr y = J + (size_t)r*nv;
