@@ -843,8 +843,65 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
   // memory (Y rarely fits the plan) it is staged through the unused tail of the LDS plan, a batch of
   // rows at a time, element-major ([dof][row of the batch]: the dof index is the same in every lane, so
   // the lanes of a batch touch consecutive words), and copied out coalesced.
+  int rows_done = 0;
+#if !MJH_LANE_MODE && MJH_W == 64
+  if (M.s.ld_fast && nv <= 32) {
+    rows_done = 1;
+    // Register form: lane = dof, a constraint row's vector lives in one register per lane, the two
+    // halves of the wavefront take a row each and every pass carries PR rows per half (independent
+    // chains for the scheduler).  Step i of the sweep broadcasts x_i and subtracts q_i * x_i in the
+    // lanes that are ancestors of dof i (bit mask) -- the same products in the same order as the row
+    // loop below; the coefficient q_i is the same for every row and is read once per pass.
+    constexpr int PR = 2;
+    const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);
+    const int lane = wv_lane();
+    const int half = lane >> 5, hl = lane & 31;
+    const int li = hl < nv ? hl : 0;
+    const int myadr = wv_uniform_ptr(M.M_rowadr)[li];
+    const int mynnz = wv_uniform_ptr(M.M_rownnz)[li];
+    const int mydepth = mynnz - 1;
+    const int anc_lo = ancmask[2*li];
+    const real sq = hl < nv ? (real)sqrtInvD[li] : (real)0;
+    int ilast = nv - 1;
+    while (ilast > 0 && wv_bcast_i(mynnz, ilast) == 1) ilast--;
+    for (int r0 = 0; r0 < nefc; r0 += 2*PR) {
+      real x[PR];
+      int rr[PR];
+      for (int g = 0; g < PR; g++) {
+        rr[g] = r0 + 2*g + half;
+        x[g] = (hl < nv && rr[g] < nefc) ? (real)J[(size_t)rr[g]*nv + li] : (real)0;
+      }
+      real q = 0;
+      {
+        const int lo = wv_bcast_i(anc_lo, ilast), adr = wv_bcast_i(myadr, ilast);
+        if ((lo >> hl) & 1) q = qLD[adr + mydepth];
+      }
+      for (int i = ilast; i > 0; ) {
+        int inext = i - 1;
+        while (inext > 0 && wv_bcast_i(mynnz, inext) == 1) inext--;
+        real qnext = 0;
+        if (inext > 0) {
+          const int lon = wv_bcast_i(anc_lo, inext), adrn = wv_bcast_i(myadr, inext);
+          if ((lon >> hl) & 1) qnext = qLD[adrn + mydepth];
+        }
+        const int isanc = (wv_bcast_i(anc_lo, i) >> hl) & 1;
+        for (int g = 0; g < PR; g++) {
+          const real a = wv_bcast(x[g], i), b = wv_bcast(x[g], 32 + i);
+          const real xi = half ? b : a;
+          if (xi != 0 && isanc) x[g] -= q * xi;
+        }
+        q = qnext;
+        i = inext;
+      }
+      for (int g = 0; g < PR; g++)
+        if (hl < nv && rr[g] < nefc) Y[(size_t)rr[g]*nv + li] = x[g] * sq;
+    }
+  }
+#endif
   const int stage_rows = (int)((unsigned)P.free_bytes / ((unsigned)nv*sizeof(real)));
-  if (!MJH_LANE_MODE && stage_rows >= 4 && !mjh_staged_home(Y)) {
+  if (rows_done) {
+    // (register form above)
+  } else if (!MJH_LANE_MODE && stage_rows >= 4 && !mjh_staged_home(Y)) {
     const int RB = stage_rows < MJH_W ? stage_rows : MJH_W;
     const auto xs = mjh_local((real*)P.free_p);        // ds_read / ds_write
     const int lane = wv_lane();
@@ -932,10 +989,23 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
     // (lane mode runs this loop serially; it is only reached there on the rare reset-and-redo path)
     crptr Yi = Y + (size_t)i*nv;
     crptr Yk = Y + (size_t)k*nv;
+    // (the reference skips zero entries of row i; selecting on the sum instead of branching around the
+    // second load keeps the 2*nv loads independent of each other -- they are in flight together)
     real acc = 0;
-    for (int j = 0; j < nv; j++) {
-      real t = Yi[j];
-      if (t != 0) acc += Yk[j]*t;
+    int j = 0;
+    for (; j + 4 <= nv; j += 4) {
+      const real t0 = Yi[j], t1 = Yi[j+1], t2 = Yi[j+2], t3 = Yi[j+3];
+      const real u0 = Yk[j], u1 = Yk[j+1], u2 = Yk[j+2], u3 = Yk[j+3];
+      real c;
+      c = acc + u0*t0; acc = (t0 != 0) ? c : acc;
+      c = acc + u1*t1; acc = (t1 != 0) ? c : acc;
+      c = acc + u2*t2; acc = (t2 != 0) ? c : acc;
+      c = acc + u3*t3; acc = (t3 != 0) ? c : acc;
+    }
+    for (; j < nv; j++) {
+      const real t = Yi[j], u = Yk[j];
+      const real c = acc + u*t;
+      acc = (t != 0) ? c : acc;
     }
     if (i == k) acc += R[i];
     AR[(size_t)i*nefc + k] = acc;
