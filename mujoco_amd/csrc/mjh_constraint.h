@@ -43,8 +43,8 @@ struct Efc {
   X(diagA, MJH_G(B, efc_diagA, e), nefc, 1)                          \
   X(vel, MJH_G(B, efc_vel, e), nefc, 1)                              \
   X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, nv, 2)                  \
-  X(J, MJH_G(B, efc_J, e), nefc*nv, 1)                               \
   X(Y, MJH_G(B, efc_Y, e), nefc*nv, 2)                               \
+  X(J, MJH_G(B, efc_J, e), nefc*nv, 1)                               \
   X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
   X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
