@@ -29,8 +29,13 @@ extern "C" bool mjh_launch_lane_forward(const DModel* M, const DBatch* B, int ne
 extern "C" bool mjh_launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int epw, void* stream);
 
 // Launch order of the next rollout launch: counting sort of the environments by the work estimate
-// of the last one (256 buckets, one workgroup), most expensive first.
-__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B) {
+// of the last one (256 buckets, one workgroup), most expensive first, then dealt to the SIMDs in
+// serpentine order.  Measured on MI355X (tools/wg_map.py): one-wavefront workgroup w of a launch lands on
+// SIMD w mod nsimd (nsimd = 4 x CUs = 1024), so with every wave slot taken SIMD s steps workgroups s,
+// s + nsimd, s + 2 nsimd, ...  Dealing rank r of block q to slot r (q even) or nsimd - 1 - r (q odd)
+// gives every SIMD one environment of each cost quartile AND nearly equal sums; a SIMD is work
+// conserving, so it finishes when the sum of its wavefronts' work is done.
+__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B, int nsimd) {
   __shared__ int hist[256];
   __shared__ int maxc;
   const int n = B->nenv, tid = (int)threadIdx.x;
@@ -48,7 +53,13 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
   __syncthreads();
   if (tid == 0) { int acc = 0; for (int b = 0; b < 256; b++) { int c = hist[b]; hist[b] = acc; acc += c; } }
   __syncthreads();
-  for (int e = tid; e < n; e += 1024) perm[atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1)] = e;
+  for (int e = tid; e < n; e += 1024) {
+    const int rank = atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
+    const int q = rank / nsimd, r = rank - q*nsimd;
+    int w = rank;
+    if ((q & 1) && (q + 1)*nsimd <= n) w = q*nsimd + (nsimd - 1 - r);      // full odd blocks run backwards
+    perm[w] = e;
+  }
 }
 
 __global__ __launch_bounds__(MJH_WAVE) void mjh_k_reset(const DModel* __restrict__ M, const DBatch* __restrict__ B) {
@@ -112,7 +123,15 @@ struct Backend {
   }
   static bool launch_balance(const DBatch* B, int nenv, void* stream) {
     (void)nenv;
-    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B);
+    static int nsimd = 0;
+    if (!nsimd) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      nsimd = 4*cus;
+      if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) if (atoi(ev) == 0) nsimd = 1 << 30;     // A/B: plain descending order
+    }
+    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {

@@ -37,6 +37,11 @@ def main():
         prev_work = work
         print("launch %d: kernel %.2f ms (%.2f M env-steps/s); per-env us: mean %.0f  quantiles(0,.5,.9,.99,.999,1) %s  max/mean %.2f" %
               (L, ms, nenv*steps/ms/1e3, c.mean(), np.round(q).tolist(), c.max()/c.mean()))
+        cnt = batch.get("counts")
+        slow = np.argsort(-c)[:6]
+        print("   slowest: " + "; ".join("env %d %.0f us work %.0f (last step: ncon %d nefc %d niter %d)" %
+                                         (i, c[i], work[i], cnt[i, 0], cnt[i, 1], cnt[i, 5]) for i in slow))
+        print("   work estimate: mean %.0f, of the slowest six %s" % (work.mean(), np.round(work[slow]).tolist()))
 
 if __name__ == "__main__":
     main()
