@@ -87,169 +87,96 @@ MJH_DEV void contact_force(MREF M, BREF B, int e, const Efc& P, int k, real* res
   }
 }
 
-// does the ray pnt + x*vec (x >= 0) meet the site's zone?  (mju_rayGeom >= 0 for sphere, ellipsoid
-// and box sites: ray_quad / ray_sphere / ray_ellipsoid / ray_box, engine_ray.c:103-560)
-MJH_DEV real ray_quad_min(real a, real b, real c) {
-  real det = b*b - a*c;
-  if (det < 0 || a < MJH_MINVAL) return -1;
-  det = sqrt(det);
-  const real x0 = (-b - det)/a, x1 = (-b + det)/a;
-  if (x0 >= 0) return x0;
-  if (x1 >= 0) return x1;
-  return -1;
+// ---- rays against primitive shapes (mju_rayGeom, engine_ray.c:103-560, distances only) ----------
+// A ray is carried in the shape's own frame: origin o, direction d (not normalised: distances are in
+// units of |d|, like the reference).  Curved surfaces reduce to the roots of a x^2 + 2 b x + c = 0 with
+// a = <d,d>_W, b = <d,o>_W, c = <o,o>_W - 1 for a diagonal metric W; flat faces to one division per
+// slab.  The nearest admissible root wins; -1 = no hit.
+struct RayRoots { real near_, far_; };
+MJH_DEV RayRoots ray_roots(real a, real b, real c) {
+  real disc = b*b - a*c;
+  if (disc < 0 || a < MJH_MINVAL) return RayRoots{-1, -1};
+  disc = sqrt(disc);
+  return RayRoots{(-b - disc)/a, (-b + disc)/a};
 }
-template <class P0, class P1, class P2>
-MJH_DEV int ray_hits_zone(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
-  real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
-  if (type == 2) {           // mjGEOM_SPHERE
-    const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
-    const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
-    const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - size[0]*size[0];
-    return ray_quad_min(a, b, c) >= 0;
+MJH_DEV real ray_first(RayRoots r) { return r.near_ >= 0 ? r.near_ : (r.far_ >= 0 ? r.far_ : (real)-1); }
+MJH_DEV void ray_keep_nearest(real& best, real x) { if (best < 0 || x < best) best = x; }
+// quadric <p,p>_W = radius2 about `centre`, metric W = diag(w)
+MJH_DEV RayRoots ray_quadric(V3 o, V3 d, V3 centre, V3 w, real radius2) {
+  const V3 p = o - centre;
+  const real a = w.x*d.x*d.x + w.y*d.y*d.y + w.z*d.z*d.z;
+  const real b = w.x*d.x*p.x + w.y*d.y*p.y + w.z*d.z*p.z;
+  const real c = w.x*p.x*p.x + w.y*p.y*p.y + w.z*p.z*p.z - radius2;
+  return ray_roots(a, b, c);
+}
+// the two faces perpendicular to axis k at +-half: keep the nearest crossing that `inside` accepts
+template <class F>
+MJH_DEV void ray_slab(real& best, V3 o, V3 d, int k, real half, F inside) {
+  const real dk = comp(d, k);
+  if (!(fabs(dk) > MJH_MINVAL)) return;
+  for (int side = -1; side <= 1; side += 2) {
+    const real x = (side*half - comp(o, k))/dk;
+    if (x >= 0 && inside(V3{o.x + x*d.x, o.y + x*d.y, o.z + x*d.z})) ray_keep_nearest(best, x);
   }
-  real lpnt[3], lvec[3];
-  for (int k = 0; k < 3; k++) {
-    lpnt[k] = mat[k]*dif[0] + mat[3 + k]*dif[1] + mat[6 + k]*dif[2];
-    lvec[k] = mat[k]*vec[0] + mat[3 + k]*vec[1] + mat[6 + k]*vec[2];
-  }
-  if (type == 4) {           // mjGEOM_ELLIPSOID
-    real sz[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
-    const real a = sz[0]*lvec[0]*lvec[0] + sz[1]*lvec[1]*lvec[1] + sz[2]*lvec[2]*lvec[2];
-    const real b = sz[0]*lvec[0]*lpnt[0] + sz[1]*lvec[1]*lpnt[1] + sz[2]*lvec[2]*lpnt[2];
-    const real c = sz[0]*lpnt[0]*lpnt[0] + sz[1]*lpnt[1]*lpnt[1] + sz[2]*lpnt[2]*lpnt[2] - 1;
-    return ray_quad_min(a, b, c) >= 0;
-  }
-  // mjGEOM_BOX: bounding-sphere test, then the six faces
-  {
-    const real ssz = size[0]*size[0] + size[1]*size[1] + size[2]*size[2];
-    const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
-    const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
-    const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - ssz;
-    if (ray_quad_min(a, b, c) < 0) return 0;
-  }
-  for (int i = 0; i < 3; i++) {
-    if (fabs(lvec[i]) > MJH_MINVAL) {
-      const int f0 = (i == 0) ? 1 : 0, f1 = (i == 2) ? 1 : 2;
-      for (int side = -1; side <= 1; side += 2) {
-        const real sol = (side*size[i] - lpnt[i])/lvec[i];
-        if (sol >= 0) {
-          const real p0 = lpnt[f0] + sol*lvec[f0];
-          const real p1 = lpnt[f1] + sol*lvec[f1];
-          if (fabs(p0) <= size[f0] && fabs(p1) <= size[f1]) return 1;
-        }
-      }
-    }
-  }
-  return 0;
 }
 
-// distance along the ray pnt + x*vec to one primitive geom, -1 if missed (mju_rayGeom without the
-// normals: ray_plane / ray_sphere / ray_capsule / ray_ellipsoid / ray_cylinder / ray_box,
-// engine_ray.c:204-560)
-MJH_DEV real ray_quad2(real a, real b, real c, real* xx) {
-  real det = b*b - a*c;
-  if (det < 0 || a < MJH_MINVAL) { xx[0] = -1; xx[1] = -1; return -1; }
-  det = sqrt(det);
-  xx[0] = (-b - det)/a;
-  xx[1] = (-b + det)/a;
-  if (xx[0] >= 0) return xx[0];
-  if (xx[1] >= 0) return xx[1];
-  return -1;
-}
-template <class P0>
-MJH_DEV real ray_sphere_dist(P0 pos, real dist_sqr, const real* pnt, const real* vec) {
-  real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
-  const real a = vec[0]*vec[0] + vec[1]*vec[1] + vec[2]*vec[2];
-  const real b = vec[0]*dif[0] + vec[1]*dif[1] + vec[2]*dif[2];
-  const real c = dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2] - dist_sqr;
-  real xx[2];
-  return ray_quad2(a, b, c, xx);
-}
 template <class P0, class P1, class P2>
 MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
-  if (type == 2) return ray_sphere_dist(pos, size[0]*size[0], pnt, vec);
-  real lpnt[3], lvec[3], xx[2];
-  {
-    real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
-    for (int k = 0; k < 3; k++) {
-      lpnt[k] = mat[k]*dif[0] + mat[3 + k]*dif[1] + mat[6 + k]*dif[2];
-      lvec[k] = mat[k]*vec[0] + mat[3 + k]*vec[1] + mat[6 + k]*vec[2];
-    }
-  }
-  if (type == 0) {                    // plane
-    if (lvec[2] > -MJH_MINVAL) return -1;
-    const real x = -lpnt[2]/lvec[2];
+  const V3 wo{pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, wd{vec[0], vec[1], vec[2]};
+  const V3 one{1, 1, 1}, origin{0, 0, 0};
+  // bounding sphere in world coordinates (the rotation does not change it)
+  auto misses_ball = [&](real radius2) -> int { return ray_first(ray_quadric(wo, wd, origin, one, radius2)) < 0; };
+  if (type == 2) return ray_first(ray_quadric(wo, wd, origin, one, size[0]*size[0]));          // sphere
+  const V3 o{mtrow(mat, 0, wo), mtrow(mat, 1, wo), mtrow(mat, 2, wo)};
+  const V3 d{mtrow(mat, 0, wd), mtrow(mat, 1, wd), mtrow(mat, 2, wd)};
+  const V3 xy{1, 1, 0};                                                                       // metric of the z axis' cylinder
+  if (type == 0) {                    // plane z = 0, seen from above; size[0], size[1] > 0 bound it
+    if (d.z > -MJH_MINVAL) return -1;
+    const real x = -o.z/d.z;
     if (x < 0) return -1;
-    const real p0 = lpnt[0] + x*lvec[0], p1 = lpnt[1] + x*lvec[1];
-    if ((size[0] <= 0 || fabs(p0) <= size[0]) && (size[1] <= 0 || fabs(p1) <= size[1])) return x;
-    return -1;
+    const real px = o.x + x*d.x, py = o.y + x*d.y;
+    return ((size[0] <= 0 || fabs(px) <= size[0]) && (size[1] <= 0 || fabs(py) <= size[1])) ? x : (real)-1;
   }
-  if (type == 3) {                    // capsule
-    const real ssz = size[0] + size[1];
-    if (ray_sphere_dist(pos, ssz*ssz, pnt, vec) < 0) return -1;
-    real x = -1;
-    real a = lvec[0]*lvec[0] + lvec[1]*lvec[1];
-    real b = lvec[0]*lpnt[0] + lvec[1]*lpnt[1];
-    real c = lpnt[0]*lpnt[0] + lpnt[1]*lpnt[1] - size[0]*size[0];
-    const real sol = ray_quad2(a, b, c, xx);
-    if (sol >= 0 && fabs(lpnt[2] + sol*lvec[2]) <= size[1]) { if (x < 0 || sol < x) x = sol; }
-    real ldif[3] = {lpnt[0], lpnt[1], lpnt[2] - size[1]};
-    a = lvec[0]*lvec[0] + lvec[1]*lvec[1] + lvec[2]*lvec[2];
-    b = lvec[0]*ldif[0] + lvec[1]*ldif[1] + lvec[2]*ldif[2];
-    c = ldif[0]*ldif[0] + ldif[1]*ldif[1] + ldif[2]*ldif[2] - size[0]*size[0];
-    ray_quad2(a, b, c, xx);
-    for (int i = 0; i < 2; i++)
-      if (xx[i] >= 0 && lpnt[2] + xx[i]*lvec[2] >= size[1]) { if (x < 0 || xx[i] < x) x = xx[i]; }
-    ldif[2] = lpnt[2] + size[1];
-    b = lvec[0]*ldif[0] + lvec[1]*ldif[1] + lvec[2]*ldif[2];
-    c = ldif[0]*ldif[0] + ldif[1]*ldif[1] + ldif[2]*ldif[2] - size[0]*size[0];
-    ray_quad2(a, b, c, xx);
-    for (int i = 0; i < 2; i++)
-      if (xx[i] >= 0 && lpnt[2] + xx[i]*lvec[2] <= -size[1]) { if (x < 0 || xx[i] < x) x = xx[i]; }
-    return x;
-  }
-  if (type == 4) {                    // ellipsoid
-    real sz[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
-    const real a = sz[0]*lvec[0]*lvec[0] + sz[1]*lvec[1]*lvec[1] + sz[2]*lvec[2]*lvec[2];
-    const real b = sz[0]*lvec[0]*lpnt[0] + sz[1]*lvec[1]*lpnt[1] + sz[2]*lvec[2]*lpnt[2];
-    const real c = sz[0]*lpnt[0]*lpnt[0] + sz[1]*lpnt[1]*lpnt[1] + sz[2]*lpnt[2]*lpnt[2] - 1;
-    return ray_quad2(a, b, c, xx);
-  }
-  if (type == 5) {                    // cylinder
-    if (ray_sphere_dist(pos, size[0]*size[0] + size[1]*size[1], pnt, vec) < 0) return -1;
-    real x = -1;
-    if (fabs(lvec[2]) > MJH_MINVAL) {
-      for (int side = -1; side <= 1; side += 2) {
-        const real sol = (side*size[1] - lpnt[2])/lvec[2];
-        if (sol >= 0) {
-          const real p0 = lpnt[0] + sol*lvec[0], p1 = lpnt[1] + sol*lvec[1];
-          if (p0*p0 + p1*p1 <= size[0]*size[0]) { if (x < 0 || sol < x) x = sol; }
-        }
+  if (type == 3) {                    // capsule: barrel between the cap centres, a half sphere beyond each
+    const real reach = size[0] + size[1];
+    if (misses_ball(reach*reach)) return -1;
+    real best = -1;
+    const real r2 = size[0]*size[0];
+    const real barrel = ray_first(ray_quadric(o, d, origin, xy, r2));
+    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel);
+    for (int cap = 1; cap >= -1; cap -= 2) {
+      const RayRoots rr = ray_quadric(o, d, V3{0, 0, cap*size[1]}, one, r2);
+      for (int k = 0; k < 2; k++) {
+        const real x = k ? rr.far_ : rr.near_;
+        if (x >= 0 && cap*(o.z + x*d.z) >= size[1]) ray_keep_nearest(best, x);
       }
     }
-    const real a = lvec[0]*lvec[0] + lvec[1]*lvec[1];
-    const real b = lvec[0]*lpnt[0] + lvec[1]*lpnt[1];
-    const real c = lpnt[0]*lpnt[0] + lpnt[1]*lpnt[1] - size[0]*size[0];
-    const real sol = ray_quad2(a, b, c, xx);
-    if (sol >= 0 && fabs(lpnt[2] + sol*lvec[2]) <= size[1]) { if (x < 0 || sol < x) x = sol; }
-    return x;
+    return best;
   }
-  // box
-  if (ray_sphere_dist(pos, size[0]*size[0] + size[1]*size[1] + size[2]*size[2], pnt, vec) < 0) return -1;
-  real x = -1;
-  for (int i = 0; i < 3; i++) {
-    if (fabs(lvec[i]) > MJH_MINVAL) {
-      const int f0 = (i == 0) ? 1 : 0, f1 = (i == 2) ? 1 : 2;
-      for (int side = -1; side <= 1; side += 2) {
-        const real sol = (side*size[i] - lpnt[i])/lvec[i];
-        if (sol >= 0) {
-          const real p0 = lpnt[f0] + sol*lvec[f0], p1 = lpnt[f1] + sol*lvec[f1];
-          if (fabs(p0) <= size[f0] && fabs(p1) <= size[f1]) { if (x < 0 || sol < x) x = sol; }
-        }
-      }
-    }
+  if (type == 4)                      // ellipsoid
+    return ray_first(ray_quadric(o, d, origin, V3{1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])}, 1));
+  if (type == 5) {                    // cylinder: the two caps, then the barrel
+    if (misses_ball(size[0]*size[0] + size[1]*size[1])) return -1;
+    real best = -1;
+    const real r2 = size[0]*size[0];
+    ray_slab(best, o, d, 2, size[1], [&](V3 p) -> int { return p.x*p.x + p.y*p.y <= r2; });
+    const real barrel = ray_first(ray_quadric(o, d, origin, xy, r2));
+    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel);
+    return best;
   }
-  return x;
+  // box: three slabs
+  if (misses_ball(size[0]*size[0] + size[1]*size[1] + size[2]*size[2])) return -1;
+  real best = -1;
+  for (int k = 0; k < 3; k++) {
+    const int u = (k == 0) ? 1 : 0, v = (k == 2) ? 1 : 2;
+    ray_slab(best, o, d, k, size[k], [&](V3 p) -> int { return fabs(comp(p, u)) <= size[u] && fabs(comp(p, v)) <= size[v]; });
+  }
+  return best;
+}
+// does the ray meet a site's zone at all (touch sensors: sphere, ellipsoid and box zones)?
+template <class P0, class P1, class P2>
+MJH_DEV int ray_hits_zone(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
+  return ray_geom_dist(type, pos, mat, size, pnt, vec) >= 0;
 }
 
 // mj_subtreeVel (lane 0)

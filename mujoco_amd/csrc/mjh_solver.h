@@ -620,111 +620,108 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
 // cooperative in mju_dot's association; the small block algebra is evaluated redundantly by every
 // lane and lane 0 stores the result, so the sweep stays bit-compatible with the CPU.
 // ------------------------------------------------------------------------------------------------
-// Cholesky of a small dense matrix with rank threshold / solve     (engine_util_solve.c:33-101)
-MJH_DEV int small_chol_factor(real* mat, int n, real mindiag) {
-  int rank = n;
-  for (int j = 0; j < n; j++) {
-    real tmp = mat[j*(n+1)];
-    if (j) tmp -= dot_ref(mat + j*n, mat + j*n, j);
-    const int deficient = tmp < mindiag;
-    if (deficient) { tmp = mindiag; rank--; }
-    mat[j*(n+1)] = sqrt(tmp);
-    if (deficient) {
-      for (int i = j + 1; i < n; i++) mat[i*n+j] = 0;
-    } else {
-      tmp = 1/mat[j*(n+1)];
-      for (int i = j + 1; i < n; i++) mat[i*n+j] = (mat[i*n+j] - dot_ref(mat + i*n, mat + j*n, j)) * tmp;
-    }
+// The friction QCQP of an elliptic block (mju_QCQP2 / QCQP3 / QCQP, engine_util_solve.c:1197-1443):
+//     minimise  x'Ax/2 + x'b   subject to   sum (x_k / d_k)^2 <= r^2
+// In the scaled variable y = x ./ d the constraint is a ball; the KKT system (S + lambda I) y = -c with
+// S = D A D, c = D b is solved for the multiplier lambda >= 0 by Newton's method on
+// phi(lambda) = |y(lambda)|^2 - r^2 (at most 20 steps, stops at 1e-10 like the reference).  One routine
+// for every size: the shifted matrix is inverted through its cofactors for n = 2, 3 and through a
+// Cholesky factor for n = 4, 5; the operation order of each formula is the reference's, which is what
+// keeps the sweep bit-compatible.  Returns 1 when the constraint is active (lambda != 0).
+struct SmallSym {          // symmetric n x n, n <= 5, full storage (row-major) so that rows are contiguous
+  real a[25];
+  int n;
+  MJH_MEM real& at(int i, int j) { return a[i*n + j]; }
+  MJH_MEM real at(int i, int j) const { return a[i*n + j]; }
+};
+
+// lower Cholesky factor in place; a pivot below `floor_` is clamped and its column zeroed; returns the
+// number of pivots that passed (engine_util_solve.c:33-80)
+MJH_DEV int small_chol_factor(SmallSym& m, real floor_) {
+  const int n = m.n;
+  int passed = 0;
+  for (int c = 0; c < n; c++) {
+    real piv = m.at(c, c);
+    if (c) piv -= dot_ref(m.a + c*n, m.a + c*n, c);
+    const int ok = !(piv < floor_);
+    passed += ok;
+    const real root = sqrt(ok ? piv : floor_);
+    m.at(c, c) = root;
+    const real inv = ok ? 1/root : (real)0;
+    for (int r = c + 1; r < n; r++)
+      m.at(r, c) = ok ? (m.at(r, c) - dot_ref(m.a + r*n, m.a + c*n, c)) * inv : (real)0;
   }
-  return rank;
+  return passed;
 }
-MJH_DEV void small_chol_solve(real* res, const real* mat, const real* vec, int n) {
-  for (int i = 0; i < n; i++) res[i] = vec[i];
+// out = (L L')^-1 rhs                                             (engine_util_solve.c:84-101)
+MJH_DEV void small_chol_solve(real* out, const SmallSym& m, const real* rhs) {
+  const int n = m.n;
   for (int i = 0; i < n; i++) {
-    if (i) res[i] -= dot_ref(mat + i*n, res, i);
-    res[i] /= mat[i*(n+1)];
+    real v = rhs[i];
+    if (i) { out[i] = v; v = out[i] - dot_ref(m.a + i*n, out, i); }
+    out[i] = v / m.at(i, i);
   }
   for (int i = n - 1; i >= 0; i--) {
-    for (int j = i + 1; j < n; j++) res[i] -= mat[j*n+i] * res[j];
-    res[i] /= mat[i*(n+1)];
+    real v = out[i];
+    for (int j = i + 1; j < n; j++) v -= m.at(j, i) * out[j];
+    out[i] = v / m.at(i, i);
   }
 }
 
-// min 0.5 x'Ax + x'b  s.t.  sum (x_i/d_i)^2 <= r^2, Newton iteration on the multiplier; returns 1
-// when the constraint is active                           (engine_util_solve.c:1197-1443)
 MJH_DEV int qcqp_solve(real* res, const real* Ain, const real* bin, const real* d, real r, int n) {
-  real la = 0;
-  if (n == 2) {
-    const real b1 = bin[0]*d[0], b2 = bin[1]*d[1];
-    const real A11 = Ain[0]*d[0]*d[0], A22 = Ain[3]*d[1]*d[1], A12 = Ain[1]*d[0]*d[1];
-    real v1 = 0, v2 = 0;
-    for (int iter = 0; iter < 20; iter++) {
-      const real det = (A11+la)*(A22+la) - A12*A12;
-      if (det < 1e-10) { res[0] = 0; res[1] = 0; return 0; }
-      const real detinv = 1/det;
-      const real P11 = (A22+la)*detinv, P22 = (A11+la)*detinv, P12 = -A12*detinv;
-      v1 = -P11*b1 - P12*b2;
-      v2 = -P12*b1 - P22*b2;
-      const real val = v1*v1 + v2*v2 - r*r;
-      if (val < 1e-10) break;
-      const real deriv = -2.0*(P11*v1*v1 + 2.0*P12*v1*v2 + P22*v2*v2);
-      const real delta = -val/deriv;
-      if (delta < 1e-10) break;
-      la += delta;
-    }
-    res[0] = v1*d[0]; res[1] = v2*d[1];
-    return la != 0;
-  }
-  if (n == 3) {
-    const real b1 = bin[0]*d[0], b2 = bin[1]*d[1], b3 = bin[2]*d[2];
-    const real A11 = Ain[0]*d[0]*d[0], A22 = Ain[4]*d[1]*d[1], A33 = Ain[8]*d[2]*d[2];
-    const real A12 = Ain[1]*d[0]*d[1], A13 = Ain[2]*d[0]*d[2], A23 = Ain[5]*d[1]*d[2];
-    real v1 = 0, v2 = 0, v3 = 0;
-    for (int iter = 0; iter < 20; iter++) {
-      real P11 = (A22+la)*(A33+la) - A23*A23;
-      real P22 = (A11+la)*(A33+la) - A13*A13;
-      real P33 = (A11+la)*(A22+la) - A12*A12;
-      real P12 = A13*A23 - A12*(A33+la);
-      real P13 = A12*A23 - A13*(A22+la);
-      real P23 = A12*A13 - A23*(A11+la);
-      const real det = (A11+la)*P11 + A12*P12 + A13*P13;
-      if (det < 1e-10) { res[0] = 0; res[1] = 0; res[2] = 0; return 0; }
-      const real detinv = 1/det;
-      P11 *= detinv; P22 *= detinv; P33 *= detinv; P12 *= detinv; P13 *= detinv; P23 *= detinv;
-      v1 = -P11*b1 - P12*b2 - P13*b3;
-      v2 = -P12*b1 - P22*b2 - P23*b3;
-      v3 = -P13*b1 - P23*b2 - P33*b3;
-      const real val = v1*v1 + v2*v2 + v3*v3 - r*r;
-      if (val < 1e-10) break;
-      const real deriv = -2.0*(P11*v1*v1 + P22*v2*v2 + P33*v3*v3) - 4.0*(P12*v1*v2 + P13*v1*v3 + P23*v2*v3);
-      const real delta = -val/deriv;
-      if (delta < 1e-10) break;
-      la += delta;
-    }
-    res[0] = v1*d[0]; res[1] = v2*d[1]; res[2] = v3*d[2];
-    return la != 0;
-  }
-  real A[25], Ala[25], b[5], tmp[5];
+  // scaled problem: c = D b, S = D A D (upper triangle s[i][j], i <= j)
+  real c[5], y[5];
+  SmallSym S;
+  S.n = n;
   for (int i = 0; i < n; i++) {
-    b[i] = bin[i] * d[i];
-    for (int j = 0; j < n; j++) A[j+i*n] = Ain[j+i*n] * d[i] * d[j];
+    c[i] = bin[i]*d[i];
+    y[i] = 0;
+    for (int j = 0; j < n; j++) S.at(i, j) = Ain[i*n + j]*d[i]*d[j];
   }
-  for (int iter = 0; iter < 20; iter++) {
-    for (int i = 0; i < n*n; i++) Ala[i] = A[i];
-    for (int i = 0; i < n; i++) Ala[i*(n+1)] += la;
-    if (small_chol_factor(Ala, n, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return 0; }
-    small_chol_solve(res, Ala, b, n);
-    for (int i = 0; i < n; i++) res[i] = res[i]*-1;
-    const real val = dot_ref(res, res, n) - r*r;
-    if (val < 1e-10) break;
-    small_chol_solve(tmp, Ala, res, n);
-    const real deriv = -2.0 * dot_ref(res, tmp, n);
-    const real delta = -val/deriv;
-    if (delta < 1e-10) break;
-    la += delta;
+  real lambda = 0;
+  for (int step = 0; step < 20; step++) {
+    real slope;           // phi'(lambda) = -2 y' (S + lambda I)^-1 y
+    if (n == 2) {
+      const real g0 = S.at(0, 0) + lambda, g1 = S.at(1, 1) + lambda, o = S.at(0, 1);
+      const real det = g0*g1 - o*o;
+      if (det < 1e-10) { res[0] = 0; res[1] = 0; return 0; }
+      const real inv = 1/det;
+      const real i00 = g1*inv, i11 = g0*inv, i01 = -o*inv;            // inverse of the shifted matrix
+      y[0] = -i00*c[0] - i01*c[1];
+      y[1] = -i01*c[0] - i11*c[1];
+      slope = -2.0*(i00*y[0]*y[0] + 2.0*i01*y[0]*y[1] + i11*y[1]*y[1]);
+    } else if (n == 3) {
+      const real g0 = S.at(0, 0) + lambda, g1 = S.at(1, 1) + lambda, g2 = S.at(2, 2) + lambda;
+      const real o01 = S.at(0, 1), o02 = S.at(0, 2), o12 = S.at(1, 2);
+      // cofactors (the matrix is symmetric, so is its adjugate)
+      real k00 = g1*g2 - o12*o12, k11 = g0*g2 - o02*o02, k22 = g0*g1 - o01*o01;
+      real k01 = o02*o12 - o01*g2, k02 = o01*o12 - o02*g1, k12 = o01*o02 - o12*g0;
+      const real det = g0*k00 + o01*k01 + o02*k02;
+      if (det < 1e-10) { res[0] = 0; res[1] = 0; res[2] = 0; return 0; }
+      const real inv = 1/det;
+      k00 *= inv; k11 *= inv; k22 *= inv; k01 *= inv; k02 *= inv; k12 *= inv;
+      y[0] = -k00*c[0] - k01*c[1] - k02*c[2];
+      y[1] = -k01*c[0] - k11*c[1] - k12*c[2];
+      y[2] = -k02*c[0] - k12*c[1] - k22*c[2];
+      slope = -2.0*(k00*y[0]*y[0] + k11*y[1]*y[1] + k22*y[2]*y[2]) - 4.0*(k01*y[0]*y[1] + k02*y[0]*y[2] + k12*y[1]*y[2]);
+    } else {
+      SmallSym F = S;
+      for (int i = 0; i < n; i++) F.at(i, i) += lambda;
+      if (small_chol_factor(F, 1e-10) < n) { for (int i = 0; i < n; i++) res[i] = 0; return 0; }
+      small_chol_solve(y, F, c);
+      for (int i = 0; i < n; i++) y[i] = y[i]*-1;
+      real z[5];
+      small_chol_solve(z, F, y);
+      slope = -2.0 * dot_ref(y, z, n);
+    }
+    const real gap = (n == 2 ? y[0]*y[0] + y[1]*y[1] : (n == 3 ? y[0]*y[0] + y[1]*y[1] + y[2]*y[2] : dot_ref(y, y, n))) - r*r;
+    if (gap < 1e-10) break;
+    const real advance = -gap/slope;
+    if (advance < 1e-10) break;
+    lambda += advance;
   }
-  for (int i = 0; i < n; i++) res[i] = res[i] * d[i];
-  return la != 0;
+  for (int i = 0; i < n; i++) res[i] = y[i]*d[i];
+  return lambda != 0;
 }
 
 // scale the friction part of a contact force onto / into the friction ellipsoid  (:366-381)
