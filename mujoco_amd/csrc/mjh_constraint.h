@@ -528,7 +528,15 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   // ---- contact Jacobians: per contact, lanes over dof columns ------------------------------------
   crptr cdof = MJH_F(B, cdof, e);
   crptr subtree_com = MJH_F(B, subtree_com, e);
-  for (int k = 0; k < ncon; k++) {
+  // (nv <= 32: the two halves of the wavefront take a contact each)
+#if !MJH_LANE_MODE && MJH_W == 64
+  const int cpair = nv <= 32;
+#else
+  const int cpair = 0;
+#endif
+  for (int k0 = 0; k0 < ncon; k0 += 1 + cpair) {
+    const int k = k0 + (cpair ? (wv_lane() >> 5) : 0);
+    if (k >= ncon) continue;
     int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     if (r0 < 0) continue;
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
@@ -541,7 +549,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     real off1[3], off2[3];
     v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
     v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
-    MJH_FOR_LANES(j, nv) {
+    for (int j = cpair ? (wv_lane() & 31) : wv_lane(); j < nv; j += cpair ? 32 : MJH_W) {
       // translational point Jacobians of both bodies (mj_jac, engine_core_util.c:176)
       int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
       int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
