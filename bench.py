@@ -203,7 +203,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--chunk", type=int, default=100, help="steps per rollout-kernel launch (one open-loop rollout call)")
+    ap.add_argument("--chunk", type=int, default=250,
+                    help="steps per rollout-kernel launch (one open-loop rollout call); 250 measured best: longer launches average the per-environment cost, shorter ones re-deal the environments over the SIMDs more often")
     ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")

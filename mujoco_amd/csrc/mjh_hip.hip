@@ -35,7 +35,7 @@ extern "C" bool mjh_launch_lane_reset(const DModel* M, const DBatch* B, int nenv
 // s + nsimd, s + 2 nsimd, ...  Dealing rank r of block q to slot r (q even) or nsimd - 1 - r (q odd)
 // gives every SIMD one environment of each cost quartile AND nearly equal sums; a SIMD is work
 // conserving, so it finishes when the sum of its wavefronts' work is done.
-__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B, int nsimd) {
+__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B, int nsimd, int mode) {
   __shared__ int hist[256];
   __shared__ int maxc;
   const int n = B->nenv, tid = (int)threadIdx.x;
@@ -57,7 +57,10 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
     const int rank = atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
     const int q = rank / nsimd, r = rank - q*nsimd;
     int w = rank;
-    if ((q & 1) && (q + 1)*nsimd <= n) w = q*nsimd + (nsimd - 1 - r);      // full odd blocks run backwards
+    if (mode == 2 && n == 4*nsimd) {
+      // the nsimd heaviest get a SIMD each, and the three lightest of the rest as company
+      if (rank >= nsimd) { const int u = n - 1 - rank; w = (u % 3 + 1)*nsimd + u / 3; }
+    } else if ((q & 1) && (q + 1)*nsimd <= n) w = q*nsimd + (nsimd - 1 - r);      // full odd blocks run backwards
     perm[w] = e;
   }
 }
@@ -123,15 +126,15 @@ struct Backend {
   }
   static bool launch_balance(const DBatch* B, int nenv, void* stream) {
     (void)nenv;
-    static int nsimd = 0;
+    static int nsimd = 0, mode = 1;
     if (!nsimd) {
       int dev = 0, cus = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
       nsimd = 4*cus;
-      if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) if (atoi(ev) == 0) nsimd = 1 << 30;     // A/B: plain descending order
+      if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) { mode = atoi(ev); if (mode == 0) nsimd = 1 << 30; }     // A/B: 0 plain descending order, 2 heaviest + three lightest
     }
-    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd);
+    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd, mode);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {

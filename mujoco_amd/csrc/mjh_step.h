@@ -350,14 +350,24 @@ MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
     crptr Mq = MJH_G(B, M, e);
     rptr qH = MJH_F(B, qLD, e);
     rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
-    MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
-    wv_sync();
-    MJH_FOR_LANES(i, nv) {
-      real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
-      qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+    if (pairs_euler_factor(M, B, e)) {
+      // stage_factor_m factorised qH next to M and parked it (primal solvers, steps without constraints:
+      // stage_finish had no solve to share, so the factor is picked up here)
+      crptr qHg = MJH_G(B, qH2, e);
+      crptr qHDg = MJH_G(B, qH2DiagInv, e);
+      MJH_FOR_LANES(k, s.nC) qH[k] = qHg[k];
+      MJH_FOR_LANES(i, nv) qHDiagInv[i] = qHDg[i];
+      wv_sync();
+    } else {
+      MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
+      wv_sync();
+      MJH_FOR_LANES(i, nv) {
+        real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+        qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+      }
+      wv_sync();
+      factor_ld(M, qH, qHDiagInv);
     }
-    wv_sync();
-    factor_ld(M, qH, qHDiagInv);
     crptr fs = MJH_F(B, qfrc_smooth, e);
     crptr fc = MJH_F(B, qfrc_constraint, e);
     MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
