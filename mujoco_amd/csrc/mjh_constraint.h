@@ -31,7 +31,7 @@ struct Efc {
   X(force, MJH_G(B, efc_force, e), nefc, 1)                          \
   X(b, MJH_G(B, efc_b, e), nefc, 1)                                  \
   X(floss, MJH_G(B, efc_frictionloss, e), nefc, 1)                   \
-  X(AR, MJH_G(B, efc_AR, e), nefc*nefc, 2)                           \
+  X(AR, MJH_G(B, efc_AR, e), dual_*nefc*nefc, 2)                     \
   X(R, MJH_G(B, efc_R, e), nefc, 1)                                  \
   X(D, MJH_G(B, efc_D, e), nefc, 1)                                  \
   X(aref, MJH_G(B, efc_aref, e), nefc, 1)                            \
@@ -42,8 +42,8 @@ struct Efc {
   X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc, 1)                          \
   X(diagA, MJH_G(B, efc_diagA, e), nefc, 1)                          \
   X(vel, MJH_G(B, efc_vel, e), nefc, 1)                              \
-  X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, nv, 2)                  \
-  X(Y, MJH_G(B, efc_Y, e), nefc*nv, 2)                               \
+  X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, dual_*nv, 2)            \
+  X(Y, MJH_G(B, efc_Y, e), dual_*nefc*nv, 2)                         \
   X(J, MJH_G(B, efc_J, e), nefc*nv, 1)                               \
   X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
@@ -67,6 +67,8 @@ template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* 
 // ints first)
 MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int nv = M.s.nv, nmax = M.s.nefcmax;
+  // AR, Y and sqrtInvD belong to the dual (PGS) solver: the primal ones leave their bytes to J
+  const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
   int off1 = B.dyn_off, off2 = B.dyn2_off;
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
   unsigned mask = 0, bit = 1;
@@ -97,7 +99,8 @@ MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   const int nv = M.s.nv, nmax = M.s.nefcmax;
-  (void)nv; (void)nmax;
+  const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
+  (void)nv; (void)nmax; (void)dual_;
   if (!nefc) return;
   Efc P;
   const unsigned mask = efc_layout(M, B, e, nefc, P);
