@@ -191,13 +191,14 @@ MJH_DEV void tree_accumulate_to_parent(MREF M, P0 x, int n, int include_world) {
   const MJH_CONST_AS DSizes& s = M.s;
   for (int L = s.nlevel - 2; L >= (include_world ? 0 : 1); L--) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
-    MJH_FOR_LANES(k, a1 - a0) {
+    // a lane per (parent of the level, component): the children are added in their order, per component
+    MJH_FOR_LANES(w, (a1 - a0)*n) {
+      const int k = w / n, q = w - k*n;
       int p = M.body_level_ids[a0 + k];
       int c0 = M.body_child_adr[p], c1 = M.body_child_adr[p+1];
-      for (int c = c0; c < c1; c++) {
-        int ch = M.body_child_ids[c];
-        for (int q = 0; q < n; q++) x[n*p + q] += x[n*ch + q];
-      }
+      real acc = x[n*p + q];
+      for (int c = c0; c < c1; c++) acc += x[n*M.body_child_ids[c] + q];
+      x[n*p + q] = acc;
     }
     wv_sync();
   }
