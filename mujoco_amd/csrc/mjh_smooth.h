@@ -996,39 +996,72 @@ MJH_DEVN void stage_comvel(MREF M_, BREF B_, int e_) {
   crptr cdof = MJH_F(B, cdof, e);
   rptr cvel = MJH_F(B, cvel, e);
   rptr cdof_dot = MJH_F(B, cdof_dot, e);
+  // A body's dofs come in groups that enter its velocity one after the other: a hinge / slide dof, the three
+  // rotational dofs of a ball or free joint, the three translational dofs of a free joint.  Only the
+  // running sum v (parent velocity, then group after group) follows the tree.  So:
+  //  (1) every group's term cdof * qvel at once, parked in the cdof_dot slot of the group's first dof;
+  //  (2) the level loop adds the terms, a lane per (body of the level, component), and leaves the velocity
+  //      BEFORE each group in that slot;
+  //  (3) every dof's cdof_dot = v_before x cdof at once (zero for free translations).
+  // Operands and operation order per component are those of the body-by-body recursion.
+  // group start of dof d: itself for hinge / slide, the joint's first (or fourth) dof otherwise
+  auto group_of = [&](int d, int& first, int& n, int& spins) {
+    const int jt = M.dof_jnttype[d];
+    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+      const int off = d - M.jnt_dofadr[M.dof_jntid[d]];
+      first = d - off % 3;
+      n = 3;
+      spins = !(jt == MJH_JNT_FREE && off < 3);
+    } else { first = d; n = 1; spins = 1; }
+  };
+  MJH_FOR_LANES(d, s.nv) {
+    int first, n, spins;
+    group_of(d, first, n, spins);
+    if (first == d) {
+      real tmp[6];
+      mul_dof_vec(tmp, cdof + 6*d, qvel + d, n);
+      for (int q = 0; q < 6; q++) cdof_dot[6*d + q] = tmp[q];
+    }
+  }
   if (wv_lane() == 0) for (int k = 0; k < 6; k++) cvel[k] = 0;
   wv_sync();
   for (int L = 1; L < s.nlevel; L++) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
-    MJH_FOR_LANES(k, a1 - a0) {
-      int i = M.body_level_ids[a0 + k];
-      real v[6], tmp[6];
-      for (int q = 0; q < 6; q++) v[q] = cvel[6*M.body_parentid[i] + q];
-      int dofnum = M.body_dofnum[i], bda = M.body_dofadr[i];
-      for (int j = 0; j < dofnum; j++) {
-        int jt = M.dof_jnttype[bda + j];
-        if (jt == MJH_JNT_FREE) {
-          for (int q = 0; q < 18; q++) cdof_dot[6*bda + q] = 0;
-          mul_dof_vec(tmp, cdof + 6*bda, qvel + bda, 3);
-          for (int q = 0; q < 6; q++) v[q] += tmp[q];
-          j += 3;
-        }
-        if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
-          for (int r = 0; r < 3; r++)
-            sp_cross_motion(cdof_dot + 6*(bda + j + r), v, cdof + 6*(bda + j + r));
-          mul_dof_vec(tmp, cdof + 6*(bda + j), qvel + bda + j, 3);
-          for (int q = 0; q < 6; q++) v[q] += tmp[q];
-          j += 2;
-        } else {
-          sp_cross_motion(cdof_dot + 6*(bda + j), v, cdof + 6*(bda + j));
-          mul_dof_vec(tmp, cdof + 6*(bda + j), qvel + bda + j, 1);
-          for (int q = 0; q < 6; q++) v[q] += tmp[q];
-        }
+    MJH_FOR_LANES(w, (a1 - a0)*6) {
+      const int k = w / 6, q = w - 6*k;
+      const int i = M.body_level_ids[a0 + k];
+      real v = cvel[6*M.body_parentid[i] + q];
+      const int dofnum = M.body_dofnum[i], bda = M.body_dofadr[i];
+      for (int j = 0; j < dofnum; ) {
+        const int jt = M.dof_jnttype[bda + j];
+        const int n = (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) ? 3 : 1;
+        const real t = cdof_dot[6*(bda + j) + q];
+        cdof_dot[6*(bda + j) + q] = v;
+        v += t;
+        j += n;
       }
-      for (int q = 0; q < 6; q++) cvel[6*i + q] = v[q];
+      cvel[6*i + q] = v;
     }
     wv_sync();
   }
+  // (rounds from the top: the dofs of a group that sit in a later round than its first dof read the slot
+  // before the first dof's round overwrites it; inside a round the barrier separates reads from writes)
+  for (int d0 = ((s.nv - 1) / MJH_W) * MJH_W; d0 >= 0; d0 -= MJH_W) {
+    const int d = d0 + wv_lane();
+    real out[6] = {0, 0, 0, 0, 0, 0};
+    if (d < s.nv) {
+      int first, n, spins;
+      group_of(d, first, n, spins);
+      if (spins) {
+        real vb[6];
+        for (int q = 0; q < 6; q++) vb[q] = cdof_dot[6*first + q];
+        sp_cross_motion(out, vb, cdof + 6*d);
+      }
+    }
+    wv_sync();          // the group's first slot is read by its other dofs before it is overwritten
+    if (d < s.nv) for (int q = 0; q < 6; q++) cdof_dot[6*d + q] = out[q];
+  }
+  wv_sync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1284,23 +1317,36 @@ MJH_DEVN void stage_rne(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  // Only the sum cacc[i] = cacc[parent] + cdof_dot_i * qvel_i follows the tree; the joint term and the body
+  // force are per-body work.  So: (1) every body's joint term at once (parked in its cacc slot), (2) the level
+  // loop adds the parent's acceleration, a lane per (body of the level, component), (3) every body's
+  // force at once.  Same operands, same operations as the body-by-body recursion.
+  MJH_FOR_LANES(k, s.nbody - 1) {
+    const int i = k + 1;
+    const int bda = M.body_dofadr[i];
+    real tmp[6];
+    mul_dof_vec(tmp, cdof_dot + 6*bda, qvel + bda, M.body_dofnum[i]);
+    for (int q = 0; q < 6; q++) cacc[6*i + q] = tmp[q];
+  }
+  wv_sync();
   for (int L = 1; L < s.nlevel; L++) {
     int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L+1];
-    MJH_FOR_LANES(k, a1 - a0) {
-      int i = M.body_level_ids[a0 + k];
-      int bda = M.body_dofadr[i];
-      real tmp[6], tmp1[6];
-      mul_dof_vec(tmp, cdof_dot + 6*bda, qvel + bda, M.body_dofnum[i]);
-      for (int q = 0; q < 6; q++) cacc[6*i + q] = cacc[6*M.body_parentid[i] + q] + tmp[q];
-      real f[6];
-      sp_mul_inert(f, cinert + 10*i, cacc + 6*i);
-      sp_mul_inert(tmp, cinert + 10*i, cvel + 6*i);
-      sp_cross_force(tmp1, cvel + 6*i, tmp);
-      for (int q = 0; q < 6; q++) cfrc[6*i + q] = f[q] + tmp1[q];
+    MJH_FOR_LANES(w, (a1 - a0)*6) {
+      const int k = w / 6, q = w - 6*k;
+      const int i = M.body_level_ids[a0 + k];
+      cacc[6*i + q] = cacc[6*M.body_parentid[i] + q] + cacc[6*i + q];
     }
     wv_sync();
   }
-  if (wv_lane() == 0) for (int k = 0; k < 6; k++) cfrc[k] = 0;
+  MJH_FOR_LANES(k, s.nbody) {
+    const int i = k;
+    if (i == 0) { for (int q = 0; q < 6; q++) cfrc[q] = 0; continue; }
+    real f[6], tmp[6], tmp1[6];
+    sp_mul_inert(f, cinert + 10*i, cacc + 6*i);
+    sp_mul_inert(tmp, cinert + 10*i, cvel + 6*i);
+    sp_cross_force(tmp1, cvel + 6*i, tmp);
+    for (int q = 0; q < 6; q++) cfrc[6*i + q] = f[q] + tmp1[q];
+  }
   wv_sync();
   tree_accumulate_to_parent(M, cfrc, 6, 0);
   MJH_FOR_LANES(i, s.nv) bias[i] = sp_dot6(cdof + 6*i, cfrc + 6*M.dof_bodyid[i]);
