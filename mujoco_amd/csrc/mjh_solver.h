@@ -64,7 +64,7 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // LT >= 0: the chain length L = nefc/4 is a compile-time constant (the caller dispatches on it): the
 // chain of a row update is then straight-line code -- no scalar branch per chain step, the DPP moves
 // of a row scheduled ahead of the dependent adds.
-template <int ARL, int LT = -1>
+template <int ARL, int LT = -1, int NT = -1>
 MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
   BREF B = B_;
@@ -74,7 +74,7 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   Efc P;
   efc_layout(M, B, e, n, P);
   const int lane = wv_lane();
-  const int n4 = n & ~3, L = LT >= 0 ? LT : (n4 >> 2), ntail = n - n4;
+  const int n4 = n & ~3, L = LT >= 0 ? LT : (n4 >> 2), ntail = NT >= 0 ? NT : (n - n4);
   const int row = lane >> 4, col = lane & 15;
   // constraint owned by this lane (-1: none)
   int j = -1;
@@ -1057,13 +1057,16 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 #else
 #if MJH_W == 64 && !defined(MJH_PGS_NO_LSPEC)
     if (mjh_in_lds(P.AR)) {
-      switch (nefc >> 2) {
-#define MJH_PGS_CASE(k) case k: solve_pgs_fast<1, k>(M, B, e); break;
-        MJH_PGS_CASE(0) MJH_PGS_CASE(1) MJH_PGS_CASE(2) MJH_PGS_CASE(3) MJH_PGS_CASE(4) MJH_PGS_CASE(5)
-        MJH_PGS_CASE(6) MJH_PGS_CASE(7) MJH_PGS_CASE(8) MJH_PGS_CASE(9) MJH_PGS_CASE(10) MJH_PGS_CASE(11)
-        MJH_PGS_CASE(12) MJH_PGS_CASE(13) MJH_PGS_CASE(14) MJH_PGS_CASE(15)
+      // (chain length nefc/4 and tail length nefc%4 as compile-time constants: 65 instances)
+      switch (nefc) {
+#define MJH_PGS_CASE(n_) case n_: solve_pgs_fast<1, (n_) / 4, (n_) % 4>(M, B, e); break;
+#define MJH_PGS_CASE8(b_) MJH_PGS_CASE(b_) MJH_PGS_CASE(b_ + 1) MJH_PGS_CASE(b_ + 2) MJH_PGS_CASE(b_ + 3) \
+                          MJH_PGS_CASE(b_ + 4) MJH_PGS_CASE(b_ + 5) MJH_PGS_CASE(b_ + 6) MJH_PGS_CASE(b_ + 7)
+        MJH_PGS_CASE8(0) MJH_PGS_CASE8(8) MJH_PGS_CASE8(16) MJH_PGS_CASE8(24)
+        MJH_PGS_CASE8(32) MJH_PGS_CASE8(40) MJH_PGS_CASE8(48) MJH_PGS_CASE8(56)
+#undef MJH_PGS_CASE8
 #undef MJH_PGS_CASE
-        default: solve_pgs_fast<1, 16>(M, B, e); break;
+        default: solve_pgs_fast<1, 16, 0>(M, B, e); break;
       }
     }
 #else
