@@ -452,6 +452,22 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_BALL ? 3 : (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_FREE ? 6 : 1)) :
         (m->actuator_trntype[i] == mjTRN_TENDON ? std::max(1, m->ten_J_rownnz[m->actuator_trnid[2*i]]) : 1)));
   s.nmoment = H->actuator_momentadr[m->nu];
+  {
+    H->dof_act_adr.assign(m->nv + 1, 0);
+    H->dof_act_ids.assign(m->nu + 1, 0);
+    int fill = 0;
+    for (int j = 0; j < m->nv; j++) {
+      H->dof_act_adr[j] = fill;
+      for (int i = 0; i < m->nu; i++) {
+        const int tt = m->actuator_trntype[i];
+        if (tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT) continue;
+        const int id = m->actuator_trnid[2*i];
+        if (m->jnt_type[id] != mjJNT_HINGE && m->jnt_type[id] != mjJNT_SLIDE) continue;
+        if (m->jnt_dofadr[id] == j) H->dof_act_ids[fill++] = i;
+      }
+    }
+    H->dof_act_adr[m->nv] = fill;
+  }
 
   // ---------------- derived: tree levels, children, dof ancestors --------------------------------------
   std::vector<int> depth(m->nbody, 0);

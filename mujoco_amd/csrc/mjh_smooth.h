@@ -1463,6 +1463,19 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
   crptr mom = MJH_F(B, actuator_moment, e);
   ciptr rownnz = MJH_F(B, moment_rownnz, e);
   ciptr colind = MJH_F(B, moment_colind, e);
+  if (!MJH_HAS(MJH_FT_TRNMISC)) {
+    // scalar joint transmissions only: the rows that touch dof j are known at upload (same order, same skips)
+    MJH_FOR_LANES(j, s.nv) {
+      real r = 0;
+      for (int a = M.dof_act_adr[j]; a < M.dof_act_adr[j + 1]; a++) {
+        const int i = M.dof_act_ids[a];
+        const real scl = force[i];
+        if (scl == 0) continue;
+        r += mom[M.actuator_momentadr[i]]*scl;
+      }
+      qfa[j] = r;
+    }
+  } else
   MJH_FOR_LANES(j, s.nv) {
     real r = 0;
     for (int i = 0; i < s.nu; i++) {

@@ -89,6 +89,9 @@
   X(actuator_actlimited, s.nu)                 \
   X(actuator_actearly, s.nu)                   \
   X(actuator_momentadr, s.nu + 1)              \
+  /* scalar joint transmissions by dof (ascending actuator ids): qfrc_actuator without the search over all rows */ \
+  X(dof_act_adr, s.nv + 1)                     \
+  X(dof_act_ids, s.nu + 1)                     \
   X(jnt_actfrclimited, s.njnt)                 \
   X(pair_geom1, s.npair)                       \
   X(pair_geom2, s.npair)                       \
