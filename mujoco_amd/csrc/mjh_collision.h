@@ -963,8 +963,8 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
 }
 
 #if !MJH_LANE_MODE
-// The group-cooperative colliders of one chunk of MJH_W pairs, in pair order (bit q of `todo`: pair
-// p0 + q).  `slot` is the contact slot my own pair's first contact would take; each cooperative pair
+// The group-cooperative colliders of one chunk of MJH_W pairs, in pair order (bit q of `todo`: the pair
+// lane q holds in `mypair`).  `slot` is the contact slot my own pair's first contact would take; each cooperative pair
 // before mine pushes it back by that pair's count.  Returns (how far my slot moved) | (contacts
 // emitted) << 12 | overflow << 24.  Out of line: the point colliders around the call site are the hot
 // path of most models, and keeping the clipping code out of their function keeps its register
@@ -995,14 +995,14 @@ MJH_DEVN int collide_coop_pair(MREF M_, BREF B_, int e_, int pq, int first) {
   return cnt | (overflow << 8);
 }
 
-MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int p0, unsigned todo_lo, unsigned todo_hi, int slot) {
+MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int mypair, unsigned todo_lo, unsigned todo_hi, int slot) {
   MJH_ENTER(M_, B_, e_);
   unsigned long long todo = ((unsigned long long)todo_hi << 32) | todo_lo;
   int moved = 0, emitted = 0, overflow = 0;
   while (todo) {
     const int q = __builtin_ctzll(todo);
     todo &= todo - 1;
-    const int r = collide_coop_pair(M, B, e, p0 + q, wv_bcast_i(slot + moved, q));
+    const int r = collide_coop_pair(M, B, e, wv_bcast_i(mypair, q), wv_bcast_i(slot + moved, q));
     const int cnt = r & 0xff;
     overflow |= r >> 8;
     if (wv_lane() > q) moved += cnt;
@@ -1034,47 +1034,46 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   // sweep-and-prune predicate of the reference, evaluated only for pairs that would emit a contact;
   // the PCA frame is computed the first time a group needs it (-1: not yet)
   int frame_state = -1;
-  for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
-    const int p = p0 + wv_lane();
+
+  // One round of narrowphase: lane's pair p (-1: none), already through the bounding-sphere filter.
+  auto narrow = [&](const int p) {
     Hit ha, hb;          // the (at most two) contacts of my pair's point collider
     int n = 0;
     int coop = 0;        // my pair needs a group-cooperative collider
     int unsupported = 0;
-    if (p < s.npair) {
+    if (p >= 0) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
       const real margin = M.pair_margin[p];       // margin + gap: collider threshold
-      if (!filter_sphere(M, gx, gm, g1, g2, margin)) {
-        crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
-        crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
-        const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
-        const int func = M.pair_func[p];
-        switch (func) {
-          case MJH_COL_PLANE_SPHERE:
-            n = hit_plane_sphere(ha, margin, c1, mcol(mat1, 2), c2, size2[0]); break;
-          case MJH_COL_PLANE_CAPSULE:
-            n = hit_plane_capsule(ha, hb, margin, c1, mcol(mat1, 2), c2, mat2, size2); break;
-          case MJH_COL_SPHERE_SPHERE:
-            n = hit_sphere_sphere(ha, margin, c1, mat1, size1[0], c2, mat2, size2[0]); break;
-          case MJH_COL_SPHERE_CAPSULE:
-            n = hit_sphere_capsule(ha, margin, c1, mat1, size1[0], c2, mat2, size2); break;
-          case MJH_COL_CAPSULE_CAPSULE:
-            n = hit_capsule_capsule(ha, hb, margin, c1, mat1, size1, c2, mat2, size2); break;
-          default:
-            if (MJH_HAS(MJH_FT_COLCONVEX)) {
-              // (out-of-line colliders write through a reference: a local of their own keeps `ha` in registers)
-              if (func == MJH_COL_SPHERE_BOX) { Hit hx; n = hit_sphere_box(hx, margin, c1, size1[0], c2, mat2, size2); ha = hx; }
-              else if (func == MJH_COL_SPHERE_CYLINDER) { Hit hx; n = hit_sphere_cylinder(hx, margin, c1, mat1, size1[0], c2, mat2, size2); ha = hx; }
-              else if (func == MJH_COL_UNSUPPORTED || MJH_LANE_MODE) unsupported = 1;
-              else coop = 1;
-            }
-            break;
-        }
+      crptr mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+      crptr mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
+      const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
+      const int func = M.pair_func[p];
+      switch (func) {
+        case MJH_COL_PLANE_SPHERE:
+          n = hit_plane_sphere(ha, margin, c1, mcol(mat1, 2), c2, size2[0]); break;
+        case MJH_COL_PLANE_CAPSULE:
+          n = hit_plane_capsule(ha, hb, margin, c1, mcol(mat1, 2), c2, mat2, size2); break;
+        case MJH_COL_SPHERE_SPHERE:
+          n = hit_sphere_sphere(ha, margin, c1, mat1, size1[0], c2, mat2, size2[0]); break;
+        case MJH_COL_SPHERE_CAPSULE:
+          n = hit_sphere_capsule(ha, margin, c1, mat1, size1[0], c2, mat2, size2); break;
+        case MJH_COL_CAPSULE_CAPSULE:
+          n = hit_capsule_capsule(ha, hb, margin, c1, mat1, size1, c2, mat2, size2); break;
+        default:
+          if (MJH_HAS(MJH_FT_COLCONVEX)) {
+            // (out-of-line colliders write through a reference: a local of their own keeps `ha` in registers)
+            if (func == MJH_COL_SPHERE_BOX) { Hit hx; n = hit_sphere_box(hx, margin, c1, size1[0], c2, mat2, size2); ha = hx; }
+            else if (func == MJH_COL_SPHERE_CYLINDER) { Hit hx; n = hit_sphere_cylinder(hx, margin, c1, mat1, size1[0], c2, mat2, size2); ha = hx; }
+            else if (func == MJH_COL_UNSUPPORTED || MJH_LANE_MODE) unsupported = 1;
+            else coop = 1;
+          }
+          break;
       }
     }
     if (s.nbp) {
       // would the reference's broad / midphase have let the pair reach its narrowphase at all?
       // (asked only by lanes about to emit a contact of a pair that is subject to one of the culls)
-      int ask = (p < s.npair && (n > 0 || coop) && (M.pair_sap[p] >= 0 || M.pair_route[p] == 2)) ? p : -1;
+      int ask = (p >= 0 && (n > 0 || coop) && (M.pair_sap[p] >= 0 || M.pair_route[p] == 2)) ? p : -1;
       if (ask >= 0 && n > 0) {
         // A contact at distance `dist` below the pair's margin means the two geoms' projections on ANY
         // axis come within dist of each other, so the (margin-inflated) bounds the culls compare overlap
@@ -1098,13 +1097,13 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     // from the reference's, so the environment is flagged (and frozen by the rollout loop)
     if (MJH_HAS(MJH_FT_COLCONVEX) && wv_any(unsupported) && wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++;
 
-    int before = wv_exscan_i(n);     // contacts of the chunk's earlier pairs (point colliders so far)
+    int before = wv_exscan_i(n);     // contacts of the round's earlier pairs (point colliders so far)
     int total = wv_sum_i(n);
 #if !MJH_LANE_MODE
     if (MJH_HAS(MJH_FT_COLCONVEX)) {
       const unsigned long long todo = wv_ballot(coop);
       if (todo) {
-        const int r = collide_coop_pairs(M, B, e, p0, (unsigned)todo, (unsigned)(todo >> 32), base + before);
+        const int r = collide_coop_pairs(M, B, e, p, (unsigned)todo, (unsigned)(todo >> 32), base + before);
         before += r & 0xfff;
         total += (r >> 12) & 0xfff;
         overflow |= r >> 24;
@@ -1117,6 +1116,42 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
       if (n > 1) { if (c + 1 >= s.nconmax) overflow = 1; else store_contact(M, B, e, c + 1, p, hb); }
     }
     base += total;
+  };
+  auto passes_filter = [&](int p) -> int {
+    if (p >= s.npair) return 0;
+    return !filter_sphere(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p]);
+  };
+
+#if !MJH_LANE_MODE
+  // Phase 1: the bounding-sphere filter over the whole pair list, survivors compacted into the lanes in
+  // pair order (lane r takes the r-th survivor: the position of the r-th set bit of the chunk's ballot).
+  // Phase 2: ONE narrowphase round over the survivors -- a humanoid has ~130 candidate pairs and a
+  // handful in reach, and the narrowphase (divergent over the collider kinds) was run per chunk of 64.
+  // More than MJH_W survivors: chunk by chunk as before.
+  int mine = -1, nsurv = 0;
+  for (int p0 = 0; p0 < s.npair && nsurv <= MJH_W; p0 += MJH_W) {
+    const unsigned long long m = wv_ballot(passes_filter(p0 + wv_lane()));
+    const int cnt = __builtin_popcountll(m);
+    const int k = wv_lane() - nsurv;
+    if (k >= 0 && k < cnt) {
+      // position of the k-th set bit of m
+      unsigned long long mm = m;
+      int kk = k, pos = 0;
+      for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __builtin_popcountll(mm & ((1ull << w) - 1));
+        if (kk >= c) { kk -= c; mm >>= w; pos += w; }
+      }
+      mine = p0 + pos;
+    }
+    nsurv += cnt;
+  }
+  if (nsurv <= MJH_W) {
+    if (nsurv > 0) narrow(mine);
+  } else
+#endif
+  for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
+    const int p = p0 + wv_lane();
+    narrow(passes_filter(p) ? p : -1);
   }
   overflow = wv_any(overflow);
   if (wv_lane() == 0) {

@@ -163,7 +163,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   rptr qfc = MJH_F(B, qfrc_constraint, e);
   rptr Md = MJH_G(B, nt_M, e);          // dense M
   rptr H = MJH_G(B, nt_H, e);           // Hessian, then its Cholesky factor (lower)
+  // the work vectors live in the unused tail of the LDS plan when it is large enough (the dual-only arrays
+  // AR / Y take no LDS under the primal solvers), else in their global home
   rptr vec = MJH_G(B, nt_vec, e);
+  if (P.free_bytes >= (int)(8*nv*sizeof(real))) vec = SP<real>{(real*)P.free_p, 1};
   rptr Ma = vec, grad = vec + nv, Mgrad = vec + 2*nv, search = vec + 3*nv, Mv = vec + 4*nv;
   rptr gradold = vec + 6*nv, Mgradold = vec + 7*nv;
   rptr jar = P.jar, Jv = P.ARf;
