@@ -8,14 +8,15 @@
 // pair list with its mixed contact parameters (mjh_model_build.h).
 //
 // Mapping onto a lane group (the MJH_W lanes that step one environment):
-//   * the pair list is walked in chunks of MJH_W pairs, one pair per lane: bounding-sphere filter,
-//     then the closed-form point colliders (plane/sphere/capsule: at most two contacts, kept in
-//     registers -- no contact array in private memory);
+//   * the pair list is walked in chunks of MJH_W pairs, one pair per lane, through the bounding-sphere
+//     filter; the survivors are compacted into the lanes in pair order and take ONE round of the
+//     closed-form point colliders (plane/sphere/capsule: at most two contacts, kept in registers -- no
+//     contact array in private memory); more than MJH_W survivors: chunk by chunk;
 //   * pairs of the chunk that need a multi-contact collider (box, cylinder) are taken ONE AT A
 //     TIME BY THE WHOLE GROUP: separating axes, box corners, polygon vertices and contact
 //     candidates are spread over lanes, selections are ballots / in-order scans that reproduce
 //     the reference's first-wins tie rules, and every surviving lane holds exactly one contact;
-//   * slots: a contact's index is (contacts of earlier chunks) + (exclusive scan of the per-pair
+//   * slots: a contact's index is (contacts of earlier rounds) + (exclusive scan of the per-pair
 //     counts) + its rank inside the pair, so lanes write their contacts straight into the
 //     (LDS-resident) contact slots in reference order.
 // All arithmetic that reaches a contact is evaluated in the reference's association

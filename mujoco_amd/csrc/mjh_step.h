@@ -327,9 +327,11 @@ MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
 }
 
 // mj_EulerSkip + mj_advance                        (engine_forward.c:1398-1476, :1261-1395)
-// The implicit-damping matrix qH = M + h*diag(B) is factorised in the slots of qLD/qLDiagInv,
-// which are dead once the constraint solve has produced qacc; M itself was parked in the global
-// field qH by stage_factor_m.
+// The implicit-damping matrix qH = M + h*diag(B): normally its factor was produced next to M's
+// (stage_factor_m, two matrices per pass) and its solve shared stage_finish's pass -- then the damped
+// acceleration already waits in qe (counts[MJH_C_PAIRED]).  Otherwise the parked factor is picked up
+// here, or (models outside the paired routines' range) qH is rebuilt from the copy of M that stage_crb
+// left in M's global home and factorised in the slots of qLD/qLDiagInv, dead once qacc is known.
 MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
