@@ -429,6 +429,16 @@ CAPBOX_XML = """
 """
 
 
+# 90 free spheres dropping onto a plane: more than 64 pairs survive the bounding-sphere filter (every
+# plane-sphere pair does), so the collision stage takes its chunk-by-chunk route, and the 30 spheres that
+# land first give 120 pyramid rows: the two-constraints-per-lane PGS
+def many_spheres_xml():
+    bodies = "".join(f'<body pos="{0.25*(i % 10)} {0.25*(i // 10)} {0.06 + 0.002*(i % 3)}"><freejoint/>'
+                     f'<geom type="sphere" size=".05" condim="1"/></body>' for i in range(90))
+    return (f'<mujoco><option timestep="0.004" solver="PGS" iterations="30"/><worldbody>'
+            f'<geom type="plane" size="5 5 .01"/>{bodies}</worldbody></mujoco>')
+
+
 # mocap bodies: a gripper-like box welded to a mocap target that the control array moves
 # (mjSTATE_MOCAP_POS | mjSTATE_MOCAP_QUAT in the control spec), a second mocap body carrying a
 # collision geom that pushes a free sphere around

@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -388,6 +388,27 @@ def test_capsule_box_collider_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+
+
+def test_many_filter_survivors_and_wide_pgs_vs_live_oracle(rb, hip_lib, tmp_path):
+    """90 spheres over a plane (nv = 540, generic kernel): > 64 filter survivors, up to 120 rows"""
+    xml = tmp_path / "many.xml"
+    xml.write_text(many_spheres_xml())
+    m = rb.MjModel.from_xml_path(str(xml))
+    dmb = K.DeviceModel(hip_lib, m, 128, 512)       # 90 contacts x 4 rows in the end
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 40
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmb, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("many spheres rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max(), "max nefc", ints[0, :, 1].max())
+    assert relerr(out, ref) <= TOL
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+    assert b.get("warning").sum() == 0
 
 
 def test_mocap_bodies_vs_live_oracle(rb, hip_lib, tmp_path):

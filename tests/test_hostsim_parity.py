@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -523,6 +523,28 @@ def test_capsule_box_random_poses_bit_exact(rb, hostsim_lib, tmp_path):
         rc = d.contact[:n]
         assert np.array_equal(cd[k, :n], rc["dist"]) and np.array_equal(cp[k, :n], rc["pos"]) and np.array_equal(cf[k, :n], rc["frame"]), k
     assert hist[1] > 50 and hist[2] > 20
+
+
+def test_many_filter_survivors_and_wide_pgs_bit_exact(rb, hostsim_lib, tmp_path):
+    """90 spheres over a plane: > 64 pairs pass the bounding-sphere filter (chunk-by-chunk narrowphase
+    instead of the single compacted round), up to 120 constraint rows (two-per-lane PGS), nv = 540"""
+    xml = tmp_path / "many.xml"
+    xml.write_text(many_spheres_xml())
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m, 128, 512)       # 90 contacts x 4 rows in the end
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 15                  # 30 / 60 / 90 spheres in contact from step 12 on: 120, 240, 360 rows
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[0, :, 1].max() > 64
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    c = b.get("counts")[0]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1] and c[5] == ints[0, -1, 2]
+    assert b.get("warning").sum() == 0
 
 
 def _mocap_controls(m, T):
