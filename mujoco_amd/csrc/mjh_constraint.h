@@ -863,7 +863,6 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
     // chains for the scheduler).  Step i of the sweep broadcasts x_i and subtracts q_i * x_i in the
     // lanes that are ancestors of dof i (bit mask) -- the same products in the same order as the row
     // loop below; the coefficient q_i is the same for every row and is read once per pass.
-    constexpr int PR = 2;
     const auto* ancmask = wv_uniform_ptr(M.dof_ancmask);
     const int lane = wv_lane();
     const int half = lane >> 5, hl = lane & 31;
@@ -875,38 +874,47 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
     const real sq = hl < nv ? (real)sqrtInvD[li] : (real)0;
     int ilast = nv - 1;
     while (ilast > 0 && wv_bcast_i(mynnz, ilast) == 1) ilast--;
-    for (int r0 = 0; r0 < nefc; r0 += 2*PR) {
-      real x[PR];
-      int rr[PR];
-      for (int g = 0; g < PR; g++) {
-        rr[g] = r0 + 2*g + half;
-        x[g] = (hl < nv && rr[g] < nefc) ? (real)J[(size_t)rr[g]*nv + li] : (real)0;
-      }
-      real q = 0;
-      {
-        const int lo = wv_bcast_i(anc_lo, ilast), adr = wv_bcast_i(myadr, ilast);
-        if ((lo >> hl) & 1) q = qLD[adr + mydepth];
-      }
-      for (int i = ilast; i > 0; ) {
-        int inext = i - 1;
-        while (inext > 0 && wv_bcast_i(mynnz, inext) == 1) inext--;
-        real qnext = 0;
-        if (inext > 0) {
-          const int lon = wv_bcast_i(anc_lo, inext), adrn = wv_bcast_i(myadr, inext);
-          if ((lon >> hl) & 1) qnext = qLD[adrn + mydepth];
-        }
-        const int isanc = (wv_bcast_i(anc_lo, i) >> hl) & 1;
+    // PR rows per half and pass: every pass pays the sweep's bookkeeping once, so few passes with many rows
+    // each -- but a slot without a row still costs its updates, hence the choice by nefc
+    auto sweep = [&](auto pr_) {
+      constexpr int PR = decltype(pr_)::value;
+      for (int r0 = 0; r0 < nefc; r0 += 2*PR) {
+        real x[PR];
+        int rr[PR];
         for (int g = 0; g < PR; g++) {
-          const real a = wv_bcast(x[g], i), b = wv_bcast(x[g], 32 + i);
-          const real xi = half ? b : a;
-          if (xi != 0 && isanc) x[g] -= q * xi;
+          rr[g] = r0 + 2*g + half;
+          x[g] = (hl < nv && rr[g] < nefc) ? (real)J[(size_t)rr[g]*nv + li] : (real)0;
         }
-        q = qnext;
-        i = inext;
+        real q = 0;
+        {
+          const int lo = wv_bcast_i(anc_lo, ilast), adr = wv_bcast_i(myadr, ilast);
+          if ((lo >> hl) & 1) q = qLD[adr + mydepth];
+        }
+        for (int i = ilast; i > 0; ) {
+          int inext = i - 1;
+          while (inext > 0 && wv_bcast_i(mynnz, inext) == 1) inext--;
+          real qnext = 0;
+          if (inext > 0) {
+            const int lon = wv_bcast_i(anc_lo, inext), adrn = wv_bcast_i(myadr, inext);
+            if ((lon >> hl) & 1) qnext = qLD[adrn + mydepth];
+          }
+          const int isanc = (wv_bcast_i(anc_lo, i) >> hl) & 1;
+          for (int g = 0; g < PR; g++) {
+            const real a = wv_bcast(x[g], i), b = wv_bcast(x[g], 32 + i);
+            const real xi = half ? b : a;
+            if (xi != 0 && isanc) x[g] -= q * xi;
+          }
+          q = qnext;
+          i = inext;
+        }
+        for (int g = 0; g < PR; g++)
+          if (hl < nv && rr[g] < nefc) Y[(size_t)rr[g]*nv + li] = x[g] * sq;
       }
-      for (int g = 0; g < PR; g++)
-        if (hl < nv && rr[g] < nefc) Y[(size_t)rr[g]*nv + li] = x[g] * sq;
-    }
+    };
+    struct PR2 { enum { value = 2 }; }; struct PR3 { enum { value = 3 }; }; struct PR5 { enum { value = 5 }; };
+    if (nefc <= 4) sweep(PR2{});
+    else if (nefc <= 6 || (nefc > 10 && nefc <= 12)) sweep(PR3{});
+    else sweep(PR5{});
   }
 #endif
   const int stage_rows = (int)((unsigned)P.free_bytes / ((unsigned)nv*sizeof(real)));
