@@ -516,7 +516,8 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
 // ------------------------------------------------------------------------------------------------
 // mj_crb (+ mj_makeM)                            (engine_core_smooth.c:1890-1971)
 // ------------------------------------------------------------------------------------------------
-MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
+MJH_DEV int pairs_euler_factor(MREF M, BREF B, int e);
+MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_, int nopark) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   crptr cinert = MJH_F(B, cinert, e);
@@ -545,9 +546,15 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
-  rptr Mhome = MJH_G(B, M, e);
-  MJH_FOR_LANES(k, s.nC) Mhome[k] = Mq[k];
-  wv_sync();
+  // the global copy of M: what tests inspect and what mj_Euler's fallback, implicitfast and the primal
+  // solvers read once qLD has been factorised in place.  A step of the PGS + Euler path whose qH factor
+  // is produced next to M's never reads it.
+  const int unread = nopark && pairs_euler_factor(M, B, e) && (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS);
+  if (!unread) {
+    rptr Mhome = MJH_G(B, M, e);
+    MJH_FOR_LANES(k, s.nC) Mhome[k] = Mq[k];
+    wv_sync();
+  }
 }
 
 #if !MJH_LANE_MODE

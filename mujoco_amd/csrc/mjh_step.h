@@ -149,7 +149,7 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_RNE, stage_rne(M, B, e));
   }
   if (stages & MJH_STAGE_INERTIA) {
-    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e));
+    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e, (stages & MJH_STAGE_NOPARK) != 0));
     MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
   }
   if (stages & MJH_STAGE_ACTUATION) {
@@ -623,7 +623,7 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
   check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
   check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL);
   for (int attempt = 0; attempt < 2; attempt++) {
-    forward(M, B, e, MJH_STAGE_ALL | MJH_STAGE_SENSOR);
+    forward(M, B, e, MJH_STAGE_ALL | MJH_STAGE_SENSOR | MJH_STAGE_NOPARK);
     int bad = check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC);
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;

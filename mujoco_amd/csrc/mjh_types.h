@@ -617,6 +617,7 @@ enum {
   MJH_STAGE_CHECKPV    = 1<<23,  // mj_checkPos + mj_checkVel first (head of mj_step1)
   MJH_STAGE_CHECKACC   = 1<<24,  // mj_checkAcc after the solve (mj_step2)
   MJH_STAGE_INTEGRATE  = 1<<25,  // integrate with the model's integrator, RK4 -> Euler (tail of mj_step2)
+  MJH_STAGE_NOPARK     = 1<<26,  // step kernels: skip the global copy of M when nothing in the step will read it
   MJH_STAGE_FINISH     = 1<<10,  // qacc = M^-1 qfrc_constraint + qacc_smooth (tail of fwdConstraint)
   MJH_STAGE_ALL        = ((1<<9) - 1) | (1<<10) | (1<<11),
   MJH_STAGE_EULER      = 1<<9,   // mj_Euler + mj_advance (not part of mj_forward; for per-stage runs)
