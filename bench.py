@@ -384,7 +384,7 @@ def main() -> None:
                        "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv),
-                         "kernel": "mjh_k_rollout_" + {"generic": "wv", "lean": "wl", "lean2": "w2", "lean4": "w4"}.get(
+                         "kernel": "mjh_k_rollout_" + {"generic": "wv", "lean": "wl"}.get(
                              batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic", "wv"),
                          "steps_per_launch": C,
                          "launch_ms": launch_ms_timed, "kernel_ms_total": kernel_ms,

@@ -95,9 +95,7 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* h
  *   "generic"  one wavefront per environment, every supported model feature;
  *   "lean"     the same mapping compiled for the lean feature set only (PGS, pyramidal cones, Euler,
  *              plane/sphere/capsule colliders, no sensors/equalities/...): no stack frames or register
- *              pressure from features the model does not use;
- *   "lean2"    lean, TWO environments per wavefront (32 lanes each, 256 VGPRs);
- *   "lean4"    lean, four environments per wavefront (16 lanes each).
+ *              pressure from features the model does not use.
  * mjhip_batch_create picks the leanest variant that covers the model ("auto"; $MJHIP_VARIANT
  * overrides).  All variants produce bit-identical results.  set: 0 on success, <0 if the model needs
  * a feature the variant lacks. */

@@ -279,7 +279,7 @@ class Batch:
         return rc
 
     def kernel_variant(self) -> str:
-        """name of the kernel mapping that steps this batch: generic | lean | lean2 | lean4"""
+        """name of the kernel mapping that steps this batch: generic | lean"""
         return self._lib.c.mjhip_batch_variant(self._h).decode()
 
     def set_mfma(self, on: bool) -> None:

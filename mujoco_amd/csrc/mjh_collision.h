@@ -963,6 +963,9 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
   MJH_CON(B, con_mu, e, 1, c)[0] = 0;
 }
 
+// general convex pairs (GJK / EPA / multicontact): one pair per lane
+#include "mjh_convex.h"
+
 #if !MJH_LANE_MODE
 // The group-cooperative colliders of one chunk of MJH_W pairs, in pair order (bit q of `todo`: the pair
 // lane q holds in `mypair`).  `slot` is the contact slot my own pair's first contact would take; each cooperative pair
@@ -1041,6 +1044,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     Hit ha, hb;          // the (at most two) contacts of my pair's point collider
     int n = 0;
     int coop = 0;        // my pair needs a group-cooperative collider
+    int convex = 0;      // my pair takes the GJK / EPA narrowphase (1) or plane-convex (2): its contacts sit in my workspace records
     int unsupported = 0;
     if (p >= 0) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
@@ -1066,11 +1070,20 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
             if (func == MJH_COL_SPHERE_BOX) { Hit hx; n = hit_sphere_box(hx, margin, c1, size1[0], c2, mat2, size2); ha = hx; }
             else if (func == MJH_COL_SPHERE_CYLINDER) { Hit hx; n = hit_sphere_cylinder(hx, margin, c1, mat1, size1[0], c2, mat2, size2); ha = hx; }
             else if (func == MJH_COL_UNSUPPORTED || MJH_LANE_MODE) unsupported = 1;
+            else if (func == MJH_COL_CONVEX) convex = 1;
+            else if (func == MJH_COL_PLANE_CONVEX) convex = 2;
             else coop = 1;
           }
           break;
       }
     }
+#if !MJH_LANE_MODE
+    if (MJH_HAS(MJH_FT_COLCONVEX) && s.ccd_any) {
+      // every lane runs its own pair's GJK / EPA to completion (mjh_convex.h)
+      if (wv_any(convex == 1)) { const int r = ccd_convex_pair(M, B, e, convex == 1 ? p : -1); if (convex == 1) n = r; }
+      if (wv_any(convex == 2)) { const int r = ccd_plane_convex_pair(M, B, e, convex == 2 ? p : -1); if (convex == 2) n = r; }
+    }
+#endif
     if (s.nbp) {
       // would the reference's broad / midphase have let the pair reach its narrowphase at all?
       // (asked only by lanes about to emit a contact of a pair that is subject to one of the culls)
@@ -1082,7 +1095,14 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
         // float (2^-24 relative, two end points within body reach of the geom centres) can eat, the
         // pair certainly reached the reference's narrowphase: no need to ask.
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-        const real deepest = n > 1 ? r_min(ha.dist, hb.dist) : ha.dist;
+        real deepest = n > 1 ? r_min(ha.dist, hb.dist) : ha.dist;
+#if !MJH_LANE_MODE
+        if (MJH_HAS(MJH_FT_COLCONVEX) && convex) {
+          const real* rec = ccd_out_records(M, B, e);
+          deepest = rec[0];
+          for (int k = 1; k < n; k++) deepest = r_min(deepest, rec[7*k]);
+        }
+#endif
         const real slack = M.pair_margin[p] - deepest;
         const real reach = fabs(gx[3*g1]) + fabs(gx[3*g1 + 1]) + fabs(gx[3*g1 + 2]) + fabs(gx[3*g2]) + fabs(gx[3*g2 + 1]) +
                            fabs(gx[3*g2 + 2]) + M.body_bpext[M.geom_bodyid[g1]] + M.body_bpext[M.geom_bodyid[g2]];
@@ -1113,8 +1133,20 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
 #endif
     if (n > 0) {
       const int c = base + before;
-      if (c >= s.nconmax) overflow = 1; else store_contact(M, B, e, c, p, ha);
-      if (n > 1) { if (c + 1 >= s.nconmax) overflow = 1; else store_contact(M, B, e, c + 1, p, hb); }
+#if !MJH_LANE_MODE
+      if (MJH_HAS(MJH_FT_COLCONVEX) && convex) {
+        const real* rec = ccd_out_records(M, B, e);
+        for (int k = 0; k < n; k++) {
+          if (c + k >= s.nconmax) { overflow = 1; break; }
+          Hit hx{rec[7*k], ld3(rec + 7*k + 1), ld3(rec + 7*k + 4), V3{0, 0, 0}};
+          store_contact(M, B, e, c + k, p, hx);
+        }
+      } else
+#endif
+      {
+        if (c >= s.nconmax) overflow = 1; else store_contact(M, B, e, c, p, ha);
+        if (n > 1) { if (c + 1 >= s.nconmax) overflow = 1; else store_contact(M, B, e, c + 1, p, hb); }
+      }
     }
     base += total;
   };

@@ -20,8 +20,6 @@
 
 MJH_DEFINE_WAVE_KERNELS(wv, 1, 4, 0)
 MJH_DECLARE_WAVE_LAUNCHERS(wl)
-MJH_DECLARE_WAVE_LAUNCHERS(w2)
-MJH_DECLARE_WAVE_LAUNCHERS(w4)
 extern "C" bool mjh_launch_forward_soa(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
 extern "C" bool mjh_launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
 extern "C" bool mjh_launch_integrate(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
@@ -111,16 +109,12 @@ struct Backend {
     if (soa) return mjh_launch_forward_soa(M, B, nenv, stages, lds, stream);
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_forward_wl(M, B, nenv, stages, lds, stream);
-      case MJH_VAR_LEAN2: return mjh_launch_forward_w2(M, B, nenv, stages, lds, stream);
-      case MJH_VAR_LEAN4: return mjh_launch_forward_w4(M, B, nenv, stages, lds, stream);
       default: return mjh_launch_forward_wv(M, B, nenv, stages, lds, stream);
     }
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void* stream) {
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_rollout_wl(M, B, nenv, &A, lds, stream);
-      case MJH_VAR_LEAN2: return mjh_launch_rollout_w2(M, B, nenv, &A, lds, stream);
-      case MJH_VAR_LEAN4: return mjh_launch_rollout_w4(M, B, nenv, &A, lds, stream);
       default: return mjh_launch_rollout_wv(M, B, nenv, &A, lds, stream);
     }
   }

@@ -105,8 +105,10 @@ static real actuator_contrib(const mjModel* m, int is_tendon, int id, int want_a
   return out;
 }
 
-// pair collider available on the GPU path; -1 if the reference collides the types but we do not
-static int pair_func(int t1, int t2, int* maxcon) {
+// narrowphase routine of a type-ordered geom pair (mjCOLLISIONFUNC, engine_collision_driver.c:45-56) and the
+// contact bound mj_maxContact gives it (:66-146); -1: the reference collides the types but mjhip does not
+// (height fields, signed distance fields)
+static int pair_func(int t1, int t2, bool has_margin, bool multiccd, int* maxcon) {
   if (t1 == mjGEOM_PLANE && t2 == mjGEOM_SPHERE) { *maxcon = 1; return MJH_COL_PLANE_SPHERE; }
   if (t1 == mjGEOM_PLANE && t2 == mjGEOM_CAPSULE) { *maxcon = 2; return MJH_COL_PLANE_CAPSULE; }
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_SPHERE) { *maxcon = 1; return MJH_COL_SPHERE_SPHERE; }
@@ -118,11 +120,18 @@ static int pair_func(int t1, int t2, int* maxcon) {
   if (t1 == mjGEOM_SPHERE && t2 == mjGEOM_CYLINDER) { *maxcon = 1; return MJH_COL_SPHERE_CYLINDER; }
   if (t1 == mjGEOM_BOX && t2 == mjGEOM_BOX) { *maxcon = 8; return MJH_COL_BOX_BOX; }
   if (t1 == mjGEOM_CAPSULE && t2 == mjGEOM_BOX) { *maxcon = 2; return MJH_COL_CAPSULE_BOX; }
-  // convex primitives the reference sends to its GJK/EPA or box routines: the pair stays in the list
-  // (so ordering and filtering match) but reaching its narrowphase raises mjhip's UNSUPPORTED warning
-  auto prim = [](int t) { return t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER ||
-                                 t == mjGEOM_ELLIPSOID || t == mjGEOM_BOX; };
-  if ((t1 == mjGEOM_PLANE || prim(t1)) && prim(t2)) { *maxcon = 0; return MJH_COL_UNSUPPORTED; }
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_ELLIPSOID) { *maxcon = 1; return MJH_COL_PLANE_CONVEX; }
+  if (t1 == mjGEOM_PLANE && t2 == mjGEOM_MESH) { *maxcon = 3; return MJH_COL_PLANE_CONVEX; }
+  // everything else between convex primitives and meshes goes to mjc_Convex (GJK / EPA)
+  auto convex = [](int t) { return t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER ||
+                                   t == mjGEOM_ELLIPSOID || t == mjGEOM_BOX || t == mjGEOM_MESH; };
+  if (convex(t1) && convex(t2)) {
+    if (t1 == mjGEOM_SPHERE || t1 == mjGEOM_ELLIPSOID || t2 == mjGEOM_SPHERE || t2 == mjGEOM_ELLIPSOID) *maxcon = 1;
+    else if (!multiccd) *maxcon = 1;
+    else if (t1 == mjGEOM_CAPSULE || t2 == mjGEOM_CAPSULE || t1 == mjGEOM_CYLINDER || t2 == mjGEOM_CYLINDER) *maxcon = 5;
+    else *maxcon = has_margin ? 5 : 4;
+    return MJH_COL_CONVEX;
+  }
   *maxcon = 0;
   return -1;
 }
@@ -134,7 +143,7 @@ static bool ref_collides(int t1, int t2) {
   return true;
 }
 
-struct BuildCaps { int nconmax = 0; int nefcmax = 0; };
+struct BuildCaps { int nconmax = 0; int nefcmax = 0; long long efc_bytes = 0; };
 
 #define MJH_REJECT(cond, msg) do { if (cond) { *err = std::string("mjhip: unsupported model feature: ") + (msg); return false; } } while (0)
 
@@ -520,8 +529,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       for (const GP& gp : gps) {
         int g1 = gp.g1, g2 = gp.g2;
         int maxcon = 0;
-        int func = pair_func(m->geom_type[g1], m->geom_type[g2], &maxcon);
-        MJH_REJECT(func < 0, "collision with mesh/hfield/sdf geoms");
+        int func = -2;
         // mj_contactParam (engine_collision_driver.c:1740-1835)
         int condim;
         real solref[2], solimp[5], fri[3];
@@ -579,6 +587,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         }
         for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
         MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
+        func = pair_func(m->geom_type[g1], m->geom_type[g2], margin + gap > 0, !(m->opt.disableflags & mjDSBL_MULTICCD), &maxcon);
+        MJH_REJECT(func < 0, "collision with height-field / signed-distance-field geoms");
+        if (func == MJH_COL_CONVEX || func == MJH_COL_PLANE_CONVEX) {
+          MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+          for (int g : {g1, g2})
+            if (m->geom_type[g] == mjGEOM_MESH)
+              MJH_REJECT(m->geom_dataid[g] < 0 || m->mesh_vertnum[m->geom_dataid[g]] < 1, "mesh geom without vertices");
+          s.ccd_any = 1;
+        }
         H->pair_geom1.push_back(g1);
         H->pair_geom2.push_back(g2);
         H->pair_dim.push_back(condim);
@@ -770,6 +787,53 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     s.bp_any_mid = any_mid ? 1 : 0;
   }
 
+  // ---------------- convex meshes + GJK / EPA workspace (mjh_convex.h) -----------------------------------
+  {
+    const bool any = s.ccd_any != 0;
+    s.nmesh = any ? (int)m->nmesh : 0;
+    s.nmeshvert = any ? (int)m->nmeshvert : 0;
+    s.nmeshgraph = any ? (int)m->nmeshgraph : 0;
+    s.nmeshpoly = any ? (int)m->nmeshpoly : 0;
+    s.nmeshpolyvert = any ? (int)m->nmeshpolyvert : 0;
+    s.nmeshpolymap = any ? (int)m->nmeshpolymap : 0;
+    copy_arr(H->geom_dataid, m->geom_dataid, m->ngeom);
+    copy_arr(H->mesh_vertadr, m->mesh_vertadr, s.nmesh);
+    copy_arr(H->mesh_vertnum, m->mesh_vertnum, s.nmesh);
+    copy_arr(H->mesh_graphadr, m->mesh_graphadr, s.nmesh);
+    copy_arr(H->mesh_polynum, m->mesh_polynum, s.nmesh);
+    copy_arr(H->mesh_polyadr, m->mesh_polyadr, s.nmesh);
+    copy_arr(H->mesh_graph, m->mesh_graph, s.nmeshgraph);
+    copy_arr(H->mesh_extrema, m->mesh_extrema, 27*(size_t)s.nmesh);
+    copy_arr(H->mesh_polyvertadr, m->mesh_polyvertadr, s.nmeshpoly);
+    copy_arr(H->mesh_polyvertnum, m->mesh_polyvertnum, s.nmeshpoly);
+    copy_arr(H->mesh_polyvert, m->mesh_polyvert, s.nmeshpolyvert);
+    copy_arr(H->mesh_polymapadr, m->mesh_polymapadr, s.nmeshvert);
+    copy_arr(H->mesh_polymapnum, m->mesh_polymapnum, s.nmeshvert);
+    copy_arr(H->mesh_polymap, m->mesh_polymap, s.nmeshpolymap);
+    copy_arr(H->mesh_vert, m->mesh_vert, 3*(size_t)s.nmeshvert);          // float -> double: exact
+    copy_arr(H->mesh_polynormal, m->mesh_polynormal, 3*(size_t)s.nmeshpoly);
+    o.ccd_tolerance = m->opt.ccd_tolerance;
+    o.ccd_sin = std::sin(0.5*1e-3);
+    o.ccd_cos = std::cos(0.5*1e-3);
+    if (any) {
+      MJH_REJECT(m->opt.ccd_iterations < 1 || m->opt.ccd_iterations > 200, "opt.ccd_iterations outside 1..200 (bounds the per-lane EPA workspace)");
+      s.ccd_N = m->opt.ccd_iterations;
+      s.ccd_P = std::max(4, (int)m->npolygonmax);
+      s.ccd_D = std::max(3, (int)m->nmeshdegmax);
+      // mirror of ccd_carve (mjh_convex.h): fixed slots, then the polytope with the clipping buffers overlaid
+      const int N = s.ccd_N, P = s.ccd_P, D = s.ccd_D;
+      const int fixed_r = 2*16 + 3*4 + 3*4 + 4 + 4*9 + 5*9 + 7*5;
+      const int poly_r = (5 + N)*9 + 6*N*4;
+      const int multi_r = 9*D + 6*P + 16*P;
+      s.ccd_nreal = fixed_r + std::max(poly_r, multi_r);
+      const int fixed_i = 2*6 + 4*2 + 5*2 + 6*N + 6*N + 2*(6*N + 1);
+      const int poly_i = (5 + N)*2 + 6*N*5 + 6*N;
+      const int multi_i = 2*D;
+      s.ccd_nint = (fixed_i + std::max(poly_i, multi_i) + 1) & ~1;
+      s.ccd_lane_bytes = s.ccd_nreal*(int)sizeof(real) + s.ccd_nint*(int)sizeof(int);
+    }
+  }
+
   // ---------------- capacities ---------------------------------------------------------------------------
   int nlimit = 0;
   for (int i = 0; i < m->njnt; i++) if (m->jnt_limited[i]) nlimit += (m->jnt_type[i] == mjJNT_BALL) ? 1 : 2;
@@ -777,7 +841,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int nfric = 0;
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_frictionloss[i] > 0) nfric++;
-  s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 128));
+  // contact capacity: the bound mj_maxContact gives the static pair list (the reference's arena grows
+  // on demand; a fixed 512 stands in for "as many as a scene of this size can touch at once")
+  s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 512));
   s.nconlds = std::min(s.nconmax, 8);
   // tree ids (constraint islands, engine_island.c)
   H->body_treeid.assign(m->body_treeid, m->body_treeid + m->nbody);
@@ -920,7 +986,18 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int k = 0; k < 3; k++) o.magnetic[k] = m->opt.magnetic[k];
   s.nconH = (m->opt.cone != mjCONE_PYRAMIDAL && m->opt.solver != mjSOL_PGS) ? s.nconmax : 0;
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
-  s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : std::max(1, std::min(nefc_bound, 256));
+  // row capacity: the model's bound, cut back (not below 256 rows) until the per-environment constraint
+  // arrays -- efc_J, efc_Y, the dense efc_AR under the dual solver, ~24 row vectors -- fit the budget
+  // ($MJHIP_EFC_BYTES, default 2 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
+  {
+    const bool dual = m->opt.solver == mjSOL_PGS;
+    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : 2.0*1024*1024;
+    auto bytes = [&](int n) { return 8.0*n*(2.0*m->nv + (dual ? n : 0) + 24); };
+    int n = std::max(1, std::min(nefc_bound, 4096));
+    while (n > 256 && bytes(n) > budget) n = std::max(256, n*7/8);
+    s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : n;
+    s.nefcAR = dual ? s.nefcmax : 0;
+  }
   // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with
   // state = 0, inc = 1 and one warm-up draw per solver call; every iteration Fisher-Yates-shuffles
   // the order array left by the previous iteration with j = next % (i+1), i = n-1 .. 1

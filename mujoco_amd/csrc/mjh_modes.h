@@ -12,12 +12,6 @@
 //   wl : wv restricted to the LEAN feature set (PGS, pyramidal cones, Euler, primitive colliders,
 //        no sensors / equalities / ...): the kernel a model like humanoid.xml actually needs,
 //        without the stack frames and register pressure of everything else.
-//   w2 : LEAN, "two environments per wavefront": MJH_W = 32, lanes 0-31 step environment 2b,
-//        lanes 32-63 environment 2b+1 (b = workgroup).  Most phases of a small model occupy fewer
-//        than 32 lanes, so one instruction now serves two environments; with half as many
-//        wavefronts for the same batch each may use 256 VGPRs (2 waves/SIMD).  The two halves
-//        diverge only where their data does (contact / constraint counts, solver iterations).
-//   w4 : LEAN, four environments per wavefront (MJH_W = 16, one DPP row each).
 //
 // A translation unit selects what it compiles with MJH_BUILD_<NS> (none given: everything, which
 // is what the host emulation does); libmjhip.so compiles the namespaces in separate .hip files so
@@ -28,22 +22,21 @@
 #include "mjh_math.h"
 #include "mjh_types.h"
 
-#if !defined(MJH_BUILD_WV) && !defined(MJH_BUILD_WS) && !defined(MJH_BUILD_LN) && !defined(MJH_BUILD_WL) && \
-    !defined(MJH_BUILD_W2) && !defined(MJH_BUILD_W4)
+#if !defined(MJH_BUILD_WV) && !defined(MJH_BUILD_WS) && !defined(MJH_BUILD_LN) && !defined(MJH_BUILD_WL)
 #define MJH_BUILD_WV 1
 #define MJH_BUILD_WS 1
 #define MJH_BUILD_LN 1
 #define MJH_BUILD_WL 1
-#define MJH_BUILD_W2 1
-#define MJH_BUILD_W4 1
 #endif
 
 // kernel variants (mjhipBatch_::variant, RolloutArgs consumers): which namespace steps a batch
-enum { MJH_VAR_GENERIC = 0, MJH_VAR_LEAN = 1, MJH_VAR_LEAN2 = 2, MJH_VAR_LEAN4 = 3, MJH_NVARIANT = 4 };
-static inline int mjh_variant_nsub(int v) { return v == MJH_VAR_LEAN2 ? 2 : (v == MJH_VAR_LEAN4 ? 4 : 1); }
+// (round 2 also carried "lean2" / "lean4": two / four environments per wavefront.  Measured 2-3x slower
+// at every batch size of interest (profiles/r02_variants) and deleted in round 3.)
+enum { MJH_VAR_GENERIC = 0, MJH_VAR_LEAN = 1, MJH_NVARIANT = 2 };
+static inline int mjh_variant_nsub(int) { return 1; }
 static inline int mjh_variant_features(int v) { return v == MJH_VAR_GENERIC ? MJH_FT_ALL : MJH_FT_LEAN; }
 static inline const char* mjh_variant_name(int v) {
-  return v == MJH_VAR_GENERIC ? "generic" : v == MJH_VAR_LEAN ? "lean" : v == MJH_VAR_LEAN2 ? "lean2" : "lean4";
+  return v == MJH_VAR_GENERIC ? "generic" : "lean";
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -86,51 +79,8 @@ namespace ws {
 #undef MJH_FOR_LANES
 #undef MJH_ENTER
 
-// ------------------------------------------------------------------------------------------------
-// sub-wave modes (several environments per wavefront), environment-major batches only
-// ------------------------------------------------------------------------------------------------
-#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
-// (e differs between the groups of a wavefront: it stays in a VGPR; the descriptors are uniform)
-#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = e_; \
-                              if (B.soa != 0) __builtin_unreachable()
-#define MJH_FEATURES MJH_FT_LEAN
-// the SPMD vocabulary restricted to the caller's group of MJH_W lanes: these hide the wave-wide
-// primitives of mjh_spmd.h (which stay reachable as ::wv_* for values every group shares)
-#define MJH_SUBWAVE_VOCABULARY                                                            \
-  MJH_DEV int wv_lane() { return sw_lane<MJH_W>(); }                                      \
-  MJH_DEV int wv_sub() { return sw_sub<MJH_W>(); }                                        \
-  MJH_DEV void wv_sync() { ::wv_sync(); }                                                 \
-  MJH_DEV double wv_bcast(double v, int src) { return sw_bcast<MJH_W>(v, src); }          \
-  MJH_DEV int wv_bcast_i(int v, int src) { return sw_bcast_i<MJH_W>(v, src); }            \
-  MJH_DEV uint64_t wv_ballot(int pred) { return sw_ballot<MJH_W>(pred); }                 \
-  MJH_DEV int wv_sum_i(int v) { return sw_sum_i<MJH_W>(v); }                              \
-  MJH_DEV int wv_exscan_i(int v) { return sw_exscan_i<MJH_W>(v); }                        \
-  MJH_DEV int wv_any(int pred) { return sw_ballot<MJH_W>(pred) != 0; }                    \
-  MJH_DEV double wv_shfl(double v, int src) { return sw_bcast<MJH_W>(v, src); }           \
-  MJH_DEV int wv_shfl_i(int v, int src) { return sw_bcast_i<MJH_W>(v, src); }             \
-  MJH_DEV double wv_shfl_xor(double v, int mask) { return sw_shfl_xor<MJH_W>(v, mask); }  \
-  MJH_DEV int wv_uniform_i(int v) { return v; }
-#if MJH_BUILD_W2
-#define MJH_W 32
-namespace w2 {
-MJH_SUBWAVE_VOCABULARY
-#include "mjh_stages.inc"
-}
-#undef MJH_W
-#endif
-#if MJH_BUILD_W4
-#define MJH_W 16
-namespace w4 {
-MJH_SUBWAVE_VOCABULARY
-#include "mjh_stages.inc"
-}
-#undef MJH_W
-#endif
-#undef MJH_FEATURES
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
-#undef MJH_FOR_LANES
-#undef MJH_ENTER
 
 // ------------------------------------------------------------------------------------------------
 // lane mode

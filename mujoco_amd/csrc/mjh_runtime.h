@@ -86,6 +86,7 @@ struct mjhipBatch_ {
   bool balance = true;             // order the next rollout launch by the work estimate of the last
   void* arena = nullptr;
   size_t arena_bytes = 0;
+  void* ccd_ws = nullptr;          // GJK / EPA workspace (models with convex pairs)
   std::map<std::string, FieldInfo> fields;
   int nenv = 0;
 };
@@ -253,6 +254,7 @@ MJHIP_API mjhipModel* mjhip_model_create(const struct mjModel_* m, int nconmax, 
   if (nconmax <= 0) if (const char* ev = getenv("MJHIP_NCONMAX")) nconmax = atoi(ev);
   if (nefcmax <= 0) if (const char* ev = getenv("MJHIP_NEFCMAX")) nefcmax = atoi(ev);
   caps.nconmax = nconmax; caps.nefcmax = nefcmax;
+  if (const char* ev = getenv("MJHIP_EFC_BYTES")) caps.efc_bytes = atoll(ev);
   if (!mjhb::build((const mjModel*)m, caps, &M->H, &err) || !mjhb::check_sizes(M->H, &err)) {
     set_err(err);
     delete M;
@@ -300,7 +302,7 @@ MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
   const DSizes& s = M->H.s;
 #define SZ(n) if (!strcmp(name, #n)) return s.n;
   SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
-  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment)
+  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment) SZ(ccd_any) SZ(ccd_lane_bytes) SZ(nmesh)
 #undef SZ
   set_err(std::string("mjhip_model_size: unknown size ") + name);
   return -1;
@@ -386,6 +388,18 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   Bt->D.l_##name = -1; Bt->fields[#name] = FieldInfo{(void*)Bt->D.name, ((cnt) > 0 ? (int)(cnt) : 0), 1}; k++;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
+  // GJK / EPA workspace (mjh_convex.h): one private block per lane of every environment's wavefront;
+  // raw memory, never read before it is written
+  if (s.ccd_any) {
+    const size_t bytes = (size_t)nalloc*MJH_WAVE*(size_t)s.ccd_lane_bytes;
+    Bt->ccd_ws = Backend::alloc(bytes);
+    if (!Bt->ccd_ws) {
+      set_err("mjhip: device allocation failed (convex-collision workspace of " + std::to_string(bytes) + " bytes)");
+      mjhip_batch_destroy(Bt);
+      return nullptr;
+    }
+    Bt->D.ccd_ws = Bt->ccd_ws;
+  }
   Bt->D_dev = (DBatch*)Backend::alloc(sizeof(DBatch));
   Bt->L_dev = (DBatch*)Backend::alloc(sizeof(DBatch));
   if (!Bt->D_dev || !Bt->L_dev || !Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr)) {
@@ -426,6 +440,7 @@ MJHIP_API void mjhip_batch_destroy(mjhipBatch* Bt) {
   Backend::set_device(Bt->device, &err_);
   if (Bt->stage) stage_release(Bt->stage);
   if (Bt->arena) Backend::free(Bt->arena);
+  if (Bt->ccd_ws) Backend::free(Bt->ccd_ws);
   if (Bt->D_dev) Backend::free(Bt->D_dev);
   if (Bt->L_dev) Backend::free(Bt->L_dev);
   delete Bt;
@@ -449,7 +464,7 @@ static int default_variant(const mjhipModel_* M, int soa) {
   // one environment per wavefront: measured fastest at the batch sizes of interest (4096 envs on
   // 1024 SIMDs: profiles/r02_variants -- with every environment resident the step is bound by the
   // dependent chain of one environment, and the two / four environments of a shared wavefront run
-  // their solver loops to the longer of their iteration counts); lean2 / lean4 stay selectable
+  // their solver loops to the longer of their iteration counts); those variants were deleted in round 3
   if (variant_ok(M, soa, MJH_VAR_LEAN, nullptr)) return MJH_VAR_LEAN;
   return MJH_VAR_GENERIC;
 }
@@ -465,8 +480,8 @@ MJHIP_API int mjhip_batch_set_variant(mjhipBatch* Bt, const char* name) {
     return -2;
   }
   Bt->variant = v;
-  // the LDS budget of a workgroup is shared by the environments of a wavefront: re-plan
-  if (Bt->L_dev) return mjhip_batch_plan_lds(Bt, Bt->L.lds_bytes ? Bt->L.lds_bytes : Bt->lds_request) < 0 ? -3 : 0;
+  // re-plan with the budget originally asked for (plan_lds clamps it per variant)
+  if (Bt->L_dev) return mjhip_batch_plan_lds(Bt, Bt->lds_request) < 0 ? -3 : 0;
   return 0;
 }
 // AR = Y Y' on the matrix cores (tolerance parity); default off, $MJHIP_MFMA=1 turns it on at creation

@@ -171,57 +171,16 @@ MJH_DEV double wv_rows_sum(double v) {
 MJH_DEV long long wv_clock() { return 0; }
 MJH_DEV int wv_sub() { return 0; }
 
-// ---- sub-wave primitives (tests only): W consecutive lanes form one group; a group never reads
-// another group's scratch slots, so groups may sit at different program points
-template <int W> MJH_DEV int sw_lane() { return mjhsim::lane() & (W - 1); }
-template <int W> MJH_DEV int sw_sub() { return mjhsim::lane() / W; }
-template <int W> MJH_DEV int sw_base() { return mjhsim::lane() & ~(W - 1); }
-template <int W> MJH_DEV double sw_bcast(double v, int src) {
+
+// value of lane (lane ^ 16): the neighbouring 16-lane row
+MJH_DEV double sw_row_swap(double v) {
   mjhsim::WaveSim* w = mjhsim::g_wave;
   w->dscratch[w->cur] = v;
   mjhsim::yield();
-  double r = w->dscratch[sw_base<W>() + (src & (W - 1))];
+  double r = w->dscratch[w->cur ^ 16];
   mjhsim::yield();
   return r;
 }
-template <int W> MJH_DEV int sw_bcast_i(int v, int src) {
-  mjhsim::WaveSim* w = mjhsim::g_wave;
-  w->iscratch[w->cur] = v;
-  mjhsim::yield();
-  int r = (int)w->iscratch[sw_base<W>() + (src & (W - 1))];
-  mjhsim::yield();
-  return r;
-}
-template <int W> MJH_DEV uint64_t sw_ballot(int pred) {
-  mjhsim::WaveSim* w = mjhsim::g_wave;
-  w->iscratch[w->cur] = pred ? 1 : 0;
-  mjhsim::yield();
-  uint64_t m = 0;
-  for (int l = 0; l < W; l++) if (w->iscratch[sw_base<W>() + l]) m |= (1ull << l);
-  mjhsim::yield();
-  return m;
-}
-template <int W> MJH_DEV int sw_sum_i(int v) {
-  mjhsim::WaveSim* w = mjhsim::g_wave;
-  w->iscratch[w->cur] = v;
-  mjhsim::yield();
-  long long s = 0;
-  for (int l = 0; l < W; l++) s += w->iscratch[sw_base<W>() + l];
-  mjhsim::yield();
-  return (int)s;
-}
-template <int W> MJH_DEV int sw_exscan_i(int v) {
-  mjhsim::WaveSim* w = mjhsim::g_wave;
-  w->iscratch[w->cur] = v;
-  mjhsim::yield();
-  long long s = 0;
-  for (int l = sw_base<W>(); l < w->cur; l++) s += w->iscratch[l];
-  mjhsim::yield();
-  return (int)s;
-}
-template <int W> MJH_DEV double sw_shfl_xor(double v, int mask) { return sw_bcast<W>(v, sw_lane<W>() ^ mask); }
-// value of lane (lane ^ 16): the other 16-lane row of a 32-lane group
-MJH_DEV double sw_row_swap(double v) { return sw_bcast<32>(v, sw_lane<32>() ^ 16); }
 
 #else
 // ------------------------------------------------------------------------------------------------
@@ -346,34 +305,7 @@ MJH_DEV double wv_rows_sum(double v) {
 MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 MJH_DEV int wv_sub() { return 0; }
 
-// ---- sub-wave primitives: W consecutive lanes (W = 32 or 16) step one environment, a wavefront
-// steps 64/W of them.  Everything stays inside the caller's group: ds_bpermute / DPP reach any lane of
-// the wavefront, the index arithmetic keeps them in the group.  Values that are the same in every
-// group (model constants, loop counters over model sizes) can still travel through v_readlane:
-// use the wave-wide primitives for those.
-template <int W> MJH_DEV int sw_lane() { return (int)threadIdx.x & (W - 1); }
-template <int W> MJH_DEV int sw_sub() { return (int)threadIdx.x / W; }
-template <int W> MJH_DEV double sw_bcast(double v, int src) { return __shfl(v, src, W); }
-template <int W> MJH_DEV int sw_bcast_i(int v, int src) { return __shfl(v, src, W); }
-template <int W> MJH_DEV uint64_t sw_ballot(int pred) {
-  const uint64_t b = __ballot(pred);
-  return (b >> ((int)threadIdx.x & ~(W - 1))) & ((1ull << W) - 1);
-}
-template <int W> MJH_DEV int sw_sum_i(int v) {
-  for (int m = W/2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
-template <int W> MJH_DEV int sw_exscan_i(int v) {
-  int x = v;
-  const int lane = (int)threadIdx.x & (W - 1);
-  for (int d = 1; d < W; d <<= 1) {
-    int y = __shfl_up(x, d, W);
-    if (lane >= d) x += y;
-  }
-  return x - v;
-}
-template <int W> MJH_DEV double sw_shfl_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
-// value of lane (lane ^ 16): the other 16-lane row of a 32-lane group.  v_permlane16_swap exchanges
+// value of lane (lane ^ 16): the neighbouring 16-lane row.  v_permlane16_swap exchanges
 // the odd rows of its first operand with the even rows of its second; with both operands = v each
 // lane ends up with {own value, partner row's value} in the two results -- the one whose bits differ
 // from the own value is the partner's (if neither differs they are equal anyway).

@@ -122,7 +122,22 @@
   X(dof_ancmask, 2 * s.nv)                     \
   X(ld_prog_adr, s.nv + 1)                     \
   X(ld_prog, s.nldprog)                        \
-  X(pgs_order, s.npgsorder)
+  X(pgs_order, s.npgsorder)               \
+  /* convex meshes (mjh_convex.h): hull graph, polygons (mjModel mesh_*, include/mujoco/mjmodel.h:1040-1075) */ \
+  X(geom_dataid, s.ngeom)                      \
+  X(mesh_vertadr, s.nmesh)                     \
+  X(mesh_vertnum, s.nmesh)                     \
+  X(mesh_graphadr, s.nmesh)                    \
+  X(mesh_polynum, s.nmesh)                     \
+  X(mesh_polyadr, s.nmesh)                     \
+  X(mesh_graph, s.nmeshgraph)                  \
+  X(mesh_extrema, 27 * s.nmesh)                \
+  X(mesh_polyvertadr, s.nmeshpoly)             \
+  X(mesh_polyvertnum, s.nmeshpoly)             \
+  X(mesh_polyvert, s.nmeshpolyvert)            \
+  X(mesh_polymapadr, s.nmeshvert)              \
+  X(mesh_polymapnum, s.nmeshvert)              \
+  X(mesh_polymap, s.nmeshpolymap)
 
 // ---- model: real arrays -----------------------------------------------------------------------
 #define MJH_MODEL_REAL_FIELDS(X)               \
@@ -200,7 +215,10 @@
   X(eq_solref, 2 * s.neq)                      \
   X(eq_solimp, 5 * s.neq)                      \
   X(eq_data, 11 * s.neq)                       \
-  X(tendon_length0, s.ntendon)
+  X(tendon_length0, s.ntendon)                 \
+  /* mesh vertices (float in mjModel; widened exactly) and polygon normals */ \
+  X(mesh_vert, 3 * s.nmeshvert)                \
+  X(mesh_polynormal, 3 * s.nmeshpoly)
 
 // ---- compile-time feature set of a kernel variant -------------------------------------------------
 // The stage sources are compiled several times (mjh_modes.h); each compilation defines MJH_FEATURES,
@@ -224,7 +242,6 @@ enum {
   MJH_FT_MOCAP         = 1<<12,
   MJH_FT_ISLANDS       = 1<<13,  // more than one kinematic tree (union-find; per-island solves)
   MJH_FT_GAINBIAS      = 1<<14,  // affine gains / biases, force / act limits, joint actuator-force limits
-  MJH_FT_BIGMODEL      = 1<<15,  // nv > 32 or L'DL outside the register-resident fast path
   MJH_FT_ALL           = 0x7fffffff,
   MJH_FT_LEAN          = 0,
 };
@@ -247,6 +264,7 @@ struct DSizes {
   int nconlds;     // contact slots kept in LDS by the residency plan
   int nconH;       // contacts with a cone-Hessian slot (elliptic cones + primal solver), else 0
   int nefcmax;     // per-env constraint-row capacity
+  int nefcAR;      // rows of the dense efc_AR home: nefcmax under the dual solver (PGS), 0 under the primal ones (never built)
   int nstate;      // mj_stateSize(FULLPHYSICS)
   int nsensor, nsensordata;
   int nmocap;
@@ -259,6 +277,12 @@ struct DSizes {
   int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
   int pgs_iters;   // iterations covered by that table (min(opt.iterations, 128))
   int pgs_nmax;    // largest nefc covered by that table (64, or 128 when the constraint capacity allows more than 64 rows)
+  // convex collision (mjh_convex.h): mesh table sizes and the per-lane GJK / EPA workspace
+  int nmesh, nmeshvert, nmeshgraph, nmeshpoly, nmeshpolyvert, nmeshpolymap;
+  int ccd_any;         // some static pair uses the GJK / EPA narrowphase
+  int ccd_N;           // opt.ccd_iterations
+  int ccd_P, ccd_D;    // max(npolygonmax, 4), max(nmeshdegmax, 3)
+  int ccd_nreal, ccd_nint, ccd_lane_bytes;   // workspace per lane: reals, ints, bytes (0 without convex pairs)
 };
 
 struct DOptions {
@@ -274,6 +298,8 @@ struct DOptions {
   int has_surfacevel; // some geom has a surface velocity (conveyor belts)
   int has_fluid;      // opt.density / opt.viscosity set: inertia-box fluid forces
   real density, viscosity, wind[3];
+  real ccd_tolerance;     // opt.ccd_tolerance
+  real ccd_sin, ccd_cos;  // sin / cos of 5e-4 (half the multiccd perturbation angle), evaluated by the host's libm
 };
 
 // (device build: the table pointers are constant-address-space pointers, so a wave-uniform index
@@ -384,7 +410,7 @@ enum {
   X(con_mu, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                  \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
-  X(efc_AR, s.nefcmax * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                       \
+  X(efc_AR, s.nefcAR * s.nefcAR, 0, MJH_T_GLB, MJH_T_GLB)                          \
   X(efc_pos, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(efc_margin, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                               \
   X(efc_frictionloss, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                         \
@@ -473,6 +499,7 @@ struct DBatch {
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
   int mfma;          // 1: AR = Y Y' on the matrix cores (v_mfma_f64_16x16x4_f64): tolerance parity, not bit parity
   int xfrc_on;       // 1: xfrc_applied may be non-zero (mj_xfrcAccumulate runs; xipos stays readable at MJH_T_ACCEL)
+  void* ccd_ws;      // GJK / EPA workspace: [nenv][64 lanes][ccd_lane_bytes], null without convex pairs (mjh_convex.h)
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
@@ -597,7 +624,9 @@ enum {
   MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
   MJH_COL_PLANE_BOX = 7, MJH_COL_SPHERE_BOX = 8, MJH_COL_SPHERE_CYLINDER = 9, MJH_COL_BOX_BOX = 10, MJH_COL_CAPSULE_BOX = 11,
-  MJH_COL_UNSUPPORTED = 6,   // convex pair without a GPU collider: raises MJH_WARN_UNSUPPORTED if it survives the filter
+  MJH_COL_UNSUPPORTED = 6,   // pair without a GPU collider (hfield, sdf): raises MJH_WARN_UNSUPPORTED if it survives the filter
+  MJH_COL_CONVEX = 12,       // mjc_Convex: GJK / EPA / multicontact, one pair per lane (mjh_convex.h)
+  MJH_COL_PLANE_CONVEX = 13, // mjc_PlaneConvex: plane against ellipsoid / mesh
 };
 
 // stage bits for partial forward evaluation (tests and per-stage profiling)

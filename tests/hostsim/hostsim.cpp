@@ -124,16 +124,12 @@ struct Backend {
   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void*) {
     if (soa) run_waves(nenv, 1, lds, [&](int e) { ws::forward_or_euler(*M, *B, e, stages); });
     else if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int e) { wl::forward_or_euler(*M, *B, e, stages); });
-    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int e) { w2::forward_or_euler(*M, *B, e, stages); });
-    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int e) { w4::forward_or_euler(*M, *B, e, stages); });
     else run_waves(nenv, 1, lds, [&](int e) { wv::forward_or_euler(*M, *B, e, stages); });
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void*) {
     // (slot w of the launch steps environment perm[w], like the kernels)
     if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int w) { wl::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
-    else if (variant == MJH_VAR_LEAN2) run_waves(nenv, 2, lds, [&](int w) { w2::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
-    else if (variant == MJH_VAR_LEAN4) run_waves(nenv, 4, lds, [&](int w) { w4::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
     else run_waves(nenv, 1, lds, [&](int w) { wv::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
     return true;
   }

@@ -1,0 +1,66 @@
+"""CPU: the GJK / EPA / multicontact narrowphase (mujoco_amd/csrc/mjh_convex.h) on the host wavefront
+emulation against the compiled reference, bit for bit.
+
+Reference: mjc_Convex (engine_collision_convex.c:881), mjc_PlaneConvex (:1004), mjc_ccd
+(engine_collision_gjk.c:2318).  The GPU counterparts are in tests/test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from convex_scenes import MESH_PAIRS, PRIMITIVE_PAIRS, scene, sweep
+from mujoco_amd import _capi as K
+
+
+@pytest.mark.parametrize("pair", PRIMITIVE_PAIRS, ids=lambda p: "-".join(p))
+def test_primitive_convex_pairs_bit_exact(rb, hostsim_lib, tmp_path, pair):
+    """the primitive cells of mjCOLLISIONFUNC that the reference routes to GJK/EPA (cylinder-box,
+    capsule-cylinder, ellipsoid-anything, plane-ellipsoid): contact lists identical over a pose sweep,
+    without margin (one contact, or the perturbation multi-contact of mjc_Convex: up to 5) and with"""
+    total = {}
+    for margin in (0.0, 0.02):
+        xml = tmp_path / "s.xml"
+        xml.write_text(scene(pair[0], pair[1], margin))
+        hist, bad = sweep(rb, K, hostsim_lib, xml, 60, seed=int(margin*100))
+        assert bad == 0, (pair, margin, hist)
+        for n, c in hist.items(): total[n] = total.get(n, 0) + c
+    assert sum(c for n, c in total.items() if n > 0) >= 30, total
+
+
+@pytest.mark.parametrize("pair", MESH_PAIRS, ids=lambda p: "-".join(p))
+def test_mesh_convex_pairs_bit_exact(rb, hostsim_lib, tmp_path, pair):
+    """convex meshes: exhaustive and hill-climbing support (mjc_meshSupport / mjc_hillclimbSupport),
+    EPA on discrete geoms (repeated-support termination), multicontact face / edge clipping against
+    meshes and boxes (polygonClip, polygonQuad), plane-mesh vertex contacts; random, axis-aligned and
+    nearly aligned poses (the degenerate simplices polytope2/3/4 have to repair)"""
+    xml = tmp_path / "s.xml"
+    any_multi = 0
+    for margin, aligned in ((0.0, False), (0.02, False), (0.0, True)):
+        xml.write_text(scene(pair[0], pair[1], margin, aligned))
+        hist, bad = sweep(rb, K, hostsim_lib, xml, 50, seed=3, aligned=aligned)
+        assert bad == 0, (pair, margin, aligned, hist)
+        any_multi += sum(c for n, c in hist.items() if n > 1)
+    if pair[0] not in ("sph", "ell") and pair[1] not in ("sph", "ell"):
+        assert any_multi > 0
+
+
+def test_cube_3x3x3_single_steps_vs_golden(hostsim_lib):
+    """BASELINE config 4 (model/cube/cube_3x3x3.xml: 26 mesh cubelets, Newton, implicitfast, nv = 66,
+    ~150 mesh-mesh contacts): single steps from (state, warm start, ctrl) of the committed reference
+    trajectory reproduce the reference's next state, contact / row counts and Newton iteration count"""
+    fx = np.load(os.path.join(GOLDEN, "cube_3x3x3_steps.npz"))
+    mm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "cube_3x3x3.mjb"))
+    dm = K.DeviceModel(hostsim_lib, mm)
+    assert dm.size("ccd_any") == 1 and dm.size("nconmax") >= 300
+    idx = [0, 1, 2, 5, 17, 40, 77, 120, 159]
+    b = K.Batch(dm, len(idx))
+    out = b.rollout_host(1, K.mjSTATE_CTRL, fx["state"][idx], fx["warmstart"][idx], fx["ctrl"][idx][:, None])
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], fx["ints"][idx, 0])          # ncon
+    assert np.array_equal(c[:, 1], fx["ints"][idx, 1])          # nefc
+    assert np.array_equal(c[:, 5], fx["ints"][idx, 2])          # solver_niter
+    ref = fx["next"][idx]
+    assert np.max(np.abs(out[:, 0] - ref)/np.maximum(1.0, np.abs(ref))) <= 1e-9

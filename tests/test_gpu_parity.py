@@ -34,24 +34,28 @@ def test_forward_vs_live_oracle(rb, hip_lib, dm):
     print("forward: worst relative error over all fields:", worst)
 
 
-def test_rollout_vs_golden(hip_lib, dm, golden):
+def test_rollout_vs_golden(rb, hip_lib, dm, golden):
     fx = golden("humanoid")
     n, T = fx["state0"].shape[0], fx["ctrl"].shape[1]
     b = K.Batch(dm, n)
     out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"])
-    # per-step parity from identical inputs: restart every step from the oracle's previous state
     err_short = relerr(out[:, :10], fx["state"][:, :10])
     print("rollout: rel err first 10 steps", err_short, " full horizon", relerr(out, fx["state"]),
           " bit-exact:", np.array_equal(out, fx["state"]))
     assert err_short <= TOL
+    # per-step parity from identical inputs over the whole horizon: 20 restart points per trajectory,
+    # one step each from the golden state (cold warm start on both sides), against the live oracle
     s_prev = np.concatenate([fx["state0"][:, None], fx["state"][:, :-1]], axis=1)
-    bb = K.Batch(dm, n * 20)
     idx = np.linspace(0, T - 1, 20).astype(int)
     s0 = s_prev[:, idx].reshape(-1, s_prev.shape[-1])
     c0 = fx["ctrl"][:, idx].reshape(-1, 1, fx["ctrl"].shape[-1])
-    one = bb.rollout_host(1, K.mjSTATE_CTRL, s0, None, c0)[:, 0]
-    # (warmstart differs from the oracle's running warmstart, so compare against a live oracle when present)
-    assert np.all(np.isfinite(one))
+    bb = K.Batch(dm, n * 20)
+    one = bb.rollout_host(1, K.mjSTATE_CTRL, s0, None, c0)
+    ref, ints = oracle_rollout(rb, humanoid_pgs_oracle(rb), s0, c0)
+    assert relerr(one, ref) <= TOL
+    counts = bb.get("counts")
+    assert np.array_equal(counts[:, 0], ints[:, 0, 0]) and np.array_equal(counts[:, 1], ints[:, 0, 1])
+    assert np.array_equal(counts[:, 5], ints[:, 0, 2])
 
 
 def test_soa_layout_forward_and_rollout_vs_live_oracle(rb, hip_lib, dm, golden):
@@ -104,6 +108,7 @@ def test_single_step_parity_vs_live_oracle(rb, hip_lib, dm):
     out = b.rollout_host(1, K.mjSTATE_CTRL, s0, ws, ctrl)[:, 0]
     counts = b.get("counts")
     d = rb.MjData(m)
+    worst = 0.0
     for e in range(n):
         rb.mj_resetData(m, d)
         rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
@@ -111,9 +116,10 @@ def test_single_step_parity_vs_live_oracle(rb, hip_lib, dm):
         d.ctrl[:] = ctrl[e, 0]
         rb.mj_step(m, d)
         ref = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        worst = max(worst, relerr(out[e], ref))
         assert relerr(out[e], ref) <= TOL, (e, relerr(out[e], ref))
         assert counts[e][0] == d.ncon and counts[e][1] == d.nefc and counts[e][5] == d.solver_niter[0]
-    print("single step: worst rel err", max(relerr(out[e], out[e]) for e in range(1)))
+    print("single step: worst rel err", worst)
 
 
 def test_rollout_api_matches_serial_oracle(rb, hip_lib):
@@ -629,11 +635,10 @@ def test_closed_loop_step_matches_rollout(hip_lib, dm, golden):
     assert np.array_equal(b.get("qvel"), ref[:, 2, 29:])
 
 
-@pytest.mark.parametrize("variant", ["generic", "lean", "lean2", "lean4"])
+@pytest.mark.parametrize("variant", ["generic", "lean"])
 def test_kernel_variants_field_parity(rb, hip_lib, dm, variant):
-    """every mapping of the stage sources (1 / 2 / 4 environments per wavefront, generic or lean
-    feature set: mjh_modes.h) against the live oracle, field by field, on contact-rich states whose
-    constraint counts differ between the environments that share a wavefront"""
+    """both feature sets of the stage sources (generic or lean: mjh_modes.h) against the live oracle,
+    field by field, on contact-rich states"""
     m = humanoid_pgs_oracle(rb)
     states = contact_rich_states(rb, m, 35, seed=23)       # odd count: the last wavefront is partly empty
     b = K.Batch(dm, len(states))
@@ -649,22 +654,20 @@ def test_kernel_variants_bit_identical_rollouts(hip_lib, dm, golden):
     fx = golden("humanoid")
     n, T = fx["state0"].shape[0], fx["ctrl"].shape[1]
     outs = {}
-    for variant in ["generic", "lean", "lean2", "lean4"]:
+    for variant in ["generic", "lean"]:
         b = K.Batch(dm, n)
         b.set_variant(variant)
         outs[variant] = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"])
         assert b.get("warning").sum() == 0
-    for variant in ["lean", "lean2", "lean4"]:
-        assert np.array_equal(outs[variant], outs["generic"]), variant
-    assert relerr(outs["lean2"][:, :10], fx["state"][:, :10]) <= TOL
+    assert np.array_equal(outs["lean"], outs["generic"])
+    assert relerr(outs["lean"][:, :10], fx["state"][:, :10]) <= TOL
 
 
 # ---- warning semantics on the GPU path (rollout.cc:135-155; engine_forward.c:54-113) -------------------
 
 def test_bad_state_freezes_and_resets_on_gpu(rb, hip_lib, dm):
     """a bad qvel raises mjWARN_BADQVEL, auto-resets the environment (mj_checkVel) and the rollout
-    loop back-fills the rest of its trajectory; the other environments of the batch (and of the
-    wavefront, for the sub-wave variants) are unaffected"""
+    loop back-fills the rest of its trajectory; the other environments of the batch are unaffected"""
     m = humanoid_pgs_oracle(rb)
     d = rb.MjData(m)
     base = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
@@ -677,7 +680,7 @@ def test_bad_state_freezes_and_resets_on_gpu(rb, hip_lib, dm):
     ctrl = rng.uniform(-1, 1, size=(n, T, m.nu))
     ref, _ = oracle_rollout(rb, m, s0, ctrl)        # (a plain mj_step loop: no freeze rule)
     ok = [0, 1, 3, 4]
-    for variant in ["lean", "lean2", "generic"]:
+    for variant in ["lean", "generic"]:
         b = K.Batch(dm, n)
         b.set_variant(variant)
         out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
@@ -894,3 +897,67 @@ def test_broadphase_and_midphase_counts_exact_on_gpu(rb, hip_lib, tmp_path):
         assert int(bb.get("counts")[0, 0]) == d.ncon, t
         if d.ncon:
             assert np.array_equal(bb.get("con_geom")[0].reshape(-1, 2)[:d.ncon], d.contact["geom"]), t
+
+
+# ---- GJK / EPA / multicontact narrowphase (mjh_convex.h) on the GPU ---------------------------------------
+
+def test_convex_pairs_on_gpu(rb, hip_lib, tmp_path):
+    """mjc_Convex / mjc_PlaneConvex (engine_collision_convex.c:881,:1004; engine_collision_gjk.c) on the
+    HIP path: pose sweeps over primitive pairs the reference routes to GJK/EPA (cylinder-box,
+    capsule-cylinder, ellipsoids) and over convex meshes (exhaustive and hill-climbing support,
+    multicontact clipping).  The narrowphase uses only + - * / sqrt, all correctly rounded on the
+    device and evaluated in the reference's order, so contact count, geom ids, distance, position and
+    frame are asserted identical, not merely close."""
+    from convex_scenes import scene, sweep
+    pairs = [("box", "cyl"), ("cyl", "cap"), ("cyl", "cyl"), ("ell", "box"), ("ell", "ell"), ("pla", "ell"),
+             ("cub", "cub"), ("cub", "box"), ("ico", "cub"), ("tet", "tet"), ("cub", "cyl"), ("sph", "cub"), ("pla", "cub"), ("pla", "tet")]
+    xml = tmp_path / "s.xml"
+    contacts = multi = 0
+    for pair in pairs:
+        for margin, aligned in ((0.0, False), (0.02, False), (0.0, True)):
+            xml.write_text(scene(pair[0], pair[1], margin, aligned))
+            hist, bad = sweep(rb, K, hip_lib, xml, 128, seed=5, aligned=aligned)
+            assert bad == 0, (pair, margin, aligned, hist)
+            contacts += sum(c for n, c in hist.items() if n > 0)
+            multi += sum(c for n, c in hist.items() if n > 1)
+    print("convex sweep: poses with contacts", contacts, "with several contacts", multi)
+    assert contacts > 1500 and multi > 300
+
+
+def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
+    """BASELINE config 4: model/cube/cube_3x3x3.xml as shipped (26 convex mesh cubelets, Newton,
+    implicitfast, nv = 66, ~150 mesh-mesh contacts).  Every step of the committed reference trajectory
+    is re-stepped from (state, warm start, ctrl): contact / row / Newton-iteration counts exact, the next
+    state within the north star's 1e-6; then the same against the live oracle with the contact list
+    compared record by record"""
+    fx = np.load(os.path.join(GOLDEN, "cube_3x3x3_steps.npz"))
+    mm = mujoco_amd.MjbModel(hip_lib, os.path.join(GOLDEN, "cube_3x3x3.mjb"))
+    dm = K.DeviceModel(hip_lib, mm)
+    n = fx["state"].shape[0]
+    b = K.Batch(dm, n)
+    out = b.rollout_host(1, K.mjSTATE_CTRL, fx["state"], fx["warmstart"], fx["ctrl"][:, None])
+    assert b.get("warning").sum() == 0
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], fx["ints"][:, 0]) and np.array_equal(c[:, 1], fx["ints"][:, 1])
+    assert np.array_equal(c[:, 5], fx["ints"][:, 2])
+    err = relerr(out[:, 0], fx["next"])
+    print("cube: ncon up to", fx["ints"][:, 0].max(), "nefc up to", fx["ints"][:, 1].max(), "single-step rel err", err)
+    assert err <= TOL
+    # contact records against the live oracle
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "cube_3x3x3.mjb"))
+    d = rb.MjData(m)
+    b.reset()
+    nq = m.nq
+    b.set("qpos", fx["state"][:, 1:1 + nq])
+    b.set("qvel", fx["state"][:, 1 + nq:])
+    b.forward()
+    cd = b.get("con_dist"); cg = b.get("con_geom").reshape(n, -1, 2); cp = b.get("con_pos").reshape(n, -1, 3)
+    for e in range(0, n, 8):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, fx["state"][e], rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        k = d.ncon
+        assert b.get("counts")[e, 0] == k
+        rc = d.contact[:k]
+        assert np.array_equal(cg[e, :k], rc["geom"])
+        assert np.abs(cd[e, :k] - rc["dist"]).max() <= 1e-9 and np.abs(cp[e, :k] - rc["pos"]).max() <= 1e-9

@@ -7,6 +7,15 @@
                                trajectory (PGS, Euler, fp64) and per-step integer observables
                                (ncon, nefc, solver_niter, contact geom pairs)
 
+  cube_3x3x3.mjb / _steps.npz  BASELINE config 4 (model/cube/cube_3x3x3.xml as shipped: Newton, implicitfast,
+                               26 convex mesh cubelets).  The .mjb is compiled from the reference's XML with
+                               the <texture>/<material> assets removed (28 PNG skins = 36 MB of pixels that
+                               mj_step never reads); every array mj_step does read is asserted equal to the
+                               unstripped model's.  The fixture holds single steps: (state, warm start, ctrl)
+                               -> next state + ncon / nefc / solver_niter along one reference trajectory of
+                               random-action steps (contact sets flip at the 1e-16 level in this model, so
+                               free-running trajectories are only comparable between bit-identical engines).
+
 Usage: python tools/make_golden.py
 """
 import os
@@ -46,8 +55,58 @@ def initial_states(m, d, nenv, rng):
     return s0
 
 
+def strip_visuals(xml_text):
+    """remove <texture>, <material> elements and material="..." attributes (rendering only)"""
+    import re
+    xml_text = re.sub(r"\s*<texture\b[^>]*/>", "", xml_text)
+    xml_text = re.sub(r"\s*<material\b[^>]*/>", "", xml_text)
+    return re.sub(r'\smaterial="[^"]*"', "", xml_text)
+
+
+PHYSICS_ARRAYS = ["body_pos", "body_quat", "body_mass", "body_inertia", "body_ipos", "body_iquat", "jnt_axis", "jnt_pos",
+                  "dof_armature", "dof_damping", "dof_frictionloss", "geom_pos", "geom_quat", "geom_size", "geom_rbound",
+                  "geom_aabb", "geom_friction", "geom_solref", "geom_solimp", "geom_margin", "mesh_vert", "mesh_graph",
+                  "mesh_polynormal", "mesh_polyvert", "mesh_polymap", "actuator_gear", "actuator_ctrlrange", "qpos0"]
+
+
+def make_cube():
+    import tempfile
+    src = os.path.join(REF, "model/cube/cube_3x3x3.xml")
+    full = rb.MjModel.from_xml_path(src)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cube_3x3x3.xml")
+        with open(path, "w") as f:
+            f.write(strip_visuals(open(src).read()))
+        m = rb.MjModel.from_xml_path(path)
+    for name in PHYSICS_ARRAYS:
+        assert np.array_equal(getattr(m, name), getattr(full, name)), name
+    assert (m.nq, m.nv, m.nu, m.ngeom, m.nmesh) == (full.nq, full.nv, full.nu, full.ngeom, full.nmesh)
+    m.save_binary(os.path.join(OUT, "cube_3x3x3.mjb"))
+    d = rb.MjData(m)
+    rng = np.random.Generator(np.random.PCG64(99))
+    nstep = 160
+    nstate = rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)
+    lo, hi = m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]
+    state = np.zeros((nstep, nstate)); warm = np.zeros((nstep, m.nv)); ctrl = np.zeros((nstep, m.nu))
+    nxt = np.zeros((nstep, nstate)); ints = np.zeros((nstep, 3), np.int32)
+    rb.mj_resetData(m, d)
+    for t in range(nstep):
+        state[t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        warm[t] = d.qacc_warmstart
+        ctrl[t] = rng.uniform(lo, hi)
+        d.ctrl[:] = ctrl[t]
+        rb.mj_step(m, d)
+        nxt[t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        ints[t] = d.ncon, d.nefc, d.solver_niter[0]
+    np.savez_compressed(os.path.join(OUT, "cube_3x3x3_steps.npz"), state=state, warmstart=warm, ctrl=ctrl, next=nxt, ints=ints)
+    print("cube_3x3x3", "nv", m.nv, "ncon max", ints[:, 0].max(), "nefc max", ints[:, 1].max(), "niter max", ints[:, 2].max())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_cube()
+    if "--cube-only" in sys.argv:
+        return
     for name, rel in MODELS.items():
         m = rb.MjModel.from_xml_path(os.path.join(REF, rel))
         m.save_binary(os.path.join(OUT, name + ".mjb"))
