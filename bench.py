@@ -45,16 +45,35 @@ sys.path.insert(0, ROOT)
 NENV_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0
 
+# --config: the BASELINE.json configurations that fit one GPU.  `humanoid` (configs[1]) is the metric;
+# the others are additional lines (`python bench.py --config cube`), never the driver's default.
+#   solver / integrator None = as the model file ships them; ctrl range and dt from the XML cited
+CONFIGS = {
+    "humanoid": dict(mjb="humanoid.mjb", xml="model/humanoid/humanoid.xml", nenv=4096, solver="pgs", integrator="euler",
+                     ctrl=(-1.0, 1.0), dt=0.005, free_root=True,
+                     metric="env-steps/sec on humanoid.xml, 4096 envs/GPU"),
+    # model/cube/cube_3x3x3.xml: Newton (default solver), implicitfast (:4), motors ctrlrange +-0.05 (:16), dt 0.01
+    "cube": dict(mjb="cube_3x3x3.mjb", xml="model/cube/cube_3x3x3.xml", nenv=2048, solver=None, integrator=None,
+                 ctrl=(-0.05, 0.05), dt=0.01, free_root=False,
+                 metric="env-steps/sec on cube_3x3x3.xml (convex mesh contacts, Newton), 2048 envs/GPU"),
+    # model/slider_crank/slider_crank.xml: position actuators ctrlrange +-0.1 (:10), default dt 0.002
+    "slider_crank": dict(mjb="slider_crank.mjb", xml="model/slider_crank/slider_crank.xml", nenv=64, solver="pgs",
+                         integrator="euler", ctrl=(-0.1, 0.1), dt=0.002, free_root=False,
+                         metric="env-steps/sec on slider_crank.xml, 64 envs"),
+}
 
-def initial_states(qpos0: np.ndarray, nv: int, nenv: int, seed: int) -> np.ndarray:
+
+def initial_states(qpos0: np.ndarray, nv: int, nenv: int, seed: int, free_root: bool = True) -> np.ndarray:
     """reset state + hinge perturbation N(0,0.05^2), qvel ~ N(0,0.1^2), env-major draws.
-    humanoid: qpos[0:7] is the free joint (left untouched), the rest are hinges."""
+    humanoid: qpos[0:7] is the free joint (left untouched), the rest are hinges.  Models whose
+    joints are not all hinges (cube: ball joints, unit quaternions) keep qpos0 and draw qvel only."""
     rng = np.random.Generator(np.random.PCG64(seed))
     nq = qpos0.size
     s0 = np.zeros((nenv, 1 + nq + nv))
     for e in range(nenv):
         s0[e, 1:1 + nq] = qpos0
-        s0[e, 8:1 + nq] += rng.normal(0, 0.05, size=nq - 7)
+        if free_root:
+            s0[e, 8:1 + nq] += rng.normal(0, 0.05, size=nq - 7)
         s0[e, 1 + nq:] = rng.normal(0, 0.1, size=nv)
     return s0
 
@@ -86,20 +105,21 @@ def ctrl_noise(nstep: int, nu: int, dt: float, lo: np.ndarray, hi: np.ndarray,
     return out
 
 
-def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
+def cpu_baseline(nthread: int, budget_s: float = 15.0, mjb_name: str = "humanoid.mjb", solver_flag: str | None = "PGS") -> dict | None:
     """reference CPU engine timed by the reference's own sample/testspeed.cc (compiled from the
     reference sources into oracle/_ref by oracle/Makefile) on the host cores of this box."""
     exe = os.path.join(ROOT, "oracle", "_ref", "testspeed")
-    mjb = os.path.join(ROOT, "tests", "golden", "humanoid.mjb")
+    mjb = os.path.join(ROOT, "tests", "golden", mjb_name)
     if not os.path.exists(exe):
         return None
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"))
+    extra = [f"--solver={solver_flag}"] if solver_flag else []
 
     def run(nstep):
-        out = subprocess.run([exe, mjb, f"--nstep={nstep}", f"--nthread={nthread}", "--solver=PGS"],
+        out = subprocess.run([exe, mjb, f"--nstep={nstep}", f"--nthread={nthread}", *extra],
                              capture_output=True, text=True, env=env, timeout=600).stdout
         m = re.search(r"Total steps per second\s*:\s*([0-9.]+)", out)
-        it = re.search(r"PGS iters / step\s*:\s*([0-9.]+)", out)
+        it = re.search(r"(?:PGS|Newton|CG) iters / step\s*:\s*([0-9.]+)", out)
         nc = re.search(r"Contacts / step\s*:\s*([0-9.]+)", out)
         ne = re.search(r"Constraints / step\s*:\s*([0-9.]+)", out)
         g = lambda x: float(x.group(1)) if x else None
@@ -112,9 +132,38 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0) -> dict | None:
     sps, iters, ncon, nefc = run(nstep)
     return {"value": sps, "unit": "env-steps/s", "cores": nthread, "kind": "reference",
             "mean_ncon": ncon, "mean_nefc": nefc, "mean_pgs_iter": iters,
-            "sample": f"reference sample/testspeed.cc on liboracle_fast (-O3 -mavx), humanoid.mjb --solver=PGS "
+            "sample": f"reference sample/testspeed.cc on liboracle_fast (-O3 -mavx), {mjb_name} {' '.join(extra)} "
                       f"--nthread={nthread} --nstep={nstep} (OU-Halton ctrl noise, its default regime; "
-                      f"{iters} PGS iters/step)"}
+                      f"{iters} solver iters/step)"}
+
+
+def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread):
+    """The like-for-like CPU number for `value`: the reference engine (oracle/_ref/liboracle_fast.so) stepping
+    the bench's OWN initial states and control stream -- rows [0, R) of the GPU batch, warm-up + timed steps
+    -- on all host cores, through oracle/rollout_bench.cc (the work of _unsafe_rollout_threaded,
+    python/mujoco/rollout.cc:181-216).  TEST INFRASTRUCTURE used as a baseline, never as the product."""
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "rollout_bench")
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"))
+    R, T = ctrl.shape[0], ctrl.shape[1]
+    with tempfile.TemporaryDirectory() as td:
+        np.ascontiguousarray(s0[:R], dtype=np.float64).tofile(os.path.join(td, "s0.bin"))
+        np.ascontiguousarray(ctrl, dtype=np.float64).tofile(os.path.join(td, "ctrl.bin"))
+        out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", mjb_name), os.path.join(td, "s0.bin"),
+                              os.path.join(td, "ctrl.bin"), str(R), str(T), str(nthread),
+                              str(-1 if solver_id is None else solver_id), str(-1 if integ_id is None else integ_id),
+                              os.path.join(td, "final.bin")], capture_output=True, text=True, env=env, timeout=900).stdout
+        final = np.fromfile(os.path.join(td, "final.bin")) if os.path.exists(os.path.join(td, "final.bin")) else None
+    kv = dict(x.split("=") for x in out.split() if "=" in x)
+    if "env_steps_per_s" not in kv:
+        return None
+    return {"value": float(kv["env_steps_per_s"]), "unit": "env-steps/s", "cores": nthread, "kind": "reference",
+            "rollouts": R, "nstep": T, "seconds": float(kv["seconds"]), "mean_ncon": float(kv["mean_ncon"]),
+            "mean_nefc": float(kv["mean_nefc"]), "mean_solver_iter": float(kv["mean_niter"]),
+            "sample": f"oracle/rollout_bench (liboracle_fast, -O3 -mavx): rows [0,{R}) of the GPU batch, the same state0 and "
+                      f"U(ctrlrange) control stream, {T} steps (warm-up + timed) from reset, {nthread} threads"}, final
 
 
 def measured_traffic(steps_per_launch: int, nenv: int):
@@ -137,7 +186,7 @@ def measured_traffic(steps_per_launch: int, nenv: int):
     return best
 
 
-def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once):
+def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0)):
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).
@@ -154,8 +203,10 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     except Exception:
         return None
     m = rb.MjModel.from_binary_path(model_path)
-    m.opt.solver = solver
-    m.opt.integrator = integrator
+    if solver is not None:
+        m.opt.solver = solver
+    if integrator is not None:
+        m.opt.integrator = integrator
     spec = rb.mjSTATE_FULLPHYSICS
     worst, worst_at = 0.0, None
     T = ctrl.shape[1]
@@ -178,7 +229,7 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     # (2) one step from identical (state, warm start, control)
     rng = np.random.Generator(np.random.PCG64(99))
     ws = np.stack([np.array(d.qacc_warmstart) for d in datas])
-    u = rng.uniform(-1.0, 1.0, size=(len(envs), 1, ctrl.shape[2]))
+    u = rng.uniform(ctrl_range[0], ctrl_range[1], size=(len(envs), 1, ctrl.shape[2]))
     got, counts = step_once(gpu_state[:, -1], ws, u)
     nbad, worst1 = 0, 0.0
     for k, d in enumerate(datas):
@@ -205,12 +256,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--chunk", type=int, default=250,
                     help="steps per rollout-kernel launch (one open-loop rollout call); 250 measured best: longer launches average the per-environment cost, shorter ones re-deal the environments over the SIMDs more often")
-    ap.add_argument("--envs-per-gpu", type=int, default=NENV_PER_GPU)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="humanoid",
+                    help="humanoid = BASELINE configs[1], the metric; cube = configs[3] (many-contact convex meshes, Newton); "
+                         "slider_crank = configs[0]")
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="0: the configuration's own count (humanoid 4096, cube 2048, slider_crank 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-state-output", action="store_true", help="do not write the per-step state array")
-    ap.add_argument("--solver", choices=["pgs", "newton", "cg"], default="pgs",
-                    help="pgs = BASELINE config 2 (the metric); newton = the reference's default solver")
-    ap.add_argument("--integrator", choices=["euler", "rk4", "implicitfast"], default="euler")
+    ap.add_argument("--solver", choices=["pgs", "newton", "cg"], default=None,
+                    help="default: the configuration's (humanoid: pgs = BASELINE config 2, the metric; cube: as shipped = newton)")
+    ap.add_argument("--integrator", choices=["euler", "rk4", "implicitfast"], default=None)
     ap.add_argument("--ctrl", choices=["uniform", "ou-halton"], default="uniform",
                     help="uniform = U(ctrlrange) per (env, step) (SURVEY 8d mode B, the metric); ou-halton = "
                          "testspeed's CtrlNoise sequence shared by all envs (mode A)")
@@ -220,11 +274,14 @@ def main() -> None:
     ap.add_argument("--regime-steps", type=int, default=200, help="timed steps of the testspeed-regime leg")
     ap.add_argument("--regime-settle", type=int, default=1000, help="untimed settling steps of that leg")
     ap.add_argument("--parity-envs", type=int, default=64)
+    ap.add_argument("--gather", choices=["per-chunk", "final"], default="per-chunk",
+                    help="N > 1: per-chunk = every launch's per-step state array goes to rank 0 over RCCL, overlapped with the "
+                         "next launch (north star's observation gather; the default); final = only the end-of-run final states")
     args = ap.parse_args()
 
     import torch
     import mujoco_amd as ma
-    from mujoco_amd.sharding import gather_to_rank0
+    from mujoco_amd.sharding import ChunkGather, gather_to_rank0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -241,21 +298,28 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     lib = ma.lib()
-    model_path = os.path.join(ROOT, "tests", "golden", "humanoid.mjb")
+    cfg = CONFIGS[args.config]
+    model_path = os.path.join(ROOT, "tests", "golden", cfg["mjb"])
     model = ma.MjbModel(lib, model_path)
-    solver_id = {"pgs": 0, "cg": 1, "newton": 2}[args.solver]
-    integ_id = {"euler": 0, "rk4": 1, "implicitfast": 3}[args.integrator]
-    model.set_option("solver", solver_id)     # PGS = BASELINE config 2
-    model.set_option("integrator", integ_id)
+    solver_name = args.solver or cfg["solver"]
+    integ_name = args.integrator or cfg["integrator"]
+    solver_id = {"pgs": 0, "cg": 1, "newton": 2}[solver_name] if solver_name else None
+    integ_id = {"euler": 0, "rk4": 1, "implicitfast": 3}[integ_name] if integ_name else None
+    if solver_id is not None:
+        model.set_option("solver", solver_id)     # PGS = BASELINE config 2
+    if integ_id is not None:
+        model.set_option("integrator", integ_id)
+    solver_name = solver_name or "newton"            # (cube_3x3x3.xml ships the default solver)
+    integ_name = integ_name or "implicitfast"        # (cube_3x3x3.xml:4)
     dm = ma.DeviceModel(lib, model)
-    nenv, K, W = args.envs_per_gpu, args.steps, args.warmup
+    nenv, K, W = (args.envs_per_gpu or cfg["nenv"]), args.steps, args.warmup
     nq, nv, nu, nstate = dm.nq, dm.nv, dm.nu, dm.nstate
     batch = ma.Batch(dm, nenv, device=local_rank)
     qpos0 = batch.get("qpos")[0]
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream
-    lo, hi = -np.ones(nu), np.ones(nu)       # humanoid ctrlrange
-    dt = 0.005                                # humanoid.xml:17
+    lo, hi = cfg["ctrl"][0]*np.ones(nu), cfg["ctrl"][1]*np.ones(nu)       # ctrlrange of the model's actuators
+    dt = cfg["dt"]
 
     C = max(1, min(args.chunk, K))
 
@@ -268,6 +332,7 @@ def main() -> None:
         torch.cuda.synchronize()
 
     events = []
+    obs = ChunkGather(rank, world, dist)      # per-chunk observation gather to rank 0 (no-op at N = 1)
 
     def launch(ctrl, out, state0=None):
         """one rollout-kernel launch of ctrl.shape[1] steps; state0 given: load the initial states,
@@ -280,12 +345,17 @@ def main() -> None:
         e1.record()
         events.append((e0, e1, ctrl.shape[1]))
 
+    cpu_rows = min(nenv, max(1024, 4*(os.cpu_count() or 1)))     # rows of the batch the CPU leg re-steps
+    host_ctrl = []                                                   # their control stream, in launch order
+
     def make_controls(kind, crng, sizes, t_begin):
         """device control arrays [nenv][c][nu] for consecutive launches of the given sizes"""
         out, t = [], t_begin
         if kind == "uniform":
             for c in sizes:
-                out.append(torch.from_numpy(crng.uniform(-1.0, 1.0, size=(nenv, c, nu))).to(dev))
+                u = crng.uniform(lo[0], hi[0], size=(nenv, c, nu))
+                host_ctrl.append(u[:cpu_rows].copy())
+                out.append(torch.from_numpy(u).to(dev))
         else:
             seq = ctrl_noise(t_begin + sum(sizes), nu, dt, lo, hi)
             for c in sizes:
@@ -315,7 +385,10 @@ def main() -> None:
 
         for c, o in zip(ctrl_w, state_w):
             launch(c, o, first)
+            if o is not None and args.gather == "per-chunk":
+                obs.submit(o)          # (warm-up: the gather path runs once before the timer starts)
             first = None
+        obs.wait()
         if not ctrl_w:
             # no warm-up steps asked for: still load the copy / gather code paths (zero simulation steps)
             finish(torch.zeros((nenv, 1, nstate), dtype=torch.float64, device=dev) if want_state else None)
@@ -323,10 +396,14 @@ def main() -> None:
             finish(state_w[-1])
         barrier()
         n_warm = len(events)
+        obs.chunks = obs.bytes_sent = 0
         t0 = time.perf_counter()
         for c, o in zip(ctrl_k, state_k):
             launch(c, o, first)
+            if o is not None and args.gather == "per-chunk":
+                obs.submit(o)          # observation gather of this chunk, overlapped with the next launch
             first = None
+        obs.wait()
         finish(state_k[-1] if state_k else None)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -334,13 +411,14 @@ def main() -> None:
         return elapsed, timed, state_w, state_k
 
     # ---------------- the metric: random actions U(ctrlrange), BASELINE config 2 -----------------
-    s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank)
+    s0 = initial_states(qpos0, nv, nenv, seed=1234 + rank, free_root=cfg["free_root"])
     state0 = torch.from_numpy(s0).to(dev)
     crng = np.random.Generator(np.random.PCG64(4321 + rank))
     want_state = not args.no_state_output
     ctrl_s = make_controls(args.ctrl, crng, chunks(args.settle) if args.settle else [], 0)
     ctrl_w = make_controls(args.ctrl, crng, chunks(W) if W else [], args.settle)
     ctrl_k = make_controls(args.ctrl, crng, chunks(K), args.settle + W)
+    n_metric_ctrl = len(host_ctrl)          # control chunks of the metric leg (warm-up + timed), in order
     elapsed, timed, state_w, state_k = timed_region(state0, ctrl_s, ctrl_w, ctrl_k, want_state)
     kernel_ms = sum(t for t, _ in timed)
     launch_ms_timed = float(np.mean([t for t, n in timed if n == C])) if any(n == C for _, n in timed) else kernel_ms
@@ -361,7 +439,7 @@ def main() -> None:
         # one launch = C steps of nenv envs; achieved = algorithmic bytes per launch / avg launch time
         achieved = bytes_per_env_step * nenv * C / (launch_ms_timed * 1e-3) / 1e9
         res = {
-            "metric": "env-steps/sec on humanoid.xml, 4096 envs/GPU",
+            "metric": cfg["metric"],
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -373,10 +451,10 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"model/humanoid/humanoid.xml, {nenv} envs/GPU, {args.solver.upper()} solver, {args.integrator}, fp64, "
+            "config": {"workload": f"{cfg['xml']}, {nenv} envs/GPU, {solver_name.upper()} solver, {integ_name}, fp64, "
                                    + ("random actions U(ctrlrange)" if args.ctrl == "uniform" else "testspeed OU-Halton ctrl noise")
                                    + ", per-step state output" + ("" if want_state else " disabled"),
-                       "envs_per_gpu": nenv, "nstep": K, "solver": args.solver.upper(), "integrator": args.integrator,
+                       "envs_per_gpu": nenv, "nstep": K, "solver": solver_name.upper(), "integrator": integ_name,
                        "ctrl": args.ctrl, "settle": args.settle,
                        "parallelism": f"env-sharded x{world}",
                        "mapping": batch.lds_report().splitlines()[0] if batch.lds_report() else "no LDS plan",
@@ -391,8 +469,12 @@ def main() -> None:
                          "wall_ms_total": elapsed * 1e3,
                          "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "algorithmic_bytes_per_launch": bytes_per_env_step * nenv * C},
+            "gather": {"mode": args.gather if world > 1 else "none (1 GPU)", "chunks": obs.chunks,
+                       "bytes_per_rank": obs.bytes_sent,
+                       "note": "per-step state arrays of every rank gathered on rank 0 after each launch (RCCL, async, overlapped "
+                               "with the next launch), inside the timed region: its exposed cost is wall_ms_total - kernel_ms_total"},
             "end_state": {"warnings": warn, "mean_ncon": float(counts[:, 0].mean()),
-                          "mean_nefc": float(counts[:, 1].mean()), "mean_pgs_iter": float(counts[:, 5].mean())},
+                          "mean_nefc": float(counts[:, 1].mean()), "mean_solver_iter": float(counts[:, 5].mean())},
         }
 
     # ---------------- parity of the timed workload against the compiled reference ----------------
@@ -407,13 +489,13 @@ def main() -> None:
             return out, small.get("counts")
 
         try:
-            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once)
+            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once, cfg["ctrl"])
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
             res["parity_sample"] = {"ok": False, "error": repr(exc)}
     del state_w, state_k, ctrl_w, ctrl_k
 
     # ---------------- the same kernel in the reference testspeed's control regime ----------------
-    if not args.no_extra and args.ctrl == "uniform" and args.regime_steps > 0:
+    if not args.no_extra and args.ctrl == "uniform" and args.regime_steps > 0 and args.config == "humanoid":
         K2, S2, W2 = args.regime_steps, args.regime_settle, 20
         C2 = max(1, min(args.chunk, K2))
         sizes = lambda n: [C2] * (n // C2) + ([n % C2] if n % C2 else [])
@@ -438,9 +520,20 @@ def main() -> None:
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not args.no_extra:
-            cb = cpu_baseline(os.cpu_count() or 1)
+            cb = cpu_baseline(os.cpu_count() or 1, mjb_name=cfg["mjb"], solver_flag=(args.solver or cfg["solver"] or "").upper() or None)
             if cb:
                 res["cpu_baseline"] = cb
+            # the same workload as `value` (same states, same controls, same steps) on the host cores
+            if args.ctrl == "uniform" and args.settle == 0 and n_metric_ctrl > 0:
+                try:
+                    leg = cpu_rollout_leg(cfg["mjb"], solver_id, integ_id, s0, np.concatenate(host_ctrl[:n_metric_ctrl], axis=1),
+                                          os.cpu_count() or 1)
+                except Exception as exc:
+                    leg = ({"error": repr(exc)}, None)
+                if leg:
+                    res.setdefault("cpu_baseline", {"value": leg[0].get("value"), "unit": "env-steps/s", "cores": os.cpu_count() or 1,
+                                                    "kind": "reference", "sample": leg[0].get("sample")})
+                    res["cpu_baseline"]["rollout_regime"] = leg[0]
         print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -120,14 +120,18 @@ struct Backend {
   }
   static bool launch_balance(const DBatch* B, int nenv, void* stream) {
     (void)nenv;
-    static int nsimd = 0, mode = 1;
-    if (!nsimd) {
+    // (function-local statics: initialised once, thread-safely -- the per-GPU host threads of mjhip_rollout all land here)
+    struct Cfg { int nsimd, mode; };
+    static const Cfg cfg = [] {
+      Cfg c{0, 1};
       int dev = 0, cus = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-      nsimd = 4*cus;
-      if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) { mode = atoi(ev); if (mode == 0) nsimd = 1 << 30; }     // A/B: 0 plain descending order, 2 heaviest + three lightest
-    }
+      c.nsimd = 4*cus;
+      if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) { c.mode = atoi(ev); if (c.mode == 0) c.nsimd = 1 << 30; }     // A/B: 0 plain descending order, 2 heaviest + three lightest
+      return c;
+    }();
+    const int nsimd = cfg.nsimd, mode = cfg.mode;
     hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd, mode);
     return hipGetLastError() == hipSuccess;
   }

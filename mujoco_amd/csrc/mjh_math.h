@@ -86,6 +86,58 @@ MJH_DEV void m3_multvec(P0 r, P1 m, P2 v) {
   r[2] = m[2]*v[0] + m[5]*v[1] + m[8]*v[2];
 }
 
+// ---- sine and cosine ---------------------------------------------------------------------------
+// The device libm's sin / cos carry a Payne-Hanek path for huge arguments whose tables and spills are
+// paid -- in scratch memory and registers -- by every kernel that calls them, although joint angles
+// are O(1).  mjh_sincos replaces them on the device: Cody-Waite reduction by pi/2 in three 53-bit pieces
+// with error-free products (explicit fma), good to |x| ~ 1e10 (mjMAXVAL, beyond which mj_checkPos has
+// already reset the state), then the classic minimax kernels on [-pi/4, pi/4] (fdlibm k_sin.c / k_cos.c
+// coefficients) fed with the reduced argument as head + tail.  Error < 1 ulp, like libm's; no tables, no
+// scratch.  The explicit fma calls are correctly rounded on host and device alike, so the routine is
+// bit-reproducible across both (tests/hostsim exports it: mjh_test_sincos).
+MJH_DEV void mjh_sincos(real x, real* sn, real* cs) {
+  const real P1 = 0x1.921fb54442d18p+0, P2 = 0x1.1a62633145c07p-54, P3 = -0x1.f1976b7ed8fbcp-110;
+  const real k = rint(x * 0x1.45f306dc9c883p-1);
+  // x - k*pi/2 as head + tail: k*P1 = p1 + e1 and k*P2 = p2 + e2 exactly; x - p1 is exact (Sterbenz)
+  const real p1 = k*P1, e1 = fma(k, P1, -p1);
+  const real p2 = k*P2, e2 = fma(k, P2, -p2);
+  const real r0 = x - p1;
+  const real s1 = r0 - e1;
+  real bb = s1 - r0;
+  const real t1 = (r0 - (s1 - bb)) + (-e1 - bb);
+  const real s2 = s1 - p2;
+  bb = s2 - s1;
+  const real t2 = (s1 - (s2 - bb)) + (-p2 - bb);
+  const real lo = ((t1 + t2) - e2) - k*P3;
+  const real rh = s2 + lo;
+  const real rl = lo - (rh - s2);
+  // kernels
+  const real z = rh*rh;
+  const real v = z*rh;
+  const real rs = 8.33333333332248946124e-03 + z*(-1.98412698298579493134e-04 + z*(2.75573137070700676789e-06 +
+                  z*(-2.50507602534068634195e-08 + z*1.58969099521155010221e-10)));
+  const real ksin = rh - ((z*(0.5*rl - v*rs) - rl) - v*-1.66666666666666324348e-01);
+  const real rc = z*(4.16666666666666019037e-02 + z*(-1.38888888888741095749e-03 + z*(2.48015872894767294178e-05 +
+                  z*(-2.75573143513906633035e-07 + z*(2.08757232129817482790e-09 + z*-1.13596475577881948265e-11)))));
+  const real hz = 0.5*z;
+  const real w = 1.0 - hz;
+  const real kcos = w + (((1.0 - w) - hz) + (z*rc - rh*rl));
+  const int q = (int)((long long)k & 3);
+  const real a = (q & 1) ? kcos : ksin;      // |sin|-role value of this quadrant
+  const real b = (q & 1) ? ksin : kcos;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
+}
+// sin and cos of x: libm on the host emulation (it is compared bit for bit with the reference, which
+// calls the host's libm), mjh_sincos on the device
+MJH_DEV void r_sincos(real x, real* sn, real* cs) {
+#ifdef MJH_HOSTSIM
+  *sn = sin(x); *cs = cos(x);
+#else
+  mjh_sincos(x, sn, cs);
+#endif
+}
+
 template <class P0, class P1>
 MJH_DEV void q_copy(P0 r, P1 q) { r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3]; }
 // normalize quaternion in place                (mju_normalize4 / mji__normalize4, engine_inline.h:228)
@@ -131,8 +183,9 @@ MJH_DEV void q_axisangle(P0 r, P1 axis, real angle) {
   if (angle == 0) {
     r[0] = 1; r[1] = 0; r[2] = 0; r[3] = 0;
   } else {
-    real s = sin(angle*0.5);
-    r[0] = cos(angle*0.5);
+    real s, c;
+    r_sincos(angle*0.5, &s, &c);
+    r[0] = c;
     r[1] = axis[0]*s;
     r[2] = axis[1]*s;
     r[3] = axis[2]*s;

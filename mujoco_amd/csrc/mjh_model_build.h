@@ -175,6 +175,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
              "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
+  MJH_REJECT(m->opt.solver == mjSOL_NEWTON && m->nv > 128, "the Newton solver with more than 128 degrees of freedom (its dof vectors live in two registers per lane; CG and PGS have no such bound)");
   // mj_isSparse (engine_core_util.c:29): with jacobian=sparse, or auto and nv >= 60, the reference
   // runs its sparse code paths.  They compute the same quantities with sums taken over the non-zeros
   // only; this path always evaluates the dense form, so such models agree with the reference to
@@ -313,6 +314,20 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->M_rownnz, m->M_rownnz, m->nv);
   copy_arr(H->M_rowadr, m->M_rowadr, m->nv);
   copy_arr(H->M_colind, m->M_colind, m->nC);
+  {
+    // column lists of M's strict lower triangle (see M_cscadr in mjh_types.h)
+    std::vector<std::vector<int>> col(m->nv);
+    for (int i = 0; i < m->nv; i++)
+      for (int k = 0; k < m->M_rownnz[i] - 1; k++) col[m->M_colind[m->M_rowadr[i] + k]].push_back(m->M_rowadr[i] + k);
+    H->M_cscadr.assign((size_t)m->nv + 1, 0);
+    H->M_cscind.assign((size_t)m->nC, 0);
+    int fill = 0;
+    for (int t = 0; t < m->nv; t++) {
+      H->M_cscadr[t] = fill;
+      for (int a : col[t]) H->M_cscind[fill++] = a;
+    }
+    H->M_cscadr[m->nv] = fill;
+  }
   copy_arr(H->geom_type, m->geom_type, m->ngeom);
   copy_arr(H->geom_bodyid, m->geom_bodyid, m->ngeom);
   copy_arr(H->geom_sameframe, m->geom_sameframe, m->ngeom);
@@ -904,6 +919,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->sensor_dim, m->sensor_dim, m->nsensor);
   copy_arr(H->sensor_adr, m->sensor_adr, m->nsensor);
   copy_arr(H->sensor_cutoff, m->sensor_cutoff, m->nsensor);
+  copy_arr(H->sensor_needstage, m->sensor_needstage, m->nsensor);
   H->sensor_intprm0.resize(m->nsensor);
   for (int i = 0; i < m->nsensor; i++) H->sensor_intprm0[i] = m->sensor_intprm[i*mjNSENS];
   // geoms a ray never sees: fully transparent colour or material (ray_eliminate, engine_ray.c:74-82)

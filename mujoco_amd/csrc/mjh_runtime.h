@@ -45,6 +45,7 @@
 #include "mjh_modes.h"
 
 #include <algorithm>
+#include <atomic>
 
 #ifndef MJHIP_DEFAULT_LAYOUT
 #define MJHIP_DEFAULT_LAYOUT MJHIP_LAYOUT_AOS
@@ -676,8 +677,9 @@ MJHIP_API int mjhip_batch_forward(mjhipBatch* Bt, int stages, void* stream) {
 }
 
 // mj_step1 / mj_step2 (engine_forward.c:1884, :1916): the step split around the point where a
-// controller may read positions / velocities and write ctrl.  Between the two calls every
-// intermediate lives in its global field (inspectable with mjhip_batch_get).
+// controller may read positions / velocities / position- and velocity-stage sensors and write ctrl
+// (mj_step1 ends with mj_sensorPos + mj_sensorVel; mj_sensorAcc runs inside mj_step2).  Between the two
+// calls every intermediate lives in its global field (inspectable with mjhip_batch_get).
 static int step_half(mjhipBatch_* Bt, int stages, const char* who, void* stream) {
   if (!Bt) return -1;
   { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
@@ -690,11 +692,11 @@ static int step_half(mjhipBatch_* Bt, int stages, const char* who, void* stream)
 }
 MJHIP_API int mjhip_batch_step1(mjhipBatch* Bt, void* stream) {
   return step_half(Bt, MJH_STAGE_CHECKPV | MJH_STAGE_KINEMATICS | MJH_STAGE_INERTIA | MJH_STAGE_COLLISION | MJH_STAGE_MAKE |
-                       MJH_STAGE_PROJECT | MJH_STAGE_TRANSMISSION | MJH_STAGE_VELOCITY | MJH_STAGE_REFERENCE,
+                       MJH_STAGE_PROJECT | MJH_STAGE_TRANSMISSION | MJH_STAGE_VELOCITY | MJH_STAGE_REFERENCE | MJH_STAGE_SENSPV,
                    "mjhip_batch_step1", stream);
 }
 MJHIP_API int mjhip_batch_step2(mjhipBatch* Bt, void* stream) {
-  return step_half(Bt, MJH_STAGE_ACTUATION | MJH_STAGE_CONSTRAINT | MJH_STAGE_FINISH | MJH_STAGE_SENSOR |
+  return step_half(Bt, MJH_STAGE_ACTUATION | MJH_STAGE_CONSTRAINT | MJH_STAGE_FINISH | MJH_STAGE_SENSACC |
                        MJH_STAGE_CHECKACC | MJH_STAGE_INTEGRATE, "mjhip_batch_step2", stream);
 }
 
@@ -915,7 +917,7 @@ struct RollEntry {
   mjhipBatch_* batch = nullptr;
   unsigned long long stamp = 0;
 };
-struct RollDevice { std::vector<RollEntry> cache; };
+struct RollDevice { std::vector<RollEntry> cache; std::mutex mu; };   // mu: one rollout call at a time per GPU
 struct RollJob {
   const mjModel* m = nullptr;
   std::vector<int> rows;       // rollout indices, ascending
@@ -924,9 +926,18 @@ struct RollJob {
   int ncap = 0, nuns = 0;
   std::string err;
 };
-static std::mutex g_roll_mu;
-static std::vector<RollDevice> g_roll_dev;
-static unsigned long long g_roll_stamp = 0;
+// Concurrency: concurrent mjhip_rollout calls serialise per GPU, not globally -- a call locks the
+// devices it uses in ascending order (no deadlock) and two calls on disjoint devices overlap.  The
+// device table has a fixed size so that its elements (and their mutexes) never move.
+enum { MJH_MAX_DEVICES = 64 };
+static RollDevice g_roll_dev[MJH_MAX_DEVICES];
+static std::atomic<unsigned long long> g_roll_stamp{0};
+// the caller's d[0] inputs, copied before any device thread starts: the thread that owns the last
+// rollout writes d[0] at its end while the others may still be seeding their batches
+struct RollSeed {
+  std::vector<real> ctrl, qfrc_applied, xfrc_applied, mocap_pos, mocap_quat, userdata;
+  std::vector<int> eq_active;
+};
 
 static bool same_model(const mjModel* a, const mjModel* b) {
   return a == b || (a->nbuffer == b->nbuffer && !memcmp(&a->opt, &b->opt, sizeof(a->opt)) &&
@@ -934,9 +945,10 @@ static bool same_model(const mjModel* a, const mjModel* b) {
 }
 
 MJHIP_API void mjhip_rollout_clear_cache(void) {
-  std::lock_guard<std::mutex> lock(g_roll_mu);
   std::string err;
-  for (size_t dv = 0; dv < g_roll_dev.size(); dv++) {
+  const int ndev_ = std::min((int)MJH_MAX_DEVICES, std::max(0, Backend::device_count()));
+  for (size_t dv = 0; dv < (size_t)ndev_; dv++) {
+    std::lock_guard<std::mutex> lock(g_roll_dev[dv].mu);
     Backend::set_device((int)dv, &err);
     for (auto& c : g_roll_dev[dv].cache) {
       if (c.batch) mjhip_batch_destroy(c.batch);
@@ -947,7 +959,7 @@ MJHIP_API void mjhip_rollout_clear_cache(void) {
 }
 
 // one job on its device (called from that device's host thread)
-static void roll_run_job(RollJob& J, struct mjData_* const* dp, int nbatch, int nstep, unsigned control_spec,
+static void roll_run_job(RollJob& J, const RollSeed& seed0, struct mjData_* const* dp, int nbatch, int nstep, unsigned control_spec,
                          const double* state0, const double* warmstart0, const double* control,
                          double* state, double* sensordata) {
   auto fail = [&](int rc, const std::string& msg) { J.rc = rc; J.err = msg; };
@@ -995,25 +1007,30 @@ static void roll_run_job(RollJob& J, struct mjData_* const* dp, int nbatch, int 
   // inputs of the control spec with no control array: the rollout steps with the caller's values
   // (the reference only clears inputs that are NOT in the spec, rollout.cc:85-115)
   mjData* d0 = (mjData*)dp[0];
-  if (!control && d0) {
-    auto seed = [&](const char* name, const mjtNum* src, int cnt) -> bool {
-      if (cnt <= 0 || !src) return true;
+  if (d0) {
+    auto seed = [&](const char* name, const std::vector<real>& src, int cnt) -> bool {
+      if (cnt <= 0 || (int)src.size() < cnt) return true;
       std::vector<real> rep((size_t)Bt->nenv*cnt);
-      for (int e = 0; e < Bt->nenv; e++) memcpy(rep.data() + (size_t)e*cnt, src, (size_t)cnt*sizeof(real));
+      for (int e = 0; e < Bt->nenv; e++) memcpy(rep.data() + (size_t)e*cnt, src.data(), (size_t)cnt*sizeof(real));
       return mjhip_batch_set(Bt, name, rep.data()) == 0;
     };
     bool ok = true;
-    if (control_spec & mjSTATE_CTRL) ok = ok && seed("ctrl", d0->ctrl, s.nu);
-    if (control_spec & mjSTATE_QFRC_APPLIED) ok = ok && seed("qfrc_applied", d0->qfrc_applied, s.nv);
-    if (control_spec & mjSTATE_XFRC_APPLIED) ok = ok && seed("xfrc_applied", d0->xfrc_applied, 6*s.nbody);
-    if (control_spec & mjSTATE_MOCAP_POS) ok = ok && seed("mocap_pos", d0->mocap_pos, 3*s.nmocap);
-    if (control_spec & mjSTATE_MOCAP_QUAT) ok = ok && seed("mocap_quat", d0->mocap_quat, 4*s.nmocap);
-    if (control_spec & mjSTATE_USERDATA) ok = ok && seed("userdata", d0->userdata, s.nuserdata);
-    if ((control_spec & mjSTATE_EQ_ACTIVE) && s.neq > 0) {
-      std::vector<int> rep((size_t)Bt->nenv*s.neq);
-      for (int e = 0; e < Bt->nenv; e++) for (int k = 0; k < s.neq; k++) rep[(size_t)e*s.neq + k] = d0->eq_active[k];
-      ok = ok && mjhip_batch_set(Bt, "eq_active", rep.data()) == 0;
+    if (!control) {
+      if (control_spec & mjSTATE_CTRL) ok = ok && seed("ctrl", seed0.ctrl, s.nu);
+      if (control_spec & mjSTATE_QFRC_APPLIED) ok = ok && seed("qfrc_applied", seed0.qfrc_applied, s.nv);
+      if (control_spec & mjSTATE_XFRC_APPLIED) ok = ok && seed("xfrc_applied", seed0.xfrc_applied, 6*s.nbody);
+      if (control_spec & mjSTATE_MOCAP_POS) ok = ok && seed("mocap_pos", seed0.mocap_pos, 3*s.nmocap);
+      if (control_spec & mjSTATE_MOCAP_QUAT) ok = ok && seed("mocap_quat", seed0.mocap_quat, 4*s.nmocap);
+      if ((control_spec & mjSTATE_EQ_ACTIVE) && s.neq > 0) {
+        std::vector<int> rep((size_t)Bt->nenv*s.neq);
+        for (int e = 0; e < Bt->nenv; e++) for (int k = 0; k < s.neq; k++) rep[(size_t)e*s.neq + k] = seed0.eq_active[(size_t)k];
+        ok = ok && mjhip_batch_set(Bt, "eq_active", rep.data()) == 0;
+      }
     }
+    // userdata: the reference never clears it (rollout.cc:85-115 has no userdata branch), so unless a
+    // control array supplies it every rollout steps with -- and d[0] ends with -- the caller's values;
+    // the cached batch may hold an earlier call's
+    if (!(control && (control_spec & mjSTATE_USERDATA))) ok = ok && seed("userdata", seed0.userdata, s.nuserdata);
     if (!ok) return fail(-5, g_mjhip_err);
   }
 
@@ -1092,6 +1109,7 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
   if (ndev_all <= 0) { set_err("mjhip: no HIP device visible -- libmjhip has no CPU fallback"); return -3; }
   int ndev = ndev_all;
   if (const char* ev = getenv("MJHIP_DEVICES")) ndev = std::max(1, std::min(ndev_all, atoi(ev)));
+  ndev = std::min(ndev, (int)MJH_MAX_DEVICES);
   const int home = Backend::current_device();
 
   // group the rollouts by model; sizes must agree (the caller's arrays have one row width)
@@ -1135,11 +1153,25 @@ MJHIP_API int mjhip_rollout(const struct mjModel_* const* mp, struct mjData_* co
     }
   }
 
-  std::lock_guard<std::mutex> lock(g_roll_mu);
-  if (g_roll_dev.size() < (size_t)ndev_all) g_roll_dev.resize((size_t)ndev_all);
+  // snapshot of the caller's d[0] inputs (see RollSeed)
+  RollSeed seed0;
+  if (const mjData* d0 = (const mjData*)dp[0]) {
+    auto snap = [](std::vector<real>& dst, const mjtNum* src, size_t cnt) { if (src && cnt) dst.assign(src, src + cnt); };
+    snap(seed0.ctrl, d0->ctrl, (size_t)m0->nu);
+    snap(seed0.qfrc_applied, d0->qfrc_applied, (size_t)m0->nv);
+    snap(seed0.xfrc_applied, d0->xfrc_applied, 6*(size_t)m0->nbody);
+    snap(seed0.mocap_pos, d0->mocap_pos, 3*(size_t)m0->nmocap);
+    snap(seed0.mocap_quat, d0->mocap_quat, 4*(size_t)m0->nmocap);
+    snap(seed0.userdata, d0->userdata, (size_t)m0->nuserdata);
+    if (d0->eq_active) for (int k = 0; k < m0->neq; k++) seed0.eq_active.push_back(d0->eq_active[k]);
+  }
   auto run_device = [&](int dev) {
+    bool any = false;
+    for (auto& J : jobs) if (J.device == dev) any = true;
+    if (!any) return;
+    std::lock_guard<std::mutex> lock(g_roll_dev[dev].mu);
     for (auto& J : jobs) if (J.device == dev)
-      roll_run_job(J, dp, nbatch, nstep, control_spec, state0, warmstart0, control, state, sensordata);
+      roll_run_job(J, seed0, dp, nbatch, nstep, control_spec, state0, warmstart0, control, state, sensordata);
   };
   int used = 0;
   for (int dv = 0; dv < ndev; dv++) for (auto& J : jobs) if (J.device == dv) { used++; break; }

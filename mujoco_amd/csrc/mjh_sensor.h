@@ -300,13 +300,16 @@ MJH_DEV void sens_rne_post(MREF M, BREF B, int e) {
     for (int q = 0; q < 6; q++) cint[6*M.body_parentid[j] + q] += cint[6*j + q];
 }
 
-MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
+// which: bit 0 = position-stage sensors (mj_sensorPos, engine_sensor.c:369), bit 1 = velocity stage
+// (mj_sensorVel, :640), bit 2 = acceleration stage (mj_sensorAcc, :868); a rollout step evaluates all
+// three at once, mj_step1 / mj_step2 split them around the controller call
+MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   if (!s.nsensor || (M.o.disableflags & (1<<13))) return;
   if (wv_lane() == 0) {
-    if (s.sens_subtreevel) sens_subtree_vel(M, B, e);
-    if (s.sens_rnepost) sens_rne_post(M, B, e);
+    if (s.sens_subtreevel && (which & 2)) sens_subtree_vel(M, B, e);
+    if (s.sens_rnepost && (which & 4)) sens_rne_post(M, B, e);
   }
   wv_sync();
   ciptr counts = MJH_F(B, counts, e);
@@ -315,6 +318,8 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_) {
   if (nefc) efc_layout(M, B, e, nefc, P);
   rptr out = MJH_G(B, sensordata, e);
   MJH_FOR_LANES(i, s.nsensor) {
+    // mjSTAGE_POS = 1, mjSTAGE_VEL = 2, mjSTAGE_ACC = 3 (mjtStage, include/mujoco/mjmodel.h)
+    if (!((which >> (M.sensor_needstage[i] - 1)) & 1)) continue;
     const int type = M.sensor_type[i], objtype = M.sensor_objtype[i], objid = M.sensor_objid[i];
     const int reftype = M.sensor_reftype[i], refid = M.sensor_refid[i];
     const int dim = M.sensor_dim[i];

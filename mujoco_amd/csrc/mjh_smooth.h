@@ -71,7 +71,7 @@ MJH_DEVN void stage_kinematics(MREF M_, BREF B_, int e_) {
       const int qadr = M.jnt_qposadr[j];
       const real angle = qpos[qadr] - M.qpos0[qadr];
       real sn = 0, cs = 2;
-      if (angle != 0) { sn = sin(angle*0.5); cs = cos(angle*0.5); }
+      if (angle != 0) r_sincos(angle*0.5, &sn, &cs);
       xanchor[3*j] = sn;
       xanchor[3*j + 1] = cs;
     }

@@ -182,6 +182,31 @@ MJH_DEV double sw_row_swap(double v) {
   return r;
 }
 
+// ---- ordered reductions: the reference sums in a FIXED sequential order (plain loops, or mju_dot's four
+// interleaved accumulators); these reproduce that order with the addends spread over lanes
+// init (+|-) v[lo] (+|-) v[lo+1] ... (+|-) v[hi-1], left to right (lo, hi wave-uniform)
+MJH_DEV double wv_chain(double init, double v, int lo, int hi, int sub) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = init;
+  for (int l = lo; l < hi; l++) r = sub ? r - w->dscratch[l] : r + w->dscratch[l];
+  mjhsim::yield();
+  return r;
+}
+// six chains at once: acc[q] += v[q] of lanes 0..n-1 in lane order
+MJH_DEV void wv_chain6(double* acc, const double* v, int n) {
+  for (int q = 0; q < 6; q++) acc[q] = wv_chain(acc[q], v[q], 0, n, 0);
+}
+// mju_dot's accumulators: r[c] += v[4g + c] for g = 0 .. ngroup-1, in order of g
+MJH_DEV void wv_dot4_acc(double* r, double v, int ngroup) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  for (int g = 0; g < ngroup; g++) for (int c = 0; c < 4; c++) r[c] += w->dscratch[4*g + c];
+  mjhsim::yield();
+}
+
 #else
 // ------------------------------------------------------------------------------------------------
 // CDNA4 device build
@@ -316,6 +341,33 @@ MJH_DEV double sw_row_swap(double v) {
   const u32x2_ h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   const bool x_is_own = (l.x == lo) && (h.x == hi);
   return __hiloint2double((int)(x_is_own ? h.y : h.x), (int)(x_is_own ? l.y : l.x));
+}
+
+// ---- ordered reductions: the reference sums in a FIXED sequential order (plain loops, or mju_dot's four
+// interleaved accumulators); these reproduce that order with the addends spread over lanes.  One
+// v_readlane pair + one dependent v_add_f64 per addend: a serial chain, but of register operands.
+MJH_DEV double wv_chain(double init, double v, int lo, int hi, int sub) {
+  double r = init;
+  if (sub) { for (int l = lo; l < hi; l++) r = r - wv_bcast(v, l); }
+  else { for (int l = lo; l < hi; l++) r = r + wv_bcast(v, l); }
+  return r;
+}
+// six chains at once (independent accumulators: the chains overlap in the pipeline)
+MJH_DEV void wv_chain6(double* acc, const double* v, int n) {
+  double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
+  for (int l = 0; l < n; l++) {
+    a0 += wv_bcast(v[0], l); a1 += wv_bcast(v[1], l); a2 += wv_bcast(v[2], l);
+    a3 += wv_bcast(v[3], l); a4 += wv_bcast(v[4], l); a5 += wv_bcast(v[5], l);
+  }
+  acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3; acc[4] = a4; acc[5] = a5;
+}
+// mju_dot's accumulators: r[c] += v[4g + c] for g = 0 .. ngroup-1, in order of g
+MJH_DEV void wv_dot4_acc(double* r, double v, int ngroup) {
+  double r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  for (int g = 0; g < ngroup; g++) {
+    r0 += wv_bcast(v, 4*g); r1 += wv_bcast(v, 4*g + 1); r2 += wv_bcast(v, 4*g + 2); r3 += wv_bcast(v, 4*g + 3);
+  }
+  r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
 }
 
 #endif  // MJH_HOSTSIM

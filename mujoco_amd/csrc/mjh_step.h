@@ -4,7 +4,8 @@
 
 
 // mocap poses back to the model's body_pos / body_quat (mj_resetData, engine_io.c)
-MJH_DEV void reset_mocap(MREF M, BREF B, int e) {
+// (positions and orientations are reset independently: rollout.cc:98-109 does so per control-spec bit)
+MJH_DEV void reset_mocap(MREF M, BREF B, int e, int do_pos = 1, int do_quat = 1) {
   const MJH_CONST_AS DSizes& s = M.s;
   if (!MJH_HAS(MJH_FT_MOCAP) || !s.nmocap) return;
   rptr mp = MJH_G(B, mocap_pos, e);
@@ -12,8 +13,8 @@ MJH_DEV void reset_mocap(MREF M, BREF B, int e) {
   MJH_FOR_LANES(i, s.nbody) {
     const int mid = M.body_mocapid[i];
     if (mid < 0) continue;
-    for (int k = 0; k < 3; k++) mp[3*mid + k] = M.body_pos[3*i + k];
-    for (int k = 0; k < 4; k++) mq[4*mid + k] = M.body_quat[4*i + k];
+    if (do_pos) for (int k = 0; k < 3; k++) mp[3*mid + k] = M.body_pos[3*i + k];
+    if (do_quat) for (int k = 0; k < 4; k++) mq[4*mid + k] = M.body_quat[4*i + k];
   }
 }
 
@@ -164,7 +165,8 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
-  if (MJH_HAS(MJH_FT_SENSOR) && (stages & MJH_STAGE_SENSOR) && M.s.nsensor) stage_sensors(M, B, e);
+  if (MJH_HAS(MJH_FT_SENSOR) && (stages & (MJH_STAGE_SENSOR | MJH_STAGE_SENSPV | MJH_STAGE_SENSACC)) && M.s.nsensor)
+    stage_sensors(M, B, e, (stages & MJH_STAGE_SENSOR) ? 7 : (((stages & MJH_STAGE_SENSPV) ? 3 : 0) | ((stages & MJH_STAGE_SENSACC) ? 4 : 0)));
 }
 
 // mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
@@ -666,7 +668,7 @@ MJH_DEV void rollout_clear_inputs(MREF M, BREF B, int e, const RolloutArgs& A) {
   if (!A.has_ctrl) { rptr c = MJH_F(B, ctrl, e); MJH_FOR_LANES(i, s.nu) c[i] = 0; }
   if (!A.has_qfrc) { rptr f = MJH_F(B, qfrc_applied, e); MJH_FOR_LANES(i, s.nv) f[i] = 0; }
   if (A.xfrc_off < 0) { rptr x = MJH_G(B, xfrc_applied, e); MJH_FOR_LANES(i, 6*s.nbody) x[i] = 0; }
-  if (A.mpos_off < 0 || A.mquat_off < 0) reset_mocap(M, B, e);
+  if (A.mpos_off < 0 || A.mquat_off < 0) reset_mocap(M, B, e, A.mpos_off < 0, A.mquat_off < 0);
   if (A.eq_off < 0) { iptr q = MJH_G(B, eq_active, e); MJH_FOR_LANES(i, s.neq) q[i] = M.eq_active0[i]; }
 }
 

@@ -54,6 +54,10 @@
   X(M_rownnz, s.nv)                            \
   X(M_rowadr, s.nv)                            \
   X(M_colind, s.nC)                            \
+  /* strict lower triangle of M by COLUMN: for dof t, the addresses (into M / M_colind) of the entries M[i][t], i > t, \
+     in ascending row order -- the order in which mju_mulSymVecSparse adds the upper-triangle terms to res[t] */ \
+  X(M_cscadr, s.nv + 1)                        \
+  X(M_cscind, s.nC)                            \
   X(geom_type, s.ngeom)                        \
   X(geom_bodyid, s.ngeom)                      \
   X(geom_sameframe, s.ngeom)                   \
@@ -70,6 +74,7 @@
   X(sensor_dim, s.nsensor)                     \
   X(sensor_adr, s.nsensor)                     \
   X(sensor_intprm0, s.nsensor)                 \
+  X(sensor_needstage, s.nsensor)               \
   X(geom_rayskip, s.ngeom)                     \
   X(tendon_num, s.ntendon)                     \
   X(tendon_limited, s.ntendon)                 \
@@ -642,6 +647,8 @@ enum {
   MJH_STAGE_CONSTRAINT = 1<<8,   // fwdConstraint (solve)
   MJH_STAGE_REFERENCE  = 1<<11,  // mj_referenceConstraint (efc_vel, efc_aref)
   MJH_STAGE_SENSOR     = 1<<12,  // mj_sensorPos/Vel/Acc (not part of MJH_STAGE_ALL: RK4 sub-steps skip it)
+  MJH_STAGE_SENSPV     = 1<<13,  // only the position- and velocity-stage sensors (mj_sensorPos + mj_sensorVel: tail of mj_step1)
+  MJH_STAGE_SENSACC    = 1<<14,  // only the acceleration-stage sensors (mj_sensorAcc: inside mj_step2)
   MJH_STAGE_IFACTIVE   = 1<<22,  // pipeline flag: skip environments whose `active` flag is 0
   MJH_STAGE_CHECKPV    = 1<<23,  // mj_checkPos + mj_checkVel first (head of mj_step1)
   MJH_STAGE_CHECKACC   = 1<<24,  // mj_checkAcc after the solve (mj_step2)

@@ -197,3 +197,9 @@ mjh_ctx_switch:
   ret
 .size mjh_ctx_switch, .-mjh_ctx_switch
 )");
+
+// test hook: the device's sine / cosine routine (mjh_math.h) compiled for the host -- its explicit fma
+// calls are correctly rounded on both sides, so this is bit for bit what the GPU evaluates
+extern "C" __attribute__((visibility("default"))) void mjh_test_sincos(int n, const double* x, double* sn, double* cs) {
+  for (int i = 0; i < n; i++) mjh_sincos(x[i], sn + i, cs + i);
+}

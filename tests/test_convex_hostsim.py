@@ -64,3 +64,30 @@ def test_cube_3x3x3_single_steps_vs_golden(hostsim_lib):
     assert np.array_equal(c[:, 5], fx["ints"][idx, 2])          # solver_niter
     ref = fx["next"][idx]
     assert np.max(np.abs(out[:, 0] - ref)/np.maximum(1.0, np.abs(ref))) <= 1e-9
+
+
+def test_device_sincos_within_one_ulp():
+    """mjh_sincos (mjh_math.h) -- what the kernels evaluate on the GPU instead of the device libm's
+    sin / cos -- against 200-bit references: < 1 ulp from |x| ~ 1e-8 to 1e10 (mjMAXVAL) and right
+    next to multiples of pi/2, where the three-piece Cody-Waite reduction has to carry ~60 extra bits.
+    Its explicit fma calls make it bit-reproducible between host and device, so this CPU test pins the
+    GPU's values too."""
+    import ctypes
+    mpmath = pytest.importorskip("mpmath")
+    from conftest import HOSTSIM_LIB
+    mpmath.mp.prec = 200
+    f = ctypes.CDLL(HOSTSIM_LIB).mjh_test_sincos
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-np.pi, np.pi, 1500), rng.uniform(-100, 100, 1000), rng.uniform(-1e6, 1e6, 500),
+                         rng.uniform(-1e10, 1e10, 500), rng.uniform(-1e-8, 1e-8, 200),
+                         np.arange(-200, 200)*(np.pi/2) + rng.normal(0, 1e-9, 400)])
+    s = np.zeros_like(xs); c = np.zeros_like(xs)
+    f(len(xs), xs.ctypes.data, s.ctypes.data, c.ctypes.data)
+    worst = 0.0
+    for x, si, ci in zip(xs, s, c):
+        rs, rc = mpmath.sin(mpmath.mpf(float(x))), mpmath.cos(mpmath.mpf(float(x)))
+        worst = max(worst, float(abs(mpmath.mpf(float(si)) - rs)/mpmath.mpf(float(np.spacing(abs(float(rs)))))),
+                    float(abs(mpmath.mpf(float(ci)) - rc)/mpmath.mpf(float(np.spacing(abs(float(rc)))))))
+    assert worst < 1.0, worst
+    assert np.abs(s - np.sin(xs)).max() <= 2.3e-16 and np.abs(c - np.cos(xs)).max() <= 2.3e-16

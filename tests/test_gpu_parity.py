@@ -960,4 +960,5 @@ def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
         assert b.get("counts")[e, 0] == k
         rc = d.contact[:k]
         assert np.array_equal(cg[e, :k], rc["geom"])
-        assert np.abs(cd[e, :k] - rc["dist"]).max() <= 1e-9 and np.abs(cp[e, :k] - rc["pos"]).max() <= 1e-9
+        if k:
+            assert np.abs(cd[e, :k] - rc["dist"]).max() <= 1e-9 and np.abs(cp[e, :k] - rc["pos"]).max() <= 1e-9

@@ -1052,6 +1052,41 @@ def test_step1_step2_split_bit_exact(rb, setup):
     assert b.get("warning").sum() == 0
 
 
+def test_step1_step2_sensors_between_the_halves(rb, hostsim_lib, tmp_path):
+    """mj_step1 ends with mj_sensorPos + mj_sensorVel (engine_forward.c:1884-1912), so a controller may
+    read position- and velocity-stage sensors between the halves; mj_sensorAcc runs inside mj_step2.
+    After step1 the pos/vel sensors hold THIS step's readings and the acc-stage ones still last
+    step's -- exactly the reference's sensordata, bit for bit, through a closed loop on a sensor"""
+    xml = tmp_path / "sens.xml"
+    xml.write_text(SENSOR_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    b = K.Batch(dm, 1)
+    b.set("qpos", np.array(d.qpos)[None]); b.set("qvel", np.array(d.qvel)[None])
+    stage = np.array(m.sensor_needstage)
+    adr, dim = np.array(m.sensor_adr), np.array(m.sensor_dim)
+    assert (stage == 1).any() and (stage == 2).any() and (stage == 3).any()
+    for t in range(25):
+        rb.mj_step1(m, d)
+        b.step1()
+        mid_ref, mid = np.array(d.sensordata), b.get("sensordata")[0]
+        assert np.array_equal(mid, mid_ref), t          # (acc-stage entries: both still hold the previous step's)
+        ctrl = np.clip(0.5*mid[:m.nu] - 0.1, -3, 3)     # the controller reads sensors written by step1
+        d.ctrl[:] = ctrl
+        b.set("ctrl", ctrl[None])
+        rb.mj_step2(m, d)
+        b.step2()
+        assert np.array_equal(b.get("sensordata")[0], np.array(d.sensordata)), t
+        assert np.array_equal(b.get("qpos")[0], np.array(d.qpos)) and np.array_equal(b.get("qvel")[0], np.array(d.qvel)), t
+        # the pos/vel readings changed during step1, the acc-stage ones during step2
+        for i in np.nonzero(stage == 3)[0][:1]:
+            sl = slice(adr[i], adr[i] + dim[i])
+            assert np.array_equal(mid_ref[sl], mid[sl])
+
+
 def _contact_lists_equal(rb, m, b, d, e=0):
     c = b.get("counts")[e]
     assert c[0] == d.ncon, (c[0], d.ncon)

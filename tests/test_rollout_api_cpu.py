@@ -353,3 +353,65 @@ def test_capacity_overflow_is_reported(rb, api, monkeypatch):
         rollout.rollout(m, d, s0, np.zeros((1, 3, m.nu)))
     monkeypatch.delenv("MJHIP_NCONMAX")
     mujoco_amd.lib().c.mjhip_rollout_clear_cache()
+
+
+def test_partial_mocap_spec_and_userdata_follow_the_reference(rb, hostsim_lib, monkeypatch, tmp_path):
+    """rollout.cc:98-109 resets mocap_pos and mocap_quat INDEPENDENTLY (each only when its bit is absent
+    from the control spec) and never touches userdata: with control=None and only MOCAP_POS in the spec,
+    the rollout steps with the caller's mocap_pos, the MODEL's mocap_quat and the caller's userdata --
+    also when an earlier call left other values in the cached device batch"""
+    monkeypatch.setattr(mujoco_amd, "lib", lambda: hostsim_lib)
+    xml = tmp_path / "user.xml"
+    xml.write_text(USER_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    nstep = 12
+    # an earlier call that leaves foreign userdata / mocap values in the cached batch
+    spec_all = rb.mjSTATE_USER
+    junk = np.zeros((1, 2, rb.mj_stateSize(m, spec_all)))
+    junk[..., -m.nuserdata:] = 7.0
+    junk[..., -m.nuserdata - 4:-m.nuserdata] = [0, 1, 0, 0]
+    junk[..., 1 + m.nv + 6*m.nbody:1 + m.nv + 6*m.nbody + m.neq] = 1
+    rollout.rollout(m, d, s0, junk, control_spec=spec_all)
+    # now: only MOCAP_POS in the spec, no control array
+    rb.mj_resetData(m, d)
+    d.mocap_pos[:] = [[.05, -.02, .45]]
+    d.mocap_quat[:] = [[0, 0, 1, 0]]             # must be reset to the model's (1,0,0,0)
+    d.userdata[:] = [1.5, -2.5, 3.5]             # must survive
+    spec = rb.mjSTATE_MOCAP_POS
+    state, _ = rollout.rollout(m, d, s0, nstep=nstep, control_spec=spec)
+    dd = rb.MjData(m)
+    rb.mj_resetData(m, dd)
+    rb.mj_setState(m, dd, s0[0], rb.mjSTATE_FULLPHYSICS)
+    dd.mocap_pos[:] = [[.05, -.02, .45]]
+    ref = np.zeros((nstep, s0.shape[1]))
+    for t in range(nstep):
+        rb.mj_step(m, dd)
+        ref[t] = rb.mj_getState(m, dd, rb.mjSTATE_FULLPHYSICS)
+    np.testing.assert_array_equal(state[0], ref)
+    np.testing.assert_array_equal(np.array(d.userdata), [1.5, -2.5, 3.5])
+    np.testing.assert_array_equal(np.array(d.mocap_quat), [[1, 0, 0, 0]])
+    np.testing.assert_array_equal(np.array(d.mocap_pos), [[.05, -.02, .45]])
+
+
+def test_rollout_shards_over_eight_devices_with_ragged_batch(rb, api, monkeypatch):
+    """BASELINE config 3's shape: 8 GPUs, a batch that does not divide by 8.  Every rollout is owned by
+    exactly one device piece (disjoint, covering row ranges), the outputs equal the serial reference
+    row by row, and d[0] holds the LAST rollout's final state whichever device stepped it"""
+    m, d, states, rng = api
+    nbatch, nstep = 19, 2
+    s0 = states(nbatch)
+    ctrl = rng.uniform(-1, 1, size=(nbatch, nstep, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    monkeypatch.setenv("MJH_HOSTSIM_DEVICES", "8")
+    monkeypatch.setenv("MJHIP_DEVICES", "8")
+    state = np.full((nbatch, nstep, s0.shape[1]), np.nan)
+    out, _ = rollout.rollout(m, d, s0, ctrl, state=state)
+    assert not np.isnan(out).any()                    # every row written by some piece
+    np.testing.assert_array_equal(out, ref)
+    np.testing.assert_array_equal(np.array(d.qpos), ref[-1, -1, 1:29])
+    # the partition mjhip_rollout uses (one contiguous piece per device: [n*k/8, n*(k+1)/8))
+    edges = [nbatch*k//8 for k in range(9)]
+    assert edges[0] == 0 and edges[-1] == nbatch and all(b > a for a, b in zip(edges, edges[1:]))

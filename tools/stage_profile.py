@@ -12,18 +12,21 @@ NAMES = ["begin", "kin", "collision", "compos", "tendon", "transmission", "tavel
          "passive", "rne", "crb", "factor", "actuation", "accel", "make", "project", "reference", "constraint",
          "finish", "euler", "end"]
 lib = ma.lib()
-model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", "humanoid.mjb"))
-model.set_option("solver", int(os.environ.get("SOLVER", "0")))     # 0 PGS, 1 CG, 2 Newton
+from bench import CONFIGS
+cfg = CONFIGS[os.environ.get("MODEL", "humanoid")]        # MODEL=cube: BASELINE config 4 as shipped (Newton, implicitfast)
+model = ma.MjbModel(lib, os.path.join(ROOT, "tests", "golden", cfg["mjb"]))
+if cfg["solver"] or "SOLVER" in os.environ:
+    model.set_option("solver", int(os.environ.get("SOLVER", "0")))     # 0 PGS, 1 CG, 2 Newton
 dm = ma.DeviceModel(lib, model)
-nenv = int(os.environ.get("NENV", 4096)); K = 100; W = 50
+nenv = int(os.environ.get("NENV", cfg["nenv"])); K = int(os.environ.get("K", 100)); W = int(os.environ.get("W", 50))
 b = ma.Batch(dm, nenv)
 print("variant", b.kernel_variant(), "|", b.lds_report().splitlines()[0])
-s0 = initial_states(b.get("qpos")[0], dm.nv, nenv, 1234)
+s0 = initial_states(b.get("qpos")[0], dm.nv, nenv, 1234, cfg["free_root"])
 rng = np.random.Generator(np.random.PCG64(4321))
 dev = torch.device("cuda", 0)
 st0 = torch.from_numpy(s0).to(dev)
-cw = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, W, dm.nu))).to(dev)
-ck = torch.from_numpy(rng.uniform(-1, 1, size=(nenv, K, dm.nu))).to(dev)
+cw = torch.from_numpy(rng.uniform(cfg["ctrl"][0], cfg["ctrl"][1], size=(nenv, W, dm.nu))).to(dev)
+ck = torch.from_numpy(rng.uniform(cfg["ctrl"][0], cfg["ctrl"][1], size=(nenv, K, dm.nu))).to(dev)
 
 b.rollout_device(W, ma.mjSTATE_CTRL, st0.data_ptr(), 0, cw.data_ptr(), 0, 0)
 b.sync()
