@@ -190,12 +190,16 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).
-      (1) every step of the run: the oracle is stepped from s0 with its own warm start; after every
-          step its state is compared with the GPU's and then re-synchronised to it, so the figure is
-          the per-step error of every step of the timed workload, not a chaotic accumulation;
-      (2) integer observables from IDENTICAL inputs: one more step from the run's final states with
-          the oracle's warm start handed to the GPU (`step_once`), where contact count, constraint
-          count and solver iteration count must agree exactly."""
+      (1) trajectory: the oracle is stepped from s0 with its own warm start; after every step its state
+          is compared with the GPU's and then re-synchronised to it (per-step error, not a chaotic
+          accumulation).  The warm start is NOT part of the rollout's state output, so the two engines
+          enter each step with warm starts that differ in the last bits: on a contact-rich stiff model
+          (cube_3x3x3) that alone can move a step's result by far more than 1e-6 -- reported, not gated;
+      (2) identical inputs, EVERY step of the run: each (state, the oracle's warm start, control) of (1) is
+          handed to the GPU for one mj_step (`step_once`, one batch of len(envs)*T environments); the next
+          state must agree within 1e-6 and contact count, constraint count and solver iteration count
+          exactly.  This is the north star's statement ("matches reference mj_step on identical inputs")
+          over the timed workload, and it decides `ok`."""
     try:
         from oracle import refbind as rb
         if not rb.available():
@@ -210,14 +214,16 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     spec = rb.mjSTATE_FULLPHYSICS
     worst, worst_at = 0.0, None
     T = ctrl.shape[1]
-    datas = []
+    pre_s, pre_w, pre_u, nxt, ints = [], [], [], [], []
     for k, e in enumerate(envs):
         d = rb.MjData(m)
         rb.mj_setState(m, d, s0[k], spec)
         for t in range(T):
+            pre_s.append(rb.mj_getState(m, d, spec)); pre_w.append(np.array(d.qacc_warmstart)); pre_u.append(ctrl[k, t])
             d.ctrl[:] = ctrl[k, t]
             rb.mj_step(m, d)
             ref = rb.mj_getState(m, d, spec)
+            nxt.append(ref); ints.append((int(d.ncon), int(d.nefc), int(d.solver_niter[0])))
             got = gpu_state[k, t]
             err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
             if not np.isfinite(err):
@@ -225,28 +231,22 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
             if err > worst:
                 worst, worst_at = err, (int(e), t)
             rb.mj_setState(m, d, got, spec)
-        datas.append(d)
-    # (2) one step from identical (state, warm start, control)
-    rng = np.random.Generator(np.random.PCG64(99))
-    ws = np.stack([np.array(d.qacc_warmstart) for d in datas])
-    u = rng.uniform(ctrl_range[0], ctrl_range[1], size=(len(envs), 1, ctrl.shape[2]))
-    got, counts = step_once(gpu_state[:, -1], ws, u)
-    nbad, worst1 = 0, 0.0
-    for k, d in enumerate(datas):
-        d.ctrl[:] = u[k, 0]
-        rb.mj_step(m, d)
-        ref = rb.mj_getState(m, d, spec)
-        worst1 = max(worst1, float(np.max(np.abs(got[k] - ref) / np.maximum(1.0, np.abs(ref)))))
-        c = counts[k]
-        if (int(c[0]), int(c[1]), int(c[5])) != (int(d.ncon), int(d.nefc), int(d.solver_niter[0])):
-            nbad += 1
-    return {"envs": len(envs), "steps_checked": T, "max_rel_err": worst, "worst_env_step": worst_at,
-            "tolerance": 1e-6, "identical_input_step": {"max_rel_err": worst1, "count_mismatches": nbad,
-                                                         "checked": "ncon, nefc, solver_niter exact"},
-            "ok": bool(worst <= 1e-6 and worst1 <= 1e-6 and nbad == 0),
-            "protocol": "oracle/_ref mj_step from the same state0/controls, compared after every step of "
-                        "warm-up + timed region and re-synchronised to the GPU state; then one step from "
-                        "identical (state, warm start, control) with exact integer observables"}
+    # (2) every step again from identical (state, warm start, control)
+    got, counts = step_once(np.array(pre_s), np.array(pre_w), np.array(pre_u)[:, None])
+    nxt, ints = np.array(nxt), np.array(ints)
+    worst1 = float(np.max(np.abs(got - nxt) / np.maximum(1.0, np.abs(nxt))))
+    nbad = int(np.sum((counts[:, 0] != ints[:, 0]) | (counts[:, 1] != ints[:, 1]) | (counts[:, 5] != ints[:, 2])))
+    return {"envs": len(envs), "steps_checked": T,
+            "identical_input_steps": {"steps": int(len(nxt)), "max_rel_err": worst1, "count_mismatches": nbad,
+                                      "checked": "next state within 1e-6; ncon, nefc, solver_niter exact",
+                                      "mean_ncon": float(ints[:, 0].mean()), "mean_nefc": float(ints[:, 1].mean()),
+                                      "mean_solver_iter": float(ints[:, 2].mean())},
+            "trajectory": {"max_rel_err": worst, "worst_env_step": worst_at, "within_tolerance": bool(worst <= 1e-6)},
+            "tolerance": 1e-6,
+            "ok": bool(worst1 <= 1e-6 and nbad == 0),
+            "protocol": "oracle/_ref mj_step from the same state0/controls over warm-up + timed region, re-synchronised to the "
+                        "GPU state after every step (trajectory); then every one of those steps re-run on the GPU from "
+                        "identical (state, warm start, control) with exact integer observables (identical_input_steps: decides ok)"}
 
 
 def main() -> None:
@@ -484,7 +484,7 @@ def main() -> None:
         gs = torch.cat([x.index_select(0, idx) for x in state_w + state_k], dim=1).cpu().numpy()
         cs = torch.cat([x.index_select(0, idx) for x in ctrl_w + ctrl_k], dim=1).cpu().numpy()
         def step_once(states, warm, u):
-            small = ma.Batch(dm, len(envs), device=local_rank)
+            small = ma.Batch(dm, len(states), device=local_rank)
             out = small.rollout_host(1, ma.mjSTATE_CTRL, states, warm, u)[:, 0]
             return out, small.get("counts")
 

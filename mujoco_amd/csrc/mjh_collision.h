@@ -1098,7 +1098,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
         real deepest = n > 1 ? r_min(ha.dist, hb.dist) : ha.dist;
 #if !MJH_LANE_MODE
         if (MJH_HAS(MJH_FT_COLCONVEX) && convex) {
-          const real* rec = ccd_out_records(M, B, e);
+          const crptr rec = ccd_out_records(M, B, e);
           deepest = rec[0];
           for (int k = 1; k < n; k++) deepest = r_min(deepest, rec[7*k]);
         }
@@ -1135,7 +1135,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
       const int c = base + before;
 #if !MJH_LANE_MODE
       if (MJH_HAS(MJH_FT_COLCONVEX) && convex) {
-        const real* rec = ccd_out_records(M, B, e);
+        const crptr rec = ccd_out_records(M, B, e);
         for (int k = 0; k < n; k++) {
           if (c + k >= s.nconmax) { overflow = 1; break; }
           Hit hx{rec[7*k], ld3(rec + 7*k + 1), ld3(rec + 7*k + 4), V3{0, 0, 0}};
@@ -1178,8 +1178,43 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     }
     nsurv += cnt;
   }
+  // position of the k-th set bit of m
+  auto kth_bit = [](unsigned long long m, int k) -> int {
+    int pos = 0;
+    for (int w = 32; w >= 1; w >>= 1) {
+      const int c = __builtin_popcountll(m & ((1ull << w) - 1));
+      if (k >= c) { k -= c; m >>= w; pos += w; }
+    }
+    return pos;
+  };
+  const int nchunk = (s.npair + MJH_W - 1)/MJH_W;
   if (nsurv <= MJH_W) {
     if (nsurv > 0) narrow(mine);
+  } else if (2*nchunk <= B.n_iscratch) {
+    // more survivors than lanes (contact-rich scenes: the 3x3x3 cube has ~200 of 325 pairs in reach): the
+    // chunks' survivor ballots are parked, then the survivors are dealt to the lanes in pair order, a full
+    // wavefront per narrowphase round -- the colliders (GJK / EPA above all) run with every lane busy
+    // instead of once per chunk of the static pair list with whatever that chunk happens to hold
+    iptr park = MJH_G(B, iscratch, e);
+    int total = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+      const unsigned long long m = wv_ballot(passes_filter(ch*MJH_W + wv_lane()));
+      if (wv_lane() == 0) { park[2*ch] = (int)(unsigned)m; park[2*ch + 1] = (int)(unsigned)(m >> 32); }
+      total += __builtin_popcountll(m);
+    }
+    wv_sync();
+    for (int r0 = 0; r0 < total; r0 += MJH_W) {
+      int k = r0 + wv_lane(), pick = -1;
+      if (k < total) {
+        for (int ch = 0; ch < nchunk; ch++) {
+          const unsigned long long m = ((unsigned long long)(unsigned)park[2*ch + 1] << 32) | (unsigned)park[2*ch];
+          const int cnt = __builtin_popcountll(m);
+          if (k < cnt) { pick = ch*MJH_W + kth_bit(m, k); break; }
+          k -= cnt;
+        }
+      }
+      narrow(pick);
+    }
   } else
 #endif
   for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {

@@ -13,10 +13,14 @@
 // vertices and its hill-climbing support touches 3-5 of them, an EPA run visits ~10 faces -- there is
 // nothing for 64 lanes to share, and the pairs would queue behind each other.
 //
-// State: every lane owns a private block of the batch's `ccd_ws` workspace (global memory; sized by
+// State: every lane owns a private slice of the batch's `ccd_ws` workspace (global memory; sized by
 // the model: opt.ccd_iterations, npolygonmax, nmeshdegmax): the two objects, the GJK simplex, the
 // EPA polytope (vertices, faces, the face map, the horizon) and, overlaid on the polytope once EPA
-// is done, the face-clipping buffers.  Nothing here touches LDS or other lanes.
+// is done, the face-clipping buffers.  The slices of an environment's 64 lanes are INTERLEAVED word
+// by word (word w of lane l at [w][l]): lanes that touch the same slot -- object frames, the early
+// simplex / polytope entries, the clipping buffers: most of the traffic -- read and write one
+// contiguous 512-byte row instead of 64 cache lines 20 KB apart (measured on the cube: the latter
+// made the narrowphase L1-throughput bound).  Nothing here touches LDS or other lanes.
 //
 // Arithmetic follows the reference expression by expression (association, comparison direction,
 // first-wins tie rules), which is what makes contact counts and iteration counts agree exactly.
@@ -42,22 +46,22 @@ enum { CV_NREAL = 9, CV_NINT = 2 };
 enum { CF_NREAL = 4, CF_NINT = 5 };
 enum { CCD_MAXWIT = 4, CCD_MAXOUT = 5 };
 
-struct CcdObj { real* r; int* i; };
-struct CcdVtx { real* r; int* i; };
+struct CcdObj { rptr r; iptr i; };
+struct CcdVtx { rptr r; iptr i; };
 
 // the lane's workspace, carved up (host mirror of the sizes: mjh_model_build.h ccd_sizes)
 struct Ccd {
   CcdObj o1, o2;
-  real *x1, *x2, *dist;            // witness points / distances (CCD_MAXWIT)
-  real* simr; int* simi;           // GJK simplex: 4 vertices
-  real* tmpr; int* tmpi;           // scratch: 5 vertices (gjkIntersect's copy + the final separation probe)
-  real* out;                       // contacts handed back: CCD_MAXOUT x (dist, pos[3], normal[3])
-  real* vr; int* vi;               // polytope vertices
-  real* fr; int* fi;               // polytope faces
-  int* map;                        // face map
-  int *hidx, *hedge;               // horizon
-  int* stack;                      // horizon depth-first stack
-  real* mcr; int* mci;             // multicontact buffers (overlay the polytope)
+  rptr x1, x2, dist;               // witness points / distances (CCD_MAXWIT)
+  rptr simr; iptr simi;            // GJK simplex: 4 vertices
+  rptr tmpr; iptr tmpi;            // scratch: 5 vertices (gjkIntersect's copy + the final separation probe)
+  rptr out;                        // contacts handed back: CCD_MAXOUT x (dist, pos[3], normal[3])
+  rptr vr; iptr vi;                // polytope vertices
+  rptr fr; iptr fi;                // polytope faces
+  iptr map;                        // face map
+  iptr hidx, hedge;                // horizon
+  iptr stack;                      // horizon depth-first stack
+  rptr mcr; iptr mci;              // multicontact buffers (overlay the polytope)
   // configuration / status scalars
   int N, P, D;                     // ccd_iterations, polygon size bound, vertex degree bound
   int maxfaces, maxhorizon;
@@ -70,7 +74,7 @@ struct Ccd {
   V3 horizon_w;
 };
 
-MJH_DEV CcdVtx ccd_vtx(real* r, int* i, int k) { return CcdVtx{r + CV_NREAL*k, i + CV_NINT*k}; }
+MJH_DEV CcdVtx ccd_vtx(rptr r, iptr i, int k) { return CcdVtx{r + CV_NREAL*k, i + CV_NINT*k}; }
 MJH_DEV void ccd_vcopy(CcdVtx d, CcdVtx s) {
   for (int k = 0; k < CV_NREAL; k++) d.r[k] = s.r[k];
   d.i[0] = s.i[0]; d.i[1] = s.i[1];
@@ -81,18 +85,21 @@ MJH_DEV real ccd_norm(V3 v) { return sqrt(dot(v, v)); }
 MJH_DEV real ccd_abs(real x) { return fabs(x); }
 
 // mat' * dir and mat * l + pos (mulMatTVec3 / localToGlobal, engine_collision_convex.c:179-197)
-MJH_DEV V3 ccd_to_local(const real* mat, V3 d) {
+template <class PM> MJH_DEV V3 ccd_to_local(PM mat, V3 d) {
   return V3{mat[0]*d.x + mat[3]*d.y + mat[6]*d.z, mat[1]*d.x + mat[4]*d.y + mat[7]*d.z, mat[2]*d.x + mat[5]*d.y + mat[8]*d.z};
 }
-MJH_DEV V3 ccd_to_global(const real* mat, V3 l, const real* pos) {
+template <class PM, class PP> MJH_DEV V3 ccd_to_global(PM mat, V3 l, PP pos) {
   V3 r{mat[0]*l.x + mat[1]*l.y + mat[2]*l.z, mat[3]*l.x + mat[4]*l.y + mat[5]*l.z, mat[6]*l.x + mat[7]*l.y + mat[8]*l.z};
   r.x += pos[0]; r.y += pos[1]; r.z += pos[2];
   return r;
 }
 // globalcoord (engine_collision_gjk.c:1756): mat * (l1,l2,l3) (+ pos)
-MJH_DEV V3 ccd_globalcoord(const real* mat, const real* pos, real l1, real l2, real l3) {
-  V3 r{mat[0]*l1 + mat[1]*l2 + mat[2]*l3, mat[3]*l1 + mat[4]*l2 + mat[5]*l3, mat[6]*l1 + mat[7]*l2 + mat[8]*l3};
-  if (pos) { r.x += pos[0]; r.y += pos[1]; r.z += pos[2]; }
+template <class PM> MJH_DEV V3 ccd_globalrot(PM mat, real l1, real l2, real l3) {
+  return V3{mat[0]*l1 + mat[1]*l2 + mat[2]*l3, mat[3]*l1 + mat[4]*l2 + mat[5]*l3, mat[6]*l1 + mat[7]*l2 + mat[8]*l3};
+}
+template <class PM, class PP> MJH_DEV V3 ccd_globalcoord(PM mat, PP pos, real l1, real l2, real l3) {
+  V3 r = ccd_globalrot(mat, l1, l2, l3);
+  r.x += pos[0]; r.y += pos[1]; r.z += pos[2];
   return r;
 }
 MJH_DEV real ccd_dot3f(MREF M, V3 a, int vbase) {
@@ -100,8 +107,8 @@ MJH_DEV real ccd_dot3f(MREF M, V3 a, int vbase) {
 }
 
 // ---- support functions (engine_collision_convex.c:201-460) ------------------------------------------
-MJH_DEVN_HOT void ccd_obj_support(MREF M, CcdObj o, V3 dir, real* res) {
-  const real* pos = o.r + CO_POS; const real* mat = o.r + CO_MAT; const real* size = o.r + CO_SIZE;
+MJH_DEVN_HOT void ccd_obj_support(MREF M, CcdObj o, V3 dir, rptr res) {
+  const crptr pos = o.r + CO_POS; const crptr mat = o.r + CO_MAT; const crptr size = o.r + CO_SIZE;
   V3 out;
   switch (o.i[CI_SUP]) {
     case CCD_SUP_POINT: out = ld3(pos); break;
@@ -258,7 +265,7 @@ MJH_DEV V3 ccd_lincomb3(const real* l, V3 a, V3 b, V3 d) {
   return V3{l[0]*a.x + l[1]*b.x + l[2]*d.x, l[0]*a.y + l[1]*b.y + l[2]*d.y, l[0]*a.z + l[1]*b.z + l[2]*d.z};
 }
 // lincomb (:475): n-term combination of the rows of a vertex array (row stride `st`, column offset in p)
-MJH_DEV V3 ccd_lincomb(const real* l, int n, const real* p, int st) {
+template <class PV> MJH_DEV V3 ccd_lincomb(const real* l, int n, PV p, int st) {
   V3 r{0, 0, 0};
   if (n == 1) r = V3{l[0]*p[0], l[0]*p[1], l[0]*p[2]};
   else if (n == 2) r = ccd_lincomb2(l, ld3(p), ld3(p + st));
@@ -288,7 +295,7 @@ MJH_DEV int ccd_project_plane(V3& res, V3 v1, V3 v2, V3 v3) {
   return 0;
 }
 
-MJH_DEVN_HOT void ccd_S1D(real* lambda, const real* s1, const real* s2) {
+MJH_DEVN_HOT void ccd_S1D(real* lambda, crptr s1, crptr s2) {
   // projectOriginLine (:548)
   const V3 a = ld3(s1), b = ld3(s2);
   const V3 diff = b - a;
@@ -307,7 +314,7 @@ MJH_DEVN_HOT void ccd_S1D(real* lambda, const real* s1, const real* s2) {
   lambda[1] = same ? C2/mu_max : 1;
 }
 
-MJH_DEVN_HOT void ccd_S2D(real* lambda, const real* p1, const real* p2, const real* p3) {
+MJH_DEVN_HOT void ccd_S2D(real* lambda, crptr p1, crptr p2, crptr p3) {
   const V3 s1 = ld3(p1), s2 = ld3(p2), s3 = ld3(p3);
   V3 po;
   if (ccd_project_plane(po, s1, s2, s3)) {
@@ -361,7 +368,7 @@ MJH_DEVN_HOT void ccd_S2D(real* lambda, const real* p1, const real* p2, const re
   }
 }
 
-MJH_DEVN_HOT void ccd_S3D(real* lambda, const real* p1, const real* p2, const real* p3, const real* p4) {
+MJH_DEVN_HOT void ccd_S3D(real* lambda, crptr p1, crptr p2, crptr p3, crptr p4) {
   const V3 s1 = ld3(p1), s2 = ld3(p2), s3 = ld3(p3), s4 = ld3(p4);
   const real C41 = -ccd_det3(s2, s3, s4);
   const real C42 = ccd_det3(s1, s3, s4);
@@ -414,7 +421,7 @@ MJH_DEV int ccd_discrete(const Ccd& c) {
 }
 
 // signedDistance (:409)
-MJH_DEV real ccd_signed_distance(V3& normal, const real* v1, const real* v2, const real* v3) {
+MJH_DEV real ccd_signed_distance(V3& normal, crptr v1, crptr v2, crptr v3) {
   const V3 a = ld3(v1);
   const V3 diff1 = ld3(v3) - a, diff2 = ld3(v2) - a;
   normal = cross(diff1, diff2);
@@ -554,8 +561,8 @@ MJH_DEV V3 ccd_pv(const Ccd& c, int v) { return ld3(c.vr + CV_NREAL*v); }
 // attachFace (:1254): squared distance of the new face to the origin
 MJH_DEVN_HOT real ccd_attach_face(Ccd& c, int v1, int v2, int v3, int adj1, int adj2, int adj3) {
   const int f = c.nfaces++;
-  int* fi = c.fi + CF_NINT*f;
-  real* fr = c.fr + CF_NREAL*f;
+  const iptr fi = c.fi + CF_NINT*f;
+  const rptr fr = c.fr + CF_NREAL*f;
   fi[0] = v1 + (v2 << 10) + (v3 << 20);
   fi[1] = adj1; fi[2] = adj2; fi[3] = adj3;
   V3 fv;
@@ -714,7 +721,7 @@ MJH_DEVN_HOT int ccd_polytope4(MREF M, Ccd& c) {
 }
 
 MJH_DEV void ccd_delete_face(Ccd& c, int f) {
-  int* fi = c.fi + CF_NINT*f;
+  const iptr fi = c.fi + CF_NINT*f;
   if (fi[4] >= 0) {
     c.map[fi[4]] = c.map[--c.nmap];
     c.fi[CF_NINT*c.map[fi[4]] + 4] = fi[4];
@@ -743,7 +750,7 @@ MJH_DEVN_HOT int ccd_horizon_rec(Ccd& c, int face0, int e0) {
     const int face = c.stack[2*sp];
     const int e = c.stack[2*sp + 1] & 0xff;
     int k = c.stack[2*sp + 1] >> 8;
-    const int* fi = c.fi + CF_NINT*face;
+    const ciptr fi = c.fi + CF_NINT*face;
     if (returning) {
       // child of edge slot k-1 came back
       returning = 0;
@@ -753,7 +760,7 @@ MJH_DEVN_HOT int ccd_horizon_rec(Ccd& c, int face0, int e0) {
         ccd_add_edge(c, adj, ccd_get_edge(c, adj, ccd_face_vert(c, face, (i + 1) % 3)));
       }
     } else if (k == 0) {
-      const real* fr = c.fr + CF_NREAL*face;
+      const crptr fr = c.fr + CF_NREAL*face;
       if (!(dot(ld3(fr), c.horizon_w) - fr[3] > MJH_MINVAL)) { result = 0; returning = 1; sp--; continue; }
       ccd_delete_face(c, face);
       k = 1;
@@ -782,7 +789,7 @@ MJH_DEVN_HOT int ccd_horizon_rec(Ccd& c, int face0, int e0) {
 // horizon (:1322)
 MJH_DEV void ccd_horizon(Ccd& c, int face) {
   ccd_delete_face(c, face);
-  const int* fi = c.fi + CF_NINT*face;
+  const ciptr fi = c.fi + CF_NINT*face;
   int adj = fi[1];
   int adj_edge = ccd_get_edge(c, adj, ccd_face_vert(c, face, 1));
   if (!ccd_horizon_rec(c, adj, adj_edge)) ccd_add_edge(c, adj, adj_edge);
@@ -883,7 +890,7 @@ MJH_DEV real ccd_area4(V3 a, V3 b, V3 c, V3 d) {
   return 0.5*ccd_norm(g);
 }
 // polygonQuad (:1523): indices of a maximum-area quadrilateral of a convex polygon
-MJH_DEV void ccd_polygon_quad(int* res, const real* polygon, int nvert) {
+MJH_DEV void ccd_polygon_quad(int* res, crptr polygon, int nvert) {
   auto P = [&](int i) { return ld3(polygon + 3*i); };
   auto nxt = [&](int i) { return i == nvert - 1 ? 0 : i + 1; };
   int a = 0, b = 1, cc = 2, d = 3;
@@ -921,7 +928,7 @@ MJH_DEV void ccd_polygon_quad(int* res, const real* polygon, int nvert) {
   }
 }
 // witnessOnFace (:1605)
-MJH_DEV real ccd_witness_on_face(real* w1, real* w2, V3 v, V3 p, V3 n, V3 dir) {
+MJH_DEV real ccd_witness_on_face(rptr w1, rptr w2, V3 v, V3 p, V3 n, V3 dir) {
   const V3 d = v - p;
   const real dist = dot(d, n);
   const real s = -ccd_abs(dist);
@@ -931,14 +938,14 @@ MJH_DEV real ccd_witness_on_face(real* w1, real* w2, V3 v, V3 p, V3 n, V3 dir) {
 }
 
 // polygonClip (:1617): clip face2 against the side planes of face1 (Sutherland-Hodgman)
-MJH_DEVN_HOT void ccd_polygon_clip(Ccd& c, const real* face1, int nface1, const real* face2, int nface2, V3 n, V3 dir,
-                                   real* buffer) {
+MJH_DEVN_HOT void ccd_polygon_clip(Ccd& c, crptr face1, int nface1, crptr face2, int nface2, V3 n, V3 dir,
+                                   rptr buffer) {
   if (nface1 < 3) return;
   const int P = c.P;
-  real* polygon = buffer;
-  real* clipped = polygon + 6*P;
-  real* pn = clipped + 6*P;
-  real* pd = pn + 3*P;
+  rptr polygon = buffer;
+  rptr clipped = polygon + 6*P;
+  const rptr pn = clipped + 6*P;
+  const rptr pd = pn + 3*P;
   // planeNormal (:1581) of every edge of face1
   for (int i = 0; i < nface1; i++) {
     const V3 v1 = ld3(face1 + 3*i), v2 = ld3(face1 + 3*(i < nface1 - 1 ? i + 1 : 0));
@@ -970,7 +977,7 @@ MJH_DEVN_HOT void ccd_polygon_clip(Ccd& c, const real* face1, int nface1, const 
       }
       if (inside2) { if (nclipped < 2*P) st3(clipped + 3*nclipped, Q); nclipped++; }
     }
-    real* t = polygon; polygon = clipped; clipped = t;
+    const rptr t = polygon; polygon = clipped; clipped = t;
     npolygon = nclipped < 2*P ? nclipped : 2*P;
     nclipped = 0;
   }
@@ -1037,10 +1044,10 @@ MJH_DEV int ccd_intersect_arr(MREF M, int* res, const int* arr1, int n, int adr2
 }
 MJH_DEV V3 ccd_polynormal(MREF M, CcdObj o, int poly) {
   const int base = 3*(M.mesh_polyadr[o.i[CI_MESH]] + poly);
-  return ccd_globalcoord(o.r + CO_MAT, nullptr, M.mesh_polynormal[base], M.mesh_polynormal[base + 1], M.mesh_polynormal[base + 2]);
+  return ccd_globalrot(o.r + CO_MAT, M.mesh_polynormal[base], M.mesh_polynormal[base + 1], M.mesh_polynormal[base + 2]);
 }
 // meshNormals (:1787)
-MJH_DEV int ccd_mesh_normals(MREF M, const Ccd& c, real* res, int* resind, int dim, CcdObj o, const int* vi) {
+MJH_DEV int ccd_mesh_normals(MREF M, const Ccd& c, rptr res, iptr resind, int dim, CcdObj o, const int* vi) {
   const int vadr = M.mesh_vertadr[o.i[CI_MESH]];
   const int a1 = M.mesh_polymapadr[vadr + vi[0]], n1 = M.mesh_polymapnum[vadr + vi[0]];
   if (dim == 3) {
@@ -1075,7 +1082,7 @@ MJH_DEV int ccd_mesh_normals(MREF M, const Ccd& c, real* res, int* resind, int d
   return 0;
 }
 // meshEdgeNormals (:1852)
-MJH_DEV int ccd_mesh_edge_normals(MREF M, const Ccd& c, real* res, real* endverts, int dim, CcdObj o, const real* v, int v1i) {
+MJH_DEV int ccd_mesh_edge_normals(MREF M, const Ccd& c, rptr res, rptr endverts, int dim, CcdObj o, const real* v, int v1i) {
   const V3 v1 = ld3(v), v2 = ld3(v + 3);
   if (dim == 2) {
     st3(endverts, v2);
@@ -1111,13 +1118,13 @@ MJH_DEV int ccd_mesh_edge_normals(MREF M, const Ccd& c, real* res, real* endvert
   return 0;
 }
 // boxNormals2 (:1898)
-MJH_DEV int ccd_box_normals2(real* res, int* resind, const real* mat, V3 n) {
+MJH_DEV int ccd_box_normals2(rptr res, iptr resind, crptr mat, V3 n) {
   V3 ln{mat[0]*n.x + mat[3]*n.y + mat[6]*n.z, mat[1]*n.x + mat[4]*n.y + mat[7]*n.z, mat[2]*n.x + mat[5]*n.y + mat[8]*n.z};
   ln = ccd_scl(ln, 1/sqrt(dot(ln, ln)));
   for (int i = 0; i < 6; i++) {
     const V3 nr = with_comp(V3{0, 0, 0}, i >> 1, (i & 1) ? -1 : 1);
     if (dot(ln, nr) > MJH_CCD_FACE_TOL) {
-      st3(res, ccd_globalcoord(mat, nullptr, nr.x, nr.y, nr.z));
+      st3(res, ccd_globalrot(mat, nr.x, nr.y, nr.z));
       resind[0] = i;
       return 1;
     }
@@ -1125,15 +1132,15 @@ MJH_DEV int ccd_box_normals2(real* res, int* resind, const real* mat, V3 n) {
   return 0;
 }
 // boxNormals (:1924)
-MJH_DEV int ccd_box_normals(real* res, int* resind, int dim, CcdObj o, const int* vi, V3 dir) {
+MJH_DEV int ccd_box_normals(rptr res, iptr resind, int dim, CcdObj o, const int* vi, V3 dir) {
   const int v1 = vi[0], v2 = vi[1], v3 = vi[2];
-  const real* mat = o.r + CO_MAT;
+  const crptr mat = o.r + CO_MAT;
   if (dim == 3) {
     int cn = 0;
     const int x = ((v1 & 1) && (v2 & 1) && (v3 & 1)) - (!(v1 & 1) && !(v2 & 1) && !(v3 & 1));
     const int y = ((v1 & 2) && (v2 & 2) && (v3 & 2)) - (!(v1 & 2) && !(v2 & 2) && !(v3 & 2));
     const int z = ((v1 & 4) && (v2 & 4) && (v3 & 4)) - (!(v1 & 4) && !(v2 & 4) && !(v3 & 4));
-    st3(res, ccd_globalcoord(mat, nullptr, x, y, z));
+    st3(res, ccd_globalrot(mat, x, y, z));
     const int sgn = x + y + z;
     if (x) resind[cn++] = 0;
     if (y) resind[cn++] = 2;
@@ -1146,16 +1153,16 @@ MJH_DEV int ccd_box_normals(real* res, int* resind, int dim, CcdObj o, const int
     const int x = ((v1 & 1) && (v2 & 1)) - (!(v1 & 1) && !(v2 & 1));
     const int y = ((v1 & 2) && (v2 & 2)) - (!(v1 & 2) && !(v2 & 2));
     const int z = ((v1 & 4) && (v2 & 4)) - (!(v1 & 4) && !(v2 & 4));
-    if (x) { st3(res, ccd_globalcoord(mat, nullptr, x, 0, 0)); resind[cn++] = (x > 0) ? 0 : 1; }
-    if (y) { st3(res + 3*cn, ccd_globalcoord(mat, nullptr, 0, y, 0)); resind[cn++] = (y > 0) ? 2 : 3; }
-    if (z) { st3(res + 3, ccd_globalcoord(mat, nullptr, 0, 0, z)); resind[cn++] = (z > 0) ? 4 : 5; }
+    if (x) { st3(res, ccd_globalrot(mat, x, 0, 0)); resind[cn++] = (x > 0) ? 0 : 1; }
+    if (y) { st3(res + 3*cn, ccd_globalrot(mat, 0, y, 0)); resind[cn++] = (y > 0) ? 2 : 3; }
+    if (z) { st3(res + 3, ccd_globalrot(mat, 0, 0, z)); resind[cn++] = (z > 0) ? 4 : 5; }
     return cn == 2 ? 2 : ccd_box_normals2(res, resind, mat, dir);
   }
   if (dim == 1) {
     const real x = (v1 & 1) ? 1 : -1, y = (v1 & 2) ? 1 : -1, z = (v1 & 4) ? 1 : -1;
-    st3(res, ccd_globalcoord(mat, nullptr, x, 0, 0));
-    st3(res + 3, ccd_globalcoord(mat, nullptr, 0, y, 0));
-    st3(res + 6, ccd_globalcoord(mat, nullptr, 0, 0, z));
+    st3(res, ccd_globalrot(mat, x, 0, 0));
+    st3(res + 3, ccd_globalrot(mat, 0, y, 0));
+    st3(res + 6, ccd_globalrot(mat, 0, 0, z));
     resind[0] = (x > 0) ? 0 : 1;
     resind[1] = (y > 0) ? 2 : 3;
     resind[2] = (z > 0) ? 4 : 5;
@@ -1164,9 +1171,9 @@ MJH_DEV int ccd_box_normals(real* res, int* resind, int dim, CcdObj o, const int
   return 0;
 }
 // boxEdgeNormals (:1973)
-MJH_DEV int ccd_box_edge_normals(real* res, real* endverts, int dim, CcdObj o, const real* v, int v1i) {
+MJH_DEV int ccd_box_edge_normals(rptr res, rptr endverts, int dim, CcdObj o, const real* v, int v1i) {
   const V3 v1 = ld3(v), v2 = ld3(v + 3);
-  const real* mat = o.r + CO_MAT; const real* pos = o.r + CO_POS; const real* size = o.r + CO_SIZE;
+  const crptr mat = o.r + CO_MAT; const crptr pos = o.r + CO_POS; const crptr size = o.r + CO_SIZE;
   if (dim == 2) {
     st3(endverts, v2);
     V3 r = v2 - v1;
@@ -1190,8 +1197,8 @@ MJH_DEV int ccd_box_edge_normals(real* res, real* endverts, int dim, CcdObj o, c
   return 0;
 }
 // boxFace (:2011): the four corners of face idx, counter-clockwise seen from outside
-MJH_DEV int ccd_box_face(real* res, CcdObj o, int idx) {
-  const real* mat = o.r + CO_MAT; const real* pos = o.r + CO_POS; const real* size = o.r + CO_SIZE;
+MJH_DEV int ccd_box_face(rptr res, CcdObj o, int idx) {
+  const crptr mat = o.r + CO_MAT; const crptr pos = o.r + CO_POS; const crptr size = o.r + CO_SIZE;
   // sign patterns (x, y, z) of the four corners of each face, in the reference's order
   const signed char pat[6][4][3] = {
     {{1, 1, 1}, {1, 1, -1}, {1, -1, -1}, {1, -1, 1}},
@@ -1207,7 +1214,7 @@ MJH_DEV int ccd_box_face(real* res, CcdObj o, int idx) {
   return 4;
 }
 // meshFace (:2068): polygon idx in reverse vertex order
-MJH_DEV int ccd_mesh_face(MREF M, const Ccd& c, real* res, CcdObj o, int idx) {
+MJH_DEV int ccd_mesh_face(MREF M, const Ccd& c, rptr res, CcdObj o, int idx) {
   const int mesh = o.i[CI_MESH];
   const int vadr = M.mesh_vertadr[mesh], padr = M.mesh_polyadr[mesh];
   const int adr = M.mesh_polyvertadr[padr + idx];
@@ -1245,9 +1252,9 @@ MJH_DEVN_HOT void ccd_multicontact(MREF M, Ccd& c, int face) {
   }
   // buffers (overlay the polytope, whose data was saved above)
   const int D = c.D, P = c.P;
-  int* idx1 = c.mci; int* idx2 = idx1 + D;
-  real* n1 = c.mcr; real* n2 = n1 + 3*D; real* endverts = n2 + 3*D;
-  real* face1 = endverts + 3*D; real* face2 = face1 + 3*P; real* polygon = face2 + 3*P;
+  const iptr idx1 = c.mci, idx2 = idx1 + D;
+  const rptr n1 = c.mcr, n2 = n1 + 3*D, endverts = n2 + 3*D;
+  const rptr face1 = endverts + 3*D, face2 = face1 + 3*P, polygon = face2 + 3*P;
   int nface1 = ccd_simplex_dim(v1i, v1);
   int nface2 = ccd_simplex_dim(v2i, v2);
   int nnorms1 = 0, nnorms2 = 0;
@@ -1385,7 +1392,7 @@ MJH_DEV int ccd_penetration(MREF M, Ccd& c, int first, int nconmax, real margin)
   if (ccd_run(M, c) < 0) {
     const int nw = c.nx;
     for (int i = 0; i < nw; i++) {
-      real* o = c.out + 7*(first + i);
+      const rptr o = c.out + 7*(first + i);
       o[0] = margin + c.dist[i];
       V3 pos = ld3(c.x1 + 3*i) + ld3(c.x2 + 3*i);
       pos = V3{pos.x*0.5, pos.y*0.5, pos.z*0.5};
@@ -1424,35 +1431,35 @@ MJH_DEV void ccd_init_obj(MREF M, CcdObj o, GX gx, GM gm, int g, real margin) {
   o.i[CI_SUP] = sup;
 }
 
-// carve the lane's workspace block
+// carve the lane's workspace slice: word w of lane l of environment e sits at [e][w][l]
 MJH_DEV void ccd_carve(MREF M, BREF B, int e, Ccd& c) {
   const MJH_CONST_AS DSizes& s = M.s;
-  char* base = (char*)B.ccd_ws + ((size_t)e*MJH_WAVE + (size_t)wv_lane())*(size_t)s.ccd_lane_bytes;
-  real* r = (real*)base;
-  int* ip = (int*)(base + (size_t)s.ccd_nreal*sizeof(real));
+  char* base = (char*)B.ccd_ws + (size_t)e*MJH_WAVE*(size_t)s.ccd_lane_bytes;
+  rptr r{(real*)base + wv_lane(), MJH_WAVE};
+  iptr ip{(int*)(base + (size_t)s.ccd_nreal*MJH_WAVE*sizeof(real)) + wv_lane(), MJH_WAVE};
   const int N = s.ccd_N;
   c.N = N; c.P = s.ccd_P; c.D = s.ccd_D;
   c.maxfaces = 6*N; c.maxhorizon = 6*N;
   c.tolerance = M.o.ccd_tolerance;
-  c.o1.r = r; r += CO_NREAL;
-  c.o2.r = r; r += CO_NREAL;
-  c.x1 = r; r += 3*CCD_MAXWIT;
-  c.x2 = r; r += 3*CCD_MAXWIT;
-  c.dist = r; r += CCD_MAXWIT;
-  c.simr = r; r += 4*CV_NREAL;
-  c.tmpr = r; r += 5*CV_NREAL;
-  c.out = r; r += 7*CCD_MAXOUT;
-  c.vr = r; c.mcr = r; r += (5 + N)*CV_NREAL;
+  c.o1.r = r; r = r + CO_NREAL;
+  c.o2.r = r; r = r + CO_NREAL;
+  c.x1 = r; r = r + 3*CCD_MAXWIT;
+  c.x2 = r; r = r + 3*CCD_MAXWIT;
+  c.dist = r; r = r + CCD_MAXWIT;
+  c.simr = r; r = r + 4*CV_NREAL;
+  c.tmpr = r; r = r + 5*CV_NREAL;
+  c.out = r; r = r + 7*CCD_MAXOUT;
+  c.vr = r; c.mcr = r; r = r + (5 + N)*CV_NREAL;
   c.fr = r;
-  c.o1.i = ip; ip += CI_NINT;
-  c.o2.i = ip; ip += CI_NINT;
-  c.simi = ip; ip += 4*CV_NINT;
-  c.tmpi = ip; ip += 5*CV_NINT;
-  c.hidx = ip; ip += 6*N;
-  c.hedge = ip; ip += 6*N;
-  c.stack = ip; ip += 2*(6*N + 1);
-  c.vi = ip; c.mci = ip; ip += (5 + N)*CV_NINT;
-  c.fi = ip; ip += 6*N*CF_NINT;
+  c.o1.i = ip; ip = ip + CI_NINT;
+  c.o2.i = ip; ip = ip + CI_NINT;
+  c.simi = ip; ip = ip + 4*CV_NINT;
+  c.tmpi = ip; ip = ip + 5*CV_NINT;
+  c.hidx = ip; ip = ip + 6*N;
+  c.hedge = ip; ip = ip + 6*N;
+  c.stack = ip; ip = ip + 2*(6*N + 1);
+  c.vi = ip; c.mci = ip; ip = ip + (5 + N)*CV_NINT;
+  c.fi = ip; ip = ip + 6*N*CF_NINT;
   c.map = ip;
   c.separated = 0; c.nx = 0; c.nsimplex = 0; c.gjk_iterations = 0;
   c.nverts = c.nfaces = c.nmap = c.nedges = 0;
@@ -1461,9 +1468,9 @@ MJH_DEV void ccd_carve(MREF M, BREF B, int e, Ccd& c) {
 }
 
 // the calling lane's contact records (dist, pos[3], normal[3]) x CCD_MAXOUT
-MJH_DEV real* ccd_out_records(MREF M, BREF B, int e) {
-  char* base = (char*)B.ccd_ws + ((size_t)e*MJH_WAVE + (size_t)wv_lane())*(size_t)M.s.ccd_lane_bytes;
-  return (real*)base + (2*CO_NREAL + 7*CCD_MAXWIT + 4*CV_NREAL + 5*CV_NREAL);
+MJH_DEV crptr ccd_out_records(MREF M, BREF B, int e) {
+  const real* base = (const real*)((const char*)B.ccd_ws + (size_t)e*MJH_WAVE*(size_t)M.s.ccd_lane_bytes);
+  return crptr{base + (size_t)(2*CO_NREAL + 7*CCD_MAXWIT + 4*CV_NREAL + 5*CV_NREAL)*MJH_WAVE + wv_lane(), MJH_WAVE};
 }
 
 // mjc_Convex (:881): returns the number of contacts left in the lane's `out` records
@@ -1504,8 +1511,8 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
         for (int side = 0; side < 2; side++) {
           // mju_rotateFrame (:834)
           const real* R = side == 0 ? rot : invrot;
-          real* xmat = (side == 0 ? c.o1.r : c.o2.r) + CO_MAT;
-          real* xpos = (side == 0 ? c.o1.r : c.o2.r) + CO_POS;
+          const rptr xmat = (side == 0 ? c.o1.r : c.o2.r) + CO_MAT;
+          const rptr xpos = (side == 0 ? c.o1.r : c.o2.r) + CO_POS;
           real mat[9];
           for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++)
             mat[3*r + q] = R[3*r]*xmat[q] + R[3*r + 1]*xmat[3 + q] + R[3*r + 2]*xmat[6 + q];
@@ -1536,7 +1543,7 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
 
 // mjccd_support (:518) for the geoms mjc_PlaneConvex sees (ellipsoid, mesh): libccd-style support
 MJH_DEV V3 ccd_legacy_support(MREF M, CcdObj o, V3 dir) {
-  const real* mat = o.r + CO_MAT; const real* pos = o.r + CO_POS; const real* size = o.r + CO_SIZE;
+  const crptr mat = o.r + CO_MAT; const crptr pos = o.r + CO_POS; const crptr size = o.r + CO_SIZE;
   const V3 ld = ccd_to_local(mat, dir);
   V3 res;
   if (o.i[CI_TYPE] == MJH_GEOM_ELLIPSOID) {
@@ -1599,7 +1606,7 @@ MJH_DEVN_HOT int ccd_plane_convex_pair(MREF M_, BREF B_, int e_, int p) {
   ccd_init_obj(M, c.o1, gx, gm, g2, 0);
   const V3 cdir{-mat1[2], -mat1[5], -mat1[8]};
   const V3 sup = ccd_legacy_support(M, c.o1, cdir);
-  real* o = c.out;
+  const rptr o = c.out;
   o[0] = dot(normal, sup - pos1);
   if (o[0] > margin) return 0;
   const real h = -0.5*o[0];
@@ -1609,7 +1616,7 @@ MJH_DEVN_HOT int ccd_plane_convex_pair(MREF M_, BREF B_, int e_, int p) {
   if (M.geom_dataid[g2] == -1) return count;
   const int mesh = M.geom_dataid[g2];
   const int vadr = 3*M.mesh_vertadr[mesh];
-  const real* mat2 = c.o1.r + CO_MAT;
+  const crptr mat2 = c.o1.r + CO_MAT;
   const V3 locdir = ccd_to_local(mat2, cdir);
   const real threshold = dot(normal, pos2 - pos1) - margin;
   const V3 first = ld3(o + 1);
@@ -1620,7 +1627,7 @@ MJH_DEVN_HOT int ccd_plane_convex_pair(MREF M_, BREF B_, int e_, int p) {
     const V3 pnt = mmul(mat2, v) + pos2;
     const V3 df = pnt - first;
     if (sqrt(df.x*df.x + df.y*df.y + df.z*df.z) < 0.3*rbound) return 0;
-    real* oc = c.out + 7*count;
+    const rptr oc = c.out + 7*count;
     oc[0] = dot(normal, pnt - pos1);
     const real hh = -0.5*oc[0];
     st3(oc + 1, V3{pnt.x + normal.x*hh, pnt.y + normal.y*hh, pnt.z + normal.z*hh});

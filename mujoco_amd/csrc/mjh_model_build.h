@@ -1004,10 +1004,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   // row capacity: the model's bound, cut back (not below 256 rows) until the per-environment constraint
   // arrays -- efc_J, efc_Y, the dense efc_AR under the dual solver, ~24 row vectors -- fit the budget
-  // ($MJHIP_EFC_BYTES, default 2 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
+  // ($MJHIP_EFC_BYTES, default 4 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
   {
     const bool dual = m->opt.solver == mjSOL_PGS;
-    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : 2.0*1024*1024;
+    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : 4.0*1024*1024;
     auto bytes = [&](int n) { return 8.0*n*(2.0*m->nv + (dual ? n : 0) + 24); };
     int n = std::max(1, std::min(nefc_bound, 4096));
     while (n > 256 && bytes(n) > budget) n = std::max(256, n*7/8);

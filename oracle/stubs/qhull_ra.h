@@ -141,7 +141,18 @@ inline bool build(const double* P, int n, std::vector<int>& out) {
   }
   out.clear();
   for (const Tri& t : T) if (t.alive) { out.push_back(t.a); out.push_back(t.b); out.push_back(t.c); }
-  return out.size() >= 12;
+  if (out.size() < 12) return false;
+  // MakeGraph sizes its edge table as V + 3F, which holds exactly for a closed 2-manifold: refuse
+  // anything else (tolerance trouble on near-degenerate inputs) instead of letting it overrun that table
+  std::map<std::pair<int,int>, int> dir;
+  for (size_t f = 0; f < out.size()/3; f++)
+    for (int k = 0; k < 3; k++) dir[{out[3*f + k], out[3*f + (k + 1) % 3]}]++;
+  for (const auto& kv : dir)
+    if (kv.second != 1 || dir.find({kv.first.second, kv.first.first}) == dir.end()) return false;
+  std::vector<char> isv(n, 0);
+  int nvh = 0;
+  for (int v : out) if (!isv[v]) { isv[v] = 1; nvh++; }
+  return nvh - (int)dir.size()/2 + (int)out.size()/3 == 2;
 }
 inline setT* make_set(qhT* qh, const std::vector<void*>& items) {
   setT* s = (setT*)calloc(1, sizeof(setT) + sizeof(setelemT) * (items.size() + 1));

@@ -595,10 +595,34 @@ def test_newton_solver_vs_live_oracle(rb, hip_lib, golden):
     ref, ints = oracle_rollout(rb, m, fx["state0"], fx["ctrl"][:, :T])
     b = K.Batch(dmn, n)
     out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
-    print("newton rollout rel err", relerr(out, ref))
+    print("newton rollout rel err", relerr(out, ref), " bit-exact:", np.array_equal(out, ref))
     assert relerr(out, ref) <= TOL
     c = b.get("counts")
     assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1])
+    # the solver is an operation-for-operation restatement (mjh_newton.h): from identical (state, warm
+    # start, ctrl) the Newton iteration count of every step is the reference's, pyramidal and elliptic
+    for cone in (0, 1):
+        m.opt.cone = cone
+        mm.set_option("cone", cone)
+        dmc = K.DeviceModel(hip_lib, mm)
+        d = rb.MjData(m)
+        S, W, C, R, NI = [], [], [], [], []
+        for e in range(n):
+            rb.mj_resetData(m, d)
+            rb.mj_setState(m, d, fx["state0"][e], rb.mjSTATE_FULLPHYSICS)
+            for t in range(T):
+                S.append(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)); W.append(np.array(d.qacc_warmstart)); C.append(fx["ctrl"][e, t])
+                d.ctrl[:] = fx["ctrl"][e, t]
+                rb.mj_step(m, d)
+                R.append(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)); NI.append((d.ncon, d.nefc, d.solver_niter[0]))
+        bb = K.Batch(dmc, len(S))
+        one = bb.rollout_host(1, K.mjSTATE_CTRL, np.array(S), np.array(W), np.array(C)[:, None])[:, 0]
+        cc = bb.get("counts")
+        NI = np.array(NI)
+        assert relerr(one, np.array(R)) <= TOL
+        assert np.array_equal(cc[:, 0], NI[:, 0]) and np.array_equal(cc[:, 1], NI[:, 1])
+        assert np.array_equal(cc[:, 5], NI[:, 2]), (cone, np.nonzero(cc[:, 5] != NI[:, 2])[0][:10])
+        print("newton cone", cone, "single steps", len(S), "rel err", relerr(one, np.array(R)), "solver_niter exact, max", NI[:, 2].max())
 
 
 def test_full_size_batch_properties(hip_lib, dm, golden):

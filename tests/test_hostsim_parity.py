@@ -127,69 +127,72 @@ def test_rk4_rollout_bit_exact(rb, hostsim_lib, golden, layout):
 
 
 @pytest.mark.parametrize("layout", ["aos", "soa"])
-def test_newton_solver_matches_reference(rb, hostsim_lib, golden, layout):
-    """the reference's DEFAULT solver (mjSOL_NEWTON, engine_solver.c:2344-2587) on humanoid as shipped:
-    not an operation-for-operation restatement (see mjh_newton.h), so the bar is the north star's
-    1e-6 relative on qpos/qvel -- observed ~1e-12 -- with contact/constraint counts exact"""
+@pytest.mark.parametrize("cone", [0, 1])
+def test_newton_solver_bit_exact(rb, hostsim_lib, golden, layout, cone):
+    """the reference's DEFAULT solver (mjSOL_NEWTON, engine_solver.c:2344-2563) on humanoid, pyramidal and
+    elliptic cones: an operation-for-operation restatement (mjh_newton.h: MakeHessian once, rank-one
+    Cholesky updates per state change, the reference's summation orders), so whole trajectories and the
+    Newton iteration count of EVERY step equal the oracle's bit for bit"""
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
     assert m.opt.solver == 2
+    m.opt.cone = cone
     dm = K.DeviceModel(hostsim_lib, m)
     fx = golden("humanoid")
-    n, T = 4, 30
+    n, T = 4, 60
     s0, ctrl = fx["state0"][:n], fx["ctrl"][:n, :T]
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dm, n, layout=layout)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
-    err = relerr(out, ref)
-    assert err <= 1e-9, err
+    assert np.array_equal(out, ref)
     c = b.get("counts")
     assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1])
-    assert np.all(np.abs(c[:, 5] - ints[:, -1, 2]) <= 1)          # Newton iterations, last step
-    # one forward pass from contact-rich keyframes: constraint forces and accelerations
+    assert np.array_equal(c[:, 5], ints[:, -1, 2])                # Newton iterations of the last step
+    assert ints[..., 2].max() >= 4
+    # every step's iteration count: single steps from the oracle's own (state, warm start)
+    d = rb.MjData(m)
+    b1 = K.Batch(dm, 1, layout=layout)
+    rb.mj_setState(m, d, s0[1], rb.mjSTATE_FULLPHYSICS)
+    for t in range(40):
+        st = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+        ws = np.array(d.qacc_warmstart)[None]
+        d.ctrl[:] = ctrl[1, t]
+        rb.mj_step(m, d)
+        o = b1.rollout_host(1, K.mjSTATE_CTRL, st, ws, ctrl[1:2, t:t + 1])
+        assert b1.get("counts")[0, 5] == d.solver_niter[0], t
+        assert np.array_equal(o[0, 0], rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)), t
+    # one forward pass from contact-rich keyframes: constraint forces and accelerations, exactly
     states = contact_rich_states(rb, m, 4, seed=2)
     b2 = K.Batch(dm, len(states), layout=layout)
     from parity_utils import load_states
     load_states(b2, states)
     b2.forward()
-    d = rb.MjData(m)
     for e, st in enumerate(states):
         d.qpos[:] = st["qpos"]; d.qvel[:] = st["qvel"]; d.qacc_warmstart[:] = st["qacc_warmstart"]; d.ctrl[:] = st["ctrl"]
         rb.mj_forward(m, d)
         assert b2.get("counts")[e, 1] == d.nefc
         for f in ["qacc", "qfrc_constraint"]:
-            assert relerr(b2.get(f)[e], np.asarray(getattr(d, f))) <= 1e-7, (e, f)
+            assert np.array_equal(b2.get(f)[e], np.asarray(getattr(d, f))), (e, f)
         if d.nefc:
-            scale = max(1.0, np.abs(d.efc_force).max())
-            assert np.max(np.abs(b2.get("efc_force")[e][:d.nefc] - d.efc_force)) / scale <= 1e-7
+            assert np.array_equal(b2.get("efc_force")[e][:d.nefc], np.array(d.efc_force))
 
 
-def test_cg_solver_single_step_parity(rb, hostsim_lib, golden):
-    """mjSOL_CG (mj_solPrimal without the Hessian): one mj_step from identical (state, warm start,
-    ctrl) within the north star's 1e-6.  CG stops at a cost tolerance, not a force tolerance, so two
-    implementations whose iterations differ in the last bits drift apart over long rollouts at the
-    solver's own accuracy -- the per-step statement is the meaningful one."""
+@pytest.mark.parametrize("cone", [0, 1])
+def test_cg_solver_bit_exact(rb, hostsim_lib, golden, cone):
+    """mjSOL_CG (mj_solPrimal without the Hessian: M^-1-preconditioned gradient, Hager-Zhang direction,
+    engine_solver.c:2489-2521): the same restatement, bit-exact over a rollout including the (up to 100)
+    iterations of every step"""
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
     m.opt.solver = 1
+    m.opt.cone = cone
     dm = K.DeviceModel(hostsim_lib, m)
-    states = contact_rich_states(rb, m, 8, seed=13)
-    n = len(states)
-    s0 = np.zeros((n, 56))
-    for e, st in enumerate(states):
-        s0[e, 0] = st["time"]; s0[e, 1:29] = st["qpos"]; s0[e, 29:] = st["qvel"]
-    ws = np.stack([st["qacc_warmstart"] for st in states])
-    ctrl = np.stack([st["ctrl"] for st in states])[:, None]
+    fx = golden("humanoid")
+    n, T = 3, 40
+    s0, ctrl = fx["state0"][:n], fx["ctrl"][:n, :T]
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dm, n)
-    out = b.rollout_host(1, K.mjSTATE_CTRL, s0, ws, ctrl)[:, 0]
-    d = rb.MjData(m)
-    for e in range(n):
-        rb.mj_resetData(m, d)
-        rb.mj_setState(m, d, s0[e], rb.mjSTATE_FULLPHYSICS)
-        d.qacc_warmstart[:] = ws[e]
-        d.ctrl[:] = ctrl[e, 0]
-        rb.mj_step(m, d)
-        ref = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
-        assert relerr(out[e], ref) <= 1e-6, (e, relerr(out[e], ref))
-        assert b.get("counts")[e, 1] == d.nefc
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(b.get("counts")[:, 5], ints[:, -1, 2])
 
 
 def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
