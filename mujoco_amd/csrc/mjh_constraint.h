@@ -15,6 +15,9 @@ struct Efc {
   rptr force, b, ARinv, fprev, fmom, R, D, floss, aref, jar, ARf, pos, margin, KBIP,
        diagA, vel, sqrtInvD, AR, J, Y, cone;
   iptr order, state, type, id, island;
+  // sparse constraint path (mjh_sparse.h): compressed J and its transpose, packed factor(s), row patterns
+  rptr spJ, spJT, spL, spLc;
+  iptr rowmask, rowadr, JTadr, JTrow, Lmask, spar;
   // the larger of the two regions' unused tails (staging space for stage_project)
   char* free_p;
   int free_bytes;
@@ -37,6 +40,8 @@ struct Efc {
   X(aref, MJH_G(B, efc_aref, e), nefc, 1)                            \
   X(jar, MJH_G(B, scratch, e) + 3*nmax, nefc, 1)                     \
   X(ARf, MJH_G(B, scratch, e) + 4*nmax, nefc, 1)                     \
+  X(spL, MJH_G(B, sp_L, e), M.s.nLp, 1)                              \
+  X(spLc, MJH_G(B, sp_Lc, e), M.s.nLpc, 1)                           \
   X(pos, MJH_G(B, efc_pos, e), nefc, 1)                              \
   X(margin, MJH_G(B, efc_margin, e), nefc, 1)                        \
   X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc, 1)                          \
@@ -44,17 +49,27 @@ struct Efc {
   X(vel, MJH_G(B, efc_vel, e), nefc, 1)                              \
   X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, dual_*nv, 2)            \
   X(Y, MJH_G(B, efc_Y, e), dual_*nefc*nv, 2)                         \
-  X(J, MJH_G(B, efc_J, e), nefc*nv, 1)                               \
+  X(J, MJH_G(B, efc_J, e), (1 - sp_)*nefc*nv, 1)                     \
   X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
   X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
-  X(cone, MJH_G(B, efc_cone, e), nefc, 1)
+  X(cone, MJH_G(B, efc_cone, e), nefc, 1)                            \
+  X(spJ, MJH_G(B, sp_J, e), nJ_, 1)                                  \
+  X(spJT, MJH_G(B, sp_JT, e), nJ_, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
   X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
   X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
   X(type, MJH_G(B, efc_type, e), nefc, 1)                            \
   X(id, MJH_G(B, efc_id, e), nefc, 1)                                \
-  X(island, MJH_G(B, efc_island, e), nefc, 1)
+  X(island, MJH_G(B, efc_island, e), nefc, 1)                        \
+  X(spar, MJH_G(B, iscratch, e) + nmax, sp_*nv, 1)                   \
+  X(Lmask, MJH_G(B, sp_Lmask, e), 4*sp_*nv, 1)                       \
+  X(rowadr, MJH_G(B, sp_rowadr, e), sp_*(nefc + 1), 1)               \
+  X(JTadr, MJH_G(B, sp_JTadr, e), sp_*(nv + 1), 1)                   \
+  X(rowmask, MJH_G(B, sp_rowmask, e), 4*sp_*nefc, 1)
+// int arrays packed after the real ones (sized by nJ, see efc_layout)
+#define MJH_EFC_LATE_INT_ARRAYS(X)                                   \
+  X(JTrow, MJH_G(B, sp_JTrow, e), nJ_, 1)
 
 // (stage_project) does this array already live in the LDS plan?  (pointer inside the workgroup's block)
 template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* lds, int bytes) {
@@ -65,17 +80,23 @@ template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* 
 
 // returns a bit mask of the arrays that were placed in LDS (bit = position in the lists above,
 // ints first)
-MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
+MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   // AR, Y and sqrtInvD belong to the dual (PGS) solver: the primal ones leave their bytes to J
   const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
+  // sparse primal path: the dense J stays in its global home (it is only the staging copy the compressed
+  // rows are cut from); the arrays sized by nJ come last in the packing order, so the layout of everything
+  // else is already final while nJ is still being counted
+  const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
   int off1 = B.dyn_off, off2 = B.dyn2_off;
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
-  unsigned mask = 0, bit = 1;
+  unsigned long long mask = 0, bit = 1;
   char* const lds_ = MJH_LDS(B);
   // a region-2 array that does not fit its region falls through to what is left of region 1
 #define MJH_EFC_PLACE(T, m, home, bytes, region)                                              \
-    if ((region) == 2 && off2 + (bytes) <= end2) { P.m = SP<T>{(T*)(lds_ + off2), 1}; off2 += ((bytes) + 7) & ~7; mask |= bit; } \
+    if ((bytes) <= 0) P.m = (home);                                                           \
+    else if ((region) == 2 && off2 + (bytes) <= end2) { P.m = SP<T>{(T*)(lds_ + off2), 1}; off2 += ((bytes) + 7) & ~7; mask |= bit; } \
     else if (off1 + (bytes) <= end1) { P.m = SP<T>{(T*)(lds_ + off1), 1}; off1 += ((bytes) + 7) & ~7; mask |= bit; }            \
     else P.m = (home);                                                                        \
     bit <<= 1;
@@ -84,6 +105,9 @@ MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
 #undef X
 #define X(m, home, cnt, region) { const int bytes_ = (int)sizeof(real)*(cnt); MJH_EFC_PLACE(real, m, home, bytes_, region) }
   MJH_EFC_REAL_ARRAYS(X)
+#undef X
+#define X(m, home, cnt, region) { const int bytes_ = (int)sizeof(int)*(cnt); MJH_EFC_PLACE(int, m, home, bytes_, region) }
+  MJH_EFC_LATE_INT_ARRAYS(X)
 #undef X
 #undef MJH_EFC_PLACE
   {
@@ -94,22 +118,48 @@ MJH_DEV unsigned efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   return mask;
 }
 
+// ---- sparse constraint path (mjh_sparse.h)
+// mju_dotSparse(row r of J, v): four accumulators over the stored entries in groups of four, then the rest one by one
+template <class P0>
+MJH_DEV real sp_row_dot(const Efc& P, int r, P0 v) {
+  M128 pm = m128_ld(P.rowmask + 4*r);
+  crptr a = P.spJ + P.rowadr[r];
+  const int nnz = m128_count(pm);
+  real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int k = 0;
+  for (; k <= nnz - 4; k += 4) {
+    const int j0 = m128_lowest(pm); pm = m128_drop_lowest(pm);
+    const int j1 = m128_lowest(pm); pm = m128_drop_lowest(pm);
+    const int j2 = m128_lowest(pm); pm = m128_drop_lowest(pm);
+    const int j3 = m128_lowest(pm); pm = m128_drop_lowest(pm);
+    r0 += a[k]*v[j0]; r1 += a[k + 1]*v[j1]; r2 += a[k + 2]*v[j2]; r3 += a[k + 3]*v[j3];
+  }
+  real res = (r0 + r2) + (r1 + r3);
+  for (; k < nnz; k++) { const int j = m128_lowest(pm); pm = m128_drop_lowest(pm); res += a[k]*v[j]; }
+  return res;
+}
+
 // debug write-back of the LDS-resident constraint arrays to their global homes
 MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
-  (void)nv; (void)nmax; (void)dual_;
+  const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
+  (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_;
   if (!nefc) return;
   Efc P;
-  const unsigned mask = efc_layout(M, B, e, nefc, P);
-  unsigned bit = 1;
+  const unsigned long long mask = efc_layout(M, B, e, nefc, P);
+  unsigned long long bit = 1;
 #define X(m, home, cnt, region) { iptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_INT_ARRAYS(X)
 #undef X
 #define X(m, home, cnt, region) { rptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
   MJH_EFC_REAL_ARRAYS(X)
+#undef X
+#define X(m, home, cnt, region) { iptr g = (home); if (mask & bit) MJH_FOR_LANES(i, (cnt)) g[i] = P.m[i]; bit <<= 1; }
+  MJH_EFC_LATE_INT_ARRAYS(X)
 #undef X
 }
 
@@ -1050,8 +1100,9 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
   crptr margin = P.margin;
   rptr vel = P.vel;
   rptr aref = P.aref;
+  const int sparse = MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse;     // mj_mulJacVec takes mju_mulMatVecSparse
   MJH_FOR_LANES(r, nefc) {
-    real v = dot_ref(J + (size_t)r*nv, qvel, nv);
+    real v = sparse ? sp_row_dot(P, r, qvel) : dot_ref(J + (size_t)r*nv, qvel, nv);
     vel[r] = v;
     aref[r] = -KBIP[4*r+1]*v - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
   }
@@ -1166,6 +1217,17 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
           for (int k = 0; k < 3; k++) { colp[k*nv + j] = jp[k]; colp[(3 + k)*nv + j] = jr[k]; }
         }
         wv_sync();
+        if (sparse) {
+          // sparse: mju_dotSparseX3 over the merged chain of BOTH bodies (mj_mergeChain, common dofs kept), one
+          // running sum per component in ascending dof order (engine_util_sparse.c:30-55)
+          const M128 both = m128_or(m128_ldw(M.body_dofanc + (size_t)b0*s.nvw, s.nvw), m128_ldw(M.body_dofanc + (size_t)b1*s.nvw, s.nvw));
+          for (int k = 0; k < 3; k++) { jdv[side][k] = 0; jrdv[side][k] = 0; }
+          for (M128 um = both; m128_any(um); um = m128_drop_lowest(um)) {
+            const int j = m128_lowest(um);
+            const real v2 = qvel[j];
+            for (int k = 0; k < 3; k++) { jdv[side][k] += colp[k*nv + j]*v2; jrdv[side][k] += colp[(3 + k)*nv + j]*v2; }
+          }
+        } else
         for (int k = 0; k < 3; k++) {
           jdv[side][k] = dot_ref(colp + k*nv, qvel, nv);
           jrdv[side][k] = dot_ref(colp + (3 + k)*nv, qvel, nv);

@@ -30,6 +30,48 @@ typedef SP<const real> crptr;
 typedef SP<int> iptr;
 typedef SP<const int> ciptr;
 
+
+// ---- 128-bit sets of dofs (sparse constraint path: row patterns of J, H and the Cholesky factor; nv <= 128)
+struct M128 { uint64_t lo, hi; };
+MJH_DEV M128 m128_zero() { return M128{0, 0}; }
+MJH_DEV M128 m128_bit(int i) { return i < 64 ? M128{1ull << i, 0} : M128{0, 1ull << (i - 64)}; }
+MJH_DEV int m128_test(M128 m, int i) { return (int)(((i < 64 ? m.lo : m.hi) >> (i & 63)) & 1); }
+MJH_DEV M128 m128_or(M128 a, M128 b) { return M128{a.lo | b.lo, a.hi | b.hi}; }
+MJH_DEV M128 m128_and(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
+MJH_DEV M128 m128_xor(M128 a, M128 b) { return M128{a.lo ^ b.lo, a.hi ^ b.hi}; }
+// bits [0, i)
+MJH_DEV M128 m128_below(int i) {
+  if (i <= 0) return M128{0, 0};
+  if (i < 64) return M128{(1ull << i) - 1, 0};
+  if (i == 64) return M128{~0ull, 0};
+  if (i < 128) return M128{~0ull, (1ull << (i - 64)) - 1};
+  return M128{~0ull, ~0ull};
+}
+MJH_DEV int m128_any(M128 m) { return (m.lo | m.hi) != 0; }
+MJH_DEV int m128_count(M128 m) { return __builtin_popcountll(m.lo) + __builtin_popcountll(m.hi); }
+// number of members below i = position of member i in the ascending list
+MJH_DEV int m128_rank(M128 m, int i) { return m128_count(m128_and(m, m128_below(i))); }
+MJH_DEV int m128_lowest(M128 m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }
+MJH_DEV int m128_highest(M128 m) { return m.hi ? 127 - __builtin_clzll(m.hi) : 63 - __builtin_clzll(m.lo); }
+MJH_DEV M128 m128_drop_lowest(M128 m) { return m.lo ? M128{m.lo & (m.lo - 1), m.hi} : M128{0, m.hi & (m.hi - 1)}; }
+// four 32-bit words of an int array <-> mask
+template <class P0>
+MJH_DEV M128 m128_ld(P0 w) {
+  return M128{((uint64_t)(unsigned)w[1] << 32) | (unsigned)w[0], ((uint64_t)(unsigned)w[3] << 32) | (unsigned)w[2]};
+}
+template <class P0>
+MJH_DEV void m128_st(P0 w, M128 m) {
+  w[0] = (int)(unsigned)m.lo; w[1] = (int)(unsigned)(m.lo >> 32); w[2] = (int)(unsigned)m.hi; w[3] = (int)(unsigned)(m.hi >> 32);
+}
+// nw (<= 4) 32-bit words, the rest zero
+template <class P0>
+MJH_DEV M128 m128_ldw(P0 w, int nw) {
+  unsigned a[4] = {0, 0, 0, 0};
+  for (int k = 0; k < nw && k < 4; k++) a[k] = (unsigned)w[k];
+  return M128{((uint64_t)a[1] << 32) | a[0], ((uint64_t)a[3] << 32) | a[2]};
+}
+MJH_DEV M128 wv_uniform_m128(M128 m) { return M128{wv_uniform_u64(m.lo), wv_uniform_u64(m.hi)}; }
+
 template <class P0>
 MJH_DEV void v3_zero(P0 r) { r[0] = 0; r[1] = 0; r[2] = 0; }
 template <class P0, class P1>

@@ -1014,6 +1014,28 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : n;
     s.nefcAR = dual ? s.nefcmax : 0;
   }
+  // sparse constraint path (mj_isSparse, engine_core_util.c:32): the primal solvers follow the reference's
+  // sparse routines operation for operation (mjh_sparse.h); its dof sets are 128-bit masks
+  {
+    const bool ref_sparse = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
+    s.sparse = (ref_sparse && m->opt.solver != mjSOL_PGS && m->nv <= 128) ? 1 : 0;
+    s.nJmax = 0; s.nLp = 0; s.nLpc = 0;
+    if (s.sparse) {
+      // longest row pattern: two body chains (contacts, connect / weld), two tendons, a ball joint limit
+      int chainmax = 1;
+      for (int b = 0; b < m->nbody; b++) {
+        int cnt = 0;
+        for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)b*s.nvw + w]);
+        chainmax = std::max(chainmax, cnt);
+      }
+      int tenmax = 0;
+      for (int t = 0; t < m->ntendon; t++) tenmax = std::max(tenmax, (int)m->ten_J_rownnz[t]);
+      const int rowmax = std::min((int)m->nv, std::max(std::max(2*chainmax, 2*tenmax), 3));
+      s.nJmax = s.nefcmax*rowmax;
+      s.nLp = m->opt.solver == mjSOL_NEWTON ? m->nv*(m->nv + 1)/2 : 0;
+      s.nLpc = (m->opt.cone != mjCONE_PYRAMIDAL) ? s.nLp : 0;
+    }
+  }
   // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with
   // state = 0, inc = 1 and one warm-up draw per solver call; every iteration Fisher-Yates-shuffles
   // the order array left by the previous iteration with j = next % (i+1), i = n-1 .. 1

@@ -103,7 +103,9 @@ MJH_DEV real nt_elliptic_costdif(Q q, real alpha, real mu, real Dm) {
 struct NtPoint { real alpha, cost, d0, d1; };
 
 // ELL = 0: instantiation without elliptic-cone code (the common pyramidal case keeps its register budget)
-template <int ELL>
+// SPA = 1: the reference's sparse path (mj_isSparse): compressed J / J', packed sparse factor -- mjh_sparse.h describes the
+// data model; the blocks marked "sparse" below restate engine_util_sparse.c / engine_util_solve.c operation for operation
+template <int ELL, int SPA>
 MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -121,20 +123,28 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   rptr qfc = MJH_F(B, qfrc_constraint, e);
   crptr Ms = MJH_G(B, M, e);              // mass matrix, CSR lower triangle (diagonal last in each row)
   const int lane = wv_lane();
+#ifdef MJH_PROFILE
+  // sub-stage accumulators (us): 32 set-up / warm start, 33 Hessian + factorisation, 34 factor solves, 35 incremental
+  // updates, 36 line search, 37 constraint update + gradient
+  long long ptick = wv_clock();
+  auto tick = [&](int slot) { const long long c_ = wv_clock(); if (lane == 0) MJH_G(B, prof, e)[slot] += (real)(c_ - ptick)*0.01; ptick = c_; };
+#else
+  auto tick = [](int) {};
+#endif
   const real tol = M.o.tolerance;
   const int elliptic = ELL ? (M.o.cone != 0) : 0;
 
   // ---- storage
   // factor(s): column-major n x n; in LDS when the plan's unused tail takes them (primal solvers leave
   // the dual arrays' bytes free), else their global homes
-  rptr Lt = MJH_G(B, nt_H, e);
-  rptr Lc = MJH_G(B, nt_M, e);                    // Lcone (elliptic)
+  rptr Lt = SPA ? P.spL : MJH_G(B, nt_H, e);
+  rptr Lc = SPA ? P.spLc : MJH_G(B, nt_M, e);     // Lcone (elliptic)
   rptr vec = MJH_G(B, nt_vec, e);
   {
     char* fp = P.free_p;
     int fb = P.free_bytes;
     const int lbytes = nv*nv*(int)sizeof(real);
-    if (flg_newton && fb >= lbytes) { Lt = SP<real>{(real*)fp, 1}; fp += lbytes; fb -= lbytes; }
+    if (!SPA && flg_newton && fb >= lbytes) { Lt = SP<real>{(real*)fp, 1}; fp += lbytes; fb -= lbytes; }
     if (fb >= (int)(8*nv*sizeof(real))) vec = SP<real>{(real*)fp, 1};
   }
   rptr Ma = vec, grad = vec + nv, Mgrad = vec + 2*nv, search = vec + 3*nv, Mv = vec + 4*nv;
@@ -160,7 +170,15 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // ---- building blocks ------------------------------------------------------------------------------------
   // mju_dot(a, b, nv) evaluated by every lane on its own (uniform result, no exchange): nv serial
   // multiply-adds in four chains
+  // (sparse path: the reference's vectors are island-local -- the island's dofs in ascending order, contiguous -- so
+  // mju_dot groups them by their position inside the island: ordered reduction over the island's dof mask)
+  M128 isl_dofs = m128_below(nv);
   auto dotv = [&](crptr a, crptr b) -> real {
+    if (SPA) {
+      const real p0 = (lane < nv) ? (real)(a[lane]*b[lane]) : (real)0;
+      const real p1 = (lane + MJH_W < nv) ? (real)(a[lane + MJH_W]*b[lane + MJH_W]) : (real)0;
+      return wv_dot4m(p0, p1, isl_dofs.lo, isl_dofs.hi, 1);
+    }
     if (!multi_tree) return dot_ref(a, b, nv);
     real r0 = 0, r1 = 0, r2 = 0, r3 = 0;      // masked: the island's dofs only (vectors are zero elsewhere anyway)
     int i = 0;
@@ -184,7 +202,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // out = J v (mju_mulMatVec: one mju_dot per row), optionally - aref
   auto mul_J = [&](rptr out, crptr v, int sub_aref) {
     MJH_FOR_LANES(r, nefc) {
-      const real acc = dot_ref(J + (size_t)r*nv, v, nv);
+      const real acc = SPA ? sp_row_dot(P, r, v) : dot_ref(J + (size_t)r*nv, v, nv);
       out[r] = sub_aref ? acc - aref[r] : acc;
     }
     wv_sync();
@@ -222,6 +240,26 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
     ncone = ELL ? wv_sum_i(cones) : 0;
     wv_sync();
+    if (SPA) {
+      // sparse: mju_mulMatVecSparse(J', force) -- one mju_dotSparse per dof over the rows that contain it
+      MJH_FOR_LANES(j, nv) {
+        if (!in_dof(j)) continue;
+        const int a0 = P.JTadr[j], n = P.JTadr[j + 1] - a0;
+        crptr v = P.spJT + a0;
+        ciptr ri = P.JTrow + a0;
+        real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        int k = 0;
+        for (; k <= n - 4; k += 4) {
+          r0 += v[k]*P.force[ri[k]]; r1 += v[k + 1]*P.force[ri[k + 1]];
+          r2 += v[k + 2]*P.force[ri[k + 2]]; r3 += v[k + 3]*P.force[ri[k + 3]];
+        }
+        real res = (r0 + r2) + (r1 + r3);
+        for (; k < n; k++) res += v[k]*P.force[ri[k]];
+        qfc[j] = res;
+      }
+      wv_sync();
+      return;
+    }
     MJH_FOR_LANES(j, nv) {
       real acc = 0;
       for (int r = 0; r < nefc; r++) if (in_row(r)) acc += J[(size_t)r*nv + j]*P.force[r];
@@ -380,9 +418,161 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     return rank;
   };
 
+
+  // ---- sparse Cholesky machinery (Newton on the reference's sparse path) -----------------------------------
+  // packed factor: row r at r(r+1)/2, lane j (second slot: j + 64) owns column j; the island's rows only
+  auto tri = [](int r) { return r*(r + 1)/2; };
+  // MakeHessian + FactorizeHessian.  H = J' D J (mju_sqrMatTDSparseNumeric: row r accumulates, over the rows k of
+  // J that contain dof r in ascending order, (D[k]*J[k][r]) * J[k][c]) + M (mju_addToMatSparse), then the reverse
+  // Cholesky H = L' L (mju_cholFactorNumeric) with its symbolic phase (mju_cholFactorSymbolic: elimination-tree
+  // parents, and for every row r the order in which the rows c > r with L[c][r] != 0 are visited) fused in
+  auto sp_factorize = [&](rptr L) {
+    MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
+    wv_sync();
+    M128 hm0 = m128_zero(), hm1 = m128_zero();      // H row patterns below the diagonal: rows lane, lane + 64
+    for (M128 rows = isl_dofs; m128_any(rows); rows = m128_drop_lowest(rows)) {
+      const int r = m128_lowest(rows);
+      real acc0 = 0, acc1 = 0;
+      M128 pat = m128_zero();
+      const int t1 = P.JTadr[r + 1];
+      for (int t = P.JTadr[r]; t < t1; t++) {
+        const int k = P.JTrow[t];
+        const M128 pm = m128_ld(P.rowmask + 4*k);
+        pat = m128_or(pat, pm);
+        const real scale = Dact[k]*P.spJT[t];
+        if (scale == 0) continue;
+        const int adr = P.rowadr[k];
+        if (lane <= r && m128_test(pm, lane)) acc0 += scale*P.spJ[adr + m128_rank(pm, lane)];
+        if (lane + MJH_W <= r && m128_test(pm, lane + MJH_W)) acc1 += scale*P.spJ[adr + m128_rank(pm, lane + MJH_W)];
+      }
+      const int ma = M.M_rowadr[r], mn = M.M_rownnz[r];
+      for (int q = 0; q < mn; q++) {
+        const int c = M.M_colind[ma + q];
+        pat = m128_or(pat, m128_bit(c));
+        if (c == lane) acc0 += Ms[ma + q];
+        if (c == lane + MJH_W) acc1 += Ms[ma + q];
+      }
+      pat = m128_and(pat, m128_below(r));
+      if (lane <= r) L[tri(r) + lane] = acc0;
+      if (lane + MJH_W <= r) L[tri(r) + lane + MJH_W] = acc1;
+      if (lane == (r & (MJH_W - 1))) { if (r < MJH_W) hm0 = pat; else hm1 = pat; }
+    }
+    MJH_FOR_LANES(i, nv) P.spar[i] = -1;
+    wv_sync();
+    for (M128 rows = isl_dofs; m128_any(rows); ) {
+      const int r = m128_highest(rows);
+      rows = m128_xor(rows, m128_bit(r));
+      // rows i > r with H[i][r] != 0, ascending: the seeds of the walk up the elimination tree
+      M128 colm;
+      colm.lo = wv_ballot(m128_test(hm0, r));
+      colm.hi = wv_ballot(m128_test(hm1, r));
+      M128 pat;
+      pat.lo = wv_bcast_u64(r < MJH_W ? hm0.lo : hm1.lo, r & (MJH_W - 1));
+      pat.hi = wv_bcast_u64(r < MJH_W ? hm0.hi : hm1.hi, r & (MJH_W - 1));
+      real d0 = lane <= r ? (real)L[tri(r) + lane] : (real)0;
+      real d1 = lane + MJH_W <= r ? (real)L[tri(r) + lane + MJH_W] : (real)0;
+      M128 visited = m128_bit(r);
+      const M128 below_r = m128_below(r);
+      for (; m128_any(colm); colm = m128_drop_lowest(colm)) {
+        int c = m128_lowest(colm);
+        while (!m128_test(visited, c)) {
+          if (P.spar[c] == -1) P.spar[c] = r;
+          visited = m128_or(visited, m128_bit(c));
+          const real Lcr = L[tri(c) + r];
+          if (lane <= r) d0 -= Lcr*L[tri(c) + lane];
+          if (lane + MJH_W <= r) d1 -= Lcr*L[tri(c) + lane + MJH_W];
+          pat = m128_or(pat, m128_and(m128_ld(P.Lmask + 4*c), below_r));
+          c = P.spar[c];
+        }
+      }
+      real diag = wv_bcast(r < MJH_W ? d0 : d1, r & (MJH_W - 1));
+      if (diag < MJH_MINVAL) diag = MJH_MINVAL;
+      const real Lrr = sqrt(diag);
+      const real inv = 1.0/Lrr;
+      if (lane < r) L[tri(r) + lane] = d0*inv;
+      if (lane + MJH_W < r) L[tri(r) + lane + MJH_W] = d1*inv;
+      L[tri(r) + r] = Lrr;
+      m128_st(P.Lmask + 4*r, pat);
+      wv_sync();
+    }
+  };
+  // mju_cholSolveSparse(Mgrad, L, grad)
+  auto sp_chol_solve = [&](crptr L) {
+    real y0 = (lane < nv && m128_test(isl_dofs, lane)) ? (real)grad[lane] : (real)0;
+    real y1 = (lane + MJH_W < nv && m128_test(isl_dofs, lane + MJH_W)) ? (real)grad[lane + MJH_W] : (real)0;
+    for (M128 rows = isl_dofs; m128_any(rows); ) {           // x <- L^-T x
+      const int i = m128_highest(rows);
+      rows = m128_xor(rows, m128_bit(i));
+      real xi = wv_bcast(i < MJH_W ? y0 : y1, i & (MJH_W - 1));
+      if (xi == 0) continue;
+      xi /= L[tri(i) + i];
+      if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
+      if (lane < i) y0 -= L[tri(i) + lane]*xi;
+      if (lane + MJH_W < i) y1 -= L[tri(i) + lane + MJH_W]*xi;
+    }
+    for (M128 rows = isl_dofs; m128_any(rows); rows = m128_drop_lowest(rows)) {   // x <- L^-1 x
+      const int i = m128_lowest(rows);
+      const M128 lm = m128_ld(P.Lmask + 4*i);
+      real xi = wv_bcast(i < MJH_W ? y0 : y1, i & (MJH_W - 1));
+      if (m128_any(lm)) {
+        const real p0 = lane < i ? (real)(L[tri(i) + lane]*y0) : (real)0;
+        const real p1 = lane + MJH_W < i ? (real)(L[tri(i) + lane + MJH_W]*y1) : (real)0;
+        xi -= wv_dot4m(p0, p1, lm.lo, lm.hi, 0);
+      }
+      xi /= L[tri(i) + i];
+      if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
+    }
+    if (lane < nv) Mgrad[lane] = y0;
+    if (lane + MJH_W < nv) Mgrad[lane + MJH_W] = y1;
+    wv_sync();
+  };
+  // mju_cholUpdateSparse(L, x, flg_plus): x in registers (x0: dof lane, x1: dof lane + 64), xm its pattern; returns
+  // the rank (nv minus the clamped pivots).  Only the rows whose dense[row] can be non-zero are visited: the
+  // pattern of x, grown by the pattern of every row that was rotated
+  auto sp_chol_update = [&](rptr L, real x0, real x1, M128 xm, int flg_plus) -> int {
+    int rank = nv;
+    M128 nz = xm;
+    while (m128_any(nz)) {
+      const int row = m128_highest(nz);
+      nz = m128_xor(nz, m128_bit(row));
+      // (the pivot is read by every lane BEFORE the exchange below and rewritten by every lane after it: under the
+      // host emulation, which runs the lanes one after the other between exchanges, no lane may see the new pivot)
+      const real diag = L[tri(row) + row];
+      const real xr = wv_bcast(row < MJH_W ? x0 : x1, row & (MJH_W - 1));
+      if (xr == 0) continue;
+      const M128 lm = m128_ld(P.Lmask + 4*row);
+      nz = m128_or(nz, lm);
+      real tmp = diag*diag + (flg_plus ? xr*xr : -xr*xr);
+      if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; rank--; }
+      const real rr = sqrt(tmp);
+      L[tri(row) + row] = rr;
+      const real c = diag/rr;
+      const real sn = -xr/rr;
+      const real ss = flg_plus ? -sn : sn;
+      if (lane < row && m128_test(lm, lane)) {
+        const real mat = L[tri(row) + lane];
+        L[tri(row) + lane] = c*mat + ss*x0;
+        x0 = sn*mat + c*x0;
+      }
+      if (lane + MJH_W < row && m128_test(lm, lane + MJH_W)) {
+        const real mat = L[tri(row) + lane + MJH_W];
+        L[tri(row) + lane + MJH_W] = c*mat + ss*x1;
+        x1 = sn*mat + c*x1;
+      }
+    }
+    wv_sync();
+    return rank;
+  };
+  // row i of J, scaled, spread over the dof lanes
+  auto sp_row_lanes = [&](int i, real scl, real& x0, real& x1, M128& pm) {
+    pm = m128_ld(P.rowmask + 4*i);
+    const int adr = P.rowadr[i];
+    x0 = (lane < nv && m128_test(pm, lane)) ? (real)(P.spJ[adr + m128_rank(pm, lane)]*scl) : (real)0;
+    x1 = (lane + MJH_W < nv && m128_test(pm, lane + MJH_W)) ? (real)(P.spJ[adr + m128_rank(pm, lane + MJH_W)]*scl) : (real)0;
+  };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
-    MJH_FOR_LANES(w, nv*nv) Lc[w] = Lt[w];
+    MJH_FOR_LANES(w, SPA ? s.nLp : nv*nv) Lc[w] = Lt[w];
     wv_sync();
     for (int i = 0; i < nefc; i++) {
       if (!in_row(i) || P.state[i] != MJH_STATE_CONE) continue;
@@ -403,6 +593,23 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           for (int r = j + 1; r < dim; r++) local[r*dim + j] = (local[r*dim + j] - dot_ref(local + r*dim, local + j*dim, j))*tmp;
         }
       }
+      if (SPA) {
+        // sparse: LTJ over the contact's shared pattern, one mju_cholUpdateSparse per column of L_local
+        const M128 pm = m128_ld(P.rowmask + 4*i);
+        const int k0 = m128_rank(pm, lane), k1 = m128_rank(pm, lane + MJH_W);
+        const int in0 = lane < nv && m128_test(pm, lane), in1 = lane + MJH_W < nv && m128_test(pm, lane + MJH_W);
+        for (int c = 0; c < dim; c++) {
+          real x0 = 0, x1 = 0;
+          for (int r = c; r < dim; r++) {
+            const int adr = P.rowadr[i + r];
+            if (in0) x0 += P.spJ[adr + k0]*local[r*dim + c];
+            if (in1) x1 += P.spJ[adr + k1]*local[r*dim + c];
+          }
+          sp_chol_update(Lc, x0, x1, pm, 1);
+        }
+        i += dim - 1;
+        continue;
+      }
       // LTJ[c] = sum_{r >= c} J[i+r] * local[r][c], rows added in order of r
       MJH_FOR_LANES(j, nv) {
         for (int c = 0; c < dim; c++) {
@@ -422,12 +629,34 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // FactorizeHessian
   auto factorize = [&](int recompute) {
+    if (SPA) {
+      sp_factorize(Lt);
+      if (ELL && ncone) hessian_cone();
+      return;
+    }
     if (recompute) make_hessian(Lt);
     chol_factor(Lt);
     if (ELL && ncone) hessian_cone();
   };
   // HessianIncremental
   auto hessian_incremental = [&]() {
+    if (SPA) {
+      for (int r0 = 0; r0 < nefc; r0 += MJH_W) {
+        const int r = r0 + lane;
+        int changed = 0;
+        if (r < nefc && in_row(r)) changed = (oldstate[r] == MJH_STATE_QUADRATIC) != (P.state[r] == MJH_STATE_QUADRATIC);
+        for (unsigned long long chg = wv_ballot(changed); chg; chg &= chg - 1) {
+          const int i = r0 + __builtin_ctzll(chg);
+          real x0, x1;
+          M128 pm;
+          sp_row_lanes(i, sqrt(P.D[i]), x0, x1, pm);
+          const int rank = sp_chol_update(Lt, x0, x1, pm, P.state[i] == MJH_STATE_QUADRATIC);
+          if (rank < nv) { factorize(1); return; }
+        }
+      }
+      if (ELL && ncone) hessian_cone();
+      return;
+    }
     for (int i = 0; i < nefc; i++) {
       if (!in_row(i)) continue;
       const int was = oldstate[i] == MJH_STATE_QUADRATIC, is = P.state[i] == MJH_STATE_QUADRATIC;
@@ -440,7 +669,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
     if (ELL && ncone) hessian_cone();
   };
-  auto newton_mgrad = [&]() { chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt); };
+  auto newton_mgrad = [&]() {
+    if (SPA) sp_chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
+    else chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
+  };
 
   // ---- warm start: best of (qacc_warmstart, qacc_smooth)        (warmstart, engine_forward.c:1056-1132)
   // (jar = J qacc_warmstart - aref and efc_b = J qacc_smooth - aref were left by stage_fwd_constraint)
@@ -468,9 +700,15 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   mul_J(jar, qacc, 1);
   if (multi_tree) { MJH_FOR_LANES(j, nv) qfc[j] = 0; wv_sync(); }
   int niter0 = 0;
+  tick(32);
   for (isl = 0; isl < nisl; isl++) {
+    if (SPA) {
+      isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
+      isl_dofs.hi = wv_ballot(lane + MJH_W < nv && in_dof(lane + MJH_W));
+    }
     update_constraint();
     update_grad();
+    tick(37);
 
     // scale: 1/(meaninertia*nv) monolithic, 1/trace(M over the island's dofs) per island
     real scale;
@@ -487,9 +725,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     const int flg_gap = r_max(0, 0.5*scale*dotv(grad, Mgrad)) < tol;
     const int flg_gradient = scale*sqrt(dotv(grad, grad)) < tol;
     int done = flg_gap && (!flg_newton || flg_gradient);
+    tick(32);
     if (!done && flg_newton) {
       factorize(1);
+      tick(33);
       newton_mgrad();
+      tick(34);
       done = flg_gradient && (r_max(0, 0.5*scale*dotv(grad, Mgrad)) < tol);
     }
     if (!done) { MJH_FOR_LANES(i, nv) search[i] = -1*Mgrad[i]; wv_sync(); }
@@ -638,6 +879,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           }
         }
       }
+      tick(36);
       if (alpha == 0) break;
 
       // ================= move, update
@@ -647,9 +889,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       MJH_FOR_LANES(r, nefc) oldstate[r] = P.state[r];
       wv_sync();
       update_constraint();
+      tick(37);
       if (flg_newton) hessian_incremental();
+      tick(35);
       update_grad();
       if (flg_newton) newton_mgrad(); else precondition();
+      tick(34);
       const real improvement = scale*ls_improvement;
       const real gradient = scale*sqrt(dotv(grad, grad));
       const real decrement = flg_newton ? r_max(0, 0.5*scale*dotv(grad, Mgrad)) : 0;
@@ -687,9 +932,13 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 }
 
 MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
-  if (MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0) solve_primal<1>(M_, B_, e_, 1); else solve_primal<0>(M_, B_, e_, 1);
+  const int ell = MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0;
+  if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 1); else solve_primal<0, 1>(M_, B_, e_, 1); }
+  else { if (ell) solve_primal<1, 0>(M_, B_, e_, 1); else solve_primal<0, 0>(M_, B_, e_, 1); }
 }
 MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) {
-  if (MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0) solve_primal<1>(M_, B_, e_, 0); else solve_primal<0>(M_, B_, e_, 0);
+  const int ell = MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0;
+  if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 0); else solve_primal<0, 1>(M_, B_, e_, 0); }
+  else { if (ell) solve_primal<1, 0>(M_, B_, e_, 0); else solve_primal<0, 0>(M_, B_, e_, 0); }
 }
 #endif  // !MJH_LANE_MODE

@@ -33,6 +33,7 @@ template <class T> static inline const T* wv_uniform_ptr(const T* p) { return p;
 template <class T> static inline const T& wv_uniform_ref(const T& r) { return r; }
 template <class T> static inline const T& wv_const_ref(const T* p) { return *p; }
 static inline int wv_uniform_i(int v) { return v; }
+static inline uint64_t wv_uniform_u64(uint64_t v) { return v; }
 #define MJH_DEVN_WAVE static __attribute__((noinline))
 #define MJH_DEVN_HOT static __attribute__((noinline))
 #define MJH_DEVN_LANE static inline
@@ -50,6 +51,7 @@ struct WaveSim {
   int reverse;        // run lanes 63..0 instead of 0..63 (race detector)
   // scratch for cross-lane primitives
   double dscratch[MJH_WAVE];
+  double dscratch2[MJH_WAVE];
   long long iscratch[MJH_WAVE];
 };
 extern thread_local WaveSim* g_wave;
@@ -205,6 +207,45 @@ MJH_DEV void wv_dot4_acc(double* r, double v, int ngroup) {
   mjhsim::yield();
   for (int g = 0; g < ngroup; g++) for (int c = 0; c < 4; c++) r[c] += w->dscratch[4*g + c];
   mjhsim::yield();
+}
+
+// 64-bit word held by lane src (src wave-uniform)
+MJH_DEV uint64_t wv_bcast_u64(uint64_t v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = (long long)v;
+  mjhsim::yield();
+  uint64_t r = (uint64_t)w->iscratch[src];
+  mjhsim::yield();
+  return r;
+}
+// mju_dot / mju_dotSparse over the lanes selected by a wave-uniform 128-bit mask: element t lives in p0 of lane t
+// (t < 64) or in p1 of lane t - 64.  The selected elements, in ascending order, are the operands of the
+// reference's loop: four interleaved accumulators over groups of four, (r0 + r2) + (r1 + r3), then the
+// remainder -- added as ONE grouped term (mju_dot, engine_util_blas.c:517-525) when dense_tail, else one by one
+// (mju_dotSparse, engine_util_sparse.h:218-221)
+MJH_DEV double wv_dot4m(double p0, double p1, uint64_t mlo, uint64_t mhi, int dense_tail) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = p0;
+  w->dscratch2[w->cur] = p1;
+  mjhsim::yield();
+  double v[128];
+  int cnt = 0;
+  for (int l = 0; l < 64; l++) if ((mlo >> l) & 1) v[cnt++] = w->dscratch[l];
+  for (int l = 0; l < 64; l++) if ((mhi >> l) & 1) v[cnt++] = w->dscratch2[l];
+  double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int i = 0;
+  for (; i <= cnt - 4; i += 4) { r0 += v[i]; r1 += v[i+1]; r2 += v[i+2]; r3 += v[i+3]; }
+  double res = (r0 + r2) + (r1 + r3);
+  const int rem = cnt - i;
+  if (dense_tail) {
+    if (rem == 3) res += v[i] + v[i+1] + v[i+2];
+    else if (rem == 2) res += v[i] + v[i+1];
+    else if (rem == 1) res += v[i];
+  } else {
+    for (; i < cnt; i++) res += v[i];
+  }
+  mjhsim::yield();
+  return res;
 }
 
 #else
@@ -368,6 +409,40 @@ MJH_DEV void wv_dot4_acc(double* r, double v, int ngroup) {
     r0 += wv_bcast(v, 4*g); r1 += wv_bcast(v, 4*g + 1); r2 += wv_bcast(v, 4*g + 2); r3 += wv_bcast(v, 4*g + 3);
   }
   r[0] = r0; r[1] = r1; r[2] = r2; r[3] = r3;
+}
+
+MJH_DEV uint64_t wv_bcast_u64(uint64_t v, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+MJH_DEV uint64_t wv_uniform_u64(uint64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// mju_dot / mju_dotSparse over the lanes selected by a wave-uniform 128-bit mask (see the host build's
+// comment): a scalar walk over the set bits, one v_readlane pair + one dependent v_add_f64 per element
+MJH_DEV double wv_dot4m(double p0, double p1, uint64_t mlo, uint64_t mhi, int dense_tail) {
+  mlo = wv_uniform_u64(mlo);
+  mhi = wv_uniform_u64(mhi);
+  const int cnt = __builtin_popcountll(mlo) + __builtin_popcountll(mhi);
+  auto next = [&]() -> double {
+    if (mlo) { const int b = __builtin_ctzll(mlo); mlo &= mlo - 1; return wv_bcast(p0, b); }
+    const int b = __builtin_ctzll(mhi); mhi &= mhi - 1; return wv_bcast(p1, b);
+  };
+  double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  for (int g = cnt >> 2; g > 0; g--) { r0 += next(); r1 += next(); r2 += next(); r3 += next(); }
+  double res = (r0 + r2) + (r1 + r3);
+  const int rem = cnt & 3;
+  if (dense_tail) {
+    if (rem == 3) { const double a = next(), b = next(), c = next(); res += a + b + c; }
+    else if (rem == 2) { const double a = next(), b = next(); res += a + b; }
+    else if (rem == 1) res += next();
+  } else {
+    for (int k = 0; k < rem; k++) res += next();
+  }
+  return res;
 }
 
 #endif  // MJH_HOSTSIM

@@ -160,6 +160,9 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   if (stages & MJH_STAGE_MAKE) {
     MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
     stage_island(M, B, e);
+#if !MJH_LANE_MODE
+    if (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) stage_sparsify(M, B, e);
+#endif
   }
   if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));

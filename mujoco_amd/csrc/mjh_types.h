@@ -288,6 +288,9 @@ struct DSizes {
   int ccd_N;           // opt.ccd_iterations
   int ccd_P, ccd_D;    // max(npolygonmax, 4), max(nmeshdegmax, 3)
   int ccd_nreal, ccd_nint, ccd_lane_bytes;   // workspace per lane: reals, ints, bytes (0 without convex pairs)
+  // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse) and the solver
+  // is a primal one; capacity of the CSR Jacobian; entries of the packed lower-triangular factor (x2 with cones)
+  int sparse, nJmax, nLp, nLpc;
 };
 
 struct DOptions {
@@ -437,9 +440,14 @@ enum {
   X(subtree_angmom, 3 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                    \
   X(con_H, 36 * s.nconH, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
-  X(nt_M, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
-  X(nt_H, s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  X(nt_M, (1 - s.sparse) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
+  X(nt_H, (1 - s.sparse) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
   X(nt_vec, 8 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  /* sparse constraint path: CSR Jacobian values, its transpose, packed factor L (row r at r(r+1)/2), Lcone */ \
+  X(sp_J, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                       \
+  X(sp_JT, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                      \
+  X(sp_L, s.nLp, 0, MJH_T_GLB, MJH_T_GLB)                                         \
+  X(sp_Lc, s.nLpc, 0, MJH_T_GLB, MJH_T_GLB)                                       \
   /* mj_RungeKutta intermediates: X[4] = (qpos, qvel), F[4] = qacc, dX */           \
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
@@ -447,11 +455,11 @@ enum {
   X(rk_act, 9 * s.na, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
   /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
-  X(prof, 32, 0, MJH_T_GLB, MJH_T_GLB)
+  X(prof, 48, 0, MJH_T_GLB, MJH_T_GLB)
 
 #define MJH_BATCH_INT_FIELDS(X)                                                   \
-  /* counts: ncon, nefc, ne, nf, nl, solver_niter, nisland, - */                  \
-  X(counts, 8, 8, MJH_T_COLLISION, MJH_T_END)                                     \
+  /* counts: ncon, nefc, ne, nf, nl, solver_niter, nisland, paired, nJ, - */       \
+  X(counts, 12, 12, MJH_T_COLLISION, MJH_T_END)                                   \
   /* per mjtWarning counter (include/mujoco/mjdata.h:74) */                       \
   X(warning, 8, 8, MJH_T_BEGIN, MJH_T_END)                                        \
   /* con_pair: index into the static pair list */                                 \
@@ -469,6 +477,13 @@ enum {
   X(efc_island, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                               \
   X(island_work, s.nefcmax + 2 * s.ntree + 8, 0, MJH_T_GLB, MJH_T_GLB)            \
   X(iscratch, 4 * s.nefcmax + 4 * s.nconmax + 64, 0, MJH_T_GLB, MJH_T_GLB)         \
+  /* sparse constraint path: row pattern of every constraint (128-bit dof set, 4 words), CSR row addresses, \
+     transpose (row addresses per dof, constraint index per entry), pattern of every row of the factor */ \
+  X(sp_rowmask, 4 * s.sparse * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                \
+  X(sp_rowadr, s.sparse * (s.nefcmax + 1), 0, MJH_T_GLB, MJH_T_GLB)               \
+  X(sp_JTadr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                     \
+  X(sp_JTrow, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  X(sp_Lmask, 4 * s.sparse * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                       \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
   /* mjData.eq_active (user-switchable), first efc row of every equality this step */ \
   X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \
@@ -491,6 +506,7 @@ enum {
 #define MJH_C_NITER 5
 #define MJH_C_NISLAND 6
 #define MJH_C_PAIRED 7     // stage_finish already produced mj_Euler's damped acceleration (qe) for this step
+#define MJH_C_NJ 8         // non-zeros of the sparse constraint Jacobian (mjData.nJ)
 
 // name : global home, n_name : per-env element count of the home, l_name : byte offset inside the
 // workgroup's LDS block or -1, io_name : bit 0 = copy home -> LDS at kernel entry (live-in),

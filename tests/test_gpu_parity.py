@@ -965,8 +965,15 @@ def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
     assert np.array_equal(c[:, 0], fx["ints"][:, 0]) and np.array_equal(c[:, 1], fx["ints"][:, 1])
     assert np.array_equal(c[:, 5], fx["ints"][:, 2])
     err = relerr(out[:, 0], fx["next"])
-    print("cube: ncon up to", fx["ints"][:, 0].max(), "nefc up to", fx["ints"][:, 1].max(), "single-step rel err", err)
+    exact = np.array_equal(out[:, 0], fx["next"])
+    print("cube: ncon up to", fx["ints"][:, 0].max(), "nefc up to", fx["ints"][:, 1].max(), "single-step rel err", err, "bit-exact:", exact)
     assert err <= TOL
+    # nv = 66 puts the reference on its sparse path; mjh_sparse.h follows it operation for operation (bit for bit on
+    # the host emulation, tests/test_sparse_hostsim.py); on the device most steps are bit-exact as well
+    assert dm.size("sparse") == 1
+    nexact = int(np.all(out[:, 0] == fx["next"], axis=1).sum())
+    print("cube: steps reproduced bit for bit on the device:", nexact, "of", n)
+    assert nexact >= n//2
     # contact records against the live oracle
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "cube_3x3x3.mjb"))
     d = rb.MjData(m)
@@ -986,3 +993,19 @@ def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
         assert np.array_equal(cg[e, :k], rc["geom"])
         if k:
             assert np.abs(cd[e, :k] - rc["dist"]).max() <= 1e-9 and np.abs(cp[e, :k] - rc["pos"]).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["chain", "equality", "islands", "tendon", "condim", "boxbox"])
+@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0)], ids=["newton-pyr", "newton-ell", "cg-pyr"])
+def test_sparse_primal_solvers_bit_exact_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone):
+    """the sparse constraint path (opt.jacobian = sparse; mjh_sparse.h, SPA instantiation of mjh_newton.h) on the
+    device: state trajectories, Newton / CG iteration counts, contact / row / island counts identical to the
+    reference's sparse routines (tests/test_sparse_hostsim.py is the CPU counterpart)"""
+    from test_sparse_hostsim import SCENES, _run
+    make, T = SCENES[scene]
+    # exact=False: integer observables of every step exact; states to 1e-9 per step from identical inputs and 1e-6
+    # over the rollout -- the device's atan2 / pow / exp are not glibc's to the last bit (ball-joint limits, welds,
+    # stateful actuators), everything else is
+    ints = _run(rb, hip_lib, make(), tmp_path, solver, cone, T, exact=False)
+    assert ints[:, 1].max() > 0 and ints[:, 2].max() > 0

@@ -30,7 +30,7 @@ ck = torch.from_numpy(rng.uniform(cfg["ctrl"][0], cfg["ctrl"][1], size=(nenv, K,
 
 b.rollout_device(W, ma.mjSTATE_CTRL, st0.data_ptr(), 0, cw.data_ptr(), 0, 0)
 b.sync()
-b.set("prof", np.zeros((nenv, 32)))
+b.set("prof", np.zeros((nenv, b.get("prof").shape[1])))
 import time
 t0 = time.perf_counter()
 for c in range(0, K, 10):
@@ -49,6 +49,9 @@ for i, n in enumerate(NAMES):
     if v > 0: print(f"  {n:14s} {v:9.2f} us")
 print(f"  {'sum':14s} {tot:9.2f} us")
 print("  inside constraint: b/jar/warmstart %.2f  PGS %.2f  J'f %.2f us" % tuple(p[:, k].mean()/nst for k in (22, 23, 24)))
+if p.shape[1] >= 40 and p[:, 32:38].sum() > 0:
+    print("  inside constraint (primal solvers): set-up %.1f  Hessian+factor %.1f  factor solves %.1f  incremental updates %.1f  line search %.1f  constraint update+grad %.1f us"
+          % tuple(p[:, k].mean()/nst for k in (32, 33, 34, 35, 36, 37)))
 c = b.get("counts")
 print("mean ncon", c[:, 0].mean(), "nefc", c[:, 1].mean(), "pgs iter", c[:, 5].mean())
 
