@@ -16,8 +16,11 @@ struct Efc {
        diagA, vel, sqrtInvD, AR, J, Y, cone;
   iptr order, state, type, id, island;
   // sparse constraint path (mjh_sparse.h): compressed J and its transpose, packed factor(s), row patterns
-  rptr spJ, spJT, spL, spLc;
-  iptr rowmask, rowadr, JTadr, JTrow, Lmask, spar;
+  // (the factor is stored compressed by its symbolic pattern; spL is an LDS slot of spL_cap entries when the plan has
+  // room -- a factorisation with more fill than that works in spL_home -- else spL == spL_home)
+  rptr spJ, spJT, spL, spLc, spL_home, vec;
+  int spL_cap;
+  iptr rowmask, rowadr, JTadr, JTrow, Lmask, Ladr, spar;
   // the larger of the two regions' unused tails (staging space for stage_project)
   char* free_p;
   int free_bytes;
@@ -40,8 +43,6 @@ struct Efc {
   X(aref, MJH_G(B, efc_aref, e), nefc, 1)                            \
   X(jar, MJH_G(B, scratch, e) + 3*nmax, nefc, 1)                     \
   X(ARf, MJH_G(B, scratch, e) + 4*nmax, nefc, 1)                     \
-  X(spL, MJH_G(B, sp_L, e), M.s.nLp, 1)                              \
-  X(spLc, MJH_G(B, sp_Lc, e), M.s.nLpc, 1)                           \
   X(pos, MJH_G(B, efc_pos, e), nefc, 1)                              \
   X(margin, MJH_G(B, efc_margin, e), nefc, 1)                        \
   X(KBIP, MJH_G(B, efc_KBIP, e), 4*nefc, 1)                          \
@@ -62,8 +63,6 @@ struct Efc {
   X(type, MJH_G(B, efc_type, e), nefc, 1)                            \
   X(id, MJH_G(B, efc_id, e), nefc, 1)                                \
   X(island, MJH_G(B, efc_island, e), nefc, 1)                        \
-  X(spar, MJH_G(B, iscratch, e) + nmax, sp_*nv, 1)                   \
-  X(Lmask, MJH_G(B, sp_Lmask, e), 4*sp_*nv, 1)                       \
   X(rowadr, MJH_G(B, sp_rowadr, e), sp_*(nefc + 1), 1)               \
   X(JTadr, MJH_G(B, sp_JTadr, e), sp_*(nv + 1), 1)                   \
   X(rowmask, MJH_G(B, sp_rowmask, e), 4*sp_*nefc, 1)
@@ -93,6 +92,26 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
   unsigned long long mask = 0, bit = 1;
   char* const lds_ = MJH_LDS(B);
+  // sparse primal path: what the solver's serial chains touch goes first -- row addresses and patterns of the factor,
+  // the dof vectors, then the factor itself takes ALL that is left of region 1 (up to its full size); the per-row
+  // arrays below are streamed lane-parallel and can live in global memory
+  P.spL_home = MJH_G(B, sp_L, e); P.spL = P.spL_home; P.spL_cap = M.s.nLp;
+  P.spLc = MJH_G(B, sp_Lc, e);
+  P.Ladr = MJH_G(B, sp_Ladr, e); P.Lmask = MJH_G(B, sp_Lmask, e);
+  P.vec = MJH_G(B, nt_vec, e);
+  P.spar = MJH_G(B, iscratch, e) + nmax;
+  if (sp_) {
+    const int nvec = (M.o.solver == MJH_SOL_NEWTON ? 5 : 8)*nv*(int)sizeof(real);
+    const int b_adr = (((nv + 1)*(int)sizeof(int)) + 7) & ~7, b_mask = 4*nv*(int)sizeof(int);
+    if (off1 + b_adr <= end1) { P.Ladr = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_adr; }
+    if (off1 + b_mask <= end1) { P.Lmask = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_mask; }
+    if (off1 + b_adr <= end1) { P.spar = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_adr; }
+    if (off2 + nvec <= end2) { P.vec = SP<real>{(real*)(lds_ + off2), 1}; off2 += nvec; }
+    else if (off1 + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + off1), 1}; off1 += nvec; }
+    int lb = (end1 - off1) & ~7;
+    if (lb > M.s.nLp*(int)sizeof(real)) lb = M.s.nLp*(int)sizeof(real);
+    if (lb >= 64*(int)sizeof(real)) { P.spL = SP<real>{(real*)(lds_ + off1), 1}; P.spL_cap = lb/(int)sizeof(real); off1 += lb; }
+  }
   // a region-2 array that does not fit its region falls through to what is left of region 1
 #define MJH_EFC_PLACE(T, m, home, bytes, region)                                              \
     if ((bytes) <= 0) P.m = (home);                                                           \

@@ -103,6 +103,13 @@ struct Backend {
   // largest dynamic LDS block a workgroup may request (gfx950: 160 KB per CU; one workgroup is
   // allowed 64 KB without opting in, which is already far beyond the useful range here)
   static int max_lds() { return 64 * 1024; }
+  // compute units of the current device (256 on MI355X)
+  static int num_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }
   // `variant` (MJH_VAR_*, mjh_modes.h): which mapping of the stage sources steps the batch; lds = LDS
   // bytes per ENVIRONMENT (a workgroup of a sub-wave variant allocates one block per lane group)
   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void* stream) {

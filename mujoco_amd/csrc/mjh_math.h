@@ -71,6 +71,10 @@ MJH_DEV M128 m128_ldw(P0 w, int nw) {
   return M128{((uint64_t)a[1] << 32) | a[0], ((uint64_t)a[3] << 32) | a[2]};
 }
 MJH_DEV M128 wv_uniform_m128(M128 m) { return M128{wv_uniform_u64(m.lo), wv_uniform_u64(m.hi)}; }
+MJH_DEV M128 wv_bcast_m128(M128 m, int src) { M128 r; wv_bcast_u128(m.lo, m.hi, src, &r.lo, &r.hi); return r; }
+// position of the calling lane's dof (slot 0: dof = lane, slot 1: dof = lane + 64) among the members of m
+MJH_DEV int m128_rank_lane0(M128 m) { return wv_rank_lt(m.lo); }
+MJH_DEV int m128_rank_lane1(M128 m) { return __builtin_popcountll(m.lo) + wv_rank_lt(m.hi); }
 
 template <class P0>
 MJH_DEV void v3_zero(P0 r) { r[0] = 0; r[1] = 0; r[2] = 0; }

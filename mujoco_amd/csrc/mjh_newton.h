@@ -139,8 +139,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // the dual arrays' bytes free), else their global homes
   rptr Lt = SPA ? P.spL : MJH_G(B, nt_H, e);
   rptr Lc = SPA ? P.spLc : MJH_G(B, nt_M, e);     // Lcone (elliptic)
-  rptr vec = MJH_G(B, nt_vec, e);
-  {
+  rptr vec = SPA ? P.vec : MJH_G(B, nt_vec, e);
+  if (!SPA) {
     char* fp = P.free_p;
     int fb = P.free_bytes;
     const int lbytes = nv*nv*(int)sizeof(real);
@@ -419,149 +419,30 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
 
 
-  // ---- sparse Cholesky machinery (Newton on the reference's sparse path) -----------------------------------
-  // packed factor: row r at r(r+1)/2, lane j (second slot: j + 64) owns column j; the island's rows only
-  auto tri = [](int r) { return r*(r + 1)/2; };
-  // MakeHessian + FactorizeHessian.  H = J' D J (mju_sqrMatTDSparseNumeric: row r accumulates, over the rows k of
-  // J that contain dof r in ascending order, (D[k]*J[k][r]) * J[k][c]) + M (mju_addToMatSparse), then the reverse
-  // Cholesky H = L' L (mju_cholFactorNumeric) with its symbolic phase (mju_cholFactorSymbolic: elimination-tree
-  // parents, and for every row r the order in which the rows c > r with L[c][r] != 0 are visited) fused in
-  auto sp_factorize = [&](rptr L) {
+  // ---- sparse Cholesky machinery (Newton on the reference's sparse path): mjh_sparse.h ------------------------
+  // the factor is stored compressed by its pattern; it works in the LDS slot when its fill fits, else in its global home
+  int sp_nL = 0;
+  auto sp_factorize = [&]() {
     MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
     wv_sync();
-    M128 hm0 = m128_zero(), hm1 = m128_zero();      // H row patterns below the diagonal: rows lane, lane + 64
-    for (M128 rows = isl_dofs; m128_any(rows); rows = m128_drop_lowest(rows)) {
-      const int r = m128_lowest(rows);
-      real acc0 = 0, acc1 = 0;
-      M128 pat = m128_zero();
-      const int t1 = P.JTadr[r + 1];
-      for (int t = P.JTadr[r]; t < t1; t++) {
-        const int k = P.JTrow[t];
-        const M128 pm = m128_ld(P.rowmask + 4*k);
-        pat = m128_or(pat, pm);
-        const real scale = Dact[k]*P.spJT[t];
-        if (scale == 0) continue;
-        const int adr = P.rowadr[k];
-        if (lane <= r && m128_test(pm, lane)) acc0 += scale*P.spJ[adr + m128_rank(pm, lane)];
-        if (lane + MJH_W <= r && m128_test(pm, lane + MJH_W)) acc1 += scale*P.spJ[adr + m128_rank(pm, lane + MJH_W)];
-      }
-      const int ma = M.M_rowadr[r], mn = M.M_rownnz[r];
-      for (int q = 0; q < mn; q++) {
-        const int c = M.M_colind[ma + q];
-        pat = m128_or(pat, m128_bit(c));
-        if (c == lane) acc0 += Ms[ma + q];
-        if (c == lane + MJH_W) acc1 += Ms[ma + q];
-      }
-      pat = m128_and(pat, m128_below(r));
-      if (lane <= r) L[tri(r) + lane] = acc0;
-      if (lane + MJH_W <= r) L[tri(r) + lane + MJH_W] = acc1;
-      if (lane == (r & (MJH_W - 1))) { if (r < MJH_W) hm0 = pat; else hm1 = pat; }
-    }
-    MJH_FOR_LANES(i, nv) P.spar[i] = -1;
-    wv_sync();
-    for (M128 rows = isl_dofs; m128_any(rows); ) {
-      const int r = m128_highest(rows);
-      rows = m128_xor(rows, m128_bit(r));
-      // rows i > r with H[i][r] != 0, ascending: the seeds of the walk up the elimination tree
-      M128 colm;
-      colm.lo = wv_ballot(m128_test(hm0, r));
-      colm.hi = wv_ballot(m128_test(hm1, r));
-      M128 pat;
-      pat.lo = wv_bcast_u64(r < MJH_W ? hm0.lo : hm1.lo, r & (MJH_W - 1));
-      pat.hi = wv_bcast_u64(r < MJH_W ? hm0.hi : hm1.hi, r & (MJH_W - 1));
-      real d0 = lane <= r ? (real)L[tri(r) + lane] : (real)0;
-      real d1 = lane + MJH_W <= r ? (real)L[tri(r) + lane + MJH_W] : (real)0;
-      M128 visited = m128_bit(r);
-      const M128 below_r = m128_below(r);
-      for (; m128_any(colm); colm = m128_drop_lowest(colm)) {
-        int c = m128_lowest(colm);
-        while (!m128_test(visited, c)) {
-          if (P.spar[c] == -1) P.spar[c] = r;
-          visited = m128_or(visited, m128_bit(c));
-          const real Lcr = L[tri(c) + r];
-          if (lane <= r) d0 -= Lcr*L[tri(c) + lane];
-          if (lane + MJH_W <= r) d1 -= Lcr*L[tri(c) + lane + MJH_W];
-          pat = m128_or(pat, m128_and(m128_ld(P.Lmask + 4*c), below_r));
-          c = P.spar[c];
-        }
-      }
-      real diag = wv_bcast(r < MJH_W ? d0 : d1, r & (MJH_W - 1));
-      if (diag < MJH_MINVAL) diag = MJH_MINVAL;
-      const real Lrr = sqrt(diag);
-      const real inv = 1.0/Lrr;
-      if (lane < r) L[tri(r) + lane] = d0*inv;
-      if (lane + MJH_W < r) L[tri(r) + lane + MJH_W] = d1*inv;
-      L[tri(r) + r] = Lrr;
-      m128_st(P.Lmask + 4*r, pat);
-      wv_sync();
-    }
+    sp_nL = sp_symbolic(M, B, e, P, isl_dofs);
+    Lt = sp_nL <= P.spL_cap ? P.spL : P.spL_home;
+    if (mjh_in_lds(Lt)) sp_numeric(M, B, e, P, mjh_local(Lt.p), isl_dofs, Dact, Ms);
+    else sp_numeric(M, B, e, P, Lt, isl_dofs, Dact, Ms);
   };
-  // mju_cholSolveSparse(Mgrad, L, grad)
-  auto sp_chol_solve = [&](crptr L) {
+  auto sp_chol_solve = [&](rptr L) {
     real y0 = (lane < nv && m128_test(isl_dofs, lane)) ? (real)grad[lane] : (real)0;
     real y1 = (lane + MJH_W < nv && m128_test(isl_dofs, lane + MJH_W)) ? (real)grad[lane + MJH_W] : (real)0;
-    for (M128 rows = isl_dofs; m128_any(rows); ) {           // x <- L^-T x
-      const int i = m128_highest(rows);
-      rows = m128_xor(rows, m128_bit(i));
-      real xi = wv_bcast(i < MJH_W ? y0 : y1, i & (MJH_W - 1));
-      if (xi == 0) continue;
-      xi /= L[tri(i) + i];
-      if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
-      if (lane < i) y0 -= L[tri(i) + lane]*xi;
-      if (lane + MJH_W < i) y1 -= L[tri(i) + lane + MJH_W]*xi;
-    }
-    for (M128 rows = isl_dofs; m128_any(rows); rows = m128_drop_lowest(rows)) {   // x <- L^-1 x
-      const int i = m128_lowest(rows);
-      const M128 lm = m128_ld(P.Lmask + 4*i);
-      real xi = wv_bcast(i < MJH_W ? y0 : y1, i & (MJH_W - 1));
-      if (m128_any(lm)) {
-        const real p0 = lane < i ? (real)(L[tri(i) + lane]*y0) : (real)0;
-        const real p1 = lane + MJH_W < i ? (real)(L[tri(i) + lane + MJH_W]*y1) : (real)0;
-        xi -= wv_dot4m(p0, p1, lm.lo, lm.hi, 0);
-      }
-      xi /= L[tri(i) + i];
-      if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
-    }
+    if (mjh_in_lds(L)) sp_solve(M, P, mjh_local(L.p), isl_dofs, y0, y1);
+    else sp_solve(M, P, L, isl_dofs, y0, y1);
     if (lane < nv) Mgrad[lane] = y0;
     if (lane + MJH_W < nv) Mgrad[lane + MJH_W] = y1;
     wv_sync();
   };
-  // mju_cholUpdateSparse(L, x, flg_plus): x in registers (x0: dof lane, x1: dof lane + 64), xm its pattern; returns
-  // the rank (nv minus the clamped pivots).  Only the rows whose dense[row] can be non-zero are visited: the
-  // pattern of x, grown by the pattern of every row that was rotated
+  // returns the rank, like mju_cholUpdateSparse
   auto sp_chol_update = [&](rptr L, real x0, real x1, M128 xm, int flg_plus) -> int {
-    int rank = nv;
-    M128 nz = xm;
-    while (m128_any(nz)) {
-      const int row = m128_highest(nz);
-      nz = m128_xor(nz, m128_bit(row));
-      // (the pivot is read by every lane BEFORE the exchange below and rewritten by every lane after it: under the
-      // host emulation, which runs the lanes one after the other between exchanges, no lane may see the new pivot)
-      const real diag = L[tri(row) + row];
-      const real xr = wv_bcast(row < MJH_W ? x0 : x1, row & (MJH_W - 1));
-      if (xr == 0) continue;
-      const M128 lm = m128_ld(P.Lmask + 4*row);
-      nz = m128_or(nz, lm);
-      real tmp = diag*diag + (flg_plus ? xr*xr : -xr*xr);
-      if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; rank--; }
-      const real rr = sqrt(tmp);
-      L[tri(row) + row] = rr;
-      const real c = diag/rr;
-      const real sn = -xr/rr;
-      const real ss = flg_plus ? -sn : sn;
-      if (lane < row && m128_test(lm, lane)) {
-        const real mat = L[tri(row) + lane];
-        L[tri(row) + lane] = c*mat + ss*x0;
-        x0 = sn*mat + c*x0;
-      }
-      if (lane + MJH_W < row && m128_test(lm, lane + MJH_W)) {
-        const real mat = L[tri(row) + lane + MJH_W];
-        L[tri(row) + lane + MJH_W] = c*mat + ss*x1;
-        x1 = sn*mat + c*x1;
-      }
-    }
-    wv_sync();
-    return rank;
+    const int clamped = mjh_in_lds(L) ? sp_update(M, P, mjh_local(L.p), x0, x1, xm, flg_plus) : sp_update(M, P, L, x0, x1, xm, flg_plus);
+    return nv - clamped;
   };
   // row i of J, scaled, spread over the dof lanes
   auto sp_row_lanes = [&](int i, real scl, real& x0, real& x1, M128& pm) {
@@ -572,7 +453,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
-    MJH_FOR_LANES(w, SPA ? s.nLp : nv*nv) Lc[w] = Lt[w];
+    MJH_FOR_LANES(w, SPA ? sp_nL : nv*nv) Lc[w] = Lt[w];
     wv_sync();
     for (int i = 0; i < nefc; i++) {
       if (!in_row(i) || P.state[i] != MJH_STATE_CONE) continue;
@@ -630,7 +511,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // FactorizeHessian
   auto factorize = [&](int recompute) {
     if (SPA) {
-      sp_factorize(Lt);
+      sp_factorize();
       if (ELL && ncone) hessian_cone();
       return;
     }
@@ -670,7 +551,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     if (ELL && ncone) hessian_cone();
   };
   auto newton_mgrad = [&]() {
-    if (SPA) sp_chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
+    if (SPA) sp_chol_solve((ELL && ncone) ? Lc : Lt);
     else chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
   };
 
@@ -821,8 +702,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
                 else c[0] = -cost0;
               }
             }
-            const int cnt = nefc - r0 < MJH_W ? nefc - r0 : MJH_W;
-            wv_chain6(acc, c, cnt);
+            // (rows that contribute an exact zero to a sum cannot change it: only the others are chained --
+            // friction rows feed cost / derivatives, active contacts the quadratic totals, seldom both)
+            for (int q = 0; q < 6; q++) acc[q] = wv_chain_mask(acc[q], c[q], wv_ballot(c[q] != 0));
           }
           real cost = acc[0], d0 = acc[1], d1 = acc[2];
           cost += al*al*acc[5] + al*acc[4] + acc[3];

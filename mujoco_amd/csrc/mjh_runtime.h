@@ -28,6 +28,7 @@
 //   static bool launch_lane_forward(const DModel* M, const DBatch* B, int nenv, int epw, int stages, void* stream);
 //   static bool launch_lane_reset(const DModel* M, const DBatch* B, int nenv, int epw, void* stream);
 //   static int  max_lds();                       // largest LDS block one workgroup may ask for
+//   static int  num_cus();                       // compute units of the current device
 #pragma once
 
 #include <cstdio>
@@ -425,7 +426,17 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   if (const char* ev = getenv("MJHIP_VARIANT")) (void)mjhip_batch_set_variant(Bt, ev);
   // residency plan: MJHIP_LDS_BYTES overrides the default per-workgroup LDS budget (0 disables)
   {
+    // default: the CU's 160 KB shared by the one-wavefront workgroups a full launch puts on it -- 10 KB at 4096
+    // environments on 256 CUs (all of them resident at once), 20 KB at 2048 (the cube's solver then keeps its sparse
+    // factor in LDS: profiles/r03*/cube_lds_sweep.txt), never less than the 10 KB the stage lifetimes were tuned for
     int budget = MJHIP_DEFAULT_LDS_BYTES;
+    {
+      const int cus = Backend::num_cus();
+      const int per_cu = (nenv + cus - 1)/cus;
+      int b = (160*1024/(per_cu > 0 ? per_cu : 1)) & ~1023;
+      if (b > Backend::max_lds()) b = Backend::max_lds();
+      if (b > budget) budget = b;
+    }
     if (const char* ev = getenv("MJHIP_LDS_BYTES")) budget = atoi(ev);
     if (mjhip_batch_plan_lds(Bt, budget) < 0) { mjhip_batch_destroy(Bt); return nullptr; }
   }

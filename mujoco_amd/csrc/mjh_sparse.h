@@ -127,4 +127,299 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The factor.  Row r of L holds its off-diagonal entries in ascending column order, then the diagonal, at
+// Ladr[r]; Lmask[r] is the set of off-diagonal columns, so entry (r, j) sits at Ladr[r] + rank(Lmask[r], j).
+// The routines below are out of line (their own register scope) and keep, per lane, the pattern / address /
+// diagonal of the rows the lane is named after (rows lane and lane + 64): the serial sweeps fetch them with
+// v_readlane instead of chasing them through memory.
+// ------------------------------------------------------------------------------------------------------------
+
+// H row pattern strictly below the diagonal for rows lane (hm0) and lane + 64 (hm1): the union of the patterns of
+// the rows of J that contain the dof (mju_sqrMatTDSparseSymbolic), plus M's row (mju_addToMatSparse)
+MJH_DEV void sp_hmask(MREF M, const Efc& P, M128 isl, int nv, M128& hm0, M128& hm1) {
+  const int lane = wv_lane();
+  hm0 = m128_zero(); hm1 = m128_zero();
+  for (int slot = 0; slot < 2; slot++) {
+    const int r = lane + MJH_W*slot;
+    if (r < nv && m128_test(isl, r)) {
+      M128 pat = m128_zero();
+      const int t1 = P.JTadr[r + 1];
+      for (int t = P.JTadr[r]; t < t1; t++) pat = m128_or(pat, m128_ld(P.rowmask + 4*P.JTrow[t]));
+      const int ma = M.M_rowadr[r], mn = M.M_rownnz[r];
+      for (int q = 0; q < mn; q++) pat = m128_or(pat, m128_bit(M.M_colind[ma + q]));
+      pat = m128_and(pat, m128_below(r));
+      if (slot) hm1 = pat; else hm0 = pat;
+    }
+  }
+}
+
+// pattern and address of row i of the factor from the lane registers that hold them (rows lane: slot 0, lane + 64:
+// slot 1).  A row below 64 has no column above 63: its high word is known to be zero and is not fetched.
+MJH_DEV void sp_row_bcast(M128 lm0, M128 lm1, int adr0, int adr1, int i, M128& lm, int& adr) {
+  if (i < MJH_W) {
+    lm.lo = wv_bcast_u64(lm0.lo, i);
+    lm.hi = 0;
+    adr = wv_bcast_i(adr0, i);
+  } else {
+    lm = wv_bcast_m128(lm1, i - MJH_W);
+    adr = wv_bcast_i(adr1, i - MJH_W);
+  }
+}
+
+// mju_cholFactorSymbolic for the island's rows: elimination-tree parents (spar), row patterns (Lmask), row addresses
+// (Ladr); returns the number of stored entries.  Row r (descending): seeds = the rows i > r with H[i][r] != 0 in
+// ascending order; from each seed the walk climbs the tree until it meets a row already visited for r; every row c
+// it passes has L[c][r] != 0 and contributes its pattern below r to row r's.
+MJH_DEVN_HOT int sp_symbolic(MREF M_, BREF B_, int e_, const Efc& P, M128 isl) {
+  MJH_ENTER(M_, B_, e_);
+  (void)B; (void)e;
+  const int nv = M.s.nv, lane = wv_lane();
+  isl = wv_uniform_m128(isl);
+  M128 hm0, hm1;
+  sp_hmask(M, P, isl, nv, hm0, hm1);
+  M128 lm0 = m128_zero(), lm1 = m128_zero();
+  int par0 = -1, par1 = -1;
+  for (M128 rows = isl; m128_any(rows); ) {
+    const int r = m128_highest(rows);
+    rows = m128_xor(rows, m128_bit(r));
+    M128 colm;
+    colm.lo = wv_ballot(m128_test(hm0, r));
+    colm.hi = wv_ballot(m128_test(hm1, r));
+    M128 pat = wv_bcast_m128(r < MJH_W ? hm0 : hm1, r & (MJH_W - 1));
+    M128 visited = m128_bit(r);
+    const M128 below_r = m128_below(r);
+    for (; m128_any(colm); colm = m128_drop_lowest(colm)) {
+      int c = m128_lowest(colm);
+      while (!m128_test(visited, c)) {
+        int p = wv_bcast_i(c < MJH_W ? par0 : par1, c & (MJH_W - 1));
+        if (p == -1) {
+          p = r;
+          if (lane == (c & (MJH_W - 1))) { if (c < MJH_W) par0 = r; else par1 = r; }
+        }
+        visited = m128_or(visited, m128_bit(c));
+        pat = m128_or(pat, m128_and(wv_bcast_m128(c < MJH_W ? lm0 : lm1, c & (MJH_W - 1)), below_r));
+        c = p;
+      }
+    }
+    if (lane == (r & (MJH_W - 1))) { if (r < MJH_W) lm0 = pat; else lm1 = pat; }
+  }
+  const int c0 = (lane < nv && m128_test(isl, lane)) ? m128_count(lm0) + 1 : 0;
+  const int c1 = (lane + MJH_W < nv && m128_test(isl, lane + MJH_W)) ? m128_count(lm1) + 1 : 0;
+  const int n0 = wv_sum_i(c0), n1 = wv_sum_i(c1);
+  const int a0 = wv_exscan_i(c0), a1 = n0 + wv_exscan_i(c1);
+  if (lane < nv) { m128_st(P.Lmask + 4*lane, lm0); P.spar[lane] = par0; P.Ladr[lane] = a0; }
+  if (lane + MJH_W < nv) { m128_st(P.Lmask + 4*(lane + MJH_W), lm1); P.spar[lane + MJH_W] = par1; P.Ladr[lane + MJH_W] = a1; }
+  if (lane == 0) P.Ladr[nv] = n0 + n1;
+  wv_sync();
+  return n0 + n1;
+}
+
+// H = J' D J + M written into the factor's storage (mju_sqrMatTDSparseNumeric: row r accumulates, over the rows k of
+// J that contain dof r in ascending order, (D[k] J[k][r]) * J[k][c]; mju_addToMatSparse), then mju_cholFactorNumeric:
+// rows descending, dense[j] -= L[c][r] * L[c][j] over the rows c in the symbolic visiting order, scale by 1/L[r][r].
+// Lane = column; the visiting order of a row is first walked into the lanes (list), its L[c][r] gathered in one go,
+// then applied one c at a time.
+template <class PL>
+MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 isl, crptr Dact, crptr Ms) {
+  MJH_ENTER(M_, B_, e_);
+  (void)B; (void)e;
+  const int nv = M.s.nv, lane = wv_lane();
+  isl = wv_uniform_m128(isl);
+  const int in0 = lane < nv && m128_test(isl, lane), in1 = lane + MJH_W < nv && m128_test(isl, lane + MJH_W);
+  M128 lm0 = m128_zero(), lm1 = m128_zero(), hm0, hm1;
+  int par0 = -1, par1 = -1, adr0 = 0, adr1 = 0;
+  if (in0) { lm0 = m128_ld(P.Lmask + 4*lane); par0 = P.spar[lane]; adr0 = P.Ladr[lane]; }
+  if (in1) { lm1 = m128_ld(P.Lmask + 4*(lane + MJH_W)); par1 = P.spar[lane + MJH_W]; adr1 = P.Ladr[lane + MJH_W]; }
+  sp_hmask(M, P, isl, nv, hm0, hm1);
+  // ---- H rows, ascending
+  for (M128 rows = isl; m128_any(rows); rows = m128_drop_lowest(rows)) {
+    const int r = m128_lowest(rows);
+    const M128 lmr = wv_bcast_m128(r < MJH_W ? lm0 : lm1, r & (MJH_W - 1));
+    const int adr_r = wv_bcast_i(r < MJH_W ? adr0 : adr1, r & (MJH_W - 1));
+    real acc0 = 0, acc1 = 0;
+    const int t0 = P.JTadr[r], n = P.JTadr[r + 1] - t0;
+    for (int tb = 0; tb < n; tb += MJH_W) {
+      // the row's J' entries, one per lane: scale, pattern and address of the J row each one points to
+      real sc = 0;
+      M128 pm = m128_zero();
+      int adr = 0;
+      if (tb + lane < n) {
+        const int t = t0 + tb + lane, k = P.JTrow[t];
+        sc = Dact[k]*P.spJT[t];
+        pm = m128_ld(P.rowmask + 4*k);
+        adr = P.rowadr[k];
+      }
+      const int m = n - tb < MJH_W ? n - tb : MJH_W;
+      for (int u = 0; u < m; u++) {
+        const real scu = wv_bcast(sc, u);
+        if (scu == 0) continue;
+        const M128 pmu = wv_bcast_m128(pm, u);
+        const int adru = wv_bcast_i(adr, u);
+        if (lane <= r && m128_test(pmu, lane)) acc0 += scu*P.spJ[adru + m128_rank_lane0(pmu)];
+        if (r >= MJH_W) { if (lane + MJH_W <= r && m128_test(pmu, lane + MJH_W)) acc1 += scu*P.spJ[adru + m128_rank_lane1(pmu)]; }
+      }
+    }
+    const int ma = M.M_rowadr[r], mn = M.M_rownnz[r];
+    for (int q = 0; q < mn; q++) {
+      const int c = M.M_colind[ma + q];
+      if (c == lane) acc0 += Ms[ma + q];
+      if (c == lane + MJH_W) acc1 += Ms[ma + q];
+    }
+    const int cnt = m128_count(lmr);
+    if (lane < r && m128_test(lmr, lane)) L[adr_r + m128_rank_lane0(lmr)] = acc0;
+    if (lane + MJH_W < r && m128_test(lmr, lane + MJH_W)) L[adr_r + m128_rank_lane1(lmr)] = acc1;
+    if (lane == r) L[adr_r + cnt] = acc0;
+    if (lane + MJH_W == r) L[adr_r + cnt] = acc1;
+  }
+  wv_sync();
+  // ---- reverse Cholesky, rows descending
+  for (M128 rows = isl; m128_any(rows); ) {
+    const int r = m128_highest(rows);
+    rows = m128_xor(rows, m128_bit(r));
+    const M128 lmr = wv_bcast_m128(r < MJH_W ? lm0 : lm1, r & (MJH_W - 1));
+    const int adr_r = wv_bcast_i(r < MJH_W ? adr0 : adr1, r & (MJH_W - 1));
+    const int cnt = m128_count(lmr);
+    real d0 = 0, d1 = 0;
+    if (lane < r && m128_test(lmr, lane)) d0 = L[adr_r + m128_rank_lane0(lmr)];
+    if (lane + MJH_W < r && m128_test(lmr, lane + MJH_W)) d1 = L[adr_r + m128_rank_lane1(lmr)];
+    if (lane == r) d0 = L[adr_r + cnt];
+    if (lane + MJH_W == r) d1 = L[adr_r + cnt];
+    // the visiting order of column r, walked into the lanes (list entry u in lane u % 64, slot u / 64)
+    M128 colm;
+    colm.lo = wv_ballot(m128_test(hm0, r));
+    colm.hi = wv_ballot(m128_test(hm1, r));
+    int nlist = 0, myc0 = -1, myc1 = -1;
+    M128 visited = m128_bit(r);
+    for (; m128_any(colm); colm = m128_drop_lowest(colm)) {
+      int c = m128_lowest(colm);
+      while (!m128_test(visited, c)) {
+        if (lane == (nlist & (MJH_W - 1))) { if (nlist < MJH_W) myc0 = c; else myc1 = c; }
+        nlist++;
+        visited = m128_or(visited, m128_bit(c));
+        c = wv_bcast_i(c < MJH_W ? par0 : par1, c & (MJH_W - 1));
+      }
+    }
+    // every list entry's pattern, address and L[c][r], gathered by the lane that holds the entry
+    M128 lc0 = m128_zero(), lc1 = m128_zero();
+    int ac0 = 0, ac1 = 0;
+    real v0 = 0, v1 = 0;
+    if (myc0 >= 0) { lc0 = m128_ld(P.Lmask + 4*myc0); ac0 = P.Ladr[myc0]; v0 = L[ac0 + m128_rank(lc0, r)]; }
+    if (myc1 >= 0) { lc1 = m128_ld(P.Lmask + 4*myc1); ac1 = P.Ladr[myc1]; v1 = L[ac1 + m128_rank(lc1, r)]; }
+    for (int u = 0; u < nlist; u++) {
+      const int src = u & (MJH_W - 1);
+      const real Lcr = wv_bcast(u < MJH_W ? v0 : v1, src);
+      const M128 lmu = wv_bcast_m128(u < MJH_W ? lc0 : lc1, src);
+      const int au = wv_bcast_i(u < MJH_W ? ac0 : ac1, src);
+      if (lane <= r && m128_test(lmu, lane)) d0 -= Lcr*L[au + m128_rank_lane0(lmu)];
+      if (r >= MJH_W) { if (lane + MJH_W <= r && m128_test(lmu, lane + MJH_W)) d1 -= Lcr*L[au + m128_rank_lane1(lmu)]; }
+    }
+    real diag = wv_bcast(r < MJH_W ? d0 : d1, r & (MJH_W - 1));
+    if (diag < MJH_MINVAL) diag = MJH_MINVAL;
+    const real Lrr = sqrt(diag);
+    const real inv = 1.0/Lrr;
+    if (lane < r && m128_test(lmr, lane)) L[adr_r + m128_rank_lane0(lmr)] = d0*inv;
+    if (lane + MJH_W < r && m128_test(lmr, lane + MJH_W)) L[adr_r + m128_rank_lane1(lmr)] = d1*inv;
+    if (lane == (r & (MJH_W - 1))) L[adr_r + cnt] = Lrr;
+    wv_sync();
+  }
+}
+
+// mju_cholSolveSparse: x <- L^-T x over the rows descending (x[j] -= L[i][j] x[i]), then x <- L^-1 x ascending
+// (x[i] -= mju_dotSparse(row i, x)); x in registers (y0: dof lane, y1: dof lane + 64)
+template <class PL>
+MJH_DEVN_HOT void sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real& y0, real& y1) {
+  const MJH_CONST_AS DModel& M = wv_uniform_ref(M_);
+  const int nv = M.s.nv, lane = wv_lane();
+  isl = wv_uniform_m128(isl);
+  const int in0 = lane < nv && m128_test(isl, lane), in1 = lane + MJH_W < nv && m128_test(isl, lane + MJH_W);
+  M128 lm0 = m128_zero(), lm1 = m128_zero();
+  int adr0 = 0, adr1 = 0;
+  real dg0 = 1, dg1 = 1;
+  if (in0) { lm0 = m128_ld(P.Lmask + 4*lane); adr0 = P.Ladr[lane]; dg0 = L[adr0 + m128_count(lm0)]; }
+  if (in1) { lm1 = m128_ld(P.Lmask + 4*(lane + MJH_W)); adr1 = P.Ladr[lane + MJH_W]; dg1 = L[adr1 + m128_count(lm1)]; }
+  for (M128 rows = isl; m128_any(rows); ) {
+    const int i = m128_highest(rows), src = i & (MJH_W - 1);
+    rows = m128_xor(rows, m128_bit(i));
+    M128 lm;
+    int adr;
+    sp_row_bcast(lm0, lm1, adr0, adr1, i, lm, adr);
+    const int hi = i > MJH_W;           // (uniform) the row has columns in the second slot
+    const int t0 = lane < i && m128_test(lm, lane);
+    const real l0 = t0 ? (real)L[adr + m128_rank_lane0(lm)] : (real)0;
+    int t1 = 0;
+    real l1 = 0;
+    if (hi) { t1 = lane + MJH_W < i && m128_test(lm, lane + MJH_W); l1 = t1 ? (real)L[adr + m128_rank_lane1(lm)] : (real)0; }
+    real xi = wv_bcast(i < MJH_W ? y0 : y1, src);
+    if (xi == 0) continue;
+    xi /= wv_bcast(i < MJH_W ? dg0 : dg1, src);
+    if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
+    if (t0) y0 -= l0*xi;
+    if (hi && t1) y1 -= l1*xi;
+  }
+  for (M128 rows = isl; m128_any(rows); rows = m128_drop_lowest(rows)) {
+    const int i = m128_lowest(rows), src = i & (MJH_W - 1);
+    M128 lm;
+    int adr;
+    sp_row_bcast(lm0, lm1, adr0, adr1, i, lm, adr);
+    real xi = wv_bcast(i < MJH_W ? y0 : y1, src);
+    if (m128_any(lm)) {
+      const real p0 = (lane < i && m128_test(lm, lane)) ? (real)(L[adr + m128_rank_lane0(lm)]*y0) : (real)0;
+      real p1 = 0;
+      if (i > MJH_W) p1 = (lane + MJH_W < i && m128_test(lm, lane + MJH_W)) ? (real)(L[adr + m128_rank_lane1(lm)]*y1) : (real)0;
+      xi -= wv_dot4m(p0, p1, lm.lo, lm.hi, 0);
+    }
+    xi /= wv_bcast(i < MJH_W ? dg0 : dg1, src);
+    if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
+  }
+}
+
+// mju_cholUpdateSparse(L, x, flg_plus): rows from the last non-zero of x downwards, Givens rotation of (row, x) for
+// every row whose x entry is non-zero; x in registers, xm its pattern.  Returns the number of clamped pivots.
+// Only the rows that can hold a non-zero are visited: the pattern of x grown by the pattern of every rotated row.
+template <class PL>
+MJH_DEVN_HOT int sp_update(MREF M_, const Efc& P, PL L, real x0, real x1, M128 xm, int flg_plus) {
+  const MJH_CONST_AS DModel& M = wv_uniform_ref(M_);
+  const int nv = M.s.nv, lane = wv_lane();
+  xm = wv_uniform_m128(xm);
+  M128 lm0 = m128_zero(), lm1 = m128_zero();
+  int adr0 = 0, adr1 = 0;
+  real dg0 = 1, dg1 = 1;
+  if (lane < nv) { lm0 = m128_ld(P.Lmask + 4*lane); adr0 = P.Ladr[lane]; dg0 = L[adr0 + m128_count(lm0)]; }
+  if (lane + MJH_W < nv) { lm1 = m128_ld(P.Lmask + 4*(lane + MJH_W)); adr1 = P.Ladr[lane + MJH_W]; dg1 = L[adr1 + m128_count(lm1)]; }
+  int clamped = 0;
+  M128 nz = xm;
+  while (m128_any(nz)) {
+    const int row = m128_highest(nz), src = row & (MJH_W - 1);
+    nz = m128_xor(nz, m128_bit(row));
+    const real xr = wv_bcast(row < MJH_W ? x0 : x1, src);
+    if (xr == 0) continue;
+    M128 lm;
+    int adr;
+    sp_row_bcast(lm0, lm1, adr0, adr1, row, lm, adr);
+    // (the pivot travels in its owner's register: no lane reads it from memory while the owner rewrites it)
+    const real diag = wv_bcast(row < MJH_W ? dg0 : dg1, src);
+    nz = m128_or(nz, lm);
+    const int hi = row > MJH_W;         // (uniform) the row has columns in the second slot
+    const int t0 = lane < row && m128_test(lm, lane);
+    const int k0 = adr + m128_rank_lane0(lm), kd = adr + m128_count(lm);
+    const real m0 = t0 ? (real)L[k0] : (real)0;
+    int t1 = 0, k1 = 0;
+    real m1 = 0;
+    if (hi) { t1 = lane + MJH_W < row && m128_test(lm, lane + MJH_W); k1 = adr + m128_rank_lane1(lm); m1 = t1 ? (real)L[k1] : (real)0; }
+    real tmp = diag*diag + (flg_plus ? xr*xr : -xr*xr);
+    if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; clamped++; }
+    const real rr = sqrt(tmp);
+    const real c = diag/rr;
+    const real sn = -xr/rr;
+    const real ss = flg_plus ? -sn : sn;
+    if (lane == src) { if (row < MJH_W) dg0 = rr; else dg1 = rr; L[kd] = rr; }
+    if (t0) { L[k0] = c*m0 + ss*x0; x0 = sn*m0 + c*x0; }
+    if (hi && t1) { L[k1] = c*m1 + ss*x1; x1 = sn*m1 + c*x1; }
+  }
+  wv_sync();
+  return clamped;
+}
+
 #endif  // !MJH_LANE_MODE

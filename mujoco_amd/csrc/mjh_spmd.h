@@ -53,6 +53,7 @@ struct WaveSim {
   double dscratch[MJH_WAVE];
   double dscratch2[MJH_WAVE];
   long long iscratch[MJH_WAVE];
+  long long iscratch2[MJH_WAVE];
 };
 extern thread_local WaveSim* g_wave;
 static inline int lane() { return g_wave->cur; }
@@ -196,6 +197,17 @@ MJH_DEV double wv_chain(double init, double v, int lo, int hi, int sub) {
   mjhsim::yield();
   return r;
 }
+// init + v[l] over the lanes l selected by the wave-uniform mask, ascending (an ordered sum whose zero addends,
+// which cannot change it, were dropped by the caller's mask)
+MJH_DEV double wv_chain_mask(double init, double v, uint64_t mask) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = init;
+  for (int l = 0; l < MJH_WAVE; l++) if ((mask >> l) & 1) r += w->dscratch[l];
+  mjhsim::yield();
+  return r;
+}
 // six chains at once: acc[q] += v[q] of lanes 0..n-1 in lane order
 MJH_DEV void wv_chain6(double* acc, const double* v, int n) {
   for (int q = 0; q < 6; q++) acc[q] = wv_chain(acc[q], v[q], 0, n, 0);
@@ -218,6 +230,18 @@ MJH_DEV uint64_t wv_bcast_u64(uint64_t v, int src) {
   mjhsim::yield();
   return r;
 }
+// 128-bit value (two words) held by lane src (src wave-uniform)
+MJH_DEV void wv_bcast_u128(uint64_t lo, uint64_t hi, int src, uint64_t* rlo, uint64_t* rhi) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = (long long)lo;
+  w->iscratch2[w->cur] = (long long)hi;
+  mjhsim::yield();
+  *rlo = (uint64_t)w->iscratch[src];
+  *rhi = (uint64_t)w->iscratch2[src];
+  mjhsim::yield();
+}
+// number of set bits of m below the calling lane's position
+MJH_DEV int wv_rank_lt(uint64_t m) { const int l = mjhsim::lane(); return l ? __builtin_popcountll(m & ((1ull << l) - 1)) : 0; }
 // mju_dot / mju_dotSparse over the lanes selected by a wave-uniform 128-bit mask: element t lives in p0 of lane t
 // (t < 64) or in p1 of lane t - 64.  The selected elements, in ascending order, are the operands of the
 // reference's loop: four interleaved accumulators over groups of four, (r0 + r2) + (r1 + r3), then the
@@ -393,6 +417,18 @@ MJH_DEV double wv_chain(double init, double v, int lo, int hi, int sub) {
   else { for (int l = lo; l < hi; l++) r = r + wv_bcast(v, l); }
   return r;
 }
+// init + v[l] over the lanes l selected by the wave-uniform mask, ascending: a scalar walk over the set bits
+MJH_DEV double wv_chain_mask(double init, double v, uint64_t mask) {
+  mask = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask);
+  double r = init;
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    r += wv_bcast(v, l);
+  }
+  return r;
+}
 // six chains at once (independent accumulators: the chains overlap in the pipeline)
 MJH_DEV void wv_chain6(double* acc, const double* v, int n) {
   double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];
@@ -420,6 +456,14 @@ MJH_DEV uint64_t wv_uniform_u64(uint64_t v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
+}
+MJH_DEV void wv_bcast_u128(uint64_t lo, uint64_t hi, int src, uint64_t* rlo, uint64_t* rhi) {
+  *rlo = wv_bcast_u64(lo, src);
+  *rhi = wv_bcast_u64(hi, src);
+}
+// number of set bits of m below the calling lane's position (v_mbcnt)
+MJH_DEV int wv_rank_lt(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 // mju_dot / mju_dotSparse over the lanes selected by a wave-uniform 128-bit mask (see the host build's
 // comment): a scalar walk over the set bits, one v_readlane pair + one dependent v_add_f64 per element

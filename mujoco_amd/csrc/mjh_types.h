@@ -484,6 +484,7 @@ enum {
   X(sp_JTadr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                     \
   X(sp_JTrow, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(sp_Lmask, 4 * s.sparse * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                       \
+  X(sp_Ladr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
   /* mjData.eq_active (user-switchable), first efc row of every equality this step */ \
   X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \

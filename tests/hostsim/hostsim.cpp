@@ -107,6 +107,7 @@ struct Backend {
   static bool zero(void* dst, size_t n, void*) { memset(dst, 0, n); return true; }
   static bool sync(void*) { return true; }
   static int max_lds() { return 64 * 1024; }
+  static int num_cus() { return 256; }
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
   // run NS's body for the nsub environments of every emulated wavefront (lanes of group g step
