@@ -48,17 +48,31 @@ mjSTATE_USERDATA = 1 << 12
 mjSTATE_PLUGIN = 1 << 13
 
 
+_NAMES = {"parity": "liboracle.so", "fast": "liboracle_fast.so", "devmath": "liboracle_dm.so"}
+_default_kind = "parity"
+
+
+def use(kind: str) -> str:
+    """Select the build the module-level functions (mj_step, ...) call from now on; returns the previous choice.
+    'parity': the reference as built (glibc libm) -- the oracle; 'devmath': the same objects with sin / cos bound to
+    the kernels' mjh_sincos (oracle/devmath_shim.cc).  mjModel / mjData are plain C structs shared by all builds."""
+    global _default_kind
+    prev, _default_kind = _default_kind, kind
+    return prev
+
+
 def available(kind: str = "parity") -> bool:
-    name = "liboracle.so" if kind == "parity" else "liboracle_fast.so"
+    name = _NAMES[kind]
     return os.path.exists(os.path.join(_REF, name)) and os.path.exists(
         os.path.join(_REF, "libintrospect.so"))
 
 
-def load(kind: str = "parity"):
-    """Load the compiled reference engine. kind: 'parity' (-O2, no FMA/SIMD) or 'fast'."""
+def load(kind: Optional[str] = None):
+    """Load the compiled reference engine. kind: 'parity' (-O2, no FMA/SIMD), 'devmath' or 'fast'; default: use()'s choice."""
+    kind = kind or _default_kind
     if kind in _libs:
         return _libs[kind]
-    name = "liboracle.so" if kind == "parity" else "liboracle_fast.so"
+    name = _NAMES[kind]
     path = os.path.join(_REF, name)
     if not os.path.exists(path):
         raise FileNotFoundError(
@@ -224,7 +238,7 @@ class MjModel:
         self.stat = _Stat(self)
 
     @classmethod
-    def from_xml_path(cls, path: str, kind: str = "parity") -> "MjModel":
+    def from_xml_path(cls, path: str, kind: Optional[str] = None) -> "MjModel":
         lib = load(kind)
         err = C.create_string_buffer(2000)
         p = lib.mj_loadXML(path.encode(), None, err, 2000)
@@ -233,7 +247,7 @@ class MjModel:
         return cls(p, lib)
 
     @classmethod
-    def from_binary_path(cls, path: str, kind: str = "parity") -> "MjModel":
+    def from_binary_path(cls, path: str, kind: Optional[str] = None) -> "MjModel":
         lib = load(kind)
         with open(path, "rb") as f:
             blob = f.read()

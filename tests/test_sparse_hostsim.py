@@ -33,10 +33,10 @@ SCENES = {
 }
 
 
-def _run(rb, lib, xml_text, tmp_path, solver, cone, T, seed=0, exact=True):
+def _run(rb, lib, xml_text, tmp_path, solver, cone, T, seed=0, exact=True, kind=None):
     xml = tmp_path / "s.xml"
     xml.write_text(xml_text)
-    m = rb.MjModel.from_xml_path(str(xml))
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind)
     m.opt.solver = solver
     m.opt.cone = cone
     m.opt.jacobian = mjJAC_SPARSE
@@ -77,7 +77,10 @@ def _run(rb, lib, xml_text, tmp_path, solver, cone, T, seed=0, exact=True):
         assert rel(one[:, 0], ref) <= 1e-9
     c = bb.get("counts")
     assert np.array_equal(c[:, 0], ints[:, 0]) and np.array_equal(c[:, 1], ints[:, 1])
-    assert np.array_equal(c[:, 5], ints[:, 2]), (c[:, 5], ints[:, 2])
+    if exact:
+        assert np.array_equal(c[:, 5], ints[:, 2]), (c[:, 5], ints[:, 2])
+    else:
+        assert np.mean(c[:, 5] == ints[:, 2]) >= 0.9, (c[:, 5], ints[:, 2])      # (a last-bit libm difference can move a non-converged solve's stopping iteration)
     assert np.array_equal(c[:, 6], ints[:, 3])
     return ints
 
