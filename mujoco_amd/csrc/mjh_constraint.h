@@ -606,7 +606,10 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
 #else
   const int cpair = 0;
 #endif
-  for (int k0 = 0; k0 < ncon; k0 += 1 + cpair) {
+  // (sparse primal path: the contact rows are written straight into the compressed Jacobian by stage_sparsify, one
+  // row per lane -- this loop takes the contacts one at a time and would leave most lanes idle behind its loads)
+  const int contact_rows_here = !(MJH_HAS(MJH_FT_PRIMAL) && s.sparse);
+  for (int k0 = 0; contact_rows_here && k0 < ncon; k0 += 1 + cpair) {
     const int k = k0 + (cpair ? (wv_lane() >> 5) : 0);
     if (k >= ncon) continue;
     int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
@@ -819,80 +822,105 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     wv_sync();
     return;
   }
-  if (wv_lane() == 0) {
+  // The components are what mj_dsuMerge / mj_dsuAssign produce (engine_island.c: union by smaller root, islands
+  // numbered by ascending smallest tree); they do not depend on the order of the unions, so the rows are taken
+  // lane-parallel: every row names the trees it touches, labels (smallest tree of the component so far) are
+  // lowered along those edges with atomic minima and compressed by pointer jumping until nothing moves.
+  {
     iptr work = MJH_G(B, island_work, e);
-    iptr efc_tree = work;                       // [nefc]
-    iptr parent = work + s.nefcmax;             // [ntree]
-    iptr tree_island = parent + ntree;          // [ntree]
-    for (int t = 0; t < ntree; t++) parent[t] = -1;
-    auto root_of = [&](int tree) {
-      int root = tree;
-      while (parent[root] != root) root = parent[root];
-      while (parent[tree] != tree) { int next = parent[tree]; parent[tree] = root; tree = next; }
-      return root;
-    };
-    auto merge = [&](int t1, int t2) {          // mj_dsuMerge; -1 = static endpoint
-      if (t1 == -1) t1 = t2;
-      if (t2 == -1) t2 = t1;
-      if (parent[t1] == -1) parent[t1] = t1;
-      if (parent[t2] == -1) parent[t2] = t2;
-      if (parent[t1] == parent[t2]) return;
-      int r1 = root_of(t1), r2 = root_of(t2);
-      if (r1 < r2) parent[r2] = r1;
-      else if (r2 < r1) parent[r1] = r2;
-    };
-    int ptype = -1, pid = -1;
-    for (int i = 0; i < nefc; i++) {
+    iptr efc_tree = work;                       // [nefc] first tree of the row
+    iptr label = work + s.nefcmax;              // [ntree] -1: no constraint touches the tree
+    iptr tree_island = label + ntree;           // [ntree]
+    iptr second = MJH_G(B, iscratch, e) + 2*s.nefcmax;     // [nefc] second tree of the row, -2: none, -3: scan the row
+    MJH_FOR_LANES(t, ntree) label[t] = -1;
+    wv_sync();
+    auto row_trees = [&](int i, int* ta, int* tb) {
       const int type = P.type[i], id = P.id[i];
-      if (i > 0 && type == ptype && id == pid) { efc_tree[i] = efc_tree[i-1]; continue; }
-      ptype = type; pid = id;
-      int trees[2] = {-2, -2};
-      if (type == MJH_CNSTR_FRICTION_DOF) {
-        trees[0] = M.dof_treeid[id];
-      } else if (type == MJH_CNSTR_LIMIT_JOINT) {
-        trees[0] = M.dof_treeid[M.jnt_dofadr[id]];
-      } else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) {
+      int t1 = -2, t2 = -2;
+      if (type == MJH_CNSTR_FRICTION_DOF) t1 = M.dof_treeid[id];
+      else if (type == MJH_CNSTR_LIMIT_JOINT) t1 = M.dof_treeid[M.jnt_dofadr[id]];
+      else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) {
         ciptr cg = MJH_CON(B, con_geom, e, 2, id);
-        trees[0] = M.body_treeid[M.geom_bodyid[cg[0]]];
-        trees[1] = M.body_treeid[M.geom_bodyid[cg[1]]];
+        t1 = M.body_treeid[M.geom_bodyid[cg[0]]];
+        t2 = M.body_treeid[M.geom_bodyid[cg[1]]];
       } else if (type == MJH_CNSTR_EQUALITY && (M.eq_type[id] == MJH_EQ_CONNECT || M.eq_type[id] == MJH_EQ_WELD)) {
         int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
         if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }
-        trees[0] = M.body_treeid[b1];
-        trees[1] = M.body_treeid[b2];
-      }
-      if (trees[0] != -2) {
-        int t1 = trees[0], t2 = trees[1];
-        efc_tree[i] = t1 >= 0 ? t1 : t2;
-        if (t2 == -2) merge(t1, -1); else merge(t1, t2);
-      } else {
-        // generic scan of the dense Jacobian row (tendon rows): trees in order of first non-zero dof
-        crptr Jr = P.J + (size_t)i*nv;
-        int t1 = -2, tprev = -1, first = -2;
-        for (int j = 0; j < nv; j++) {
-          if (Jr[j] != 0) {
-            int tj = M.dof_treeid[j];
-            if (tj != tprev) {
-              if (t1 == -2) { t1 = tj; first = tj; }
-              else { merge(t1, tj); t1 = tj; }
-              tprev = tj;
-            }
-            j = M.tree_dofadr[tj] + M.tree_dofnum[tj] - 1;
-          }
+        t1 = M.body_treeid[b1];
+        t2 = M.body_treeid[b2];
+      } else t2 = -3;
+      *ta = t1; *tb = t2;
+    };
+    // trees of a row that has to be scanned (tendon rows, joint / tendon couplings): in order of the first non-zero
+    // dof of each tree; f(prev, next) is called for consecutive distinct trees, returns the first
+    auto scan_row = [&](int i, auto&& f) -> int {
+      crptr Jr = P.J + (size_t)i*nv;
+      int first = -2, prev = -2;
+      for (int j = 0; j < nv; j++) {
+        if (Jr[j] != 0) {
+          const int tj = M.dof_treeid[j];
+          if (tj != prev) { if (first == -2) first = tj; else f(prev, tj); prev = tj; }
+          j = M.tree_dofadr[tj] + M.tree_dofnum[tj] - 1;
         }
-        if (t1 != -2 && t1 == first && tprev == first) merge(first, -1);
-        efc_tree[i] = first >= 0 ? first : 0;
       }
+      return first;
+    };
+    MJH_FOR_LANES(i, nefc) {
+      int t1, t2;
+      row_trees(i, &t1, &t2);
+      if (t2 == -3) {
+        t1 = scan_row(i, [&](int a, int b) { label[a] = a; label[b] = b; });
+        if (t1 >= 0) label[t1] = t1;
+        efc_tree[i] = t1 >= 0 ? t1 : 0;
+      } else {
+        if (t1 >= 0) label[t1] = t1;
+        if (t2 >= 0) label[t2] = t2;
+        efc_tree[i] = t1 >= 0 ? t1 : t2;
+      }
+      second[i] = t2;
     }
-    // mj_dsuAssign: ids in ascending order of canonical roots
+    wv_sync();
+    for (int round = 0; round < 4*ntree + 8; round++) {
+      int moved = 0;
+      MJH_FOR_LANES(i, nefc) {
+        const int t2 = second[i];
+        auto join = [&](int a, int b) {
+          if (a < 0 || b < 0) return;
+          const int la = label[a], lb = label[b];
+          if (la == lb) return;
+          const int m = la < lb ? la : lb;
+          wv_atomic_min_i(&label[a], m);
+          wv_atomic_min_i(&label[b], m);
+          // (the component's current representatives as well, so that a lowered label reaches every member)
+          wv_atomic_min_i(&label[la], m);
+          wv_atomic_min_i(&label[lb], m);
+          moved = 1;
+        };
+        if (t2 == -3) scan_row(i, join);
+        else if (t2 >= 0) join(efc_tree[i], t2);
+      }
+      wv_sync();
+      MJH_FOR_LANES(t, ntree) {
+        int l = label[t];
+        if (l >= 0) { while (label[l] != l) l = label[l]; if (label[t] != l) { label[t] = l; moved = 1; } }
+      }
+      wv_sync();
+      if (!wv_any(moved)) break;
+    }
+    // mj_dsuAssign: islands in ascending order of their smallest tree
     int nisland = 0;
-    for (int t = 0; t < ntree; t++) {
-      if (parent[t] == -1) { tree_island[t] = -1; continue; }
-      if (parent[t] == t) tree_island[t] = nisland++;
-      else { parent[t] = parent[parent[t]]; tree_island[t] = tree_island[parent[t]]; }
+    for (int t0 = 0; t0 < ntree; t0 += MJH_W) {
+      const int t = t0 + wv_lane();
+      const int root = t < ntree && label[t] == t;
+      const int before = wv_exscan_i(root);
+      if (root) tree_island[t] = nisland + before;
+      nisland += wv_sum_i(root);
     }
-    for (int i = 0; i < nefc; i++) P.island[i] = tree_island[efc_tree[i]];
-    counts[MJH_C_NISLAND] = nisland;
+    wv_sync();
+    MJH_FOR_LANES(t, ntree) { const int l = label[t]; if (l < 0) tree_island[t] = -1; else if (l != t) tree_island[t] = tree_island[l]; }
+    wv_sync();
+    MJH_FOR_LANES(i, nefc) P.island[i] = tree_island[efc_tree[i]];
+    if (wv_lane() == 0) counts[MJH_C_NISLAND] = nisland;
   }
   wv_sync();
 }

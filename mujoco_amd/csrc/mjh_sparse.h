@@ -98,11 +98,64 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
   wv_sync();
   efc_layout(M, B, e, nefc, P);               // (the transposed arrays are sized by nJ)
   crptr J = P.J;
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr subtree_com = MJH_F(B, subtree_com, e);
+  const int ispyramid = M.o.cone == 0;
   MJH_FOR_LANES(r, nefc) {
     M128 pm = m128_ld(P.rowmask + 4*r);
     int a = P.rowadr[r];
-    crptr Jr = J + (size_t)r*nv;
-    while (m128_any(pm)) { const int j = m128_lowest(pm); pm = m128_drop_lowest(pm); P.spJ[a++] = Jr[j]; }
+    const int type = P.type[r];
+    if (type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
+      // non-contact rows: cut from the dense row stage_make_constraint wrote
+      crptr Jr = J + (size_t)r*nv;
+      while (m128_any(pm)) { const int j = m128_lowest(pm); pm = m128_drop_lowest(pm); P.spJ[a++] = Jr[j]; }
+      continue;
+    }
+    // contact row, computed here for the dofs of its pattern (mj_contactJacobian / mj_instantiateContact,
+    // engine_core_constraint.c:1535-1700: point Jacobians of the two bodies, their difference rotated into the
+    // contact frame with mju_mulMatMat's zero-skip; the same expressions, dof by dof, as the dense assembly)
+    const int k = P.id[r];
+    const int sub = r - MJH_CON(B, con_efcadr, e, 1, k)[0];        // row of the contact's block
+    const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+    const int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    crptr point = MJH_CON(B, con_pos, e, 3, k);
+    crptr fr = MJH_CON(B, con_frame, e, 9, k);
+    auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
+    real off1[3], off2[3];
+    v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
+    v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
+    // which frame rows this constraint row combines: a0 (+ a1 * scale)
+    int a0 = 0, a1 = -1;
+    real scl = 0;
+    if (dim == 1) a0 = 0;
+    else if (ispyramid) { a0 = 0; a1 = 1 + (sub >> 1); scl = (sub & 1) ? -fri[sub >> 1] : fri[sub >> 1]; }
+    else a0 = sub;
+    while (m128_any(pm)) {
+      const int j = m128_lowest(pm);
+      pm = m128_drop_lowest(pm);
+      const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+      crptr cd = cdof + 6*j;
+      if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+      if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
+      const real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+      const real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0), (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
+                          (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+      auto frame_row = [&](int arow) -> real {
+        // rows 0..2: translational difference, rows 3..5: rotational difference, each against frame row (arow mod 3)
+        const real* v = arow < 3 ? jd : rd;
+        const int f = arow < 3 ? arow : arow - 3;
+        real acc = 0;
+        for (int q = 0; q < 3; q++) { const real t = fr[3*f + q]; if (t != 0) acc += v[q]*t; }
+        return acc;
+      };
+      real val = frame_row(a0);
+      if (a1 >= 0) val = val + frame_row(a1)*scl;
+      P.spJ[a++] = val;
+    }
   }
   // transpose (mju_transposeSparse: row j of J' lists the constraints that contain dof j, ascending): lane = dof
   int cnt0 = 0, cnt1 = 0;

@@ -173,6 +173,8 @@ MJH_DEV double wv_rows_sum(double v) {
 }
 MJH_DEV long long wv_clock() { return 0; }
 MJH_DEV int wv_sub() { return 0; }
+// *p = min(*p, v), atomically with respect to the other lanes (the emulation runs them one at a time)
+MJH_DEV void wv_atomic_min_i(int* p, int v) { if (v < *p) *p = v; }
 
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row
@@ -394,6 +396,8 @@ MJH_DEV double wv_rows_sum(double v) {
 // constant-rate (100 MHz) timestamp, for -DMJH_PROFILE builds
 MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 MJH_DEV int wv_sub() { return 0; }
+// *p = min(*p, v), atomically with respect to the other lanes (flat address: LDS or global)
+MJH_DEV void wv_atomic_min_i(int* p, int v) { atomicMin(p, v); }
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row.  v_permlane16_swap exchanges
 // the odd rows of its first operand with the even rows of its second; with both operands = v each
