@@ -433,10 +433,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto sp_chol_solve = [&](rptr L) {
     real y0 = (lane < nv && m128_test(isl_dofs, lane)) ? (real)grad[lane] : (real)0;
     real y1 = (lane + MJH_W < nv && m128_test(isl_dofs, lane + MJH_W)) ? (real)grad[lane + MJH_W] : (real)0;
-    if (mjh_in_lds(L)) sp_solve(M, P, mjh_local(L.p), isl_dofs, y0, y1);
-    else sp_solve(M, P, L, isl_dofs, y0, y1);
-    if (lane < nv) Mgrad[lane] = y0;
-    if (lane + MJH_W < nv) Mgrad[lane + MJH_W] = y1;
+    const SpVec2 y = mjh_in_lds(L) ? sp_solve(M, P, mjh_local(L.p), isl_dofs, y0, y1) : sp_solve(M, P, L, isl_dofs, y0, y1);
+    if (lane < nv) Mgrad[lane] = y.y0;
+    if (lane + MJH_W < nv) Mgrad[lane + MJH_W] = y.y1;
     wv_sync();
   };
   // returns the rank, like mju_cholUpdateSparse

@@ -381,8 +381,11 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
 
 // mju_cholSolveSparse: x <- L^-T x over the rows descending (x[j] -= L[i][j] x[i]), then x <- L^-1 x ascending
 // (x[i] -= mju_dotSparse(row i, x)); x in registers (y0: dof lane, y1: dof lane + 64)
+// (the vector goes in and comes back BY VALUE: a reference parameter of an out-of-line routine lives in scratch memory,
+// and the sweeps would round-trip it through there at every row)
+struct SpVec2 { real y0, y1; };
 template <class PL>
-MJH_DEVN_HOT void sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real& y0, real& y1) {
+MJH_DEVN_HOT SpVec2 sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real y0, real y1) {
   const MJH_CONST_AS DModel& M = wv_uniform_ref(M_);
   const int nv = M.s.nv, lane = wv_lane();
   isl = wv_uniform_m128(isl);
@@ -426,6 +429,7 @@ MJH_DEVN_HOT void sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real& y0, real
     xi /= wv_bcast(i < MJH_W ? dg0 : dg1, src);
     if (i < MJH_W) { if (lane == i) y0 = xi; } else { if (lane == i - MJH_W) y1 = xi; }
   }
+  return SpVec2{y0, y1};
 }
 
 // mju_cholUpdateSparse(L, x, flg_plus): rows from the last non-zero of x downwards, Givens rotation of (row, x) for
