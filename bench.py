@@ -166,10 +166,10 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread):
                       f"U(ctrlrange) control stream, {T} steps (warm-up + timed) from reset, {nthread} threads"}, final
 
 
-def measured_traffic(steps_per_launch: int, nenv: int):
+def measured_traffic(steps_per_launch: int, nenv: int, model_xml: str = ""):
     """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
     same command (tools/gpu_profile.sh -> profiles/<round>/pmc_summary*.txt; FETCH_SIZE x2 per the
-    gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the launch."""
+    gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the workload."""
     import glob
     best = None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.txt")))
@@ -179,11 +179,43 @@ def measured_traffic(steps_per_launch: int, nenv: int):
         pref = os.path.join(ROOT, "profiles", open(cur).read().strip()) + os.sep
         files = [f for f in files if not f.startswith(pref)] + [f for f in files if f.startswith(pref)]
     for f in files:
-        m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB",
-                      open(f).read())
+        text = open(f).read()
+        if model_xml and model_xml not in text:
+            continue
+        m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB", text)
         if m and int(m.group(1)) == steps_per_launch and int(m.group(2)) == nenv:
             best = (float(m.group(4)) + float(m.group(5))) * 1e6
     return best
+
+
+def measured_sq(config: str):
+    """Instruction-level evidence for `roofline` from the committed SQ-counter summary of the rollout kernel
+    (tools/gpu_sq.sh -> profiles/<CURRENT>/sq_summary_<config>.txt, regime uniform): vector / scalar instructions per
+    env-step and the mean fraction of the 64 lanes a vector instruction has active.  None without a summary."""
+    cur = os.path.join(ROOT, "profiles", "CURRENT")
+    if not os.path.exists(cur):
+        return None
+    f = os.path.join(ROOT, "profiles", open(cur).read().strip(), "sq_summary_%s.txt" % config)
+    if not os.path.exists(f):
+        return None
+    vals = {}
+    take = False
+    for line in open(f):
+        if line.startswith("-- rollout kernel"):
+            take = "regime uniform" in line
+        elif line.startswith("=="):
+            take = False
+        elif take:
+            m = re.match(r"\s+(SQ_[A-Z_]+)\s+([0-9.]+)", line)
+            if m:
+                vals[m.group(1)] = float(m.group(2))
+    if "SQ_INSTS_VALU" not in vals:
+        return None
+    out = {"valu_insts_per_env_step": vals["SQ_INSTS_VALU"], "salu_insts_per_env_step": vals.get("SQ_INSTS_SALU"),
+           "source": os.path.relpath(f, ROOT)}
+    if "SQ_THREAD_CYCLES_VALU" in vals and vals.get("SQ_ACTIVE_INST_VALU"):
+        out["active_lane_frac"] = vals["SQ_THREAD_CYCLES_VALU"] / vals["SQ_ACTIVE_INST_VALU"] / 64.0
+    return out
 
 
 def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0)):
@@ -480,7 +512,8 @@ def main() -> None:
                        "kernel_variant": batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic",
                        "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv, cfg["xml"]),
+                         **(measured_sq(args.config) or {}),
                          "kernel": "mjh_k_rollout_" + {"generic": "wv", "lean": "wl"}.get(
                              batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic", "wv"),
                          "steps_per_launch": C,
