@@ -705,6 +705,59 @@ MJH_DEV void make_frame(P0 frame) {
   v3_cross(frame + 6, frame, frame + 3);
 }
 
+// Oriented-box cull for the GJK / EPA pairs: 1 = the geoms' local bounding boxes (geom_aabb: centre and half sizes
+// in the geom frame) are separated by more than `margin` along one of the 15 candidate axes.  Every convex shape lies
+// inside its box, so the true distance is at least that separation; GJK reports an UPPER bound of the true distance
+// and mjc_Convex keeps a contact only if it is below the margin: a culled pair cannot produce a contact, and a pair
+// that passes is handed to the narrowphase exactly as before -- the contact list is unchanged, the narrowphase just
+// sees about half as many pairs on contact-rich scenes (cube_3x3x3: edge- and corner-adjacent cubelets pass the
+// bounding-sphere test but not this one).  A tiny slack keeps rounding of the test itself on the safe side.
+template <class P0, class P1>
+MJH_DEV int filter_obb(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
+  auto a1 = M.geom_aabb + 6*g1;
+  auto a2 = M.geom_aabb + 6*g2;
+  crptr R1 = gm + 9*g1; crptr R2 = gm + 9*g2;
+  real c1[3], c2[3], t[3];
+  for (int k = 0; k < 3; k++) {
+    c1[k] = gx[3*g1 + k] + (R1[3*k]*a1[0] + R1[3*k + 1]*a1[1] + R1[3*k + 2]*a1[2]);
+    c2[k] = gx[3*g2 + k] + (R2[3*k]*a2[0] + R2[3*k + 1]*a2[1] + R2[3*k + 2]*a2[2]);
+    t[k] = c2[k] - c1[k];
+  }
+  const real h1[3] = {a1[3], a1[4], a1[5]}, h2[3] = {a2[3], a2[4], a2[5]};
+  const real bound = margin + 1e-9;
+  // C[i][j] = axis i of box 1 . axis j of box 2 (axes = columns of the rotation matrices)
+  real C[3][3], Cabs[3][3], t1[3], t2[3];
+  for (int i = 0; i < 3; i++) {
+    t1[i] = t[0]*R1[i] + t[1]*R1[3 + i] + t[2]*R1[6 + i];
+    t2[i] = t[0]*R2[i] + t[1]*R2[3 + i] + t[2]*R2[6 + i];
+    for (int j = 0; j < 3; j++) {
+      C[i][j] = R1[i]*R2[j] + R1[3 + i]*R2[3 + j] + R1[6 + i]*R2[6 + j];
+      Cabs[i][j] = fabs(C[i][j]);
+    }
+  }
+  for (int i = 0; i < 3; i++) {
+    const real rb = h2[0]*Cabs[i][0] + h2[1]*Cabs[i][1] + h2[2]*Cabs[i][2];
+    if (fabs(t1[i]) - (h1[i] + rb) > bound) return 1;
+  }
+  for (int j = 0; j < 3; j++) {
+    const real ra = h1[0]*Cabs[0][j] + h1[1]*Cabs[1][j] + h1[2]*Cabs[2][j];
+    if (fabs(t2[j]) - (ra + h2[j]) > bound) return 1;
+  }
+  for (int i = 0; i < 3; i++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    for (int j = 0; j < 3; j++) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      // axis L = a_i x b_j: |L|^2 = 1 - C[i][j]^2 (unit axes); nearly parallel edges give no usable axis
+      const real len2 = 1 - C[i][j]*C[i][j];
+      if (len2 < 1e-6) continue;
+      const real sep = fabs(t1[i2]*C[i1][j] - t1[i1]*C[i2][j]) -
+                       (h1[i1]*Cabs[i2][j] + h1[i2]*Cabs[i1][j] + h2[j1]*Cabs[i][j2] + h2[j2]*Cabs[i][j1]);
+      if (sep > 0 && sep*sep > bound*bound*len2*(1 + 1e-9)) return 1;
+    }
+  }
+  return 0;
+}
+
 // mj_filterSphere, engine_collision_driver.c:267: 1 = cull
 template <class P0, class P1>
 MJH_DEV int filter_sphere(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
@@ -1152,7 +1205,10 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   };
   auto passes_filter = [&](int p) -> int {
     if (p >= s.npair) return 0;
-    return !filter_sphere(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p]);
+    if (filter_sphere(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p])) return 0;
+    if (MJH_HAS(MJH_FT_COLCONVEX) && M.pair_func[p] == MJH_COL_CONVEX &&
+        filter_obb(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p])) return 0;
+    return 1;
   };
 
 #if !MJH_LANE_MODE
