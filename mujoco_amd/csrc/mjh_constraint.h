@@ -92,25 +92,40 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
   unsigned long long mask = 0, bit = 1;
   char* const lds_ = MJH_LDS(B);
-  // sparse primal path: what the solver's serial chains touch goes first -- row addresses and patterns of the factor,
-  // the dof vectors, then the factor itself takes ALL that is left of region 1 (up to its full size); the per-row
-  // arrays below are streamed lane-parallel and can live in global memory
-  P.spL_home = MJH_G(B, sp_L, e); P.spL = P.spL_home; P.spL_cap = M.s.nLp;
-  P.spLc = MJH_G(B, sp_Lc, e);
+  // Primal solvers: what the solver's serial chains touch is placed first -- row addresses / patterns of the sparse
+  // factor, the dof vectors, the factor itself (sparse: compressed by pattern, takes all that is left up to its full
+  // size; dense: packed lower triangle).  These arrays are born in the solver, after the fields of region 2 have
+  // died, and the dual-only arrays that would use region 2 do not exist here: the block grows upward from the bottom
+  // of region 2 across the boundary into region 1, and the arrays written by constraint assembly get what is left
+  // above it.  They are streamed lane-parallel and can live in global memory.
+  const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
+  P.spL_home = sp_ ? MJH_G(B, sp_L, e) : MJH_G(B, nt_H, e);
+  P.spL = P.spL_home; P.spL_cap = sp_ ? M.s.nLp : nv*nv;
+  P.spLc = sp_ ? MJH_G(B, sp_Lc, e) : MJH_G(B, nt_M, e);
   P.Ladr = MJH_G(B, sp_Ladr, e); P.Lmask = MJH_G(B, sp_Lmask, e);
   P.vec = MJH_G(B, nt_vec, e);
   P.spar = MJH_G(B, iscratch, e) + nmax;
-  if (sp_) {
-    const int nvec = (M.o.solver == MJH_SOL_NEWTON ? 5 : 8)*nv*(int)sizeof(real);
-    const int b_adr = (((nv + 1)*(int)sizeof(int)) + 7) & ~7, b_mask = 4*nv*(int)sizeof(int);
-    if (off1 + b_adr <= end1) { P.Ladr = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_adr; }
-    if (off1 + b_mask <= end1) { P.Lmask = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_mask; }
-    if (off1 + b_adr <= end1) { P.spar = SP<int>{(int*)(lds_ + off1), 1}; off1 += b_adr; }
-    if (off2 + nvec <= end2) { P.vec = SP<real>{(real*)(lds_ + off2), 1}; off2 += nvec; }
-    else if (off1 + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + off1), 1}; off1 += nvec; }
-    int lb = (end1 - off1) & ~7;
-    if (lb > M.s.nLp*(int)sizeof(real)) lb = M.s.nLp*(int)sizeof(real);
-    if (lb >= 64*(int)sizeof(real)) { P.spL = SP<real>{(real*)(lds_ + off1), 1}; P.spL_cap = lb/(int)sizeof(real); off1 += lb; }
+  if (primal_ && B.lds_bytes) {
+    int lo = off2;
+    const int newton = M.o.solver == MJH_SOL_NEWTON;
+    const int nvec = (newton ? 5 : 8)*nv*(int)sizeof(real);
+    if (sp_) {
+      const int b_adr = (((nv + 1)*(int)sizeof(int)) + 7) & ~7, b_mask = 4*nv*(int)sizeof(int);
+      if (lo + b_adr <= end1) { P.Ladr = SP<int>{(int*)(lds_ + lo), 1}; lo += b_adr; }
+      if (lo + b_mask <= end1) { P.Lmask = SP<int>{(int*)(lds_ + lo), 1}; lo += b_mask; }
+      if (lo + b_adr <= end1) { P.spar = SP<int>{(int*)(lds_ + lo), 1}; lo += b_adr; }
+    }
+    if (lo + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + lo), 1}; lo += nvec; }
+    if (newton) {
+      const int full = (sp_ ? M.s.nLp : nv*(nv + 1)/2)*(int)sizeof(real);
+      int lb = (end1 - lo) & ~7;
+      if (lb > full) lb = full;
+      // (the dense factor is not addressed through a capacity: all or nothing)
+      if (sp_ ? lb >= 64*(int)sizeof(real) : lb == full) { P.spL = SP<real>{(real*)(lds_ + lo), 1}; P.spL_cap = lb/(int)sizeof(real); lo += lb; }
+      if (!sp_ && M.o.cone != 0 && lo + full <= end1) { P.spLc = SP<real>{(real*)(lds_ + lo), 1}; lo += full; }
+    }
+    off2 = end2;
+    if (lo > off1) off1 = lo;
   }
   // a region-2 array that does not fit its region falls through to what is left of region 1
 #define MJH_EFC_PLACE(T, m, home, bytes, region)                                              \

@@ -12,8 +12,8 @@
 // slow and its iteration counts approximate.
 //
 // Mapping (one wavefront per environment):
-//   * the factor L lives column-major (Lt[k*n + i] = L[i][k]) so that "lane = row i" walks a column
-//     with unit stride: the dot products of mju_cholFactor, the column sweeps of mju_cholUpdate and the
+//   * the factor L lives column-major, lower triangle packed (column k holds rows k..n-1) so that "lane = row i"
+//     walks a column with unit stride: the dot products of mju_cholFactor, the column sweeps of mju_cholUpdate and the
 //     back substitution all read coalesced; L sits in LDS when the residency plan leaves room;
 //   * vectors over dofs live in registers (lane = dof, a second register for dofs 64..127);
 //   * the reference's sums are sequential: dot products in mju_dot's four-accumulator order, constraint
@@ -100,6 +100,71 @@ MJH_DEV real nt_elliptic_costdif(Q q, real alpha, real mu, real Dm) {
   return 0;
 }
 
+// ---- dense factor, nv <= 64: out-of-line solve and rank-one update (own register scope; the factor through a local
+// -- ds_read / ds_write -- pointer when it sits in LDS; vectors by value; every pivot in the register of the lane named
+// after its row, so no lane reads a pivot from memory while its owner rewrites it).  Packed lower triangle,
+// column-major: element (row i, column k), i >= k, at k*nv - k(k-1)/2 + (i - k).
+MJH_DEV int nt_lx(int nv, int k, int i) { return k*nv - k*(k - 1)/2 + (i - k); }
+// mju_cholSolve: forward substitution by row dots (mju_dot's order), back substitution by sequential subtraction
+template <class PL>
+MJH_DEVN_HOT real dn_solve(PL L, int nv, real y0) {
+  const int lane = wv_lane();
+  const real dg = lane < nv ? (real)L[nt_lx(nv, lane, lane)] : (real)1;
+  for (int i = 0; i < nv; i++) {
+    const real p0 = lane < i ? (real)(L[nt_lx(nv, lane, i)]*y0) : (real)0;
+    real yi = wv_bcast(y0, i);
+    if (i) {
+      real r[4] = {0, 0, 0, 0};
+      const int G = i >> 2;
+      wv_dot4_acc(r, p0, G);
+      real res = (r[0] + r[2]) + (r[1] + r[3]);
+      const int c = 4*G, rem = i - c;
+      if (rem == 3) res += wv_bcast(p0, c) + wv_bcast(p0, c + 1) + wv_bcast(p0, c + 2);
+      else if (rem == 2) res += wv_bcast(p0, c) + wv_bcast(p0, c + 1);
+      else if (rem == 1) res += wv_bcast(p0, c);
+      yi -= res;
+    }
+    yi /= wv_bcast(dg, i);
+    if (lane == i) y0 = yi;
+  }
+  for (int i = nv - 1; i >= 0; i--) {
+    const real p0 = (lane > i && lane < nv) ? (real)(L[nt_lx(nv, i, lane)]*y0) : (real)0;
+    real yi = wv_bcast(y0, i);
+    yi = wv_chain(yi, p0, i + 1, nv, 1);
+    yi /= wv_bcast(dg, i);
+    if (lane == i) y0 = yi;
+  }
+  return y0;
+}
+// mju_cholUpdate(L, x, flg_plus); returns the number of clamped pivots
+template <class PL>
+MJH_DEVN_HOT int dn_update(PL L, int nv, real x0, int flg_plus) {
+  const int lane = wv_lane();
+  real dg = lane < nv ? (real)L[nt_lx(nv, lane, lane)] : (real)1;
+  int clamped = 0;
+  for (int k = 0; k < nv; k++) {
+    const real xk = wv_bcast(x0, k);
+    if (xk == 0) continue;
+    const real Lkk = wv_bcast(dg, k);
+    real tmp = Lkk*Lkk + (flg_plus ? xk*xk : -xk*xk);
+    if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; clamped++; }
+    const real r = sqrt(tmp);
+    const real c = r/Lkk;
+    const real cinv = 1/c;
+    const real sx = xk/Lkk;
+    if (lane == k) { dg = r; L[nt_lx(nv, k, k)] = r; }
+    else if (lane > k && lane < nv) {
+      const int a = nt_lx(nv, k, lane);
+      const real l0 = L[a];
+      const real lik = flg_plus ? (l0 + sx*x0)*cinv : (l0 - sx*x0)*cinv;
+      L[a] = lik;
+      x0 = c*x0 - sx*lik;
+    }
+  }
+  wv_sync();
+  return clamped;
+}
+
 struct NtPoint { real alpha, cost, d0, d1; };
 
 // ELL = 0: instantiation without elliptic-cone code (the common pyramidal case keeps its register budget)
@@ -137,16 +202,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // ---- storage
   // factor(s): column-major n x n; in LDS when the plan's unused tail takes them (primal solvers leave
   // the dual arrays' bytes free), else their global homes
-  rptr Lt = SPA ? P.spL : MJH_G(B, nt_H, e);
-  rptr Lc = SPA ? P.spLc : MJH_G(B, nt_M, e);     // Lcone (elliptic)
-  rptr vec = SPA ? P.vec : MJH_G(B, nt_vec, e);
-  if (!SPA) {
-    char* fp = P.free_p;
-    int fb = P.free_bytes;
-    const int lbytes = nv*nv*(int)sizeof(real);
-    if (!SPA && flg_newton && fb >= lbytes) { Lt = SP<real>{(real*)fp, 1}; fp += lbytes; fb -= lbytes; }
-    if (fb >= (int)(8*nv*sizeof(real))) vec = SP<real>{(real*)fp, 1};
-  }
+  // (sparse: compressed by pattern, mjh_sparse.h; dense: packed lower triangle, column-major -- element (row i, column k),
+  // i >= k, at LX(k, i); both sit in the LDS slot efc_layout reserves for the solver when the plan has room)
+  rptr Lt = P.spL;
+  rptr Lc = P.spLc;                               // Lcone (elliptic)
+  rptr vec = P.vec;
+  auto LX = [nv](int k, int i) { return k*nv - k*(k - 1)/2 + (i - k); };
   rptr Ma = vec, grad = vec + nv, Mgrad = vec + 2*nv, search = vec + 3*nv, Mv = vec + 4*nv;
   rptr gradold = vec + 5*nv, Mgradold = vec + 6*nv, tmpv = vec + 7*nv;
   rptr jar = P.jar, Jv = P.ARf;
@@ -318,11 +379,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         if (tmp == 0) continue;
         acc += J[(size_t)j*nv + k]*(tmp*dj);
       }
-      L[k*nv + i] = acc;
+      L[LX(k, i)] = acc;
     }
     wv_sync();
     // mju_addToSymSparse: + M on the lower triangle
-    MJH_FOR_LANES(a, s.nC) { const int i = M.M_rowid[a], k = M.M_colind[a]; L[k*nv + i] += Ms[a]; }
+    MJH_FOR_LANES(a, s.nC) { const int i = M.M_rowid[a], k = M.M_colind[a]; L[LX(k, i)] += Ms[a]; }
     wv_sync();
   };
 
@@ -330,27 +391,40 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // i >= j, the dot of rows i and j over the finished columns [0, j).  Rows lane and lane + 64.
   const int two = nv > MJH_W;                    // dof vectors occupy a second register slot
   auto chol_factor = [&](rptr L) {
-    const long long cs = (long long)nv*L.s;      // column stride
+    // mju_dot over the finished columns c < j of rows i and j
+    auto rowdot = [&](int i, int j) -> real {
+      real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      int c = 0;
+      for (; c <= j - 4; c += 4) {
+        r0 += L[LX(c, i)]*L[LX(c, j)]; r1 += L[LX(c + 1, i)]*L[LX(c + 1, j)];
+        r2 += L[LX(c + 2, i)]*L[LX(c + 2, j)]; r3 += L[LX(c + 3, i)]*L[LX(c + 3, j)];
+      }
+      real res = (r0 + r2) + (r1 + r3);
+      const int rem = j - c;
+      if (rem == 3) res += L[LX(c, i)]*L[LX(c, j)] + L[LX(c + 1, i)]*L[LX(c + 1, j)] + L[LX(c + 2, i)]*L[LX(c + 2, j)];
+      else if (rem == 2) res += L[LX(c, i)]*L[LX(c, j)] + L[LX(c + 1, i)]*L[LX(c + 1, j)];
+      else if (rem == 1) res += L[LX(c, i)]*L[LX(c, j)];
+      return res;
+    };
     for (int j = 0; j < nv; j++) {
       real d0 = 0, d1 = 0;
-      const SP<const real> rowj{L.p + (long long)j*L.s, (int)cs};
       if (j > 0) {
-        if (lane >= j && lane < nv) d0 = dot_ref(SP<const real>{L.p + (long long)lane*L.s, (int)cs}, rowj, j);
-        if (two && lane + MJH_W >= j && lane + MJH_W < nv) d1 = dot_ref(SP<const real>{L.p + (long long)(lane + MJH_W)*L.s, (int)cs}, rowj, j);
+        if (lane >= j && lane < nv) d0 = rowdot(lane, j);
+        if (two && lane + MJH_W >= j && lane + MJH_W < nv) d1 = rowdot(lane + MJH_W, j);
       }
-      real tmp = L[j*nv + j];
+      real tmp = L[LX(j, j)];
       if (j) tmp -= dof_get(d0, d1, j);
       const int deficient = tmp < MJH_MINVAL;
       if (deficient) tmp = MJH_MINVAL;
       const real djj = sqrt(tmp);
       const real inv = 1/djj;
       wv_sync();
-      if (lane == j) L[j*nv + j] = djj;
-      else if (lane > j && lane < nv) L[j*nv + lane] = deficient ? (real)0 : (L[j*nv + lane] - d0)*inv;
+      if (lane == j) L[LX(j, j)] = djj;
+      else if (lane > j && lane < nv) L[LX(j, lane)] = deficient ? (real)0 : (L[LX(j, lane)] - d0)*inv;
       if (two) {
         const int i = lane + MJH_W;
-        if (i == j) L[j*nv + j] = djj;
-        else if (i > j && i < nv) L[j*nv + i] = deficient ? (real)0 : (L[j*nv + i] - d1)*inv;
+        if (i == j) L[LX(j, j)] = djj;
+        else if (i > j && i < nv) L[LX(j, i)] = deficient ? (real)0 : (L[LX(j, i)] - d1)*inv;
       }
       wv_sync();
     }
@@ -359,24 +433,31 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // mju_cholSolve(Mgrad, L, grad, nv): forward substitution by row dots, back substitution by sequential
   // subtraction; the vector stays in registers (y0: dof lane, y1: dof lane + 64)
   auto chol_solve = [&](crptr L) {
+    if (!two) {
+      real y = lane < nv ? (real)grad[lane] : (real)0;
+      y = mjh_in_lds(L) ? dn_solve(mjh_local(L.p), nv, y) : dn_solve(L, nv, y);
+      if (lane < nv) Mgrad[lane] = y;
+      wv_sync();
+      return;
+    }
     real y0 = lane < nv ? (real)grad[lane] : (real)0;
     real y1 = (two && lane + MJH_W < nv) ? (real)grad[lane + MJH_W] : (real)0;
     for (int i = 0; i < nv; i++) {
-      const real p0 = lane < i ? L[lane*nv + i]*y0 : (real)0;
-      const real p1 = (two && lane + MJH_W < i) ? L[(lane + MJH_W)*nv + i]*y1 : (real)0;
+      const real p0 = lane < i ? L[LX(lane, i)]*y0 : (real)0;
+      const real p1 = (two && lane + MJH_W < i) ? L[LX((lane + MJH_W), i)]*y1 : (real)0;
       real yi = dof_get(y0, y1, i);
       if (i) yi -= dot_lanes(p0, p1, i);
-      yi /= L[i*nv + i];
+      yi /= L[LX(i, i)];
       if (i < MJH_W) { if (lane == i) y0 = yi; } else { if (lane == i - MJH_W) y1 = yi; }
     }
     for (int i = nv - 1; i >= 0; i--) {
-      const real p0 = (lane > i && lane < nv) ? L[i*nv + lane]*y0 : (real)0;
-      const real p1 = (two && lane + MJH_W > i && lane + MJH_W < nv) ? L[i*nv + lane + MJH_W]*y1 : (real)0;
+      const real p0 = (lane > i && lane < nv) ? L[LX(i, lane)]*y0 : (real)0;
+      const real p1 = (two && lane + MJH_W > i && lane + MJH_W < nv) ? L[LX(i, lane + MJH_W)]*y1 : (real)0;
       real yi = dof_get(y0, y1, i);
       // res[i] -= L[j][i]*res[j], j = i+1 .. n-1 in order
       if (i + 1 < MJH_W) yi = wv_chain(yi, p0, i + 1, nv < MJH_W ? nv : MJH_W, 1);
       if (two) yi = wv_chain(yi, p1, i + 1 > MJH_W ? i + 1 - MJH_W : 0, nv - MJH_W, 1);
-      yi /= L[i*nv + i];
+      yi /= L[LX(i, i)];
       if (i < MJH_W) { if (lane == i) y0 = yi; } else { if (lane == i - MJH_W) y1 = yi; }
     }
     if (lane < nv) Mgrad[lane] = y0;
@@ -386,11 +467,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
   // mju_cholUpdate(L, x, nv, flg_plus): x in registers (x0: dof lane, x1: dof lane + 64); returns the rank
   auto chol_update = [&](rptr L, real x0, real x1, int flg_plus) -> int {
+    if (!two) return nv - (mjh_in_lds(L) ? dn_update(mjh_local(L.p), nv, x0, flg_plus) : dn_update(L, nv, x0, flg_plus));
     int rank = nv;
     for (int k = 0; k < nv; k++) {
       const real xk = dof_get(x0, x1, k);
       if (xk == 0) continue;
-      const real Lkk = L[k*nv + k];
+      const real Lkk = L[LX(k, k)];
       real tmp = Lkk*Lkk + (flg_plus ? xk*xk : -xk*xk);
       if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; rank--; }
       const real r = sqrt(tmp);
@@ -398,18 +480,18 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const real cinv = 1/c;
       const real sx = xk/Lkk;
       wv_sync();                                  // (every lane has read L[k][k] before its owner overwrites it)
-      if (lane == k) L[k*nv + k] = r;
+      if (lane == k) L[LX(k, k)] = r;
       else if (lane > k && lane < nv) {
-        const real lik = flg_plus ? (L[k*nv + lane] + sx*x0)*cinv : (L[k*nv + lane] - sx*x0)*cinv;
-        L[k*nv + lane] = lik;
+        const real lik = flg_plus ? (L[LX(k, lane)] + sx*x0)*cinv : (L[LX(k, lane)] - sx*x0)*cinv;
+        L[LX(k, lane)] = lik;
         x0 = c*x0 - sx*lik;
       }
       if (two) {
         const int i = lane + MJH_W;
-        if (i == k) L[k*nv + k] = r;
+        if (i == k) L[LX(k, k)] = r;
         else if (i > k && i < nv) {
-          const real lik = flg_plus ? (L[k*nv + i] + sx*x1)*cinv : (L[k*nv + i] - sx*x1)*cinv;
-          L[k*nv + i] = lik;
+          const real lik = flg_plus ? (L[LX(k, i)] + sx*x1)*cinv : (L[LX(k, i)] - sx*x1)*cinv;
+          L[LX(k, i)] = lik;
           x1 = c*x1 - sx*lik;
         }
       }
@@ -452,7 +534,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
-    MJH_FOR_LANES(w, SPA ? sp_nL : nv*nv) Lc[w] = Lt[w];
+    MJH_FOR_LANES(w, SPA ? sp_nL : nv*(nv + 1)/2) Lc[w] = Lt[w];
     wv_sync();
     for (int i = 0; i < nefc; i++) {
       if (!in_row(i) || P.state[i] != MJH_STATE_CONE) continue;
