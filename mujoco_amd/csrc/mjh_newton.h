@@ -603,19 +603,33 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // HessianIncremental
   auto hessian_incremental = [&]() {
     if (SPA) {
+      // the rows that entered or left the quadratic zone, in order, MJH_SP_KB at a time through one sweep over the
+      // factor (sp_update_batch); a clamped pivot anywhere means the reference refactorises from scratch
+      SpBatch bt;
+      bt.n = 0; bt.plus = 0;
+      for (int u = 0; u < MJH_SP_KB/2; u++) bt.rows[u] = 0;
+      auto flush = [&]() -> int {
+        if (!bt.n) return 0;
+        const int clamped = mjh_in_lds(Lt) ? sp_update_batch(M, P, mjh_local(Lt.p), bt) : sp_update_batch(M, P, Lt, bt);
+        bt.n = 0; bt.plus = 0;
+        for (int u = 0; u < MJH_SP_KB/2; u++) bt.rows[u] = 0;
+        return clamped;
+      };
       for (int r0 = 0; r0 < nefc; r0 += MJH_W) {
         const int r = r0 + lane;
         int changed = 0;
         if (r < nefc && in_row(r)) changed = (oldstate[r] == MJH_STATE_QUADRATIC) != (P.state[r] == MJH_STATE_QUADRATIC);
         for (unsigned long long chg = wv_ballot(changed); chg; chg &= chg - 1) {
           const int i = r0 + __builtin_ctzll(chg);
-          real x0, x1;
-          M128 pm;
-          sp_row_lanes(i, sqrt(P.D[i]), x0, x1, pm);
-          const int rank = sp_chol_update(Lt, x0, x1, pm, P.state[i] == MJH_STATE_QUADRATIC);
-          if (rank < nv) { factorize(1); return; }
+          const int u = bt.n;
+#pragma unroll
+          for (int q = 0; q < MJH_SP_KB/2; q++) if (q == (u >> 1)) bt.rows[q] |= i << (16*(u & 1));
+          if (P.state[i] == MJH_STATE_QUADRATIC) bt.plus |= 1 << u;
+          bt.n = u + 1;
+          if (bt.n == MJH_SP_KB && flush()) { factorize(1); return; }
         }
       }
+      if (flush()) { factorize(1); return; }
       if (ELL && ncone) hessian_cone();
       return;
     }

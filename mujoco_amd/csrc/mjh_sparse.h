@@ -479,4 +479,92 @@ MJH_DEVN_HOT int sp_update(MREF M_, const Efc& P, PL L, real x0, real x1, M128 x
   return clamped;
 }
 
+// Several rank-one updates in ONE sweep over the rows.  The reference applies the updates of a Newton iteration one
+// after the other, each as a sweep from its last non-zero row down to row 0 (HessianIncremental -> mju_cholUpdateSparse).
+// Update u rotates row r using only row r of the factor and its own vector x_u; so update u+1 may rotate row r as soon
+// as update u has -- before update u has gone on to row r-1.  Visiting the rows once, top down, and applying at each row
+// the pending rotations in update order performs exactly the reference's operations on exactly the same operands; the
+// row's pattern / address / values are fetched and stored once for all of them.
+#define MJH_SP_KB 8
+// the caller names the constraint rows (two 16-bit indices per word); their scaled Jacobian rows J[i]*sqrt(D[i]) are
+// spread over the dof lanes here, so that the register-hungry part stays out of the solver's own frame
+struct SpBatch {
+  int rows[MJH_SP_KB/2];
+  int plus;                               // bit u: update (1) or downdate (0)
+  int n;
+};
+struct SpBatchRegs { real x0[MJH_SP_KB], x1[MJH_SP_KB]; M128 nz[MJH_SP_KB]; int n, plus; };
+template <class PL>
+MJH_DEVN_HOT int sp_update_batch(MREF M_, const Efc& P, PL L, SpBatch bi) {
+  const MJH_CONST_AS DModel& M = wv_uniform_ref(M_);
+  const int nv = M.s.nv, lane = wv_lane();
+  SpBatchRegs b;
+  b.n = wv_uniform_i(bi.n); b.plus = wv_uniform_i(bi.plus);
+#pragma unroll
+  for (int u = 0; u < MJH_SP_KB; u++) {
+    b.x0[u] = 0; b.x1[u] = 0; b.nz[u] = m128_zero();
+    if (u < b.n) {
+      const int i = wv_uniform_i((bi.rows[u >> 1] >> (16*(u & 1))) & 0xffff);
+      const M128 pm = m128_ld(P.rowmask + 4*i);
+      const int adr = P.rowadr[i];
+      const real scl = sqrt(P.D[i]);
+      b.nz[u] = pm;
+      if (lane < nv && m128_test(pm, lane)) b.x0[u] = P.spJ[adr + m128_rank(pm, lane)]*scl;
+      if (lane + MJH_W < nv && m128_test(pm, lane + MJH_W)) b.x1[u] = P.spJ[adr + m128_rank(pm, lane + MJH_W)]*scl;
+    }
+  }
+  M128 lm0 = m128_zero(), lm1 = m128_zero();
+  int adr0 = 0, adr1 = 0;
+  real dg0 = 1, dg1 = 1;
+  if (lane < nv) { lm0 = m128_ld(P.Lmask + 4*lane); adr0 = P.Ladr[lane]; dg0 = L[adr0 + m128_count(lm0)]; }
+  if (lane + MJH_W < nv) { lm1 = m128_ld(P.Lmask + 4*(lane + MJH_W)); adr1 = P.Ladr[lane + MJH_W]; dg1 = L[adr1 + m128_count(lm1)]; }
+  const int n = b.n, plus = b.plus;
+  M128 all = m128_zero();
+#pragma unroll
+  for (int u = 0; u < MJH_SP_KB; u++) { b.nz[u] = wv_uniform_m128(b.nz[u]); if (u < n) all = m128_or(all, b.nz[u]); }
+  int clamped = 0;
+  while (m128_any(all)) {
+    const int row = m128_highest(all), src = row & (MJH_W - 1);
+    all = m128_xor(all, m128_bit(row));
+    M128 lm;
+    int adr;
+    sp_row_bcast(lm0, lm1, adr0, adr1, row, lm, adr);
+    const int hi = row > MJH_W;
+    const int t0 = lane < row && m128_test(lm, lane);
+    const int k0 = adr + m128_rank_lane0(lm), kd = adr + m128_count(lm);
+    real m0 = t0 ? (real)L[k0] : (real)0;
+    int t1 = 0, k1 = 0;
+    real m1 = 0;
+    if (hi) { t1 = lane + MJH_W < row && m128_test(lm, lane + MJH_W); k1 = adr + m128_rank_lane1(lm); m1 = t1 ? (real)L[k1] : (real)0; }
+    real d = wv_bcast(row < MJH_W ? dg0 : dg1, src);
+    int touched = 0;
+#pragma unroll
+    for (int u = 0; u < MJH_SP_KB; u++) {
+      if (u >= n || !m128_test(b.nz[u], row)) continue;
+      const real xr = wv_bcast(row < MJH_W ? b.x0[u] : b.x1[u], src);
+      if (xr == 0) continue;
+      b.nz[u] = m128_or(b.nz[u], lm);
+      all = m128_or(all, lm);
+      const int up = (plus >> u) & 1;
+      real tmp = d*d + (up ? xr*xr : -xr*xr);
+      if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; clamped++; }
+      const real rr = sqrt(tmp);
+      const real c = d/rr;
+      const real sn = -xr/rr;
+      const real ss = up ? -sn : sn;
+      if (t0) { const real nm = c*m0 + ss*b.x0[u]; b.x0[u] = sn*m0 + c*b.x0[u]; m0 = nm; }
+      if (hi && t1) { const real nm = c*m1 + ss*b.x1[u]; b.x1[u] = sn*m1 + c*b.x1[u]; m1 = nm; }
+      d = rr;
+      touched = 1;
+    }
+    if (touched) {
+      if (lane == src) { if (row < MJH_W) dg0 = d; else dg1 = d; L[kd] = d; }
+      if (t0) L[k0] = m0;
+      if (hi && t1) L[k1] = m1;
+    }
+  }
+  wv_sync();
+  return clamped;
+}
+
 #endif  // !MJH_LANE_MODE
