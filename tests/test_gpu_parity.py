@@ -58,6 +58,31 @@ def test_rollout_vs_golden(rb, hip_lib, dm, golden):
     assert np.array_equal(counts[:, 5], ints[:, 0, 2])
 
 
+@pytest.mark.parametrize("solver", [0, 2, 1], ids=["pgs", "newton", "cg"])
+def test_humanoid_rollout_bit_exact_vs_device_sincos_reference(rb, hip_lib, golden, solver):
+    """BASELINE config 2's model, whole 120-step rollouts on the device against the compiled reference linked with
+    the kernels' own sin / cos (oracle/devmath_shim.cc: liboracle_dm.so; humanoid's step calls no other libm
+    function): states bit for bit, contact / row / solver-iteration counts exact at every step -- PGS (the lean
+    kernel), Newton and CG (the generic kernel, dense primal path)."""
+    fx = golden("humanoid")
+    n, T = 8, fx["ctrl"].shape[1]
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"), kind="devmath")
+    m.opt.solver = solver
+    mm = mujoco_amd.MjbModel(hip_lib, os.path.join(GOLDEN, "humanoid.mjb"))
+    mm.set_option("solver", solver)
+    dmv = K.DeviceModel(hip_lib, mm)
+    s0, ctrl = fx["state0"][:n], fx["ctrl"][:n]
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmv, n)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    nbad = int(np.sum(np.any(out != ref, axis=2)))
+    print("solver", solver, "variant", b.kernel_variant(), ": steps not bit-exact", nbad, "of", n*T, " max niter", ints[:, :, 2].max())
+    assert nbad == 0
+    c = b.get("counts")
+    assert np.array_equal(c[:, 0], ints[:, -1, 0]) and np.array_equal(c[:, 1], ints[:, -1, 1]) and np.array_equal(c[:, 5], ints[:, -1, 2])
+
+
 def test_soa_layout_forward_and_rollout_vs_live_oracle(rb, hip_lib, dm, golden):
     """the SoA-across-environments layout (north_star's coalesced layout: lane-per-environment smooth
     and integrate kernels + the wave-per-environment constraint kernel): every FORWARD field against
