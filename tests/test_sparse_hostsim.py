@@ -19,17 +19,17 @@ from parity_utils import (CONDIM_XML, EQ_XML, ISLANDS_XML, TENDON_XML, BOXBOX_XM
 mjJAC_SPARSE = 1
 SCENES = {
     # 67-dof serial chain (nv >= 60: sparse under jacobian=auto as well): long row patterns, ball / slide / hinge limits
-    "chain": (lambda: chain_xml(62).replace('jacobian="dense"', 'jacobian="auto"'), 60),
+    "chain": (lambda: chain_xml(62).replace('jacobian="dense"', 'jacobian="auto"'), 25),
     # connect / weld / joint / tendon equalities, site anchors, a static-static weld (empty chain: dropped)
-    "equality": (lambda: EQ_XML, 40),
+    "equality": (lambda: EQ_XML, 12),
     # four kinematic trees: several islands, some trees unconstrained at times
-    "islands": (lambda: ISLANDS_XML, 60),
+    "islands": (lambda: ISLANDS_XML, 30),
     # fixed and spatial tendons with limits and friction loss: tendon row patterns
-    "tendon": (lambda: TENDON_XML, 60),
+    "tendon": (lambda: TENDON_XML, 30),
     # condim 1 / 3 / 4 / 6 contacts
-    "condim": (lambda: CONDIM_XML, 50),
+    "condim": (lambda: CONDIM_XML, 25),
     # stacked boxes: many contacts per body pair, rows with identical patterns
-    "boxbox": (lambda: BOXBOX_XML, 40),
+    "boxbox": (lambda: BOXBOX_XML, 20),
 }
 
 
@@ -85,8 +85,16 @@ def _run(rb, lib, xml_text, tmp_path, solver, cone, T, seed=0, exact=True, kind=
     return ints
 
 
-@pytest.mark.parametrize("scene", sorted(SCENES))
-@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0), (1, 1)], ids=["newton-pyr", "newton-ell", "cg-pyr", "cg-ell"])
+# (solver, cone) per scene -- the host emulation switches 64 fibers at every cross-lane exchange and the sparse routines
+# make thousands of them per solve, so the CPU matrix is thinned (the GPU test runs every scene with three combinations)
+NEWTON, CG = 2, 1
+CASES = [("chain", NEWTON, 0), ("chain", NEWTON, 1), ("chain", CG, 0), ("chain", CG, 1),
+         ("condim", NEWTON, 0), ("condim", NEWTON, 1), ("condim", CG, 0), ("condim", CG, 1),
+         ("equality", NEWTON, 0), ("equality", NEWTON, 1), ("islands", NEWTON, 0), ("islands", CG, 0),
+         ("tendon", NEWTON, 0), ("tendon", CG, 1), ("boxbox", NEWTON, 1), ("boxbox", CG, 0)]
+
+
+@pytest.mark.parametrize("scene,solver,cone", CASES, ids=lambda v: {NEWTON: "newton", CG: "cg"}.get(v, str(v)) if not isinstance(v, str) else v)
 def test_sparse_primal_solvers_bit_exact(rb, hostsim_lib, tmp_path, scene, solver, cone):
     make, T = SCENES[scene]
     ints = _run(rb, hostsim_lib, make(), tmp_path, solver, cone, T)
@@ -100,7 +108,7 @@ def test_cube_3x3x3_bit_exact(hostsim_lib):
     mm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "cube_3x3x3.mjb"))
     dm = K.DeviceModel(hostsim_lib, mm)
     assert dm.size("sparse") == 1
-    idx = np.arange(0, len(fx["state"]), 4)
+    idx = np.arange(0, len(fx["state"]), 8)
     b = K.Batch(dm, len(idx))
     out = b.rollout_host(1, K.mjSTATE_CTRL, fx["state"][idx], fx["warmstart"][idx], fx["ctrl"][idx][:, None])
     assert b.get("warning").sum() == 0
