@@ -49,8 +49,17 @@ static inline const char* mjh_variant_name(int v) {
 // entry of an out-of-line stage function: its arguments arrive in VGPRs; all three are wave-uniform
 // namespace wv serves environment-major batches only (B.soa == 0): telling the compiler makes every
 // strided view a unit-stride view (no index multiply per access)
+#if defined(MJH_HOSTSIM) || !defined(MJH_STAGE_LAUNDER)
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
                               if (B.soa != 0) __builtin_unreachable()
+#else
+// (experiment -DMJH_STAGE_LAUNDER: every stage reaches the descriptors through pointers the compiler cannot relate to the
+// previous stage's, so a descriptor word is re-read from the scalar cache per stage instead of being carried in SGPRs)
+#define MJH_ENTER(M_, B_, e_) const MJH_CONST_AS DModel* mp_ = &wv_uniform_ref(M_); const MJH_CONST_AS DBatch* bp_ = &wv_uniform_ref(B_); \
+                              asm volatile("" : "+s"(mp_), "+s"(bp_)); \
+                              MREF M = *mp_; BREF B = *bp_; const int e = wv_uniform_i(e_); \
+                              if (B.soa != 0) __builtin_unreachable()
+#endif
 #if MJH_BUILD_WV
 #define MJH_FEATURES MJH_FT_ALL
 namespace wv {

@@ -689,7 +689,9 @@ MJH_DEV void rollout_load_control(MREF M, BREF B, int e, const RolloutArgs& A, c
 }
 
 // _unsafe_rollout for one environment                (python/mujoco/rollout.cc:74-178)
-MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
+MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
+  MREF M = M_;
+  BREF B = B_;
   const MJH_CONST_AS DSizes& s = M.s;
   const size_t r = (size_t)(A.env_offset + e);
   const long long c_begin = wv_clock();
@@ -709,6 +711,20 @@ MJH_DEV void rollout_env(MREF M, BREF B, int e, const RolloutArgs& A) {
 #endif
   int work = 0;
   for (int t = 0; t < A.nstep; t++) {
+#if !defined(MJH_HOSTSIM) && !defined(MJH_NO_LAUNDER)
+    // The two descriptors are re-read through "new" pointers every step.  With every stage inlined the compiler
+    // otherwise hoists hundreds of loop-invariant table pointers and sizes out of the step loop, keeps them in SGPRs
+    // across all of it, runs out, and spills them (and, through the spill lanes, VGPRs) to scratch: re-loading a
+    // descriptor word from the scalar cache where it is used is cheaper than carrying it.
+    const MJH_CONST_AS DModel* Mp_ = &M_;
+    const MJH_CONST_AS DBatch* Bp_ = &B_;
+    asm volatile("" : "+s"(Mp_), "+s"(Bp_));
+    MREF M = *Mp_;
+    BREF B = *Bp_;
+#else
+    MREF M = M_;
+    BREF B = B_;
+#endif
     // any warning freezes the trajectory: back-fill the rest with the current state (:135-155)
     int nw = 0;
     for (int k = 0; k < 8; k++) nw |= warn[k];
