@@ -50,13 +50,13 @@ struct Efc {
   X(vel, MJH_G(B, efc_vel, e), nefc, 1)                              \
   X(sqrtInvD, MJH_G(B, scratch, e) + 5*nmax, dual_*nv, 2)            \
   X(Y, MJH_G(B, efc_Y, e), dual_*nefc*nv, 2)                         \
-  X(J, MJH_G(B, efc_J, e), (1 - sp_)*nefc*nv, 1)                     \
+  X(J, MJH_G(B, efc_J, e), (1 - sp_*primal_)*nefc*nv, 1)             \
   X(ARinv, MJH_G(B, scratch, e), nefc, 1)                            \
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
   X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
   X(cone, MJH_G(B, efc_cone, e), nefc, 1)                            \
   X(spJ, MJH_G(B, sp_J, e), nJ_, 1)                                  \
-  X(spJT, MJH_G(B, sp_JT, e), nJ_, 1)
+  X(spJT, MJH_G(B, sp_JT, e), primal_*nJ_, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
   X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
   X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
@@ -64,11 +64,11 @@ struct Efc {
   X(id, MJH_G(B, efc_id, e), nefc, 1)                                \
   X(island, MJH_G(B, efc_island, e), nefc, 1)                        \
   X(rowadr, MJH_G(B, sp_rowadr, e), sp_*(nefc + 1), 1)               \
-  X(JTadr, MJH_G(B, sp_JTadr, e), sp_*(nv + 1), 1)                   \
+  X(JTadr, MJH_G(B, sp_JTadr, e), sp_*primal_*(nv + 1), 1)           \
   X(rowmask, MJH_G(B, sp_rowmask, e), 4*sp_*nefc, 1)
 // int arrays packed after the real ones (sized by nJ, see efc_layout)
 #define MJH_EFC_LATE_INT_ARRAYS(X)                                   \
-  X(JTrow, MJH_G(B, sp_JTrow, e), nJ_, 1)
+  X(JTrow, MJH_G(B, sp_JTrow, e), primal_*nJ_, 1)
 
 // (stage_project) does this array already live in the LDS plan?  (pointer inside the workgroup's block)
 template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* lds, int bytes) {
@@ -87,6 +87,7 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   // rows are cut from); the arrays sized by nJ come last in the packing order, so the layout of everything
   // else is already final while nJ is still being counted
   const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
   int off1 = B.dyn_off, off2 = B.dyn2_off;
   const int end1 = B.lds_bytes, end2 = B.dyn_off;
@@ -98,7 +99,6 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   // died, and the dual-only arrays that would use region 2 do not exist here: the block grows upward from the bottom
   // of region 2 across the boundary into region 1, and the arrays written by constraint assembly get what is left
   // above it.  They are streamed lane-parallel and can live in global memory.
-  const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   P.spL_home = sp_ ? MJH_G(B, sp_L, e) : MJH_G(B, nt_H, e);
   P.spL = P.spL_home; P.spL_cap = sp_ ? M.s.nLp : nv*nv;
   P.spLc = sp_ ? MJH_G(B, sp_Lc, e) : MJH_G(B, nt_M, e);
@@ -180,8 +180,9 @@ MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
   const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
-  (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_;
+  (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_; (void)primal_;
   if (!nefc) return;
   Efc P;
   const unsigned long long mask = efc_layout(M, B, e, nefc, P);
@@ -621,9 +622,10 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
 #else
   const int cpair = 0;
 #endif
-  // (sparse primal path: the contact rows are written straight into the compressed Jacobian by stage_sparsify, one
-  // row per lane -- this loop takes the contacts one at a time and would leave most lanes idle behind its loads)
-  const int contact_rows_here = !(MJH_HAS(MJH_FT_PRIMAL) && s.sparse);
+  // (sparse path under a primal solver: the contact rows are written straight into the compressed Jacobian by
+  // stage_sparsify, one row per lane -- this loop takes the contacts one at a time and would leave most lanes idle behind
+  // its loads; the dual solver still needs the dense rows for Y = J L^-T D^-1/2)
+  const int contact_rows_here = !(MJH_HAS(MJH_FT_PRIMAL) && s.sparse && M.o.solver != MJH_SOL_PGS);
   for (int k0 = 0; contact_rows_here && k0 < ncon; k0 += 1 + cpair) {
     const int k = k0 + (cpair ? (wv_lane() >> 5) : 0);
     if (k >= ncon) continue;
@@ -940,6 +942,45 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 
+// Sparse path under the dual solver: the reference keeps efc_Y and efc_AR compressed (computeY_precount / _fill /
+// _backsub, mju_sqrMatTDSparse; engine_core_constraint.c:2698-3090).  Their VALUES are those of the dense arrays built
+// above -- a sparse routine only skips structural zeros -- but the PGS sweep and the warm start then take
+// mju_dotSparse over a row's stored entries, four accumulators by position in the COMPRESSED row.  What is needed
+// from the sparse representation is therefore each row's structural pattern: row i of Y holds the dofs of J's row
+// closed under "ancestor of" (row j of M for every dof j of the row), and AR[i][j] is stored iff the Y patterns of
+// rows i and j share a dof.  One bit per (i, j), nARw 64-bit words per row.
+MJH_DEV void project_sparse_patterns(MREF M, BREF B, int e, const Efc& P, int nefc) {
+#if !MJH_LANE_MODE
+  const int nw = M.s.nARw;
+  iptr ymask = MJH_G(B, iscratch, e);                 // [4*nefc] closed row patterns (scratch: free between make and the solve)
+  iptr arm = MJH_G(B, sp_ARmask, e);
+  MJH_FOR_LANES(r, nefc) {
+    M128 pm = m128_ld(P.rowmask + 4*r), ym = m128_zero();
+    while (m128_any(pm)) {
+      const int j = m128_lowest(pm);
+      pm = m128_drop_lowest(pm);
+      const int ma = M.M_rowadr[j], mn = M.M_rownnz[j];
+      for (int q = 0; q < mn; q++) ym = m128_or(ym, m128_bit(M.M_colind[ma + q]));
+    }
+    m128_st(ymask + 4*r, ym);
+  }
+  wv_sync();
+  for (int i = 0; i < nefc; i++) {
+    const M128 yi = m128_ld(ymask + 4*i);
+    for (int w = 0; w < nw; w++) {
+      const int j = 64*w + wv_lane();
+      int bit = 0;
+      if (j < nefc) { const M128 yj = m128_ld(ymask + 4*j); bit = m128_any(m128_and(yi, yj)); }
+      const unsigned long long m = wv_ballot(bit);
+      if (wv_lane() == 0) { arm[2*(i*nw + w)] = (int)(unsigned)m; arm[2*(i*nw + w) + 1] = (int)(unsigned)(m >> 32); }
+    }
+  }
+  wv_sync();
+#else
+  (void)M; (void)B; (void)e; (void)P; (void)nefc;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // mj_projectConstraint for dual solvers: Y = J L^-T D^-1/2, AR = Y Y' + diag(R)
 //                                                  (engine_core_constraint.c:2918-3137)
@@ -1107,6 +1148,7 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
       }
     }
     wv_sync();
+    if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) project_sparse_patterns(M, B, e, P, nefc);
     return;
   }
 #endif
@@ -1143,6 +1185,7 @@ MJH_DEVN void stage_project(MREF M_, BREF B_, int e_) {
     AR[(size_t)k*nefc + i] = acc;
   }
   wv_sync();
+  if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) project_sparse_patterns(M, B, e, P, nefc);
 }
 
 // ------------------------------------------------------------------------------------------------

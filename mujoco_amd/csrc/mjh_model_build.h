@@ -1014,12 +1014,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     s.nefcmax = caps.nefcmax > 0 ? caps.nefcmax : n;
     s.nefcAR = dual ? s.nefcmax : 0;
   }
-  // sparse constraint path (mj_isSparse, engine_core_util.c:32): the primal solvers follow the reference's
-  // sparse routines operation for operation (mjh_sparse.h); its dof sets are 128-bit masks
+  // sparse constraint path (mj_isSparse, engine_core_util.c:32): the reference's sparse routines are followed
+  // operation for operation (mjh_sparse.h); dof sets are 128-bit masks
   {
     const bool ref_sparse = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
-    s.sparse = (ref_sparse && m->opt.solver != mjSOL_PGS && m->nv <= 128) ? 1 : 0;
-    s.nJmax = 0; s.nLp = 0; s.nLpc = 0;
+    s.sparse = (ref_sparse && m->nv <= 128) ? 1 : 0;
+    s.nJmax = 0; s.nLp = 0; s.nLpc = 0; s.nARw = 0;
     if (s.sparse) {
       // longest row pattern: two body chains (contacts, connect / weld), two tendons, a ball joint limit
       int chainmax = 1;
@@ -1034,6 +1034,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.nJmax = s.nefcmax*rowmax;
       s.nLp = m->opt.solver == mjSOL_NEWTON ? m->nv*(m->nv + 1)/2 : 0;
       s.nLpc = (m->opt.cone != mjCONE_PYRAMIDAL) ? s.nLp : 0;
+      if (m->opt.solver == mjSOL_PGS) s.nARw = (s.nefcmax + 63)/64;
     }
   }
   // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with
@@ -1074,7 +1075,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // every `MJH_HAS(x) && condition` of the stage sources has its condition mirrored here
   {
     int ft = 0;
-    if (m->opt.solver != mjSOL_PGS) ft |= MJH_FT_PRIMAL;
+    // (the sparse constraint path lives in the generic kernel, whatever the solver)
+    if (m->opt.solver != mjSOL_PGS || s.sparse) ft |= MJH_FT_PRIMAL;
     if (m->opt.cone != mjCONE_PYRAMIDAL) ft |= MJH_FT_ELLIPTIC;
     if (m->neq > 0) ft |= MJH_FT_EQUALITY;
     if (m->opt.integrator == mjINT_RK4) ft |= MJH_FT_RK4;

@@ -32,6 +32,39 @@ MJH_DEV real wave_dot_ref(P0 a, P1 b, int n) {
 #endif
 }
 
+// mju_dotSparse(row of efc_AR, b) when efc_AR is kept dense here: the row's structural pattern (nw 64-bit words, two
+// ints each) names the entries the reference stores, in ascending order; four accumulators by POSITION in that
+// compressed row, (r0 + r2) + (r1 + r3), the remainder one by one.  Lanes 0..3 take an accumulator each.
+template <class P0, class P1>
+MJH_DEV real wave_dot_masked(P0 a, P1 b, ciptr mw, int nw) {
+#if MJH_LANE_MODE
+  (void)a; (void)b; (void)mw; (void)nw;
+  return 0;
+#else
+  const int lane = wv_lane();
+  int nnz = 0;
+  for (int w = 0; w < nw; w++) nnz += __builtin_popcount((unsigned)mw[2*w]) + __builtin_popcount((unsigned)mw[2*w + 1]);
+  const int n4 = nnz & ~3;
+  real r = 0;
+  int tail[3] = {0, 0, 0};
+  int k = 0;
+  for (int w = 0; w < nw; w++) {
+    unsigned long long m = ((unsigned long long)(unsigned)mw[2*w + 1] << 32) | (unsigned)mw[2*w];
+    while (m) {
+      const int j = 64*w + __builtin_ctzll(m);
+      m &= m - 1;
+      if (k < n4) { if ((k & 3) == lane) r += a[j]*b[j]; }
+      else tail[k - n4] = j;
+      k++;
+    }
+  }
+  const real r0 = wv_bcast(r, 0), r1 = wv_bcast(r, 1), r2 = wv_bcast(r, 2), r3 = wv_bcast(r, 3);
+  real res = (r0 + r2) + (r1 + r3);
+  for (int t = 0; t < nnz - n4; t++) res += a[tail[t]]*b[tail[t]];
+  return res;
+#endif
+}
+
 // PCG32, engine_solver.c:241-254
 struct Pcg32 { uint64_t state, inc; };
 MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
@@ -755,6 +788,10 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
   const int maxiter = M.o.iterations;
   const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
   const int elliptic = MJH_HAS(MJH_FT_ELLIPTIC) && (M.o.cone != 0);
+  // sparse path: residuals in mju_dotSparse's order over the row's stored entries (wave_dot_masked)
+  const int sparse = MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse;
+  const int nARw = M.s.nARw;
+  ciptr armask = MJH_G(B, sp_ARmask, e);
 
   MJH_FOR_LANES(i, nefc) ARinv[i] = 1 / AR[(size_t)i*nefc + i];
   wv_sync();
@@ -843,7 +880,7 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
         const int c = blockstart[bi];
         const int i = efclist[c];
         if (!(elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC)) {
-          real res = b[i] + wave_dot_ref(AR + (size_t)i*nefc, force, nefc);
+          real res = b[i] + (sparse ? wave_dot_masked(AR + (size_t)i*nefc, force, armask + 2*i*nARw, nARw) : wave_dot_ref(AR + (size_t)i*nefc, force, nefc));
           real oldf = force[i];
           real f = oldf - res*ARinv[i];
           if (c >= ne && c < ne + nf) {
@@ -867,7 +904,7 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
         const int dim = cone_dim(P, i, nefc);
         real res[6], oldforce[6], fl[6], Athis[36], mu[5];
         for (int j = 0; j < dim; j++) {
-          res[j] = b[i+j] + wave_dot_ref(AR + (size_t)(i+j)*nefc, force, nefc);
+          res[j] = b[i+j] + (sparse ? wave_dot_masked(AR + (size_t)(i+j)*nefc, force, armask + 2*(i+j)*nARw, nARw) : wave_dot_ref(AR + (size_t)(i+j)*nefc, force, nefc));
           oldforce[j] = force[i+j];
           fl[j] = oldforce[j];
           for (int k = 0; k < dim; k++) Athis[j*dim + k] = AR[(size_t)(i+j)*nefc + i + k];
@@ -1036,6 +1073,34 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   if (!(M.o.disableflags & (1<<9))) {
     constraint_update(B, e, P, jar, 0, MJH_HAS(MJH_FT_ELLIPTIC) && M.o.cone != 0);        // efc_force(qacc_warmstart), syncs internally
     // PGS_warmstart = f.b + 0.5 f.AR.f ; keep the warmstart forces only if that is <= 0
+    if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) {
+      // mju_mulMatVecSparse(ARf, efc_AR, force): one mju_dotSparse per row over its stored entries
+      ciptr armask = MJH_G(B, sp_ARmask, e);
+      const int nARw = s.nARw;
+      MJH_FOR_LANES(r, nefc) {
+        ciptr mw = armask + 2*r*nARw;
+        int nnz = 0;
+        for (int w = 0; w < nARw; w++) nnz += __builtin_popcount((unsigned)mw[2*w]) + __builtin_popcount((unsigned)mw[2*w + 1]);
+        const int n4 = nnz & ~3;
+        crptr a = AR + (size_t)r*nefc;
+        real acc[4] = {0, 0, 0, 0}, tl = 0;
+        int k = 0;
+        real res = 0;
+        for (int w = 0; w < nARw; w++) {
+          unsigned long long m = ((unsigned long long)(unsigned)mw[2*w + 1] << 32) | (unsigned)mw[2*w];
+          while (m) {
+            const int j = 64*w + __builtin_ctzll(m);
+            m &= m - 1;
+            if (k < n4) acc[k & 3] += a[j]*force[j];
+            else { if (k == n4) res = (acc[0] + acc[2]) + (acc[1] + acc[3]); res += a[j]*force[j]; }
+            k++;
+          }
+        }
+        if (nnz == n4) res = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+        (void)tl;
+        ARf[r] = res;
+      }
+    } else
     MJH_FOR_LANES(r, nefc) ARf[r] = dot_ref(AR + (size_t)r*nefc, force, nefc);
     wv_sync();
     real pgs_ws = wave_dot_ref(force, eb, nefc);
@@ -1050,6 +1115,13 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   wv_sync();
   MJH_SUBPROF(22);     // efc_b, jar, warm start
 
+#if !MJH_LANE_MODE && MJH_W >= 32
+  if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) {
+    // (the register-resident sweeps group a row's products by dense index; the reference's sparse sweep groups them
+    // by position among the row's stored entries: the generic sweep takes those through wave_dot_masked)
+    solve_pgs(M, B, e);
+  } else
+#endif
 #if !MJH_LANE_MODE && MJH_W == 64
   if (nefc > 64 && nefc <= 128 && nefc <= M.s.pgs_nmax && M.o.iterations <= M.s.pgs_iters && counts[MJH_C_NISLAND] <= 1 &&
       (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {

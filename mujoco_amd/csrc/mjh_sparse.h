@@ -101,11 +101,12 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
   crptr cdof = MJH_F(B, cdof, e);
   crptr subtree_com = MJH_F(B, subtree_com, e);
   const int ispyramid = M.o.cone == 0;
+  const int dual = M.o.solver == MJH_SOL_PGS;       // (the dual solver keeps the dense rows: everything is cut from them)
   MJH_FOR_LANES(r, nefc) {
     M128 pm = m128_ld(P.rowmask + 4*r);
     int a = P.rowadr[r];
     const int type = P.type[r];
-    if (type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
+    if (dual || type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
       // non-contact rows: cut from the dense row stage_make_constraint wrote
       crptr Jr = J + (size_t)r*nv;
       while (m128_any(pm)) { const int j = m128_lowest(pm); pm = m128_drop_lowest(pm); P.spJ[a++] = Jr[j]; }
@@ -157,6 +158,7 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
       P.spJ[a++] = val;
     }
   }
+  if (dual) { wv_sync(); return; }
   // transpose (mju_transposeSparse: row j of J' lists the constraints that contain dof j, ascending): lane = dof
   int cnt0 = 0, cnt1 = 0;
   for (int r = 0; r < nefc; r++) {

@@ -288,9 +288,10 @@ struct DSizes {
   int ccd_N;           // opt.ccd_iterations
   int ccd_P, ccd_D;    // max(npolygonmax, 4), max(nmeshdegmax, 3)
   int ccd_nreal, ccd_nint, ccd_lane_bytes;   // workspace per lane: reals, ints, bytes (0 without convex pairs)
-  // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse) and the solver
-  // is a primal one; capacity of the CSR Jacobian; entries of the packed lower-triangular factor (x2 with cones)
+  // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse; nv <= 128 here);
+  // capacity of the CSR Jacobian; entries of the compressed factor (Newton; x2 with cones)
   int sparse, nJmax, nLp, nLpc;
+  int nARw;        // 64-bit words per row of the structural pattern of efc_AR (sparse path under the dual solver), else 0
 };
 
 struct DOptions {
@@ -485,6 +486,8 @@ enum {
   X(sp_JTrow, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
   X(sp_Lmask, 4 * s.sparse * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                       \
   X(sp_Ladr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* structural pattern of every row of efc_AR (bit j of row i: the rows' Y patterns share a dof), 2 ints per word */ \
+  X(sp_ARmask, 2 * s.nARw * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                   \
   /* 1: the env takes this step (no warning raised so far) -- written by the first kernel of a step */ \
   /* mjData.eq_active (user-switchable), first efc row of every equality this step */ \
   X(eq_active, s.neq, 0, MJH_T_GLB, MJH_T_GLB)                                    \

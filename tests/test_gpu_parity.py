@@ -1043,7 +1043,7 @@ DEVICE_EXACT_SCENES = ("islands", "tendon", "condim", "boxbox")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["chain", "equality", "islands", "tendon", "condim", "boxbox"])
-@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0)], ids=["newton-pyr", "newton-ell", "cg-pyr"])
+@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0), (0, 0), (0, 1)], ids=["newton-pyr", "newton-ell", "cg-pyr", "pgs-pyr", "pgs-ell"])
 def test_sparse_primal_solvers_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone):
     """the sparse constraint path (opt.jacobian = sparse; mjh_sparse.h, SPA instantiation of mjh_newton.h) on the
     device (tests/test_sparse_hostsim.py is the CPU counterpart, bit-exact against the reference as built).

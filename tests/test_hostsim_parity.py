@@ -893,16 +893,17 @@ def test_stateful_actuators_bit_exact(rb, hostsim_lib, tmp_path, integrator):
 
 
 @pytest.mark.parametrize("solver", [0, 2])
-def test_sparse_jacobian_model_within_tolerance(rb, hostsim_lib, tmp_path, solver):
+def test_sparse_jacobian_model_bit_exact(rb, hostsim_lib, tmp_path, solver):
     """nv >= 60 with jacobian=auto: the reference switches to its sparse code paths (mj_isSparse,
-    engine_core_util.c:29); this path evaluates the same quantities densely, so parity is to
-    rounding instead of bit for bit.  67 dofs, up to ~230 constraint rows (generic PGS and L'DL)."""
+    engine_core_util.c:29) and so does this path (mjh_sparse.h; PGS: compressed-row order of the efc_AR sweep).
+    67 dofs, up to ~230 constraint rows, 120 steps: bit for bit"""
     xml = tmp_path / "chain.xml"
     xml.write_text(chain_xml(62).replace('jacobian="dense"', 'jacobian="auto"'))
     m = rb.MjModel.from_xml_path(str(xml))
     assert m.nv >= 60
     m.opt.solver = solver
     dm = K.DeviceModel(hostsim_lib, m, 80, 300)
+    assert dm.size("sparse") == 1
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
     d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
@@ -913,10 +914,10 @@ def test_sparse_jacobian_model_within_tolerance(rb, hostsim_lib, tmp_path, solve
     assert ints[0, :, 1].max() > 64
     b = K.Batch(dm, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
-    assert relerr(out, ref) <= 1e-7
+    assert np.array_equal(out, ref)
     assert b.get("warning").sum() == 0
     c = b.get("counts")[0]
-    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
+    assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1] and c[5] == ints[0, -1, 2]
 
 
 @pytest.mark.parametrize("cone,solver,tol", [(0, 0, 0.0), (1, 0, 0.0), (1, 2, 1e-9), (1, 1, 1e-7)])

@@ -3,7 +3,8 @@ host wavefront emulation against the compiled reference, BIT FOR BIT.
 
 With jacobian = sparse (or auto and nv >= 60) the reference stores efc_J in compressed rows and its primal
 solvers run mju_mulMatVecSparse / mju_sqrMatTDSparse / mju_cholFactorNumeric / mju_cholUpdateSparse /
-mju_cholSolveSparse (engine_util_sparse.c, engine_util_solve.c:145-500).  Every scene below forces that path
+mju_cholSolveSparse (engine_util_sparse.c, engine_util_solve.c:145-500); its dual solver (PGS) sweeps compressed rows of
+efc_AR (mju_dotSparse).  Every scene below forces that path
 (opt.jacobian = mjJAC_SPARSE) and demands identical state trajectories and identical Newton / CG iteration
 counts at every step.  The GPU counterparts are in tests/test_gpu_parity.py.
 """
@@ -87,14 +88,15 @@ def _run(rb, lib, xml_text, tmp_path, solver, cone, T, seed=0, exact=True, kind=
 
 # (solver, cone) per scene -- the host emulation switches 64 fibers at every cross-lane exchange and the sparse routines
 # make thousands of them per solve, so the CPU matrix is thinned (the GPU test runs every scene with three combinations)
-NEWTON, CG = 2, 1
-CASES = [("chain", NEWTON, 0), ("chain", NEWTON, 1), ("chain", CG, 0), ("chain", CG, 1),
+NEWTON, CG, PGS = 2, 1, 0
+CASES = [("condim", PGS, 0), ("condim", PGS, 1), ("boxbox", PGS, 0), ("islands", PGS, 0), ("equality", PGS, 1),
+         ("chain", NEWTON, 0), ("chain", NEWTON, 1), ("chain", CG, 0), ("chain", CG, 1),
          ("condim", NEWTON, 0), ("condim", NEWTON, 1), ("condim", CG, 0), ("condim", CG, 1),
          ("equality", NEWTON, 0), ("equality", NEWTON, 1), ("islands", NEWTON, 0), ("islands", CG, 0),
          ("tendon", NEWTON, 0), ("tendon", CG, 1), ("boxbox", NEWTON, 1), ("boxbox", CG, 0)]
 
 
-@pytest.mark.parametrize("scene,solver,cone", CASES, ids=lambda v: {NEWTON: "newton", CG: "cg"}.get(v, str(v)) if not isinstance(v, str) else v)
+@pytest.mark.parametrize("scene,solver,cone", CASES, ids=lambda v: v if isinstance(v, str) else str(v))
 def test_sparse_primal_solvers_bit_exact(rb, hostsim_lib, tmp_path, scene, solver, cone):
     make, T = SCENES[scene]
     ints = _run(rb, hostsim_lib, make(), tmp_path, solver, cone, T)
