@@ -174,6 +174,102 @@ MJH_DEV void mjh_sincos(real x, real* sn, real* cs) {
   *sn = (q & 2) ? -a : a;
   *cs = ((q + 1) & 2) ? -b : b;
 }
+// ---- atan2 and exp ------------------------------------------------------------------------------
+// Like mjh_sincos: what the DEVICE evaluates instead of its library's routines, so that the compiled reference can
+// be linked against the very same code (oracle/devmath_shim.cc) and the two sides agree bit for bit.  Plain
+// multiplications, additions and divisions only (all correctly rounded on both sides, -ffp-contract=off): the
+// classic fdlibm algorithms (s_atan.c / e_atan2.c / e_exp.c: argument reduction to a table of four arctangents,
+// resp. to |r| <= ln2/2, then a minimax polynomial): exp < 0.8 ulp, atan2 < 1.5 ulp (the rounding of y/x on top of atan's);
+// tests/test_convex_hostsim.py::test_device_atan2_exp_accuracy.
+MJH_DEV real mjh_atan(real x) {
+  const real hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+  const real lo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+  const real aT[11] = {3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+                       -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+                       6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+                       -3.65315727442169155270e-02, 1.62858201153657823623e-02};
+  if (x != x) return x;
+  const int neg = x < 0;
+  real a = fabs(x);
+  if (a >= 0x1p66) { const real z = hi[3] + lo[3]; return neg ? -z : z; }
+  int id;
+  if (a < 0.4375) {
+    if (a < 0x1p-29) return x;
+    id = -1;
+  } else if (a < 1.1875) {
+    if (a < 0.6875) { id = 0; a = (2.0*a - 1.0)/(2.0 + a); }
+    else { id = 1; a = (a - 1.0)/(a + 1.0); }
+  } else if (a < 2.4375) { id = 2; a = (a - 1.5)/(1.0 + 1.5*a); }
+  else { id = 3; a = -1.0/a; }
+  const real z = a*a, w = z*z;
+  const real s1 = z*(aT[0] + w*(aT[2] + w*(aT[4] + w*(aT[6] + w*(aT[8] + w*aT[10])))));
+  const real s2 = w*(aT[1] + w*(aT[3] + w*(aT[5] + w*(aT[7] + w*aT[9]))));
+  if (id < 0) { const real r = a - a*(s1 + s2); return neg ? -r : r; }
+  const real r = hi[id] - ((a*(s1 + s2) - lo[id]) - a);
+  return neg ? -r : r;
+}
+MJH_DEV real mjh_atan2(real y, real x) {
+  const real pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+  if (x != x || y != y) return x + y;
+  if (x == 1.0) return mjh_atan(y);
+  const int sy = signbit(y) ? 1 : 0, sx = signbit(x) ? 1 : 0, m = sy + 2*sx;
+  if (y == 0) return m == 0 ? y : (m == 1 ? y : (m == 2 ? pi : -pi));
+  if (x == 0) return sy ? -pi/2 : pi/2;
+  if (isinf(x)) {
+    if (isinf(y)) return m == 0 ? pi/4 : (m == 1 ? -pi/4 : (m == 2 ? 3.0*(pi/4) : -3.0*(pi/4)));
+    return m == 0 ? (real)0 : (m == 1 ? -(real)0 : (m == 2 ? pi : -pi));
+  }
+  if (isinf(y)) return sy ? -pi/2 : pi/2;
+  // |y/x| beyond 2^60: pi/2 (+ its tail); x < 0 with |y/x| below 2^-60: 0
+  const real ay = fabs(y), ax = fabs(x);
+  real z;
+  if (ay > ax*0x1p60) z = pi/2 + 0.5*pi_lo;
+  else if (sx && ay*0x1p60 < ax) z = 0;
+  else z = mjh_atan(ay/ax);
+  if (m == 0) return z;
+  if (m == 1) return -z;
+  if (m == 2) return pi - (z - pi_lo);
+  return (z - pi_lo) - pi;
+}
+MJH_DEV real mjh_exp(real x) {
+  const real ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+  const real P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+             P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
+  if (x < -7.45133219101941108420e+02) return 0;
+  real hi = x, lo = 0;
+  int k = 0;
+  const real ax = fabs(x);
+  if (ax > 0.34657359027997264) {            // 0.5 ln2
+    k = ax < 1.0397207708399179 ? (x < 0 ? -1 : 1) : (int)(invln2*x + (x < 0 ? -0.5 : 0.5));     // 1.5 ln2
+    hi = x - k*ln2HI;
+    lo = k*ln2LO;
+    x = hi - lo;
+  } else if (ax < 0x1p-28) return 1.0 + x;
+  const real t = x*x;
+  const real c = x - t*(P1 + t*(P2 + t*(P3 + t*(P4 + t*P5))));
+  if (k == 0) return 1.0 - ((x*c)/(c - 2.0) - x);
+  const real y = 1.0 - ((lo - (x*c)/(2.0 - c)) - hi);
+  return ldexp(y, k);
+}
+// atan2 / exp as the kernels take them: libm on the host emulation (compared bit for bit with the reference, which
+// calls the host's libm), the routines above on the device
+MJH_DEV real r_atan2(real y, real x) {
+#ifdef MJH_HOSTSIM
+  return atan2(y, x);
+#else
+  return mjh_atan2(y, x);
+#endif
+}
+MJH_DEV real r_exp(real x) {
+#ifdef MJH_HOSTSIM
+  return exp(x);
+#else
+  return mjh_exp(x);
+#endif
+}
+
 // sin and cos of x: libm on the host emulation (it is compared bit for bit with the reference, which
 // calls the host's libm), mjh_sincos on the device
 MJH_DEV void r_sincos(real x, real* sn, real* cs) {
@@ -264,7 +360,7 @@ template <class P0, class P1>
 MJH_DEV void q_tovel(P0 r, P1 q, real dt) {
   real axis[3] = {q[1], q[2], q[3]};
   real sin_a_2 = v3_normalize(axis);
-  real speed = 2 * atan2(sin_a_2, q[0]);
+  real speed = 2 * r_atan2(sin_a_2, q[0]);
   if (speed > MJH_PI) speed -= 2*MJH_PI;
   speed /= dt;
   v3_scl(r, axis, speed);

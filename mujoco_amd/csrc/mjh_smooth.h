@@ -1398,7 +1398,7 @@ MJH_DEVN void stage_ten_act_velocity(MREF M_, BREF B_, int e_) {
 MJH_DEV real next_activation(MREF M, int a, real act, real act_dot) {
   if (M.actuator_dyntype[a] == MJH_DYN_FILTEREXACT) {
     const real tau = r_max(MJH_MINVAL, M.actuator_dyntau[a]);
-    act = act + act_dot * tau * (1 - exp(-M.o.timestep / tau));
+    act = act + act_dot * tau * (1 - r_exp(-M.o.timestep / tau));
   } else {
     act = act + act_dot * M.o.timestep;
   }

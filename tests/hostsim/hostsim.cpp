@@ -204,3 +204,7 @@ mjh_ctx_switch:
 extern "C" __attribute__((visibility("default"))) void mjh_test_sincos(int n, const double* x, double* sn, double* cs) {
   for (int i = 0; i < n; i++) mjh_sincos(x[i], sn + i, cs + i);
 }
+// likewise the device's atan2 and exp
+extern "C" __attribute__((visibility("default"))) void mjh_test_atan2_exp(int n, const double* y, const double* x, double* at, double* ex) {
+  for (int i = 0; i < n; i++) { at[i] = mjh_atan2(y[i], x[i]); ex[i] = mjh_exp(x[i]); }
+}

@@ -91,3 +91,38 @@ def test_device_sincos_within_one_ulp():
                     float(abs(mpmath.mpf(float(ci)) - rc)/mpmath.mpf(float(np.spacing(abs(float(rc)))))))
     assert worst < 1.0, worst
     assert np.abs(s - np.sin(xs)).max() <= 2.3e-16 and np.abs(c - np.cos(xs)).max() <= 2.3e-16
+
+
+def test_device_atan2_exp_accuracy():
+    """mjh_atan2 / mjh_exp (mjh_math.h) -- what the kernels evaluate on the GPU instead of the device library's
+    atan2 (ball-joint limits, welds: mju_quat2Vel) and exp (filterexact actuators) -- against 200-bit references.
+    Plain IEEE operations only, so the host build pins the GPU's values and oracle/devmath_shim.cc can hand the very
+    same routines to the compiled reference."""
+    import ctypes
+    mpmath = pytest.importorskip("mpmath")
+    from conftest import HOSTSIM_LIB
+    mpmath.mp.prec = 200
+    f = ctypes.CDLL(HOSTSIM_LIB).mjh_test_atan2_exp
+    f.argtypes = [ctypes.c_int] + [ctypes.c_void_p]*4
+    rng = np.random.default_rng(0)
+    y = np.concatenate([rng.normal(0, 1, 3000), rng.uniform(-1e-3, 1e-3, 800), rng.normal(0, 1e6, 400), [0.0, 1.0, -1.0, 1e-300, 0.0, -0.0]])
+    x = np.concatenate([rng.normal(0, 1, 3000), rng.uniform(-1, 1, 800), rng.normal(0, 1, 400), [1.0, 0.0, -0.0, -1.0, -1.0, -1.0]])
+    xe = np.concatenate([rng.uniform(-20, 20, 3000), rng.uniform(-1, 1, 800), rng.uniform(-700, 700, 400), [0.0, 1e-30, -1e-30, 0.3, 709.0, -745.0]])
+    at = np.zeros_like(y); ex = np.zeros_like(y)
+    f(len(y), y.ctypes.data, x.ctypes.data, at.ctypes.data, ex.ctypes.data)
+    worst = 0.0
+    for yi, xi, ai in zip(y, x, at):
+        if yi == 0:
+            continue            # (mpmath has no signed zero; the +-0 cases are checked against the host libm below)
+        r = mpmath.atan2(mpmath.mpf(float(yi)), mpmath.mpf(float(xi)))
+        if r != 0:
+            worst = max(worst, float(abs(mpmath.mpf(float(ai)) - r)/mpmath.mpf(float(np.spacing(abs(float(r)))))))
+    assert worst < 1.5, worst
+    assert np.abs(at - np.arctan2(y, x)).max() <= 9e-16
+    f(len(y), y.ctypes.data, xe.ctypes.data, at.ctypes.data, ex.ctypes.data)
+    worst = 0.0
+    for xi, ei in zip(xe, ex):
+        r = mpmath.exp(mpmath.mpf(float(xi)))
+        if float(r) > 1e-300:
+            worst = max(worst, float(abs(mpmath.mpf(float(ei)) - r)/mpmath.mpf(float(np.spacing(float(r))))))
+    assert worst < 1.0, worst

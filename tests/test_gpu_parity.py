@@ -1035,10 +1035,9 @@ def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
             assert np.abs(cd[e, :k] - rc["dist"]).max() <= 1e-9 and np.abs(cp[e, :k] - rc["pos"]).max() <= 1e-9
 
 
-# scenes whose steps call no libm function other than sin / cos / sqrt (no ball-joint limits or welds: atan2; no
-# stateful actuators: exp; default solimp power: no pow): bit for bit against the reference linked with the
-# kernels' own sin / cos (oracle/devmath_shim.cc)
-DEVICE_EXACT_SCENES = ("islands", "tendon", "condim", "boxbox")
+# scenes whose steps call no libm function other than sin / cos / atan2 / exp / sqrt (default solimp power: no pow): bit
+# for bit against the reference linked with the kernels' own sin / cos / atan2 / exp (oracle/devmath_shim.cc)
+DEVICE_EXACT_SCENES = ("chain", "equality", "islands", "tendon", "condim", "boxbox")
 
 
 @pytest.mark.gpu
