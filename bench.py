@@ -223,8 +223,8 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).  Two builds of the reference are consulted (oracle/Makefile):
       * `reference_glibc`: the reference as built, against the host's libm -- the oracle;
-      * `reference_device_sincos`: the same objects with sin / cos bound to mjh_sincos, the routine the kernels
-        evaluate (oracle/devmath_shim.cc).  glibc's and the kernels' sin / cos are both < 1 ulp and differ in the
+      * `reference_device_libm`: the same objects with sin / cos / atan2 / exp bound to the routines the kernels evaluate
+        (mjh_sincos, mjh_atan2, mjh_exp; oracle/devmath_shim.cc).  glibc's and the kernels' are both ~1 ulp and differ in the
         last bit for a small fraction of arguments; on a stiff, geometrically degenerate model (cube_3x3x3: aligned
         cubelet faces; EPA and face clipping are discontinuous in the poses) one such bit in a hinge's quaternion can
         move a contact point by millimetres, i.e. the next state by far more than 1e-6.  Against this build such
@@ -235,7 +235,7 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
       (2) identical inputs, EVERY step of the run: each (state, the oracle's warm start, control) of (1) is
           handed to the GPU for one mj_step (`step_once`, one batch of len(envs)*T environments); the next
           state must agree within 1e-6 and contact count, constraint count and solver iteration count exactly.
-    `ok`: (2) holds for every step against the device-sincos build AND for at least 99 % of the steps against the glibc
+    `ok`: (2) holds for every step against the device-libm build AND for at least 99 % of the steps against the glibc
     build, with no count mismatch in either."""
     try:
         from oracle import refbind as rb
@@ -246,7 +246,7 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     spec = rb.mjSTATE_FULLPHYSICS
     T = ctrl.shape[1]
     out = {"envs": len(envs), "steps_checked": T, "tolerance": 1e-6}
-    for label, kind in (("reference_glibc", "parity"), ("reference_device_sincos", "devmath")):
+    for label, kind in (("reference_glibc", "parity"), ("reference_device_libm", "devmath")):
         if not rb.available(kind):
             continue
         m = rb.MjModel.from_binary_path(model_path, kind=kind)
@@ -286,7 +286,7 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
                                       "mean_solver_iter": float(ints[:, 2].mean())},
             "trajectory": {"max_rel_err": worst, "worst_env_step": worst_at, "within_tolerance": bool(worst <= 1e-6)}}
     g = out.get("reference_glibc", {}).get("identical_input_steps")
-    dmath = out.get("reference_device_sincos", {}).get("identical_input_steps")
+    dmath = out.get("reference_device_libm", {}).get("identical_input_steps")
     if g is not None and dmath is not None:
         out["ok"] = bool(dmath["max_rel_err"] <= 1e-6 and dmath["count_mismatches"] == 0 and
                          g["frac_within_tolerance"] >= 0.99 and g["count_mismatches"] == 0)
@@ -295,7 +295,7 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     out["protocol"] = ("oracle/_ref mj_step from the same state0/controls over warm-up + timed region, re-synchronised to the GPU state "
                        "after every step (trajectory); then every one of those steps re-run on the GPU from identical (state, warm "
                        "start, control) with exact integer observables (identical_input_steps).  reference_glibc = the reference as "
-                       "built; reference_device_sincos = the same objects with sin / cos bound to the kernels' mjh_sincos "
+                       "built; reference_device_libm = the same objects with sin / cos / atan2 / exp bound to the kernels' own routines "
                        "(oracle/devmath_shim.cc): ok needs every step within 1e-6 against the latter and >= 99 % of them against the former")
     return out
 
