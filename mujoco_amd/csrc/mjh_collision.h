@@ -706,12 +706,13 @@ MJH_DEV void make_frame(P0 frame) {
 }
 
 // Oriented-box cull for the GJK / EPA pairs: 1 = the geoms' local bounding boxes (geom_aabb: centre and half sizes
-// in the geom frame) are separated by more than `margin` along one of the 15 candidate axes.  Every convex shape lies
-// inside its box, so the true distance is at least that separation; GJK reports an UPPER bound of the true distance
-// and mjc_Convex keeps a contact only if it is below the margin: a culled pair cannot produce a contact, and a pair
-// that passes is handed to the narrowphase exactly as before -- the contact list is unchanged, the narrowphase just
-// sees about half as many pairs on contact-rich scenes (cube_3x3x3: edge- and corner-adjacent cubelets pass the
-// bounding-sphere test but not this one).  A tiny slack keeps rounding of the test itself on the safe side.
+// in the geom frame) are separated by clearly more than `margin` along one of the 15 candidate axes.  Every convex shape
+// lies inside its box, so the true distance is at least that separation.  mjc_Convex keeps a contact only if the
+// distance GJK / EPA report is below the margin, and that distance is accurate to opt.ccd_tolerance -- NOT an upper
+// bound: two boxes a nanometre apart come back as touching with a slightly negative depth (stacked_boxes.xml).  The
+// cull therefore leaves a band of 1000 tolerances (1 mm at the default 1e-6) above the margin to the narrowphase: a
+// culled pair cannot produce a contact, a pair that passes is handled exactly as before -- the contact list is unchanged,
+// the narrowphase just sees fewer pairs on contact-rich scenes.
 template <class P0, class P1>
 MJH_DEV int filter_obb(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
   auto a1 = M.geom_aabb + 6*g1;
@@ -724,7 +725,10 @@ MJH_DEV int filter_obb(MREF M, P0 gx, P1 gm, int g1, int g2, real margin) {
     t[k] = c2[k] - c1[k];
   }
   const real h1[3] = {a1[3], a1[4], a1[5]}, h2[3] = {a2[3], a2[4], a2[5]};
-  const real bound = margin + 1e-9;
+#ifndef MJH_OBB_SLACK_TOLS
+#define MJH_OBB_SLACK_TOLS 1000
+#endif
+  const real bound = margin + MJH_OBB_SLACK_TOLS*M.o.ccd_tolerance + 1e-9;
   // C[i][j] = axis i of box 1 . axis j of box 2 (axes = columns of the rotation matrices)
   real C[3][3], Cabs[3][3], t1[3], t2[3];
   for (int i = 0; i < 3; i++) {
@@ -1206,8 +1210,10 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   auto passes_filter = [&](int p) -> int {
     if (p >= s.npair) return 0;
     if (filter_sphere(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p])) return 0;
+#ifndef MJH_NO_OBB_CULL
     if (MJH_HAS(MJH_FT_COLCONVEX) && M.pair_func[p] == MJH_COL_CONVEX &&
         filter_obb(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p])) return 0;
+#endif
     return 1;
   };
 

@@ -126,3 +126,52 @@ def test_device_atan2_exp_accuracy():
         if float(r) > 1e-300:
             worst = max(worst, float(abs(mpmath.mpf(float(ei)) - r)/mpmath.mpf(float(np.spacing(float(r))))))
     assert worst < 1.0, worst
+
+
+def test_nearly_touching_boxes_keep_their_contacts(rb, hostsim_lib, tmp_path):
+    """the oriented-box cull in front of GJK / EPA (mjh_collision.h: filter_obb) must not drop what the reference
+    reports: GJK's distance is accurate to ccd_tolerance, not an upper bound, so two mesh boxes an edge apart by a
+    nanometre come back as touching (found by the model sweep on stacked_boxes.xml).  Edge-to-edge and face-to-face
+    placements with gaps from -1e-5 to +1e-3, plus tests/golden/obb_cull_states.npy: twelve slightly rotated edge-to-edge
+    states (gaps 1e-10 .. 1e-6, found by random search) on which a cull without the tolerance band loses contacts the
+    reference keeps.  Contact counts and records identical to the oracle's."""
+    verts = "-1 -1 -1 1 -1 -1 1 1 -1 1 1 1 1 -1 1 -1 1 -1 -1 1 1 -1 -1 1"
+    xml = tmp_path / "gap.xml"
+    xml.write_text(f"""
+<mujoco>
+  <option gravity="0 0 0"/>
+  <asset><mesh name="box" vertex="{verts}" scale=".05 .05 .05"/></asset>
+  <worldbody>
+    <body pos="0 0 0"><freejoint/><geom type="mesh" mesh="box"/></body>
+    <body pos="0 -.1 .1"><freejoint/><geom type="mesh" mesh="box"/></body>
+  </worldbody>
+</mujoco>""")
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    gaps = [-1e-5, -1e-7, -1e-9, -1e-10, 0.0, 1e-10, 1e-9, 3e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3]
+    placements = [((0.0, -0.1, 0.1), (0.0, -1.0, 1.0)), ((0.0, 0.0, 0.1), (0.0, 0.0, 1.0))]     # edge-edge, face-face
+    states = []
+    for base, dirn in placements:
+        for g in gaps:
+            rb.mj_resetData(m, d)
+            s = np.sqrt(sum(c*c for c in dirn))
+            d.qpos[7:10] = [b + g*c/s for b, c in zip(base, dirn)]
+            states.append(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS))
+    states += list(np.load(os.path.join(os.path.dirname(__file__), "golden", "obb_cull_states.npy")))
+    b = K.Batch(dm, len(states))
+    S = np.array(states)
+    b.set("qpos", S[:, 1:1 + m.nq]); b.set("qvel", S[:, 1 + m.nq:])
+    b.forward()
+    cnt = b.get("counts")
+    cd = b.get("con_dist"); cp = b.get("con_pos")
+    total = 0
+    for e, s in enumerate(states):
+        rb.mj_setState(m, d, s, rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        assert cnt[e, 0] == d.ncon, (e, cnt[e, 0], d.ncon)
+        if d.ncon:
+            c = d.contact[:d.ncon]
+            assert np.array_equal(cd[e][:d.ncon], c["dist"]) and np.array_equal(cp[e][:3*d.ncon], np.asarray(c["pos"]).ravel())
+        total += d.ncon
+    assert total > 0
