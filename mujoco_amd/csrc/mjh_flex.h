@@ -1,0 +1,271 @@
+// Flexes: vertex-based deformable objects (lines, triangle shells, tetrahedral solids).
+//
+//   stage_flex_pos     vertex positions                                  mj_flex, engine_core_smooth.c:558-575
+//   stage_flex_edges   edge lengths and the sparse edge Jacobian         mj_flex, engine_core_smooth.c:700-745
+//   flex_edge_velocity flexedge_velocity = flexedge_J qvel               mj_fwdVelocity, engine_forward.c:188-197
+//   flex_passive       bending, stretch (finite-element) and edge spring-damper forces
+//                                                                        engine_passive.c:459-649, :739-787
+//
+// Mapping.  One wavefront owns the environment; its lanes take vertices, edges or elements in turn.  The
+// reference accumulates the forces of all elements / edges into shared dof slots in element / edge order;
+// here every element (edge) writes its own force block, and every vertex (dof) then sums the blocks that
+// touch it in that same order through the gather tables of the model (mjh_model_build.h), so the sums carry
+// the reference's rounding without a serial pass.
+//
+// Scope (checked by the model build): vertex flexes (flex_interp 0) whose vertices are bodies with three
+// axis-aligned sliders (body_simple 2) or are pinned to the static world; no flex equality constraints.
+// (included once per SPMD mode by mjh_stages.inc: no include guard)
+
+// ------------------------------------------------------------------------------------------------
+// vertex positions                                     (mj_flex, engine_core_smooth.c:558-575)
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN void stage_flex_pos(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr xpos = MJH_F(B, xpos, e);
+  crptr xmat = MJH_F(B, xmat, e);
+  rptr vx = MJH_F(B, flexvert_xpos, e);
+  MJH_FOR_LANES(v, s.nflexvert) {
+    const int b = M.flexvert_bodyid[v];
+    auto lv = M.flex_vert + 3*v;
+    if (lv[0] == 0 && lv[1] == 0 && lv[2] == 0) {
+      vx[3*v] = xpos[3*b]; vx[3*v + 1] = xpos[3*b + 1]; vx[3*v + 2] = xpos[3*b + 2];
+    } else {
+      real l[3] = {lv[0], lv[1], lv[2]}, r[3];
+      m3_mulvec(r, xmat + 9*b, l);
+      vx[3*v] = r[0] + xpos[3*b]; vx[3*v + 1] = r[1] + xpos[3*b + 1]; vx[3*v + 2] = r[2] + xpos[3*b + 2];
+    }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge lengths and Jacobians                           (mj_flex, engine_core_smooth.c:700-745)
+// One lane per edge.  Row e of flexedge_J holds, for every dof of the two end bodies (the model's
+// flexedge_J_colind), vec' (jac2 - jac1) with vec the unit vector from vertex 1 to vertex 2: the point
+// Jacobian column of a dof is cdof_lin + cdof_ang x (pos - subtree_com[root]) (mj_jacSparseSimple,
+// engine_core_util.c:375-433), entered with a minus sign for the first body; the product with vec adds the
+// three rows in order and skips zero components of vec (mju_mulMatTVec, engine_util_blas.c:554-563).
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr scom = MJH_F(B, subtree_com, e);
+  rptr len = MJH_F(B, flexedge_length, e);
+  rptr J = MJH_F(B, flexedge_J, e);
+  MJH_FOR_LANES(ed, s.nflexedge) {
+    const int f = M.flexedge_flex[ed];
+    const int adr = M.flexedge_J_rowadr[ed], nnz = M.flexedge_J_rownnz[ed];
+    if (M.flex_rigid[f]) {                 // (rigid flexes: no edge forces; lengths stay zero, Jacobian cleared)
+      len[ed] = 0;
+      for (int j = adr; j < adr + nnz; j++) J[j] = 0;
+      continue;
+    }
+    const int v1 = M.flexedge_vert[2*ed], v2 = M.flexedge_vert[2*ed + 1];
+    const int b1 = M.flexvert_bodyid[v1], b2 = M.flexvert_bodyid[v2];
+    real vec[3] = {vx[3*v2] - vx[3*v1], vx[3*v2 + 1] - vx[3*v1 + 1], vx[3*v2 + 2] - vx[3*v1 + 2]};
+    len[ed] = v3_normalize(vec);
+    const int skipjac = M.flex_edgedamping[f] == 0 && M.flex_edgestiffness[f] == 0 && M.flex_damping[f] == 0;
+    if (skipjac) {
+      for (int j = adr; j < adr + nnz; j++) J[j] = 0;
+      continue;
+    }
+    real off1[3], off2[3];
+    v3_sub(off1, vx + 3*v1, scom + 3*M.body_rootid[b1]);
+    v3_sub(off2, vx + 3*v2, scom + 3*M.body_rootid[b2]);
+    for (int j = adr; j < adr + nnz; j++) {
+      const int col = M.flexedge_J_colind[j];
+      const int second = M.dof_bodyid[col] == b2;
+      crptr cd = cdof + 6*col;
+      real t[3];
+      v3_cross(t, cd, second ? off2 : off1);
+      real jd[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+      if (!second) { jd[0] = -jd[0]; jd[1] = -jd[1]; jd[2] = -jd[2]; }
+      real acc = 0;
+      for (int r = 0; r < 3; r++)
+        if (vec[r] != 0) acc += jd[r]*vec[r];
+      J[j] = acc;
+    }
+  }
+  wv_sync();
+}
+
+// flexedge_velocity = flexedge_J qvel                  (mj_fwdVelocity, engine_forward.c:188-197)
+MJH_DEV void flex_edge_velocity(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr J = MJH_F(B, flexedge_J, e);
+  rptr vel = MJH_F(B, flexedge_velocity, e);
+  MJH_FOR_LANES(ed, s.nflexedge) {
+    const int adr = M.flexedge_J_rowadr[ed];
+    vel[ed] = M.flex_rigid[M.flexedge_flex[ed]] ? (real)0
+                                                 : dot_sparse_ref(J + adr, qvel, M.flexedge_J_rownnz[ed], M.flexedge_J_colind + adr);
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// passive flex forces, added to qfrc_spring / qfrc_damper after the joint springs and dampers and
+// before the tendons (mj_springdamper, engine_passive.c:739-787)
+// ------------------------------------------------------------------------------------------------
+// local edge -> corner indexing of an element (engine_passive.c:43-44)
+MJH_DEV int flex_edge_corner(int dim, int ed, int i) {
+  // dim 2: {1,2},{2,0},{0,1}      dim 3: {0,1},{1,2},{2,0},{2,3},{0,3},{1,3}
+  const unsigned t2 = 0x21u | (0x02u << 8) | (0x10u << 16);            // nibbles: corner 0 | corner 1 << 4
+  const unsigned long long t3 = 0x10ull | (0x21ull << 8) | (0x02ull << 16) | (0x32ull << 24) | (0x30ull << 32) | (0x31ull << 40);
+  const unsigned byte = dim == 2 ? (t2 >> (8*ed)) & 0xffu : (unsigned)((t3 >> (8*ed)) & 0xffu);
+  return (byte >> (4*i)) & 0xf;
+}
+
+MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_damper) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr xmat = MJH_F(B, xmat, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr len = MJH_F(B, flexedge_length, e);
+  crptr evel = MJH_F(B, flexedge_velocity, e);
+  crptr J = MJH_F(B, flexedge_J, e);
+  rptr fs = MJH_F(B, qfrc_spring, e);
+  rptr fd = MJH_F(B, qfrc_damper, e);
+  rptr efrc = MJH_F(B, flexelem_frc, e);
+  const real h = M.o.timestep;
+
+  // ---- bending: one lane per interior edge of a shell (mj_flexPassiveBend, :459-547); block = spring[12] | damper[12],
+  //      already rotated into the vertex bodies' frames
+  if (s.nflexbend) {
+    rptr bfrc = MJH_F(B, flexbend_frc, e);
+    MJH_FOR_LANES(ed, s.nflexedge) {
+      const int f = M.flexedge_flex[ed];
+      const int v3i = M.flexedge_flap[2*ed + 1];
+      if (M.flex_dim[f] != 2 || M.flex_bendingadr[f] < 0 || M.flex_rigid[f] || v3i < 0) continue;
+      const int v[4] = {M.flexedge_vert[2*ed], M.flexedge_vert[2*ed + 1], M.flexedge_flap[2*ed], v3i};
+      auto b = M.flex_bending + M.flex_bendingadr[f] + 17*(ed - M.flex_edgeadr[f]);
+      real ed3[3][3];
+      for (int k = 0; k < 3; k++) v3_sub(ed3[k], vx + 3*v[k + 1], vx + 3*v[0]);
+      real frc[4][3];
+      v3_cross(frc[1], ed3[1], ed3[2]);
+      v3_cross(frc[2], ed3[2], ed3[0]);
+      v3_cross(frc[3], ed3[0], ed3[1]);
+      for (int x = 0; x < 3; x++) frc[0][x] = -(frc[1][x] + frc[2][x] + frc[3][x]);
+      int isfree[4], dadr[4];
+      for (int i = 0; i < 4; i++) {
+        const int bid = M.flexvert_bodyid[v[i]];
+        isfree[i] = M.body_dofnum[bid] == 3;
+        dadr[i] = M.body_dofadr[bid];
+      }
+      for (int i = 0; i < 4; i++) {
+        real spring[3] = {0, 0, 0}, damper[3] = {0, 0, 0};
+        for (int x = 0; x < 3; x++) {
+          for (int j = 0; j < 4; j++) {
+            if (enbl_spring) spring[x] += b[4*i + j] * vx[3*v[j] + x];
+            if (enbl_damper) damper[x] += b[4*i + j] * (isfree[j] ? qvel[dadr[j] + x] : (real)0);
+          }
+          if (enbl_spring) spring[x] += b[16] * frc[i][x];
+        }
+        real sl[3], dl[3];
+        m3_multvec(sl, xmat + 9*M.flexvert_bodyid[v[i]], spring);
+        m3_multvec(dl, xmat + 9*M.flexvert_bodyid[v[i]], damper);
+        for (int x = 0; x < 3; x++) {
+          bfrc[24*ed + 3*i + x] = sl[x];
+          bfrc[24*ed + 12 + 3*i + x] = dl[x] * M.flex_damping[f];
+        }
+      }
+    }
+  }
+
+  // ---- stretch: one lane per element (mj_flexPassiveStretch, :551-630); block = force on the element's corners
+  MJH_FOR_LANES(t, s.nflexelem) {
+    const int f = M.flexelem_flex[t];
+    const int dim = M.flex_dim[f];
+    const int sadr = M.flex_stiffnessadr[f];
+    if (dim < 2 || M.flex_rigid[f] || sadr < 0 || M.flex_stiffness[sadr] == 0) continue;
+    const int nedge = dim == 2 ? 3 : 6;
+    auto k = M.flex_stiffness + sadr + 21*(t - M.flex_elemadr[f]);
+    const real kD = h > 0 ? M.flex_damping[f] / h : 0;
+    int vert[4];
+    for (int i = 0; i <= dim; i++) vert[i] = M.flexelem_vert[4*t + i];
+    real elong[6];
+    for (int q = 0; q < nedge; q++) {
+      const int idx = M.flexelem_edge[6*t + q];
+      const real def = len[idx], ref = M.flexedge_length0[idx];
+      const real prev = def - evel[idx] * h;
+      elong[q] = def*def - ref*ref + (def*def - prev*prev) * kD;
+    }
+    real force[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ed1 = 0; ed1 < nedge; ed1++) {
+      for (int ed2 = 0; ed2 < nedge; ed2++) {
+        // (metric: the packed upper triangle, row-major)
+        const int a = ed1 < ed2 ? ed1 : ed2, c = ed1 < ed2 ? ed2 : ed1;
+        const real metric = k[a*nedge - a*(a - 1)/2 + (c - a)];
+        const int c0 = flex_edge_corner(dim, ed2, 0), c1 = flex_edge_corner(dim, ed2, 1);
+        for (int i = 0; i < 2; i++) {
+          const int ci = i ? c1 : c0, cj = i ? c0 : c1;
+          for (int x = 0; x < 3; x++) {
+            const real grad = vx[3*vert[ci] + x] - vx[3*vert[cj] + x];
+            force[3*ci + x] -= elong[ed1] * grad * metric;
+          }
+        }
+      }
+    }
+    for (int i = 0; i < 3*(dim + 1); i++) efrc[12*t + i] = force[i];
+  }
+  wv_sync();
+
+  // ---- per vertex: bending blocks in edge order, then the stretch sum (elements in order, rotated into the body frame),
+  //      for vertices that are slider bodies (pinned vertices have no dofs to receive force)
+  MJH_FOR_LANES(v, s.nflexvert) {
+    const int bid = M.flexvert_bodyid[v];
+    const int nd = M.body_dofnum[bid];
+    if (nd == 0) continue;
+    const int dadr = M.body_dofadr[bid];
+    const int f = M.flexvert_flex[v];
+    if (M.flex_dim[f] == 1 || M.flex_rigid[f]) continue;
+    if (s.nflexbend && nd == 3) {
+      crptr bfrc = MJH_F(B, flexbend_frc, e);
+      for (int a = M.flexvert_bendadr[v]; a < M.flexvert_bendadr[v + 1]; a++) {
+        const int it = M.flexvert_bend[a];
+        const int ed = it >> 2, i = it & 3;
+        for (int x = 0; x < 3; x++) {
+          if (enbl_spring) fs[dadr + x] -= bfrc[24*ed + 3*i + x];
+          if (enbl_damper) fd[dadr + x] -= bfrc[24*ed + 12 + 3*i + x];
+        }
+      }
+    }
+    const int sadr = M.flex_stiffnessadr[f];
+    if (M.flex_dim[f] >= 2 && sadr >= 0 && M.flex_stiffness[sadr] != 0) {
+      real q[3] = {0, 0, 0};
+      for (int a = M.flexvert_elemadr[v]; a < M.flexvert_elemadr[v + 1]; a++) {
+        const int it = M.flexvert_elem[a];
+        const int t = it >> 2, i = it & 3;
+        for (int x = 0; x < 3; x++) q[x] += efrc[12*t + 3*i + x];
+      }
+      real ql[3];
+      m3_multvec(ql, xmat + 9*bid, q);
+      for (int x = 0; x < nd; x++) fs[dadr + x] += ql[x];
+    }
+  }
+  wv_sync();
+
+  // ---- edge spring-dampers: every dof sums its edges in edge order (:757-787)
+  MJH_FOR_LANES(i, s.nv) {
+    real as = fs[i], ad = fd[i];
+    int any = 0;
+    for (int a = M.flexJ_cscadr[i]; a < M.flexJ_cscadr[i + 1]; a++) {
+      const int j = M.flexJ_cscind[a];
+      const int ed = M.flexedge_J_rowid[j];
+      const int f = M.flexedge_flex[ed];
+      const real stiffness = enbl_spring ? M.flex_edgestiffness[f] : 0;
+      const real damping = enbl_damper ? M.flex_edgedamping[f] : 0;
+      if (M.flex_rigid[f] || (stiffness == 0 && damping == 0) || M.flexedge_rigid[ed]) continue;
+      const real frc_spring = stiffness * (M.flexedge_length0[ed] - len[ed]);
+      const real frc_damper = -damping * evel[ed];
+      as += J[j] * frc_spring;
+      ad += J[j] * frc_damper;
+      any = 1;
+    }
+    if (any) { fs[i] = as; fd[i] = ad; }
+  }
+  wv_sync();
+}

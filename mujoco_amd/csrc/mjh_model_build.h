@@ -163,7 +163,23 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const mjtNum* r = m->eq_solref + 2*i;
     MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on an equality constraint");
   }
-  MJH_REJECT(m->nflex > 0, "flex objects");
+  // flexes (mjh_flex.h): vertex-based deformables -- elasticity, bending, edge spring-dampers; interpolated (nodal)
+  // flexes, flex equality constraints and penalty ("passive") flex contacts are not built
+  for (int f = 0; f < m->nflex; f++) {
+    MJH_REJECT(m->flex_interp[f] != 0, "interpolated (trilinear / quadratic) flexes");
+    MJH_REJECT(m->flex_edgeequality[f] != 0, "flex edge / vertex / strain equality constraints");
+    MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
+    MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
+    MJH_REJECT(m->flex_contype[f] != 0 || m->flex_conaffinity[f] != 0, "flex collisions (contype / conaffinity not zero)");
+    for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
+      // a vertex is a body with three axis-aligned sliders (body_simple 2), or is pinned to a body without degrees of
+      // freedom up to the world (elastic forces on vertices riding on articulated bodies go through mj_applyFT: not built)
+      const int b = m->flex_vertbodyid[v];
+      bool fixed = true;
+      for (int a = b; a > 0; a = m->body_parentid[a]) if (m->body_dofnum[a] > 0) fixed = false;
+      MJH_REJECT(!(m->body_simple[b] == 2 || fixed), "flex vertices attached to articulated bodies");
+    }
+  }
   MJH_REJECT(m->nplugin > 0, "plugins");
   for (int i = 0; i < m->nsensor; i++) {
     MJH_REJECT(m->sensor_history[2*i] != 0 || m->sensor_delay[i] != 0, "sensor history / delay");
@@ -1071,6 +1087,113 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     s.npgsorder = (int)H->pgs_order.size();
   }
 
+  // ---------------- flexes (mjh_flex.h) --------------------------------------------------------------------
+  {
+    const int nf = m->nflex;
+    s.nflex = nf; s.nflexvert = m->nflexvert; s.nflexedge = m->nflexedge; s.nflexelem = m->nflexelem;
+    s.nflexelemdata = m->nflexelemdata; s.nflexstiffness = m->nflexstiffness; s.nflexbending = m->nflexbending;
+    s.nJfe = m->nJfe; s.nflexdof = nf ? m->nv : 0;
+    bool anybend = false;
+    for (int f = 0; f < nf; f++) if (m->flex_dim[f] == 2 && m->flex_bendingadr[f] >= 0) anybend = true;
+    s.nflexbend = anybend ? m->nflexedge : 0;
+    copy_arr(H->flex_dim, m->flex_dim, nf);
+    copy_arr(H->flex_vertadr, m->flex_vertadr, nf);
+    copy_arr(H->flex_vertnum, m->flex_vertnum, nf);
+    copy_arr(H->flex_edgeadr, m->flex_edgeadr, nf);
+    copy_arr(H->flex_edgenum, m->flex_edgenum, nf);
+    copy_arr(H->flex_elemadr, m->flex_elemadr, nf);
+    copy_arr(H->flex_elemnum, m->flex_elemnum, nf);
+    copy_arr(H->flex_rigid, m->flex_rigid, nf);
+    copy_arr(H->flex_centered, m->flex_centered, nf);
+    copy_arr(H->flex_stiffnessadr, m->flex_stiffnessadr, nf);
+    copy_arr(H->flex_bendingadr, m->flex_bendingadr, nf);
+    copy_arr(H->flexvert_bodyid, m->flex_vertbodyid, m->nflexvert);
+    copy_arr(H->flexedge_rigid, m->flexedge_rigid, m->nflexedge);
+    copy_arr(H->flexedge_J_rownnz, m->flexedge_J_rownnz, m->nflexedge);
+    copy_arr(H->flexedge_J_rowadr, m->flexedge_J_rowadr, m->nflexedge);
+    copy_arr(H->flexedge_J_colind, m->flexedge_J_colind, m->nJfe);
+    copy_arr(H->flex_vert, m->flex_vert, 3*m->nflexvert);
+    copy_arr(H->flexedge_length0, m->flexedge_length0, m->nflexedge);
+    copy_arr(H->flex_stiffness, m->flex_stiffness, m->nflexstiffness);
+    copy_arr(H->flex_bending, m->flex_bending, m->nflexbending);
+    copy_arr(H->flex_damping, m->flex_damping, nf);
+    copy_arr(H->flex_edgestiffness, m->flex_edgestiffness, nf);
+    copy_arr(H->flex_edgedamping, m->flex_edgedamping, nf);
+    copy_arr(H->flex_radius, m->flex_radius, nf);
+    // (centered flexes and vertices at the body origin copy the body position: flag them once, mj_flex :567-572)
+    for (int f = 0; f < nf; f++)
+      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++)
+        if (m->flex_centered[f]) { H->flex_vert[3*v] = 0; H->flex_vert[3*v+1] = 0; H->flex_vert[3*v+2] = 0; }
+    H->flexvert_flex.assign(m->nflexvert, 0);
+    H->flexedge_flex.assign(m->nflexedge, 0);
+    H->flexedge_vert.assign((size_t)2*m->nflexedge, 0);
+    H->flexedge_flap.assign((size_t)2*s.nflexbend, -1);
+    H->flexelem_flex.assign(m->nflexelem, 0);
+    H->flexelem_vert.assign((size_t)4*m->nflexelem, -1);
+    H->flexelem_edge.assign((size_t)6*m->nflexelem, -1);
+    H->flexedge_J_rowid.assign(m->nJfe, 0);
+    std::vector<std::vector<int>> velem(m->nflexvert), vbend(m->nflexvert);
+    for (int f = 0; f < nf; f++) {
+      const int va = m->flex_vertadr[f], ea = m->flex_edgeadr[f], ta = m->flex_elemadr[f], dim = m->flex_dim[f];
+      const int nedge = dim == 1 ? 1 : dim == 2 ? 3 : 6;
+      for (int v = 0; v < m->flex_vertnum[f]; v++) H->flexvert_flex[va + v] = f;
+      for (int e = 0; e < m->flex_edgenum[f]; e++) {
+        H->flexedge_flex[ea + e] = f;
+        H->flexedge_vert[2*(ea + e)] = va + m->flex_edge[2*(ea + e)];
+        H->flexedge_vert[2*(ea + e) + 1] = va + m->flex_edge[2*(ea + e) + 1];
+        if (s.nflexbend && dim == 2 && m->flex_bendingadr[f] >= 0) {
+          const int* flap = m->flex_edgeflap + 2*(ea + e);
+          H->flexedge_flap[2*(ea + e)] = flap[0] < 0 ? -1 : va + flap[0];
+          H->flexedge_flap[2*(ea + e) + 1] = flap[1] < 0 ? -1 : va + flap[1];
+          if (flap[1] != -1) {    // (boundary edges carry no bending force, mj_flexPassiveBend :479)
+            const int vv[4] = {H->flexedge_vert[2*(ea + e)], H->flexedge_vert[2*(ea + e) + 1], va + flap[0], va + flap[1]};
+            for (int i = 0; i < 4; i++) vbend[vv[i]].push_back(((ea + e) << 2) | i);
+          }
+        }
+      }
+      for (int t = 0; t < m->flex_elemnum[f]; t++) {
+        const int* ed = m->flex_elem + m->flex_elemdataadr[f] + t*(dim + 1);
+        for (int i = 0; i <= dim; i++) {
+          H->flexelem_vert[4*(ta + t) + i] = va + ed[i];
+          velem[va + ed[i]].push_back(((ta + t) << 2) | i);
+        }
+        if (dim >= 2)
+          for (int k = 0; k < nedge; k++) H->flexelem_edge[6*(ta + t) + k] = ea + m->flex_elemedge[m->flex_elemedgeadr[f] + t*nedge + k];
+        H->flexelem_flex[ta + t] = f;
+      }
+    }
+    H->flexvert_elemadr.assign((size_t)m->nflexvert + 1, 0);
+    H->flexvert_bendadr.assign((size_t)m->nflexvert + 1, 0);
+    H->flexvert_elem.clear(); H->flexvert_bend.clear();
+    for (int v = 0; v < m->nflexvert; v++) {
+      H->flexvert_elemadr[v] = (int)H->flexvert_elem.size();
+      H->flexvert_bendadr[v] = (int)H->flexvert_bend.size();
+      H->flexvert_elem.insert(H->flexvert_elem.end(), velem[v].begin(), velem[v].end());
+      H->flexvert_bend.insert(H->flexvert_bend.end(), vbend[v].begin(), vbend[v].end());
+    }
+    H->flexvert_elemadr[m->nflexvert] = (int)H->flexvert_elem.size();
+    H->flexvert_bendadr[m->nflexvert] = (int)H->flexvert_bend.size();
+    H->flexvert_elem.resize(s.nflexelemdata, 0);
+    H->flexvert_bend.resize((size_t)4*s.nflexbend, 0);
+    // flexedge_J by column, entries in ascending edge order (the order mj_springdamper adds edge forces to a dof, :770-787)
+    {
+      std::vector<std::vector<int>> col(nf ? m->nv : 0);
+      for (int e = 0; e < m->nflexedge; e++)
+        for (int j = m->flexedge_J_rowadr[e]; j < m->flexedge_J_rowadr[e] + m->flexedge_J_rownnz[e]; j++) {
+          H->flexedge_J_rowid[j] = e;
+          col[m->flexedge_J_colind[j]].push_back(j);
+        }
+      H->flexJ_cscadr.assign((size_t)s.nflexdof + 1, 0);
+      H->flexJ_cscind.clear();
+      for (int i = 0; i < (nf ? m->nv : 0); i++) {
+        H->flexJ_cscadr[i] = (int)H->flexJ_cscind.size();
+        H->flexJ_cscind.insert(H->flexJ_cscind.end(), col[i].begin(), col[i].end());
+      }
+      if (nf) H->flexJ_cscadr[m->nv] = (int)H->flexJ_cscind.size();
+      H->flexJ_cscind.resize(m->nJfe, 0);
+    }
+  }
+
   // ---------------- features this model needs from a kernel variant (MJH_FT_*, mjh_types.h) ------------
   // every `MJH_HAS(x) && condition` of the stage sources has its condition mirrored here
   {
@@ -1104,6 +1227,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     if (o.has_gravcomp || o.has_fluid || o.has_surfacevel) ft |= MJH_FT_PASSIVEMISC;
     if (m->nmocap > 0) ft |= MJH_FT_MOCAP;
     if (m->ntree > 1) ft |= MJH_FT_ISLANDS;
+    if (m->nflex > 0) ft |= MJH_FT_FLEX;
     s.features = ft;
   }
   return true;

@@ -1154,6 +1154,7 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  if (MJH_HAS(MJH_FT_FLEX) && s.nflex) flex_passive(M, B, e, enbl_spring, enbl_damper);
 
   // tendon spring-dampers accumulate into shared dofs: keep the reference's tendon order
   if (s.ntendon && wv_lane() == 0) {
@@ -1387,6 +1388,7 @@ MJH_DEVN void stage_ten_act_velocity(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  if (MJH_HAS(MJH_FT_FLEX) && s.nflexedge) flex_edge_velocity(M, B, e);
 }
 
 // ------------------------------------------------------------------------------------------------

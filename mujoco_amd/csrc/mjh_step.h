@@ -134,13 +134,13 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   MJH_ENTER(M_, B_, e_);
   const int pgs = !MJH_HAS(MJH_FT_PRIMAL) || (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
-    MJH_RUN(MJH_T_KIN, stage_kinematics(M, B, e));
+    MJH_RUN(MJH_T_KIN, { stage_kinematics(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflex) stage_flex_pos(M, B, e); });
   }
   // (collision needs nothing but the frames kinematics just produced)
   if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
   if (stages & MJH_STAGE_KINEMATICS) {
     MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
-    MJH_RUN(MJH_T_TENDON, stage_tendon(M, B, e));
+    MJH_RUN(MJH_T_TENDON, { stage_tendon(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflexedge) stage_flex_edges(M, B, e); });
   }
   if (stages & MJH_STAGE_TRANSMISSION) MJH_RUN(MJH_T_TRANSMISSION, stage_transmission(M, B, e));
   if (stages & MJH_STAGE_VELOCITY) {

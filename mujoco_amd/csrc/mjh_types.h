@@ -142,7 +142,41 @@
   X(mesh_polyvert, s.nmeshpolyvert)            \
   X(mesh_polymapadr, s.nmeshvert)              \
   X(mesh_polymapnum, s.nmeshvert)              \
-  X(mesh_polymap, s.nmeshpolymap)
+  X(mesh_polymap, s.nmeshpolymap)              \
+  /* flexes (mjh_flex.h): mjModel flex_* tables (include/mujoco/mjmodel.h:541-624) with vertex / edge / element ids \
+     made global over all flexes, plus the gather tables that let every dof sum its force contributions in the    \
+     reference's order: elements of a vertex (elem<<2 | corner, ascending element), bending edges of a vertex      \
+     (edge<<2 | slot), non-zeros of flexedge_J by column (entry index, ascending edge) */                          \
+  X(flex_dim, s.nflex)                         \
+  X(flex_vertadr, s.nflex)                     \
+  X(flex_vertnum, s.nflex)                     \
+  X(flex_edgeadr, s.nflex)                     \
+  X(flex_edgenum, s.nflex)                     \
+  X(flex_elemadr, s.nflex)                     \
+  X(flex_elemnum, s.nflex)                     \
+  X(flex_rigid, s.nflex)                       \
+  X(flex_centered, s.nflex)                    \
+  X(flex_stiffnessadr, s.nflex)                \
+  X(flex_bendingadr, s.nflex)                  \
+  X(flexvert_flex, s.nflexvert)                \
+  X(flexvert_bodyid, s.nflexvert)              \
+  X(flexedge_flex, s.nflexedge)                \
+  X(flexedge_vert, 2 * s.nflexedge)            \
+  X(flexedge_flap, 2 * s.nflexbend)            \
+  X(flexedge_rigid, s.nflexedge)               \
+  X(flexedge_J_rownnz, s.nflexedge)            \
+  X(flexedge_J_rowadr, s.nflexedge)            \
+  X(flexedge_J_colind, s.nJfe)                 \
+  X(flexedge_J_rowid, s.nJfe)                  \
+  X(flexJ_cscadr, s.nflexdof + 1)              \
+  X(flexJ_cscind, s.nJfe)                      \
+  X(flexelem_flex, s.nflexelem)                \
+  X(flexelem_vert, 4 * s.nflexelem)            \
+  X(flexelem_edge, 6 * s.nflexelem)            \
+  X(flexvert_elemadr, s.nflexvert + 1)         \
+  X(flexvert_elem, s.nflexelemdata)            \
+  X(flexvert_bendadr, s.nflexvert + 1)         \
+  X(flexvert_bend, 4 * s.nflexbend)
 
 // ---- model: real arrays -----------------------------------------------------------------------
 #define MJH_MODEL_REAL_FIELDS(X)               \
@@ -223,7 +257,16 @@
   X(tendon_length0, s.ntendon)                 \
   /* mesh vertices (float in mjModel; widened exactly) and polygon normals */ \
   X(mesh_vert, 3 * s.nmeshvert)                \
-  X(mesh_polynormal, 3 * s.nmeshpoly)
+  X(mesh_polynormal, 3 * s.nmeshpoly)          \
+  /* flexes */                                 \
+  X(flex_vert, 3 * s.nflexvert)                \
+  X(flexedge_length0, s.nflexedge)             \
+  X(flex_stiffness, s.nflexstiffness)          \
+  X(flex_bending, s.nflexbending)              \
+  X(flex_damping, s.nflex)                     \
+  X(flex_edgestiffness, s.nflex)               \
+  X(flex_edgedamping, s.nflex)                 \
+  X(flex_radius, s.nflex)
 
 // ---- compile-time feature set of a kernel variant -------------------------------------------------
 // The stage sources are compiled several times (mjh_modes.h); each compilation defines MJH_FEATURES,
@@ -247,6 +290,7 @@ enum {
   MJH_FT_MOCAP         = 1<<12,
   MJH_FT_ISLANDS       = 1<<13,  // more than one kinematic tree (union-find; per-island solves)
   MJH_FT_GAINBIAS      = 1<<14,  // affine gains / biases, force / act limits, joint actuator-force limits
+  MJH_FT_FLEX          = 1<<15,  // flex objects (mjh_flex.h)
   MJH_FT_ALL           = 0x7fffffff,
   MJH_FT_LEAN          = 0,
 };
@@ -292,6 +336,9 @@ struct DSizes {
   // capacity of the CSR Jacobian; entries of the compressed factor (Newton; x2 with cones)
   int sparse, nJmax, nLp, nLpc;
   int nARw;        // 64-bit words per row of the structural pattern of efc_AR (sparse path under the dual solver), else 0
+  // flexes (mjh_flex.h): mjModel sizes; nflexbend = nflexedge when some flex has bending stiffness, else 0;
+  // nflexdof = nv with flexes, else 0
+  int nflex, nflexvert, nflexedge, nflexelem, nflexelemdata, nflexstiffness, nflexbending, nJfe, nflexbend, nflexdof;
 };
 
 struct DOptions {
@@ -368,7 +415,8 @@ enum {
   X(userdata, s.nuserdata, 0, MJH_T_GLB, MJH_T_GLB)                               \
   X(xpos, 3 * s.nbody, 3 * s.nbody, MJH_T_KIN, MJH_T_KIN)                         \
   X(xquat, 4 * s.nbody, 4 * s.nbody, MJH_T_KIN, MJH_T_KIN)                        \
-  X(xmat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                      \
+  /* (flex forces are rotated into the vertex bodies' frames in the passive stage) */ \
+  X(xmat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, (s.nflex ? MJH_T_PASSIVE : MJH_T_COMPOS))  \
   X(xipos, 3 * s.nbody, 3 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                     \
   X(ximat, 9 * s.nbody, 9 * s.nbody, MJH_T_KIN, MJH_T_COMPOS)                     \
   X(xanchor, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                     \
@@ -417,6 +465,14 @@ enum {
   X(con_pos, 3 * s.nconmax, 3 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)         \
   X(con_frame, 9 * s.nconmax, 9 * MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)       \
   X(con_mu, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                  \
+  /* flexes: mjData flexvert_xpos / flexedge_length / flexedge_velocity / flexedge_J; per-element and per-bending-edge \
+     force blocks before the ordered per-vertex sums (mjh_flex.h) */                 \
+  X(flexvert_xpos, 3 * s.nflexvert, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexedge_length, s.nflexedge, 0, MJH_T_GLB, MJH_T_GLB)                        \
+  X(flexedge_velocity, s.nflexedge, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexedge_J, s.nJfe, 0, MJH_T_GLB, MJH_T_GLB)                                  \
+  X(flexelem_frc, 12 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_AR, s.nefcAR * s.nefcAR, 0, MJH_T_GLB, MJH_T_GLB)                          \
