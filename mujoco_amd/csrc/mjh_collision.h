@@ -1018,6 +1018,7 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
   MJH_CON(B, con_exclude, e, 1, c)[0] = (h.dist >= M.pair_includemargin[p]) ? 1 : 0;
   MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
   MJH_CON(B, con_mu, e, 1, c)[0] = 0;
+  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) { iptr cf = MJH_G(B, con_flex, e) + 3*c; cf[0] = -1; cf[1] = -1; cf[2] = -1; }
 }
 
 // general convex pairs (GJK / EPA / multicontact): one pair per lane
@@ -1073,6 +1074,9 @@ MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int mypair, unsigned t
 }
 #endif
 
+#if !MJH_LANE_MODE
+MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base);     // mjh_flexcol.h
+#endif
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
 // ------------------------------------------------------------------------------------------------
@@ -1081,7 +1085,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   const MJH_CONST_AS DSizes& s = M.s;
   iptr counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;
-  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || s.npair == 0) {
+  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || (s.npair == 0 && s.ncolseg <= 1)) {
     if (wv_lane() == 0) counts[MJH_C_NCON] = 0;
     wv_sync();
     return;
@@ -1207,8 +1211,11 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     }
     base += total;
   };
+  // the static pairs are taken in ranges [plo, phi): one range for models without flexes, else the ranges between the
+  // body : flex jobs (colseg, mjh_flexcol.h)
+  int plo = 0, phi = s.npair;
   auto passes_filter = [&](int p) -> int {
-    if (p >= s.npair) return 0;
+    if (p >= phi) return 0;
     if (filter_sphere(M, gx, gm, M.pair_geom1[p], M.pair_geom2[p], M.pair_margin[p])) return 0;
 #ifndef MJH_NO_OBB_CULL
     if (MJH_HAS(MJH_FT_COLCONVEX) && M.pair_func[p] == MJH_COL_CONVEX &&
@@ -1217,6 +1224,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     return 1;
   };
 
+  auto run_pairs = [&]() {
 #if !MJH_LANE_MODE
   // Phase 1: the bounding-sphere filter over the whole pair list, survivors compacted into the lanes in
   // pair order (lane r takes the r-th survivor: the position of the r-th set bit of the chunk's ballot).
@@ -1224,7 +1232,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   // handful in reach, and the narrowphase (divergent over the collider kinds) was run per chunk of 64.
   // More than MJH_W survivors: chunk by chunk as before.
   int mine = -1, nsurv = 0;
-  for (int p0 = 0; p0 < s.npair && nsurv <= MJH_W; p0 += MJH_W) {
+  for (int p0 = plo; p0 < phi && nsurv <= MJH_W; p0 += MJH_W) {
     const unsigned long long m = wv_ballot(passes_filter(p0 + wv_lane()));
     const int cnt = __builtin_popcountll(m);
     const int k = wv_lane() - nsurv;
@@ -1249,7 +1257,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     }
     return pos;
   };
-  const int nchunk = (s.npair + MJH_W - 1)/MJH_W;
+  const int nchunk = (phi - plo + MJH_W - 1)/MJH_W;
   if (nsurv <= MJH_W) {
     if (nsurv > 0) narrow(mine);
   } else if (2*nchunk <= B.n_iscratch) {
@@ -1260,7 +1268,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     iptr park = MJH_G(B, iscratch, e);
     int total = 0;
     for (int ch = 0; ch < nchunk; ch++) {
-      const unsigned long long m = wv_ballot(passes_filter(ch*MJH_W + wv_lane()));
+      const unsigned long long m = wv_ballot(passes_filter(plo + ch*MJH_W + wv_lane()));
       if (wv_lane() == 0) { park[2*ch] = (int)(unsigned)m; park[2*ch + 1] = (int)(unsigned)(m >> 32); }
       total += __builtin_popcountll(m);
     }
@@ -1271,7 +1279,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
         for (int ch = 0; ch < nchunk; ch++) {
           const unsigned long long m = ((unsigned long long)(unsigned)park[2*ch + 1] << 32) | (unsigned)park[2*ch];
           const int cnt = __builtin_popcountll(m);
-          if (k < cnt) { pick = ch*MJH_W + kth_bit(m, k); break; }
+          if (k < cnt) { pick = plo + ch*MJH_W + kth_bit(m, k); break; }
           k -= cnt;
         }
       }
@@ -1279,10 +1287,26 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     }
   } else
 #endif
-  for (int p0 = 0; p0 < s.npair; p0 += MJH_W) {
+  for (int p0 = plo; p0 < phi; p0 += MJH_W) {
     const int p = p0 + wv_lane();
     narrow(passes_filter(p) ? p : -1);
   }
+  };   // run_pairs
+#if !MJH_LANE_MODE
+  if (MJH_HAS(MJH_FT_FLEX) && s.ncolseg > 1) {
+    for (int seg = 0; seg < s.ncolseg; seg++) {
+      phi = M.colseg[3*seg];
+      if (phi > plo) run_pairs();
+      plo = phi;
+      if (M.colseg[3*seg + 1] >= 0) {
+        const int r = flex_collide_job(M, B, e, seg, base);
+        base += r & 0xffff;
+        overflow |= r >> 16;
+      }
+    }
+  } else
+#endif
+  run_pairs();
   overflow = wv_any(overflow);
   if (wv_lane() == 0) {
     if (overflow) {

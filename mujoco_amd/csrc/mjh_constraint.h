@@ -633,7 +633,11 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     if (r0 < 0) continue;
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+    // flex contacts: the second side is a vertex body, or the weighted corner bodies of an element (mj_contactJacobian
+    // :1559-1611: sum of the bodies' point Jacobians times their weights, -1 for the geom's body)
+    int fbody[4]; real fw[4];
+    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+    int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
     int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
@@ -658,6 +662,19 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
       }
       real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+      if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
+        // element contact: weight -1 on the geom's body, the normalised weights on the corner bodies
+        jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
+        for (int q = 0; q < nfb; q++) {
+          const int wq = M.body_weldid[fbody[q]];
+          if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+          real offq[3], t[3];
+          v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
+          v3_cross(t, cd, offq);
+          const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
+          jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
+        }
+      }
       // rotate into the contact frame (mju_mulMatMat with zero-skip, engine_util_blas.c:619)
       int nr = dim > 1 ? 3 : 1;
       real jr[6] = {0, 0, 0, 0, 0, 0};
@@ -758,11 +775,18 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     int type = P.type[r0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+    int fbody[4]; real fw[4];
+    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+    int b1 = M.geom_bodyid[cg[0]];
     // mj_diagApprox, contact case (:1895-1970)
     real tran = 0, rot = 0;
     tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
-    tran += M.body_invweight0[2*b2] * 1;  rot += M.body_invweight0[2*b2+1] * 1;
+    if (nfb) {
+      for (int q = 0; q < nfb; q++) { tran += M.body_invweight0[2*fbody[q]] * fw[q]; rot += M.body_invweight0[2*fbody[q]+1] * fw[q]; }
+    } else {
+      int b2 = M.geom_bodyid[cg[1]];
+      tran += M.body_invweight0[2*b2] * 1;  rot += M.body_invweight0[2*b2+1] * 1;
+    }
     auto fri = M.pair_friction + 5*p;
     real solref[2] = {M.pair_solref[2*p], M.pair_solref[2*p+1]};
     real solimp[5];
@@ -858,8 +882,10 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
       else if (type == MJH_CNSTR_LIMIT_JOINT) t1 = M.dof_treeid[M.jnt_dofadr[id]];
       else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) {
         ciptr cg = MJH_CON(B, con_geom, e, 2, id);
-        t1 = M.body_treeid[M.geom_bodyid[cg[0]]];
-        t2 = M.body_treeid[M.geom_bodyid[cg[1]]];
+        if (cg[1] >= 0) {
+          t1 = M.body_treeid[M.geom_bodyid[cg[0]]];
+          t2 = M.body_treeid[M.geom_bodyid[cg[1]]];
+        } else t2 = -3;          // flex contacts: the generic scan of the row (treeIterInit, engine_island.c:315-318)
       } else if (type == MJH_CNSTR_EQUALITY && (M.eq_type[id] == MJH_EQ_CONNECT || M.eq_type[id] == MJH_EQ_WELD)) {
         int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
         if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }
@@ -897,6 +923,16 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
       second[i] = t2;
     }
     wv_sync();
+    // the trees of every stiffness-active flex form one component, with or without rows of their own (unionConstraintTrees,
+    // engine_island.c:409-447): start them at the flex's smallest tree
+    if (MJH_HAS(MJH_FT_FLEX) && s.nflex) {
+      MJH_FOR_LANES(v, s.nflexvert) {
+        const int mt = M.flex_mintree[M.flexvert_flex[v]];
+        const int tv = M.body_treeid[M.flexvert_bodyid[v]];
+        if (mt >= 0 && tv >= 0) { const int l = label[tv]; if (l < 0 || l > mt) label[tv] = mt; }
+      }
+      wv_sync();
+    }
     for (int round = 0; round < 4*ntree + 8; round++) {
       int moved = 0;
       MJH_FOR_LANES(i, nefc) {
@@ -1230,6 +1266,7 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
       int active = 0;
       for (int side = 0; side < 2; side++) {
         const int g = cg[side];
+        if (g < 0) continue;
         auto sv = M.geom_surfacevel + 6*g;
         if (!sv[0] && !sv[1] && !sv[2] && !sv[3] && !sv[4] && !sv[5]) continue;
         active = 1;

@@ -36,9 +36,12 @@
 #define MJH_CCD_EDGE_TOL 0.0888                  // mjEDGE_TOL
 
 enum { CCD_SUP_POINT = 0, CCD_SUP_SPHERE, CCD_SUP_LINE, CCD_SUP_CAPSULE, CCD_SUP_ELLIPSOID, CCD_SUP_CYLINDER,
-       CCD_SUP_BOX, CCD_SUP_MESH, CCD_SUP_HILLCLIMB };
-// object slots: reals pos[3] mat[9] size[3] margin; ints below
-enum { CO_POS = 0, CO_MAT = 3, CO_SIZE = 12, CO_MARGIN = 15, CO_NREAL = 16 };
+       CCD_SUP_BOX, CCD_SUP_MESH, CCD_SUP_HILLCLIMB, CCD_SUP_FLEXELEM };
+// object slots: reals pos[3] mat[9] size[3] margin centre[3] -; ints below
+// (a flex element keeps its corner positions in pos | mat (4 x 3), its radius + margin/2 in size[0], its corner count in
+// the CI_MESH slot and the centre mjc_center returns -- the centre of its bounding box -- in centre)
+enum { CO_POS = 0, CO_MAT = 3, CO_SIZE = 12, CO_MARGIN = 15, CO_CENTER = 16, CO_NREAL = 20 };
+#define MJH_GEOM_FLEX 100
 enum { CI_TYPE = 0, CI_SUP = 1, CI_VERTINDEX = 2, CI_MESHINDEX = 3, CI_MESH = 4, CI_NINT = 6 };
 // vertex slots: reals vert[3] (Minkowski difference) vert1[3] vert2[3]; ints index1 index2
 enum { CV_NREAL = 9, CV_NINT = 2 };
@@ -115,6 +118,21 @@ MJH_DEVN_HOT void ccd_obj_support(MREF M, CcdObj o, V3 dir, rptr res) {
     case CCD_SUP_SPHERE: {
       const real radius = size[0];
       out = V3{radius*dir.x + pos[0], radius*dir.y + pos[1], radius*dir.z + pos[2]};
+      break;
+    }
+    case CCD_SUP_FLEXELEM: {
+      // mjc_flexSupport (engine_collision_convex.c:480-506): the corner with the largest projection (first wins), pushed
+      // out along dir by the flex radius plus half the margin
+      const int n = o.i[CI_MESH];
+      out = ld3(o.r);
+      real best = out.x*dir.x + out.y*dir.y + out.z*dir.z;
+      for (int i = 1; i < n; i++) {
+        const V3 v = ld3(o.r + 3*i);
+        const real d = v.x*dir.x + v.y*dir.y + v.z*dir.z;
+        if (d > best) { best = d; out = v; }
+      }
+      const real scl = size[0];
+      out = V3{out.x + dir.x*scl, out.y + dir.y*scl, out.z + dir.z*scl};
       break;
     }
     case CCD_SUP_LINE: {
@@ -1335,8 +1353,11 @@ MJH_DEVN_HOT void ccd_multicontact(MREF M, Ccd& c, int face) {
 // ---- mjc_ccd (:2318) --------------------------------------------------------------------------------------------
 // returns the smallest witness distance (negative: penetration)
 MJH_DEVN_HOT real ccd_run(MREF M, Ccd& c) {
-  st3(c.x1, ld3(c.o1.r + CO_POS));
-  st3(c.x2, ld3(c.o2.r + CO_POS));
+  // (mjc_center: a geom's position, the bounding-box centre of a flex element)
+  const int ctr1 = c.o1.i[CI_SUP] == CCD_SUP_FLEXELEM ? CO_CENTER : CO_POS;
+  const int ctr2 = c.o2.i[CI_SUP] == CCD_SUP_FLEXELEM ? CO_CENTER : CO_POS;
+  st3(c.x1, ld3(c.o1.r + ctr1));
+  st3(c.x2, ld3(c.o2.r + ctr2));
   c.gjk_iterations = 0;
   c.dist_cutoff = 0;
   const int t1 = c.o1.i[CI_TYPE], t2 = c.o2.i[CI_TYPE];
@@ -1365,8 +1386,8 @@ MJH_DEVN_HOT real ccd_run(MREF M, Ccd& c) {
       return c.dist[0];
     }
     c.gjk_iterations = 0;
-    st3(c.x1, ld3(c.o1.r + CO_POS));
-    st3(c.x2, ld3(c.o2.r + CO_POS));
+    st3(c.x1, ld3(c.o1.r + ctr1));
+    st3(c.x2, ld3(c.o2.r + ctr2));
   }
   ccd_gjk(M, c);
   if (c.dist[0] <= c.tolerance && c.nsimplex > 1 && !c.separated) {
@@ -1539,6 +1560,35 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
     }
   }
   return ncon;
+}
+
+// mjc_ConvexElem (:1559) for a geom against a solid flex element (tetrahedron, 4 corners): one contact at most, left in the
+// lane's first `out` record.  g < 0: the lane has no pair.
+MJH_DEVN_HOT int ccd_geom_elem_pair(MREF M_, BREF B_, int e_, int g, int elem, real margin) {
+  MJH_ENTER(M_, B_, e_);
+  if (g < 0) return 0;
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr aabb = MJH_F(B, flexelem_aabb, e);
+  Ccd c;
+  ccd_carve(M, B, e, c);
+  ccd_init_obj(M, c.o1, gx, gm, g, margin);
+  const int f = M.flexelem_flex[elem];
+  const int n = M.flex_dim[f] + 1;
+  for (int i = 0; i < n; i++) {
+    const int v = M.flexelem_vert[4*elem + i];
+    for (int k = 0; k < 3; k++) c.o2.r[3*i + k] = vx[3*v + k];
+  }
+  c.o2.r[CO_SIZE] = M.flex_radius[f] + 0.5*margin;
+  c.o2.r[CO_MARGIN] = 0;
+  for (int k = 0; k < 3; k++) c.o2.r[CO_CENTER + k] = aabb[6*elem + k];
+  c.o2.i[CI_TYPE] = MJH_GEOM_FLEX;
+  c.o2.i[CI_SUP] = CCD_SUP_FLEXELEM;
+  c.o2.i[CI_VERTINDEX] = -1;
+  c.o2.i[CI_MESHINDEX] = -1;
+  c.o2.i[CI_MESH] = n;
+  return ccd_penetration(M, c, 0, 1, margin);
 }
 
 // mjccd_support (:518) for the geoms mjc_PlaneConvex sees (ellipsoid, mesh): libccd-style support

@@ -37,6 +37,26 @@ MJH_DEVN void stage_flex_pos(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  // element bounding boxes: centre and half sizes, inflated by the flex radius (mj_flex :630-660)
+  if (s.nflexpair) {
+    rptr aabb = MJH_F(B, flexelem_aabb, e);
+    MJH_FOR_LANES(t, s.nflexelem) {
+      const int f = M.flexelem_flex[t];
+      const int dim = M.flex_dim[f];
+      const real radius = M.flex_radius[f];
+      const int v0 = M.flexelem_vert[4*t];
+      real lo[3] = {vx[3*v0], vx[3*v0 + 1], vx[3*v0 + 2]}, hi[3] = {lo[0], lo[1], lo[2]};
+      for (int i = 1; i <= dim; i++) {
+        const int v = M.flexelem_vert[4*t + i];
+        for (int j = 0; j < 3; j++) { const real x = vx[3*v + j]; lo[j] = r_min(lo[j], x); hi[j] = r_max(hi[j], x); }
+      }
+      for (int j = 0; j < 3; j++) {
+        aabb[6*t + j] = 0.5*(hi[j] + lo[j]);
+        aabb[6*t + 3 + j] = 0.5*(hi[j] - lo[j]) + radius;
+      }
+    }
+    wv_sync();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -268,4 +288,38 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     if (any) { fs[i] = as; fd[i] = ad; }
   }
   wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// bodies and weights on the flex side of a contact (mj_contactJacobian / mj_diagApprox,
+// engine_core_constraint.c:1573-1607, :1908-1936).  Contact k of a model with flexes: returns 0 for a geom : geom
+// contact, else the number of vertex bodies (1 for a vertex contact; the corners of the element, weighted by inverse
+// distance to the contact point and normalised, for an element contact: mj_elemBodyWeight :223-259).
+// ------------------------------------------------------------------------------------------------
+MJH_DEV int flex_contact_weights(MREF M, BREF B, int e, int k, int* body, real* w) {
+  if (!M.s.nconflex) return 0;
+  ciptr cf = MJH_G(B, con_flex, e) + 3*k;
+  const int f = cf[0];
+  if (f < 0) return 0;
+  if (cf[2] >= 0) {
+    body[0] = M.flexvert_bodyid[M.flex_vertadr[f] + cf[2]];
+    w[0] = 1;
+    return 1;
+  }
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr point = MJH_CON(B, con_pos, e, 3, k);
+  const int el = M.flex_elemadr[f] + cf[1];
+  const int n = M.flex_dim[f] + 1;
+  for (int i = 0; i < n; i++) {
+    const int v = M.flexelem_vert[4*el + i];
+    const real dx = point[0] - vx[3*v], dy = point[1] - vx[3*v + 1], dz = point[2] - vx[3*v + 2];
+    const real dist = sqrt(dx*dx + dy*dy + dz*dz);
+    w[i] = 1.0/r_max(MJH_MINVAL, dist);
+    body[i] = M.flexvert_bodyid[v];
+  }
+  real sum = 0;
+  for (int i = 0; i < n; i++) sum += w[i];
+  const real inv = 1.0/sum;
+  for (int i = 0; i < n; i++) w[i] = w[i]*inv;
+  return n;
 }

@@ -170,7 +170,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->flex_edgeequality[f] != 0, "flex edge / vertex / strain equality constraints");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
-    MJH_REJECT(m->flex_contype[f] != 0 || m->flex_conaffinity[f] != 0, "flex collisions (contype / conaffinity not zero)");
     for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
       // a vertex is a body with three axis-aligned sliders (body_simple 2), or is pinned to a body without degrees of
       // freedom up to the world (elastic forces on vertices riding on articulated bodies go through mj_applyFT: not built)
@@ -184,6 +183,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->nsensor; i++) {
     MJH_REJECT(m->sensor_history[2*i] != 0 || m->sensor_delay[i] != 0, "sensor history / delay");
   }
+  MJH_REJECT(m->nsensor > 0 && m->nflex > 0, "sensors in models with flexes");
   MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
@@ -645,8 +645,21 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       }
       return true;
   };
+  struct FlexJob { int pair_end, body, flex; };
+  std::vector<FlexJob> flexjobs;
   for (int b1 = 0; b1 < m->nbody; b1++) {
     const bool b1_on = m->body_contype[b1] || m->body_conaffinity[b1];
+    if (b1 > 0 && m->nflex) {
+      // body : flex pairs of the previous body follow its body : body pairs (signature order, bodyflex id of a flex = nbody + f;
+      // mj_collision, engine_collision_driver.c:637-700).  The sweep-and-prune cull of such a pair compares margin-inflated
+      // bounds and is conservative: every pair is taken to the per-vertex / per-element tests.
+      const int b = b1 - 1;
+      if ((m->body_contype[b] || m->body_conaffinity[b]) && m->body_geomnum[b] > 0)
+        for (int f = 0; f < m->nflex; f++)
+          if ((m->flex_contype[f] || m->flex_conaffinity[f]) &&
+              !filter_bitmask(m->body_contype[b], m->body_conaffinity[b], m->flex_contype[f], m->flex_conaffinity[f]))
+            flexjobs.push_back({(int)H->pair_geom1.size(), b, f});
+    }
     for (int b2 = b1 + 1; b2 < m->nbody; b2++) {
       const unsigned sig_here = ((unsigned)b1 << 16) + (unsigned)b2;
       const int startadr = pairadr;
@@ -709,7 +722,158 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     if (!emit_pairs(ex)) return false;
   }
+  if (m->nflex) {
+    const int b = m->nbody - 1;
+    if ((m->body_contype[b] || m->body_conaffinity[b]) && m->body_geomnum[b] > 0)
+      for (int f = 0; f < m->nflex; f++)
+        if ((m->flex_contype[f] || m->flex_conaffinity[f]) &&
+            !filter_bitmask(m->body_contype[b], m->body_conaffinity[b], m->flex_contype[f], m->flex_conaffinity[f]))
+          flexjobs.push_back({(int)H->pair_geom1.size(), b, f});
+  }
   s.npair = (int)H->pair_geom1.size();
+
+  // ---------------- body : flex collision jobs (mjh_flexcol.h) -------------------------------------------------
+  // The geoms of a job's body get parameter records appended to the pair tables (index npair + k): mj_contactParam with
+  // the flex on the second side (engine_collision_driver.c:1740-1835).
+  {
+    H->colseg.clear(); H->flexjob_adr.clear(); H->flexjob_geom.clear();
+    for (const FlexJob& j : flexjobs) {
+      const int f = j.flex, b = j.body;
+      MJH_REJECT(midphase == 0, "flex collisions with the midphase disabled");
+      MJH_REJECT(m->flex_bvhadr[f] < 0 || m->body_bvhadr[b] < 0, "flex collisions without bounding volume hierarchies");
+      MJH_REJECT(m->flex_rigid[f], "collisions of rigid flexes");
+      const bool dofless = m->body_dofnum[m->body_weldid[b]] == 0;
+      H->colseg.push_back(j.pair_end); H->colseg.push_back(b); H->colseg.push_back(f);
+      H->flexjob_adr.push_back((int)H->flexjob_geom.size());
+      for (int g = m->body_geomadr[b]; g < m->body_geomadr[b] + m->body_geomnum[b]; g++) {
+        const int type = m->geom_type[g];
+        MJH_REJECT(type == mjGEOM_SDF || type == mjGEOM_HFIELD, "flex collisions with height-field / signed-distance-field geoms");
+        if (type == mjGEOM_PLANE) {
+          if (!dofless) continue;                 // (planes on moving bodies never reach a flex collider, mj_collideTree :1030-1038, :1128)
+        } else {
+          if (filter_bitmask(m->geom_contype[g], m->geom_conaffinity[g], m->flex_contype[f], m->flex_conaffinity[f])) continue;
+          MJH_REJECT(m->flex_dim[f] != 3, "collisions of line / shell flexes with geoms other than planes");
+          MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+          if (type == mjGEOM_MESH)
+            MJH_REJECT(m->geom_dataid[g] < 0 || m->mesh_vertnum[m->geom_dataid[g]] < 1, "mesh geom without vertices");
+          s.ccd_any = 1;
+        }
+        // mj_contactParam(g, -1, -1, f)
+        int condim; real solref[2], solimp[5], fri[3];
+        const int p1 = m->geom_priority[g], p2 = m->flex_priority[f];
+        const mjtNum *sr1 = m->geom_solref + 2*g, *sr2 = m->flex_solref + 2*f;
+        const mjtNum *si1 = m->geom_solimp + 5*g, *si2 = m->flex_solimp + 5*f;
+        const mjtNum *f1 = m->geom_friction + 3*g, *f2 = m->flex_friction + 3*f;
+        if (p1 > p2) {
+          condim = m->geom_condim[g];
+          for (int k = 0; k < 2; k++) solref[k] = sr1[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si1[k];
+          for (int k = 0; k < 3; k++) fri[k] = f1[k];
+        } else if (p1 < p2) {
+          condim = m->flex_condim[f];
+          for (int k = 0; k < 2; k++) solref[k] = sr2[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = f2[k];
+        } else {
+          condim = std::max(m->geom_condim[g], m->flex_condim[f]);
+          real m1 = m->geom_solmix[g], m2 = m->flex_solmix[f], mix;
+          if (m1 >= mjMINVAL && m2 >= mjMINVAL) mix = m1 / (m1 + m2);
+          else if (m1 < mjMINVAL && m2 < mjMINVAL) mix = 0.5;
+          else if (m1 < mjMINVAL) mix = 0.0;
+          else mix = 1.0;
+          if (sr1[0] > 0 && sr2[0] > 0) { for (int k = 0; k < 2; k++) solref[k] = mix*sr1[k] + (1-mix)*sr2[k]; }
+          else { for (int k = 0; k < 2; k++) solref[k] = std::min(sr1[k], sr2[k]); }
+          for (int k = 0; k < 5; k++) solimp[k] = mix*si1[k] + (1-mix)*si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = std::max(f1[k], f2[k]);
+        }
+        real friction[5] = {fri[0], fri[0], fri[1], fri[2], fri[2]};
+        real margin = m->geom_margin[g] + m->flex_margin[f];
+        const real gap = m->geom_gap[g] + m->flex_gap[f];
+        if (override_) {
+          margin = m->opt.o_margin;
+          for (int k = 0; k < 2; k++) solref[k] = m->opt.o_solref[k];
+          for (int k = 0; k < 5; k++) solimp[k] = m->opt.o_solimp[k];
+          for (int k = 0; k < 5; k++) friction[k] = m->opt.o_friction[k];
+        }
+        for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
+        MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
+        H->flexjob_geom.push_back(g);
+        H->pair_geom1.push_back(g);
+        H->pair_geom2.push_back(-1);
+        H->pair_dim.push_back(condim);
+        H->pair_margin.push_back(margin + gap);
+        H->pair_includemargin.push_back(margin);
+        for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
+        for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
+        for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
+        for (int k = 0; k < 5; k++) H->pair_solimp.push_back(solimp[k]);
+      }
+    }
+    H->colseg.push_back(s.npair); H->colseg.push_back(-1); H->colseg.push_back(-1);
+    H->flexjob_adr.push_back((int)H->flexjob_geom.size());
+    H->flexjob_adr.push_back((int)H->flexjob_geom.size());
+    s.ncolseg = (int)H->colseg.size()/3;
+    s.nflexpair = (int)H->flexjob_geom.size();
+    // flex : flex pairs, self collisions, internal collisions: not built
+    for (int f1 = 0; f1 < m->nflex; f1++) {
+      if (!(m->flex_contype[f1] || m->flex_conaffinity[f1])) continue;
+      for (int f2 = f1 + 1; f2 < m->nflex; f2++)
+        MJH_REJECT((m->flex_contype[f2] || m->flex_conaffinity[f2]) &&
+                   !filter_bitmask(m->flex_contype[f1], m->flex_conaffinity[f1], m->flex_contype[f2], m->flex_conaffinity[f2]),
+                   "collisions between two flexes");
+      if (!m->flex_rigid[f1] && (m->flex_contype[f1] & m->flex_conaffinity[f1]))
+        MJH_REJECT(m->flex_internal[f1] || m->flex_selfcollide[f1] != mjFLEXSELF_NONE, "flex self-collisions / internal collisions");
+    }
+    // BVH leaves of every flex in depth-first order (second child first: mj_collideTree pushes child 0 then child 1 and pops the last)
+    H->flex_leafadr.assign((size_t)m->nflex + 1, 0);
+    H->flexleaf_elem.clear();
+    for (int f = 0; f < m->nflex; f++) {
+      H->flex_leafadr[f] = (int)H->flexleaf_elem.size();
+      const int adr = m->flex_bvhadr[f];
+      if (adr < 0 || m->flex_bvhnum[f] <= 0) continue;
+      std::vector<int> stack{0};
+      while (!stack.empty()) {
+        const int node = stack.back(); stack.pop_back();
+        const int c0 = m->bvh_child[2*(adr + node)], c1 = m->bvh_child[2*(adr + node) + 1];
+        if (c0 < 0 && c1 < 0) {
+          if (m->bvh_nodeid[adr + node] >= 0) H->flexleaf_elem.push_back(m->flex_elemadr[f] + m->bvh_nodeid[adr + node]);
+          continue;
+        }
+        if (c0 >= 0) stack.push_back(c0);
+        if (c1 >= 0) stack.push_back(c1);
+      }
+    }
+    H->flex_leafadr[m->nflex] = (int)H->flexleaf_elem.size();
+    s.nflexleaf = (int)H->flexleaf_elem.size();
+    // smallest tree of every flex whose stiffness couples its vertices (dim >= 2, bending or a non-zero stiffness), else -1
+    H->flex_mintree.assign(m->nflex, -1);
+    for (int f = 0; f < m->nflex; f++) {
+      if (m->flex_rigid[f] || m->flex_dim[f] < 2) continue;
+      const int sadr = m->flex_stiffnessadr[f];
+      if (m->flex_bendingadr[f] < 0 && (sadr < 0 || m->flex_stiffness[sadr] == 0)) continue;
+      int mt = -1;
+      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
+        const int tr = m->body_treeid[m->flex_vertbodyid[v]];
+        if (tr >= 0 && (mt < 0 || tr < mt)) mt = tr;
+      }
+      H->flex_mintree[f] = mt;
+    }
+    copy_arr(H->flex_contype, m->flex_contype, m->nflex);
+    copy_arr(H->flex_conaffinity, m->flex_conaffinity, m->nflex);
+    s.ngeomflex = m->nflex ? m->ngeom : 0;
+    copy_arr(H->geom_contype, m->geom_contype, s.ngeomflex);
+    copy_arr(H->geom_conaffinity, m->geom_conaffinity, s.ngeomflex);
+    // candidate capacity of one job: every vertex against every plane of the body, every BVH leaf against every other geom
+    int cand = 0;
+    for (int k = 0; k + 1 < s.ncolseg; k++) {
+      const int f = H->colseg[3*k + 2];
+      int c = 0;
+      for (int a = H->flexjob_adr[k]; a < H->flexjob_adr[k + 1]; a++)
+        c += m->geom_type[H->flexjob_geom[a]] == mjGEOM_PLANE ? m->flex_vertnum[f] : (H->flex_leafadr[f + 1] - H->flex_leafadr[f]);
+      cand = std::max(cand, c);
+    }
+    s.nflexcand = cand;
+  }
 
   // ---------------- broad / midphase emulation tables (mjh_collision.h: stage_broadphase) ----------------
   // The reference culls BODY pairs by sweep-and-prune over float-rounded bounding intervals in a
@@ -853,7 +1017,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.ccd_D = std::max(3, (int)m->nmeshdegmax);
       // mirror of ccd_carve (mjh_convex.h): fixed slots, then the polytope with the clipping buffers overlaid
       const int N = s.ccd_N, P = s.ccd_P, D = s.ccd_D;
-      const int fixed_r = 2*16 + 3*4 + 3*4 + 4 + 4*9 + 5*9 + 7*5;
+      const int fixed_r = 2*20 + 3*4 + 3*4 + 4 + 4*9 + 5*9 + 7*5;
       const int poly_r = (5 + N)*9 + 6*N*4;
       const int multi_r = 9*D + 6*P + 16*P;
       s.ccd_nreal = fixed_r + std::max(poly_r, multi_r);
@@ -874,7 +1038,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_frictionloss[i] > 0) nfric++;
   // contact capacity: the bound mj_maxContact gives the static pair list (the reference's arena grows
   // on demand; a fixed 512 stands in for "as many as a scene of this size can touch at once")
+  // (a body : flex job leaves at most mjMAXCONPAIR contacts, filterFlexContacts :447-515)
+  for (int k = 0; k + 1 < s.ncolseg; k++) maxcon_total += std::min(s.nflexcand, (int)mjMAXCONPAIR);
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 512));
+  s.nconflex = m->nflex ? s.nconmax : 0;
   s.nconlds = std::min(s.nconmax, 8);
   // tree ids (constraint islands, engine_island.c)
   H->body_treeid.assign(m->body_treeid, m->body_treeid + m->nbody);
@@ -1035,6 +1202,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   {
     const bool ref_sparse = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
     s.sparse = (ref_sparse && m->nv <= 128) ? 1 : 0;
+    MJH_REJECT(s.sparse && s.nflexpair > 0, "flex collisions in a model that takes the compressed-Jacobian path (sparse Jacobian with at most 128 dofs)");
     s.nJmax = 0; s.nLp = 0; s.nLpc = 0; s.nARw = 0;
     if (s.sparse) {
       // longest row pattern: two body chains (contacts, connect / weld), two tendons, a ball joint limit

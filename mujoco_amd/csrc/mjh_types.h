@@ -98,9 +98,9 @@
   X(dof_act_adr, s.nv + 1)                     \
   X(dof_act_ids, s.nu + 1)                     \
   X(jnt_actfrclimited, s.njnt)                 \
-  X(pair_geom1, s.npair)                       \
-  X(pair_geom2, s.npair)                       \
-  X(pair_dim, s.npair)                         \
+  X(pair_geom1, (s.npair + s.nflexpair))                       \
+  X(pair_geom2, (s.npair + s.nflexpair))                       \
+  X(pair_dim, (s.npair + s.nflexpair))                         \
   X(pair_maxcon, s.npair)                      \
   X(pair_func, s.npair)                        \
   /* broad / midphase emulation (stage_broadphase): index pair into the collidable-body list for  \
@@ -176,7 +176,21 @@
   X(flexvert_elemadr, s.nflexvert + 1)         \
   X(flexvert_elem, s.nflexelemdata)            \
   X(flexvert_bendadr, s.nflexvert + 1)         \
-  X(flexvert_bend, 4 * s.nflexbend)
+  X(flexvert_bend, 4 * s.nflexbend)            \
+  /* flex collisions (mjh_flexcol.h).  colseg: the collision pass as segments (end of a range of static geom pairs, then \
+     the body : flex job that follows it in the reference's bodyflex order, -1 -1 for none); flexjob_*: the geoms of \
+     each job's body (their parameter records are pairs npair + k); flexleaf_elem: the elements in every flex's BVH \
+     (the active layers), in the order a depth-first walk of the tree visits its leaves */ \
+  X(colseg, 3 * s.ncolseg)                     \
+  X(flexjob_adr, s.ncolseg + 1)                \
+  X(flexjob_geom, s.nflexpair)                 \
+  X(flex_leafadr, s.nflex + 1)                 \
+  X(flexleaf_elem, s.nflexleaf)                \
+  X(flex_mintree, s.nflex)                     \
+  X(flex_contype, s.nflex)                     \
+  X(flex_conaffinity, s.nflex)                 \
+  X(geom_contype, s.ngeomflex)                 \
+  X(geom_conaffinity, s.ngeomflex)
 
 // ---- model: real arrays -----------------------------------------------------------------------
 #define MJH_MODEL_REAL_FIELDS(X)               \
@@ -245,12 +259,12 @@
   X(actuator_gainprm, 10 * s.nu)               \
   X(actuator_biasprm, 10 * s.nu)               \
   X(actuator_cranklength, s.nu)                \
-  X(pair_margin, s.npair)                      \
-  X(pair_includemargin, s.npair)               \
-  X(pair_friction, 5 * s.npair)                \
-  X(pair_solref, 2 * s.npair)                  \
-  X(pair_solreffriction, 2 * s.npair)          \
-  X(pair_solimp, 5 * s.npair)                  \
+  X(pair_margin, (s.npair + s.nflexpair))                      \
+  X(pair_includemargin, (s.npair + s.nflexpair))               \
+  X(pair_friction, 5 * (s.npair + s.nflexpair))                \
+  X(pair_solref, 2 * (s.npair + s.nflexpair))                  \
+  X(pair_solreffriction, 2 * (s.npair + s.nflexpair))          \
+  X(pair_solimp, 5 * (s.npair + s.nflexpair))                  \
   X(eq_solref, 2 * s.neq)                      \
   X(eq_solimp, 5 * s.neq)                      \
   X(eq_data, 11 * s.neq)                       \
@@ -339,6 +353,9 @@ struct DSizes {
   // flexes (mjh_flex.h): mjModel sizes; nflexbend = nflexedge when some flex has bending stiffness, else 0;
   // nflexdof = nv with flexes, else 0
   int nflex, nflexvert, nflexedge, nflexelem, nflexelemdata, nflexstiffness, nflexbending, nJfe, nflexbend, nflexdof;
+  // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
+  // body : flex job, ngeom with flexes (else 0), per-env capacity of the flex contact identity table (nconmax or 0)
+  int nflexpair, ncolseg, nflexleaf, nflexcand, ngeomflex, nconflex;
 };
 
 struct DOptions {
@@ -473,6 +490,9 @@ enum {
   X(flexedge_J, s.nJfe, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(flexelem_frc, 12 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* mjData flexelem_aabb; candidate contacts of one body : flex job (dist, pos[3], normal[3], min_dist) */ \
+  X(flexelem_aabb, 6 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexcand, 8 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                           \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_AR, s.nefcAR * s.nefcAR, 0, MJH_T_GLB, MJH_T_GLB)                          \
@@ -525,6 +545,10 @@ enum {
   X(con_dim, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)                 \
   X(con_exclude, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)             \
   X(con_efcadr, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)              \
+  /* mjContact flex[1] / elem[1] / vert[1] of every contact (models with flexes), -1 -1 -1 for geom : geom; candidate \
+     table of a body : flex job (geom, vertex or element, parameter record, kind, selected flag; then the surviving leaves) */ \
+  X(con_flex, 3 * s.nconflex, 0, MJH_T_GLB, MJH_T_GLB)                            \
+  X(flexcand_i, 6 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                         \
   X(moment_rownnz, s.nu, s.nu, MJH_T_TRANSMISSION, MJH_T_ACTUATION)               \
   X(moment_colind, s.nmoment, s.nmoment, MJH_T_TRANSMISSION, MJH_T_ACTUATION)     \
   X(efc_type, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \
