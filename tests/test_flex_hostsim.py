@@ -1,0 +1,209 @@
+"""Flexes (mjh_flex.h, mjh_flexcol.h) on the host wavefront emulation against the oracle.
+
+Free motion -- vertex positions, edge lengths / Jacobians / velocities, finite-element stretch, shell bending and edge
+dampers -- is held to bit equality.  With contacts the constraint solve of these large models (nv of several hundred
+to 1536, one island spanning the flex) sums in a different order than the reference's island-compressed sparse
+routines, so steps are compared from identical inputs: contact lists exact, ncon / nefc exact, next state within
+1e-9; the CG iteration count may differ by one on a step whose last improvement sits at the tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from mujoco_amd import _capi as K
+
+VERTS = 'count="{n}" spacing=".05 .05 .05"'
+
+
+def flex_xml(count, pos, extra_world="", flex_attr='dim="3"', flex_body='<edge damping="1"/><contact selfcollide="none"/><elasticity young="5e4"/>',
+             option='solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"'):
+    return f"""
+<mujoco>
+  <option {option}/>
+  <size memory="10M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    {extra_world}
+    <flexcomp type="grid" count="{count}" spacing=".05 .05 .05" pos="{pos}" {flex_attr} radius=".005" mass="2" name="soft">
+      {flex_body}
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _fields_exact(b, d, names):
+    bad = []
+    for f in names:
+        a = b.get(f)[0]
+        r = np.asarray(getattr(d, f)).ravel()
+        if not np.array_equal(a[:len(r)], r):
+            bad.append((f, float(np.abs(a[:len(r)] - r).max())))
+    return bad
+
+
+def _free_motion(rb, lib, m, nstep=3):
+    dm = K.DeviceModel(lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    rng = np.random.default_rng(0)
+    d.qvel[:] = rng.normal(0, .1, m.nv)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
+    rb.mj_forward(m, d); b.forward()
+    assert _fields_exact(b, d, ["flexvert_xpos", "flexedge_length", "flexedge_velocity", "flexedge_J", "qfrc_spring",
+                                "qfrc_damper", "qfrc_passive", "qacc"]) == []
+    assert np.abs(d.qfrc_spring).max() > 0 or np.abs(d.qfrc_damper).max() > 0
+    for _ in range(nstep):
+        b.step(); rb.mj_step(m, d)
+    assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel)
+
+
+def test_jelly_free_motion_bit_exact(rb, hostsim_lib):
+    """BASELINE config 5's model: 512 vertices, 2863 edges, 2058 tetrahedra; stretch + edge damping, no contact yet."""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "jelly.mjb"))
+    assert (m.nv, m.nflexvert, m.nflexelem) == (1536, 512, 2058)
+    _free_motion(rb, hostsim_lib, m)
+
+
+def test_shell_bending_free_motion_bit_exact(rb, hostsim_lib, tmp_path):
+    """a triangle shell with bending stiffness, Rayleigh damping and pinned corners (mj_flexPassiveBend, :459-547)"""
+    xml = tmp_path / "shell.xml"
+    xml.write_text(flex_xml("6 6 1", "0 0 1", flex_attr='dim="2"',
+                            flex_body='<edge equality="false" damping="10"/><contact contype="0" conaffinity="0"/>'
+                                      '<elasticity young="3e5" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="both"/><pin id="0 5 30 35"/>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.flex_dim[0] == 2 and m.flex_bendingadr[0] >= 0
+    _free_motion(rb, hostsim_lib, m)
+
+
+def _resync_steps(rb, lib, m, pre, nstep, mocap=None):
+    """the oracle's trajectory from reset; after `pre` steps every step is repeated by the kernels from the oracle's
+    (state, warm start) and compared"""
+    dm = K.DeviceModel(lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    if mocap is not None: d.mocap_pos[:] = mocap
+    for _ in range(pre): rb.mj_step(m, d)
+    same_iter = 0; worst = 0.0; maxcon = 0; kinds = set()
+    for t in range(nstep):
+        s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
+        b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+        if m.nmocap: b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+        b.step(); rb.mj_step(m, d)
+        c = b.get("counts")[0]
+        assert (c[0], c[1]) == (d.ncon, d.nefc), (t, c[:2], d.ncon, d.nefc)
+        assert abs(int(c[5]) - int(d.solver_niter[0])) <= 1, (t, c[5], d.solver_niter[0])
+        assert not b.get("warning")[0].any()
+        maxcon = max(maxcon, d.ncon)
+        if d.ncon:
+            con = d.contact[:d.ncon]
+            kinds |= {"vert"} if (np.asarray(con["vert"])[:, 1] >= 0).any() else set()
+            kinds |= {"elem"} if (np.asarray(con["elem"])[:, 1] >= 0).any() else set()
+        if c[5] == d.solver_niter[0]:
+            same_iter += 1
+            err = max(np.abs(b.get("qpos")[0] - d.qpos).max(), np.abs(b.get("qvel")[0] - d.qvel).max()/max(1.0, np.abs(d.qvel).max()))
+            worst = max(worst, err)
+    assert worst < 1e-9, worst
+    assert same_iter >= 0.9*nstep, (same_iter, nstep)
+    return maxcon, kinds
+
+
+def test_flex_contact_lists_exact(rb, hostsim_lib, tmp_path):
+    """vertex-plane and element-geom (sphere, box, capsule: GJK / EPA against tetrahedra) contacts of one forward pass:
+    every contact record and every constraint row parameter identical to the oracle's"""
+    xml = tmp_path / "mix.xml"
+    xml.write_text(flex_xml("5 5 3", "0 0 .12", extra_world='''
+    <geom name="wall" type="plane" size=".5 .5 .05" zaxis="1 0 0" pos="-.12 0 0"/>
+    <body mocap="true" pos=".06 .06 .03"><geom type="sphere" size=".05" condim="1"/></body>
+    <body mocap="true" pos="-.05 -.05 .03"><geom type="box" size=".04 .03 .03" euler="10 20 30"/></body>
+    <body mocap="true" pos=".05 -.06 .04" zaxis="1 .3 0"><geom type="capsule" size=".03 .05"/></body>'''))
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    seen = set()
+    for pre in (60, 90, 140):
+        rb.mj_resetData(m, d)
+        for _ in range(pre): rb.mj_step(m, d)
+        s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:]); b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+        b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+        rb.mj_forward(m, d); b.forward()
+        n = d.ncon
+        assert b.get("counts")[0][0] == n and n > 0
+        con = d.contact[:n]
+        assert np.array_equal(b.get("con_dist")[0][:n], con["dist"])
+        assert np.array_equal(b.get("con_pos")[0][:3*n], np.asarray(con["pos"]).ravel())
+        assert np.array_equal(b.get("con_frame")[0][:9*n], np.asarray(con["frame"]).ravel())
+        assert np.array_equal(b.get("con_geom")[0][:2*n].reshape(-1, 2), np.asarray(con["geom"]))
+        cf = b.get("con_flex")[0][:3*n].reshape(-1, 3)
+        assert np.array_equal(cf[:, 0], np.asarray(con["flex"])[:, 1])
+        assert np.array_equal(cf[:, 1], np.asarray(con["elem"])[:, 1]) and np.array_equal(cf[:, 2], np.asarray(con["vert"])[:, 1])
+        assert _fields_exact(b, d, ["efc_pos", "efc_margin", "efc_D", "efc_R"]) == []
+        seen |= set(np.asarray(con["geom"])[:, 0].tolist())
+    assert len(seen) >= 3, seen
+
+
+def test_flex_on_floor_keeps_fifty_contacts(rb, hostsim_lib, tmp_path):
+    """81 vertices of the bottom layer reach the floor: filterFlexContacts keeps mjMAXCONPAIR = 50 of them (deepest first,
+    then farthest-point sampling with the reference's positional bookkeeping), sorted by vertex"""
+    xml = tmp_path / "floor.xml"
+    xml.write_text(flex_xml("9 9 2", "0 0 .035"))
+    m = rb.MjModel.from_xml_path(str(xml))
+    maxcon, kinds = _resync_steps(rb, hostsim_lib, m, pre=30, nstep=40)
+    assert maxcon == 50 and kinds == {"vert"}
+
+
+def test_jelly_on_the_capsule(rb, hostsim_lib):
+    """jelly.xml falling onto its capsule: element contacts, one island of 1536 dofs under CG"""
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "jelly.mjb"))
+    maxcon, kinds = _resync_steps(rb, hostsim_lib, m, pre=385, nstep=30)
+    assert maxcon >= 20 and "elem" in kinds
+
+
+def test_flex_against_an_actuated_body(rb, hostsim_lib, tmp_path):
+    """a solid flex draped over a hinged, motor-driven cylinder (the geom's own dofs enter the element rows with weight -1)"""
+    xml = tmp_path / "drum.xml"
+    xml.write_text(f"""
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001"/>
+  <size memory="20M"/>
+  <worldbody>
+    <geom type="plane" size="0 0 .05"/>
+    <flexcomp type="grid" count="8 3 3" spacing=".05 .05 .05" pos="0 0 .36" radius="0" name="soft" dim="3" mass="3">
+      <contact condim="3" solref="0.01 1" solimp=".95 .99 .0001" selfcollide="none"/>
+      <elasticity young="5e4" damping="0.002" poisson="0.2"/>
+    </flexcomp>
+    <body><joint name="hinge" pos="0 0 .15" axis="0 1 0" damping="5"/><geom type="cylinder" size=".12" fromto="0 -.2 .15 0 .2 .15" density="300"/></body>
+  </worldbody>
+  <actuator><motor joint="hinge" ctrlrange="-10 10"/></actuator>
+</mujoco>""")
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    d.ctrl[:] = 3.0
+    for _ in range(160): rb.mj_step(m, d)
+    assert d.ncon > 0
+    hit = 0
+    for t in range(25):
+        s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
+        b.set("qacc_warmstart", d.qacc_warmstart[None, :]); b.set("ctrl", d.ctrl[None, :])
+        b.step(); rb.mj_step(m, d)
+        c = b.get("counts")[0]
+        assert (c[0], c[1]) == (d.ncon, d.nefc) and abs(int(c[5]) - int(d.solver_niter[0])) <= 1
+        if c[5] == d.solver_niter[0]:
+            hit += 1
+            assert np.abs(b.get("qpos")[0] - d.qpos).max() < 1e-9 and np.abs(b.get("qvel")[0] - d.qvel).max() < 1e-8
+    assert hit >= 20
+
+
+def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
+    xml = tmp_path / "eq.xml"
+    xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    with pytest.raises(K.MjhipError, match="flex"):
+        K.DeviceModel(hostsim_lib, m)

@@ -102,8 +102,35 @@ def make_cube():
     print("cube_3x3x3", "nv", m.nv, "ncon max", ints[:, 0].max(), "nefc max", ints[:, 1].max(), "niter max", ints[:, 2].max())
 
 
+def make_jelly():
+    """BASELINE config 5: model/flex/jelly.xml as shipped (512-vertex solid flex, nv 1536, CG, dt 1 ms)."""
+    import re
+    import tempfile
+    src = os.path.join(REF, "model/flex/jelly.xml")
+    full = rb.MjModel.from_xml_path(src)
+    # the included scene carries two 512 x 512 builtin textures (7 MB of pixels mj_step never reads): compiled from the
+    # reference's XML with the <texture> / <material> elements removed, physics arrays asserted equal
+    scene = open(os.path.join(REF, "model/flex/scene.xml")).read()
+    scene = re.sub(r"<texture\b[^>]*?/>", "", scene, flags=re.S)
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "scene.xml"), "w") as f:
+            f.write(strip_visuals(scene))
+        with open(os.path.join(td, "jelly.xml"), "w") as f:
+            f.write(open(src).read())
+        m = rb.MjModel.from_xml_path(os.path.join(td, "jelly.xml"))
+    for name in PHYSICS_ARRAYS + ["flex_vert", "flex_elem", "flex_edge", "flex_stiffness", "flexedge_length0", "flex_vertbodyid",
+                                  "bvh_child", "bvh_nodeid", "flex_elemlayer", "geom_type", "body_invweight0"]:
+        assert np.array_equal(getattr(m, name), getattr(full, name)), name
+    assert (m.nq, m.nv, m.ngeom, m.nflexelem, m.nbvh) == (full.nq, full.nv, full.ngeom, full.nflexelem, full.nbvh)
+    m.save_binary(os.path.join(OUT, "jelly.mjb"))
+    print("jelly", "nv", m.nv, "nflexvert", m.nflexvert, "nflexelem", m.nflexelem)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_jelly()
+    if "--jelly-only" in sys.argv:
+        return
     make_cube()
     if "--cube-only" in sys.argv:
         return
