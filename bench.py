@@ -60,6 +60,13 @@ CONFIGS = {
     "slider_crank": dict(mjb="slider_crank.mjb", xml="model/slider_crank/slider_crank.xml", nenv=64, solver="pgs",
                          integrator="euler", ctrl=(-0.1, 0.1), dt=0.002, free_root=False,
                          metric="env-steps/sec on slider_crank.xml, 64 envs"),
+    # model/flex/jelly.xml (BASELINE configs[4]: 1024 envs over 4 GPUs = 256 per GPU): 512-vertex solid flex, nv 1536, CG,
+    # Euler, dt 1 ms, no actuators -- the environments differ by their initial vertex velocities; the jelly reaches its
+    # capsule after ~340 steps, so the default warm-up is 400 steps (the timed steps are then all in contact)
+    "flex": dict(mjb="jelly.mjb", xml="model/flex/jelly.xml", nenv=256, solver=None, integrator=None,
+                 ctrl=(0.0, 0.0), dt=0.001, free_root=False, warmup=400, solver_label="cg", integ_label="euler",
+                 parity_envs=4,
+                 metric="env-steps/sec on flex/jelly.xml (512-vertex solid flex, CG), 256 envs/GPU"),
 }
 
 
@@ -218,7 +225,7 @@ def measured_sq(config: str):
     return out
 
 
-def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0)):
+def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0), iter_exact=True):
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).  Two builds of the reference are consulted (oracle/Makefile):
@@ -276,12 +283,19 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
         got, counts = step_once(np.array(pre_s), np.array(pre_w), np.array(pre_u)[:, None])
         nxt, ints = np.array(nxt), np.array(ints)
         per_step = np.max(np.abs(got - nxt) / np.maximum(1.0, np.abs(nxt)), axis=1)
-        nbad = int(np.sum((counts[:, 0] != ints[:, 0]) | (counts[:, 1] != ints[:, 1]) | (counts[:, 5] != ints[:, 2])))
+        # (iter_exact False -- the flex configuration, whose 1536-dof island is summed in a different order than the
+        # reference's island-compressed sparse routines: an iteration count may differ by one on a step whose last
+        # improvement sits at the solver tolerance; reported, not counted as a mismatch)
+        nbad = int(np.sum((counts[:, 0] != ints[:, 0]) | (counts[:, 1] != ints[:, 1]) |
+                          ((counts[:, 5] != ints[:, 2]) if iter_exact else (np.abs(counts[:, 5] - ints[:, 2]) > 1))))
+        niter_diff = int(np.sum(counts[:, 5] != ints[:, 2]))
         out[label] = {
             "identical_input_steps": {"steps": int(len(nxt)), "max_rel_err": float(per_step.max()),
                                       "frac_within_tolerance": float(np.mean(per_step <= 1e-6)),
                                       "bit_exact_steps": int(np.sum(np.all(got == nxt, axis=1))), "count_mismatches": nbad,
-                                      "checked": "next state within 1e-6; ncon, nefc, solver_niter exact",
+                                      "solver_iter_differs": niter_diff,
+                                      "checked": "next state within 1e-6; ncon, nefc, solver_niter exact" if iter_exact else
+                                                 "next state within 1e-6; ncon, nefc exact; solver_niter within one",
                                       "mean_ncon": float(ints[:, 0].mean()), "mean_nefc": float(ints[:, 1].mean()),
                                       "mean_solver_iter": float(ints[:, 2].mean())},
             "trajectory": {"max_rel_err": worst, "worst_env_step": worst_at, "within_tolerance": bool(worst <= 1e-6)}}
@@ -304,7 +318,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 100; flex: 400, the fall onto the capsule)")
     ap.add_argument("--chunk", type=int, default=250,
                     help="steps per rollout-kernel launch (one open-loop rollout call); 250 measured best: longer launches average the per-environment cost, shorter ones re-deal the environments over the SIMDs more often")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="humanoid",
@@ -360,8 +374,12 @@ def main() -> None:
         model.set_option("solver", solver_id)     # PGS = BASELINE config 2
     if integ_id is not None:
         model.set_option("integrator", integ_id)
-    solver_name = solver_name or "newton"            # (cube_3x3x3.xml ships the default solver)
-    integ_name = integ_name or "implicitfast"        # (cube_3x3x3.xml:4)
+    solver_name = solver_name or cfg.get("solver_label", "newton")            # (cube_3x3x3.xml ships the default solver)
+    integ_name = integ_name or cfg.get("integ_label", "implicitfast")        # (cube_3x3x3.xml:4)
+    if args.warmup is None:
+        args.warmup = cfg.get("warmup", 100)
+    if "parity_envs" in cfg:
+        args.parity_envs = min(args.parity_envs, cfg["parity_envs"])
     dm = ma.DeviceModel(lib, model)
     nenv, K, W = (args.envs_per_gpu or cfg["nenv"]), args.steps, args.warmup
     nq, nv, nu, nstate = dm.nq, dm.nv, dm.nu, dm.nstate
@@ -404,7 +422,7 @@ def main() -> None:
         out, t = [], t_begin
         if kind == "uniform":
             for c in sizes:
-                u = crng.uniform(lo[0], hi[0], size=(nenv, c, nu))
+                u = crng.uniform(cfg["ctrl"][0], cfg["ctrl"][1], size=(nenv, c, nu))
                 host_ctrl.append(u[:cpu_rows].copy())
                 out.append(torch.from_numpy(u).to(dev))
         else:
@@ -541,7 +559,8 @@ def main() -> None:
             return out, small.get("counts")
 
         try:
-            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once, cfg["ctrl"])
+            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once, cfg["ctrl"],
+                                                 iter_exact=cfg.get("iter_exact", True))
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
             res["parity_sample"] = {"ok": False, "error": repr(exc)}
     del state_w, state_k, ctrl_w, ctrl_k

@@ -21,6 +21,7 @@ struct Efc {
   rptr spJ, spJT, spL, spLc, spL_home, vec;
   int spL_cap;
   iptr rowmask, rowadr, JTadr, JTrow, Lmask, Ladr, spar;
+  iptr colind;       // explicit column indices of the compressed rows (mjh_csr.h), else unused
   // the larger of the two regions' unused tails (staging space for stage_project)
   char* free_p;
   int free_bytes;
@@ -55,8 +56,8 @@ struct Efc {
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
   X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
   X(cone, MJH_G(B, efc_cone, e), nefc, 1)                            \
-  X(spJ, MJH_G(B, sp_J, e), nJ_, 1)                                  \
-  X(spJT, MJH_G(B, sp_JT, e), primal_*nJ_, 1)
+  X(spJ, MJH_G(B, sp_J, e), (1 - csr_)*nJ_, 1)                       \
+  X(spJT, MJH_G(B, sp_JT, e), (1 - csr_)*primal_*nJ_, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
   X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
   X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
@@ -65,10 +66,11 @@ struct Efc {
   X(island, MJH_G(B, efc_island, e), nefc, 1)                        \
   X(rowadr, MJH_G(B, sp_rowadr, e), sp_*(nefc + 1), 1)               \
   X(JTadr, MJH_G(B, sp_JTadr, e), sp_*primal_*(nv + 1), 1)           \
-  X(rowmask, MJH_G(B, sp_rowmask, e), 4*sp_*nefc, 1)
+  X(rowmask, MJH_G(B, sp_rowmask, e), 4*spm_*nefc, 1)
 // int arrays packed after the real ones (sized by nJ, see efc_layout)
 #define MJH_EFC_LATE_INT_ARRAYS(X)                                   \
-  X(JTrow, MJH_G(B, sp_JTrow, e), primal_*nJ_, 1)
+  X(JTrow, MJH_G(B, sp_JTrow, e), (1 - csr_)*primal_*nJ_, 1)         \
+  X(colind, MJH_G(B, sp_colind, e), 0*csr_, 1)
 
 // (stage_project) does this array already live in the LDS plan?  (pointer inside the workgroup's block)
 template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* lds, int bytes) {
@@ -86,7 +88,10 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   // sparse primal path: the dense J stays in its global home (it is only the staging copy the compressed
   // rows are cut from); the arrays sized by nJ come last in the packing order, so the layout of everything
   // else is already final while nJ is still being counted
-  const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  // (sp_: a compressed Jacobian exists -- the 128-bit-mask form of mjh_sparse.h (spm_) or the explicit-index form of mjh_csr.h (csr_))
+  const int spm_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int csr_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) ? 1 : 0;
+  const int sp_ = spm_ | csr_;
   const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
   int off1 = B.dyn_off, off2 = B.dyn2_off;
@@ -99,9 +104,9 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   // died, and the dual-only arrays that would use region 2 do not exist here: the block grows upward from the bottom
   // of region 2 across the boundary into region 1, and the arrays written by constraint assembly get what is left
   // above it.  They are streamed lane-parallel and can live in global memory.
-  P.spL_home = sp_ ? MJH_G(B, sp_L, e) : MJH_G(B, nt_H, e);
-  P.spL = P.spL_home; P.spL_cap = sp_ ? M.s.nLp : nv*nv;
-  P.spLc = sp_ ? MJH_G(B, sp_Lc, e) : MJH_G(B, nt_M, e);
+  P.spL_home = spm_ ? MJH_G(B, sp_L, e) : MJH_G(B, nt_H, e);
+  P.spL = P.spL_home; P.spL_cap = spm_ ? M.s.nLp : nv*nv;
+  P.spLc = spm_ ? MJH_G(B, sp_Lc, e) : MJH_G(B, nt_M, e);
   P.Ladr = MJH_G(B, sp_Ladr, e); P.Lmask = MJH_G(B, sp_Lmask, e);
   P.vec = MJH_G(B, nt_vec, e);
   P.spar = MJH_G(B, iscratch, e) + nmax;
@@ -109,7 +114,7 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
     int lo = off2;
     const int newton = M.o.solver == MJH_SOL_NEWTON;
     const int nvec = (newton ? 5 : 8)*nv*(int)sizeof(real);
-    if (sp_) {
+    if (spm_) {
       const int b_adr = (((nv + 1)*(int)sizeof(int)) + 7) & ~7, b_mask = 4*nv*(int)sizeof(int);
       if (lo + b_adr <= end1) { P.Ladr = SP<int>{(int*)(lds_ + lo), 1}; lo += b_adr; }
       if (lo + b_mask <= end1) { P.Lmask = SP<int>{(int*)(lds_ + lo), 1}; lo += b_mask; }
@@ -117,12 +122,12 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
     }
     if (lo + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + lo), 1}; lo += nvec; }
     if (newton) {
-      const int full = (sp_ ? M.s.nLp : nv*(nv + 1)/2)*(int)sizeof(real);
+      const int full = (spm_ ? M.s.nLp : nv*(nv + 1)/2)*(int)sizeof(real);
       int lb = (end1 - lo) & ~7;
       if (lb > full) lb = full;
       // (the dense factor is not addressed through a capacity: all or nothing)
-      if (sp_ ? lb >= 64*(int)sizeof(real) : lb == full) { P.spL = SP<real>{(real*)(lds_ + lo), 1}; P.spL_cap = lb/(int)sizeof(real); lo += lb; }
-      if (!sp_ && M.o.cone != 0 && lo + full <= end1) { P.spLc = SP<real>{(real*)(lds_ + lo), 1}; lo += full; }
+      if (spm_ ? lb >= 64*(int)sizeof(real) : lb == full) { P.spL = SP<real>{(real*)(lds_ + lo), 1}; P.spL_cap = lb/(int)sizeof(real); lo += lb; }
+      if (!spm_ && M.o.cone != 0 && lo + full <= end1) { P.spLc = SP<real>{(real*)(lds_ + lo), 1}; lo += full; }
     }
     off2 = end2;
     if (lo > off1) off1 = lo;
@@ -173,13 +178,29 @@ MJH_DEV real sp_row_dot(const Efc& P, int r, P0 v) {
   return res;
 }
 
+// the same for the explicit-index form (mjh_csr.h): row r = spJ / colind [rowadr[r], rowadr[r+1])
+template <class P0>
+MJH_DEV real csr_row_dot(const Efc& P, int r, P0 v) {
+  const int a0 = P.rowadr[r], nnz = P.rowadr[r + 1] - a0;
+  crptr a = P.spJ + a0;
+  ciptr ci = P.colind + a0;
+  real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int k = 0;
+  for (; k <= nnz - 4; k += 4) { r0 += a[k]*v[ci[k]]; r1 += a[k + 1]*v[ci[k + 1]]; r2 += a[k + 2]*v[ci[k + 2]]; r3 += a[k + 3]*v[ci[k + 3]]; }
+  real res = (r0 + r2) + (r1 + r3);
+  for (; k < nnz; k++) res += a[k]*v[ci[k]];
+  return res;
+}
+
 // debug write-back of the LDS-resident constraint arrays to their global homes
 MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const int nefc = MJH_F(B, counts, e)[MJH_C_NEFC];
   const int nv = M.s.nv, nmax = M.s.nefcmax;
   const int dual_ = (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) ? 1 : 0;
-  const int sp_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int spm_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
+  const int csr_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) ? 1 : 0;
+  const int sp_ = spm_ | csr_;
   const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
   (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_; (void)primal_;
@@ -625,7 +646,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
   // (sparse path under a primal solver: the contact rows are written straight into the compressed Jacobian by
   // stage_sparsify, one row per lane -- this loop takes the contacts one at a time and would leave most lanes idle behind
   // its loads; the dual solver still needs the dense rows for Y = J L^-T D^-1/2)
-  const int contact_rows_here = !(MJH_HAS(MJH_FT_PRIMAL) && s.sparse && M.o.solver != MJH_SOL_PGS);
+  const int contact_rows_here = !(MJH_HAS(MJH_FT_PRIMAL) && (s.sparse || s.csr) && M.o.solver != MJH_SOL_PGS);
   for (int k0 = 0; contact_rows_here && k0 < ncon; k0 += 1 + cpair) {
     const int k = k0 + (cpair ? (wv_lane() >> 5) : 0);
     if (k >= ncon) continue;
@@ -899,6 +920,14 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     auto scan_row = [&](int i, auto&& f) -> int {
       crptr Jr = P.J + (size_t)i*nv;
       int first = -2, prev = -2;
+      if (MJH_HAS(MJH_FT_PRIMAL) && s.csr) {
+        // compressed rows (mjh_csr.h): the trees of the stored dofs, in order
+        for (int q = P.rowadr[i]; q < P.rowadr[i + 1]; q++) {
+          const int tj = M.dof_treeid[P.colind[q]];
+          if (tj != prev) { if (first == -2) first = tj; else f(prev, tj); prev = tj; }
+        }
+        return first;
+      }
       for (int j = 0; j < nv; j++) {
         if (Jr[j] != 0) {
           const int tj = M.dof_treeid[j];
@@ -1242,8 +1271,9 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
   rptr vel = P.vel;
   rptr aref = P.aref;
   const int sparse = MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse;     // mj_mulJacVec takes mju_mulMatVecSparse
+  const int csr = MJH_HAS(MJH_FT_PRIMAL) && M.s.csr;
   MJH_FOR_LANES(r, nefc) {
-    real v = sparse ? sp_row_dot(P, r, qvel) : dot_ref(J + (size_t)r*nv, qvel, nv);
+    real v = csr ? csr_row_dot(P, r, qvel) : sparse ? sp_row_dot(P, r, qvel) : dot_ref(J + (size_t)r*nv, qvel, nv);
     vel[r] = v;
     aref[r] = -KBIP[4*r+1]*v - KBIP[4*r]*KBIP[4*r+2]*(pos[r] - margin[r]);
   }

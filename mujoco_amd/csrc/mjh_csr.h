@@ -1,0 +1,215 @@
+// Compressed constraint Jacobian with explicit column indices, for models beyond the 128 dofs the mask form of
+// mjh_sparse.h covers (flexes: jelly.xml has 1536).  The reference keeps efc_J compressed whenever mj_isSparse holds
+// (engine_core_util.c:32); a row stores the dofs of the bodies it touches in ascending order
+// (mj_jacDifPair / mj_jacSum, engine_core_util.c:437-600, common dofs of the two chains left out for contacts), products
+// J v and J' f are mju_dotSparse sums over the stored entries (four accumulators by position, engine_util_sparse.c).
+// This header builds the same rows -- values by the expressions of the dense path (mjh_constraint.h), kept next to
+// their column indices -- and their transpose; the CG solver (mjh_newton.h, SPA = 2) and the row products of
+// mj_referenceConstraint / mj_fwdConstraint read them instead of streaming nv-wide dense rows.
+//
+// Scope (mjh_model_build.h: s.csr): CG, no equality or tendon rows (their dense rows would have to be cut by a scan),
+// contacts up to condim 3, islands enabled.  (included once per SPMD mode by mjh_stages.inc: no include guard)
+
+#if !MJH_LANE_MODE
+
+// dofs of body b's chain into out[] (descending), returns the count
+template <class IP>
+MJH_DEV int csr_body_chain(MREF M, int b, IP out) {
+  const int w = M.body_weldid[b];
+  int n = 0;
+  if (M.body_dofnum[w] == 0) return 0;
+  for (int j = M.body_dofadr[w] + M.body_dofnum[w] - 1; j >= 0; j = M.dof_parentid[j]) out[n++] = j;
+  return n;
+}
+
+MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  iptr counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ncon = counts[MJH_C_NCON];
+  if (!nefc) { if (wv_lane() == 0) counts[MJH_C_NJ] = 0; wv_sync(); return; }
+  const int nv = s.nv;
+  const int ispyramid = M.o.cone == 0;
+  // (the arrays sized by nJ take their global homes while nJ is unknown: same convention as stage_sparsify)
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  iptr rowadr = P.rowadr;
+  iptr colind = MJH_G(B, sp_colind, e);
+  rptr val = MJH_G(B, sp_J, e);
+  crptr Jd = MJH_G(B, efc_J, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr subtree_com = MJH_F(B, subtree_com, e);
+  const int cap = s.csr_rowmax;
+
+  // ---- pass 1: stored entries per row (rowadr[r + 1] <- nnz of row r)
+  MJH_FOR_LANES(r, nefc) {
+    const int type = P.type[r], id = P.id[r];
+    int nnz = 0;
+    if (type == MJH_CNSTR_FRICTION_DOF) nnz = 1;
+    else if (type == MJH_CNSTR_LIMIT_JOINT) nnz = M.jnt_type[id] == MJH_JNT_BALL ? 3 : 1;
+    else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) nnz = -1;          // set by its contact below
+    if (nnz >= 0) rowadr[r + 1] = nnz;
+  }
+  wv_sync();
+  // contacts: the merged chain, written (sorted, common dofs removed) to the head of a private slot of the column array;
+  // slot of contact k: [k*cap, (k+1)*cap) of the TAIL half of sp_colind is not available before nJ is known, so the chain
+  // is rebuilt in pass 2 -- here only its length
+  MJH_FOR_LANES(k, ncon) {
+    const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
+    if (r0 < 0) continue;
+    const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+    const int nrow = dim == 1 ? 1 : (ispyramid ? 2*(dim - 1) : dim);
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+    int fbody[4]; real fw[4];
+    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+    int cols[64];
+    int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
+    if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
+    else n += csr_body_chain(M, M.geom_bodyid[cg[1]], cols + n);
+    // common dofs appear twice: they cancel (flg_skipcommon)
+    int dup = 0;
+    for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (cols[a] == cols[b]) dup++;
+    const int nnz = n - 2*dup;
+    for (int a = 0; a < nrow; a++) rowadr[r0 + a + 1] = nnz;
+  }
+  wv_sync();
+  // exclusive scan of the counts -> row addresses
+  int total = 0;
+  for (int r0 = 0; r0 < nefc; r0 += MJH_W) {
+    const int r = r0 + wv_lane();
+    const int c = r < nefc ? rowadr[r + 1] : 0;
+    const int before = wv_exscan_i(c);
+    const int sum = wv_sum_i(c);
+    wv_sync();
+    if (r < nefc) rowadr[r + 1] = total + before + c;
+    total += sum;
+  }
+  if (wv_lane() == 0) { rowadr[0] = 0; counts[MJH_C_NJ] = total; }
+  wv_sync();
+
+  // ---- pass 2: columns and values
+  MJH_FOR_LANES(r, nefc) {
+    const int type = P.type[r], id = P.id[r];
+    const int a0 = rowadr[r];
+    if (type == MJH_CNSTR_FRICTION_DOF) { colind[a0] = id; val[a0] = Jd[(size_t)r*nv + id]; }
+    else if (type == MJH_CNSTR_LIMIT_JOINT) {
+      const int d0 = M.jnt_dofadr[id], nd = M.jnt_type[id] == MJH_JNT_BALL ? 3 : 1;
+      for (int q = 0; q < nd; q++) { colind[a0 + q] = d0 + q; val[a0 + q] = Jd[(size_t)r*nv + d0 + q]; }
+    }
+  }
+  MJH_FOR_LANES(k, ncon) {
+    const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
+    if (r0 < 0) continue;
+    const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+    int fbody[4]; real fw[4];
+    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+    const int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
+    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    int cols[64];
+    int n = csr_body_chain(M, b1, cols);
+    if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
+    else n += csr_body_chain(M, b2, cols + n);
+    // ascending, common dofs removed
+    for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
+    int m = 0;
+    for (int a = 0; a < n; a++) {
+      if (a + 1 < n && cols[a] == cols[a + 1]) { a++; continue; }
+      cols[m++] = cols[a];
+    }
+    crptr point = MJH_CON(B, con_pos, e, 3, k);
+    crptr fr = MJH_CON(B, con_frame, e, 9, k);
+    auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
+    real off1[3], off2[3];
+    v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
+    v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
+    const int a0 = rowadr[r0];
+    const int stride = rowadr[r0 + 1] - a0;             // every row of the contact has the same pattern
+    for (int c = 0; c < m; c++) {
+      const int j = cols[c];
+      // (the expressions of stage_make_constraint's dense contact rows)
+      const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+      real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+      crptr cd = cdof + 6*j;
+      if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+      if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
+      real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+      if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
+        jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
+        for (int q = 0; q < nfb; q++) {
+          const int wq = M.body_weldid[fbody[q]];
+          if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+          real offq[3], t[3];
+          v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
+          v3_cross(t, cd, offq);
+          const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
+          jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
+        }
+      }
+      const int nr = dim > 1 ? 3 : 1;
+      real jr[3] = {0, 0, 0};
+      for (int a = 0; a < nr; a++) {
+        real acc = 0;
+        for (int q = 0; q < 3; q++) { const real t = fr[3*a + q]; if (t != 0) acc += jd[q]*t; }
+        jr[a] = acc;
+      }
+      if (dim == 1) { colind[a0 + c] = j; val[a0 + c] = jr[0]; }
+      else if (ispyramid) {
+        for (int a = 1; a < dim; a++) {
+          const int ra = a0 + (2*(a - 1))*stride + c, rb = a0 + (2*(a - 1) + 1)*stride + c;
+          colind[ra] = j; val[ra] = jr[0] + jr[a]*fri[a - 1];
+          colind[rb] = j; val[rb] = jr[0] + jr[a]*(-fri[a - 1]);
+        }
+      } else {
+        for (int a = 0; a < dim; a++) { colind[a0 + a*stride + c] = j; val[a0 + a*stride + c] = jr[a]; }
+      }
+    }
+  }
+  wv_sync();
+
+  // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse); counting pass with integer atomics,
+  //      then each dof sorts its (short) list by row
+  iptr JTadr = P.JTadr;
+  iptr JTrow = MJH_G(B, sp_JTrow, e);
+  rptr JTval = MJH_G(B, sp_JT, e);
+  iptr cursor = MJH_G(B, csr_idof, e);
+  MJH_FOR_LANES(j, nv + 1) JTadr[j] = 0;
+  MJH_FOR_LANES(j, nv) cursor[j] = 0;
+  wv_sync();
+  MJH_FOR_LANES(q, total) wv_atomic_add_i(&JTadr[colind[q] + 1], 1);
+  wv_sync();
+  {
+    int run = 0;
+    for (int j0 = 0; j0 <= nv; j0 += MJH_W) {
+      const int j = j0 + wv_lane();
+      const int c = j <= nv ? JTadr[j] : 0;
+      const int before = wv_exscan_i(c);
+      const int sum = wv_sum_i(c);
+      wv_sync();
+      if (j <= nv) JTadr[j] = run + before + c;
+      run += sum;
+    }
+  }
+  wv_sync();
+  MJH_FOR_LANES(r, nefc) {
+    for (int q = rowadr[r]; q < rowadr[r + 1]; q++) {
+      const int j = colind[q];
+      const int pos = JTadr[j] + wv_atomic_add_i(&cursor[j], 1);
+      JTrow[pos] = r; JTval[pos] = val[q];
+    }
+  }
+  wv_sync();
+  MJH_FOR_LANES(j, nv) {
+    const int a0 = JTadr[j], a1 = JTadr[j + 1];
+    for (int a = a0 + 1; a < a1; a++) {
+      const int rr = JTrow[a]; const real vv = JTval[a];
+      int b = a - 1;
+      while (b >= a0 && JTrow[b] > rr) { JTrow[b + 1] = JTrow[b]; JTval[b + 1] = JTval[b]; b--; }
+      JTrow[b + 1] = rr; JTval[b + 1] = vv;
+    }
+  }
+  wv_sync();
+}
+
+#endif   // !MJH_LANE_MODE

@@ -1190,7 +1190,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // ($MJHIP_EFC_BYTES, default 4 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
   {
     const bool dual = m->opt.solver == mjSOL_PGS;
-    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : 4.0*1024*1024;
+    // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
+    const bool ref_sparse0 = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
+    s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && m->neq == 0 && m->ntendon == 0 &&
+             !(m->opt.disableflags & mjDSBL_ISLAND)) ? 1 : 0;
+    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : (s.csr ? 64.0 : 4.0)*1024*1024;
     auto bytes = [&](int n) { return 8.0*n*(2.0*m->nv + (dual ? n : 0) + 24); };
     int n = std::max(1, std::min(nefc_bound, 4096));
     while (n > 256 && bytes(n) > budget) n = std::max(256, n*7/8);
@@ -1219,6 +1223,17 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.nLp = m->opt.solver == mjSOL_NEWTON ? m->nv*(m->nv + 1)/2 : 0;
       s.nLpc = (m->opt.cone != mjCONE_PYRAMIDAL) ? s.nLp : 0;
       if (m->opt.solver == mjSOL_PGS) s.nARw = (s.nefcmax + 63)/64;
+    }
+    if (s.csr) {
+      // longest row: the dof chains of two bodies, or one chain and the three sliders of each corner of a flex element
+      int chainmax = 1;
+      for (int b = 0; b < m->nbody; b++) {
+        int cnt = 0;
+        for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)b*s.nvw + w]);
+        chainmax = std::max(chainmax, cnt);
+      }
+      s.csr_rowmax = std::min((int)m->nv, std::max(2*chainmax, chainmax + 12));
+      s.nJmax = s.nefcmax*s.csr_rowmax;
     }
   }
   // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with

@@ -168,6 +168,39 @@ MJH_DEVN_HOT int dn_update(PL L, int nv, real x0, int flg_plus) {
 struct NtPoint { real alpha, cost, d0, d1; };
 
 // ELL = 0: instantiation without elliptic-cone code (the common pyramidal case keeps its register budget)
+// nd <= 16 dot products over the dofs idof[0..n) at once: product d in the four lanes 4d..4d+3, lane 4d + a running mju_dot's
+// accumulator a (elements a, a + 4, ... of the list, in order), then (r0 + r2) + (r1 + r3) plus the sum of the tail
+// (engine_util_blas.c:mju_dot).  A chain of n/4 dependent additions is the floor for a sum in the reference's order; the
+// independent products of a solver iteration share it.
+template <class IP>
+MJH_DEV void csr_dots(int n, IP idof, int nd, const crptr* xs, const crptr* ys, real* out) {
+  const int lane = wv_lane();
+  const int d = lane >> 2, a = lane & 3;
+  const int n4 = n & ~3;
+  real r = 0;
+  if (d < nd) {
+    crptr x = xs[0], y = ys[0];
+    for (int q = 1; q < nd; q++) if (q == d) { x = xs[q]; y = ys[q]; }
+    for (int k = a; k < n4; k += 4) { const int i = idof[k]; r += x[i]*y[i]; }
+    const real r2 = wv_shfl(r, lane ^ 2);           // (lane a = 0 adds chain 2, lane 1 chain 3: r0 + r2, r1 + r3)
+    const real s02 = r + r2;
+    const real s13 = wv_shfl(s02, lane ^ 1);
+    real res = s02 + s13;                            // (in lane 4d: (r0 + r2) + (r1 + r3))
+    if (a == 0 && n > n4) {
+      // (mju_dot adds the sum of the remaining one to three products, engine_util_blas.c:517-525)
+      const int i0 = idof[n4];
+      real tail = x[i0]*y[i0];
+      for (int k = n4 + 1; k < n; k++) { const int i = idof[k]; tail += x[i]*y[i]; }
+      res += tail;
+    }
+    r = res;
+  } else {
+    // (collectives are entered by every lane)
+    const real r2 = wv_shfl(r, lane ^ 2); const real s13 = wv_shfl(r2, lane ^ 1); (void)s13;
+  }
+  for (int q = 0; q < nd; q++) out[q] = wv_bcast(r, 4*q);
+}
+
 // SPA = 1: the reference's sparse path (mj_isSparse): compressed J / J', packed sparse factor -- mjh_sparse.h describes the
 // data model; the blocks marked "sparse" below restate engine_util_sparse.c / engine_util_solve.c operation for operation
 template <int ELL, int SPA>
@@ -234,7 +267,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // (sparse path: the reference's vectors are island-local -- the island's dofs in ascending order, contiguous -- so
   // mju_dot groups them by their position inside the island: ordered reduction over the island's dof mask)
   M128 isl_dofs = m128_below(nv);
+  // (SPA = 2, mjh_csr.h: the island's dofs as a list, ascending -- the reference's island-local vectors; sums take the four
+  // accumulator chains of mju_dot over positions in that list, one chain per lane, several products at a time: csr_dots)
+  iptr idof = MJH_G(B, csr_idof, e);
+  int nidof = nv;
   auto dotv = [&](crptr a, crptr b) -> real {
+    if (SPA == 2) { real out[1]; const crptr xs[1] = {a}, ys[1] = {b}; csr_dots(nidof, idof, 1, xs, ys, out); return out[0]; }
     if (SPA) {
       const real p0 = (lane < nv) ? (real)(a[lane]*b[lane]) : (real)0;
       const real p1 = (lane + MJH_W < nv) ? (real)(a[lane + MJH_W]*b[lane + MJH_W]) : (real)0;
@@ -263,7 +301,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // out = J v (mju_mulMatVec: one mju_dot per row), optionally - aref
   auto mul_J = [&](rptr out, crptr v, int sub_aref) {
     MJH_FOR_LANES(r, nefc) {
-      const real acc = SPA ? sp_row_dot(P, r, v) : dot_ref(J + (size_t)r*nv, v, nv);
+      const real acc = SPA == 2 ? csr_row_dot(P, r, v) : SPA ? sp_row_dot(P, r, v) : dot_ref(J + (size_t)r*nv, v, nv);
       out[r] = sub_aref ? acc - aref[r] : acc;
     }
     wv_sync();
@@ -678,7 +716,17 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   int niter0 = 0;
   tick(32);
   for (isl = 0; isl < nisl; isl++) {
-    if (SPA) {
+    if (SPA == 2) {
+      nidof = 0;
+      for (int j0 = 0; j0 < nv; j0 += MJH_W) {
+        const int j = j0 + lane;
+        const int in = j < nv && in_dof(j);
+        const unsigned long long m = wv_ballot(in);
+        if (in) idof[nidof + wv_rank_lt(m)] = j;
+        nidof += __builtin_popcountll(m);
+      }
+      wv_sync();
+    } else if (SPA) {
       isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
       isl_dofs.hi = wv_ballot(lane + MJH_W < nv && in_dof(lane + MJH_W));
     }
@@ -698,8 +746,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
     // convergence certificate with M^-1
     precondition();
-    const int flg_gap = r_max(0, 0.5*scale*dotv(grad, Mgrad)) < tol;
-    const int flg_gradient = scale*sqrt(dotv(grad, grad)) < tol;
+    real gm_gg[2];
+    if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, 2, xs, ys, gm_gg); }
+    else { gm_gg[0] = dotv(grad, Mgrad); gm_gg[1] = dotv(grad, grad); }
+    const int flg_gap = r_max(0, 0.5*scale*gm_gg[0]) < tol;
+    const int flg_gradient = scale*sqrt(gm_gg[1]) < tol;
     int done = flg_gap && (!flg_newton || flg_gradient);
     tick(32);
     if (!done && flg_newton) {
@@ -722,8 +773,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         mul_M(Mv, search);
         mul_J(Jv, search, 0);
         // PrimalPrepare
-        const real qg1 = dotv(search, Ma) - dotv(qfs, search);
-        const real qg2 = 0.5*dotv(search, Mv);
+        real q3[3];
+        if (SPA == 2) { const crptr xs[3] = {search, qfs, search}, ys[3] = {Ma, search, Mv}; csr_dots(nidof, idof, 3, xs, ys, q3); }
+        else { q3[0] = dotv(search, Ma); q3[1] = dotv(qfs, search); q3[2] = dotv(search, Mv); }
+        const real qg1 = q3[0] - q3[1];
+        const real qg2 = 0.5*q3[2];
         MJH_FOR_LANES(r, nefc) {
           if (!in_row(r)) continue;
           if (is_cone_row(r) && !cone_leader(P, r)) continue;
@@ -885,15 +939,20 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         wv_sync();
         crptr graddif = tmpv, Mgraddif = gradold;
         real beta;
-        const real d_dot_y = dotv(search, graddif);
+        real hz[6];
+        if (SPA == 2) {
+          const crptr xs[6] = {search, graddif, graddif, search, search, grad}, ys[6] = {graddif, Mgraddif, Mgrad, grad, search, grad};
+          csr_dots(nidof, idof, 6, xs, ys, hz);
+        } else hz[0] = dotv(search, graddif);
+        const real d_dot_y = hz[0];
         if (d_dot_y < MJH_MINVAL) beta = 0;
         else {
-          const real y_dot_My = dotv(graddif, Mgraddif);
-          const real y_dot_Mgrad = dotv(graddif, Mgrad);
-          const real d_dot_grad = dotv(search, grad);
+          const real y_dot_My = SPA == 2 ? hz[1] : dotv(graddif, Mgraddif);
+          const real y_dot_Mgrad = SPA == 2 ? hz[2] : dotv(graddif, Mgrad);
+          const real d_dot_grad = SPA == 2 ? hz[3] : dotv(search, grad);
           const real beta_hz = (y_dot_Mgrad - 2*(y_dot_My/d_dot_y)*d_dot_grad)/d_dot_y;
-          const real d_norm = sqrt(dotv(search, search));
-          const real grad_norm = sqrt(dotv(grad, grad));
+          const real d_norm = sqrt(SPA == 2 ? hz[4] : dotv(search, search));
+          const real grad_norm = sqrt(SPA == 2 ? hz[5] : dotv(grad, grad));
           const real eta_k = -1.0/r_max(MJH_MINVAL, d_norm*r_min(0.01, grad_norm));
           beta = r_max(eta_k, beta_hz);
         }
@@ -915,7 +974,8 @@ MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
 }
 MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) {
   const int ell = MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0;
-  if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 0); else solve_primal<0, 1>(M_, B_, e_, 0); }
+  if (M_.s.csr) { if (ell) solve_primal<1, 2>(M_, B_, e_, 0); else solve_primal<0, 2>(M_, B_, e_, 0); }
+  else if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 0); else solve_primal<0, 1>(M_, B_, e_, 0); }
   else { if (ell) solve_primal<1, 0>(M_, B_, e_, 0); else solve_primal<0, 0>(M_, B_, e_, 0); }
 }
 #endif  // !MJH_LANE_MODE

@@ -1049,7 +1049,12 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 #define MJH_SUBPROF(slot) do {} while (0)
 #endif
   // efc_b = J*qacc_smooth - aref ; jar = J*qacc_warmstart - aref
-  if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) {
+  if (MJH_HAS(MJH_FT_PRIMAL) && s.csr) {
+    MJH_FOR_LANES(r, nefc) {
+      eb[r] = csr_row_dot(P, r, qas) - aref[r];
+      jar[r] = csr_row_dot(P, r, qws) - aref[r];
+    }
+  } else if (MJH_HAS(MJH_FT_PRIMAL) && s.sparse) {
     MJH_FOR_LANES(r, nefc) {
       eb[r] = sp_row_dot(P, r, qas) - aref[r];
       jar[r] = sp_row_dot(P, r, qws) - aref[r];

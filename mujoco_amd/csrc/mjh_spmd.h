@@ -175,6 +175,7 @@ MJH_DEV long long wv_clock() { return 0; }
 MJH_DEV int wv_sub() { return 0; }
 // *p = min(*p, v), atomically with respect to the other lanes (the emulation runs them one at a time)
 MJH_DEV void wv_atomic_min_i(int* p, int v) { if (v < *p) *p = v; }
+MJH_DEV int wv_atomic_add_i(int* p, int v) { const int old = *p; *p = old + v; return old; }
 
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row
@@ -398,6 +399,7 @@ MJH_DEV long long wv_clock() { return (long long)wall_clock64(); }
 MJH_DEV int wv_sub() { return 0; }
 // *p = min(*p, v), atomically with respect to the other lanes (flat address: LDS or global)
 MJH_DEV void wv_atomic_min_i(int* p, int v) { atomicMin(p, v); }
+MJH_DEV int wv_atomic_add_i(int* p, int v) { return atomicAdd(p, v); }
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row.  v_permlane16_swap exchanges
 // the odd rows of its first operand with the even rows of its second; with both operands = v each

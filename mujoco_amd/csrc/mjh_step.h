@@ -159,6 +159,9 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   }
   if (stages & MJH_STAGE_MAKE) {
     MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
+#if !MJH_LANE_MODE
+    if (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) stage_csr_rows(M, B, e);      // (the island scan reads the compressed rows)
+#endif
     stage_island(M, B, e);
 #if !MJH_LANE_MODE
     if (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) stage_sparsify(M, B, e);

@@ -356,6 +356,9 @@ struct DSizes {
   // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
   // body : flex job, ngeom with flexes (else 0), per-env capacity of the flex contact identity table (nconmax or 0)
   int nflexpair, ncolseg, nflexleaf, nflexcand, ngeomflex, nconflex;
+  // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
+  // capacity of one row
+  int csr, csr_rowmax;
 };
 
 struct DOptions {
@@ -517,8 +520,8 @@ enum {
   X(subtree_angmom, 3 * s.nbody_sens, 0, MJH_T_GLB, MJH_T_GLB)                    \
   X(con_H, 36 * s.nconH, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   /* primal Newton solver: dense M, Hessian / Cholesky factor, nv-vectors */       \
-  X(nt_M, (1 - s.sparse) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
-  X(nt_H, (1 - s.sparse) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
+  X(nt_M, (1 - s.sparse - s.csr) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
+  X(nt_H, (1 - s.sparse - s.csr) * s.nv * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                  \
   X(nt_vec, 8 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   /* sparse constraint path: CSR Jacobian values, its transpose, packed factor L (row r at r(r+1)/2), Lcone */ \
   X(sp_J, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                       \
@@ -561,9 +564,12 @@ enum {
   /* sparse constraint path: row pattern of every constraint (128-bit dof set, 4 words), CSR row addresses, \
      transpose (row addresses per dof, constraint index per entry), pattern of every row of the factor */ \
   X(sp_rowmask, 4 * s.sparse * s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                \
-  X(sp_rowadr, s.sparse * (s.nefcmax + 1), 0, MJH_T_GLB, MJH_T_GLB)               \
-  X(sp_JTadr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                     \
+  X(sp_rowadr, (s.sparse + s.csr) * (s.nefcmax + 1), 0, MJH_T_GLB, MJH_T_GLB)               \
+  X(sp_JTadr, (s.sparse + s.csr) * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                     \
   X(sp_JTrow, s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                                   \
+  /* explicit column indices of the compressed rows, dofs of the island being solved (mjh_csr.h) */ \
+  X(sp_colind, s.csr * s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                          \
+  X(csr_idof, s.csr * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
   X(sp_Lmask, 4 * s.sparse * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                       \
   X(sp_Ladr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* structural pattern of every row of efc_AR (bit j of row i: the rows' Y patterns share a dof), 2 ints per word */ \

@@ -1,10 +1,9 @@
 """Flexes (mjh_flex.h, mjh_flexcol.h) on the host wavefront emulation against the oracle.
 
-Free motion -- vertex positions, edge lengths / Jacobians / velocities, finite-element stretch, shell bending and edge
-dampers -- is held to bit equality.  With contacts the constraint solve of these large models (nv of several hundred
-to 1536, one island spanning the flex) sums in a different order than the reference's island-compressed sparse
-routines, so steps are compared from identical inputs: contact lists exact, ncon / nefc exact, next state within
-1e-9; the CG iteration count may differ by one on a step whose last improvement sits at the tolerance."""
+Everything is held to bit equality: vertex positions, edge lengths / Jacobians / velocities, finite-element stretch,
+shell bending, edge dampers; contact lists; and the constraint solve -- these models (nv of several hundred to 1536,
+one island spanning the flex, CG) keep the Jacobian compressed with explicit column indices (mjh_csr.h) and sum in the
+reference's order, so states, contact / row counts and CG iteration counts of free-running trajectories are identical."""
 import os
 
 import numpy as np
@@ -78,41 +77,35 @@ def test_shell_bending_free_motion_bit_exact(rb, hostsim_lib, tmp_path):
 
 
 def _resync_steps(rb, lib, m, pre, nstep, mocap=None):
-    """the oracle's trajectory from reset; after `pre` steps every step is repeated by the kernels from the oracle's
-    (state, warm start) and compared"""
+    """the oracle's trajectory from reset: after `pre` steps the kernels take over its state once and both run `nstep`
+    steps freely; states, ncon / nefc and CG iteration counts identical at every step"""
     dm = K.DeviceModel(lib, m)
+    assert dm.size("csr") == 1
     b = K.Batch(dm, 1)
     d = rb.MjData(m)
     if mocap is not None: d.mocap_pos[:] = mocap
     for _ in range(pre): rb.mj_step(m, d)
-    same_iter = 0; worst = 0.0; maxcon = 0; kinds = set()
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    if m.nmocap: b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+    maxcon = 0; kinds = set(); iters = 0
     for t in range(nstep):
-        s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
-        b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
-        b.set("qacc_warmstart", d.qacc_warmstart[None, :])
-        if m.nmocap: b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
         b.step(); rb.mj_step(m, d)
         c = b.get("counts")[0]
-        assert (c[0], c[1]) == (d.ncon, d.nefc), (t, c[:2], d.ncon, d.nefc)
-        assert abs(int(c[5]) - int(d.solver_niter[0])) <= 1, (t, c[5], d.solver_niter[0])
+        assert (c[0], c[1], c[5]) == (d.ncon, d.nefc, d.solver_niter[0]), (t, c[:6], d.ncon, d.nefc, d.solver_niter[0])
         assert not b.get("warning")[0].any()
-        maxcon = max(maxcon, d.ncon)
+        assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel), t
+        maxcon = max(maxcon, d.ncon); iters += int(d.solver_niter[0])
         if d.ncon:
             con = d.contact[:d.ncon]
             kinds |= {"vert"} if (np.asarray(con["vert"])[:, 1] >= 0).any() else set()
             kinds |= {"elem"} if (np.asarray(con["elem"])[:, 1] >= 0).any() else set()
-        if c[5] == d.solver_niter[0]:
-            same_iter += 1
-            err = max(np.abs(b.get("qpos")[0] - d.qpos).max(), np.abs(b.get("qvel")[0] - d.qvel).max()/max(1.0, np.abs(d.qvel).max()))
-            worst = max(worst, err)
-    assert worst < 1e-9, worst
-    assert same_iter >= 0.9*nstep, (same_iter, nstep)
+    assert iters > 0
     return maxcon, kinds
 
 
-def test_flex_contact_lists_exact(rb, hostsim_lib, tmp_path):
-    """vertex-plane and element-geom (sphere, box, capsule: GJK / EPA against tetrahedra) contacts of one forward pass:
-    every contact record and every constraint row parameter identical to the oracle's"""
+def _contact_lists(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "mix.xml"
     xml.write_text(flex_xml("5 5 3", "0 0 .12", extra_world='''
     <geom name="wall" type="plane" size=".5 .5 .05" zaxis="1 0 0" pos="-.12 0 0"/>
@@ -146,6 +139,12 @@ def test_flex_contact_lists_exact(rb, hostsim_lib, tmp_path):
     assert len(seen) >= 3, seen
 
 
+def test_flex_contact_lists_exact(rb, hostsim_lib, tmp_path):
+    """vertex-plane and element-geom (sphere, box, capsule: GJK / EPA against tetrahedra) contacts of one forward pass:
+    every contact record and every constraint row parameter identical to the oracle's"""
+    _contact_lists(rb, hostsim_lib, tmp_path)
+
+
 def test_flex_on_floor_keeps_fifty_contacts(rb, hostsim_lib, tmp_path):
     """81 vertices of the bottom layer reach the floor: filterFlexContacts keeps mjMAXCONPAIR = 50 of them (deepest first,
     then farthest-point sampling with the reference's positional bookkeeping), sorted by vertex"""
@@ -163,8 +162,7 @@ def test_jelly_on_the_capsule(rb, hostsim_lib):
     assert maxcon >= 20 and "elem" in kinds
 
 
-def test_flex_against_an_actuated_body(rb, hostsim_lib, tmp_path):
-    """a solid flex draped over a hinged, motor-driven cylinder (the geom's own dofs enter the element rows with weight -1)"""
+def _actuated_body(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "drum.xml"
     xml.write_text(f"""
 <mujoco>
@@ -187,18 +185,20 @@ def test_flex_against_an_actuated_body(rb, hostsim_lib, tmp_path):
     d.ctrl[:] = 3.0
     for _ in range(160): rb.mj_step(m, d)
     assert d.ncon > 0
-    hit = 0
-    for t in range(25):
-        s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
-        b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
-        b.set("qacc_warmstart", d.qacc_warmstart[None, :]); b.set("ctrl", d.ctrl[None, :])
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :]); b.set("ctrl", d.ctrl[None, :])
+    for t in range(40):
         b.step(); rb.mj_step(m, d)
         c = b.get("counts")[0]
-        assert (c[0], c[1]) == (d.ncon, d.nefc) and abs(int(c[5]) - int(d.solver_niter[0])) <= 1
-        if c[5] == d.solver_niter[0]:
-            hit += 1
-            assert np.abs(b.get("qpos")[0] - d.qpos).max() < 1e-9 and np.abs(b.get("qvel")[0] - d.qvel).max() < 1e-8
-    assert hit >= 20
+        assert (c[0], c[1], c[5]) == (d.ncon, d.nefc, d.solver_niter[0]), t
+        assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel), t
+    assert d.ncon > 0
+
+
+def test_flex_against_an_actuated_body(rb, hostsim_lib, tmp_path):
+    """a solid flex draped over a hinged, motor-driven cylinder (the geom's own dofs enter the element rows with weight -1)"""
+    _actuated_body(rb, hostsim_lib, tmp_path)
 
 
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
