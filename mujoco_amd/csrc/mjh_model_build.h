@@ -1082,6 +1082,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     if (H->ld_prog.empty()) H->ld_prog.push_back(0);
     s.nldprog = (int)H->ld_prog.size();
+    H->ld_rows.clear();
+    for (int i = 0; i < nv; i++) if (m->M_rownnz[i] > 1) H->ld_rows.push_back(i);
+    s.nldrows = (int)H->ld_rows.size();
   }
   int rows_per_con = 1;
   for (int c : H->pair_dim)

@@ -840,7 +840,10 @@ MJH_DEVN void factor_ld(MREF M, P0 mat, P1 diaginv) {
     return;
   }
 #endif
-  for (int k = nv - 1; k >= 0; k--) {
+  // (rows without off-diagonals update nobody: only the rows that have some -- M.ld_rows, ascending -- are taken in
+  // sequence, the others all at once afterwards, when their descendants have finished with their diagonals)
+  for (int q = M.s.nldrows - 1; q >= 0; q--) {
+    const int k = M.ld_rows[q];
     int start = M.M_rowadr[k];
     int diag = M.M_rownnz[k] - 1;
     int end = start + diag;
@@ -871,6 +874,8 @@ MJH_DEVN void factor_ld(MREF M, P0 mat, P1 diaginv) {
     if (wv_lane() == 0) diaginv[k] = invD;
     wv_sync();
   }
+  MJH_FOR_LANES(k, nv) if (M.M_rownnz[k] == 1) diaginv[k] = 1 / mat[M.M_rowadr[k]];
+  wv_sync();
 }
 
 // does stage_finish also produce mj_Euler's damped acceleration, and stage_factor_m the factor it needs?
@@ -939,9 +944,9 @@ MJH_DEVN void solve_ld(MREF M, P0 x, P1 qLD, P2 diaginv) {
   }
 #endif
   // x <- L^-T x : row i scatters into its ancestors (independent targets)
-  for (int i = nv - 1; i >= 0; i--) {
+  for (int q = M.s.nldrows - 1; q >= 0; q--) {
+    const int i = M.ld_rows[q];
     int nnz = M.M_rownnz[i];
-    if (nnz == 1) continue;
     real xi = x[i];
     if (xi != 0) {
       int start = M.M_rowadr[i];
@@ -953,9 +958,9 @@ MJH_DEVN void solve_ld(MREF M, P0 x, P1 qLD, P2 diaginv) {
   MJH_FOR_LANES(i, nv) x[i] *= diaginv[i];
   wv_sync();
   // x <- L^-1 x : row i gathers from its ancestors (mju_dotSparse association)
-  for (int i = 0; i < nv; i++) {
+  for (int q = 0; q < M.s.nldrows; q++) {
+    const int i = M.ld_rows[q];
     int nnz = M.M_rownnz[i];
-    if (nnz == 1) continue;
     if (wv_lane() == 0) {
       int adr = M.M_rowadr[i];
       x[i] -= dot_sparse_ref(qLD + adr, x, nnz - 1, M.M_colind + adr);

@@ -127,6 +127,8 @@
   X(dof_ancmask, 2 * s.nv)                     \
   X(ld_prog_adr, s.nv + 1)                     \
   X(ld_prog, s.nldprog)                        \
+  /* dofs whose row of M has off-diagonal entries, ascending (the generic L'DL routines take only these in sequence) */ \
+  X(ld_rows, s.nldrows)                        \
   X(pgs_order, s.npgsorder)               \
   /* convex meshes (mjh_convex.h): hull graph, polygons (mjModel mesh_*, include/mujoco/mjmodel.h:1040-1075) */ \
   X(geom_dataid, s.ngeom)                      \
@@ -337,6 +339,7 @@ struct DSizes {
   int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
   int npgsorder;   // entries of the precomputed PGS visitation-order table
   int nldprog;     // entries of the flattened L'DL update list
+  int nldrows;     // dofs whose row of M has off-diagonal entries
   int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
   int pgs_iters;   // iterations covered by that table (min(opt.iterations, 128))
   int pgs_nmax;    // largest nefc covered by that table (64, or 128 when the constraint capacity allows more than 64 rows)
