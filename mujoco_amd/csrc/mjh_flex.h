@@ -139,6 +139,49 @@ MJH_DEV int flex_edge_corner(int dim, int ed, int i) {
   return (byte >> (4*i)) & 0xf;
 }
 
+// force block of one element: force[3*corner + x] -= elongation[ed1] * gradient[ed2][i][x] * metric[ed1][ed2] over ed1, ed2, the
+// two ends i of edge ed2, x -- in that loop order (:606-617).  DIM is a template argument so that the edge -> corner table
+// and every index into the force block are compile-time constants: the block stays in registers.
+template <int DIM, class KP, class VX, class LP, class EP, class FP>
+MJH_DEV void flex_stretch_element(MREF M, int t, KP k, real kD, real h, VX vx, LP len, EP evel, FP efrc) {
+  constexpr int NE = DIM == 2 ? 3 : 6;
+  constexpr int E0[6] = {DIM == 2 ? 1 : 0, DIM == 2 ? 2 : 1, DIM == 2 ? 0 : 2, 2, 0, 1};     // first corner of local edge q
+  constexpr int E1[6] = {DIM == 2 ? 2 : 1, DIM == 2 ? 0 : 2, DIM == 2 ? 1 : 0, 3, 3, 3};     // second corner
+  real p[DIM + 1][3];
+#pragma unroll
+  for (int i = 0; i <= DIM; i++) {
+    const int v = M.flexelem_vert[4*t + i];
+    p[i][0] = vx[3*v]; p[i][1] = vx[3*v + 1]; p[i][2] = vx[3*v + 2];
+  }
+  real elong[NE];
+#pragma unroll
+  for (int q = 0; q < NE; q++) {
+    const int idx = M.flexelem_edge[6*t + q];
+    const real def = len[idx], ref = M.flexedge_length0[idx];
+    const real prev = def - evel[idx] * h;
+    elong[q] = def*def - ref*ref + (def*def - prev*prev) * kD;
+  }
+  real force[3*(DIM + 1)];
+#pragma unroll
+  for (int i = 0; i < 3*(DIM + 1); i++) force[i] = 0;
+#pragma unroll
+  for (int ed1 = 0; ed1 < NE; ed1++) {
+#pragma unroll
+    for (int ed2 = 0; ed2 < NE; ed2++) {
+      // (metric: the packed upper triangle, row-major)
+      const int a = ed1 < ed2 ? ed1 : ed2, c = ed1 < ed2 ? ed2 : ed1;
+      const real metric = k[a*NE - a*(a - 1)/2 + (c - a)];
+      const int c0 = E0[ed2], c1 = E1[ed2];
+#pragma unroll
+      for (int x = 0; x < 3; x++) force[3*c0 + x] -= elong[ed1] * (p[c0][x] - p[c1][x]) * metric;
+#pragma unroll
+      for (int x = 0; x < 3; x++) force[3*c1 + x] -= elong[ed1] * (p[c1][x] - p[c0][x]) * metric;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3*(DIM + 1); i++) efrc[12*t + i] = force[i];
+}
+
 MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_damper) {
   const MJH_CONST_AS DSizes& s = M.s;
   crptr vx = MJH_F(B, flexvert_xpos, e);
@@ -201,35 +244,10 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     const int dim = M.flex_dim[f];
     const int sadr = M.flex_stiffnessadr[f];
     if (dim < 2 || M.flex_rigid[f] || sadr < 0 || M.flex_stiffness[sadr] == 0) continue;
-    const int nedge = dim == 2 ? 3 : 6;
     auto k = M.flex_stiffness + sadr + 21*(t - M.flex_elemadr[f]);
     const real kD = h > 0 ? M.flex_damping[f] / h : 0;
-    int vert[4];
-    for (int i = 0; i <= dim; i++) vert[i] = M.flexelem_vert[4*t + i];
-    real elong[6];
-    for (int q = 0; q < nedge; q++) {
-      const int idx = M.flexelem_edge[6*t + q];
-      const real def = len[idx], ref = M.flexedge_length0[idx];
-      const real prev = def - evel[idx] * h;
-      elong[q] = def*def - ref*ref + (def*def - prev*prev) * kD;
-    }
-    real force[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int ed1 = 0; ed1 < nedge; ed1++) {
-      for (int ed2 = 0; ed2 < nedge; ed2++) {
-        // (metric: the packed upper triangle, row-major)
-        const int a = ed1 < ed2 ? ed1 : ed2, c = ed1 < ed2 ? ed2 : ed1;
-        const real metric = k[a*nedge - a*(a - 1)/2 + (c - a)];
-        const int c0 = flex_edge_corner(dim, ed2, 0), c1 = flex_edge_corner(dim, ed2, 1);
-        for (int i = 0; i < 2; i++) {
-          const int ci = i ? c1 : c0, cj = i ? c0 : c1;
-          for (int x = 0; x < 3; x++) {
-            const real grad = vx[3*vert[ci] + x] - vx[3*vert[cj] + x];
-            force[3*ci + x] -= elong[ed1] * grad * metric;
-          }
-        }
-      }
-    }
-    for (int i = 0; i < 3*(dim + 1); i++) efrc[12*t + i] = force[i];
+    if (dim == 3) flex_stretch_element<3>(M, t, k, kD, h, vx, len, evel, efrc);
+    else flex_stretch_element<2>(M, t, k, kD, h, vx, len, evel, efrc);
   }
   wv_sync();
 

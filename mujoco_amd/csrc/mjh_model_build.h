@@ -170,6 +170,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->flex_edgeequality[f] != 0, "flex edge / vertex / strain equality constraints");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
+    // mj_flexCG (engine_forward.c:1640): CG with an implicit integrator and pyramidal cones runs deformable flexes under the
+    // implicit effective metric (mjd_effBuild / mjd_effMulAdd / mjd_effPrec) -- not built
+    MJH_REJECT(m->opt.solver == mjSOL_CG && (m->opt.integrator == mjINT_IMPLICIT || m->opt.integrator == mjINT_IMPLICITFAST) &&
+               m->opt.cone != mjCONE_ELLIPTIC && !m->flex_rigid[f] && m->flex_dim[f] >= 2,
+               "flexes under CG with an implicit integrator (the reference's implicit effective metric, mj_flexCG)");
     for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
       // a vertex is a body with three axis-aligned sliders (body_simple 2), or is pinned to a body without degrees of
       // freedom up to the world (elastic forces on vertices riding on articulated bodies go through mj_applyFT: not built)

@@ -173,32 +173,58 @@ struct NtPoint { real alpha, cost, d0, d1; };
 // (engine_util_blas.c:mju_dot).  A chain of n/4 dependent additions is the floor for a sum in the reference's order; the
 // independent products of a solver iteration share it.
 template <class IP>
-MJH_DEV void csr_dots(int n, IP idof, int nd, const crptr* xs, const crptr* ys, real* out) {
+MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const crptr* ys, real* out, real* stage, int stage_cap) {
+  // The products are formed lane-parallel (coalesced reads) into a staging block -- LDS when the plan leaves room, else
+  // global memory -- so that a chain lane's loop is a stream of independent loads feeding one dependent addition each
+  // (reading x[idof[k]] inside the chain put two dependent memory latencies into every link).  stage_cap: reals.
   const int lane = wv_lane();
   const int d = lane >> 2, a = lane & 3;
   const int n4 = n & ~3;
-  real r = 0;
-  if (d < nd) {
-    crptr x = xs[0], y = ys[0];
-    for (int q = 1; q < nd; q++) if (q == d) { x = xs[q]; y = ys[q]; }
-    for (int k = a; k < n4; k += 4) { const int i = idof[k]; r += x[i]*y[i]; }
-    const real r2 = wv_shfl(r, lane ^ 2);           // (lane a = 0 adds chain 2, lane 1 chain 3: r0 + r2, r1 + r3)
-    const real s02 = r + r2;
-    const real s13 = wv_shfl(s02, lane ^ 1);
-    real res = s02 + s13;                            // (in lane 4d: (r0 + r2) + (r1 + r3))
-    if (a == 0 && n > n4) {
-      // (mju_dot adds the sum of the remaining one to three products, engine_util_blas.c:517-525)
-      const int i0 = idof[n4];
-      real tail = x[i0]*y[i0];
-      for (int k = n4 + 1; k < n; k++) { const int i = idof[k]; tail += x[i]*y[i]; }
-      res += tail;
+  int done = 0;
+  const int per = stage_cap/(n > 0 ? n : 1) < 16 ? stage_cap/(n > 0 ? n : 1) : 16;
+  while (done < nd) {
+    const int nb = (nd - done) < per ? (nd - done) : per;
+    // (four rounds of loads are issued before the first product is stored: with one wavefront per SIMD nothing else
+    // hides the latency of these reads, and a store in between would keep the compiler from hoisting the next loads)
+    for (int k0 = lane; k0 < n; k0 += 4*MJH_W) {
+      int ii[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; ii[u] = k < n ? (ident ? k : (int)idof[k]) : 0; }
+      for (int q = 0; q < nb; q++) {
+        const crptr x = xs[done + q], y = ys[done + q];
+        real xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xv[u] = x[ii[u]]; yv[u] = y[ii[u]]; }
+        real* p = stage + (size_t)q*n;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; if (k < n) p[k] = xv[u]*yv[u]; }
+      }
     }
-    r = res;
-  } else {
-    // (collectives are entered by every lane)
-    const real r2 = wv_shfl(r, lane ^ 2); const real s13 = wv_shfl(r2, lane ^ 1); (void)s13;
+    wv_sync();
+    real r = 0;
+    if (d < nb) {
+      const real* p = stage + (size_t)d*n;
+#pragma unroll 8
+      for (int k = a; k < n4; k += 4) r += p[k];
+      const real r2 = wv_shfl(r, lane ^ 2);           // (lane a = 0 adds chain 2, lane 1 chain 3: r0 + r2, r1 + r3)
+      const real s02 = r + r2;
+      const real s13 = wv_shfl(s02, lane ^ 1);
+      real res = s02 + s13;                            // (in lane 4d: (r0 + r2) + (r1 + r3))
+      if (a == 0 && n > n4) {
+        // (mju_dot adds the sum of the remaining one to three products, engine_util_blas.c:517-525)
+        real tail = p[n4];
+        for (int k = n4 + 1; k < n; k++) tail += p[k];
+        res += tail;
+      }
+      r = res;
+    } else {
+      // (collectives are entered by every lane)
+      const real r2 = wv_shfl(r, lane ^ 2); const real s13 = wv_shfl(r2, lane ^ 1); (void)s13;
+    }
+    for (int q = 0; q < nb; q++) out[done + q] = wv_bcast(r, 4*q);
+    wv_sync();
+    done += nb;
   }
-  for (int q = 0; q < nd; q++) out[q] = wv_bcast(r, 4*q);
 }
 
 // SPA = 1: the reference's sparse path (mj_isSparse): compressed J / J', packed sparse factor -- mjh_sparse.h describes the
@@ -271,8 +297,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // accumulator chains of mju_dot over positions in that list, one chain per lane, several products at a time: csr_dots)
   iptr idof = MJH_G(B, csr_idof, e);
   int nidof = nv;
+  // staging block of csr_dots: the unused tail of the LDS regions when it holds at least one product vector, else global
+  real* dstage = nullptr; int dstage_cap = 0;
+  if (SPA == 2) {
+    if (P.free_bytes >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = P.free_bytes/(int)sizeof(real); }
+    else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }
+  }
   auto dotv = [&](crptr a, crptr b) -> real {
-    if (SPA == 2) { real out[1]; const crptr xs[1] = {a}, ys[1] = {b}; csr_dots(nidof, idof, 1, xs, ys, out); return out[0]; }
+    if (SPA == 2) { real out[1]; const crptr xs[1] = {a}, ys[1] = {b}; csr_dots(nidof, idof, nidof == nv, 1, xs, ys, out, dstage, dstage_cap); return out[0]; }
     if (SPA) {
       const real p0 = (lane < nv) ? (real)(a[lane]*b[lane]) : (real)0;
       const real p1 = (lane + MJH_W < nv) ? (real)(a[lane + MJH_W]*b[lane + MJH_W]) : (real)0;
@@ -289,6 +321,18 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // out = M v in mju_mulSymVecSparse's order: diagonal, own row right to left, then the column's
   // entries by ascending row
   auto mul_M = [&](rptr out, crptr v) {
+    if (SPA == 2 && s.nC == nv) {
+      // (diagonal mass matrix -- every dof a slider of its own body: row t is the single entry Ms[t])
+      for (int t0 = lane; t0 < nv; t0 += 4*MJH_W) {
+        real a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = Ms[tt]; b[u] = v[tt]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (t0 + u*MJH_W < nv) out[t0 + u*MJH_W] = a[u]*b[u];
+      }
+      wv_sync();
+      return;
+    }
     MJH_FOR_LANES(t, nv) {
       const int adr = M.M_rowadr[t], diag = M.M_rownnz[t] - 1;
       real acc = Ms[adr + diag]*v[t];
@@ -341,6 +385,35 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     wv_sync();
     if (SPA) {
       // sparse: mju_mulMatVecSparse(J', force) -- one mju_dotSparse per dof over the rows that contain it
+      // (SPA = 2: lanes over the island's dof list instead of testing every dof of the model)
+      if (SPA == 2) {
+        // (lanes over the island's dof list, four rounds of address loads in flight; most dofs of a flex hold no row at all)
+        for (int k0 = lane; k0 < nidof; k0 += 4*MJH_W) {
+          int jj[4], b0[4], b1[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : -1; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) { b0[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u]] : 0; b1[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u] + 1] : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (jj[u] < 0) continue;
+            const int a0 = b0[u], n = b1[u] - a0;
+            crptr v = P.spJT + a0;
+            ciptr ri = P.JTrow + a0;
+            real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            int k = 0;
+            for (; k <= n - 4; k += 4) {
+              r0 += v[k]*P.force[ri[k]]; r1 += v[k + 1]*P.force[ri[k + 1]];
+              r2 += v[k + 2]*P.force[ri[k + 2]]; r3 += v[k + 3]*P.force[ri[k + 3]];
+            }
+            real res = (r0 + r2) + (r1 + r3);
+            for (; k < n; k++) res += v[k]*P.force[ri[k]];
+            qfc[jj[u]] = res;
+          }
+        }
+        wv_sync();
+        return;
+      }
       MJH_FOR_LANES(j, nv) {
         if (!in_dof(j)) continue;
         const int a0 = P.JTadr[j], n = P.JTadr[j + 1] - a0;
@@ -368,11 +441,38 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // grad = Ma - qfrc_smooth - qfrc_constraint (PrimalUpdateGrad)
   auto update_grad = [&]() {
+    if (SPA == 2) {
+      // (dofs outside the island: zeroed once when the island starts, never written afterwards)
+      for (int k0 = lane; k0 < nidof; k0 += 4*MJH_W) {
+        int jj[4]; real a[4], b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = Ma[jj[u]]; b[u] = qfs[jj[u]]; c[u] = qfc[jj[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (k0 + u*MJH_W < nidof) grad[jj[u]] = a[u] - b[u] - c[u];
+      }
+      wv_sync();
+      return;
+    }
     MJH_FOR_LANES(j, nv) grad[j] = in_dof(j) ? (Ma[j] - qfs[j] - qfc[j]) : (real)0;
     wv_sync();
   };
   // Mgrad = M \ grad (CG preconditioner; Newton's convergence certificate)
   auto precondition = [&]() {
+    if (SPA == 2 && s.nC == nv) {
+      // (diagonal mass matrix: mj_solveLD reduces to x * qLDiagInv)
+      crptr dinv = MJH_F(B, qLDiagInv, e);
+      for (int t0 = lane; t0 < nv; t0 += 4*MJH_W) {
+        real a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = grad[tt]; b[u] = dinv[tt]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (t0 + u*MJH_W < nv) Mgrad[t0 + u*MJH_W] = a[u]*b[u];
+      }
+      wv_sync();
+      return;
+    }
     MJH_FOR_LANES(i, nv) Mgrad[i] = grad[i];
     wv_sync();
     solve_ld(M, Mgrad, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
@@ -693,6 +793,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   if (!(M.o.disableflags & (1<<9))) {
     mul_M(Ma, qws);
     real cost_ws = constraint_update(B, e, P, jar, 1, elliptic);
+    if (SPA == 2) {
+      // (the addends lane-parallel into the staging block, then the reference's single running sum over them)
+      MJH_FOR_LANES(i, nv) dstage[i] = 0.5*(Ma[i] - qfs[i])*(qws[i] - qas[i]);
+      wv_sync();
+      for (int i = 0; i < nv; i++) cost_ws += dstage[i];
+    } else
     for (int i = 0; i < nv; i++) cost_ws += 0.5*(Ma[i] - qfs[i])*(qws[i] - qas[i]);
     wv_sync();
     const real cost_smooth = constraint_update(B, e, P, P.b, 1, elliptic);
@@ -725,6 +831,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         if (in) idof[nidof + wv_rank_lt(m)] = j;
         nidof += __builtin_popcountll(m);
       }
+      MJH_FOR_LANES(j, nv) grad[j] = 0;
       wv_sync();
     } else if (SPA) {
       isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
@@ -738,6 +845,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     real scale;
     if (!(M.o.disableflags & (1<<18)) && nisl_raw > 0) {
       real tr = 0;
+      if (SPA == 2) {
+        MJH_FOR_LANES(k, nidof) { const int i = idof[k]; dstage[k] = Ms[M.M_rowadr[i] + M.M_rownnz[i] - 1]; }
+        wv_sync();
+        for (int k = 0; k < nidof; k++) tr += dstage[k];
+        wv_sync();
+      } else
       for (int i = 0; i < nv; i++) if (in_dof(i)) tr += Ms[M.M_rowadr[i] + M.M_rownnz[i] - 1];
       scale = 1/tr;
     } else {
@@ -747,7 +860,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // convergence certificate with M^-1
     precondition();
     real gm_gg[2];
-    if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, 2, xs, ys, gm_gg); }
+    if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, nidof == nv, 2, xs, ys, gm_gg, dstage, dstage_cap); }
     else { gm_gg[0] = dotv(grad, Mgrad); gm_gg[1] = dotv(grad, grad); }
     const int flg_gap = r_max(0, 0.5*scale*gm_gg[0]) < tol;
     const int flg_gradient = scale*sqrt(gm_gg[1]) < tol;
@@ -774,7 +887,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         mul_J(Jv, search, 0);
         // PrimalPrepare
         real q3[3];
-        if (SPA == 2) { const crptr xs[3] = {search, qfs, search}, ys[3] = {Ma, search, Mv}; csr_dots(nidof, idof, 3, xs, ys, q3); }
+        if (SPA == 2) { const crptr xs[3] = {search, qfs, search}, ys[3] = {Ma, search, Mv}; csr_dots(nidof, idof, nidof == nv, 3, xs, ys, q3, dstage, dstage_cap); }
         else { q3[0] = dotv(search, Ma); q3[1] = dotv(qfs, search); q3[2] = dotv(search, Mv); }
         const real qg1 = q3[0] - q3[1];
         const real qg2 = 0.5*q3[2];
@@ -914,9 +1027,25 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       if (alpha == 0) break;
 
       // ================= move, update
+      if (SPA == 2) {
+        for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
+          real q[4], sv[4], ma[4], mv[4], g[4], mg[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
+            q[u] = qacc[i]; sv[u] = search[i]; ma[u] = Ma[i]; mv[u] = Mv[i]; g[u] = grad[i]; mg[u] = Mgrad[i];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u*MJH_W;
+            if (i < nv) { qacc[i] = q[u] + sv[u]*alpha; Ma[i] = ma[u] + mv[u]*alpha; gradold[i] = g[u]; Mgradold[i] = mg[u]; }
+          }
+        }
+      } else {
       MJH_FOR_LANES(i, nv) { qacc[i] += search[i]*alpha; Ma[i] += Mv[i]*alpha; }
-      MJH_FOR_LANES(r, nefc) jar[r] += Jv[r]*alpha;
       if (!flg_newton) MJH_FOR_LANES(i, nv) { gradold[i] = grad[i]; Mgradold[i] = Mgrad[i]; }
+      }
+      MJH_FOR_LANES(r, nefc) jar[r] += Jv[r]*alpha;
       MJH_FOR_LANES(r, nefc) oldstate[r] = P.state[r];
       wv_sync();
       update_constraint();
@@ -935,6 +1064,15 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         MJH_FOR_LANES(i, nv) search[i] = -1*Mgrad[i];
       } else {
         // Hager-Zhang conjugate direction (engine_solver.c:2489-2521)
+        if (SPA == 2) {
+          for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
+            real g[4], go[4], mg[4], mgo[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; g[u] = grad[i]; go[u] = gradold[i]; mg[u] = Mgrad[i]; mgo[u] = Mgradold[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
+          }
+        } else
         MJH_FOR_LANES(i, nv) { tmpv[i] = grad[i] - gradold[i]; gradold[i] = Mgrad[i] - Mgradold[i]; }   // graddif, Mgraddif
         wv_sync();
         crptr graddif = tmpv, Mgraddif = gradold;
@@ -942,7 +1080,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         real hz[6];
         if (SPA == 2) {
           const crptr xs[6] = {search, graddif, graddif, search, search, grad}, ys[6] = {graddif, Mgraddif, Mgrad, grad, search, grad};
-          csr_dots(nidof, idof, 6, xs, ys, hz);
+          csr_dots(nidof, idof, nidof == nv, 6, xs, ys, hz, dstage, dstage_cap);
         } else hz[0] = dotv(search, graddif);
         const real d_dot_y = hz[0];
         if (d_dot_y < MJH_MINVAL) beta = 0;
@@ -957,6 +1095,15 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           beta = r_max(eta_k, beta_hz);
         }
         wv_sync();
+        if (SPA == 2) {
+          for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
+            real mg[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; mg[u] = Mgrad[i]; sv[u] = search[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W; if (i < nv) search[i] = -mg[u] + beta*sv[u]; }
+          }
+        } else
         MJH_FOR_LANES(i, nv) search[i] = -Mgrad[i] + beta*search[i];
       }
       wv_sync();

@@ -135,11 +135,15 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
   auto listed = [](const std::vector<std::string>& v, const char* n) {
     return std::find(v.begin(), v.end(), std::string(n)) != v.end();
   };
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && touches((t0), (t1)) && !listed(skip, #name)) \
+  // (models on the explicit-index constraint path -- mjh_csr.h, hundreds to thousands of dofs: their dof / body sized
+  // fields are streamed lane-parallel and gain nothing from LDS, while the solver's ordered sums need the block as
+  // staging space: fields above 2 KB stay in global memory)
+  const size_t big = s.csr ? 2048 : (size_t)1 << 30;
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (size_t)(lcnt)*sizeof(real) <= big && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && touches((t0), (t1)) && !listed(skip, #name)) \
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (size_t)(lcnt)*sizeof(int) <= big && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_INT_FIELDS(X)
 #undef X

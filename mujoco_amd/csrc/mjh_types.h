@@ -498,6 +498,8 @@ enum {
   X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* mjData flexelem_aabb; candidate contacts of one body : flex job (dist, pos[3], normal[3], min_dist) */ \
   X(flexelem_aabb, 6 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* product vectors of the solver's ordered sums when the LDS block has no room for them (mjh_newton.h: csr_dots) */ \
+  X(csr_prod, 6 * s.csr * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                          \
   X(flexcand, 8 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                           \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \

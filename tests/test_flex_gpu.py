@@ -43,3 +43,7 @@ def test_jelly_on_the_capsule_on_gpu(rb, hip_lib):
 
 def test_flex_against_an_actuated_body_on_gpu(rb, hip_lib, tmp_path):
     fh._actuated_body(rb, hip_lib, tmp_path)
+
+
+def test_flex_island_next_to_rigid_islands_on_gpu(rb, hip_lib, tmp_path):
+    fh._multi_island(rb, hip_lib, tmp_path)

@@ -201,6 +201,40 @@ def test_flex_against_an_actuated_body(rb, hostsim_lib, tmp_path):
     _actuated_body(rb, hostsim_lib, tmp_path)
 
 
+MULTI_ISLAND_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"/>
+  <size memory="10M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body pos=".6 0 .05"><freejoint/><geom type="box" size=".05 .04 .03"/></body>
+    <body pos=".6 .4 .04"><freejoint/><geom type="sphere" size=".04"/></body>
+    <body pos="-.6 0 .2"><joint type="hinge" axis="0 1 0"/><geom type="capsule" size=".03 .1"/></body>
+    <flexcomp type="grid" count="6 6 3" spacing=".05 .05 .05" pos="0 0 .08" dim="3" radius=".005" mass="2" name="soft">
+      <edge damping="1"/><contact selfcollide="none"/><elasticity young="5e4"/>
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _multi_island(rb, lib, tmp_path):
+    xml = tmp_path / "multi.xml"
+    xml.write_text(MULTI_ISLAND_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    d = rb.MjData(m)
+    rb.mj_forward(m, d)
+    _resync_steps(rb, lib, m, pre=20, nstep=60)
+    d = rb.MjData(m)
+    for _ in range(60): rb.mj_step(m, d)
+    assert d.nisland >= 2
+
+
+def test_flex_island_next_to_rigid_islands(rb, hostsim_lib, tmp_path):
+    """a flex resting on the floor (one island of all its trees), a box and a sphere on the floor (an island each) and an
+    unconstrained pendulum: island-local dot products over each island's dof list"""
+    _multi_island(rb, hostsim_lib, tmp_path)
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
