@@ -286,17 +286,20 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
   }
   wv_sync();
 
-  // ---- edge spring-dampers: every dof sums its edges in edge order (:757-787)
+  // ---- edge spring-dampers: every dof sums its edges in edge order (:757-787).  (flexedge_k / flexedge_d: the edge's flex
+  //      coefficients, zero for rigid edges -- an edge whose two coefficients are off adds nothing and is skipped as in
+  //      the reference; the entry's edge id sits next to its index, so the loads of an entry do not wait on one another)
   MJH_FOR_LANES(i, s.nv) {
+    const int a0 = M.flexJ_cscadr[i], a1 = M.flexJ_cscadr[i + 1];
+    if (a0 == a1) continue;
     real as = fs[i], ad = fd[i];
     int any = 0;
-    for (int a = M.flexJ_cscadr[i]; a < M.flexJ_cscadr[i + 1]; a++) {
+    for (int a = a0; a < a1; a++) {
       const int j = M.flexJ_cscind[a];
-      const int ed = M.flexedge_J_rowid[j];
-      const int f = M.flexedge_flex[ed];
-      const real stiffness = enbl_spring ? M.flex_edgestiffness[f] : 0;
-      const real damping = enbl_damper ? M.flex_edgedamping[f] : 0;
-      if (M.flex_rigid[f] || (stiffness == 0 && damping == 0) || M.flexedge_rigid[ed]) continue;
+      const int ed = M.flexJ_cscedge[a];
+      const real stiffness = enbl_spring ? (real)M.flexedge_k[ed] : (real)0;
+      const real damping = enbl_damper ? (real)M.flexedge_d[ed] : (real)0;
+      if (stiffness == 0 && damping == 0) continue;
       const real frc_spring = stiffness * (M.flexedge_length0[ed] - len[ed]);
       const real frc_damper = -damping * evel[ed];
       as += J[j] * frc_spring;

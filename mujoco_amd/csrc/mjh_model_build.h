@@ -1382,6 +1382,16 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       }
       if (nf) H->flexJ_cscadr[m->nv] = (int)H->flexJ_cscind.size();
       H->flexJ_cscind.resize(m->nJfe, 0);
+      H->flexJ_cscedge.assign(m->nJfe, 0);
+      for (int a = 0; a < m->nJfe; a++) H->flexJ_cscedge[a] = H->flexedge_J_rowid[H->flexJ_cscind[a]];
+      H->flexedge_k.assign(m->nflexedge, 0);
+      H->flexedge_d.assign(m->nflexedge, 0);
+      for (int ed = 0; ed < m->nflexedge; ed++) {
+        const int f = H->flexedge_flex[ed];
+        if (m->flex_rigid[f] || m->flexedge_rigid[ed]) continue;
+        H->flexedge_k[ed] = m->flex_edgestiffness[f];
+        H->flexedge_d[ed] = m->flex_edgedamping[f];
+      }
     }
   }
 

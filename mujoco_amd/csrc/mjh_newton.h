@@ -915,6 +915,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           quad[3*r] = q0*0.5; quad[3*r + 1] = q1; quad[3*r + 2] = q2*0.5;
         }
         wv_sync();
+        tick(38);          // (profile builds: direction products and quadratic coefficients, apart from the evaluations)
 
         int lsiter = 0;
         // PrimalEval: the six running sums of the reference's loop over rows -- cost, deriv[0..1],
@@ -966,7 +967,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
             }
             // (rows that contribute an exact zero to a sum cannot change it: only the others are chained --
             // friction rows feed cost / derivatives, active contacts the quadratic totals, seldom both)
-            for (int q = 0; q < 6; q++) acc[q] = wv_chain_mask(acc[q], c[q], wv_ballot(c[q] != 0));
+            // (the three quadratic totals come from the same rows -- the active contacts: one walk, three overlapping chains)
+            for (int q = 0; q < 3; q++) acc[q] = wv_chain_mask(acc[q], c[q], wv_ballot(c[q] != 0));
+            wv_chain3_mask(acc + 3, c + 3, wv_ballot(c[3] != 0 || c[4] != 0 || c[5] != 0));
           }
           real cost = acc[0], d0 = acc[1], d1 = acc[2];
           cost += al*al*acc[5] + al*acc[4] + acc[3];
@@ -975,6 +978,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           if (d1 <= 0) d1 = MJH_MINVAL;
           p.cost = cost; p.d0 = d0; p.d1 = d1;
           lsiter++;
+#ifdef MJH_PROFILE
+          if (lane == 0) MJH_G(B, prof, e)[40] += 1;    // line-search evaluations
+#endif
         };
         const int lsmax = M.o.ls_iterations;
         NtPoint p0, p1, p2, pmid, p1next, p2next;
@@ -1024,6 +1030,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         }
       }
       tick(36);
+#ifdef MJH_PROFILE
+      if (lane == 0) MJH_G(B, prof, e)[39] += 1;      // line searches
+#endif
       if (alpha == 0) break;
 
       // ================= move, update

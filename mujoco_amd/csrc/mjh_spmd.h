@@ -215,6 +215,10 @@ MJH_DEV double wv_chain_mask(double init, double v, uint64_t mask) {
 MJH_DEV void wv_chain6(double* acc, const double* v, int n) {
   for (int q = 0; q < 6; q++) acc[q] = wv_chain(acc[q], v[q], 0, n, 0);
 }
+// three chains over one mask (addends that are exact zeros may be included: they cannot change a sum)
+MJH_DEV void wv_chain3_mask(double* acc, const double* v, uint64_t mask) {
+  for (int q = 0; q < 3; q++) acc[q] = wv_chain_mask(acc[q], v[q], mask);
+}
 // mju_dot's accumulators: r[c] += v[4g + c] for g = 0 .. ngroup-1, in order of g
 MJH_DEV void wv_dot4_acc(double* r, double v, int ngroup) {
   mjhsim::WaveSim* w = mjhsim::g_wave;
@@ -434,6 +438,18 @@ MJH_DEV double wv_chain_mask(double init, double v, uint64_t mask) {
     r += wv_bcast(v, l);
   }
   return r;
+}
+// three chains over one mask: one walk over the set bits, the three dependent additions of a step overlap
+MJH_DEV void wv_chain3_mask(double* acc, const double* v, uint64_t mask) {
+  mask = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mask >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mask);
+  double a0 = acc[0], a1 = acc[1], a2 = acc[2];
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    a0 += wv_bcast(v[0], l); a1 += wv_bcast(v[1], l); a2 += wv_bcast(v[2], l);
+  }
+  acc[0] = a0; acc[1] = a1; acc[2] = a2;
 }
 // six chains at once (independent accumulators: the chains overlap in the pipeline)
 MJH_DEV void wv_chain6(double* acc, const double* v, int n) {

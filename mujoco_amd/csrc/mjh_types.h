@@ -172,6 +172,7 @@
   X(flexedge_J_rowid, s.nJfe)                  \
   X(flexJ_cscadr, s.nflexdof + 1)              \
   X(flexJ_cscind, s.nJfe)                      \
+  X(flexJ_cscedge, s.nJfe)                     \
   X(flexelem_flex, s.nflexelem)                \
   X(flexelem_vert, 4 * s.nflexelem)            \
   X(flexelem_edge, 6 * s.nflexelem)            \
@@ -282,7 +283,10 @@
   X(flex_damping, s.nflex)                     \
   X(flex_edgestiffness, s.nflex)               \
   X(flex_edgedamping, s.nflex)                 \
-  X(flex_radius, s.nflex)
+  X(flex_radius, s.nflex)                      \
+  /* edge spring / damper coefficients of every edge's flex (0 for rigid edges and rigid flexes) */ \
+  X(flexedge_k, s.nflexedge)                   \
+  X(flexedge_d, s.nflexedge)
 
 // ---- compile-time feature set of a kernel variant -------------------------------------------------
 // The stage sources are compiled several times (mjh_modes.h); each compilation defines MJH_FEATURES,
