@@ -532,8 +532,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv, cfg["xml"]),
                          **(measured_sq(args.config) or {}),
-                         "kernel": "mjh_k_rollout_" + {"generic": "wv", "lean": "wl"}.get(
-                             batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic", "wv"),
+                         "kernel": batch.kernel_name(),
                          "steps_per_launch": C,
                          "launch_ms": launch_ms_timed, "kernel_ms_total": kernel_ms,
                          "wall_ms_total": elapsed * 1e3,

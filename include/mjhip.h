@@ -101,6 +101,9 @@ MJHIP_API int mjhip_batch_set(mjhipBatch* batch, const char* name, const void* h
  * a feature the variant lacks. */
 MJHIP_API int mjhip_batch_set_variant(mjhipBatch* batch, const char* name);
 MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* batch);
+/* Name of the HIP kernel a rollout of this batch launches (the generic mapping exists for two register budgets; profiles
+ * and bench.py's roofline name the kernel they measured). */
+MJHIP_API const char* mjhip_batch_kernel(const mjhipBatch* batch);
 /* Opt-in: build AR = Y Y' + diag(R) (mj_makeAR, src/engine/engine_core_constraint.c:3009 -- the one
  * dense contraction of the step) with v_mfma_f64_16x16x4_f64 instead of the reference-ordered
  * vector sums.  Results then agree with the reference to rounding (tolerance parity: states within

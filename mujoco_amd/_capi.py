@@ -96,6 +96,8 @@ class Lib:
         lib.mjhip_batch_set_mfma.argtypes = [vp, ci]
         lib.mjhip_batch_variant.restype = C.c_char_p
         lib.mjhip_batch_variant.argtypes = [vp]
+        lib.mjhip_batch_kernel.restype = C.c_char_p
+        lib.mjhip_batch_kernel.argtypes = [vp]
         lib.mjhip_batch_plan_lds.restype = ci
         lib.mjhip_batch_plan_lds.argtypes = [vp, ci]
         lib.mjhip_batch_lds_report.restype = C.c_char_p
@@ -127,7 +129,7 @@ class Lib:
         "mjhip_model_destroy", "mjhip_model_size", "mjhip_load_mjb", "mjhip_free_mjb", "mjhip_set_option",
         "mjhip_batch_create", "mjhip_batch_create_layout", "mjhip_batch_destroy", "mjhip_batch_nenv", "mjhip_batch_reset",
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
-        "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant",
+        "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant", "mjhip_batch_kernel",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
         "mjhip_batch_trouble", "mjhip_rollout_clear_cache", "mjhip_batch_step1", "mjhip_batch_step2", "mjhip_batch_set_mfma",
     )
@@ -281,6 +283,10 @@ class Batch:
     def kernel_variant(self) -> str:
         """name of the kernel mapping that steps this batch: generic | lean"""
         return self._lib.c.mjhip_batch_variant(self._h).decode()
+
+    def kernel_name(self) -> str:
+        """name of the HIP kernel a rollout of this batch launches"""
+        return self._lib.c.mjhip_batch_kernel(self._h).decode()
 
     def set_mfma(self, on: bool) -> None:
         """AR = Y Y' on the matrix cores (tolerance parity instead of bit parity)"""

@@ -56,8 +56,8 @@ struct Efc {
   X(fprev, MJH_G(B, scratch, e) + nmax, nefc, 1)                     \
   X(fmom, MJH_G(B, scratch, e) + 2*nmax, nefc, 1)                    \
   X(cone, MJH_G(B, efc_cone, e), nefc, 1)                            \
-  X(spJ, MJH_G(B, sp_J, e), (1 - csr_)*nJ_, 1)                       \
-  X(spJT, MJH_G(B, sp_JT, e), (1 - csr_)*primal_*nJ_, 1)
+  X(spJ, MJH_G(B, sp_J, e), (1 - csr_ + csrl_)*nJ_, 1)                    \
+  X(spJT, MJH_G(B, sp_JT, e), (1 - csr_ + csrl_)*primal_*nJ_, 1)
 #define MJH_EFC_INT_ARRAYS(X)                                        \
   X(order, MJH_G(B, iscratch, e), nefc, 1)                           \
   X(state, MJH_G(B, efc_state, e), nefc, 1)                          \
@@ -69,8 +69,8 @@ struct Efc {
   X(rowmask, MJH_G(B, sp_rowmask, e), 4*spm_*nefc, 1)
 // int arrays packed after the real ones (sized by nJ, see efc_layout)
 #define MJH_EFC_LATE_INT_ARRAYS(X)                                   \
-  X(JTrow, MJH_G(B, sp_JTrow, e), (1 - csr_)*primal_*nJ_, 1)         \
-  X(colind, MJH_G(B, sp_colind, e), 0*csr_, 1)
+  X(JTrow, MJH_G(B, sp_JTrow, e), (1 - csr_ + csrl_)*primal_*nJ_, 1)      \
+  X(colind, MJH_G(B, sp_colind, e), csrl_*nJ_, 1)
 
 // (stage_project) does this array already live in the LDS plan?  (pointer inside the workgroup's block)
 template <class T> MJH_DEV int mjh_staged_home_impl(const SP<T>& v, const char* lds, int bytes) {
@@ -92,6 +92,9 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   const int spm_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
   const int csr_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) ? 1 : 0;
   const int sp_ = spm_ | csr_;
+  // (explicit-index rows take LDS only in launches whose workgroups own most of a CU's block: with less, the solver's
+  // ordered sums need the room as staging space)
+  const int csrl_ = (csr_ && B.lds_bytes >= 128*1024) ? 1 : 0;
   const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
   int off1 = B.dyn_off, off2 = B.dyn2_off;
@@ -201,9 +204,10 @@ MJH_DEVN void efc_writeback(MREF M_, BREF B_, int e_) {
   const int spm_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) ? 1 : 0;
   const int csr_ = (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) ? 1 : 0;
   const int sp_ = spm_ | csr_;
+  const int csrl_ = (csr_ && B.lds_bytes >= 128*1024) ? 1 : 0;
   const int primal_ = (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) ? 1 : 0;
   const int nJ_ = sp_ ? MJH_F(B, counts, e)[MJH_C_NJ] : 0;
-  (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_; (void)primal_;
+  (void)csrl_; (void)nv; (void)nmax; (void)dual_; (void)sp_; (void)nJ_; (void)primal_;
   if (!nefc) return;
   Efc P;
   const unsigned long long mask = efc_layout(M, B, e, nefc, P);

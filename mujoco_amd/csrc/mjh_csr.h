@@ -86,6 +86,11 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   }
   if (wv_lane() == 0) { rowadr[0] = 0; counts[MJH_C_NJ] = total; }
   wv_sync();
+  // (nJ is known now: with the CU's whole LDS block to itself -- launches of one workgroup per CU -- the layout gives
+  // the compressed rows and their transpose LDS slots, and they are written there directly)
+  efc_layout(M, B, e, nefc, P);
+  colind = P.colind;
+  val = P.spJ;
 
   // ---- pass 2: columns and values
   MJH_FOR_LANES(r, nefc) {
@@ -171,8 +176,8 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse); counting pass with integer atomics,
   //      then each dof sorts its (short) list by row
   iptr JTadr = P.JTadr;
-  iptr JTrow = MJH_G(B, sp_JTrow, e);
-  rptr JTval = MJH_G(B, sp_JT, e);
+  iptr JTrow = P.JTrow;
+  rptr JTval = P.spJT;
   iptr cursor = MJH_G(B, csr_idof, e);
   MJH_FOR_LANES(j, nv + 1) JTadr[j] = 0;
   MJH_FOR_LANES(j, nv) cursor[j] = 0;

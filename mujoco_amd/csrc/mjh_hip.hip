@@ -20,6 +20,7 @@
 
 MJH_DEFINE_WAVE_KERNELS(wv, 1, 4, 0)
 MJH_DECLARE_WAVE_LAUNCHERS(wl)
+MJH_DECLARE_WAVE_LAUNCHERS(wv2)     // mjh_kern_wide.hip: the generic kernels with a 256-VGPR budget
 extern "C" bool mjh_launch_forward_soa(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
 extern "C" bool mjh_launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
 extern "C" bool mjh_launch_integrate(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
@@ -100,9 +101,21 @@ struct Backend {
     return hipMemsetAsync(dst, 0, n, (hipStream_t)stream) == hipSuccess;
   }
   static bool sync(void* stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess; }
-  // largest dynamic LDS block a workgroup may request (gfx950: 160 KB per CU; one workgroup is
-  // allowed 64 KB without opting in, which is already far beyond the useful range here)
-  static int max_lds() { return 64 * 1024; }
+  // largest dynamic LDS block a workgroup may request: what the device reports per block, at most the CU's 160 KB,
+  // at least the 64 KB every kernel gets without opting in (the launchers raise the per-kernel limit above that:
+  // mjh_raise_lds); $MJHIP_MAX_LDS overrides (A/B runs)
+  static int max_lds() {
+    static const int v = [] {
+      if (const char* ev = getenv("MJHIP_MAX_LDS")) return atoi(ev);
+      int dev = 0, b = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) b = 0;
+      if (b > 160*1024) b = 160*1024;
+      if (b < 64*1024) b = 64*1024;
+      return b;
+    }();
+    return v;
+  }
   // compute units of the current device (256 on MI355X)
   static int num_cus() {
     int dev = 0, cus = 0;
@@ -110,20 +123,32 @@ struct Backend {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     return cus;
   }
+  // generic kernels: a launch that cannot put more than two wavefronts on a SIMD takes the 256-VGPR build
+  // ($MJHIP_WIDE_REGS=0/1 forces the choice: A/B runs)
+  static bool wide_regs(int nenv) {
+    static const int force = [] { const char* ev = getenv("MJHIP_WIDE_REGS"); return ev ? atoi(ev) : -1; }();
+    if (force >= 0) return force != 0;
+    return nenv <= 2*4*num_cus();
+  }
   // `variant` (MJH_VAR_*, mjh_modes.h): which mapping of the stage sources steps the batch; lds = LDS
   // bytes per ENVIRONMENT (a workgroup of a sub-wave variant allocates one block per lane group)
   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void* stream) {
     if (soa) return mjh_launch_forward_soa(M, B, nenv, stages, lds, stream);
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_forward_wl(M, B, nenv, stages, lds, stream);
-      default: return mjh_launch_forward_wv(M, B, nenv, stages, lds, stream);
+      default: return wide_regs(nenv) ? mjh_launch_forward_wv2(M, B, nenv, stages, lds, stream)
+                                      : mjh_launch_forward_wv(M, B, nenv, stages, lds, stream);
     }
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void* stream) {
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_rollout_wl(M, B, nenv, &A, lds, stream);
-      default: return mjh_launch_rollout_wv(M, B, nenv, &A, lds, stream);
+      default: return wide_regs(nenv) ? mjh_launch_rollout_wv2(M, B, nenv, &A, lds, stream)
+                                      : mjh_launch_rollout_wv(M, B, nenv, &A, lds, stream);
     }
+  }
+  static const char* rollout_kernel_name(int variant, int nenv) {
+    return variant == MJH_VAR_LEAN ? "mjh_k_rollout_wl" : wide_regs(nenv) ? "mjh_k_rollout_wv2" : "mjh_k_rollout_wv";
   }
   static bool launch_balance(const DBatch* B, int nenv, void* stream) {
     (void)nenv;

@@ -33,6 +33,7 @@ MJH_LANE_KERNEL void mjh_k_lane_reset(const DModel* __restrict__ M, const DBatch
 
 static dim3 lane_grid(int nenv, int epw) { return dim3((nenv + epw - 1) / epw); }
 extern "C" bool mjh_launch_forward_soa(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream) {
+  if (!mjh_raise_lds((const void*)mjh_k_forward_soa, (size_t)lds)) return false;
   hipLaunchKernelGGL(mjh_k_forward_soa, dim3(nenv), dim3(MJH_WAVE), (size_t)lds, (hipStream_t)stream, M, B, stages);
   return hipGetLastError() == hipSuccess;
 }

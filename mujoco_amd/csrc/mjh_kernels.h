@@ -16,15 +16,25 @@
 // WPE = waves per SIMD the register budget is sized for: 4 (128 VGPRs) keeps 4096 one-environment
 // wavefronts co-resident; the two-environment mapping needs only half as many wavefronts and gets
 // 256 VGPRs.  SUBEXPR = index of the calling lane's group inside its wavefront.
-#define MJH_DEFINE_WAVE_KERNELS(NS, NSUB, WPE, SUBEXPR)                                                        \
+// A workgroup may take up to the CU's whole 160 KB of LDS (one-wavefront workgroups of a launch with at most one
+// workgroup per CU: flexes at BASELINE config 5's 256 environments keep the CG solver's dof vectors there); beyond the
+// 64 KB every kernel may ask for, the limit has to be raised per kernel (and per device: called before every such launch).
+static inline bool mjh_raise_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 64*1024) return true;
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+#define MJH_DEFINE_WAVE_KERNELS(NS, NSUB, WPE, SUBEXPR) MJH_DEFINE_WAVE_KERNELS_AS(NS, NS, NSUB, WPE, SUBEXPR)
+// (NM: suffix of the kernel / launcher names -- the generic namespace is compiled twice, for two register budgets)
+#define MJH_DEFINE_WAVE_KERNELS_AS(NS, NM, NSUB, WPE, SUBEXPR)                                                        \
   __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
-  void mjh_k_forward_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages) {            \
+  void mjh_k_forward_##NM(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages) {            \
     const int e = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
     if (e >= B->nenv) return;                                                                                  \
     NS::forward_or_euler(wv_const_ref(M), wv_const_ref(B), e, stages);                                         \
   }                                                                                                            \
   __global__ __launch_bounds__(MJH_WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                        \
-  void mjh_k_rollout_##NS(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {         \
+  void mjh_k_rollout_##NM(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {         \
     const int w = (int)blockIdx.x*(NSUB) + (SUBEXPR);                                                          \
     if (w >= (A.nlaunch ? A.nlaunch : B->nenv)) return;                                                        \
     /* perm lists the environments by decreasing cost: workgroups are dispatched in blockIdx order  */        \
@@ -32,15 +42,17 @@
     /* and the environments that share a wavefront (NSUB > 1) have similar solver work              */        \
     NS::rollout_env(wv_const_ref(M), wv_const_ref(B), A.nlaunch ? w : B->perm[w], A);                          \
   }                                                                                                            \
-  extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
+  extern "C" bool mjh_launch_forward_##NM(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
                                           void* stream) {                                                      \
-    hipLaunchKernelGGL(mjh_k_forward_##NS, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
+    if (!mjh_raise_lds((const void*)mjh_k_forward_##NM, (size_t)lds*(NSUB))) return false;                     \
+    hipLaunchKernelGGL(mjh_k_forward_##NM, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
                        (size_t)lds*(NSUB), (hipStream_t)stream, M, B, stages);                                 \
     return hipGetLastError() == hipSuccess;                                                                    \
   }                                                                                                            \
-  extern "C" bool mjh_launch_rollout_##NS(const DModel* M, const DBatch* B, int nenv, const RolloutArgs* A,    \
+  extern "C" bool mjh_launch_rollout_##NM(const DModel* M, const DBatch* B, int nenv, const RolloutArgs* A,    \
                                           int lds, void* stream) {                                             \
-    hipLaunchKernelGGL(mjh_k_rollout_##NS, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
+    if (!mjh_raise_lds((const void*)mjh_k_rollout_##NM, (size_t)lds*(NSUB))) return false;                     \
+    hipLaunchKernelGGL(mjh_k_rollout_##NM, dim3((nenv + (NSUB) - 1)/(NSUB)), dim3(MJH_WAVE),                   \
                        (size_t)lds*(NSUB), (hipStream_t)stream, M, B, *A);                                     \
     return hipGetLastError() == hipSuccess;                                                                    \
   }

@@ -172,32 +172,76 @@ struct NtPoint { real alpha, cost, d0, d1; };
 // accumulator a (elements a, a + 4, ... of the list, in order), then (r0 + r2) + (r1 + r3) plus the sum of the tail
 // (engine_util_blas.c:mju_dot).  A chain of n/4 dependent additions is the floor for a sum in the reference's order; the
 // independent products of a solver iteration share it.
+// elements per lane whose loads are issued together in the nv-long passes of the explicit-index path: with one or two
+// wavefronts on a SIMD nothing else hides a global-memory round trip, so the 256-VGPR build (mjh_kern_wide.hip) takes
+// eight at a time
+#ifdef MJH_WIDE_REGS
+#define MJH_NVU 8
+#else
+#define MJH_NVU 4
+#endif
+// 1 if the contiguous slice lies in the workgroup's LDS block (also on the host emulation, where mjh_in_lds is 0)
+MJH_DEV int csr_lds_resident(const crptr& v) {
+  const long long off = mjh_lds_offset((const void*)v.p);
+  return v.s == 1 && off >= 0 && off < 160*1024;
+}
 template <class IP>
 MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const crptr* ys, real* out, real* stage, int stage_cap) {
-  // The products are formed lane-parallel (coalesced reads) into a staging block -- LDS when the plan leaves room, else
-  // global memory -- so that a chain lane's loop is a stream of independent loads feeding one dependent addition each
-  // (reading x[idof[k]] inside the chain put two dependent memory latencies into every link).  stage_cap: reals.
+  // A product whose two vectors are LDS-resident (launches with one workgroup per CU give the solver the CU's whole
+  // 160 KB) over the identity list is summed DIRECT: the chain lane reads x[k], y[k] itself -- two LDS reads that do not
+  // depend on the running sum.  The other products are formed lane-parallel (coalesced reads) into a staging block --
+  // LDS when the plan leaves room, else global memory -- so that a chain lane's loop is a stream of independent loads
+  // feeding one dependent addition each (reading x[idof[k]] from global memory inside the chain put two dependent
+  // memory latencies into every link).  stage_cap: reals.
   const int lane = wv_lane();
   const int d = lane >> 2, a = lane & 3;
   const int n4 = n & ~3;
-  int done = 0;
+  unsigned direct = 0;
+  if (ident) for (int q = 0; q < nd; q++) if (csr_lds_resident(xs[q]) && csr_lds_resident(ys[q])) direct |= 1u << q;
   const int per = stage_cap/(n > 0 ? n : 1) < 16 ? stage_cap/(n > 0 ? n : 1) : 16;
+  // ---- direct products: one pass for all of them
+  if (direct) {
+    const real* px = nullptr; const real* py = nullptr;
+    for (int q = 0; q < nd; q++) if (d == q && ((direct >> q) & 1)) { px = xs[q].p; py = ys[q].p; }
+    real r = 0;
+    if (px) {
+      // (local-address-space reads: LDS returns in order, so the additions start with the first pair that arrives
+      // instead of waiting for the whole unrolled batch as flat loads must)
+      const auto lx = mjh_local(px), ly = mjh_local(py);
+#pragma unroll 8
+      for (int k = a; k < n4; k += 4) r += lx[k]*ly[k];
+    }
+    const real r2 = wv_shfl(r, lane ^ 2);
+    const real s02 = r + r2;
+    const real s13 = wv_shfl(s02, lane ^ 1);
+    real res = s02 + s13;
+    if (px && a == 0 && n > n4) {
+      real tail = px[n4]*py[n4];
+      for (int k = n4 + 1; k < n; k++) tail += px[k]*py[k];
+      res += tail;
+    }
+    for (int q = 0; q < nd; q++) if ((direct >> q) & 1) out[q] = wv_bcast(res, 4*q);
+  }
+  // ---- staged products, `per` at a time
+  int done = 0;
   while (done < nd) {
-    const int nb = (nd - done) < per ? (nd - done) : per;
+    int qs[16]; int nb = 0;
+    while (done < nd && nb < per) { if (!((direct >> done) & 1)) qs[nb++] = done; done++; }
+    if (!nb) break;
     // (four rounds of loads are issued before the first product is stored: with one wavefront per SIMD nothing else
     // hides the latency of these reads, and a store in between would keep the compiler from hoisting the next loads)
-    for (int k0 = lane; k0 < n; k0 += 4*MJH_W) {
-      int ii[4];
+    for (int k0 = lane; k0 < n; k0 += MJH_NVU*MJH_W) {
+      int ii[MJH_NVU];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; ii[u] = k < n ? (ident ? k : (int)idof[k]) : 0; }
+      for (int u = 0; u < MJH_NVU; u++) { const int k = k0 + u*MJH_W; ii[u] = k < n ? (ident ? k : (int)idof[k]) : 0; }
       for (int q = 0; q < nb; q++) {
-        const crptr x = xs[done + q], y = ys[done + q];
-        real xv[4], yv[4];
+        const crptr x = xs[qs[q]], y = ys[qs[q]];
+        real xv[MJH_NVU], yv[MJH_NVU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { xv[u] = x[ii[u]]; yv[u] = y[ii[u]]; }
+        for (int u = 0; u < MJH_NVU; u++) { xv[u] = x[ii[u]]; yv[u] = y[ii[u]]; }
         real* p = stage + (size_t)q*n;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; if (k < n) p[k] = xv[u]*yv[u]; }
+        for (int u = 0; u < MJH_NVU; u++) { const int k = k0 + u*MJH_W; if (k < n) p[k] = xv[u]*yv[u]; }
       }
     }
     wv_sync();
@@ -221,9 +265,8 @@ MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const 
       // (collectives are entered by every lane)
       const real r2 = wv_shfl(r, lane ^ 2); const real s13 = wv_shfl(r2, lane ^ 1); (void)s13;
     }
-    for (int q = 0; q < nb; q++) out[done + q] = wv_bcast(r, 4*q);
+    for (int q = 0; q < nb; q++) out[qs[q]] = wv_bcast(r, 4*q);
     wv_sync();
-    done += nb;
   }
 }
 
@@ -300,7 +343,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // staging block of csr_dots: the unused tail of the LDS regions when it holds at least one product vector, else global
   real* dstage = nullptr; int dstage_cap = 0;
   if (SPA == 2) {
-    if (P.free_bytes >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = P.free_bytes/(int)sizeof(real); }
+    int fb = P.free_bytes;
+    // (the line search's quadratic coefficients are read row by row in every evaluation: they take the top of the free
+    // tail when it has room for them next to one product vector)
+    const int qb = 3*nefc*(int)sizeof(real);
+    if (fb >= qb + nv*(int)sizeof(real)) { fb -= qb; quad = SP<real>{(real*)(P.free_p + fb), 1}; }
+    if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
     else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }
   }
   auto dotv = [&](crptr a, crptr b) -> real {
@@ -323,12 +371,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto mul_M = [&](rptr out, crptr v) {
     if (SPA == 2 && s.nC == nv) {
       // (diagonal mass matrix -- every dof a slider of its own body: row t is the single entry Ms[t])
-      for (int t0 = lane; t0 < nv; t0 += 4*MJH_W) {
-        real a[4], b[4];
+      for (int t0 = lane; t0 < nv; t0 += MJH_NVU*MJH_W) {
+        real a[MJH_NVU], b[MJH_NVU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = Ms[tt]; b[u] = v[tt]; }
+        for (int u = 0; u < MJH_NVU; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = Ms[tt]; b[u] = v[tt]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (t0 + u*MJH_W < nv) out[t0 + u*MJH_W] = a[u]*b[u];
+        for (int u = 0; u < MJH_NVU; u++) if (t0 + u*MJH_W < nv) out[t0 + u*MJH_W] = a[u]*b[u];
       }
       wv_sync();
       return;
@@ -388,14 +436,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       // (SPA = 2: lanes over the island's dof list instead of testing every dof of the model)
       if (SPA == 2) {
         // (lanes over the island's dof list, four rounds of address loads in flight; most dofs of a flex hold no row at all)
-        for (int k0 = lane; k0 < nidof; k0 += 4*MJH_W) {
-          int jj[4], b0[4], b1[4];
+        for (int k0 = lane; k0 < nidof; k0 += MJH_NVU*MJH_W) {
+          int jj[MJH_NVU], b0[MJH_NVU], b1[MJH_NVU];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : -1; }
+          for (int u = 0; u < MJH_NVU; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : -1; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) { b0[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u]] : 0; b1[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u] + 1] : 0; }
+          for (int u = 0; u < MJH_NVU; u++) { b0[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u]] : 0; b1[u] = jj[u] >= 0 ? (int)P.JTadr[jj[u] + 1] : 0; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < MJH_NVU; u++) {
             if (jj[u] < 0) continue;
             const int a0 = b0[u], n = b1[u] - a0;
             crptr v = P.spJT + a0;
@@ -443,14 +491,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto update_grad = [&]() {
     if (SPA == 2) {
       // (dofs outside the island: zeroed once when the island starts, never written afterwards)
-      for (int k0 = lane; k0 < nidof; k0 += 4*MJH_W) {
-        int jj[4]; real a[4], b[4], c[4];
+      for (int k0 = lane; k0 < nidof; k0 += MJH_NVU*MJH_W) {
+        int jj[MJH_NVU]; real a[MJH_NVU], b[MJH_NVU], c[MJH_NVU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : 0; }
+        for (int u = 0; u < MJH_NVU; u++) { const int k = k0 + u*MJH_W; jj[u] = k < nidof ? (nidof == nv ? k : (int)idof[k]) : 0; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = Ma[jj[u]]; b[u] = qfs[jj[u]]; c[u] = qfc[jj[u]]; }
+        for (int u = 0; u < MJH_NVU; u++) { a[u] = Ma[jj[u]]; b[u] = qfs[jj[u]]; c[u] = qfc[jj[u]]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (k0 + u*MJH_W < nidof) grad[jj[u]] = a[u] - b[u] - c[u];
+        for (int u = 0; u < MJH_NVU; u++) if (k0 + u*MJH_W < nidof) grad[jj[u]] = a[u] - b[u] - c[u];
       }
       wv_sync();
       return;
@@ -463,12 +511,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     if (SPA == 2 && s.nC == nv) {
       // (diagonal mass matrix: mj_solveLD reduces to x * qLDiagInv)
       crptr dinv = MJH_F(B, qLDiagInv, e);
-      for (int t0 = lane; t0 < nv; t0 += 4*MJH_W) {
-        real a[4], b[4];
+      for (int t0 = lane; t0 < nv; t0 += MJH_NVU*MJH_W) {
+        real a[MJH_NVU], b[MJH_NVU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = grad[tt]; b[u] = dinv[tt]; }
+        for (int u = 0; u < MJH_NVU; u++) { const int tt = t0 + u*MJH_W < nv ? t0 + u*MJH_W : 0; a[u] = grad[tt]; b[u] = dinv[tt]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (t0 + u*MJH_W < nv) Mgrad[t0 + u*MJH_W] = a[u]*b[u];
+        for (int u = 0; u < MJH_NVU; u++) if (t0 + u*MJH_W < nv) Mgrad[t0 + u*MJH_W] = a[u]*b[u];
       }
       wv_sync();
       return;
@@ -883,14 +931,18 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const real snorm = sqrt(dotv(search, search));
       if (!(snorm < MJH_MINVAL)) {
         const real gtol = tol*M.o.ls_tolerance*snorm/scale;
+        tick(42);
         mul_M(Mv, search);
+        tick(43);
         mul_J(Jv, search, 0);
+        tick(44);
         // PrimalPrepare
         real q3[3];
         if (SPA == 2) { const crptr xs[3] = {search, qfs, search}, ys[3] = {Ma, search, Mv}; csr_dots(nidof, idof, nidof == nv, 3, xs, ys, q3, dstage, dstage_cap); }
         else { q3[0] = dotv(search, Ma); q3[1] = dotv(qfs, search); q3[2] = dotv(search, Mv); }
         const real qg1 = q3[0] - q3[1];
         const real qg2 = 0.5*q3[2];
+        tick(45);
         MJH_FOR_LANES(r, nefc) {
           if (!in_row(r)) continue;
           if (is_cone_row(r) && !cone_leader(P, r)) continue;
@@ -1037,15 +1089,15 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
       // ================= move, update
       if (SPA == 2) {
-        for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
-          real q[4], sv[4], ma[4], mv[4], g[4], mg[4];
+        for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+          real q[MJH_NVU], sv[MJH_NVU], ma[MJH_NVU], mv[MJH_NVU], g[MJH_NVU], mg[MJH_NVU];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < MJH_NVU; u++) {
             const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
             q[u] = qacc[i]; sv[u] = search[i]; ma[u] = Ma[i]; mv[u] = Mv[i]; g[u] = grad[i]; mg[u] = Mgrad[i];
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < MJH_NVU; u++) {
             const int i = i0 + u*MJH_W;
             if (i < nv) { qacc[i] = q[u] + sv[u]*alpha; Ma[i] = ma[u] + mv[u]*alpha; gradold[i] = g[u]; Mgradold[i] = mg[u]; }
           }
@@ -1066,6 +1118,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       tick(34);
       const real improvement = scale*ls_improvement;
       const real gradient = scale*sqrt(dotv(grad, grad));
+      tick(41);          // (profile builds, slots 41..45: gradient norm | direction update | |search|, M search | J search | PrimalPrepare sums)
       const real decrement = flg_newton ? r_max(0, 0.5*scale*dotv(grad, Mgrad)) : 0;
       iter++;
       if ((improvement > 0 && improvement < tol) || gradient < tol || (flg_newton && decrement < tol)) break;
@@ -1074,12 +1127,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       } else {
         // Hager-Zhang conjugate direction (engine_solver.c:2489-2521)
         if (SPA == 2) {
-          for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
-            real g[4], go[4], mg[4], mgo[4];
+          for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+            real g[MJH_NVU], go[MJH_NVU], mg[MJH_NVU], mgo[MJH_NVU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; g[u] = grad[i]; go[u] = gradold[i]; mg[u] = Mgrad[i]; mgo[u] = Mgradold[i]; }
+            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; g[u] = grad[i]; go[u] = gradold[i]; mg[u] = Mgrad[i]; mgo[u] = Mgradold[i]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
+            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
           }
         } else
         MJH_FOR_LANES(i, nv) { tmpv[i] = grad[i] - gradold[i]; gradold[i] = Mgrad[i] - Mgradold[i]; }   // graddif, Mgraddif
@@ -1105,12 +1158,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         }
         wv_sync();
         if (SPA == 2) {
-          for (int i0 = lane; i0 < nv; i0 += 4*MJH_W) {
-            real mg[4], sv[4];
+          for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+            real mg[MJH_NVU], sv[MJH_NVU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; mg[u] = Mgrad[i]; sv[u] = search[i]; }
+            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; mg[u] = Mgrad[i]; sv[u] = search[i]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = i0 + u*MJH_W; if (i < nv) search[i] = -mg[u] + beta*sv[u]; }
+            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) search[i] = -mg[u] + beta*sv[u]; }
           }
         } else
         MJH_FOR_LANES(i, nv) search[i] = -Mgrad[i] + beta*search[i];

@@ -21,6 +21,7 @@
 //   (variant = MJH_VAR_* of mjh_modes.h: the kernel mapping that steps the batch; lds is per environment)
 //   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void* stream);
 //   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs&, int lds, int variant, void* stream);
+//   static const char* rollout_kernel_name(int variant, int nenv);   // name of the kernel launch_rollout launches
 //   static bool launch_reset(const DModel* M, const DBatch* B, int nenv, void* stream);
 //   lane-mode kernels of the SoA pipeline (epw = environments per wavefront):
 //   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs&, void* stream);
@@ -510,6 +511,7 @@ MJHIP_API int mjhip_batch_set_mfma(mjhipBatch* Bt, int on) {
   return 0;
 }
 MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* Bt) { return Bt ? mjh_variant_name(Bt->variant) : ""; }
+MJHIP_API const char* mjhip_batch_kernel(const mjhipBatch* Bt) { return Bt ? Backend::rollout_kernel_name(Bt->variant, Bt->nenv) : ""; }
 
 MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   if (!Bt) return -1;

@@ -106,7 +106,7 @@ struct Backend {
   static bool d2h(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
   static bool zero(void* dst, size_t n, void*) { memset(dst, 0, n); return true; }
   static bool sync(void*) { return true; }
-  static int max_lds() { return 64 * 1024; }
+  static int max_lds() { return 160 * 1024; }   // (gfx950: a workgroup may take the whole CU block)
   static int num_cus() { return 256; }
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
@@ -135,6 +135,7 @@ struct Backend {
     return true;
   }
   // the launch order of the next rollout launch: environments by decreasing work estimate
+  static const char* rollout_kernel_name(int variant, int) { return variant == MJH_VAR_LEAN ? "hostsim:wl" : "hostsim:wv"; }
   static bool launch_balance(const DBatch* B, int nenv, void*) {
     std::vector<int> idx(nenv);
     for (int i = 0; i < nenv; i++) idx[i] = i;

@@ -52,6 +52,9 @@ print("  inside constraint: b/jar/warmstart %.2f  PGS %.2f  J'f %.2f us" % tuple
 if p.shape[1] >= 40 and p[:, 32:38].sum() > 0:
     print("  inside constraint (primal solvers): set-up %.1f  Hessian+factor %.1f  factor solves %.1f  incremental updates %.1f  line search %.1f  constraint update+grad %.1f us"
           % tuple(p[:, k].mean()/nst for k in (32, 33, 34, 35, 36, 37)))
+if p.shape[1] >= 46 and p[:, 41:46].sum() > 0:
+    print("  per step: gradient norm %.1f  direction update + |search| %.1f  M search %.1f  J search %.1f  PrimalPrepare sums %.1f  quadratic coefficients %.1f us"
+          % tuple(p[:, k].mean()/nst for k in (41, 42, 43, 44, 45, 38)))
 if p.shape[1] >= 41 and p[:, 39].sum() > 0:
     print("  line search, not in the figure above: products + quadratic coefficients %.1f us; %.1f searches and %.1f evaluations per step"
           % (p[:, 38].mean()/nst, p[:, 39].mean()/nst, p[:, 40].mean()/nst))
