@@ -180,6 +180,69 @@ struct NtPoint { real alpha, cost, d0, d1; };
 #else
 #define MJH_NVU 4
 #endif
+// One accumulator chain of mju_dot: r += x[a + 4 i]*y[a + 4 i] (or r += p[a + 4 i]), i = 0 .. L-1, in order.  The additions
+// depend on each other; the reads do not: they are issued a batch ahead (six pairs: with the next batch in flight the
+// wait for the oldest stays inside the 4-bit lgkmcnt), so a link costs the latency of an addition, not of a memory access.
+template <class PX, class PY>
+MJH_DEV real csr_chain2(PX x, PY y, int a, int L) {
+  // (two register sets used alternately, each refilled in place as soon as it has been consumed: no copies, and the
+  // refill past the end re-reads the last batch instead of branching, so every wait is a partial one)
+  real r = 0;
+  int i = 0;
+  if (L >= 6) {
+    const int last = L - 6;
+    real xa[6], ya[6], xb[6], yb[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) { xa[u] = x[a + 4*u]; ya[u] = y[a + 4*u]; }
+    for (; i + 12 <= L; i += 12) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) { xb[u] = x[a + 4*(i + 6 + u)]; yb[u] = y[a + 4*(i + 6 + u)]; }
+#pragma unroll
+      for (int u = 0; u < 6; u++) r += xa[u]*ya[u];
+      const int nx = i + 12 < last ? i + 12 : last;
+#pragma unroll
+      for (int u = 0; u < 6; u++) { xa[u] = x[a + 4*(nx + u)]; ya[u] = y[a + 4*(nx + u)]; }
+#pragma unroll
+      for (int u = 0; u < 6; u++) r += xb[u]*yb[u];
+    }
+    if (i + 6 <= L) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) r += xa[u]*ya[u];
+      i += 6;
+    }
+  }
+  for (; i < L; i++) r += x[a + 4*i]*y[a + 4*i];
+  return r;
+}
+template <class PP>
+MJH_DEV real csr_chain1(PP p, int a, int L) {
+  real r = 0;
+  int i = 0;
+  if (L >= 8) {
+    const int last = L - 8;
+    real xa[8], xb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) xa[u] = p[a + 4*u];
+    for (; i + 16 <= L; i += 16) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) xb[u] = p[a + 4*(i + 8 + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xa[u];
+      const int nx = i + 16 < last ? i + 16 : last;
+#pragma unroll
+      for (int u = 0; u < 8; u++) xa[u] = p[a + 4*(nx + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xb[u];
+    }
+    if (i + 8 <= L) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xa[u];
+      i += 8;
+    }
+  }
+  for (; i < L; i++) r += p[a + 4*i];
+  return r;
+}
 // 1 if the contiguous slice lies in the workgroup's LDS block (also on the host emulation, where mjh_in_lds is 0)
 MJH_DEV int csr_lds_resident(const crptr& v) {
   const long long off = mjh_lds_offset((const void*)v.p);
@@ -207,9 +270,7 @@ MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const 
     if (px) {
       // (local-address-space reads: LDS returns in order, so the additions start with the first pair that arrives
       // instead of waiting for the whole unrolled batch as flat loads must)
-      const auto lx = mjh_local(px), ly = mjh_local(py);
-#pragma unroll 8
-      for (int k = a; k < n4; k += 4) r += lx[k]*ly[k];
+      r = csr_chain2(mjh_local(px), mjh_local(py), a, n4 >> 2);
     }
     const real r2 = wv_shfl(r, lane ^ 2);
     const real s02 = r + r2;
@@ -248,8 +309,8 @@ MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const 
     real r = 0;
     if (d < nb) {
       const real* p = stage + (size_t)d*n;
-#pragma unroll 8
-      for (int k = a; k < n4; k += 4) r += p[k];
+      const long long soff = mjh_lds_offset((const void*)stage);
+      r = (soff >= 0 && soff < 160*1024) ? csr_chain1(mjh_local(p), a, n4 >> 2) : csr_chain1(p, a, n4 >> 2);
       const real r2 = wv_shfl(r, lane ^ 2);           // (lane a = 0 adds chain 2, lane 1 chain 3: r0 + r2, r1 + r3)
       const real s02 = r + r2;
       const real s13 = wv_shfl(s02, lane ^ 1);
@@ -348,6 +409,22 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // tail when it has room for them next to one product vector)
     const int qb = 3*nefc*(int)sizeof(real);
     if (fb >= qb + nv*(int)sizeof(real)) { fb -= qb; quad = SP<real>{(real*)(P.free_p + fb), 1}; }
+    // (qfrc_smooth is read twice per iteration -- PrimalPrepare's sums, the gradient: with room for it next to one
+    // product vector the solver works on an LDS copy, and every ordered sum of the iteration is a direct one)
+    // (the staging block below may then fall back to global memory: with qfrc_smooth in LDS no sum of the iteration is staged)
+    if (fb >= nv*(int)sizeof(real)) {
+      fb -= nv*(int)sizeof(real);
+      real* c = (real*)(P.free_p + fb);
+      for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+        real t[MJH_NVU];
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) t[u] = qfs[i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0];
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) if (i0 + u*MJH_W < nv) c[i0 + u*MJH_W] = t[u];
+      }
+      qfs = SP<const real>{c, 1};
+      wv_sync();
+    }
     if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
     else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }
   }
@@ -928,21 +1005,28 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     while (!done && iter < maxiter) {
       // ================= PrimalSearch
       real alpha = 0, ls_improvement = 0;
-      const real snorm = sqrt(dotv(search, search));
+      real snorm, q3[3];
+      if (SPA == 2) {
+        // (a chain of nv/4 dependent additions costs the same for one product as for sixteen: |search|^2 shares the pass
+        // of PrimalPrepare's three sums, so M search is formed first -- it is not read again if the norm ends the solve)
+        mul_M(Mv, search);
+        tick(43);
+        real q4[4];
+        const crptr xs[4] = {search, search, qfs, search}, ys[4] = {search, Ma, search, Mv};
+        csr_dots(nidof, idof, nidof == nv, 4, xs, ys, q4, dstage, dstage_cap);
+        snorm = sqrt(q4[0]); q3[0] = q4[1]; q3[1] = q4[2]; q3[2] = q4[3];
+        tick(45);
+      } else snorm = sqrt(dotv(search, search));
       if (!(snorm < MJH_MINVAL)) {
         const real gtol = tol*M.o.ls_tolerance*snorm/scale;
         tick(42);
-        mul_M(Mv, search);
-        tick(43);
+        if (SPA != 2) mul_M(Mv, search);
         mul_J(Jv, search, 0);
         tick(44);
         // PrimalPrepare
-        real q3[3];
-        if (SPA == 2) { const crptr xs[3] = {search, qfs, search}, ys[3] = {Ma, search, Mv}; csr_dots(nidof, idof, nidof == nv, 3, xs, ys, q3, dstage, dstage_cap); }
-        else { q3[0] = dotv(search, Ma); q3[1] = dotv(qfs, search); q3[2] = dotv(search, Mv); }
+        if (SPA != 2) { q3[0] = dotv(search, Ma); q3[1] = dotv(qfs, search); q3[2] = dotv(search, Mv); }
         const real qg1 = q3[0] - q3[1];
         const real qg2 = 0.5*q3[2];
-        tick(45);
         MJH_FOR_LANES(r, nefc) {
           if (!in_row(r)) continue;
           if (is_cone_row(r) && !cone_leader(P, r)) continue;
@@ -1117,7 +1201,22 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       if (flg_newton) newton_mgrad(); else precondition();
       tick(34);
       const real improvement = scale*ls_improvement;
-      const real gradient = scale*sqrt(dotv(grad, grad));
+      // (CG on the explicit-index path: the six sums of the Hager-Zhang update -- |grad|^2 among them -- are taken in one
+      // pass before the termination test instead of |grad|^2 now and the others afterwards)
+      real hz[6];
+      if (SPA == 2 && !flg_newton) {
+        for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+          real g[MJH_NVU], go[MJH_NVU], mg[MJH_NVU], mgo[MJH_NVU];
+#pragma unroll
+          for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; g[u] = grad[i]; go[u] = gradold[i]; mg[u] = Mgrad[i]; mgo[u] = Mgradold[i]; }
+#pragma unroll
+          for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
+        }
+        wv_sync();
+        const crptr xs[6] = {search, tmpv, tmpv, search, search, grad}, ys[6] = {tmpv, gradold, Mgrad, grad, search, grad};
+        csr_dots(nidof, idof, nidof == nv, 6, xs, ys, hz, dstage, dstage_cap);
+      }
+      const real gradient = scale*sqrt((SPA == 2 && !flg_newton) ? hz[5] : dotv(grad, grad));
       tick(41);          // (profile builds, slots 41..45: gradient norm | direction update | |search|, M search | J search | PrimalPrepare sums)
       const real decrement = flg_newton ? r_max(0, 0.5*scale*dotv(grad, Mgrad)) : 0;
       iter++;
@@ -1126,24 +1225,13 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         MJH_FOR_LANES(i, nv) search[i] = -1*Mgrad[i];
       } else {
         // Hager-Zhang conjugate direction (engine_solver.c:2489-2521)
-        if (SPA == 2) {
-          for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
-            real g[MJH_NVU], go[MJH_NVU], mg[MJH_NVU], mgo[MJH_NVU];
-#pragma unroll
-            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; g[u] = grad[i]; go[u] = gradold[i]; mg[u] = Mgrad[i]; mgo[u] = Mgradold[i]; }
-#pragma unroll
-            for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
-          }
-        } else
-        MJH_FOR_LANES(i, nv) { tmpv[i] = grad[i] - gradold[i]; gradold[i] = Mgrad[i] - Mgradold[i]; }   // graddif, Mgraddif
-        wv_sync();
+        if (SPA != 2) {
+          MJH_FOR_LANES(i, nv) { tmpv[i] = grad[i] - gradold[i]; gradold[i] = Mgrad[i] - Mgradold[i]; }   // graddif, Mgraddif
+          wv_sync();
+        }
         crptr graddif = tmpv, Mgraddif = gradold;
         real beta;
-        real hz[6];
-        if (SPA == 2) {
-          const crptr xs[6] = {search, graddif, graddif, search, search, grad}, ys[6] = {graddif, Mgraddif, Mgrad, grad, search, grad};
-          csr_dots(nidof, idof, nidof == nv, 6, xs, ys, hz, dstage, dstage_cap);
-        } else hz[0] = dotv(search, graddif);
+        if (SPA != 2) hz[0] = dotv(search, graddif);
         const real d_dot_y = hz[0];
         if (d_dot_y < MJH_MINVAL) beta = 0;
         else {

@@ -139,12 +139,20 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
   // (models on the explicit-index constraint path -- mjh_csr.h, hundreds to thousands of dofs: their dof / body sized
   // fields are streamed lane-parallel and gain nothing from LDS, while the solver's ordered sums need the block as
   // staging space: fields above 2 KB stay in global memory)
+  // (with most of a CU's block to itself -- launches of one workgroup per CU -- a big field whose lifetime ends before
+  // constraint assembly, or starts after the solve, may overlay the solver's region: the per-body arrays of the smooth
+  // stages are then read at LDS instead of global-memory latency, which a lone wavefront cannot hide)
   const size_t big = s.csr ? 2048 : (size_t)1 << 30;
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (size_t)(lcnt)*sizeof(real) <= big && touches((t0), (t1)) && !listed(skip, #name)) \
+  const bool big_overlay = s.csr && budget >= 128*1024 && !getenv("MJHIP_NO_BIG_OVERLAY");
+  auto fits = [&](size_t bytes, int t0, int t1) {
+    if (bytes <= big) return true;
+    return big_overlay && (t1 < MJH_T_MAKE || t0 > MJH_T_CONSTRAINT) && t0 != MJH_T_BEGIN;
+  };
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && fits((size_t)(lcnt)*sizeof(real), (t0), (t1)) && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(real) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_REAL_FIELDS(X)
 #undef X
-#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && (size_t)(lcnt)*sizeof(int) <= big && touches((t0), (t1)) && !listed(skip, #name)) \
+#define X(name, cnt, lcnt, t0, t1) if ((t0) != MJH_T_GLB && (int)(lcnt) > 0 && fits((size_t)(lcnt)*sizeof(int), (t0), (t1)) && touches((t0), (t1)) && !listed(skip, #name)) \
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_INT_FIELDS(X)
 #undef X
