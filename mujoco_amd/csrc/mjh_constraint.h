@@ -368,6 +368,14 @@ MJH_DEV void stage_equality_rows(MREF M, BREF B, int e, const Efc& P) {
     if (r0 < 0) continue;
     const int et = M.eq_type[q];
     auto data = M.eq_data + 11*q;
+    if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEX) {
+      // edge constraints (mj_instantiateEquality, engine_core_constraint.c:982-1010): one row per non-rigid edge,
+      // position error = length - rest length; the row itself is the edge's flexedge_J row (cut by stage_csr_rows)
+      crptr len = MJH_F(B, flexedge_length, e);
+      const int k0 = M.eq_rowadr[q], nk = M.eq_rowadr[q + 1] - k0;
+      MJH_FOR_LANES(k, nk) { const int ed = M.eqrow_edge[k0 + k]; P.pos[r0 + k] = len[ed] - M.flexedge_length0[ed]; }
+      continue;
+    }
     if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
       real pos0[3], pos1[3], cpos[6] = {0, 0, 0, 0, 0, 0};
       int b0, b1;
@@ -750,7 +758,9 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       // mj_diagApprox :1733-1780, getsolparam :1988, getposdim :2070-2078
       const int et = M.eq_type[id];
       const int r0 = MJH_G(B, eq_efcadr, e)[id];
-      if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
+      if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEX) {
+        dA = M.flexedge_invweight0[M.eqrow_edge[M.eq_rowadr[id] + (r - r0)]];      // (mj_diagApprox :1779-1790)
+      } else if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
         int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
         if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }
         const int rot = (et == MJH_EQ_WELD && r - r0 > 2) ? 1 : 0;

@@ -7,7 +7,8 @@
 // their column indices -- and their transpose; the CG solver (mjh_newton.h, SPA = 2) and the row products of
 // mj_referenceConstraint / mj_fwdConstraint read them instead of streaming nv-wide dense rows.
 //
-// Scope (mjh_model_build.h: s.csr): CG, no equality or tendon rows (their dense rows would have to be cut by a scan),
+// Scope (mjh_model_build.h: s.csr): CG, no tendon rows and no equality rows other than flex edge constraints (dense
+// rows would have to be cut by a scan; an edge constraint's row is the model's flexedge_J row),
 // contacts up to condim 3, islands enabled.  (included once per SPMD mode by mjh_stages.inc: no include guard)
 
 #if !MJH_LANE_MODE
@@ -45,7 +46,12 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   MJH_FOR_LANES(r, nefc) {
     const int type = P.type[r], id = P.id[r];
     int nnz = 0;
-    if (type == MJH_CNSTR_FRICTION_DOF) nnz = 1;
+    if (type == MJH_CNSTR_EQUALITY) {
+      // (flex edge constraints, the only equality kind on this path: the edge's flexedge_J row)
+      const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+      nnz = M.flexedge_J_rownnz[ed];
+    }
+    else if (type == MJH_CNSTR_FRICTION_DOF) nnz = 1;
     else if (type == MJH_CNSTR_LIMIT_JOINT) nnz = M.jnt_type[id] == MJH_JNT_BALL ? 3 : 1;
     else if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) nnz = -1;          // set by its contact below
     if (nnz >= 0) rowadr[r + 1] = nnz;
@@ -96,7 +102,13 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   MJH_FOR_LANES(r, nefc) {
     const int type = P.type[r], id = P.id[r];
     const int a0 = rowadr[r];
-    if (type == MJH_CNSTR_FRICTION_DOF) { colind[a0] = id; val[a0] = Jd[(size_t)r*nv + id]; }
+    if (type == MJH_CNSTR_EQUALITY) {
+      const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+      const int f0 = M.flexedge_J_rowadr[ed], fn = M.flexedge_J_rownnz[ed];
+      crptr fJ = MJH_F(B, flexedge_J, e);
+      for (int q = 0; q < fn; q++) { colind[a0 + q] = M.flexedge_J_colind[f0 + q]; val[a0 + q] = fJ[f0 + q]; }
+    }
+    else if (type == MJH_CNSTR_FRICTION_DOF) { colind[a0] = id; val[a0] = Jd[(size_t)r*nv + id]; }
     else if (type == MJH_CNSTR_LIMIT_JOINT) {
       const int d0 = M.jnt_dofadr[id], nd = M.jnt_type[id] == MJH_JNT_BALL ? 3 : 1;
       for (int q = 0; q < nd; q++) { colind[a0 + q] = d0 + q; val[a0 + q] = Jd[(size_t)r*nv + d0 + q]; }

@@ -87,7 +87,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
     const int b1 = M.flexvert_bodyid[v1], b2 = M.flexvert_bodyid[v2];
     real vec[3] = {vx[3*v2] - vx[3*v1], vx[3*v2 + 1] - vx[3*v1 + 1], vx[3*v2 + 2] - vx[3*v1 + 2]};
     len[ed] = v3_normalize(vec);
-    const int skipjac = M.flex_edgedamping[f] == 0 && M.flex_edgestiffness[f] == 0 && M.flex_damping[f] == 0;
+    const int skipjac = M.flex_edgeequality[f] != 1 && M.flex_edgedamping[f] == 0 && M.flex_edgestiffness[f] == 0 && M.flex_damping[f] == 0;
     if (skipjac) {
       for (int j = adr; j < adr + nnz; j++) J[j] = 0;
       continue;

@@ -157,7 +157,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->nv == 0, "model without degrees of freedom");
   for (int i = 0; i < m->neq; i++) {
     MJH_REJECT(m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT &&
-               m->eq_type[i] != mjEQ_TENDON, "flex equality constraints");
+               m->eq_type[i] != mjEQ_TENDON && m->eq_type[i] != mjEQ_FLEX, "flex vertex / strain equality constraints");
     if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD)
       MJH_REJECT(m->eq_objtype[i] != mjOBJ_BODY && m->eq_objtype[i] != mjOBJ_SITE, "connect/weld between objects other than bodies or sites");
     const mjtNum* r = m->eq_solref + 2*i;
@@ -167,7 +167,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // flexes, flex equality constraints and penalty ("passive") flex contacts are not built
   for (int f = 0; f < m->nflex; f++) {
     MJH_REJECT(m->flex_interp[f] != 0, "interpolated (trilinear / quadratic) flexes");
-    MJH_REJECT(m->flex_edgeequality[f] != 0, "flex edge / vertex / strain equality constraints");
+    MJH_REJECT(m->flex_edgeequality[f] != 0 && m->flex_edgeequality[f] != 1, "flex vertex / strain equality constraints");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
     // mj_flexCG (engine_forward.c:1640): CG with an implicit integrator and pyramidal cones runs deformable flexes under the
@@ -364,6 +364,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     H->eq_objsite[i] = (m->eq_objtype[i] == mjOBJ_SITE) ? 1 : 0;
     H->eq_active0[i] = m->eq_active0[i] ? 1 : 0;
     int size = m->eq_type[i] == mjEQ_CONNECT ? 3 : (m->eq_type[i] == mjEQ_WELD ? 6 : 1);
+    if (m->eq_type[i] == mjEQ_FLEX) {
+      // one row per non-rigid edge of the flex (mj_instantiateEquality, engine_core_constraint.c:982-1010)
+      const int f = m->eq_obj1id[i];
+      size = 0;
+      for (int ed = m->flex_edgeadr[f]; ed < m->flex_edgeadr[f] + m->flex_edgenum[f]; ed++) if (!m->flexedge_rigid[ed]) size++;
+    }
     if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD) {
       // both bodies static: the Jacobian block is identically zero and mj_addConstraint drops the
       // whole constraint (empty-block guard, engine_core_constraint.c:424-447)
@@ -372,6 +378,18 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       if (m->body_treeid[b1] < 0 && m->body_treeid[b2] < 0) size = 0;
     }
     H->eq_rowadr[i + 1] = H->eq_rowadr[i] + size;
+  }
+  {
+    bool anyflex = false;
+    for (int i = 0; i < m->neq; i++) if (m->eq_type[i] == mjEQ_FLEX) anyflex = true;
+    s.neqrow = anyflex ? H->eq_rowadr[m->neq] : 0;
+    H->eqrow_edge.assign((size_t)s.neqrow, -1);
+    for (int i = 0; i < m->neq && anyflex; i++) {
+      if (m->eq_type[i] != mjEQ_FLEX) continue;
+      const int f = m->eq_obj1id[i];
+      int k = H->eq_rowadr[i];
+      for (int ed = m->flex_edgeadr[f]; ed < m->flex_edgeadr[f] + m->flex_edgenum[f]; ed++) if (!m->flexedge_rigid[ed]) H->eqrow_edge[k++] = ed;
+    }
   }
   copy_arr(H->eq_solref, m->eq_solref, 2*m->neq);
   copy_arr(H->eq_solimp, m->eq_solimp, 5*m->neq);
@@ -1200,8 +1218,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const bool dual = m->opt.solver == mjSOL_PGS;
     // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
     const bool ref_sparse0 = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
-    s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && m->neq == 0 && m->ntendon == 0 &&
+    // (equality rows: flex edge constraints only -- their rows are the model's flexedge_J rows; the dense rows of the other
+    // kinds would have to be cut by a scan)
+    bool eq_ok = true, eq_flex = false;
+    for (int i = 0; i < m->neq; i++) { if (m->eq_type[i] != mjEQ_FLEX) eq_ok = false; else eq_flex = true; }
+    s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && eq_ok && m->ntendon == 0 &&
              !(m->opt.disableflags & mjDSBL_ISLAND)) ? 1 : 0;
+    MJH_REJECT(eq_flex && !s.csr, "flex edge equality constraints outside the explicit-index CG path (more than 128 dofs, CG, "
+                                  "sparse Jacobian, no other equality or tendon)");
     const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : (s.csr ? 64.0 : 4.0)*1024*1024;
     auto bytes = [&](int n) { return 8.0*n*(2.0*m->nv + (dual ? n : 0) + 24); };
     int n = std::max(1, std::min(nefc_bound, 4096));
@@ -1300,6 +1324,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     copy_arr(H->flex_bendingadr, m->flex_bendingadr, nf);
     copy_arr(H->flexvert_bodyid, m->flex_vertbodyid, m->nflexvert);
     copy_arr(H->flexedge_rigid, m->flexedge_rigid, m->nflexedge);
+    copy_arr(H->flex_edgeequality, m->flex_edgeequality, nf);
+    copy_arr(H->flexedge_invweight0, m->flexedge_invweight0, m->nflexedge);
     copy_arr(H->flexedge_J_rownnz, m->flexedge_J_rownnz, m->nflexedge);
     copy_arr(H->flexedge_J_rowadr, m->flexedge_J_rowadr, m->nflexedge);
     copy_arr(H->flexedge_J_colind, m->flexedge_J_colind, m->nJfe);

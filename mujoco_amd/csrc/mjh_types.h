@@ -166,6 +166,10 @@
   X(flexedge_vert, 2 * s.nflexedge)            \
   X(flexedge_flap, 2 * s.nflexbend)            \
   X(flexedge_rigid, s.nflexedge)               \
+  /* flex edge equality constraints (mjEQ_FLEX): 1 where a flex's edges are constrained; the edge of every row of   \
+     such an equality, indexed like the rows eq_rowadr hands out */                                              \
+  X(flex_edgeequality, s.nflex)                \
+  X(eqrow_edge, s.neqrow)                      \
   X(flexedge_J_rownnz, s.nflexedge)            \
   X(flexedge_J_rowadr, s.nflexedge)            \
   X(flexedge_J_colind, s.nJfe)                 \
@@ -278,6 +282,7 @@
   /* flexes */                                 \
   X(flex_vert, 3 * s.nflexvert)                \
   X(flexedge_length0, s.nflexedge)             \
+  X(flexedge_invweight0, s.nflexedge)          \
   X(flex_stiffness, s.nflexstiffness)          \
   X(flex_bending, s.nflexbending)              \
   X(flex_damping, s.nflex)                     \
@@ -366,6 +371,8 @@ struct DSizes {
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row
   int csr, csr_rowmax;
+  // rows of the flex edge equality constraints (eq_rowadr[neq] when the model has one, else 0)
+  int neqrow;
 };
 
 struct DOptions {
@@ -741,7 +748,7 @@ enum {
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
   // pair_func: which narrowphase routine a static pair uses
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
-  MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3,
+  MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3, MJH_EQ_FLEX = 4,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
   MJH_COL_PLANE_BOX = 7, MJH_COL_SPHERE_BOX = 8, MJH_COL_SPHERE_CYLINDER = 9, MJH_COL_BOX_BOX = 10, MJH_COL_CAPSULE_BOX = 11,
   MJH_COL_UNSUPPORTED = 6,   // pair without a GPU collider (hfield, sdf): raises MJH_WARN_UNSUPPORTED if it survives the filter

@@ -47,3 +47,8 @@ def test_flex_against_an_actuated_body_on_gpu(rb, hip_lib, tmp_path):
 
 def test_flex_island_next_to_rigid_islands_on_gpu(rb, hip_lib, tmp_path):
     fh._multi_island(rb, hip_lib, tmp_path)
+
+def test_flex_edge_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
+    """mjEQ_FLEX rows (one per non-rigid edge) in front of the contact rows: bit-exact incl. CG iteration counts"""
+    maxcon, kinds = fh._edge_equality(rb, hip_lib, tmp_path, nstep=60)
+    assert maxcon > 0

@@ -155,6 +155,26 @@ def test_flex_on_floor_keeps_fifty_contacts(rb, hostsim_lib, tmp_path):
     assert maxcon == 50 and kinds == {"vert"}
 
 
+def _edge_equality(rb, lib, tmp_path, nstep=40):
+    xml = tmp_path / "softbox.xml"
+    xml.write_text(flex_xml("5 4 4", "0 0 .09", extra_world='<body mocap="true" pos=".02 .01 .04"><geom type="sphere" size=".03"/></body>',
+                            flex_body='<edge equality="true"/><contact selfcollide="none"/>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.neq == 1 and m.eq_type[0] == 4 and m.flex_edgeequality[0] == 1 and m.nv > 128
+    d = rb.MjData(m)
+    rb.mj_forward(m, d)
+    assert d.ne == int((np.asarray(m.flexedge_rigid) == 0).sum()) and d.ne > 100
+    return _resync_steps(rb, lib, m, pre=60, nstep=nstep)
+
+
+def test_flex_edge_equality_constraints(rb, hostsim_lib, tmp_path):
+    """mjEQ_FLEX (model/flex/softbox.xml's kind): one equality row per non-rigid edge -- the edge's flexedge_J row, position
+    error length - length0, diagApprox from flexedge_invweight0 -- in front of the contact rows; the box lands on the floor
+    and on a sphere: states, ncon / nefc and CG iteration counts identical to the oracle's at every step"""
+    maxcon, kinds = _edge_equality(rb, hostsim_lib, tmp_path)
+    assert maxcon > 0
+
+
 def test_jelly_on_the_capsule(rb, hostsim_lib):
     """jelly.xml falling onto its capsule: element contacts, one island of 1536 dofs under CG"""
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "jelly.mjb"))
