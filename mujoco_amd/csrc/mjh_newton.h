@@ -534,6 +534,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
             real res = (r0 + r2) + (r1 + r3);
             for (; k < n; k++) res += v[k]*P.force[ri[k]];
             qfc[jj[u]] = res;
+            // (the gradient Ma - qfrc_smooth - qfrc_constraint is formed here, from the value in the register: update_grad
+            // follows every call, and its pass would read qfrc_constraint back from global memory)
+            grad[jj[u]] = Ma[jj[u]] - qfs[jj[u]] - res;
           }
         }
         wv_sync();
@@ -566,6 +569,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // grad = Ma - qfrc_smooth - qfrc_constraint (PrimalUpdateGrad)
   auto update_grad = [&]() {
+    if (SPA == 2) return;          // (formed by update_constraint's pass over the island's dofs)
     if (SPA == 2) {
       // (dofs outside the island: zeroed once when the island starts, never written afterwards)
       for (int k0 = lane; k0 < nidof; k0 += MJH_NVU*MJH_W) {
