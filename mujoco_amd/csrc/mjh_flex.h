@@ -142,8 +142,8 @@ MJH_DEV int flex_edge_corner(int dim, int ed, int i) {
 // force block of one element: force[3*corner + x] -= elongation[ed1] * gradient[ed2][i][x] * metric[ed1][ed2] over ed1, ed2, the
 // two ends i of edge ed2, x -- in that loop order (:606-617).  DIM is a template argument so that the edge -> corner table
 // and every index into the force block are compile-time constants: the block stays in registers.
-template <int DIM, class KP, class VX, class LP, class EP, class FP>
-MJH_DEV void flex_stretch_element(MREF M, int t, KP k, real kD, real h, VX vx, LP len, EP evel, FP efrc) {
+template <int DIM, class KP, class VX, class LP, class EP>
+MJH_DEV void flex_stretch_force(MREF M, int t, KP k, real kD, real h, VX vx, LP len, EP evel, real* force) {
   constexpr int NE = DIM == 2 ? 3 : 6;
   constexpr int E0[6] = {DIM == 2 ? 1 : 0, DIM == 2 ? 2 : 1, DIM == 2 ? 0 : 2, 2, 0, 1};     // first corner of local edge q
   constexpr int E1[6] = {DIM == 2 ? 2 : 1, DIM == 2 ? 0 : 2, DIM == 2 ? 1 : 0, 3, 3, 3};     // second corner
@@ -161,7 +161,6 @@ MJH_DEV void flex_stretch_element(MREF M, int t, KP k, real kD, real h, VX vx, L
     const real prev = def - evel[idx] * h;
     elong[q] = def*def - ref*ref + (def*def - prev*prev) * kD;
   }
-  real force[3*(DIM + 1)];
 #pragma unroll
   for (int i = 0; i < 3*(DIM + 1); i++) force[i] = 0;
 #pragma unroll
@@ -178,6 +177,11 @@ MJH_DEV void flex_stretch_element(MREF M, int t, KP k, real kD, real h, VX vx, L
       for (int x = 0; x < 3; x++) force[3*c1 + x] -= elong[ed1] * (p[c1][x] - p[c0][x]) * metric;
     }
   }
+}
+template <int DIM, class KP, class VX, class LP, class EP, class FP>
+MJH_DEV void flex_stretch_element(MREF M, int t, KP k, real kD, real h, VX vx, LP len, EP evel, FP efrc) {
+  real force[3*(DIM + 1)];
+  flex_stretch_force<DIM>(M, t, k, kD, h, vx, len, evel, force);
 #pragma unroll
   for (int i = 0; i < 3*(DIM + 1); i++) efrc[12*t + i] = force[i];
 }
@@ -239,6 +243,26 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
   }
 
   // ---- stretch: one lane per element (mj_flexPassiveStretch, :551-630); block = force on the element's corners
+  // (a model of one solid flex -- jelly.xml: 2058 tetrahedra, 33 per lane -- takes its elements two at a time per lane, in a
+  // branch-free body: an element is a chain of dependent loads (corner ids -> positions, edge ids -> lengths), and with one
+  // or two wavefronts on a SIMD only a second, independent chain hides its round trips)
+  const int sadr0 = s.nflex == 1 ? (int)M.flex_stiffnessadr[0] : -1;
+  if (s.nflex == 1 && M.flex_dim[0] == 3 && !M.flex_rigid[0] && sadr0 >= 0 && M.flex_stiffness[sadr0] != 0 && s.nflexelem > 0) {
+    const real kD = h > 0 ? M.flex_damping[0] / h : 0;
+    const int e0 = M.flex_elemadr[0], nel = s.nflexelem;
+    for (int t0 = wv_lane(); t0 < nel; t0 += 2*MJH_W) {
+      const int t1 = t0 + MJH_W < nel ? t0 + MJH_W : t0;
+      real fa[12], fb[12];
+      flex_stretch_force<3>(M, t0, M.flex_stiffness + sadr0 + 21*(t0 - e0), kD, h, vx, len, evel, fa);
+      flex_stretch_force<3>(M, t1, M.flex_stiffness + sadr0 + 21*(t1 - e0), kD, h, vx, len, evel, fb);
+#pragma unroll
+      for (int i = 0; i < 12; i++) efrc[12*t0 + i] = fa[i];
+      if (t1 != t0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) efrc[12*t1 + i] = fb[i];
+      }
+    }
+  } else
   MJH_FOR_LANES(t, s.nflexelem) {
     const int f = M.flexelem_flex[t];
     const int dim = M.flex_dim[f];

@@ -243,6 +243,36 @@ MJH_DEV real csr_chain1(PP p, int a, int L) {
   for (; i < L; i++) r += p[a + 4*i];
   return r;
 }
+// r + p[0] + p[1] + ... + p[n-1], strictly left to right (a single running sum of the reference), every lane on its own
+// (uniform result); the reads run a batch ahead of the additions like csr_chain1's
+template <class PP>
+MJH_DEV real csr_chain_serial(PP p, int n, real r) {
+  int i = 0;
+  if (n >= 8) {
+    const int last = n - 8;
+    real xa[8], xb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) xa[u] = p[u];
+    for (; i + 16 <= n; i += 16) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) xb[u] = p[i + 8 + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xa[u];
+      const int nx = i + 16 < last ? i + 16 : last;
+#pragma unroll
+      for (int u = 0; u < 8; u++) xa[u] = p[nx + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xb[u];
+    }
+    if (i + 8 <= n) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) r += xa[u];
+      i += 8;
+    }
+  }
+  for (; i < n; i++) r += p[i];
+  return r;
+}
 // 1 if the contiguous slice lies in the workgroup's LDS block (also on the host emulation, where mjh_in_lds is 0)
 MJH_DEV int csr_lds_resident(const crptr& v) {
   const long long off = mjh_lds_offset((const void*)v.p);
@@ -924,14 +954,33 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     real cost_ws = constraint_update(B, e, P, jar, 1, elliptic);
     if (SPA == 2) {
       // (the addends lane-parallel into the staging block, then the reference's single running sum over them)
-      MJH_FOR_LANES(i, nv) dstage[i] = 0.5*(Ma[i] - qfs[i])*(qws[i] - qas[i]);
+      for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+        real a[MJH_NVU], b[MJH_NVU], c[MJH_NVU], d[MJH_NVU];
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; a[u] = Ma[i]; b[u] = qfs[i]; c[u] = qws[i]; d[u] = qas[i]; }
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) dstage[i] = 0.5*(a[u] - b[u])*(c[u] - d[u]); }
+      }
       wv_sync();
-      for (int i = 0; i < nv; i++) cost_ws += dstage[i];
+      {
+        const long long soff = mjh_lds_offset((const void*)dstage);
+        cost_ws = (soff >= 0 && soff < 160*1024) ? csr_chain_serial(mjh_local((const real*)dstage), nv, cost_ws)
+                                                  : csr_chain_serial((const real*)dstage, nv, cost_ws);
+      }
     } else
     for (int i = 0; i < nv; i++) cost_ws += 0.5*(Ma[i] - qfs[i])*(qws[i] - qas[i]);
     wv_sync();
     const real cost_smooth = constraint_update(B, e, P, P.b, 1, elliptic);
     const int use_smooth = cost_ws > cost_smooth;
+    if (SPA == 2) {
+      for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
+        real c[MJH_NVU];
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; c[u] = use_smooth ? qas[i] : qws[i]; }
+#pragma unroll
+        for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) qacc[i] = c[u]; }
+      }
+    } else
     MJH_FOR_LANES(i, nv) qacc[i] = use_smooth ? qas[i] : qws[i];
     wv_sync();
     if (multi_tree) {
