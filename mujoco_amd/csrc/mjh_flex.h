@@ -75,6 +75,56 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
   crptr scom = MJH_F(B, subtree_com, e);
   rptr len = MJH_F(B, flexedge_length, e);
   rptr J = MJH_F(B, flexedge_J, e);
+  // (a model of one deformable flex whose edges all carry six entries -- both ends slider bodies, jelly.xml: 2863 edges, 45
+  // per lane -- takes its edges two at a time per lane in a branch-free body, for the reason given at the stretch pass: the
+  // second edge's chain of dependent loads hides the first one's round trips)
+  int paired = 0;
+  if (s.nflex == 1 && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge &&
+      !(M.flex_edgeequality[0] != 1 && M.flex_edgedamping[0] == 0 && M.flex_edgestiffness[0] == 0 && M.flex_damping[0] == 0)) paired = 1;
+  if (paired) {
+    const int ne = s.nflexedge;
+    auto edge = [&](int ed, real& length, real* Jr) {
+      const int v1 = M.flexedge_vert[2*ed], v2 = M.flexedge_vert[2*ed + 1];
+      const int b1 = M.flexvert_bodyid[v1], b2 = M.flexvert_bodyid[v2];
+      real vec[3] = {vx[3*v2] - vx[3*v1], vx[3*v2 + 1] - vx[3*v1 + 1], vx[3*v2 + 2] - vx[3*v1 + 2]};
+      length = v3_normalize(vec);
+      real off1[3], off2[3];
+      v3_sub(off1, vx + 3*v1, scom + 3*M.body_rootid[b1]);
+      v3_sub(off2, vx + 3*v2, scom + 3*M.body_rootid[b2]);
+      const int adr = M.flexedge_J_rowadr[ed];
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        const int col = M.flexedge_J_colind[adr + q];
+        const int second = M.dof_bodyid[col] == b2;
+        crptr cd = cdof + 6*col;
+        real t[3];
+        v3_cross(t, cd, second ? off2 : off1);
+        real jd[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+        if (!second) { jd[0] = -jd[0]; jd[1] = -jd[1]; jd[2] = -jd[2]; }
+        real acc = 0;
+        for (int r = 0; r < 3; r++)
+          if (vec[r] != 0) acc += jd[r]*vec[r];
+        Jr[q] = acc;
+      }
+    };
+    for (int e0 = wv_lane(); e0 < ne; e0 += 2*MJH_W) {
+      const int e1 = e0 + MJH_W < ne ? e0 + MJH_W : e0;
+      real la, lb, Ja[6], Jb[6];
+      edge(e0, la, Ja);
+      edge(e1, lb, Jb);
+      const int a0 = M.flexedge_J_rowadr[e0], a1 = M.flexedge_J_rowadr[e1];
+      len[e0] = la;
+#pragma unroll
+      for (int q = 0; q < 6; q++) J[a0 + q] = Ja[q];
+      if (e1 != e0) {
+        len[e1] = lb;
+#pragma unroll
+        for (int q = 0; q < 6; q++) J[a1 + q] = Jb[q];
+      }
+    }
+    wv_sync();
+    return;
+  }
   MJH_FOR_LANES(ed, s.nflexedge) {
     const int f = M.flexedge_flex[ed];
     const int adr = M.flexedge_J_rowadr[ed], nnz = M.flexedge_J_rownnz[ed];
@@ -118,6 +168,20 @@ MJH_DEV void flex_edge_velocity(MREF M, BREF B, int e) {
   crptr qvel = MJH_F(B, qvel, e);
   crptr J = MJH_F(B, flexedge_J, e);
   rptr vel = MJH_F(B, flexedge_velocity, e);
+  if (s.nflex == 1 && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge) {
+    // (rows of six entries, two edges per lane at a time: see stage_flex_edges)
+    const int ne = s.nflexedge;
+    for (int e0 = wv_lane(); e0 < ne; e0 += 2*MJH_W) {
+      const int e1 = e0 + MJH_W < ne ? e0 + MJH_W : e0;
+      const int a0 = M.flexedge_J_rowadr[e0], a1 = M.flexedge_J_rowadr[e1];
+      const real r0 = dot_sparse_ref(J + a0, qvel, 6, M.flexedge_J_colind + a0);
+      const real r1 = dot_sparse_ref(J + a1, qvel, 6, M.flexedge_J_colind + a1);
+      vel[e0] = r0;
+      if (e1 != e0) vel[e1] = r1;
+    }
+    wv_sync();
+    return;
+  }
   MJH_FOR_LANES(ed, s.nflexedge) {
     const int adr = M.flexedge_J_rowadr[ed];
     vel[ed] = M.flex_rigid[M.flexedge_flex[ed]] ? (real)0
@@ -298,10 +362,16 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     const int sadr = M.flex_stiffnessadr[f];
     if (M.flex_dim[f] >= 2 && sadr >= 0 && M.flex_stiffness[sadr] != 0) {
       real q[3] = {0, 0, 0};
-      for (int a = M.flexvert_elemadr[v]; a < M.flexvert_elemadr[v + 1]; a++) {
-        const int it = M.flexvert_elem[a];
-        const int t = it >> 2, i = it & 3;
-        for (int x = 0; x < 3; x++) q[x] += efrc[12*t + 3*i + x];
+      // (four blocks' loads in flight at a time; the additions stay in element order)
+      const int ea0 = M.flexvert_elemadr[v], ea1 = M.flexvert_elemadr[v + 1];
+      for (int a = ea0; a < ea1; a += 4) {
+        int it[4]; real fx[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) it[u] = M.flexvert_elem[a + u < ea1 ? a + u : ea1 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int o = 12*(it[u] >> 2) + 3*(it[u] & 3); fx[u][0] = efrc[o]; fx[u][1] = efrc[o + 1]; fx[u][2] = efrc[o + 2]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (a + u < ea1) { q[0] += fx[u][0]; q[1] += fx[u][1]; q[2] += fx[u][2]; }
       }
       real ql[3];
       m3_multvec(ql, xmat + 9*bid, q);
@@ -318,17 +388,28 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     if (a0 == a1) continue;
     real as = fs[i], ad = fd[i];
     int any = 0;
-    for (int a = a0; a < a1; a++) {
-      const int j = M.flexJ_cscind[a];
-      const int ed = M.flexJ_cscedge[a];
-      const real stiffness = enbl_spring ? (real)M.flexedge_k[ed] : (real)0;
-      const real damping = enbl_damper ? (real)M.flexedge_d[ed] : (real)0;
-      if (stiffness == 0 && damping == 0) continue;
-      const real frc_spring = stiffness * (M.flexedge_length0[ed] - len[ed]);
-      const real frc_damper = -damping * evel[ed];
-      as += J[j] * frc_spring;
-      ad += J[j] * frc_damper;
-      any = 1;
+    for (int a = a0; a < a1; a += 4) {
+      // (four entries' loads in flight at a time; the sums stay in edge order)
+      int jj[4], ee[4]; real kk[4], dd[4], l0[4], ll[4], vv[4], Jv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int idx = a + u < a1 ? a + u : a1 - 1; jj[u] = M.flexJ_cscind[idx]; ee[u] = M.flexJ_cscedge[idx]; }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        kk[u] = enbl_spring ? (real)M.flexedge_k[ee[u]] : (real)0;
+        dd[u] = enbl_damper ? (real)M.flexedge_d[ee[u]] : (real)0;
+        l0[u] = M.flexedge_length0[ee[u]]; ll[u] = len[ee[u]]; vv[u] = evel[ee[u]]; Jv[u] = J[jj[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (a + u >= a1) continue;
+        const real stiffness = kk[u], damping = dd[u];
+        if (stiffness == 0 && damping == 0) continue;
+        const real frc_spring = stiffness * (l0[u] - ll[u]);
+        const real frc_damper = -damping * vv[u];
+        as += Jv[u] * frc_spring;
+        ad += Jv[u] * frc_damper;
+        any = 1;
+      }
     }
     if (any) { fs[i] = as; fd[i] = ad; }
   }
