@@ -486,9 +486,11 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
 
   // candidate index space: [equalities | dof friction | tendon friction | joints (2 sides) | tendons (2 sides) | contacts]
   const int c_df = (!MJH_HAS(MJH_FT_EQUALITY) || (dsbl & (1<<1))) ? 0 : s.neq;          // mjDSBL_EQUALITY
-  const int c_tf = c_df + nv;
+  // (a model without friction-loss dofs / limited joints -- a flex has thousands of dofs and joints and neither -- leaves
+  // those ranges out: the scans below cost a round of table reads per 64 candidates)
+  const int c_tf = c_df + (s.ndoffric ? nv : 0);
   const int c_jl = c_tf + s.ntendon;
-  const int c_tl = c_jl + 2*s.njnt;
+  const int c_tl = c_jl + (s.njntlim ? 2*s.njnt : 0);
   const int c_con = c_tl + 2*s.ntendon;
   const int ncand = c_con + ncon;
   const int ispyramid = !MJH_HAS(MJH_FT_ELLIPTIC) || (M.o.cone == 0);

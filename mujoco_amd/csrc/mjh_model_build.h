@@ -1058,6 +1058,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_limited[i]) nlimit += 2;
   int nfric = 0;
   for (int i = 0; i < m->nv; i++) if (m->dof_frictionloss[i] != 0) nfric++;
+  s.ndoffric = nfric;
+  s.njntlim = 0;
+  for (int i = 0; i < m->njnt; i++) if (m->jnt_limited[i]) s.njntlim++;
   for (int i = 0; i < m->ntendon; i++) if (m->tendon_frictionloss[i] > 0) nfric++;
   // contact capacity: the bound mj_maxContact gives the static pair list (the reference's arena grows
   // on demand; a fixed 512 stands in for "as many as a scene of this size can touch at once")

@@ -373,6 +373,8 @@ struct DSizes {
   int csr, csr_rowmax;
   // rows of the flex edge equality constraints (eq_rowadr[neq] when the model has one, else 0)
   int neqrow;
+  // dofs with friction loss / limited joints (0: stage_make_constraint leaves their candidate ranges out of its scans)
+  int ndoffric, njntlim;
 };
 
 struct DOptions {
