@@ -51,22 +51,24 @@ HBM_PEAK_GBS = 8000.0
 CONFIGS = {
     "humanoid": dict(mjb="humanoid.mjb", xml="model/humanoid/humanoid.xml", nenv=4096, solver="pgs", integrator="euler",
                      ctrl=(-1.0, 1.0), dt=0.005, free_root=True,
-                     metric="env-steps/sec on humanoid.xml, 4096 envs/GPU"),
+                     metric="env-steps/sec on humanoid.xml, {nenv} envs/GPU"),
     # model/cube/cube_3x3x3.xml: Newton (default solver), implicitfast (:4), motors ctrlrange +-0.05 (:16), dt 0.01
     "cube": dict(mjb="cube_3x3x3.mjb", xml="model/cube/cube_3x3x3.xml", nenv=2048, solver=None, integrator=None,
                  ctrl=(-0.05, 0.05), dt=0.01, free_root=False,
-                 metric="env-steps/sec on cube_3x3x3.xml (convex mesh contacts, Newton), 2048 envs/GPU"),
+                 metric="env-steps/sec on cube_3x3x3.xml (convex mesh contacts, Newton), {nenv} envs/GPU"),
     # model/slider_crank/slider_crank.xml: position actuators ctrlrange +-0.1 (:10), default dt 0.002
     "slider_crank": dict(mjb="slider_crank.mjb", xml="model/slider_crank/slider_crank.xml", nenv=64, solver="pgs",
                          integrator="euler", ctrl=(-0.1, 0.1), dt=0.002, free_root=False,
-                         metric="env-steps/sec on slider_crank.xml, 64 envs"),
+                         metric="env-steps/sec on slider_crank.xml, {nenv} envs"),
     # model/flex/jelly.xml (BASELINE configs[4]: 1024 envs over 4 GPUs = 256 per GPU): 512-vertex solid flex, nv 1536, CG,
-    # Euler, dt 1 ms, no actuators -- the environments differ by their initial vertex velocities; the jelly reaches its
-    # capsule after ~340 steps, so the default warm-up is 400 steps (the timed steps are then all in contact)
+    # Euler, dt 1 ms, no actuators -- the environments differ by their initial vertex velocities.  The jelly reaches its
+    # capsule after ~340 steps and has settled on it after ~1000 (mean nefc ~ 80, ~17 CG iterations per step): the
+    # metric is timed in THAT regime (settle 1000 untimed steps); the nearly contact-free fall from the reset state is
+    # reported separately as `free_fall_regime`, never under the metric's name
     "flex": dict(mjb="jelly.mjb", xml="model/flex/jelly.xml", nenv=256, solver=None, integrator=None,
-                 ctrl=(0.0, 0.0), dt=0.001, free_root=False, warmup=400, solver_label="cg", integ_label="euler",
-                 parity_envs=4,
-                 metric="env-steps/sec on flex/jelly.xml (512-vertex solid flex, CG), 256 envs/GPU"),
+                 ctrl=(0.0, 0.0), dt=0.001, free_root=False, settle=1000, warmup=20, solver_label="cg", integ_label="euler",
+                 parity_envs=2, free_fall_steps=100,
+                 metric="env-steps/sec on flex/jelly.xml (512-vertex solid flex, CG, settled contact regime), {nenv} envs/GPU"),
 }
 
 
@@ -144,7 +146,7 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0, mjb_name: str = "humanoid
                       f"{iters} solver iters/step)"}
 
 
-def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread):
+def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None):
     """The like-for-like CPU number for `value`: the reference engine (oracle/_ref/liboracle_fast.so) stepping
     the bench's OWN initial states and control stream -- rows [0, R) of the GPU batch, warm-up + timed steps
     -- on all host cores, through oracle/rollout_bench.cc (the work of _unsafe_rollout_threaded,
@@ -158,10 +160,14 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread):
     with tempfile.TemporaryDirectory() as td:
         np.ascontiguousarray(s0[:R], dtype=np.float64).tofile(os.path.join(td, "s0.bin"))
         np.ascontiguousarray(ctrl, dtype=np.float64).tofile(os.path.join(td, "ctrl.bin"))
+        extra = []
+        if warm0 is not None:
+            np.ascontiguousarray(warm0[:R], dtype=np.float64).tofile(os.path.join(td, "warm0.bin"))
+            extra = [os.path.join(td, "warm0.bin")]
         out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", mjb_name), os.path.join(td, "s0.bin"),
                               os.path.join(td, "ctrl.bin"), str(R), str(T), str(nthread),
                               str(-1 if solver_id is None else solver_id), str(-1 if integ_id is None else integ_id),
-                              os.path.join(td, "final.bin")], capture_output=True, text=True, env=env, timeout=900).stdout
+                              os.path.join(td, "final.bin"), *extra], capture_output=True, text=True, env=env, timeout=900).stdout
         final = np.fromfile(os.path.join(td, "final.bin")) if os.path.exists(os.path.join(td, "final.bin")) else None
     kv = dict(x.split("=") for x in out.split() if "=" in x)
     if "env_steps_per_s" not in kv:
@@ -170,7 +176,8 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread):
             "rollouts": R, "nstep": T, "seconds": float(kv["seconds"]), "mean_ncon": float(kv["mean_ncon"]),
             "mean_nefc": float(kv["mean_nefc"]), "mean_solver_iter": float(kv["mean_niter"]),
             "sample": f"oracle/rollout_bench (liboracle_fast, -O3 -mavx): rows [0,{R}) of the GPU batch, the same state0 and "
-                      f"U(ctrlrange) control stream, {T} steps (warm-up + timed) from reset, {nthread} threads"}, final
+                      f"U(ctrlrange) control stream, {T} steps (warm-up + timed) from "
+                      + ("reset" if warm0 is None else "the GPU batch's settled state and warm start") + f", {nthread} threads"}, final
 
 
 def measured_traffic(steps_per_launch: int, nenv: int, model_xml: str = ""):
@@ -225,7 +232,8 @@ def measured_sq(config: str):
     return out
 
 
-def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0), iter_exact=True):
+def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0), iter_exact=True,
+                  warm0=None):
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).  Two builds of the reference are consulted (oracle/Makefile):
@@ -266,6 +274,8 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
         for k, e in enumerate(envs):
             d = rb.MjData(m)
             rb.mj_setState(m, d, s0[k], spec)
+            if warm0 is not None:
+                d.qacc_warmstart[:] = warm0[k]     # (run starts from a settled GPU state: its warm start comes along)
             for t in range(T):
                 pre_s.append(rb.mj_getState(m, d, spec)); pre_w.append(np.array(d.qacc_warmstart)); pre_u.append(ctrl[k, t])
                 d.ctrl[:] = ctrl[k, t]
@@ -314,6 +324,35 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     return out
 
 
+LEGS = {
+    # name: bench arguments of the sub-run (BASELINE configs[3], [4] per GPU, [0])
+    "cube": ["--config", "cube", "--steps", "100", "--warmup", "20", "--parity-envs", "16"],
+    "flex": ["--config", "flex", "--steps", "200"],
+    "slider_crank": ["--config", "slider_crank", "--steps", "1000", "--warmup", "100"],
+}
+
+
+def config_legs() -> dict:
+    """BASELINE configs 4 (cube), 5 (flex, one GPU's 256 environments) and 1 (slider-crank) as short sub-runs of this
+    script, so that the driver's default command measures them too: each leg is the complete line of
+    `python bench.py --config <name> ...` (value, roofline, cpu_baseline with the like-for-like rollout leg,
+    parity_sample), with the CPU legs bounded to a few seconds."""
+    out = {}
+    for name, argv in LEGS.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), *argv, "--leg"], capture_output=True, text=True,
+                               timeout=420, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            leg = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-800:], "returncode": r.returncode}
+        except Exception as exc:      # a failing leg is reported in place, the metric line survives
+            leg = {"error": repr(exc)}
+        leg["leg_wall_s"] = time.perf_counter() - t0
+        leg["command"] = "python bench.py " + " ".join(argv)
+        out[name] = leg
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,7 +372,10 @@ def main() -> None:
     ap.add_argument("--ctrl", choices=["uniform", "ou-halton"], default="uniform",
                     help="uniform = U(ctrlrange) per (env, step) (SURVEY 8d mode B, the metric); ou-halton = "
                          "testspeed's CtrlNoise sequence shared by all envs (mode A)")
-    ap.add_argument("--settle", type=int, default=0, help="untimed steps before the warm-up (contact-rich regime)")
+    ap.add_argument("--settle", type=int, default=None, help="untimed steps before the warm-up (default 0; flex: 1000, the settled contact regime)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="humanoid, N = 1: do not append the `configs` legs (cube, flex, slider_crank; one short sub-run each)")
+    ap.add_argument("--leg", action="store_true", help="(internal) this run is a `configs` leg of the default run: short CPU legs")
     ap.add_argument("--no-extra", action="store_true",
                     help="only the timed region (profiling runs): no parity sample, no testspeed-regime leg, no CPU baseline")
     ap.add_argument("--regime-steps", type=int, default=200, help="timed steps of the testspeed-regime leg")
@@ -378,6 +420,8 @@ def main() -> None:
     integ_name = integ_name or cfg.get("integ_label", "implicitfast")        # (cube_3x3x3.xml:4)
     if args.warmup is None:
         args.warmup = cfg.get("warmup", 100)
+    if args.settle is None:
+        args.settle = cfg.get("settle", 0)
     if "parity_envs" in cfg:
         args.parity_envs = min(args.parity_envs, cfg["parity_envs"])
     dm = ma.DeviceModel(lib, model)
@@ -414,6 +458,7 @@ def main() -> None:
         e1.record()
         events.append((e0, e1, ctrl.shape[1]))
 
+    snap = {}
     cpu_rows = min(nenv, max(1024, 4*(os.cpu_count() or 1)))     # rows of the batch the CPU leg re-steps
     host_ctrl = []                                                   # their control stream, in launch order
 
@@ -437,9 +482,19 @@ def main() -> None:
         region -> barrier -> K timed steps -> final-state copy (+ gather) -> barrier"""
         del events[:]
         first = state0
-        for c in ctrl_settle:
-            launch(c, None, first)
+        snap.clear()
+        for i, c in enumerate(ctrl_settle):
+            last = i == len(ctrl_settle) - 1
+            so = torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if last else None
+            launch(c, so, first)
             first = None
+            if last:
+                # the settled state and warm start the measured steps begin from: what the parity sample and the CPU
+                # rollout leg start from as well (taken before the warm-up, outside the timed region)
+                torch.cuda.synchronize()
+                snap["state"] = so[:, -1].cpu().numpy().copy()
+                snap["warm"] = batch.get("qacc_warmstart").copy()
+                del so
         state_w = [torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if want_state else None
                    for c in ctrl_w]
         state_k = [torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if want_state else None
@@ -485,10 +540,12 @@ def main() -> None:
     crng = np.random.Generator(np.random.PCG64(4321 + rank))
     want_state = not args.no_state_output
     ctrl_s = make_controls(args.ctrl, crng, chunks(args.settle) if args.settle else [], 0)
+    n_settle_ctrl = len(host_ctrl)
     ctrl_w = make_controls(args.ctrl, crng, chunks(W) if W else [], args.settle)
     ctrl_k = make_controls(args.ctrl, crng, chunks(K), args.settle + W)
     n_metric_ctrl = len(host_ctrl)          # control chunks of the metric leg (warm-up + timed), in order
     elapsed, timed, state_w, state_k = timed_region(state0, ctrl_s, ctrl_w, ctrl_k, want_state)
+    snap_metric = dict(snap)   # (later regions take their own snapshots)
     kernel_ms = sum(t for t, _ in timed)
     launch_ms_timed = float(np.mean([t for t, n in timed if n == C])) if any(n == C for _, n in timed) else kernel_ms
     if dist:
@@ -508,7 +565,7 @@ def main() -> None:
         # one launch = C steps of nenv envs; achieved = algorithmic bytes per launch / avg launch time
         achieved = bytes_per_env_step * nenv * C / (launch_ms_timed * 1e-3) / 1e9
         res = {
-            "metric": cfg["metric"],
+            "metric": cfg["metric"].format(nenv=nenv),
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -547,7 +604,7 @@ def main() -> None:
         }
 
     # ---------------- parity of the timed workload against the compiled reference ----------------
-    if rank == 0 and not args.no_extra and want_state and args.settle == 0 and args.parity_envs > 0:
+    if rank == 0 and not args.no_extra and want_state and (args.settle == 0 or snap_metric) and args.parity_envs > 0:
         envs = np.unique(np.linspace(0, nenv - 1, min(args.parity_envs, nenv)).astype(int))
         idx = torch.from_numpy(envs).to(dev)
         gs = torch.cat([x.index_select(0, idx) for x in state_w + state_k], dim=1).cpu().numpy()
@@ -558,8 +615,11 @@ def main() -> None:
             return out, small.get("counts")
 
         try:
-            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once, cfg["ctrl"],
-                                                 iter_exact=cfg.get("iter_exact", True))
+            res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, snap_metric["state"][envs] if snap_metric else s0[envs], cs, gs, envs,
+                                                 step_once, cfg["ctrl"], iter_exact=cfg.get("iter_exact", True),
+                                                 warm0=snap_metric["warm"][envs] if snap_metric else None)
+            if snap_metric:
+                res["parity_sample"]["start"] = f"the GPU batch's state and warm start after the {args.settle} settle steps"
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
             res["parity_sample"] = {"ok": False, "error": repr(exc)}
     del state_w, state_k, ctrl_w, ctrl_k
@@ -588,22 +648,44 @@ def main() -> None:
                 "end_state": {"warnings": int(batch.get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
                               "mean_nefc": float(cn[:, 1].mean()), "mean_pgs_iter": float(cn[:, 5].mean())}}
 
+    # ---------------- flex: the fall from the reset state, reported apart from the metric ----------------
+    if not args.no_extra and cfg.get("free_fall_steps") and args.settle > 0:
+        K3, W3 = cfg["free_fall_steps"], 20
+        c_w = make_controls("uniform", crng, [W3], 0)
+        c_k = make_controls("uniform", crng, [K3], W3)
+        el3, timed3, _, _ = timed_region(state0, [], c_w, c_k, want_state)
+        cn = batch.get("counts")
+        if rank == 0:
+            res["free_fall_regime"] = {
+                "value": nenv * world * K3 / el3, "unit": "env-steps/s", "steps": K3, "warmup": W3, "ms_per_step": el3 * 1e3 / K3,
+                "note": "the same kernel from the reset state (no settle): nearly contact-free -- a different regime from `value`, "
+                        "reported for completeness and never under the metric's name",
+                "end_state": {"mean_ncon": float(cn[:, 0].mean()), "mean_nefc": float(cn[:, 1].mean()),
+                              "mean_solver_iter": float(cn[:, 5].mean())}}
+
     if rank == 0:
+        ncpu = os.cpu_count() or 1
         if world == 1 and not args.no_cpu_baseline and not args.no_extra:
-            cb = cpu_baseline(os.cpu_count() or 1, mjb_name=cfg["mjb"], solver_flag=(args.solver or cfg["solver"] or "").upper() or None)
+            cb = cpu_baseline(ncpu, budget_s=4.0 if args.leg else 15.0, mjb_name=cfg["mjb"],
+                              solver_flag=(args.solver or cfg["solver"] or "").upper() or None)
             if cb:
                 res["cpu_baseline"] = cb
             # the same workload as `value` (same states, same controls, same steps) on the host cores
-            if args.ctrl == "uniform" and args.settle == 0 and n_metric_ctrl > 0:
+            if args.ctrl == "uniform" and (args.settle == 0 or snap_metric) and n_metric_ctrl > n_settle_ctrl:
                 try:
-                    leg = cpu_rollout_leg(cfg["mjb"], solver_id, integ_id, s0, np.concatenate(host_ctrl[:n_metric_ctrl], axis=1),
-                                          os.cpu_count() or 1)
+                    leg = cpu_rollout_leg(cfg["mjb"], solver_id, integ_id, snap_metric["state"] if snap_metric else s0,
+                                          np.concatenate(host_ctrl[n_settle_ctrl:n_metric_ctrl], axis=1), ncpu,
+                                          warm0=snap_metric["warm"] if snap_metric else None)
                 except Exception as exc:
                     leg = ({"error": repr(exc)}, None)
                 if leg:
-                    res.setdefault("cpu_baseline", {"value": leg[0].get("value"), "unit": "env-steps/s", "cores": os.cpu_count() or 1,
+                    res.setdefault("cpu_baseline", {"value": leg[0].get("value"), "unit": "env-steps/s", "cores": ncpu,
                                                     "kind": "reference", "sample": leg[0].get("sample")})
                     res["cpu_baseline"]["rollout_regime"] = leg[0]
+        # ---------------- the other single-GPU BASELINE configurations, one short sub-run each ----------------
+        if (args.config == "humanoid" and world == 1 and not args.no_extra and not args.no_legs and not args.leg
+                and not args.envs_per_gpu):
+            res["configs"] = config_legs()
         print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -68,7 +68,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
     int fbody[4]; real fw[4];
     const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-    int cols[64];
+    int cols[MJH_CSR_CHAIN_MAX];
     int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
     if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
     else n += csr_body_chain(M, M.geom_bodyid[cg[1]], cols + n);
@@ -123,7 +123,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
     const int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
     const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
-    int cols[64];
+    int cols[MJH_CSR_CHAIN_MAX];
     int n = csr_body_chain(M, b1, cols);
     if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
     else n += csr_body_chain(M, b2, cols + n);

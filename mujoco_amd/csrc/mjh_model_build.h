@@ -1038,17 +1038,18 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.ccd_N = m->opt.ccd_iterations;
       s.ccd_P = std::max(4, (int)m->npolygonmax);
       s.ccd_D = std::max(3, (int)m->nmeshdegmax);
-      // mirror of ccd_carve (mjh_convex.h): fixed slots, then the polytope with the clipping buffers overlaid
+      // mirror of the row workspace layout (mjh_convex.h: RO_* / IO_* offsets, rc_attach)
       const int N = s.ccd_N, P = s.ccd_P, D = s.ccd_D;
-      const int fixed_r = 2*20 + 3*4 + 3*4 + 4 + 4*9 + 5*9 + 7*5;
-      const int poly_r = (5 + N)*9 + 6*N*4;
-      const int multi_r = 9*D + 6*P + 16*P;
-      s.ccd_nreal = fixed_r + std::max(poly_r, multi_r);
-      const int fixed_i = 2*6 + 4*2 + 5*2 + 6*N + 6*N + 2*(6*N + 1);
-      const int poly_i = (5 + N)*2 + 6*N*5 + 6*N;
-      const int multi_i = 2*D;
-      s.ccd_nint = (fixed_i + std::max(poly_i, multi_i) + 1) & ~1;
-      s.ccd_lane_bytes = s.ccd_nreal*(int)sizeof(real) + s.ccd_nint*(int)sizeof(int);
+      const int VFAST = 10, FFAST = 24, MFAST = 24, HFAST = 12, KFAST = 12;
+      const int poly_r = 6*VFAST + 4*FFAST, clip_r = 9*D + 18*P;
+      s.ccd_row_freal = 96 + std::max(poly_r, clip_r);
+      const int poly_i = 2*VFAST + 6*FFAST + MFAST + 2*HFAST + KFAST, clip_i = 2*D;
+      const int row_i = 32 + std::max(poly_i, clip_i);
+      s.ccd_row_reals = s.ccd_row_freal + (row_i + 1)/2;
+      // overflow page of a row: full-capacity vertex / face / map / horizon / crossing-stack arrays
+      const int nsv = 5 + N, nsf = 6*N;
+      s.ccd_slow_bytes = (6*nsv + 4*nsf)*(int)sizeof(real) + ((2*nsv + 6*nsf + nsf + 2*nsf + 2*nsf + 16 + 1) & ~1)*(int)sizeof(int);
+      s.ccd_env_bytes = 192*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + 4*s.ccd_slow_bytes;
     }
   }
 
@@ -1227,6 +1228,20 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     for (int i = 0; i < m->neq; i++) { if (m->eq_type[i] != mjEQ_FLEX) eq_ok = false; else eq_flex = true; }
     s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && eq_ok && m->ntendon == 0 &&
              !(m->opt.disableflags & mjDSBL_ISLAND)) ? 1 : 0;
+    if (s.csr) {
+      // the explicit-index rows hold translational contact rows only (condim 1 / 3), and a row's merged dof chain is
+      // assembled in a 64-entry per-lane array (mjh_csr.h): models outside either bound keep the dense rows
+      int chainmax = 1;
+      for (int b = 0; b < m->nbody; b++) {
+        int cnt = 0;
+        for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)b*s.nvw + w]);
+        chainmax = std::max(chainmax, cnt);
+      }
+      if (std::max(2*chainmax, chainmax + 12) > MJH_CSR_CHAIN_MAX) s.csr = 0;
+      for (int p = 0; p < s.npair && s.csr; p++) if (H->pair_dim[p] > 3) s.csr = 0;
+      for (int g = 0; g < m->ngeom && s.csr && s.nflexpair > 0; g++) if (m->geom_condim[g] > 3) s.csr = 0;
+      for (int f = 0; f < m->nflex && s.csr; f++) if (m->flex_condim[f] > 3) s.csr = 0;
+    }
     MJH_REJECT(eq_flex && !s.csr, "flex edge equality constraints outside the explicit-index CG path (more than 128 dofs, CG, "
                                   "sparse Jacobian, no other equality or tendon)");
     const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : (s.csr ? 64.0 : 4.0)*1024*1024;

@@ -317,7 +317,7 @@ MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
   const DSizes& s = M->H.s;
 #define SZ(n) if (!strcmp(name, #n)) return s.n;
   SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
-  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment) SZ(ccd_any) SZ(ccd_lane_bytes) SZ(nmesh) SZ(sparse) SZ(nJmax) SZ(nLp) SZ(nflex) SZ(nflexvert) SZ(nflexedge) SZ(nflexelem) SZ(csr) SZ(neqrow) SZ(ndoffric) SZ(njntlim)
+  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment) SZ(ccd_any) SZ(ccd_env_bytes) SZ(ccd_row_reals) SZ(nmesh) SZ(sparse) SZ(nJmax) SZ(nLp) SZ(nflex) SZ(nflexvert) SZ(nflexedge) SZ(nflexelem) SZ(csr) SZ(neqrow) SZ(ndoffric) SZ(njntlim)
 #undef SZ
   set_err(std::string("mjhip_model_size: unknown size ") + name);
   return -1;
@@ -406,7 +406,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   // GJK / EPA workspace (mjh_convex.h): one private block per lane of every environment's wavefront;
   // raw memory, never read before it is written
   if (s.ccd_any) {
-    const size_t bytes = (size_t)nalloc*MJH_WAVE*(size_t)s.ccd_lane_bytes;
+    const size_t bytes = (size_t)nalloc*(size_t)s.ccd_env_bytes;
     Bt->ccd_ws = Backend::alloc(bytes);
     if (!Bt->ccd_ws) {
       set_err("mjhip: device allocation failed (convex-collision workspace of " + std::to_string(bytes) + " bytes)");

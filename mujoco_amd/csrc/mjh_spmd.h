@@ -54,6 +54,8 @@ struct WaveSim {
   double dscratch2[MJH_WAVE];
   long long iscratch[MJH_WAVE];
   long long iscratch2[MJH_WAVE];
+  long long arrive_row[MJH_WAVE];    // wv_row_converge / wv_converge arrival counts
+  long long arrive_wave[MJH_WAVE];
 };
 extern thread_local WaveSim* g_wave;
 static inline int lane() { return g_wave->cur; }
@@ -277,6 +279,87 @@ MJH_DEV double wv_dot4m(double p0, double p1, uint64_t mlo, uint64_t mhi, int de
   }
   mjhsim::yield();
   return res;
+}
+
+// ---- 16-lane rows as independent work groups (mjh_convex.h: one geom pair per row) ------------------------------
+// A row's lanes run in lockstep with each other but the four rows of a wavefront may sit in different iterations of a
+// data-dependent loop: on the device that is ordinary divergence (the hardware serialises, reconvergence is
+// structural); the emulation runs every lane as a fiber, so the row primitives below exchange data through per-lane
+// slots that only row-mates read, and wv_row_converge / wv_converge are real barriers here (no-ops on the device).
+// value of the partner lane: S = 0: lane ^ 1, 1: lane ^ 2, 2: mirrored inside the 8-lane half, 3: mirrored inside the row
+template <int S>
+MJH_DEV int wv_row_partner(int l) { return S == 0 ? (l ^ 1) : S == 1 ? (l ^ 2) : S == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15))); }
+template <int S>
+MJH_DEV double wv_row_xchg(double v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[wv_row_partner<S>(w->cur)];
+  mjhsim::yield();
+  return r;
+}
+template <int S>
+MJH_DEV int wv_row_xchg_i(int v) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  int r = (int)w->iscratch[wv_row_partner<S>(w->cur)];
+  mjhsim::yield();
+  return r;
+}
+// value / int held by lane src (0..15) of the caller's row
+MJH_DEV double wv_row_get(double v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->dscratch[w->cur] = v;
+  mjhsim::yield();
+  double r = w->dscratch[(w->cur & ~15) | (src & 15)];
+  mjhsim::yield();
+  return r;
+}
+MJH_DEV int wv_row_get_i(int v, int src) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = v;
+  mjhsim::yield();
+  int r = (int)w->iscratch[(w->cur & ~15) | (src & 15)];
+  mjhsim::yield();
+  return r;
+}
+// 16-bit mask of the row's lanes with pred != 0 (bit k: lane k of the row)
+MJH_DEV unsigned wv_row_ballot(int pred) {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  w->iscratch[w->cur] = pred ? 1 : 0;
+  mjhsim::yield();
+  unsigned m = 0;
+  const int b = w->cur & ~15;
+  for (int l = 0; l < 16; l++) if (w->iscratch[b + l]) m |= (1u << l);
+  mjhsim::yield();
+  return m;
+}
+// memory written by a row-mate before the call is visible after it (LDS / global exchange inside a row)
+MJH_DEV void wv_row_sync() { mjhsim::yield(); }
+// barriers of the emulation: every lane of the row / the wavefront has arrived
+MJH_DEV void wv_row_converge() {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  const int b = w->cur & ~15;
+  const long long mine = ++w->arrive_row[w->cur];
+  for (;;) {
+    bool all = true;
+    for (int l = 0; l < 16; l++) if (w->arrive_row[b + l] < mine) all = false;
+    if (all) break;
+    mjhsim::yield();
+  }
+  mjhsim::yield();
+}
+MJH_DEV void wv_converge() {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  const long long mine = ++w->arrive_wave[w->cur];
+  for (;;) {
+    bool all = true;
+    for (int l = 0; l < MJH_WAVE; l++) if (!w->done[l] && w->arrive_wave[l] < mine) all = false;
+    if (all) break;
+    mjhsim::yield();
+  }
+  mjhsim::yield();
 }
 
 #else
@@ -510,6 +593,26 @@ MJH_DEV double wv_dot4m(double p0, double p1, uint64_t mlo, uint64_t mhi, int de
   }
   return res;
 }
+
+// ---- 16-lane rows as independent work groups (mjh_convex.h: one geom pair per row; see the host build's comment)
+// partner exchanges as DPP moves: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+template <int S>
+MJH_DEV int wv_row_xchg_i(int v) {
+  constexpr int ctrl = S == 0 ? 0xB1 : S == 1 ? 0x4E : S == 2 ? 0x141 : 0x140;
+  return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false);
+}
+template <int S>
+MJH_DEV double wv_row_xchg(double v) {
+  return __hiloint2double(wv_row_xchg_i<S>(__double2hiint(v)), wv_row_xchg_i<S>(__double2loint(v)));
+}
+MJH_DEV int wv_row_get_i(int v, int src) { return __shfl(v, (int)(threadIdx.x & 48u) | (src & 15), 64); }
+MJH_DEV double wv_row_get(double v, int src) { return __shfl(v, (int)(threadIdx.x & 48u) | (src & 15), 64); }
+MJH_DEV unsigned wv_row_ballot(int pred) { return (unsigned)(__ballot(pred) >> (threadIdx.x & 48u)) & 0xffffu; }
+// a wavefront's LDS / memory instructions complete in program order: only the compiler has to be kept from moving
+// accesses across the exchange point
+MJH_DEV void wv_row_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+MJH_DEV void wv_row_converge() { __builtin_amdgcn_wave_barrier(); }
+MJH_DEV void wv_converge() { __builtin_amdgcn_wave_barrier(); }
 
 #endif  // MJH_HOSTSIM
 

@@ -357,7 +357,10 @@ struct DSizes {
   int ccd_any;         // some static pair uses the GJK / EPA narrowphase
   int ccd_N;           // opt.ccd_iterations
   int ccd_P, ccd_D;    // max(npolygonmax, 4), max(nmeshdegmax, 3)
-  int ccd_nreal, ccd_nint, ccd_lane_bytes;   // workspace per lane: reals, ints, bytes (0 without convex pairs)
+  // row workspace of the convex narrowphase (mjh_convex.h; all 0 without convex pairs): reals of a row's fast page,
+  // reals + ints of it counted in reals (the LDS-planned field ccd_row holds 4 of these per environment), bytes of a
+  // row's overflow page and of an environment's global block (header, contact records, 4 overflow pages)
+  int ccd_row_freal, ccd_row_reals, ccd_slow_bytes, ccd_env_bytes;
   // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse; nv <= 128 here);
   // capacity of the CSR Jacobian; entries of the compressed factor (Newton; x2 with cones)
   int sparse, nJmax, nLp, nLpc;
@@ -371,6 +374,7 @@ struct DSizes {
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row
   int csr, csr_rowmax;
+#define MJH_CSR_CHAIN_MAX 64   // per-lane array a contact row's merged dof chain is assembled in (model build keeps csr_rowmax below it)
   // rows of the flex edge equality constraints (eq_rowadr[neq] when the model has one, else 0)
   int neqrow;
   // dofs with friction loss / limited joints (0: stage_make_constraint leaves their candidate ranges out of its scans)
@@ -459,6 +463,8 @@ enum {
   X(xaxis, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                       \
   X(geom_xpos, 3 * s.ngeom, 3 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
   X(geom_xmat, 9 * s.ngeom, 9 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
+  /* row workspaces of the convex narrowphase (mjh_convex.h): 4 rows x (shape frames, simplex, polytope / clipping buffers) */ \
+  X(ccd_row, 4 * s.ccd_row_reals, 4 * s.ccd_row_reals, MJH_T_COLLISION, MJH_T_COLLISION)  \
   X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \
@@ -628,7 +634,7 @@ struct DBatch {
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
   int mfma;          // 1: AR = Y Y' on the matrix cores (v_mfma_f64_16x16x4_f64): tolerance parity, not bit parity
   int xfrc_on;       // 1: xfrc_applied may be non-zero (mj_xfrcAccumulate runs; xipos stays readable at MJH_T_ACCEL)
-  void* ccd_ws;      // GJK / EPA workspace: [nenv][64 lanes][ccd_lane_bytes], null without convex pairs (mjh_convex.h)
+  void* ccd_ws;      // convex narrowphase: [nenv][ccd_env_bytes] pair lists, contact records, overflow pages; null without convex pairs (mjh_convex.h)
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_REAL_FIELDS(X)
 #undef X

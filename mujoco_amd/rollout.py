@@ -98,85 +98,101 @@ class Rollout:
     def rollout(self, model, data, initial_state, control=None, *, control_spec: int = mjSTATE_CTRL,
                 skip_checks: bool = False, nstep: Optional[int] = None, initial_warmstart=None,
                 state=None, sensordata=None, chunk_size: Optional[int] = None):
-        """See `mujoco.rollout.Rollout.rollout`; returns (state, sensordata)."""
+        """Same contract as `mujoco.rollout.Rollout.rollout` (python/mujoco/rollout.py:87-241): returns
+        (state[nbatch, nstep, nstate], sensordata[nbatch, nstep, nsensordata]).  `chunk_size` is accepted and has
+        no effect (it tunes the reference's thread pool)."""
         if self.rollout_ is None:
             raise RuntimeError("rollout requested after thread pool shutdown")
-
-        if skip_checks:
-            self._call(model, data, nstep, control_spec, initial_state, initial_warmstart, control,
-                       state, sensordata)
-            return state, sensordata
-
-        if not _is_model(model):
-            model = list(model)
-        if control_spec & ~mjSTATE_USER:
-            raise ValueError("control_spec can only contain bits in mjSTATE_USER")
-        if nstep and not isinstance(nstep, int):
-            raise ValueError("nstep must be an integer")
-        if chunk_size and not isinstance(chunk_size, int):
-            raise ValueError("chunk_size must be an integer")
-        _check_must_be_numeric(initial_state=initial_state, initial_warmstart=initial_warmstart,
-                               control=control, state=state, sensordata=sensordata)
-        _check_number_of_dimensions(2, initial_state=initial_state, initial_warmstart=initial_warmstart)
-        _check_number_of_dimensions(3, control=control, state=state, sensordata=sensordata)
-
-        initial_state = _ensure_2d(initial_state)
-        initial_warmstart = _ensure_2d(initial_warmstart)
-        control = _ensure_3d(control)
-        state = _ensure_3d(state)
-        sensordata = _ensure_3d(sensordata)
-
-        nbatch = _infer_dimension(0, 1, initial_state=initial_state, initial_warmstart=initial_warmstart,
-                                  control=control, state=state, sensordata=sensordata)
-        if isinstance(model, list) and nbatch == 1:
-            nbatch = len(model)
-        if isinstance(model, list) and len(model) > 1 and len(model) != nbatch:
-            raise ValueError(f"nbatch inferred as {nbatch} but model is length {len(model)}")
-        elif not isinstance(model, list):
-            model = [model]
-        if not isinstance(data, list):
-            data = [data]
-
-        nstep = _infer_dimension(1, nstep or 1, control=control, state=state, sensordata=sensordata)
-
-        nstate = state_size(model[0], mjSTATE_FULLPHYSICS)
-        ncontrol = state_size(model[0], control_spec)
-        nv = int(model[0].nv)
-        nsensordata = int(getattr(model[0], "nsensordata", 0) or 0)
-        for m in model[1:]:
-            if (nstate != state_size(m, mjSTATE_FULLPHYSICS) or ncontrol != state_size(m, control_spec)
-                    or nv != int(m.nv) or nsensordata != int(getattr(m, "nsensordata", 0) or 0)):
-                raise ValueError("models are not compatible")
-
-        _check_trailing_dimension(nstate, initial_state=initial_state, state=state)
-        _check_trailing_dimension(ncontrol, control=control)
-        _check_trailing_dimension(nv, initial_warmstart=initial_warmstart)
-        _check_trailing_dimension(nsensordata, sensordata=sensordata)
-
-        model = model * nbatch if len(model) == 1 else model
-        initial_state = _tile_if_required(initial_state, nbatch)
-        initial_warmstart = _tile_if_required(initial_warmstart, nbatch)
-        control = _tile_if_required(control, nbatch, nstep)
-
-        if state is None:
-            state = np.empty((nbatch, nstep, nstate), dtype=np.float64)
-        if sensordata is None:
-            sensordata = np.empty((nbatch, nstep, nsensordata), dtype=np.float64)
-
-        self._call(model, data, nstep, control_spec, initial_state, initial_warmstart, control,
-                   state, sensordata)
-        return state, sensordata
+        args = {"initial_state": initial_state, "initial_warmstart": initial_warmstart, "control": control,
+                "state": state, "sensordata": sensordata}
+        if not skip_checks:
+            model, data, nstep, args = _prepare(model, data, nstep, chunk_size, control_spec, args)
+        self._call(model, data, nstep, control_spec, args["initial_state"], args["initial_warmstart"],
+                   args["control"], args["state"], args["sensordata"])
+        return args["state"], args["sensordata"]
 
 
-persistent_rollout = None
+# One row per array argument of a rollout: its rank once the leading singleton axes are added back, and which model
+# size its last axis must have.  The reference checks the same things argument by argument (rollout.py:129-212).
+_ARGS = (("initial_state", 2, "nstate"), ("initial_warmstart", 2, "nv"), ("control", 3, "ncontrol"),
+         ("state", 3, "nstate"), ("sensordata", 3, "nsensordata"))
+
+
+def _model_sizes(m, control_spec):
+    return {"nstate": state_size(m, mjSTATE_FULLPHYSICS), "ncontrol": state_size(m, control_spec), "nv": int(m.nv),
+            "nsensordata": int(getattr(m, "nsensordata", 0) or 0)}
+
+
+def _agree(axis, current, arrays):
+    """the common extent of `axis` over the given (name, array) pairs; 1 stretches to anything"""
+    for name, a in arrays:
+        n = a.shape[axis]
+        if n == current or n == 1:
+            continue
+        if current != 1:
+            raise ValueError(f"dimension {axis} inferred as {current} but {name} has {n}")
+        current = n
+    return current
+
+
+def _prepare(model, data, nstep, chunk_size, control_spec, args):
+    """validation, shape inference and singleton expansion of a rollout call; returns what `_call` needs"""
+    if control_spec & ~mjSTATE_USER:
+        raise ValueError("control_spec can only contain bits in mjSTATE_USER")
+    for label, v in (("nstep", nstep), ("chunk_size", chunk_size)):
+        if v and not isinstance(v, int):
+            raise ValueError(f"{label} must be an integer")
+    models = [model] if _is_model(model) else list(model)
+    given = []
+    for name, rank, _ in _ARGS:
+        v = args[name]
+        if v is None:
+            continue
+        if not isinstance(v, (np.ndarray, float)):
+            raise ValueError(f"{name} must be a numpy array or float")
+        if np.ndim(v) > rank:
+            raise ValueError(f"{name} can have at most {rank} dimensions")
+        a = np.asarray(v, dtype=np.float64)
+        a = np.ascontiguousarray(a.reshape((1,) * (rank - a.ndim) + a.shape))
+        args[name] = a
+        given.append((name, a))
+    nbatch = _agree(0, 1, given)
+    if nbatch == 1 and len(models) > 1:
+        nbatch = len(models)
+    if len(models) > 1 and len(models) != nbatch:
+        raise ValueError(f"nbatch inferred as {nbatch} but model is length {len(models)}")
+    nstep = _agree(1, nstep or 1, [(n, a) for n, a in given if a.ndim == 3])
+    sizes = _model_sizes(models[0], control_spec)
+    if any(_model_sizes(m, control_spec) != sizes for m in models[1:]):
+        raise ValueError("models are not compatible")
+    for name, _, key in _ARGS:
+        a = args[name]
+        if a is not None and a.shape[-1] != sizes[key]:
+            raise ValueError(f"trailing dimension of {name} must be {sizes[key]}, got {a.shape[-1]}")
+    # inputs given once are repeated for every rollout (and step); outputs are allocated when absent
+    for name, rank, key in _ARGS:
+        a = args[name]
+        if name in ("state", "sensordata"):
+            if a is None:
+                args[name] = np.empty((nbatch, nstep, sizes[key]), dtype=np.float64)
+        elif a is not None:
+            full = (nbatch,) + ((nstep,) if rank == 3 else ()) + (a.shape[-1],)
+            if a.shape != full:
+                args[name] = np.ascontiguousarray(np.broadcast_to(a, full))
+    if len(models) == 1:
+        models = models * nbatch
+    return models, (data if isinstance(data, list) else [data]), nstep, args
+
+
+_shared = None          # the Rollout object kept alive by rollout(..., persistent_pool=True)
 
 
 def shutdown_persistent_pool():
-    """Shut down the persistent Rollout object optionally created by `rollout`."""
-    global persistent_rollout
-    if persistent_rollout is not None:
-        persistent_rollout.close()
-    persistent_rollout = None
+    """drop the persistent Rollout object that `rollout(..., persistent_pool=True)` may have created"""
+    global _shared
+    if _shared is not None:
+        _shared.close()
+        _shared = None
 
 
 atexit.register(shutdown_persistent_pool)
@@ -186,87 +202,22 @@ def rollout(model, data, initial_state, control=None, *, control_spec: int = mjS
             skip_checks: bool = False, nstep: Optional[int] = None, initial_warmstart=None,
             state=None, sensordata=None, chunk_size: Optional[int] = None,
             persistent_pool: bool = False):
-    """See `mujoco.rollout.rollout` (python/mujoco/rollout.py:261); returns (state, sensordata)."""
-    if not isinstance(data, list):
-        data = [data]
-    nthread = len(data) if len(data) > 1 else 0
-    global persistent_rollout
+    """Module-level entry point with the signature of `mujoco.rollout.rollout` (python/mujoco/rollout.py:261);
+    returns (state, sensordata).  The number of mjData objects stands for the reference's thread count and only
+    decides whether a persistent object is rebuilt."""
+    global _shared
+    nthread = len(data) if isinstance(data, list) and len(data) > 1 else 0
     if persistent_pool:
-        if persistent_rollout is None:
-            persistent_rollout = Rollout(nthread=nthread)
-        if persistent_rollout.nthread != nthread:
-            persistent_rollout.close()
-            persistent_rollout = Rollout(nthread=nthread)
-        rollout_ = persistent_rollout
+        if _shared is None or _shared.nthread != nthread:
+            shutdown_persistent_pool()
+            _shared = Rollout(nthread=nthread)
+        runner = _shared
     else:
-        rollout_ = Rollout(nthread=nthread)
+        runner = Rollout(nthread=nthread)
     try:
-        return rollout_.rollout(model, data, initial_state, control, control_spec=control_spec,
-                                skip_checks=skip_checks, nstep=nstep,
-                                initial_warmstart=initial_warmstart, state=state,
-                                sensordata=sensordata, chunk_size=chunk_size)
+        return runner.rollout(model, data, initial_state, control, control_spec=control_spec, skip_checks=skip_checks,
+                              nstep=nstep, initial_warmstart=initial_warmstart, state=state, sensordata=sensordata,
+                              chunk_size=chunk_size)
     finally:
-        if not persistent_pool:
-            rollout_.close()
-
-
-def _check_must_be_numeric(**kwargs):
-    for key, value in kwargs.items():
-        if value is None:
-            continue
-        if not isinstance(value, np.ndarray) and not isinstance(value, float):
-            raise ValueError(f"{key} must be a numpy array or float")
-
-
-def _check_number_of_dimensions(ndim, **kwargs):
-    for key, value in kwargs.items():
-        if value is None:
-            continue
-        if np.ndim(value) > ndim:
-            raise ValueError(f"{key} can have at most {ndim} dimensions")
-
-
-def _check_trailing_dimension(dim, **kwargs):
-    for key, value in kwargs.items():
-        if value is None:
-            continue
-        if value.shape[-1] != dim:
-            raise ValueError(f"trailing dimension of {key} must be {dim}, got {value.shape[-1]}")
-
-
-def _ensure_2d(arg):
-    if arg is None:
-        return None
-    return np.ascontiguousarray(np.atleast_2d(arg), dtype=np.float64)
-
-
-def _ensure_3d(arg):
-    if arg is None:
-        return None
-    arg = np.asarray(arg)
-    while arg.ndim < 3:
-        arg = arg[np.newaxis, ...]   # leading singleton dims only
-    return np.ascontiguousarray(arg, dtype=np.float64)
-
-
-def _infer_dimension(dim, value, **kwargs):
-    for name, array in kwargs.items():
-        if array is None:
-            continue
-        if array.shape[dim] != value:
-            if value == 1:
-                value = array.shape[dim]
-            elif array.shape[dim] != 1:
-                raise ValueError(f"dimension {dim} inferred as {value} but {name} has {array.shape[dim]}")
-    return value
-
-
-def _tile_if_required(array, dim0, dim1=None):
-    if array is None:
-        return None
-    reps = np.ones(array.ndim, dtype=int)
-    if array.shape[0] == 1:
-        reps[0] = dim0
-    if dim1 is not None and array.shape[1] == 1:
-        reps[1] = dim1
-    return np.tile(array, reps)
+        if runner is not _shared:
+            runner.close()

@@ -5,9 +5,10 @@
 // rollout = mj_setState + nstep x (set control, mj_step, mj_getState)), restated here as a plain thread team
 // over contiguous slices of the batch.
 //
-//   rollout_bench <model.mjb> <state0.bin> <ctrl.bin> <nroll> <nstep> <nthread> <solver|-1> <integrator|-1> [out_final.bin]
+//   rollout_bench <model.mjb> <state0.bin> <ctrl.bin> <nroll> <nstep> <nthread> <solver|-1> <integrator|-1> [out_final.bin [warm0.bin]]
 //
-// state0.bin: [nroll][nstate] doubles (mjSTATE_FULLPHYSICS); ctrl.bin: [nroll][nstep][nu] doubles.
+// state0.bin: [nroll][nstate] doubles (mjSTATE_FULLPHYSICS); ctrl.bin: [nroll][nstep][nu] doubles; warm0.bin (optional):
+// [nroll][nv] doubles, the rollouts' initial qacc_warmstart (the rollout API's initial_warmstart).
 // Prints one line: env_steps_per_s=<v> seconds=<t> nroll=<n> nstep=<k> nthread=<c> mean_ncon=.. mean_nefc=.. mean_niter=..
 #include <mujoco/mujoco.h>
 
@@ -36,6 +37,8 @@ int main(int argc, char** argv) {
   const int nstate = mj_stateSize(m, mjSTATE_FULLPHYSICS), nu = m->nu;
   const std::vector<double> state0 = read_doubles(argv[2], (size_t)nroll*nstate);
   const std::vector<double> ctrl = read_doubles(argv[3], (size_t)nroll*nstep*nu);
+  std::vector<double> warm0;
+  if (argc > 10) warm0 = read_doubles(argv[10], (size_t)nroll*m->nv);
   std::vector<double> final_state((size_t)nroll*nstate);
   if (nthread < 1) nthread = 1;
   if (nthread > nroll) nthread = nroll;
@@ -49,6 +52,7 @@ int main(int argc, char** argv) {
     for (int r = lo; r < hi; r++) {
       mj_resetData(m, d);                       // (cold warm start, like a rollout without initial_warmstart)
       mj_setState(m, d, state0.data() + (size_t)r*nstate, mjSTATE_FULLPHYSICS);
+      if (!warm0.empty()) mju_copy(d->qacc_warmstart, warm0.data() + (size_t)r*m->nv, m->nv);
       for (int k = 0; k < nstep; k++) {
         mju_copy(d->ctrl, ctrl.data() + ((size_t)r*nstep + k)*nu, nu);
         mj_step(m, d);

@@ -50,6 +50,8 @@ struct Runner {
     asm volatile("stmxcsr %0\n\tfnstcw %1" : "=m"(csr[0]), "=m"(csr[1]));
     for (int l = 0; l < MJH_WAVE; l++) {
       w.done[l] = 0;
+      w.arrive_row[l] = 0;
+      w.arrive_wave[l] = 0;
       // initial frame popped by mjh_ctx_switch: [mxcsr|x87cw] r15 r14 r13 r12 rbx rbp, return address
       uintptr_t top = ((uintptr_t)(w.stacks + kStack * (l + 1))) & ~(uintptr_t)15;
       uintptr_t* sp = (uintptr_t*)top;

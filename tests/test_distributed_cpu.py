@@ -19,13 +19,22 @@ def test_env_slices_partition_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_rollout_matches_golden(hostsim_lib):
+def _run_world(world, ntot):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_worker.py")]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MJHIP_TEST_NTOT=str(ntot))
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_two_rank_gloo_rollout_matches_golden(hostsim_lib):
+    _run_world(2, 6)
+
+
+def test_four_rank_gloo_ragged_split_and_sliced_gather(hostsim_lib):
+    # 7 environments over 4 ranks (2, 2, 2, 1): padded collectives, per-environment slices, pool of depth 2
+    _run_world(4, 7)

@@ -56,3 +56,44 @@ def test_rollout_equals_serial_step_property(rb, golden):
     a, _ = oracle_rollout(rb, m, fx["state0"][:1], fx["ctrl"][:1, :30])
     b, _ = oracle_rollout(rb, m, fx["state0"][:1], fx["ctrl"][:1, :30])
     assert np.array_equal(a, b)
+
+
+def test_cube_contact_discontinuity(rb):
+    """The evidence behind bench.py's glibc gate (>= 99 % of the cube's steps within 1e-6), from the REFERENCE ALONE:
+    move one qpos component of a golden cube_3x3x3 sample by ONE ulp and step the compiled reference -- about 1 % of such
+    perturbations move its own next state by more than 1e-6 (often by 1e-2 .. 1e-1), with contact, row and Newton
+    iteration counts unchanged: EPA's closest-face choice and the clipping of exactly parallel cubelet faces are
+    discontinuous in the poses (engine_collision_gjk.c:1358 epa, :1616 polygonClip).  Two correct libm's that differ
+    in the last bit of a sin / cos therefore cannot agree to 1e-6 on every step; full scan: tools/cube_discontinuity.py
+    -> profiles/r04/cube_discontinuity.txt (346 of 27520 perturbations above 1e-9, 340 above 1e-3)."""
+    fx = np.load(os.path.join(GOLDEN, "cube_3x3x3_steps.npz"))
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "cube_3x3x3.mjb"))
+    d = rb.MjData(m)
+    spec = rb.mjSTATE_FULLPHYSICS
+
+    def step(state, warm, ctrl):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, state, spec)
+        d.qacc_warmstart[:] = warm
+        d.ctrl[:] = ctrl
+        rb.mj_step(m, d)
+        return rb.mj_getState(m, d, spec).copy(), (int(d.ncon), int(d.nefc), int(d.solver_niter[0]))
+
+    trials, moved, jumps_same_counts = 0, 0, 0
+    for k in (2, 3, 14, 152):
+        s0, w, u = fx["state"][k], fx["warmstart"][k], fx["ctrl"][k]
+        base, ints = step(s0, w, u)
+        again, ints2 = step(s0, w, u)
+        assert np.array_equal(base, again) and ints == ints2          # the reference is deterministic
+        for j in range(m.nq):
+            for toward in (np.inf, -np.inf):
+                s1 = s0.copy()
+                s1[1 + j] = np.nextafter(s1[1 + j], toward)
+                nxt, ints1 = step(s1, w, u)
+                err = float(np.max(np.abs(nxt - base)/np.maximum(1, np.abs(base))))
+                trials += 1
+                moved += err > 1e-6
+                jumps_same_counts += err > 1e-3 and ints1 == ints
+    # rare, but far beyond the tolerance when it happens -- and invisible in the integer observables
+    assert jumps_same_counts >= 4, (trials, moved, jumps_same_counts)
+    assert 0.002 < moved/trials < 0.05, (trials, moved)

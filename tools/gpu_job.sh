@@ -1,0 +1,70 @@
+#!/bin/bash
+# One parameterised GPU job script (runs on the GPU box through gpurun; everything lands under gpurun_out/<tag>/).
+#   bash tools/gpu_job.sh <tag> <step> [<step> ...]
+# steps:
+#   suite            pytest -m gpu + smoke()
+#   driver           bench.py exactly as the driver runs it (--gpus 1 --steps 20 --warmup 5; carries the `configs` legs)
+#   default          bench.py with its defaults (500 steps), --no-legs
+#   bench:<args>     bench.py <args> (use , for spaces: bench:--config,cube,--steps,100)  -> bench_<n>.json
+#   ab:<VAR=VAL>:<args>   the same bench line with and without an environment variable (A/B)
+#   profile:<args>   tools/gpu_profile.sh <tag>_<n> <args>: bench + rocprofv3 kernel stats + PMC FETCH/WRITE passes
+#   stages:<MODEL>   per-stage profile (tools/stage_profile.py on tools/variants/libmjhip_prof.so)
+#   sq:<config>      SQ instruction counters of the rollout kernel (tools/gpu_sq.sh)
+#   tail             tools/tail_stats.py
+#   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
+# (the one-shot scripts of rounds 2-3 -- gpu_r2*.sh, gpu_r3[a-s].sh, gpu_flex*.sh -- were sequences of these steps;
+#  their outputs are quoted in profiles/r02* and profiles/r03*)
+set -u
+TAG=${1:?tag}; shift
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+n=0
+summ() { python - "$1" <<'PY'
+import json, sys
+try:
+    j = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+except Exception as exc:
+    print("  (no JSON line:", exc, ")"); sys.exit(0)
+ps = j.get("parity_sample", {})
+print("  value %.4g %s  ms/step %.4g  frac %.3g  parity_ok %s  kernel %s" % (j["value"], j["unit"], j["ms_per_step"], j["roofline"]["frac"], ps.get("ok"), j["roofline"].get("kernel")))
+for k, v in j.get("configs", {}).items():
+    print("  leg %-12s value %s parity_ok %s wall %.1fs %s" % (k, v.get("value"), v.get("parity_sample", {}).get("ok"), v.get("leg_wall_s", 0), v.get("error", "")))
+PY
+}
+for step in "$@"; do
+  n=$((n+1))
+  kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
+  args=${rest//,/ }
+  echo "== [$TAG] $step"
+  case $kind in
+    suite)
+      timeout 1700 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; tail -3 "$OUT/pytest_gpu.log"
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
+    driver)
+      ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real
+      summ "$OUT/bench_driver.json" ;;
+    default)
+      ( time timeout 900 python bench.py --no-legs > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real
+      summ "$OUT/bench_default.json" ;;
+    bench)
+      timeout 900 python bench.py $args > "$OUT/bench_$n.json" 2> "$OUT/bench_$n.err"; echo "  args: $args"; summ "$OUT/bench_$n.json" ;;
+    ab)
+      var=${rest%%:*}; a2=${rest#*:}; a2=${a2//,/ }
+      timeout 900 python bench.py $a2 > "$OUT/ab_${n}_base.json" 2> "$OUT/ab_$n.err"; echo "  base: $a2"; summ "$OUT/ab_${n}_base.json"
+      env "$var" timeout 900 python bench.py $a2 > "$OUT/ab_${n}_var.json" 2>> "$OUT/ab_$n.err"; echo "  $var"; summ "$OUT/ab_${n}_var.json" ;;
+    profile)
+      bash tools/gpu_profile.sh "${TAG}_$n" $args > "$OUT/profile_$n.log" 2>&1; tail -4 "$OUT/profile_$n.log"
+      mv "gpurun_out/prof_${TAG}_$n" "$OUT/prof_$n" 2>/dev/null ;;
+    stages)
+      MODEL=${rest:-humanoid} MJHIP_LIB=$PWD/tools/variants/libmjhip_prof.so timeout 900 python tools/stage_profile.py > "$OUT/stage_profile_${rest:-humanoid}.txt" 2>&1
+      head -40 "$OUT/stage_profile_${rest:-humanoid}.txt" ;;
+    sq)
+      bash tools/gpu_sq.sh ${rest:-humanoid} > "$OUT/sq_${rest:-humanoid}.log" 2>&1; tail -5 "$OUT/sq_${rest:-humanoid}.log" ;;
+    tail)
+      timeout 600 python tools/tail_stats.py > "$OUT/tail_stats.txt" 2>&1; tail -12 "$OUT/tail_stats.txt" ;;
+    resources)
+      python tools/kernel_resources.py > "$OUT/kernel_resource_usage.txt" 2>&1; cat "$OUT/kernel_resource_usage.txt" ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
