@@ -66,6 +66,15 @@ static inline void yield() { mjh_ctx_switch(&g_wave->ctx_sp[g_wave->cur], g_wave
 
 MJH_DEV int wv_lane() { return mjhsim::lane(); }
 MJH_DEV int wv_env() { return mjhsim::env(); }
+#include <stdio.h>
+// work counters of the convex narrowphase (mjh_convex.h), printed at exit when $MJH_RC_STATS is set
+namespace mjhsim { inline long long* rc_stats() {
+  static long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static bool reg = false;
+  if (!reg) { reg = true; if (getenv("MJH_RC_STATS")) atexit([]() { long long* q = rc_stats();
+    fprintf(stderr, "rc_stats: queries %lld distance-iterations %lld containment-tests %lld polytopes %lld expansions %lld multicontacts %lld\n",
+            q[0], q[1], q[2], q[3], q[4], q[5]); }); }
+  return c; } }
 MJH_DEV void wv_sync() { mjhsim::yield(); }
 
 // broadcast v from lane src to all lanes (src must be wave-uniform)
