@@ -1726,31 +1726,8 @@ MJH_DEV int rc_max_contacts(MREF M, int p) {
     return (t1 == MJH_GEOM_BOX && t2 == MJH_GEOM_BOX) ? 8 : 4;
   return 1;
 }
-// polyhedral pair, first half: the distance query alone.  Returns 1 when the shapes overlap (the penetration query has
-// to follow); the simplex, its vertex ids and the support caches are then parked in the owner's record slot.
-MJH_DEV int rc_poly_pair_distance(MREF M, BREF B, int e, RowPair& c, int p, real* park) {
-  crptr gx = MJH_F(B, geom_xpos, e);
-  crptr gm = MJH_F(B, geom_xmat, e);
-  const int L = rw_l();
-  const real margin = M.pair_margin[p];
-  c.a = rp_load_geom(M, c, 0, gx, gm, M.pair_geom1[p], margin);
-  c.b = rp_load_geom(M, c, 1, gx, gm, M.pair_geom2[p], margin);
-  wv_row_sync();
-  c.w1 = ld3(rp_frame(c, 0) + FR_POS); c.w2 = ld3(rp_frame(c, 1) + FR_POS);
-  c.spent = 0; c.cutoff = 0; c.tabled = 0;
-  rc_distance(M, c);
-  const int overlap = c.dist0 <= c.tol && c.nsim > 1 && !c.apart;
-  if (overlap) {
-    const real* sim = c.m.R + RO_SIM; const int* sid = c.m.I + IO_SIM;
-    int* pi = (int*)(park + 24);
-    for (int q = L; q < 24; q += 16) park[q] = sim[q];
-    if (L < 8) pi[L] = sid[L];
-    if (L == 8) { pi[8] = c.nsim; pi[9] = c.a.vcache; pi[10] = c.a.gcache; pi[11] = c.b.vcache; pi[12] = c.b.gcache; }
-  }
-  wv_row_sync();
-  return overlap;
-}
-// second half: polytope, expansion, multi-contact from the parked simplex; contact records into rec (= park)
+// Penetration phase of a polyhedral pair whose distance phase (ccd_poly_distance, below) found the shapes overlapping:
+// polytope, expansion, multi-contact from the parked simplex; contact records into rec (= the parking slot)
 MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, real* rec) {
   crptr gx = MJH_F(B, geom_xpos, e);
   crptr gm = MJH_F(B, geom_xmat, e);
@@ -1795,6 +1772,408 @@ MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, r
   return n;
 }
 
+// ---- lane-parallel distance phase for polyhedral pairs ------------------------------------------------------------------
+// The distance query of a box / mesh pair without margin needs no workspace beyond its simplex, and two out of three
+// pairs in reach of each other turn out to be apart after one to three iterations: run as four pairs per wavefront the
+// query is pure instruction-issue cost (SQ counters, profiles/r04*: 0.3 M vector instructions per cube step, as many as
+// the one-pair-per-lane code of round 3 that kept its workspace in global memory).  So the distance phase of THESE
+// pairs runs with ONE PAIR PER LANE AND THE SIMPLEX IN REGISTERS -- no memory traffic at all except the model's mesh
+// tables -- and only the pairs that overlap (their simplex parked in the owner's record slot) go on to the
+// row-cooperative penetration phase above.  The sub-simplex evaluation is the same table as rc_simplex_weights, filled
+// lazily: an entry (tetrahedron, 4 triangles, 6 segments) is computed when some lane of the wavefront needs it.
+struct LaneVert { V3 pa, pb; int ia, ib; };
+MJH_DEV V3 lv_mink(const LaneVert& v) { return V3{v.pa.x - v.pb.x, v.pa.y - v.pb.y, v.pa.z - v.pb.z}; }
+MJH_DEV V3 lv_pick(int k, V3 a, V3 b, V3 c, V3 d) {
+  return V3{k == 0 ? a.x : (k == 1 ? b.x : (k == 2 ? c.x : d.x)), k == 0 ? a.y : (k == 1 ? b.y : (k == 2 ? c.y : d.y)),
+            k == 0 ? a.z : (k == 1 ? b.z : (k == 2 ? c.z : d.z))};
+}
+MJH_DEV LaneVert lv_pickv(int k, const LaneVert& a, const LaneVert& b, const LaneVert& c, const LaneVert& d) {
+  LaneVert r;
+  r.pa = lv_pick(k, a.pa, b.pa, c.pa, d.pa); r.pb = lv_pick(k, a.pb, b.pb, c.pb, d.pb);
+  r.ia = k == 0 ? a.ia : (k == 1 ? b.ia : (k == 2 ? c.ia : d.ia));
+  r.ib = k == 0 ? a.ib : (k == 1 ? b.ib : (k == 2 ? c.ib : d.ib));
+  return r;
+}
+MJH_DEV void lv_put(int k, int on, LaneVert& a, LaneVert& b, LaneVert& c, LaneVert& d, const LaneVert& v) {
+  if (on && k == 0) a = v;
+  if (on && k == 1) b = v;
+  if (on && k == 2) c = v;
+  if (on && k == 3) d = v;
+}
+struct LaneShape { int g, kind, mesh, vcache, gcache; };
+
+// farthest point of the lane's shape along dir (box, mesh by exhaustive search, mesh by hill climbing), lanes with on == 0 idle
+template <class GX, class GM>
+MJH_DEV V3 lp_far(MREF M, GX gx, GM gm, LaneShape& s, V3 dir, int on) {
+  const int g = on ? s.g : 0;
+  const V3 ld = rw_to_local(gm + 9*g, dir);
+  V3 local{0, 0, 0};
+  if (on && s.kind == SK_BOX) {
+    const real sx = M.geom_size[3*g], sy = M.geom_size[3*g + 1], sz = M.geom_size[3*g + 2];
+    local = V3{ld.x >= 0 ? sx : -sx, ld.y >= 0 ? sy : -sy, ld.z >= 0 ? sz : -sz};
+    s.vcache = ((local.x > 0) ? 1 : 0) | ((local.y > 0) ? 2 : 0) | ((local.z > 0) ? 4 : 0);
+  }
+  const int all = on && s.kind == SK_MESH_ALL;
+  if (wv_any(all)) {
+    const int mesh = all ? s.mesh : 0;
+    const int vadr = 3*M.mesh_vertadr[mesh], nverts = all ? M.mesh_vertnum[mesh] : 0;
+    real top = -RC_FLTMAX;
+    int itop = 0;
+    if (all && s.vcache >= 0) { itop = s.vcache; top = rw_vdot(M, ld, vadr + 3*itop); }
+    for (int k = 0; wv_any(k < nverts); k++) {
+      if (k < nverts) { const real v = rw_vdot(M, ld, vadr + 3*k); if (v > top) { top = v; itop = k; } }
+    }
+    if (all) { s.vcache = itop; local = rw_mesh_vert(M, vadr + 3*itop); }
+  }
+  const int climb = on && s.kind == SK_MESH_CLIMB;
+  if (wv_any(climb)) {
+    const int mesh = climb ? s.mesh : 0;
+    const int vadr = 3*M.mesh_vertadr[mesh];
+    const int gadr = M.mesh_graphadr[mesh];
+    const int numvert = climb ? M.mesh_graph[gadr] : 0;
+    const int edgeadr = gadr + 2, globalid = gadr + 2 + numvert, localid = gadr + 2 + 2*numvert;
+    int cur = 0;
+    real top = 0;
+    if (climb) {
+      const int cx = (ld.x > 0.4) - (ld.x < -0.4) + 1;
+      const int cy = (ld.y > 0.4) - (ld.y < -0.4) + 1;
+      const int cz = (ld.z > 0.4) - (ld.z < -0.4) + 1;
+      const int seed = M.mesh_extrema[27*mesh + cx*9 + cy*3 + cz];
+      cur = seed;
+      if (s.gcache >= 0) {
+        const real vc = rw_vdot(M, ld, vadr + 3*M.mesh_graph[globalid + s.gcache]);
+        const real vs = rw_vdot(M, ld, vadr + 3*M.mesh_graph[globalid + seed]);
+        cur = (vs > vc) ? seed : s.gcache;
+      }
+      top = rw_vdot(M, ld, vadr + 3*M.mesh_graph[globalid + cur]);
+    }
+    int moving = climb;
+    while (wv_any(moving)) {
+      const int from = cur;
+      int k = moving ? M.mesh_graph[edgeadr + from] : 0;
+      int scanning = moving;
+      while (wv_any(scanning)) {
+        if (scanning) {
+          const int nb = M.mesh_graph[localid + k];
+          if (nb < 0) scanning = 0;
+          else {
+            const real v = rw_vdot(M, ld, vadr + 3*M.mesh_graph[globalid + nb]);
+            if (v > top) { top = v; cur = nb; }
+            k++;
+          }
+        }
+      }
+      if (moving && cur == from) moving = 0;
+    }
+    if (climb) {
+      s.gcache = cur;
+      s.vcache = M.mesh_graph[globalid + cur];
+      local = rw_mesh_vert(M, vadr + 3*s.vcache);
+    }
+  }
+  return rw_to_world(gm + 9*g, local, gx + 3*g);
+}
+template <class GX, class GM>
+MJH_DEV LaneVert lp_pair_far(MREF M, GX gx, GM gm, LaneShape& a, LaneShape& b, V3 d, V3 dn, int on) {
+  LaneVert v;
+  v.pa = lp_far(M, gx, gm, a, d, on);
+  v.pb = lp_far(M, gx, gm, b, dn, on);
+  v.ia = a.vcache; v.ib = b.vcache;
+  return v;
+}
+
+// triangle (s1 s2 s3) of the sub-simplex table: weights if the origin's foot point lies inside, else which of its
+// segments (bit 0: (s2,s3), 1: (s1,s3), 2: (s1,s2)) have to decide; degenerate: segment (s1,s2) alone (bit 3)
+MJH_DEV int lp_triangle(V3 s1, V3 s2, V3 s3, real* w) {
+  V3 foot;
+  if (rw_plane_foot(foot, s1, s2, s3)) return 8;
+  const real m23 = s2.y*s3.z - s2.z*s3.y - s1.y*s3.z + s1.z*s3.y + s1.y*s2.z - s1.z*s2.y;
+  const real m13 = s2.x*s3.z - s2.z*s3.x - s1.x*s3.z + s1.z*s3.x + s1.x*s2.z - s1.z*s2.x;
+  const real m12 = s2.x*s3.y - s2.y*s3.x - s1.x*s3.y + s1.y*s3.x + s1.x*s2.y - s1.y*s2.x;
+  const real g1 = fabs(m23), g2 = fabs(m13), g3 = fabs(m12);
+  const int drop = (g1 >= g2 && g1 >= g3) ? 0 : (g2 >= g3 ? 1 : 2);
+  const real area = drop == 0 ? m23 : (drop == 1 ? m13 : m12);
+  const int u = drop == 0 ? 1 : 0, v = drop == 2 ? 1 : 2;
+  const real a0 = comp(s1, u), a1 = comp(s1, v), b0 = comp(s2, u), b1 = comp(s2, v), c0 = comp(s3, u), c1 = comp(s3, v);
+  const real q0 = comp(foot, u), q1 = comp(foot, v);
+  const real ka = q0*b1 + q1*c0 + b0*c1 - q0*c1 - q1*b0 - c0*b1;
+  const real kb = q0*c1 + q1*a0 + c0*a1 - q0*a1 - q1*c0 - a0*c1;
+  const real kc = q0*a1 + q1*b0 + a0*b1 - q0*b1 - q1*a0 - b0*a1;
+  const int ina = rw_sign_match(area, ka), inb = rw_sign_match(area, kb), inc = rw_sign_match(area, kc);
+  if (ina && inb && inc) { w[0] = ka/area; w[1] = kb/area; w[2] = kc/area; return 0; }
+  return (ina ? 0 : 1) | (inb ? 0 : 2) | (inc ? 0 : 4);
+}
+// the triangle's answer from its segments' weights (same precedence as the row version): e23, e13, e12 = weights of
+// segments (s2,s3), (s1,s3), (s1,s2)
+MJH_DEV void lp_triangle_fallback(int need, V3 s1, V3 s2, V3 s3, const real* e23, const real* e13, const real* e12, real* w) {
+  if (need & 8) { w[0] = e12[0]; w[1] = e12[1]; w[2] = 0; return; }
+  real nearest = RC_DBLMAX;
+  w[0] = w[1] = w[2] = 0;
+  if (need & 1) {
+    const V3 x{e23[0]*s2.x + e23[1]*s3.x, e23[0]*s2.y + e23[1]*s3.y, e23[0]*s2.z + e23[1]*s3.z};
+    w[0] = 0; w[1] = e23[0]; w[2] = e23[1];
+    nearest = dot(x, x);
+  }
+  if (need & 2) {
+    const V3 x{e13[0]*s1.x + e13[1]*s3.x, e13[0]*s1.y + e13[1]*s3.y, e13[0]*s1.z + e13[1]*s3.z};
+    const real dd = dot(x, x);
+    if (dd < nearest) { w[0] = e13[0]; w[1] = 0; w[2] = e13[1]; nearest = dd; }
+  }
+  if (need & 4) {
+    const V3 x{e12[0]*s1.x + e12[1]*s2.x, e12[0]*s1.y + e12[1]*s2.y, e12[0]*s1.z + e12[1]*s2.z};
+    const real dd = dot(x, x);
+    if (dd < nearest) { w[0] = e12[0]; w[1] = e12[1]; w[2] = 0; }
+  }
+}
+// weights of the lane's simplex points P[0..n) (n = 2..4) for the point closest to the origin; lanes with on == 0 idle
+MJH_DEV void lp_simplex_weights(const V3* P, int n, int on, real* lam) {
+  // what the lane needs from the table: triangles t = 0..3 (the triangle without point t), segments 0..5 in the
+  // order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+  int need_tri = 0, need_seg = 0, tet_fall = 0;
+  real k1 = 0, k2 = 0, k3 = 0, k4 = 0, vol = 1;
+  if (on && n == 4) {
+    k1 = -rw_det(P[1], P[2], P[3]);
+    k2 = rw_det(P[0], P[2], P[3]);
+    k3 = -rw_det(P[0], P[1], P[3]);
+    k4 = rw_det(P[0], P[1], P[2]);
+    vol = k1 + k2 + k3 + k4;
+    const int in1 = rw_sign_match(vol, k1), in2 = rw_sign_match(vol, k2), in3 = rw_sign_match(vol, k3), in4 = rw_sign_match(vol, k4);
+    if (!(in1 && in2 && in3 && in4)) { tet_fall = (in1 ? 0 : 1) | (in2 ? 0 : 2) | (in3 ? 0 : 4) | (in4 ? 0 : 8); need_tri = tet_fall; }
+  } else if (on && n == 3) need_tri = 8;
+  else if (on && n == 2) need_seg = 1;
+  real tw[4][3];
+  int tneed[4] = {0, 0, 0, 0};
+  for (int t = 0; t < 4; t++) {
+    tw[t][0] = tw[t][1] = tw[t][2] = 0;
+    if (!wv_any((need_tri >> t) & 1)) continue;
+    const int i = t == 0 ? 1 : 0, j = t <= 1 ? 2 : 1, k = t == 3 ? 2 : 3;
+    if ((need_tri >> t) & 1) {
+      tneed[t] = lp_triangle(P[i], P[j], P[k], tw[t]);
+      if (tneed[t] & 1) need_seg |= 1 << rw_edge_slot(j, k);
+      if (tneed[t] & 2) need_seg |= 1 << rw_edge_slot(i, k);
+      if (tneed[t] & 12) need_seg |= 1 << rw_edge_slot(i, j);
+    }
+  }
+  real sw[6][2];
+  for (int q = 0; q < 6; q++) {
+    sw[q][0] = sw[q][1] = 0;
+    if (!wv_any((need_seg >> q) & 1)) continue;
+    const int a = q < 3 ? 0 : (q < 5 ? 1 : 2), b = q < 3 ? q + 1 : (q < 5 ? q - 1 : 3);
+    if ((need_seg >> q) & 1) rw_segment_weights(P[a], P[b], sw[q][0], sw[q][1]);
+  }
+  for (int t = 0; t < 4; t++) {
+    if (!wv_any(tneed[t] != 0)) continue;
+    const int i = t == 0 ? 1 : 0, j = t <= 1 ? 2 : 1, k = t == 3 ? 2 : 3;
+    if (tneed[t]) lp_triangle_fallback(tneed[t], P[i], P[j], P[k], sw[rw_edge_slot(j, k)], sw[rw_edge_slot(i, k)], sw[rw_edge_slot(i, j)], tw[t]);
+  }
+  if (!on) return;
+  if (n == 2) { lam[0] = sw[0][0]; lam[1] = sw[0][1]; lam[2] = 0; lam[3] = 0; }
+  else if (n == 3) { lam[0] = tw[3][0]; lam[1] = tw[3][1]; lam[2] = tw[3][2]; lam[3] = 0; }
+  else if (!tet_fall) { lam[0] = k1/vol; lam[1] = k2/vol; lam[2] = k3/vol; lam[3] = k4/vol; }
+  else {
+    real r0 = 0, r1 = 0, r2 = 0, r3 = 0, nearest = RC_DBLMAX;
+    if (tet_fall & 1) {
+      const real a = tw[0][0], b = tw[0][1], c = tw[0][2];
+      const V3 x{a*P[1].x + b*P[2].x + c*P[3].x, a*P[1].y + b*P[2].y + c*P[3].y, a*P[1].z + b*P[2].z + c*P[3].z};
+      r0 = 0; r1 = a; r2 = b; r3 = c;
+      nearest = dot(x, x);
+    }
+    if (tet_fall & 2) {
+      const real a = tw[1][0], b = tw[1][1], c = tw[1][2];
+      const V3 x{a*P[0].x + b*P[2].x + c*P[3].x, a*P[0].y + b*P[2].y + c*P[3].y, a*P[0].z + b*P[2].z + c*P[3].z};
+      const real dd = dot(x, x);
+      if (dd < nearest) { r0 = a; r1 = 0; r2 = b; r3 = c; nearest = dd; }
+    }
+    if (tet_fall & 4) {
+      const real a = tw[2][0], b = tw[2][1], c = tw[2][2];
+      const V3 x{a*P[0].x + b*P[1].x + c*P[3].x, a*P[0].y + b*P[1].y + c*P[3].y, a*P[0].z + b*P[1].z + c*P[3].z};
+      const real dd = dot(x, x);
+      if (dd < nearest) { r0 = a; r1 = b; r2 = 0; r3 = c; nearest = dd; }
+    }
+    if (tet_fall & 8) {
+      const real a = tw[3][0], b = tw[3][1], c = tw[3][2];
+      const V3 x{a*P[0].x + b*P[1].x + c*P[2].x, a*P[0].y + b*P[1].y + c*P[2].y, a*P[0].z + b*P[1].z + c*P[2].z};
+      const real dd = dot(x, x);
+      if (dd < nearest) { r0 = a; r1 = b; r2 = c; r3 = 0; }
+    }
+    lam[0] = r0; lam[1] = r1; lam[2] = r2; lam[3] = r3;
+  }
+}
+
+// layout of a parked simplex in a record slot: 24 reals (4 x point on A, point on B), then ints: 8 vertex ids, nsim,
+// the four support caches
+MJH_DEV void lp_park(real* park, const LaneVert& s0, const LaneVert& s1, const LaneVert& s2, const LaneVert& s3) {
+  int* pi = (int*)(park + 24);
+  const LaneVert* v[4] = {&s0, &s1, &s2, &s3};
+  for (int q = 0; q < 4; q++) {
+    st3(park + 6*q, v[q]->pa); st3(park + 6*q + 3, v[q]->pb);
+    pi[2*q] = v[q]->ia; pi[2*q + 1] = v[q]->ib;
+  }
+}
+MJH_DEV LaneVert lp_unpark(const real* park, int q) {
+  const int* pi = (const int*)(park + 24);
+  LaneVert v;
+  v.pa = ld3(park + 6*q); v.pb = ld3(park + 6*q + 3); v.ia = pi[2*q]; v.ib = pi[2*q + 1];
+  return v;
+}
+
+// Distance phase of the lane's polyhedral pair p (p < 0: none).  Returns 1 when the shapes overlap: the simplex, its
+// size and the support caches are then parked in the lane's record slot for rc_poly_pair_penetration.  (gjk :198 with
+// gjkIntersect :420 for pairs without margin: dist_cutoff 0, discrete geoms)
+MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
+  MJH_ENTER(M_, B_, e_);
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  real* park = rc_records(M, B, e, wv_lane());
+  const int have = p >= 0;
+  const int iters = M.s.ccd_N;
+  const real tol = M.o.ccd_tolerance;
+  LaneShape a, b;
+  {
+    const int g1 = have ? M.pair_geom1[p] : 0, g2 = have ? M.pair_geom2[p] : 0;
+    auto shape = [&](int g) {
+      LaneShape s;
+      s.g = g; s.vcache = -1; s.gcache = -1; s.mesh = -1; s.kind = SK_BOX;
+      if (M.geom_type[g] == MJH_GEOM_MESH) {
+        s.mesh = M.geom_dataid[g];
+        s.kind = (M.mesh_graphadr[s.mesh] < 0 || M.mesh_vertnum[s.mesh] < 10) ? SK_MESH_ALL : SK_MESH_CLIMB;
+      }
+      return s;
+    };
+    a = shape(g1); b = shape(g2);
+  }
+  LaneVert s0, s1, s2, s3;
+  s0.pa = s0.pb = V3{0, 0, 0}; s0.ia = s0.ib = -1;
+  s1 = s0; s2 = s0; s3 = s0;
+  V3 x = ld3(gx + 3*a.g) - ld3(gx + 3*b.g);
+  real xlen = rw_len(x), xlen_before = 0;
+  int n = 0, k = 0, try_containment = 1;
+  int apart = 0, nsim = 0;
+  real dist0 = 0;
+  real lam[4] = {0, 0, 0, 0};
+  int st = have ? 0 : 2;              // 0 iterating, 1 leaves the loop for the closing support query, 2 finished
+  while (wv_any(st == 0)) {
+    int it = st == 0;
+    if (have) RC_COUNT(1);
+    if (it && !(k < iters)) { st = 1; it = 0; }
+    if (it && (xlen < MJH_MINVAL || fabs(xlen_before - xlen) < MJH_MINVAL)) { st = 1; it = 0; }
+    const V3 dn = rw_scl(x, 1/xlen);
+    const LaneVert f = lp_pair_far(M, gx, gm, a, b, rw_scl(dn, -1), dn, it);
+    lv_put(n, it, s0, s1, s2, s3, f);
+    const V3 s = lv_mink(f);
+    if (it && dot(x, x - s) < 0) { st = 1; it = 0; }
+    if (it && dot(x, s) > 0) { apart = 1; nsim = 0; dist0 = RC_DBLMAX; st = 2; it = 0; }
+    // the tetrahedron test once the simplex has four points
+    const int ct = it && n == 3 && try_containment;
+    if (wv_any(ct)) {
+      if (ct) lp_park(park, s0, s1, s2, s3);
+      int p0 = 0, p1 = 1, p2 = 2, p3 = 3, kk = k, ans = -1, run = ct;
+      while (wv_any(run)) {
+        if (run && !(kk < iters)) run = 0;
+        const V3 m0 = lv_mink(s0), m1 = lv_mink(s1), m2 = lv_mink(s2), m3 = lv_mink(s3);
+        real sd[4]; V3 nr[4];
+        for (int q = 0; q < 4; q++) {
+          const int ia = q == 0 ? p2 : (q == 2 ? p1 : p0);
+          const int ib = q == 0 ? p1 : (q == 1 ? p2 : (q == 2 ? p0 : p1));
+          const int ic = q == 3 ? p2 : p3;
+          const V3 pt = lv_pick(ia, m0, m1, m2, m3);
+          V3 nrm = cross(lv_pick(ic, m0, m1, m2, m3) - pt, lv_pick(ib, m0, m1, m2, m3) - pt);
+          const real n2 = dot(nrm, nrm);
+          sd[q] = RC_DBLMAX;
+          if (n2 > RC_TINY2 && n2 < RC_HUGE2) { nrm = rw_scl(nrm, 1/sqrt(n2)); sd[q] = dot(nrm, pt); }
+          nr[q] = nrm;
+        }
+        if (run && (!sd[3] || !sd[2] || !sd[1] || !sd[0])) run = 0;
+        const int lo = (sd[0] < sd[1]) ? 0 : 1, hi = (sd[2] < sd[3]) ? 2 : 3;
+        const real dlo = lo ? sd[1] : sd[0], dhi = hi == 2 ? sd[2] : sd[3];
+        const int near = (dlo < dhi) ? lo : hi;
+        const real dnear = (dlo < dhi) ? dlo : dhi;
+        if (run && dnear > 0) {
+          const LaneVert t0 = lv_pickv(p0, s0, s1, s2, s3), t1 = lv_pickv(p1, s0, s1, s2, s3),
+                         t2 = lv_pickv(p2, s0, s1, s2, s3), t3 = lv_pickv(p3, s0, s1, s2, s3);
+          s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+          ans = 1; run = 0;
+        }
+        const V3 nrm = near == 0 ? nr[0] : (near == 1 ? nr[1] : (near == 2 ? nr[2] : nr[3]));
+        const LaneVert g = lp_pair_far(M, gx, gm, a, b, nrm, V3{-nrm.x, -nrm.y, -nrm.z}, run);
+        lv_put(rw_pick4(p0, p1, p2, p3, near), run, s0, s1, s2, s3, g);
+        if (run && dot(nrm, lv_mink(g)) < 0) { ans = 0; run = 0; }
+        if (run) {
+          const int i = (near + 1) & 3, j = (near + 2) & 3;
+          const int vi = rw_pick4(p0, p1, p2, p3, i), vj = rw_pick4(p0, p1, p2, p3, j);
+          p0 = i == 0 ? vj : (j == 0 ? vi : p0);
+          p1 = i == 1 ? vj : (j == 1 ? vi : p1);
+          p2 = i == 2 ? vj : (j == 2 ? vi : p2);
+          p3 = i == 3 ? vj : (j == 3 ? vi : p3);
+          kk++;
+        }
+      }
+      if (ct) {
+        if (have) RC_COUNT(2);
+        if (ans != -1) {
+          apart = ans == 0; dist0 = ans > 0 ? 0 : RC_DBLMAX; nsim = ans > 0 ? 4 : 0;
+          st = 2; it = 0;
+        } else {
+          // undecided: the simplex as it was, the iteration count where the test stopped
+          s0 = lp_unpark(park, 0); s1 = lp_unpark(park, 1); s2 = lp_unpark(park, 2); s3 = lp_unpark(park, 3);
+          k = kk;
+          try_containment = 0;
+        }
+      }
+    }
+    if (wv_any(it && n > 0)) {
+      const V3 P[4] = {lv_mink(s0), lv_mink(s1), lv_mink(s2), lv_mink(s3)};
+      lp_simplex_weights(P, n + 1, it && n > 0, lam);
+    }
+    if (it) {
+      if (n == 0) { lam[0] = 1; lam[1] = lam[2] = lam[3] = 0; }
+      // keep the points that carry weight, in order
+      int idx[4] = {0, 0, 0, 0}, m = 0;
+      for (int i = 0; i < 4; i++) if (lam[i]) { idx[m] = i; lam[m] = lam[i]; m++; }
+      const LaneVert t0 = lv_pickv(idx[0], s0, s1, s2, s3), t1 = lv_pickv(idx[1], s0, s1, s2, s3),
+                     t2 = lv_pickv(idx[2], s0, s1, s2, s3), t3 = lv_pickv(idx[3], s0, s1, s2, s3);
+      if (m > 0) s0 = t0;
+      if (m > 1) s1 = t1;
+      if (m > 2) s2 = t2;
+      if (m > 3) s3 = t3;
+      n = m;
+      if (n < 1) { nsim = 0; dist0 = RC_DBLMAX; apart = 1; st = 2; }
+      else {
+        const V3 p0 = lv_mink(s0), p1 = lv_mink(s1), p2 = lv_mink(s2), p3 = lv_mink(s3);
+        if (n == 1) x = V3{lam[0]*p0.x, lam[0]*p0.y, lam[0]*p0.z};
+        else if (n == 2) x = V3{lam[0]*p0.x + lam[1]*p1.x, lam[0]*p0.y + lam[1]*p1.y, lam[0]*p0.z + lam[1]*p1.z};
+        else if (n == 3) x = V3{lam[0]*p0.x + lam[1]*p1.x + lam[2]*p2.x, lam[0]*p0.y + lam[1]*p1.y + lam[2]*p2.y,
+                                lam[0]*p0.z + lam[1]*p1.z + lam[2]*p2.z};
+        else x = V3{lam[0]*p0.x + lam[1]*p1.x + lam[2]*p2.x + lam[3]*p3.x, lam[0]*p0.y + lam[1]*p1.y + lam[2]*p2.y + lam[3]*p3.y,
+                    lam[0]*p0.z + lam[1]*p1.z + lam[2]*p2.z + lam[3]*p3.z};
+        xlen_before = xlen;
+        xlen = rw_len(x);
+        if (n == 4) st = 1; else k++;
+      }
+    }
+  }
+  // the closing support query along x: apart after all?
+  {
+    const int fin = st == 1;
+    const V3 dn = rw_scl(x, 1/xlen);
+    const LaneVert f = lp_pair_far(M, gx, gm, a, b, rw_scl(dn, -1), dn, fin);
+    if (fin) {
+      if (dot(x, lv_mink(f)) > 0) apart = 1;
+      nsim = n;
+      dist0 = (n == 4 && !apart) ? 0 : xlen;
+    }
+  }
+  const int overlap = have && dist0 <= tol && nsim > 1 && !apart;
+  if (have) RC_COUNT(0);
+  if (overlap) {
+    lp_park(park, s0, s1, s2, s3);
+    int* pi = (int*)(park + 24);
+    pi[8] = nsim; pi[9] = a.vcache; pi[10] = a.gcache; pi[11] = b.vcache; pi[12] = b.gcache;
+  }
+  wv_sync();
+  return overlap;
+}
+
 // Every lane of the wavefront brings (at most) one pair: the pairs are listed, row r takes entries r, r + 4, ... of the
 // list, the results go to the owning lane's records.  Polyhedral pairs (box / mesh against box / mesh, no margin: the
 // pairs that may return several contacts) go through TWO passes: the distance query for all of them, then -- the
@@ -1812,14 +2191,23 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   wv_sync();
   RowPair c;
   rc_attach(M, B, e, c);
+  // (single-contact pairs -- curved shapes, margins -- take the whole query at once, four at a time)
   for (int t = row; t < total; t += 4) {
     const int owner = head[64 + t], pp = head[t];
-    int n;
-    if (rc_max_contacts(M, pp) > 1) n = rc_poly_pair_distance(M, B, e, c, pp, rc_records(M, B, e, owner)) ? -1 : 0;
-    else n = rc_geom_pair(M, B, e, c, pp, rc_records(M, B, e, owner));
+    if (rc_max_contacts(M, pp) > 1) continue;
+    const int n = rc_geom_pair(M, B, e, c, pp, rc_records(M, B, e, owner));
     if (rw_l() == 0) head[128 + owner] = n;
   }
   wv_converge();
+  wv_sync();
+  // first pass of the polyhedral pairs: one pair per lane, simplex in registers
+  {
+    const int poly = p >= 0 && rc_max_contacts(M, p) > 1;
+    if (wv_any(poly)) {
+      const int overlap = ccd_poly_distance(M, B, e, poly ? p : -1);
+      if (poly) head[128 + wv_lane()] = overlap ? -1 : 0;
+    }
+  }
   wv_sync();
   // second pass over the pairs marked -1
   const unsigned long long deep = wv_ballot(head[128 + wv_lane()] < 0);
