@@ -1607,6 +1607,9 @@ MJH_DEV void rc_attach(MREF M, BREF B, int e, RowPair& c) {
   const MJH_CONST_AS DSizes& s = M.s;
   const int row = wv_lane() >> 4;
   real* fast = MJH_F(B, ccd_row, e).p + (size_t)row*s.ccd_row_reals;
+#if defined(MJH_CCD_ASSUME_LDS) && !defined(MJH_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_assume(__builtin_amdgcn_is_shared(fast));
+#endif
   c.m.R = fast;
   c.m.I = (int*)(fast + s.ccd_row_freal);
   char* slow = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes + 192*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real)
@@ -1800,6 +1803,7 @@ MJH_DEV void lv_put(int k, int on, LaneVert& a, LaneVert& b, LaneVert& c, LaneVe
   if (on && k == 2) c = v;
   if (on && k == 3) d = v;
 }
+MJH_DEV real rw_pickr(const real* v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
 struct LaneShape { int g, kind, mesh, vcache, gcache; };
 
 // farthest point of the lane's shape along dir (box, mesh by exhaustive search, mesh by hill climbing), lanes with on == 0 idle
@@ -1943,6 +1947,7 @@ MJH_DEV void lp_simplex_weights(const V3* P, int n, int on, real* lam) {
   else if (on && n == 2) need_seg = 1;
   real tw[4][3];
   int tneed[4] = {0, 0, 0, 0};
+#pragma unroll
   for (int t = 0; t < 4; t++) {
     tw[t][0] = tw[t][1] = tw[t][2] = 0;
     if (!wv_any((need_tri >> t) & 1)) continue;
@@ -1955,12 +1960,14 @@ MJH_DEV void lp_simplex_weights(const V3* P, int n, int on, real* lam) {
     }
   }
   real sw[6][2];
+#pragma unroll
   for (int q = 0; q < 6; q++) {
     sw[q][0] = sw[q][1] = 0;
     if (!wv_any((need_seg >> q) & 1)) continue;
     const int a = q < 3 ? 0 : (q < 5 ? 1 : 2), b = q < 3 ? q + 1 : (q < 5 ? q - 1 : 3);
     if ((need_seg >> q) & 1) rw_segment_weights(P[a], P[b], sw[q][0], sw[q][1]);
   }
+#pragma unroll
   for (int t = 0; t < 4; t++) {
     if (!wv_any(tneed[t] != 0)) continue;
     const int i = t == 0 ? 1 : 0, j = t <= 1 ? 2 : 1, k = t == 3 ? 2 : 3;
@@ -2072,6 +2079,7 @@ MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
         if (run && !(kk < iters)) run = 0;
         const V3 m0 = lv_mink(s0), m1 = lv_mink(s1), m2 = lv_mink(s2), m3 = lv_mink(s3);
         real sd[4]; V3 nr[4];
+#pragma unroll
         for (int q = 0; q < 4; q++) {
           const int ia = q == 0 ? p2 : (q == 2 ? p1 : p0);
           const int ib = q == 0 ? p1 : (q == 1 ? p2 : (q == 2 ? p0 : p1));
@@ -2127,15 +2135,20 @@ MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
     }
     if (it) {
       if (n == 0) { lam[0] = 1; lam[1] = lam[2] = lam[3] = 0; }
-      // keep the points that carry weight, in order
-      int idx[4] = {0, 0, 0, 0}, m = 0;
-      for (int i = 0; i < 4; i++) if (lam[i]) { idx[m] = i; lam[m] = lam[i]; m++; }
-      const LaneVert t0 = lv_pickv(idx[0], s0, s1, s2, s3), t1 = lv_pickv(idx[1], s0, s1, s2, s3),
-                     t2 = lv_pickv(idx[2], s0, s1, s2, s3), t3 = lv_pickv(idx[3], s0, s1, s2, s3);
-      if (m > 0) s0 = t0;
-      if (m > 1) s1 = t1;
-      if (m > 2) s2 = t2;
-      if (m > 3) s3 = t3;
+      // keep the points that carry weight, in order: slot d takes the d-th point with a non-zero weight (selects only:
+      // an array indexed by a running count would live in scratch memory)
+      const int k0 = lam[0] != 0, k1 = lam[1] != 0, k2 = lam[2] != 0, k3 = lam[3] != 0;
+      const int r1 = k0, r2 = k0 + k1, r3 = k0 + k1 + k2;          // rank of point i among the kept ones
+      const int m = r3 + k3;
+      const int i0 = k0 ? 0 : (k1 ? 1 : (k2 ? 2 : 3));
+      const int i1 = (k1 && r1 == 1) ? 1 : ((k2 && r2 == 1) ? 2 : 3);
+      const int i2 = (k2 && r2 == 2) ? 2 : 3;
+      const real l0 = rw_pickr(lam, i0), l1 = rw_pickr(lam, i1), l2 = rw_pickr(lam, i2), l3 = lam[3];
+      const LaneVert t0 = lv_pickv(i0, s0, s1, s2, s3), t1 = lv_pickv(i1, s0, s1, s2, s3), t2 = lv_pickv(i2, s0, s1, s2, s3);
+      if (m > 0) { s0 = t0; lam[0] = l0; }
+      if (m > 1) { s1 = t1; lam[1] = l1; }
+      if (m > 2) { s2 = t2; lam[2] = l2; }
+      if (m > 3) lam[3] = l3;
       n = m;
       if (n < 1) { nsim = 0; dist0 = RC_DBLMAX; apart = 1; st = 2; }
       else {
@@ -2189,6 +2202,13 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   if (p >= 0) { const int t = wv_rank_lt(have); head[t] = p; head[64 + t] = wv_lane(); }
   head[128 + wv_lane()] = 0;
   wv_sync();
+#ifdef MJH_PROFILE
+  // sub-stage accumulators (us): 25 single-contact pairs, 46 lane-parallel distance phase, 47 row-cooperative penetration phase
+  long long ptick = wv_clock();
+  auto tick = [&](int slot) { const long long c_ = wv_clock(); if (wv_lane() == 0) MJH_G(B, prof, e)[slot] += (real)(c_ - ptick)*0.01; ptick = c_; };
+#else
+  auto tick = [](int) {};
+#endif
   RowPair c;
   rc_attach(M, B, e, c);
   // (single-contact pairs -- curved shapes, margins -- take the whole query at once, four at a time)
@@ -2200,6 +2220,7 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   }
   wv_converge();
   wv_sync();
+  tick(25);
   // first pass of the polyhedral pairs: one pair per lane, simplex in registers
   {
     const int poly = p >= 0 && rc_max_contacts(M, p) > 1;
@@ -2209,6 +2230,7 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
     }
   }
   wv_sync();
+  tick(46);
   // second pass over the pairs marked -1
   const unsigned long long deep = wv_ballot(head[128 + wv_lane()] < 0);
   const int ndeep = __builtin_popcountll(deep);
@@ -2224,6 +2246,7 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
     wv_converge();
     wv_sync();
   }
+  tick(47);
   return p >= 0 ? head[128 + wv_lane()] : 0;
 }
 
