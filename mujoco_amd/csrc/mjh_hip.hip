@@ -21,6 +21,7 @@
 MJH_DEFINE_WAVE_KERNELS(wv, 1, 4, 0)
 MJH_DECLARE_WAVE_LAUNCHERS(wl)
 MJH_DECLARE_WAVE_LAUNCHERS(wv2)     // mjh_kern_wide.hip: the generic kernels with a 256-VGPR budget
+MJH_DECLARE_WAVE_LAUNCHERS(wn)      // mjh_kern_mw.hip: MJH_MW wavefronts per environment
 extern "C" bool mjh_launch_forward_soa(const DModel* M, const DBatch* B, int nenv, int stages, int lds, void* stream);
 extern "C" bool mjh_launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
 extern "C" bool mjh_launch_integrate(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs* A, void* stream);
@@ -136,6 +137,7 @@ struct Backend {
     if (soa) return mjh_launch_forward_soa(M, B, nenv, stages, lds, stream);
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_forward_wl(M, B, nenv, stages, lds, stream);
+      case MJH_VAR_MULTIWAVE: return mjh_launch_forward_wn(M, B, nenv, stages, lds, stream);
       default: return wide_regs(nenv) ? mjh_launch_forward_wv2(M, B, nenv, stages, lds, stream)
                                       : mjh_launch_forward_wv(M, B, nenv, stages, lds, stream);
     }
@@ -143,12 +145,14 @@ struct Backend {
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void* stream) {
     switch (variant) {
       case MJH_VAR_LEAN: return mjh_launch_rollout_wl(M, B, nenv, &A, lds, stream);
+      case MJH_VAR_MULTIWAVE: return mjh_launch_rollout_wn(M, B, nenv, &A, lds, stream);
       default: return wide_regs(nenv) ? mjh_launch_rollout_wv2(M, B, nenv, &A, lds, stream)
                                       : mjh_launch_rollout_wv(M, B, nenv, &A, lds, stream);
     }
   }
   static const char* rollout_kernel_name(int variant, int nenv) {
-    return variant == MJH_VAR_LEAN ? "mjh_k_rollout_wl" : wide_regs(nenv) ? "mjh_k_rollout_wv2" : "mjh_k_rollout_wv";
+    return variant == MJH_VAR_LEAN ? "mjh_k_rollout_wl" : variant == MJH_VAR_MULTIWAVE ? "mjh_k_rollout_wn" :
+           wide_regs(nenv) ? "mjh_k_rollout_wv2" : "mjh_k_rollout_wv";
   }
   static bool launch_balance(const DBatch* B, int nenv, void* stream) {
     (void)nenv;

@@ -57,6 +57,40 @@ static inline bool mjh_raise_lds(const void* kernel, size_t bytes) {
     return hipGetLastError() == hipSuccess;                                                                    \
   }
 
+// Multi-wavefront workgroups (mjh_modes.h: wn + wq): MJH_MW wavefronts per environment; wave 0 runs the step, the
+// others wait for the stages it posts.  WPE = wavefronts per SIMD the register budget is sized for.
+#define MJH_DEFINE_MULTIWAVE_KERNELS(WPE)                                                                      \
+  __global__ __launch_bounds__(MJH_WAVE*MJH_MW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                 \
+  void mjh_k_forward_wn(const DModel* __restrict__ M, const DBatch* __restrict__ B, int stages) {              \
+    const int e = (int)blockIdx.x;                                                                             \
+    if (e >= B->nenv) return;                                                                                  \
+    if (threadIdx.x >= MJH_WAVE) { mw_helper_loop(wv_const_ref(M), wv_const_ref(B)); return; }                 \
+    wn::forward_or_euler(wv_const_ref(M), wv_const_ref(B), e, stages);                                         \
+    mw_release_helpers(wv_const_ref(B));                                                                       \
+  }                                                                                                            \
+  __global__ __launch_bounds__(MJH_WAVE*MJH_MW) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))                 \
+  void mjh_k_rollout_wn(const DModel* __restrict__ M, const DBatch* __restrict__ B, RolloutArgs A) {           \
+    const int w = (int)blockIdx.x;                                                                             \
+    if (w >= (A.nlaunch ? A.nlaunch : B->nenv)) return;                                                        \
+    if (threadIdx.x >= MJH_WAVE) { mw_helper_loop(wv_const_ref(M), wv_const_ref(B)); return; }                 \
+    wn::rollout_env(wv_const_ref(M), wv_const_ref(B), A.nlaunch ? w : B->perm[w], A);                          \
+    mw_release_helpers(wv_const_ref(B));                                                                       \
+  }                                                                                                            \
+  extern "C" bool mjh_launch_forward_wn(const DModel* M, const DBatch* B, int nenv, int stages, int lds,       \
+                                        void* stream) {                                                        \
+    const size_t bytes = (size_t)lds + MJH_MW_LDS_TAIL;                                                        \
+    if (!mjh_raise_lds((const void*)mjh_k_forward_wn, bytes)) return false;                                    \
+    hipLaunchKernelGGL(mjh_k_forward_wn, dim3(nenv), dim3(MJH_WAVE*MJH_MW), bytes, (hipStream_t)stream, M, B, stages); \
+    return hipGetLastError() == hipSuccess;                                                                    \
+  }                                                                                                            \
+  extern "C" bool mjh_launch_rollout_wn(const DModel* M, const DBatch* B, int nenv, const RolloutArgs* A,      \
+                                        int lds, void* stream) {                                               \
+    const size_t bytes = (size_t)lds + MJH_MW_LDS_TAIL;                                                        \
+    if (!mjh_raise_lds((const void*)mjh_k_rollout_wn, bytes)) return false;                                    \
+    hipLaunchKernelGGL(mjh_k_rollout_wn, dim3(nenv), dim3(MJH_WAVE*MJH_MW), bytes, (hipStream_t)stream, M, B, *A); \
+    return hipGetLastError() == hipSuccess;                                                                    \
+  }
+
 #define MJH_DECLARE_WAVE_LAUNCHERS(NS)                                                                         \
   extern "C" bool mjh_launch_forward_##NS(const DModel* M, const DBatch* B, int nenv, int stages, int lds,     \
                                           void* stream);                                                       \

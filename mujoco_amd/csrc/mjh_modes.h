@@ -22,22 +22,31 @@
 #include "mjh_math.h"
 #include "mjh_types.h"
 
-#if !defined(MJH_BUILD_WV) && !defined(MJH_BUILD_WS) && !defined(MJH_BUILD_LN) && !defined(MJH_BUILD_WL)
+#if !defined(MJH_BUILD_WV) && !defined(MJH_BUILD_WS) && !defined(MJH_BUILD_LN) && !defined(MJH_BUILD_WL) && !defined(MJH_BUILD_WN)
 #define MJH_BUILD_WV 1
 #define MJH_BUILD_WS 1
 #define MJH_BUILD_LN 1
 #define MJH_BUILD_WL 1
+#define MJH_BUILD_WN 1
 #endif
 
 // kernel variants (mjhipBatch_::variant, RolloutArgs consumers): which namespace steps a batch
 // (round 2 also carried "lean2" / "lean4": two / four environments per wavefront.  Measured 2-3x slower
 // at every batch size of interest (profiles/r02_variants) and deleted in round 3.)
-enum { MJH_VAR_GENERIC = 0, MJH_VAR_LEAN = 1, MJH_NVARIANT = 2 };
+// MJH_VAR_MULTIWAVE: MJH_MW wavefronts per environment (namespaces wn + wq below), the generic feature set; chosen for
+// flex models at launches of at most one workgroup per CU (BASELINE config 5)
+enum { MJH_VAR_GENERIC = 0, MJH_VAR_LEAN = 1, MJH_VAR_MULTIWAVE = 2, MJH_NVARIANT = 3 };
 static inline int mjh_variant_nsub(int) { return 1; }
-static inline int mjh_variant_features(int v) { return v == MJH_VAR_GENERIC ? MJH_FT_ALL : MJH_FT_LEAN; }
+static inline int mjh_variant_features(int v) { return v == MJH_VAR_LEAN ? MJH_FT_LEAN : MJH_FT_ALL; }
 static inline const char* mjh_variant_name(int v) {
-  return v == MJH_VAR_GENERIC ? "generic" : "lean";
+  return v == MJH_VAR_GENERIC ? "generic" : (v == MJH_VAR_LEAN ? "lean" : "multiwave");
 }
+// stages every wavefront of a multi-wavefront workgroup runs together (mw_exec below)
+enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH_MWS_TAVEL, MJH_MWS_COMVEL, MJH_MWS_PASSIVE,
+       MJH_MWS_RNE };
+// bytes at the end of a multi-wavefront workgroup's LDS block that the residency plan leaves alone: the command word
+// wave 0 posts for the helper wavefronts
+#define MJH_MW_LDS_TAIL 64
 
 // ------------------------------------------------------------------------------------------------
 // wave mode (one environment per wavefront)
@@ -45,6 +54,8 @@ static inline const char* mjh_variant_name(int v) {
 #define MJH_W 64
 #define MJH_LANE_MODE 0
 #define MJH_DEVN MJH_DEVN_WAVE
+// a stage call that a multi-wavefront workgroup runs on all of its wavefronts (namespace wn redefines this)
+#define MJH_WIDE(id, call) call
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 // entry of an out-of-line stage function: its arguments arrive in VGPRs; all three are wave-uniform
 // namespace wv serves environment-major batches only (B.soa == 0): telling the compiler makes every
@@ -87,16 +98,140 @@ namespace ws {
 #undef MJH_W
 #undef MJH_FOR_LANES
 #undef MJH_ENTER
+#undef MJH_WIDE
 
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
 
+
+// ------------------------------------------------------------------------------------------------
+// multi-wavefront workgroups: MJH_MW wavefronts per environment
+//
+// A launch of at most one workgroup per CU (256 environments of a flex model: BASELINE config 5) leaves three of a
+// CU's four SIMDs idle under the one-wavefront mapping.  Here a workgroup is MJH_MW wavefronts:
+//   * wave 0 runs the whole step (namespace wn: the wave mapping above, except that wv_sync() is a memory fence and
+//     not a workgroup barrier -- the other wavefronts are not there to meet it);
+//   * the helper wavefronts wait at a workgroup barrier; when wave 0 reaches a stage whose work is nothing but
+//     independent items between barriers (MJH_FOR_LANES loops separated by wv_sync(): kinematics, comPos, the flex
+//     position / edge / passive passes, comVel, rne -- no wavefront collective inside), it posts the stage's id in
+//     LDS, meets the helpers at the barrier, and ALL wavefronts run the stage from namespace wq, where the "group" is
+//     the workgroup: MJH_W = 64 MJH_MW lanes, wv_lane() = thread index in the workgroup, wv_sync() = s_barrier.
+//     Same items, same arithmetic per item: results are bit-identical to the one-wavefront mapping.
+// The LDS block (and its residency plan) belongs to the workgroup, so every wavefront sees the same fields.
+// ------------------------------------------------------------------------------------------------
+#if MJH_BUILD_WN
+#define MJH_W (MJH_WAVE*MJH_MW)
+#define MJH_LANE_MODE 0
+#define MJH_DEVN MJH_DEVN_WAVE
+#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
+#define MJH_WIDE(id, call) call
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
+                              if (B.soa != 0) __builtin_unreachable()
+#define MJH_FEATURES MJH_FT_ALL
+namespace wq {
+#ifdef MJH_HOSTSIM
+MJH_DEV int wv_lane() { return mjhsim::lane(); }
+// (all fibers of the emulated workgroup pass the same barriers inside a stage: one switch each, in lockstep)
+MJH_DEV void wv_sync() { mjhsim::yield(); }
+#else
+MJH_DEV int wv_lane() { return (int)threadIdx.x; }
+MJH_DEV void wv_sync() { __syncthreads(); }
+#endif
+#include "mjh_flex.h"
+#include "mjh_smooth.h"
+}
+#undef MJH_FEATURES
+#undef MJH_W
+#undef MJH_FOR_LANES
+#undef MJH_WIDE
+#undef MJH_ENTER
+
+// a posted stage, run by every wavefront of the workgroup
+MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
+  switch (id) {
+    case MJH_MWS_KIN: wq::stage_kinematics(M, B, e); if (M.s.nflex) wq::stage_flex_pos(M, B, e); break;
+    case MJH_MWS_COMPOS: wq::stage_compos(M, B, e); break;
+    case MJH_MWS_FLEXEDGES: wq::stage_flex_edges(M, B, e); break;
+    case MJH_MWS_TAVEL: wq::stage_ten_act_velocity(M, B, e); break;
+    case MJH_MWS_COMVEL: wq::stage_comvel(M, B, e); break;
+    case MJH_MWS_PASSIVE: wq::stage_passive(M, B, e); break;
+    case MJH_MWS_RNE: wq::stage_rne(M, B, e); break;
+    default: break;
+  }
+}
+// the workgroup barrier at which the helper wavefronts wait for a stage, and the command word in LDS
+#ifdef MJH_HOSTSIM
+MJH_DEV void mw_barrier() {
+  mjhsim::WaveSim* w = mjhsim::g_wave;
+  const long long mine = ++w->arrive_all[w->cur];
+  for (;;) {
+    bool all = true;
+    for (int l = 0; l < w->nfib; l++) if (w->arrive_all[l] < mine) all = false;
+    if (all) break;
+    mjhsim::yield();
+  }
+  mjhsim::yield();
+}
+#else
+MJH_DEV void mw_barrier() { __syncthreads(); }
+#endif
+MJH_DEV volatile int* mw_command(BREF B) { return (volatile int*)(mjh_lds() + B.lds_bytes); }
+// wave 0: post stage `id` for environment e and run it together with the helpers
+MJH_DEV void mw_run(MREF M, BREF B, int e, int id) {
+  volatile int* cmd = mw_command(B);
+  if (wv_lane() == 0) { cmd[0] = id; cmd[1] = e; }
+  mw_barrier();
+  mw_exec(M, B, e, id);
+}
+// the helper wavefronts' whole program
+MJH_DEV void mw_helper_loop(MREF M, BREF B) {
+  volatile int* cmd = mw_command(B);
+  for (;;) {
+    mw_barrier();
+    const int id = wv_uniform_i(cmd[0]), e = wv_uniform_i(cmd[1]);
+    if (id == MJH_MWS_EXIT) break;
+    mw_exec(M, B, e, id);
+  }
+}
+MJH_DEV void mw_release_helpers(BREF B) {
+  volatile int* cmd = mw_command(B);
+  if (wv_lane() == 0) cmd[0] = MJH_MWS_EXIT;
+  mw_barrier();
+}
+
+#define MJH_W 64
+#define MJH_LANE_MODE 0
+#define MJH_DEVN MJH_DEVN_WAVE
+#define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
+#define MJH_WIDE(id, call) mw_run(M, B, e, id)
+#define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
+                              if (B.soa != 0) __builtin_unreachable()
+#define MJH_FEATURES MJH_FT_ALL
+namespace wn {
+// (wave 0 of a multi-wavefront workgroup: phases are separated by a memory fence -- its own accesses complete, in
+// order -- not by the workgroup barrier the helpers would have to meet)
+#ifdef MJH_HOSTSIM
+MJH_DEV void wv_sync() { mjhsim::yield(); }
+#else
+MJH_DEV void wv_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+#endif
+#include "mjh_stages.inc"
+}
+#undef MJH_FEATURES
+#undef MJH_W
+#undef MJH_FOR_LANES
+#undef MJH_WIDE
+#undef MJH_ENTER
+#undef MJH_LANE_MODE
+#undef MJH_DEVN
+#endif   // MJH_BUILD_WN
 // ------------------------------------------------------------------------------------------------
 // lane mode
 // ------------------------------------------------------------------------------------------------
 #define MJH_W 1
 #define MJH_LANE_MODE 1
 #define MJH_DEVN MJH_DEVN_LANE
+#define MJH_WIDE(id, call) call
 #define MJH_FOR_LANES(i, n) for (int i = 0; i < (n); i++)
 // (stage functions are inlined into the kernel here: descriptors are already uniform, e is per lane)
 #define MJH_ENTER(M_, B_, e_) MREF M = M_; BREF B = B_; const int e = e_
@@ -122,3 +257,4 @@ MJH_DEV int wv_any(int pred) { return pred != 0; }
 #undef MJH_DEVN
 #undef MJH_FOR_LANES
 #undef MJH_ENTER
+#undef MJH_WIDE

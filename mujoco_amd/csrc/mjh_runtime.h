@@ -345,7 +345,7 @@ MJHIP_API int mjhip_set_option(struct mjModel_* mm, const char* name, double val
   return -2;
 }
 
-static int default_variant(const mjhipModel_* M, int soa);
+static int default_variant(const mjhipModel_* M, int soa, int nenv);
 
 MJHIP_API mjhipBatch* mjhip_batch_create(mjhipModel* M, int nenv, int device) {
   // $MJHIP_LAYOUT = aos | soa overrides the default layout
@@ -433,7 +433,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   if (const char* ev = getenv("MJHIP_BALANCE")) Bt->balance = atoi(ev) != 0;
   if (const char* ev = getenv("MJHIP_MFMA")) { Bt->D.mfma = atoi(ev) != 0; Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr); }
   // kernel variant: the leanest mapping whose feature set covers the model ($MJHIP_VARIANT overrides)
-  Bt->variant = default_variant(M, Bt->soa);
+  Bt->variant = default_variant(M, Bt->soa, Bt->nenv);
   // ($MJHIP_VARIANT is a preference: batches it cannot serve -- SoA layout, models that need
   // features the lean kernels lack -- keep their default)
   if (const char* ev = getenv("MJHIP_VARIANT")) (void)mjhip_batch_set_variant(Bt, ev);
@@ -477,7 +477,8 @@ MJHIP_API int mjhip_batch_nenv(const mjhipBatch* Bt) { return Bt ? Bt->nenv : -1
 static bool variant_ok(const mjhipModel_* M, int soa, int variant, std::string* why) {
   if (variant < 0 || variant >= MJH_NVARIANT) { if (why) *why = "unknown variant"; return false; }
   if (variant == MJH_VAR_GENERIC) return true;
-  if (soa) { if (why) *why = "the lean kernel variants step environment-major (AoS) batches only"; return false; }
+  if (soa) { if (why) *why = "the lean and multi-wavefront kernel variants step environment-major (AoS) batches only"; return false; }
+  if (variant == MJH_VAR_MULTIWAVE) return true;
   const int missing = M->H.s.features & ~mjh_variant_features(variant);
   if (missing) {
     if (why) { char b[96]; snprintf(b, sizeof b, "the model needs features 0x%x that the lean kernels do not carry", missing); *why = b; }
@@ -485,7 +486,13 @@ static bool variant_ok(const mjhipModel_* M, int soa, int variant, std::string* 
   }
   return true;
 }
-static int default_variant(const mjhipModel_* M, int soa) {
+static int default_variant(const mjhipModel_* M, int soa, int nenv) {
+  // flex models at launches of at most one workgroup per CU: MJH_MW wavefronts per environment ($MJHIP_MW=0 turns
+  // the choice off: A/B runs)
+  {
+    static const int mw = [] { const char* ev = getenv("MJHIP_MW"); return ev ? atoi(ev) : 1; }();
+    if (mw && !soa && M->H.s.nflex > 0 && nenv <= Backend::num_cus()) return MJH_VAR_MULTIWAVE;
+  }
   // one environment per wavefront: measured fastest at the batch sizes of interest (4096 envs on
   // 1024 SIMDs: profiles/r02_variants -- with every environment resident the step is bound by the
   // dependent chain of one environment, and the two / four environments of a shared wavefront run
@@ -498,7 +505,7 @@ MJHIP_API int mjhip_batch_set_variant(mjhipBatch* Bt, const char* name) {
   if (!Bt || !name) return -1;
   int v = -1;
   for (int k = 0; k < MJH_NVARIANT; k++) if (!strcmp(name, mjh_variant_name(k))) v = k;
-  if (!strcmp(name, "auto")) v = default_variant(Bt->model, Bt->soa);
+  if (!strcmp(name, "auto")) v = default_variant(Bt->model, Bt->soa, Bt->nenv);
   std::string why;
   if (!variant_ok(Bt->model, Bt->soa, v, &why)) {
     set_err(std::string("mjhip_batch_set_variant(") + name + "): " + why);
@@ -526,7 +533,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
   if (lds_bytes < 0) lds_bytes = 0;
   Bt->lds_request = lds_bytes;
-  const int max_lds = Backend::max_lds() / mjh_variant_nsub(Bt->variant);
+  const int max_lds = Backend::max_lds() / mjh_variant_nsub(Bt->variant) - (Bt->variant == MJH_VAR_MULTIWAVE ? MJH_MW_LDS_TAIL : 0);
   if (lds_bytes > max_lds) lds_bytes = max_lds;
 
   // equality constraints read kinematics / velocity quantities long after their usual lifetimes

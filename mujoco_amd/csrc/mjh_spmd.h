@@ -17,6 +17,8 @@
 #include <stdint.h>
 
 #define MJH_WAVE 64
+// wavefronts of a multi-wavefront workgroup (mjh_modes.h: namespaces wn / wq; low-occupancy launches of flex models)
+#define MJH_MW 4
 
 #ifdef MJH_HOSTSIM
 // ------------------------------------------------------------------------------------------------
@@ -43,10 +45,13 @@ static inline uint64_t wv_uniform_u64(uint64_t v) { return v; }
 namespace mjhsim {
 struct WaveSim {
   void* sched_sp;            // saved stack pointers of the scheduler and of the 64 lane fibers
-  void* ctx_sp[MJH_WAVE];    // (mjh_ctx_switch, hostsim.cpp: a register-only switch, no syscalls)
+  void* ctx_sp[MJH_WAVE*MJH_MW];    // (mjh_ctx_switch, hostsim.cpp: a register-only switch, no syscalls)
   char* stacks;
-  int cur;            // lane currently running
-  int done[MJH_WAVE];
+  int cur;            // lane currently running (0 .. nfib-1; wavefront = cur / 64)
+  int nfib;           // fibers of the emulated workgroup: 64, or 64*MJH_MW for the multi-wavefront kernels
+  int done[MJH_WAVE*MJH_MW];
+  long long arrive_all[MJH_WAVE*MJH_MW];   // workgroup barrier of the multi-wavefront kernels
+  long long orscratch[MJH_WAVE*MJH_MW];
   int env;            // blockIdx.x
   int reverse;        // run lanes 63..0 instead of 0..63 (race detector)
   // scratch for cross-lane primitives

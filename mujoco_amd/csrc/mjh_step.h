@@ -134,20 +134,20 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
   MJH_ENTER(M_, B_, e_);
   const int pgs = !MJH_HAS(MJH_FT_PRIMAL) || (M.o.solver == MJH_SOL_PGS);
   if (stages & MJH_STAGE_KINEMATICS) {
-    MJH_RUN(MJH_T_KIN, { stage_kinematics(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflex) stage_flex_pos(M, B, e); });
+    MJH_RUN(MJH_T_KIN, MJH_WIDE(MJH_MWS_KIN, { stage_kinematics(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflex) stage_flex_pos(M, B, e); }));
   }
   // (collision needs nothing but the frames kinematics just produced)
   if (stages & MJH_STAGE_COLLISION) MJH_RUN(MJH_T_COLLISION, stage_collision(M, B, e));
   if (stages & MJH_STAGE_KINEMATICS) {
-    MJH_RUN(MJH_T_COMPOS, stage_compos(M, B, e));
-    MJH_RUN(MJH_T_TENDON, { stage_tendon(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflexedge) stage_flex_edges(M, B, e); });
+    MJH_RUN(MJH_T_COMPOS, MJH_WIDE(MJH_MWS_COMPOS, stage_compos(M, B, e)));
+    MJH_RUN(MJH_T_TENDON, { stage_tendon(M, B, e); if (MJH_HAS(MJH_FT_FLEX) && M.s.nflexedge) MJH_WIDE(MJH_MWS_FLEXEDGES, stage_flex_edges(M, B, e)); });
   }
   if (stages & MJH_STAGE_TRANSMISSION) MJH_RUN(MJH_T_TRANSMISSION, stage_transmission(M, B, e));
   if (stages & MJH_STAGE_VELOCITY) {
-    MJH_RUN(MJH_T_TAVEL, stage_ten_act_velocity(M, B, e));
-    MJH_RUN(MJH_T_COMVEL, stage_comvel(M, B, e));
-    MJH_RUN(MJH_T_PASSIVE, stage_passive(M, B, e));
-    MJH_RUN(MJH_T_RNE, stage_rne(M, B, e));
+    MJH_RUN(MJH_T_TAVEL, MJH_WIDE(MJH_MWS_TAVEL, stage_ten_act_velocity(M, B, e)));
+    MJH_RUN(MJH_T_COMVEL, MJH_WIDE(MJH_MWS_COMVEL, stage_comvel(M, B, e)));
+    MJH_RUN(MJH_T_PASSIVE, MJH_WIDE(MJH_MWS_PASSIVE, stage_passive(M, B, e)));
+    MJH_RUN(MJH_T_RNE, MJH_WIDE(MJH_MWS_RNE, stage_rne(M, B, e)));
   }
   if (stages & MJH_STAGE_INERTIA) {
     MJH_RUN(MJH_T_CRB, stage_crb(M, B, e, (stages & MJH_STAGE_NOPARK) != 0));

@@ -35,23 +35,25 @@ struct Runner {
   mjhsim::WaveSim w;
   std::function<void()> body;
   Runner() {
-    w.stacks = (char*)malloc(kStack * MJH_WAVE);
+    w.stacks = (char*)malloc(kStack * MJH_WAVE * MJH_MW);
     w.reverse = getenv("MJH_HOSTSIM_REVERSE") && atoi(getenv("MJH_HOSTSIM_REVERSE"));
   }
   ~Runner() { free(w.stacks); }
   // first frame of every lane fiber: runs the kernel body, marks the lane done and hands control
   // back to the scheduler for good
   static void fiber_entry();
-  void run(int env, const std::function<void()>& fn) {
+  void run(int env, const std::function<void()>& fn, int nfib = MJH_WAVE) {
     body = fn;
     w.env = env;
+    w.nfib = nfib;
     mjhsim::g_wave = &w;
     unsigned csr[2] = {0, 0};
     asm volatile("stmxcsr %0\n\tfnstcw %1" : "=m"(csr[0]), "=m"(csr[1]));
-    for (int l = 0; l < MJH_WAVE; l++) {
+    for (int l = 0; l < MJH_WAVE*MJH_MW; l++) w.done[l] = 1;
+    for (int l = 0; l < nfib; l++) {
       w.done[l] = 0;
-      w.arrive_row[l] = 0;
-      w.arrive_wave[l] = 0;
+      w.arrive_all[l] = 0;
+      if (l < MJH_WAVE) { w.arrive_row[l] = 0; w.arrive_wave[l] = 0; }
       // initial frame popped by mjh_ctx_switch: [mxcsr|x87cw] r15 r14 r13 r12 rbx rbp, return address
       uintptr_t top = ((uintptr_t)(w.stacks + kStack * (l + 1))) & ~(uintptr_t)15;
       uintptr_t* sp = (uintptr_t*)top;
@@ -61,11 +63,11 @@ struct Runner {
       *--sp = (uintptr_t)csr[0] | ((uintptr_t)csr[1] << 32);
       w.ctx_sp[l] = sp;
     }
-    int remaining = MJH_WAVE;
+    int remaining = nfib;
     while (remaining) {
       remaining = 0;
-      for (int k = 0; k < MJH_WAVE; k++) {
-        int l = w.reverse ? MJH_WAVE - 1 - k : k;
+      for (int k = 0; k < nfib; k++) {
+        int l = w.reverse ? nfib - 1 - k : k;
         if (w.done[l]) continue;
         w.cur = l;
         mjhsim::mjh_ctx_switch(&w.sched_sp, w.ctx_sp[l]);
@@ -114,6 +116,18 @@ struct Backend {
   static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
   // run NS's body for the nsub environments of every emulated wavefront (lanes of group g step
   // environment wave*nsub + g; a group past the end of the batch exits at once, like the kernels)
+  // multi-wavefront workgroups (mjh_modes.h: wn + wq): fibers 0..63 are wave 0, the others the helper wavefronts
+  template <class F>
+  static void run_multiwave(int nenv, int lds, const DModel* M, const DBatch* B, F main_body) {
+    for (int w = nenv - 1; w >= 0; w--) {
+      poison_lds(lds + MJH_MW_LDS_TAIL);
+      runner()->run(w, [&]() {
+        if (mjhsim::lane() >= MJH_WAVE) { mw_helper_loop(*M, *B); return; }
+        main_body(wv_env());
+        mw_release_helpers(*B);
+      }, MJH_WAVE*MJH_MW);
+    }
+  }
   template <class F>
   static void run_waves(int nenv, int nsub, int lds, F body) {
     for (int w = (nenv + nsub - 1)/nsub - 1; w >= 0; w--) {     // (back to front: order must not matter)
@@ -127,17 +141,19 @@ struct Backend {
   static bool launch_forward(const DModel* M, const DBatch* B, int nenv, int stages, int lds, int soa, int variant, void*) {
     if (soa) run_waves(nenv, 1, lds, [&](int e) { ws::forward_or_euler(*M, *B, e, stages); });
     else if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int e) { wl::forward_or_euler(*M, *B, e, stages); });
+    else if (variant == MJH_VAR_MULTIWAVE) run_multiwave(nenv, lds, M, B, [&](int e) { wn::forward_or_euler(*M, *B, e, stages); });
     else run_waves(nenv, 1, lds, [&](int e) { wv::forward_or_euler(*M, *B, e, stages); });
     return true;
   }
   static bool launch_rollout(const DModel* M, const DBatch* B, int nenv, const RolloutArgs& A, int lds, int variant, void*) {
     // (slot w of the launch steps environment perm[w], like the kernels)
     if (variant == MJH_VAR_LEAN) run_waves(nenv, 1, lds, [&](int w) { wl::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
+    else if (variant == MJH_VAR_MULTIWAVE) run_multiwave(nenv, lds, M, B, [&](int w) { wn::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
     else run_waves(nenv, 1, lds, [&](int w) { wv::rollout_env(*M, *B, A.nlaunch ? w : B->perm[w], A); });
     return true;
   }
   // the launch order of the next rollout launch: environments by decreasing work estimate
-  static const char* rollout_kernel_name(int variant, int) { return variant == MJH_VAR_LEAN ? "hostsim:wl" : "hostsim:wv"; }
+  static const char* rollout_kernel_name(int variant, int) { return variant == MJH_VAR_LEAN ? "hostsim:wl" : variant == MJH_VAR_MULTIWAVE ? "hostsim:wn" : "hostsim:wv"; }
   static bool launch_balance(const DBatch* B, int nenv, void*) {
     std::vector<int> idx(nenv);
     for (int i = 0; i < nenv; i++) idx[i] = i;
