@@ -161,16 +161,25 @@ MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
 }
 // the workgroup barrier at which the helper wavefronts wait for a stage, and the command word in LDS
 #ifdef MJH_HOSTSIM
+// (emulation: helper fibers PARK at the barrier -- the scheduler skips them -- until the last fiber of wave 0 arrives;
+// everyone leaves in the same scheduler pass, see wv_converge)
 MJH_DEV void mw_barrier() {
   mjhsim::WaveSim* w = mjhsim::g_wave;
   const long long mine = ++w->arrive_all[w->cur];
+  bool last = true;
+  for (int l = 0; l < w->nfib; l++) if (w->arrive_all[l] < mine) last = false;
+  if (last) {
+    w->all_done = w->round;
+    for (int l = 0; l < w->nfib; l++) w->parked[l] = 0;
+  } else if (w->cur >= MJH_WAVE) {
+    w->parked[w->cur] = 1;
+  }
   for (;;) {
     bool all = true;
     for (int l = 0; l < w->nfib; l++) if (w->arrive_all[l] < mine) all = false;
-    if (all) break;
+    if (all && w->round >= w->all_done + 2) break;
     mjhsim::yield();
   }
-  mjhsim::yield();
 }
 #else
 MJH_DEV void mw_barrier() { __syncthreads(); }

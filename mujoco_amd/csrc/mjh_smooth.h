@@ -197,7 +197,20 @@ MJH_DEV void tree_accumulate_to_parent(MREF M, P0 x, int n, int include_world) {
       int p = M.body_level_ids[a0 + k];
       int c0 = M.body_child_adr[p], c1 = M.body_child_adr[p+1];
       real acc = x[n*p + q];
-      for (int c = c0; c < c1; c++) acc += x[n*M.body_child_ids[c] + q];
+      // (a flex body hangs hundreds of vertex bodies on one parent: the children's values are fetched sixteen at a
+      // time -- independent loads in flight together -- and added in order)
+      int c = c0;
+      for (; c + 16 <= c1; c += 16) {
+        int id[16];
+        real v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) id[u] = M.body_child_ids[c + u];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = x[n*id[u] + q];
+#pragma unroll
+        for (int u = 0; u < 16; u++) acc += v[u];
+      }
+      for (; c < c1; c++) acc += x[n*M.body_child_ids[c] + q];
       x[n*p + q] = acc;
     }
     wv_sync();

@@ -18,7 +18,9 @@
 
 #define MJH_WAVE 64
 // wavefronts of a multi-wavefront workgroup (mjh_modes.h: namespaces wn / wq; low-occupancy launches of flex models)
-#define MJH_MW 4
+#ifndef MJH_MW
+#define MJH_MW 8
+#endif
 
 #ifdef MJH_HOSTSIM
 // ------------------------------------------------------------------------------------------------
@@ -51,7 +53,9 @@ struct WaveSim {
   int nfib;           // fibers of the emulated workgroup: 64, or 64*MJH_MW for the multi-wavefront kernels
   int done[MJH_WAVE*MJH_MW];
   long long arrive_all[MJH_WAVE*MJH_MW];   // workgroup barrier of the multi-wavefront kernels
-  long long orscratch[MJH_WAVE*MJH_MW];
+  int parked[MJH_WAVE*MJH_MW];             // helper fibers waiting at that barrier: the scheduler skips them
+  long long round;                         // scheduler passes so far
+  long long row_done[MJH_WAVE/16], wave_done, all_done;   // pass in which the last fiber reached the current barrier
   int env;            // blockIdx.x
   int reverse;        // run lanes 63..0 instead of 0..63 (race detector)
   // scratch for cross-lane primitives
@@ -352,28 +356,34 @@ MJH_DEV unsigned wv_row_ballot(int pred) {
 // memory written by a row-mate before the call is visible after it (LDS / global exchange inside a row)
 MJH_DEV void wv_row_sync() { mjhsim::yield(); }
 // barriers of the emulation: every lane of the row / the wavefront has arrived
+// (every fiber leaves a barrier in the SAME scheduler pass -- two passes after the last one arrived -- so that the
+// one-switch-per-phase lockstep the other primitives rely on holds again afterwards)
 MJH_DEV void wv_row_converge() {
   mjhsim::WaveSim* w = mjhsim::g_wave;
   const int b = w->cur & ~15;
   const long long mine = ++w->arrive_row[w->cur];
+  bool last = true;
+  for (int l = 0; l < 16; l++) if (w->arrive_row[b + l] < mine) last = false;
+  if (last) w->row_done[b >> 4] = w->round;
   for (;;) {
     bool all = true;
     for (int l = 0; l < 16; l++) if (w->arrive_row[b + l] < mine) all = false;
-    if (all) break;
+    if (all && w->round >= w->row_done[b >> 4] + 2) break;
     mjhsim::yield();
   }
-  mjhsim::yield();
 }
 MJH_DEV void wv_converge() {
   mjhsim::WaveSim* w = mjhsim::g_wave;
   const long long mine = ++w->arrive_wave[w->cur];
+  bool last = true;
+  for (int l = 0; l < MJH_WAVE; l++) if (w->arrive_wave[l] < mine) last = false;
+  if (last) w->wave_done = w->round;
   for (;;) {
     bool all = true;
-    for (int l = 0; l < MJH_WAVE; l++) if (!w->done[l] && w->arrive_wave[l] < mine) all = false;
-    if (all) break;
+    for (int l = 0; l < MJH_WAVE; l++) if (w->arrive_wave[l] < mine) all = false;
+    if (all && w->round >= w->wave_done + 2) break;
     mjhsim::yield();
   }
-  mjhsim::yield();
 }
 
 #else

@@ -52,6 +52,7 @@ struct Runner {
     for (int l = 0; l < MJH_WAVE*MJH_MW; l++) w.done[l] = 1;
     for (int l = 0; l < nfib; l++) {
       w.done[l] = 0;
+      w.parked[l] = 0;
       w.arrive_all[l] = 0;
       if (l < MJH_WAVE) { w.arrive_row[l] = 0; w.arrive_wave[l] = 0; }
       // initial frame popped by mjh_ctx_switch: [mxcsr|x87cw] r15 r14 r13 r12 rbx rbp, return address
@@ -63,12 +64,16 @@ struct Runner {
       *--sp = (uintptr_t)csr[0] | ((uintptr_t)csr[1] << 32);
       w.ctx_sp[l] = sp;
     }
+    w.round = 0; w.wave_done = w.all_done = 0;
+    for (int r = 0; r < MJH_WAVE/16; r++) w.row_done[r] = 0;
     int remaining = nfib;
     while (remaining) {
       remaining = 0;
+      w.round++;
       for (int k = 0; k < nfib; k++) {
         int l = w.reverse ? nfib - 1 - k : k;
         if (w.done[l]) continue;
+        if (w.parked[l]) { remaining++; continue; }
         w.cur = l;
         mjhsim::mjh_ctx_switch(&w.sched_sp, w.ctx_sp[l]);
         if (!w.done[l]) remaining++;

@@ -261,3 +261,29 @@ def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     m = rb.MjModel.from_xml_path(str(xml))
     with pytest.raises(K.MjhipError, match="flex"):
         K.DeviceModel(hostsim_lib, m)
+
+
+def test_multiwave_variant_is_default_for_flex_and_bit_identical(hostsim_lib):
+    """Multi-wavefront workgroups (mjh_modes.h: wn + wq; MJH_MW wavefronts per environment): the default mapping of a
+    flex model at launches of at most one workgroup per CU (BASELINE config 5).  Wave 0 runs the step, the tree / flex
+    passes run workgroup-wide; the trajectory has to be bit-identical to the one-wavefront mapping's (the emulation
+    runs 64 x MJH_MW fibers per environment; MJH_HOSTSIM_REVERSE=1 is the race detector)."""
+    mm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "jelly.mjb"))
+    dm = K.DeviceModel(hostsim_lib, mm)
+    nenv, T = 2, 10
+    b = K.Batch(dm, nenv)
+    assert b.kernel_variant() == "multiwave" and b.kernel_name().endswith("wn")
+    b.reset()
+    s0 = np.zeros((nenv, dm.nstate))
+    s0[:, 1:1 + dm.nq] = b.get("qpos")[0]
+    s0[:, 1 + dm.nq:1 + dm.nq + dm.nv] = np.random.default_rng(5).normal(0, 0.1, size=(nenv, dm.nv))
+    ctrl = np.zeros((nenv, T, dm.nu))
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    g = K.Batch(dm, nenv)
+    g.set_variant("generic")
+    assert g.kernel_variant() == "generic"
+    ref = g.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+    # a model without flexes keeps its one-wavefront mapping
+    hm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "humanoid.mjb"))
+    assert K.Batch(K.DeviceModel(hostsim_lib, hm), 2).kernel_variant() != "multiwave"
