@@ -52,3 +52,37 @@ def test_flex_edge_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
     """mjEQ_FLEX rows (one per non-rigid edge) in front of the contact rows: bit-exact incl. CG iteration counts"""
     maxcon, kinds = fh._edge_equality(rb, hip_lib, tmp_path, nstep=60)
     assert maxcon > 0
+
+
+def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
+    """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
+    fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference
+    stepped from the same state; all environments distinct; the launch is at most one workgroup per CU, so this runs
+    the multi-wavefront mapping (8 wavefronts per environment)"""
+    from mujoco_amd import _capi as K
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "jelly.mjb"))
+    dm = K.DeviceModel(hip_lib, m)
+    nenv, T = 64, 400
+    b = K.Batch(dm, nenv)
+    assert b.kernel_variant() == "multiwave"
+    b.reset()
+    rng = np.random.default_rng(11)
+    s0 = np.zeros((nenv, dm.nstate))
+    s0[:, 1:1 + dm.nq] = b.get("qpos")[0]
+    s0[:, 1 + dm.nq:1 + dm.nq + dm.nv] = rng.normal(0, 0.1, size=(nenv, dm.nv))
+    ctrl = np.zeros((nenv, T, dm.nu))
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    assert len({out[e, -1].tobytes() for e in range(nenv)}) == nenv
+    d = rb.MjData(m)
+    spec = rb.mjSTATE_FULLPHYSICS
+    ncon_seen = 0
+    for e in (0, 63):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], spec)
+        for t in range(T):
+            rb.mj_step(m, d)
+            assert np.array_equal(out[e, t], rb.mj_getState(m, d, spec)), (e, t)
+        ncon_seen = max(ncon_seen, int(d.ncon))
+    print("jelly batch: contacts at the end of the sampled rollouts up to", ncon_seen)
+    assert ncon_seen > 0

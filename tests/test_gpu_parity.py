@@ -998,7 +998,9 @@ def test_cube_3x3x3_single_steps_on_gpu(rb, hip_lib):
     assert dm.size("sparse") == 1
     nexact = int(np.all(out[:, 0] == fx["next"], axis=1).sum())
     print("cube: steps reproduced bit for bit on the device against the reference as built (glibc sin / cos):", nexact, "of", n)
-    assert nexact >= n//2
+    # (measured: 158-160 of 160; a last-bit libm difference in a hinge quaternion moves about 1 % of the reference's own
+    # cube steps beyond 1e-6, tests/test_oracle_golden.py::test_cube_contact_discontinuity -- none of them in this sample)
+    assert nexact >= int(0.95*n)
     # against the reference linked with the kernels' own sin / cos (oracle/devmath_shim.cc) EVERY step is bit-exact:
     # the six face-centre hinges are the only libm calls of this model's step
     md = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "cube_3x3x3.mjb"), kind="devmath")
