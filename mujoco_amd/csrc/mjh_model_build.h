@@ -1217,7 +1217,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   int nefc_bound = H->eq_rowadr[m->neq] + nfric + nlimit + rows_per_con*s.nconmax;
   // row capacity: the model's bound, cut back (not below 256 rows) until the per-environment constraint
   // arrays -- efc_J, efc_Y, the dense efc_AR under the dual solver, ~24 row vectors -- fit the budget
-  // ($MJHIP_EFC_BYTES, default 4 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
+  // ($MJHIP_EFC_BYTES, default: the reference arena size clamped to 4..16 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
   {
     const bool dual = m->opt.solver == mjSOL_PGS;
     // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
@@ -1244,7 +1244,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     MJH_REJECT(eq_flex && !s.csr, "flex edge equality constraints outside the explicit-index CG path (more than 128 dofs, CG, "
                                   "sparse Jacobian, no other equality or tendon)");
-    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : (s.csr ? 64.0 : 4.0)*1024*1024;
+    // default budget: what the reference's own arena (mjModel.narena, engine_memory.c:107-138) could hold, between 4 and
+    // 16 MiB per environment (64 MiB for the compressed-row CG path) -- stacked_boxes.xml under PGS needs ~1000 rows
+    const double MiB = 1024.0*1024.0;
+    const double arena = std::min(std::max((double)m->narena, 4*MiB), 16*MiB);
+    const double budget = caps.efc_bytes > 0 ? (double)caps.efc_bytes : (s.csr ? 64*MiB : arena);
     auto bytes = [&](int n) { return 8.0*n*(2.0*m->nv + (dual ? n : 0) + 24); };
     int n = std::max(1, std::min(nefc_bound, 4096));
     while (n > 256 && bytes(n) > budget) n = std::max(256, n*7/8);

@@ -173,6 +173,33 @@ def test_rollout_api_matches_serial_oracle(rb, hip_lib):
         rollout.rollout(m, d, s0[:, :-1], ctrl)
 
 
+def test_rollout_api_shards_over_real_devices(rb, hip_lib):
+    """`mjhip_rollout` on a node with several GPUs: the rollouts of one call are split over the visible
+    devices -- one host thread, stream, model / batch cache and lock per device -- and every row comes back from the
+    device that owns it.  Checked against the serial reference, with a batch that does not divide by the device count,
+    twice (the second call hits the per-device caches).  Skipped on single-GPU boxes; the same code path runs on
+    emulated devices in tests/test_rollout_api_cpu.py."""
+    ndev = hip_lib.device_count()
+    if ndev < 2:
+        pytest.skip("needs at least two visible HIP devices")
+    from mujoco_amd import rollout
+    m = humanoid_pgs_oracle(rb)
+    d = rb.MjData(m)
+    rng = np.random.default_rng(7)
+    nbatch, nstep = 4*ndev + 3, 6
+    s0 = np.zeros((nbatch, 56))
+    for e in range(nbatch):
+        rb.mj_resetDataKeyframe(m, d, e % m.nkey)
+        s0[e] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        s0[e, 29:] += rng.normal(0, 0.05, size=27)
+    ctrl = rng.uniform(-1, 1, size=(nbatch, nstep, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    for _ in range(2):
+        state, _sd = rollout.rollout(m, d, s0, ctrl)
+        assert relerr(state, ref) <= TOL
+        assert relerr(np.array(d.qpos), ref[-1, -1, 1:29]) <= TOL
+
+
 def test_rk4_rollout_vs_live_oracle(rb, hip_lib, golden):
     """RK4 integrator (mj_RungeKutta, engine_forward.c:1486-1587) on the GPU against the oracle"""
     m = humanoid_pgs_oracle(rb)
