@@ -1598,21 +1598,21 @@ MJH_DEV Shape rp_load_geom(MREF M, RowPair& c, int k, GX gx, GM gm, int g, real 
 }
 
 // ---- the environment's workspace: row pages in the LDS-planned field ccd_row, the rest in the global buffer ccd_ws -----
-// ccd_ws of environment e: [header: 64 pairs, 64 lanes, 64 counts] [records: 64 x RC_MAXOUT x 7 reals] [4 overflow pages]
+// ccd_ws of environment e: [header: 64 pairs, 64 lanes, 64 counts, 64 arguments] [records: 64 x RC_MAXOUT x 7 reals] [one overflow page per row]
 MJH_DEV int* rc_header(MREF M, BREF B, int e) { return (int*)((char*)B.ccd_ws + (size_t)e*(size_t)M.s.ccd_env_bytes); }
 MJH_DEV real* rc_records(MREF M, BREF B, int e, int slot) {
-  return (real*)((char*)B.ccd_ws + (size_t)e*(size_t)M.s.ccd_env_bytes + 192*sizeof(int)) + RC_MAXOUT*RC_RECORD*slot;
+  return (real*)((char*)B.ccd_ws + (size_t)e*(size_t)M.s.ccd_env_bytes + 256*sizeof(int)) + RC_MAXOUT*RC_RECORD*slot;
 }
 MJH_DEV void rc_attach(MREF M, BREF B, int e, RowPair& c) {
   const MJH_CONST_AS DSizes& s = M.s;
-  const int row = wv_lane() >> 4;
+  const int row = wv_lane() >> 4;          // (row of the group: up to s.ccd_rows in a multi-wavefront workgroup)
   real* fast = MJH_F(B, ccd_row, e).p + (size_t)row*s.ccd_row_reals;
 #if defined(MJH_CCD_ASSUME_LDS) && !defined(MJH_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
   __builtin_assume(__builtin_amdgcn_is_shared(fast));
 #endif
   c.m.R = fast;
   c.m.I = (int*)(fast + s.ccd_row_freal);
-  char* slow = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes + 192*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real)
+  char* slow = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes + 256*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real)
                + (size_t)row*(size_t)s.ccd_slow_bytes;
   c.m.RS = (real*)slow;
   c.m.nslow_v = 5 + s.ccd_N;
@@ -2250,7 +2250,26 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   return p >= 0 ? head[128 + wv_lane()] : 0;
 }
 
-// the same for (geom, flex element) pairs; g < 0: the lane has none
+// The listed (geom, flex element) pairs, one per row: entry t is taken by row t mod (rows of the group).  The group is the
+// wavefront (4 rows) -- or, in a multi-wavefront workgroup, the workgroup (mjh_modes.h: this function is one of the
+// stages every wavefront runs, 4 rows each).
+MJH_DEVN void rc_elem_rows(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  int* head = rc_header(M, B, e);
+  const int total = head[192];
+  RowPair c;
+  rc_attach(M, B, e, c);
+  for (int t = wv_lane() >> 4; t < total; t += MJH_W/16) {
+    const int owner = (head[t] >> 24) & 63;
+    real* rec = rc_records(M, B, e, owner);
+    const real mg = rec[0];
+    wv_row_sync();
+    const int n = rc_geom_elem(M, B, e, c, head[t] & 0xffffff, head[64 + t], mg, rec);
+    if (rw_l() == 0) head[128 + owner] = n;
+  }
+  MJH_GROUP_JOIN();
+}
+// (geom, flex element) pairs, one per lane of the calling wavefront; g < 0: the lane has none.  Returns the lane's contact count.
 MJH_DEVN_HOT int ccd_geom_elem_pair(MREF M_, BREF B_, int e_, int g, int elem, real margin) {
   MJH_ENTER(M_, B_, e_);
   int* head = rc_header(M, B, e);
@@ -2262,19 +2281,9 @@ MJH_DEVN_HOT int ccd_geom_elem_pair(MREF M_, BREF B_, int e_, int g, int elem, r
     head[t] = g | (wv_lane() << 24); head[64 + t] = elem;
     rc_records(M, B, e, wv_lane())[0] = margin;
   }
+  if (wv_lane() == 0) head[192] = total;
   wv_sync();
-  RowPair c;
-  rc_attach(M, B, e, c);
-  for (int t = wv_lane() >> 4; t < total; t += 4) {
-    const int owner = (head[t] >> 24) & 63;
-    real* rec = rc_records(M, B, e, owner);
-    const real mg = rec[0];
-    wv_row_sync();
-    const int n = rc_geom_elem(M, B, e, c, head[t] & 0xffffff, head[64 + t], mg, rec);
-    if (rw_l() == 0) head[128 + owner] = n;
-  }
-  wv_converge();
-  wv_sync();
+  MJH_WIDE(MJH_MWS_ELEMS, rc_elem_rows(M, B, e));
   return g >= 0 ? head[128 + wv_lane()] : 0;
 }
 

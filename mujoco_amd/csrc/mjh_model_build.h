@@ -1049,7 +1049,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       // overflow page of a row: full-capacity vertex / face / map / horizon / crossing-stack arrays
       const int nsv = 5 + N, nsf = 6*N;
       s.ccd_slow_bytes = (6*nsv + 4*nsf)*(int)sizeof(real) + ((2*nsv + 6*nsf + nsf + 2*nsf + 2*nsf + 16 + 1) & ~1)*(int)sizeof(int);
-      s.ccd_env_bytes = 192*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + 4*s.ccd_slow_bytes;
+      s.ccd_rows = m->nflex > 0 ? 4*MJH_MW : 4;
+      s.ccd_env_bytes = 256*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + s.ccd_rows*s.ccd_slow_bytes;
     }
   }
 

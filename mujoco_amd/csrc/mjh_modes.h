@@ -43,7 +43,7 @@ static inline const char* mjh_variant_name(int v) {
 }
 // stages every wavefront of a multi-wavefront workgroup runs together (mw_exec below)
 enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH_MWS_TAVEL, MJH_MWS_COMVEL, MJH_MWS_PASSIVE,
-       MJH_MWS_RNE };
+       MJH_MWS_RNE, MJH_MWS_ELEMS };
 // bytes at the end of a multi-wavefront workgroup's LDS block that the residency plan leaves alone: the command word
 // wave 0 posts for the helper wavefronts
 #define MJH_MW_LDS_TAIL 64
@@ -56,6 +56,8 @@ enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH
 #define MJH_DEVN MJH_DEVN_WAVE
 // a stage call that a multi-wavefront workgroup runs on all of its wavefronts (namespace wn redefines this)
 #define MJH_WIDE(id, call) call
+// end of a section in which the rows of the group ran apart: everyone is back, memory is visible
+#define MJH_GROUP_JOIN() do { wv_converge(); wv_sync(); } while (0)
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 // entry of an out-of-line stage function: its arguments arrive in VGPRs; all three are wave-uniform
 // namespace wv serves environment-major batches only (B.soa == 0): telling the compiler makes every
@@ -125,40 +127,11 @@ namespace ws {
 #define MJH_DEVN MJH_DEVN_WAVE
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 #define MJH_WIDE(id, call) call
+#undef MJH_GROUP_JOIN
+#define MJH_GROUP_JOIN() wv_sync()
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
                               if (B.soa != 0) __builtin_unreachable()
 #define MJH_FEATURES MJH_FT_ALL
-namespace wq {
-#ifdef MJH_HOSTSIM
-MJH_DEV int wv_lane() { return mjhsim::lane(); }
-// (all fibers of the emulated workgroup pass the same barriers inside a stage: one switch each, in lockstep)
-MJH_DEV void wv_sync() { mjhsim::yield(); }
-#else
-MJH_DEV int wv_lane() { return (int)threadIdx.x; }
-MJH_DEV void wv_sync() { __syncthreads(); }
-#endif
-#include "mjh_flex.h"
-#include "mjh_smooth.h"
-}
-#undef MJH_FEATURES
-#undef MJH_W
-#undef MJH_FOR_LANES
-#undef MJH_WIDE
-#undef MJH_ENTER
-
-// a posted stage, run by every wavefront of the workgroup
-MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
-  switch (id) {
-    case MJH_MWS_KIN: wq::stage_kinematics(M, B, e); if (M.s.nflex) wq::stage_flex_pos(M, B, e); break;
-    case MJH_MWS_COMPOS: wq::stage_compos(M, B, e); break;
-    case MJH_MWS_FLEXEDGES: wq::stage_flex_edges(M, B, e); break;
-    case MJH_MWS_TAVEL: wq::stage_ten_act_velocity(M, B, e); break;
-    case MJH_MWS_COMVEL: wq::stage_comvel(M, B, e); break;
-    case MJH_MWS_PASSIVE: wq::stage_passive(M, B, e); break;
-    case MJH_MWS_RNE: wq::stage_rne(M, B, e); break;
-    default: break;
-  }
-}
 // the workgroup barrier at which the helper wavefronts wait for a stage, and the command word in LDS
 #ifdef MJH_HOSTSIM
 // (emulation: helper fibers PARK at the barrier -- the scheduler skips them -- until the last fiber of wave 0 arrives;
@@ -184,6 +157,42 @@ MJH_DEV void mw_barrier() {
 #else
 MJH_DEV void mw_barrier() { __syncthreads(); }
 #endif
+namespace wq {
+#ifdef MJH_HOSTSIM
+MJH_DEV int wv_lane() { return mjhsim::lane(); }
+// (a counted barrier: the rows of the convex narrowphase leave their loops at different times)
+MJH_DEV void wv_sync() { ::mw_barrier(); }
+#else
+MJH_DEV int wv_lane() { return (int)threadIdx.x; }
+MJH_DEV void wv_sync() { __syncthreads(); }
+#endif
+#include "mjh_flex.h"
+#include "mjh_smooth.h"
+#include "mjh_collision.h"
+#include "mjh_flexcol.h"
+}
+#undef MJH_FEATURES
+#undef MJH_W
+#undef MJH_FOR_LANES
+#undef MJH_WIDE
+#undef MJH_ENTER
+#undef MJH_GROUP_JOIN
+#define MJH_GROUP_JOIN() do { wv_converge(); wv_sync(); } while (0)
+
+// a posted stage, run by every wavefront of the workgroup
+MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
+  switch (id) {
+    case MJH_MWS_KIN: wq::stage_kinematics(M, B, e); if (M.s.nflex) wq::stage_flex_pos(M, B, e); break;
+    case MJH_MWS_COMPOS: wq::stage_compos(M, B, e); break;
+    case MJH_MWS_FLEXEDGES: wq::stage_flex_edges(M, B, e); break;
+    case MJH_MWS_TAVEL: wq::stage_ten_act_velocity(M, B, e); break;
+    case MJH_MWS_COMVEL: wq::stage_comvel(M, B, e); break;
+    case MJH_MWS_PASSIVE: wq::stage_passive(M, B, e); break;
+    case MJH_MWS_RNE: wq::stage_rne(M, B, e); break;
+    case MJH_MWS_ELEMS: wq::rc_elem_rows(M, B, e); break;
+    default: break;
+  }
+}
 MJH_DEV volatile int* mw_command(BREF B) { return (volatile int*)(mjh_lds() + B.lds_bytes); }
 // wave 0: post stage `id` for environment e and run it together with the helpers
 MJH_DEV void mw_run(MREF M, BREF B, int e, int id) {

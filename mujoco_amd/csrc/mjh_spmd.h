@@ -55,15 +55,15 @@ struct WaveSim {
   long long arrive_all[MJH_WAVE*MJH_MW];   // workgroup barrier of the multi-wavefront kernels
   int parked[MJH_WAVE*MJH_MW];             // helper fibers waiting at that barrier: the scheduler skips them
   long long round;                         // scheduler passes so far
-  long long row_done[MJH_WAVE/16], wave_done, all_done;   // pass in which the last fiber reached the current barrier
+  long long row_done[MJH_WAVE*MJH_MW/16], wave_done, all_done;   // pass in which the last fiber reached the current barrier
   int env;            // blockIdx.x
   int reverse;        // run lanes 63..0 instead of 0..63 (race detector)
   // scratch for cross-lane primitives
-  double dscratch[MJH_WAVE];
-  double dscratch2[MJH_WAVE];
-  long long iscratch[MJH_WAVE];
-  long long iscratch2[MJH_WAVE];
-  long long arrive_row[MJH_WAVE];    // wv_row_converge / wv_converge arrival counts
+  double dscratch[MJH_WAVE*MJH_MW];     // (sized for the workgroup: the row primitives also run on helper wavefronts)
+  double dscratch2[MJH_WAVE*MJH_MW];
+  long long iscratch[MJH_WAVE*MJH_MW];
+  long long iscratch2[MJH_WAVE*MJH_MW];
+  long long arrive_row[MJH_WAVE*MJH_MW];    // wv_row_converge / wv_converge arrival counts
   long long arrive_wave[MJH_WAVE];
 };
 extern thread_local WaveSim* g_wave;

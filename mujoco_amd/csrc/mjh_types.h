@@ -361,6 +361,7 @@ struct DSizes {
   // reals + ints of it counted in reals (the LDS-planned field ccd_row holds 4 of these per environment), bytes of a
   // row's overflow page and of an environment's global block (header, contact records, 4 overflow pages)
   int ccd_row_freal, ccd_row_reals, ccd_slow_bytes, ccd_env_bytes;
+  int ccd_rows;        // row workspaces per environment: 4 (one wavefront), 4 MJH_MW for flex models (multi-wavefront workgroups)
   // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse; nv <= 128 here);
   // capacity of the CSR Jacobian; entries of the compressed factor (Newton; x2 with cones)
   int sparse, nJmax, nLp, nLpc;
@@ -463,8 +464,8 @@ enum {
   X(xaxis, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                       \
   X(geom_xpos, 3 * s.ngeom, 3 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
   X(geom_xmat, 9 * s.ngeom, 9 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
-  /* row workspaces of the convex narrowphase (mjh_convex.h): 4 rows x (shape frames, simplex, polytope / clipping buffers) */ \
-  X(ccd_row, 4 * s.ccd_row_reals, 4 * s.ccd_row_reals, MJH_T_COLLISION, MJH_T_COLLISION)  \
+  /* row workspaces of the convex narrowphase (mjh_convex.h): ccd_rows x (shape frames, simplex, polytope / clipping buffers) */ \
+  X(ccd_row, s.ccd_rows * s.ccd_row_reals, s.ccd_rows * s.ccd_row_reals, MJH_T_COLLISION, MJH_T_COLLISION)  \
   X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \

@@ -54,7 +54,8 @@ struct Runner {
       w.done[l] = 0;
       w.parked[l] = 0;
       w.arrive_all[l] = 0;
-      if (l < MJH_WAVE) { w.arrive_row[l] = 0; w.arrive_wave[l] = 0; }
+      w.arrive_row[l] = 0;
+      if (l < MJH_WAVE) w.arrive_wave[l] = 0;
       // initial frame popped by mjh_ctx_switch: [mxcsr|x87cw] r15 r14 r13 r12 rbx rbp, return address
       uintptr_t top = ((uintptr_t)(w.stacks + kStack * (l + 1))) & ~(uintptr_t)15;
       uintptr_t* sp = (uintptr_t*)top;
@@ -65,7 +66,7 @@ struct Runner {
       w.ctx_sp[l] = sp;
     }
     w.round = 0; w.wave_done = w.all_done = 0;
-    for (int r = 0; r < MJH_WAVE/16; r++) w.row_done[r] = 0;
+    for (int r = 0; r < MJH_WAVE*MJH_MW/16; r++) w.row_done[r] = 0;
     int remaining = nfib;
     while (remaining) {
       remaining = 0;
