@@ -1606,14 +1606,17 @@ MJH_DEV real* rc_records(MREF M, BREF B, int e, int slot) {
 MJH_DEV void rc_attach(MREF M, BREF B, int e, RowPair& c) {
   const MJH_CONST_AS DSizes& s = M.s;
   const int row = wv_lane() >> 4;          // (row of the group: up to s.ccd_rows in a multi-wavefront workgroup)
-  real* fast = MJH_F(B, ccd_row, e).p + (size_t)row*s.ccd_row_reals;
+  char* block = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes;
+  char* pages = block + 256*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real);
+  // fast page: the LDS-planned field ccd_row, else (no plan, or no room in it) the tail of the environment's global block
+  real* fast = (B.l_ccd_row >= 0 ? (real*)(MJH_LDS(B) + B.l_ccd_row) : (real*)(pages + (size_t)s.ccd_rows*(size_t)s.ccd_slow_bytes))
+               + (size_t)row*s.ccd_row_reals;
 #if defined(MJH_CCD_ASSUME_LDS) && !defined(MJH_HOSTSIM) && defined(__HIP_DEVICE_COMPILE__)
   __builtin_assume(__builtin_amdgcn_is_shared(fast));
 #endif
   c.m.R = fast;
   c.m.I = (int*)(fast + s.ccd_row_freal);
-  char* slow = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes + 256*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real)
-               + (size_t)row*(size_t)s.ccd_slow_bytes;
+  char* slow = pages + (size_t)row*(size_t)s.ccd_slow_bytes;
   c.m.RS = (real*)slow;
   c.m.nslow_v = 5 + s.ccd_N;
   c.m.nslow_f = 6*s.ccd_N;

@@ -1050,7 +1050,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       const int nsv = 5 + N, nsf = 6*N;
       s.ccd_slow_bytes = (6*nsv + 4*nsf)*(int)sizeof(real) + ((2*nsv + 6*nsf + nsf + 2*nsf + 2*nsf + 16 + 1) & ~1)*(int)sizeof(int);
       s.ccd_rows = m->nflex > 0 ? 4*MJH_MW : 4;
-      s.ccd_env_bytes = 256*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + s.ccd_rows*s.ccd_slow_bytes;
+      // (header, contact records, overflow pages, and the rows' fast pages for launches whose LDS plan has no room for them)
+      s.ccd_env_bytes = 256*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + s.ccd_rows*s.ccd_slow_bytes +
+                        s.ccd_rows*s.ccd_row_reals*(int)sizeof(real);
     }
   }
 

@@ -205,6 +205,10 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
   // big ones, and first-fit by lifetime alone left holes they did not fit into)
   std::vector<int> orderB(order);
   std::stable_sort(orderB.begin(), orderB.end(), [&](int a, int b) {
+    // (the convex narrowphase's row workspaces first: every access of its inner loops lands there, while the tree
+    // fields they would displace are written once and read once or twice)
+    const bool ha = !strcmp(f[a].name, "ccd_row"), hb = !strcmp(f[b].name, "ccd_row");
+    if (ha != hb) return ha;
     return (long long)f[a].bytes*(f[a].t1 - f[a].t0 + 1) > (long long)f[b].bytes*(f[b].t1 - f[b].t0 + 1);
   });
   for (int i : orderB) {

@@ -464,8 +464,9 @@ enum {
   X(xaxis, 3 * s.njnt, 3 * s.njnt, MJH_T_KIN, MJH_T_COMPOS)                       \
   X(geom_xpos, 3 * s.ngeom, 3 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
   X(geom_xmat, 9 * s.ngeom, 9 * s.ngeom, MJH_T_KIN, MJH_T_COLLISION)              \
-  /* row workspaces of the convex narrowphase (mjh_convex.h): ccd_rows x (shape frames, simplex, polytope / clipping buffers) */ \
-  X(ccd_row, s.ccd_rows * s.ccd_row_reals, s.ccd_rows * s.ccd_row_reals, MJH_T_COLLISION, MJH_T_COLLISION)  \
+  /* row workspaces of the convex narrowphase (mjh_convex.h): ccd_rows x (shape frames, simplex, polytope / clipping buffers); \
+     LDS only -- no global home here: when the plan leaves it out, the rows work in the environment's block of ccd_ws */ \
+  X(ccd_row, 0, s.ccd_rows * s.ccd_row_reals, MJH_T_COLLISION, MJH_T_COLLISION)  \
   X(site_xpos, 3 * s.nsite, 3 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(site_xmat, 9 * s.nsite, 9 * s.nsite, MJH_T_KIN, MJH_T_TRANSMISSION)             \
   X(subtree_com, 3 * s.nbody, 3 * s.nbody, MJH_T_COMPOS, MJH_T_MAKE)              \

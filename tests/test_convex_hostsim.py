@@ -175,3 +175,25 @@ def test_nearly_touching_boxes_keep_their_contacts(rb, hostsim_lib, tmp_path):
             assert np.array_equal(cd[e][:d.ncon], c["dist"]) and np.array_equal(cp[e][:3*d.ncon], np.asarray(c["pos"]).ravel())
         total += d.ncon
     assert total > 0
+
+
+def test_cube_steps_in_soa_layout_and_without_lds_plan(hostsim_lib):
+    """the convex narrowphase's row workspaces live in the LDS-planned field `ccd_row` -- or, when the plan has no room
+    for it (small budgets) or the batch is laid out SoA-across-environments (its fields are strided, a row workspace is
+    not), in the environment's block of the global buffer `ccd_ws`: same results either way"""
+    fx = np.load(os.path.join(GOLDEN, "cube_3x3x3_steps.npz"))
+    mm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "cube_3x3x3.mjb"))
+    dm = K.DeviceModel(hostsim_lib, mm)
+    idx = [0, 5, 40]
+    outs = []
+    for layout, budget in (("aos", 20480), ("aos", 8192), ("soa", 20480)):
+        b = K.Batch(dm, len(idx), layout=layout)
+        b.plan_lds(budget)
+        in_lds = any("ccd_row" in ln and "lds@" in ln for ln in b.lds_report().splitlines())
+        assert in_lds == (budget == 20480 and layout == "aos") or layout == "soa"
+        out = b.rollout_host(1, K.mjSTATE_CTRL, fx["state"][idx], fx["warmstart"][idx], fx["ctrl"][idx][:, None])
+        assert b.get("warning").sum() == 0
+        assert np.array_equal(b.get("counts")[:, 0], fx["ints"][idx, 0])
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0][:, 0], fx["next"][idx])
