@@ -477,6 +477,9 @@ struct RowPair {
   int nsim, apart, nw, spent;     // simplex size, "shapes are separated", witness pairs found, distance iterations used
   real dist0; V3 w1, w2;          // first witness pair and its signed distance
   int tabled;                     // the witness pairs are in the row's witness table (multi-contact), not in w1 / w2
+#ifdef MJH_PROFILE
+  long long t_far, t_clip;        // (profiling builds) clock ticks inside support queries / multi-contact of the penetration phase
+#endif
   int nv, nf, nm;                 // polytope: vertices, faces, entries of the priority map
   V3 centre;                      // a point inside the polytope (orients the faces)
 };
@@ -710,7 +713,13 @@ MJH_DEV void rp_restart_from_triangle(RowPair& c, int va, int vb, int vc) {
 MJH_DEV int rp_grow(MREF M, RowPair& c, V3 d, real dlen, Far& f) {
   V3 dir{1, 0, 0}, dn{-1, 0, 0};
   if (dlen > MJH_MINVAL) { dir = V3{d.x/dlen, d.y/dlen, d.z/dlen}; dn = rw_scl(dir, -1); }
+#ifdef MJH_PROFILE
+  const long long t0_ = wv_clock();
+#endif
   f = rc_farthest(M, rp_frame(c, 0), c.a, c.b, dir, dn);
+#ifdef MJH_PROFILE
+  c.t_far += wv_clock() - t0_;
+#endif
   rp_take_caches(c, f);
   const int v = c.nv++;
   rp_store_vertex(rm_vert(c.m, v), rm_vid(c.m, v), f);
@@ -1628,6 +1637,9 @@ MJH_DEV void rc_attach(MREF M, BREF B, int e, RowPair& c) {
   c.nv = c.nf = c.nm = 0;
   c.dist0 = 0;
   c.w1 = c.w2 = c.centre = V3{0, 0, 0};
+#ifdef MJH_PROFILE
+  c.t_far = c.t_clip = 0;
+#endif
 }
 // the calling lane's contact records (dist, pos[3], normal[3]) x RC_MAXOUT
 MJH_DEV crptr ccd_out_records(MREF M, BREF B, int e) { return crptr{rc_records(M, B, e, wv_lane()), 1}; }
@@ -1756,7 +1768,13 @@ MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, r
                    : (c.nsim == 3 ? rc_polytope_from_triangle(M, c) : rc_polytope_from_tetrahedron(M, c));
   if (failed) return 0;
   const int face = rc_expand(M, c);
+#ifdef MJH_PROFILE
+  const long long t1_ = wv_clock();
+#endif
   if (c.maxcon > 1 && face >= 0) { RC_COUNT(5); rc_multicontact(M, c, face); }
+#ifdef MJH_PROFILE
+  c.t_clip += wv_clock() - t1_;
+#endif
   real deepest = c.dist0;
   if (c.tabled) deepest = rw_min_all(L < c.nw ? (c.m.R + RO_SCR)[7*L] : HUGE_VAL);
   wv_row_sync();
@@ -2223,7 +2241,7 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   }
   wv_converge();
   wv_sync();
-  tick(25);
+  tick(46);
   // first pass of the polyhedral pairs: one pair per lane, simplex in registers
   {
     const int poly = p >= 0 && rc_max_contacts(M, p) > 1;
@@ -2249,6 +2267,9 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
     wv_converge();
     wv_sync();
   }
+#ifdef MJH_PROFILE
+  if (wv_lane() == 0) { MJH_G(B, prof, e)[25] += (real)c.t_far*0.01; MJH_G(B, prof, e)[21] += (real)c.t_clip*0.01; }
+#endif
   tick(47);
   return p >= 0 ? head[128 + wv_lane()] : 0;
 }

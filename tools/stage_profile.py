@@ -49,8 +49,8 @@ for i, n in enumerate(NAMES):
     if v > 0: print(f"  {n:14s} {v:9.2f} us")
 print(f"  {'sum':14s} {tot:9.2f} us")
 if p.shape[1] >= 48 and p[:, 46:48].sum() > 0:
-    print("  inside collision (convex narrowphase): single-contact pairs %.1f  lane-parallel distance phase %.1f  row-cooperative penetration phase %.1f us"
-          % tuple(p[:, k].mean()/nst for k in (25, 46, 47)))
+    print("  inside collision (convex narrowphase): lane-parallel distance phase %.1f  row-cooperative penetration phase %.1f us (row 0 of it: support queries %.1f, multi-contact %.1f)"
+          % tuple(p[:, k].mean()/nst for k in (46, 47, 25, 21)))
 print("  inside constraint: b/jar/warmstart %.2f  PGS %.2f  J'f %.2f us" % tuple(p[:, k].mean()/nst for k in (22, 23, 24)))
 if p.shape[1] >= 40 and p[:, 32:38].sum() > 0:
     print("  inside constraint (primal solvers): set-up %.1f  Hessian+factor %.1f  factor solves %.1f  incremental updates %.1f  line search %.1f  constraint update+grad %.1f us"
