@@ -1093,6 +1093,9 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   crptr gx = MJH_F(B, geom_xpos, e);
   crptr gm = MJH_F(B, geom_xmat, e);
   iptr warn = MJH_F(B, warning, e);
+#if !MJH_LANE_MODE
+  if (MJH_HAS(MJH_FT_COLCONVEX) && s.ccd_any) { if (wv_lane() == 0) rc_header(M, B, e)[193] = 0; wv_sync(); }
+#endif
 
   int base = 0;        // contacts emitted by earlier chunks (uniform over the group)
   int overflow = 0;
@@ -1273,18 +1276,40 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
       total += __builtin_popcountll(m);
     }
     wv_sync();
-    for (int r0 = 0; r0 < total; r0 += MJH_W) {
-      int k = r0 + wv_lane(), pick = -1;
-      if (k < total) {
-        for (int ch = 0; ch < nchunk; ch++) {
-          const unsigned long long m = ((unsigned long long)(unsigned)park[2*ch + 1] << 32) | (unsigned)park[2*ch];
-          const int cnt = __builtin_popcountll(m);
-          if (k < cnt) { pick = plo + ch*MJH_W + kth_bit(m, k); break; }
-          k -= cnt;
-        }
+    // the k-th pair in reach (pair order)
+    auto pick_of = [&](int k) -> int {
+      if (k >= total) return -1;
+      for (int ch = 0; ch < nchunk; ch++) {
+        const unsigned long long m = ((unsigned long long)(unsigned)park[2*ch + 1] << 32) | (unsigned)park[2*ch];
+        const int cnt = __builtin_popcountll(m);
+        if (k < cnt) return plo + ch*MJH_W + kth_bit(m, k);
+        k -= cnt;
       }
-      narrow(pick);
+      return -1;
+    };
+    // polyhedral convex pairs: their distance phase for ALL pairs in reach at once, ahead of the rounds (a lane that has
+    // finished its pair takes the next one: mjh_convex.h, ccd_poly_distance); the rounds look the results up
+    int prepassed = 0;
+    if (MJH_HAS(MJH_FT_COLCONVEX) && s.ccd_npoly > MJH_W) {
+      const PolyTab tab = rc_poly_tables(M, B, e);
+      int npoly = 0;
+      for (int r0 = 0; r0 < total; r0 += MJH_W) {
+        const int pick = pick_of(r0 + wv_lane());
+        const int poly = pick >= 0 && M.pair_func[pick] == MJH_COL_CONVEX && rc_max_contacts(M, pick) > 1;
+        const unsigned long long m = wv_ballot(poly);
+        if (poly) { const int t = npoly + wv_rank_lt(m); tab.list[t] = pick; tab.slot[pick] = t; }
+        npoly += __builtin_popcountll(m);
+      }
+      wv_sync();
+      if (npoly > MJH_W) {
+        ccd_poly_distance(M, B, e, npoly);
+        if (wv_lane() == 0) rc_header(M, B, e)[193] = 1;
+        wv_sync();
+        prepassed = 1;
+      }
     }
+    for (int r0 = 0; r0 < total; r0 += MJH_W) narrow(pick_of(r0 + wv_lane()));
+    if (prepassed) { if (wv_lane() == 0) rc_header(M, B, e)[193] = 0; wv_sync(); }
   } else
 #endif
   for (int p0 = plo; p0 < phi; p0 += MJH_W) {

@@ -1612,6 +1612,20 @@ MJH_DEV int* rc_header(MREF M, BREF B, int e) { return (int*)((char*)B.ccd_ws + 
 MJH_DEV real* rc_records(MREF M, BREF B, int e, int slot) {
   return (real*)((char*)B.ccd_ws + (size_t)e*(size_t)M.s.ccd_env_bytes + 256*sizeof(int)) + RC_MAXOUT*RC_RECORD*slot;
 }
+// tables of the polyhedral pairs' distance phase (behind the rows' fallback pages): slot of every static pair in the
+// current list (-1: not listed), overlap flag and parked simplex (32 reals) per list entry, the list itself
+struct PolyTab { int* slot; int* flag; int* list; real* park; };
+MJH_DEV PolyTab rc_poly_tables(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  char* q = (char*)B.ccd_ws + (size_t)e*(size_t)s.ccd_env_bytes + 256*sizeof(int) + 64*RC_MAXOUT*RC_RECORD*sizeof(real)
+            + (size_t)s.ccd_rows*((size_t)s.ccd_slow_bytes + (size_t)s.ccd_row_reals*sizeof(real));
+  PolyTab t;
+  t.park = (real*)q; q += (size_t)s.ccd_npoly*32*sizeof(real);
+  t.slot = (int*)q; q += (size_t)s.npair*sizeof(int);
+  t.flag = (int*)q; q += (size_t)s.ccd_npoly*sizeof(int);
+  t.list = (int*)q;
+  return t;
+}
 MJH_DEV void rc_attach(MREF M, BREF B, int e, RowPair& c) {
   const MJH_CONST_AS DSizes& s = M.s;
   const int row = wv_lane() >> 4;          // (row of the group: up to s.ccd_rows in a multi-wavefront workgroup)
@@ -1746,7 +1760,7 @@ MJH_DEV int rc_max_contacts(MREF M, int p) {
 }
 // Penetration phase of a polyhedral pair whose distance phase (ccd_poly_distance, below) found the shapes overlapping:
 // polytope, expansion, multi-contact from the parked simplex; contact records into rec (= the parking slot)
-MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, real* rec) {
+MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, const real* park, real* rec) {
   crptr gx = MJH_F(B, geom_xpos, e);
   crptr gm = MJH_F(B, geom_xmat, e);
   const int L = rw_l();
@@ -1754,8 +1768,8 @@ MJH_DEV int rc_poly_pair_penetration(MREF M, BREF B, int e, RowPair& c, int p, r
   c.a = rp_load_geom(M, c, 0, gx, gm, M.pair_geom1[p], margin);
   c.b = rp_load_geom(M, c, 1, gx, gm, M.pair_geom2[p], margin);
   real* sim = c.m.R + RO_SIM; int* sid = c.m.I + IO_SIM;
-  const int* pi = (const int*)(rec + 24);
-  for (int q = L; q < 24; q += 16) sim[q] = rec[q];
+  const int* pi = (const int*)(park + 24);
+  for (int q = L; q < 24; q += 16) sim[q] = park[q];
   if (L < 8) sid[L] = pi[L];
   c.nsim = pi[8]; c.a.vcache = pi[9]; c.a.gcache = pi[10]; c.b.vcache = pi[11]; c.b.gcache = pi[12];
   wv_row_sync();
@@ -2045,48 +2059,72 @@ MJH_DEV LaneVert lp_unpark(const real* park, int q) {
   return v;
 }
 
-// Distance phase of the lane's polyhedral pair p (p < 0: none).  Returns 1 when the shapes overlap: the simplex, its
-// size and the support caches are then parked in the lane's record slot for rc_poly_pair_penetration.  (gjk :198 with
-// gjkIntersect :420 for pairs without margin: dist_cutoff 0, discrete geoms)
-MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
+// Distance phase of the polyhedral pairs list[0 .. npairs): every lane takes a pair, and a lane that has finished its pair
+// takes the next one of the list at once (the pairs need 1 to ~13 iterations each: without the refill a round of 64 lasts
+// as long as its longest pair).  Per list entry t: flag[t] = the shapes overlap, and then the simplex, its size and the
+// support caches parked at park + 32 t for rc_poly_pair_penetration.  (gjk :198 with gjkIntersect :420 for pairs without
+// margin: dist_cutoff 0, discrete geoms)
+MJH_DEVN_HOT void ccd_poly_distance(MREF M_, BREF B_, int e_, int npairs) {
   MJH_ENTER(M_, B_, e_);
   crptr gx = MJH_F(B, geom_xpos, e);
   crptr gm = MJH_F(B, geom_xmat, e);
-  real* park = rc_records(M, B, e, wv_lane());
-  const int have = p >= 0;
+  const PolyTab tab = rc_poly_tables(M, B, e);
+  real* hold = rc_records(M, B, e, wv_lane());          // the lane's own scratch record (containment test)
   const int iters = M.s.ccd_N;
   const real tol = M.o.ccd_tolerance;
+  npairs = wv_uniform_i(npairs);
   LaneShape a, b;
-  {
-    const int g1 = have ? M.pair_geom1[p] : 0, g2 = have ? M.pair_geom2[p] : 0;
-    auto shape = [&](int g) {
-      LaneShape s;
-      s.g = g; s.vcache = -1; s.gcache = -1; s.mesh = -1; s.kind = SK_BOX;
-      if (M.geom_type[g] == MJH_GEOM_MESH) {
-        s.mesh = M.geom_dataid[g];
-        s.kind = (M.mesh_graphadr[s.mesh] < 0 || M.mesh_vertnum[s.mesh] < 10) ? SK_MESH_ALL : SK_MESH_CLIMB;
-      }
-      return s;
-    };
-    a = shape(g1); b = shape(g2);
-  }
   LaneVert s0, s1, s2, s3;
-  s0.pa = s0.pb = V3{0, 0, 0}; s0.ia = s0.ib = -1;
-  s1 = s0; s2 = s0; s3 = s0;
-  V3 x = ld3(gx + 3*a.g) - ld3(gx + 3*b.g);
-  real xlen = rw_len(x), xlen_before = 0;
+  V3 x{0, 0, 0};
+  real xlen = 0, xlen_before = 0;
   int n = 0, k = 0, try_containment = 1;
   int apart = 0, nsim = 0;
   real dist0 = 0;
   real lam[4] = {0, 0, 0, 0};
-  int st = have ? 0 : 2;              // 0 iterating, 1 leaves the loop for the closing support query, 2 finished
-  while (wv_any(st == 0)) {
+  int cur = -1;
+  // 0 iterating, 1 closing support query pending, 2 finished (result to be stored), 3 no pair
+  int st = 3;
+  auto start = [&](int t) {
+    cur = t;
+    const int p = tab.list[t];
+    const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+    auto shape = [&](int g) {
+      LaneShape sh;
+      sh.g = g; sh.vcache = -1; sh.gcache = -1; sh.mesh = -1; sh.kind = SK_BOX;
+      if (M.geom_type[g] == MJH_GEOM_MESH) {
+        sh.mesh = M.geom_dataid[g];
+        sh.kind = (M.mesh_graphadr[sh.mesh] < 0 || M.mesh_vertnum[sh.mesh] < 10) ? SK_MESH_ALL : SK_MESH_CLIMB;
+      }
+      return sh;
+    };
+    a = shape(g1); b = shape(g2);
+    s0.pa = s0.pb = V3{0, 0, 0}; s0.ia = s0.ib = -1;
+    s1 = s0; s2 = s0; s3 = s0;
+    x = ld3(gx + 3*g1) - ld3(gx + 3*g2);
+    xlen = rw_len(x); xlen_before = 0;
+    n = 0; k = 0; try_containment = 1; apart = 0; nsim = 0; dist0 = 0;
+    lam[0] = lam[1] = lam[2] = lam[3] = 0;
+    st = 0;
+  };
+  a.g = b.g = 0; a.kind = b.kind = SK_BOX; a.mesh = b.mesh = -1; a.vcache = a.gcache = b.vcache = b.gcache = -1;
+  s0.pa = s0.pb = V3{0, 0, 0}; s0.ia = s0.ib = -1;
+  s1 = s0; s2 = s0; s3 = s0;
+  if (wv_lane() < npairs) start(wv_lane());
+  int next_free = npairs < MJH_WAVE ? npairs : MJH_WAVE;
+  while (wv_any(st != 3)) {
+    if (st == 0) RC_COUNT(1);
+    if (st == 0 && (!(k < iters) || xlen < MJH_MINVAL || fabs(xlen_before - xlen) < MJH_MINVAL)) st = 1;
     int it = st == 0;
-    if (have) RC_COUNT(1);
-    if (it && !(k < iters)) { st = 1; it = 0; }
-    if (it && (xlen < MJH_MINVAL || fabs(xlen_before - xlen) < MJH_MINVAL)) { st = 1; it = 0; }
+    const int closing = st == 1;
     const V3 dn = rw_scl(x, 1/xlen);
-    const LaneVert f = lp_pair_far(M, gx, gm, a, b, rw_scl(dn, -1), dn, it);
+    const LaneVert f = lp_pair_far(M, gx, gm, a, b, rw_scl(dn, -1), dn, it || closing);
+    if (closing) {
+      // the closing support query along x: apart after all?
+      if (dot(x, lv_mink(f)) > 0) apart = 1;
+      nsim = n;
+      dist0 = (n == 4 && !apart) ? 0 : xlen;
+      st = 2;
+    }
     lv_put(n, it, s0, s1, s2, s3, f);
     const V3 s = lv_mink(f);
     if (it && dot(x, x - s) < 0) { st = 1; it = 0; }
@@ -2094,7 +2132,7 @@ MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
     // the tetrahedron test once the simplex has four points
     const int ct = it && n == 3 && try_containment;
     if (wv_any(ct)) {
-      if (ct) lp_park(park, s0, s1, s2, s3);
+      if (ct) lp_park(hold, s0, s1, s2, s3);
       int p0 = 0, p1 = 1, p2 = 2, p3 = 3, kk = k, ans = -1, run = ct;
       while (wv_any(run)) {
         if (run && !(kk < iters)) run = 0;
@@ -2138,13 +2176,13 @@ MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
         }
       }
       if (ct) {
-        if (have) RC_COUNT(2);
+        RC_COUNT(2);
         if (ans != -1) {
           apart = ans == 0; dist0 = ans > 0 ? 0 : RC_DBLMAX; nsim = ans > 0 ? 4 : 0;
           st = 2; it = 0;
         } else {
           // undecided: the simplex as it was, the iteration count where the test stopped
-          s0 = lp_unpark(park, 0); s1 = lp_unpark(park, 1); s2 = lp_unpark(park, 2); s3 = lp_unpark(park, 3);
+          s0 = lp_unpark(hold, 0); s1 = lp_unpark(hold, 1); s2 = lp_unpark(hold, 2); s3 = lp_unpark(hold, 3);
           k = kk;
           try_containment = 0;
         }
@@ -2185,27 +2223,25 @@ MJH_DEVN_HOT int ccd_poly_distance(MREF M_, BREF B_, int e_, int p) {
         if (n == 4) st = 1; else k++;
       }
     }
-  }
-  // the closing support query along x: apart after all?
-  {
-    const int fin = st == 1;
-    const V3 dn = rw_scl(x, 1/xlen);
-    const LaneVert f = lp_pair_far(M, gx, gm, a, b, rw_scl(dn, -1), dn, fin);
+    // finished pairs: store the result, take the next pair of the list
+    const int fin = st == 2;
+    const unsigned long long finished = wv_ballot(fin);
     if (fin) {
-      if (dot(x, lv_mink(f)) > 0) apart = 1;
-      nsim = n;
-      dist0 = (n == 4 && !apart) ? 0 : xlen;
+      RC_COUNT(0);
+      const int overlap = dist0 <= tol && nsim > 1 && !apart;
+      tab.flag[cur] = overlap;
+      if (overlap) {
+        real* park = tab.park + 32*(size_t)cur;
+        lp_park(park, s0, s1, s2, s3);
+        int* pi = (int*)(park + 24);
+        pi[8] = nsim; pi[9] = a.vcache; pi[10] = a.gcache; pi[11] = b.vcache; pi[12] = b.gcache;
+      }
+      const int t = next_free + wv_rank_lt(finished);
+      if (t < npairs) start(t); else { st = 3; cur = -1; }
     }
-  }
-  const int overlap = have && dist0 <= tol && nsim > 1 && !apart;
-  if (have) RC_COUNT(0);
-  if (overlap) {
-    lp_park(park, s0, s1, s2, s3);
-    int* pi = (int*)(park + 24);
-    pi[8] = nsim; pi[9] = a.vcache; pi[10] = a.gcache; pi[11] = b.vcache; pi[12] = b.gcache;
+    next_free += __builtin_popcountll(finished);
   }
   wv_sync();
-  return overlap;
 }
 
 // Every lane of the wavefront brings (at most) one pair: the pairs are listed, row r takes entries r, r + 4, ... of the
@@ -2241,13 +2277,21 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   }
   wv_converge();
   wv_sync();
-  tick(46);
-  // first pass of the polyhedral pairs: one pair per lane, simplex in registers
+  // first pass of the polyhedral pairs: one pair per lane, simplex in registers -- unless stage_collision ran it for all
+  // pairs in reach at once (ccd_poly_prepass: head[193] set), then the results are looked up
+  const PolyTab tab = rc_poly_tables(M, B, e);
+  int entry = -1;                               // my pair's entry in the tables
   {
     const int poly = p >= 0 && rc_max_contacts(M, p) > 1;
-    if (wv_any(poly)) {
-      const int overlap = ccd_poly_distance(M, B, e, poly ? p : -1);
-      if (poly) head[128 + wv_lane()] = overlap ? -1 : 0;
+    const unsigned long long polys = wv_ballot(poly);
+    if (polys) {
+      if (head[193]) { if (poly) entry = tab.slot[p]; }
+      else {
+        if (poly) { entry = wv_rank_lt(polys); tab.list[entry] = p; }
+        wv_sync();
+        ccd_poly_distance(M, B, e, __builtin_popcountll(polys));
+      }
+      if (poly) head[128 + wv_lane()] = tab.flag[entry] ? -1 : 0;
     }
   }
   wv_sync();
@@ -2257,11 +2301,11 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
   const int ndeep = __builtin_popcountll(deep);
   if (ndeep) {
     wv_sync();
-    if ((deep >> wv_lane()) & 1) { const int t = wv_rank_lt(deep); head[t] = p; head[64 + t] = wv_lane(); }
+    if ((deep >> wv_lane()) & 1) { const int t = wv_rank_lt(deep); head[t] = p; head[64 + t] = wv_lane() | (entry << 8); }
     wv_sync();
     for (int t = row; t < ndeep; t += 4) {
-      const int owner = head[64 + t];
-      const int n = rc_poly_pair_penetration(M, B, e, c, head[t], rc_records(M, B, e, owner));
+      const int owner = head[64 + t] & 63;
+      const int n = rc_poly_pair_penetration(M, B, e, c, head[t], tab.park + 32*(size_t)(head[64 + t] >> 8), rc_records(M, B, e, owner));
       if (rw_l() == 0) head[128 + owner] = n;
     }
     wv_converge();

@@ -1051,8 +1051,19 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.ccd_slow_bytes = (6*nsv + 4*nsf)*(int)sizeof(real) + ((2*nsv + 6*nsf + nsf + 2*nsf + 2*nsf + 16 + 1) & ~1)*(int)sizeof(int);
       s.ccd_rows = m->nflex > 0 ? 4*MJH_MW : 4;
       // (header, contact records, overflow pages, and the rows' fast pages for launches whose LDS plan has no room for them)
+      // polyhedral pairs (rc_max_contacts > 1, mjh_convex.h): tables of their distance phase (rc_poly_tables)
+      s.ccd_npoly = 0;
+      {
+        const bool multiccd = !(m->opt.disableflags & (1 << 19));
+        for (int p = 0; p < s.npair; p++) {
+          const int t1 = m->geom_type[H->pair_geom1[p]], t2 = m->geom_type[H->pair_geom2[p]];
+          if (multiccd && !(H->pair_margin[p] > 0) && (t1 == mjGEOM_BOX || t1 == mjGEOM_MESH) && (t2 == mjGEOM_BOX || t2 == mjGEOM_MESH))
+            s.ccd_npoly++;
+        }
+      }
+      const int poly_tables = s.ccd_npoly*32*(int)sizeof(real) + ((s.npair + 2*s.ccd_npoly + 1) & ~1)*(int)sizeof(int);
       s.ccd_env_bytes = 256*(int)sizeof(int) + 64*5*7*(int)sizeof(real) + s.ccd_rows*s.ccd_slow_bytes +
-                        s.ccd_rows*s.ccd_row_reals*(int)sizeof(real);
+                        s.ccd_rows*s.ccd_row_reals*(int)sizeof(real) + poly_tables;
     }
   }
 

@@ -361,6 +361,7 @@ struct DSizes {
   // reals + ints of it counted in reals (the LDS-planned field ccd_row holds 4 of these per environment), bytes of a
   // row's overflow page and of an environment's global block (header, contact records, 4 overflow pages)
   int ccd_row_freal, ccd_row_reals, ccd_slow_bytes, ccd_env_bytes;
+  int ccd_npoly;       // static pairs that may return several contacts (box / mesh against box / mesh without margin)
   int ccd_rows;        // row workspaces per environment: 4 (one wavefront), 4 MJH_MW for flex models (multi-wavefront workgroups)
   // sparse constraint path (mjh_sparse.h): 1 when the reference runs its sparse code (mj_isSparse; nv <= 128 here);
   // capacity of the CSR Jacobian; entries of the compressed factor (Newton; x2 with cones)
