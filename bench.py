@@ -459,7 +459,9 @@ def main() -> None:
         events.append((e0, e1, ctrl.shape[1]))
 
     snap = {}
-    cpu_rows = min(nenv, max(1024, 4*(os.cpu_count() or 1)))     # rows of the batch the CPU leg re-steps
+    # rows of the batch the CPU leg re-steps: as many as ~2 M env-steps allow (all 4096 at the driver's 25 steps -- a leg of
+    # 1024 rollouts x 25 steps lasted 12 ms, thread start-up included), never fewer than 4 per host thread
+    cpu_rows = min(nenv, max(1024, 4*(os.cpu_count() or 1), 2_000_000 // max(1, W + K)))
     host_ctrl = []                                                   # their control stream, in launch order
 
     def make_controls(kind, crng, sizes, t_begin):
