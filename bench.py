@@ -612,9 +612,16 @@ def main() -> None:
         gs = torch.cat([x.index_select(0, idx) for x in state_w + state_k], dim=1).cpu().numpy()
         cs = torch.cat([x.index_select(0, idx) for x in ctrl_w + ctrl_k], dim=1).cpu().numpy()
         def step_once(states, warm, u):
-            small = ma.Batch(dm, len(states), device=local_rank)
-            out = small.rollout_host(1, ma.mjSTATE_CTRL, states, warm, u)[:, 0]
-            return out, small.get("counts")
+            # (in slices of at most `nenv` environments: a batch reserves the reference's arena -- up to 16 MiB of
+            # constraint rows -- per environment, and the sample at 500 steps is 38400 environments)
+            outs, cnts = [], []
+            for a in range(0, len(states), nenv):
+                b = min(len(states), a + nenv)
+                small = ma.Batch(dm, b - a, device=local_rank)
+                outs.append(small.rollout_host(1, ma.mjSTATE_CTRL, states[a:b], warm[a:b], u[a:b])[:, 0])
+                cnts.append(small.get("counts"))
+                small.close()
+            return np.concatenate(outs), np.concatenate(cnts)
 
         try:
             res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, snap_metric["state"][envs] if snap_metric else s0[envs], cs, gs, envs,

@@ -953,10 +953,24 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
       }
       return first;
     };
+    // compressed rows with explicit column indices (mjh_csr.h): a scanned row's trees are those of its stored dofs, and
+    // its edges join the trees of consecutive entries -- taken one lane per stored ENTRY instead of one lane walking a
+    // row (a flex contact's row holds a dozen dofs; the labels live in global memory)
+    const int csr = MJH_HAS(MJH_FT_PRIMAL) && s.csr;
+    const int nJ = csr ? counts[MJH_C_NJ] : 0;
+    auto entry_row = [&](int q) -> int {
+      int lo = 0, hi = nefc;                               // the row r with rowadr[r] <= q < rowadr[r + 1]
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.rowadr[mid] <= q) lo = mid; else hi = mid; }
+      return lo;
+    };
+    if (csr) { MJH_FOR_LANES(q, nJ) { const int t = M.dof_treeid[P.colind[q]]; label[t] = t; } }
     MJH_FOR_LANES(i, nefc) {
       int t1, t2;
       row_trees(i, &t1, &t2);
-      if (t2 == -3) {
+      if (t2 == -3 && csr) {
+        const int a = P.rowadr[i];
+        efc_tree[i] = a < P.rowadr[i + 1] ? (int)M.dof_treeid[P.colind[a]] : 0;
+      } else if (t2 == -3) {
         t1 = scan_row(i, [&](int a, int b) { label[a] = a; label[b] = b; });
         if (t1 >= 0) label[t1] = t1;
         efc_tree[i] = t1 >= 0 ? t1 : 0;
@@ -994,8 +1008,24 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
           wv_atomic_min_i(&label[lb], m);
           moved = 1;
         };
-        if (t2 == -3) scan_row(i, join);
+        if (t2 == -3) { if (!csr) scan_row(i, join); }
         else if (t2 >= 0) join(efc_tree[i], t2);
+      }
+      if (csr) {
+        MJH_FOR_LANES(q, nJ - 1) {
+          const int r = entry_row(q);
+          if (second[r] != -3 || q + 1 >= P.rowadr[r + 1]) continue;
+          const int a = M.dof_treeid[P.colind[q]], b = M.dof_treeid[P.colind[q + 1]];
+          if (a == b) continue;
+          const int la = label[a], lb = label[b];
+          if (la == lb) continue;
+          const int m = la < lb ? la : lb;
+          wv_atomic_min_i(&label[a], m);
+          wv_atomic_min_i(&label[b], m);
+          wv_atomic_min_i(&label[la], m);
+          wv_atomic_min_i(&label[lb], m);
+          moved = 1;
+        }
       }
       wv_sync();
       MJH_FOR_LANES(t, ntree) {

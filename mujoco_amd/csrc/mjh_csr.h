@@ -13,14 +13,31 @@
 
 #if !MJH_LANE_MODE
 
-// dofs of body b's chain into out[] (descending), returns the count
+// dofs of body b's chain into out[] (descending), returns the count: the walk from the last dof of the weld body through
+// dof_parentid, tabulated at upload (M.body_chain) so that the loads do not depend on each other
 template <class IP>
 MJH_DEV int csr_body_chain(MREF M, int b, IP out) {
-  const int w = M.body_weldid[b];
-  int n = 0;
-  if (M.body_dofnum[w] == 0) return 0;
-  for (int j = M.body_dofadr[w] + M.body_dofnum[w] - 1; j >= 0; j = M.dof_parentid[j]) out[n++] = j;
+  const int a0 = M.body_chainadr[b], n = M.body_chainadr[b + 1] - a0;
+  for (int i = 0; i < n; i++) out[i] = M.body_chain[a0 + i];
   return n;
+}
+
+// the stored dofs of contact k's rows: the merged chains of its bodies, ascending, dofs common to two chains removed
+// (flg_skipcommon of mj_jacDifPair); returns their number.  fbody / fw / nfb: the flex side (flex_contact_weights)
+MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, int* cols, int* fbody, real* fw, int* nfb_out) {
+  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+  const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+  int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
+  if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
+  else n += csr_body_chain(M, M.geom_bodyid[cg[1]], cols + n);
+  for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
+  int m = 0;
+  for (int a = 0; a < n; a++) {
+    if (a + 1 < n && cols[a] == cols[a + 1]) { a++; continue; }
+    cols[m++] = cols[a];
+  }
+  *nfb_out = nfb;
+  return m;
 }
 
 MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
@@ -35,12 +52,9 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   Efc P;
   efc_layout(M, B, e, nefc, P);
   iptr rowadr = P.rowadr;
-  iptr colind = MJH_G(B, sp_colind, e);
-  rptr val = MJH_G(B, sp_J, e);
   crptr Jd = MJH_G(B, efc_J, e);
   crptr cdof = MJH_F(B, cdof, e);
   crptr subtree_com = MJH_F(B, subtree_com, e);
-  const int cap = s.csr_rowmax;
 
   // ---- pass 1: stored entries per row (rowadr[r + 1] <- nnz of row r)
   MJH_FOR_LANES(r, nefc) {
@@ -57,25 +71,14 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     if (nnz >= 0) rowadr[r + 1] = nnz;
   }
   wv_sync();
-  // contacts: the merged chain, written (sorted, common dofs removed) to the head of a private slot of the column array;
-  // slot of contact k: [k*cap, (k+1)*cap) of the TAIL half of sp_colind is not available before nJ is known, so the chain
-  // is rebuilt in pass 2 -- here only its length
   MJH_FOR_LANES(k, ncon) {
     const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     if (r0 < 0) continue;
     const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     const int nrow = dim == 1 ? 1 : (ispyramid ? 2*(dim - 1) : dim);
-    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int fbody[4]; real fw[4];
-    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
+    int fbody[4]; real fw[4]; int nfb;
     int cols[MJH_CSR_CHAIN_MAX];
-    int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
-    if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
-    else n += csr_body_chain(M, M.geom_bodyid[cg[1]], cols + n);
-    // common dofs appear twice: they cancel (flg_skipcommon)
-    int dup = 0;
-    for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (cols[a] == cols[b]) dup++;
-    const int nnz = n - 2*dup;
+    const int nnz = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
     for (int a = 0; a < nrow; a++) rowadr[r0 + a + 1] = nnz;
   }
   wv_sync();
@@ -95,8 +98,11 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   // (nJ is known now: with the CU's whole LDS block to itself -- launches of one workgroup per CU -- the layout gives
   // the compressed rows and their transpose LDS slots, and they are written there directly)
   efc_layout(M, B, e, nefc, P);
-  colind = P.colind;
-  val = P.spJ;
+  iptr colind = P.colind;
+  rptr val = P.spJ;
+  iptr JTadr = P.JTadr;
+  iptr JTrow = P.JTrow;
+  rptr JTval = P.spJT;
 
   // ---- pass 2: columns and values
   MJH_FOR_LANES(r, nefc) {
@@ -114,26 +120,38 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
       for (int q = 0; q < nd; q++) { colind[a0 + q] = d0 + q; val[a0 + q] = Jd[(size_t)r*nv + d0 + q]; }
     }
   }
-  MJH_FOR_LANES(k, ncon) {
+  // contacts, (a): one lane per contact lists the stored dofs in the first row's column slots and deals the (contact,
+  // column) items of (b) -- into the transpose's row array, which is not written before the transpose below
+  iptr items = JTrow;
+  int nitems = 0;
+  for (int k0 = 0; k0 < ncon; k0 += MJH_W) {
+    const int k = k0 + wv_lane();
+    int m = 0, a0 = 0;
+    int cols[MJH_CSR_CHAIN_MAX];
+    if (k < ncon) {
+      const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
+      if (r0 >= 0) {
+        int fbody[4]; real fw[4]; int nfb;
+        m = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
+        a0 = rowadr[r0];
+      }
+    }
+    const int before = wv_exscan_i(m);
+    const int sum = wv_sum_i(m);
+    for (int c = 0; c < m; c++) { colind[a0 + c] = cols[c]; items[nitems + before + c] = k*MJH_CSR_CHAIN_MAX + c; }
+    nitems += sum;
+  }
+  wv_sync();
+  // (b): one lane per (contact, stored dof): the column of the contact's rows
+  MJH_FOR_LANES(w, nitems) {
+    const int k = items[w]/MJH_CSR_CHAIN_MAX, c = items[w]%MJH_CSR_CHAIN_MAX;
     const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
-    if (r0 < 0) continue;
     const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
     int fbody[4]; real fw[4];
     const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
     const int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
     const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
-    int cols[MJH_CSR_CHAIN_MAX];
-    int n = csr_body_chain(M, b1, cols);
-    if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
-    else n += csr_body_chain(M, b2, cols + n);
-    // ascending, common dofs removed
-    for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
-    int m = 0;
-    for (int a = 0; a < n; a++) {
-      if (a + 1 < n && cols[a] == cols[a + 1]) { a++; continue; }
-      cols[m++] = cols[a];
-    }
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
     auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
@@ -142,55 +160,52 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
     const int a0 = rowadr[r0];
     const int stride = rowadr[r0 + 1] - a0;             // every row of the contact has the same pattern
-    for (int c = 0; c < m; c++) {
-      const int j = cols[c];
-      // (the expressions of stage_make_constraint's dense contact rows)
-      const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-      const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-      real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
-      crptr cd = cdof + 6*j;
-      if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
-      if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
-      real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
-      if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
-        jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
-        for (int q = 0; q < nfb; q++) {
-          const int wq = M.body_weldid[fbody[q]];
-          if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
-          real offq[3], t[3];
-          v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
-          v3_cross(t, cd, offq);
-          const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
-          jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
-        }
+    const int j = colind[a0 + c];
+    // (the expressions of stage_make_constraint's dense contact rows)
+    const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+    const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+    real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+    crptr cd = cdof + 6*j;
+    if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+    if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
+    real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+    if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
+      jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
+      for (int q = 0; q < nfb; q++) {
+        const int wq = M.body_weldid[fbody[q]];
+        if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+        real offq[3], t[3];
+        v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
+        v3_cross(t, cd, offq);
+        const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
+        jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
       }
-      const int nr = dim > 1 ? 3 : 1;
-      real jr[3] = {0, 0, 0};
-      for (int a = 0; a < nr; a++) {
-        real acc = 0;
-        for (int q = 0; q < 3; q++) { const real t = fr[3*a + q]; if (t != 0) acc += jd[q]*t; }
-        jr[a] = acc;
+    }
+    const int nr = dim > 1 ? 3 : 1;
+    real jr[3] = {0, 0, 0};
+    for (int a = 0; a < nr; a++) {
+      real acc = 0;
+      for (int q = 0; q < 3; q++) { const real t = fr[3*a + q]; if (t != 0) acc += jd[q]*t; }
+      jr[a] = acc;
+    }
+    if (dim == 1) { val[a0 + c] = jr[0]; }
+    else if (ispyramid) {
+      for (int a = 1; a < dim; a++) {
+        const int ra = a0 + (2*(a - 1))*stride + c, rb = a0 + (2*(a - 1) + 1)*stride + c;
+        colind[ra] = j; val[ra] = jr[0] + jr[a]*fri[a - 1];
+        colind[rb] = j; val[rb] = jr[0] + jr[a]*(-fri[a - 1]);
       }
-      if (dim == 1) { colind[a0 + c] = j; val[a0 + c] = jr[0]; }
-      else if (ispyramid) {
-        for (int a = 1; a < dim; a++) {
-          const int ra = a0 + (2*(a - 1))*stride + c, rb = a0 + (2*(a - 1) + 1)*stride + c;
-          colind[ra] = j; val[ra] = jr[0] + jr[a]*fri[a - 1];
-          colind[rb] = j; val[rb] = jr[0] + jr[a]*(-fri[a - 1]);
-        }
-      } else {
-        for (int a = 0; a < dim; a++) { colind[a0 + a*stride + c] = j; val[a0 + a*stride + c] = jr[a]; }
-      }
+    } else {
+      for (int a = 0; a < dim; a++) { colind[a0 + a*stride + c] = j; val[a0 + a*stride + c] = jr[a]; }
     }
   }
   wv_sync();
 
-  // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse); counting pass with integer atomics,
-  //      then each dof sorts its (short) list by row
-  iptr JTadr = P.JTadr;
-  iptr JTrow = P.JTrow;
-  rptr JTval = P.spJT;
+  // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse): counting pass with integer atomics,
+  //      one lane per stored entry scatters it (its row by bisection of the row addresses), then each dof sorts its
+  //      (short) list by row.  The cursors sit in the unused tail of the LDS regions when it has room.
   iptr cursor = MJH_G(B, csr_idof, e);
+  if (P.free_bytes >= nv*(int)sizeof(int)) cursor = SP<int>{(int*)P.free_p, 1};
   MJH_FOR_LANES(j, nv + 1) JTadr[j] = 0;
   MJH_FOR_LANES(j, nv) cursor[j] = 0;
   wv_sync();
@@ -209,12 +224,12 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
-  MJH_FOR_LANES(r, nefc) {
-    for (int q = rowadr[r]; q < rowadr[r + 1]; q++) {
-      const int j = colind[q];
-      const int pos = JTadr[j] + wv_atomic_add_i(&cursor[j], 1);
-      JTrow[pos] = r; JTval[pos] = val[q];
-    }
+  MJH_FOR_LANES(q, total) {
+    int lo = 0, hi = nefc;                                 // the row r with rowadr[r] <= q < rowadr[r + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowadr[mid] <= q) lo = mid; else hi = mid; }
+    const int j = colind[q];
+    const int pos = JTadr[j] + wv_atomic_add_i(&cursor[j], 1);
+    JTrow[pos] = lo; JTval[pos] = val[q];
   }
   wv_sync();
   MJH_FOR_LANES(j, nv) {

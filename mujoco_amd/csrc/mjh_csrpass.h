@@ -1,0 +1,128 @@
+// Passes over the dofs of the explicit-index CG solver (mjh_newton.h, SPA = 2) as functions of an ARGUMENT BLOCK, so that a
+// multi-wavefront workgroup can run them on all of its wavefronts (mjh_modes.h: namespace wq, MJH_WIDE_ARGS).
+//
+// A CG iteration of mj_solPrimal (engine_solver.c:2344-2563) touches every dof a dozen times -- M search, the move along
+// the search direction, qfrc_constraint = J' force, the gradient, the preconditioner, the Hager-Zhang differences, the new
+// direction -- and with nv = 1536 (jelly.xml) one wavefront spends most of the solve waiting for those element-wise passes'
+// memory round trips, 24 elements per lane at a time.  Nothing in them crosses dofs: here they are FUSED into two passes per
+// iteration (CSR_OP_STEP after the line search, CSR_OP_DIR after the termination tests) and two for the set-up
+// (CSR_OP_WARM, CSR_OP_START), each a loop over "lane = dof" with the group's width -- 64 lanes in the one-wavefront
+// mappings, 64 MJH_MW in a multi-wavefront workgroup.  Every element is computed by the expressions of the unfused code in
+// mjh_newton.h (same operands, same order), so results are bit-identical; the ORDERED sums of the iteration (mju_dot's four
+// accumulator chains, csr_dots) stay on one wavefront and read the vectors these passes leave in LDS.
+//
+// Preconditions (solve_primal checks them, else it takes the unfused path): CG, environment-major batch, the island spans
+// every dof (flex stiffness unions the trees of a flex: engine_island.c:409-440), diagonal mass matrix (every dof a slider of
+// its own body: nC == nv), so mul_M is Ms[i]*v[i] and mj_solveLD is x[i]*qLDiagInv[i].
+// (included once per SPMD mode by mjh_stages.inc and by namespace wq: no include guard; CsrPass itself lives in mjh_types.h)
+
+#if !MJH_LANE_MODE
+
+#define MJH_CSR_U 4           // elements per lane whose loads are issued together
+
+// qfrc_constraint[i] = mju_dotSparse over the rows that contain dof i (mju_mulMatVecSparse on J', engine_util_sparse.c):
+// four accumulators over the stored entries in groups of four, then the rest one by one
+MJH_DEV real csr_pass_jtf(const CsrPass& A, int a0, int n) {
+  const real* v = A.spJT + a0;
+  const int* ri = A.JTrow + a0;
+  real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int k = 0;
+  for (; k <= n - 4; k += 4) {
+    r0 += v[k]*A.force[ri[k]]; r1 += v[k + 1]*A.force[ri[k + 1]];
+    r2 += v[k + 2]*A.force[ri[k + 2]]; r3 += v[k + 3]*A.force[ri[k + 3]];
+  }
+  real res = (r0 + r2) + (r1 + r3);
+  for (; k < n; k++) res += v[k]*A.force[ri[k]];
+  return res;
+}
+
+MJH_DEV void csr_pass(MREF M, const CsrPass& A) {
+  const int lane = wv_lane(), nv = A.nv;
+  real* const Ma = A.vec; real* const grad = A.vec + nv; real* const Mgrad = A.vec + 2*nv; real* const search = A.vec + 3*nv;
+  real* const Mv = A.vec + 4*nv; real* const Mgraddif = A.vec + 5*nv; real* const graddif = A.vec + 7*nv;
+  if (A.op == CSR_OP_WARM) {
+    // warm start (engine_forward.c:1056-1132): Ma = M qacc_warmstart and the addends of
+    // 0.5 (Ma - qfrc_smooth)' (qacc_warmstart - qacc_smooth), which the caller sums in the reference's order
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+      real ms[MJH_CSR_U], w[MJH_CSR_U], f[MJH_CSR_U], s[MJH_CSR_U];
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; ms[u] = A.Ms[i]; w[u] = A.qws[i]; f[u] = A.qfs[i]; s[u] = A.qas[i]; }
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W;
+        if (i < nv) { const real ma = ms[u]*w[u]; Ma[i] = ma; A.stage[i] = 0.5*(ma - f[u])*(w[u] - s[u]); }
+      }
+    }
+  } else if (A.op == CSR_OP_START) {
+    // the starting point: qacc_warmstart or qacc_smooth (flag bit 0), qacc_smooth on the dofs of unconstrained trees
+    // (bit 1: islands), Ma = M qacc; bit 2: the diagonal of M into the staging vector (the island's trace, summed by the
+    // caller); copy: qfrc_smooth into its LDS copy
+    const int use_smooth = A.flag & 1, trees = A.flag & 2, trace = A.flag & 4;
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+      real ms[MJH_CSR_U], q[MJH_CSR_U], s[MJH_CSR_U], f[MJH_CSR_U]; int out[MJH_CSR_U];
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
+        ms[u] = A.Ms[i]; s[u] = A.qas[i]; q[u] = use_smooth ? s[u] : (real)A.qws[i];
+        out[u] = trees ? (int)(A.tree_island[M.dof_treeid[i]] < 0) : 0;
+        f[u] = A.copy ? (real)A.qfs[i] : (real)0;
+      }
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W;
+        if (i < nv) {
+          const real qq = out[u] ? s[u] : q[u];
+          A.qacc[i] = qq; Ma[i] = ms[u]*qq;
+          if (trace) A.stage[i] = ms[u];
+          if (A.copy) A.copy[i] = f[u];
+        }
+      }
+    }
+  } else if (A.op == CSR_OP_GRAD || A.op == CSR_OP_STEP) {
+    // PrimalUpdateConstraint's qfrc_constraint = J' force, PrimalUpdateGrad, the preconditioner Mgrad = M \ grad; CSR_OP_STEP
+    // first moves qacc and Ma along the search direction and afterwards leaves the Hager-Zhang differences
+    // graddif = grad - grad_old, Mgraddif = Mgrad - Mgrad_old (engine_solver.c:2489-2496)
+    const int step = A.op == CSR_OP_STEP;
+    const real alpha = A.alpha;
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+      int b0[MJH_CSR_U], b1[MJH_CSR_U];
+      real ma[MJH_CSR_U], f[MJH_CSR_U], di[MJH_CSR_U], q[MJH_CSR_U], sv[MJH_CSR_U], mv[MJH_CSR_U], g0[MJH_CSR_U], mg0[MJH_CSR_U];
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
+        b0[u] = A.JTadr[i]; b1[u] = A.JTadr[i + 1];
+        ma[u] = Ma[i]; f[u] = A.qfs[i]; di[u] = A.dinv[i];
+        if (step) { q[u] = A.qacc[i]; sv[u] = search[i]; mv[u] = Mv[i]; g0[u] = grad[i]; mg0[u] = Mgrad[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W;
+        if (i >= nv) continue;
+        if (step) { A.qacc[i] = q[u] + sv[u]*alpha; ma[u] = ma[u] + mv[u]*alpha; Ma[i] = ma[u]; }
+        const real res = csr_pass_jtf(A, b0[u], b1[u] - b0[u]);
+        A.qfc[i] = res;
+        const real g = ma[u] - f[u] - res;
+        const real mg = g*di[u];
+        grad[i] = g; Mgrad[i] = mg;
+        if (step) { graddif[i] = g - g0[u]; Mgraddif[i] = mg - mg0[u]; }
+      }
+    }
+  } else if (A.op == CSR_OP_DIR) {
+    // the search direction -- -Mgrad at the start, Hager-Zhang's -Mgrad + beta search afterwards -- and Mv = M search
+    const int first = A.flag & 1;
+    const real beta = A.alpha;
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+      real mg[MJH_CSR_U], sv[MJH_CSR_U], ms[MJH_CSR_U];
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; mg[u] = Mgrad[i]; sv[u] = first ? (real)0 : search[i]; ms[u] = A.Ms[i]; }
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*MJH_W;
+        if (i < nv) { const real s = first ? -1*mg[u] : -mg[u] + beta*sv[u]; search[i] = s; Mv[i] = ms[u]*s; }
+      }
+    }
+  }
+  wv_sync();
+}
+
+#endif   // !MJH_LANE_MODE

@@ -1256,6 +1256,19 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       for (int g = 0; g < m->ngeom && s.csr && s.nflexpair > 0; g++) if (m->geom_condim[g] > 3) s.csr = 0;
       for (int f = 0; f < m->nflex && s.csr; f++) if (m->flex_condim[f] > 3) s.csr = 0;
     }
+    // the dof chains csr_body_chain would walk through dof_parentid, as a table (independent loads on the device)
+    H->body_chainadr.assign(m->nbody + 1, 0);
+    H->body_chain.clear();
+    if (s.csr) {
+      for (int b = 0; b < m->nbody; b++) {
+        H->body_chainadr[b] = (int)H->body_chain.size();
+        const int w = m->body_weldid[b];
+        if (m->body_dofnum[w]) for (int j = m->body_dofadr[w] + m->body_dofnum[w] - 1; j >= 0; j = m->dof_parentid[j]) H->body_chain.push_back(j);
+      }
+      H->body_chainadr[m->nbody] = (int)H->body_chain.size();
+    }
+    if (H->body_chain.empty()) H->body_chain.push_back(0);
+    s.nchain = (int)H->body_chain.size();
     MJH_REJECT(eq_flex && !s.csr, "flex edge equality constraints outside the explicit-index CG path (more than 128 dofs, CG, "
                                   "sparse Jacobian, no other equality or tendon)");
     // default budget: what the reference's own arena (mjModel.narena, engine_memory.c:107-138) could hold, between 4 and

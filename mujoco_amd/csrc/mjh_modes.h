@@ -43,10 +43,11 @@ static inline const char* mjh_variant_name(int v) {
 }
 // stages every wavefront of a multi-wavefront workgroup runs together (mw_exec below)
 enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH_MWS_TAVEL, MJH_MWS_COMVEL, MJH_MWS_PASSIVE,
-       MJH_MWS_RNE, MJH_MWS_ELEMS };
+       MJH_MWS_RNE, MJH_MWS_ELEMS, MJH_MWS_CSRPASS, MJH_MWS_CRB, MJH_MWS_FACTOR, MJH_MWS_ACCEL, MJH_MWS_EULER };
 // bytes at the end of a multi-wavefront workgroup's LDS block that the residency plan leaves alone: the command word
-// wave 0 posts for the helper wavefronts
-#define MJH_MW_LDS_TAIL 64
+// wave 0 posts for the helper wavefronts (first 64 bytes) and the argument block of a stage that takes one (CsrPass)
+#define MJH_MW_LDS_TAIL 256
+#define MJH_MW_LDS_ARGS 64
 
 // ------------------------------------------------------------------------------------------------
 // wave mode (one environment per wavefront)
@@ -56,6 +57,9 @@ enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH
 #define MJH_DEVN MJH_DEVN_WAVE
 // a stage call that a multi-wavefront workgroup runs on all of its wavefronts (namespace wn redefines this)
 #define MJH_WIDE(id, call) call
+// the same for a stage that takes an argument block (posted through LDS in a multi-wavefront workgroup)
+#define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_WIDE_IF(cond, id, call) call
 // end of a section in which the rows of the group ran apart: everyone is back, memory is visible
 #define MJH_GROUP_JOIN() do { wv_converge(); wv_sync(); } while (0)
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
@@ -101,6 +105,8 @@ namespace ws {
 #undef MJH_FOR_LANES
 #undef MJH_ENTER
 #undef MJH_WIDE
+#undef MJH_WIDE_ARGS
+#undef MJH_WIDE_IF
 
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
@@ -127,6 +133,8 @@ namespace ws {
 #define MJH_DEVN MJH_DEVN_WAVE
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 #define MJH_WIDE(id, call) call
+#define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_WIDE_IF(cond, id, call) call
 #undef MJH_GROUP_JOIN
 #define MJH_GROUP_JOIN() wv_sync()
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
@@ -170,11 +178,14 @@ MJH_DEV void wv_sync() { __syncthreads(); }
 #include "mjh_smooth.h"
 #include "mjh_collision.h"
 #include "mjh_flexcol.h"
+#include "mjh_csrpass.h"
 }
 #undef MJH_FEATURES
 #undef MJH_W
 #undef MJH_FOR_LANES
 #undef MJH_WIDE
+#undef MJH_WIDE_ARGS
+#undef MJH_WIDE_IF
 #undef MJH_ENTER
 #undef MJH_GROUP_JOIN
 #define MJH_GROUP_JOIN() do { wv_converge(); wv_sync(); } while (0)
@@ -190,6 +201,11 @@ MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
     case MJH_MWS_PASSIVE: wq::stage_passive(M, B, e); break;
     case MJH_MWS_RNE: wq::stage_rne(M, B, e); break;
     case MJH_MWS_ELEMS: wq::rc_elem_rows(M, B, e); break;
+    case MJH_MWS_CRB: wq::stage_crb(M, B, e, 0); break;
+    case MJH_MWS_FACTOR: wq::stage_factor_m(M, B, e); break;
+    case MJH_MWS_ACCEL: wq::stage_acceleration(M, B, e); break;
+    case MJH_MWS_EULER: wq::euler_advance(M, B, e); break;
+    case MJH_MWS_CSRPASS: { const CsrPass A = *(const CsrPass*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS); wq::csr_pass(M, A); break; }
     default: break;
   }
 }
@@ -200,6 +216,11 @@ MJH_DEV void mw_run(MREF M, BREF B, int e, int id) {
   if (wv_lane() == 0) { cmd[0] = id; cmd[1] = e; }
   mw_barrier();
   mw_exec(M, B, e, id);
+}
+// wave 0: post a stage together with its argument block
+MJH_DEV void mw_run_args(MREF M, BREF B, int e, int id, const CsrPass& A) {
+  if (wv_lane() == 0) *(CsrPass*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS) = A;
+  mw_run(M, B, e, id);
 }
 // the helper wavefronts' whole program
 MJH_DEV void mw_helper_loop(MREF M, BREF B) {
@@ -222,6 +243,9 @@ MJH_DEV void mw_release_helpers(BREF B) {
 #define MJH_DEVN MJH_DEVN_WAVE
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 #define MJH_WIDE(id, call) mw_run(M, B, e, id)
+#define MJH_WIDE_ARGS(id, A, call) mw_run_args(M, B, e, id, A)
+// (a stage that is workgroup-wide only under a condition -- e.g. not when a register-resident one-wavefront routine applies)
+#define MJH_WIDE_IF(cond, id, call) do { if (cond) mw_run(M, B, e, id); else { call; } } while (0)
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
                               if (B.soa != 0) __builtin_unreachable()
 #define MJH_FEATURES MJH_FT_ALL
@@ -239,6 +263,8 @@ MJH_DEV void wv_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); 
 #undef MJH_W
 #undef MJH_FOR_LANES
 #undef MJH_WIDE
+#undef MJH_WIDE_ARGS
+#undef MJH_WIDE_IF
 #undef MJH_ENTER
 #undef MJH_LANE_MODE
 #undef MJH_DEVN
@@ -250,6 +276,8 @@ MJH_DEV void wv_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); 
 #define MJH_LANE_MODE 1
 #define MJH_DEVN MJH_DEVN_LANE
 #define MJH_WIDE(id, call) call
+#define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_WIDE_IF(cond, id, call) call
 #define MJH_FOR_LANES(i, n) for (int i = 0; i < (n); i++)
 // (stage functions are inlined into the kernel here: descriptors are already uniform, e is per lane)
 #define MJH_ENTER(M_, B_, e_) MREF M = M_; BREF B = B_; const int e = e_
@@ -276,3 +304,5 @@ MJH_DEV int wv_any(int pred) { return pred != 0; }
 #undef MJH_FOR_LANES
 #undef MJH_ENTER
 #undef MJH_WIDE
+#undef MJH_WIDE_ARGS
+#undef MJH_WIDE_IF

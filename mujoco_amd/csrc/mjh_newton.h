@@ -433,6 +433,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   int nidof = nv;
   // staging block of csr_dots: the unused tail of the LDS regions when it holds at least one product vector, else global
   real* dstage = nullptr; int dstage_cap = 0;
+  // the passes over the dofs as fused, possibly workgroup-wide functions of an argument block (mjh_csrpass.h): CG on an
+  // environment-major batch with a diagonal mass matrix; per island, when it spans every dof (`fused` below)
+  const int fuse_ok = SPA == 2 && !flg_newton && s.nC == nv && !B.soa;
+  real* qfs_copy = nullptr;
   if (SPA == 2) {
     int fb = P.free_bytes;
     // (the line search's quadratic coefficients are read row by row in every evaluation: they take the top of the free
@@ -442,6 +446,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // (qfrc_smooth is read twice per iteration -- PrimalPrepare's sums, the gradient: with room for it next to one
     // product vector the solver works on an LDS copy, and every ordered sum of the iteration is a direct one)
     // (the staging block below may then fall back to global memory: with qfrc_smooth in LDS no sum of the iteration is staged)
+    if (fuse_ok) {
+      // (fused passes, mjh_csrpass.h: CSR_OP_START makes the copy)
+      if (fb >= nv*(int)sizeof(real)) { fb -= nv*(int)sizeof(real); qfs_copy = (real*)(P.free_p + fb); }
+    } else
     if (fb >= nv*(int)sizeof(real)) {
       fb -= nv*(int)sizeof(real);
       real* c = (real*)(P.free_p + fb);
@@ -458,6 +466,27 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
     else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }
   }
+  CsrPass pa;
+  if (SPA == 2) {
+    pa.op = 0; pa.nv = nv; pa.flag = 0; pa.pad_ = 0; pa.alpha = 0;
+    pa.vec = vec.p; pa.qacc = qacc.p; pa.qfc = qfc.p; pa.stage = vec.p + 6*nv; pa.copy = nullptr;
+    pa.qfs = qfs.p; pa.dinv = MJH_F(B, qLDiagInv, e).p; pa.Ms = Ms.p; pa.qws = qws.p; pa.qas = qas.p;
+    pa.spJT = P.spJT.p; pa.force = P.force.p; pa.JTadr = P.JTadr.p; pa.JTrow = P.JTrow.p;
+    pa.tree_island = tree_island.p;
+  }
+  auto run_pass = [&](int op, int flag, real alpha) {
+    pa.op = op; pa.flag = flag; pa.alpha = alpha;
+#ifdef MJH_HOSTSIM
+    if (lane == 0) ::mjhsim::rc_stats()[6]++;
+#endif
+    MJH_WIDE_ARGS(MJH_MWS_CSRPASS, pa, csr_pass(M, pa));
+  };
+  // r + stage[0] + stage[1] + ... in order (one running sum of the reference over addends a pass left in the staging vector)
+  auto stage_sum = [&](real r) -> real {
+    const real* st = pa.stage;
+    const long long soff = mjh_lds_offset((const void*)st);
+    return (soff >= 0 && soff < 160*1024) ? csr_chain_serial(mjh_local(st), nv, r) : csr_chain_serial(st, nv, r);
+  };
   auto dotv = [&](crptr a, crptr b) -> real {
     if (SPA == 2) { real out[1]; const crptr xs[1] = {a}, ys[1] = {b}; csr_dots(nidof, idof, nidof == nv, 1, xs, ys, out, dstage, dstage_cap); return out[0]; }
     if (SPA) {
@@ -510,7 +539,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // PrimalUpdateConstraint (without the cost, which the solver never reads back): force, state, cone
   // Hessians, qfrc_constraint = J' force (mju_mulMatTVec: rows added in order), ncone
   int ncone = 0;
-  auto update_constraint = [&]() {
+  auto update_rows = [&]() {
     int cones = 0;
     MJH_FOR_LANES(r, nefc) {
       if (!in_row(r)) continue;
@@ -538,6 +567,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
     ncone = ELL ? wv_sum_i(cones) : 0;
     wv_sync();
+  };
+  auto update_constraint = [&]() {
+    update_rows();
     if (SPA) {
       // sparse: mju_mulMatVecSparse(J', force) -- one mju_dotSparse per dof over the rows that contain it
       // (SPA = 2: lanes over the island's dof list instead of testing every dof of the model)
@@ -949,6 +981,22 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
   // ---- warm start: best of (qacc_warmstart, qacc_smooth)        (warmstart, engine_forward.c:1056-1132)
   // (jar = J qacc_warmstart - aref and efc_b = J qacc_smooth - aref were left by stage_fwd_constraint)
+  const int trace_scale = !(M.o.disableflags & (1<<18)) && nisl_raw > 0;
+  if (fuse_ok) {
+    int use_smooth = 1;
+    if (!(M.o.disableflags & (1<<9))) {
+      run_pass(CSR_OP_WARM, 0, 0);
+      real cost_ws = constraint_update(B, e, P, jar, 1, elliptic);
+      cost_ws = stage_sum(cost_ws);
+      wv_sync();
+      const real cost_smooth = constraint_update(B, e, P, P.b, 1, elliptic);
+      use_smooth = cost_ws > cost_smooth;
+    }
+    pa.copy = qfs_copy;
+    run_pass(CSR_OP_START, use_smooth | (multi_tree ? 2 : 0) | (trace_scale ? 4 : 0), 0);
+    pa.copy = nullptr;
+    if (qfs_copy) { qfs = SP<const real>{qfs_copy, 1}; pa.qfs = qfs_copy; }
+  } else
   if (!(M.o.disableflags & (1<<9))) {
     mul_M(Ma, qws);
     real cost_ws = constraint_update(B, e, P, jar, 1, elliptic);
@@ -994,13 +1042,21 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   }
 
   // ---- mj_solPrimal -------------------------------------------------------------------------------------------
-  mul_M(Ma, qacc);
+  if (!fuse_ok) mul_M(Ma, qacc);
   mul_J(jar, qacc, 1);
   if (multi_tree) { MJH_FOR_LANES(j, nv) qfc[j] = 0; wv_sync(); }
   int niter0 = 0;
   tick(32);
   for (isl = 0; isl < nisl; isl++) {
-    if (SPA == 2) {
+    int fused = 0;
+    if (fuse_ok) {
+      // does the island span every dof?  (every tree belongs to it; without islands the solve is one problem anyway)
+      int miss = 0;
+      if (multi_tree) MJH_FOR_LANES(t, s.ntree) miss |= tree_island[t] != isl;
+      fused = !wv_any(miss);
+      if (fused) nidof = nv;
+    }
+    if (SPA == 2 && !fused) {
       nidof = 0;
       for (int j0 = 0; j0 < nv; j0 += MJH_W) {
         const int j = j0 + lane;
@@ -1015,14 +1071,19 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
       isl_dofs.hi = wv_ballot(lane + MJH_W < nv && in_dof(lane + MJH_W));
     }
-    update_constraint();
-    update_grad();
+    if (fused) { update_rows(); run_pass(CSR_OP_GRAD, 0, 0); }
+    else { update_constraint(); update_grad(); }
     tick(37);
 
     // scale: 1/(meaninertia*nv) monolithic, 1/trace(M over the island's dofs) per island
     real scale;
-    if (!(M.o.disableflags & (1<<18)) && nisl_raw > 0) {
+    if (trace_scale) {
       real tr = 0;
+      if (fused) {
+        // (the diagonal of M, left in the staging vector by CSR_OP_START, summed in order; the staging vector of a second
+        // island of this kind would have been overwritten -- there is only one island that spans every dof)
+        tr = stage_sum(0);
+      } else
       if (SPA == 2) {
         MJH_FOR_LANES(k, nidof) { const int i = idof[k]; dstage[k] = Ms[M.M_rowadr[i] + M.M_rownnz[i] - 1]; }
         wv_sync();
@@ -1036,7 +1097,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     }
 
     // convergence certificate with M^-1
-    precondition();
+    if (!fused) precondition();
     real gm_gg[2];
     if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, nidof == nv, 2, xs, ys, gm_gg, dstage, dstage_cap); }
     else { gm_gg[0] = dotv(grad, Mgrad); gm_gg[1] = dotv(grad, grad); }
@@ -1051,7 +1112,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       tick(34);
       done = flg_gradient && (r_max(0, 0.5*scale*dotv(grad, Mgrad)) < tol);
     }
-    if (!done) { MJH_FOR_LANES(i, nv) search[i] = -1*Mgrad[i]; wv_sync(); }
+    if (!done) {
+      if (fused) run_pass(CSR_OP_DIR, 1, 0);
+      else { MJH_FOR_LANES(i, nv) search[i] = -1*Mgrad[i]; wv_sync(); }
+    }
 
     int iter = 0;
     const int maxiter = M.o.iterations;
@@ -1062,7 +1126,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       if (SPA == 2) {
         // (a chain of nv/4 dependent additions costs the same for one product as for sixteen: |search|^2 shares the pass
         // of PrimalPrepare's three sums, so M search is formed first -- it is not read again if the norm ends the solve)
-        mul_M(Mv, search);
+        if (!fused) mul_M(Mv, search);
         tick(43);
         real q4[4];
         const crptr xs[4] = {search, search, qfs, search}, ys[4] = {search, Ma, search, Mv};
@@ -1225,6 +1289,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       if (alpha == 0) break;
 
       // ================= move, update
+      if (fused) {
+        // (rows first, then ONE pass over the dofs: move, J' force, gradient, preconditioner, Hager-Zhang differences)
+        MJH_FOR_LANES(r, nefc) jar[r] += Jv[r]*alpha;
+        MJH_FOR_LANES(r, nefc) oldstate[r] = P.state[r];
+        wv_sync();
+        update_rows();
+        run_pass(CSR_OP_STEP, 0, alpha);
+      } else {
       if (SPA == 2) {
         for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
           real q[MJH_NVU], sv[MJH_NVU], ma[MJH_NVU], mv[MJH_NVU], g[MJH_NVU], mg[MJH_NVU];
@@ -1247,17 +1319,21 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       MJH_FOR_LANES(r, nefc) oldstate[r] = P.state[r];
       wv_sync();
       update_constraint();
+      }
       tick(37);
       if (flg_newton) hessian_incremental();
       tick(35);
-      update_grad();
-      if (flg_newton) newton_mgrad(); else precondition();
+      if (!fused) {
+        update_grad();
+        if (flg_newton) newton_mgrad(); else precondition();
+      }
       tick(34);
       const real improvement = scale*ls_improvement;
       // (CG on the explicit-index path: the six sums of the Hager-Zhang update -- |grad|^2 among them -- are taken in one
       // pass before the termination test instead of |grad|^2 now and the others afterwards)
       real hz[6];
       if (SPA == 2 && !flg_newton) {
+        if (!fused)
         for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
           real g[MJH_NVU], go[MJH_NVU], mg[MJH_NVU], mgo[MJH_NVU];
 #pragma unroll
@@ -1298,7 +1374,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           beta = r_max(eta_k, beta_hz);
         }
         wv_sync();
-        if (SPA == 2) {
+        if (fused) run_pass(CSR_OP_DIR, 0, beta);
+        else if (SPA == 2) {
           for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
             real mg[MJH_NVU], sv[MJH_NVU];
 #pragma unroll

@@ -1572,3 +1572,103 @@ MJH_DEVN void stage_acceleration(MREF M_, BREF B_, int e_) {
   wv_sync();
   solve_ld(M, qas, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
 }
+
+// ------------------------------------------------------------------------------------------------
+// integration (kept with the smooth stages so that a multi-wavefront workgroup can run it on all of its wavefronts)
+// ------------------------------------------------------------------------------------------------
+// mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
+template <class P0, class P1>
+MJH_DEV void integrate_pos(MREF M, P0 qpos, P1 qvel, real h) {
+  MJH_FOR_LANES(j, M.s.njnt) {
+    int padr = M.jnt_qposadr[j], vadr = M.jnt_dofadr[j];
+    int jt = M.jnt_type[j];
+    if (jt == MJH_JNT_FREE) {
+      for (int i = 0; i < 3; i++) qpos[padr + i] += h * qvel[vadr + i];
+      padr += 3; vadr += 3;
+    }
+    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+      q_integrate(qpos + padr, qvel + vadr, h);
+    } else {
+      qpos[padr] += h * qvel[vadr];
+    }
+  }
+}
+
+// mj_advance, activation part                      (engine_forward.c:1314-1323)
+template <class P0>
+MJH_DEV void advance_act(MREF M, BREF B, int e, P0 act_dot) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!MJH_HAS(MJH_FT_ACT) || !s.na || (M.o.disableflags & (1<<11))) return;
+  rptr act = MJH_F(B, act, e);
+  MJH_FOR_LANES(i, s.nu) {
+    if (M.actuator_dyntype[i] == MJH_DYN_NONE) continue;
+    const int aa = M.actuator_actadr[i];
+    act[aa] = next_activation(M, i, act[aa], act_dot[aa]);
+  }
+}
+
+// mj_EulerSkip + mj_advance                        (engine_forward.c:1398-1476, :1261-1395)
+// The implicit-damping matrix qH = M + h*diag(B): normally its factor was produced next to M's
+// (stage_factor_m, two matrices per pass) and its solve shared stage_finish's pass -- then the damped
+// acceleration already waits in qe (counts[MJH_C_PAIRED]).  Otherwise the parked factor is picked up
+// here, or (models outside the paired routines' range) qH is rebuilt from the copy of M that stage_crb
+// left in M's global home and factorised in the slots of qLD/qLDiagInv, dead once qacc is known.
+MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nv = s.nv;
+  const real h = M.o.timestep;
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr qpos = MJH_F(B, qpos, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  rptr qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
+
+  iptr counts = MJH_F(B, counts, e);
+  const int paired = counts[MJH_C_PAIRED];      // stage_finish already solved the damped system into qe
+  wv_sync();
+  if (wv_lane() == 0) counts[MJH_C_PAIRED] = 0;
+  if (paired) {
+    // nothing to do
+  } else if (M.o.euler_damp) {
+    crptr Mq = MJH_G(B, M, e);
+    rptr qH = MJH_F(B, qLD, e);
+    rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
+    if (pairs_euler_factor(M, B, e)) {
+      // stage_factor_m factorised qH next to M and parked it (primal solvers, steps without constraints:
+      // stage_finish had no solve to share, so the factor is picked up here)
+      crptr qHg = MJH_G(B, qH2, e);
+      crptr qHDg = MJH_G(B, qH2DiagInv, e);
+      MJH_FOR_LANES(k, s.nC) qH[k] = qHg[k];
+      MJH_FOR_LANES(i, nv) qHDiagInv[i] = qHDg[i];
+      wv_sync();
+    } else {
+      MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
+      wv_sync();
+      MJH_FOR_LANES(i, nv) {
+        real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+        qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
+      }
+      wv_sync();
+      factor_ld(M, qH, qHDiagInv);
+    }
+    crptr fs = MJH_F(B, qfrc_smooth, e);
+    crptr fc = MJH_F(B, qfrc_constraint, e);
+    MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
+    wv_sync();
+    solve_ld(M, qe, qH, qHDiagInv);
+  } else {
+    MJH_FOR_LANES(i, nv) qe[i] = qacc[i];
+    wv_sync();
+  }
+
+  // mj_advance: activations ; qvel += h*qacc ; qpos integrates the NEW qvel ; time ; warmstart
+  advance_act(M, B, e, MJH_F(B, act_dot, e));
+  MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
+  wv_sync();
+  integrate_pos(M, qpos, qvel, h);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
+  MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
+  if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
+  wv_sync();
+}
+

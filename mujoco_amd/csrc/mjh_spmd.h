@@ -81,8 +81,8 @@ namespace mjhsim { inline long long* rc_stats() {
   static long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   static bool reg = false;
   if (!reg) { reg = true; if (getenv("MJH_RC_STATS")) atexit([]() { long long* q = rc_stats();
-    fprintf(stderr, "rc_stats: queries %lld distance-iterations %lld containment-tests %lld polytopes %lld expansions %lld multicontacts %lld\n",
-            q[0], q[1], q[2], q[3], q[4], q[5]); }); }
+    fprintf(stderr, "rc_stats: queries %lld distance-iterations %lld containment-tests %lld polytopes %lld expansions %lld multicontacts %lld; fused CG passes %lld\n",
+            q[0], q[1], q[2], q[3], q[4], q[5], q[6]); }); }
   return c; } }
 MJH_DEV void wv_sync() { mjhsim::yield(); }
 

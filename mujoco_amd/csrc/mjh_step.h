@@ -150,15 +150,17 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_RNE, MJH_WIDE(MJH_MWS_RNE, stage_rne(M, B, e)));
   }
   if (stages & MJH_STAGE_INERTIA) {
-    MJH_RUN(MJH_T_CRB, stage_crb(M, B, e, (stages & MJH_STAGE_NOPARK) != 0));
-    MJH_RUN(MJH_T_FACTOR, stage_factor_m(M, B, e));
+    // (models beyond the register-resident L'DL routines -- flexes: the generic, collective-free forms on every wavefront)
+    MJH_RUN(MJH_T_CRB, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_CRB, stage_crb(M, B, e, (stages & MJH_STAGE_NOPARK) != 0)));
+    MJH_RUN(MJH_T_FACTOR, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_FACTOR, stage_factor_m(M, B, e)));
   }
   if (stages & MJH_STAGE_ACTUATION) {
     MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));
-    MJH_RUN(MJH_T_ACCEL, stage_acceleration(M, B, e));
+    MJH_RUN(MJH_T_ACCEL, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_ACCEL, stage_acceleration(M, B, e)));
   }
   if (stages & MJH_STAGE_MAKE) {
     MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
+    MJH_TIMED(49, {
 #if !MJH_LANE_MODE
     if (MJH_HAS(MJH_FT_PRIMAL) && M.s.csr) stage_csr_rows(M, B, e);      // (the island scan reads the compressed rows)
 #endif
@@ -166,47 +168,17 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
 #if !MJH_LANE_MODE
     if (MJH_HAS(MJH_FT_PRIMAL) && M.s.sparse) stage_sparsify(M, B, e);
 #endif
+    });
   }
   if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));
   if (MJH_HAS(MJH_FT_SENSOR) && (stages & (MJH_STAGE_SENSOR | MJH_STAGE_SENSPV | MJH_STAGE_SENSACC)) && M.s.nsensor)
-    stage_sensors(M, B, e, (stages & MJH_STAGE_SENSOR) ? 7 : (((stages & MJH_STAGE_SENSPV) ? 3 : 0) | ((stages & MJH_STAGE_SENSACC) ? 4 : 0)));
-}
-
-// mj_integratePos: qpos <- qpos (+) qvel*h, joint by joint            (engine_support.c:639-690)
-template <class P0, class P1>
-MJH_DEV void integrate_pos(MREF M, P0 qpos, P1 qvel, real h) {
-  MJH_FOR_LANES(j, M.s.njnt) {
-    int padr = M.jnt_qposadr[j], vadr = M.jnt_dofadr[j];
-    int jt = M.jnt_type[j];
-    if (jt == MJH_JNT_FREE) {
-      for (int i = 0; i < 3; i++) qpos[padr + i] += h * qvel[vadr + i];
-      padr += 3; vadr += 3;
-    }
-    if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
-      q_integrate(qpos + padr, qvel + vadr, h);
-    } else {
-      qpos[padr] += h * qvel[vadr];
-    }
-  }
+    MJH_TIMED(52, stage_sensors(M, B, e, (stages & MJH_STAGE_SENSOR) ? 7 : (((stages & MJH_STAGE_SENSPV) ? 3 : 0) | ((stages & MJH_STAGE_SENSACC) ? 4 : 0))));
 }
 
 MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages);
-
-// mj_advance, activation part                      (engine_forward.c:1314-1323)
-template <class P0>
-MJH_DEV void advance_act(MREF M, BREF B, int e, P0 act_dot) {
-  const MJH_CONST_AS DSizes& s = M.s;
-  if (!MJH_HAS(MJH_FT_ACT) || !s.na || (M.o.disableflags & (1<<11))) return;
-  rptr act = MJH_F(B, act, e);
-  MJH_FOR_LANES(i, s.nu) {
-    if (M.actuator_dyntype[i] == MJH_DYN_NONE) continue;
-    const int aa = M.actuator_actadr[i];
-    act[aa] = next_activation(M, i, act[aa], act_dot[aa]);
-  }
-}
 
 // mj_RungeKutta(m, d, 4) + mj_advance                 (engine_forward.c:1486-1587, :1261-1395)
 // mj_forward for stage 0 has already run (mj_step); the three further evaluations warm-start from
@@ -332,71 +304,6 @@ MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
     if (stages & MJH_STAGE_WRITEBACK) lds_writeback(M, B, e, MJH_T_EULER);
   }
   lds_exit(M, B, e);
-}
-
-// mj_EulerSkip + mj_advance                        (engine_forward.c:1398-1476, :1261-1395)
-// The implicit-damping matrix qH = M + h*diag(B): normally its factor was produced next to M's
-// (stage_factor_m, two matrices per pass) and its solve shared stage_finish's pass -- then the damped
-// acceleration already waits in qe (counts[MJH_C_PAIRED]).  Otherwise the parked factor is picked up
-// here, or (models outside the paired routines' range) qH is rebuilt from the copy of M that stage_crb
-// left in M's global home and factorised in the slots of qLD/qLDiagInv, dead once qacc is known.
-MJH_DEVN void euler_advance(MREF M_, BREF B_, int e_) {
-  MJH_ENTER(M_, B_, e_);
-  const MJH_CONST_AS DSizes& s = M.s;
-  const int nv = s.nv;
-  const real h = M.o.timestep;
-  rptr qvel = MJH_F(B, qvel, e);
-  rptr qpos = MJH_F(B, qpos, e);
-  crptr qacc = MJH_F(B, qacc, e);
-  rptr qe = MJH_F(B, qe, e);               // integrated acceleration [nv]
-
-  iptr counts = MJH_F(B, counts, e);
-  const int paired = counts[MJH_C_PAIRED];      // stage_finish already solved the damped system into qe
-  wv_sync();
-  if (wv_lane() == 0) counts[MJH_C_PAIRED] = 0;
-  if (paired) {
-    // nothing to do
-  } else if (M.o.euler_damp) {
-    crptr Mq = MJH_G(B, M, e);
-    rptr qH = MJH_F(B, qLD, e);
-    rptr qHDiagInv = MJH_F(B, qLDiagInv, e);
-    if (pairs_euler_factor(M, B, e)) {
-      // stage_factor_m factorised qH next to M and parked it (primal solvers, steps without constraints:
-      // stage_finish had no solve to share, so the factor is picked up here)
-      crptr qHg = MJH_G(B, qH2, e);
-      crptr qHDg = MJH_G(B, qH2DiagInv, e);
-      MJH_FOR_LANES(k, s.nC) qH[k] = qHg[k];
-      MJH_FOR_LANES(i, nv) qHDiagInv[i] = qHDg[i];
-      wv_sync();
-    } else {
-      MJH_FOR_LANES(k, s.nC) qH[k] = Mq[k];
-      wv_sync();
-      MJH_FOR_LANES(i, nv) {
-        real dd = poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
-        qH[M.M_rowadr[i] + M.M_rownnz[i] - 1] += h * dd;
-      }
-      wv_sync();
-      factor_ld(M, qH, qHDiagInv);
-    }
-    crptr fs = MJH_F(B, qfrc_smooth, e);
-    crptr fc = MJH_F(B, qfrc_constraint, e);
-    MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
-    wv_sync();
-    solve_ld(M, qe, qH, qHDiagInv);
-  } else {
-    MJH_FOR_LANES(i, nv) qe[i] = qacc[i];
-    wv_sync();
-  }
-
-  // mj_advance: activations ; qvel += h*qacc ; qpos integrates the NEW qvel ; time ; warmstart
-  advance_act(M, B, e, MJH_F(B, act_dot, e));
-  MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
-  wv_sync();
-  integrate_pos(M, qpos, qvel, h);
-  rptr ws = MJH_F(B, qacc_warmstart, e);
-  MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
-  if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
-  wv_sync();
 }
 
 // 3x3 blocks of d(qfrc_bias)/d(qvel) of a standalone free body: the rotational columns of the 6x6
@@ -628,17 +535,19 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
 
 // mj_step                                          (engine_forward.c:1846-1880)
 MJH_DEV void step_env(MREF M, BREF B, int e) {
-  check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
-  check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL);
+  // (profile builds, slots 48..52: state checks | compressed rows + islands | state / sensor output | control input | sensors)
+  MJH_TIMED(48, { check_bad(M, B, e, MJH_F(B, qpos, e), M.s.nq, MJH_WARN_BADQPOS);
+                  check_bad(M, B, e, MJH_F(B, qvel, e), M.s.nv, MJH_WARN_BADQVEL); });
   for (int attempt = 0; attempt < 2; attempt++) {
     forward(M, B, e, MJH_STAGE_ALL | MJH_STAGE_SENSOR | MJH_STAGE_NOPARK);
-    int bad = check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC);
+    int bad;
+    MJH_TIMED(48, bad = check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC));
     // bad qacc: state was reset; the reference re-runs mj_forward before integrating
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
   if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
   else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
-  else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
+  else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
 }
 
 // pack FULLPHYSICS state [time, qpos, qvel, act]    (mj_getState, engine_support.c:214)
@@ -734,19 +643,20 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
     const size_t step = r*(size_t)A.nstep + t;
     if (!nw) {
       if (A.control) {
-        rollout_load_control(M, B, e, A, A.control + step*A.ncontrol);
-        wv_sync();
+        MJH_TIMED(51, { rollout_load_control(M, B, e, A, A.control + step*A.ncontrol); wv_sync(); });
       }
       step_env(M, B, e);
       ciptr cnt = MJH_F(B, counts, e);
       work += 64 + cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4);
     }
+    MJH_TIMED(50, {
     if (A.state) get_state(M, B, e, A.state + step*s.nstate);
     if (A.sensordata) {
       crptr sd = MJH_G(B, sensordata, e);
       MJH_FOR_LANES(i, s.nsensordata) A.sensordata[step*s.nsensordata + i] = sd[i];
     }
     wv_sync();
+    });
   }
   lds_exit(M, B, e);
   // what this environment cost: the next launch deals the environments to the SIMDs by it
@@ -816,7 +726,7 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
     if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
     else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
-    else MJH_TIMED(MJH_T_EULER, euler_advance(M, B, e));
+    else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);
 }

@@ -129,6 +129,9 @@
   X(ld_prog, s.nldprog)                        \
   /* dofs whose row of M has off-diagonal entries, ascending (the generic L'DL routines take only these in sequence) */ \
   X(ld_rows, s.nldrows)                        \
+  /* explicit-index rows (mjh_csr.h): the dof chain of every body -- dofs of its weld body, then ancestors, descending -- as a table */ \
+  X(body_chainadr, s.nbody + 1)                \
+  X(body_chain, s.nchain)                      \
   X(pgs_order, s.npgsorder)               \
   /* convex meshes (mjh_convex.h): hull graph, polygons (mjModel mesh_*, include/mujoco/mjmodel.h:1040-1075) */ \
   X(geom_dataid, s.ngeom)                      \
@@ -349,6 +352,7 @@ struct DSizes {
   int npgsorder;   // entries of the precomputed PGS visitation-order table
   int nldprog;     // entries of the flattened L'DL update list
   int nldrows;     // dofs whose row of M has off-diagonal entries
+  int nchain;      // entries of the body dof-chain table (explicit-index rows; 1 otherwise)
   int ld_fast;     // 1: the register-resident L'DL routines apply (nv <= 64, nC <= 1024, depth <= 16)
   int pgs_iters;   // iterations covered by that table (min(opt.iterations, 128))
   int pgs_nmax;    // largest nefc covered by that table (64, or 128 when the constraint capacity allows more than 64 rows)
@@ -562,7 +566,7 @@ enum {
   X(rk_act, 9 * s.na, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
   /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
-  X(prof, 48, 0, MJH_T_GLB, MJH_T_GLB)
+  X(prof, 64, 0, MJH_T_GLB, MJH_T_GLB)
 
 #define MJH_BATCH_INT_FIELDS(X)                                                   \
   /* counts: ncon, nefc, ne, nf, nl, solver_niter, nisland, paired, nJ, - */       \
@@ -644,6 +648,19 @@ struct DBatch {
 #define X(name, cnt, lcnt, t0, t1) int* name; int n_##name; int l_##name; int io_##name;
   MJH_BATCH_INT_FIELDS(X)
 #undef X
+};
+
+// argument block of the explicit-index CG solver's passes over the dofs (mjh_csrpass.h): plain pointers to unit-stride
+// slices, so that wave 0 of a multi-wavefront workgroup can hand it to the helper wavefronts through LDS
+enum { CSR_OP_WARM = 1, CSR_OP_START = 2, CSR_OP_GRAD = 3, CSR_OP_STEP = 4, CSR_OP_DIR = 5 };
+struct CsrPass {
+  int op, nv, flag, pad_;
+  real alpha;                  // step length (CSR_OP_STEP) or Hager-Zhang's beta (CSR_OP_DIR)
+  real* vec;                   // Ma | grad | Mgrad | search | Mv | Mgraddif | (staging) | graddif, nv each
+  real* qacc; real* qfc; real* stage; real* copy;
+  const real* qfs; const real* dinv; const real* Ms; const real* qws; const real* qas;
+  const real* spJT; const real* force;
+  const int* JTadr; const int* JTrow; const int* tree_island;
 };
 
 // how the stage functions receive the two descriptors: read-only, constant address space

@@ -61,6 +61,9 @@ if p.shape[1] >= 46 and p[:, 41:46].sum() > 0:
 if p.shape[1] >= 41 and p[:, 39].sum() > 0:
     print("  line search, not in the figure above: products + quadratic coefficients %.1f us; %.1f searches and %.1f evaluations per step"
           % (p[:, 38].mean()/nst, p[:, 39].mean()/nst, p[:, 40].mean()/nst))
+if p.shape[1] >= 53 and p[:, 48:53].sum() > 0:
+    print("  outside the stages: state checks %.1f  compressed rows + islands %.1f  state / sensor output %.1f  control input %.1f  sensors %.1f us"
+          % tuple(p[:, k].mean()/nst for k in (48, 49, 50, 51, 52)))
 c = b.get("counts")
 print("mean ncon", c[:, 0].mean(), "nefc", c[:, 1].mean(), "pgs iter", c[:, 5].mean())
 
