@@ -910,6 +910,15 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     iptr label = work + s.nefcmax;              // [ntree] -1: no constraint touches the tree
     iptr tree_island = label + ntree;           // [ntree]
     iptr second = MJH_G(B, iscratch, e) + 2*s.nefcmax;     // [nefc] second tree of the row, -2: none, -3: scan the row
+    // (every pass below is a handful of dependent reads of these arrays: they work in the unused tail of the LDS regions
+    // when it has room; tree_island, which the primal solvers read, is copied to its global home at the end)
+    const iptr tree_island_home = tree_island;
+    // (only a tail of region 1: region 2 still holds the contact slots this stage reads)
+    const int in_lds = P.free_bytes >= (2*nefc + 2*ntree)*(int)sizeof(int) && P.free_p >= MJH_LDS(B) + B.dyn_off;
+    if (in_lds) {
+      int* w = (int*)P.free_p;
+      efc_tree = SP<int>{w, 1}; second = SP<int>{w + nefc, 1}; label = SP<int>{w + 2*nefc, 1}; tree_island = SP<int>{w + 2*nefc + ntree, 1};
+    }
     MJH_FOR_LANES(t, ntree) label[t] = -1;
     wv_sync();
     auto row_trees = [&](int i, int* ta, int* tb) {
@@ -1048,6 +1057,7 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     MJH_FOR_LANES(t, ntree) { const int l = label[t]; if (l < 0) tree_island[t] = -1; else if (l != t) tree_island[t] = tree_island[l]; }
     wv_sync();
     MJH_FOR_LANES(i, nefc) P.island[i] = tree_island[efc_tree[i]];
+    if (in_lds) MJH_FOR_LANES(t, ntree) tree_island_home[t] = tree_island[t];
     if (wv_lane() == 0) counts[MJH_C_NISLAND] = nisland;
   }
   wv_sync();

@@ -24,7 +24,8 @@ MJH_DEV int csr_body_chain(MREF M, int b, IP out) {
 
 // the stored dofs of contact k's rows: the merged chains of its bodies, ascending, dofs common to two chains removed
 // (flg_skipcommon of mj_jacDifPair); returns their number.  fbody / fw / nfb: the flex side (flex_contact_weights)
-MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, int* cols, int* fbody, real* fw, int* nfb_out) {
+template <class IP>
+MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, IP cols, int* fbody, real* fw, int* nfb_out) {
   ciptr cg = MJH_CON(B, con_geom, e, 2, k);
   const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
   int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
@@ -103,7 +104,6 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   iptr JTadr = P.JTadr;
   iptr JTrow = P.JTrow;
   rptr JTval = P.spJT;
-
   // ---- pass 2: columns and values
   MJH_FOR_LANES(r, nefc) {
     const int type = P.type[r], id = P.id[r];
@@ -127,7 +127,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   for (int k0 = 0; k0 < ncon; k0 += MJH_W) {
     const int k = k0 + wv_lane();
     int m = 0, a0 = 0;
-    int cols[MJH_CSR_CHAIN_MAX];
+    int cols[MJH_CSR_CHAIN_MAX];     // (a private array: kept in LDS -- lane-interleaved, in the unused tail -- the launch faulted on the GPU, cause not found)
     if (k < ncon) {
       const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
       if (r0 >= 0) {
@@ -142,64 +142,13 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     nitems += sum;
   }
   wv_sync();
-  // (b): one lane per (contact, stored dof): the column of the contact's rows
-  MJH_FOR_LANES(w, nitems) {
-    const int k = items[w]/MJH_CSR_CHAIN_MAX, c = items[w]%MJH_CSR_CHAIN_MAX;
-    const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
-    const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
-    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int fbody[4]; real fw[4];
-    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-    const int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
-    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
-    crptr point = MJH_CON(B, con_pos, e, 3, k);
-    crptr fr = MJH_CON(B, con_frame, e, 9, k);
-    auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
-    real off1[3], off2[3];
-    v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
-    v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
-    const int a0 = rowadr[r0];
-    const int stride = rowadr[r0 + 1] - a0;             // every row of the contact has the same pattern
-    const int j = colind[a0 + c];
-    // (the expressions of stage_make_constraint's dense contact rows)
-    const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-    const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-    real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
-    crptr cd = cdof + 6*j;
-    if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
-    if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
-    real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
-    if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
-      jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
-      for (int q = 0; q < nfb; q++) {
-        const int wq = M.body_weldid[fbody[q]];
-        if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
-        real offq[3], t[3];
-        v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
-        v3_cross(t, cd, offq);
-        const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
-        jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
-      }
-    }
-    const int nr = dim > 1 ? 3 : 1;
-    real jr[3] = {0, 0, 0};
-    for (int a = 0; a < nr; a++) {
-      real acc = 0;
-      for (int q = 0; q < 3; q++) { const real t = fr[3*a + q]; if (t != 0) acc += jd[q]*t; }
-      jr[a] = acc;
-    }
-    if (dim == 1) { val[a0 + c] = jr[0]; }
-    else if (ispyramid) {
-      for (int a = 1; a < dim; a++) {
-        const int ra = a0 + (2*(a - 1))*stride + c, rb = a0 + (2*(a - 1) + 1)*stride + c;
-        colind[ra] = j; val[ra] = jr[0] + jr[a]*fri[a - 1];
-        colind[rb] = j; val[rb] = jr[0] + jr[a]*(-fri[a - 1]);
-      }
-    } else {
-      for (int a = 0; a < dim; a++) { colind[a0 + a*stride + c] = j; val[a0 + a*stride + c] = jr[a]; }
-    }
+  // (b): one lane per (contact, stored dof): the column of the contact's rows -- on every wavefront of a multi-wavefront
+  // workgroup (csr_row_values, mjh_csrpass.h)
+  {
+    CsrRowArgs ra;
+    ra.nitems = nitems; ra.ispyramid = ispyramid; ra.colind = colind; ra.val = val; ra.rowadr = rowadr; ra.items = items;
+    MJH_WIDE_ARGS(MJH_MWS_CSRVALS, ra, csr_row_values(M, B, e, ra));
   }
-  wv_sync();
 
   // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse): counting pass with integer atomics,
   //      one lane per stored entry scatters it (its row by bisection of the row addresses), then each dof sorts its

@@ -43,7 +43,7 @@ static inline const char* mjh_variant_name(int v) {
 }
 // stages every wavefront of a multi-wavefront workgroup runs together (mw_exec below)
 enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH_MWS_TAVEL, MJH_MWS_COMVEL, MJH_MWS_PASSIVE,
-       MJH_MWS_RNE, MJH_MWS_ELEMS, MJH_MWS_CSRPASS, MJH_MWS_CRB, MJH_MWS_FACTOR, MJH_MWS_ACCEL, MJH_MWS_EULER };
+       MJH_MWS_RNE, MJH_MWS_ELEMS, MJH_MWS_CSRPASS, MJH_MWS_CRB, MJH_MWS_FACTOR, MJH_MWS_ACCEL, MJH_MWS_EULER, MJH_MWS_CSRVALS };
 // bytes at the end of a multi-wavefront workgroup's LDS block that the residency plan leaves alone: the command word
 // wave 0 posts for the helper wavefronts (first 64 bytes) and the argument block of a stage that takes one (CsrPass)
 #define MJH_MW_LDS_TAIL 256
@@ -205,6 +205,7 @@ MJH_DEV void mw_exec(MREF M, BREF B, int e, int id) {
     case MJH_MWS_FACTOR: wq::stage_factor_m(M, B, e); break;
     case MJH_MWS_ACCEL: wq::stage_acceleration(M, B, e); break;
     case MJH_MWS_EULER: wq::euler_advance(M, B, e); break;
+    case MJH_MWS_CSRVALS: { const CsrRowArgs A = *(const CsrRowArgs*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS); wq::csr_row_values(M, B, e, A); break; }
     case MJH_MWS_CSRPASS: { const CsrPass A = *(const CsrPass*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS); wq::csr_pass(M, A); break; }
     default: break;
   }
@@ -218,8 +219,10 @@ MJH_DEV void mw_run(MREF M, BREF B, int e, int id) {
   mw_exec(M, B, e, id);
 }
 // wave 0: post a stage together with its argument block
-MJH_DEV void mw_run_args(MREF M, BREF B, int e, int id, const CsrPass& A) {
-  if (wv_lane() == 0) *(CsrPass*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS) = A;
+template <class T>
+MJH_DEV void mw_run_args(MREF M, BREF B, int e, int id, const T& A) {
+  static_assert(sizeof(T) <= MJH_MW_LDS_TAIL - MJH_MW_LDS_ARGS, "argument block larger than the LDS tail");
+  if (wv_lane() == 0) *(T*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS) = A;
   mw_run(M, B, e, id);
 }
 // the helper wavefronts' whole program

@@ -663,6 +663,9 @@ struct CsrPass {
   const int* JTadr; const int* JTrow; const int* tree_island;
 };
 
+// argument block of the compressed rows' value pass (csr_row_values, mjh_csrpass.h)
+struct CsrRowArgs { int nitems, ispyramid; SP<int> colind; SP<real> val; SP<const int> rowadr; SP<const int> items; };
+
 // how the stage functions receive the two descriptors: read-only, constant address space
 typedef const MJH_CONST_AS DModel& MREF;
 typedef const MJH_CONST_AS DBatch& BREF;
