@@ -41,6 +41,69 @@ MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, IP cols, int* fbody, 
   return m;
 }
 
+// The same for merged chains of at most 16 dofs (csr_rowmax <= 16: a flex element against a geom is 12 + the geom's
+// chain), entirely in registers: the private array of the general form lives in scratch memory, and its insertion sort is
+// a chain of dependent memory round trips per contact.  Slots are filled from the chain table by position, sorted by a
+// 63-exchange network (Batcher's odd-even merge sort), and equal entries cancel in pairs (a dof common to two chains is
+// not stored).  v: the sorted entries, keep: bit i set if v[i] is stored, m: their number.
+struct CsrCols16 { int v[16]; unsigned keep; int m; };
+MJH_DEV void csr_contact_cols16(MREF M, BREF B, int e, int k, CsrCols16& R) {
+  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+  int body[5] = {(int)M.geom_bodyid[cg[0]], -1, -1, -1, -1};
+  int nb = 2;
+  int flexed = 0;
+  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) {
+    ciptr cf = MJH_G(B, con_flex, e) + 3*k;
+    const int f = cf[0];
+    if (f >= 0) {
+      flexed = 1;
+      if (cf[2] >= 0) { body[1] = M.flexvert_bodyid[M.flex_vertadr[f] + cf[2]]; nb = 2; }
+      else {
+        const int el = M.flex_elemadr[f] + cf[1];
+        const int n = M.flex_dim[f] + 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i < n) body[1 + i] = M.flexvert_bodyid[M.flexelem_vert[4*el + i]];
+        nb = 1 + n;
+      }
+    }
+  }
+  if (!flexed) body[1] = M.geom_bodyid[cg[1]];
+  int adr[5], start[6];
+  start[0] = 0;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    int len = 0;
+    adr[j] = 0;
+    if (j < nb) { adr[j] = M.body_chainadr[body[j]]; len = M.body_chainadr[body[j] + 1] - adr[j]; }
+    start[j + 1] = start[j] + len;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    int src = -1;
+#pragma unroll
+    for (int j = 0; j < 5; j++) if (q >= start[j] && q < start[j + 1]) src = adr[j] + (q - start[j]);
+    R.v[q] = src >= 0 ? (int)M.body_chain[src] : 0x7fffffff;
+  }
+  constexpr unsigned char NA[63] = {0,2,4,6,8,10,12,14,0,1,4,5,8,9,12,13,1,5,9,13,0,1,2,3,8,9,10,11,2,3,10,11,1,3,5,9,11,13,0,1,2,3,4,5,6,7,4,5,6,7,2,3,6,7,10,11,1,3,5,7,9,11,13};
+  constexpr unsigned char NB[63] = {1,3,5,7,9,11,13,15,2,3,6,7,10,11,14,15,2,6,10,14,4,5,6,7,12,13,14,15,4,5,12,13,2,4,6,10,12,14,8,9,10,11,12,13,14,15,8,9,10,11,4,5,8,9,12,13,2,4,6,8,10,12,14};
+#pragma unroll
+  for (int t = 0; t < 63; t++) {
+    const int a = R.v[NA[t]], b = R.v[NB[t]];
+    R.v[NA[t]] = a < b ? a : b;
+    R.v[NB[t]] = a < b ? b : a;
+  }
+  // (equal entries cancel in pairs from the left, as in the general form: the last of a run of odd length stays)
+  unsigned keep = 0;
+  int m = 0, run = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    run = (i > 0 && R.v[i] == R.v[i - 1]) ? run + 1 : 1;
+    const int last = i == 15 || R.v[i] != R.v[i + 1];
+    if (last && (run & 1) && R.v[i] != 0x7fffffff) { keep |= 1u << i; m++; }
+  }
+  R.keep = keep; R.m = m;
+}
+
 MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -56,6 +119,8 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   crptr Jd = MJH_G(B, efc_J, e);
   crptr cdof = MJH_F(B, cdof, e);
   crptr subtree_com = MJH_F(B, subtree_com, e);
+
+  const int small = s.csr_rowmax <= 16;       // merged chains fit the register form (csr_contact_cols16)
 
   // ---- pass 1: stored entries per row (rowadr[r + 1] <- nnz of row r)
   MJH_FOR_LANES(r, nefc) {
@@ -77,9 +142,13 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     if (r0 < 0) continue;
     const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     const int nrow = dim == 1 ? 1 : (ispyramid ? 2*(dim - 1) : dim);
-    int fbody[4]; real fw[4]; int nfb;
-    int cols[MJH_CSR_CHAIN_MAX];
-    const int nnz = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
+    int nnz;
+    if (small) { CsrCols16 R; csr_contact_cols16(M, B, e, k, R); nnz = R.m; }
+    else {
+      int fbody[4]; real fw[4]; int nfb;
+      int cols[MJH_CSR_CHAIN_MAX];
+      nnz = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
+    }
     for (int a = 0; a < nrow; a++) rowadr[r0 + a + 1] = nnz;
   }
   wv_sync();
@@ -127,18 +196,26 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   for (int k0 = 0; k0 < ncon; k0 += MJH_W) {
     const int k = k0 + wv_lane();
     int m = 0, a0 = 0;
-    int cols[MJH_CSR_CHAIN_MAX];     // (a private array: kept in LDS -- lane-interleaved, in the unused tail -- the launch faulted on the GPU, cause not found)
+    int cols[MJH_CSR_CHAIN_MAX];
+    CsrCols16 R;
+    R.keep = 0;
     if (k < ncon) {
       const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
       if (r0 >= 0) {
-        int fbody[4]; real fw[4]; int nfb;
-        m = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
+        if (small) { csr_contact_cols16(M, B, e, k, R); m = R.m; }
+        else { int fbody[4]; real fw[4]; int nfb; m = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb); }
         a0 = rowadr[r0];
       }
     }
     const int before = wv_exscan_i(m);
     const int sum = wv_sum_i(m);
-    for (int c = 0; c < m; c++) { colind[a0 + c] = cols[c]; items[nitems + before + c] = k*MJH_CSR_CHAIN_MAX + c; }
+    if (small) {
+      int c = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) if ((R.keep >> i) & 1) { colind[a0 + c] = R.v[i]; items[nitems + before + c] = k*MJH_CSR_CHAIN_MAX + c; c++; }
+    } else {
+      for (int c = 0; c < m; c++) { colind[a0 + c] = cols[c]; items[nitems + before + c] = k*MJH_CSR_CHAIN_MAX + c; }
+    }
     nitems += sum;
   }
   wv_sync();

@@ -8,8 +8,11 @@
 // iteration (CSR_OP_STEP after the line search, CSR_OP_DIR after the termination tests) and two for the set-up
 // (CSR_OP_WARM, CSR_OP_START), each a loop over "lane = dof" with the group's width -- 64 lanes in the one-wavefront
 // mappings, 64 MJH_MW in a multi-wavefront workgroup.  Every element is computed by the expressions of the unfused code in
-// mjh_newton.h (same operands, same order), so results are bit-identical; the ORDERED sums of the iteration (mju_dot's four
-// accumulator chains, csr_dots) stay on one wavefront and read the vectors these passes leave in LDS.
+// mjh_newton.h (same operands, same order), so results are bit-identical.  The ORDERED sums of the iteration (mju_dot's four
+// accumulator chains) stay on one wavefront, but their ADDENDS -- the element-wise products -- are formed here too and left
+// in six LDS vectors: a link of a chain is then one LDS read and one dependent addition (csr_sums, mjh_newton.h) instead of
+// two reads, a multiplication and the addition.  The vectors nothing but these passes touch (Ma, Mv, Mgrad) live in
+// global memory, which is what makes room for the products.
 //
 // Preconditions (solve_primal checks them, else it takes the unfused path): CG, environment-major batch, the island spans
 // every dof (flex stiffness unions the trees of a flex: engine_island.c:409-440), diagonal mass matrix (every dof a slider of
@@ -36,67 +39,75 @@ MJH_DEV real csr_pass_jtf(const CsrPass& A, int a0, int n) {
   return res;
 }
 
-MJH_DEV void csr_pass(MREF M, const CsrPass& A) {
-  const int lane = wv_lane(), nv = A.nv;
-  real* const Ma = A.vec; real* const grad = A.vec + nv; real* const Mgrad = A.vec + 2*nv; real* const search = A.vec + 3*nv;
-  real* const Mv = A.vec + 4*nv; real* const Mgraddif = A.vec + 5*nv; real* const graddif = A.vec + 7*nv;
+// PV: how the solver's block (grad | search | six product vectors, contiguous) is addressed -- local (ds_read / ds_write) when
+// the plan placed it in LDS, else flat
+MJH_DEV LP<real> csr_at(LP<real> b, int k) { return LP<real>{b.p + k}; }
+MJH_DEV SP<real> csr_at(SP<real> b, int k) { return SP<real>{b.p + k, 1}; }
+template <class PV>
+MJH_DEV void csr_pass_body(MREF M, const CsrPass& A, PV blk) {
+  const int lane = wv_lane() - A.lane0, nv = A.nv, W = A.width;
+  if (lane >= 0) {
+  real* const Ma = A.Ma; real* const Mgrad = A.Mgrad; real* const Mv = A.Mv;
+  const PV grad = blk, search = csr_at(blk, nv);
+  const PV p0 = csr_at(blk, 2*nv), p1 = csr_at(blk, 3*nv), p2 = csr_at(blk, 4*nv), p3 = csr_at(blk, 5*nv), p4 = csr_at(blk, 6*nv), p5 = csr_at(blk, 7*nv);
+  const PV stage = p5;
   if (A.op == CSR_OP_WARM) {
     // warm start (engine_forward.c:1056-1132): Ma = M qacc_warmstart and the addends of
     // 0.5 (Ma - qfrc_smooth)' (qacc_warmstart - qacc_smooth), which the caller sums in the reference's order
-    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*W) {
       real ms[MJH_CSR_U], w[MJH_CSR_U], f[MJH_CSR_U], s[MJH_CSR_U];
 #pragma unroll
-      for (int u = 0; u < MJH_CSR_U; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; ms[u] = A.Ms[i]; w[u] = A.qws[i]; f[u] = A.qfs[i]; s[u] = A.qas[i]; }
+      for (int u = 0; u < MJH_CSR_U; u++) { const int i = i0 + u*W < nv ? i0 + u*W : 0; ms[u] = A.Ms[i]; w[u] = A.qws[i]; f[u] = A.qfs[i]; s[u] = A.qas[i]; }
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W;
-        if (i < nv) { const real ma = ms[u]*w[u]; Ma[i] = ma; A.stage[i] = 0.5*(ma - f[u])*(w[u] - s[u]); }
+        const int i = i0 + u*W;
+        if (i < nv) { const real ma = ms[u]*w[u]; Ma[i] = ma; stage[i] = 0.5*(ma - f[u])*(w[u] - s[u]); }
       }
     }
   } else if (A.op == CSR_OP_START) {
     // the starting point: qacc_warmstart or qacc_smooth (flag bit 0), qacc_smooth on the dofs of unconstrained trees
     // (bit 1: islands), Ma = M qacc; bit 2: the diagonal of M into the staging vector (the island's trace, summed by the
-    // caller); copy: qfrc_smooth into its LDS copy
+    // caller)
     const int use_smooth = A.flag & 1, trees = A.flag & 2, trace = A.flag & 4;
-    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
-      real ms[MJH_CSR_U], q[MJH_CSR_U], s[MJH_CSR_U], f[MJH_CSR_U]; int out[MJH_CSR_U];
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*W) {
+      real ms[MJH_CSR_U], q[MJH_CSR_U], s[MJH_CSR_U]; int out[MJH_CSR_U];
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
+        const int i = i0 + u*W < nv ? i0 + u*W : 0;
         ms[u] = A.Ms[i]; s[u] = A.qas[i]; q[u] = use_smooth ? s[u] : (real)A.qws[i];
         out[u] = trees ? (int)(A.tree_island[M.dof_treeid[i]] < 0) : 0;
-        f[u] = A.copy ? (real)A.qfs[i] : (real)0;
       }
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W;
+        const int i = i0 + u*W;
         if (i < nv) {
           const real qq = out[u] ? s[u] : q[u];
           A.qacc[i] = qq; Ma[i] = ms[u]*qq;
-          if (trace) A.stage[i] = ms[u];
-          if (A.copy) A.copy[i] = f[u];
+          if (trace) stage[i] = ms[u];
         }
       }
     }
   } else if (A.op == CSR_OP_GRAD || A.op == CSR_OP_STEP) {
-    // PrimalUpdateConstraint's qfrc_constraint = J' force, PrimalUpdateGrad, the preconditioner Mgrad = M \ grad; CSR_OP_STEP
-    // first moves qacc and Ma along the search direction and afterwards leaves the Hager-Zhang differences
-    // graddif = grad - grad_old, Mgraddif = Mgrad - Mgrad_old (engine_solver.c:2489-2496)
+    // PrimalUpdateConstraint's qfrc_constraint = J' force, PrimalUpdateGrad, the preconditioner Mgrad = M \ grad.
+    // CSR_OP_GRAD leaves the addends of grad.Mgrad and grad.grad (the convergence certificate).  CSR_OP_STEP first moves qacc
+    // and Ma along the search direction, forms the Hager-Zhang differences graddif = grad - grad_old, Mgraddif = Mgrad -
+    // Mgrad_old (engine_solver.c:2489-2496) and leaves the addends of the six sums of the direction update:
+    // search.graddif, graddif.Mgraddif, graddif.Mgrad, search.grad, search.search, grad.grad
     const int step = A.op == CSR_OP_STEP;
     const real alpha = A.alpha;
-    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*W) {
       int b0[MJH_CSR_U], b1[MJH_CSR_U];
       real ma[MJH_CSR_U], f[MJH_CSR_U], di[MJH_CSR_U], q[MJH_CSR_U], sv[MJH_CSR_U], mv[MJH_CSR_U], g0[MJH_CSR_U], mg0[MJH_CSR_U];
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0;
+        const int i = i0 + u*W < nv ? i0 + u*W : 0;
         b0[u] = A.JTadr[i]; b1[u] = A.JTadr[i + 1];
         ma[u] = Ma[i]; f[u] = A.qfs[i]; di[u] = A.dinv[i];
         if (step) { q[u] = A.qacc[i]; sv[u] = search[i]; mv[u] = Mv[i]; g0[u] = grad[i]; mg0[u] = Mgrad[i]; }
       }
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W;
+        const int i = i0 + u*W;
         if (i >= nv) continue;
         if (step) { A.qacc[i] = q[u] + sv[u]*alpha; ma[u] = ma[u] + mv[u]*alpha; Ma[i] = ma[u]; }
         const real res = csr_pass_jtf(A, b0[u], b1[u] - b0[u]);
@@ -104,27 +115,47 @@ MJH_DEV void csr_pass(MREF M, const CsrPass& A) {
         const real g = ma[u] - f[u] - res;
         const real mg = g*di[u];
         grad[i] = g; Mgrad[i] = mg;
-        if (step) { graddif[i] = g - g0[u]; Mgraddif[i] = mg - mg0[u]; }
+        if (step) {
+          const real gd = g - g0[u], mgd = mg - mg0[u];
+          p0[i] = sv[u]*gd; p1[i] = gd*mgd; p2[i] = gd*mg; p3[i] = sv[u]*g; p4[i] = sv[u]*sv[u]; p5[i] = g*g;
+        } else {
+          p0[i] = g*mg; p1[i] = g*g;
+        }
       }
     }
   } else if (A.op == CSR_OP_DIR) {
-    // the search direction -- -Mgrad at the start, Hager-Zhang's -Mgrad + beta search afterwards -- and Mv = M search
+    // the search direction -- -Mgrad at the start, Hager-Zhang's -Mgrad + beta search afterwards --, Mv = M search, and the
+    // addends of |search|^2 and PrimalPrepare's three sums: search.search, search.Ma, qfrc_smooth.search, search.Mv
     const int first = A.flag & 1;
     const real beta = A.alpha;
-    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*MJH_W) {
-      real mg[MJH_CSR_U], sv[MJH_CSR_U], ms[MJH_CSR_U];
-#pragma unroll
-      for (int u = 0; u < MJH_CSR_U; u++) { const int i = i0 + u*MJH_W < nv ? i0 + u*MJH_W : 0; mg[u] = Mgrad[i]; sv[u] = first ? (real)0 : search[i]; ms[u] = A.Ms[i]; }
+    for (int i0 = lane; i0 < nv; i0 += MJH_CSR_U*W) {
+      real mg[MJH_CSR_U], sv[MJH_CSR_U], ms[MJH_CSR_U], ma[MJH_CSR_U], f[MJH_CSR_U];
 #pragma unroll
       for (int u = 0; u < MJH_CSR_U; u++) {
-        const int i = i0 + u*MJH_W;
-        if (i < nv) { const real s = first ? -1*mg[u] : -mg[u] + beta*sv[u]; search[i] = s; Mv[i] = ms[u]*s; }
+        const int i = i0 + u*W < nv ? i0 + u*W : 0;
+        mg[u] = Mgrad[i]; sv[u] = first ? (real)0 : search[i]; ms[u] = A.Ms[i]; ma[u] = Ma[i]; f[u] = A.qfs[i];
+      }
+#pragma unroll
+      for (int u = 0; u < MJH_CSR_U; u++) {
+        const int i = i0 + u*W;
+        if (i < nv) {
+          const real s = first ? -1*mg[u] : -mg[u] + beta*sv[u];
+          const real mv = ms[u]*s;
+          search[i] = s; Mv[i] = mv;
+          p0[i] = s*s; p1[i] = s*ma[u]; p2[i] = f[u]*s; p3[i] = s*mv;
+        }
       }
     }
   }
+  }
   wv_sync();
 }
-
+// the solver's block is grad (it starts there) .. the last product vector
+MJH_DEV void csr_pass(MREF M, const CsrPass& A) {
+  const long long off = mjh_lds_offset((const void*)A.grad);
+  if (A.search == A.grad + A.nv && A.prod == A.grad + 2*A.nv && off >= 0 && off < 160*1024) csr_pass_body(M, A, mjh_local(A.grad));
+  else csr_pass_body(M, A, SP<real>{A.grad, 1});
+}
 
 // The values of the contact rows of the explicit-index Jacobian (mjh_csr.h, pass 2b): one lane per (contact, stored dof)
 // item computes that dof's column of the contact's rows -- the expressions of stage_make_constraint's dense contact rows.
@@ -162,7 +193,9 @@ MJH_DEV void csr_row_values(MREF M, BREF B, int e, const CsrRowArgs& A) {
     real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
     if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
       jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
-      for (int q = 0; q < nfb; q++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (q >= nfb) continue;
         const int wq = M.body_weldid[fbody[q]];
         if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
         real offq[3], t[3];

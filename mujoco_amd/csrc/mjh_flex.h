@@ -436,7 +436,10 @@ MJH_DEV int flex_contact_weights(MREF M, BREF B, int e, int k, int* body, real* 
   crptr point = MJH_CON(B, con_pos, e, 3, k);
   const int el = M.flex_elemadr[f] + cf[1];
   const int n = M.flex_dim[f] + 1;
-  for (int i = 0; i < n; i++) {
+  // (loops of constant length with a predicate: body[] / w[] stay in the caller's registers instead of scratch memory)
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (i >= n) continue;
     const int v = M.flexelem_vert[4*el + i];
     const real dx = point[0] - vx[3*v], dy = point[1] - vx[3*v + 1], dz = point[2] - vx[3*v + 2];
     const real dist = sqrt(dx*dx + dy*dy + dz*dz);
@@ -444,8 +447,10 @@ MJH_DEV int flex_contact_weights(MREF M, BREF B, int e, int k, int* body, real* 
     body[i] = M.flexvert_bodyid[v];
   }
   real sum = 0;
-  for (int i = 0; i < n; i++) sum += w[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < n) sum += w[i];
   const real inv = 1.0/sum;
-  for (int i = 0; i < n; i++) w[i] = w[i]*inv;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i < n) w[i] = w[i]*inv;
   return n;
 }

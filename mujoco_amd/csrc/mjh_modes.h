@@ -59,6 +59,7 @@ enum { MJH_MWS_EXIT = 0, MJH_MWS_KIN = 1, MJH_MWS_COMPOS, MJH_MWS_FLEXEDGES, MJH
 #define MJH_WIDE(id, call) call
 // the same for a stage that takes an argument block (posted through LDS in a multi-wavefront workgroup)
 #define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_HELPERS_ARGS(id, A, call) call
 #define MJH_WIDE_IF(cond, id, call) call
 // end of a section in which the rows of the group ran apart: everyone is back, memory is visible
 #define MJH_GROUP_JOIN() do { wv_converge(); wv_sync(); } while (0)
@@ -106,6 +107,7 @@ namespace ws {
 #undef MJH_ENTER
 #undef MJH_WIDE
 #undef MJH_WIDE_ARGS
+#undef MJH_HELPERS_ARGS
 #undef MJH_WIDE_IF
 
 #undef MJH_LANE_MODE
@@ -134,6 +136,7 @@ namespace ws {
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 #define MJH_WIDE(id, call) call
 #define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_HELPERS_ARGS(id, A, call) call
 #define MJH_WIDE_IF(cond, id, call) call
 #undef MJH_GROUP_JOIN
 #define MJH_GROUP_JOIN() wv_sync()
@@ -185,6 +188,7 @@ MJH_DEV void wv_sync() { __syncthreads(); }
 #undef MJH_FOR_LANES
 #undef MJH_WIDE
 #undef MJH_WIDE_ARGS
+#undef MJH_HELPERS_ARGS
 #undef MJH_WIDE_IF
 #undef MJH_ENTER
 #undef MJH_GROUP_JOIN
@@ -225,6 +229,18 @@ MJH_DEV void mw_run_args(MREF M, BREF B, int e, int id, const T& A) {
   if (wv_lane() == 0) *(T*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS) = A;
   mw_run(M, B, e, id);
 }
+// wave 0: post the explicit-index CG solver's pass for the HELPER wavefronts alone and wait for them.  Wave 0 holds the
+// solver's state in registers; running its share of the pass inline cost it a spill / reload of that state around every
+// pass (out of line: the same through the call, measured slower still) -- it now only posts the block and meets the two
+// barriers, and the pass runs on 64 (MJH_MW - 1) lanes.
+MJH_DEV void mw_run_helpers(MREF M, BREF B, int e, int id, CsrPass& A) {
+  A.lane0 = MJH_WAVE; A.width = MJH_WAVE*(MJH_MW - 1);
+  if (wv_lane() == 0) *(CsrPass*)(mjh_lds() + B.lds_bytes + MJH_MW_LDS_ARGS) = A;
+  volatile int* cmd = mw_command(B);
+  if (wv_lane() == 0) { cmd[0] = id; cmd[1] = e; }
+  mw_barrier();
+  mw_barrier();
+}
 // the helper wavefronts' whole program
 MJH_DEV void mw_helper_loop(MREF M, BREF B) {
   volatile int* cmd = mw_command(B);
@@ -247,6 +263,7 @@ MJH_DEV void mw_release_helpers(BREF B) {
 #define MJH_FOR_LANES(i, n) for (int i = wv_lane(); i < (n); i += MJH_W)
 #define MJH_WIDE(id, call) mw_run(M, B, e, id)
 #define MJH_WIDE_ARGS(id, A, call) mw_run_args(M, B, e, id, A)
+#define MJH_HELPERS_ARGS(id, A, call) mw_run_helpers(M, B, e, id, A)
 // (a stage that is workgroup-wide only under a condition -- e.g. not when a register-resident one-wavefront routine applies)
 #define MJH_WIDE_IF(cond, id, call) do { if (cond) mw_run(M, B, e, id); else { call; } } while (0)
 #define MJH_ENTER(M_, B_, e_) MREF M = wv_uniform_ref(M_); BREF B = wv_uniform_ref(B_); const int e = wv_uniform_i(e_); \
@@ -267,6 +284,7 @@ MJH_DEV void wv_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); 
 #undef MJH_FOR_LANES
 #undef MJH_WIDE
 #undef MJH_WIDE_ARGS
+#undef MJH_HELPERS_ARGS
 #undef MJH_WIDE_IF
 #undef MJH_ENTER
 #undef MJH_LANE_MODE
@@ -280,6 +298,7 @@ MJH_DEV void wv_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); 
 #define MJH_DEVN MJH_DEVN_LANE
 #define MJH_WIDE(id, call) call
 #define MJH_WIDE_ARGS(id, A, call) call
+#define MJH_HELPERS_ARGS(id, A, call) call
 #define MJH_WIDE_IF(cond, id, call) call
 #define MJH_FOR_LANES(i, n) for (int i = 0; i < (n); i++)
 // (stage functions are inlined into the kernel here: descriptors are already uniform, e is per lane)
@@ -308,4 +327,5 @@ MJH_DEV int wv_any(int pred) { return pred != 0; }
 #undef MJH_ENTER
 #undef MJH_WIDE
 #undef MJH_WIDE_ARGS
+#undef MJH_HELPERS_ARGS
 #undef MJH_WIDE_IF

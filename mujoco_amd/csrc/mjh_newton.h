@@ -361,6 +361,33 @@ MJH_DEV void csr_dots(int n, IP idof, int ident, int nd, const crptr* xs, const 
   }
 }
 
+// nd <= 16 ordered sums whose ADDENDS sit in consecutive vectors of n reals (the fused passes of mjh_csrpass.h leave the
+// element-wise products there): sum d in the four lanes 4d..4d+3, one accumulator chain of mju_dot each -- a link is one read
+// and one dependent addition --, then (r0 + r2) + (r1 + r3) plus the sum of the tail, as in csr_dots
+MJH_DEV void csr_sums(int n, int nd, const real* prod, real* out) {
+  const int lane = wv_lane();
+  const int d = lane >> 2, a = lane & 3;
+  const int n4 = n & ~3;
+  const real* p = prod + (size_t)(d < nd ? d : 0)*n;
+  real r = 0;
+  if (d < nd) {
+    const long long soff = mjh_lds_offset((const void*)prod);
+    r = (soff >= 0 && soff < 160*1024) ? csr_chain1(mjh_local(p), a, n4 >> 2) : csr_chain1(p, a, n4 >> 2);
+  }
+  const real r2 = wv_shfl(r, lane ^ 2);           // (lane a = 0 adds chain 2, lane 1 chain 3: r0 + r2, r1 + r3)
+  const real s02 = r + r2;
+  const real s13 = wv_shfl(s02, lane ^ 1);
+  real res = s02 + s13;                            // (in lane 4d: (r0 + r2) + (r1 + r3))
+  if (d < nd && a == 0 && n > n4) {
+    // (mju_dot adds the sum of the remaining one to three products, engine_util_blas.c:517-525)
+    real tail = p[n4];
+    for (int k = n4 + 1; k < n; k++) tail += p[k];
+    res += tail;
+  }
+  for (int q = 0; q < nd; q++) out[q] = wv_bcast(res, 4*q);
+  wv_sync();
+}
+
 // SPA = 1: the reference's sparse path (mj_isSparse): compressed J / J', packed sparse factor -- mjh_sparse.h describes the
 // data model; the blocks marked "sparse" below restate engine_util_sparse.c / engine_util_solve.c operation for operation
 template <int ELL, int SPA>
@@ -403,6 +430,20 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto LX = [nv](int k, int i) { return k*nv - k*(k - 1)/2 + (i - k); };
   rptr Ma = vec, grad = vec + nv, Mgrad = vec + 2*nv, search = vec + 3*nv, Mv = vec + 4*nv;
   rptr gradold = vec + 5*nv, Mgradold = vec + 6*nv, tmpv = vec + 7*nv;
+  // the passes over the dofs as fused, possibly workgroup-wide functions of an argument block (mjh_csrpass.h): CG on an
+  // environment-major batch with a diagonal mass matrix; per island, when it spans every dof (`fused` below).  The dof
+  // vectors are then laid out for those passes: grad and search next to SIX PRODUCT vectors in the solver's block (LDS by
+  // plan) -- the addends of the iteration's ordered sums, which the passes leave there --, and Ma, Mv, Mgrad, which only
+  // the passes touch, in global memory.  (An island that does not span every dof takes the unfused code on the same
+  // pointers; its three difference vectors use the product vectors' bytes.)
+  const int fuse_ok = SPA == 2 && !flg_newton && s.nC == nv && !B.soa;
+  real* prodv = nullptr;
+  if (fuse_ok) {
+    const rptr gp = MJH_G(B, csr_prod, e);
+    Ma = gp; Mv = gp + nv; Mgrad = gp + 2*nv;
+    grad = vec; search = vec + nv; prodv = vec.p + 2*nv;
+    gradold = vec + 2*nv; Mgradold = vec + 3*nv; tmpv = vec + 4*nv;
+  }
   rptr jar = P.jar, Jv = P.ARf;
   rptr scr = MJH_G(B, scratch, e);
   rptr quad = scr;                                 // [3*nefc] (+ cone extras in the block's slots)
@@ -433,10 +474,6 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   int nidof = nv;
   // staging block of csr_dots: the unused tail of the LDS regions when it holds at least one product vector, else global
   real* dstage = nullptr; int dstage_cap = 0;
-  // the passes over the dofs as fused, possibly workgroup-wide functions of an argument block (mjh_csrpass.h): CG on an
-  // environment-major batch with a diagonal mass matrix; per island, when it spans every dof (`fused` below)
-  const int fuse_ok = SPA == 2 && !flg_newton && s.nC == nv && !B.soa;
-  real* qfs_copy = nullptr;
   if (SPA == 2) {
     int fb = P.free_bytes;
     // (the line search's quadratic coefficients are read row by row in every evaluation: they take the top of the free
@@ -446,11 +483,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // (qfrc_smooth is read twice per iteration -- PrimalPrepare's sums, the gradient: with room for it next to one
     // product vector the solver works on an LDS copy, and every ordered sum of the iteration is a direct one)
     // (the staging block below may then fall back to global memory: with qfrc_smooth in LDS no sum of the iteration is staged)
-    if (fuse_ok) {
-      // (fused passes, mjh_csrpass.h: CSR_OP_START makes the copy)
-      if (fb >= nv*(int)sizeof(real)) { fb -= nv*(int)sizeof(real); qfs_copy = (real*)(P.free_p + fb); }
-    } else
-    if (fb >= nv*(int)sizeof(real)) {
+    // (fused passes: the sums read product vectors, never qfrc_smooth itself)
+    if (!fuse_ok && fb >= nv*(int)sizeof(real)) {
       fb -= nv*(int)sizeof(real);
       real* c = (real*)(P.free_p + fb);
       for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
@@ -464,12 +498,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       wv_sync();
     }
     if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
+    else if (fuse_ok) { dstage = &MJH_G(B, csr_prod, e)[0] + 3*nv; dstage_cap = 3*nv; }     // (the first three hold Ma, Mv, Mgrad)
     else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }
   }
   CsrPass pa;
   if (SPA == 2) {
-    pa.op = 0; pa.nv = nv; pa.flag = 0; pa.pad_ = 0; pa.alpha = 0;
-    pa.vec = vec.p; pa.qacc = qacc.p; pa.qfc = qfc.p; pa.stage = vec.p + 6*nv; pa.copy = nullptr;
+    pa.op = 0; pa.nv = nv; pa.flag = 0; pa.pad_ = 0; pa.alpha = 0; pa.lane0 = 0; pa.width = MJH_W;
+    pa.grad = grad.p; pa.search = search.p; pa.prod = prodv; pa.stage = prodv + 5*nv;
+    pa.Ma = Ma.p; pa.Mv = Mv.p; pa.Mgrad = Mgrad.p; pa.qacc = qacc.p; pa.qfc = qfc.p;
     pa.qfs = qfs.p; pa.dinv = MJH_F(B, qLDiagInv, e).p; pa.Ms = Ms.p; pa.qws = qws.p; pa.qas = qas.p;
     pa.spJT = P.spJT.p; pa.force = P.force.p; pa.JTadr = P.JTadr.p; pa.JTrow = P.JTrow.p;
     pa.tree_island = tree_island.p;
@@ -479,7 +515,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 #ifdef MJH_HOSTSIM
     if (lane == 0) ::mjhsim::rc_stats()[6]++;
 #endif
-    MJH_WIDE_ARGS(MJH_MWS_CSRPASS, pa, csr_pass(M, pa));
+    MJH_HELPERS_ARGS(MJH_MWS_CSRPASS, pa, csr_pass(M, pa));
   };
   // r + stage[0] + stage[1] + ... in order (one running sum of the reference over addends a pass left in the staging vector)
   auto stage_sum = [&](real r) -> real {
@@ -992,10 +1028,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const real cost_smooth = constraint_update(B, e, P, P.b, 1, elliptic);
       use_smooth = cost_ws > cost_smooth;
     }
-    pa.copy = qfs_copy;
     run_pass(CSR_OP_START, use_smooth | (multi_tree ? 2 : 0) | (trace_scale ? 4 : 0), 0);
-    pa.copy = nullptr;
-    if (qfs_copy) { qfs = SP<const real>{qfs_copy, 1}; pa.qfs = qfs_copy; }
   } else
   if (!(M.o.disableflags & (1<<9))) {
     mul_M(Ma, qws);
@@ -1099,7 +1132,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // convergence certificate with M^-1
     if (!fused) precondition();
     real gm_gg[2];
-    if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, nidof == nv, 2, xs, ys, gm_gg, dstage, dstage_cap); }
+    if (fused) csr_sums(nv, 2, prodv, gm_gg);
+    else if (SPA == 2) { const crptr xs[2] = {grad, grad}, ys[2] = {Mgrad, grad}; csr_dots(nidof, idof, nidof == nv, 2, xs, ys, gm_gg, dstage, dstage_cap); }
     else { gm_gg[0] = dotv(grad, Mgrad); gm_gg[1] = dotv(grad, grad); }
     const int flg_gap = r_max(0, 0.5*scale*gm_gg[0]) < tol;
     const int flg_gradient = scale*sqrt(gm_gg[1]) < tol;
@@ -1129,8 +1163,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         if (!fused) mul_M(Mv, search);
         tick(43);
         real q4[4];
-        const crptr xs[4] = {search, search, qfs, search}, ys[4] = {search, Ma, search, Mv};
-        csr_dots(nidof, idof, nidof == nv, 4, xs, ys, q4, dstage, dstage_cap);
+        if (fused) csr_sums(nv, 4, prodv, q4);
+        else {
+          const crptr xs[4] = {search, search, qfs, search}, ys[4] = {search, Ma, search, Mv};
+          csr_dots(nidof, idof, nidof == nv, 4, xs, ys, q4, dstage, dstage_cap);
+        }
         snorm = sqrt(q4[0]); q3[0] = q4[1]; q3[1] = q4[2]; q3[2] = q4[3];
         tick(45);
       } else snorm = sqrt(dotv(search, search));
@@ -1342,8 +1379,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           for (int u = 0; u < MJH_NVU; u++) { const int i = i0 + u*MJH_W; if (i < nv) { tmpv[i] = g[u] - go[u]; gradold[i] = mg[u] - mgo[u]; } }
         }
         wv_sync();
-        const crptr xs[6] = {search, tmpv, tmpv, search, search, grad}, ys[6] = {tmpv, gradold, Mgrad, grad, search, grad};
-        csr_dots(nidof, idof, nidof == nv, 6, xs, ys, hz, dstage, dstage_cap);
+        if (fused) csr_sums(nv, 6, prodv, hz);
+        else {
+          const crptr xs[6] = {search, tmpv, tmpv, search, search, grad}, ys[6] = {tmpv, gradold, Mgrad, grad, search, grad};
+          csr_dots(nidof, idof, nidof == nv, 6, xs, ys, hz, dstage, dstage_cap);
+        }
       }
       const real gradient = scale*sqrt((SPA == 2 && !flg_newton) ? hz[5] : dotv(grad, grad));
       tick(41);          // (profile builds, slots 41..45: gradient norm | direction update | |search|, M search | J search | PrimalPrepare sums)

@@ -654,10 +654,15 @@ struct DBatch {
 // slices, so that wave 0 of a multi-wavefront workgroup can hand it to the helper wavefronts through LDS
 enum { CSR_OP_WARM = 1, CSR_OP_START = 2, CSR_OP_GRAD = 3, CSR_OP_STEP = 4, CSR_OP_DIR = 5 };
 struct CsrPass {
-  int op, nv, flag, pad_;
+  int op, nv, flag;
+  int lane0, width;            // the lanes that run the pass: wv_lane() in [lane0, lane0 + width)
+  int pad_;
   real alpha;                  // step length (CSR_OP_STEP) or Hager-Zhang's beta (CSR_OP_DIR)
-  real* vec;                   // Ma | grad | Mgrad | search | Mv | Mgraddif | (staging) | graddif, nv each
-  real* qacc; real* qfc; real* stage; real* copy;
+  real* grad; real* search;    // read by nothing but these passes, kept next to the products
+  real* prod;                  // six product vectors, nv each: the addends of the iteration's ordered sums (LDS by plan)
+  real* stage;                 // addends of the set-up's running sums (the sixth product vector)
+  real* Ma; real* Mv; real* Mgrad;          // touched by these passes only: global memory, coalesced
+  real* qacc; real* qfc;
   const real* qfs; const real* dinv; const real* Ms; const real* qws; const real* qas;
   const real* spJT; const real* force;
   const int* JTadr; const int* JTrow; const int* tree_island;
