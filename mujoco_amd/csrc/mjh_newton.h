@@ -273,6 +273,12 @@ MJH_DEV real csr_chain_serial(PP p, int n, real r) {
   for (; i < n; i++) r += p[i];
   return r;
 }
+// element k of a strided walk through a vector (csr_chain_serial over one column of a row-major block)
+template <class PP>
+struct CsrStrided {
+  PP p; int s;
+  template <class I> MJH_MEM real operator[](I i) const { return p[i*s]; }
+};
 // 1 if the contiguous slice lies in the workgroup's LDS block (also on the host emulation, where mjh_in_lds is 0)
 MJH_DEV int csr_lds_resident(const crptr& v) {
   const long long off = mjh_lds_offset((const void*)v.p);
@@ -1210,6 +1216,13 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         int lsiter = 0;
         // PrimalEval: the six running sums of the reference's loop over rows -- cost, deriv[0..1],
         // quadTotal[0..2] -- as ordered chains over the rows' contributions
+        // (explicit-index path with room in the LDS tail: the rows' addends are written to a row-major block and the six
+        // sums are taken by six lanes, one read and one addition per row, instead of a v_readlane walk per contributing
+        // row and sum.  Rows that contribute an exact zero are added too: no accumulator here can be -0.0 -- mju_dot never
+        // returns it, so neither initial value is -- hence x + (+-0) = x for every partial sum.)
+        real* const ev = dstage;
+        const long long ev_off = mjh_lds_offset((const void*)dstage);
+        const int ev_ok = SPA == 2 && ev_off >= 0 && ev_off < 160*1024 && dstage_cap >= 6*nefc;
         auto eval = [&](NtPoint& p) {
           const real al = p.alpha;
           real acc[6] = {0, 0, 0, 0, qg1, qg2};          // cost, d0, d1, qT0, qT1, qT2
@@ -1258,8 +1271,25 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
             // (rows that contribute an exact zero to a sum cannot change it: only the others are chained --
             // friction rows feed cost / derivatives, active contacts the quadratic totals, seldom both)
             // (the three quadratic totals come from the same rows -- the active contacts: one walk, three overlapping chains)
+            if (ev_ok) {
+              if (r < nefc) { for (int q = 0; q < 6; q++) ev[6*r + q] = c[q]; }
+              continue;
+            }
             for (int q = 0; q < 3; q++) acc[q] = wv_chain_mask(acc[q], c[q], wv_ballot(c[q] != 0));
             wv_chain3_mask(acc + 3, c + 3, wv_ballot(c[3] != 0 || c[4] != 0 || c[5] != 0));
+          }
+          if (ev_ok) {
+            wv_sync();
+            real a = lane == 4 ? qg1 : (lane == 5 ? qg2 : (real)0);
+            if (lane < 6) {
+#ifdef MJH_HOSTSIM
+              a = csr_chain_serial(CsrStrided<const real*>{(const real*)ev + lane, 6}, nefc, a);
+#else
+              a = csr_chain_serial(CsrStrided<LP<const real>>{mjh_local((const real*)ev + lane), 6}, nefc, a);
+#endif
+            }
+            for (int q = 0; q < 6; q++) acc[q] = wv_bcast(a, q);
+            wv_sync();
           }
           real cost = acc[0], d0 = acc[1], d1 = acc[2];
           cost += al*al*acc[5] + al*acc[4] + acc[3];
