@@ -972,7 +972,16 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.rowadr[mid] <= q) lo = mid; else hi = mid; }
       return lo;
     };
-    if (csr) { MJH_FOR_LANES(q, nJ) { const int t = M.dof_treeid[P.colind[q]]; label[t] = t; } }
+    // (these passes walk index tables -- column -> tree -> label: four items per lane and trip, their loads issued together)
+    if (csr) {
+      for (int q0 = wv_lane(); q0 < nJ; q0 += 4*MJH_W) {
+        int t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int q = q0 + u*MJH_W; t[u] = q < nJ ? (int)M.dof_treeid[P.colind[q]] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (t[u] >= 0) label[t[u]] = t[u];
+      }
+    }
     MJH_FOR_LANES(i, nefc) {
       int t1, t2;
       row_trees(i, &t1, &t2);
@@ -994,10 +1003,16 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     // the trees of every stiffness-active flex form one component, with or without rows of their own (unionConstraintTrees,
     // engine_island.c:409-447): start them at the flex's smallest tree
     if (MJH_HAS(MJH_FT_FLEX) && s.nflex) {
-      MJH_FOR_LANES(v, s.nflexvert) {
-        const int mt = M.flex_mintree[M.flexvert_flex[v]];
-        const int tv = M.body_treeid[M.flexvert_bodyid[v]];
-        if (mt >= 0 && tv >= 0) { const int l = label[tv]; if (l < 0 || l > mt) label[tv] = mt; }
+      for (int v0 = wv_lane(); v0 < s.nflexvert; v0 += 4*MJH_W) {
+        int mt[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int v = v0 + u*MJH_W;
+          mt[u] = -1; tv[u] = -1;
+          if (v < s.nflexvert) { mt[u] = M.flex_mintree[M.flexvert_flex[v]]; tv[u] = M.body_treeid[M.flexvert_bodyid[v]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (mt[u] >= 0 && tv[u] >= 0) { const int l = label[tv[u]]; if (l < 0 || l > mt[u]) label[tv[u]] = mt[u]; }
       }
       wv_sync();
     }
@@ -1021,19 +1036,29 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
         else if (t2 >= 0) join(efc_tree[i], t2);
       }
       if (csr) {
-        MJH_FOR_LANES(q, nJ - 1) {
-          const int r = entry_row(q);
-          if (second[r] != -3 || q + 1 >= P.rowadr[r + 1]) continue;
-          const int a = M.dof_treeid[P.colind[q]], b = M.dof_treeid[P.colind[q + 1]];
-          if (a == b) continue;
-          const int la = label[a], lb = label[b];
-          if (la == lb) continue;
-          const int m = la < lb ? la : lb;
-          wv_atomic_min_i(&label[a], m);
-          wv_atomic_min_i(&label[b], m);
-          wv_atomic_min_i(&label[la], m);
-          wv_atomic_min_i(&label[lb], m);
-          moved = 1;
+        for (int q0 = wv_lane(); q0 < nJ - 1; q0 += 4*MJH_W) {
+          int a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u*MJH_W;
+            a[u] = -1; b[u] = -1;
+            if (q < nJ - 1) {
+              const int r = entry_row(q);
+              if (second[r] == -3 && q + 1 < P.rowadr[r + 1]) { a[u] = M.dof_treeid[P.colind[q]]; b[u] = M.dof_treeid[P.colind[q + 1]]; }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (a[u] < 0 || a[u] == b[u]) continue;
+            const int la = label[a[u]], lb = label[b[u]];
+            if (la == lb) continue;
+            const int m = la < lb ? la : lb;
+            wv_atomic_min_i(&label[a[u]], m);
+            wv_atomic_min_i(&label[b[u]], m);
+            wv_atomic_min_i(&label[la], m);
+            wv_atomic_min_i(&label[lb], m);
+            moved = 1;
+          }
         }
       }
       wv_sync();

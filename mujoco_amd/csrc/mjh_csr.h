@@ -121,6 +121,13 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   crptr subtree_com = MJH_F(B, subtree_com, e);
 
   const int small = s.csr_rowmax <= 16;       // merged chains fit the register form (csr_contact_cols16)
+#ifdef MJH_PROFILE
+  // (profile builds, slots 57..59: row lengths + addresses | columns and values | transpose)
+  long long ptick = wv_clock();
+  auto tick = [&](int slot) { const long long c_ = wv_clock(); if (wv_lane() == 0) MJH_G(B, prof, e)[slot] += (real)(c_ - ptick)*0.01; ptick = c_; };
+#else
+  auto tick = [](int) {};
+#endif
 
   // ---- pass 1: stored entries per row (rowadr[r + 1] <- nnz of row r)
   MJH_FOR_LANES(r, nefc) {
@@ -173,6 +180,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   iptr JTadr = P.JTadr;
   iptr JTrow = P.JTrow;
   rptr JTval = P.spJT;
+  tick(57);
   // ---- pass 2: columns and values
   MJH_FOR_LANES(r, nefc) {
     const int type = P.type[r], id = P.id[r];
@@ -227,6 +235,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     MJH_WIDE_ARGS(MJH_MWS_CSRVALS, ra, csr_row_values(M, B, e, ra));
   }
 
+  tick(58);
   // ---- transpose: entries of every dof in ascending row order (mju_transposeSparse): counting pass with integer atomics,
   //      one lane per stored entry scatters it (its row by bisection of the row addresses), then each dof sorts its
   //      (short) list by row.  The cursors sit in the unused tail of the LDS regions when it has room.
@@ -268,6 +277,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  tick(59);
 }
 
 #endif   // !MJH_LANE_MODE

@@ -49,6 +49,13 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
   const int vadr = M.flex_vertadr[f], nvert = M.flex_vertnum[f];
   const int eadr = M.flex_elemadr[f];
   int n = 0;
+#ifdef MJH_PROFILE
+  // (profile builds, slots 53..56: planes | leaf culling | element narrowphase | filter, sort, emission)
+  long long ptick = wv_clock();
+  auto tick = [&](int slot) { const long long c_ = wv_clock(); if (wv_lane() == 0) MJH_G(B, prof, e)[slot] += (real)(c_ - ptick)*0.01; ptick = c_; };
+#else
+  auto tick = [](int) {};
+#endif
 
   // ---- planes: every vertex (mj_collidePlaneFlex)
   for (int a = a0; a < a1; a++) {
@@ -58,31 +65,40 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
     const real bound = M.pair_margin[p] + radius;           // margin + gap + radius
     const V3 pos = ld3(gx + 3*g);
     const V3 nrm = mcol(gm + 9*g, 2);
-    for (int v0 = 0; v0 < nvert; v0 += MJH_W) {
-      const int v = v0 + wv_lane();
-      int hit = 0;
-      real dist = 0;
-      V3 vp{0, 0, 0};
-      if (v < nvert) {
-        vp = ld3(vx + 3*(vadr + v));
-        const V3 dif = vp - pos;
-        dist = dif.x*nrm.x + dif.y*nrm.y + dif.z*nrm.z;
-        hit = !(dist > bound);
+    // (four blocks of vertices per trip: a lone wavefront pays the position loads' round trip once instead of four times;
+    // the hits are compacted block by block, in vertex order)
+    for (int v0 = 0; v0 < nvert; v0 += 4*MJH_W) {
+      int hit[4]; real dist[4]; V3 vp[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int v = v0 + u*MJH_W + wv_lane();
+        hit[u] = 0; dist[u] = 0; vp[u] = V3{0, 0, 0};
+        if (v < nvert) {
+          vp[u] = ld3(vx + 3*(vadr + v));
+          const V3 dif = vp[u] - pos;
+          dist[u] = dif.x*nrm.x + dif.y*nrm.y + dif.z*nrm.z;
+          hit[u] = !(dist[u] > bound);
+        }
       }
-      const unsigned long long m = wv_ballot(hit);
-      if (hit) {
-        const int c = n + wv_rank_lt(m);
-        const real cd = dist - radius;
-        const real scl = -cd*0.5 - radius;
-        cand[FC_NREAL*c + FC_DIST] = cd;
-        cand[FC_NREAL*c + FC_POS] = vp.x + nrm.x*scl; cand[FC_NREAL*c + FC_POS + 1] = vp.y + nrm.y*scl; cand[FC_NREAL*c + FC_POS + 2] = vp.z + nrm.z*scl;
-        cand[FC_NREAL*c + FC_NRM] = nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = nrm.z;
-        ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = v; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int v = v0 + u*MJH_W + wv_lane();
+        const unsigned long long m = wv_ballot(hit[u]);
+        if (hit[u]) {
+          const int c = n + wv_rank_lt(m);
+          const real cd = dist[u] - radius;
+          const real scl = -cd*0.5 - radius;
+          cand[FC_NREAL*c + FC_DIST] = cd;
+          cand[FC_NREAL*c + FC_POS] = vp[u].x + nrm.x*scl; cand[FC_NREAL*c + FC_POS + 1] = vp[u].y + nrm.y*scl; cand[FC_NREAL*c + FC_POS + 2] = vp[u].z + nrm.z*scl;
+          cand[FC_NREAL*c + FC_NRM] = nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = nrm.z;
+          ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = v; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 0;
+        }
+        n += __builtin_popcountll(m);
       }
-      n += __builtin_popcountll(m);
     }
   }
 
+  tick(53);
   // ---- other geoms: BVH leaves in reach, then GJK / EPA per surviving (geom, element)
   const int l0 = M.flex_leafadr[f], l1 = M.flex_leafadr[f + 1];
   for (int a = a0; a < a1; a++) {
@@ -94,25 +110,37 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
     const int gbody = M.geom_bodyid[g];
     const real ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero3[3] = {0, 0, 0};
     int nsurv = 0;
-    for (int k0 = l0; k0 < l1; k0 += MJH_W) {
-      const int k = k0 + wv_lane();
-      int ok = 0, el = -1;
-      if (k < l1) {
-        el = M.flexleaf_elem[k];
-        crptr bx = aabb + 6*el;
-        const real sx = gx[3*g], sy = gx[3*g + 1], sz = gx[3*g + 2];
-        // filterSphereBox (:236-244)
-        ok = !(sx + sbound < bx[0] - bx[3] || sy + sbound < bx[1] - bx[4] || sz + sbound < bx[2] - bx[5] ||
-               sx - sbound > bx[0] + bx[3] || sy - sbound > bx[1] + bx[4] || sz - sbound > bx[2] + bx[5]);
-        if (ok) ok = bp_obb<0>(M.geom_aabb + 6*g, bx, gx + 3*g, gm + 9*g, zero3, ident, mg);
-        // an element with a vertex on the geom's own body is skipped (mj_collideGeomElem :2387-2394)
-        if (ok) for (int i = 0; i < 4; i++) { const int v = M.flexelem_vert[4*el + i]; if (v >= 0 && M.flexvert_bodyid[v] == gbody) ok = 0; }
+    // (two blocks of leaves per trip, for the same reason; survivors compacted in leaf order)
+    for (int k0 = l0; k0 < l1; k0 += 2*MJH_W) {
+      int ok[2], el[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int k = k0 + u*MJH_W + wv_lane();
+        ok[u] = 0; el[u] = -1;
+        if (k < l1) {
+          el[u] = M.flexleaf_elem[k];
+          crptr bx = aabb + 6*el[u];
+          const real sx = gx[3*g], sy = gx[3*g + 1], sz = gx[3*g + 2];
+          // filterSphereBox (:236-244)
+          ok[u] = !(sx + sbound < bx[0] - bx[3] || sy + sbound < bx[1] - bx[4] || sz + sbound < bx[2] - bx[5] ||
+                    sx - sbound > bx[0] + bx[3] || sy - sbound > bx[1] + bx[4] || sz - sbound > bx[2] + bx[5]);
+        }
       }
-      const unsigned long long m = wv_ballot(ok);
-      if (ok) surv[nsurv + wv_rank_lt(m)] = el;
-      nsurv += __builtin_popcountll(m);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (ok[u]) ok[u] = bp_obb<0>(M.geom_aabb + 6*g, aabb + 6*el[u], gx + 3*g, gm + 9*g, zero3, ident, mg);
+        // an element with a vertex on the geom's own body is skipped (mj_collideGeomElem :2387-2394)
+        if (ok[u]) for (int i = 0; i < 4; i++) { const int v = M.flexelem_vert[4*el[u] + i]; if (v >= 0 && M.flexvert_bodyid[v] == gbody) ok[u] = 0; }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const unsigned long long m = wv_ballot(ok[u]);
+        if (ok[u]) surv[nsurv + wv_rank_lt(m)] = el[u];
+        nsurv += __builtin_popcountll(m);
+      }
     }
     wv_sync();
+    tick(54);
     for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
       const int r = r0 + wv_lane();
       const int el = r < nsurv ? surv[r] : -1;
@@ -127,6 +155,7 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
       n += __builtin_popcountll(m);
     }
     wv_sync();
+    tick(55);
   }
   wv_sync();
   if (n == 0) return 0;
@@ -193,6 +222,7 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
   }
   overflow = wv_any(overflow);
   wv_sync();
+  tick(56);
   return nsel | (overflow << 16);
 }
 

@@ -876,6 +876,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // the factor is stored compressed by its pattern; it works in the LDS slot when its fill fits, else in its global home
   int sp_nL = 0;
   auto sp_factorize = [&]() {
+#ifdef MJH_HOSTSIM
+    { static int once = 0; if (getenv("MJH_DBG_LAYOUT") && lane == 0 && once++ < 3) fprintf(stderr, "layout: nefc %d nv %d free_bytes %d spL_cap %d (reals) nLp %d lds %d\n", nefc, nv, P.free_bytes, P.spL_cap, s.nLp, B.lds_bytes); }
+#endif
     MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
     wv_sync();
     sp_nL = sp_symbolic(M, B, e, P, isl_dofs);

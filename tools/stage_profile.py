@@ -64,6 +64,11 @@ if p.shape[1] >= 41 and p[:, 39].sum() > 0:
 if p.shape[1] >= 53 and p[:, 48:53].sum() > 0:
     print("  outside the stages: state checks %.1f  compressed rows + islands %.1f  state / sensor output %.1f  control input %.1f  sensors %.1f us"
           % tuple(p[:, k].mean()/nst for k in (48, 49, 50, 51, 52)))
+if p.shape[1] >= 60 and p[:, 53:60].sum() > 0:
+    print("  inside collision (flex jobs): planes %.1f  leaf culling %.1f  element narrowphase %.1f  filter / sort / emission %.1f us"
+          % tuple(p[:, k].mean()/nst for k in (53, 54, 55, 56)))
+    print("  inside compressed rows: row lengths + addresses %.1f  columns and values %.1f  transpose %.1f us (the rest of that figure: mj_island)"
+          % tuple(p[:, k].mean()/nst for k in (57, 58, 59)))
 c = b.get("counts")
 print("mean ncon", c[:, 0].mean(), "nefc", c[:, 1].mean(), "pgs iter", c[:, 5].mean())
 
