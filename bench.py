@@ -312,15 +312,18 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     g = out.get("reference_glibc", {}).get("identical_input_steps")
     dmath = out.get("reference_device_libm", {}).get("identical_input_steps")
     if g is not None and dmath is not None:
+        # (against glibc a step may differ in its last bit of sin / cos, which on ~1 % of the cube's steps moves a degenerate
+        # contact -- floats and counts alike, tests/test_oracle_golden.py::test_cube_contact_discontinuity: the same 99 % gate
+        # for both; against the device-libm build everything is exact)
         out["ok"] = bool(dmath["max_rel_err"] <= 1e-6 and dmath["count_mismatches"] == 0 and
-                         g["frac_within_tolerance"] >= 0.99 and g["count_mismatches"] == 0)
+                         g["frac_within_tolerance"] >= 0.99 and g["count_mismatches"] <= 0.01*g["steps"])
     elif g is not None:
         out["ok"] = bool(g["max_rel_err"] <= 1e-6 and g["count_mismatches"] == 0)
     out["protocol"] = ("oracle/_ref mj_step from the same state0/controls over warm-up + timed region, re-synchronised to the GPU state "
                        "after every step (trajectory); then every one of those steps re-run on the GPU from identical (state, warm "
                        "start, control) with exact integer observables (identical_input_steps).  reference_glibc = the reference as "
                        "built; reference_device_libm = the same objects with sin / cos / atan2 / exp bound to the kernels' own routines "
-                       "(oracle/devmath_shim.cc): ok needs every step within 1e-6 against the latter and >= 99 % of them against the former")
+                       "(oracle/devmath_shim.cc): ok needs every step within 1e-6 and every count exact against the latter, and >= 99 % of the steps (floats and counts) against the former")
     return out
 
 

@@ -25,6 +25,8 @@ struct Efc {
   // the larger of the two regions' unused tails (staging space for stage_project)
   char* free_p;
   int free_bytes;
+  // primal solvers' line search: LDS block of one 64-row group's addends (6 reals per row), or null
+  real* ev;
 };
 
 // Two regions of the workgroup's LDS block take these arrays:
@@ -113,6 +115,7 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   P.Ladr = MJH_G(B, sp_Ladr, e); P.Lmask = MJH_G(B, sp_Lmask, e);
   P.vec = MJH_G(B, nt_vec, e);
   P.spar = MJH_G(B, iscratch, e) + nmax;
+  P.ev = nullptr;
   if (primal_ && B.lds_bytes) {
     int lo = off2;
     const int newton = M.o.solver == MJH_SOL_NEWTON;
@@ -125,6 +128,8 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
     }
     if (lo + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + lo), 1}; lo += nvec; }
     if (newton) {
+      // (sparse Newton: 3 KB ahead of the factor for the line search's row-ordered sums, when the factor keeps a useful share)
+      if (spm_ && end1 - lo >= 6*MJH_WAVE*(int)sizeof(real) + 512*(int)sizeof(real)) { P.ev = (real*)(lds_ + lo); lo += 6*MJH_WAVE*(int)sizeof(real); }
       const int full = (spm_ ? M.s.nLp : nv*(nv + 1)/2)*(int)sizeof(real);
       int lb = (end1 - lo) & ~7;
       if (lb > full) lb = full;

@@ -876,9 +876,6 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // the factor is stored compressed by its pattern; it works in the LDS slot when its fill fits, else in its global home
   int sp_nL = 0;
   auto sp_factorize = [&]() {
-#ifdef MJH_HOSTSIM
-    { static int once = 0; if (getenv("MJH_DBG_LAYOUT") && lane == 0 && once++ < 3) fprintf(stderr, "layout: nefc %d nv %d free_bytes %d spL_cap %d (reals) nLp %d lds %d\n", nefc, nv, P.free_bytes, P.spL_cap, s.nLp, B.lds_bytes); }
-#endif
     MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
     wv_sync();
     sp_nL = sp_symbolic(M, B, e, P, isl_dofs);
@@ -1223,12 +1220,16 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         // sums are taken by six lanes, one read and one addition per row, instead of a v_readlane walk per contributing
         // row and sum.  Rows that contribute an exact zero are added too: no accumulator here can be -0.0 -- mju_dot never
         // returns it, so neither initial value is -- hence x + (+-0) = x for every partial sum.)
-        real* const ev = dstage;
-        const long long ev_off = mjh_lds_offset((const void*)dstage);
-        const int ev_ok = SPA == 2 && ev_off >= 0 && ev_off < 160*1024 && dstage_cap >= 6*nefc;
+        // (one 64-row group at a time: 3 KB -- the explicit-index path takes them from the staging block in the LDS tail, the
+        // sparse Newton path from the slot efc_layout reserves ahead of the factor)
+        real* const ev = SPA == 2 ? dstage : P.ev;
+        const long long ev_off = mjh_lds_offset((const void*)ev);
+        const int ev_ok = ev != nullptr && ev_off >= 0 && ev_off < 160*1024 && (SPA != 2 || dstage_cap >= 6*MJH_W);
+        real ev_a = 0;
         auto eval = [&](NtPoint& p) {
           const real al = p.alpha;
           real acc[6] = {0, 0, 0, 0, qg1, qg2};          // cost, d0, d1, qT0, qT1, qT2
+          ev_a = lane == 4 ? qg1 : (lane == 5 ? qg2 : (real)0);
           for (int r0 = 0; r0 < nefc; r0 += MJH_W) {
             const int r = r0 + lane;
             real c[6] = {0, 0, 0, 0, 0, 0};
@@ -1275,25 +1276,23 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
             // friction rows feed cost / derivatives, active contacts the quadratic totals, seldom both)
             // (the three quadratic totals come from the same rows -- the active contacts: one walk, three overlapping chains)
             if (ev_ok) {
-              if (r < nefc) { for (int q = 0; q < 6; q++) ev[6*r + q] = c[q]; }
+              if (r < nefc) { for (int q = 0; q < 6; q++) ev[6*(r - r0) + q] = c[q]; }
+              wv_sync();
+              if (lane < 6) {
+                const int nr = nefc - r0 < MJH_W ? nefc - r0 : MJH_W;
+#ifdef MJH_HOSTSIM
+                ev_a = csr_chain_serial(CsrStrided<const real*>{(const real*)ev + lane, 6}, nr, ev_a);
+#else
+                ev_a = csr_chain_serial(CsrStrided<LP<const real>>{mjh_local((const real*)ev + lane), 6}, nr, ev_a);
+#endif
+              }
+              wv_sync();
               continue;
             }
             for (int q = 0; q < 3; q++) acc[q] = wv_chain_mask(acc[q], c[q], wv_ballot(c[q] != 0));
             wv_chain3_mask(acc + 3, c + 3, wv_ballot(c[3] != 0 || c[4] != 0 || c[5] != 0));
           }
-          if (ev_ok) {
-            wv_sync();
-            real a = lane == 4 ? qg1 : (lane == 5 ? qg2 : (real)0);
-            if (lane < 6) {
-#ifdef MJH_HOSTSIM
-              a = csr_chain_serial(CsrStrided<const real*>{(const real*)ev + lane, 6}, nefc, a);
-#else
-              a = csr_chain_serial(CsrStrided<LP<const real>>{mjh_local((const real*)ev + lane), 6}, nefc, a);
-#endif
-            }
-            for (int q = 0; q < 6; q++) acc[q] = wv_bcast(a, q);
-            wv_sync();
-          }
+          if (ev_ok) { for (int q = 0; q < 6; q++) acc[q] = wv_bcast(ev_a, q); }
           real cost = acc[0], d0 = acc[1], d1 = acc[2];
           cost += al*al*acc[5] + al*acc[4] + acc[3];
           d0 += 2*al*acc[5] + acc[4];
