@@ -919,9 +919,13 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
     // when it has room; tree_island, which the primal solvers read, is copied to its global home at the end)
     const iptr tree_island_home = tree_island;
     // (only a tail of region 1: region 2 still holds the contact slots this stage reads)
-    const int in_lds = P.free_bytes >= (2*nefc + 2*ntree)*(int)sizeof(int) && P.free_p >= MJH_LDS(B) + B.dyn_off;
+    // (sparse Newton: the factor takes the whole tail, but the line search's block ahead of it is idle until the solve)
+    const int need = (2*nefc + 2*ntree)*(int)sizeof(int);
+    int* w = nullptr;
+    if (P.free_bytes >= need && P.free_p >= MJH_LDS(B) + B.dyn_off) w = (int*)P.free_p;
+    else if (P.ev && need <= 6*MJH_WAVE*(int)sizeof(real) && (char*)P.ev >= MJH_LDS(B) + B.dyn_off) w = (int*)P.ev;
+    const int in_lds = w != nullptr;
     if (in_lds) {
-      int* w = (int*)P.free_p;
       efc_tree = SP<int>{w, 1}; second = SP<int>{w + nefc, 1}; label = SP<int>{w + 2*nefc, 1}; tree_island = SP<int>{w + 2*nefc + ntree, 1};
     }
     MJH_FOR_LANES(t, ntree) label[t] = -1;
