@@ -48,6 +48,10 @@ def test_flex_against_an_actuated_body_on_gpu(rb, hip_lib, tmp_path):
 def test_flex_island_next_to_rigid_islands_on_gpu(rb, hip_lib, tmp_path):
     fh._multi_island(rb, hip_lib, tmp_path)
 
+def test_two_flexes_are_two_islands_of_sliders_on_gpu(rb, hip_lib, tmp_path):
+    fh._two_flexes(rb, hip_lib, tmp_path)
+
+
 def test_flex_edge_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
     """mjEQ_FLEX rows (one per non-rigid edge) in front of the contact rows: bit-exact incl. CG iteration counts"""
     maxcon, kinds = fh._edge_equality(rb, hip_lib, tmp_path, nstep=60)

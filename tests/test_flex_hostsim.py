@@ -255,6 +255,39 @@ def test_flex_island_next_to_rigid_islands(rb, hostsim_lib, tmp_path):
     _multi_island(rb, hostsim_lib, tmp_path)
 
 
+def _two_flexes(rb, lib, tmp_path):
+    """two flexes on the floor: the mass matrix is diagonal (every dof a slider), so the solver lays its vectors out for the
+    fused passes of mjh_csrpass.h -- but neither island spans every dof, so each is solved by the unfused code on that
+    layout (Ma / Mv / Mgrad in global memory, the difference vectors in the product vectors' bytes): states, counts and CG
+    iteration counts identical to the oracle's"""
+    xml = tmp_path / "two.xml"
+    xml.write_text("""
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"/>
+  <size memory="10M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05" contype="3" conaffinity="3"/>
+    <flexcomp type="grid" count="4 4 3" spacing=".05 .05 .05" pos="-.3 0 .06" dim="3" radius=".005" mass="1" name="a">
+      <edge damping="1"/><contact selfcollide="none" contype="1" conaffinity="1"/><elasticity young="5e4"/>
+    </flexcomp>
+    <flexcomp type="grid" count="4 3 3" spacing=".05 .05 .05" pos=".3 0 .07" dim="3" radius=".005" mass="1" name="b">
+      <edge damping="1"/><contact selfcollide="none" contype="2" conaffinity="2"/><elasticity young="4e4"/>
+    </flexcomp>
+  </worldbody>
+</mujoco>""")
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.nflex == 2 and m.nv == 3*(48 + 36) and m.nv > 128
+    d = rb.MjData(m)
+    for _ in range(80): rb.mj_step(m, d)
+    assert d.nisland == 2, d.nisland
+    maxcon, kinds = _resync_steps(rb, lib, m, pre=60, nstep=40)
+    assert maxcon >= 12 and kinds == {"vert"}
+
+
+def test_two_flexes_are_two_islands_of_sliders(rb, hostsim_lib, tmp_path):
+    _two_flexes(rb, hostsim_lib, tmp_path)
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
