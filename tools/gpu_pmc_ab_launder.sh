@@ -1,4 +1,6 @@
 #!/bin/bash
+# PMC FETCH_SIZE / WRITE_SIZE passes of the humanoid driver line on the product build and on the -DMJH_NO_LAUNDER lean kernel
+# (tools/build_variants.sh builds tools/variants/libmjhip_nolaunder.so); summary: profiles/r04/launder_traffic_ab.txt
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r04n
 mkdir -p $OUT
