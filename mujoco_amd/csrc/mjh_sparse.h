@@ -416,6 +416,9 @@ MJH_DEVN_HOT SpVec2 sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real y0, rea
     if (t0) y0 -= l0*xi;
     if (hi && t1) y1 -= l1*xi;
   }
+  // (the line search's LDS block, idle during a solve: staging space for the row dot products; 128 entries suffice)
+  const int ev = P.ev != nullptr;
+  const auto evp = mjh_local(P.ev);
   for (M128 rows = isl; m128_any(rows); rows = m128_drop_lowest(rows)) {
     const int i = m128_lowest(rows), src = i & (MJH_W - 1);
     M128 lm;
@@ -426,6 +429,22 @@ MJH_DEVN_HOT SpVec2 sp_solve(MREF M_, const Efc& P, PL L, M128 isl, real y0, rea
       const real p0 = (lane < i && m128_test(lm, lane)) ? (real)(L[adr + m128_rank_lane0(lm)]*y0) : (real)0;
       real p1 = 0;
       if (i > MJH_W) p1 = (lane + MJH_W < i && m128_test(lm, lane + MJH_W)) ? (real)(L[adr + m128_rank_lane1(lm)]*y1) : (real)0;
+      if (ev) {
+        // (mju_dotSparse over the row's stored entries: the products go to the LDS block in storage order -- a lane's
+        // entry sits at its rank in the row's pattern -- and the four accumulators walk them with one read and one
+        // addition per entry, instead of a v_readlane pair per entry; then (r0 + r2) + (r1 + r3) and the tail in order)
+        const int cnt = m128_count(lm);
+        if (lane < i && m128_test(lm, lane)) evp[m128_rank_lane0(lm)] = p0;
+        if (i > MJH_W && lane + MJH_W < i && m128_test(lm, lane + MJH_W)) evp[m128_rank_lane1(lm)] = p1;
+        wv_sync();
+        const int G = cnt >> 2, a = lane & 3;
+        real r = 0;
+        for (int g = 0; g < G; g++) r += evp[4*g + a];
+        real res = (wv_bcast(r, 0) + wv_bcast(r, 2)) + (wv_bcast(r, 1) + wv_bcast(r, 3));
+        for (int k = 4*G; k < cnt; k++) res += evp[k];
+        wv_sync();
+        xi -= res;
+      } else
       xi -= wv_dot4m(p0, p1, lm.lo, lm.hi, 0);
     }
     xi /= wv_bcast(i < MJH_W ? dg0 : dg1, src);
