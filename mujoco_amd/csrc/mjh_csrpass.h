@@ -1,13 +1,15 @@
 // Passes over the dofs of the explicit-index CG solver (mjh_newton.h, SPA = 2) as functions of an ARGUMENT BLOCK, so that a
-// multi-wavefront workgroup can run them on all of its wavefronts (mjh_modes.h: namespace wq, MJH_WIDE_ARGS).
+// multi-wavefront workgroup can run them on its helper wavefronts (mjh_modes.h: namespace wq, MJH_HELPERS_ARGS) -- and the
+// value pass of the compressed rows (csr_row_values) on all of them (MJH_WIDE_ARGS).
 //
 // A CG iteration of mj_solPrimal (engine_solver.c:2344-2563) touches every dof a dozen times -- M search, the move along
 // the search direction, qfrc_constraint = J' force, the gradient, the preconditioner, the Hager-Zhang differences, the new
 // direction -- and with nv = 1536 (jelly.xml) one wavefront spends most of the solve waiting for those element-wise passes'
 // memory round trips, 24 elements per lane at a time.  Nothing in them crosses dofs: here they are FUSED into two passes per
 // iteration (CSR_OP_STEP after the line search, CSR_OP_DIR after the termination tests) and two for the set-up
-// (CSR_OP_WARM, CSR_OP_START), each a loop over "lane = dof" with the group's width -- 64 lanes in the one-wavefront
-// mappings, 64 MJH_MW in a multi-wavefront workgroup.  Every element is computed by the expressions of the unfused code in
+// (CSR_OP_WARM, CSR_OP_START), each a loop over "lane = dof" with the width the argument block names (lane0, width) -- the 64
+// lanes of the wavefront in the one-wavefront mappings, the 64 (MJH_MW - 1) lanes of the helper wavefronts in a
+// multi-wavefront workgroup (wave 0 keeps the solver's registers and only posts the block).  Every element is computed by the expressions of the unfused code in
 // mjh_newton.h (same operands, same order), so results are bit-identical.  The ORDERED sums of the iteration (mju_dot's four
 // accumulator chains) stay on one wavefront, but their ADDENDS -- the element-wise products -- are formed here too and left
 // in six LDS vectors: a link of a chain is then one LDS read and one dependent addition (csr_sums, mjh_newton.h) instead of
