@@ -39,7 +39,9 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
   __shared__ int hist[256];
   __shared__ int maxc;
   const int n = B->nenv, tid = (int)threadIdx.x;
-  const int* cost = B->cost;
+  // (mode bit 2: deal by the MEASURED wall time of the previous launch instead of the work estimate -- $MJHIP_BALANCE_COST=wall)
+  const int* cost = (mode & 4) ? B->wall : B->cost;
+  mode &= 3;
   int* perm = B->perm;
   if (tid < 256) hist[tid] = 0;
   if (tid == 0) maxc = 1;
@@ -165,6 +167,7 @@ struct Backend {
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
       c.nsimd = 4*cus;
       if (const char* ev = getenv("MJHIP_BALANCE_SNAKE")) { c.mode = atoi(ev); if (c.mode == 0) c.nsimd = 1 << 30; }     // A/B: 0 plain descending order, 2 heaviest + three lightest
+      if (const char* ev = getenv("MJHIP_BALANCE_COST")) { if (ev[0] == 'w') c.mode |= 4; }
       return c;
     }();
     const int nsimd = cfg.nsimd, mode = cfg.mode;
