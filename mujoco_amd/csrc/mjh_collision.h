@@ -1018,7 +1018,7 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
   MJH_CON(B, con_exclude, e, 1, c)[0] = (h.dist >= M.pair_includemargin[p]) ? 1 : 0;
   MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
   MJH_CON(B, con_mu, e, 1, c)[0] = 0;
-  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) { iptr cf = MJH_G(B, con_flex, e) + 3*c; cf[0] = -1; cf[1] = -1; cf[2] = -1; }
+  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) { iptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*c; for (int q = 0; q < MJH_CONFLEX; q++) cf[q] = -1; }
 }
 
 // general convex pairs (GJK / EPA / multicontact): one pair per lane
@@ -1076,6 +1076,7 @@ MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int mypair, unsigned t
 
 #if !MJH_LANE_MODE
 MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base);     // mjh_flexcol.h
+MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base);
 #endif
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
@@ -1085,7 +1086,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   const MJH_CONST_AS DSizes& s = M.s;
   iptr counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;
-  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || (s.npair == 0 && s.ncolseg <= 1)) {
+  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || (s.npair == 0 && s.ncolseg <= 1 && s.nflexself == 0)) {
     if (wv_lane() == 0) counts[MJH_C_NCON] = 0;
     wv_sync();
     return;
@@ -1332,6 +1333,15 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   } else
 #endif
   run_pairs();
+#if !MJH_LANE_MODE
+  // flex self-collisions, after every body pair (mj_collision :834-881)
+  if (MJH_HAS(MJH_FT_FLEX))
+    for (int k = 0; k < s.nflexself; k++) {
+      const int r = flex_self_collide(M, B, e, k, base);
+      base += r & 0xffff;
+      overflow |= r >> 16;
+    }
+#endif
   overflow = wv_any(overflow);
   if (wv_lane() == 0) {
     if (overflow) {

@@ -673,11 +673,12 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     if (r0 < 0) continue;
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    // flex contacts: the second side is a vertex body, or the weighted corner bodies of an element (mj_contactJacobian
-    // :1559-1611: sum of the bodies' point Jacobians times their weights, -1 for the geom's body)
-    int fbody[4]; real fw[4];
-    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-    int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
+    // flex contacts: a side is a vertex body, or the weighted corner bodies of an element (mj_contactJacobian
+    // :1559-1611: sum of the bodies' point Jacobians times their weights, -1 for a geom's body; contact_sides, mjh_flex.h)
+    ConSides S;
+    if (MJH_HAS(MJH_FT_FLEX)) contact_sides(M, B, e, k, S);
+    const int general = MJH_HAS(MJH_FT_FLEX) && !S.simple;
+    int b1 = MJH_HAS(MJH_FT_FLEX) ? S.body[0] : (int)M.geom_bodyid[cg[0]], b2 = MJH_HAS(MJH_FT_FLEX) ? S.body[1] : (int)M.geom_bodyid[cg[1]];
     int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
@@ -702,19 +703,8 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
       }
       real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
-      if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
-        // element contact: weight -1 on the geom's body, the normalised weights on the corner bodies
-        jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
-        for (int q = 0; q < nfb; q++) {
-          const int wq = M.body_weldid[fbody[q]];
-          if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
-          real offq[3], t[3];
-          v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
-          v3_cross(t, cd, offq);
-          const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
-          jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
-        }
-      }
+      real rdg[3] = {0, 0, 0};
+      if (general) contact_jac_col(M, S, cdof, subtree_com, point, j, jd, (MJH_HAS(MJH_FT_CONDIM46) && dim > 3) ? rdg : (real*)nullptr);
       // rotate into the contact frame (mju_mulMatMat with zero-skip, engine_util_blas.c:619)
       int nr = dim > 1 ? 3 : 1;
       real jr[6] = {0, 0, 0, 0, 0, 0};
@@ -731,6 +721,7 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
         real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0),
                       (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
                       (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+        if (general) { rd[0] = rdg[0]; rd[1] = rdg[1]; rd[2] = rdg[2]; }
         for (int a = 0; a < dim - 3; a++) {
           real acc = 0;
           for (int q = 0; q < 3; q++) {
@@ -817,15 +808,20 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     int type = P.type[r0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int fbody[4]; real fw[4];
-    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-    int b1 = M.geom_bodyid[cg[0]];
-    // mj_diagApprox, contact case (:1895-1970)
+    // mj_diagApprox, contact case (:1895-1970): the bodies of side 0, then of side 1, with their (unsigned) weights
     real tran = 0, rot = 0;
-    tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
-    if (nfb) {
-      for (int q = 0; q < nfb; q++) { tran += M.body_invweight0[2*fbody[q]] * fw[q]; rot += M.body_invweight0[2*fbody[q]+1] * fw[q]; }
+    if (MJH_HAS(MJH_FT_FLEX)) {
+      ConSides S;
+      contact_sides(M, B, e, k, S);
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (q >= S.n) continue;
+        const real wq = fabs(S.w[q]);
+        tran += M.body_invweight0[2*S.body[q]] * wq;  rot += M.body_invweight0[2*S.body[q]+1] * wq;
+      }
     } else {
+      int b1 = M.geom_bodyid[cg[0]];
+      tran += M.body_invweight0[2*b1] * 1;  rot += M.body_invweight0[2*b1+1] * 1;
       int b2 = M.geom_bodyid[cg[1]];
       tran += M.body_invweight0[2*b2] * 1;  rot += M.body_invweight0[2*b2+1] * 1;
     }

@@ -1750,6 +1750,26 @@ MJH_DEV int rc_geom_elem(MREF M, BREF B, int e, RowPair& c, int g, int elem, rea
   return rc_contacts(M, c, rec, 0, 1, margin);
 }
 
+// mjc_ConvexElem for two flex elements (mj_collideElems, engine_collision_driver.c:2568): both shapes are elements
+MJH_DEV int rc_elem_elem(MREF M, BREF B, int e, RowPair& c, int elem1, int elem2, real margin, real* rec) {
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr aabb = MJH_F(B, flexelem_aabb, e);
+  const int L = rw_l();
+  for (int side = 0; side < 2; side++) {
+    const int elem = side ? elem2 : elem1;
+    const int fl = M.flexelem_flex[elem];
+    const int n = M.flex_dim[fl] + 1;
+    real* f = rp_frame(c, side);
+    if (L < 3*n) f[L] = vx[3*M.flexelem_vert[4*elem + L/3] + L%3];
+    if (L == 12) f[FR_SIZE] = M.flex_radius[fl] + 0.5*margin;
+    if (L >= 13) f[FR_CENTRE + L - 13] = aabb[6*elem + L - 13];
+    Shape& sh = side ? c.b : c.a;
+    sh.type = MJH_GEOM_FLEX; sh.kind = SK_FLEXELEM; sh.vcache = -1; sh.gcache = -1; sh.mesh = n; sh.margin = 0;
+  }
+  wv_row_sync();
+  return rc_contacts(M, c, rec, 0, 1, margin);
+}
+
 // number of contacts a polyhedral pair may return (maxContacts :855); 1: the pair takes the single-contact path
 MJH_DEV int rc_max_contacts(MREF M, int p) {
   const int t1 = M.geom_type[M.pair_geom1[p]], t2 = M.geom_type[M.pair_geom2[p]];
@@ -2332,7 +2352,10 @@ MJH_DEVN void rc_elem_rows(MREF M_, BREF B_, int e_) {
     real* rec = rc_records(M, B, e, owner);
     const real mg = rec[0];
     wv_row_sync();
-    const int n = rc_geom_elem(M, B, e, c, head[t] & 0xffffff, head[64 + t], mg, rec);
+    // (entry: geom | owner << 24, element; geom = 0xffffff: two elements, the first one's id in the owner's second record slot)
+    const int g = head[t] & 0xffffff;
+    const int n = g == 0xffffff ? rc_elem_elem(M, B, e, c, (int)rec[1], head[64 + t], mg, rec)
+                                : rc_geom_elem(M, B, e, c, g, head[64 + t], mg, rec);
     if (rw_l() == 0) head[128 + owner] = n;
   }
   MJH_GROUP_JOIN();
@@ -2353,6 +2376,23 @@ MJH_DEVN_HOT int ccd_geom_elem_pair(MREF M_, BREF B_, int e_, int g, int elem, r
   wv_sync();
   MJH_WIDE(MJH_MWS_ELEMS, rc_elem_rows(M, B, e));
   return g >= 0 ? head[128 + wv_lane()] : 0;
+}
+// pairs of flex elements (global ids), one per lane of the calling wavefront; elem1 < 0: the lane has none
+MJH_DEVN_HOT int ccd_elem_elem_pair(MREF M_, BREF B_, int e_, int elem1, int elem2, real margin) {
+  MJH_ENTER(M_, B_, e_);
+  int* head = rc_header(M, B, e);
+  const unsigned long long have = wv_ballot(elem1 >= 0);
+  const int total = __builtin_popcountll(have);
+  if (elem1 >= 0) {
+    const int t = wv_rank_lt(have);
+    head[t] = 0xffffff | (wv_lane() << 24); head[64 + t] = elem2;
+    real* rec = rc_records(M, B, e, wv_lane());
+    rec[0] = margin; rec[1] = (real)elem1;
+  }
+  if (wv_lane() == 0) head[192] = total;
+  wv_sync();
+  MJH_WIDE(MJH_MWS_ELEMS, rc_elem_rows(M, B, e));
+  return elem1 >= 0 ? head[128 + wv_lane()] : 0;
 }
 
 // mjc_PlaneConvex (:1004): plane against ellipsoid / mesh -- the point of the geom deepest below the plane, plus up to

@@ -22,66 +22,49 @@ MJH_DEV int csr_body_chain(MREF M, int b, IP out) {
   return n;
 }
 
-// the stored dofs of contact k's rows: the merged chains of its bodies, ascending, dofs common to two chains removed
-// (flg_skipcommon of mj_jacDifPair); returns their number.  fbody / fw / nfb: the flex side (flex_contact_weights)
+// the stored dofs of contact k's rows, ascending; returns their number.  One body on each side: the merged chains with the
+// dofs common to both removed (flg_skipcommon of mj_jacDifPair); a flex element on a side: the union of the chains of all
+// bodies involved (mj_jacSum / mju_addToSparseMat).  (contact_sides, mjh_flex.h)
 template <class IP>
-MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, IP cols, int* fbody, real* fw, int* nfb_out) {
-  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-  const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-  int n = csr_body_chain(M, M.geom_bodyid[cg[0]], cols);
-  if (nfb) { for (int q = 0; q < nfb; q++) n += csr_body_chain(M, fbody[q], cols + n); }
-  else n += csr_body_chain(M, M.geom_bodyid[cg[1]], cols + n);
+MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, IP cols) {
+  ConSides S;
+  contact_sides(M, B, e, k, S);
+  int n = 0;
+  for (int q = 0; q < S.n; q++) n += csr_body_chain(M, S.body[q], cols + n);
   for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
   int m = 0;
   for (int a = 0; a < n; a++) {
-    if (a + 1 < n && cols[a] == cols[a + 1]) { a++; continue; }
+    if (S.simple) { if (a + 1 < n && cols[a] == cols[a + 1]) { a++; continue; } }
+    else if (m > 0 && cols[m - 1] == cols[a]) continue;
     cols[m++] = cols[a];
   }
-  *nfb_out = nfb;
   return m;
 }
 
 // The same for merged chains of at most 16 dofs (csr_rowmax <= 16: a flex element against a geom is 12 + the geom's
 // chain), entirely in registers: the private array of the general form lives in scratch memory, and its insertion sort is
 // a chain of dependent memory round trips per contact.  Slots are filled from the chain table by position, sorted by a
-// 63-exchange network (Batcher's odd-even merge sort), and equal entries cancel in pairs (a dof common to two chains is
-// not stored).  v: the sorted entries, keep: bit i set if v[i] is stored, m: their number.
+// 63-exchange network (Batcher's odd-even merge sort); in the two-body form equal entries cancel in pairs (a dof common to
+// two chains is not stored), in the weighted-sum form one of each run stays.  v: the sorted entries, keep: bit i set if v[i]
+// is stored, m: their number.
 struct CsrCols16 { int v[16]; unsigned keep; int m; };
 MJH_DEV void csr_contact_cols16(MREF M, BREF B, int e, int k, CsrCols16& R) {
-  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-  int body[5] = {(int)M.geom_bodyid[cg[0]], -1, -1, -1, -1};
-  int nb = 2;
-  int flexed = 0;
-  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) {
-    ciptr cf = MJH_G(B, con_flex, e) + 3*k;
-    const int f = cf[0];
-    if (f >= 0) {
-      flexed = 1;
-      if (cf[2] >= 0) { body[1] = M.flexvert_bodyid[M.flex_vertadr[f] + cf[2]]; nb = 2; }
-      else {
-        const int el = M.flex_elemadr[f] + cf[1];
-        const int n = M.flex_dim[f] + 1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (i < n) body[1 + i] = M.flexvert_bodyid[M.flexelem_vert[4*el + i]];
-        nb = 1 + n;
-      }
-    }
-  }
-  if (!flexed) body[1] = M.geom_bodyid[cg[1]];
-  int adr[5], start[6];
+  ConSides S;
+  contact_sides(M, B, e, k, S);
+  int adr[8], start[9];
   start[0] = 0;
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
+  for (int j = 0; j < 8; j++) {
     int len = 0;
     adr[j] = 0;
-    if (j < nb) { adr[j] = M.body_chainadr[body[j]]; len = M.body_chainadr[body[j] + 1] - adr[j]; }
+    if (j < S.n) { adr[j] = M.body_chainadr[S.body[j]]; len = M.body_chainadr[S.body[j] + 1] - adr[j]; }
     start[j + 1] = start[j] + len;
   }
 #pragma unroll
   for (int q = 0; q < 16; q++) {
     int src = -1;
 #pragma unroll
-    for (int j = 0; j < 5; j++) if (q >= start[j] && q < start[j + 1]) src = adr[j] + (q - start[j]);
+    for (int j = 0; j < 8; j++) if (q >= start[j] && q < start[j + 1]) src = adr[j] + (q - start[j]);
     R.v[q] = src >= 0 ? (int)M.body_chain[src] : 0x7fffffff;
   }
   constexpr unsigned char NA[63] = {0,2,4,6,8,10,12,14,0,1,4,5,8,9,12,13,1,5,9,13,0,1,2,3,8,9,10,11,2,3,10,11,1,3,5,9,11,13,0,1,2,3,4,5,6,7,4,5,6,7,2,3,6,7,10,11,1,3,5,7,9,11,13};
@@ -92,14 +75,15 @@ MJH_DEV void csr_contact_cols16(MREF M, BREF B, int e, int k, CsrCols16& R) {
     R.v[NA[t]] = a < b ? a : b;
     R.v[NB[t]] = a < b ? b : a;
   }
-  // (equal entries cancel in pairs from the left, as in the general form: the last of a run of odd length stays)
+  // (two-body form: equal entries cancel in pairs from the left, as in the general form -- the last of a run of odd length
+  // stays; weighted-sum form: the last of every run stays)
   unsigned keep = 0;
   int m = 0, run = 0;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     run = (i > 0 && R.v[i] == R.v[i - 1]) ? run + 1 : 1;
     const int last = i == 15 || R.v[i] != R.v[i + 1];
-    if (last && (run & 1) && R.v[i] != 0x7fffffff) { keep |= 1u << i; m++; }
+    if (last && ((run & 1) || !S.simple) && R.v[i] != 0x7fffffff) { keep |= 1u << i; m++; }
   }
   R.keep = keep; R.m = m;
 }
@@ -152,9 +136,8 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     int nnz;
     if (small) { CsrCols16 R; csr_contact_cols16(M, B, e, k, R); nnz = R.m; }
     else {
-      int fbody[4]; real fw[4]; int nfb;
       int cols[MJH_CSR_CHAIN_MAX];
-      nnz = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb);
+      nnz = csr_contact_cols(M, B, e, k, cols);
     }
     for (int a = 0; a < nrow; a++) rowadr[r0 + a + 1] = nnz;
   }
@@ -211,7 +194,7 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
       const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
       if (r0 >= 0) {
         if (small) { csr_contact_cols16(M, B, e, k, R); m = R.m; }
-        else { int fbody[4]; real fw[4]; int nfb; m = csr_contact_cols(M, B, e, k, cols, fbody, fw, &nfb); }
+        else m = csr_contact_cols(M, B, e, k, cols);
         a0 = rowadr[r0];
       }
     }

@@ -171,42 +171,17 @@ MJH_DEV void csr_row_values(MREF M, BREF B, int e, const CsrRowArgs& A) {
     const int k = items[w]/MJH_CSR_CHAIN_MAX, c = items[w]%MJH_CSR_CHAIN_MAX;
     const int r0 = MJH_CON(B, con_efcadr, e, 1, k)[0];
     const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
-    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    int fbody[4]; real fw[4];
-    const int nfb = MJH_HAS(MJH_FT_FLEX) ? flex_contact_weights(M, B, e, k, fbody, fw) : 0;
-    const int b1 = M.geom_bodyid[cg[0]], b2 = nfb ? fbody[0] : M.geom_bodyid[cg[1]];
-    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    ConSides S;
+    contact_sides(M, B, e, k, S);
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
     auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, k)[0];
-    real off1[3], off2[3];
-    v3_sub(off1, point, subtree_com + 3*M.body_rootid[b1]);
-    v3_sub(off2, point, subtree_com + 3*M.body_rootid[b2]);
     const int a0 = rowadr[r0];
     const int stride = rowadr[r0 + 1] - a0;             // every row of the contact has the same pattern
     const int j = colind[a0 + c];
     // (the expressions of stage_make_constraint's dense contact rows)
-    const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-    const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
-    real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
-    crptr cd = cdof + 6*j;
-    if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
-    if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
-    real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
-    if (MJH_HAS(MJH_FT_FLEX) && nfb > 1) {
-      jd[0] = in1 ? -j1[0] : (real)0; jd[1] = in1 ? -j1[1] : (real)0; jd[2] = in1 ? -j1[2] : (real)0;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        if (q >= nfb) continue;
-        const int wq = M.body_weldid[fbody[q]];
-        if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
-        real offq[3], t[3];
-        v3_sub(offq, point, subtree_com + 3*M.body_rootid[fbody[q]]);
-        v3_cross(t, cd, offq);
-        const real x0 = (cd[3] + t[0])*fw[q], x1 = (cd[4] + t[1])*fw[q], x2 = (cd[5] + t[2])*fw[q];
-        jd[0] = in1 ? jd[0] + x0 : x0; jd[1] = in1 ? jd[1] + x1 : x1; jd[2] = in1 ? jd[2] + x2 : x2;
-      }
-    }
+    real jd[3];
+    contact_jac_col(M, S, cdof, subtree_com, point, j, jd, (real*)nullptr);
     const int nr = dim > 1 ? 3 : 1;
     real jr[3] = {0, 0, 0};
     for (int a = 0; a < nr; a++) {

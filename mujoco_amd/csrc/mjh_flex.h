@@ -57,6 +57,31 @@ MJH_DEVN void stage_flex_pos(MREF M_, BREF B_, int e_) {
     }
     wv_sync();
   }
+  // the flexes' bounding volume hierarchies, recomputed bottom-up from the element boxes exactly as mj_updateDynamicBVH
+  // does (engine_core_smooth.c:490-533: an inner box is the union of its children's boxes, converted back to centre /
+  // half size at every level): the sweep axis of a self-collision is the longest side of the ROOT box
+  if (s.nflexbvh) {
+    crptr aabb = MJH_F(B, flexelem_aabb, e);
+    rptr bb = MJH_G(B, flexbvh_aabb, e);
+    MJH_FOR_LANES(i, s.nflexbvh) {
+      const int el = M.flexbvh_elem[i];
+      if (el >= 0) for (int q = 0; q < 6; q++) bb[6*i + q] = aabb[6*el + q];
+    }
+    wv_sync();
+    for (int h = 1; h < s.nflexbvhh; h++) {
+      for (int t = M.flexbvh_hadr[h] + wv_lane(); t < M.flexbvh_hadr[h + 1]; t += MJH_W) {
+        const int i = M.flexbvh_order[t];
+        const int c1 = M.flexbvh_child[2*i], c2 = M.flexbvh_child[2*i + 1];
+        for (int k = 0; k < 3; k++) {
+          const real lo = r_min(bb[6*c1 + k] - bb[6*c1 + k + 3], bb[6*c2 + k] - bb[6*c2 + k + 3]);
+          const real hi = r_max(bb[6*c1 + k] + bb[6*c1 + k + 3], bb[6*c2 + k] + bb[6*c2 + k + 3]);
+          bb[6*i + k] = 0.5*(hi + lo);
+          bb[6*i + k + 3] = 0.5*(hi - lo);
+        }
+      }
+      wv_sync();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,26 +442,23 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
 }
 
 // ------------------------------------------------------------------------------------------------
-// bodies and weights on the flex side of a contact (mj_contactJacobian / mj_diagApprox,
-// engine_core_constraint.c:1573-1607, :1908-1936).  Contact k of a model with flexes: returns 0 for a geom : geom
-// contact, else the number of vertex bodies (1 for a vertex contact; the corners of the element, weighted by inverse
-// distance to the contact point and normalised, for an element contact: mj_elemBodyWeight :223-259).
+// bodies and weights of a contact (mj_contactJacobian / mj_diagApprox, engine_core_constraint.c:1535-1613, :1895-1944).
+// `simple`: one body on each side (geom : geom, geom : flex vertex) -- the Jacobian is the difference of the two bodies'
+// point Jacobians, dofs common to both chains left out of a compressed row (mj_jacDifPair, flg_skipcommon).  Otherwise a
+// flex element is involved and the Jacobian is the weighted sum, in list order, of the listed bodies' point Jacobians
+// (mj_jacSum; a compressed row stores the union of the chains): side 0 first with negative weights (-1 for a geom's
+// body), then side 1; the corners of an element are weighted by inverse distance to the contact point, normalised
+// (mj_elemBodyWeight :223-261).
 // ------------------------------------------------------------------------------------------------
-MJH_DEV int flex_contact_weights(MREF M, BREF B, int e, int k, int* body, real* w) {
-  if (!M.s.nconflex) return 0;
-  ciptr cf = MJH_G(B, con_flex, e) + 3*k;
-  const int f = cf[0];
-  if (f < 0) return 0;
-  if (cf[2] >= 0) {
-    body[0] = M.flexvert_bodyid[M.flex_vertadr[f] + cf[2]];
-    w[0] = 1;
-    return 1;
-  }
+struct ConSides { int n, simple; int body[8]; real w[8]; };
+
+// corners of element el (global id) of flex f: bodies and normalised inverse-distance weights times sign, into S from slot at
+MJH_DEV void flex_elem_weights(MREF M, BREF B, int e, int k, int f, int el, real sign, ConSides& S, int at) {
   crptr vx = MJH_F(B, flexvert_xpos, e);
   crptr point = MJH_CON(B, con_pos, e, 3, k);
-  const int el = M.flex_elemadr[f] + cf[1];
   const int n = M.flex_dim[f] + 1;
-  // (loops of constant length with a predicate: body[] / w[] stay in the caller's registers instead of scratch memory)
+  real w[4] = {0, 0, 0, 0};
+  int body[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (i >= n) continue;
@@ -451,6 +473,96 @@ MJH_DEV int flex_contact_weights(MREF M, BREF B, int e, int k, int* body, real* 
   for (int i = 0; i < 4; i++) if (i < n) sum += w[i];
   const real inv = 1.0/sum;
 #pragma unroll
-  for (int i = 0; i < 4; i++) if (i < n) w[i] = w[i]*inv;
-  return n;
+  for (int q = 0; q < 8; q++) {
+    const int i = q - at;
+    if (i < 0 || i >= n) continue;
+    const real wi = i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : w[3]));
+    S.body[q] = i == 0 ? body[0] : (i == 1 ? body[1] : (i == 2 ? body[2] : body[3]));
+    S.w[q] = (wi*inv)*sign;
+  }
+}
+
+MJH_DEV void contact_sides(MREF M, BREF B, int e, int k, ConSides& S) {
+  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+#pragma unroll
+  for (int q = 0; q < 8; q++) { S.body[q] = 0; S.w[q] = 0; }
+  S.n = 2; S.simple = 1;
+  int f1 = -1, e1 = -1, v1 = -1, f0 = -1, e0 = -1;
+  if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) {
+    ciptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*k;
+    f1 = cf[0]; e1 = cf[1]; v1 = cf[2]; f0 = cf[3]; e0 = cf[4];
+  }
+  if (f1 < 0) {
+    S.body[0] = M.geom_bodyid[cg[0]]; S.w[0] = -1;
+    S.body[1] = M.geom_bodyid[cg[1]]; S.w[1] = 1;
+    return;
+  }
+  if (f0 < 0 && v1 >= 0) {
+    S.body[0] = M.geom_bodyid[cg[0]]; S.w[0] = -1;
+    S.body[1] = M.flexvert_bodyid[M.flex_vertadr[f1] + v1]; S.w[1] = 1;
+    return;
+  }
+  S.simple = 0;
+  int at = 0;
+  if (f0 < 0) { S.body[0] = M.geom_bodyid[cg[0]]; S.w[0] = -1; at = 1; }
+  else { flex_elem_weights(M, B, e, k, f0, M.flex_elemadr[f0] + e0, -1, S, 0); at = M.flex_dim[f0] + 1; }
+  flex_elem_weights(M, B, e, k, f1, M.flex_elemadr[f1] + e1, 1, S, at);
+  S.n = at + M.flex_dim[f1] + 1;
+}
+
+// column j of the contact's translational point Jacobian (world frame, before the rotation into the contact frame):
+// jd = sum over the bodies whose chain holds dof j of weight x (cdof_lin + cdof_ang x (point - subtree_com[root]))
+// (mj_jac, engine_core_util.c:176).  simple: jac2 - jac1.  rd (may be null): the rotational rows' column.
+template <class CD, class SC, class PT>
+MJH_DEV void contact_jac_col(MREF M, const ConSides& S, CD cdof, SC subtree_com, PT point, int j, real* jd, real* rd) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  auto cd = cdof + 6*j;
+  if (S.simple) {
+    const int b1 = S.body[0], b2 = S.body[1];
+    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+    const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+    real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+    if (in1) {
+      real off[3], t[3];
+      v3_sub(off, point, subtree_com + 3*M.body_rootid[b1]);
+      v3_cross(t, cd, off);
+      j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2];
+    }
+    if (in2) {
+      real off[3], t[3];
+      v3_sub(off, point, subtree_com + 3*M.body_rootid[b2]);
+      v3_cross(t, cd, off);
+      j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
+    }
+    jd[0] = j2[0] - j1[0]; jd[1] = j2[1] - j1[1]; jd[2] = j2[2] - j1[2];
+    if (rd) {
+      rd[0] = (in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0);
+      rd[1] = (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0);
+      rd[2] = (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0);
+    }
+    return;
+  }
+  jd[0] = 0; jd[1] = 0; jd[2] = 0;
+  if (rd) { rd[0] = 0; rd[1] = 0; rd[2] = 0; }
+  int have = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    if (q >= S.n) continue;
+    const int b = S.body[q];
+    const int wq = M.body_weldid[b];
+    if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+    real off[3], t[3];
+    v3_sub(off, point, subtree_com + 3*M.body_rootid[b]);
+    v3_cross(t, cd, off);
+    const real wt = S.w[q];
+    // (a geom's body enters negated, a weighted corner multiplied: mju_scl by -1 / mju_addToScl)
+    const real x0 = (cd[3] + t[0])*wt, x1 = (cd[4] + t[1])*wt, x2 = (cd[5] + t[2])*wt;
+    jd[0] = have ? jd[0] + x0 : x0; jd[1] = have ? jd[1] + x1 : x1; jd[2] = have ? jd[2] + x2 : x2;
+    if (rd) {
+      const real r0 = cd[0]*wt, r1 = cd[1]*wt, r2 = cd[2]*wt;
+      rd[0] = have ? rd[0] + r0 : r0; rd[1] = have ? rd[1] + r1 : r1; rd[2] = have ? rd[2] + r2 : r2;
+    }
+    have = 1;
+  }
 }

@@ -31,6 +31,214 @@ MJH_DEV int flex_argmax(real v, int idx) {
   return bi == 0x7fffffff ? -1 : bi;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// triangle elements of a shell flex against spheres, capsules and boxes: closed forms
+// (mjraw_SphereTriangle / mjraw_CapsuleTriangle / mjraw_BoxTriangle, engine_collision_primitive.c:566-809).
+// A (geom, triangle) pair yields up to 1 / 5 / 11 contacts, each from an independent test; the tests are enumerated
+// as "sub-items" in the reference's emission order, one per lane.
+// ------------------------------------------------------------------------------------------------
+// sphere (centre s, radius rs) against triangle (t1, t2, t3) of radius rt
+MJH_DEV int tri_sphere(Hit& h, real margin, V3 s, real rs, V3 t1, V3 t2, V3 t3, real rt) {
+  const real rbound = margin + rs + rt;
+  const V3 S = s - t1, A = t2 - t1, Bv = t3 - t1;
+  V3 N = cross(A, Bv);
+  unitize(N);
+  const real dstS = dot(N, S);
+  if (fabs(dstS) > rbound) return 0;
+  const V3 P{S.x + N.x*(-dstS), S.y + N.y*(-dstS), S.z + N.z*(-dstS)};
+  V3 V1 = A;
+  const real lenA = unitize(V1);
+  V3 V2 = cross(N, A);
+  unitize(V2);
+  const real o[2] = {0, 0}, a[2] = {lenA, 0}, b[2] = {dot(V1, Bv), dot(V2, Bv)}, p[2] = {dot(V1, P), dot(V2, P)};
+  auto area_sign = [](const real* p1, const real* p2, const real* p3) {
+    const real x = (p1[0] - p3[0])*(p2[1] - p3[1]) - (p2[0] - p3[0])*(p1[1] - p3[1]);
+    return (real)((x > 0) - (x < 0));
+  };
+  const real sign1 = area_sign(p, o, a), sign2 = area_sign(p, a, b), sign3 = area_sign(p, b, o);
+  V3 X;
+  if (sign1 == sign2 && sign2 == sign3) X = P;
+  else {
+    // nearest point of the three edges (pointSegment :540), first smallest distance in the order (o,a) (a,b) (b,o)
+    auto point_segment = [](real* res, const real* pp, const real* u, const real* v) {
+      const real uv[2] = {v[0] - u[0], v[1] - u[1]}, up[2] = {pp[0] - u[0], pp[1] - u[1]};
+      const real num = (real)0 + (uv[0]*up[0] + uv[1]*up[1]), den = (real)0 + (uv[0]*uv[0] + uv[1]*uv[1]);
+      const real t = num / r_max(MJH_MINVAL, den);
+      if (t <= 0) { res[0] = u[0]; res[1] = u[1]; }
+      else if (t >= 1) { res[0] = v[0]; res[1] = v[1]; }
+      else { res[0] = u[0] + uv[0]*t; res[1] = u[1] + uv[1]*t; }
+      return sqrt((res[0] - pp[0])*(res[0] - pp[0]) + (res[1] - pp[1])*(res[1] - pp[1]));
+    };
+    real x0[2], x1[2], x2[2];
+    const real d0 = point_segment(x0, p, o, a), d1 = point_segment(x1, p, a, b), d2 = point_segment(x2, p, b, o);
+    const int best = (d0 < d1 && d0 < d2) ? 0 : (d1 < d2 ? 1 : 2);
+    const real bx = best == 0 ? x0[0] : (best == 1 ? x1[0] : x2[0]), by = best == 0 ? x0[1] : (best == 1 ? x1[1] : x2[1]);
+    X = V3{V1.x*bx, V1.y*bx, V1.z*bx};
+    X = V3{X.x + V2.x*by, X.y + V2.y*by, X.z + V2.z*by};
+  }
+  V3 nrm = X - S;
+  const real dst = unitize(nrm);
+  if (dst > rbound) return 0;
+  h.dist = dst - rs - rt;
+  const real scl = rs + h.dist/2;
+  h.pos = V3{s.x + nrm.x*scl, s.y + nrm.y*scl, s.z + nrm.z*scl};
+  h.nrm = nrm;
+  h.tan = V3{0, 0, 0};
+  return 1;
+}
+
+// sub-item `sub` of capsule (pos, mat, size) against the triangle: 0, 1 the end spheres, 2..4 the triangle's vertices
+// against the interior of the axis segment
+template <class PM, class PS>
+MJH_DEV int tri_capsule_item(Hit& h, int sub, real margin, V3 pos, PM mat, PS size, V3 t1, V3 t2, V3 t3, real rt) {
+  const real radius = size[0], len = size[1];
+  const V3 axis = mcol(mat, 2);
+  const V3 p1{pos.x + axis.x*(-len), pos.y + axis.y*(-len), pos.z + axis.z*(-len)};
+  const V3 p2{pos.x + axis.x*len, pos.y + axis.y*len, pos.z + axis.z*len};
+  if (sub < 2) return tri_sphere(h, margin, sub == 0 ? p1 : p2, radius, t1, t2, t3, rt);
+  const V3 vert = sub == 2 ? t1 : (sub == 3 ? t2 : t3);
+  V3 vec = vert - p1;
+  const V3 ab = p2 - p1;
+  const real t = dot(vec, ab) / (4*len*len);
+  if (t <= MJH_MINVAL || t >= 1 - MJH_MINVAL) return 0;
+  const V3 closest{p1.x + ab.x*t, p1.y + ab.y*t, p1.z + ab.z*t};
+  vec = vert - closest;
+  const real dist = unitize(vec);
+  if (dist > radius + rt + margin) return 0;
+  h.dist = dist - radius - rt;
+  h.nrm = vec;
+  h.tan = V3{0, 0, 0};
+  V3 q = closest + vert;
+  const real k = radius - rt;
+  q = V3{q.x + vec.x*k, q.y + vec.y*k, q.z + vec.z*k};
+  h.pos = V3{q.x*0.5, q.y*0.5, q.z*0.5};
+  return 1;
+}
+
+// sub-item `sub` of box (pos, mat, size) against the triangle: 0..2 the triangle's vertices against the box faces,
+// 3..10 the box corners (radius 0) against the triangle
+template <class PM, class PS>
+MJH_DEV int tri_box_item(Hit& h, int sub, real margin, V3 pos, PM mat, PS size, V3 t1, V3 t2, V3 t3, real rt) {
+  if (sub >= 3) {
+    const int i = sub - 3;
+    const V3 vec{(i & 1) ? (real)size[0] : -(real)size[0], (i & 2) ? (real)size[1] : -(real)size[1], (i & 4) ? (real)size[2] : -(real)size[2]};
+    V3 corner = mmul(mat, vec);
+    corner = corner + pos;
+    return tri_sphere(h, margin, corner, 0, t1, t2, t3, rt);
+  }
+  const V3 vert = sub == 0 ? t1 : (sub == 1 ? t2 : t3);
+  const V3 diff = vert - pos;
+  const real local[3] = {mtrow(mat, 0, diff), mtrow(mat, 1, diff), mtrow(mat, 2, diff)};
+  int maxaxis = 0;
+  real maxval = fabs(local[0]) - size[0];
+  for (int j = 1; j < 3; j++) {
+    const real val = fabs(local[j]) - size[j];
+    if (val > maxval) { maxval = val; maxaxis = j; }
+  }
+  if (maxval - rt > margin) return 0;
+  for (int j = 0; j < 3; j++) if (fabs(local[j]) > size[j] + margin + rt) return 0;
+  const real sgn = (maxaxis == 0 ? local[0] : (maxaxis == 1 ? local[1] : local[2])) > 0 ? 1 : -1;
+  const V3 nl{maxaxis == 0 ? sgn : (real)0, maxaxis == 1 ? sgn : (real)0, maxaxis == 2 ? sgn : (real)0};
+  h.nrm = mmul(mat, nl);
+  h.dist = maxval - rt;
+  const real offset = rt + h.dist*0.5;
+  h.pos = V3{vert.x + h.nrm.x*(-offset), vert.y + h.nrm.y*(-offset), vert.z + h.nrm.z*(-offset)};
+  h.tan = V3{0, 0, 0};
+  return 1;
+}
+
+// mjc_fixNormal (engine_collision_convex.c:1410) for a contact between a CYLINDER geom (first side) and a triangle of a
+// shell flex: on the round wall the normal found by GJK / EPA is replaced by the radial direction
+template <class PM, class PS>
+MJH_DEV V3 tri_fix_normal_cylinder(V3 normal, V3 cpos, V3 gpos, PM mat, PS size) {
+  const V3 dif = cpos - gpos;
+  const real pos1[3] = {mtrow(mat, 0, dif), mtrow(mat, 1, dif), mtrow(mat, 2, dif)};
+  if (fabs(pos1[2]) > 0.95*size[1]) return normal;
+  const real dst1 = fabs(size[1] - fabs(pos1[2]));
+  const real dst2 = fabs(size[0] - sqrt((real)0 + (pos1[0]*pos1[0] + pos1[1]*pos1[1])));
+  if (dst1 < 0.25*dst2) return normal;
+  V3 nrm{pos1[0], pos1[1], 0};
+  unitize(nrm);
+  return mmul(mat, nrm);
+}
+
+// filterFlexContacts + (optionally) contactSort + emission of the n candidates in (cand, ci); returns the number of
+// contacts written from slot `base` on | overflow << 16.  sorted: stable sort by (geom, vertex / element) (body : flex
+// jobs, mj_collision :717-724); self-collisions are emitted in candidate order.
+template <class CP, class IP>
+MJH_DEV int flex_filter_emit(MREF M, BREF B, int e, int f, CP cand, IP ci, int n, int base, int sorted) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  // ---- filterFlexContacts: more candidates than a pair may keep.  The reference works on array positions: it swaps the
+  //      chosen contact forward but leaves the `selected` / `min_dist` entries where they are -- reproduced as is.
+  int nsel = n;
+  if (n > MJH_FLEX_MAXCON) {
+    MJH_FOR_LANES(i, n) { cand[FC_NREAL*i + FC_MIND] = MJH_MAXVAL; ci[FI_NINT*i + FI_SEL] = 0; }
+    wv_sync();
+    int best;
+    {
+      real bv = 0; int bi = -1;
+      MJH_FOR_LANES(i, n) { const real v = -cand[FC_NREAL*i + FC_DIST]; if (bi < 0 || v > bv) { bv = v; bi = i; } }
+      best = flex_argmax(bv, bi);
+    }
+    nsel = 0;
+    while (nsel < MJH_FLEX_MAXCON && best >= 0) {
+      if (wv_lane() == 0) ci[FI_NINT*best + FI_SEL] = 1;
+      wv_sync();
+      const V3 bp = ld3(cand + FC_NREAL*best + FC_POS);
+      real bv = 0; int bi = -1;
+      MJH_FOR_LANES(i, n) {
+        if (ci[FI_NINT*i + FI_SEL]) continue;
+        const real dx = cand[FC_NREAL*i + FC_POS] - bp.x, dy = cand[FC_NREAL*i + FC_POS + 1] - bp.y, dz = cand[FC_NREAL*i + FC_POS + 2] - bp.z;
+        const real d2 = dx*dx + dy*dy + dz*dz;
+        real md = cand[FC_NREAL*i + FC_MIND];
+        if (d2 < md) { md = d2; cand[FC_NREAL*i + FC_MIND] = md; }
+        if (bi < 0 || md > bv) { bv = md; bi = i; }
+      }
+      int next = flex_argmax(bv, bi);
+      wv_sync();
+      if (nsel < MJH_FLEX_MAXCON - 1) {
+        if (wv_lane() == 0 && best != nsel) {
+          for (int q = 0; q < 7; q++) { const real t = cand[FC_NREAL*nsel + q]; cand[FC_NREAL*nsel + q] = cand[FC_NREAL*best + q]; cand[FC_NREAL*best + q] = t; }
+          for (int q = 0; q < 4; q++) { const int t = ci[FI_NINT*nsel + q]; ci[FI_NINT*nsel + q] = ci[FI_NINT*best + q]; ci[FI_NINT*best + q] = t; }
+        }
+        if (next == nsel) next = best;
+        wv_sync();
+      }
+      nsel++;
+      best = next;
+    }
+  }
+
+  // ---- contactSort (stable, by geom then vertex / element) and emission
+  int overflow = 0;
+  for (int i0 = 0; i0 < nsel; i0 += MJH_W) {
+    const int i = i0 + wv_lane();
+    if (i >= nsel) continue;
+    int rank = i;
+    if (sorted) {
+      const long long key = ((long long)ci[FI_NINT*i + FI_GEOM] << 32) | (unsigned)ci[FI_NINT*i + FI_OBJ];
+      rank = 0;
+      for (int j = 0; j < nsel; j++) {
+        const long long kj = ((long long)ci[FI_NINT*j + FI_GEOM] << 32) | (unsigned)ci[FI_NINT*j + FI_OBJ];
+        if (kj < key || (kj == key && j < i)) rank++;
+      }
+    }
+    const int c = base + rank;
+    if (c >= s.nconmax) { overflow = 1; continue; }
+    Hit h{cand[FC_NREAL*i + FC_DIST], ld3(cand + FC_NREAL*i + FC_POS), ld3(cand + FC_NREAL*i + FC_NRM), V3{0, 0, 0}};
+    store_contact(M, B, e, c, ci[FI_NINT*i + FI_PAIR], h);
+    iptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*c;
+    const int kind = ci[FI_NINT*i + FI_KIND], obj = ci[FI_NINT*i + FI_OBJ];
+    // kind 0: geom : vertex, 1: geom : element, 2: element (FI_GEOM) : element (FI_OBJ) of the same flex
+    cf[0] = f; cf[1] = kind ? obj : -1; cf[2] = kind ? -1 : obj;
+    cf[3] = kind == 2 ? f : -1; cf[4] = kind == 2 ? ci[FI_NINT*i + FI_GEOM] : -1; cf[5] = -1;
+  }
+  overflow = wv_any(overflow);
+  wv_sync();
+  return nsel | (overflow << 16);
+}
+
 // returns the number of contacts written from slot `base` on | overflow << 16
 MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
   MJH_ENTER(M_, B_, e_);
@@ -141,18 +349,54 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
     }
     wv_sync();
     tick(54);
-    for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
-      const int r = r0 + wv_lane();
-      const int el = r < nsurv ? surv[r] : -1;
-      const int got = ccd_geom_elem_pair(M, B, e, el >= 0 ? g : -1, el, mg);
-      const unsigned long long m = wv_ballot(got > 0);
-      if (got > 0) {
-        const crptr rec = ccd_out_records(M, B, e);
-        const int c = n + wv_rank_lt(m);
-        for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
-        ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = el - eadr; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 1;
+    const int nsub = M.flexjob_nsub[a];
+    const int gtype = M.geom_type[g];
+    if (nsub) {
+      // triangles against a sphere / capsule / box: the closed-form tests, one (triangle, sub-test) per lane, hits compacted
+      // in (leaf, sub-test) order -- the order in which the reference emits them
+      const V3 gp = ld3(gx + 3*g);
+      const int nitems = nsurv*nsub;
+      for (int i0 = 0; i0 < nitems; i0 += MJH_W) {
+        const int it = i0 + wv_lane();
+        int got = 0, el = -1;
+        Hit h{0, V3{0, 0, 0}, V3{0, 0, 0}, V3{0, 0, 0}};
+        if (it < nitems) {
+          el = surv[it / nsub];
+          const int sub = it % nsub;
+          const V3 t1 = ld3(vx + 3*M.flexelem_vert[4*el]), t2 = ld3(vx + 3*M.flexelem_vert[4*el + 1]), t3 = ld3(vx + 3*M.flexelem_vert[4*el + 2]);
+          if (gtype == MJH_GEOM_SPHERE) got = tri_sphere(h, mg, gp, M.geom_size[3*g], t1, t2, t3, radius);
+          else if (gtype == MJH_GEOM_CAPSULE) got = tri_capsule_item(h, sub, mg, gp, gm + 9*g, M.geom_size + 3*g, t1, t2, t3, radius);
+          else got = tri_box_item(h, sub, mg, gp, gm + 9*g, M.geom_size + 3*g, t1, t2, t3, radius);
+        }
+        const unsigned long long m = wv_ballot(got > 0);
+        if (got > 0) {
+          const int c = n + wv_rank_lt(m);
+          cand[FC_NREAL*c + FC_DIST] = h.dist;
+          cand[FC_NREAL*c + FC_POS] = h.pos.x; cand[FC_NREAL*c + FC_POS + 1] = h.pos.y; cand[FC_NREAL*c + FC_POS + 2] = h.pos.z;
+          cand[FC_NREAL*c + FC_NRM] = h.nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = h.nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = h.nrm.z;
+          ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = el - eadr; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 1;
+        }
+        n += __builtin_popcountll(m);
       }
-      n += __builtin_popcountll(m);
+    } else {
+      const int fixnormal = M.flex_dim[f] == 2 && gtype == MJH_GEOM_CYLINDER;
+      for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+        const int r = r0 + wv_lane();
+        const int el = r < nsurv ? surv[r] : -1;
+        const int got = ccd_geom_elem_pair(M, B, e, el >= 0 ? g : -1, el, mg);
+        const unsigned long long m = wv_ballot(got > 0);
+        if (got > 0) {
+          const crptr rec = ccd_out_records(M, B, e);
+          const int c = n + wv_rank_lt(m);
+          for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
+          if (fixnormal) {
+            const V3 nn = tri_fix_normal_cylinder(ld3(rec + 4), ld3(rec + 1), ld3(gx + 3*g), gm + 9*g, M.geom_size + 3*g);
+            cand[FC_NREAL*c + FC_NRM] = nn.x; cand[FC_NREAL*c + FC_NRM + 1] = nn.y; cand[FC_NREAL*c + FC_NRM + 2] = nn.z;
+          }
+          ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = el - eadr; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 1;
+        }
+        n += __builtin_popcountll(m);
+      }
     }
     wv_sync();
     tick(55);
@@ -160,70 +404,148 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
   wv_sync();
   if (n == 0) return 0;
 
-  // ---- filterFlexContacts: more candidates than a pair may keep.  The reference works on array positions: it swaps the
-  //      chosen contact forward but leaves the `selected` / `min_dist` entries where they are -- reproduced as is.
-  int nsel = n;
-  if (n > MJH_FLEX_MAXCON) {
-    MJH_FOR_LANES(i, n) { cand[FC_NREAL*i + FC_MIND] = MJH_MAXVAL; ci[FI_NINT*i + FI_SEL] = 0; }
-    wv_sync();
-    int best;
-    {
-      real bv = 0; int bi = -1;
-      MJH_FOR_LANES(i, n) { const real v = -cand[FC_NREAL*i + FC_DIST]; if (bi < 0 || v > bv) { bv = v; bi = i; } }
-      best = flex_argmax(bv, bi);
-    }
-    nsel = 0;
-    while (nsel < MJH_FLEX_MAXCON && best >= 0) {
-      if (wv_lane() == 0) ci[FI_NINT*best + FI_SEL] = 1;
-      wv_sync();
-      const V3 bp = ld3(cand + FC_NREAL*best + FC_POS);
-      real bv = 0; int bi = -1;
-      MJH_FOR_LANES(i, n) {
-        if (ci[FI_NINT*i + FI_SEL]) continue;
-        const real dx = cand[FC_NREAL*i + FC_POS] - bp.x, dy = cand[FC_NREAL*i + FC_POS + 1] - bp.y, dz = cand[FC_NREAL*i + FC_POS + 2] - bp.z;
-        const real d2 = dx*dx + dy*dy + dz*dz;
-        real md = cand[FC_NREAL*i + FC_MIND];
-        if (d2 < md) { md = d2; cand[FC_NREAL*i + FC_MIND] = md; }
-        if (bi < 0 || md > bv) { bv = md; bi = i; }
-      }
-      int next = flex_argmax(bv, bi);
-      wv_sync();
-      if (nsel < MJH_FLEX_MAXCON - 1) {
-        if (wv_lane() == 0 && best != nsel) {
-          for (int q = 0; q < 7; q++) { const real t = cand[FC_NREAL*nsel + q]; cand[FC_NREAL*nsel + q] = cand[FC_NREAL*best + q]; cand[FC_NREAL*best + q] = t; }
-          for (int q = 0; q < 4; q++) { const int t = ci[FI_NINT*nsel + q]; ci[FI_NINT*nsel + q] = ci[FI_NINT*best + q]; ci[FI_NINT*best + q] = t; }
-        }
-        if (next == nsel) next = best;
-        wv_sync();
-      }
-      nsel++;
-      best = next;
-    }
-  }
-
-  // ---- contactSort (stable, by geom then vertex / element) and emission
-  int overflow = 0;
-  for (int i0 = 0; i0 < nsel; i0 += MJH_W) {
-    const int i = i0 + wv_lane();
-    if (i >= nsel) continue;
-    const long long key = ((long long)ci[FI_NINT*i + FI_GEOM] << 32) | (unsigned)ci[FI_NINT*i + FI_OBJ];
-    int rank = 0;
-    for (int j = 0; j < nsel; j++) {
-      const long long kj = ((long long)ci[FI_NINT*j + FI_GEOM] << 32) | (unsigned)ci[FI_NINT*j + FI_OBJ];
-      if (kj < key || (kj == key && j < i)) rank++;
-    }
-    const int c = base + rank;
-    if (c >= s.nconmax) { overflow = 1; continue; }
-    Hit h{cand[FC_NREAL*i + FC_DIST], ld3(cand + FC_NREAL*i + FC_POS), ld3(cand + FC_NREAL*i + FC_NRM), V3{0, 0, 0}};
-    store_contact(M, B, e, c, ci[FI_NINT*i + FI_PAIR], h);
-    iptr cf = MJH_G(B, con_flex, e) + 3*c;
-    const int kind = ci[FI_NINT*i + FI_KIND], obj = ci[FI_NINT*i + FI_OBJ];
-    cf[0] = f; cf[1] = kind ? obj : -1; cf[2] = kind ? -1 : obj;
-  }
-  overflow = wv_any(overflow);
-  wv_sync();
+  const int r = flex_filter_emit(M, B, e, f, cand, ci, n, base, 1);
   tick(56);
-  return nsel | (overflow << 16);
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-collisions of flex number `sidx` of the self-colliding flexes (mj_collision, engine_collision_driver.c:834-881;
+// mj_collideFlexSAP :2315, mj_SAP :1439, mj_collideElems :2518).
+//
+// The reference sorts the float-rounded end points of the active elements' boxes along the longest axis of the flex's root
+// box (stable sort: equal values keep the order min_0 max_0 min_1 max_1 ...), sweeps, and sends every pair of boxes that are
+// open at the same time and overlap on the other two axes to mj_collideElems -- in the order the sweep meets them: by the
+// sort position of the later box's lower end, then of the earlier box's.  Here every pair (i < j) of active elements is
+// tested directly ("would the sweep report it?" is a comparison of four float keys), the surviving pairs -- few: elements
+// that share a vertex body are skipped -- go through GJK / EPA one per lane, and their contacts are put in the sweep's
+// order afterwards (the candidates' keys are unique), before filterFlexContacts looks at them.  mode 2 (no midphase /
+// selfcollide = narrow): all pairs e1 < e2 in lexicographic order.
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int f = M.flexself_flex[sidx], p = M.flexself_pair[sidx], mode = M.flexself_mode[sidx];
+  const int a0 = M.flexact_adr[f], nact = M.flexact_adr[f + 1] - a0;
+  if (nact < 2) return 0;
+  crptr aabb = MJH_F(B, flexelem_aabb, e);
+  rptr cand = MJH_G(B, flexcand, e);
+  iptr ci = MJH_G(B, flexcand_i, e);
+  iptr warn = MJH_F(B, warning, e);
+  const int half = s.nflexcand/2;
+  iptr surv = ci + FI_NINT*s.nflexcand;                       // (a << 16 | b: active-element indices, a the box the sweep opens first)
+  const int eadr = M.flex_elemadr[f];
+  int axis = 0;
+  if (mode == 1) {
+    crptr root = MJH_G(B, flexbvh_aabb, e) + 6*M.flexbvh_adr[f];
+    axis = (root[3] > root[4] && root[3] > root[5]) ? 0 : (root[4] > root[5] ? 1 : 2);
+  }
+  // ---- pairs of elements the reference's narrowphase would see
+  int nsurv = 0, toomany = 0;
+  for (int i = 0; i + 1 < nact; i++) {
+    const int ei = M.flexact_elem[a0 + i];
+    crptr bi = aabb + 6*ei;
+    const real ilo[3] = {bi[0] - bi[3], bi[1] - bi[4], bi[2] - bi[5]}, ihi[3] = {bi[0] + bi[3], bi[1] + bi[4], bi[2] + bi[5]};
+    const float iminf = (float)(axis == 0 ? ilo[0] : (axis == 1 ? ilo[1] : ilo[2])), imaxf = (float)(axis == 0 ? ihi[0] : (axis == 1 ? ihi[1] : ihi[2]));
+    int vb[3];
+    for (int q = 0; q < 3; q++) { const int v = M.flexelem_vert[4*ei + q]; vb[q] = v >= 0 ? (int)M.flexvert_bodyid[v] : -1; }
+    for (int j0 = i + 1; j0 < nact; j0 += MJH_W) {
+      const int j = j0 + wv_lane();
+      int ok = 0, first_i = 1;
+      if (j < nact) {
+        const int ej = M.flexact_elem[a0 + j];
+        crptr bj = aabb + 6*ej;
+        const real jlo[3] = {bj[0] - bj[3], bj[1] - bj[4], bj[2] - bj[5]}, jhi[3] = {bj[0] + bj[3], bj[1] + bj[4], bj[2] + bj[5]};
+        ok = 1;
+        if (mode == 1) {
+          // the sweep: keys (float value, position in the unsorted end-point array: 2 id for a lower, 2 id + 1 for an upper end)
+          const float jminf = (float)(axis == 0 ? jlo[0] : (axis == 1 ? jlo[1] : jlo[2])), jmaxf = (float)(axis == 0 ? jhi[0] : (axis == 1 ? jhi[1] : jhi[2]));
+          first_i = iminf <= jminf;                                   // (i < j: equal values keep i's lower end first)
+          ok = first_i ? (jminf < imaxf) : (iminf <= jmaxf);         // the later box opens before the earlier one closes
+          for (int q = 0; q < 3 && ok; q++) {
+            if (q == axis) continue;
+            if (ilo[q] > jhi[q] || jlo[q] > ihi[q]) ok = 0;
+          }
+        }
+        // filterBox with margin 0 (mj_collideElems :2531)
+        for (int q = 0; q < 3 && ok; q++) if (ihi[q] + 0 < jlo[q] || jhi[q] + 0 < ilo[q]) ok = 0;
+        // elements with vertices on the same body (:2536-2548)
+        if (ok) for (int q = 0; q < 3; q++) {
+          const int v = M.flexelem_vert[4*ej + q];
+          const int b = v >= 0 ? (int)M.flexvert_bodyid[v] : -1;
+          if (b >= 0 && (b == vb[0] || b == vb[1] || b == vb[2])) ok = 0;
+        }
+      }
+      const unsigned long long m = wv_ballot(ok);
+      if (m) {
+        const int at = nsurv + wv_rank_lt(m);
+        if (ok) { if (at < half) surv[at] = first_i ? ((i << 16) | j) : ((j << 16) | i); else toomany = 1; }
+        nsurv += __builtin_popcountll(m);
+      }
+    }
+  }
+  if (wv_any(toomany)) {
+    // more overlapping pairs than the table holds: not a state the reference would flag -- stop the environment instead
+    if (wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++;
+    nsurv = half;
+  }
+  wv_sync();
+  if (nsurv == 0) return 0;
+  // ---- GJK / EPA per surviving pair (mjc_ConvexElem, one contact at most)
+  int n = 0;
+  for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+    const int r = r0 + wv_lane();
+    const int pr = r < nsurv ? surv[r] : -1;
+    const int ia = pr >= 0 ? (pr >> 16) : -1, ib = pr >= 0 ? (pr & 0xffff) : -1;
+    const int got = ccd_elem_elem_pair(M, B, e, pr >= 0 ? (int)M.flexact_elem[a0 + ia] : -1, pr >= 0 ? (int)M.flexact_elem[a0 + ib] : -1, 0);
+    const unsigned long long m = wv_ballot(got > 0);
+    if (got > 0) {
+      const crptr rec = ccd_out_records(M, B, e);
+      const int c = n + wv_rank_lt(m);
+      if (c < half) {
+        for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
+        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2;
+      }
+    }
+    n += __builtin_popcountll(m);
+    wv_sync();
+  }
+  if (n > half) n = half;
+  if (n == 0) return 0;
+  // ---- the sweep's order: by the key of the later box's lower end, then of the earlier box's (mode 2: by (e1, e2))
+  rptr cand2 = cand + FC_NREAL*half;
+  iptr ci2 = ci + FI_NINT*half;
+  auto lower_key = [&](int ia, float* val) {
+    crptr bx = aabb + 6*M.flexact_elem[a0 + ia];
+    *val = mode == 1 ? (float)(axis == 0 ? bx[0] - bx[3] : (axis == 1 ? bx[1] - bx[4] : bx[2] - bx[5])) : 0.0f;
+  };
+  for (int i0 = 0; i0 < n; i0 += MJH_W) {
+    const int i = i0 + wv_lane();
+    if (i >= n) continue;
+    const int ia = ci[FI_NINT*i + FI_GEOM], ib = ci[FI_NINT*i + FI_OBJ];
+    float ka, kb;
+    lower_key(ia, &ka); lower_key(ib, &kb);
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const int ja = ci[FI_NINT*j + FI_GEOM], jb = ci[FI_NINT*j + FI_OBJ];
+      float la, lb;
+      lower_key(ja, &la); lower_key(jb, &lb);
+      int before;
+      if (mode == 1) {
+        if (lb != kb) before = lb < kb; else if (jb != ib) before = jb < ib;
+        else if (la != ka) before = la < ka; else before = ja < ia;
+      } else {
+        before = ja != ia ? ja < ia : jb < ib;
+      }
+      rank += before;
+    }
+    for (int q = 0; q < 7; q++) cand2[FC_NREAL*rank + q] = cand[FC_NREAL*i + q];
+    // (the element ids the contact record carries: local to the flex)
+    ci2[FI_NINT*rank + FI_GEOM] = M.flexact_elem[a0 + ia] - eadr; ci2[FI_NINT*rank + FI_OBJ] = M.flexact_elem[a0 + ib] - eadr;
+    ci2[FI_NINT*rank + FI_PAIR] = p; ci2[FI_NINT*rank + FI_KIND] = 2;
+  }
+  wv_sync();
+  return flex_filter_emit(M, B, e, f, cand2, ci2, n, base, 0);
 }
 
 #endif   // !MJH_LANE_MODE

@@ -759,7 +759,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // The geoms of a job's body get parameter records appended to the pair tables (index npair + k): mj_contactParam with
   // the flex on the second side (engine_collision_driver.c:1740-1835).
   {
-    H->colseg.clear(); H->flexjob_adr.clear(); H->flexjob_geom.clear();
+    H->colseg.clear(); H->flexjob_adr.clear(); H->flexjob_geom.clear(); H->flexjob_nsub.clear();
     for (const FlexJob& j : flexjobs) {
       const int f = j.flex, b = j.body;
       MJH_REJECT(midphase == 0, "flex collisions with the midphase disabled");
@@ -770,16 +770,31 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       H->flexjob_adr.push_back((int)H->flexjob_geom.size());
       for (int g = m->body_geomadr[b]; g < m->body_geomadr[b] + m->body_geomnum[b]; g++) {
         const int type = m->geom_type[g];
+        int nsub = 0;
         MJH_REJECT(type == mjGEOM_SDF || type == mjGEOM_HFIELD, "flex collisions with height-field / signed-distance-field geoms");
         if (type == mjGEOM_PLANE) {
           if (!dofless) continue;                 // (planes on moving bodies never reach a flex collider, mj_collideTree :1030-1038, :1128)
         } else {
           if (filter_bitmask(m->geom_contype[g], m->geom_conaffinity[g], m->flex_contype[f], m->flex_conaffinity[f])) continue;
-          MJH_REJECT(m->flex_dim[f] != 3, "collisions of line / shell flexes with geoms other than planes");
-          MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
-          if (type == mjGEOM_MESH)
-            MJH_REJECT(m->geom_dataid[g] < 0 || m->mesh_vertnum[m->geom_dataid[g]] < 1, "mesh geom without vertices");
-          s.ccd_any = 1;
+          // mj_collideGeomElem (engine_collision_driver.c:2372): triangles against spheres / capsules / boxes have closed
+          // forms (mjraw_SphereTriangle / CapsuleTriangle / BoxTriangle), every other pairing goes through GJK / EPA with the
+          // element as a convex object (mjc_ConvexElem).  Not built: line elements against spheres / capsules / boxes (the raw
+          // capsule colliders on a capsule made of the two vertices), and the ellipsoid case of mjc_fixNormal for triangles
+          const int dim = m->flex_dim[f];
+          MJH_REJECT(dim == 1 && (type == mjGEOM_SPHERE || type == mjGEOM_CAPSULE || type == mjGEOM_BOX),
+                     "collisions of line flexes with spheres / capsules / boxes");
+          MJH_REJECT(dim == 2 && type == mjGEOM_ELLIPSOID, "collisions of shell flexes with ellipsoids");
+          int sub = 0;                            // closed form: candidate contacts per (geom, triangle)
+          if (dim == 2 && type == mjGEOM_SPHERE) sub = 1;
+          else if (dim == 2 && type == mjGEOM_CAPSULE) sub = 5;
+          else if (dim == 2 && type == mjGEOM_BOX) sub = 11;
+          nsub = sub;
+          if (!sub) {
+            MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+            if (type == mjGEOM_MESH)
+              MJH_REJECT(m->geom_dataid[g] < 0 || m->mesh_vertnum[m->geom_dataid[g]] < 1, "mesh geom without vertices");
+            s.ccd_any = 1;
+          }
         }
         // mj_contactParam(g, -1, -1, f)
         int condim; real solref[2], solimp[5], fri[3];
@@ -821,6 +836,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
         MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
         H->flexjob_geom.push_back(g);
+        H->flexjob_nsub.push_back(nsub);
         H->pair_geom1.push_back(g);
         H->pair_geom2.push_back(-1);
         H->pair_dim.push_back(condim);
@@ -836,16 +852,109 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     H->flexjob_adr.push_back((int)H->flexjob_geom.size());
     H->flexjob_adr.push_back((int)H->flexjob_geom.size());
     s.ncolseg = (int)H->colseg.size()/3;
-    s.nflexpair = (int)H->flexjob_geom.size();
-    // flex : flex pairs, self collisions, internal collisions: not built
+    // flex : flex pairs between different flexes and internal collisions: not built.  Self-collisions of line / shell
+    // flexes (mj_collision, engine_collision_driver.c:834-881): by sweep-and-prune over the element boxes
+    // (mj_collideFlexSAP :2315) or over all pairs of active elements; the walk of the flex's bounding volume hierarchy
+    // against itself (solid flexes under selfcollide = auto, or selfcollide = bvh) is not built.
+    H->flexself_flex.clear(); H->flexself_pair.clear(); H->flexself_mode.clear();
+    bool need_bvh = false;
     for (int f1 = 0; f1 < m->nflex; f1++) {
       if (!(m->flex_contype[f1] || m->flex_conaffinity[f1])) continue;
       for (int f2 = f1 + 1; f2 < m->nflex; f2++)
         MJH_REJECT((m->flex_contype[f2] || m->flex_conaffinity[f2]) &&
                    !filter_bitmask(m->flex_contype[f1], m->flex_conaffinity[f1], m->flex_contype[f2], m->flex_conaffinity[f2]),
                    "collisions between two flexes");
-      if (!m->flex_rigid[f1] && (m->flex_contype[f1] & m->flex_conaffinity[f1]))
-        MJH_REJECT(m->flex_internal[f1] || m->flex_selfcollide[f1] != mjFLEXSELF_NONE, "flex self-collisions / internal collisions");
+      if (m->flex_rigid[f1] || !(m->flex_contype[f1] & m->flex_conaffinity[f1])) continue;
+      MJH_REJECT(m->flex_internal[f1], "flex internal collisions");
+      const int sc = m->flex_selfcollide[f1];
+      if (sc == mjFLEXSELF_NONE) continue;
+      int mode = 2;
+      if (midphase && sc != mjFLEXSELF_NARROW && m->flex_bvhadr[f1] >= 0) {
+        MJH_REJECT(sc == mjFLEXSELF_BVH || (sc == mjFLEXSELF_AUTO && m->flex_dim[f1] == 3),
+                   "flex self-collisions through the bounding volume hierarchy (solid flexes with selfcollide = auto, selfcollide = bvh)");
+        mode = 1;
+        need_bvh = true;
+      }
+      MJH_REJECT(m->flex_dim[f1] == 1, "self-collisions of line flexes (the raw capsule : capsule collider on capsules made of vertex pairs)");
+      MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+      MJH_REJECT(m->flex_elemnum[f1] >= 0x10000, "flex self-collisions with 65536 or more elements");
+      s.ccd_any = 1;
+      // parameter record: mj_contactParam(-1, -1, f, f) -- both sides the same flex, so the mixing rules return the flex's own
+      // parameters (0.5 x + 0.5 x = x exactly); margin and gap are ignored in self-collisions (mj_collideElems :2524)
+      const int f = f1;
+      real friction[5] = {(real)m->flex_friction[3*f], (real)m->flex_friction[3*f], (real)m->flex_friction[3*f + 1],
+                          (real)m->flex_friction[3*f + 2], (real)m->flex_friction[3*f + 2]};
+      real solref[2], solimp[5];
+      const real mix = m->flex_solmix[f] >= mjMINVAL ? m->flex_solmix[f]/(m->flex_solmix[f] + m->flex_solmix[f]) : 0.5;
+      if (m->flex_solref[2*f] > 0) { for (int k = 0; k < 2; k++) solref[k] = mix*m->flex_solref[2*f + k] + (1 - mix)*m->flex_solref[2*f + k]; }
+      else { for (int k = 0; k < 2; k++) solref[k] = m->flex_solref[2*f + k]; }
+      for (int k = 0; k < 5; k++) solimp[k] = mix*m->flex_solimp[5*f + k] + (1 - mix)*m->flex_solimp[5*f + k];
+      if (override_) {
+        for (int k = 0; k < 2; k++) solref[k] = m->opt.o_solref[k];
+        for (int k = 0; k < 5; k++) solimp[k] = m->opt.o_solimp[k];
+        for (int k = 0; k < 5; k++) friction[k] = m->opt.o_friction[k];
+      }
+      for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
+      MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
+      H->flexself_flex.push_back(f);
+      H->flexself_pair.push_back((int)H->pair_geom1.size());
+      H->flexself_mode.push_back(mode);
+      H->flexjob_geom.push_back(-1);
+      H->flexjob_nsub.push_back(0);
+      H->pair_geom1.push_back(-1);
+      H->pair_geom2.push_back(-1);
+      H->pair_dim.push_back(m->flex_condim[f]);
+      H->pair_margin.push_back(0);
+      H->pair_includemargin.push_back(0);
+      for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
+      for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
+      for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
+      for (int k = 0; k < 5; k++) H->pair_solimp.push_back(solimp[k]);
+    }
+    s.nflexself = (int)H->flexself_flex.size();
+    s.nflexpair = (int)H->flexjob_geom.size();
+    // active elements of every flex, in element order (mj_isElemActive :347)
+    H->flexact_adr.assign((size_t)m->nflex + 1, 0);
+    H->flexact_elem.clear();
+    for (int f = 0; f < m->nflex; f++) {
+      H->flexact_adr[f] = (int)H->flexact_elem.size();
+      if (s.nflexself)
+        for (int t = 0; t < m->flex_elemnum[f]; t++)
+          if (m->flex_dim[f] < 3 || m->flex_elemlayer[m->flex_elemadr[f] + t] < m->flex_activelayers[f]) H->flexact_elem.push_back(m->flex_elemadr[f] + t);
+    }
+    H->flexact_adr[m->nflex] = (int)H->flexact_elem.size();
+    s.nflexact = (int)H->flexact_elem.size();
+    // the flexes' bounding volume hierarchies (only where the sweep axis of a self-collision is read off the root box)
+    H->flexbvh_adr.assign((size_t)m->nflex + 1, 0);
+    H->flexbvh_child.clear(); H->flexbvh_elem.clear(); H->flexbvh_order.clear(); H->flexbvh_hadr.clear();
+    {
+      std::vector<int> height;
+      for (int f = 0; f < m->nflex; f++) {
+        const int base = (int)H->flexbvh_elem.size();
+        H->flexbvh_adr[f] = base;
+        const int adr = m->flex_bvhadr[f], num = need_bvh && adr >= 0 ? m->flex_bvhnum[f] : 0;
+        for (int i = 0; i < num; i++) {
+          const int c0 = m->bvh_child[2*(adr + i)], c1 = m->bvh_child[2*(adr + i) + 1], id = m->bvh_nodeid[adr + i];
+          MJH_REJECT(id < 0 && (c0 <= i || c1 <= i || c0 >= num || c1 >= num), "internal: flex bounding volume hierarchy (children)");
+          H->flexbvh_child.push_back(id >= 0 ? -1 : base + c0);
+          H->flexbvh_child.push_back(id >= 0 ? -1 : base + c1);
+          H->flexbvh_elem.push_back(id >= 0 ? m->flex_elemadr[f] + id : -1);
+        }
+        height.resize(base + num, 0);
+        for (int i = num - 1; i >= 0; i--)
+          if (H->flexbvh_elem[base + i] < 0)
+            height[base + i] = 1 + std::max(height[H->flexbvh_child[2*(base + i)]], height[H->flexbvh_child[2*(base + i) + 1]]);
+      }
+      H->flexbvh_adr[m->nflex] = (int)H->flexbvh_elem.size();
+      s.nflexbvh = (int)H->flexbvh_elem.size();
+      int hmax = 0;
+      for (int h : height) hmax = std::max(hmax, h);
+      s.nflexbvhh = s.nflexbvh ? hmax + 1 : 0;
+      for (int h = 0; h < s.nflexbvhh; h++) {
+        H->flexbvh_hadr.push_back((int)H->flexbvh_order.size());
+        for (int i = 0; i < s.nflexbvh; i++) if (height[i] == h) H->flexbvh_order.push_back(i);
+      }
+      H->flexbvh_hadr.push_back((int)H->flexbvh_order.size());
     }
     // BVH leaves of every flex in depth-first order (second child first: mj_collideTree pushes child 0 then child 1 and pops the last)
     H->flex_leafadr.assign((size_t)m->nflex + 1, 0);
@@ -892,9 +1001,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       const int f = H->colseg[3*k + 2];
       int c = 0;
       for (int a = H->flexjob_adr[k]; a < H->flexjob_adr[k + 1]; a++)
-        c += m->geom_type[H->flexjob_geom[a]] == mjGEOM_PLANE ? m->flex_vertnum[f] : (H->flex_leafadr[f + 1] - H->flex_leafadr[f]);
+        c += m->geom_type[H->flexjob_geom[a]] == mjGEOM_PLANE ? m->flex_vertnum[f]
+                                                                : (H->flex_leafadr[f + 1] - H->flex_leafadr[f])*std::max(1, H->flexjob_nsub[a]);
       cand = std::max(cand, c);
     }
+    // self-collisions: the pairs of elements whose boxes overlap (beyond the capacity the environment raises the mjhip-only
+    // UNSUPPORTED warning); their contacts are put in order in the second half of the table
+    for (int k = 0; k < s.nflexself; k++) cand = std::max(cand, 2*16*(int)m->flex_elemnum[H->flexself_flex[k]]);
     s.nflexcand = cand;
   }
 
@@ -1081,6 +1194,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // on demand; a fixed 512 stands in for "as many as a scene of this size can touch at once")
   // (a body : flex job leaves at most mjMAXCONPAIR contacts, filterFlexContacts :447-515)
   for (int k = 0; k + 1 < s.ncolseg; k++) maxcon_total += std::min(s.nflexcand, (int)mjMAXCONPAIR);
+  maxcon_total += s.nflexself*(int)mjMAXCONPAIR;              // (and so does a flex's collision with itself, mj_collision :878)
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 512));
   s.nconflex = m->nflex ? s.nconmax : 0;
   s.nconlds = std::min(s.nconmax, 8);
@@ -1232,6 +1346,25 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // row capacity: the model's bound, cut back (not below 256 rows) until the per-environment constraint
   // arrays -- efc_J, efc_Y, the dense efc_AR under the dual solver, ~24 row vectors -- fit the budget
   // ($MJHIP_EFC_BYTES, default: the reference arena size clamped to 4..16 MiB; rows beyond the capacity raise mjWARN_CNSTRFULL like a full arena)
+  // longest compressed contact row (stored before duplicates are merged): the dof chains of two bodies; a geom's chain and
+  // the chains of the corners of a flex element; the chains of the corners of two elements of a flex that collides with itself
+  auto csr_row_bound = [&]() {
+    auto chain_len = [&](int b) {
+      int cnt = 0;
+      for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)m->body_weldid[b]*s.nvw + w]);
+      return cnt;
+    };
+    int chainmax = 1;
+    for (int b = 0; b < m->nbody; b++) chainmax = std::max(chainmax, chain_len(b));
+    int bound = 2*chainmax;
+    for (int f = 0; f < m->nflex; f++) {
+      int vchain = 0;
+      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) vchain = std::max(vchain, chain_len(m->flex_vertbodyid[v]));
+      bound = std::max(bound, chainmax + (m->flex_dim[f] + 1)*vchain);
+      for (int k = 0; k < s.nflexself; k++) if (H->flexself_flex[k] == f) bound = std::max(bound, 2*(m->flex_dim[f] + 1)*vchain);
+    }
+    return bound;
+  };
   {
     const bool dual = m->opt.solver == mjSOL_PGS;
     // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
@@ -1245,13 +1378,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     if (s.csr) {
       // the explicit-index rows hold translational contact rows only (condim 1 / 3), and a row's merged dof chain is
       // assembled in a 64-entry per-lane array (mjh_csr.h): models outside either bound keep the dense rows
-      int chainmax = 1;
-      for (int b = 0; b < m->nbody; b++) {
-        int cnt = 0;
-        for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)b*s.nvw + w]);
-        chainmax = std::max(chainmax, cnt);
-      }
-      if (std::max(2*chainmax, chainmax + 12) > MJH_CSR_CHAIN_MAX) s.csr = 0;
+      if (csr_row_bound() > MJH_CSR_CHAIN_MAX) s.csr = 0;
       for (int p = 0; p < s.npair && s.csr; p++) if (H->pair_dim[p] > 3) s.csr = 0;
       for (int g = 0; g < m->ngeom && s.csr && s.nflexpair > 0; g++) if (m->geom_condim[g] > 3) s.csr = 0;
       for (int f = 0; f < m->nflex && s.csr; f++) if (m->flex_condim[f] > 3) s.csr = 0;
@@ -1306,14 +1433,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       if (m->opt.solver == mjSOL_PGS) s.nARw = (s.nefcmax + 63)/64;
     }
     if (s.csr) {
-      // longest row: the dof chains of two bodies, or one chain and the three sliders of each corner of a flex element
-      int chainmax = 1;
-      for (int b = 0; b < m->nbody; b++) {
-        int cnt = 0;
-        for (int w = 0; w < s.nvw; w++) cnt += __builtin_popcount((unsigned)H->body_dofanc[(size_t)b*s.nvw + w]);
-        chainmax = std::max(chainmax, cnt);
-      }
-      s.csr_rowmax = std::min((int)m->nv, std::max(2*chainmax, chainmax + 12));
+      s.csr_rowmax = std::min((int)m->nv, csr_row_bound());
       s.nJmax = s.nefcmax*s.csr_rowmax;
     }
   }

@@ -194,7 +194,23 @@
   X(colseg, 3 * s.ncolseg)                     \
   X(flexjob_adr, s.ncolseg + 1)                \
   X(flexjob_geom, s.nflexpair)                 \
+  X(flexjob_nsub, s.nflexpair)                 \
   X(flex_leafadr, s.nflex + 1)                 \
+  /* flex self-collisions (mjh_flexcol.h: flex_self_collide).  flexself_*: the flexes that collide with themselves (flex, \
+     parameter record = pair index, mode 1 sweep-and-prune / 2 all pairs); flexact_*: the active elements of every flex in \
+     element order (mj_isElemActive); flexbvh_*: every flex's bounding volume hierarchy -- node range of the flex, children \
+     (node ids of this table, -1), element of a leaf (global id, -1 for inner nodes), and the inner nodes ordered by height \
+     (children before parents: mj_updateDynamicBVH recomputes the inner boxes bottom-up) */ \
+  X(flexself_flex, s.nflexself)                \
+  X(flexself_pair, s.nflexself)                \
+  X(flexself_mode, s.nflexself)                \
+  X(flexact_adr, s.nflex + 1)                  \
+  X(flexact_elem, s.nflexact)                  \
+  X(flexbvh_adr, s.nflex + 1)                  \
+  X(flexbvh_child, 2 * s.nflexbvh)             \
+  X(flexbvh_elem, s.nflexbvh)                  \
+  X(flexbvh_hadr, s.nflexbvhh + 1)             \
+  X(flexbvh_order, s.nflexbvh)                 \
   X(flexleaf_elem, s.nflexleaf)                \
   X(flex_mintree, s.nflex)                     \
   X(flex_contype, s.nflex)                     \
@@ -377,6 +393,10 @@ struct DSizes {
   // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
   // body : flex job, ngeom with flexes (else 0), per-env capacity of the flex contact identity table (nconmax or 0)
   int nflexpair, ncolseg, nflexleaf, nflexcand, ngeomflex, nconflex;
+  // flex self-collisions: flexes that collide with themselves, active elements, nodes / heights of the flex bounding volume
+  // hierarchies (0 unless some flex collides with itself by sweep-and-prune: the sweep axis is read off the root box)
+  int nflexself, nflexact, nflexbvh, nflexbvhh;
+#define MJH_CONFLEX 6          // ints of a contact's flex identity: flex, element, vertex of side 1, then of side 0 (-1: a geom)
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row
   int csr, csr_rowmax;
@@ -527,6 +547,7 @@ enum {
   /* product vectors of the solver's ordered sums when the LDS block has no room for them (mjh_newton.h: csr_dots) */ \
   X(csr_prod, 6 * s.csr * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                          \
   X(flexcand, 8 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                           \
+  X(flexbvh_aabb, 6 * s.nflexbvh, 0, MJH_T_GLB, MJH_T_GLB)                        \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_Y, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(efc_AR, s.nefcAR * s.nefcAR, 0, MJH_T_GLB, MJH_T_GLB)                          \
@@ -581,7 +602,7 @@ enum {
   X(con_efcadr, s.nconmax, MJH_LDS_CON, MJH_T_COLLISION, MJH_T_MAKE)              \
   /* mjContact flex[1] / elem[1] / vert[1] of every contact (models with flexes), -1 -1 -1 for geom : geom; candidate \
      table of a body : flex job (geom, vertex or element, parameter record, kind, selected flag; then the surviving leaves) */ \
-  X(con_flex, 3 * s.nconflex, 0, MJH_T_GLB, MJH_T_GLB)                            \
+  X(con_flex, MJH_CONFLEX * s.nconflex, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(flexcand_i, 6 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                         \
   X(moment_rownnz, s.nu, s.nu, MJH_T_TRANSMISSION, MJH_T_ACTUATION)               \
   X(moment_colind, s.nmoment, s.nmoment, MJH_T_TRANSMISSION, MJH_T_ACTUATION)     \

@@ -58,6 +58,19 @@ def test_flex_edge_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
     assert maxcon > 0
 
 
+def test_shell_flex_on_sphere_box_capsule_cylinder_on_gpu(rb, hip_lib, tmp_path):
+    """triangle elements against sphere / box / capsule (closed forms) and cylinder (GJK / EPA + fixNormal), explicit-index rows"""
+    assert fh._shell_on_geoms(rb, hip_lib, tmp_path) > 40
+
+
+def test_shell_flex_on_geoms_dense_rows_on_gpu(rb, hip_lib, tmp_path):
+    fh._shell_on_geoms(rb, hip_lib, tmp_path, count="4 4 1", csr=0, geoms=fh.SHELL_GEOMS.replace(".06 .06 .15", ".02 .02 .15"))
+
+
+def test_line_flex_on_cylinder_and_ellipsoid_on_gpu(rb, hip_lib, tmp_path):
+    fh._line_on_cylinder(rb, hip_lib, tmp_path)
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

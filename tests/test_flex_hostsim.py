@@ -131,7 +131,7 @@ def _contact_lists(rb, hostsim_lib, tmp_path):
         assert np.array_equal(b.get("con_pos")[0][:3*n], np.asarray(con["pos"]).ravel())
         assert np.array_equal(b.get("con_frame")[0][:9*n], np.asarray(con["frame"]).ravel())
         assert np.array_equal(b.get("con_geom")[0][:2*n].reshape(-1, 2), np.asarray(con["geom"]))
-        cf = b.get("con_flex")[0][:3*n].reshape(-1, 3)
+        cf = b.get("con_flex")[0][:6*n].reshape(-1, 6)
         assert np.array_equal(cf[:, 0], np.asarray(con["flex"])[:, 1])
         assert np.array_equal(cf[:, 1], np.asarray(con["elem"])[:, 1]) and np.array_equal(cf[:, 2], np.asarray(con["vert"])[:, 1])
         assert _fields_exact(b, d, ["efc_pos", "efc_margin", "efc_D", "efc_R"]) == []
@@ -286,6 +286,89 @@ def _two_flexes(rb, lib, tmp_path):
 
 def test_two_flexes_are_two_islands_of_sliders(rb, hostsim_lib, tmp_path):
     _two_flexes(rb, hostsim_lib, tmp_path)
+
+
+SHELL_GEOMS = """
+    <body mocap="true" pos=".06 .06 .15"><geom type="sphere" size=".05"/></body>
+    <body mocap="true" pos="-.07 -.05 .15"><geom type="box" size=".04 .03 .03" euler="10 20 30"/></body>
+    <body mocap="true" pos=".05 -.08 .16" zaxis="1 .3 0"><geom type="capsule" size=".03 .05"/></body>
+    <body mocap="true" pos="-.06 .07 .15" zaxis="1 .3 .2"><geom type="cylinder" size=".04 .05"/></body>"""
+
+
+def shell_xml(count, geoms, dim=2, body='<edge equality="false" damping="1"/><contact selfcollide="none"/>'
+                                        '<elasticity young="3e4" poisson="0" thickness="1e-2" elastic2d="both"/>',
+              option='solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"', spacing=".04 .04 .04", pos="0 0 .25"):
+    return f"""
+<mujoco>
+  <option {option}/>
+  <size memory="50M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    {geoms}
+    <flexcomp type="grid" count="{count}" spacing="{spacing}" pos="{pos}" dim="{dim}" radius=".005" mass="1" name="soft">
+      {body}
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _free_run(rb, lib, m, pre, nstep, csr=None):
+    """as _resync_steps, for models on any Jacobian path; returns (max contacts, first-side geoms seen in contacts)"""
+    dm = K.DeviceModel(lib, m)
+    if csr is not None: assert dm.size("csr") == csr
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    for _ in range(pre): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:1 + m.nq + m.nv])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    if m.nmocap: b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+    maxcon = 0; geoms = set()
+    for t in range(nstep):
+        b.step(); rb.mj_step(m, d)
+        c = b.get("counts")[0]
+        assert (c[0], c[1], c[5]) == (d.ncon, d.nefc, d.solver_niter[0]), (t, c[:6], d.ncon, d.nefc, d.solver_niter[0])
+        assert not b.get("warning")[0].any()
+        assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel), t
+        maxcon = max(maxcon, d.ncon)
+        if d.ncon: geoms |= set(np.asarray(d.contact[:d.ncon]["geom"])[:, 0].tolist())
+    return maxcon, geoms
+
+
+def _shell_on_geoms(rb, lib, tmp_path, count="9 9 1", csr=1, geoms=SHELL_GEOMS):
+    xml = tmp_path / "shellgeoms.xml"
+    xml.write_text(shell_xml(count, geoms))
+    m = rb.MjModel.from_xml_path(str(xml))
+    maxcon, seen = _free_run(rb, lib, m, pre=60, nstep=100, csr=csr)
+    assert seen >= {1, 2, 3, 4}, seen
+    return maxcon
+
+
+def test_shell_flex_on_sphere_box_capsule_cylinder(rb, hostsim_lib, tmp_path):
+    """a triangle shell falling on a sphere, a box, a capsule (mjraw_SphereTriangle / BoxTriangle / CapsuleTriangle: up to
+    1 / 11 / 5 contacts per triangle) and a cylinder (GJK / EPA against the triangle + mjc_fixNormal): contact, row and CG
+    iteration counts and the states of 100 free-running steps identical to the oracle's; explicit-index rows (243 dofs)"""
+    assert _shell_on_geoms(rb, hostsim_lib, tmp_path) > 40
+
+
+def test_shell_flex_on_geoms_dense_rows(rb, hostsim_lib, tmp_path):
+    """the same colliders with the constraint Jacobian dense (48 dofs)"""
+    _shell_on_geoms(rb, hostsim_lib, tmp_path, count="4 4 1", csr=0, geoms=SHELL_GEOMS.replace(".06 .06 .15", ".02 .02 .15"))
+
+
+def _line_on_cylinder(rb, lib, tmp_path):
+    xml = tmp_path / "line.xml"
+    xml.write_text(shell_xml("50 1 1", '<body mocap="true" pos="0 0 .15" zaxis="0 1 0"><geom type="cylinder" size=".05 .1"/></body>'
+                                        '<body mocap="true" pos=".15 0 .12"><geom type="ellipsoid" size=".05 .08 .04"/></body>',
+                             dim=1, body='<edge equality="false" damping=".5" stiffness="200"/><contact selfcollide="none"/>', spacing=".01 .01 .01"))
+    m = rb.MjModel.from_xml_path(str(xml))
+    maxcon, seen = _free_run(rb, lib, m, pre=100, nstep=100, csr=1)
+    assert seen >= {1, 2}, seen
+
+
+def test_line_flex_on_cylinder_and_ellipsoid(rb, hostsim_lib, tmp_path):
+    """a cable (line elements: capsules of two vertices) on a cylinder and an ellipsoid: mjc_ConvexElem with two-corner elements"""
+    _line_on_cylinder(rb, hostsim_lib, tmp_path)
 
 
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
