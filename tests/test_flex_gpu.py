@@ -71,6 +71,12 @@ def test_line_flex_on_cylinder_and_ellipsoid_on_gpu(rb, hip_lib, tmp_path):
     fh._line_on_cylinder(rb, hip_lib, tmp_path)
 
 
+def test_shell_flex_self_collision_on_gpu(rb, hip_lib, tmp_path):
+    """flex : flex contacts of a cloth folding over a bar (sweep-and-prune order, two-sided weighted rows), bit for bit"""
+    assert fh._self_collision(rb, hip_lib, tmp_path, "auto", nstep=100) == 50
+    assert fh._self_collision(rb, hip_lib, tmp_path, "narrow", nstep=60) > 10
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference
