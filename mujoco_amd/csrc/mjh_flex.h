@@ -104,7 +104,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
   // per lane -- takes its edges two at a time per lane in a branch-free body, for the reason given at the stretch pass: the
   // second edge's chain of dependent loads hides the first one's round trips)
   int paired = 0;
-  if (s.nflex == 1 && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge &&
+  if (s.nflex == 1 && s.flex_sliders && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge &&
       !(M.flex_edgeequality[0] != 1 && M.flex_edgedamping[0] == 0 && M.flex_edgestiffness[0] == 0 && M.flex_damping[0] == 0)) paired = 1;
   if (paired) {
     const int ne = s.nflexedge;
@@ -170,14 +170,28 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
     real off1[3], off2[3];
     v3_sub(off1, vx + 3*v1, scom + 3*M.body_rootid[b1]);
     v3_sub(off2, vx + 3*v2, scom + 3*M.body_rootid[b2]);
+    const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+    const int both_simple = M.body_simple[b1] && M.body_simple[b2];
     for (int j = adr; j < adr + nnz; j++) {
       const int col = M.flexedge_J_colind[j];
-      const int second = M.dof_bodyid[col] == b2;
       crptr cd = cdof + 6*col;
-      real t[3];
-      v3_cross(t, cd, second ? off2 : off1);
-      real jd[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-      if (!second) { jd[0] = -jd[0]; jd[1] = -jd[1]; jd[2] = -jd[2]; }
+      real jd[3];
+      if (both_simple) {
+        // (mj_jacSparseSimple: a dof belongs to exactly one of the two bodies; the first body's block is written negated)
+        const int second = M.dof_bodyid[col] == b2;
+        real t[3];
+        v3_cross(t, cd, second ? off2 : off1);
+        jd[0] = cd[3] + t[0]; jd[1] = cd[4] + t[1]; jd[2] = cd[5] + t[2];
+        if (!second) { jd[0] = -jd[0]; jd[1] = -jd[1]; jd[2] = -jd[2]; }
+      } else {
+        // (mj_jacDifPair over the merged chain, common dofs kept: jac2 - jac1, each zero off its body's chain)
+        const int in1 = (M.body_dofanc[w1*s.nvw + (col >> 5)] >> (col & 31)) & 1;
+        const int in2 = (M.body_dofanc[w2*s.nvw + (col >> 5)] >> (col & 31)) & 1;
+        real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0}, t[3];
+        if (in1) { v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+        if (in2) { v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
+        jd[0] = j2[0] - j1[0]; jd[1] = j2[1] - j1[1]; jd[2] = j2[2] - j1[2];
+      }
       real acc = 0;
       for (int r = 0; r < 3; r++)
         if (vec[r] != 0) acc += jd[r]*vec[r];
@@ -193,7 +207,7 @@ MJH_DEV void flex_edge_velocity(MREF M, BREF B, int e) {
   crptr qvel = MJH_F(B, qvel, e);
   crptr J = MJH_F(B, flexedge_J, e);
   rptr vel = MJH_F(B, flexedge_velocity, e);
-  if (s.nflex == 1 && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge) {
+  if (s.nflex == 1 && s.flex_sliders && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge) {
     // (rows of six entries, two edges per lane at a time: see stage_flex_edges)
     const int ne = s.nflexedge;
     for (int e0 = wv_lane(); e0 < ne; e0 += 2*MJH_W) {
@@ -369,7 +383,7 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
   MJH_FOR_LANES(v, s.nflexvert) {
     const int bid = M.flexvert_bodyid[v];
     const int nd = M.body_dofnum[bid];
-    if (nd == 0) continue;
+    if (nd == 0 && (!s.nflexdofv || M.body_dofnum[M.body_weldid[bid]] == 0)) continue;
     const int dadr = M.body_dofadr[bid];
     const int f = M.flexvert_flex[v];
     if (M.flex_dim[f] == 1 || M.flex_rigid[f]) continue;
@@ -398,12 +412,47 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
 #pragma unroll
         for (int u = 0; u < 4; u++) if (a + u < ea1) { q[0] += fx[u][0]; q[1] += fx[u][1]; q[2] += fx[u][2]; }
       }
-      real ql[3];
-      m3_multvec(ql, xmat + 9*bid, q);
-      for (int x = 0; x < nd; x++) fs[dadr + x] += ql[x];
+      if (M.body_simple[bid] == 2) {
+        real ql[3];
+        m3_multvec(ql, xmat + 9*bid, q);
+        for (int x = 0; x < nd; x++) fs[dadr + x] += ql[x];
+      } else {
+        // (a vertex riding on an articulated body: its force is applied below, dof by dof)
+        rptr vf = MJH_G(B, flexvert_frc, e);
+        vf[3*v] = q[0]; vf[3*v + 1] = q[1]; vf[3*v + 2] = q[2];
+      }
     }
   }
   wv_sync();
+  // ---- stretch forces of vertices on articulated bodies: mj_applyFT (engine_support.c) adds J' f to every dof of the
+  //      body's chain; a dof sums its vertices in vertex order (flexdof_vert)
+  if (s.nflexdofv) {
+    crptr vf = MJH_G(B, flexvert_frc, e);
+    crptr cdof = MJH_F(B, cdof, e);
+    crptr scom = MJH_F(B, subtree_com, e);
+    MJH_FOR_LANES(j, s.nv) {
+      const int a0 = M.flexdof_vadr[j], a1 = M.flexdof_vadr[j + 1];
+      if (a0 == a1) continue;
+      crptr cd = cdof + 6*j;
+      real acc = fs[j];
+      for (int a = a0; a < a1; a++) {
+        const int v = M.flexdof_vert[a];
+        const int f = M.flexvert_flex[v];
+        const int sadr = M.flex_stiffnessadr[f];
+        if (M.flex_dim[f] < 2 || M.flex_rigid[f] || sadr < 0 || M.flex_stiffness[sadr] == 0) continue;
+        const int bid = M.flexvert_bodyid[v];
+        real off[3], t[3];
+        v3_sub(off, vx + 3*v, scom + 3*M.body_rootid[bid]);
+        v3_cross(t, cd, off);
+        const real jp[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+        real qf = 0;
+        for (int r = 0; r < 3; r++) { const real fr = vf[3*v + r]; if (fr != 0) qf += jp[r]*fr; }
+        acc += qf;
+      }
+      fs[j] = acc;
+    }
+    wv_sync();
+  }
 
   // ---- edge spring-dampers: every dof sums its edges in edge order (:757-787).  (flexedge_k / flexedge_d: the edge's flex
   //      coefficients, zero for rigid edges -- an edge whose two coefficients are off adds nothing and is skipped as in

@@ -175,14 +175,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->opt.solver == mjSOL_CG && (m->opt.integrator == mjINT_IMPLICIT || m->opt.integrator == mjINT_IMPLICITFAST) &&
                m->opt.cone != mjCONE_ELLIPTIC && !m->flex_rigid[f] && m->flex_dim[f] >= 2,
                "flexes under CG with an implicit integrator (the reference's implicit effective metric, mj_flexCG)");
-    for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
-      // a vertex is a body with three axis-aligned sliders (body_simple 2), or is pinned to a body without degrees of
-      // freedom up to the world (elastic forces on vertices riding on articulated bodies go through mj_applyFT: not built)
-      const int b = m->flex_vertbodyid[v];
-      bool fixed = true;
-      for (int a = b; a > 0; a = m->body_parentid[a]) if (m->body_dofnum[a] > 0) fixed = false;
-      MJH_REJECT(!(m->body_simple[b] == 2 || fixed), "flex vertices attached to articulated bodies");
-    }
   }
   MJH_REJECT(m->nplugin > 0, "plugins");
   for (int i = 0; i < m->nsensor; i++) {
@@ -301,6 +293,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_parentid, m->body_parentid, m->nbody);
   copy_arr(H->body_rootid, m->body_rootid, m->nbody);
   copy_arr(H->body_weldid, m->body_weldid, m->nbody);
+  copy_arr(H->body_simple, m->body_simple, m->nbody);
   copy_arr(H->body_mocapid, m->body_mocapid, m->nbody);
   copy_arr(H->body_jntnum, m->body_jntnum, m->nbody);
   copy_arr(H->body_jntadr, m->body_jntadr, m->nbody);
@@ -1560,6 +1553,28 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     H->flexvert_elemadr[m->nflexvert] = (int)H->flexvert_elem.size();
     H->flexvert_bendadr[m->nflexvert] = (int)H->flexvert_bend.size();
     H->flexvert_elem.resize(s.nflexelemdata, 0);
+    // vertices on articulated bodies: per dof, the vertices whose chain holds it (mj_flexPassiveStretch :632-648 applies the
+    // stretch force of such a vertex through mj_applyFT, i.e. to every dof of its body's chain)
+    {
+      s.flex_sliders = 1;
+      std::vector<std::vector<int>> dv(m->nv);
+      for (int v = 0; v < m->nflexvert; v++) {
+        const int b = m->flex_vertbodyid[v];
+        if (m->body_simple[b] == 2) continue;
+        const int w = m->body_weldid[b];
+        if (m->body_dofnum[w] == 0) continue;
+        s.flex_sliders = 0;
+        for (int j = m->body_dofadr[w] + m->body_dofnum[w] - 1; j >= 0; j = m->dof_parentid[j]) dv[j].push_back(v);
+      }
+      H->flexdof_vadr.assign((size_t)s.nflexdof + 1, 0);
+      H->flexdof_vert.clear();
+      for (int j = 0; j < s.nflexdof; j++) {
+        H->flexdof_vadr[j] = (int)H->flexdof_vert.size();
+        H->flexdof_vert.insert(H->flexdof_vert.end(), dv[j].begin(), dv[j].end());
+      }
+      if (s.nflexdof) H->flexdof_vadr[s.nflexdof] = (int)H->flexdof_vert.size();
+      s.nflexdofv = (int)H->flexdof_vert.size();
+    }
     H->flexvert_bend.resize((size_t)4*s.nflexbend, 0);
     // flexedge_J by column, entries in ascending edge order (the order mj_springdamper adds edge forces to a dof, :770-787)
     {

@@ -22,6 +22,7 @@
   X(body_parentid, s.nbody)                    \
   X(body_rootid, s.nbody)                      \
   X(body_weldid, s.nbody)                      \
+  X(body_simple, s.nbody)                      \
   X(body_mocapid, s.nbody)                     \
   X(body_jntnum, s.nbody)                      \
   X(body_jntadr, s.nbody)                      \
@@ -186,6 +187,10 @@
   X(flexvert_elemadr, s.nflexvert + 1)         \
   X(flexvert_elem, s.nflexelemdata)            \
   X(flexvert_bendadr, s.nflexvert + 1)         \
+  /* vertices riding on articulated bodies (not three axis-aligned sliders of their own): for every dof, the vertices whose \
+     body chain holds it, in vertex order -- the order in which mj_flexPassiveStretch's mj_applyFT calls add to that dof */ \
+  X(flexdof_vadr, s.nflexdof + 1)              \
+  X(flexdof_vert, s.nflexdofv)                 \
   X(flexvert_bend, 4 * s.nflexbend)            \
   /* flex collisions (mjh_flexcol.h).  colseg: the collision pass as segments (end of a range of static geom pairs, then \
      the body : flex job that follows it in the reference's bodyflex order, -1 -1 for none); flexjob_*: the geoms of \
@@ -390,6 +395,8 @@ struct DSizes {
   // flexes (mjh_flex.h): mjModel sizes; nflexbend = nflexedge when some flex has bending stiffness, else 0;
   // nflexdof = nv with flexes, else 0
   int nflex, nflexvert, nflexedge, nflexelem, nflexelemdata, nflexstiffness, nflexbending, nJfe, nflexbend, nflexdof;
+  int nflexdofv;       // entries of flexdof_vert (0: every vertex body is three sliders of its own, or pinned to the world)
+  int flex_sliders;    // 1: every flex vertex body has body_simple 2 or no dofs up to the world (fast paths of mjh_flex.h)
   // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
   // body : flex job, ngeom with flexes (else 0), per-env capacity of the flex contact identity table (nconmax or 0)
   int nflexpair, ncolseg, nflexleaf, nflexcand, ngeomflex, nconflex;
@@ -541,6 +548,7 @@ enum {
   X(flexedge_velocity, s.nflexedge, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(flexedge_J, s.nJfe, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(flexelem_frc, 12 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexvert_frc, 3 * (s.nflexdofv ? s.nflexvert : 0), 0, MJH_T_GLB, MJH_T_GLB)   \
   X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* mjData flexelem_aabb; candidate contacts of one body : flex job (dist, pos[3], normal[3], min_dist) */ \
   X(flexelem_aabb, 6 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \

@@ -77,6 +77,12 @@ def test_shell_flex_self_collision_on_gpu(rb, hip_lib, tmp_path):
     assert fh._self_collision(rb, hip_lib, tmp_path, "narrow", nstep=60) > 10
 
 
+def test_flex_vertices_on_articulated_bodies_on_gpu(rb, hip_lib, tmp_path):
+    """radial sliders under a free body (softbox.xml's kind) and a cloth riding on a hinged pole"""
+    fh._articulated_vertices(rb, hip_lib, tmp_path, "radial")
+    fh._articulated_vertices(rb, hip_lib, tmp_path, "hinge")
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

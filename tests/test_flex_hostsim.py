@@ -418,6 +418,93 @@ def test_shell_flex_self_collision_all_pairs(rb, hostsim_lib, tmp_path):
     assert _self_collision(rb, hostsim_lib, tmp_path, "narrow", nstep=40) > 10
 
 
+RADIAL_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".002"/>
+  <size memory="50M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body mocap="true" pos=".1 .05 .1"><geom type="sphere" size=".08"/></body>
+    <body pos="0 0 .35" name="body">
+      <freejoint/>
+      <geom size=".05" contype="0" conaffinity="0"/>
+      <flexcomp name="softbox" type="box" count="6 6 6" spacing=".04 .04 .04" radius="0.01" dim="3" dof="radial">
+        <contact internal="false" selfcollide="none"/>
+        <edge equality="true"/>
+      </flexcomp>
+    </body>
+  </worldbody>
+</mujoco>"""
+
+ON_HINGE_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001"/>
+  <size memory="50M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body mocap="true" pos=".25 .03 .42"><geom type="sphere" size=".06"/></body>
+    <body name="pole" pos="0 0 .6">
+      <joint type="hinge" axis="0 0 1" damping=".01"/>
+      <joint type="slide" axis="0 0 1" damping="1" stiffness="50"/>
+      <geom type="capsule" size=".01 .2" contype="0" conaffinity="0"/>
+      <flexcomp type="grid" count="7 8 1" spacing=".04 .04 .04" pos=".14 0 0" zaxis="0 1 0" mass=".2" name="flag" radius="0.004" dim="2">
+        <edge equality="false" damping=".02"/>
+        <contact selfcollide="none"/>
+        <elasticity young="3e4" poisson="0" thickness="4e-3" elastic2d="stretch"/>
+        <pin id="0 1 2 3"/>
+      </flexcomp>
+    </body>
+  </worldbody>
+</mujoco>"""
+
+
+def _articulated_vertices(rb, lib, tmp_path, which):
+    xml = tmp_path / "art.xml"
+    xml.write_text(RADIAL_XML if which == "radial" else ON_HINGE_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    vb = np.asarray(m.flex_vertbodyid)
+    assert (np.asarray(m.body_simple)[vb] != 2).all() and m.nv > 128
+    dm = K.DeviceModel(lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    if which != "radial": d.qvel[:2] = (3.0, 0.5)
+    pre = 100 if which == "radial" else 150
+    for _ in range(pre): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    def load():
+        b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:1 + m.nq + m.nv])
+        b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+        b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+    load()
+    rb.mj_forward(m, d); b.forward()
+    assert _fields_exact(b, d, ["flexvert_xpos", "flexedge_length", "flexedge_velocity", "flexedge_J", "qfrc_spring", "qfrc_damper",
+                                "qfrc_passive", "qacc_smooth", "qacc"]) == []
+    load()
+    maxcon = 0
+    for t in range(80):
+        b.step(); rb.mj_step(m, d)
+        c = b.get("counts")[0]
+        assert (c[0], c[1], c[5]) == (d.ncon, d.nefc, d.solver_niter[0]), (t, c[:6], d.ncon, d.nefc, d.solver_niter[0])
+        assert not b.get("warning")[0].any()
+        assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel), t
+        maxcon = max(maxcon, d.ncon)
+    assert maxcon > 0
+    return maxcon
+
+
+def test_flex_vertices_on_radial_sliders_of_a_free_body(rb, hostsim_lib, tmp_path):
+    """model/flex/softbox.xml's kind: every vertex a radial slider under one free body -- edge Jacobians over merged chains
+    (common dofs kept), contact rows as weighted sums over the union of the corners' chains, edge equalities; lands on
+    the floor and a sphere"""
+    _articulated_vertices(rb, hostsim_lib, tmp_path, "radial")
+
+
+def test_flex_vertices_riding_on_a_hinged_body(rb, hostsim_lib, tmp_path):
+    """a cloth whose vertex bodies are children of a spinning, sliding pole (four of them pinned to it): the stretch force of
+    every vertex goes through mj_applyFT to the pole's dofs, summed in vertex order; contact with a sphere"""
+    _articulated_vertices(rb, hostsim_lib, tmp_path, "hinge")
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
