@@ -88,6 +88,27 @@ MJH_DEV void csr_contact_cols16(MREF M, BREF B, int e, int k, CsrCols16& R) {
   R.keep = keep; R.m = m;
 }
 
+// stored dofs of the rows of equality constraint id (connect / weld: both body chains, common dofs kept -- mj_jacDifPair
+// without flg_skipcommon, engine_core_constraint.c:655, :676; joint couplings: the joints' dofs), ascending
+template <class IP>
+MJH_DEV int csr_equality_cols(MREF M, int id, IP cols) {
+  const int et = M.eq_type[id];
+  int o1 = M.eq_obj1id[id], o2 = M.eq_obj2id[id];
+  int n = 0;
+  if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
+    if (M.eq_objsite[id]) { o1 = M.site_bodyid[o1]; o2 = M.site_bodyid[o2]; }
+    n = csr_body_chain(M, o1, cols);
+    n += csr_body_chain(M, o2, cols + n);
+  } else {
+    cols[n++] = M.jnt_dofadr[o1];
+    if (o2 >= 0) cols[n++] = M.jnt_dofadr[o2];
+  }
+  for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
+  int m = 0;
+  for (int a = 0; a < n; a++) { if (m > 0 && cols[m - 1] == cols[a]) continue; cols[m++] = cols[a]; }
+  return m;
+}
+
 MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -118,9 +139,15 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     const int type = P.type[r], id = P.id[r];
     int nnz = 0;
     if (type == MJH_CNSTR_EQUALITY) {
-      // (flex edge constraints, the only equality kind on this path: the edge's flexedge_J row)
-      const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
-      nnz = M.flexedge_J_rownnz[ed];
+      const int et = M.eq_type[id];
+      if (et == MJH_EQ_FLEX) {
+        // (flex edge constraints: the edge's flexedge_J row)
+        const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+        nnz = M.flexedge_J_rownnz[ed];
+      } else {
+        int cols[MJH_CSR_CHAIN_MAX];
+        nnz = csr_equality_cols(M, id, cols);
+      }
     }
     else if (type == MJH_CNSTR_FRICTION_DOF) nnz = 1;
     else if (type == MJH_CNSTR_LIMIT_JOINT) nnz = M.jnt_type[id] == MJH_JNT_BALL ? 3 : 1;
@@ -169,10 +196,17 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
     const int type = P.type[r], id = P.id[r];
     const int a0 = rowadr[r];
     if (type == MJH_CNSTR_EQUALITY) {
-      const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
-      const int f0 = M.flexedge_J_rowadr[ed], fn = M.flexedge_J_rownnz[ed];
-      crptr fJ = MJH_F(B, flexedge_J, e);
-      for (int q = 0; q < fn; q++) { colind[a0 + q] = M.flexedge_J_colind[f0 + q]; val[a0 + q] = fJ[f0 + q]; }
+      if (M.eq_type[id] == MJH_EQ_FLEX) {
+        const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+        const int f0 = M.flexedge_J_rowadr[ed], fn = M.flexedge_J_rownnz[ed];
+        crptr fJ = MJH_F(B, flexedge_J, e);
+        for (int q = 0; q < fn; q++) { colind[a0 + q] = M.flexedge_J_colind[f0 + q]; val[a0 + q] = fJ[f0 + q]; }
+      } else {
+        // connect / weld / joint couplings: cut from the dense row stage_equality_rows wrote
+        int cols[MJH_CSR_CHAIN_MAX];
+        const int n = csr_equality_cols(M, id, cols);
+        for (int q = 0; q < n; q++) { colind[a0 + q] = cols[q]; val[a0 + q] = Jd[(size_t)r*nv + cols[q]]; }
+      }
     }
     else if (type == MJH_CNSTR_FRICTION_DOF) { colind[a0] = id; val[a0] = Jd[(size_t)r*nv + id]; }
     else if (type == MJH_CNSTR_LIMIT_JOINT) {

@@ -1365,7 +1365,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // (equality rows: flex edge constraints only -- their rows are the model's flexedge_J rows; the dense rows of the other
     // kinds would have to be cut by a scan)
     bool eq_ok = true, eq_flex = false;
-    for (int i = 0; i < m->neq; i++) { if (m->eq_type[i] != mjEQ_FLEX) eq_ok = false; else eq_flex = true; }
+    for (int i = 0; i < m->neq; i++) {
+      if (m->eq_type[i] == mjEQ_FLEX) eq_flex = true;
+      else if (m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT) eq_ok = false;   // (tendon couplings: not on this path)
+    }
     s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && eq_ok && m->ntendon == 0 &&
              !(m->opt.disableflags & mjDSBL_ISLAND)) ? 1 : 0;
     if (s.csr) {
@@ -1389,8 +1392,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     if (H->body_chain.empty()) H->body_chain.push_back(0);
     s.nchain = (int)H->body_chain.size();
-    MJH_REJECT(eq_flex && !s.csr, "flex edge equality constraints outside the explicit-index CG path (more than 128 dofs, CG, "
-                                  "sparse Jacobian, no other equality or tendon)");
+    // flex edge constraints have no dense row: they need one of the compressed-row paths under a primal solver
+    {
+      const bool mask_path = ref_sparse0 && m->nv <= 128 && m->opt.solver != mjSOL_PGS;
+      MJH_REJECT(eq_flex && !s.csr && !mask_path, "flex edge equality constraints outside the compressed-Jacobian paths (sparse Jacobian "
+                                                  "under CG / Newton up to 128 dofs; beyond: CG, no tendons or tendon couplings)");
+    }
     // default budget: what the reference's own arena (mjModel.narena, engine_memory.c:107-138) could hold, between 4 and
     // 16 MiB per environment (64 MiB for the compressed-row CG path) -- stacked_boxes.xml under PGS needs ~1000 rows
     const double MiB = 1024.0*1024.0;
@@ -1407,7 +1414,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   {
     const bool ref_sparse = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
     s.sparse = (ref_sparse && m->nv <= 128) ? 1 : 0;
-    MJH_REJECT(s.sparse && s.nflexpair > 0, "flex collisions in a model that takes the compressed-Jacobian path (sparse Jacobian with at most 128 dofs)");
+    MJH_REJECT(s.sparse && s.nflexpair > 0 && m->opt.solver == mjSOL_PGS,
+               "flex collisions under PGS in a model that takes the compressed-Jacobian path (sparse Jacobian with at most 128 dofs)");
     s.nJmax = 0; s.nLp = 0; s.nLpc = 0; s.nARw = 0;
     if (s.sparse) {
       // longest row pattern: two body chains (contacts, connect / weld), two tendons, a ball joint limit

@@ -37,7 +37,7 @@ MJH_DEV M128 sp_tendon_pattern(MREF M, int t) {
 //   tendon rows: the tendon's ten_J pattern (:1318, :1505)
 //   contacts: mj_jacDifPair with flg_skipcommon = 1 (:1551) -- the two body chains without their common part
 //   connect / weld: both body chains, common dofs included (:655, :676); joint / tendon couplings: union of the two objects
-MJH_DEV M128 sp_row_pattern(MREF M, BREF B, int e, int type, int id) {
+MJH_DEV M128 sp_row_pattern(MREF M, BREF B, int e, int type, int id, int r) {
   if (type == MJH_CNSTR_FRICTION_DOF) return m128_bit(id);
   if (type == MJH_CNSTR_LIMIT_JOINT) {
     const int adr = M.jnt_dofadr[id];
@@ -46,10 +46,31 @@ MJH_DEV M128 sp_row_pattern(MREF M, BREF B, int e, int type, int id) {
   }
   if (type == MJH_CNSTR_FRICTION_TENDON || type == MJH_CNSTR_LIMIT_TENDON) return sp_tendon_pattern(M, id);
   if (type >= MJH_CNSTR_CONTACT_FRICTIONLESS) {
+    if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) {
+      // flex contacts: one body on each side as below; a flex element on a side: the union of the chains of every body
+      // involved (mj_jacSum; contact_sides, mjh_flex.h)
+      ConSides S;
+      contact_sides(M, B, e, id, S);
+      if (!S.simple) {
+        M128 pm = m128_zero();
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q < S.n) pm = m128_or(pm, sp_body_chain(M, S.body[q]));
+        return pm;
+      }
+      return m128_xor(sp_body_chain(M, S.body[0]), sp_body_chain(M, S.body[1]));
+    }
     ciptr cg = MJH_CON(B, con_geom, e, 2, id);
     return m128_xor(sp_body_chain(M, M.geom_bodyid[cg[0]]), sp_body_chain(M, M.geom_bodyid[cg[1]]));
   }
   const int et = M.eq_type[id];
+  if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEX) {
+    // a flex edge constraint's row is the edge's flexedge_J row (mj_instantiateEquality :982-1010)
+    const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+    M128 pm = m128_zero();
+    const int adr = M.flexedge_J_rowadr[ed], n = M.flexedge_J_rownnz[ed];
+    for (int k = 0; k < n; k++) pm = m128_or(pm, m128_bit(M.flexedge_J_colind[adr + k]));
+    return pm;
+  }
   int o1 = M.eq_obj1id[id], o2 = M.eq_obj2id[id];
   if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
     if (M.eq_objsite[id]) { o1 = M.site_bodyid[o1]; o2 = M.site_bodyid[o2]; }
@@ -86,7 +107,7 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
     const int r = r0 + lane;
     int nnz = 0;
     if (r < nefc) {
-      const M128 pm = sp_row_pattern(M, B, e, P.type[r], P.id[r]);
+      const M128 pm = sp_row_pattern(M, B, e, P.type[r], P.id[r], r);
       nnz = m128_count(pm);
       m128_st(P.rowmask + 4*r, pm);
     }
@@ -108,6 +129,14 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
     const int type = P.type[r];
     if (dual || type < MJH_CNSTR_CONTACT_FRICTIONLESS) {
       // non-contact rows: cut from the dense row stage_make_constraint wrote
+      if (MJH_HAS(MJH_FT_FLEX) && type == MJH_CNSTR_EQUALITY && M.eq_type[P.id[r]] == MJH_EQ_FLEX) {
+        // (no dense row is written for a flex edge constraint: the edge's row, whose columns ascend like the pattern's)
+        const int ed = M.eqrow_edge[M.eq_rowadr[P.id[r]] + (r - MJH_G(B, eq_efcadr, e)[P.id[r]])];
+        crptr fJ = MJH_F(B, flexedge_J, e);
+        const int f0 = M.flexedge_J_rowadr[ed], fn = M.flexedge_J_rownnz[ed];
+        for (int q = 0; q < fn; q++) P.spJ[a++] = fJ[f0 + q];
+        continue;
+      }
       crptr Jr = J + (size_t)r*nv;
       while (m128_any(pm)) { const int j = m128_lowest(pm); pm = m128_drop_lowest(pm); P.spJ[a++] = Jr[j]; }
       continue;
@@ -119,7 +148,10 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
     const int sub = r - MJH_CON(B, con_efcadr, e, 1, k)[0];        // row of the contact's block
     const int dim = MJH_CON(B, con_dim, e, 1, k)[0];
     ciptr cg = MJH_CON(B, con_geom, e, 2, k);
-    const int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+    ConSides S;
+    int general = 0;
+    if (MJH_HAS(MJH_FT_FLEX) && s.nconflex) { contact_sides(M, B, e, k, S); general = 1; }
+    const int b1 = general ? S.body[0] : (int)M.geom_bodyid[cg[0]], b2 = general ? S.body[1] : (int)M.geom_bodyid[cg[1]];
     const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
     crptr point = MJH_CON(B, con_pos, e, 3, k);
     crptr fr = MJH_CON(B, con_frame, e, 9, k);
@@ -142,9 +174,10 @@ MJH_DEVN void stage_sparsify(MREF M_, BREF B_, int e_) {
       crptr cd = cdof + 6*j;
       if (in1) { real t[3]; v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
       if (in2) { real t[3]; v3_cross(t, cd, off2); j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2]; }
-      const real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
-      const real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0), (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
-                          (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+      real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+      real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0), (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
+                    (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+      if (MJH_HAS(MJH_FT_FLEX) && general && !S.simple) contact_jac_col(M, S, cdof, subtree_com, point, j, jd, rd);
       auto frame_row = [&](int arow) -> real {
         // rows 0..2: translational difference, rows 3..5: rotational difference, each against frame row (arow mod 3)
         const real* v = arow < 3 ? jd : rd;

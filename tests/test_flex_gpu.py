@@ -83,6 +83,15 @@ def test_flex_vertices_on_articulated_bodies_on_gpu(rb, hip_lib, tmp_path):
     fh._articulated_vertices(rb, hip_lib, tmp_path, "hinge")
 
 
+@pytest.mark.parametrize("solver,equality", [("Newton", True), ("CG", False)])
+def test_flex_on_mask_rows_on_gpu(rb, hip_lib, tmp_path, solver, equality):
+    fh._flex_on_mask_path(rb, hip_lib, tmp_path, solver, equality)
+
+
+def test_connect_and_weld_rows_next_to_flex_edge_constraints_on_gpu(rb, hip_lib, tmp_path):
+    fh._hanging_cloth(rb, hip_lib, tmp_path)
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

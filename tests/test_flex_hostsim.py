@@ -505,6 +505,41 @@ def test_flex_vertices_riding_on_a_hinged_body(rb, hostsim_lib, tmp_path):
     _articulated_vertices(rb, hostsim_lib, tmp_path, "hinge")
 
 
+def _flex_on_mask_path(rb, lib, tmp_path, solver, equality):
+    """a shell of 75 dofs with jacobian = sparse: the 128-bit mask rows of mjh_sparse.h carry flex contact rows (weighted
+    sums over the union of the corners' chains) and, with equality, flex edge constraint rows"""
+    opt = f'solver="{solver}" tolerance="1e-8" timestep=".001" integrator="Euler" jacobian="sparse"'
+    body = ('<edge equality="true" damping="1"/><contact selfcollide="none"/>' if equality else
+            '<edge equality="false" damping="1"/><contact selfcollide="none"/><elasticity young="3e4" poisson="0" thickness="1e-2" elastic2d="both"/>')
+    xml = tmp_path / "mask.xml"
+    xml.write_text(shell_xml("5 5 1", SHELL_GEOMS.replace(".06 .06 .15", ".02 .02 .15"), option=opt, body=body))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert K.DeviceModel(lib, m).size("sparse") == 1
+    maxcon, seen = _free_run(rb, lib, m, pre=60, nstep=80, csr=0)
+    assert maxcon > 30 and seen >= {1, 2, 3, 4}
+
+
+@pytest.mark.parametrize("solver,equality", [("Newton", True), ("Newton", False), ("CG", True)])
+def test_flex_contacts_and_edge_constraints_on_mask_rows(rb, hostsim_lib, tmp_path, solver, equality):
+    _flex_on_mask_path(rb, hostsim_lib, tmp_path, solver, equality)
+
+
+def _hanging_cloth(rb, lib, tmp_path):
+    """model/flex/flag.xml's kind: edge constraints plus a connect equality (and a weld) on the explicit-index rows"""
+    xml = tmp_path / "hang.xml"
+    xml.write_text(shell_xml("7 7 1", '<body mocap="true" pos=".05 0 .1"><geom type="sphere" size=".06"/></body>', pos="0 0 .3",
+                             body='<edge equality="true" damping=".01"/><contact selfcollide="none"/>').replace(
+        "</worldbody>", '</worldbody><equality><connect body1="soft_0" anchor="0 0 0"/><weld body1="soft_48" body2="soft_47"/></equality>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.neq == 3
+    maxcon, seen = _free_run(rb, lib, m, pre=150, nstep=80, csr=1)
+    assert maxcon > 0
+
+
+def test_connect_and_weld_rows_next_to_flex_edge_constraints(rb, hostsim_lib, tmp_path):
+    _hanging_cloth(rb, hostsim_lib, tmp_path)
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
