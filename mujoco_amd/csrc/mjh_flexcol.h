@@ -163,6 +163,31 @@ MJH_DEV V3 tri_fix_normal_cylinder(V3 normal, V3 cpos, V3 gpos, PM mat, PS size)
   return mmul(mat, nrm);
 }
 
+// capsule of a line element: the two vertices' segment with the flex radius (mj_makeCapsule, engine_collision_driver.c:1879;
+// the frame through mju_quatZ2Vec / mju_quat2Mat, engine_util_spatial.c)
+MJH_DEV void flex_make_capsule(V3 v1, V3 v2, real radius, V3& pos, real* mat, real* size) {
+  V3 dif = v1 - v2;
+  size[0] = radius;
+  size[1] = 0.5*unitize(dif);
+  const V3 sum = v1 + v2;
+  pos = V3{sum.x*0.5, sum.y*0.5, sum.z*0.5};
+  real quat[4] = {1, 0, 0, 0};
+  V3 vn = dif;
+  if (!(unitize(vn) < MJH_MINVAL)) {
+    const V3 z{0, 0, 1};
+    V3 axis = cross(z, vn);
+    real a = unitize(axis);
+    if (fabs(a) < MJH_MINVAL) {
+      if (dot(vn, z) < 0) { quat[0] = 0; quat[1] = 1; }
+    } else {
+      a = r_atan2(a, dot(vn, z));
+      const real ax[3] = {axis.x, axis.y, axis.z};
+      q_axisangle(quat, ax, a);
+    }
+  }
+  q_tomat(mat, quat);
+}
+
 // filterFlexContacts + (optionally) contactSort + emission of the n candidates in (cand, ci); returns the number of
 // contacts written from slot `base` on | overflow << 16.  sorted: stable sort by (geom, vertex / element) (body : flex
 // jobs, mj_collision :717-724); self-collisions are emitted in candidate order.
@@ -351,7 +376,34 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
     tick(54);
     const int nsub = M.flexjob_nsub[a];
     const int gtype = M.geom_type[g];
-    if (nsub) {
+    if (nsub && M.flex_dim[f] == 1) {
+      // line elements against a sphere / capsule: the raw capsule colliders on the capsule made of the element's two
+      // vertices (mj_collideGeomElem :2401-2425); up to two contacts per element, compacted in (leaf, contact) order
+      const V3 gp = ld3(gx + 3*g);
+      for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+        const int r = r0 + wv_lane();
+        int got = 0, el = -1;
+        Hit ha{0, V3{0, 0, 0}, V3{0, 0, 0}, V3{0, 0, 0}}, hb = ha;
+        if (r < nsurv) {
+          el = surv[r];
+          V3 cpos; real cmat[9], csize[2];
+          flex_make_capsule(ld3(vx + 3*M.flexelem_vert[4*el]), ld3(vx + 3*M.flexelem_vert[4*el + 1]), radius, cpos, cmat, csize);
+          if (gtype == MJH_GEOM_SPHERE) got = hit_sphere_capsule(ha, mg, gp, gm + 9*g, M.geom_size[3*g], cpos, cmat, csize);
+          else got = hit_capsule_capsule(ha, hb, mg, gp, gm + 9*g, M.geom_size + 3*g, cpos, cmat, csize);
+        }
+        const int before = wv_exscan_i(got);
+        const int total = wv_sum_i(got);
+        for (int q = 0; q < got; q++) {
+          const int c = n + before + q;
+          const Hit& h = q ? hb : ha;
+          cand[FC_NREAL*c + FC_DIST] = h.dist;
+          cand[FC_NREAL*c + FC_POS] = h.pos.x; cand[FC_NREAL*c + FC_POS + 1] = h.pos.y; cand[FC_NREAL*c + FC_POS + 2] = h.pos.z;
+          cand[FC_NREAL*c + FC_NRM] = h.nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = h.nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = h.nrm.z;
+          ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = el - eadr; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 1;
+        }
+        n += total;
+      }
+    } else if (nsub) {
       // triangles against a sphere / capsule / box: the closed-form tests, one (triangle, sub-test) per lane, hits compacted
       // in (leaf, sub-test) order -- the order in which the reference emits them
       const V3 gp = ld3(gx + 3*g);
@@ -447,8 +499,8 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
     crptr bi = aabb + 6*ei;
     const real ilo[3] = {bi[0] - bi[3], bi[1] - bi[4], bi[2] - bi[5]}, ihi[3] = {bi[0] + bi[3], bi[1] + bi[4], bi[2] + bi[5]};
     const float iminf = (float)(axis == 0 ? ilo[0] : (axis == 1 ? ilo[1] : ilo[2])), imaxf = (float)(axis == 0 ? ihi[0] : (axis == 1 ? ihi[1] : ihi[2]));
-    int vb[3];
-    for (int q = 0; q < 3; q++) { const int v = M.flexelem_vert[4*ei + q]; vb[q] = v >= 0 ? (int)M.flexvert_bodyid[v] : -1; }
+    int vb[4];
+    for (int q = 0; q < 4; q++) { const int v = M.flexelem_vert[4*ei + q]; vb[q] = v >= 0 ? (int)M.flexvert_bodyid[v] : -1; }
     for (int j0 = i + 1; j0 < nact; j0 += MJH_W) {
       const int j = j0 + wv_lane();
       int ok = 0, first_i = 1;
@@ -470,10 +522,10 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
         // filterBox with margin 0 (mj_collideElems :2531)
         for (int q = 0; q < 3 && ok; q++) if (ihi[q] + 0 < jlo[q] || jhi[q] + 0 < ilo[q]) ok = 0;
         // elements with vertices on the same body (:2536-2548)
-        if (ok) for (int q = 0; q < 3; q++) {
+        if (ok) for (int q = 0; q < 4; q++) {
           const int v = M.flexelem_vert[4*ej + q];
           const int b = v >= 0 ? (int)M.flexvert_bodyid[v] : -1;
-          if (b >= 0 && (b == vb[0] || b == vb[1] || b == vb[2])) ok = 0;
+          if (b >= 0 && (b == vb[0] || b == vb[1] || b == vb[2] || b == vb[3])) ok = 0;
         }
       }
       const unsigned long long m = wv_ballot(ok);
@@ -491,8 +543,41 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
   }
   wv_sync();
   if (nsurv == 0) return 0;
-  // ---- GJK / EPA per surviving pair (mjc_ConvexElem, one contact at most)
   int n = 0;
+  if (M.flex_dim[f] == 1) {
+    // ---- line elements: mjraw_CapsuleCapsule on the two elements' capsules, margin 0 (mj_collideElems :2555-2566)
+    crptr vx = MJH_F(B, flexvert_xpos, e);
+    const real radius = M.flex_radius[f];
+    for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+      const int r = r0 + wv_lane();
+      const int pr = r < nsurv ? surv[r] : -1;
+      const int ia = pr >= 0 ? (pr >> 16) : -1, ib = pr >= 0 ? (pr & 0xffff) : -1;
+      int got = 0;
+      Hit ha{0, V3{0, 0, 0}, V3{0, 0, 0}, V3{0, 0, 0}}, hb = ha;
+      if (pr >= 0) {
+        const int e1 = M.flexact_elem[a0 + ia], e2 = M.flexact_elem[a0 + ib];
+        V3 p1, p2; real m1[9], m2[9], s1[2], s2[2];
+        flex_make_capsule(ld3(vx + 3*M.flexelem_vert[4*e1]), ld3(vx + 3*M.flexelem_vert[4*e1 + 1]), radius, p1, m1, s1);
+        flex_make_capsule(ld3(vx + 3*M.flexelem_vert[4*e2]), ld3(vx + 3*M.flexelem_vert[4*e2 + 1]), radius, p2, m2, s2);
+        got = hit_capsule_capsule(ha, hb, 0, p1, m1, s1, p2, m2, s2);
+      }
+      const int before = wv_exscan_i(got);
+      const int total = wv_sum_i(got);
+      for (int q = 0; q < got; q++) {
+        const int c = n + before + q;
+        if (c >= half) continue;
+        const Hit& h = q ? hb : ha;
+        cand[FC_NREAL*c + FC_DIST] = h.dist;
+        cand[FC_NREAL*c + FC_POS] = h.pos.x; cand[FC_NREAL*c + FC_POS + 1] = h.pos.y; cand[FC_NREAL*c + FC_POS + 2] = h.pos.z;
+        cand[FC_NREAL*c + FC_NRM] = h.nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = h.nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = h.nrm.z;
+        // (the second contact of a pair follows the first: FI_SEL breaks the tie of the ordering below)
+        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2; ci[FI_NINT*c + FI_SEL] = q;
+      }
+      n += total;
+    }
+    wv_sync();
+  } else
+  // ---- GJK / EPA per surviving pair (mjc_ConvexElem, one contact at most)
   for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
     const int r = r0 + wv_lane();
     const int pr = r < nsurv ? surv[r] : -1;
@@ -504,7 +589,7 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
       const int c = n + wv_rank_lt(m);
       if (c < half) {
         for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
-        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2;
+        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2; ci[FI_NINT*c + FI_SEL] = 0;
       }
     }
     n += __builtin_popcountll(m);
@@ -531,7 +616,8 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
       float la, lb;
       lower_key(ja, &la); lower_key(jb, &lb);
       int before;
-      if (mode == 1) {
+      if (ja == ia && jb == ib) before = ci[FI_NINT*j + FI_SEL] < ci[FI_NINT*i + FI_SEL];
+      else if (mode == 1) {
         if (lb != kb) before = lb < kb; else if (jb != ib) before = jb < ib;
         else if (la != ka) before = la < ka; else before = ja < ia;
       } else {

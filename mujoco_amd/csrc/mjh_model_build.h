@@ -774,13 +774,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           // element as a convex object (mjc_ConvexElem).  Not built: line elements against spheres / capsules / boxes (the raw
           // capsule colliders on a capsule made of the two vertices), and the ellipsoid case of mjc_fixNormal for triangles
           const int dim = m->flex_dim[f];
-          MJH_REJECT(dim == 1 && (type == mjGEOM_SPHERE || type == mjGEOM_CAPSULE || type == mjGEOM_BOX),
-                     "collisions of line flexes with spheres / capsules / boxes");
+          MJH_REJECT(dim == 1 && type == mjGEOM_BOX, "collisions of line flexes with boxes");
           MJH_REJECT(dim == 2 && type == mjGEOM_ELLIPSOID, "collisions of shell flexes with ellipsoids");
           int sub = 0;                            // closed form: candidate contacts per (geom, triangle)
           if (dim == 2 && type == mjGEOM_SPHERE) sub = 1;
           else if (dim == 2 && type == mjGEOM_CAPSULE) sub = 5;
           else if (dim == 2 && type == mjGEOM_BOX) sub = 11;
+          else if (dim == 1 && type == mjGEOM_SPHERE) sub = 1;      // (mjraw_SphereCapsule / CapsuleCapsule on the element's capsule)
+          else if (dim == 1 && type == mjGEOM_CAPSULE) sub = 2;
           nsub = sub;
           if (!sub) {
             MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
@@ -868,10 +869,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         mode = 1;
         need_bvh = true;
       }
-      MJH_REJECT(m->flex_dim[f1] == 1, "self-collisions of line flexes (the raw capsule : capsule collider on capsules made of vertex pairs)");
-      MJH_REJECT(m->opt.disableflags & mjDSBL_NATIVECCD, "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+      MJH_REJECT(m->flex_dim[f1] != 1 && (m->opt.disableflags & mjDSBL_NATIVECCD), "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
       MJH_REJECT(m->flex_elemnum[f1] >= 0x10000, "flex self-collisions with 65536 or more elements");
-      s.ccd_any = 1;
+      if (m->flex_dim[f1] != 1) s.ccd_any = 1;
       // parameter record: mj_contactParam(-1, -1, f, f) -- both sides the same flex, so the mixing rules return the flex's own
       // parameters (0.5 x + 0.5 x = x exactly); margin and gap are ignored in self-collisions (mj_collideElems :2524)
       const int f = f1;

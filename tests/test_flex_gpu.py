@@ -92,6 +92,12 @@ def test_connect_and_weld_rows_next_to_flex_edge_constraints_on_gpu(rb, hip_lib,
     fh._hanging_cloth(rb, hip_lib, tmp_path)
 
 
+def test_line_flex_capsule_colliders_on_gpu(rb, hip_lib, tmp_path):
+    """against the reference linked with the kernels' atan2 / sin / cos (the capsule frames call them): bit for bit"""
+    assert 2 in fh._cable(rb, hip_lib, tmp_path, 30, 150, kind="devmath")
+    fh._cable(rb, hip_lib, tmp_path, 50, 110, kind="devmath")
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

@@ -540,6 +540,42 @@ def test_connect_and_weld_rows_next_to_flex_edge_constraints(rb, hostsim_lib, tm
     _hanging_cloth(rb, hostsim_lib, tmp_path)
 
 
+CABLE_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".002" integrator="Euler" jacobian="sparse"/>
+  <size memory="50M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body mocap="true" pos=".0 .05 .12"><geom type="sphere" size=".05"/></body>
+    <body mocap="true" pos="0 -.06 .06" zaxis="1 0 0"><geom type="capsule" size=".02 .15"/></body>
+    <flexcomp name="cable" type="circle" count="COUNT 1 1" spacing=".03 1 1" dim="1" radius="0.008" pos="0 0 .3" mass=".2" euler="80 0 0">
+      <edge equality="true" damping=".002"/>
+      <contact selfcollide="auto"/>
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _cable(rb, lib, tmp_path, count, pre, kind=None):
+    """a ring of line elements (model/flex/pulley.xml's kind) collapsing over a sphere and a capsule onto the floor: the
+    elements are capsules made of vertex pairs (mj_makeCapsule: frame through mju_quatZ2Vec -- atan2, sin, cos), against
+    the geoms (mjraw_SphereCapsule / CapsuleCapsule) and against each other (sweep-and-prune + mjraw_CapsuleCapsule)"""
+    xml = tmp_path / "cable.xml"
+    xml.write_text(CABLE_XML.replace("COUNT", str(count)))
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind)
+    maxcon, seen = _free_run(rb, lib, m, pre, 160)
+    assert -1 in seen and 1 in seen, seen
+    return seen
+
+
+def test_line_flex_self_collision_and_capsule_colliders(rb, hostsim_lib, tmp_path):
+    assert 2 in _cable(rb, hostsim_lib, tmp_path, 30, 150)            # mask rows (87 dofs): sphere, capsule, itself
+
+
+def test_line_flex_self_collision_explicit_index_rows(rb, hostsim_lib, tmp_path):
+    _cable(rb, hostsim_lib, tmp_path, 50, 110)                        # 147 dofs
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))

@@ -97,6 +97,7 @@ def run_one(lib, path, steps, lds, changes):
     ctrl = np.zeros((1, steps, max(m.nu, 0)))
     # the reference trajectory
     ref = np.zeros((steps, nstate)); ref_int = np.zeros((steps, 2), int); ref_sens = np.zeros((steps, m.nsensordata))
+    ctrl0 = np.array(d.ctrl).copy() if m.nu > 0 else None      # (a keyframe may carry controls: pulley.xml)
     mocap = None
     if m.nmocap > 0:
         mocap = (np.array(d.mocap_pos).copy(), np.array(d.mocap_quat).copy())
@@ -114,6 +115,8 @@ def run_one(lib, path, steps, lds, changes):
         b.set("act", s0[None, 1 + m.nq + m.nv:1 + m.nq + m.nv + m.na])
     if mocap is not None:
         b.set("mocap_pos", mocap[0].reshape(1, -1)); b.set("mocap_quat", mocap[1].reshape(1, -1))
+    if ctrl0 is not None:
+        b.set("ctrl", ctrl0[None, :])
     worst = 0.0; worst_sens = 0.0; int_ok = True
     for t in range(steps):
         b.step(1)
