@@ -327,6 +327,57 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
     return out
 
 
+def api_regime(model_path, solver_id, integ_id, nenv, nstep, s0, cfg, batch, stream, dev):
+    """The drop-in entry point as a caller uses it: `mujoco_amd.rollout.rollout(model, data, initial_state, control,
+    state=...)` with numpy arrays (python/mujoco/rollout.py's signature; underneath `mjhip_rollout`, include/mjhip.h:192 =
+    `_unsafe_rollout`'s contract, rollout.cc:74-178): controls go host -> device and the per-step states come back inside the
+    timer.  The rollout is launched in chunks of 50 steps whose copies overlap the kernels (mjh_runtime.h: rollout_impl).
+    Next to it the same work device-resident (one launch of `nstep` steps from the same state0 / controls), the rate
+    `value` is the ceiling of.  mjModel / mjData are the CALLER's objects: here made by the compiled reference standing in
+    for the caller's MuJoCo (as in tests/); the product only reads mjModel and writes the last state into mjData."""
+    import torch
+    import mujoco_amd as ma
+    from mujoco_amd import rollout as ro
+    from oracle import refbind as rb          # the caller's MuJoCo (mj_loadModel / mj_makeData), not part of the timed path
+    if not rb.available():
+        return {"error": "no MuJoCo library on this box to make the caller's mjModel / mjData"}
+    m = rb.MjModel.from_binary_path(model_path)
+    if solver_id is not None:
+        m.opt.solver = solver_id
+    if integ_id is not None:
+        m.opt.integrator = integ_id
+    d = rb.MjData(m)
+    rng = np.random.Generator(np.random.PCG64(97))
+    nu = m.nu
+    ctrl = rng.uniform(cfg["ctrl"][0], cfg["ctrl"][1], size=(nenv, nstep, nu))
+    state = np.empty((nenv, nstep, s0.shape[1]))
+    state[:] = 0                                                   # (touch the pages: an RL loop reuses its output array)
+    ro.rollout(m, d, s0, ctrl, state=state)                        # warm-up: device model / batch cache, staging buffers
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out, _ = ro.rollout(m, d, s0, ctrl, state=state)
+        times.append(time.perf_counter() - t0)
+    t_api = min(times)
+    # the same rollout device-resident: arrays already in HBM, one launch
+    cd = torch.from_numpy(ctrl).to(dev); sd = torch.from_numpy(s0).to(dev)
+    od = torch.empty((nenv, nstep, s0.shape[1]), dtype=torch.float64, device=dev)
+    tdev = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch.rollout_device(nstep, ma.mjSTATE_CTRL, sd.data_ptr(), 0, cd.data_ptr(), od.data_ptr(), stream, cont=False)
+        torch.cuda.synchronize()
+        tdev.append(time.perf_counter() - t0)
+    t_dev = min(tdev)
+    same = bool(np.array_equal(od.cpu().numpy(), out))
+    return {"value": nenv*nstep/t_api, "unit": "env-steps/s", "envs": nenv, "steps": nstep, "seconds": t_api, "all_seconds": times,
+            "device_resident_value": nenv*nstep/t_dev, "ratio_to_device_resident": t_dev/t_api,
+            "host_mb_in": (ctrl.nbytes + s0.nbytes)/1e6, "host_mb_out": state.nbytes/1e6, "identical_to_device_resident": same,
+            "entry_point": "mujoco_amd.rollout.rollout(model, data, initial_state, control, state=preallocated) -> mjhip_rollout",
+            "note": "H2D of the controls and D2H of every step's state inside the timer, overlapped with the kernels in 50-step chunks"}
+
+
 LEGS = {
     # name: bench arguments of the sub-run (BASELINE configs[3], [4] per GPU, [0])
     "cube": ["--config", "cube", "--steps", "100", "--warmup", "20", "--parity-envs", "16"],
@@ -384,6 +435,8 @@ def main() -> None:
     ap.add_argument("--regime-steps", type=int, default=200, help="timed steps of the testspeed-regime leg")
     ap.add_argument("--regime-settle", type=int, default=1000, help="untimed settling steps of that leg")
     ap.add_argument("--parity-envs", type=int, default=64)
+    ap.add_argument("--api-steps", type=int, default=250,
+                    help="steps of the api_regime leg: mujoco_amd.rollout.rollout with numpy arrays in and out (0: skip)")
     ap.add_argument("--gather", choices=["per-chunk", "final"], default="per-chunk",
                     help="N > 1: per-chunk = every launch's per-step state array goes to rank 0 over RCCL, overlapped with the "
                          "next launch (north star's observation gather; the default); final = only the end-of-run final states")
@@ -659,6 +712,13 @@ def main() -> None:
                         "initial states as in the metric leg",
                 "end_state": {"warnings": int(batch.get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
                               "mean_nefc": float(cn[:, 1].mean()), "mean_pgs_iter": float(cn[:, 5].mean())}}
+
+    # ---------------- the drop-in entry point itself: host arrays in and out through mjhip_rollout ----------------
+    if rank == 0 and world == 1 and not args.no_extra and not args.leg and args.config == "humanoid" and args.api_steps > 0:
+        try:
+            res["api_regime"] = api_regime(model_path, solver_id, integ_id, nenv, args.api_steps, s0, cfg, batch, stream, dev)
+        except Exception as exc:
+            res["api_regime"] = {"error": repr(exc)}
 
     # ---------------- flex: the fall from the reset state, reported apart from the metric ----------------
     if not args.no_extra and cfg.get("free_fall_steps") and args.settle > 0:

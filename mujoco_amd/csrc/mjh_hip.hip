@@ -100,6 +100,21 @@ struct Backend {
   static bool d2h(void* dst, const void* src, size_t n, void* stream) {
     return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess;
   }
+  // `height` rows of `width` bytes between arrays of different row pitch (kind: 0 host->device, 1 device->host)
+  static bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int kind, void* stream) {
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice,
+                            (hipStream_t)stream) == hipSuccess;
+  }
+  // a second stream for copies that overlap the rollout kernel, and "stream b waits for what stream a has queued so far"
+  static void* stream_create() { hipStream_t st = nullptr; return hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess ? (void*)st : nullptr; }
+  static void stream_destroy(void* st) { if (st) (void)hipStreamDestroy((hipStream_t)st); }
+  static bool stream_follow(void* b, void* a) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return false;
+    bool ok = hipEventRecord(ev, (hipStream_t)a) == hipSuccess && hipStreamWaitEvent((hipStream_t)b, ev, 0) == hipSuccess;
+    (void)hipEventDestroy(ev);
+    return ok;
+  }
   static bool zero(void* dst, size_t n, void* stream) {
     return hipMemsetAsync(dst, 0, n, (hipStream_t)stream) == hipSuccess;
   }

@@ -811,9 +811,10 @@ struct StageBuf {
   }
   void release() { if (p) Backend::free(p); p = nullptr; cap = 0; }
 };
-struct mjhipStage_ { StageBuf state0, warm, control, state, sens; };
+struct mjhipStage_ { StageBuf state0, warm, control, state, sens; void* copy_in = nullptr; void* copy_out = nullptr; };
 static void stage_release(mjhipStage_* st) {
   st->state0.release(); st->warm.release(); st->control.release(); st->state.release(); st->sens.release();
+  Backend::stream_destroy(st->copy_in); Backend::stream_destroy(st->copy_out);
   delete st;
 }
 
@@ -855,7 +856,64 @@ static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned contro
   A.xfrc_off = CL.xfrc; A.eq_off = CL.eq; A.ud_off = CL.ud;
   A.nlaunch = (nlaunch && nlaunch < Bt->nenv) ? nlaunch : 0;
   A.init = (on_device & MJHIP_ROLLOUT_CONTINUE) ? 0 : 1;
+  A.pitch = nstep; A.tbase = 0;
   on_device &= MJHIP_ROLLOUT_ON_DEVICE;
+  // Host arrays, long rollouts: the rollout is launched in chunks of steps so that the copies overlap the kernels -- the
+  // controls of chunk k + 1 go up and the states / sensor data of chunk k - 1 come down while chunk k runs (two copy
+  // streams next to the caller's).  The device arrays keep the caller's layout [env][step][...], so a chunk is a strided
+  // block on both sides (2-D copies); the kernels address it through (pitch, tbase).  $MJHIP_ROLLOUT_CHUNK sets the chunk
+  // length (0: one launch, copies before and after it, as for short rollouts).
+  static const int chunk_steps = [] { const char* ev = getenv("MJHIP_ROLLOUT_CHUNK"); return ev ? atoi(ev) : 50; }();
+  if (!on_device && !Bt->soa && chunk_steps > 0 && nstep >= 2*chunk_steps && (state || sensordata)) {
+    if (!Bt->stage) Bt->stage = new mjhipStage_();
+    mjhipStage_* S = Bt->stage;
+    if (!S->copy_in) S->copy_in = Backend::stream_create();
+    if (!S->copy_out) S->copy_out = Backend::stream_create();
+    if (S->copy_in && S->copy_out) {
+      auto up = [&](StageBuf& b, const double* src, size_t n, const real** dst) -> bool {
+        if (!src || n == 0) { *dst = nullptr; return true; }
+        if (!b.ensure(n*sizeof(real))) return false;
+        *dst = (const real*)b.p;
+        return Backend::h2d(b.p, src, n*sizeof(real), stream);
+      };
+      bool ok = up(S->state0, state0, nenv*s.nstate, &A.state0) && up(S->warm, warmstart0, nenv*s.nv, &A.warmstart0);
+      const size_t crow = (size_t)nstep*CL.n*sizeof(real), srow = (size_t)nstep*s.nstate*sizeof(real),
+                   drow = (size_t)nstep*s.nsensordata*sizeof(real);
+      if (ok && control && CL.n) { ok = S->control.ensure(nenv*crow); A.control = (const real*)S->control.p; }
+      if (ok && state) { ok = S->state.ensure(nenv*srow); A.state = (real*)S->state.p; }
+      if (ok && sensordata) { ok = S->sens.ensure(nenv*drow); A.sensordata = (real*)S->sens.p; }
+      if (!ok) { set_err("mjhip_batch_rollout: staging allocation/copy failed"); return -3; }
+      const int nchunk = (nstep + chunk_steps - 1)/chunk_steps;
+      auto ctrl_up = [&](int k) -> bool {
+        if (!A.control || k >= nchunk) return true;
+        const int t0 = k*chunk_steps, c = std::min(chunk_steps, nstep - t0);
+        const size_t off = (size_t)t0*CL.n*sizeof(real);
+        return Backend::copy2d((char*)S->control.p + off, crow, (const char*)control + off, crow, (size_t)c*CL.n*sizeof(real), nenv, 0, S->copy_in);
+      };
+      // the uploads may not overwrite a staging buffer an earlier call's kernel still reads, nor the downloads race it
+      ok = Backend::stream_follow(S->copy_in, stream) && ctrl_up(0);
+      for (int k = 0; k < nchunk && ok; k++) {
+        const int t0 = k*chunk_steps, c = std::min(chunk_steps, nstep - t0);
+        ok = Backend::stream_follow(stream, S->copy_in);            // chunk k's controls have been queued on copy_in
+        if (ok) ok = ctrl_up(k + 1);                                 // (behind them: the next chunk's, overlapping kernel k)
+        A.nstep = c; A.tbase = t0;
+        if (ok) ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
+        A.init = 0;
+        if (ok) ok = Backend::stream_follow(S->copy_out, stream);   // the downloads of chunk k wait for kernel k only
+        if (ok && state) ok = Backend::copy2d((char*)state + (size_t)t0*s.nstate*sizeof(real), srow, (const char*)S->state.p + (size_t)t0*s.nstate*sizeof(real),
+                                              srow, (size_t)c*s.nstate*sizeof(real), nenv, 1, S->copy_out);
+        if (ok && sensordata) ok = Backend::copy2d((char*)sensordata + (size_t)t0*s.nsensordata*sizeof(real), drow,
+                                                   (const char*)S->sens.p + (size_t)t0*s.nsensordata*sizeof(real), drow,
+                                                   (size_t)c*s.nsensordata*sizeof(real), nenv, 1, S->copy_out);
+      }
+      if (ok && Bt->balance && !A.nlaunch) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
+      ok = Backend::sync(stream) && ok;
+      ok = Backend::sync(S->copy_out) && ok;
+      ok = Backend::sync(S->copy_in) && ok;
+      if (!ok) { set_err("mjhip_batch_rollout: chunked rollout (launch or copy) failed"); return -5; }
+      return 0;
+    }
+  }
   if (on_device) {
     A.state0 = state0; A.warmstart0 = warmstart0; A.control = control; A.state = state;
     A.sensordata = sensordata;

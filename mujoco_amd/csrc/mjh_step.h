@@ -640,7 +640,7 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
     // any warning freezes the trajectory: back-fill the rest with the current state (:135-155)
     int nw = 0;
     for (int k = 0; k < 8; k++) nw |= warn[k];
-    const size_t step = r*(size_t)A.nstep + t;
+    const size_t step = r*(size_t)A.pitch + A.tbase + t;
     if (!nw) {
       if (A.control) {
         MJH_TIMED(51, { rollout_load_control(M, B, e, A, A.control + step*A.ncontrol); wv_sync(); });

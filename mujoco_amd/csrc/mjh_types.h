@@ -871,5 +871,7 @@ struct RolloutArgs {
   real* sensordata;        // [nenv][nstep][nsensordata] or null
   int env_offset;          // first env of this launch inside state0/control/state
   int nlaunch;             // > 0: only environments [0, nlaunch) take part, in identity order (partial launch)
+  int pitch;               // steps of one environment's row in control / state / sensordata (>= tbase + nstep)
+  int tbase;               // this launch's first step inside those rows (the host-array path launches a rollout in chunks)
 };
 

@@ -114,6 +114,13 @@ struct Backend {
   static void free(void* p) { ::free(p); }
   static bool h2d(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
   static bool d2h(void* dst, const void* src, size_t n, void*) { memcpy(dst, src, n); return true; }
+  static bool copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, int, void*) {
+    for (size_t r = 0; r < height; r++) memcpy((char*)dst + r*dpitch, (const char*)src + r*spitch, width);
+    return true;
+  }
+  static void* stream_create() { return (void*)1; }      // (no streams on the host: a token, so that the chunked path runs)
+  static void stream_destroy(void*) {}
+  static bool stream_follow(void*, void*) { return true; }
   static bool zero(void* dst, size_t n, void*) { memset(dst, 0, n); return true; }
   static bool sync(void*) { return true; }
   static int max_lds() { return 160 * 1024; }   // (gfx950: a workgroup may take the whole CU block)

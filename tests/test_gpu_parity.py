@@ -1084,3 +1084,31 @@ def test_sparse_primal_solvers_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone
     exact = scene in DEVICE_EXACT_SCENES
     ints = _run(rb, hip_lib, make(), tmp_path, solver, cone, T, exact=exact, kind="devmath" if exact else None)
     assert ints[:, 1].max() > 0 and ints[:, 2].max() > 0
+
+
+def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden):
+    """`mujoco_amd.rollout.rollout` with numpy arrays (mjhip_rollout: chunked launches, strided copies overlapped with the
+    kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times, sensordata included"""
+    import torch
+    from mujoco_amd import rollout as ro
+    fx = golden("humanoid")
+    m = humanoid_pgs_oracle(rb)
+    d = rb.MjData(m)
+    n, T = 96, 230                                          # (4.6 chunks of 50 steps)
+    rng = np.random.default_rng(5)
+    s0 = np.ascontiguousarray(np.tile(fx["state0"], (n // fx["state0"].shape[0] + 1, 1))[:n])
+    s0[:, 1 + 7:1 + m.nq] += rng.normal(0, 0.02, size=(n, m.nq - 7))
+    ctrl = rng.uniform(-1, 1, size=(n, T, m.nu))
+    state, sens = ro.rollout(m, d, s0, ctrl)
+    assert state.shape == (n, T, s0.shape[1])
+    dmv = K.DeviceModel(hip_lib, m)
+    b = K.Batch(dmv, n)
+    dev = torch.device("cuda", 0)
+    sd, cd = torch.from_numpy(s0).to(dev), torch.from_numpy(ctrl).to(dev)
+    od = torch.empty((n, T, s0.shape[1]), dtype=torch.float64, device=dev)
+    b.rollout_device(T, K.mjSTATE_CTRL, sd.data_ptr(), 0, cd.data_ptr(), od.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(od.cpu().numpy(), state)
+    # and a second call reuses the cached batch / staging buffers / copy streams
+    state2, _ = ro.rollout(m, d, s0, ctrl)
+    assert np.array_equal(state2, state)

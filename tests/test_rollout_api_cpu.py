@@ -415,3 +415,25 @@ def test_rollout_shards_over_eight_devices_with_ragged_batch(rb, api, monkeypatc
     # the partition mjhip_rollout uses (one contiguous piece per device: [n*k/8, n*(k+1)/8))
     edges = [nbatch*k//8 for k in range(9)]
     assert edges[0] == 0 and edges[-1] == nbatch and all(b > a for a, b in zip(edges, edges[1:]))
+
+
+def test_long_host_rollout_runs_in_overlapped_chunks(rb, hostsim_lib, golden):
+    """host arrays, nstep >= 100: rollout_impl launches the rollout in 50-step chunks (controls up / states and sensor data
+    down as strided 2-D copies around the kernels, addressed through RolloutArgs.pitch / tbase).  The result has to be
+    the one-launch result: compared with the same rollout taken through device-resident arrays (on the emulation "device"
+    memory is host memory, so the device-pointer entry point can be fed numpy arrays), and with the golden trajectory."""
+    fx = golden("humanoid")
+    m = humanoid_pgs_oracle(rb)
+    dm = K.DeviceModel(hostsim_lib, m)
+    n, T = 3, fx["ctrl"].shape[1]
+    assert T >= 100
+    s0, ctrl = np.ascontiguousarray(fx["state0"][:n]), np.ascontiguousarray(fx["ctrl"][:n])
+    b = K.Batch(dm, n)
+    chunked = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    one = np.zeros_like(chunked)
+    b2 = K.Batch(dm, n)
+    b2.rollout_device(T, K.mjSTATE_CTRL, s0.ctypes.data, 0, ctrl.ctypes.data, one.ctypes.data)
+    b2.sync()
+    assert np.array_equal(chunked, one)
+    ref = fx["state"][:n]
+    assert np.max(np.abs(chunked - ref)/np.maximum(1.0, np.abs(ref))) <= 1e-6
