@@ -54,7 +54,7 @@ CONFIGS = {
                      metric="env-steps/sec on humanoid.xml, {nenv} envs/GPU"),
     # model/cube/cube_3x3x3.xml: Newton (default solver), implicitfast (:4), motors ctrlrange +-0.05 (:16), dt 0.01
     "cube": dict(mjb="cube_3x3x3.mjb", xml="model/cube/cube_3x3x3.xml", nenv=2048, solver=None, integrator=None,
-                 ctrl=(-0.05, 0.05), dt=0.01, free_root=False,
+                 ctrl=(-0.05, 0.05), dt=0.01, free_root=False, glibc_slack=0.01,
                  metric="env-steps/sec on cube_3x3x3.xml (convex mesh contacts, Newton), {nenv} envs/GPU"),
     # model/slider_crank/slider_crank.xml: position actuators ctrlrange +-0.1 (:10), default dt 0.002
     "slider_crank": dict(mjb="slider_crank.mjb", xml="model/slider_crank/slider_crank.xml", nenv=64, solver="pgs",
@@ -67,7 +67,7 @@ CONFIGS = {
     # reported separately as `free_fall_regime`, never under the metric's name
     "flex": dict(mjb="jelly.mjb", xml="model/flex/jelly.xml", nenv=256, solver=None, integrator=None,
                  ctrl=(0.0, 0.0), dt=0.001, free_root=False, settle=1000, warmup=20, solver_label="cg", integ_label="euler",
-                 parity_envs=2, free_fall_steps=100,
+                 parity_envs=8, free_fall_steps=100,
                  metric="env-steps/sec on flex/jelly.xml (512-vertex solid flex, CG, settled contact regime), {nenv} envs/GPU"),
 }
 
@@ -181,24 +181,29 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None
 
 
 def measured_traffic(steps_per_launch: int, nenv: int, model_xml: str = ""):
-    """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    same command (tools/gpu_profile.sh -> profiles/<round>/pmc_summary*.txt; FETCH_SIZE x2 per the
-    gfx950 correction of MI355X_MICROARCH.md).  None when no committed summary matches the workload."""
+    """HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same workload
+    (tools/gpu_profile.sh -> profiles/<round>/pmc_summary*.txt; FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md).  Only the summaries of profiles/CURRENT -- the directory measured on the committed build --
+    are consulted, for the same model and environment count; the counters are normalised per env-step and scaled to
+    this run's launch, so a summary taken at another steps-per-launch still applies (the kernel's traffic is
+    proportional to the steps it runs).  Returns (bytes per launch, source) or (None, None): never an older round's number."""
     import glob
-    best = None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary*.txt")))
-    # profiles/CURRENT names the directory measured on the committed build; it is read last (wins)
     cur = os.path.join(ROOT, "profiles", "CURRENT")
-    if os.path.exists(cur):
-        pref = os.path.join(ROOT, "profiles", open(cur).read().strip()) + os.sep
-        files = [f for f in files if not f.startswith(pref)] + [f for f in files if f.startswith(pref)]
-    for f in files:
+    if not os.path.exists(cur):
+        return None, None
+    pref = os.path.join(ROOT, "profiles", open(cur).read().strip())
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(pref, "pmc_summary*.txt"))):
         text = open(f).read()
         if model_xml and model_xml not in text:
             continue
         m = re.search(r"per launch \((\d+) steps x (\d+) envs\): read ([0-9.]+) MB raw / ([0-9.]+) MB with .*?written ([0-9.]+) MB", text)
-        if m and int(m.group(1)) == steps_per_launch and int(m.group(2)) == nenv:
-            best = (float(m.group(4)) + float(m.group(5))) * 1e6
+        if m and int(m.group(2)) == nenv:
+            per_env_step = (float(m.group(4)) + float(m.group(5))) * 1e6 / (int(m.group(1)) * nenv)
+            exact = int(m.group(1)) == steps_per_launch
+            if best[0] is None or exact:
+                best = (per_env_step * steps_per_launch * nenv,
+                        os.path.relpath(f, ROOT) + ("" if exact else f" (taken at {m.group(1)} steps per launch, scaled per env-step)"))
     return best
 
 
@@ -233,7 +238,7 @@ def measured_sq(config: str):
 
 
 def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, step_once, ctrl_range=(-1.0, 1.0), iter_exact=True,
-                  warm0=None):
+                  warm0=None, glibc_slack=0.0):
     """Re-step the sampled environments on the compiled reference (TEST INFRASTRUCTURE, used here
     as the checker only).  ctrl / gpu_state: [len(envs)][T][...] host arrays of the whole run
     (warm-up + timed).  Two builds of the reference are consulted (oracle/Makefile):
@@ -250,8 +255,10 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
       (2) identical inputs, EVERY step of the run: each (state, the oracle's warm start, control) of (1) is
           handed to the GPU for one mj_step (`step_once`, one batch of len(envs)*T environments); the next
           state must agree within 1e-6 and contact count, constraint count and solver iteration count exactly.
-    `ok`: (2) holds for every step against the device-libm build AND for at least 99 % of the steps against the glibc
-    build, with no count mismatch in either."""
+    `ok`: (2) holds for every step against the device-libm build AND against the glibc build -- except for the cube
+    (glibc_slack = 0.01: a model whose own reference moves by more than 1e-6 under a one-ulp change of the state on ~1 % of
+    its steps, tests/test_oracle_golden.py::test_cube_contact_discontinuity), where 99 % of the steps, floats and counts,
+    have to agree with glibc."""
     try:
         from oracle import refbind as rb
         if not rb.available():
@@ -315,8 +322,10 @@ def parity_sample(model_path, solver, integrator, s0, ctrl, gpu_state, envs, ste
         # (against glibc a step may differ in its last bit of sin / cos, which on ~1 % of the cube's steps moves a degenerate
         # contact -- floats and counts alike, tests/test_oracle_golden.py::test_cube_contact_discontinuity: the same 99 % gate
         # for both; against the device-libm build everything is exact)
+        # glibc_slack: the fraction of steps allowed to differ from the glibc build -- 0 except for the cube (0.01)
         out["ok"] = bool(dmath["max_rel_err"] <= 1e-6 and dmath["count_mismatches"] == 0 and
-                         g["frac_within_tolerance"] >= 0.99 and g["count_mismatches"] <= 0.01*g["steps"])
+                         g["frac_within_tolerance"] >= 1.0 - glibc_slack and g["count_mismatches"] <= glibc_slack*g["steps"])
+        out["glibc_slack"] = glibc_slack
     elif g is not None:
         out["ok"] = bool(g["max_rel_err"] <= 1e-6 and g["count_mismatches"] == 0)
     out["protocol"] = ("oracle/_ref mj_step from the same state0/controls over warm-up + timed region, re-synchronised to the GPU state "
@@ -622,6 +631,7 @@ def main() -> None:
         bytes_per_env_step = 8 * (2 * nstate + nu + 2 * nv)
         # one launch = C steps of nenv envs; achieved = algorithmic bytes per launch / avg launch time
         achieved = bytes_per_env_step * nenv * C / (launch_ms_timed * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(C, nenv, cfg["xml"])
         res = {
             "metric": cfg["metric"].format(nenv=nenv),
             "value": value,
@@ -645,7 +655,7 @@ def main() -> None:
                        "kernel_variant": batch.kernel_variant() if hasattr(batch, "kernel_variant") else "generic",
                        "layout": os.environ.get("MJHIP_LAYOUT", "aos")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(C, nenv, cfg["xml"]),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          **(measured_sq(args.config) or {}),
                          "kernel": batch.kernel_name(),
                          "steps_per_launch": C,
@@ -682,7 +692,8 @@ def main() -> None:
         try:
             res["parity_sample"] = parity_sample(model_path, solver_id, integ_id, snap_metric["state"][envs] if snap_metric else s0[envs], cs, gs, envs,
                                                  step_once, cfg["ctrl"], iter_exact=cfg.get("iter_exact", True),
-                                                 warm0=snap_metric["warm"][envs] if snap_metric else None)
+                                                 warm0=snap_metric["warm"][envs] if snap_metric else None,
+                                                 glibc_slack=cfg.get("glibc_slack", 0.0))
             if snap_metric:
                 res["parity_sample"]["start"] = f"the GPU batch's state and warm start after the {args.settle} settle steps"
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
@@ -750,14 +761,38 @@ def main() -> None:
                                           warm0=snap_metric["warm"] if snap_metric else None)
                 except Exception as exc:
                     leg = ({"error": repr(exc)}, None)
-                if leg:
-                    res.setdefault("cpu_baseline", {"value": leg[0].get("value"), "unit": "env-steps/s", "cores": ncpu,
-                                                    "kind": "reference", "sample": leg[0].get("sample")})
-                    res["cpu_baseline"]["rollout_regime"] = leg[0]
+                if leg and leg[0].get("value"):
+                    # `cpu_baseline.value` is the LIKE-FOR-LIKE figure: the reference stepping this run's own states and
+                    # controls; the testspeed binary's own (quieter / noisier) regime sits beside it
+                    ts = res.get("cpu_baseline")
+                    res["cpu_baseline"] = {"value": leg[0]["value"], "unit": "env-steps/s", "cores": ncpu, "kind": "reference",
+                                           "sample": leg[0].get("sample"), "rollout_regime": leg[0]}
+                    if ts:
+                        res["cpu_baseline"]["testspeed_regime"] = ts
+                elif leg:
+                    res.setdefault("cpu_baseline", {})["rollout_regime"] = leg[0]
         # ---------------- the other single-GPU BASELINE configurations, one short sub-run each ----------------
         if (args.config == "humanoid" and world == 1 and not args.no_extra and not args.no_legs and not args.leg
                 and not args.envs_per_gpu):
+            # (the legs are processes of their own on the same GPU: give the parent's batch back first)
+            try:
+                batch.close()
+                del state0
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
             res["configs"] = config_legs()
+            # what the driver's `parsed` keeps is `config`: the legs' headline figures go there too
+            res["config"]["legs"] = {
+                k: ({"value": v.get("value"), "roofline_frac": (v.get("roofline") or {}).get("frac"),
+                     "parity_ok": (v.get("parity_sample") or {}).get("ok"),
+                     "cpu_like_for_like": (v.get("cpu_baseline") or {}).get("value")} if "error" not in v else {"error": v["error"][-200:]})
+                for k, v in res["configs"].items()}
+            res["configs_ok"] = all("error" not in v and (v.get("parity_sample") or {}).get("ok") is True for v in res["configs"].values())
+        if "api_regime" in res and "value" in res["api_regime"]:
+            res["config"]["api_regime"] = {k: res["api_regime"].get(k) for k in ("value", "ratio_to_device_resident", "identical_to_device_resident")}
+        if "parity_sample" in res:
+            res["config"]["parity_ok"] = res["parity_sample"].get("ok")
         print(json.dumps(res), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -42,8 +42,8 @@ class ChunkGather:
     """The north star's "end-of-step observation gather": after every rollout launch (a chunk of steps)
     each rank's per-step state array [nlocal][c][nstate] travels to rank 0, asynchronously -- the
     collective is enqueued behind the producing kernel (NCCL/RCCL orders it after the work already on the
-    current stream and runs it on its own stream), so it overlaps the NEXT chunk's compute; wait() joins
-    everything outstanding.
+    current stream and runs it on its own stream), so it overlaps the NEXT chunk's compute (on CUDA the gathers are ordered on a side
+    stream: the compute stream never waits for one, whatever the number of slices); wait() joins everything outstanding.
 
     A chunk is streamed in SLICES of whole environments of at most `slice_bytes` per rank (default 64 MiB): rank 0
     keeps `depth` receive-buffer sets of one slice each -- depth x world x slice_bytes resident (1 GiB at 8 ranks)
@@ -55,10 +55,15 @@ class ChunkGather:
     """
 
     def __init__(self, rank: int, world: int, dist=None, depth: int = 2, slice_bytes: int = 64 << 20, sink=None,
-                 pad_to: int = 0):
+                 pad_to: int = 0, nenv_total: int = 0):
         self.rank, self.world, self.dist = rank, world, dist
         self.pad_to = int(pad_to)    # ragged splits: every rank pads its array to this many environments (the
                                      # collective needs equal shapes; rank 0's consumer trims by env_slice)
+        if nenv_total and world > 1:
+            # the split of env_slice(nenv_total, r, world): pad to its longest block, so that every rank -- one that owns
+            # no environment included -- issues the same number of equally shaped gathers
+            self.pad_to = max(self.pad_to, max((lambda sl: sl.stop - sl.start)(env_slice(nenv_total, r, world)) for r in range(world)))
+        self._side = None            # CUDA: the stream the gathers are ordered on (the compute stream never waits for them)
         self.depth = max(1, depth)
         self.slice_bytes = max(1, int(slice_bytes))
         self.sink = sink
@@ -93,28 +98,60 @@ class ChunkGather:
             pad = torch.zeros((self.pad_to - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], dim=0)
         nloc = local.shape[0]
+        if nloc == 0:
+            raise ValueError("ChunkGather.submit: a rank without environments has to pad (pass nenv_total or pad_to), "
+                             "or the ranks issue different numbers of collectives")
         per_env = max(1, (local.numel() // max(1, nloc)) * local.element_size())
         step = max(1, min(nloc, self.slice_bytes // per_env))
-        for lo in range(0, nloc, step):
-            piece = local[lo:lo + step]          # whole environments: a contiguous view
-            # (all ranks) a buffer set / send view is reused only after the gather that used it has completed
-            while len(self._pending) >= self.depth:
-                self._finish_one()
-            bufs = self._recv_set(piece) if self.rank == 0 else None
-            work = self.dist.gather(piece, bufs, dst=0, async_op=True)
-            self._pending.append((work, bufs, piece, self.chunks - 1, lo))
-            self.slices += 1
+        # On CUDA the whole exchange is ordered on a SIDE stream: it first waits for what the compute stream has queued
+        # (the kernel that produces `local`), the collectives are enqueued behind it, and recycling a receive-buffer set
+        # -- `work.wait()` makes the CURRENT stream wait for that gather -- stalls the side stream only.  The next rollout
+        # launch on the compute stream is never queued behind a gather, however many slices a chunk has.
+        ctx = None
+        if local.is_cuda:
+            import torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=local.device)
+            self._side.wait_stream(torch.cuda.current_stream(local.device))
+            local.record_stream(self._side)
+            ctx = torch.cuda.stream(self._side)
+            ctx.__enter__()
+        try:
+            for lo in range(0, nloc, step):
+                piece = local[lo:lo + step]          # whole environments: a contiguous view
+                # (all ranks) a buffer set / send view is reused only after the gather that used it has completed
+                while len(self._pending) >= self.depth:
+                    self._finish_one()
+                bufs = self._recv_set(piece) if self.rank == 0 else None
+                work = self.dist.gather(piece, bufs, dst=0, async_op=True)
+                self._pending.append((work, bufs, piece, self.chunks - 1, lo))
+                self.slices += 1
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
 
     def _finish_one(self):
-        work, bufs, _piece, chunk, lo = self._pending.pop(0)
-        work.wait()
-        if bufs is not None:
-            self.last = bufs
-            if self.sink is not None:
-                self.sink(chunk, lo, bufs)
+        work, bufs, piece, chunk, lo = self._pending.pop(0)
+        ctx = None
+        if piece.is_cuda and self._side is not None:
+            import torch
+            ctx = torch.cuda.stream(self._side)
+            ctx.__enter__()
+        try:
+            work.wait()
+            if bufs is not None:
+                self.last = bufs
+                if self.sink is not None:
+                    self.sink(chunk, lo, bufs)       # (runs on the side stream: the buffers are recycled in its order)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
 
     def wait(self):
         """join every outstanding gather; returns rank 0's last gathered per-rank tensors (else None)"""
         while self._pending:
             self._finish_one()
+        if self._side is not None:
+            import torch
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)    # the consumer reads `last` on the compute stream
         return self.last if self.rank == 0 else None

@@ -38,7 +38,8 @@ def main():
         for r, t in enumerate(bufs):
             got.setdefault(chunk, {})[(r, lo)] = t.numpy().copy()
 
-    obs = ChunkGather(rank, world, dist, depth=2, slice_bytes=8, sink=sink, pad_to=max(counts))
+    obs = ChunkGather(rank, world, dist, depth=2, slice_bytes=8, sink=sink, nenv_total=ntot)     # (pads ragged blocks itself)
+    assert obs.pad_to == max(counts)
     chunks = ((0, 3), (3, 6), (6, T))
     for ci, (c0, c1) in enumerate(chunks):
         obs.submit(torch.from_numpy(np.ascontiguousarray(out[:, c0:c1])))
