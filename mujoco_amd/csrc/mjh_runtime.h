@@ -156,6 +156,12 @@ static bool plan_lds(mjhipBatch_* Bt, int budget, unsigned executed,
     f.push_back(PlanField{#name, &L.l_##name, &L.io_##name, (int)(((size_t)(lcnt)*sizeof(int) + 7) & ~(size_t)7), (t0), (t1), -1});
   MJH_BATCH_INT_FIELDS(X)
 #undef X
+  // the convex narrowphase's row workspaces: a one-wavefront mapping uses rows 0..3 only (row = lane >> 4); the model sizes
+  // the field for a multi-wavefront workgroup's 4 MJH_MW rows (flex models) -- eight times what the other mappings can
+  // touch, taken ahead of every other field
+  if (Bt->variant != MJH_VAR_MULTIWAVE)
+    for (auto& x : f)
+      if (!strcmp(x.name, "ccd_row")) x.bytes = std::min(x.bytes, (int)((4*(size_t)s.ccd_row_reals*sizeof(real) + 7) & ~(size_t)7));
   budget &= ~7;
   // a field this kernel does not produce is copied in at kernel entry: it occupies its bytes from the
   // kernel's first stage on, whatever its nominal first write is
@@ -890,22 +896,33 @@ static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned contro
         const size_t off = (size_t)t0*CL.n*sizeof(real);
         return Backend::copy2d((char*)S->control.p + off, crow, (const char*)control + off, crow, (size_t)c*CL.n*sizeof(real), nenv, 0, S->copy_in);
       };
-      // the uploads may not overwrite a staging buffer an earlier call's kernel still reads, nor the downloads race it
+      auto state_down = [&](int k) -> bool {
+        const int t0 = k*chunk_steps, c = std::min(chunk_steps, nstep - t0);
+        bool okd = true;
+        if (state) okd = Backend::copy2d((char*)state + (size_t)t0*s.nstate*sizeof(real), srow, (const char*)S->state.p + (size_t)t0*s.nstate*sizeof(real),
+                                         srow, (size_t)c*s.nstate*sizeof(real), nenv, 1, S->copy_out);
+        if (okd && sensordata) okd = Backend::copy2d((char*)sensordata + (size_t)t0*s.nsensordata*sizeof(real), drow,
+                                                     (const char*)S->sens.p + (size_t)t0*s.nsensordata*sizeof(real), drow,
+                                                     (size_t)c*s.nsensordata*sizeof(real), nenv, 1, S->copy_out);
+        return okd;
+      };
+      // Copies between the device and PAGEABLE host memory (numpy arrays) keep the calling thread until they are done, so
+      // the order of the calls matters: kernel k is launched FIRST, then -- while it runs -- chunk k - 1 comes down and the
+      // controls of chunk k + 1 go up.  copy_in starts behind whatever the caller's stream still has queued (an earlier
+      // call's kernel may read the staging buffers); copy_out's copy of chunk k waits for kernel k through an event
+      // recorded right after that launch.
       ok = Backend::stream_follow(S->copy_in, stream) && ctrl_up(0);
       for (int k = 0; k < nchunk && ok; k++) {
         const int t0 = k*chunk_steps, c = std::min(chunk_steps, nstep - t0);
-        ok = Backend::stream_follow(stream, S->copy_in);            // chunk k's controls have been queued on copy_in
-        if (ok) ok = ctrl_up(k + 1);                                 // (behind them: the next chunk's, overlapping kernel k)
+        ok = Backend::stream_follow(stream, S->copy_in);            // kernel k waits for the uploads queued so far (chunk k's)
         A.nstep = c; A.tbase = t0;
         if (ok) ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
         A.init = 0;
-        if (ok) ok = Backend::stream_follow(S->copy_out, stream);   // the downloads of chunk k wait for kernel k only
-        if (ok && state) ok = Backend::copy2d((char*)state + (size_t)t0*s.nstate*sizeof(real), srow, (const char*)S->state.p + (size_t)t0*s.nstate*sizeof(real),
-                                              srow, (size_t)c*s.nstate*sizeof(real), nenv, 1, S->copy_out);
-        if (ok && sensordata) ok = Backend::copy2d((char*)sensordata + (size_t)t0*s.nsensordata*sizeof(real), drow,
-                                                   (const char*)S->sens.p + (size_t)t0*s.nsensordata*sizeof(real), drow,
-                                                   (size_t)c*s.nsensordata*sizeof(real), nenv, 1, S->copy_out);
+        if (ok && k > 0) ok = state_down(k - 1);                     // (copy_out already waits for kernel k - 1)
+        if (ok) ok = Backend::stream_follow(S->copy_out, stream);   // what copy_out is given next waits for kernel k
+        if (ok) ok = ctrl_up(k + 1);
       }
+      if (ok) ok = state_down(nchunk - 1);
       if (ok && Bt->balance && !A.nlaunch) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
       ok = Backend::sync(stream) && ok;
       ok = Backend::sync(S->copy_out) && ok;

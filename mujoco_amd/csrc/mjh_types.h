@@ -707,7 +707,9 @@ typedef const MJH_CONST_AS DBatch& BREF;
 // the workgroup's LDS block
 #ifdef MJH_HOSTSIM
 #define MJH_LDS_MAX (160 * 1024)
-namespace mjhsim { extern thread_local char g_lds[MJH_LDS_MAX]; }
+// (the emulated block ENDS at an inaccessible page: an access beyond the launch's allocation faults, as a flat access
+// beyond a workgroup's LDS allocation does on the device -- tests/hostsim/hostsim.cpp: lds_block)
+namespace mjhsim { extern thread_local char* g_lds; }
 MJH_DEV char* mjh_lds() { return mjhsim::g_lds; }
 #else
 // The block is the launch's dynamic LDS allocation; the kernels declare no static __shared__

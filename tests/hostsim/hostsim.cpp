@@ -13,6 +13,8 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <algorithm>
 
 #include "../../mujoco_amd/csrc/mjh_spmd.h"
@@ -22,7 +24,7 @@
 
 namespace mjhsim {
 thread_local WaveSim* g_wave = nullptr;
-thread_local char g_lds[MJH_LDS_MAX];     // the emulated workgroup's LDS block
+thread_local char* g_lds = nullptr;       // the emulated workgroup's LDS block (set per launch: lds_block)
 }
 
 #include "../../mujoco_amd/csrc/mjh_modes.h"
@@ -126,7 +128,37 @@ struct Backend {
   static int max_lds() { return 160 * 1024; }   // (gfx950: a workgroup may take the whole CU block)
   static int num_cus() { return 256; }
   // a fresh workgroup sees garbage in LDS: poison it so stale-data bugs cannot hide
-  static void poison_lds(int lds) { memset(mjhsim::g_lds, 0xff, lds > 0 ? (size_t)lds : 0); }
+  // The block of a launch that allocates `lds` bytes ends (up to alignment) at a PROT_NONE page, and the alignment slack
+  // in between holds a canary that is checked when the next launch re-uses the region: a flat access beyond a
+  // workgroup's LDS allocation raises HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the device (profiles/r04/
+  // negative_results.txt #6 met one that the emulation, with its fixed 160 KB array, let through).
+  struct LdsRegion { char* base = nullptr; char* guard = nullptr; size_t slack = 0; };
+  static LdsRegion& lds_region() {
+    static thread_local LdsRegion R;
+    if (!R.base) {
+      const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+      const size_t bytes = ((size_t)MJH_LDS_MAX + 512 + page - 1)/page*page;
+      const size_t guard_bytes = ((size_t)2*MJH_LDS_MAX + page - 1)/page*page;      // (any offset a 160 KB plan could produce)
+      R.base = (char*)mmap(nullptr, bytes + guard_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (R.base == (char*)MAP_FAILED) { perror("hostsim: mmap"); abort(); }
+      R.guard = R.base + bytes;
+      if (mprotect(R.guard, guard_bytes, PROT_NONE)) { perror("hostsim: mprotect"); abort(); }
+    }
+    return R;
+  }
+  static void poison_lds(int lds) {
+    LdsRegion& R = lds_region();
+    if (mjhsim::g_lds && R.slack) {
+      for (size_t i = 0; i < R.slack; i++)
+        if ((unsigned char)R.guard[-(long)R.slack + (long)i] != 0xA5) { fprintf(stderr, "hostsim: write beyond the LDS allocation (slack byte %zu)\n", i); abort(); }
+    }
+    const size_t n = lds > 0 ? (size_t)lds : 0;
+    const size_t aligned = (n + 255)/256*256;
+    mjhsim::g_lds = R.guard - aligned;
+    R.slack = aligned - n;
+    memset(mjhsim::g_lds, 0xff, n);
+    memset(mjhsim::g_lds + n, 0xA5, R.slack);
+  }
   // run NS's body for the nsub environments of every emulated wavefront (lanes of group g step
   // environment wave*nsub + g; a group past the end of the batch exits at once, like the kernels)
   // multi-wavefront workgroups (mjh_modes.h: wn + wq): fibers 0..63 are wave 0, the others the helper wavefronts
@@ -239,4 +271,16 @@ extern "C" __attribute__((visibility("default"))) void mjh_test_sincos(int n, co
 // likewise the device's atan2 and exp
 extern "C" __attribute__((visibility("default"))) void mjh_test_atan2_exp(int n, const double* y, const double* x, double* at, double* ex) {
   for (int i = 0; i < n; i++) { at[i] = mjh_atan2(y[i], x[i]); ex[i] = mjh_exp(x[i]); }
+}
+// test hook for the emulation's LDS bounds: a launch that allocates `lds` bytes, then one access at byte `offset` of the
+// block.  Beyond the allocation (rounded up to 256) the read faults like a flat access beyond a workgroup's LDS
+// allocation does on the device (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION); a write into the rounding slack is caught
+// by the canary check of the next launch.
+extern "C" __attribute__((visibility("default"))) int mjh_test_lds_probe(int lds, int offset, int write) {
+  Backend::poison_lds(lds);
+  volatile char* p = mjh_lds() + offset;
+  if (write) *p = 1;
+  const int v = *p;
+  Backend::poison_lds(lds);          // (checks the canary the first launch left)
+  return v;
 }

@@ -1088,9 +1088,23 @@ def test_sparse_primal_solvers_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone
 
 def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden):
     """`mujoco_amd.rollout.rollout` with numpy arrays (mjhip_rollout: chunked launches, strided copies overlapped with the
-    kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times, sensordata included"""
-    import torch
+    kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times.  (Device arrays through
+    the HIP runtime the library itself is linked against: initialising torch's own copy of the runtime after libmjhip
+    has initialised HIP fails with "No HIP GPUs are available".)"""
+    import ctypes as C
     from mujoco_amd import rollout as ro
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def dev_array(nbytes, src=None):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        if src is not None:
+            assert hip.hipMemcpy(p, src.ctypes.data, nbytes, 1) == 0        # hipMemcpyHostToDevice
+        return p
+
     fx = golden("humanoid")
     m = humanoid_pgs_oracle(rb)
     d = rb.MjData(m)
@@ -1103,12 +1117,14 @@ def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip
     assert state.shape == (n, T, s0.shape[1])
     dmv = K.DeviceModel(hip_lib, m)
     b = K.Batch(dmv, n)
-    dev = torch.device("cuda", 0)
-    sd, cd = torch.from_numpy(s0).to(dev), torch.from_numpy(ctrl).to(dev)
-    od = torch.empty((n, T, s0.shape[1]), dtype=torch.float64, device=dev)
-    b.rollout_device(T, K.mjSTATE_CTRL, sd.data_ptr(), 0, cd.data_ptr(), od.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert np.array_equal(od.cpu().numpy(), state)
+    sd, cd = dev_array(s0.nbytes, s0), dev_array(ctrl.nbytes, ctrl)
+    od = dev_array(state.nbytes)
+    b.rollout_device(T, K.mjSTATE_CTRL, sd.value, 0, cd.value, od.value)
+    b.sync()
+    one = np.empty_like(state)
+    assert hip.hipMemcpy(one.ctypes.data, od, state.nbytes, 2) == 0        # hipMemcpyDeviceToHost
+    for p in (sd, cd, od): hip.hipFree(p)
+    assert np.array_equal(one, state)
     # and a second call reuses the cached batch / staging buffers / copy streams
     state2, _ = ro.rollout(m, d, s0, ctrl)
     assert np.array_equal(state2, state)

@@ -1194,3 +1194,26 @@ def test_broadphase_emulation_closes_the_touching_gap(rb, hostsim_lib, tmp_path,
                     d_off += 1
     assert d_on == 0
     assert d_off > 0, "these scenes are supposed to expose the conservative pair list"
+
+
+def test_emulated_lds_block_faults_beyond_the_launch_allocation(hostsim_lib):
+    """profiles/r04/negative_results.txt #6: a variant that kept a scratch array "in the unused tail of the LDS block" was
+    bit-exact on the emulation and died on the GPU with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- a flat access beyond
+    the workgroup's LDS allocation, which the emulation (then a fixed 160 KB array) let through.  The emulated block now
+    ends at an inaccessible page: an access beyond the launch's allocation kills the process, a write into the
+    alignment slack trips a canary.  (Probes run in subprocesses: they are supposed to die.)"""
+    import subprocess, sys, textwrap
+    from conftest import HOSTSIM_LIB
+    def probe(lds, offset, write):
+        code = textwrap.dedent(f"""
+            import ctypes
+            lib = ctypes.CDLL({HOSTSIM_LIB!r})
+            lib.mjh_test_lds_probe.restype = ctypes.c_int
+            print(lib.mjh_test_lds_probe({lds}, {offset}, {write}))
+        """)
+        return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    ok = probe(10240, 10239, 1)
+    assert ok.returncode == 0 and ok.stdout.strip() == "1"
+    assert probe(10240, 10240 + 4096, 0).returncode < 0          # read far beyond the allocation: SIGSEGV
+    assert probe(10240 + 8, 10240 + 256, 0).returncode < 0       # the first byte behind the (256-byte aligned) block
+    assert probe(10240 + 8, 10240 + 100, 1).returncode != 0      # write into the alignment slack: canary abort
