@@ -340,7 +340,8 @@ def api_regime(model_path, solver_id, integ_id, nenv, nstep, s0, cfg, batch, str
     """The drop-in entry point as a caller uses it: `mujoco_amd.rollout.rollout(model, data, initial_state, control,
     state=...)` with numpy arrays (python/mujoco/rollout.py's signature; underneath `mjhip_rollout`, include/mjhip.h:192 =
     `_unsafe_rollout`'s contract, rollout.cc:74-178): controls go host -> device and the per-step states come back inside the
-    timer.  The rollout is launched in chunks of 50 steps whose copies overlap the kernels (mjh_runtime.h: rollout_impl).
+    timer: one launch, the controls copied up before it and the states down after it (launching in chunks with overlapped
+    copies measured slower -- profiles/r05/api_rate.txt, mjh_runtime.h: rollout_impl, $MJHIP_ROLLOUT_CHUNK).
     Next to it the same work device-resident (one launch of `nstep` steps from the same state0 / controls), the rate
     `value` is the ceiling of.  mjModel / mjData are the CALLER's objects: here made by the compiled reference standing in
     for the caller's MuJoCo (as in tests/); the product only reads mjModel and writes the last state into mjData."""
@@ -384,7 +385,7 @@ def api_regime(model_path, solver_id, integ_id, nenv, nstep, s0, cfg, batch, str
             "device_resident_value": nenv*nstep/t_dev, "ratio_to_device_resident": t_dev/t_api,
             "host_mb_in": (ctrl.nbytes + s0.nbytes)/1e6, "host_mb_out": state.nbytes/1e6, "identical_to_device_resident": same,
             "entry_point": "mujoco_amd.rollout.rollout(model, data, initial_state, control, state=preallocated) -> mjhip_rollout",
-            "note": "H2D of the controls and D2H of every step's state inside the timer, overlapped with the kernels in 50-step chunks"}
+            "note": "H2D of the controls and D2H of every step's state inside the timer (pageable numpy arrays, one launch in between)"}
 
 
 LEGS = {

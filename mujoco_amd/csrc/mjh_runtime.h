@@ -868,8 +868,12 @@ static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned contro
   // controls of chunk k + 1 go up and the states / sensor data of chunk k - 1 come down while chunk k runs (two copy
   // streams next to the caller's).  The device arrays keep the caller's layout [env][step][...], so a chunk is a strided
   // block on both sides (2-D copies); the kernels address it through (pitch, tbase).  $MJHIP_ROLLOUT_CHUNK sets the chunk
-  // length (0: one launch, copies before and after it, as for short rollouts).
-  static const int chunk_steps = [] { const char* ev = getenv("MJHIP_ROLLOUT_CHUNK"); return ev ? atoi(ev) : 50; }();
+  // length (0, the default: one launch, copies before and after it).
+  // (measured on MI355X, humanoid 4096 x 250 steps, profiles/r05/api_rate.txt: ONE launch with the copies before and after it
+  // reaches 0.89 of the device-resident rate -- pageable 1-D copies run at ~50 GB/s --, while 2 / 3 / 5 chunks reach 0.76 / 0.68 /
+  // 0.61: every launch ends with its stragglers, and the strided 2-D copies are slower than the 12 ms they hide.  So the
+  // default is one launch; the chunked path stays selectable.)
+  const int chunk_steps = [] { const char* ev = getenv("MJHIP_ROLLOUT_CHUNK"); return ev ? atoi(ev) : 0; }();
   if (!on_device && !Bt->soa && chunk_steps > 0 && nstep >= 2*chunk_steps && (state || sensordata)) {
     if (!Bt->stage) Bt->stage = new mjhipStage_();
     mjhipStage_* S = Bt->stage;

@@ -1086,13 +1086,14 @@ def test_sparse_primal_solvers_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone
     assert ints[:, 1].max() > 0 and ints[:, 2].max() > 0
 
 
-def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden):
+def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden, monkeypatch):
     """`mujoco_amd.rollout.rollout` with numpy arrays (mjhip_rollout: chunked launches, strided copies overlapped with the
     kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times.  (Device arrays through
     the HIP runtime the library itself is linked against: initialising torch's own copy of the runtime after libmjhip
     has initialised HIP fails with "No HIP GPUs are available".)"""
     import ctypes as C
     from mujoco_amd import rollout as ro
+    monkeypatch.setenv("MJHIP_ROLLOUT_CHUNK", "50")          # (the second call below runs with the default: one launch)
     hip = C.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -1125,6 +1126,7 @@ def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip
     assert hip.hipMemcpy(one.ctypes.data, od, state.nbytes, 2) == 0        # hipMemcpyDeviceToHost
     for p in (sd, cd, od): hip.hipFree(p)
     assert np.array_equal(one, state)
-    # and a second call reuses the cached batch / staging buffers / copy streams
+    # and a second call reuses the cached batch / staging buffers -- as ONE launch (the default)
+    monkeypatch.delenv("MJHIP_ROLLOUT_CHUNK")
     state2, _ = ro.rollout(m, d, s0, ctrl)
     assert np.array_equal(state2, state)

@@ -417,11 +417,12 @@ def test_rollout_shards_over_eight_devices_with_ragged_batch(rb, api, monkeypatc
     assert edges[0] == 0 and edges[-1] == nbatch and all(b > a for a, b in zip(edges, edges[1:]))
 
 
-def test_long_host_rollout_runs_in_overlapped_chunks(rb, hostsim_lib, golden):
-    """host arrays, nstep >= 100: rollout_impl launches the rollout in 50-step chunks (controls up / states and sensor data
+def test_long_host_rollout_runs_in_overlapped_chunks(rb, hostsim_lib, golden, monkeypatch):
+    """host arrays, $MJHIP_ROLLOUT_CHUNK = 50, nstep >= 100: rollout_impl launches the rollout in 50-step chunks (controls up / states and sensor data
     down as strided 2-D copies around the kernels, addressed through RolloutArgs.pitch / tbase).  The result has to be
     the one-launch result: compared with the same rollout taken through device-resident arrays (on the emulation "device"
     memory is host memory, so the device-pointer entry point can be fed numpy arrays), and with the golden trajectory."""
+    monkeypatch.setenv("MJHIP_ROLLOUT_CHUNK", "50")          # (the default is one launch: see rollout_impl)
     fx = golden("humanoid")
     m = humanoid_pgs_oracle(rb)
     dm = K.DeviceModel(hostsim_lib, m)
