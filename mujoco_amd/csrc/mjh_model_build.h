@@ -18,6 +18,7 @@
 #include <string>
 #include <functional>
 #include <vector>
+#include <map>
 
 #include "mjh_types.h"
 
@@ -170,11 +171,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->flex_edgeequality[f] != 0 && m->flex_edgeequality[f] != 1, "flex vertex / strain equality constraints");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
-    // mj_flexCG (engine_forward.c:1640): CG with an implicit integrator and pyramidal cones runs deformable flexes under the
-    // implicit effective metric (mjd_effBuild / mjd_effMulAdd / mjd_effPrec) -- not built
-    MJH_REJECT(m->opt.solver == mjSOL_CG && (m->opt.integrator == mjINT_IMPLICIT || m->opt.integrator == mjINT_IMPLICITFAST) &&
-               m->opt.cone != mjCONE_ELLIPTIC && !m->flex_rigid[f] && m->flex_dim[f] >= 2,
-               "flexes under CG with an implicit integrator (the reference's implicit effective metric, mj_flexCG)");
   }
   MJH_REJECT(m->nplugin > 0, "plugins");
   for (int i = 0; i < m->nsensor; i++) {
@@ -1582,6 +1578,136 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       }
       if (s.nflexdof) H->flexdof_vadr[s.nflexdof] = (int)H->flexdof_vert.size();
       s.nflexdofv = (int)H->flexdof_vert.size();
+    }
+
+    // ---------------- implicit effective metric (mjh_effmetric.h) ----------------
+    // mj_flexCG (engine_forward.c:1640): CG + implicit / implicitfast + pyramidal cones + a flex with implicit stiffness: the
+    // solve runs in the metric M + K, K = (h^2 + h damping)(K_bend + K_stretch) assembled per step into a dof-level CSR
+    // (mjd_flexStiff_assemble, engine_derivative.c:1810).  Its STRUCTURE is static for standard flexes: vertex slots (bodies
+    // with three dofs), neighbours through bending flaps and element cliques, sorted by dof address -- built here together
+    // with, per 3 x 3 block, the list of its contributions in the reference's order of accumulation.
+    s.efm = 0;
+    H->efm_rownnz.clear(); H->efm_rowadr.clear(); H->efm_colind.clear(); H->efm_slotvert.clear(); H->efm_slotdiag.clear();
+    H->efm_vertslot.clear(); H->efmblk_slot.clear(); H->efmblk_pos.clear(); H->efmblk_cadr.assign(1, 0); H->efmblk_c.clear(); H->efmblk_cij.clear();
+    {
+      bool implicit_stiff = false, has_stretch = false;
+      for (int f = 0; f < nf; f++) {
+        if (m->flex_rigid[f]) continue;
+        MJH_REJECT(m->flex_interp[f] != 0, "interpolated (trilinear / quadratic) flexes");      // (rejected above already)
+        if (m->flex_dim[f] == 2 && m->flex_bendingadr[f] >= 0) implicit_stiff = true;
+        if (m->flex_dim[f] >= 2 && m->flex_stiffnessadr[f] >= 0 && m->flex_stiffness[m->flex_stiffnessadr[f]] != 0) { implicit_stiff = true; has_stretch = true; }
+      }
+      const bool flexcg = m->opt.solver == mjSOL_CG && (m->opt.integrator == mjINT_IMPLICIT || m->opt.integrator == mjINT_IMPLICITFAST) &&
+                          m->opt.cone != mjCONE_ELLIPTIC && implicit_stiff;
+      if (flexcg) {
+        // (bending alone: the reference keeps the stencil operator and a constant sparse factor from mj_setConst -- not built;
+        // vertices with one or two dofs of their own: mjd_flexStretch_mul reads three consecutive dofs at their address)
+        MJH_REJECT(!has_stretch, "the implicit effective metric of a flex with bending stiffness only (constant factor of mj_setConst)");
+        MJH_REJECT(m->nv <= 128, "the implicit effective metric (mj_flexCG) in models of at most 128 degrees of freedom");
+        for (int v = 0; v < m->nflexvert; v++) {
+          const int b = m->flex_vertbodyid[v], f = 0;
+          (void)f;
+          MJH_REJECT(m->body_dofnum[b] != 0 && !(m->body_dofnum[b] == 3 && m->body_simple[b] == 2),
+                     "the implicit effective metric with flex vertices that are not three sliders of their own (or pinned)");
+        }
+        s.efm = 1;
+        std::vector<int> vslot(m->nflexvert, -1), vdof;
+        auto active = [&](int f) {
+          if (m->flex_interp[f] || m->flex_rigid[f] || m->flex_dim[f] < 2) return false;
+          const bool bend = m->flex_bendingadr[f] >= 0;
+          const bool stretch = m->flex_stiffnessadr[f] >= 0 && m->flex_stiffness[m->flex_stiffnessadr[f]] != 0;
+          return bend || stretch;
+        };
+        for (int f = 0; f < nf; f++) {
+          if (!active(f)) continue;
+          for (int lv = 0; lv < m->flex_vertnum[f]; lv++) {
+            const int gv = m->flex_vertadr[f] + lv;
+            if (m->body_dofnum[m->flex_vertbodyid[gv]] == 3) { vslot[gv] = (int)vdof.size(); vdof.push_back(m->body_dofadr[m->flex_vertbodyid[gv]]); H->efm_slotvert.push_back(gv); }
+          }
+        }
+        const int nvert = (int)vdof.size();
+        // candidate neighbours (with duplicates), in the reference's order; contributions keyed by (slot, neighbour slot)
+        struct Con { int kind_id, cij; };
+        std::vector<std::vector<int>> cand(nvert);
+        std::map<std::pair<int, int>, std::vector<Con>> cons;
+        for (int f = 0; f < nf; f++) {
+          if (!active(f)) continue;
+          const int dim = m->flex_dim[f], nvrt = dim + 1, va = m->flex_vertadr[f];
+          if (m->flex_bendingadr[f] >= 0 && dim == 2) {
+            for (int e = 0; e < m->flex_edgenum[f]; e++) {
+              const int* edge = m->flex_edge + 2*(e + m->flex_edgeadr[f]);
+              const int* flap = m->flex_edgeflap + 2*(e + m->flex_edgeadr[f]);
+              if (flap[1] == -1) continue;
+              const int v[4] = {edge[0], edge[1], flap[0], flap[1]};
+              for (int i = 0; i < 4; i++) {
+                const int si = vslot[va + v[i]];
+                if (si < 0) continue;
+                for (int j = 0; j < 4; j++) {
+                  const int sj = vslot[va + v[j]];
+                  if (sj < 0) continue;
+                  cand[si].push_back(sj);
+                  cons[{si, sj}].push_back({0 | ((m->flex_edgeadr[f] + e) << 1), (i << 2) | j});
+                }
+              }
+            }
+          }
+          if (m->flex_stiffnessadr[f] >= 0 && m->flex_stiffness[m->flex_stiffnessadr[f]] != 0) {
+            const int* elem = m->flex_elem + m->flex_elemdataadr[f];
+            for (int t = 0; t < m->flex_elemnum[f]; t++) {
+              const int* vert = elem + (dim + 1)*t;
+              for (int i = 0; i < nvrt; i++) {
+                const int si = vslot[va + vert[i]];
+                if (si < 0) continue;
+                for (int j = 0; j < nvrt; j++) {
+                  const int sj = vslot[va + vert[j]];
+                  if (sj < 0) continue;
+                  cand[si].push_back(sj);
+                  cons[{si, sj}].push_back({1 | ((m->flex_elemadr[f] + t) << 1), (i << 2) | j});
+                }
+              }
+            }
+          }
+        }
+        // NOTE: the reference accumulates bending of flex f, then stretch of flex f, flex by flex, into zeroed values: a
+        // block belongs to one flex, so its list above is already in that order
+        std::vector<int> nadr(nvert + 1, 0), neigh;
+        for (int sl = 0; sl < nvert; sl++) {
+          std::vector<int>& c = cand[sl];
+          std::stable_sort(c.begin(), c.end(), [&](int a, int b) { return vdof[a] < vdof[b]; });     // (insertion sort by dof address: stable)
+          nadr[sl] = (int)neigh.size();
+          for (size_t i = 0; i < c.size(); i++) if ((int)neigh.size() == nadr[sl] || neigh.back() != c[i]) neigh.push_back(c[i]);
+        }
+        nadr[nvert] = (int)neigh.size();
+        H->efm_rownnz.assign(m->nv, 0);
+        H->efm_rowadr.assign(m->nv, 0);
+        for (int sl = 0; sl < nvert; sl++) for (int k = 0; k < 3; k++) H->efm_rownnz[vdof[sl] + k] = 3*(nadr[sl + 1] - nadr[sl]);
+        for (int i = 1; i < m->nv; i++) H->efm_rowadr[i] = H->efm_rowadr[i - 1] + H->efm_rownnz[i - 1];
+        int nnz = 0;
+        for (int i = 0; i < m->nv; i++) nnz += H->efm_rownnz[i];
+        H->efm_colind.assign(nnz, 0);
+        H->efm_slotdiag.assign(nvert, -1);
+        for (int sl = 0; sl < nvert; sl++) {
+          for (int k = 0; k < 3; k++) {
+            int adr = H->efm_rowadr[vdof[sl] + k];
+            for (int j = nadr[sl]; j < nadr[sl + 1]; j++) for (int c = 0; c < 3; c++) H->efm_colind[adr++] = vdof[neigh[j]] + c;
+          }
+          for (int j = nadr[sl]; j < nadr[sl + 1]; j++) {
+            const int pos = j - nadr[sl];
+            if (neigh[j] == sl) H->efm_slotdiag[sl] = pos;
+            H->efmblk_slot.push_back(sl);
+            H->efmblk_pos.push_back(pos);
+            for (const Con& c : cons[{sl, neigh[j]}]) { H->efmblk_c.push_back(c.kind_id); H->efmblk_cij.push_back(c.cij); }
+            H->efmblk_cadr.push_back((int)H->efmblk_c.size());
+          }
+          MJH_REJECT(H->efm_slotdiag[sl] < 0, "internal: effective-metric diagonal block");
+        }
+        // the covered dofs come in the triples of the slots, ascending (effBlocks walks the covered rows)
+        for (int sl = 1; sl < nvert; sl++) MJH_REJECT(vdof[sl] <= vdof[sl - 1], "internal: effective-metric slots not in dof order");
+        H->efm_vertslot = vslot;
+        s.nefmrow = m->nv; s.nefmK = nnz; s.nefmslot = nvert; s.nefmvert = m->nflexvert;
+        s.nefmblk = (int)H->efmblk_slot.size(); s.nefmcon = (int)H->efmblk_c.size();
+      }
+      if (!s.efm) { s.nefmrow = s.nefmK = s.nefmslot = s.nefmvert = s.nefmblk = s.nefmcon = 0; H->efmblk_cadr.assign(1, 0); }
     }
     H->flexvert_bend.resize((size_t)4*s.nflexbend, 0);
     // flexedge_J by column, entries in ascending edge order (the order mj_springdamper adds edge forces to a dof, :770-787)

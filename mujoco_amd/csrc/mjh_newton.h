@@ -442,7 +442,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // plan) -- the addends of the iteration's ordered sums, which the passes leave there --, and Ma, Mv, Mgrad, which only
   // the passes touch, in global memory.  (An island that does not span every dof takes the unfused code on the same
   // pointers; its three difference vectors use the product vectors' bytes.)
-  const int fuse_ok = SPA == 2 && !flg_newton && s.nC == nv && !B.soa;
+  // implicit effective metric (mj_flexCG; mjh_effmetric.h): after the warm start the solve is ONE problem over every dof
+  // (mj_fwdConstraint forces the monolithic solver, engine_forward.c:1187), Ma / Mv carry + K, the preconditioner is the
+  // block one, and qfrc_smooth is shifted by efm_c (PrimalAllocate, engine_solver.c:1358-1365)
+  const int efm = SPA == 2 && !ELL && !flg_newton && MJH_HAS(MJH_FT_FLEX) && s.efm;
+  int efm_on = 0;
+  const int fuse_ok = SPA == 2 && !flg_newton && s.nC == nv && !B.soa && !efm;
   real* prodv = nullptr;
   if (fuse_ok) {
     const rptr gp = MJH_G(B, csr_prod, e);
@@ -460,9 +465,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
   // ---- islands (engine_forward.c:1187-1212).  Exact when the solve is one problem over every dof; with
   // several islands, or an island that leaves trees out, dofs / rows outside the island are masked
-  const int nisl_raw = counts[MJH_C_NISLAND];
-  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
-  const int multi_tree = (s.ntree > 1) && (nisl_raw > 0);
+  int nisl_raw = counts[MJH_C_NISLAND];
+  int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  int multi_tree = (s.ntree > 1) && (nisl_raw > 0);
   ciptr tree_island = MJH_G(B, island_work, e) + s.nefcmax + s.ntree;   // left by stage_island
   int isl = 0;
   auto in_dof = [&](int i) { return !multi_tree || tree_island[M.dof_treeid[i]] == isl; };
@@ -490,7 +495,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // product vector the solver works on an LDS copy, and every ordered sum of the iteration is a direct one)
     // (the staging block below may then fall back to global memory: with qfrc_smooth in LDS no sum of the iteration is staged)
     // (fused passes: the sums read product vectors, never qfrc_smooth itself)
-    if (!fuse_ok && fb >= nv*(int)sizeof(real)) {
+    if (!fuse_ok && !efm && fb >= nv*(int)sizeof(real)) {
       fb -= nv*(int)sizeof(real);
       real* c = (real*)(P.free_p + fb);
       for (int i0 = lane; i0 < nv; i0 += MJH_NVU*MJH_W) {
@@ -547,7 +552,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // out = M v in mju_mulSymVecSparse's order: diagonal, own row right to left, then the column's
   // entries by ascending row
   auto mul_M = [&](rptr out, crptr v) {
-    if (SPA == 2 && s.nC == nv) {
+    if (SPA == 2 && s.nC == nv && !efm) {
       // (diagonal mass matrix -- every dof a slider of its own body: row t is the single entry Ms[t])
       for (int t0 = lane; t0 < nv; t0 += MJH_NVU*MJH_W) {
         real a[MJH_NVU], b[MJH_NVU];
@@ -557,6 +562,13 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         for (int u = 0; u < MJH_NVU; u++) if (t0 + u*MJH_W < nv) out[t0 + u*MJH_W] = a[u]*b[u];
       }
       wv_sync();
+      return;
+    }
+    if (SPA == 2 && efm) {
+#if !MJH_LANE_MODE
+      eff_mul_M(M, B, e, out, v);
+      if (efm_on) eff_mul_add(M, B, e, out, v);
+#endif
       return;
     }
     MJH_FOR_LANES(t, nv) {
@@ -693,6 +705,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // Mgrad = M \ grad (CG preconditioner; Newton's convergence certificate)
   auto precondition = [&]() {
+    if (SPA == 2 && efm && efm_on) {
+#if !MJH_LANE_MODE
+      eff_block_apply(M, B, e, Mgrad, grad, MJH_G(B, efm_work, e));      // mjd_effPrec
+#endif
+      return;
+    }
     if (SPA == 2 && s.nC == nv) {
       // (diagonal mass matrix: mj_solveLD reduces to x * qLDiagInv)
       crptr dinv = MJH_F(B, qLDiagInv, e);
@@ -1023,7 +1041,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
   // ---- warm start: best of (qacc_warmstart, qacc_smooth)        (warmstart, engine_forward.c:1056-1132)
   // (jar = J qacc_warmstart - aref and efc_b = J qacc_smooth - aref were left by stage_fwd_constraint)
-  const int trace_scale = !(M.o.disableflags & (1<<18)) && nisl_raw > 0;
+  const int trace_scale = !(M.o.disableflags & (1<<18)) && nisl_raw > 0 && !efm;
   if (fuse_ok) {
     int use_smooth = 1;
     if (!(M.o.disableflags & (1<<9))) {
@@ -1081,6 +1099,17 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   }
 
   // ---- mj_solPrimal -------------------------------------------------------------------------------------------
+  if (efm) {
+    // from here on the effective metric: monolithic, shifted smooth force (the warm start above used M and qfrc_smooth)
+    efm_on = 1;
+    nisl_raw = 0; nisl = 1; multi_tree = 0;
+    rptr qeff = MJH_G(B, efm_work, e) + 5*nv;
+    crptr cs = MJH_G(B, efm_c, e);
+    crptr qf0 = MJH_F(B, qfrc_smooth, e);
+    MJH_FOR_LANES(i, nv) qeff[i] = qf0[i] + cs[i];
+    wv_sync();
+    qfs = qeff;
+  }
   if (!fuse_ok) mul_M(Ma, qacc);
   mul_J(jar, qacc, 1);
   if (multi_tree) { MJH_FOR_LANES(j, nv) qfc[j] = 0; wv_sync(); }

@@ -154,9 +154,18 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
     MJH_RUN(MJH_T_CRB, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_CRB, stage_crb(M, B, e, (stages & MJH_STAGE_NOPARK) != 0)));
     MJH_RUN(MJH_T_FACTOR, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_FACTOR, stage_factor_m(M, B, e)));
   }
+#if !MJH_LANE_MODE
+  // implicit effective metric M + K of a flex model under CG with an implicit integrator (mjd_effBuild at the end of
+  // mj_fwdPosition, mjd_effShift at the end of mj_fwdVelocity: both need nothing later than M here)
+  if (MJH_HAS(MJH_FT_FLEX) && M.s.efm && (stages & MJH_STAGE_INERTIA)) MJH_TIMED(MJH_T_FACTOR, stage_eff_build(M, B, e));
+#endif
   if (stages & MJH_STAGE_ACTUATION) {
     MJH_RUN(MJH_T_ACTUATION, stage_actuation(M, B, e));
     MJH_RUN(MJH_T_ACCEL, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_ACCEL, stage_acceleration(M, B, e)));
+#if !MJH_LANE_MODE
+    // (M + K) qacc_smooth = qfrc_smooth + efm_c (mj_fwdAcceleration, engine_forward.c:1033-1040)
+    if (MJH_HAS(MJH_FT_FLEX) && M.s.efm) MJH_TIMED(MJH_T_ACCEL, stage_eff_accel(M, B, e));
+#endif
   }
   if (stages & MJH_STAGE_MAKE) {
     MJH_RUN(MJH_T_MAKE, stage_make_constraint(M, B, e));
@@ -533,6 +542,25 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 
+// mj_implicitSkip under mj_flexCG (engine_forward.c:1675, :1727-1729, :1766): the constraint solver's qacc already carries
+// the implicit flex force -- no qDeriv, no factorisation: mj_advance with qacc itself
+MJH_DEVN void flexcg_advance(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const int nv = M.s.nv;
+  const real h = M.o.timestep;
+  rptr qvel = MJH_F(B, qvel, e);
+  rptr qpos = MJH_F(B, qpos, e);
+  crptr qacc = MJH_F(B, qacc, e);
+  advance_act(M, B, e, MJH_F(B, act_dot, e));
+  MJH_FOR_LANES(i, nv) qvel[i] += qacc[i]*h;
+  wv_sync();
+  integrate_pos(M, qpos, qvel, h);
+  rptr ws = MJH_F(B, qacc_warmstart, e);
+  MJH_FOR_LANES(i, nv) ws[i] = qacc[i];
+  if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
+  wv_sync();
+}
+
 // mj_step                                          (engine_forward.c:1846-1880)
 MJH_DEV void step_env(MREF M, BREF B, int e) {
   // (profile builds, slots 48..52: state checks | compressed rows + islands | state / sensor output | control input | sensors)
@@ -546,6 +574,7 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
     if (!bad || (M.o.disableflags & (1<<16))) break;
   }
   if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
+  else if (MJH_HAS(MJH_FT_IMPLICIT) && MJH_HAS(MJH_FT_FLEX) && M.s.efm) MJH_TIMED(MJH_T_EULER, flexcg_advance(M, B, e));
   else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
   else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
 }
@@ -725,7 +754,8 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     // (engine_forward.c:1863-1870).  Rare, so the whole forward pass is redone right here.
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
     if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
-    else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
+    else if (MJH_HAS(MJH_FT_IMPLICIT) && MJH_HAS(MJH_FT_FLEX) && M.s.efm) MJH_TIMED(MJH_T_EULER, flexcg_advance(M, B, e));
+  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
     else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);

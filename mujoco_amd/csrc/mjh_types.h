@@ -190,6 +190,23 @@
   /* vertices riding on articulated bodies (not three axis-aligned sliders of their own): for every dof, the vertices whose \
      body chain holds it, in vertex order -- the order in which mj_flexPassiveStretch's mj_applyFT calls add to that dof */ \
   X(flexdof_vadr, s.nflexdof + 1)              \
+  /* implicit effective metric M + K (mjh_effmetric.h; mj_flexCG, engine_forward.c:1640; mjd_effBuild, engine_derivative.c:3414): \
+     the per-step stiffness K of the standard flexes in dof-level CSR -- structure static (mjd_flexStiff_assemble :1810-2073: \
+     vertex slots with three sliders, neighbours through bending flaps and element cliques, sorted by dof address) --; \
+     efmblk_*: the 3 x 3 blocks in storage order (slot, neighbour position) with the vertices (global ids) they couple and \
+     their contributions in the reference's order of accumulation (kind 0 bending / 1 stretch | edge or element << 1, \
+     corner pair i << 2 | j packed in efmblk_cij) */ \
+  X(efm_rownnz, s.nefmrow)                     \
+  X(efm_rowadr, s.nefmrow)                     \
+  X(efm_colind, s.nefmK)                       \
+  X(efm_slotvert, s.nefmslot)                  \
+  X(efm_slotdiag, s.nefmslot)                  \
+  X(efm_vertslot, s.nefmvert)                  \
+  X(efmblk_slot, s.nefmblk)                    \
+  X(efmblk_pos, s.nefmblk)                     \
+  X(efmblk_cadr, s.nefmblk + 1)                \
+  X(efmblk_c, s.nefmcon)                       \
+  X(efmblk_cij, s.nefmcon)                     \
   X(flexdof_vert, s.nflexdofv)                 \
   X(flexvert_bend, 4 * s.nflexbend)            \
   /* flex collisions (mjh_flexcol.h).  colseg: the collision pass as segments (end of a range of static geom pairs, then \
@@ -395,6 +412,9 @@ struct DSizes {
   // flexes (mjh_flex.h): mjModel sizes; nflexbend = nflexedge when some flex has bending stiffness, else 0;
   // nflexdof = nv with flexes, else 0
   int nflex, nflexvert, nflexedge, nflexelem, nflexelemdata, nflexstiffness, nflexbending, nJfe, nflexbend, nflexdof;
+  // implicit effective metric (0 unless mj_flexCG holds): rows (nv), stored entries of K, vertex slots, flex vertices (nflexvert),
+  // 3 x 3 blocks, contributions
+  int efm, nefmrow, nefmK, nefmslot, nefmvert, nefmblk, nefmcon;
   int nflexdofv;       // entries of flexdof_vert (0: every vertex body is three sliders of its own, or pinned to the world)
   int flex_sliders;    // 1: every flex vertex body has body_simple 2 or no dofs up to the world (fast paths of mjh_flex.h)
   // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
@@ -548,6 +568,12 @@ enum {
   X(flexedge_velocity, s.nflexedge, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(flexedge_J, s.nJfe, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(flexelem_frc, 12 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* implicit effective metric: K's values, factored diagonal blocks, shift c, per-element stretch blocks / edge terms, PCG vectors */ \
+  X(efm_K_val, s.nefmK, 0, MJH_T_GLB, MJH_T_GLB)                                  \
+  X(efm_L, 9 * s.nefmslot, 0, MJH_T_GLB, MJH_T_GLB)                               \
+  X(efm_c, s.nefmrow, 0, MJH_T_GLB, MJH_T_GLB)                                    \
+  X(efm_eblk, (s.efm ? 144 * s.nflexelem : 0), 0, MJH_T_GLB, MJH_T_GLB)           \
+  X(efm_work, 6 * s.nefmrow, 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(flexvert_frc, 3 * (s.nflexdofv ? s.nflexvert : 0), 0, MJH_T_GLB, MJH_T_GLB)   \
   X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* mjData flexelem_aabb; candidate contacts of one body : flex job (dist, pos[3], normal[3], min_dist) */ \

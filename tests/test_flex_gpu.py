@@ -98,6 +98,12 @@ def test_line_flex_capsule_colliders_on_gpu(rb, hip_lib, tmp_path):
     fh._cable(rb, hip_lib, tmp_path, 50, 110, kind="devmath")
 
 
+@pytest.mark.parametrize("which", ["solid", "shell"])
+def test_implicit_effective_metric_on_gpu(rb, hip_lib, tmp_path, which):
+    """mj_flexCG: K assembly, block factors, shift, PCG for qacc_smooth and the CG solve in the metric M + K, bit for bit"""
+    fh._effective_metric(rb, hip_lib, tmp_path, which)
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

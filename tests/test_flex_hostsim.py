@@ -576,6 +576,54 @@ def test_line_flex_self_collision_explicit_index_rows(rb, hostsim_lib, tmp_path)
     _cable(rb, hostsim_lib, tmp_path, 50, 110)                        # 147 dofs
 
 
+EFM_OPTION = 'solver="CG" tolerance="1e-6" timestep=".001" integrator="implicitfast"'
+
+
+def _effective_metric(rb, lib, tmp_path, which):
+    """mj_flexCG (engine_forward.c:1640): CG + implicitfast + a flex with stretch stiffness -> the solve runs in the metric
+    M + K.  Checked field by field against the oracle's arena arrays (efm_K_val: the assembled stiffness; efm_L: the
+    factored 3 x 3 blocks; efm_c: the shift through the stencil operators), qacc_smooth (PCG with the block
+    preconditioner), then free-running steps with contacts (Ma / Mv / Mgrad through the metric, monolithic solve, mj_advance
+    with the solver's qacc): states, contact / row counts and CG iteration counts identical."""
+    xml = tmp_path / "efm.xml"
+    if which == "solid":
+        xml.write_text(flex_xml("5 5 3", "0 0 .09", option=EFM_OPTION,
+                                extra_world='<body mocap="true" pos=".02 .01 .04"><geom type="sphere" size=".03"/></body>'
+                                            '<body pos=".3 0 .1"><freejoint/><geom type="box" size=".04 .04 .04"/></body>',
+                                flex_body='<edge damping="1"/><contact selfcollide="none"/><elasticity young="5e4" damping="1e-3"/><pin id="0 1"/>'))
+    else:
+        xml.write_text(shell_xml("8 8 1", SHELL_GEOMS, option=EFM_OPTION,
+                                 body='<edge equality="false" damping="1"/><contact selfcollide="auto"/>'
+                                      '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="both"/>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(lib, m)
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    d.qvel[:] = np.random.default_rng(0).normal(0, .05, m.nv)
+    for _ in range(5): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:1 + m.nq + m.nv])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    if m.nmocap: b.set("mocap_pos", d.mocap_pos.reshape(1, -1)); b.set("mocap_quat", d.mocap_quat.reshape(1, -1))
+    rb.mj_forward(m, d); b.forward()
+    assert d.efm_active == 1 and d.nefmK > 1000 and d.nefmdof > 0
+    for name in ("efm_K_val", "efm_L", "efm_c"):
+        ref = np.asarray(getattr(d, name)).ravel()
+        assert np.array_equal(b.get(name)[0][:ref.size], ref), name
+    assert _fields_exact(b, d, ["qfrc_smooth", "qacc_smooth", "qacc"]) == []
+    maxcon, seen = _free_run(rb, lib, m, pre=40 if which == "solid" else 60, nstep=80, csr=1)
+    assert maxcon > 5
+    return maxcon
+
+
+def test_implicit_effective_metric_solid_flex(rb, hostsim_lib, tmp_path):
+    _effective_metric(rb, hostsim_lib, tmp_path, "solid")
+
+
+def test_implicit_effective_metric_shell_with_bending(rb, hostsim_lib, tmp_path):
+    assert _effective_metric(rb, hostsim_lib, tmp_path, "shell") > 40
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
