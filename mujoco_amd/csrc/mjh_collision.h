@@ -1077,6 +1077,7 @@ MJH_DEVN int collide_coop_pairs(MREF M_, BREF B_, int e_, int mypair, unsigned t
 #if !MJH_LANE_MODE
 MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base);     // mjh_flexcol.h
 MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base);
+MJH_DEVN int flex_pair_collide(MREF M_, BREF B_, int e_, int k, int base);
 #endif
 // ------------------------------------------------------------------------------------------------
 // mj_collision over the static pair list
@@ -1086,7 +1087,7 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
   const MJH_CONST_AS DSizes& s = M.s;
   iptr counts = MJH_F(B, counts, e);
   const int dsbl = M.o.disableflags;
-  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || (s.npair == 0 && s.ncolseg <= 1 && s.nflexself == 0)) {
+  if ((dsbl & (1<<0)) || (dsbl & (1<<4)) || (s.npair == 0 && s.ncolseg <= 1 && s.nflexself == 0 && s.nflexff == 0)) {
     if (wv_lane() == 0) counts[MJH_C_NCON] = 0;
     wv_sync();
     return;
@@ -1334,7 +1335,13 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
 #endif
   run_pairs();
 #if !MJH_LANE_MODE
-  // flex self-collisions, after every body pair (mj_collision :834-881)
+  // flex : flex pairs (the last of the body / flex pairs, mj_collision :795-813), then flex self-collisions (:834-881)
+  if (MJH_HAS(MJH_FT_FLEX))
+    for (int k = 0; k < s.nflexff; k++) {
+      const int r = flex_pair_collide(M, B, e, k, base);
+      base += r & 0xffff;
+      overflow |= r >> 16;
+    }
   if (MJH_HAS(MJH_FT_FLEX))
     for (int k = 0; k < s.nflexself; k++) {
       const int r = flex_self_collide(M, B, e, k, base);
@@ -1354,4 +1361,5 @@ MJH_DEVN void stage_collision(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  if (MJH_HAS(MJH_FT_FLEX) && s.nconside) flex_contact_nodes(M, B, e, overflow ? s.nconmax : base);
 }

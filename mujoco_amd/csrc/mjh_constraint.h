@@ -813,6 +813,13 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
     if (MJH_HAS(MJH_FT_FLEX)) {
       ConSides S;
       contact_sides(M, B, e, k, S);
+      if (S.ext) {
+        // (a list of node bodies: mj_diagApprox passes the side's unsigned vertex weights, so the basis values enter as they are)
+        for (int q = 0; q < S.n; q++) {
+          const real wq = fabs(S.xw[q]);
+          tran += M.body_invweight0[2*S.xb[q]] * wq;  rot += M.body_invweight0[2*S.xb[q]+1] * wq;
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < 8; q++) {
         if (q >= S.n) continue;
@@ -1014,10 +1021,15 @@ MJH_DEVN void stage_island(MREF M_, BREF B_, int e_) {
         for (int u = 0; u < 4; u++) {
           const int v = v0 + u*MJH_W;
           mt[u] = -1; tv[u] = -1;
-          if (v < s.nflexvert) { mt[u] = M.flex_mintree[M.flexvert_flex[v]]; tv[u] = M.body_treeid[M.flexvert_bodyid[v]]; }
+          if (v < s.nflexvert && M.flexvert_bodyid[v] >= 0) { mt[u] = M.flex_mintree[M.flexvert_flex[v]]; tv[u] = M.body_treeid[M.flexvert_bodyid[v]]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) if (mt[u] >= 0 && tv[u] >= 0) { const int l = label[tv[u]]; if (l < 0 || l > mt[u]) label[tv[u]] = mt[u]; }
+      }
+      // (interpolated flexes: the node bodies)
+      MJH_FOR_LANES(i, s.nflexnode) {
+        const int mtn = M.flex_mintree[M.flexnode_flex[i]], tn = M.body_treeid[M.flexnode_bodyid[i]];
+        if (mtn >= 0 && tn >= 0) { const int l = label[tn]; if (l < 0 || l > mtn) label[tn] = mtn; }
       }
       wv_sync();
     }

@@ -30,7 +30,7 @@ MJH_DEV int csr_contact_cols(MREF M, BREF B, int e, int k, IP cols) {
   ConSides S;
   contact_sides(M, B, e, k, S);
   int n = 0;
-  for (int q = 0; q < S.n; q++) n += csr_body_chain(M, S.body[q], cols + n);
+  for (int q = 0; q < S.n; q++) n += csr_body_chain(M, cs_body(S, q), cols + n);
   for (int a = 1; a < n; a++) { const int c = cols[a]; int b = a - 1; while (b >= 0 && cols[b] > c) { cols[b + 1] = cols[b]; b--; } cols[b + 1] = c; }
   int m = 0;
   for (int a = 0; a < n; a++) {

@@ -25,8 +25,10 @@ MJH_DEVN void stage_flex_pos(MREF M_, BREF B_, int e_) {
   crptr xpos = MJH_F(B, xpos, e);
   crptr xmat = MJH_F(B, xmat, e);
   rptr vx = MJH_F(B, flexvert_xpos, e);
+  if (s.nflexnode) flex_interp_pos(M, B, e);
   MJH_FOR_LANES(v, s.nflexvert) {
     const int b = M.flexvert_bodyid[v];
+    if (b < 0) continue;                 // (a vertex of an interpolated flex: placed by flex_interp_pos)
     auto lv = M.flex_vert + 3*v;
     if (lv[0] == 0 && lv[1] == 0 && lv[2] == 0) {
       vx[3*v] = xpos[3*b]; vx[3*v + 1] = xpos[3*b + 1]; vx[3*v + 2] = xpos[3*b + 2];
@@ -104,7 +106,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
   // per lane -- takes its edges two at a time per lane in a branch-free body, for the reason given at the stretch pass: the
   // second edge's chain of dependent loads hides the first one's round trips)
   int paired = 0;
-  if (s.nflex == 1 && s.flex_sliders && !M.flex_rigid[0] && s.nJfe == 6*s.nflexedge &&
+  if (s.nflex == 1 && s.flex_sliders && !M.flex_rigid[0] && !M.flex_interp[0] && s.nJfe == 6*s.nflexedge &&
       !(M.flex_edgeequality[0] != 1 && M.flex_edgedamping[0] == 0 && M.flex_edgestiffness[0] == 0 && M.flex_damping[0] == 0)) paired = 1;
   if (paired) {
     const int ne = s.nflexedge;
@@ -153,7 +155,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
   MJH_FOR_LANES(ed, s.nflexedge) {
     const int f = M.flexedge_flex[ed];
     const int adr = M.flexedge_J_rowadr[ed], nnz = M.flexedge_J_rownnz[ed];
-    if (M.flex_rigid[f]) {                 // (rigid flexes: no edge forces; lengths stay zero, Jacobian cleared)
+    if (M.flex_rigid[f] || M.flex_interp[f]) {   // (rigid and interpolated flexes: no edge forces; lengths stay zero, Jacobian cleared)
       len[ed] = 0;
       for (int j = adr; j < adr + nnz; j++) J[j] = 0;
       continue;
@@ -350,7 +352,7 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
   // branch-free body: an element is a chain of dependent loads (corner ids -> positions, edge ids -> lengths), and with one
   // or two wavefronts on a SIMD only a second, independent chain hides its round trips)
   const int sadr0 = s.nflex == 1 ? (int)M.flex_stiffnessadr[0] : -1;
-  if (s.nflex == 1 && M.flex_dim[0] == 3 && !M.flex_rigid[0] && sadr0 >= 0 && M.flex_stiffness[sadr0] != 0 && s.nflexelem > 0) {
+  if (s.nflex == 1 && M.flex_dim[0] == 3 && !M.flex_rigid[0] && !M.flex_interp[0] && sadr0 >= 0 && M.flex_stiffness[sadr0] != 0 && s.nflexelem > 0) {
     const real kD = h > 0 ? M.flex_damping[0] / h : 0;
     const int e0 = M.flex_elemadr[0], nel = s.nflexelem;
     for (int t0 = wv_lane(); t0 < nel; t0 += 2*MJH_W) {
@@ -370,7 +372,7 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     const int f = M.flexelem_flex[t];
     const int dim = M.flex_dim[f];
     const int sadr = M.flex_stiffnessadr[f];
-    if (dim < 2 || M.flex_rigid[f] || sadr < 0 || M.flex_stiffness[sadr] == 0) continue;
+    if (dim < 2 || M.flex_rigid[f] || M.flex_interp[f] || sadr < 0 || M.flex_stiffness[sadr] == 0) continue;
     auto k = M.flex_stiffness + sadr + 21*(t - M.flex_elemadr[f]);
     const real kD = h > 0 ? M.flex_damping[f] / h : 0;
     if (dim == 3) flex_stretch_element<3>(M, t, k, kD, h, vx, len, evel, efrc);
@@ -382,6 +384,7 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
   //      for vertices that are slider bodies (pinned vertices have no dofs to receive force)
   MJH_FOR_LANES(v, s.nflexvert) {
     const int bid = M.flexvert_bodyid[v];
+    if (bid < 0) continue;               // (interpolated flexes: flex_passive_interp)
     const int nd = M.body_dofnum[bid];
     if (nd == 0 && (!s.nflexdofv || M.body_dofnum[M.body_weldid[bid]] == 0)) continue;
     const int dadr = M.body_dofadr[bid];
@@ -454,6 +457,9 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
     wv_sync();
   }
 
+  // ---- interpolated flexes: cell elasticity on the node bodies (mj_flexPassiveInterp)
+  if (s.nflexnode) flex_passive_interp(M, B, e, enbl_spring, enbl_damper);
+
   // ---- edge spring-dampers: every dof sums its edges in edge order (:757-787).  (flexedge_k / flexedge_d: the edge's flex
   //      coefficients, zero for rigid edges -- an edge whose two coefficients are off adds nothing and is skipped as in
   //      the reference; the entry's edge id sits next to its index, so the loads of an entry do not wait on one another)
@@ -499,7 +505,11 @@ MJH_DEV void flex_passive(MREF M, BREF B, int e, int enbl_spring, int enbl_dampe
 // body), then side 1; the corners of an element are weighted by inverse distance to the contact point, normalised
 // (mj_elemBodyWeight :223-261).
 // ------------------------------------------------------------------------------------------------
-struct ConSides { int n, simple; int body[8]; real w[8]; };
+// A contact with an interpolated flex on a side lists NODE bodies: up to 27 per side, kept per contact in con_nodeb /
+// con_nodew by flex_contact_nodes below (xb / xw point at the contact's lists; null otherwise).
+struct ConSides { int n, simple, ext; int body[8]; real w[8]; ciptr xb; crptr xw; };
+MJH_DEV int cs_body(const ConSides& S, int q) { return S.ext ? (int)S.xb[q] : S.body[q]; }
+MJH_DEV real cs_w(const ConSides& S, int q) { return S.ext ? (real)S.xw[q] : S.w[q]; }
 
 // corners of element el (global id) of flex f: bodies and normalised inverse-distance weights times sign, into S from slot at
 MJH_DEV void flex_elem_weights(MREF M, BREF B, int e, int k, int f, int el, real sign, ConSides& S, int at) {
@@ -535,11 +545,16 @@ MJH_DEV void contact_sides(MREF M, BREF B, int e, int k, ConSides& S) {
   ciptr cg = MJH_CON(B, con_geom, e, 2, k);
 #pragma unroll
   for (int q = 0; q < 8; q++) { S.body[q] = 0; S.w[q] = 0; }
-  S.n = 2; S.simple = 1;
+  S.n = 2; S.simple = 1; S.ext = 0;
   int f1 = -1, e1 = -1, v1 = -1, f0 = -1, e0 = -1;
   if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) {
     ciptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*k;
     f1 = cf[0]; e1 = cf[1]; v1 = cf[2]; f0 = cf[3]; e0 = cf[4];
+    if (M.s.nconside && f1 >= 0 && (M.flex_interp[f1] || (f0 >= 0 && M.flex_interp[f0]))) {
+      ciptr nb = MJH_G(B, con_nodeb, e) + (M.s.nconside + 1)*k;
+      S.simple = 0; S.ext = 1; S.n = nb[0]; S.xb = nb + 1; S.xw = MJH_G(B, con_nodew, e) + M.s.nconside*k;
+      return;
+    }
   }
   if (f1 < 0) {
     S.body[0] = M.geom_bodyid[cg[0]]; S.w[0] = -1;
@@ -557,6 +572,64 @@ MJH_DEV void contact_sides(MREF M, BREF B, int e, int k, ConSides& S) {
   else { flex_elem_weights(M, B, e, k, f0, M.flex_elemadr[f0] + e0, -1, S, 0); at = M.flex_dim[f0] + 1; }
   flex_elem_weights(M, B, e, k, f1, M.flex_elemadr[f1] + e1, 1, S, at);
   S.n = at + M.flex_dim[f1] + 1;
+}
+
+// The node lists of the contacts that touch an interpolated flex, one lane per contact, once per step after the collision
+// pass.  A side that is a vertex or an element of an interpolated flex: its parametric coordinate (the vertices' flex_vert0
+// weighted by the absolute vertex weights), the cell that holds it, the cell's nodes with basis value at least 1e-5, weights
+// signed like the side (mj_vertBodyWeight :265-384; nodes that share a body are merged within the side).  The other side
+// as in contact_sides.  Layout: con_nodeb[(nconside + 1) k] = number of entries, then the bodies; con_nodew: the weights.
+MJH_DEV void flex_contact_nodes(MREF M, BREF B, int e, int ncon) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int cap = s.nconside;
+  MJH_FOR_LANES(k, ncon) {
+    ciptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*k;
+    const int ff[2] = {cf[3], cf[0]}, ee[2] = {cf[4], cf[1]}, vv[2] = {cf[5], cf[2]};
+    if (ff[1] < 0 || !(M.flex_interp[ff[1]] || (ff[0] >= 0 && M.flex_interp[ff[0]]))) continue;
+    ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+    iptr ob = MJH_G(B, con_nodeb, e) + (cap + 1)*k + 1;
+    rptr ow = MJH_G(B, con_nodew, e) + cap*k;
+    int nb = 0;
+    for (int side = 0; side < 2; side++) {
+      const int f = ff[side];
+      if (f < 0) { ob[nb] = M.geom_bodyid[cg[side]]; ow[nb] = side ? 1 : -1; nb++; continue; }
+      int vid[4] = {0, 0, 0, 0}, nw = 0;
+      real vw[4] = {0, 0, 0, 0};
+      if (vv[side] >= 0) { vid[0] = M.flex_vertadr[f] + vv[side]; vw[0] = side ? 1 : -1; nw = 1; }
+      else {
+        ConSides T;
+        const int el = M.flex_elemadr[f] + ee[side];
+        flex_elem_weights(M, B, e, k, f, el, side ? 1 : -1, T, 0);
+        nw = M.flex_dim[f] + 1;
+        for (int i = 0; i < nw; i++) { vid[i] = M.flexelem_vert[4*el + i]; vw[i] = T.w[i]; }
+      }
+      if (!M.flex_interp[f]) {
+        for (int i = 0; i < nw; i++) { ob[nb] = M.flexvert_bodyid[vid[i]]; ow[nb] = vw[i]; nb++; }
+        continue;
+      }
+      const real sign = vw[0] < 0 ? -1 : 1;
+      real coord[3] = {0, 0, 0}, local[3], basis[27];
+      int idx[27];
+      for (int i = 0; i < nw; i++) {
+        const real a = fabs(vw[i]);
+        coord[0] += M.flex_vert0[3*vid[i]]*a; coord[1] += M.flex_vert0[3*vid[i] + 1]*a; coord[2] += M.flex_vert0[3*vid[i] + 2]*a;
+      }
+      const int order = M.flex_interp[f], npc = (order + 1)*(order + 1)*(order + 1), na = M.flex_nodeadr[f];
+      interp_cell_lookup(M, f, coord, local, idx);
+      interp_basis(basis, local, order);
+      const int start = nb;
+      for (int j = 0; j < npc; j++) {
+        const real w = basis[j];
+        if (w < 1e-5) continue;
+        const int b = M.flexnode_bodyid[na + idx[j]];
+        int found = 0;
+        for (int q = start; q < nb; q++) if (ob[q] == b) { ow[q] = ow[q] + sign*w; found = 1; break; }
+        if (!found && nb < cap) { ob[nb] = b; ow[nb] = sign*w; nb++; }
+      }
+    }
+    MJH_G(B, con_nodeb, e)[(cap + 1)*k] = nb;
+  }
+  wv_sync();
 }
 
 // column j of the contact's translational point Jacobian (world frame, before the rotation into the contact frame):
@@ -595,6 +668,25 @@ MJH_DEV void contact_jac_col(MREF M, const ConSides& S, CD cdof, SC subtree_com,
   jd[0] = 0; jd[1] = 0; jd[2] = 0;
   if (rd) { rd[0] = 0; rd[1] = 0; rd[2] = 0; }
   int have = 0;
+  if (S.ext) {
+    for (int q = 0; q < S.n; q++) {
+      const int b = S.xb[q];
+      const int wq = M.body_weldid[b];
+      if (!((M.body_dofanc[wq*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+      real off[3], t[3];
+      v3_sub(off, point, subtree_com + 3*M.body_rootid[b]);
+      v3_cross(t, cd, off);
+      const real wt = S.xw[q];
+      const real x0 = (cd[3] + t[0])*wt, x1 = (cd[4] + t[1])*wt, x2 = (cd[5] + t[2])*wt;
+      jd[0] = have ? jd[0] + x0 : x0; jd[1] = have ? jd[1] + x1 : x1; jd[2] = have ? jd[2] + x2 : x2;
+      if (rd) {
+        const real r0 = cd[0]*wt, r1 = cd[1]*wt, r2 = cd[2]*wt;
+        rd[0] = have ? rd[0] + r0 : r0; rd[1] = have ? rd[1] + r1 : r1; rd[2] = have ? rd[2] + r2 : r2;
+      }
+      have = 1;
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     if (q >= S.n) continue;

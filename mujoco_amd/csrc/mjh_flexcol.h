@@ -188,11 +188,67 @@ MJH_DEV void flex_make_capsule(V3 v1, V3 v2, real radius, V3& pos, real* mat, re
   q_tomat(mat, quat);
 }
 
+// Position of a leaf pair in the order of mj_collideTree's walk over two bounding volume hierarchies (:1053-1240).  From
+// (root, root) a node pair splits the tree that is not at a leaf, or, both inner, the one whose box has the larger
+// "surface" (as the reference computes it: entries 3..5 minus entries 0..2 of the node's box), pushes child 0 then child 1
+// and pops child 1 first.  Two leaf pairs share their path up to the node pair where they part, and the one in child 1
+// comes first: the path's (1 - child) bits, most significant first, are a sort key (at most 52 steps: exact in a double).
+// Tree 1: a flex's hierarchy (body_tree 0: flexbvh_* tables, dynamic boxes bb) or a body's (jobbvh_* tables, static
+// surfaces); tree 2: a flex's.
+template <class BB>
+MJH_DEV real flex_walk_key(MREF M, BB bb, int leaf1, int body_tree, int leaf2) {
+  int c1[32], c2[32], d1 = 0, d2 = 0;
+  for (int nd = leaf1; nd >= 0 && d1 < 32; nd = body_tree ? (int)M.jobbvh_parent[nd] : (int)M.flexbvh_parent[nd]) c1[d1++] = nd;
+  for (int nd = leaf2; nd >= 0 && d2 < 32; nd = M.flexbvh_parent[nd]) c2[d2++] = nd;
+  // (c[d - 1] is the root, c[0] the leaf)
+  int i1 = d1 - 1, i2 = d2 - 1, len = 0;
+  unsigned long long key = 0;
+  while ((i1 > 0 || i2 > 0) && len < 52) {
+    const int n1 = c1[i1], n2 = c2[i2];
+    int split1;
+    if (i1 == 0) split1 = 0;
+    else if (i2 == 0) split1 = 1;
+    else {
+      real surface1;
+      if (body_tree) surface1 = M.jobbvh_surface[n1];
+      else {
+        const real x1 = bb[6*n1 + 3] - bb[6*n1], y1 = bb[6*n1 + 4] - bb[6*n1 + 1], z1 = bb[6*n1 + 5] - bb[6*n1 + 2];
+        surface1 = x1*y1 + y1*z1 + z1*x1;
+      }
+      const real x2 = bb[6*n2 + 3] - bb[6*n2], y2 = bb[6*n2 + 4] - bb[6*n2 + 1], z2 = bb[6*n2 + 5] - bb[6*n2 + 2];
+      const real surface2 = x2*y2 + y2*z2 + z2*x2;
+      split1 = surface1 > surface2;
+    }
+    int child;
+    if (split1) { i1--; child = c1[i1] == (body_tree ? (int)M.jobbvh_child[2*n1 + 1] : (int)M.flexbvh_child[2*n1 + 1]); }
+    else { i2--; child = c2[i2] == M.flexbvh_child[2*n2 + 1]; }
+    key = (key << 1) | (unsigned long long)(1 - child);
+    len++;
+  }
+  key <<= (52 - len);                            // (paths part before the shorter one ends)
+  return (real)(long long)key;
+}
+// candidates [0, n) re-ordered by the key in their FC_MIND column (ties: candidate order) into the n slots behind them
+template <class CP, class IP>
+MJH_DEV void flex_order_by_key(CP cand, IP ci, int n) {
+  MJH_FOR_LANES(i, n) {
+    const real ki = cand[FC_NREAL*i + FC_MIND];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const real kj = cand[FC_NREAL*j + FC_MIND];
+      rank += kj < ki || (kj == ki && j < i);
+    }
+    for (int q = 0; q < 7; q++) cand[FC_NREAL*(n + rank) + q] = cand[FC_NREAL*i + q];
+    for (int q = 0; q < 4; q++) ci[FI_NINT*(n + rank) + q] = ci[FI_NINT*i + q];
+  }
+  wv_sync();
+}
+
 // filterFlexContacts + (optionally) contactSort + emission of the n candidates in (cand, ci); returns the number of
 // contacts written from slot `base` on | overflow << 16.  sorted: stable sort by (geom, vertex / element) (body : flex
 // jobs, mj_collision :717-724); self-collisions are emitted in candidate order.
 template <class CP, class IP>
-MJH_DEV int flex_filter_emit(MREF M, BREF B, int e, int f, CP cand, IP ci, int n, int base, int sorted) {
+MJH_DEV int flex_filter_emit(MREF M, BREF B, int e, int f, CP cand, IP ci, int n, int base, int sorted, int f0 = -1) {
   const MJH_CONST_AS DSizes& s = M.s;
   // ---- filterFlexContacts: more candidates than a pair may keep.  The reference works on array positions: it swaps the
   //      chosen contact forward but leaves the `selected` / `min_dist` entries where they are -- reproduced as is.
@@ -255,9 +311,9 @@ MJH_DEV int flex_filter_emit(MREF M, BREF B, int e, int f, CP cand, IP ci, int n
     store_contact(M, B, e, c, ci[FI_NINT*i + FI_PAIR], h);
     iptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*c;
     const int kind = ci[FI_NINT*i + FI_KIND], obj = ci[FI_NINT*i + FI_OBJ];
-    // kind 0: geom : vertex, 1: geom : element, 2: element (FI_GEOM) : element (FI_OBJ) of the same flex
+    // kind 0: geom : vertex, 1: geom : element, 2: element (FI_GEOM) of flex f0 (f if not given) : element (FI_OBJ) of flex f
     cf[0] = f; cf[1] = kind ? obj : -1; cf[2] = kind ? -1 : obj;
-    cf[3] = kind == 2 ? f : -1; cf[4] = kind == 2 ? ci[FI_NINT*i + FI_GEOM] : -1; cf[5] = -1;
+    cf[3] = kind == 2 ? (f0 >= 0 ? f0 : f) : -1; cf[4] = kind == 2 ? ci[FI_NINT*i + FI_GEOM] : -1; cf[5] = -1;
   }
   overflow = wv_any(overflow);
   wv_sync();
@@ -456,7 +512,26 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
   wv_sync();
   if (n == 0) return 0;
 
-  const int r = flex_filter_emit(M, B, e, f, cand, ci, n, base, 1);
+  int r;
+  if (s.njobbvh && M.flexjob_leaf[a0] >= 0 && n > MJH_FLEX_MAXCON) {
+    // a body with several geoms, more contacts than the pair may keep: the thinning works on the candidates in the order
+    // the reference's walk over the body's and the flex's hierarchies emits them (plane contacts come before the walk)
+    crptr bb = MJH_G(B, flexbvh_aabb, e);
+    const int eadr0 = M.flex_elemadr[f];
+    MJH_FOR_LANES(i, n) {
+      real key = -1;
+      if (ci[FI_NINT*i + FI_KIND] != 0) {
+        int leaf1 = -1;
+        for (int a = a0; a < a1; a++) if (M.flexjob_geom[a] == ci[FI_NINT*i + FI_GEOM]) leaf1 = M.flexjob_leaf[a];
+        key = flex_walk_key(M, bb, leaf1, 1, M.flexelem_bvhleaf[eadr0 + ci[FI_NINT*i + FI_OBJ]]);
+      }
+      cand[FC_NREAL*i + FC_MIND] = key;
+    }
+    wv_sync();
+    flex_order_by_key(cand, ci, n);
+    r = flex_filter_emit(M, B, e, f, cand + FC_NREAL*n, ci + FI_NINT*n, n, base, 1);
+  } else
+  r = flex_filter_emit(M, B, e, f, cand, ci, n, base, 1);
   tick(56);
   return r;
 }
@@ -632,6 +707,142 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
   }
   wv_sync();
   return flex_filter_emit(M, B, e, f, cand2, ci2, n, base, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Collisions between two different flexes, pair k of the model's list (mj_collideElems for every pair of elements whose boxes
+// overlap; see the model build for what the order of the reference's tree walk would matter for).  Survivors as in the
+// self-collision pass -- element a of the first flex in the upper half of the entry -- then GJK / EPA or capsule : capsule per
+// survivor, contacts sorted by (element, element) (contactSort after mj_collideTree; without midphase the double loop emits
+// them in that order already).
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN int flex_pair_collide(MREF M_, BREF B_, int e_, int k, int base) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int f1 = M.flexff_flex[2*k], f2 = M.flexff_flex[2*k + 1], p = M.flexff_pair[k];
+  const int a1 = M.flex_elemadr[f1], n1 = M.flex_elemnum[f1], a2 = M.flex_elemadr[f2], n2 = M.flex_elemnum[f2];
+  if (n1 == 0 || n2 == 0) return 0;
+  crptr aabb = MJH_F(B, flexelem_aabb, e);
+  rptr cand = MJH_G(B, flexcand, e);
+  iptr ci = MJH_G(B, flexcand_i, e);
+  iptr warn = MJH_F(B, warning, e);
+  const int half = s.nflexcand/2;
+  iptr surv = ci + FI_NINT*s.nflexcand;
+  const real mg = M.pair_margin[p];
+  // ---- the second flex's bounding box (exact union of its element boxes): an element of the first flex that misses it
+  //      (by more than the margin) misses every element
+  real lo2[3] = {MJH_MAXVAL, MJH_MAXVAL, MJH_MAXVAL}, hi2[3] = {-MJH_MAXVAL, -MJH_MAXVAL, -MJH_MAXVAL};
+  MJH_FOR_LANES(j, n2) {
+    crptr bj = aabb + 6*(a2 + j);
+    for (int q = 0; q < 3; q++) { lo2[q] = r_min(lo2[q], bj[q] - bj[q + 3]); hi2[q] = r_max(hi2[q], bj[q] + bj[q + 3]); }
+  }
+  // (per-lane partial boxes through the candidate table, every lane reduces all of them)
+  for (int q = 0; q < 3; q++) { cand[6*wv_lane() + q] = lo2[q]; cand[6*wv_lane() + 3 + q] = hi2[q]; }
+  wv_sync();
+  for (int l = 0; l < MJH_W; l++)
+    for (int q = 0; q < 3; q++) { lo2[q] = r_min(lo2[q], cand[6*l + q]); hi2[q] = r_max(hi2[q], cand[6*l + 3 + q]); }
+  wv_sync();
+  // (with midphase only the elements held by the hierarchy's leaves take part: the walk reaches no others)
+  const int tree = M.flexff_mode[k] == 1;
+  int nsurv = 0, toomany = 0;
+  for (int i = 0; i < n1; i++) {
+    const int ei = a1 + i;
+    if (tree && M.flexelem_bvhleaf[ei] < 0) continue;
+    crptr bi = aabb + 6*ei;
+    const real ilo[3] = {bi[0] - bi[3], bi[1] - bi[4], bi[2] - bi[5]}, ihi[3] = {bi[0] + bi[3], bi[1] + bi[4], bi[2] + bi[5]};
+    if (ihi[0] + mg < lo2[0] || hi2[0] + mg < ilo[0] || ihi[1] + mg < lo2[1] || hi2[1] + mg < ilo[1] || ihi[2] + mg < lo2[2] || hi2[2] + mg < ilo[2]) continue;
+    int vb[4];
+    for (int q = 0; q < 4; q++) { const int v = M.flexelem_vert[4*ei + q]; vb[q] = v >= 0 ? (int)M.flexvert_bodyid[v] : -1; }
+    for (int j0 = 0; j0 < n2; j0 += MJH_W) {
+      const int j = j0 + wv_lane();
+      int ok = 0;
+      if (j < n2) {
+        const int ej = a2 + j;
+        crptr bj = aabb + 6*ej;
+        ok = !tree || M.flexelem_bvhleaf[ej] >= 0;
+        // filterBox (engine_collision_driver.c:230: centre / half-size boxes, apart by more than the margin along an axis)
+        for (int q = 0; q < 3 && ok; q++) {
+          const real jlo = bj[q] - bj[q + 3], jhi = bj[q] + bj[q + 3];
+          if (ihi[q] + mg < jlo || jhi + mg < ilo[q]) ok = 0;
+        }
+        if (ok) for (int q = 0; q < 4; q++) {
+          const int v = M.flexelem_vert[4*ej + q];
+          const int b = v >= 0 ? (int)M.flexvert_bodyid[v] : -1;
+          if (b >= 0 && (b == vb[0] || b == vb[1] || b == vb[2] || b == vb[3])) ok = 0;
+        }
+      }
+      const unsigned long long m = wv_ballot(ok);
+      if (m) {
+        const int at = nsurv + wv_rank_lt(m);
+        if (ok) { if (at < half) surv[at] = (i << 16) | j; else toomany = 1; }
+        nsurv += __builtin_popcountll(m);
+      }
+    }
+  }
+  if (wv_any(toomany)) { if (wv_lane() == 0) warn[MJH_WARN_UNSUPPORTED]++; nsurv = half; }
+  wv_sync();
+  if (nsurv == 0) return 0;
+  int n = 0;
+  if (M.flex_dim[f1] == 1) {
+    crptr vx = MJH_F(B, flexvert_xpos, e);
+    for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+      const int r = r0 + wv_lane();
+      const int pr = r < nsurv ? surv[r] : -1;
+      const int ia = pr >= 0 ? (pr >> 16) : -1, ib = pr >= 0 ? (pr & 0xffff) : -1;
+      int got = 0;
+      Hit ha{0, V3{0, 0, 0}, V3{0, 0, 0}, V3{0, 0, 0}}, hb = ha;
+      if (pr >= 0) {
+        const int e1 = a1 + ia, e2 = a2 + ib;
+        V3 p1, p2; real m1[9], m2[9], s1[2], s2[2];
+        flex_make_capsule(ld3(vx + 3*M.flexelem_vert[4*e1]), ld3(vx + 3*M.flexelem_vert[4*e1 + 1]), M.flex_radius[f1], p1, m1, s1);
+        flex_make_capsule(ld3(vx + 3*M.flexelem_vert[4*e2]), ld3(vx + 3*M.flexelem_vert[4*e2 + 1]), M.flex_radius[f2], p2, m2, s2);
+        got = hit_capsule_capsule(ha, hb, mg, p1, m1, s1, p2, m2, s2);
+      }
+      const int before = wv_exscan_i(got);
+      const int total = wv_sum_i(got);
+      for (int q = 0; q < got; q++) {
+        const int c = n + before + q;
+        if (c >= half) continue;
+        const Hit& h = q ? hb : ha;
+        cand[FC_NREAL*c + FC_DIST] = h.dist;
+        cand[FC_NREAL*c + FC_POS] = h.pos.x; cand[FC_NREAL*c + FC_POS + 1] = h.pos.y; cand[FC_NREAL*c + FC_POS + 2] = h.pos.z;
+        cand[FC_NREAL*c + FC_NRM] = h.nrm.x; cand[FC_NREAL*c + FC_NRM + 1] = h.nrm.y; cand[FC_NREAL*c + FC_NRM + 2] = h.nrm.z;
+        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2; ci[FI_NINT*c + FI_SEL] = q;
+      }
+      n += total;
+    }
+    wv_sync();
+  } else
+  for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
+    const int r = r0 + wv_lane();
+    const int pr = r < nsurv ? surv[r] : -1;
+    const int ia = pr >= 0 ? (pr >> 16) : -1, ib = pr >= 0 ? (pr & 0xffff) : -1;
+    const int got = ccd_elem_elem_pair(M, B, e, pr >= 0 ? a1 + ia : -1, pr >= 0 ? a2 + ib : -1, mg);
+    const unsigned long long m = wv_ballot(got > 0);
+    if (got > 0) {
+      const crptr rec = ccd_out_records(M, B, e);
+      const int c = n + wv_rank_lt(m);
+      if (c < half) {
+        for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
+        ci[FI_NINT*c + FI_GEOM] = ia; ci[FI_NINT*c + FI_OBJ] = ib; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 2; ci[FI_NINT*c + FI_SEL] = 0;
+      }
+    }
+    n += __builtin_popcountll(m);
+    wv_sync();
+  }
+  if (n > half) n = half;
+  if (n == 0) return 0;
+  // (survivors, and with them the candidates, are in (element, element) order: the order of the double loop without midphase)
+  if (!tree) return flex_filter_emit(M, B, e, f2, cand, ci, n, base, 0, f1);
+  // ---- the order of mj_collideTree's walk (flex_walk_key), then thinning, then the sort by (element, element)
+  crptr bb = MJH_G(B, flexbvh_aabb, e);
+  MJH_FOR_LANES(i, n)
+    cand[FC_NREAL*i + FC_MIND] = flex_walk_key(M, bb, M.flexelem_bvhleaf[a1 + ci[FI_NINT*i + FI_GEOM]], 0, M.flexelem_bvhleaf[a2 + ci[FI_NINT*i + FI_OBJ]]);
+  wv_sync();
+  flex_order_by_key(cand, ci, n);
+  rptr cand2 = cand + FC_NREAL*n;
+  iptr ci2 = ci + FI_NINT*n;
+  return flex_filter_emit(M, B, e, f2, cand2, ci2, n, base, 1, f1);
 }
 
 #endif   // !MJH_LANE_MODE

@@ -167,7 +167,21 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // flexes (mjh_flex.h): vertex-based deformables -- elasticity, bending, edge spring-dampers; interpolated (nodal)
   // flexes, flex equality constraints and penalty ("passive") flex contacts are not built
   for (int f = 0; f < m->nflex; f++) {
-    MJH_REJECT(m->flex_interp[f] != 0, "interpolated (trilinear / quadratic) flexes");
+    if (m->flex_interp[f] != 0) {
+      // interpolated flexes (nodes are bodies, vertices follow them): volume cells of order 1 or 2; every node either the
+      // origin of a body with three dofs of its own (the force path of mj_flexPassiveInterp :185-199 that writes the body's
+      // three dofs) or fixed to the world; explicit elasticity (Euler / RK4 -- the implicit integrators add mjd_flexInterp terms)
+      MJH_REJECT(m->flex_interp[f] < 0 || m->flex_interp[f] > 2, "interpolated flexes in shell mode or of order above 2");
+      MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4, "interpolated flexes with an implicit integrator");
+      MJH_REJECT(m->flex_selfcollide[f] != mjFLEXSELF_NONE && (m->flex_contype[f] & m->flex_conaffinity[f]), "self-collisions of an interpolated flex");
+      for (int i = m->flex_nodeadr[f]; i < m->flex_nodeadr[f] + m->flex_nodenum[f]; i++) {
+        const int b = m->flex_nodebodyid[i];
+        const bool origin = m->flex_centered[f] || (m->flex_node[3*i] == 0 && m->flex_node[3*i+1] == 0 && m->flex_node[3*i+2] == 0);
+        const bool fixed = m->body_dofnum[m->body_weldid[b]] == 0 && m->body_weldid[b] == 0;
+        MJH_REJECT(!fixed && !(origin && m->body_dofnum[b] == 3 && m->body_simple[b] == 2),
+                   "interpolated flex nodes other than bodies with three sliders of their own or fixed to the world");
+      }
+    }
     MJH_REJECT(m->flex_edgeequality[f] != 0 && m->flex_edgeequality[f] != 1, "flex vertex / strain equality constraints");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
@@ -749,8 +763,29 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // the flex on the second side (engine_collision_driver.c:1740-1835).
   {
     H->colseg.clear(); H->flexjob_adr.clear(); H->flexjob_geom.clear(); H->flexjob_nsub.clear();
+    H->flexjob_leaf.clear(); H->jobbvh_child.clear(); H->jobbvh_parent.clear(); H->jobbvh_surface.clear();
+    bool need_bvh = false;
     for (const FlexJob& j : flexjobs) {
       const int f = j.flex, b = j.body;
+      // (a body with several geoms: its hierarchy's nodes, for the walk order -- see flex_collide_job)
+      int treebase = -1;
+      if (midphase && m->body_bvhadr[b] >= 0 && m->body_bvhnum[b] > 1) {
+        treebase = (int)H->jobbvh_parent.size();
+        const int adr = m->body_bvhadr[b], num = m->body_bvhnum[b];
+        H->jobbvh_parent.resize(treebase + num, -1);
+        for (int i = 0; i < num; i++) {
+          const int c0 = m->bvh_child[2*(adr + i)], c1 = m->bvh_child[2*(adr + i) + 1];
+          MJH_REJECT((c0 < 0) != (c1 < 0), "internal: body bounding volume hierarchy node with one child");
+          H->jobbvh_child.push_back(c0 < 0 ? -1 : treebase + c0);
+          H->jobbvh_child.push_back(c1 < 0 ? -1 : treebase + c1);
+          if (c0 >= 0) { H->jobbvh_parent[treebase + c0] = treebase + i; H->jobbvh_parent[treebase + c1] = treebase + i; }
+          // (the "surface" mj_collideTree compares, :1207-1215: from entries 3..5 minus entries 0..2 of the node's box)
+          const mjtNum* bx = m->bvh_aabb + 6*(adr + i);
+          const mjtNum x1 = bx[3] - bx[0], y1 = bx[4] - bx[1], z1 = bx[5] - bx[2];
+          H->jobbvh_surface.push_back(x1*y1 + y1*z1 + z1*x1);
+        }
+        need_bvh = true;
+      }
       MJH_REJECT(midphase == 0, "flex collisions with the midphase disabled");
       MJH_REJECT(m->flex_bvhadr[f] < 0 || m->body_bvhadr[b] < 0, "flex collisions without bounding volume hierarchies");
       MJH_REJECT(m->flex_rigid[f], "collisions of rigid flexes");
@@ -827,6 +862,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
         H->flexjob_geom.push_back(g);
         H->flexjob_nsub.push_back(nsub);
+        {
+          int leaf = -1;
+          if (treebase >= 0)
+            for (int i = 0; i < m->body_bvhnum[b]; i++)
+              if (m->bvh_child[2*(m->body_bvhadr[b] + i)] < 0 && m->bvh_nodeid[m->body_bvhadr[b] + i] == g) leaf = treebase + i;
+          MJH_REJECT(treebase >= 0 && leaf < 0, "internal: geom without a leaf in its body's bounding volume hierarchy");
+          H->flexjob_leaf.push_back(leaf);
+        }
         H->pair_geom1.push_back(g);
         H->pair_geom2.push_back(-1);
         H->pair_dim.push_back(condim);
@@ -842,18 +885,90 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     H->flexjob_adr.push_back((int)H->flexjob_geom.size());
     H->flexjob_adr.push_back((int)H->flexjob_geom.size());
     s.ncolseg = (int)H->colseg.size()/3;
-    // flex : flex pairs between different flexes and internal collisions: not built.  Self-collisions of line / shell
+    // internal collisions: not built.  Self-collisions of line / shell
     // flexes (mj_collision, engine_collision_driver.c:834-881): by sweep-and-prune over the element boxes
     // (mj_collideFlexSAP :2315) or over all pairs of active elements; the walk of the flex's bounding volume hierarchy
     // against itself (solid flexes under selfcollide = auto, or selfcollide = bvh) is not built.
+    // Pairs of different flexes (mj_collision :795-813 without midphase, mj_collideTree :1166-1181 with it): every pair of
+    // elements whose boxes overlap goes to mj_collideElems.  With midphase the walk over the two bounding volume hierarchies
+    // meets the pairs in depth-first order (the thinning of more than mjMAXCONPAIR contacts -- filterFlexContacts -- works on
+    // array positions, so the order matters); the contacts are sorted by (element, element) afterwards.  The position of a
+    // leaf pair in that order is a function of its own path from the roots (flex_pair_collide, mjh_flexcol.h); mode 1.
+    // Without midphase (mode 2) the double loop emits in (element, element) order and nothing is sorted.  Contacts of these
+    // pairs follow all geom contacts.
+    H->flexff_flex.clear(); H->flexff_pair.clear(); H->flexff_mode.clear();
+    for (int f1 = 0; f1 < m->nflex; f1++)
+      for (int f2 = f1 + 1; f2 < m->nflex; f2++) {
+        if (!(m->flex_contype[f1] || m->flex_conaffinity[f1]) || !(m->flex_contype[f2] || m->flex_conaffinity[f2])) continue;
+        if (filter_bitmask(m->flex_contype[f1], m->flex_conaffinity[f1], m->flex_contype[f2], m->flex_conaffinity[f2])) continue;
+        MJH_REJECT(m->flex_rigid[f1] || m->flex_rigid[f2], "collisions of rigid flexes");
+        MJH_REJECT((m->flex_dim[f1] == 1) != (m->flex_dim[f2] == 1), "collisions between a line flex and a shell / solid flex");
+        MJH_REJECT(m->flex_gap[f1] + m->flex_gap[f2] != 0, "collisions between two flexes with a contact gap");
+        MJH_REJECT(m->flex_dim[f1] != 1 && (m->opt.disableflags & mjDSBL_NATIVECCD), "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
+        MJH_REJECT(m->flex_elemnum[f1] >= 0x10000 || m->flex_elemnum[f2] >= 0x10000, "flex : flex collisions with 65536 or more elements");
+        if (m->flex_dim[f1] != 1) s.ccd_any = 1;
+        // mj_contactParam(-1, -1, f1, f2)
+        int condim; real solref[2], solimp[5], fri[3];
+        const int p1 = m->flex_priority[f1], p2 = m->flex_priority[f2];
+        const mjtNum *sr1 = m->flex_solref + 2*f1, *sr2 = m->flex_solref + 2*f2;
+        const mjtNum *si1 = m->flex_solimp + 5*f1, *si2 = m->flex_solimp + 5*f2;
+        const mjtNum *fr1 = m->flex_friction + 3*f1, *fr2 = m->flex_friction + 3*f2;
+        if (p1 > p2) {
+          condim = m->flex_condim[f1];
+          for (int k = 0; k < 2; k++) solref[k] = sr1[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si1[k];
+          for (int k = 0; k < 3; k++) fri[k] = fr1[k];
+        } else if (p1 < p2) {
+          condim = m->flex_condim[f2];
+          for (int k = 0; k < 2; k++) solref[k] = sr2[k];
+          for (int k = 0; k < 5; k++) solimp[k] = si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = fr2[k];
+        } else {
+          condim = std::max(m->flex_condim[f1], m->flex_condim[f2]);
+          real m1 = m->flex_solmix[f1], m2 = m->flex_solmix[f2], mix;
+          if (m1 >= mjMINVAL && m2 >= mjMINVAL) mix = m1 / (m1 + m2);
+          else if (m1 < mjMINVAL && m2 < mjMINVAL) mix = 0.5;
+          else if (m1 < mjMINVAL) mix = 0.0;
+          else mix = 1.0;
+          if (sr1[0] > 0 && sr2[0] > 0) { for (int k = 0; k < 2; k++) solref[k] = mix*sr1[k] + (1-mix)*sr2[k]; }
+          else { for (int k = 0; k < 2; k++) solref[k] = std::min(sr1[k], sr2[k]); }
+          for (int k = 0; k < 5; k++) solimp[k] = mix*si1[k] + (1-mix)*si2[k];
+          for (int k = 0; k < 3; k++) fri[k] = std::max(fr1[k], fr2[k]);
+        }
+        real friction[5] = {fri[0], fri[0], fri[1], fri[2], fri[2]};
+        real margin = m->flex_margin[f1] + m->flex_margin[f2];
+        if (override_) {
+          margin = m->opt.o_margin;
+          for (int k = 0; k < 2; k++) solref[k] = m->opt.o_solref[k];
+          for (int k = 0; k < 5; k++) solimp[k] = m->opt.o_solimp[k];
+          for (int k = 0; k < 5; k++) friction[k] = m->opt.o_friction[k];
+        }
+        for (int k = 0; k < 5; k++) friction[k] = std::max((real)mjMINMU, friction[k]);
+        MJH_REJECT((solref[0] > 0) != (solref[1] > 0), "mixed-sign contact solref");
+        H->flexff_flex.push_back(f1); H->flexff_flex.push_back(f2);
+        H->flexff_pair.push_back((int)H->pair_geom1.size());
+        {
+          const bool tree = midphase && m->flex_bvhadr[f1] >= 0 && m->flex_bvhadr[f2] >= 0;
+          H->flexff_mode.push_back(tree ? 1 : 2);
+          if (tree) need_bvh = true;
+        }
+        H->flexjob_geom.push_back(-1);
+        H->flexjob_nsub.push_back(0);
+        H->flexjob_leaf.push_back(-1);
+        H->pair_geom1.push_back(-1);
+        H->pair_geom2.push_back(-1);
+        H->pair_dim.push_back(condim);
+        H->pair_margin.push_back(margin);
+        H->pair_includemargin.push_back(margin);
+        for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
+        for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
+        for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
+        for (int k = 0; k < 5; k++) H->pair_solimp.push_back(solimp[k]);
+      }
+    s.nflexff = (int)H->flexff_pair.size();
     H->flexself_flex.clear(); H->flexself_pair.clear(); H->flexself_mode.clear();
-    bool need_bvh = false;
     for (int f1 = 0; f1 < m->nflex; f1++) {
       if (!(m->flex_contype[f1] || m->flex_conaffinity[f1])) continue;
-      for (int f2 = f1 + 1; f2 < m->nflex; f2++)
-        MJH_REJECT((m->flex_contype[f2] || m->flex_conaffinity[f2]) &&
-                   !filter_bitmask(m->flex_contype[f1], m->flex_conaffinity[f1], m->flex_contype[f2], m->flex_conaffinity[f2]),
-                   "collisions between two flexes");
       if (m->flex_rigid[f1] || !(m->flex_contype[f1] & m->flex_conaffinity[f1])) continue;
       MJH_REJECT(m->flex_internal[f1], "flex internal collisions");
       const int sc = m->flex_selfcollide[f1];
@@ -890,6 +1005,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       H->flexself_mode.push_back(mode);
       H->flexjob_geom.push_back(-1);
       H->flexjob_nsub.push_back(0);
+      H->flexjob_leaf.push_back(-1);
       H->pair_geom1.push_back(-1);
       H->pair_geom2.push_back(-1);
       H->pair_dim.push_back(m->flex_condim[f]);
@@ -902,6 +1018,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     s.nflexself = (int)H->flexself_flex.size();
     s.nflexpair = (int)H->flexjob_geom.size();
+    s.njobbvh = (int)H->jobbvh_parent.size();
     // active elements of every flex, in element order (mj_isElemActive :347)
     H->flexact_adr.assign((size_t)m->nflex + 1, 0);
     H->flexact_elem.clear();
@@ -936,6 +1053,27 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       }
       H->flexbvh_adr[m->nflex] = (int)H->flexbvh_elem.size();
       s.nflexbvh = (int)H->flexbvh_elem.size();
+      // parents, and the leaf of every element (the path of a leaf pair through mj_collideTree's walk)
+      H->flexbvh_parent.assign(s.nflexbvh, -1);
+      H->flexelem_bvhleaf.assign((s.nflexff || s.njobbvh) ? m->nflexelem : 0, -1);
+      for (int i = 0; i < s.nflexbvh; i++) {
+        if (H->flexbvh_elem[i] < 0) { H->flexbvh_parent[H->flexbvh_child[2*i]] = i; H->flexbvh_parent[H->flexbvh_child[2*i + 1]] = i; }
+        else if (s.nflexff || s.njobbvh) H->flexelem_bvhleaf[H->flexbvh_elem[i]] = i;
+      }
+      for (int k = 0; k + 1 < s.ncolseg; k++)
+        if (H->flexjob_adr[k] < H->flexjob_adr[k + 1] && H->flexjob_leaf[H->flexjob_adr[k]] >= 0) {
+          int depth = 0;
+          for (int nd = H->flexjob_leaf[H->flexjob_adr[k]]; nd >= 0; nd = H->jobbvh_parent[nd]) depth++;
+          // (an upper bound for every geom of the body: the body's node count)
+          MJH_REJECT(height[H->flexbvh_adr[H->colseg[3*k + 2]]] + m->body_bvhnum[H->colseg[3*k + 1]] > 50 && depth > 0,
+                     "body : flex collisions with bounding volume hierarchies deeper than 50 levels together");
+        }
+      for (int k = 0; k < s.nflexff; k++)
+        if (H->flexff_mode[k] == 1)
+          for (int side = 0; side < 2; side++) {
+            const int f = H->flexff_flex[2*k + side];
+            MJH_REJECT(height[H->flexbvh_adr[f]] > 26, "flex : flex collisions with a bounding volume hierarchy deeper than 26 levels");
+          }
       int hmax = 0;
       for (int h : height) hmax = std::max(hmax, h);
       s.nflexbvhh = s.nflexbvh ? hmax + 1 : 0;
@@ -973,8 +1111,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       const int sadr = m->flex_stiffnessadr[f];
       if (m->flex_bendingadr[f] < 0 && (sadr < 0 || m->flex_stiffness[sadr] == 0)) continue;
       int mt = -1;
+      if (m->flex_interp[f])
+        for (int i = m->flex_nodeadr[f]; i < m->flex_nodeadr[f] + m->flex_nodenum[f]; i++) {
+          const int tr = m->body_treeid[m->flex_nodebodyid[i]];
+          if (tr >= 0 && (mt < 0 || tr < mt)) mt = tr;
+        }
       for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) {
-        const int tr = m->body_treeid[m->flex_vertbodyid[v]];
+        const int tr = m->flex_vertbodyid[v] < 0 ? -1 : m->body_treeid[m->flex_vertbodyid[v]];
         if (tr >= 0 && (mt < 0 || tr < mt)) mt = tr;
       }
       H->flex_mintree[f] = mt;
@@ -992,11 +1135,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       for (int a = H->flexjob_adr[k]; a < H->flexjob_adr[k + 1]; a++)
         c += m->geom_type[H->flexjob_geom[a]] == mjGEOM_PLANE ? m->flex_vertnum[f]
                                                                 : (H->flex_leafadr[f + 1] - H->flex_leafadr[f])*std::max(1, H->flexjob_nsub[a]);
+      // (a multi-geom body's candidates are put in walk order in the second half of the table)
+      if (H->flexjob_adr[k] < H->flexjob_adr[k + 1] && H->flexjob_leaf[H->flexjob_adr[k]] >= 0) c *= 2;
       cand = std::max(cand, c);
     }
     // self-collisions: the pairs of elements whose boxes overlap (beyond the capacity the environment raises the mjhip-only
     // UNSUPPORTED warning); their contacts are put in order in the second half of the table
     for (int k = 0; k < s.nflexself; k++) cand = std::max(cand, 2*16*(int)m->flex_elemnum[H->flexself_flex[k]]);
+    for (int k = 0; k < s.nflexff; k++) cand = std::max(cand, 2*16*(int)std::max(m->flex_elemnum[H->flexff_flex[2*k]], m->flex_elemnum[H->flexff_flex[2*k + 1]]));
     s.nflexcand = cand;
   }
 
@@ -1183,7 +1329,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   // on demand; a fixed 512 stands in for "as many as a scene of this size can touch at once")
   // (a body : flex job leaves at most mjMAXCONPAIR contacts, filterFlexContacts :447-515)
   for (int k = 0; k + 1 < s.ncolseg; k++) maxcon_total += std::min(s.nflexcand, (int)mjMAXCONPAIR);
-  maxcon_total += s.nflexself*(int)mjMAXCONPAIR;              // (and so does a flex's collision with itself, mj_collision :878)
+  maxcon_total += (s.nflexself + s.nflexff)*(int)mjMAXCONPAIR;              // (and so does a flex's collision with itself, mj_collision :878)
   s.nconmax = caps.nconmax > 0 ? caps.nconmax : std::max(1, std::min(maxcon_total, 512));
   s.nconflex = m->nflex ? s.nconmax : 0;
   s.nconlds = std::min(s.nconmax, 8);
@@ -1346,12 +1492,16 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     int chainmax = 1;
     for (int b = 0; b < m->nbody; b++) chainmax = std::max(chainmax, chain_len(b));
     int bound = 2*chainmax;
+    std::vector<int> sidemax(m->nflex, 0);
     for (int f = 0; f < m->nflex; f++) {
       int vchain = 0;
-      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) vchain = std::max(vchain, chain_len(m->flex_vertbodyid[v]));
+      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) vchain = std::max(vchain, m->flex_vertbodyid[v] < 0 ? 0 : chain_len(m->flex_vertbodyid[v]));
       bound = std::max(bound, chainmax + (m->flex_dim[f] + 1)*vchain);
+      sidemax[f] = (m->flex_dim[f] + 1)*vchain;
+      if (m->flex_interp[f]) { const int o = m->flex_interp[f] + 1; bound = std::max(bound, chainmax + 3*o*o*o); sidemax[f] = 3*o*o*o; }
       for (int k = 0; k < s.nflexself; k++) if (H->flexself_flex[k] == f) bound = std::max(bound, 2*(m->flex_dim[f] + 1)*vchain);
     }
+    for (int k = 0; k < s.nflexff; k++) bound = std::max(bound, sidemax[H->flexff_flex[2*k]] + sidemax[H->flexff_flex[2*k + 1]]);
     return bound;
   };
   {
@@ -1503,6 +1653,79 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     copy_arr(H->flex_edgestiffness, m->flex_edgestiffness, nf);
     copy_arr(H->flex_edgedamping, m->flex_edgedamping, nf);
     copy_arr(H->flex_radius, m->flex_radius, nf);
+    // interpolated flexes: nodes, cells, and per node the cells' contributions in scatter order (mj_flexPassiveInterp :131-180)
+    {
+      bool any = false;
+      for (int f = 0; f < nf; f++) any = any || m->flex_interp[f] != 0;
+      s.nflexnode = any ? m->nflexnode : 0;
+      s.nflexivert = any ? m->nflexvert : 0;
+      s.nconside = 0;
+      H->flex_interp.assign(nf, 0);
+      H->flex_cellnum.assign((size_t)3*nf, 0);
+      H->flex_nodeadr.assign((size_t)nf + 1, 0);
+      H->flexnode_bodyid.assign(s.nflexnode, 0);
+      H->flexnode_flex.assign(s.nflexnode, 0);
+      H->flexcell_flex.clear(); H->flexcell_kadr.clear(); H->flexcell_node.clear();
+      H->flexnode_celladr.assign((size_t)s.nflexnode + 1, 0);
+      H->flexnode_cell.clear();
+      H->flex_node.assign((size_t)3*s.nflexnode, 0); H->flex_node0.assign((size_t)3*s.nflexnode, 0);
+      H->flex_vert0.assign((size_t)3*s.nflexivert, 0);
+      if (any) {
+        copy_arr(H->flex_interp, m->flex_interp, nf);
+        copy_arr(H->flex_cellnum, m->flex_cellnum, 3*nf);
+        copy_arr(H->flexnode_bodyid, m->flex_nodebodyid, m->nflexnode);
+        copy_arr(H->flex_node, m->flex_node, 3*m->nflexnode);
+        copy_arr(H->flex_node0, m->flex_node0, 3*m->nflexnode);
+        copy_arr(H->flex_vert0, m->flex_vert0, 3*m->nflexvert);
+        std::vector<std::vector<int>> items(m->nflexnode);
+        int maxnpc = 0;
+        for (int f = 0; f < nf; f++) {
+          H->flex_nodeadr[f] = m->flex_nodeadr[f];
+          const int order = m->flex_interp[f];
+          if (!order) continue;
+          const int na = m->flex_nodeadr[f];
+          for (int i = 0; i < m->flex_nodenum[f]; i++) {
+            H->flexnode_flex[na + i] = f;
+            if (m->flex_centered[f]) { H->flex_node[3*(na + i)] = 0; H->flex_node[3*(na + i) + 1] = 0; H->flex_node[3*(na + i) + 2] = 0; }
+          }
+          const int cx = m->flex_cellnum[3*f], cy = m->flex_cellnum[3*f + 1], cz = m->flex_cellnum[3*f + 2];
+          const int npc = (order + 1)*(order + 1)*(order + 1);
+          maxnpc = std::max(maxnpc, npc);
+          MJH_REJECT(m->flex_nodenum[f] != (cx*order + 1)*(cy*order + 1)*(cz*order + 1), "an interpolated flex whose node grid does not match its cells");
+          const int sadr = m->flex_stiffnessadr[f];
+          const bool stretch = sadr >= 0 && m->flex_stiffness[sadr] != 0 && m->flex_edgeequality[f] != 3 && !m->flex_rigid[f] && m->flex_dim[f] != 1;
+          if (!stretch) continue;
+          const int ny_g = cy*order + 1, nz_g = cz*order + 1;
+          for (int fe = 0; fe < cx*cy*cz; fe++) {
+            const int cell = (int)H->flexcell_flex.size();
+            const mjtNum* k_elem = m->flex_stiffness + sadr + (size_t)fe*3*npc*3*npc;
+            H->flexcell_flex.push_back(f);
+            H->flexcell_kadr.push_back(k_elem[0] == 0 ? -1 : (int)(k_elem - m->flex_stiffness));
+            const int ci = fe/(cy*cz), cj = (fe/cz) % cy, ck = fe % cz;
+            int local = 0;
+            for (int li = 0; li <= order; li++)
+              for (int lj = 0; lj <= order; lj++)
+                for (int lk = 0; lk <= order; lk++) {
+                  const int gidx = (ci*order + li)*ny_g*nz_g + (cj*order + lj)*nz_g + (ck*order + lk);
+                  H->flexcell_node.push_back(na + gidx);
+                  if (k_elem[0] != 0) items[na + gidx].push_back((cell << 5) | local);
+                  local++;
+                }
+            H->flexcell_node.resize((size_t)27*(cell + 1), 0);
+          }
+        }
+        for (int i = 0; i < m->nflexnode; i++) {
+          H->flexnode_celladr[i] = (int)H->flexnode_cell.size();
+          H->flexnode_cell.insert(H->flexnode_cell.end(), items[i].begin(), items[i].end());
+        }
+        H->flexnode_celladr[m->nflexnode] = (int)H->flexnode_cell.size();
+        // a contact's body list: the nodes of a cell on an interpolated side, the corners of an element (or a geom) otherwise
+        s.nconside = 2*std::max(4, maxnpc);
+      }
+      H->flex_nodeadr[nf] = s.nflexnode;
+      s.nflexcell = (int)H->flexcell_flex.size();
+      s.nflexnodecell = (int)H->flexnode_cell.size();
+    }
     // (centered flexes and vertices at the body origin copy the body position: flag them once, mj_flex :567-572)
     for (int f = 0; f < nf; f++)
       for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++)
@@ -1564,7 +1787,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       std::vector<std::vector<int>> dv(m->nv);
       for (int v = 0; v < m->nflexvert; v++) {
         const int b = m->flex_vertbodyid[v];
-        if (m->body_simple[b] == 2) continue;
+        if (b < 0 || m->body_simple[b] == 2) continue;    // (vertices of an interpolated flex have no body)
         const int w = m->body_weldid[b];
         if (m->body_dofnum[w] == 0) continue;
         s.flex_sliders = 0;
@@ -1593,7 +1816,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       bool implicit_stiff = false, has_stretch = false;
       for (int f = 0; f < nf; f++) {
         if (m->flex_rigid[f]) continue;
-        MJH_REJECT(m->flex_interp[f] != 0, "interpolated (trilinear / quadratic) flexes");      // (rejected above already)
+        if (m->flex_interp[f] != 0) continue;      // (explicit integrators only, checked with the other gates)
         if (m->flex_dim[f] == 2 && m->flex_bendingadr[f] >= 0) implicit_stiff = true;
         if (m->flex_dim[f] >= 2 && m->flex_stiffnessadr[f] >= 0 && m->flex_stiffness[m->flex_stiffnessadr[f]] != 0) { implicit_stiff = true; has_stretch = true; }
       }

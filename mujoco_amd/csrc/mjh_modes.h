@@ -177,6 +177,7 @@ MJH_DEV void wv_sync() { ::mw_barrier(); }
 MJH_DEV int wv_lane() { return (int)threadIdx.x; }
 MJH_DEV void wv_sync() { __syncthreads(); }
 #endif
+#include "mjh_flexinterp.h"
 #include "mjh_flex.h"
 #include "mjh_smooth.h"
 #include "mjh_collision.h"

@@ -53,6 +53,7 @@ MJH_DEV M128 sp_row_pattern(MREF M, BREF B, int e, int type, int id, int r) {
       contact_sides(M, B, e, id, S);
       if (!S.simple) {
         M128 pm = m128_zero();
+        if (S.ext) { for (int q = 0; q < S.n; q++) pm = m128_or(pm, sp_body_chain(M, S.xb[q])); return pm; }
 #pragma unroll
         for (int q = 0; q < 8; q++) if (q < S.n) pm = m128_or(pm, sp_body_chain(M, S.body[q]));
         return pm;

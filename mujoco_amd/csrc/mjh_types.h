@@ -190,6 +190,21 @@
   /* vertices riding on articulated bodies (not three axis-aligned sliders of their own): for every dof, the vertices whose \
      body chain holds it, in vertex order -- the order in which mj_flexPassiveStretch's mj_applyFT calls add to that dof */ \
   X(flexdof_vadr, s.nflexdof + 1)              \
+  /* interpolated flexes (flex_interp 1 trilinear / 2 quadratic; mj_flex :580-626, mj_flexPassiveInterp): nodes are bodies, \
+     vertices are interpolated from the nodes of their cell.  flexnode_*: nodes (global ids),                                \
+     flexcell_*: the finite cells (flex, address of the cell's stiffness matrix or -1 for an empty cell, its nodes in \
+     mju_flexGatherCellState's order, global ids), flexnode_cell*: for every node the (cell << 5 | local node) items in \
+     the order the cells scatter their forces into it */ \
+  X(flex_interp, s.nflex)                      \
+  X(flex_cellnum, 3 * s.nflex)                 \
+  X(flex_nodeadr, s.nflex + 1)                 \
+  X(flexnode_bodyid, s.nflexnode)              \
+  X(flexnode_flex, s.nflexnode)                \
+  X(flexcell_flex, s.nflexcell)                \
+  X(flexcell_kadr, s.nflexcell)                \
+  X(flexcell_node, 27 * s.nflexcell)           \
+  X(flexnode_celladr, s.nflexnode + 1)         \
+  X(flexnode_cell, s.nflexnodecell)            \
   /* implicit effective metric M + K (mjh_effmetric.h; mj_flexCG, engine_forward.c:1640; mjd_effBuild, engine_derivative.c:3414): \
      the per-step stiffness K of the standard flexes in dof-level CSR -- structure static (mjd_flexStiff_assemble :1810-2073: \
      vertex slots with three sliders, neighbours through bending flaps and element cliques, sorted by dof address) --; \
@@ -223,6 +238,18 @@
      element order (mj_isElemActive); flexbvh_*: every flex's bounding volume hierarchy -- node range of the flex, children \
      (node ids of this table, -1), element of a leaf (global id, -1 for inner nodes), and the inner nodes ordered by height \
      (children before parents: mj_updateDynamicBVH recomputes the inner boxes bottom-up) */ \
+  /* pairs of different flexes that collide: the two flexes, the pair's parameter record */ \
+  X(flexff_flex, 2 * s.nflexff)                \
+  X(flexff_pair, s.nflexff)                    \
+  /* body : flex jobs whose body holds several geoms (its hierarchy has inner nodes): the order in which mj_collideTree's \
+     walk meets the (geom, element) pairs matters when more than mjMAXCONPAIR contacts are thinned out.  flexjob_leaf: the \
+     node of the job geom's leaf (-1: single-geom body, static order), jobbvh_*: the bodies' nodes (children, parent) */ \
+  X(flexjob_leaf, s.nflexpair)                 \
+  X(jobbvh_child, 2 * s.njobbvh)               \
+  X(jobbvh_parent, s.njobbvh)                  \
+  X(flexff_mode, s.nflexff)                    \
+  X(flexbvh_parent, s.nflexbvh)                \
+  X(flexelem_bvhleaf, ((s.nflexff || s.njobbvh) ? s.nflexelem : 0)) \
   X(flexself_flex, s.nflexself)                \
   X(flexself_pair, s.nflexself)                \
   X(flexself_mode, s.nflexself)                \
@@ -322,6 +349,11 @@
   X(mesh_polynormal, 3 * s.nmeshpoly)          \
   /* flexes */                                 \
   X(flex_vert, 3 * s.nflexvert)                \
+  /* interpolated flexes: node offsets in their bodies' frames, node positions in qpos0, the vertices' parametric coordinates */ \
+  X(jobbvh_surface, s.njobbvh)                 \
+  X(flex_node, 3 * s.nflexnode)                \
+  X(flex_node0, 3 * s.nflexnode)               \
+  X(flex_vert0, 3 * s.nflexivert)              \
   X(flexedge_length0, s.nflexedge)             \
   X(flexedge_invweight0, s.nflexedge)          \
   X(flex_stiffness, s.nflexstiffness)          \
@@ -415,6 +447,10 @@ struct DSizes {
   // implicit effective metric (0 unless mj_flexCG holds): rows (nv), stored entries of K, vertex slots, flex vertices (nflexvert),
   // 3 x 3 blocks, contributions
   int efm, nefmrow, nefmK, nefmslot, nefmvert, nefmblk, nefmcon;
+  // interpolated flexes: nodes, vertices with interpolation tables (nflexvert when some flex is interpolated, else 0), finite
+  // cells, entries of flexnode_cell
+  int nflexnode, nflexivert, nflexcell, nflexnodecell;
+  int nconside;        // interpolated flexes: capacity of a contact's list of node bodies (both sides), else 0
   int nflexdofv;       // entries of flexdof_vert (0: every vertex body is three sliders of its own, or pinned to the world)
   int flex_sliders;    // 1: every flex vertex body has body_simple 2 or no dofs up to the world (fast paths of mjh_flex.h)
   // flex collisions: geom : flex parameter records, collision segments, BVH leaves, candidate capacity of one
@@ -423,6 +459,8 @@ struct DSizes {
   // flex self-collisions: flexes that collide with themselves, active elements, nodes / heights of the flex bounding volume
   // hierarchies (0 unless some flex collides with itself by sweep-and-prune: the sweep axis is read off the root box)
   int nflexself, nflexact, nflexbvh, nflexbvhh;
+  int nflexff;         // pairs of different flexes that collide
+  int njobbvh;         // nodes of the body hierarchies of multi-geom body : flex jobs
 #define MJH_CONFLEX 6          // ints of a contact's flex identity: flex, element, vertex of side 1, then of side 0 (-1: a geom)
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row
@@ -568,6 +606,13 @@ enum {
   X(flexedge_velocity, s.nflexedge, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(flexedge_J, s.nJfe, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(flexelem_frc, 12 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* interpolated flexes: node positions / velocities, the cells' node forces (spring | damper, 81 reals each), and per \
+     contact the node bodies and weights of an interpolated side (mj_vertBodyWeight) */ \
+  X(flexnode_xpos, 3 * s.nflexnode, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexnode_vel, 3 * s.nflexnode, 0, MJH_T_GLB, MJH_T_GLB)                       \
+  X(flexcell_in, 166 * s.nflexcell, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  X(flexcell_frc, 162 * s.nflexcell, 0, MJH_T_GLB, MJH_T_GLB)                     \
+  X(con_nodew, s.nconside * s.nconmax, 0, MJH_T_GLB, MJH_T_GLB)       \
   /* implicit effective metric: K's values, factored diagonal blocks, shift c, per-element stretch blocks / edge terms, PCG vectors */ \
   X(efm_K_val, s.nefmK, 0, MJH_T_GLB, MJH_T_GLB)                                  \
   X(efm_L, 9 * s.nefmslot, 0, MJH_T_GLB, MJH_T_GLB)                               \
@@ -638,6 +683,7 @@ enum {
      table of a body : flex job (geom, vertex or element, parameter record, kind, selected flag; then the surviving leaves) */ \
   X(con_flex, MJH_CONFLEX * s.nconflex, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(flexcand_i, 6 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                         \
+  X(con_nodeb, (s.nconside ? (s.nconside + 1) * s.nconmax : 0), 0, MJH_T_GLB, MJH_T_GLB)       \
   X(moment_rownnz, s.nu, s.nu, MJH_T_TRANSMISSION, MJH_T_ACTUATION)               \
   X(moment_colind, s.nmoment, s.nmoment, MJH_T_TRANSMISSION, MJH_T_ACTUATION)     \
   X(efc_type, s.nefcmax, 0, MJH_T_GLB, MJH_T_GLB)                                 \

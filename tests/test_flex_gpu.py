@@ -104,6 +104,20 @@ def test_implicit_effective_metric_on_gpu(rb, hip_lib, tmp_path, which):
     fh._effective_metric(rb, hip_lib, tmp_path, which)
 
 
+@pytest.mark.parametrize("dof", ["trilinear", "quadratic"])
+def test_interpolated_flex_on_gpu(rb, hip_lib, tmp_path, dof):
+    """node bodies, interpolated vertices, corotational cells (mju_mat2Rot calls sin / cos: against the reference linked with
+    the kernels' routines), node-weighted contact rows, thinning in walk order -- bit for bit"""
+    if dof == "trilinear": assert fh._interpolated(rb, hip_lib, tmp_path, dof, kind="devmath")[0] == 50
+    else: assert fh._interpolated(rb, hip_lib, tmp_path, dof, kind="devmath", pre=100, nstep=120)[0] == 50
+
+
+def test_flex_on_flex_on_gpu(rb, hip_lib, tmp_path):
+    """element : element contacts between two flexes, more than fifty thinned in the order of the walk over both hierarchies"""
+    assert fh._flex_on_flex(rb, hip_lib, tmp_path, "") == 50
+    assert fh._flex_on_flex(rb, hip_lib, tmp_path, "trilinear", kind="devmath") == 50
+
+
 def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
     """a BATCH of flex environments (64 x jelly.xml with different vertex velocities, 400 steps from the reset state: the
     fall and the first ~60 steps on the capsule): two of the environments bit for bit, every step, against the reference

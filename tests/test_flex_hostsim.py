@@ -76,11 +76,11 @@ def test_shell_bending_free_motion_bit_exact(rb, hostsim_lib, tmp_path):
     _free_motion(rb, hostsim_lib, m)
 
 
-def _resync_steps(rb, lib, m, pre, nstep, mocap=None):
+def _resync_steps(rb, lib, m, pre, nstep, mocap=None, csr=1):
     """the oracle's trajectory from reset: after `pre` steps the kernels take over its state once and both run `nstep`
     steps freely; states, ncon / nefc and CG iteration counts identical at every step"""
     dm = K.DeviceModel(lib, m)
-    assert dm.size("csr") == 1
+    assert dm.size("csr") == csr
     b = K.Batch(dm, 1)
     d = rb.MjData(m)
     if mocap is not None: d.mocap_pos[:] = mocap
@@ -656,3 +656,112 @@ def test_multiwave_variant_is_default_for_flex_and_bit_identical(hostsim_lib):
     # a model without flexes keeps its one-wavefront mapping
     hm = K.MjbModel(hostsim_lib, os.path.join(GOLDEN, "humanoid.mjb"))
     assert K.Batch(K.DeviceModel(hostsim_lib, hm), 2).kernel_variant() != "multiwave"
+
+
+INTERP_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"/>
+  <size memory="10M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <geom type="box" pos=".25 0 .05" size=".1 .3 .05"/>
+    <geom type="box" pos="0 0 .04" size=".3 .3 .01" euler="0 12 0"/>
+    <body mocap="true" pos="-.13 .03 .13" zaxis=".5 0 1"><geom type="capsule" size=".03 .05" condim="1"/></body>
+    <flexcomp type="grid" count="COUNT" spacing=".05 .05 .05" pos="0 0 ZPOS" dim="3" radius=".002" mass="2" name="soft" dof="DOF">
+      ELASTICITY
+      <contact selfcollide="none" internal="false"/>
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _interpolated(rb, lib, tmp_path, dof, kind=None, count="5 5 5", pre=0, nstep=200):
+    """an interpolated flex (model/flex/trilinear.xml / quadratic.xml's kind: 8 or 27 node bodies carry 125 vertices) falling
+    onto a capsule, a tilted plate, a box and the floor: vertex interpolation (mj_flex), corotational cell elasticity with
+    the rotation from mju_mat2Rot (mj_flexPassiveInterp), contact rows spread over the cell's nodes (mj_vertBodyWeight),
+    more than fifty candidates against the two boxes of the world body (thinned in the order of mj_collideTree's walk
+    over the body's and the flex's hierarchies).  trilinear: dense rows (24 dofs); quadratic: mask rows (81 dofs)."""
+    xml = tmp_path / "interp.xml"
+    tri = dof == "trilinear"
+    xml.write_text(INTERP_XML.replace("COUNT", count).replace("DOF", dof).replace("ZPOS", ".17" if tri else ".21")
+                   .replace("ELASTICITY", '<elasticity young="1e4" poisson="0.2" damping="0.003"/>' if tri else
+                            '<elasticity young="3e3" poisson="0.1" damping="0.0005"/>'))
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind)
+    assert m.nv == (24 if dof == "trilinear" else 81)
+    dm = K.DeviceModel(lib, m)
+    assert dm.size("csr") == 0 and dm.size("sparse") == (0 if dof == "trilinear" else 1)
+    maxcon, seen = _free_run(rb, lib, m, pre, nstep)
+    return maxcon, seen
+
+
+def test_trilinear_flex_free_run(rb, hostsim_lib, tmp_path):
+    maxcon, seen = _interpolated(rb, hostsim_lib, tmp_path, "trilinear")
+    assert maxcon == 50 and seen >= {1, 2, 3}, (maxcon, seen)
+
+
+def test_quadratic_flex_free_run(rb, hostsim_lib, tmp_path):
+    maxcon, seen = _interpolated(rb, hostsim_lib, tmp_path, "quadratic", pre=100, nstep=120)
+    assert maxcon == 50 and seen >= {1, 2}, (maxcon, seen)
+
+
+FLEXFLEX_XML = """
+<mujoco>
+  <option solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"/>
+  <size memory="10M"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <flexcomp type="grid" count="4 4 3" spacing=".05 .05 .05" pos="0 0 .07" dim="3" radius=".005" mass="1" name="a"DOF>
+      BODY
+    </flexcomp>
+    <flexcomp type="grid" count="3 3 3" spacing=".05 .05 .05" pos=".03 .02 .24" dim="3" radius=".005" mass="1" name="b"DOF>
+      BODY
+    </flexcomp>
+  </worldbody>
+</mujoco>"""
+
+
+def _flex_on_flex(rb, lib, tmp_path, dof, nstep=100, kind=None):
+    """one flex dropped onto another (mj_collideElems over the element pairs whose boxes overlap, GJK / EPA between two
+    tetrahedra; flat faces meet, so more than fifty contacts are thinned in the order of the walk over the two flexes'
+    hierarchies, then sorted by (element, element)); rows carry the four corners of both elements (standard flexes, 225
+    dofs: explicit-index rows) or the eight nodes of both cells (trilinear, 48 dofs: dense rows)"""
+    xml = tmp_path / "ff.xml"
+    body = ('<edge damping="1"/><contact selfcollide="none"/><elasticity young="5e4"/>' if not dof else
+            '<contact selfcollide="none"/><elasticity young="1e4" damping="0.003"/>')
+    xml.write_text(FLEXFLEX_XML.replace("DOF", f' dof="{dof}"' if dof else "").replace("BODY", body))
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind)
+    d = rb.MjData(m)
+    first = None
+    for t in range(300):
+        rb.mj_step(m, d)
+        if d.ncon and (np.asarray(d.contact[:d.ncon]["flex"])[:, 0] >= 0).any(): first = t; break
+    assert first is not None
+    dm = K.DeviceModel(lib, m)
+    assert dm.size("csr") == (0 if dof else 1)
+    b = K.Batch(dm, 1)
+    rb.mj_resetData(m, d)
+    for _ in range(first - 5): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:]); b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    most = 0
+    for t in range(nstep):
+        b.step(); rb.mj_step(m, d)
+        c = b.get("counts")[0]
+        assert (c[0], c[1], c[5]) == (d.ncon, d.nefc, d.solver_niter[0]), (t, c[:6], d.ncon, d.nefc, d.solver_niter[0])
+        assert not b.get("warning")[0].any()
+        assert np.array_equal(b.get("qpos")[0], d.qpos) and np.array_equal(b.get("qvel")[0], d.qvel), t
+        if d.ncon:
+            con = d.contact[:d.ncon]
+            ff = np.asarray(con["flex"])[:, 0] >= 0
+            most = max(most, int(ff.sum()))
+            cf = b.get("con_flex")[0][:6*d.ncon].reshape(-1, 6)
+            assert np.array_equal(cf[:, [3, 0, 4, 1]], np.c_[np.asarray(con["flex"]), np.asarray(con["elem"])]), t
+    return most
+
+
+def test_flex_on_flex_standard(rb, hostsim_lib, tmp_path):
+    assert _flex_on_flex(rb, hostsim_lib, tmp_path, "") == 50
+
+
+def test_flex_on_flex_trilinear(rb, hostsim_lib, tmp_path):
+    assert _flex_on_flex(rb, hostsim_lib, tmp_path, "trilinear") == 50
