@@ -1063,9 +1063,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       for (int k = 0; k + 1 < s.ncolseg; k++)
         if (H->flexjob_adr[k] < H->flexjob_adr[k + 1] && H->flexjob_leaf[H->flexjob_adr[k]] >= 0) {
           int depth = 0;
-          for (int nd = H->flexjob_leaf[H->flexjob_adr[k]]; nd >= 0; nd = H->jobbvh_parent[nd]) depth++;
-          // (an upper bound for every geom of the body: the body's node count)
-          MJH_REJECT(height[H->flexbvh_adr[H->colseg[3*k + 2]]] + m->body_bvhnum[H->colseg[3*k + 1]] > 50 && depth > 0,
+          for (int a = H->flexjob_adr[k]; a < H->flexjob_adr[k + 1]; a++) {
+            int dd = 0;
+            for (int nd = H->flexjob_leaf[a]; nd >= 0; nd = H->jobbvh_parent[nd]) dd++;
+            depth = std::max(depth, dd);
+          }
+          MJH_REJECT(depth > 30 || height[H->flexbvh_adr[H->colseg[3*k + 2]]] + depth > 50,
                      "body : flex collisions with bounding volume hierarchies deeper than 50 levels together");
         }
       for (int k = 0; k < s.nflexff; k++)
