@@ -60,7 +60,8 @@ for step in "$@"; do
       MODEL=${rest:-humanoid} MJHIP_LIB=$PWD/tools/variants/libmjhip_prof.so timeout 900 python tools/stage_profile.py > "$OUT/stage_profile_${rest:-humanoid}.txt" 2>&1
       head -40 "$OUT/stage_profile_${rest:-humanoid}.txt" ;;
     sq)
-      bash tools/gpu_sq.sh ${rest:-humanoid} > "$OUT/sq_${rest:-humanoid}.log" 2>&1; tail -5 "$OUT/sq_${rest:-humanoid}.log" ;;
+      bash tools/gpu_sq.sh ${TAG}_${rest:-humanoid} ${rest:-humanoid} uniform > "$OUT/sq_${rest:-humanoid}.log" 2>&1; tail -5 "$OUT/sq_${rest:-humanoid}.log"
+      cp gpurun_out/sq_${TAG}_${rest:-humanoid}/sq_summary.txt "$OUT/sq_summary_${rest:-humanoid}.txt" 2>/dev/null ;;
     tail)
       timeout 600 python tools/tail_stats.py > "$OUT/tail_stats.txt" 2>&1; tail -12 "$OUT/tail_stats.txt" ;;
     resources)

@@ -1,9 +1,15 @@
 """Workload for per-STAGE hardware counters (run under rocprofv3 --pmc ...; tools/gpu_sq.sh).
 
-rocprofv3 counters are per dispatch, so the stages of one mj_step are issued as separate dispatches
-of the forward kernel (mjhip_batch_forward with a stage mask, LDS residency plan on), REPS times
-each, on a batch that first ran SETTLE rollout steps (so contacts / constraint rows are those of the
-benchmark regime).  tools/sq_summary.py maps dispatch order back to stage names.
+rocprofv3 counters are per dispatch, so one mj_step is issued as dispatches of the forward kernel
+(mjhip_batch_forward with a stage mask, LDS residency plan on) over PREFIXES of the stage list --
+kinematics; kinematics + collision; ... ; everything -- REPS times each, on a batch that first ran
+SETTLE rollout steps (so contacts / constraint rows are those of the benchmark regime).  A stage's
+counters are the difference of two consecutive prefixes (tools/sq_summary.py): every dispatch runs
+all the stages its last one depends on, in the same launch, so LDS-resident intermediates exist and
+the stage solves the benchmark's problem.  (Round 4 dispatched single-stage masks: a stage whose
+inputs live only in the LDS plan of the previous stages -- the constraint rows -- then worked on
+whatever the fresh LDS block held; its "constraint" row exceeded the row of the whole step.)
+A last group of dispatches runs STAGE_ALL as the cross-check of the final prefix.
 Prints the stage order as JSON on the last line.
 """
 import json, os, sys
@@ -43,9 +49,14 @@ STAGES = [("kinematics", K.STAGE_KINEMATICS), ("collision", K.STAGE_COLLISION), 
           ("velocity", K.STAGE_VELOCITY), ("inertia", K.STAGE_INERTIA), ("actuation", K.STAGE_ACTUATION),
           ("make", K.STAGE_MAKE), ("project", K.STAGE_PROJECT), ("reference", K.STAGE_REFERENCE),
           ("constraint", K.STAGE_CONSTRAINT | K.STAGE_FINISH), ("all", K.STAGE_ALL)]
+STAGES = [(n, m) for n, m in STAGES if n != "all"]
+prefix = 0
 for name, mask in STAGES:
+    prefix |= mask
     for _ in range(REPS):
-        b.forward(mask, lds=True)
-print(json.dumps({"stages": [n for n, _ in STAGES], "reps": REPS, "nenv": nenv, "regime": REGIME, "settle": SETTLE,
+        b.forward(prefix, lds=True)
+for _ in range(REPS):
+    b.forward(K.STAGE_ALL, lds=True)
+print(json.dumps({"stages": [n for n, _ in STAGES] + ["all"], "prefix": True, "reps": REPS, "nenv": nenv, "regime": REGIME, "settle": SETTLE,
                   "variant": b.kernel_variant(), "mean_ncon": float(cnt[:, 0].mean()), "mean_nefc": float(cnt[:, 1].mean()),
                   "mean_niter": float(cnt[:, 5].mean())}))

@@ -34,8 +34,14 @@ for regime in ("uniform", "testspeed"):
             vals = [v for _, v in vals][-n*reps:]
             if len(vals) != n*reps:
                 continue
+            per = [sum(vals[i*reps:(i + 1)*reps])/reps/nenv for i in range(n)]
             for i, st in enumerate(meta["stages"]):
-                table.setdefault(st, {})[cname] = sum(vals[i*reps:(i + 1)*reps])/reps/nenv
+                if meta.get("prefix") and st != "all":
+                    # dispatches are prefixes of the stage list: a stage is the difference of two consecutive prefixes
+                    table.setdefault(st, {})[cname] = per[i] - (per[i - 1] if i else 0.0)
+                    if i == n - 2: table.setdefault("sum (last prefix)", {})[cname] = per[i]
+                else:
+                    table.setdefault(st, {})[cname] = per[i]
     if meta:
         print(f"== per stage, regime {regime}: {meta['variant']} kernel, {meta['nenv']} envs, mean ncon {meta['mean_ncon']:.1f} nefc {meta['mean_nefc']:.1f} "
               f"solver iterations {meta['mean_niter']:.1f}; counters per env-step (one wavefront)")
@@ -43,9 +49,18 @@ for regime in ("uniform", "testspeed"):
         print("stage".ljust(14) + "".join(c.replace("SQ_", "")[:15].rjust(16) for c in names))
         for st, t in table.items():
             print(st.ljust(14) + "".join(("%.0f" % t.get(c, float("nan"))).rjust(16) for c in names))
+        # one table for the "issuing" question: SQ_WAVE_CYCLES, SQ_WAIT_INST_* and SQ_ACTIVE_INST_* all count QUAD-cycles
+        # (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"), so their ratios need no conversion; SQ_BUSY_CYCLES counts
+        # cycles of the SQ (per XCD-level unit), reported as is
+        print("stage".ljust(22) + "VALU insts".rjust(12) + "wave qcyc".rjust(12) + "issuing any".rjust(12) + "issuing VALU".rjust(13) + "waiting".rjust(10) + "lanes/VALU".rjust(12))
         for st, t in table.items():
-            if "SQ_INSTS_VALU" in t and "SQ_ACTIVE_INST_VALU" in t and "SQ_WAVE_CYCLES" in t:
-                pass
+            wc = t.get("SQ_WAVE_CYCLES")
+            if not wc:
+                continue
+            lanes = t["SQ_THREAD_CYCLES_VALU"]/t["SQ_ACTIVE_INST_VALU"] if t.get("SQ_THREAD_CYCLES_VALU") and t.get("SQ_ACTIVE_INST_VALU") else float("nan")
+            print(st.ljust(22) + ("%.0f" % t.get("SQ_INSTS_VALU", float("nan"))).rjust(12) + ("%.0f" % wc).rjust(12)
+                  + ("%.3f" % (t.get("SQ_ACTIVE_INST_ANY", float("nan"))/wc)).rjust(12) + ("%.3f" % (t.get("SQ_ACTIVE_INST_VALU", float("nan"))/wc)).rjust(13)
+                  + ("%.3f" % (t.get("SQ_WAIT_INST_ANY", float("nan"))/wc)).rjust(10) + ("%.1f" % lanes).rjust(12))
     # whole rollout kernel
     for lg in sorted(glob.glob(os.path.join(out, f"rollout_{regime}_p*.log"))):
         try:
