@@ -112,6 +112,14 @@ def test_interpolated_flex_on_gpu(rb, hip_lib, tmp_path, dof):
     else: assert fh._interpolated(rb, hip_lib, tmp_path, dof, kind="devmath", pre=100, nstep=120)[0] == 50
 
 
+@pytest.mark.parametrize("name", sorted(fh.REFERENCE_INTERP))
+def test_reference_interpolated_flex_models_on_gpu(rb, hip_lib, name):
+    """the reference's own interpolated flex models, several hundred steps through their contact phase, bit for bit against
+    the reference linked with the kernels' sin / cos"""
+    maxcon = fh._reference_interp_model(rb, hip_lib, name, kind="devmath", nstep=400)
+    if name == "sphere_trilinear": assert maxcon > 50
+
+
 def test_flex_on_flex_on_gpu(rb, hip_lib, tmp_path):
     """element : element contacts between two flexes, more than fifty thinned in the order of the walk over both hierarchies"""
     assert fh._flex_on_flex(rb, hip_lib, tmp_path, "") == 50

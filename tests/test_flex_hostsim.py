@@ -765,3 +765,25 @@ def test_flex_on_flex_standard(rb, hostsim_lib, tmp_path):
 
 def test_flex_on_flex_trilinear(rb, hostsim_lib, tmp_path):
     assert _flex_on_flex(rb, hostsim_lib, tmp_path, "trilinear") == 50
+
+
+REFERENCE_INTERP = {"trilinear": (330, 120, 24), "quadratic": (990, 60, 81), "sphere_trilinear": (1340, 60, 48)}
+
+
+def _reference_interp_model(rb, lib, name, kind=None, nstep=None):
+    """model/flex/{trilinear, quadratic, sphere_trilinear}.xml as shipped (tests/golden/*.mjb, tools/make_golden.py): 512 / 594
+    interpolated vertices on 8 / 27 / 2 x 8 node bodies.  The oracle runs `pre` steps from reset (free fall, first contacts),
+    the kernels take over its state and both run on: the capsule under the trilinear / quadratic block; the two spheres on the
+    tilted plate and the box, where more than fifty contacts of the world body's two boxes are thinned in walk order."""
+    pre, n, nv = REFERENCE_INTERP[name]
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, name + ".mjb"), kind=kind)
+    assert m.nv == nv
+    maxcon, seen = _free_run(rb, lib, m, pre, nstep or n)
+    assert maxcon > 0
+    return maxcon
+
+
+@pytest.mark.parametrize("name", sorted(REFERENCE_INTERP))
+def test_reference_interpolated_flex_models(rb, hostsim_lib, name):
+    maxcon = _reference_interp_model(rb, hostsim_lib, name)
+    if name == "sphere_trilinear": assert maxcon > 50

@@ -102,11 +102,12 @@ def make_cube():
     print("cube_3x3x3", "nv", m.nv, "ncon max", ints[:, 0].max(), "nefc max", ints[:, 1].max(), "niter max", ints[:, 2].max())
 
 
-def make_jelly():
-    """BASELINE config 5: model/flex/jelly.xml as shipped (512-vertex solid flex, nv 1536, CG, dt 1 ms)."""
+def make_jelly(name="jelly"):
+    """BASELINE config 5: model/flex/jelly.xml as shipped (512-vertex solid flex, nv 1536, CG, dt 1 ms); with another name:
+    that model of model/flex (trilinear / quadratic / sphere_trilinear: the interpolated flexes of round 5's GPU tests)."""
     import re
     import tempfile
-    src = os.path.join(REF, "model/flex/jelly.xml")
+    src = os.path.join(REF, "model/flex/%s.xml" % name)
     full = rb.MjModel.from_xml_path(src)
     # the included scene carries two 512 x 512 builtin textures (7 MB of pixels mj_step never reads): compiled from the
     # reference's XML with the <texture> / <material> elements removed, physics arrays asserted equal
@@ -115,21 +116,24 @@ def make_jelly():
     with tempfile.TemporaryDirectory() as td:
         with open(os.path.join(td, "scene.xml"), "w") as f:
             f.write(strip_visuals(scene))
-        with open(os.path.join(td, "jelly.xml"), "w") as f:
+        with open(os.path.join(td, name + ".xml"), "w") as f:
             f.write(open(src).read())
-        m = rb.MjModel.from_xml_path(os.path.join(td, "jelly.xml"))
-    for name in PHYSICS_ARRAYS + ["flex_vert", "flex_elem", "flex_edge", "flex_stiffness", "flexedge_length0", "flex_vertbodyid",
-                                  "bvh_child", "bvh_nodeid", "flex_elemlayer", "geom_type", "body_invweight0"]:
-        assert np.array_equal(getattr(m, name), getattr(full, name)), name
+        m = rb.MjModel.from_xml_path(os.path.join(td, name + ".xml"))
+    for arr in PHYSICS_ARRAYS + ["flex_vert", "flex_elem", "flex_edge", "flex_stiffness", "flexedge_length0", "flex_vertbodyid",
+                                  "bvh_child", "bvh_nodeid", "flex_elemlayer", "geom_type", "body_invweight0", "flex_vert0", "flex_node0",
+                                  "flex_nodebodyid", "flex_interp", "flex_cellnum"]:
+        assert np.array_equal(getattr(m, arr), getattr(full, arr)), arr
     assert (m.nq, m.nv, m.ngeom, m.nflexelem, m.nbvh) == (full.nq, full.nv, full.ngeom, full.nflexelem, full.nbvh)
-    m.save_binary(os.path.join(OUT, "jelly.mjb"))
-    print("jelly", "nv", m.nv, "nflexvert", m.nflexvert, "nflexelem", m.nflexelem)
+    m.save_binary(os.path.join(OUT, name + ".mjb"))
+    print(name, "nv", m.nv, "nflexvert", m.nflexvert, "nflexelem", m.nflexelem)
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     make_jelly()
-    if "--jelly-only" in sys.argv:
+    for other in ("trilinear", "quadratic", "sphere_trilinear"):
+        make_jelly(other)
+    if "--jelly-only" in sys.argv or "--flex-only" in sys.argv:
         return
     make_cube()
     if "--cube-only" in sys.argv:
