@@ -50,6 +50,17 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
   for (int e = tid; e < n; e += 1024) m = max(m, cost[e]);
   atomicMax(&maxc, m);
   __syncthreads();
+  // (mean cost per environment of the launch just finished: the reference level of the next launch's issue priorities)
+  {
+    __shared__ long long tot;
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    long long part = 0;
+    for (int e = tid; e < n; e += 1024) part += B->cost[e];
+    atomicAdd((unsigned long long*)&tot, (unsigned long long)part);
+    __syncthreads();
+    if (tid == 0) B->prio_ref[0] = (int)(tot/(n > 0 ? n : 1));
+  }
   const float scale = 255.0f / (float)maxc;
   for (int e = tid; e < n; e += 1024) atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
   __syncthreads();

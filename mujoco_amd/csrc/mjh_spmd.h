@@ -22,6 +22,13 @@
 #define MJH_MW 8
 #endif
 
+// issue priority of rollout wavefronts by solver work (mjh_step.h: rollout_env; -DMJH_NO_STEP_PRIO: measurement builds)
+#if defined(MJH_HOSTSIM) || defined(MJH_NO_STEP_PRIO)
+#define MJH_STEP_PRIO 0
+#else
+#define MJH_STEP_PRIO 1
+#endif
+
 #ifdef MJH_HOSTSIM
 // ------------------------------------------------------------------------------------------------
 // host emulation of a wavefront (tests only)

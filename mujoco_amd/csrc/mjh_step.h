@@ -651,6 +651,28 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
   const long long c_start = wv_clock();
 #endif
   int work = 0;
+#if MJH_STEP_PRIO && !MJH_LANE_MODE
+  // Issue priority (s_setprio: the SIMD's arbiter serves the higher level first).  A launch ends with its slowest
+  // wavefront, and the slowest ones are environments in long solves that stay expensive for many consecutive steps; while
+  // such a wavefront shares its SIMD with three cheap environments it should run at its own speed, the cheap ones filling
+  // the gaps -- the SIMD's total work does not change, the launch's tail does (profiles/r05/step_priority_ab.txt: +8..10 %
+  // on the humanoid).  Levels: by the solver work of the step just taken against the batch's mean work per step of the
+  // previous launch (prio_ref, written by mjh_k_balance: 2x / 4x / 6x the mean); on the first step by the position in the
+  // launch order, which lists the environments by decreasing cost of the previous launch.  No reference yet: no priorities.
+  int prio_ref = 0;
+  {
+    ciptr pr = MJH_G(B, prio_ref, 0);
+    const int tot = wv_uniform_i(pr[0]), ns = wv_uniform_i(pr[1]);
+    prio_ref = (ns > 0 && (int)blockDim.x == MJH_WAVE) ? tot/ns : 0;      // (one-wavefront workgroups only: a multi-wavefront
+                                                                           //  environment's helpers would fall behind its wave 0)
+    if (prio_ref > 0 && !A.nlaunch) {
+      const int w = (int)blockIdx.x, n = B.nenv;
+      if (w*64 < n) __builtin_amdgcn_s_setprio(3);
+      else if (w*16 < n) __builtin_amdgcn_s_setprio(2);
+      else if (w*4 < n) __builtin_amdgcn_s_setprio(1);
+    }
+  }
+#endif
   for (int t = 0; t < A.nstep; t++) {
 #if !defined(MJH_HOSTSIM) && !defined(MJH_NO_LAUNDER)
     // The two descriptors are re-read through "new" pointers every step.  With every stage inlined the compiler
@@ -677,6 +699,15 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
       step_env(M, B, e);
       ciptr cnt = MJH_F(B, counts, e);
       work += 64 + cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4);
+#if MJH_STEP_PRIO && !MJH_LANE_MODE
+      if (prio_ref > 0) {
+        const int wk = wv_uniform_i(cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4));
+        if (wk >= 6*prio_ref) __builtin_amdgcn_s_setprio(3);
+        else if (wk >= 4*prio_ref) __builtin_amdgcn_s_setprio(2);
+        else if (wk >= 2*prio_ref) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
     }
     MJH_TIMED(50, {
     if (A.state) get_state(M, B, e, A.state + step*s.nstate);
@@ -693,6 +724,7 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
   if (wv_lane() == 0) {
     MJH_G(B, cost, e)[0] = work;
     MJH_G(B, wall, e)[0] = (int)((wv_clock() - c_begin) >> 4);
+    if (e == 0) MJH_G(B, prio_ref, 0)[1] = A.nstep;
   }
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {

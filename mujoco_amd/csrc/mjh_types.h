@@ -717,7 +717,10 @@ enum {
      ticks (100 MHz >> 4) of the env's wavefront in its last launch (tail statistics) */          \
   X(cost, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
   X(perm, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
-  X(wall, 1, 0, MJH_T_GLB, MJH_T_GLB)
+  X(wall, 1, 0, MJH_T_GLB, MJH_T_GLB)                                             \
+  /* issue priority of the rollout wavefronts (mjh_step.h: rollout_env): environment 0's two slots hold the mean cost per  \
+     environment of the previous launch (written by mjh_k_balance) and that launch's step count */ \
+  X(prio_ref, 2, 0, MJH_T_GLB, MJH_T_GLB)
 
 // indices into DBatch::counts
 #define MJH_C_NCON 0
