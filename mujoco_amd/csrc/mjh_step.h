@@ -659,17 +659,28 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
   // on the humanoid).  Levels: by the solver work of the step just taken against the batch's mean work per step of the
   // previous launch (prio_ref, written by mjh_k_balance: 2x / 4x / 6x the mean); on the first step by the position in the
   // launch order, which lists the environments by decreasing cost of the previous launch.  No reference yet: no priorities.
-  int prio_ref = 0;
+  int prio_ref = 0, prio_floor = 0;
+  (void)prio_floor;
   {
     ciptr pr = MJH_G(B, prio_ref, 0);
     const int tot = wv_uniform_i(pr[0]), ns = wv_uniform_i(pr[1]);
     prio_ref = (ns > 0 && (int)blockDim.x == MJH_WAVE) ? tot/ns : 0;      // (one-wavefront workgroups only: a multi-wavefront
                                                                            //  environment's helpers would fall behind its wave 0)
+#ifndef MJH_PRIO_MODE
+#define MJH_PRIO_MODE 0
+#endif
     if (prio_ref > 0 && !A.nlaunch) {
       const int w = (int)blockIdx.x, n = B.nenv;
+#if MJH_PRIO_MODE == 0
       if (w*64 < n) __builtin_amdgcn_s_setprio(3);
       else if (w*16 < n) __builtin_amdgcn_s_setprio(2);
       else if (w*4 < n) __builtin_amdgcn_s_setprio(1);
+#else
+      // (measurement builds: the launch order deals one environment of each cost quartile to every SIMD -- quartile = level)
+      if (w*4 < n) { prio_floor = 3; __builtin_amdgcn_s_setprio(3); }
+      else if (w*2 < n) { prio_floor = 2; __builtin_amdgcn_s_setprio(2); }
+      else if (w*4 < 3*n) { prio_floor = 1; __builtin_amdgcn_s_setprio(1); }
+#endif
     }
   }
 #endif
@@ -700,11 +711,18 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
       ciptr cnt = MJH_F(B, counts, e);
       work += 64 + cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4);
 #if MJH_STEP_PRIO && !MJH_LANE_MODE
+#if MJH_PRIO_MODE == 1
+      if (false)
+#endif
       if (prio_ref > 0) {
         const int wk = wv_uniform_i(cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4));
-        if (wk >= 6*prio_ref) __builtin_amdgcn_s_setprio(3);
-        else if (wk >= 4*prio_ref) __builtin_amdgcn_s_setprio(2);
-        else if (wk >= 2*prio_ref) __builtin_amdgcn_s_setprio(1);
+        int lvl = wk >= 6*prio_ref ? 3 : (wk >= 4*prio_ref ? 2 : (wk >= 2*prio_ref ? 1 : 0));
+#if MJH_PRIO_MODE == 2
+        lvl = lvl > prio_floor ? lvl : prio_floor;
+#endif
+        if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+        else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+        else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
 #endif

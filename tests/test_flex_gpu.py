@@ -158,3 +158,35 @@ def test_jelly_batch_of_64_on_gpu(rb, hip_lib):
         ncon_seen = max(ncon_seen, int(d.ncon))
     print("jelly batch: contacts at the end of the sampled rollouts up to", ncon_seen)
     assert ncon_seen > 0
+
+
+def test_trilinear_batch_of_128_on_gpu(rb, hip_lib):
+    """a BATCH of interpolated-flex environments (128 x trilinear.xml, different node velocities, 450 steps from the reset state:
+    the fall and the first ~100 steps on the capsule): three of the environments bit for bit, every step, against the
+    reference (linked with the kernels' sin / cos) stepped from the same state; all environments distinct"""
+    from mujoco_amd import _capi as K
+    m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "trilinear.mjb"), kind="devmath")
+    dm = K.DeviceModel(hip_lib, m)
+    nenv, T = 128, 450
+    b = K.Batch(dm, nenv)
+    b.reset()
+    rng = np.random.default_rng(5)
+    s0 = np.zeros((nenv, dm.nstate))
+    s0[:, 1:1 + dm.nq] = b.get("qpos")[0]
+    s0[:, 1 + dm.nq:1 + dm.nq + dm.nv] = rng.normal(0, 0.05, size=(nenv, dm.nv))
+    d = rb.MjData(m)
+    mocap = (np.asarray(d.mocap_pos).reshape(1, -1), np.asarray(d.mocap_quat).reshape(1, -1))
+    b.set("mocap_pos", np.repeat(mocap[0], nenv, 0)); b.set("mocap_quat", np.repeat(mocap[1], nenv, 0))
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((nenv, T, dm.nu)))
+    assert b.get("warning").sum() == 0
+    assert len({out[e, -1].tobytes() for e in range(nenv)}) == nenv
+    spec = rb.mjSTATE_FULLPHYSICS
+    ncon_seen = 0
+    for e in (0, 77, 127):
+        rb.mj_resetData(m, d)
+        rb.mj_setState(m, d, s0[e], spec)
+        for t in range(T):
+            rb.mj_step(m, d)
+            assert np.array_equal(out[e, t], rb.mj_getState(m, d, spec)), (e, t)
+            ncon_seen = max(ncon_seen, int(d.ncon))
+    assert ncon_seen > 0
