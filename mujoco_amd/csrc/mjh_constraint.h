@@ -381,6 +381,14 @@ MJH_DEV void stage_equality_rows(MREF M, BREF B, int e, const Efc& P) {
       MJH_FOR_LANES(k, nk) { const int ed = M.eqrow_edge[k0 + k]; P.pos[r0 + k] = len[ed] - M.flexedge_length0[ed]; }
       continue;
     }
+    if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEXVERT) {
+      // vertex constraints (:1013-1038): two rows per vertex, position error = the strain invariants mj_flex left in
+      // flexvert_length; the rows are the vertex's flexvert_J rows (cut by stage_csr_rows)
+      crptr vl = MJH_G(B, flexvert_length, e);
+      const int k0 = M.eq_rowadr[q], nk = M.eq_rowadr[q + 1] - k0;
+      MJH_FOR_LANES(k, nk) P.pos[r0 + k] = vl[M.eqrow_edge[k0 + k]];
+      continue;
+    }
     if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
       real pos0[3], pos1[3], cpos[6] = {0, 0, 0, 0, 0, 0};
       int b0, b1;
@@ -758,6 +766,8 @@ MJH_DEVN void stage_make_constraint(MREF M_, BREF B_, int e_) {
       const int r0 = MJH_G(B, eq_efcadr, e)[id];
       if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEX) {
         dA = M.flexedge_invweight0[M.eqrow_edge[M.eq_rowadr[id] + (r - r0)]];      // (mj_diagApprox :1779-1790)
+      } else if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEXVERT) {
+        dA = M.body_invweight0[2*M.flexvert_bodyid[M.eqrow_edge[M.eq_rowadr[id] + (r - r0)] >> 1]];      // (:1794-1806)
       } else if (et == MJH_EQ_CONNECT || et == MJH_EQ_WELD) {
         int b1 = M.eq_obj1id[id], b2 = M.eq_obj2id[id];
         if (M.eq_objsite[id]) { b1 = M.site_bodyid[b1]; b2 = M.site_bodyid[b2]; }

@@ -144,6 +144,8 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
         // (flex edge constraints: the edge's flexedge_J row)
         const int ed = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
         nnz = M.flexedge_J_rownnz[ed];
+      } else if (et == MJH_EQ_FLEXVERT) {
+        nnz = M.fv_rownnz[M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])]];
       } else {
         int cols[MJH_CSR_CHAIN_MAX];
         nnz = csr_equality_cols(M, id, cols);
@@ -201,6 +203,12 @@ MJH_DEVN void stage_csr_rows(MREF M_, BREF B_, int e_) {
         const int f0 = M.flexedge_J_rowadr[ed], fn = M.flexedge_J_rownnz[ed];
         crptr fJ = MJH_F(B, flexedge_J, e);
         for (int q = 0; q < fn; q++) { colind[a0 + q] = M.flexedge_J_colind[f0 + q]; val[a0 + q] = fJ[f0 + q]; }
+      } else if (M.eq_type[id] == MJH_EQ_FLEXVERT) {
+        // (vertex constraints: the vertex's flexvert_J row)
+        const int vr = M.eqrow_edge[M.eq_rowadr[id] + (r - MJH_G(B, eq_efcadr, e)[id])];
+        const int f0 = M.fv_rowadr[vr], fn = M.fv_rownnz[vr];
+        crptr fJ = MJH_G(B, flexvert_J, e);
+        for (int q = 0; q < fn; q++) { colind[a0 + q] = M.fv_colind[f0 + q]; val[a0 + q] = fJ[f0 + q]; }
       } else {
         // connect / weld / joint couplings: cut from the dense row stage_equality_rows wrote
         int cols[MJH_CSR_CHAIN_MAX];

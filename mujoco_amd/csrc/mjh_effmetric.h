@@ -13,8 +13,12 @@
 // blocks once (lane per element), and a lane per CSR block then sums the block's contributions in the reference's order
 // (bending stencils in edge order, then stretch elements in element order: the list of the model build).  The stencil
 // operators of the shift likewise: per-edge / per-element terms first, then a lane per vertex sums them in the order the
-// reference adds them to that vertex's dofs.  Scope (model build): standard flexes with stretch stiffness whose vertices
-// are bodies of three sliders or pinned; no passive contacts.
+// reference adds them to that vertex's dofs.  Scope (model build): standard flexes whose vertices are bodies of three
+// sliders or pinned; no passive contacts.  With bending stiffness ONLY (s.efm == 2) the reference assembles no CSR: K vec
+// is the bending stencil operator (mjd_flexBend_mul :1358) and the preconditioner solves the covered dofs with the CONSTANT
+// sparse factor of M + (h^2 + h damping) K_bend that mj_setConst left in the model (effBlockApply's flg_bend branch :3288;
+// mju_cholSolveSparse, engine_util_solve.c:387 -- its two sweeps run level by level, a lane per row whose operands are final,
+// every row's subtractions in the reference's order).
 // (included once per SPMD mode by mjh_stages.inc: no include guard)
 
 #if !MJH_LANE_MODE
@@ -64,6 +68,64 @@ MJH_DEV int em_flex_stretch(MREF M, int f) {
 }
 MJH_DEV int em_flex_bend(MREF M, int f) { return !M.flex_rigid[f] && M.flex_dim[f] == 2 && M.flex_bendingadr[f] >= 0; }
 
+
+// per-edge terms of (s1 + s2 damping) K_bend vec (mjd_flexBend_mul :1358): the four flap vertices' 3-vectors of every
+// interior edge, into flexbend_frc[24 ed + 3 i + x]; a lane per vertex then adds them in edge order (eff_bend_gather)
+template <class VP>
+MJH_DEV void eff_bend_terms(MREF M, BREF B, int e, VP vec, real s1, real s2) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr xmat = MJH_F(B, xmat, e);
+  rptr bterm = MJH_G(B, flexbend_frc, e);
+  if (!s.nflexbend) return;
+  MJH_FOR_LANES(ed, s.nflexedge) {
+    const int f = M.flexedge_flex[ed];
+    const int v3i = M.flexedge_flap[2*ed + 1];
+    if (!em_flex_bend(M, f) || v3i < 0) continue;
+    const real scale = s1 + s2*M.flex_damping[f];
+    const int v[4] = {(int)M.flexedge_vert[2*ed], (int)M.flexedge_vert[2*ed + 1], (int)M.flexedge_flap[2*ed], v3i};
+    auto b = M.flex_bending + M.flex_bendingadr[f] + 17*(ed - M.flex_edgeadr[f]);
+    real w[4][3]; int has[4];
+    for (int j = 0; j < 4; j++) {
+      const int bj = M.flexvert_bodyid[v[j]];
+      has[j] = M.body_dofnum[bj] != 0;
+      if (has[j]) { real qv[3] = {vec[M.body_dofadr[bj]], vec[M.body_dofadr[bj] + 1], vec[M.body_dofadr[bj] + 2]}; m3_mulvec(w[j], xmat + 9*bj, qv); }
+      else { w[j][0] = 0; w[j][1] = 0; w[j][2] = 0; }
+    }
+    for (int i = 0; i < 4; i++) {
+      real vl[3] = {0, 0, 0};
+      if (has[i]) {
+        real vw[3] = {0, 0, 0};
+        for (int j = 0; j < 4; j++) {
+          if (!has[j]) continue;
+          const real q = b[4*i + j];
+          for (int x = 0; x < 3; x++) vw[x] += q*w[j][x];
+        }
+        m3_multvec(vl, xmat + 9*M.flexvert_bodyid[v[i]], vw);
+      }
+      for (int x = 0; x < 3; x++) bterm[24*ed + 3*i + x] = scale*vl[x];
+    }
+  }
+}
+// res += K_bend-terms of eff_bend_terms, vertex by vertex in the order the reference's edge loop reaches the vertex
+template <class RP>
+MJH_DEV void eff_bend_gather(MREF M, BREF B, int e, RP res) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr bterm = MJH_G(B, flexbend_frc, e);
+  if (!s.nflexbend) return;
+  MJH_FOR_LANES(v, s.nflexvert) {
+    const int bid = M.flexvert_bodyid[v];
+    if (!M.body_dofnum[bid] || !em_flex_bend(M, M.flexvert_flex[v])) continue;
+    const int d0 = M.body_dofadr[bid];
+    real acc[3] = {res[d0], res[d0 + 1], res[d0 + 2]};
+    for (int a = M.flexvert_bendadr[v]; a < M.flexvert_bendadr[v + 1]; a++) {
+      const int it = M.flexvert_bend[a];
+      const int ed = it >> 2, i = it & 3;
+      for (int x = 0; x < 3; x++) acc[x] += bterm[24*ed + 3*i + x];
+    }
+    for (int x = 0; x < 3; x++) res[d0 + x] = acc[x];
+  }
+}
+
 MJH_DEVN void stage_eff_build(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -78,6 +140,7 @@ MJH_DEVN void stage_eff_build(MREF M_, BREF B_, int e_) {
   rptr Lb = MJH_G(B, efm_L, e);
   rptr cs = MJH_G(B, efm_c, e);
 
+  if (s.efm == 1) {
   // ---- (a) stretch blocks of every element, in dof space: blkd(i, j) = R_bi' [2 scale sum_ab M_ab s_a s_b d_a d_b' + scale (sum_a Me_a s_a s_b) I] R_bj
   MJH_FOR_LANES(t, s.nflexelem) {
     const int f = M.flexelem_flex[t];
@@ -178,41 +241,13 @@ MJH_DEVN void stage_eff_build(MREF M_, BREF B_, int e_) {
     }
     for (int q = 0; q < 9; q++) Lb[9*sl + q] = Bk[q];
   }
+  }
   // ---- (d) the shift c = -h (K_bend + K_stretch) qvel through the stencil operators (mjd_effShift :3398)
   // per-edge bending terms (scale vl of the four flap vertices) and per-element stretch terms (rl of both ends of every
   // local edge); eblk is free again: the blocks above have been consumed
   wv_sync();
-  rptr bterm = MJH_G(B, flexbend_frc, e);
-  if (s.nflexbend) {
-    MJH_FOR_LANES(ed, s.nflexedge) {
-      const int f = M.flexedge_flex[ed];
-      const int v3i = M.flexedge_flap[2*ed + 1];
-      if (!em_flex_bend(M, f) || v3i < 0) continue;
-      const real scale = -h + 0*M.flex_damping[f];
-      const int v[4] = {(int)M.flexedge_vert[2*ed], (int)M.flexedge_vert[2*ed + 1], (int)M.flexedge_flap[2*ed], v3i};
-      auto b = M.flex_bending + M.flex_bendingadr[f] + 17*(ed - M.flex_edgeadr[f]);
-      real w[4][3]; int has[4];
-      for (int j = 0; j < 4; j++) {
-        const int bj = M.flexvert_bodyid[v[j]];
-        has[j] = M.body_dofnum[bj] != 0;
-        if (has[j]) { real qv[3] = {qvel[M.body_dofadr[bj]], qvel[M.body_dofadr[bj] + 1], qvel[M.body_dofadr[bj] + 2]}; m3_mulvec(w[j], xmat + 9*bj, qv); }
-        else { w[j][0] = 0; w[j][1] = 0; w[j][2] = 0; }
-      }
-      for (int i = 0; i < 4; i++) {
-        real vl[3] = {0, 0, 0};
-        if (has[i]) {
-          real vw[3] = {0, 0, 0};
-          for (int j = 0; j < 4; j++) {
-            if (!has[j]) continue;
-            const real q = b[4*i + j];
-            for (int x = 0; x < 3; x++) vw[x] += q*w[j][x];
-          }
-          m3_multvec(vl, xmat + 9*M.flexvert_bodyid[v[i]], vw);
-        }
-        for (int x = 0; x < 3; x++) bterm[24*ed + 3*i + x] = scale*vl[x];
-      }
-    }
-  }
+  crptr bterm = MJH_G(B, flexbend_frc, e);
+  eff_bend_terms(M, B, e, qvel, -h, (real)0);
   MJH_FOR_LANES(t, s.nflexelem) {
     const int f = M.flexelem_flex[t];
     if (!em_flex_stretch(M, f)) continue;
@@ -279,6 +314,15 @@ MJH_DEVN void stage_eff_build(MREF M_, BREF B_, int e_) {
 // res += K vec (mjd_effMulAdd :3185: rows with stored entries only)
 template <class RP, class VP>
 MJH_DEV void eff_mul_add(MREF M, BREF B, int e, RP res, VP vec) {
+  if (M.s.efm == 2) {
+    // no assembled CSR: the bending stencil operator with scale h^2 + h damping (mjd_effMulAdd :3203)
+    const real h = M.o.timestep;
+    eff_bend_terms(M, B, e, vec, h*h, h);
+    wv_sync();
+    eff_bend_gather(M, B, e, res);
+    wv_sync();
+    return;
+  }
   crptr Kv = MJH_G(B, efm_K_val, e);
   MJH_FOR_LANES(i, M.s.nv) {
     const int nnz = M.efm_rownnz[i];
@@ -312,6 +356,44 @@ MJH_DEV void eff_block_apply(MREF M, BREF B, int e, XP x, BP b, WP rhs) {
   crptr Lb = MJH_G(B, efm_L, e);
   MJH_FOR_LANES(i, s.nv) rhs[i] = b[i];
   wv_sync();
+  if (s.efm == 2) {
+    // bending only: M^-1 off the dofs the constant factor covers, the exact (M + K_bend)^-1 on them
+    MJH_FOR_LANES(i, s.nv) x[i] = M.e0_cov[i] ? (real)0 : (real)rhs[i];
+    wv_sync();
+    solve_ld(M, x, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));
+    rptr z = MJH_G(B, efm_bz, e);
+    // x <- L^-T x: row c is final once every row i > c that holds an entry in column c is; its subtractions in descending i
+    for (int l = 0; l < s.ne0lev1; l++) {
+      const int k0 = M.e0_l1adr[l], kn = M.e0_l1adr[l + 1] - k0;
+      MJH_FOR_LANES(k, kn) {
+        const int c = M.e0_l1row[k0 + k];
+        real acc = rhs[M.e0_dof[c]];
+        for (int q = M.e0_cscadr[c]; q < M.e0_cscadr[c + 1]; q++) {
+          const real t = z[M.e0_cscrow[q]];
+          if (t != 0) acc -= M.e0_L[M.e0_cscind[q]]*t;
+        }
+        if (acc != 0) acc /= M.e0_L[M.e0_rowadr[c] + M.e0_rownnz[c] - 1];
+        z[c] = acc;
+      }
+      wv_sync();
+    }
+    // x <- L^-1 x: row i is final once the rows of its columns are
+    for (int l = 0; l < s.ne0lev2; l++) {
+      const int k0 = M.e0_l2adr[l], kn = M.e0_l2adr[l + 1] - k0;
+      MJH_FOR_LANES(k, kn) {
+        const int i = M.e0_l2row[k0 + k];
+        const int adr = M.e0_rowadr[i], nnz = M.e0_rownnz[i];
+        real v = z[i];
+        if (nnz > 1) v -= dot_sparse_ref(M.e0_L + adr, z, nnz - 1, M.e0_colind + adr);
+        v /= M.e0_L[adr + nnz - 1];
+        z[i] = v;
+      }
+      wv_sync();
+    }
+    MJH_FOR_LANES(i, s.ne0) x[M.e0_dof[i]] = z[i];
+    wv_sync();
+    return;
+  }
   MJH_FOR_LANES(i, s.nv) x[i] = M.efm_rownnz[i] ? (real)0 : (real)rhs[i];
   wv_sync();
   solve_ld(M, x, MJH_F(B, qLD, e), MJH_F(B, qLDiagInv, e));

@@ -87,6 +87,115 @@ MJH_DEVN void stage_flex_pos(MREF M_, BREF B_, int e_) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// vertex constraints of shell flexes with edge equality "vert" (mj_flex, engine_core_smooth.c:745-918; Chen, Kry, Vouga:
+// "Locking-free Simulation of Isometric Thin Plates"): per vertex the mass-weighted deformation gradient over its edge
+// fan, the two invariants of its Cauchy strain as constraint residuals (flexvert_length) and their Jacobian rows
+// (flexvert_J).  One lane per vertex.  The reference scatters every edge's end-point Jacobians into two dense rows
+// (J0_dense / J1_dense: first body's chain, then the second's, edge after edge) and compresses them at the end; here an
+// entry of the row accumulates the same terms in the same order in place -- for every edge of the fan, every entry
+// whose dof lies on the first / second end body's chain (body_dofanc) takes that body's point-Jacobian column
+// (cdof_lin + cdof_ang x (pos - subtree_com[root]), mj_jacSparse) against the edge's derivative vectors
+// (mju_mulMatTVec: three rows in order, zero components skipped) -- and is scaled by sqrt(mass) at the end.
+// ------------------------------------------------------------------------------------------------
+MJH_DEV void flex_vert_rows(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  if (!s.nfv) return;
+  crptr vx = MJH_F(B, flexvert_xpos, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr scom = MJH_F(B, subtree_com, e);
+  rptr vlen = MJH_G(B, flexvert_length, e);
+  rptr Jv = MJH_G(B, flexvert_J, e);
+  MJH_FOR_LANES(v, s.nflexvert) {
+    const int f = M.flexvert_flex[v];
+    const int a0 = M.fv_rowadr[2*v], a1 = M.fv_rowadr[2*v + 1], nnz = M.fv_rownnz[2*v];
+    for (int j = 0; j < nnz; j++) { Jv[a0 + j] = 0; Jv[a1 + j] = 0; }
+    if (M.flex_edgeequality[f] != 2) { vlen[2*v] = 0; vlen[2*v + 1] = 0; continue; }
+    const int ebase = M.flex_edgeadr[f];
+    const int ne = M.fv_edgenum[v], ea = M.fv_edgeadr[v];
+    auto metric = M.fv_metric + 4*v;
+    auto mul322 = [](real* C, const real* A, auto Bm) {
+      C[0] = A[0]*Bm[0] + A[1]*Bm[2]; C[1] = A[0]*Bm[1] + A[1]*Bm[3];
+      C[2] = A[2]*Bm[0] + A[3]*Bm[2]; C[3] = A[2]*Bm[1] + A[3]*Bm[3];
+      C[4] = A[4]*Bm[0] + A[5]*Bm[2]; C[5] = A[4]*Bm[1] + A[5]*Bm[3];
+    };
+    auto edge_weight = [&](int v1, int v2) -> real {
+      const int bn = M.flexvert_bodyid[v == v1 ? v2 : v1];
+      real w = 1;
+      if (bn >= 0) { w = M.body_mass[bn]; if (w < MJH_MINVAL) w = MJH_MINVAL; }
+      return w;
+    };
+    real A[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < ne; k++) {
+      const int ge = ebase + M.fv_edge[ea + k];
+      const int v1 = M.flexedge_vert[2*ge], v2 = M.flexedge_vert[2*ge + 1];
+      auto dx = M.fv_dx + 3*ge;
+      const real dy[3] = {vx[3*v2] - vx[3*v1], vx[3*v2 + 1] - vx[3*v1 + 1], vx[3*v2 + 2] - vx[3*v1 + 2]};
+      const real w = edge_weight(v1, v2);
+      A[0] += w*dy[0]*dx[0]; A[1] += w*dy[0]*dx[1];
+      A[2] += w*dy[1]*dx[0]; A[3] += w*dy[1]*dx[1];
+      A[4] += w*dy[2]*dx[0]; A[5] += w*dy[2]*dx[1];
+    }
+    real F[6], cauchy[4];
+    mul322(F, A, metric);
+    cauchy[0] = F[0]*F[0] + F[2]*F[2] + F[4]*F[4];
+    cauchy[1] = F[0]*F[1] + F[2]*F[3] + F[4]*F[5];
+    cauchy[2] = F[1]*F[0] + F[3]*F[2] + F[5]*F[4];
+    cauchy[3] = F[1]*F[1] + F[3]*F[3] + F[5]*F[5];
+    real scale = 1;
+    {
+      const int b = M.flexvert_bodyid[v];
+      if (b >= 0) { const real mass = M.body_mass[b]; if (mass > MJH_MINVAL) scale = sqrt(mass); }
+    }
+    vlen[2*v] = (cauchy[0] + cauchy[3] - 2)*scale;
+    vlen[2*v + 1] = (cauchy[0]*cauchy[3] - cauchy[1]*cauchy[2] - 1)*scale;
+    real FB[6], Fadj[6], FadjBinv[6];
+    const real adj[4] = {cauchy[3], -cauchy[1], -cauchy[2], cauchy[0]};
+    mul322(FB, F, metric);
+    mul322(Fadj, F, adj);
+    mul322(FadjBinv, Fadj, metric);
+    for (int k = 0; k < ne; k++) {
+      const int ge = ebase + M.fv_edge[ea + k];
+      const int v1 = M.flexedge_vert[2*ge], v2 = M.flexedge_vert[2*ge + 1];
+      auto dx = M.fv_dx + 3*ge;
+      const real w = edge_weight(v1, v2);
+      real d1a[3], d1b[3], d2a[3], d2b[3];        // dI1/dy1, dI1/dy2, dI2/dy1, dI2/dy2
+      for (int r = 0; r < 3; r++) {
+        const real t1 = dot_ref(FB + 2*r, dx, 2), t2 = dot_ref(FadjBinv + 2*r, dx, 2);
+        d1a[r] = t1*(-2*w); d1b[r] = d1a[r]*(real)(-1);
+        d2a[r] = t2*(-2*w); d2b[r] = d2a[r]*(real)(-1);
+      }
+      const int b1 = M.flexvert_bodyid[v1], b2 = M.flexvert_bodyid[v2];
+      const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+      real off1[3], off2[3];
+      v3_sub(off1, vx + 3*v1, scom + 3*M.body_rootid[b1]);
+      v3_sub(off2, vx + 3*v2, scom + 3*M.body_rootid[b2]);
+      for (int j = 0; j < nnz; j++) {
+        const int col = M.fv_colind[a0 + j];
+        const int in1 = (M.body_dofanc[w1*s.nvw + (col >> 5)] >> (col & 31)) & 1;
+        const int in2 = (M.body_dofanc[w2*s.nvw + (col >> 5)] >> (col & 31)) & 1;
+        if (!in1 && !in2) continue;
+        crptr cd = cdof + 6*col;
+        real r0 = Jv[a0 + j], r1 = Jv[a1 + j];
+        auto add = [&](const real* off, const real* da, const real* db) {
+          real t[3];
+          v3_cross(t, cd, off);
+          const real jc[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+          real q0 = 0, q1 = 0;
+          for (int r = 0; r < 3; r++) { if (da[r] != 0) q0 += jc[r]*da[r]; }
+          for (int r = 0; r < 3; r++) { if (db[r] != 0) q1 += jc[r]*db[r]; }
+          r0 += q0; r1 += q1;
+        };
+        if (in1) add(off1, d1a, d2a);
+        if (in2) add(off2, d1b, d2b);
+        Jv[a0 + j] = r0; Jv[a1 + j] = r1;
+      }
+    }
+    for (int j = 0; j < nnz; j++) { Jv[a0 + j] = (real)0 + Jv[a0 + j]*scale; Jv[a1 + j] = (real)0 + Jv[a1 + j]*scale; }
+  }
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // edge lengths and Jacobians                           (mj_flex, engine_core_smooth.c:700-745)
 // One lane per edge.  Row e of flexedge_J holds, for every dof of the two end bodies (the model's
 // flexedge_J_colind), vec' (jac2 - jac1) with vec the unit vector from vertex 1 to vertex 2: the point
@@ -150,6 +259,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
       }
     }
     wv_sync();
+    flex_vert_rows(M, B, e);
     return;
   }
   MJH_FOR_LANES(ed, s.nflexedge) {
@@ -201,6 +311,7 @@ MJH_DEVN void stage_flex_edges(MREF M_, BREF B_, int e_) {
     }
   }
   wv_sync();
+  flex_vert_rows(M, B, e);
 }
 
 // flexedge_velocity = flexedge_J qvel                  (mj_fwdVelocity, engine_forward.c:188-197)

@@ -158,7 +158,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->nv == 0, "model without degrees of freedom");
   for (int i = 0; i < m->neq; i++) {
     MJH_REJECT(m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT &&
-               m->eq_type[i] != mjEQ_TENDON && m->eq_type[i] != mjEQ_FLEX, "flex vertex / strain equality constraints");
+               m->eq_type[i] != mjEQ_TENDON && m->eq_type[i] != mjEQ_FLEX && m->eq_type[i] != mjEQ_FLEXVERT, "flex strain equality constraints");
     if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD)
       MJH_REJECT(m->eq_objtype[i] != mjOBJ_BODY && m->eq_objtype[i] != mjOBJ_SITE, "connect/weld between objects other than bodies or sites");
     const mjtNum* r = m->eq_solref + 2*i;
@@ -182,7 +182,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                    "interpolated flex nodes other than bodies with three sliders of their own or fixed to the world");
       }
     }
-    MJH_REJECT(m->flex_edgeequality[f] != 0 && m->flex_edgeequality[f] != 1, "flex vertex / strain equality constraints");
+    MJH_REJECT(m->flex_edgeequality[f] != 0 && m->flex_edgeequality[f] != 1 && m->flex_edgeequality[f] != 2, "flex strain equality constraints");
+    MJH_REJECT(m->flex_edgeequality[f] == 2 && (m->flex_dim[f] != 2 || m->flex_interp[f] != 0 || m->flex_rigid[f]),
+               "flex vertex equality constraints on a flex that is not a deformable shell");
     MJH_REJECT(m->flex_passive[f] != 0, "passive (penalty) flex contacts");
     MJH_REJECT(m->flex_dim[f] < 1 || m->flex_dim[f] > 3, "flex dimension outside 1..3");
   }
@@ -373,6 +375,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       size = 0;
       for (int ed = m->flex_edgeadr[f]; ed < m->flex_edgeadr[f] + m->flex_edgenum[f]; ed++) if (!m->flexedge_rigid[ed]) size++;
     }
+    if (m->eq_type[i] == mjEQ_FLEXVERT) {
+      // two rows per vertex of the flex (mj_instantiateEquality :1013-1038); a row without entries would be dropped by
+      // mj_addConstraint's empty guard while mj_diagApprox still counts it: not reproduced
+      const int f = m->eq_obj1id[i];
+      MJH_REJECT(m->flex_edgeequality[f] != 2, "a flex vertex equality constraint on a flex without vertex constraints");
+      size = 2*m->flex_vertnum[f];
+      for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++)
+        MJH_REJECT(m->flexvert_J_rownnz[2*v] == 0, "flex vertex equality constraints with a vertex whose row is empty");
+    }
     if (m->eq_type[i] == mjEQ_CONNECT || m->eq_type[i] == mjEQ_WELD) {
       // both bodies static: the Jacobian block is identically zero and mj_addConstraint drops the
       // whole constraint (empty-block guard, engine_core_constraint.c:424-447)
@@ -384,10 +395,17 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   {
     bool anyflex = false;
-    for (int i = 0; i < m->neq; i++) if (m->eq_type[i] == mjEQ_FLEX) anyflex = true;
+    for (int i = 0; i < m->neq; i++) if (m->eq_type[i] == mjEQ_FLEX || m->eq_type[i] == mjEQ_FLEXVERT) anyflex = true;
     s.neqrow = anyflex ? H->eq_rowadr[m->neq] : 0;
     H->eqrow_edge.assign((size_t)s.neqrow, -1);
     for (int i = 0; i < m->neq && anyflex; i++) {
+      if (m->eq_type[i] == mjEQ_FLEXVERT) {
+        // (vertex constraints: the flexvert row 2 v + j of every row)
+        const int f = m->eq_obj1id[i];
+        int k = H->eq_rowadr[i];
+        for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) { H->eqrow_edge[k++] = 2*v; H->eqrow_edge[k++] = 2*v + 1; }
+        continue;
+      }
       if (m->eq_type[i] != mjEQ_FLEX) continue;
       const int f = m->eq_obj1id[i];
       int k = H->eq_rowadr[i];
@@ -1513,9 +1531,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const bool ref_sparse0 = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
     // (equality rows: flex edge constraints only -- their rows are the model's flexedge_J rows; the dense rows of the other
     // kinds would have to be cut by a scan)
-    bool eq_ok = true, eq_flex = false;
+    bool eq_ok = true, eq_flex = false, eq_flexvert = false;
     for (int i = 0; i < m->neq; i++) {
       if (m->eq_type[i] == mjEQ_FLEX) eq_flex = true;
+      else if (m->eq_type[i] == mjEQ_FLEXVERT) eq_flexvert = true;
       else if (m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT) eq_ok = false;   // (tendon couplings: not on this path)
     }
     s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && eq_ok && m->ntendon == 0 &&
@@ -1544,6 +1563,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // flex edge constraints have no dense row: they need one of the compressed-row paths under a primal solver
     {
       const bool mask_path = ref_sparse0 && m->nv <= 128 && m->opt.solver != mjSOL_PGS;
+      MJH_REJECT(eq_flexvert && !s.csr, "flex vertex equality constraints outside the explicit-index row path (CG, sparse Jacobian, more than 128 dofs)");
       MJH_REJECT(eq_flex && !s.csr && !mask_path, "flex edge equality constraints outside the compressed-Jacobian paths (sparse Jacobian "
                                                   "under CG / Newton up to 128 dofs; beyond: CG, no tendons or tendon couplings)");
     }
@@ -1648,6 +1668,43 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     copy_arr(H->flexedge_J_rownnz, m->flexedge_J_rownnz, m->nflexedge);
     copy_arr(H->flexedge_J_rowadr, m->flexedge_J_rowadr, m->nflexedge);
     copy_arr(H->flexedge_J_colind, m->flexedge_J_colind, m->nJfe);
+    {
+      // flex vertex constraints (mjh_flex.h: flex_vert_rows)
+      bool anyvert = false;
+      for (int f = 0; f < nf; f++) if (m->flex_edgeequality[f] == 2) anyvert = true;
+      s.nfv = anyvert ? m->nflexvert : 0;
+      s.nJfv2 = anyvert ? 2*(int)m->nJfv : 0;
+      s.nfvedge = anyvert ? 2*m->nflexedge : 0;
+      s.nfvdx = anyvert ? m->nflexedge : 0;
+      H->fv_rownnz.clear(); H->fv_rowadr.clear(); H->fv_colind.clear(); H->fv_edgeadr.clear(); H->fv_edgenum.clear(); H->fv_edge.clear();
+      H->fv_metric.clear(); H->fv_dx.clear();
+      if (anyvert) {
+        copy_arr(H->fv_rownnz, m->flexvert_J_rownnz, 2*m->nflexvert);
+        copy_arr(H->fv_rowadr, m->flexvert_J_rowadr, 2*m->nflexvert);
+        copy_arr(H->fv_colind, m->flexvert_J_colind, s.nJfv2);
+        copy_arr(H->fv_edgeadr, m->flex_vertedgeadr, m->nflexvert);
+        copy_arr(H->fv_edgenum, m->flex_vertedgenum, m->nflexvert);
+        copy_arr(H->fv_edge, m->flex_vertedge, 2*m->nflexedge);
+        copy_arr(H->fv_metric, m->flex_vertmetric, 4*m->nflexvert);
+        H->fv_dx.assign((size_t)3*m->nflexedge, 0);
+        for (int f = 0; f < nf; f++) {
+          if (m->flex_edgeequality[f] != 2) continue;
+          const int vbase = m->flex_vertadr[f], ebase = m->flex_edgeadr[f];
+          for (int ed = 0; ed < m->flex_edgenum[f]; ed++) {
+            // rest edge vector, scaled: the vertices are stored in units of the half sizes (mj_flex :765-772)
+            const int v1 = m->flex_edge[2*(ebase + ed)], v2 = m->flex_edge[2*(ebase + ed) + 1];
+            mjtNum dx[3];
+            for (int x = 0; x < 3; x++) dx[x] = m->flex_vert0[3*(vbase + v2) + x] - m->flex_vert0[3*(vbase + v1) + x];
+            for (int x = 0; x < 3; x++) dx[x] *= 2*m->flex_size[3*f + x];
+            for (int x = 0; x < 3; x++) H->fv_dx[3*(ebase + ed) + x] = dx[x];
+          }
+          for (int v = vbase; v < vbase + m->flex_vertnum[f]; v++) {
+            MJH_REJECT(m->flexvert_J_rownnz[2*v] != m->flexvert_J_rownnz[2*v + 1], "internal: flex vertex constraint rows with different patterns");
+            MJH_REJECT(m->flex_vertedgeadr[v] < 0 || m->flex_vertedgeadr[v] + m->flex_vertedgenum[v] > 2*m->nflexedge, "internal: flex vertex adjacency");
+          }
+        }
+      }
+    }
     copy_arr(H->flex_vert, m->flex_vert, 3*m->nflexvert);
     copy_arr(H->flexedge_length0, m->flexedge_length0, m->nflexedge);
     copy_arr(H->flex_stiffness, m->flex_stiffness, m->nflexstiffness);
@@ -1814,6 +1871,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // with, per 3 x 3 block, the list of its contributions in the reference's order of accumulation.
     s.efm = 0;
     H->efm_rownnz.clear(); H->efm_rowadr.clear(); H->efm_colind.clear(); H->efm_slotvert.clear(); H->efm_slotdiag.clear();
+    H->e0_dof.clear(); H->e0_rownnz.clear(); H->e0_rowadr.clear(); H->e0_colind.clear(); H->e0_L.clear(); H->e0_cov.clear();
+    H->e0_cscind.clear(); H->e0_cscrow.clear(); H->e0_l1row.clear(); H->e0_l2row.clear();
     H->efm_vertslot.clear(); H->efmblk_slot.clear(); H->efmblk_pos.clear(); H->efmblk_cadr.assign(1, 0); H->efmblk_c.clear(); H->efmblk_cij.clear();
     {
       bool implicit_stiff = false, has_stretch = false;
@@ -1828,7 +1887,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       if (flexcg) {
         // (bending alone: the reference keeps the stencil operator and a constant sparse factor from mj_setConst -- not built;
         // vertices with one or two dofs of their own: mjd_flexStretch_mul reads three consecutive dofs at their address)
-        MJH_REJECT(!has_stretch, "the implicit effective metric of a flex with bending stiffness only (constant factor of mj_setConst)");
         MJH_REJECT(m->nv <= 128, "the implicit effective metric (mj_flexCG) in models of at most 128 degrees of freedom");
         for (int v = 0; v < m->nflexvert; v++) {
           const int b = m->flex_vertbodyid[v], f = 0;
@@ -1836,7 +1894,71 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           MJH_REJECT(m->body_dofnum[b] != 0 && !(m->body_dofnum[b] == 3 && m->body_simple[b] == 2),
                      "the implicit effective metric with flex vertices that are not three sliders of their own (or pinned)");
         }
-        s.efm = 1;
+        s.efm = has_stretch ? 1 : 2;
+        if (!has_stretch) {
+          // bending alone: no per-step CSR (mjd_effBuild leaves nefmK = 0); the matrix-vector product is the stencil operator
+          // (mjd_flexBend_mul) and the preconditioner the CONSTANT factor of mj_setConst on the dofs it covers
+          // (effBlockApply's flg_bend branch, engine_derivative.c:3262-3301)
+          const int nbd = (int)m->nefm0dof, nL = (int)m->nefm0L;
+          MJH_REJECT(nbd <= 0 || nL < nbd, "internal: bending-only effective metric without the constant factor of mj_setConst");
+          s.ne0 = nbd; s.ne0L = nL; s.ne0off = nL - nbd;
+          H->e0_dof.assign(m->efm0_dofid, m->efm0_dofid + nbd);
+          H->e0_rownnz.assign(m->efm0_L_rownnz, m->efm0_L_rownnz + nbd);
+          H->e0_rowadr.assign(m->efm0_L_rowadr, m->efm0_L_rowadr + nbd);
+          H->e0_colind.assign(m->efm0_L_colind, m->efm0_L_colind + nL);
+          H->e0_L.assign(m->efm0_L, m->efm0_L + nL);
+          H->e0_cov.assign(m->nv, 0);
+          for (int i = 0; i < nbd; i++) { MJH_REJECT(H->e0_dof[i] < 0 || H->e0_dof[i] >= m->nv, "internal: constant metric factor (dof id)"); H->e0_cov[H->e0_dof[i]] = 1; }
+          // columns: the rows i > c that hold an entry in column c, descending (the order in which the first sweep of
+          // mju_cholSolveSparse subtracts from x[c]); levels of the two sweeps
+          std::vector<std::vector<std::pair<int, int>>> col(nbd);
+          for (int i = 0; i < nbd; i++) {
+            const int adr = H->e0_rowadr[i], nnz = H->e0_rownnz[i];
+            MJH_REJECT(nnz < 1 || adr < 0 || adr + nnz > nL || H->e0_colind[adr + nnz - 1] != i, "internal: constant metric factor (row layout)");
+            for (int j = 0; j < nnz - 1; j++) {
+              const int c = H->e0_colind[adr + j];
+              MJH_REJECT(c < 0 || c >= i, "internal: constant metric factor (column index)");
+              col[c].push_back({i, adr + j});
+            }
+          }
+          H->e0_cscadr.assign(nbd + 1, 0);
+          H->e0_cscind.clear(); H->e0_cscrow.clear();
+          std::vector<int> lev1(nbd, 0), lev2(nbd, 0);
+          for (int c = nbd - 1; c >= 0; c--) {
+            int l = 0;
+            for (auto& it : col[c]) l = std::max(l, lev1[it.first] + 1);
+            lev1[c] = l;
+          }
+          for (int c = 0; c < nbd; c++) {
+            H->e0_cscadr[c] = (int)H->e0_cscind.size();
+            for (int q = (int)col[c].size() - 1; q >= 0; q--) { H->e0_cscrow.push_back(col[c][q].first); H->e0_cscind.push_back(col[c][q].second); }
+          }
+          H->e0_cscadr[nbd] = (int)H->e0_cscind.size();
+          for (int i = 0; i < nbd; i++) {
+            int l = 0;
+            const int adr = H->e0_rowadr[i], nnz = H->e0_rownnz[i];
+            for (int j = 0; j < nnz - 1; j++) l = std::max(l, lev2[H->e0_colind[adr + j]] + 1);
+            lev2[i] = l;
+          }
+          auto schedule = [&](const std::vector<int>& lev, std::vector<int>& ladr, std::vector<int>& lrow) {
+            int nl = 0;
+            for (int i = 0; i < nbd; i++) nl = std::max(nl, lev[i] + 1);
+            ladr.assign(nl + 1, 0);
+            for (int i = 0; i < nbd; i++) ladr[lev[i] + 1]++;
+            for (int l = 0; l < nl; l++) ladr[l + 1] += ladr[l];
+            lrow.assign(nbd, 0);
+            std::vector<int> fill(ladr.begin(), ladr.end() - 1);
+            for (int i = 0; i < nbd; i++) lrow[fill[lev[i]]++] = i;
+            return nl;
+          };
+          s.ne0lev1 = schedule(lev1, H->e0_l1adr, H->e0_l1row);
+          s.ne0lev2 = schedule(lev2, H->e0_l2adr, H->e0_l2row);
+          H->efm_rownnz.assign(m->nv, 0);
+          H->efm_rowadr.assign(m->nv, 0);
+          s.nefmrow = m->nv; s.nefmK = 0; s.nefmslot = 0; s.nefmvert = 0; s.nefmblk = 0; s.nefmcon = 0;
+          H->efmblk_cadr.assign(1, 0);
+        }
+        if (has_stretch) {
         std::vector<int> vslot(m->nflexvert, -1), vdof;
         auto active = [&](int f) {
           if (m->flex_interp[f] || m->flex_rigid[f] || m->flex_dim[f] < 2) return false;
@@ -1932,8 +2054,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         H->efm_vertslot = vslot;
         s.nefmrow = m->nv; s.nefmK = nnz; s.nefmslot = nvert; s.nefmvert = m->nflexvert;
         s.nefmblk = (int)H->efmblk_slot.size(); s.nefmcon = (int)H->efmblk_c.size();
+        H->e0_cov.assign(m->nv, 0);
+        }
       }
       if (!s.efm) { s.nefmrow = s.nefmK = s.nefmslot = s.nefmvert = s.nefmblk = s.nefmcon = 0; H->efmblk_cadr.assign(1, 0); }
+      if (s.efm != 2) {
+        s.ne0 = s.ne0L = s.ne0off = s.ne0lev1 = s.ne0lev2 = 0;
+        H->e0_cscadr.assign(1, 0); H->e0_l1adr.assign(1, 0); H->e0_l2adr.assign(1, 0);
+      }
     }
     H->flexvert_bend.resize((size_t)4*s.nflexbend, 0);
     // flexedge_J by column, entries in ascending edge order (the order mj_springdamper adds edge forces to a dof, :770-787)

@@ -222,6 +222,31 @@
   X(efmblk_cadr, s.nefmblk + 1)                \
   X(efmblk_c, s.nefmcon)                       \
   X(efmblk_cij, s.nefmcon)                     \
+  /* flex vertex equality constraints (mjEQ_FLEXVERT; mj_flex, engine_core_smooth.c:745-918): the two rows of every \
+     vertex of a shell flex with edge equality "vert" (mjModel flexvert_J_*: both rows share one pattern, the dofs of the \
+     vertex body and of its edge neighbours), and the vertex -> adjacent edges lists (local edge ids) */ \
+  X(fv_rownnz, 2 * s.nfv)                      \
+  X(fv_rowadr, 2 * s.nfv)                      \
+  X(fv_colind, s.nJfv2)                        \
+  X(fv_edgeadr, s.nfv)                         \
+  X(fv_edgenum, s.nfv)                         \
+  X(fv_edge, s.nfvedge)                        \
+  /* bending-only metric (s.efm == 2): the CONSTANT sparse factor of M + (h^2 + h damping) K_bend from mj_setConst \
+     (mjModel efm0_*, engine_setconst.c:1366): row -> dof, the factor's rows (off-diagonal entries ascending, diagonal \
+     last), its off-diagonal entries by column with the rows descending (e0_cscind: address of the entry, e0_cscrow: its \
+     row), and the two level schedules of mju_cholSolveSparse's sweeps (rows whose operands are final, level by level) */ \
+  X(e0_dof, s.ne0)                             \
+  X(e0_rownnz, s.ne0)                          \
+  X(e0_rowadr, s.ne0)                          \
+  X(e0_colind, s.ne0L)                         \
+  X(e0_cscadr, s.ne0 + 1)                      \
+  X(e0_cscind, s.ne0off)                       \
+  X(e0_cscrow, s.ne0off)                       \
+  X(e0_l1adr, s.ne0lev1 + 1)                   \
+  X(e0_l1row, s.ne0)                           \
+  X(e0_l2adr, s.ne0lev2 + 1)                   \
+  X(e0_l2row, s.ne0)                           \
+  X(e0_cov, s.nefmrow)                         \
   X(flexdof_vert, s.nflexdofv)                 \
   X(flexvert_bend, 4 * s.nflexbend)            \
   /* flex collisions (mjh_flexcol.h).  colseg: the collision pass as segments (end of a range of static geom pairs, then \
@@ -358,6 +383,11 @@
   X(flexedge_invweight0, s.nflexedge)          \
   X(flex_stiffness, s.nflexstiffness)          \
   X(flex_bending, s.nflexbending)              \
+  X(e0_L, s.ne0L)                              \
+  /* flex vertex constraints: inverse reference shape matrix of every vertex (flex_vertmetric), rest vector of every \
+     edge from its first to its second vertex scaled by the flex's bounding box (2 flex_size) */ \
+  X(fv_metric, 4 * s.nfv)                      \
+  X(fv_dx, 3 * s.nfvdx)                        \
   X(flex_damping, s.nflex)                     \
   X(flex_edgestiffness, s.nflex)               \
   X(flex_edgedamping, s.nflex)                 \
@@ -447,6 +477,11 @@ struct DSizes {
   // implicit effective metric (0 unless mj_flexCG holds): rows (nv), stored entries of K, vertex slots, flex vertices (nflexvert),
   // 3 x 3 blocks, contributions
   int efm, nefmrow, nefmK, nefmslot, nefmvert, nefmblk, nefmcon;
+  // efm == 2 (bending stiffness only): rows / entries / off-diagonal entries of the constant factor, levels of its two sweeps
+  int ne0, ne0L, ne0off, ne0lev1, ne0lev2;
+  // flex vertex equality constraints: nflexvert when some flex carries them (else 0), entries of both rows of all vertices
+  // (2 nJfv), entries of flex_vertedge, edges with a rest vector (nflexedge)
+  int nfv, nJfv2, nfvedge, nfvdx;
   // interpolated flexes: nodes, vertices with interpolation tables (nflexvert when some flex is interpolated, else 0), finite
   // cells, entries of flexnode_cell
   int nflexnode, nflexivert, nflexcell, nflexnodecell;
@@ -619,6 +654,10 @@ enum {
   X(efm_c, s.nefmrow, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(efm_eblk, (s.efm ? 144 * s.nflexelem : 0), 0, MJH_T_GLB, MJH_T_GLB)           \
   X(efm_work, 6 * s.nefmrow, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(efm_bz, s.ne0, 0, MJH_T_GLB, MJH_T_GLB)                                       \
+  /* mjData flexvert_length, flexvert_J */ \
+  X(flexvert_length, 2 * s.nfv, 0, MJH_T_GLB, MJH_T_GLB)                          \
+  X(flexvert_J, s.nJfv2, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(flexvert_frc, 3 * (s.nflexdofv ? s.nflexvert : 0), 0, MJH_T_GLB, MJH_T_GLB)   \
   X(flexbend_frc, 24 * s.nflexbend, 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* mjData flexelem_aabb; candidate contacts of one body : flex job (dist, pos[3], normal[3], min_dist) */ \
@@ -890,7 +929,7 @@ enum {
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
   // pair_func: which narrowphase routine a static pair uses
   MJH_COL_PLANE_SPHERE = 0, MJH_COL_PLANE_CAPSULE = 1, MJH_COL_SPHERE_SPHERE = 2,
-  MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3, MJH_EQ_FLEX = 4,
+  MJH_EQ_CONNECT = 0, MJH_EQ_WELD = 1, MJH_EQ_JOINT = 2, MJH_EQ_TENDON = 3, MJH_EQ_FLEX = 4, MJH_EQ_FLEXVERT = 5,
   MJH_COL_SPHERE_CAPSULE = 3, MJH_COL_CAPSULE_CAPSULE = 4, MJH_COL_PLANE_CYLINDER = 5,
   MJH_COL_PLANE_BOX = 7, MJH_COL_SPHERE_BOX = 8, MJH_COL_SPHERE_CYLINDER = 9, MJH_COL_BOX_BOX = 10, MJH_COL_CAPSULE_BOX = 11,
   MJH_COL_UNSUPPORTED = 6,   // pair without a GPU collider (hfield, sdf): raises MJH_WARN_UNSUPPORTED if it survives the filter

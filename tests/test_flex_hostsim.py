@@ -624,6 +624,79 @@ def test_implicit_effective_metric_shell_with_bending(rb, hostsim_lib, tmp_path)
     assert _effective_metric(rb, hostsim_lib, tmp_path, "shell") > 40
 
 
+def _bending_only_metric(rb, lib, tmp_path, equality):
+    """A flex with bending stiffness ONLY under mj_flexCG: the reference assembles no CSR (nefmK = 0) -- K vec is the
+    bending stencil operator (mjd_flexBend_mul, engine_derivative.c:1358) and the preconditioner solves the covered dofs with
+    the constant sparse factor of mj_setConst (effBlockApply's flg_bend branch :3288, mju_cholSolveSparse).  The shift, the PCG
+    for qacc_smooth and free-running steps on the geoms: fields / states / counts / CG iteration counts identical."""
+    xml = tmp_path / "efm0.xml"
+    xml.write_text(shell_xml("8 8 1", SHELL_GEOMS, option=EFM_OPTION,
+                             body=f'<edge equality="{equality}" damping="1"/><contact selfcollide="none"/>'
+                                  '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="bend"/>'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.nefm0dof == m.nv and m.nefm0L > m.nv
+    dm = K.DeviceModel(lib, m)
+    assert dm.size("efm") == 2 and dm.size("ne0") == m.nv and dm.size("ne0lev1") > 1
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    d.qvel[:] = np.random.default_rng(0).normal(0, .05, m.nv)
+    for _ in range(5): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:1 + m.nq + m.nv])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    rb.mj_forward(m, d); b.forward()
+    assert d.efm_active == 1 and d.nefmK == 0 and d.nefmdof == 0
+    ref = np.asarray(d.efm_c).ravel()
+    assert np.array_equal(b.get("efm_c")[0][:ref.size], ref)
+    assert _fields_exact(b, d, ["qfrc_smooth", "qacc_smooth", "qacc"]) == []
+    maxcon, seen = _free_run(rb, lib, m, pre=60, nstep=60, csr=1)
+    return maxcon
+
+
+@pytest.mark.parametrize("equality", ["false", "true"])
+def test_implicit_effective_metric_bending_only(rb, hostsim_lib, tmp_path, equality):
+    assert _bending_only_metric(rb, hostsim_lib, tmp_path, equality) > 10
+
+
+def _vertex_constraints(rb, lib, tmp_path, option, elastic):
+    """mjEQ_FLEXVERT (edge equality "vert"; mj_flex engine_core_smooth.c:745-918, mj_instantiateEquality :1013): per vertex the
+    two invariants of the Cauchy strain of its mass-weighted edge fan as residuals, their Jacobian rows over the dofs of the
+    vertex and its neighbours.  flexvert_length / flexvert_J field by field, then free-running steps on the geoms."""
+    xml = tmp_path / "vert.xml"
+    xml.write_text(shell_xml("13 13 1", SHELL_GEOMS, option=option,
+                             body=f'<edge equality="vert" damping="1"/><contact selfcollide="none"/>{elastic}'))
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.nv > 128 and m.neq == 1 and m.eq_type[0] == 5
+    dm = K.DeviceModel(lib, m)
+    assert dm.size("csr") == 1
+    b = K.Batch(dm, 1)
+    d = rb.MjData(m)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .05, m.nv)
+    for _ in range(5): rb.mj_step(m, d)
+    s = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    b.set("time", s[None, :1]); b.set("qpos", s[None, 1:1 + m.nq]); b.set("qvel", s[None, 1 + m.nq:1 + m.nq + m.nv])
+    b.set("qacc_warmstart", d.qacc_warmstart[None, :])
+    rb.mj_forward(m, d); b.forward()
+    for name in ("flexvert_length", "flexvert_J"):
+        ref = np.asarray(getattr(d, name)).ravel()
+        assert ref.size and np.abs(ref).max() > 0
+        assert np.array_equal(b.get(name)[0][:ref.size], ref), name
+    assert d.ne == 2*m.nflexvert
+    assert _fields_exact(b, d, ["qfrc_smooth", "qacc_smooth", "qacc"]) == []
+    maxcon, seen = _free_run(rb, lib, m, pre=60, nstep=60, csr=1)
+    return maxcon
+
+
+def test_flex_vertex_equality_constraints(rb, hostsim_lib, tmp_path):
+    assert _vertex_constraints(rb, hostsim_lib, tmp_path, 'solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"',
+                               '<elasticity young="3e4" poisson="0" thickness="1e-2" elastic2d="bend"/>') > 10
+
+
+def test_flex_vertex_equality_constraints_in_the_bending_metric(rb, hostsim_lib, tmp_path):
+    assert _vertex_constraints(rb, hostsim_lib, tmp_path, EFM_OPTION,
+                               '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="bend"/>') > 10
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
