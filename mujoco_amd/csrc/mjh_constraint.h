@@ -119,7 +119,9 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
   if (primal_ && B.lds_bytes) {
     int lo = off2;
     const int newton = M.o.solver == MJH_SOL_NEWTON;
-    const int nvec = (newton ? 5 : 8)*nv*(int)sizeof(real);
+    // (Newton on the explicit-index rows -- mjh_newtonx.h -- shares the CG layout of eight dof vectors; its factor is a
+    // packed triangle in global memory)
+    const int nvec = ((newton && !csr_) ? 5 : 8)*nv*(int)sizeof(real);
     if (spm_) {
       const int b_adr = (((nv + 1)*(int)sizeof(int)) + 7) & ~7, b_mask = 4*nv*(int)sizeof(int);
       if (lo + b_adr <= end1) { P.Ladr = SP<int>{(int*)(lds_ + lo), 1}; lo += b_adr; }
@@ -127,7 +129,7 @@ MJH_DEV unsigned long long efc_layout(MREF M, BREF B, int e, int nefc, Efc& P) {
       if (lo + b_adr <= end1) { P.spar = SP<int>{(int*)(lds_ + lo), 1}; lo += b_adr; }
     }
     if (lo + nvec <= end1) { P.vec = SP<real>{(real*)(lds_ + lo), 1}; lo += nvec; }
-    if (newton) {
+    if (newton && !csr_) {
       // (sparse Newton: 3 KB ahead of the factor for the line search's row-ordered sums, when the factor keeps a useful share)
       if (spm_ && end1 - lo >= 6*MJH_WAVE*(int)sizeof(real) + 512*(int)sizeof(real)) { P.ev = (real*)(lds_ + lo); lo += 6*MJH_WAVE*(int)sizeof(real); }
       const int full = (spm_ ? M.s.nLp : nv*(nv + 1)/2)*(int)sizeof(real);

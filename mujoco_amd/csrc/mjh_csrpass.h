@@ -180,13 +180,20 @@ MJH_DEV void csr_row_values(MREF M, BREF B, int e, const CsrRowArgs& A) {
     const int stride = rowadr[r0 + 1] - a0;             // every row of the contact has the same pattern
     const int j = colind[a0 + c];
     // (the expressions of stage_make_constraint's dense contact rows)
-    real jd[3];
-    contact_jac_col(M, S, cdof, subtree_com, point, j, jd, (real*)nullptr);
-    const int nr = dim > 1 ? 3 : 1;
-    real jr[3] = {0, 0, 0};
+    // (condim 4 / 6: rows 3..5 are the rotational difference against frame rows 0..2 -- torsion about the normal, rolling
+    // about the tangents; mj_instantiateContact, engine_core_constraint.c:1613-1700)
+    real jd[3], rd[3];
+    contact_jac_col(M, S, cdof, subtree_com, point, j, jd, dim > 3 ? rd : (real*)nullptr);
+    const int nr = dim > 1 ? (dim < 3 ? dim : 3) : 1;
+    real jr[6] = {0, 0, 0, 0, 0, 0};
     for (int a = 0; a < nr; a++) {
       real acc = 0;
       for (int q = 0; q < 3; q++) { const real t = fr[3*a + q]; if (t != 0) acc += jd[q]*t; }
+      jr[a] = acc;
+    }
+    for (int a = 3; a < dim; a++) {
+      real acc = 0;
+      for (int q = 0; q < 3; q++) { const real t = fr[3*(a - 3) + q]; if (t != 0) acc += rd[q]*t; }
       jr[a] = acc;
     }
     if (dim == 1) { val[a0 + c] = jr[0]; }

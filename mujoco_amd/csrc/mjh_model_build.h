@@ -200,7 +200,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
              "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
-  MJH_REJECT(m->opt.solver == mjSOL_NEWTON && m->nv > 128, "the Newton solver with more than 128 degrees of freedom (its dof vectors live in two registers per lane; CG and PGS have no such bound)");
   // mj_isSparse (engine_core_util.c:29): with jacobian=sparse, or auto and nv >= 60, the reference
   // runs its sparse code paths.  They compute the same quantities with sums taken over the non-zeros
   // only; this path always evaluates the dense form, so such models agree with the reference to
@@ -1537,16 +1536,26 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       else if (m->eq_type[i] == mjEQ_FLEXVERT) eq_flexvert = true;
       else if (m->eq_type[i] != mjEQ_CONNECT && m->eq_type[i] != mjEQ_WELD && m->eq_type[i] != mjEQ_JOINT) eq_ok = false;   // (tendon couplings: not on this path)
     }
-    s.csr = (ref_sparse0 && m->nv > 128 && m->opt.solver == mjSOL_CG && eq_ok && m->ntendon == 0 &&
+    // (tendons: none that could produce a constraint row -- limits, friction loss, couplings; a tendon that only carries an
+    // actuator's transmission does not touch the rows)
+    bool tendon_rows = false;
+    for (int t = 0; t < m->ntendon; t++) if (m->tendon_limited[t] || m->tendon_frictionloss[t] != 0) tendon_rows = true;
+    s.csr = (ref_sparse0 && m->nv > 128 && (m->opt.solver == mjSOL_CG || m->opt.solver == mjSOL_NEWTON) && eq_ok && !tendon_rows &&
              !(m->opt.disableflags & mjDSBL_ISLAND)) ? 1 : 0;
     if (s.csr) {
-      // the explicit-index rows hold translational contact rows only (condim 1 / 3), and a row's merged dof chain is
-      // assembled in a 64-entry per-lane array (mjh_csr.h): models outside either bound keep the dense rows
+      // a row's merged dof chain is assembled in a 64-entry per-lane array (mjh_csr.h): models beyond that bound keep the
+      // dense rows
       if (csr_row_bound() > MJH_CSR_CHAIN_MAX) s.csr = 0;
-      for (int p = 0; p < s.npair && s.csr; p++) if (H->pair_dim[p] > 3) s.csr = 0;
-      for (int g = 0; g < m->ngeom && s.csr && s.nflexpair > 0; g++) if (m->geom_condim[g] > 3) s.csr = 0;
-      for (int f = 0; f < m->nflex && s.csr; f++) if (m->flex_condim[f] > 3) s.csr = 0;
     }
+    // Newton beyond 128 dofs runs on the explicit-index rows (mjh_newtonx.h): the factor as a packed lower triangle
+    s.xn = (s.csr && m->opt.solver == mjSOL_NEWTON) ? 1 : 0;
+    MJH_REJECT(m->opt.solver == mjSOL_NEWTON && m->nv > 128 && !s.csr,
+               "the Newton solver with more than 128 degrees of freedom outside the explicit-index row path (sparse Jacobian, islands "
+               "enabled, no tendon limits / friction / couplings, contacts up to condim 3)");
+    MJH_REJECT(s.xn && m->nv > 2048, "the Newton solver with more than 2048 degrees of freedom");
+    s.xncap = s.xn ? m->nv*(m->nv + 1)/2 : 0;
+    s.xnw = s.xn ? (m->nv + 31)/32 : 0;
+    s.xnell = (s.xn && m->opt.cone == mjCONE_ELLIPTIC) ? 1 : 0;
     // the dof chains csr_body_chain would walk through dof_parentid, as a table (independent loads on the device)
     H->body_chainadr.assign(m->nbody + 1, 0);
     H->body_chain.clear();

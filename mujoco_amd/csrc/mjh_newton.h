@@ -463,6 +463,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   iptr oldstate = MJH_G(B, iscratch, e);
   rptr conH = MJH_G(B, con_H, e);
 
+  // Newton on the explicit-index rows (mjh_newtonx.h): the factor(s) as packed lower triangles in global memory
+  const int xn = SPA == 2 && flg_newton;
+  XnWork XW;
+  if (SPA == 2) {
+    XW = xn_work(M, B, e);
+    if (xn) { Lt = MJH_G(B, xn_L, e); Lc = MJH_G(B, xn_Lc, e); }
+  }
+
   // ---- islands (engine_forward.c:1187-1212).  Exact when the solve is one problem over every dof; with
   // several islands, or an island that leaves trees out, dofs / rows outside the island are masked
   int nisl_raw = counts[MJH_C_NISLAND];
@@ -923,6 +931,10 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
+    if (SPA == 2) {
+      // (only the island's rows of the packed triangle are in use)
+      for (int k = 0; k < nidof; k++) { const int r = idof[k]; const long long a = xn_row(r); for (int j = lane; j <= r; j += MJH_W) Lc[a + j] = Lt[a + j]; }
+    } else
     MJH_FOR_LANES(w, SPA ? sp_nL : nv*(nv + 1)/2) Lc[w] = Lt[w];
     wv_sync();
     for (int i = 0; i < nefc; i++) {
@@ -943,6 +955,23 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           tmp = 1/local[j*(dim + 1)];
           for (int r = j + 1; r < dim; r++) local[r*dim + j] = (local[r*dim + j] - dot_ref(local + r*dim, local + j*dim, j))*tmp;
         }
+      }
+      if (SPA == 2) {
+        // explicit-index rows: LTJ over the contact's shared columns (HessianCone :2245-2262: row c of LTJ accumulates
+        // J[i + r] * local[r][c] over r = c .. dim-1 in order, from zero), one mju_cholUpdateSparse per row of LTJ
+        const int a0 = P.rowadr[i], m = P.rowadr[i + 1] - a0;
+        rptr ltj = XW.stage;                       // (idle between solves; m <= 64 entries)
+        for (int c = 0; c < dim; c++) {
+          MJH_FOR_LANES(q, m) {
+            real acc = 0;
+            for (int r = c; r < dim; r++) acc += P.spJ[P.rowadr[i + r] + q]*local[r*dim + c];
+            ltj[q] = acc;
+          }
+          wv_sync();
+          xn_update(XW, Lc, P.colind + a0, ltj, m, 1);
+        }
+        i += dim - 1;
+        continue;
       }
       if (SPA) {
         // sparse: LTJ over the contact's shared pattern, one mju_cholUpdateSparse per column of L_local
@@ -980,6 +1009,13 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // FactorizeHessian
   auto factorize = [&](int recompute) {
+    if (SPA == 2) {
+      MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
+      wv_sync();
+      xn_factorize(M, P, XW, Lt, idof, nidof, nefc, Dact, Ms, nisl_raw > 1 ? isl : -1);
+      if (ELL && ncone) hessian_cone();
+      return;
+    }
     if (SPA) {
       sp_factorize();
       if (ELL && ncone) hessian_cone();
@@ -991,6 +1027,22 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianIncremental
   auto hessian_incremental = [&]() {
+    if (SPA == 2) {
+      // one mju_cholUpdateSparse per row that entered or left the quadratic zone, in row order, with J[i] * sqrt(D[i])
+      for (int i = 0; i < nefc; i++) {
+        if (!in_row(i)) continue;
+        const int was = oldstate[i] == MJH_STATE_QUADRATIC, is = P.state[i] == MJH_STATE_QUADRATIC;
+        if (was == is) continue;
+        const int a0 = P.rowadr[i], m = P.rowadr[i + 1] - a0;
+        const real sq = sqrt(P.D[i]);
+        rptr cu = XW.stage;
+        MJH_FOR_LANES(q, m) cu[q] = P.spJ[a0 + q]*sq;
+        wv_sync();
+        if (xn_update(XW, Lt, P.colind + a0, cu, m, is ? 1 : 0)) { factorize(1); return; }
+      }
+      if (ELL && ncone) hessian_cone();
+      return;
+    }
     if (SPA) {
       // the rows that entered or left the quadratic zone, in order, MJH_SP_KB at a time through one sweep over the
       // factor (sp_update_batch); a clamped pivot anywhere means the reference refactorises from scratch
@@ -1035,6 +1087,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     if (ELL && ncone) hessian_cone();
   };
   auto newton_mgrad = [&]() {
+    if (SPA == 2) { xn_solve(XW, (ELL && ncone) ? (crptr)Lc : (crptr)Lt, idof, nidof, grad, Mgrad); return; }
     if (SPA) sp_chol_solve((ELL && ncone) ? Lc : Lt);
     else chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
   };
@@ -1497,7 +1550,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
 MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
   const int ell = MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0;
-  if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 1); else solve_primal<0, 1>(M_, B_, e_, 1); }
+  if (M_.s.csr) { if (ell) solve_primal<1, 2>(M_, B_, e_, 1); else solve_primal<0, 2>(M_, B_, e_, 1); }
+  else if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 1); else solve_primal<0, 1>(M_, B_, e_, 1); }
   else { if (ell) solve_primal<1, 0>(M_, B_, e_, 1); else solve_primal<0, 0>(M_, B_, e_, 1); }
 }
 MJH_DEVN void solve_cg(MREF M_, BREF B_, int e_) {

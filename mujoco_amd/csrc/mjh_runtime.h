@@ -327,7 +327,7 @@ MJHIP_API int mjhip_model_size(const mjhipModel* M, const char* name) {
   const DSizes& s = M->H.s;
 #define SZ(n) if (!strcmp(name, #n)) return s.n;
   SZ(nq) SZ(nv) SZ(nu) SZ(na) SZ(nbody) SZ(njnt) SZ(ngeom) SZ(nsite) SZ(ntendon) SZ(npair)
-  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment) SZ(ccd_any) SZ(ccd_env_bytes) SZ(ccd_row_reals) SZ(nmesh) SZ(sparse) SZ(nJmax) SZ(nLp) SZ(nflex) SZ(nflexvert) SZ(nflexedge) SZ(nflexelem) SZ(csr) SZ(neqrow) SZ(ndoffric) SZ(njntlim) SZ(efm) SZ(ne0) SZ(ne0L) SZ(ne0lev1) SZ(ne0lev2)
+  SZ(features) SZ(nsensor) SZ(nsensordata) SZ(nconmax) SZ(nefcmax) SZ(nstate) SZ(nC) SZ(nJten) SZ(ntree) SZ(nlevel) SZ(nmoment) SZ(ccd_any) SZ(ccd_env_bytes) SZ(ccd_row_reals) SZ(nmesh) SZ(sparse) SZ(nJmax) SZ(nLp) SZ(nflex) SZ(nflexvert) SZ(nflexedge) SZ(nflexelem) SZ(csr) SZ(neqrow) SZ(ndoffric) SZ(njntlim) SZ(xn) SZ(xncap) SZ(nfv) SZ(efm) SZ(ne0) SZ(ne0L) SZ(ne0lev1) SZ(ne0lev2)
 #undef SZ
   set_err(std::string("mjhip_model_size: unknown size ") + name);
   return -1;

@@ -203,6 +203,7 @@ MJH_DEV int wv_sub() { return 0; }
 // *p = min(*p, v), atomically with respect to the other lanes (the emulation runs them one at a time)
 MJH_DEV void wv_atomic_min_i(int* p, int v) { if (v < *p) *p = v; }
 MJH_DEV int wv_atomic_add_i(int* p, int v) { const int old = *p; *p = old + v; return old; }
+MJH_DEV void wv_atomic_or_i(int* p, int v) { *p |= v; }
 
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row
@@ -518,6 +519,7 @@ MJH_DEV int wv_sub() { return 0; }
 // *p = min(*p, v), atomically with respect to the other lanes (flat address: LDS or global)
 MJH_DEV void wv_atomic_min_i(int* p, int v) { atomicMin(p, v); }
 MJH_DEV int wv_atomic_add_i(int* p, int v) { return atomicAdd(p, v); }
+MJH_DEV void wv_atomic_or_i(int* p, int v) { atomicOr(p, v); }
 
 // value of lane (lane ^ 16): the neighbouring 16-lane row.  v_permlane16_swap exchanges
 // the odd rows of its first operand with the even rows of its second; with both operands = v each

@@ -431,6 +431,19 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
     }
     if (damper_on) {
       if (i == j) q -= poly_force_deriv(M.dof_damping_eff[i], M.dof_dampingpoly_eff + 2*i, qvel[i], 1);
+      if (MJH_HAS(MJH_FT_FLEX) && s.nflexdof) {
+        // flex edge damping (mjd_passive_vel :3090-3111): J' B J of every non-rigid edge with B = -flex_edgedamping, flex by
+        // flex, edge by edge; the edges that hold dof i come from the by-column table (ascending edge order)
+        crptr fJ = MJH_F(B, flexedge_J, e);
+        for (int a = M.flexJ_cscadr[i]; a < M.flexJ_cscadr[i + 1]; a++) {
+          const int ai = M.flexJ_cscind[a], ed = M.flexedge_J_rowid[ai];
+          const int f = M.flexedge_flex[ed];
+          const real Bf = -M.flex_edgedamping[f];
+          if (M.flex_rigid[f] || !Bf || M.flexedge_rigid[ed]) continue;
+          const int adr = M.flexedge_J_rowadr[ed], nn = M.flexedge_J_rownnz[ed];
+          for (int c = 0; c < nn; c++) if (M.flexedge_J_colind[adr + c] == j) q += fJ[adr + c]*(fJ[ai]*Bf);
+        }
+      }
       for (int t = 0; t < s.ntendon; t++) {
         real dp[2] = {M.tendon_dampingpoly_eff[2*t], M.tendon_dampingpoly_eff[2*t+1]};
         real bt = -poly_force_deriv(M.tendon_damping_eff[t], dp, tvel[t], 1);

@@ -500,6 +500,9 @@ struct DSizes {
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row
   int csr, csr_rowmax;
+  // Newton on the explicit-index rows (mjh_newtonx.h): 1 when that path is taken, entries of the packed lower triangle
+  // nv (nv + 1) / 2 (the factor; x2 with elliptic cones), 32-bit words of a dof set
+  int xn, xncap, xnw, xnell;
 #define MJH_CSR_CHAIN_MAX 64   // per-lane array a contact row's merged dof chain is assembled in (model build keeps csr_rowmax below it)
   // rows of the flex edge equality constraints (eq_rowadr[neq] when the model has one, else 0)
   int neqrow;
@@ -664,6 +667,10 @@ enum {
   X(flexelem_aabb, 6 * s.nflexelem, 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* product vectors of the solver's ordered sums when the LDS block has no room for them (mjh_newton.h: csr_dots) */ \
   X(csr_prod, 6 * s.csr * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                          \
+  /* Newton on the explicit-index rows: the factor(s) as packed lower triangles, dense row / vector work space */ \
+  X(xn_L, s.xn * s.xncap, 0, MJH_T_GLB, MJH_T_GLB)                                \
+  X(xn_Lc, s.xnell * s.xncap, 0, MJH_T_GLB, MJH_T_GLB)                             \
+  X(xn_rw, 2 * s.xn * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
   X(flexcand, 8 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                           \
   X(flexbvh_aabb, 6 * s.nflexbvh, 0, MJH_T_GLB, MJH_T_GLB)                        \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
@@ -741,6 +748,11 @@ enum {
   /* explicit column indices of the compressed rows, dofs of the island being solved (mjh_csr.h) */ \
   X(sp_colind, s.csr * s.nJmax, 0, MJH_T_GLB, MJH_T_GLB)                          \
   X(csr_idof, s.csr * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
+  /* Newton on the explicit-index rows: elimination-tree parents | visit flags | lengths of the visiting lists | seeds, the \
+     visiting lists (row r at (nv-1-r)(nv-2-r)/2), structural patterns of H and of the factor (xnw words per row) */ \
+  X(xn_iw, 4 * s.xn * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
+  X(xn_LT, s.xn * s.xncap, 0, MJH_T_GLB, MJH_T_GLB)                               \
+  X(xn_bits, 2 * s.xn * s.nv * s.xnw, 0, MJH_T_GLB, MJH_T_GLB)                    \
   X(sp_Lmask, 4 * s.sparse * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                       \
   X(sp_Ladr, s.sparse * (s.nv + 1), 0, MJH_T_GLB, MJH_T_GLB)                      \
   /* structural pattern of every row of efc_AR (bit j of row i: the rows' Y patterns share a dof), 2 ints per word */ \

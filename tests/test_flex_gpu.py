@@ -104,6 +104,27 @@ def test_implicit_effective_metric_on_gpu(rb, hip_lib, tmp_path, which):
     fh._effective_metric(rb, hip_lib, tmp_path, which)
 
 
+@pytest.mark.parametrize("equality", ["false", "true"])
+def test_implicit_effective_metric_bending_only_on_gpu(rb, hip_lib, tmp_path, equality):
+    """bending stiffness only: the stencil operator and the level-scheduled solve with mj_setConst's constant factor"""
+    assert fh._bending_only_metric(rb, hip_lib, tmp_path, equality) > 10
+
+
+def test_flex_vertex_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
+    """mjEQ_FLEXVERT: flexvert_length / flexvert_J field by field, then through contact -- explicit and in the bending metric"""
+    assert fh._vertex_constraints(rb, hip_lib, tmp_path, 'solver="CG" tolerance="1e-6" timestep=".001" integrator="Euler"',
+                                  '<elasticity young="3e4" poisson="0" thickness="1e-2" elastic2d="bend"/>') > 10
+    assert fh._vertex_constraints(rb, hip_lib, tmp_path, fh.EFM_OPTION,
+                                  '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="bend"/>') > 10
+
+
+@pytest.mark.parametrize("which,cone", [("shell", "pyramidal"), ("shell", "elliptic"), ("equality", "pyramidal"), ("solid", "elliptic")])
+def test_newton_beyond_128_dofs_on_gpu(rb, hip_lib, tmp_path, which, cone):
+    """Newton on the explicit-index rows (mjh_newtonx.h): factorisation in the reference's visiting order, sparse solves,
+    rank-one updates, cone Hessians; states, counts and Newton iteration counts identical through contact"""
+    assert fh._newton_beyond_128(rb, hip_lib, tmp_path, which, cone) > 3
+
+
 @pytest.mark.parametrize("dof", ["trilinear", "quadratic"])
 def test_interpolated_flex_on_gpu(rb, hip_lib, tmp_path, dof):
     """node bodies, interpolated vertices, corotational cells (mju_mat2Rot calls sin / cos: against the reference linked with

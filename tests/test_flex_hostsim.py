@@ -697,6 +697,41 @@ def test_flex_vertex_equality_constraints_in_the_bending_metric(rb, hostsim_lib,
                                '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="bend"/>') > 10
 
 
+def _newton_beyond_128(rb, lib, tmp_path, which, cone):
+    """Newton on the explicit-index rows (mjh_newtonx.h; MakeHessian / FactorizeHessian / HessianIncremental / HessianCone,
+    engine_solver.c:2057-2340 on the reference's sparse matrices): H = J' D J + M, the reverse Cholesky factor in the
+    order of mju_cholFactorSymbolic's tree walks, mju_cholSolveSparse, one mju_cholUpdateSparse per row that changes zone
+    (per cone row with elliptic cones).  Free-running steps through contact: states, counts and Newton iteration counts."""
+    xml = tmp_path / "newton.xml"
+    option = f'solver="Newton" cone="{cone}" tolerance="1e-8" timestep=".001" integrator="Euler"'
+    if which == "shell":
+        xml.write_text(shell_xml("9 9 1", SHELL_GEOMS, option=option))
+        pre, nstep = 60, 70
+    elif which == "equality":
+        xml.write_text(shell_xml("8 8 1", SHELL_GEOMS, option=option,
+                                 body='<edge equality="true"/><contact selfcollide="none"/>'))
+        pre, nstep = 60, 60
+    else:
+        # a solid flex on a sphere next to a free box and a hinged pendulum: several islands, one of them the flex
+        xml.write_text(flex_xml("4 4 4", "0 0 .12", option=option,
+                                extra_world='<geom type="sphere" size=".05" pos=".02 .01 .0"/>'
+                                            '<body pos=".5 0 .045"><freejoint/><geom type="box" size=".04 .04 .04"/></body>'
+                                            '<body pos="-.5 0 .3"><joint type="hinge" axis="0 1 0" range="-20 20"/><geom type="capsule" fromto="0 0 0 .2 0 0" size=".02"/></body>'))
+        pre, nstep = 100, 60
+    m = rb.MjModel.from_xml_path(str(xml))
+    assert m.nv > 128
+    dm = K.DeviceModel(lib, m)
+    assert dm.size("csr") == 1 and dm.size("xn") == 1
+    maxcon, seen = _free_run(rb, lib, m, pre=pre, nstep=nstep, csr=1)
+    return maxcon
+
+
+@pytest.mark.parametrize("which,cone", [("shell", "pyramidal"), ("shell", "elliptic"), ("equality", "pyramidal"),
+                                        ("solid", "pyramidal"), ("solid", "elliptic")])
+def test_newton_beyond_128_dofs(rb, hostsim_lib, tmp_path, which, cone):
+    assert _newton_beyond_128(rb, hostsim_lib, tmp_path, which, cone) > 3
+
+
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
     xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
