@@ -1613,7 +1613,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     if (s.csr) {
       s.csr_rowmax = std::min((int)m->nv, csr_row_bound());
-      s.nJmax = s.nefcmax*s.csr_rowmax;
+      // (capacity of the compressed rows: the longest row -- a contact's merged chains, or a flex vertex constraint's row
+      // over the dofs of the vertex and its edge neighbours -- times the row capacity)
+      int rowcap = s.csr_rowmax;
+      for (int f = 0; f < m->nflex; f++)
+        if (m->flex_edgeequality[f] == 2)
+          for (int v = m->flex_vertadr[f]; v < m->flex_vertadr[f] + m->flex_vertnum[f]; v++) rowcap = std::max(rowcap, (int)m->flexvert_J_rownnz[2*v]);
+      s.nJmax = s.nefcmax*rowcap;
     }
   }
   // PGS visitation orders for nefc = 1..64 (..128 when the capacity allows more than 64 rows) (engine_solver.c:241-265, :498-502): PCG32 with

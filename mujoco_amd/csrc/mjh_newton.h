@@ -516,6 +516,19 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       qfs = SP<const real>{c, 1};
       wv_sync();
     }
+    // (Newton on the explicit-index rows: the arrays its scalar walks and row sweeps go through -- elimination-tree
+    // parents, visit flags, list lengths, seeds, the dense vector of a solve / update and the products of a row dot --
+    // take the top of the tail when it has room for them next to one product vector; the factor stays in global memory)
+    if (xn) {
+      const int need = 4*nv*(int)sizeof(int) + 2*nv*(int)sizeof(real);
+      if (fb >= need + nv*(int)sizeof(real)) {
+        fb -= need;
+        char* const q = P.free_p + fb;
+        XW.x = SP<real>{(real*)q, 1}; XW.stage = XW.x + nv;
+        int* const iw = (int*)(q + 2*nv*(int)sizeof(real));
+        XW.parent = SP<int>{iw, 1}; XW.flag = XW.parent + nv; XW.ltn = XW.parent + 2*nv; XW.seed = XW.parent + 3*nv;
+      }
+    }
     if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
     else if (fuse_ok) { dstage = &MJH_G(B, csr_prod, e)[0] + 3*nv; dstage_cap = 3*nv; }     // (the first three hold Ma, Mv, Mgrad)
     else { dstage = &MJH_G(B, csr_prod, e)[0]; dstage_cap = 6*nv; }

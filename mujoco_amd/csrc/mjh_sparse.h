@@ -341,6 +341,26 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
         adr = P.rowadr[k];
       }
       const int m = n - tb < MJH_W ? n - tb : MJH_W;
+#ifndef MJH_SP_NO_PIPELINE
+      // (four entries at a time: their loads are issued together, the additions stay in entry order.  An entry with a zero
+      // scale, or a lane outside the entry's pattern, adds +-0 -- no accumulator here can be -0, it starts at +0 -- where the
+      // reference skips the entry: the sum is the same)
+      for (int u = 0; u < m; u += 4) {
+        real scv[4], v0[4], v1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int uu = u + q < m ? u + q : m - 1;
+          scv[q] = u + q < m ? wv_bcast(sc, uu) : (real)0;
+          const M128 pmu = wv_bcast_m128(pm, uu);
+          const int adru = wv_bcast_i(adr, uu);
+          v0[q] = (lane <= r && m128_test(pmu, lane)) ? (real)P.spJ[adru + m128_rank_lane0(pmu)] : (real)0;
+          v1[q] = 0;
+          if (r >= MJH_W) v1[q] = (lane + MJH_W <= r && m128_test(pmu, lane + MJH_W)) ? (real)P.spJ[adru + m128_rank_lane1(pmu)] : (real)0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { acc0 += scv[q]*v0[q]; if (r >= MJH_W) acc1 += scv[q]*v1[q]; }
+      }
+#else
       for (int u = 0; u < m; u++) {
         const real scu = wv_bcast(sc, u);
         if (scu == 0) continue;
@@ -349,6 +369,7 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
         if (lane <= r && m128_test(pmu, lane)) acc0 += scu*P.spJ[adru + m128_rank_lane0(pmu)];
         if (r >= MJH_W) { if (lane + MJH_W <= r && m128_test(pmu, lane + MJH_W)) acc1 += scu*P.spJ[adru + m128_rank_lane1(pmu)]; }
       }
+#endif
     }
     const int ma = M.M_rowadr[r], mn = M.M_rownnz[r];
     for (int q = 0; q < mn; q++) {
@@ -396,6 +417,26 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
     real v0 = 0, v1 = 0;
     if (myc0 >= 0) { lc0 = m128_ld(P.Lmask + 4*myc0); ac0 = P.Ladr[myc0]; v0 = L[ac0 + m128_rank(lc0, r)]; }
     if (myc1 >= 0) { lc1 = m128_ld(P.Lmask + 4*myc1); ac1 = P.Ladr[myc1]; v1 = L[ac1 + m128_rank(lc1, r)]; }
+#ifndef MJH_SP_NO_PIPELINE
+    // (four rows of the visiting list at a time, loads together, subtractions in list order; a lane outside a row's pattern
+    // subtracts L[c][r] * 0 = +-0)
+    for (int u = 0; u < nlist; u += 4) {
+      real Lcr[4], w0[4], w1[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int uu = u + q < nlist ? u + q : nlist - 1;
+        const int src = uu & (MJH_W - 1);
+        Lcr[q] = u + q < nlist ? wv_bcast(uu < MJH_W ? v0 : v1, src) : (real)0;
+        const M128 lmu = wv_bcast_m128(uu < MJH_W ? lc0 : lc1, src);
+        const int au = wv_bcast_i(uu < MJH_W ? ac0 : ac1, src);
+        w0[q] = (lane <= r && m128_test(lmu, lane)) ? (real)L[au + m128_rank_lane0(lmu)] : (real)0;
+        w1[q] = 0;
+        if (r >= MJH_W) w1[q] = (lane + MJH_W <= r && m128_test(lmu, lane + MJH_W)) ? (real)L[au + m128_rank_lane1(lmu)] : (real)0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { d0 -= Lcr[q]*w0[q]; if (r >= MJH_W) d1 -= Lcr[q]*w1[q]; }
+    }
+#else
     for (int u = 0; u < nlist; u++) {
       const int src = u & (MJH_W - 1);
       const real Lcr = wv_bcast(u < MJH_W ? v0 : v1, src);
@@ -404,6 +445,7 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
       if (lane <= r && m128_test(lmu, lane)) d0 -= Lcr*L[au + m128_rank_lane0(lmu)];
       if (r >= MJH_W) { if (lane + MJH_W <= r && m128_test(lmu, lane + MJH_W)) d1 -= Lcr*L[au + m128_rank_lane1(lmu)]; }
     }
+#endif
     real diag = wv_bcast(r < MJH_W ? d0 : d1, r & (MJH_W - 1));
     if (diag < MJH_MINVAL) diag = MJH_MINVAL;
     const real Lrr = sqrt(diag);
