@@ -1574,7 +1574,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       const bool mask_path = ref_sparse0 && m->nv <= 128 && m->opt.solver != mjSOL_PGS;
       MJH_REJECT(eq_flexvert && !s.csr, "flex vertex equality constraints outside the explicit-index row path (CG, sparse Jacobian, more than 128 dofs)");
       MJH_REJECT(eq_flex && !s.csr && !mask_path, "flex edge equality constraints outside the compressed-Jacobian paths (sparse Jacobian "
-                                                  "under CG / Newton up to 128 dofs; beyond: CG, no tendons or tendon couplings)");
+                                                  "under CG / Newton up to 128 dofs; beyond: CG / Newton, no tendon limit / friction / coupling rows)");
     }
     // default budget: what the reference's own arena (mjModel.narena, engine_memory.c:107-138) could hold, between 4 and
     // 16 MiB per environment (64 MiB for the compressed-row CG path) -- stacked_boxes.xml under PGS needs ~1000 rows

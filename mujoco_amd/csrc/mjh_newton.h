@@ -520,12 +520,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     // parents, visit flags, list lengths, seeds, the dense vector of a solve / update and the products of a row dot --
     // take the top of the tail when it has room for them next to one product vector; the factor stays in global memory)
     if (xn) {
-      const int need = 4*nv*(int)sizeof(int) + 2*nv*(int)sizeof(real);
+      const int need = 4*nv*(int)sizeof(int) + 4*nv*(int)sizeof(real);
       if (fb >= need + nv*(int)sizeof(real)) {
         fb -= need;
         char* const q = P.free_p + fb;
-        XW.x = SP<real>{(real*)q, 1}; XW.stage = XW.x + nv;
-        int* const iw = (int*)(q + 2*nv*(int)sizeof(real));
+        XW.x = SP<real>{(real*)q, 1}; XW.stage = XW.x + nv; XW.diag = XW.x + 2*nv; XW.y = XW.x + 3*nv;
+        int* const iw = (int*)(q + 4*nv*(int)sizeof(real));
         XW.parent = SP<int>{iw, 1}; XW.flag = XW.parent + nv; XW.ltn = XW.parent + 2*nv; XW.seed = XW.parent + 3*nv;
       }
     }

@@ -33,7 +33,8 @@ struct XnWork {
   iptr parent, flag, ltn, seed;      // [nv] each
   iptr LT;                           // visiting lists: row r at xn_ltoff(nv, r)
   iptr hbits, lbits;                 // [nv][nw]
-  rptr x, stage;                     // [nv] each: dense vector of a solve / update, products of a row dot
+  rptr x, stage, diag, y;            // [nv] each: dense vector of a solve / update | products of a row dot, L[c][r] of a visiting
+                                     // list | the pivots of the factor being solved with | the vector of a solve after its first sweep
 };
 MJH_DEV long long xn_row(int r) { return (long long)r*(r + 1)/2; }
 MJH_DEV long long xn_ltoff(int nv, int r) { return (long long)(nv - 1 - r)*(nv - 2 - r)/2; }
@@ -44,7 +45,7 @@ MJH_DEV XnWork xn_work(MREF M, BREF B, int e) {
   W.parent = iw; W.flag = iw + W.nv; W.ltn = iw + 2*W.nv; W.seed = iw + 3*W.nv;
   W.LT = MJH_G(B, xn_LT, e);
   W.hbits = MJH_G(B, xn_bits, e); W.lbits = W.hbits + (long long)W.nv*W.nw;
-  W.x = MJH_G(B, xn_rw, e); W.stage = W.x + W.nv;
+  W.x = MJH_G(B, xn_rw, e); W.stage = W.x + W.nv; W.diag = W.x + 2*W.nv; W.y = W.x + 3*W.nv;
   return W;
 }
 
@@ -134,7 +135,6 @@ MJH_DEVN_HOT void xn_factorize(MREF M_, const Efc& P, const XnWork& W, rptr L, c
         while (W.flag[i] != r) {
           if (W.parent[i] == -1) W.parent[i] = r;
           W.LT[off + cnt++] = i;
-          W.lbits[(long long)i*nw + (r >> 5)] |= 1 << (r & 31);
           W.flag[i] = r;
           i = W.parent[i];
         }
@@ -146,55 +146,68 @@ MJH_DEVN_HOT void xn_factorize(MREF M_, const Efc& P, const XnWork& W, rptr L, c
 #ifdef MJH_XN_DEBUG
   if (lane == 0) fprintf(stderr, "xn_factorize symbolic done\n");
 #endif
-  // ---- mju_cholFactorNumeric: rows descending; dense[j] -= L[c][r] L[c][j] over the visiting list, then the pivot
+  // (the factor's row patterns: row i holds column r when i is on r's visiting list -- set after the walks, a lane per list
+  // entry, so that the walk itself is a chain of LDS accesses without a read-modify-write of global memory in it)
+  for (int kr = 0; kr < n; kr++) {
+    const int r = idof[kr];
+    const long long off = xn_ltoff(nv, r);
+    const int cnt = W.ltn[r];
+    for (int q = lane; q < cnt; q += MJH_W) wv_atomic_or_i(&W.lbits[(long long)W.LT[off + q]*nw + (r >> 5)], 1 << (r & 31));
+  }
+  wv_sync();
+  // ---- mju_cholFactorNumeric: rows descending; dense[j] -= L[c][r] L[c][j] over the visiting list, then the pivot.
+  //      The list's rows and their L[c][r] are fetched once, lane-parallel (seed / stage); a lane then walks the list for its
+  //      columns with four rows' loads in flight, the subtractions in list order; the dense row is W.x
   for (int kr = n - 1; kr >= 0; kr--) {
     const int r = idof[kr];
     const long long ar = xn_row(r), off = xn_ltoff(nv, r);
     const int cnt = W.ltn[r];
+    for (int q = lane; q < cnt; q += MJH_W) { const int c = W.LT[off + q]; W.seed[q] = c; W.stage[q] = L[xn_row(c) + r]; }
+    wv_sync();
     for (int j = lane; j <= r; j += MJH_W) {
       real d = L[ar + j];
-      for (int q = 0; q < cnt; q++) {
-        const long long ac = xn_row(W.LT[off + q]);
-        d -= L[ac + r]*L[ac + j];
+      int q = 0;
+      for (; q + 4 <= cnt; q += 4) {
+        real lc[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { lc[u] = W.stage[q + u]; v[u] = L[xn_row(W.seed[q + u]) + j]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) d -= lc[u]*v[u];
       }
-      L[ar + j] = d;
+      for (; q < cnt; q++) d -= W.stage[q]*L[xn_row(W.seed[q]) + j];
+      W.x[j] = d;
     }
     wv_sync();
-    real diag = L[ar + r];
+    real diag = W.x[r];
     if (diag < MJH_MINVAL) diag = MJH_MINVAL;
     const real Lrr = sqrt(diag);
     const real inv = 1.0/Lrr;
-    wv_sync();
-    for (int j = lane; j <= r; j += MJH_W) L[ar + j] = j == r ? Lrr : (real)(L[ar + j]*inv);
+    for (int j = lane; j <= r; j += MJH_W) L[ar + j] = j == r ? Lrr : (real)(W.x[j]*inv);
     wv_sync();
   }
 }
 
-// mju_cholSolveSparse: out = (L' L)^-1 in over the island's dofs (zero elsewhere)
+// mju_cholSolveSparse: out = (L' L)^-1 in over the island's dofs (zero elsewhere).  The pivots are fetched once, lane-parallel;
+// the first sweep leaves its result in y (x[i] is read by every lane at row i's turn and never again), so a row costs one
+// barrier there
 MJH_DEVN_HOT void xn_solve(const XnWork& W, crptr L, ciptr idof, int n, crptr in, rptr out) {
   const int nv = W.nv, nw = W.nw, lane = wv_lane();
-  rptr x = W.x;
-#ifdef MJH_XN_DEBUG
-  if (lane == 0) fprintf(stderr, "xn_solve n %d\n", n);
-#endif
-  MJH_FOR_LANES(j, nv) x[j] = 0;
+  rptr x = W.x, y = W.y;
+  MJH_FOR_LANES(j, nv) { x[j] = 0; y[j] = 0; }
   wv_sync();
-  MJH_FOR_LANES(k, n) x[idof[k]] = in[idof[k]];
+  MJH_FOR_LANES(k, n) { const int i = idof[k]; x[i] = in[i]; W.diag[i] = L[xn_row(i) + i]; }
   wv_sync();
   // x <- L^-T x, rows descending: x[j] -= L[i][j] x[i]
   for (int k = n - 1; k >= 0; k--) {
     const int i = idof[k];
     const long long ai = xn_row(i);
     real xi = x[i];
-    if (xi == 0) continue;                  // (uniform: every lane reads the same element)
-    xi /= L[ai + i];
-    wv_sync();
-    for (int j = lane; j <= i; j += MJH_W) { if (j == i) x[i] = xi; else x[j] -= L[ai + j]*xi; }
+    if (xi == 0) continue;                  // (uniform: every lane reads the same element; y[i] stays 0)
+    xi /= W.diag[i];
+    if (lane == 0) y[i] = xi;
+    for (int j = lane; j < i; j += MJH_W) x[j] -= L[ai + j]*xi;
     wv_sync();
   }
-#ifdef MJH_XN_DEBUG
-  if (lane == 0) fprintf(stderr, "xn_solve sweep 1 done\n");
-#endif
   // x <- L^-1 x, rows ascending: x[i] -= mju_dotSparse(row i, x) -- the stored entries' products by their position in the
   // compressed row (rank of the column in the row's pattern), four accumulators, (r0 + r2) + (r1 + r3), then the tail
   for (int k = 0; k < n; k++) {
@@ -206,32 +219,26 @@ MJH_DEVN_HOT void xn_solve(const XnWork& W, crptr L, ciptr idof, int n, crptr in
       unsigned long long word = (unsigned)W.lbits[(long long)i*nw + w0];
       if (w0 + 1 < nw) word |= (unsigned long long)(unsigned)W.lbits[(long long)i*nw + w0 + 1] << 32;
       const int j = j0 + lane;
-      if (j < i && ((word >> lane) & 1)) W.stage[cnt + __builtin_popcountll(word & ((1ull << lane) - 1))] = L[ai + j]*x[j];
+      if (j < i && ((word >> lane) & 1)) W.stage[cnt + __builtin_popcountll(word & ((1ull << lane) - 1))] = L[ai + j]*y[j];
       cnt += __builtin_popcountll(word);
     }
-    wv_sync();
-    real xi = x[i];
+    real yi = y[i];
     if (cnt) {
+      wv_sync();
       const int G = cnt >> 2, a = lane & 3;
       real r = 0;
       for (int g = 0; g < G; g++) r += W.stage[4*g + a];
       real res = (wv_bcast(r, 0) + wv_bcast(r, 2)) + (wv_bcast(r, 1) + wv_bcast(r, 3));
       for (int q = 4*G; q < cnt; q++) res += W.stage[q];
-      xi -= res;
+      yi -= res;
     }
-    xi /= L[ai + i];
+    yi /= W.diag[i];
     wv_sync();
-    if (lane == 0) x[i] = xi;
+    if (lane == 0) y[i] = yi;
     wv_sync();
   }
-#ifdef MJH_XN_DEBUG
-  if (lane == 0) fprintf(stderr, "xn_solve sweep 2 done\n");
-#endif
-  MJH_FOR_LANES(j, nv) out[j] = x[j];
+  MJH_FOR_LANES(j, nv) out[j] = y[j];
   wv_sync();
-#ifdef MJH_XN_DEBUG
-  if (lane == 0) fprintf(stderr, "xn_solve done\n");
-#endif
 }
 
 // mju_cholUpdateSparse(L, x, flg_plus) with x = scl * (the m entries vals[0..m) at columns cols[0..m), ascending); returns

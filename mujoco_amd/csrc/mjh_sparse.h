@@ -341,7 +341,8 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
         adr = P.rowadr[k];
       }
       const int m = n - tb < MJH_W ? n - tb : MJH_W;
-#ifndef MJH_SP_NO_PIPELINE
+#ifdef MJH_SP_PIPELINE
+      // (measurement build, -DMJH_SP_PIPELINE: 1 % SLOWER on the cube, profiles/r05/negative_results.txt -- not the default)
       // (four entries at a time: their loads are issued together, the additions stay in entry order.  An entry with a zero
       // scale, or a lane outside the entry's pattern, adds +-0 -- no accumulator here can be -0, it starts at +0 -- where the
       // reference skips the entry: the sum is the same)
@@ -417,7 +418,7 @@ MJH_DEVN_HOT void sp_numeric(MREF M_, BREF B_, int e_, const Efc& P, PL L, M128 
     real v0 = 0, v1 = 0;
     if (myc0 >= 0) { lc0 = m128_ld(P.Lmask + 4*myc0); ac0 = P.Ladr[myc0]; v0 = L[ac0 + m128_rank(lc0, r)]; }
     if (myc1 >= 0) { lc1 = m128_ld(P.Lmask + 4*myc1); ac1 = P.Ladr[myc1]; v1 = L[ac1 + m128_rank(lc1, r)]; }
-#ifndef MJH_SP_NO_PIPELINE
+#ifdef MJH_SP_PIPELINE
     // (four rows of the visiting list at a time, loads together, subtractions in list order; a lane outside a row's pattern
     // subtracts L[c][r] * 0 = +-0)
     for (int u = 0; u < nlist; u += 4) {
