@@ -527,6 +527,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         XW.x = SP<real>{(real*)q, 1}; XW.stage = XW.x + nv; XW.diag = XW.x + 2*nv; XW.y = XW.x + 3*nv;
         int* const iw = (int*)(q + 4*nv*(int)sizeof(real));
         XW.parent = SP<int>{iw, 1}; XW.flag = XW.parent + nv; XW.ltn = XW.parent + 2*nv; XW.seed = XW.parent + 3*nv;
+        // (the dense vectors of a batch of rank-one updates, when there is room for them too)
+        const int needb = MJH_XN_KB*nv*(int)sizeof(real);
+        if (fb >= needb + nv*(int)sizeof(real)) { fb -= needb; XW.xb = SP<real>{(real*)(P.free_p + fb), 1}; }
       }
     }
     if (fb >= nv*(int)sizeof(real)) { dstage = (real*)P.free_p; dstage_cap = fb/(int)sizeof(real); }
@@ -942,6 +945,29 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     x0 = (lane < nv && m128_test(pm, lane)) ? (real)(P.spJ[adr + m128_rank(pm, lane)]*scl) : (real)0;
     x1 = (lane + MJH_W < nv && m128_test(pm, lane + MJH_W)) ? (real)(P.spJ[adr + m128_rank(pm, lane + MJH_W)]*scl) : (real)0;
   };
+  // explicit-index Newton: rank-one updates are queued (their dense vectors side by side) and applied MJH_XN_KB at a time in
+  // one sweep over the factor (xn_update_batch); a clamped pivot anywhere means the reference refactorises from scratch
+  int xq_n = 0, xq_plus = 0, xq_start = -1;
+  auto xq_flush = [&](rptr L) -> int {
+    if (!xq_n) return 0;
+    const int clamped = xn_update_batch(XW, L, xq_n, xq_plus, xq_start);
+    xq_n = 0; xq_plus = 0; xq_start = -1;
+    return clamped;
+  };
+  // entry q of the vector = valfn(q) at column cols[q], q < m (ascending columns); returns the clamped count of a flush
+  auto xq_push = [&](rptr L, ciptr cols, int m, auto valfn, int plus) -> int {
+    if (m <= 0) return 0;
+    const rptr xv = XW.xb + (long long)xq_n*nv;
+    MJH_FOR_LANES(j, nv) xv[j] = 0;
+    wv_sync();
+    MJH_FOR_LANES(q, m) xv[cols[q]] = valfn(q);
+    wv_sync();
+    if (plus) xq_plus |= 1 << xq_n;
+    const int last = cols[m - 1];
+    if (last > xq_start) xq_start = last;
+    xq_n++;
+    return xq_n == MJH_XN_KB ? xq_flush(L) : 0;
+  };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
     if (SPA == 2) {
@@ -973,16 +999,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
         // explicit-index rows: LTJ over the contact's shared columns (HessianCone :2245-2262: row c of LTJ accumulates
         // J[i + r] * local[r][c] over r = c .. dim-1 in order, from zero), one mju_cholUpdateSparse per row of LTJ
         const int a0 = P.rowadr[i], m = P.rowadr[i + 1] - a0;
-        rptr ltj = XW.stage;                       // (idle between solves; m <= 64 entries)
-        for (int c = 0; c < dim; c++) {
-          MJH_FOR_LANES(q, m) {
+        for (int c = 0; c < dim; c++)
+          xq_push(Lc, P.colind + a0, m, [&](int q) -> real {
             real acc = 0;
             for (int r = c; r < dim; r++) acc += P.spJ[P.rowadr[i + r] + q]*local[r*dim + c];
-            ltj[q] = acc;
-          }
-          wv_sync();
-          xn_update(XW, Lc, P.colind + a0, ltj, m, 1);
-        }
+            return acc;
+          }, 1);
         i += dim - 1;
         continue;
       }
@@ -1019,6 +1041,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       }
       i += dim - 1;
     }
+    if (SPA == 2) xq_flush(Lc);
   };
   // FactorizeHessian
   auto factorize = [&](int recompute) {
@@ -1041,18 +1064,17 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // HessianIncremental
   auto hessian_incremental = [&]() {
     if (SPA == 2) {
-      // one mju_cholUpdateSparse per row that entered or left the quadratic zone, in row order, with J[i] * sqrt(D[i])
+      // one mju_cholUpdateSparse per row that entered or left the quadratic zone, in row order, with J[i] * sqrt(D[i]) --
+      // queued and applied MJH_XN_KB at a time
       for (int i = 0; i < nefc; i++) {
         if (!in_row(i)) continue;
         const int was = oldstate[i] == MJH_STATE_QUADRATIC, is = P.state[i] == MJH_STATE_QUADRATIC;
         if (was == is) continue;
         const int a0 = P.rowadr[i], m = P.rowadr[i + 1] - a0;
         const real sq = sqrt(P.D[i]);
-        rptr cu = XW.stage;
-        MJH_FOR_LANES(q, m) cu[q] = P.spJ[a0 + q]*sq;
-        wv_sync();
-        if (xn_update(XW, Lt, P.colind + a0, cu, m, is ? 1 : 0)) { factorize(1); return; }
+        if (xq_push(Lt, P.colind + a0, m, [&](int q) -> real { return P.spJ[a0 + q]*sq; }, is ? 1 : 0)) { xq_flush(Lt); factorize(1); return; }
       }
+      if (xq_flush(Lt)) { factorize(1); return; }
       if (ELL && ncone) hessian_cone();
       return;
     }

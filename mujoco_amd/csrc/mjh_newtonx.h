@@ -28,11 +28,13 @@
 
 #if !MJH_LANE_MODE
 
+#define MJH_XN_KB 8
 struct XnWork {
   int nv, nw;
   iptr parent, flag, ltn, seed;      // [nv] each
   iptr LT;                           // visiting lists: row r at xn_ltoff(nv, r)
   iptr hbits, lbits;                 // [nv][nw]
+  rptr xb;                           // [MJH_XN_KB][nv]: the dense vectors of a batch of rank-one updates
   rptr x, stage, diag, y;            // [nv] each: dense vector of a solve / update | products of a row dot, L[c][r] of a visiting
                                      // list | the pivots of the factor being solved with | the vector of a solve after its first sweep
 };
@@ -46,6 +48,7 @@ MJH_DEV XnWork xn_work(MREF M, BREF B, int e) {
   W.LT = MJH_G(B, xn_LT, e);
   W.hbits = MJH_G(B, xn_bits, e); W.lbits = W.hbits + (long long)W.nv*W.nw;
   W.x = MJH_G(B, xn_rw, e); W.stage = W.x + W.nv; W.diag = W.x + 2*W.nv; W.y = W.x + 3*W.nv;
+  W.xb = W.x + 4*W.nv;
   return W;
 }
 
@@ -280,6 +283,72 @@ MJH_DEVN_HOT int xn_update(const XnWork& W, rptr L, ciptr cols, crptr vals, int 
       L[ar + j] = c*mv + ss*xj;
       x[j] = sn*mv + c*xj;
     }
+    wv_sync();
+    row--;
+  }
+  return clamped;
+}
+
+// Several rank-one updates in ONE sweep over the rows (the reference applies them one after the other, each as a sweep from
+// its last non-zero row down: HessianIncremental / HessianCone -> mju_cholUpdateSparse).  Update u rotates row r using only
+// row r of the factor and its own vector; update u + 1 may therefore rotate row r as soon as update u has, before update u
+// goes on to row r - 1: visiting the rows once, top down, and applying at each row the pending rotations in update order
+// performs the reference's operations on the reference's operands, and a row of the factor is read and written once for
+// all of them (as sp_update_batch does for the mask form).  The rotation parameters of a row depend on its pivot and on the
+// vectors' entries AT that row only, which no rotation of this row changes: they are computed first, in update order.
+// xb[u][0..nv): the dense vectors (zero outside their patterns), nb <= MJH_XN_KB of them, bit u of plus: update (1) or
+// downdate (0); start: the last row that can hold a non-zero.  Returns the number of clamped pivots.
+MJH_DEVN_HOT int xn_update_batch(const XnWork& W, rptr L, int nb, int plus, int start) {
+  const int lane = wv_lane(), nv = W.nv;
+  rptr xb = W.xb;
+  int clamped = 0;
+  int row = start;
+  while (row >= 0) {
+    {
+      const int j = row - lane;
+      int any = 0;
+      if (j >= 0) {
+#pragma unroll
+        for (int u = 0; u < MJH_XN_KB; u++) if (u < nb) any |= xb[(long long)u*nv + j] != 0;
+      }
+      const unsigned long long nzm = wv_ballot(any);
+      if (!nzm) { row -= MJH_W; continue; }
+      row -= __builtin_ctzll(nzm);
+    }
+    const long long ar = xn_row(row);
+    real d = L[ar + row];
+    real cu[MJH_XN_KB], su[MJH_XN_KB], qu[MJH_XN_KB];
+    int act = 0;
+#pragma unroll
+    for (int u = 0; u < MJH_XN_KB; u++) {
+      cu[u] = 1; su[u] = 0; qu[u] = 0;
+      if (u >= nb) continue;
+      const real xr = xb[(long long)u*nv + row];
+      if (xr == 0) continue;
+      const int up = (plus >> u) & 1;
+      real tmp = d*d + (up ? xr*xr : -xr*xr);
+      if (tmp < MJH_MINVAL) { tmp = MJH_MINVAL; clamped++; }
+      const real rr = sqrt(tmp);
+      cu[u] = d/rr;
+      su[u] = -xr/rr;
+      qu[u] = up ? -su[u] : su[u];
+      d = rr;
+      act |= 1 << u;
+    }
+    wv_sync();
+    for (int j = lane; j < row; j += MJH_W) {
+      real mv = L[ar + j];
+#pragma unroll
+      for (int u = 0; u < MJH_XN_KB; u++) {
+        if (!((act >> u) & 1)) continue;
+        const real xj = xb[(long long)u*nv + j];
+        const real nm = cu[u]*mv + qu[u]*xj;
+        xb[(long long)u*nv + j] = su[u]*mv + cu[u]*xj;
+        mv = nm;
+      }
+      L[ar + j] = mv;
+    }
+    if (lane == 0) L[ar + row] = d;
     wv_sync();
     row--;
   }

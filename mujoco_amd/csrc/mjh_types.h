@@ -670,7 +670,7 @@ enum {
   /* Newton on the explicit-index rows: the factor(s) as packed lower triangles, dense row / vector work space */ \
   X(xn_L, s.xn * s.xncap, 0, MJH_T_GLB, MJH_T_GLB)                                \
   X(xn_Lc, s.xnell * s.xncap, 0, MJH_T_GLB, MJH_T_GLB)                             \
-  X(xn_rw, 4 * s.xn * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
+  X(xn_rw, 12 * s.xn * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                              \
   X(flexcand, 8 * s.nflexcand, 0, MJH_T_GLB, MJH_T_GLB)                           \
   X(flexbvh_aabb, 6 * s.nflexbvh, 0, MJH_T_GLB, MJH_T_GLB)                        \
   X(efc_J, s.nefcmax * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                             \
