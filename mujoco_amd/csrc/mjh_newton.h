@@ -396,7 +396,9 @@ MJH_DEV void csr_sums(int n, int nd, const real* prod, real* out) {
 
 // SPA = 1: the reference's sparse path (mj_isSparse): compressed J / J', packed sparse factor -- mjh_sparse.h describes the
 // data model; the blocks marked "sparse" below restate engine_util_sparse.c / engine_util_solve.c operation for operation
-template <int ELL, int SPA>
+// XN = 1: the instantiation that carries Newton on the explicit-index rows (mjh_newtonx.h; SPA = 2 only) -- CG on those rows
+// keeps its own instance without that code (measured: 3.4 % of the flex configuration's throughput, profiles/r05/negative_results.txt)
+template <int ELL, int SPA, int XN = 0>
 MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -464,9 +466,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   rptr conH = MJH_G(B, con_H, e);
 
   // Newton on the explicit-index rows (mjh_newtonx.h): the factor(s) as packed lower triangles in global memory
-  const int xn = SPA == 2 && flg_newton;
+  const int xn = XN && SPA == 2 && flg_newton;
   XnWork XW;
-  if (SPA == 2) {
+  if (XN && SPA == 2) {
     XW = xn_work(M, B, e);
     if (xn) { Lt = MJH_G(B, xn_L, e); Lc = MJH_G(B, xn_Lc, e); }
   }
@@ -970,7 +972,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianCone: Lcone = L, then one rank-one update per row of L_local' J of every contact in the cone zone
   auto hessian_cone = [&]() {
-    if (SPA == 2) {
+    if (XN && SPA == 2) {
       // (only the island's rows of the packed triangle are in use)
       for (int k = 0; k < nidof; k++) { const int r = idof[k]; const long long a = xn_row(r); for (int j = lane; j <= r; j += MJH_W) Lc[a + j] = Lt[a + j]; }
     } else
@@ -995,7 +997,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
           for (int r = j + 1; r < dim; r++) local[r*dim + j] = (local[r*dim + j] - dot_ref(local + r*dim, local + j*dim, j))*tmp;
         }
       }
-      if (SPA == 2) {
+      if (XN && SPA == 2) {
         // explicit-index rows: LTJ over the contact's shared columns (HessianCone :2245-2262: row c of LTJ accumulates
         // J[i + r] * local[r][c] over r = c .. dim-1 in order, from zero), one mju_cholUpdateSparse per row of LTJ
         const int a0 = P.rowadr[i], m = P.rowadr[i + 1] - a0;
@@ -1041,11 +1043,11 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       }
       i += dim - 1;
     }
-    if (SPA == 2) xq_flush(Lc);
+    if (XN && SPA == 2) xq_flush(Lc);
   };
   // FactorizeHessian
   auto factorize = [&](int recompute) {
-    if (SPA == 2) {
+    if (XN && SPA == 2) {
       MJH_FOR_LANES(r, nefc) Dact[r] = (in_row(r) && P.state[r] == MJH_STATE_QUADRATIC) ? (real)P.D[r] : (real)0;
       wv_sync();
       xn_factorize(M, P, XW, Lt, idof, nidof, nefc, Dact, Ms, nisl_raw > 1 ? isl : -1);
@@ -1063,7 +1065,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   };
   // HessianIncremental
   auto hessian_incremental = [&]() {
-    if (SPA == 2) {
+    if (XN && SPA == 2) {
       // one mju_cholUpdateSparse per row that entered or left the quadratic zone, in row order, with J[i] * sqrt(D[i]) --
       // queued and applied MJH_XN_KB at a time
       for (int i = 0; i < nefc; i++) {
@@ -1122,7 +1124,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     if (ELL && ncone) hessian_cone();
   };
   auto newton_mgrad = [&]() {
-    if (SPA == 2) { xn_solve(XW, (ELL && ncone) ? (crptr)Lc : (crptr)Lt, idof, nidof, grad, Mgrad); return; }
+    if (XN && SPA == 2) { xn_solve(XW, (ELL && ncone) ? (crptr)Lc : (crptr)Lt, idof, nidof, grad, Mgrad); return; }
     if (SPA) sp_chol_solve((ELL && ncone) ? Lc : Lt);
     else chol_solve((ELL && ncone) ? (crptr)Lc : (crptr)Lt);
   };
@@ -1585,7 +1587,7 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
 
 MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_) {
   const int ell = MJH_HAS(MJH_FT_ELLIPTIC) && M_.o.cone != 0;
-  if (M_.s.csr) { if (ell) solve_primal<1, 2>(M_, B_, e_, 1); else solve_primal<0, 2>(M_, B_, e_, 1); }
+  if (M_.s.csr) { if (ell) solve_primal<1, 2, 1>(M_, B_, e_, 1); else solve_primal<0, 2, 1>(M_, B_, e_, 1); }
   else if (M_.s.sparse) { if (ell) solve_primal<1, 1>(M_, B_, e_, 1); else solve_primal<0, 1>(M_, B_, e_, 1); }
   else { if (ell) solve_primal<1, 0>(M_, B_, e_, 1); else solve_primal<0, 0>(M_, B_, e_, 1); }
 }
