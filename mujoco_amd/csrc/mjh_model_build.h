@@ -1418,6 +1418,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->sensor_needstage, m->sensor_needstage, m->nsensor);
   H->sensor_intprm0.resize(m->nsensor);
   for (int i = 0; i < m->nsensor; i++) H->sensor_intprm0[i] = m->sensor_intprm[i*mjNSENS];
+  H->sensor_intprm1.resize(m->nsensor);
+  for (int i = 0; i < m->nsensor; i++) H->sensor_intprm1[i] = m->sensor_intprm[i*mjNSENS + 1];
   // geoms a ray never sees: fully transparent colour or material (ray_eliminate, engine_ray.c:74-82)
   H->geom_rayskip.assign(m->ngeom, 0);
   for (int g = 0; g < m->ngeom; g++) {
@@ -1465,8 +1467,19 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_INSIDESITE: t = MJH_SENS_INSIDESITE; break;
       case mjSENS_TENDONACTFRC: t = MJH_SENS_TENDONACTFRC; break;
       case mjSENS_RANGEFINDER:
-        // site-attached rangefinders; the surface normal output needs the colliders' normals (not evaluated)
-        if (m->sensor_objtype[i] == mjOBJ_SITE && !(m->sensor_intprm[i*mjNSENS] & (1 << mjRAYDATA_NORMAL))) t = MJH_SENS_RANGEFINDER;
+        // site-attached rangefinders (camera-attached ones cast a ray per pixel: not evaluated)
+        if (m->sensor_objtype[i] == mjOBJ_SITE) {
+          t = MJH_SENS_RANGEFINDER;
+          // (rays against primitives only: mj_rayMesh / mj_rayHfield / mj_raySdf are not evaluated)
+          for (int g = 0; g < m->ngeom; g++)
+            MJH_REJECT(!H->geom_rayskip[g] && m->geom_bodyid[g] != m->site_bodyid[m->sensor_objid[i]] &&
+                       (m->geom_type[g] == mjGEOM_MESH || m->geom_type[g] == mjGEOM_HFIELD || m->geom_type[g] == mjGEOM_SDF),
+                       "rangefinders in models with visible mesh / height-field / signed-distance-field geoms");
+        }
+        break;
+      case mjSENS_CONTACT:
+        // contact sensors: matching by site / geom / body / subtree, the four reductions (engine_sensor.c:1027-1150)
+        t = MJH_SENS_CONTACT;
         break;
       case mjSENS_TOUCH: {
         const int st = m->site_type[m->sensor_objid[i]];
@@ -1476,7 +1489,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       default: break;
     }
     MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
-                      "touch with sphere, ellipsoid or box zones / site rangefinders without normals (camprojection, contact, geom distance, energy, "
+                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact (camera rangefinders, camprojection, geom distance, energy, "
                       "tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {
@@ -1489,6 +1502,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     };
     if (t == MJH_SENS_INSIDESITE)
       MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "insidesite sensors attached to cameras");
+    if (t == MJH_SENS_CONTACT) {
+      // (either side: nothing -- mjOBJ_UNKNOWN --, a site's volume, a geom, a body, a subtree)
+      auto side = [&](int ot, int* out) -> bool { if (ot == mjOBJ_UNKNOWN) { *out = MJH_OBJ_NONE; return true; } return frame_obj(ot, out); };
+      MJH_REJECT(!side(m->sensor_objtype[i], &H->sensor_objtype[i]) || !side(m->sensor_reftype[i], &H->sensor_reftype[i]),
+                 "contact sensors matched against objects other than sites / geoms / bodies / subtrees");
+    }
     if (t >= MJH_SENS_FRAMEPOS && t <= MJH_SENS_FRAMEANGACC) {
       MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "frame sensors attached to cameras");
       if (m->sensor_refid[i] >= 0)

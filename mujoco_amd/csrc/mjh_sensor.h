@@ -87,6 +87,56 @@ MJH_DEV void contact_force(MREF M, BREF B, int e, const Efc& P, int k, real* res
   }
 }
 
+// mju_insideGeom (engine_util_misc.c:452-496): is the world point inside the site's volume?
+template <class PT>
+MJH_DEV int site_holds_point(MREF M, BREF B, int e, int site, PT pt) {
+  crptr sp = MJH_F(B, site_xpos, e) + 3*site;
+  crptr sm = MJH_F(B, site_xmat, e) + 9*site;
+  auto sz = M.site_size + 3*site;
+  const int st = M.site_type[site];
+  real vec[3], pl[3];
+  v3_sub(vec, pt, sp);
+  if (st == 2) return v3_dot(vec, vec) < sz[0]*sz[0];
+  m3_multvec(pl, sm, vec);
+  if (st == 3) {
+    const real z = pl[2], zc = r_clip(z, -sz[1], sz[1]);
+    const real zd = (z - zc)*(z - zc);
+    return pl[0]*pl[0] + pl[1]*pl[1] + zd < sz[0]*sz[0];
+  }
+  if (st == 4) return pl[0]*pl[0]/(sz[0]*sz[0]) + pl[1]*pl[1]/(sz[1]*sz[1]) + pl[2]*pl[2]/(sz[2]*sz[2]) < 1;
+  if (st == 5) return fabs(pl[2]) < sz[1] && pl[0]*pl[0] + pl[1]*pl[1] < sz[0]*sz[0];
+  if (st == 6) return fabs(pl[0]) < sz[0] && fabs(pl[1]) < sz[1] && fabs(pl[2]) < sz[2];
+  return 0;
+}
+
+// matchContact (engine_sensor.c:339-392): 0 no match, 1 match, -1 match with the normal flipped
+MJH_DEV int contact_matches(MREF M, BREF B, int e, int k, int type1, int id1, int type2, int id2) {
+  if (type1 == MJH_OBJ_NONE && type2 == MJH_OBJ_NONE) return 1;
+  if (type1 == MJH_OBJ_SITE && !site_holds_point(M, B, e, id1, MJH_CON(B, con_pos, e, 3, k))) return 0;
+  ciptr cg = MJH_CON(B, con_geom, e, 2, k);
+  const int g1 = cg[0], g2 = cg[1];
+  const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+  auto check = [&](int body, int geom, int type, int id) -> int {
+    if (type == MJH_OBJ_NONE || type == MJH_OBJ_SITE) return 1;
+    if (type == MJH_OBJ_GEOM) return id == geom;
+    if (type == MJH_OBJ_BODY) return id == body;
+    while (body > id) body = M.body_parentid[body];        // (subtree: up the tree until at or above id)
+    return body == id;
+  };
+  const int m11 = check(b1, g1, type1, id1), m12 = check(b2, g2, type1, id1);
+  const int m21 = check(b1, g1, type2, id2), m22 = check(b2, g2, type2, id2);
+  if (!m11 && !m12) return 0;
+  if (!m21 && !m22) return 0;
+  if (type1 != MJH_OBJ_NONE && type2 != MJH_OBJ_NONE) {
+    const int regular = m11 && m22, reverse = m12 && m21;
+    if (regular && !reverse) return 1;
+    if (reverse && !regular) return -1;
+    if (regular && reverse) return 1;
+  } else if (type1 != MJH_OBJ_NONE) return m11 ? 1 : -1;
+  else if (type2 != MJH_OBJ_NONE) return m22 ? 1 : -1;
+  return 0;
+}
+
 // ---- rays against primitive shapes (mju_rayGeom, engine_ray.c:103-560, distances only) ----------
 // A ray is carried in the shape's own frame: origin o, direction d (not normalised: distances are in
 // units of |d|, like the reference).  Curved surfaces reduce to the roots of a x^2 + 2 b x + c = 0 with
@@ -101,6 +151,8 @@ MJH_DEV RayRoots ray_roots(real a, real b, real c) {
 }
 MJH_DEV real ray_first(RayRoots r) { return r.near_ >= 0 ? r.near_ : (r.far_ >= 0 ? r.far_ : (real)-1); }
 MJH_DEV void ray_keep_nearest(real& best, real x) { if (best < 0 || x < best) best = x; }
+// (the same with the part of the surface that was hit: capsule / cylinder 0 = barrel, +-1 = cap; box 4 axis + 2 + side)
+MJH_DEV void ray_keep_nearest(real& best, real x, int& part, int p) { if (best < 0 || x < best) { best = x; part = p; } }
 // quadric <p,p>_W = radius2 about `centre`, metric W = diag(w)
 MJH_DEV RayRoots ray_quadric(V3 o, V3 d, V3 centre, V3 w, real radius2) {
   const V3 p = o - centre;
@@ -111,17 +163,19 @@ MJH_DEV RayRoots ray_quadric(V3 o, V3 d, V3 centre, V3 w, real radius2) {
 }
 // the two faces perpendicular to axis k at +-half: keep the nearest crossing that `inside` accepts
 template <class F>
-MJH_DEV void ray_slab(real& best, V3 o, V3 d, int k, real half, F inside) {
+MJH_DEV void ray_slab(real& best, V3 o, V3 d, int k, real half, F inside, int* part = nullptr, int base = 0) {
   const real dk = comp(d, k);
   if (!(fabs(dk) > MJH_MINVAL)) return;
   for (int side = -1; side <= 1; side += 2) {
     const real x = (side*half - comp(o, k))/dk;
-    if (x >= 0 && inside(V3{o.x + x*d.x, o.y + x*d.y, o.z + x*d.z})) ray_keep_nearest(best, x);
+    if (x >= 0 && inside(V3{o.x + x*d.x, o.y + x*d.y, o.z + x*d.z})) {
+      if (part) ray_keep_nearest(best, x, *part, base + side); else ray_keep_nearest(best, x);
+    }
   }
 }
 
 template <class P0, class P1, class P2>
-MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
+MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec, int* part = nullptr) {
   const V3 wo{pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]}, wd{vec[0], vec[1], vec[2]};
   const V3 one{1, 1, 1}, origin{0, 0, 0};
   // bounding sphere in world coordinates (the rotation does not change it)
@@ -142,15 +196,17 @@ MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, c
     if (misses_ball(reach*reach)) return -1;
     real best = -1;
     const real r2 = size[0]*size[0];
+    int pt = 0;
     const real barrel = ray_first(ray_quadric(o, d, origin, xy, r2));
-    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel);
+    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel, pt, 0);
     for (int cap = 1; cap >= -1; cap -= 2) {
       const RayRoots rr = ray_quadric(o, d, V3{0, 0, cap*size[1]}, one, r2);
       for (int k = 0; k < 2; k++) {
         const real x = k ? rr.far_ : rr.near_;
-        if (x >= 0 && cap*(o.z + x*d.z) >= size[1]) ray_keep_nearest(best, x);
+        if (x >= 0 && cap*(o.z + x*d.z) >= size[1]) ray_keep_nearest(best, x, pt, cap);
       }
     }
+    if (part) *part = pt;
     return best;
   }
   if (type == 4)                      // ellipsoid
@@ -159,19 +215,62 @@ MJH_DEV real ray_geom_dist(int type, P0 pos, P1 mat, P2 size, const real* pnt, c
     if (misses_ball(size[0]*size[0] + size[1]*size[1])) return -1;
     real best = -1;
     const real r2 = size[0]*size[0];
-    ray_slab(best, o, d, 2, size[1], [&](V3 p) -> int { return p.x*p.x + p.y*p.y <= r2; });
+    int pt = 0;
+    ray_slab(best, o, d, 2, size[1], [&](V3 p) -> int { return p.x*p.x + p.y*p.y <= r2; }, &pt, 0);
     const real barrel = ray_first(ray_quadric(o, d, origin, xy, r2));
-    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel);
+    if (barrel >= 0 && fabs(o.z + barrel*d.z) <= size[1]) ray_keep_nearest(best, barrel, pt, 0);
+    if (part) *part = pt;
     return best;
   }
   // box: three slabs
   if (misses_ball(size[0]*size[0] + size[1]*size[1] + size[2]*size[2])) return -1;
   real best = -1;
+  int pt = 0;
   for (int k = 0; k < 3; k++) {
     const int u = (k == 0) ? 1 : 0, v = (k == 2) ? 1 : 2;
-    ray_slab(best, o, d, k, size[k], [&](V3 p) -> int { return fabs(comp(p, u)) <= size[u] && fabs(comp(p, v)) <= size[v]; });
+    ray_slab(best, o, d, k, size[k], [&](V3 p) -> int { return fabs(comp(p, u)) <= size[u] && fabs(comp(p, v)) <= size[v]; }, &pt, 4*k + 2);
   }
+  if (part) *part = pt;
   return best;
+}
+
+// surface normal at the intersection x of the ray with a primitive (mju_rayGeom's `normal` output, engine_ray.c:204-560:
+// the gradient of the surface that was hit -- `part` from ray_geom_dist -- in the shape's frame, normalised, rotated into
+// the world frame)
+template <class P0, class P1, class P2>
+MJH_DEV void ray_geom_normal(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec, real x, int part, real* out) {
+  auto rotate = [&](const real* n) {            // mju_mulMatVec3
+    const real r0 = mat[0]*n[0] + mat[1]*n[1] + mat[2]*n[2];
+    const real r1 = mat[3]*n[0] + mat[4]*n[1] + mat[5]*n[2];
+    const real r2 = mat[6]*n[0] + mat[7]*n[1] + mat[8]*n[2];
+    out[0] = r0; out[1] = r1; out[2] = r2;
+  };
+  if (type == 0) { out[0] = mat[2]; out[1] = mat[5]; out[2] = mat[8]; return; }
+  if (type == 2) {
+    real n[3] = {(pnt[0] + vec[0]*x) - pos[0], (pnt[1] + vec[1]*x) - pos[1], (pnt[2] + vec[2]*x) - pos[2]};
+    v3_normalize(n);
+    out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+    return;
+  }
+  const real dif[3] = {pnt[0] - pos[0], pnt[1] - pos[1], pnt[2] - pos[2]};
+  const real lp[3] = {mat[0]*dif[0] + mat[3]*dif[1] + mat[6]*dif[2], mat[1]*dif[0] + mat[4]*dif[1] + mat[7]*dif[2], mat[2]*dif[0] + mat[5]*dif[1] + mat[8]*dif[2]};
+  const real lv[3] = {mat[0]*vec[0] + mat[3]*vec[1] + mat[6]*vec[2], mat[1]*vec[0] + mat[4]*vec[1] + mat[7]*vec[2], mat[2]*vec[0] + mat[5]*vec[1] + mat[8]*vec[2]};
+  real n[3] = {0, 0, 0};
+  if (type == 3) {
+    n[0] = lp[0] + lv[0]*x; n[1] = lp[1] + lv[1]*x;
+    n[2] = part == 0 ? (real)0 : (real)(lp[2] + lv[2]*x - size[1]*part);
+    v3_normalize(n);
+  } else if (type == 4) {
+    const real sc[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
+    for (int k = 0; k < 3; k++) n[k] = sc[k]*(lp[k] + lv[k]*x);
+    v3_normalize(n);
+  } else if (type == 5) {
+    if (part == 0) { n[0] = lp[0] + lv[0]*x; n[1] = lp[1] + lv[1]*x; n[2] = 0; v3_normalize(n); }
+    else n[2] = part;
+  } else {
+    n[part >> 2] = (part & 3) == 3 ? (real)1 : (real)-1;        // (part = 4 axis + 2 + side)
+  }
+  rotate(n);
 }
 // does the ray meet a site's zone at all (touch sensors: sphere, ellipsoid and box zones)?
 template <class P0, class P1, class P2>
@@ -323,7 +422,7 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
     const int type = M.sensor_type[i], objtype = M.sensor_objtype[i], objid = M.sensor_objid[i];
     const int reftype = M.sensor_reftype[i], refid = M.sensor_refid[i];
     const int dim = M.sensor_dim[i];
-    real v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    real v[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (a site rangefinder with every field: 14 values)
     // limit sensors: the first matching constraint row
     int lrow = -1;
     if (type >= MJH_SENS_JOINTLIMITPOS && type <= MJH_SENS_TENDONLIMITFRC) {
@@ -456,10 +555,12 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
       crptr gx = MJH_F(B, geom_xpos, e);
       crptr gm = MJH_F(B, geom_xmat, e);
       real dist = -1;
+      int gbest = -1, pbest = 0;
       for (int g = 0; g < s.ngeom; g++) {
         if (M.geom_bodyid[g] == exclude || M.geom_rayskip[g]) continue;
-        const real nd = ray_geom_dist(M.geom_type[g], gx + 3*g, gm + 9*g, M.geom_size + 3*g, origin, rvec);
-        if (nd >= 0 && (nd < dist || dist < 0)) dist = nd;
+        int pt = 0;
+        const real nd = ray_geom_dist(M.geom_type[g], gx + 3*g, gm + 9*g, M.geom_size + 3*g, origin, rvec, &pt);
+        if (nd >= 0 && (nd < dist || dist < 0)) { dist = nd; gbest = g; pbest = pt; }
       }
       const int spec = M.sensor_intprm0[i];
       const int hit = dist >= 0;
@@ -468,6 +569,12 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
       if (spec & 2) { for (int k = 0; k < 3; k++) v[o + k] = hit ? rvec[k] : (real)0; o += 3; }   // DIR
       if (spec & 4) { for (int k = 0; k < 3; k++) v[o + k] = origin[k]; o += 3; }          // ORIGIN
       if (spec & 8) { for (int k = 0; k < 3; k++) v[o + k] = hit ? origin[k] + rvec[k]*dist : (real)0; o += 3; }   // POINT
+      if (spec & 16) {                                                         // NORMAL
+        real nrm[3] = {0, 0, 0};
+        if (hit) ray_geom_normal(M.geom_type[gbest], gx + 3*gbest, gm + 9*gbest, M.geom_size + 3*gbest, origin, rvec, dist, pbest, nrm);
+        for (int k = 0; k < 3; k++) v[o + k] = nrm[k];
+        o += 3;
+      }
       if (spec & 32) v[o++] = hit ? dist : (real)-1;                            // DEPTH
     } break;
     case MJH_SENS_TENDONACTFRC: {
@@ -505,6 +612,114 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
       }
       v[0] = inside ? 1 : 0;
     } break;
+    case MJH_SENS_CONTACT: {
+      // contact sensor (engine_sensor.c:1027-1150): the contacts that match (object, reference) fill `num` slots of the
+      // fields the data specification names -- in contact order, or the nearest / strongest first, or reduced to one net
+      // wrench.  The reference collects the matches in an array and partially sorts it; here a lane has no such array: the
+      // order (criterion, contact id) is a strict total order, so slot j takes the smallest key above slot j - 1's by a scan
+      const int spec = M.sensor_intprm0[i], reduce = M.sensor_intprm1[i];
+      const int ncon = counts[MJH_C_NCON];
+      const int fsize[7] = {1, 3, 3, 1, 3, 3, 3};          // found, force, torque, dist, pos, normal, tangent
+      int size = 0, foff[7];
+      for (int q = 0; q < 7; q++) { foff[q] = -1; if (spec & (1 << q)) { foff[q] = size; size += fsize[q]; } }
+      const int num = size ? dim/size : 0;
+      const int adr0 = M.sensor_adr[i];
+      for (int k = 0; k < dim; k++) out[adr0 + k] = 0;
+      int nmatch = 0;
+      for (int k = 0; k < ncon; k++) if (contact_matches(M, B, e, k, objtype, objid, reftype, refid)) nmatch++;
+      const int nslot = num < nmatch ? num : nmatch;
+      auto criterion = [&](int k) -> real {
+        if (reduce == 1) return MJH_CON(B, con_dist, e, 1, k)[0];
+        real ft[6];
+        contact_force(M, B, e, P, k, ft);
+        return -(ft[0]*ft[0] + ft[1]*ft[1] + ft[2]*ft[2]);
+      };
+      auto fill = [&](int slot, int k, int flip) {           // copySensorData
+        const int a = adr0 + slot*size;
+        if (foff[0] >= 0) out[a + foff[0]] = nmatch;
+        if (foff[1] >= 0 || foff[2] >= 0) {
+          real ft[6];
+          contact_force(M, B, e, P, k, ft);
+          if (foff[1] >= 0) { out[a + foff[1]] = ft[0]; out[a + foff[1] + 1] = ft[1]; out[a + foff[1] + 2] = flip ? (real)(ft[2]*-1) : ft[2]; }
+          if (foff[2] >= 0) { out[a + foff[2]] = ft[3]; out[a + foff[2] + 1] = ft[4]; out[a + foff[2] + 2] = flip ? (real)(ft[5]*-1) : ft[5]; }
+        }
+        if (foff[3] >= 0) out[a + foff[3]] = MJH_CON(B, con_dist, e, 1, k)[0];
+        crptr cp = MJH_CON(B, con_pos, e, 3, k);
+        crptr fr = MJH_CON(B, con_frame, e, 9, k);
+        if (foff[4] >= 0) for (int x = 0; x < 3; x++) out[a + foff[4] + x] = cp[x];
+        if (foff[5] >= 0) for (int x = 0; x < 3; x++) out[a + foff[5] + x] = flip ? (real)(fr[x]*-1) : (real)fr[x];
+        if (foff[6] >= 0) for (int x = 0; x < 3; x++) out[a + foff[6] + x] = flip ? (real)(fr[3 + x]*-1) : (real)fr[3 + x];
+      };
+      if (reduce == 0) {
+        int slot = 0;
+        for (int k = 0; k < ncon && slot < nslot; k++) {
+          const int mt = contact_matches(M, B, e, k, objtype, objid, reftype, refid);
+          if (mt) fill(slot++, k, mt < 0);
+        }
+      } else if (reduce == 1 || reduce == 2) {
+        real lastc = 0; int lastk = -1;
+        for (int slot = 0; slot < nslot; slot++) {
+          int best = -1, bflip = 0; real bc = 0;
+          for (int k = 0; k < ncon; k++) {
+            const int mt = contact_matches(M, B, e, k, objtype, objid, reftype, refid);
+            if (!mt) continue;
+            const real c = criterion(k);
+            if (lastk >= 0 && (c < lastc || (c == lastc && k <= lastk))) continue;       // already taken
+            if (best < 0 || c < bc) { best = k; bc = c; bflip = mt < 0; }
+          }
+          fill(slot, best, bflip);
+          lastc = bc; lastk = best;
+        }
+      } else if (nmatch > 0 && num > 0) {
+        // net force: force-weighted centroid of the contact positions, then the total wrench about it in the world frame
+        real point[3] = {0, 0, 0}, total = 0;
+        for (int k = 0; k < ncon; k++) {
+          const int mt = contact_matches(M, B, e, k, objtype, objid, reftype, refid);
+          if (!mt) continue;
+          real ft[6];
+          contact_force(M, B, e, P, k, ft);
+          if (mt < 0) for (int q = 0; q < 6; q++) ft[q] = ft[q]*-1;
+          const real w = sqrt(ft[0]*ft[0] + ft[1]*ft[1] + ft[2]*ft[2]);
+          crptr cp = MJH_CON(B, con_pos, e, 3, k);
+          for (int x = 0; x < 3; x++) point[x] += cp[x]*w;
+          total += w;
+        }
+        const real inv = 1.0/r_max(total, MJH_MINVAL);
+        for (int x = 0; x < 3; x++) point[x] = point[x]*inv;
+        real force[3] = {0, 0, 0}, torque[3] = {0, 0, 0};
+        for (int k = 0; k < ncon; k++) {
+          const int mt = contact_matches(M, B, e, k, objtype, objid, reftype, refid);
+          if (!mt) continue;
+          real ft[6];
+          contact_force(M, B, e, P, k, ft);
+          if (mt < 0) for (int q = 0; q < 6; q++) ft[q] = ft[q]*-1;
+          crptr fr = MJH_CON(B, con_frame, e, 9, k);
+          crptr cp = MJH_CON(B, con_pos, e, 3, k);
+          real fj[3], tj[3], diff[3], ind[3];
+          m3_multvec(fj, fr, ft);
+          m3_multvec(tj, fr, ft + 3);
+          for (int x = 0; x < 3; x++) { force[x] += fj[x]; torque[x] += tj[x]; }
+          v3_sub(diff, cp, point);
+          v3_cross(ind, diff, fj);
+          for (int x = 0; x < 3; x++) torque[x] += ind[x];
+        }
+        const int a = adr0;
+        if (foff[0] >= 0) out[a + foff[0]] = nmatch;
+        if (foff[1] >= 0) for (int x = 0; x < 3; x++) out[a + foff[1] + x] = force[x];
+        if (foff[2] >= 0) for (int x = 0; x < 3; x++) out[a + foff[2] + x] = torque[x];
+        if (foff[3] >= 0) out[a + foff[3]] = 0;
+        if (foff[4] >= 0) for (int x = 0; x < 3; x++) out[a + foff[4] + x] = point[x];
+        if (foff[5] >= 0) out[a + foff[5]] = 1;
+        if (foff[6] >= 0) out[a + foff[6] + 1] = 1;
+      }
+      // (apply_cutoff on the values in place)
+      const real cut = M.sensor_cutoff[i];
+      if (cut > 0) for (int k = 0; k < dim; k++) {
+        if (M.sensor_datatype[i] == 0) out[adr0 + k] = r_clip(out[adr0 + k], -cut, cut);
+        else if (M.sensor_datatype[i] == 1) out[adr0 + k] = r_min(cut, out[adr0 + k]);
+      }
+      continue;
+    }
     case MJH_SENS_MAGNETOMETER: {
       real mg[3] = {M.o.magnetic[0], M.o.magnetic[1], M.o.magnetic[2]};
       m3_multvec(v, MJH_F(B, site_xmat, e) + 9*objid, mg);

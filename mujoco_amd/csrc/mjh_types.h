@@ -75,6 +75,7 @@
   X(sensor_dim, s.nsensor)                     \
   X(sensor_adr, s.nsensor)                     \
   X(sensor_intprm0, s.nsensor)                 \
+  X(sensor_intprm1, s.nsensor)                 \
   X(sensor_needstage, s.nsensor)               \
   X(geom_rayskip, s.ngeom)                     \
   X(tendon_num, s.ntendon)                     \
@@ -935,6 +936,7 @@ enum {
   MJH_SENS_FRAMEANGACC, MJH_SENS_SUBTREECOM, MJH_SENS_SUBTREELINVEL, MJH_SENS_SUBTREEANGMOM, MJH_SENS_CLOCK,
   MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
   MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
+  MJH_SENS_CONTACT,
   MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
