@@ -370,6 +370,8 @@ MJH_DEV void stage_equality_rows(MREF M, BREF B, int e, const Efc& P) {
   crptr subtree_com = MJH_F(B, subtree_com, e);
   ciptr efcadr = MJH_G(B, eq_efcadr, e);
   rptr J = P.J;
+  // (do the dense rows exist?  everywhere but under a primal solver on one of the compressed-row paths)
+  const int densej = !(s.sparse || s.csr) || M.o.solver == MJH_SOL_PGS;
   for (int q = 0; q < s.neq; q++) {
     const int r0 = efcadr[q];
     if (r0 < 0) continue;
@@ -381,6 +383,18 @@ MJH_DEV void stage_equality_rows(MREF M, BREF B, int e, const Efc& P) {
       crptr len = MJH_F(B, flexedge_length, e);
       const int k0 = M.eq_rowadr[q], nk = M.eq_rowadr[q + 1] - k0;
       MJH_FOR_LANES(k, nk) { const int ed = M.eqrow_edge[k0 + k]; P.pos[r0 + k] = len[ed] - M.flexedge_length0[ed]; }
+      if (densej) {
+        // (dense rows -- the dual solver, or a model below the reference's sparse threshold: the edge's row scattered into a
+        // cleared row, mj_instantiateEquality :998-1006)
+        crptr fJ = MJH_F(B, flexedge_J, e);
+        for (int k = 0; k < nk; k++) MJH_FOR_LANES(j, nv) J[(size_t)(r0 + k)*nv + j] = 0;
+        wv_sync();
+        MJH_FOR_LANES(k, nk) {
+          const int ed = M.eqrow_edge[k0 + k];
+          const int a = M.flexedge_J_rowadr[ed], n = M.flexedge_J_rownnz[ed];
+          for (int c = 0; c < n; c++) J[(size_t)(r0 + k)*nv + M.flexedge_J_colind[a + c]] = fJ[a + c];
+        }
+      }
       continue;
     }
     if (MJH_HAS(MJH_FT_FLEX) && et == MJH_EQ_FLEXVERT) {

@@ -195,16 +195,21 @@ MJH_DEV void flex_make_capsule(V3 v1, V3 v2, real radius, V3& pos, real* mat, re
 // comes first: the path's (1 - child) bits, most significant first, are a sort key (at most 52 steps: exact in a double).
 // Tree 1: a flex's hierarchy (body_tree 0: flexbvh_* tables, dynamic boxes bb) or a body's (jobbvh_* tables, static
 // surfaces); tree 2: a flex's.
+// valid (may be null; a flex's hierarchy against ITSELF): 0 when some node pair on the path has node1 > node2 -- mj_collideTree
+// drops such a pair when it pops it ("self-collision: avoid repeated pairs", :1065), so the walk never reaches the leaf pair in
+// this orientation
 template <class BB>
-MJH_DEV real flex_walk_key(MREF M, BB bb, int leaf1, int body_tree, int leaf2) {
+MJH_DEV real flex_walk_key(MREF M, BB bb, int leaf1, int body_tree, int leaf2, int* valid = nullptr) {
   int c1[32], c2[32], d1 = 0, d2 = 0;
   for (int nd = leaf1; nd >= 0 && d1 < 32; nd = body_tree ? (int)M.jobbvh_parent[nd] : (int)M.flexbvh_parent[nd]) c1[d1++] = nd;
   for (int nd = leaf2; nd >= 0 && d2 < 32; nd = M.flexbvh_parent[nd]) c2[d2++] = nd;
   // (c[d - 1] is the root, c[0] the leaf)
   int i1 = d1 - 1, i2 = d2 - 1, len = 0;
   unsigned long long key = 0;
+  int ok = 1;
   while ((i1 > 0 || i2 > 0) && len < 52) {
     const int n1 = c1[i1], n2 = c2[i2];
+    if (n1 > n2) ok = 0;
     int split1;
     if (i1 == 0) split1 = 0;
     else if (i2 == 0) split1 = 1;
@@ -225,6 +230,8 @@ MJH_DEV real flex_walk_key(MREF M, BB bb, int leaf1, int body_tree, int leaf2) {
     key = (key << 1) | (unsigned long long)(1 - child);
     len++;
   }
+  if (c1[0] > c2[0] || i1 > 0 || i2 > 0) ok = 0;      // (the leaf pair itself; a path longer than the key holds)
+  if (valid) *valid = ok;
   key <<= (52 - len);                            // (paths part before the shorter one ends)
   return (real)(long long)key;
 }
@@ -547,7 +554,8 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
 // tested directly ("would the sweep report it?" is a comparison of four float keys), the surviving pairs -- few: elements
 // that share a vertex body are skipped -- go through GJK / EPA one per lane, and their contacts are put in the sweep's
 // order afterwards (the candidates' keys are unique), before filterFlexContacts looks at them.  mode 2 (no midphase /
-// selfcollide = narrow): all pairs e1 < e2 in lexicographic order.
+// selfcollide = narrow): all pairs e1 < e2 in lexicographic order.  mode 3 (selfcollide = bvh, and auto on solid flexes): the
+// flex's hierarchy against itself -- every pair of leaves whose boxes overlap, in the orientation and order of mj_collideTree's walk.
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
   MJH_ENTER(M_, B_, e_);
@@ -584,6 +592,7 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
         crptr bj = aabb + 6*ej;
         const real jlo[3] = {bj[0] - bj[3], bj[1] - bj[4], bj[2] - bj[5]}, jhi[3] = {bj[0] + bj[3], bj[1] + bj[4], bj[2] + bj[5]};
         ok = 1;
+        if (mode == 3) ok = M.flexelem_bvhleaf[ei] >= 0 && M.flexelem_bvhleaf[ej] >= 0;      // (the walk reaches the hierarchy's leaves only)
         if (mode == 1) {
           // the sweep: keys (float value, position in the unsorted end-point array: 2 id for a lower, 2 id + 1 for an upper end)
           const float jminf = (float)(axis == 0 ? jlo[0] : (axis == 1 ? jlo[1] : jlo[2])), jmaxf = (float)(axis == 0 ? jhi[0] : (axis == 1 ? jhi[1] : jhi[2]));
@@ -601,6 +610,15 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
           const int v = M.flexelem_vert[4*ej + q];
           const int b = v >= 0 ? (int)M.flexvert_bodyid[v] : -1;
           if (b >= 0 && (b == vb[0] || b == vb[1] || b == vb[2] || b == vb[3])) ok = 0;
+        }
+        if (ok && mode == 3) {
+          // the orientation in which mj_collideTree's walk reaches the pair (node1 <= node2 all the way down), if any
+          crptr bb3 = MJH_G(B, flexbvh_aabb, e);
+          int v1 = 0, v2 = 0;
+          flex_walk_key(M, bb3, M.flexelem_bvhleaf[ei], 0, M.flexelem_bvhleaf[ej], &v1);
+          if (!v1) flex_walk_key(M, bb3, M.flexelem_bvhleaf[ej], 0, M.flexelem_bvhleaf[ei], &v2);
+          first_i = v1;
+          ok = v1 || v2;
         }
       }
       const unsigned long long m = wv_ballot(ok);
@@ -672,6 +690,24 @@ MJH_DEVN int flex_self_collide(MREF M_, BREF B_, int e_, int sidx, int base) {
   }
   if (n > half) n = half;
   if (n == 0) return 0;
+  if (mode == 3) {
+    // ---- the order of mj_collideTree's walk over the hierarchy against itself (flex_walk_key), candidates of one pair together
+    crptr bb3 = MJH_G(B, flexbvh_aabb, e);
+    MJH_FOR_LANES(i, n)
+      cand[FC_NREAL*i + FC_MIND] = flex_walk_key(M, bb3, M.flexelem_bvhleaf[M.flexact_elem[a0 + ci[FI_NINT*i + FI_GEOM]]], 0,
+                                                 M.flexelem_bvhleaf[M.flexact_elem[a0 + ci[FI_NINT*i + FI_OBJ]]]);
+    wv_sync();
+    flex_order_by_key(cand, ci, n);
+    rptr cand3 = cand + FC_NREAL*n;
+    iptr ci3 = ci + FI_NINT*n;
+    MJH_FOR_LANES(i, n) {
+      ci3[FI_NINT*i + FI_GEOM] = M.flexact_elem[a0 + ci3[FI_NINT*i + FI_GEOM]] - eadr;
+      ci3[FI_NINT*i + FI_OBJ] = M.flexact_elem[a0 + ci3[FI_NINT*i + FI_OBJ]] - eadr;
+      ci3[FI_NINT*i + FI_PAIR] = p; ci3[FI_NINT*i + FI_KIND] = 2;
+    }
+    wv_sync();
+    return flex_filter_emit(M, B, e, f, cand3, ci3, n, base, 0);
+  }
   // ---- the sweep's order: by the key of the later box's lower end, then of the earlier box's (mode 2: by (e1, e2))
   rptr cand2 = cand + FC_NREAL*half;
   iptr ci2 = ci + FI_NINT*half;

@@ -992,9 +992,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       if (sc == mjFLEXSELF_NONE) continue;
       int mode = 2;
       if (midphase && sc != mjFLEXSELF_NARROW && m->flex_bvhadr[f1] >= 0) {
-        MJH_REJECT(sc == mjFLEXSELF_BVH || (sc == mjFLEXSELF_AUTO && m->flex_dim[f1] == 3),
-                   "flex self-collisions through the bounding volume hierarchy (solid flexes with selfcollide = auto, selfcollide = bvh)");
-        mode = 1;
+        // (mode 1: the sweep-and-prune of mj_collideFlexSAP; mode 3: mj_collideTree of the flex's hierarchy against itself)
+        mode = (sc == mjFLEXSELF_BVH || (sc == mjFLEXSELF_AUTO && m->flex_dim[f1] == 3)) ? 3 : 1;
         need_bvh = true;
       }
       MJH_REJECT(m->flex_dim[f1] != 1 && (m->opt.disableflags & mjDSBL_NATIVECCD), "the libccd convex collision pipeline (mjDSBL_NATIVECCD; libccd is a third-party library)");
@@ -1072,10 +1071,12 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       s.nflexbvh = (int)H->flexbvh_elem.size();
       // parents, and the leaf of every element (the path of a leaf pair through mj_collideTree's walk)
       H->flexbvh_parent.assign(s.nflexbvh, -1);
-      H->flexelem_bvhleaf.assign((s.nflexff || s.njobbvh) ? m->nflexelem : 0, -1);
+      s.nselfbvh = 0;
+      for (int md : H->flexself_mode) if (md == 3) s.nselfbvh++;
+      H->flexelem_bvhleaf.assign((s.nflexff || s.njobbvh || s.nselfbvh) ? m->nflexelem : 0, -1);
       for (int i = 0; i < s.nflexbvh; i++) {
         if (H->flexbvh_elem[i] < 0) { H->flexbvh_parent[H->flexbvh_child[2*i]] = i; H->flexbvh_parent[H->flexbvh_child[2*i + 1]] = i; }
-        else if (s.nflexff || s.njobbvh) H->flexelem_bvhleaf[H->flexbvh_elem[i]] = i;
+        else if (s.nflexff || s.njobbvh || s.nselfbvh) H->flexelem_bvhleaf[H->flexbvh_elem[i]] = i;
       }
       for (int k = 0; k + 1 < s.ncolseg; k++)
         if (H->flexjob_adr[k] < H->flexjob_adr[k + 1] && H->flexjob_leaf[H->flexjob_adr[k]] >= 0) {
@@ -1088,6 +1089,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           MJH_REJECT(depth > 30 || height[H->flexbvh_adr[H->colseg[3*k + 2]]] + depth > 50,
                      "body : flex collisions with bounding volume hierarchies deeper than 50 levels together");
         }
+      for (int k = 0; k < (int)H->flexself_mode.size(); k++)
+        if (H->flexself_mode[k] == 3)
+          MJH_REJECT(height[H->flexbvh_adr[H->flexself_flex[k]]] > 26, "flex self-collisions through a bounding volume hierarchy deeper than 26 levels");
       for (int k = 0; k < s.nflexff; k++)
         if (H->flexff_mode[k] == 1)
           for (int side = 0; side < 2; side++) {
@@ -1591,8 +1595,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // flex edge constraints have no dense row: they need one of the compressed-row paths under a primal solver
     {
       const bool mask_path = ref_sparse0 && m->nv <= 128 && m->opt.solver != mjSOL_PGS;
+      // (dense rows -- the dual solver, or a model the reference runs densely -- take the edge's row scattered into a
+      // cleared row)
+      const bool dense_rows = dual || !ref_sparse0;
       MJH_REJECT(eq_flexvert && !s.csr, "flex vertex equality constraints outside the explicit-index row path (CG, sparse Jacobian, more than 128 dofs)");
-      MJH_REJECT(eq_flex && !s.csr && !mask_path, "flex edge equality constraints outside the compressed-Jacobian paths (sparse Jacobian "
+      MJH_REJECT(eq_flex && !s.csr && !mask_path && !dense_rows, "flex edge equality constraints outside the compressed-Jacobian paths (sparse Jacobian "
                                                   "under CG / Newton up to 128 dofs; beyond: CG / Newton, no tendon limit / friction / coupling rows)");
     }
     // default budget: what the reference's own arena (mjModel.narena, engine_memory.c:107-138) could hold, between 4 and

@@ -275,7 +275,7 @@
   X(jobbvh_parent, s.njobbvh)                  \
   X(flexff_mode, s.nflexff)                    \
   X(flexbvh_parent, s.nflexbvh)                \
-  X(flexelem_bvhleaf, ((s.nflexff || s.njobbvh) ? s.nflexelem : 0)) \
+  X(flexelem_bvhleaf, ((s.nflexff || s.njobbvh || s.nselfbvh) ? s.nflexelem : 0)) \
   X(flexself_flex, s.nflexself)                \
   X(flexself_pair, s.nflexself)                \
   X(flexself_mode, s.nflexself)                \
@@ -497,6 +497,7 @@ struct DSizes {
   int nflexself, nflexact, nflexbvh, nflexbvhh;
   int nflexff;         // pairs of different flexes that collide
   int njobbvh;         // nodes of the body hierarchies of multi-geom body : flex jobs
+  int nselfbvh;        // flexes whose self-collisions go through their bounding volume hierarchy
 #define MJH_CONFLEX 6          // ints of a contact's flex identity: flex, element, vertex of side 1, then of side 0 (-1: a geom)
   // compressed constraint Jacobian with explicit column indices (mjh_csr.h): 1 for models beyond 128 dofs under CG;
   // capacity of one row

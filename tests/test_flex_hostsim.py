@@ -413,6 +413,14 @@ def test_shell_flex_self_collision_sweep_and_prune(rb, hostsim_lib, tmp_path):
     assert _self_collision(rb, hostsim_lib, tmp_path, "auto") == 50
 
 
+def test_shell_flex_self_collision_through_the_hierarchy(rb, hostsim_lib, tmp_path):
+    """selfcollide = bvh (what auto selects for solid flexes): mj_collideTree of the flex's bounding volume hierarchy against
+    itself (engine_collision_driver.c:855-858, :1053-1240) -- every pair of leaves whose boxes overlap, in the ORIENTATION the
+    walk reaches it in (node pairs with node1 > node2 are dropped when popped) and in the walk's order, which decides which 50
+    contacts filterFlexContacts keeps"""
+    assert _self_collision(rb, hostsim_lib, tmp_path, "bvh") == 50
+
+
 def test_shell_flex_self_collision_all_pairs(rb, hostsim_lib, tmp_path):
     """selfcollide = narrow: every pair of active elements in lexicographic order"""
     assert _self_collision(rb, hostsim_lib, tmp_path, "narrow", nstep=40) > 10
