@@ -75,6 +75,7 @@ def test_shell_flex_self_collision_on_gpu(rb, hip_lib, tmp_path):
     """flex : flex contacts of a cloth folding over a bar (sweep-and-prune order, two-sided weighted rows), bit for bit"""
     assert fh._self_collision(rb, hip_lib, tmp_path, "auto", nstep=100) == 50
     assert fh._self_collision(rb, hip_lib, tmp_path, "narrow", nstep=60) > 10
+    assert fh._self_collision(rb, hip_lib, tmp_path, "bvh", nstep=100) == 50        # (the hierarchy against itself: walk order)
 
 
 def test_flex_vertices_on_articulated_bodies_on_gpu(rb, hip_lib, tmp_path):

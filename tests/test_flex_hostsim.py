@@ -742,9 +742,9 @@ def test_newton_beyond_128_dofs(rb, hostsim_lib, tmp_path, which, cone):
 
 def test_unsupported_flex_features_are_named(rb, hostsim_lib, tmp_path):
     xml = tmp_path / "eq.xml"
-    xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="true"/>'))
+    xml.write_text(flex_xml("4 4 1", "0 0 1", flex_attr='dim="2"', flex_body='<edge equality="false"/><contact internal="true"/>'))
     m = rb.MjModel.from_xml_path(str(xml))
-    with pytest.raises(K.MjhipError, match="flex"):
+    with pytest.raises(K.MjhipError, match="flex internal collisions"):
         K.DeviceModel(hostsim_lib, m)
 
 

@@ -70,7 +70,7 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
 
 
-def run_one(lib, path, steps, lds, changes):
+def run_one(lib, path, steps, lds, changes, progress=None):
     """returns (status, detail).  status in {'ok', 'deviates', 'warning', 'rejected', 'noload', 'skip'}"""
     try:
         m = rb.MjModel.from_xml_path(path)
@@ -108,6 +108,7 @@ def run_one(lib, path, steps, lds, changes):
         if m.nsensordata:
             ref_sens[t] = d.sensordata
     ref_warn = sum(d.warning_number(i) for i in range(7))
+    if progress: progress()                                    # (the reference's trajectory is done)
     # mjhip: closed-loop steps so that the integer observables can be read after each
     b.reset()
     b.set("time", s0[None, :1]); b.set("qpos", s0[None, 1:1 + m.nq]); b.set("qvel", s0[None, 1 + m.nq:1 + m.nq + m.nv])
@@ -137,6 +138,31 @@ def run_one(lib, path, steps, lds, changes):
     if worst > 1e-6 or worst_sens > 1e-6:
         return "deviates", detail
     return "ok", detail
+
+
+def run_isolated(lib, path, steps, lds, changes):
+    """run_one in a forked child: a crash of the compiled reference (sphere_radial.xml forced to PGS overflows its 10 MB
+    arena and the reference's own mj_step then dies) or of the emulation is a status of that model, not the end of the sweep"""
+    import pickle
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(r)
+        try:
+            res = run_one(lib, path, steps, lds, changes, progress=lambda: os.write(w, b"R"))
+        except Exception as ex:                                # a failure of the harness itself: reported, not hidden
+            res = ("error", f"{type(ex).__name__}: {ex}")
+        os.write(w, b"D" + pickle.dumps(res))
+        os._exit(0)
+    os.close(w)
+    with os.fdopen(r, "rb") as fh:
+        data = fh.read()
+    _, status = os.waitpid(pid, 0)
+    if b"D" in data[:2]:
+        return pickle.loads(data[data.index(b"D") + 1:])
+    sig = status & 0x7f
+    who = "the emulation of the kernels" if data[:1] == b"R" else "the compiled REFERENCE (before mjhip ran a step)"
+    return "crash", f"the process died (signal {sig}) inside {who}"
 
 
 def main():
@@ -173,10 +199,7 @@ def main():
         for name, changes in VARIATIONS:
             if args.variations != "all" and name not in args.variations.split(","):
                 continue
-            try:
-                st, detail = run_one(lib, f, args.steps, args.lds, changes)
-            except Exception as ex:                            # a failure of the harness itself: reported, not hidden
-                st, detail = "error", f"{type(ex).__name__}: {ex}"
+            st, detail = run_isolated(lib, f, args.steps, args.lds, changes)
             if name == "as-shipped":
                 status_count[st] += 1
                 if st == "rejected":
