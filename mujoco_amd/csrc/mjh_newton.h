@@ -572,7 +572,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     int i = 0;
     for (; i <= nv - 4; i += 4) { r0 += a[i]*b[i]; r1 += a[i+1]*b[i+1]; r2 += a[i+2]*b[i+2]; r3 += a[i+3]*b[i+3]; }
     real res = (r0 + r2) + (r1 + r3);
-    for (; i < nv; i++) res += a[i]*b[i];
+    // (mju_dot adds the SUM of the last one to three products: an island that spans every dof -- a flex whose vertices are
+    // trees of their own -- then gets the reference's bits; engine_util_blas.c:517-525)
+    const int rem = nv - i;
+    if (rem == 3) res += a[i]*b[i] + a[i+1]*b[i+1] + a[i+2]*b[i+2];
+    else if (rem == 2) res += a[i]*b[i] + a[i+1]*b[i+1];
+    else if (rem == 1) res += a[i]*b[i];
     return res;
   };
   // out = M v in mju_mulSymVecSparse's order: diagonal, own row right to left, then the column's
