@@ -146,7 +146,7 @@ def cpu_baseline(nthread: int, budget_s: float = 15.0, mjb_name: str = "humanoid
                       f"{iters} solver iters/step)"}
 
 
-def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None):
+def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None, min_seconds=3.0):
     """The like-for-like CPU number for `value`: the reference engine (oracle/_ref/liboracle_fast.so) stepping
     the bench's OWN initial states and control stream -- rows [0, R) of the GPU batch, warm-up + timed steps
     -- on all host cores, through oracle/rollout_bench.cc (the work of _unsafe_rollout_threaded,
@@ -155,7 +155,9 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None
     exe = os.path.join(ROOT, "oracle", "_ref", "rollout_bench")
     if not os.path.exists(exe):
         return None
-    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"))
+    # (the batch is repeated inside one thread team until the timed work lasts min_seconds: round 5's single 60 ms pass
+    # read 0.53, 1.68 and 1.96 M env-steps/s in three runs of one build)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref"), ROLLOUT_BENCH_MIN_S=str(min_seconds))
     R, T = ctrl.shape[0], ctrl.shape[1]
     with tempfile.TemporaryDirectory() as td:
         np.ascontiguousarray(s0[:R], dtype=np.float64).tofile(os.path.join(td, "s0.bin"))
@@ -173,11 +175,12 @@ def cpu_rollout_leg(mjb_name, solver_id, integ_id, s0, ctrl, nthread, warm0=None
     if "env_steps_per_s" not in kv:
         return None
     return {"value": float(kv["env_steps_per_s"]), "unit": "env-steps/s", "cores": nthread, "kind": "reference",
-            "rollouts": R, "nstep": T, "seconds": float(kv["seconds"]), "mean_ncon": float(kv["mean_ncon"]),
+            "rollouts": R, "nstep": T, "seconds": float(kv["seconds"]), "repeats": int(kv.get("repeats", 1)), "mean_ncon": float(kv["mean_ncon"]),
             "mean_nefc": float(kv["mean_nefc"]), "mean_solver_iter": float(kv["mean_niter"]),
             "sample": f"oracle/rollout_bench (liboracle_fast, -O3 -mavx): rows [0,{R}) of the GPU batch, the same state0 and "
                       f"U(ctrlrange) control stream, {T} steps (warm-up + timed) from "
-                      + ("reset" if warm0 is None else "the GPU batch's settled state and warm start") + f", {nthread} threads"}, final
+                      + ("reset" if warm0 is None else "the GPU batch's settled state and warm start")
+                      + f", {nthread} threads, batch repeated x{kv.get('repeats', 1)} = {kv['seconds']} s timed"}, final
 
 
 def measured_traffic(steps_per_launch: int, nenv: int, model_xml: str = ""):
@@ -415,6 +418,143 @@ def config_legs() -> dict:
         leg["command"] = "python bench.py " + " ".join(argv)
         out[name] = leg
     return out
+
+
+LINE_LIMIT = 8192        # bytes of the driver's line (round 5's 20 KB line was not parsed: BENCH_r05.json "parsed": null)
+
+
+def _finite(x):
+    """the record with every non-finite float replaced by None (strict JSON: no NaN / Infinity tokens)"""
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (float, np.floating)):
+        return float(x) if np.isfinite(x) else None
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def _scalars(d: dict, keys, clip: int = 160) -> dict:
+    """d restricted to `keys`, scalar values only, strings clipped"""
+    out = {}
+    for k in keys:
+        v = (d or {}).get(k)
+        if isinstance(v, str):
+            out[k] = v if len(v) <= clip else v[:clip - 1] + "~"
+        elif isinstance(v, (bool, int, float)) or (v is None and k in ("vs_baseline", "traffic")):
+            out[k] = v
+    return out
+
+
+def driver_line(res: dict, full_path: str | None) -> dict:
+    """The ONE line the driver parses, built from the full record: the contract's keys, `config` with scalar values only,
+    `roofline` and `cpu_baseline` as flat objects, the other legs' headline figures as top-level scalars (leg_<name>_*),
+    and the path of the full record.  Kept under LINE_LIMIT bytes -- tests/test_bench_line.py holds it to that."""
+    res = _finite(res)
+    line = _scalars(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                          "vs_baseline", "dtype", "data"), clip=200)
+    line["config"] = _scalars(res.get("config"), ("workload", "envs_per_gpu", "nstep", "solver", "integrator", "ctrl", "settle",
+                                                  "parallelism", "kernel_variant", "layout", "mapping"), clip=200)
+    line["roofline"] = _scalars(res.get("roofline"), ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
+                                                      "steps_per_launch", "launch_ms", "kernel_ms_total", "wall_ms_total",
+                                                      "algorithmic_bytes_per_env_step", "algorithmic_bytes_per_launch",
+                                                      "valu_insts_per_env_step", "salu_insts_per_env_step", "active_lane_frac"), clip=120)
+    cb = res.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _scalars(cb, ("value", "unit", "cores", "kind", "sample", "seconds", "repeats", "mean_ncon", "mean_nefc",
+                                             "mean_solver_iter", "mean_pgs_iter"), clip=260)
+        rr, ts = cb.get("rollout_regime") or {}, cb.get("testspeed_regime") or {}
+        for k in ("seconds", "repeats", "rollouts", "nstep", "mean_ncon", "mean_nefc", "mean_solver_iter"):
+            if k in rr and k not in line["cpu_baseline"]:
+                line["cpu_baseline"][k] = rr[k]
+        if ts.get("value") is not None:
+            line["cpu_baseline"]["testspeed_value"] = ts["value"]
+            line["cpu_baseline"]["testspeed_mean_nefc"] = ts.get("mean_nefc")
+            line["cpu_baseline"]["testspeed_iters"] = ts.get("mean_pgs_iter")
+    es = res.get("end_state") or {}
+    line.update({"end_" + k: es[k] for k in ("warnings", "mean_ncon", "mean_nefc", "mean_solver_iter") if k in es})
+    ps = res.get("parity_sample")
+    if ps is not None:
+        line["parity_ok"] = ps.get("ok")
+        line["parity_steps_checked"] = ps.get("steps_checked")
+        line["parity_envs"] = ps.get("envs")
+        for lab, short in (("reference_glibc", "glibc"), ("reference_device_libm", "devlibm")):
+            ii = (ps.get(lab) or {}).get("identical_input_steps")
+            if ii:
+                line[f"parity_{short}_max_rel_err"] = ii.get("max_rel_err")
+                line[f"parity_{short}_bit_exact_steps"] = ii.get("bit_exact_steps")
+                line[f"parity_{short}_steps"] = ii.get("steps")
+                line[f"parity_{short}_count_mismatches"] = ii.get("count_mismatches")
+        if "error" in ps:
+            line["parity_error"] = str(ps["error"])[:200]
+    for name in ("testspeed_regime", "newton_regime", "free_fall_regime"):
+        r = res.get(name)
+        if r and r.get("value") is not None:
+            line[name + "_value"] = r["value"]
+            e = r.get("end_state") or {}
+            if "mean_nefc" in e:
+                line[name + "_mean_nefc"] = e["mean_nefc"]
+            it = e.get("mean_pgs_iter", e.get("mean_solver_iter"))
+            if it is not None:
+                line[name + "_iters"] = it
+    ar = res.get("api_regime")
+    if ar:
+        if "value" in ar:
+            line["api_regime_value"] = ar["value"]
+            line["api_regime_ratio_to_device_resident"] = ar.get("ratio_to_device_resident")
+            line["api_regime_identical"] = ar.get("identical_to_device_resident")
+        else:
+            line["api_regime_error"] = str(ar.get("error"))[:200]
+    for name, leg in (res.get("configs") or {}).items():
+        p = f"leg_{name}_"
+        if "error" in leg:
+            line[p + "error"] = str(leg["error"])[-200:]
+            continue
+        rl, lcb, lps = leg.get("roofline") or {}, leg.get("cpu_baseline") or {}, leg.get("parity_sample") or {}
+        line[p + "value"] = leg.get("value")
+        line[p + "envs"] = (leg.get("config") or {}).get("envs_per_gpu")
+        line[p + "steps"] = leg.get("steps")
+        line[p + "roofline_frac"] = rl.get("frac")
+        line[p + "traffic"] = rl.get("traffic")
+        line[p + "kernel"] = rl.get("kernel")
+        line[p + "parity_ok"] = lps.get("ok")
+        line[p + "cpu_like_for_like"] = lcb.get("value")
+        line[p + "cpu_seconds"] = (lcb.get("rollout_regime") or {}).get("seconds")
+        line[p + "wall_s"] = leg.get("leg_wall_s")
+    if "configs_ok" in res:
+        line["configs_ok"] = res["configs_ok"]
+    if full_path:
+        line["full_record"] = full_path
+    # the size gate: drop the optional detail, longest first, until the line fits
+    order = [k for k in line if k.startswith("leg_") and k.endswith(("_kernel", "_wall_s", "_cpu_seconds", "_steps", "_envs"))] + \
+            [k for k in line if k.startswith("parity_") and k not in ("parity_ok",)] + \
+            [k for k in reversed(list(line)) if k.startswith("leg_")]
+    while len(json.dumps(line, allow_nan=False)) >= LINE_LIMIT and order:
+        line.pop(order.pop(0), None)
+    return line
+
+
+def emit(res: dict, config: str) -> None:
+    """write the full record to a side file (gpurun_out/, else the system's temp dir) and print the driver's line"""
+    import tempfile
+    res = _finite(res)
+    full_path = None
+    for d in (os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            p = os.path.join(d, f"bench_full_{config}_n{res.get('n_gpus', 1)}.json")
+            with open(p, "w") as f:
+                json.dump(res, f, indent=1, allow_nan=False)
+            full_path = os.path.relpath(p, ROOT) if p.startswith(ROOT) else p
+            break
+        except OSError:
+            continue
+    sys.stdout.flush()
+    print(json.dumps(driver_line(res, full_path), allow_nan=False), flush=True)
 
 
 def main() -> None:
@@ -759,7 +899,8 @@ def main() -> None:
                 try:
                     leg = cpu_rollout_leg(cfg["mjb"], solver_id, integ_id, snap_metric["state"] if snap_metric else s0,
                                           np.concatenate(host_ctrl[n_settle_ctrl:n_metric_ctrl], axis=1), ncpu,
-                                          warm0=snap_metric["warm"] if snap_metric else None)
+                                          warm0=snap_metric["warm"] if snap_metric else None,
+                                          min_seconds=2.0 if args.leg else 3.0)
                 except Exception as exc:
                     leg = ({"error": repr(exc)}, None)
                 if leg and leg[0].get("value"):
@@ -783,18 +924,11 @@ def main() -> None:
             except Exception:
                 pass
             res["configs"] = config_legs()
-            # what the driver's `parsed` keeps is `config`: the legs' headline figures go there too
-            res["config"]["legs"] = {
-                k: ({"value": v.get("value"), "roofline_frac": (v.get("roofline") or {}).get("frac"),
-                     "parity_ok": (v.get("parity_sample") or {}).get("ok"),
-                     "cpu_like_for_like": (v.get("cpu_baseline") or {}).get("value")} if "error" not in v else {"error": v["error"][-200:]})
-                for k, v in res["configs"].items()}
             res["configs_ok"] = all("error" not in v and (v.get("parity_sample") or {}).get("ok") is True for v in res["configs"].values())
-        if "api_regime" in res and "value" in res["api_regime"]:
-            res["config"]["api_regime"] = {k: res["api_regime"].get(k) for k in ("value", "ratio_to_device_resident", "identical_to_device_resident")}
-        if "parity_sample" in res:
-            res["config"]["parity_ok"] = res["parity_sample"].get("ok")
-        print(json.dumps(res), flush=True)
+        if args.leg:
+            print(json.dumps(_finite(res)), flush=True)       # (read by the parent run, never by the driver)
+        else:
+            emit(res, args.config)
     if dist:
         dist.destroy_process_group()
 

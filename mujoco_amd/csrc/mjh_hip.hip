@@ -35,7 +35,7 @@ extern "C" bool mjh_launch_lane_reset(const DModel* M, const DBatch* B, int nenv
 // s + nsimd, s + 2 nsimd, ...  Dealing rank r of block q to slot r (q even) or nsimd - 1 - r (q odd)
 // gives every SIMD one environment of each cost quartile AND nearly equal sums; a SIMD is work
 // conserving, so it finishes when the sum of its wavefronts' work is done.
-__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B, int nsimd, int mode) {
+__global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__ B, int nsimd, int mode, int nstep) {
   __shared__ int hist[256];
   __shared__ int maxc;
   const int n = B->nenv, tid = (int)threadIdx.x;
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(1024) void mjh_k_balance(const DBatch* __restrict__
     for (int e = tid; e < n; e += 1024) part += B->cost[e];
     atomicAdd((unsigned long long*)&tot, (unsigned long long)part);
     __syncthreads();
-    if (tid == 0) B->prio_ref[0] = (int)(tot/(n > 0 ? n : 1));
+    // (both words written HERE, after the launch they describe: a wavefront of the launch itself writing the step count
+    //  raced with later-dispatched wavefronts of the same launch reading it)
+    if (tid == 0) { B->prio_ref[0] = (int)(tot/(n > 0 ? n : 1)); B->prio_ref[1] = nstep; }
   }
   const float scale = 255.0f / (float)maxc;
   for (int e = tid; e < n; e += 1024) atomicAdd(&hist[255 - (int)(cost[e] * scale)], 1);
@@ -182,7 +184,7 @@ struct Backend {
     return variant == MJH_VAR_LEAN ? "mjh_k_rollout_wl" : variant == MJH_VAR_MULTIWAVE ? "mjh_k_rollout_wn" :
            wide_regs(nenv) ? "mjh_k_rollout_wv2" : "mjh_k_rollout_wv";
   }
-  static bool launch_balance(const DBatch* B, int nenv, void* stream) {
+  static bool launch_balance(const DBatch* B, int nenv, int nstep, void* stream) {
     (void)nenv;
     // (function-local statics: initialised once, thread-safely -- the per-GPU host threads of mjhip_rollout all land here)
     struct Cfg { int nsimd, mode; };
@@ -197,7 +199,7 @@ struct Backend {
       return c;
     }();
     const int nsimd = cfg.nsimd, mode = cfg.mode;
-    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd, mode);
+    hipLaunchKernelGGL(mjh_k_balance, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, nsimd, mode, nstep);
     return hipGetLastError() == hipSuccess;
   }
   static bool launch_smooth(const DModel* M, const DBatch* B, int nenv, int epw, const RolloutArgs& A, void* stream) {

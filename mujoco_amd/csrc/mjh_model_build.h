@@ -1551,8 +1551,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const bool dual = m->opt.solver == mjSOL_PGS;
     // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
     const bool ref_sparse0 = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
-    // (equality rows: flex edge constraints only -- their rows are the model's flexedge_J rows; the dense rows of the other
-    // kinds would have to be cut by a scan)
+    // (equality rows on this path: flex edge / flex vertex constraints -- their rows are the model's flexedge_J rows -- and
+    // connect, weld and joint equalities, whose rows are cut to their dof chains; tendon couplings are not)
     bool eq_ok = true, eq_flex = false, eq_flexvert = false;
     for (int i = 0; i < m->neq; i++) {
       if (m->eq_type[i] == mjEQ_FLEX) eq_flex = true;
@@ -1576,6 +1576,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                "the Newton solver with more than 128 degrees of freedom outside the explicit-index row path (sparse Jacobian, islands "
                "enabled, no tendon limits / friction / couplings, contacts up to condim 3)");
     MJH_REJECT(s.xn && m->nv > 2048, "the Newton solver with more than 2048 degrees of freedom");
+    if (s.xn && m->opt.cone == mjCONE_ELLIPTIC) {
+      // (the cone Hessian of this path addresses every row of a contact through ONE column pattern -- hessian_cone, XN
+      // branch: true for the translational rows of condim 3, not established for the torsional / rolling rows)
+      bool high = false;
+      for (size_t k = 0; k < H->pair_dim.size(); k++) if (H->pair_dim[k] > 3) high = true;
+      MJH_REJECT(high, "elliptic contacts of condim 4 / 6 under the Newton solver with more than 128 degrees of freedom");
+    }
     s.xncap = s.xn ? m->nv*(m->nv + 1)/2 : 0;
     s.xnw = s.xn ? (m->nv + 31)/32 : 0;
     s.xnell = (s.xn && m->opt.cone == mjCONE_ELLIPTIC) ? 1 : 0;

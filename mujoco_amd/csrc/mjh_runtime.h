@@ -15,7 +15,7 @@
 //   static bool zero(void* dst, size_t bytes, void* stream);
 //   static bool sync(void* stream);
 //   static int  current_device();
-//   static bool launch_balance(const DBatch* B, int nenv, void* stream);   // launch order of the next rollout launch
+//   static bool launch_balance(const DBatch* B, int nenv, int nstep, void* stream);   // launch order of the next rollout launch
 //   (M, B below are DEVICE pointers to the descriptor structs)
 //   (lds = bytes of LDS per one-wavefront workgroup demanded by the batch descriptor's plan, 0 = none)
 //   (variant = MJH_VAR_* of mjh_modes.h: the kernel mapping that steps the batch; lds is per environment)
@@ -757,7 +757,7 @@ MJHIP_API int mjhip_batch_step(mjhipBatch* Bt, int nstep, void* stream) {
     for (int t = 0; t < nstep && ok; t++) { A.t0 = t; ok = pipeline_step(Bt, A, stream); }
   } else {
     ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, Bt->nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
-    if (ok && Bt->balance) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
+    if (ok && Bt->balance) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, nstep, stream);
   }
   if (!ok) { set_err("mjhip_batch_step: kernel launch failed"); return -2; }
   return 0;
@@ -916,22 +916,26 @@ static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned contro
       // call's kernel may read the staging buffers); copy_out's copy of chunk k waits for kernel k through an event
       // recorded right after that launch.
       ok = Backend::stream_follow(S->copy_in, stream) && ctrl_up(0);
+      bool launched = true;
       for (int k = 0; k < nchunk && ok; k++) {
         const int t0 = k*chunk_steps, c = std::min(chunk_steps, nstep - t0);
         ok = Backend::stream_follow(stream, S->copy_in);            // kernel k waits for the uploads queued so far (chunk k's)
         A.nstep = c; A.tbase = t0;
-        if (ok) ok = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
+        // (chunks after the first add their work to the environment's cost word -- rollout_env, tbase > 0 -- so that the
+        //  launch order and the priority reference of the next call come from the whole rollout, as in the one-launch path)
+        if (ok) ok = launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
         A.init = 0;
         if (ok && k > 0) ok = state_down(k - 1);                     // (copy_out already waits for kernel k - 1)
         if (ok) ok = Backend::stream_follow(S->copy_out, stream);   // what copy_out is given next waits for kernel k
         if (ok) ok = ctrl_up(k + 1);
       }
       if (ok) ok = state_down(nchunk - 1);
-      if (ok && Bt->balance && !A.nlaunch) ok = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
+      if (ok && Bt->balance && !A.nlaunch) ok = launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, nstep, stream);
       ok = Backend::sync(stream) && ok;
       ok = Backend::sync(S->copy_out) && ok;
       ok = Backend::sync(S->copy_in) && ok;
-      if (!ok) { set_err("mjhip_batch_rollout: chunked rollout (launch or copy) failed"); return -5; }
+      if (!launched) { set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }       // (same codes as the one-launch path)
+      if (!ok) { set_err("mjhip_batch_rollout: device<->host copy failed"); return -5; }
       return 0;
     }
   }
@@ -970,7 +974,7 @@ static int rollout_impl(mjhipBatch_* Bt, int nlaunch, int nstep, unsigned contro
   } else {
     launched = Backend::launch_rollout(Bt->model->D_dev, Bt->L_dev, (int)nenv, A, Bt->L.lds_bytes, Bt->variant, stream);
     // (a partial launch runs in identity order and leaves the launch order of full launches alone)
-    if (launched && Bt->balance && !A.nlaunch) launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, stream);
+    if (launched && Bt->balance && !A.nlaunch) launched = Backend::launch_balance(Bt->L_dev, Bt->nenv, nstep, stream);
   }
   if (!launched) { set_err("mjhip_batch_rollout: kernel launch failed"); return -4; }
   if (!on_device) {

@@ -712,12 +712,7 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
         if (foff[5] >= 0) out[a + foff[5]] = 1;
         if (foff[6] >= 0) out[a + foff[6] + 1] = 1;
       }
-      // (apply_cutoff on the values in place)
-      const real cut = M.sensor_cutoff[i];
-      if (cut > 0) for (int k = 0; k < dim; k++) {
-        if (M.sensor_datatype[i] == 0) out[adr0 + k] = r_clip(out[adr0 + k], -cut, cut);
-        else if (M.sensor_datatype[i] == 1) out[adr0 + k] = r_min(cut, out[adr0 + k]);
-      }
+      // (no cutoff: apply_cutoff returns early for contact and fromto sensors, engine_sensor.c:204-208)
       continue;
     }
     case MJH_SENS_MAGNETOMETER: {

@@ -274,8 +274,12 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
     // (a solve that does not converge is what makes an environment the launch's straggler: raise the wavefront's issue
     // priority while it lasts -- a quarter / half of the iteration budget spent; the step loop sets the level again after
     // the step (rollout_env, mjh_step.h); a forward-kernel dispatch ends with the wavefront)
-    if (iter == (maxiter >> 2)) __builtin_amdgcn_s_setprio(2);
-    else if (iter == (maxiter >> 1)) __builtin_amdgcn_s_setprio(3);
+    // One-wavefront workgroups only, like the step loop's levels: in a multi-wavefront environment only the waves that run
+    // the solver would be raised -- the skew rollout_env avoids.
+    if ((int)blockDim.x == MJH_WAVE) {
+      if (iter == (maxiter >> 2)) __builtin_amdgcn_s_setprio(2);
+      else if (iter == (maxiter >> 1)) __builtin_amdgcn_s_setprio(3);
+    }
 #endif
     if (improvement < M.o.tolerance) break;
   }

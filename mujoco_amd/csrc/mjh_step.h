@@ -663,7 +663,7 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
 #ifdef MJH_PROFILE
   const long long c_start = wv_clock();
 #endif
-  int work = 0;
+  int work = A.tbase > 0 ? wv_uniform_i(MJH_G(B, cost, e)[0]) : 0;      // (a later chunk of one host rollout continues the count)
 #if MJH_STEP_PRIO && !MJH_LANE_MODE
   // Issue priority (s_setprio: the SIMD's arbiter serves the higher level first).  A launch ends with its slowest
   // wavefront, and the slowest ones are environments in long solves that stay expensive for many consecutive steps; while
@@ -738,6 +738,9 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
         else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
+#if MJH_PRIO_MODE != 1
+      else __builtin_amdgcn_s_setprio(0);      // (no reference level: undo what a long PGS solve raised, mjh_solver.h solve_pgs_fast)
+#endif
 #endif
     }
     MJH_TIMED(50, {
@@ -755,7 +758,6 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
   if (wv_lane() == 0) {
     MJH_G(B, cost, e)[0] = work;
     MJH_G(B, wall, e)[0] = (int)((wv_clock() - c_begin) >> 4);
-    if (e == 0) MJH_G(B, prio_ref, 0)[1] = A.nstep;
   }
 #ifdef MJH_PROFILE
   if (wv_lane() == 0) {

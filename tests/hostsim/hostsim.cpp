@@ -199,7 +199,7 @@ struct Backend {
   }
   // the launch order of the next rollout launch: environments by decreasing work estimate
   static const char* rollout_kernel_name(int variant, int) { return variant == MJH_VAR_LEAN ? "hostsim:wl" : variant == MJH_VAR_MULTIWAVE ? "hostsim:wn" : "hostsim:wv"; }
-  static bool launch_balance(const DBatch* B, int nenv, void*) {
+  static bool launch_balance(const DBatch* B, int nenv, int, void*) {
     std::vector<int> idx(nenv);
     for (int i = 0; i < nenv; i++) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return B->cost[a] > B->cost[b]; });

@@ -356,7 +356,7 @@ SENSOR_XML = """
     <rangefinder site="rf_down" data="dist normal"/><rangefinder site="rf_side" data="dist dir origin point normal depth"/><rangefinder site="rf_tip" data="dist point normal"/><rangefinder site="rf_up"/>
     <insidesite objtype="body" objname="f1" site="zone_box"/><insidesite objtype="site" objname="tip" site="zone_cyl"/><insidesite objtype="xbody" objname="a3" site="zone_sph"/><insidesite objtype="geom" objname="g3" site="zone_cap"/>
     <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
-    <contact geom1="gf" num="2" data="found force torque dist pos normal tangent"/><contact body2="f1" num="2" data="force normal"/>
+    <contact geom1="gf" num="2" data="found force torque dist pos normal tangent"/><contact body2="f1" num="2" data="force normal" cutoff="0.05"/>
     <contact body1="f1" num="3" data="found dist pos" reduce="mindist"/><contact site="zone_box" num="2" data="found force" reduce="maxforce"/>
     <contact subtree1="a1" data="found force torque pos" reduce="netforce"/><contact subtree1="f1" geom2="floor" data="force torque pos" reduce="netforce"/>
     <contact/>
