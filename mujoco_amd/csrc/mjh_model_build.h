@@ -1321,6 +1321,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       // overflow page of a row: full-capacity vertex / face / map / horizon / crossing-stack arrays
       const int nsv = 5 + N, nsf = 6*N;
       s.ccd_slow_bytes = (6*nsv + 4*nsf)*(int)sizeof(real) + ((2*nsv + 6*nsf + nsf + 2*nsf + 2*nsf + 16 + 1) & ~1)*(int)sizeof(int);
+      // (global-memory sizing only: the LDS plan of a one-wavefront mapping places 4 rows whatever this says -- plan_lds, mjh_runtime.h)
       s.ccd_rows = m->nflex > 0 ? 4*MJH_MW : 4;
       // (header, contact records, overflow pages, and the rows' fast pages for launches whose LDS plan has no room for them)
       // polyhedral pairs (rc_max_contacts > 1, mjh_convex.h): tables of their distance phase (rc_poly_tables)
@@ -1576,13 +1577,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                "the Newton solver with more than 128 degrees of freedom outside the explicit-index row path (sparse Jacobian, islands "
                "enabled, no tendon limits / friction / couplings, contacts up to condim 3)");
     MJH_REJECT(s.xn && m->nv > 2048, "the Newton solver with more than 2048 degrees of freedom");
-    if (s.xn && m->opt.cone == mjCONE_ELLIPTIC) {
-      // (the cone Hessian of this path addresses every row of a contact through ONE column pattern -- hessian_cone, XN
-      // branch: true for the translational rows of condim 3, not established for the torsional / rolling rows)
-      bool high = false;
-      for (size_t k = 0; k < H->pair_dim.size(); k++) if (H->pair_dim[k] > 3) high = true;
-      MJH_REJECT(high, "elliptic contacts of condim 4 / 6 under the Newton solver with more than 128 degrees of freedom");
-    }
     s.xncap = s.xn ? m->nv*(m->nv + 1)/2 : 0;
     s.xnw = s.xn ? (m->nv + 31)/32 : 0;
     s.xnell = (s.xn && m->opt.cone == mjCONE_ELLIPTIC) ? 1 : 0;

@@ -119,7 +119,8 @@ def test_flex_vertex_equality_constraints_on_gpu(rb, hip_lib, tmp_path):
                                   '<elasticity young="3e4" poisson="0" thickness="1e-2" damping="1e-3" elastic2d="bend"/>') > 10
 
 
-@pytest.mark.parametrize("which,cone", [("shell", "pyramidal"), ("shell", "elliptic"), ("equality", "pyramidal"), ("solid", "elliptic")])
+@pytest.mark.parametrize("which,cone", [("shell", "pyramidal"), ("shell", "elliptic"), ("equality", "pyramidal"), ("solid", "elliptic"),
+                                        ("condim6", "elliptic")])
 def test_newton_beyond_128_dofs_on_gpu(rb, hip_lib, tmp_path, which, cone):
     """Newton on the explicit-index rows (mjh_newtonx.h): factorisation in the reference's visiting order, sparse solves,
     rank-one updates, cone Hessians; states, counts and Newton iteration counts identical through contact"""

@@ -719,6 +719,15 @@ def _newton_beyond_128(rb, lib, tmp_path, which, cone):
         xml.write_text(shell_xml("8 8 1", SHELL_GEOMS, option=option,
                                  body='<edge equality="true"/><contact selfcollide="none"/>'))
         pre, nstep = 60, 60
+    elif which == "condim6":
+        # the same scene with condim 6 everywhere (flex-geom and geom-geom contacts; rows 3..5 of a contact are its
+        # torsional / rolling rows, on the contact's one column pattern): the cone Hessian's explicit-index branch
+        xml.write_text(flex_xml("4 4 4", "0 0 .12", option=option,
+                                flex_body='<edge damping="1"/><contact selfcollide="none" condim="6"/><elasticity young="5e4"/>',
+                                extra_world='<geom type="sphere" size=".05" pos=".02 .01 .0" condim="6"/>'
+                                            '<body pos=".5 0 .045"><freejoint/><geom type="box" size=".04 .04 .04" condim="6"/></body>'
+                                            '<body pos="-.5 0 .3"><joint type="hinge" axis="0 1 0" range="-20 20"/><geom type="capsule" fromto="0 0 0 .2 0 0" size=".02" condim="4"/></body>'))
+        pre, nstep = 100, 60
     else:
         # a solid flex on a sphere next to a free box and a hinged pendulum: several islands, one of them the flex
         xml.write_text(flex_xml("4 4 4", "0 0 .12", option=option,
@@ -735,7 +744,8 @@ def _newton_beyond_128(rb, lib, tmp_path, which, cone):
 
 
 @pytest.mark.parametrize("which,cone", [("shell", "pyramidal"), ("shell", "elliptic"), ("equality", "pyramidal"),
-                                        ("solid", "pyramidal"), ("solid", "elliptic")])
+                                        ("solid", "pyramidal"), ("solid", "elliptic"),
+                                        ("condim6", "elliptic"), ("condim6", "pyramidal")])
 def test_newton_beyond_128_dofs(rb, hostsim_lib, tmp_path, which, cone):
     assert _newton_beyond_128(rb, hostsim_lib, tmp_path, which, cone) > 3
 

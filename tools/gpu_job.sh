@@ -11,6 +11,7 @@
 #   stages:<MODEL>   per-stage profile (tools/stage_profile.py on tools/variants/libmjhip_prof.so)
 #   sq:<config>      SQ instruction counters of the rollout kernel (tools/gpu_sq.sh)
 #   tail             tools/tail_stats.py
+#   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
 #   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
 # (the one-shot scripts of rounds 2-3 -- gpu_r2*.sh, gpu_r3[a-s].sh, gpu_flex*.sh -- were sequences of these steps;
 #  their outputs are quoted in profiles/r02* and profiles/r03*)
@@ -26,10 +27,12 @@ try:
     j = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
 except Exception as exc:
     print("  (no JSON line:", exc, ")"); sys.exit(0)
-ps = j.get("parity_sample", {})
-print("  value %.4g %s  ms/step %.4g  frac %.3g  parity_ok %s  kernel %s" % (j["value"], j["unit"], j["ms_per_step"], j["roofline"]["frac"], ps.get("ok"), j["roofline"].get("kernel")))
-for k, v in j.get("configs", {}).items():
-    print("  leg %-12s value %s parity_ok %s wall %.1fs %s" % (k, v.get("value"), v.get("parity_sample", {}).get("ok"), v.get("leg_wall_s", 0), v.get("error", "")))
+print("  value %.4g %s  ms/step %.4g  frac %.3g  parity_ok %s  kernel %s  line %d B" % (j["value"], j["unit"], j["ms_per_step"], j["roofline"]["frac"], j.get("parity_ok"), j["roofline"].get("kernel"), len(json.dumps(j))))
+cb = j.get("cpu_baseline") or {}
+print("  cpu_baseline %s (%s s, x%s) testspeed %s | testspeed_regime %s newton_regime %s api %s" % (cb.get("value"), cb.get("seconds"), cb.get("repeats"), cb.get("testspeed_value"), j.get("testspeed_regime_value"), j.get("newton_regime_value"), j.get("api_regime_value")))
+for name in ("cube", "flex", "slider_crank"):
+    if ("leg_%s_value" % name) in j or ("leg_%s_error" % name) in j:
+        print("  leg %-12s value %s frac %s parity_ok %s cpu %s wall %s %s" % (name, j.get("leg_%s_value" % name), j.get("leg_%s_roofline_frac" % name), j.get("leg_%s_parity_ok" % name), j.get("leg_%s_cpu_like_for_like" % name), j.get("leg_%s_wall_s" % name), j.get("leg_%s_error" % name, "")))
 PY
 }
 for step in "$@"; do
@@ -43,7 +46,7 @@ for step in "$@"; do
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     driver)
       ( time timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver.json" 2> "$OUT/bench_driver.err" ) 2>&1 | grep real
-      summ "$OUT/bench_driver.json" ;;
+      summ "$OUT/bench_driver.json"; cp gpurun_out/bench_full_humanoid_n1.json "$OUT/bench_driver_full.json" 2>/dev/null ;;
     default)
       ( time timeout 900 python bench.py --no-legs > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" ) 2>&1 | grep real
       summ "$OUT/bench_default.json" ;;
@@ -64,6 +67,9 @@ for step in "$@"; do
       cp gpurun_out/sq_${TAG}_${rest:-humanoid}/sq_summary.txt "$OUT/sq_summary_${rest:-humanoid}.txt" 2>/dev/null ;;
     tail)
       timeout 600 python tools/tail_stats.py > "$OUT/tail_stats.txt" 2>&1; tail -12 "$OUT/tail_stats.txt" ;;
+    sweep)
+      ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 320 --out "$OUT/sweep_gpu" > "$OUT/sweep_gpu.log" 2>&1 ) 2>&1 | grep real
+      head -4 "$OUT/sweep_gpu/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu/sweep.txt" | head -40 ;;
     resources)
       python tools/kernel_resources.py > "$OUT/kernel_resource_usage.txt" 2>&1; cat "$OUT/kernel_resource_usage.txt" ;;
     *) echo "unknown step $step" ;;

@@ -17,6 +17,16 @@ For each model that the reference's compiler loads (nv <= nvmax, nv > 0):
   * the worst relative deviation of the FULLPHYSICS state (and sensordata) over the trajectory, the
     integer observables (ncon, nefc) and mjhip's warnings are recorded.
 Output: <out>/sweep.txt (one line per model and variation + census of rejection reasons), also printed.
+
+The same sweep ON THE DEVICE (round 6): the reference tree does not exist on the GPU box, the compiled reference
+(oracle/_ref) does.  So
+  python tools/model_sweep.py --export tools/sweep_export [--nvmax 320]
+writes every model the emulation accepts as <name>.mjb.gz (mj_saveModel of the compiled model: bit-identical constants)
+plus an index, here; and on the box
+  python tools/model_sweep.py --from-mjb tools/sweep_export --device --out gpurun_out/sweep_gpu
+loads each .mjb with the oracle (reference trajectory, live) and with libmjhip.so (the product, on cuda:0) and applies the
+same comparison.  `--fixtures DIR --subset file` additionally stores the reference trajectories of a subset as .npz
+next to the .mjb files (tests/golden/sweep: what tests/test_gpu_sweep.py replays without the live oracle).
 """
 import argparse
 import collections
@@ -61,6 +71,26 @@ def model_files(only):
     return seen
 
 
+def load_model(path):
+    """the oracle's mjModel of an .xml, .mjb or .mjb.gz file (textures make an .mjb large: the exports are gzipped)"""
+    if path.endswith(".mjb.gz"):
+        import gzip
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".mjb") as tmp:
+            tmp.write(gzip.open(path, "rb").read())
+            tmp.flush()
+            return rb.MjModel.from_binary_path(tmp.name)
+    return rb.MjModel.from_binary_path(path) if path.endswith(".mjb") else rb.MjModel.from_xml_path(path)
+
+
+def save_gz(m, dst_stem):
+    import gzip
+    m.save_binary(dst_stem + ".mjb")
+    with open(dst_stem + ".mjb", "rb") as fh, gzip.GzipFile(dst_stem + ".mjb.gz", "wb", mtime=0) as out:
+        out.write(fh.read())
+    os.remove(dst_stem + ".mjb")
+
+
 def rel(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
     if a.size == 0:
@@ -70,10 +100,11 @@ def rel(a, b):
     return float(np.max(np.abs(a - b) / (1.0 + np.abs(b))))
 
 
-def run_one(lib, path, steps, lds, changes, progress=None):
-    """returns (status, detail).  status in {'ok', 'deviates', 'warning', 'rejected', 'noload', 'skip'}"""
+def run_one(lib, path, steps, lds, changes, progress=None, record=None):
+    """returns (status, detail).  status in {'ok', 'deviates', 'warning', 'rejected', 'noload', 'skip'}
+    record: a dict that receives the inputs and the reference trajectory (fixtures for tests/test_gpu_sweep.py)"""
     try:
-        m = rb.MjModel.from_xml_path(path)
+        m = load_model(path)
     except Exception as ex:                                   # the reference's compiler refuses it (or a stub dependency)
         return "noload", str(ex).splitlines()[0][:100] if str(ex) else "compile error"
     if m.nv == 0:
@@ -92,7 +123,8 @@ def run_one(lib, path, steps, lds, changes, progress=None):
     spec = rb.mjSTATE_FULLPHYSICS
     s0 = rb.mj_getState(m, d, spec).copy()
     b = K.Batch(dm, 1)
-    b.plan_lds(lds)
+    if lds:
+        b.plan_lds(lds)          # (the emulation: the device's default plan; on the device the batch has planned already)
     nstate = s0.size
     ctrl = np.zeros((1, steps, max(m.nu, 0)))
     # the reference trajectory
@@ -108,6 +140,10 @@ def run_one(lib, path, steps, lds, changes, progress=None):
         if m.nsensordata:
             ref_sens[t] = d.sensordata
     ref_warn = sum(d.warning_number(i) for i in range(7))
+    if record is not None:
+        record.update(state0=s0, ref_state=ref, ref_counts=ref_int, ref_sensordata=ref_sens, ref_warnings=np.array(ref_warn),
+                      ctrl0=ctrl0 if ctrl0 is not None else np.zeros(0),
+                      mocap_pos=mocap[0].ravel() if mocap else np.zeros(0), mocap_quat=mocap[1].ravel() if mocap else np.zeros(0))
     if progress: progress()                                    # (the reference's trajectory is done)
     # mjhip: closed-loop steps so that the integer observables can be read after each
     b.reset()
@@ -140,29 +176,64 @@ def run_one(lib, path, steps, lds, changes, progress=None):
     return "ok", detail
 
 
-def run_isolated(lib, path, steps, lds, changes):
-    """run_one in a forked child: a crash of the compiled reference (sphere_radial.xml forced to PGS overflows its 10 MB
-    arena and the reference's own mj_step then dies) or of the emulation is a status of that model, not the end of the sweep"""
+def run_isolated(lib, path, steps, lds, variations, want_record=False, stop_after_first=False):
+    """run_one for each (name, changes) of `variations` in a forked child: a crash of the compiled reference
+    (sphere_radial.xml forced to PGS overflows its 10 MB arena and the reference's own mj_step then dies) or of the
+    kernels / their emulation is a status of that model and variation, not the end of the sweep.  One child runs all the
+    variations of a model (on the device: one initialisation of the HIP runtime per model -- the parent never touches it);
+    after a crash the remaining variations run in a new child.  Returns [(name, status, detail, record or None)]; the
+    variations after a rejected / unloadable / skipped first one are not run."""
     import pickle
-    r, w = os.pipe()
-    pid = os.fork()
-    if pid == 0:
-        os.close(r)
-        try:
-            res = run_one(lib, path, steps, lds, changes, progress=lambda: os.write(w, b"R"))
-        except Exception as ex:                                # a failure of the harness itself: reported, not hidden
-            res = ("error", f"{type(ex).__name__}: {ex}")
-        os.write(w, b"D" + pickle.dumps(res))
-        os._exit(0)
-    os.close(w)
-    with os.fdopen(r, "rb") as fh:
-        data = fh.read()
-    _, status = os.waitpid(pid, 0)
-    if b"D" in data[:2]:
-        return pickle.loads(data[data.index(b"D") + 1:])
-    sig = status & 0x7f
-    who = "the emulation of the kernels" if data[:1] == b"R" else "the compiled REFERENCE (before mjhip ran a step)"
-    return "crash", f"the process died (signal {sig}) inside {who}"
+    import struct
+    results = []
+    todo = list(variations)
+    while todo:
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            for name, changes in todo:
+                os.write(w, b"S")
+                try:
+                    rec = {} if want_record else None
+                    st, detail = run_one(lib, path, steps, lds, changes, progress=lambda: os.write(w, b"R"), record=rec)
+                except Exception as ex:                            # a failure of the harness itself: reported, not hidden
+                    st, detail, rec = "error", f"{type(ex).__name__}: {ex}", None
+                blob = pickle.dumps((name, st, detail, rec))
+                os.write(w, b"D" + struct.pack("<Q", len(blob)) + blob)
+                if (st in ("rejected", "noload", "skip") and name == variations[0][0]) or stop_after_first:
+                    break
+            os._exit(0)
+        os.close(w)
+        with os.fdopen(r, "rb") as fh:
+            data = fh.read()
+        _, status = os.waitpid(pid, 0)
+        pos, started, in_mjhip = 0, False, False
+        while pos < len(data):
+            tag = data[pos:pos + 1]
+            if tag == b"S":
+                started, in_mjhip, pos = True, False, pos + 1
+            elif tag == b"R":
+                in_mjhip, pos = True, pos + 1
+            else:
+                n = struct.unpack("<Q", data[pos + 1:pos + 9])[0]
+                results.append(pickle.loads(data[pos + 9:pos + 9 + n]))
+                todo.pop(0)
+                started, pos = False, pos + 9 + n
+        if started:                                               # the child died inside this variation
+            sig = status & 0x7f
+            who = "the kernels (or their emulation)" if in_mjhip else "the compiled REFERENCE (before mjhip ran a step)"
+            results.append((todo.pop(0)[0], "crash", f"the process died (signal {sig}) inside {who}", None))
+        elif results and ((results[-1][1] in ("rejected", "noload", "skip") and results[-1][0] == variations[0][0]) or stop_after_first):
+            break
+        elif not started and todo and os.WIFSIGNALED(status):
+            results.append((todo.pop(0)[0], "crash", f"the process died (signal {status & 0x7f}) between variations", None))
+    return results
+
+
+def export_name(short):
+    """file stem of an exported model: the path under the reference tree, flattened"""
+    return re.sub(r"[^A-Za-z0-9_.-]", "_", short[:-4].replace("/", "__"))
 
 
 def main():
@@ -173,20 +244,42 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_sweep"))
     ap.add_argument("--only", default="")
     ap.add_argument("--variations", default="all")
+    ap.add_argument("--export", default="", help="write every accepted model as <dir>/<name>.mjb + index.txt (build container)")
+    ap.add_argument("--from-mjb", default="", help="sweep the exported .mjb files of this directory instead of the reference tree")
+    ap.add_argument("--device", action="store_true", help="step with libmjhip.so on the GPU instead of the host emulation")
+    ap.add_argument("--fixtures", default="", help="with --subset: store <name>.mjb + <name>.npz (inputs + reference trajectories of every variation) here")
+    ap.add_argument("--subset", default="", help="file with one model path (as in sweep.txt) per line")
     args = ap.parse_args()
-    if not os.path.isdir(os.path.join(REF, "model")):
+    if not args.from_mjb and not os.path.isdir(os.path.join(REF, "model")):
         sys.exit(f"reference tree not found at {REF} (this tool runs in the build container)")
-    lib = K.Lib(HOSTSIM_LIB)
-    files = model_files(args.only)
+    lib = K.Lib(os.path.join(ROOT, 'mujoco_amd', 'csrc', 'libmjhip.so')) if args.device else K.Lib(HOSTSIM_LIB)
+    if args.device:
+        args.lds = 0
+    if args.from_mjb:
+        index = [ln.split() for ln in open(os.path.join(args.from_mjb, "index.txt")) if ln.strip() and not ln.startswith("#")]
+        files = [os.path.join(args.from_mjb, stem + ".mjb.gz") for stem, _ in index if not args.only or args.only in _]
+        shorts = {os.path.join(args.from_mjb, stem + ".mjb.gz"): short for stem, short in index}
+    else:
+        files = model_files(args.only)
+        shorts = {f: os.path.relpath(f, REF) for f in files}
+    subset = set(ln.strip() for ln in open(args.subset) if ln.strip() and not ln.startswith("#")) if args.subset else None
+    if subset is not None:
+        files = [f for f in files if shorts[f] in subset]
+    exported = []
     lines = []
     census = collections.Counter()
     status_count = collections.Counter()
     t0 = time.time()
     for f in files:
-        short = os.path.relpath(f, REF)
+        short = shorts[f]
         try:
-            m = rb.MjModel.from_xml_path(f)
+            m = load_model(f)
             nv = m.nv
+            if (args.export or args.fixtures) and 0 < nv <= args.nvmax:
+                # (saved before anything runs; kept only if the model is accepted)
+                dst = args.export or args.fixtures
+                os.makedirs(dst, exist_ok=True)
+                save_gz(m, os.path.join(dst, export_name(short)))
             del m
         except Exception as ex:
             status_count["noload"] += 1
@@ -196,24 +289,41 @@ def main():
             status_count["skip"] += 1
             lines.append(f"skip       {short}: nv = {nv}")
             continue
-        for name, changes in VARIATIONS:
-            if args.variations != "all" and name not in args.variations.split(","):
-                continue
-            st, detail = run_isolated(lib, f, args.steps, args.lds, changes)
-            if name == "as-shipped":
+        todo = [(n, c) for n, c in VARIATIONS if args.variations == "all" or n in args.variations.split(",")]
+        res = run_isolated(lib, f, args.steps, args.lds, todo, want_record=bool(args.fixtures),
+                           stop_after_first=bool(args.export and not args.fixtures))   # (exporting: the as-shipped run decides)
+        for name, st, detail, rec in res:
+            if args.fixtures and st == "ok" and rec:
+                fx = os.path.join(args.fixtures, export_name(short) + ".npz")
+                old = dict(np.load(fx)) if os.path.exists(fx) and name != todo[0][0] else {}
+                for k, v in rec.items():
+                    old[f"{name}:{k}" if k.startswith("ref_") else k] = v
+                old[f"{name}:changes"] = np.array([f"{k}={v}" for k, v in dict(todo)[name].items()], dtype="U32")
+                np.savez_compressed(fx, **old)
+            if name == todo[0][0]:
                 status_count[st] += 1
                 if st == "rejected":
                     reason = re.sub(r"\s*\(.*", "", detail.split(":")[-1].strip())[:70]
                     census[reason] += 1
+                if args.export or args.fixtures:
+                    if st in ("ok", "deviates", "warning"):
+                        exported.append((export_name(short), short))
+                    else:
+                        try: os.remove(os.path.join(args.export or args.fixtures, export_name(short) + ".mjb.gz"))
+                        except OSError: pass
             else:
                 status_count[f"{name}:{st}"] += 1
             lines.append(f"{st:10s} {short} [{name}]: {detail}")
-            if st in ("rejected", "noload", "skip") and name == "as-shipped":
-                break
-        print(lines[-1], flush=True)
+            print(lines[-1], flush=True)
     out = []
-    out.append(f"# model sweep: {len(files)} files under {REF}/model and test/**/testdata, {args.steps} steps, nv <= {args.nvmax}, "
-               f"hostsim with a {args.lds} B LDS plan; {time.time() - t0:.0f} s")
+    if args.export or args.fixtures:
+        with open(os.path.join(args.export or args.fixtures, "index.txt"), "w") as fh:
+            fh.write("# <file stem> <model path under the reference tree>: models the emulation accepted, saved by mj_saveModel\n")
+            fh.write("".join(f"{a} {b}\n" for a, b in exported))
+    where = (f"{len(files)} exported .mjb files of {args.from_mjb}" if args.from_mjb else
+             f"{len(files)} files under {REF}/model and test/**/testdata")
+    how = (f"libmjhip.so on {lib.backend()}" if args.device else f"hostsim with a {args.lds} B LDS plan")
+    out.append(f"# model sweep: {where}, {args.steps} steps, nv <= {args.nvmax}, {how}; {time.time() - t0:.0f} s")
     out.append("# as-shipped status counts: " + ", ".join(f"{k} {v}" for k, v in sorted(status_count.items()) if ":" not in k))
     out.append("# variations: " + ", ".join(f"{k} {v}" for k, v in sorted(status_count.items()) if ":" in k))
     out.append("# rejection census (as shipped):")
