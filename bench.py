@@ -501,6 +501,22 @@ def driver_line(res: dict, full_path: str | None) -> dict:
             it = e.get("mean_pgs_iter", e.get("mean_solver_iter"))
             if it is not None:
                 line[name + "_iters"] = it
+            if (r.get("cpu_testspeed") or {}).get("value") is not None:
+                line[name + "_cpu_testspeed_value"] = r["cpu_testspeed"]["value"]
+    pr = res.get("pgs_residual")
+    if pr:
+        if "value" in pr:
+            line["pgs_residual_value"] = pr["value"]
+            pps = pr.get("parity_sample") or {}
+            line["pgs_residual_parity_ok"] = pps.get("ok")
+            ii = (pps.get("reference_device_libm") or {}).get("identical_input_steps") or {}
+            line["pgs_residual_max_rel_err"] = ii.get("max_rel_err")
+            line["pgs_residual_iter_differs"] = ii.get("solver_iter_differs")
+            line["pgs_residual_steps"] = ii.get("steps")
+            if (pr.get("testspeed_regime") or {}).get("value") is not None:
+                line["pgs_residual_testspeed_regime_value"] = pr["testspeed_regime"]["value"]
+        else:
+            line["pgs_residual_error"] = str(pr.get("error"))[:200]
     ar = res.get("api_regime")
     if ar:
         if "value" in ar:
@@ -582,6 +598,8 @@ def main() -> None:
     ap.add_argument("--leg", action="store_true", help="(internal) this run is a `configs` leg of the default run: short CPU legs")
     ap.add_argument("--no-extra", action="store_true",
                     help="only the timed region (profiling runs): no parity sample, no testspeed-regime leg, no CPU baseline")
+    ap.add_argument("--no-pgs-residual", action="store_true", help="skip the pgs_residual leg (the metric's workload with the opt-in tolerance-parity PGS sweep)")
+    ap.add_argument("--no-newton-regime", action="store_true", help="skip the newton_regime leg (the testspeed regime with the model's own solver)")
     ap.add_argument("--regime-steps", type=int, default=200, help="timed steps of the testspeed-regime leg")
     ap.add_argument("--regime-settle", type=int, default=1000, help="untimed settling steps of that leg")
     ap.add_argument("--parity-envs", type=int, default=64)
@@ -651,6 +669,7 @@ def main() -> None:
         torch.cuda.synchronize()
 
     events = []
+    cur = {"batch": batch}                    # the batch the launches step (the newton_regime leg swaps in its own)
     obs = ChunkGather(rank, world, dist)      # per-chunk observation gather to rank 0 (no-op at N = 1)
 
     def launch(ctrl, out, state0=None):
@@ -658,7 +677,7 @@ def main() -> None:
         else continue from the batch's own state, warm start and warning counters"""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        batch.rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, 0 if state0 is None else state0.data_ptr(),
+        cur["batch"].rollout_device(ctrl.shape[1], ma.mjSTATE_CTRL, 0 if state0 is None else state0.data_ptr(),
                              0, ctrl.data_ptr(), 0 if out is None else out.data_ptr(), stream,
                              cont=state0 is None)
         e1.record()
@@ -701,7 +720,7 @@ def main() -> None:
                 # rollout leg start from as well (taken before the warm-up, outside the timed region)
                 torch.cuda.synchronize()
                 snap["state"] = so[:, -1].cpu().numpy().copy()
-                snap["warm"] = batch.get("qacc_warmstart").copy()
+                snap["warm"] = cur["batch"].get("qacc_warmstart").copy()
                 del so
         state_w = [torch.empty((nenv, c.shape[1], nstate), dtype=torch.float64, device=dev) if want_state else None
                    for c in ctrl_w]
@@ -839,7 +858,55 @@ def main() -> None:
                 res["parity_sample"]["start"] = f"the GPU batch's state and warm start after the {args.settle} settle steps"
         except Exception as exc:  # the bench line must survive a checker problem; it is reported, not hidden
             res["parity_sample"] = {"ok": False, "error": repr(exc)}
-    del state_w, state_k, ctrl_w, ctrl_k
+    del state_w, state_k
+
+    # ---------------- the metric's workload once more with the OPT-IN residual-update PGS sweep ----------------
+    # (mjhip_batch_set_pgs_mode(1), mjh_solver.h: solve_pgs_resid -- tolerance parity instead of bit parity: reported beside
+    # `value`, never as it; its own parity sample with the 1e-6 bar, exact contact / constraint counts, solver_niter within one)
+    if (not args.no_extra and not args.no_pgs_residual and args.config == "humanoid" and solver_name == "pgs" and args.settle == 0
+            and hasattr(batch, "set_pgs_mode")):
+        try:
+            cur["batch"] = ma.Batch(dm, nenv, device=local_rank)
+            cur["batch"].set_pgs_mode(1)
+            el_r, timed_r, sw_r, sk_r = timed_region(state0, [], ctrl_w, ctrl_k, want_state)
+            k_r = sum(t for t, _ in timed_r)
+            if dist:
+                t = torch.tensor([el_r, k_r], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el_r, k_r = float(t[0]), float(t[1])
+            cn = cur["batch"].get("counts")
+            if rank == 0:
+                res["pgs_residual"] = {
+                    "value": nenv * world * K / el_r, "unit": "env-steps/s", "steps": K, "warmup": W, "ms_per_step": el_r * 1e3 / K,
+                    "kernel_ms_total": k_r, "mode": "mjhip_batch_set_pgs_mode(1): residual-update PGS sweep, tolerance parity (opt-in)",
+                    "end_state": {"warnings": int(cur["batch"].get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
+                                  "mean_nefc": float(cn[:, 1].mean()), "mean_solver_iter": float(cn[:, 5].mean())}}
+                if want_state and args.parity_envs > 0:
+                    envs = np.unique(np.linspace(0, nenv - 1, min(args.parity_envs, nenv)).astype(int))
+                    idx = torch.from_numpy(envs).to(dev)
+                    gs = torch.cat([x.index_select(0, idx) for x in sw_r + sk_r], dim=1).cpu().numpy()
+                    cs = torch.cat([x.index_select(0, idx) for x in ctrl_w + ctrl_k], dim=1).cpu().numpy()
+
+                    def step_once_r(states, warm, u):
+                        outs, cnts = [], []
+                        for a in range(0, len(states), nenv):
+                            b = min(len(states), a + nenv)
+                            small = ma.Batch(dm, b - a, device=local_rank)
+                            small.set_pgs_mode(1)
+                            outs.append(small.rollout_host(1, ma.mjSTATE_CTRL, states[a:b], warm[a:b], u[a:b])[:, 0])
+                            cnts.append(small.get("counts"))
+                            small.close()
+                        return np.concatenate(outs), np.concatenate(cnts)
+
+                    res["pgs_residual"]["parity_sample"] = parity_sample(model_path, solver_id, integ_id, s0[envs], cs, gs, envs, step_once_r,
+                                                                         cfg["ctrl"], iter_exact=False)
+            del sw_r, sk_r
+            cur["batch"].close()
+        except Exception as exc:
+            if rank == 0:
+                res["pgs_residual"] = {"error": repr(exc)}
+        cur["batch"] = batch
+    del ctrl_w, ctrl_k
 
     # ---------------- the same kernel in the reference testspeed's control regime ----------------
     if not args.no_extra and args.ctrl == "uniform" and args.regime_steps > 0 and args.config == "humanoid":
@@ -864,6 +931,59 @@ def main() -> None:
                         "initial states as in the metric leg",
                 "end_state": {"warnings": int(batch.get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
                               "mean_nefc": float(cn[:, 1].mean()), "mean_pgs_iter": float(cn[:, 5].mean())}}
+
+        # ---- the same regime with the opt-in residual-update PGS sweep (tolerance parity)
+        if not args.no_pgs_residual and solver_name == "pgs" and hasattr(batch, "set_pgs_mode"):
+            try:
+                cur["batch"] = ma.Batch(dm, nenv, device=local_rank)
+                cur["batch"].set_pgs_mode(1)
+                el4, timed4, _, _ = timed_region(state0, c_s, c_w, c_k, want_state)
+                if dist:
+                    t = torch.tensor([el4], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    el4 = float(t[0])
+                cn = cur["batch"].get("counts")
+                if rank == 0 and "pgs_residual" in res:
+                    res["pgs_residual"]["testspeed_regime"] = {
+                        "value": nenv * world * K2 / el4, "unit": "env-steps/s", "steps": K2, "settle": S2 + W2, "ms_per_step": el4 * 1e3 / K2,
+                        "end_state": {"warnings": int(cur["batch"].get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
+                                      "mean_nefc": float(cn[:, 1].mean()), "mean_pgs_iter": float(cn[:, 5].mean())}}
+                cur["batch"].close()
+            except Exception as exc:
+                if rank == 0:
+                    res.setdefault("pgs_residual", {})["testspeed_regime"] = {"error": repr(exc)}
+            cur["batch"] = batch
+
+        # ---- the same regime with the model's OWN solver (humanoid.xml ships the default: Newton): the configuration the
+        # reference's published figures are quoted on (doc/mjx.rst:187-215, :663-676: humanoid, Newton, testspeed), so the
+        # number can sit next to them; generic kernel variant (the lean one is PGS-only)
+        if not args.no_newton_regime and solver_name == "pgs":
+            try:
+                model_n = ma.MjbModel(lib, model_path)
+                if integ_id is not None:
+                    model_n.set_option("integrator", integ_id)
+                dm_n = ma.DeviceModel(lib, model_n)
+                cur["batch"] = ma.Batch(dm_n, nenv, device=local_rank)
+                el3, timed3, _, _ = timed_region(state0, c_s, c_w, c_k, want_state)
+                k3 = sum(t for t, _ in timed3)
+                if dist:
+                    t = torch.tensor([el3, k3], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    el3, k3 = float(t[0]), float(t[1])
+                cn = cur["batch"].get("counts")
+                if rank == 0:
+                    res["newton_regime"] = {
+                        "value": nenv * world * K2 / el3, "unit": "env-steps/s", "steps": K2, "settle": S2 + W2, "solver": "NEWTON",
+                        "ms_per_step": el3 * 1e3 / K2, "kernel_ms_total": k3, "kernel": cur["batch"].kernel_name(),
+                        "ctrl": "as testspeed_regime; humanoid.xml's own solver (Newton), " + integ_name,
+                        "end_state": {"warnings": int(cur["batch"].get("warning").sum()), "mean_ncon": float(cn[:, 0].mean()),
+                                      "mean_nefc": float(cn[:, 1].mean()), "mean_solver_iter": float(cn[:, 5].mean())}}
+                cur["batch"].close()
+            except Exception as exc:
+                if rank == 0:
+                    res["newton_regime"] = {"error": repr(exc)}
+            cur["batch"] = batch
+        del c_s, c_w, c_k
 
     # ---------------- the drop-in entry point itself: host arrays in and out through mjhip_rollout ----------------
     if rank == 0 and world == 1 and not args.no_extra and not args.leg and args.config == "humanoid" and args.api_steps > 0:
@@ -894,6 +1014,11 @@ def main() -> None:
                               solver_flag=(args.solver or cfg["solver"] or "").upper() or None)
             if cb:
                 res["cpu_baseline"] = cb
+            # the CPU side of newton_regime: the reference's testspeed with the model's own solver
+            if cb and "newton_regime" in res and "value" in res["newton_regime"]:
+                cbn = cpu_baseline(ncpu, budget_s=5.0, mjb_name=cfg["mjb"], solver_flag="Newton")
+                if cbn:
+                    res["newton_regime"]["cpu_testspeed"] = cbn
             # the same workload as `value` (same states, same controls, same steps) on the host cores
             if args.ctrl == "uniform" and (args.settle == 0 or snap_metric) and n_metric_ctrl > n_settle_ctrl:
                 try:

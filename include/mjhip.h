@@ -110,6 +110,14 @@ MJHIP_API const char* mjhip_batch_kernel(const mjhipBatch* batch);
  * 1e-6, solver iteration counts within one), not bit for bit.  Default off ($MJHIP_MFMA=1 turns it
  * on for new batches); measured in profiles/r02_mfma. */
 MJHIP_API int mjhip_batch_set_mfma(mjhipBatch* batch, int on);
+/* Opt-in: the PGS sweep (mj_solPGS, src/engine/engine_solver.c:457-741) in residual-update form.  mode 0 (default): every
+ * row visit takes a fresh mju_dot in the reference's association -- forces, states and iteration counts bit for bit.
+ * mode 1: every constraint keeps its residual b + AR f and a row visit folds the one changed force into all of them with a
+ * multiply-add -- the same sweep, projections, cost guard, momentum, restart and termination, but a residual's rounding
+ * differs, so results agree with the reference to rounding (next states within 1e-6, contact / constraint counts exact,
+ * solver_niter may differ) and not bit for bit.  About 2x less solver time on humanoid.xml.
+ * $MJHIP_PGS=residual selects mode 1 for new batches.  Applies to solves of at most 64 rows with pyramidal cones. */
+MJHIP_API int mjhip_batch_set_pgs_mode(mjhipBatch* batch, int mode);
 
 /* LDS residency plan of the batch kernels (no reference counterpart: the reference keeps mjData in
  * host DRAM).  Each environment is stepped by one 64-lane wavefront that owns `lds_bytes` of LDS;

@@ -94,6 +94,8 @@ class Lib:
         lib.mjhip_batch_set_variant.argtypes = [vp, C.c_char_p]
         lib.mjhip_batch_set_mfma.restype = ci
         lib.mjhip_batch_set_mfma.argtypes = [vp, ci]
+        lib.mjhip_batch_set_pgs_mode.restype = ci
+        lib.mjhip_batch_set_pgs_mode.argtypes = [vp, ci]
         lib.mjhip_batch_variant.restype = C.c_char_p
         lib.mjhip_batch_variant.argtypes = [vp]
         lib.mjhip_batch_kernel.restype = C.c_char_p
@@ -131,7 +133,7 @@ class Lib:
         "mjhip_batch_field", "mjhip_batch_get", "mjhip_batch_set", "mjhip_batch_forward",
         "mjhip_batch_plan_lds", "mjhip_batch_lds_report", "mjhip_batch_set_variant", "mjhip_batch_variant", "mjhip_batch_kernel",
         "mjhip_batch_step", "mjhip_batch_rollout", "mjhip_batch_rollout_sensors", "mjhip_batch_sync", "mjhip_rollout",
-        "mjhip_batch_trouble", "mjhip_rollout_clear_cache", "mjhip_batch_step1", "mjhip_batch_step2", "mjhip_batch_set_mfma",
+        "mjhip_batch_trouble", "mjhip_rollout_clear_cache", "mjhip_batch_step1", "mjhip_batch_step2", "mjhip_batch_set_mfma", "mjhip_batch_set_pgs_mode",
     )
 
     def backend(self) -> str:
@@ -291,6 +293,10 @@ class Batch:
     def set_mfma(self, on: bool) -> None:
         """AR = Y Y' on the matrix cores (tolerance parity instead of bit parity)"""
         self._lib.check(self._lib.c.mjhip_batch_set_mfma(self._h, 1 if on else 0), "set_mfma")
+
+    def set_pgs_mode(self, mode: int) -> None:
+        """0: the reference's PGS sweep, bit for bit (default); 1: residual-update sweep (tolerance parity, opt-in)"""
+        self._lib.check(self._lib.c.mjhip_batch_set_pgs_mode(self._h, int(mode)), "set_pgs_mode")
 
     def set_variant(self, name: str) -> None:
         self._lib.check(self._lib.c.mjhip_batch_set_variant(self._h, name.encode()), f"set_variant {name}")

@@ -442,6 +442,7 @@ MJHIP_API mjhipBatch* mjhip_batch_create_layout(mjhipModel* M, int nenv, int dev
   // launch balancing ($MJHIP_BALANCE=0 keeps the identity order; measured in profiles/r02_balance)
   if (const char* ev = getenv("MJHIP_BALANCE")) Bt->balance = atoi(ev) != 0;
   if (const char* ev = getenv("MJHIP_MFMA")) { Bt->D.mfma = atoi(ev) != 0; Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr); }
+  if (const char* ev = getenv("MJHIP_PGS")) { Bt->D.pgs_mode = (ev[0] == 'r' || ev[0] == '1') ? 1 : 0; Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr); }
   // kernel variant: the leanest mapping whose feature set covers the model ($MJHIP_VARIANT overrides)
   Bt->variant = default_variant(M, Bt->soa, Bt->nenv);
   // ($MJHIP_VARIANT is a preference: batches it cannot serve -- SoA layout, models that need
@@ -533,6 +534,15 @@ MJHIP_API int mjhip_batch_set_mfma(mjhipBatch* Bt, int on) {
   Bt->D.mfma = Bt->L.mfma = on ? 1 : 0;
   if (!Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr) || !Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) ||
       !Backend::sync(nullptr)) { set_err("mjhip_batch_set_mfma: descriptor upload failed"); return -2; }
+  return 0;
+}
+// PGS sweep: 0 = the reference's, bit for bit (default); 1 = residual-update form (tolerance parity); $MJHIP_PGS=residual at creation
+MJHIP_API int mjhip_batch_set_pgs_mode(mjhipBatch* Bt, int mode) {
+  if (!Bt || mode < 0 || mode > 1) { set_err("mjhip_batch_set_pgs_mode: bad arguments"); return -1; }
+  { std::string e_; if (!Backend::set_device(Bt->device, &e_)) { set_err(e_); return -1; } }
+  Bt->D.pgs_mode = Bt->L.pgs_mode = mode;
+  if (!Backend::h2d(Bt->D_dev, &Bt->D, sizeof(DBatch), nullptr) || !Backend::h2d(Bt->L_dev, &Bt->L, sizeof(DBatch), nullptr) ||
+      !Backend::sync(nullptr)) { set_err("mjhip_batch_set_pgs_mode: descriptor upload failed"); return -2; }
   return 0;
 }
 MJHIP_API const char* mjhip_batch_variant(const mjhipBatch* Bt) { return Bt ? mjh_variant_name(Bt->variant) : ""; }

@@ -302,6 +302,182 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 // ------------------------------------------------------------------------------------------------
+// solPGS in RESIDUAL-UPDATE form, nefc <= 64 -- OPT-IN, tolerance parity (mjhip_batch_set_pgs_mode(1), $MJHIP_PGS=residual).
+//
+// Lane j owns constraint j and carries, next to force / bounds / momentum, the row's residual r_j = b_j + AR_j . f.
+// Visiting row i changes ONE force by delta; every lane folds that into its own residual with one multiply-add,
+// r_j += AR[i][j] * delta (row i of AR is contiguous across the lanes).  A row visit is then
+//   owner: f_i - r_i/AR_ii, projection, cost guard  ->  v_readlane(delta)  ->  one v_fma per lane
+// instead of a fresh mju_dot per visit (nefc/4 dependent adds + the combine): ~10 dependent instructions instead of
+// ~20 + nefc/4, and a third of the vector instructions.  The sweep, the projections, the cost guard, Nesterov momentum,
+// the gradient restart and the termination test are the reference's (engine_solver.c:457-741); what differs is the
+// ROUNDING of a residual (an accumulation of updates since the start of the iteration, where every lane's residual is
+// computed afresh, instead of a four-chain dot product per visit) and of the restart's sum (a butterfly instead of a
+// serial loop).  Forces therefore agree with the reference to rounding, not bit for bit, and the iteration at which
+// `improvement < tolerance` fires may move: next states within 1e-6 (measured: bench.py `pgs_residual`,
+// tests/test_gpu_parity.py), contact and constraint counts exact.  The default (mode 0) stays the bit-exact sweep above.
+// ------------------------------------------------------------------------------------------------
+template <int ARL>
+MJH_DEVN_HOT void solve_pgs_resid(MREF M_, BREF B_, int e_) {
+  const auto& M = wv_uniform_ref(M_);
+  BREF B = B_;
+  const int e = wv_uniform_i(e_);
+  iptr counts = MJH_F(B, counts, e);
+  const int n = wv_uniform_i(counts[MJH_C_NEFC]), ne = wv_uniform_i(counts[MJH_C_NE]), nf = wv_uniform_i(counts[MJH_C_NF]);
+  Efc P;
+  efc_layout(M, B, e, n, P);
+  const int lane = wv_lane();
+  const int own = lane < n;
+  const int jj = own ? lane : 0;
+  const int kind = (jj < ne) ? 0 : (jj < ne + nf ? 1 : 2);   // equality / friction / inequality
+  const bool isfric = (kind == 1), isineq = (kind == 2);
+  real f = own ? P.force[jj] : 0;
+  const real bj = own ? P.b[jj] : 0;
+  const real fl = own ? P.floss[jj] : 0;
+#if defined(MJH_HOSTSIM)
+  const real* ARl = nullptr;
+#else
+  const __attribute__((address_space(3))) real* ARl =
+      (const __attribute__((address_space(3))) real*)(unsigned)(size_t)((const char*)P.AR.p - mjh_lds());
+#endif
+  (void)ARl;
+  auto ar_load = [&](int r) -> real {       // AR[r][jj]
+    if (ARL) return ARl[r*n + jj];
+    return P.AR[(size_t)r*n + jj];
+  };
+  const real arjj = own ? ar_load(jj) : 1;
+  const real ainv = 1 / arjj;
+  const real A = 1/ainv;
+  const real pinf = __builtin_huge_val();
+  const real blo = isfric ? -fl : (isineq ? 0.0 : -pinf);
+  const real bhi = isfric ? fl : pinf;
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const auto* otab_all = wv_uniform_ptr(M.pgs_order);
+  const auto* otab_adr = wv_uniform_ptr(M.pgs_order_adr);
+  const int nisl_raw = wv_uniform_i(counts[MJH_C_NISLAND]);
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  const int myisl = (own && nisl > 1) ? P.island[jj] : 0;
+  int niter0 = 0;
+
+  for (int isl = 0; isl < nisl; isl++) {
+    const int member = own && myisl == isl;
+    int nk = n;
+    int crank = jj;
+    if (nisl > 1) {
+      nk = wv_uniform_i(wv_sum_i(member));
+      crank = 0;
+      for (int q = 0; q < n; q++) {
+        const int inq = (P.island[q] == isl);
+        if (inq && q < jj) crank++;
+      }
+      if (member) P.order[crank] = jj;
+      wv_sync();
+    }
+    if (nk == 0) continue;
+    int grow = lane;                 // global row (= owner lane) of island-local index `lane`
+    if (nisl > 1) grow = (lane < nk) ? P.order[lane] : 0;
+    wv_sync();
+    const auto* otab = otab_all + otab_adr[nk];
+    real fprev = f, fmom = f;
+    int iter = 0, nesterov_k = 0;
+    int ord_next = (lane < nk) ? otab[lane] : 0;
+    while (iter < maxiter) {
+      const int ordc = ord_next;
+      if (iter + 1 < maxiter) ord_next = (lane < nk) ? otab[(iter + 1)*nk + lane] : 0;
+      const int ord = (nisl > 1) ? wv_shfl_i(grow, ordc) : ordc;      // lane b: the row visited at position b
+      // ---- Nesterov extrapolation (:508-554)
+      real beta = 0;
+      if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+      if (member) {
+        if (beta > 0) {
+          const real f_save = f;
+          real fx = f_save + beta*(f_save - fprev);
+          fprev = f_save;
+          if (kind == 1) fx = r_clip(fx, -fl, fl);
+          else if (kind == 2 && fx < 0) fx = 0;
+          f = fx;
+          fmom = fx;
+        } else {
+          fprev = f;
+          fmom = f;
+        }
+      }
+      // ---- every row's residual afresh, once per iteration: r_j = b_j + sum_k AR[k][j] f_k (AR is symmetric; row k of it
+      // is contiguous across the lanes), two interleaved partial sums
+      real r = bj;
+      {
+        real r1 = 0;
+        int k = 0;
+        for (; k + 1 < n; k += 2) {
+          r = __builtin_fma(ar_load(k), wv_bcast(f, k), r);
+          r1 = __builtin_fma(ar_load(k + 1), wv_bcast(f, k + 1), r1);
+        }
+        if (k < n) r = __builtin_fma(ar_load(k), wv_bcast(f, k), r);
+        r += r1;
+      }
+
+      // ---- one sweep
+      real improvement = 0;
+      int i = wv_bcast_i(ord, 0);
+      real a = ar_load(i);                   // row of the first visited constraint (lanes without a constraint read column 0: unused)
+      for (int bi = 0; bi < nk; bi++) {
+        const int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
+        const real anext = ar_load(inext);   // the coming row, in flight while this one is applied
+        // every lane evaluates the update of its own constraint from its residual; the visited row's owner's counts
+        const real res = r;
+        real fn = f - res*ainv;
+        fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
+        const real delta = fn - f;
+        // the residuals move on with the owner's delta at once; the cost guard (costChange, :216-237) is evaluated beside
+        // that and, where it rejects the update (change > 1e-10: rare), the step is taken back
+        const real d = wv_bcast(delta, i);
+        const real rn = __builtin_fma(a, d, r);
+        const real change = 0.5*delta*delta*A + delta*res;
+        const real ch = wv_bcast(change, i);
+        if (ch > 1e-10) {
+          // rejected: force and residuals stay
+        } else {
+          r = rn;
+          if (lane == i) f = fn;
+          improvement -= ch;
+        }
+        i = inext;
+        a = anext;
+      }
+      improvement *= scale;
+
+      // ---- gradient restart (:694-713)
+      int restart = 0;
+      if (iter > 0) {
+        real ce = member ? (f - fmom) * (fmom - fprev) : 0;
+        for (int m = 1; m < MJH_W; m <<= 1) ce += wv_shfl_xor(ce, m);
+        restart = (wv_bcast(ce, 0) < 0);
+      }
+      if (restart) nesterov_k = 0; else nesterov_k++;
+      iter++;
+      if (improvement < M.o.tolerance) break;
+    }
+    if (isl == 0) niter0 = iter;
+  }
+
+  // final dual state (dualState, :270-345), forces back to memory, iteration count
+  if (own) {
+    int st;
+    if (kind == 0) st = MJH_STATE_QUADRATIC;
+    else if (kind == 1) {
+      if (f <= -fl) st = MJH_STATE_LINEARPOS;
+      else if (f >= fl) st = MJH_STATE_LINEARNEG;
+      else st = MJH_STATE_QUADRATIC;
+    } else st = (f <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+    P.state[jj] = st;
+    P.force[jj] = f;
+  }
+  if (lane == 0) counts[MJH_C_NITER] = niter0;
+  wv_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // solPGS for 64 < nefc <= 128, iterate in registers, TWO constraints per lane.
 //
 // Same layout idea with chains of up to 32 positions: position k of chain c is lane 16*c + (k & 15),
@@ -1142,6 +1318,17 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
   if (nefc > 64 && nefc <= 128 && nefc <= M.s.pgs_nmax && M.o.iterations <= M.s.pgs_iters && counts[MJH_C_NISLAND] <= 1 &&
       (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
     solve_pgs_wide(M, B, e);
+  } else
+#endif
+#if !MJH_LANE_MODE && MJH_W == 64
+  if (B.pgs_mode == 1 && nefc <= MJH_W && M.o.iterations <= M.s.pgs_iters && (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
+    // (opt-in: the residual-update sweep, tolerance parity)
+#if defined(MJH_HOSTSIM)
+    solve_pgs_resid<0>(M, B, e);
+#else
+    if (mjh_in_lds(P.AR)) solve_pgs_resid<1>(M, B, e);
+    else solve_pgs_resid<0>(M, B, e);
+#endif
   } else
 #endif
 #if !MJH_LANE_MODE && MJH_W >= 32

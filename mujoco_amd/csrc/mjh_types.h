@@ -797,6 +797,7 @@ struct DBatch {
   int nconlds;       // contact slots resident in LDS
   int soa;           // 0: fields are [nenv][count]; else = nenvpad, fields are [count][nenvpad]
   int mfma;          // 1: AR = Y Y' on the matrix cores (v_mfma_f64_16x16x4_f64): tolerance parity, not bit parity
+  int pgs_mode;      // 0: the reference's PGS sweep bit for bit; 1: residual-update sweep (solve_pgs_resid: tolerance parity, opt-in)
   int xfrc_on;       // 1: xfrc_applied may be non-zero (mj_xfrcAccumulate runs; xipos stays readable at MJH_T_ACCEL)
   void* ccd_ws;      // convex narrowphase: [nenv][ccd_env_bytes] pair lists, contact records, overflow pages; null without convex pairs (mjh_convex.h)
 #define X(name, cnt, lcnt, t0, t1) real* name; int n_##name; int l_##name; int io_##name;

@@ -78,6 +78,53 @@ def check_forward(rb, m, batch, states, tol, exact_ints=True, lds=False):
     return worst
 
 
+def pgs_residual_parity(rb, K, m, dm, states, T=6):
+    """The opt-in residual-update PGS sweep (mjhip_batch_set_pgs_mode(1), mjh_solver.h: solve_pgs_resid) against the
+    reference: one mj_forward from contact-rich states (forces / accelerations to rounding, counts exact) and T mj_step
+    calls from each of them re-synchronised to the oracle's state (every next state within 1e-6).  Returns the worst
+    relative errors and the largest iteration-count difference."""
+    b = K.Batch(dm, len(states))
+    b.set_pgs_mode(1)
+    load_states(b, states)
+    b.forward()
+    counts, qacc, force = b.get("counts"), b.get("qacc"), b.get("efc_force")
+    d = rb.MjData(m)
+    worst_q = worst_f = 0.0
+    dn = 0
+    for e, s in enumerate(states):
+        d.qpos[:] = s["qpos"]; d.qvel[:] = s["qvel"]; d.qacc_warmstart[:] = s["qacc_warmstart"]; d.ctrl[:] = s["ctrl"]
+        rb.mj_forward(m, d)
+        n = d.nefc
+        assert counts[e][0] == d.ncon and counts[e][1] == n
+        if n:
+            ref = np.array(d.efc_force)[:n]
+            worst_f = max(worst_f, float(np.max(np.abs(force[e][:n] - ref) / np.maximum(1.0, np.abs(ref)))))
+        worst_q = max(worst_q, relerr(qacc[e], np.array(d.qacc)))
+        dn = max(dn, abs(int(counts[e][5]) - int(d.solver_niter[0])))
+    # steps from identical inputs (state, warm start, control), the oracle's trajectory as the common thread
+    s0 = np.stack([np.concatenate([[s["time"]], s["qpos"], s["qvel"]]) for s in states])
+    ws = np.stack([s["qacc_warmstart"] for s in states])
+    u = np.stack([s["ctrl"] for s in states])
+    worst_s = 0.0
+    spec = rb.mjSTATE_FULLPHYSICS
+    cur_s, cur_w = s0.copy(), ws.copy()
+    for t in range(T):
+        out = b.rollout_host(1, K.mjSTATE_CTRL, cur_s, cur_w, u[:, None])[:, 0]
+        c = b.get("counts")
+        for e in range(len(states)):
+            rb.mj_setState(m, d, cur_s[e], spec)
+            d.qacc_warmstart[:] = cur_w[e]
+            d.ctrl[:] = u[e]
+            rb.mj_step(m, d)
+            ref = rb.mj_getState(m, d, spec)
+            worst_s = max(worst_s, relerr(out[e], ref))
+            assert c[e][0] == d.ncon and c[e][1] == d.nefc, (t, e)
+            dn = max(dn, abs(int(c[e][5]) - int(d.solver_niter[0])))
+            cur_s[e] = ref
+            cur_w[e] = np.array(d.qacc_warmstart)
+    return worst_f, worst_q, worst_s, dn, int(counts[:, 1].max())
+
+
 def oracle_rollout(rb, m, state0, ctrl, warmstart0=None):
     """serial mj_step loop: the py_rollout of the reference's rollout_test.py:976-1001"""
     nenv, nstep = ctrl.shape[:2]

@@ -924,6 +924,24 @@ def test_mfma_ar_tolerance_parity(rb, hip_lib, dm, golden):
     assert relerr(out[:, :10], fx["state"][:, :10]) <= TOL
 
 
+def test_pgs_residual_mode_tolerance_parity_on_gpu(rb, hip_lib, dm, golden):
+    """opt-in residual-update PGS sweep (mjhip_batch_set_pgs_mode(1)): next states within the 1e-6 bar, counts exact,
+    iteration counts reported; the default mode stays bit-exact (every other test of this file)"""
+    from parity_utils import pgs_residual_parity
+    m = humanoid_pgs_oracle(rb)
+    states = contact_rich_states(rb, m, 48, seed=37)
+    worst_f, worst_q, worst_s, dn, nmax = pgs_residual_parity(rb, K, m, dm, states, T=6)
+    print("pgs residual: force", worst_f, "qacc", worst_q, "state", worst_s, "max |delta niter|", dn, "max nefc", nmax)
+    assert nmax > 16
+    assert worst_s <= TOL and worst_q <= 1e-6
+    fx = golden("humanoid")
+    n, T = fx["state0"].shape[0], 40
+    b2 = K.Batch(dm, n)
+    b2.set_pgs_mode(1)
+    out = b2.rollout_host(T, K.mjSTATE_CTRL, fx["state0"], None, fx["ctrl"][:, :T])
+    assert relerr(out[:, :10], fx["state"][:, :10]) <= TOL
+
+
 def test_broadphase_and_midphase_counts_exact_on_gpu(rb, hip_lib, tmp_path):
     """the reproduced sweep-and-prune / BVH culls on the GPU: exactly touching spheres (contact
     counts equal to the reference's in every scene) and a pile of multi-geom bodies that takes the

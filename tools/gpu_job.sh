@@ -12,6 +12,7 @@
 #   sq:<config>      SQ instruction counters of the rollout kernel (tools/gpu_sq.sh)
 #   tail             tools/tail_stats.py
 #   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
+#   flexab           tools/gpu_flex_ab.sh: flex bench, current build against the round-4 final tree (tools/variants/r04_tree)
 #   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
 # (the one-shot scripts of rounds 2-3 -- gpu_r2*.sh, gpu_r3[a-s].sh, gpu_flex*.sh -- were sequences of these steps;
 #  their outputs are quoted in profiles/r02* and profiles/r03*)
@@ -68,8 +69,14 @@ for step in "$@"; do
     tail)
       timeout 600 python tools/tail_stats.py > "$OUT/tail_stats.txt" 2>&1; tail -12 "$OUT/tail_stats.txt" ;;
     sweep)
-      ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 320 --out "$OUT/sweep_gpu" > "$OUT/sweep_gpu.log" 2>&1 ) 2>&1 | grep real
-      head -4 "$OUT/sweep_gpu/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu/sweep.txt" | head -40 ;;
+      # against the reference linked with the kernels' own sin / cos (what the device reproduces to the bit), then against
+      # the reference as built (glibc libm): the difference between the two columns is libm's last bit
+      ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 1600 --out "$OUT/sweep_gpu" > "$OUT/sweep_gpu.log" 2>&1 ) 2>&1 | grep real
+      head -3 "$OUT/sweep_gpu/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu/sweep.txt" | head -40
+      ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 1600 --oracle parity --out "$OUT/sweep_gpu_glibc" > "$OUT/sweep_gpu_glibc.log" 2>&1 ) 2>&1 | grep real
+      head -3 "$OUT/sweep_gpu_glibc/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu_glibc/sweep.txt" | grep -v rejected | head -20 ;;
+    flexab)
+      bash tools/gpu_flex_ab.sh "gpurun_out/$TAG/flex_ab" 2>&1 | tee "$OUT/flex_ab.txt" ;;
     resources)
       python tools/kernel_resources.py > "$OUT/kernel_resource_usage.txt" 2>&1; cat "$OUT/kernel_resource_usage.txt" ;;
     *) echo "unknown step $step" ;;

@@ -144,6 +144,31 @@ def run_one(lib, path, steps, lds, changes, progress=None, record=None):
         record.update(state0=s0, ref_state=ref, ref_counts=ref_int, ref_sensordata=ref_sens, ref_warnings=np.array(ref_warn),
                       ctrl0=ctrl0 if ctrl0 is not None else np.zeros(0),
                       mocap_pos=mocap[0].ravel() if mocap else np.zeros(0), mocap_quat=mocap[1].ravel() if mocap else np.zeros(0))
+        # the same trajectory from the reference linked with the KERNELS' sin / cos / atan2 / exp (liboracle_dm.so,
+        # oracle/devmath_shim.cc): what the device is expected to reproduce to the bit -- the emulation calls the host's
+        # libm, as the reference as built does, the device evaluates its own routines
+        if rb.available("devmath"):
+            prev = rb.use("devmath")
+            try:
+                m2 = load_model(path)
+                for k, v in changes.items():
+                    setattr(m2.opt, k, v)
+                d2 = rb.MjData(m2)
+                if m2.nkey > 0:
+                    rb.mj_resetDataKeyframe(m2, d2, 0)
+                else:
+                    rb.mj_resetData(m2, d2)
+                r2 = np.zeros_like(ref); i2 = np.zeros_like(ref_int); s2 = np.zeros_like(ref_sens)
+                for t in range(steps):
+                    rb.mj_step(m2, d2)
+                    r2[t] = rb.mj_getState(m2, d2, spec)
+                    i2[t] = (d2.ncon, d2.nefc)
+                    if m2.nsensordata:
+                        s2[t] = d2.sensordata
+                record.update(ref_state_dm=r2, ref_counts_dm=i2, ref_sensordata_dm=s2)
+                del d2, m2
+            finally:
+                rb.use(prev)
     if progress: progress()                                    # (the reference's trajectory is done)
     # mjhip: closed-loop steps so that the integer observables can be read after each
     b.reset()
@@ -248,6 +273,9 @@ def main():
     ap.add_argument("--from-mjb", default="", help="sweep the exported .mjb files of this directory instead of the reference tree")
     ap.add_argument("--device", action="store_true", help="step with libmjhip.so on the GPU instead of the host emulation")
     ap.add_argument("--fixtures", default="", help="with --subset: store <name>.mjb + <name>.npz (inputs + reference trajectories of every variation) here")
+    ap.add_argument("--oracle", choices=["parity", "devmath"], default="",
+                    help="the reference build to compare with: parity = as built (glibc libm), devmath = linked with the kernels' "
+                         "sin / cos / atan2 / exp; default: parity on the emulation (which calls the host's libm), devmath on the device")
     ap.add_argument("--subset", default="", help="file with one model path (as in sweep.txt) per line")
     args = ap.parse_args()
     if not args.from_mjb and not os.path.isdir(os.path.join(REF, "model")):
@@ -255,6 +283,8 @@ def main():
     lib = K.Lib(os.path.join(ROOT, 'mujoco_amd', 'csrc', 'libmjhip.so')) if args.device else K.Lib(HOSTSIM_LIB)
     if args.device:
         args.lds = 0
+    oracle = args.oracle or ("devmath" if args.device else "parity")
+    rb.use(oracle)
     if args.from_mjb:
         index = [ln.split() for ln in open(os.path.join(args.from_mjb, "index.txt")) if ln.strip() and not ln.startswith("#")]
         files = [os.path.join(args.from_mjb, stem + ".mjb.gz") for stem, _ in index if not args.only or args.only in _]
@@ -323,7 +353,7 @@ def main():
     where = (f"{len(files)} exported .mjb files of {args.from_mjb}" if args.from_mjb else
              f"{len(files)} files under {REF}/model and test/**/testdata")
     how = (f"libmjhip.so on {lib.backend()}" if args.device else f"hostsim with a {args.lds} B LDS plan")
-    out.append(f"# model sweep: {where}, {args.steps} steps, nv <= {args.nvmax}, {how}; {time.time() - t0:.0f} s")
+    out.append(f"# model sweep: {where}, {args.steps} steps, nv <= {args.nvmax}, {how}; oracle build: {oracle}; {time.time() - t0:.0f} s")
     out.append("# as-shipped status counts: " + ", ".join(f"{k} {v}" for k, v in sorted(status_count.items()) if ":" not in k))
     out.append("# variations: " + ", ".join(f"{k} {v}" for k, v in sorted(status_count.items()) if ":" in k))
     out.append("# rejection census (as shipped):")
