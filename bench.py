@@ -206,7 +206,7 @@ def measured_traffic(steps_per_launch: int, nenv: int, model_xml: str = ""):
             exact = int(m.group(1)) == steps_per_launch
             if best[0] is None or exact:
                 best = (per_env_step * steps_per_launch * nenv,
-                        os.path.relpath(f, ROOT) + ("" if exact else f" (taken at {m.group(1)} steps per launch, scaled per env-step)"))
+                        os.path.relpath(f, ROOT) + ("" if exact else f" (counters taken at {m.group(1)} steps per launch, scaled per env-step to this run's {steps_per_launch})"))
     return best
 
 

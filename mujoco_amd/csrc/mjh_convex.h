@@ -2288,16 +2288,11 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
 #endif
   RowPair c;
   rc_attach(M, B, e, c);
-  // (single-contact pairs -- curved shapes, margins -- take the whole query at once, four at a time)
-  for (int t = row; t < total; t += 4) {
-    const int owner = head[64 + t], pp = head[t];
-    if (rc_max_contacts(M, pp) > 1) continue;
-    const int n = rc_geom_pair(M, B, e, c, pp, rc_records(M, B, e, owner));
-    if (rw_l() == 0) head[128 + owner] = n;
-  }
-  wv_converge();
-  wv_sync();
-  // first pass of the polyhedral pairs: one pair per lane, simplex in registers -- unless stage_collision ran it for all
+  // first the distance phase of the polyhedral pairs, THEN the single-contact pairs: the lane-parallel distance phase uses
+  // the record of the lane it runs on as scratch (ccd_poly_distance: `hold`), and lane k works on the k-th polyhedral pair,
+  // not on its own -- run after the single-contact pairs it overwrote the finished contact of a curved pair owned by
+  // that lane (round 6: discardvisual.xml, a sphere : mesh pair next to a mesh : mesh pair read dist 1.2 instead of -0.199)
+  // one polyhedral pair per lane, simplex in registers -- unless stage_collision ran it for all
   // pairs in reach at once (ccd_poly_prepass: head[193] set), then the results are looked up
   const PolyTab tab = rc_poly_tables(M, B, e);
   int entry = -1;                               // my pair's entry in the tables
@@ -2314,6 +2309,15 @@ MJH_DEVN_HOT int ccd_convex_pair(MREF M_, BREF B_, int e_, int p) {
       if (poly) head[128 + wv_lane()] = tab.flag[entry] ? -1 : 0;
     }
   }
+  wv_sync();
+  // (single-contact pairs -- curved shapes, margins -- take the whole query at once, four at a time)
+  for (int t = row; t < total; t += 4) {
+    const int owner = head[64 + t], pp = head[t];
+    if (rc_max_contacts(M, pp) > 1) continue;
+    const int n = rc_geom_pair(M, B, e, c, pp, rc_records(M, B, e, owner));
+    if (rw_l() == 0) head[128 + owner] = n;
+  }
+  wv_converge();
   wv_sync();
   tick(46);
   // second pass over the pairs marked -1

@@ -498,3 +498,206 @@ MJH_DEV real dot_sparse_ref(P0 a, P1 x, int nnz, P2 ind) {
   for (; i < nnz; i++) res += a[i]*x[ind[i]];
   return res;
 }
+
+// ---- tendon wrapping around spheres and cylinders ------------------------------------------------------------------
+// mju_wrap and its helpers (engine_util_misc.c:36-413), operation for operation: plain scalar code, one tendon per
+// caller.  acos / asin: libm on the host emulation; on the device through mjh_atan2 (which oracle/devmath_shim.cc binds
+// the reference's acos / asin to as well, for the device-libm build of the oracle).
+MJH_DEV real mjh_acos(real x) { return mjh_atan2(sqrt((1 - x)*(1 + x)), x); }
+MJH_DEV real mjh_asin(real x) { return mjh_atan2(x, sqrt((1 - x)*(1 + x))); }
+MJH_DEV real r_acos(real x) {
+#ifdef MJH_HOSTSIM
+  return acos(x);
+#else
+  return mjh_acos(x);
+#endif
+}
+MJH_DEV real r_asin(real x) {
+#ifdef MJH_HOSTSIM
+  return asin(x);
+#else
+  return mjh_asin(x);
+#endif
+}
+// mju_dot / mju_normalize for n = 2 (the four-accumulator dot product degenerates to 0 + (a0 b0 + a1 b1))
+MJH_DEV real wr_dot2(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1]; }
+MJH_DEV real wr_normalize2(real* v) {
+  const real n = sqrt(wr_dot2(v, v));
+  if (n < MJH_MINVAL) { v[0] = 1; v[1] = 0; }
+  else { const real inv = 1/n; v[0] *= inv; v[1] *= inv; }
+  return n;
+}
+// do the 2D segments (p1, p2) and (p3, p4) cross?                                   (is_intersect, :36-51)
+MJH_DEV int wr_intersect(const real* p1, const real* p2, const real* p3, const real* p4) {
+  const real det = (p4[1] - p3[1])*(p2[0] - p1[0]) - (p4[0] - p3[0])*(p2[1] - p1[1]);
+  if (fabs(det) < MJH_MINVAL) return 0;
+  const real a = ((p4[0] - p3[0])*(p1[1] - p3[1]) - (p4[1] - p3[1])*(p1[0] - p3[0])) / det;
+  const real b = ((p2[0] - p1[0])*(p1[1] - p3[1]) - (p2[1] - p1[1])*(p1[0] - p3[0])) / det;
+  return a >= 0 && a <= 1 && b >= 0 && b <= 1;
+}
+// arc length on the circle between two of its points                                (length_circle, :55-71)
+MJH_DEV real wr_arc(const real* p0, const real* p1, int ind, real radius) {
+  real p0n[2] = {p0[0], p0[1]}, p1n[2] = {p1[0], p1[1]};
+  wr_normalize2(p0n);
+  wr_normalize2(p1n);
+  real angle = r_acos(wr_dot2(p0n, p1n));
+  const real cross = p0[1]*p1[0] - p0[0]*p1[1];
+  if ((cross > 0 && ind) || (cross < 0 && !ind)) angle = 2*MJH_PI - angle;
+  return radius*angle;
+}
+// 2D wrap around a circle at the origin: tangent points in pnt[4], arc length or -1    (wrap_circle, :78-151)
+MJH_DEV real wr_circle(real* pnt, const real* end, const real* side, real radius) {
+  const real sqlen0 = end[0]*end[0] + end[1]*end[1];
+  const real sqlen1 = end[2]*end[2] + end[3]*end[3];
+  const real sqrad = radius*radius;
+  if (sqlen0 < sqrad || sqlen1 < sqrad || radius < MJH_MINVAL) return -1;
+  const real dif[2] = {end[2] - end[0], end[3] - end[1]};
+  const real dd = dif[0]*dif[0] + dif[1]*dif[1];
+  if (dd < MJH_MINVAL) return -1;
+  real a = -(dif[0]*end[0] + dif[1]*end[1])/dd;
+  if (a < 0) a = 0; else if (a > 1) a = 1;
+  const real tmp0[2] = {a*dif[0] + end[0], a*dif[1] + end[1]};
+  if (tmp0[0]*tmp0[0] + tmp0[1]*tmp0[1] > sqrad && (!side || wr_dot2(side, tmp0) >= 0)) return -1;
+  const real sqrt0 = sqrt(sqlen0 - sqrad), sqrt1 = sqrt(sqlen1 - sqrad);
+  real sol[2][2][2], good[2];
+  for (int i = 0; i < 2; i++) {
+    const int sgn = i == 0 ? 1 : -1;
+    sol[i][0][0] = (end[0]*sqrad + sgn*radius*end[1]*sqrt0)/sqlen0;
+    sol[i][0][1] = (end[1]*sqrad - sgn*radius*end[0]*sqrt0)/sqlen0;
+    sol[i][1][0] = (end[2]*sqrad - sgn*radius*end[3]*sqrt1)/sqlen1;
+    sol[i][1][1] = (end[3]*sqrad + sgn*radius*end[2]*sqrt1)/sqlen1;
+    real tmp[2];
+    if (side) {
+      tmp[0] = sol[i][0][0] + sol[i][1][0]; tmp[1] = sol[i][0][1] + sol[i][1][1];
+      wr_normalize2(tmp);
+      good[i] = wr_dot2(tmp, side);
+    } else {
+      tmp[0] = sol[i][0][0] - sol[i][1][0]; tmp[1] = sol[i][0][1] - sol[i][1][1];
+      good[i] = -wr_dot2(tmp, tmp);
+    }
+    if (wr_intersect(end, sol[i][0], end + 2, sol[i][1])) good[i] = -10000;
+  }
+  const int i = good[0] > good[1] ? 0 : 1;
+  pnt[0] = sol[i][0][0]; pnt[1] = sol[i][0][1]; pnt[2] = sol[i][1][0]; pnt[3] = sol[i][1][1];
+  if (wr_intersect(end, pnt, end + 2, pnt + 2)) return -1;
+  return wr_arc(sol[i][0], sol[i][1], i, radius);
+}
+// 2D wrap on the INSIDE of a circle: one touching point (twice) in pnt[4]; 0, or -1 without a wrap   (wrap_inside, :158-272)
+MJH_DEV real wr_inside(real* pnt, const real* end, real radius) {
+  const int maxiter = 20;
+  const real zinit = 1 - 1e-7, tolerance = 1e-6;
+  const real len0 = sqrt(wr_dot2(end, end)), len1 = sqrt(wr_dot2(end + 2, end + 2));
+  const real dif[2] = {end[2] - end[0], end[3] - end[1]};
+  const real dd = dif[0]*dif[0] + dif[1]*dif[1];
+  if (len0 <= radius || len1 <= radius || radius < MJH_MINVAL || len0 < MJH_MINVAL || len1 < MJH_MINVAL) return -1;
+  if (dd > MJH_MINVAL) {
+    const real a = -(dif[0]*end[0] + dif[1]*end[1]) / dd;
+    if (a > 0 && a < 1) {
+      const real tmp[2] = {end[0] + dif[0]*a, end[1] + dif[1]*a};
+      if (sqrt(wr_dot2(tmp, tmp)) <= radius) return -1;
+    }
+  }
+  pnt[0] = 0.5*(end[0] + end[2]);
+  pnt[1] = 0.5*(end[1] + end[3]);
+  wr_normalize2(pnt);
+  pnt[0] = pnt[0]*radius; pnt[1] = pnt[1]*radius;
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  const real A = radius/len0, Bc = radius/len1;
+  const real cosG = (len0*len0 + len1*len1 - dd) / (2*len0*len1);
+  if (cosG < -1 + MJH_MINVAL) return -1;
+  else if (cosG > 1 - MJH_MINVAL) return 0;
+  const real G = r_acos(cosG);
+  real z = zinit;
+  real f = r_asin(A*z) + r_asin(Bc*z) - 2*r_asin(z) + G;
+  if (f > 0) return 0;
+  int iter;
+  for (iter = 0; iter < maxiter && fabs(f) > tolerance; iter++) {
+    const real s0 = sqrt(1 - z*z*A*A), s1 = sqrt(1 - z*z*Bc*Bc), s2 = sqrt(1 - z*z);
+    const real df = A/(MJH_MINVAL > s0 ? MJH_MINVAL : s0) + Bc/(MJH_MINVAL > s1 ? MJH_MINVAL : s1) - 2/(MJH_MINVAL > s2 ? MJH_MINVAL : s2);
+    if (df > -MJH_MINVAL) return 0;
+    const real z1 = z - f/df;
+    if (z1 > z) return 0;
+    z = z1;
+    f = r_asin(A*z) + r_asin(Bc*z) - 2*r_asin(z) + G;
+    if (f > tolerance) return 0;
+  }
+  if (iter >= maxiter) return 0;
+  real vec[2], ang;
+  if (end[0]*end[3] - end[1]*end[2] > 0) { vec[0] = end[0]; vec[1] = end[1]; ang = r_asin(z) - r_asin(A*z); }
+  else { vec[0] = end[2]; vec[1] = end[3]; ang = r_asin(z) - r_asin(Bc*z); }
+  wr_normalize2(vec);
+  real sn, cs;
+  r_sincos(ang, &sn, &cs);
+  pnt[0] = radius*(cs*vec[0] - sn*vec[1]);
+  pnt[1] = radius*(sn*vec[0] + cs*vec[1]);
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  return 0;
+}
+// mju_wrap (:283-413): the two points where the path x0 -> x1 meets the wrapping geom (type 4: sphere, 5: cylinder, the
+// mjtWrap values) in wpnt[6], arc length between them, or -1 when the straight segment does not touch it
+MJH_DEV real mjh_wrap(real* wpnt, const real* x0, const real* x1, const real* xpos, const real* xmat, real radius,
+                      int type, const real* side) {
+  real tmp[3], p[2][3];
+  for (int k = 0; k < 3; k++) tmp[k] = x0[k] - xpos[k];
+  m3_multvec(p[0], xmat, tmp);
+  for (int k = 0; k < 3; k++) tmp[k] = x1[k] - xpos[k];
+  m3_multvec(p[1], xmat, tmp);
+  if (v3_norm(p[0]) < MJH_MINVAL || v3_norm(p[1]) < MJH_MINVAL) return -1;
+  real axis[2][3];
+  if (type == 4) {
+    v3_copy(axis[0], p[0]);
+    v3_normalize(axis[0]);
+    real normal[3];
+    v3_cross(normal, p[0], p[1]);
+    const real nrm = v3_normalize(normal);
+    if (nrm < MJH_MINVAL) {
+      int i = 0;
+      if (fabs(axis[0][1]) > fabs(axis[0][0]) && fabs(axis[0][1]) > fabs(axis[0][2])) i = 1;
+      if (fabs(axis[0][2]) > fabs(axis[0][0]) && fabs(axis[0][2]) > fabs(axis[0][1])) i = 2;
+      axis[1][0] = 1; axis[1][1] = 1; axis[1][2] = 1;
+      axis[1][i] = 0;
+      v3_cross(normal, axis[0], axis[1]);
+      v3_normalize(normal);
+    }
+    v3_cross(axis[1], normal, axis[0]);
+    v3_normalize(axis[1]);
+  } else {
+    axis[0][0] = 1; axis[0][1] = 0; axis[0][2] = 0;
+    axis[1][0] = 0; axis[1][1] = 1; axis[1][2] = 0;
+  }
+  real s[3] = {0, 0, 0}, d[4], sd[2] = {0, 0};
+  d[0] = v3_dot(p[0], axis[0]);
+  d[1] = v3_dot(p[0], axis[1]);
+  d[2] = v3_dot(p[1], axis[0]);
+  d[3] = v3_dot(p[1], axis[1]);
+  if (side) {
+    for (int k = 0; k < 3; k++) tmp[k] = side[k] - xpos[k];
+    m3_multvec(s, xmat, tmp);
+    sd[0] = v3_dot(s, axis[0]);
+    sd[1] = v3_dot(s, axis[1]);
+    wr_normalize2(sd);
+    sd[0] = sd[0]*radius; sd[1] = sd[1]*radius;
+  }
+  real wlen, pnt[4];
+  if (side && v3_norm(s) < radius) wlen = wr_inside(pnt, d, radius);
+  else wlen = wr_circle(pnt, d, side ? sd : (const real*)nullptr, radius);
+  if (wlen < 0) return -1;
+  real res[6];
+  for (int i = 0; i < 2; i++) {
+    for (int k = 0; k < 3; k++) res[3*i + k] = axis[0][k]*pnt[2*i];
+    for (int k = 0; k < 3; k++) tmp[k] = axis[1][k]*pnt[2*i + 1];
+    for (int k = 0; k < 3; k++) res[3*i + k] += tmp[k];
+  }
+  if (type == 5) {
+    const real L0 = sqrt((p[0][0] - res[0])*(p[0][0] - res[0]) + (p[0][1] - res[1])*(p[0][1] - res[1]));
+    const real L1 = sqrt((p[1][0] - res[3])*(p[1][0] - res[3]) + (p[1][1] - res[4])*(p[1][1] - res[4]));
+    res[2] = p[0][2] + (p[1][2] - p[0][2])*L0 / (L0 + wlen + L1);
+    res[5] = p[0][2] + (p[1][2] - p[0][2])*(L0 + wlen) / (L0 + wlen + L1);
+    const real height = fabs(res[5] - res[2]);
+    wlen = sqrt(wlen*wlen + height*height);
+  }
+  m3_mulvec(wpnt, xmat, res);
+  m3_mulvec(wpnt + 3, xmat, res + 3);
+  for (int k = 0; k < 3; k++) { wpnt[k] += xpos[k]; wpnt[3 + k] += xpos[k]; }
+  return wlen;
+}

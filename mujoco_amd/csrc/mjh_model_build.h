@@ -193,7 +193,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->sensor_history[2*i] != 0 || m->sensor_delay[i] != 0, "sensor history / delay");
   }
   MJH_REJECT(m->nsensor > 0 && m->nflex > 0, "sensors in models with flexes");
-  MJH_REJECT(m->opt.disableactuator != 0, "actuator groups disabled through opt.disableactuator");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
@@ -261,14 +260,18 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     // servo wrap period (wrapPeriod, engine_forward.c:305-342) is zero for hinge/slide joint transmissions
   }
   for (int i = 0; i < m->ntendon; i++) {
+    // (tendons wrapping around spheres / cylinders: round 6, mjh_math.h mjh_wrap + stage_tendon)
     for (int w = m->tendon_adr[i]; w < m->tendon_adr[i] + m->tendon_num[i]; w++)
-      MJH_REJECT(m->wrap_type[w] == mjWRAP_SPHERE || m->wrap_type[w] == mjWRAP_CYLINDER, "tendons wrapping around spheres / cylinders");
+      if (m->wrap_type[w] == mjWRAP_SPHERE || m->wrap_type[w] == mjWRAP_CYLINDER) o.has_tendon_wrap = 1;
     if (m->tendon_frictionloss[i] > 0) {
       const mjtNum* r = m->tendon_solref_fri + 2*i;
       MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on tendon friction");
     }
-    MJH_REJECT(m->tendon_armature[i] != 0 || actuator_contrib(m, 1, i, 1, nullptr) != 0, "tendon armature");
-    MJH_REJECT(m->tendon_actfrclimited[i], "tendon actuator force limits");
+    // (tendon armature, round 6: mj_tendonArmature / mj_tendonBias -- stage_crb, stage_rne; the fully implicit integrator,
+    //  whose derivative of the bias term would be needed, is rejected as a whole)
+    MJH_REJECT((m->tendon_armature[i] != 0 || actuator_contrib(m, 1, i, 1, nullptr) != 0) && m->nv > 128 &&
+               (m->opt.jacobian == mjJAC_SPARSE || m->opt.jacobian == mjJAC_AUTO),
+               "tendon armature in a model with more than 128 degrees of freedom and a sparse Jacobian");
   }
   for (int i = 0; i < m->njnt; i++) {
     MJH_REJECT(m->jnt_actgravcomp[i], "actuator-level gravity compensation");
@@ -434,6 +437,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->actuator_actadr, m->actuator_actadr, m->nu);
   copy_arr(H->actuator_actlimited, m->actuator_actlimited, m->nu);
   copy_arr(H->actuator_actearly, m->actuator_actearly, m->nu);
+  // mj_actuatorDisabled (engine_support.c:695): groups 0..30 named in opt.disableactuator
+  H->actuator_disabled.assign(m->nu, 0);
+  for (int i = 0; i < m->nu; i++) {
+    const int g = m->actuator_group[i];
+    if (g >= 0 && g <= 30 && (m->opt.disableactuator & (1 << g))) { H->actuator_disabled[i] = 1; o.has_act_disabled = 1; }
+  }
+  copy_arr(H->tendon_actfrclimited, m->tendon_actfrclimited, m->ntendon);
+  copy_arr(H->tendon_actfrcrange, m->tendon_actfrcrange, 2*m->ntendon);
+  for (int i = 0; i < m->ntendon; i++) if (m->tendon_actfrclimited[i]) o.has_ten_actfrc = 1;
   copy_arr(H->actuator_actrange, m->actuator_actrange, 2*m->nu);
   H->actuator_dyntau.resize(m->nu);
   for (int i = 0; i < m->nu; i++) H->actuator_dyntau[i] = m->actuator_dynprm[mjNDYN*i];
@@ -520,7 +532,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   H->tendon_damping_eff.resize(m->ntendon);
   H->tendon_dampingpoly_eff.assign(2*m->ntendon, 0);
   H->tendon_armature_eff.assign(m->ntendon, 0);
+  o.has_ten_armature = 0;
   for (int i = 0; i < m->ntendon; i++) {
+    // mj_tendonArmature / mj_tendonBias: tendon_armature + mj_actuatorArmature(mjOBJ_TENDON) (engine_core_smooth.c:1860, :2617)
+    H->tendon_armature_eff[i] = m->tendon_armature[i] + actuator_contrib(m, 1, i, 1, nullptr);
+    if (H->tendon_armature_eff[i] != 0) o.has_ten_armature = 1;
     real poly[2] = {m->tendon_dampingpoly[2*i], m->tendon_dampingpoly[2*i+1]};
     H->tendon_damping_eff[i] = m->tendon_damping[i] + actuator_contrib(m, 1, i, 0, poly);
     H->tendon_dampingpoly_eff[2*i] = poly[0];
@@ -2162,10 +2178,11 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         if (jt == mjJNT_BALL || jt == mjJNT_FREE) ft |= MJH_FT_TRNMISC;
       }
       if (m->actuator_gaintype[i] != mjGAIN_FIXED || m->actuator_biastype[i] != mjBIAS_NONE ||
-          m->actuator_forcelimited[i]) ft |= MJH_FT_GAINBIAS;
+          m->actuator_forcelimited[i] || H->actuator_disabled[i]) ft |= MJH_FT_GAINBIAS;
     }
     for (int i = 0; i < m->njnt; i++) if (m->jnt_actfrclimited[i]) ft |= MJH_FT_GAINBIAS;
-    if (o.has_gravcomp || o.has_fluid || o.has_surfacevel) ft |= MJH_FT_PASSIVEMISC;
+    if (o.has_ten_actfrc) ft |= MJH_FT_GAINBIAS;
+    if (o.has_gravcomp || o.has_fluid || o.has_surfacevel || o.has_ten_armature) ft |= MJH_FT_PASSIVEMISC;
     if (m->nmocap > 0) ft |= MJH_FT_MOCAP;
     if (m->ntree > 1) ft |= MJH_FT_ISLANDS;
     if (m->nflex > 0) ft |= MJH_FT_FLEX;

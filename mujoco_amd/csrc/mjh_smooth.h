@@ -302,53 +302,89 @@ MJH_DEVN void stage_tendon(MREF M_, BREF B_, int e_) {
     real len = 0;
     for (int k = 0; k < rnnz; k++) J[radr + k] = 0;
     if (MJH_HAS(MJH_FT_TENDONSPATIAL) && M.wrap_type[adr] != 1) {
-      // spatial tendon through sites, with pulleys (mj_tendon, engine_core_smooth.c:988-1105; wrapping
-      // geoms are rejected at upload): straight segments between consecutive sites, moments from the
-      // difference of the end-point Jacobians along the segment direction
+      // spatial tendon through sites, with pulleys and wrapping geoms (mj_tendon, engine_core_smooth.c:988-1105): straight
+      // segments between consecutive path points, moments from the difference of the end-point Jacobians along the
+      // segment direction.  A site - geom - site triple (round 6) asks mju_wrap for the two points where the path meets
+      // the sphere / cylinder: with a wrap the path is site -> wpnt1 -> (arc) -> wpnt2 -> site, the two inner points on
+      // the geom's body (the arc itself has no moment: both ends on one body)
       crptr sx = MJH_F(B, site_xpos, e);
       crptr cdof = MJH_F(B, cdof, e);
       crptr com = MJH_F(B, subtree_com, e);
       real divisor = 1;
+      // moment of the straight segment pa -> pb between bodies ba and bb (skipped when they coincide)
+      auto segment = [&](const real* pa, const real* pb, int ba, int bb) {
+        if (ba == bb) return;
+        real dif[3];
+        v3_sub(dif, pb, pa);
+        v3_normalize(dif);
+        real off0[3], off1[3];
+        v3_sub(off0, pa, com + 3*M.body_rootid[ba]);
+        v3_sub(off1, pb, com + 3*M.body_rootid[bb]);
+        const real binv = 1/divisor;
+        for (int k = 0; k < rnnz; k++) {
+          const int c = M.ten_J_colind[radr + k];
+          const int in0 = (M.body_dofanc[ba*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+          const int in1 = (M.body_dofanc[bb*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+          if (!in0 && !in1) continue;
+          crptr cd = cdof + 6*c;
+          real j0[3] = {0, 0, 0}, j1[3] = {0, 0, 0}, t[3];
+          if (in0) { v3_cross(t, cd, off0); j0[0] = cd[3] + t[0]; j0[1] = cd[4] + t[1]; j0[2] = cd[5] + t[2]; }
+          if (in1) { v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
+          real tmp = 0;
+          for (int r = 0; r < 3; r++) if (dif[r] != 0) tmp += (j1[r] - j0[r])*dif[r];
+          J[radr + k] += binv*tmp;
+        }
+      };
+      auto dist3 = [](const real* a, const real* b) -> real {
+        const real dd[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+        return sqrt(dd[0]*dd[0] + dd[1]*dd[1] + dd[2]*dd[2]);
+      };
       int j = 0;
       while (j < num - 1) {
-        const int type0 = M.wrap_type[adr + j], type1 = M.wrap_type[adr + j + 1];
+        const int type0 = M.wrap_type[adr + j];
+        int type1 = M.wrap_type[adr + j + 1];
         if (type0 == 2 || type1 == 2) {            // mjWRAP_PULLEY
           if (type0 == 2) divisor = M.wrap_prm[adr + j];
           j++;
           continue;
         }
-        const int id0 = M.wrap_objid[adr + j], id1 = M.wrap_objid[adr + j + 1];
-        real p0[3], p1[3];
-        v3_copy(p0, sx + 3*id0);
-        v3_copy(p1, sx + 3*id1);
-        const int b0 = M.site_bodyid[id0], b1 = M.site_bodyid[id1];
-        {
-          real dd[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-          len += sqrt(dd[0]*dd[0] + dd[1]*dd[1] + dd[2]*dd[2]) / divisor;
+        const int id0 = M.wrap_objid[adr + j];
+        int id1 = M.wrap_objid[adr + j + 1];
+        real wp[12];
+        v3_copy(wp, sx + 3*id0);
+        const int b0 = M.site_bodyid[id0];
+        real wlen = -1;
+        int wrapid = -1, wrapped = 0;
+        if (type1 == 4 || type1 == 5) {            // mjWRAP_SPHERE / mjWRAP_CYLINDER: site - geom - site
+          wrapped = 1;
+          wrapid = id1;
+          const int wtype = type1;
+          type1 = M.wrap_type[adr + j + 2];
+          id1 = M.wrap_objid[adr + j + 2];
+          const int sideid = (int)round(M.wrap_prm[adr + j + 1]);      // (mju_round; -1: no side site)
+          real x0[3], x1[3], gp[3], gm[9], sd[3];
+          v3_copy(x0, sx + 3*id0);
+          v3_copy(x1, sx + 3*id1);
+          crptr gxp = MJH_F(B, geom_xpos, e);
+          crptr gxm = MJH_F(B, geom_xmat, e);
+          v3_copy(gp, gxp + 3*wrapid);
+          for (int k = 0; k < 9; k++) gm[k] = gxm[9*wrapid + k];
+          if (sideid >= 0) v3_copy(sd, sx + 3*sideid);
+          wlen = mjh_wrap(wp + 3, x0, x1, gp, gm, M.geom_size[3*wrapid], wtype, sideid >= 0 ? (const real*)sd : (const real*)nullptr);
         }
-        if (b0 != b1) {
-          real dif[3];
-          v3_sub(dif, p1, p0);
-          v3_normalize(dif);
-          real off0[3], off1[3];
-          v3_sub(off0, p0, com + 3*M.body_rootid[b0]);
-          v3_sub(off1, p1, com + 3*M.body_rootid[b1]);
-          const real binv = 1/divisor;
-          for (int k = 0; k < rnnz; k++) {
-            const int c = M.ten_J_colind[radr + k];
-            const int in0 = (M.body_dofanc[b0*s.nvw + (c >> 5)] >> (c & 31)) & 1;
-            const int in1 = (M.body_dofanc[b1*s.nvw + (c >> 5)] >> (c & 31)) & 1;
-            if (!in0 && !in1) continue;
-            crptr cd = cdof + 6*c;
-            real j0[3] = {0, 0, 0}, j1[3] = {0, 0, 0}, t[3];
-            if (in0) { v3_cross(t, cd, off0); j0[0] = cd[3] + t[0]; j0[1] = cd[4] + t[1]; j0[2] = cd[5] + t[2]; }
-            if (in1) { v3_cross(t, cd, off1); j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2]; }
-            real tmp = 0;
-            for (int r = 0; r < 3; r++) if (dif[r] != 0) tmp += (j1[r] - j0[r])*dif[r];
-            J[radr + k] += binv*tmp;
-          }
+        const int b1 = M.site_bodyid[id1];
+        if (wlen < 0) {
+          v3_copy(wp + 3, sx + 3*id1);
+          len += dist3(wp, wp + 3) / divisor;
+          segment(wp, wp + 3, b0, b1);
+        } else {
+          v3_copy(wp + 9, sx + 3*id1);
+          const int gb = M.geom_bodyid[wrapid];
+          len += (dist3(wp, wp + 3) + wlen + dist3(wp + 6, wp + 9)) / divisor;
+          segment(wp, wp + 3, b0, gb);
+          segment(wp + 6, wp + 9, gb, b1);
         }
-        j++;
+        j += wrapped ? 2 : 1;
       }
       L[i] = len;
       continue;
@@ -559,6 +595,33 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_, int nopark) {
     }
   }
   wv_sync();
+  // mj_tendonArmature (engine_core_smooth.c:1845-1886): M += armature * ten_J' ten_J, restricted to M's own pattern -- per
+  // non-zero ten_J[i], row i of M gains (armature * ten_J[i]) * ten_J where the column lists meet
+  // (mju_addToSclSparseInc).  Tendons in order (their rows may coincide), a tendon's rows lane-parallel.
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_ten_armature) {
+    crptr tJ = MJH_F(B, ten_J, e);
+    for (int k = 0; k < s.ntendon; k++) {
+      const real arm = M.tendon_armature_eff[k];
+      if (!arm) continue;
+      const int radr = M.ten_J_rowadr[k], rnnz = M.ten_J_rownnz[k];
+      MJH_FOR_LANES(j, rnnz) {
+        const real Ji = tJ[radr + j];
+        if (Ji != 0) {
+          const int i = M.ten_J_colind[radr + j];
+          const int madr = M.M_rowadr[i], mn = M.M_rownnz[i];
+          const real scl = arm * Ji;
+          int as = 0, ad = 0;
+          while (as < rnnz && ad < mn) {
+            const int is = M.ten_J_colind[radr + as], id = M.M_colind[madr + ad];
+            if (is == id) { Mq[madr + ad] += scl * tJ[radr + as]; as++; ad++; }
+            else if (is < id) as++;
+            else ad++;
+          }
+        }
+      }
+      wv_sync();
+    }
+  }
   // the global copy of M: what tests inspect and what mj_Euler's fallback, implicitfast and the primal
   // solvers read once qLD has been factorised in place.  A step of the PGS + Euler path whose qH factor
   // is produced next to M's never reads it.
@@ -1322,6 +1385,113 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// mj_tendonBias (engine_core_smooth.c:2606-2641): qfrc += ten_J * armature * (d/dt(ten_J) . qvel), with
+// mj_tendonDot (:1115-1260) for spatial tendons through sites (a fixed tendon's Jacobian is constant).  Per straight
+// segment between sites on different bodies: dpnt = the unit direction, dvel = its time derivative;
+//   d/dt(ten_J) = (JacDot(p1) - JacDot(p0))' dpnt + (Jac(p1) - Jac(p0))' dvel      (both over the divisor of the pulley branch)
+// Every lane builds the two addends of the dofs it owns (mj_jacDot's / mj_jac's column, mju_mulMatTVec's row order with
+// its skip of zero components); the contraction with qvel follows the reference: one running sum over the merged dof
+// chain of the two bodies in ascending order, first term then second (sparse Jacobians), or mju_dot over all dofs (dense).
+// ------------------------------------------------------------------------------------------------
+template <class PB>
+MJH_DEV void tendon_bias(MREF M, BREF B, int e, PB bias) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nv = s.nv;
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr cdof_dot = MJH_F(B, cdof_dot, e);
+  crptr cvel = MJH_F(B, cvel, e);
+  crptr sx = MJH_F(B, site_xpos, e);
+  crptr com = MJH_F(B, subtree_com, e);
+  crptr tJ = MJH_F(B, ten_J, e);
+  rptr col = MJH_G(B, scratch, e) + 8*s.nefcmax;        // [2*nv]: the two addends per dof (scratch holds 8*nv there)
+  for (int t = 0; t < s.ntendon; t++) {
+    const real arm = M.tendon_armature_eff[t];
+    const int adr = M.tendon_adr[t], num = M.tendon_num[t];
+    if (!arm || M.wrap_type[adr] == 1) continue;          // (mjWRAP_JOINT: a fixed tendon has zero Jdot)
+    real res = 0, divisor = 1;
+    int j = 0;
+    while (j < num - 1) {
+      const int type0 = M.wrap_type[adr + j], type1 = M.wrap_type[adr + j + 1];
+      if (type0 == 2 || type1 == 2) {                     // mjWRAP_PULLEY
+        if (type0 == 2) divisor = M.wrap_prm[adr + j];
+        j++;
+        continue;
+      }
+      const int id0 = M.wrap_objid[adr + j], id1 = M.wrap_objid[adr + j + 1];
+      const int b0 = M.site_bodyid[id0], b1 = M.site_bodyid[id1];
+      if (b0 != b1) {
+        real p0[3], p1[3], v0[3], v1[3], off0[3], off1[3];
+        v3_copy(p0, sx + 3*id0);
+        v3_copy(p1, sx + 3*id1);
+        v3_sub(off0, p0, com + 3*M.body_rootid[b0]);
+        v3_sub(off1, p1, com + 3*M.body_rootid[b1]);
+        // mj_objectVelocity(site, flg_local = 0): linear part of mju_transformSpatial(cvel[body], site, subtree_com[root])
+        { real cr[3]; v3_cross(cr, off0, cvel + 6*b0); v3_sub(v0, cvel + 6*b0 + 3, cr); }
+        { real cr[3]; v3_cross(cr, off1, cvel + 6*b1); v3_sub(v1, cvel + 6*b1 + 3, cr); }
+        real dpnt[3], dvel[3];
+        v3_sub(dpnt, p1, p0);
+        const real norm = v3_normalize(dpnt);
+        v3_sub(dvel, v1, v0);
+        const real dt = dpnt[0]*dvel[0] + dpnt[1]*dvel[1] + dpnt[2]*dvel[2];
+        for (int r = 0; r < 3; r++) dvel[r] += dpnt[r]*(-dt);
+        const real sc = norm > MJH_MINVAL ? 1/norm : 0;
+        for (int r = 0; r < 3; r++) dvel[r] = dvel[r]*sc;
+        MJH_FOR_LANES(c, nv) {
+          const int in0 = (M.body_dofanc[b0*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+          const int in1 = (M.body_dofanc[b1*s.nvw + (c >> 5)] >> (c & 31)) & 1;
+          real a = 0, b = 0;
+          if (in0 || in1) {
+            crptr cd = cdof + 6*c;
+            real cdd[6];
+            for (int q = 0; q < 6; q++) cdd[q] = cdof_dot[6*c + q];
+            const int jt = M.dof_jnttype[c];
+            const int dadr = M.jnt_dofadr[M.dof_jntid[c]];
+            if (jt == MJH_JNT_BALL || (jt == MJH_JNT_FREE && c >= dadr + 3)) sp_cross_motion(cdd, cvel + 6*M.dof_bodyid[c], cd);
+            real jd0[3] = {0, 0, 0}, jd1[3] = {0, 0, 0}, j0[3] = {0, 0, 0}, j1[3] = {0, 0, 0}, t1[3], t2[3];
+            if (in0) {
+              v3_cross(t1, cdd, off0); v3_cross(t2, cd, v0);
+              for (int r = 0; r < 3; r++) jd0[r] += cdd[3 + r] + t1[r] + t2[r];
+              v3_cross(t1, cd, off0);
+              for (int r = 0; r < 3; r++) j0[r] = cd[3 + r] + t1[r];
+            }
+            if (in1) {
+              v3_cross(t1, cdd, off1); v3_cross(t2, cd, v1);
+              for (int r = 0; r < 3; r++) jd1[r] += cdd[3 + r] + t1[r] + t2[r];
+              v3_cross(t1, cd, off1);
+              for (int r = 0; r < 3; r++) j1[r] = cd[3 + r] + t1[r];
+            }
+            for (int r = 0; r < 3; r++) if (dpnt[r] != 0) a += (jd1[r] - jd0[r])*dpnt[r];
+            for (int r = 0; r < 3; r++) if (dvel[r] != 0) b += (j1[r] - j0[r])*dvel[r];
+          }
+          col[c] = a; col[nv + c] = b;
+        }
+        wv_sync();
+        if (s.sparse) {
+          const M128 both = m128_or(m128_ldw(M.body_dofanc + (size_t)b0*s.nvw, s.nvw), m128_ldw(M.body_dofanc + (size_t)b1*s.nvw, s.nvw));
+          for (int term = 0; term < 2; term++)
+            for (M128 um = both; m128_any(um); um = m128_drop_lowest(um)) {
+              const int c = m128_lowest(um);
+              res += (col[term*nv + c] / divisor) * qvel[c];
+            }
+        } else {
+          res += dot_ref(col, qvel, nv) / divisor;
+          res += dot_ref(col + nv, qvel, nv) / divisor;
+        }
+        wv_sync();
+      }
+      j++;
+    }
+    const real coef = arm * res;
+    if (coef != 0) {
+      const int radr = M.ten_J_rowadr[t], rnnz = M.ten_J_rownnz[t];
+      MJH_FOR_LANES(k, rnnz) bias[M.ten_J_colind[radr + k]] += coef * tJ[radr + k];
+    }
+    wv_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mj_rne(flg_acc=0) -> qfrc_bias                  (engine_core_smooth.c:2328-2389)
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void stage_rne(MREF M_, BREF B_, int e_) {
@@ -1377,6 +1547,7 @@ MJH_DEVN void stage_rne(MREF M_, BREF B_, int e_) {
   tree_accumulate_to_parent(M, cfrc, 6, 0);
   MJH_FOR_LANES(i, s.nv) bias[i] = sp_dot6(cdof + 6*i, cfrc + 6*M.dof_bodyid[i]);
   wv_sync();
+  if (MJH_HAS(MJH_FT_TENDONSPATIAL) && MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_ten_armature) tendon_bias(M, B, e, bias);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1480,11 +1651,39 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
     real bias = 0.0;
     if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_biastype[i] == MJH_BIAS_AFFINE) bias = bp[0] + bp[1]*len[i] + bp[2]*vel[i];
     f += bias;
+    // (a disabled actuator keeps its act_dot -- mj_advance ignores it -- and produces no force: engine_forward.c:617)
+    if (MJH_HAS(MJH_FT_GAINBIAS) && M.o.has_act_disabled && M.actuator_disabled[i]) f = 0;     // (its force stays 0; the clamp below still sees it)
+    if (MJH_HAS(MJH_FT_GAINBIAS) && M.o.has_ten_actfrc) { force[i] = f; continue; }      // (clamped after the tendon totals, below)
     if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_forcelimited[i])
       f = r_clip(f, M.actuator_forcerange[2*i], M.actuator_forcerange[2*i+1]);
     force[i] = f;
   }
   wv_sync();
+  if (MJH_HAS(MJH_FT_GAINBIAS) && M.o.has_ten_actfrc) {
+    // total actuator force per limited tendon (in actuator order), then every actuator on a tendon whose total leaves the
+    // range is scaled by range / total (engine_forward.c:880-915); the per-actuator force clamp comes after that
+    MJH_FOR_LANES(i, s.nu) {
+      real f = force[i];
+      if (M.actuator_trntype[i] == MJH_TRN_TENDON) {
+        const int t = M.actuator_trnid[2*i];
+        if (M.tendon_actfrclimited[t]) {
+          real total = 0;
+          for (int k = 0; k < s.nu; k++)
+            if (M.actuator_trntype[k] == MJH_TRN_TENDON && M.actuator_trnid[2*k] == t) total += force[k];
+          if (total) {
+            if (total < M.tendon_actfrcrange[2*t]) f *= M.tendon_actfrcrange[2*t] / total;
+            else if (total > M.tendon_actfrcrange[2*t + 1]) f *= M.tendon_actfrcrange[2*t + 1] / total;
+          }
+        }
+      }
+      if (M.actuator_forcelimited[i])
+        f = r_clip(f, M.actuator_forcerange[2*i], M.actuator_forcerange[2*i+1]);
+      MJH_G(B, scratch, e)[i] = f;
+    }
+    wv_sync();
+    MJH_FOR_LANES(i, s.nu) force[i] = MJH_G(B, scratch, e)[i];
+    wv_sync();
+  }
 
   // qfrc_actuator = moment' * force, rows added in actuator order (mju_mulMatTVecSparse)
   crptr mom = MJH_F(B, actuator_moment, e);
@@ -1603,7 +1802,9 @@ MJH_DEV void advance_act(MREF M, BREF B, int e, P0 act_dot) {
   MJH_FOR_LANES(i, s.nu) {
     if (M.actuator_dyntype[i] == MJH_DYN_NONE) continue;
     const int aa = M.actuator_actadr[i];
-    act[aa] = next_activation(M, i, act[aa], act_dot[aa]);
+    // (a disabled actuator's activation advances with act_dot = 0: mj_advance, engine_forward.c:1321)
+    const real ad = (MJH_HAS(MJH_FT_GAINBIAS) && M.o.has_act_disabled && M.actuator_disabled[i]) ? (real)0 : (real)act_dot[aa];
+    act[aa] = next_activation(M, i, act[aa], ad);
   }
 }
 

@@ -97,6 +97,9 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // LT >= 0: the chain length L = nefc/4 is a compile-time constant (the caller dispatches on it): the
 // chain of a row update is then straight-line code -- no scalar branch per chain step, the DPP moves
 // of a row scheduled ahead of the dependent adds.
+#ifndef MJH_PGS_PREFETCH2
+#define MJH_PGS_PREFETCH2 1
+#endif
 template <int ARL, int LT = -1, int NT = -1>
 MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
   const auto& M = wv_uniform_ref(M_);
@@ -213,11 +216,21 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
     real improvement = 0;
     int i = wv_bcast_i(ord, 0);
     real a = own ? ar_load(i) : 0;                   // row of the first visited constraint
+#if MJH_PGS_PREFETCH2
+    // (AR in global memory: TWO rows ahead -- a visit of a short row is shorter than an L2 round trip, and a lone
+    //  straggler has no other wavefront to hide it behind)
+    int i1 = wv_bcast_i(ord, 1 < nk ? 1 : 0);
+    real a1 = (!ARL && own) ? ar_load(i1) : 0;
+#endif
     for (int bi = 0; bi < nk; bi++) {
       const real p = a*f;
       // prefetch the next row while this one is reduced (issued after the product so that the
       // wait for the current row does not also drain this load)
+#if MJH_PGS_PREFETCH2
+      int inext = ARL ? wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi) : wv_bcast_i(ord, bi + 2 < nk ? bi + 2 : nk - 1);
+#else
       int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
+#endif
 #if !defined(MJH_HOSTSIM)
       asm volatile("" : "+s"(inext) : "v"(p));      // orders the prefetch after the product
 #endif
@@ -255,8 +268,13 @@ MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {
       const int li = wv_bcast_i(ordlane, bi);          // owner lane of constraint i
       if (lane == li) f = fn;
       improvement -= wv_bcast(change, li);
+#if MJH_PGS_PREFETCH2
+      if (ARL) { i = inext; a = anext; }
+      else { i = i1; a = a1; i1 = inext; a1 = anext; }
+#else
       i = inext;
       a = anext;
+#endif
     }
     improvement *= scale;
 
@@ -407,11 +425,25 @@ MJH_DEVN_HOT void solve_pgs_resid(MREF M_, BREF B_, int e_) {
       // is contiguous across the lanes), two interleaved partial sums
       real r = bj;
       {
+        // (eight rows of AR in flight at a time: out of LDS the loads return in order at ds latency, out of global memory
+        //  -- AR beyond the LDS plan's room, nefc above ~27 at 4096 environments -- one load per multiply-add would wait a
+        //  full L2 round trip each)
         real r1 = 0;
         int k = 0;
+        for (; k + 8 <= n; k += 8) {
+          real av[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) av[q] = ar_load(k + q);
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            r = __builtin_fma(av[q], wv_bcast(f, k + q), r);
+            r1 = __builtin_fma(av[q + 1], wv_bcast(f, k + q + 1), r1);
+          }
+        }
         for (; k + 1 < n; k += 2) {
-          r = __builtin_fma(ar_load(k), wv_bcast(f, k), r);
-          r1 = __builtin_fma(ar_load(k + 1), wv_bcast(f, k + 1), r1);
+          const real a0 = ar_load(k), a1 = ar_load(k + 1);
+          r = __builtin_fma(a0, wv_bcast(f, k), r);
+          r1 = __builtin_fma(a1, wv_bcast(f, k + 1), r1);
         }
         if (k < n) r = __builtin_fma(ar_load(k), wv_bcast(f, k), r);
         r += r1;
@@ -419,31 +451,52 @@ MJH_DEVN_HOT void solve_pgs_resid(MREF M_, BREF B_, int e_) {
 
       // ---- one sweep
       real improvement = 0;
-      int i = wv_bcast_i(ord, 0);
-      real a = ar_load(i);                   // row of the first visited constraint (lanes without a constraint read column 0: unused)
-      for (int bi = 0; bi < nk; bi++) {
-        const int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
-        const real anext = ar_load(inext);   // the coming row, in flight while this one is applied
-        // every lane evaluates the update of its own constraint from its residual; the visited row's owner's counts
+      // a visit: every lane evaluates the update of its own constraint from its residual; the visited row's owner's
+      // counts.  The residuals move on with the owner's delta at once; the cost guard (costChange, :216-237) is evaluated
+      // beside that and, where it rejects the update (change > 1e-10: rare), the step is taken back.
+      auto visit = [&](int i, real a) {
         const real res = r;
         real fn = f - res*ainv;
         fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
         const real delta = fn - f;
-        // the residuals move on with the owner's delta at once; the cost guard (costChange, :216-237) is evaluated beside
-        // that and, where it rejects the update (change > 1e-10: rare), the step is taken back
         const real d = wv_bcast(delta, i);
         const real rn = __builtin_fma(a, d, r);
         const real change = 0.5*delta*delta*A + delta*res;
         const real ch = wv_bcast(change, i);
-        if (ch > 1e-10) {
-          // rejected: force and residuals stay
-        } else {
+        if (!(ch > 1e-10)) {
           r = rn;
           if (lane == i) f = fn;
           improvement -= ch;
         }
-        i = inext;
-        a = anext;
+      };
+      if (ARL) {
+        // AR in LDS: the coming row is read while this one is applied
+        int i = wv_bcast_i(ord, 0);
+        real a = ar_load(i);
+        for (int bi = 0; bi < nk; bi++) {
+          const int inext = wv_bcast_i(ord, bi + 1 < nk ? bi + 1 : bi);
+          const real anext = ar_load(inext);
+          visit(i, a);
+          i = inext;
+          a = anext;
+        }
+      } else {
+        // AR in global memory: the visiting order is known, so the rows of the NEXT four visits are requested before the
+        // current four are applied (a visit is ~170 cycles, an L2 round trip several times that)
+        int i0 = wv_bcast_i(ord, 0), i1 = wv_bcast_i(ord, 1 < nk ? 1 : 0), i2 = wv_bcast_i(ord, 2 < nk ? 2 : 0), i3 = wv_bcast_i(ord, 3 < nk ? 3 : 0);
+        real a0 = ar_load(i0), a1 = ar_load(i1), a2 = ar_load(i2), a3 = ar_load(i3);
+        for (int bi = 0; bi < nk; bi += 4) {
+          const int last = nk - 1;
+          const int j0 = wv_bcast_i(ord, bi + 4 < nk ? bi + 4 : last), j1 = wv_bcast_i(ord, bi + 5 < nk ? bi + 5 : last),
+                    j2 = wv_bcast_i(ord, bi + 6 < nk ? bi + 6 : last), j3 = wv_bcast_i(ord, bi + 7 < nk ? bi + 7 : last);
+          const real n0 = ar_load(j0), n1 = ar_load(j1), n2 = ar_load(j2), n3 = ar_load(j3);
+          visit(i0, a0);
+          if (bi + 1 < nk) visit(i1, a1);
+          if (bi + 2 < nk) visit(i2, a2);
+          if (bi + 3 < nk) visit(i3, a3);
+          i0 = j0; i1 = j1; i2 = j2; i3 = j3;
+          a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        }
       }
       improvement *= scale;
 

@@ -411,6 +411,7 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
     real q = 0;
     if (act_on) {
       for (int a = 0; a < s.nu; a++) {
+        if (M.o.has_act_disabled && M.actuator_disabled[a]) continue;      // (mjd_actuator_vel skips disabled actuators, :2365)
         // the gain multiplies ctrl, or the (next, if actearly) activation (:2475-2490)
         real u = ctrl[a];
         if (M.actuator_dyntype[a] != MJH_DYN_NONE) {

@@ -95,6 +95,8 @@
   X(actuator_actadr, s.nu)                     \
   X(actuator_actlimited, s.nu)                 \
   X(actuator_actearly, s.nu)                   \
+  X(actuator_disabled, s.nu)  /* mj_actuatorDisabled: the actuator's group is in opt.disableactuator */ \
+  X(tendon_actfrclimited, s.ntendon)           \
   X(actuator_momentadr, s.nu + 1)              \
   /* scalar joint transmissions by dof (ascending actuator ids): qfrc_actuator without the search over all rows */ \
   X(dof_act_adr, s.nv + 1)                     \
@@ -338,6 +340,7 @@
   X(site_size, 3 * s.nsite)                    \
   X(geom_surfacevel, 6 * s.ngeom)              \
   X(tendon_range, 2 * s.ntendon)               \
+  X(tendon_actfrcrange, 2 * s.ntendon)         \
   X(tendon_margin, s.ntendon)                  \
   X(tendon_solref_lim, 2 * s.ntendon)          \
   X(tendon_solimp_lim, 5 * s.ntendon)          \
@@ -521,6 +524,9 @@ struct DOptions {
   int disableflags, enableflags;
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_ten_armature;
+  int has_act_disabled;  // some actuator is disabled through its group (opt.disableactuator)
+  int has_ten_actfrc;    // some tendon limits the total force of the actuators acting on it
+  int has_tendon_wrap;   // some spatial tendon wraps around a sphere / cylinder: the tendon stage reads the geom frames
   int has_gravcomp;
   int has_surfacevel; // some geom has a surface velocity (conveyor belts)
   int has_fluid;      // opt.density / opt.viscosity set: inertia-box fluid forces

@@ -609,6 +609,64 @@ TENDON_XML = """
 """
 
 
+# tendons wrapping around a sphere and a cylinder (mju_wrap), with and without side sites, one side site INSIDE its sphere
+# (the inside wrap: Newton iteration on asin terms), a pulley branch whose second half wraps, springs / limits / an actuator
+WRAP_XML = """
+<mujoco>
+  <option timestep="0.002" solver="PGS" iterations="50"/>
+  <default><geom type="capsule" size=".02" contype="0" conaffinity="0"/><joint damping=".05"/></default>
+  <worldbody>
+    <site name="w0" pos="-.35 .02 .75"/><site name="w1" pos=".5 0 .9"/><site name="w2" pos="-.1 .3 .8"/>
+    <body pos="0 0 .6"><joint name="a" axis="0 1 0"/><joint name="a2" axis="1 0 0"/><geom fromto="0 0 0 .3 0 0"/>
+      <geom name="ws" type="sphere" size=".07" pos=".12 0 0"/><site name="ss" pos=".12 0 .09"/><site name="sin" pos=".13 .01 -.02"/>
+      <geom name="wc" type="cylinder" size=".05 .1" pos=".25 0 0" euler="90 10 0"/><site name="sc" pos=".25 0 -.08"/>
+      <body pos=".3 0 0"><joint name="b" axis="0 1 0"/><joint name="b2" axis="0 0 1"/><geom fromto="0 0 0 .25 0 0"/>
+        <site name="e1" pos=".2 .01 .03"/><site name="e2" pos=".1 -.02 -.03"/><site name="e3" pos=".22 0 -.02"/>
+        <geom name="ws2" type="sphere" size=".04" pos=".12 0 0"/></body></body>
+    <body pos=".6 .3 .7"><freejoint/><geom type="sphere" size=".05"/><site name="f" pos="0 0 .05"/></body>
+  </worldbody>
+  <tendon>
+    <spatial name="t_sphere" stiffness="30" damping=".3" springlength=".5"><site site="w0"/><geom geom="ws" sidesite="ss"/><site site="e1"/></spatial>
+    <spatial name="t_cyl" stiffness="20" range="0 .9" limited="true"><site site="w0"/><geom geom="wc" sidesite="sc"/><site site="e2"/></spatial>
+    <spatial name="t_noside" stiffness="25"><site site="w2"/><geom geom="ws2"/><site site="f"/></spatial>
+    <spatial name="t_inside" stiffness="15"><site site="w0"/><geom geom="ws" sidesite="sin"/><site site="e3"/></spatial>
+    <spatial name="t_pulley" stiffness="10"><site site="w1"/><site site="f"/><pulley divisor="2"/><site site="w1"/><geom geom="wc"/><site site="e1"/></spatial>
+  </tendon>
+  <actuator><motor joint="a" gear="2"/><motor joint="b" gear="1"/><motor tendon="t_sphere" gear="3"/><position tendon="t_cyl" kp="5"/></actuator>
+  <sensor><tendonpos tendon="t_sphere"/><tendonvel tendon="t_cyl"/><tendonpos tendon="t_inside"/></sensor>
+</mujoco>
+"""
+
+
+# actuator groups disabled through opt.disableactuator (mj_actuatorDisabled: no force, the activation frozen at integration
+# time) and tendons that limit the TOTAL force of the actuators acting on them (engine_forward.c:880-915), next to the
+# per-actuator force range
+ACT_GROUP_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="30" actuatorgroupdisable="1 3"/>
+  <default><geom type="capsule" size=".03" contype="0" conaffinity="0"/><joint damping=".2"/></default>
+  <worldbody>
+    <body pos="0 0 1"><joint name="j1" axis="0 1 0"/><geom fromto="0 0 0 .3 0 0"/><site name="s1" pos=".15 0 .05"/>
+      <body pos=".3 0 0"><joint name="j2" axis="0 1 0"/><geom fromto="0 0 0 .25 0 0"/><site name="s2" pos=".12 0 .05"/>
+        <body pos=".25 0 0"><joint name="j3" axis="0 0 1"/><geom fromto="0 0 0 .2 0 0"/><site name="s3" pos=".1 0 .05"/></body></body></body>
+  </worldbody>
+  <tendon>
+    <spatial name="sp" actuatorfrclimited="true" actuatorfrcrange="-.6 .4"><site site="s1"/><site site="s2"/><site site="s3"/></spatial>
+    <fixed name="fx" actuatorfrclimited="true" actuatorfrcrange="0 .5"><joint joint="j1" coef=".4"/><joint joint="j3" coef="-.7"/></fixed>
+    <fixed name="free"><joint joint="j2" coef="1"/></fixed>
+  </tendon>
+  <actuator>
+    <motor joint="j1" gear="2" group="0"/><position joint="j2" kp="8" kv=".3" group="1"/>
+    <intvelocity joint="j3" kp="6" actrange="-1 1" group="3"/><general joint="j1" dyntype="filter" dynprm=".05" gainprm="2" group="3" forcelimited="true" forcerange=".1 .3"/>
+    <general joint="j2" dyntype="integrator" gainprm="1.5" group="2" actlimited="true" actrange="-.5 .5"/>
+    <motor tendon="sp" gear="1"/><motor tendon="sp" gear="-.5" forcelimited="true" forcerange="-.2 .2"/><motor tendon="sp" gear="2" group="1"/>
+    <motor tendon="fx" gear="1.5"/><motor tendon="fx" gear="1"/><motor tendon="free" gear="1"/>
+  </actuator>
+  <sensor><tendonactuatorfrc tendon="sp"/><tendonactuatorfrc tendon="fx"/></sensor>
+</mujoco>
+"""
+
+
 # site transmissions without a reference site: Cartesian force / torque actuators (a thruster on a
 # free body, forces and torques at an arm's tip), one of them with filter dynamics
 SITE_ACT_XML = """

@@ -177,6 +177,63 @@ def test_nearly_touching_boxes_keep_their_contacts(rb, hostsim_lib, tmp_path):
     assert total > 0
 
 
+def _mixed_convex_rounds(rb, lib, tmp_path, nstate=12):
+    """single-contact convex pairs (sphere / capsule / ellipsoid against a mesh) in the SAME narrowphase round as polyhedral
+    pairs (mesh : mesh, box : mesh), the curved pairs first in the list so that they are owned by the low lanes: the
+    lane-parallel distance phase of the polyhedral pairs uses the record of the lane it runs on as scratch and must not
+    run after those lanes' contacts are finished (found by the model sweep on test/user/testdata/discardvisual.xml, where a
+    sphere : mesh pair read dist 1.2 instead of -0.199).  Contact lists identical to the oracle's over random poses."""
+    xml = tmp_path / "mixed.xml"
+    xml.write_text("""
+<mujoco>
+  <option gravity="0 0 0"/>
+  <asset><mesh name="tet" vertex="0 0 0  1 0 0  0 1 0  0 0 1"/></asset>
+  <worldbody>
+    <geom name="sp" type="sphere" size=".2" pos=".3 0 .4"/>
+    <geom name="cp" type="capsule" size=".1 .2" pos=".9 .1 -.3" euler="20 40 0"/>
+    <geom name="el" type="ellipsoid" size=".15 .1 .25" pos=".5 .5 -.2"/>
+    <body pos=".2 0 -.5"><geom name="m0" type="mesh" mesh="tet"/></body>
+    <body pos=".1 .2 -.6"><geom name="b0" type="box" size=".3 .3 .3"/></body>
+    <body pos=".3 0 -.5"><freejoint/><geom name="m1" type="mesh" mesh="tet"/></body>
+  </worldbody>
+</mujoco>""")
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(lib, m)
+    d = rb.MjData(m)
+    rng = np.random.default_rng(12)
+    states = []
+    for k in range(nstate):
+        rb.mj_resetData(m, d)
+        if k:
+            d.qpos[:3] += rng.normal(0, .08, 3)
+            q = np.array([1, 0, 0, 0.0]) + rng.normal(0, .15, 4)
+            d.qpos[3:7] = q/np.linalg.norm(q)
+        states.append(rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS))
+    S = np.array(states)
+    b = K.Batch(dm, len(states))
+    b.set("qpos", S[:, 1:1 + m.nq]); b.set("qvel", S[:, 1 + m.nq:])
+    b.forward()
+    cnt, cd, cg = b.get("counts"), b.get("con_dist"), b.get("con_geom")
+    curved = poly = 0
+    worst = 0.0
+    for e, s in enumerate(states):
+        rb.mj_setState(m, d, s, rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        assert cnt[e, 0] == d.ncon, (e, cnt[e, 0], d.ncon)
+        c = d.contact[:d.ncon]
+        assert np.array_equal(cg[e][:2*d.ncon], np.asarray(c["geom"]).ravel())
+        worst = max(worst, float(np.max(np.abs(cd[e][:d.ncon] - c["dist"]))) if d.ncon else 0.0)
+        curved += int(np.sum(np.asarray(c["geom"])[:, 0] < 3))
+        poly += int(np.sum(np.asarray(c["geom"])[:, 0] >= 3))
+    return worst, curved, poly
+
+
+def test_curved_pairs_next_to_polyhedral_pairs_bit_exact(rb, hostsim_lib, tmp_path):
+    worst, curved, poly = _mixed_convex_rounds(rb, hostsim_lib, tmp_path)
+    assert curved >= 12 and poly >= 12
+    assert worst == 0.0
+
+
 def test_cube_steps_in_soa_layout_and_without_lds_plan(hostsim_lib):
     """the convex narrowphase's row workspaces live in the LDS-planned field `ccd_row` -- or, when the plan has no room
     for it (small budgets) or the batch is laid out SoA-across-environments (its fields are strided, a row workspace is

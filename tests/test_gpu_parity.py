@@ -555,6 +555,36 @@ def test_spatial_tendons_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     assert relerr(out, ref) <= TOL
 
 
+@pytest.mark.parametrize("jacobian,integrator", [(0, 0), (1, 1), (1, 3)])
+def test_tendon_armature_vs_live_oracle(rb, hip_lib, tmp_path, jacobian, integrator):
+    """tendon armature on spatial / pulley / fixed tendons and as an actuator's armature: inertia term, bias force with the
+    time derivative of the tendon Jacobian (tests/test_hostsim_parity.py::test_tendon_armature_bit_exact is the bit-exact
+    statement; the device evaluates its own sin / cos in the kinematics)"""
+    import test_hostsim_parity as th
+    out, ref, eM, eb = th._tendon_armature(rb, hip_lib, tmp_path, jacobian, integrator)
+    print("tendon armature: rel err", relerr(out, ref), "M", eM, "bias", eb)
+    assert relerr(out, ref) <= TOL and eM <= 1e-12 and eb <= 1e-9
+
+
+@pytest.mark.parametrize("integrator", [0, 3])
+def test_tendon_wrapping_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """tendons wrapping around spheres / cylinders (mjh_math.h: mjh_wrap) on the device, where acos / asin go through
+    mjh_atan2: trajectory within the 1e-6 bar of the reference as built, lengths and moments to rounding"""
+    import test_hostsim_parity as th
+    out, ref, eL, eJ, nwrap = th._tendon_wrap(rb, hip_lib, tmp_path, integrator)
+    print("tendon wrapping: rel err", relerr(out, ref), "length", eL, "moment", eJ, "wrap points", nwrap)
+    assert nwrap > 10 and relerr(out, ref) <= TOL and eL <= 1e-12 and eJ <= 1e-10
+
+
+@pytest.mark.parametrize("integrator", [0, 3])
+def test_disabled_actuator_groups_and_tendon_force_limits_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """opt.disableactuator groups (no force, frozen activation) and tendon-level limits on the total actuator force"""
+    import test_hostsim_parity as th
+    out, ref, eF, clamped = th._actuator_groups(rb, hip_lib, tmp_path, integrator)
+    print("actuator groups / tendon force limits: rel err", relerr(out, ref), "force", eF, "steps at a limit", clamped)
+    assert clamped >= 2 and relerr(out, ref) <= TOL and eF <= 1e-10
+
+
 @pytest.mark.parametrize("scene", ["SITE_ACT_XML", "BALL_ACT_XML"])
 def test_cartesian_and_ball_actuators_vs_live_oracle(rb, hip_lib, tmp_path, scene):
     """site transmissions and actuators on ball / free joints, implicitfast (their moments enter qDeriv)"""

@@ -74,8 +74,9 @@ def replay(lib, stem, tmp_path, lds=0, dm=False):
             b.set("mocap_pos", fx["mocap_pos"][None]); b.set("mocap_quat", fx["mocap_quat"][None])
         if fx["ctrl0"].size:
             b.set("ctrl", fx["ctrl0"][None])
-        sfx = "_dm" if dm and (var + ":ref_state_dm") in fx.files else ""
-        ref, ref_int, ref_sens = fx[var + ":ref_state" + sfx], fx[var + ":ref_counts" + sfx], fx[var + ":ref_sensordata" + sfx]
+        # (an array of the device-libm build is stored only where it differs from the reference as built)
+        pick = lambda k: fx[var + ":" + k + "_dm"] if dm and (var + ":" + k + "_dm") in fx.files else fx[var + ":" + k]
+        ref, ref_int, ref_sens = pick("ref_state"), pick("ref_counts"), pick("ref_sensordata")
         worst = worst_s = 0.0
         exact = True
         for t in range(ref.shape[0]):

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -774,6 +774,135 @@ def test_spatial_tendons(rb, hostsim_lib, tmp_path, solver, integrator, tol):
     assert relerr(b.get("ten_length")[0], np.array(d.ten_length)) <= 1e-12
     assert relerr(b.get("ten_J")[0][:m.nJten], np.array(d.ten_J)[:m.nJten]) <= 1e-12
     assert relerr(b.get("sensordata")[0], np.array(d.sensordata)) <= 1e-12
+
+def _tendon_armature(rb, lib, tmp_path, jacobian, integrator):
+    """tendon armature (mj_tendonArmature: M += armature ten_J' ten_J on M's pattern; mj_tendonBias with mj_tendonDot: the
+    time derivative of a spatial tendon's Jacobian through mj_jacDot; engine_core_smooth.c:1115-1260, :1845-1886,
+    :2606-2641) on spatial tendons incl. a pulley branch, on a fixed tendon, and as an actuator's armature on a tendon
+    transmission (mj_actuatorArmature); dense (mju_dot) and sparse (running sum over the merged chain) contractions"""
+    xml = tmp_path / "tendon_armature.xml"
+    text = TENDON_XML.replace('<spatial name="sp1"', '<spatial name="sp1" armature=".3"').replace(
+        '<spatial name="pul"', '<spatial name="pul" armature=".12"').replace('<fixed name="fx">', '<fixed name="fx" armature=".05">').replace(
+        '<motor tendon="pul" gear="2"/>', '<motor tendon="pul" gear="2" armature=".02"/>')
+    assert text.count("armature") == 4
+    xml.write_text(text)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.jacobian = jacobian
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(4).normal(0, .7, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 60
+    ctrl = np.random.default_rng(2).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    # the inertia matrix and the bias force after mj_forward at the last state
+    rb.mj_setState(m, d, ref[0, -1], rb.mjSTATE_FULLPHYSICS)
+    d.ctrl[:] = ctrl[0, -1]
+    rb.mj_forward(m, d)
+    b.forward()
+    return out, ref, relerr(b.get("M")[0][:m.nC], np.array(d.M)[:m.nC]), relerr(b.get("qfrc_bias")[0], np.array(d.qfrc_bias))
+
+
+@pytest.mark.parametrize("jacobian,integrator", [(0, 0), (1, 0), (0, 1), (1, 3)])
+def test_tendon_armature_bit_exact(rb, hostsim_lib, tmp_path, jacobian, integrator):
+    out, ref, eM, eb = _tendon_armature(rb, hostsim_lib, tmp_path, jacobian, integrator)
+    assert np.array_equal(out, ref)
+    assert eM == 0.0 and eb == 0.0
+
+
+def _tendon_wrap(rb, lib, tmp_path, integrator, T=150):
+    """tendons wrapping around spheres and cylinders (mju_wrap, engine_util_misc.c:36-413, inside mj_tendon,
+    engine_core_smooth.c:1024-1100): tangent points on the circle through the two sites, the side-site rule, the inside
+    wrap, the cylinder's height correction; lengths and moments, through a swinging motion that wraps and unwraps"""
+    xml = tmp_path / "wrap.xml"
+    xml.write_text(WRAP_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(7).normal(0, 1.5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    ctrl = np.random.default_rng(3).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    # lengths and moments along the reference trajectory: how many of the steps wrapped
+    nwrap, eL, eJ = 0, 0.0, 0.0
+    for t in range(0, T, 10):
+        rb.mj_setState(m, d, ref[0, t], rb.mjSTATE_FULLPHYSICS)
+        rb.mj_forward(m, d)
+        bb = K.Batch(dm, 1)
+        load = {"time": ref[0, t, :1], "qpos": ref[0, t, 1:1 + m.nq], "qvel": ref[0, t, 1 + m.nq:1 + m.nq + m.nv]}
+        for k, v in load.items():
+            bb.set(k, v[None])
+        bb.forward()
+        eL = max(eL, relerr(bb.get("ten_length")[0], np.array(d.ten_length)))
+        eJ = max(eJ, relerr(bb.get("ten_J")[0][:m.nJten], np.array(d.ten_J)[:m.nJten]))
+        nwrap += int(np.sum(np.array(d.wrap_obj)[:int(np.sum(np.array(d.ten_wrapnum)))] >= 0))
+        bb.close()
+    return out, ref, eL, eJ, nwrap
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_tendon_wrapping_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    out, ref, eL, eJ, nwrap = _tendon_wrap(rb, hostsim_lib, tmp_path, integrator)
+    assert nwrap > 10                       # wrap points were active on the sampled steps
+    assert eL == 0.0 and eJ == 0.0
+    assert np.array_equal(out, ref)
+
+
+def _actuator_groups(rb, lib, tmp_path, integrator, T=80):
+    """disabled actuator groups and tendon-level actuator force limits: forces after mj_forward, states and activations
+    over a rollout with controls that drive the tendon totals through both ends of their ranges"""
+    xml = tmp_path / "actgroups.xml"
+    xml.write_text(ACT_GROUP_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    assert m.opt.disableactuator == (1 << 1) | (1 << 3) and m.na == 3
+    dm = K.DeviceModel(lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(5).normal(0, .8, m.nv)
+    d.act[:] = [.2, -.1, .3]
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    ctrl = np.random.default_rng(6).uniform(-1.5, 1.5, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    eF, clamped = 0.0, 0
+    for t in range(0, T, 4):
+        rb.mj_setState(m, d, ref[0, t], rb.mjSTATE_FULLPHYSICS)
+        d.ctrl[:] = ctrl[0, t]
+        rb.mj_forward(m, d)
+        bb = K.Batch(dm, 1)
+        nq, nv = m.nq, m.nv
+        bb.set("time", ref[0, t, None, :1]); bb.set("qpos", ref[0, t, None, 1:1 + nq]); bb.set("qvel", ref[0, t, None, 1 + nq:1 + nq + nv])
+        bb.set("act", ref[0, t, None, 1 + nq + nv:1 + nq + nv + m.na]); bb.set("ctrl", ctrl[0, t][None])
+        bb.forward()
+        f = np.array(d.actuator_force)
+        eF = max(eF, relerr(bb.get("actuator_force")[0], f))
+        tot = f[5] + f[6] + f[7]
+        clamped += int(abs(tot - (-.6)) < 1e-12 or abs(tot - .4) < 1e-12)
+        assert f[1] == 0 and f[2] == 0 and f[7] == 0                   # the disabled groups
+        bb.close()
+    return out, ref, eF, clamped
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_disabled_actuator_groups_and_tendon_force_limits_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    out, ref, eF, clamped = _actuator_groups(rb, hostsim_lib, tmp_path, integrator)
+    assert clamped >= 2                      # the tendon total sat at a limit on some of the sampled steps
+    assert eF == 0.0
+    assert np.array_equal(out, ref)
+
 
 
 @pytest.mark.parametrize("integrator", [0, 1, 3])
