@@ -13,6 +13,7 @@
 #   tail             tools/tail_stats.py
 #   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
 #   flexab           tools/gpu_flex_ab.sh: flex bench, current build against the round-4 final tree (tools/variants/r04_tree)
+#   ablib:<variant.so>   tools/gpu_ab_lib.sh: shipped library against tools/variants/<variant.so>, three alternating pairs
 #   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
 # (the one-shot scripts of rounds 2-3 -- gpu_r2*.sh, gpu_r3[a-s].sh, gpu_flex*.sh -- were sequences of these steps;
 #  their outputs are quoted in profiles/r02* and profiles/r03*)
@@ -31,6 +32,7 @@ except Exception as exc:
 print("  value %.4g %s  ms/step %.4g  frac %.3g  parity_ok %s  kernel %s  line %d B" % (j["value"], j["unit"], j["ms_per_step"], j["roofline"]["frac"], j.get("parity_ok"), j["roofline"].get("kernel"), len(json.dumps(j))))
 cb = j.get("cpu_baseline") or {}
 print("  cpu_baseline %s (%s s, x%s) testspeed %s | testspeed_regime %s newton_regime %s api %s" % (cb.get("value"), cb.get("seconds"), cb.get("repeats"), cb.get("testspeed_value"), j.get("testspeed_regime_value"), j.get("newton_regime_value"), j.get("api_regime_value")))
+print("  pgs_residual %s (parity_ok %s, max rel err %s, niter differs on %s of %s steps) testspeed %s" % (j.get("pgs_residual_value"), j.get("pgs_residual_parity_ok"), j.get("pgs_residual_max_rel_err"), j.get("pgs_residual_iter_differs"), j.get("pgs_residual_steps"), j.get("pgs_residual_testspeed_regime_value")))
 for name in ("cube", "flex", "slider_crank"):
     if ("leg_%s_value" % name) in j or ("leg_%s_error" % name) in j:
         print("  leg %-12s value %s frac %s parity_ok %s cpu %s wall %s %s" % (name, j.get("leg_%s_value" % name), j.get("leg_%s_roofline_frac" % name), j.get("leg_%s_parity_ok" % name), j.get("leg_%s_cpu_like_for_like" % name), j.get("leg_%s_wall_s" % name), j.get("leg_%s_error" % name, "")))
@@ -77,6 +79,8 @@ for step in "$@"; do
       head -3 "$OUT/sweep_gpu_glibc/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu_glibc/sweep.txt" | grep -v rejected | head -20 ;;
     flexab)
       bash tools/gpu_flex_ab.sh "gpurun_out/$TAG/flex_ab" 2>&1 | tee "$OUT/flex_ab.txt" ;;
+    ablib)
+      bash tools/gpu_ab_lib.sh "gpurun_out/$TAG/ab_${rest%.so}" "tools/variants/$rest" 3 2>&1 | tee "$OUT/ab_${rest%.so}.txt" ;;
     resources)
       python tools/kernel_resources.py > "$OUT/kernel_resource_usage.txt" 2>&1; cat "$OUT/kernel_resource_usage.txt" ;;
     *) echo "unknown step $step" ;;
