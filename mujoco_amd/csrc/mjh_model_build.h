@@ -221,13 +221,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->actuator_outnum[i] != 1 || m->actuator_outadr[i] != i, "actuator output blocks other than one scalar");
     {
       const int dt = m->actuator_dyntype[i];
-      MJH_REJECT(dt != mjDYN_NONE && dt != mjDYN_INTEGRATOR && dt != mjDYN_FILTER && dt != mjDYN_FILTEREXACT,
-                 "actuator dynamics other than none/integrator/filter/filterexact (muscle, dcmotor, pid, user)");
+      MJH_REJECT(dt != mjDYN_NONE && dt != mjDYN_INTEGRATOR && dt != mjDYN_FILTER && dt != mjDYN_FILTEREXACT && dt != mjDYN_MUSCLE,
+                 "actuator dynamics other than none/integrator/filter/filterexact/muscle (dcmotor, pid, user)");
       MJH_REJECT(dt == mjDYN_NONE ? m->actuator_actnum[i] != 0 : m->actuator_actnum[i] != 1,
                  "actuators with more than one activation variable");
     }
-    MJH_REJECT(m->actuator_gaintype[i] != mjGAIN_FIXED && m->actuator_gaintype[i] != mjGAIN_AFFINE, "actuator gain types other than fixed/affine");
-    MJH_REJECT(m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE, "actuator bias types other than none/affine");
+    MJH_REJECT(m->actuator_gaintype[i] != mjGAIN_FIXED && m->actuator_gaintype[i] != mjGAIN_AFFINE && m->actuator_gaintype[i] != mjGAIN_MUSCLE,
+               "actuator gain types other than fixed/affine/muscle");
+    MJH_REJECT(m->actuator_biastype[i] != mjBIAS_NONE && m->actuator_biastype[i] != mjBIAS_AFFINE && m->actuator_biastype[i] != mjBIAS_MUSCLE,
+               "actuator bias types other than none/affine/muscle");
     MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
     MJH_REJECT(m->actuator_delay[i] != 0, "actuator delays");
     int tt = m->actuator_trntype[i];
@@ -449,6 +451,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->actuator_actrange, m->actuator_actrange, 2*m->nu);
   H->actuator_dyntau.resize(m->nu);
   for (int i = 0; i < m->nu; i++) H->actuator_dyntau[i] = m->actuator_dynprm[mjNDYN*i];
+  H->actuator_dynprm.resize(3*m->nu);
+  for (int i = 0; i < m->nu; i++) for (int k = 0; k < 3; k++) H->actuator_dynprm[3*i + k] = m->actuator_dynprm[mjNDYN*i + k];
+  copy_arr(H->actuator_lengthrange, m->actuator_lengthrange, 2*m->nu);
+  copy_arr(H->actuator_acc0, m->actuator_acc0, m->nu);
 
   copy_arr(H->qpos0, m->qpos0, m->nq);
   copy_arr(H->qpos_spring, m->qpos_spring, m->nq);

@@ -565,7 +565,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
   // free bodies need their frames for the gyroscopic derivative
   if (Bt->model->H.o.integrator == MJH_INT_IMPLICITFAST) {
     for (const char* f : {"xpos", "xmat", "xipos", "ximat", "ten_J", "ten_velocity", "actuator_moment",
-                          "moment_rownnz", "moment_colind", "actuator_force"})
+                          "moment_rownnz", "moment_colind", "actuator_force", "actuator_length", "actuator_velocity"})
       eqskip.push_back(f);
   }
   // sensors are evaluated after the solve and read kinematic / velocity / actuator / contact

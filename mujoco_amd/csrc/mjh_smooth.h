@@ -1586,6 +1586,76 @@ MJH_DEVN void stage_ten_act_velocity(MREF M_, BREF B_, int e_) {
 // ------------------------------------------------------------------------------------------------
 // mj_nextActivation                               (engine_support.c:706-775)
 // integrator / filter: Euler; filterexact: closed form; then the actrange clamp
+// muscle model (mju_muscleGainLength / mju_muscleGain / mju_muscleBias / mju_muscleDynamics, engine_util_misc.c:1049-1195;
+// mjd_muscleGain_vel, engine_derivative.c:969-1014): prm = (range[2], force, scale, lmin, lmax, vmax, fpmax, fvmax)
+MJH_DEV real muscle_gain_length(real length, real lmin, real lmax) {
+  if (lmin <= length && length <= lmax) {
+    const real a = 0.5*(lmin + 1), b = 0.5*(1 + lmax);
+    if (length <= a) { const real x = (length - lmin) / r_max(MJH_MINVAL, a - lmin); return 0.5*x*x; }
+    else if (length <= 1) { const real x = (1 - length) / r_max(MJH_MINVAL, 1 - a); return 1 - 0.5*x*x; }
+    else if (length <= b) { const real x = (length - 1) / r_max(MJH_MINVAL, b - 1); return 1 - 0.5*x*x; }
+    else { const real x = (lmax - length) / r_max(MJH_MINVAL, lmax - b); return 0.5*x*x; }
+  }
+  return 0.0;
+}
+// deriv = 0: the active force -force FL FV; 1: its derivative with respect to the actuator velocity
+template <class PP, class PR>
+MJH_DEV real muscle_gain(real len, real vel, PR lengthrange, real acc0, PP prm, int deriv) {
+  const real range0 = prm[0], range1 = prm[1];
+  real force = prm[2];
+  const real scale = prm[3], lmin = prm[4], lmax = prm[5], vmax = prm[6], fvmax = prm[8];
+  if (force < 0) force = scale / r_max(MJH_MINVAL, acc0);
+  const real L0 = (lengthrange[1] - lengthrange[0]) / r_max(MJH_MINVAL, range1 - range0);
+  const real L = range0 + (len - lengthrange[0]) / r_max(MJH_MINVAL, L0);
+  const real V = vel / r_max(MJH_MINVAL, L0*vmax);
+  const real FL = muscle_gain_length(L, lmin, lmax);
+  const real y = fvmax - 1;
+  if (deriv) {
+    real dFV;
+    if (V <= -1) dFV = 0;
+    else if (V <= 0) dFV = 2*V + 2;
+    else if (V <= y) dFV = (-2*V + 2*y) / r_max(MJH_MINVAL, y);
+    else dFV = 0;
+    return -force*FL*dFV/r_max(MJH_MINVAL, L0*vmax);
+  }
+  real FV;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V + 1)*(V + 1);
+  else if (V <= y) FV = fvmax - (y - V)*(y - V) / r_max(MJH_MINVAL, y);
+  else FV = fvmax;
+  return -force*FL*FV;
+}
+template <class PP, class PR>
+MJH_DEV real muscle_bias(real len, PR lengthrange, real acc0, PP prm) {
+  const real range0 = prm[0], range1 = prm[1];
+  real force = prm[2];
+  const real scale = prm[3], lmax = prm[5], fpmax = prm[7];
+  if (force < 0) force = scale / r_max(MJH_MINVAL, acc0);
+  const real L0 = (lengthrange[1] - lengthrange[0]) / r_max(MJH_MINVAL, range1 - range0);
+  const real L = range0 + (len - lengthrange[0]) / r_max(MJH_MINVAL, L0);
+  const real b = 0.5*(1 + lmax);
+  if (L <= 1) return 0;
+  else if (L <= b) { const real x = (L - 1) / r_max(MJH_MINVAL, b - 1); return -force*fpmax*0.5*x*x; }
+  else { const real x = (L - b) / r_max(MJH_MINVAL, b - 1); return -force*fpmax*(0.5 + x); }
+}
+template <class PP>
+MJH_DEV real muscle_dynamics(real ctrl, real act, PP prm) {
+  const real ctrlclamp = r_clip(ctrl, 0, 1), actclamp = r_clip(act, 0, 1);
+  const real tau_act = prm[0] * (0.5 + 1.5*actclamp);
+  const real tau_deact = prm[1] / (0.5 + 1.5*actclamp);
+  const real width = prm[2];
+  const real dctrl = ctrlclamp - act;
+  real tau;
+  if (width < MJH_MINVAL) tau = dctrl > 0 ? tau_act : tau_deact;
+  else {
+    // mju_sigmoid: 0 below 0, 1 above 1, 6x^5 - 15x^4 + 10x^3 between
+    const real x = dctrl/width + 0.5;
+    const real sg = x <= 0 ? (real)0 : (x >= 1 ? (real)1 : x*x*x * (3*x * (2*x - 5) + 10));
+    tau = tau_deact + (tau_act - tau_deact)*sg;
+  }
+  return dctrl / r_max(MJH_MINVAL, tau);
+}
+
 MJH_DEV real next_activation(MREF M, int a, real act, real act_dot) {
   if (M.actuator_dyntype[a] == MJH_DYN_FILTEREXACT) {
     const real tau = r_max(MJH_MINVAL, M.actuator_dyntau[a]);
@@ -1638,6 +1708,7 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
       const int aa = M.actuator_actadr[i];
       real ad;
       if (dyn == MJH_DYN_INTEGRATOR) ad = c;
+      else if (dyn == MJH_DYN_MUSCLE) ad = muscle_dynamics(c, act[aa], M.actuator_dynprm + 3*i);
       else ad = (c - act[aa]) / r_max(MJH_MINVAL, M.actuator_dyntau[i]);
       act_dot[aa] = ad;
       c = M.actuator_actearly[i] ? next_activation(M, i, act[aa], ad) : (real)act[aa];
@@ -1646,10 +1717,12 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
     auto bp = M.actuator_biasprm + 10*i;
     real gain;
     if (!MJH_HAS(MJH_FT_GAINBIAS) || M.actuator_gaintype[i] == MJH_GAIN_FIXED) gain = gp[0];
+    else if (M.actuator_gaintype[i] == MJH_GAIN_MUSCLE) gain = muscle_gain(len[i], vel[i], M.actuator_lengthrange + 2*i, M.actuator_acc0[i], gp, 0);
     else gain = gp[0] + gp[1]*len[i] + gp[2]*vel[i];
     real f = gain * c;
     real bias = 0.0;
     if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_biastype[i] == MJH_BIAS_AFFINE) bias = bp[0] + bp[1]*len[i] + bp[2]*vel[i];
+    else if (MJH_HAS(MJH_FT_GAINBIAS) && M.actuator_biastype[i] == MJH_BIAS_MUSCLE) bias = muscle_bias(len[i], M.actuator_lengthrange + 2*i, M.actuator_acc0[i], bp);
     f += bias;
     // (a disabled actuator keeps its act_dot -- mj_advance ignores it -- and produces no force: engine_forward.c:617)
     if (MJH_HAS(MJH_FT_GAINBIAS) && M.o.has_act_disabled && M.actuator_disabled[i]) f = 0;     // (its force stays 0; the clamp below still sees it)

@@ -363,13 +363,15 @@ MJH_DEV void free_bias_blocks(real mass, const real* R, const real* Xi, const re
 
 // velocity derivative of one actuator's force, 0 when it does not contribute
 // (mjd_actuator_vel, engine_derivative.c:2350-2490: affine gain/bias, stateless actuators)
-MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl_or_act) {
+MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl_or_act, real len, real vel) {
   if (M.actuator_forcelimited[a]) {
     if (force <= M.actuator_forcerange[2*a] || force >= M.actuator_forcerange[2*a+1]) return 0;
   }
   real bias_vel = 0, gain_vel = 0;
   if (M.actuator_biastype[a] == MJH_BIAS_AFFINE) bias_vel = M.actuator_biasprm[10*a + 2];
-  if (M.actuator_gaintype[a] != MJH_GAIN_FIXED) gain_vel = M.actuator_gainprm[10*a + 2];
+  if (M.actuator_gaintype[a] == MJH_GAIN_AFFINE) gain_vel = M.actuator_gainprm[10*a + 2];
+  else if (M.actuator_gaintype[a] == MJH_GAIN_MUSCLE)
+    gain_vel = muscle_gain(len, vel, M.actuator_lengthrange + 2*a, M.actuator_acc0[a], M.actuator_gainprm + 10*a, 1);
   if (gain_vel != 0) bias_vel += gain_vel * ctrl_or_act;
   return bias_vel;
 }
@@ -400,6 +402,8 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   crptr actd = MJH_F(B, act_dot, e);
   crptr tJ = MJH_F(B, ten_J, e);
   crptr tvel = MJH_F(B, ten_velocity, e);
+  crptr alen = MJH_F(B, actuator_length, e);
+  crptr avel = MJH_F(B, actuator_velocity, e);
   const int act_on = !(dsbl & (1<<11)) && s.nu > 0;
   const int passive_on = !((dsbl & (1<<5)) && (dsbl & (1<<6)));
   const int damper_on = passive_on && !(dsbl & (1<<6));
@@ -418,7 +422,7 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
           const int aa = M.actuator_actadr[a];
           u = M.actuator_actearly[a] ? next_activation(M, a, actv[aa], actd[aa]) : (real)actv[aa];
         }
-        real bv = actuator_vel_deriv(M, a, force[a], u);
+        real bv = actuator_vel_deriv(M, a, force[a], u, alen[a], avel[a]);
         if (bv == 0) continue;
         const int adr = M.actuator_momentadr[a];
         real mi = 0, mj = 0;

@@ -360,6 +360,9 @@
   X(actuator_forcerange, 2 * s.nu)             \
   X(actuator_actrange, 2 * s.nu)               \
   X(actuator_dyntau, s.nu)                     \
+  X(actuator_dynprm, 3 * s.nu)   /* muscle dynamics: tau_act, tau_deact, smoothing width */ \
+  X(actuator_lengthrange, 2 * s.nu)            \
+  X(actuator_acc0, s.nu)                       \
   X(actuator_gainprm, 10 * s.nu)               \
   X(actuator_biasprm, 10 * s.nu)               \
   X(actuator_cranklength, s.nu)                \
@@ -933,8 +936,8 @@ enum {
   MJH_WARN_BADQPOS = 3, MJH_WARN_BADQVEL = 4, MJH_WARN_BADQACC = 5, MJH_WARN_BADCTRL = 6,
   MJH_WARN_UNSUPPORTED = 7,   // mjhip-only: an env reached a feature the GPU path does not implement
   MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2, MJH_TRN_TENDON = 3, MJH_TRN_SITE = 4,
-  MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1,
-  MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1,
+  MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1, MJH_GAIN_MUSCLE = 2,
+  MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1, MJH_BIAS_MUSCLE = 2,
   // sensor kinds (host translation of mjtSensor) and frame-object kinds (mjtObj)
   MJH_SENS_JOINTPOS = 0, MJH_SENS_JOINTVEL, MJH_SENS_TENDONPOS, MJH_SENS_TENDONVEL, MJH_SENS_ACTUATORPOS,
   MJH_SENS_ACTUATORVEL, MJH_SENS_ACTUATORFRC, MJH_SENS_JOINTACTFRC, MJH_SENS_BALLQUAT, MJH_SENS_BALLANGVEL,
@@ -946,7 +949,7 @@ enum {
   MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
   MJH_SENS_CONTACT,
   MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4,
-  MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3,
+  MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3, MJH_DYN_MUSCLE = 4,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,
   // pair_func: which narrowphase routine a static pair uses

@@ -667,6 +667,34 @@ ACT_GROUP_XML = """
 """
 
 
+# muscle actuators (activation dynamics with two time constants, hard and smoothed switching; FLV gain; passive force) on a
+# wrapping tendon, a fixed tendon and a joint; peak force given directly and through scale / acc0
+MUSCLE_XML = """
+<mujoco>
+  <option timestep="0.002" solver="PGS" iterations="30"/>
+  <default><geom type="capsule" size=".02" contype="0" conaffinity="0"/><joint damping=".3" armature=".01"/></default>
+  <worldbody>
+    <site name="o1" pos="-.05 0 1.05"/><site name="o2" pos=".05 0 .95"/>
+    <body pos="0 0 1"><joint name="sh" axis="0 1 0" range="-60 80"/><geom fromto="0 0 0 .3 0 0"/>
+      <geom name="wrap" type="cylinder" size=".04 .05" pos="0 0 0" euler="90 0 0"/><site name="side" pos="0 0 .08"/>
+      <site name="i1" pos=".15 0 .03"/><site name="i2" pos=".2 0 -.03"/>
+      <body pos=".3 0 0"><joint name="el" axis="0 1 0" range="0 120"/><geom fromto="0 0 0 .25 0 0"/><site name="i3" pos=".08 0 .03"/></body></body>
+  </worldbody>
+  <tendon>
+    <spatial name="flex"><site site="o1"/><geom geom="wrap" sidesite="side"/><site site="i1"/></spatial>
+    <spatial name="ext"><site site="o2"/><site site="i2"/><site site="i3"/></spatial>
+    <fixed name="fx"><joint joint="el" coef=".05"/><joint joint="sh" coef="-.02"/></fixed>
+  </tendon>
+  <actuator>
+    <muscle name="m_flex" tendon="flex" ctrllimited="true" ctrlrange="0 1" force="120"/>
+    <muscle name="m_ext" tendon="ext" ctrllimited="true" ctrlrange="0 1" scale="300" timeconst=".02 .06" tausmooth=".3" range=".7 1.1" lmin=".4" lmax="1.7" vmax="2" fpmax="1.5" fvmax="1.3"/>
+    <muscle name="m_fx" tendon="fx" ctrllimited="true" ctrlrange="0 1" force="40" tausmooth=".05"/>
+    <muscle name="m_jnt" joint="el" ctrllimited="true" ctrlrange="0 1" force="15" lengthrange="0 2"/>
+  </actuator>
+</mujoco>
+"""
+
+
 # site transmissions without a reference site: Cartesian force / torque actuators (a thruster on a
 # free body, forces and torques at an arm's tip), one of them with filter dynamics
 SITE_ACT_XML = """

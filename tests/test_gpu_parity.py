@@ -585,6 +585,15 @@ def test_disabled_actuator_groups_and_tendon_force_limits_vs_live_oracle(rb, hip
     assert clamped >= 2 and relerr(out, ref) <= TOL and eF <= 1e-10
 
 
+@pytest.mark.parametrize("integrator", [0, 3])
+def test_muscle_actuators_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """muscle dynamics / gain / bias on wrapping and fixed tendons and on a joint (arm26.xml's actuators)"""
+    import test_hostsim_parity as th
+    out, ref, eF, fmax = th._muscles(rb, hip_lib, tmp_path, integrator)
+    print("muscles: rel err", relerr(out, ref), "force / act_dot", eF, "largest force", fmax)
+    assert fmax > 5.0 and relerr(out, ref) <= TOL and eF <= 1e-9
+
+
 @pytest.mark.parametrize("scene", ["SITE_ACT_XML", "BALL_ACT_XML"])
 def test_cartesian_and_ball_actuators_vs_live_oracle(rb, hip_lib, tmp_path, scene):
     """site transmissions and actuators on ball / free joints, implicitfast (their moments enter qDeriv)"""

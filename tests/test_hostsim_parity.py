@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -900,6 +900,52 @@ def _actuator_groups(rb, lib, tmp_path, integrator, T=80):
 def test_disabled_actuator_groups_and_tendon_force_limits_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     out, ref, eF, clamped = _actuator_groups(rb, hostsim_lib, tmp_path, integrator)
     assert clamped >= 2                      # the tendon total sat at a limit on some of the sampled steps
+    assert eF == 0.0
+    assert np.array_equal(out, ref)
+
+
+def _muscles(rb, lib, tmp_path, integrator, T=120):
+    """muscle actuators (mju_muscleDynamics / mju_muscleGain / mju_muscleBias, engine_util_misc.c:1049-1195; the gain's
+    velocity derivative in the implicitfast integrator, engine_derivative.c:969): activations, forces, states"""
+    xml = tmp_path / "muscle.xml"
+    xml.write_text(MUSCLE_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    assert m.na == 4
+    dm = K.DeviceModel(lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qpos[:] = [.3, .8]
+    d.qvel[:] = [1.5, -2.0]
+    d.act[:] = [.1, .6, .9, .3]
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    rng = np.random.default_rng(9)
+    ctrl = np.clip(np.repeat(rng.uniform(-.3, 1.3, (1, T//10, m.nu)), 10, axis=1), None, None)     # excitation steps of 10 samples
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    eF, fmax = 0.0, 0.0
+    nq, nv = m.nq, m.nv
+    for t in range(0, T, 6):
+        rb.mj_setState(m, d, ref[0, t], rb.mjSTATE_FULLPHYSICS)
+        d.ctrl[:] = ctrl[0, t]
+        rb.mj_forward(m, d)
+        bb = K.Batch(dm, 1)
+        bb.set("time", ref[0, t, None, :1]); bb.set("qpos", ref[0, t, None, 1:1 + nq]); bb.set("qvel", ref[0, t, None, 1 + nq:1 + nq + nv])
+        bb.set("act", ref[0, t, None, 1 + nq + nv:1 + nq + nv + m.na]); bb.set("ctrl", ctrl[0, t][None])
+        bb.forward()
+        f = np.array(d.actuator_force)
+        eF = max(eF, relerr(bb.get("actuator_force")[0], f), relerr(bb.get("act_dot")[0], np.array(d.act_dot)))
+        fmax = max(fmax, float(np.abs(f).max()))
+        bb.close()
+    return out, ref, eF, fmax
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 3])
+def test_muscle_actuators_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    out, ref, eF, fmax = _muscles(rb, hostsim_lib, tmp_path, integrator)
+    assert fmax > 5.0
     assert eF == 0.0
     assert np.array_equal(out, ref)
 

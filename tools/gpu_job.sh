@@ -10,6 +10,8 @@
 #   profile:<args>   tools/gpu_profile.sh <tag>_<n> <args>: bench + rocprofv3 kernel stats + PMC FETCH/WRITE passes
 #   stages:<MODEL>   per-stage profile (tools/stage_profile.py on tools/variants/libmjhip_prof.so)
 #   sq:<config>      SQ instruction counters of the rollout kernel (tools/gpu_sq.sh)
+#   settled          per-stage profile of the humanoid in its settled regime (1000 warm-up steps), exact and residual PGS
+#   regime           tools/regime_stats.py (testspeed regime: per-environment cost against the constraint count), both sweeps
 #   tail             tools/tail_stats.py
 #   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
 #   flexab           tools/gpu_flex_ab.sh: flex bench, current build against the round-4 final tree (tools/variants/r04_tree)
@@ -65,6 +67,15 @@ for step in "$@"; do
     stages)
       MODEL=${rest:-humanoid} MJHIP_LIB=$PWD/tools/variants/libmjhip_prof.so timeout 900 python tools/stage_profile.py > "$OUT/stage_profile_${rest:-humanoid}.txt" 2>&1
       head -40 "$OUT/stage_profile_${rest:-humanoid}.txt" ;;
+    settled)
+      # the humanoid after 1000 steps of random actions (lying on the floor: nefc ~ 40+), exact and residual PGS sweeps
+      W=1000 K=100 MODEL=humanoid MJHIP_LIB=$PWD/tools/variants/libmjhip_prof.so timeout 900 python tools/stage_profile.py > "$OUT/stage_profile_humanoid_settled.txt" 2>&1
+      head -32 "$OUT/stage_profile_humanoid_settled.txt"
+      MJHIP_PGS=residual W=1000 K=100 MODEL=humanoid MJHIP_LIB=$PWD/tools/variants/libmjhip_prof.so timeout 900 python tools/stage_profile.py > "$OUT/stage_profile_humanoid_settled_pgs_residual.txt" 2>&1
+      head -32 "$OUT/stage_profile_humanoid_settled_pgs_residual.txt" ;;
+    regime)
+      timeout 900 python tools/regime_stats.py > "$OUT/regime_stats.txt" 2>&1; tail -14 "$OUT/regime_stats.txt"
+      MJHIP_PGS=residual timeout 900 python tools/regime_stats.py > "$OUT/regime_stats_pgs_residual.txt" 2>&1; tail -14 "$OUT/regime_stats_pgs_residual.txt" ;;
     sq)
       bash tools/gpu_sq.sh ${TAG}_${rest:-humanoid} ${rest:-humanoid} uniform > "$OUT/sq_${rest:-humanoid}.log" 2>&1; tail -5 "$OUT/sq_${rest:-humanoid}.log"
       cp gpurun_out/sq_${TAG}_${rest:-humanoid}/sq_summary.txt "$OUT/sq_summary_${rest:-humanoid}.txt" 2>/dev/null ;;

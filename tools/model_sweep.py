@@ -150,7 +150,15 @@ def run_one(lib, path, steps, lds, changes, progress=None, record=None):
         if rb.available("devmath"):
             prev = rb.use("devmath")
             try:
-                m2 = load_model(path)
+                # (the SAME compiled model: saved by the build that compiled it and re-loaded here -- compiling the XML
+                #  again under this build would round the model's own constants, e.g. quaternions of euler angles, with
+                #  the other libm, and a pile of boxes amplifies that last bit to centimetres in 15 steps: planks.xml)
+                import tempfile
+                with tempfile.NamedTemporaryFile(suffix=".mjb") as tmpf:
+                    prev2 = rb.use(prev)
+                    m.save_binary(tmpf.name)
+                    rb.use(prev2)
+                    m2 = rb.MjModel.from_binary_path(tmpf.name)
                 for k, v in changes.items():
                     setattr(m2.opt, k, v)
                 d2 = rb.MjData(m2)
