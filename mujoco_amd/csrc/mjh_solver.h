@@ -530,6 +530,147 @@ MJH_DEVN_HOT void solve_pgs_resid(MREF M_, BREF B_, int e_) {
   wv_sync();
 }
 
+// The residual-update sweep for 64 < nefc <= 128: two constraints per lane (row lane in slot 0, row lane + 64 in slot 1),
+// AR in global memory (> 32 KB), the rows of the next four visits requested ahead.  One island (the caller falls back
+// otherwise, like solve_pgs_wide).  Opt-in with the routine above: in the settled humanoid regime the handful of
+// environments beyond 64 rows end every launch (tools/regime_stats.py: 126 ms against a mean of 99 ms per 100 steps).
+MJH_DEVN_HOT void solve_pgs_resid_wide(MREF M_, BREF B_, int e_) {
+  const auto& M = wv_uniform_ref(M_);
+  BREF B = B_;
+  const int e = wv_uniform_i(e_);
+  iptr counts = MJH_F(B, counts, e);
+  const int n = wv_uniform_i(counts[MJH_C_NEFC]), ne = wv_uniform_i(counts[MJH_C_NE]), nf = wv_uniform_i(counts[MJH_C_NF]);
+  Efc P;
+  efc_layout(M, B, e, n, P);
+  const int lane = wv_lane();
+  const int j0 = lane, own1 = lane + MJH_W < n, j1 = own1 ? lane + MJH_W : 0;
+  auto kind_of = [&](int j) -> int { return (j < ne) ? 0 : (j < ne + nf ? 1 : 2); };
+  const int kind0 = kind_of(j0), kind1 = kind_of(j1);
+  real f0 = P.force[j0], f1 = own1 ? (real)P.force[j1] : 0;
+  const real b0 = P.b[j0], b1 = own1 ? (real)P.b[j1] : 0;
+  const real fl0 = P.floss[j0], fl1 = own1 ? (real)P.floss[j1] : 0;
+  auto ar0 = [&](int r) -> real { return P.AR[(size_t)r*n + j0]; };
+  auto ar1 = [&](int r) -> real { return P.AR[(size_t)r*n + j1]; };
+  const real ainv0 = 1 / ar0(j0), ainv1 = 1 / (own1 ? ar1(j1) : (real)1);
+  const real A0 = 1/ainv0, A1 = 1/ainv1;
+  const real pinf = __builtin_huge_val();
+  const real blo0 = kind0 == 1 ? -fl0 : (kind0 == 2 ? 0.0 : -pinf), bhi0 = kind0 == 1 ? fl0 : pinf;
+  const real blo1 = kind1 == 1 ? -fl1 : (kind1 == 2 ? 0.0 : -pinf), bhi1 = kind1 == 1 ? fl1 : pinf;
+  const int maxiter = M.o.iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const auto* otab = wv_uniform_ptr(M.pgs_order) + wv_uniform_ptr(M.pgs_order_adr)[n];
+  real fprev0 = f0, fmom0 = f0, fprev1 = f1, fmom1 = f1;
+  int iter = 0, nesterov_k = 0;
+  int ordn0 = otab[lane], ordn1 = own1 ? otab[MJH_W + lane] : 0;
+  auto order_at = [&](int o0, int o1, int b) -> int { return b < MJH_W ? wv_bcast_i(o0, b) : wv_bcast_i(o1, b - MJH_W); };
+  while (iter < maxiter) {
+    const int ord0 = ordn0, ord1 = ordn1;
+    if (iter + 1 < maxiter) {
+      ordn0 = otab[(iter + 1)*n + lane];
+      ordn1 = own1 ? otab[(iter + 1)*n + MJH_W + lane] : 0;
+    }
+    // ---- Nesterov extrapolation (:508-554)
+    real beta = 0;
+    if (iter > 0) beta = (real)(nesterov_k - 1) / (real)(nesterov_k + 2);
+    if (beta > 0) {
+      {
+        const real fs = f0;
+        real fx = fs + beta*(fs - fprev0);
+        fprev0 = fs;
+        if (kind0 == 1) fx = r_clip(fx, -fl0, fl0);
+        else if (kind0 == 2 && fx < 0) fx = 0;
+        f0 = fx; fmom0 = fx;
+      }
+      if (own1) {
+        const real fs = f1;
+        real fx = fs + beta*(fs - fprev1);
+        fprev1 = fs;
+        if (kind1 == 1) fx = r_clip(fx, -fl1, fl1);
+        else if (kind1 == 2 && fx < 0) fx = 0;
+        f1 = fx; fmom1 = fx;
+      }
+    } else {
+      fprev0 = f0; fmom0 = f0;
+      fprev1 = f1; fmom1 = f1;
+    }
+    // ---- residuals afresh: r_j = b_j + sum_k AR[k][j] f_k, four rows of AR in flight
+    real r0 = b0, r1 = b1;
+    for (int k = 0; k < n; k += 4) {
+      real a0v[4], a1v[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const int kk = k + q < n ? k + q : n - 1; a0v[q] = ar0(kk); a1v[q] = ar1(kk); }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if (k + q < n) {
+          const int kk = k + q;
+          const real fk = kk < MJH_W ? wv_bcast(f0, kk) : wv_bcast(f1, kk - MJH_W);
+          r0 = __builtin_fma(a0v[q], fk, r0);
+          r1 = __builtin_fma(a1v[q], fk, r1);
+        }
+      }
+    }
+    // ---- one sweep
+    real improvement = 0;
+    auto visit = [&](int i, real a0, real a1) {
+      const int s = i >= MJH_W, src = i & (MJH_W - 1);
+      const real res = s ? r1 : r0, fc = s ? f1 : f0, ainv = s ? ainv1 : ainv0, A = s ? A1 : A0;
+      const real blo = s ? blo1 : blo0, bhi = s ? bhi1 : bhi0;
+      real fn = fc - res*ainv;
+      fn = (fn < blo) ? blo : ((fn > bhi) ? bhi : fn);
+      const real delta = fn - fc;
+      const real d = wv_bcast(delta, src);
+      const real rn0 = __builtin_fma(a0, d, r0), rn1 = __builtin_fma(a1, d, r1);
+      const real change = 0.5*delta*delta*A + delta*res;
+      const real ch = wv_bcast(change, src);
+      if (!(ch > 1e-10)) {
+        r0 = rn0; r1 = rn1;
+        if (lane == src) { if (s) f1 = fn; else f0 = fn; }
+        improvement -= ch;
+      }
+    };
+    {
+      const int last = n - 1;
+      int i0 = order_at(ord0, ord1, 0), i1 = order_at(ord0, ord1, 1), i2 = order_at(ord0, ord1, 2), i3 = order_at(ord0, ord1, 3);
+      real p0 = ar0(i0), p1 = ar0(i1), p2 = ar0(i2), p3 = ar0(i3);
+      real q0 = ar1(i0), q1 = ar1(i1), q2 = ar1(i2), q3 = ar1(i3);
+      for (int bi = 0; bi < n; bi += 4) {
+        const int g0 = order_at(ord0, ord1, bi + 4 < n ? bi + 4 : last), g1 = order_at(ord0, ord1, bi + 5 < n ? bi + 5 : last),
+                  g2 = order_at(ord0, ord1, bi + 6 < n ? bi + 6 : last), g3 = order_at(ord0, ord1, bi + 7 < n ? bi + 7 : last);
+        const real np0 = ar0(g0), np1 = ar0(g1), np2 = ar0(g2), np3 = ar0(g3);
+        const real nq0 = ar1(g0), nq1 = ar1(g1), nq2 = ar1(g2), nq3 = ar1(g3);
+        visit(i0, p0, q0);
+        if (bi + 1 < n) visit(i1, p1, q1);
+        if (bi + 2 < n) visit(i2, p2, q2);
+        if (bi + 3 < n) visit(i3, p3, q3);
+        i0 = g0; i1 = g1; i2 = g2; i3 = g3;
+        p0 = np0; p1 = np1; p2 = np2; p3 = np3;
+        q0 = nq0; q1 = nq1; q2 = nq2; q3 = nq3;
+      }
+    }
+    improvement *= scale;
+    // ---- gradient restart (:694-713)
+    int restart = 0;
+    if (iter > 0) {
+      real ce = (f0 - fmom0) * (fmom0 - fprev0) + (own1 ? (f1 - fmom1) * (fmom1 - fprev1) : (real)0);
+      for (int m = 1; m < MJH_W; m <<= 1) ce += wv_shfl_xor(ce, m);
+      restart = (wv_bcast(ce, 0) < 0);
+    }
+    if (restart) nesterov_k = 0; else nesterov_k++;
+    iter++;
+    if (improvement < M.o.tolerance) break;
+  }
+  auto final_state = [&](int kind, real f, real fl) -> int {
+    if (kind == 0) return MJH_STATE_QUADRATIC;
+    if (kind == 1) return f <= -fl ? MJH_STATE_LINEARPOS : (f >= fl ? MJH_STATE_LINEARNEG : MJH_STATE_QUADRATIC);
+    return f <= 0 ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+  };
+  P.state[j0] = final_state(kind0, f0, fl0);
+  P.force[j0] = f0;
+  if (own1) { P.state[j1] = final_state(kind1, f1, fl1); P.force[j1] = f1; }
+  if (lane == 0) counts[MJH_C_NITER] = iter;
+  wv_sync();
+}
+
 // ------------------------------------------------------------------------------------------------
 // solPGS for 64 < nefc <= 128, iterate in registers, TWO constraints per lane.
 //
@@ -622,9 +763,18 @@ MJH_DEVN_HOT void solve_pgs_wide(MREF M_, BREF B_, int e_) {
     real improvement = 0;
     int i = wv_bcast_i(ord0, 0);
     real a0 = ar(i, j0), a1 = own1 ? ar(i, jj1) : 0;
+#if MJH_PGS_PREFETCH2
+    // (two rows ahead, as in solve_pgs_fast's global-memory case: these environments are the ones a launch waits for)
+    int ix = wv_bcast_i(ord0, 1);
+    real ax0 = ar(ix, j0), ax1 = own1 ? ar(ix, jj1) : 0;
+#endif
     for (int bi = 0; bi < n; bi++) {
       const real p0 = a0*f0, p1 = a1*f1;
+#if MJH_PGS_PREFETCH2
+      const int bn = bi + 2 < n ? bi + 2 : n - 1;
+#else
       const int bn = bi + 1 < n ? bi + 1 : bi;
+#endif
       int inext = bn < 64 ? wv_bcast_i(ord0, bn) : wv_bcast_i(ord1, bn - 64);
 #if !defined(MJH_HOSTSIM)
       asm volatile("" : "+s"(inext) : "v"(p0), "v"(p1));      // orders the prefetch after the products
@@ -654,8 +804,13 @@ MJH_DEVN_HOT void solve_pgs_wide(MREF M_, BREF B_, int e_) {
       if (change > 1e-10) { fn = oldf; change = 0; }
       if (lane == li) { if (si) f1 = fn; else f0 = fn; }
       improvement -= wv_bcast(change, li);
+#if MJH_PGS_PREFETCH2
+      i = ix; a0 = ax0; a1 = ax1;
+      ix = inext; ax0 = an0; ax1 = an1;
+#else
       i = inext;
       a0 = an0; a1 = an1;
+#endif
     }
     improvement *= scale;
 
@@ -1370,7 +1525,8 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
 #if !MJH_LANE_MODE && MJH_W == 64
   if (nefc > 64 && nefc <= 128 && nefc <= M.s.pgs_nmax && M.o.iterations <= M.s.pgs_iters && counts[MJH_C_NISLAND] <= 1 &&
       (!MJH_HAS(MJH_FT_ELLIPTIC) || M.o.cone == 0)) {
-    solve_pgs_wide(M, B, e);
+    if (B.pgs_mode == 1) solve_pgs_resid_wide(M, B, e);      // (opt-in: the residual-update sweep, tolerance parity)
+    else solve_pgs_wide(M, B, e);
   } else
 #endif
 #if !MJH_LANE_MODE && MJH_W == 64

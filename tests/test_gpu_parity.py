@@ -981,6 +981,17 @@ def test_pgs_residual_mode_tolerance_parity_on_gpu(rb, hip_lib, dm, golden):
     assert relerr(out[:, :10], fx["state"][:, :10]) <= TOL
 
 
+def test_pgs_residual_mode_two_constraints_per_lane_on_gpu(rb, hip_lib, dm):
+    """the residual-update sweep beyond 64 rows (solve_pgs_resid_wide) on the device: tolerance parity"""
+    from parity_utils import pgs_residual_parity
+    m = humanoid_pgs_oracle(rb)
+    states, nefcs = many_constraint_states(rb, m, 16)
+    assert min(nefcs) > 64
+    worst_f, worst_q, worst_s, dn, nmax = pgs_residual_parity(rb, K, m, dm, states, T=4)
+    print("pgs residual wide: force", worst_f, "qacc", worst_q, "state", worst_s, "max |delta niter|", dn, "max nefc", nmax)
+    assert nmax > 64 and worst_s <= TOL and worst_q <= 1e-6
+
+
 def test_broadphase_and_midphase_counts_exact_on_gpu(rb, hip_lib, tmp_path):
     """the reproduced sweep-and-prune / BVH culls on the GPU: exactly touching spheres (contact
     counts equal to the reference's in every scene) and a pile of multi-geom bodies that takes the

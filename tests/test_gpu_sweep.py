@@ -96,6 +96,11 @@ def replay(lib, stem, tmp_path, lds=0, dm=False):
 def _assert_ok(stem, short, results):
     assert results, f"{short}: no variation in the fixture"
     for var, err, err_s, exact, warn, ref_warn in results:
+        if ref_warn > 0:
+            # the reference itself gave up on this variation (planks.xml forced to PGS: 1360 rows, its arena cannot hold
+            # efc_AR -- mjWARN_CNSTRFULL); what follows a warning is not a trajectory to reproduce: mjhip has to warn too
+            assert warn > 0, f"{short} [{var}]: the reference raises a warning, mjhip does not"
+            continue
         assert err <= 1e-6, f"{short} [{var}]: state deviates by {err:.2e}"
         assert err_s <= 1e-6, f"{short} [{var}]: sensordata deviates by {err_s:.2e}"
         assert exact, f"{short} [{var}]: contact / constraint counts differ"

@@ -217,6 +217,17 @@ def test_pgs_residual_mode_tolerance_parity(rb, setup, golden):
     assert np.array_equal(b.rollout_host(T, K.mjSTATE_CTRL, fx["state0"][:n], None, fx["ctrl"][:n, :T]), fx["state"][:n, :T])
 
 
+def test_pgs_residual_mode_two_constraints_per_lane(rb, setup):
+    """the residual-update sweep beyond 64 rows (solve_pgs_resid_wide: the settled humanoid's stragglers): tolerance parity"""
+    from parity_utils import pgs_residual_parity
+    m, dm = setup
+    states, nefcs = many_constraint_states(rb, m, 6)
+    assert min(nefcs) > 64
+    worst_f, worst_q, worst_s, dn, nmax = pgs_residual_parity(rb, K, m, dm, states, T=3)
+    print("pgs residual wide: force", worst_f, "qacc", worst_q, "state", worst_s, "max |delta niter|", dn, "max nefc", nmax)
+    assert nmax > 64 and worst_s <= 1e-6 and worst_q <= 1e-6
+
+
 def test_generic_pgs_path_bit_exact(rb, hostsim_lib, golden):
     """opt.iterations above the precomputed visitation-order table (128) takes the generic PGS sweep
     (LDS/HBM-resident iterate, in-kernel PCG32 shuffle) instead of the register-resident one"""
