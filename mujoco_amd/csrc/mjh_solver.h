@@ -97,8 +97,12 @@ MJH_DEV uint32_t pcg32_next(Pcg32* rng) {
 // LT >= 0: the chain length L = nefc/4 is a compile-time constant (the caller dispatches on it): the
 // chain of a row update is then straight-line code -- no scalar branch per chain step, the DPP moves
 // of a row scheduled ahead of the dependent adds.
+// MJH_PGS_PREFETCH2 = 1: the exact sweeps request AR rows TWO visits ahead when AR sits in global memory (solve_pgs_fast<0>,
+// solve_pgs_wide).  Measured and NOT the default (profiles/r06/negative_results.txt): three alternating pairs on one box, the
+// humanoid's testspeed regime 2.83 M with it against 2.88 M without (-2 %), the driver configuration unchanged within noise --
+// a visit is already longer than an L2 round trip at four wavefronts per SIMD, and the extra live row costs registers.
 #ifndef MJH_PGS_PREFETCH2
-#define MJH_PGS_PREFETCH2 1
+#define MJH_PGS_PREFETCH2 0
 #endif
 template <int ARL, int LT = -1, int NT = -1>
 MJH_DEVN_HOT void solve_pgs_fast(MREF M_, BREF B_, int e_) {

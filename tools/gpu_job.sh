@@ -14,7 +14,7 @@
 #   regime           tools/regime_stats.py (testspeed regime: per-environment cost against the constraint count), both sweeps
 #   tail             tools/tail_stats.py
 #   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
-#   flexab           tools/gpu_flex_ab.sh: flex bench, current build against the round-4 final tree (tools/variants/r04_tree)
+#   flexab[:t1,t2]   tools/gpu_flex_ab.sh: flex bench, current build against earlier trees (tools/variants/<t>_tree; default r04)
 #   ablib:<variant.so>   tools/gpu_ab_lib.sh: shipped library against tools/variants/<variant.so>, three alternating pairs
 #   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
 # (the one-shot scripts of rounds 2-3 -- gpu_r2*.sh, gpu_r3[a-s].sh, gpu_flex*.sh -- were sequences of these steps;
@@ -89,7 +89,7 @@ for step in "$@"; do
       ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 1600 --oracle parity --out "$OUT/sweep_gpu_glibc" > "$OUT/sweep_gpu_glibc.log" 2>&1 ) 2>&1 | grep real
       head -3 "$OUT/sweep_gpu_glibc/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu_glibc/sweep.txt" | grep -v rejected | head -20 ;;
     flexab)
-      bash tools/gpu_flex_ab.sh "gpurun_out/$TAG/flex_ab" 2>&1 | tee "$OUT/flex_ab.txt" ;;
+      bash tools/gpu_flex_ab.sh "gpurun_out/$TAG/flex_ab" ${args:-r04} 2>&1 | tee "$OUT/flex_ab.txt" ;;
     ablib)
       bash tools/gpu_ab_lib.sh "gpurun_out/$TAG/ab_${rest%.so}" "tools/variants/$rest" 3 2>&1 | tee "$OUT/ab_${rest%.so}.txt" ;;
     resources)
