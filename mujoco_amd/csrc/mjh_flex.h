@@ -690,7 +690,8 @@ MJH_DEV void contact_sides(MREF M, BREF B, int e, int k, ConSides& S) {
 // weighted by the absolute vertex weights), the cell that holds it, the cell's nodes with basis value at least 1e-5, weights
 // signed like the side (mj_vertBodyWeight :265-384; nodes that share a body are merged within the side).  The other side
 // as in contact_sides.  Layout: con_nodeb[(nconside + 1) k] = number of entries, then the bodies; con_nodew: the weights.
-MJH_DEV void flex_contact_nodes(MREF M, BREF B, int e, int ncon) {
+MJH_DEVN_HOT void flex_contact_nodes(MREF M_, BREF B_, int e_, int ncon) {
+  MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   const int cap = s.nconside;
   MJH_FOR_LANES(k, ncon) {

@@ -58,7 +58,11 @@ MJH_DEV void interp_cell_lookup(MREF M, int f, const real* coord, real* local, i
 
 // node positions (body frame offset rotated into the world, or the body origin), then every vertex as the basis-weighted sum
 // of its cell's nodes in node order, starting from zero (mju_interpolate3D :672)
-MJH_DEV void flex_interp_pos(MREF M, BREF B, int e) {
+// (out of line, like flex_passive_interp and flex_contact_nodes: their 27-entry basis / index arrays otherwise sit in the
+//  frame of every kernel that inlines them -- round 6's bisect put 3 % of the jelly benchmark, a model without
+//  interpolated flexes, on the commit that added these routines: profiles/r06/flex_bisect.txt)
+MJH_DEVN_HOT void flex_interp_pos(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   crptr xpos = MJH_F(B, xpos, e);
   crptr xmat = MJH_F(B, xmat, e);
@@ -150,7 +154,8 @@ MJH_DEV void interp_rotvec(real* r, const real* v, const real* q) {
 // per ROW of the cell's stiffness matrix takes the two products K displ and K vel (mju_mulMatVec: a 4-accumulator dot per row);
 // per node one lane rotates the cells' forces back and adds them in the order the reference's cell loop scatters them, scales
 // the damper force and writes the node body's three dofs (xmat' f).
-MJH_DEV void flex_passive_interp(MREF M, BREF B, int e, int enbl_spring, int enbl_damper) {
+MJH_DEVN_HOT void flex_passive_interp(MREF M_, BREF B_, int e_, int enbl_spring, int enbl_damper) {
+  MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   if (!s.nflexcell) return;
   crptr xmat = MJH_F(B, xmat, e);

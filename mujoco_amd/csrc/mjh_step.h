@@ -734,7 +734,13 @@ MJH_DEV void rollout_env(MREF M_, BREF B_, int e, const RolloutArgs& A) {
 #endif
       if (prio_ref > 0) {
         const int wk = wv_uniform_i(cnt[MJH_C_NEFC]*(cnt[MJH_C_NITER] + 4));
-        int lvl = wk >= 6*prio_ref ? 3 : (wk >= 4*prio_ref ? 2 : (wk >= 2*prio_ref ? 1 : 0));
+        // (thresholds in quarters of the batch's mean work per step: 8 / 16 / 24 = 2x / 4x / 6x; -DMJH_PRIO_Q1.. for A/B builds)
+#ifndef MJH_PRIO_Q1
+#define MJH_PRIO_Q1 8
+#define MJH_PRIO_Q2 16
+#define MJH_PRIO_Q3 24
+#endif
+        int lvl = 4*wk >= MJH_PRIO_Q3*prio_ref ? 3 : (4*wk >= MJH_PRIO_Q2*prio_ref ? 2 : (4*wk >= MJH_PRIO_Q1*prio_ref ? 1 : 0));
 #if MJH_PRIO_MODE == 2
         lvl = lvl > prio_floor ? lvl : prio_floor;
 #endif
