@@ -807,8 +807,17 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     for (const FlexJob& j : flexjobs) {
       const int f = j.flex, b = j.body;
       // (a body with several geoms: its hierarchy's nodes, for the walk order -- see flex_collide_job)
+      // (needed only when at least TWO geoms of the body can emit (geom, element) pairs: for one geom the pairs come in the
+      //  flex hierarchy's own depth-first order whatever the body's hierarchy splits in between -- the children of a flex
+      //  node are pushed in a fixed order, :1196-1240 --, and planes never reach the walk's colliders (:1128).  A world body
+      //  that holds nothing but planes -- jelly.xml's walls -- must not make every step recompute the flex's hierarchy:
+      //  that cost the jelly benchmark 3 % in round 5, profiles/r06/flex_bisect.txt)
+      int nwalk = 0;
+      for (int g = m->body_geomadr[b]; g < m->body_geomadr[b] + m->body_geomnum[b]; g++)
+        if (m->geom_type[g] != mjGEOM_PLANE && m->geom_type[g] != mjGEOM_SDF &&
+            !filter_bitmask(m->geom_contype[g], m->geom_conaffinity[g], m->flex_contype[f], m->flex_conaffinity[f])) nwalk++;
       int treebase = -1;
-      if (midphase && m->body_bvhadr[b] >= 0 && m->body_bvhnum[b] > 1) {
+      if (midphase && m->body_bvhadr[b] >= 0 && m->body_bvhnum[b] > 1 && nwalk > 1) {
         treebase = (int)H->jobbvh_parent.size();
         const int adr = m->body_bvhadr[b], num = m->body_bvhnum[b];
         H->jobbvh_parent.resize(treebase + num, -1);
