@@ -209,7 +209,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   {
     const bool fluid = m->opt.density != 0 || m->opt.viscosity != 0;
     MJH_REJECT(!fluid && (m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0), "wind without a fluid medium");
-    MJH_REJECT(fluid && m->opt.integrator == mjINT_IMPLICITFAST, "fluid forces with the implicitfast integrator (their velocity derivative is not implemented)");
+
     if (fluid)
       for (int g = 0; g < m->ngeom; g++)
         MJH_REJECT(m->geom_fluid[mjNFLUID*g] > 0, "the ellipsoid fluid model (geom fluidshape)");

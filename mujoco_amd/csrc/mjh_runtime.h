@@ -567,6 +567,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
     for (const char* f : {"xpos", "xmat", "xipos", "ximat", "ten_J", "ten_velocity", "actuator_moment",
                           "moment_rownnz", "moment_colind", "actuator_force", "actuator_length", "actuator_velocity"})
       eqskip.push_back(f);
+    if (Bt->model->H.o.has_fluid) { eqskip.push_back("cdof"); eqskip.push_back("subtree_com"); }   // the fluid forces' velocity derivative
   }
   // sensors are evaluated after the solve and read kinematic / velocity / actuator / contact
   // quantities past their usual lifetimes: those fields stay in their global homes; the constraint

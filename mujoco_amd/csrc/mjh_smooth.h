@@ -1281,6 +1281,7 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
     rptr bf = MJH_G(B, fluid_frc, e);
     MJH_FOR_LANES(i, s.nbody) {
       real out[6] = {0, 0, 0, 0, 0, 0};
+      real coef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       const real mass = M.body_mass[i];
       if (!(mass < MJH_MINVAL)) {
         auto inertia = M.body_inertia + 3*i;
@@ -1328,8 +1329,26 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
         }
         m3_mulvec(out, ximat + 9*i, lfrc);
         m3_mulvec(out + 3, ximat + 9*i, lfrc + 3);
+        // d(lfrc) / d(lvel), one scalar per local axis (mjd_inertiaBoxFluid, engine_derivative.c:2953-3035): read by the
+        // implicit integrators at the end of the step (same qvel)
+        if (MJH_HAS(MJH_FT_IMPLICIT)) {
+          if (visc > 0) {
+            const real diam = (box[0] + box[1] + box[2])/3.0;
+            coef[0] = -MJH_PI*diam*diam*diam*visc;
+            coef[1] = -3.0*MJH_PI*diam*visc;
+          }
+          if (dens > 0) {
+            coef[2] = -dens*box[0]*(box[1]*box[1]*box[1]*box[1]+box[2]*box[2]*box[2]*box[2])*2*fabs(lvel[0])/64.0;
+            coef[3] = -dens*box[1]*(box[0]*box[0]*box[0]*box[0]+box[2]*box[2]*box[2]*box[2])*2*fabs(lvel[1])/64.0;
+            coef[4] = -dens*box[2]*(box[0]*box[0]*box[0]*box[0]+box[1]*box[1]*box[1]*box[1])*2*fabs(lvel[2])/64.0;
+            coef[5] = -0.5*dens*box[1]*box[2]*2*fabs(lvel[3]);
+            coef[6] = -0.5*dens*box[0]*box[2]*2*fabs(lvel[4]);
+            coef[7] = -0.5*dens*box[0]*box[1]*2*fabs(lvel[5]);
+          }
+        }
       }
       for (int k = 0; k < 6; k++) bf[6*i + k] = out[k];
+      if (MJH_HAS(MJH_FT_IMPLICIT)) for (int k = 0; k < 8; k++) bf[6*s.nbody + 8*i + k] = coef[k];
     }
     wv_sync();
     MJH_FOR_LANES(j, s.nv) {

@@ -407,6 +407,13 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
   const int act_on = !(dsbl & (1<<11)) && s.nu > 0;
   const int passive_on = !((dsbl & (1<<5)) && (dsbl & (1<<6)));
   const int damper_on = passive_on && !(dsbl & (1<<6));
+  const int fluid_on = MJH_HAS(MJH_FT_PASSIVEMISC) && passive_on && M.o.has_fluid && (M.o.viscosity > 0 || M.o.density > 0);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr com = MJH_F(B, subtree_com, e);
+  crptr xpos = MJH_F(B, xpos, e);
+  crptr xipos = MJH_F(B, xipos, e);
+  crptr xmat = MJH_F(B, xmat, e);
+  crptr ximat = MJH_F(B, ximat, e);
 
   // qDeriv(i, j) = d(qfrc_actuator + qfrc_passive)(i) / d(qvel)(j), accumulated in the reference's
   // order: actuators, dof damping, tendon damping  (mjd_actuator_vel, mjd_passive_vel; an entry of
@@ -432,6 +439,40 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
           if (mcol[adr + c] == j) { mj = mom[adr + c]; hj = 1; }
         }
         if (hi && hj) q += mj * (mi*bv);
+      }
+    }
+    // fluid forces, inertia-box model (mjd_passive_vel :3051-3072 -> mjd_inertiaBoxFluid :2884-3038): per body with mass, J'BJ
+    // of the body's COM Jacobian rotated into the inertial frame (mju_mulMatTMat: the three terms of a row in order, zero
+    // entries of ximat skipped), one scalar B per local axis -- viscous torque (rows 0-2), viscous force (3-5), then the
+    // quadratic drag on rows 0..5; the coefficients were left next to the fluid wrench by the passive stage
+    if (fluid_on) {
+      crptr bf = MJH_G(B, fluid_frc, e);
+      crptr cdi = cdof + 6*i, cdj = cdof + 6*j;
+      for (int b = 0; b < s.nbody; b++) {
+        if (M.body_mass[b] < MJH_MINVAL) continue;
+        if (!((M.body_dofanc[b*s.nvw + (i >> 5)] >> (i & 31)) & 1) || !((M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+        crptr cf = bf + 6*s.nbody + 8*b;
+        real off[3], ci[3], cj[3], Ji[6], Jj[6];
+        v3_sub(off, xipos + 3*b, com + 3*M.body_rootid[b]);
+        v3_cross(ci, cdi, off);
+        v3_cross(cj, cdj, off);
+        const real gi[6] = {cdi[0], cdi[1], cdi[2], cdi[3] + ci[0], cdi[4] + ci[1], cdi[5] + ci[2]};
+        const real gj[6] = {cdj[0], cdj[1], cdj[2], cdj[3] + cj[0], cdj[4] + cj[1], cdj[5] + cj[2]};
+        crptr xm = ximat + 9*b;
+        for (int r = 0; r < 3; r++) {
+          real ai = 0, aj = 0, li = 0, lj = 0;
+          for (int c = 0; c < 3; c++) {
+            const real t = xm[3*c + r];
+            if (t) { ai += gi[c]*t; aj += gj[c]*t; li += gi[3 + c]*t; lj += gj[3 + c]*t; }
+          }
+          Ji[r] = ai; Jj[r] = aj; Ji[3 + r] = li; Jj[3 + r] = lj;
+        }
+        if (M.o.viscosity > 0) {
+          for (int r = 0; r < 3; r++) if (cf[0]) q += Jj[r]*(Ji[r]*cf[0]);
+          for (int r = 3; r < 6; r++) if (cf[1]) q += Jj[r]*(Ji[r]*cf[1]);
+        }
+        if (M.o.density > 0)
+          for (int r = 0; r < 6; r++) if (cf[2 + r]) q += Jj[r]*(Ji[r]*cf[2 + r]);
       }
     }
     if (damper_on) {
@@ -485,10 +526,6 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
 
   // standalone free bodies: A = M_block - h*qDeriv_block + h*d(bias)/dv, LU with partial pivoting
   // (mjd_freeMhat engine_derivative.c:844-893, mju_factorLU6/solveLU6 engine_util_solve.c:857-931)
-  crptr xpos = MJH_F(B, xpos, e);
-  crptr xipos = MJH_F(B, xipos, e);
-  crptr xmat = MJH_F(B, xmat, e);
-  crptr ximat = MJH_F(B, ximat, e);
   MJH_FOR_LANES(jn, s.njnt) {
     if (!M.jnt_freebody[jn]) continue;
     const int b = M.jnt_bodyid[jn], adr = M.jnt_dofadr[jn];

@@ -586,7 +586,9 @@ enum {
   X(act, s.na, s.na, MJH_T_BEGIN, MJH_T_END)                                      \
   X(act_dot, s.na, s.na, MJH_T_ACTUATION, MJH_T_END)                              \
   X(mocap_pos, 3 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                             \
-  X(fluid_frc, 6 * s.nbody_fluid, 0, MJH_T_GLB, MJH_T_GLB)                        \
+  /* per body: the fluid wrench (6), then -- for the implicit integrators' velocity derivative, mjd_inertiaBoxFluid -- the       \
+     scalar coefficients B of its twelve J'BJ terms: viscous torque, viscous force, quadratic drag on the six local axes (8) */ \
+  X(fluid_frc, 14 * s.nbody_fluid, 0, MJH_T_GLB, MJH_T_GLB)                       \
   X(mocap_quat, 4 * s.nmocap, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(ctrl, s.nu, s.nu, MJH_T_BEGIN, MJH_T_END)                                     \
   X(qfrc_applied, s.nv, s.nv, MJH_T_BEGIN, MJH_T_END)                             \
