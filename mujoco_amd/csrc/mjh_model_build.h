@@ -195,8 +195,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->nsensor > 0 && m->nflex > 0, "sensors in models with flexes");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
   MJH_REJECT(m->flg_adhesion, "contact adhesion");
-  MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST,
-             "the fully implicit integrator (Euler, RK4 and implicitfast are implemented)");
+  MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST &&
+             m->opt.integrator != mjINT_IMPLICIT, "unknown integrator");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
   MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
   // mj_isSparse (engine_core_util.c:29): with jacobian=sparse, or auto and nv >= 60, the reference
@@ -332,6 +332,45 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     int adr = m->jnt_dofadr[j];
     if (m->tree_dofnum[m->dof_treeid[adr]] != 6 || m->body_subtreemass[b] != m->body_mass[b]) continue;
     H->jnt_freebody[j] = 1;
+  }
+  // the fully implicit integrator (round 6; mj_implicitSkip, engine_forward.c:1649-1770): the patterns of qDeriv and of
+  // mjd_rne_vel's body-by-dof work arrays
+  s.nD = 0; s.nB = 0;
+  H->D_rowadr.clear(); H->D_rownnz.clear(); H->D_diag.clear(); H->D_colind.clear(); H->D_rowid.clear(); H->D_mapM.clear();
+  H->B_rowadr.clear(); H->B_rownnz.clear(); H->B_ncopy.clear(); H->B_pmap.clear();
+  if (m->opt.integrator == mjINT_IMPLICIT && m->nv > 0) {
+    s.nD = m->nD; s.nB = m->nB;
+    copy_arr(H->D_rowadr, m->D_rowadr, m->nv);
+    copy_arr(H->D_rownnz, m->D_rownnz, m->nv);
+    copy_arr(H->D_diag, m->D_diag, m->nv);
+    copy_arr(H->D_colind, m->D_colind, m->nD);
+    copy_arr(H->D_mapM, m->mapM2D, m->nD);
+    H->D_rowid.assign(m->nD, 0);
+    for (int i = 0; i < m->nv; i++) {
+      for (int k = 0; k < m->D_rownnz[i]; k++) H->D_rowid[m->D_rowadr[i] + k] = i;
+      // (mjd_rne_vel: "Dcacc[row i] and Dcdofdot[row j] have identical sparsity", and the last pass subtracts a B row from a D row)
+      MJH_REJECT(m->D_rownnz[i] != m->B_rownnz[m->dof_bodyid[i]], "internal: qDeriv row and body row of different lengths");
+      MJH_REJECT(m->D_colind[m->D_rowadr[i] + m->D_diag[i]] != i, "internal: qDeriv diagonal index");
+    }
+    copy_arr(H->B_rowadr, m->B_rowadr, m->nbody);
+    copy_arr(H->B_rownnz, m->B_rownnz, m->nbody);
+    H->B_ncopy.assign(m->nbody, 0);
+    H->B_pmap.assign(m->nB, -1);
+    for (int n = 1; n < m->nbody; n++) {
+      const int np = m->body_parentid[n];
+      if (m->body_weldid[np] == 0) continue;
+      int ndof = 0;
+      for (int a = m->body_weldid[np]; a > 0; a = m->body_weldid[m->body_parentid[a]]) ndof += m->body_dofnum[a];
+      H->B_ncopy[n] = ndof;
+      MJH_REJECT(ndof > m->B_rownnz[n] || ndof > m->B_rownnz[np], "internal: body row shorter than its chain");
+      int ip = 0;
+      for (int i = 0; i < m->B_rownnz[n]; i++) {
+        const int c = m->B_colind[m->B_rowadr[n] + i];
+        while (ip < m->B_rownnz[np] && m->B_colind[m->B_rowadr[np] + ip] < c) ip++;
+        MJH_REJECT(ip >= m->B_rownnz[np] || m->B_colind[m->B_rowadr[np] + ip] != c, "internal: body row not a subset of its parent's");
+        H->B_pmap[m->B_rowadr[n] + i] = ip;
+      }
+    }
   }
   H->M_rowid.assign(m->nC, 0);
   for (int i = 0; i < m->nv; i++)
@@ -2175,7 +2214,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     if (m->opt.cone != mjCONE_PYRAMIDAL) ft |= MJH_FT_ELLIPTIC;
     if (m->neq > 0) ft |= MJH_FT_EQUALITY;
     if (m->opt.integrator == mjINT_RK4) ft |= MJH_FT_RK4;
-    if (m->opt.integrator == mjINT_IMPLICITFAST) ft |= MJH_FT_IMPLICIT;
+    if (m->opt.integrator == mjINT_IMPLICITFAST || m->opt.integrator == mjINT_IMPLICIT) ft |= MJH_FT_IMPLICIT;
     if (m->nsensor > 0) ft |= MJH_FT_SENSOR;
     for (int p = 0; p < s.npair; p++) {
       const int f = H->pair_func[p];

@@ -563,7 +563,9 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
     eqskip = {"xpos", "xquat", "xmat", "site_xpos", "cdof", "subtree_com", "cvel", "cdof_dot"};
   // implicitfast differentiates the actuator / damper forces at integration time, and standalone
   // free bodies need their frames for the gyroscopic derivative
-  if (Bt->model->H.o.integrator == MJH_INT_IMPLICITFAST) {
+  if (Bt->model->H.o.integrator == MJH_INT_IMPLICIT)          // (mjd_rne_vel at integration time)
+    for (const char* f : {"cdof", "cdof_dot", "cvel", "cinert", "subtree_com"}) eqskip.push_back(f);
+  if (Bt->model->H.o.integrator == MJH_INT_IMPLICITFAST || Bt->model->H.o.integrator == MJH_INT_IMPLICIT) {
     for (const char* f : {"xpos", "xmat", "xipos", "ximat", "ten_J", "ten_velocity", "actuator_moment",
                           "moment_rownnz", "moment_colind", "actuator_force", "actuator_length", "actuator_velocity"})
       eqskip.push_back(f);

@@ -306,7 +306,7 @@ MJH_DEV void forward_or_euler(MREF M, BREF B, int e, int stages) {
   if (stages & MJH_STAGE_CHECKACC) check_bad(M, B, e, MJH_F(B, qacc, e), M.s.nv, MJH_WARN_BADQACC);
   if (stages & MJH_STAGE_INTEGRATE) {
     // mj_step2: implicit integrators as configured, everything else (RK4 included) is Euler
-    if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) implicitfast_advance(M, B, e);
+    if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator >= MJH_INT_IMPLICIT) implicitfast_advance(M, B, e);
     else euler_advance(M, B, e);
   } else if (stages & MJH_STAGE_EULER) {
     euler_advance(M, B, e);
@@ -374,6 +374,250 @@ MJH_DEV real actuator_vel_deriv(MREF M, int a, real force, real ctrl_or_act, rea
     gain_vel = muscle_gain(len, vel, M.actuator_lengthrange + 2*a, M.actuator_acc0[a], M.actuator_gainprm + 10*a, 1);
   if (gain_vel != 0) bias_vel += gain_vel * ctrl_or_act;
   return bias_vel;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fully implicit integrator's solve (round 6).  mjd_smooth_vel with flg_bias (engine_derivative.c:3145-3166),
+// mjd_rne_vel / mjd_comVel_vel (:527-720), mju_factorLUSparse / mju_solveLUSparse (engine_util_solve.c:938-1060).
+//
+// Mapping.  qDeriv's actuator / passive part: one lane per entry of the pattern D (the evaluator implicitfast uses on
+// M's pattern).  The derivative of the bias force works on body-by-dof arrays of 6-vectors (pattern B: a body's row
+// holds the dofs of its chain, its own, its subtree's).  The two forward passes go level by level, one lane per body
+// of the level (a body reads its parent's row and writes its own and its dofs' rows); the backward accumulation of
+// Dcfrcbody takes the bodies in descending order, as the reference does -- several children add into one parent row --,
+// with the lanes over a row's components.  A 6 x 6 product of the reference (mju_mulMatMat with the transposed
+// derivative matrix) is, per row of the work array, "matrix times that 6-vector" summed in component order with the
+// vector's zero components skipped: mat6_apply.  The LU factorisation eliminates column by column from the last;
+// the rows that hold the pivot's column are independent: one lane per such row.  First landing: correctness and the
+// reference's rounding, not speed (a lane per body, global-memory work arrays).
+// ------------------------------------------------------------------------------------------------
+// out = A v with A row-major 6 x 6: out[c] = sum over k in order of A[c][k] v[k], terms with v[k] == 0 skipped
+MJH_DEV void mat6_apply(real* out, const real* A, const real* v) {
+  for (int c = 0; c < 6; c++) out[c] = 0;
+  for (int k = 0; k < 6; k++) {
+    const real t = v[k];
+    if (t) for (int c = 0; c < 6; c++) out[c] += A[6*c + k]*t;
+  }
+}
+// 3 x 3 block of D at (r0, c0): sgn [b]x, the matrix of the cross product b x . (sgn = -1: of . x b)
+MJH_DEV void mat6_skew(real* D, int r0, int c0, const real* b, real sgn) {
+  D[6*r0 + c0 + 1] = -sgn*b[2];       D[6*r0 + c0 + 2] = sgn*b[1];
+  D[6*(r0 + 1) + c0] = sgn*b[2];      D[6*(r0 + 1) + c0 + 2] = -sgn*b[0];
+  D[6*(r0 + 2) + c0] = -sgn*b[1];     D[6*(r0 + 2) + c0 + 1] = sgn*b[0];
+}
+// d crossMotion(vel, v) / d vel = [[-[v_ang]x, 0], [-[v_lin]x, -[v_ang]x]]     (mjd_crossMotion_vel)
+MJH_DEV void d_cross_motion_vel(real* D, const real* v) {
+  for (int k = 0; k < 36; k++) D[k] = 0;
+  mat6_skew(D, 0, 0, v, -1); mat6_skew(D, 3, 0, v + 3, -1); mat6_skew(D, 3, 3, v, -1);
+}
+// d crossForce(vel, f) / d vel = [[-[f_ang]x, -[f_lin]x], [-[f_lin]x, 0]]       (mjd_crossForce_vel)
+MJH_DEV void d_cross_force_vel(real* D, const real* f) {
+  for (int k = 0; k < 36; k++) D[k] = 0;
+  mat6_skew(D, 0, 0, f, -1); mat6_skew(D, 0, 3, f + 3, -1); mat6_skew(D, 3, 0, f + 3, -1);
+}
+// d crossForce(vel, f) / d f = [[[vel_ang]x, [vel_lin]x], [0, [vel_ang]x]]       (mjd_crossForce_frc)
+MJH_DEV void d_cross_force_frc(real* D, const real* vel) {
+  for (int k = 0; k < 36; k++) D[k] = 0;
+  mat6_skew(D, 0, 0, vel, 1); mat6_skew(D, 0, 3, vel + 3, 1); mat6_skew(D, 3, 3, vel, 1);
+}
+// the spatial inertia as a 6 x 6 matrix (mjd_mulInertVec_vel): [[I, [c]x], [-[c]x, m 1]] from the ten numbers of cinert
+MJH_DEV void d_mul_inert_vec(real* D, const real* ci) {
+  for (int k = 0; k < 36; k++) D[k] = 0;
+  D[0] = ci[0]; D[1] = ci[3]; D[2] = ci[4];
+  D[6] = ci[3]; D[7] = ci[1]; D[8] = ci[5];
+  D[12] = ci[4]; D[13] = ci[5]; D[14] = ci[2];
+  mat6_skew(D, 0, 3, ci + 6, 1); mat6_skew(D, 3, 0, ci + 6, -1);
+  D[21] = ci[9]; D[28] = ci[9]; D[35] = ci[9];
+}
+
+template <class QE>
+MJH_DEV void implicit_full_solve(MREF M, BREF B, int e, QE& qderiv_entry) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  const int nv = s.nv, nD = s.nD, nB = s.nB;
+  const real h = M.o.timestep;
+  rptr qD = MJH_G(B, qDeriv, e);
+  rptr qLU = MJH_G(B, qLU, e);
+  rptr Dd = MJH_G(B, Dcdofdot, e);
+  rptr Dv = MJH_G(B, Dcvel, e);
+  rptr Da = MJH_G(B, Dcacc, e);
+  rptr Df = MJH_G(B, Dcfrcbody, e);
+  crptr cdof = MJH_F(B, cdof, e);
+  crptr cdofdot = MJH_F(B, cdof_dot, e);
+  crptr cvel = MJH_F(B, cvel, e);
+  crptr cinert = MJH_F(B, cinert, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  crptr Mq = MJH_G(B, M, e);
+  rptr qe = MJH_F(B, qe, e);
+
+  // ---- qDeriv = d(qfrc_actuator + qfrc_passive) / d(qvel); work arrays cleared
+  MJH_FOR_LANES(k, nD) qD[k] = qderiv_entry((int)M.D_rowid[k], (int)M.D_colind[k]);
+  MJH_FOR_LANES(k, 6*nD) Dd[k] = 0;
+  MJH_FOR_LANES(k, 6*nB) { Dv[k] = 0; Da[k] = 0; Df[k] = 0; }
+  wv_sync();
+
+  // ---- mjd_comVel_vel: Dcvel (per body) and Dcdofdot (per dof), parents before children
+  for (int L = 1; L < s.nlevel; L++) {
+    const int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L + 1];
+    MJH_FOR_LANES(kb, a1 - a0) {
+      const int i = M.body_level_ids[a0 + kb];
+      const int bi = M.B_rowadr[i];
+      { const int nc = 6*M.B_ncopy[i], bp = M.B_rowadr[M.body_parentid[i]]; for (int t = 0; t < nc; t++) Dv[6*bi + t] = Dv[6*bp + t]; }
+      const int d0 = M.body_dofadr[i], d1 = d0 + M.body_dofnum[i];
+      for (int j = d0; j < d1; j++) {
+        int Jadr = M.D_diag[j];                    // (number of dof ancestors of dof j; M's own pattern drops the zero couplings of simple dofs)
+        const int jt = M.jnt_type[M.dof_jntid[j]];
+        real mat[36], v6[6], o6[6];
+        if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+          if (jt == MJH_JNT_FREE) {
+            for (int q = 0; q < 3; q++) for (int c = 0; c < 6; c++) Dv[6*(bi + Jadr + q) + c] += cdof[6*(j + q) + c];
+            j += 3; Jadr += 3;
+          }
+          for (int dj = 0; dj < 3; dj++) {
+            for (int c = 0; c < 6; c++) v6[c] = cdof[6*(j + dj) + c];
+            d_cross_motion_vel(mat, v6);
+            const int da = M.D_rowadr[j + dj];
+            for (int t = 0; t < Jadr + dj; t++) {
+              for (int c = 0; c < 6; c++) v6[c] = Dv[6*(bi + t) + c];
+              mat6_apply(o6, mat, v6);
+              for (int c = 0; c < 6; c++) Dd[6*(da + t) + c] = o6[c];
+            }
+          }
+          for (int q = 0; q < 3; q++) for (int c = 0; c < 6; c++) Dv[6*(bi + Jadr + q) + c] += cdof[6*(j + q) + c];
+          j += 2;
+        } else {
+          for (int c = 0; c < 6; c++) v6[c] = cdof[6*j + c];
+          d_cross_motion_vel(mat, v6);
+          const int da = M.D_rowadr[j];
+          for (int t = 0; t < Jadr; t++) {
+            for (int c = 0; c < 6; c++) v6[c] = Dv[6*(bi + t) + c];
+            mat6_apply(o6, mat, v6);
+            for (int c = 0; c < 6; c++) Dd[6*(da + t) + c] = o6[c];
+          }
+          for (int c = 0; c < 6; c++) Dv[6*(bi + Jadr) + c] += cdof[6*j + c];
+        }
+      }
+    }
+    wv_sync();
+  }
+
+  // ---- forward pass of mjd_rne_vel: Dcacc, then Dcfrcbody = D(cinert cacc + cvel x* (cinert cvel))
+  for (int L = 1; L < s.nlevel; L++) {
+    const int a0 = M.body_level_adr[L], a1 = M.body_level_adr[L + 1];
+    MJH_FOR_LANES(kb, a1 - a0) {
+      const int i = M.body_level_ids[a0 + kb];
+      const int bi = M.B_rowadr[i], bn = M.B_rownnz[i];
+      { const int nc = 6*M.B_ncopy[i], bp = M.B_rowadr[M.body_parentid[i]]; for (int t = 0; t < nc; t++) Da[6*bi + t] = Da[6*bp + t]; }
+      const int d0 = M.body_dofadr[i], d1 = d0 + M.body_dofnum[i];
+      for (int j = d0; j < d1; j++) {
+        const int Jadr = M.D_diag[j];
+        for (int c = 0; c < 6; c++) Da[6*(bi + Jadr) + c] += cdofdot[6*j + c];
+        const int da = M.D_rowadr[j];
+        const real qv = qvel[j];
+        for (int t = 0; t < 6*bn; t++) Da[6*bi + t] += Dd[6*da + t]*qv;
+      }
+      real dmul[36], mat[36], mat1[36], ci[10], cv[6], tmp[6], v6[6], o6[6];
+      for (int c = 0; c < 10; c++) ci[c] = cinert[10*i + c];
+      for (int c = 0; c < 6; c++) cv[c] = cvel[6*i + c];
+      d_mul_inert_vec(dmul, ci);
+      for (int t = 0; t < bn; t++) {
+        for (int c = 0; c < 6; c++) v6[c] = Da[6*(bi + t) + c];
+        mat6_apply(o6, dmul, v6);
+        for (int c = 0; c < 6; c++) Df[6*(bi + t) + c] = o6[c];
+      }
+      sp_mul_inert(tmp, ci, cv);
+      d_cross_force_vel(mat, tmp);
+      d_cross_force_frc(mat1, cv);
+      // mat += mat1 dmul  (mju_mulMatMat: row i of the product = sum over k of dmul's row k times mat1[i][k], zero mat1[i][k] skipped)
+      for (int r = 0; r < 6; r++) {
+        real acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 6; k++) { const real t = mat1[6*r + k]; if (t) for (int c = 0; c < 6; c++) acc[c] += dmul[6*k + c]*t; }
+        for (int c = 0; c < 6; c++) mat[6*r + c] += acc[c];
+      }
+      for (int t = 0; t < bn; t++) {
+        for (int c = 0; c < 6; c++) v6[c] = Dv[6*(bi + t) + c];
+        mat6_apply(o6, mat, v6);
+        for (int c = 0; c < 6; c++) Df[6*(bi + t) + c] += o6[c];
+      }
+    }
+    wv_sync();
+  }
+
+  // ---- backward pass: a body's row joins its parent's (bodies in descending order, as the reference adds them)
+  for (int b = s.nbody - 1; b > 0; b--) {
+    const int bb = M.B_rowadr[b], bn = M.B_rownnz[b], bp = M.B_rowadr[M.body_parentid[b]];
+    if (bn == 0 || M.B_pmap[bb] < 0) continue;
+    MJH_FOR_LANES(w, 6*bn) {
+      const int t = w / 6, c = w - 6*t;
+      Df[6*(bp + M.B_pmap[bb + t]) + c] += Df[6*(bb + t) + c];
+    }
+    wv_sync();
+  }
+
+  // ---- qDeriv -= D(cdof . cfrc_body): entry t of dof j's row takes mju_dot(Dcfrcbody[body of j][t], cdof_j, 6)
+  MJH_FOR_LANES(k, nD) {
+    const int j = M.D_rowid[k], t = k - M.D_rowadr[j];
+    const int bi = M.B_rowadr[M.dof_bodyid[j]];
+    real a[6], c6[6];
+    for (int c = 0; c < 6; c++) { a[c] = Df[6*(bi + t) + c]; c6[c] = cdof[6*j + c]; }
+    const real r0 = a[0]*c6[0], r1 = a[1]*c6[1], r2 = a[2]*c6[2], r3 = a[3]*c6[3];
+    real res = (r0 + r2) + (r1 + r3);
+    res += a[4]*c6[4] + a[5]*c6[5];
+    qD[k] -= res;
+  }
+  wv_sync();
+
+  // ---- qLU = M (lower to full) - h qDeriv
+  MJH_FOR_LANES(k, nD) {
+    const int im = M.D_mapM[k];
+    real v = im >= 0 ? (real)Mq[im] : 0;
+    v += qD[k]*(-h);
+    qLU[k] = v;
+  }
+  wv_sync();
+
+  // ---- mju_factorLUSparse: pivots from the last row; row j < i holds column i iff its last remaining entry is i
+  //      (rows above a pivot are independent of one another)
+  for (int i = nv - 1; i >= 0; i--) {
+    const int ra = M.D_rowadr[i], di = M.D_diag[i];
+    const real piv = qLU[ra + di];
+    MJH_FOR_LANES(j, i) {
+      // (entries of row j beyond column i have been eliminated: what remains of it ends at the last column <= i)
+      const int rj = M.D_rowadr[j], nj = M.D_rownnz[j];
+      int last = nj - 1;
+      while (last >= 0 && M.D_colind[rj + last] > i) last--;
+      if (last < 0 || M.D_colind[rj + last] != i) continue;
+      const real lji = qLU[rj + last] / piv;
+      qLU[rj + last] = lji;
+      int ic = ra;
+      for (int jc = rj; jc < rj + last; jc++) {
+        // (row i's remaining entries, columns < i, are a subset of row j's: the reference stops on fill-in)
+        if (ic < ra + di && M.D_colind[ic] == M.D_colind[jc]) { qLU[jc] -= qLU[ic]*lji; ic++; }
+      }
+    }
+    wv_sync();
+  }
+
+  // ---- mju_solveLUSparse on qfrc_smooth + qfrc_constraint: (U + I) y = b from the last row, L x = y from the first;
+  //      one lane walks the rows (every row needs the ones before it), the row's sparse dot is mju_dotSparse's
+  crptr fs = MJH_F(B, qfrc_smooth, e);
+  crptr fc = MJH_F(B, qfrc_constraint, e);
+  MJH_FOR_LANES(i, nv) qe[i] = fs[i] + fc[i];
+  wv_sync();
+  if (wv_lane() == 0) {
+    for (int i = nv - 1; i >= 0; i--) {
+      const int d1 = M.D_diag[i] + 1, nn = M.D_rownnz[i] - d1, adr = M.D_rowadr[i] + d1;
+      real r = qe[i];
+      if (nn > 0) r -= dot_sparse_ref(qLU + adr, qe, nn, M.D_colind + adr);
+      qe[i] = r;
+    }
+    for (int i = 0; i < nv; i++) {
+      const int d = M.D_diag[i], adr = M.D_rowadr[i];
+      real r = qe[i];
+      if (d > 0) r -= dot_sparse_ref(qLU + adr, qe, d, M.D_colind + adr);
+      qe[i] = r / qLU[adr + d];
+    }
+  }
+  wv_sync();
 }
 
 // mj_implicitSkip (implicitfast branch) + mj_advance        (engine_forward.c:1649-1770)
@@ -507,6 +751,20 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
     return q;
   };
 
+  if (M.o.integrator == MJH_INT_IMPLICIT) {
+    // ---- the fully implicit integrator (mj_implicitSkip :1680-1690, :1718-1733): qDeriv on its own pattern with the
+    //      derivative of the bias force, qLU = M - h qDeriv factorised without pivoting, one sparse LU solve
+    implicit_full_solve(M, B, e, qderiv_entry);
+    advance_act(M, B, e, MJH_F(B, act_dot, e));
+    MJH_FOR_LANES(i, nv) qvel[i] += qe[i]*h;
+    wv_sync();
+    integrate_pos(M, qpos, qvel, h);
+    rptr ws2 = MJH_F(B, qacc_warmstart, e);
+    MJH_FOR_LANES(i, nv) ws2[i] = qacc[i];
+    if (wv_lane() == 0) MJH_F(B, time, e)[0] += h;
+    wv_sync();
+    return;
+  }
   MJH_FOR_LANES(k, s.nC) {
     const int i = M.M_rowid[k], j = M.M_colind[k];
     const real q = qderiv_entry(i, j);
@@ -630,7 +888,7 @@ MJH_DEV void step_env(MREF M, BREF B, int e) {
   }
   if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
   else if (MJH_HAS(MJH_FT_IMPLICIT) && MJH_HAS(MJH_FT_FLEX) && M.s.efm) MJH_TIMED(MJH_T_EULER, flexcg_advance(M, B, e));
-  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
+  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator >= MJH_INT_IMPLICIT) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
   else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
 }
 
@@ -868,7 +1126,7 @@ MJH_DEV void integrate_env(MREF M, BREF B, int e, const RolloutArgs& A) {
     if (bad && !(M.o.disableflags & (1<<16))) forward(M, B, e, MJH_STAGE_ALL);
     if (MJH_HAS(MJH_FT_RK4) && M.o.integrator == MJH_INT_RK4) MJH_TIMED(MJH_T_EULER, rk4_advance(M, B, e));
     else if (MJH_HAS(MJH_FT_IMPLICIT) && MJH_HAS(MJH_FT_FLEX) && M.s.efm) MJH_TIMED(MJH_T_EULER, flexcg_advance(M, B, e));
-  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator == MJH_INT_IMPLICITFAST) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
+  else if (MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator >= MJH_INT_IMPLICIT) MJH_TIMED(MJH_T_EULER, implicitfast_advance(M, B, e));
     else MJH_TIMED(MJH_T_EULER, MJH_WIDE_IF(!M.s.ld_fast, MJH_MWS_EULER, euler_advance(M, B, e)));
   }
   if (A.state) get_state(M, B, e, A.state + (r*(size_t)A.nstep + A.t0)*s.nstate);

@@ -47,6 +47,21 @@
   X(jnt_limited, s.njnt)                       \
   X(jnt_freebody, s.njnt)                      \
   X(M_rowid, s.nC)                             \
+  /* the fully implicit integrator (mj_implicit; sizes 0 otherwise): qDeriv's pattern D (rows = dofs: the dofs of the row's  \
+     body chain and subtree; D_mapM: the entry's index in M's lower triangle or -1, mju_gatherMasked), the body-by-dof        \
+     pattern B of mjd_rne_vel's work arrays (row = ancestors' dofs, own dofs, subtree's dofs), B_pmap: position of an entry \
+     in the PARENT's row (-1: the parent is welded to the world, addToParent returns), B_ncopy: leading entries a row        \
+     takes over from the parent's (copyFromParent) */ \
+  X(D_rowadr, (s.nD ? s.nv : 0))               \
+  X(D_rownnz, (s.nD ? s.nv : 0))               \
+  X(D_diag, (s.nD ? s.nv : 0))                 \
+  X(D_colind, s.nD)                            \
+  X(D_rowid, s.nD)                             \
+  X(D_mapM, s.nD)                              \
+  X(B_rowadr, (s.nD ? s.nbody : 0))            \
+  X(B_rownnz, (s.nD ? s.nbody : 0))            \
+  X(B_ncopy, (s.nD ? s.nbody : 0))             \
+  X(B_pmap, s.nB)                              \
   X(dof_bodyid, s.nv)                          \
   X(dof_jntid, s.nv)                           \
   X(dof_parentid, s.nv)                        \
@@ -433,6 +448,7 @@ enum {
 
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int nD, nB;          // the fully implicit integrator: entries of qDeriv's pattern, of the body-by-dof pattern (else 0)
   int features;    // MJH_FT_* bits this model needs from a kernel variant
   int neq;         // equality constraints
   int nlevel;      // depth levels of the kinematic tree (world = level 0)
@@ -721,6 +737,13 @@ enum {
   /* mj_RungeKutta intermediates: X[4] = (qpos, qvel), F[4] = qacc, dX */           \
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
+  /* the fully implicit integrator: qDeriv, qLU = M - h qDeriv (factorised in place), and mjd_rne_vel's work arrays */ \
+  X(qDeriv, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                        \
+  X(qLU, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                           \
+  X(Dcdofdot, 6 * s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                  \
+  X(Dcvel, 6 * s.nB, 0, MJH_T_GLB, MJH_T_GLB)                                     \
+  X(Dcacc, 6 * s.nB, 0, MJH_T_GLB, MJH_T_GLB)                                     \
+  X(Dcfrcbody, 6 * s.nB, 0, MJH_T_GLB, MJH_T_GLB)                                 \
   X(rk_dX, 2 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                     \
   X(rk_act, 9 * s.na, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \

@@ -58,6 +58,7 @@ VARIATIONS = [
     ("newton+elliptic", {"solver": mjSOL_NEWTON, "cone": mjCONE_ELLIPTIC}),
     ("rk4", {"integrator": mjINT_RK4}),
     ("implicitfast", {"integrator": mjINT_IMPLICITFAST}),
+    ("implicit", {"integrator": mjINT_IMPLICIT}),
 ]
 
 
