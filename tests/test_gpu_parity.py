@@ -276,13 +276,16 @@ def test_equality_constraints_vs_live_oracle(rb, hip_lib, tmp_path, solver):
     assert c[0] == ints[0, -1, 0] and c[1] == ints[0, -1, 1]
 
 
+@pytest.mark.parametrize("integrator", [3, 2])
 @pytest.mark.parametrize("solver", [0, 2])
-def test_implicitfast_vs_live_oracle(rb, hip_lib, tmp_path, solver):
-    """implicitfast: velocity-dependent actuators, tendon damping, standalone free bodies"""
+def test_implicitfast_vs_live_oracle(rb, hip_lib, tmp_path, solver, integrator):
+    """implicitfast: velocity-dependent actuators, tendon damping, standalone free bodies; round 6: the fully
+    implicit integrator on the same scene (mjd_rne_vel, sparse LU)"""
     xml = tmp_path / "impl.xml"
     xml.write_text(IMPL_XML)
     m = rb.MjModel.from_xml_path(str(xml))
     m.opt.solver = solver
+    m.opt.integrator = integrator
     dmi = K.DeviceModel(hip_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
@@ -515,11 +518,13 @@ def test_predefined_contact_pairs_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     assert relerr(out, ref) <= TOL
 
 
-def test_fluid_forces_vs_live_oracle(rb, hip_lib, tmp_path):
-    """inertia-box fluid forces with wind, RK4"""
+@pytest.mark.parametrize("integrator", [1, 2, 3])
+def test_fluid_forces_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """inertia-box fluid forces with wind: RK4, and the implicit integrators (the forces' velocity derivative in qDeriv)"""
     xml = tmp_path / "fluid.xml"
     xml.write_text(FLUID_XML)
     m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
     dmf = K.DeviceModel(hip_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)

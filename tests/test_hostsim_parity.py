@@ -421,11 +421,41 @@ def test_implicitfast_integrator(rb, hostsim_lib, tmp_path, solver, tol):
     assert b.get("warning").sum() == 0
 
 
-def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden):
-    """the BASELINE humanoid with integrator=implicitfast: damping-only qDeriv, one tree"""
+@pytest.mark.parametrize("solver,tol", [(0, 0.0), (2, 1e-9)])
+def test_implicit_integrator(rb, hostsim_lib, tmp_path, solver, tol):
+    """mj_implicitSkip, fully implicit branch (engine_forward.c:1680-1690, :1718-1733): qDeriv on its own pattern with the
+    derivative of the bias force (mjd_rne_vel / mjd_comVel_vel, engine_derivative.c:527-720) next to the actuator /
+    damper terms, qLU = M - h qDeriv, mju_factorLUSparse / mju_solveLUSparse; hinge, slide and free joints, a free
+    body with a child, tendon damping"""
+    xml = tmp_path / "impl.xml"
+    xml.write_text(IMPL_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    m.opt.integrator = 2
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 80 if solver == 0 else 40
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
+    assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("integrator", [2, 3])
+def test_implicitfast_humanoid_bit_exact(rb, hostsim_lib, golden, integrator):
+    """the BASELINE humanoid with integrator=implicitfast (damping-only qDeriv, one tree) and -- round 6 -- implicit
+    (ball-free chain of 27 dofs through mjd_rne_vel and the sparse LU)"""
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
     m.opt.solver = 0
-    m.opt.integrator = 3
+    m.opt.integrator = integrator
     dm = K.DeviceModel(hostsim_lib, m)
     fx = golden("humanoid")
     T = 12
@@ -708,10 +738,12 @@ def test_soa_pipeline_feature_scenes(rb, hostsim_lib, tmp_path, scene, opts, exa
     assert b.get("warning").sum() == 0
 
 
-@pytest.mark.parametrize("integrator", [0, 1])
+@pytest.mark.parametrize("integrator", [0, 1, 2, 3])
 def test_fluid_forces_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     """mj_fluid, inertia-box model (engine_passive.c:871-903, :1154-1210): viscous and quadratic drag
-    with wind on a swimmer-like chain and a tumbling box; Euler and RK4"""
+    with wind on a swimmer-like chain and a tumbling box; Euler and RK4, and -- round 6 -- the implicit
+    integrators, whose qDeriv takes the forces' velocity derivative (mjd_inertiaBoxFluid,
+    engine_derivative.c:2884-3038)"""
     xml = tmp_path / "fluid.xml"
     xml.write_text(FLUID_XML)
     m = rb.MjModel.from_xml_path(str(xml))
