@@ -237,7 +237,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                "actuator transmissions other than joint / slider-crank / tendon / site (body, SO3)");
     if (tt == mjTRN_TENDON) continue;      // (tendon-level armature / force limits are checked with the tendons)
     if (tt == mjTRN_SITE) {
-      MJH_REJECT(m->actuator_trnid[2*i + 1] != -1, "site transmissions with a reference site");
+      if (m->actuator_trnid[2*i + 1] != -1) o.has_refsite = 1;      // (round 6: relative pose against a reference site)
       MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
                  m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
                  "actuator-level armature/damping on a site transmission");
@@ -276,7 +276,6 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                "tendon armature in a model with more than 128 degrees of freedom and a sparse Jacobian");
   }
   for (int i = 0; i < m->njnt; i++) {
-    MJH_REJECT(m->jnt_actgravcomp[i], "actuator-level gravity compensation");
     if (m->jnt_limited[i]) {
       const mjtNum* r = m->jnt_solref + mjNREF*i;
       MJH_REJECT((r[0] > 0) != (r[1] > 0), "mixed-sign solref on a joint limit");
@@ -504,6 +503,15 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_mass, m->body_mass, m->nbody);
   copy_arr(H->body_gravcomp, m->body_gravcomp, m->nbody);
   o.has_gravcomp = m->flg_gravcomp ? 1 : 0;
+  // actuator-level gravity compensation (round 6; engine_forward.c:981-996, engine_passive.c:1112-1122): the compensation
+  // force of such a joint's dofs joins qfrc_actuator (before the joint-level force limits) instead of qfrc_passive
+  s.nv_actgc = 0;
+  H->dof_actgravcomp.clear();
+  for (int j = 0; j < m->njnt; j++) if (m->jnt_actgravcomp[j] && m->flg_gravcomp) s.nv_actgc = m->nv;
+  if (s.nv_actgc) {
+    H->dof_actgravcomp.assign(m->nv, 0);
+    for (int i = 0; i < m->nv; i++) H->dof_actgravcomp[i] = m->jnt_actgravcomp[m->dof_jntid[i]] ? 1 : 0;
+  }
   o.has_surfacevel = m->flg_surfacevel ? 1 : 0;
   copy_arr(H->geom_surfacevel, m->geom_surfacevel, 6*m->ngeom);
   o.has_fluid = (m->opt.density != 0 || m->opt.viscosity != 0) ? 1 : 0;

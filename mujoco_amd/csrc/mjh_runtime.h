@@ -585,6 +585,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_gravcomp) eqskip.push_back("xipos");    // read by the passive stage
+  if (Bt->model->H.o.has_refsite) eqskip.push_back("xquat");     // site transmissions with a reference site: relative orientation
   if (Bt->model->H.o.has_tendon_wrap) { eqskip.push_back("geom_xpos"); eqskip.push_back("geom_xmat"); }   // mju_wrap at the tendon stage
   if (Bt->model->H.o.has_ten_armature) eqskip.push_back("site_xpos");   // mj_tendonDot reads the sites at the bias-force stage
   if (Bt->model->H.o.has_surfacevel) {   // contact geometry is read again by the reference stage

@@ -492,6 +492,56 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       crptr cdof = MJH_F(B, cdof, e);
       crptr subtree_com = MJH_F(B, subtree_com, e);
       real g[6] = {gear[0], gear[1], gear[2], gear[3], gear[4], gear[5]};
+      const int refid = M.actuator_trnid[2*i + 1];
+      if (refid >= 0) {
+        // reference site defined (:1596-1702): the site's pose RELATIVE to the reference site.  Length = position in the
+        // reference frame . gear + orientation difference (expmap) . gear; moment = (J_site - J_ref), the columns of the dofs
+        // both chains share cleared, projected on the gear expressed in the reference site's frame
+        crptr xquat = MJH_F(B, xquat, e);
+        const int b0 = M.site_bodyid[id], b1 = M.site_bodyid[refid];
+        const int w0 = M.body_weldid[b0], w1 = M.body_weldid[b1];
+        const int tr = !(g[0] == 0 && g[1] == 0 && g[2] == 0), ro = !(g[3] == 0 && g[4] == 0 && g[5] == 0);
+        real len = 0, wt[3] = {0, 0, 0}, wr[3] = {0, 0, 0};
+        if (tr) {
+          real d3[3], v[3];
+          v3_sub(d3, site_xpos + 3*id, site_xpos + 3*refid);
+          m3_multvec(v, site_xmat + 9*refid, d3);
+          len += v3_dot(v, g);
+          m3_mulvec(wt, site_xmat + 9*refid, g);
+        }
+        if (ro) {
+          real qa[4], qb[4], v[3];
+          q_mul(qa, M.site_quat + 4*id, xquat + 4*b0);
+          q_mul(qb, M.site_quat + 4*refid, xquat + 4*b1);
+          q_sub(v, qa, qb);
+          len += v3_dot(v, g + 3);
+          m3_mulvec(wr, site_xmat + 9*refid, g + 3);
+        }
+        real off0[3], off1[3];
+        v3_sub(off0, site_xpos + 3*id, subtree_com + 3*M.body_rootid[b0]);
+        v3_sub(off1, site_xpos + 3*refid, subtree_com + 3*M.body_rootid[b1]);
+        int nnz = 0;
+        for (int j = 0; j < s.nv; j++) {
+          const int in0 = (M.body_dofanc[w0*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          real jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
+          if (in0 != in1) {
+            crptr cd = cdof + 6*j;
+            real cr[3];
+            v3_cross(cr, cd, in0 ? off0 : off1);
+            for (int r = 0; r < 3; r++) { jp[r] = cd[3 + r] + cr[r]; jr[r] = cd[r]; }
+            if (in1) for (int r = 0; r < 3; r++) { jp[r] = 0 - jp[r]; jr[r] = 0 - jr[r]; }
+          }
+          real t1 = 0, t2 = 0;
+          if (tr) for (int r = 0; r < 3; r++) if (wt[r] != 0) t1 += jp[r]*wt[r];
+          if (ro) for (int r = 0; r < 3; r++) if (wr[r] != 0) t2 += jr[r]*wr[r];
+          const real mrow = ro ? t1 + t2 : t1;
+          if (mrow != 0) { moment[adr + nnz] = mrow; colind[adr + nnz] = j; nnz++; }
+        }
+        length[i] = len;
+        rownnz[i] = nnz;
+        continue;
+      }
       real wrench[6];
       m3_mulvec(wrench, site_xmat + 9*id, g);
       m3_mulvec(wrench + 3, site_xmat + 9*id, g + 3);
@@ -1397,7 +1447,9 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
         }
         acc += t;
       }
-      fp[j] += acc;
+      // (a joint with actuator-level compensation: the force waits for stage_actuation)
+      if (s.nv_actgc && M.dof_actgravcomp[j]) MJH_G(B, qfrc_gravcomp, e)[j] = acc;
+      else fp[j] += acc;
     }
     wv_sync();
   }
@@ -1805,6 +1857,13 @@ MJH_DEVN void stage_actuation(MREF M_, BREF B_, int e_) {
     qfa[j] = r;
   }
   wv_sync();
+  // actuator-level gravity compensation (engine_forward.c:981-996; the condition of the passive stage's gravcomp block)
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && s.nv_actgc && M.o.has_gravcomp && !(dsbl & (1<<7)) &&
+      sqrt(M.o.gravity[0]*M.o.gravity[0] + M.o.gravity[1]*M.o.gravity[1] + M.o.gravity[2]*M.o.gravity[2]) != 0) {
+    crptr gc = MJH_G(B, qfrc_gravcomp, e);
+    MJH_FOR_LANES(j, s.nv) if (M.dof_actgravcomp[j]) qfa[j] += gc[j];
+    wv_sync();
+  }
   // joint-level actuator force limits (clampVec with jnt_dofadr index)
   MJH_FOR_LANES(j, s.njnt) {
     if (MJH_HAS(MJH_FT_GAINBIAS) && M.jnt_actfrclimited[j]) {

@@ -117,6 +117,8 @@
   X(dof_act_adr, s.nv + 1)                     \
   X(dof_act_ids, s.nu + 1)                     \
   X(jnt_actfrclimited, s.njnt)                 \
+  /* dofs whose joint takes its gravity compensation through qfrc_actuator (jnt_actgravcomp) */ \
+  X(dof_actgravcomp, s.nv_actgc)               \
   X(pair_geom1, (s.npair + s.nflexpair))                       \
   X(pair_geom2, (s.npair + s.nflexpair))                       \
   X(pair_dim, (s.npair + s.nflexpair))                         \
@@ -448,6 +450,7 @@ enum {
 
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int nv_actgc;        // nv when some joint has actuator-level gravity compensation, else 0
   int nD, nB;          // the fully implicit integrator: entries of qDeriv's pattern, of the body-by-dof pattern (else 0)
   int features;    // MJH_FT_* bits this model needs from a kernel variant
   int neq;         // equality constraints
@@ -542,6 +545,7 @@ struct DOptions {
   int integrator, cone, solver, iterations, ls_iterations;
   int disableflags, enableflags;
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
+  int has_refsite;    // a site transmission with a reference site (reads xquat at the transmission stage)
   int has_ten_armature;
   int has_act_disabled;  // some actuator is disabled through its group (opt.disableactuator)
   int has_ten_actfrc;    // some tendon limits the total force of the actuators acting on it
@@ -738,6 +742,7 @@ enum {
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
   /* the fully implicit integrator: qDeriv, qLU = M - h qDeriv (factorised in place), and mjd_rne_vel's work arrays */ \
+  X(qfrc_gravcomp, s.nv_actgc, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(qDeriv, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                        \
   X(qLU, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                           \
   X(Dcdofdot, 6 * s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                  \
