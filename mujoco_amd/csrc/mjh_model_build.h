@@ -210,9 +210,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const bool fluid = m->opt.density != 0 || m->opt.viscosity != 0;
     MJH_REJECT(!fluid && (m->opt.wind[0] != 0 || m->opt.wind[1] != 0 || m->opt.wind[2] != 0), "wind without a fluid medium");
 
-    if (fluid)
-      for (int g = 0; g < m->ngeom; g++)
-        MJH_REJECT(m->geom_fluid[mjNFLUID*g] > 0, "the ellipsoid fluid model (geom fluidshape)");
+    // (round 6: the ellipsoid fluid model -- mj_ellipsoidFluidModel, engine_passive.c:1213-1270 -- per geom; tables below)
   }
   MJH_REJECT(m->nactuator != m->nu, "multi-input actuators (nactuator != nu)");
   MJH_REJECT(m->nout != m->nu, "multi-output actuators (nout != nu)");
@@ -502,6 +500,29 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   copy_arr(H->body_iquat, m->body_iquat, 4*m->nbody);
   copy_arr(H->body_mass, m->body_mass, m->nbody);
   copy_arr(H->body_gravcomp, m->body_gravcomp, m->nbody);
+  // ellipsoid fluid model: interaction coefficients and semi-axes of every geom, the bodies that use it
+  s.ngeom_fluid = 0;
+  H->geom_fluid.clear(); H->geom_semiaxes.clear(); H->body_ellipsoid.clear();
+  if (m->opt.density != 0 || m->opt.viscosity != 0)
+    for (int g = 0; g < m->ngeom; g++) if (m->geom_fluid[mjNFLUID*g] > 0) s.ngeom_fluid = m->ngeom;
+  if (s.ngeom_fluid) {
+    static_assert(mjNFLUID == 12, "geom_fluid layout");
+    copy_arr(H->geom_fluid, m->geom_fluid, (size_t)mjNFLUID*m->ngeom);
+    H->geom_semiaxes.assign(3*(size_t)m->ngeom, 0);
+    for (int g = 0; g < m->ngeom; g++) {
+      const mjtNum* sz = m->geom_size + 3*g;
+      real* ax = &H->geom_semiaxes[3*g];
+      // (mju_geomSemiAxes, engine_util_misc.c:423: sphere r r r; capsule r r h + r; cylinder r r h; else the sizes)
+      const int t = m->geom_type[g];
+      ax[0] = sz[0];
+      ax[1] = (t == mjGEOM_SPHERE || t == mjGEOM_CAPSULE || t == mjGEOM_CYLINDER) ? sz[0] : sz[1];
+      ax[2] = t == mjGEOM_SPHERE ? sz[0] : (t == mjGEOM_CAPSULE ? sz[1] + sz[0] : (t == mjGEOM_CYLINDER ? sz[1] : sz[2]));
+    }
+    H->body_ellipsoid.assign(m->nbody, 0);
+    for (int b = 0; b < m->nbody; b++)
+      for (int g = m->body_geomadr[b]; g < m->body_geomadr[b] + m->body_geomnum[b]; g++)
+        if (m->geom_fluid[mjNFLUID*g] > 0) H->body_ellipsoid[b] = 1;
+  }
   o.has_gravcomp = m->flg_gravcomp ? 1 : 0;
   // actuator-level gravity compensation (round 6; engine_forward.c:981-996, engine_passive.c:1112-1122): the compensation
   // force of such a joint's dofs joins qfrc_actuator (before the joint-level force limits) instead of qfrc_passive

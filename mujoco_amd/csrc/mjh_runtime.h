@@ -570,6 +570,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
                           "moment_rownnz", "moment_colind", "actuator_force", "actuator_length", "actuator_velocity"})
       eqskip.push_back(f);
     if (Bt->model->H.o.has_fluid) { eqskip.push_back("cdof"); eqskip.push_back("subtree_com"); }   // the fluid forces' velocity derivative
+    if (Bt->model->H.s.ngeom_fluid) { eqskip.push_back("geom_xpos"); eqskip.push_back("geom_xmat"); }
   }
   // sensors are evaluated after the solve and read kinematic / velocity / actuator / contact
   // quantities past their usual lifetimes: those fields stay in their global homes; the constraint
@@ -593,6 +594,7 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
       eqskip.push_back(f);
   }
   if (Bt->model->H.o.has_fluid) { eqskip.push_back("xipos"); eqskip.push_back("ximat"); }
+  if (Bt->model->H.s.ngeom_fluid) { eqskip.push_back("geom_xpos"); eqskip.push_back("geom_xmat"); }   // ellipsoid fluid model: geom frames at the passive stage
   if (Bt->xfrc_on) eqskip.push_back("xipos");                  // Cartesian forces act at the body COMs (stage_acceleration)
   if (Bt->soa) {
     // the constraint kernel of the per-step pipeline: collision .. PGS

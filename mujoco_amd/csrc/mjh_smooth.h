@@ -1230,6 +1230,223 @@ MJH_DEV real poly_force_deriv(real linear, P0 poly, real x, int odd) {
   return res;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ellipsoid fluid model, per geom (round 6).  mj_ellipsoidFluidModel / mj_addedMassForces / mj_viscousForces
+// (engine_passive.c:1213-1410) for the wrench, mjd_ellipsoidFluid and its components (engine_derivative.c:2531-2880)
+// for the 6 x 6 derivative B of the local wrench (torque; force) by the local velocity (angular; linear) that the
+// implicit integrators put into qDeriv as J' B J.  One lane per geom; results in fluid_geom: the world-frame wrench
+// (torque, force), then B row-major.  Every expression keeps the reference's order of operations.
+// ------------------------------------------------------------------------------------------------
+MJH_DEV real el_pow2(real v) { return v*v; }
+MJH_DEV real el_pow4(real v) { return (v*v)*(v*v); }
+MJH_DEV real el_max_moment(const real* sz, int dir) {
+  const real d0 = sz[dir], d1 = sz[(dir + 1) % 3], d2 = sz[(dir + 2) % 3];
+  return 8.0/15.0 * MJH_PI * d0 * el_pow4(r_max(d1, d2));
+}
+// Da = d(a x b)/da, Db = d(a x b)/db (row-major 3 x 3; mjd_cross)
+MJH_DEV void el_dcross(const real* a, const real* b, real* Da, real* Db) {
+  for (int k = 0; k < 9; k++) { Da[k] = 0; Db[k] = 0; }
+  Da[1] = b[2]; Da[2] = -b[1]; Da[3] = -b[2]; Da[5] = b[0]; Da[6] = b[1]; Da[7] = -b[0];
+  Db[1] = -a[2]; Db[2] = a[1]; Db[3] = a[2]; Db[5] = -a[0]; Db[6] = -a[1]; Db[7] = a[0];
+}
+// 3 x 3 block D (as the reference fills it) into quadrant (column block cq, row block rq) of the 6 x 6 matrix:
+// element D[3 i + j] lands at Bm[6 (3 cq + i) + 3 rq + j]   (addToQuadrant)
+MJH_DEV void el_add_quadrant(real* Bm, const real* D, int cq, int rq) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Bm[6*(3*cq + i) + 3*rq + j] += D[3*i + j];
+}
+MJH_DEVN void ellipsoid_fluid_geoms(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr gx = MJH_F(B, geom_xpos, e);
+  crptr gm = MJH_F(B, geom_xmat, e);
+  crptr cvel = MJH_F(B, cvel, e);
+  crptr com = MJH_F(B, subtree_com, e);
+  rptr out = MJH_G(B, fluid_geom, e);
+  const real dens = M.o.density, visc = M.o.viscosity;
+  const int want_B = MJH_HAS(MJH_FT_IMPLICIT) && M.o.integrator >= MJH_INT_IMPLICIT;
+  MJH_FOR_LANES(g, s.ngeom) {
+    const int b = M.geom_bodyid[g];
+    for (int k = 0; k < 42; k++) out[42*g + k] = 0;
+    if (!M.body_ellipsoid[b] || M.body_mass[b] < MJH_MINVAL) continue;
+    auto fc = M.geom_fluid + 12*g;
+    const real icoef = fc[0], blunt = fc[1], slender = fc[2], angc = fc[3], kutta = fc[4], magnus = fc[5];
+    if (icoef == 0) continue;
+    const real vm[3] = {fc[6], fc[7], fc[8]}, vi[3] = {fc[9], fc[10], fc[11]};
+    const real sz[3] = {M.geom_semiaxes[3*g], M.geom_semiaxes[3*g + 1], M.geom_semiaxes[3*g + 2]};
+    // local 6D velocity of the geom frame (mj_objectVelocity, flg_local) minus the wind
+    real lvel[6] = {0, 0, 0, 0, 0, 0}, lwind[6];
+    crptr cref = com + 3*M.body_rootid[b];
+    if (M.body_dofnum[M.body_weldid[b]] != 0) {
+      real dif[3], cr[3], tran[6];
+      v3_sub(dif, gx + 3*g, cref);
+      for (int k = 0; k < 6; k++) tran[k] = cvel[6*b + k];
+      v3_cross(cr, dif, cvel + 6*b);
+      tran[3] = cvel[6*b + 3] - cr[0]; tran[4] = cvel[6*b + 4] - cr[1]; tran[5] = cvel[6*b + 5] - cr[2];
+      m3_multvec(lvel, gm + 9*g, tran);
+      m3_multvec(lvel + 3, gm + 9*g, tran + 3);
+    }
+    {
+      real wind[6] = {0, 0, 0, M.o.wind[0], M.o.wind[1], M.o.wind[2]};
+      real dif[3], cr[3], tran[6];
+      v3_sub(dif, gx + 3*g, cref);
+      for (int k = 0; k < 6; k++) tran[k] = wind[k];
+      v3_cross(cr, dif, wind);
+      tran[3] = wind[3] - cr[0]; tran[4] = wind[4] - cr[1]; tran[5] = wind[5] - cr[2];
+      m3_multvec(lwind, gm + 9*g, tran);
+      m3_multvec(lwind + 3, gm + 9*g, tran + 3);
+    }
+    lvel[3] -= lwind[3]; lvel[4] -= lwind[4]; lvel[5] -= lwind[5];
+    const real lin[3] = {lvel[3], lvel[4], lvel[5]}, ang[3] = {lvel[0], lvel[1], lvel[2]};
+    real lfrc[6] = {0, 0, 0, 0, 0, 0};
+    // ---- added mass (mj_addedMassForces)
+    const real plin[3] = {dens*vm[0]*lin[0], dens*vm[1]*lin[1], dens*vm[2]*lin[2]};
+    const real pang[3] = {dens*vi[0]*ang[0], dens*vi[1]*ang[1], dens*vi[2]*ang[2]};
+    {
+      real f[3], t1[3], t2[3];
+      v3_cross(f, plin, ang);
+      v3_cross(t1, plin, lin);
+      v3_cross(t2, pang, ang);
+      for (int k = 0; k < 3; k++) { lfrc[k] += t1[k]; }
+      for (int k = 0; k < 3; k++) { lfrc[k] += t2[k]; }
+      for (int k = 0; k < 3; k++) { lfrc[3 + k] += f[k]; }
+    }
+    // ---- lift and drag (mj_viscousForces)
+    const real volume = 4.0/3.0 * MJH_PI * sz[0] * sz[1] * sz[2];
+    const real d_max = r_max(r_max(sz[0], sz[1]), sz[2]);
+    const real d_min = r_min(r_min(sz[0], sz[1]), sz[2]);
+    const real d_mid = sz[0] + sz[1] + sz[2] - d_max - d_min;
+    const real A_max = MJH_PI * d_max * d_mid;
+    real magf[3];
+    v3_cross(magf, ang, lin);
+    for (int k = 0; k < 3; k++) magf[k] *= magnus * dens * volume;
+    const real proj_denom = el_pow4(sz[1]*sz[2])*el_pow2(lin[0]) + el_pow4(sz[2]*sz[0])*el_pow2(lin[1]) + el_pow4(sz[0]*sz[1])*el_pow2(lin[2]);
+    const real proj_num = el_pow2(sz[1]*sz[2]*lin[0]) + el_pow2(sz[2]*sz[0]*lin[1]) + el_pow2(sz[0]*sz[1]*lin[2]);
+    const real A_proj = MJH_PI * sqrt(proj_denom/r_max(MJH_MINVAL, proj_num));
+    const real nrm[3] = {el_pow2(sz[1]*sz[2])*lin[0], el_pow2(sz[2]*sz[0])*lin[1], el_pow2(sz[0]*sz[1])*lin[2]};
+    const real linnorm = sqrt(lin[0]*lin[0] + lin[1]*lin[1] + lin[2]*lin[2]);
+    const real cos_alpha = proj_num / r_max(MJH_MINVAL, linnorm * proj_denom);
+    real circ[3], kutf[3];
+    v3_cross(circ, nrm, lin);
+    for (int k = 0; k < 3; k++) circ[k] *= kutta * dens * cos_alpha * A_proj;
+    v3_cross(kutf, circ, lin);
+    const real eqD = 2.0/3.0 * (sz[0] + sz[1] + sz[2]);
+    const real lin_force_coef = 3.0 * MJH_PI * eqD;
+    const real lin_torq_coef = MJH_PI * eqD*eqD*eqD;
+    const real I_max = 8.0/15.0 * MJH_PI * d_mid * el_pow4(d_max);
+    const real II[3] = {el_max_moment(sz, 0), el_max_moment(sz, 1), el_max_moment(sz, 2)};
+    const real momv[3] = {ang[0]*(angc*II[0] + slender*(I_max - II[0])), ang[1]*(angc*II[1] + slender*(I_max - II[1])),
+                          ang[2]*(angc*II[2] + slender*(I_max - II[2]))};
+    const real drag_lin = visc*lin_force_coef + dens*linnorm*(A_proj*blunt + slender*(A_max - A_proj));
+    const real drag_ang = visc*lin_torq_coef + dens*sqrt(momv[0]*momv[0] + momv[1]*momv[1] + momv[2]*momv[2]);
+    for (int k = 0; k < 3; k++) lfrc[k] -= drag_ang*ang[k];
+    for (int k = 0; k < 3; k++) lfrc[3 + k] += magf[k] + kutf[k] - drag_lin*lin[k];
+    for (int k = 0; k < 6; k++) lfrc[k] = lfrc[k]*icoef;
+    real w6[6];
+    m3_mulvec(w6, gm + 9*g, lfrc);
+    m3_mulvec(w6 + 3, gm + 9*g, lfrc + 3);
+    for (int k = 0; k < 6; k++) out[42*g + k] = w6[k];
+    if (!want_B) continue;
+
+    // ---- the derivative (mjd_ellipsoidFluid :2832-2850: magnus, kutta, viscous drag, viscous torque, added mass)
+    real Bm[36], D[9], Da[9], Db[9];
+    for (int k = 0; k < 36; k++) Bm[k] = 0;
+    {  // mjd_magnus_force
+      const real mc = magnus * dens * volume;
+      const real l3[3] = {mc*lvel[3], mc*lvel[4], mc*lvel[5]}, a3[3] = {mc*lvel[0], mc*lvel[1], mc*lvel[2]};
+      el_dcross(a3, l3, Da, Db);
+      el_add_quadrant(Bm, Da, 1, 0);
+      el_add_quadrant(Bm, Db, 1, 1);
+    }
+    const real qa = el_pow2(sz[1]*sz[2]), qb = el_pow2(sz[2]*sz[0]), qc = el_pow2(sz[0]*sz[1]);
+    const real aa = qa*qa, bb = qb*qb, cc = qc*qc;
+    {  // mjd_kutta_lift
+      const real x = lvel[3], y = lvel[4], z = lvel[5];
+      const real xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+      const real pden = aa*xx + bb*yy + cc*zz;
+      const real pnum = qa*xx + qb*yy + qc*zz;
+      const real norm2 = xx + yy + zz;
+      const real df_denom = MJH_PI * kutta * dens / r_max(MJH_MINVAL, sqrt(pden * pnum * norm2));
+      const real dfx = yy*(qa - qb) + zz*(qa - qc);
+      const real dfy = xx*(qb - qa) + zz*(qb - qc);
+      const real dfz = xx*(qc - qa) + yy*(qc - qb);
+      const real proj_term = pnum / r_max(MJH_MINVAL, pden);
+      const real cos_term = pnum / r_max(MJH_MINVAL, norm2);
+      D[0] = qa - qa; D[1] = qb - qa; D[2] = qc - qa;
+      D[3] = qa - qb; D[4] = qb - qb; D[5] = qc - qb;
+      D[6] = qa - qc; D[7] = qb - qc; D[8] = qc - qc;
+      for (int k = 0; k < 9; k++) D[k] = D[k]*(2*pnum);
+      const real inner[3] = {aa*proj_term - qa + cos_term, bb*proj_term - qb + cos_term, cc*proj_term - qc + cos_term};
+      for (int k = 0; k < 3; k++) { D[k] += inner[k]*dfx; D[3 + k] += inner[k]*dfy; D[6 + k] += inner[k]*dfz; }
+      D[0] *= xx; D[1] *= xy; D[2] *= xz;
+      D[3] *= xy; D[4] *= yy; D[5] *= yz;
+      D[6] *= xz; D[7] *= yz; D[8] *= zz;
+      D[0] -= dfx*pnum; D[4] -= dfy*pnum; D[8] -= dfz*pnum;
+      for (int k = 0; k < 9; k++) D[k] = D[k]*df_denom;
+      el_add_quadrant(Bm, D, 1, 1);
+    }
+    {  // mjd_viscous_drag
+      const real x = lvel[3], y = lvel[4], z = lvel[5];
+      const real xx = x*x, yy = y*y, zz = z*z, xy = x*y, yz = y*z, xz = x*z;
+      const real pden = aa*xx + bb*yy + cc*zz;
+      const real pnum = qa*xx + qb*yy + qc*zz;
+      const real dA_coef = MJH_PI / r_max(MJH_MINVAL, sqrt(pnum*pnum*pnum * pden));
+      const real Ap = MJH_PI * sqrt(pden/r_max(MJH_MINVAL, pnum));
+      const real norm = sqrt(xx + yy + zz);
+      const real inv_norm = 1.0 / r_max(MJH_MINVAL, norm);
+      const real lin_coef = visc * 3.0 * MJH_PI * eqD;
+      const real quad_coef = dens * (Ap*blunt + slender*(A_max - Ap));
+      const real Aproj_coef = dens * norm * (blunt - slender);
+      const real dAp[3] = {Aproj_coef * dA_coef * qa * x * (qb * yy * (qa - qb) + qc * zz * (qa - qc)),
+                           Aproj_coef * dA_coef * qb * y * (qa * xx * (qb - qa) + qc * zz * (qb - qc)),
+                           Aproj_coef * dA_coef * qc * z * (qa * xx * (qc - qa) + qb * yy * (qc - qb))};
+      D[0] = xx; D[1] = xy; D[2] = xz; D[3] = xy; D[4] = yy; D[5] = yz; D[6] = xz; D[7] = yz; D[8] = zz;
+      const real inner = xx + yy + zz;
+      D[0] += inner; D[4] += inner; D[8] += inner;
+      const real sc = -quad_coef*inv_norm;
+      for (int k = 0; k < 9; k++) D[k] = D[k]*sc;
+      for (int k = 0; k < 3; k++) { D[k] += dAp[k]*(-x); D[3 + k] += dAp[k]*(-y); D[6 + k] += dAp[k]*(-z); }
+      D[0] -= lin_coef; D[4] -= lin_coef; D[8] -= lin_coef;
+      el_add_quadrant(Bm, D, 1, 1);
+    }
+    {  // mjd_viscous_torque
+      const real x = lvel[0], y = lvel[1], z = lvel[2];
+      const real mcf[3] = {angc*II[0] + slender*(I_max - II[0]), angc*II[1] + slender*(I_max - II[1]), angc*II[2] + slender*(I_max - II[2])};
+      const real mv[3] = {x*mcf[0], y*mcf[1], z*mcf[2]};
+      const real density = dens / r_max(MJH_MINVAL, sqrt(mv[0]*mv[0] + mv[1]*mv[1] + mv[2]*mv[2]));
+      const real msq[3] = {-density * x * mcf[0] * mcf[0], -density * y * mcf[1] * mcf[1], -density * z * mcf[2] * mcf[2]};
+      const real lin_coef = visc * lin_torq_coef;
+      for (int k = 0; k < 9; k++) D[k] = 0;
+      const real dg = x*msq[0] + y*msq[1] + z*msq[2] - lin_coef;
+      D[0] = dg; D[4] = dg; D[8] = dg;
+      for (int k = 0; k < 3; k++) { D[k] += msq[k]*x; D[3 + k] += msq[k]*y; D[6 + k] += msq[k]*z; }
+      el_add_quadrant(Bm, D, 0, 0);
+    }
+    {  // mjd_addedMassForces
+      el_dcross(pang, ang, Da, Db);
+      el_add_quadrant(Bm, Db, 0, 0);
+      for (int k = 0; k < 9; k++) Da[k] *= dens * vi[k % 3];
+      el_add_quadrant(Bm, Da, 0, 0);
+      el_dcross(plin, lin, Da, Db);
+      el_add_quadrant(Bm, Db, 0, 1);
+      for (int k = 0; k < 9; k++) Da[k] *= dens * vm[k % 3];
+      el_add_quadrant(Bm, Da, 0, 1);
+      el_dcross(plin, ang, Da, Db);
+      el_add_quadrant(Bm, Db, 1, 0);
+      for (int k = 0; k < 9; k++) Da[k] *= dens * vm[k % 3];
+      el_add_quadrant(Bm, Da, 1, 1);
+    }
+    // (implicitfast symmetrises B except on standalone free bodies: mju_symmetrize, 0.5 (B + B'))
+    if (M.o.integrator == MJH_INT_IMPLICITFAST) {
+      int freebody = 0;
+      if (M.body_jntnum[b] == 1 && M.jnt_freebody[M.body_jntadr[b]]) freebody = 1;
+      if (!freebody)
+        for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) { const real v = 0.5*(Bm[6*i + j] + Bm[6*j + i]); Bm[6*i + j] = v; Bm[6*j + i] = v; }
+    }
+    for (int k = 0; k < 36; k++) out[42*g + 6 + k] = Bm[k];
+  }
+  wv_sync();
+}
+
 MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
@@ -1333,7 +1550,7 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
       real out[6] = {0, 0, 0, 0, 0, 0};
       real coef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       const real mass = M.body_mass[i];
-      if (!(mass < MJH_MINVAL)) {
+      if (!(mass < MJH_MINVAL) && !(s.ngeom_fluid && M.body_ellipsoid[i])) {
         auto inertia = M.body_inertia + 3*i;
         real box[3];
         box[0] = sqrt(r_max(MJH_MINVAL, (inertia[1] + inertia[2] - inertia[0])) / mass * 6.0);
@@ -1400,12 +1617,34 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
       for (int k = 0; k < 6; k++) bf[6*i + k] = out[k];
       if (MJH_HAS(MJH_FT_IMPLICIT)) for (int k = 0; k < 8; k++) bf[6*s.nbody + 8*i + k] = coef[k];
     }
+    // ellipsoid model (mj_ellipsoidFluidModel, engine_passive.c:1213-1270), one lane per geom of a body that uses it
+    if (s.ngeom_fluid) ellipsoid_fluid_geoms(M, B, e);
     wv_sync();
     MJH_FOR_LANES(j, s.nv) {
       real acc = 0;
       crptr cd = cdof + 6*j;
       for (int b = 0; b < s.nbody; b++) {
         if (M.body_mass[b] < MJH_MINVAL) continue;
+        if (s.ngeom_fluid && M.body_ellipsoid[b]) {
+          // (mj_applyFT per geom, at the geom's position: force part, then torque part)
+          crptr gx = MJH_F(B, geom_xpos, e);
+          crptr gw = MJH_G(B, fluid_geom, e);
+          const int inch = (M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          for (int g = M.body_geomadr[b]; g < M.body_geomadr[b] + M.body_geomnum[b]; g++) {
+            if (M.geom_fluid[12*g] == 0) continue;
+            real tf = 0, tt = 0;
+            if (inch) {
+              real off[3], cr[3];
+              v3_sub(off, gx + 3*g, com + 3*M.body_rootid[b]);
+              v3_cross(cr, cd, off);
+              for (int r = 0; r < 3; r++) { const real f = gw[42*g + 3 + r]; if (f != 0) tf += (cd[3 + r] + cr[r])*f; }
+              for (int r = 0; r < 3; r++) { const real t = gw[42*g + r]; if (t != 0) tt += cd[r]*t; }
+            }
+            acc += tf;
+            acc += tt;
+          }
+          continue;
+        }
         real tf = 0, tt = 0;
         if ((M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1) {
           real off[3], cr[3];

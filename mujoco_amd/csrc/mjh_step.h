@@ -695,6 +695,39 @@ MJH_DEVN void implicitfast_advance(MREF M_, BREF B_, int e_) {
       for (int b = 0; b < s.nbody; b++) {
         if (M.body_mass[b] < MJH_MINVAL) continue;
         if (!((M.body_dofanc[b*s.nvw + (i >> 5)] >> (i & 31)) & 1) || !((M.body_dofanc[b*s.nvw + (j >> 5)] >> (j & 31)) & 1)) continue;
+        if (s.ngeom_fluid && M.body_ellipsoid[b]) {
+          // ellipsoid model (mjd_ellipsoidFluid :2778-2880): per geom J' B J with the geom's Jacobian (rotation rows, then
+          // translation rows, rotated into the geom frame) and the full 6 x 6 B the passive stage left in fluid_geom;
+          // addJTBJ's order: rows a of B, columns c, zero entries of B skipped
+          crptr gx = MJH_F(B, geom_xpos, e);
+          crptr gmat = MJH_F(B, geom_xmat, e);
+          crptr gw = MJH_G(B, fluid_geom, e);
+          for (int g = M.body_geomadr[b]; g < M.body_geomadr[b] + M.body_geomnum[b]; g++) {
+            if (M.geom_fluid[12*g] == 0) continue;
+            real off[3], ci[3], cj[3], Ji[6], Jj[6];
+            v3_sub(off, gx + 3*g, com + 3*M.body_rootid[b]);
+            v3_cross(ci, cdi, off);
+            v3_cross(cj, cdj, off);
+            const real gi[6] = {cdi[0], cdi[1], cdi[2], cdi[3] + ci[0], cdi[4] + ci[1], cdi[5] + ci[2]};
+            const real gj[6] = {cdj[0], cdj[1], cdj[2], cdj[3] + cj[0], cdj[4] + cj[1], cdj[5] + cj[2]};
+            crptr xm = gmat + 9*g;
+            for (int r = 0; r < 3; r++) {
+              real ai = 0, aj = 0, li = 0, lj = 0;
+              for (int c = 0; c < 3; c++) {
+                const real t = xm[3*c + r];
+                if (t) { ai += gi[c]*t; aj += gj[c]*t; li += gi[3 + c]*t; lj += gj[3 + c]*t; }
+              }
+              Ji[r] = ai; Jj[r] = aj; Ji[3 + r] = li; Jj[3 + r] = lj;
+            }
+            crptr Bm = gw + 42*g + 6;
+            for (int a = 0; a < 6; a++)
+              for (int c = 0; c < 6; c++) {
+                const real bv = Bm[6*a + c];
+                if (bv) q += Jj[c]*(Ji[a]*bv);
+              }
+          }
+          continue;
+        }
         crptr cf = bf + 6*s.nbody + 8*b;
         real off[3], ci[3], cj[3], Ji[6], Jj[6];
         v3_sub(off, xipos + 3*b, com + 3*M.body_rootid[b]);

@@ -119,6 +119,8 @@
   X(jnt_actfrclimited, s.njnt)                 \
   /* dofs whose joint takes its gravity compensation through qfrc_actuator (jnt_actgravcomp) */ \
   X(dof_actgravcomp, s.nv_actgc)               \
+  /* 1: some geom of the body uses the ellipsoid fluid model (the inertia-box model is then off for the body) */ \
+  X(body_ellipsoid, (s.ngeom_fluid ? s.nbody : 0)) \
   X(pair_geom1, (s.npair + s.nflexpair))                       \
   X(pair_geom2, (s.npair + s.nflexpair))                       \
   X(pair_dim, (s.npair + s.nflexpair))                         \
@@ -346,6 +348,10 @@
   X(geom_pos, 3 * s.ngeom)                     \
   X(geom_quat, 4 * s.ngeom)                    \
   X(geom_size, 3 * s.ngeom)                    \
+  /* ellipsoid fluid model (geoms with fluidshape = ellipsoid; sizes 0 otherwise): the twelve interaction coefficients of a  \
+     geom (mjNFLUID) and its semi-axes (mju_geomSemiAxes) */ \
+  X(geom_fluid, 12 * s.ngeom_fluid)            \
+  X(geom_semiaxes, 3 * s.ngeom_fluid)          \
   X(geom_rbound, s.ngeom)                      \
   X(geom_aabb, 6 * s.ngeom)                    \
   X(geom_bpmargin, s.ngeom)                    \
@@ -450,6 +456,7 @@ enum {
 
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int ngeom_fluid;     // ngeom when some geom uses the ellipsoid fluid model, else 0
   int nv_actgc;        // nv when some joint has actuator-level gravity compensation, else 0
   int nD, nB;          // the fully implicit integrator: entries of qDeriv's pattern, of the body-by-dof pattern (else 0)
   int features;    // MJH_FT_* bits this model needs from a kernel variant
@@ -742,6 +749,9 @@ enum {
   X(rk_X, 4 * (s.nq + s.nv), 0, MJH_T_GLB, MJH_T_GLB)                             \
   X(rk_F, 4 * s.nv, 0, MJH_T_GLB, MJH_T_GLB)                                      \
   /* the fully implicit integrator: qDeriv, qLU = M - h qDeriv (factorised in place), and mjd_rne_vel's work arrays */ \
+  /* ellipsoid fluid model, per geom: the wrench in the world frame (6), then the 6 x 6 derivative of the local wrench with  \
+     respect to the local velocity (implicit integrators; mjd_ellipsoidFluid) */ \
+  X(fluid_geom, 42 * s.ngeom_fluid, 0, MJH_T_GLB, MJH_T_GLB)                      \
   X(qfrc_gravcomp, s.nv_actgc, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(qDeriv, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                        \
   X(qLU, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                           \

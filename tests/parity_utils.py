@@ -560,6 +560,32 @@ FLUID_XML = """
 """
 
 
+# the same medium with the ELLIPSOID fluid model on some geoms (fluidshape = ellipsoid: added mass, Kutta and Magnus lift,
+# blunt / slender / angular drag with non-default coefficients) next to inertia-box bodies: capsules, a cylinder, a box,
+# an ellipsoid and a sphere; one body mixes a fluid geom with a plain one (the whole body then leaves the inertia-box model)
+ELLIPSOID_FLUID_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="40" density="1200" viscosity=".15" wind=".3 -.1 .05"/>
+  <default><geom type="capsule" size=".04" condim="1"/><joint damping=".02"/></default>
+  <worldbody>
+    <geom type="plane" size="4 4 .01" pos="0 0 -1"/>
+    <body name="head" pos="0 0 0">
+      <joint type="slide" axis="1 0 0"/><joint type="slide" axis="0 1 0"/><joint type="hinge" axis="0 0 1"/>
+      <geom fromto="0 0 0 -.3 0 0" fluidshape="ellipsoid"/>
+      <body pos="-.3 0 0"><joint name="r1" axis="0 0 1" range="-100 100" limited="true"/>
+        <geom fromto="0 0 0 -.3 0 0" fluidshape="ellipsoid" fluidcoef=".6 .3 1.2 .8 .9"/><geom type="sphere" size=".05" pos="-.15 0 .06"/>
+        <body pos="-.3 0 0"><joint name="r2" axis="0 0 1" range="-100 100" limited="true"/><geom fromto="0 0 0 -.3 0 0" size=".03"/></body></body>
+    </body>
+    <body pos="1 1 0" euler="20 30 40"><freejoint/><geom type="box" size=".1 .05 .2" density="700" fluidshape="ellipsoid"/></body>
+    <body pos="-1 1 0" euler="50 10 0"><freejoint/><geom type="ellipsoid" size=".1 .06 .03" density="500" fluidshape="ellipsoid" fluidcoef=".5 .25 1.5 1 1"/>
+      <body pos=".15 0 0"><joint axis="0 1 0"/><geom type="cylinder" size=".03 .08" fluidshape="ellipsoid"/></body></body>
+    <body pos="0 -1 0"><freejoint/><geom type="sphere" size=".07" density="300" fluidshape="ellipsoid"/></body>
+  </worldbody>
+  <actuator><motor joint="r1" gear="3"/><motor joint="r2" gear="3"/></actuator>
+</mujoco>
+"""
+
+
 # three separate trees, each tied to the world by its own equality: three constraint islands made
 # of equality rows only (the primal solvers visit them one after the other)
 ISLANDS_XML = """

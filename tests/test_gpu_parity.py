@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -536,6 +536,27 @@ def test_fluid_forces_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
     b = K.Batch(dmf, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("fluid scene rel err", relerr(out, ref))
+    assert relerr(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("integrator", [0, 2, 3])
+def test_ellipsoid_fluid_model_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
+    """the ellipsoid fluid model per geom (added mass, lift, drag) and its velocity derivative under the implicit integrators"""
+    xml = tmp_path / "efluid.xml"
+    xml.write_text(ELLIPSOID_FLUID_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dmf = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 150
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dmf, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("ellipsoid fluid scene integrator", integrator, "rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL
 
 

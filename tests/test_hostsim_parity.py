@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -754,6 +754,28 @@ def test_fluid_forces_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
     T = 80
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ref, _ = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("integrator", [0, 1, 2, 3])
+def test_ellipsoid_fluid_model_bit_exact(rb, hostsim_lib, tmp_path, integrator):
+    """mj_ellipsoidFluidModel (engine_passive.c:1213-1410): added mass, Magnus and Kutta lift, viscous drag and torque per
+    geom, next to inertia-box bodies; under the implicit integrators the 6 x 6 derivative of every geom's wrench enters
+    qDeriv (mjd_ellipsoidFluid, engine_derivative.c:2531-2880; symmetrised under implicitfast except on standalone free bodies)"""
+    xml = tmp_path / "efluid.xml"
+    xml.write_text(ELLIPSOID_FLUID_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 60
     ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
     ref, _ = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dm, 1)
