@@ -1530,6 +1530,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     const int mat = m->geom_matid[g];
     if ((mat < 0 && m->geom_rgba[4*g + 3] == 0) || (mat >= 0 && m->mat_rgba[4*mat + 3] == 0)) H->geom_rayskip[g] = 1;
   }
+  bool use_cameras = false;
   for (int i = 0; i < m->nsensor; i++) {
     int t = -1;
     switch (m->sensor_type[i]) {
@@ -1570,6 +1571,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_MAGNETOMETER: t = MJH_SENS_MAGNETOMETER; break;
       case mjSENS_INSIDESITE: t = MJH_SENS_INSIDESITE; break;
       case mjSENS_TENDONACTFRC: t = MJH_SENS_TENDONACTFRC; break;
+      case mjSENS_CAMPROJECTION:
+        // (round 6: a site projected into a camera's image, engine_sensor.c:541-545; the focal lengths are model constants)
+        if (m->sensor_objtype[i] == mjOBJ_SITE && m->sensor_reftype[i] == mjOBJ_CAMERA) { t = MJH_SENS_CAMPROJECTION; use_cameras = true; }
+        break;
       case mjSENS_RANGEFINDER:
         // site-attached rangefinders (camera-attached ones cast a ray per pixel: not evaluated)
         if (m->sensor_objtype[i] == mjOBJ_SITE) {
@@ -1601,11 +1606,13 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       else if (ot == mjOBJ_XBODY) *out = MJH_OBJ_XBODY;
       else if (ot == mjOBJ_GEOM) *out = MJH_OBJ_GEOM;
       else if (ot == mjOBJ_SITE) *out = MJH_OBJ_SITE;
+      else if (ot == mjOBJ_CAMERA) { *out = MJH_OBJ_CAMERA; use_cameras = true; }     // (round 6: camera frames, mj_camlight)
       else return false;
       return true;
     };
+    if (t == MJH_SENS_CAMPROJECTION) { H->sensor_objtype[i] = MJH_OBJ_SITE; H->sensor_reftype[i] = MJH_OBJ_CAMERA; }
     if (t == MJH_SENS_INSIDESITE)
-      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "insidesite sensors attached to cameras");
+      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "insidesite sensors attached to objects without a frame");
     if (t == MJH_SENS_CONTACT) {
       // (either side: nothing -- mjOBJ_UNKNOWN --, a site's volume, a geom, a body, a subtree)
       auto side = [&](int ot, int* out) -> bool { if (ot == mjOBJ_UNKNOWN) { *out = MJH_OBJ_NONE; return true; } return frame_obj(ot, out); };
@@ -1613,9 +1620,33 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
                  "contact sensors matched against objects other than sites / geoms / bodies / subtrees");
     }
     if (t >= MJH_SENS_FRAMEPOS && t <= MJH_SENS_FRAMEANGACC) {
-      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "frame sensors attached to cameras");
+      MJH_REJECT(!frame_obj(m->sensor_objtype[i], &H->sensor_objtype[i]), "frame sensors attached to objects without a frame");
       if (m->sensor_refid[i] >= 0)
-        MJH_REJECT(!frame_obj(m->sensor_reftype[i], &H->sensor_reftype[i]), "frame sensors with a camera reference frame");
+        MJH_REJECT(!frame_obj(m->sensor_reftype[i], &H->sensor_reftype[i]), "frame sensors with a reference object without a frame");
+    }
+  }
+  // cameras that sensors use: the inputs of mj_camlight (engine_core_smooth.c:354-432) and cam_project's constants
+  s.ncam_s = (use_cameras && m->ncam > 0) ? m->ncam : 0;
+  H->cam_bodyid.clear(); H->cam_mode.clear(); H->cam_targetbodyid.clear(); H->cam_pos.clear(); H->cam_quat.clear();
+  H->cam_mat0.clear(); H->cam_pos0.clear(); H->cam_poscom0.clear(); H->cam_proj.clear();
+  if (s.ncam_s) {
+    copy_arr(H->cam_bodyid, m->cam_bodyid, m->ncam);
+    copy_arr(H->cam_mode, m->cam_mode, m->ncam);
+    copy_arr(H->cam_targetbodyid, m->cam_targetbodyid, m->ncam);
+    copy_arr(H->cam_pos, m->cam_pos, 3*(size_t)m->ncam);
+    copy_arr(H->cam_quat, m->cam_quat, 4*(size_t)m->ncam);
+    copy_arr(H->cam_mat0, m->cam_mat0, 9*(size_t)m->ncam);
+    copy_arr(H->cam_pos0, m->cam_pos0, 3*(size_t)m->ncam);
+    copy_arr(H->cam_poscom0, m->cam_poscom0, 3*(size_t)m->ncam);
+    H->cam_proj.assign(4*(size_t)m->ncam, 0);
+    for (int c = 0; c < m->ncam; c++) {
+      const float* ss = m->cam_sensorsize + 2*c;
+      const float* in = m->cam_intrinsic + 4*c;
+      const int* res = m->cam_resolution + 2*c;
+      mjtNum fx, fy;
+      if (ss[0] && ss[1]) { fx = in[0] / ss[0] * res[0]; fy = in[1] / ss[1] * res[1]; }
+      else { fx = fy = .5 / std::tan(m->cam_fovy[c] * mjPI / 360.) * res[1]; }
+      H->cam_proj[4*c] = fx; H->cam_proj[4*c + 1] = fy; H->cam_proj[4*c + 2] = (mjtNum)res[0]; H->cam_proj[4*c + 3] = (mjtNum)res[1];
     }
   }
   for (int k = 0; k < 3; k++) o.magnetic[k] = m->opt.magnetic[k];

@@ -38,6 +38,7 @@ MJH_DEV SensFrame sens_frame(MREF M, BREF B, int e, int objtype, int id) {
   if (objtype == MJH_OBJ_BODY) { f.pos = MJH_F(B, xipos, e) + 3*id; f.mat = MJH_F(B, ximat, e) + 9*id; f.body = id; }
   else if (objtype == MJH_OBJ_XBODY) { f.pos = MJH_F(B, xpos, e) + 3*id; f.mat = MJH_F(B, xmat, e) + 9*id; f.body = id; }
   else if (objtype == MJH_OBJ_GEOM) { f.pos = MJH_F(B, geom_xpos, e) + 3*id; f.mat = MJH_F(B, geom_xmat, e) + 9*id; f.body = M.geom_bodyid[id]; }
+  else if (objtype == MJH_OBJ_CAMERA) { f.pos = MJH_G(B, cam_xpos, e) + 3*id; f.mat = MJH_G(B, cam_xmat, e) + 9*id; f.body = M.cam_bodyid[id]; }
   else { f.pos = MJH_F(B, site_xpos, e) + 3*id; f.mat = MJH_F(B, site_xmat, e) + 9*id; f.body = M.site_bodyid[id]; }
   return f;
 }
@@ -46,6 +47,7 @@ MJH_DEV void sens_quat(MREF M, BREF B, int e, int objtype, int id, real* quat) {
   if (objtype == MJH_OBJ_XBODY) q_copy(quat, xquat + 4*id);
   else if (objtype == MJH_OBJ_BODY) q_mul(quat, xquat + 4*id, M.body_iquat + 4*id);
   else if (objtype == MJH_OBJ_GEOM) q_mul(quat, xquat + 4*M.geom_bodyid[id], M.geom_quat + 4*id);
+  else if (objtype == MJH_OBJ_CAMERA) q_mul(quat, xquat + 4*M.cam_bodyid[id], M.cam_quat + 4*id);
   else q_mul(quat, xquat + 4*M.site_bodyid[id], M.site_quat + 4*id);
 }
 
@@ -406,6 +408,39 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
   MJH_ENTER(M_, B_, e_);
   const MJH_CONST_AS DSizes& s = M.s;
   if (!s.nsensor || (M.o.disableflags & (1<<13))) return;
+  // camera frames (mj_camlight, engine_core_smooth.c:354-432), one lane per camera, before the position-stage sensors
+  if (s.ncam_s && (which & 1)) {
+    crptr xpos = MJH_F(B, xpos, e);
+    crptr xquat = MJH_F(B, xquat, e);
+    crptr xmat = MJH_F(B, xmat, e);
+    crptr com = MJH_F(B, subtree_com, e);
+    rptr cpos = MJH_G(B, cam_xpos, e);
+    rptr cmat = MJH_G(B, cam_xmat, e);
+    MJH_FOR_LANES(c, s.ncam_s) {
+      const int id = M.cam_bodyid[c], id1 = M.cam_targetbodyid[c], mode = M.cam_mode[c];
+      real p[3], R[9];
+      local2global(p, R, M.cam_pos + 3*c, M.cam_quat + 4*c, xpos + 3*id, xquat + 4*id, xmat + 9*id, xpos, xmat, MJH_SAMEFRAME_NONE);
+      if (mode == 1 || mode == 2) {            // mjCAMLIGHT_TRACK / TRACKCOM: fixed global orientation
+        for (int k = 0; k < 9; k++) R[k] = M.cam_mat0[9*c + k];
+        if (mode == 1) for (int k = 0; k < 3; k++) p[k] = xpos[3*id + k] + M.cam_pos0[3*c + k];
+        else for (int k = 0; k < 3; k++) p[k] = com[3*id + k] + M.cam_poscom0[3*c + k];
+      } else if ((mode == 3 || mode == 4) && id1 >= 0) {     // TARGETBODY / TARGETBODYCOM: look at the target
+        real t[3], T[9];
+        for (int k = 0; k < 3; k++) t[k] = mode == 3 ? (real)xpos[3*id1 + k] : (real)com[3*id1 + k];
+        v3_sub(T + 6, p, t);
+        v3_normalize(T + 6);
+        T[3] = 0; T[4] = 0; T[5] = 1;
+        v3_cross(T, T + 3, T + 6);
+        v3_normalize(T);
+        v3_cross(T + 3, T + 6, T);
+        v3_normalize(T + 3);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3*j + i] = T[3*i + j];
+      }
+      for (int k = 0; k < 3; k++) cpos[3*c + k] = p[k];
+      for (int k = 0; k < 9; k++) cmat[9*c + k] = R[k];
+    }
+    wv_sync();
+  }
   if (wv_lane() == 0) {
     if (s.sens_subtreevel && (which & 2)) sens_subtree_vel(M, B, e);
     if (s.sens_rnepost && (which & 4)) sens_rne_post(M, B, e);
@@ -459,6 +494,22 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
         if (type == MJH_SENS_FRAMEPOS) { real rv[3]; v3_sub(rv, a, r.pos); m3_multvec(v, r.mat, rv); }
         else m3_multvec(v, r.mat, a);
       }
+    } break;
+    case MJH_SENS_CAMPROJECTION: {
+      // cam_project (engine_sensor.c:281-316): the site in the camera frame, pinhole projection to pixels
+      crptr tp = MJH_F(B, site_xpos, e) + 3*objid;
+      crptr cp = MJH_G(B, cam_xpos, e) + 3*refid;
+      crptr cm = MJH_G(B, cam_xmat, e) + 9*refid;
+      const real fx = M.cam_proj[4*refid], fy = M.cam_proj[4*refid + 1], rx = M.cam_proj[4*refid + 2], ry = M.cam_proj[4*refid + 3];
+      real rel[3], cpv[3];
+      v3_sub(rel, tp, cp);
+      // (mju_mulMatTVec: rows of the matrix in order, zero components of the vector skipped)
+      for (int k = 0; k < 3; k++) cpv[k] = 0;
+      for (int r = 0; r < 3; r++) { const real t = rel[r]; if (t) for (int k = 0; k < 3; k++) cpv[k] += cm[3*r + k]*t; }
+      real denom = cpv[2];
+      if (fabs(denom) < MJH_MINVAL) denom = denom < 0 ? r_min(denom, -MJH_MINVAL) : r_max(denom, MJH_MINVAL);
+      v[0] = -fx * (cpv[0] / denom) + 0.5 * rx;
+      v[1] = fy * (cpv[1] / denom) + 0.5 * ry;
     } break;
     case MJH_SENS_FRAMEQUAT: {
       real oq[4];

@@ -119,6 +119,10 @@
   X(jnt_actfrclimited, s.njnt)                 \
   /* dofs whose joint takes its gravity compensation through qfrc_actuator (jnt_actgravcomp) */ \
   X(dof_actgravcomp, s.nv_actgc)               \
+  /* cameras that sensors refer to (frame sensors on cameras, camprojection; sizes 0 otherwise): mj_camlight's inputs */ \
+  X(cam_bodyid, s.ncam_s)                      \
+  X(cam_mode, s.ncam_s)                        \
+  X(cam_targetbodyid, s.ncam_s)                \
   /* 1: some geom of the body uses the ellipsoid fluid model (the inertia-box model is then off for the body) */ \
   X(body_ellipsoid, (s.ngeom_fluid ? s.nbody : 0)) \
   X(pair_geom1, (s.npair + s.nflexpair))                       \
@@ -350,6 +354,13 @@
   X(geom_size, 3 * s.ngeom)                    \
   /* ellipsoid fluid model (geoms with fluidshape = ellipsoid; sizes 0 otherwise): the twelve interaction coefficients of a  \
      geom (mjNFLUID) and its semi-axes (mju_geomSemiAxes) */ \
+  X(cam_pos, 3 * s.ncam_s)                     \
+  X(cam_quat, 4 * s.ncam_s)                    \
+  X(cam_mat0, 9 * s.ncam_s)                    \
+  X(cam_pos0, 3 * s.ncam_s)                    \
+  X(cam_poscom0, 3 * s.ncam_s)                 \
+  /* camprojection: focal lengths in pixels (fx, fy) and the resolution (cam_project, engine_sensor.c:281-316; model constants) */ \
+  X(cam_proj, 4 * s.ncam_s)                    \
   X(geom_fluid, 12 * s.ngeom_fluid)            \
   X(geom_semiaxes, 3 * s.ngeom_fluid)          \
   X(geom_rbound, s.ngeom)                      \
@@ -456,6 +467,7 @@ enum {
 
 struct DSizes {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, nC, nJten, ntree;
+  int ncam_s;          // ncam when some sensor is attached to / projects into a camera, else 0
   int ngeom_fluid;     // ngeom when some geom uses the ellipsoid fluid model, else 0
   int nv_actgc;        // nv when some joint has actuator-level gravity compensation, else 0
   int nD, nB;          // the fully implicit integrator: entries of qDeriv's pattern, of the body-by-dof pattern (else 0)
@@ -752,6 +764,9 @@ enum {
   /* ellipsoid fluid model, per geom: the wrench in the world frame (6), then the 6 x 6 derivative of the local wrench with  \
      respect to the local velocity (implicit integrators; mjd_ellipsoidFluid) */ \
   X(fluid_geom, 42 * s.ngeom_fluid, 0, MJH_T_GLB, MJH_T_GLB)                      \
+  /* camera frames (mj_camlight), evaluated with the position-stage sensors */ \
+  X(cam_xpos, 3 * s.ncam_s, 0, MJH_T_GLB, MJH_T_GLB)                              \
+  X(cam_xmat, 9 * s.ncam_s, 0, MJH_T_GLB, MJH_T_GLB)                              \
   X(qfrc_gravcomp, s.nv_actgc, 0, MJH_T_GLB, MJH_T_GLB)                            \
   X(qDeriv, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                        \
   X(qLU, s.nD, 0, MJH_T_GLB, MJH_T_GLB)                                           \
@@ -987,8 +1002,8 @@ enum {
   MJH_SENS_FRAMEANGACC, MJH_SENS_SUBTREECOM, MJH_SENS_SUBTREELINVEL, MJH_SENS_SUBTREEANGMOM, MJH_SENS_CLOCK,
   MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
   MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
-  MJH_SENS_CONTACT,
-  MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4,
+  MJH_SENS_CONTACT, MJH_SENS_CAMPROJECTION,
+  MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4, MJH_OBJ_CAMERA = 5,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3, MJH_DYN_MUSCLE = 4,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,
   MJH_INT_EULER = 0, MJH_INT_RK4 = 1, MJH_INT_IMPLICIT = 2, MJH_INT_IMPLICITFAST = 3,

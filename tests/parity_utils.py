@@ -586,6 +586,50 @@ ELLIPSOID_FLUID_XML = """
 """
 
 
+# cameras in every mode of mj_camlight (fixed, track, trackcom, targetbody, targetbodycom) with frame sensors attached to
+# them / referenced to them, and sites projected into their images (pinhole by fovy, and by intrinsics + sensor size)
+CAMERA_XML = """
+<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <camera name="world_cam" pos="0 -2 1.5" xyaxes="1 0 0 0 .6 .8" fovy="50" resolution="640 480"/>
+    <body name="base" pos="0 0 .8">
+      <joint name="j0" axis="0 0 1"/><geom type="capsule" fromto="0 0 0 .3 0 0" size=".03"/>
+      <camera name="fixed_cam" pos=".1 0 .1" euler="10 20 30" fovy="40" resolution="320 240"/>
+      <camera name="track_cam" mode="track" pos="0 -1 .5" xyaxes="1 0 0 0 0 1"/>
+      <camera name="trackcom_cam" mode="trackcom" pos="0 -1.5 .7" xyaxes="1 0 0 0 .5 1"/>
+      <body name="arm" pos=".3 0 0">
+        <joint name="j1" axis="0 1 0"/><geom type="capsule" fromto="0 0 0 .25 0 0" size=".025"/>
+        <site name="tip" pos=".25 0 0"/>
+        <camera name="target_cam" mode="targetbody" target="ball" pos="0 0 .2"/>
+        <camera name="intr_cam" pos=".1 .05 .05" euler="0 90 0" resolution="800 600" sensorsize=".0036 .0027" focal=".004 .004"/>
+      </body>
+    </body>
+    <body name="ball" pos=".6 .4 .5"><freejoint/><geom type="sphere" size=".05"/><site name="ballsite"/>
+      <camera name="targetcom_cam" mode="targetbodycom" target="base" pos="0 0 .1"/></body>
+  </worldbody>
+  <actuator><motor joint="j0" gear="2"/><motor joint="j1" gear="2"/></actuator>
+  <sensor>
+    <framepos objtype="camera" objname="fixed_cam"/><framequat objtype="camera" objname="fixed_cam"/>
+    <framexaxis objtype="camera" objname="track_cam"/><framepos objtype="camera" objname="track_cam"/>
+    <framepos objtype="camera" objname="trackcom_cam"/><framezaxis objtype="camera" objname="trackcom_cam"/>
+    <framepos objtype="camera" objname="target_cam"/><framexaxis objtype="camera" objname="target_cam"/>
+    <frameyaxis objtype="camera" objname="target_cam"/><framezaxis objtype="camera" objname="target_cam"/>
+    <framezaxis objtype="camera" objname="targetcom_cam"/><framepos objtype="camera" objname="targetcom_cam"/>
+    <framelinvel objtype="camera" objname="fixed_cam"/><frameangvel objtype="camera" objname="target_cam"/>
+    <framelinacc objtype="camera" objname="fixed_cam"/><frameangacc objtype="camera" objname="intr_cam"/>
+    <framepos objtype="site" objname="ballsite" reftype="camera" refname="fixed_cam"/>
+    <framequat objtype="body" objname="ball" reftype="camera" refname="target_cam"/>
+    <framelinvel objtype="site" objname="tip" reftype="camera" refname="world_cam"/>
+    <camprojection site="ballsite" camera="world_cam"/><camprojection site="tip" camera="fixed_cam"/>
+    <camprojection site="ballsite" camera="intr_cam"/><camprojection site="ballsite" camera="target_cam"/>
+    <camprojection site="tip" camera="trackcom_cam"/>
+  </sensor>
+</mujoco>
+"""
+
+
 # three separate trees, each tied to the world by its own equality: three constraint islands made
 # of equality rows only (the primal solvers visit them one after the other)
 ISLANDS_XML = """

@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -537,6 +537,31 @@ def test_fluid_forces_vs_live_oracle(rb, hip_lib, tmp_path, integrator):
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("fluid scene rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL
+
+
+def test_camera_sensors_vs_live_oracle(rb, hip_lib, tmp_path):
+    """cameras in every mj_camlight mode, frame sensors attached / referenced to them, camprojection: sensordata every step"""
+    xml = tmp_path / "cam.xml"
+    xml.write_text(CAMERA_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dmc = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 200
+    ctrl = np.random.default_rng(0).uniform(-3, 3, (1, T, m.nu))
+    ref = np.zeros((1, T, s0.shape[1])); sref = np.zeros((1, T, m.nsensordata))
+    rb.mj_setState(m, d, s0[0], rb.mjSTATE_FULLPHYSICS)
+    for t in range(T):
+        d.ctrl[:] = ctrl[0, t]
+        rb.mj_step(m, d)
+        ref[0, t] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+        sref[0, t] = d.sensordata
+    b = K.Batch(dmc, 1)
+    out, sd = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl, want_sensordata=True)
+    print("camera scene rel err state", relerr(out, ref), "sensordata", relerr(sd, sref))
+    assert relerr(out, ref) <= TOL and relerr(sd, sref) <= TOL
 
 
 @pytest.mark.parametrize("integrator", [0, 2, 3])

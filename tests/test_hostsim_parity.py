@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -1127,6 +1127,26 @@ def test_sensors_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     rb.mj_forward(m, d)
     b.forward()
     assert relerr(b.get("sensordata")[0], np.array(d.sensordata)) <= 1e-12
+
+
+def test_camera_sensors_bit_exact(rb, hostsim_lib, tmp_path):
+    """mj_camlight (engine_core_smooth.c:354-432: fixed / track / trackcom / targetbody / targetbodycom cameras), frame
+    sensors attached to and referenced to cameras, camprojection (engine_sensor.c:281-316, :541): sensordata every step"""
+    xml = tmp_path / "cam.xml"
+    xml.write_text(CAMERA_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    dm = K.DeviceModel(hostsim_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[:] = np.random.default_rng(1).normal(0, .5, m.nv)
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 120
+    ctrl = np.random.default_rng(0).uniform(-3, 3, (1, T, m.nu))
+    ref, sref = _sensor_reference(rb, m, s0, ctrl)
+    b = K.Batch(dm, 1)
+    out, sd = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl, want_sensordata=True)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(sd, sref)
 
 
 @pytest.mark.parametrize("integrator", [0, 1, 3])
