@@ -289,12 +289,16 @@ def test_implicitfast_vs_live_oracle(rb, hip_lib, tmp_path, solver, integrator):
     dmi = K.DeviceModel(hip_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
-    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
-    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    # (three environments with their own initial velocities and controls: every per-environment address is exercised)
+    NE = 3
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(1 + k).normal(0, 1.0, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     T = 100
-    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (NE, T, m.nu))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
-    b = K.Batch(dmi, 1)
+    b = K.Batch(dmi, NE)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("implicitfast scene solver", solver, "rel err", relerr(out, ref), "max nefc", ints[0, :, 1].max())
     assert relerr(out, ref) <= TOL
@@ -574,12 +578,16 @@ def test_ellipsoid_fluid_model_vs_live_oracle(rb, hip_lib, tmp_path, integrator)
     dmf = K.DeviceModel(hip_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
-    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
-    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    # (three environments with their own initial velocities and controls: every per-environment address is exercised)
+    NE = 3
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(1 + k).normal(0, 1.0, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     T = 150
-    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (NE, T, m.nu))
     ref, _ = oracle_rollout(rb, m, s0, ctrl)
-    b = K.Batch(dmf, 1)
+    b = K.Batch(dmf, NE)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("ellipsoid fluid scene integrator", integrator, "rel err", relerr(out, ref))
     assert relerr(out, ref) <= TOL

@@ -435,12 +435,16 @@ def test_implicit_integrator(rb, hostsim_lib, tmp_path, solver, tol):
     dm = K.DeviceModel(hostsim_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
-    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
-    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    # (three environments with their own initial velocities and controls: every per-environment address is exercised)
+    NE = 3
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(1 + k).normal(0, 1.0, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     T = 80 if solver == 0 else 40
-    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (NE, T, m.nu))
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
-    b = K.Batch(dm, 1)
+    b = K.Batch(dm, NE)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     if tol == 0.0:
         assert np.array_equal(out, ref)
@@ -773,12 +777,16 @@ def test_ellipsoid_fluid_model_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     dm = K.DeviceModel(hostsim_lib, m)
     d = rb.MjData(m)
     rb.mj_resetData(m, d)
-    d.qvel[:] = np.random.default_rng(1).normal(0, 1.0, m.nv)
-    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    # (three environments with their own initial velocities and controls: every per-environment address is exercised)
+    NE = 3
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(1 + k).normal(0, 1.0, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
     T = 60
-    ctrl = np.random.default_rng(0).uniform(-1, 1, (1, T, m.nu))
+    ctrl = np.random.default_rng(0).uniform(-1, 1, (NE, T, m.nu))
     ref, _ = oracle_rollout(rb, m, s0, ctrl)
-    b = K.Batch(dm, 1)
+    b = K.Batch(dm, NE)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     assert np.array_equal(out, ref)
 
