@@ -14,6 +14,7 @@
 #   regime           tools/regime_stats.py (testspeed regime: per-environment cost against the constraint count), both sweeps
 #   tail             tools/tail_stats.py
 #   sweep            tools/model_sweep.py over tests/golden/sweep with libmjhip.so on the device, against the live oracle
+#   sweeplong[:N]    the same over N steps (default 100) instead of the fixtures' 15
 #   flexab[:t1,t2]   tools/gpu_flex_ab.sh: flex bench, current build against earlier trees (tools/variants/<t>_tree; default r04)
 #   ablib:<variant.so>   tools/gpu_ab_lib.sh: shipped library against tools/variants/<variant.so>, three alternating pairs
 #   resources        kernel resource usage (VGPRs, scratch, spills) of the shipped code object
@@ -88,6 +89,10 @@ for step in "$@"; do
       head -3 "$OUT/sweep_gpu/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu/sweep.txt" | head -40
       ( time timeout 2400 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 1600 --oracle parity --out "$OUT/sweep_gpu_glibc" > "$OUT/sweep_gpu_glibc.log" 2>&1 ) 2>&1 | grep real
       head -3 "$OUT/sweep_gpu_glibc/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu_glibc/sweep.txt" | grep -v rejected | head -20 ;;
+    sweeplong)
+      # the same sweep over a longer horizon (default 100 steps; sweeplong:<steps>), against the reference linked with the kernels' libm
+      ( time timeout 3000 python tools/model_sweep.py --from-mjb tests/golden/sweep --device --nvmax 1600 --steps ${rest:-100} --out "$OUT/sweep_gpu_long" > "$OUT/sweep_gpu_long.log" 2>&1 ) 2>&1 | grep real
+      head -3 "$OUT/sweep_gpu_long/sweep.txt"; grep -v "^ok\|^#" "$OUT/sweep_gpu_long/sweep.txt" | grep -v rejected | head -40 ;;
     flexab)
       bash tools/gpu_flex_ab.sh "gpurun_out/$TAG/flex_ab" ${args:-r04} 2>&1 | tee "$OUT/flex_ab.txt" ;;
     ablib)
