@@ -136,6 +136,31 @@ MJH_DEVN_HOT real dn_solve(PL L, int nv, real y0) {
   }
   return y0;
 }
+// the same for an island that leaves dofs out (`mask`: the island's dofs): the reference solves the island-local system, so
+// the row dots of the forward substitution group the island's finished entries by their position inside the island; rows
+// outside the island carry a zero right-hand side and are skipped
+template <class PL>
+MJH_DEVN real dn_solve_isl(PL L, int nv, real y0, uint64_t mask) {
+  const int lane = wv_lane();
+  const real dg = lane < nv ? (real)L[nt_lx(nv, lane, lane)] : (real)1;
+  for (int i = 0; i < nv; i++) {
+    if (!((mask >> i) & 1)) continue;
+    const real p0 = lane < i ? (real)(L[nt_lx(nv, lane, i)]*y0) : (real)0;
+    real yi = wv_bcast(y0, i);
+    yi -= wv_dot4m(p0, (real)0, mask & ((1ull << i) - 1), 0ull, 1);
+    yi /= wv_bcast(dg, i);
+    if (lane == i) y0 = yi;
+  }
+  for (int i = nv - 1; i >= 0; i--) {
+    if (!((mask >> i) & 1)) continue;
+    const real p0 = (lane > i && lane < nv) ? (real)(L[nt_lx(nv, i, lane)]*y0) : (real)0;
+    real yi = wv_bcast(y0, i);
+    yi = wv_chain(yi, p0, i + 1, nv, 1);
+    yi /= wv_bcast(dg, i);
+    if (lane == i) y0 = yi;
+  }
+  return y0;
+}
 // mju_cholUpdate(L, x, flg_plus); returns the number of clamped pivots
 template <class PL>
 MJH_DEVN_HOT int dn_update(PL L, int nv, real x0, int flg_plus) {
@@ -489,6 +514,32 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // (sparse path: the reference's vectors are island-local -- the island's dofs in ascending order, contiguous -- so
   // mju_dot groups them by their position inside the island: ordered reduction over the island's dof mask)
   M128 isl_dofs = m128_below(nv);
+  // (dense path, an island that leaves trees out: the reference's dense vectors and matrices are island-local too --
+  // PrimalPointers, engine_solver.c:1148-1290 -- so every mju_dot groups its operands by their position INSIDE the island.
+  // dpart marks that case; the dots below then walk the island's dof mask instead of [0, nv).)
+  int dpart = 0;
+  // mju_dot over the island's dofs, evaluated by one lane on its own: fn(i) = the product at dof i; elements below `lim`
+  auto dot_isl = [&](int lim, auto fn) -> real {
+    uint64_t lo = isl_dofs.lo, hi = isl_dofs.hi;
+    if (lim < 64) { lo &= lim > 0 ? ((1ull << lim) - 1) : 0ull; hi = 0; }
+    else if (lim < 128) hi &= lim > 64 ? ((1ull << (lim - 64)) - 1) : 0ull;
+    const int cnt = __builtin_popcountll(lo) + __builtin_popcountll(hi);
+    auto next = [&]() -> int {
+      if (lo) { const int b = __builtin_ctzll(lo); lo &= lo - 1; return b; }
+      const int b = __builtin_ctzll(hi); hi &= hi - 1; return 64 + b;
+    };
+    real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (int g = cnt >> 2; g > 0; g--) {
+      const int i0 = next(), i1 = next(), i2 = next(), i3 = next();
+      r0 += fn(i0); r1 += fn(i1); r2 += fn(i2); r3 += fn(i3);
+    }
+    real res = (r0 + r2) + (r1 + r3);
+    const int rem = cnt & 3;
+    if (rem == 3) { const int i0 = next(), i1 = next(), i2 = next(); res += fn(i0) + fn(i1) + fn(i2); }
+    else if (rem == 2) { const int i0 = next(), i1 = next(); res += fn(i0) + fn(i1); }
+    else if (rem == 1) { const int i0 = next(); res += fn(i0); }
+    return res;
+  };
   // (SPA = 2, mjh_csr.h: the island's dofs as a list, ascending -- the reference's island-local vectors; sums take the four
   // accumulator chains of mju_dot over positions in that list, one chain per lane, several products at a time: csr_dots)
   iptr idof = MJH_G(B, csr_idof, e);
@@ -568,7 +619,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       return wv_dot4m(p0, p1, isl_dofs.lo, isl_dofs.hi, 1);
     }
     if (!multi_tree) return dot_ref(a, b, nv);
-    real r0 = 0, r1 = 0, r2 = 0, r3 = 0;      // masked: the island's dofs only (vectors are zero elsewhere anyway)
+    if (dpart) return dot_isl(nv, [&](int i) -> real { return a[i]*b[i]; });
+    real r0 = 0, r1 = 0, r2 = 0, r3 = 0;      // the island spans every dof: mju_dot over [0, nv)
     int i = 0;
     for (; i <= nv - 4; i += 4) { r0 += a[i]*b[i]; r1 += a[i+1]*b[i+1]; r2 += a[i+2]*b[i+2]; r3 += a[i+3]*b[i+3]; }
     real res = (r0 + r2) + (r1 + r3);
@@ -614,6 +666,14 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   // out = J v (mju_mulMatVec: one mju_dot per row), optionally - aref
   auto mul_J = [&](rptr out, crptr v, int sub_aref) {
     MJH_FOR_LANES(r, nefc) {
+      if (!SPA && dpart) {
+        // (the island's rows over the island's columns: the reference's island-local dense J)
+        if (!in_row(r)) continue;
+        crptr Jr = J + (size_t)r*nv;
+        const real acc = dot_isl(nv, [&](int i) -> real { return Jr[i]*v[i]; });
+        out[r] = sub_aref ? acc - aref[r] : acc;
+        continue;
+      }
       const real acc = SPA == 2 ? csr_row_dot(P, r, v) : SPA ? sp_row_dot(P, r, v) : dot_ref(J + (size_t)r*nv, v, nv);
       out[r] = sub_aref ? acc - aref[r] : acc;
     }
@@ -813,6 +873,9 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto chol_factor = [&](rptr L) {
     // mju_dot over the finished columns c < j of rows i and j
     auto rowdot = [&](int i, int j) -> real {
+      // (column of an island that leaves trees out: the finished columns of the ISLAND, grouped by their position in it;
+      //  rows and columns of other trees hold exact zeros against the island's and are factorised in the global order)
+      if (dpart && m128_test(isl_dofs, j)) return dot_isl(j, [&](int c) -> real { return L[LX(c, i)]*L[LX(c, j)]; });
       real r0 = 0, r1 = 0, r2 = 0, r3 = 0;
       int c = 0;
       for (; c <= j - 4; c += 4) {
@@ -855,6 +918,8 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
   auto chol_solve = [&](crptr L) {
     if (!two) {
       real y = lane < nv ? (real)grad[lane] : (real)0;
+      if (dpart) y = mjh_in_lds(L) ? dn_solve_isl(mjh_local(L.p), nv, y, isl_dofs.lo) : dn_solve_isl(L, nv, y, isl_dofs.lo);
+      else
       y = mjh_in_lds(L) ? dn_solve(mjh_local(L.p), nv, y) : dn_solve(L, nv, y);
       if (lane < nv) Mgrad[lane] = y;
       wv_sync();
@@ -866,6 +931,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
       const real p0 = lane < i ? L[LX(lane, i)]*y0 : (real)0;
       const real p1 = (two && lane + MJH_W < i) ? L[LX((lane + MJH_W), i)]*y1 : (real)0;
       real yi = dof_get(y0, y1, i);
+      if (dpart) {
+        if (!m128_test(isl_dofs, i)) continue;       // (a dof outside the island: its gradient entry is zero and stays zero)
+        const uint64_t blo = i < 64 ? (i ? ((1ull << i) - 1) : 0ull) : ~0ull;
+        const uint64_t bhi = i > 64 ? ((1ull << (i - 64)) - 1) : 0ull;
+        yi -= wv_dot4m(p0, p1, isl_dofs.lo & blo, isl_dofs.hi & bhi, 1);
+      } else
       if (i) yi -= dot_lanes(p0, p1, i);
       yi /= L[LX(i, i)];
       if (i < MJH_W) { if (lane == i) y0 = yi; } else { if (lane == i - MJH_W) y1 = yi; }
@@ -1233,6 +1304,12 @@ MJH_DEVN void solve_primal(MREF M_, BREF B_, int e_, int flg_newton) {
     } else if (SPA) {
       isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
       isl_dofs.hi = wv_ballot(lane + MJH_W < nv && in_dof(lane + MJH_W));
+    } else if (multi_tree) {
+      // dense path: does this island leave dofs out?  Then its sums run over the island-local vectors of the reference
+      isl_dofs.lo = wv_ballot(lane < nv && in_dof(lane));
+      isl_dofs.hi = wv_ballot(lane + MJH_W < nv && in_dof(lane + MJH_W));
+      dpart = __builtin_popcountll(isl_dofs.lo) + __builtin_popcountll(isl_dofs.hi) != nv;
+      if (dpart) mul_J(jar, qacc, 1);          // (Jaref of the island's rows: J qacc in the island's own grouping)
     }
     if (fused) { update_rows(); run_pass(CSR_OP_GRAD, 0, 0); }
     else { update_constraint(); update_grad(); }

@@ -1213,6 +1213,16 @@ def test_sparse_primal_solvers_on_gpu(rb, hip_lib, tmp_path, scene, solver, cone
     assert ints[:, 1].max() > 0 and ints[:, 2].max() > 0
 
 
+@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0)], ids=["newton-pyr", "newton-ell", "cg-pyr"])
+def test_primal_solvers_partial_islands_dense_on_gpu(rb, hip_lib, tmp_path, solver, cone):
+    """islands that leave trees out, dense path: sums over the reference's island-local vectors (round 6; the CPU
+    counterpart is tests/test_hostsim_parity.py::test_primal_solvers_partial_islands_dense_bit_exact).  Bit for bit
+    against the reference linked with the kernels' sin / cos."""
+    import test_hostsim_parity as th
+    out, ref = th._partial_islands(rb, hip_lib, tmp_path, solver, cone, kind="devmath")
+    assert np.array_equal(out, ref), relerr(out, ref)
+
+
 def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden, monkeypatch):
     """`mujoco_amd.rollout.rollout` with numpy arrays (mjhip_rollout: chunked launches, strided copies overlapped with the
     kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times.  (Device arrays through

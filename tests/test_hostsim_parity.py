@@ -304,8 +304,10 @@ def test_unsupported_models_are_rejected(rb, hostsim_lib):
         K.DeviceModel(hostsim_lib, m)
     sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
     sc.opt.solver = 0
-    sc.opt.integrator = 2      # mjINT_IMPLICIT
-    with pytest.raises(K.MjhipError, match="unsupported"):
+    sc.opt.integrator = 2      # mjINT_IMPLICIT: accepted since round 6
+    K.DeviceModel(hostsim_lib, sc)
+    sc.opt.enableflags |= 1 << 4      # mjENBL_SLEEP (out of scope: SURVEY.md section 2)
+    with pytest.raises(K.MjhipError, match="unsupported.*sleep"):
         K.DeviceModel(hostsim_lib, sc)
 
 
@@ -812,6 +814,60 @@ def test_newton_islands_any_lds_budget(rb, hostsim_lib, tmp_path, lds):
     assert np.isfinite(out).all()
     assert relerr(out, ref) <= 1e-9
     assert b.get("warning").sum() == 0
+
+
+# islands that leave trees out, on the reference's DENSE path (nv < 60): an arm that touches nothing, a ball in free fall,
+# a stack of two boxes on the floor (one island of 12 dofs among 22) and a capsule lying apart (a second island)
+PARTIAL_ISLANDS_XML = """
+<mujoco>
+  <option timestep="0.004" solver="Newton" iterations="50" tolerance="1e-10"/>
+  <default><geom condim="3" friction=".6"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01"/>
+    <body pos="-1 0 1"><joint axis="0 1 0" damping=".1"/><geom type="capsule" size=".03" fromto="0 0 0 .4 0 0"/>
+      <body pos=".4 0 0"><joint axis="0 1 0" damping=".1"/><geom type="capsule" size=".03" fromto="0 0 0 .3 0 0"/></body></body>
+    <body pos="0 0 .1"><freejoint/><geom type="box" size=".1 .1 .1"/></body>
+    <body pos="1 1 2"><freejoint/><geom type="sphere" size=".05"/></body>
+    <body pos=".03 .02 .2999" euler="0 0 20"><freejoint/><geom type="box" size=".08 .08 .1"/></body>
+    <body pos="1.5 0 .05" euler="90 0 0"><freejoint/><geom type="capsule" size=".05 .2"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _partial_islands(rb, lib, tmp_path, solver, cone, kind=None):
+    xml = tmp_path / "partial_islands.xml"
+    xml.write_text(PARTIAL_ISLANDS_XML)
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind) if kind else rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    m.opt.cone = cone
+    assert m.nv == 26 and not (m.opt.disableflags & (1 << 18))
+    dm = K.DeviceModel(lib, m, 64, 300)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    NE = 2
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(3 + k).normal(0, .3, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    T = 80
+    ctrl = np.zeros((NE, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[:, :, 0].max() >= 6
+    b = K.Batch(dm, NE)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    return out, ref
+
+
+@pytest.mark.parametrize("solver,cone", [(2, 0), (2, 1), (1, 0), (1, 1)])
+def test_primal_solvers_partial_islands_dense_bit_exact(rb, hostsim_lib, tmp_path, solver, cone):
+    """Newton / CG on the dense path when an island leaves trees out: the reference solves every island on island-local
+    vectors and matrices (PrimalPointers, engine_solver.c:1148-1290), so mju_dot groups operands by their position INSIDE
+    the island -- J rows, vector dots, the Cholesky factor's row dots and the forward substitution.  (Found by the
+    100-step device sweep on actuator_group_disable.xml: 1e-14 after the first multi-contact step, 4e-3 eighty steps on.)"""
+    out, ref = _partial_islands(rb, hostsim_lib, tmp_path, solver, cone)
+    assert np.array_equal(out, ref)
 
 
 @pytest.mark.parametrize("solver,integrator,tol", [(0, 0, 0.0), (2, 0, 1e-9), (0, 1, 0.0), (0, 3, 0.0)])
