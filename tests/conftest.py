@@ -17,6 +17,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X GPU (libmjhip.so HIP path)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """the CPU selection (-m "not gpu": host emulation + compiled reference, ~15 core-minutes) spreads over four xdist
+    workers unless -n was given; $MJHIP_TEST_WORKERS=0 keeps it serial.  GPU selections stay in one process."""
+    if not config.pluginmanager.hasplugin("xdist") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
+    if getattr(config.option, "numprocesses", None) or "not gpu" not in (getattr(config.option, "markexpr", "") or ""):
+        return None
+    n = int(os.environ.get("MJHIP_TEST_WORKERS", min(4, os.cpu_count() or 1)))
+    if n > 1:
+        config.option.numprocesses = n
+    return None
+
+
 def _have_reference():
     return os.path.isdir(os.path.join(REF, "src", "engine"))
 
