@@ -198,7 +198,10 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST &&
              m->opt.integrator != mjINT_IMPLICIT, "unknown integrator");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
-  MJH_REJECT(m->opt.noslip_iterations > 0, "noslip iterations");
+  // mj_solNoSlip (engine_solver.c:764-958) runs on the reference's dense constraint path here (mju_dot residuals over
+  // dense efc_AR rows); the sparse path's AR is a compressed matrix with its own summation order
+  MJH_REJECT(m->opt.noslip_iterations > 0 && (m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60) || m->nflex > 0),
+             "noslip iterations outside the dense constraint path (sparse Jacobian, flexes)");
   // mj_isSparse (engine_core_util.c:29): with jacobian=sparse, or auto and nv >= 60, the reference
   // runs its sparse code paths.  They compute the same quantities with sums taken over the non-zeros
   // only; this path always evaluates the dense form, so such models agree with the reference to
@@ -300,6 +303,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   o.meaninertia = m->stat.meaninertia;
   o.integrator = m->opt.integrator; o.cone = m->opt.cone; o.solver = m->opt.solver;
   o.iterations = m->opt.iterations;
+  o.noslip_iterations = m->opt.noslip_iterations > 0 ? m->opt.noslip_iterations : 0; o.noslip_tolerance = m->opt.noslip_tolerance;
   o.disableflags = m->opt.disableflags; o.enableflags = m->opt.enableflags;
 
   // ---------------- direct copies ----------------------------------------------------------------------
@@ -1679,7 +1683,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     return bound;
   };
   {
-    const bool dual = m->opt.solver == mjSOL_PGS;
+    const bool dual = m->opt.solver == mjSOL_PGS || m->opt.noslip_iterations > 0;      // (mj_isDual: efc_AR exists)
     // (large models under CG keep the constraint Jacobian compressed -- mjh_csr.h -- and do not stream the dense rows)
     const bool ref_sparse0 = m->opt.jacobian == mjJAC_SPARSE || (m->opt.jacobian == mjJAC_AUTO && m->nv >= 60);
     // (equality rows on this path: flex edge / flex vertex constraints -- their rows are the model's flexedge_J rows -- and
@@ -2270,7 +2274,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   {
     int ft = 0;
     // (the sparse constraint path lives in the generic kernel, whatever the solver)
-    if (m->opt.solver != mjSOL_PGS || s.sparse) ft |= MJH_FT_PRIMAL;
+    if (m->opt.solver != mjSOL_PGS || s.sparse || m->opt.noslip_iterations > 0) ft |= MJH_FT_PRIMAL;      // (noslip: carried by the generic kernels only)
     if (m->opt.cone != mjCONE_PYRAMIDAL) ft |= MJH_FT_ELLIPTIC;
     if (m->neq > 0) ft |= MJH_FT_EQUALITY;
     if (m->opt.integrator == mjINT_RK4) ft |= MJH_FT_RK4;

@@ -1411,6 +1411,183 @@ MJH_DEVN void solve_pgs(MREF M_, BREF B_, int e_) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// mj_solNoSlip / mj_solNoSlip_island                 (engine_solver.c:764-972)
+// A Gauss-Seidel pass over the friction rows only (dry friction, then the friction dimensions of every contact) with the
+// regulariser R taken out of efc_AR's diagonal; runs after the main solver -- PGS, CG or Newton -- on the forces it
+// left, per island when islands are in use.  Dense constraint path (residuals are mju_dot over a dense efc_AR row).
+// ------------------------------------------------------------------------------------------------
+MJH_DEVN void solve_noslip(MREF M_, BREF B_, int e_) {
+  MJH_ENTER(M_, B_, e_);
+  iptr counts = MJH_F(B, counts, e);
+  const int nefc = counts[MJH_C_NEFC], ne_all = counts[MJH_C_NE], nf_all = counts[MJH_C_NF];
+  Efc P;
+  efc_layout(M, B, e, nefc, P);
+  crptr AR = P.AR;
+  crptr b = P.b;
+  crptr R = P.R;
+  crptr floss = P.floss;
+  rptr force = P.force;
+  rptr ARinv = P.ARinv;                                   // [nk] by island position
+  iptr efclist = MJH_G(B, iscratch, e) + M.s.nefcmax;     // [nk] island position -> row
+  iptr state = P.state;
+  const int lane = wv_lane();
+  const int maxiter = M.o.noslip_iterations;
+  const real scale = 1 / (M.o.meaninertia * (real)(M.s.nv > 1 ? M.s.nv : 1));
+  const int elliptic = MJH_HAS(MJH_FT_ELLIPTIC) && (M.o.cone != 0);
+  // residual(..., flg_subR = 1): b + AR row . force - R force
+  auto resid = [&](int i) -> real { return (b[i] + wave_dot_ref(AR + (size_t)i*nefc, force, nefc)) - R[i]*force[i]; };
+  // extractBlock(..., flg_subR = 1): the diagonal block with R taken out, its diagonal clamped to 1e-10 from below
+  auto block = [&](real* Ac, int start, int n) {
+    for (int j = 0; j < n; j++) for (int k = 0; k < n; k++) Ac[j*n + k] = AR[(size_t)(start + j)*nefc + start + k];
+    for (int j = 0; j < n; j++) { real dd = Ac[j*(n + 1)] - R[start + j]; Ac[j*(n + 1)] = dd > 1e-10 ? dd : (real)1e-10; }
+  };
+  // costChange with dim >= 2 (:216-237); restores the old forces on a positive change
+  auto cost_change = [&](const real* A, real* f, const real* oldf, const real* res, int dim) -> real {
+    real delta[6];
+    for (int j = 0; j < dim; j++) delta[j] = f[j] - oldf[j];
+    real quadf = 0;
+    for (int j = 0; j < dim; j++) quadf += delta[j] * dot_ref(A + j*dim, delta, dim);
+    real change = 0.5*quadf + dot_ref(delta, res, dim);
+    if (change > 1e-10) { for (int j = 0; j < dim; j++) f[j] = oldf[j]; change = 0; }
+    return change;
+  };
+
+  const int nisl_raw = counts[MJH_C_NISLAND];
+  const int nisl = nisl_raw > 1 ? nisl_raw : 1;
+  for (int isl = 0; isl < nisl; isl++) {
+    int nk = 0, ne = 0, nf = 0;
+    if (lane == 0) {
+      for (int i = 0; i < nefc; i++) {
+        if (nisl > 1 && P.island[i] != isl) continue;
+        efclist[nk++] = i;
+        if (i < ne_all) ne++; else if (i < ne_all + nf_all) nf++;
+      }
+    }
+    nk = wv_bcast_i(nk, 0); ne = wv_bcast_i(ne, 0); nf = wv_bcast_i(nf, 0);
+    wv_sync();
+    if (nk == 0) continue;
+    // ARdiaginv(..., flg_subR = 1)
+    MJH_FOR_LANES(c, nk) { const int i = efclist[c]; real dd = AR[(size_t)i*nefc + i] - R[i]; if (dd < MJH_MINVAL) dd = MJH_MINVAL; ARinv[c] = 1/dd; }
+    // dualState (:270-345)
+    auto dual_state = [&]() {
+      MJH_FOR_LANES(c, nk) {
+        const int i = efclist[c];
+        int st;
+        if (c < ne) st = MJH_STATE_QUADRATIC;
+        else if (c < ne + nf) {
+          if (force[i] <= -floss[i]) st = MJH_STATE_LINEARPOS;
+          else if (force[i] >= floss[i]) st = MJH_STATE_LINEARNEG;
+          else st = MJH_STATE_QUADRATIC;
+        } else if (elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+          if (!cone_leader(P, i)) continue;
+          const int dim = cone_dim(P, i, nefc);
+          const real mu = P.cone[i];
+          real f[6];
+          f[0] = force[i]/mu;
+          for (int j = 1; j < dim; j++) f[j] = force[i+j]/P.cone[i+j];
+          const real N = f[0];
+          const real T = sqrt(dot_ref(f + 1, f + 1, dim - 1));
+          if (mu*N >= T) st = MJH_STATE_SATISFIED;
+          else if (N + mu*T <= 0) st = MJH_STATE_QUADRATIC;
+          else st = MJH_STATE_CONE;
+          for (int j = 1; j < dim; j++) state[i+j] = st;
+        } else st = (force[i] <= 0) ? MJH_STATE_SATISFIED : MJH_STATE_QUADRATIC;
+        state[i] = st;
+      }
+      wv_sync();
+    };
+    dual_state();
+
+    int iter = 0;
+    while (iter < maxiter) {
+      real improvement = 0;
+      // correct for the cost change at iteration 0 (the regulariser's share of the cost the main solver minimised)
+      if (iter == 0) for (int c = 0; c < nk; c++) { const int i = efclist[c]; improvement += 0.5*force[i]*force[i]*R[i]; }
+      // dry friction
+      for (int c = ne; c < ne + nf; c++) {
+        const int i = efclist[c];
+        const real res = resid(i);
+        const real oldf = force[i];
+        real f = oldf - res*ARinv[c];
+        if (f < -floss[i]) f = -floss[i];
+        else if (f > floss[i]) f = floss[i];
+        const real delta = f - oldf;
+        improvement -= 0.5*delta*delta/ARinv[c] + delta*res;
+        wv_sync();
+        if (lane == 0) force[i] = f;
+        wv_sync();
+      }
+      // contact friction
+      for (int c = ne + nf; c < nk; c++) {
+        const int i = efclist[c];
+        if (P.type[i] == MJH_CNSTR_CONTACT_PYRAMIDAL) {
+          // (contact.dim from the rows: 2 (dim - 1) pyramid edges share the contact's id; the contact records' LDS
+          // slots are no longer live at this stage)
+          int nrow = 1;
+          while (i + nrow < nefc && P.type[i + nrow] == MJH_CNSTR_CONTACT_PYRAMIDAL && P.id[i + nrow] == P.id[i]) nrow++;
+          const int dim = nrow/2 + 1;
+          // pairs of opposing pyramid edges
+          for (int j = i; j < i + 2*(dim - 1); j += 2) {
+            real res[2], oldforce[2], fl[2], Ac[4], bc[2];
+            res[0] = resid(j); res[1] = resid(j + 1);
+            oldforce[0] = force[j]; oldforce[1] = force[j + 1];
+            block(Ac, j, 2);
+            for (int k = 0; k < 2; k++) bc[k] = res[k] - dot_ref(Ac + k*2, oldforce, 2);
+            const real mid = 0.5*(oldforce[0] + oldforce[1]);
+            real y = 0.5*(oldforce[0] - oldforce[1]);
+            const real K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2];
+            const real K0 = mid*(Ac[0] - Ac[3]) + bc[0] - bc[1];
+            if (K1 < MJH_MINVAL) { fl[0] = mid; fl[1] = mid; }
+            else {
+              y = -K0/K1;
+              if (y < -mid) { fl[0] = 0; fl[1] = 2*mid; }
+              else if (y > mid) { fl[0] = 2*mid; fl[1] = 0; }
+              else { fl[0] = mid + y; fl[1] = mid - y; }
+            }
+            improvement -= cost_change(Ac, fl, oldforce, res, 2);
+            wv_sync();
+            if (lane == 0) { force[j] = fl[0]; force[j + 1] = fl[1]; }
+            wv_sync();
+          }
+          c += 2*(dim - 1) - 1;
+        } else if (elliptic && P.type[i] == MJH_CNSTR_CONTACT_ELLIPTIC) {
+          const int dim = cone_dim(P, i, nefc);
+          real res[5], oldforce[5], fl[5], Ac[25], bc[5], mu[5];
+          for (int j = 0; j < dim - 1; j++) { res[j] = resid(i + 1 + j); oldforce[j] = force[i + 1 + j]; mu[j] = P.cone[i + 1 + j]; }
+          block(Ac, i + 1, dim - 1);
+          for (int j = 0; j < dim - 1; j++) bc[j] = res[j] - dot_ref(Ac + j*(dim - 1), oldforce, dim - 1);
+          if (force[i] < MJH_MINVAL) { for (int j = 0; j < dim - 1; j++) fl[j] = 0; }
+          else {
+            // solveQCQP (:388-410)
+            const int active = qcqp_solve(fl, Ac, bc, mu, force[i], dim - 1);
+            if (active) project_ellipsoid(fl, force[i], mu, dim, 0);
+          }
+          if (dim == 2) {
+            // costChange, dim == 1 (one friction dimension cannot occur with condim 3 / 4 / 6; kept for completeness)
+            const real delta = fl[0] - oldforce[0];
+            real change = 0.5*delta*delta*Ac[0] + delta*res[0];
+            if (change > 1e-10) { fl[0] = oldforce[0]; change = 0; }
+            improvement -= change;
+          } else improvement -= cost_change(Ac, fl, oldforce, res, dim - 1);
+          wv_sync();
+          if (lane == 0) for (int j = 0; j < dim - 1; j++) force[i + 1 + j] = fl[j];
+          wv_sync();
+          c += dim - 1;
+        }
+      }
+      // dualStateChange: the states follow the forces (counts of active / changed rows are statistics only)
+      dual_state();
+      improvement *= scale;
+      iter++;
+      if (improvement < M.o.noslip_tolerance) break;
+    }
+    // solver_niter of island 0 accumulates the noslip iterations after the main solver's
+    if (isl == 0 && lane == 0) counts[MJH_C_NITER] += iter;
+    wv_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mj_fwdConstraint (PGS path)                      (engine_forward.c:1148-1252, warmstart :1056-1132)
 // ------------------------------------------------------------------------------------------------
 MJH_DEVN void solve_newton(MREF M_, BREF B_, int e_);
@@ -1472,6 +1649,16 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
     // primal solvers (mjh_newton.h) leave qacc, qfrc_constraint, efc_force/state
     wv_sync();
     if (M.o.solver == MJH_SOL_NEWTON) solve_newton(M, B, e); else solve_cg(M, B, e);
+    if (M.o.noslip_iterations > 0) {
+      // mj_solNoSlip on the forces the primal solver left, then mj_dualFinish's first half; stage_finish solves for qacc
+      solve_noslip(M, B, e);
+      MJH_FOR_LANES(j, nv) {
+        real acc = 0;
+        for (int r = 0; r < nefc; r++) { const real f = force[r]; if (f != 0) acc += J[(size_t)r*nv + j]*f; }
+        qfc[j] = acc;
+      }
+      wv_sync();
+    }
     return;
   }
   if (!(M.o.disableflags & (1<<9))) {
@@ -1574,6 +1761,7 @@ MJH_DEVN void stage_fwd_constraint(MREF M_, BREF B_, int e_) {
     solve_pgs(M, B, e);
   }
   MJH_SUBPROF(23);     // PGS
+  if (MJH_HAS(MJH_FT_PRIMAL) && M.o.noslip_iterations > 0) solve_noslip(M, B, e);
 
   // mj_dualFinish, first half (engine_solver.c:72-85): qfrc_constraint = J' f
   MJH_FOR_LANES(j, nv) {
@@ -1603,7 +1791,8 @@ MJH_DEVN void stage_finish(MREF M_, BREF B_, int e_) {
     wv_sync();
     return;
   }
-  if (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS) return;         // the primal solvers work on qacc itself
+  // the primal solvers work on qacc itself -- unless the noslip pass changed the forces: mj_dualFinish then
+  if (MJH_HAS(MJH_FT_PRIMAL) && M.o.solver != MJH_SOL_PGS && !(M.o.noslip_iterations > 0)) return;
   MJH_FOR_LANES(j, nv) qacc[j] = qfc[j];
 #if !MJH_LANE_MODE && MJH_W == 64
   // mj_Euler with joint damping solves (M + h*diag(B)) qe = qfrc_smooth + qfrc_constraint right after

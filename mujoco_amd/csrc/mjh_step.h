@@ -179,7 +179,8 @@ MJH_DEVN void forward(MREF M_, BREF B_, int e_, int stages) {
 #endif
     });
   }
-  if ((stages & MJH_STAGE_PROJECT) && pgs) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
+  // (mj_isDual, engine_core_constraint.c:167: efc_AR is built for the PGS solver and whenever the noslip pass will run)
+  if ((stages & MJH_STAGE_PROJECT) && (pgs || (MJH_HAS(MJH_FT_PRIMAL) && M.o.noslip_iterations > 0))) MJH_RUN(MJH_T_PROJECT, stage_project(M, B, e));
   if (stages & MJH_STAGE_REFERENCE) MJH_RUN(MJH_T_REFERENCE, stage_reference(M, B, e));
   if (stages & MJH_STAGE_CONSTRAINT) MJH_RUN(MJH_T_CONSTRAINT, stage_fwd_constraint(M, B, e));
   if (stages & MJH_STAGE_FINISH) MJH_RUN(MJH_T_FINISH, stage_finish(M, B, e));

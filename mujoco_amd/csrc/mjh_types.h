@@ -562,6 +562,8 @@ struct DOptions {
   real magnetic[3];
   real meaninertia;
   int integrator, cone, solver, iterations, ls_iterations;
+  int noslip_iterations;   // > 0: mj_solNoSlip after the main solver (dense constraint path; efc_AR is built under every solver)
+  real noslip_tolerance;
   int disableflags, enableflags;
   int euler_damp;   // 1: mj_EulerSkip takes the implicit-damping branch (engine_forward.c:1409-1420)
   int has_refsite;    // a site transmission with a reference site (reads xquat at the transmission stage)

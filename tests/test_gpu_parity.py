@@ -1223,6 +1223,16 @@ def test_primal_solvers_partial_islands_dense_on_gpu(rb, hip_lib, tmp_path, solv
     assert np.array_equal(out, ref), relerr(out, ref)
 
 
+@pytest.mark.parametrize("solver,cone", [(0, 0), (2, 0), (2, 1), (1, 1)], ids=["pgs-pyr", "newton-pyr", "newton-ell", "cg-ell"])
+def test_noslip_solver_on_gpu(rb, hip_lib, tmp_path, solver, cone):
+    """mj_solNoSlip after PGS / Newton / CG on the device (round 6; CPU counterpart:
+    tests/test_hostsim_parity.py::test_noslip_solver_bit_exact): bit for bit against the reference linked with the
+    kernels' sin / cos, iteration counts of island 0 included"""
+    import test_hostsim_parity as th
+    out, ref = th._noslip(rb, hip_lib, tmp_path, solver, cone, kind="devmath")
+    assert np.array_equal(out, ref), relerr(out, ref)
+
+
 def test_drop_in_rollout_with_host_arrays_equals_device_resident_rollout(rb, hip_lib, golden, monkeypatch):
     """`mujoco_amd.rollout.rollout` with numpy arrays (mjhip_rollout: chunked launches, strided copies overlapped with the
     kernels on two copy streams) returns the bytes of the device-resident rollout bench.py times.  (Device arrays through

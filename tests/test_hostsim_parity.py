@@ -299,7 +299,9 @@ def test_capacity_overflow_raises_warning(rb, hostsim_lib, golden):
 
 def test_unsupported_models_are_rejected(rb, hostsim_lib):
     m = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "humanoid.mjb"))
-    m.opt.noslip_iterations = 3
+    m.opt.noslip_iterations = 3            # accepted on the dense constraint path since round 6 ...
+    K.DeviceModel(hostsim_lib, m)
+    m.opt.jacobian = 1                     # ... not on the sparse one (mjJAC_SPARSE)
     with pytest.raises(K.MjhipError, match="noslip"):
         K.DeviceModel(hostsim_lib, m)
     sc = rb.MjModel.from_binary_path(os.path.join(GOLDEN, "slider_crank.mjb"))
@@ -868,6 +870,67 @@ def test_primal_solvers_partial_islands_dense_bit_exact(rb, hostsim_lib, tmp_pat
     100-step device sweep on actuator_group_disable.xml: 1e-14 after the first multi-contact step, 4e-3 eighty steps on.)"""
     out, ref = _partial_islands(rb, hostsim_lib, tmp_path, solver, cone)
     assert np.array_equal(out, ref)
+
+
+# mj_solNoSlip: friction-loss rows, pyramidal and elliptic contacts of condim 3 / 4 / 6, several islands and an arm that
+# touches nothing
+NOSLIP_XML = """
+<mujoco>
+  <option timestep="0.004" noslip_iterations="4" noslip_tolerance="1e-8" iterations="60"/>
+  <default><geom condim="3" friction=".7 .02 .01"/></default>
+  <worldbody>
+    <geom type="plane" size="3 3 .01" euler="4 -3 0"/>
+    <body pos="-1 0 1"><joint axis="0 1 0" damping=".1" frictionloss=".3"/><geom type="capsule" size=".03" fromto="0 0 0 .4 0 0"/>
+      <body pos=".4 0 0"><joint axis="0 1 0" damping=".1" frictionloss=".2"/><geom type="capsule" size=".03" fromto="0 0 0 .3 0 0"/></body></body>
+    <body pos="0 0 .12"><freejoint/><geom type="box" size=".1 .1 .1"/></body>
+    <body pos=".03 .02 .33" euler="0 0 20"><freejoint/><geom type="box" size=".08 .08 .1" condim="4"/></body>
+    <body pos="1.5 0 .08" euler="90 0 0"><freejoint/><geom type="capsule" size=".05 .2" condim="6"/></body>
+    <body pos="0 1.2 .2"><joint type="slide" axis="1 0 0" frictionloss=".5"/><joint type="slide" axis="0 0 1"/>
+      <geom type="sphere" size=".07" condim="4"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _noslip(rb, lib, tmp_path, solver, cone, kind=None):
+    xml = tmp_path / "noslip.xml"
+    xml.write_text(NOSLIP_XML)
+    m = rb.MjModel.from_xml_path(str(xml), kind=kind) if kind else rb.MjModel.from_xml_path(str(xml))
+    m.opt.solver = solver
+    m.opt.cone = cone
+    dm = K.DeviceModel(lib, m, 64, 300)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    NE = 2
+    s0 = np.zeros((NE, rb.mj_stateSize(m, rb.mjSTATE_FULLPHYSICS)))
+    for k in range(NE):
+        d.qvel[:] = np.random.default_rng(5 + k).normal(0, .4, m.nv)
+        s0[k] = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)
+    T = 90
+    ctrl = np.zeros((NE, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    assert ints[:, :, 0].max() >= 6
+    b = K.Batch(dm, NE)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    assert b.get("warning").sum() == 0
+    # the iteration count of island 0 includes the noslip iterations (engine_solver.c:951)
+    c = b.get("counts")
+    assert np.array_equal(c[:, 5], ints[:, -1, 2]), (c[:, 5], ints[:, -1, 2])
+    # and the same trajectory WITHOUT the noslip pass differs (the pass does something in this scene)
+    m.opt.noslip_iterations = 0
+    ref0, _ = oracle_rollout(rb, m, s0, ctrl)
+    assert relerr(ref0, ref) > 1e-6
+    return out, ref
+
+
+@pytest.mark.parametrize("solver,cone", [(0, 0), (0, 1), (2, 0), (2, 1), (1, 1)],
+                         ids=["pgs-pyr", "pgs-ell", "newton-pyr", "newton-ell", "cg-ell"])
+def test_noslip_solver_bit_exact(rb, hostsim_lib, tmp_path, solver, cone):
+    """mj_solNoSlip (engine_solver.c:764-972) after PGS, Newton and CG, per island: dry-friction rows, opposing pyramid edge
+    pairs, the QCQP of an elliptic contact's friction dimensions (condim 3 / 4 / 6), efc_AR built under the primal solvers
+    too (mj_isDual), mj_dualFinish afterwards"""
+    out, ref = _noslip(rb, hostsim_lib, tmp_path, solver, cone)
+    assert np.array_equal(out, ref), relerr(out, ref)
 
 
 @pytest.mark.parametrize("solver,integrator,tol", [(0, 0, 0.0), (2, 0, 1e-9), (0, 1, 0.0), (0, 3, 0.0)])
