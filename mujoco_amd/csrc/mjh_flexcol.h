@@ -163,6 +163,61 @@ MJH_DEV V3 tri_fix_normal_cylinder(V3 normal, V3 cpos, V3 gpos, PM mat, PS size)
   return mmul(mat, nrm);
 }
 
+// the same for an ELLIPSOID geom: the normal of the ellipsoid's surface at the point closest to the contact position --
+// from inside by ray projection along the current normal (mjc_ellipsoidInside, :1306), from outside by Newton's method on
+// the multiplier of the diagonal QCQP (mjc_ellipsoidOutside, :1361)
+template <class PM, class PS>
+MJH_DEV V3 tri_fix_normal_ellipsoid(V3 normal, V3 cpos, V3 gpos, PM mat, PS size) {
+  if (size[0] < MJH_MINVAL || size[1] < MJH_MINVAL || size[2] < MJH_MINVAL) return normal;
+  const V3 dif = cpos - gpos;
+  const real pos[3] = {mtrow(mat, 0, dif), mtrow(mat, 1, dif), mtrow(mat, 2, dif)};
+  real nrm[3] = {mtrow(mat, 0, normal), mtrow(mat, 1, normal), mtrow(mat, 2, normal)};
+  const real dst1 = pos[0]*pos[0]/(size[0]*size[0]) + pos[1]*pos[1]/(size[1]*size[1]) + pos[2]*pos[2]/(size[2]*size[2]);
+  int processed;
+  if (dst1 <= 1) {
+    const real S2inv[3] = {1/(size[0]*size[0]), 1/(size[1]*size[1]), 1/(size[2]*size[2])};
+    const real C = pos[0]*pos[0]*S2inv[0] + pos[1]*pos[1]*S2inv[1] + pos[2]*pos[2]*S2inv[2] - 1;
+    if (C > 0) return normal;
+    { V3 n{nrm[0], nrm[1], nrm[2]}; unitize(n); nrm[0] = n.x; nrm[1] = n.y; nrm[2] = n.z; }
+    processed = 1;
+    for (int iter = 0; iter < 30; iter++) {
+      const real A = nrm[0]*nrm[0]*S2inv[0] + nrm[1]*nrm[1]*S2inv[1] + nrm[2]*nrm[2]*S2inv[2];
+      const real Bq = pos[0]*nrm[0]*S2inv[0] + pos[1]*nrm[1]*S2inv[1] + pos[2]*nrm[2]*S2inv[2];
+      const real det = Bq*Bq - A*C;
+      if (det < MJH_MINVAL || A < MJH_MINVAL) { processed = iter > 0; break; }
+      const real x = (-Bq + sqrt(det))/A;
+      if (x < 0) { processed = iter > 0; break; }
+      const real pnt[3] = {pos[0] + nrm[0]*x, pos[1] + nrm[1]*x, pos[2] + nrm[2]*x};
+      V3 nn{pnt[0]*S2inv[0], pnt[1]*S2inv[1], pnt[2]*S2inv[2]};
+      unitize(nn);
+      const V3 dd{nrm[0] - nn.x, nrm[1] - nn.y, nrm[2] - nn.z};
+      const real change = sqrt(dd.x*dd.x + dd.y*dd.y + dd.z*dd.z);
+      nrm[0] = nn.x; nrm[1] = nn.y; nrm[2] = nn.z;
+      if (change < 1e-6) break;
+    }
+  } else {
+    const real S2[3] = {size[0]*size[0], size[1]*size[1], size[2]*size[2]};
+    const real PS2[3] = {pos[0]*pos[0]*S2[0], pos[1]*pos[1]*S2[1], pos[2]*pos[2]*S2[2]};
+    real la = 0;
+    for (int iter = 0; iter < 30; iter++) {
+      const real R[3] = {1/(S2[0] + la), 1/(S2[1] + la), 1/(S2[2] + la)};
+      const real val = PS2[0]*R[0]*R[0] + PS2[1]*R[1]*R[1] + PS2[2]*R[2]*R[2] - 1;
+      if (val < 1e-6) break;
+      const real deriv = -2*(PS2[0]*R[0]*R[0]*R[0] + PS2[1]*R[1]*R[1]*R[1] + PS2[2]*R[2]*R[2]*R[2]);
+      if (deriv > -MJH_MINVAL) break;
+      const real delta = -val/deriv;
+      if (delta < 1e-6) break;
+      la += delta;
+    }
+    nrm[0] = pos[0]/(S2[0] + la); nrm[1] = pos[1]/(S2[1] + la); nrm[2] = pos[2]/(S2[2] + la);
+    processed = 1;
+  }
+  if (!processed) return normal;
+  V3 n{nrm[0], nrm[1], nrm[2]};
+  unitize(n);
+  return mmul(mat, n);
+}
+
 // capsule of a line element: the two vertices' segment with the flex radius (mj_makeCapsule, engine_collision_driver.c:1879;
 // the frame through mju_quatZ2Vec / mju_quat2Mat, engine_util_spatial.c)
 MJH_DEV void flex_make_capsule(V3 v1, V3 v2, real radius, V3& pos, real* mat, real* size) {
@@ -494,7 +549,7 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
         n += __builtin_popcountll(m);
       }
     } else {
-      const int fixnormal = M.flex_dim[f] == 2 && gtype == MJH_GEOM_CYLINDER;
+      const int fixnormal = M.flex_dim[f] == 2 && (gtype == MJH_GEOM_CYLINDER || gtype == MJH_GEOM_ELLIPSOID);
       for (int r0 = 0; r0 < nsurv; r0 += MJH_W) {
         const int r = r0 + wv_lane();
         const int el = r < nsurv ? surv[r] : -1;
@@ -505,7 +560,8 @@ MJH_DEVN int flex_collide_job(MREF M_, BREF B_, int e_, int seg, int base) {
           const int c = n + wv_rank_lt(m);
           for (int q = 0; q < 7; q++) cand[FC_NREAL*c + q] = rec[q];
           if (fixnormal) {
-            const V3 nn = tri_fix_normal_cylinder(ld3(rec + 4), ld3(rec + 1), ld3(gx + 3*g), gm + 9*g, M.geom_size + 3*g);
+            const V3 nn = gtype == MJH_GEOM_ELLIPSOID ? tri_fix_normal_ellipsoid(ld3(rec + 4), ld3(rec + 1), ld3(gx + 3*g), gm + 9*g, M.geom_size + 3*g)
+                                                      : tri_fix_normal_cylinder(ld3(rec + 4), ld3(rec + 1), ld3(gx + 3*g), gm + 9*g, M.geom_size + 3*g);
             cand[FC_NREAL*c + FC_NRM] = nn.x; cand[FC_NREAL*c + FC_NRM + 1] = nn.y; cand[FC_NREAL*c + FC_NRM + 2] = nn.z;
           }
           ci[FI_NINT*c + FI_GEOM] = g; ci[FI_NINT*c + FI_OBJ] = el - eadr; ci[FI_NINT*c + FI_PAIR] = p; ci[FI_NINT*c + FI_KIND] = 1;

@@ -923,10 +923,9 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           // mj_collideGeomElem (engine_collision_driver.c:2372): triangles against spheres / capsules / boxes have closed
           // forms (mjraw_SphereTriangle / CapsuleTriangle / BoxTriangle), every other pairing goes through GJK / EPA with the
           // element as a convex object (mjc_ConvexElem).  Not built: line elements against spheres / capsules / boxes (the raw
-          // capsule colliders on a capsule made of the two vertices), and the ellipsoid case of mjc_fixNormal for triangles
+          // capsule colliders on a capsule made of the two vertices)
           const int dim = m->flex_dim[f];
           MJH_REJECT(dim == 1 && type == mjGEOM_BOX, "collisions of line flexes with boxes");
-          MJH_REJECT(dim == 2 && type == mjGEOM_ELLIPSOID, "collisions of shell flexes with ellipsoids");
           int sub = 0;                            // closed form: candidate contacts per (geom, triangle)
           if (dim == 2 && type == mjGEOM_SPHERE) sub = 1;
           else if (dim == 2 && type == mjGEOM_CAPSULE) sub = 5;

@@ -356,6 +356,27 @@ def test_shell_flex_on_geoms_dense_rows(rb, hostsim_lib, tmp_path):
     _shell_on_geoms(rb, hostsim_lib, tmp_path, count="4 4 1", csr=0, geoms=SHELL_GEOMS.replace(".06 .06 .15", ".02 .02 .15"))
 
 
+SHELL_ELLIPSOIDS = """
+    <body mocap="true" pos=".05 .05 .15" euler="20 -15 30"><geom type="ellipsoid" size=".06 .04 .03"/></body>
+    <body mocap="true" pos="-.06 -.05 .16" euler="0 40 10"><geom type="ellipsoid" size=".03 .07 .05"/></body>"""
+
+
+def _shell_on_ellipsoids(rb, lib, tmp_path):
+    xml = tmp_path / "shellell.xml"
+    xml.write_text(shell_xml("9 9 1", SHELL_ELLIPSOIDS))
+    m = rb.MjModel.from_xml_path(str(xml))
+    maxcon, seen = _free_run(rb, lib, m, pre=60, nstep=100, csr=1)
+    assert seen >= {1, 2}, seen
+    return maxcon
+
+
+def test_shell_flex_on_ellipsoids(rb, hostsim_lib, tmp_path):
+    """a triangle shell falling on two ellipsoids: GJK / EPA against the triangle, then mjc_fixNormal's ellipsoid case (the
+    surface normal at the point closest to the contact: ray projection from inside, Newton's method on the QCQP
+    multiplier from outside; engine_collision_convex.c:1306-1408) -- round 6"""
+    assert _shell_on_ellipsoids(rb, hostsim_lib, tmp_path) > 10
+
+
 def _line_on_cylinder(rb, lib, tmp_path):
     xml = tmp_path / "line.xml"
     xml.write_text(shell_xml("50 1 1", '<body mocap="true" pos="0 0 .15" zaxis="0 1 0"><geom type="cylinder" size=".05 .1"/></body>'
