@@ -1512,7 +1512,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   s.nsensor = m->nsensor;
   s.nsensordata = m->nsensordata;
   s.nbody_sens = m->nsensor ? m->nbody : 0;
-  s.sens_rnepost = 0; s.sens_subtreevel = 0;
+  s.sens_rnepost = 0; s.sens_subtreevel = 0; s.sens_energy = 0;
   H->sensor_type.assign(m->nsensor, 0);
   H->sensor_objtype.assign(m->nsensor, MJH_OBJ_NONE);
   H->sensor_reftype.assign(m->nsensor, MJH_OBJ_NONE);
@@ -1566,6 +1566,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_SUBTREELINVEL: t = MJH_SENS_SUBTREELINVEL; s.sens_subtreevel = 1; break;
       case mjSENS_SUBTREEANGMOM: t = MJH_SENS_SUBTREEANGMOM; s.sens_subtreevel = 1; break;
       case mjSENS_CLOCK: t = MJH_SENS_CLOCK; break;
+      case mjSENS_E_POTENTIAL: t = MJH_SENS_E_POTENTIAL; s.sens_energy |= 1; break;
+      case mjSENS_E_KINETIC: t = MJH_SENS_E_KINETIC; s.sens_energy |= 2; break;
       case mjSENS_VELOCIMETER: t = MJH_SENS_VELOCIMETER; break;
       case mjSENS_GYRO: t = MJH_SENS_GYRO; break;
       case mjSENS_ACCELEROMETER: t = MJH_SENS_ACCELEROMETER; s.sens_rnepost = 1; break;
@@ -1601,7 +1603,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       default: break;
     }
     MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
-                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact (camera rangefinders, camprojection, geom distance, energy, "
+                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact / camprojection / energy (camera rangefinders, geom distance, "
                       "tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {

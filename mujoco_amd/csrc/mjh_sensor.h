@@ -401,6 +401,72 @@ MJH_DEV void sens_rne_post(MREF M, BREF B, int e) {
     for (int q = 0; q < 6; q++) cint[6*M.body_parentid[j] + q] += cint[6*j + q];
 }
 
+// mj_energyPos (engine_sensor.c:1659-1762): gravitational potential of the body inertial frames, joint springs (with
+// their polynomial terms: mju_polyPotential, engine_util_misc.c:2344), tendon springs outside their dead band.  One lane,
+// sums in the reference's order.  (Flex edge springs: sensors in models with flexes are rejected.)
+MJH_DEV void sens_energy_pos(MREF M, BREF B, int e) {
+  const MJH_CONST_AS DSizes& s = M.s;
+  crptr xipos = MJH_F(B, xipos, e);
+  crptr qpos = MJH_F(B, qpos, e);
+  auto pot = [&](real linear, auto poly, real x) -> real {
+    real res = 0.5*linear*(x*x);
+    real xpow = x;
+    for (int i = 0; i < 2; i++) { xpow *= x; res += poly[i]/(i + 3)*(xpow*x); }
+    return res;
+  };
+  real en = 0;
+  if (!(M.o.disableflags & (1<<7)))
+    for (int i = 1; i < s.nbody; i++) en -= M.body_mass[i]*(M.o.gravity[0]*xipos[3*i] + M.o.gravity[1]*xipos[3*i + 1] + M.o.gravity[2]*xipos[3*i + 2]);
+  if (!(M.o.disableflags & (1<<5))) {
+    for (int j = 0; j < s.njnt; j++) {          // (joints in body order are joints in index order)
+      const real stiffness = M.jnt_stiffness[j];
+      auto poly = M.jnt_stiffnesspoly + 2*j;
+      if (stiffness == 0 && poly[0] == 0 && poly[1] == 0) continue;
+      int padr = M.jnt_qposadr[j];
+      const int jt = M.jnt_type[j];
+      if (jt == MJH_JNT_FREE) {
+        const real d0 = qpos[padr] - M.qpos_spring[padr], d1 = qpos[padr + 1] - M.qpos_spring[padr + 1], d2 = qpos[padr + 2] - M.qpos_spring[padr + 2];
+        en += pot(stiffness, poly, sqrt(d0*d0 + d1*d1 + d2*d2));
+        padr += 3;
+      }
+      if (jt == MJH_JNT_FREE || jt == MJH_JNT_BALL) {
+        real dif[3];
+        q_sub(dif, qpos + padr, M.qpos_spring + padr);
+        en += pot(stiffness, poly, sqrt(dif[0]*dif[0] + dif[1]*dif[1] + dif[2]*dif[2]));
+      } else {
+        en += pot(stiffness, poly, qpos[padr] - M.qpos_spring[padr]);
+      }
+    }
+    crptr len = MJH_F(B, ten_length, e);
+    for (int i = 0; i < s.ntendon; i++) {
+      const real length = len[i], lower = M.tendon_lengthspring[2*i], upper = M.tendon_lengthspring[2*i + 1];
+      const real x = (length > upper) ? length - upper : (length < lower) ? length - lower : (real)0;
+      en += pot(M.tendon_stiffness[i], M.tendon_stiffnesspoly + 2*i, x);
+    }
+  }
+  MJH_G(B, energy, e)[0] = en;
+}
+
+// mj_energyVel (:1766-1779): 0.5 qvel' M qvel with M v in mju_mulSymVecSparse's order (engine_util_sparse.c:254) and mju_dot
+MJH_DEV void sens_energy_vel(MREF M, BREF B, int e) {
+  const int nv = M.s.nv;
+  crptr Mq = MJH_G(B, M, e);
+  crptr qvel = MJH_F(B, qvel, e);
+  rptr vec = MJH_G(B, scratch, e) + 5*M.s.nefcmax;          // (sqrtInvD's slot: dead after the projection stage)
+  for (int i = 0; i < nv; i++) vec[i] = 0;
+  for (int i = 0; i < nv; i++) {
+    const int adr = M.M_rowadr[i], diag = M.M_rownnz[i] - 1;
+    vec[i] = Mq[adr + diag]*qvel[i];
+    for (int k = diag - 1; k >= 0; k--) {
+      const int j = M.M_colind[adr + k];
+      const real val = Mq[adr + k];
+      vec[i] += val*qvel[j];
+      vec[j] += val*qvel[i];
+    }
+  }
+  MJH_G(B, energy, e)[1] = 0.5*dot_ref(vec, qvel, nv);
+}
+
 // which: bit 0 = position-stage sensors (mj_sensorPos, engine_sensor.c:369), bit 1 = velocity stage
 // (mj_sensorVel, :640), bit 2 = acceleration stage (mj_sensorAcc, :868); a rollout step evaluates all
 // three at once, mj_step1 / mj_step2 split them around the controller call
@@ -444,6 +510,8 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
   if (wv_lane() == 0) {
     if (s.sens_subtreevel && (which & 2)) sens_subtree_vel(M, B, e);
     if (s.sens_rnepost && (which & 4)) sens_rne_post(M, B, e);
+    if ((s.sens_energy & 1) && (which & 1)) sens_energy_pos(M, B, e);
+    if ((s.sens_energy & 2) && (which & 2)) sens_energy_vel(M, B, e);
   }
   wv_sync();
   ciptr counts = MJH_F(B, counts, e);
@@ -551,6 +619,8 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
     case MJH_SENS_SUBTREELINVEL: { crptr c = MJH_G(B, subtree_linvel, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
     case MJH_SENS_SUBTREEANGMOM: { crptr c = MJH_G(B, subtree_angmom, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
     case MJH_SENS_CLOCK: v[0] = MJH_F(B, time, e)[0]; break;
+    case MJH_SENS_E_POTENTIAL: v[0] = MJH_G(B, energy, e)[0]; break;
+    case MJH_SENS_E_KINETIC: v[0] = MJH_G(B, energy, e)[1]; break;
     case MJH_SENS_VELOCIMETER: case MJH_SENS_GYRO: {
       real xvel[6];
       object_velocity(M, B, e, MJH_OBJ_SITE, objid, xvel, 1);

@@ -675,7 +675,8 @@ MJH_DEVN void stage_crb(MREF M_, BREF B_, int e_, int nopark) {
   // the global copy of M: what tests inspect and what mj_Euler's fallback, implicitfast and the primal
   // solvers read once qLD has been factorised in place.  A step of the PGS + Euler path whose qH factor
   // is produced next to M's never reads it.
-  const int unread = nopark && pairs_euler_factor(M, B, e) && (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS);
+  const int unread = nopark && pairs_euler_factor(M, B, e) && (!MJH_HAS(MJH_FT_PRIMAL) || M.o.solver == MJH_SOL_PGS) &&
+                     !(MJH_HAS(MJH_FT_SENSOR) && (s.sens_energy & 2));      // (a kinetic-energy sensor reads M)
   if (!unread) {
     rptr Mhome = MJH_G(B, M, e);
     MJH_FOR_LANES(k, s.nC) Mhome[k] = Mq[k];

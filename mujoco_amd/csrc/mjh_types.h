@@ -494,6 +494,7 @@ struct DSizes {
   int nbody_fluid;  // nbody when fluid forces are on, else 0
   int nbody_sens;  // nbody when the model has sensors (cacc / cfrc / subtree velocity arrays), else 0
   int sens_rnepost, sens_subtreevel;   // some sensor needs mj_rnePostConstraint / mj_subtreeVel
+  int sens_energy;     // bit 0: a potential-energy sensor (mj_energyPos), bit 1: a kinetic-energy sensor (mj_energyVel, reads M's global home)
   int npgsorder;   // entries of the precomputed PGS visitation-order table
   int nldprog;     // entries of the flattened L'DL update list
   int nldrows;     // dofs whose row of M has off-diagonal entries
@@ -780,6 +781,7 @@ enum {
   X(rk_act, 9 * s.na, 0, MJH_T_GLB, MJH_T_GLB)                                    \
   X(scratch, 8 * s.nefcmax + 8 * s.nv + 64, 0, MJH_T_GLB, MJH_T_GLB)              \
   /* per-stage time accumulators in microseconds (builds with -DMJH_PROFILE only) */ \
+  X(energy, 2, 0, MJH_T_GLB, MJH_T_GLB)                                            \
   X(prof, 64, 0, MJH_T_GLB, MJH_T_GLB)
 
 #define MJH_BATCH_INT_FIELDS(X)                                                   \
@@ -1004,7 +1006,7 @@ enum {
   MJH_SENS_FRAMEANGACC, MJH_SENS_SUBTREECOM, MJH_SENS_SUBTREELINVEL, MJH_SENS_SUBTREEANGMOM, MJH_SENS_CLOCK,
   MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
   MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
-  MJH_SENS_CONTACT, MJH_SENS_CAMPROJECTION,
+  MJH_SENS_CONTACT, MJH_SENS_CAMPROJECTION, MJH_SENS_E_POTENTIAL, MJH_SENS_E_KINETIC,
   MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4, MJH_OBJ_CAMERA = 5,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3, MJH_DYN_MUSCLE = 4,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,

@@ -357,10 +357,10 @@ SENSOR_XML = """
     <site name="zone_box" type="box" size=".3 .3 .06" pos="-.5 0 .05"/><site name="zone_cyl" type="cylinder" size=".3 .2" pos=".5 0 .5" euler="0 20 0"/>
     <site name="zone_sph" type="sphere" size=".25" pos=".45 0 .45"/><site name="zone_cap" type="capsule" size=".15 .3" pos=".4 0 .6" euler="0 90 0"/>
     <body name="a1" pos="0 0 .6">
-      <joint name="j1" axis="0 1 0" range="-40 40" limited="true"/><geom name="g1" fromto="0 0 0 .25 0 0"/>
+      <joint name="j1" axis="0 1 0" range="-40 40" limited="true" stiffness="3" springref="10"/><geom name="g1" fromto="0 0 0 .25 0 0"/>
       <site name="imu1" pos=".1 0 .02" euler="0 15 40"/><site name="rf_side" pos="0 0 .05" euler="0 100 0"/>
       <body name="a2" pos=".25 0 0">
-        <joint name="j2" type="ball"/><geom fromto="0 0 0 .2 0 0"/>
+        <joint name="j2" type="ball" stiffness=".8"/><geom fromto="0 0 0 .2 0 0"/>
         <site name="imu2" pos=".15 .01 0" euler="30 0 0"/>
         <body name="a3" pos=".2 0 0"><joint name="j3" type="slide" axis="1 0 0" range="-.05 .05" limited="true"/>
           <geom name="g3" type="sphere" size=".05"/><site name="tip" pos=".05 0 0"/><site name="rf_tip" pos=".06 0 0" euler="0 130 20"/></body>
@@ -374,7 +374,7 @@ SENSOR_XML = """
     <body name="p1" pos=".3 -.5 .5"><joint name="q1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/>
       <body pos="0 0 -.2"><joint name="q2" axis="1 0 0" range="-30 30" limited="true"/><geom fromto="0 0 0 0 0 -.2"/><site name="p_end" pos="0 0 -.2"/></body></body>
   </worldbody>
-  <tendon><fixed name="t1" range="-.2 .2" limited="true"><joint joint="q1" coef="1"/><joint joint="q2" coef=".5"/></fixed></tendon>
+  <tendon><fixed name="t1" range="-.2 .2" limited="true" stiffness="4" springlength="-.05 .05"><joint joint="q1" coef="1"/><joint joint="q2" coef=".5"/></fixed></tendon>
   <equality><weld body1="f2" body2="a1" solref=".02 1"/></equality>
   <actuator>
     <motor name="m1" joint="j1" gear="2"/><position name="m2" joint="j3" kp="30"/><motor name="m3" joint="q1" gear=".8"/>
@@ -395,7 +395,7 @@ SENSOR_XML = """
     <framelinvel objtype="site" objname="tip" reftype="site" refname="imuf"/><frameangvel objtype="xbody" objname="f1" reftype="body" refname="a2"/>
     <framelinacc objtype="site" objname="tip"/><frameangacc objtype="body" objname="f1"/>
     <subtreecom body="a1"/><subtreelinvel body="a1"/><subtreeangmom body="a1"/><subtreeangmom body="p1"/>
-    <clock/>
+    <clock/><e_potential/><e_kinetic/>
     <velocimeter site="imu1"/><gyro site="imu2"/><accelerometer site="imu1"/><accelerometer site="imuf"/>
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>

@@ -1230,8 +1230,8 @@ def _sensor_reference(rb, m, s0, ctrl):
 def test_sensors_bit_exact(rb, hostsim_lib, tmp_path, integrator):
     """mj_sensorPos/Vel/Acc (engine_sensor.c:1498-1660) with mj_subtreeVel and mj_rnePostConstraint:
     joint/tendon/actuator/ball/limit sensors, frame sensors with and without reference frames,
-    subtree COM / velocity / angular momentum, clock, velocimeter, gyro, accelerometer, force,
-    torque, magnetometer, cutoff -- the `sensordata` output of the rollout, every step"""
+    subtree COM / velocity / angular momentum, clock, potential and kinetic energy (mj_energyPos / mj_energyVel: joint,
+    ball-joint and tendon springs), velocimeter, gyro, accelerometer, force, torque, magnetometer, cutoff -- the `sensordata` output of the rollout, every step"""
     xml = tmp_path / "sens.xml"
     xml.write_text(SENSOR_XML)
     m = rb.MjModel.from_xml_path(str(xml))
