@@ -67,6 +67,11 @@ def test_shell_flex_on_geoms_dense_rows_on_gpu(rb, hip_lib, tmp_path):
     fh._shell_on_geoms(rb, hip_lib, tmp_path, count="4 4 1", csr=0, geoms=fh.SHELL_GEOMS.replace(".06 .06 .15", ".02 .02 .15"))
 
 
+def test_shell_flex_on_ellipsoids_on_gpu(rb, hip_lib, tmp_path):
+    """triangle elements against ellipsoids: GJK / EPA + the ellipsoid case of mjc_fixNormal (round 6)"""
+    assert fh._shell_on_ellipsoids(rb, hip_lib, tmp_path) > 10
+
+
 def test_line_flex_on_cylinder_and_ellipsoid_on_gpu(rb, hip_lib, tmp_path):
     fh._line_on_cylinder(rb, hip_lib, tmp_path)
 
