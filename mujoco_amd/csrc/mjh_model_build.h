@@ -1566,6 +1566,31 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       case mjSENS_SUBTREELINVEL: t = MJH_SENS_SUBTREELINVEL; s.sens_subtreevel = 1; break;
       case mjSENS_SUBTREEANGMOM: t = MJH_SENS_SUBTREEANGMOM; s.sens_subtreevel = 1; break;
       case mjSENS_CLOCK: t = MJH_SENS_CLOCK; break;
+      case mjSENS_GEOMDIST: case mjSENS_GEOMNORMAL: case mjSENS_GEOMFROMTO: {
+        // mj_geomDistance (engine_support.c:553) through the closed-form colliders: planes, spheres, capsules, and a sphere
+        // against a box / cylinder.  Pairs that take the convex pipeline (mjc_ccd with a distance cutoff) or a
+        // wave-cooperative box collider are not evaluated by the sensor stage.
+        const int ot = m->sensor_objtype[i], rt = m->sensor_reftype[i];
+        bool ok = (ot == mjOBJ_GEOM || ot == mjOBJ_BODY) && (rt == mjOBJ_GEOM || rt == mjOBJ_BODY);
+        if (ok) {
+          const int n1 = ot == mjOBJ_BODY ? m->body_geomnum[m->sensor_objid[i]] : 1, a1 = ot == mjOBJ_BODY ? m->body_geomadr[m->sensor_objid[i]] : m->sensor_objid[i];
+          const int n2 = rt == mjOBJ_BODY ? m->body_geomnum[m->sensor_refid[i]] : 1, a2 = rt == mjOBJ_BODY ? m->body_geomadr[m->sensor_refid[i]] : m->sensor_refid[i];
+          for (int g1 = a1; g1 < a1 + n1 && ok; g1++)
+            for (int g2 = a2; g2 < a2 + n2 && ok; g2++) {
+              int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+              if (t1 > t2) std::swap(t1, t2);
+              const bool point = (t1 == mjGEOM_PLANE || t1 == mjGEOM_SPHERE || t1 == mjGEOM_CAPSULE) && (t2 == mjGEOM_PLANE || t2 == mjGEOM_SPHERE || t2 == mjGEOM_CAPSULE);
+              const bool sph = t1 == mjGEOM_SPHERE && (t2 == mjGEOM_BOX || t2 == mjGEOM_CYLINDER);
+              if (!point && !sph) ok = false;
+            }
+        }
+        if (ok) {
+          t = m->sensor_type[i] == mjSENS_GEOMDIST ? MJH_SENS_GEOMDIST : (m->sensor_type[i] == mjSENS_GEOMNORMAL ? MJH_SENS_GEOMNORMAL : MJH_SENS_GEOMFROMTO);
+          H->sensor_objtype[i] = ot == mjOBJ_BODY ? MJH_OBJ_BODY : MJH_OBJ_GEOM;
+          H->sensor_reftype[i] = rt == mjOBJ_BODY ? MJH_OBJ_BODY : MJH_OBJ_GEOM;
+        }
+        break;
+      }
       case mjSENS_E_POTENTIAL: t = MJH_SENS_E_POTENTIAL; s.sens_energy |= 1; break;
       case mjSENS_E_KINETIC: t = MJH_SENS_E_KINETIC; s.sens_energy |= 2; break;
       case mjSENS_VELOCIMETER: t = MJH_SENS_VELOCIMETER; break;
@@ -1603,8 +1628,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       default: break;
     }
     MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
-                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact / camprojection / energy (camera rangefinders, geom distance, "
-                      "tactile, user, plugin)");
+                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact / camprojection / energy / geom distance between planes, spheres and "
+                      "capsules (camera rangefinders, geom distance through the convex pipeline or the box colliders, tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {
       if (ot == mjOBJ_BODY) *out = MJH_OBJ_BODY;

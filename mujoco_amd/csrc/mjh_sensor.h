@@ -401,6 +401,41 @@ MJH_DEV void sens_rne_post(MREF M, BREF B, int e) {
     for (int q = 0; q < 6; q++) cint[6*M.body_parentid[j] + q] += cint[6*j + q];
 }
 
+// mj_geomDistance (engine_support.c:553-604) for pairs with a closed-form collider: the collider runs with the cutoff as its
+// margin, the contact of smallest distance wins (the first one on ties), and the segment runs from the surface of geom1
+// to the surface of geom2 through the contact point.  Returns the distance (distmax when nothing is in reach).
+template <class GX, class GM>
+MJH_DEV real sens_geom_distance(MREF M, GX gx, GM gm, int geom1, int geom2, real distmax, real* fromto) {
+  for (int k = 0; k < 6; k++) fromto[k] = 0;
+  const int flip = M.geom_type[geom1] > M.geom_type[geom2];
+  const int g1 = flip ? geom2 : geom1, g2 = flip ? geom1 : geom2;
+  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  auto mat1 = gm + 9*g1; auto size1 = M.geom_size + 3*g1;
+  auto mat2 = gm + 9*g2; auto size2 = M.geom_size + 3*g2;
+  const V3 c1 = ld3(gx + 3*g1), c2 = ld3(gx + 3*g2);
+  Hit ha, hb;
+  int n = 0;
+  if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_SPHERE) n = hit_plane_sphere(ha, distmax, c1, mcol(mat1, 2), c2, size2[0]);
+  else if (t1 == MJH_GEOM_PLANE && t2 == MJH_GEOM_CAPSULE) n = hit_plane_capsule(ha, hb, distmax, c1, mcol(mat1, 2), c2, mat2, size2);
+  else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_SPHERE) n = hit_sphere_sphere(ha, distmax, c1, mat1, size1[0], c2, mat2, size2[0]);
+  else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CAPSULE) n = hit_sphere_capsule(ha, distmax, c1, mat1, size1[0], c2, mat2, size2);
+  else if (t1 == MJH_GEOM_CAPSULE && t2 == MJH_GEOM_CAPSULE) n = hit_capsule_capsule(ha, hb, distmax, c1, mat1, size1, c2, mat2, size2);
+  else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_BOX) n = hit_sphere_box(ha, distmax, c1, size1[0], c2, mat2, size2);
+  else if (t1 == MJH_GEOM_SPHERE && t2 == MJH_GEOM_CYLINDER) n = hit_sphere_cylinder(ha, distmax, c1, mat1, size1[0], c2, mat2, size2);
+  real dist = distmax;
+  int smallest = -1;
+  if (n > 0 && ha.dist < dist) { dist = ha.dist; smallest = 0; }
+  if (n > 1 && hb.dist < dist) { dist = hb.dist; smallest = 1; }
+  if (smallest >= 0) {
+    const V3 pos = smallest ? hb.pos : ha.pos, nrm = smallest ? hb.nrm : ha.nrm;
+    const real sign = flip ? -1 : 1;
+    const real s0 = -0.5*sign*dist, s1 = 0.5*sign*dist;
+    fromto[0] = pos.x + nrm.x*s0; fromto[1] = pos.y + nrm.y*s0; fromto[2] = pos.z + nrm.z*s0;
+    fromto[3] = pos.x + nrm.x*s1; fromto[4] = pos.y + nrm.y*s1; fromto[5] = pos.z + nrm.z*s1;
+  }
+  return dist;
+}
+
 // mj_energyPos (engine_sensor.c:1659-1762): gravitational potential of the body inertial frames, joint springs (with
 // their polynomial terms: mju_polyPotential, engine_util_misc.c:2344), tendon springs outside their dead band.  One lane,
 // sums in the reference's order.  (Flex edge springs: sensors in models with flexes are rejected.)
@@ -619,6 +654,32 @@ MJH_DEVN void stage_sensors(MREF M_, BREF B_, int e_, int which) {
     case MJH_SENS_SUBTREELINVEL: { crptr c = MJH_G(B, subtree_linvel, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
     case MJH_SENS_SUBTREEANGMOM: { crptr c = MJH_G(B, subtree_angmom, e) + 3*objid; v[0] = c[0]; v[1] = c[1]; v[2] = c[2]; } break;
     case MJH_SENS_CLOCK: v[0] = MJH_F(B, time, e)[0]; break;
+    case MJH_SENS_GEOMDIST: case MJH_SENS_GEOMNORMAL: case MJH_SENS_GEOMFROMTO: {
+      // (engine_sensor.c:759-812: every geom of the one side against every geom of the other, the closest pair wins)
+      const real cut = M.sensor_cutoff[i];
+      crptr gx = MJH_F(B, geom_xpos, e);
+      crptr gm = MJH_F(B, geom_xmat, e);
+      real dist = cut, ft[6] = {0, 0, 0, 0, 0, 0};
+      const int n1 = objtype == MJH_OBJ_BODY ? (int)M.body_geomnum[objid] : 1, id1 = objtype == MJH_OBJ_BODY ? (int)M.body_geomadr[objid] : objid;
+      const int n2 = reftype == MJH_OBJ_BODY ? (int)M.body_geomnum[refid] : 1, id2 = reftype == MJH_OBJ_BODY ? (int)M.body_geomadr[refid] : refid;
+      for (int g1 = id1; g1 < id1 + n1; g1++)
+        for (int g2 = id2; g2 < id2 + n2; g2++) {
+          real fn[6];
+          const real dn = sens_geom_distance(M, gx, gm, g1, g2, cut, fn);
+          if (dn < dist) { dist = dn; for (int k = 0; k < 6; k++) ft[k] = fn[k]; }
+        }
+      if (type == MJH_SENS_GEOMDIST) v[0] = dist;
+      else if (type == MJH_SENS_GEOMNORMAL) {
+        real nn[3] = {ft[3] - ft[0], ft[4] - ft[1], ft[5] - ft[2]};
+        if (nn[0] != 0 || nn[1] != 0 || nn[2] != 0) v3_normalize(nn);
+        v[0] = nn[0]; v[1] = nn[1]; v[2] = nn[2];
+      } else {
+        // (the cutoff of a fromto sensor is its search radius, not a clamp: apply_cutoff returns early, :204-208)
+        const int adr = M.sensor_adr[i];
+        for (int k = 0; k < 6; k++) out[adr + k] = ft[k];
+        continue;
+      }
+    } break;
     case MJH_SENS_E_POTENTIAL: v[0] = MJH_G(B, energy, e)[0]; break;
     case MJH_SENS_E_KINETIC: v[0] = MJH_G(B, energy, e)[1]; break;
     case MJH_SENS_VELOCIMETER: case MJH_SENS_GYRO: {

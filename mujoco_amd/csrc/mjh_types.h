@@ -1007,6 +1007,7 @@ enum {
   MJH_SENS_VELOCIMETER, MJH_SENS_GYRO, MJH_SENS_ACCELEROMETER, MJH_SENS_FORCE, MJH_SENS_TORQUE,
   MJH_SENS_MAGNETOMETER, MJH_SENS_TOUCH, MJH_SENS_INSIDESITE, MJH_SENS_TENDONACTFRC, MJH_SENS_RANGEFINDER,
   MJH_SENS_CONTACT, MJH_SENS_CAMPROJECTION, MJH_SENS_E_POTENTIAL, MJH_SENS_E_KINETIC,
+  MJH_SENS_GEOMDIST, MJH_SENS_GEOMNORMAL, MJH_SENS_GEOMFROMTO,
   MJH_OBJ_BODY = 0, MJH_OBJ_XBODY = 1, MJH_OBJ_GEOM = 2, MJH_OBJ_SITE = 3, MJH_OBJ_NONE = 4, MJH_OBJ_CAMERA = 5,
   MJH_DYN_NONE = 0, MJH_DYN_INTEGRATOR = 1, MJH_DYN_FILTER = 2, MJH_DYN_FILTEREXACT = 3, MJH_DYN_MUSCLE = 4,
   MJH_SOL_PGS = 0, MJH_SOL_CG = 1, MJH_SOL_NEWTON = 2,

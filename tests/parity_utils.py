@@ -396,6 +396,10 @@ SENSOR_XML = """
     <framelinacc objtype="site" objname="tip"/><frameangacc objtype="body" objname="f1"/>
     <subtreecom body="a1"/><subtreelinvel body="a1"/><subtreeangmom body="a1"/><subtreeangmom body="p1"/>
     <clock/><e_potential/><e_kinetic/>
+    <distance geom1="g3" geom2="floor" cutoff="1"/><normal geom1="g1" geom2="gf" cutoff="2"/><fromto geom1="gf" geom2="g3" cutoff="3"/>
+    <distance body1="a2" body2="f1" cutoff="2"/><fromto body1="f1" body2="a1" cutoff="2"/><normal geom1="floor" geom2="gf" cutoff=".5"/>
+    <fromto geom1="g3" geom2="tgt_box" cutoff="2"/><distance geom1="tgt_cyl" geom2="g3" cutoff="2"/><fromto geom1="ghost" geom2="g3" cutoff=".2"/>
+    <distance geom1="floor" geom2="g3" cutoff=".01"/>
     <velocimeter site="imu1"/><gyro site="imu2"/><accelerometer site="imu1"/><accelerometer site="imuf"/>
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>
