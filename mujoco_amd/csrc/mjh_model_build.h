@@ -1622,13 +1622,14 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         break;
       case mjSENS_TOUCH: {
         const int st = m->site_type[m->sensor_objid[i]];
-        if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX) t = MJH_SENS_TOUCH;
-        break;     // capsule / cylinder touch zones: not evaluated yet -> rejected below
+        // (the zone test is mju_rayGeom on the site: every primitive the rangefinders intersect)
+        if (st == mjGEOM_SPHERE || st == mjGEOM_ELLIPSOID || st == mjGEOM_BOX || st == mjGEOM_CAPSULE || st == mjGEOM_CYLINDER) t = MJH_SENS_TOUCH;
+        break;
       }
       default: break;
     }
     MJH_REJECT(t < 0, "sensor types other than joint/tendon/actuator/ball/limit/frame/subtree/clock/IMU/force/torque/magnetometer/insidesite/"
-                      "touch with sphere, ellipsoid or box zones / site rangefinders / contact / camprojection / energy / geom distance between planes, spheres and "
+                      "touch / site rangefinders / contact / camprojection / energy / geom distance between planes, spheres and "
                       "capsules (camera rangefinders, geom distance through the convex pipeline or the box colliders, tactile, user, plugin)");
     H->sensor_type[i] = t;
     auto frame_obj = [&](int ot, int* out) -> bool {

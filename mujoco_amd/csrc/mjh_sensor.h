@@ -274,7 +274,7 @@ MJH_DEV void ray_geom_normal(int type, P0 pos, P1 mat, P2 size, const real* pnt,
   }
   rotate(n);
 }
-// does the ray meet a site's zone at all (touch sensors: sphere, ellipsoid and box zones)?
+// does the ray meet a site's zone at all (touch sensors: sphere, ellipsoid, box, capsule and cylinder zones)?
 template <class P0, class P1, class P2>
 MJH_DEV int ray_hits_zone(int type, P0 pos, P1 mat, P2 size, const real* pnt, const real* vec) {
   return ray_geom_dist(type, pos, mat, size, pnt, vec) >= 0;

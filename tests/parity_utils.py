@@ -369,7 +369,8 @@ SENSOR_XML = """
     <body name="f1" pos="-.5 0 .08" euler="0 70 20"><freejoint/><geom name="gf" fromto="-.1 0 0 .1 0 0" size=".04"/>
       <site name="imuf" pos=".05 0 .01" euler="5 10 15"/>
       <site name="touch_box" type="box" size=".16 .06 .06"/><site name="touch_sph" type="sphere" size=".045" pos=".1 0 0"/>
-      <site name="touch_ell" type="ellipsoid" size=".13 .05 .03" pos="-.04 0 0"/></body>
+      <site name="touch_ell" type="ellipsoid" size=".13 .05 .03" pos="-.04 0 0"/>
+      <site name="touch_cap" type="capsule" size=".042 .07" pos=".02 0 0" euler="0 90 0"/><site name="touch_cyl" type="cylinder" size=".045 .12" euler="0 90 5"/></body>
     <body name="f2" pos="-.5 .4 .3"><freejoint/><geom type="sphere" size=".05"/><site name="f2s"/><site name="rf_down" pos="0 0 -.06" euler="180 0 0"/><site name="rf_up" pos="0 0 .06"/></body>
     <body name="p1" pos=".3 -.5 .5"><joint name="q1" axis="1 0 0"/><geom fromto="0 0 0 0 0 -.2"/>
       <body pos="0 0 -.2"><joint name="q2" axis="1 0 0" range="-30 30" limited="true"/><geom fromto="0 0 0 0 0 -.2"/><site name="p_end" pos="0 0 -.2"/></body></body>
@@ -403,7 +404,7 @@ SENSOR_XML = """
     <velocimeter site="imu1"/><gyro site="imu2"/><accelerometer site="imu1"/><accelerometer site="imuf"/>
     <force site="imu2"/><torque site="imu2"/><force site="imuf"/><torque site="p_end"/>
     <magnetometer site="imu1"/>
-    <touch site="touch_box"/><touch site="touch_sph"/><touch site="touch_ell"/>
+    <touch site="touch_box"/><touch site="touch_sph"/><touch site="touch_ell"/><touch site="touch_cap"/><touch site="touch_cyl"/>
     <rangefinder site="rf_down" data="dist normal"/><rangefinder site="rf_side" data="dist dir origin point normal depth"/><rangefinder site="rf_tip" data="dist point normal"/><rangefinder site="rf_up"/>
     <insidesite objtype="body" objname="f1" site="zone_box"/><insidesite objtype="site" objname="tip" site="zone_cyl"/><insidesite objtype="xbody" objname="a3" site="zone_sph"/><insidesite objtype="geom" objname="g3" site="zone_cap"/>
     <framepos objtype="site" objname="world_s"/><framelinvel objtype="site" objname="world_s"/>
