@@ -1014,8 +1014,11 @@ MJH_DEV void store_contact(MREF M, BREF B, int e, int c, int p, const Hit& h) {
   iptr cgeom = MJH_CON(B, con_geom, e, 2, c);
   cgeom[0] = M.pair_geom1[p];
   cgeom[1] = M.pair_geom2[p];
-  MJH_CON(B, con_dim, e, 1, c)[0] = M.pair_dim[p];
-  MJH_CON(B, con_exclude, e, 1, c)[0] = (h.dist >= M.pair_includemargin[p]) ? 1 : 0;
+  // (an adhesive contact stays active in the gap, as one frictionless row whose reference acceleration pulls: :1853-1862)
+  const int ingap = (h.dist >= M.pair_includemargin[p]) ? 1 : 0;
+  const int adhesive = MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_adhesion && M.pair_adhesion[p] != 0;
+  MJH_CON(B, con_dim, e, 1, c)[0] = (adhesive && ingap) ? 1 : (int)M.pair_dim[p];
+  MJH_CON(B, con_exclude, e, 1, c)[0] = (ingap && !adhesive) ? 1 : 0;
   MJH_CON(B, con_efcadr, e, 1, c)[0] = -1;
   MJH_CON(B, con_mu, e, 1, c)[0] = 0;
   if (MJH_HAS(MJH_FT_FLEX) && M.s.nconflex) { iptr cf = MJH_G(B, con_flex, e) + MJH_CONFLEX*c; for (int q = 0; q < MJH_CONFLEX; q++) cf[q] = -1; }

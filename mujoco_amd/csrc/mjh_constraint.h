@@ -1457,6 +1457,25 @@ MJH_DEVN void stage_reference(MREF M_, BREF B_, int e_) {
     }
     wv_sync();
   }
+  // adhesive contact rows: aref += R * adhesion on the normal row, or the pyramid's edges in equal shares
+  // (mj_adhesionRef, :3214-3241)
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_adhesion) {
+    const int ncon = MJH_F(B, counts, e)[MJH_C_NCON];
+    crptr R = P.R;
+    MJH_FOR_LANES(c, ncon) {
+      const int adr = MJH_CON(B, con_efcadr, e, 1, c)[0];
+      const real adh = M.pair_adhesion[MJH_CON(B, con_pair, e, 1, c)[0]];
+      if (adh == 0 || adr < 0) continue;
+      const int dim = MJH_CON(B, con_dim, e, 1, c)[0];
+      if (dim == 1 || M.o.cone != 0) {
+        aref[adr] += R[adr]*adh;
+      } else {
+        const real edge = adh / (2*(dim - 1));
+        for (int j = 0; j < 2*(dim - 1); j++) aref[adr + j] += R[adr + j]*edge;
+      }
+    }
+    wv_sync();
+  }
   // subtract Jdot*v for connect / weld equalities               (mj_Jdotv, :1056-1250)
   const int ne = MJH_F(B, counts, e)[MJH_C_NE];
   if (MJH_HAS(MJH_FT_EQUALITY) && ne) {

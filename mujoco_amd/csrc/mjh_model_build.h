@@ -194,7 +194,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   }
   MJH_REJECT(m->nsensor > 0 && m->nflex > 0, "sensors in models with flexes");
   MJH_REJECT(m->nhistory > 0, "history buffers / delays");
-  MJH_REJECT(m->flg_adhesion, "contact adhesion");
+  MJH_REJECT(m->flg_adhesion && m->nflex > 0, "contact adhesion in models with flexes");
   MJH_REJECT(m->opt.integrator != mjINT_EULER && m->opt.integrator != mjINT_RK4 && m->opt.integrator != mjINT_IMPLICITFAST &&
              m->opt.integrator != mjINT_IMPLICIT, "unknown integrator");
   MJH_REJECT(m->opt.solver != mjSOL_PGS && m->opt.solver != mjSOL_NEWTON && m->opt.solver != mjSOL_CG, "unknown solver type");
@@ -538,6 +538,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     for (int i = 0; i < m->nv; i++) H->dof_actgravcomp[i] = m->jnt_actgravcomp[m->dof_jntid[i]] ? 1 : 0;
   }
   o.has_surfacevel = m->flg_surfacevel ? 1 : 0;
+  o.has_adhesion = m->flg_adhesion ? 1 : 0;
   copy_arr(H->geom_surfacevel, m->geom_surfacevel, 6*m->ngeom);
   o.has_fluid = (m->opt.density != 0 || m->opt.viscosity != 0) ? 1 : 0;
   o.density = m->opt.density; o.viscosity = m->opt.viscosity;
@@ -731,6 +732,8 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           for (int k = 0; k < 3; k++) fri[k] = std::max(f1[k], f2[k]);
         }
         real friction[5] = {fri[0], fri[0], fri[1], fri[2], fri[2]};
+        // adhesion: each surface contributes its own attraction; the side with the higher priority alone (:1763-1779)
+        real adhesion = p1 > p2 ? m->geom_adhesion[g1] : p1 < p2 ? m->geom_adhesion[g2] : m->geom_adhesion[g1] + m->geom_adhesion[g2];
         real margin = m->geom_margin[g1] + m->geom_margin[g2];
         real gap = m->geom_gap[g1] + m->geom_gap[g2];
         real solreffriction[2] = {0, 0};
@@ -744,6 +747,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
           for (int k = 0; k < 2; k++) solreffriction[k] = m->pair_solreffriction[2*ip + k];
           margin = m->pair_margin[ip];
           gap = m->pair_gap[ip];
+          adhesion = m->pair_adhesion[ip];
           MJH_REJECT((solreffriction[0] > 0) != (solreffriction[1] > 0), "mixed-sign pair solreffriction");
         }
         if (override_) {
@@ -774,6 +778,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         pair_b2.push_back(gp.b2);
         H->pair_margin.push_back(margin + gap);
         H->pair_includemargin.push_back(margin);
+        H->pair_adhesion.push_back(adhesion);
         for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
         for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
         for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(solreffriction[k]);
@@ -994,6 +999,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         H->pair_dim.push_back(condim);
         H->pair_margin.push_back(margin + gap);
         H->pair_includemargin.push_back(margin);
+        H->pair_adhesion.push_back(0);
         for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
         for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
         for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
@@ -1079,6 +1085,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
         H->pair_dim.push_back(condim);
         H->pair_margin.push_back(margin);
         H->pair_includemargin.push_back(margin);
+        H->pair_adhesion.push_back(0);
         for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
         for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
         for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
@@ -1129,6 +1136,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
       H->pair_dim.push_back(m->flex_condim[f]);
       H->pair_margin.push_back(0);
       H->pair_includemargin.push_back(0);
+      H->pair_adhesion.push_back(0);
       for (int k = 0; k < 5; k++) H->pair_friction.push_back(friction[k]);
       for (int k = 0; k < 2; k++) H->pair_solref.push_back(solref[k]);
       for (int k = 0; k < 2; k++) H->pair_solreffriction.push_back(0);
@@ -2327,7 +2335,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     }
     for (int i = 0; i < m->njnt; i++) if (m->jnt_actfrclimited[i]) ft |= MJH_FT_GAINBIAS;
     if (o.has_ten_actfrc) ft |= MJH_FT_GAINBIAS;
-    if (o.has_gravcomp || o.has_fluid || o.has_surfacevel || o.has_ten_armature) ft |= MJH_FT_PASSIVEMISC;
+    if (o.has_gravcomp || o.has_fluid || o.has_surfacevel || o.has_ten_armature || o.has_adhesion) ft |= MJH_FT_PASSIVEMISC;
     if (m->nmocap > 0) ft |= MJH_FT_MOCAP;
     if (m->ntree > 1) ft |= MJH_FT_ISLANDS;
     if (m->nflex > 0) ft |= MJH_FT_FLEX;

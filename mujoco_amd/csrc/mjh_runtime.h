@@ -593,6 +593,9 @@ MJHIP_API int mjhip_batch_plan_lds(mjhipBatch* Bt, int lds_bytes) {
     for (const char* f : {"geom_xpos", "geom_xmat", "con_pos", "con_frame", "con_pair", "con_geom", "con_dim", "con_efcadr"})
       eqskip.push_back(f);
   }
+  if (Bt->model->H.o.has_adhesion) {     // the reference stage looks the adhesive rows up through the contacts
+    for (const char* f : {"con_pair", "con_dim", "con_efcadr"}) eqskip.push_back(f);
+  }
   if (Bt->model->H.o.has_fluid) { eqskip.push_back("xipos"); eqskip.push_back("ximat"); }
   if (Bt->model->H.s.ngeom_fluid) { eqskip.push_back("geom_xpos"); eqskip.push_back("geom_xmat"); }   // ellipsoid fluid model: geom frames at the passive stage
   if (Bt->xfrc_on) eqskip.push_back("xipos");                  // Cartesian forces act at the body COMs (stage_acceleration)

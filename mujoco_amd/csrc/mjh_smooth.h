@@ -1661,6 +1661,55 @@ MJH_DEVN void stage_passive(MREF M_, BREF B_, int e_) {
     }
     wv_sync();
   }
+  // adhesion (mj_adhesion, engine_passive.c:982-1050 + :1104-1109): a constant attraction -adhesion along the normal of
+  // every adhesive contact (active or in the gap), through the normal row of the contact Jacobian; the contacts in
+  // order per dof, summed from zero (qfrc_adhesion) and then added to qfrc_passive -- after the fluid forces, before
+  // gravity compensation
+  if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_adhesion && !(dsbl & (1<<4))) {
+    const int ncon = MJH_F(B, counts, e)[MJH_C_NCON];
+    crptr cdof = MJH_F(B, cdof, e);
+    crptr com = MJH_F(B, subtree_com, e);
+    MJH_FOR_LANES(j, s.nv) {
+      real acc = 0;
+      int any = 0;
+      crptr cd = cdof + 6*j;
+      for (int c = 0; c < ncon; c++) {
+        const real adh = M.pair_adhesion[MJH_CON(B, con_pair, e, 1, c)[0]];
+        if (adh == 0 || MJH_CON(B, con_exclude, e, 1, c)[0] > 1) continue;
+        any = 1;
+        ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+        crptr point = MJH_CON(B, con_pos, e, 3, c);
+        crptr fr = MJH_CON(B, con_frame, e, 9, c);
+        const int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+        const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+        const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+        // translational point Jacobians of both bodies (mj_jac, engine_core_util.c:176), their difference,
+        // its projection on the normal (mju_mulMatMat with zero-skip)
+        real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+        if (in1) {
+          real off[3], t[3];
+          v3_sub(off, point, com + 3*M.body_rootid[b1]);
+          v3_cross(t, cd, off);
+          j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2];
+        }
+        if (in2) {
+          real off[3], t[3];
+          v3_sub(off, point, com + 3*M.body_rootid[b2]);
+          v3_cross(t, cd, off);
+          j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
+        }
+        real jn = 0;
+        for (int q = 0; q < 3; q++) {
+          const real t = fr[q];
+          if (t != 0) jn += (j2[q] - j1[q])*t;
+        }
+        acc += jn*(-adh);
+      }
+      if (any) fp[j] += acc;
+    }
+    wv_sync();
+  }
   // gravity compensation (mj_gravcomp, engine_passive.c:846-867 + :1112-1122): per compensated
   // body a force -gravity*mass*gravcomp at its COM, mapped through the point Jacobian (mj_applyFT)
   if (MJH_HAS(MJH_FT_PASSIVEMISC) && M.o.has_gravcomp && !(dsbl & (1<<7)) &&

@@ -402,6 +402,7 @@
   X(actuator_cranklength, s.nu)                \
   X(pair_margin, (s.npair + s.nflexpair))                      \
   X(pair_includemargin, (s.npair + s.nflexpair))               \
+  X(pair_adhesion, (s.npair + s.nflexpair))   /* mj_contactParam's adhesion of the pair (0: none) */ \
   X(pair_friction, 5 * (s.npair + s.nflexpair))                \
   X(pair_solref, 2 * (s.npair + s.nflexpair))                  \
   X(pair_solreffriction, 2 * (s.npair + s.nflexpair))          \
@@ -574,6 +575,7 @@ struct DOptions {
   int has_tendon_wrap;   // some spatial tendon wraps around a sphere / cylinder: the tendon stage reads the geom frames
   int has_gravcomp;
   int has_surfacevel; // some geom has a surface velocity (conveyor belts)
+  int has_adhesion;   // some geom or pair is adhesive (mjModel.flg_adhesion)
   int has_fluid;      // opt.density / opt.viscosity set: inertia-box fluid forces
   real density, viscosity, wind[3];
   real ccd_tolerance;     // opt.ccd_tolerance

@@ -827,6 +827,32 @@ SURFACEVEL_XML = """<mujoco>
 """
 
 
+# contact adhesion (geom `adhesion`, pair `adhesion`): a magnetic door catch working across its gap band, adhesive
+# spheres on / above the floor (pyramid and ellipse rows biased by mj_adhesionRef, a tether row in the gap), the
+# higher priority taking its own adhesion alone, a predefined pair with its own adhesion
+ADHESION_XML = """<mujoco>
+  <option timestep="0.004" solver="PGS" iterations="50"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="4 4 .01"/>
+    <geom name="strike" type="box" size=".005 .01 .3" pos="-.015 .19 .4" adhesion="1.5" gap=".003"/>
+    <body name="door" pos="0 .45 .4">
+      <joint name="hinge" axis="0 0 1" pos=".02 .25 0" damping=".02"/>
+      <geom type="box" size=".01 .25 .3" mass="1"/>
+      <geom name="catch" type="box" size=".005 .01 .3" pos="-.005 -.251 0" adhesion="1.5" gap=".003" mass=".05"/>
+    </body>
+    <body pos="1 0 .0505"><freejoint/><geom name="sticky" type="sphere" size=".05" adhesion="4" gap=".02" condim="3"/></body>
+    <body pos="1 .5 .062"><freejoint/><geom name="hover" type="sphere" size=".05" adhesion=".3" gap=".03" mass=".02"/></body>
+    <body pos="1 1 .049"><freejoint/><geom name="prio" type="capsule" size=".05 .1" euler="90 0 0" adhesion="2" priority="1" condim="4" gap=".01"/></body>
+    <body pos="-1 0 .3"><freejoint/><geom name="pa" type="sphere" size=".06"/></body>
+    <body pos="-1 0 .1"><freejoint/><geom name="pb" type="box" size=".1 .1 .1" adhesion=".5"/></body>
+  </worldbody>
+  <contact>
+    <pair geom1="pa" geom2="pb" adhesion="3" gap=".02" condim="3"/>
+  </contact>
+</mujoco>
+"""
+
+
 # geoms that touch EXACTLY (to the last bit): the reference's sweep-and-prune rounds the sweep-axis
 # end points to float and breaks ties by array position (engine_collision_driver.c:1456-1470), so
 # whether such a body pair reaches the narrowphase depends on body order; plus stacked spheres on a

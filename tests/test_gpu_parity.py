@@ -13,7 +13,7 @@ import pytest
 from mujoco_amd import _capi as K
 import mujoco_amd
 from conftest import GOLDEN, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, TENDON_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, TENDON_XML, ADHESION_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -520,6 +520,39 @@ def test_predefined_contact_pairs_vs_live_oracle(rb, hip_lib, tmp_path, cone):
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     print("pair scene cone", cone, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
     assert relerr(out, ref) <= TOL
+
+
+@pytest.mark.parametrize("cone,solver,integrator", [(0, 0, 0), (1, 0, 0), (0, 2, 2), (1, 2, 3)])
+def test_contact_adhesion_vs_live_oracle(rb, hip_lib, tmp_path, cone, solver, integrator):
+    """geom / pair adhesion: adhesive contacts active in the gap (one frictionless row), the attraction in qfrc_passive
+    (mj_adhesion), the rows' biased reference acceleration (mj_adhesionRef); a magnetic door catch and adhesive geoms"""
+    xml = tmp_path / "adh.xml"
+    xml.write_text(ADHESION_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    m.opt.solver = solver
+    m.opt.integrator = integrator
+    dma = K.DeviceModel(hip_lib, m)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[0] = -1.0
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 200
+    ctrl = np.zeros((1, T, 0))
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
+    b = K.Batch(dma, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
+    print("adhesion scene cone", cone, "solver", solver, "integrator", integrator, "rel err", relerr(out, ref), "max ncon", ints[0, :, 0].max())
+    assert relerr(out, ref) <= TOL
+    assert b.get("warning").sum() == 0
+    if solver == 0:
+        rb.mj_resetData(m, d)
+        d.qvel[0] = -1.0
+        for stop in (1, 25, 60):
+            while round(d.time / m.opt.timestep) < stop:
+                rb.mj_step(m, d)
+            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.zeros(0))]
+            check_forward(rb, m, b, st, tol=TOL)
 
 
 @pytest.mark.parametrize("integrator", [1, 2, 3])

@@ -10,7 +10,7 @@ import pytest
 
 from mujoco_amd import _capi as K
 from conftest import GOLDEN, HOSTSIM_LIB, ROOT, contact_rich_states, humanoid_pgs_oracle, many_constraint_states
-from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
+from parity_utils import CYL_XML, EQ_XML, IMPL_XML, CONDIM_XML, ACT_XML, SENSOR_XML, BOX_XML, BOXBOX_XML, CAPBOX_XML, MOCAP_XML, PAIR_XML, FLUID_XML, ELLIPSOID_FLUID_XML, CAMERA_XML, ISLANDS_XML, TENDON_XML, WRAP_XML, ACT_GROUP_XML, MUSCLE_XML, SITE_ACT_XML, BALL_ACT_XML, SURFACEVEL_XML, ADHESION_XML, condim_scene_state, chain_xml, many_spheres_xml, check_forward, oracle_rollout, relerr
 
 
 @pytest.fixture(scope="module")
@@ -1209,6 +1209,42 @@ def test_geom_surface_velocity(rb, hostsim_lib, tmp_path, cone, solver, tol):
     else:
         assert relerr(out, ref) <= tol
     assert b.get("warning").sum() == 0
+
+
+@pytest.mark.parametrize("cone,solver,integrator,tol", [(0, 0, 0, 0.0), (1, 0, 0, 0.0), (0, 2, 2, 1e-9), (1, 2, 3, 1e-9), (0, 0, 1, 0.0)])
+def test_contact_adhesion(rb, hostsim_lib, tmp_path, cone, solver, integrator, tol):
+    """geom / pair adhesion: mj_contactParam's adhesion (engine_collision_driver.c:1763-1779), adhesive contacts active in
+    the gap as one frictionless row (mj_setContact :1853-1862), the constant attraction in qfrc_passive (mj_adhesion,
+    engine_passive.c:982-1050) and the bias of the rows' reference acceleration (mj_adhesionRef, engine_core_constraint.c:3214)"""
+    xml = tmp_path / "adh.xml"
+    xml.write_text(ADHESION_XML)
+    m = rb.MjModel.from_xml_path(str(xml))
+    m.opt.cone = cone
+    m.opt.solver = solver
+    m.opt.integrator = integrator
+    dm = K.DeviceModel(hostsim_lib, m, 64, 200)
+    d = rb.MjData(m)
+    rb.mj_resetData(m, d)
+    d.qvel[0] = -1.0                       # the door swings shut and is caught
+    s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
+    T = 120 if integrator != 1 else 40
+    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    b = K.Batch(dm, 1)
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    if tol == 0.0:
+        assert np.array_equal(out, ref)
+    else:
+        assert relerr(out, ref) <= tol
+    assert b.get("warning").sum() == 0
+    # every field of mj_forward along the way (qfrc_passive with the attraction, efc_aref with the bias, contact dims)
+    if solver == 0:
+        rb.mj_resetData(m, d)
+        d.qvel[0] = -1.0
+        for stop in (1, 25, 60):
+            while round(d.time / m.opt.timestep) < stop:
+                rb.mj_step(m, d)
+            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.zeros(0))]
+            assert check_forward(rb, m, b, st, tol=0.0) == 0.0
 
 
 def _sensor_reference(rb, m, s0, ctrl):
