@@ -234,9 +234,18 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
     MJH_REJECT(m->actuator_plugin[i] >= 0, "actuator plugins");
     MJH_REJECT(m->actuator_delay[i] != 0, "actuator delays");
     int tt = m->actuator_trntype[i];
-    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT && tt != mjTRN_SLIDERCRANK && tt != mjTRN_TENDON && tt != mjTRN_SITE,
-               "actuator transmissions other than joint / slider-crank / tendon / site (body, SO3)");
+    MJH_REJECT(tt != mjTRN_JOINT && tt != mjTRN_JOINTINPARENT && tt != mjTRN_SLIDERCRANK && tt != mjTRN_TENDON && tt != mjTRN_SITE && tt != mjTRN_BODY,
+               "actuator transmissions other than joint / slider-crank / tendon / site / body (SO3)");
     if (tt == mjTRN_TENDON) continue;      // (tendon-level armature / force limits are checked with the tendons)
+    if (tt == mjTRN_BODY) {
+      // adhesion actuators: the moment averages the normal rows of the body's contacts (mj_mulJacTVec over efc_J: dense or
+      // compressed, every moment entry sums the rows in order)
+      MJH_REJECT(m->nflex > 0, "body transmissions (adhesion actuators) in models with flexes");
+      MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
+                 m->actuator_dampingpoly[mjNPOLY*i] != 0 || m->actuator_dampingpoly[mjNPOLY*i + 1] != 0,
+                 "actuator-level armature/damping on a body transmission");
+      continue;
+    }
     if (tt == mjTRN_SITE) {
       if (m->actuator_trnid[2*i + 1] != -1) o.has_refsite = 1;      // (round 6: relative pose against a reference site)
       MJH_REJECT(m->actuator_armature[i] != 0 || m->actuator_damping[i] != 0 ||
@@ -625,7 +634,7 @@ static bool build(const mjModel* m, const BuildCaps& caps, HostModel* H, std::st
   H->actuator_momentadr.resize(m->nu + 1);
   H->actuator_momentadr[0] = 0;
   for (int i = 0; i < m->nu; i++)
-    H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + ((m->actuator_trntype[i] == mjTRN_SLIDERCRANK || m->actuator_trntype[i] == mjTRN_SITE) ? m->nv :
+    H->actuator_momentadr[i + 1] = H->actuator_momentadr[i] + ((m->actuator_trntype[i] == mjTRN_SLIDERCRANK || m->actuator_trntype[i] == mjTRN_SITE || m->actuator_trntype[i] == mjTRN_BODY) ? m->nv :
         ((m->actuator_trntype[i] == mjTRN_JOINT || m->actuator_trntype[i] == mjTRN_JOINTINPARENT) ?
           (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_BALL ? 3 : (m->jnt_type[m->actuator_trnid[2*i]] == mjJNT_FREE ? 6 : 1)) :
         (m->actuator_trntype[i] == mjTRN_TENDON ? std::max(1, m->ten_J_rownnz[m->actuator_trnid[2*i]]) : 1)));

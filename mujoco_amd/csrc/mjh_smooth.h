@@ -563,6 +563,90 @@ MJH_DEVN void stage_transmission(MREF M_, BREF B_, int e_) {
       }
       length[i] = 0;
       rownnz[i] = nnz;
+    } else if (MJH_HAS(MJH_FT_TRNMISC) && M.actuator_trntype[i] == MJH_TRN_BODY) {
+      // body (adhesion actuators; engine_core_smooth.c:1719-1830): moment = minus the average over the body's contacts of
+      // the normal Jacobian.  Active contacts enter through mj_mulJacTVec(efc_J, w) with w = 1 on the normal row
+      // (condim 1, elliptic cones) or 0.5 / (dim - 1) on every pyramid edge -- a sum over the constraint rows in order, i.e.
+      // over the contacts in order and their rows; efc_J's contact rows are a function of the contact and cdof alone
+      // (stage_make_constraint builds them later with the arithmetic restated here), and a contact has rows exactly when it
+      // is not excluded.  Contacts in the gap add their normal Jacobian directly; then the sum of both is scaled by
+      // -1 / count.  No meaningful length.
+      crptr cdof = MJH_F(B, cdof, e);
+      crptr com = MJH_F(B, subtree_com, e);
+      const int ncon = (M.o.disableflags & (1<<4)) ? 0 : MJH_F(B, counts, e)[MJH_C_NCON];
+      const int ispyramid = M.o.cone == 0;
+      int counter = 0;
+      for (int c = 0; c < ncon; c++) {
+        ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+        if (cg[0] < 0 || cg[1] < 0) continue;
+        if (M.geom_bodyid[cg[0]] != id && M.geom_bodyid[cg[1]] != id) continue;
+        if (MJH_CON(B, con_exclude, e, 1, c)[0] <= 1) counter++;
+      }
+      int nnz = 0;
+      for (int j = 0; counter && j < s.nv; j++) {
+        crptr cd = cdof + 6*j;
+        real act = 0, exc = 0;
+        for (int c = 0; c < ncon; c++) {
+          ciptr cg = MJH_CON(B, con_geom, e, 2, c);
+          if (cg[0] < 0 || cg[1] < 0) continue;
+          const int b1 = M.geom_bodyid[cg[0]], b2 = M.geom_bodyid[cg[1]];
+          if (b1 != id && b2 != id) continue;
+          const int excl = MJH_CON(B, con_exclude, e, 1, c)[0];
+          if (excl > 1) continue;
+          crptr point = MJH_CON(B, con_pos, e, 3, c);
+          crptr fr = MJH_CON(B, con_frame, e, 9, c);
+          const int w1 = M.body_weldid[b1], w2 = M.body_weldid[b2];
+          const int in1 = (M.body_dofanc[w1*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          const int in2 = (M.body_dofanc[w2*s.nvw + (j >> 5)] >> (j & 31)) & 1;
+          if (!in1 && !in2) continue;        // (a zero column: nothing to add)
+          real j1[3] = {0, 0, 0}, j2[3] = {0, 0, 0};
+          if (in1) {
+            real off[3], t[3];
+            v3_sub(off, point, com + 3*M.body_rootid[b1]);
+            v3_cross(t, cd, off);
+            j1[0] = cd[3] + t[0]; j1[1] = cd[4] + t[1]; j1[2] = cd[5] + t[2];
+          }
+          if (in2) {
+            real off[3], t[3];
+            v3_sub(off, point, com + 3*M.body_rootid[b2]);
+            v3_cross(t, cd, off);
+            j2[0] = cd[3] + t[0]; j2[1] = cd[4] + t[1]; j2[2] = cd[5] + t[2];
+          }
+          const real jd[3] = {j2[0] - j1[0], j2[1] - j1[1], j2[2] - j1[2]};
+          const real rd[3] = {(in2 ? cd[0] : (real)0) - (in1 ? cd[0] : (real)0),
+                              (in2 ? cd[1] : (real)0) - (in1 ? cd[1] : (real)0),
+                              (in2 ? cd[2] : (real)0) - (in1 ? cd[2] : (real)0)};
+          // one row of the contact-frame Jacobian: translational rows 0..2, rotational rows 3..5 (mju_mulMatMat with zero-skip)
+          auto frame_row = [&](int a) -> real {
+            const real* v = a < 3 ? jd : rd;
+            const int r = a < 3 ? a : a - 3;
+            real acc = 0;
+            for (int q = 0; q < 3; q++) {
+              const real t = fr[3*r + q];
+              if (t != 0) acc += v[q]*t;
+            }
+            return acc;
+          };
+          const real jn = frame_row(0);
+          if (excl == 1) { exc += jn; continue; }
+          const int dim = MJH_CON(B, con_dim, e, 1, c)[0];
+          if (dim == 1 || !ispyramid) {
+            act += jn*(real)1;
+          } else {
+            auto fri = M.pair_friction + 5*MJH_CON(B, con_pair, e, 1, c)[0];
+            const real w = 0.5/(dim - 1);
+            for (int a = 1; a < dim; a++) {
+              const real ja = frame_row(a);
+              act += (jn + ja*fri[a-1])*w;
+              act += (jn + ja*(-fri[a-1]))*w;
+            }
+          }
+        }
+        const real mrow = (act + exc)*(-1.0/counter);
+        if (mrow != 0) { moment[adr + nnz] = mrow; colind[adr + nnz] = j; nnz++; }
+      }
+      length[i] = 0;
+      rownnz[i] = nnz;
     } else if (MJH_HAS(MJH_FT_TRNMISC) && M.actuator_trntype[i] == MJH_TRN_TENDON) {
       // tendon (engine_core_smooth.c:1468-1480): the tendon's length and moment row, scaled by the gear
       crptr tl = MJH_F(B, ten_length, e);

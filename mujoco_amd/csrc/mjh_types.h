@@ -996,7 +996,7 @@ enum {
   MJH_WARN_INERTIA = 0, MJH_WARN_CONTACTFULL = 1, MJH_WARN_CNSTRFULL = 2,
   MJH_WARN_BADQPOS = 3, MJH_WARN_BADQVEL = 4, MJH_WARN_BADQACC = 5, MJH_WARN_BADCTRL = 6,
   MJH_WARN_UNSUPPORTED = 7,   // mjhip-only: an env reached a feature the GPU path does not implement
-  MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2, MJH_TRN_TENDON = 3, MJH_TRN_SITE = 4,
+  MJH_TRN_JOINT = 0, MJH_TRN_JOINTINPARENT = 1, MJH_TRN_SLIDERCRANK = 2, MJH_TRN_TENDON = 3, MJH_TRN_SITE = 4, MJH_TRN_BODY = 5,
   MJH_GAIN_FIXED = 0, MJH_GAIN_AFFINE = 1, MJH_GAIN_MUSCLE = 2,
   MJH_BIAS_NONE = 0, MJH_BIAS_AFFINE = 1, MJH_BIAS_MUSCLE = 2,
   // sensor kinds (host translation of mjtSensor) and frame-object kinds (mjtObj)

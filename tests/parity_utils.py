@@ -845,10 +845,19 @@ ADHESION_XML = """<mujoco>
     <body pos="1 1 .049"><freejoint/><geom name="prio" type="capsule" size=".05 .1" euler="90 0 0" adhesion="2" priority="1" condim="4" gap=".01"/></body>
     <body pos="-1 0 .3"><freejoint/><geom name="pa" type="sphere" size=".06"/></body>
     <body pos="-1 0 .1"><freejoint/><geom name="pb" type="box" size=".1 .1 .1" adhesion=".5"/></body>
+    <body name="grip" pos="1 1.5 .07"><freejoint/><geom type="sphere" size=".05" gap=".03" condim="3"/></body>
+    <body name="grip4" pos="1 2 .05"><freejoint/><geom type="box" size=".05 .06 .05" condim="4" gap=".01"/></body>
   </worldbody>
   <contact>
     <pair geom1="pa" geom2="pb" adhesion="3" gap=".02" condim="3"/>
   </contact>
+  <!-- adhesion actuators (body transmission): the moment averages the normal Jacobians of the body's contacts, active
+       (through the rows of efc_J) and in the gap -->
+  <actuator>
+    <adhesion body="grip" ctrlrange="0 1" gain="3"/>
+    <adhesion body="grip4" ctrlrange="0 1" gain="4"/>
+    <adhesion body="door" ctrlrange="0 1" gain="1"/>
+  </actuator>
 </mujoco>
 """
 

@@ -538,7 +538,7 @@ def test_contact_adhesion_vs_live_oracle(rb, hip_lib, tmp_path, cone, solver, in
     d.qvel[0] = -1.0
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
     T = 200
-    ctrl = np.zeros((1, T, 0))
+    ctrl = np.random.default_rng(5).uniform(0, 1, (1, T, m.nu))      # adhesion actuators (body transmission)
     ref, ints = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dma, 1)
     out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
@@ -550,8 +550,9 @@ def test_contact_adhesion_vs_live_oracle(rb, hip_lib, tmp_path, cone, solver, in
         d.qvel[0] = -1.0
         for stop in (1, 25, 60):
             while round(d.time / m.opt.timestep) < stop:
+                d.ctrl[:] = ctrl[0, int(round(d.time / m.opt.timestep))]
                 rb.mj_step(m, d)
-            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.zeros(0))]
+            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.array(d.ctrl))]
             check_forward(rb, m, b, st, tol=TOL)
 
 

@@ -1228,9 +1228,10 @@ def test_contact_adhesion(rb, hostsim_lib, tmp_path, cone, solver, integrator, t
     d.qvel[0] = -1.0                       # the door swings shut and is caught
     s0 = rb.mj_getState(m, d, rb.mjSTATE_FULLPHYSICS)[None].copy()
     T = 120 if integrator != 1 else 40
-    ref, ints = oracle_rollout(rb, m, s0, np.zeros((1, T, 0)))
+    ctrl = np.random.default_rng(5).uniform(0, 1, (1, T, m.nu))      # adhesion actuators (body transmission)
+    ref, ints = oracle_rollout(rb, m, s0, ctrl)
     b = K.Batch(dm, 1)
-    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, np.zeros((1, T, 0)))
+    out = b.rollout_host(T, K.mjSTATE_CTRL, s0, None, ctrl)
     if tol == 0.0:
         assert np.array_equal(out, ref)
     else:
@@ -1240,10 +1241,11 @@ def test_contact_adhesion(rb, hostsim_lib, tmp_path, cone, solver, integrator, t
     if solver == 0:
         rb.mj_resetData(m, d)
         d.qvel[0] = -1.0
-        for stop in (1, 25, 60):
+        for stop in (1, 25, min(60, T - 1)):
             while round(d.time / m.opt.timestep) < stop:
+                d.ctrl[:] = ctrl[0, int(round(d.time / m.opt.timestep))]
                 rb.mj_step(m, d)
-            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.zeros(0))]
+            st = [dict(qpos=np.array(d.qpos), qvel=np.array(d.qvel), qacc_warmstart=np.array(d.qacc_warmstart), ctrl=np.array(d.ctrl))]
             assert check_forward(rb, m, b, st, tol=0.0) == 0.0
 
 
